@@ -1,0 +1,124 @@
+"""Seeded synthetic data (assembly, gaps, error-laden reads) for tests and bench.py.
+
+Stands in for DAZZ_DB's ``simulator`` which the reference's tests shell out to
+(tests/test-commands.sh:7-13, 102-105); workload shapes follow SURVEY.md section 8(d).
+Pure host code (C++ via ctypes), no GPU involved.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libdh_sim.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run `make` (or __graft_entry__.build())")
+        lib = ctypes.CDLL(path)
+        lib.dhsim_genome.argtypes = [ctypes.c_uint64, ctypes.c_int64, ctypes.c_void_p]
+        lib.dhsim_gaps.argtypes = [ctypes.c_uint64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                   ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+        lib.dhsim_gaps.restype = ctypes.c_int32
+        lib.dhsim_reads.argtypes = [ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                    ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_double,
+                                    ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
+                                    ctypes.c_void_p]
+        lib.dhsim_reads.restype = ctypes.c_int64
+        _LIB = lib
+    return _LIB
+
+
+class SeqDb:
+    """Host-side sequence collection: concatenated base codes (a,c,g,t=0..3, other=4) + offsets."""
+
+    def __init__(self, bases, off, group=None):
+        self.bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        self.off = np.ascontiguousarray(off, dtype=np.int64)
+        self.group = None if group is None else np.ascontiguousarray(group, dtype=np.int32)
+
+    @property
+    def n(self):
+        return len(self.off) - 1
+
+    def seq(self, i):
+        return self.bases[self.off[i]:self.off[i + 1]]
+
+    def length(self, i):
+        return int(self.off[i + 1] - self.off[i])
+
+    @staticmethod
+    def from_list(seqs, group=None):
+        off = np.zeros(len(seqs) + 1, dtype=np.int64)
+        for i, s in enumerate(seqs):
+            off[i + 1] = off[i] + len(s)
+        bases = np.concatenate([np.asarray(s, dtype=np.uint8) for s in seqs]) if seqs else np.zeros(0, np.uint8)
+        return SeqDb(bases, off, group)
+
+
+_ENC = np.full(256, 4, dtype=np.uint8)
+for _i, _c in enumerate("acgt"):
+    _ENC[ord(_c)] = _i
+    _ENC[ord(_c.upper())] = _i
+_DEC = np.frombuffer(b"acgtn", dtype=np.uint8)
+
+
+def encode(s):
+    return _ENC[np.frombuffer(s.encode() if isinstance(s, str) else s, dtype=np.uint8)]
+
+
+def decode(codes):
+    return _DEC[np.minimum(np.asarray(codes, dtype=np.uint8), 4)].tobytes().decode()
+
+
+def revcomp(codes):
+    c = np.asarray(codes, dtype=np.uint8)[::-1]
+    return np.where(c < 4, 3 - c, c).astype(np.uint8)
+
+
+def genome(seed, n):
+    out = np.empty(n, dtype=np.uint8)
+    _lib().dhsim_genome(seed, n, out.ctypes.data)
+    return out
+
+
+def gaps(seed, genome_len, ngaps, minlen=50, maxlen=5000, spacing=20000):
+    b = np.zeros(ngaps, dtype=np.int64)
+    e = np.zeros(ngaps, dtype=np.int64)
+    n = _lib().dhsim_gaps(seed, genome_len, ngaps, minlen, maxlen, spacing, b.ctypes.data, e.ctypes.data)
+    return b[:n].copy(), e[:n].copy()
+
+
+def reads(seed, genome_codes, nreads, mean_len, sd_len=0, min_len=100, err=0.13, p_ins=0.60, p_del=0.25):
+    g = np.ascontiguousarray(genome_codes, dtype=np.uint8)
+    off = np.zeros(nreads + 1, dtype=np.int64)
+    truth = np.zeros((nreads, 3), dtype=np.int64)
+    total = _lib().dhsim_reads(seed, g.ctypes.data, len(g), nreads, mean_len, sd_len, min_len, err, p_ins,
+                               p_del, off.ctypes.data, None, truth.ctypes.data)
+    bases = np.empty(total, dtype=np.uint8)
+    _lib().dhsim_reads(seed, g.ctypes.data, len(g), nreads, mean_len, sd_len, min_len, err, p_ins, p_del,
+                       off.ctypes.data, bases.ctypes.data, truth.ctypes.data)
+    return SeqDb(bases, off), truth
+
+
+def contigs_from_gaps(genome_codes, gap_begin, gap_end):
+    """Split the truth sequence at the gaps: contig i = genome[end[i-1], begin[i])."""
+    starts = [0] + [int(e) for e in gap_end]
+    ends = [int(b) for b in gap_begin] + [len(genome_codes)]
+    db = SeqDb.from_list([genome_codes[s:e] for s, e in zip(starts, ends)])
+    return db, np.asarray(starts, dtype=np.int64)
+
+
+class Workload:
+    """A BASELINE.json-style synthetic workload (SURVEY.md 8(d) seeds: asm, +1 gaps, +2 reads)."""
+
+    def __init__(self, genome_len, ngaps, nreads, read_len, seed=20260929, err=0.13, sd_len=0,
+                 gap_min=50, gap_max=5000, spacing=20000):
+        self.truth = genome(seed, genome_len)
+        self.gap_begin, self.gap_end = gaps(seed + 1, genome_len, ngaps, gap_min, gap_max, spacing)
+        self.contigs, self.contig_start = contigs_from_gaps(self.truth, self.gap_begin, self.gap_end)
+        self.reads, self.read_truth = reads(seed + 2, self.truth, nreads, read_len, sd_len, err=err)

@@ -1,0 +1,781 @@
+/*
+ * align.c -- oracle restatement of the local-alignment pass (daligner / damapper role).
+ *
+ * TEST INFRASTRUCTURE ONLY (see dh_oracle.h).  PARITY UNPINNED for this file: the reference
+ * delegates this arithmetic to external tools (call sites source/dentist/dazzler.d:6121-6140
+ * `dalign`, :6158-6170 `damapper`; argv source/dentist/commandline.d:2886-2902, 2918-2955),
+ * whose sources are not under /root/reference.  The algorithm below restates the published
+ * scheme (Myers, "Efficient local alignment discovery amongst noisy long reads", WABI 2014):
+ *   1. all k-mers of A are indexed, k-mers of B (and of its reverse complement) are looked up;
+ *   2. hits are binned by diagonal into bands of 2^w; a pair of adjacent bands whose
+ *      hit-covered bases reach h triggers an alignment through a seed hit;
+ *   3. from the seed an O(ND) furthest-reaching wave runs forward and backward, trimmed to the
+ *      points within `xdrop` of the best score, with at most `width` live diagonals, recording a
+ *      trace point (diffs, b-bases) every `tspace` A-bases;
+ *   4. LAs shorter than `min_len` or noisier than 1-e are dropped.
+ * What the consumer pins (and this file honours): the record layout and the trace invariants
+ * of source/dentist/common/alignments/base.d:434-458 (sum(bbases) == bepos-bbpos,
+ * sum(diffs) == diffs, #trace points == ceil(aepos/s) - floor(abpos/s)).
+ */
+#include "dh_oracle.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+void oz_default_opts(oz_opts *o)
+{
+    memset(o, 0, sizeof(*o));
+    o->k = 14;
+    o->hmin = 35;
+    o->band_shift = 6;
+    o->tspace = 100;
+    o->min_len = 500;
+    o->pen = 6; /* floor(2 / (1 - 0.7)) */
+    o->xdrop = 120;
+    o->max_err_ppm = 300000;
+    o->max_cand = 32;
+    o->max_la = 4;
+    o->tcap = 64;
+    o->strands = 3;
+    o->skip_self = 0;
+    o->dmax = 60000;
+    o->width = 64;
+}
+
+/* ------------------------------------------------------------------ LA set ---------- */
+
+void oz_la_set_init(oz_la_set *s) { memset(s, 0, sizeof(*s)); }
+
+void oz_la_set_free(oz_la_set *s)
+{
+    free(s->la);
+    free(s->trace);
+    memset(s, 0, sizeof(*s));
+}
+
+static void la_set_push(oz_la_set *s, const oz_la *la, const uint16_t *trace)
+{
+    if (s->n == s->cap) {
+        s->cap = s->cap ? s->cap * 2 : 64;
+        s->la = (oz_la *)realloc(s->la, (size_t)s->cap * sizeof(oz_la));
+    }
+    if (s->tn + la->tlen > s->tcap) {
+        while (s->tn + la->tlen > s->tcap) s->tcap = s->tcap ? s->tcap * 2 : 4096;
+        s->trace = (uint16_t *)realloc(s->trace, (size_t)s->tcap * sizeof(uint16_t));
+    }
+    s->la[s->n] = *la;
+    s->la[s->n].toff = s->tn;
+    memcpy(s->trace + s->tn, trace, (size_t)la->tlen * sizeof(uint16_t));
+    s->tn += la->tlen;
+    s->n++;
+}
+
+/* LAsort order: (a, b, comp, abpos, aepos, bbpos, bepos, diffs)
+ * source/dentist/common/alignments/base.d:1787-1809 */
+static int la_cmp(const void *x, const void *y)
+{
+    const oz_la *p = (const oz_la *)x, *q = (const oz_la *)y;
+#define CMPF(f)                                                                                  \
+    if (p->f != q->f) return p->f < q->f ? -1 : 1;
+    CMPF(aread)
+    CMPF(bread)
+    if ((p->flags & OZ_FLAG_COMP) != (q->flags & OZ_FLAG_COMP))
+        return (p->flags & OZ_FLAG_COMP) < (q->flags & OZ_FLAG_COMP) ? -1 : 1;
+    CMPF(abpos)
+    CMPF(aepos)
+    CMPF(bbpos)
+    CMPF(bepos)
+    CMPF(diffs)
+#undef CMPF
+    return 0;
+}
+
+void oz_la_set_sort(oz_la_set *s)
+{
+    if (s->n < 2) return;
+    oz_la *copy = (oz_la *)malloc((size_t)s->n * sizeof(oz_la));
+    memcpy(copy, s->la, (size_t)s->n * sizeof(oz_la));
+    qsort(copy, (size_t)s->n, sizeof(oz_la), la_cmp);
+    uint16_t *nt = (uint16_t *)malloc((size_t)(s->tn ? s->tn : 1) * sizeof(uint16_t));
+    int64_t t = 0;
+    for (int64_t i = 0; i < s->n; i++) {
+        memcpy(nt + t, s->trace + copy[i].toff, (size_t)copy[i].tlen * sizeof(uint16_t));
+        copy[i].toff = t;
+        t += copy[i].tlen;
+    }
+    free(s->la);
+    free(s->trace);
+    s->la = copy;
+    s->cap = s->n;
+    s->trace = nt;
+    s->tcap = s->tn ? s->tn : 1;
+}
+
+/* ------------------------------------------------------------------ k-mer index ------ */
+
+typedef struct {
+    uint64_t key; /* group * 4^k + kmer */
+    int32_t aseq;
+    int32_t apos;
+} ix_ent;
+
+struct oz_index {
+    int64_t n;
+    ix_ent *e;
+    int64_t *goff; /* virtual global offset of every A sequence: sum(len + sepv) */
+    int32_t na;
+    int32_t sepv;
+    int32_t k;
+};
+
+static int ent_cmp(const void *x, const void *y)
+{
+    const ix_ent *p = (const ix_ent *)x, *q = (const ix_ent *)y;
+    if (p->key != q->key) return p->key < q->key ? -1 : 1;
+    if (p->aseq != q->aseq) return p->aseq < q->aseq ? -1 : 1;
+    if (p->apos != q->apos) return p->apos < q->apos ? -1 : 1;
+    return 0;
+}
+
+/* sepv separates the sequences of A on the virtual diagonal axis so that no band of 2^w
+ * diagonals is shared by two A sequences; it has to be >= the longest B sequence + 2^w. */
+static int32_t sepv_for(int32_t max_blen) { return ((max_blen + 64) + 63) & ~63; }
+
+static oz_index *index_build(const oz_db *A, const oz_opts *o, int32_t max_blen)
+{
+    oz_index *ix = (oz_index *)calloc(1, sizeof(*ix));
+    const int k = o->k;
+    ix->k = k;
+    ix->na = A->n;
+    ix->sepv = sepv_for(max_blen);
+    ix->goff = (int64_t *)malloc(((size_t)A->n + 1) * sizeof(int64_t));
+    int64_t g = 0, total = 0;
+    for (int32_t s = 0; s < A->n; s++) {
+        ix->goff[s] = g;
+        int64_t len = A->off[s + 1] - A->off[s];
+        g += len + ix->sepv;
+        if (len >= k) total += len - k + 1;
+    }
+    ix->goff[A->n] = g;
+    ix->e = (ix_ent *)malloc((size_t)(total ? total : 1) * sizeof(ix_ent));
+    const uint64_t mask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1);
+    int64_t n = 0;
+    for (int32_t s = 0; s < A->n; s++) {
+        const uint8_t *a = A->bases + A->off[s];
+        int64_t len = A->off[s + 1] - A->off[s];
+        uint64_t grp = A->group ? (uint64_t)A->group[s] : 0;
+        uint64_t km = 0;
+        int valid = 0;
+        for (int64_t p = 0; p < len; p++) {
+            if (a[p] < 4) {
+                km = ((km << 2) | a[p]) & mask;
+                valid++;
+            } else {
+                valid = 0;
+                km = 0;
+            }
+            if (valid >= k) {
+                ix->e[n].key = (grp << (2 * k)) | km;
+                ix->e[n].aseq = s;
+                ix->e[n].apos = (int32_t)(p - k + 1);
+                n++;
+            }
+        }
+    }
+    ix->n = n;
+    qsort(ix->e, (size_t)n, sizeof(ix_ent), ent_cmp);
+    return ix;
+}
+
+oz_index *oz_index_build(const oz_db *A, const oz_opts *o) { return index_build(A, o, 1 << 20); }
+
+void oz_index_free(oz_index *ix)
+{
+    if (!ix) return;
+    free(ix->e);
+    free(ix->goff);
+    free(ix);
+}
+
+int64_t oz_index_size(const oz_index *ix) { return ix->n; }
+
+/* first entry with key >= key */
+static int64_t ix_lower(const oz_index *ix, uint64_t key)
+{
+    int64_t lo = 0, hi = ix->n;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (ix->e[mid].key < key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+/* ------------------------------------------------------------------ seeds ------------- */
+
+static int u64_cmp(const void *x, const void *y)
+{
+    uint64_t p = *(const uint64_t *)x, q = *(const uint64_t *)y;
+    return p < q ? -1 : (p > q ? 1 : 0);
+}
+
+typedef struct {
+    int64_t band;
+    int32_t s, e; /* hit range */
+    int32_t cov;
+} band_ent;
+
+static int cand_cmp(const void *x, const void *y)
+{
+    const oz_cand *p = (const oz_cand *)x, *q = (const oz_cand *)y;
+    if (p->score != q->score) return p->score > q->score ? -1 : 1;
+    if (p->band != q->band) return p->band < q->band ? -1 : 1;
+    return 0;
+}
+
+#define HIT_QBITS 24
+#define HIT_QMASK ((1u << HIT_QBITS) - 1)
+
+int oz_seed_candidates(const oz_index *ix, const oz_db *A, const uint8_t *b, int32_t blen,
+                       int32_t bgroup, int32_t bself, int32_t sepv_unused, const oz_opts *o,
+                       oz_cand *out, int32_t *nhits_out)
+{
+    (void)A;
+    (void)sepv_unused;
+    const int k = o->k;
+    const int32_t sepv = ix->sepv;
+    const uint64_t mask = (1ull << (2 * k)) - 1;
+    int64_t cap = 1024, n = 0;
+    uint64_t *hits = (uint64_t *)malloc((size_t)cap * sizeof(uint64_t));
+    uint64_t km = 0;
+    int valid = 0;
+    for (int32_t p = 0; p < blen; p++) {
+        if (b[p] < 4) {
+            km = ((km << 2) | b[p]) & mask;
+            valid++;
+        } else {
+            valid = 0;
+            km = 0;
+        }
+        if (valid < k) continue;
+        const int32_t q = p - k + 1;
+        const uint64_t key = ((uint64_t)bgroup << (2 * k)) | km;
+        int64_t s = ix_lower(ix, key), e = s;
+        while (e < ix->n && ix->e[e].key == key) e++;
+        if (e == s || e - s > o->tcap) continue;
+        for (int64_t t = s; t < e; t++) {
+            if (o->skip_self && ix->e[t].aseq == bself) continue;
+            int64_t D = ix->goff[ix->e[t].aseq] + ix->e[t].apos + sepv - q;
+            if (n == cap) {
+                cap *= 2;
+                hits = (uint64_t *)realloc(hits, (size_t)cap * sizeof(uint64_t));
+            }
+            hits[n++] = ((uint64_t)D << HIT_QBITS) | (uint32_t)q;
+        }
+    }
+    if (nhits_out) *nhits_out = (int32_t)n;
+    if (n == 0) {
+        free(hits);
+        return 0;
+    }
+    qsort(hits, (size_t)n, sizeof(uint64_t), u64_cmp);
+
+    /* per-hit covered-base contribution and band runs */
+    int32_t *c = (int32_t *)malloc((size_t)n * sizeof(int32_t));
+    band_ent *bd = (band_ent *)malloc((size_t)n * sizeof(band_ent));
+    int64_t m = 0;
+    for (int64_t i = 0; i < n; i++) {
+        int64_t D = (int64_t)(hits[i] >> HIT_QBITS);
+        int32_t q = (int32_t)(hits[i] & HIT_QMASK);
+        if (i > 0 && (int64_t)(hits[i - 1] >> HIT_QBITS) == D) {
+            int32_t dq = q - (int32_t)(hits[i - 1] & HIT_QMASK);
+            c[i] = dq < k ? dq : k;
+        } else
+            c[i] = k;
+        int64_t band = D >> o->band_shift;
+        if (m == 0 || bd[m - 1].band != band) {
+            bd[m].band = band;
+            bd[m].s = (int32_t)i;
+            bd[m].e = (int32_t)i;
+            bd[m].cov = 0;
+            m++;
+        }
+        bd[m - 1].e = (int32_t)i + 1;
+        bd[m - 1].cov += c[i];
+    }
+
+    int64_t ccap = 64, nc = 0;
+    oz_cand *cands = (oz_cand *)malloc((size_t)ccap * sizeof(oz_cand));
+    for (int64_t j = 0; j < m; j++) {
+        const int64_t bj = bd[j].band;
+        /* coverage of band x looked up among the neighbouring entries */
+#define COV(x)                                                                                   \
+    ((j > 0 && bd[j - 1].band == (x))                                                            \
+         ? bd[j - 1].cov                                                                         \
+         : (bd[j].band == (x)                                                                    \
+                ? bd[j].cov                                                                      \
+                : ((j + 1 < m && bd[j + 1].band == (x))                                          \
+                       ? bd[j + 1].cov                                                           \
+                       : ((j + 2 < m && bd[j + 2].band == (x)) ? bd[j + 2].cov : 0))))
+        const int32_t P = COV(bj) + COV(bj + 1);
+        const int32_t Pm1 = COV(bj - 1) + COV(bj);
+        const int32_t Pp1 = COV(bj + 1) + COV(bj + 2);
+#undef COV
+        if (P < o->hmin || P < Pm1 || P <= Pp1) continue;
+        int32_t rs = bd[j].s, re = bd[j].e;
+        if (j + 1 < m && bd[j + 1].band == bj + 1) re = bd[j + 1].e;
+        /* seed = first hit of the run (same diagonal, steps <= k) covering most bases */
+        int32_t best_first = rs, best_cov = -1, run_first = rs;
+        for (int32_t i = rs; i < re; i++) {
+            int linked = 0;
+            if (i > rs && (hits[i] >> HIT_QBITS) == (hits[i - 1] >> HIT_QBITS)) {
+                int32_t dq = (int32_t)(hits[i] & HIT_QMASK) - (int32_t)(hits[i - 1] & HIT_QMASK);
+                linked = dq <= k;
+            }
+            if (!linked) run_first = i;
+            int32_t cov = k + (int32_t)(hits[i] & HIT_QMASK) - (int32_t)(hits[run_first] & HIT_QMASK);
+            if (cov > best_cov) {
+                best_cov = cov;
+                best_first = run_first;
+            }
+        }
+        int64_t D = (int64_t)(hits[best_first] >> HIT_QBITS);
+        int32_t q = (int32_t)(hits[best_first] & HIT_QMASK);
+        int64_t gv = D - sepv + q;
+        /* aseq = last sequence with goff <= gv */
+        int32_t lo = 0, hi = ix->na;
+        while (hi - lo > 1) {
+            int32_t mid = (lo + hi) >> 1;
+            if (ix->goff[mid] <= gv)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        if (nc == ccap) {
+            ccap *= 2;
+            cands = (oz_cand *)realloc(cands, (size_t)ccap * sizeof(oz_cand));
+        }
+        cands[nc].score = P;
+        cands[nc].aseq = lo;
+        cands[nc].apos = (int32_t)(gv - ix->goff[lo]);
+        cands[nc].bpos = q;
+        cands[nc].band = bj;
+        nc++;
+    }
+    qsort(cands, (size_t)nc, sizeof(oz_cand), cand_cmp);
+    if (nc > o->max_cand) nc = o->max_cand;
+    memcpy(out, cands, (size_t)nc * sizeof(oz_cand));
+    free(cands);
+    free(bd);
+    free(c);
+    free(hits);
+    return (int)nc;
+}
+
+/* ------------------------------------------------------------------ wave -------------- */
+
+typedef struct {
+    int32_t parent, d, j;
+} tp_node;
+
+typedef struct {
+    tp_node *v;
+    int32_t n, cap;
+} tp_pool;
+
+static int32_t pool_push(tp_pool *p, int32_t parent, int32_t d, int32_t j)
+{
+    if (p->n == p->cap) {
+        p->cap = p->cap ? p->cap * 2 : 256;
+        p->v = (tp_node *)realloc(p->v, (size_t)p->cap * sizeof(tp_node));
+    }
+    p->v[p->n].parent = parent;
+    p->v[p->n].d = d;
+    p->v[p->n].j = j;
+    return p->n++;
+}
+
+#define WMASK 127
+
+/* number of trace boundaries (first at tp_first, then every ts) that are <= x */
+static inline int32_t nbound(int32_t x, int32_t tp_first, int32_t ts)
+{
+    return x >= tp_first ? (x - tp_first) / ts + 1 : 0;
+}
+
+/*
+ * One-directional greedy extension.  Sequence element i of A' is ap[i*astep], of B' bp[j*bstep].
+ * Diagonal k = i - j.  R[k] = furthest i reached on k with the current number of diffs.
+ * Score of a point = i + j - pen*d.  Returns best point and the boundary crossings
+ * (cd[m], cj[m]) = (diffs, j) when the best path first reached A'-offset tp_first + m*ts.
+ */
+static int extend(const uint8_t *ap, int astep, int32_t an, const uint8_t *bp, int bstep,
+                  int32_t bn, int32_t tp_first, const oz_opts *o, int32_t *bi, int32_t *bj,
+                  int32_t *bd_, int32_t *cd, int32_t *cj, int32_t *dlo, int32_t *dhi,
+                  int64_t *cells)
+{
+    const int32_t ts = o->tspace, pen = o->pen, xdrop = o->xdrop;
+    int32_t R[2][WMASK + 1], H[2][WMASK + 1];
+    uint8_t alive[2][WMASK + 1];
+    tp_pool pool = {0, 0, 0};
+    memset(alive, 0, sizeof(alive));
+
+    int32_t i = 0;
+    while (i < an && i < bn && ap[(int64_t)i * astep] == bp[(int64_t)i * bstep]) i++;
+    int32_t head = -1;
+    for (int32_t m = 0, nb = nbound(i, tp_first, ts); m < nb; m++)
+        head = pool_push(&pool, head, 0, tp_first + m * ts);
+    int cur = 0;
+    R[cur][0] = i;
+    H[cur][0] = head;
+    alive[cur][0] = 1;
+    int32_t L = 0, U = 0;
+    int32_t best_score = 2 * i, best_i = i, best_k = 0, best_d = 0, best_head = head;
+    int64_t ncell = 1;
+
+    for (int32_t d = 1; d <= o->dmax; d++) {
+        const int prv = cur;
+        cur ^= 1;
+        const int32_t nL = L - 1, nU = U + 1;
+        int32_t step_best = INT32_MIN, step_k = 0;
+        for (int32_t k = nL; k <= nU; k++) {
+            int32_t ni = -1, src = 0;
+            /* substitution on k, deletion from k-1 (consumes A), insertion from k+1 (consumes B) */
+            if (k >= L && k <= U && alive[prv][k & WMASK]) {
+                int32_t c = R[prv][k & WMASK] + 1;
+                if (c <= an && c - k <= bn && c - k >= 0) {
+                    ni = c;
+                    src = k;
+                }
+            }
+            if (k - 1 >= L && k - 1 <= U && alive[prv][(k - 1) & WMASK]) {
+                int32_t c = R[prv][(k - 1) & WMASK] + 1;
+                if (c <= an && c - k <= bn && c - k >= 0 && c > ni) {
+                    ni = c;
+                    src = k - 1;
+                }
+            }
+            if (k + 1 >= L && k + 1 <= U && alive[prv][(k + 1) & WMASK]) {
+                int32_t c = R[prv][(k + 1) & WMASK];
+                if (c <= an && c - k <= bn && c - k >= 0 && c > ni) {
+                    ni = c;
+                    src = k + 1;
+                }
+            }
+            if (ni < 0) {
+                alive[cur][k & WMASK] = 0;
+                continue;
+            }
+            const int32_t prev_i = R[prv][src & WMASK];
+            int32_t hd = H[prv][src & WMASK];
+            int32_t j = ni - k;
+            while (ni < an && j < bn && ap[(int64_t)ni * astep] == bp[(int64_t)j * bstep]) {
+                ni++;
+                j++;
+            }
+            ncell++;
+            for (int32_t m = nbound(prev_i, tp_first, ts), nb = nbound(ni, tp_first, ts); m < nb;
+                 m++)
+                hd = pool_push(&pool, hd, d, tp_first + m * ts - k);
+            R[cur][k & WMASK] = ni;
+            H[cur][k & WMASK] = hd;
+            alive[cur][k & WMASK] = 1;
+            const int32_t sc = 2 * ni - k - pen * d;
+            if (sc > step_best) {
+                step_best = sc;
+                step_k = k;
+            }
+        }
+        if (step_best == INT32_MIN) break;
+        if (step_best > best_score) {
+            best_score = step_best;
+            best_k = step_k;
+            best_i = R[cur][step_k & WMASK];
+            best_d = d;
+            best_head = H[cur][step_k & WMASK];
+        }
+        /* trim to points within xdrop of the best */
+        int32_t l2 = INT32_MAX, u2 = INT32_MIN;
+        for (int32_t k = nL; k <= nU; k++) {
+            if (!alive[cur][k & WMASK]) continue;
+            const int32_t sc = 2 * R[cur][k & WMASK] - k - pen * d;
+            if (sc < best_score - xdrop) {
+                alive[cur][k & WMASK] = 0;
+                continue;
+            }
+            if (k < l2) l2 = k;
+            if (k > u2) u2 = k;
+        }
+        if (l2 > u2) break;
+        /* at most `width` live diagonals: drop the lower-scoring edge (ties: the low edge) */
+        while (u2 - l2 + 1 > o->width) {
+            const int32_t sl = 2 * R[cur][l2 & WMASK] - l2, su = 2 * R[cur][u2 & WMASK] - u2;
+            if (sl <= su) {
+                alive[cur][l2 & WMASK] = 0;
+                do l2++;
+                while (!alive[cur][l2 & WMASK]);
+            } else {
+                alive[cur][u2 & WMASK] = 0;
+                do u2--;
+                while (!alive[cur][u2 & WMASK]);
+            }
+        }
+        /* clear stale slots just outside the new window so they cannot alias */
+        for (int32_t k = nL; k < l2; k++) alive[cur][k & WMASK] = 0;
+        for (int32_t k = u2 + 1; k <= nU; k++) alive[cur][k & WMASK] = 0;
+        L = l2;
+        U = u2;
+    }
+
+    *bi = best_i;
+    *bj = best_i - best_k;
+    *bd_ = best_d;
+    int32_t nb = nbound(best_i, tp_first, ts);
+    int32_t h = best_head;
+    int32_t lo = 0, hi = 0; /* diagonal excursion of the path relative to the seed */
+    if (best_k < lo) lo = best_k;
+    if (best_k > hi) hi = best_k;
+    for (int32_t m = nb - 1; m >= 0; m--) {
+        if (h < 0) {
+            fprintf(stderr, "oracle: trace chain too short\n");
+            abort();
+        }
+        cd[m] = pool.v[h].d;
+        cj[m] = pool.v[h].j;
+        int32_t kk = (tp_first + m * ts) - cj[m];
+        if (kk < lo) lo = kk;
+        if (kk > hi) hi = kk;
+        h = pool.v[h].parent;
+    }
+    if (h >= 0) {
+        fprintf(stderr, "oracle: trace chain too long\n");
+        abort();
+    }
+    *dlo = lo;
+    *dhi = hi;
+    if (cells) *cells += ncell;
+    free(pool.v);
+    return nb;
+}
+
+int oz_local_align(const uint8_t *a, int32_t alen, const uint8_t *b, int32_t blen, int32_t as,
+                   int32_t bs, const oz_opts *o, oz_la *la, uint16_t *trace, int32_t *dlo,
+                   int32_t *dhi, int64_t *cells)
+{
+    const int32_t ts = o->tspace;
+    /* forward: boundaries at real a = m*ts > as ; reverse: at real a = m*ts < as */
+    const int32_t fwd_first = ts - (as % ts);                      /* in (0, ts] */
+    const int32_t rev_first = (as % ts) ? (as % ts) : ts;          /* in (0, ts] */
+    const int32_t maxb = alen / ts + 3;
+    int32_t *fd = (int32_t *)malloc((size_t)maxb * 4 * sizeof(int32_t));
+    int32_t *fj = fd + maxb, *rd = fj + maxb, *rj = rd + maxb;
+    int32_t fi, fjv, fdv, ri, rjv, rdv, flo, fhi, rlo, rhi;
+    int32_t nf = extend(a + as, 1, alen - as, b + bs, 1, blen - bs, fwd_first, o, &fi, &fjv, &fdv,
+                        fd, fj, &flo, &fhi, cells);
+    int32_t nr = extend(a + as - 1, -1, as, b + bs - 1, -1, bs, rev_first, o, &ri, &rjv, &rdv,
+                        rd, rj, &rlo, &rhi, cells);
+    la->abpos = as - ri;
+    la->bbpos = bs - rjv;
+    la->aepos = as + fi;
+    la->bepos = bs + fjv;
+    la->diffs = fdv + rdv;
+    /* diagonal range (a - b) touched by the path; reverse extension mirrors the sign */
+    const int32_t sd = as - bs;
+    int32_t lo = sd + flo, hi = sd + fhi;
+    if (sd - rhi < lo) lo = sd - rhi;
+    if (sd - rlo > hi) hi = sd - rlo;
+    *dlo = lo;
+    *dhi = hi;
+    /* assemble trace: walk boundaries in increasing a */
+    int32_t n = 0;
+    int32_t pa = la->abpos, pb = la->bbpos, pD = -rdv;
+    (void)pa;
+    /* reverse crossings, outermost first: m = nr-1 .. 0 ; real a = as - (rev_first + m*ts) */
+    for (int32_t m = nr - 1; m >= 0; m--) {
+        const int32_t ra = as - (rev_first + m * ts);
+        if (ra <= la->abpos) continue;
+        const int32_t rb = bs - rj[m], rD = -rd[m];
+        trace[n++] = (uint16_t)(rD - pD);
+        trace[n++] = (uint16_t)(rb - pb);
+        pb = rb;
+        pD = rD;
+    }
+    /* the seed itself is a boundary when as is a multiple of ts */
+    if (as % ts == 0 && as > la->abpos && as < la->aepos) {
+        trace[n++] = (uint16_t)(0 - pD);
+        trace[n++] = (uint16_t)(bs - pb);
+        pb = bs;
+        pD = 0;
+    }
+    for (int32_t m = 0; m < nf; m++) {
+        const int32_t ra = as + fwd_first + m * ts;
+        if (ra >= la->aepos) break;
+        const int32_t rb = bs + fj[m], rD = fd[m];
+        trace[n++] = (uint16_t)(rD - pD);
+        trace[n++] = (uint16_t)(rb - pb);
+        pb = rb;
+        pD = rD;
+    }
+    if (la->aepos > la->abpos) {
+        trace[n++] = (uint16_t)(fdv - pD);
+        trace[n++] = (uint16_t)(la->bepos - pb);
+    }
+    la->tlen = n;
+    free(fd);
+    return la->aepos > la->abpos;
+}
+
+/* ------------------------------------------------------------------ whole pass -------- */
+
+typedef struct {
+    int32_t aseq, abpos, aepos, bbpos, bepos, dlo, dhi;
+} region;
+
+static int la_accept(const oz_la *la, const oz_opts *o)
+{
+    const int64_t al = la->aepos - la->abpos, bl = la->bepos - la->bbpos;
+    if (al < o->min_len) return 0;
+    return (int64_t)2 * la->diffs * 1000000 <= (int64_t)o->max_err_ppm * (al + bl);
+}
+
+static void align_read(const oz_index *ix, const oz_db *A, const oz_db *B, int32_t r,
+                       const oz_opts *o, oz_la_set *out, int64_t *stats, oz_cand *cands,
+                       uint8_t *rc, uint16_t *trace)
+{
+    const uint8_t *bf = B->bases + B->off[r];
+    const int32_t blen = (int32_t)(B->off[r + 1] - B->off[r]);
+    const int32_t bgroup = B->group ? B->group[r] : 0;
+    for (int strand = 0; strand < 2; strand++) {
+        if (!(o->strands & (1 << strand))) continue;
+        const uint8_t *b = bf;
+        if (strand) {
+            oz_revcomp(bf, blen, rc);
+            b = rc;
+        }
+        int32_t nh = 0;
+        int nc = oz_seed_candidates(ix, A, b, blen, bgroup, r, 0, o, cands, &nh);
+        stats[0] += nh;
+        stats[1] += nc;
+        region done[64];
+        int nd = 0, nacc = 0;
+        for (int c = 0; c < nc && nacc < o->max_la && nd < 64; c++) {
+            const oz_cand *cd = &cands[c];
+            const int32_t sd = cd->apos - cd->bpos;
+            int covered = 0;
+            for (int t = 0; t < nd; t++)
+                if (done[t].aseq == cd->aseq && cd->apos >= done[t].abpos &&
+                    cd->apos < done[t].aepos && cd->bpos >= done[t].bbpos &&
+                    cd->bpos < done[t].bepos && sd >= done[t].dlo - 64 && sd <= done[t].dhi + 64)
+                    covered = 1;
+            if (covered) continue;
+            const uint8_t *a = A->bases + A->off[cd->aseq];
+            const int32_t alen = (int32_t)(A->off[cd->aseq + 1] - A->off[cd->aseq]);
+            oz_la la;
+            memset(&la, 0, sizeof(la));
+            int32_t dlo, dhi;
+            oz_local_align(a, alen, b, blen, cd->apos, cd->bpos, o, &la, trace, &dlo, &dhi,
+                           &stats[3]);
+            stats[2]++;
+            done[nd].aseq = cd->aseq;
+            done[nd].abpos = la.abpos;
+            done[nd].aepos = la.aepos;
+            done[nd].bbpos = la.bbpos;
+            done[nd].bepos = la.bepos;
+            done[nd].dlo = dlo;
+            done[nd].dhi = dhi;
+            nd++;
+            if (!la_accept(&la, o)) continue;
+            la.aread = cd->aseq;
+            la.bread = r;
+            la.flags = strand ? OZ_FLAG_COMP : 0;
+            la_set_push(out, &la, trace);
+            nacc++;
+        }
+    }
+}
+
+int oz_align_db(const oz_db *A, const oz_db *B, const oz_opts *o, int nthreads, oz_la_set *out,
+                int64_t *stats)
+{
+    int32_t max_blen = 0, max_alen = 0;
+    for (int32_t r = 0; r < B->n; r++) {
+        int32_t l = (int32_t)(B->off[r + 1] - B->off[r]);
+        if (l > max_blen) max_blen = l;
+    }
+    for (int32_t s = 0; s < A->n; s++) {
+        int32_t l = (int32_t)(A->off[s + 1] - A->off[s]);
+        if (l > max_alen) max_alen = l;
+    }
+    oz_index *ix = index_build(A, o, max_blen);
+    int64_t st[4] = {0, 0, 0, 0};
+    if (nthreads < 1) nthreads = 1;
+    oz_la_set *parts = (oz_la_set *)calloc((size_t)nthreads, sizeof(oz_la_set));
+    int64_t(*pst)[4] = (int64_t(*)[4])calloc((size_t)nthreads, sizeof(int64_t[4]));
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads)
+#endif
+    {
+#ifdef _OPENMP
+        const int tid = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+        const int tid = 0, nt = 1;
+#endif
+        oz_cand *cands = (oz_cand *)malloc((size_t)(o->max_cand + 1) * sizeof(oz_cand));
+        uint8_t *rc = (uint8_t *)malloc((size_t)max_blen + 1);
+        uint16_t *trace = (uint16_t *)malloc((size_t)(2 * (max_alen / o->tspace + 4)) * sizeof(uint16_t));
+        /* contiguous read ranges per thread keep the merged output in read order */
+        const int64_t lo = (int64_t)B->n * tid / nt, hi = (int64_t)B->n * (tid + 1) / nt;
+        for (int64_t r = lo; r < hi; r++)
+            align_read(ix, A, B, (int32_t)r, o, &parts[tid], pst[tid], cands, rc, trace);
+        free(cands);
+        free(rc);
+        free(trace);
+    }
+    for (int t = 0; t < nthreads; t++) {
+        for (int64_t i = 0; i < parts[t].n; i++)
+            la_set_push(out, &parts[t].la[i], parts[t].trace + parts[t].la[i].toff);
+        for (int q = 0; q < 4; q++) st[q] += pst[t][q];
+        oz_la_set_free(&parts[t]);
+    }
+    free(parts);
+    free(pst);
+    if (stats)
+        for (int q = 0; q < 4; q++) stats[q] = st[q];
+    oz_index_free(ix);
+    return 0;
+}
+
+/*
+ * damapper-style selection per B read: every LA is a chain of its own (START); the LA is the
+ * BEST chain of its read segment unless a higher-scoring LA of the same read overlaps more than
+ * half of it on B.  Consumer semantics: source/dentist/dazzler.d:1728-1758 (START without BEST
+ * is read as `alternateChain`).  Expects LAs grouped by bread (any order inside the group).
+ */
+void oz_select_best(oz_la_set *s)
+{
+    for (int64_t i = 0; i < s->n; i++) s->la[i].flags |= OZ_FLAG_START | OZ_FLAG_BEST;
+    for (int64_t i = 0; i < s->n; i++) {
+        const oz_la *p = &s->la[i];
+        const int64_t pscore = (int64_t)(p->aepos - p->abpos) - 2 * (int64_t)p->diffs;
+        /* B coordinates of complemented LAs are relative to the reverse complement */
+        for (int64_t j = 0; j < s->n; j++) {
+            if (i == j) continue;
+            const oz_la *q = &s->la[j];
+            if (q->bread != p->bread) continue;
+            const int64_t qscore = (int64_t)(q->aepos - q->abpos) - 2 * (int64_t)q->diffs;
+            if (qscore < pscore || (qscore == pscore && j > i)) continue;
+            /* compare on the forward strand of B: need read length -> not available here, so
+             * only LAs of the same orientation compete (different orientation = other locus) */
+            if ((q->flags & OZ_FLAG_COMP) != (p->flags & OZ_FLAG_COMP)) continue;
+            int32_t lo = p->bbpos > q->bbpos ? p->bbpos : q->bbpos;
+            int32_t hi = p->bepos < q->bepos ? p->bepos : q->bepos;
+            if (hi - lo > (p->bepos - p->bbpos) / 2) s->la[i].flags &= ~OZ_FLAG_BEST;
+        }
+    }
+}

@@ -1,0 +1,154 @@
+/*
+ * dh_oracle.h -- CPU restatement ("oracle") of DENTIST's alignment + consensus hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is linked, imported or executed by the
+ * product path (dentist_amd/, libdentist_hip.so).  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may use it -- as the checker / the timed CPU baseline.
+ *
+ * Parity status (see DESIGN.md "Oracle"):
+ *   PINNED against reference-owned vectors:
+ *     - .las codec                 source/dentist/dazzler.d:1665-1834, 1913-1960, 1988-2032, 2130-2170
+ *                                  goldens dazzler.d:962-1166 (testLasDump)
+ *     - trace-point translation    source/dentist/common/alignments/base.d:169-299, goldens :883-944, 993-1129
+ *     - Needleman-Wunsch           source/dentist/util/string.d:478-520, 775-831, goldens :523-751
+ *     - gap closing fixture        tests/test-commands.sh:17-44, 62-65 (md5 of gap-closed.fasta)
+ *     - 3-read consensus           source/dentist/dazzler.d:4257-4299
+ *   PARITY UNPINNED (restated from the public literature, the arithmetic lives in third-party
+ *   tools that are absent from /root/reference -- DALIGNER c2b47da, DAMAPPER b2c9d7f,
+ *   daccord 0.0.18 / libmaus2 2.0.724, DASCRUBBER a53dbe8, DAZZ_DB d22ae58):
+ *     - k-mer seeding + diagonal band filter, O(ND) wave local alignment with trace points
+ *       (call sites dazzler.d:6121-6170), tile QV (dazzler.d:6142-6156), pile-up consensus
+ *       (dazzler.d:6172-6231).
+ */
+#ifndef DH_ORACLE_H
+#define DH_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------- sequences (DAZZ_DB code order a,c,g,t = 0..3; anything else = 4) ---------- */
+
+typedef struct {
+    int32_t n;            /* number of sequences                                   */
+    const int64_t *off;   /* off[n+1] offsets into bases                           */
+    const uint8_t *bases; /* codes 0..4                                            */
+    const int32_t *group; /* optional group id per sequence (NULL = all group 0)   */
+} oz_db;
+
+void oz_encode(const char *ascii, int64_t n, uint8_t *codes);
+void oz_decode(const uint8_t *codes, int64_t n, char *ascii);
+void oz_revcomp(const uint8_t *src, int64_t n, uint8_t *dst);
+
+/* ---------- alignment options (all integer so CPU and GPU agree bit for bit) ---------- */
+
+typedef struct {
+    int32_t k;           /* k-mer length (daligner -k, default 14)                         */
+    int32_t hmin;        /* min covered bases in a band pair (daligner -h, default 35)     */
+    int32_t band_shift;  /* log2 band width (daligner -w, default 6)                       */
+    int32_t tspace;      /* trace point spacing (daligner -s: 100 mapping, 126 pile-ups)   */
+    int32_t min_len;     /* min A-length of a reported LA (daligner -l)                    */
+    int32_t pen;         /* wave score penalty per difference: floor(2 / (1 - e))          */
+    int32_t xdrop;       /* wave is trimmed to points within xdrop of the best score       */
+    int32_t max_err_ppm; /* 2*diffs*1e6 <= max_err_ppm * (alen + blen)  (1 - e)            */
+    int32_t max_cand;    /* seed candidates kept per (B read, strand)                      */
+    int32_t max_la;      /* LAs reported per (B read, strand)                              */
+    int32_t tcap;        /* k-mers occurring more than tcap times in A are ignored (-t)    */
+    int32_t strands;     /* bit0: forward B, bit1: reverse-complement B                    */
+    int32_t skip_self;   /* 1: A and B are the same DB, skip aread == bread (no -I)        */
+    int32_t dmax;        /* hard cap on differences per extension                          */
+    int32_t width;       /* max live diagonals of the wave (64 = one wavefront)            */
+    int32_t reserved;
+} oz_opts;
+
+void oz_default_opts(oz_opts *o);
+
+/* ---------- local alignments (the .las record, source/dentist/dazzler.d:1988-2032) ---------- */
+
+#define OZ_FLAG_COMP 0x1u
+#define OZ_FLAG_START 0x4u
+#define OZ_FLAG_NEXT 0x8u
+#define OZ_FLAG_BEST 0x10u
+#define OZ_FLAG_DISABLED 0x20u
+
+typedef struct {
+    int32_t tlen, diffs, abpos, bbpos, aepos, bepos;
+    uint32_t flags;
+    int32_t aread, bread; /* 0-based, as on disk */
+    int32_t pad;
+    int64_t toff;         /* offset (in u16 units) of this LA's trace in the trace array */
+} oz_la;
+
+typedef struct {
+    int64_t n, cap;
+    oz_la *la;
+    int64_t tn, tcap;
+    uint16_t *trace; /* (diffs, bbases) pairs */
+} oz_la_set;
+
+void oz_la_set_init(oz_la_set *s);
+void oz_la_set_free(oz_la_set *s);
+void oz_la_set_sort(oz_la_set *s); /* LAsort order, base.d:1787-1809 */
+
+/* seed candidate produced by the k-mer band filter */
+typedef struct {
+    int32_t score;  /* covered bases of the band pair */
+    int32_t aseq;
+    int32_t apos;
+    int32_t bpos;
+    int64_t band;
+} oz_cand;
+
+typedef struct oz_index oz_index;
+oz_index *oz_index_build(const oz_db *A, const oz_opts *o);
+void oz_index_free(oz_index *ix);
+int64_t oz_index_size(const oz_index *ix);
+
+/* k-mer hits + band filter for one B sequence (already strand-oriented). Returns #cands. */
+int oz_seed_candidates(const oz_index *ix, const oz_db *A, const uint8_t *b, int32_t blen,
+                       int32_t bgroup, int32_t bself, int32_t sepv, const oz_opts *o,
+                       oz_cand *out, int32_t *nhits_out);
+
+/* one local alignment through seed (as, bs); returns 1 and fills la/trace (trace capacity
+ * >= 2*(alen/tspace+3)) when an alignment was produced (not yet filtered for length/error). */
+int oz_local_align(const uint8_t *a, int32_t alen, const uint8_t *b, int32_t blen, int32_t as,
+                   int32_t bs, const oz_opts *o, oz_la *la, uint16_t *trace, int32_t *dlo,
+                   int32_t *dhi, int64_t *cells);
+
+/* whole pass: every B read against the index of A (daligner / damapper role) */
+int oz_align_db(const oz_db *A, const oz_db *B, const oz_opts *o, int nthreads, oz_la_set *out,
+                int64_t *stats /* [0]=hits [1]=cands [2]=alignments [3]=wave cells */);
+
+/* damapper-style per-read selection: sets START/BEST flags (dazzler.d:1728-1758 consumer) */
+void oz_select_best(oz_la_set *s);
+
+/* ---------- .las codec ---------- */
+int oz_las_write(const char *path, const oz_la_set *s, int32_t tspace);
+int oz_las_read(const char *path, oz_la_set *s, int32_t *tspace);
+
+/* ---------- trace semantics (base.d:169-299) ---------- */
+#define OZ_FLOOR 0
+#define OZ_CEIL 1
+int32_t oz_trace_points_up_to_a(int32_t abpos, int32_t aepos, int32_t tspace, int32_t ntp,
+                                int32_t apos, int mode);
+int32_t oz_trace_points_up_to_b(int32_t bbpos, int32_t bepos, const uint16_t *trace, int32_t ntp,
+                                int32_t bpos, int mode);
+void oz_translate_trace_point_a(int32_t abpos, int32_t aepos, int32_t bbpos, int32_t tspace,
+                                const uint16_t *trace, int32_t ntp, int32_t apos, int mode,
+                                int32_t *outa, int32_t *outb);
+
+/* ---------- Needleman-Wunsch (util/string.d:478-520 + traceback :775-831) ---------- */
+#define OZ_OP_SUB 0
+#define OZ_OP_DEL 1
+#define OZ_OP_INS 2
+/* returns score; ops (capacity rlen+qlen) receives the edit path, *nops its length */
+uint32_t oz_nw(const uint8_t *ref, int32_t rlen, const uint8_t *qry, int32_t qlen,
+               uint32_t indel, int free_shift, uint8_t *ops, int32_t *nops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

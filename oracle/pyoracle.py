@@ -1,0 +1,165 @@
+"""ctypes binding of the CPU oracle (oracle/libdh_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the cpu_baseline leg
+of bench.py -- never by the product path under dentist_amd/.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class Opts(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "k", "hmin", "band_shift", "tspace", "min_len", "pen", "xdrop", "max_err_ppm", "max_cand",
+        "max_la", "tcap", "strands", "skip_self", "dmax", "width", "reserved")]
+
+
+class La(ctypes.Structure):
+    _fields_ = [("tlen", ctypes.c_int32), ("diffs", ctypes.c_int32), ("abpos", ctypes.c_int32),
+                ("bbpos", ctypes.c_int32), ("aepos", ctypes.c_int32), ("bepos", ctypes.c_int32),
+                ("flags", ctypes.c_uint32), ("aread", ctypes.c_int32), ("bread", ctypes.c_int32),
+                ("pad", ctypes.c_int32), ("toff", ctypes.c_int64)]
+
+
+LA_DTYPE = np.dtype([("tlen", "<i4"), ("diffs", "<i4"), ("abpos", "<i4"), ("bbpos", "<i4"),
+                     ("aepos", "<i4"), ("bepos", "<i4"), ("flags", "<u4"), ("aread", "<i4"),
+                     ("bread", "<i4"), ("pad", "<i4"), ("toff", "<i8")])
+
+
+class LaSet(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int64), ("cap", ctypes.c_int64), ("la", ctypes.POINTER(La)),
+                ("tn", ctypes.c_int64), ("tcap", ctypes.c_int64),
+                ("trace", ctypes.POINTER(ctypes.c_uint16))]
+
+
+class Db(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int32), ("off", ctypes.c_void_p), ("bases", ctypes.c_void_p),
+                ("group", ctypes.c_void_p)]
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libdh_oracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run `make -C oracle`")
+        L = ctypes.CDLL(path)
+        L.oz_default_opts.argtypes = [ctypes.POINTER(Opts)]
+        L.oz_align_db.argtypes = [ctypes.POINTER(Db), ctypes.POINTER(Db), ctypes.POINTER(Opts),
+                                  ctypes.c_int, ctypes.POINTER(LaSet), ctypes.c_void_p]
+        L.oz_la_set_init.argtypes = [ctypes.POINTER(LaSet)]
+        L.oz_la_set_free.argtypes = [ctypes.POINTER(LaSet)]
+        L.oz_la_set_sort.argtypes = [ctypes.POINTER(LaSet)]
+        L.oz_select_best.argtypes = [ctypes.POINTER(LaSet)]
+        L.oz_las_write.argtypes = [ctypes.c_char_p, ctypes.POINTER(LaSet), ctypes.c_int32]
+        L.oz_las_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(LaSet), ctypes.POINTER(ctypes.c_int32)]
+        L.oz_nw.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+                            ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p,
+                            ctypes.POINTER(ctypes.c_int32)]
+        L.oz_nw.restype = ctypes.c_uint32
+        L.oz_trace_points_up_to_a.restype = ctypes.c_int32
+        L.oz_trace_points_up_to_a.argtypes = [ctypes.c_int32] * 5 + [ctypes.c_int]
+        L.oz_trace_points_up_to_b.restype = ctypes.c_int32
+        L.oz_trace_points_up_to_b.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+                                              ctypes.c_int32, ctypes.c_int32, ctypes.c_int]
+        L.oz_translate_trace_point_a.argtypes = [ctypes.c_int32] * 4 + [ctypes.c_void_p, ctypes.c_int32,
+                                                                        ctypes.c_int32, ctypes.c_int,
+                                                                        ctypes.POINTER(ctypes.c_int32),
+                                                                        ctypes.POINTER(ctypes.c_int32)]
+        L.oz_local_align.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+                                     ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(Opts),
+                                     ctypes.POINTER(La), ctypes.c_void_p,
+                                     ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
+                                     ctypes.c_void_p]
+        L.oz_local_align.restype = ctypes.c_int
+        _LIB = L
+    return _LIB
+
+
+def default_opts(**kw):
+    o = Opts()
+    lib().oz_default_opts(ctypes.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def _db(seqdb):
+    d = Db()
+    d.n = seqdb.n
+    d.off = seqdb.off.ctypes.data
+    d.bases = seqdb.bases.ctypes.data
+    d.group = seqdb.group.ctypes.data if seqdb.group is not None else None
+    return d
+
+
+def _take(ls):
+    """Copy an oz_la_set into numpy (records, trace) and free it."""
+    n, tn = ls.n, ls.tn
+    if n:
+        buf = ctypes.string_at(ls.la, n * ctypes.sizeof(La))
+        las = np.frombuffer(buf, dtype=LA_DTYPE).copy()
+        trace = np.ctypeslib.as_array(ls.trace, shape=(max(tn, 1),))[:tn].copy()
+    else:
+        las = np.zeros(0, dtype=LA_DTYPE)
+        trace = np.zeros(0, dtype=np.uint16)
+    lib().oz_la_set_free(ctypes.byref(ls))
+    return las, trace
+
+
+def align_db(A, B, opts, nthreads=1, sort=True, select_best=False):
+    """Every read of B against A. Returns (records, trace u16, stats[4])."""
+    L = lib()
+    ls = LaSet()
+    L.oz_la_set_init(ctypes.byref(ls))
+    stats = np.zeros(4, dtype=np.int64)
+    da, dbb = _db(A), _db(B)
+    L.oz_align_db(ctypes.byref(da), ctypes.byref(dbb), ctypes.byref(opts), nthreads, ctypes.byref(ls),
+                  stats.ctypes.data)
+    if select_best:
+        L.oz_select_best(ctypes.byref(ls))
+    if sort:
+        L.oz_la_set_sort(ctypes.byref(ls))
+    las, trace = _take(ls)
+    return las, trace, stats
+
+
+def nw(ref, qry, indel=1, free_shift=False):
+    ref = np.ascontiguousarray(ref, dtype=np.uint8)
+    qry = np.ascontiguousarray(qry, dtype=np.uint8)
+    ops = np.zeros(len(ref) + len(qry) + 1, dtype=np.uint8)
+    nops = ctypes.c_int32(0)
+    score = lib().oz_nw(ref.ctypes.data, len(ref), qry.ctypes.data, len(qry), indel, int(free_shift),
+                        ops.ctypes.data, ctypes.byref(nops))
+    return int(score), ops[:nops.value].copy()
+
+
+def las_write(path, las, trace, tspace):
+    ls = LaSet()
+    arr = np.ascontiguousarray(las)
+    tr = np.ascontiguousarray(trace, dtype=np.uint16)
+    ls.n = len(arr)
+    ls.la = ctypes.cast(arr.ctypes.data, ctypes.POINTER(La))
+    ls.tn = len(tr)
+    ls.trace = ctypes.cast(tr.ctypes.data, ctypes.POINTER(ctypes.c_uint16))
+    rc = lib().oz_las_write(path.encode(), ctypes.byref(ls), tspace)
+    if rc:
+        raise IOError(f"oz_las_write({path}) = {rc}")
+
+
+def las_read(path):
+    ls = LaSet()
+    ts = ctypes.c_int32(0)
+    rc = lib().oz_las_read(path.encode(), ctypes.byref(ls), ctypes.byref(ts))
+    if rc:
+        raise IOError(f"oz_las_read({path}) = {rc}")
+    las, trace = _take(ls)
+    return las, trace, ts.value
