@@ -1,0 +1,23 @@
+# Top-level build: HIP library (gfx950 only), simulator, oracle.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
+CSRC := dentist_amd/csrc
+LIB := dentist_amd/libdentist_hip.so
+SIM := dentist_amd/sim/libdh_sim.so
+
+all: $(LIB) $(SIM) oracle
+
+$(LIB): $(CSRC)/dh_kernels.hip $(CSRC)/dh_api.cpp $(CSRC)/dh_device.h include/dentist_hip.h $(wildcard $(CSRC)/*.hip $(CSRC)/*.cpp $(CSRC)/*.h)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(wildcard $(CSRC)/*.hip) $(wildcard $(CSRC)/*.cpp)
+
+$(SIM): dentist_amd/sim/sim.cpp
+	g++ -O2 -fPIC -shared -fopenmp -o $@ $<
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -f $(LIB) $(SIM); $(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

@@ -1,0 +1,10 @@
+"""dentist_amd -- MI355X (gfx950) implementation of DENTIST's alignment + consensus hot path.
+
+The product is ``libdentist_hip.so`` (hand-written HIP kernels behind the C ABI declared in
+``include/dentist_hip.h``).  This package is the thin ctypes binding tests and ``bench.py`` use to
+call that ABI; it contains no compute of its own and no CPU fallback -- loading fails loudly when
+the library is missing, and every compute call fails with ``DhError`` when no HIP device is
+usable.
+"""
+from ._lib import (AlignOpts, AlignStats, Context, Db, DhError, LA_DTYPE, default_align_opts,  # noqa: F401
+                   las_read, las_write, lib, lib_path)

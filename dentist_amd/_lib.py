@@ -1,0 +1,203 @@
+"""ctypes binding of include/dentist_hip.h (libdentist_hip.so). No compute, no fallback."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path():
+    return os.path.join(_HERE, "libdentist_hip.so")
+
+
+class DhError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libdentist_hip error {code}: {msg}")
+        self.code = code
+
+
+class AlignOpts(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "k", "hmin", "band_shift", "tspace", "min_len", "pen", "xdrop", "max_err_ppm", "max_cand",
+        "max_la", "tcap", "strands", "skip_self", "dmax", "width", "reserved")]
+
+
+class AlignStats(ctypes.Structure):
+    _fields_ = [("hits", ctypes.c_int64), ("cands", ctypes.c_int64), ("alignments", ctypes.c_int64),
+                ("wave_cells", ctypes.c_int64), ("las", ctypes.c_int64), ("b_bases", ctypes.c_int64),
+                ("ms_index", ctypes.c_float), ("ms_seed", ctypes.c_float), ("ms_wave", ctypes.c_float),
+                ("ms_gather", ctypes.c_float), ("ms_total", ctypes.c_float),
+                ("wave_launches", ctypes.c_int32), ("pad", ctypes.c_int32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "pad"}
+
+
+LA_DTYPE = np.dtype([("tlen", "<i4"), ("diffs", "<i4"), ("abpos", "<i4"), ("bbpos", "<i4"),
+                     ("aepos", "<i4"), ("bepos", "<i4"), ("flags", "<u4"), ("aread", "<i4"),
+                     ("bread", "<i4"), ("pad", "<i4"), ("toff", "<i8")])
+
+# every symbol include/dentist_hip.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "dh_last_error", "dh_abi_version", "dh_ctx_create", "dh_ctx_destroy", "dh_ctx_sync",
+    "dh_default_align_opts", "dh_db_create", "dh_db_destroy", "dh_db_drop_cache", "dh_db_nreads",
+    "dh_db_total_bases", "dh_la_set_destroy", "dh_la_set_count", "dh_la_set_trace_len",
+    "dh_la_set_records", "dh_la_set_trace", "dh_la_set_tspace", "dh_get_align_stats", "dh_align_db",
+    "dh_las_write", "dh_las_read",
+]
+
+_LIB = None
+
+
+def lib():
+    """Load libdentist_hip.so; raises if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: build it with `make` or __graft_entry__.build(); "
+                           "dentist_amd has no CPU fallback")
+    L = ctypes.CDLL(path)
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+    L.dh_last_error.restype = ctypes.c_char_p
+    L.dh_abi_version.restype = i32
+    L.dh_ctx_create.argtypes = [i32, vp, ctypes.POINTER(vp)]
+    L.dh_ctx_destroy.argtypes = [vp]
+    L.dh_ctx_sync.argtypes = [vp]
+    L.dh_default_align_opts.argtypes = [ctypes.POINTER(AlignOpts)]
+    L.dh_db_create.argtypes = [vp, vp, vp, i32, vp, ctypes.POINTER(vp)]
+    L.dh_db_destroy.argtypes = [vp]
+    L.dh_db_drop_cache.argtypes = [vp]
+    L.dh_db_nreads.argtypes = [vp]
+    L.dh_db_nreads.restype = i32
+    L.dh_db_total_bases.argtypes = [vp]
+    L.dh_db_total_bases.restype = i64
+    L.dh_la_set_destroy.argtypes = [vp]
+    L.dh_la_set_count.argtypes = [vp]
+    L.dh_la_set_count.restype = i64
+    L.dh_la_set_trace_len.argtypes = [vp]
+    L.dh_la_set_trace_len.restype = i64
+    L.dh_la_set_records.argtypes = [vp]
+    L.dh_la_set_records.restype = vp
+    L.dh_la_set_trace.argtypes = [vp]
+    L.dh_la_set_trace.restype = vp
+    L.dh_la_set_tspace.argtypes = [vp]
+    L.dh_la_set_tspace.restype = i32
+    L.dh_get_align_stats.argtypes = [vp, ctypes.POINTER(AlignStats)]
+    L.dh_align_db.argtypes = [vp, vp, vp, ctypes.POINTER(AlignOpts), i32, ctypes.POINTER(vp)]
+    L.dh_las_write.argtypes = [ctypes.c_char_p, vp, i64, vp, i32]
+    L.dh_las_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
+    _LIB = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise DhError(rc, lib().dh_last_error().decode(errors="replace"))
+
+
+def default_align_opts(**kw):
+    o = AlignOpts()
+    lib().dh_default_align_opts(ctypes.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def _take_la_set(h):
+    L = lib()
+    n, tn = L.dh_la_set_count(h), L.dh_la_set_trace_len(h)
+    ts = L.dh_la_set_tspace(h)
+    if n:
+        las = np.frombuffer(ctypes.string_at(L.dh_la_set_records(h), n * LA_DTYPE.itemsize),
+                            dtype=LA_DTYPE).copy()
+    else:
+        las = np.zeros(0, dtype=LA_DTYPE)
+    if tn:
+        trace = np.frombuffer(ctypes.string_at(L.dh_la_set_trace(h), tn * 2), dtype=np.uint16).copy()
+    else:
+        trace = np.zeros(0, dtype=np.uint16)
+    L.dh_la_set_destroy(h)
+    return las, trace, ts
+
+
+class Context:
+    """One per process / GPU. ``stream``: a raw hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
+
+    def __init__(self, device=0, stream=None):
+        h = ctypes.c_void_p()
+        _check(lib().dh_ctx_create(device, ctypes.c_void_p(stream) if stream else None, ctypes.byref(h)))
+        self._h = h
+
+    def close(self):
+        if self._h:
+            lib().dh_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _check(lib().dh_ctx_sync(self._h))
+
+    def db(self, seqdb):
+        return Db(self, seqdb)
+
+    def align_stats(self):
+        st = AlignStats()
+        _check(lib().dh_get_align_stats(self._h, ctypes.byref(st)))
+        return st
+
+    def align_db(self, A, B, opts, select_best=False):
+        """Every read of B against A on the GPU. Returns (records, trace u16) in LAsort order."""
+        h = ctypes.c_void_p()
+        _check(lib().dh_align_db(self._h, A._h, B._h, ctypes.byref(opts), int(select_best), ctypes.byref(h)))
+        las, trace, _ = _take_la_set(h)
+        return las, trace
+
+
+class Db:
+    """Device-resident sequence DB (HBM); built from a dentist_amd.sim.SeqDb-like object."""
+
+    def __init__(self, ctx, seqdb):
+        self.ctx = ctx
+        bases = np.ascontiguousarray(seqdb.bases, dtype=np.uint8)
+        off = np.ascontiguousarray(seqdb.off, dtype=np.int64)
+        group = None if getattr(seqdb, "group", None) is None else np.ascontiguousarray(seqdb.group, np.int32)
+        h = ctypes.c_void_p()
+        _check(lib().dh_db_create(ctx._h, bases.ctypes.data, off.ctypes.data, len(off) - 1,
+                                  group.ctypes.data if group is not None else None, ctypes.byref(h)))
+        self._h = h
+
+    def drop_cache(self):
+        _check(lib().dh_db_drop_cache(self._h))
+
+    def close(self):
+        if self._h:
+            lib().dh_db_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def las_write(path, las, trace, tspace):
+    arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
+    tr = np.ascontiguousarray(trace, dtype=np.uint16)
+    _check(lib().dh_las_write(path.encode(), arr.ctypes.data, len(arr), tr.ctypes.data, tspace))
+
+
+def las_read(path):
+    h = ctypes.c_void_p()
+    _check(lib().dh_las_read(path.encode(), ctypes.byref(h)))
+    return _take_la_set(h)

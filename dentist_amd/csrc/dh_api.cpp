@@ -1,0 +1,707 @@
+// dh_api.cpp -- host side of libdentist_hip.so: the C ABI of include/dentist_hip.h.
+//
+// Owns device memory (hipMalloc, sized for 288 GB HBM3E: whole DBs stay resident, the k-mer
+// index is built in HBM, per-slot wave scratch is preallocated), sequences launches on the
+// context's stream and times the stages with HIP events on that stream.  No CPU fallback: every
+// compute entry point needs a working HIP device.
+#include "../../include/dentist_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "dh_device.h"
+
+static_assert(sizeof(dh_align_opts) == sizeof(DhOpts), "opts layout");
+static_assert(sizeof(dh_la) == sizeof(DhLa), "la layout");
+static_assert(sizeof(dh_la) == 48, "la size");
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(DH_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));             \
+    } while (0)
+
+extern "C" const char *dh_last_error(void) { return g_err.c_str(); }
+extern "C" int32_t dh_abi_version(void) { return 1; }
+
+// ------------------------------------------------------------------------------------ context
+
+struct dh_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int ncu = 0;
+    hipEvent_t ev[6] = {};
+    dh_align_stats stats = {};
+};
+
+extern "C" int dh_ctx_create(int32_t device, void *stream, dh_ctx **out)
+{
+    if (!out) return fail(DH_EINVAL, "dh_ctx_create: out is NULL");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(DH_ENODEV, "no HIP device available (libdentist_hip has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(DH_EINVAL, "dh_ctx_create: bad device index");
+    HIPCHK(hipSetDevice(device));
+    dh_ctx *c = new dh_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    c->ncu = prop.multiProcessorCount;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    for (auto &e : c->ev) HIPCHK(hipEventCreate(&e));
+    *out = c;
+    return DH_OK;
+}
+
+extern "C" void dh_ctx_destroy(dh_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int dh_ctx_sync(dh_ctx *c)
+{
+    if (!c) return fail(DH_EINVAL, "ctx is NULL");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return DH_OK;
+}
+
+extern "C" int dh_get_align_stats(dh_ctx *c, dh_align_stats *out)
+{
+    if (!c || !out) return fail(DH_EINVAL, "dh_get_align_stats: NULL");
+    *out = c->stats;
+    return DH_OK;
+}
+
+extern "C" void dh_default_align_opts(dh_align_opts *o)
+{
+    memset(o, 0, sizeof(*o));
+    o->k = 14;
+    o->hmin = 35;
+    o->band_shift = 6;
+    o->tspace = 100;
+    o->min_len = 500;
+    o->pen = 6;
+    o->xdrop = 120;
+    o->max_err_ppm = 300000;
+    o->max_cand = 32;
+    o->max_la = 4;
+    o->tcap = 64;
+    o->strands = 3;
+    o->skip_self = 0;
+    o->dmax = 60000;
+    o->width = 62;
+}
+
+// ------------------------------------------------------------------------------------ DB
+
+struct dh_index {
+    uint32_t *d_dir = nullptr;
+    uint64_t *d_ekey = nullptr;
+    uint64_t *d_eval = nullptr;
+    int64_t *d_goff = nullptr;
+    int64_t n = 0;
+    int32_t k = 0, sepv = 0, shift = 0, pbits = 0, na = 0;
+    void release()
+    {
+        (void)hipFree(d_dir);
+        (void)hipFree(d_ekey);
+        (void)hipFree(d_eval);
+        (void)hipFree(d_goff);
+        d_dir = nullptr;
+        d_ekey = d_eval = nullptr;
+        d_goff = nullptr;
+    }
+};
+
+struct dh_db {
+    dh_ctx *ctx = nullptr;
+    int32_t n = 0, max_len = 0, ngroups = 1;
+    int64_t total = 0;
+    uint8_t *d_bases = nullptr, *d_rc = nullptr;
+    int64_t *d_off = nullptr;
+    int32_t *d_group = nullptr;
+    std::vector<int64_t> h_off;
+    std::vector<int32_t> h_group;
+    dh_index ix;
+    bool has_ix = false;
+    DbView view() const { return DbView{d_bases, d_off, d_group, n}; }
+};
+
+extern "C" int dh_db_create(dh_ctx *ctx, const uint8_t *bases, const int64_t *off, int32_t n,
+                            const int32_t *group, dh_db **out)
+{
+    if (!ctx || !off || !out || n < 0) return fail(DH_EINVAL, "dh_db_create: bad argument");
+    if (n > 0 && !bases) return fail(DH_EINVAL, "dh_db_create: bases is NULL");
+    HIPCHK(hipSetDevice(ctx->device));
+    dh_db *db = new dh_db();
+    db->ctx = ctx;
+    db->n = n;
+    db->h_off.assign(off, off + n + 1);
+    db->total = off[n] - off[0];
+    if (off[0] != 0) {
+        delete db;
+        return fail(DH_EINVAL, "dh_db_create: off[0] must be 0");
+    }
+    for (int32_t i = 0; i < n; i++) {
+        const int64_t l = off[i + 1] - off[i];
+        if (l < 0 || l >= (1 << 24)) {
+            delete db;
+            return fail(DH_EINVAL, "dh_db_create: sequence length must be in [0, 2^24)");
+        }
+        db->max_len = std::max<int32_t>(db->max_len, (int32_t)l);
+    }
+    if (group) {
+        db->h_group.assign(group, group + n);
+        for (int32_t g : db->h_group) {
+            if (g < 0) {
+                delete db;
+                return fail(DH_EINVAL, "dh_db_create: negative group id");
+            }
+            db->ngroups = std::max(db->ngroups, g + 1);
+        }
+    }
+    const size_t nb = (size_t)std::max<int64_t>(db->total, 1) + 64;  // slack for wide loads
+    HIPCHK(hipMalloc(&db->d_bases, nb));
+    HIPCHK(hipMemsetAsync(db->d_bases, 4, nb, ctx->stream));
+    HIPCHK(hipMalloc(&db->d_off, sizeof(int64_t) * (size_t)(n + 1)));
+    if (db->total > 0)
+        HIPCHK(hipMemcpyAsync(db->d_bases, bases, (size_t)db->total, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(db->d_off, off, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyHostToDevice,
+                          ctx->stream));
+    if (group && n > 0) {
+        HIPCHK(hipMalloc(&db->d_group, sizeof(int32_t) * (size_t)n));
+        HIPCHK(hipMemcpyAsync(db->d_group, group, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice,
+                              ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *out = db;
+    return DH_OK;
+}
+
+extern "C" void dh_db_destroy(dh_db *db)
+{
+    if (!db) return;
+    (void)hipSetDevice(db->ctx->device);
+    (void)hipStreamSynchronize(db->ctx->stream);
+    (void)hipFree(db->d_bases);
+    (void)hipFree(db->d_rc);
+    (void)hipFree(db->d_off);
+    (void)hipFree(db->d_group);
+    if (db->has_ix) db->ix.release();
+    delete db;
+}
+
+extern "C" int32_t dh_db_nreads(const dh_db *db) { return db ? db->n : 0; }
+extern "C" int64_t dh_db_total_bases(const dh_db *db) { return db ? db->total : 0; }
+
+// drop cached derived data (k-mer index, reverse complement) so the next call rebuilds it
+extern "C" int dh_db_drop_cache(dh_db *db)
+{
+    if (!db) return fail(DH_EINVAL, "db is NULL");
+    (void)hipSetDevice(db->ctx->device);
+    (void)hipStreamSynchronize(db->ctx->stream);
+    if (db->has_ix) db->ix.release();
+    db->has_ix = false;
+    (void)hipFree(db->d_rc);
+    db->d_rc = nullptr;
+    return DH_OK;
+}
+
+static int ensure_rc(dh_db *db)
+{
+    if (db->d_rc) return DH_OK;
+    const size_t nb = (size_t)std::max<int64_t>(db->total, 1) + 64;
+    HIPCHK(hipMalloc(&db->d_rc, nb));
+    HIPCHK(hipMemsetAsync(db->d_rc, 4, nb, db->ctx->stream));
+    dhk_revcomp(db->ctx->stream, db->d_bases, db->d_rc, db->d_off, db->n, db->max_len);
+    HIPCHK(hipGetLastError());
+    return DH_OK;
+}
+
+static int32_t ceil_log2(uint64_t x)
+{
+    int32_t b = 0;
+    while ((1ull << b) < x) b++;
+    return b;
+}
+
+static int build_index(dh_db *A, int32_t k, int32_t sepv)
+{
+    dh_ctx *ctx = A->ctx;
+    if (A->has_ix && A->ix.k == k && A->ix.sepv == sepv) return DH_OK;
+    if (A->has_ix) A->ix.release();
+    A->has_ix = false;
+    dh_index &ix = A->ix;
+    ix = dh_index();
+    ix.k = k;
+    ix.sepv = sepv;
+    ix.na = A->n;
+    // virtual offsets and tile table
+    std::vector<int64_t> goff((size_t)A->n + 1);
+    std::vector<int2> tiles;
+    int64_t g = 0, nk = 0;
+    for (int32_t s = 0; s < A->n; s++) {
+        goff[(size_t)s] = g;
+        const int64_t len = A->h_off[(size_t)s + 1] - A->h_off[(size_t)s];
+        g += len + sepv;
+        if (len >= k) {
+            nk += len - k + 1;
+            for (int64_t st = 0; st < len - k + 1; st += KM_TILE) tiles.push_back(int2{s, (int32_t)st});
+        }
+    }
+    goff[(size_t)A->n] = g;
+    if (g >= (1ll << 40)) return fail(DH_EINVAL, "index: virtual coordinate space exceeds 2^40");
+    if (A->n >= (1 << 24)) return fail(DH_EINVAL, "index: more than 2^24 sequences");
+    const int32_t keybits = 2 * k + ceil_log2((uint64_t)A->ngroups);
+    if (keybits > 62) return fail(DH_EINVAL, "index: k-mer key does not fit 62 bits");
+    int32_t pbits = ceil_log2((uint64_t)std::max<int64_t>(nk, 1));
+    pbits = std::max(10, std::min(pbits, std::min(keybits, 27)));
+    ix.pbits = pbits;
+    ix.shift = keybits - pbits;
+    // the largest key is ngroups * 4^k - 1, so buckets up to (that >> shift) are addressable
+    const int64_t nb = (int64_t)((((uint64_t)A->ngroups << (2 * k)) - 1) >> ix.shift) + 1;
+    ix.n = nk;
+    HIPCHK(hipMalloc(&ix.d_dir, sizeof(uint32_t) * (size_t)(nb + 1)));
+    HIPCHK(hipMalloc(&ix.d_ekey, sizeof(uint64_t) * (size_t)std::max<int64_t>(nk, 1)));
+    HIPCHK(hipMalloc(&ix.d_eval, sizeof(uint64_t) * (size_t)std::max<int64_t>(nk, 1)));
+    HIPCHK(hipMalloc(&ix.d_goff, sizeof(int64_t) * (size_t)(A->n + 1)));
+    int2 *d_tiles = nullptr;
+    uint32_t *d_sums = nullptr;
+    const int64_t nsum = (nb + 1 + 2047) / 2048 + 1;
+    HIPCHK(hipMalloc(&d_tiles, sizeof(int2) * std::max<size_t>(tiles.size(), 1)));
+    HIPCHK(hipMalloc(&d_sums, sizeof(uint32_t) * (size_t)nsum));
+    HIPCHK(hipMemcpyAsync(ix.d_goff, goff.data(), sizeof(int64_t) * goff.size(), hipMemcpyHostToDevice,
+                          ctx->stream));
+    if (!tiles.empty())
+        HIPCHK(hipMemcpyAsync(d_tiles, tiles.data(), sizeof(int2) * tiles.size(), hipMemcpyHostToDevice,
+                              ctx->stream));
+    HIPCHK(hipMemsetAsync(ix.d_dir, 0, sizeof(uint32_t) * (size_t)(nb + 1), ctx->stream));
+    const DbView av = A->view();
+    dhk_kmer_pass(ctx->stream, 0, av, d_tiles, (int32_t)tiles.size(), k, ix.shift, ix.d_dir, ix.d_ekey,
+                  ix.d_eval, ix.d_goff);
+    dhk_scan(ctx->stream, ix.d_dir, nb + 1, d_sums);
+    dhk_kmer_pass(ctx->stream, 1, av, d_tiles, (int32_t)tiles.size(), k, ix.shift, ix.d_dir, ix.d_ekey,
+                  ix.d_eval, ix.d_goff);
+    dhk_bucket_sort(ctx->stream, ix.d_dir, nb, ix.d_ekey, ix.d_eval);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // tiles vector goes out of scope
+    (void)hipFree(d_tiles);
+    (void)hipFree(d_sums);
+    A->has_ix = true;
+    return DH_OK;
+}
+
+// ------------------------------------------------------------------------------------ LA sets
+
+struct dh_la_set {
+    std::vector<dh_la> la;
+    std::vector<uint16_t> trace;
+    int32_t tspace = 0;
+};
+
+extern "C" void dh_la_set_destroy(dh_la_set *s) { delete s; }
+extern "C" int64_t dh_la_set_count(const dh_la_set *s) { return s ? (int64_t)s->la.size() : 0; }
+extern "C" int64_t dh_la_set_trace_len(const dh_la_set *s) { return s ? (int64_t)s->trace.size() : 0; }
+extern "C" const dh_la *dh_la_set_records(const dh_la_set *s) { return s ? s->la.data() : nullptr; }
+extern "C" const uint16_t *dh_la_set_trace(const dh_la_set *s) { return s ? s->trace.data() : nullptr; }
+extern "C" int32_t dh_la_set_tspace(const dh_la_set *s) { return s ? s->tspace : 0; }
+
+// LAsort order (a, b, comp, abpos, aepos, bbpos, bepos, diffs): base.d:1787-1809
+static bool la_less(const dh_la &p, const dh_la &q)
+{
+    if (p.aread != q.aread) return p.aread < q.aread;
+    if (p.bread != q.bread) return p.bread < q.bread;
+    const uint32_t pc = p.flags & DH_FLAG_COMP, qc = q.flags & DH_FLAG_COMP;
+    if (pc != qc) return pc < qc;
+    if (p.abpos != q.abpos) return p.abpos < q.abpos;
+    if (p.aepos != q.aepos) return p.aepos < q.aepos;
+    if (p.bbpos != q.bbpos) return p.bbpos < q.bbpos;
+    if (p.bepos != q.bepos) return p.bepos < q.bepos;
+    return p.diffs < q.diffs;
+}
+
+// damapper-style chain flags per B read: every LA is a chain of its own (START); it is BEST
+// unless a higher-scoring LA of the same read and orientation covers more than half of it on B
+// (consumer: dazzler.d:1728-1758 reads START without BEST as alternateChain).
+static void select_best(std::vector<dh_la> &la)
+{
+    std::vector<int64_t> idx(la.size());
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(),
+                     [&](int64_t x, int64_t y) { return la[(size_t)x].bread < la[(size_t)y].bread; });
+    for (auto &l : la) l.flags |= DH_FLAG_START | DH_FLAG_BEST;
+    size_t g0 = 0;
+    while (g0 < idx.size()) {
+        size_t g1 = g0;
+        while (g1 < idx.size() && la[(size_t)idx[g1]].bread == la[(size_t)idx[g0]].bread) g1++;
+        for (size_t x = g0; x < g1; x++) {
+            dh_la &p = la[(size_t)idx[x]];
+            const int64_t ps = (int64_t)(p.aepos - p.abpos) - 2 * (int64_t)p.diffs;
+            for (size_t y = g0; y < g1; y++) {
+                if (x == y) continue;
+                const dh_la &q = la[(size_t)idx[y]];
+                const int64_t qs = (int64_t)(q.aepos - q.abpos) - 2 * (int64_t)q.diffs;
+                if (qs < ps || (qs == ps && idx[y] > idx[x])) continue;
+                if ((q.flags & DH_FLAG_COMP) != (p.flags & DH_FLAG_COMP)) continue;
+                const int32_t lo = std::max(p.bbpos, q.bbpos), hi = std::min(p.bepos, q.bepos);
+                if (hi - lo > (p.bepos - p.bbpos) / 2) p.flags &= ~DH_FLAG_BEST;
+            }
+        }
+        g0 = g1;
+    }
+}
+
+// ------------------------------------------------------------------------------------ align
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    ~DevBuf() { (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, sizeof(T) * std::max<size_t>(n, 1)); }
+};
+
+extern "C" int dh_align_db(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts,
+                           int32_t want_best, dh_la_set **out)
+{
+    if (!ctx || !A || !B || !opts || !out) return fail(DH_EINVAL, "dh_align_db: NULL argument");
+    if (A->ctx != ctx || B->ctx != ctx) return fail(DH_EINVAL, "dh_align_db: DB of another context");
+    const dh_align_opts &o = *opts;
+    if (o.k < 8 || o.k > 16) return fail(DH_EINVAL, "k must be in [8, 16]");
+    if (o.width < 1 || o.width > 62) return fail(DH_EINVAL, "width must be in [1, 62]");
+    if (o.tspace < 16 || o.tspace > 32767) return fail(DH_EINVAL, "tspace out of range");
+    if (o.max_cand < 1 || o.max_cand > 256) return fail(DH_EINVAL, "max_cand must be in [1, 256]");
+    if (o.max_la < 1 || o.max_la > 64) return fail(DH_EINVAL, "max_la must be in [1, 64]");
+    if (o.pen < 2) return fail(DH_EINVAL, "pen must be >= 2");
+    if (o.band_shift < 1 || o.band_shift > 12) return fail(DH_EINVAL, "band_shift out of range");
+    if (o.skip_self && A != B) return fail(DH_EINVAL, "skip_self needs A == B");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    dh_align_stats stats = {};
+    stats.b_bases = B->total;
+    dh_la_set *res = new dh_la_set();
+    res->tspace = o.tspace;
+    *out = nullptr;
+    struct Guard {
+        dh_la_set *&r;
+        bool ok = false;
+        ~Guard()
+        {
+            if (!ok) delete r;
+        }
+    } guard{res};
+
+    HIPCHK(hipEventRecord(ctx->ev[0], st));
+    const int32_t sepv = ((B->max_len + 64) + 63) & ~63;
+    if (int rc = build_index(A, o.k, sepv)) return rc;
+    if (int rc = ensure_rc(B)) return rc;
+    HIPCHK(hipEventRecord(ctx->ev[1], st));
+
+    DhOpts dopt;
+    memcpy(&dopt, &o, sizeof(dopt));
+    IndexView iv{A->ix.d_dir, A->ix.d_ekey, A->ix.d_eval, A->ix.d_goff, A->ix.n,
+                 A->ix.na,    A->ix.sepv,   A->ix.shift,  A->ix.pbits};
+    const DbView av = A->view(), bv = B->view();
+
+    // capacity planning
+    const int64_t maxext =
+        std::min<int64_t>(A->max_len, (int64_t)B->max_len + (2ll * B->max_len + o.xdrop) / (o.pen - 1) + 1);
+    const int32_t nbmax = (int32_t)(maxext / o.tspace + 3);
+    const int32_t trmax = 2 * (2 * nbmax + 2);
+    const int32_t poolcap = 96 * nbmax;
+    int32_t slots_per_cu = 8;
+    if (const char *e = getenv("DH_WAVE_SLOTS_PER_CU")) slots_per_cu = std::max(1, atoi(e));
+    const int64_t nitems_total = 2ll * B->n;
+    const int32_t nslots = (int32_t)std::min<int64_t>((int64_t)ctx->ncu * slots_per_cu,
+                                                      std::max<int64_t>(nitems_total, 1));
+    int32_t chunk = 1 << 18;
+    if (const char *e = getenv("DH_ALIGN_CHUNK")) chunk = std::max(2, atoi(e)) & ~1;
+
+    DevBuf<DhCand> d_cand;
+    DevBuf<int32_t> d_ncand, d_nhits, d_status, d_nla, d_cdj;
+    DevBuf<DhNode> d_pool;
+    DevBuf<uint32_t> d_queue;
+    DevBuf<DhLa> d_la;
+    DevBuf<uint16_t> d_trslots;
+    DevBuf<unsigned long long> d_counters;
+    const int32_t cn = (int32_t)std::min<int64_t>(chunk, std::max<int64_t>(nitems_total, 2));
+    HIPCHK(d_cand.alloc((size_t)cn * o.max_cand));
+    HIPCHK(d_ncand.alloc((size_t)nitems_total));
+    HIPCHK(d_nhits.alloc((size_t)nitems_total));
+    HIPCHK(d_status.alloc(1));
+    HIPCHK(d_nla.alloc((size_t)nitems_total));
+    HIPCHK(d_pool.alloc((size_t)nslots * poolcap));
+    HIPCHK(d_cdj.alloc((size_t)nslots * 4 * nbmax));
+    HIPCHK(d_queue.alloc(1));
+    HIPCHK(d_la.alloc((size_t)cn * o.max_la));
+    HIPCHK(d_trslots.alloc((size_t)cn * o.max_la * trmax));
+    HIPCHK(d_counters.alloc(2));
+    HIPCHK(hipMemsetAsync(d_status.p, 0, sizeof(int32_t), st));
+    HIPCHK(hipMemsetAsync(d_counters.p, 0, 2 * sizeof(unsigned long long), st));
+
+    // expected hits per (read, strand): random matches + true seeds; pick the LDS hit capacity
+    const double dens = (double)A->ix.n / std::pow(4.0, o.k) / std::max(1, A->ngroups);
+    const double exp_hits = B->max_len * (dens * (A->ngroups > 1 ? 1.0 : 1.0) + 0.2);
+    int cap = exp_hits * 1.5 < 4096 ? 4096 : 16384;
+
+    std::vector<int32_t> h_nla((size_t)cn), h_ncand((size_t)cn), h_nhits((size_t)cn);
+    std::vector<DhLa> h_la;
+    float ms_seed = 0, ms_wave = 0, ms_gather = 0;
+
+    for (int64_t item0 = 0; item0 < nitems_total; item0 += cn) {
+        const int32_t ni = (int32_t)std::min<int64_t>(cn, nitems_total - item0);
+        // candidates are indexed by absolute item: shift the base pointer so item0 maps to 0
+        DhCand *candbase = d_cand.p - item0 * o.max_cand;
+        DhLa *labase = d_la.p - item0 * o.max_la;
+        uint16_t *trbase = d_trslots.p - item0 * (int64_t)o.max_la * trmax;
+        HIPCHK(hipEventRecord(ctx->ev[2], st));
+        for (;;) {
+            dhk_seed(st, cap, bv, B->d_rc, iv, dopt, (int32_t)item0, ni, candbase, d_ncand.p, d_nhits.p,
+                     d_status.p);
+            HIPCHK(hipGetLastError());
+            int32_t status = 0;
+            HIPCHK(hipMemcpyAsync(&status, d_status.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (status & DH_ST_CAND_OVERFLOW)
+                return fail(DH_EOVERFLOW, "seed filter: more than 256 candidate band pairs for one read");
+            if (status & DH_ST_HIT_OVERFLOW) {
+                if (cap >= 16384)
+                    return fail(DH_EOVERFLOW,
+                                "seed filter: more than 16384 k-mer hits for one (read, strand); lower -t");
+                cap = 16384;
+                HIPCHK(hipMemsetAsync(d_status.p, 0, sizeof(int32_t), st));
+                continue;
+            }
+            break;
+        }
+        HIPCHK(hipEventRecord(ctx->ev[3], st));
+        HIPCHK(hipMemsetAsync(d_queue.p, 0, sizeof(uint32_t), st));
+        WaveScratch ws{d_pool.p, d_cdj.p, d_queue.p, poolcap, nbmax};
+        dhk_wave(st, nslots, av, bv, B->d_rc, dopt, (int32_t)item0, ni, candbase, d_ncand.p, ws, labase,
+                 trbase, trmax, d_nla.p, d_counters.p, d_status.p);
+        HIPCHK(hipGetLastError());
+        stats.wave_launches++;
+        HIPCHK(hipEventRecord(ctx->ev[4], st));
+        // counts back, compact on the host, gather traces on the device
+        HIPCHK(hipMemcpyAsync(h_nla.data(), d_nla.p + item0, sizeof(int32_t) * (size_t)ni,
+                              hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(h_ncand.data(), d_ncand.p + item0, sizeof(int32_t) * (size_t)ni,
+                              hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(h_nhits.data(), d_nhits.p + item0, sizeof(int32_t) * (size_t)ni,
+                              hipMemcpyDeviceToHost, st));
+        int32_t status = 0;
+        HIPCHK(hipMemcpyAsync(&status, d_status.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (status & DH_ST_POOL_OVERFLOW)
+            return fail(DH_EOVERFLOW, "wave: trace-tree pool or boundary capacity exceeded");
+        h_la.resize((size_t)ni * o.max_la);
+        HIPCHK(hipMemcpyAsync(h_la.data(), d_la.p, sizeof(DhLa) * h_la.size(), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        std::vector<int64_t> src, dst;
+        std::vector<int32_t> tl;
+        int64_t toff = (int64_t)res->trace.size(), tbase = toff;
+        for (int32_t it = 0; it < ni; it++) {
+            stats.hits += h_nhits[(size_t)it];
+            stats.cands += h_ncand[(size_t)it];
+            for (int32_t x = 0; x < h_nla[(size_t)it]; x++) {
+                const int64_t slot = (int64_t)it * o.max_la + x;
+                dh_la la;
+                memcpy(&la, &h_la[(size_t)slot], sizeof(la));
+                la.toff = toff;
+                src.push_back(slot);
+                dst.push_back(toff - tbase);
+                tl.push_back(la.tlen);
+                toff += la.tlen;
+                res->la.push_back(la);
+            }
+        }
+        DevBuf<int64_t> d_src, d_dst;
+        DevBuf<int32_t> d_tlen;
+        DevBuf<uint16_t> d_trout;
+        if (!src.empty()) {
+            HIPCHK(d_src.alloc(src.size()));
+            HIPCHK(d_dst.alloc(dst.size()));
+            HIPCHK(d_tlen.alloc(tl.size()));
+            HIPCHK(d_trout.alloc((size_t)(toff - tbase)));
+            HIPCHK(hipMemcpyAsync(d_src.p, src.data(), sizeof(int64_t) * src.size(), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(d_dst.p, dst.data(), sizeof(int64_t) * dst.size(), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(d_tlen.p, tl.data(), sizeof(int32_t) * tl.size(), hipMemcpyHostToDevice, st));
+            dhk_gather_trace(st, (int64_t)src.size(), d_trslots.p, trmax, d_src.p, d_dst.p, d_tlen.p,
+                             d_trout.p);
+            HIPCHK(hipGetLastError());
+            res->trace.resize((size_t)toff);
+            HIPCHK(hipMemcpyAsync(res->trace.data() + tbase, d_trout.p, sizeof(uint16_t) * (size_t)(toff - tbase),
+                                  hipMemcpyDeviceToHost, st));
+        }
+        HIPCHK(hipEventRecord(ctx->ev[5], st));
+        HIPCHK(hipStreamSynchronize(st));
+        float t;
+        HIPCHK(hipEventElapsedTime(&t, ctx->ev[2], ctx->ev[3]));
+        ms_seed += t;
+        HIPCHK(hipEventElapsedTime(&t, ctx->ev[3], ctx->ev[4]));
+        ms_wave += t;
+        HIPCHK(hipEventElapsedTime(&t, ctx->ev[4], ctx->ev[5]));
+        ms_gather += t;
+    }
+    unsigned long long counters[2] = {0, 0};
+    HIPCHK(hipMemcpy(counters, d_counters.p, sizeof(counters), hipMemcpyDeviceToHost));
+    stats.wave_cells = (int64_t)counters[0];
+    stats.alignments = (int64_t)counters[1];
+
+    if (want_best) select_best(res->la);
+    // LAsort order; traces are re-laid out in that order
+    {
+        std::vector<int64_t> idx(res->la.size());
+        std::iota(idx.begin(), idx.end(), 0);
+        std::sort(idx.begin(), idx.end(),
+                  [&](int64_t x, int64_t y) { return la_less(res->la[(size_t)x], res->la[(size_t)y]); });
+        std::vector<dh_la> la2(res->la.size());
+        std::vector<uint16_t> tr2(res->trace.size());
+        int64_t t = 0;
+        for (size_t i = 0; i < idx.size(); i++) {
+            la2[i] = res->la[(size_t)idx[i]];
+            memcpy(tr2.data() + t, res->trace.data() + la2[i].toff, sizeof(uint16_t) * (size_t)la2[i].tlen);
+            la2[i].toff = t;
+            t += la2[i].tlen;
+        }
+        res->la.swap(la2);
+        res->trace.swap(tr2);
+    }
+    stats.las = (int64_t)res->la.size();
+    float t;
+    HIPCHK(hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[1]));
+    stats.ms_index = t;
+    stats.ms_seed = ms_seed;
+    stats.ms_wave = ms_wave;
+    stats.ms_gather = ms_gather;
+    stats.ms_total = stats.ms_index + ms_seed + ms_wave + ms_gather;
+    ctx->stats = stats;
+    guard.ok = true;
+    *out = res;
+    return DH_OK;
+}
+
+// ------------------------------------------------------------------------------------ .las
+
+// header int64 novl + int32 tspace; record = 40 bytes (9 x int32 + pad); trace values are u8 when
+// tspace <= 125 (TRACE_XOVR) else u16 -- dazzler.d:1665-1834, 1988-2032, 2130-2170.
+extern "C" int dh_las_write(const char *path, const dh_la *las, int64_t n, const uint16_t *trace,
+                            int32_t tspace)
+{
+    if (!path || (n > 0 && (!las || !trace))) return fail(DH_EINVAL, "dh_las_write: NULL argument");
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(DH_EIO, std::string("cannot open ") + path);
+    bool ok = fwrite(&n, 8, 1, f) == 1 && fwrite(&tspace, 4, 1, f) == 1;
+    const bool small = tspace <= 125;
+    std::vector<uint8_t> tmp;
+    for (int64_t i = 0; ok && i < n; i++) {
+        const dh_la &l = las[i];
+        const int32_t rec[10] = {l.tlen, l.diffs, l.abpos, l.bbpos, l.aepos,
+                                 l.bepos, (int32_t)l.flags, l.aread, l.bread, 0};
+        ok = fwrite(rec, 4, 10, f) == 10;
+        const uint16_t *t = trace + l.toff;
+        if (small) {
+            tmp.resize((size_t)l.tlen);
+            for (int32_t j = 0; j < l.tlen; j++) {
+                if (t[j] > 255) {
+                    fclose(f);
+                    return fail(DH_EINVAL, "dh_las_write: trace value exceeds 8 bits at tspace <= 125");
+                }
+                tmp[(size_t)j] = (uint8_t)t[j];
+            }
+            ok = ok && (l.tlen == 0 || fwrite(tmp.data(), 1, (size_t)l.tlen, f) == (size_t)l.tlen);
+        } else
+            ok = ok && (l.tlen == 0 || fwrite(t, 2, (size_t)l.tlen, f) == (size_t)l.tlen);
+    }
+    if (fclose(f) != 0) ok = false;
+    return ok ? DH_OK : fail(DH_EIO, std::string("short write to ") + path);
+}
+
+extern "C" int dh_las_read(const char *path, dh_la_set **out)
+{
+    if (!path || !out) return fail(DH_EINVAL, "dh_las_read: NULL argument");
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(DH_EIO, std::string("cannot open ") + path);
+    int64_t novl = 0;
+    int32_t ts = 0;
+    if (fread(&novl, 8, 1, f) != 1 || fread(&ts, 4, 1, f) != 1) {
+        fclose(f);
+        return fail(DH_EIO, std::string("error reading LAS file `") + path + "`: unexpected end of file");
+    }
+    dh_la_set *s = new dh_la_set();
+    s->tspace = ts;
+    const bool small = ts <= 125;
+    std::vector<uint8_t> tmp;
+    for (int64_t i = 0; i < novl; i++) {
+        int32_t rec[10];
+        if (fread(rec, 4, 10, f) != 10) {
+            fclose(f);
+            delete s;
+            return fail(DH_EIO, std::string("error reading LAS file `") + path +
+                                    "`: unexpected end of file; expected overlapHead");
+        }
+        dh_la l = {};
+        l.tlen = rec[0];
+        l.diffs = rec[1];
+        l.abpos = rec[2];
+        l.bbpos = rec[3];
+        l.aepos = rec[4];
+        l.bepos = rec[5];
+        l.flags = (uint32_t)rec[6];
+        l.aread = rec[7];
+        l.bread = rec[8];
+        l.toff = (int64_t)s->trace.size();
+        if (l.tlen < 0 || l.tlen % 2) {
+            fclose(f);
+            delete s;
+            return fail(DH_EIO, "illegal value for tlen: must be multiple of 2");
+        }
+        s->trace.resize(s->trace.size() + (size_t)l.tlen);
+        uint16_t *t = s->trace.data() + l.toff;
+        bool ok;
+        if (small) {
+            tmp.resize((size_t)l.tlen);
+            ok = l.tlen == 0 || fread(tmp.data(), 1, (size_t)l.tlen, f) == (size_t)l.tlen;
+            for (int32_t j = 0; ok && j < l.tlen; j++) t[j] = tmp[(size_t)j];
+        } else
+            ok = l.tlen == 0 || fread(t, 2, (size_t)l.tlen, f) == (size_t)l.tlen;
+        if (!ok) {
+            fclose(f);
+            delete s;
+            return fail(DH_EIO, std::string("error reading LAS file `") + path +
+                                    "`: unexpected end of file; expected tracePoints");
+        }
+        s->la.push_back(l);
+    }
+    fclose(f);
+    *out = s;
+    return DH_OK;
+}

@@ -1,0 +1,81 @@
+// dh_device.h -- POD views shared by the kernels (dh_kernels.hip) and the host side (dh_api.cpp).
+#ifndef DH_DEVICE_H
+#define DH_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define KM_TILE 4096 /* A positions per block of the k-mer passes (256 threads x 16) */
+
+#define DH_ST_HIT_OVERFLOW 0x1
+#define DH_ST_CAND_OVERFLOW 0x2
+#define DH_ST_POOL_OVERFLOW 0x4
+
+struct DhOpts {  // == dh_align_opts
+    int32_t k, hmin, band_shift, tspace, min_len, pen, xdrop, max_err_ppm, max_cand, max_la, tcap,
+        strands, skip_self, dmax, width, reserved;
+};
+
+struct DbView {
+    const uint8_t *bases;  // concatenated base codes
+    const int64_t *off;    // n + 1 offsets
+    const int32_t *group;  // optional
+    int32_t n;
+};
+
+struct IndexView {
+    const uint32_t *dir;   // dir[b] = end of bucket b (start = dir[b-1])
+    const uint64_t *ekey;  // group * 4^k + kmer, sorted inside every bucket
+    const uint64_t *eval;  // aseq << 40 | virtual position
+    const int64_t *goff;   // virtual offset of every A sequence
+    int64_t n;
+    int32_t na, sepv, shift, pbits;
+};
+
+struct DhCand {
+    int32_t score, aseq, apos, bpos;
+};
+
+struct DhLa {  // == dh_la
+    int32_t tlen, diffs, abpos, bbpos, aepos, bepos;
+    uint32_t flags;
+    int32_t aread, bread, pad;
+    int64_t toff;
+};
+
+struct DhNode {
+    int32_t parent, d, j;
+};
+
+struct WaveScratch {
+    DhNode *pool;     // nslots * poolcap trace-tree nodes
+    int32_t *cdj;     // nslots * 4 * nbmax boundary records
+    uint32_t *queue;  // work-item counter
+    int32_t poolcap, nbmax;
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+void dhk_revcomp(hipStream_t st, const uint8_t *src, uint8_t *dst, const int64_t *off, int32_t n,
+                 int32_t max_len);
+void dhk_kmer_pass(hipStream_t st, int fill, DbView A, const int2 *tiles, int32_t ntiles, int32_t k,
+                   int32_t shift, uint32_t *dir, uint64_t *ekey, uint64_t *eval,
+                   const int64_t *goff);
+void dhk_scan(hipStream_t st, uint32_t *v, int64_t n, uint32_t *sums);
+void dhk_bucket_sort(hipStream_t st, const uint32_t *dir_end, int64_t nb, uint64_t *ekey,
+                     uint64_t *eval);
+void dhk_seed(hipStream_t st, int cap, DbView B, const uint8_t *brc, IndexView ix, DhOpts o,
+              int32_t item0, int32_t nitems, DhCand *cand, int32_t *ncand, int32_t *nhits,
+              int32_t *status);
+void dhk_wave(hipStream_t st, int32_t nslots, DbView A, DbView B, const uint8_t *brc, DhOpts o,
+              int32_t item0, int32_t nitems, const DhCand *cand, const int32_t *ncand,
+              WaveScratch ws, DhLa *out_la, uint16_t *out_trace, int32_t trmax, int32_t *out_nla,
+              unsigned long long *counters, int32_t *status);
+void dhk_gather_trace(hipStream_t st, int64_t n, const uint16_t *slots, int32_t trmax,
+                      const int64_t *src_slot, const int64_t *dst_off, const int32_t *tlen,
+                      uint16_t *dst);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,822 @@
+// dh_kernels.hip -- gfx950 (CDNA4, wave64) kernels of the alignment pass.
+//
+// K1  k_revcomp        reverse-complement copy of a DB                     (HBM stream)
+// K2  k_kmer_pass      k-mer extraction of A: count pass and fill pass     (HBM stream + atomics)
+//     k_scan*          exclusive scan of the bucket directory
+//     k_bucket_sort    order every directory bucket by (key, position)
+// K4  k_seed           per (B read, strand): k-mer lookups, LDS-staged hit buffer, in-LDS
+//                      bitonic sort by (diagonal, position), band-pair coverage filter, seeds
+// K5  k_wave           per (B read, strand): O(ND) furthest-reaching wave, one 64-lane wavefront
+//                      per alignment (lane == diagonal), trace points every tspace A-bases
+//     k_gather_trace   compaction of the per-slot trace vectors
+//
+// The arithmetic specification these kernels implement is written down in DESIGN.md
+// ("Algorithm DH-1"); reference call sites: source/dentist/dazzler.d:6121-6170.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dh_device.h"
+
+#define LANES 64
+
+// ------------------------------------------------------------------------------------ K1
+
+__global__ void k_revcomp(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+                          const int64_t *__restrict__ off, int32_t n)
+{
+    // one block per sequence chunk: blockIdx.y = sequence, grid-stride over its bases
+    const int32_t s = blockIdx.y;
+    if (s >= n) return;
+    const int64_t o = off[s], len = off[s + 1] - o;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const uint8_t c = src[o + len - 1 - i];
+        dst[o + i] = c < 4 ? (uint8_t)(3 - c) : c;
+    }
+}
+
+// ------------------------------------------------------------------------------------ K2
+
+// tiles: (sequence, start) pairs, KM_TILE positions each; 256 threads x 16 positions.
+template <bool FILL>
+__global__ void __launch_bounds__(256)
+k_kmer_pass(DbView A, const int2 *__restrict__ tiles, int32_t ntiles, int32_t k, int32_t shift,
+            uint32_t *__restrict__ dir, uint64_t *__restrict__ ekey, uint64_t *__restrict__ eval,
+            const int64_t *__restrict__ goff)
+{
+    const int32_t t = blockIdx.x;
+    if (t >= ntiles) return;
+    const int32_t s = tiles[t].x;
+    const int64_t o = A.off[s];
+    const int32_t len = (int32_t)(A.off[s + 1] - o);
+    const uint64_t grp = A.group ? (uint64_t)A.group[s] : 0ull;
+    const uint64_t mask = (1ull << (2 * k)) - 1;
+    const int32_t p0 = tiles[t].y + threadIdx.x * (KM_TILE / 256);
+    uint64_t km = 0;
+    int32_t valid = 0;
+    const uint8_t *a = A.bases + o;
+    for (int32_t x = 0; x < KM_TILE / 256 + k - 1; x++) {
+        const int32_t p = p0 + x;
+        if (p >= len) break;
+        const uint8_t c = a[p];
+        if (c < 4) {
+            km = ((km << 2) | c) & mask;
+            valid++;
+        } else {
+            km = 0;
+            valid = 0;
+        }
+        if (x >= k - 1 && valid >= k) {
+            const uint64_t key = (grp << (2 * k)) | km;
+            const uint32_t b = (uint32_t)(key >> shift);
+            if (FILL) {
+                const uint32_t slot = atomicAdd(&dir[b], 1u);
+                ekey[slot] = key;
+                eval[slot] = ((uint64_t)s << 40) | (uint64_t)(goff[s] + (p - k + 1));
+            } else
+                atomicAdd(&dir[b], 1u);
+        }
+    }
+}
+template __global__ void k_kmer_pass<false>(DbView, const int2 *, int32_t, int32_t, int32_t,
+                                            uint32_t *, uint64_t *, uint64_t *, const int64_t *);
+template __global__ void k_kmer_pass<true>(DbView, const int2 *, int32_t, int32_t, int32_t,
+                                           uint32_t *, uint64_t *, uint64_t *, const int64_t *);
+
+// exclusive scan of n uint32 in place: block sums, scan of sums, add-back
+#define SCAN_PER_BLOCK 2048
+__global__ void __launch_bounds__(256) k_scan_sums(const uint32_t *__restrict__ v, int64_t n,
+                                                   uint32_t *__restrict__ sums)
+{
+    __shared__ uint32_t red[256];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_PER_BLOCK;
+    uint32_t acc = 0;
+    for (int i = threadIdx.x; i < SCAN_PER_BLOCK; i += 256)
+        if (base + i < n) acc += v[base + i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[blockIdx.x] = red[0];
+}
+
+__global__ void __launch_bounds__(1024) k_scan_top(uint32_t *__restrict__ sums, int32_t nb)
+{
+    // single block: serial chunks per thread then a block scan of the 1024 partials
+    __shared__ uint32_t part[1024];
+    const int32_t per = (nb + 1023) / 1024;
+    const int32_t lo = threadIdx.x * per, hi = min(nb, lo + per);
+    uint32_t acc = 0;
+    for (int32_t i = lo; i < hi; i++) acc += sums[i];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    // Hillis-Steele inclusive scan
+    for (int s = 1; s < 1024; s <<= 1) {
+        uint32_t add = (int)threadIdx.x >= s ? part[threadIdx.x - s] : 0;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+    for (int32_t i = lo; i < hi; i++) {
+        const uint32_t x = sums[i];
+        sums[i] = run;
+        run += x;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_scan_apply(uint32_t *__restrict__ v, int64_t n,
+                                                    const uint32_t *__restrict__ sums)
+{
+    __shared__ uint32_t part[256];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_PER_BLOCK;
+    const int per = SCAN_PER_BLOCK / 256;
+    uint32_t loc[SCAN_PER_BLOCK / 256];
+    uint32_t acc = 0;
+    for (int i = 0; i < per; i++) {
+        const int64_t idx = base + threadIdx.x * per + i;
+        loc[i] = idx < n ? v[idx] : 0;
+        acc += loc[i];
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 1; s < 256; s <<= 1) {
+        uint32_t add = (int)threadIdx.x >= s ? part[threadIdx.x - s] : 0;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = sums[blockIdx.x] + (threadIdx.x ? part[threadIdx.x - 1] : 0);
+    for (int i = 0; i < per; i++) {
+        const int64_t idx = base + threadIdx.x * per + i;
+        if (idx < n) v[idx] = run;
+        run += loc[i];
+    }
+}
+
+// after the fill pass dir[b] holds the END of bucket b (the cursor ran through it); bucket b is
+// [b ? dir[b-1] : 0, dir[b]).  Order each bucket by (key, value): the fill order is racy, the
+// sorted order is unique because (key, position) pairs are distinct.
+__global__ void __launch_bounds__(256) k_bucket_sort(const uint32_t *__restrict__ dir_end,
+                                                     int64_t nb, uint64_t *__restrict__ ekey,
+                                                     uint64_t *__restrict__ eval)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const uint32_t s = b ? dir_end[b - 1] : 0, e = dir_end[b];
+    for (uint32_t i = s + 1; i < e; i++) {
+        const uint64_t kk = ekey[i], vv = eval[i];
+        uint32_t j = i;
+        while (j > s && (ekey[j - 1] > kk || (ekey[j - 1] == kk && eval[j - 1] > vv))) {
+            ekey[j] = ekey[j - 1];
+            eval[j] = eval[j - 1];
+            j--;
+        }
+        ekey[j] = kk;
+        eval[j] = vv;
+    }
+}
+
+// ------------------------------------------------------------------------------------ K4
+
+#define HIT_QBITS 24
+#define HIT_QMASK ((1u << HIT_QBITS) - 1u)
+#define SEED_THREADS 256
+#define SEED_CCAP 256 /* candidate band pairs collected per (read, strand) before ranking */
+
+__device__ __forceinline__ int64_t hitD(uint64_t h) { return (int64_t)(h >> HIT_QBITS); }
+__device__ __forceinline__ int32_t hitQ(uint64_t h) { return (int32_t)(h & HIT_QMASK); }
+
+// covered-base contribution of sorted hit i (needs hit i-1)
+__device__ __forceinline__ int32_t hit_cov(const uint64_t *h, int32_t i, int32_t k)
+{
+    if (i > 0 && hitD(h[i - 1]) == hitD(h[i])) {
+        const int32_t dq = hitQ(h[i]) - hitQ(h[i - 1]);
+        return dq < k ? dq : k;
+    }
+    return k;
+}
+
+template <int CAP>
+__global__ void __launch_bounds__(SEED_THREADS)
+k_seed(DbView B, const uint8_t *__restrict__ brc, IndexView ix, DhOpts o, int32_t item0,
+       int32_t nitems, DhCand *__restrict__ cand_out, int32_t *__restrict__ ncand_out,
+       int32_t *__restrict__ nhits_out, int32_t *__restrict__ status)
+{
+    __shared__ uint64_t hits[CAP];
+    __shared__ DhCand cands[SEED_CCAP];
+    __shared__ int64_t cband[SEED_CCAP];
+    __shared__ int32_t s_n, s_nc;
+
+    const int32_t item = item0 + blockIdx.x;
+    if (blockIdx.x >= (unsigned)nitems) return;
+    const int32_t r = item >> 1, strand = item & 1;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        s_n = 0;
+        s_nc = 0;
+    }
+    __syncthreads();
+    if (!(o.strands & (1 << strand))) {
+        if (tid == 0) {
+            ncand_out[item] = 0;
+            nhits_out[item] = 0;
+        }
+        return;
+    }
+    const int64_t bo = B.off[r];
+    const int32_t blen = (int32_t)(B.off[r + 1] - bo);
+    const uint8_t *b = (strand ? brc : B.bases) + bo;
+    const uint64_t grp = B.group ? (uint64_t)B.group[r] : 0ull;
+    const int k = o.k;
+    const uint64_t mask = (1ull << (2 * k)) - 1;
+    const int32_t npos = blen - k + 1;
+
+    // ---- k-mer lookups: thread t rolls over a contiguous chunk of positions
+    if (npos > 0) {
+        const int32_t per = (npos + SEED_THREADS - 1) / SEED_THREADS;
+        const int32_t q0 = tid * per, q1 = min(npos, q0 + per);
+        uint64_t km = 0;
+        int32_t valid = 0;
+        for (int32_t p = q0; p < q1 + k - 1 && q0 < q1; p++) {
+            const uint8_t c = b[p];
+            if (c < 4) {
+                km = ((km << 2) | c) & mask;
+                valid++;
+            } else {
+                km = 0;
+                valid = 0;
+            }
+            if (p - q0 < k - 1 || valid < k) continue;
+            const int32_t q = p - k + 1;
+            const uint64_t key = (grp << (2 * k)) | km;
+            const uint32_t bk = (uint32_t)(key >> ix.shift);
+            uint32_t s = bk ? ix.dir[bk - 1] : 0u;
+            const uint32_t e = ix.dir[bk];
+            // bucket is sorted by key: find the run of equal keys
+            while (s < e && ix.ekey[s] < key) s++;
+            uint32_t f = s;
+            while (f < e && ix.ekey[f] == key) f++;
+            const int32_t run = (int32_t)(f - s);
+            if (run == 0 || run > o.tcap) continue;
+            for (uint32_t t = s; t < f; t++) {
+                const uint64_t v = ix.eval[t];
+                const int32_t aseq = (int32_t)(v >> 40);
+                if (o.skip_self && aseq == r) continue;
+                const int64_t gv = (int64_t)(v & ((1ull << 40) - 1));
+                const int64_t D = gv + ix.sepv - q;
+                const int32_t slot = atomicAdd(&s_n, 1);
+                if (slot < CAP) hits[slot] = ((uint64_t)D << HIT_QBITS) | (uint32_t)q;
+            }
+        }
+    }
+    __syncthreads();
+    int32_t n = s_n;
+    if (tid == 0) nhits_out[item] = n;
+    if (n > CAP) {
+        // capacity exceeded: reported, never silently truncated
+        if (tid == 0) {
+            atomicOr(status, DH_ST_HIT_OVERFLOW);
+            ncand_out[item] = 0;
+        }
+        return;
+    }
+    if (n == 0) {
+        if (tid == 0) ncand_out[item] = 0;
+        return;
+    }
+    // ---- bitonic sort of the padded hit buffer (keys are distinct)
+    int32_t N = 1;
+    while (N < n) N <<= 1;
+    for (int32_t i = n + tid; i < N; i += SEED_THREADS) hits[i] = ~0ull;
+    __syncthreads();
+    for (int32_t kk = 2; kk <= N; kk <<= 1) {
+        for (int32_t j = kk >> 1; j > 0; j >>= 1) {
+            for (int32_t i = tid; i < N; i += SEED_THREADS) {
+                const int32_t ixj = i ^ j;
+                if (ixj > i) {
+                    const uint64_t x = hits[i], y = hits[ixj];
+                    const bool up = (i & kk) == 0;
+                    if ((x > y) == up) {
+                        hits[i] = y;
+                        hits[ixj] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- band heads: coverage of bands b-1, b, b+1, b+2 by walking the sorted hits
+    const int bs = o.band_shift;
+    for (int32_t i = tid; i < n; i += SEED_THREADS) {
+        const int64_t band = hitD(hits[i]) >> bs;
+        if (i > 0 && (hitD(hits[i - 1]) >> bs) == band) continue;  // not a band head
+        int32_t covm1 = 0;
+        for (int32_t j = i - 1; j >= 0 && (hitD(hits[j]) >> bs) == band - 1; j--)
+            covm1 += hit_cov(hits, j, k);
+        int32_t cov0 = 0, cov1 = 0, cov2 = 0;
+        int32_t j = i;
+        for (; j < n && (hitD(hits[j]) >> bs) == band; j++) cov0 += hit_cov(hits, j, k);
+        const int32_t e0 = j;
+        for (; j < n && (hitD(hits[j]) >> bs) == band + 1; j++) cov1 += hit_cov(hits, j, k);
+        const int32_t e1 = j;
+        for (; j < n && (hitD(hits[j]) >> bs) == band + 2; j++) cov2 += hit_cov(hits, j, k);
+        const int32_t P = cov0 + cov1, Pm1 = covm1 + cov0, Pp1 = cov1 + cov2;
+        if (P < o.hmin || P < Pm1 || P <= Pp1) continue;
+        // seed: first hit of the same-diagonal run (steps <= k) covering most bases
+        (void)e0;
+        int32_t best_first = i, best_cov = -1, run_first = i;
+        for (int32_t x = i; x < e1; x++) {
+            bool linked = false;
+            if (x > i && hitD(hits[x]) == hitD(hits[x - 1]))
+                linked = (hitQ(hits[x]) - hitQ(hits[x - 1])) <= k;
+            if (!linked) run_first = x;
+            const int32_t cov = k + hitQ(hits[x]) - hitQ(hits[run_first]);
+            if (cov > best_cov) {
+                best_cov = cov;
+                best_first = run_first;
+            }
+        }
+        const int64_t D = hitD(hits[best_first]);
+        const int32_t q = hitQ(hits[best_first]);
+        const int64_t gv = D - ix.sepv + q;
+        int32_t lo = 0, hi = ix.na;
+        while (hi - lo > 1) {
+            const int32_t mid = (lo + hi) >> 1;
+            if (ix.goff[mid] <= gv)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const int32_t slot = atomicAdd(&s_nc, 1);
+        if (slot < SEED_CCAP) {
+            cands[slot].score = P;
+            cands[slot].aseq = lo;
+            cands[slot].apos = (int32_t)(gv - ix.goff[lo]);
+            cands[slot].bpos = q;
+            cband[slot] = band;
+        }
+    }
+    __syncthreads();
+    int32_t nc = s_nc;
+    if (nc > SEED_CCAP) {
+        if (tid == 0) {
+            atomicOr(status, DH_ST_CAND_OVERFLOW);
+            ncand_out[item] = 0;
+        }
+        return;
+    }
+    // ---- rank by (score desc, band asc); bands are distinct so ranks are a permutation
+    for (int32_t c = tid; c < nc; c += SEED_THREADS) {
+        int32_t rank = 0;
+        for (int32_t x = 0; x < nc; x++)
+            if (cands[x].score > cands[c].score ||
+                (cands[x].score == cands[c].score && cband[x] < cband[c]))
+                rank++;
+        if (rank < o.max_cand) cand_out[(int64_t)item * o.max_cand + rank] = cands[c];
+    }
+    if (tid == 0) ncand_out[item] = nc < o.max_cand ? nc : o.max_cand;
+}
+template __global__ void k_seed<4096>(DbView, const uint8_t *, IndexView, DhOpts, int32_t, int32_t,
+                                      DhCand *, int32_t *, int32_t *, int32_t *);
+template __global__ void k_seed<16384>(DbView, const uint8_t *, IndexView, DhOpts, int32_t, int32_t,
+                                       DhCand *, int32_t *, int32_t *, int32_t *);
+
+// ------------------------------------------------------------------------------------ K5
+
+__device__ __forceinline__ int32_t nbound(int32_t x, int32_t tp_first, int32_t ts)
+{
+    return x >= tp_first ? (x - tp_first) / ts + 1 : 0;
+}
+
+__device__ __forceinline__ int64_t wave_max_i64(int64_t v)
+{
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        const int64_t other = __shfl_xor(v, s, LANES);
+        v = other > v ? other : v;
+    }
+    return v;
+}
+
+struct ExtResult {
+    int32_t i, j, d, head, nb;
+};
+
+// One-directional greedy extension by one wavefront; lane (k & 63) owns diagonal k.
+// All lanes execute every shuffle; per-lane state: R (furthest i, -1 = dead) and H (trace head).
+__device__ ExtResult ext_wave(const uint8_t *__restrict__ ap, int astep, int32_t an,
+                              const uint8_t *__restrict__ bp, int bstep, int32_t bn,
+                              int32_t tp_first, const DhOpts &o, DhNode *__restrict__ pool,
+                              int32_t poolcap, int32_t &pool_n, unsigned long long &cells,
+                              int32_t &err)
+{
+    const int lane = threadIdx.x & (LANES - 1);
+    const int32_t ts = o.tspace, pen = o.pen, xdrop = o.xdrop;
+    int32_t R = -1, H = -1;
+    int32_t L = 0, U = 0;
+
+    // d = 0: the seed diagonal, slid by lane 0
+    int32_t i0 = 0, h0 = -1;
+    if (lane == 0) {
+        while (i0 < an && i0 < bn && ap[(int64_t)i0 * astep] == bp[(int64_t)i0 * bstep]) i0++;
+        const int32_t nb0 = nbound(i0, tp_first, ts);
+        for (int32_t m = 0; m < nb0; m++) {
+            const int32_t idx = pool_n + m;
+            if (idx < poolcap) {
+                pool[idx].parent = h0;
+                pool[idx].d = 0;
+                pool[idx].j = tp_first + m * ts;
+            }
+            h0 = idx;
+        }
+        R = i0;
+        H = h0;
+    }
+    i0 = __shfl(i0, 0, LANES);
+    h0 = __shfl(h0, 0, LANES);
+    pool_n += nbound(i0, tp_first, ts);
+    int32_t best_score = 2 * i0, best_i = i0, best_k = 0, best_d = 0, best_head = h0;
+    unsigned long long ncell = 1;
+
+    for (int32_t d = 1; d <= o.dmax; d++) {
+        const int32_t nL = L - 1, nU = U + 1;
+        const int32_t kidx = (lane - nL) & (LANES - 1);
+        const int32_t k = nL + kidx;
+        const bool inwin = k <= nU;
+        const int32_t Rm = __shfl(R, (lane + LANES - 1) & (LANES - 1), LANES);
+        const int32_t Hm = __shfl(H, (lane + LANES - 1) & (LANES - 1), LANES);
+        const int32_t Rp = __shfl(R, (lane + 1) & (LANES - 1), LANES);
+        const int32_t Hp = __shfl(H, (lane + 1) & (LANES - 1), LANES);
+        int32_t ni = -1, prev_i = 0, hd = -1;
+        if (inwin) {
+            if (R >= 0) {  // substitution on k
+                const int32_t c = R + 1;
+                if (c <= an && c - k <= bn && c - k >= 0) {
+                    ni = c;
+                    prev_i = R;
+                    hd = H;
+                }
+            }
+            if (Rm >= 0) {  // deletion from k-1 (consumes A)
+                const int32_t c = Rm + 1;
+                if (c <= an && c - k <= bn && c - k >= 0 && c > ni) {
+                    ni = c;
+                    prev_i = Rm;
+                    hd = Hm;
+                }
+            }
+            if (Rp >= 0) {  // insertion from k+1 (consumes B)
+                const int32_t c = Rp;
+                if (c <= an && c - k <= bn && c - k >= 0 && c > ni) {
+                    ni = c;
+                    prev_i = Rp;
+                    hd = Hp;
+                }
+            }
+        }
+        bool alive = ni >= 0;
+        if (alive) {
+            int32_t j = ni - k;
+            while (ni < an && j < bn && ap[(int64_t)ni * astep] == bp[(int64_t)j * bstep]) {
+                ni++;
+                j++;
+            }
+        }
+        const unsigned long long amask = __ballot(alive);
+        if (amask == 0ull) break;
+        ncell += __popcll(amask);
+        // trace nodes for the boundaries crossed in (prev_i, ni]
+        int32_t bidx = alive ? nbound(prev_i, tp_first, ts) : 0;
+        int32_t cnt = alive ? nbound(ni, tp_first, ts) - bidx : 0;
+        for (;;) {
+            const unsigned long long m = __ballot(cnt > 0);
+            if (m == 0ull) break;
+            if (cnt > 0) {
+                const int32_t idx = pool_n + __popcll(m & ((1ull << lane) - 1ull));
+                if (idx < poolcap) {
+                    pool[idx].parent = hd;
+                    pool[idx].d = d;
+                    pool[idx].j = tp_first + bidx * ts - k;
+                }
+                hd = idx;
+                bidx++;
+                cnt--;
+            }
+            pool_n += __popcll(m);
+        }
+        if (pool_n > poolcap) {
+            err |= DH_ST_POOL_OVERFLOW;
+            break;
+        }
+        R = alive ? ni : -1;
+        H = hd;
+        // best of this step: highest score, then lowest diagonal
+        const int32_t sc = alive ? 2 * ni - k - pen * d : INT32_MIN;
+        const int64_t key = alive ? ((((int64_t)sc + (1ll << 31)) << 8) | (int64_t)(127 - kidx)) : -1;
+        const int64_t kmax = wave_max_i64(key);
+        const int32_t step_best = (int32_t)((kmax >> 8) - (1ll << 31));
+        const int32_t step_kidx = 127 - (int32_t)(kmax & 0xff);
+        if (step_best > best_score) {
+            const int src = (nL + step_kidx) & (LANES - 1);
+            best_score = step_best;
+            best_k = nL + step_kidx;
+            best_i = __shfl(R, src, LANES);
+            best_head = __shfl(H, src, LANES);
+            best_d = d;
+        }
+        // trim to xdrop of the best
+        if (alive && sc < best_score - xdrop) {
+            alive = false;
+            R = -1;
+        }
+        unsigned long long lm = __ballot(alive);
+        if (lm == 0ull) break;
+        const int rot = nL & (LANES - 1);
+        unsigned long long rm = rot ? ((lm >> rot) | (lm << (LANES - rot))) : lm;
+        int32_t l2 = nL + (__ffsll((long long)rm) - 1);
+        int32_t u2 = nL + (63 - __clzll((long long)rm));
+        while (u2 - l2 + 1 > o.width) {
+            // drop the lower-scoring edge (same d: compare 2R - k), ties drop the low edge
+            const int32_t val = 2 * R - k;
+            const int32_t sl = __shfl(val, l2 & (LANES - 1), LANES);
+            const int32_t su = __shfl(val, u2 & (LANES - 1), LANES);
+            const int32_t kill = sl <= su ? l2 : u2;
+            if (k == kill) {
+                alive = false;
+                R = -1;
+            }
+            lm = __ballot(alive);
+            rm = rot ? ((lm >> rot) | (lm << (LANES - rot))) : lm;
+            l2 = nL + (__ffsll((long long)rm) - 1);
+            u2 = nL + (63 - __clzll((long long)rm));
+        }
+        L = l2;
+        U = u2;
+    }
+    cells += ncell;
+    ExtResult res;
+    res.i = best_i;
+    res.j = best_i - best_k;
+    res.d = best_d;
+    res.head = best_head;
+    res.nb = nbound(best_i, tp_first, ts);
+    return res;
+}
+
+// walk a trace chain (serial, one lane); writes cd/cj[m], returns diagonal excursion
+__device__ void walk_chain(const DhNode *__restrict__ pool, int32_t head, int32_t nb,
+                           int32_t tp_first, int32_t ts, int32_t best_k, int32_t *cd, int32_t *cj,
+                           int32_t &lo, int32_t &hi)
+{
+    lo = best_k < 0 ? best_k : 0;
+    hi = best_k > 0 ? best_k : 0;
+    int32_t h = head;
+    for (int32_t m = nb - 1; m >= 0 && h >= 0; m--) {
+        const DhNode nd = pool[h];
+        cd[m] = nd.d;
+        cj[m] = nd.j;
+        const int32_t kk = (tp_first + m * ts) - nd.j;
+        lo = kk < lo ? kk : lo;
+        hi = kk > hi ? kk : hi;
+        h = nd.parent;
+    }
+}
+
+__global__ void __launch_bounds__(LANES)
+k_wave(DbView A, DbView B, const uint8_t *__restrict__ brc, DhOpts o, int32_t item0,
+       int32_t nitems, const DhCand *__restrict__ cand, const int32_t *__restrict__ ncand,
+       WaveScratch ws, DhLa *__restrict__ out_la, uint16_t *__restrict__ out_trace,
+       int32_t trmax, int32_t *__restrict__ out_nla, unsigned long long *__restrict__ counters,
+       int32_t *__restrict__ status)
+{
+    const int lane = threadIdx.x;
+    DhNode *pool = ws.pool + (int64_t)blockIdx.x * ws.poolcap;
+    int32_t *cdj = ws.cdj + (int64_t)blockIdx.x * 4 * ws.nbmax;  // fd, fj, rd, rj
+    int32_t *fd = cdj, *fj = cdj + ws.nbmax, *rd = cdj + 2 * ws.nbmax, *rj = cdj + 3 * ws.nbmax;
+    const int32_t ts = o.tspace;
+    unsigned long long cells = 0, naln = 0;
+    int32_t err = 0;
+
+    for (;;) {
+        int32_t it = 0;
+        if (lane == 0) it = (int32_t)atomicAdd(ws.queue, 1u);
+        it = __shfl(it, 0, LANES);
+        if (it >= nitems) break;
+        const int32_t item = item0 + it;
+        const int32_t r = item >> 1, strand = item & 1;
+        const int32_t nc = ncand[item];
+        const int64_t bo = B.off[r];
+        const int32_t blen = (int32_t)(B.off[r + 1] - bo);
+        const uint8_t *b = (strand ? brc : B.bases) + bo;
+        // regions already aligned for this (read, strand): kept in registers of lanes 0..nd-1
+        int32_t g_aseq = -1, g_ab = 0, g_ae = 0, g_bb = 0, g_be = 0, g_lo = 0, g_hi = 0;
+        int32_t nd = 0, nacc = 0;
+        for (int32_t c = 0; c < nc && nacc < o.max_la && nd < LANES; c++) {
+            const DhCand cd = cand[(int64_t)item * o.max_cand + c];
+            const int32_t sd = cd.apos - cd.bpos;
+            const bool cov = lane < nd && g_aseq == cd.aseq && cd.apos >= g_ab && cd.apos < g_ae &&
+                             cd.bpos >= g_bb && cd.bpos < g_be && sd >= g_lo - 64 && sd <= g_hi + 64;
+            if (__ballot(cov) != 0ull) continue;
+            const int64_t ao = A.off[cd.aseq];
+            const int32_t alen = (int32_t)(A.off[cd.aseq + 1] - ao);
+            const uint8_t *a = A.bases + ao;
+            const int32_t as = cd.apos, bs = cd.bpos;
+            const int32_t fwd_first = ts - (as % ts);
+            const int32_t rev_first = (as % ts) ? (as % ts) : ts;
+            int32_t pool_n = 0;
+            const ExtResult fw = ext_wave(a + as, 1, alen - as, b + bs, 1, blen - bs, fwd_first, o,
+                                          pool, ws.poolcap, pool_n, cells, err);
+            const ExtResult rv = ext_wave(a + as - 1, -1, as, b + bs - 1, -1, bs, rev_first, o,
+                                          pool, ws.poolcap, pool_n, cells, err);
+            naln++;
+            if (err || fw.nb > ws.nbmax || rv.nb > ws.nbmax) {
+                err |= DH_ST_POOL_OVERFLOW;
+                break;
+            }
+            // chains: lane 0 walks the forward chain, lane 1 the reverse chain
+            int32_t flo = 0, fhi = 0, rlo = 0, rhi = 0;
+            if (lane == 0)
+                walk_chain(pool, fw.head, fw.nb, fwd_first, ts, fw.i - fw.j, fd, fj, flo, fhi);
+            if (lane == 1)
+                walk_chain(pool, rv.head, rv.nb, rev_first, ts, rv.i - rv.j, rd, rj, rlo, rhi);
+            __threadfence_block();
+            flo = __shfl(flo, 0, LANES);
+            fhi = __shfl(fhi, 0, LANES);
+            rlo = __shfl(rlo, 1, LANES);
+            rhi = __shfl(rhi, 1, LANES);
+            const int32_t abpos = as - rv.i, bbpos = bs - rv.j, aepos = as + fw.i, bepos = bs + fw.j;
+            const int32_t diffs = fw.d + rv.d;
+            int32_t lo = sd + flo, hi = sd + fhi;
+            lo = (sd - rhi) < lo ? (sd - rhi) : lo;
+            hi = (sd - rlo) > hi ? (sd - rlo) : hi;
+            if (lane == nd) {
+                g_aseq = cd.aseq;
+                g_ab = abpos;
+                g_ae = aepos;
+                g_bb = bbpos;
+                g_be = bepos;
+                g_lo = lo;
+                g_hi = hi;
+            }
+            nd++;
+            const int64_t al = aepos - abpos, bl = bepos - bbpos;
+            const bool accept = al >= o.min_len &&
+                                (int64_t)2 * diffs * 1000000ll <= (int64_t)o.max_err_ppm * (al + bl);
+            if (!accept) continue;
+            // trace assembly: points in increasing a, pair e = point[e+1] - point[e]
+            const int32_t nrv = rv.nb - ((rv.nb > 0 && rev_first + (rv.nb - 1) * ts == rv.i) ? 1 : 0);
+            const int32_t nfv = fw.nb - ((fw.nb > 0 && fwd_first + (fw.nb - 1) * ts == fw.i) ? 1 : 0);
+            const int32_t seedb = (as % ts == 0 && rv.i > 0 && fw.i > 0) ? 1 : 0;
+            const int32_t npairs = nrv + seedb + nfv + 1;
+            const int64_t slot = (int64_t)item * o.max_la + nacc;
+            uint16_t *tr = out_trace + slot * trmax;
+            for (int32_t e = lane; e < npairs; e += LANES) {
+                int32_t pb[2], pD[2];
+#pragma unroll
+                for (int w = 0; w < 2; w++) {
+                    const int32_t idx = e + w;
+                    if (idx == 0) {
+                        pb[w] = bbpos;
+                        pD[w] = -rv.d;
+                    } else if (idx <= nrv) {
+                        const int32_t m = nrv - idx;
+                        pb[w] = bs - rj[m];
+                        pD[w] = -rd[m];
+                    } else if (idx <= nrv + seedb) {
+                        pb[w] = bs;
+                        pD[w] = 0;
+                    } else if (idx <= nrv + seedb + nfv) {
+                        const int32_t m = idx - 1 - nrv - seedb;
+                        pb[w] = bs + fj[m];
+                        pD[w] = fd[m];
+                    } else {
+                        pb[w] = bepos;
+                        pD[w] = fw.d;
+                    }
+                }
+                tr[2 * e] = (uint16_t)(pD[1] - pD[0]);
+                tr[2 * e + 1] = (uint16_t)(pb[1] - pb[0]);
+            }
+            if (lane == 0) {
+                DhLa la;
+                la.tlen = 2 * npairs;
+                la.diffs = diffs;
+                la.abpos = abpos;
+                la.bbpos = bbpos;
+                la.aepos = aepos;
+                la.bepos = bepos;
+                la.flags = strand ? 1u : 0u;
+                la.aread = cd.aseq;
+                la.bread = r;
+                la.pad = 0;
+                la.toff = 0;
+                out_la[slot] = la;
+            }
+            nacc++;
+        }
+        if (lane == 0) out_nla[item] = nacc;
+        if (err) break;
+    }
+    if (lane == 0) {
+        atomicAdd(&counters[0], cells);
+        atomicAdd(&counters[1], naln);
+        if (err) atomicOr(status, err);
+    }
+}
+
+// gather the accepted LAs' traces into one compact array: one block per LA
+__global__ void __launch_bounds__(64)
+k_gather_trace(const uint16_t *__restrict__ slots, int32_t trmax, const int64_t *__restrict__ src_slot,
+               const int64_t *__restrict__ dst_off, const int32_t *__restrict__ tlen,
+               uint16_t *__restrict__ dst)
+{
+    const int64_t i = blockIdx.x;
+    const uint16_t *s = slots + src_slot[i] * trmax;
+    uint16_t *d = dst + dst_off[i];
+    for (int32_t x = threadIdx.x; x < tlen[i]; x += blockDim.x) d[x] = s[x];
+}
+
+// ------------------------------------------------------------------------------------ launchers
+
+extern "C" {
+
+void dhk_revcomp(hipStream_t st, const uint8_t *src, uint8_t *dst, const int64_t *off, int32_t n,
+                 int32_t max_len)
+{
+    if (n <= 0) return;
+    int gx = (max_len + 255) / 256;
+    if (gx > 64) gx = 64;
+    if (gx < 1) gx = 1;
+    // grid.y is limited to 65535: loop in slabs
+    for (int32_t s0 = 0; s0 < n; s0 += 65535) {
+        const int32_t cnt = n - s0 < 65535 ? n - s0 : 65535;
+        // shifted views: off + s0 keeps absolute offsets into src/dst
+        hipLaunchKernelGGL(k_revcomp, dim3(gx, cnt), dim3(256), 0, st, src, dst, off + s0, cnt);
+    }
+}
+
+void dhk_kmer_pass(hipStream_t st, int fill, DbView A, const int2 *tiles, int32_t ntiles, int32_t k,
+                   int32_t shift, uint32_t *dir, uint64_t *ekey, uint64_t *eval,
+                   const int64_t *goff)
+{
+    if (ntiles <= 0) return;
+    if (fill)
+        hipLaunchKernelGGL(k_kmer_pass<true>, dim3(ntiles), dim3(256), 0, st, A, tiles, ntiles, k,
+                           shift, dir, ekey, eval, goff);
+    else
+        hipLaunchKernelGGL(k_kmer_pass<false>, dim3(ntiles), dim3(256), 0, st, A, tiles, ntiles, k,
+                           shift, dir, ekey, eval, goff);
+}
+
+// exclusive scan in place; sums must hold ceil(n / 2048) uint32
+void dhk_scan(hipStream_t st, uint32_t *v, int64_t n, uint32_t *sums)
+{
+    const int32_t nb = (int32_t)((n + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
+    hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(256), 0, st, v, n, sums);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, sums, nb);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, v, n, sums);
+}
+
+void dhk_bucket_sort(hipStream_t st, const uint32_t *dir_end, int64_t nb, uint64_t *ekey,
+                     uint64_t *eval)
+{
+    hipLaunchKernelGGL(k_bucket_sort, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, dir_end,
+                       nb, ekey, eval);
+}
+
+void dhk_seed(hipStream_t st, int cap, DbView B, const uint8_t *brc, IndexView ix, DhOpts o,
+              int32_t item0, int32_t nitems, DhCand *cand, int32_t *ncand, int32_t *nhits,
+              int32_t *status)
+{
+    if (nitems <= 0) return;
+    if (cap <= 4096)
+        hipLaunchKernelGGL(k_seed<4096>, dim3(nitems), dim3(SEED_THREADS), 0, st, B, brc, ix, o,
+                           item0, nitems, cand, ncand, nhits, status);
+    else
+        hipLaunchKernelGGL(k_seed<16384>, dim3(nitems), dim3(SEED_THREADS), 0, st, B, brc, ix, o,
+                           item0, nitems, cand, ncand, nhits, status);
+}
+
+void dhk_wave(hipStream_t st, int32_t nslots, DbView A, DbView B, const uint8_t *brc, DhOpts o,
+              int32_t item0, int32_t nitems, const DhCand *cand, const int32_t *ncand,
+              WaveScratch ws, DhLa *out_la, uint16_t *out_trace, int32_t trmax, int32_t *out_nla,
+              unsigned long long *counters, int32_t *status)
+{
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL(k_wave, dim3(nslots), dim3(LANES), 0, st, A, B, brc, o, item0, nitems, cand,
+                       ncand, ws, out_la, out_trace, trmax, out_nla, counters, status);
+}
+
+void dhk_gather_trace(hipStream_t st, int64_t n, const uint16_t *slots, int32_t trmax,
+                      const int64_t *src_slot, const int64_t *dst_off, const int32_t *tlen,
+                      uint16_t *dst)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_gather_trace, dim3((unsigned)n), dim3(64), 0, st, slots, trmax, src_slot,
+                       dst_off, tlen, dst);
+}
+
+}  // extern "C"
