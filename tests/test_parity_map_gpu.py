@@ -1,0 +1,164 @@
+"""Parity of the HIP alignment pass (through the C ABI) with the CPU oracle -- bit exact.
+
+Coordinates, read ids, flags, diffs and every trace value must be identical (integer work).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import dentist_amd
+from dentist_amd import sim
+from helpers import assert_same_las, check_trace_invariants
+from oracle import pyoracle as oz
+
+pytestmark = pytest.mark.gpu
+
+OPT_FIELDS = ("k", "hmin", "band_shift", "tspace", "min_len", "pen", "xdrop", "max_err_ppm", "max_cand",
+              "max_la", "tcap", "strands", "skip_self", "dmax", "width")
+
+
+def both_opts(**kw):
+    g = dentist_amd.default_align_opts(**kw)
+    o = oz.default_opts()
+    for f in OPT_FIELDS:
+        setattr(o, f, getattr(g, f))
+    return g, o
+
+
+def run_both(ctx, A, B, same=False, **kw):
+    g, o = both_opts(**kw)
+    exp = oz.align_db(A, B, o, nthreads=os.cpu_count() or 1)
+    dA = ctx.db(A)
+    dB = dA if same else ctx.db(B)
+    got = ctx.align_db(dA, dB, g)
+    st = ctx.align_stats()
+    assert (st.hits, st.cands, st.alignments, st.wave_cells) == tuple(int(x) for x in exp[2])
+    assert_same_las(got, exp[:2])
+    check_trace_invariants(got[0], got[1], g.tspace)
+    return got
+
+
+def test_mapping_reads_to_contigs(gpu_ctx):
+    w = sim.Workload(400_000, 4, 800, 5000, seed=7, spacing=20000)
+    las, _ = run_both(gpu_ctx, w.contigs, w.reads)
+    assert len(set(las["bread"].tolist())) == w.reads.n
+
+
+@pytest.mark.parametrize("seed,rl,err", [(3, 2500, 0.13), (5, 9000, 0.13), (9, 6000, 0.05), (13, 4000, 0.20)])
+def test_mapping_various_lengths_and_error_rates(gpu_ctx, seed, rl, err):
+    w = sim.Workload(250_000, 3, 250, rl, seed=seed, err=err, spacing=15000)
+    run_both(gpu_ctx, w.contigs, w.reads)
+
+
+def test_lognormal_read_lengths_like_the_reference_fixture(gpu_ctx):
+    """simulator -m25000 -s12500 -e.13 (tests/test-commands.sh:7-13) on the 4 097 bp fixture."""
+    raw = open(os.path.join(os.path.dirname(__file__), "golden", "test_commands_assembly_reference.fasta")).read()
+    seq = sim.encode("".join(raw.split("\n")[1:]))
+    contigs = sim.SeqDb.from_list([seq[:2000], seq[2097:]])
+    reads, _ = sim.reads(1724161952, seq, 33, 25000, 12500, min_len=500)
+    las, _ = run_both(gpu_ctx, contigs, reads, min_len=500)
+    assert len(las) > 0
+
+
+def pile(seed, glen=20000, n=30, rl=6000):
+    g = sim.genome(seed, glen)
+    reads, _ = sim.reads(seed + 1, g, n, rl)
+    return reads
+
+
+def test_pile_all_vs_all_tspace_126(gpu_ctx):
+    """daligner -s126 -l500 on a pile-up DB against itself (commandline.d:2886-2902)."""
+    p = pile(21)
+    las, _ = run_both(gpu_ctx, p, p, same=True, tspace=126, skip_self=1, min_len=500)
+    assert len(las) > p.n
+    assert not np.any(las["aread"] == las["bread"])
+
+
+def test_grouped_piles_never_cross_groups(gpu_ctx):
+    p1, p2 = pile(31, n=12), pile(41, n=9)
+    both = sim.SeqDb(np.concatenate([p1.bases, p2.bases]), np.concatenate([p1.off, p2.off[1:] + p1.off[-1]]),
+                     group=np.asarray([0] * p1.n + [1] * p2.n, dtype=np.int32))
+    las, trace = run_both(gpu_ctx, both, both, same=True, tspace=126, skip_self=1)
+    grp = both.group
+    assert np.all(grp[las["aread"]] == grp[las["bread"]])
+    # property: the batched result is the union of the per-pile results
+    g, _ = both_opts(tspace=126, skip_self=1)
+    d1 = gpu_ctx.db(p1)
+    l1, _ = gpu_ctx.align_db(d1, d1, g)
+    d2 = gpu_ctx.db(p2)
+    l2, _ = gpu_ctx.align_db(d2, d2, g)
+    assert len(l1) + len(l2) == len(las)
+    sel = las[grp[las["aread"]] == 0]
+    for f in ("abpos", "aepos", "bbpos", "bepos", "diffs", "aread", "bread"):
+        assert np.array_equal(sel[f], l1[f])
+
+
+def test_edge_cases_empty_short_and_n_reads(gpu_ctx):
+    g = sim.genome(5, 30000)
+    rd, _ = sim.reads(6, g, 20, 3000)
+    seqs = [rd.seq(i).copy() for i in range(rd.n)]
+    seqs[3] = seqs[3][:9]                      # shorter than k
+    seqs[5] = np.zeros(0, dtype=np.uint8)      # empty
+    seqs[7][100:140] = 4                       # run of N
+    seqs[8] = np.full(500, 4, dtype=np.uint8)  # all N
+    B = sim.SeqDb.from_list(seqs)
+    A = sim.SeqDb.from_list([g[:14000], g[14100:], np.zeros(0, dtype=np.uint8), g[:5]])
+    las, _ = run_both(gpu_ctx, A, B)
+    assert 3 not in las["bread"] and 5 not in las["bread"] and 8 not in las["bread"]
+
+
+def test_no_alignments_at_all(gpu_ctx):
+    A = sim.SeqDb.from_list([sim.genome(1, 20000)])
+    B = sim.SeqDb.from_list([sim.genome(2, 3000), sim.genome(3, 3000)])
+    las, trace = run_both(gpu_ctx, A, B)
+    assert len(las) == 0 and len(trace) == 0
+
+
+def test_seed_on_trace_boundary_and_sequence_ends(gpu_ctx):
+    """Reads that start exactly on a multiple of tspace and reach both contig ends."""
+    g = sim.genome(77, 6000)
+    A = sim.SeqDb.from_list([g])
+    B = sim.SeqDb.from_list([g[0:3000].copy(), g[3000:6000].copy(), g[1400:4400].copy(), sim.revcomp(g[200:5800])])
+    las, trace = run_both(gpu_ctx, A, B, min_len=100)
+    assert len(las) == 4 and int(las["diffs"].sum()) == 0
+    full = las[las["bread"] == 3][0]
+    assert (full["abpos"], full["aepos"], full["flags"] & 1) == (200, 5800, 1)
+
+
+def test_chunked_launches_give_identical_results(gpu_ctx, monkeypatch):
+    w = sim.Workload(200_000, 2, 300, 3000, seed=19, spacing=15000)
+    g, _ = both_opts()
+    A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
+    one = gpu_ctx.align_db(A, B, g)
+    monkeypatch.setenv("DH_ALIGN_CHUNK", "64")
+    many = gpu_ctx.align_db(A, B, g)
+    assert gpu_ctx.align_stats().wave_launches > 1
+    assert_same_las(many, one)
+
+
+def test_select_best_flags(gpu_ctx):
+    w = sim.Workload(200_000, 2, 200, 4000, seed=23, spacing=15000)
+    g, _ = both_opts()
+    A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
+    las, _ = gpu_ctx.align_db(A, B, g, select_best=True)
+    assert np.all(las["flags"] & 0x4) and np.any(las["flags"] & 0x10)
+
+
+def test_larger_run_properties(gpu_ctx):
+    """At a size the oracle would take long for: size-independent properties only."""
+    w = sim.Workload(3_000_000, 20, 20000, 8000, seed=101)
+    g, _ = both_opts()
+    A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
+    las, trace = gpu_ctx.align_db(A, B, g)
+    check_trace_invariants(las[:: max(1, len(las) // 2000)], trace, 100)
+    assert len(set(las["bread"].tolist())) >= 0.995 * w.reads.n
+    s = w.read_truth[las["bread"], 0]
+    e = w.read_truth[las["bread"], 1]
+    cs = w.contig_start[las["aread"]]
+    ok = ((las["flags"] & 1) == w.read_truth[las["bread"], 2]) & (cs + las["abpos"] >= s - 80) & (cs + las["aepos"] <= e + 80)
+    assert ok.mean() > 0.999
+    # idempotence: a second run (index rebuilt) is bit-identical
+    A.drop_cache()
+    las2, trace2 = gpu_ctx.align_db(A, B, g)
+    assert np.array_equal(las, las2) and np.array_equal(trace, trace2)
