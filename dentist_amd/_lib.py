@@ -34,6 +34,17 @@ class AlignStats(ctypes.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "pad"}
 
 
+class ProcessOpts(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "tspace_map", "allowance", "min_anchor", "min_reads", "max_reads", "tspace_pile", "rounds",
+        "flank_window", "max_align_err_ppm", "max_ins_err_ppm", "bad_fraction_ppm", "reserved")]
+
+
+INSERTION_DTYPE = np.dtype([(n, "<i4") for n in (
+    "contig_left", "status", "nreads", "ref_read", "ref_read_id", "crop_left", "crop_right", "left_aepos",
+    "right_abpos", "ins_begin", "ins_end", "comp", "cons_len", "left_diffs", "right_diffs", "pad")]
+    + [("cons_off", "<i8")])
+
 LA_DTYPE = np.dtype([("tlen", "<i4"), ("diffs", "<i4"), ("abpos", "<i4"), ("bbpos", "<i4"),
                      ("aepos", "<i4"), ("bepos", "<i4"), ("flags", "<u4"), ("aread", "<i4"),
                      ("bread", "<i4"), ("pad", "<i4"), ("toff", "<i8")])
@@ -44,7 +55,10 @@ SYMBOLS = [
     "dh_default_align_opts", "dh_db_create", "dh_db_destroy", "dh_db_drop_cache", "dh_db_nreads",
     "dh_db_total_bases", "dh_la_set_destroy", "dh_la_set_count", "dh_la_set_trace_len",
     "dh_la_set_records", "dh_la_set_trace", "dh_la_set_tspace", "dh_get_align_stats", "dh_align_db",
-    "dh_las_write", "dh_las_read",
+    "dh_las_write", "dh_las_read", "dh_default_process_opts", "dh_collect_spanning", "dh_pileups_destroy",
+    "dh_pileups_count", "dh_pileups_get", "dh_process_pileups", "dh_insertions_destroy",
+    "dh_insertions_count", "dh_insertions_records", "dh_insertions_bases", "dh_insertions_bases_len",
+    "dh_get_process_stats",
 ]
 
 _LIB = None
@@ -89,6 +103,24 @@ def lib():
     L.dh_align_db.argtypes = [vp, vp, vp, ctypes.POINTER(AlignOpts), i32, ctypes.POINTER(vp)]
     L.dh_las_write.argtypes = [ctypes.c_char_p, vp, i64, vp, i32]
     L.dh_las_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
+    L.dh_default_process_opts.argtypes = [ctypes.POINTER(ProcessOpts)]
+    L.dh_collect_spanning.argtypes = [vp, i64, vp, i32, ctypes.POINTER(ProcessOpts), ctypes.POINTER(vp)]
+    L.dh_pileups_destroy.argtypes = [vp]
+    L.dh_pileups_count.argtypes = [vp]
+    L.dh_pileups_count.restype = i32
+    L.dh_pileups_get.argtypes = [vp, i32, ctypes.POINTER(i32), ctypes.POINTER(vp)]
+    L.dh_pileups_get.restype = i32
+    L.dh_process_pileups.argtypes = [vp, vp, vp, vp, i64, vp, vp, ctypes.POINTER(ProcessOpts), ctypes.POINTER(vp)]
+    L.dh_insertions_destroy.argtypes = [vp]
+    L.dh_insertions_count.argtypes = [vp]
+    L.dh_insertions_count.restype = i32
+    L.dh_insertions_records.argtypes = [vp]
+    L.dh_insertions_records.restype = vp
+    L.dh_insertions_bases.argtypes = [vp]
+    L.dh_insertions_bases.restype = vp
+    L.dh_insertions_bases_len.argtypes = [vp]
+    L.dh_insertions_bases_len.restype = i64
+    L.dh_get_process_stats.argtypes = [vp, vp, vp]
     _LIB = L
     return L
 
@@ -201,3 +233,74 @@ def las_read(path):
     h = ctypes.c_void_p()
     _check(lib().dh_las_read(path.encode(), ctypes.byref(h)))
     return _take_la_set(h)
+
+
+def default_process_opts(**kw):
+    o = ProcessOpts()
+    lib().dh_default_process_opts(ctypes.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+class Pileups:
+    """Spanning-read pile-ups per gap (host only): dh_collect_spanning."""
+
+    def __init__(self, las, contig_off, opts):
+        arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
+        off = np.ascontiguousarray(contig_off, dtype=np.int64)
+        h = ctypes.c_void_p()
+        _check(lib().dh_collect_spanning(arr.ctypes.data, len(arr), off.ctypes.data, len(off) - 1,
+                                         ctypes.byref(opts), ctypes.byref(h)))
+        self._h = h
+
+    def __len__(self):
+        return lib().dh_pileups_count(self._h)
+
+    def get(self, i):
+        g = ctypes.c_int32()
+        p = ctypes.c_void_p()
+        n = lib().dh_pileups_get(self._h, i, ctypes.byref(g), ctypes.byref(p))
+        tri = np.frombuffer(ctypes.string_at(p, n * 12), dtype=np.int32).reshape(n, 3).copy()
+        return g.value, tri
+
+    def close(self):
+        if self._h:
+            lib().dh_pileups_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def process_pileups(ctx, contigs, reads, las, trace, piles, opts):
+    """dentist `process` for a batch of pile-ups on the GPU. Returns (records, consensus bases)."""
+    L = lib()
+    arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
+    tr = np.ascontiguousarray(trace, dtype=np.uint16)
+    h = ctypes.c_void_p()
+    _check(L.dh_process_pileups(ctx._h, contigs._h, reads._h, arr.ctypes.data, len(arr), tr.ctypes.data,
+                                piles._h, ctypes.byref(opts), ctypes.byref(h)))
+    n = L.dh_insertions_count(h)
+    nb = L.dh_insertions_bases_len(h)
+    rec = (np.frombuffer(ctypes.string_at(L.dh_insertions_records(h), n * INSERTION_DTYPE.itemsize),
+                         dtype=INSERTION_DTYPE).copy() if n else np.zeros(0, dtype=INSERTION_DTYPE))
+    bases = (np.frombuffer(ctypes.string_at(L.dh_insertions_bases(h), nb), dtype=np.uint8).copy()
+             if nb else np.zeros(0, dtype=np.uint8))
+    L.dh_insertions_destroy(h)
+    return rec, bases
+
+
+def process_stats(ctx):
+    ms = (ctypes.c_float * 7)()
+    cnt = (ctypes.c_int64 * 3)()
+    _check(lib().dh_get_process_stats(ctx._h, ms, cnt))
+    names = ("crop", "pile_align", "tile_qv", "consensus", "realign", "flank_align", "total")
+    d = {f"ms_{n}": float(ms[i]) for i, n in enumerate(names)}
+    d.update(pile_las=int(cnt[0]), tiles=int(cnt[1]), nw_cells=int(cnt[2]))
+    return d

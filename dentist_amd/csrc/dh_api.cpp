@@ -4,20 +4,13 @@
 // index is built in HBM, per-slot wave scratch is preallocated), sequences launches on the
 // context's stream and times the stages with HIP events on that stream.  No CPU fallback: every
 // compute entry point needs a working HIP device.
-#include "../../include/dentist_hip.h"
-
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
-#include <string>
-#include <vector>
 
-#include "dh_device.h"
+#include "dh_internal.h"
 
 static_assert(sizeof(dh_align_opts) == sizeof(DhOpts), "opts layout");
 static_assert(sizeof(dh_la) == sizeof(DhLa), "la layout");
@@ -25,32 +18,18 @@ static_assert(sizeof(dh_la) == 48, "la size");
 
 static thread_local std::string g_err;
 
-static int fail(int code, const std::string &msg)
+int dh_fail(int code, const std::string &msg)
 {
     g_err = msg;
     return code;
 }
-
-#define HIPCHK(expr)                                                                             \
-    do {                                                                                         \
-        hipError_t e_ = (expr);                                                                  \
-        if (e_ != hipSuccess)                                                                    \
-            return fail(DH_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));             \
-    } while (0)
+#define fail dh_fail
 
 extern "C" const char *dh_last_error(void) { return g_err.c_str(); }
 extern "C" int32_t dh_abi_version(void) { return 1; }
 
 // ------------------------------------------------------------------------------------ context
 
-struct dh_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    int ncu = 0;
-    hipEvent_t ev[6] = {};
-    dh_align_stats stats = {};
-};
 
 extern "C" int dh_ctx_create(int32_t device, void *stream, dh_ctx **out)
 {
@@ -123,38 +102,7 @@ extern "C" void dh_default_align_opts(dh_align_opts *o)
 
 // ------------------------------------------------------------------------------------ DB
 
-struct dh_index {
-    uint32_t *d_dir = nullptr;
-    uint64_t *d_ekey = nullptr;
-    uint64_t *d_eval = nullptr;
-    int64_t *d_goff = nullptr;
-    int64_t n = 0;
-    int32_t k = 0, sepv = 0, shift = 0, pbits = 0, na = 0;
-    void release()
-    {
-        (void)hipFree(d_dir);
-        (void)hipFree(d_ekey);
-        (void)hipFree(d_eval);
-        (void)hipFree(d_goff);
-        d_dir = nullptr;
-        d_ekey = d_eval = nullptr;
-        d_goff = nullptr;
-    }
-};
 
-struct dh_db {
-    dh_ctx *ctx = nullptr;
-    int32_t n = 0, max_len = 0, ngroups = 1;
-    int64_t total = 0;
-    uint8_t *d_bases = nullptr, *d_rc = nullptr;
-    int64_t *d_off = nullptr;
-    int32_t *d_group = nullptr;
-    std::vector<int64_t> h_off;
-    std::vector<int32_t> h_group;
-    dh_index ix;
-    bool has_ix = false;
-    DbView view() const { return DbView{d_bases, d_off, d_group, n}; }
-};
 
 extern "C" int dh_db_create(dh_ctx *ctx, const uint8_t *bases, const int64_t *off, int32_t n,
                             const int32_t *group, dh_db **out)
@@ -236,7 +184,7 @@ extern "C" int dh_db_drop_cache(dh_db *db)
     return DH_OK;
 }
 
-static int ensure_rc(dh_db *db)
+int dh_ensure_rc(dh_db *db)
 {
     if (db->d_rc) return DH_OK;
     const size_t nb = (size_t)std::max<int64_t>(db->total, 1) + 64;
@@ -322,11 +270,6 @@ static int build_index(dh_db *A, int32_t k, int32_t sepv)
 
 // ------------------------------------------------------------------------------------ LA sets
 
-struct dh_la_set {
-    std::vector<dh_la> la;
-    std::vector<uint16_t> trace;
-    int32_t tspace = 0;
-};
 
 extern "C" void dh_la_set_destroy(dh_la_set *s) { delete s; }
 extern "C" int64_t dh_la_set_count(const dh_la_set *s) { return s ? (int64_t)s->la.size() : 0; }
@@ -382,12 +325,6 @@ static void select_best(std::vector<dh_la> &la)
 
 // ------------------------------------------------------------------------------------ align
 
-template <typename T>
-struct DevBuf {
-    T *p = nullptr;
-    ~DevBuf() { (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, sizeof(T) * std::max<size_t>(n, 1)); }
-};
 
 extern "C" int dh_align_db(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts,
                            int32_t want_best, dh_la_set **out)
@@ -422,7 +359,7 @@ extern "C" int dh_align_db(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts 
     HIPCHK(hipEventRecord(ctx->ev[0], st));
     const int32_t sepv = ((B->max_len + 64) + 63) & ~63;
     if (int rc = build_index(A, o.k, sepv)) return rc;
-    if (int rc = ensure_rc(B)) return rc;
+    if (int rc = dh_ensure_rc(B)) return rc;
     HIPCHK(hipEventRecord(ctx->ev[1], st));
 
     DhOpts dopt;

@@ -1,0 +1,363 @@
+// dh_consensus.hip -- gfx950 kernels of the pile-up consensus path.
+//
+// K1b k_gather_slices   build a DB from slices of another DB (cropped reads, flank windows,
+//                       reference reads) without leaving HBM
+// K7  k_tile_qv         intrinsic QV per trace tile of every pile-up read (DASqv role)
+// K8a k_seg_vote        one thread per (overlap, trace tile): Needleman-Wunsch of the tile
+//                       (findAlignment semantics, util/string.d:478-520, 775-831) with the score
+//                       matrix interleaved in HBM, canonical indel placement, column votes
+// K8b k_emit            run-length aware majority emission of the new consensus
+//
+// Arithmetic spec: DESIGN.md "Algorithm DH-1 / consensus"; reference call sites
+// source/dentist/dazzler.d:6142-6156 (DASqv), 6185-6231 (daccord).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dh_device.h"
+
+#define MAXINS 4
+#define VSTRIDE (6 + 4 * MAXINS)
+#define MAXQV 50
+#define SEG_MAX 250 /* longest tile side the u8 score matrix supports */
+
+// ------------------------------------------------------------------------------------ K1b
+
+__global__ void __launch_bounds__(256)
+k_gather_slices(const uint8_t *__restrict__ src, const int64_t *__restrict__ src_off,
+                const int32_t *__restrict__ sidx, const int32_t *__restrict__ sbeg,
+                const int64_t *__restrict__ dst_off, int32_t n, uint8_t *__restrict__ dst)
+{
+    const int32_t s = blockIdx.y;
+    if (s >= n) return;
+    const int64_t so = src_off[sidx[s]] + sbeg[s];
+    const int64_t d0 = dst_off[s], len = dst_off[s + 1] - d0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len;
+         i += (int64_t)gridDim.x * blockDim.x)
+        dst[d0 + i] = src[so + i];
+}
+
+// ------------------------------------------------------------------------------------ K7
+
+// las sorted by aread; la_first[r] .. la_first[r+1] are the LAs with aread == r.
+// qv[r * maxtiles + t]; tile value = floor(200 * diffs / (tile_len + bbases)), the QV is the mean
+// of the lowest min(cov, m) values, capped at MAXQV; MAXQV when no overlap covers the tile.
+__global__ void __launch_bounds__(64)
+k_tile_qv(const DhLa *__restrict__ las, const uint16_t *__restrict__ trace,
+          const int32_t *__restrict__ la_first, const int64_t *__restrict__ roff, int32_t nreads,
+          int32_t tspace, int32_t cov, int32_t maxtiles, uint8_t *__restrict__ qv)
+{
+    const int32_t r = blockIdx.x;
+    if (r >= nreads) return;
+    const int32_t rlen = (int32_t)(roff[r + 1] - roff[r]);
+    const int32_t nt = (rlen + tspace - 1) / tspace;
+    for (int32_t t = threadIdx.x; t < nt && t < maxtiles; t += blockDim.x) {
+        const int32_t t0 = t * tspace, t1 = (t0 + tspace < rlen) ? t0 + tspace : rlen;
+        int32_t vals[64];
+        int32_t m = 0;
+        for (int32_t i = la_first[r]; i < la_first[r + 1]; i++) {
+            const DhLa la = las[i];
+            if (la.flags & 0x20u) continue;
+            if (la.abpos > t0 || la.aepos < t1) continue;
+            const int32_t e = t - la.abpos / tspace;
+            const int32_t seg0 = e == 0 ? la.abpos : t0;
+            const int32_t seg1 = (e == la.tlen / 2 - 1) ? la.aepos : t1;
+            if (seg0 != t0 || seg1 != t1) continue;
+            const uint16_t *tr = trace + la.toff;
+            const int32_t val = 200 * (int32_t)tr[2 * e] / ((t1 - t0) + (int32_t)tr[2 * e + 1]);
+            // insertion into the sorted prefix; only the lowest 64 matter (cov <= 64)
+            int32_t p = m < 64 ? m : 63;
+            if (m >= 64 && val >= vals[63]) continue;
+            while (p > 0 && vals[p - 1] > val) {
+                vals[p] = vals[p - 1];
+                p--;
+            }
+            vals[p] = val;
+            if (m < 64) m++;
+        }
+        int32_t q = MAXQV;
+        if (m > 0) {
+            const int32_t use = m < cov ? m : cov;
+            int64_t sum = 0;
+            for (int32_t x = 0; x < use; x++) sum += vals[x];
+            q = (int32_t)(sum / use);
+            if (q > MAXQV) q = MAXQV;
+        }
+        qv[(int64_t)r * maxtiles + t] = (uint8_t)q;
+    }
+}
+
+// ------------------------------------------------------------------------------------ K8a
+
+struct SegDesc {
+    int32_t tmpl;        // template (A) sequence index in the template DB
+    int32_t a0, a1;      // A interval of the tile
+    int32_t bseq;        // B sequence index in the read DB
+    int32_t b0, b1;      // B interval (in the orientation of the overlap)
+    int32_t comp;        // 1: B is reverse-complemented
+    int32_t pad;
+};
+
+__global__ void __launch_bounds__(64)
+k_seg_vote(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R,
+           const uint8_t *__restrict__ rrc, const int64_t *__restrict__ voff,
+           uint8_t *__restrict__ fmat, int32_t wmax, uint8_t *__restrict__ opbuf,
+           uint32_t *__restrict__ votes, int32_t *__restrict__ status)
+{
+    const int32_t dp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (dp >= nseg) return;
+    const SegDesc sg = segs[dp];
+    const int32_t rl = sg.a1 - sg.a0, ql = sg.b1 - sg.b0;
+    if (rl > SEG_MAX || ql > SEG_MAX || ql > wmax) {
+        atomicOr(status, DH_ST_POOL_OVERFLOW);
+        return;
+    }
+    const uint8_t *ref = T.bases + T.off[sg.tmpl] + sg.a0;
+    const uint8_t *qry = (sg.comp ? rrc : R.bases) + R.off[sg.bseq] + sg.b0;
+    const int64_t NDP = nseg;
+    const int32_t W = wmax + 1;
+#define FM(i, j) fmat[((int64_t)(i) * W + (j)) * NDP + dp]
+    // ---- fill (unit mismatch, indel 1, no free shift)
+    for (int32_t j = 0; j <= ql; j++) FM(0, j) = (uint8_t)j;
+    for (int32_t i = 1; i <= rl; i++) {
+        const uint8_t rc = ref[i - 1];
+        uint8_t left = (uint8_t)i;      // F[i][0]
+        uint8_t diag = (uint8_t)(i - 1);  // F[i-1][0]
+        FM(i, 0) = left;
+        for (int32_t j = 1; j <= ql; j++) {
+            const uint8_t up = FM(i - 1, j);
+            const uint8_t m = (uint8_t)(diag + (rc == qry[j - 1] ? 0 : 1));
+            uint8_t v = m < (uint8_t)(up + 1) ? m : (uint8_t)(up + 1);
+            v = v < (uint8_t)(left + 1) ? v : (uint8_t)(left + 1);
+            FM(i, j) = v;
+            diag = up;
+            left = v;
+        }
+    }
+    // ---- traceback (tracebackScoringMatrix: smallest neighbour, diagonal > insertion > deletion)
+    // ops are produced back to front into the interleaved op buffer; opbuf row t = op number t
+    // counted from the END of the path.
+    const int32_t opcap = 2 * SEG_MAX;
+#define OPB(t) opbuf[(int64_t)(t)*NDP + dp]
+    int32_t i = rl, j = ql, nops = 0;
+    while (i > 0 && j > 0) {
+        const uint8_t ms = FM(i - 1, j - 1), is = FM(i, j - 1), ds = FM(i - 1, j);
+        uint8_t nx = ms < ds ? ms : ds;
+        nx = is < nx ? is : nx;
+        uint8_t op;
+        if (nx == ms) {
+            op = 0;
+            --i;
+            --j;
+        } else if (nx == is) {
+            op = 2;
+            --j;
+        } else {
+            op = 1;
+            --i;
+        }
+        OPB(nops) = op;
+        nops++;
+    }
+    while (i > 0) {
+        OPB(nops) = 1;
+        nops++;
+        --i;
+    }
+    while (j > 0) {
+        OPB(nops) = 2;
+        nops++;
+        --j;
+    }
+    (void)opcap;
+    // ---- per-column view of the tile
+    uint8_t colst[SEG_MAX + 1];
+    uint8_t icnt[SEG_MAX + 2];
+    uint8_t ibase[(SEG_MAX + 2) * MAXINS];
+    for (int32_t x = 0; x <= rl; x++) icnt[x] = 0;
+    {
+        int32_t x = 0, y = 0;
+        for (int32_t t = nops - 1; t >= 0; t--) {
+            const uint8_t op = OPB(t);
+            if (op == 0) {
+                colst[x++] = qry[y++];
+            } else if (op == 1) {
+                colst[x++] = 5;
+            } else {
+                if (icnt[x] < MAXINS) ibase[x * MAXINS + icnt[x]] = qry[y];
+                if (icnt[x] < 255) icnt[x]++;
+                y++;
+            }
+        }
+    }
+    // ---- canonical (leftmost) placement of indels inside homopolymer runs of the template
+    for (int32_t x = 0; x < rl; x++) {
+        if (colst[x] != 5) continue;
+        const uint8_t c = ref[x];
+        int32_t st = x;
+        while (st > 0 && colst[st - 1] == c && ref[st - 1] == c && icnt[st] == 0) st--;
+        if (st < x) {
+            colst[st] = 5;
+            colst[x] = c;
+        }
+    }
+    for (int32_t x = 1; x <= rl; x++) {
+        const int32_t n = icnt[x];
+        if (n == 0 || n > MAXINS) continue;
+        const uint8_t c = ibase[x * MAXINS];
+        bool same = c < 4;
+        for (int32_t t = 1; t < n; t++) same = same && ibase[x * MAXINS + t] == c;
+        if (!same) continue;
+        int32_t st = x;
+        while (st > 0 && colst[st - 1] == c && ref[st - 1] == c && icnt[st - 1] == 0) st--;
+        if (st < x) {
+            for (int32_t t = 0; t < n; t++) ibase[st * MAXINS + t] = c;
+            icnt[st] = (uint8_t)n;
+            icnt[x] = 0;
+        }
+    }
+    // ---- votes
+    uint32_t *v = votes + (voff[sg.tmpl] + sg.a0) * VSTRIDE;
+    for (int32_t x = 0; x <= rl; x++) {
+        uint32_t *col = v + (int64_t)x * VSTRIDE;
+        const int32_t n = icnt[x] < MAXINS ? icnt[x] : MAXINS;
+        for (int32_t t = 0; t < n; t++) {
+            const uint8_t c = ibase[x * MAXINS + t];
+            if (c < 4) atomicAdd(&col[6 + 4 * t + c], 1u);
+        }
+        if (x == rl) break;
+        if (colst[x] == 5)
+            atomicAdd(&col[4], 1u);
+        else if (colst[x] < 4)
+            atomicAdd(&col[colst[x]], 1u);
+        atomicAdd(&col[5], 1u);
+    }
+#undef FM
+#undef OPB
+}
+
+// ------------------------------------------------------------------------------------ K8b
+
+// one thread per template: sequential run-by-run emission (identical order of decisions as the
+// specification; templates are a few kb, the work is tiny next to K8a)
+__global__ void __launch_bounds__(64)
+k_emit(DbView T, int32_t ntmpl, const int64_t *__restrict__ voff, const uint32_t *__restrict__ votes,
+       const int64_t *__restrict__ out_off, uint8_t *__restrict__ out, int32_t *__restrict__ out_len)
+{
+    const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntmpl) return;
+    const uint8_t *ref = T.bases + T.off[t];
+    const int32_t rlen = (int32_t)(T.off[t + 1] - T.off[t]);
+    const uint32_t *v = votes + voff[t] * VSTRIDE;
+    uint8_t *o = out + out_off[t];
+    int32_t n = 0;
+    for (int32_t rs = 0; rs < rlen;) {
+        int32_t re = rs + 1;
+        while (re < rlen && ref[re] == ref[rs]) re++;
+        const uint8_t c = ref[rs];
+        const int64_t den = (int64_t)v[(int64_t)rs * VSTRIDE + 5] + 1;
+        int64_t net = 0;
+        int32_t ncols = 0;
+        for (int32_t x = rs; x < re; x++) {
+            const uint32_t *col = v + (int64_t)x * VSTRIDE;
+            net += col[4];
+            if (c < 4)
+                for (int k = 0; k < MAXINS; k++) net -= col[6 + 4 * k + c];
+        }
+        if (c < 4 && re < rlen)
+            for (int k = 0; k < MAXINS; k++) net -= v[(int64_t)re * VSTRIDE + 6 + 4 * k + c];
+        const int64_t adj = net >= 0 ? (2 * net + den) / (2 * den) : -((2 * (-net) + den) / (2 * den));
+        for (int32_t x = rs; x < re; x++) {
+            const uint32_t *col = v + (int64_t)x * VSTRIDE;
+            int best = c < 4 ? c : 0;
+            uint32_t bv[4];
+            for (int k = 0; k < 4; k++) bv[k] = col[k] + ((c == k) ? 1u : 0u);
+            for (int k = 0; k < 4; k++)
+                if (bv[k] > bv[best]) best = k;
+            if (best == c) ncols++;
+        }
+        int64_t target = (int64_t)ncols - adj;
+        if (target < 0) target = 0;
+        if (target > ncols + MAXINS) target = ncols + MAXINS;
+        int64_t extra = target > ncols ? target - ncols : 0, keep = target < ncols ? target : ncols;
+        for (int32_t x = rs; x < re; x++) {
+            const uint32_t *col = v + (int64_t)x * VSTRIDE;
+            const uint32_t cover = col[5];
+            const uint8_t pc = (x == rs && rs > 0) ? ref[rs - 1] : 255;
+            for (int k = 0; k < MAXINS; k++) {
+                const uint32_t *iv = col + 6 + 4 * k;
+                uint32_t tot = 0;
+                int best = -1;
+                for (int b = 0; b < 4; b++) {
+                    if (b == c || b == pc) continue;
+                    tot += iv[b];
+                    if (best < 0 || iv[b] > iv[best]) best = b;
+                }
+                if (best < 0 || 2 * tot <= cover + 1) break;
+                o[n++] = (uint8_t)best;
+            }
+            int best = c < 4 ? c : 0;
+            uint32_t bv[4];
+            for (int k = 0; k < 4; k++) bv[k] = col[k] + ((c == k) ? 1u : 0u);
+            for (int k = 0; k < 4; k++)
+                if (bv[k] > bv[best]) best = k;
+            if (best != c) {
+                if (2 * col[4] <= cover + 1) o[n++] = (uint8_t)best;
+                continue;
+            }
+            if (x == rs)
+                for (int64_t e = 0; e < extra; e++) o[n++] = c;
+            if (keep > 0) {
+                o[n++] = c;
+                keep--;
+            }
+        }
+        rs = re;
+    }
+    out_len[t] = n;
+}
+
+// ------------------------------------------------------------------------------------ launchers
+
+extern "C" {
+
+void dhk_gather_slices(hipStream_t st, const uint8_t *src, const int64_t *src_off, const int32_t *sidx,
+                       const int32_t *sbeg, const int64_t *dst_off, int32_t n, int32_t max_len,
+                       uint8_t *dst)
+{
+    if (n <= 0) return;
+    int gx = (max_len + 255) / 256;
+    gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+    for (int32_t s0 = 0; s0 < n; s0 += 65535) {
+        const int32_t cnt = n - s0 < 65535 ? n - s0 : 65535;
+        hipLaunchKernelGGL(k_gather_slices, dim3(gx, cnt), dim3(256), 0, st, src, src_off, sidx + s0,
+                           sbeg + s0, dst_off + s0, cnt, dst);
+    }
+}
+
+void dhk_tile_qv(hipStream_t st, const DhLa *las, const uint16_t *trace, const int32_t *la_first,
+                 const int64_t *roff, int32_t nreads, int32_t tspace, int32_t cov, int32_t maxtiles,
+                 uint8_t *qv)
+{
+    if (nreads <= 0) return;
+    hipLaunchKernelGGL(k_tile_qv, dim3(nreads), dim3(64), 0, st, las, trace, la_first, roff, nreads,
+                       tspace, cov, maxtiles, qv);
+}
+
+void dhk_seg_vote(hipStream_t st, const void *segs, int32_t nseg, DbView T, DbView R,
+                  const uint8_t *rrc, const int64_t *voff, uint8_t *fmat, int32_t wmax, uint8_t *opbuf,
+                  uint32_t *votes, int32_t *status)
+{
+    if (nseg <= 0) return;
+    hipLaunchKernelGGL(k_seg_vote, dim3((nseg + 63) / 64), dim3(64), 0, st, (const SegDesc *)segs, nseg,
+                       T, R, rrc, voff, fmat, wmax, opbuf, votes, status);
+}
+
+void dhk_emit(hipStream_t st, DbView T, int32_t ntmpl, const int64_t *voff, const uint32_t *votes,
+              const int64_t *out_off, uint8_t *out, int32_t *out_len)
+{
+    if (ntmpl <= 0) return;
+    hipLaunchKernelGGL(k_emit, dim3((ntmpl + 63) / 64), dim3(64), 0, st, T, ntmpl, voff, votes, out_off,
+                       out, out_len);
+}
+
+}  // extern "C"

@@ -1,0 +1,88 @@
+// dh_internal.h -- declarations shared by the host translation units of libdentist_hip.so.
+#ifndef DH_INTERNAL_H
+#define DH_INTERNAL_H
+
+#include "../../include/dentist_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "dh_device.h"
+
+int dh_fail(int code, const std::string &msg);
+
+#define HIPCHK(expr)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return dh_fail(DH_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+struct dh_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int ncu = 0;
+    hipEvent_t ev[6] = {};
+    dh_align_stats stats = {};
+};
+
+struct dh_index {
+    uint32_t *d_dir = nullptr;
+    uint64_t *d_ekey = nullptr;
+    uint64_t *d_eval = nullptr;
+    int64_t *d_goff = nullptr;
+    int64_t n = 0;
+    int32_t k = 0, sepv = 0, shift = 0, pbits = 0, na = 0;
+    void release()
+    {
+        (void)hipFree(d_dir);
+        (void)hipFree(d_ekey);
+        (void)hipFree(d_eval);
+        (void)hipFree(d_goff);
+        d_dir = nullptr;
+        d_ekey = d_eval = nullptr;
+        d_goff = nullptr;
+    }
+};
+
+struct dh_db {
+    dh_ctx *ctx = nullptr;
+    int32_t n = 0, max_len = 0, ngroups = 1;
+    int64_t total = 0;
+    uint8_t *d_bases = nullptr, *d_rc = nullptr;
+    int64_t *d_off = nullptr;
+    int32_t *d_group = nullptr;
+    std::vector<int64_t> h_off;
+    std::vector<int32_t> h_group;
+    dh_index ix;
+    bool has_ix = false;
+    DbView view() const { return DbView{d_bases, d_off, d_group, n}; }
+};
+
+struct dh_la_set {
+    std::vector<dh_la> la;
+    std::vector<uint16_t> trace;
+    int32_t tspace = 0;
+};
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    ~DevBuf() { (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, sizeof(T) * std::max<size_t>(n, 1)); }
+};
+
+// build a DB whose bases are slices [beg, beg+len) of sequences of `src` (device-to-device)
+int dh_db_from_slices(dh_ctx *ctx, const dh_db *src, const std::vector<int32_t> &sidx,
+                      const std::vector<int32_t> &sbeg, const std::vector<int32_t> &slen,
+                      const std::vector<int32_t> &group, dh_db **out);
+// adopt device bases (ownership moves to the DB); offsets live on the host
+int dh_db_adopt(dh_ctx *ctx, uint8_t *d_bases, const std::vector<int64_t> &off,
+                const std::vector<int32_t> &group, dh_db **out);
+int dh_ensure_rc(dh_db *db);
+
+#endif

@@ -1,0 +1,771 @@
+// dh_process.cpp -- host side of the pile-up consensus path: the call sequence of
+// `dentist process` (source/dentist/commands/processPileUps/package.d:283-374) over a BATCH of
+// pile-ups, with every tool spawn of the reference replaced by kernels on the context's stream:
+//   crop (cropper.d:113-175, 446-550)            -> k_gather_slices
+//   daligner pile-up all-vs-all (package.d:478)  -> dh_align_db on the grouped pile-up DB
+//   filters (dazzler.d:3879-3899, 4043-4141)     -> host flags (same predicates as the reference)
+//   DASqv (dazzler.d:6142-6156)                  -> k_tile_qv
+//   reference-read ranking (package.d:518-568)   -> host (the reference's own D logic)
+//   daccord (dazzler.d:6185-6231)                -> k_seg_vote + k_emit, `rounds` times
+//   daligner -A flanks vs consensus (:655-667)   -> dh_align_db
+//   insertion (package.d:699-805, insertions.d:110-146) -> host
+#include <cstring>
+#include <map>
+#include <numeric>
+
+#include "dh_internal.h"
+
+extern "C" {
+void dhk_gather_slices(hipStream_t st, const uint8_t *src, const int64_t *src_off, const int32_t *sidx,
+                       const int32_t *sbeg, const int64_t *dst_off, int32_t n, int32_t max_len,
+                       uint8_t *dst);
+void dhk_tile_qv(hipStream_t st, const DhLa *las, const uint16_t *trace, const int32_t *la_first,
+                 const int64_t *roff, int32_t nreads, int32_t tspace, int32_t cov, int32_t maxtiles,
+                 uint8_t *qv);
+void dhk_seg_vote(hipStream_t st, const void *segs, int32_t nseg, DbView T, DbView R,
+                  const uint8_t *rrc, const int64_t *voff, uint8_t *fmat, int32_t wmax, uint8_t *opbuf,
+                  uint32_t *votes, int32_t *status);
+void dhk_emit(hipStream_t st, DbView T, int32_t ntmpl, const int64_t *voff, const uint32_t *votes,
+              const int64_t *out_off, uint8_t *out, int32_t *out_len);
+}
+
+#define MAXINS 4
+#define VSTRIDE (6 + 4 * MAXINS)
+#define MAXQV 50
+#define SEG_MAX 250
+
+struct SegDescH {
+    int32_t tmpl, a0, a1, bseq, b0, b1, comp, pad;
+};
+
+extern "C" void dh_default_process_opts(dh_process_opts *o)
+{
+    memset(o, 0, sizeof(*o));
+    o->tspace_map = 100;
+    o->allowance = 100;
+    o->min_anchor = 500;
+    o->min_reads = 3;
+    o->max_reads = 60;
+    o->tspace_pile = 126;
+    o->rounds = 2;
+    o->flank_window = 20000;
+    o->max_align_err_ppm = 300000;
+    o->max_ins_err_ppm = 100000;
+    o->bad_fraction_ppm = 80000;
+}
+
+// ------------------------------------------------------------------------------------ DB helpers
+
+int dh_db_adopt(dh_ctx *ctx, uint8_t *d_bases, const std::vector<int64_t> &off,
+                const std::vector<int32_t> &group, dh_db **out)
+{
+    dh_db *db = new dh_db();
+    db->ctx = ctx;
+    db->n = (int32_t)off.size() - 1;
+    db->h_off = off;
+    db->total = off.back();
+    db->d_bases = d_bases;
+    for (int32_t i = 0; i < db->n; i++)
+        db->max_len = std::max<int32_t>(db->max_len, (int32_t)(off[(size_t)i + 1] - off[(size_t)i]));
+    HIPCHK(hipMalloc(&db->d_off, sizeof(int64_t) * off.size()));
+    HIPCHK(hipMemcpyAsync(db->d_off, off.data(), sizeof(int64_t) * off.size(), hipMemcpyHostToDevice,
+                          ctx->stream));
+    if (!group.empty()) {
+        db->h_group = group;
+        for (int32_t g : group) db->ngroups = std::max(db->ngroups, g + 1);
+        HIPCHK(hipMalloc(&db->d_group, sizeof(int32_t) * group.size()));
+        HIPCHK(hipMemcpyAsync(db->d_group, group.data(), sizeof(int32_t) * group.size(),
+                              hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *out = db;
+    return DH_OK;
+}
+
+int dh_db_from_slices(dh_ctx *ctx, const dh_db *src, const std::vector<int32_t> &sidx,
+                      const std::vector<int32_t> &sbeg, const std::vector<int32_t> &slen,
+                      const std::vector<int32_t> &group, dh_db **out)
+{
+    const int32_t n = (int32_t)sidx.size();
+    std::vector<int64_t> off((size_t)n + 1, 0);
+    int32_t max_len = 0;
+    for (int32_t i = 0; i < n; i++) {
+        off[(size_t)i + 1] = off[(size_t)i] + slen[(size_t)i];
+        max_len = std::max(max_len, slen[(size_t)i]);
+    }
+    uint8_t *d_bases = nullptr;
+    const size_t nb = (size_t)std::max<int64_t>(off.back(), 1) + 64;
+    HIPCHK(hipMalloc(&d_bases, nb));
+    HIPCHK(hipMemsetAsync(d_bases, 4, nb, ctx->stream));
+    if (int rc = dh_db_adopt(ctx, d_bases, off, group, out)) {
+        (void)hipFree(d_bases);
+        return rc;
+    }
+    if (n > 0) {
+        DevBuf<int32_t> d_sidx, d_sbeg;
+        HIPCHK(d_sidx.alloc((size_t)n));
+        HIPCHK(d_sbeg.alloc((size_t)n));
+        HIPCHK(hipMemcpyAsync(d_sidx.p, sidx.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice,
+                              ctx->stream));
+        HIPCHK(hipMemcpyAsync(d_sbeg.p, sbeg.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice,
+                              ctx->stream));
+        dhk_gather_slices(ctx->stream, src->d_bases, src->d_off, d_sidx.p, d_sbeg.p, (*out)->d_off, n,
+                          max_len, d_bases);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    return DH_OK;
+}
+
+// ------------------------------------------------------------------------------------ collect
+
+struct dh_pileups {
+    std::vector<int32_t> contig_left;
+    std::vector<std::vector<int32_t>> triples;  // read, left LA, right LA
+};
+
+extern "C" int dh_collect_spanning(const dh_la *las, int64_t n, const int64_t *contig_off,
+                                   int32_t ncontigs, const dh_process_opts *opts, dh_pileups **out)
+{
+    if ((n > 0 && !las) || !contig_off || !opts || !out) return dh_fail(DH_EINVAL, "dh_collect_spanning: NULL");
+    const dh_process_opts &o = *opts;
+    std::map<int32_t, std::vector<int64_t>> by_read;
+    for (int64_t i = 0; i < n; i++) by_read[las[i].bread].push_back(i);
+    std::map<int32_t, std::vector<int32_t>> piles;
+    for (auto &kv : by_read) {
+        const std::vector<int64_t> &idx = kv.second;
+        for (int64_t iL : idx) {
+            const dh_la &L = las[iL];
+            if (L.aread < 0 || L.aread + 1 >= ncontigs) continue;
+            const int64_t cl = contig_off[L.aread + 1] - contig_off[L.aread];
+            if (L.aepos + o.allowance < cl || L.aepos - L.abpos < o.min_anchor) continue;
+            for (int64_t iR : idx) {
+                const dh_la &R = las[iR];
+                if (R.aread != L.aread + 1 || (R.flags & DH_FLAG_COMP) != (L.flags & DH_FLAG_COMP)) continue;
+                if (R.abpos > o.allowance || R.aepos - R.abpos < o.min_anchor) continue;
+                if (R.bbpos + o.allowance < L.bepos - o.allowance) continue;
+                std::vector<int32_t> &v = piles[L.aread];
+                v.push_back(kv.first);
+                v.push_back((int32_t)iL);
+                v.push_back((int32_t)iR);
+            }
+        }
+    }
+    dh_pileups *p = new dh_pileups();
+    for (auto &kv : piles) {
+        if ((int32_t)kv.second.size() / 3 < o.min_reads) continue;
+        std::vector<int32_t> v = kv.second;
+        if ((int32_t)v.size() / 3 > o.max_reads) v.resize((size_t)o.max_reads * 3);
+        p->contig_left.push_back(kv.first);
+        p->triples.push_back(std::move(v));
+    }
+    *out = p;
+    return DH_OK;
+}
+
+extern "C" void dh_pileups_destroy(dh_pileups *p) { delete p; }
+extern "C" int32_t dh_pileups_count(const dh_pileups *p) { return p ? (int32_t)p->contig_left.size() : 0; }
+extern "C" int32_t dh_pileups_get(const dh_pileups *p, int32_t i, int32_t *contig_left,
+                                  const int32_t **triples)
+{
+    if (!p || i < 0 || i >= (int32_t)p->contig_left.size()) return -1;
+    if (contig_left) *contig_left = p->contig_left[(size_t)i];
+    if (triples) *triples = p->triples[(size_t)i].data();
+    return (int32_t)p->triples[(size_t)i].size() / 3;
+}
+
+// ------------------------------------------------------------------------------------ trace maths
+
+static int32_t ceil_to(int32_t x, int32_t m) { return (x + m - 1) / m * m; }
+
+// getCommonTracePoint, cropper.d:446-500, with an empty repeat mask: candidates are the trace
+// points of the common A interval (plus the contig end), innermost first for `front` seeds.
+static int32_t common_trace_point(int32_t lo, int32_t hi, int32_t contig_len, int32_t ts, bool seed_front)
+{
+    if (lo >= hi) return -1;
+    const int32_t tp_min = ceil_to(lo, ts), tp_sup = ceil_to(hi, ts);
+    std::vector<int32_t> cands;
+    for (int32_t c = tp_min; c < tp_sup; c += ts) cands.push_back(c);
+    if (tp_sup > contig_len) cands.push_back(contig_len);
+    if (seed_front) std::reverse(cands.begin(), cands.end());
+    for (int32_t c : cands)
+        if ((lo <= c && c < hi) || c == hi) return c;
+    return -1;
+}
+
+// Trace.translateTracePoint!"contigA"(pos, floor).contigB, base.d:185-237
+static int32_t translate_floor_b(const dh_la &la, const uint16_t *tr, int32_t ts, int32_t apos)
+{
+    const int32_t ntp = la.tlen / 2;
+    const int32_t second = la.abpos / ts * ts + ts;
+    int32_t idx;
+    if (apos < second)
+        idx = 0;
+    else if (apos < la.aepos)
+        idx = 1 + (apos - second) / ts;
+    else
+        idx = ntp;
+    int32_t b = la.bbpos;
+    for (int32_t i = 0; i < idx; i++) b += tr[2 * i + 1];
+    return b;
+}
+
+// isValidPileUpAlignment (flat), dazzler.d:4126-4141
+static bool valid_pileup_alignment(const dh_la &la, bool same, int32_t alen, int32_t blen, int32_t allow)
+{
+    const bool ab = la.abpos <= allow, bb = la.bbpos <= allow;
+    const bool ae = la.aepos + allow >= alen, be = la.bepos + allow >= blen;
+    return !same && (((ab && bb) && (ae || be)) || ((ae && be) && (ab || bb)));
+}
+
+// ------------------------------------------------------------------------------------ results
+
+struct dh_insertions {
+    std::vector<dh_insertion> rec;
+    std::vector<uint8_t> bases;
+};
+
+extern "C" void dh_insertions_destroy(dh_insertions *r) { delete r; }
+extern "C" int32_t dh_insertions_count(const dh_insertions *r) { return r ? (int32_t)r->rec.size() : 0; }
+extern "C" const dh_insertion *dh_insertions_records(const dh_insertions *r) { return r ? r->rec.data() : nullptr; }
+extern "C" const uint8_t *dh_insertions_bases(const dh_insertions *r) { return r ? r->bases.data() : nullptr; }
+extern "C" int64_t dh_insertions_bases_len(const dh_insertions *r) { return r ? (int64_t)r->bases.size() : 0; }
+
+struct ProcStats {
+    float ms[7] = {0, 0, 0, 0, 0, 0, 0};
+    int64_t counters[3] = {0, 0, 0};
+};
+static thread_local ProcStats g_pstats;
+
+extern "C" int dh_get_process_stats(dh_ctx *ctx, float *ms7, int64_t *counters3)
+{
+    if (!ctx) return dh_fail(DH_EINVAL, "ctx is NULL");
+    if (ms7) memcpy(ms7, g_pstats.ms, sizeof(g_pstats.ms));
+    if (counters3) memcpy(counters3, g_pstats.counters, sizeof(g_pstats.counters));
+    return DH_OK;
+}
+
+// ------------------------------------------------------------------------------------ consensus round
+
+// One voting + emission round.  T: templates (one per active pile-up), R: pile-up reads.
+// las: overlaps with A = a template coordinate system; tmpl_of[i] = template of LA i or -1.
+static int consensus_round(dh_ctx *ctx, dh_db *T, dh_db *R, const std::vector<dh_la> &las,
+                           const std::vector<uint16_t> &trace, const std::vector<int32_t> &tmpl_of,
+                           int32_t ts, dh_db **newT, int64_t *nseg_out, int64_t *ncell_out)
+{
+    hipStream_t st = ctx->stream;
+    std::vector<SegDescH> segs;
+    int32_t wmax = 1;
+    int64_t ncell = 0;
+    for (size_t i = 0; i < las.size(); i++) {
+        const int32_t t = tmpl_of[i];
+        if (t < 0 || (las[i].flags & DH_FLAG_DISABLED)) continue;
+        const dh_la &la = las[i];
+        const uint16_t *tr = trace.data() + la.toff;
+        int32_t a0 = la.abpos, b0 = la.bbpos;
+        for (int32_t e = 0; e < la.tlen / 2; e++) {
+            int32_t a1 = (a0 / ts + 1) * ts;
+            if (a1 > la.aepos) a1 = la.aepos;
+            const int32_t b1 = b0 + tr[2 * e + 1];
+            SegDescH s{t, a0, a1, la.bread, b0, b1, (int32_t)(la.flags & DH_FLAG_COMP), 0};
+            segs.push_back(s);
+            wmax = std::max(wmax, b1 - b0);
+            ncell += (int64_t)(a1 - a0) * (b1 - b0);
+            a0 = a1;
+            b0 = b1;
+        }
+    }
+    if (wmax > SEG_MAX) return dh_fail(DH_EOVERFLOW, "consensus: a trace tile is longer than 250 bases on B");
+    *nseg_out = (int64_t)segs.size();
+    *ncell_out = ncell;
+    const int32_t nt = T->n;
+    std::vector<int64_t> voff((size_t)nt + 1, 0), ooff((size_t)nt + 1, 0);
+    for (int32_t t = 0; t < nt; t++) {
+        const int64_t len = T->h_off[(size_t)t + 1] - T->h_off[(size_t)t];
+        voff[(size_t)t + 1] = voff[(size_t)t] + len + 1;
+        ooff[(size_t)t + 1] = ooff[(size_t)t] + len * (1 + MAXINS) + 8;
+    }
+    DevBuf<int64_t> d_voff, d_ooff;
+    DevBuf<uint32_t> d_votes;
+    DevBuf<uint8_t> d_out, d_fmat, d_opbuf;
+    DevBuf<int32_t> d_status, d_outlen;
+    DevBuf<SegDescH> d_segs;
+    HIPCHK(d_voff.alloc(voff.size()));
+    HIPCHK(d_ooff.alloc(ooff.size()));
+    HIPCHK(d_votes.alloc((size_t)voff.back() * VSTRIDE));
+    HIPCHK(d_out.alloc((size_t)ooff.back()));
+    HIPCHK(d_status.alloc(1));
+    HIPCHK(d_outlen.alloc((size_t)nt));
+    HIPCHK(hipMemcpyAsync(d_voff.p, voff.data(), sizeof(int64_t) * voff.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_ooff.p, ooff.data(), sizeof(int64_t) * ooff.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(d_votes.p, 0, sizeof(uint32_t) * (size_t)voff.back() * VSTRIDE, st));
+    HIPCHK(hipMemsetAsync(d_status.p, 0, sizeof(int32_t), st));
+    if (int rc = dh_ensure_rc(R)) return rc;
+    // the score matrices of one launch live interleaved in HBM: bound the launch to ~6 GB
+    const int64_t per_dp = (int64_t)(ts + 1) * (wmax + 1) + 2 * SEG_MAX;
+    const int64_t max_dp = std::max<int64_t>(4096, (6ll << 30) / per_dp);
+    for (size_t s0 = 0; s0 < segs.size(); s0 += (size_t)max_dp) {
+        const int32_t cnt = (int32_t)std::min<size_t>((size_t)max_dp, segs.size() - s0);
+        DevBuf<SegDescH> ds;
+        DevBuf<uint8_t> fm, ob;
+        HIPCHK(ds.alloc((size_t)cnt));
+        HIPCHK(fm.alloc((size_t)cnt * (size_t)(ts + 1) * (size_t)(wmax + 1)));
+        HIPCHK(ob.alloc((size_t)cnt * 2 * SEG_MAX));
+        HIPCHK(hipMemcpyAsync(ds.p, segs.data() + s0, sizeof(SegDescH) * (size_t)cnt, hipMemcpyHostToDevice, st));
+        dhk_seg_vote(st, ds.p, cnt, T->view(), R->view(), R->d_rc, d_voff.p, fm.p, wmax, ob.p, d_votes.p,
+                     d_status.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    dhk_emit(st, T->view(), nt, d_voff.p, d_votes.p, d_ooff.p, d_out.p, d_outlen.p);
+    HIPCHK(hipGetLastError());
+    std::vector<int32_t> outlen((size_t)nt);
+    int32_t status = 0;
+    HIPCHK(hipMemcpyAsync(outlen.data(), d_outlen.p, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&status, d_status.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (status) return dh_fail(DH_EOVERFLOW, "consensus: tile exceeds the score-matrix capacity");
+    // compact the emitted sequences into the next template DB (device to device)
+    std::vector<int64_t> noff((size_t)nt + 1, 0);
+    int32_t max_len = 0;
+    for (int32_t t = 0; t < nt; t++) {
+        noff[(size_t)t + 1] = noff[(size_t)t] + outlen[(size_t)t];
+        max_len = std::max(max_len, outlen[(size_t)t]);
+    }
+    uint8_t *d_bases = nullptr;
+    const size_t nb = (size_t)std::max<int64_t>(noff.back(), 1) + 64;
+    HIPCHK(hipMalloc(&d_bases, nb));
+    HIPCHK(hipMemsetAsync(d_bases, 4, nb, st));
+    if (int rc = dh_db_adopt(ctx, d_bases, noff, T->h_group, newT)) {
+        (void)hipFree(d_bases);
+        return rc;
+    }
+    std::vector<int32_t> ident((size_t)nt), zero((size_t)nt, 0);
+    std::iota(ident.begin(), ident.end(), 0);
+    DevBuf<int32_t> d_id, d_zero;
+    HIPCHK(d_id.alloc((size_t)nt));
+    HIPCHK(d_zero.alloc((size_t)nt));
+    HIPCHK(hipMemcpyAsync(d_id.p, ident.data(), sizeof(int32_t) * (size_t)nt, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_zero.p, zero.data(), sizeof(int32_t) * (size_t)nt, hipMemcpyHostToDevice, st));
+    dhk_gather_slices(st, d_out.p, d_ooff.p, d_id.p, d_zero.p, (*newT)->d_off, nt, max_len, d_bases);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    return DH_OK;
+}
+
+// ------------------------------------------------------------------------------------ process
+
+struct DbGuard {
+    std::vector<dh_db *> dbs;
+    ~DbGuard()
+    {
+        for (dh_db *d : dbs) dh_db_destroy(d);
+    }
+};
+struct SetGuard {
+    std::vector<dh_la_set *> sets;
+    ~SetGuard()
+    {
+        for (dh_la_set *s : sets) dh_la_set_destroy(s);
+    }
+};
+
+extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, const dh_la *las, int64_t n,
+                                  const uint16_t *trace, const dh_pileups *piles,
+                                  const dh_process_opts *opts, dh_insertions **out)
+{
+    if (!ctx || !contigs || !reads || !piles || !opts || !out || (n > 0 && (!las || !trace)))
+        return dh_fail(DH_EINVAL, "dh_process_pileups: NULL argument");
+    const dh_process_opts &o = *opts;
+    if (o.max_reads < 3 || o.max_reads > 60) return dh_fail(DH_EINVAL, "max_reads must be in [3, 60]");
+    if (o.rounds < 1 || o.rounds > 8) return dh_fail(DH_EINVAL, "rounds must be in [1, 8]");
+    if (o.tspace_pile < 16 || o.tspace_pile > SEG_MAX) return dh_fail(DH_EINVAL, "tspace_pile out of range");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    ProcStats ps;
+    hipEvent_t ev[8];
+    for (auto &e : ev) HIPCHK(hipEventCreate(&e));
+    struct EvGuard {
+        hipEvent_t *e;
+        ~EvGuard()
+        {
+            for (int i = 0; i < 8; i++) (void)hipEventDestroy(e[i]);
+        }
+    } evg{ev};
+    auto elapsed = [&](int a, int b, float &acc) -> int {
+        float t = 0;
+        HIPCHK(hipEventSynchronize(ev[b]));
+        HIPCHK(hipEventElapsedTime(&t, ev[a], ev[b]));
+        acc += t;
+        return DH_OK;
+    };
+    DbGuard dbg;
+    SetGuard sg;
+    dh_insertions *res = new dh_insertions();
+    struct ResGuard {
+        dh_insertions *&r;
+        bool ok = false;
+        ~ResGuard()
+        {
+            if (!ok) delete r;
+        }
+    } rg{res};
+    const int32_t np = (int32_t)piles->contig_left.size();
+    res->rec.resize((size_t)np);
+    const int32_t tsm = o.tspace_map, tsp = o.tspace_pile;
+
+    HIPCHK(hipEventRecord(ev[0], st));
+    // ---- 1. crop every pile-up to its common trace points; collect the slices of the reads
+    std::vector<int32_t> sidx, sbeg, slen, sgroup;  // slices of `reads` -> pile-up DB
+    std::vector<int32_t> pile_of_active;             // active index -> pile-up index
+    std::vector<int32_t> first_read;                 // active index -> first read in pile-up DB
+    std::vector<int32_t> read_id;                    // pile-up DB read -> read id in `reads`
+    for (int32_t p = 0; p < np; p++) {
+        dh_insertion &r = res->rec[(size_t)p];
+        memset(&r, 0, sizeof(r));
+        const int32_t g = piles->contig_left[(size_t)p];
+        r.contig_left = g;
+        r.ref_read = r.ref_read_id = -1;
+        r.crop_left = r.crop_right = -1;
+        const std::vector<int32_t> &tr3 = piles->triples[(size_t)p];
+        const int32_t ne = (int32_t)tr3.size() / 3;
+        int32_t llo = 0, lhi = INT32_MAX, rlo = 0, rhi = INT32_MAX;
+        for (int32_t e = 0; e < ne; e++) {
+            const dh_la &L = las[tr3[(size_t)e * 3 + 1]], &R = las[tr3[(size_t)e * 3 + 2]];
+            llo = std::max(llo, L.abpos);
+            lhi = std::min(lhi, L.aepos);
+            rlo = std::max(rlo, R.abpos);
+            rhi = std::min(rhi, R.aepos);
+        }
+        const int32_t cll = (int32_t)(contigs->h_off[(size_t)g + 1] - contigs->h_off[(size_t)g]);
+        const int32_t clr = (int32_t)(contigs->h_off[(size_t)g + 2] - contigs->h_off[(size_t)g + 1]);
+        const int32_t cropL = common_trace_point(llo, lhi, cll, tsm, false);
+        const int32_t cropR = common_trace_point(rlo, rhi, clr, tsm, true);
+        r.crop_left = cropL;
+        r.crop_right = cropR;
+        if (cropL < 0 || cropR < 0) {
+            r.status = DH_PILE_NO_COMMON_TRACE_POINT;
+            continue;
+        }
+        const size_t mark = sidx.size();
+        for (int32_t e = 0; e < ne; e++) {
+            const int32_t rd = tr3[(size_t)e * 3];
+            const dh_la &L = las[tr3[(size_t)e * 3 + 1]], &R = las[tr3[(size_t)e * 3 + 2]];
+            const int32_t bL = translate_floor_b(L, trace + L.toff, tsm, cropL);
+            const int32_t bR = translate_floor_b(R, trace + R.toff, tsm, cropR);
+            const int32_t rl = (int32_t)(reads->h_off[(size_t)rd + 1] - reads->h_off[(size_t)rd]);
+            int32_t b0 = bL, b1 = bR;
+            if (L.flags & DH_FLAG_COMP) {  // getCroppingSlice, cropper.d:533-538
+                b0 = rl - bR;
+                b1 = rl - bL;
+            }
+            if (b1 - b0 < 14) continue;  // records shorter than 14 bp are dropped (dazzler.d:150)
+            sidx.push_back(rd);
+            sbeg.push_back(b0);
+            slen.push_back(b1 - b0);
+        }
+        const int32_t cnt = (int32_t)(sidx.size() - mark);
+        r.nreads = cnt;
+        if (cnt < 3) {
+            r.status = DH_PILE_TOO_SMALL;
+            sidx.resize(mark);
+            sbeg.resize(mark);
+            slen.resize(mark);
+            continue;
+        }
+        const int32_t a = (int32_t)pile_of_active.size();
+        pile_of_active.push_back(p);
+        first_read.push_back((int32_t)mark);
+        for (size_t x = mark; x < sidx.size(); x++) {
+            sgroup.push_back(a);
+            read_id.push_back(sidx[x]);
+        }
+    }
+    const int32_t na = (int32_t)pile_of_active.size();
+    first_read.push_back((int32_t)sidx.size());
+    dh_db *pile = nullptr;
+    if (int rc = dh_db_from_slices(ctx, reads, sidx, sbeg, slen, sgroup, &pile)) return rc;
+    dbg.dbs.push_back(pile);
+    HIPCHK(hipEventRecord(ev[1], st));
+    if (int rc = elapsed(0, 1, ps.ms[0])) return rc;
+
+    std::vector<uint8_t> active_ok((size_t)na, 1);
+    dh_db *T = nullptr;
+    if (na > 0) {
+        // ---- 2. pile-up all-vs-all: daligner -s126 -l500 -e0.7 (commandline.d:2886-2902)
+        dh_align_opts ao;
+        dh_default_align_opts(&ao);
+        ao.tspace = tsp;
+        ao.min_len = 500;
+        ao.skip_self = 1;
+        ao.max_la = 64;
+        ao.max_cand = 128;
+        dh_la_set *pset = nullptr;
+        HIPCHK(hipEventRecord(ev[0], st));
+        if (int rc = dh_align_db(ctx, pile, pile, &ao, 0, &pset)) return rc;
+        sg.sets.push_back(pset);
+        HIPCHK(hipEventRecord(ev[1], st));
+        if (int rc = elapsed(0, 1, ps.ms[1])) return rc;
+        std::vector<dh_la> &pl = pset->la;
+        ps.counters[0] = (int64_t)pl.size();
+        // ---- 3. filters: averageErrorRate <= maxAlignmentError (package.d:483-485), then
+        //         isValidPileUpAlignment with allowance = trace spacing (dazzler.d:4066-4141)
+        for (dh_la &la : pl) {
+            const int64_t al = la.aepos - la.abpos;
+            bool bad = (int64_t)la.diffs * 1000000 > (int64_t)o.max_align_err_ppm * al;
+            if (!bad) {
+                const int32_t alen = (int32_t)(pile->h_off[(size_t)la.aread + 1] - pile->h_off[(size_t)la.aread]);
+                const int32_t blen = (int32_t)(pile->h_off[(size_t)la.bread + 1] - pile->h_off[(size_t)la.bread]);
+                bad = !valid_pileup_alignment(la, la.aread == la.bread, alen, blen, tsp);
+            }
+            if (bad) la.flags |= DH_FLAG_DISABLED;
+        }
+        // ---- 4. tile QVs on the device (LAs are sorted by aread)
+        HIPCHK(hipEventRecord(ev[0], st));
+        const int32_t npr = pile->n;
+        std::vector<int32_t> la_first((size_t)npr + 1, 0);
+        for (const dh_la &la : pl) la_first[(size_t)la.aread + 1]++;
+        for (int32_t r = 0; r < npr; r++) la_first[(size_t)r + 1] += la_first[(size_t)r];
+        const int32_t maxtiles = std::max(1, (pile->max_len + tsp - 1) / tsp);
+        std::vector<uint8_t> qv((size_t)npr * maxtiles, 255);
+        {
+            DevBuf<DhLa> d_las;
+            DevBuf<uint16_t> d_tr;
+            DevBuf<int32_t> d_first;
+            DevBuf<uint8_t> d_qv;
+            HIPCHK(d_las.alloc(pl.size()));
+            HIPCHK(d_tr.alloc(pset->trace.size()));
+            HIPCHK(d_first.alloc(la_first.size()));
+            HIPCHK(d_qv.alloc(qv.size()));
+            HIPCHK(hipMemcpyAsync(d_las.p, pl.data(), sizeof(dh_la) * pl.size(), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(d_tr.p, pset->trace.data(), sizeof(uint16_t) * pset->trace.size(),
+                                  hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(d_first.p, la_first.data(), sizeof(int32_t) * la_first.size(),
+                                  hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemsetAsync(d_qv.p, 255, qv.size(), st));
+            // cov = max(#allowed reference reads, 4 if pile >= 4) == pile size here (package.d:498-503);
+            // piles differ in size, so one launch per distinct size would be needed for a per-pile
+            // cov: the kernel takes cov per launch, piles are launched grouped by size below.
+            std::map<int32_t, std::vector<int32_t>> by_size;
+            for (int32_t a = 0; a < na; a++) by_size[first_read[(size_t)a + 1] - first_read[(size_t)a]].push_back(a);
+            for (auto &kv : by_size)
+                for (int32_t a : kv.second) {
+                    const int32_t r0 = first_read[(size_t)a], cnt = kv.first;
+                    dhk_tile_qv(st, d_las.p, d_tr.p, d_first.p + r0, pile->d_off + r0, cnt, tsp, cnt, maxtiles,
+                                d_qv.p + (size_t)r0 * maxtiles);
+                }
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(qv.data(), d_qv.p, qv.size(), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
+        HIPCHK(hipEventRecord(ev[1], st));
+        if (int rc = elapsed(0, 1, ps.ms[2])) return rc;
+        // ---- 5. reference read per pile-up: findReferenceReadCandidates (package.d:518-568)
+        std::vector<int32_t> ref_of((size_t)na, -1);
+        const double bad_fraction = (double)o.bad_fraction_ppm / 1e6;
+        for (int32_t a = 0; a < na; a++) {
+            const int32_t r0 = first_read[(size_t)a], r1 = first_read[(size_t)a + 1];
+            bool any = false;
+            for (int32_t i = la_first[(size_t)r0]; i < la_first[(size_t)r1]; i++)
+                if (!(pl[(size_t)i].flags & DH_FLAG_DISABLED)) any = true;
+            dh_insertion &rec = res->rec[(size_t)pile_of_active[(size_t)a]];
+            if (!any) {
+                rec.status = DH_PILE_EMPTY_ALIGNMENT;
+                active_ok[(size_t)a] = 0;
+                continue;
+            }
+            int64_t hist[MAXQV] = {0};
+            int64_t total = 0;
+            for (int32_t r = r0; r < r1; r++) {
+                const int32_t len = (int32_t)(pile->h_off[(size_t)r + 1] - pile->h_off[(size_t)r]);
+                const int32_t nt = (len + tsp - 1) / tsp;
+                for (int32_t t = 0; t < nt; t++) {
+                    const int32_t q = qv[(size_t)r * maxtiles + t];
+                    if (q < MAXQV) {
+                        hist[q]++;
+                        total++;
+                    }
+                }
+            }
+            const int64_t bad_thres = (int64_t)(bad_fraction * (double)total);
+            int32_t idx = -1;
+            int64_t cum = 0;
+            for (int32_t x = 0; x < MAXQV; x++) {
+                cum += hist[MAXQV - 1 - x];
+                if (cum >= bad_thres) {
+                    idx = x;
+                    break;
+                }
+            }
+            const int32_t bad_qv = MAXQV - 1 - idx;
+            int32_t best = -1;
+            int64_t best_nbad = 0;
+            double best_mean = 0;
+            for (int32_t r = r0; r < r1; r++) {
+                const int32_t len = (int32_t)(pile->h_off[(size_t)r + 1] - pile->h_off[(size_t)r]);
+                const int32_t nt = (len + tsp - 1) / tsp;
+                int64_t nb = 0, sum = 0;
+                for (int32_t t = 0; t < nt; t++) {
+                    const int32_t q = qv[(size_t)r * maxtiles + t];
+                    if (q >= bad_qv) nb++;
+                    sum += q;
+                }
+                const double mean = nt > 0 ? (double)sum / (double)nt : 0.0;
+                if (best < 0 || nb < best_nbad || (nb == best_nbad && mean < best_mean)) {
+                    best = r;
+                    best_nbad = nb;
+                    best_mean = mean;
+                }
+            }
+            ref_of[(size_t)a] = best;
+            rec.ref_read = best - r0;
+            rec.ref_read_id = read_id[(size_t)best];
+        }
+        // ---- 6. consensus rounds.  Templates are indexed by active pile-up (group = active idx)
+        std::vector<int32_t> tidx, tbeg, tlen, tgrp;
+        for (int32_t a = 0; a < na; a++) {
+            const int32_t r = ref_of[(size_t)a] >= 0 ? ref_of[(size_t)a] : first_read[(size_t)a];
+            tidx.push_back(r);
+            tbeg.push_back(0);
+            tlen.push_back((int32_t)(pile->h_off[(size_t)r + 1] - pile->h_off[(size_t)r]));
+            tgrp.push_back(a);
+        }
+        if (int rc = dh_db_from_slices(ctx, pile, tidx, tbeg, tlen, tgrp, &T)) return rc;
+        dbg.dbs.push_back(T);
+        {
+            std::vector<int32_t> tmpl_of(pl.size(), -1);
+            for (size_t i = 0; i < pl.size(); i++) {
+                const int32_t a = pile->h_group[(size_t)pl[i].aread];
+                if (active_ok[(size_t)a] && pl[i].aread == ref_of[(size_t)a]) tmpl_of[i] = a;
+            }
+            HIPCHK(hipEventRecord(ev[0], st));
+            dh_db *nT = nullptr;
+            int64_t nseg = 0, ncell = 0;
+            if (int rc = consensus_round(ctx, T, pile, pl, pset->trace, tmpl_of, tsp, &nT, &nseg, &ncell)) return rc;
+            dbg.dbs.push_back(nT);
+            T = nT;
+            ps.counters[1] += nseg;
+            ps.counters[2] += ncell;
+            HIPCHK(hipEventRecord(ev[1], st));
+            if (int rc = elapsed(0, 1, ps.ms[3])) return rc;
+        }
+        for (int32_t round = 1; round < o.rounds; round++) {
+            dh_align_opts ro;
+            dh_default_align_opts(&ro);
+            ro.tspace = tsp;
+            ro.min_len = 500;
+            ro.max_la = 4;
+            ro.max_cand = 32;
+            dh_la_set *rset = nullptr;
+            HIPCHK(hipEventRecord(ev[0], st));
+            if (int rc = dh_align_db(ctx, T, pile, &ro, 0, &rset)) return rc;
+            sg.sets.push_back(rset);
+            HIPCHK(hipEventRecord(ev[1], st));
+            if (int rc = elapsed(0, 1, ps.ms[4])) return rc;
+            std::vector<int32_t> tmpl_of(rset->la.size(), -1);
+            for (size_t i = 0; i < rset->la.size(); i++) {
+                dh_la &la = rset->la[i];
+                const int32_t a = la.aread;
+                const int32_t alen = (int32_t)(T->h_off[(size_t)a + 1] - T->h_off[(size_t)a]);
+                const int32_t blen = (int32_t)(pile->h_off[(size_t)la.bread + 1] - pile->h_off[(size_t)la.bread]);
+                if (!valid_pileup_alignment(la, false, alen, blen, tsp)) la.flags |= DH_FLAG_DISABLED;
+                if (active_ok[(size_t)a]) tmpl_of[i] = a;
+            }
+            HIPCHK(hipEventRecord(ev[0], st));
+            dh_db *nT = nullptr;
+            int64_t nseg = 0, ncell = 0;
+            if (int rc = consensus_round(ctx, T, pile, rset->la, rset->trace, tmpl_of, tsp, &nT, &nseg, &ncell))
+                return rc;
+            dbg.dbs.push_back(nT);
+            T = nT;
+            ps.counters[1] += nseg;
+            ps.counters[2] += ncell;
+            HIPCHK(hipEventRecord(ev[1], st));
+            if (int rc = elapsed(0, 1, ps.ms[3])) return rc;
+        }
+        // ---- 7. flank re-alignment: daligner -A -s126 -l126 contigs consensus (commandline.d:2918-2935)
+        std::vector<int32_t> fidx, fbeg, flen, fgrp, foff((size_t)na, 0);
+        for (int32_t a = 0; a < na; a++) {
+            const int32_t g = piles->contig_left[(size_t)pile_of_active[(size_t)a]];
+            const int32_t cll = (int32_t)(contigs->h_off[(size_t)g + 1] - contigs->h_off[(size_t)g]);
+            const int32_t clr = (int32_t)(contigs->h_off[(size_t)g + 2] - contigs->h_off[(size_t)g + 1]);
+            const int32_t wl = std::max(0, cll - o.flank_window);
+            foff[(size_t)a] = wl;
+            fidx.push_back(g);
+            fbeg.push_back(wl);
+            flen.push_back(cll - wl);
+            fgrp.push_back(a);
+            fidx.push_back(g + 1);
+            fbeg.push_back(0);
+            flen.push_back(std::min(clr, o.flank_window));
+            fgrp.push_back(a);
+        }
+        dh_db *F = nullptr;
+        if (int rc = dh_db_from_slices(ctx, contigs, fidx, fbeg, flen, fgrp, &F)) return rc;
+        dbg.dbs.push_back(F);
+        dh_align_opts fo;
+        dh_default_align_opts(&fo);
+        fo.tspace = tsp;
+        fo.min_len = 126;
+        fo.max_la = 4;
+        fo.max_cand = 32;
+        dh_la_set *fset = nullptr;
+        HIPCHK(hipEventRecord(ev[0], st));
+        if (int rc = dh_align_db(ctx, F, T, &fo, 0, &fset)) return rc;
+        sg.sets.push_back(fset);
+        HIPCHK(hipEventRecord(ev[1], st));
+        if (int rc = elapsed(0, 1, ps.ms[5])) return rc;
+        // ---- 8. consensus bases to the host, insertion per pile-up
+        std::vector<uint8_t> cons((size_t)std::max<int64_t>(T->total, 1));
+        if (T->total > 0) HIPCHK(hipMemcpy(cons.data(), T->d_bases, (size_t)T->total, hipMemcpyDeviceToHost));
+        for (int32_t a = 0; a < na; a++) {
+            dh_insertion &rec = res->rec[(size_t)pile_of_active[(size_t)a]];
+            if (!active_ok[(size_t)a]) continue;
+            const int64_t c0 = T->h_off[(size_t)a], c1 = T->h_off[(size_t)a + 1];
+            rec.cons_off = (int64_t)res->bases.size();
+            rec.cons_len = (int32_t)(c1 - c0);
+            res->bases.insert(res->bases.end(), cons.begin() + c0, cons.begin() + c1);
+            const int32_t fl_len = flen[(size_t)2 * a], clen = rec.cons_len;
+            const dh_la *L = nullptr, *R = nullptr;
+            int nL = 0, nR = 0;
+            for (const dh_la &la : fset->la) {
+                if (la.bread != a) continue;
+                if (la.aread == 2 * a && la.aepos + tsp >= fl_len && la.bbpos <= tsp) {
+                    L = &la;
+                    nL++;
+                }
+                if (la.aread == 2 * a + 1 && la.abpos <= tsp && la.bepos + tsp >= clen) {
+                    R = &la;
+                    nR++;
+                }
+            }
+            if (nL != 1 || nR != 1) {
+                rec.status = DH_PILE_FLANKS_NOT_UNIQUE;
+                continue;
+            }
+            if ((L->flags & DH_FLAG_COMP) != (R->flags & DH_FLAG_COMP)) {
+                rec.status = DH_PILE_ORIENTATION;
+                continue;
+            }
+            rec.left_diffs = L->diffs;
+            rec.right_diffs = R->diffs;
+            // ensureHighQualityConsensus, output.d:388-410
+            if ((int64_t)L->diffs * 1000000 > (int64_t)o.max_ins_err_ppm * (L->aepos - L->abpos) ||
+                (int64_t)R->diffs * 1000000 > (int64_t)o.max_ins_err_ppm * (R->aepos - R->abpos)) {
+                rec.status = DH_PILE_MAX_INSERTION_ERROR;
+                continue;
+            }
+            rec.comp = (L->flags & DH_FLAG_COMP) ? 1 : 0;
+            rec.left_aepos = foff[(size_t)a] + L->aepos;   // getCroppingPosition!"contigA", seed back
+            rec.right_abpos = R->abpos;                    //                                seed front
+            rec.ins_begin = L->bepos;                      // getCroppingPosition!"contigB"
+            rec.ins_end = R->bbpos;
+            if (rec.ins_end < rec.ins_begin) rec.status = DH_PILE_NEGATIVE_INSERTION;
+        }
+    }
+    ps.ms[6] = ps.ms[0] + ps.ms[1] + ps.ms[2] + ps.ms[3] + ps.ms[4] + ps.ms[5];
+    g_pstats = ps;
+    rg.ok = true;
+    *out = res;
+    return DH_OK;
+}

@@ -127,6 +127,85 @@ int dh_las_write(const char *path, const dh_la *las, int64_t n, const uint16_t *
                  int32_t tspace);
 int dh_las_read(const char *path, dh_la_set **out);
 
+
+/* ---- pile-ups: which reads span which gap.  Host-side stand-in for the part of `dentist collect`
+ *      the consensus path needs (spanning reads only; the scaffold-graph builder of
+ *      source/dentist/commands/collectPileUps/pileups.d is outside this library). */
+typedef struct {
+    int32_t tspace_map;        /* trace spacing of the read->contig LAs (100)                       */
+    int32_t allowance;         /* proper-alignment-allowance of the mapping LAs (= tspace_map)      */
+    int32_t min_anchor;        /* --min-anchor-length, commandline.d:2036 (500)                     */
+    int32_t min_reads;         /* --min-reads-per-pile-up, commandline.d:2125-2187 (3)              */
+    int32_t max_reads;         /* reads kept per pile-up (<= 60)                                    */
+    int32_t tspace_pile;       /* -s126 of the pile-up daligner call, commandline.d:2886-2902       */
+    int32_t rounds;            /* consensus rounds (1 = reference read + its overlaps only)         */
+    int32_t flank_window;      /* bases of each flanking contig given to the flank re-alignment     */
+    int32_t max_align_err_ppm; /* --max-alignment-error 0.30, commandline.d:1808                    */
+    int32_t max_ins_err_ppm;   /* --max-insertion-error 0.10, commandline.d:1997                    */
+    int32_t bad_fraction_ppm;  /* --bad-fraction 0.08, commandline.d:1101                           */
+    int32_t reserved;
+} dh_process_opts;
+void dh_default_process_opts(dh_process_opts *o);
+
+typedef struct dh_pileups dh_pileups;
+/* las/trace: read->contig LAs (A = contig, B = read) as returned by dh_align_db.  A read spans
+ * the gap between contig c and c+1 when it has an LA reaching the end of c and an LA starting at
+ * the begin of c+1, same orientation, in read order, both anchors >= min_anchor. */
+int dh_collect_spanning(const dh_la *las, int64_t n, const int64_t *contig_off, int32_t ncontigs,
+                        const dh_process_opts *opts, dh_pileups **out);
+void dh_pileups_destroy(dh_pileups *p);
+int32_t dh_pileups_count(const dh_pileups *p);
+/* pile-up i: left contig id (gap lies between it and the next contig), number of reads, and the
+ * (read, left LA index, right LA index) triples */
+int32_t dh_pileups_get(const dh_pileups *p, int32_t i, int32_t *contig_left, const int32_t **triples);
+
+/* ---- `dentist process` for a batch of pile-ups: crop -> pile-up alignment -> filter -> tile QV
+ *      -> reference read -> consensus -> flank re-alignment -> insertion
+ *      (source/dentist/commands/processPileUps/package.d:283-374; cropper.d:446-550;
+ *      common/insertions.d:110-146).  Replaces the ~15 tool spawns per pile-up of
+ *      package.d:474-697 (daligner, DAScover/DASqv, computeintrinsicqv, daccord, daligner -A). */
+#define DH_PILE_OK 0
+#define DH_PILE_NO_COMMON_TRACE_POINT 1
+#define DH_PILE_TOO_SMALL 2
+#define DH_PILE_EMPTY_ALIGNMENT 3
+#define DH_PILE_FLANKS_NOT_UNIQUE 4
+#define DH_PILE_ORIENTATION 5
+#define DH_PILE_MAX_INSERTION_ERROR 6
+#define DH_PILE_NEGATIVE_INSERTION 7
+typedef struct {
+    int32_t contig_left;   /* gap between contig_left and contig_left + 1                          */
+    int32_t status;        /* DH_PILE_*                                                             */
+    int32_t nreads;        /* reads in the cropped pile-up                                          */
+    int32_t ref_read;      /* index of the reference read inside the pile-up, -1 if none            */
+    int32_t ref_read_id;   /* its read id in the reads DB                                           */
+    int32_t crop_left;     /* common trace point on the left contig                                 */
+    int32_t crop_right;    /* common trace point on the right contig                                */
+    int32_t left_aepos;    /* left contig is kept up to here  (insertions.d:110-118, seed back)    */
+    int32_t right_abpos;   /* right contig is kept from here (seed front)                           */
+    int32_t ins_begin;     /* insertion = oriented consensus [ins_begin, ins_end)                   */
+    int32_t ins_end;
+    int32_t comp;          /* 1: the consensus is reverse-complemented relative to the contigs      */
+    int32_t cons_len;
+    int32_t left_diffs, right_diffs; /* of the two flank overlaps                                   */
+    int32_t pad;
+    int64_t cons_off;      /* consensus bases (read orientation) in the result's sequence buffer    */
+} dh_insertion;
+
+typedef struct dh_insertions dh_insertions;
+int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, const dh_la *las, int64_t n,
+                       const uint16_t *trace, const dh_pileups *piles, const dh_process_opts *opts,
+                       dh_insertions **out);
+void dh_insertions_destroy(dh_insertions *r);
+int32_t dh_insertions_count(const dh_insertions *r);
+const dh_insertion *dh_insertions_records(const dh_insertions *r);
+const uint8_t *dh_insertions_bases(const dh_insertions *r);
+int64_t dh_insertions_bases_len(const dh_insertions *r);
+/* per-stage HIP-event times (ms) of the last dh_process_pileups call on this context:
+ * [0] crop+gather [1] pile-up alignment [2] tile QV [3] consensus vote+emit (all rounds)
+ * [4] read->consensus re-alignment (rounds > 1) [5] flank re-alignment [6] total;
+ * counters: [0] pile LAs [1] tiles aligned (NW) [2] NW cells */
+int dh_get_process_stats(dh_ctx *ctx, float *ms7, int64_t *counters3);
+
 #ifdef __cplusplus
 }
 #endif

@@ -148,6 +148,19 @@ void oz_translate_trace_point_a(int32_t abpos, int32_t aepos, int32_t bbpos, int
 uint32_t oz_nw(const uint8_t *ref, int32_t rlen, const uint8_t *qry, int32_t qlen,
                uint32_t indel, int free_shift, uint8_t *ops, int32_t *nops);
 
+/* ---------- pile-up consensus path (consensus.c) ---------- */
+#define OZ_MAXQV 50
+#define OZ_MAXINS 4
+#define OZ_VOTE_STRIDE (6 + 4 * OZ_MAXINS)
+int oz_valid_pileup_alignment(const oz_la *la, int32_t alen, int32_t blen, int32_t allowance);
+void oz_tile_qv(const oz_la_set *s, int32_t nreads, const int32_t *rlen, int32_t tspace,
+                int32_t cov, uint8_t *qv, int32_t maxtiles);
+int32_t oz_rank_reference_reads(const uint8_t *qv, int32_t nreads, const int32_t *rlen,
+                                int32_t tspace, int32_t maxtiles, const uint8_t *allowed,
+                                double bad_fraction, int32_t *order, int32_t *norder);
+int32_t oz_consensus(const uint8_t *ref, int32_t rlen, const oz_db *reads, const oz_la_set *s,
+                     int32_t aidx, int32_t tspace, uint8_t *out, uint32_t *votes_out);
+
 #ifdef __cplusplus
 }
 #endif

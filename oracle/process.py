@@ -1,0 +1,183 @@
+"""Oracle-side restatement of DENTIST's `collect` (spanning reads only) and `process` call
+sequence, driving the C oracle.  TEST INFRASTRUCTURE ONLY (never imported by dentist_amd/).
+
+Follows source/dentist/commands/processPileUps/package.d:283-374 (crop -> pile-up alignment ->
+filter -> QV -> reference read -> consensus -> flank re-alignment -> insertion), the cropping
+arithmetic of processPileUps/cropper.d:446-550 and the splice coordinates of
+common/insertions.d:110-146.  Pure-Python loops: small cases only.
+"""
+import numpy as np
+
+from dentist_amd.sim import SeqDb, revcomp
+from . import pyoracle as oz
+
+MIN_ANCHOR = 500       # commandline.d:2036 minAnchorLength
+ALLOWANCE_MAP = 100    # proper-alignment-allowance = trace spacing (commandline.d:2331)
+TS_PILE = 126
+MAX_PILE = 60          # reads kept per pile-up (one wavefront tracks <= 64 aligned regions)
+MAX_INS_ERR_PPM = 100000  # commandline.d:1997 maxInsertionError 0.10
+
+
+def collect_spanning(las, trace, contigs, reads, allowance=ALLOWANCE_MAP, min_anchor=MIN_ANCHOR):
+    """Gap g lies between contig g and g+1.  A read spans it when it has an LA reaching the end of
+    contig g and an LA starting at the begin of contig g+1, same orientation, in read order."""
+    by_read = {}
+    for i, la in enumerate(las):
+        by_read.setdefault(int(la["bread"]), []).append(i)
+    piles = {}
+    for r, idxs in sorted(by_read.items()):
+        for iL in idxs:
+            L = las[iL]
+            cl = contigs.length(int(L["aread"]))
+            if L["aepos"] + allowance < cl or L["aepos"] - L["abpos"] < min_anchor:
+                continue
+            for iR in idxs:
+                R = las[iR]
+                if R["aread"] != L["aread"] + 1 or (R["flags"] & 1) != (L["flags"] & 1):
+                    continue
+                if R["abpos"] > allowance or R["aepos"] - R["abpos"] < min_anchor:
+                    continue
+                if R["bbpos"] + allowance < L["bepos"] - allowance:  # right part must follow the left part
+                    continue
+                piles.setdefault(int(L["aread"]), []).append((r, iL, iR))
+    return {g: v[:MAX_PILE] for g, v in piles.items() if len(v) >= 3}  # min-reads-per-pile-up 3
+
+
+def ceil_to(x, m):
+    return -(-x // m) * m
+
+
+def common_trace_point(intervals, contig_len, ts, seed_front):
+    """getCommonTracePoint, cropper.d:446-500, with an empty repeat mask."""
+    lo = max(a for a, _ in intervals)
+    hi = min(e for _, e in intervals)
+    if lo >= hi:
+        return -1
+    tp_min, tp_sup = ceil_to(lo, ts), ceil_to(hi, ts)
+    cands = list(range(tp_min, tp_sup, ts)) + ([contig_len] if tp_sup > contig_len else [])
+    if seed_front:
+        cands = cands[::-1]
+    for c in cands:
+        if lo <= c < hi or c == hi:
+            return c
+    return -1
+
+
+def translate_floor(la, tr, apos, ts):
+    import ctypes
+    a, b = ctypes.c_int32(), ctypes.c_int32()
+    t = np.ascontiguousarray(tr, dtype=np.uint16)
+    oz.lib().oz_translate_trace_point_a(int(la["abpos"]), int(la["aepos"]), int(la["bbpos"]), ts, t.ctypes.data,
+                                        len(t) // 2, int(apos), 0, ctypes.byref(a), ctypes.byref(b))
+    return a.value, b.value
+
+
+def crop_pile(entries, las, trace, contigs, reads, g, ts_map=100):
+    """cropPileUp: returns (cropL, cropR, SeqDb of cropped reads in read orientation, read ids)."""
+    left = [las[iL] for _, iL, _ in entries]
+    right = [las[iR] for _, _, iR in entries]
+    cropL = common_trace_point([(int(l["abpos"]), int(l["aepos"])) for l in left], contigs.length(g), ts_map, False)
+    cropR = common_trace_point([(int(r["abpos"]), int(r["aepos"])) for r in right], contigs.length(g + 1), ts_map, True)
+    if cropL < 0 or cropR < 0:
+        return None
+    seqs, ids = [], []
+    for (r, iL, iR) in entries:
+        L, R = las[iL], las[iR]
+        _, bL = translate_floor(L, trace[L["toff"]:L["toff"] + L["tlen"]], cropL, ts_map)
+        _, bR = translate_floor(R, trace[R["toff"]:R["toff"] + R["tlen"]], cropR, ts_map)
+        rl = reads.length(r)
+        if L["flags"] & 1:          # getCroppingSlice: complement -> swap and mirror (cropper.d:533-538)
+            b0, b1 = rl - bR, rl - bL
+        else:
+            b0, b1 = bL, bR
+        if b1 - b0 < 14:
+            continue
+        seqs.append(reads.seq(r)[b0:b1].copy())
+        ids.append(r)
+    return cropL, cropR, SeqDb.from_list(seqs), ids
+
+
+def pile_opts():
+    return oz.default_opts(tspace=TS_PILE, min_len=500, skip_self=1, max_la=64, max_cand=128, width=62)
+
+
+def filter_pile_las(las, pile, max_err_ppm=300000, allowance=TS_PILE):
+    """filterLocalAlignments(averageErrorRate <= maxAlignmentError) (package.d:483-485) followed by
+    filterPileUpAlignments(properAlignmentAllowance) (dazzler.d:4066-4094): sets DISABLED (0x20)."""
+    las = las.copy()
+    for la in las:
+        al = int(la["aepos"] - la["abpos"])
+        bad = int(la["diffs"]) * 1000000 > max_err_ppm * al
+        if not bad:
+            bad = not oz.valid_pileup_alignment(la, pile.length(int(la["aread"])), pile.length(int(la["bread"])), allowance)
+        if bad:
+            la["flags"] |= 0x20
+    return las
+
+
+def process_pile(entries, las, trace, contigs, reads, g, rounds=2, nthreads=1, flank_window=20000):
+    """One pile-up through the `process` sequence; returns a dict describing the insertion."""
+    res = {"gap": g, "status": "ok", "nreads": len(entries)}
+    crop = crop_pile(entries, las, trace, contigs, reads, g)
+    if crop is None:
+        res["status"] = "no common trace point"
+        return res
+    cropL, cropR, pile, ids = crop
+    res.update(cropL=cropL, cropR=cropR, pile=pile, read_ids=ids)
+    if pile.n < 3:
+        res["status"] = "pile too small"
+        return res
+    o = pile_opts()
+    plas, ptrace, _ = oz.align_db(pile, pile, o, nthreads=nthreads)
+    plas = filter_pile_las(plas, pile)
+    res.update(pile_las=plas, pile_trace=ptrace)
+    if not np.any((plas["flags"] & 0x20) == 0):
+        res["status"] = "empty pileup alignment after filtering"
+        return res
+    rlen = np.asarray([pile.length(i) for i in range(pile.n)], dtype=np.int32)
+    cov = pile.n if pile.n >= 4 else pile.n   # max(#allowed reference reads, 4 if pile >= 4) (package.d:498-503)
+    qv = oz.tile_qv(plas, ptrace, rlen, TS_PILE, max(cov, 4) if pile.n >= 4 else cov)
+    order, badqv = oz.rank_reference_reads(qv, rlen, TS_PILE)
+    ref_idx = int(order[0])
+    res.update(qv=qv, order=order, ref_idx=ref_idx)
+    cons = oz.consensus(pile.seq(ref_idx), pile, plas, ptrace, ref_idx, TS_PILE)
+    for _ in range(1, rounds):
+        tdb = SeqDb.from_list([cons])
+        o2 = oz.default_opts(tspace=TS_PILE, min_len=500, max_la=4, max_cand=32, width=62)
+        rl, rt, _ = oz.align_db(tdb, pile, o2, nthreads=nthreads)
+        for la in rl:   # proper overlaps only
+            if not oz.valid_pileup_alignment({**{f: la[f] for f in la.dtype.names}, "aread": -1},
+                                             len(cons), pile.length(int(la["bread"])), TS_PILE):
+                la["flags"] |= 0x20
+        cons = oz.consensus(cons, pile, rl, rt, 0, TS_PILE)
+    res["consensus"] = cons
+    # flank re-alignment: daligner -A -s126 -l126 contigs consensus (commandline.d:2918-2935)
+    cl, cr = contigs.seq(g), contigs.seq(g + 1)
+    wl = max(0, len(cl) - flank_window)
+    fl, fr = cl[wl:], cr[:flank_window]
+    fdb = SeqDb.from_list([fl, fr])
+    o3 = oz.default_opts(tspace=TS_PILE, min_len=126, max_la=4, max_cand=32, width=62)
+    fl_las, fl_tr, _ = oz.align_db(fdb, SeqDb.from_list([cons]), o3, nthreads=nthreads)
+    res.update(flank_las=fl_las, flank_trace=fl_tr, flank_off=wl)
+    allow = TS_PILE
+    L = [la for la in fl_las if la["aread"] == 0 and la["aepos"] + allow >= len(fl) and la["bbpos"] <= allow]
+    R = [la for la in fl_las if la["aread"] == 1 and la["abpos"] <= allow and la["bepos"] + allow >= len(cons)]
+    if len(L) != 1 or len(R) != 1:
+        res["status"] = f"consensus does not align uniquely to the flanks ({len(L)},{len(R)})"
+        return res
+    L, R = L[0], R[0]
+    if (L["flags"] & 1) != (R["flags"] & 1):
+        res["status"] = "flank orientation mismatch"
+        return res
+    for la in (L, R):
+        if int(la["diffs"]) * 1000000 > MAX_INS_ERR_PPM * int(la["aepos"] - la["abpos"]):   # ensureHighQualityConsensus output.d:388-410
+            res["status"] = "maxInsertionError"
+            return res
+    cseq = revcomp(cons) if (L["flags"] & 1) else cons
+    b0, b1 = int(L["bepos"]), int(R["bbpos"])
+    res.update(left_aepos=wl + int(L["aepos"]), right_abpos=int(R["abpos"]), ins_begin=b0, ins_end=b1)
+    if b1 < b0:
+        res["status"] = "negative insertion"
+        return res
+    res["insertion"] = cseq[b0:b1].copy()
+    return res

@@ -163,3 +163,83 @@ def las_read(path):
         raise IOError(f"oz_las_read({path}) = {rc}")
     las, trace = _take(ls)
     return las, trace, ts.value
+
+
+# ---------------------------------------------------------------- consensus path (consensus.c)
+MAXQV = 50
+MAXINS = 4
+VOTE_STRIDE = 6 + 4 * MAXINS
+
+
+def _la_set_view(las, trace):
+    """Borrow numpy arrays as an oz_la_set (keep the arrays alive while it is used)."""
+    ls = LaSet()
+    arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
+    tr = np.ascontiguousarray(trace, dtype=np.uint16)
+    ls.n = len(arr)
+    ls.la = ctypes.cast(arr.ctypes.data, ctypes.POINTER(La))
+    ls.tn = len(tr)
+    ls.trace = ctypes.cast(tr.ctypes.data, ctypes.POINTER(ctypes.c_uint16))
+    return ls, (arr, tr)
+
+
+def _bind_consensus():
+    L = lib()
+    if getattr(L, "_cons_bound", False):
+        return L
+    L.oz_valid_pileup_alignment.argtypes = [ctypes.POINTER(La), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+    L.oz_valid_pileup_alignment.restype = ctypes.c_int
+    L.oz_tile_qv.argtypes = [ctypes.POINTER(LaSet), ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+                             ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32]
+    L.oz_rank_reference_reads.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+                                          ctypes.c_int32, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p,
+                                          ctypes.POINTER(ctypes.c_int32)]
+    L.oz_rank_reference_reads.restype = ctypes.c_int32
+    L.oz_consensus.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(Db), ctypes.POINTER(LaSet),
+                               ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    L.oz_consensus.restype = ctypes.c_int32
+    L._cons_bound = True
+    return L
+
+
+def tile_qv(las, trace, rlen, tspace, cov):
+    L = _bind_consensus()
+    rlen = np.ascontiguousarray(rlen, dtype=np.int32)
+    maxtiles = int((rlen.max() + tspace - 1) // tspace) if len(rlen) else 1
+    qv = np.full((len(rlen), max(maxtiles, 1)), 255, dtype=np.uint8)
+    ls, keep = _la_set_view(las, trace)
+    L.oz_tile_qv(ctypes.byref(ls), len(rlen), rlen.ctypes.data, tspace, cov, qv.ctypes.data, qv.shape[1])
+    return qv
+
+
+def rank_reference_reads(qv, rlen, tspace, bad_fraction=0.08, allowed=None):
+    L = _bind_consensus()
+    rlen = np.ascontiguousarray(rlen, dtype=np.int32)
+    qv = np.ascontiguousarray(qv, dtype=np.uint8)
+    order = np.zeros(len(rlen), dtype=np.int32)
+    n = ctypes.c_int32(0)
+    al = None if allowed is None else np.ascontiguousarray(allowed, dtype=np.uint8)
+    bad = L.oz_rank_reference_reads(qv.ctypes.data, len(rlen), rlen.ctypes.data, tspace, qv.shape[1],
+                                    al.ctypes.data if al is not None else None, bad_fraction,
+                                    order.ctypes.data, ctypes.byref(n))
+    return order[:n.value].copy(), int(bad)
+
+
+def consensus(ref, reads, las, trace, aidx, tspace, want_votes=False):
+    L = _bind_consensus()
+    ref = np.ascontiguousarray(ref, dtype=np.uint8)
+    out = np.zeros(len(ref) * (1 + MAXINS) + 1, dtype=np.uint8)
+    votes = np.zeros((len(ref), VOTE_STRIDE), dtype=np.uint32) if want_votes else None
+    ls, keep = _la_set_view(las, trace)
+    d = _db(reads)
+    n = L.oz_consensus(ref.ctypes.data, len(ref), ctypes.byref(d), ctypes.byref(ls), aidx, tspace,
+                       out.ctypes.data, votes.ctypes.data if want_votes else None)
+    return (out[:n].copy(), votes) if want_votes else out[:n].copy()
+
+
+def valid_pileup_alignment(la, alen, blen, allowance):
+    L = _bind_consensus()
+    rec = La()
+    for f, _ in La._fields_:
+        setattr(rec, f, int(la[f]))
+    return bool(L.oz_valid_pileup_alignment(ctypes.byref(rec), alen, blen, allowance))

@@ -1,0 +1,106 @@
+"""Parity of the pile-up consensus path (dh_collect_spanning + dh_process_pileups through the C
+ABI) with the oracle's restatement of `dentist process` -- bit exact: pile-up membership, crop
+points, reference read, every consensus base and the insertion coordinates."""
+import os
+
+import numpy as np
+import pytest
+
+import dentist_amd
+from dentist_amd import sim
+from oracle import process as pr
+from oracle import pyoracle as oz
+
+pytestmark = pytest.mark.gpu
+
+STATUS = {0: "ok", 1: "no common trace point", 2: "pile too small",
+          3: "empty pileup alignment after filtering"}
+
+
+def run_case(ctx, w, rounds):
+    g = dentist_amd.default_align_opts()
+    A, B = ctx.db(w.contigs), ctx.db(w.reads)
+    las, trace = ctx.align_db(A, B, g)
+    # the mapping LAs themselves are covered by test_parity_map_gpu; the oracle re-derives them
+    olas, otrace, _ = oz.align_db(w.contigs, w.reads, oz.default_opts(width=g.width), nthreads=os.cpu_count() or 1)
+    assert np.array_equal(las, olas) and np.array_equal(trace, otrace)
+    po = dentist_amd.default_process_opts(rounds=rounds)
+    piles = dentist_amd.Pileups(las, w.contigs.off, po)
+    exp_piles = pr.collect_spanning(olas, otrace, w.contigs, w.reads)
+    assert len(piles) == len(exp_piles) and len(piles) > 0
+    rec, bases = dentist_amd.process_pileups(ctx, A, B, las, trace, piles, po)
+    assert len(rec) == len(piles)
+    closed = 0
+    for i in range(len(piles)):
+        gap, tri = piles.get(i)
+        assert [tuple(t) for t in tri.tolist()] == [tuple(int(x) for x in e) for e in exp_piles[gap]]
+        exp = pr.process_pile(exp_piles[gap], olas, otrace, w.contigs, w.reads, gap, rounds=rounds,
+                              nthreads=os.cpu_count() or 1)
+        r = rec[i]
+        assert r["contig_left"] == gap
+        if exp["status"] != "ok":
+            assert r["status"] != 0, (gap, exp["status"])
+            if r["status"] in STATUS:
+                assert STATUS[int(r["status"])] == exp["status"]
+            continue
+        assert r["status"] == 0, (gap, int(r["status"]))
+        assert (r["crop_left"], r["crop_right"]) == (exp["cropL"], exp["cropR"])
+        assert r["nreads"] == exp["pile"].n and r["ref_read"] == exp["ref_idx"]
+        assert r["ref_read_id"] == exp["read_ids"][exp["ref_idx"]]
+        cons = bases[r["cons_off"]:r["cons_off"] + r["cons_len"]]
+        assert np.array_equal(cons, exp["consensus"]), f"gap {gap}: consensus differs"
+        assert (r["left_aepos"], r["right_abpos"], r["ins_begin"], r["ins_end"]) == \
+               (exp["left_aepos"], exp["right_abpos"], exp["ins_begin"], exp["ins_end"])
+        cseq = sim.revcomp(cons) if r["comp"] else cons
+        ins = cseq[r["ins_begin"]:r["ins_end"]]
+        assert np.array_equal(ins, exp["insertion"])
+        # against the truth: the spliced region must be close to what was cut out
+        truth = w.truth[w.contig_start[gap] + r["left_aepos"]: w.gap_end[gap] + r["right_abpos"]]
+        ed, _ = oz.nw(truth, ins)
+        assert ed <= max(2, 0.02 * len(truth)), (gap, ed, len(truth))
+        closed += 1
+    assert closed >= 1
+    return rec
+
+
+@pytest.mark.parametrize("rounds", [1, 2])
+def test_process_small_gaps(gpu_ctx, rounds):
+    w = sim.Workload(300_000, 3, 1200, 6000, seed=17, spacing=20000, gap_max=800)
+    rec = run_case(gpu_ctx, w, rounds)
+    assert (rec["status"] == 0).sum() >= 2
+
+
+def test_process_longer_gaps(gpu_ctx):
+    w = sim.Workload(600_000, 4, 2400, 8000, seed=7, spacing=20000, gap_max=2000)
+    rec = run_case(gpu_ctx, w, 2)
+    assert (rec["status"] == 0).sum() >= 3
+
+
+def test_process_reference_fixture_gap_is_closed_perfectly(gpu_ctx):
+    """tests/test-commands.sh:17-44, 62-65: the 97 bp gap at [2000, 2097) of the 4 097 bp contig is
+    reconstructed exactly from 20x / 13 %-error reads (md5 of gap-closed.fasta)."""
+    import hashlib
+    raw = open(os.path.join(os.path.dirname(__file__), "golden", "test_commands_assembly_reference.fasta")).read()
+    header, seq = raw.split("\n")[0], "".join(raw.split("\n")[1:])
+    codes = sim.encode(seq)
+    contigs = sim.SeqDb.from_list([codes[:2000], codes[2097:]])
+    # simulator -m25000 -s12500 -e.13 -c20: reads are longer than the contig, so every read spans
+    reads, _ = sim.reads(1724161952, codes, 40, 3000, 0, min_len=500)
+    g = dentist_amd.default_align_opts()
+    A, B = gpu_ctx.db(contigs), gpu_ctx.db(reads)
+    las, trace = gpu_ctx.align_db(A, B, g)
+    po = dentist_amd.default_process_opts(rounds=2, flank_window=20000)
+    piles = dentist_amd.Pileups(las, contigs.off, po)
+    assert len(piles) == 1
+    rec, bases = dentist_amd.process_pileups(gpu_ctx, A, B, las, trace, piles, po)
+    r = rec[0]
+    assert r["status"] == 0
+    cons = bases[r["cons_off"]:r["cons_off"] + r["cons_len"]]
+    cseq = sim.revcomp(cons) if r["comp"] else cons
+    ins = sim.decode(cseq[r["ins_begin"]:r["ins_end"]])
+    # output.d:782-925: lower-case contig slices, upper-case insertion, 50 columns, header rule :743-759
+    out = seq[:r["left_aepos"]] + ins.upper() + seq[2097 + r["right_abpos"]:]
+    fasta = f"{header}\tscaffold-1\n" + "\n".join(out[i:i + 50] for i in range(0, len(out), 50)) + "\n"
+    assert out.lower() == seq, "gap not reconstructed exactly"
+    if r["left_aepos"] == 2000 and r["right_abpos"] == 0:
+        assert hashlib.md5(fasta.encode()).hexdigest() == "c3836dc00a3f5e1e2aa8f2a802da4d67"
