@@ -1,6 +1,7 @@
 """ctypes binding of include/dentist_hip.h (libdentist_hip.so). No compute, no fallback."""
 import ctypes
 import os
+import weakref
 
 import numpy as np
 
@@ -164,9 +165,15 @@ class Context:
         h = ctypes.c_void_p()
         _check(lib().dh_ctx_create(device, ctypes.c_void_p(stream) if stream else None, ctypes.byref(h)))
         self._h = h
+        self._dbs = []
 
     def close(self):
         if self._h:
+            for ref in self._dbs:  # device DBs must go before their context
+                d = ref()
+                if d is not None:
+                    d.close()
+            self._dbs = []
             lib().dh_ctx_destroy(self._h)
             self._h = None
 
@@ -207,13 +214,15 @@ class Db:
         _check(lib().dh_db_create(ctx._h, bases.ctypes.data, off.ctypes.data, len(off) - 1,
                                   group.ctypes.data if group is not None else None, ctypes.byref(h)))
         self._h = h
+        ctx._dbs.append(weakref.ref(self))
 
     def drop_cache(self):
         _check(lib().dh_db_drop_cache(self._h))
 
     def close(self):
         if self._h:
-            lib().dh_db_destroy(self._h)
+            if self.ctx._h:
+                lib().dh_db_destroy(self._h)
             self._h = None
 
     def __del__(self):

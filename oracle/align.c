@@ -130,6 +130,9 @@ struct oz_index {
     int32_t na;
     int32_t sepv;
     int32_t k;
+    int32_t shift;
+    int64_t nb;
+    int64_t *dir; /* bucket directory over key >> shift */
 };
 
 static int ent_cmp(const void *x, const void *y)
@@ -187,7 +190,33 @@ static oz_index *index_build(const oz_db *A, const oz_opts *o, int32_t max_blen)
         }
     }
     ix->n = n;
-    qsort(ix->e, (size_t)n, sizeof(ix_ent), ent_cmp);
+    /* order by (key, aseq, apos): counting sort on the top bits of the key, then each bucket is
+     * sorted on its own -- same final order as one big sort, but O(n) instead of O(n log n) */
+    int ngrp = 1;
+    if (A->group)
+        for (int32_t s = 0; s < A->n; s++)
+            if (A->group[s] + 1 > ngrp) ngrp = A->group[s] + 1;
+    int keybits = 2 * k, gb = 0;
+    while ((1 << gb) < ngrp) gb++;
+    keybits += gb;
+    int pbits = 10;
+    while (pbits < 24 && (1ll << pbits) < n) pbits++;
+    if (pbits > keybits) pbits = keybits;
+    ix->shift = keybits - pbits;
+    ix->nb = (int64_t)((((uint64_t)ngrp << (2 * k)) - 1) >> ix->shift) + 1;
+    ix->dir = (int64_t *)calloc((size_t)ix->nb + 1, sizeof(int64_t));
+    for (int64_t i = 0; i < n; i++) ix->dir[(ix->e[i].key >> ix->shift) + 1]++;
+    for (int64_t b = 0; b < ix->nb; b++) ix->dir[b + 1] += ix->dir[b];
+    ix_ent *tmp = (ix_ent *)malloc((size_t)(n ? n : 1) * sizeof(ix_ent));
+    int64_t *cur = (int64_t *)malloc((size_t)ix->nb * sizeof(int64_t));
+    memcpy(cur, ix->dir, (size_t)ix->nb * sizeof(int64_t));
+    for (int64_t i = 0; i < n; i++) tmp[cur[ix->e[i].key >> ix->shift]++] = ix->e[i];
+    free(cur);
+    free(ix->e);
+    ix->e = tmp;
+    for (int64_t b = 0; b < ix->nb; b++)
+        if (ix->dir[b + 1] - ix->dir[b] > 1)
+            qsort(ix->e + ix->dir[b], (size_t)(ix->dir[b + 1] - ix->dir[b]), sizeof(ix_ent), ent_cmp);
     return ix;
 }
 
@@ -198,22 +227,20 @@ void oz_index_free(oz_index *ix)
     if (!ix) return;
     free(ix->e);
     free(ix->goff);
+    free(ix->dir);
     free(ix);
 }
 
 int64_t oz_index_size(const oz_index *ix) { return ix->n; }
 
-/* first entry with key >= key */
+/* first entry with key >= key: directory bucket, then a short scan */
 static int64_t ix_lower(const oz_index *ix, uint64_t key)
 {
-    int64_t lo = 0, hi = ix->n;
-    while (lo < hi) {
-        int64_t mid = (lo + hi) >> 1;
-        if (ix->e[mid].key < key)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
+    const int64_t b = (int64_t)(key >> ix->shift);
+    if (b >= ix->nb) return ix->n;
+    int64_t lo = ix->dir[b];
+    const int64_t hi = ix->dir[b + 1];
+    while (lo < hi && ix->e[lo].key < key) lo++;
     return lo;
 }
 
