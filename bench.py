@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=3000)
     ap.add_argument("--cpu-sample-gaps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kmer-mod", type=int, default=4)
     args = ap.parse_args()
 
     import torch
@@ -95,7 +96,8 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     ctx = dentist_amd.Context(local_rank, stream=stream)
     A, B = ctx.db(w.contigs), ctx.db(w.reads)
-    mopts = dentist_amd.default_align_opts()
+    # mapping pass: modimer sampling 1/4 (daligner's -%), every other option at its default
+    mopts = dentist_amd.default_align_opts(kmer_mod=args.kmer_mod)
     popts = dentist_amd.default_process_opts()
     read_bp = int(len(w.reads.bases))
 
@@ -166,7 +168,8 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": args.workload, "per_gpu": spec, "read_bp_total": read_all,
+            "config": {"workload": args.workload, "per_gpu": spec, "mapping_kmer_mod": args.kmer_mod,
+                       "read_bp_total": read_all,
                        "pile_ups": npiles_all, "gaps_closed": nclosed_all, "gap_bases_closed": gap_all,
                        "consensus_edit_distance_vs_truth": edits_all, "consensus_truth_bases": truth_all,
                        "consensus_error_rate": (edits_all / truth_all) if truth_all else None},
@@ -202,7 +205,7 @@ def cpu_baseline(w, last, mopts, popts, args):
     cores = os.cpu_count() or 1
     n = min(args.cpu_sample_reads, w.reads.n)
     sub = sim.SeqDb(w.reads.bases[:w.reads.off[n]], w.reads.off[:n + 1])
-    o = oz.default_opts(width=mopts.width)
+    o = oz.default_opts(width=mopts.width, kmer_mod=mopts.kmer_mod)
     t0 = time.perf_counter()
     oz.align_db(w.contigs, sub, o, nthreads=cores)
     t_map = time.perf_counter() - t0

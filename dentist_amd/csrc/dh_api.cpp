@@ -4,6 +4,7 @@
 // index is built in HBM, per-slot wave scratch is preallocated), sequences launches on the
 // context's stream and times the stages with HIP events on that stream.  No CPU fallback: every
 // compute entry point needs a working HIP device.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -62,8 +63,28 @@ extern "C" void dh_ctx_destroy(dh_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto &a : c->arena)
+        if (a.p) (void)hipFree(a.p);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+int dh_scratch(dh_ctx *ctx, int id, size_t bytes, void **out)
+{
+    dh_ctx::Arena &a = ctx->arena[id];
+    if (bytes > a.cap) {
+        if (a.p) {
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            (void)hipFree(a.p);
+            a.p = nullptr;
+            a.cap = 0;
+        }
+        const size_t want = bytes + bytes / 8 + 256;
+        HIPCHK(hipMalloc(&a.p, want));
+        a.cap = want;
+    }
+    *out = a.p;
+    return DH_OK;
 }
 
 extern "C" int dh_ctx_sync(dh_ctx *c)
@@ -98,9 +119,19 @@ extern "C" void dh_default_align_opts(dh_align_opts *o)
     o->skip_self = 0;
     o->dmax = 60000;
     o->width = 62;
+    o->kmer_mod = 1;
 }
 
 // ------------------------------------------------------------------------------------ DB
+
+int dh_alloc_bases(hipStream_t st, int64_t total, uint8_t **alloc, uint8_t **base)
+{
+    const size_t nb = (size_t)std::max<int64_t>(total, 0) + 2 * DB_PAD;
+    HIPCHK(hipMalloc(alloc, nb));
+    HIPCHK(hipMemsetAsync(*alloc, 4, nb, st));
+    *base = *alloc + DB_PAD;
+    return DH_OK;
+}
 
 
 
@@ -137,9 +168,10 @@ extern "C" int dh_db_create(dh_ctx *ctx, const uint8_t *bases, const int64_t *of
             db->ngroups = std::max(db->ngroups, g + 1);
         }
     }
-    const size_t nb = (size_t)std::max<int64_t>(db->total, 1) + 64;  // slack for wide loads
-    HIPCHK(hipMalloc(&db->d_bases, nb));
-    HIPCHK(hipMemsetAsync(db->d_bases, 4, nb, ctx->stream));
+    if (int rc = dh_alloc_bases(ctx->stream, db->total, &db->d_bases_alloc, &db->d_bases)) {
+        delete db;
+        return rc;
+    }
     HIPCHK(hipMalloc(&db->d_off, sizeof(int64_t) * (size_t)(n + 1)));
     if (db->total > 0)
         HIPCHK(hipMemcpyAsync(db->d_bases, bases, (size_t)db->total, hipMemcpyHostToDevice, ctx->stream));
@@ -160,8 +192,8 @@ extern "C" void dh_db_destroy(dh_db *db)
     if (!db) return;
     (void)hipSetDevice(db->ctx->device);
     (void)hipStreamSynchronize(db->ctx->stream);
-    (void)hipFree(db->d_bases);
-    (void)hipFree(db->d_rc);
+    (void)hipFree(db->d_bases_alloc);
+    (void)hipFree(db->d_rc_alloc);
     (void)hipFree(db->d_off);
     (void)hipFree(db->d_group);
     if (db->has_ix) db->ix.release();
@@ -179,17 +211,15 @@ extern "C" int dh_db_drop_cache(dh_db *db)
     (void)hipStreamSynchronize(db->ctx->stream);
     if (db->has_ix) db->ix.release();
     db->has_ix = false;
-    (void)hipFree(db->d_rc);
-    db->d_rc = nullptr;
+    (void)hipFree(db->d_rc_alloc);
+    db->d_rc = db->d_rc_alloc = nullptr;
     return DH_OK;
 }
 
 int dh_ensure_rc(dh_db *db)
 {
     if (db->d_rc) return DH_OK;
-    const size_t nb = (size_t)std::max<int64_t>(db->total, 1) + 64;
-    HIPCHK(hipMalloc(&db->d_rc, nb));
-    HIPCHK(hipMemsetAsync(db->d_rc, 4, nb, db->ctx->stream));
+    if (int rc = dh_alloc_bases(db->ctx->stream, db->total, &db->d_rc_alloc, &db->d_rc)) return rc;
     dhk_revcomp(db->ctx->stream, db->d_bases, db->d_rc, db->d_off, db->n, db->max_len);
     HIPCHK(hipGetLastError());
     return DH_OK;
@@ -202,16 +232,17 @@ static int32_t ceil_log2(uint64_t x)
     return b;
 }
 
-static int build_index(dh_db *A, int32_t k, int32_t sepv)
+static int build_index(dh_db *A, int32_t k, int32_t sepv, int32_t kmer_mod)
 {
     dh_ctx *ctx = A->ctx;
-    if (A->has_ix && A->ix.k == k && A->ix.sepv == sepv) return DH_OK;
+    if (A->has_ix && A->ix.k == k && A->ix.sepv == sepv && A->ix.kmer_mod == kmer_mod) return DH_OK;
     if (A->has_ix) A->ix.release();
     A->has_ix = false;
     dh_index &ix = A->ix;
     ix = dh_index();
     ix.k = k;
     ix.sepv = sepv;
+    ix.kmer_mod = kmer_mod;
     ix.na = A->n;
     // virtual offsets and tile table
     std::vector<int64_t> goff((size_t)A->n + 1);
@@ -254,10 +285,10 @@ static int build_index(dh_db *A, int32_t k, int32_t sepv)
                               ctx->stream));
     HIPCHK(hipMemsetAsync(ix.d_dir, 0, sizeof(uint32_t) * (size_t)(nb + 1), ctx->stream));
     const DbView av = A->view();
-    dhk_kmer_pass(ctx->stream, 0, av, d_tiles, (int32_t)tiles.size(), k, ix.shift, ix.d_dir, ix.d_ekey,
+    dhk_kmer_pass(ctx->stream, 0, av, d_tiles, (int32_t)tiles.size(), k, kmer_mod, ix.shift, ix.d_dir, ix.d_ekey,
                   ix.d_eval, ix.d_goff);
     dhk_scan(ctx->stream, ix.d_dir, nb + 1, d_sums);
-    dhk_kmer_pass(ctx->stream, 1, av, d_tiles, (int32_t)tiles.size(), k, ix.shift, ix.d_dir, ix.d_ekey,
+    dhk_kmer_pass(ctx->stream, 1, av, d_tiles, (int32_t)tiles.size(), k, kmer_mod, ix.shift, ix.d_dir, ix.d_ekey,
                   ix.d_eval, ix.d_goff);
     dhk_bucket_sort(ctx->stream, ix.d_dir, nb, ix.d_ekey, ix.d_eval);
     HIPCHK(hipGetLastError());
@@ -329,6 +360,14 @@ static void select_best(std::vector<dh_la> &la)
 extern "C" int dh_align_db(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts,
                            int32_t want_best, dh_la_set **out)
 {
+    return dh_align_db_ex(ctx, A, B, opts, want_best, 1, out);
+}
+
+int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, int32_t want_best,
+                   int32_t want_sorted, dh_la_set **out)
+{
+    const double wall0 = (double)std::chrono::duration_cast<std::chrono::microseconds>(
+                             std::chrono::steady_clock::now().time_since_epoch()).count();
     if (!ctx || !A || !B || !opts || !out) return fail(DH_EINVAL, "dh_align_db: NULL argument");
     if (A->ctx != ctx || B->ctx != ctx) return fail(DH_EINVAL, "dh_align_db: DB of another context");
     const dh_align_opts &o = *opts;
@@ -340,6 +379,7 @@ extern "C" int dh_align_db(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts 
     if (o.pen < 2) return fail(DH_EINVAL, "pen must be >= 2");
     if (o.band_shift < 1 || o.band_shift > 12) return fail(DH_EINVAL, "band_shift out of range");
     if (o.skip_self && A != B) return fail(DH_EINVAL, "skip_self needs A == B");
+    if (o.kmer_mod < 1 || o.kmer_mod > 64) return fail(DH_EINVAL, "kmer_mod must be in [1, 64]");
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     dh_align_stats stats = {};
@@ -358,7 +398,7 @@ extern "C" int dh_align_db(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts 
 
     HIPCHK(hipEventRecord(ctx->ev[0], st));
     const int32_t sepv = ((B->max_len + 64) + 63) & ~63;
-    if (int rc = build_index(A, o.k, sepv)) return rc;
+    if (int rc = build_index(A, o.k, sepv, o.kmer_mod)) return rc;
     if (int rc = dh_ensure_rc(B)) return rc;
     HIPCHK(hipEventRecord(ctx->ev[1], st));
 
@@ -374,7 +414,7 @@ extern "C" int dh_align_db(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts 
     const int32_t nbmax = (int32_t)(maxext / o.tspace + 3);
     const int32_t trmax = 2 * (2 * nbmax + 2);
     const int32_t poolcap = 96 * nbmax;
-    int32_t slots_per_cu = 8;
+    int32_t slots_per_cu = 20;  // 86 VGPRs -> 5 waves/SIMD; measured 141 -> 39 ms from 8 to 20
     if (const char *e = getenv("DH_WAVE_SLOTS_PER_CU")) slots_per_cu = std::max(1, atoi(e));
     const int64_t nitems_total = 2ll * B->n;
     const int32_t nslots = (int32_t)std::min<int64_t>((int64_t)ctx->ncu * slots_per_cu,
@@ -382,50 +422,54 @@ extern "C" int dh_align_db(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts 
     int32_t chunk = 1 << 18;
     if (const char *e = getenv("DH_ALIGN_CHUNK")) chunk = std::max(2, atoi(e)) & ~1;
 
-    DevBuf<DhCand> d_cand;
-    DevBuf<int32_t> d_ncand, d_nhits, d_status, d_nla, d_cdj;
-    DevBuf<DhNode> d_pool;
-    DevBuf<uint32_t> d_queue;
-    DevBuf<DhLa> d_la;
-    DevBuf<uint16_t> d_trslots;
-    DevBuf<unsigned long long> d_counters;
     const int32_t cn = (int32_t)std::min<int64_t>(chunk, std::max<int64_t>(nitems_total, 2));
-    HIPCHK(d_cand.alloc((size_t)cn * o.max_cand));
-    HIPCHK(d_ncand.alloc((size_t)nitems_total));
-    HIPCHK(d_nhits.alloc((size_t)nitems_total));
-    HIPCHK(d_status.alloc(1));
-    HIPCHK(d_nla.alloc((size_t)nitems_total));
-    HIPCHK(d_pool.alloc((size_t)nslots * poolcap));
-    HIPCHK(d_cdj.alloc((size_t)nslots * 4 * nbmax));
-    HIPCHK(d_queue.alloc(1));
-    HIPCHK(d_la.alloc((size_t)cn * o.max_la));
-    HIPCHK(d_trslots.alloc((size_t)cn * o.max_la * trmax));
-    HIPCHK(d_counters.alloc(2));
-    HIPCHK(hipMemsetAsync(d_status.p, 0, sizeof(int32_t), st));
-    HIPCHK(hipMemsetAsync(d_counters.p, 0, 2 * sizeof(unsigned long long), st));
+    DhCand *d_cand;
+    int32_t *d_ncand, *d_nhits, *d_status, *d_cdj;
+    uint32_t *d_nla, *d_ntr, *d_queue, *d_sums;
+    DhNode *d_pool;
+    DhLa *d_la, *d_laout;
+    uint16_t *d_trslots, *d_trout;
+    unsigned long long *d_counters;
+#define SCR(id, ptr, count)                                                                      \
+    if (int rc_ = dh_scratch(ctx, id, sizeof(*ptr) * std::max<size_t>((size_t)(count), 1), (void **)&ptr)) return rc_;
+    SCR(0, d_cand, (size_t)cn * o.max_cand)
+    SCR(1, d_ncand, cn)
+    SCR(2, d_nhits, cn)
+    SCR(3, d_status, 4)
+    SCR(4, d_nla, cn + 1)
+    SCR(5, d_ntr, cn + 1)
+    SCR(6, d_pool, (size_t)nslots * poolcap)
+    SCR(7, d_cdj, (size_t)nslots * 4 * nbmax)
+    SCR(8, d_queue, 4)
+    SCR(9, d_la, (size_t)cn * o.max_la)
+    SCR(10, d_trslots, (size_t)cn * o.max_la * trmax)
+    SCR(11, d_counters, 2)
+    SCR(12, d_sums, (size_t)cn / 2048 + 4)
+    HIPCHK(hipMemsetAsync(d_status, 0, sizeof(int32_t), st));
+    HIPCHK(hipMemsetAsync(d_counters, 0, 2 * sizeof(unsigned long long), st));
 
     // expected hits per (read, strand): random matches + true seeds; pick the LDS hit capacity
     const double dens = (double)A->ix.n / std::pow(4.0, o.k) / std::max(1, A->ngroups);
-    const double exp_hits = B->max_len * (dens * (A->ngroups > 1 ? 1.0 : 1.0) + 0.2);
+    const double exp_hits = B->max_len * (dens + 0.2);
     int cap = exp_hits * 1.5 < 4096 ? 4096 : 16384;
 
-    std::vector<int32_t> h_nla((size_t)cn), h_ncand((size_t)cn), h_nhits((size_t)cn);
-    std::vector<DhLa> h_la;
+    std::vector<int32_t> h_ncand((size_t)cn), h_nhits((size_t)cn);
     float ms_seed = 0, ms_wave = 0, ms_gather = 0;
 
     for (int64_t item0 = 0; item0 < nitems_total; item0 += cn) {
         const int32_t ni = (int32_t)std::min<int64_t>(cn, nitems_total - item0);
-        // candidates are indexed by absolute item: shift the base pointer so item0 maps to 0
-        DhCand *candbase = d_cand.p - item0 * o.max_cand;
-        DhLa *labase = d_la.p - item0 * o.max_la;
-        uint16_t *trbase = d_trslots.p - item0 * (int64_t)o.max_la * trmax;
+        // per-chunk arrays are indexed by absolute item inside the kernels: shift the bases
+        DhCand *candbase = d_cand - item0 * o.max_cand;
+        DhLa *labase = d_la - item0 * o.max_la;
+        uint16_t *trbase = d_trslots - item0 * (int64_t)o.max_la * trmax;
+        int32_t *ncandbase = d_ncand - item0, *nhitsbase = d_nhits - item0;
+        int32_t *nlabase = (int32_t *)d_nla - item0, *ntrbase = (int32_t *)d_ntr - item0;
         HIPCHK(hipEventRecord(ctx->ev[2], st));
         for (;;) {
-            dhk_seed(st, cap, bv, B->d_rc, iv, dopt, (int32_t)item0, ni, candbase, d_ncand.p, d_nhits.p,
-                     d_status.p);
+            dhk_seed(st, cap, bv, B->d_rc, iv, dopt, (int32_t)item0, ni, candbase, ncandbase, nhitsbase, d_status);
             HIPCHK(hipGetLastError());
             int32_t status = 0;
-            HIPCHK(hipMemcpyAsync(&status, d_status.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(&status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             if (status & DH_ST_CAND_OVERFLOW)
                 return fail(DH_EOVERFLOW, "seed filter: more than 256 candidate band pairs for one read");
@@ -434,69 +478,51 @@ extern "C" int dh_align_db(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts 
                     return fail(DH_EOVERFLOW,
                                 "seed filter: more than 16384 k-mer hits for one (read, strand); lower -t");
                 cap = 16384;
-                HIPCHK(hipMemsetAsync(d_status.p, 0, sizeof(int32_t), st));
+                HIPCHK(hipMemsetAsync(d_status, 0, sizeof(int32_t), st));
                 continue;
             }
             break;
         }
         HIPCHK(hipEventRecord(ctx->ev[3], st));
-        HIPCHK(hipMemsetAsync(d_queue.p, 0, sizeof(uint32_t), st));
-        WaveScratch ws{d_pool.p, d_cdj.p, d_queue.p, poolcap, nbmax};
-        dhk_wave(st, nslots, av, bv, B->d_rc, dopt, (int32_t)item0, ni, candbase, d_ncand.p, ws, labase,
-                 trbase, trmax, d_nla.p, d_counters.p, d_status.p);
+        HIPCHK(hipMemsetAsync(d_queue, 0, sizeof(uint32_t), st));
+        HIPCHK(hipMemsetAsync(d_nla + ni, 0, sizeof(uint32_t), st));
+        HIPCHK(hipMemsetAsync(d_ntr + ni, 0, sizeof(uint32_t), st));
+        WaveScratch ws{d_pool, d_cdj, d_queue, poolcap, nbmax};
+        dhk_wave(st, nslots, av, bv, B->d_rc, dopt, (int32_t)item0, ni, candbase, ncandbase, ws, labase, trbase,
+                 trmax, nlabase, ntrbase, d_counters, d_status);
         HIPCHK(hipGetLastError());
         stats.wave_launches++;
         HIPCHK(hipEventRecord(ctx->ev[4], st));
-        // counts back, compact on the host, gather traces on the device
-        HIPCHK(hipMemcpyAsync(h_nla.data(), d_nla.p + item0, sizeof(int32_t) * (size_t)ni,
-                              hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(h_ncand.data(), d_ncand.p + item0, sizeof(int32_t) * (size_t)ni,
-                              hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(h_nhits.data(), d_nhits.p + item0, sizeof(int32_t) * (size_t)ni,
-                              hipMemcpyDeviceToHost, st));
+        // compaction on the device: exclusive scans of the per-item counts, then one copy kernel
+        dhk_scan(st, d_nla, (int64_t)ni + 1, d_sums);
+        dhk_scan(st, d_ntr, (int64_t)ni + 1, d_sums);
+        uint32_t totals[2] = {0, 0};
         int32_t status = 0;
-        HIPCHK(hipMemcpyAsync(&status, d_status.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&totals[0], d_nla + ni, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&totals[1], d_ntr + ni, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(h_ncand.data(), d_ncand, sizeof(int32_t) * (size_t)ni, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(h_nhits.data(), d_nhits, sizeof(int32_t) * (size_t)ni, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         if (status & DH_ST_POOL_OVERFLOW)
             return fail(DH_EOVERFLOW, "wave: trace-tree pool or boundary capacity exceeded");
-        h_la.resize((size_t)ni * o.max_la);
-        HIPCHK(hipMemcpyAsync(h_la.data(), d_la.p, sizeof(DhLa) * h_la.size(), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        std::vector<int64_t> src, dst;
-        std::vector<int32_t> tl;
-        int64_t toff = (int64_t)res->trace.size(), tbase = toff;
         for (int32_t it = 0; it < ni; it++) {
             stats.hits += h_nhits[(size_t)it];
             stats.cands += h_ncand[(size_t)it];
-            for (int32_t x = 0; x < h_nla[(size_t)it]; x++) {
-                const int64_t slot = (int64_t)it * o.max_la + x;
-                dh_la la;
-                memcpy(&la, &h_la[(size_t)slot], sizeof(la));
-                la.toff = toff;
-                src.push_back(slot);
-                dst.push_back(toff - tbase);
-                tl.push_back(la.tlen);
-                toff += la.tlen;
-                res->la.push_back(la);
-            }
         }
-        DevBuf<int64_t> d_src, d_dst;
-        DevBuf<int32_t> d_tlen;
-        DevBuf<uint16_t> d_trout;
-        if (!src.empty()) {
-            HIPCHK(d_src.alloc(src.size()));
-            HIPCHK(d_dst.alloc(dst.size()));
-            HIPCHK(d_tlen.alloc(tl.size()));
-            HIPCHK(d_trout.alloc((size_t)(toff - tbase)));
-            HIPCHK(hipMemcpyAsync(d_src.p, src.data(), sizeof(int64_t) * src.size(), hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(d_dst.p, dst.data(), sizeof(int64_t) * dst.size(), hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(d_tlen.p, tl.data(), sizeof(int32_t) * tl.size(), hipMemcpyHostToDevice, st));
-            dhk_gather_trace(st, (int64_t)src.size(), d_trslots.p, trmax, d_src.p, d_dst.p, d_tlen.p,
-                             d_trout.p);
+        if (totals[0] > 0) {
+            SCR(13, d_laout, totals[0])
+            SCR(14, d_trout, totals[1])
+            const size_t l0 = res->la.size(), t0 = res->trace.size();
+            dhk_compact(st, d_la, d_trslots, trmax, o.max_la, ni, d_nla, d_ntr, (int64_t)t0, d_laout, d_trout);
             HIPCHK(hipGetLastError());
-            res->trace.resize((size_t)toff);
-            HIPCHK(hipMemcpyAsync(res->trace.data() + tbase, d_trout.p, sizeof(uint16_t) * (size_t)(toff - tbase),
+            res->la.resize(l0 + totals[0]);
+            res->trace.resize(t0 + totals[1]);
+            HIPCHK(hipMemcpyAsync(res->la.data() + l0, d_laout, sizeof(dh_la) * (size_t)totals[0],
                                   hipMemcpyDeviceToHost, st));
+            if (totals[1] > 0)
+                HIPCHK(hipMemcpyAsync(res->trace.data() + t0, d_trout, sizeof(uint16_t) * (size_t)totals[1],
+                                      hipMemcpyDeviceToHost, st));
         }
         HIPCHK(hipEventRecord(ctx->ev[5], st));
         HIPCHK(hipStreamSynchronize(st));
@@ -508,14 +534,15 @@ extern "C" int dh_align_db(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts 
         HIPCHK(hipEventElapsedTime(&t, ctx->ev[4], ctx->ev[5]));
         ms_gather += t;
     }
+#undef SCR
     unsigned long long counters[2] = {0, 0};
-    HIPCHK(hipMemcpy(counters, d_counters.p, sizeof(counters), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(counters, d_counters, sizeof(counters), hipMemcpyDeviceToHost));
     stats.wave_cells = (int64_t)counters[0];
     stats.alignments = (int64_t)counters[1];
 
     if (want_best) select_best(res->la);
     // LAsort order; traces are re-laid out in that order
-    {
+    if (want_sorted) {
         std::vector<int64_t> idx(res->la.size());
         std::iota(idx.begin(), idx.end(), 0);
         std::sort(idx.begin(), idx.end(),
@@ -541,6 +568,15 @@ extern "C" int dh_align_db(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts 
     stats.ms_gather = ms_gather;
     stats.ms_total = stats.ms_index + ms_seed + ms_wave + ms_gather;
     ctx->stats = stats;
+    if (getenv("DH_TRACE"))
+        fprintf(stderr,
+                "[dh_align_db] A=%d seqs/%lld bp B=%d seqs/%lld bp hits=%lld cands=%lld aln=%lld las=%lld cells=%lld | "
+                "index %.2f seed %.2f wave %.2f gather %.2f ms, wall %.2f ms\n",
+                A->n, (long long)A->total, B->n, (long long)B->total, (long long)stats.hits, (long long)stats.cands,
+                (long long)stats.alignments, (long long)stats.las, (long long)stats.wave_cells, stats.ms_index,
+                stats.ms_seed, stats.ms_wave, stats.ms_gather,
+                ((double)std::chrono::duration_cast<std::chrono::microseconds>(
+                     std::chrono::steady_clock::now().time_since_epoch()).count() - wall0) / 1e3);
     guard.ok = true;
     *out = res;
     return DH_OK;

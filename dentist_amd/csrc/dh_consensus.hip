@@ -44,10 +44,11 @@ k_gather_slices(const uint8_t *__restrict__ src, const int64_t *__restrict__ src
 __global__ void __launch_bounds__(64)
 k_tile_qv(const DhLa *__restrict__ las, const uint16_t *__restrict__ trace,
           const int32_t *__restrict__ la_first, const int64_t *__restrict__ roff, int32_t nreads,
-          int32_t tspace, int32_t cov, int32_t maxtiles, uint8_t *__restrict__ qv)
+          int32_t tspace, const int32_t *__restrict__ cov_of, int32_t maxtiles, uint8_t *__restrict__ qv)
 {
     const int32_t r = blockIdx.x;
     if (r >= nreads) return;
+    const int32_t cov = cov_of[r];
     const int32_t rlen = (int32_t)(roff[r + 1] - roff[r]);
     const int32_t nt = (rlen + tspace - 1) / tspace;
     for (int32_t t = threadIdx.x; t < nt && t < maxtiles; t += blockDim.x) {
@@ -116,18 +117,30 @@ k_seg_vote(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R,
     const int64_t NDP = nseg;
     const int32_t W = wmax + 1;
 #define FM(i, j) fmat[((int64_t)(i) * W + (j)) * NDP + dp]
-    // ---- fill (unit mismatch, indel 1, no free shift)
-    for (int32_t j = 0; j <= ql; j++) FM(0, j) = (uint8_t)j;
+    // ---- fill (unit mismatch, indel 1, no free shift).  The rolling row lives in LDS
+    // ([column][lane], one byte per cell: conflict-free), so the only global traffic of the
+    // inner loop is the fire-and-forget store of the matrix cell the traceback will read.
+    __shared__ uint8_t rowbuf[(SEG_MAX + 1) * 64];
+    __shared__ uint8_t qrybuf[SEG_MAX * 64];
+    uint8_t *row = rowbuf + threadIdx.x;
+    uint8_t *qs = qrybuf + threadIdx.x;
+    for (int32_t j = 0; j < ql; j++) qs[j * 64] = qry[j];
+    for (int32_t j = 0; j <= ql; j++) {
+        row[j * 64] = (uint8_t)j;
+        FM(0, j) = (uint8_t)j;
+    }
     for (int32_t i = 1; i <= rl; i++) {
         const uint8_t rc = ref[i - 1];
-        uint8_t left = (uint8_t)i;      // F[i][0]
+        uint8_t left = (uint8_t)i;        // F[i][0]
         uint8_t diag = (uint8_t)(i - 1);  // F[i-1][0]
+        row[0] = left;
         FM(i, 0) = left;
         for (int32_t j = 1; j <= ql; j++) {
-            const uint8_t up = FM(i - 1, j);
-            const uint8_t m = (uint8_t)(diag + (rc == qry[j - 1] ? 0 : 1));
+            const uint8_t up = row[j * 64];
+            const uint8_t m = (uint8_t)(diag + (rc == qs[(j - 1) * 64] ? 0 : 1));
             uint8_t v = m < (uint8_t)(up + 1) ? m : (uint8_t)(up + 1);
             v = v < (uint8_t)(left + 1) ? v : (uint8_t)(left + 1);
+            row[j * 64] = v;
             FM(i, j) = v;
             diag = up;
             left = v;
@@ -237,73 +250,77 @@ k_seg_vote(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R,
 
 // ------------------------------------------------------------------------------------ K8b
 
-// one thread per template: sequential run-by-run emission (identical order of decisions as the
-// specification; templates are a few kb, the work is tiny next to K8a)
-__global__ void __launch_bounds__(64)
-k_emit(DbView T, int32_t ntmpl, const int64_t *__restrict__ voff, const uint32_t *__restrict__ votes,
-       const int64_t *__restrict__ out_off, uint8_t *__restrict__ out, int32_t *__restrict__ out_len)
+// Emission in two kernels.  k_emit_runs: one thread per column; the first column of every
+// homopolymer run of the template decides the whole run (run-length vote) and stages the
+// symbols of each of its columns (at most ESTR per column).  k_emit_pack: one block per template
+// scans the per-column counts and packs the staged symbols.
+#define ESTR (1 + 2 * MAXINS)
+
+__global__ void __launch_bounds__(256)
+k_emit_runs(DbView T, int32_t ntmpl, const int64_t *__restrict__ voff, const uint32_t *__restrict__ votes,
+            const int32_t *__restrict__ col_tmpl, int64_t ncols_total, uint8_t *__restrict__ stage,
+            uint8_t *__restrict__ cnt)
 {
-    const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= ntmpl) return;
+    const int64_t gc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // column in vote space
+    if (gc >= ncols_total) return;
+    const int32_t t = col_tmpl[gc];
+    if (t < 0) return;  // the spare column after each template
+    const int32_t rs = (int32_t)(gc - voff[t]);
     const uint8_t *ref = T.bases + T.off[t];
     const int32_t rlen = (int32_t)(T.off[t + 1] - T.off[t]);
+    if (rs > 0 && ref[rs - 1] == ref[rs]) return;  // not the first column of its run
     const uint32_t *v = votes + voff[t] * VSTRIDE;
-    uint8_t *o = out + out_off[t];
-    int32_t n = 0;
-    for (int32_t rs = 0; rs < rlen;) {
-        int32_t re = rs + 1;
-        while (re < rlen && ref[re] == ref[rs]) re++;
-        const uint8_t c = ref[rs];
-        const int64_t den = (int64_t)v[(int64_t)rs * VSTRIDE + 5] + 1;
-        int64_t net = 0;
-        int32_t ncols = 0;
-        for (int32_t x = rs; x < re; x++) {
-            const uint32_t *col = v + (int64_t)x * VSTRIDE;
-            net += col[4];
-            if (c < 4)
-                for (int k = 0; k < MAXINS; k++) net -= col[6 + 4 * k + c];
-        }
-        if (c < 4 && re < rlen)
-            for (int k = 0; k < MAXINS; k++) net -= v[(int64_t)re * VSTRIDE + 6 + 4 * k + c];
-        const int64_t adj = net >= 0 ? (2 * net + den) / (2 * den) : -((2 * (-net) + den) / (2 * den));
-        for (int32_t x = rs; x < re; x++) {
-            const uint32_t *col = v + (int64_t)x * VSTRIDE;
-            int best = c < 4 ? c : 0;
-            uint32_t bv[4];
-            for (int k = 0; k < 4; k++) bv[k] = col[k] + ((c == k) ? 1u : 0u);
-            for (int k = 0; k < 4; k++)
-                if (bv[k] > bv[best]) best = k;
-            if (best == c) ncols++;
-        }
-        int64_t target = (int64_t)ncols - adj;
-        if (target < 0) target = 0;
-        if (target > ncols + MAXINS) target = ncols + MAXINS;
-        int64_t extra = target > ncols ? target - ncols : 0, keep = target < ncols ? target : ncols;
-        for (int32_t x = rs; x < re; x++) {
-            const uint32_t *col = v + (int64_t)x * VSTRIDE;
-            const uint32_t cover = col[5];
-            const uint8_t pc = (x == rs && rs > 0) ? ref[rs - 1] : 255;
-            for (int k = 0; k < MAXINS; k++) {
-                const uint32_t *iv = col + 6 + 4 * k;
-                uint32_t tot = 0;
-                int best = -1;
-                for (int b = 0; b < 4; b++) {
-                    if (b == c || b == pc) continue;
-                    tot += iv[b];
-                    if (best < 0 || iv[b] > iv[best]) best = b;
-                }
-                if (best < 0 || 2 * tot <= cover + 1) break;
-                o[n++] = (uint8_t)best;
+    int32_t re = rs + 1;
+    while (re < rlen && ref[re] == ref[rs]) re++;
+    const uint8_t c = ref[rs];
+    const int64_t den = (int64_t)v[(int64_t)rs * VSTRIDE + 5] + 1;
+    int64_t net = 0;
+    int32_t ncols = 0;
+    for (int32_t x = rs; x < re; x++) {
+        const uint32_t *col = v + (int64_t)x * VSTRIDE;
+        net += col[4];
+        if (c < 4)
+            for (int k = 0; k < MAXINS; k++) net -= col[6 + 4 * k + c];
+        int best = c < 4 ? c : 0;
+        uint32_t bv[4];
+        for (int k = 0; k < 4; k++) bv[k] = col[k] + ((c == k) ? 1u : 0u);
+        for (int k = 0; k < 4; k++)
+            if (bv[k] > bv[best]) best = k;
+        if (best == c) ncols++;
+    }
+    if (c < 4 && re < rlen)
+        for (int k = 0; k < MAXINS; k++) net -= v[(int64_t)re * VSTRIDE + 6 + 4 * k + c];
+    const int64_t adj = net >= 0 ? (2 * net + den) / (2 * den) : -((2 * (-net) + den) / (2 * den));
+    int64_t target = (int64_t)ncols - adj;
+    if (target < 0) target = 0;
+    if (target > ncols + MAXINS) target = ncols + MAXINS;
+    int64_t extra = target > ncols ? target - ncols : 0, keep = target < ncols ? target : ncols;
+    for (int32_t x = rs; x < re; x++) {
+        const uint32_t *col = v + (int64_t)x * VSTRIDE;
+        uint8_t *o = stage + (voff[t] + x) * ESTR;
+        int32_t n = 0;
+        const uint32_t cover = col[5];
+        const uint8_t pc = (x == rs && rs > 0) ? ref[rs - 1] : 255;
+        for (int k = 0; k < MAXINS; k++) {
+            const uint32_t *iv = col + 6 + 4 * k;
+            uint32_t tot = 0;
+            int best = -1;
+            for (int b = 0; b < 4; b++) {
+                if (b == c || b == pc) continue;
+                tot += iv[b];
+                if (best < 0 || iv[b] > iv[best]) best = b;
             }
-            int best = c < 4 ? c : 0;
-            uint32_t bv[4];
-            for (int k = 0; k < 4; k++) bv[k] = col[k] + ((c == k) ? 1u : 0u);
-            for (int k = 0; k < 4; k++)
-                if (bv[k] > bv[best]) best = k;
-            if (best != c) {
-                if (2 * col[4] <= cover + 1) o[n++] = (uint8_t)best;
-                continue;
-            }
+            if (best < 0 || 2 * tot <= cover + 1) break;
+            o[n++] = (uint8_t)best;
+        }
+        int best = c < 4 ? c : 0;
+        uint32_t bv[4];
+        for (int k = 0; k < 4; k++) bv[k] = col[k] + ((c == k) ? 1u : 0u);
+        for (int k = 0; k < 4; k++)
+            if (bv[k] > bv[best]) best = k;
+        if (best != c) {
+            if (2 * col[4] <= cover + 1) o[n++] = (uint8_t)best;
+        } else {
             if (x == rs)
                 for (int64_t e = 0; e < extra; e++) o[n++] = c;
             if (keep > 0) {
@@ -311,9 +328,43 @@ k_emit(DbView T, int32_t ntmpl, const int64_t *__restrict__ voff, const uint32_t
                 keep--;
             }
         }
-        rs = re;
+        cnt[voff[t] + x] = (uint8_t)n;
     }
-    out_len[t] = n;
+}
+
+__global__ void __launch_bounds__(256)
+k_emit_pack(DbView T, int32_t ntmpl, const int64_t *__restrict__ voff, const uint8_t *__restrict__ stage,
+            const uint8_t *__restrict__ cnt, const int64_t *__restrict__ out_off,
+            uint8_t *__restrict__ out, int32_t *__restrict__ out_len)
+{
+    __shared__ int32_t part[256];
+    __shared__ int32_t carry;
+    const int32_t t = blockIdx.x;
+    if (t >= ntmpl) return;
+    const int32_t rlen = (int32_t)(T.off[t + 1] - T.off[t]);
+    const uint8_t *cn = cnt + voff[t];
+    const uint8_t *st = stage + voff[t] * ESTR;
+    uint8_t *o = out + out_off[t];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int32_t base = 0; base < rlen; base += 256) {
+        const int32_t x = base + threadIdx.x;
+        const int32_t my = x < rlen ? cn[x] : 0;
+        part[threadIdx.x] = my;
+        __syncthreads();
+        for (int s = 1; s < 256; s <<= 1) {
+            const int32_t add = (int)threadIdx.x >= s ? part[threadIdx.x - s] : 0;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        const int32_t off = carry + part[threadIdx.x] - my;
+        for (int32_t e = 0; e < my; e++) o[off + e] = st[(int64_t)x * ESTR + e];
+        __syncthreads();
+        if (threadIdx.x == 255) carry += part[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out_len[t] = carry;
 }
 
 // ------------------------------------------------------------------------------------ launchers
@@ -335,7 +386,7 @@ void dhk_gather_slices(hipStream_t st, const uint8_t *src, const int64_t *src_of
 }
 
 void dhk_tile_qv(hipStream_t st, const DhLa *las, const uint16_t *trace, const int32_t *la_first,
-                 const int64_t *roff, int32_t nreads, int32_t tspace, int32_t cov, int32_t maxtiles,
+                 const int64_t *roff, int32_t nreads, int32_t tspace, const int32_t *cov, int32_t maxtiles,
                  uint8_t *qv)
 {
     if (nreads <= 0) return;
@@ -353,11 +404,14 @@ void dhk_seg_vote(hipStream_t st, const void *segs, int32_t nseg, DbView T, DbVi
 }
 
 void dhk_emit(hipStream_t st, DbView T, int32_t ntmpl, const int64_t *voff, const uint32_t *votes,
+              const int32_t *col_tmpl, int64_t ncols_total, uint8_t *stage, uint8_t *cnt,
               const int64_t *out_off, uint8_t *out, int32_t *out_len)
 {
     if (ntmpl <= 0) return;
-    hipLaunchKernelGGL(k_emit, dim3((ntmpl + 63) / 64), dim3(64), 0, st, T, ntmpl, voff, votes, out_off,
-                       out, out_len);
+    hipLaunchKernelGGL(k_emit_runs, dim3((unsigned)((ncols_total + 255) / 256)), dim3(256), 0, st, T, ntmpl,
+                       voff, votes, col_tmpl, ncols_total, stage, cnt);
+    hipLaunchKernelGGL(k_emit_pack, dim3(ntmpl), dim3(256), 0, st, T, ntmpl, voff, stage, cnt, out_off, out,
+                       out_len);
 }
 
 }  // extern "C"

@@ -13,7 +13,7 @@
 
 struct DhOpts {  // == dh_align_opts
     int32_t k, hmin, band_shift, tspace, min_len, pen, xdrop, max_err_ppm, max_cand, max_la, tcap,
-        strands, skip_self, dmax, width, reserved;
+        strands, skip_self, dmax, width, kmer_mod;
 };
 
 struct DbView {
@@ -60,7 +60,7 @@ extern "C" {
 void dhk_revcomp(hipStream_t st, const uint8_t *src, uint8_t *dst, const int64_t *off, int32_t n,
                  int32_t max_len);
 void dhk_kmer_pass(hipStream_t st, int fill, DbView A, const int2 *tiles, int32_t ntiles, int32_t k,
-                   int32_t shift, uint32_t *dir, uint64_t *ekey, uint64_t *eval,
+                   int32_t kmer_mod, int32_t shift, uint32_t *dir, uint64_t *ekey, uint64_t *eval,
                    const int64_t *goff);
 void dhk_scan(hipStream_t st, uint32_t *v, int64_t n, uint32_t *sums);
 void dhk_bucket_sort(hipStream_t st, const uint32_t *dir_end, int64_t nb, uint64_t *ekey,
@@ -71,10 +71,10 @@ void dhk_seed(hipStream_t st, int cap, DbView B, const uint8_t *brc, IndexView i
 void dhk_wave(hipStream_t st, int32_t nslots, DbView A, DbView B, const uint8_t *brc, DhOpts o,
               int32_t item0, int32_t nitems, const DhCand *cand, const int32_t *ncand,
               WaveScratch ws, DhLa *out_la, uint16_t *out_trace, int32_t trmax, int32_t *out_nla,
-              unsigned long long *counters, int32_t *status);
-void dhk_gather_trace(hipStream_t st, int64_t n, const uint16_t *slots, int32_t trmax,
-                      const int64_t *src_slot, const int64_t *dst_off, const int32_t *tlen,
-                      uint16_t *dst);
+              int32_t *out_ntr, unsigned long long *counters, int32_t *status);
+void dhk_compact(hipStream_t st, const DhLa *la_slots, const uint16_t *tr_slots, int32_t trmax,
+                 int32_t max_la, int32_t nitems, const uint32_t *la_off, const uint32_t *tr_off,
+                 int64_t tr_base, DhLa *la_out, uint16_t *tr_out);
 #ifdef __cplusplus
 }
 #endif

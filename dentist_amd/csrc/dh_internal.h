@@ -12,7 +12,11 @@
 
 #include "dh_device.h"
 
+#define DB_PAD 64
+
 int dh_fail(int code, const std::string &msg);
+// allocate total + 2 * DB_PAD bytes filled with code 4; *base = alloc + DB_PAD
+int dh_alloc_bases(hipStream_t st, int64_t total, uint8_t **alloc, uint8_t **base);
 
 #define HIPCHK(expr)                                                                             \
     do {                                                                                         \
@@ -28,7 +32,15 @@ struct dh_ctx {
     int ncu = 0;
     hipEvent_t ev[6] = {};
     dh_align_stats stats = {};
+    // grow-only device scratch buffers reused across calls (hipMalloc/hipFree of GB-sized
+    // buffers per call costs milliseconds and synchronises the device)
+    struct Arena {
+        void *p = nullptr;
+        size_t cap = 0;
+    } arena[24];
 };
+// slot `id` of the context's scratch arena, at least `bytes` large
+int dh_scratch(dh_ctx *ctx, int id, size_t bytes, void **out);
 
 struct dh_index {
     uint32_t *d_dir = nullptr;
@@ -36,7 +48,7 @@ struct dh_index {
     uint64_t *d_eval = nullptr;
     int64_t *d_goff = nullptr;
     int64_t n = 0;
-    int32_t k = 0, sepv = 0, shift = 0, pbits = 0, na = 0;
+    int32_t k = 0, sepv = 0, shift = 0, pbits = 0, na = 0, kmer_mod = 1;
     void release()
     {
         (void)hipFree(d_dir);
@@ -53,7 +65,9 @@ struct dh_db {
     dh_ctx *ctx = nullptr;
     int32_t n = 0, max_len = 0, ngroups = 1;
     int64_t total = 0;
-    uint8_t *d_bases = nullptr, *d_rc = nullptr;
+    // bases/rc point DB_PAD bytes into their allocations: kernels read 8 bases at a time on both
+    // sides of a position, the padding (code 4) keeps those loads inside the buffer
+    uint8_t *d_bases = nullptr, *d_rc = nullptr, *d_bases_alloc = nullptr, *d_rc_alloc = nullptr;
     int64_t *d_off = nullptr;
     int32_t *d_group = nullptr;
     std::vector<int64_t> h_off;
@@ -80,9 +94,12 @@ struct DevBuf {
 int dh_db_from_slices(dh_ctx *ctx, const dh_db *src, const std::vector<int32_t> &sidx,
                       const std::vector<int32_t> &sbeg, const std::vector<int32_t> &slen,
                       const std::vector<int32_t> &group, dh_db **out);
-// adopt device bases (ownership moves to the DB); offsets live on the host
-int dh_db_adopt(dh_ctx *ctx, uint8_t *d_bases, const std::vector<int64_t> &off,
+// adopt device bases allocated with dh_alloc_bases (ownership moves to the DB)
+int dh_db_adopt(dh_ctx *ctx, uint8_t *d_alloc, uint8_t *d_bases, const std::vector<int64_t> &off,
                 const std::vector<int32_t> &group, dh_db **out);
 int dh_ensure_rc(dh_db *db);
+// dh_align_db with the final LAsort made optional (internal callers regroup on their own)
+int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, int32_t want_best,
+                   int32_t want_sorted, dh_la_set **out);
 
 #endif

@@ -19,6 +19,19 @@
 
 #define LANES 64
 
+// modimer sampling (daligner -%): the same k-mers are kept on the A and on the B side
+__device__ __forceinline__ bool kmer_sampled(uint64_t km, int32_t mod)
+{
+    return mod <= 1 || (uint32_t)((km * 0x9E3779B97F4A7C15ull) >> 32) % (uint32_t)mod == 0;
+}
+
+__device__ __forceinline__ uint64_t load8(const uint8_t *p)
+{
+    uint64_t x;
+    __builtin_memcpy(&x, p, 8);  // unaligned global_load_dwordx2 (DB buffers are padded)
+    return x;
+}
+
 // ------------------------------------------------------------------------------------ K1
 
 __global__ void k_revcomp(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
@@ -40,7 +53,8 @@ __global__ void k_revcomp(const uint8_t *__restrict__ src, uint8_t *__restrict__
 // tiles: (sequence, start) pairs, KM_TILE positions each; 256 threads x 16 positions.
 template <bool FILL>
 __global__ void __launch_bounds__(256)
-k_kmer_pass(DbView A, const int2 *__restrict__ tiles, int32_t ntiles, int32_t k, int32_t shift,
+k_kmer_pass(DbView A, const int2 *__restrict__ tiles, int32_t ntiles, int32_t k, int32_t kmer_mod,
+            int32_t shift,
             uint32_t *__restrict__ dir, uint64_t *__restrict__ ekey, uint64_t *__restrict__ eval,
             const int64_t *__restrict__ goff)
 {
@@ -66,7 +80,7 @@ k_kmer_pass(DbView A, const int2 *__restrict__ tiles, int32_t ntiles, int32_t k,
             km = 0;
             valid = 0;
         }
-        if (x >= k - 1 && valid >= k) {
+        if (x >= k - 1 && valid >= k && kmer_sampled(km, kmer_mod)) {
             const uint64_t key = (grp << (2 * k)) | km;
             const uint32_t b = (uint32_t)(key >> shift);
             if (FILL) {
@@ -78,9 +92,9 @@ k_kmer_pass(DbView A, const int2 *__restrict__ tiles, int32_t ntiles, int32_t k,
         }
     }
 }
-template __global__ void k_kmer_pass<false>(DbView, const int2 *, int32_t, int32_t, int32_t,
+template __global__ void k_kmer_pass<false>(DbView, const int2 *, int32_t, int32_t, int32_t, int32_t,
                                             uint32_t *, uint64_t *, uint64_t *, const int64_t *);
-template __global__ void k_kmer_pass<true>(DbView, const int2 *, int32_t, int32_t, int32_t,
+template __global__ void k_kmer_pass<true>(DbView, const int2 *, int32_t, int32_t, int32_t, int32_t,
                                            uint32_t *, uint64_t *, uint64_t *, const int64_t *);
 
 // exclusive scan of n uint32 in place: block sums, scan of sums, add-back
@@ -240,35 +254,60 @@ k_seed(DbView B, const uint8_t *__restrict__ brc, IndexView ix, DhOpts o, int32_
         const int32_t q0 = tid * per, q1 = min(npos, q0 + per);
         uint64_t km = 0;
         int32_t valid = 0;
-        for (int32_t p = q0; p < q1 + k - 1 && q0 < q1; p++) {
-            const uint8_t c = b[p];
-            if (c < 4) {
-                km = ((km << 2) | c) & mask;
-                valid++;
-            } else {
-                km = 0;
-                valid = 0;
+        const int32_t pend = q0 < q1 ? q1 + k - 1 : q0;
+        // 8 bases per iteration: one 8-byte load of the read, 8 k-mers rolled in registers, the
+        // 8 directory lookups issued back to back (memory-level parallelism), then the rare
+        // non-empty buckets are resolved
+        for (int32_t p = q0; p < pend; p += 8) {
+            const uint64_t w = load8(b + p);
+            uint64_t keys[8];
+            uint32_t bks[8];
+            bool em[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int32_t pp = p + u;
+                const uint8_t c = (uint8_t)(w >> (8 * u));
+                if (pp < pend) {
+                    if (c < 4) {
+                        km = ((km << 2) | c) & mask;
+                        valid++;
+                    } else {
+                        km = 0;
+                        valid = 0;
+                    }
+                }
+                em[u] = pp < pend && pp - q0 >= k - 1 && valid >= k && kmer_sampled(km, o.kmer_mod);
+                keys[u] = (grp << (2 * k)) | km;
+                bks[u] = em[u] ? (uint32_t)(keys[u] >> ix.shift) : 0u;
             }
-            if (p - q0 < k - 1 || valid < k) continue;
-            const int32_t q = p - k + 1;
-            const uint64_t key = (grp << (2 * k)) | km;
-            const uint32_t bk = (uint32_t)(key >> ix.shift);
-            uint32_t s = bk ? ix.dir[bk - 1] : 0u;
-            const uint32_t e = ix.dir[bk];
-            // bucket is sorted by key: find the run of equal keys
-            while (s < e && ix.ekey[s] < key) s++;
-            uint32_t f = s;
-            while (f < e && ix.ekey[f] == key) f++;
-            const int32_t run = (int32_t)(f - s);
-            if (run == 0 || run > o.tcap) continue;
-            for (uint32_t t = s; t < f; t++) {
-                const uint64_t v = ix.eval[t];
-                const int32_t aseq = (int32_t)(v >> 40);
-                if (o.skip_self && aseq == r) continue;
-                const int64_t gv = (int64_t)(v & ((1ull << 40) - 1));
-                const int64_t D = gv + ix.sepv - q;
-                const int32_t slot = atomicAdd(&s_n, 1);
-                if (slot < CAP) hits[slot] = ((uint64_t)D << HIT_QBITS) | (uint32_t)q;
+            uint32_t ss[8], ee[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                ss[u] = bks[u] ? ix.dir[bks[u] - 1] : 0u;
+                ee[u] = ix.dir[bks[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (!em[u] || ss[u] >= ee[u]) continue;
+                const uint64_t key = keys[u];
+                const int32_t q = p + u - k + 1;
+                uint32_t s = ss[u];
+                const uint32_t e = ee[u];
+                // bucket is sorted by key: find the run of equal keys
+                while (s < e && ix.ekey[s] < key) s++;
+                uint32_t f = s;
+                while (f < e && ix.ekey[f] == key) f++;
+                const int32_t run = (int32_t)(f - s);
+                if (run == 0 || run > o.tcap) continue;
+                for (uint32_t t = s; t < f; t++) {
+                    const uint64_t v = ix.eval[t];
+                    const int32_t aseq = (int32_t)(v >> 40);
+                    if (o.skip_self && aseq == r) continue;
+                    const int64_t gv = (int64_t)(v & ((1ull << 40) - 1));
+                    const int64_t D = gv + ix.sepv - q;
+                    const int32_t slot = atomicAdd(&s_n, 1);
+                    if (slot < CAP) hits[slot] = ((uint64_t)D << HIT_QBITS) | (uint32_t)q;
+                }
             }
         }
     }
@@ -391,14 +430,49 @@ __device__ __forceinline__ int32_t nbound(int32_t x, int32_t tp_first, int32_t t
     return x >= tp_first ? (x - tp_first) / ts + 1 : 0;
 }
 
-__device__ __forceinline__ int64_t wave_max_i64(int64_t v)
+// ---- wave64 primitives (verified on gfx950 by scripts/dpp_probe.cpp)
+// value of lane-1 / lane+1 (rotation over the whole wave): one DPP mov each, no LDS crossbar
+__device__ __forceinline__ int32_t from_lower_lane(int32_t v)
 {
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) {
-        const int64_t other = __shfl_xor(v, s, LANES);
-        v = other > v ? other : v;
+    return __builtin_amdgcn_update_dpp(0, v, 0x13C, 0xF, 0xF, false);  // wave_ror:1
+}
+__device__ __forceinline__ int32_t from_upper_lane(int32_t v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, 0x134, 0xF, 0xF, false);  // wave_rol:1
+}
+// max over the 64 lanes, result uniform: 4 DPP steps inside each row of 16, then 4 readlanes
+__device__ __forceinline__ int32_t wave_max_i32(int32_t v)
+{
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));  // row_half_mirror
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));  // row_mirror
+    const int32_t r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+    const int32_t r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    return max(max(r0, r1), max(r2, r3));
+}
+// extend a run of matches: element i of A' is ap[i * step], 8 bases per compare.
+// DB buffers carry 64 bytes of padding on both sides, so the wide loads stay inside them.
+template <int STEP>
+__device__ __forceinline__ void slide(const uint8_t *__restrict__ ap, int32_t an,
+                                      const uint8_t *__restrict__ bp, int32_t bn, int32_t &i, int32_t &j)
+{
+    for (;;) {
+        const int32_t rem = min(an - i, bn - j);
+        if (rem <= 0) break;
+        int32_t m;
+        if (STEP > 0) {
+            const uint64_t x = load8(ap + i) ^ load8(bp + j);
+            m = x ? ((__ffsll((long long)x) - 1) >> 3) : 8;
+        } else {
+            const uint64_t x = load8(ap - i - 7) ^ load8(bp - j - 7);
+            m = x ? (__clzll((long long)x) >> 3) : 8;
+        }
+        m = min(m, rem);
+        i += m;
+        j += m;
+        if (m < 8) break;
     }
-    return v;
 }
 
 struct ExtResult {
@@ -407,38 +481,44 @@ struct ExtResult {
 
 // One-directional greedy extension by one wavefront; lane (k & 63) owns diagonal k.
 // All lanes execute every shuffle; per-lane state: R (furthest i, -1 = dead) and H (trace head).
-__device__ ExtResult ext_wave(const uint8_t *__restrict__ ap, int astep, int32_t an,
-                              const uint8_t *__restrict__ bp, int bstep, int32_t bn,
+template <int STEP>
+__device__ ExtResult ext_wave(const uint8_t *__restrict__ ap, int32_t an,
+                              const uint8_t *__restrict__ bp, int32_t bn,
                               int32_t tp_first, const DhOpts &o, DhNode *__restrict__ pool,
                               int32_t poolcap, int32_t &pool_n, unsigned long long &cells,
                               int32_t &err)
 {
     const int lane = threadIdx.x & (LANES - 1);
     const int32_t ts = o.tspace, pen = o.pen, xdrop = o.xdrop;
-    int32_t R = -1, H = -1;
+    // per-lane state of diagonal k: R = furthest i (-1 dead), H = head of its trace chain,
+    // NB = number of trace boundaries <= R (carried along so that no division is needed)
+    int32_t R = -1, H = -1, NB = 0;
     int32_t L = 0, U = 0;
 
     // d = 0: the seed diagonal, slid by lane 0
-    int32_t i0 = 0, h0 = -1;
+    int32_t i0 = 0, h0 = -1, nb0 = 0;
     if (lane == 0) {
-        while (i0 < an && i0 < bn && ap[(int64_t)i0 * astep] == bp[(int64_t)i0 * bstep]) i0++;
-        const int32_t nb0 = nbound(i0, tp_first, ts);
-        for (int32_t m = 0; m < nb0; m++) {
-            const int32_t idx = pool_n + m;
+        int32_t j0 = 0;
+        slide<STEP>(ap, an, bp, bn, i0, j0);
+        for (int32_t nextb = tp_first; nextb <= i0; nextb += ts) {
+            const int32_t idx = pool_n + nb0;
             if (idx < poolcap) {
                 pool[idx].parent = h0;
                 pool[idx].d = 0;
-                pool[idx].j = tp_first + m * ts;
+                pool[idx].j = nextb;
             }
             h0 = idx;
+            nb0++;
         }
         R = i0;
         H = h0;
+        NB = nb0;
     }
     i0 = __shfl(i0, 0, LANES);
     h0 = __shfl(h0, 0, LANES);
-    pool_n += nbound(i0, tp_first, ts);
-    int32_t best_score = 2 * i0, best_i = i0, best_k = 0, best_d = 0, best_head = h0;
+    nb0 = __shfl(nb0, 0, LANES);
+    pool_n += nb0;
+    int32_t best_score = 2 * i0, best_i = i0, best_k = 0, best_d = 0, best_head = h0, best_nb = nb0;
     unsigned long long ncell = 1;
 
     for (int32_t d = 1; d <= o.dmax; d++) {
@@ -446,64 +526,56 @@ __device__ ExtResult ext_wave(const uint8_t *__restrict__ ap, int astep, int32_t
         const int32_t kidx = (lane - nL) & (LANES - 1);
         const int32_t k = nL + kidx;
         const bool inwin = k <= nU;
-        const int32_t Rm = __shfl(R, (lane + LANES - 1) & (LANES - 1), LANES);
-        const int32_t Hm = __shfl(H, (lane + LANES - 1) & (LANES - 1), LANES);
-        const int32_t Rp = __shfl(R, (lane + 1) & (LANES - 1), LANES);
-        const int32_t Hp = __shfl(H, (lane + 1) & (LANES - 1), LANES);
-        int32_t ni = -1, prev_i = 0, hd = -1;
+        const int32_t Rm = from_lower_lane(R), Hm = from_lower_lane(H), Nm = from_lower_lane(NB);
+        const int32_t Rp = from_upper_lane(R), Hp = from_upper_lane(H), Np = from_upper_lane(NB);
+        // substitution on k, deletion from k-1 (consumes A), insertion from k+1 (consumes B);
+        // a candidate i is valid iff 0 <= i - k <= bn and i <= an; ties prefer sub, then del
+        int32_t ni = -1, hd = -1, nbp = 0;
         if (inwin) {
-            if (R >= 0) {  // substitution on k
-                const int32_t c = R + 1;
-                if (c <= an && c - k <= bn && c - k >= 0) {
-                    ni = c;
-                    prev_i = R;
-                    hd = H;
-                }
+            const int32_t lim = min(an, bn + k);  // i <= an and i - k <= bn
+            const int32_t cs = R + 1, cd = Rm + 1, ci = Rp;
+            if (R >= 0 && cs <= lim && cs >= k) {
+                ni = cs;
+                hd = H;
+                nbp = NB;
             }
-            if (Rm >= 0) {  // deletion from k-1 (consumes A)
-                const int32_t c = Rm + 1;
-                if (c <= an && c - k <= bn && c - k >= 0 && c > ni) {
-                    ni = c;
-                    prev_i = Rm;
-                    hd = Hm;
-                }
+            if (Rm >= 0 && cd <= lim && cd >= k && cd > ni) {
+                ni = cd;
+                hd = Hm;
+                nbp = Nm;
             }
-            if (Rp >= 0) {  // insertion from k+1 (consumes B)
-                const int32_t c = Rp;
-                if (c <= an && c - k <= bn && c - k >= 0 && c > ni) {
-                    ni = c;
-                    prev_i = Rp;
-                    hd = Hp;
-                }
+            if (Rp >= 0 && ci <= lim && ci >= k && ci > ni) {
+                ni = ci;
+                hd = Hp;
+                nbp = Np;
             }
         }
         bool alive = ni >= 0;
         if (alive) {
             int32_t j = ni - k;
-            while (ni < an && j < bn && ap[(int64_t)ni * astep] == bp[(int64_t)j * bstep]) {
-                ni++;
-                j++;
-            }
+            slide<STEP>(ap, an, bp, bn, ni, j);
         }
         const unsigned long long amask = __ballot(alive);
         if (amask == 0ull) break;
         ncell += __popcll(amask);
-        // trace nodes for the boundaries crossed in (prev_i, ni]
-        int32_t bidx = alive ? nbound(prev_i, tp_first, ts) : 0;
-        int32_t cnt = alive ? nbound(ni, tp_first, ts) - bidx : 0;
+        // trace nodes for the boundaries crossed in (prev_i, ni]: boundary number nbp is the
+        // first one above prev_i
+        int32_t nextb = tp_first + nbp * ts;
+        bool cross = alive && ni >= nextb;
         for (;;) {
-            const unsigned long long m = __ballot(cnt > 0);
+            const unsigned long long m = __ballot(cross);
             if (m == 0ull) break;
-            if (cnt > 0) {
+            if (cross) {
                 const int32_t idx = pool_n + __popcll(m & ((1ull << lane) - 1ull));
                 if (idx < poolcap) {
                     pool[idx].parent = hd;
                     pool[idx].d = d;
-                    pool[idx].j = tp_first + bidx * ts - k;
+                    pool[idx].j = nextb - k;
                 }
                 hd = idx;
-                bidx++;
-                cnt--;
+                nbp++;
+                nextb += ts;
+                cross = ni >= nextb;
             }
             pool_n += __popcll(m);
         }
@@ -513,18 +585,22 @@ __device__ ExtResult ext_wave(const uint8_t *__restrict__ ap, int astep, int32_t
         }
         R = alive ? ni : -1;
         H = hd;
-        // best of this step: highest score, then lowest diagonal
+        NB = nbp;
+        // best of this step: highest score, then lowest diagonal (ballot of the max holders,
+        // rotated so that bit x is diagonal nL + x)
         const int32_t sc = alive ? 2 * ni - k - pen * d : INT32_MIN;
-        const int64_t key = alive ? ((((int64_t)sc + (1ll << 31)) << 8) | (int64_t)(127 - kidx)) : -1;
-        const int64_t kmax = wave_max_i64(key);
-        const int32_t step_best = (int32_t)((kmax >> 8) - (1ll << 31));
-        const int32_t step_kidx = 127 - (int32_t)(kmax & 0xff);
+        const int32_t step_best = wave_max_i32(sc);
+        const int rot = nL & (LANES - 1);
         if (step_best > best_score) {
+            const unsigned long long hm = __ballot(alive && sc == step_best);
+            const unsigned long long hr = rot ? ((hm >> rot) | (hm << (LANES - rot))) : hm;
+            const int32_t step_kidx = __ffsll((long long)hr) - 1;
             const int src = (nL + step_kidx) & (LANES - 1);
             best_score = step_best;
             best_k = nL + step_kidx;
             best_i = __shfl(R, src, LANES);
             best_head = __shfl(H, src, LANES);
+            best_nb = __shfl(NB, src, LANES);
             best_d = d;
         }
         // trim to xdrop of the best
@@ -534,7 +610,6 @@ __device__ ExtResult ext_wave(const uint8_t *__restrict__ ap, int astep, int32_t
         }
         unsigned long long lm = __ballot(alive);
         if (lm == 0ull) break;
-        const int rot = nL & (LANES - 1);
         unsigned long long rm = rot ? ((lm >> rot) | (lm << (LANES - rot))) : lm;
         int32_t l2 = nL + (__ffsll((long long)rm) - 1);
         int32_t u2 = nL + (63 - __clzll((long long)rm));
@@ -562,7 +637,7 @@ __device__ ExtResult ext_wave(const uint8_t *__restrict__ ap, int astep, int32_t
     res.j = best_i - best_k;
     res.d = best_d;
     res.head = best_head;
-    res.nb = nbound(best_i, tp_first, ts);
+    res.nb = best_nb;
     return res;
 }
 
@@ -589,7 +664,8 @@ __global__ void __launch_bounds__(LANES)
 k_wave(DbView A, DbView B, const uint8_t *__restrict__ brc, DhOpts o, int32_t item0,
        int32_t nitems, const DhCand *__restrict__ cand, const int32_t *__restrict__ ncand,
        WaveScratch ws, DhLa *__restrict__ out_la, uint16_t *__restrict__ out_trace,
-       int32_t trmax, int32_t *__restrict__ out_nla, unsigned long long *__restrict__ counters,
+       int32_t trmax, int32_t *__restrict__ out_nla, int32_t *__restrict__ out_ntr,
+       unsigned long long *__restrict__ counters,
        int32_t *__restrict__ status)
 {
     const int lane = threadIdx.x;
@@ -613,7 +689,7 @@ k_wave(DbView A, DbView B, const uint8_t *__restrict__ brc, DhOpts o, int32_t it
         const uint8_t *b = (strand ? brc : B.bases) + bo;
         // regions already aligned for this (read, strand): kept in registers of lanes 0..nd-1
         int32_t g_aseq = -1, g_ab = 0, g_ae = 0, g_bb = 0, g_be = 0, g_lo = 0, g_hi = 0;
-        int32_t nd = 0, nacc = 0;
+        int32_t nd = 0, nacc = 0, ntr = 0;
         for (int32_t c = 0; c < nc && nacc < o.max_la && nd < LANES; c++) {
             const DhCand cd = cand[(int64_t)item * o.max_cand + c];
             const int32_t sd = cd.apos - cd.bpos;
@@ -627,10 +703,10 @@ k_wave(DbView A, DbView B, const uint8_t *__restrict__ brc, DhOpts o, int32_t it
             const int32_t fwd_first = ts - (as % ts);
             const int32_t rev_first = (as % ts) ? (as % ts) : ts;
             int32_t pool_n = 0;
-            const ExtResult fw = ext_wave(a + as, 1, alen - as, b + bs, 1, blen - bs, fwd_first, o,
-                                          pool, ws.poolcap, pool_n, cells, err);
-            const ExtResult rv = ext_wave(a + as - 1, -1, as, b + bs - 1, -1, bs, rev_first, o,
-                                          pool, ws.poolcap, pool_n, cells, err);
+            const ExtResult fw = ext_wave<1>(a + as, alen - as, b + bs, blen - bs, fwd_first, o, pool,
+                                             ws.poolcap, pool_n, cells, err);
+            const ExtResult rv = ext_wave<-1>(a + as - 1, as, b + bs - 1, bs, rev_first, o, pool,
+                                              ws.poolcap, pool_n, cells, err);
             naln++;
             if (err || fw.nb > ws.nbmax || rv.nb > ws.nbmax) {
                 err |= DH_ST_POOL_OVERFLOW;
@@ -716,8 +792,12 @@ k_wave(DbView A, DbView B, const uint8_t *__restrict__ brc, DhOpts o, int32_t it
                 out_la[slot] = la;
             }
             nacc++;
+            ntr += 2 * npairs;
         }
-        if (lane == 0) out_nla[item] = nacc;
+        if (lane == 0) {
+            out_nla[item] = nacc;
+            out_ntr[item] = ntr;
+        }
         if (err) break;
     }
     if (lane == 0) {
@@ -727,16 +807,31 @@ k_wave(DbView A, DbView B, const uint8_t *__restrict__ brc, DhOpts o, int32_t it
     }
 }
 
-// gather the accepted LAs' traces into one compact array: one block per LA
-__global__ void __launch_bounds__(64)
-k_gather_trace(const uint16_t *__restrict__ slots, int32_t trmax, const int64_t *__restrict__ src_slot,
-               const int64_t *__restrict__ dst_off, const int32_t *__restrict__ tlen,
-               uint16_t *__restrict__ dst)
+// compaction of the per-item output slots: la_off / tr_off are the exclusive scans of the
+// per-item LA counts and trace lengths; one wavefront per item copies its records and traces.
+__global__ void __launch_bounds__(LANES)
+k_compact(const DhLa *__restrict__ la_slots, const uint16_t *__restrict__ tr_slots, int32_t trmax,
+          int32_t max_la, int32_t item_base, int32_t nitems, const uint32_t *__restrict__ la_off,
+          const uint32_t *__restrict__ tr_off, int64_t tr_base, DhLa *__restrict__ la_out,
+          uint16_t *__restrict__ tr_out)
 {
-    const int64_t i = blockIdx.x;
-    const uint16_t *s = slots + src_slot[i] * trmax;
-    uint16_t *d = dst + dst_off[i];
-    for (int32_t x = threadIdx.x; x < tlen[i]; x += blockDim.x) d[x] = s[x];
+    const int32_t it = blockIdx.x;
+    if (it >= nitems) return;
+    const int lane = threadIdx.x;
+    const uint32_t l0 = la_off[it], n = la_off[it + 1] - l0;
+    uint32_t t = tr_off[it];
+    for (uint32_t x = 0; x < n; x++) {
+        const int64_t slot = (int64_t)it * max_la + x;
+        DhLa la = la_slots[slot];
+        const uint16_t *src = tr_slots + slot * trmax;
+        for (int32_t e = lane; e < la.tlen; e += LANES) tr_out[t + e] = src[e];
+        if (lane == 0) {
+            la.toff = tr_base + t;
+            la_out[l0 + x] = la;
+        }
+        t += la.tlen;
+    }
+    (void)item_base;
 }
 
 // ------------------------------------------------------------------------------------ launchers
@@ -759,16 +854,16 @@ void dhk_revcomp(hipStream_t st, const uint8_t *src, uint8_t *dst, const int64_t
 }
 
 void dhk_kmer_pass(hipStream_t st, int fill, DbView A, const int2 *tiles, int32_t ntiles, int32_t k,
-                   int32_t shift, uint32_t *dir, uint64_t *ekey, uint64_t *eval,
+                   int32_t kmer_mod, int32_t shift, uint32_t *dir, uint64_t *ekey, uint64_t *eval,
                    const int64_t *goff)
 {
     if (ntiles <= 0) return;
     if (fill)
         hipLaunchKernelGGL(k_kmer_pass<true>, dim3(ntiles), dim3(256), 0, st, A, tiles, ntiles, k,
-                           shift, dir, ekey, eval, goff);
+                           kmer_mod, shift, dir, ekey, eval, goff);
     else
         hipLaunchKernelGGL(k_kmer_pass<false>, dim3(ntiles), dim3(256), 0, st, A, tiles, ntiles, k,
-                           shift, dir, ekey, eval, goff);
+                           kmer_mod, shift, dir, ekey, eval, goff);
 }
 
 // exclusive scan in place; sums must hold ceil(n / 2048) uint32
@@ -803,20 +898,20 @@ void dhk_seed(hipStream_t st, int cap, DbView B, const uint8_t *brc, IndexView i
 void dhk_wave(hipStream_t st, int32_t nslots, DbView A, DbView B, const uint8_t *brc, DhOpts o,
               int32_t item0, int32_t nitems, const DhCand *cand, const int32_t *ncand,
               WaveScratch ws, DhLa *out_la, uint16_t *out_trace, int32_t trmax, int32_t *out_nla,
-              unsigned long long *counters, int32_t *status)
+              int32_t *out_ntr, unsigned long long *counters, int32_t *status)
 {
     if (nitems <= 0) return;
     hipLaunchKernelGGL(k_wave, dim3(nslots), dim3(LANES), 0, st, A, B, brc, o, item0, nitems, cand,
-                       ncand, ws, out_la, out_trace, trmax, out_nla, counters, status);
+                       ncand, ws, out_la, out_trace, trmax, out_nla, out_ntr, counters, status);
 }
 
-void dhk_gather_trace(hipStream_t st, int64_t n, const uint16_t *slots, int32_t trmax,
-                      const int64_t *src_slot, const int64_t *dst_off, const int32_t *tlen,
-                      uint16_t *dst)
+void dhk_compact(hipStream_t st, const DhLa *la_slots, const uint16_t *tr_slots, int32_t trmax,
+                 int32_t max_la, int32_t nitems, const uint32_t *la_off, const uint32_t *tr_off,
+                 int64_t tr_base, DhLa *la_out, uint16_t *tr_out)
 {
-    if (n <= 0) return;
-    hipLaunchKernelGGL(k_gather_trace, dim3((unsigned)n), dim3(64), 0, st, slots, trmax, src_slot,
-                       dst_off, tlen, dst);
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL(k_compact, dim3(nitems), dim3(LANES), 0, st, la_slots, tr_slots, trmax, max_la, 0,
+                       nitems, la_off, tr_off, tr_base, la_out, tr_out);
 }
 
 }  // extern "C"

@@ -20,12 +20,13 @@ void dhk_gather_slices(hipStream_t st, const uint8_t *src, const int64_t *src_of
                        const int32_t *sbeg, const int64_t *dst_off, int32_t n, int32_t max_len,
                        uint8_t *dst);
 void dhk_tile_qv(hipStream_t st, const DhLa *las, const uint16_t *trace, const int32_t *la_first,
-                 const int64_t *roff, int32_t nreads, int32_t tspace, int32_t cov, int32_t maxtiles,
+                 const int64_t *roff, int32_t nreads, int32_t tspace, const int32_t *cov, int32_t maxtiles,
                  uint8_t *qv);
 void dhk_seg_vote(hipStream_t st, const void *segs, int32_t nseg, DbView T, DbView R,
                   const uint8_t *rrc, const int64_t *voff, uint8_t *fmat, int32_t wmax, uint8_t *opbuf,
                   uint32_t *votes, int32_t *status);
 void dhk_emit(hipStream_t st, DbView T, int32_t ntmpl, const int64_t *voff, const uint32_t *votes,
+              const int32_t *col_tmpl, int64_t ncols_total, uint8_t *stage, uint8_t *cnt,
               const int64_t *out_off, uint8_t *out, int32_t *out_len);
 }
 
@@ -56,7 +57,7 @@ extern "C" void dh_default_process_opts(dh_process_opts *o)
 
 // ------------------------------------------------------------------------------------ DB helpers
 
-int dh_db_adopt(dh_ctx *ctx, uint8_t *d_bases, const std::vector<int64_t> &off,
+int dh_db_adopt(dh_ctx *ctx, uint8_t *d_alloc, uint8_t *d_bases, const std::vector<int64_t> &off,
                 const std::vector<int32_t> &group, dh_db **out)
 {
     dh_db *db = new dh_db();
@@ -65,6 +66,7 @@ int dh_db_adopt(dh_ctx *ctx, uint8_t *d_bases, const std::vector<int64_t> &off,
     db->h_off = off;
     db->total = off.back();
     db->d_bases = d_bases;
+    db->d_bases_alloc = d_alloc;
     for (int32_t i = 0; i < db->n; i++)
         db->max_len = std::max<int32_t>(db->max_len, (int32_t)(off[(size_t)i + 1] - off[(size_t)i]));
     HIPCHK(hipMalloc(&db->d_off, sizeof(int64_t) * off.size()));
@@ -93,12 +95,10 @@ int dh_db_from_slices(dh_ctx *ctx, const dh_db *src, const std::vector<int32_t> 
         off[(size_t)i + 1] = off[(size_t)i] + slen[(size_t)i];
         max_len = std::max(max_len, slen[(size_t)i]);
     }
-    uint8_t *d_bases = nullptr;
-    const size_t nb = (size_t)std::max<int64_t>(off.back(), 1) + 64;
-    HIPCHK(hipMalloc(&d_bases, nb));
-    HIPCHK(hipMemsetAsync(d_bases, 4, nb, ctx->stream));
-    if (int rc = dh_db_adopt(ctx, d_bases, off, group, out)) {
-        (void)hipFree(d_bases);
+    uint8_t *d_alloc = nullptr, *d_bases = nullptr;
+    if (int rc = dh_alloc_bases(ctx->stream, off.back(), &d_alloc, &d_bases)) return rc;
+    if (int rc = dh_db_adopt(ctx, d_alloc, d_bases, off, group, out)) {
+        (void)hipFree(d_alloc);
         return rc;
     }
     if (n > 0) {
@@ -283,12 +283,13 @@ static int consensus_round(dh_ctx *ctx, dh_db *T, dh_db *R, const std::vector<dh
     for (int32_t t = 0; t < nt; t++) {
         const int64_t len = T->h_off[(size_t)t + 1] - T->h_off[(size_t)t];
         voff[(size_t)t + 1] = voff[(size_t)t] + len + 1;
-        ooff[(size_t)t + 1] = ooff[(size_t)t] + len * (1 + MAXINS) + 8;
+        ooff[(size_t)t + 1] = ooff[(size_t)t] + len * (1 + 2 * MAXINS) + 8;
     }
     DevBuf<int64_t> d_voff, d_ooff;
     DevBuf<uint32_t> d_votes;
     DevBuf<uint8_t> d_out, d_fmat, d_opbuf;
-    DevBuf<int32_t> d_status, d_outlen;
+    DevBuf<int32_t> d_status, d_outlen, d_coltmpl;
+    DevBuf<uint8_t> d_stage, d_cnt;
     DevBuf<SegDescH> d_segs;
     HIPCHK(d_voff.alloc(voff.size()));
     HIPCHK(d_ooff.alloc(ooff.size()));
@@ -317,7 +318,20 @@ static int consensus_round(dh_ctx *ctx, dh_db *T, dh_db *R, const std::vector<dh
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(st));
     }
-    dhk_emit(st, T->view(), nt, d_voff.p, d_votes.p, d_ooff.p, d_out.p, d_outlen.p);
+    {
+        // column -> template map of the vote space (-1 for the spare column after each template)
+        std::vector<int32_t> col_tmpl((size_t)voff.back(), -1);
+        for (int32_t t = 0; t < nt; t++)
+            for (int64_t x = voff[(size_t)t]; x < voff[(size_t)t + 1] - 1; x++) col_tmpl[(size_t)x] = t;
+        HIPCHK(d_coltmpl.alloc(col_tmpl.size()));
+        HIPCHK(d_stage.alloc((size_t)voff.back() * (1 + 2 * MAXINS)));
+        HIPCHK(d_cnt.alloc((size_t)voff.back()));
+        HIPCHK(hipMemcpyAsync(d_coltmpl.p, col_tmpl.data(), sizeof(int32_t) * col_tmpl.size(), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemsetAsync(d_cnt.p, 0, (size_t)voff.back(), st));
+        dhk_emit(st, T->view(), nt, d_voff.p, d_votes.p, d_coltmpl.p, voff.back(), d_stage.p, d_cnt.p, d_ooff.p,
+                 d_out.p, d_outlen.p);
+        HIPCHK(hipStreamSynchronize(st));
+    }
     HIPCHK(hipGetLastError());
     std::vector<int32_t> outlen((size_t)nt);
     int32_t status = 0;
@@ -332,12 +346,10 @@ static int consensus_round(dh_ctx *ctx, dh_db *T, dh_db *R, const std::vector<dh
         noff[(size_t)t + 1] = noff[(size_t)t] + outlen[(size_t)t];
         max_len = std::max(max_len, outlen[(size_t)t]);
     }
-    uint8_t *d_bases = nullptr;
-    const size_t nb = (size_t)std::max<int64_t>(noff.back(), 1) + 64;
-    HIPCHK(hipMalloc(&d_bases, nb));
-    HIPCHK(hipMemsetAsync(d_bases, 4, nb, st));
-    if (int rc = dh_db_adopt(ctx, d_bases, noff, T->h_group, newT)) {
-        (void)hipFree(d_bases);
+    uint8_t *d_alloc = nullptr, *d_bases = nullptr;
+    if (int rc = dh_alloc_bases(st, noff.back(), &d_alloc, &d_bases)) return rc;
+    if (int rc = dh_db_adopt(ctx, d_alloc, d_bases, noff, T->h_group, newT)) {
+        (void)hipFree(d_alloc);
         return rc;
     }
     std::vector<int32_t> ident((size_t)nt), zero((size_t)nt, 0);
@@ -502,8 +514,16 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
         ao.max_cand = 128;
         dh_la_set *pset = nullptr;
         HIPCHK(hipEventRecord(ev[0], st));
-        if (int rc = dh_align_db(ctx, pile, pile, &ao, 0, &pset)) return rc;
+        if (int rc = dh_align_db_ex(ctx, pile, pile, &ao, 0, 0, &pset)) return rc;
         sg.sets.push_back(pset);
+        {   // group by aread (counting sort, stable); traces stay where they are
+            std::vector<int32_t> cnt((size_t)pile->n + 1, 0);
+            for (const dh_la &la : pset->la) cnt[(size_t)la.aread + 1]++;
+            for (int32_t r = 0; r < pile->n; r++) cnt[(size_t)r + 1] += cnt[(size_t)r];
+            std::vector<dh_la> tmp(pset->la.size());
+            for (const dh_la &la : pset->la) tmp[(size_t)cnt[(size_t)la.aread]++] = la;
+            pset->la.swap(tmp);
+        }
         HIPCHK(hipEventRecord(ev[1], st));
         if (int rc = elapsed(0, 1, ps.ms[1])) return rc;
         std::vector<dh_la> &pl = pset->la;
@@ -543,17 +563,15 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
             HIPCHK(hipMemcpyAsync(d_first.p, la_first.data(), sizeof(int32_t) * la_first.size(),
                                   hipMemcpyHostToDevice, st));
             HIPCHK(hipMemsetAsync(d_qv.p, 255, qv.size(), st));
-            // cov = max(#allowed reference reads, 4 if pile >= 4) == pile size here (package.d:498-503);
-            // piles differ in size, so one launch per distinct size would be needed for a per-pile
-            // cov: the kernel takes cov per launch, piles are launched grouped by size below.
-            std::map<int32_t, std::vector<int32_t>> by_size;
-            for (int32_t a = 0; a < na; a++) by_size[first_read[(size_t)a + 1] - first_read[(size_t)a]].push_back(a);
-            for (auto &kv : by_size)
-                for (int32_t a : kv.second) {
-                    const int32_t r0 = first_read[(size_t)a], cnt = kv.first;
-                    dhk_tile_qv(st, d_las.p, d_tr.p, d_first.p + r0, pile->d_off + r0, cnt, tsp, cnt, maxtiles,
-                                d_qv.p + (size_t)r0 * maxtiles);
-                }
+            // cov = max(#allowed reference reads, 4 if pile >= 4) == pile size here (package.d:498-503)
+            std::vector<int32_t> cov_of((size_t)npr, 1);
+            for (int32_t a = 0; a < na; a++)
+                for (int32_t r = first_read[(size_t)a]; r < first_read[(size_t)a + 1]; r++)
+                    cov_of[(size_t)r] = first_read[(size_t)a + 1] - first_read[(size_t)a];
+            DevBuf<int32_t> d_cov;
+            HIPCHK(d_cov.alloc(cov_of.size()));
+            HIPCHK(hipMemcpyAsync(d_cov.p, cov_of.data(), sizeof(int32_t) * cov_of.size(), hipMemcpyHostToDevice, st));
+            dhk_tile_qv(st, d_las.p, d_tr.p, d_first.p, pile->d_off, npr, tsp, d_cov.p, maxtiles, d_qv.p);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(qv.data(), d_qv.p, qv.size(), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
@@ -658,7 +676,7 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
             ro.max_cand = 32;
             dh_la_set *rset = nullptr;
             HIPCHK(hipEventRecord(ev[0], st));
-            if (int rc = dh_align_db(ctx, T, pile, &ro, 0, &rset)) return rc;
+            if (int rc = dh_align_db_ex(ctx, T, pile, &ro, 0, 0, &rset)) return rc;
             sg.sets.push_back(rset);
             HIPCHK(hipEventRecord(ev[1], st));
             if (int rc = elapsed(0, 1, ps.ms[4])) return rc;
@@ -711,7 +729,7 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
         fo.max_cand = 32;
         dh_la_set *fset = nullptr;
         HIPCHK(hipEventRecord(ev[0], st));
-        if (int rc = dh_align_db(ctx, F, T, &fo, 0, &fset)) return rc;
+        if (int rc = dh_align_db_ex(ctx, F, T, &fo, 0, 0, &fset)) return rc;
         sg.sets.push_back(fset);
         HIPCHK(hipEventRecord(ev[1], st));
         if (int rc = elapsed(0, 1, ps.ms[5])) return rc;

@@ -59,7 +59,7 @@ typedef struct {
     int32_t skip_self;   /* 1: A is B, skip aread == bread (absence of -I)                   */
     int32_t dmax;        /* cap on differences per extension                                 */
     int32_t width;       /* live diagonals of the wave, <= 62 (one 64-lane wavefront)        */
-    int32_t reserved;
+    int32_t kmer_mod;    /* -%  modimer sampling: only k-mers with hash % kmer_mod == 0; 1 = all     */
 } dh_align_opts;
 void dh_default_align_opts(dh_align_opts *o);
 

@@ -44,6 +44,7 @@ void oz_default_opts(oz_opts *o)
     o->skip_self = 0;
     o->dmax = 60000;
     o->width = 64;
+    o->kmer_mod = 1;
 }
 
 /* ------------------------------------------------------------------ LA set ---------- */
@@ -117,6 +118,13 @@ void oz_la_set_sort(oz_la_set *s)
 
 /* ------------------------------------------------------------------ k-mer index ------ */
 
+/* modimer sampling: the same k-mers are kept on the A and on the B side */
+static inline int kmer_sampled(uint64_t km, int32_t mod)
+{
+    return mod <= 1 || (uint32_t)((km * 0x9E3779B97F4A7C15ull) >> 32) % (uint32_t)mod == 0;
+}
+
+
 typedef struct {
     uint64_t key; /* group * 4^k + kmer */
     int32_t aseq;
@@ -181,7 +189,7 @@ static oz_index *index_build(const oz_db *A, const oz_opts *o, int32_t max_blen)
                 valid = 0;
                 km = 0;
             }
-            if (valid >= k) {
+            if (valid >= k && kmer_sampled(km, o->kmer_mod)) {
                 ix->e[n].key = (grp << (2 * k)) | km;
                 ix->e[n].aseq = s;
                 ix->e[n].apos = (int32_t)(p - k + 1);
@@ -290,7 +298,7 @@ int oz_seed_candidates(const oz_index *ix, const oz_db *A, const uint8_t *b, int
             valid = 0;
             km = 0;
         }
-        if (valid < k) continue;
+        if (valid < k || !kmer_sampled(km, o->kmer_mod)) continue;
         const int32_t q = p - k + 1;
         const uint64_t key = ((uint64_t)bgroup << (2 * k)) | km;
         int64_t s = ix_lower(ix, key), e = s;

@@ -61,7 +61,7 @@ typedef struct {
     int32_t skip_self;   /* 1: A and B are the same DB, skip aread == bread (no -I)        */
     int32_t dmax;        /* hard cap on differences per extension                          */
     int32_t width;       /* max live diagonals of the wave (64 = one wavefront)            */
-    int32_t reserved;
+    int32_t kmer_mod;    /* modimer sampling (daligner -%): only k-mers with hash % kmer_mod == 0, 1 = all */
 } oz_opts;
 
 void oz_default_opts(oz_opts *o);

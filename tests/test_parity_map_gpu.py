@@ -15,7 +15,7 @@ from oracle import pyoracle as oz
 pytestmark = pytest.mark.gpu
 
 OPT_FIELDS = ("k", "hmin", "band_shift", "tspace", "min_len", "pen", "xdrop", "max_err_ppm", "max_cand",
-              "max_la", "tcap", "strands", "skip_self", "dmax", "width")
+              "max_la", "tcap", "strands", "skip_self", "dmax", "width", "kmer_mod")
 
 
 def both_opts(**kw):
@@ -59,6 +59,14 @@ def test_lognormal_read_lengths_like_the_reference_fixture(gpu_ctx):
     reads, _ = sim.reads(1724161952, seq, 33, 25000, 12500, min_len=500)
     las, _ = run_both(gpu_ctx, contigs, reads, min_len=500)
     assert len(las) > 0
+
+
+@pytest.mark.parametrize("mod", [2, 4])
+def test_modimer_sampling(gpu_ctx, mod):
+    """daligner -%: index and query only k-mers whose hash is 0 modulo kmer_mod."""
+    w = sim.Workload(300_000, 3, 400, 6000, seed=29, spacing=15000)
+    las, _ = run_both(gpu_ctx, w.contigs, w.reads, kmer_mod=mod)
+    assert len(set(las["bread"].tolist())) == w.reads.n
 
 
 def pile(seed, glen=20000, n=30, rl=6000):
