@@ -145,13 +145,14 @@ def _take_la_set(h):
     L = lib()
     n, tn = L.dh_la_set_count(h), L.dh_la_set_trace_len(h)
     ts = L.dh_la_set_tspace(h)
-    if n:
-        las = np.frombuffer(ctypes.string_at(L.dh_la_set_records(h), n * LA_DTYPE.itemsize),
-                            dtype=LA_DTYPE).copy()
+    if n:  # one copy out of the library-owned buffers
+        buf = (ctypes.c_uint8 * (n * LA_DTYPE.itemsize)).from_address(L.dh_la_set_records(h))
+        las = np.frombuffer(buf, dtype=LA_DTYPE).copy()
     else:
         las = np.zeros(0, dtype=LA_DTYPE)
     if tn:
-        trace = np.frombuffer(ctypes.string_at(L.dh_la_set_trace(h), tn * 2), dtype=np.uint16).copy()
+        buf = (ctypes.c_uint16 * tn).from_address(L.dh_la_set_trace(h))
+        trace = np.frombuffer(buf, dtype=np.uint16).copy()
     else:
         trace = np.zeros(0, dtype=np.uint16)
     L.dh_la_set_destroy(h)

@@ -326,25 +326,23 @@ static bool la_less(const dh_la &p, const dh_la &q)
 // damapper-style chain flags per B read: every LA is a chain of its own (START); it is BEST
 // unless a higher-scoring LA of the same read and orientation covers more than half of it on B
 // (consumer: dazzler.d:1728-1758 reads START without BEST as alternateChain).
+// `la` must be grouped by bread (the kernels emit it that way).
 static void select_best(std::vector<dh_la> &la)
 {
-    std::vector<int64_t> idx(la.size());
-    std::iota(idx.begin(), idx.end(), 0);
-    std::stable_sort(idx.begin(), idx.end(),
-                     [&](int64_t x, int64_t y) { return la[(size_t)x].bread < la[(size_t)y].bread; });
     for (auto &l : la) l.flags |= DH_FLAG_START | DH_FLAG_BEST;
     size_t g0 = 0;
-    while (g0 < idx.size()) {
+    while (g0 < la.size()) {
         size_t g1 = g0;
-        while (g1 < idx.size() && la[(size_t)idx[g1]].bread == la[(size_t)idx[g0]].bread) g1++;
+        while (g1 < la.size() && la[g1].bread == la[g0].bread) g1++;
         for (size_t x = g0; x < g1; x++) {
-            dh_la &p = la[(size_t)idx[x]];
+            dh_la &p = la[x];
             const int64_t ps = (int64_t)(p.aepos - p.abpos) - 2 * (int64_t)p.diffs;
             for (size_t y = g0; y < g1; y++) {
                 if (x == y) continue;
-                const dh_la &q = la[(size_t)idx[y]];
+                const dh_la &q = la[y];
                 const int64_t qs = (int64_t)(q.aepos - q.abpos) - 2 * (int64_t)q.diffs;
-                if (qs < ps || (qs == ps && idx[y] > idx[x])) continue;
+                // ties: the LA that sorts later (LAsort order) wins
+                if (qs < ps || (qs == ps && la_less(q, p))) continue;
                 if ((q.flags & DH_FLAG_COMP) != (p.flags & DH_FLAG_COMP)) continue;
                 const int32_t lo = std::max(p.bbpos, q.bbpos), hi = std::min(p.bepos, q.bepos);
                 if (hi - lo > (p.bepos - p.bbpos) / 2) p.flags &= ~DH_FLAG_BEST;
@@ -352,6 +350,38 @@ static void select_best(std::vector<dh_la> &la)
         }
         g0 = g1;
     }
+}
+
+// LAsort order of a B-major (bread, strand, ...) list in O(n): stable counting sort by aread
+// keeps (bread, comp) ascending inside every aread; the rare runs with equal (aread, bread, comp)
+// are finished with an insertion sort.  Traces are re-laid out in the final order.
+static void lasort(dh_la_set *res, int32_t na)
+{
+    const size_t n = res->la.size();
+    std::vector<int64_t> first((size_t)na + 2, 0);
+    for (const dh_la &l : res->la) first[(size_t)l.aread + 1]++;
+    for (int32_t a = 0; a <= na; a++) first[(size_t)a + 1] += first[(size_t)a];
+    std::vector<dh_la> out(n);
+    for (const dh_la &l : res->la) out[(size_t)first[(size_t)l.aread]++] = l;
+    for (size_t i = 1; i < n; i++) {
+        if (!la_less(out[i], out[i - 1])) continue;
+        dh_la x = out[i];
+        size_t j = i;
+        while (j > 0 && la_less(x, out[j - 1])) {
+            out[j] = out[j - 1];
+            j--;
+        }
+        out[j] = x;
+    }
+    std::vector<uint16_t> tr(res->trace.size());
+    int64_t t = 0;
+    for (dh_la &l : out) {
+        memcpy(tr.data() + t, res->trace.data() + l.toff, sizeof(uint16_t) * (size_t)l.tlen);
+        l.toff = t;
+        t += l.tlen;
+    }
+    res->la.swap(out);
+    res->trace.swap(tr);
 }
 
 // ------------------------------------------------------------------------------------ align
@@ -451,7 +481,7 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
     // expected hits per (read, strand): random matches + true seeds; pick the LDS hit capacity
     const double dens = (double)A->ix.n / std::pow(4.0, o.k) / std::max(1, A->ngroups);
     const double exp_hits = B->max_len * (dens + 0.2);
-    int cap = exp_hits * 1.5 < 4096 ? 4096 : 16384;
+    int cap = exp_hits * 1.5 < 4096 ? 4096 : (exp_hits * 1.5 < 8192 ? 8192 : 16384);
 
     std::vector<int32_t> h_ncand((size_t)cn), h_nhits((size_t)cn);
     float ms_seed = 0, ms_wave = 0, ms_gather = 0;
@@ -477,7 +507,7 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
                 if (cap >= 16384)
                     return fail(DH_EOVERFLOW,
                                 "seed filter: more than 16384 k-mer hits for one (read, strand); lower -t");
-                cap = 16384;
+                cap *= 2;
                 HIPCHK(hipMemsetAsync(d_status, 0, sizeof(int32_t), st));
                 continue;
             }
@@ -541,24 +571,7 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
     stats.alignments = (int64_t)counters[1];
 
     if (want_best) select_best(res->la);
-    // LAsort order; traces are re-laid out in that order
-    if (want_sorted) {
-        std::vector<int64_t> idx(res->la.size());
-        std::iota(idx.begin(), idx.end(), 0);
-        std::sort(idx.begin(), idx.end(),
-                  [&](int64_t x, int64_t y) { return la_less(res->la[(size_t)x], res->la[(size_t)y]); });
-        std::vector<dh_la> la2(res->la.size());
-        std::vector<uint16_t> tr2(res->trace.size());
-        int64_t t = 0;
-        for (size_t i = 0; i < idx.size(); i++) {
-            la2[i] = res->la[(size_t)idx[i]];
-            memcpy(tr2.data() + t, res->trace.data() + la2[i].toff, sizeof(uint16_t) * (size_t)la2[i].tlen);
-            la2[i].toff = t;
-            t += la2[i].tlen;
-        }
-        res->la.swap(la2);
-        res->trace.swap(tr2);
-    }
+    if (want_sorted) lasort(res, A->n);
     stats.las = (int64_t)res->la.size();
     float t;
     HIPCHK(hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[1]));

@@ -420,6 +420,8 @@ k_seed(DbView B, const uint8_t *__restrict__ brc, IndexView ix, DhOpts o, int32_
 }
 template __global__ void k_seed<4096>(DbView, const uint8_t *, IndexView, DhOpts, int32_t, int32_t,
                                       DhCand *, int32_t *, int32_t *, int32_t *);
+template __global__ void k_seed<8192>(DbView, const uint8_t *, IndexView, DhOpts, int32_t, int32_t,
+                                      DhCand *, int32_t *, int32_t *, int32_t *);
 template __global__ void k_seed<16384>(DbView, const uint8_t *, IndexView, DhOpts, int32_t, int32_t,
                                        DhCand *, int32_t *, int32_t *, int32_t *);
 
@@ -514,10 +516,12 @@ __device__ ExtResult ext_wave(const uint8_t *__restrict__ ap, int32_t an,
         H = h0;
         NB = nb0;
     }
-    i0 = __shfl(i0, 0, LANES);
-    h0 = __shfl(h0, 0, LANES);
-    nb0 = __shfl(nb0, 0, LANES);
-    pool_n += nb0;
+    // wave-uniform values are pinned to SGPRs (readfirstlane) so that the window arithmetic,
+    // mask rotations and find-first-set below run on the scalar unit
+    i0 = __builtin_amdgcn_readfirstlane(i0);
+    h0 = __builtin_amdgcn_readfirstlane(h0);
+    nb0 = __builtin_amdgcn_readfirstlane(nb0);
+    pool_n = __builtin_amdgcn_readfirstlane(pool_n + nb0);
     int32_t best_score = 2 * i0, best_i = i0, best_k = 0, best_d = 0, best_head = h0, best_nb = nb0;
     unsigned long long ncell = 1;
 
@@ -577,7 +581,7 @@ __device__ ExtResult ext_wave(const uint8_t *__restrict__ ap, int32_t an,
                 nextb += ts;
                 cross = ni >= nextb;
             }
-            pool_n += __popcll(m);
+            pool_n = __builtin_amdgcn_readfirstlane(pool_n + __popcll(m));
         }
         if (pool_n > poolcap) {
             err |= DH_ST_POOL_OVERFLOW;
@@ -595,12 +599,12 @@ __device__ ExtResult ext_wave(const uint8_t *__restrict__ ap, int32_t an,
             const unsigned long long hm = __ballot(alive && sc == step_best);
             const unsigned long long hr = rot ? ((hm >> rot) | (hm << (LANES - rot))) : hm;
             const int32_t step_kidx = __ffsll((long long)hr) - 1;
-            const int src = (nL + step_kidx) & (LANES - 1);
+            const int src = __builtin_amdgcn_readfirstlane((nL + step_kidx) & (LANES - 1));
             best_score = step_best;
             best_k = nL + step_kidx;
-            best_i = __shfl(R, src, LANES);
-            best_head = __shfl(H, src, LANES);
-            best_nb = __shfl(NB, src, LANES);
+            best_i = __builtin_amdgcn_readlane(R, src);
+            best_head = __builtin_amdgcn_readlane(H, src);
+            best_nb = __builtin_amdgcn_readlane(NB, src);
             best_d = d;
         }
         // trim to xdrop of the best
@@ -611,13 +615,13 @@ __device__ ExtResult ext_wave(const uint8_t *__restrict__ ap, int32_t an,
         unsigned long long lm = __ballot(alive);
         if (lm == 0ull) break;
         unsigned long long rm = rot ? ((lm >> rot) | (lm << (LANES - rot))) : lm;
-        int32_t l2 = nL + (__ffsll((long long)rm) - 1);
-        int32_t u2 = nL + (63 - __clzll((long long)rm));
+        int32_t l2 = __builtin_amdgcn_readfirstlane(nL + (__ffsll((long long)rm) - 1));
+        int32_t u2 = __builtin_amdgcn_readfirstlane(nL + (63 - __clzll((long long)rm)));
         while (u2 - l2 + 1 > o.width) {
             // drop the lower-scoring edge (same d: compare 2R - k), ties drop the low edge
             const int32_t val = 2 * R - k;
-            const int32_t sl = __shfl(val, l2 & (LANES - 1), LANES);
-            const int32_t su = __shfl(val, u2 & (LANES - 1), LANES);
+            const int32_t sl = __builtin_amdgcn_readlane(val, l2 & (LANES - 1));
+            const int32_t su = __builtin_amdgcn_readlane(val, u2 & (LANES - 1));
             const int32_t kill = sl <= su ? l2 : u2;
             if (k == kill) {
                 alive = false;
@@ -625,8 +629,8 @@ __device__ ExtResult ext_wave(const uint8_t *__restrict__ ap, int32_t an,
             }
             lm = __ballot(alive);
             rm = rot ? ((lm >> rot) | (lm << (LANES - rot))) : lm;
-            l2 = nL + (__ffsll((long long)rm) - 1);
-            u2 = nL + (63 - __clzll((long long)rm));
+            l2 = __builtin_amdgcn_readfirstlane(nL + (__ffsll((long long)rm) - 1));
+            u2 = __builtin_amdgcn_readfirstlane(nL + (63 - __clzll((long long)rm)));
         }
         L = l2;
         U = u2;
@@ -889,6 +893,9 @@ void dhk_seed(hipStream_t st, int cap, DbView B, const uint8_t *brc, IndexView i
     if (nitems <= 0) return;
     if (cap <= 4096)
         hipLaunchKernelGGL(k_seed<4096>, dim3(nitems), dim3(SEED_THREADS), 0, st, B, brc, ix, o,
+                           item0, nitems, cand, ncand, nhits, status);
+    else if (cap <= 8192)
+        hipLaunchKernelGGL(k_seed<8192>, dim3(nitems), dim3(SEED_THREADS), 0, st, B, brc, ix, o,
                            item0, nitems, cand, ncand, nhits, status);
     else
         hipLaunchKernelGGL(k_seed<16384>, dim3(nitems), dim3(SEED_THREADS), 0, st, B, brc, ix, o,

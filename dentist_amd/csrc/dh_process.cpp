@@ -129,23 +129,34 @@ extern "C" int dh_collect_spanning(const dh_la *las, int64_t n, const int64_t *c
 {
     if ((n > 0 && !las) || !contig_off || !opts || !out) return dh_fail(DH_EINVAL, "dh_collect_spanning: NULL");
     const dh_process_opts &o = *opts;
-    std::map<int32_t, std::vector<int64_t>> by_read;
-    for (int64_t i = 0; i < n; i++) by_read[las[i].bread].push_back(i);
+    // group the LA indices by read (counting sort, keeps the LA order inside a read)
+    int32_t nreads = 0;
+    for (int64_t i = 0; i < n; i++) nreads = std::max(nreads, las[i].bread + 1);
+    std::vector<int64_t> first((size_t)nreads + 1, 0), order((size_t)n);
+    for (int64_t i = 0; i < n; i++) first[(size_t)las[i].bread + 1]++;
+    for (int32_t r = 0; r < nreads; r++) first[(size_t)r + 1] += first[(size_t)r];
+    {
+        std::vector<int64_t> cur(first.begin(), first.end() - 1);
+        for (int64_t i = 0; i < n; i++) order[(size_t)cur[(size_t)las[i].bread]++] = i;
+    }
     std::map<int32_t, std::vector<int32_t>> piles;
-    for (auto &kv : by_read) {
-        const std::vector<int64_t> &idx = kv.second;
-        for (int64_t iL : idx) {
+    for (int32_t rd = 0; rd < nreads; rd++) {
+        const int64_t *idx = order.data() + first[(size_t)rd], cnt = first[(size_t)rd + 1] - first[(size_t)rd];
+        if (cnt < 2) continue;
+        for (int64_t x = 0; x < cnt; x++) {
+            const int64_t iL = idx[x];
             const dh_la &L = las[iL];
             if (L.aread < 0 || L.aread + 1 >= ncontigs) continue;
             const int64_t cl = contig_off[L.aread + 1] - contig_off[L.aread];
             if (L.aepos + o.allowance < cl || L.aepos - L.abpos < o.min_anchor) continue;
-            for (int64_t iR : idx) {
+            for (int64_t y = 0; y < cnt; y++) {
+                const int64_t iR = idx[y];
                 const dh_la &R = las[iR];
                 if (R.aread != L.aread + 1 || (R.flags & DH_FLAG_COMP) != (L.flags & DH_FLAG_COMP)) continue;
                 if (R.abpos > o.allowance || R.aepos - R.abpos < o.min_anchor) continue;
                 if (R.bbpos + o.allowance < L.bepos - o.allowance) continue;
                 std::vector<int32_t> &v = piles[L.aread];
-                v.push_back(kv.first);
+                v.push_back(rd);
                 v.push_back((int32_t)iL);
                 v.push_back((int32_t)iR);
             }

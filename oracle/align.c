@@ -804,7 +804,8 @@ void oz_select_best(oz_la_set *s)
             const oz_la *q = &s->la[j];
             if (q->bread != p->bread) continue;
             const int64_t qscore = (int64_t)(q->aepos - q->abpos) - 2 * (int64_t)q->diffs;
-            if (qscore < pscore || (qscore == pscore && j > i)) continue;
+            /* ties: the LA that sorts later in LAsort order wins */
+            if (qscore < pscore || (qscore == pscore && la_cmp(q, p) < 0)) continue;
             /* compare on the forward strand of B: need read length -> not available here, so
              * only LAs of the same orientation compete (different orientation = other locus) */
             if ((q->flags & OZ_FLAG_COMP) != (p->flags & OZ_FLAG_COMP)) continue;
