@@ -6,7 +6,15 @@ CSRC := dentist_amd/csrc
 LIB := dentist_amd/libdentist_hip.so
 SIM := dentist_amd/sim/libdh_sim.so
 
-all: $(LIB) $(SIM) oracle
+TOOLS := tools/daligner tools/damapper
+
+all: $(LIB) $(SIM) oracle $(TOOLS)
+
+tools/daligner: tools/aligner_main.cpp include/dentist_hip.h $(LIB)
+	$(HIPCC) -O2 -std=c++17 -o $@ $< -Ldentist_amd -ldentist_hip -Wl,-rpath,'$$ORIGIN/../dentist_amd'
+
+tools/damapper: tools/daligner
+	cp $< $@
 
 $(LIB): $(CSRC)/dh_kernels.hip $(CSRC)/dh_api.cpp $(CSRC)/dh_device.h include/dentist_hip.h $(wildcard $(CSRC)/*.hip $(CSRC)/*.cpp $(CSRC)/*.h)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(wildcard $(CSRC)/*.hip) $(wildcard $(CSRC)/*.cpp)
@@ -18,6 +26,6 @@ oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(LIB) $(SIM); $(MAKE) -C oracle clean
+	rm -f $(LIB) $(SIM) $(TOOLS); $(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

@@ -59,7 +59,9 @@ SYMBOLS = [
     "dh_las_write", "dh_las_read", "dh_default_process_opts", "dh_collect_spanning", "dh_pileups_destroy",
     "dh_pileups_count", "dh_pileups_get", "dh_process_pileups", "dh_insertions_destroy",
     "dh_insertions_count", "dh_insertions_records", "dh_insertions_bases", "dh_insertions_bases_len",
-    "dh_get_process_stats",
+    "dh_get_process_stats", "dh_dazz_create_dam", "dh_dazz_create_db", "dh_dazz_split", "dh_dazz_open",
+    "dh_dazz_close", "dh_dazz_nreads", "dh_dazz_first_id", "dh_dazz_bases", "dh_dazz_offsets",
+    "dh_dazz_origin", "dh_dazz_fpulse", "dh_dazz_header",
 ]
 
 _LIB = None
@@ -122,6 +124,20 @@ def lib():
     L.dh_insertions_bases_len.argtypes = [vp]
     L.dh_insertions_bases_len.restype = i64
     L.dh_get_process_stats.argtypes = [vp, vp, vp]
+    L.dh_dazz_create_dam.argtypes = [ctypes.c_char_p, ctypes.c_char_p, i64]
+    L.dh_dazz_create_db.argtypes = [ctypes.c_char_p, ctypes.c_char_p, i64]
+    L.dh_dazz_split.argtypes = [ctypes.c_char_p, i32, i32, i64]
+    L.dh_dazz_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
+    L.dh_dazz_close.argtypes = [vp]
+    L.dh_dazz_nreads.argtypes = [vp]
+    L.dh_dazz_nreads.restype = i32
+    L.dh_dazz_first_id.argtypes = [vp]
+    L.dh_dazz_first_id.restype = i32
+    for fn in (L.dh_dazz_bases, L.dh_dazz_offsets, L.dh_dazz_origin, L.dh_dazz_fpulse):
+        fn.argtypes = [vp]
+        fn.restype = vp
+    L.dh_dazz_header.argtypes = [vp, i32]
+    L.dh_dazz_header.restype = ctypes.c_char_p
     _LIB = L
     return L
 
@@ -314,3 +330,47 @@ def process_stats(ctx):
     d = {f"ms_{n}": float(ms[i]) for i, n in enumerate(names)}
     d.update(pile_las=int(cnt[0]), tiles=int(cnt[1]), nw_cells=int(cnt[2]))
     return d
+
+
+# ---------------------------------------------------------------- DAZZ_DB files (host only)
+def dazz_create_dam(path, fasta_text):
+    b = fasta_text.encode() if isinstance(fasta_text, str) else fasta_text
+    _check(lib().dh_dazz_create_dam(path.encode(), b, len(b)))
+
+
+def dazz_create_db(path, fasta_text):
+    b = fasta_text.encode() if isinstance(fasta_text, str) else fasta_text
+    _check(lib().dh_dazz_create_db(path.encode(), b, len(b)))
+
+
+def dazz_split(path, cutoff=0, all_reads=True, size_mb=200):
+    _check(lib().dh_dazz_split(path.encode(), cutoff, int(all_reads), size_mb))
+
+
+class DazzDb:
+    """Trimmed view of a DAZZ_DB (or of one block, e.g. ``reads.3``) read from disk."""
+
+    def __init__(self, path):
+        L = lib()
+        h = ctypes.c_void_p()
+        _check(L.dh_dazz_open(path.encode(), ctypes.byref(h)))
+        n = L.dh_dazz_nreads(h)
+        self.first_id = L.dh_dazz_first_id(h)
+        self.off = np.frombuffer((ctypes.c_int64 * (n + 1)).from_address(L.dh_dazz_offsets(h)), dtype=np.int64).copy()
+        tot = int(self.off[-1])
+        self.bases = (np.frombuffer((ctypes.c_uint8 * tot).from_address(L.dh_dazz_bases(h)), dtype=np.uint8).copy()
+                      if tot else np.zeros(0, np.uint8))
+        self.origin = (np.frombuffer((ctypes.c_int32 * n).from_address(L.dh_dazz_origin(h)), dtype=np.int32).copy()
+                       if n else np.zeros(0, np.int32))
+        self.fpulse = (np.frombuffer((ctypes.c_int32 * n).from_address(L.dh_dazz_fpulse(h)), dtype=np.int32).copy()
+                       if n else np.zeros(0, np.int32))
+        self.headers = [L.dh_dazz_header(h, i).decode() for i in range(n)]
+        self.group = None
+        L.dh_dazz_close(h)
+
+    @property
+    def n(self):
+        return len(self.off) - 1
+
+    def seq(self, i):
+        return self.bases[self.off[i]:self.off[i + 1]]

@@ -206,6 +206,26 @@ int64_t dh_insertions_bases_len(const dh_insertions *r);
  * counters: [0] pile LAs [1] tiles aligned (NW) [2] NW cells */
 int dh_get_process_stats(dh_ctx *ctx, float *ms7, int64_t *counters3);
 
+
+/* ---- DAZZ_DB files on disk (.db / .dam stub + hidden .idx / .bps / .hdr), host only.
+ *      Replaces what DENTIST obtains by spawning fasta2DB / fasta2DAM / DBsplit
+ *      (source/dentist/dazzler.d:6233-6330) and what the aligners open themselves.  The .idx, .bps
+ *      and .hdr images are byte-identical to DAZZ_DB's (pinned by tests/test-commands.sh:54-61). */
+typedef struct dh_dazz dh_dazz;
+int dh_dazz_create_dam(const char *path, const char *fasta_text, int64_t n); /* fasta2DAM -i */
+int dh_dazz_create_db(const char *path, const char *fasta_text, int64_t n);  /* fasta2DB -i  */
+int dh_dazz_split(const char *path, int32_t cutoff, int32_t all, int64_t size_mb); /* DBsplit -x -a -s */
+/* path may name a block ("reads.3"); the trimmed view is returned (ids are trimmed ids) */
+int dh_dazz_open(const char *path, dh_dazz **out);
+void dh_dazz_close(dh_dazz *db);
+int32_t dh_dazz_nreads(const dh_dazz *db);
+int32_t dh_dazz_first_id(const dh_dazz *db);         /* trimmed id of the first read of the block */
+const uint8_t *dh_dazz_bases(const dh_dazz *db);      /* base codes 0..3, concatenated              */
+const int64_t *dh_dazz_offsets(const dh_dazz *db);    /* nreads + 1                                 */
+const int32_t *dh_dazz_origin(const dh_dazz *db);     /* well (DB) / contig number in scaffold (DAM)*/
+const int32_t *dh_dazz_fpulse(const dh_dazz *db);     /* first pulse (DB) / contig start (DAM)      */
+const char *dh_dazz_header(const dh_dazz *db, int32_t i); /* DAM: scaffold header of contig i        */
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,142 @@
+// aligner_main.cpp -- drop-in `daligner` / `damapper` executables over libdentist_hip.so.
+//
+// DENTIST spawns these tools by name with cwd = output directory and absolute (or stub) DB
+// arguments and then expects `<A>.<B>.las` next to it (source/dentist/dazzler.d:6121-6170,
+// getLasFile :4339-4354; literal instance tests/test-commands.sh:190-197).  The flag subset DENTIST
+// emits is parsed (source/dentist/commandline.d:2886-2955); unknown -m tracks
+// are accepted and reported (masks are not applied yet).  The mode is chosen
+// by argv[0] (daligner | damapper) or `--mode`.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../include/dentist_hip.h"
+
+static void die(const std::string &msg, int rc = 1)
+{
+    fprintf(stderr, "%s\n", msg.c_str());
+    exit(rc);
+}
+#define CHK(call)                                                                                 \
+    do {                                                                                          \
+        if (int rc_ = (call)) die(std::string(#call) + ": " + dh_last_error(), rc_ < 0 ? -rc_ : rc_); \
+    } while (0)
+
+struct OpenDb {
+    dh_dazz *dz = nullptr;
+    dh_db *dev = nullptr;
+    std::string name;  // root[.block] as used in .las file names
+};
+
+static std::string las_name_part(const std::string &arg)
+{
+    std::string s = arg;
+    const size_t slash = s.find_last_of('/');
+    if (slash != std::string::npos) s = s.substr(slash + 1);
+    for (const char *e : {".dam", ".db"}) {
+        const size_t n = strlen(e);
+        if (s.size() > n && s.compare(s.size() - n, n, e) == 0) s.resize(s.size() - n);
+    }
+    return s;
+}
+
+static OpenDb open_db(dh_ctx *ctx, const std::string &arg)
+{
+    OpenDb o;
+    o.name = las_name_part(arg);
+    CHK(dh_dazz_open(arg.c_str(), &o.dz));
+    CHK(dh_db_create(ctx, dh_dazz_bases(o.dz), dh_dazz_offsets(o.dz), dh_dazz_nreads(o.dz), nullptr, &o.dev));
+    return o;
+}
+
+// write one .las: ids are trimmed DB ids (block first id + local index)
+static void write_las(const std::string &path, dh_la_set *set, int afirst, int bfirst, int tspace)
+{
+    const int64_t n = dh_la_set_count(set);
+    std::vector<dh_la> las(dh_la_set_records(set), dh_la_set_records(set) + n);
+    for (dh_la &l : las) {
+        l.aread += afirst;
+        l.bread += bfirst;
+    }
+    CHK(dh_las_write(path.c_str(), las.data(), n, dh_la_set_trace(set), tspace));
+}
+
+int main(int argc, char **argv)
+{
+    std::string mode = argv[0];
+    const size_t slash = mode.find_last_of('/');
+    if (slash != std::string::npos) mode = mode.substr(slash + 1);
+    dh_align_opts o;
+    dh_default_align_opts(&o);
+    bool flagA = false, flagI = false, flagC = false, verbose = false;
+    double e = 0.7;
+    std::vector<std::string> dbs;
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        if (a == "--mode" && i + 1 < argc) {
+            mode = argv[++i];
+            continue;
+        }
+        if (a.size() < 2 || a[0] != '-') {
+            dbs.push_back(a);
+            continue;
+        }
+        const char *v = a.c_str() + 2;
+        switch (a[1]) {
+        case 'k': o.k = atoi(v); break;
+        case 'w': o.band_shift = atoi(v); break;
+        case 'h': o.hmin = atoi(v); break;
+        case 't': o.tcap = atoi(v); break;
+        case 's': o.tspace = atoi(v); break;
+        case 'l': o.min_len = atoi(v); break;
+        case 'e': e = atof(v); break;
+        case '%': o.kmer_mod = atoi(v); break;
+        case 'A': flagA = true; break;
+        case 'I': flagI = true; break;
+        case 'C': flagC = true; break;
+        case 'v': verbose = true; break;
+        case 'm': fprintf(stderr, "%s: mask track `%s` accepted, not applied\n", mode.c_str(), v); break;
+        case 'B': case 'b': case 'p': case 'T': case 'P': case 'M': case 'n': case 'z': case 'H': break;
+        default: die(mode + ": unknown option " + a);
+        }
+    }
+    if (dbs.size() < 2) die("usage: " + mode + " [-k -w -h -t -s -l -e -A -I -C -T -m...] <subject:db|dam> <target:db|dam> ...");
+    if (e <= 0.5 || e >= 1.0) die(mode + ": -e must be in (0.5, 1)");
+    o.pen = (int)floor(2.0 / (1.0 - e));
+    o.max_err_ppm = (int)llround((1.0 - e) * 1e6);
+    const bool mapper = mode.find("damapper") != std::string::npos;
+    if (mapper && o.min_len == 500 && o.tspace == 100) o.min_len = 500;
+
+    dh_ctx *ctx = nullptr;
+    CHK(dh_ctx_create(0, nullptr, &ctx));
+    OpenDb A = open_db(ctx, dbs[0]);
+    for (size_t bi = 1; bi < dbs.size(); bi++) {
+        const bool same = las_name_part(dbs[bi]) == A.name;
+        OpenDb B = same ? A : open_db(ctx, dbs[bi]);
+        dh_align_opts oo = o;
+        oo.skip_self = (same && !flagI) ? 1 : 0;
+        dh_la_set *ab = nullptr;
+        CHK(dh_align_db(ctx, A.dev, B.dev, &oo, mapper ? 1 : 0, &ab));
+        write_las(A.name + "." + B.name + ".las", ab, dh_dazz_first_id(A.dz), dh_dazz_first_id(B.dz), o.tspace);
+        if (verbose) fprintf(stderr, "%s: %lld local alignments -> %s.%s.las\n", mode.c_str(), (long long)dh_la_set_count(ab), A.name.c_str(), B.name.c_str());
+        dh_la_set_destroy(ab);
+        // the symmetric file: daligner writes B.A.las unless -A (or A == B), damapper only with -C
+        if (!same && ((!mapper && !flagA) || (mapper && flagC))) {
+            dh_la_set *ba = nullptr;
+            CHK(dh_align_db(ctx, B.dev, A.dev, &oo, mapper ? 1 : 0, &ba));
+            write_las(B.name + "." + A.name + ".las", ba, dh_dazz_first_id(B.dz), dh_dazz_first_id(A.dz), o.tspace);
+            dh_la_set_destroy(ba);
+        }
+        if (!same) {
+            dh_db_destroy(B.dev);
+            dh_dazz_close(B.dz);
+        }
+    }
+    dh_db_destroy(A.dev);
+    dh_dazz_close(A.dz);
+    dh_ctx_destroy(ctx);
+    return 0;
+}
