@@ -495,23 +495,47 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
         int32_t *ncandbase = d_ncand - item0, *nhitsbase = d_nhits - item0;
         int32_t *nlabase = (int32_t *)d_nla - item0, *ntrbase = (int32_t *)d_ntr - item0;
         HIPCHK(hipEventRecord(ctx->ev[2], st));
-        for (;;) {
-            dhk_seed(st, cap, bv, B->d_rc, iv, dopt, (int32_t)item0, ni, candbase, ncandbase, nhitsbase, d_status);
-            HIPCHK(hipGetLastError());
+        dhk_seed(st, cap, bv, B->d_rc, iv, dopt, (int32_t)item0, ni, candbase, ncandbase, nhitsbase, d_status);
+        HIPCHK(hipGetLastError());
+        {
+            // items whose hits did not fit the LDS buffer (ncand == -1) are redone with their hits
+            // staged in HBM: same kernel code, capacity = the item's own hit count
             int32_t status = 0;
             HIPCHK(hipMemcpyAsync(&status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(h_ncand.data(), d_ncand, sizeof(int32_t) * (size_t)ni, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(h_nhits.data(), d_nhits, sizeof(int32_t) * (size_t)ni, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             if (status & DH_ST_CAND_OVERFLOW)
                 return fail(DH_EOVERFLOW, "seed filter: more than 256 candidate band pairs for one read");
-            if (status & DH_ST_HIT_OVERFLOW) {
-                if (cap >= 16384)
-                    return fail(DH_EOVERFLOW,
-                                "seed filter: more than 16384 k-mer hits for one (read, strand); lower -t");
-                cap *= 2;
-                HIPCHK(hipMemsetAsync(d_status, 0, sizeof(int32_t), st));
-                continue;
+            std::vector<int32_t> big;
+            int32_t gcap = 0;
+            for (int32_t it = 0; it < ni; it++)
+                if (h_ncand[(size_t)it] < 0) {
+                    big.push_back((int32_t)item0 + it);
+                    gcap = std::max(gcap, h_nhits[(size_t)it]);
+                }
+            if (!big.empty()) {
+                if (gcap > (1 << 22)) return fail(DH_EOVERFLOW, "seed filter: more than 4M k-mer hits for one sequence; lower -t");
+                int32_t pow2 = 1;
+                while (pow2 < gcap) pow2 <<= 1;  // the bitonic sort pads to a power of two
+                const size_t per_launch = std::max<size_t>(1, (size_t)(2ull << 30) / ((size_t)pow2 * 8));
+                int32_t *d_list;
+                uint64_t *d_gbuf;
+                SCR(15, d_list, big.size())
+                SCR(16, d_gbuf, std::min(per_launch, big.size()) * (size_t)pow2)
+                HIPCHK(hipMemcpyAsync(d_list, big.data(), sizeof(int32_t) * big.size(), hipMemcpyHostToDevice, st));
+                for (size_t b0 = 0; b0 < big.size(); b0 += per_launch) {
+                    const int32_t cnt = (int32_t)std::min(per_launch, big.size() - b0);
+                    dhk_seed_big(st, bv, B->d_rc, iv, dopt, d_list + b0, cnt, d_gbuf, pow2, candbase, ncandbase,
+                                 nhitsbase, d_status);
+                    HIPCHK(hipGetLastError());
+                }
+                HIPCHK(hipMemcpyAsync(&status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                if (status & (DH_ST_HIT_OVERFLOW | DH_ST_CAND_OVERFLOW))
+                    return fail(DH_EOVERFLOW, "seed filter: capacity exceeded in the HBM-staged pass");
+                stats.big_items += (int64_t)big.size();
             }
-            break;
         }
         HIPCHK(hipEventRecord(ctx->ev[3], st));
         HIPCHK(hipMemsetAsync(d_queue, 0, sizeof(uint32_t), st));

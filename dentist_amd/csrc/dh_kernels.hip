@@ -213,19 +213,25 @@ __device__ __forceinline__ int32_t hit_cov(const uint64_t *h, int32_t i, int32_t
     return k;
 }
 
-template <int CAP>
+// LCAP > 0: hits are staged in LDS (LCAP entries); items that do not fit are marked with
+// ncand = -1 and redone by the LCAP == 0 instantiation, whose hit buffer is a slab of HBM
+// (gcap entries per block, items taken from item_list) -- same code, same results.
+template <int LCAP>
 __global__ void __launch_bounds__(SEED_THREADS)
 k_seed(DbView B, const uint8_t *__restrict__ brc, IndexView ix, DhOpts o, int32_t item0,
        int32_t nitems, DhCand *__restrict__ cand_out, int32_t *__restrict__ ncand_out,
-       int32_t *__restrict__ nhits_out, int32_t *__restrict__ status)
+       int32_t *__restrict__ nhits_out, int32_t *__restrict__ status, uint64_t *__restrict__ gbuf,
+       int32_t gcap, const int32_t *__restrict__ item_list)
 {
-    __shared__ uint64_t hits[CAP];
+    __shared__ uint64_t lhits[LCAP > 0 ? LCAP : 1];
     __shared__ DhCand cands[SEED_CCAP];
     __shared__ int64_t cband[SEED_CCAP];
     __shared__ int32_t s_n, s_nc;
 
-    const int32_t item = item0 + blockIdx.x;
     if (blockIdx.x >= (unsigned)nitems) return;
+    const int32_t item = LCAP > 0 ? item0 + (int32_t)blockIdx.x : item_list[blockIdx.x];
+    uint64_t *hits = LCAP > 0 ? lhits : gbuf + (int64_t)blockIdx.x * gcap;
+    const int32_t CAP = LCAP > 0 ? LCAP : gcap;
     const int32_t r = item >> 1, strand = item & 1;
     const int tid = threadIdx.x;
     if (tid == 0) {
@@ -315,10 +321,11 @@ k_seed(DbView B, const uint8_t *__restrict__ brc, IndexView ix, DhOpts o, int32_
     int32_t n = s_n;
     if (tid == 0) nhits_out[item] = n;
     if (n > CAP) {
-        // capacity exceeded: reported, never silently truncated
+        // capacity exceeded: never silently truncated.  LDS variant: hand the item to the HBM
+        // variant (ncand = -1); HBM variant: report
         if (tid == 0) {
-            atomicOr(status, DH_ST_HIT_OVERFLOW);
-            ncand_out[item] = 0;
+            if (LCAP == 0) atomicOr(status, DH_ST_HIT_OVERFLOW);
+            ncand_out[item] = LCAP > 0 ? -1 : 0;
         }
         return;
     }
@@ -418,12 +425,14 @@ k_seed(DbView B, const uint8_t *__restrict__ brc, IndexView ix, DhOpts o, int32_
     }
     if (tid == 0) ncand_out[item] = nc < o.max_cand ? nc : o.max_cand;
 }
-template __global__ void k_seed<4096>(DbView, const uint8_t *, IndexView, DhOpts, int32_t, int32_t,
-                                      DhCand *, int32_t *, int32_t *, int32_t *);
-template __global__ void k_seed<8192>(DbView, const uint8_t *, IndexView, DhOpts, int32_t, int32_t,
-                                      DhCand *, int32_t *, int32_t *, int32_t *);
-template __global__ void k_seed<16384>(DbView, const uint8_t *, IndexView, DhOpts, int32_t, int32_t,
-                                       DhCand *, int32_t *, int32_t *, int32_t *);
+#define SEED_INST(C)                                                                              \
+    template __global__ void k_seed<C>(DbView, const uint8_t *, IndexView, DhOpts, int32_t, int32_t,  \
+                                       DhCand *, int32_t *, int32_t *, int32_t *, uint64_t *, int32_t, \
+                                       const int32_t *);
+SEED_INST(4096)
+SEED_INST(8192)
+SEED_INST(16384)
+SEED_INST(0)
 
 // ------------------------------------------------------------------------------------ K5
 
@@ -687,7 +696,7 @@ k_wave(DbView A, DbView B, const uint8_t *__restrict__ brc, DhOpts o, int32_t it
         if (it >= nitems) break;
         const int32_t item = item0 + it;
         const int32_t r = item >> 1, strand = item & 1;
-        const int32_t nc = ncand[item];
+        const int32_t nc = max(ncand[item], 0);
         const int64_t bo = B.off[r];
         const int32_t blen = (int32_t)(B.off[r + 1] - bo);
         const uint8_t *b = (strand ? brc : B.bases) + bo;
@@ -891,15 +900,26 @@ void dhk_seed(hipStream_t st, int cap, DbView B, const uint8_t *brc, IndexView i
               int32_t *status)
 {
     if (nitems <= 0) return;
+#define SEED_LAUNCH(C)                                                                            \
+    hipLaunchKernelGGL(k_seed<C>, dim3(nitems), dim3(SEED_THREADS), 0, st, B, brc, ix, o, item0, nitems, \
+                       cand, ncand, nhits, status, (uint64_t *)nullptr, 0, (const int32_t *)nullptr)
     if (cap <= 4096)
-        hipLaunchKernelGGL(k_seed<4096>, dim3(nitems), dim3(SEED_THREADS), 0, st, B, brc, ix, o,
-                           item0, nitems, cand, ncand, nhits, status);
+        SEED_LAUNCH(4096);
     else if (cap <= 8192)
-        hipLaunchKernelGGL(k_seed<8192>, dim3(nitems), dim3(SEED_THREADS), 0, st, B, brc, ix, o,
-                           item0, nitems, cand, ncand, nhits, status);
+        SEED_LAUNCH(8192);
     else
-        hipLaunchKernelGGL(k_seed<16384>, dim3(nitems), dim3(SEED_THREADS), 0, st, B, brc, ix, o,
-                           item0, nitems, cand, ncand, nhits, status);
+        SEED_LAUNCH(16384);
+#undef SEED_LAUNCH
+}
+
+// the items listed in item_list (absolute ids) with their hits staged in HBM, gcap entries each
+void dhk_seed_big(hipStream_t st, DbView B, const uint8_t *brc, IndexView ix, DhOpts o,
+                  const int32_t *item_list, int32_t nitems, uint64_t *gbuf, int32_t gcap, DhCand *cand,
+                  int32_t *ncand, int32_t *nhits, int32_t *status)
+{
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL(k_seed<0>, dim3(nitems), dim3(SEED_THREADS), 0, st, B, brc, ix, o, 0, nitems, cand,
+                       ncand, nhits, status, gbuf, gcap, item_list);
 }
 
 void dhk_wave(hipStream_t st, int32_t nslots, DbView A, DbView B, const uint8_t *brc, DhOpts o,

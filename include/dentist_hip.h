@@ -105,6 +105,7 @@ typedef struct {
     int64_t b_bases;       /* bases of B processed (both strands counted once)               */
     float ms_index, ms_seed, ms_wave, ms_gather, ms_total; /* HIP-event times on ctx stream   */
     int32_t wave_launches, pad;
+    int64_t big_items;     /* (read, strand) items whose hits were staged in HBM instead of LDS  */
 } dh_align_stats;
 int dh_get_align_stats(dh_ctx *ctx, dh_align_stats *out);
 

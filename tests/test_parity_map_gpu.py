@@ -69,6 +69,15 @@ def test_modimer_sampling(gpu_ctx, mod):
     assert len(set(las["bread"].tolist())) == w.reads.n
 
 
+def test_long_b_sequences_use_the_hbm_staged_seed_path(gpu_ctx):
+    """Contigs as B against an index of the reads (the transposed `damapper -C` file): far more
+    than 16384 k-mer hits per sequence -> hits are staged in HBM, results still bit-exact."""
+    w = sim.Workload(150_000, 1, 600, 4000, seed=37, spacing=15000)
+    las, _ = run_both(gpu_ctx, w.reads, w.contigs, max_la=64, max_cand=256)
+    assert gpu_ctx.align_stats().big_items > 0
+    assert len(las) > 100
+
+
 def pile(seed, glen=20000, n=30, rl=6000):
     g = sim.genome(seed, glen)
     reads, _ = sim.reads(seed + 1, g, n, rl)
