@@ -104,6 +104,7 @@ def main():
     def step():
         A.drop_cache()  # the k-mer index and the reverse complement are rebuilt every step
         B.drop_cache()
+        ctx.cum_stats(reset=True)
         t0 = time.perf_counter()
         las, trace = ctx.align_db(A, B, mopts, select_best=True)
         ast = ctx.align_stats()
@@ -113,8 +114,9 @@ def main():
         rec, bases = dentist_amd.process_pileups(ctx, A, B, las, trace, piles, popts)
         t3 = time.perf_counter()
         pst = dentist_amd.process_stats(ctx)
+        cum = ctx.cum_stats().as_dict()  # every k_wave / k_seed launch of the step
         gathered = all_gather_closed_gaps(rec, bases, rank, world) if world > 1 else None
-        return dict(las=las, rec=rec, bases=bases, ast=ast, pst=pst, npiles=len(piles), gathered=gathered,
+        return dict(las=las, rec=rec, bases=bases, ast=ast, pst=pst, cum=cum, npiles=len(piles), gathered=gathered,
                     t_map=t1 - t0, t_collect=t2 - t1, t_process=t3 - t2)
 
     def barrier():
@@ -149,12 +151,21 @@ def main():
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         mean = lambda f: float(np.mean([f(r) for r in runs]))  # noqa: E731
-        wave_ms = mean(lambda r: r["ast"].ms_wave)
-        # dominant kernel of the step: k_wave of the mapping pass (one launch per step here).
-        # Algorithmic bytes per launch: both sequences of every alignment streamed once (2 B per
-        # aligned A base at one byte per base) + its trace (2 x u16 per tspace A-bases); DESIGN.md.
-        alg_bytes = aligned_bp * 2.0 + aligned_bp / mopts.tspace * 4.0
+        # dominant kernel of the step: k_wave (mapping launch + pile-up all-vs-all launch + the small
+        # re-alignment and flank launches).  Algorithmic bytes of a launch = both sequences of every
+        # alignment it emits streamed once (2 B per aligned A base at one byte per base) + its trace
+        # (2 B per trace value); summed over the step's launches and divided by their summed
+        # HIP-event durations, i.e. the per-launch average weighted by work.
+        cum = last["cum"]
+        wave_ms = mean(lambda r: r["cum"]["ms_wave"])
+        alg_bytes = 2.0 * cum["aligned_bp"] + 2.0 * cum["trace_values"]
         achieved = alg_bytes / (wave_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "k_wave_traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("workload") == args.workload and tj.get("mapping_kmer_mod") == args.kmer_mod:
+                traffic = tj["hbm_bytes_per_step"] / max(1, cum["wave_launches"])
         out = {
             "metric": "gap-bases closed/sec",
             "value": gap_all * args.steps / dt,
@@ -176,12 +187,18 @@ def main():
             "read_bp_aligned_per_sec": aligned_all * args.steps / dt,
             "read_bp_aligned_per_sec_mapping_stage": aligned_bp / mean(lambda r: r["t_map"]),
             "roofline": {"bound": "hbm", "kernel": "k_wave", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel_ms": wave_ms, "wave_cells_per_s": last["ast"].wave_cells / (wave_ms * 1e-3)},
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "launches_per_step": cum["wave_launches"], "kernel_ms_per_step": wave_ms,
+                         "avg_launch_ms": wave_ms / max(1, cum["wave_launches"]),
+                         "algorithmic_bytes_per_step": alg_bytes,
+                         "wave_cells_per_s": cum["wave_cells"] / (wave_ms * 1e-3),
+                         "note": "integer VALU/latency-bound by nature (SURVEY 7d); cell updates/s is the "
+                                 "honest secondary"},
             "stages_ms": {"map_wall": mean(lambda r: r["t_map"]) * 1e3,
                           "map_index": mean(lambda r: r["ast"].ms_index),
                           "map_seed": mean(lambda r: r["ast"].ms_seed),
-                          "map_wave": wave_ms,
+                          "map_wave": mean(lambda r: r["ast"].ms_wave),
+                          "all_wave": wave_ms, "all_seed": mean(lambda r: r["cum"]["ms_seed"]),
                           "map_gather": mean(lambda r: r["ast"].ms_gather),
                           "collect_wall": mean(lambda r: r["t_collect"]) * 1e3,
                           "process_wall": mean(lambda r: r["t_process"]) * 1e3,

@@ -35,6 +35,16 @@ class AlignStats(ctypes.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "pad"}
 
 
+class CumStats(ctypes.Structure):
+    _fields_ = [("ms_index", ctypes.c_double), ("ms_seed", ctypes.c_double), ("ms_wave", ctypes.c_double),
+                ("ms_gather", ctypes.c_double)] + [(n, ctypes.c_int64) for n in (
+                    "wave_launches", "wave_cells", "alignments", "las", "aligned_bp", "trace_values", "hits",
+                    "b_bases")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 class ProcessOpts(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "tspace_map", "allowance", "min_anchor", "min_reads", "max_reads", "tspace_pile", "rounds",
@@ -55,7 +65,8 @@ SYMBOLS = [
     "dh_last_error", "dh_abi_version", "dh_ctx_create", "dh_ctx_destroy", "dh_ctx_sync",
     "dh_default_align_opts", "dh_db_create", "dh_db_destroy", "dh_db_drop_cache", "dh_db_nreads",
     "dh_db_total_bases", "dh_la_set_destroy", "dh_la_set_count", "dh_la_set_trace_len",
-    "dh_la_set_records", "dh_la_set_trace", "dh_la_set_tspace", "dh_get_align_stats", "dh_align_db",
+    "dh_la_set_records", "dh_la_set_trace", "dh_la_set_tspace", "dh_get_align_stats", "dh_get_cum_stats",
+    "dh_align_db",
     "dh_las_write", "dh_las_read", "dh_default_process_opts", "dh_collect_spanning", "dh_pileups_destroy",
     "dh_pileups_count", "dh_pileups_get", "dh_process_pileups", "dh_insertions_destroy",
     "dh_insertions_count", "dh_insertions_records", "dh_insertions_bases", "dh_insertions_bases_len",
@@ -103,6 +114,7 @@ def lib():
     L.dh_la_set_tspace.argtypes = [vp]
     L.dh_la_set_tspace.restype = i32
     L.dh_get_align_stats.argtypes = [vp, ctypes.POINTER(AlignStats)]
+    L.dh_get_cum_stats.argtypes = [vp, ctypes.POINTER(CumStats), i32]
     L.dh_align_db.argtypes = [vp, vp, vp, ctypes.POINTER(AlignOpts), i32, ctypes.POINTER(vp)]
     L.dh_las_write.argtypes = [ctypes.c_char_p, vp, i64, vp, i32]
     L.dh_las_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
@@ -209,6 +221,11 @@ class Context:
     def align_stats(self):
         st = AlignStats()
         _check(lib().dh_get_align_stats(self._h, ctypes.byref(st)))
+        return st
+
+    def cum_stats(self, reset=False):
+        st = CumStats()
+        _check(lib().dh_get_cum_stats(self._h, ctypes.byref(st), int(reset)))
         return st
 
     def align_db(self, A, B, opts, select_best=False):

@@ -101,6 +101,14 @@ extern "C" int dh_get_align_stats(dh_ctx *c, dh_align_stats *out)
     return DH_OK;
 }
 
+extern "C" int dh_get_cum_stats(dh_ctx *c, dh_cum_stats *out, int32_t reset)
+{
+    if (!c || !out) return fail(DH_EINVAL, "dh_get_cum_stats: NULL");
+    *out = c->cum;
+    if (reset) c->cum = dh_cum_stats();
+    return DH_OK;
+}
+
 extern "C" void dh_default_align_opts(dh_align_opts *o)
 {
     memset(o, 0, sizeof(*o));
@@ -482,6 +490,7 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
     const double dens = (double)A->ix.n / std::pow(4.0, o.k) / std::max(1, A->ngroups);
     const double exp_hits = B->max_len * (dens + 0.2);
     int cap = exp_hits * 1.5 < 4096 ? 4096 : (exp_hits * 1.5 < 8192 ? 8192 : 16384);
+    if (A == B && cap < 8192) cap = 8192;  // all-vs-all inside pile-ups: every read overlaps every other
 
     std::vector<int32_t> h_ncand((size_t)cn), h_nhits((size_t)cn);
     float ms_seed = 0, ms_wave = 0, ms_gather = 0;
@@ -514,6 +523,11 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
                     big.push_back((int32_t)item0 + it);
                     gcap = std::max(gcap, h_nhits[(size_t)it]);
                 }
+            if (big.size() > (size_t)ni / 50 + 8 && cap < 16384) {
+                cap *= 2;  // many items overflow the LDS buffer: the next size is cheaper than HBM staging
+                item0 -= cn;
+                continue;
+            }
             if (!big.empty()) {
                 if (gcap > (1 << 22)) return fail(DH_EOVERFLOW, "seed filter: more than 4M k-mer hits for one sequence; lower -t");
                 int32_t pow2 = 1;
@@ -605,6 +619,21 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
     stats.ms_gather = ms_gather;
     stats.ms_total = stats.ms_index + ms_seed + ms_wave + ms_gather;
     ctx->stats = stats;
+    {
+        dh_cum_stats &c = ctx->cum;
+        c.ms_index += stats.ms_index;
+        c.ms_seed += stats.ms_seed;
+        c.ms_wave += stats.ms_wave;
+        c.ms_gather += stats.ms_gather;
+        c.wave_launches += stats.wave_launches;
+        c.wave_cells += stats.wave_cells;
+        c.alignments += stats.alignments;
+        c.las += stats.las;
+        c.hits += stats.hits;
+        c.b_bases += stats.b_bases;
+        c.trace_values += (int64_t)res->trace.size();
+        for (const dh_la &l : res->la) c.aligned_bp += l.aepos - l.abpos;
+    }
     if (getenv("DH_TRACE"))
         fprintf(stderr,
                 "[dh_align_db] A=%d seqs/%lld bp B=%d seqs/%lld bp hits=%lld cands=%lld aln=%lld las=%lld cells=%lld | "

@@ -32,6 +32,7 @@ struct dh_ctx {
     int ncu = 0;
     hipEvent_t ev[6] = {};
     dh_align_stats stats = {};
+    dh_cum_stats cum = {};
     // grow-only device scratch buffers reused across calls (hipMalloc/hipFree of GB-sized
     // buffers per call costs milliseconds and synchronises the device)
     struct Arena {

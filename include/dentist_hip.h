@@ -109,6 +109,14 @@ typedef struct {
 } dh_align_stats;
 int dh_get_align_stats(dh_ctx *ctx, dh_align_stats *out);
 
+/* cumulative over every dh_align_db executed on the context since the last reset (the pile-up
+ * path calls it several times per batch): HIP-event kernel times and work counters */
+typedef struct {
+    double ms_index, ms_seed, ms_wave, ms_gather;
+    int64_t wave_launches, wave_cells, alignments, las, aligned_bp, trace_values, hits, b_bases;
+} dh_cum_stats;
+int dh_get_cum_stats(dh_ctx *ctx, dh_cum_stats *out, int32_t reset);
+
 /*
  * dh_align_db -- every sequence of B against all of A: k-mer seeds, diagonal band filter, wave
  * local alignment with trace points.  Replaces the spawns
