@@ -48,7 +48,7 @@ extern "C" void dh_default_process_opts(dh_process_opts *o)
     o->min_reads = 3;
     o->max_reads = 60;
     o->tspace_pile = 126;
-    o->rounds = 2;
+    o->rounds = 3;
     o->flank_window = 20000;
     o->max_align_err_ppm = 300000;
     o->max_ins_err_ppm = 100000;
@@ -227,6 +227,89 @@ static bool valid_pileup_alignment(const dh_la &la, bool same, int32_t alen, int
     const bool ab = la.abpos <= allow, bb = la.bbpos <= allow;
     const bool ae = la.aepos + allow >= alen, be = la.bepos + allow >= blen;
     return !same && (((ab && bb) && (ae || be)) || ((ae && be) && (ab || bb)));
+}
+
+// chainLocalAlignments / buildAlignmentChains (common/alignments/chaining.d:122-334) with the
+// defaults of commandline.d:1819, 1982, 2014, 2153, 2165-2173.  `la` is grouped by (aread, bread)
+// [first, last); only chains scoring >= max(minScore, minRelativeScore * best) survive, every
+// other enabled LA of the pair gets DISABLED.  First LA of a chain: START|BEST, the others NEXT.
+static void chain_pair(std::vector<dh_la> &la, size_t first, size_t last, int32_t min_score)
+{
+    const int32_t max_indel = 1000, max_gap = 10000;
+    const double max_rel_overlap = 0.3, min_rel_score = 1.0;
+    // fast path (the common case): a single enabled LA is its own best chain
+    size_t nen = 0, only = first;
+    for (size_t i = first; i < last; i++)
+        if (!(la[i].flags & DH_FLAG_DISABLED)) {
+            nen++;
+            only = i;
+        }
+    if (nen == 0) return;
+    if (nen == 1) {
+        dh_la &l = la[only];
+        const int32_t sc = ((l.aepos - l.abpos) + (l.bepos - l.bbpos)) / 2;
+        if (sc < (int32_t)std::max<double>(min_score, 1.0 * sc))
+            l.flags |= DH_FLAG_DISABLED;
+        else
+            l.flags = (l.flags & ~(DH_FLAG_START | DH_FLAG_NEXT | DH_FLAG_BEST)) | DH_FLAG_START | DH_FLAG_BEST;
+        return;
+    }
+    std::vector<size_t> order;
+    for (size_t i = first; i < last; i++)
+        if (!(la[i].flags & DH_FLAG_DISABLED)) order.push_back(i);
+    const size_t n = order.size();
+    std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) {
+        if (la[x].abpos != la[y].abpos) return la[x].abpos < la[y].abpos;
+        if (la[x].bbpos != la[y].bbpos) return la[x].bbpos < la[y].bbpos;
+        return x < y;
+    });
+    auto score = [&](const dh_la &x) { return ((x.aepos - x.abpos) + (x.bepos - x.bbpos)) / 2; };
+    auto chainable = [&](const dh_la &x, const dh_la &y) {
+        if ((x.flags & DH_FLAG_COMP) != (y.flags & DH_FLAG_COMP)) return false;
+        const int32_t ga = y.abpos - x.aepos, gb = y.bbpos - x.bepos;
+        if (!(x.abpos < y.abpos && x.bbpos < y.bbpos)) return false;
+        if (std::abs(ga - gb) > max_indel || std::max(std::abs(ga), std::abs(gb)) > max_gap) return false;
+        const int32_t mla = std::min(x.aepos - x.abpos, y.aepos - y.abpos);
+        const int32_t mlb = std::min(x.bepos - x.bbpos, y.bepos - y.bbpos);
+        return std::max(0, -ga) <= max_rel_overlap * mla && std::max(0, -gb) <= max_rel_overlap * mlb;
+    };
+    auto chain_score = [&](const dh_la &x, const dh_la &y) {
+        const int32_t ga = y.abpos - x.aepos, gb = y.bbpos - x.bepos;
+        return std::abs(ga - gb) + std::max(std::abs(ga), std::abs(gb)) / 10 - score(y);
+    };
+    std::vector<int32_t> dist(n), pred(n, -1);
+    for (size_t v = 0; v < n; v++) dist[v] = -score(la[order[v]]);
+    for (size_t u = 0; u < n; u++)
+        for (size_t v = u + 1; v < n; v++)
+            if (chainable(la[order[u]], la[order[v]])) {
+                const int32_t d = dist[u] + chain_score(la[order[u]], la[order[v]]);
+                if (dist[v] > d) {
+                    dist[v] = d;
+                    pred[v] = (int32_t)u;
+                }
+            }
+    const int32_t best = -*std::min_element(dist.begin(), dist.end());
+    const int32_t thr = (int32_t)std::max<double>(min_score, min_rel_score * best);
+    std::vector<size_t> ends(n);
+    std::iota(ends.begin(), ends.end(), 0);
+    std::stable_sort(ends.begin(), ends.end(), [&](size_t x, size_t y) { return dist[x] < dist[y]; });
+    std::vector<uint8_t> keep(n, 0);
+    for (size_t e : ends) {
+        if (-dist[e] < thr || keep[e]) continue;
+        std::vector<size_t> path;
+        for (int32_t v = (int32_t)e; v >= 0; v = pred[(size_t)v]) path.push_back((size_t)v);
+        std::reverse(path.begin(), path.end());
+        for (size_t k = 0; k < path.size(); k++) {
+            const size_t v = path[k];
+            if (keep[v]) continue;
+            keep[v] = 1;
+            dh_la &l = la[order[v]];
+            l.flags &= ~(DH_FLAG_START | DH_FLAG_NEXT | DH_FLAG_BEST);
+            l.flags |= k == 0 ? (DH_FLAG_START | DH_FLAG_BEST) : DH_FLAG_NEXT;
+        }
+    }
+    for (size_t v = 0; v < n; v++)
+        if (!keep[v]) la[order[v]].flags |= DH_FLAG_DISABLED;
 }
 
 // ------------------------------------------------------------------------------------ results
@@ -539,17 +622,36 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
         if (int rc = elapsed(0, 1, ps.ms[1])) return rc;
         std::vector<dh_la> &pl = pset->la;
         ps.counters[0] = (int64_t)pl.size();
-        // ---- 3. filters: averageErrorRate <= maxAlignmentError (package.d:483-485), then
-        //         isValidPileUpAlignment with allowance = trace spacing (dazzler.d:4066-4141)
-        for (dh_la &la : pl) {
-            const int64_t al = la.aepos - la.abpos;
-            bool bad = (int64_t)la.diffs * 1000000 > (int64_t)o.max_align_err_ppm * al;
-            if (!bad) {
-                const int32_t alen = (int32_t)(pile->h_off[(size_t)la.aread + 1] - pile->h_off[(size_t)la.aread]);
-                const int32_t blen = (int32_t)(pile->h_off[(size_t)la.bread + 1] - pile->h_off[(size_t)la.bread]);
-                bad = !valid_pileup_alignment(la, la.aread == la.bread, alen, blen, tsp);
+        // ---- 3. the alignment funnel of computeQVs (package.d:474-516): averageErrorRate <=
+        //         maxAlignmentError -> chainLocalAlignments -> isValidPileUpAlignment with
+        //         allowance = trace spacing (dazzler.d:4066-4141)
+        for (dh_la &la : pl)
+            if ((int64_t)la.diffs * 1000000 > (int64_t)o.max_align_err_ppm * (la.aepos - la.abpos))
+                la.flags |= DH_FLAG_DISABLED;
+        {
+            // LAs are grouped by aread; inside an aread group order by bread to get (A, B) pairs
+            size_t g0 = 0;
+            while (g0 < pl.size()) {
+                size_t g1 = g0;
+                while (g1 < pl.size() && pl[g1].aread == pl[g0].aread) g1++;
+                auto by_b = [](const dh_la &x, const dh_la &y) { return x.bread < y.bread; };
+                if (!std::is_sorted(pl.begin() + (long)g0, pl.begin() + (long)g1, by_b))
+                    std::stable_sort(pl.begin() + (long)g0, pl.begin() + (long)g1, by_b);
+                size_t p0 = g0;
+                while (p0 < g1) {
+                    size_t p1 = p0;
+                    while (p1 < g1 && pl[p1].bread == pl[p0].bread) p1++;
+                    chain_pair(pl, p0, p1, tsp);
+                    p0 = p1;
+                }
+                g0 = g1;
             }
-            if (bad) la.flags |= DH_FLAG_DISABLED;
+        }
+        for (dh_la &la : pl) {
+            if (la.flags & DH_FLAG_DISABLED) continue;
+            const int32_t alen = (int32_t)(pile->h_off[(size_t)la.aread + 1] - pile->h_off[(size_t)la.aread]);
+            const int32_t blen = (int32_t)(pile->h_off[(size_t)la.bread + 1] - pile->h_off[(size_t)la.bread]);
+            if (!valid_pileup_alignment(la, la.aread == la.bread, alen, blen, tsp)) la.flags |= DH_FLAG_DISABLED;
         }
         // ---- 4. tile QVs on the device (LAs are sorted by aread)
         HIPCHK(hipEventRecord(ev[0], st));

@@ -102,20 +102,91 @@ def pile_opts():
 
 
 def filter_pile_las(las, pile, max_err_ppm=300000, allowance=TS_PILE):
-    """filterLocalAlignments(averageErrorRate <= maxAlignmentError) (package.d:483-485) followed by
-    filterPileUpAlignments(properAlignmentAllowance) (dazzler.d:4066-4094): sets DISABLED (0x20)."""
+    """computeQVs' alignment funnel (processPileUps/package.d:474-516): filterLocalAlignments
+    (averageErrorRate <= maxAlignmentError) -> chainLocalAlignments -> filterPileUpAlignments
+    (properAlignmentAllowance, forceFlat; dazzler.d:4066-4094).  Dropped LAs get DISABLED (0x20)."""
     las = las.copy()
     for la in las:
         al = int(la["aepos"] - la["abpos"])
-        bad = int(la["diffs"]) * 1000000 > max_err_ppm * al
-        if not bad:
-            bad = not oz.valid_pileup_alignment(la, pile.length(int(la["aread"])), pile.length(int(la["bread"])), allowance)
-        if bad:
+        if int(la["diffs"]) * 1000000 > max_err_ppm * al:
+            la["flags"] |= 0x20
+    las = chain_pile_las(las)
+    for la in las:
+        if la["flags"] & 0x20:
+            continue
+        if not oz.valid_pileup_alignment(la, pile.length(int(la["aread"])), pile.length(int(la["bread"])), allowance):
             la["flags"] |= 0x20
     return las
 
 
-def process_pile(entries, las, trace, contigs, reads, g, rounds=2, nthreads=1, flank_window=20000):
+def chain_pile_las(las, max_indel=1000, max_gap=10000, max_rel_overlap=0.3, min_rel_score=1.0, min_score=TS_PILE):
+    """chainLocalAlignments (common/alignments/chaining.d:122-334) with the defaults of
+    commandline.d:1819, 1982, 2014, 2153, 2165-2173: per (A, B) pair the chains of collinear LAs are
+    rated by a shortest-path problem (node bonus = mean length, edge penalty = indel + gap/10) and
+    only chains scoring >= max(minScore, minRelativeScore * best) survive; every other enabled LA
+    of the pair is dropped (DISABLED).  Flags: first LA of a chain START|BEST, the others NEXT."""
+    las = las.copy()
+    groups = {}
+    for i, la in enumerate(las):
+        if la["flags"] & 0x20:
+            continue
+        groups.setdefault((int(la["aread"]), int(la["bread"])), []).append(i)
+
+    def score(x):
+        return (int(x["aepos"] - x["abpos"]) + int(x["bepos"] - x["bbpos"])) // 2
+
+    def chainable(x, y):
+        if (x["flags"] & 1) != (y["flags"] & 1):
+            return False
+        ga, gb = int(y["abpos"]) - int(x["aepos"]), int(y["bbpos"]) - int(x["bepos"])
+        if not (x["abpos"] < y["abpos"] and x["bbpos"] < y["bbpos"]):
+            return False
+        if abs(ga - gb) > max_indel or max(abs(ga), abs(gb)) > max_gap:
+            return False
+        mla = min(int(x["aepos"] - x["abpos"]), int(y["aepos"] - y["abpos"]))
+        mlb = min(int(x["bepos"] - x["bbpos"]), int(y["bepos"] - y["bbpos"]))
+        return max(0, -ga) <= max_rel_overlap * mla and max(0, -gb) <= max_rel_overlap * mlb
+
+    def chain_score(x, y):
+        ga, gb = int(y["abpos"]) - int(x["aepos"]), int(y["bbpos"]) - int(x["bepos"])
+        return abs(ga - gb) + max(abs(ga), abs(gb)) // 10 - score(y)
+
+    for idxs in groups.values():
+        order = sorted(idxs, key=lambda i: (int(las[i]["abpos"]), int(las[i]["bbpos"]), i))   # a topological order
+        n = len(order)
+        dist = [-score(las[i]) for i in order]
+        pred = [-1] * n
+        for u in range(n):
+            for v in range(u + 1, n):
+                if chainable(las[order[u]], las[order[v]]):
+                    d = dist[u] + chain_score(las[order[u]], las[order[v]])
+                    if dist[v] > d:
+                        dist[v], pred[v] = d, u
+        best = -min(dist)
+        thr = int(max(min_score, min_rel_score * best))
+        keep = set()
+        for e in sorted(range(n), key=lambda v: (dist[v], v)):
+            if -dist[e] < thr or e in keep:
+                continue
+            path = []
+            v = e
+            while v >= 0:
+                path.append(v)
+                v = pred[v]
+            path.reverse()
+            for k, v in enumerate(path):
+                if v in keep:
+                    continue
+                keep.add(v)
+                f = int(las[order[v]]["flags"]) & ~(0x4 | 0x8 | 0x10)
+                las[order[v]]["flags"] = f | ((0x4 | 0x10) if k == 0 else 0x8)
+        for v in range(n):
+            if v not in keep:
+                las[order[v]]["flags"] |= 0x20
+    return las
+
+
+def process_pile(entries, las, trace, contigs, reads, g, rounds=3, nthreads=1, flank_window=20000):
     """One pile-up through the `process` sequence; returns a dict describing the insertion."""
     res = {"gap": g, "status": "ok", "nreads": len(entries)}
     crop = crop_pile(entries, las, trace, contigs, reads, g)
