@@ -26,6 +26,71 @@ int dh_fail(int code, const std::string &msg)
 }
 #define fail dh_fail
 
+// ------------------------------------------------------------------------------------ allocator
+#include <map>
+#include <mutex>
+#include <unordered_map>
+namespace {
+std::mutex g_alloc_mu;
+std::map<size_t, std::vector<void *>> g_free_lists;
+std::unordered_map<void *, size_t> g_block_size;
+size_t size_class(size_t bytes)
+{
+    if (bytes < 4096) return 4096;
+    size_t p = 4096;
+    while (p < bytes) p <<= 1;  // next power of two, then steps of p/8 below it
+    const size_t step = p >> 4;
+    return (bytes + step - 1) / step * step;
+}
+}  // namespace
+
+hipError_t dh_dev_alloc(void **p, size_t bytes)
+{
+    const size_t cls = size_class(bytes);
+    {
+        std::lock_guard<std::mutex> lk(g_alloc_mu);
+        auto it = g_free_lists.find(cls);
+        if (it != g_free_lists.end() && !it->second.empty()) {
+            *p = it->second.back();
+            it->second.pop_back();
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(p, cls);
+    if (e != hipSuccess) {  // out of memory: drop the cache and retry once
+        dh_dev_trim();
+        e = hipMalloc(p, cls);
+    }
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_alloc_mu);
+        g_block_size[*p] = cls;
+    }
+    return e;
+}
+
+void dh_dev_free(void *p)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_alloc_mu);
+    auto it = g_block_size.find(p);
+    if (it == g_block_size.end()) {
+        (void)hipFree(p);
+        return;
+    }
+    g_free_lists[it->second].push_back(p);
+}
+
+void dh_dev_trim()
+{
+    std::lock_guard<std::mutex> lk(g_alloc_mu);
+    for (auto &kv : g_free_lists)
+        for (void *p : kv.second) {
+            g_block_size.erase(p);
+            (void)hipFree(p);
+        }
+    g_free_lists.clear();
+}
+
 extern "C" const char *dh_last_error(void) { return g_err.c_str(); }
 extern "C" int32_t dh_abi_version(void) { return 1; }
 
@@ -64,7 +129,8 @@ extern "C" void dh_ctx_destroy(dh_ctx *c)
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto &a : c->arena)
-        if (a.p) (void)hipFree(a.p);
+        if (a.p) dh_dev_free(a.p);
+    dh_dev_trim();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -75,12 +141,12 @@ int dh_scratch(dh_ctx *ctx, int id, size_t bytes, void **out)
     if (bytes > a.cap) {
         if (a.p) {
             HIPCHK(hipStreamSynchronize(ctx->stream));
-            (void)hipFree(a.p);
+            dh_dev_free(a.p);
             a.p = nullptr;
             a.cap = 0;
         }
         const size_t want = bytes + bytes / 8 + 256;
-        HIPCHK(hipMalloc(&a.p, want));
+        HIPCHK(dh_dev_alloc(&a.p, want));
         a.cap = want;
     }
     *out = a.p;
@@ -135,7 +201,7 @@ extern "C" void dh_default_align_opts(dh_align_opts *o)
 int dh_alloc_bases(hipStream_t st, int64_t total, uint8_t **alloc, uint8_t **base)
 {
     const size_t nb = (size_t)std::max<int64_t>(total, 0) + 2 * DB_PAD;
-    HIPCHK(hipMalloc(alloc, nb));
+    HIPCHK(dh_dev_alloc(alloc, nb));
     HIPCHK(hipMemsetAsync(*alloc, 4, nb, st));
     *base = *alloc + DB_PAD;
     return DH_OK;
@@ -180,13 +246,13 @@ extern "C" int dh_db_create(dh_ctx *ctx, const uint8_t *bases, const int64_t *of
         delete db;
         return rc;
     }
-    HIPCHK(hipMalloc(&db->d_off, sizeof(int64_t) * (size_t)(n + 1)));
+    HIPCHK(dh_dev_alloc(&db->d_off, sizeof(int64_t) * (size_t)(n + 1)));
     if (db->total > 0)
         HIPCHK(hipMemcpyAsync(db->d_bases, bases, (size_t)db->total, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(db->d_off, off, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyHostToDevice,
                           ctx->stream));
     if (group && n > 0) {
-        HIPCHK(hipMalloc(&db->d_group, sizeof(int32_t) * (size_t)n));
+        HIPCHK(dh_dev_alloc(&db->d_group, sizeof(int32_t) * (size_t)n));
         HIPCHK(hipMemcpyAsync(db->d_group, group, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice,
                               ctx->stream));
     }
@@ -200,10 +266,10 @@ extern "C" void dh_db_destroy(dh_db *db)
     if (!db) return;
     (void)hipSetDevice(db->ctx->device);
     (void)hipStreamSynchronize(db->ctx->stream);
-    (void)hipFree(db->d_bases_alloc);
-    (void)hipFree(db->d_rc_alloc);
-    (void)hipFree(db->d_off);
-    (void)hipFree(db->d_group);
+    dh_dev_free(db->d_bases_alloc);
+    dh_dev_free(db->d_rc_alloc);
+    dh_dev_free(db->d_off);
+    dh_dev_free(db->d_group);
     if (db->has_ix) db->ix.release();
     delete db;
 }
@@ -219,7 +285,7 @@ extern "C" int dh_db_drop_cache(dh_db *db)
     (void)hipStreamSynchronize(db->ctx->stream);
     if (db->has_ix) db->ix.release();
     db->has_ix = false;
-    (void)hipFree(db->d_rc_alloc);
+    dh_dev_free(db->d_rc_alloc);
     db->d_rc = db->d_rc_alloc = nullptr;
     return DH_OK;
 }
@@ -277,15 +343,15 @@ static int build_index(dh_db *A, int32_t k, int32_t sepv, int32_t kmer_mod)
     // the largest key is ngroups * 4^k - 1, so buckets up to (that >> shift) are addressable
     const int64_t nb = (int64_t)((((uint64_t)A->ngroups << (2 * k)) - 1) >> ix.shift) + 1;
     ix.n = nk;
-    HIPCHK(hipMalloc(&ix.d_dir, sizeof(uint32_t) * (size_t)(nb + 1)));
-    HIPCHK(hipMalloc(&ix.d_ekey, sizeof(uint64_t) * (size_t)std::max<int64_t>(nk, 1)));
-    HIPCHK(hipMalloc(&ix.d_eval, sizeof(uint64_t) * (size_t)std::max<int64_t>(nk, 1)));
-    HIPCHK(hipMalloc(&ix.d_goff, sizeof(int64_t) * (size_t)(A->n + 1)));
+    HIPCHK(dh_dev_alloc(&ix.d_dir, sizeof(uint32_t) * (size_t)(nb + 1)));
+    HIPCHK(dh_dev_alloc(&ix.d_ekey, sizeof(uint64_t) * (size_t)std::max<int64_t>(nk, 1)));
+    HIPCHK(dh_dev_alloc(&ix.d_eval, sizeof(uint64_t) * (size_t)std::max<int64_t>(nk, 1)));
+    HIPCHK(dh_dev_alloc(&ix.d_goff, sizeof(int64_t) * (size_t)(A->n + 1)));
     int2 *d_tiles = nullptr;
     uint32_t *d_sums = nullptr;
     const int64_t nsum = (nb + 1 + 2047) / 2048 + 1;
-    HIPCHK(hipMalloc(&d_tiles, sizeof(int2) * std::max<size_t>(tiles.size(), 1)));
-    HIPCHK(hipMalloc(&d_sums, sizeof(uint32_t) * (size_t)nsum));
+    HIPCHK(dh_dev_alloc(&d_tiles, sizeof(int2) * std::max<size_t>(tiles.size(), 1)));
+    HIPCHK(dh_dev_alloc(&d_sums, sizeof(uint32_t) * (size_t)nsum));
     HIPCHK(hipMemcpyAsync(ix.d_goff, goff.data(), sizeof(int64_t) * goff.size(), hipMemcpyHostToDevice,
                           ctx->stream));
     if (!tiles.empty())
@@ -301,8 +367,8 @@ static int build_index(dh_db *A, int32_t k, int32_t sepv, int32_t kmer_mod)
     dhk_bucket_sort(ctx->stream, ix.d_dir, nb, ix.d_ekey, ix.d_eval);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));  // tiles vector goes out of scope
-    (void)hipFree(d_tiles);
-    (void)hipFree(d_sums);
+    dh_dev_free(d_tiles);
+    dh_dev_free(d_sums);
     A->has_ix = true;
     return DH_OK;
 }
@@ -362,7 +428,7 @@ static void select_best(std::vector<dh_la> &la)
 
 // LAsort order of a B-major (bread, strand, ...) list in O(n): stable counting sort by aread
 // keeps (bread, comp) ascending inside every aread; the rare runs with equal (aread, bread, comp)
-// are finished with an insertion sort.  Traces are re-laid out in the final order.
+// are finished with an insertion sort.
 static void lasort(dh_la_set *res, int32_t na)
 {
     const size_t n = res->la.size();
@@ -381,15 +447,9 @@ static void lasort(dh_la_set *res, int32_t na)
         }
         out[j] = x;
     }
-    std::vector<uint16_t> tr(res->trace.size());
-    int64_t t = 0;
-    for (dh_la &l : out) {
-        memcpy(tr.data() + t, res->trace.data() + l.toff, sizeof(uint16_t) * (size_t)l.tlen);
-        l.toff = t;
-        t += l.tlen;
-    }
+    // the traces stay where the device compaction put them: every record's toff still points at
+    // its (diffs, bbases) pairs, only the records are permuted (saves re-laying out tens of MB)
     res->la.swap(out);
-    res->trace.swap(tr);
 }
 
 // ------------------------------------------------------------------------------------ align
@@ -404,8 +464,12 @@ extern "C" int dh_align_db(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts 
 int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, int32_t want_best,
                    int32_t want_sorted, dh_la_set **out)
 {
-    const double wall0 = (double)std::chrono::duration_cast<std::chrono::microseconds>(
-                             std::chrono::steady_clock::now().time_since_epoch()).count();
+    auto now_ms = [] {
+        return (double)std::chrono::duration_cast<std::chrono::microseconds>(
+                   std::chrono::steady_clock::now().time_since_epoch()).count() / 1e3;
+    };
+    const double wall0 = now_ms() * 1e3;
+    double w_a = now_ms(), w_index = 0, w_loop = 0, w_post = 0;
     if (!ctx || !A || !B || !opts || !out) return fail(DH_EINVAL, "dh_align_db: NULL argument");
     if (A->ctx != ctx || B->ctx != ctx) return fail(DH_EINVAL, "dh_align_db: DB of another context");
     const dh_align_opts &o = *opts;
@@ -439,6 +503,8 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
     if (int rc = build_index(A, o.k, sepv, o.kmer_mod)) return rc;
     if (int rc = dh_ensure_rc(B)) return rc;
     HIPCHK(hipEventRecord(ctx->ev[1], st));
+    w_index = now_ms() - w_a;
+    w_a = now_ms();
 
     DhOpts dopt;
     memcpy(&dopt, &o, sizeof(dopt));
@@ -603,6 +669,8 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
         ms_gather += t;
     }
 #undef SCR
+    w_loop = now_ms() - w_a;
+    w_a = now_ms();
     unsigned long long counters[2] = {0, 0};
     HIPCHK(hipMemcpy(counters, d_counters, sizeof(counters), hipMemcpyDeviceToHost));
     stats.wave_cells = (int64_t)counters[0];
@@ -610,6 +678,7 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
 
     if (want_best) select_best(res->la);
     if (want_sorted) lasort(res, A->n);
+    w_post = now_ms() - w_a;
     stats.las = (int64_t)res->la.size();
     float t;
     HIPCHK(hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[1]));
@@ -637,12 +706,13 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
     if (getenv("DH_TRACE"))
         fprintf(stderr,
                 "[dh_align_db] A=%d seqs/%lld bp B=%d seqs/%lld bp hits=%lld cands=%lld aln=%lld las=%lld cells=%lld | "
-                "index %.2f seed %.2f wave %.2f gather %.2f ms, wall %.2f ms\n",
+                "index %.2f seed %.2f wave %.2f gather %.2f ms, wall %.2f ms (host: index %.2f loop %.2f post %.2f)\n",
                 A->n, (long long)A->total, B->n, (long long)B->total, (long long)stats.hits, (long long)stats.cands,
                 (long long)stats.alignments, (long long)stats.las, (long long)stats.wave_cells, stats.ms_index,
                 stats.ms_seed, stats.ms_wave, stats.ms_gather,
                 ((double)std::chrono::duration_cast<std::chrono::microseconds>(
-                     std::chrono::steady_clock::now().time_since_epoch()).count() - wall0) / 1e3);
+                     std::chrono::steady_clock::now().time_since_epoch()).count() - wall0) / 1e3,
+                w_index, w_loop, w_post);
     guard.ok = true;
     *out = res;
     return DH_OK;

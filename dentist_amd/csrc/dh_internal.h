@@ -14,6 +14,19 @@
 
 #define DB_PAD 64
 
+// Caching device allocator: hipMalloc / hipFree synchronise the device and cost 0.1-1 ms each;
+// the same buffer sizes recur on every call, so freed blocks are kept in size-class free lists and
+// handed out again (all work runs on one stream, so stream order protects reuse).  The cache is
+// released when the last context is destroyed.
+hipError_t dh_dev_alloc(void **p, size_t bytes);
+void dh_dev_free(void *p);
+void dh_dev_trim();
+template <typename T>
+inline hipError_t dh_dev_alloc(T **p, size_t bytes)
+{
+    return dh_dev_alloc((void **)p, bytes);
+}
+
 int dh_fail(int code, const std::string &msg);
 // allocate total + 2 * DB_PAD bytes filled with code 4; *base = alloc + DB_PAD
 int dh_alloc_bases(hipStream_t st, int64_t total, uint8_t **alloc, uint8_t **base);
@@ -52,10 +65,10 @@ struct dh_index {
     int32_t k = 0, sepv = 0, shift = 0, pbits = 0, na = 0, kmer_mod = 1;
     void release()
     {
-        (void)hipFree(d_dir);
-        (void)hipFree(d_ekey);
-        (void)hipFree(d_eval);
-        (void)hipFree(d_goff);
+        dh_dev_free(d_dir);
+        dh_dev_free(d_ekey);
+        dh_dev_free(d_eval);
+        dh_dev_free(d_goff);
         d_dir = nullptr;
         d_ekey = d_eval = nullptr;
         d_goff = nullptr;
@@ -87,8 +100,8 @@ struct dh_la_set {
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
-    ~DevBuf() { (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, sizeof(T) * std::max<size_t>(n, 1)); }
+    ~DevBuf() { dh_dev_free(p); }
+    hipError_t alloc(size_t n) { return dh_dev_alloc(&p, sizeof(T) * std::max<size_t>(n, 1)); }
 };
 
 // build a DB whose bases are slices [beg, beg+len) of sequences of `src` (device-to-device)

@@ -9,6 +9,9 @@
 //   daccord (dazzler.d:6185-6231)                -> k_seg_vote + k_emit, `rounds` times
 //   daligner -A flanks vs consensus (:655-667)   -> dh_align_db
 //   insertion (package.d:699-805, insertions.d:110-146) -> host
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <numeric>
@@ -69,13 +72,13 @@ int dh_db_adopt(dh_ctx *ctx, uint8_t *d_alloc, uint8_t *d_bases, const std::vect
     db->d_bases_alloc = d_alloc;
     for (int32_t i = 0; i < db->n; i++)
         db->max_len = std::max<int32_t>(db->max_len, (int32_t)(off[(size_t)i + 1] - off[(size_t)i]));
-    HIPCHK(hipMalloc(&db->d_off, sizeof(int64_t) * off.size()));
+    HIPCHK(dh_dev_alloc(&db->d_off, sizeof(int64_t) * off.size()));
     HIPCHK(hipMemcpyAsync(db->d_off, off.data(), sizeof(int64_t) * off.size(), hipMemcpyHostToDevice,
                           ctx->stream));
     if (!group.empty()) {
         db->h_group = group;
         for (int32_t g : group) db->ngroups = std::max(db->ngroups, g + 1);
-        HIPCHK(hipMalloc(&db->d_group, sizeof(int32_t) * group.size()));
+        HIPCHK(dh_dev_alloc(&db->d_group, sizeof(int32_t) * group.size()));
         HIPCHK(hipMemcpyAsync(db->d_group, group.data(), sizeof(int32_t) * group.size(),
                               hipMemcpyHostToDevice, ctx->stream));
     }
@@ -98,7 +101,7 @@ int dh_db_from_slices(dh_ctx *ctx, const dh_db *src, const std::vector<int32_t> 
     uint8_t *d_alloc = nullptr, *d_bases = nullptr;
     if (int rc = dh_alloc_bases(ctx->stream, off.back(), &d_alloc, &d_bases)) return rc;
     if (int rc = dh_db_adopt(ctx, d_alloc, d_bases, off, group, out)) {
-        (void)hipFree(d_alloc);
+        dh_dev_free(d_alloc);
         return rc;
     }
     if (n > 0) {
@@ -379,18 +382,25 @@ static int consensus_round(dh_ctx *ctx, dh_db *T, dh_db *R, const std::vector<dh
         voff[(size_t)t + 1] = voff[(size_t)t] + len + 1;
         ooff[(size_t)t + 1] = ooff[(size_t)t] + len * (1 + 2 * MAXINS) + 8;
     }
-    DevBuf<int64_t> d_voff, d_ooff;
-    DevBuf<uint32_t> d_votes;
-    DevBuf<uint8_t> d_out, d_fmat, d_opbuf;
-    DevBuf<int32_t> d_status, d_outlen, d_coltmpl;
-    DevBuf<uint8_t> d_stage, d_cnt;
-    DevBuf<SegDescH> d_segs;
-    HIPCHK(d_voff.alloc(voff.size()));
-    HIPCHK(d_ooff.alloc(ooff.size()));
-    HIPCHK(d_votes.alloc((size_t)voff.back() * VSTRIDE));
-    HIPCHK(d_out.alloc((size_t)ooff.back()));
-    HIPCHK(d_status.alloc(1));
-    HIPCHK(d_outlen.alloc((size_t)nt));
+    // big per-round buffers come from the context's grow-only scratch arena (slots 17..23)
+    struct P {
+        void *p = nullptr;
+    };
+    struct { int64_t *p; } d_voff, d_ooff;
+    struct { uint32_t *p; } d_votes;
+    struct { uint8_t *p; } d_out, d_stage, d_cnt;
+    struct { int32_t *p; } d_status, d_outlen, d_coltmpl;
+#define SCRP(id, buf, count)                                                                     \
+    if (int rc_ = dh_scratch(ctx, id, sizeof(*buf.p) * std::max<size_t>((size_t)(count), 1), (void **)&buf.p)) return rc_;
+    SCRP(17, d_voff, voff.size() + ooff.size())
+    d_ooff.p = d_voff.p + voff.size();
+    SCRP(18, d_votes, (size_t)voff.back() * VSTRIDE)
+    SCRP(19, d_out, (size_t)ooff.back())
+    SCRP(20, d_status, 2 + (size_t)nt + (size_t)voff.back())
+    d_outlen.p = d_status.p + 2;
+    d_coltmpl.p = d_outlen.p + nt;
+    SCRP(21, d_stage, (size_t)voff.back() * (2 + 2 * MAXINS))
+    d_cnt.p = d_stage.p + (size_t)voff.back() * (1 + 2 * MAXINS);
     HIPCHK(hipMemcpyAsync(d_voff.p, voff.data(), sizeof(int64_t) * voff.size(), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_ooff.p, ooff.data(), sizeof(int64_t) * ooff.size(), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(d_votes.p, 0, sizeof(uint32_t) * (size_t)voff.back() * VSTRIDE, st));
@@ -401,11 +411,11 @@ static int consensus_round(dh_ctx *ctx, dh_db *T, dh_db *R, const std::vector<dh
     const int64_t max_dp = std::max<int64_t>(4096, (6ll << 30) / per_dp);
     for (size_t s0 = 0; s0 < segs.size(); s0 += (size_t)max_dp) {
         const int32_t cnt = (int32_t)std::min<size_t>((size_t)max_dp, segs.size() - s0);
-        DevBuf<SegDescH> ds;
-        DevBuf<uint8_t> fm, ob;
-        HIPCHK(ds.alloc((size_t)cnt));
-        HIPCHK(fm.alloc((size_t)cnt * (size_t)(ts + 1) * (size_t)(wmax + 1)));
-        HIPCHK(ob.alloc((size_t)cnt * 2 * SEG_MAX));
+        struct { SegDescH *p; } ds;
+        struct { uint8_t *p; } fm, ob;
+        SCRP(22, ds, (size_t)cnt)
+        SCRP(23, fm, (size_t)cnt * (size_t)(ts + 1) * (size_t)(wmax + 1) + (size_t)cnt * 2 * SEG_MAX)
+        ob.p = fm.p + (size_t)cnt * (size_t)(ts + 1) * (size_t)(wmax + 1);
         HIPCHK(hipMemcpyAsync(ds.p, segs.data() + s0, sizeof(SegDescH) * (size_t)cnt, hipMemcpyHostToDevice, st));
         dhk_seg_vote(st, ds.p, cnt, T->view(), R->view(), R->d_rc, d_voff.p, fm.p, wmax, ob.p, d_votes.p,
                      d_status.p);
@@ -417,9 +427,6 @@ static int consensus_round(dh_ctx *ctx, dh_db *T, dh_db *R, const std::vector<dh
         std::vector<int32_t> col_tmpl((size_t)voff.back(), -1);
         for (int32_t t = 0; t < nt; t++)
             for (int64_t x = voff[(size_t)t]; x < voff[(size_t)t + 1] - 1; x++) col_tmpl[(size_t)x] = t;
-        HIPCHK(d_coltmpl.alloc(col_tmpl.size()));
-        HIPCHK(d_stage.alloc((size_t)voff.back() * (1 + 2 * MAXINS)));
-        HIPCHK(d_cnt.alloc((size_t)voff.back()));
         HIPCHK(hipMemcpyAsync(d_coltmpl.p, col_tmpl.data(), sizeof(int32_t) * col_tmpl.size(), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemsetAsync(d_cnt.p, 0, (size_t)voff.back(), st));
         dhk_emit(st, T->view(), nt, d_voff.p, d_votes.p, d_coltmpl.p, voff.back(), d_stage.p, d_cnt.p, d_ooff.p,
@@ -443,7 +450,7 @@ static int consensus_round(dh_ctx *ctx, dh_db *T, dh_db *R, const std::vector<dh
     uint8_t *d_alloc = nullptr, *d_bases = nullptr;
     if (int rc = dh_alloc_bases(st, noff.back(), &d_alloc, &d_bases)) return rc;
     if (int rc = dh_db_adopt(ctx, d_alloc, d_bases, noff, T->h_group, newT)) {
-        (void)hipFree(d_alloc);
+        dh_dev_free(d_alloc);
         return rc;
     }
     std::vector<int32_t> ident((size_t)nt), zero((size_t)nt, 0);
@@ -504,6 +511,17 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
         HIPCHK(hipEventElapsedTime(&t, ev[a], ev[b]));
         acc += t;
         return DH_OK;
+    };
+    const bool tr_on = getenv("DH_TRACE") != nullptr;
+    auto now_ms = [] {
+        return (double)std::chrono::duration_cast<std::chrono::microseconds>(
+                   std::chrono::steady_clock::now().time_since_epoch()).count() / 1e3;
+    };
+    double tmark = now_ms();
+    auto lap = [&](const char *what) {
+        const double t = now_ms();
+        if (tr_on) fprintf(stderr, "[dh_process] %-28s %.2f ms\n", what, t - tmark);
+        tmark = t;
     };
     DbGuard dbg;
     SetGuard sg;
@@ -594,6 +612,7 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
     dbg.dbs.push_back(pile);
     HIPCHK(hipEventRecord(ev[1], st));
     if (int rc = elapsed(0, 1, ps.ms[0])) return rc;
+    lap("crop + pile DB");
 
     std::vector<uint8_t> active_ok((size_t)na, 1);
     dh_db *T = nullptr;
@@ -610,6 +629,7 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
         HIPCHK(hipEventRecord(ev[0], st));
         if (int rc = dh_align_db_ex(ctx, pile, pile, &ao, 0, 0, &pset)) return rc;
         sg.sets.push_back(pset);
+        lap("pile align call");
         {   // group by aread (counting sort, stable); traces stay where they are
             std::vector<int32_t> cnt((size_t)pile->n + 1, 0);
             for (const dh_la &la : pset->la) cnt[(size_t)la.aread + 1]++;
@@ -622,6 +642,7 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
         if (int rc = elapsed(0, 1, ps.ms[1])) return rc;
         std::vector<dh_la> &pl = pset->la;
         ps.counters[0] = (int64_t)pl.size();
+        lap("group by aread");
         // ---- 3. the alignment funnel of computeQVs (package.d:474-516): averageErrorRate <=
         //         maxAlignmentError -> chainLocalAlignments -> isValidPileUpAlignment with
         //         allowance = trace spacing (dazzler.d:4066-4141)
@@ -653,6 +674,7 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
             const int32_t blen = (int32_t)(pile->h_off[(size_t)la.bread + 1] - pile->h_off[(size_t)la.bread]);
             if (!valid_pileup_alignment(la, la.aread == la.bread, alen, blen, tsp)) la.flags |= DH_FLAG_DISABLED;
         }
+        lap("filter + chain");
         // ---- 4. tile QVs on the device (LAs are sorted by aread)
         HIPCHK(hipEventRecord(ev[0], st));
         const int32_t npr = pile->n;
@@ -691,6 +713,7 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
         }
         HIPCHK(hipEventRecord(ev[1], st));
         if (int rc = elapsed(0, 1, ps.ms[2])) return rc;
+        lap("tile qv");
         // ---- 5. reference read per pile-up: findReferenceReadCandidates (package.d:518-568)
         std::vector<int32_t> ref_of((size_t)na, -1);
         const double bad_fraction = (double)o.bad_fraction_ppm / 1e6;
@@ -752,6 +775,7 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
             rec.ref_read = best - r0;
             rec.ref_read_id = read_id[(size_t)best];
         }
+        lap("rank reference reads");
         // ---- 6. consensus rounds.  Templates are indexed by active pile-up (group = active idx)
         std::vector<int32_t> tidx, tbeg, tlen, tgrp;
         for (int32_t a = 0; a < na; a++) {
@@ -814,6 +838,7 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
             HIPCHK(hipEventRecord(ev[1], st));
             if (int rc = elapsed(0, 1, ps.ms[3])) return rc;
         }
+        lap("consensus rounds");
         // ---- 7. flank re-alignment: daligner -A -s126 -l126 contigs consensus (commandline.d:2918-2935)
         std::vector<int32_t> fidx, fbeg, flen, fgrp, foff((size_t)na, 0);
         for (int32_t a = 0; a < na; a++) {
@@ -846,6 +871,7 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
         sg.sets.push_back(fset);
         HIPCHK(hipEventRecord(ev[1], st));
         if (int rc = elapsed(0, 1, ps.ms[5])) return rc;
+        lap("flank align");
         // ---- 8. consensus bases to the host, insertion per pile-up
         std::vector<uint8_t> cons((size_t)std::max<int64_t>(T->total, 1));
         if (T->total > 0) HIPCHK(hipMemcpy(cons.data(), T->d_bases, (size_t)T->total, hipMemcpyDeviceToHost));
@@ -894,6 +920,7 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
             if (rec.ins_end < rec.ins_begin) rec.status = DH_PILE_NEGATIVE_INSERTION;
         }
     }
+    lap("insertions");
     ps.ms[6] = ps.ms[0] + ps.ms[1] + ps.ms[2] + ps.ms[3] + ps.ms[4] + ps.ms[5];
     g_pstats = ps;
     rg.ok = true;

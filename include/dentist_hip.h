@@ -124,7 +124,8 @@ int dh_get_cum_stats(dh_ctx *ctx, dh_cum_stats *out, int32_t reset);
  *                                                 workflow call snakemake/Snakefile:1143-1170)
  *   `daligner -T<a> -B -s126 -l500 -e0.7 db db`   dazzler.d:6121-6140 (getDalignment :3829-3844)
  *   `daligner -A ... contigs consensus`           processPileUps/package.d:655-667
- * Output: LAs in LAsort order (base.d:1787-1809).  select_best != 0 additionally sets the
+ * Output: LAs in LAsort order (base.d:1787-1809); each record's toff locates its trace pairs in
+ * the trace array (the trace array itself is not reordered).  select_best != 0 additionally sets the
  * chain flags damapper emits (START/BEST, consumer dazzler.d:1728-1758).
  */
 int dh_align_db(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, int32_t select_best,

@@ -178,4 +178,4 @@ def test_larger_run_properties(gpu_ctx):
     # idempotence: a second run (index rebuilt) is bit-identical
     A.drop_cache()
     las2, trace2 = gpu_ctx.align_db(A, B, g)
-    assert np.array_equal(las, las2) and np.array_equal(trace, trace2)
+    assert_same_las((las2, trace2), (las, trace))

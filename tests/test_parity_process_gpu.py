@@ -8,6 +8,7 @@ import pytest
 
 import dentist_amd
 from dentist_amd import sim
+from helpers import assert_same_las
 from oracle import process as pr
 from oracle import pyoracle as oz
 
@@ -23,7 +24,7 @@ def run_case(ctx, w, rounds):
     las, trace = ctx.align_db(A, B, g)
     # the mapping LAs themselves are covered by test_parity_map_gpu; the oracle re-derives them
     olas, otrace, _ = oz.align_db(w.contigs, w.reads, oz.default_opts(width=g.width), nthreads=os.cpu_count() or 1)
-    assert np.array_equal(las, olas) and np.array_equal(trace, otrace)
+    assert_same_las((las, trace), (olas, otrace))
     po = dentist_amd.default_process_opts(rounds=rounds)
     piles = dentist_amd.Pileups(las, w.contigs.off, po)
     exp_piles = pr.collect_spanning(olas, otrace, w.contigs, w.reads)
