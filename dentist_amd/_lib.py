@@ -72,7 +72,8 @@ SYMBOLS = [
     "dh_insertions_count", "dh_insertions_records", "dh_insertions_bases", "dh_insertions_bases_len",
     "dh_get_process_stats", "dh_dazz_create_dam", "dh_dazz_create_db", "dh_dazz_split", "dh_dazz_open",
     "dh_dazz_close", "dh_dazz_nreads", "dh_dazz_first_id", "dh_dazz_bases", "dh_dazz_offsets",
-    "dh_dazz_origin", "dh_dazz_fpulse", "dh_dazz_header",
+    "dh_dazz_origin", "dh_dazz_fpulse", "dh_dazz_header", "dh_dazz_read_mask", "dh_dazz_write_mask",
+    "dh_db_set_mask",
 ]
 
 _LIB = None
@@ -149,6 +150,10 @@ def lib():
         fn.argtypes = [vp]
         fn.restype = vp
     L.dh_dazz_header.argtypes = [vp, i32]
+    L.dh_dazz_read_mask.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, vp, vp, i64]
+    L.dh_dazz_read_mask.restype = i64
+    L.dh_dazz_write_mask.argtypes = [ctypes.c_char_p, ctypes.c_char_p, i32, vp, vp]
+    L.dh_db_set_mask.argtypes = [vp, vp, vp]
     L.dh_dazz_header.restype = ctypes.c_char_p
     _LIB = L
     return L
@@ -243,15 +248,27 @@ class Db:
         self.ctx = ctx
         bases = np.ascontiguousarray(seqdb.bases, dtype=np.uint8)
         off = np.ascontiguousarray(seqdb.off, dtype=np.int64)
+        mask = getattr(seqdb, "mask", None)
         group = None if getattr(seqdb, "group", None) is None else np.ascontiguousarray(seqdb.group, np.int32)
         h = ctypes.c_void_p()
         _check(lib().dh_db_create(ctx._h, bases.ctypes.data, off.ctypes.data, len(off) - 1,
                                   group.ctypes.data if group is not None else None, ctypes.byref(h)))
         self._h = h
         ctx._dbs.append(weakref.ref(self))
+        if mask is not None:
+            self.set_mask(mask[0], mask[1])
 
     def drop_cache(self):
         _check(lib().dh_db_drop_cache(self._h))
+
+    def set_mask(self, ptr, iv):
+        """Soft mask (union of -m tracks): ptr int64[n+1], iv int32 (begin, end) pairs; None clears."""
+        if ptr is None:
+            _check(lib().dh_db_set_mask(self._h, None, None))
+            return
+        p = np.ascontiguousarray(ptr, dtype=np.int64)
+        v = np.ascontiguousarray(iv, dtype=np.int32)
+        _check(lib().dh_db_set_mask(self._h, p.ctypes.data, v.ctypes.data))
 
     def close(self):
         if self._h:
@@ -383,7 +400,31 @@ class DazzDb:
                        if n else np.zeros(0, np.int32))
         self.headers = [L.dh_dazz_header(h, i).decode() for i in range(n)]
         self.group = None
-        L.dh_dazz_close(h)
+        self.mask = None
+        self._h = h
+        self._path = path
+
+    def read_mask(self, name):
+        """Intervals of mask track `name` for this (trimmed) view: (ptr int64[n+1], iv int32 pairs)."""
+        L = lib()
+        ptr = np.zeros(self.n + 1, dtype=np.int64)
+        m = L.dh_dazz_read_mask(self._h, self._path.encode(), name.encode(), ptr.ctypes.data, None, 0)
+        if m < 0:
+            _check(int(m))
+        iv = np.zeros(max(2 * m, 2), dtype=np.int32)
+        L.dh_dazz_read_mask(self._h, self._path.encode(), name.encode(), ptr.ctypes.data, iv.ctypes.data, m)
+        return ptr, iv[:2 * m]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().dh_dazz_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     @property
     def n(self):
@@ -391,3 +432,9 @@ class DazzDb:
 
     def seq(self, i):
         return self.bases[self.off[i]:self.off[i + 1]]
+
+
+def dazz_write_mask(db_path, name, ptr, iv):
+    p = np.ascontiguousarray(ptr, dtype=np.int64)
+    v = np.ascontiguousarray(iv, dtype=np.int32)
+    _check(lib().dh_dazz_write_mask(db_path.encode(), name.encode(), len(p) - 1, p.ctypes.data, v.ctypes.data))

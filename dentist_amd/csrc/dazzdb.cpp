@@ -333,7 +333,7 @@ struct dh_dazz {
     std::vector<int64_t> off;
     std::vector<int32_t> origin, fpulse, uid;
     std::vector<std::string> header;  // DAM only: scaffold header of every contig
-    int32_t tfirst = 0, cutoff = 0, is_dam = 0;
+    int32_t tfirst = 0, cutoff = 0, is_dam = 0, ureads = 0, treads = 0;
     std::string root;
 };
 
@@ -399,6 +399,8 @@ extern "C" int dh_dazz_open(const char *path, dh_dazz **out)
     }
     dh_dazz *db = new dh_dazz();
     db->is_dam = is_dam;
+    db->ureads = h.ureads;
+    db->treads = h.treads;
     db->cutoff = h.cutoff;
     db->root = p.root;
     const int ulo = p.block > 0 ? blocks[(size_t)p.block - 1].first : 0;
@@ -445,4 +447,88 @@ extern "C" const int32_t *dh_dazz_fpulse(const dh_dazz *db) { return db ? db->fp
 extern "C" const char *dh_dazz_header(const dh_dazz *db, int32_t i)
 {
     return (db && i >= 0 && (size_t)i < db->header.size()) ? db->header[(size_t)i].c_str() : "";
+}
+
+// ---------------------------------------------------------------------------------- mask tracks
+// source/dentist/dazzler.d:4870-5170 (getMaskFiles / readMask / writeMask).
+
+extern "C" int dh_dazz_write_mask(const char *db_path, const char *name, int32_t nreads, const int64_t *ptr,
+                                  const int32_t *iv)
+{
+    Paths p;
+    if (!db_path || !name || !ptr || !split_path(std::string(db_path), p, true)) return dh_fail(DH_EIO, "DAZZ_DB not found");
+    if (strchr(name, '/') || strchr(name, '.')) return dh_fail(DH_EINVAL, "mask name must not contain dots or slashes");
+    FILE *an = fopen(p.hidden((std::string(name) + ".anno").c_str()).c_str(), "wb");
+    FILE *da = fopen(p.hidden((std::string(name) + ".data").c_str()).c_str(), "wb");
+    if (!an || !da) {
+        if (an) fclose(an);
+        if (da) fclose(da);
+        return dh_fail(DH_EIO, "cannot create mask files");
+    }
+    const int32_t head[2] = {nreads, 0};  // size 0 marks the track as a mask (dazzler.d:5143)
+    fwrite(head, 4, 2, an);
+    for (int32_t i = 0; i <= nreads; i++) {
+        const int64_t off = ptr[i] * 2 * (int64_t)sizeof(int32_t);
+        fwrite(&off, 8, 1, an);
+    }
+    if (ptr[nreads] > 0) fwrite(iv, 4, (size_t)(2 * ptr[nreads]), da);
+    const bool ok = fclose(an) == 0;
+    return (fclose(da) == 0 && ok) ? DH_OK : dh_fail(DH_EIO, "short write of mask files");
+}
+
+extern "C" int64_t dh_dazz_read_mask(const dh_dazz *db, const char *db_path, const char *name, int64_t *ptr,
+                                     int32_t *iv, int64_t iv_cap)
+{
+    Paths p;
+    if (!db || !db_path || !name || !ptr || !split_path(std::string(db_path), p, true)) return dh_fail(DH_EIO, "DAZZ_DB not found");
+    FILE *an = fopen(p.hidden((std::string(name) + ".anno").c_str()).c_str(), "rb");
+    FILE *da = fopen(p.hidden((std::string(name) + ".data").c_str()).c_str(), "rb");
+    if (!an || !da) {
+        if (an) fclose(an);
+        if (da) fclose(da);
+        return dh_fail(DH_EIO, std::string("mask track not found: ") + name);
+    }
+    int32_t head[2] = {0, 0};
+    if (fread(head, 4, 2, an) != 2 || head[1] != 0 || head[0] < 0) {
+        fclose(an);
+        fclose(da);
+        return dh_fail(DH_EIO, "corrupted mask: expected 0");
+    }
+    std::vector<int64_t> offs((size_t)head[0] + 1);
+    if (fread(offs.data(), 8, offs.size(), an) != offs.size()) {
+        fclose(an);
+        fclose(da);
+        return dh_fail(DH_EIO, "corrupted mask: unexpected number of data pointers");
+    }
+    fclose(an);
+    std::vector<int32_t> data;
+    {
+        int32_t buf[4096];
+        size_t got;
+        while ((got = fread(buf, 4, 4096, da)) > 0) data.insert(data.end(), buf, buf + got);
+    }
+    fclose(da);
+    // the track is stored for the whole DB: trimmed ids if it has as many entries as the trimmed DB,
+    // untrimmed ids otherwise (dazzler.d:4960-4969); the opened view knows both
+    const int32_t nview = (int32_t)db->off.size() - 1;
+    int64_t n = 0;
+    ptr[0] = 0;
+    for (int32_t i = 0; i < nview; i++) {
+        const bool untrimmed_ids = head[0] == db->ureads && db->ureads != db->treads;
+        const int64_t id = untrimmed_ids ? db->uid[(size_t)i] : (int64_t)db->tfirst + i;
+        if (id < head[0]) {
+            const int64_t a = offs[(size_t)id] / 4, b = offs[(size_t)id + 1] / 4;
+            if (a < 0 || a > b || b > (int64_t)data.size() || (a % 2) || (b % 2))
+                return dh_fail(DH_EIO, "corrupted mask: data pointer out of bounds");
+            for (int64_t x = a; x < b; x += 2) {
+                if (iv && n < iv_cap) {
+                    iv[2 * n] = data[(size_t)x];
+                    iv[2 * n + 1] = data[(size_t)x + 1];
+                }
+                n++;
+            }
+        }
+        ptr[i + 1] = n;
+    }
+    return n;
 }

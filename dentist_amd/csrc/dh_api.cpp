@@ -270,8 +270,44 @@ extern "C" void dh_db_destroy(dh_db *db)
     dh_dev_free(db->d_rc_alloc);
     dh_dev_free(db->d_off);
     dh_dev_free(db->d_group);
+    dh_dev_free(db->d_mask_ptr);
+    dh_dev_free(db->d_mask_iv);
     if (db->has_ix) db->ix.release();
     delete db;
+}
+
+// soft mask of the DB (union of the daligner -m tracks): per sequence sorted, disjoint intervals.
+// Passing ptr == NULL clears it.  The cached k-mer index is dropped.
+extern "C" int dh_db_set_mask(dh_db *db, const int64_t *ptr, const int32_t *iv)
+{
+    if (!db) return fail(DH_EINVAL, "db is NULL");
+    HIPCHK(hipSetDevice(db->ctx->device));
+    HIPCHK(hipStreamSynchronize(db->ctx->stream));
+    dh_dev_free(db->d_mask_ptr);
+    dh_dev_free(db->d_mask_iv);
+    db->d_mask_ptr = nullptr;
+    db->d_mask_iv = nullptr;
+    if (db->has_ix) db->ix.release();
+    db->has_ix = false;
+    if (!ptr) return DH_OK;
+    const int64_t m = ptr[db->n];
+    for (int32_t s = 0; s < db->n; s++) {
+        if (ptr[s] > ptr[s + 1]) return fail(DH_EINVAL, "dh_db_set_mask: pointers must be non-decreasing");
+        const int64_t len = db->h_off[(size_t)s + 1] - db->h_off[(size_t)s];
+        for (int64_t j = ptr[s]; j < ptr[s + 1]; j++)
+            if (iv[2 * j] < 0 || iv[2 * j] > iv[2 * j + 1] || iv[2 * j + 1] > len ||
+                (j > ptr[s] && iv[2 * j] < iv[2 * j - 1]))
+                return fail(DH_EINVAL, "dh_db_set_mask: intervals must be sorted, disjoint and inside the sequence");
+    }
+    HIPCHK(dh_dev_alloc(&db->d_mask_ptr, sizeof(int64_t) * (size_t)(db->n + 1)));
+    HIPCHK(dh_dev_alloc(&db->d_mask_iv, sizeof(int32_t) * (size_t)std::max<int64_t>(2 * m, 2)));
+    HIPCHK(hipMemcpyAsync(db->d_mask_ptr, ptr, sizeof(int64_t) * (size_t)(db->n + 1), hipMemcpyHostToDevice,
+                          db->ctx->stream));
+    if (m > 0)
+        HIPCHK(hipMemcpyAsync(db->d_mask_iv, iv, sizeof(int32_t) * (size_t)(2 * m), hipMemcpyHostToDevice,
+                              db->ctx->stream));
+    HIPCHK(hipStreamSynchronize(db->ctx->stream));
+    return DH_OK;
 }
 
 extern "C" int32_t dh_db_nreads(const dh_db *db) { return db ? db->n : 0; }

@@ -21,6 +21,10 @@ struct DbView {
     const int64_t *off;    // n + 1 offsets
     const int32_t *group;  // optional
     int32_t n;
+    // optional soft mask (daligner -m): sorted disjoint intervals mask_iv[2j], mask_iv[2j+1] for
+    // j in [mask_ptr[s], mask_ptr[s+1]); k-mers touching one are neither indexed nor looked up
+    const int64_t *mask_ptr;
+    const int32_t *mask_iv;
 };
 
 struct IndexView {

@@ -88,7 +88,9 @@ struct dh_db {
     std::vector<int32_t> h_group;
     dh_index ix;
     bool has_ix = false;
-    DbView view() const { return DbView{d_bases, d_off, d_group, n}; }
+    int64_t *d_mask_ptr = nullptr;
+    int32_t *d_mask_iv = nullptr;
+    DbView view() const { return DbView{d_bases, d_off, d_group, n, d_mask_ptr, d_mask_iv}; }
 };
 
 struct dh_la_set {

@@ -32,6 +32,57 @@ __device__ __forceinline__ uint64_t load8(const uint8_t *p)
     return x;
 }
 
+// ---- soft masks: cursor over the sorted intervals of one sequence, optionally mirrored for the
+// reverse-complement strand; positions are visited in increasing order by each thread
+struct MaskCur {
+    const int32_t *iv;
+    int64_t lo, n, cur;
+    int32_t len, rc;
+};
+__device__ __forceinline__ void mask_get(const MaskCur &m, int64_t j, int32_t &b, int32_t &e)
+{
+    if (!m.rc) {
+        b = m.iv[2 * (m.lo + j)];
+        e = m.iv[2 * (m.lo + j) + 1];
+    } else {
+        const int64_t o = m.lo + m.n - 1 - j;
+        b = m.len - m.iv[2 * o + 1];
+        e = m.len - m.iv[2 * o];
+    }
+}
+__device__ __forceinline__ MaskCur mask_open(const DbView &db, int32_t s, int32_t len, int32_t rc, int32_t p)
+{
+    MaskCur m;
+    m.iv = db.mask_iv;
+    m.lo = db.mask_ptr ? db.mask_ptr[s] : 0;
+    m.n = db.mask_ptr ? db.mask_ptr[s + 1] - m.lo : 0;
+    m.len = len;
+    m.rc = rc;
+    // first interval whose end is > p
+    int64_t lo = 0, hi = m.n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        int32_t b, e;
+        mask_get(m, mid, b, e);
+        if (e <= p)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    m.cur = lo;
+    return m;
+}
+__device__ __forceinline__ bool mask_touch(MaskCur &m, int32_t p, int32_t k)
+{
+    int32_t b = 0, e = 0;
+    while (m.cur < m.n) {
+        mask_get(m, m.cur, b, e);
+        if (e > p) break;
+        m.cur++;
+    }
+    return m.cur < m.n && b < p + k;
+}
+
 // ------------------------------------------------------------------------------------ K1
 
 __global__ void k_revcomp(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
@@ -69,6 +120,7 @@ k_kmer_pass(DbView A, const int2 *__restrict__ tiles, int32_t ntiles, int32_t k,
     uint64_t km = 0;
     int32_t valid = 0;
     const uint8_t *a = A.bases + o;
+    MaskCur mc = mask_open(A, s, len, 0, p0);
     for (int32_t x = 0; x < KM_TILE / 256 + k - 1; x++) {
         const int32_t p = p0 + x;
         if (p >= len) break;
@@ -80,7 +132,8 @@ k_kmer_pass(DbView A, const int2 *__restrict__ tiles, int32_t ntiles, int32_t k,
             km = 0;
             valid = 0;
         }
-        if (x >= k - 1 && valid >= k && kmer_sampled(km, kmer_mod)) {
+        if (x >= k - 1 && valid >= k && kmer_sampled(km, kmer_mod) &&
+            !(A.mask_ptr && mask_touch(mc, p - k + 1, k))) {
             const uint64_t key = (grp << (2 * k)) | km;
             const uint32_t b = (uint32_t)(key >> shift);
             if (FILL) {
@@ -261,6 +314,7 @@ k_seed(DbView B, const uint8_t *__restrict__ brc, IndexView ix, DhOpts o, int32_
         uint64_t km = 0;
         int32_t valid = 0;
         const int32_t pend = q0 < q1 ? q1 + k - 1 : q0;
+        MaskCur mc = mask_open(B, r, blen, strand, q0);
         // 8 bases per iteration: one 8-byte load of the read, 8 k-mers rolled in registers, the
         // 8 directory lookups issued back to back (memory-level parallelism), then the rare
         // non-empty buckets are resolved
@@ -283,6 +337,7 @@ k_seed(DbView B, const uint8_t *__restrict__ brc, IndexView ix, DhOpts o, int32_
                     }
                 }
                 em[u] = pp < pend && pp - q0 >= k - 1 && valid >= k && kmer_sampled(km, o.kmer_mod);
+                if (em[u] && B.mask_ptr && mask_touch(mc, pp - k + 1, k)) em[u] = false;
                 keys[u] = (grp << (2 * k)) | km;
                 bks[u] = em[u] ? (uint32_t)(keys[u] >> ix.shift) : 0u;
             }

@@ -71,6 +71,11 @@ typedef struct dh_db dh_db;
 int dh_db_create(dh_ctx *ctx, const uint8_t *bases, const int64_t *off, int32_t n,
                  const int32_t *group, dh_db **out);
 void dh_db_destroy(dh_db *db);
+/* soft mask = union of the daligner/damapper -m tracks (commandline.d:2886-2955 passes -mdust,
+ * -mdentist-self, -mtan, -mrep): per sequence sorted disjoint intervals iv[2j], iv[2j+1] for j in
+ * [ptr[s], ptr[s+1]).  k-mers touching a masked interval are neither indexed (A side) nor looked
+ * up (B side); alignments still extend through masked sequence.  ptr == NULL clears the mask. */
+int dh_db_set_mask(dh_db *db, const int64_t *ptr, const int32_t *iv);
 /* drop cached derived data (k-mer index, reverse complement): the next dh_align_db rebuilds it */
 int dh_db_drop_cache(dh_db *db);
 int32_t dh_db_nreads(const dh_db *db);
@@ -235,6 +240,14 @@ const int64_t *dh_dazz_offsets(const dh_dazz *db);    /* nreads + 1             
 const int32_t *dh_dazz_origin(const dh_dazz *db);     /* well (DB) / contig number in scaffold (DAM)*/
 const int32_t *dh_dazz_fpulse(const dh_dazz *db);     /* first pulse (DB) / contig start (DAM)      */
 const char *dh_dazz_header(const dh_dazz *db, int32_t i); /* DAM: scaffold header of contig i        */
+/* mask tracks `<dir>/.<db>.<name>.anno/.data` (source/dentist/dazzler.d:4870-5170): .anno = int32
+ * nreads, int32 size (0), int64 byte offsets[nreads + 1]; .data = int32 (begin, end) pairs.
+ * read: intervals of the opened (trimmed) view, ptr has nreads + 1 entries; returns the number of
+ * intervals or a negative error; iv may be NULL to size.  write: for the whole trimmed DB. */
+int64_t dh_dazz_read_mask(const dh_dazz *db, const char *db_path, const char *name, int64_t *ptr, int32_t *iv,
+                          int64_t iv_cap);
+int dh_dazz_write_mask(const char *db_path, const char *name, int32_t nreads, const int64_t *ptr,
+                       const int32_t *iv);
 
 #ifdef __cplusplus
 }

@@ -118,6 +118,17 @@ void oz_la_set_sort(oz_la_set *s)
 
 /* ------------------------------------------------------------------ k-mer index ------ */
 
+/* does the k-mer [p, p+k) of sequence s touch a masked interval?  *cur walks the sorted intervals
+ * of the sequence (positions are visited in increasing order) */
+static inline int kmer_masked(const oz_db *db, int32_t s, int64_t p, int k, int64_t *cur)
+{
+    if (!db->mask_ptr) return 0;
+    const int64_t end = db->mask_ptr[s + 1];
+    while (*cur < end && db->mask_iv[2 * *cur + 1] <= p) (*cur)++;
+    return *cur < end && db->mask_iv[2 * *cur] < p + k;
+}
+
+
 /* modimer sampling: the same k-mers are kept on the A and on the B side */
 static inline int kmer_sampled(uint64_t km, int32_t mod)
 {
@@ -181,6 +192,7 @@ static oz_index *index_build(const oz_db *A, const oz_opts *o, int32_t max_blen)
         uint64_t grp = A->group ? (uint64_t)A->group[s] : 0;
         uint64_t km = 0;
         int valid = 0;
+        int64_t mcur = A->mask_ptr ? A->mask_ptr[s] : 0;
         for (int64_t p = 0; p < len; p++) {
             if (a[p] < 4) {
                 km = ((km << 2) | a[p]) & mask;
@@ -189,7 +201,7 @@ static oz_index *index_build(const oz_db *A, const oz_opts *o, int32_t max_blen)
                 valid = 0;
                 km = 0;
             }
-            if (valid >= k && kmer_sampled(km, o->kmer_mod)) {
+            if (valid >= k && kmer_sampled(km, o->kmer_mod) && !kmer_masked(A, s, p - k + 1, k, &mcur)) {
                 ix->e[n].key = (grp << (2 * k)) | km;
                 ix->e[n].aseq = s;
                 ix->e[n].apos = (int32_t)(p - k + 1);
@@ -277,14 +289,27 @@ static int cand_cmp(const void *x, const void *y)
 #define HIT_QBITS 24
 #define HIT_QMASK ((1u << HIT_QBITS) - 1)
 
+/* bmask/nbmask: sorted masked intervals of this B sequence in the orientation of `b` (or NULL) */
+static int seed_candidates(const oz_index *ix, const uint8_t *b, int32_t blen, int32_t bgroup,
+                           int32_t bself, const int32_t *bmask, int64_t nbmask, const oz_opts *o,
+                           oz_cand *out, int32_t *nhits_out);
+
 int oz_seed_candidates(const oz_index *ix, const oz_db *A, const uint8_t *b, int32_t blen,
                        int32_t bgroup, int32_t bself, int32_t sepv_unused, const oz_opts *o,
                        oz_cand *out, int32_t *nhits_out)
 {
     (void)A;
     (void)sepv_unused;
+    return seed_candidates(ix, b, blen, bgroup, bself, NULL, 0, o, out, nhits_out);
+}
+
+static int seed_candidates(const oz_index *ix, const uint8_t *b, int32_t blen, int32_t bgroup,
+                           int32_t bself, const int32_t *bmask, int64_t nbmask, const oz_opts *o,
+                           oz_cand *out, int32_t *nhits_out)
+{
     const int k = o->k;
     const int32_t sepv = ix->sepv;
+    int64_t bcur = 0;
     const uint64_t mask = (1ull << (2 * k)) - 1;
     int64_t cap = 1024, n = 0;
     uint64_t *hits = (uint64_t *)malloc((size_t)cap * sizeof(uint64_t));
@@ -300,6 +325,10 @@ int oz_seed_candidates(const oz_index *ix, const oz_db *A, const uint8_t *b, int
         }
         if (valid < k || !kmer_sampled(km, o->kmer_mod)) continue;
         const int32_t q = p - k + 1;
+        if (bmask) {
+            while (bcur < nbmask && bmask[2 * bcur + 1] <= q) bcur++;
+            if (bcur < nbmask && bmask[2 * bcur] < q + k) continue;
+        }
         const uint64_t key = ((uint64_t)bgroup << (2 * k)) | km;
         int64_t s = ix_lower(ix, key), e = s;
         while (e < ix->n && ix->e[e].key == key) e++;
@@ -694,7 +723,24 @@ static void align_read(const oz_index *ix, const oz_db *A, const oz_db *B, int32
             b = rc;
         }
         int32_t nh = 0;
-        int nc = oz_seed_candidates(ix, A, b, blen, bgroup, r, 0, o, cands, &nh);
+        /* mask of this B read in the orientation of the strand (mirrored for the complement) */
+        const int32_t *bm = NULL;
+        int64_t nbm = 0;
+        int32_t *tmpm = NULL;
+        if (B->mask_ptr) {
+            nbm = B->mask_ptr[r + 1] - B->mask_ptr[r];
+            bm = B->mask_iv + 2 * B->mask_ptr[r];
+            if (strand && nbm > 0) {
+                tmpm = (int32_t *)malloc((size_t)nbm * 2 * sizeof(int32_t));
+                for (int64_t x = 0; x < nbm; x++) {
+                    tmpm[2 * x] = blen - bm[2 * (nbm - 1 - x) + 1];
+                    tmpm[2 * x + 1] = blen - bm[2 * (nbm - 1 - x)];
+                }
+                bm = tmpm;
+            }
+        }
+        int nc = seed_candidates(ix, b, blen, bgroup, r, bm, nbm, o, cands, &nh);
+        free(tmpm);
         stats[0] += nh;
         stats[1] += nc;
         region done[64];

@@ -37,6 +37,11 @@ typedef struct {
     const int64_t *off;   /* off[n+1] offsets into bases                           */
     const uint8_t *bases; /* codes 0..4                                            */
     const int32_t *group; /* optional group id per sequence (NULL = all group 0)   */
+    /* optional soft mask (daligner -m tracks): intervals mask_iv[2*j], mask_iv[2*j+1] for
+     * j in [mask_ptr[s], mask_ptr[s+1]) of sequence s, sorted, disjoint; k-mers touching a
+     * masked interval are neither indexed nor looked up */
+    const int64_t *mask_ptr;
+    const int32_t *mask_iv;
 } oz_db;
 
 void oz_encode(const char *ascii, int64_t n, uint8_t *codes);

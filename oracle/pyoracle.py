@@ -37,7 +37,7 @@ class LaSet(ctypes.Structure):
 
 class Db(ctypes.Structure):
     _fields_ = [("n", ctypes.c_int32), ("off", ctypes.c_void_p), ("bases", ctypes.c_void_p),
-                ("group", ctypes.c_void_p)]
+                ("group", ctypes.c_void_p), ("mask_ptr", ctypes.c_void_p), ("mask_iv", ctypes.c_void_p)]
 
 
 _LIB = None
@@ -98,6 +98,10 @@ def _db(seqdb):
     d.off = seqdb.off.ctypes.data
     d.bases = seqdb.bases.ctypes.data
     d.group = seqdb.group.ctypes.data if seqdb.group is not None else None
+    mask = getattr(seqdb, "mask", None)   # (ptr int64[n+1], iv int32[2m]) or None
+    if mask is not None:
+        d.mask_ptr = mask[0].ctypes.data
+        d.mask_iv = mask[1].ctypes.data
     return d
 
 

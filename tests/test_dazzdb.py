@@ -71,3 +71,28 @@ def test_db_with_pacbio_headers_and_blocks(tmp_path):
         assert np.array_equal(db.seq(i), rd.seq(i))
     with open(path) as f:
         assert f.readline().startswith("files =")
+
+
+def test_mask_track_files_follow_the_reference_layout(tmp_path):
+    """writeMask / readMask, source/dentist/dazzler.d:4943-5170: .anno = int32 nreads, int32 0,
+    int64 byte offsets[nreads + 1]; .data = int32 (begin, end) pairs; files `.<db>.<mask>.anno/.data`."""
+    import struct
+    g = sim.genome(9, 3000)
+    text = ">a\n" + sim.decode(g[:1000]) + "\n>b\n" + sim.decode(g[1000:1010]) + "\n>c\n" + sim.decode(g[1010:]) + "\n"
+    path = str(tmp_path / "ref.dam")
+    dentist_amd.dazz_create_dam(path, text)
+    dentist_amd.dazz_split(path, cutoff=20)            # hides the 10 bp contig `b`
+    ptr = np.asarray([0, 2, 2, 3], dtype=np.int64)     # written for the untrimmed DB (3 contigs)
+    iv = np.asarray([10, 50, 700, 800, 5, 25], dtype=np.int32)
+    dentist_amd.dazz_write_mask(path, "dentist-self", ptr, iv)
+    anno = open(tmp_path / ".ref.dentist-self.anno", "rb").read()
+    data = open(tmp_path / ".ref.dentist-self.data", "rb").read()
+    assert struct.unpack("<ii", anno[:8]) == (3, 0)
+    assert struct.unpack("<4q", anno[8:]) == (0, 16, 16, 24)
+    assert struct.unpack("<6i", data) == (10, 50, 700, 800, 5, 25)
+    db = dentist_amd.DazzDb(path)                        # trimmed view: contigs a and c
+    p2, iv2 = db.read_mask("dentist-self")
+    assert p2.tolist() == [0, 2, 3] and iv2.tolist() == [10, 50, 700, 800, 5, 25]
+    import pytest
+    with pytest.raises(dentist_amd.DhError):
+        db.read_mask("missing")

@@ -78,6 +78,37 @@ def test_long_b_sequences_use_the_hbm_staged_seed_path(gpu_ctx):
     assert len(las) > 100
 
 
+def test_soft_masks_exclude_seeds_on_both_sides(gpu_ctx):
+    """daligner/damapper -m<track>: k-mers touching a masked interval are neither indexed (A) nor
+    looked up (B, mirrored for the complement strand); alignments still extend through the mask."""
+    w = sim.Workload(200_000, 2, 300, 5000, seed=43, spacing=15000)
+    rng = np.random.default_rng(5)
+
+    def random_mask(db, frac):
+        ptr, iv = [0], []
+        for i in range(db.n):
+            n, pos = db.length(i), 0
+            while True:
+                pos += int(rng.integers(200, 3000))
+                ln = int(rng.integers(20, int(3000 * frac) + 30))
+                if pos + ln >= n:
+                    break
+                iv += [pos, pos + ln]
+                pos += ln
+            ptr.append(len(iv) // 2)
+        return np.asarray(ptr, dtype=np.int64), np.asarray(iv + [0, 0], dtype=np.int32)
+
+    w.contigs.mask = random_mask(w.contigs, 0.5)
+    w.reads.mask = random_mask(w.reads, 0.3)
+    plain_hits = None
+    las, _ = run_both(gpu_ctx, w.contigs, w.reads)
+    masked_hits = gpu_ctx.align_stats().hits
+    w.contigs.mask = w.reads.mask = None
+    run_both(gpu_ctx, w.contigs, w.reads)
+    assert masked_hits < 0.8 * gpu_ctx.align_stats().hits
+    assert len(set(las["bread"].tolist())) >= 0.95 * w.reads.n
+
+
 def pile(seed, glen=20000, n=30, rl=6000):
     g = sim.genome(seed, glen)
     reads, _ = sim.reads(seed + 1, g, n, rl)

@@ -49,6 +49,23 @@ def test_damapper_executable_matches_the_library(gpu_ctx, tmp_path):
     assert os.path.exists(tmp_path / "reads.1.ref.las")
     back, _, _ = dentist_amd.las_read(str(tmp_path / "reads.1.ref.las"))
     assert len(back) > 0 and set(back["aread"].tolist()) <= set(range(w.reads.n))
+    # -m<track>: an existing track is applied (fewer seeds, same reads mapped), a missing one is reported
+    db = dentist_amd.DazzDb(ref)
+    ptr = np.zeros(db.n + 1, dtype=np.int64)
+    iv = []
+    for i in range(db.n):
+        iv += [1000, 1400, 5000, 5600]
+        ptr[i + 1] = len(iv) // 2
+    dentist_amd.dazz_write_mask(ref, "dentist-self", ptr, np.asarray(iv, dtype=np.int32))
+    r = subprocess.run([os.path.join(ROOT, "tools", "damapper"), "-T1", "-e0.7", "-mdentist-self", "-mtan", "ref", "reads.1"],
+                       cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "`tan` not found for ref" in r.stderr and "`dentist-self` not found for ref" not in r.stderr, r.stderr
+    w.contigs.mask = (ptr, np.asarray(iv, dtype=np.int32))
+    Am = gpu_ctx.db(w.contigs)
+    expm = gpu_ctx.align_db(Am, B, dentist_amd.default_align_opts(), select_best=True)
+    lasm, tracem, _ = dentist_amd.las_read(str(tmp_path / "ref.reads.1.las"))
+    assert_same_las((lasm, tracem), expm)
     # a missing DB is an error with a non-zero exit status (DazzlerCommandException, dazzler.d:6586-6591)
     r = subprocess.run([os.path.join(ROOT, "tools", "damapper"), "-C", "nope", "reads.1"], cwd=tmp_path,
                        capture_output=True, text=True)

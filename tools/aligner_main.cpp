@@ -3,9 +3,10 @@
 // DENTIST spawns these tools by name with cwd = output directory and absolute (or stub) DB
 // arguments and then expects `<A>.<B>.las` next to it (source/dentist/dazzler.d:6121-6170,
 // getLasFile :4339-4354; literal instance tests/test-commands.sh:190-197).  The flag subset DENTIST
-// emits is parsed (source/dentist/commandline.d:2886-2955); unknown -m tracks
-// are accepted and reported (masks are not applied yet).  The mode is chosen
+// emits is parsed (source/dentist/commandline.d:2886-2955); -m<track> loads the
+// mask files DENTIST writes (dazzler.d:4870-5170) and excludes masked k-mers from seeding.  The mode is chosen
 // by argv[0] (daligner | damapper) or `--mode`.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -43,12 +44,62 @@ static std::string las_name_part(const std::string &arg)
     return s;
 }
 
-static OpenDb open_db(dh_ctx *ctx, const std::string &arg)
+// union of the -m tracks that exist for this DB (a missing track is reported and skipped, the
+// way daligner treats a track that was never computed for a block)
+static void apply_masks(const std::string &arg, OpenDb &o, const std::vector<std::string> &tracks)
+{
+    const int32_t n = dh_dazz_nreads(o.dz);
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> per((size_t)n);
+    bool any = false;
+    for (const std::string &t : tracks) {
+        std::vector<int64_t> ptr((size_t)n + 1);
+        const int64_t m = dh_dazz_read_mask(o.dz, arg.c_str(), t.c_str(), ptr.data(), nullptr, 0);
+        if (m < 0) {
+            fprintf(stderr, "mask track `%s` not found for %s: skipped\n", t.c_str(), arg.c_str());
+            continue;
+        }
+        std::vector<int32_t> iv((size_t)std::max<int64_t>(2 * m, 2));
+        dh_dazz_read_mask(o.dz, arg.c_str(), t.c_str(), ptr.data(), iv.data(), m);
+        for (int32_t i = 0; i < n; i++)
+            for (int64_t j = ptr[(size_t)i]; j < ptr[(size_t)i + 1]; j++) per[(size_t)i].push_back({iv[(size_t)(2 * j)], iv[(size_t)(2 * j + 1)]});
+        any = true;
+    }
+    if (!any) return;
+    std::vector<int64_t> ptr((size_t)n + 1, 0);
+    std::vector<int32_t> iv;
+    for (int32_t i = 0; i < n; i++) {
+        auto &v = per[(size_t)i];
+        std::sort(v.begin(), v.end());
+        int32_t cb = -1, ce = -1;
+        for (auto &x : v) {
+            if (cb >= 0 && x.first <= ce) {
+                ce = std::max(ce, x.second);
+                continue;
+            }
+            if (cb >= 0) {
+                iv.push_back(cb);
+                iv.push_back(ce);
+            }
+            cb = x.first;
+            ce = x.second;
+        }
+        if (cb >= 0) {
+            iv.push_back(cb);
+            iv.push_back(ce);
+        }
+        ptr[(size_t)i + 1] = (int64_t)iv.size() / 2;
+    }
+    iv.push_back(0);
+    CHK(dh_db_set_mask(o.dev, ptr.data(), iv.data()));
+}
+
+static OpenDb open_db(dh_ctx *ctx, const std::string &arg, const std::vector<std::string> &tracks)
 {
     OpenDb o;
     o.name = las_name_part(arg);
     CHK(dh_dazz_open(arg.c_str(), &o.dz));
     CHK(dh_db_create(ctx, dh_dazz_bases(o.dz), dh_dazz_offsets(o.dz), dh_dazz_nreads(o.dz), nullptr, &o.dev));
+    if (!tracks.empty()) apply_masks(arg, o, tracks);
     return o;
 }
 
@@ -73,7 +124,7 @@ int main(int argc, char **argv)
     dh_default_align_opts(&o);
     bool flagA = false, flagI = false, flagC = false, verbose = false;
     double e = 0.7;
-    std::vector<std::string> dbs;
+    std::vector<std::string> dbs, tracks;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         if (a == "--mode" && i + 1 < argc) {
@@ -98,7 +149,7 @@ int main(int argc, char **argv)
         case 'I': flagI = true; break;
         case 'C': flagC = true; break;
         case 'v': verbose = true; break;
-        case 'm': fprintf(stderr, "%s: mask track `%s` accepted, not applied\n", mode.c_str(), v); break;
+        case 'm': tracks.push_back(v); break;
         case 'B': case 'b': case 'p': case 'T': case 'P': case 'M': case 'n': case 'z': case 'H': break;
         default: die(mode + ": unknown option " + a);
         }
@@ -112,10 +163,10 @@ int main(int argc, char **argv)
 
     dh_ctx *ctx = nullptr;
     CHK(dh_ctx_create(0, nullptr, &ctx));
-    OpenDb A = open_db(ctx, dbs[0]);
+    OpenDb A = open_db(ctx, dbs[0], tracks);
     for (size_t bi = 1; bi < dbs.size(); bi++) {
         const bool same = las_name_part(dbs[bi]) == A.name;
-        OpenDb B = same ? A : open_db(ctx, dbs[bi]);
+        OpenDb B = same ? A : open_db(ctx, dbs[bi], tracks);
         dh_align_opts oo = o;
         oo.skip_self = (same && !flagI) ? 1 : 0;
         dh_la_set *ab = nullptr;
