@@ -36,6 +36,29 @@ k_gather_slices(const uint8_t *__restrict__ src, const int64_t *__restrict__ src
         dst[d0 + i] = src[so + i];
 }
 
+// multi-part gather: every output sequence is the concatenation of parts taken from one of two
+// source DBs, optionally reverse-complemented (cropped read + contig support patches)
+struct PartDesc {
+    int32_t src, sidx, sbeg, len, rc, pad;
+    int64_t dst;
+};
+
+__global__ void __launch_bounds__(256)
+k_gather_parts(const uint8_t *__restrict__ src0, const int64_t *__restrict__ off0,
+               const uint8_t *__restrict__ src1, const int64_t *__restrict__ off1,
+               const PartDesc *__restrict__ parts, int32_t n, uint8_t *__restrict__ dst)
+{
+    const int32_t p = blockIdx.y;
+    if (p >= n) return;
+    const PartDesc d = parts[p];
+    const uint8_t *s = (d.src ? src1 + off1[d.sidx] : src0 + off0[d.sidx]) + d.sbeg;
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < d.len; i += gridDim.x * blockDim.x) {
+        uint8_t c = d.rc ? s[d.len - 1 - i] : s[i];
+        if (d.rc && c < 4) c = (uint8_t)(3 - c);
+        dst[d.dst + i] = c;
+    }
+}
+
 // ------------------------------------------------------------------------------------ K7
 
 // las sorted by aread; la_first[r] .. la_first[r+1] are the LAs with aread == r.
@@ -382,6 +405,19 @@ void dhk_gather_slices(hipStream_t st, const uint8_t *src, const int64_t *src_of
         const int32_t cnt = n - s0 < 65535 ? n - s0 : 65535;
         hipLaunchKernelGGL(k_gather_slices, dim3(gx, cnt), dim3(256), 0, st, src, src_off, sidx + s0,
                            sbeg + s0, dst_off + s0, cnt, dst);
+    }
+}
+
+void dhk_gather_parts(hipStream_t st, const uint8_t *src0, const int64_t *off0, const uint8_t *src1,
+                      const int64_t *off1, const void *parts, int32_t n, int32_t max_len, uint8_t *dst)
+{
+    if (n <= 0) return;
+    int gx = (max_len + 255) / 256;
+    gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+    for (int32_t s0 = 0; s0 < n; s0 += 65535) {
+        const int32_t cnt = n - s0 < 65535 ? n - s0 : 65535;
+        hipLaunchKernelGGL(k_gather_parts, dim3(gx, cnt), dim3(256), 0, st, src0, off0, src1, off1,
+                           (const PartDesc *)parts + s0, cnt, dst);
     }
 }
 

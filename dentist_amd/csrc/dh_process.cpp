@@ -22,6 +22,8 @@ extern "C" {
 void dhk_gather_slices(hipStream_t st, const uint8_t *src, const int64_t *src_off, const int32_t *sidx,
                        const int32_t *sbeg, const int64_t *dst_off, int32_t n, int32_t max_len,
                        uint8_t *dst);
+void dhk_gather_parts(hipStream_t st, const uint8_t *src0, const int64_t *off0, const uint8_t *src1,
+                      const int64_t *off1, const void *parts, int32_t n, int32_t max_len, uint8_t *dst);
 void dhk_tile_qv(hipStream_t st, const DhLa *las, const uint16_t *trace, const int32_t *la_first,
                  const int64_t *roff, int32_t nreads, int32_t tspace, const int32_t *cov, int32_t maxtiles,
                  uint8_t *qv);
@@ -37,6 +39,11 @@ void dhk_emit(hipStream_t st, DbView T, int32_t ntmpl, const int64_t *voff, cons
 #define VSTRIDE (6 + 4 * MAXINS)
 #define MAXQV 50
 #define SEG_MAX 250
+
+struct PartDescH {
+    int32_t src, sidx, sbeg, len, rc, pad;
+    int64_t dst;
+};
 
 struct SegDescH {
     int32_t tmpl, a0, a1, bseq, b0, b1, comp, pad;
@@ -540,10 +547,15 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
 
     HIPCHK(hipEventRecord(ev[0], st));
     // ---- 1. crop every pile-up to its common trace points; collect the slices of the reads
-    std::vector<int32_t> sidx, sbeg, slen, sgroup;  // slices of `reads` -> pile-up DB
+    // every pile-up read = [support patch] + read slice + [support patch]; parts are gathered on
+    // the device from the reads DB (src 0) and the contigs DB (src 1)
+    std::vector<PartDescH> parts;
+    std::vector<int64_t> poff{0};                    // offsets of the pile-up DB sequences
+    std::vector<int32_t> sgroup;
     std::vector<int32_t> pile_of_active;             // active index -> pile-up index
     std::vector<int32_t> first_read;                 // active index -> first read in pile-up DB
     std::vector<int32_t> read_id;                    // pile-up DB read -> read id in `reads`
+    int32_t pile_max_len = 0;
     for (int32_t p = 0; p < np; p++) {
         dh_insertion &r = res->rec[(size_t)p];
         memset(&r, 0, sizeof(r));
@@ -571,7 +583,17 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
             r.status = DH_PILE_NO_COMMON_TRACE_POINT;
             continue;
         }
-        const size_t mark = sidx.size();
+        // fetchSupportPatches, cropper.d:224-262
+        int32_t lp0 = 0, lp1 = 0, rp0 = 0, rp1 = 0;
+        if (cll - cropL < o.min_anchor) {
+            lp0 = std::max(0, cll - o.min_anchor);
+            lp1 = cropL;
+        }
+        if (cropR < o.min_anchor) {
+            rp0 = cropR;
+            rp1 = std::min(clr, o.min_anchor);
+        }
+        const size_t mark_parts = parts.size(), mark_seqs = poff.size();
         for (int32_t e = 0; e < ne; e++) {
             const int32_t rd = tr3[(size_t)e * 3];
             const dh_la &L = las[tr3[(size_t)e * 3 + 1]], &R = las[tr3[(size_t)e * 3 + 2]];
@@ -579,37 +601,66 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
             const int32_t bR = translate_floor_b(R, trace + R.toff, tsm, cropR);
             const int32_t rl = (int32_t)(reads->h_off[(size_t)rd + 1] - reads->h_off[(size_t)rd]);
             int32_t b0 = bL, b1 = bR;
-            if (L.flags & DH_FLAG_COMP) {  // getCroppingSlice, cropper.d:533-538
+            const bool comp = (L.flags & DH_FLAG_COMP) != 0;
+            if (comp) {  // getCroppingSlice, cropper.d:533-538
                 b0 = rl - bR;
                 b1 = rl - bL;
             }
             if (b1 - b0 < 14) continue;  // records shorter than 14 bp are dropped (dazzler.d:150)
-            sidx.push_back(rd);
-            sbeg.push_back(b0);
-            slen.push_back(b1 - b0);
+            int64_t dst = poff.back();
+            // getSingleReadPatch, cropper.d:363-378: complement reads get the reverse-complemented
+            // patches in swapped positions
+            const int32_t pre_c = comp ? g + 1 : g, pre0 = comp ? rp0 : lp0, pre1 = comp ? rp1 : lp1;
+            const int32_t post_c = comp ? g : g + 1, post0 = comp ? lp0 : rp0, post1 = comp ? lp1 : rp1;
+            if (pre1 > pre0) {
+                parts.push_back(PartDescH{1, pre_c, pre0, pre1 - pre0, comp ? 1 : 0, 0, dst});
+                dst += pre1 - pre0;
+            }
+            parts.push_back(PartDescH{0, rd, b0, b1 - b0, 0, 0, dst});
+            dst += b1 - b0;
+            if (post1 > post0) {
+                parts.push_back(PartDescH{1, post_c, post0, post1 - post0, comp ? 1 : 0, 0, dst});
+                dst += post1 - post0;
+            }
+            pile_max_len = std::max<int32_t>(pile_max_len, (int32_t)(dst - poff.back()));
+            poff.push_back(dst);
+            read_id.push_back(rd);
         }
-        const int32_t cnt = (int32_t)(sidx.size() - mark);
+        const int32_t cnt = (int32_t)(poff.size() - mark_seqs);
         r.nreads = cnt;
         if (cnt < 3) {
             r.status = DH_PILE_TOO_SMALL;
-            sidx.resize(mark);
-            sbeg.resize(mark);
-            slen.resize(mark);
+            parts.resize(mark_parts);
+            poff.resize(mark_seqs);
+            read_id.resize(mark_seqs - 1);
             continue;
         }
         const int32_t a = (int32_t)pile_of_active.size();
         pile_of_active.push_back(p);
-        first_read.push_back((int32_t)mark);
-        for (size_t x = mark; x < sidx.size(); x++) {
-            sgroup.push_back(a);
-            read_id.push_back(sidx[x]);
-        }
+        first_read.push_back((int32_t)mark_seqs - 1);
+        for (int32_t x = 0; x < cnt; x++) sgroup.push_back(a);
     }
     const int32_t na = (int32_t)pile_of_active.size();
-    first_read.push_back((int32_t)sidx.size());
+    first_read.push_back((int32_t)poff.size() - 1);
     dh_db *pile = nullptr;
-    if (int rc = dh_db_from_slices(ctx, reads, sidx, sbeg, slen, sgroup, &pile)) return rc;
-    dbg.dbs.push_back(pile);
+    {
+        uint8_t *d_alloc = nullptr, *d_bases = nullptr;
+        if (int rc = dh_alloc_bases(st, poff.back(), &d_alloc, &d_bases)) return rc;
+        if (int rc = dh_db_adopt(ctx, d_alloc, d_bases, poff, sgroup, &pile)) {
+            dh_dev_free(d_alloc);
+            return rc;
+        }
+        dbg.dbs.push_back(pile);
+        if (!parts.empty()) {
+            DevBuf<PartDescH> d_parts;
+            HIPCHK(d_parts.alloc(parts.size()));
+            HIPCHK(hipMemcpyAsync(d_parts.p, parts.data(), sizeof(PartDescH) * parts.size(), hipMemcpyHostToDevice, st));
+            dhk_gather_parts(st, reads->d_bases, reads->d_off, contigs->d_bases, contigs->d_off, d_parts.p,
+                             (int32_t)parts.size(), pile_max_len, d_bases);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(st));
+        }
+    }
     HIPCHK(hipEventRecord(ev[1], st));
     if (int rc = elapsed(0, 1, ps.ms[0])) return rc;
     lap("crop + pile DB");

@@ -80,6 +80,11 @@ def crop_pile(entries, las, trace, contigs, reads, g, ts_map=100):
     cropR = common_trace_point([(int(r["abpos"]), int(r["aepos"])) for r in right], contigs.length(g + 1), ts_map, True)
     if cropL < 0 or cropR < 0:
         return None
+    # fetchSupportPatches (cropper.d:224-262): if less than minAnchorLength of a flank remains after
+    # cropping, the missing piece of the contig is glued to every cropped read
+    cl, cr = contigs.seq(g), contigs.seq(g + 1)
+    left_patch = cl[max(0, len(cl) - MIN_ANCHOR):cropL] if len(cl) - cropL < MIN_ANCHOR else cl[0:0]
+    right_patch = cr[cropR:MIN_ANCHOR] if cropR < MIN_ANCHOR else cr[0:0]
     seqs, ids = [], []
     for (r, iL, iR) in entries:
         L, R = las[iL], las[iR]
@@ -88,11 +93,13 @@ def crop_pile(entries, las, trace, contigs, reads, g, ts_map=100):
         rl = reads.length(r)
         if L["flags"] & 1:          # getCroppingSlice: complement -> swap and mirror (cropper.d:533-538)
             b0, b1 = rl - bR, rl - bL
+            pre, post = revcomp(right_patch), revcomp(left_patch)   # getSingleReadPatch, cropper.d:363-378
         else:
             b0, b1 = bL, bR
+            pre, post = left_patch, right_patch
         if b1 - b0 < 14:
             continue
-        seqs.append(reads.seq(r)[b0:b1].copy())
+        seqs.append(np.concatenate([pre, reads.seq(r)[b0:b1], post]).astype(np.uint8))
         ids.append(r)
     return cropL, cropR, SeqDb.from_list(seqs), ids
 
