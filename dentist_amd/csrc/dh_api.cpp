@@ -517,6 +517,7 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
     if (o.pen < 2) return fail(DH_EINVAL, "pen must be >= 2");
     if (o.band_shift < 1 || o.band_shift > 12) return fail(DH_EINVAL, "band_shift out of range");
     if (o.skip_self && A != B) return fail(DH_EINVAL, "skip_self needs A == B");
+    if (o.skip_self < 0 || o.skip_self > 2) return fail(DH_EINVAL, "skip_self must be 0, 1 or 2");
     if (o.kmer_mod < 1 || o.kmer_mod > 64) return fail(DH_EINVAL, "kmer_mod must be in [1, 64]");
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -561,6 +562,8 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
                                                       std::max<int64_t>(nitems_total, 1));
     int32_t chunk = 1 << 18;
     if (const char *e = getenv("DH_ALIGN_CHUNK")) chunk = std::max(2, atoi(e)) & ~1;
+    // symmetric mode writes records into the slots of other items: everything is one chunk
+    if (o.skip_self == 2) chunk = (int32_t)std::min<int64_t>(std::max<int64_t>(nitems_total, 2), INT32_MAX - 1);
 
     const int32_t cn = (int32_t)std::min<int64_t>(chunk, std::max<int64_t>(nitems_total, 2));
     DhCand *d_cand;
@@ -579,7 +582,7 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
     SCR(4, d_nla, cn + 1)
     SCR(5, d_ntr, cn + 1)
     SCR(6, d_pool, (size_t)nslots * poolcap)
-    SCR(7, d_cdj, (size_t)nslots * 4 * nbmax)
+    SCR(7, d_cdj, (size_t)nslots * 8 * nbmax)
     SCR(8, d_queue, 4)
     SCR(9, d_la, (size_t)cn * o.max_la)
     SCR(10, d_trslots, (size_t)cn * o.max_la * trmax)
@@ -655,6 +658,9 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
         }
         HIPCHK(hipEventRecord(ctx->ev[3], st));
         HIPCHK(hipMemsetAsync(d_queue, 0, sizeof(uint32_t), st));
+        // symmetric mode claims slots with atomics: every counter starts at zero
+        HIPCHK(hipMemsetAsync(d_nla, 0, sizeof(uint32_t) * (size_t)(o.skip_self == 2 ? ni + 1 : 0), st));
+        HIPCHK(hipMemsetAsync(d_ntr, 0, sizeof(uint32_t) * (size_t)(o.skip_self == 2 ? ni + 1 : 0), st));
         HIPCHK(hipMemsetAsync(d_nla + ni, 0, sizeof(uint32_t), st));
         HIPCHK(hipMemsetAsync(d_ntr + ni, 0, sizeof(uint32_t), st));
         WaveScratch ws{d_pool, d_cdj, d_queue, poolcap, nbmax};

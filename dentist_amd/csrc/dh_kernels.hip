@@ -363,7 +363,10 @@ k_seed(DbView B, const uint8_t *__restrict__ brc, IndexView ix, DhOpts o, int32_
                 for (uint32_t t = s; t < f; t++) {
                     const uint64_t v = ix.eval[t];
                     const int32_t aseq = (int32_t)(v >> 40);
-                    if (o.skip_self && aseq == r) continue;
+                    if (o.skip_self == 1 && aseq == r) continue;
+                    // symmetric: each unordered pair once; which read plays B alternates with the
+                    // parity of a + b, so every read is B for about half of its partners
+                    if (o.skip_self == 2 && (aseq == r || ((aseq < r) != (((aseq + r) & 1) == 0)))) continue;
                     const int64_t gv = (int64_t)(v & ((1ull << 40) - 1));
                     const int64_t D = gv + ix.sepv - q;
                     const int32_t slot = atomicAdd(&s_n, 1);
@@ -542,32 +545,36 @@ __device__ __forceinline__ void slide(const uint8_t *__restrict__ ap, int32_t an
 }
 
 struct ExtResult {
-    int32_t i, j, d, head, nb;
+    int32_t i, j, d, head, nb, headb, nbb;
 };
 
 // One-directional greedy extension by one wavefront; lane (k & 63) owns diagonal k.
-// All lanes execute every shuffle; per-lane state: R (furthest i, -1 = dead) and H (trace head).
-template <int STEP>
+// All lanes execute every cross-lane operation.  SYM additionally records the crossings of the
+// B-offsets tpb_first + m*ts (value = i when j first reaches the boundary): the same path then
+// also yields the trace of the transposed record (symmetric all-vs-all, each pair aligned once).
+template <int STEP, bool SYM>
 __device__ ExtResult ext_wave(const uint8_t *__restrict__ ap, int32_t an,
-                              const uint8_t *__restrict__ bp, int32_t bn,
-                              int32_t tp_first, const DhOpts &o, DhNode *__restrict__ pool,
+                              const uint8_t *__restrict__ bp, int32_t bn, int32_t tp_first,
+                              int32_t tpb_first, const DhOpts &o, DhNode *__restrict__ pool,
                               int32_t poolcap, int32_t &pool_n, unsigned long long &cells,
                               int32_t &err)
 {
     const int lane = threadIdx.x & (LANES - 1);
     const int32_t ts = o.tspace, pen = o.pen, xdrop = o.xdrop;
     // per-lane state of diagonal k: R = furthest i (-1 dead), H = head of its trace chain,
-    // NB = number of trace boundaries <= R (carried along so that no division is needed)
-    int32_t R = -1, H = -1, NB = 0;
+    // NB = number of trace boundaries <= R (carried along so that no division is needed);
+    // HB / NBB the same for the B-offset boundaries (SYM only)
+    int32_t R = -1, H = -1, NB = 0, HB = -1, NBB = 0;
     int32_t L = 0, U = 0;
 
     // d = 0: the seed diagonal, slid by lane 0
-    int32_t i0 = 0, h0 = -1, nb0 = 0;
+    int32_t i0 = 0, h0 = -1, nb0 = 0, hb0 = -1, nbb0 = 0;
     if (lane == 0) {
         int32_t j0 = 0;
         slide<STEP>(ap, an, bp, bn, i0, j0);
+        int32_t cnt = 0;
         for (int32_t nextb = tp_first; nextb <= i0; nextb += ts) {
-            const int32_t idx = pool_n + nb0;
+            const int32_t idx = pool_n + cnt;
             if (idx < poolcap) {
                 pool[idx].parent = h0;
                 pool[idx].d = 0;
@@ -575,18 +582,36 @@ __device__ ExtResult ext_wave(const uint8_t *__restrict__ ap, int32_t an,
             }
             h0 = idx;
             nb0++;
+            cnt++;
         }
+        if (SYM)
+            for (int32_t nextb = tpb_first; nextb <= i0; nextb += ts) {
+                const int32_t idx = pool_n + cnt;
+                if (idx < poolcap) {
+                    pool[idx].parent = hb0;
+                    pool[idx].d = 0;
+                    pool[idx].j = nextb;
+                }
+                hb0 = idx;
+                nbb0++;
+                cnt++;
+            }
         R = i0;
         H = h0;
         NB = nb0;
+        HB = hb0;
+        NBB = nbb0;
     }
     // wave-uniform values are pinned to SGPRs (readfirstlane) so that the window arithmetic,
     // mask rotations and find-first-set below run on the scalar unit
     i0 = __builtin_amdgcn_readfirstlane(i0);
     h0 = __builtin_amdgcn_readfirstlane(h0);
     nb0 = __builtin_amdgcn_readfirstlane(nb0);
-    pool_n = __builtin_amdgcn_readfirstlane(pool_n + nb0);
+    hb0 = __builtin_amdgcn_readfirstlane(hb0);
+    nbb0 = __builtin_amdgcn_readfirstlane(nbb0);
+    pool_n = __builtin_amdgcn_readfirstlane(pool_n + nb0 + nbb0);
     int32_t best_score = 2 * i0, best_i = i0, best_k = 0, best_d = 0, best_head = h0, best_nb = nb0;
+    int32_t best_headb = hb0, best_nbb = nbb0;
     unsigned long long ncell = 1;
 
     for (int32_t d = 1; d <= o.dmax; d++) {
@@ -596,9 +621,16 @@ __device__ ExtResult ext_wave(const uint8_t *__restrict__ ap, int32_t an,
         const bool inwin = k <= nU;
         const int32_t Rm = from_lower_lane(R), Hm = from_lower_lane(H), Nm = from_lower_lane(NB);
         const int32_t Rp = from_upper_lane(R), Hp = from_upper_lane(H), Np = from_upper_lane(NB);
+        int32_t HBm = -1, NBm = 0, HBp = -1, NBp = 0;
+        if (SYM) {
+            HBm = from_lower_lane(HB);
+            NBm = from_lower_lane(NBB);
+            HBp = from_upper_lane(HB);
+            NBp = from_upper_lane(NBB);
+        }
         // substitution on k, deletion from k-1 (consumes A), insertion from k+1 (consumes B);
         // a candidate i is valid iff 0 <= i - k <= bn and i <= an; ties prefer sub, then del
-        int32_t ni = -1, hd = -1, nbp = 0;
+        int32_t ni = -1, hd = -1, nbp = 0, hb = -1, nbbp = 0;
         if (inwin) {
             const int32_t lim = min(an, bn + k);  // i <= an and i - k <= bn
             const int32_t cs = R + 1, cd = Rm + 1, ci = Rp;
@@ -606,23 +638,27 @@ __device__ ExtResult ext_wave(const uint8_t *__restrict__ ap, int32_t an,
                 ni = cs;
                 hd = H;
                 nbp = NB;
+                hb = HB;
+                nbbp = NBB;
             }
             if (Rm >= 0 && cd <= lim && cd >= k && cd > ni) {
                 ni = cd;
                 hd = Hm;
                 nbp = Nm;
+                hb = HBm;
+                nbbp = NBm;
             }
             if (Rp >= 0 && ci <= lim && ci >= k && ci > ni) {
                 ni = ci;
                 hd = Hp;
                 nbp = Np;
+                hb = HBp;
+                nbbp = NBp;
             }
         }
         bool alive = ni >= 0;
-        if (alive) {
-            int32_t j = ni - k;
-            slide<STEP>(ap, an, bp, bn, ni, j);
-        }
+        int32_t j = ni - k;
+        if (alive) slide<STEP>(ap, an, bp, bn, ni, j);
         const unsigned long long amask = __ballot(alive);
         if (amask == 0ull) break;
         ncell += __popcll(amask);
@@ -647,6 +683,27 @@ __device__ ExtResult ext_wave(const uint8_t *__restrict__ ap, int32_t an,
             }
             pool_n = __builtin_amdgcn_readfirstlane(pool_n + __popcll(m));
         }
+        if (SYM) {
+            int32_t nextbb = tpb_first + nbbp * ts;
+            bool crossb = alive && j >= nextbb;
+            for (;;) {
+                const unsigned long long m = __ballot(crossb);
+                if (m == 0ull) break;
+                if (crossb) {
+                    const int32_t idx = pool_n + __popcll(m & ((1ull << lane) - 1ull));
+                    if (idx < poolcap) {
+                        pool[idx].parent = hb;
+                        pool[idx].d = d;
+                        pool[idx].j = nextbb + k;
+                    }
+                    hb = idx;
+                    nbbp++;
+                    nextbb += ts;
+                    crossb = j >= nextbb;
+                }
+                pool_n = __builtin_amdgcn_readfirstlane(pool_n + __popcll(m));
+            }
+        }
         if (pool_n > poolcap) {
             err |= DH_ST_POOL_OVERFLOW;
             break;
@@ -654,6 +711,8 @@ __device__ ExtResult ext_wave(const uint8_t *__restrict__ ap, int32_t an,
         R = alive ? ni : -1;
         H = hd;
         NB = nbp;
+        HB = hb;
+        NBB = nbbp;
         // best of this step: highest score, then lowest diagonal (ballot of the max holders,
         // rotated so that bit x is diagonal nL + x)
         const int32_t sc = alive ? 2 * ni - k - pen * d : INT32_MIN;
@@ -669,6 +728,10 @@ __device__ ExtResult ext_wave(const uint8_t *__restrict__ ap, int32_t an,
             best_i = __builtin_amdgcn_readlane(R, src);
             best_head = __builtin_amdgcn_readlane(H, src);
             best_nb = __builtin_amdgcn_readlane(NB, src);
+            if (SYM) {
+                best_headb = __builtin_amdgcn_readlane(HB, src);
+                best_nbb = __builtin_amdgcn_readlane(NBB, src);
+            }
             best_d = d;
         }
         // trim to xdrop of the best
@@ -706,6 +769,8 @@ __device__ ExtResult ext_wave(const uint8_t *__restrict__ ap, int32_t an,
     res.d = best_d;
     res.head = best_head;
     res.nb = best_nb;
+    res.headb = best_headb;
+    res.nbb = best_nbb;
     return res;
 }
 
@@ -728,6 +793,59 @@ __device__ void walk_chain(const DhNode *__restrict__ pool, int32_t head, int32_
     }
 }
 
+// the pairs (delta diffs, delta other) of a trace between consecutive grid boundaries, written by
+// the whole wavefront.  grid = the coordinate the trace spacing refers to (boundaries at
+// grid = res mod ts), other = the opposite sequence; gs/os = seed on the two axes; rd/ro, fd/fo =
+// boundary records of the reverse / forward extension (diffs, offset on `other`).  `reverse`
+// writes the pairs back to front (transposed record of a complemented alignment).
+__device__ int32_t emit_trace(int lane, int32_t ts, int32_t res, int32_t gs, int32_t os,
+                              int32_t gbeg, int32_t gend, int32_t obeg, int32_t oend, int32_t rdv,
+                              int32_t fdv, int32_t rev_first, int32_t nr, const int32_t *rd,
+                              const int32_t *ro, int32_t fwd_first, int32_t nf, const int32_t *fd,
+                              const int32_t *fo, bool reverse, uint16_t *__restrict__ tr)
+{
+    const int32_t nrv = nr - ((nr > 0 && rev_first + (nr - 1) * ts == gs - gbeg) ? 1 : 0);
+    const int32_t nfv = nf - ((nf > 0 && fwd_first + (nf - 1) * ts == gend - gs) ? 1 : 0);
+    int32_t gm = (gs - res) % ts;
+    gm = gm < 0 ? gm + ts : gm;
+    const int32_t seedb = (gm == 0 && gs > gbeg && gs < gend) ? 1 : 0;
+    const int32_t npairs = nrv + seedb + nfv + 1;
+    for (int32_t e = lane; e < npairs; e += LANES) {
+        int32_t po[2], pD[2];
+#pragma unroll
+        for (int w = 0; w < 2; w++) {
+            const int32_t idx = e + w;
+            if (idx == 0) {
+                po[w] = obeg;
+                pD[w] = -rdv;
+            } else if (idx <= nrv) {
+                const int32_t m = nrv - idx;
+                po[w] = os - ro[m];
+                pD[w] = -rd[m];
+            } else if (idx <= nrv + seedb) {
+                po[w] = os;
+                pD[w] = 0;
+            } else if (idx <= nrv + seedb + nfv) {
+                const int32_t m = idx - 1 - nrv - seedb;
+                po[w] = os + fo[m];
+                pD[w] = fd[m];
+            } else {
+                po[w] = oend;
+                pD[w] = fdv;
+            }
+        }
+        const int32_t pos = reverse ? npairs - 1 - e : e;
+        tr[2 * pos] = (uint16_t)(pD[1] - pD[0]);
+        tr[2 * pos + 1] = (uint16_t)(po[1] - po[0]);
+    }
+    return npairs;
+}
+
+// SYM (all-vs-all inside one DB, skip_self == 2): each unordered pair has candidates in one item only; every
+// accepted alignment emits the record (a, b) into the slots of item (b, strand) and the transposed
+// record (b, a) into the slots of item (a, strand); slots are claimed with atomics because any
+// wavefront may add records to any item (the final LAsort makes the output order unique).
+template <bool SYM>
 __global__ void __launch_bounds__(LANES)
 k_wave(DbView A, DbView B, const uint8_t *__restrict__ brc, DhOpts o, int32_t item0,
        int32_t nitems, const DhCand *__restrict__ cand, const int32_t *__restrict__ ncand,
@@ -738,8 +856,10 @@ k_wave(DbView A, DbView B, const uint8_t *__restrict__ brc, DhOpts o, int32_t it
 {
     const int lane = threadIdx.x;
     DhNode *pool = ws.pool + (int64_t)blockIdx.x * ws.poolcap;
-    int32_t *cdj = ws.cdj + (int64_t)blockIdx.x * 4 * ws.nbmax;  // fd, fj, rd, rj
+    int32_t *cdj = ws.cdj + (int64_t)blockIdx.x * 8 * ws.nbmax;
     int32_t *fd = cdj, *fj = cdj + ws.nbmax, *rd = cdj + 2 * ws.nbmax, *rj = cdj + 3 * ws.nbmax;
+    int32_t *fdb = cdj + 4 * ws.nbmax, *fib = cdj + 5 * ws.nbmax, *rdb = cdj + 6 * ws.nbmax,
+            *rib = cdj + 7 * ws.nbmax;
     const int32_t ts = o.tspace;
     unsigned long long cells = 0, naln = 0;
     int32_t err = 0;
@@ -758,7 +878,7 @@ k_wave(DbView A, DbView B, const uint8_t *__restrict__ brc, DhOpts o, int32_t it
         // regions already aligned for this (read, strand): kept in registers of lanes 0..nd-1
         int32_t g_aseq = -1, g_ab = 0, g_ae = 0, g_bb = 0, g_be = 0, g_lo = 0, g_hi = 0;
         int32_t nd = 0, nacc = 0, ntr = 0;
-        for (int32_t c = 0; c < nc && nacc < o.max_la && nd < LANES; c++) {
+        for (int32_t c = 0; c < nc && (SYM || nacc < o.max_la) && nd < LANES; c++) {
             const DhCand cd = cand[(int64_t)item * o.max_cand + c];
             const int32_t sd = cd.apos - cd.bpos;
             const bool cov = lane < nd && g_aseq == cd.aseq && cd.apos >= g_ab && cd.apos < g_ae &&
@@ -770,22 +890,32 @@ k_wave(DbView A, DbView B, const uint8_t *__restrict__ brc, DhOpts o, int32_t it
             const int32_t as = cd.apos, bs = cd.bpos;
             const int32_t fwd_first = ts - (as % ts);
             const int32_t rev_first = (as % ts) ? (as % ts) : ts;
+            // B grid of the transposed record: forward strand of the read behind B
+            const int32_t resb = strand ? blen % ts : 0;
+            int32_t bm = (bs - resb) % ts;
+            bm = bm < 0 ? bm + ts : bm;
+            const int32_t fwdb_first = ts - bm, revb_first = bm ? bm : ts;
             int32_t pool_n = 0;
-            const ExtResult fw = ext_wave<1>(a + as, alen - as, b + bs, blen - bs, fwd_first, o, pool,
-                                             ws.poolcap, pool_n, cells, err);
-            const ExtResult rv = ext_wave<-1>(a + as - 1, as, b + bs - 1, bs, rev_first, o, pool,
-                                              ws.poolcap, pool_n, cells, err);
+            const ExtResult fw = ext_wave<1, SYM>(a + as, alen - as, b + bs, blen - bs, fwd_first,
+                                                  fwdb_first, o, pool, ws.poolcap, pool_n, cells, err);
+            const ExtResult rv = ext_wave<-1, SYM>(a + as - 1, as, b + bs - 1, bs, rev_first, revb_first,
+                                                   o, pool, ws.poolcap, pool_n, cells, err);
             naln++;
-            if (err || fw.nb > ws.nbmax || rv.nb > ws.nbmax) {
+            if (err || fw.nb > ws.nbmax || rv.nb > ws.nbmax || fw.nbb > ws.nbmax || rv.nbb > ws.nbmax) {
                 err |= DH_ST_POOL_OVERFLOW;
                 break;
             }
-            // chains: lane 0 walks the forward chain, lane 1 the reverse chain
+            // chains: lanes 0..3 walk the forward / reverse chains of the two boundary families
             int32_t flo = 0, fhi = 0, rlo = 0, rhi = 0;
             if (lane == 0)
                 walk_chain(pool, fw.head, fw.nb, fwd_first, ts, fw.i - fw.j, fd, fj, flo, fhi);
             if (lane == 1)
                 walk_chain(pool, rv.head, rv.nb, rev_first, ts, rv.i - rv.j, rd, rj, rlo, rhi);
+            if (SYM) {
+                int32_t x0, x1;
+                if (lane == 2) walk_chain(pool, fw.headb, fw.nbb, fwdb_first, ts, 0, fdb, fib, x0, x1);
+                if (lane == 3) walk_chain(pool, rv.headb, rv.nbb, revb_first, ts, 0, rdb, rib, x0, x1);
+            }
             __threadfence_block();
             flo = __shfl(flo, 0, LANES);
             fhi = __shfl(fhi, 0, LANES);
@@ -810,40 +940,20 @@ k_wave(DbView A, DbView B, const uint8_t *__restrict__ brc, DhOpts o, int32_t it
             const bool accept = al >= o.min_len &&
                                 (int64_t)2 * diffs * 1000000ll <= (int64_t)o.max_err_ppm * (al + bl);
             if (!accept) continue;
-            // trace assembly: points in increasing a, pair e = point[e+1] - point[e]
-            const int32_t nrv = rv.nb - ((rv.nb > 0 && rev_first + (rv.nb - 1) * ts == rv.i) ? 1 : 0);
-            const int32_t nfv = fw.nb - ((fw.nb > 0 && fwd_first + (fw.nb - 1) * ts == fw.i) ? 1 : 0);
-            const int32_t seedb = (as % ts == 0 && rv.i > 0 && fw.i > 0) ? 1 : 0;
-            const int32_t npairs = nrv + seedb + nfv + 1;
-            const int64_t slot = (int64_t)item * o.max_la + nacc;
-            uint16_t *tr = out_trace + slot * trmax;
-            for (int32_t e = lane; e < npairs; e += LANES) {
-                int32_t pb[2], pD[2];
-#pragma unroll
-                for (int w = 0; w < 2; w++) {
-                    const int32_t idx = e + w;
-                    if (idx == 0) {
-                        pb[w] = bbpos;
-                        pD[w] = -rv.d;
-                    } else if (idx <= nrv) {
-                        const int32_t m = nrv - idx;
-                        pb[w] = bs - rj[m];
-                        pD[w] = -rd[m];
-                    } else if (idx <= nrv + seedb) {
-                        pb[w] = bs;
-                        pD[w] = 0;
-                    } else if (idx <= nrv + seedb + nfv) {
-                        const int32_t m = idx - 1 - nrv - seedb;
-                        pb[w] = bs + fj[m];
-                        pD[w] = fd[m];
-                    } else {
-                        pb[w] = bepos;
-                        pD[w] = fw.d;
-                    }
+            // ---- the record (a, b): trace on the grid of A
+            int32_t s1 = nacc;
+            if (SYM) {
+                if (lane == 0) s1 = atomicAdd(&out_nla[item], 1);
+                s1 = __shfl(s1, 0, LANES);
+                if (s1 >= o.max_la) {
+                    err |= DH_ST_POOL_OVERFLOW;
+                    break;
                 }
-                tr[2 * e] = (uint16_t)(pD[1] - pD[0]);
-                tr[2 * e + 1] = (uint16_t)(pb[1] - pb[0]);
             }
+            const int64_t slot = (int64_t)item * o.max_la + s1;
+            const int32_t npairs = emit_trace(lane, ts, 0, as, bs, abpos, aepos, bbpos, bepos, rv.d, fw.d,
+                                              rev_first, rv.nb, rd, rj, fwd_first, fw.nb, fd, fj, false,
+                                              out_trace + slot * trmax);
             if (lane == 0) {
                 DhLa la;
                 la.tlen = 2 * npairs;
@@ -858,11 +968,43 @@ k_wave(DbView A, DbView B, const uint8_t *__restrict__ brc, DhOpts o, int32_t it
                 la.pad = 0;
                 la.toff = 0;
                 out_la[slot] = la;
+                if (SYM) atomicAdd(&out_ntr[item], 2 * npairs);
             }
             nacc++;
             ntr += 2 * npairs;
+            if (SYM) {
+                // ---- the transposed record (b, a): same path, trace on the grid of B
+                const int32_t item2 = 2 * cd.aseq + strand;
+                int32_t s2 = 0;
+                if (lane == 0) s2 = atomicAdd(&out_nla[item2], 1);
+                s2 = __shfl(s2, 0, LANES);
+                if (s2 >= o.max_la) {
+                    err |= DH_ST_POOL_OVERFLOW;
+                    break;
+                }
+                const int64_t slot2 = (int64_t)item2 * o.max_la + s2;
+                const int32_t np2 = emit_trace(lane, ts, resb, bs, as, bbpos, bepos, abpos, aepos, rv.d, fw.d,
+                                               revb_first, rv.nbb, rdb, rib, fwdb_first, fw.nbb, fdb, fib,
+                                               strand != 0, out_trace + slot2 * trmax);
+                if (lane == 0) {
+                    DhLa la;
+                    la.tlen = 2 * np2;
+                    la.diffs = diffs;
+                    la.abpos = strand ? blen - bepos : bbpos;
+                    la.aepos = strand ? blen - bbpos : bepos;
+                    la.bbpos = strand ? alen - aepos : abpos;
+                    la.bepos = strand ? alen - abpos : aepos;
+                    la.flags = strand ? 1u : 0u;
+                    la.aread = r;
+                    la.bread = cd.aseq;
+                    la.pad = 0;
+                    la.toff = 0;
+                    out_la[slot2] = la;
+                    atomicAdd(&out_ntr[item2], 2 * np2);
+                }
+            }
         }
-        if (lane == 0) {
+        if (!SYM && lane == 0) {
             out_nla[item] = nacc;
             out_ntr[item] = ntr;
         }
@@ -983,8 +1125,12 @@ void dhk_wave(hipStream_t st, int32_t nslots, DbView A, DbView B, const uint8_t 
               int32_t *out_ntr, unsigned long long *counters, int32_t *status)
 {
     if (nitems <= 0) return;
-    hipLaunchKernelGGL(k_wave, dim3(nslots), dim3(LANES), 0, st, A, B, brc, o, item0, nitems, cand,
-                       ncand, ws, out_la, out_trace, trmax, out_nla, out_ntr, counters, status);
+    if (o.skip_self == 2)
+        hipLaunchKernelGGL(k_wave<true>, dim3(nslots), dim3(LANES), 0, st, A, B, brc, o, item0, nitems, cand,
+                           ncand, ws, out_la, out_trace, trmax, out_nla, out_ntr, counters, status);
+    else
+        hipLaunchKernelGGL(k_wave<false>, dim3(nslots), dim3(LANES), 0, st, A, B, brc, o, item0, nitems, cand,
+                           ncand, ws, out_la, out_trace, trmax, out_nla, out_ntr, counters, status);
 }
 
 void dhk_compact(hipStream_t st, const DhLa *la_slots, const uint16_t *tr_slots, int32_t trmax,

@@ -673,7 +673,7 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
         dh_default_align_opts(&ao);
         ao.tspace = tsp;
         ao.min_len = 500;
-        ao.skip_self = 1;
+        ao.skip_self = 2;  // every unordered pair aligned once, both records emitted (as daligner does)
         ao.max_la = 64;
         ao.max_cand = 128;
         dh_la_set *pset = nullptr;

@@ -56,7 +56,8 @@ typedef struct {
     int32_t max_la;      /* local alignments reported per (B read, strand)                   */
     int32_t tcap;        /* -t  k-mers occurring more often in A are ignored                 */
     int32_t strands;     /* bit0 forward B, bit1 reverse-complement B                        */
-    int32_t skip_self;   /* 1: A is B, skip aread == bread (absence of -I)                   */
+    int32_t skip_self;   /* A is B: 1 = skip aread == bread (absence of -I); 2 = symmetric: every
+                          * unordered pair is aligned once and both records are emitted        */
     int32_t dmax;        /* cap on differences per extension                                 */
     int32_t width;       /* live diagonals of the wave, <= 62 (one 64-lane wavefront)        */
     int32_t kmer_mod;    /* -%  modimer sampling: only k-mers with hash % kmer_mod == 0; 1 = all     */

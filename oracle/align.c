@@ -334,7 +334,13 @@ static int seed_candidates(const oz_index *ix, const uint8_t *b, int32_t blen, i
         while (e < ix->n && ix->e[e].key == key) e++;
         if (e == s || e - s > o->tcap) continue;
         for (int64_t t = s; t < e; t++) {
-            if (o->skip_self && ix->e[t].aseq == bself) continue;
+            if (o->skip_self == 1 && ix->e[t].aseq == bself) continue;
+            /* symmetric: each unordered pair once; which read plays B alternates with the parity of
+             * a + b so that every read is B for about half of its partners (balanced work) */
+            if (o->skip_self == 2) {
+                const int32_t pa = ix->e[t].aseq;
+                if (pa == bself || ((pa < bself) != (((pa + bself) & 1) == 0))) continue;
+            }
             int64_t D = ix->goff[ix->e[t].aseq] + ix->e[t].apos + sepv - q;
             if (n == cap) {
                 cap *= 2;
@@ -478,29 +484,36 @@ static inline int32_t nbound(int32_t x, int32_t tp_first, int32_t ts)
  * Diagonal k = i - j.  R[k] = furthest i reached on k with the current number of diffs.
  * Score of a point = i + j - pen*d.  Returns best point and the boundary crossings
  * (cd[m], cj[m]) = (diffs, j) when the best path first reached A'-offset tp_first + m*ts.
+ * If tpb_first > 0 the crossings of the B'-offsets tpb_first + m*ts are recorded as well:
+ * (cdb[m], cib[m]) = (diffs, i) when the path first reached that j (symmetric mode: the same
+ * path also yields the trace of the transposed record); *nbb receives their number.
  */
 static int extend(const uint8_t *ap, int astep, int32_t an, const uint8_t *bp, int bstep,
-                  int32_t bn, int32_t tp_first, const oz_opts *o, int32_t *bi, int32_t *bj,
-                  int32_t *bd_, int32_t *cd, int32_t *cj, int32_t *dlo, int32_t *dhi,
-                  int64_t *cells)
+                  int32_t bn, int32_t tp_first, int32_t tpb_first, const oz_opts *o, int32_t *bi,
+                  int32_t *bj, int32_t *bd_, int32_t *cd, int32_t *cj, int32_t *cdb, int32_t *cib,
+                  int32_t *nbb, int32_t *dlo, int32_t *dhi, int64_t *cells)
 {
     const int32_t ts = o->tspace, pen = o->pen, xdrop = o->xdrop;
-    int32_t R[2][WMASK + 1], H[2][WMASK + 1];
+    int32_t R[2][WMASK + 1], H[2][WMASK + 1], HB[2][WMASK + 1];
     uint8_t alive[2][WMASK + 1];
     tp_pool pool = {0, 0, 0};
     memset(alive, 0, sizeof(alive));
 
     int32_t i = 0;
     while (i < an && i < bn && ap[(int64_t)i * astep] == bp[(int64_t)i * bstep]) i++;
-    int32_t head = -1;
+    int32_t head = -1, headb = -1;
     for (int32_t m = 0, nb = nbound(i, tp_first, ts); m < nb; m++)
         head = pool_push(&pool, head, 0, tp_first + m * ts);
+    if (tpb_first > 0)
+        for (int32_t m = 0, nb = nbound(i, tpb_first, ts); m < nb; m++)
+            headb = pool_push(&pool, headb, 0, tpb_first + m * ts);
     int cur = 0;
     R[cur][0] = i;
     H[cur][0] = head;
+    HB[cur][0] = headb;
     alive[cur][0] = 1;
     int32_t L = 0, U = 0;
-    int32_t best_score = 2 * i, best_i = i, best_k = 0, best_d = 0, best_head = head;
+    int32_t best_score = 2 * i, best_i = i, best_k = 0, best_d = 0, best_head = head, best_headb = headb;
     int64_t ncell = 1;
 
     for (int32_t d = 1; d <= o->dmax; d++) {
@@ -537,7 +550,7 @@ static int extend(const uint8_t *ap, int astep, int32_t an, const uint8_t *bp, i
                 continue;
             }
             const int32_t prev_i = R[prv][src & WMASK];
-            int32_t hd = H[prv][src & WMASK];
+            int32_t hd = H[prv][src & WMASK], hb = HB[prv][src & WMASK];
             int32_t j = ni - k;
             while (ni < an && j < bn && ap[(int64_t)ni * astep] == bp[(int64_t)j * bstep]) {
                 ni++;
@@ -547,8 +560,13 @@ static int extend(const uint8_t *ap, int astep, int32_t an, const uint8_t *bp, i
             for (int32_t m = nbound(prev_i, tp_first, ts), nb = nbound(ni, tp_first, ts); m < nb;
                  m++)
                 hd = pool_push(&pool, hd, d, tp_first + m * ts - k);
+            if (tpb_first > 0)
+                for (int32_t m = nbound(prev_i - src, tpb_first, ts), nb = nbound(j, tpb_first, ts);
+                     m < nb; m++)
+                    hb = pool_push(&pool, hb, d, tpb_first + m * ts + k);
             R[cur][k & WMASK] = ni;
             H[cur][k & WMASK] = hd;
+            HB[cur][k & WMASK] = hb;
             alive[cur][k & WMASK] = 1;
             const int32_t sc = 2 * ni - k - pen * d;
             if (sc > step_best) {
@@ -563,6 +581,7 @@ static int extend(const uint8_t *ap, int astep, int32_t an, const uint8_t *bp, i
             best_i = R[cur][step_k & WMASK];
             best_d = d;
             best_head = H[cur][step_k & WMASK];
+            best_headb = HB[cur][step_k & WMASK];
         }
         /* trim to points within xdrop of the best */
         int32_t l2 = INT32_MAX, u2 = INT32_MIN;
@@ -621,6 +640,24 @@ static int extend(const uint8_t *ap, int astep, int32_t an, const uint8_t *bp, i
         fprintf(stderr, "oracle: trace chain too long\n");
         abort();
     }
+    if (tpb_first > 0) {
+        const int32_t nbB = nbound(best_i - best_k, tpb_first, ts);
+        h = best_headb;
+        for (int32_t m = nbB - 1; m >= 0; m--) {
+            if (h < 0) {
+                fprintf(stderr, "oracle: B trace chain too short\n");
+                abort();
+            }
+            cdb[m] = pool.v[h].d;
+            cib[m] = pool.v[h].j;
+            h = pool.v[h].parent;
+        }
+        if (h >= 0) {
+            fprintf(stderr, "oracle: B trace chain too long\n");
+            abort();
+        }
+        *nbb = nbB;
+    }
     *dlo = lo;
     *dhi = hi;
     if (cells) *cells += ncell;
@@ -628,22 +665,70 @@ static int extend(const uint8_t *ap, int astep, int32_t an, const uint8_t *bp, i
     return nb;
 }
 
-int oz_local_align(const uint8_t *a, int32_t alen, const uint8_t *b, int32_t blen, int32_t as,
-                   int32_t bs, const oz_opts *o, oz_la *la, uint16_t *trace, int32_t *dlo,
-                   int32_t *dhi, int64_t *cells)
+/* trace pairs (delta diffs, delta other) between consecutive grid boundaries, in increasing grid
+ * coordinate: grid = the coordinate the trace spacing refers to, other = the opposite sequence.
+ * gs/os = seed on the grid / other axis; res = residue of the boundaries (grid = res mod ts). */
+static int32_t assemble_trace(int32_t ts, int32_t res, int32_t gs, int32_t os, int32_t gbeg,
+                              int32_t gend, int32_t obeg, int32_t oend, int32_t rdv, int32_t fdv,
+                              int32_t rev_first, int32_t nr, const int32_t *rd, const int32_t *ro,
+                              int32_t fwd_first, int32_t nf, const int32_t *fd, const int32_t *fo,
+                              uint16_t *trace)
+{
+    int32_t n = 0, po = obeg, pD = -rdv;
+    for (int32_t m = nr - 1; m >= 0; m--) { /* reverse crossings, outermost first */
+        const int32_t g = gs - (rev_first + m * ts);
+        if (g <= gbeg) continue;
+        const int32_t ov = os - ro[m], D = -rd[m];
+        trace[n++] = (uint16_t)(D - pD);
+        trace[n++] = (uint16_t)(ov - po);
+        po = ov;
+        pD = D;
+    }
+    if (((gs - res) % ts + ts) % ts == 0 && gs > gbeg && gs < gend) { /* the seed is a boundary */
+        trace[n++] = (uint16_t)(0 - pD);
+        trace[n++] = (uint16_t)(os - po);
+        po = os;
+        pD = 0;
+    }
+    for (int32_t m = 0; m < nf; m++) {
+        const int32_t g = gs + fwd_first + m * ts;
+        if (g >= gend) break;
+        const int32_t ov = os + fo[m], D = fd[m];
+        trace[n++] = (uint16_t)(D - pD);
+        trace[n++] = (uint16_t)(ov - po);
+        po = ov;
+        pD = D;
+    }
+    if (gend > gbeg) {
+        trace[n++] = (uint16_t)(fdv - pD);
+        trace[n++] = (uint16_t)(oend - po);
+    }
+    return n;
+}
+
+/* la2/trace2 (optional): the transposed record (A and B swapped) of the same alignment with its
+ * trace on the grid of B; comp2 = 1 when B is the reverse complement of its read (then the grid
+ * is the forward strand of that read and the record is mirrored accordingly). */
+static int local_align2(const uint8_t *a, int32_t alen, const uint8_t *b, int32_t blen, int32_t as,
+                        int32_t bs, const oz_opts *o, oz_la *la, uint16_t *trace, oz_la *la2,
+                        uint16_t *trace2, int comp2, int32_t *dlo, int32_t *dhi, int64_t *cells)
 {
     const int32_t ts = o->tspace;
     /* forward: boundaries at real a = m*ts > as ; reverse: at real a = m*ts < as */
-    const int32_t fwd_first = ts - (as % ts);                      /* in (0, ts] */
-    const int32_t rev_first = (as % ts) ? (as % ts) : ts;          /* in (0, ts] */
-    const int32_t maxb = alen / ts + 3;
-    int32_t *fd = (int32_t *)malloc((size_t)maxb * 4 * sizeof(int32_t));
-    int32_t *fj = fd + maxb, *rd = fj + maxb, *rj = rd + maxb;
-    int32_t fi, fjv, fdv, ri, rjv, rdv, flo, fhi, rlo, rhi;
-    int32_t nf = extend(a + as, 1, alen - as, b + bs, 1, blen - bs, fwd_first, o, &fi, &fjv, &fdv,
-                        fd, fj, &flo, &fhi, cells);
-    int32_t nr = extend(a + as - 1, -1, as, b + bs - 1, -1, bs, rev_first, o, &ri, &rjv, &rdv,
-                        rd, rj, &rlo, &rhi, cells);
+    const int32_t fwd_first = ts - (as % ts);             /* in (0, ts] */
+    const int32_t rev_first = (as % ts) ? (as % ts) : ts; /* in (0, ts] */
+    const int32_t resb = comp2 ? blen % ts : 0;           /* B grid: b = resb (mod ts) */
+    const int32_t bm = ((bs - resb) % ts + ts) % ts;
+    const int32_t fwdb_first = la2 ? ts - bm : 0, revb_first = la2 ? (bm ? bm : ts) : 0;
+    const int32_t maxb = (alen > blen ? alen : blen) / ts + 3;
+    int32_t *buf = (int32_t *)malloc((size_t)maxb * 8 * sizeof(int32_t));
+    int32_t *fd = buf, *fj = fd + maxb, *rd = fj + maxb, *rj = rd + maxb;
+    int32_t *fdb = rj + maxb, *fib = fdb + maxb, *rdb = fib + maxb, *rib = rdb + maxb;
+    int32_t fi, fjv, fdv, ri, rjv, rdv, flo, fhi, rlo, rhi, nfb = 0, nrb = 0;
+    int32_t nf = extend(a + as, 1, alen - as, b + bs, 1, blen - bs, fwd_first, fwdb_first, o, &fi,
+                        &fjv, &fdv, fd, fj, fdb, fib, &nfb, &flo, &fhi, cells);
+    int32_t nr = extend(a + as - 1, -1, as, b + bs - 1, -1, bs, rev_first, revb_first, o, &ri, &rjv,
+                        &rdv, rd, rj, rdb, rib, &nrb, &rlo, &rhi, cells);
     la->abpos = as - ri;
     la->bbpos = bs - rjv;
     la->aepos = as + fi;
@@ -656,43 +741,43 @@ int oz_local_align(const uint8_t *a, int32_t alen, const uint8_t *b, int32_t ble
     if (sd - rlo > hi) hi = sd - rlo;
     *dlo = lo;
     *dhi = hi;
-    /* assemble trace: walk boundaries in increasing a */
-    int32_t n = 0;
-    int32_t pa = la->abpos, pb = la->bbpos, pD = -rdv;
-    (void)pa;
-    /* reverse crossings, outermost first: m = nr-1 .. 0 ; real a = as - (rev_first + m*ts) */
-    for (int32_t m = nr - 1; m >= 0; m--) {
-        const int32_t ra = as - (rev_first + m * ts);
-        if (ra <= la->abpos) continue;
-        const int32_t rb = bs - rj[m], rD = -rd[m];
-        trace[n++] = (uint16_t)(rD - pD);
-        trace[n++] = (uint16_t)(rb - pb);
-        pb = rb;
-        pD = rD;
+    la->tlen = assemble_trace(ts, 0, as, bs, la->abpos, la->aepos, la->bbpos, la->bepos, rdv, fdv,
+                              rev_first, nr, rd, rj, fwd_first, nf, fd, fj, trace);
+    if (la2) {
+        const int32_t n2 = assemble_trace(ts, resb, bs, as, la->bbpos, la->bepos, la->abpos,
+                                          la->aepos, rdv, fdv, revb_first, nrb, rdb, rib, fwdb_first,
+                                          nfb, fdb, fib, trace2);
+        *la2 = *la;
+        la2->tlen = n2;
+        if (!comp2) {
+            la2->abpos = la->bbpos;
+            la2->aepos = la->bepos;
+            la2->bbpos = la->abpos;
+            la2->bepos = la->aepos;
+        } else {
+            /* grid = forward strand of the read behind B: mirror both axes, reverse the pairs */
+            la2->abpos = blen - la->bepos;
+            la2->aepos = blen - la->bbpos;
+            la2->bbpos = alen - la->aepos;
+            la2->bepos = alen - la->abpos;
+            for (int32_t x = 0, y = n2 / 2 - 1; x < y; x++, y--) {
+                uint16_t t0 = trace2[2 * x], t1 = trace2[2 * x + 1];
+                trace2[2 * x] = trace2[2 * y];
+                trace2[2 * x + 1] = trace2[2 * y + 1];
+                trace2[2 * y] = t0;
+                trace2[2 * y + 1] = t1;
+            }
+        }
     }
-    /* the seed itself is a boundary when as is a multiple of ts */
-    if (as % ts == 0 && as > la->abpos && as < la->aepos) {
-        trace[n++] = (uint16_t)(0 - pD);
-        trace[n++] = (uint16_t)(bs - pb);
-        pb = bs;
-        pD = 0;
-    }
-    for (int32_t m = 0; m < nf; m++) {
-        const int32_t ra = as + fwd_first + m * ts;
-        if (ra >= la->aepos) break;
-        const int32_t rb = bs + fj[m], rD = fd[m];
-        trace[n++] = (uint16_t)(rD - pD);
-        trace[n++] = (uint16_t)(rb - pb);
-        pb = rb;
-        pD = rD;
-    }
-    if (la->aepos > la->abpos) {
-        trace[n++] = (uint16_t)(fdv - pD);
-        trace[n++] = (uint16_t)(la->bepos - pb);
-    }
-    la->tlen = n;
-    free(fd);
+    free(buf);
     return la->aepos > la->abpos;
+}
+
+int oz_local_align(const uint8_t *a, int32_t alen, const uint8_t *b, int32_t blen, int32_t as,
+                   int32_t bs, const oz_opts *o, oz_la *la, uint16_t *trace, int32_t *dlo,
+                   int32_t *dhi, int64_t *cells)
+{
+    return local_align2(a, alen, b, blen, as, bs, o, la, trace, NULL, NULL, 0, dlo, dhi, cells);
 }
 
 /* ------------------------------------------------------------------ whole pass -------- */
@@ -710,7 +795,7 @@ static int la_accept(const oz_la *la, const oz_opts *o)
 
 static void align_read(const oz_index *ix, const oz_db *A, const oz_db *B, int32_t r,
                        const oz_opts *o, oz_la_set *out, int64_t *stats, oz_cand *cands,
-                       uint8_t *rc, uint16_t *trace)
+                       uint8_t *rc, uint16_t *trace, uint16_t *trace2)
 {
     const uint8_t *bf = B->bases + B->off[r];
     const int32_t blen = (int32_t)(B->off[r + 1] - B->off[r]);
@@ -745,7 +830,8 @@ static void align_read(const oz_index *ix, const oz_db *A, const oz_db *B, int32
         stats[1] += nc;
         region done[64];
         int nd = 0, nacc = 0;
-        for (int c = 0; c < nc && nacc < o->max_la && nd < 64; c++) {
+        /* symmetric mode: max_la is only a capacity (a record may also arrive from its partner) */
+        for (int c = 0; c < nc && (o->skip_self == 2 || nacc < o->max_la) && nd < 64; c++) {
             const oz_cand *cd = &cands[c];
             const int32_t sd = cd->apos - cd->bpos;
             int covered = 0;
@@ -757,11 +843,13 @@ static void align_read(const oz_index *ix, const oz_db *A, const oz_db *B, int32
             if (covered) continue;
             const uint8_t *a = A->bases + A->off[cd->aseq];
             const int32_t alen = (int32_t)(A->off[cd->aseq + 1] - A->off[cd->aseq]);
-            oz_la la;
+            oz_la la, la2;
             memset(&la, 0, sizeof(la));
+            memset(&la2, 0, sizeof(la2));
             int32_t dlo, dhi;
-            oz_local_align(a, alen, b, blen, cd->apos, cd->bpos, o, &la, trace, &dlo, &dhi,
-                           &stats[3]);
+            const int sym = o->skip_self == 2;
+            local_align2(a, alen, b, blen, cd->apos, cd->bpos, o, &la, trace, sym ? &la2 : NULL,
+                         sym ? trace2 : NULL, strand, &dlo, &dhi, &stats[3]);
             stats[2]++;
             done[nd].aseq = cd->aseq;
             done[nd].abpos = la.abpos;
@@ -776,6 +864,12 @@ static void align_read(const oz_index *ix, const oz_db *A, const oz_db *B, int32
             la.bread = r;
             la.flags = strand ? OZ_FLAG_COMP : 0;
             la_set_push(out, &la, trace);
+            if (sym) { /* the transposed record of the same alignment: A and B swapped */
+                la2.aread = r;
+                la2.bread = cd->aseq;
+                la2.flags = la.flags;
+                la_set_push(out, &la2, trace2);
+            }
             nacc++;
         }
     }
@@ -809,14 +903,17 @@ int oz_align_db(const oz_db *A, const oz_db *B, const oz_opts *o, int nthreads, 
 #endif
         oz_cand *cands = (oz_cand *)malloc((size_t)(o->max_cand + 1) * sizeof(oz_cand));
         uint8_t *rc = (uint8_t *)malloc((size_t)max_blen + 1);
-        uint16_t *trace = (uint16_t *)malloc((size_t)(2 * (max_alen / o->tspace + 4)) * sizeof(uint16_t));
+        const int32_t mlen = max_alen > max_blen ? max_alen : max_blen;
+        uint16_t *trace = (uint16_t *)malloc((size_t)(2 * (mlen / o->tspace + 4)) * sizeof(uint16_t));
+        uint16_t *trace2 = (uint16_t *)malloc((size_t)(2 * (mlen / o->tspace + 4)) * sizeof(uint16_t));
         /* contiguous read ranges per thread keep the merged output in read order */
         const int64_t lo = (int64_t)B->n * tid / nt, hi = (int64_t)B->n * (tid + 1) / nt;
         for (int64_t r = lo; r < hi; r++)
-            align_read(ix, A, B, (int32_t)r, o, &parts[tid], pst[tid], cands, rc, trace);
+            align_read(ix, A, B, (int32_t)r, o, &parts[tid], pst[tid], cands, rc, trace, trace2);
         free(cands);
         free(rc);
         free(trace);
+        free(trace2);
     }
     for (int t = 0; t < nthreads; t++) {
         for (int64_t i = 0; i < parts[t].n; i++)

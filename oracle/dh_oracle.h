@@ -63,7 +63,10 @@ typedef struct {
     int32_t max_la;      /* LAs reported per (B read, strand)                              */
     int32_t tcap;        /* k-mers occurring more than tcap times in A are ignored (-t)    */
     int32_t strands;     /* bit0: forward B, bit1: reverse-complement B                    */
-    int32_t skip_self;   /* 1: A and B are the same DB, skip aread == bread (no -I)        */
+    int32_t skip_self;   /* A and B are the same DB: 1 = skip aread == bread (no -I);
+                          * 2 = symmetric: every unordered pair is aligned once (the smaller id
+                          *     is A when a + b is even, else B) and both records (a,b), (b,a)
+                          *     are emitted from that alignment */
     int32_t dmax;        /* hard cap on differences per extension                          */
     int32_t width;       /* max live diagonals of the wave (64 = one wavefront)            */
     int32_t kmer_mod;    /* modimer sampling (daligner -%): only k-mers with hash % kmer_mod == 0, 1 = all */

@@ -105,7 +105,8 @@ def crop_pile(entries, las, trace, contigs, reads, g, ts_map=100):
 
 
 def pile_opts():
-    return oz.default_opts(tspace=TS_PILE, min_len=500, skip_self=1, max_la=64, max_cand=128, width=62)
+    # skip_self = 2: every unordered pair aligned once, both records emitted (what daligner does)
+    return oz.default_opts(tspace=TS_PILE, min_len=500, skip_self=2, max_la=64, max_cand=128, width=62)
 
 
 def filter_pile_las(las, pile, max_err_ppm=300000, allowance=TS_PILE):

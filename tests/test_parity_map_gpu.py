@@ -123,6 +123,32 @@ def test_pile_all_vs_all_tspace_126(gpu_ctx):
     assert not np.any(las["aread"] == las["bread"])
 
 
+@pytest.mark.parametrize("seed", [21, 57])
+def test_symmetric_all_vs_all_emits_both_records_from_one_alignment(gpu_ctx, seed):
+    """skip_self = 2: each unordered pair is aligned once (aread < bread) and the transposed record
+    with its own trace (grid of the other read, mirrored for complemented overlaps) is emitted too."""
+    p = pile(seed)
+    las, trace = run_both(gpu_ctx, p, p, same=True, tspace=126, skip_self=2, min_len=500, max_la=64, max_cand=128)
+    key = lambda x: (int(x["aread"]), int(x["bread"]), int(x["flags"]) & 1)
+    recs = {key(x): x for x in las}
+    assert len(recs) == len(las) and len(las) > p.n
+    for (a, b, c), x in recs.items():
+        y = recs[(b, a, c)]
+        la_, lb_ = p.length(a), p.length(b)
+        if c == 0:
+            assert (x["abpos"], x["aepos"], x["bbpos"], x["bepos"]) == (y["bbpos"], y["bepos"], y["abpos"], y["aepos"])
+        else:
+            assert (x["abpos"], x["aepos"], x["bbpos"], x["bepos"]) == (la_ - y["bepos"], la_ - y["bbpos"],
+                                                                          lb_ - y["aepos"], lb_ - y["abpos"])
+        assert x["diffs"] == y["diffs"]
+    # about half the wave work of the two-sided mode
+    sym_cells = gpu_ctx.align_stats().wave_cells
+    g, _ = both_opts(tspace=126, skip_self=1, min_len=500, max_la=64, max_cand=128)
+    d = gpu_ctx.db(p)
+    gpu_ctx.align_db(d, d, g)
+    assert sym_cells < 0.6 * gpu_ctx.align_stats().wave_cells
+
+
 def test_grouped_piles_never_cross_groups(gpu_ctx):
     p1, p2 = pile(31, n=12), pile(41, n=9)
     both = sim.SeqDb(np.concatenate([p1.bases, p2.bases]), np.concatenate([p1.off, p2.off[1:] + p1.off[-1]]),
