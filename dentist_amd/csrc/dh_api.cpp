@@ -380,8 +380,7 @@ static int build_index(dh_db *A, int32_t k, int32_t sepv, int32_t kmer_mod)
     const int64_t nb = (int64_t)((((uint64_t)A->ngroups << (2 * k)) - 1) >> ix.shift) + 1;
     ix.n = nk;
     HIPCHK(dh_dev_alloc(&ix.d_dir, sizeof(uint32_t) * (size_t)(nb + 1)));
-    HIPCHK(dh_dev_alloc(&ix.d_ekey, sizeof(uint64_t) * (size_t)std::max<int64_t>(nk, 1)));
-    HIPCHK(dh_dev_alloc(&ix.d_eval, sizeof(uint64_t) * (size_t)std::max<int64_t>(nk, 1)));
+    HIPCHK(dh_dev_alloc(&ix.d_ent, sizeof(ulonglong2) * (size_t)std::max<int64_t>(nk, 1)));
     HIPCHK(dh_dev_alloc(&ix.d_goff, sizeof(int64_t) * (size_t)(A->n + 1)));
     int2 *d_tiles = nullptr;
     uint32_t *d_sums = nullptr;
@@ -395,12 +394,14 @@ static int build_index(dh_db *A, int32_t k, int32_t sepv, int32_t kmer_mod)
                               ctx->stream));
     HIPCHK(hipMemsetAsync(ix.d_dir, 0, sizeof(uint32_t) * (size_t)(nb + 1), ctx->stream));
     const DbView av = A->view();
-    dhk_kmer_pass(ctx->stream, 0, av, d_tiles, (int32_t)tiles.size(), k, kmer_mod, ix.shift, ix.d_dir, ix.d_ekey,
-                  ix.d_eval, ix.d_goff);
+    dhk_kmer_pass(ctx->stream, 0, av, d_tiles, (int32_t)tiles.size(), k, kmer_mod, ix.shift, ix.d_dir, ix.d_ent,
+                  ix.d_goff);
     dhk_scan(ctx->stream, ix.d_dir, nb + 1, d_sums);
-    dhk_kmer_pass(ctx->stream, 1, av, d_tiles, (int32_t)tiles.size(), k, kmer_mod, ix.shift, ix.d_dir, ix.d_ekey,
-                  ix.d_eval, ix.d_goff);
-    dhk_bucket_sort(ctx->stream, ix.d_dir, nb, ix.d_ekey, ix.d_eval);
+    dhk_kmer_pass(ctx->stream, 1, av, d_tiles, (int32_t)tiles.size(), k, kmer_mod, ix.shift, ix.d_dir, ix.d_ent,
+                  ix.d_goff);
+    dhk_bucket_sort(ctx->stream, ix.d_dir, nb, ix.d_ent);
+    HIPCHK(dh_dev_alloc(&ix.d_bits, sizeof(uint32_t) * (size_t)((nb + 31) / 32 + 1)));
+    dhk_bucket_bits(ctx->stream, ix.d_dir, nb, ix.d_bits);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));  // tiles vector goes out of scope
     dh_dev_free(d_tiles);
@@ -545,7 +546,7 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
 
     DhOpts dopt;
     memcpy(&dopt, &o, sizeof(dopt));
-    IndexView iv{A->ix.d_dir, A->ix.d_ekey, A->ix.d_eval, A->ix.d_goff, A->ix.n,
+    IndexView iv{A->ix.d_dir, A->ix.d_bits, A->ix.d_ent, A->ix.d_goff, A->ix.n,
                  A->ix.na,    A->ix.sepv,   A->ix.shift,  A->ix.pbits};
     const DbView av = A->view(), bv = B->view();
 
@@ -593,8 +594,9 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
 
     // expected hits per (read, strand): random matches + true seeds; pick the LDS hit capacity
     const double dens = (double)A->ix.n / std::pow(4.0, o.k) / std::max(1, A->ngroups);
-    const double exp_hits = B->max_len * (dens + 0.2);
-    int cap = exp_hits * 1.5 < 4096 ? 4096 : (exp_hits * 1.5 < 8192 ? 8192 : 16384);
+    const double exp_hits = B->max_len * (dens + 0.2 / std::max(1, o.kmer_mod));
+    int cap = 1024;
+    while (cap < 16384 && exp_hits * 1.5 >= cap) cap *= 2;
     if (A == B && cap < 8192) cap = 8192;  // all-vs-all inside pile-ups: every read overlaps every other
 
     std::vector<int32_t> h_ncand((size_t)cn), h_nhits((size_t)cn);

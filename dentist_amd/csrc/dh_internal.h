@@ -57,20 +57,20 @@ struct dh_ctx {
 int dh_scratch(dh_ctx *ctx, int id, size_t bytes, void **out);
 
 struct dh_index {
-    uint32_t *d_dir = nullptr;
-    uint64_t *d_ekey = nullptr;
-    uint64_t *d_eval = nullptr;
+    uint32_t *d_dir = nullptr, *d_bits = nullptr;
+    ulonglong2 *d_ent = nullptr;
     int64_t *d_goff = nullptr;
     int64_t n = 0;
     int32_t k = 0, sepv = 0, shift = 0, pbits = 0, na = 0, kmer_mod = 1;
     void release()
     {
         dh_dev_free(d_dir);
-        dh_dev_free(d_ekey);
-        dh_dev_free(d_eval);
+        dh_dev_free(d_bits);
+        d_bits = nullptr;
+        dh_dev_free(d_ent);
         dh_dev_free(d_goff);
         d_dir = nullptr;
-        d_ekey = d_eval = nullptr;
+        d_ent = nullptr;
         d_goff = nullptr;
     }
 };

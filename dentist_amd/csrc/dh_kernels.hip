@@ -106,8 +106,7 @@ template <bool FILL>
 __global__ void __launch_bounds__(256)
 k_kmer_pass(DbView A, const int2 *__restrict__ tiles, int32_t ntiles, int32_t k, int32_t kmer_mod,
             int32_t shift,
-            uint32_t *__restrict__ dir, uint64_t *__restrict__ ekey, uint64_t *__restrict__ eval,
-            const int64_t *__restrict__ goff)
+            uint32_t *__restrict__ dir, ulonglong2 *__restrict__ ent, const int64_t *__restrict__ goff)
 {
     const int32_t t = blockIdx.x;
     if (t >= ntiles) return;
@@ -138,17 +137,16 @@ k_kmer_pass(DbView A, const int2 *__restrict__ tiles, int32_t ntiles, int32_t k,
             const uint32_t b = (uint32_t)(key >> shift);
             if (FILL) {
                 const uint32_t slot = atomicAdd(&dir[b], 1u);
-                ekey[slot] = key;
-                eval[slot] = ((uint64_t)s << 40) | (uint64_t)(goff[s] + (p - k + 1));
+                ent[slot] = make_ulonglong2(key, ((uint64_t)s << 40) | (uint64_t)(goff[s] + (p - k + 1)));
             } else
                 atomicAdd(&dir[b], 1u);
         }
     }
 }
 template __global__ void k_kmer_pass<false>(DbView, const int2 *, int32_t, int32_t, int32_t, int32_t,
-                                            uint32_t *, uint64_t *, uint64_t *, const int64_t *);
+                                            uint32_t *, ulonglong2 *, const int64_t *);
 template __global__ void k_kmer_pass<true>(DbView, const int2 *, int32_t, int32_t, int32_t, int32_t,
-                                           uint32_t *, uint64_t *, uint64_t *, const int64_t *);
+                                           uint32_t *, ulonglong2 *, const int64_t *);
 
 // exclusive scan of n uint32 in place: block sums, scan of sums, add-back
 #define SCAN_PER_BLOCK 2048
@@ -227,30 +225,45 @@ __global__ void __launch_bounds__(256) k_scan_apply(uint32_t *__restrict__ v, in
 // [b ? dir[b-1] : 0, dir[b]).  Order each bucket by (key, value): the fill order is racy, the
 // sorted order is unique because (key, position) pairs are distinct.
 __global__ void __launch_bounds__(256) k_bucket_sort(const uint32_t *__restrict__ dir_end,
-                                                     int64_t nb, uint64_t *__restrict__ ekey,
-                                                     uint64_t *__restrict__ eval)
+                                                     int64_t nb, ulonglong2 *__restrict__ ent)
 {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     const uint32_t s = b ? dir_end[b - 1] : 0, e = dir_end[b];
     for (uint32_t i = s + 1; i < e; i++) {
-        const uint64_t kk = ekey[i], vv = eval[i];
+        const ulonglong2 x = ent[i];
         uint32_t j = i;
-        while (j > s && (ekey[j - 1] > kk || (ekey[j - 1] == kk && eval[j - 1] > vv))) {
-            ekey[j] = ekey[j - 1];
-            eval[j] = eval[j - 1];
+        while (j > s && (ent[j - 1].x > x.x || (ent[j - 1].x == x.x && ent[j - 1].y > x.y))) {
+            ent[j] = ent[j - 1];
             j--;
         }
-        ekey[j] = kk;
-        eval[j] = vv;
+        ent[j] = x;
     }
+}
+
+// one bit per directory bucket: set when the bucket holds at least one k-mer.  For assemblies up
+// to a few 100 Mb the bitset (2^P / 8 bytes) stays resident in every XCD's 4 MB L2, so the
+// majority of the seed kernel's lookups (empty buckets) never leave the L2.
+__global__ void __launch_bounds__(256) k_bucket_bits(const uint32_t *__restrict__ dir_end, int64_t nb,
+                                                     uint32_t *__restrict__ bits)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 32-bucket word per thread
+    if (w * 32 >= nb) return;
+    uint32_t v = 0;
+    uint32_t prev = w ? dir_end[w * 32 - 1] : 0u;
+    for (int b = 0; b < 32 && w * 32 + b < nb; b++) {
+        const uint32_t e = dir_end[w * 32 + b];
+        v |= (e > prev ? 1u : 0u) << b;
+        prev = e;
+    }
+    bits[w] = v;
 }
 
 // ------------------------------------------------------------------------------------ K4
 
 #define HIT_QBITS 24
 #define HIT_QMASK ((1u << HIT_QBITS) - 1u)
-#define SEED_THREADS 256
+#define SEED_THREADS 512
 #define SEED_CCAP 256 /* candidate band pairs collected per (read, strand) before ranking */
 
 __device__ __forceinline__ int64_t hitD(uint64_t h) { return (int64_t)(h >> HIT_QBITS); }
@@ -315,11 +328,14 @@ k_seed(DbView B, const uint8_t *__restrict__ brc, IndexView ix, DhOpts o, int32_
         int32_t valid = 0;
         const int32_t pend = q0 < q1 ? q1 + k - 1 : q0;
         MaskCur mc = mask_open(B, r, blen, strand, q0);
-        // 8 bases per iteration: one 8-byte load of the read, 8 k-mers rolled in registers, the
-        // 8 directory lookups issued back to back (memory-level parallelism), then the rare
-        // non-empty buckets are resolved
+        // 8 bases per iteration: the 8-byte word of the read is prefetched one iteration ahead,
+        // 8 k-mers are rolled in registers, the 8 directory lookups are issued back to back
+        // (memory-level parallelism), then the rare non-empty buckets are resolved with one
+        // 16-byte (key, value) load per entry: 2 dependent memory round trips per iteration
+        uint64_t wnext = q0 < pend ? load8(b + q0) : 0ull;
         for (int32_t p = q0; p < pend; p += 8) {
-            const uint64_t w = load8(b + p);
+            const uint64_t w = wnext;
+            if (p + 8 < pend) wnext = load8(b + p + 8);
             uint64_t keys[8];
             uint32_t bks[8];
             bool em[8];
@@ -352,16 +368,16 @@ k_seed(DbView B, const uint8_t *__restrict__ brc, IndexView ix, DhOpts o, int32_
                 if (!em[u] || ss[u] >= ee[u]) continue;
                 const uint64_t key = keys[u];
                 const int32_t q = p + u - k + 1;
-                uint32_t s = ss[u];
                 const uint32_t e = ee[u];
-                // bucket is sorted by key: find the run of equal keys
-                while (s < e && ix.ekey[s] < key) s++;
-                uint32_t f = s;
-                while (f < e && ix.ekey[f] == key) f++;
-                const int32_t run = (int32_t)(f - s);
+                // the bucket is sorted by key: count the run of equal keys first (-t cap) ...
+                int32_t run = 0;
+                for (uint32_t t = ss[u]; t < e; t++) run += ix.ent[t].x == key ? 1 : 0;
                 if (run == 0 || run > o.tcap) continue;
-                for (uint32_t t = s; t < f; t++) {
-                    const uint64_t v = ix.eval[t];
+                // ... then emit its hits
+                for (uint32_t t = ss[u]; t < e; t++) {
+                    const ulonglong2 en = ix.ent[t];
+                    if (en.x != key) continue;
+                    const uint64_t v = en.y;
                     const int32_t aseq = (int32_t)(v >> 40);
                     if (o.skip_self == 1 && aseq == r) continue;
                     // symmetric: each unordered pair once; which read plays B alternates with the
@@ -396,37 +412,74 @@ k_seed(DbView B, const uint8_t *__restrict__ brc, IndexView ix, DhOpts o, int32_
     while (N < n) N <<= 1;
     for (int32_t i = n + tid; i < N; i += SEED_THREADS) hits[i] = ~0ull;
     __syncthreads();
+    // Pair p exchanges elements i = insert-zero-bit(p, j) and i | j.  Pairs are dealt to threads in
+    // runs of 64, so for strides j < 128 both elements of every pair of a wavefront live in that
+    // wavefront's own 128-element blocks: those rounds need no block barrier (LDS operations of
+    // one wavefront execute in order), only the rounds with j >= 128 do.
     for (int32_t kk = 2; kk <= N; kk <<= 1) {
         for (int32_t j = kk >> 1; j > 0; j >>= 1) {
-            for (int32_t i = tid; i < N; i += SEED_THREADS) {
-                const int32_t ixj = i ^ j;
-                if (ixj > i) {
-                    const uint64_t x = hits[i], y = hits[ixj];
-                    const bool up = (i & kk) == 0;
-                    if ((x > y) == up) {
-                        hits[i] = y;
-                        hits[ixj] = x;
-                    }
+            const bool cross = j >= 128;
+            if (cross) __syncthreads();
+            for (int32_t p = tid; p < (N >> 1); p += SEED_THREADS) {
+                const int32_t i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                const int32_t ixj = i | j;
+                const uint64_t x = hits[i], y = hits[ixj];
+                const bool up = (i & kk) == 0;
+                if ((x > y) == up) {
+                    hits[i] = y;
+                    hits[ixj] = x;
                 }
             }
-            __syncthreads();
+            if (cross)
+                __syncthreads();
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
-    // ---- band heads: coverage of bands b-1, b, b+1, b+2 by walking the sorted hits
+    __syncthreads();
+    // ---- band heads: coverage of bands b-1, b, b+1, b+2.  Small variants: every head sums its own
+    // band once and publishes (coverage, end) at the head and the coverage at the tail, the
+    // neighbours are then looked up; large variants (no LDS to spare) walk the four bands.
+    constexpr bool FASTB = LCAP > 0 && LCAP <= 4096;
+    __shared__ uint32_t bcov[FASTB ? LCAP : 1];
+    __shared__ uint16_t bend[FASTB ? LCAP : 1];
     const int bs = o.band_shift;
+    if (FASTB) {
+        for (int32_t i = tid; i < n; i += SEED_THREADS) {
+            const int64_t band = hitD(hits[i]) >> bs;
+            if (i > 0 && (hitD(hits[i - 1]) >> bs) == band) continue;  // not a band head
+            int32_t cov = 0, j = i;
+            for (; j < n && (hitD(hits[j]) >> bs) == band; j++) cov += hit_cov(hits, j, k);
+            bcov[i] = (uint32_t)cov;
+            bcov[j - 1] = (uint32_t)cov;
+            bend[i] = (uint16_t)j;
+        }
+        __syncthreads();
+    }
     for (int32_t i = tid; i < n; i += SEED_THREADS) {
         const int64_t band = hitD(hits[i]) >> bs;
         if (i > 0 && (hitD(hits[i - 1]) >> bs) == band) continue;  // not a band head
-        int32_t covm1 = 0;
-        for (int32_t j = i - 1; j >= 0 && (hitD(hits[j]) >> bs) == band - 1; j--)
-            covm1 += hit_cov(hits, j, k);
-        int32_t cov0 = 0, cov1 = 0, cov2 = 0;
-        int32_t j = i;
-        for (; j < n && (hitD(hits[j]) >> bs) == band; j++) cov0 += hit_cov(hits, j, k);
-        const int32_t e0 = j;
-        for (; j < n && (hitD(hits[j]) >> bs) == band + 1; j++) cov1 += hit_cov(hits, j, k);
-        const int32_t e1 = j;
-        for (; j < n && (hitD(hits[j]) >> bs) == band + 2; j++) cov2 += hit_cov(hits, j, k);
+        int32_t covm1 = 0, cov0 = 0, cov1 = 0, cov2 = 0, e0, e1;
+        if (FASTB) {
+            if (i > 0 && (hitD(hits[i - 1]) >> bs) == band - 1) covm1 = (int32_t)bcov[i - 1];
+            cov0 = (int32_t)bcov[i];
+            e0 = bend[i];
+            e1 = e0;
+            if (e0 < n && (hitD(hits[e0]) >> bs) == band + 1) {
+                cov1 = (int32_t)bcov[e0];
+                e1 = bend[e0];
+            }
+            if (e1 < n && (hitD(hits[e1]) >> bs) == band + 2) cov2 = (int32_t)bcov[e1];
+        } else {
+            for (int32_t j = i - 1; j >= 0 && (hitD(hits[j]) >> bs) == band - 1; j--)
+                covm1 += hit_cov(hits, j, k);
+            int32_t j = i;
+            for (; j < n && (hitD(hits[j]) >> bs) == band; j++) cov0 += hit_cov(hits, j, k);
+            e0 = j;
+            for (; j < n && (hitD(hits[j]) >> bs) == band + 1; j++) cov1 += hit_cov(hits, j, k);
+            e1 = j;
+            for (; j < n && (hitD(hits[j]) >> bs) == band + 2; j++) cov2 += hit_cov(hits, j, k);
+        }
         const int32_t P = cov0 + cov1, Pm1 = covm1 + cov0, Pp1 = cov1 + cov2;
         if (P < o.hmin || P < Pm1 || P <= Pp1) continue;
         // seed: first hit of the same-diagonal run (steps <= k) covering most bases
@@ -487,6 +540,8 @@ k_seed(DbView B, const uint8_t *__restrict__ brc, IndexView ix, DhOpts o, int32_
     template __global__ void k_seed<C>(DbView, const uint8_t *, IndexView, DhOpts, int32_t, int32_t,  \
                                        DhCand *, int32_t *, int32_t *, int32_t *, uint64_t *, int32_t, \
                                        const int32_t *);
+SEED_INST(1024)
+SEED_INST(2048)
 SEED_INST(4096)
 SEED_INST(8192)
 SEED_INST(16384)
@@ -1064,16 +1119,15 @@ void dhk_revcomp(hipStream_t st, const uint8_t *src, uint8_t *dst, const int64_t
 }
 
 void dhk_kmer_pass(hipStream_t st, int fill, DbView A, const int2 *tiles, int32_t ntiles, int32_t k,
-                   int32_t kmer_mod, int32_t shift, uint32_t *dir, uint64_t *ekey, uint64_t *eval,
-                   const int64_t *goff)
+                   int32_t kmer_mod, int32_t shift, uint32_t *dir, ulonglong2 *ent, const int64_t *goff)
 {
     if (ntiles <= 0) return;
     if (fill)
         hipLaunchKernelGGL(k_kmer_pass<true>, dim3(ntiles), dim3(256), 0, st, A, tiles, ntiles, k,
-                           kmer_mod, shift, dir, ekey, eval, goff);
+                           kmer_mod, shift, dir, ent, goff);
     else
         hipLaunchKernelGGL(k_kmer_pass<false>, dim3(ntiles), dim3(256), 0, st, A, tiles, ntiles, k,
-                           kmer_mod, shift, dir, ekey, eval, goff);
+                           kmer_mod, shift, dir, ent, goff);
 }
 
 // exclusive scan in place; sums must hold ceil(n / 2048) uint32
@@ -1085,11 +1139,16 @@ void dhk_scan(hipStream_t st, uint32_t *v, int64_t n, uint32_t *sums)
     hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, v, n, sums);
 }
 
-void dhk_bucket_sort(hipStream_t st, const uint32_t *dir_end, int64_t nb, uint64_t *ekey,
-                     uint64_t *eval)
+void dhk_bucket_bits(hipStream_t st, const uint32_t *dir_end, int64_t nb, uint32_t *bits)
+{
+    const int64_t nw = (nb + 31) / 32;
+    hipLaunchKernelGGL(k_bucket_bits, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, dir_end, nb, bits);
+}
+
+void dhk_bucket_sort(hipStream_t st, const uint32_t *dir_end, int64_t nb, ulonglong2 *ent)
 {
     hipLaunchKernelGGL(k_bucket_sort, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, dir_end,
-                       nb, ekey, eval);
+                       nb, ent);
 }
 
 void dhk_seed(hipStream_t st, int cap, DbView B, const uint8_t *brc, IndexView ix, DhOpts o,
@@ -1100,7 +1159,11 @@ void dhk_seed(hipStream_t st, int cap, DbView B, const uint8_t *brc, IndexView i
 #define SEED_LAUNCH(C)                                                                            \
     hipLaunchKernelGGL(k_seed<C>, dim3(nitems), dim3(SEED_THREADS), 0, st, B, brc, ix, o, item0, nitems, \
                        cand, ncand, nhits, status, (uint64_t *)nullptr, 0, (const int32_t *)nullptr)
-    if (cap <= 4096)
+    if (cap <= 1024)
+        SEED_LAUNCH(1024);
+    else if (cap <= 2048)
+        SEED_LAUNCH(2048);
+    else if (cap <= 4096)
         SEED_LAUNCH(4096);
     else if (cap <= 8192)
         SEED_LAUNCH(8192);
