@@ -556,7 +556,7 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
     const int32_t nbmax = (int32_t)(maxext / o.tspace + 3);
     const int32_t trmax = 2 * (2 * nbmax + 2);
     const int32_t poolcap = 96 * nbmax;
-    int32_t slots_per_cu = 20;  // 86 VGPRs -> 5 waves/SIMD; measured 141 -> 39 ms from 8 to 20
+    int32_t slots_per_cu = 32;  // <= 64 VGPRs -> 8 waves/SIMD
     if (const char *e = getenv("DH_WAVE_SLOTS_PER_CU")) slots_per_cu = std::max(1, atoi(e));
     const int64_t nitems_total = 2ll * B->n;
     const int32_t nslots = (int32_t)std::min<int64_t>((int64_t)ctx->ncu * slots_per_cu,

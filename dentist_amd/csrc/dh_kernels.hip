@@ -577,19 +577,40 @@ __device__ __forceinline__ int32_t wave_max_i32(int32_t v)
 }
 // extend a run of matches: element i of A' is ap[i * step], 8 bases per compare.
 // DB buffers carry 64 bytes of padding on both sides, so the wide loads stay inside them.
+// a wave-uniform global pointer pinned to an SGPR pair (explicit global address space so that
+// the loads stay global_load with SGPR base + 32-bit VGPR offset)
+typedef const __attribute__((address_space(1))) uint8_t *gptr_t;
+struct __attribute__((packed)) PackedU64 {
+    uint64_t v;
+};
+__device__ __forceinline__ gptr_t uniform_ptr(const uint8_t *p)
+{
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (gptr_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ uint64_t load8g(gptr_t base, uint32_t off)
+{
+    return ((const __attribute__((address_space(1))) PackedU64 *)(base + off))->v;
+}
+// extend a run of matches: element i of A' is ap[i * step], 8 bases per compare.
+// DB buffers carry 64 bytes of padding on both sides, so the wide loads stay inside them.
+// lim = min(an, bn + k) bounds i on diagonal k.  ar/br = ap - an - 7 / bp - bn - 7 (reverse only):
+// offsets are unsigned 32-bit values on wave-uniform bases.
 template <int STEP>
-__device__ __forceinline__ void slide(const uint8_t *__restrict__ ap, int32_t an,
-                                      const uint8_t *__restrict__ bp, int32_t bn, int32_t &i, int32_t &j)
+__device__ __forceinline__ void slide(gptr_t ap, gptr_t ar, int32_t an, gptr_t bp, gptr_t br,
+                                      int32_t bn, int32_t lim, int32_t &i, int32_t &j)
 {
     for (;;) {
-        const int32_t rem = min(an - i, bn - j);
+        const int32_t rem = lim - i;
         if (rem <= 0) break;
         int32_t m;
         if (STEP > 0) {
-            const uint64_t x = load8(ap + i) ^ load8(bp + j);
+            const uint64_t x = load8g(ap, (uint32_t)i) ^ load8g(bp, (uint32_t)j);
             m = x ? ((__ffsll((long long)x) - 1) >> 3) : 8;
         } else {
-            const uint64_t x = load8(ap - i - 7) ^ load8(bp - j - 7);
+            const uint64_t x = load8g(ar, (uint32_t)(an - i)) ^ load8g(br, (uint32_t)(bn - j));
             m = x ? (__clzll((long long)x) >> 3) : 8;
         }
         m = min(m, rem);
@@ -608,25 +629,31 @@ struct ExtResult {
 // B-offsets tpb_first + m*ts (value = i when j first reaches the boundary): the same path then
 // also yields the trace of the transposed record (symmetric all-vs-all, each pair aligned once).
 template <int STEP, bool SYM>
-__device__ ExtResult ext_wave(const uint8_t *__restrict__ ap, int32_t an,
-                              const uint8_t *__restrict__ bp, int32_t bn, int32_t tp_first,
+__device__ ExtResult ext_wave(const uint8_t *ap_, int32_t an, const uint8_t *bp_, int32_t bn, int32_t tp_first,
                               int32_t tpb_first, const DhOpts &o, DhNode *__restrict__ pool,
                               int32_t poolcap, int32_t &pool_n, unsigned long long &cells,
                               int32_t &err)
 {
     const int lane = threadIdx.x & (LANES - 1);
     const int32_t ts = o.tspace, pen = o.pen, xdrop = o.xdrop;
+    an = __builtin_amdgcn_readfirstlane(an);
+    bn = __builtin_amdgcn_readfirstlane(bn);
+    const gptr_t ap = uniform_ptr(ap_), bp = uniform_ptr(bp_);
+    const gptr_t ar = uniform_ptr(ap_ - an - 7), br = uniform_ptr(bp_ - bn - 7);
+    tp_first = __builtin_amdgcn_readfirstlane(tp_first);
+    tpb_first = __builtin_amdgcn_readfirstlane(tpb_first);
     // per-lane state of diagonal k: R = furthest i (-1 dead), H = head of its trace chain,
     // NB = number of trace boundaries <= R (carried along so that no division is needed);
     // HB / NBB the same for the B-offset boundaries (SYM only)
-    int32_t R = -1, H = -1, NB = 0, HB = -1, NBB = 0;
+    constexpr int32_t DEAD = -(1 << 30);
+    int32_t R = DEAD, H = -1, NB = 0, HB = -1, NBB = 0;
     int32_t L = 0, U = 0;
 
     // d = 0: the seed diagonal, slid by lane 0
     int32_t i0 = 0, h0 = -1, nb0 = 0, hb0 = -1, nbb0 = 0;
     if (lane == 0) {
         int32_t j0 = 0;
-        slide<STEP>(ap, an, bp, bn, i0, j0);
+        slide<STEP>(ap, ar, an, bp, br, bn, min(an, bn), i0, j0);
         int32_t cnt = 0;
         for (int32_t nextb = tp_first; nextb <= i0; nextb += ts) {
             const int32_t idx = pool_n + cnt;
@@ -670,10 +697,9 @@ __device__ ExtResult ext_wave(const uint8_t *__restrict__ ap, int32_t an,
     unsigned long long ncell = 1;
 
     for (int32_t d = 1; d <= o.dmax; d++) {
-        const int32_t nL = L - 1, nU = U + 1;
+        const int32_t nL = L - 1;
         const int32_t kidx = (lane - nL) & (LANES - 1);
         const int32_t k = nL + kidx;
-        const bool inwin = k <= nU;
         const int32_t Rm = from_lower_lane(R), Hm = from_lower_lane(H), Nm = from_lower_lane(NB);
         const int32_t Rp = from_upper_lane(R), Hp = from_upper_lane(H), Np = from_upper_lane(NB);
         int32_t HBm = -1, NBm = 0, HBp = -1, NBp = 0;
@@ -683,27 +709,30 @@ __device__ ExtResult ext_wave(const uint8_t *__restrict__ ap, int32_t an,
             HBp = from_upper_lane(HB);
             NBp = from_upper_lane(NBB);
         }
-        // substitution on k, deletion from k-1 (consumes A), insertion from k+1 (consumes B);
-        // a candidate i is valid iff 0 <= i - k <= bn and i <= an; ties prefer sub, then del
+        // substitution on k, deletion from k-1 (consumes A), insertion from k+1 (consumes B); ties
+        // prefer sub, then del.  Dead diagonals carry R = DEAD (very negative), so a candidate from
+        // a dead source never beats ni = -1; sources are valid points, hence j >= 0 holds for all
+        // three moves and only i <= an, j <= bn (i <= lim) has to be checked.  Lanes outside the
+        // window see dead sources only (width <= 62) and stay dead.
         int32_t ni = -1, hd = -1, nbp = 0, hb = -1, nbbp = 0;
-        if (inwin) {
-            const int32_t lim = min(an, bn + k);  // i <= an and i - k <= bn
+        const int32_t lim = min(an, bn + k);  // i <= an and i - k <= bn
+        {
             const int32_t cs = R + 1, cd = Rm + 1, ci = Rp;
-            if (R >= 0 && cs <= lim && cs >= k) {
+            if (cs <= lim && cs > ni) {
                 ni = cs;
                 hd = H;
                 nbp = NB;
                 hb = HB;
                 nbbp = NBB;
             }
-            if (Rm >= 0 && cd <= lim && cd >= k && cd > ni) {
+            if (cd <= lim && cd > ni) {
                 ni = cd;
                 hd = Hm;
                 nbp = Nm;
                 hb = HBm;
                 nbbp = NBm;
             }
-            if (Rp >= 0 && ci <= lim && ci >= k && ci > ni) {
+            if (ci <= lim && ci > ni) {
                 ni = ci;
                 hd = Hp;
                 nbp = Np;
@@ -713,7 +742,7 @@ __device__ ExtResult ext_wave(const uint8_t *__restrict__ ap, int32_t an,
         }
         bool alive = ni >= 0;
         int32_t j = ni - k;
-        if (alive) slide<STEP>(ap, an, bp, bn, ni, j);
+        if (alive) slide<STEP>(ap, ar, an, bp, br, bn, lim, ni, j);
         const unsigned long long amask = __ballot(alive);
         if (amask == 0ull) break;
         ncell += __popcll(amask);
@@ -763,7 +792,7 @@ __device__ ExtResult ext_wave(const uint8_t *__restrict__ ap, int32_t an,
             err |= DH_ST_POOL_OVERFLOW;
             break;
         }
-        R = alive ? ni : -1;
+        R = alive ? ni : DEAD;
         H = hd;
         NB = nbp;
         HB = hb;
@@ -792,7 +821,7 @@ __device__ ExtResult ext_wave(const uint8_t *__restrict__ ap, int32_t an,
         // trim to xdrop of the best
         if (alive && sc < best_score - xdrop) {
             alive = false;
-            R = -1;
+            R = DEAD;
         }
         unsigned long long lm = __ballot(alive);
         if (lm == 0ull) break;
@@ -807,7 +836,7 @@ __device__ ExtResult ext_wave(const uint8_t *__restrict__ ap, int32_t an,
             const int32_t kill = sl <= su ? l2 : u2;
             if (k == kill) {
                 alive = false;
-                R = -1;
+                R = DEAD;
             }
             lm = __ballot(alive);
             rm = rot ? ((lm >> rot) | (lm << (LANES - rot))) : lm;
@@ -922,7 +951,7 @@ k_wave(DbView A, DbView B, const uint8_t *__restrict__ brc, DhOpts o, int32_t it
     for (;;) {
         int32_t it = 0;
         if (lane == 0) it = (int32_t)atomicAdd(ws.queue, 1u);
-        it = __shfl(it, 0, LANES);
+        it = __builtin_amdgcn_readfirstlane(it);
         if (it >= nitems) break;
         const int32_t item = item0 + it;
         const int32_t r = item >> 1, strand = item & 1;
