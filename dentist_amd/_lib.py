@@ -174,21 +174,40 @@ def default_align_opts(**kw):
     return o
 
 
+class _LaSetOwner:
+    """Keeps a library-owned dh_la_set alive for as long as numpy views of its buffers exist."""
+
+    def __init__(self, h):
+        self._h = h
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().dh_la_set_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
 def _take_la_set(h):
+    """Zero-copy numpy views of the (page-locked) buffers of a dh_la_set; the set is destroyed
+    when the last view goes away."""
     L = lib()
     n, tn = L.dh_la_set_count(h), L.dh_la_set_trace_len(h)
     ts = L.dh_la_set_tspace(h)
-    if n:  # one copy out of the library-owned buffers
+    owner = _LaSetOwner(h)
+    if n:
         buf = (ctypes.c_uint8 * (n * LA_DTYPE.itemsize)).from_address(L.dh_la_set_records(h))
-        las = np.frombuffer(buf, dtype=LA_DTYPE).copy()
+        buf._owner = owner
+        las = np.frombuffer(buf, dtype=LA_DTYPE)
     else:
         las = np.zeros(0, dtype=LA_DTYPE)
     if tn:
         buf = (ctypes.c_uint16 * tn).from_address(L.dh_la_set_trace(h))
-        trace = np.frombuffer(buf, dtype=np.uint16).copy()
+        buf._owner = owner
+        trace = np.frombuffer(buf, dtype=np.uint16)
     else:
         trace = np.zeros(0, dtype=np.uint16)
-    L.dh_la_set_destroy(h)
     return las, trace, ts
 
 

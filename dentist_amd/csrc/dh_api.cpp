@@ -91,6 +91,78 @@ void dh_dev_trim()
     g_free_lists.clear();
 }
 
+// pooled page-locked host memory (power-of-two classes from 64 KiB); smaller requests and the
+// no-device case use malloc
+namespace {
+std::mutex g_pin_mu;
+std::map<size_t, std::vector<void *>> g_pin_free;
+std::unordered_map<void *, size_t> g_pin_size;  // pinned blocks (in use or pooled) -> class
+size_t g_pin_pooled = 0;
+constexpr size_t PIN_MIN = 1u << 16, PIN_POOL_MAX = 4ull << 30;
+size_t pin_class(size_t bytes)
+{
+    size_t p = PIN_MIN;
+    while (p < bytes) p <<= 1;
+    return p;
+}
+}  // namespace
+
+void *dh_pinned_alloc(size_t bytes)
+{
+    if (bytes < PIN_MIN) return malloc(std::max<size_t>(bytes, 1));
+    const size_t cls = pin_class(bytes);
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        auto it = g_pin_free.find(cls);
+        if (it != g_pin_free.end() && !it->second.empty()) {
+            void *p = it->second.back();
+            it->second.pop_back();
+            g_pin_pooled -= cls;
+            return p;
+        }
+    }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, cls, hipHostMallocDefault) == hipSuccess && p) {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        g_pin_size[p] = cls;
+        return p;
+    }
+    (void)hipGetLastError();
+    return malloc(bytes);
+}
+
+void dh_pinned_free(void *p, size_t bytes)
+{
+    if (!p) return;
+    if (bytes >= PIN_MIN) {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        auto it = g_pin_size.find(p);
+        if (it != g_pin_size.end()) {
+            if (g_pin_pooled + it->second <= PIN_POOL_MAX) {
+                g_pin_free[it->second].push_back(p);
+                g_pin_pooled += it->second;
+            } else {
+                g_pin_size.erase(it);
+                (void)hipHostFree(p);
+            }
+            return;
+        }
+    }
+    free(p);
+}
+
+void dh_pinned_trim()
+{
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (auto &kv : g_pin_free)
+        for (void *p : kv.second) {
+            g_pin_size.erase(p);
+            (void)hipHostFree(p);
+        }
+    g_pin_free.clear();
+    g_pin_pooled = 0;
+}
+
 extern "C" const char *dh_last_error(void) { return g_err.c_str(); }
 extern "C" int32_t dh_abi_version(void) { return 1; }
 
@@ -131,6 +203,7 @@ extern "C" void dh_ctx_destroy(dh_ctx *c)
     for (auto &a : c->arena)
         if (a.p) dh_dev_free(a.p);
     dh_dev_trim();
+    dh_pinned_trim();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -438,7 +511,7 @@ static bool la_less(const dh_la &p, const dh_la &q)
 // unless a higher-scoring LA of the same read and orientation covers more than half of it on B
 // (consumer: dazzler.d:1728-1758 reads START without BEST as alternateChain).
 // `la` must be grouped by bread (the kernels emit it that way).
-static void select_best(std::vector<dh_la> &la)
+static void select_best(LaVec &la)
 {
     for (auto &l : la) l.flags |= DH_FLAG_START | DH_FLAG_BEST;
     size_t g0 = 0;
@@ -472,7 +545,7 @@ static void lasort(dh_la_set *res, int32_t na)
     std::vector<int64_t> first((size_t)na + 2, 0);
     for (const dh_la &l : res->la) first[(size_t)l.aread + 1]++;
     for (int32_t a = 0; a <= na; a++) first[(size_t)a + 1] += first[(size_t)a];
-    std::vector<dh_la> out(n);
+    LaVec out(n);
     for (const dh_la &l : res->la) out[(size_t)first[(size_t)l.aread]++] = l;
     for (size_t i = 1; i < n; i++) {
         if (!la_less(out[i], out[i - 1])) continue;

@@ -8,6 +8,8 @@
 
 #include <algorithm>
 #include <string>
+#include <new>
+#include <utility>
 #include <vector>
 
 #include "dh_device.h"
@@ -93,9 +95,38 @@ struct dh_db {
     DbView view() const { return DbView{d_bases, d_off, d_group, n, d_mask_ptr, d_mask_iv}; }
 };
 
+// Result buffers live in pooled page-locked host memory: device-to-host copies into them run at
+// PCIe speed without the runtime's staging pass, and resize() does not zero-fill.  Without a
+// device (CPU-only use of the .las codec) the pool falls back to malloc.
+void *dh_pinned_alloc(size_t bytes);
+void dh_pinned_free(void *p, size_t bytes);
+void dh_pinned_trim();
+template <typename T>
+struct PinnedAlloc {
+    using value_type = T;
+    PinnedAlloc() = default;
+    template <class U>
+    PinnedAlloc(const PinnedAlloc<U> &) {}
+    T *allocate(size_t n)
+    {
+        void *p = dh_pinned_alloc(n * sizeof(T));
+        if (!p) throw std::bad_alloc();
+        return (T *)p;
+    }
+    void deallocate(T *p, size_t n) { dh_pinned_free(p, n * sizeof(T)); }
+    template <class U>
+    void construct(U *p) { ::new ((void *)p) U; }  // default-init: no zero fill on resize()
+    template <class U, class... Args>
+    void construct(U *p, Args &&...a) { ::new ((void *)p) U(std::forward<Args>(a)...); }
+    bool operator==(const PinnedAlloc &) const { return true; }
+    bool operator!=(const PinnedAlloc &) const { return false; }
+};
+using LaVec = std::vector<dh_la, PinnedAlloc<dh_la>>;
+using TraceVec = std::vector<uint16_t, PinnedAlloc<uint16_t>>;
+
 struct dh_la_set {
-    std::vector<dh_la> la;
-    std::vector<uint16_t> trace;
+    LaVec la;
+    TraceVec trace;
     int32_t tspace = 0;
 };
 

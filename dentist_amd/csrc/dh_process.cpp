@@ -243,7 +243,7 @@ static bool valid_pileup_alignment(const dh_la &la, bool same, int32_t alen, int
 // defaults of commandline.d:1819, 1982, 2014, 2153, 2165-2173.  `la` is grouped by (aread, bread)
 // [first, last); only chains scoring >= max(minScore, minRelativeScore * best) survive, every
 // other enabled LA of the pair gets DISABLED.  First LA of a chain: START|BEST, the others NEXT.
-static void chain_pair(std::vector<dh_la> &la, size_t first, size_t last, int32_t min_score)
+static void chain_pair(LaVec &la, size_t first, size_t last, int32_t min_score)
 {
     const int32_t max_indel = 1000, max_gap = 10000;
     const double max_rel_overlap = 0.3, min_rel_score = 1.0;
@@ -353,8 +353,8 @@ extern "C" int dh_get_process_stats(dh_ctx *ctx, float *ms7, int64_t *counters3)
 
 // One voting + emission round.  T: templates (one per active pile-up), R: pile-up reads.
 // las: overlaps with A = a template coordinate system; tmpl_of[i] = template of LA i or -1.
-static int consensus_round(dh_ctx *ctx, dh_db *T, dh_db *R, const std::vector<dh_la> &las,
-                           const std::vector<uint16_t> &trace, const std::vector<int32_t> &tmpl_of,
+static int consensus_round(dh_ctx *ctx, dh_db *T, dh_db *R, const LaVec &las,
+                           const TraceVec &trace, const std::vector<int32_t> &tmpl_of,
                            int32_t ts, dh_db **newT, int64_t *nseg_out, int64_t *ncell_out)
 {
     hipStream_t st = ctx->stream;
@@ -685,13 +685,13 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
             std::vector<int32_t> cnt((size_t)pile->n + 1, 0);
             for (const dh_la &la : pset->la) cnt[(size_t)la.aread + 1]++;
             for (int32_t r = 0; r < pile->n; r++) cnt[(size_t)r + 1] += cnt[(size_t)r];
-            std::vector<dh_la> tmp(pset->la.size());
+            LaVec tmp(pset->la.size());
             for (const dh_la &la : pset->la) tmp[(size_t)cnt[(size_t)la.aread]++] = la;
             pset->la.swap(tmp);
         }
         HIPCHK(hipEventRecord(ev[1], st));
         if (int rc = elapsed(0, 1, ps.ms[1])) return rc;
-        std::vector<dh_la> &pl = pset->la;
+        LaVec &pl = pset->la;
         ps.counters[0] = (int64_t)pl.size();
         lap("group by aread");
         // ---- 3. the alignment funnel of computeQVs (package.d:474-516): averageErrorRate <=
