@@ -12,6 +12,7 @@
 // source/dentist/dazzler.d:6142-6156 (DASqv), 6185-6231 (daccord).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "dh_device.h"
 
@@ -118,77 +119,112 @@ struct SegDesc {
     int32_t bseq;        // B sequence index in the read DB
     int32_t b0, b1;      // B interval (in the orientation of the overlap)
     int32_t comp;        // 1: B is reverse-complemented
-    int32_t pad;
+    int32_t band;        // half-width of the DP band: tile diffs of the trace + 1 (see k_seg_vote)
 };
 
 __global__ void __launch_bounds__(64)
 k_seg_vote(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R,
            const uint8_t *__restrict__ rrc, const int64_t *__restrict__ voff,
-           uint8_t *__restrict__ fmat, int32_t wmax, uint8_t *__restrict__ opbuf,
+           uint32_t *__restrict__ dmat, int32_t bandmax, uint8_t *__restrict__ opbuf,
            uint32_t *__restrict__ votes, int32_t *__restrict__ status)
 {
+    extern __shared__ __align__(16) uint8_t smem[];
     const int32_t dp = blockIdx.x * blockDim.x + threadIdx.x;
     if (dp >= nseg) return;
     const SegDesc sg = segs[dp];
     const int32_t rl = sg.a1 - sg.a0, ql = sg.b1 - sg.b0;
-    if (rl > SEG_MAX || ql > SEG_MAX || ql > wmax) {
+    if (rl > SEG_MAX || ql > SEG_MAX || sg.band > bandmax || rl - ql >= sg.band || ql - rl >= sg.band) {
         atomicOr(status, DH_ST_POOL_OVERFLOW);
         return;
     }
     const uint8_t *ref = T.bases + T.off[sg.tmpl] + sg.a0;
     const uint8_t *qry = (sg.comp ? rrc : R.bases) + R.off[sg.bseq] + sg.b0;
     const int64_t NDP = nseg;
-    const int32_t W = wmax + 1;
-#define FM(i, j) fmat[((int64_t)(i) * W + (j)) * NDP + dp]
-    // ---- fill (unit mismatch, indel 1, no free shift).  The rolling row lives in LDS
-    // ([column][lane], one byte per cell: conflict-free), so the only global traffic of the
-    // inner loop is the fire-and-forget store of the matrix cell the traceback will read.
-    __shared__ uint8_t rowbuf[(SEG_MAX + 1) * 64];
-    __shared__ uint8_t qrybuf[SEG_MAX * 64];
-    uint8_t *row = rowbuf + threadIdx.x;
-    uint8_t *qs = qrybuf + threadIdx.x;
-    for (int32_t j = 0; j < ql; j++) qs[j * 64] = qry[j];
-    for (int32_t j = 0; j <= ql; j++) {
-        row[j * 64] = (uint8_t)j;
-        FM(0, j) = (uint8_t)j;
+    // ---- banded fill (unit mismatch, indel 1, no free shift).  The trace already holds an
+    // alignment of this tile with `diffs` differences, so the optimum D <= diffs.  A cell whose
+    // true score is <= w is exact inside a band |i - j| <= w (its optimal path never leaves the
+    // band); the traceback only ever selects neighbours with score <= D and w = diffs + 1 > D, so
+    // fill + traceback restricted to the band give exactly the path of the full matrix
+    // (findAlignment, util/string.d:478-520).  Cells outside the band count as 255.
+    //
+    // The traceback rule (tracebackScoringMatrix, util/string.d:775-831: smallest neighbour,
+    // diagonal > insertion > deletion) depends only on the three neighbours the fill has in
+    // registers, so the fill stores the 2-bit decision of every cell (16 per dword, interleaved
+    // over the threads) instead of the scores.
+    //
+    // LDS: the rolling row in band coordinates c = j - i + w ([c][lane], one byte per cell:
+    // conflict-free, updated in place because F[i-1][j] sits at c + 1), and the query packed
+    // 8 bases per dword ([word][lane]).
+    const int32_t w = sg.band < 1 ? 1 : sg.band;
+    const int32_t WD = (2 * bandmax + 16) >> 4;  // decision dwords per matrix row
+#define DM(i, cw) dmat[((int64_t)(i) * WD + (cw)) * NDP + dp]
+    uint8_t *row = smem + threadIdx.x;
+    uint32_t *qw = (uint32_t *)(smem + (size_t)(2 * bandmax + 2) * 64) + threadIdx.x;
+    for (int32_t wd = 0; wd * 8 < ql; wd++) {
+        uint32_t x = 0;
+        for (int32_t b = 0; b < 8 && wd * 8 + b < ql; b++) x |= (uint32_t)(qry[wd * 8 + b] & 15u) << (4 * b);
+        qw[wd * 64] = x;
+    }
+    for (int32_t c = 0; c <= 2 * w + 1; c++) {
+        const int32_t j = c - w;  // F[0][j] = j
+        row[c * 64] = (uint8_t)((j >= 0 && j <= ql && j < 255) ? j : 255);
     }
     for (int32_t i = 1; i <= rl; i++) {
-        const uint8_t rc = ref[i - 1];
-        uint8_t left = (uint8_t)i;        // F[i][0]
-        uint8_t diag = (uint8_t)(i - 1);  // F[i-1][0]
-        row[0] = left;
-        FM(i, 0) = left;
-        for (int32_t j = 1; j <= ql; j++) {
-            const uint8_t up = row[j * 64];
-            const uint8_t m = (uint8_t)(diag + (rc == qs[(j - 1) * 64] ? 0 : 1));
-            uint8_t v = m < (uint8_t)(up + 1) ? m : (uint8_t)(up + 1);
-            v = v < (uint8_t)(left + 1) ? v : (uint8_t)(left + 1);
-            row[j * 64] = v;
-            FM(i, j) = v;
+        const uint32_t rc = ref[i - 1];
+        int32_t cst, left;
+        if (i <= w) {
+            cst = w - i + 1;  // j = 1
+            left = i;         // F[i][0]
+        } else {
+            cst = 0;
+            left = 255;  // F[i][i-w-1] lies outside the band
+        }
+        int32_t diag = row[cst * 64];                // F[i-1][j-1] of the first cell
+        if (i <= w) row[(w - i) * 64] = (uint8_t)i;  // F[i][0]: the next row's first diagonal
+        const int32_t cend = (ql - i + w) < 2 * w ? (ql - i + w) : 2 * w;
+        const int32_t jq = i - w + cst - 1;  // query index of the first cell
+        int32_t widx = jq >> 3, inword = 8 - (jq & 7);
+        uint32_t curw = qw[widx * 64] >> (4 * (jq & 7));
+        uint32_t acc = 0;
+        for (int32_t c = cst; c <= cend; c++) {
+            const int32_t up = c == 2 * w ? 255 : (int32_t)row[(c + 1) * 64];
+            const uint32_t qb = curw & 15u;
+            curw >>= 4;
+            if (--inword == 0) {
+                widx++;
+                curw = qw[widx * 64];
+                inword = 8;
+            }
+            const int32_t m = diag + (rc == qb ? 0 : 1);
+            int32_t v = m < up + 1 ? m : up + 1;
+            v = v < left + 1 ? v : left + 1;
+            v = v < 255 ? v : 255;
+            const uint32_t op = (diag <= left && diag <= up) ? 0u : (left <= up ? 2u : 1u);
+            acc |= op << (2 * (c & 15));
+            if ((c & 15) == 15) {
+                DM(i, c >> 4) = acc;
+                acc = 0;
+            }
+            row[c * 64] = (uint8_t)v;
             diag = up;
             left = v;
         }
+        if (cst <= cend && (cend & 15) != 15) DM(i, cend >> 4) = acc;
     }
-    // ---- traceback (tracebackScoringMatrix: smallest neighbour, diagonal > insertion > deletion)
-    // ops are produced back to front into the interleaved op buffer; opbuf row t = op number t
-    // counted from the END of the path.
+    // ---- traceback: ops are produced back to front into the interleaved op buffer; opbuf row
+    // t = op number t counted from the END of the path.
     const int32_t opcap = 2 * SEG_MAX;
 #define OPB(t) opbuf[(int64_t)(t)*NDP + dp]
     int32_t i = rl, j = ql, nops = 0;
     while (i > 0 && j > 0) {
-        const uint8_t ms = FM(i - 1, j - 1), is = FM(i, j - 1), ds = FM(i - 1, j);
-        uint8_t nx = ms < ds ? ms : ds;
-        nx = is < nx ? is : nx;
-        uint8_t op;
-        if (nx == ms) {
-            op = 0;
+        const int32_t c = j - i + w;
+        const uint8_t op = (uint8_t)((DM(i, c >> 4) >> (2 * (c & 15))) & 3u);
+        if (op == 0) {
             --i;
             --j;
-        } else if (nx == is) {
-            op = 2;
+        } else if (op == 2) {
             --j;
         } else {
-            op = 1;
             --i;
         }
         OPB(nops) = op;
@@ -267,7 +303,7 @@ k_seg_vote(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R,
             atomicAdd(&col[colst[x]], 1u);
         atomicAdd(&col[5], 1u);
     }
-#undef FM
+#undef DM
 #undef OPB
 }
 
@@ -431,12 +467,13 @@ void dhk_tile_qv(hipStream_t st, const DhLa *las, const uint16_t *trace, const i
 }
 
 void dhk_seg_vote(hipStream_t st, const void *segs, int32_t nseg, DbView T, DbView R,
-                  const uint8_t *rrc, const int64_t *voff, uint8_t *fmat, int32_t wmax, uint8_t *opbuf,
-                  uint32_t *votes, int32_t *status)
+                  const uint8_t *rrc, const int64_t *voff, uint32_t *dmat, int32_t bandmax, int32_t qmax,
+                  uint8_t *opbuf, uint32_t *votes, int32_t *status)
 {
     if (nseg <= 0) return;
-    hipLaunchKernelGGL(k_seg_vote, dim3((nseg + 63) / 64), dim3(64), 0, st, (const SegDesc *)segs, nseg,
-                       T, R, rrc, voff, fmat, wmax, opbuf, votes, status);
+    const size_t lds = (size_t)(2 * bandmax + 2) * 64 + ((size_t)(qmax + 7) / 8 + 1) * 256;
+    hipLaunchKernelGGL(k_seg_vote, dim3((nseg + 63) / 64), dim3(64), lds, st, (const SegDesc *)segs, nseg,
+                       T, R, rrc, voff, dmat, bandmax, opbuf, votes, status);
 }
 
 void dhk_emit(hipStream_t st, DbView T, int32_t ntmpl, const int64_t *voff, const uint32_t *votes,

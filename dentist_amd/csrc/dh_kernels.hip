@@ -647,7 +647,7 @@ __device__ ExtResult ext_wave(const uint8_t *ap_, int32_t an, const uint8_t *bp_
     // HB / NBB the same for the B-offset boundaries (SYM only)
     constexpr int32_t DEAD = -(1 << 30);
     int32_t R = DEAD, H = -1, NB = 0, HB = -1, NBB = 0;
-    int32_t L = 0, U = 0;
+    int32_t L = 0;
 
     // d = 0: the seed diagonal, slid by lane 0
     int32_t i0 = 0, h0 = -1, nb0 = 0, hb0 = -1, nbb0 = 0;
@@ -844,7 +844,6 @@ __device__ ExtResult ext_wave(const uint8_t *ap_, int32_t an, const uint8_t *bp_
             u2 = __builtin_amdgcn_readfirstlane(nL + (63 - __clzll((long long)rm)));
         }
         L = l2;
-        U = u2;
     }
     cells += ncell;
     ExtResult res;

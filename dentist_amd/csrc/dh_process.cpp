@@ -28,8 +28,8 @@ void dhk_tile_qv(hipStream_t st, const DhLa *las, const uint16_t *trace, const i
                  const int64_t *roff, int32_t nreads, int32_t tspace, const int32_t *cov, int32_t maxtiles,
                  uint8_t *qv);
 void dhk_seg_vote(hipStream_t st, const void *segs, int32_t nseg, DbView T, DbView R,
-                  const uint8_t *rrc, const int64_t *voff, uint8_t *fmat, int32_t wmax, uint8_t *opbuf,
-                  uint32_t *votes, int32_t *status);
+                  const uint8_t *rrc, const int64_t *voff, uint32_t *dmat, int32_t bandmax, int32_t qmax,
+                  uint8_t *opbuf, uint32_t *votes, int32_t *status);
 void dhk_emit(hipStream_t st, DbView T, int32_t ntmpl, const int64_t *voff, const uint32_t *votes,
               const int32_t *col_tmpl, int64_t ncols_total, uint8_t *stage, uint8_t *cnt,
               const int64_t *out_off, uint8_t *out, int32_t *out_len);
@@ -46,7 +46,7 @@ struct PartDescH {
 };
 
 struct SegDescH {
-    int32_t tmpl, a0, a1, bseq, b0, b1, comp, pad;
+    int32_t tmpl, a0, a1, bseq, b0, b1, comp, band;
 };
 
 extern "C" void dh_default_process_opts(dh_process_opts *o)
@@ -359,7 +359,7 @@ static int consensus_round(dh_ctx *ctx, dh_db *T, dh_db *R, const LaVec &las,
 {
     hipStream_t st = ctx->stream;
     std::vector<SegDescH> segs;
-    int32_t wmax = 1;
+    int32_t wmax = 1, bandmax = 1;
     int64_t ncell = 0;
     for (size_t i = 0; i < las.size(); i++) {
         const int32_t t = tmpl_of[i];
@@ -371,10 +371,13 @@ static int consensus_round(dh_ctx *ctx, dh_db *T, dh_db *R, const LaVec &las,
             int32_t a1 = (a0 / ts + 1) * ts;
             if (a1 > la.aepos) a1 = la.aepos;
             const int32_t b1 = b0 + tr[2 * e + 1];
-            SegDescH s{t, a0, a1, la.bread, b0, b1, (int32_t)(la.flags & DH_FLAG_COMP), 0};
+            // DP band: the trace's own path through the tile bounds the optimum (k_seg_vote)
+            const int32_t band = std::min<int32_t>((int32_t)tr[2 * e], std::max(a1 - a0, b1 - b0)) + 1;
+            SegDescH s{t, a0, a1, la.bread, b0, b1, (int32_t)(la.flags & DH_FLAG_COMP), band};
             segs.push_back(s);
             wmax = std::max(wmax, b1 - b0);
-            ncell += (int64_t)(a1 - a0) * (b1 - b0);
+            bandmax = std::max(bandmax, band);
+            ncell += (int64_t)(a1 - a0) * std::min(b1 - b0, 2 * band + 1);
             a0 = a1;
             b0 = b1;
         }
@@ -414,18 +417,19 @@ static int consensus_round(dh_ctx *ctx, dh_db *T, dh_db *R, const LaVec &las,
     HIPCHK(hipMemsetAsync(d_status.p, 0, sizeof(int32_t), st));
     if (int rc = dh_ensure_rc(R)) return rc;
     // the score matrices of one launch live interleaved in HBM: bound the launch to ~6 GB
-    const int64_t per_dp = (int64_t)(ts + 1) * (wmax + 1) + 2 * SEG_MAX;
+    const size_t mrow = 4 * (size_t)((2 * bandmax + 16) >> 4);  // bytes of 2-bit decisions per matrix row
+    const int64_t per_dp = (int64_t)(ts + 1) * (int64_t)mrow + 2 * SEG_MAX;
     const int64_t max_dp = std::max<int64_t>(4096, (6ll << 30) / per_dp);
     for (size_t s0 = 0; s0 < segs.size(); s0 += (size_t)max_dp) {
         const int32_t cnt = (int32_t)std::min<size_t>((size_t)max_dp, segs.size() - s0);
         struct { SegDescH *p; } ds;
         struct { uint8_t *p; } fm, ob;
         SCRP(22, ds, (size_t)cnt)
-        SCRP(23, fm, (size_t)cnt * (size_t)(ts + 1) * (size_t)(wmax + 1) + (size_t)cnt * 2 * SEG_MAX)
-        ob.p = fm.p + (size_t)cnt * (size_t)(ts + 1) * (size_t)(wmax + 1);
+        SCRP(23, fm, (size_t)cnt * (size_t)(ts + 1) * mrow + (size_t)cnt * 2 * SEG_MAX)
+        ob.p = fm.p + (size_t)cnt * (size_t)(ts + 1) * mrow;
         HIPCHK(hipMemcpyAsync(ds.p, segs.data() + s0, sizeof(SegDescH) * (size_t)cnt, hipMemcpyHostToDevice, st));
-        dhk_seg_vote(st, ds.p, cnt, T->view(), R->view(), R->d_rc, d_voff.p, fm.p, wmax, ob.p, d_votes.p,
-                     d_status.p);
+        dhk_seg_vote(st, ds.p, cnt, T->view(), R->view(), R->d_rc, d_voff.p, (uint32_t *)fm.p, bandmax, wmax,
+                     ob.p, d_votes.p, d_status.p);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(st));
     }
