@@ -26,6 +26,9 @@ int dh_fail(int code, const std::string &msg)
 }
 #define fail dh_fail
 
+#ifdef DH_SEED_PROF
+extern "C" void dhk_seed_prof_dump();
+#endif
 // ------------------------------------------------------------------------------------ allocator
 #include <map>
 #include <mutex>
@@ -684,7 +687,9 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
         int32_t *ncandbase = d_ncand - item0, *nhitsbase = d_nhits - item0;
         int32_t *nlabase = (int32_t *)d_nla - item0, *ntrbase = (int32_t *)d_ntr - item0;
         HIPCHK(hipEventRecord(ctx->ev[2], st));
-        dhk_seed(st, cap, bv, B->d_rc, iv, dopt, (int32_t)item0, ni, candbase, ncandbase, nhitsbase, d_status);
+        HIPCHK(hipMemsetAsync(d_queue, 0, 4 * sizeof(uint32_t), st));
+        dhk_seed(st, cap, bv, B->d_rc, iv, dopt, (int32_t)item0, ni, candbase, ncandbase, nhitsbase, d_status,
+                 d_queue + 1, ctx->ncu);
         HIPCHK(hipGetLastError());
         {
             // items whose hits did not fit the LDS buffer (ncand == -1) are redone with their hits
@@ -720,8 +725,9 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
                 HIPCHK(hipMemcpyAsync(d_list, big.data(), sizeof(int32_t) * big.size(), hipMemcpyHostToDevice, st));
                 for (size_t b0 = 0; b0 < big.size(); b0 += per_launch) {
                     const int32_t cnt = (int32_t)std::min(per_launch, big.size() - b0);
+                    HIPCHK(hipMemsetAsync(d_queue + 2, 0, sizeof(uint32_t), st));
                     dhk_seed_big(st, bv, B->d_rc, iv, dopt, d_list + b0, cnt, d_gbuf, pow2, candbase, ncandbase,
-                                 nhitsbase, d_status);
+                                 nhitsbase, d_status, d_queue + 2, ctx->ncu);
                     HIPCHK(hipGetLastError());
                 }
                 HIPCHK(hipMemcpyAsync(&status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -820,6 +826,9 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
         c.trace_values += (int64_t)res->trace.size();
         for (const dh_la &l : res->la) c.aligned_bp += l.aepos - l.abpos;
     }
+#ifdef DH_SEED_PROF
+    if (getenv("DH_TRACE")) dhk_seed_prof_dump();
+#endif
     if (getenv("DH_TRACE"))
         fprintf(stderr,
                 "[dh_align_db] A=%d seqs/%lld bp B=%d seqs/%lld bp hits=%lld cands=%lld aln=%lld las=%lld cells=%lld | "

@@ -70,10 +70,10 @@ void dhk_bucket_bits(hipStream_t st, const uint32_t *dir_end, int64_t nb, uint32
 void dhk_bucket_sort(hipStream_t st, const uint32_t *dir_end, int64_t nb, ulonglong2 *ent);
 void dhk_seed(hipStream_t st, int cap, DbView B, const uint8_t *brc, IndexView ix, DhOpts o,
               int32_t item0, int32_t nitems, DhCand *cand, int32_t *ncand, int32_t *nhits,
-              int32_t *status);
+              int32_t *status, uint32_t *queue, int32_t ncu);
 void dhk_seed_big(hipStream_t st, DbView B, const uint8_t *brc, IndexView ix, DhOpts o,
                   const int32_t *item_list, int32_t nitems, uint64_t *gbuf, int32_t gcap, DhCand *cand,
-                  int32_t *ncand, int32_t *nhits, int32_t *status);
+                  int32_t *ncand, int32_t *nhits, int32_t *status, uint32_t *queue, int32_t ncu);
 void dhk_wave(hipStream_t st, int32_t nslots, DbView A, DbView B, const uint8_t *brc, DhOpts o,
               int32_t item0, int32_t nitems, const DhCand *cand, const int32_t *ncand,
               WaveScratch ws, DhLa *out_la, uint16_t *out_trace, int32_t trmax, int32_t *out_nla,

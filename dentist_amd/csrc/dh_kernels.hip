@@ -13,16 +13,31 @@
 // The arithmetic specification these kernels implement is written down in DESIGN.md
 // ("Algorithm DH-1"); reference call sites: source/dentist/dazzler.d:6121-6170.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdint.h>
 
 #include "dh_device.h"
 
 #define LANES 64
 
-// modimer sampling (daligner -%): the same k-mers are kept on the A and on the B side
-__device__ __forceinline__ bool kmer_sampled(uint64_t km, int32_t mod)
+// modimer sampling (daligner -%): the same k-mers are kept on the A and on the B side.
+// hash % mod == 0 is evaluated without a division (Lemire & Kaser, "Faster remainder by direct
+// computation"): for 32-bit h and M = floor((2^64 - 1) / mod) + 1, mod | h  <=>  h * M mod 2^64 <= M - 1.
+struct KmerSampler {
+    uint64_t M;
+    bool all;
+};
+__device__ __forceinline__ KmerSampler kmer_sampler(int32_t mod)
 {
-    return mod <= 1 || (uint32_t)((km * 0x9E3779B97F4A7C15ull) >> 32) % (uint32_t)mod == 0;
+    KmerSampler s;
+    s.all = mod <= 1;
+    s.M = s.all ? 0ull : ~0ull / (uint64_t)(uint32_t)mod + 1ull;
+    return s;
+}
+__device__ __forceinline__ bool kmer_sampled(uint64_t km, const KmerSampler &s)
+{
+    const uint32_t h = (uint32_t)((km * 0x9E3779B97F4A7C15ull) >> 32);
+    return s.all || (uint64_t)h * s.M <= s.M - 1ull;
 }
 
 __device__ __forceinline__ uint64_t load8(const uint8_t *p)
@@ -116,6 +131,7 @@ k_kmer_pass(DbView A, const int2 *__restrict__ tiles, int32_t ntiles, int32_t k,
     const uint64_t grp = A.group ? (uint64_t)A.group[s] : 0ull;
     const uint64_t mask = (1ull << (2 * k)) - 1;
     const int32_t p0 = tiles[t].y + threadIdx.x * (KM_TILE / 256);
+    const KmerSampler smp = kmer_sampler(kmer_mod);
     uint64_t km = 0;
     int32_t valid = 0;
     const uint8_t *a = A.bases + o;
@@ -131,7 +147,7 @@ k_kmer_pass(DbView A, const int2 *__restrict__ tiles, int32_t ntiles, int32_t k,
             km = 0;
             valid = 0;
         }
-        if (x >= k - 1 && valid >= k && kmer_sampled(km, kmer_mod) &&
+        if (x >= k - 1 && valid >= k && kmer_sampled(km, smp) &&
             !(A.mask_ptr && mask_touch(mc, p - k + 1, k))) {
             const uint64_t key = (grp << (2 * k)) | km;
             const uint32_t b = (uint32_t)(key >> shift);
@@ -264,6 +280,7 @@ __global__ void __launch_bounds__(256) k_bucket_bits(const uint32_t *__restrict_
 #define HIT_QBITS 24
 #define HIT_QMASK ((1u << HIT_QBITS) - 1u)
 #define SEED_THREADS 512
+#define SEED_LOOKUP_THREADS 512 /* threads that roll k-mers (whole wavefronts; fewer = longer serial chains = slower) */
 #define SEED_CCAP 256 /* candidate band pairs collected per (read, strand) before ranking */
 
 __device__ __forceinline__ int64_t hitD(uint64_t h) { return (int64_t)(h >> HIT_QBITS); }
@@ -282,24 +299,34 @@ __device__ __forceinline__ int32_t hit_cov(const uint64_t *h, int32_t i, int32_t
 // LCAP > 0: hits are staged in LDS (LCAP entries); items that do not fit are marked with
 // ncand = -1 and redone by the LCAP == 0 instantiation, whose hit buffer is a slab of HBM
 // (gcap entries per block, items taken from item_list) -- same code, same results.
+#ifdef DH_SEED_PROF
+__device__ unsigned long long g_seed_prof[8];
+#define SP(i) if (tid == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_seed_prof[i], t_ - tp_); tp_ = t_; }
+#else
+#define SP(i)
+#endif
+// One (read, strand) item, processed by the whole block; `work` = index of the item in this
+// launch, `slab` = index of the block's HBM hit slab (LCAP == 0).
 template <int LCAP>
-__global__ void __launch_bounds__(SEED_THREADS)
-k_seed(DbView B, const uint8_t *__restrict__ brc, IndexView ix, DhOpts o, int32_t item0,
-       int32_t nitems, DhCand *__restrict__ cand_out, int32_t *__restrict__ ncand_out,
-       int32_t *__restrict__ nhits_out, int32_t *__restrict__ status, uint64_t *__restrict__ gbuf,
-       int32_t gcap, const int32_t *__restrict__ item_list)
+__device__ void seed_item(const DbView &B, const uint8_t *__restrict__ brc, const IndexView &ix,
+                          const DhOpts &o, int32_t item0, int32_t work, int32_t slab,
+                          DhCand *__restrict__ cand_out, int32_t *__restrict__ ncand_out,
+                          int32_t *__restrict__ nhits_out, int32_t *__restrict__ status,
+                          uint64_t *__restrict__ gbuf, int32_t gcap, const int32_t *__restrict__ item_list)
 {
     __shared__ uint64_t lhits[LCAP > 0 ? LCAP : 1];
     __shared__ DhCand cands[SEED_CCAP];
     __shared__ int64_t cband[SEED_CCAP];
     __shared__ int32_t s_n, s_nc;
 
-    if (blockIdx.x >= (unsigned)nitems) return;
-    const int32_t item = LCAP > 0 ? item0 + (int32_t)blockIdx.x : item_list[blockIdx.x];
-    uint64_t *hits = LCAP > 0 ? lhits : gbuf + (int64_t)blockIdx.x * gcap;
+    const int32_t item = LCAP > 0 ? item0 + work : item_list[work];
+    uint64_t *hits = LCAP > 0 ? lhits : gbuf + (int64_t)slab * gcap;
     const int32_t CAP = LCAP > 0 ? LCAP : gcap;
     const int32_t r = item >> 1, strand = item & 1;
     const int tid = threadIdx.x;
+#ifdef DH_SEED_PROF
+    unsigned long long tp_ = wall_clock64();
+#endif
     if (tid == 0) {
         s_n = 0;
         s_nc = 0;
@@ -320,78 +347,131 @@ k_seed(DbView B, const uint8_t *__restrict__ brc, IndexView ix, DhOpts o, int32_
     const uint64_t mask = (1ull << (2 * k)) - 1;
     const int32_t npos = blen - k + 1;
 
-    // ---- k-mer lookups: thread t rolls over a contiguous chunk of positions
-    if (npos > 0) {
-        const int32_t per = (npos + SEED_THREADS - 1) / SEED_THREADS;
+    // ---- k-mer lookups: thread t rolls over a contiguous chunk of positions.  Sampled k-mers are
+    // queued in registers (SEED_QN per lane); when the queue of ANY lane of the wavefront is full
+    // every lane looks up what it holds: the directory words of all queued k-mers are fetched
+    // back to back, then the first (key, value) entry of every non-empty bucket -- two memory
+    // round trips per flush for all lanes together.  Buckets hold one entry almost always (the
+    // directory has ~8 buckets per indexed k-mer); longer ones take the generic loop.
+    // The phase is bound by the latency of each lane's serial chain (measured: halving the number
+    // of rolling threads makes it 40 % slower), so every thread of the block takes a chunk.
+    if (npos > 0 && tid < SEED_LOOKUP_THREADS) {
+        constexpr int QN = 4;
+        const int32_t per = (npos + SEED_LOOKUP_THREADS - 1) / SEED_LOOKUP_THREADS;
         const int32_t q0 = tid * per, q1 = min(npos, q0 + per);
+        const KmerSampler smp = kmer_sampler(o.kmer_mod);
         uint64_t km = 0;
         int32_t valid = 0;
         const int32_t pend = q0 < q1 ? q1 + k - 1 : q0;
         MaskCur mc = mask_open(B, r, blen, strand, q0);
-        // 8 bases per iteration: the 8-byte word of the read is prefetched one iteration ahead,
-        // 8 k-mers are rolled in registers, the 8 directory lookups are issued back to back
-        // (memory-level parallelism), then the rare non-empty buckets are resolved with one
-        // 16-byte (key, value) load per entry: 2 dependent memory round trips per iteration
-        uint64_t wnext = q0 < pend ? load8(b + q0) : 0ull;
-        for (int32_t p = q0; p < pend; p += 8) {
-            const uint64_t w = wnext;
-            if (p + 8 < pend) wnext = load8(b + p + 8);
-            uint64_t keys[8];
-            uint32_t bks[8];
-            bool em[8];
+        uint64_t qk[QN];
+        int32_t qq[QN];
+        int32_t nq = 0;
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int32_t pp = p + u;
-                const uint8_t c = (uint8_t)(w >> (8 * u));
-                if (pp < pend) {
-                    if (c < 4) {
-                        km = ((km << 2) | c) & mask;
-                        valid++;
-                    } else {
-                        km = 0;
-                        valid = 0;
-                    }
+        for (int u = 0; u < QN; u++) {
+            qk[u] = 0;
+            qq[u] = 0;
+        }
+        auto emit = [&](uint64_t v, int32_t q) {
+            const int32_t aseq = (int32_t)(v >> 40);
+            if (o.skip_self == 1 && aseq == r) return;
+            // symmetric: each unordered pair once; which read plays B alternates with the
+            // parity of a + b, so every read is B for about half of its partners
+            if (o.skip_self == 2 && (aseq == r || ((aseq < r) != (((aseq + r) & 1) == 0)))) return;
+            const int64_t gv = (int64_t)(v & ((1ull << 40) - 1));
+            const int64_t D = gv + ix.sepv - q;
+            const int32_t slot = atomicAdd(&s_n, 1);
+            if (slot < CAP) hits[slot] = ((uint64_t)D << HIT_QBITS) | (uint32_t)q;
+        };
+        auto flush = [&]() {
+            uint32_t ss[QN], ee[QN];
+#pragma unroll
+            for (int u = 0; u < QN; u++) {
+                const uint32_t bk = u < nq ? (uint32_t)(qk[u] >> ix.shift) : 0u;
+                ss[u] = bk ? ix.dir[bk - 1] : 0u;
+                ee[u] = u < nq ? ix.dir[bk] : 0u;
+            }
+            ulonglong2 e0[QN];
+#pragma unroll
+            for (int u = 0; u < QN; u++)
+                if (ss[u] < ee[u]) e0[u] = ix.ent[ss[u]];
+#pragma unroll
+            for (int u = 0; u < QN; u++) {
+                if (ss[u] >= ee[u]) continue;
+                const uint64_t key = qk[u];
+                if (ee[u] - ss[u] == 1u) {
+                    if (e0[u].x == key && o.tcap >= 1) emit(e0[u].y, qq[u]);
+                    continue;
                 }
-                em[u] = pp < pend && pp - q0 >= k - 1 && valid >= k && kmer_sampled(km, o.kmer_mod);
-                if (em[u] && B.mask_ptr && mask_touch(mc, pp - k + 1, k)) em[u] = false;
-                keys[u] = (grp << (2 * k)) | km;
-                bks[u] = em[u] ? (uint32_t)(keys[u] >> ix.shift) : 0u;
-            }
-            uint32_t ss[8], ee[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                ss[u] = bks[u] ? ix.dir[bks[u] - 1] : 0u;
-                ee[u] = ix.dir[bks[u]];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                if (!em[u] || ss[u] >= ee[u]) continue;
-                const uint64_t key = keys[u];
-                const int32_t q = p + u - k + 1;
-                const uint32_t e = ee[u];
                 // the bucket is sorted by key: count the run of equal keys first (-t cap) ...
                 int32_t run = 0;
-                for (uint32_t t = ss[u]; t < e; t++) run += ix.ent[t].x == key ? 1 : 0;
+                for (uint32_t t = ss[u]; t < ee[u]; t++) run += ix.ent[t].x == key ? 1 : 0;
                 if (run == 0 || run > o.tcap) continue;
                 // ... then emit its hits
-                for (uint32_t t = ss[u]; t < e; t++) {
+                for (uint32_t t = ss[u]; t < ee[u]; t++) {
                     const ulonglong2 en = ix.ent[t];
-                    if (en.x != key) continue;
-                    const uint64_t v = en.y;
-                    const int32_t aseq = (int32_t)(v >> 40);
-                    if (o.skip_self == 1 && aseq == r) continue;
-                    // symmetric: each unordered pair once; which read plays B alternates with the
-                    // parity of a + b, so every read is B for about half of its partners
-                    if (o.skip_self == 2 && (aseq == r || ((aseq < r) != (((aseq + r) & 1) == 0)))) continue;
-                    const int64_t gv = (int64_t)(v & ((1ull << 40) - 1));
-                    const int64_t D = gv + ix.sepv - q;
-                    const int32_t slot = atomicAdd(&s_n, 1);
-                    if (slot < CAP) hits[slot] = ((uint64_t)D << HIT_QBITS) | (uint32_t)q;
+                    if (en.x == key) emit(en.y, qq[u]);
+                }
+            }
+            nq = 0;
+        };
+        // warm-up: the first k - 1 bases of the chunk only fill the rolling k-mer
+        uint64_t w = 0, wnext = q0 < pend ? load8(b + q0) : 0ull;
+        for (int32_t t = 0; t < k - 1; t++) {
+            const int32_t pp = q0 + t;
+            if ((t & 7) == 0) {
+                w = wnext;
+                if (pp + 8 < pend) wnext = load8(b + pp + 8);
+            }
+            const uint8_t c = (uint8_t)w;
+            w >>= 8;
+            if (pp < pend) {
+                if (c < 4) {
+                    km = ((km << 2) | c) & mask;
+                    valid++;
+                } else {
+                    km = 0;
+                    valid = 0;
                 }
             }
         }
+        // uniform trip count so that the wavefront flushes together
+        for (int32_t t = k - 1; t < per + k - 1; t++) {
+            const int32_t pp = q0 + t;
+            if ((t & 7) == 0) {
+                w = wnext;
+                if (pp + 8 < pend) wnext = load8(b + pp + 8);
+            }
+            const uint8_t c = (uint8_t)w;
+            w >>= 8;
+            if (pp < pend) {
+                if (c < 4) {
+                    km = ((km << 2) | c) & mask;
+                    valid++;
+                } else {
+                    km = 0;
+                    valid = 0;
+                }
+                bool em = valid >= k && kmer_sampled(km, smp);
+                if (em && B.mask_ptr && mask_touch(mc, pp - k + 1, k)) em = false;
+                if (em) {
+                    const uint64_t key = (grp << (2 * k)) | km;
+                    const int32_t q = pp - k + 1;
+#pragma unroll
+                    for (int u = 0; u < QN; u++)
+                        if (u == nq) {
+                            qk[u] = key;
+                            qq[u] = q;
+                        }
+                    nq++;
+                }
+            }
+            if (__ballot(nq == QN) != 0ull) flush();
+        }
+        if (__ballot(nq > 0) != 0ull) flush();
     }
     __syncthreads();
+    SP(0)
     int32_t n = s_n;
     if (tid == 0) nhits_out[item] = n;
     if (n > CAP) {
@@ -437,6 +517,7 @@ k_seed(DbView B, const uint8_t *__restrict__ brc, IndexView ix, DhOpts o, int32_
         }
     }
     __syncthreads();
+    SP(1)
     // ---- band heads: coverage of bands b-1, b, b+1, b+2.  Small variants: every head sums its own
     // band once and publishes (coverage, end) at the head and the coverage at the tail, the
     // neighbours are then looked up; large variants (no LDS to spare) walk the four bands.
@@ -455,6 +536,7 @@ k_seed(DbView B, const uint8_t *__restrict__ brc, IndexView ix, DhOpts o, int32_
             bend[i] = (uint16_t)j;
         }
         __syncthreads();
+        SP(2)
     }
     for (int32_t i = tid; i < n; i += SEED_THREADS) {
         const int64_t band = hitD(hits[i]) >> bs;
@@ -517,6 +599,7 @@ k_seed(DbView B, const uint8_t *__restrict__ brc, IndexView ix, DhOpts o, int32_
         }
     }
     __syncthreads();
+    SP(3)
     int32_t nc = s_nc;
     if (nc > SEED_CCAP) {
         if (tid == 0) {
@@ -535,11 +618,35 @@ k_seed(DbView B, const uint8_t *__restrict__ brc, IndexView ix, DhOpts o, int32_
         if (rank < o.max_cand) cand_out[(int64_t)item * o.max_cand + rank] = cands[c];
     }
     if (tid == 0) ncand_out[item] = nc < o.max_cand ? nc : o.max_cand;
+    SP(4)
+#ifdef DH_SEED_PROF
+    if (tid == 0) atomicAdd(&g_seed_prof[7], 1ull);
+#endif
+}
+// Persistent blocks: the grid is sized to the resident capacity of the chip and every block pulls
+// items from an atomic queue (no per-item block launch, dynamic balance over ragged read lengths).
+template <int LCAP>
+__global__ void __launch_bounds__(SEED_THREADS, (LCAP > 0 && LCAP <= 2048) ? 8 : (LCAP == 16384 ? 2 : 4))
+k_seed(DbView B, const uint8_t *__restrict__ brc, IndexView ix, DhOpts o, int32_t item0,
+       int32_t nitems, DhCand *__restrict__ cand_out, int32_t *__restrict__ ncand_out,
+       int32_t *__restrict__ nhits_out, int32_t *__restrict__ status, uint64_t *__restrict__ gbuf,
+       int32_t gcap, const int32_t *__restrict__ item_list, uint32_t *__restrict__ queue)
+{
+    __shared__ int32_t s_work;
+    for (;;) {
+        __syncthreads();  // the previous item is finished by every thread (shared state is reused)
+        if (threadIdx.x == 0) s_work = (int32_t)atomicAdd(queue, 1u);
+        __syncthreads();
+        const int32_t work = s_work;
+        if (work >= nitems) break;
+        seed_item<LCAP>(B, brc, ix, o, item0, work, (int32_t)blockIdx.x, cand_out, ncand_out, nhits_out,
+                        status, gbuf, gcap, item_list);
+    }
 }
 #define SEED_INST(C)                                                                              \
     template __global__ void k_seed<C>(DbView, const uint8_t *, IndexView, DhOpts, int32_t, int32_t,  \
                                        DhCand *, int32_t *, int32_t *, int32_t *, uint64_t *, int32_t, \
-                                       const int32_t *);
+                                       const int32_t *, uint32_t *);
 SEED_INST(1024)
 SEED_INST(2048)
 SEED_INST(4096)
@@ -1129,6 +1236,21 @@ k_compact(const DhLa *__restrict__ la_slots, const uint16_t *__restrict__ tr_slo
 
 // ------------------------------------------------------------------------------------ launchers
 
+// resident blocks of a seed variant on the whole chip (persistent grid size)
+template <int C>
+static int seed_grid(int32_t nitems, int32_t ncu)
+{
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_seed<C>, SEED_THREADS, 0) != hipSuccess || nb < 1)
+            nb = 1;
+        per_cu = nb;
+    }
+    const int64_t g = (int64_t)per_cu * ncu;
+    return (int)(g < nitems ? g : nitems);
+}
+
 extern "C" {
 
 void dhk_revcomp(hipStream_t st, const uint8_t *src, uint8_t *dst, const int64_t *off, int32_t n,
@@ -1179,14 +1301,16 @@ void dhk_bucket_sort(hipStream_t st, const uint32_t *dir_end, int64_t nb, ulongl
                        nb, ent);
 }
 
+// queue: one zeroed uint32 (work counter of the persistent blocks)
 void dhk_seed(hipStream_t st, int cap, DbView B, const uint8_t *brc, IndexView ix, DhOpts o,
               int32_t item0, int32_t nitems, DhCand *cand, int32_t *ncand, int32_t *nhits,
-              int32_t *status)
+              int32_t *status, uint32_t *queue, int32_t ncu)
 {
     if (nitems <= 0) return;
 #define SEED_LAUNCH(C)                                                                            \
-    hipLaunchKernelGGL(k_seed<C>, dim3(nitems), dim3(SEED_THREADS), 0, st, B, brc, ix, o, item0, nitems, \
-                       cand, ncand, nhits, status, (uint64_t *)nullptr, 0, (const int32_t *)nullptr)
+    hipLaunchKernelGGL(k_seed<C>, dim3(seed_grid<C>(nitems, ncu)), dim3(SEED_THREADS), 0, st, B, brc, ix, o, \
+                       item0, nitems, cand, ncand, nhits, status, (uint64_t *)nullptr, 0,         \
+                       (const int32_t *)nullptr, queue)
     if (cap <= 1024)
         SEED_LAUNCH(1024);
     else if (cap <= 2048)
@@ -1200,14 +1324,25 @@ void dhk_seed(hipStream_t st, int cap, DbView B, const uint8_t *brc, IndexView i
 #undef SEED_LAUNCH
 }
 
-// the items listed in item_list (absolute ids) with their hits staged in HBM, gcap entries each
+#ifdef DH_SEED_PROF
+void dhk_seed_prof_dump()
+{
+    unsigned long long h[8];
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_seed_prof), sizeof(h));
+    fprintf(stderr, "[seed prof] blocks %llu: lookup %.1f sort %.1f bcov %.1f bands %.1f rank %.1f us/block\n", h[7], h[0] / 100.0 / h[7], h[1] / 100.0 / h[7], h[2] / 100.0 / h[7], h[3] / 100.0 / h[7], h[4] / 100.0 / h[7]);
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_seed_prof), z, sizeof(z));
+}
+#endif
+// the items listed in item_list (absolute ids) with their hits staged in HBM: block x owns the
+// slab gbuf[x * gcap ..]; nslabs bounds the grid
 void dhk_seed_big(hipStream_t st, DbView B, const uint8_t *brc, IndexView ix, DhOpts o,
                   const int32_t *item_list, int32_t nitems, uint64_t *gbuf, int32_t gcap, DhCand *cand,
-                  int32_t *ncand, int32_t *nhits, int32_t *status)
+                  int32_t *ncand, int32_t *nhits, int32_t *status, uint32_t *queue, int32_t ncu)
 {
     if (nitems <= 0) return;
-    hipLaunchKernelGGL(k_seed<0>, dim3(nitems), dim3(SEED_THREADS), 0, st, B, brc, ix, o, 0, nitems, cand,
-                       ncand, nhits, status, gbuf, gcap, item_list);
+    hipLaunchKernelGGL(k_seed<0>, dim3(seed_grid<0>(nitems, ncu)), dim3(SEED_THREADS), 0, st, B, brc, ix, o, 0,
+                       nitems, cand, ncand, nhits, status, gbuf, gcap, item_list, queue);
 }
 
 void dhk_wave(hipStream_t st, int32_t nslots, DbView A, DbView B, const uint8_t *brc, DhOpts o,
