@@ -749,11 +749,12 @@ __device__ ExtResult ext_wave(const uint8_t *ap_, int32_t an, const uint8_t *bp_
     const gptr_t ar = uniform_ptr(ap_ - an - 7), br = uniform_ptr(bp_ - bn - 7);
     tp_first = __builtin_amdgcn_readfirstlane(tp_first);
     tpb_first = __builtin_amdgcn_readfirstlane(tpb_first);
-    // per-lane state of diagonal k: R = furthest i (-1 dead), H = head of its trace chain,
-    // NB = number of trace boundaries <= R (carried along so that no division is needed);
-    // HB / NBB the same for the B-offset boundaries (SYM only)
+    // per-lane state of diagonal k: R = furthest i (DEAD when dead), H = head of its trace chain,
+    // NB = the first trace boundary above R (tp_first + #boundaries * ts, carried along so that the
+    // loop needs neither a division nor a multiplication); HB / NBB the same for the B-offset
+    // boundaries (SYM only)
     constexpr int32_t DEAD = -(1 << 30);
-    int32_t R = DEAD, H = -1, NB = 0, HB = -1, NBB = 0;
+    int32_t R = DEAD, H = -1, NB = tp_first, HB = -1, NBB = tpb_first;
     int32_t L = 0;
 
     // d = 0: the seed diagonal, slid by lane 0
@@ -787,9 +788,9 @@ __device__ ExtResult ext_wave(const uint8_t *ap_, int32_t an, const uint8_t *bp_
             }
         R = i0;
         H = h0;
-        NB = nb0;
+        NB = tp_first + nb0 * ts;
         HB = hb0;
-        NBB = nbb0;
+        NBB = tpb_first + nbb0 * ts;
     }
     // wave-uniform values are pinned to SGPRs (readfirstlane) so that the window arithmetic,
     // mask rotations and find-first-set below run on the scalar unit
@@ -799,8 +800,8 @@ __device__ ExtResult ext_wave(const uint8_t *ap_, int32_t an, const uint8_t *bp_
     hb0 = __builtin_amdgcn_readfirstlane(hb0);
     nbb0 = __builtin_amdgcn_readfirstlane(nbb0);
     pool_n = __builtin_amdgcn_readfirstlane(pool_n + nb0 + nbb0);
-    int32_t best_score = 2 * i0, best_i = i0, best_k = 0, best_d = 0, best_head = h0, best_nb = nb0;
-    int32_t best_headb = hb0, best_nbb = nbb0;
+    int32_t best_score = 2 * i0, best_i = i0, best_k = 0, best_d = 0, best_head = h0;
+    int32_t best_nb = tp_first + nb0 * ts, best_headb = hb0, best_nbb = tpb_first + nbb0 * ts;
     unsigned long long ncell = 1;
 
     for (int32_t d = 1; d <= o.dmax; d++) {
@@ -809,7 +810,7 @@ __device__ ExtResult ext_wave(const uint8_t *ap_, int32_t an, const uint8_t *bp_
         const int32_t k = nL + kidx;
         const int32_t Rm = from_lower_lane(R), Hm = from_lower_lane(H), Nm = from_lower_lane(NB);
         const int32_t Rp = from_upper_lane(R), Hp = from_upper_lane(H), Np = from_upper_lane(NB);
-        int32_t HBm = -1, NBm = 0, HBp = -1, NBp = 0;
+        int32_t HBm = -1, NBm = tpb_first, HBp = -1, NBp = tpb_first;
         if (SYM) {
             HBm = from_lower_lane(HB);
             NBm = from_lower_lane(NBB);
@@ -821,7 +822,7 @@ __device__ ExtResult ext_wave(const uint8_t *ap_, int32_t an, const uint8_t *bp_
         // a dead source never beats ni = -1; sources are valid points, hence j >= 0 holds for all
         // three moves and only i <= an, j <= bn (i <= lim) has to be checked.  Lanes outside the
         // window see dead sources only (width <= 62) and stay dead.
-        int32_t ni = -1, hd = -1, nbp = 0, hb = -1, nbbp = 0;
+        int32_t ni = -1, hd = -1, nbp = tp_first, hb = -1, nbbp = tpb_first;
         const int32_t lim = min(an, bn + k);  // i <= an and i - k <= bn
         {
             const int32_t cs = R + 1, cd = Rm + 1, ci = Rp;
@@ -853,9 +854,8 @@ __device__ ExtResult ext_wave(const uint8_t *ap_, int32_t an, const uint8_t *bp_
         const unsigned long long amask = __ballot(alive);
         if (amask == 0ull) break;
         ncell += __popcll(amask);
-        // trace nodes for the boundaries crossed in (prev_i, ni]: boundary number nbp is the
-        // first one above prev_i
-        int32_t nextb = tp_first + nbp * ts;
+        // trace nodes for the boundaries crossed in (prev_i, ni]: nbp is the first one above prev_i
+        int32_t nextb = nbp;
         bool cross = alive && ni >= nextb;
         for (;;) {
             const unsigned long long m = __ballot(cross);
@@ -868,14 +868,14 @@ __device__ ExtResult ext_wave(const uint8_t *ap_, int32_t an, const uint8_t *bp_
                     pool[idx].j = nextb - k;
                 }
                 hd = idx;
-                nbp++;
                 nextb += ts;
                 cross = ni >= nextb;
             }
             pool_n = __builtin_amdgcn_readfirstlane(pool_n + __popcll(m));
         }
+        int32_t nextbb_out = nbbp;
         if (SYM) {
-            int32_t nextbb = tpb_first + nbbp * ts;
+            int32_t nextbb = nbbp;
             bool crossb = alive && j >= nextbb;
             for (;;) {
                 const unsigned long long m = __ballot(crossb);
@@ -888,12 +888,12 @@ __device__ ExtResult ext_wave(const uint8_t *ap_, int32_t an, const uint8_t *bp_
                         pool[idx].j = nextbb + k;
                     }
                     hb = idx;
-                    nbbp++;
                     nextbb += ts;
                     crossb = j >= nextbb;
                 }
                 pool_n = __builtin_amdgcn_readfirstlane(pool_n + __popcll(m));
             }
+            nextbb_out = nextbb;
         }
         if (pool_n > poolcap) {
             err |= DH_ST_POOL_OVERFLOW;
@@ -901,9 +901,9 @@ __device__ ExtResult ext_wave(const uint8_t *ap_, int32_t an, const uint8_t *bp_
         }
         R = alive ? ni : DEAD;
         H = hd;
-        NB = nbp;
+        NB = nextb;
         HB = hb;
-        NBB = nbbp;
+        NBB = SYM ? nextbb_out : NBB;
         // best of this step: highest score, then lowest diagonal (ballot of the max holders,
         // rotated so that bit x is diagonal nL + x)
         const int32_t sc = alive ? 2 * ni - k - pen * d : INT32_MIN;
@@ -958,9 +958,9 @@ __device__ ExtResult ext_wave(const uint8_t *ap_, int32_t an, const uint8_t *bp_
     res.j = best_i - best_k;
     res.d = best_d;
     res.head = best_head;
-    res.nb = best_nb;
+    res.nb = (best_nb - tp_first) / ts;
     res.headb = best_headb;
-    res.nbb = best_nbb;
+    res.nbb = SYM ? (best_nbb - tpb_first) / ts : 0;
     return res;
 }
 
@@ -1032,8 +1032,8 @@ __device__ int32_t emit_trace(int lane, int32_t ts, int32_t res, int32_t gs, int
 }
 
 // SYM (all-vs-all inside one DB, skip_self == 2): each unordered pair has candidates in one item only; every
-// accepted alignment emits the record (a, b) into the slots of item (b, strand) and the transposed
-// record (b, a) into the slots of item (a, strand); slots are claimed with atomics because any
+// accepted alignment emits the record (a, b) into the slots of item (a, strand) and the transposed
+// record (b, a) into the slots of item (b, strand); slots are claimed with atomics because any
 // wavefront may add records to any item (the final LAsort makes the output order unique).
 template <bool SYM>
 __global__ void __launch_bounds__(LANES)
@@ -1130,17 +1130,20 @@ k_wave(DbView A, DbView B, const uint8_t *__restrict__ brc, DhOpts o, int32_t it
             const bool accept = al >= o.min_len &&
                                 (int64_t)2 * diffs * 1000000ll <= (int64_t)o.max_err_ppm * (al + bl);
             if (!accept) continue;
-            // ---- the record (a, b): trace on the grid of A
+            // ---- the record (a, b): trace on the grid of A.  SYM: it goes to the slots of item
+            // (a, strand) and the transposed record to those of (b, strand), so that the output
+            // is grouped by A read.
+            const int32_t item_a = SYM ? 2 * cd.aseq + strand : item;
             int32_t s1 = nacc;
             if (SYM) {
-                if (lane == 0) s1 = atomicAdd(&out_nla[item], 1);
+                if (lane == 0) s1 = atomicAdd(&out_nla[item_a], 1);
                 s1 = __shfl(s1, 0, LANES);
                 if (s1 >= o.max_la) {
                     err |= DH_ST_POOL_OVERFLOW;
                     break;
                 }
             }
-            const int64_t slot = (int64_t)item * o.max_la + s1;
+            const int64_t slot = (int64_t)item_a * o.max_la + s1;
             const int32_t npairs = emit_trace(lane, ts, 0, as, bs, abpos, aepos, bbpos, bepos, rv.d, fw.d,
                                               rev_first, rv.nb, rd, rj, fwd_first, fw.nb, fd, fj, false,
                                               out_trace + slot * trmax);
@@ -1158,13 +1161,13 @@ k_wave(DbView A, DbView B, const uint8_t *__restrict__ brc, DhOpts o, int32_t it
                 la.pad = 0;
                 la.toff = 0;
                 out_la[slot] = la;
-                if (SYM) atomicAdd(&out_ntr[item], 2 * npairs);
+                if (SYM) atomicAdd(&out_ntr[item_a], 2 * npairs);
             }
             nacc++;
             ntr += 2 * npairs;
             if (SYM) {
                 // ---- the transposed record (b, a): same path, trace on the grid of B
-                const int32_t item2 = 2 * cd.aseq + strand;
+                const int32_t item2 = item;
                 int32_t s2 = 0;
                 if (lane == 0) s2 = atomicAdd(&out_nla[item2], 1);
                 s2 = __shfl(s2, 0, LANES);

@@ -358,7 +358,13 @@ static int consensus_round(dh_ctx *ctx, dh_db *T, dh_db *R, const LaVec &las,
                            int32_t ts, dh_db **newT, int64_t *nseg_out, int64_t *ncell_out)
 {
     hipStream_t st = ctx->stream;
-    std::vector<SegDescH> segs;
+    std::vector<SegDescH, PinnedAlloc<SegDescH>> segs;  // page-locked: uploaded every round
+    {
+        size_t nsegs = 0;
+        for (size_t i = 0; i < las.size(); i++)
+            if (tmpl_of[i] >= 0 && !(las[i].flags & DH_FLAG_DISABLED)) nsegs += (size_t)(las[i].tlen / 2);
+        segs.reserve(nsegs);
+    }
     int32_t wmax = 1, bandmax = 1;
     int64_t ncell = 0;
     for (size_t i = 0; i < las.size(); i++) {
@@ -685,7 +691,10 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
         if (int rc = dh_align_db_ex(ctx, pile, pile, &ao, 0, 0, &pset)) return rc;
         sg.sets.push_back(pset);
         lap("pile align call");
-        {   // group by aread (counting sort, stable); traces stay where they are
+        bool grouped = true;  // the symmetric wave kernel already emits grouped by A read
+        for (size_t i = 1; i < pset->la.size() && grouped; i++)
+            grouped = pset->la[i - 1].aread <= pset->la[i].aread;
+        if (!grouped) {  // group by aread (counting sort, stable); traces stay where they are
             std::vector<int32_t> cnt((size_t)pile->n + 1, 0);
             for (const dh_la &la : pset->la) cnt[(size_t)la.aread + 1]++;
             for (int32_t r = 0; r < pile->n; r++) cnt[(size_t)r + 1] += cnt[(size_t)r];
