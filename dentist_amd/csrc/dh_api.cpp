@@ -771,7 +771,8 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
             SCR(13, d_laout, totals[0])
             SCR(14, d_trout, totals[1])
             const size_t l0 = res->la.size(), t0 = res->trace.size();
-            dhk_compact(st, d_la, d_trslots, trmax, o.max_la, ni, d_nla, d_ntr, (int64_t)t0, d_laout, d_trout);
+            dhk_compact(st, d_la, d_trslots, trmax, o.max_la, o.skip_self == 2 ? 1 : 0, ni, d_nla, d_ntr, (int64_t)t0,
+                        d_laout, d_trout);
             HIPCHK(hipGetLastError());
             res->la.resize(l0 + totals[0]);
             res->trace.resize(t0 + totals[1]);

@@ -79,8 +79,8 @@ void dhk_wave(hipStream_t st, int32_t nslots, DbView A, DbView B, const uint8_t 
               WaveScratch ws, DhLa *out_la, uint16_t *out_trace, int32_t trmax, int32_t *out_nla,
               int32_t *out_ntr, unsigned long long *counters, int32_t *status);
 void dhk_compact(hipStream_t st, const DhLa *la_slots, const uint16_t *tr_slots, int32_t trmax,
-                 int32_t max_la, int32_t nitems, const uint32_t *la_off, const uint32_t *tr_off,
-                 int64_t tr_base, DhLa *la_out, uint16_t *tr_out);
+                 int32_t max_la, int32_t ordered, int32_t nitems, const uint32_t *la_off,
+                 const uint32_t *tr_off, int64_t tr_base, DhLa *la_out, uint16_t *tr_out);
 #ifdef __cplusplus
 }
 #endif

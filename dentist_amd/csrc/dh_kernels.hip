@@ -1212,9 +1212,12 @@ k_wave(DbView A, DbView B, const uint8_t *__restrict__ brc, DhOpts o, int32_t it
 
 // compaction of the per-item output slots: la_off / tr_off are the exclusive scans of the
 // per-item LA counts and trace lengths; one wavefront per item copies its records and traces.
+// ordered != 0 (symmetric mode: slots are claimed in racy order): the records of an item with at
+// most 64 of them are written ordered by (bread, strand, abpos, bbpos, aepos, bepos), which makes
+// the output deterministic and hands the host (A, B) pairs that are already adjacent.
 __global__ void __launch_bounds__(LANES)
 k_compact(const DhLa *__restrict__ la_slots, const uint16_t *__restrict__ tr_slots, int32_t trmax,
-          int32_t max_la, int32_t item_base, int32_t nitems, const uint32_t *__restrict__ la_off,
+          int32_t max_la, int32_t ordered, int32_t nitems, const uint32_t *__restrict__ la_off,
           const uint32_t *__restrict__ tr_off, int64_t tr_base, DhLa *__restrict__ la_out,
           uint16_t *__restrict__ tr_out)
 {
@@ -1223,6 +1226,37 @@ k_compact(const DhLa *__restrict__ la_slots, const uint16_t *__restrict__ tr_slo
     const int lane = threadIdx.x;
     const uint32_t l0 = la_off[it], n = la_off[it + 1] - l0;
     uint32_t t = tr_off[it];
+    if (ordered && n <= LANES) {
+        DhLa la;
+        uint64_t k1 = ~0ull, k2 = ~0ull;
+        int32_t tl = 0;
+        if ((uint32_t)lane < n) {
+            la = la_slots[(int64_t)it * max_la + lane];
+            k1 = ((uint64_t)(uint32_t)la.bread << 32) | ((uint64_t)(la.flags & 1u) << 31) | (uint32_t)la.abpos;
+            k2 = ((uint64_t)(uint32_t)la.bbpos << 32) | (uint32_t)la.aepos;
+            tl = la.tlen;
+        }
+        // rank among the records of the item, trace offset = prefix sum of the slot order
+        int32_t rank = 0, toff = 0;
+        for (uint32_t y = 0; y < n; y++) {
+            const uint64_t y1 = __shfl(k1, (int)y, LANES), y2 = __shfl(k2, (int)y, LANES);
+            const int32_t yt = __shfl(tl, (int)y, LANES);
+            const bool less = y1 < k1 || (y1 == k1 && (y2 < k2 || (y2 == k2 && (int)y < lane)));
+            rank += less ? 1 : 0;
+            toff += (int)y < lane ? yt : 0;
+        }
+        if ((uint32_t)lane < n) {
+            la.toff = tr_base + t + toff;
+            la_out[l0 + rank] = la;
+        }
+        for (uint32_t x = 0; x < n; x++) {
+            const int32_t xl = __shfl(tl, (int)x, LANES);
+            const uint16_t *src = tr_slots + ((int64_t)it * max_la + x) * trmax;
+            for (int32_t e = lane; e < xl; e += LANES) tr_out[t + e] = src[e];
+            t += xl;
+        }
+        return;
+    }
     for (uint32_t x = 0; x < n; x++) {
         const int64_t slot = (int64_t)it * max_la + x;
         DhLa la = la_slots[slot];
@@ -1234,7 +1268,6 @@ k_compact(const DhLa *__restrict__ la_slots, const uint16_t *__restrict__ tr_slo
         }
         t += la.tlen;
     }
-    (void)item_base;
 }
 
 // ------------------------------------------------------------------------------------ launchers
@@ -1363,11 +1396,11 @@ void dhk_wave(hipStream_t st, int32_t nslots, DbView A, DbView B, const uint8_t 
 }
 
 void dhk_compact(hipStream_t st, const DhLa *la_slots, const uint16_t *tr_slots, int32_t trmax,
-                 int32_t max_la, int32_t nitems, const uint32_t *la_off, const uint32_t *tr_off,
-                 int64_t tr_base, DhLa *la_out, uint16_t *tr_out)
+                 int32_t max_la, int32_t ordered, int32_t nitems, const uint32_t *la_off,
+                 const uint32_t *tr_off, int64_t tr_base, DhLa *la_out, uint16_t *tr_out)
 {
     if (nitems <= 0) return;
-    hipLaunchKernelGGL(k_compact, dim3(nitems), dim3(LANES), 0, st, la_slots, tr_slots, trmax, max_la, 0,
+    hipLaunchKernelGGL(k_compact, dim3(nitems), dim3(LANES), 0, st, la_slots, tr_slots, trmax, max_la, ordered,
                        nitems, la_off, tr_off, tr_base, la_out, tr_out);
 }
 

@@ -720,8 +720,15 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
                 size_t g1 = g0;
                 while (g1 < pl.size() && pl[g1].aread == pl[g0].aread) g1++;
                 auto by_b = [](const dh_la &x, const dh_la &y) { return x.bread < y.bread; };
-                if (!std::is_sorted(pl.begin() + (long)g0, pl.begin() + (long)g1, by_b))
-                    std::stable_sort(pl.begin() + (long)g0, pl.begin() + (long)g1, by_b);
+                // the device hands over one bread-ordered run per strand: merge them (stable)
+                const auto gb = pl.begin() + (long)g0, ge = pl.begin() + (long)g1;
+                const auto mid = std::is_sorted_until(gb, ge, by_b);
+                if (mid != ge) {
+                    if (std::is_sorted(mid, ge, by_b))
+                        std::inplace_merge(gb, mid, ge, by_b);
+                    else
+                        std::stable_sort(gb, ge, by_b);
+                }
                 size_t p0 = g0;
                 while (p0 < g1) {
                     size_t p1 = p0;
