@@ -475,9 +475,6 @@ static int build_index(dh_db *A, int32_t k, int32_t sepv, int32_t kmer_mod)
     dhk_scan(ctx->stream, ix.d_dir, nb + 1, d_sums);
     dhk_kmer_pass(ctx->stream, 1, av, d_tiles, (int32_t)tiles.size(), k, kmer_mod, ix.shift, ix.d_dir, ix.d_ent,
                   ix.d_goff);
-    dhk_bucket_sort(ctx->stream, ix.d_dir, nb, ix.d_ent);
-    HIPCHK(dh_dev_alloc(&ix.d_bits, sizeof(uint32_t) * (size_t)((nb + 31) / 32 + 1)));
-    dhk_bucket_bits(ctx->stream, ix.d_dir, nb, ix.d_bits);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));  // tiles vector goes out of scope
     dh_dev_free(d_tiles);
@@ -622,7 +619,7 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
 
     DhOpts dopt;
     memcpy(&dopt, &o, sizeof(dopt));
-    IndexView iv{A->ix.d_dir, A->ix.d_bits, A->ix.d_ent, A->ix.d_goff, A->ix.n,
+    IndexView iv{A->ix.d_dir, A->ix.d_ent, A->ix.d_goff, A->ix.n,
                  A->ix.na,    A->ix.sepv,   A->ix.shift,  A->ix.pbits};
     const DbView av = A->view(), bv = B->view();
 

@@ -29,7 +29,6 @@ struct DbView {
 
 struct IndexView {
     const uint32_t *dir;   // dir[b] = end of bucket b (start = dir[b-1])
-    const uint32_t *bits;  // bit b set <=> bucket b is not empty (L2-resident prefilter)
     const ulonglong2 *ent;  // x = group * 4^k + kmer (sorted inside every bucket), y = aseq << 40 | virtual position
     const int64_t *goff;   // virtual offset of every A sequence
     int64_t n;
@@ -66,8 +65,6 @@ void dhk_revcomp(hipStream_t st, const uint8_t *src, uint8_t *dst, const int64_t
 void dhk_kmer_pass(hipStream_t st, int fill, DbView A, const int2 *tiles, int32_t ntiles, int32_t k,
                    int32_t kmer_mod, int32_t shift, uint32_t *dir, ulonglong2 *ent, const int64_t *goff);
 void dhk_scan(hipStream_t st, uint32_t *v, int64_t n, uint32_t *sums);
-void dhk_bucket_bits(hipStream_t st, const uint32_t *dir_end, int64_t nb, uint32_t *bits);
-void dhk_bucket_sort(hipStream_t st, const uint32_t *dir_end, int64_t nb, ulonglong2 *ent);
 void dhk_seed(hipStream_t st, int cap, DbView B, const uint8_t *brc, IndexView ix, DhOpts o,
               int32_t item0, int32_t nitems, DhCand *cand, int32_t *ncand, int32_t *nhits,
               int32_t *status, uint32_t *queue, int32_t ncu);

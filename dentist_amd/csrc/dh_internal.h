@@ -59,7 +59,7 @@ struct dh_ctx {
 int dh_scratch(dh_ctx *ctx, int id, size_t bytes, void **out);
 
 struct dh_index {
-    uint32_t *d_dir = nullptr, *d_bits = nullptr;
+    uint32_t *d_dir = nullptr;
     ulonglong2 *d_ent = nullptr;
     int64_t *d_goff = nullptr;
     int64_t n = 0;
@@ -67,8 +67,6 @@ struct dh_index {
     void release()
     {
         dh_dev_free(d_dir);
-        dh_dev_free(d_bits);
-        d_bits = nullptr;
         dh_dev_free(d_ent);
         dh_dev_free(d_goff);
         d_dir = nullptr;

@@ -3,7 +3,6 @@
 // K1  k_revcomp        reverse-complement copy of a DB                     (HBM stream)
 // K2  k_kmer_pass      k-mer extraction of A: count pass and fill pass     (HBM stream + atomics)
 //     k_scan*          exclusive scan of the bucket directory
-//     k_bucket_sort    order every directory bucket by (key, position)
 // K4  k_seed           per (B read, strand): k-mer lookups, LDS-staged hit buffer, in-LDS
 //                      bitonic sort by (diagonal, position), band-pair coverage filter, seeds
 // K5  k_wave           per (B read, strand): O(ND) furthest-reaching wave, one 64-lane wavefront
@@ -237,44 +236,6 @@ __global__ void __launch_bounds__(256) k_scan_apply(uint32_t *__restrict__ v, in
     }
 }
 
-// after the fill pass dir[b] holds the END of bucket b (the cursor ran through it); bucket b is
-// [b ? dir[b-1] : 0, dir[b]).  Order each bucket by (key, value): the fill order is racy, the
-// sorted order is unique because (key, position) pairs are distinct.
-__global__ void __launch_bounds__(256) k_bucket_sort(const uint32_t *__restrict__ dir_end,
-                                                     int64_t nb, ulonglong2 *__restrict__ ent)
-{
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
-    const uint32_t s = b ? dir_end[b - 1] : 0, e = dir_end[b];
-    for (uint32_t i = s + 1; i < e; i++) {
-        const ulonglong2 x = ent[i];
-        uint32_t j = i;
-        while (j > s && (ent[j - 1].x > x.x || (ent[j - 1].x == x.x && ent[j - 1].y > x.y))) {
-            ent[j] = ent[j - 1];
-            j--;
-        }
-        ent[j] = x;
-    }
-}
-
-// one bit per directory bucket: set when the bucket holds at least one k-mer.  For assemblies up
-// to a few 100 Mb the bitset (2^P / 8 bytes) stays resident in every XCD's 4 MB L2, so the
-// majority of the seed kernel's lookups (empty buckets) never leave the L2.
-__global__ void __launch_bounds__(256) k_bucket_bits(const uint32_t *__restrict__ dir_end, int64_t nb,
-                                                     uint32_t *__restrict__ bits)
-{
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 32-bucket word per thread
-    if (w * 32 >= nb) return;
-    uint32_t v = 0;
-    uint32_t prev = w ? dir_end[w * 32 - 1] : 0u;
-    for (int b = 0; b < 32 && w * 32 + b < nb; b++) {
-        const uint32_t e = dir_end[w * 32 + b];
-        v |= (e > prev ? 1u : 0u) << b;
-        prev = e;
-    }
-    bits[w] = v;
-}
-
 // ------------------------------------------------------------------------------------ K4
 
 #define HIT_QBITS 24
@@ -403,7 +364,7 @@ __device__ void seed_item(const DbView &B, const uint8_t *__restrict__ brc, cons
                     if (e0[u].x == key && o.tcap >= 1) emit(e0[u].y, qq[u]);
                     continue;
                 }
-                // the bucket is sorted by key: count the run of equal keys first (-t cap) ...
+                // count the entries of the bucket with this key first (-t cap) ...
                 int32_t run = 0;
                 for (uint32_t t = ss[u]; t < ee[u]; t++) run += ix.ent[t].x == key ? 1 : 0;
                 if (run == 0 || run > o.tcap) continue;
@@ -1323,18 +1284,6 @@ void dhk_scan(hipStream_t st, uint32_t *v, int64_t n, uint32_t *sums)
     hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(256), 0, st, v, n, sums);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, sums, nb);
     hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, v, n, sums);
-}
-
-void dhk_bucket_bits(hipStream_t st, const uint32_t *dir_end, int64_t nb, uint32_t *bits)
-{
-    const int64_t nw = (nb + 31) / 32;
-    hipLaunchKernelGGL(k_bucket_bits, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, dir_end, nb, bits);
-}
-
-void dhk_bucket_sort(hipStream_t st, const uint32_t *dir_end, int64_t nb, ulonglong2 *ent)
-{
-    hipLaunchKernelGGL(k_bucket_sort, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, dir_end,
-                       nb, ent);
 }
 
 // queue: one zeroed uint32 (work counter of the persistent blocks)
