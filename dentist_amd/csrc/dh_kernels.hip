@@ -99,17 +99,36 @@ __device__ __forceinline__ bool mask_touch(MaskCur &m, int32_t p, int32_t k)
 
 // ------------------------------------------------------------------------------------ K1
 
-__global__ void k_revcomp(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
-                          const int64_t *__restrict__ off, int32_t n)
+// 8 bases per thread and step: unaligned 8-byte load of the mirrored window, byte swap,
+// complement of the codes 0..3 (c ^ 3; other codes are kept), unaligned 8-byte store.
+__global__ void __launch_bounds__(256)
+k_revcomp(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, const int64_t *__restrict__ off,
+          int32_t n)
 {
-    // one block per sequence chunk: blockIdx.y = sequence, grid-stride over its bases
+    // blockIdx.y = sequence, grid-stride over its 8-base words
     const int32_t s = blockIdx.y;
     if (s >= n) return;
     const int64_t o = off[s], len = off[s + 1] - o;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const uint8_t c = src[o + len - 1 - i];
-        dst[o + i] = c < 4 ? (uint8_t)(3 - c) : c;
+    const int64_t nw = len >> 3;
+    for (int64_t wd = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; wd < nw;
+         wd += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = wd << 3;
+        uint64_t x;
+        __builtin_memcpy(&x, src + o + len - 8 - i, 8);
+        x = __builtin_bswap64(x);
+        const uint64_t hi = x & 0xFCFCFCFCFCFCFCFCull;  // bytes >= 4 are not bases
+        const uint64_t nz = (((hi & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | hi) & 0x8080808080808080ull;
+        const uint64_t keep = (nz >> 7) * 0xFFull;
+        x ^= 0x0303030303030303ull & ~keep;
+        __builtin_memcpy(dst + o + i, &x, 8);
+    }
+    // tail (len % 8 bases): the first threads of block x == 0
+    if (blockIdx.x == 0) {
+        const int64_t i = (nw << 3) + threadIdx.x;
+        if (i < len) {
+            const uint8_t c = src[o + len - 1 - i];
+            dst[o + i] = c < 4 ? (uint8_t)(3 - c) : c;
+        }
     }
 }
 
@@ -1254,7 +1273,7 @@ void dhk_revcomp(hipStream_t st, const uint8_t *src, uint8_t *dst, const int64_t
                  int32_t max_len)
 {
     if (n <= 0) return;
-    int gx = (max_len + 255) / 256;
+    int gx = (max_len + 2047) / 2048;  // 256 threads x 8 bases per block and step
     if (gx > 64) gx = 64;
     if (gx < 1) gx = 1;
     // grid.y is limited to 65535: loop in slabs
