@@ -344,6 +344,8 @@ extern "C" void dh_db_destroy(dh_db *db)
     (void)hipStreamSynchronize(db->ctx->stream);
     dh_dev_free(db->d_bases_alloc);
     dh_dev_free(db->d_rc_alloc);
+    dh_dev_free(db->d_pk_alloc);
+    dh_dev_free(db->d_rcpk_alloc);
     dh_dev_free(db->d_off);
     dh_dev_free(db->d_group);
     dh_dev_free(db->d_mask_ptr);
@@ -399,6 +401,10 @@ extern "C" int dh_db_drop_cache(dh_db *db)
     db->has_ix = false;
     dh_dev_free(db->d_rc_alloc);
     db->d_rc = db->d_rc_alloc = nullptr;
+    dh_dev_free(db->d_pk_alloc);
+    dh_dev_free(db->d_rcpk_alloc);
+    db->d_pk = db->d_pk_alloc = db->d_rcpk = db->d_rcpk_alloc = nullptr;
+    db->has_n = -1;
     return DH_OK;
 }
 
@@ -408,6 +414,43 @@ int dh_ensure_rc(dh_db *db)
     if (int rc = dh_alloc_bases(db->ctx->stream, db->total, &db->d_rc_alloc, &db->d_rc)) return rc;
     dhk_revcomp(db->ctx->stream, db->d_bases, db->d_rc, db->d_off, db->n, db->max_len);
     HIPCHK(hipGetLastError());
+    return DH_OK;
+}
+
+// 2-bit packed copies for the wave kernel; leaves has_n = 1 (and no packed copy) when the DB
+// holds codes outside 0..3
+int dh_ensure_packed(dh_db *db, bool with_rc)
+{
+    if (db->has_n == 1) return DH_OK;
+    hipStream_t st = db->ctx->stream;
+    const size_t bytes = (size_t)((db->total + 31) / 32) * 8 + 32;
+    if (!db->d_pk) {
+        int32_t *d_flag;
+        if (int rc = dh_scratch(db->ctx, 3, 4 * sizeof(int32_t), (void **)&d_flag)) return rc;
+        HIPCHK(dh_dev_alloc((void **)&db->d_pk_alloc, bytes));
+        db->d_pk = db->d_pk_alloc + 16;
+        HIPCHK(hipMemsetAsync(d_flag + 1, 0, sizeof(int32_t), st));
+        dhk_pack2(st, db->d_bases, db->total, db->d_pk, d_flag + 1);
+        HIPCHK(hipGetLastError());
+        int32_t flag = 0;
+        HIPCHK(hipMemcpyAsync(&flag, d_flag + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        db->has_n = flag ? 1 : 0;
+        if (flag) {
+            dh_dev_free(db->d_pk_alloc);
+            db->d_pk = db->d_pk_alloc = nullptr;
+            return DH_OK;
+        }
+    }
+    if (with_rc && !db->d_rcpk) {
+        if (int rc = dh_ensure_rc(db)) return rc;
+        int32_t *d_flag;
+        if (int rc = dh_scratch(db->ctx, 3, 4 * sizeof(int32_t), (void **)&d_flag)) return rc;
+        HIPCHK(dh_dev_alloc((void **)&db->d_rcpk_alloc, bytes));
+        db->d_rcpk = db->d_rcpk_alloc + 16;
+        dhk_pack2(st, db->d_rc, db->total, db->d_rcpk, d_flag + 2);
+        HIPCHK(hipGetLastError());
+    }
     return DH_OK;
 }
 
@@ -613,6 +656,10 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
     const int32_t sepv = ((B->max_len + 64) + 63) & ~63;
     if (int rc = build_index(A, o.k, sepv, o.kmer_mod)) return rc;
     if (int rc = dh_ensure_rc(B)) return rc;
+    // the wave kernel slides over 2-bit packed copies unless a DB holds codes outside 0..3
+    if (int rc = dh_ensure_packed(A, false)) return rc;
+    if (int rc = dh_ensure_packed(B, true)) return rc;
+    const bool packed = A->has_n == 0 && B->has_n == 0 && !getenv("DH_WAVE_BYTES");
     HIPCHK(hipEventRecord(ctx->ev[1], st));
     w_index = now_ms() - w_a;
     w_a = now_ms();
@@ -742,7 +789,8 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
         HIPCHK(hipMemsetAsync(d_nla + ni, 0, sizeof(uint32_t), st));
         HIPCHK(hipMemsetAsync(d_ntr + ni, 0, sizeof(uint32_t), st));
         WaveScratch ws{d_pool, d_cdj, d_queue, poolcap, nbmax};
-        dhk_wave(st, nslots, av, bv, B->d_rc, dopt, (int32_t)item0, ni, candbase, ncandbase, ws, labase, trbase,
+        dhk_wave(st, nslots, av, bv, B->d_rc, packed ? A->d_pk : nullptr, packed ? B->d_pk : nullptr,
+                 packed ? B->d_rcpk : nullptr, dopt, (int32_t)item0, ni, candbase, ncandbase, ws, labase, trbase,
                  trmax, nlabase, ntrbase, d_counters, d_status);
         HIPCHK(hipGetLastError());
         stats.wave_launches++;

@@ -71,10 +71,12 @@ void dhk_seed(hipStream_t st, int cap, DbView B, const uint8_t *brc, IndexView i
 void dhk_seed_big(hipStream_t st, DbView B, const uint8_t *brc, IndexView ix, DhOpts o,
                   const int32_t *item_list, int32_t nitems, uint64_t *gbuf, int32_t gcap, DhCand *cand,
                   int32_t *ncand, int32_t *nhits, int32_t *status, uint32_t *queue, int32_t ncu);
-void dhk_wave(hipStream_t st, int32_t nslots, DbView A, DbView B, const uint8_t *brc, DhOpts o,
+void dhk_wave(hipStream_t st, int32_t nslots, DbView A, DbView B, const uint8_t *brc, const uint8_t *apk,
+              const uint8_t *bpk, const uint8_t *brcpk, DhOpts o,
               int32_t item0, int32_t nitems, const DhCand *cand, const int32_t *ncand,
               WaveScratch ws, DhLa *out_la, uint16_t *out_trace, int32_t trmax, int32_t *out_nla,
               int32_t *out_ntr, unsigned long long *counters, int32_t *status);
+void dhk_pack2(hipStream_t st, const uint8_t *src, int64_t total, uint8_t *dst, int32_t *flag);
 void dhk_compact(hipStream_t st, const DhLa *la_slots, const uint16_t *tr_slots, int32_t trmax,
                  int32_t max_la, int32_t ordered, int32_t nitems, const uint32_t *la_off,
                  const uint32_t *tr_off, int64_t tr_base, DhLa *la_out, uint16_t *tr_out);

@@ -82,6 +82,10 @@ struct dh_db {
     // bases/rc point DB_PAD bytes into their allocations: kernels read 8 bases at a time on both
     // sides of a position, the padding (code 4) keeps those loads inside the buffer
     uint8_t *d_bases = nullptr, *d_rc = nullptr, *d_bases_alloc = nullptr, *d_rc_alloc = nullptr;
+    // 2-bit packed copies for the wave kernel (built on demand; 16 bytes of padding on both sides);
+    // has_n: -1 unknown, 0 only codes 0..3 (packed path usable), 1 other codes present
+    uint8_t *d_pk = nullptr, *d_rcpk = nullptr, *d_pk_alloc = nullptr, *d_rcpk_alloc = nullptr;
+    int32_t has_n = -1;
     int64_t *d_off = nullptr;
     int32_t *d_group = nullptr;
     std::vector<int64_t> h_off;
@@ -143,6 +147,7 @@ int dh_db_from_slices(dh_ctx *ctx, const dh_db *src, const std::vector<int32_t> 
 int dh_db_adopt(dh_ctx *ctx, uint8_t *d_alloc, uint8_t *d_bases, const std::vector<int64_t> &off,
                 const std::vector<int32_t> &group, dh_db **out);
 int dh_ensure_rc(dh_db *db);
+int dh_ensure_packed(dh_db *db, bool with_rc);
 // dh_align_db with the final LAsort made optional (internal callers regroup on their own)
 int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, int32_t want_best,
                    int32_t want_sorted, dh_la_set **out);

@@ -132,6 +132,34 @@ k_revcomp(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, const int6
     }
 }
 
+// 2-bit packed copy of a base array for the wave kernel: base g sits in byte g >> 2 at bits
+// 2 * (g & 3), so a little-endian 8-byte load holds 32 consecutive bases, low bits first.
+// One thread per 8-byte word; flag is raised when a code outside 0..3 is met (such DBs are
+// aligned from the byte arrays instead).  The source is readable 63 bytes past `total` (DB_PAD).
+__global__ void __launch_bounds__(256)
+k_pack2(const uint8_t *__restrict__ src, int64_t total, uint64_t *__restrict__ dst,
+        int32_t *__restrict__ flag)
+{
+    const int64_t wd = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nw = (total + 31) >> 5;
+    if (wd >= nw) return;
+    uint64_t out = 0;
+    bool bad = false;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint64_t x = load8(src + (wd << 5) + 8 * q);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t c = (uint32_t)(x >> (8 * u)) & 0xFFu;
+            const int64_t g = (wd << 5) + 8 * q + u;
+            if (c > 3u && g < total) bad = true;
+            out |= (uint64_t)(c & 3u) << (2 * (8 * q + u));
+        }
+    }
+    dst[wd] = out;
+    if (bad) atomicOr(flag, 1);
+}
+
 // ------------------------------------------------------------------------------------ K2
 
 // tiles: (sequence, start) pairs, KM_TILE positions each; 256 threads x 16 positions.
@@ -707,6 +735,40 @@ __device__ __forceinline__ void slide(gptr_t ap, gptr_t ar, int32_t an, gptr_t b
     }
 }
 
+// The same on 2-bit packed sequences: 32 bases per 8-byte load.  Forward: element i of A' is
+// base (4 * qa + ra + i) and pa points at byte qa; reverse: element i is base (4 * qa + ra - i),
+// par points at byte qa - 7 - na4 and the window is the 32 bases ENDING at that base (na4 keeps
+// the unsigned load offsets non-negative).  The window of a load starts at an arbitrary base of
+// its first byte, so only 32 - max(phase) bases of a compare are valid.
+template <int STEP>
+__device__ __forceinline__ void slide_pk(gptr_t pa, int32_t ra, int32_t na4, gptr_t pb, int32_t rb,
+                                         int32_t nb4, int32_t lim, int32_t &i, int32_t &j)
+{
+    for (;;) {
+        const int32_t rem = lim - i;
+        if (rem <= 0) break;
+        int32_t m, valid;
+        if (STEP > 0) {
+            const int32_t ta = ra + i, tb = rb + j;
+            const int32_t sa = (ta & 3) << 1, sb = (tb & 3) << 1;
+            const uint64_t x = (load8g(pa, (uint32_t)ta >> 2) >> sa) ^ (load8g(pb, (uint32_t)tb >> 2) >> sb);
+            valid = 32 - (max(sa, sb) >> 1);
+            m = x ? ((__ffsll((long long)x) - 1) >> 1) : 32;
+        } else {
+            const int32_t ta = ra - i, tb = rb - j;
+            const int32_t sa = (3 - (ta & 3)) << 1, sb = (3 - (tb & 3)) << 1;
+            const uint64_t x = (load8g(pa, (uint32_t)((ta >> 2) + na4)) << sa) ^
+                               (load8g(pb, (uint32_t)((tb >> 2) + nb4)) << sb);
+            valid = 32 - (max(sa, sb) >> 1);
+            m = x ? (__clzll((long long)x) >> 1) : 32;
+        }
+        m = min(min(m, valid), rem);
+        i += m;
+        j += m;
+        if (m < valid) break;
+    }
+}
+
 struct ExtResult {
     int32_t i, j, d, head, nb, headb, nbb;
 };
@@ -715,8 +777,11 @@ struct ExtResult {
 // All lanes execute every cross-lane operation.  SYM additionally records the crossings of the
 // B-offsets tpb_first + m*ts (value = i when j first reaches the boundary): the same path then
 // also yields the trace of the transposed record (symmetric all-vs-all, each pair aligned once).
-template <int STEP, bool SYM>
-__device__ ExtResult ext_wave(const uint8_t *ap_, int32_t an, const uint8_t *bp_, int32_t bn, int32_t tp_first,
+// PK: ap_ / bp_ are the 2-bit packed arrays and ag / bg the absolute base index of element 0
+// (slide_pk); otherwise ap_ / bp_ point at element 0 of the byte arrays.
+template <int STEP, bool SYM, bool PK>
+__device__ ExtResult ext_wave(const uint8_t *ap_, int64_t ag, int32_t an, const uint8_t *bp_, int64_t bg,
+                              int32_t bn, int32_t tp_first,
                               int32_t tpb_first, const DhOpts &o, DhNode *__restrict__ pool,
                               int32_t poolcap, int32_t &pool_n, unsigned long long &cells,
                               int32_t &err)
@@ -725,8 +790,14 @@ __device__ ExtResult ext_wave(const uint8_t *ap_, int32_t an, const uint8_t *bp_
     const int32_t ts = o.tspace, pen = o.pen, xdrop = o.xdrop;
     an = __builtin_amdgcn_readfirstlane(an);
     bn = __builtin_amdgcn_readfirstlane(bn);
-    const gptr_t ap = uniform_ptr(ap_), bp = uniform_ptr(bp_);
-    const gptr_t ar = uniform_ptr(ap_ - an - 7), br = uniform_ptr(bp_ - bn - 7);
+    // byte arrays: forward base ap / bp, reverse base ar / br (slide); packed: one base per
+    // direction in ap / bp plus the phases ra / rb and the offset biases na4 / nb4 (slide_pk)
+    const int32_t ra = PK ? __builtin_amdgcn_readfirstlane((int32_t)(ag & 3)) : 0;
+    const int32_t rb = PK ? __builtin_amdgcn_readfirstlane((int32_t)(bg & 3)) : 0;
+    const int32_t na4 = (PK && STEP < 0) ? (an >> 2) + 2 : 0, nb4 = (PK && STEP < 0) ? (bn >> 2) + 2 : 0;
+    const gptr_t ap = uniform_ptr(PK ? ap_ + (ag >> 2) - (STEP < 0 ? 7 + na4 : 0) : ap_);
+    const gptr_t bp = uniform_ptr(PK ? bp_ + (bg >> 2) - (STEP < 0 ? 7 + nb4 : 0) : bp_);
+    const gptr_t ar = uniform_ptr(PK ? ap_ : ap_ - an - 7), br = uniform_ptr(PK ? bp_ : bp_ - bn - 7);
     tp_first = __builtin_amdgcn_readfirstlane(tp_first);
     tpb_first = __builtin_amdgcn_readfirstlane(tpb_first);
     // per-lane state of diagonal k: R = furthest i (DEAD when dead), H = head of its trace chain,
@@ -741,7 +812,10 @@ __device__ ExtResult ext_wave(const uint8_t *ap_, int32_t an, const uint8_t *bp_
     int32_t i0 = 0, h0 = -1, nb0 = 0, hb0 = -1, nbb0 = 0;
     if (lane == 0) {
         int32_t j0 = 0;
-        slide<STEP>(ap, ar, an, bp, br, bn, min(an, bn), i0, j0);
+        if (PK)
+            slide_pk<STEP>(ap, ra, na4, bp, rb, nb4, min(an, bn), i0, j0);
+        else
+            slide<STEP>(ap, ar, an, bp, br, bn, min(an, bn), i0, j0);
         int32_t cnt = 0;
         for (int32_t nextb = tp_first; nextb <= i0; nextb += ts) {
             const int32_t idx = pool_n + cnt;
@@ -830,7 +904,12 @@ __device__ ExtResult ext_wave(const uint8_t *ap_, int32_t an, const uint8_t *bp_
         }
         bool alive = ni >= 0;
         int32_t j = ni - k;
-        if (alive) slide<STEP>(ap, ar, an, bp, br, bn, lim, ni, j);
+        if (alive) {
+            if (PK)
+                slide_pk<STEP>(ap, ra, na4, bp, rb, nb4, lim, ni, j);
+            else
+                slide<STEP>(ap, ar, an, bp, br, bn, lim, ni, j);
+        }
         const unsigned long long amask = __ballot(alive);
         if (amask == 0ull) break;
         ncell += __popcll(amask);
@@ -1015,9 +1094,11 @@ __device__ int32_t emit_trace(int lane, int32_t ts, int32_t res, int32_t gs, int
 // accepted alignment emits the record (a, b) into the slots of item (a, strand) and the transposed
 // record (b, a) into the slots of item (b, strand); slots are claimed with atomics because any
 // wavefront may add records to any item (the final LAsort makes the output order unique).
-template <bool SYM>
+// PK: the wave slides over the 2-bit packed copies apk (A), bpk / brcpk (B, B reverse-complemented)
+template <bool SYM, bool PK>
 __global__ void __launch_bounds__(LANES)
-k_wave(DbView A, DbView B, const uint8_t *__restrict__ brc, DhOpts o, int32_t item0,
+k_wave(DbView A, DbView B, const uint8_t *__restrict__ brc, const uint8_t *__restrict__ apk,
+       const uint8_t *__restrict__ bpk, const uint8_t *__restrict__ brcpk, DhOpts o, int32_t item0,
        int32_t nitems, const DhCand *__restrict__ cand, const int32_t *__restrict__ ncand,
        WaveScratch ws, DhLa *__restrict__ out_la, uint16_t *__restrict__ out_trace,
        int32_t trmax, int32_t *__restrict__ out_nla, int32_t *__restrict__ out_ntr,
@@ -1066,10 +1147,13 @@ k_wave(DbView A, DbView B, const uint8_t *__restrict__ brc, DhOpts o, int32_t it
             bm = bm < 0 ? bm + ts : bm;
             const int32_t fwdb_first = ts - bm, revb_first = bm ? bm : ts;
             int32_t pool_n = 0;
-            const ExtResult fw = ext_wave<1, SYM>(a + as, alen - as, b + bs, blen - bs, fwd_first,
-                                                  fwdb_first, o, pool, ws.poolcap, pool_n, cells, err);
-            const ExtResult rv = ext_wave<-1, SYM>(a + as - 1, as, b + bs - 1, bs, rev_first, revb_first,
-                                                   o, pool, ws.poolcap, pool_n, cells, err);
+            const uint8_t *bsrc = PK ? (strand ? brcpk : bpk) : b;
+            const ExtResult fw = ext_wave<1, SYM, PK>(PK ? apk : a + as, ao + as, alen - as,
+                                                      PK ? bsrc : b + bs, bo + bs, blen - bs, fwd_first,
+                                                      fwdb_first, o, pool, ws.poolcap, pool_n, cells, err);
+            const ExtResult rv = ext_wave<-1, SYM, PK>(PK ? apk : a + as - 1, ao + as - 1, as,
+                                                       PK ? bsrc : b + bs - 1, bo + bs - 1, bs, rev_first,
+                                                       revb_first, o, pool, ws.poolcap, pool_n, cells, err);
             naln++;
             if (err || fw.nb > ws.nbmax || rv.nb > ws.nbmax || fw.nbb > ws.nbmax || rv.nbb > ws.nbmax) {
                 err |= DH_ST_POOL_OVERFLOW;
@@ -1349,18 +1433,38 @@ void dhk_seed_big(hipStream_t st, DbView B, const uint8_t *brc, IndexView ix, Dh
                        nitems, cand, ncand, nhits, status, gbuf, gcap, item_list, queue);
 }
 
-void dhk_wave(hipStream_t st, int32_t nslots, DbView A, DbView B, const uint8_t *brc, DhOpts o,
+// apk / bpk / brcpk: 2-bit packed copies (all three or none)
+void dhk_wave(hipStream_t st, int32_t nslots, DbView A, DbView B, const uint8_t *brc, const uint8_t *apk,
+              const uint8_t *bpk, const uint8_t *brcpk, DhOpts o,
               int32_t item0, int32_t nitems, const DhCand *cand, const int32_t *ncand,
               WaveScratch ws, DhLa *out_la, uint16_t *out_trace, int32_t trmax, int32_t *out_nla,
               int32_t *out_ntr, unsigned long long *counters, int32_t *status)
 {
     if (nitems <= 0) return;
-    if (o.skip_self == 2)
-        hipLaunchKernelGGL(k_wave<true>, dim3(nslots), dim3(LANES), 0, st, A, B, brc, o, item0, nitems, cand,
-                           ncand, ws, out_la, out_trace, trmax, out_nla, out_ntr, counters, status);
-    else
-        hipLaunchKernelGGL(k_wave<false>, dim3(nslots), dim3(LANES), 0, st, A, B, brc, o, item0, nitems, cand,
-                           ncand, ws, out_la, out_trace, trmax, out_nla, out_ntr, counters, status);
+    const bool pk = apk && bpk && brcpk;
+#define WAVE_LAUNCH(S, P)                                                                          \
+    hipLaunchKernelGGL((k_wave<S, P>), dim3(nslots), dim3(LANES), 0, st, A, B, brc, apk, bpk, brcpk, o, item0, \
+                       nitems, cand, ncand, ws, out_la, out_trace, trmax, out_nla, out_ntr, counters, status)
+    if (o.skip_self == 2) {
+        if (pk)
+            WAVE_LAUNCH(true, true);
+        else
+            WAVE_LAUNCH(true, false);
+    } else {
+        if (pk)
+            WAVE_LAUNCH(false, true);
+        else
+            WAVE_LAUNCH(false, false);
+    }
+#undef WAVE_LAUNCH
+}
+
+void dhk_pack2(hipStream_t st, const uint8_t *src, int64_t total, uint8_t *dst, int32_t *flag)
+{
+    const int64_t nw = (total + 31) >> 5;
+    if (nw <= 0) return;
+    hipLaunchKernelGGL(k_pack2, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, src, total, (uint64_t *)dst,
+                       flag);
 }
 
 void dhk_compact(hipStream_t st, const DhLa *la_slots, const uint16_t *tr_slots, int32_t trmax,
