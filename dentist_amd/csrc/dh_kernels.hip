@@ -20,23 +20,41 @@
 #define LANES 64
 
 // modimer sampling (daligner -%): the same k-mers are kept on the A and on the B side.
-// hash % mod == 0 is evaluated without a division (Lemire & Kaser, "Faster remainder by direct
-// computation"): for 32-bit h and M = floor((2^64 - 1) / mod) + 1, mod | h  <=>  h * M mod 2^64 <= M - 1.
+// Keep a k-mer iff h % mod == 0 with h = bits 32..63 of kmer * 0x9E3779B97F4A7C15.  32-bit integer
+// multiplies run at quarter rate on CDNA, and this test is evaluated for every base of every
+// read, so it is arranged to need three of them (two when k <= 16):
+//  * h = mulhi(lo, C_lo) + lo * C_hi + hi * C_lo   (lo / hi = halves of the k-mer);
+//  * h % mod == 0  <=>  rotr(h * inv(mod'), e) <= (2^32 - 1) / mod   for mod = mod' * 2^e, mod'
+//    odd, inv = inverse of mod' modulo 2^32 (test for zero remainder, Hacker's Delight 10-17).
 struct KmerSampler {
-    uint64_t M;
-    bool all;
+    uint32_t inv, thresh, rot;
+    bool all, small_k;
 };
-__device__ __forceinline__ KmerSampler kmer_sampler(int32_t mod)
+__device__ __forceinline__ KmerSampler kmer_sampler(int32_t mod, int32_t k)
 {
     KmerSampler s;
     s.all = mod <= 1;
-    s.M = s.all ? 0ull : ~0ull / (uint64_t)(uint32_t)mod + 1ull;
+    s.small_k = k <= 16;
+    uint32_t d = s.all ? 1u : (uint32_t)mod, e = 0;
+    while ((d & 1u) == 0u) {
+        d >>= 1;
+        e++;
+    }
+    uint32_t x = d;  // Newton: x <- x * (2 - d * x) doubles the number of correct low bits
+    for (int it = 0; it < 5; it++) x *= 2u - d * x;
+    s.inv = x;
+    s.rot = e;
+    s.thresh = s.all ? 0xFFFFFFFFu : 0xFFFFFFFFu / (uint32_t)mod;
     return s;
 }
 __device__ __forceinline__ bool kmer_sampled(uint64_t km, const KmerSampler &s)
 {
-    const uint32_t h = (uint32_t)((km * 0x9E3779B97F4A7C15ull) >> 32);
-    return s.all || (uint64_t)h * s.M <= s.M - 1ull;
+    const uint32_t lo = (uint32_t)km, hi = (uint32_t)(km >> 32);
+    uint32_t h = __umulhi(lo, 0x7F4A7C15u) + lo * 0x9E3779B9u;
+    if (!s.small_k) h += hi * 0x7F4A7C15u;
+    const uint32_t t = h * s.inv;
+    const uint32_t r = s.rot ? ((t >> s.rot) | (t << (32u - s.rot))) : t;
+    return s.all || r <= s.thresh;
 }
 
 __device__ __forceinline__ uint64_t load8(const uint8_t *p)
@@ -177,7 +195,7 @@ k_kmer_pass(DbView A, const int2 *__restrict__ tiles, int32_t ntiles, int32_t k,
     const uint64_t grp = A.group ? (uint64_t)A.group[s] : 0ull;
     const uint64_t mask = (1ull << (2 * k)) - 1;
     const int32_t p0 = tiles[t].y + threadIdx.x * (KM_TILE / 256);
-    const KmerSampler smp = kmer_sampler(kmer_mod);
+    const KmerSampler smp = kmer_sampler(kmer_mod, k);
     uint64_t km = 0;
     int32_t valid = 0;
     const uint8_t *a = A.bases + o;
@@ -367,7 +385,7 @@ __device__ void seed_item(const DbView &B, const uint8_t *__restrict__ brc, cons
         constexpr int QN = 4;
         const int32_t per = (npos + SEED_LOOKUP_THREADS - 1) / SEED_LOOKUP_THREADS;
         const int32_t q0 = tid * per, q1 = min(npos, q0 + per);
-        const KmerSampler smp = kmer_sampler(o.kmer_mod);
+        const KmerSampler smp = kmer_sampler(o.kmer_mod, k);
         uint64_t km = 0;
         int32_t valid = 0;
         const int32_t pend = q0 < q1 ? q1 + k - 1 : q0;
