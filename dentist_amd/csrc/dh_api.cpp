@@ -498,7 +498,8 @@ static int build_index(dh_db *A, int32_t k, int32_t sepv, int32_t kmer_mod)
     // the largest key is ngroups * 4^k - 1, so buckets up to (that >> shift) are addressable
     const int64_t nb = (int64_t)((((uint64_t)A->ngroups << (2 * k)) - 1) >> ix.shift) + 1;
     ix.n = nk;
-    HIPCHK(dh_dev_alloc(&ix.d_dir, sizeof(uint32_t) * (size_t)(nb + 1)));
+    HIPCHK(dh_dev_alloc(&ix.d_dir_alloc, sizeof(uint32_t) * (size_t)(nb + 2)));
+    ix.d_dir = ix.d_dir_alloc + 1;
     HIPCHK(dh_dev_alloc(&ix.d_ent, sizeof(ulonglong2) * (size_t)std::max<int64_t>(nk, 1)));
     HIPCHK(dh_dev_alloc(&ix.d_goff, sizeof(int64_t) * (size_t)(A->n + 1)));
     int2 *d_tiles = nullptr;
@@ -511,7 +512,7 @@ static int build_index(dh_db *A, int32_t k, int32_t sepv, int32_t kmer_mod)
     if (!tiles.empty())
         HIPCHK(hipMemcpyAsync(d_tiles, tiles.data(), sizeof(int2) * tiles.size(), hipMemcpyHostToDevice,
                               ctx->stream));
-    HIPCHK(hipMemsetAsync(ix.d_dir, 0, sizeof(uint32_t) * (size_t)(nb + 1), ctx->stream));
+    HIPCHK(hipMemsetAsync(ix.d_dir_alloc, 0, sizeof(uint32_t) * (size_t)(nb + 2), ctx->stream));
     const DbView av = A->view();
     dhk_kmer_pass(ctx->stream, 0, av, d_tiles, (int32_t)tiles.size(), k, kmer_mod, ix.shift, ix.d_dir, ix.d_ent,
                   ix.d_goff);

@@ -59,14 +59,17 @@ struct dh_ctx {
 int dh_scratch(dh_ctx *ctx, int id, size_t bytes, void **out);
 
 struct dh_index {
-    uint32_t *d_dir = nullptr;
+    // d_dir points one word into its allocation: d_dir[-1] == 0, so that (start, end) of bucket b
+    // is the 8-byte word at d_dir + b - 1 for every b (one load instead of two in the seed kernel)
+    uint32_t *d_dir = nullptr, *d_dir_alloc = nullptr;
     ulonglong2 *d_ent = nullptr;
     int64_t *d_goff = nullptr;
     int64_t n = 0;
     int32_t k = 0, sepv = 0, shift = 0, pbits = 0, na = 0, kmer_mod = 1;
     void release()
     {
-        dh_dev_free(d_dir);
+        dh_dev_free(d_dir_alloc);
+        d_dir_alloc = nullptr;
         dh_dev_free(d_ent);
         dh_dev_free(d_goff);
         d_dir = nullptr;

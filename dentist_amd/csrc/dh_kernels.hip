@@ -413,9 +413,11 @@ __device__ void seed_item(const DbView &B, const uint8_t *__restrict__ brc, cons
             uint32_t ss[QN], ee[QN];
 #pragma unroll
             for (int u = 0; u < QN; u++) {
-                const uint32_t bk = u < nq ? (uint32_t)(qk[u] >> ix.shift) : 0u;
-                ss[u] = bk ? ix.dir[bk - 1] : 0u;
-                ee[u] = u < nq ? ix.dir[bk] : 0u;
+                // (start, end) of the bucket = dir[bk - 1], dir[bk] in one 8-byte load (dir[-1] == 0)
+                uint64_t se = 0;
+                if (u < nq) se = load8((const uint8_t *)(ix.dir + (uint32_t)(qk[u] >> ix.shift)) - 4);
+                ss[u] = (uint32_t)se;
+                ee[u] = (uint32_t)(se >> 32);
             }
             ulonglong2 e0[QN];
 #pragma unroll
