@@ -1,0 +1,20 @@
+#!/bin/bash
+# Collects the profiles committed under profiles/: kernel trace summary + HBM traffic counters
+# (separate --pmc passes, never combined with other trace domains).  Run on the GPU box:
+#   bash scripts/profile_round.sh <tag>
+set -u
+tag=${1:-r01}
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$root/gpurun_out/prof_$tag
+mkdir -p "$out"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o run -- python "$root/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$out/bench_kernel_trace.log" 2>&1
+db=$(find /tmp/prof_kt -name "*.db" | head -1)
+{ echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline (4 steps in total)"; python "$root/scripts/rocpd_summary.py" "$db"; } > "$out/kernel_stats.txt"
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/prof_$c -o run -- python "$root/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > "$out/bench_$c.log" 2>&1
+done
+{ echo "# rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two separate passes), python bench.py --steps 1 --warmup 0 --no-cpu-baseline"; python "$root/scripts/pmc_summary.py" /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE; } > "$out/pmc_hbm_traffic.txt"
+tail -1 "$out/bench_kernel_trace.log" | cut -c1-300
+head -30 "$out/kernel_stats.txt"
+grep -E "k_wave|k_seed" "$out/pmc_hbm_traffic.txt"
