@@ -73,7 +73,7 @@ SYMBOLS = [
     "dh_get_process_stats", "dh_dazz_create_dam", "dh_dazz_create_db", "dh_dazz_split", "dh_dazz_open",
     "dh_dazz_close", "dh_dazz_nreads", "dh_dazz_first_id", "dh_dazz_bases", "dh_dazz_offsets",
     "dh_dazz_origin", "dh_dazz_fpulse", "dh_dazz_header", "dh_dazz_read_mask", "dh_dazz_write_mask",
-    "dh_db_set_mask",
+    "dh_db_set_mask", "dh_output_fasta",
 ]
 
 _LIB = None
@@ -154,6 +154,8 @@ def lib():
     L.dh_dazz_read_mask.restype = i64
     L.dh_dazz_write_mask.argtypes = [ctypes.c_char_p, ctypes.c_char_p, i32, vp, vp]
     L.dh_db_set_mask.argtypes = [vp, vp, vp]
+    L.dh_output_fasta.argtypes = [ctypes.c_char_p, ctypes.c_char_p, vp, vp, i32, vp, ctypes.POINTER(ctypes.c_char_p),
+                                  vp, vp, i32, vp, i32, i32]
     L.dh_dazz_header.restype = ctypes.c_char_p
     _LIB = L
     return L
@@ -373,6 +375,24 @@ def process_pileups(ctx, contigs, reads, las, trace, piles, opts):
              if nb else np.zeros(0, dtype=np.uint8))
     L.dh_insertions_destroy(h)
     return rec, bases
+
+
+def output_fasta(fasta_path, contigs, scaffold_of, headers, gap_len, rec, bases, bed_path=None, line_width=50,
+                 highlight=True):
+    """`dentist output` for linear scaffolds (host only): contigs = SeqDb-like (.bases, .off),
+    scaffold_of[c] = input scaffold of contig c, headers[s] = its FASTA header without '>',
+    gap_len[c] = gap after contig c; rec / bases = result of process_pileups."""
+    cb = np.ascontiguousarray(contigs.bases, dtype=np.uint8)
+    co = np.ascontiguousarray(contigs.off, dtype=np.int64)
+    so = np.ascontiguousarray(scaffold_of, dtype=np.int32)
+    gl = np.ascontiguousarray(gap_len, dtype=np.int32) if gap_len is not None else None
+    r = np.ascontiguousarray(rec, dtype=INSERTION_DTYPE)
+    b = np.ascontiguousarray(bases, dtype=np.uint8)
+    hs = (ctypes.c_char_p * len(headers))(*[h.encode() for h in headers])
+    _check(lib().dh_output_fasta(fasta_path.encode(), bed_path.encode() if bed_path else None, cb.ctypes.data,
+                                 co.ctypes.data, len(co) - 1, so.ctypes.data, hs,
+                                 gl.ctypes.data if gl is not None else None, r.ctypes.data, len(r),
+                                 b.ctypes.data if len(b) else None, line_width, int(bool(highlight))))
 
 
 def process_stats(ctx):

@@ -223,6 +223,19 @@ int64_t dh_insertions_bases_len(const dh_insertions *r);
 int dh_get_process_stats(dh_ctx *ctx, float *ms7, int64_t *counters3);
 
 
+/* ---- gap-closed assembly writer (host only): the linear-scaffold subset of `dentist output`
+ *      (source/dentist/commands/output.d:743-925): header "<id>\tscaffold-<first contig id>", contig
+ *      slices lower case, insertions upper case (highlight != 0), unclosed gaps as 'n' runs, lines
+ *      wrapped at line_width (commandline.d:1699, default 50); optional closed-gaps BED
+ *      (output.d:879-891).  scaffold_of[c]: input scaffold of contig c (contigs of a scaffold are
+ *      consecutive); headers[s]: its FASTA header without '>'; gap_len[c]: gap after contig c.
+ *      Splice coordinates are dh_insertion.left_aepos / right_abpos / ins_begin / ins_end
+ *      (common/insertions.d:110-146).  Pinned by the md5 of tests/test-commands.sh:62-65. */
+int dh_output_fasta(const char *fasta_path, const char *bed_path, const uint8_t *contig_bases,
+                    const int64_t *contig_off, int32_t ncontigs, const int32_t *scaffold_of,
+                    const char *const *headers, const int32_t *gap_len, const dh_insertion *ins,
+                    int32_t nins, const uint8_t *ins_bases, int32_t line_width, int32_t highlight);
+
 /* ---- DAZZ_DB files on disk (.db / .dam stub + hidden .idx / .bps / .hdr), host only.
  *      Replaces what DENTIST obtains by spawning fasta2DB / fasta2DAM / DBsplit
  *      (source/dentist/dazzler.d:6233-6330) and what the aligners open themselves.  The .idx, .bps

@@ -67,3 +67,29 @@ def test_product_las_codec_matches_oracle_bytes(tmp_path):
     open(p1, "wb").write(open(p1, "rb").read()[:-1])
     with pytest.raises(dentist_amd.DhError):
         dentist_amd.las_read(p1)
+
+
+def test_output_fasta_writer_unclosed_gaps_and_wrapping(tmp_path):
+    """`dentist output` subset (output.d:743-925) on the host: header rule, n-runs for open gaps,
+    upper-cased insertion, reverse-complemented consensus, 50-column wrapping (no GPU needed)."""
+    from dentist_amd import sim
+    from dentist_amd._lib import INSERTION_DTYPE
+    rng = np.random.default_rng(5)
+    c = [rng.integers(0, 4, n).astype(np.uint8) for n in (120, 80, 60, 40)]
+    contigs = sim.SeqDb.from_list(c)
+    cons = rng.integers(0, 4, 30).astype(np.uint8)
+    rec = np.zeros(2, dtype=INSERTION_DTYPE)
+    # gap 0|1 closed with the reverse complement of cons[5:25]; gap 1|2 skipped (status != 0)
+    rec[0] = (0, 0, 5, 0, 7, 0, 0, 110, 4, 5, 25, 1, 30, 0, 0, 0, 0)
+    rec[1] = (1, 4, 5, -1, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+    path = str(tmp_path / "o.fasta")
+    dentist_amd.output_fasta(path, contigs, [0, 0, 0, 1], ["chrA\tfoo", "chrB"], [33, 17, 0], rec, cons)
+    txt = open(path).read().split(">")[1:]
+    assert txt[0].split("\n")[0] == "chrA\tscaffold-1" and txt[1].split("\n")[0] == "chrB\tscaffold-4"
+    body = txt[0].split("\n")[1:]
+    assert all(len(l) == 50 for l in body[:-2]) and 0 < len(body[-2]) <= 50 and body[-1] == ""
+    s0 = "".join(body)
+    ins = sim.decode(sim.revcomp(cons)[5:25]).upper()
+    want = sim.decode(c[0][:110]) + ins + sim.decode(c[1][4:]) + "n" * 17 + sim.decode(c[2])
+    assert s0 == want
+    assert "".join(txt[1].split("\n")[1:]) == sim.decode(c[3])

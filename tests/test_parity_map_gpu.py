@@ -211,6 +211,25 @@ def test_chunked_launches_give_identical_results(gpu_ctx, monkeypatch):
     assert_same_las(many, one)
 
 
+@pytest.mark.parametrize("sym", [False, True])
+def test_packed_and_byte_wave_paths_agree(gpu_ctx, monkeypatch, sym):
+    """ACGT-only DBs are aligned from 2-bit packed copies (32 bases per load), DBs with other codes
+    from the byte arrays; both instantiations of the wave kernel must give the same bits."""
+    w = sim.Workload(200_000, 2, 400, 3000, seed=29, spacing=15000)
+    if sym:
+        g, _ = both_opts(skip_self=2, tspace=126, max_la=64, max_cand=128)
+        sub = sim.SeqDb.from_list([w.reads.seq(i) for i in range(60)])
+        A = B = gpu_ctx.db(sub)
+    else:
+        g, _ = both_opts()
+        A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
+    packed = gpu_ctx.align_db(A, B, g)
+    monkeypatch.setenv("DH_WAVE_BYTES", "1")
+    plain = gpu_ctx.align_db(A, B, g)
+    assert len(packed[0]) > 0
+    assert_same_las(plain, packed)
+
+
 def test_select_best_flags(gpu_ctx):
     w = sim.Workload(200_000, 2, 200, 4000, seed=23, spacing=15000)
     g, _ = both_opts()

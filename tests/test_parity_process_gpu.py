@@ -64,7 +64,7 @@ def run_case(ctx, w, rounds):
     return rec
 
 
-@pytest.mark.parametrize("rounds", [1, 2])
+@pytest.mark.parametrize("rounds", [1, 2, 3])
 def test_process_small_gaps(gpu_ctx, rounds):
     w = sim.Workload(300_000, 3, 1200, 6000, seed=17, spacing=20000, gap_max=800)
     rec = run_case(gpu_ctx, w, rounds)
@@ -77,7 +77,7 @@ def test_process_longer_gaps(gpu_ctx):
     assert (rec["status"] == 0).sum() >= 3
 
 
-def test_process_reference_fixture_gap_is_closed_perfectly(gpu_ctx):
+def test_process_reference_fixture_gap_is_closed_perfectly(gpu_ctx, tmp_path):
     """tests/test-commands.sh:17-44, 62-65: the 97 bp gap at [2000, 2097) of the 4 097 bp contig is
     reconstructed exactly from 20x / 13 %-error reads (md5 of gap-closed.fasta)."""
     import hashlib
@@ -101,7 +101,14 @@ def test_process_reference_fixture_gap_is_closed_perfectly(gpu_ctx):
     ins = sim.decode(cseq[r["ins_begin"]:r["ins_end"]])
     # output.d:782-925: lower-case contig slices, upper-case insertion, 50 columns, header rule :743-759
     out = seq[:r["left_aepos"]] + ins.upper() + seq[2097 + r["right_abpos"]:]
-    fasta = f"{header}\tscaffold-1\n" + "\n".join(out[i:i + 50] for i in range(0, len(out), 50)) + "\n"
     assert out.lower() == seq, "gap not reconstructed exactly"
+    # the library's `dentist output` writer produces the reference's gap-closed.fasta byte for byte
+    path = str(tmp_path / "gap-closed.fasta")
+    bed = str(tmp_path / "closed-gaps.bed")
+    dentist_amd.output_fasta(path, contigs, [0, 0], [header[1:]], [97], rec, bases, bed_path=bed)
+    data = open(path, "rb").read()
+    assert data.decode() == f"{header}\tscaffold-1\n" + "\n".join(out[i:i + 50] for i in range(0, len(out), 50)) + "\n"
     if r["left_aepos"] == 2000 and r["right_abpos"] == 0:
-        assert hashlib.md5(fasta.encode()).hexdigest() == "c3836dc00a3f5e1e2aa8f2a802da4d67"
+        assert hashlib.md5(data).hexdigest() == "c3836dc00a3f5e1e2aa8f2a802da4d67"
+    b = open(bed).read().split("\t")
+    assert b[0] == header[1:] and int(b[1]) == r["left_aepos"] and int(b[2]) == r["left_aepos"] + len(ins)
