@@ -693,25 +693,23 @@ __device__ __forceinline__ int32_t nbound(int32_t x, int32_t tp_first, int32_t t
 // value of lane-1 / lane+1 (rotation over the whole wave): one DPP mov each, no LDS crossbar
 __device__ __forceinline__ int32_t from_lower_lane(int32_t v)
 {
-    return __builtin_amdgcn_update_dpp(0, v, 0x13C, 0xF, 0xF, false);  // wave_ror:1
+    return __builtin_amdgcn_mov_dpp(v, 0x13C, 0xF, 0xF, false);  // wave_ror:1, every lane has a source
 }
 __device__ __forceinline__ int32_t from_upper_lane(int32_t v)
 {
-    return __builtin_amdgcn_update_dpp(0, v, 0x134, 0xF, 0xF, false);  // wave_rol:1
+    return __builtin_amdgcn_mov_dpp(v, 0x134, 0xF, 0xF, false);  // wave_rol:1
 }
 // max over the 64 lanes, result uniform: 4 DPP steps inside each row of 16, then 4 readlanes
 __device__ __forceinline__ int32_t wave_max_i32(int32_t v)
 {
-    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
-    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
-    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));  // row_half_mirror
-    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));  // row_mirror
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, false));  // row_half_mirror
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, false));  // row_mirror
     const int32_t r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
     const int32_t r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
     return max(max(r0, r1), max(r2, r3));
 }
-// extend a run of matches: element i of A' is ap[i * step], 8 bases per compare.
-// DB buffers carry 64 bytes of padding on both sides, so the wide loads stay inside them.
 // a wave-uniform global pointer pinned to an SGPR pair (explicit global address space so that
 // the loads stay global_load with SGPR base + 32-bit VGPR offset)
 typedef const __attribute__((address_space(1))) uint8_t *gptr_t;
