@@ -129,7 +129,12 @@ def main():
         step()
     barrier()
     t0 = time.perf_counter()
-    runs = [step() for _ in range(args.steps)]
+    runs = []
+    for _ in range(args.steps):
+        runs.append(step())
+        if len(runs) > 1:  # only the last step's results are inspected: release the earlier buffers
+            for key in ("las", "rec", "bases", "gathered"):
+                runs[-2].pop(key, None)
     barrier()
     dt = time.perf_counter() - t0
 
