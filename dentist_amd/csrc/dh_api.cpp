@@ -268,7 +268,7 @@ extern "C" void dh_default_align_opts(dh_align_opts *o)
     o->strands = 3;
     o->skip_self = 0;
     o->dmax = 60000;
-    o->width = 62;
+    o->width = 30;  /* two alignments per wavefront (k_wave2); up to 62 selects one per wavefront */
     o->kmer_mod = 1;
 }
 
@@ -661,6 +661,14 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
     if (int rc = dh_ensure_packed(A, false)) return rc;
     if (int rc = dh_ensure_packed(B, true)) return rc;
     const bool packed = A->has_n == 0 && B->has_n == 0 && !getenv("DH_WAVE_BYTES");
+    // up to 30 live diagonals fit a 32-lane half: two alignments per wavefront (k_wave2); its
+    // reverse extensions run forward over the reverse complements, so A needs one as well
+    const bool dual = o.width <= 30 && !getenv("DH_WAVE_SINGLE");
+    if (dual) {
+        if (int rc = dh_ensure_rc(A)) return rc;
+        if (packed)
+            if (int rc = dh_ensure_packed(A, true)) return rc;
+    }
     HIPCHK(hipEventRecord(ctx->ev[1], st));
     w_index = now_ms() - w_a;
     w_a = now_ms();
@@ -677,11 +685,14 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
     const int32_t nbmax = (int32_t)(maxext / o.tspace + 3);
     const int32_t trmax = 2 * (2 * nbmax + 2);
     const int32_t poolcap = 96 * nbmax;
-    int32_t slots_per_cu = 32;  // <= 64 VGPRs -> 8 waves/SIMD
-    if (const char *e = getenv("DH_WAVE_SLOTS_PER_CU")) slots_per_cu = std::max(1, atoi(e));
+    // resident alignment slots: one per wavefront of k_wave (<= 64 VGPRs -> 8 waves/SIMD), one per
+    // 32-lane half of k_wave2 (two per wavefront, 4 waves/SIMD)
+    int32_t slots_per_cu = 32;
+    if (o.width <= 30 && o.skip_self != 2) slots_per_cu = 40;  // k_wave2<false, *>: 96 VGPRs, 5 waves/SIMD
+    if (const char *e = getenv("DH_WAVE_SLOTS_PER_CU")) slots_per_cu = std::max(2, atoi(e)) & ~1;
     const int64_t nitems_total = 2ll * B->n;
     const int32_t nslots = (int32_t)std::min<int64_t>((int64_t)ctx->ncu * slots_per_cu,
-                                                      std::max<int64_t>(nitems_total, 1));
+                                                      (std::max<int64_t>(nitems_total, 2) + 1) & ~1ll);
     int32_t chunk = 1 << 18;
     if (const char *e = getenv("DH_ALIGN_CHUNK")) chunk = std::max(2, atoi(e)) & ~1;
     // symmetric mode writes records into the slots of other items: everything is one chunk
@@ -789,7 +800,23 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
         HIPCHK(hipMemsetAsync(d_ntr, 0, sizeof(uint32_t) * (size_t)(o.skip_self == 2 ? ni + 1 : 0), st));
         HIPCHK(hipMemsetAsync(d_nla + ni, 0, sizeof(uint32_t), st));
         HIPCHK(hipMemsetAsync(d_ntr + ni, 0, sizeof(uint32_t), st));
-        WaveScratch ws{d_pool, d_cdj, d_queue, poolcap, nbmax};
+        // symmetric all-vs-all: one work unit per (item, A read) group of candidates instead of per
+        // item (k_units); d_queue[3] counts them
+        void *d_units = nullptr;
+        if (o.skip_self == 2 && ni > 1) {
+            int4 *d_u;
+            SCR(24, d_u, (size_t)ni * (size_t)o.max_cand)  // at most one unit per candidate
+            d_units = d_u;
+            dhk_units(st, candbase, ncandbase, (int32_t)item0, ni, o.max_cand, d_units, d_queue + 3);
+            HIPCHK(hipGetLastError());
+        }
+        WaveScratch ws{d_pool, d_cdj, d_queue, (const int4 *)d_units, d_queue + 3, poolcap, nbmax};
+        if (dual)
+            dhk_wave2(st, nslots / 2, av, bv, A->d_rc, B->d_rc, packed ? A->d_pk : nullptr,
+                      packed ? A->d_rcpk : nullptr, packed ? B->d_pk : nullptr, packed ? B->d_rcpk : nullptr, dopt,
+                      (int32_t)item0, ni, candbase, ncandbase, ws, labase, trbase, trmax, nlabase, ntrbase, d_counters,
+                      d_status);
+        else
         dhk_wave(st, nslots, av, bv, B->d_rc, packed ? A->d_pk : nullptr, packed ? B->d_pk : nullptr,
                  packed ? B->d_rcpk : nullptr, dopt, (int32_t)item0, ni, candbase, ncandbase, ws, labase, trbase,
                  trmax, nlabase, ntrbase, d_counters, d_status);

@@ -54,6 +54,8 @@ struct WaveScratch {
     DhNode *pool;     // nslots * poolcap trace-tree nodes
     int32_t *cdj;     // nslots * 4 * nbmax boundary records
     uint32_t *queue;  // work-item counter
+    const int4 *units;        // optional work units (item - item0, first candidate, end candidate, 0)
+    const uint32_t *nunits;   // their number (device side)
     int32_t poolcap, nbmax;
 };
 
@@ -76,6 +78,13 @@ void dhk_wave(hipStream_t st, int32_t nslots, DbView A, DbView B, const uint8_t 
               int32_t item0, int32_t nitems, const DhCand *cand, const int32_t *ncand,
               WaveScratch ws, DhLa *out_la, uint16_t *out_trace, int32_t trmax, int32_t *out_nla,
               int32_t *out_ntr, unsigned long long *counters, int32_t *status);
+void dhk_wave2(hipStream_t st, int32_t nslots, DbView A, DbView B, const uint8_t *arc, const uint8_t *brc,
+               const uint8_t *apk, const uint8_t *arcpk, const uint8_t *bpk, const uint8_t *brcpk, DhOpts o,
+               int32_t item0, int32_t nitems, const DhCand *cand, const int32_t *ncand, WaveScratch ws,
+               DhLa *out_la, uint16_t *out_trace, int32_t trmax, int32_t *out_nla, int32_t *out_ntr,
+               unsigned long long *counters, int32_t *status);
+void dhk_units(hipStream_t st, const DhCand *cand, const int32_t *ncand, int32_t item0, int32_t nitems,
+               int32_t max_cand, void *units, uint32_t *nunits);
 void dhk_pack2(hipStream_t st, const uint8_t *src, int64_t total, uint8_t *dst, int32_t *flag);
 void dhk_compact(hipStream_t st, const DhLa *la_slots, const uint16_t *tr_slots, int32_t trmax,
                  int32_t max_la, int32_t ordered, int32_t nitems, const uint32_t *la_off,

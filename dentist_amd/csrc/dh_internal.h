@@ -53,7 +53,7 @@ struct dh_ctx {
     struct Arena {
         void *p = nullptr;
         size_t cap = 0;
-    } arena[24];
+    } arena[32];
 };
 // slot `id` of the context's scratch arena, at least `bytes` large
 int dh_scratch(dh_ctx *ctx, int id, size_t bytes, void **out);

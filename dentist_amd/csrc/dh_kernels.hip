@@ -636,14 +636,32 @@ __device__ void seed_item(const DbView &B, const uint8_t *__restrict__ brc, cons
         }
         return;
     }
-    // ---- rank by (score desc, band asc); bands are distinct so ranks are a permutation
+    // ---- rank by (score desc, band asc); bands are distinct so ranks are a permutation.  Symmetric
+    // all-vs-all: the kept candidates (rank < max_cand) are then grouped by A read, rank order inside
+    // a group -- groups are the only candidates that depend on each other (coverage skip), which
+    // makes each of them a separate work unit of the wave kernel (k_units).
+    __shared__ int32_t crank[SEED_CCAP];
     for (int32_t c = tid; c < nc; c += SEED_THREADS) {
         int32_t rank = 0;
         for (int32_t x = 0; x < nc; x++)
             if (cands[x].score > cands[c].score ||
                 (cands[x].score == cands[c].score && cband[x] < cband[c]))
                 rank++;
-        if (rank < o.max_cand) cand_out[(int64_t)item * o.max_cand + rank] = cands[c];
+        crank[c] = rank;
+    }
+    __syncthreads();
+    for (int32_t c = tid; c < nc; c += SEED_THREADS) {
+        const int32_t rank = crank[c];
+        if (rank >= o.max_cand) continue;
+        int32_t pos = rank;
+        if (o.skip_self == 2) {
+            pos = 0;
+            for (int32_t x = 0; x < nc; x++)
+                if (crank[x] < o.max_cand &&
+                    (cands[x].aseq < cands[c].aseq || (cands[x].aseq == cands[c].aseq && crank[x] < rank)))
+                    pos++;
+        }
+        cand_out[(int64_t)item * o.max_cand + pos] = cands[c];
     }
     if (tid == 0) ncand_out[item] = nc < o.max_cand ? nc : o.max_cand;
     SP(4)
@@ -681,6 +699,35 @@ SEED_INST(4096)
 SEED_INST(8192)
 SEED_INST(16384)
 SEED_INST(0)
+
+// ------------------------------------------------------------------------------------ K4b
+// Work units of the symmetric wave launch: the candidates of an item are grouped by A read
+// (k_seed), and only candidates of one group depend on each other, so every group is a unit
+// (item, first candidate, end candidate) of its own -- the heavy items of an all-vs-all no longer
+// serialise dozens of alignments in one wavefront.  Items with more than 64 candidates stay whole
+// (the cap of 64 attempted alignments per item must see them in order).
+__global__ void __launch_bounds__(256)
+k_units(const DhCand *__restrict__ cand, const int32_t *__restrict__ ncand, int32_t item0, int32_t nitems,
+        int32_t max_cand, int4 *__restrict__ units, uint32_t *__restrict__ nunits)
+{
+    const int32_t it = blockIdx.x * blockDim.x + threadIdx.x;
+    if (it >= nitems) return;
+    const int32_t item = item0 + it;
+    const int32_t nc = max(ncand[item], 0);
+    if (nc == 0) return;
+    const DhCand *cl = cand + (int64_t)item * max_cand;
+    if (nc > LANES) {
+        units[atomicAdd(nunits, 1u)] = make_int4(it, 0, nc, 0);
+        return;
+    }
+    int32_t c0 = 0;
+    while (c0 < nc) {
+        int32_t c1 = c0 + 1;
+        while (c1 < nc && cl[c1].aseq == cl[c0].aseq) c1++;
+        units[atomicAdd(nunits, 1u)] = make_int4(it, c0, c1, 0);
+        c0 = c1;
+    }
+}
 
 // ------------------------------------------------------------------------------------ K5
 
@@ -1065,7 +1112,7 @@ __device__ void walk_chain(const DhNode *__restrict__ pool, int32_t head, int32_
 // grid = res mod ts), other = the opposite sequence; gs/os = seed on the two axes; rd/ro, fd/fo =
 // boundary records of the reverse / forward extension (diffs, offset on `other`).  `reverse`
 // writes the pairs back to front (transposed record of a complemented alignment).
-__device__ int32_t emit_trace(int lane, int32_t ts, int32_t res, int32_t gs, int32_t os,
+__device__ int32_t emit_trace(int lane, int stride, int32_t ts, int32_t res, int32_t gs, int32_t os,
                               int32_t gbeg, int32_t gend, int32_t obeg, int32_t oend, int32_t rdv,
                               int32_t fdv, int32_t rev_first, int32_t nr, const int32_t *rd,
                               const int32_t *ro, int32_t fwd_first, int32_t nf, const int32_t *fd,
@@ -1077,7 +1124,7 @@ __device__ int32_t emit_trace(int lane, int32_t ts, int32_t res, int32_t gs, int
     gm = gm < 0 ? gm + ts : gm;
     const int32_t seedb = (gm == 0 && gs > gbeg && gs < gend) ? 1 : 0;
     const int32_t npairs = nrv + seedb + nfv + 1;
-    for (int32_t e = lane; e < npairs; e += LANES) {
+    for (int32_t e = lane; e < npairs; e += stride) {
         int32_t po[2], pD[2];
 #pragma unroll
         for (int w = 0; w < 2; w++) {
@@ -1137,17 +1184,25 @@ k_wave(DbView A, DbView B, const uint8_t *__restrict__ brc, const uint8_t *__res
         int32_t it = 0;
         if (lane == 0) it = (int32_t)atomicAdd(ws.queue, 1u);
         it = __builtin_amdgcn_readfirstlane(it);
-        if (it >= nitems) break;
-        const int32_t item = item0 + it;
+        if (it >= (ws.units ? (int32_t)*ws.nunits : nitems)) break;
+        // work unit: a whole item, or (symmetric mode) one group of candidates of an item
+        int32_t c0 = 0, c1 = INT32_MAX, ui = it;
+        if (ws.units) {
+            const int4 u = ws.units[it];
+            ui = u.x;
+            c0 = u.y;
+            c1 = u.z;
+        }
+        const int32_t item = item0 + ui;
         const int32_t r = item >> 1, strand = item & 1;
-        const int32_t nc = max(ncand[item], 0);
+        const int32_t nc = min(max(ncand[item], 0), c1);
         const int64_t bo = B.off[r];
         const int32_t blen = (int32_t)(B.off[r + 1] - bo);
         const uint8_t *b = (strand ? brc : B.bases) + bo;
         // regions already aligned for this (read, strand): kept in registers of lanes 0..nd-1
         int32_t g_aseq = -1, g_ab = 0, g_ae = 0, g_bb = 0, g_be = 0, g_lo = 0, g_hi = 0;
         int32_t nd = 0, nacc = 0, ntr = 0;
-        for (int32_t c = 0; c < nc && (SYM || nacc < o.max_la) && nd < LANES; c++) {
+        for (int32_t c = c0; c < nc && (SYM || nacc < o.max_la) && nd < LANES; c++) {
             const DhCand cd = cand[(int64_t)item * o.max_cand + c];
             const int32_t sd = cd.apos - cd.bpos;
             const bool cov = lane < nd && g_aseq == cd.aseq && cd.apos >= g_ab && cd.apos < g_ae &&
@@ -1226,7 +1281,7 @@ k_wave(DbView A, DbView B, const uint8_t *__restrict__ brc, const uint8_t *__res
                 }
             }
             const int64_t slot = (int64_t)item_a * o.max_la + s1;
-            const int32_t npairs = emit_trace(lane, ts, 0, as, bs, abpos, aepos, bbpos, bepos, rv.d, fw.d,
+            const int32_t npairs = emit_trace(lane, LANES, ts, 0, as, bs, abpos, aepos, bbpos, bepos, rv.d, fw.d,
                                               rev_first, rv.nb, rd, rj, fwd_first, fw.nb, fd, fj, false,
                                               out_trace + slot * trmax);
             if (lane == 0) {
@@ -1258,7 +1313,7 @@ k_wave(DbView A, DbView B, const uint8_t *__restrict__ brc, const uint8_t *__res
                     break;
                 }
                 const int64_t slot2 = (int64_t)item2 * o.max_la + s2;
-                const int32_t np2 = emit_trace(lane, ts, resb, bs, as, bbpos, bepos, abpos, aepos, rv.d, fw.d,
+                const int32_t np2 = emit_trace(lane, LANES, ts, resb, bs, as, bbpos, bepos, abpos, aepos, rv.d, fw.d,
                                                revb_first, rv.nbb, rdb, rib, fwdb_first, fw.nbb, fdb, fib,
                                                strand != 0, out_trace + slot2 * trmax);
                 if (lane == 0) {
@@ -1288,6 +1343,605 @@ k_wave(DbView A, DbView B, const uint8_t *__restrict__ brc, const uint8_t *__res
     if (lane == 0) {
         atomicAdd(&counters[0], cells);
         atomicAdd(&counters[1], naln);
+        if (err) atomicOr(status, err);
+    }
+}
+
+#define HL_LANES 32
+// ------------------------------------------------------------------------------------ K5b
+//
+// k_wave2: two alignments per wavefront.  On average only ~19 of the 64 diagonals of a wavefront
+// are alive and the kernel is bound by VALU issue, so with a wave width of at most 30 diagonals
+// (DhOpts.width <= 30) each 32-lane half runs its own alignment: lane (k & 31) of a half owns
+// diagonal k.  The halves are independent state machines sharing one instruction stream -- a half
+// that finishes an extension runs its bookkeeping (next candidate, chains, trace, records, next
+// item) while the other half keeps stepping -- and everything that is wave-uniform in k_wave is
+// half-uniform here (kept per lane, broadcast with readlane pairs / ds_bpermute, ballots split
+// into their 32-bit halves).  Reverse extensions are forward extensions over the
+// reverse-complemented copies, so both halves always run the same slide code.
+// The arithmetic is that of ext_wave / k_wave, bit for bit.
+
+enum { W2_FETCH = 0, W2_CAND = 1, W2_EXT = 2, W2_EXT_END = 3, W2_DONE = 4, W2_POST_CHAIN = 5, W2_POST_REC1 = 6,
+       W2_POST_REC2 = 7 };
+
+__device__ __forceinline__ uint32_t hballot(bool p, int hb)
+{
+    const uint64_t m = __ballot(p);
+    return hb ? (uint32_t)(m >> 32) : (uint32_t)m;
+}
+// value of lane `l` (constant) of my half
+template <int L>
+__device__ __forceinline__ int32_t hlane(int32_t v, int hb)
+{
+    const int32_t a = __builtin_amdgcn_readlane(v, L), b = __builtin_amdgcn_readlane(v, 32 + L);
+    return hb ? b : a;
+}
+// value of lane l (half-uniform, 0..31) of my half; every lane of the half must be active
+__device__ __forceinline__ int32_t hread(int32_t v, int32_t l, int hb)
+{
+    return __builtin_amdgcn_ds_bpermute((hb | l) << 2, v);
+}
+// the same without the LDS crossbar round trip: two readlanes per half on scalar indices (for the
+// serial edge trimming, where the latency of ds_bpermute would sit on the critical path)
+__device__ __forceinline__ int32_t hread_fast(int32_t v, int32_t l, int hb)
+{
+    const int32_t l0 = __builtin_amdgcn_readlane(l, 0) & 31, l1 = __builtin_amdgcn_readlane(l, 32) & 31;
+    const int32_t a = __builtin_amdgcn_readlane(v, l0), b = __builtin_amdgcn_readlane(v, 32 + l1);
+    return hb ? b : a;
+}
+// max over the 32 lanes of my half
+__device__ __forceinline__ int32_t hmax_i32(int32_t v, int hb)
+{
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, false));
+    const int32_t r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+    const int32_t r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    return hb ? max(r2, r3) : max(r0, r1);
+}
+// forward slide with per-lane base pointers (bytes: p + i; packed: base index 4 * q + r + i,
+// p points at byte q)
+template <bool PK>
+__device__ __forceinline__ void slide2(const uint8_t *pa, int32_t ra, const uint8_t *pb, int32_t rb,
+                                       int32_t lim, int32_t &i, int32_t &j)
+{
+    for (;;) {
+        const int32_t rem = lim - i;
+        if (rem <= 0) break;
+        int32_t m, valid;
+        if (PK) {
+            const int32_t ta = ra + i, tb = rb + j;
+            const int32_t sa = (ta & 3) << 1, sb = (tb & 3) << 1;
+            const uint64_t x = (load8(pa + ((uint32_t)ta >> 2)) >> sa) ^ (load8(pb + ((uint32_t)tb >> 2)) >> sb);
+            valid = 32 - (max(sa, sb) >> 1);
+            m = x ? ((__ffsll((long long)x) - 1) >> 1) : 32;
+        } else {
+            const uint64_t x = load8(pa + (uint32_t)i) ^ load8(pb + (uint32_t)j);
+            valid = 8;
+            m = x ? ((__ffsll((long long)x) - 1) >> 3) : 8;
+        }
+        m = min(min(m, valid), rem);
+        i += m;
+        j += m;
+        if (m < valid) break;
+    }
+}
+
+struct W2Cold {
+    int32_t item, r, strand, nc, c, blen, nd, nacc, ntr;
+    int32_t c_aseq, as, bs, alen, sd;
+    int32_t fwd_first, rev_first, fwdb_first, revb_first, resb;
+    int64_t bo, ao;
+    int32_t fw_i, fw_j, fw_d, fw_head, fw_nb, fw_headb, fw_nbb;
+    int32_t rv_i, rv_j, rv_d, rv_head, rv_nb, rv_headb, rv_nbb;
+    int32_t abpos, bbpos, aepos, bepos, diffs;
+    unsigned long long cells, naln;
+};
+
+template <bool SYM, bool PK>
+__global__ void __launch_bounds__(LANES, 5)
+k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__restrict__ brc,
+        const uint8_t *__restrict__ apk, const uint8_t *__restrict__ arcpk,
+        const uint8_t *__restrict__ bpk, const uint8_t *__restrict__ brcpk, DhOpts o, int32_t item0,
+        int32_t nitems, const DhCand *__restrict__ cand, const int32_t *__restrict__ ncand,
+        WaveScratch ws, DhLa *__restrict__ out_la, uint16_t *__restrict__ out_trace,
+        int32_t trmax, int32_t *__restrict__ out_nla, int32_t *__restrict__ out_ntr,
+        unsigned long long *__restrict__ counters, int32_t *__restrict__ status)
+{
+    const int lane = threadIdx.x, hl = lane & 31, hb = lane & 32;
+    const int64_t slot = (int64_t)blockIdx.x * 2 + (lane >> 5);
+    DhNode *pool = ws.pool + slot * ws.poolcap;
+    const int32_t ts = o.tspace, pen = o.pen, xdrop = o.xdrop, poolcap = ws.poolcap;
+    const int32_t addr_lo = (hb | ((hl - 1) & 31)) << 2, addr_hi = (hb | ((hl + 1) & 31)) << 2;
+    constexpr int32_t DEAD = -(1 << 30);
+
+    int32_t st = W2_FETCH, err = 0;
+    // ---- cold state of the half (item, candidate, results, counters): half-uniform values that
+    // only the bookkeeping touches live in LDS (every lane of the half writes the same value), so
+    // that the stepping loop keeps its registers -- two alignments per wavefront at 8 waves/SIMD
+    __shared__ W2Cold cold_[2];
+    __shared__ int32_t greg_[2][14][HL_LANES];  // regions already aligned: region x in lane x & 31, set x >> 5
+    W2Cold &cs = cold_[lane >> 5];
+    int32_t(*gr)[HL_LANES] = greg_[lane >> 5];
+    cs.cells = 0;
+    cs.naln = 0;
+    // ---- the running extension (hot)
+    int32_t dir = 0, ra = 0, rb = 0, an = 0, bn = 0, tp_first = 0, tpb_first = 0;
+    const uint8_t *pa = nullptr, *pb = nullptr;
+    int32_t R = DEAD, H = -1, NB = 0, HB = -1, NBB = 0;  // per lane
+    int32_t L = 0, d = 0, pool_n = 0;
+    int32_t best_score = 0, best_i = 0, best_k = 0, best_d = 0, best_head = -1, best_nb = 0, best_headb = -1,
+            best_nbb = 0;
+    uint32_t ncell = 0;
+
+    // start the extension `dir` (0 forward, 1 reverse) of the current candidate
+    auto ext_begin = [&](int32_t nd_) {
+        dir = nd_;
+        // reverse = forward over the reverse complements: base (len - pos) of the rc copy
+        const int32_t as = cs.as, bs = cs.bs, alen = cs.alen, blen = cs.blen;
+        const int64_t ga = cs.ao + (dir ? alen - as : as), gb = cs.bo + (dir ? blen - bs : bs);
+        an = dir ? as : alen - as;
+        bn = dir ? bs : blen - bs;
+        const bool brc_side = (cs.strand != 0) != (dir != 0);
+        if (PK) {
+            pa = (dir ? arcpk : apk) + (ga >> 2);
+            pb = (brc_side ? brcpk : bpk) + (gb >> 2);
+            ra = (int32_t)(ga & 3);
+            rb = (int32_t)(gb & 3);
+        } else {
+            pa = (dir ? arc : A.bases) + ga;
+            pb = (brc_side ? brc : B.bases) + gb;
+            ra = rb = 0;
+        }
+        tp_first = dir ? cs.rev_first : cs.fwd_first;
+        tpb_first = dir ? cs.revb_first : cs.fwdb_first;
+        R = DEAD;
+        H = -1;
+        NB = tp_first;
+        HB = -1;
+        NBB = tpb_first;
+        L = 0;
+        // d = 0: the seed diagonal, slid by lane 0 of the half
+        int32_t i0 = 0, h0 = -1, nb0 = 0, hb0 = -1, nbb0 = 0;
+        if (hl == 0) {
+            int32_t j0 = 0;
+            slide2<PK>(pa, ra, pb, rb, min(an, bn), i0, j0);
+            int32_t cnt = 0;
+            for (int32_t nextb = tp_first; nextb <= i0; nextb += ts) {
+                const int32_t idx = pool_n + cnt;
+                if (idx < poolcap) {
+                    pool[idx].parent = h0;
+                    pool[idx].d = 0;
+                    pool[idx].j = nextb;
+                }
+                h0 = idx;
+                nb0++;
+                cnt++;
+            }
+            if (SYM)
+                for (int32_t nextb = tpb_first; nextb <= i0; nextb += ts) {
+                    const int32_t idx = pool_n + cnt;
+                    if (idx < poolcap) {
+                        pool[idx].parent = hb0;
+                        pool[idx].d = 0;
+                        pool[idx].j = nextb;
+                    }
+                    hb0 = idx;
+                    nbb0++;
+                    cnt++;
+                }
+            R = i0;
+            H = h0;
+            NB = tp_first + nb0 * ts;
+            HB = hb0;
+            NBB = tpb_first + nbb0 * ts;
+        }
+        i0 = hlane<0>(i0, hb);
+        h0 = hlane<0>(h0, hb);
+        nb0 = hlane<0>(nb0, hb);
+        hb0 = hlane<0>(hb0, hb);
+        nbb0 = hlane<0>(nbb0, hb);
+        pool_n += nb0 + nbb0;
+        best_score = 2 * i0;
+        best_i = i0;
+        best_k = 0;
+        best_d = 0;
+        best_head = h0;
+        best_nb = tp_first + nb0 * ts;
+        best_headb = hb0;
+        best_nbb = tpb_first + nbb0 * ts;
+        ncell = 1;
+        d = 1;
+        st = d <= o.dmax ? W2_EXT : W2_EXT_END;
+    };
+
+    for (;;) {
+        // the stepping loop proper: left only when a half needs bookkeeping (or both are done)
+        while (__ballot(st != W2_EXT && st != W2_DONE) == 0ull && __ballot(st == W2_EXT) != 0ull) {
+          if (st == W2_EXT) {
+            // ======================================================== one difference level
+            const int32_t nL = L - 1;
+            const int32_t kidx = (hl - nL) & 31;
+            const int32_t k = nL + kidx;
+            const int32_t Rm = __builtin_amdgcn_ds_bpermute(addr_lo, R), Hm = __builtin_amdgcn_ds_bpermute(addr_lo, H),
+                          Nm = __builtin_amdgcn_ds_bpermute(addr_lo, NB);
+            const int32_t Rp = __builtin_amdgcn_ds_bpermute(addr_hi, R), Hp = __builtin_amdgcn_ds_bpermute(addr_hi, H),
+                          Np = __builtin_amdgcn_ds_bpermute(addr_hi, NB);
+            int32_t HBm = -1, NBm = tpb_first, HBp = -1, NBp = tpb_first;
+            if (SYM) {
+                HBm = __builtin_amdgcn_ds_bpermute(addr_lo, HB);
+                NBm = __builtin_amdgcn_ds_bpermute(addr_lo, NBB);
+                HBp = __builtin_amdgcn_ds_bpermute(addr_hi, HB);
+                NBp = __builtin_amdgcn_ds_bpermute(addr_hi, NBB);
+            }
+            int32_t ni = -1, hd = -1, nbp = tp_first, hbn = -1, nbbp = tpb_first;
+            const int32_t lim = min(an, bn + k);
+            {
+                const int32_t cs = R + 1, cdl = Rm + 1, ci = Rp;
+                if (cs <= lim && cs > ni) {
+                    ni = cs;
+                    hd = H;
+                    nbp = NB;
+                    hbn = HB;
+                    nbbp = NBB;
+                }
+                if (cdl <= lim && cdl > ni) {
+                    ni = cdl;
+                    hd = Hm;
+                    nbp = Nm;
+                    hbn = HBm;
+                    nbbp = NBm;
+                }
+                if (ci <= lim && ci > ni) {
+                    ni = ci;
+                    hd = Hp;
+                    nbp = Np;
+                    hbn = HBp;
+                    nbbp = NBp;
+                }
+            }
+            bool alive = ni >= 0;
+            int32_t j = ni - k;
+            if (alive) slide2<PK>(pa, ra, pb, rb, lim, ni, j);
+            const uint32_t amask = hballot(alive, hb);
+            bool ended = amask == 0u;
+            if (!ended) {
+                ncell += __popc(amask);
+                // trace nodes for the boundaries crossed in (prev_i, ni]
+                int32_t nextb = nbp;
+                bool cross = alive && ni >= nextb;
+                for (;;) {
+                    const uint32_t m = hballot(cross, hb);
+                    if (m == 0u) break;
+                    if (cross) {
+                        const int32_t idx = pool_n + __popc(m & ((1u << hl) - 1u));
+                        if (idx < poolcap) {
+                            pool[idx].parent = hd;
+                            pool[idx].d = d;
+                            pool[idx].j = nextb - k;
+                        }
+                        hd = idx;
+                        nextb += ts;
+                        cross = ni >= nextb;
+                    }
+                    pool_n += __popc(m);
+                }
+                int32_t nextbb = nbbp;
+                if (SYM) {
+                    bool crossb = alive && j >= nextbb;
+                    for (;;) {
+                        const uint32_t m = hballot(crossb, hb);
+                        if (m == 0u) break;
+                        if (crossb) {
+                            const int32_t idx = pool_n + __popc(m & ((1u << hl) - 1u));
+                            if (idx < poolcap) {
+                                pool[idx].parent = hbn;
+                                pool[idx].d = d;
+                                pool[idx].j = nextbb + k;
+                            }
+                            hbn = idx;
+                            nextbb += ts;
+                            crossb = j >= nextbb;
+                        }
+                        pool_n += __popc(m);
+                    }
+                }
+                if (pool_n > poolcap) {
+                    err |= DH_ST_POOL_OVERFLOW;
+                    ended = true;
+                } else {
+                    R = alive ? ni : DEAD;
+                    H = hd;
+                    NB = nextb;
+                    HB = hbn;
+                    NBB = nextbb;
+                    const int32_t sc = alive ? 2 * ni - k - pen * d : INT32_MIN;
+                    const int32_t step_best = hmax_i32(sc, hb);
+                    const uint32_t rot = (uint32_t)nL & 31u;
+                    if (step_best > best_score) {
+                        const uint32_t hm = hballot(alive && sc == step_best, hb);
+                        const uint32_t hr = __builtin_rotateright32(hm, rot);
+                        const int32_t step_kidx = __ffs((int)hr) - 1;
+                        const int32_t src = (nL + step_kidx) & 31;
+                        best_score = step_best;
+                        best_k = nL + step_kidx;
+                        best_i = hread(R, src, hb);
+                        best_head = hread(H, src, hb);
+                        best_nb = hread(NB, src, hb);
+                        if (SYM) {
+                            best_headb = hread(HB, src, hb);
+                            best_nbb = hread(NBB, src, hb);
+                        }
+                        best_d = d;
+                    }
+                    if (alive && sc < best_score - xdrop) {
+                        alive = false;
+                        R = DEAD;
+                    }
+                    uint32_t lm = hballot(alive, hb);
+                    if (lm == 0u) {
+                        ended = true;
+                    } else {
+                        uint32_t rm = __builtin_rotateright32(lm, rot);
+                        int32_t l2 = nL + (__ffs((int)rm) - 1);
+                        int32_t u2 = nL + (31 - __clz((int)rm));
+                        while (u2 - l2 + 1 > o.width) {
+                            const int32_t val = 2 * R - k;
+                            const int32_t sl = hread_fast(val, l2, hb);
+                            const int32_t su = hread_fast(val, u2, hb);
+                            const int32_t kill = sl <= su ? l2 : u2;
+                            if (k == kill) {
+                                alive = false;
+                                R = DEAD;
+                            }
+                            lm = hballot(alive, hb);
+                            rm = __builtin_rotateright32(lm, rot);
+                            l2 = nL + (__ffs((int)rm) - 1);
+                            u2 = nL + (31 - __clz((int)rm));
+                        }
+                        L = l2;
+                    }
+                }
+            }
+            d++;
+            if (ended || d > o.dmax) st = W2_EXT_END;
+          }
+        }
+        if (st != W2_EXT && st != W2_DONE) {
+            // ======================================================== bookkeeping of this half
+            while (st != W2_EXT && st != W2_DONE) {
+                if (st == W2_FETCH) {
+                    int32_t it = 0;
+                    if (hl == 0) it = (int32_t)atomicAdd(ws.queue, 1u);
+                    it = hlane<0>(it, hb);
+                    if (it >= (ws.units ? (int32_t)*ws.nunits : nitems)) {
+                        st = W2_DONE;
+                        break;
+                    }
+                    // work unit: a whole item, or (symmetric mode) one group of candidates of an item
+                    int32_t c0 = 0, c1 = INT32_MAX, ui = it;
+                    if (ws.units) {
+                        const int4 u = ws.units[it];
+                        ui = u.x;
+                        c0 = u.y;
+                        c1 = u.z;
+                    }
+                    const int32_t item = item0 + ui;
+                    cs.item = item;
+                    cs.r = item >> 1;
+                    cs.strand = item & 1;
+                    cs.nc = min(max(ncand[item], 0), c1);
+                    const int64_t bo = B.off[item >> 1];
+                    cs.bo = bo;
+                    cs.blen = (int32_t)(B.off[(item >> 1) + 1] - bo);
+                    gr[0][hl] = -1;
+                    gr[7][hl] = -1;
+                    cs.nd = cs.nacc = cs.ntr = 0;
+                    cs.c = c0;
+                    st = W2_CAND;
+                } else if (st == W2_CAND) {
+                    bool started = false;
+                    const int32_t item = cs.item, nc = cs.nc, nd = cs.nd;
+                    int32_t c = cs.c;
+                    while (c < nc && (SYM || cs.nacc < o.max_la) && nd < LANES) {
+                        const DhCand cd = cand[(int64_t)item * o.max_cand + c];
+                        const int32_t sdc = cd.apos - cd.bpos;
+                        const bool cov0 = hl < nd && gr[0][hl] == cd.aseq && cd.apos >= gr[1][hl] && cd.apos < gr[2][hl] &&
+                                          cd.bpos >= gr[3][hl] && cd.bpos < gr[4][hl] && sdc >= gr[5][hl] - 64 &&
+                                          sdc <= gr[6][hl] + 64;
+                        const bool cov1 = hl + 32 < nd && gr[7][hl] == cd.aseq && cd.apos >= gr[8][hl] &&
+                                          cd.apos < gr[9][hl] && cd.bpos >= gr[10][hl] && cd.bpos < gr[11][hl] &&
+                                          sdc >= gr[12][hl] - 64 && sdc <= gr[13][hl] + 64;
+                        if (hballot(cov0 || cov1, hb) != 0u) {
+                            c++;
+                            continue;
+                        }
+                        const int32_t as = cd.apos, bs = cd.bpos;
+                        cs.c_aseq = cd.aseq;
+                        cs.as = as;
+                        cs.bs = bs;
+                        cs.sd = sdc;
+                        const int64_t ao = A.off[cd.aseq];
+                        cs.ao = ao;
+                        cs.alen = (int32_t)(A.off[cd.aseq + 1] - ao);
+                        cs.fwd_first = ts - (as % ts);
+                        cs.rev_first = (as % ts) ? (as % ts) : ts;
+                        const int32_t resb = cs.strand ? cs.blen % ts : 0;
+                        cs.resb = resb;
+                        int32_t bm = (bs - resb) % ts;
+                        bm = bm < 0 ? bm + ts : bm;
+                        cs.fwdb_first = ts - bm;
+                        cs.revb_first = bm ? bm : ts;
+                        pool_n = 0;
+                        ext_begin(0);
+                        started = true;
+                        break;
+                    }
+                    cs.c = c;
+                    if (!started) {
+                        if (!SYM && hl == 0) {
+                            out_nla[item] = cs.nacc;
+                            out_ntr[item] = cs.ntr;
+                        }
+                        st = W2_FETCH;
+                    }
+                } else if (st == W2_EXT_END) {
+                    cs.cells += ncell;
+                    const int32_t r_nb = (best_nb - tp_first) / ts, r_nbb = SYM ? (best_nbb - tpb_first) / ts : 0;
+                    if (dir == 0 && !err) {
+                        cs.fw_i = best_i;
+                        cs.fw_j = best_i - best_k;
+                        cs.fw_d = best_d;
+                        cs.fw_head = best_head;
+                        cs.fw_nb = r_nb;
+                        cs.fw_headb = best_headb;
+                        cs.fw_nbb = r_nbb;
+                        ext_begin(1);
+                        continue;
+                    }
+                    cs.rv_i = best_i;
+                    cs.rv_j = best_i - best_k;
+                    cs.rv_d = best_d;
+                    cs.rv_head = best_head;
+                    cs.rv_nb = r_nb;
+                    cs.rv_headb = best_headb;
+                    cs.rv_nbb = r_nbb;
+                    cs.naln += 1;
+                    if (err || cs.fw_nb > ws.nbmax || r_nb > ws.nbmax || cs.fw_nbb > ws.nbmax || r_nbb > ws.nbmax) {
+                        err |= DH_ST_POOL_OVERFLOW;
+                        st = W2_DONE;
+                        break;
+                    }
+                    st = W2_POST_CHAIN;
+                } else if (st == W2_POST_CHAIN) {
+                    // chains: lane 0 forward, lane 1 reverse, lanes 2 / 3 the B-boundary families (SYM)
+                    int32_t *cdj = ws.cdj + ((int64_t)blockIdx.x * 2 + (lane >> 5)) * 8 * ws.nbmax;
+                    int32_t clo = 0, chi = 0;
+                    if (hl < (SYM ? 4 : 2)) {
+                        const bool isf = (hl & 1) == 0, isb = hl >= 2;
+                        const int32_t head = isb ? (isf ? cs.fw_headb : cs.rv_headb) : (isf ? cs.fw_head : cs.rv_head);
+                        const int32_t nb = isb ? (isf ? cs.fw_nbb : cs.rv_nbb) : (isf ? cs.fw_nb : cs.rv_nb);
+                        const int32_t first = isb ? (isf ? cs.fwdb_first : cs.revb_first)
+                                                  : (isf ? cs.fwd_first : cs.rev_first);
+                        const int32_t bk = isb ? 0 : (isf ? cs.fw_i - cs.fw_j : cs.rv_i - cs.rv_j);
+                        // layout of cdj: fd fj rd rj fdb fib rdb rib (nbmax each)
+                        int32_t *cd = cdj + (int64_t)((isb ? 4 : 0) + (isf ? 0 : 2)) * ws.nbmax;
+                        walk_chain(pool, head, nb, first, ts, bk, cd, cd + ws.nbmax, clo, chi);
+                    }
+                    __threadfence_block();
+                    const int32_t flo = hlane<0>(clo, hb), fhi = hlane<0>(chi, hb);
+                    const int32_t rlo = hlane<1>(clo, hb), rhi = hlane<1>(chi, hb);
+                    const int32_t as = cs.as, bs = cs.bs, sd = cs.sd, nd = cs.nd;
+                    const int32_t abpos = as - cs.rv_i, bbpos = bs - cs.rv_j, aepos = as + cs.fw_i, bepos = bs + cs.fw_j;
+                    const int32_t diffs = cs.fw_d + cs.rv_d;
+                    int32_t lo = sd + flo, hi = sd + fhi;
+                    lo = (sd - rhi) < lo ? (sd - rhi) : lo;
+                    hi = (sd - rlo) > hi ? (sd - rlo) : hi;
+                    if (hl == (nd & 31)) {
+                        const int g0 = nd < 32 ? 0 : 7;
+                        gr[g0 + 0][hl] = cs.c_aseq;
+                        gr[g0 + 1][hl] = abpos;
+                        gr[g0 + 2][hl] = aepos;
+                        gr[g0 + 3][hl] = bbpos;
+                        gr[g0 + 4][hl] = bepos;
+                        gr[g0 + 5][hl] = lo;
+                        gr[g0 + 6][hl] = hi;
+                    }
+                    cs.nd = nd + 1;
+                    cs.c = cs.c + 1;
+                    cs.abpos = abpos;
+                    cs.bbpos = bbpos;
+                    cs.aepos = aepos;
+                    cs.bepos = bepos;
+                    cs.diffs = diffs;
+                    const int64_t al = aepos - abpos, bl = bepos - bbpos;
+                    const bool accept = al >= o.min_len &&
+                                        (int64_t)2 * diffs * 1000000ll <= (int64_t)o.max_err_ppm * (al + bl);
+                    st = accept ? W2_POST_REC1 : W2_CAND;
+                } else if (st == W2_POST_REC1) {
+                    // ---- the record (a, b): trace on the grid of A
+                    int32_t *cdj = ws.cdj + ((int64_t)blockIdx.x * 2 + (lane >> 5)) * 8 * ws.nbmax;
+                    const int32_t item = cs.item, strand = cs.strand, c_aseq = cs.c_aseq;
+                    const int32_t item_a = SYM ? 2 * c_aseq + strand : item;
+                    int32_t s1 = cs.nacc;
+                    if (SYM) {
+                        if (hl == 0) s1 = atomicAdd(&out_nla[item_a], 1);
+                        s1 = hlane<0>(s1, hb);
+                        if (s1 >= o.max_la) {
+                            err |= DH_ST_POOL_OVERFLOW;
+                            st = W2_DONE;
+                            break;
+                        }
+                    }
+                    const int64_t oslot = (int64_t)item_a * o.max_la + s1;
+                    const int32_t npairs = emit_trace(hl, HL_LANES, ts, 0, cs.as, cs.bs, cs.abpos, cs.aepos, cs.bbpos,
+                                                      cs.bepos, cs.rv_d, cs.fw_d, cs.rev_first, cs.rv_nb,
+                                                      cdj + 2 * (int64_t)ws.nbmax, cdj + 3 * (int64_t)ws.nbmax,
+                                                      cs.fwd_first, cs.fw_nb, cdj, cdj + ws.nbmax, false,
+                                                      out_trace + oslot * trmax);
+                    if (hl == 0) {
+                        DhLa la;
+                        la.tlen = 2 * npairs;
+                        la.diffs = cs.diffs;
+                        la.abpos = cs.abpos;
+                        la.bbpos = cs.bbpos;
+                        la.aepos = cs.aepos;
+                        la.bepos = cs.bepos;
+                        la.flags = strand ? 1u : 0u;
+                        la.aread = c_aseq;
+                        la.bread = cs.r;
+                        la.pad = 0;
+                        la.toff = 0;
+                        out_la[oslot] = la;
+                        if (SYM) atomicAdd(&out_ntr[item_a], 2 * npairs);
+                    }
+                    cs.nacc = cs.nacc + 1;
+                    cs.ntr = cs.ntr + 2 * npairs;
+                    st = SYM ? W2_POST_REC2 : W2_CAND;
+                } else {  // W2_POST_REC2: the transposed record (b, a), trace on the grid of B
+                    int32_t *cdj = ws.cdj + ((int64_t)blockIdx.x * 2 + (lane >> 5)) * 8 * ws.nbmax;
+                    const int32_t item = cs.item, strand = cs.strand;
+                    int32_t s2 = 0;
+                    if (hl == 0) s2 = atomicAdd(&out_nla[item], 1);
+                    s2 = hlane<0>(s2, hb);
+                    if (s2 >= o.max_la) {
+                        err |= DH_ST_POOL_OVERFLOW;
+                        st = W2_DONE;
+                        break;
+                    }
+                    const int64_t slot2 = (int64_t)item * o.max_la + s2;
+                    const int32_t np2 = emit_trace(hl, HL_LANES, ts, cs.resb, cs.bs, cs.as, cs.bbpos, cs.bepos, cs.abpos,
+                                                   cs.aepos, cs.rv_d, cs.fw_d, cs.revb_first, cs.rv_nbb,
+                                                   cdj + 6 * (int64_t)ws.nbmax, cdj + 7 * (int64_t)ws.nbmax,
+                                                   cs.fwdb_first, cs.fw_nbb, cdj + 4 * (int64_t)ws.nbmax,
+                                                   cdj + 5 * (int64_t)ws.nbmax, strand != 0, out_trace + slot2 * trmax);
+                    if (hl == 0) {
+                        const int32_t blen = cs.blen, alen = cs.alen;
+                        DhLa la;
+                        la.tlen = 2 * np2;
+                        la.diffs = cs.diffs;
+                        la.abpos = strand ? blen - cs.bepos : cs.bbpos;
+                        la.aepos = strand ? blen - cs.bbpos : cs.bepos;
+                        la.bbpos = strand ? alen - cs.aepos : cs.abpos;
+                        la.bepos = strand ? alen - cs.abpos : cs.aepos;
+                        la.flags = strand ? 1u : 0u;
+                        la.aread = cs.r;
+                        la.bread = cs.c_aseq;
+                        la.pad = 0;
+                        la.toff = 0;
+                        out_la[slot2] = la;
+                        atomicAdd(&out_ntr[item], 2 * np2);
+                    }
+                    st = W2_CAND;
+                }
+            }
+        }
+        if (__ballot(st != W2_DONE) == 0ull) break;
+    }
+    if (hl == 0) {
+        atomicAdd(&counters[0], cs.cells);
+        atomicAdd(&counters[1], cs.naln);
         if (err) atomicOr(status, err);
     }
 }
@@ -1475,6 +2129,42 @@ void dhk_wave(hipStream_t st, int32_t nslots, DbView A, DbView B, const uint8_t 
             WAVE_LAUNCH(false, false);
     }
 #undef WAVE_LAUNCH
+}
+
+// two alignments per wavefront (o.width <= 30): nslots blocks, 2 * nslots scratch slots; needs the
+// reverse complement of A as well (arc, arcpk); apk / arcpk / bpk / brcpk all four or none
+void dhk_wave2(hipStream_t st, int32_t nslots, DbView A, DbView B, const uint8_t *arc, const uint8_t *brc,
+               const uint8_t *apk, const uint8_t *arcpk, const uint8_t *bpk, const uint8_t *brcpk, DhOpts o,
+               int32_t item0, int32_t nitems, const DhCand *cand, const int32_t *ncand, WaveScratch ws,
+               DhLa *out_la, uint16_t *out_trace, int32_t trmax, int32_t *out_nla, int32_t *out_ntr,
+               unsigned long long *counters, int32_t *status)
+{
+    if (nitems <= 0) return;
+    const bool pk = apk && arcpk && bpk && brcpk;
+#define WAVE2_LAUNCH(S, P)                                                                         \
+    hipLaunchKernelGGL((k_wave2<S, P>), dim3(nslots), dim3(LANES), 0, st, A, B, arc, brc, apk, arcpk, bpk, brcpk, o, \
+                       item0, nitems, cand, ncand, ws, out_la, out_trace, trmax, out_nla, out_ntr, counters,  \
+                       status)
+    if (o.skip_self == 2) {
+        if (pk)
+            WAVE2_LAUNCH(true, true);
+        else
+            WAVE2_LAUNCH(true, false);
+    } else {
+        if (pk)
+            WAVE2_LAUNCH(false, true);
+        else
+            WAVE2_LAUNCH(false, false);
+    }
+#undef WAVE2_LAUNCH
+}
+
+void dhk_units(hipStream_t st, const DhCand *cand, const int32_t *ncand, int32_t item0, int32_t nitems,
+               int32_t max_cand, void *units, uint32_t *nunits)
+{
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL(k_units, dim3((nitems + 255) / 256), dim3(256), 0, st, cand, ncand, item0, nitems, max_cand,
+                       (int4 *)units, nunits);
 }
 
 void dhk_pack2(hipStream_t st, const uint8_t *src, int64_t total, uint8_t *dst, int32_t *flag)

@@ -286,6 +286,13 @@ static int cand_cmp(const void *x, const void *y)
     return 0;
 }
 
+static int cand_cmp_aseq(const void *x, const void *y)
+{
+    const oz_cand *p = (const oz_cand *)x, *q = (const oz_cand *)y;
+    if (p->aseq != q->aseq) return p->aseq < q->aseq ? -1 : 1;
+    return cand_cmp(x, y);
+}
+
 #define HIT_QBITS 24
 #define HIT_QMASK ((1u << HIT_QBITS) - 1)
 
@@ -440,6 +447,10 @@ static int seed_candidates(const oz_index *ix, const uint8_t *b, int32_t blen, i
     }
     qsort(cands, (size_t)nc, sizeof(oz_cand), cand_cmp);
     if (nc > o->max_cand) nc = o->max_cand;
+    /* symmetric all-vs-all: the kept candidates are grouped by A read (rank order inside a group),
+     * so that the groups -- the only candidates that depend on each other -- are separate work
+     * units for the device */
+    if (o->skip_self == 2) qsort(cands, (size_t)nc, sizeof(oz_cand), cand_cmp_aseq);
     memcpy(out, cands, (size_t)nc * sizeof(oz_cand));
     free(cands);
     free(bd);

@@ -14,6 +14,7 @@ from . import pyoracle as oz
 MIN_ANCHOR = 500       # commandline.d:2036 minAnchorLength
 ALLOWANCE_MAP = 100    # proper-alignment-allowance = trace spacing (commandline.d:2331)
 TS_PILE = 126
+WAVE_WIDTH = 30  # live diagonals of a wave: the product default (dh_default_align_opts), two alignments per wavefront
 MAX_PILE = 60          # reads kept per pile-up (one wavefront tracks <= 64 aligned regions)
 MAX_INS_ERR_PPM = 100000  # commandline.d:1997 maxInsertionError 0.10
 
@@ -106,7 +107,7 @@ def crop_pile(entries, las, trace, contigs, reads, g, ts_map=100):
 
 def pile_opts():
     # skip_self = 2: every unordered pair aligned once, both records emitted (what daligner does)
-    return oz.default_opts(tspace=TS_PILE, min_len=500, skip_self=2, max_la=64, max_cand=128, width=62)
+    return oz.default_opts(tspace=TS_PILE, min_len=500, skip_self=2, max_la=64, max_cand=128, width=WAVE_WIDTH)
 
 
 def filter_pile_las(las, pile, max_err_ppm=300000, allowance=TS_PILE):
@@ -222,7 +223,7 @@ def process_pile(entries, las, trace, contigs, reads, g, rounds=3, nthreads=1, f
     cons = oz.consensus(pile.seq(ref_idx), pile, plas, ptrace, ref_idx, TS_PILE)
     for _ in range(1, rounds):
         tdb = SeqDb.from_list([cons])
-        o2 = oz.default_opts(tspace=TS_PILE, min_len=500, max_la=4, max_cand=32, width=62)
+        o2 = oz.default_opts(tspace=TS_PILE, min_len=500, max_la=4, max_cand=32, width=WAVE_WIDTH)
         rl, rt, _ = oz.align_db(tdb, pile, o2, nthreads=nthreads)
         for la in rl:   # proper overlaps only
             if not oz.valid_pileup_alignment({**{f: la[f] for f in la.dtype.names}, "aread": -1},
@@ -235,7 +236,7 @@ def process_pile(entries, las, trace, contigs, reads, g, rounds=3, nthreads=1, f
     wl = max(0, len(cl) - flank_window)
     fl, fr = cl[wl:], cr[:flank_window]
     fdb = SeqDb.from_list([fl, fr])
-    o3 = oz.default_opts(tspace=TS_PILE, min_len=126, max_la=4, max_cand=32, width=62)
+    o3 = oz.default_opts(tspace=TS_PILE, min_len=126, max_la=4, max_cand=32, width=WAVE_WIDTH)
     fl_las, fl_tr, _ = oz.align_db(fdb, SeqDb.from_list([cons]), o3, nthreads=nthreads)
     res.update(flank_las=fl_las, flank_trace=fl_tr, flank_off=wl)
     allow = TS_PILE
