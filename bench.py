@@ -156,7 +156,7 @@ def main():
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         mean = lambda f: float(np.mean([f(r) for r in runs]))  # noqa: E731
-        # dominant kernel of the step: k_wave (mapping launch + pile-up all-vs-all launch + the small
+        # dominant kernel of the step: k_wave2 (mapping launch + pile-up all-vs-all launch + the small
         # re-alignment and flank launches).  Algorithmic bytes of a launch = both sequences of every
         # alignment it emits streamed once (2 B per aligned A base at one byte per base) + its trace
         # (2 B per trace value); summed over the step's launches and divided by their summed
@@ -191,7 +191,7 @@ def main():
                        "consensus_error_rate": (edits_all / truth_all) if truth_all else None},
             "read_bp_aligned_per_sec": aligned_all * args.steps / dt,
             "read_bp_aligned_per_sec_mapping_stage": aligned_bp / mean(lambda r: r["t_map"]),
-            "roofline": {"bound": "hbm", "kernel": "k_wave", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_wave2", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launches_per_step": cum["wave_launches"], "kernel_ms_per_step": wave_ms,
                          "avg_launch_ms": wave_ms / max(1, cum["wave_launches"]),

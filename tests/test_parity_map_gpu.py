@@ -212,6 +212,20 @@ def test_chunked_launches_give_identical_results(gpu_ctx, monkeypatch):
 
 
 @pytest.mark.parametrize("sym", [False, True])
+def test_wide_windows_use_one_alignment_per_wavefront(gpu_ctx, sym):
+    """width <= 30 (default) runs two alignments per wavefront (k_wave2), wider windows one
+    (k_wave): both against the oracle at their own width."""
+    w = sim.Workload(200_000, 2, 300, 4000, seed=37, spacing=15000)
+    if sym:
+        sub = sim.SeqDb.from_list([w.reads.seq(i) for i in range(80)])
+        for width in (62, 30, 12):
+            run_both(gpu_ctx, sub, sub, same=True, skip_self=2, tspace=126, max_la=64, max_cand=128, width=width)
+    else:
+        for width in (62, 30, 12):
+            run_both(gpu_ctx, w.contigs, w.reads, width=width)
+
+
+@pytest.mark.parametrize("sym", [False, True])
 def test_packed_and_byte_wave_paths_agree(gpu_ctx, monkeypatch, sym):
     """ACGT-only DBs are aligned from 2-bit packed copies (32 bases per load), DBs with other codes
     from the byte arrays; both instantiations of the wave kernel must give the same bits."""
