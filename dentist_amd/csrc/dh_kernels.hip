@@ -546,54 +546,40 @@ __device__ void seed_item(const DbView &B, const uint8_t *__restrict__ brc, cons
     }
     __syncthreads();
     SP(1)
-    // ---- band heads: coverage of bands b-1, b, b+1, b+2.  Small variants: every head sums its own
-    // band once and publishes (coverage, end) at the head and the coverage at the tail, the
-    // neighbours are then looked up; large variants (no LDS to spare) walk the four bands.
+    // ---- band pairs.  Small variants (FASTB): one block-wide inclusive scan over
+    // (band-head flag << 18 | covered-base contribution) gives every band its coverage as a
+    // difference of two prefix sums and the compacted list of band heads, so the work is spread
+    // over all threads instead of one serial walk per band; large variants (no LDS to spare) walk
+    // the four bands from every band head.
     constexpr bool FASTB = LCAP > 0 && LCAP <= 4096;
-    __shared__ uint32_t bcov[FASTB ? LCAP : 1];
-    __shared__ uint16_t bend[FASTB ? LCAP : 1];
+    __shared__ uint32_t bsum[FASTB ? LCAP : 1];   // inclusive prefix sums
+    __shared__ uint16_t bhead[FASTB ? LCAP : 1];  // positions of the band heads
+    __shared__ uint32_t s_wsum[SEED_THREADS / LANES];
+    __shared__ int32_t s_nbig;
+    __shared__ int32_t bigc[64][4];  // candidate band pairs with long hit ranges: (first, end, P, slot)
+    __shared__ unsigned long long s_bestkey;
     const int bs = o.band_shift;
-    if (FASTB) {
-        for (int32_t i = tid; i < n; i += SEED_THREADS) {
-            const int64_t band = hitD(hits[i]) >> bs;
-            if (i > 0 && (hitD(hits[i - 1]) >> bs) == band) continue;  // not a band head
-            int32_t cov = 0, j = i;
-            for (; j < n && (hitD(hits[j]) >> bs) == band; j++) cov += hit_cov(hits, j, k);
-            bcov[i] = (uint32_t)cov;
-            bcov[j - 1] = (uint32_t)cov;
-            bend[i] = (uint16_t)j;
+    // seed of a band pair [i, e1): first hit of the same-diagonal run (steps <= k) covering most
+    // bases; then the candidate record
+    auto emit_cand = [&](int32_t slot, int32_t best_first, int32_t P, int64_t band) {
+        const int64_t D = hitD(hits[best_first]);
+        const int32_t q = hitQ(hits[best_first]);
+        const int64_t gv = D - ix.sepv + q;
+        int32_t lo = 0, hi = ix.na;
+        while (hi - lo > 1) {
+            const int32_t mid = (lo + hi) >> 1;
+            if (ix.goff[mid] <= gv)
+                lo = mid;
+            else
+                hi = mid;
         }
-        __syncthreads();
-        SP(2)
-    }
-    for (int32_t i = tid; i < n; i += SEED_THREADS) {
-        const int64_t band = hitD(hits[i]) >> bs;
-        if (i > 0 && (hitD(hits[i - 1]) >> bs) == band) continue;  // not a band head
-        int32_t covm1 = 0, cov0 = 0, cov1 = 0, cov2 = 0, e0, e1;
-        if (FASTB) {
-            if (i > 0 && (hitD(hits[i - 1]) >> bs) == band - 1) covm1 = (int32_t)bcov[i - 1];
-            cov0 = (int32_t)bcov[i];
-            e0 = bend[i];
-            e1 = e0;
-            if (e0 < n && (hitD(hits[e0]) >> bs) == band + 1) {
-                cov1 = (int32_t)bcov[e0];
-                e1 = bend[e0];
-            }
-            if (e1 < n && (hitD(hits[e1]) >> bs) == band + 2) cov2 = (int32_t)bcov[e1];
-        } else {
-            for (int32_t j = i - 1; j >= 0 && (hitD(hits[j]) >> bs) == band - 1; j--)
-                covm1 += hit_cov(hits, j, k);
-            int32_t j = i;
-            for (; j < n && (hitD(hits[j]) >> bs) == band; j++) cov0 += hit_cov(hits, j, k);
-            e0 = j;
-            for (; j < n && (hitD(hits[j]) >> bs) == band + 1; j++) cov1 += hit_cov(hits, j, k);
-            e1 = j;
-            for (; j < n && (hitD(hits[j]) >> bs) == band + 2; j++) cov2 += hit_cov(hits, j, k);
-        }
-        const int32_t P = cov0 + cov1, Pm1 = covm1 + cov0, Pp1 = cov1 + cov2;
-        if (P < o.hmin || P < Pm1 || P <= Pp1) continue;
-        // seed: first hit of the same-diagonal run (steps <= k) covering most bases
-        (void)e0;
+        cands[slot].score = P;
+        cands[slot].aseq = lo;
+        cands[slot].apos = (int32_t)(gv - ix.goff[lo]);
+        cands[slot].bpos = q;
+        cband[slot] = band;
+    };
+    auto serial_seed = [&](int32_t i, int32_t e1) {
         int32_t best_first = i, best_cov = -1, run_first = i;
         for (int32_t x = i; x < e1; x++) {
             bool linked = false;
@@ -606,24 +592,109 @@ __device__ void seed_item(const DbView &B, const uint8_t *__restrict__ brc, cons
                 best_first = run_first;
             }
         }
-        const int64_t D = hitD(hits[best_first]);
-        const int32_t q = hitQ(hits[best_first]);
-        const int64_t gv = D - ix.sepv + q;
-        int32_t lo = 0, hi = ix.na;
-        while (hi - lo > 1) {
-            const int32_t mid = (lo + hi) >> 1;
-            if (ix.goff[mid] <= gv)
-                lo = mid;
-            else
-                hi = mid;
+        return best_first;
+    };
+    if (FASTB) {
+        if (tid == 0) s_nbig = 0;
+        // -- scan: thread t owns the elements [t * per, t * per + per)
+        const int32_t per = (n + SEED_THREADS - 1) / SEED_THREADS;
+        const int32_t x0 = tid * per, x1 = min(n, x0 + per);
+        uint32_t acc = 0;
+        for (int32_t i = x0; i < x1; i++) {
+            const bool head = i == 0 || (hitD(hits[i - 1]) >> bs) != (hitD(hits[i]) >> bs);
+            acc += ((head ? 1u : 0u) << 18) | (uint32_t)hit_cov(hits, i, k);
+            bsum[i] = acc;
         }
-        const int32_t slot = atomicAdd(&s_nc, 1);
-        if (slot < SEED_CCAP) {
-            cands[slot].score = P;
-            cands[slot].aseq = lo;
-            cands[slot].apos = (int32_t)(gv - ix.goff[lo]);
-            cands[slot].bpos = q;
-            cband[slot] = band;
+        uint32_t incl = acc;  // inclusive scan of the per-thread totals: inside the wavefront ...
+        for (int off = 1; off < LANES; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off, LANES);
+            if ((tid & (LANES - 1)) >= off) incl += up;
+        }
+        if ((tid & (LANES - 1)) == LANES - 1) s_wsum[tid / LANES] = incl;
+        __syncthreads();
+        uint32_t base = incl - acc;  // ... plus the wavefronts before this one
+        for (int wv = 0; wv < tid / LANES; wv++) base += s_wsum[wv];
+        for (int32_t i = x0; i < x1; i++) {
+            const uint32_t v = bsum[i] + base;
+            bsum[i] = v;
+            const bool head = i == 0 || (hitD(hits[i - 1]) >> bs) != (hitD(hits[i]) >> bs);
+            if (head) bhead[(v >> 18) - 1] = (uint16_t)i;
+        }
+        __syncthreads();
+        SP(2)
+        const int32_t nheads = (int32_t)(bsum[n - 1] >> 18);
+        auto band_cov = [&](int32_t rnk) {  // coverage of the band with head number rnk
+            const int32_t st_ = bhead[rnk], en_ = rnk + 1 < nheads ? bhead[rnk + 1] : n;
+            return (int32_t)((bsum[en_ - 1] & 0x3FFFFu) - (st_ ? (bsum[st_ - 1] & 0x3FFFFu) : 0u));
+        };
+        for (int32_t rnk = tid; rnk < nheads; rnk += SEED_THREADS) {
+            const int32_t i = bhead[rnk];
+            const int64_t band = hitD(hits[i]) >> bs;
+            int32_t covm1 = 0, cov1 = 0, cov2 = 0, e1;
+            const int32_t cov0 = band_cov(rnk);
+            if (rnk > 0 && (hitD(hits[bhead[rnk - 1]]) >> bs) == band - 1) covm1 = band_cov(rnk - 1);
+            int32_t nx = rnk + 1;  // head number of the next band present
+            e1 = nx < nheads ? bhead[nx] : n;
+            if (nx < nheads && (hitD(hits[bhead[nx]]) >> bs) == band + 1) {
+                cov1 = band_cov(nx);
+                nx++;
+                e1 = nx < nheads ? bhead[nx] : n;
+            }
+            if (nx < nheads && (hitD(hits[bhead[nx]]) >> bs) == band + 2) cov2 = band_cov(nx);
+            const int32_t P = cov0 + cov1, Pm1 = covm1 + cov0, Pp1 = cov1 + cov2;
+            if (P < o.hmin || P < Pm1 || P <= Pp1) continue;
+            const int32_t slot = atomicAdd(&s_nc, 1);
+            if (slot >= SEED_CCAP) continue;
+            if (e1 - i > 64) {
+                // long range: the whole block picks the seed below
+                const int32_t bslot = atomicAdd(&s_nbig, 1);
+                if (bslot < 64) {
+                    bigc[bslot][0] = i;
+                    bigc[bslot][1] = e1;
+                    bigc[bslot][2] = P;
+                    bigc[bslot][3] = slot;
+                    continue;
+                }
+            }
+            emit_cand(slot, serial_seed(i, e1), P, band);
+        }
+        __syncthreads();
+        const int32_t nbig = min(s_nbig, 64);
+        for (int32_t bc = 0; bc < nbig; bc++) {
+            const int32_t i = bigc[bc][0], e1 = bigc[bc][1];
+            if (tid == 0) s_bestkey = 0ull;
+            __syncthreads();
+            // a run ends where the next hit is not linked; its coverage is the largest of the run
+            for (int32_t x = i + tid; x < e1; x += SEED_THREADS) {
+                const bool last = x + 1 >= e1 || hitD(hits[x + 1]) != hitD(hits[x]) ||
+                                  (hitQ(hits[x + 1]) - hitQ(hits[x])) > k;
+                if (!last) continue;
+                int32_t rf = x;
+                while (rf > i && hitD(hits[rf]) == hitD(hits[rf - 1]) && (hitQ(hits[rf]) - hitQ(hits[rf - 1])) <= k) rf--;
+                const uint32_t cov = (uint32_t)(k + hitQ(hits[x]) - hitQ(hits[rf]));
+                // largest coverage, then the earliest run
+                atomicMax(&s_bestkey, ((unsigned long long)cov << 32) | (uint32_t)(0x7FFFFFFF - rf));
+            }
+            __syncthreads();
+            if (tid == 0)
+                emit_cand(bigc[bc][3], 0x7FFFFFFF - (int32_t)(uint32_t)s_bestkey, bigc[bc][2], hitD(hits[i]) >> bs);
+        }
+    } else {
+        for (int32_t i = tid; i < n; i += SEED_THREADS) {
+            const int64_t band = hitD(hits[i]) >> bs;
+            if (i > 0 && (hitD(hits[i - 1]) >> bs) == band) continue;  // not a band head
+            int32_t covm1 = 0, cov0 = 0, cov1 = 0, cov2 = 0, e1;
+            for (int32_t j = i - 1; j >= 0 && (hitD(hits[j]) >> bs) == band - 1; j--)
+                covm1 += hit_cov(hits, j, k);
+            int32_t j = i;
+            for (; j < n && (hitD(hits[j]) >> bs) == band; j++) cov0 += hit_cov(hits, j, k);
+            for (; j < n && (hitD(hits[j]) >> bs) == band + 1; j++) cov1 += hit_cov(hits, j, k);
+            e1 = j;
+            for (; j < n && (hitD(hits[j]) >> bs) == band + 2; j++) cov2 += hit_cov(hits, j, k);
+            const int32_t P = cov0 + cov1, Pm1 = covm1 + cov0, Pp1 = cov1 + cov2;
+            if (P < o.hmin || P < Pm1 || P <= Pp1) continue;
+            const int32_t slot = atomicAdd(&s_nc, 1);
+            if (slot < SEED_CCAP) emit_cand(slot, serial_seed(i, e1), P, band);
         }
     }
     __syncthreads();
