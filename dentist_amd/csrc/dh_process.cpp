@@ -29,7 +29,11 @@ void dhk_tile_qv(hipStream_t st, const DhLa *las, const uint16_t *trace, const i
                  uint8_t *qv);
 void dhk_seg_vote(hipStream_t st, const void *segs, int32_t nseg, DbView T, DbView R,
                   const uint8_t *rrc, const int64_t *voff, uint32_t *dmat, int32_t bandmax, int32_t qmax,
-                  uint8_t *opbuf, uint32_t *votes, int32_t *status);
+                  int32_t ncolmax, uint8_t *opbuf, uint16_t *nops, uint32_t *votes, uint32_t *cdiff,
+                  uint32_t *vother, int32_t *status);
+void dhk_votes_finish(hipStream_t st, DbView T, const int64_t *voff, const int32_t *col_tmpl, int64_t ncols_total,
+                      const uint32_t *cexcl, const uint32_t *vother, uint32_t *votes);
+void dhk_scan(hipStream_t st, uint32_t *v, int64_t n, uint32_t *sums);
 void dhk_emit(hipStream_t st, DbView T, int32_t ntmpl, const int64_t *voff, const uint32_t *votes,
               const int32_t *col_tmpl, int64_t ncols_total, uint8_t *stage, uint8_t *cnt,
               const int64_t *out_off, uint8_t *out, int32_t *out_len);
@@ -421,6 +425,12 @@ static int consensus_round(dh_ctx *ctx, dh_db *T, dh_db *R, const LaVec &las,
     HIPCHK(hipMemcpyAsync(d_ooff.p, ooff.data(), sizeof(int64_t) * ooff.size(), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(d_votes.p, 0, sizeof(uint32_t) * (size_t)voff.back() * VSTRIDE, st));
     HIPCHK(hipMemsetAsync(d_status.p, 0, sizeof(int32_t), st));
+    // sparse votes: cover difference array and "other code" counts per column, scan partial sums
+    const size_t ncolp = (size_t)voff.back() + 2;
+    struct { uint32_t *p; } d_cdiff;
+    SCRP(25, d_cdiff, 2 * ncolp + ncolp / 2048 + 8)
+    uint32_t *d_vother = d_cdiff.p + ncolp, *d_csums = d_vother + ncolp;
+    HIPCHK(hipMemsetAsync(d_cdiff.p, 0, sizeof(uint32_t) * 2 * ncolp, st));
     if (int rc = dh_ensure_rc(R)) return rc;
     // the score matrices of one launch live interleaved in HBM: bound the launch to ~6 GB
     const size_t mrow = 4 * (size_t)((2 * bandmax + 16) >> 4);  // bytes of 2-bit decisions per matrix row
@@ -431,11 +441,12 @@ static int consensus_round(dh_ctx *ctx, dh_db *T, dh_db *R, const LaVec &las,
         struct { SegDescH *p; } ds;
         struct { uint8_t *p; } fm, ob;
         SCRP(22, ds, (size_t)cnt)
-        SCRP(23, fm, (size_t)cnt * (size_t)(ts + 1) * mrow + (size_t)cnt * 2 * SEG_MAX)
+        SCRP(23, fm, (size_t)cnt * (size_t)(ts + 1) * mrow + (size_t)cnt * 2 * SEG_MAX + (size_t)cnt * 2 + 16)
         ob.p = fm.p + (size_t)cnt * (size_t)(ts + 1) * mrow;
+        uint16_t *d_nops = (uint16_t *)(ob.p + (((size_t)cnt * 2 * SEG_MAX + 7) & ~(size_t)7));
         HIPCHK(hipMemcpyAsync(ds.p, segs.data() + s0, sizeof(SegDescH) * (size_t)cnt, hipMemcpyHostToDevice, st));
-        dhk_seg_vote(st, ds.p, cnt, T->view(), R->view(), R->d_rc, d_voff.p, (uint32_t *)fm.p, bandmax, wmax,
-                     ob.p, d_votes.p, d_status.p);
+        dhk_seg_vote(st, ds.p, cnt, T->view(), R->view(), R->d_rc, d_voff.p, (uint32_t *)fm.p, bandmax, wmax, ts,
+                     ob.p, d_nops, d_votes.p, d_cdiff.p, d_vother, d_status.p);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(st));
     }
@@ -446,6 +457,8 @@ static int consensus_round(dh_ctx *ctx, dh_db *T, dh_db *R, const LaVec &las,
             for (int64_t x = voff[(size_t)t]; x < voff[(size_t)t + 1] - 1; x++) col_tmpl[(size_t)x] = t;
         HIPCHK(hipMemcpyAsync(d_coltmpl.p, col_tmpl.data(), sizeof(int32_t) * col_tmpl.size(), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemsetAsync(d_cnt.p, 0, (size_t)voff.back(), st));
+        dhk_scan(st, d_cdiff.p, (int64_t)ncolp, d_csums);  // exclusive: cover of column x = [x + 1]
+        dhk_votes_finish(st, T->view(), d_voff.p, d_coltmpl.p, voff.back(), d_cdiff.p, d_vother, d_votes.p);
         dhk_emit(st, T->view(), nt, d_voff.p, d_votes.p, d_coltmpl.p, voff.back(), d_stage.p, d_cnt.p, d_ooff.p,
                  d_out.p, d_outlen.p);
         HIPCHK(hipStreamSynchronize(st));
