@@ -1630,8 +1630,11 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
     for (;;) {
         // the stepping loop proper: left only when a half needs bookkeeping (or both are done)
         while (__ballot(st != W2_EXT && st != W2_DONE) == 0ull && __ballot(st == W2_EXT) != 0ull) {
-          if (st == W2_EXT) {
+          {
             // ======================================================== one difference level
+            // (executed by every lane: a half that is done carries dead diagonals only, so the
+            // step is a no-op for it and the loop body needs no divergent region)
+            R = st == W2_EXT ? R : DEAD;
             const int32_t nL = L - 1;
             const int32_t kidx = (hl - nL) & 31;
             const int32_t k = nL + kidx;
@@ -1776,7 +1779,7 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
                 }
             }
             d++;
-            if (ended || d > o.dmax) st = W2_EXT_END;
+            st = ((ended || d > o.dmax) && st == W2_EXT) ? W2_EXT_END : st;
           }
         }
         if (st != W2_EXT && st != W2_DONE) {
