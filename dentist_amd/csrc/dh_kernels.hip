@@ -807,6 +807,8 @@ __device__ __forceinline__ int32_t nbound(int32_t x, int32_t tp_first, int32_t t
     return x >= tp_first ? (x - tp_first) / ts + 1 : 0;
 }
 
+// ballot straight from the compare (llvm.amdgcn.ballot): no bool -> int -> compare round trip
+__device__ __forceinline__ unsigned long long wballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 // ---- wave64 primitives (verified on gfx950 by scripts/dpp_probe.cpp)
 // value of lane-1 / lane+1 (rotation over the whole wave): one DPP mov each, no LDS crossbar
 __device__ __forceinline__ int32_t from_lower_lane(int32_t v)
@@ -1046,14 +1048,14 @@ __device__ ExtResult ext_wave(const uint8_t *ap_, int64_t ag, int32_t an, const 
             else
                 slide<STEP>(ap, ar, an, bp, br, bn, lim, ni, j);
         }
-        const unsigned long long amask = __ballot(alive);
+        const unsigned long long amask = wballot(alive);
         if (amask == 0ull) break;
         ncell += __popcll(amask);
         // trace nodes for the boundaries crossed in (prev_i, ni]: nbp is the first one above prev_i
         int32_t nextb = nbp;
         bool cross = alive && ni >= nextb;
         for (;;) {
-            const unsigned long long m = __ballot(cross);
+            const unsigned long long m = wballot(cross);
             if (m == 0ull) break;
             if (cross) {
                 const int32_t idx = pool_n + __popcll(m & ((1ull << lane) - 1ull));
@@ -1073,7 +1075,7 @@ __device__ ExtResult ext_wave(const uint8_t *ap_, int64_t ag, int32_t an, const 
             int32_t nextbb = nbbp;
             bool crossb = alive && j >= nextbb;
             for (;;) {
-                const unsigned long long m = __ballot(crossb);
+                const unsigned long long m = wballot(crossb);
                 if (m == 0ull) break;
                 if (crossb) {
                     const int32_t idx = pool_n + __popcll(m & ((1ull << lane) - 1ull));
@@ -1105,7 +1107,7 @@ __device__ ExtResult ext_wave(const uint8_t *ap_, int64_t ag, int32_t an, const 
         const int32_t step_best = wave_max_i32(sc);
         const int rot = nL & (LANES - 1);
         if (step_best > best_score) {
-            const unsigned long long hm = __ballot(alive && sc == step_best);
+            const unsigned long long hm = wballot(alive && sc == step_best);
             const unsigned long long hr = rot ? ((hm >> rot) | (hm << (LANES - rot))) : hm;
             const int32_t step_kidx = __ffsll((long long)hr) - 1;
             const int src = __builtin_amdgcn_readfirstlane((nL + step_kidx) & (LANES - 1));
@@ -1125,7 +1127,7 @@ __device__ ExtResult ext_wave(const uint8_t *ap_, int64_t ag, int32_t an, const 
             alive = false;
             R = DEAD;
         }
-        unsigned long long lm = __ballot(alive);
+        unsigned long long lm = wballot(alive);
         if (lm == 0ull) break;
         unsigned long long rm = rot ? ((lm >> rot) | (lm << (LANES - rot))) : lm;
         int32_t l2 = __builtin_amdgcn_readfirstlane(nL + (__ffsll((long long)rm) - 1));
@@ -1140,7 +1142,7 @@ __device__ ExtResult ext_wave(const uint8_t *ap_, int64_t ag, int32_t an, const 
                 alive = false;
                 R = DEAD;
             }
-            lm = __ballot(alive);
+            lm = wballot(alive);
             rm = rot ? ((lm >> rot) | (lm << (LANES - rot))) : lm;
             l2 = __builtin_amdgcn_readfirstlane(nL + (__ffsll((long long)rm) - 1));
             u2 = __builtin_amdgcn_readfirstlane(nL + (63 - __clzll((long long)rm)));
@@ -1278,7 +1280,7 @@ k_wave(DbView A, DbView B, const uint8_t *__restrict__ brc, const uint8_t *__res
             const int32_t sd = cd.apos - cd.bpos;
             const bool cov = lane < nd && g_aseq == cd.aseq && cd.apos >= g_ab && cd.apos < g_ae &&
                              cd.bpos >= g_bb && cd.bpos < g_be && sd >= g_lo - 64 && sd <= g_hi + 64;
-            if (__ballot(cov) != 0ull) continue;
+            if (wballot(cov) != 0ull) continue;
             const int64_t ao = A.off[cd.aseq];
             const int32_t alen = (int32_t)(A.off[cd.aseq + 1] - ao);
             const uint8_t *a = A.bases + ao;
@@ -1437,7 +1439,7 @@ enum { W2_FETCH = 0, W2_CAND = 1, W2_EXT = 2, W2_EXT_END = 3, W2_DONE = 4, W2_PO
 
 __device__ __forceinline__ uint32_t hballot(bool p, int hb)
 {
-    const uint64_t m = __ballot(p);
+    const uint64_t m = wballot(p);
     return hb ? (uint32_t)(m >> 32) : (uint32_t)m;
 }
 // value of lane `l` (constant) of my half
@@ -1629,7 +1631,7 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
 
     for (;;) {
         // the stepping loop proper: left only when a half needs bookkeeping (or both are done)
-        while (__ballot(st != W2_EXT && st != W2_DONE) == 0ull && __ballot(st == W2_EXT) != 0ull) {
+        while (wballot(st != W2_EXT && st != W2_DONE) == 0ull && wballot(st == W2_EXT) != 0ull) {
           {
             // ======================================================== one difference level
             // (executed by every lane: a half that is done carries dead diagonals only, so the
@@ -2011,7 +2013,7 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
                 }
             }
         }
-        if (__ballot(st != W2_DONE) == 0ull) break;
+        if (wballot(st != W2_DONE) == 0ull) break;
     }
     if (hl == 0) {
         atomicAdd(&counters[0], cs.cells);
