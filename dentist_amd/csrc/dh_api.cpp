@@ -12,6 +12,7 @@
 #include <numeric>
 
 #include "dh_internal.h"
+#include "dh_parallel.h"
 
 static_assert(sizeof(dh_align_opts) == sizeof(DhOpts), "opts layout");
 static_assert(sizeof(dh_la) == sizeof(DhLa), "la layout");
@@ -557,27 +558,31 @@ static bool la_less(const dh_la &p, const dh_la &q)
 // `la` must be grouped by bread (the kernels emit it that way).
 static void select_best(LaVec &la)
 {
-    for (auto &l : la) l.flags |= DH_FLAG_START | DH_FLAG_BEST;
-    size_t g0 = 0;
-    while (g0 < la.size()) {
-        size_t g1 = g0;
-        while (g1 < la.size() && la[g1].bread == la[g0].bread) g1++;
-        for (size_t x = g0; x < g1; x++) {
-            dh_la &p = la[x];
-            const int64_t ps = (int64_t)(p.aepos - p.abpos) - 2 * (int64_t)p.diffs;
-            for (size_t y = g0; y < g1; y++) {
-                if (x == y) continue;
-                const dh_la &q = la[y];
-                const int64_t qs = (int64_t)(q.aepos - q.abpos) - 2 * (int64_t)q.diffs;
-                // ties: the LA that sorts later (LAsort order) wins
-                if (qs < ps || (qs == ps && la_less(q, p))) continue;
-                if ((q.flags & DH_FLAG_COMP) != (p.flags & DH_FLAG_COMP)) continue;
-                const int32_t lo = std::max(p.bbpos, q.bbpos), hi = std::min(p.bepos, q.bepos);
-                if (hi - lo > (p.bepos - p.bbpos) / 2) p.flags &= ~DH_FLAG_BEST;
+    // groups of equal bread are independent: host threads take runs of groups
+    std::vector<size_t> gstart;
+    for (size_t i = 0; i < la.size(); i++)
+        if (i == 0 || la[i].bread != la[i - 1].bread) gstart.push_back(i);
+    gstart.push_back(la.size());
+    dh_parallel_for((int64_t)gstart.size() - 1, 2048, [&](int64_t glo, int64_t ghi) {
+        for (int64_t g = glo; g < ghi; g++) {
+            const size_t g0 = gstart[(size_t)g], g1 = gstart[(size_t)g + 1];
+            for (size_t x = g0; x < g1; x++) la[x].flags |= DH_FLAG_START | DH_FLAG_BEST;
+            for (size_t x = g0; x < g1; x++) {
+                dh_la &p = la[x];
+                const int64_t ps = (int64_t)(p.aepos - p.abpos) - 2 * (int64_t)p.diffs;
+                for (size_t y = g0; y < g1; y++) {
+                    if (x == y) continue;
+                    const dh_la &q = la[y];
+                    const int64_t qs = (int64_t)(q.aepos - q.abpos) - 2 * (int64_t)q.diffs;
+                    // ties: the LA that sorts later (LAsort order) wins
+                    if (qs < ps || (qs == ps && la_less(q, p))) continue;
+                    if ((q.flags & DH_FLAG_COMP) != (p.flags & DH_FLAG_COMP)) continue;
+                    const int32_t lo = std::max(p.bbpos, q.bbpos), hi = std::min(p.bepos, q.bepos);
+                    if (hi - lo > (p.bepos - p.bbpos) / 2) p.flags &= ~DH_FLAG_BEST;
+                }
             }
         }
-        g0 = g1;
-    }
+    });
 }
 
 // LAsort order of a B-major (bread, strand, ...) list in O(n): stable counting sort by aread
@@ -586,11 +591,42 @@ static void select_best(LaVec &la)
 static void lasort(dh_la_set *res, int32_t na)
 {
     const size_t n = res->la.size();
-    std::vector<int64_t> first((size_t)na + 2, 0);
-    for (const dh_la &l : res->la) first[(size_t)l.aread + 1]++;
-    for (int32_t a = 0; a <= na; a++) first[(size_t)a + 1] += first[(size_t)a];
     LaVec out(n);
-    for (const dh_la &l : res->la) out[(size_t)first[(size_t)l.aread]++] = l;
+    const int64_t chunk = 8192, nchunks = ((int64_t)n + chunk - 1) / chunk;
+    if (na <= 4096 && nchunks > 1) {
+        // stable counting sort by aread with one histogram per input chunk (threads scatter)
+        std::vector<int64_t> hist((size_t)nchunks * ((size_t)na + 1), 0);
+        dh_parallel_for(nchunks, 1, [&](int64_t clo, int64_t chi) {
+            for (int64_t c = clo; c < chi; c++) {
+                int64_t *h = hist.data() + (size_t)c * ((size_t)na + 1);
+                const size_t e = std::min(n, (size_t)(c + 1) * (size_t)chunk);
+                for (size_t i = (size_t)c * (size_t)chunk; i < e; i++) h[(size_t)res->la[i].aread]++;
+            }
+        });
+        int64_t run = 0;
+        for (int32_t a = 0; a <= na; a++)
+            for (int64_t c = 0; c < nchunks; c++) {
+                int64_t &h = hist[(size_t)c * ((size_t)na + 1) + (size_t)a];
+                const int64_t cnt = h;
+                h = run;
+                run += cnt;
+            }
+        dh_parallel_for(nchunks, 1, [&](int64_t clo, int64_t chi) {
+            for (int64_t c = clo; c < chi; c++) {
+                int64_t *h = hist.data() + (size_t)c * ((size_t)na + 1);
+                const size_t e = std::min(n, (size_t)(c + 1) * (size_t)chunk);
+                for (size_t i = (size_t)c * (size_t)chunk; i < e; i++) {
+                    const dh_la &l = res->la[i];
+                    out[(size_t)h[(size_t)l.aread]++] = l;
+                }
+            }
+        });
+    } else {
+        std::vector<int64_t> first((size_t)na + 2, 0);
+        for (const dh_la &l : res->la) first[(size_t)l.aread + 1]++;
+        for (int32_t a = 0; a <= na; a++) first[(size_t)a + 1] += first[(size_t)a];
+        for (const dh_la &l : res->la) out[(size_t)first[(size_t)l.aread]++] = l;
+    }
     for (size_t i = 1; i < n; i++) {
         if (!la_less(out[i], out[i - 1])) continue;
         dh_la x = out[i];

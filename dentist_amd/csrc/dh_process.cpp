@@ -14,9 +14,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <numeric>
 
 #include "dh_internal.h"
+#include "dh_parallel.h"
 
 extern "C" {
 void dhk_gather_slices(hipStream_t st, const uint8_t *src, const int64_t *src_off, const int32_t *sidx,
@@ -363,34 +365,48 @@ static int consensus_round(dh_ctx *ctx, dh_db *T, dh_db *R, const LaVec &las,
 {
     hipStream_t st = ctx->stream;
     std::vector<SegDescH, PinnedAlloc<SegDescH>> segs;  // page-locked: uploaded every round
-    {
-        size_t nsegs = 0;
-        for (size_t i = 0; i < las.size(); i++)
-            if (tmpl_of[i] >= 0 && !(las[i].flags & DH_FLAG_DISABLED)) nsegs += (size_t)(las[i].tlen / 2);
-        segs.reserve(nsegs);
-    }
     int32_t wmax = 1, bandmax = 1;
     int64_t ncell = 0;
-    for (size_t i = 0; i < las.size(); i++) {
-        const int32_t t = tmpl_of[i];
-        if (t < 0 || (las[i].flags & DH_FLAG_DISABLED)) continue;
-        const dh_la &la = las[i];
-        const uint16_t *tr = trace.data() + la.toff;
-        int32_t a0 = la.abpos, b0 = la.bbpos;
-        for (int32_t e = 0; e < la.tlen / 2; e++) {
-            int32_t a1 = (a0 / ts + 1) * ts;
-            if (a1 > la.aepos) a1 = la.aepos;
-            const int32_t b1 = b0 + tr[2 * e + 1];
-            // DP band: the trace's own path through the tile bounds the optimum (k_seg_vote)
-            const int32_t band = std::min<int32_t>((int32_t)tr[2 * e], std::max(a1 - a0, b1 - b0)) + 1;
-            SegDescH s{t, a0, a1, la.bread, b0, b1, (int32_t)(la.flags & DH_FLAG_COMP), band};
-            segs.push_back(s);
-            wmax = std::max(wmax, b1 - b0);
-            bandmax = std::max(bandmax, band);
-            ncell += (int64_t)(a1 - a0) * std::min(b1 - b0, 2 * band + 1);
-            a0 = a1;
-            b0 = b1;
-        }
+    {
+        // the selected overlaps and where their tiles go; host threads then fill the tiles
+        std::vector<size_t> sel;
+        std::vector<size_t> soff(1, 0);
+        for (size_t i = 0; i < las.size(); i++)
+            if (tmpl_of[i] >= 0 && !(las[i].flags & DH_FLAG_DISABLED)) {
+                sel.push_back(i);
+                soff.push_back(soff.back() + (size_t)(las[i].tlen / 2));
+            }
+        segs.resize(soff.back());
+        std::mutex red;
+        dh_parallel_for((int64_t)sel.size(), 256, [&](int64_t lo_, int64_t hi_) {
+            int32_t wm = 1, bm = 1;
+            int64_t nc = 0;
+            for (int64_t q = lo_; q < hi_; q++) {
+                const size_t i = sel[(size_t)q];
+                const int32_t t = tmpl_of[i];
+                const dh_la &la = las[i];
+                const uint16_t *tr = trace.data() + la.toff;
+                SegDescH *out = segs.data() + soff[(size_t)q];
+                int32_t a0 = la.abpos, b0 = la.bbpos;
+                for (int32_t e = 0; e < la.tlen / 2; e++) {
+                    int32_t a1 = (a0 / ts + 1) * ts;
+                    if (a1 > la.aepos) a1 = la.aepos;
+                    const int32_t b1 = b0 + tr[2 * e + 1];
+                    // DP band: the trace's own path through the tile bounds the optimum (k_seg_vote)
+                    const int32_t band = std::min<int32_t>((int32_t)tr[2 * e], std::max(a1 - a0, b1 - b0)) + 1;
+                    out[e] = SegDescH{t, a0, a1, la.bread, b0, b1, (int32_t)(la.flags & DH_FLAG_COMP), band};
+                    wm = std::max(wm, b1 - b0);
+                    bm = std::max(bm, band);
+                    nc += (int64_t)(a1 - a0) * std::min(b1 - b0, 2 * band + 1);
+                    a0 = a1;
+                    b0 = b1;
+                }
+            }
+            std::lock_guard<std::mutex> lk(red);
+            wmax = std::max(wmax, wm);
+            bandmax = std::max(bandmax, bm);
+            ncell += nc;
+        });
     }
     if (wmax > SEG_MAX) return dh_fail(DH_EOVERFLOW, "consensus: a trace tile is longer than 250 bases on B");
     *nseg_out = (int64_t)segs.size();
@@ -723,40 +739,49 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
         // ---- 3. the alignment funnel of computeQVs (package.d:474-516): averageErrorRate <=
         //         maxAlignmentError -> chainLocalAlignments -> isValidPileUpAlignment with
         //         allowance = trace spacing (dazzler.d:4066-4141)
-        for (dh_la &la : pl)
-            if ((int64_t)la.diffs * 1000000 > (int64_t)o.max_align_err_ppm * (la.aepos - la.abpos))
-                la.flags |= DH_FLAG_DISABLED;
         {
-            // LAs are grouped by aread; inside an aread group order by bread to get (A, B) pairs
-            size_t g0 = 0;
-            while (g0 < pl.size()) {
-                size_t g1 = g0;
-                while (g1 < pl.size() && pl[g1].aread == pl[g0].aread) g1++;
-                auto by_b = [](const dh_la &x, const dh_la &y) { return x.bread < y.bread; };
-                // the device hands over one bread-ordered run per strand: merge them (stable)
-                const auto gb = pl.begin() + (long)g0, ge = pl.begin() + (long)g1;
-                const auto mid = std::is_sorted_until(gb, ge, by_b);
-                if (mid != ge) {
-                    if (std::is_sorted(mid, ge, by_b))
-                        std::inplace_merge(gb, mid, ge, by_b);
-                    else
-                        std::stable_sort(gb, ge, by_b);
+            // the funnel of one A read is independent of the others: host threads take read groups
+            // (LAs are grouped by aread; inside a group order by bread to get (A, B) pairs)
+            std::vector<size_t> gstart;
+            for (size_t i = 0; i < pl.size(); i++)
+                if (i == 0 || pl[i].aread != pl[i - 1].aread) gstart.push_back(i);
+            gstart.push_back(pl.size());
+            const int64_t ngroups = (int64_t)gstart.size() - 1;
+            dh_parallel_for(ngroups, 64, [&](int64_t glo, int64_t ghi) {
+                for (int64_t g = glo; g < ghi; g++) {
+                    const size_t g0 = gstart[(size_t)g], g1 = gstart[(size_t)g + 1];
+                    for (size_t i = g0; i < g1; i++) {
+                        dh_la &la = pl[i];
+                        if ((int64_t)la.diffs * 1000000 > (int64_t)o.max_align_err_ppm * (la.aepos - la.abpos))
+                            la.flags |= DH_FLAG_DISABLED;
+                    }
+                    auto by_b = [](const dh_la &x, const dh_la &y) { return x.bread < y.bread; };
+                    // the device hands over one bread-ordered run per strand: merge them (stable)
+                    const auto gb = pl.begin() + (long)g0, ge = pl.begin() + (long)g1;
+                    const auto mid = std::is_sorted_until(gb, ge, by_b);
+                    if (mid != ge) {
+                        if (std::is_sorted(mid, ge, by_b))
+                            std::inplace_merge(gb, mid, ge, by_b);
+                        else
+                            std::stable_sort(gb, ge, by_b);
+                    }
+                    size_t p0 = g0;
+                    while (p0 < g1) {
+                        size_t p1 = p0;
+                        while (p1 < g1 && pl[p1].bread == pl[p0].bread) p1++;
+                        chain_pair(pl, p0, p1, tsp);
+                        p0 = p1;
+                    }
+                    for (size_t i = g0; i < g1; i++) {
+                        dh_la &la = pl[i];
+                        if (la.flags & DH_FLAG_DISABLED) continue;
+                        const int32_t alen = (int32_t)(pile->h_off[(size_t)la.aread + 1] - pile->h_off[(size_t)la.aread]);
+                        const int32_t blen = (int32_t)(pile->h_off[(size_t)la.bread + 1] - pile->h_off[(size_t)la.bread]);
+                        if (!valid_pileup_alignment(la, la.aread == la.bread, alen, blen, tsp))
+                            la.flags |= DH_FLAG_DISABLED;
+                    }
                 }
-                size_t p0 = g0;
-                while (p0 < g1) {
-                    size_t p1 = p0;
-                    while (p1 < g1 && pl[p1].bread == pl[p0].bread) p1++;
-                    chain_pair(pl, p0, p1, tsp);
-                    p0 = p1;
-                }
-                g0 = g1;
-            }
-        }
-        for (dh_la &la : pl) {
-            if (la.flags & DH_FLAG_DISABLED) continue;
-            const int32_t alen = (int32_t)(pile->h_off[(size_t)la.aread + 1] - pile->h_off[(size_t)la.aread]);
-            const int32_t blen = (int32_t)(pile->h_off[(size_t)la.bread + 1] - pile->h_off[(size_t)la.bread]);
-            if (!valid_pileup_alignment(la, la.aread == la.bread, alen, blen, tsp)) la.flags |= DH_FLAG_DISABLED;
+            });
         }
         lap("filter + chain");
         // ---- 4. tile QVs on the device (LAs are sorted by aread)
