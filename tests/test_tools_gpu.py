@@ -87,5 +87,7 @@ def test_daligner_pile_up_call(gpu_ctx, tmp_path):
     raw = open(tmp_path / "pileup-1b-2f.pileup-1b-2f.las", "rb").read()
     assert len(raw) == 12 + 40 * len(las) + 2 * len(trace)      # 16-bit traces above tspace 125
     d = gpu_ctx.db(pile)
-    exp = gpu_ctx.align_db(d, d, dentist_amd.default_align_opts(tspace=126, skip_self=1))
+    # one DB against itself = symmetric mode: each pair aligned once, both records written
+    exp = gpu_ctx.align_db(d, d, dentist_amd.default_align_opts(tspace=126, skip_self=2, max_la=64, max_cand=128))
+    assert len(las) % 2 == 0 and len(las) > 0
     assert_same_las((las, trace), exp)

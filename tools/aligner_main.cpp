@@ -168,7 +168,13 @@ int main(int argc, char **argv)
         const bool same = las_name_part(dbs[bi]) == A.name;
         OpenDb B = same ? A : open_db(ctx, dbs[bi], tracks);
         dh_align_opts oo = o;
-        oo.skip_self = (same && !flagI) ? 1 : 0;
+        // one DB against itself: every unordered pair once, both records written (daligner's own
+        // behaviour); -I also aligns a read against itself, which needs the plain all-vs-all
+        oo.skip_self = (same && !flagI) ? 2 : 0;
+        if (oo.skip_self == 2) {
+            oo.max_la = std::max(oo.max_la, 64);
+            oo.max_cand = std::max(oo.max_cand, 128);
+        }
         dh_la_set *ab = nullptr;
         CHK(dh_align_db(ctx, A.dev, B.dev, &oo, mapper ? 1 : 0, &ab));
         write_las(A.name + "." + B.name + ".las", ab, dh_dazz_first_id(A.dz), dh_dazz_first_id(B.dz), o.tspace);
