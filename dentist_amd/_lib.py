@@ -73,7 +73,7 @@ SYMBOLS = [
     "dh_get_process_stats", "dh_dazz_create_dam", "dh_dazz_create_db", "dh_dazz_split", "dh_dazz_open",
     "dh_dazz_close", "dh_dazz_nreads", "dh_dazz_first_id", "dh_dazz_bases", "dh_dazz_offsets",
     "dh_dazz_origin", "dh_dazz_fpulse", "dh_dazz_header", "dh_dazz_read_mask", "dh_dazz_write_mask",
-    "dh_db_set_mask", "dh_output_fasta",
+    "dh_db_set_mask", "dh_output_fasta", "dh_tile_qv", "dh_consensus",
 ]
 
 _LIB = None
@@ -154,6 +154,8 @@ def lib():
     L.dh_dazz_read_mask.restype = i64
     L.dh_dazz_write_mask.argtypes = [ctypes.c_char_p, ctypes.c_char_p, i32, vp, vp]
     L.dh_db_set_mask.argtypes = [vp, vp, vp]
+    L.dh_tile_qv.argtypes = [vp, vp, vp, i64, vp, i32, i32, vp, i32]
+    L.dh_consensus.argtypes = [vp, vp, vp, i64, vp, i32, i32, i32, vp, i64, ctypes.POINTER(i64)]
     L.dh_output_fasta.argtypes = [ctypes.c_char_p, ctypes.c_char_p, vp, vp, i32, vp, ctypes.POINTER(ctypes.c_char_p),
                                   vp, vp, i32, vp, i32, i32]
     L.dh_dazz_header.restype = ctypes.c_char_p
@@ -393,6 +395,33 @@ def output_fasta(fasta_path, contigs, scaffold_of, headers, gap_len, rec, bases,
                                  co.ctypes.data, len(co) - 1, so.ctypes.data, hs,
                                  gl.ctypes.data if gl is not None else None, r.ctypes.data, len(r),
                                  b.ctypes.data if len(b) else None, line_width, int(bool(highlight))))
+
+
+def tile_qv(ctx, db, las, trace, tspace, cov, maxtiles):
+    """DAScover + DASqv: intrinsic QV per (read, tile) of a pile-up DB; las grouped by aread."""
+    arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
+    tr = np.ascontiguousarray(trace, dtype=np.uint16)
+    qv = np.zeros((lib().dh_db_nreads(db._h), maxtiles), dtype=np.uint8)
+    _check(lib().dh_tile_qv(ctx._h, db._h, arr.ctypes.data, len(arr), tr.ctypes.data, tspace, cov, qv.ctypes.data,
+                            maxtiles))
+    return qv
+
+
+def consensus(ctx, db, las, trace, tspace, ref_read, rounds=1):
+    """computeintrinsicqv + daccord: consensus of read ref_read of the DB from its overlaps."""
+    arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
+    tr = np.ascontiguousarray(trace, dtype=np.uint16)
+    cap = 1 << 20
+    while True:
+        out = np.zeros(cap, dtype=np.uint8)
+        n = ctypes.c_int64(0)
+        rc = lib().dh_consensus(ctx._h, db._h, arr.ctypes.data, len(arr), tr.ctypes.data, tspace, ref_read, rounds,
+                                out.ctypes.data, cap, ctypes.byref(n))
+        if rc != 0 and n.value > cap:
+            cap = int(n.value)
+            continue
+        _check(rc)
+        return out[:n.value].copy()
 
 
 def process_stats(ctx):

@@ -529,6 +529,119 @@ struct SetGuard {
     }
 };
 
+// ------------------------------------------------------------------------------------ stage entry points
+
+static int64_t trace_extent(const dh_la *las, int64_t n)
+{
+    int64_t m = 0;
+    for (int64_t i = 0; i < n; i++) m = std::max<int64_t>(m, las[i].toff + las[i].tlen);
+    return m;
+}
+
+// DAScover + DASqv for a pile-up DB (dazzler.d:3782-3792, 6142-6156): intrinsic QV of every
+// tspace tile of every read from the overlaps of that read (las grouped by aread, ascending).
+extern "C" int dh_tile_qv(dh_ctx *ctx, dh_db *db, const dh_la *las, int64_t n, const uint16_t *trace,
+                          int32_t tspace, int32_t cov, uint8_t *qv, int32_t maxtiles)
+{
+    if (!ctx || !db || !qv || (n > 0 && (!las || !trace)) || tspace < 1 || maxtiles < 1 || cov < 1)
+        return dh_fail(DH_EINVAL, "dh_tile_qv: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int32_t npr = db->n;
+    std::vector<int32_t> la_first((size_t)npr + 1, 0);
+    for (int64_t i = 0; i < n; i++) {
+        if (las[i].aread < 0 || las[i].aread >= npr || (i > 0 && las[i].aread < las[i - 1].aread))
+            return dh_fail(DH_EINVAL, "dh_tile_qv: overlaps must be grouped by aread (ascending) and inside the DB");
+        la_first[(size_t)las[i].aread + 1]++;
+    }
+    for (int32_t r = 0; r < npr; r++) la_first[(size_t)r + 1] += la_first[(size_t)r];
+    const int64_t nt = trace_extent(las, n);
+    DevBuf<DhLa> d_las;
+    DevBuf<uint16_t> d_tr;
+    DevBuf<int32_t> d_first, d_cov;
+    DevBuf<uint8_t> d_qv;
+    std::vector<int32_t> cov_of((size_t)npr, cov);
+    HIPCHK(d_las.alloc((size_t)n));
+    HIPCHK(d_tr.alloc((size_t)nt));
+    HIPCHK(d_first.alloc(la_first.size()));
+    HIPCHK(d_cov.alloc(cov_of.size()));
+    HIPCHK(d_qv.alloc((size_t)npr * maxtiles));
+    if (n > 0) {
+        HIPCHK(hipMemcpyAsync(d_las.p, las, sizeof(dh_la) * (size_t)n, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_tr.p, trace, sizeof(uint16_t) * (size_t)nt, hipMemcpyHostToDevice, st));
+    }
+    HIPCHK(hipMemcpyAsync(d_first.p, la_first.data(), sizeof(int32_t) * la_first.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_cov.p, cov_of.data(), sizeof(int32_t) * cov_of.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(d_qv.p, 255, (size_t)npr * maxtiles, st));
+    dhk_tile_qv(st, d_las.p, d_tr.p, d_first.p, db->d_off, npr, tspace, d_cov.p, maxtiles, d_qv.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(qv, d_qv.p, (size_t)npr * maxtiles, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return DH_OK;
+}
+
+// computeintrinsicqv + daccord -f -I<i>,<i> (dazzler.d:4213-4255, 6172-6231): consensus of read
+// ref_read of the DB from its overlaps (the records with aread == ref_read).  rounds > 1 re-aligns
+// every read of the DB to the consensus and votes again, as dh_process_pileups does.
+extern "C" int dh_consensus(dh_ctx *ctx, dh_db *db, const dh_la *las, int64_t n, const uint16_t *trace,
+                            int32_t tspace, int32_t ref_read, int32_t rounds, uint8_t *out, int64_t cap,
+                            int64_t *out_len)
+{
+    if (!ctx || !db || !out || !out_len || (n > 0 && (!las || !trace)) || ref_read < 0 || ref_read >= db->n ||
+        rounds < 1 || rounds > 8 || tspace < 16 || tspace > SEG_MAX)
+        return dh_fail(DH_EINVAL, "dh_consensus: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DbGuard dbg;
+    SetGuard sg;
+    LaVec pl(las, las + n);
+    const int64_t nt = trace_extent(las, n);
+    TraceVec tr(trace, trace + nt);
+    dh_db *T = nullptr;
+    const int32_t rlen = (int32_t)(db->h_off[(size_t)ref_read + 1] - db->h_off[(size_t)ref_read]);
+    const int32_t grp = db->h_group.empty() ? 0 : db->h_group[(size_t)ref_read];
+    if (int rc = dh_db_from_slices(ctx, db, {ref_read}, {0}, {rlen}, {grp}, &T)) return rc;
+    dbg.dbs.push_back(T);
+    {
+        std::vector<int32_t> tmpl_of(pl.size(), -1);
+        for (size_t i = 0; i < pl.size(); i++)
+            if (pl[i].aread == ref_read) tmpl_of[i] = 0;
+        dh_db *nT = nullptr;
+        int64_t nseg = 0, ncell = 0;
+        if (int rc = consensus_round(ctx, T, db, pl, tr, tmpl_of, tspace, &nT, &nseg, &ncell)) return rc;
+        dbg.dbs.push_back(nT);
+        T = nT;
+    }
+    for (int32_t round = 1; round < rounds; round++) {
+        dh_align_opts ro;
+        dh_default_align_opts(&ro);
+        ro.tspace = tspace;
+        ro.min_len = 500;
+        ro.max_la = 4;
+        ro.max_cand = 32;
+        dh_la_set *rset = nullptr;
+        if (int rc = dh_align_db_ex(ctx, T, db, &ro, 0, 0, &rset)) return rc;
+        sg.sets.push_back(rset);
+        std::vector<int32_t> tmpl_of(rset->la.size(), 0);
+        const int32_t alen = (int32_t)(T->h_off[1] - T->h_off[0]);
+        for (size_t i = 0; i < rset->la.size(); i++) {
+            dh_la &la = rset->la[i];
+            const int32_t blen = (int32_t)(db->h_off[(size_t)la.bread + 1] - db->h_off[(size_t)la.bread]);
+            if (!valid_pileup_alignment(la, false, alen, blen, tspace)) la.flags |= DH_FLAG_DISABLED;
+        }
+        dh_db *nT = nullptr;
+        int64_t nseg = 0, ncell = 0;
+        if (int rc = consensus_round(ctx, T, db, rset->la, rset->trace, tmpl_of, tspace, &nT, &nseg, &ncell)) return rc;
+        dbg.dbs.push_back(nT);
+        T = nT;
+    }
+    *out_len = T->total;
+    if (T->total > cap) return dh_fail(DH_EOVERFLOW, "dh_consensus: output buffer too small");
+    if (T->total > 0) HIPCHK(hipMemcpyAsync(out, T->d_bases, (size_t)T->total, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return DH_OK;
+}
+
 extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, const dh_la *las, int64_t n,
                                   const uint16_t *trace, const dh_pileups *piles,
                                   const dh_process_opts *opts, dh_insertions **out)

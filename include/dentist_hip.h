@@ -223,6 +223,18 @@ int64_t dh_insertions_bases_len(const dh_insertions *r);
 int dh_get_process_stats(dh_ctx *ctx, float *ms7, int64_t *counters3);
 
 
+/* ---- stage-level entry points (the fused dh_process_pileups runs the same code):
+ *  dh_tile_qv    DAScover + DASqv -c<cov> (dazzler.d:3782-3792, 6142-6156): qv[r * maxtiles + t] in
+ *                [0, 50] for tile t of read r of the pile-up DB, 255 behind the last tile; las must be
+ *                grouped by aread (ascending), traces at tspace.
+ *  dh_consensus  computeintrinsicqv + daccord -f -I<i>,<i> (dazzler.d:4213-4255, 6172-6231): consensus
+ *                of read ref_read from the overlaps with aread == ref_read; rounds > 1 re-aligns the
+ *                reads of the DB to the consensus and votes again.  out: caller's buffer of cap bases. */
+int dh_tile_qv(dh_ctx *ctx, dh_db *db, const dh_la *las, int64_t n, const uint16_t *trace, int32_t tspace,
+               int32_t cov, uint8_t *qv, int32_t maxtiles);
+int dh_consensus(dh_ctx *ctx, dh_db *db, const dh_la *las, int64_t n, const uint16_t *trace, int32_t tspace,
+                 int32_t ref_read, int32_t rounds, uint8_t *out, int64_t cap, int64_t *out_len);
+
 /* ---- gap-closed assembly writer (host only): the linear-scaffold subset of `dentist output`
  *      (source/dentist/commands/output.d:743-925): header "<id>\tscaffold-<first contig id>", contig
  *      slices lower case, insertions upper case (highlight != 0), unclosed gaps as 'n' runs, lines
