@@ -1624,7 +1624,7 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
         best_nb = tp_first + nb0 * ts;
         best_headb = hb0;
         best_nbb = tpb_first + nbb0 * ts;
-        ncell = 1;
+        ncell = hl == 0 ? 1u : 0u;
         d = 1;
         st = d <= o.dmax ? W2_EXT : W2_EXT_END;
     };
@@ -1680,10 +1680,12 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
             bool alive = ni >= 0;
             int32_t j = ni - k;
             if (alive) slide2<PK>(pa, ra, pb, rb, lim, ni, j);
-            const uint32_t amask = hballot(alive, hb);
-            bool ended = amask == 0u;
-            if (!ended) {
-                ncell += __popc(amask);
+            // live diagonals of this level are counted per lane and summed when the extension ends;
+            // a level without any falls through: nothing crosses, nothing beats the best, and the
+            // window test below ends the extension
+            ncell += alive ? 1u : 0u;
+            bool ended = false;
+            {
                 // trace nodes for the boundaries crossed in (prev_i, ni]
                 int32_t nextb = nbp;
                 bool cross = alive && ni >= nextb;
@@ -1863,7 +1865,12 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
                         st = W2_FETCH;
                     }
                 } else if (st == W2_EXT_END) {
-                    cs.cells += ncell;
+                    {
+                        // sum of the per-lane counts over the half
+                        uint32_t tot = ncell;
+                        for (int off = 16; off > 0; off >>= 1) tot += (uint32_t)__shfl_xor((int)tot, off, LANES);
+                        cs.cells += tot;
+                    }
                     const int32_t r_nb = (best_nb - tp_first) / ts, r_nbb = SYM ? (best_nbb - tpb_first) / ts : 0;
                     if (dir == 0 && !err) {
                         cs.fw_i = best_i;
