@@ -199,6 +199,15 @@ def main():
                          "wave_cells_per_s": cum["wave_cells"] / (wave_ms * 1e-3),
                          "note": "integer VALU/latency-bound by nature (SURVEY 7d); cell updates/s is the "
                                  "honest secondary"},
+            # second kernel of the step: the seed filter of the mapping launch is bound by random
+            # 64-byte directory lines: per read base and strand 1 B of sequence
+            # + one 64 B line per sampled k-mer
+            "roofline_seed": (lambda ms, b: {"bound": "hbm", "kernel": "k_seed (mapping launch)",
+                                            "achieved": b / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                            "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                            "algorithmic_bytes_per_launch": b, "avg_launch_ms": ms,
+                                            "note": "random 64 B accesses: ~45 % of peak is the practical ceiling"})(
+                mean(lambda r: r["ast"].ms_seed), 2.0 * read_bp * (1.0 + 64.0 / max(1, args.kmer_mod))),
             "stages_ms": {"map_wall": mean(lambda r: r["t_map"]) * 1e3,
                           "map_index": mean(lambda r: r["ast"].ms_index),
                           "map_seed": mean(lambda r: r["ast"].ms_seed),
