@@ -1631,7 +1631,7 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
 
     for (;;) {
         // the stepping loop proper: left only when a half needs bookkeeping (or both are done)
-        while (wballot(st != W2_EXT && st != W2_DONE) == 0ull && wballot(st == W2_EXT) != 0ull) {
+        if (wballot(st != W2_EXT && st != W2_DONE) == 0ull && wballot(st == W2_EXT) != 0ull) do {
           {
             // ======================================================== one difference level
             // (executed by every lane: a half that is done carries dead diagonals only, so the
@@ -1785,7 +1785,7 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
             d++;
             st = ((ended || d > o.dmax) && st == W2_EXT) ? W2_EXT_END : st;
           }
-        }
+        } while (wballot(st == W2_EXT_END) == 0ull);  // (no half can run out of work inside the loop)
         if (st != W2_EXT && st != W2_DONE) {
             // ======================================================== bookkeeping of this half
             while (st != W2_EXT && st != W2_DONE) {
