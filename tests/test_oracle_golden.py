@@ -188,3 +188,18 @@ def test_oracle_mapping_against_truth():
     assert len(mapped) == w.reads.n
     err = las["diffs"].sum() / (las["aepos"] - las["abpos"]).sum()
     assert 0.11 < err < 0.15
+
+
+def test_consensus_known_answer_of_the_reference():
+    """dazzler.d:4257-4299 (unittest of getConsensus): three 1050 bp reads, two of them with one
+    substitution each; the consensus of the pile of read 1 must equal the clean third read."""
+    from dentist_amd import sim
+    d = json.load(open(os.path.join(GOLD, "consensus_3reads.json")))
+    db = sim.SeqDb.from_list([sim.encode(r["sequence"].lower()) for r in d["reads"]])
+    o = oz.default_opts(skip_self=2, tspace=100, min_len=d["daligner_min_alignment_length"], max_la=64, max_cand=128,
+                        width=30)
+    las, trace, _ = oz.align_db(db, db, o, nthreads=2)
+    assert len(las) == 6 and all(l["aepos"] - l["abpos"] == 1050 for l in las)
+    for ref in range(3):
+        cons = oz.consensus(db.seq(ref), db, las, trace, ref, 100)
+        assert sim.decode(cons) == d["expected_consensus"].lower()

@@ -61,3 +61,20 @@ def test_stage_entry_points_reject_bad_input(gpu_ctx):
         dentist_amd.tile_qv(gpu_ctx, d, las[::-1].copy(), trace, TS, 4, 40)  # not grouped by aread
     with pytest.raises(RuntimeError):
         dentist_amd.consensus(gpu_ctx, d, las, trace, TS, reads.n + 3)
+
+
+def test_consensus_known_answer_of_the_reference(gpu_ctx):
+    """dazzler.d:4257-4299: the HIP consensus of the reference's own three-read pile equals the
+    clean read (tests/golden/consensus_3reads.json, transcribed by scripts/make_golden_consensus3.py)."""
+    import json
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "consensus_3reads.json")))
+    db = sim.SeqDb.from_list([sim.encode(r["sequence"].lower()) for r in d["reads"]])
+    dd = gpu_ctx.db(db)
+    o = dentist_amd.default_align_opts(skip_self=2, tspace=100, min_len=d["daligner_min_alignment_length"], max_la=64,
+                                       max_cand=128)
+    las, trace = gpu_ctx.align_db(dd, dd, o)
+    assert len(las) == 6
+    for ref in range(3):
+        for rounds in (1, 3):
+            cons = dentist_amd.consensus(gpu_ctx, dd, las, trace, 100, ref, rounds=rounds)
+            assert sim.decode(cons) == d["expected_consensus"].lower()
