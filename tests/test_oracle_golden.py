@@ -203,3 +203,19 @@ def test_consensus_known_answer_of_the_reference():
     for ref in range(3):
         cons = oz.consensus(db.seq(ref), db, las, trace, ref, 100)
         assert sim.decode(cons) == d["expected_consensus"].lower()
+
+
+def test_cropping_slice_golden():
+    """cropper.d:552-646: the read interval kept by getCroppingSlice for a crop point on the contig
+    (complement + seed back: [0, |read| - b), forward + seed front: [0, b) with b = the read
+    coordinate of the trace point)."""
+    from oracle import process as pr
+    g = json.load(open(os.path.join(GOLD, "crop_cases.json")))
+    for c in g["cases"]:
+        tr = np.asarray(c["tp"], dtype=np.uint16).reshape(-1)
+        la = {"abpos": c["abpos"], "aepos": c["aepos"], "bbpos": c["bbpos"]}
+        assert int(tr[1::2].sum()) == c["bepos"] - c["bbpos"] and int(tr[0::2].sum()) == c["diffs"]
+        for apos, (b0, b1) in c["crops"]:
+            _, b = pr.translate_floor(la, tr, apos, 100)
+            got = (0, c["read_len"] - b) if c["complement"] else (0, b)
+            assert got == (b0, b1), (apos, got)
