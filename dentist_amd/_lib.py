@@ -73,7 +73,7 @@ SYMBOLS = [
     "dh_get_process_stats", "dh_dazz_create_dam", "dh_dazz_create_db", "dh_dazz_split", "dh_dazz_open",
     "dh_dazz_close", "dh_dazz_nreads", "dh_dazz_first_id", "dh_dazz_bases", "dh_dazz_offsets",
     "dh_dazz_origin", "dh_dazz_fpulse", "dh_dazz_header", "dh_dazz_read_mask", "dh_dazz_write_mask",
-    "dh_db_set_mask", "dh_output_fasta", "dh_tile_qv", "dh_consensus",
+    "dh_db_set_mask", "dh_output_fasta", "dh_tile_qv", "dh_consensus", "dh_las_merge",
 ]
 
 _LIB = None
@@ -154,6 +154,7 @@ def lib():
     L.dh_dazz_read_mask.restype = i64
     L.dh_dazz_write_mask.argtypes = [ctypes.c_char_p, ctypes.c_char_p, i32, vp, vp]
     L.dh_db_set_mask.argtypes = [vp, vp, vp]
+    L.dh_las_merge.argtypes = [ctypes.POINTER(ctypes.c_char_p), i32, ctypes.c_char_p]
     L.dh_tile_qv.argtypes = [vp, vp, vp, i64, vp, i32, i32, vp, i32]
     L.dh_consensus.argtypes = [vp, vp, vp, i64, vp, i32, i32, i32, vp, i64, ctypes.POINTER(i64)]
     L.dh_output_fasta.argtypes = [ctypes.c_char_p, ctypes.c_char_p, vp, vp, i32, vp, ctypes.POINTER(ctypes.c_char_p),
@@ -395,6 +396,12 @@ def output_fasta(fasta_path, contigs, scaffold_of, headers, gap_len, rec, bases,
                                  co.ctypes.data, len(co) - 1, so.ctypes.data, hs,
                                  gl.ctypes.data if gl is not None else None, r.ctypes.data, len(r),
                                  b.ctypes.data if len(b) else None, line_width, int(bool(highlight))))
+
+
+def las_merge(paths, out_path):
+    """LAmerge: several .las files (same trace spacing) into one, LAsort order (host only)."""
+    arr = (ctypes.c_char_p * len(paths))(*[p.encode() for p in paths])
+    _check(lib().dh_las_merge(arr, len(paths), out_path.encode()))
 
 
 def tile_qv(ctx, db, las, trace, tspace, cov, maxtiles):

@@ -1050,3 +1050,45 @@ extern "C" int dh_las_read(const char *path, dh_la_set **out)
     *out = s;
     return DH_OK;
 }
+
+// LAmerge (workflow rule snakemake/Snakefile:1173-1185): the alignment files of the read blocks
+// (one per GPU / per block) merged into one file in LAsort order.  Host only.
+extern "C" int dh_las_merge(const char *const *paths, int32_t npaths, const char *out_path)
+{
+    if (!paths || npaths < 1 || !out_path) return fail(DH_EINVAL, "dh_las_merge: bad argument");
+    std::vector<dh_la_set *> sets((size_t)npaths, nullptr);
+    struct Guard {
+        std::vector<dh_la_set *> &s;
+        ~Guard()
+        {
+            for (dh_la_set *x : s) dh_la_set_destroy(x);
+        }
+    } guard{sets};
+    int32_t tspace = -1;
+    size_t total = 0;
+    for (int32_t i = 0; i < npaths; i++) {
+        if (int rc = dh_las_read(paths[i], &sets[(size_t)i])) return rc;
+        if (tspace >= 0 && sets[(size_t)i]->tspace != tspace && !sets[(size_t)i]->la.empty())
+            return fail(DH_EINVAL, "dh_las_merge: files with different trace spacing");
+        if (!sets[(size_t)i]->la.empty() || tspace < 0) tspace = sets[(size_t)i]->tspace;
+        total += sets[(size_t)i]->la.size();
+    }
+    // records of all files with the index of their file; traces stay in their sets
+    std::vector<std::pair<dh_la, int32_t>> all;
+    all.reserve(total);
+    for (int32_t i = 0; i < npaths; i++)
+        for (const dh_la &l : sets[(size_t)i]->la) all.emplace_back(l, i);
+    std::stable_sort(all.begin(), all.end(),
+                     [](const std::pair<dh_la, int32_t> &x, const std::pair<dh_la, int32_t> &y) { return la_less(x.first, y.first); });
+    std::vector<dh_la> las(all.size());
+    std::vector<uint16_t> trace;
+    for (size_t i = 0; i < all.size(); i++) {
+        dh_la l = all[i].first;
+        const uint16_t *t = sets[(size_t)all[i].second]->trace.data() + l.toff;
+        l.toff = (int64_t)trace.size();
+        trace.insert(trace.end(), t, t + l.tlen);
+        las[i] = l;
+    }
+    static const uint16_t none = 0;
+    return dh_las_write(out_path, las.data(), (int64_t)las.size(), trace.empty() ? &none : trace.data(), tspace);
+}

@@ -142,6 +142,9 @@ int dh_align_db(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, int3
 int dh_las_write(const char *path, const dh_la *las, int64_t n, const uint16_t *trace,
                  int32_t tspace);
 int dh_las_read(const char *path, dh_la_set **out);
+/* LAmerge (snakemake/Snakefile:1173-1185): the .las files of read blocks (one per GPU) merged into one
+ * file in LAsort order; all inputs must share the trace spacing.  Host only. */
+int dh_las_merge(const char *const *paths, int32_t npaths, const char *out_path);
 
 
 /* ---- pile-ups: which reads span which gap.  Host-side stand-in for the part of `dentist collect`

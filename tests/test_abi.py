@@ -93,3 +93,40 @@ def test_output_fasta_writer_unclosed_gaps_and_wrapping(tmp_path):
     want = sim.decode(c[0][:110]) + ins + sim.decode(c[1][4:]) + "n" * 17 + sim.decode(c[2])
     assert s0 == want
     assert "".join(txt[1].split("\n")[1:]) == sim.decode(c[3])
+
+
+def test_las_merge_of_block_files(tmp_path):
+    """LAmerge (Snakefile:1173-1185): per-block .las files merge into one file in LAsort order,
+    traces intact (host only)."""
+    from dentist_amd._lib import LA_DTYPE
+    rng = np.random.default_rng(3)
+
+    def block(breads):
+        las = np.zeros(len(breads), dtype=LA_DTYPE)
+        tr = []
+        for i, b in enumerate(breads):
+            n = int(rng.integers(1, 5))
+            las[i]["aread"], las[i]["bread"] = int(rng.integers(0, 4)), b
+            las[i]["abpos"], las[i]["aepos"] = 100 * i, 100 * i + 100 * n
+            las[i]["bbpos"], las[i]["bepos"] = 0, 100 * n
+            las[i]["tlen"], las[i]["toff"] = 2 * n, len(tr)
+            tr += [int(x) for x in rng.integers(0, 200, 2 * n)]
+            las[i]["diffs"] = sum(tr[-2 * n::2])
+        order = np.lexsort((las["abpos"], las["bread"], las["aread"]))
+        return las[order], np.asarray(tr, dtype=np.uint16)
+
+    files, every = [], []
+    for k, br in enumerate(([0, 1, 2, 3], [4, 5], [6, 7, 8])):
+        las, tr = block(br)
+        p = str(tmp_path / f"ref.reads.{k + 1}.las")
+        dentist_amd.las_write(p, las, tr, 100)
+        files.append(p)
+        every += [(int(l["aread"]), int(l["bread"]), tr[l["toff"]:l["toff"] + l["tlen"]].tolist()) for l in las]
+    out = str(tmp_path / "ref.reads.las")
+    dentist_amd.las_merge(files, out)
+    las, tr, ts = dentist_amd.las_read(out)
+    assert ts == 100 and len(las) == len(every)
+    keys = [(int(l["aread"]), int(l["bread"])) for l in las]
+    assert keys == sorted(keys)
+    got = sorted((int(l["aread"]), int(l["bread"]), tr[l["toff"]:l["toff"] + l["tlen"]].tolist()) for l in las)
+    assert got == sorted(every)
