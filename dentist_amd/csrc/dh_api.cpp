@@ -890,6 +890,7 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
             if (totals[1] > 0)
                 HIPCHK(hipMemcpyAsync(res->trace.data() + t0, d_trout, sizeof(uint16_t) * (size_t)totals[1],
                                       hipMemcpyDeviceToHost, st));
+            res->d_trace = (t0 == 0 && item0 == 0 && ni == nitems_total) ? d_trout : nullptr;
         }
         HIPCHK(hipEventRecord(ctx->ev[5], st));
         HIPCHK(hipStreamSynchronize(st));

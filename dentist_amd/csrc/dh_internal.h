@@ -133,6 +133,9 @@ struct dh_la_set {
     LaVec la;
     TraceVec trace;
     int32_t tspace = 0;
+    // device copy of `trace` left behind by dh_align_db_ex (scratch arena): valid until the next
+    // alignment call on the same context, nullptr when the result came in several chunks
+    const uint16_t *d_trace = nullptr;
 };
 
 template <typename T>

@@ -911,12 +911,17 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
             DevBuf<int32_t> d_first;
             DevBuf<uint8_t> d_qv;
             HIPCHK(d_las.alloc(pl.size()));
-            HIPCHK(d_tr.alloc(pset->trace.size()));
             HIPCHK(d_first.alloc(la_first.size()));
             HIPCHK(d_qv.alloc(qv.size()));
             HIPCHK(hipMemcpyAsync(d_las.p, pl.data(), sizeof(dh_la) * pl.size(), hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(d_tr.p, pset->trace.data(), sizeof(uint16_t) * pset->trace.size(),
-                                  hipMemcpyHostToDevice, st));
+            // the traces of the pile-up alignment are still on the device (no alignment call since)
+            const uint16_t *d_trp = pset->d_trace;
+            if (!d_trp) {
+                HIPCHK(d_tr.alloc(pset->trace.size()));
+                HIPCHK(hipMemcpyAsync(d_tr.p, pset->trace.data(), sizeof(uint16_t) * pset->trace.size(),
+                                      hipMemcpyHostToDevice, st));
+                d_trp = d_tr.p;
+            }
             HIPCHK(hipMemcpyAsync(d_first.p, la_first.data(), sizeof(int32_t) * la_first.size(),
                                   hipMemcpyHostToDevice, st));
             HIPCHK(hipMemsetAsync(d_qv.p, 255, qv.size(), st));
@@ -928,7 +933,7 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
             DevBuf<int32_t> d_cov;
             HIPCHK(d_cov.alloc(cov_of.size()));
             HIPCHK(hipMemcpyAsync(d_cov.p, cov_of.data(), sizeof(int32_t) * cov_of.size(), hipMemcpyHostToDevice, st));
-            dhk_tile_qv(st, d_las.p, d_tr.p, d_first.p, pile->d_off, npr, tsp, d_cov.p, maxtiles, d_qv.p);
+            dhk_tile_qv(st, d_las.p, d_trp, d_first.p, pile->d_off, npr, tsp, d_cov.p, maxtiles, d_qv.p);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(qv.data(), d_qv.p, qv.size(), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
