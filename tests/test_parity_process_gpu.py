@@ -112,3 +112,44 @@ def test_process_reference_fixture_gap_is_closed_perfectly(gpu_ctx, tmp_path):
         assert hashlib.md5(data).hexdigest() == "c3836dc00a3f5e1e2aa8f2a802da4d67"
     b = open(bed).read().split("\t")
     assert b[0] == header[1:] and int(b[1]) == r["left_aepos"] and int(b[2]) == r["left_aepos"] + len(ins)
+
+
+def test_config1_full_size_properties(gpu_ctx):
+    """BASELINE config[1] (10 Mb assembly, 100 gaps, 100 k x 10 kb reads at 13 %): size-independent
+    properties of the whole hot path -- every mapped read lies where the simulator put it, trace
+    invariants, all gaps closed with a consensus within 0.5 % of the truth, idempotence."""
+    w = sim.Workload(10_000_000, 100, 100_000, 10_000, seed=20260929)
+    A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
+    mo = dentist_amd.default_align_opts(kmer_mod=4)
+    po = dentist_amd.default_process_opts()
+    las, trace = gpu_ctx.align_db(A, B, mo, select_best=True)
+    from helpers import check_trace_invariants
+    check_trace_invariants(las[:: max(1, len(las) // 3000)], trace, 100)
+    assert len(set(las["bread"].tolist())) >= 0.995 * w.reads.n
+    s, e = w.read_truth[las["bread"], 0], w.read_truth[las["bread"], 1]
+    cs = w.contig_start[las["aread"]]
+    ok = ((las["flags"] & 1) == w.read_truth[las["bread"], 2]) & (cs + las["abpos"] >= s - 80) & (cs + las["aepos"] <= e + 80)
+    assert ok.mean() > 0.999
+    piles = dentist_amd.Pileups(las, w.contigs.off, po)
+    assert len(piles) == 100
+    rec, bases = dentist_amd.process_pileups(gpu_ctx, A, B, las, trace, piles, po)
+    closed = rec[rec["status"] == 0]
+    assert len(closed) >= 99
+    edits = total = 0
+    for r in closed:
+        g = int(r["contig_left"])
+        cons = bases[r["cons_off"]:r["cons_off"] + r["cons_len"]]
+        cseq = sim.revcomp(cons) if r["comp"] else cons
+        ins = cseq[r["ins_begin"]:r["ins_end"]]
+        truth = w.truth[w.contig_start[g] + r["left_aepos"]: w.gap_end[g] + r["right_abpos"]]
+        ed, _ = oz.nw(truth, ins)
+        edits += ed
+        total += len(truth)
+    assert edits <= 0.005 * total, (edits, total)
+    # a second pass with every cache dropped gives the same bits
+    A.drop_cache()
+    B.drop_cache()
+    las2, trace2 = gpu_ctx.align_db(A, B, mo, select_best=True)
+    assert_same_las((las2, trace2), (las, trace))
+    rec2, bases2 = dentist_amd.process_pileups(gpu_ctx, A, B, las2, trace2, dentist_amd.Pileups(las2, w.contigs.off, po), po)
+    assert np.array_equal(rec2, rec) and np.array_equal(bases2, bases)
