@@ -722,9 +722,9 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
     const int32_t trmax = 2 * (2 * nbmax + 2);
     const int32_t poolcap = 96 * nbmax;
     // resident alignment slots: one per wavefront of k_wave (<= 64 VGPRs -> 8 waves/SIMD), one per
-    // 32-lane half of k_wave2 (two per wavefront, 5 waves/SIMD)
+    // 32-lane half of k_wave2 (two per wavefront, 6 waves/SIMD)
     int32_t slots_per_cu = 32;
-    if (o.width <= 30) slots_per_cu = 40;  // k_wave2: 96 VGPRs, 5 waves/SIMD, two slots per wavefront
+    if (o.width <= 30) slots_per_cu = 48;  // k_wave2: 80 VGPRs, 6 waves/SIMD, two slots per wavefront
     if (const char *e = getenv("DH_WAVE_SLOTS_PER_CU")) slots_per_cu = std::max(2, atoi(e)) & ~1;
     const int64_t nitems_total = 2ll * B->n;
     const int32_t nslots = (int32_t)std::min<int64_t>((int64_t)ctx->ncu * slots_per_cu,

@@ -1513,7 +1513,7 @@ struct W2Cold {
 };
 
 template <bool SYM, bool PK>
-__global__ void __launch_bounds__(LANES, 5)
+__global__ void __launch_bounds__(LANES, 6)  // 80 VGPRs: measured best of 4 / 5 / 6 / 8 waves per SIMD
 k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__restrict__ brc,
         const uint8_t *__restrict__ apk, const uint8_t *__restrict__ arcpk,
         const uint8_t *__restrict__ bpk, const uint8_t *__restrict__ brcpk, DhOpts o, int32_t item0,
