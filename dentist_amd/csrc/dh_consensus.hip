@@ -353,6 +353,24 @@ k_seg_vote2(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R,
 #undef OPB
 }
 
+// column -> template map of the vote space (-1 for the spare column after each template): binary
+// search of the column in the per-template offsets
+__global__ void __launch_bounds__(256)
+k_col_tmpl(const int64_t *__restrict__ voff, int32_t ntmpl, int64_t ncols_total, int32_t *__restrict__ col_tmpl)
+{
+    const int64_t gc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gc >= ncols_total) return;
+    int32_t lo = 0, hi = ntmpl;  // voff[lo] <= gc < voff[hi]
+    while (hi - lo > 1) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (voff[mid] <= gc)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    col_tmpl[gc] = gc < voff[lo + 1] - 1 ? lo : -1;
+}
+
 // completes the sparse votes of k_seg_vote2: cexcl = exclusive scan of the cover difference array
 // (cover of column x = cexcl[x + 1]); the template base gets the votes of all covering tiles that
 // voted for nothing else in this column
@@ -548,6 +566,13 @@ void dhk_seg_vote(hipStream_t st, const void *segs, int32_t nseg, DbView T, DbVi
         (void)hipFuncSetAttribute((const void *)k_seg_vote2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     hipLaunchKernelGGL(k_seg_vote2, dim3((nseg + 63) / 64), dim3(64), lds2, st, (const SegDesc *)segs, nseg, T, R,
                        rrc, voff, opbuf, nops, ncolmax, votes, cdiff, vother);
+}
+
+void dhk_col_tmpl(hipStream_t st, const int64_t *voff, int32_t ntmpl, int64_t ncols_total, int32_t *col_tmpl)
+{
+    if (ncols_total <= 0 || ntmpl <= 0) return;
+    hipLaunchKernelGGL(k_col_tmpl, dim3((unsigned)((ncols_total + 255) / 256)), dim3(256), 0, st, voff, ntmpl,
+                       ncols_total, col_tmpl);
 }
 
 void dhk_votes_finish(hipStream_t st, DbView T, const int64_t *voff, const int32_t *col_tmpl, int64_t ncols_total,

@@ -36,6 +36,7 @@ void dhk_seg_vote(hipStream_t st, const void *segs, int32_t nseg, DbView T, DbVi
 void dhk_votes_finish(hipStream_t st, DbView T, const int64_t *voff, const int32_t *col_tmpl, int64_t ncols_total,
                       const uint32_t *cexcl, const uint32_t *vother, uint32_t *votes);
 void dhk_scan(hipStream_t st, uint32_t *v, int64_t n, uint32_t *sums);
+void dhk_col_tmpl(hipStream_t st, const int64_t *voff, int32_t ntmpl, int64_t ncols_total, int32_t *col_tmpl);
 void dhk_emit(hipStream_t st, DbView T, int32_t ntmpl, const int64_t *voff, const uint32_t *votes,
               const int32_t *col_tmpl, int64_t ncols_total, uint8_t *stage, uint8_t *cnt,
               const int64_t *out_off, uint8_t *out, int32_t *out_len);
@@ -468,10 +469,7 @@ static int consensus_round(dh_ctx *ctx, dh_db *T, dh_db *R, const LaVec &las,
     }
     {
         // column -> template map of the vote space (-1 for the spare column after each template)
-        std::vector<int32_t> col_tmpl((size_t)voff.back(), -1);
-        for (int32_t t = 0; t < nt; t++)
-            for (int64_t x = voff[(size_t)t]; x < voff[(size_t)t + 1] - 1; x++) col_tmpl[(size_t)x] = t;
-        HIPCHK(hipMemcpyAsync(d_coltmpl.p, col_tmpl.data(), sizeof(int32_t) * col_tmpl.size(), hipMemcpyHostToDevice, st));
+        dhk_col_tmpl(st, d_voff.p, nt, voff.back(), d_coltmpl.p);
         HIPCHK(hipMemsetAsync(d_cnt.p, 0, (size_t)voff.back(), st));
         dhk_scan(st, d_cdiff.p, (int64_t)ncolp, d_csums);  // exclusive: cover of column x = [x + 1]
         dhk_votes_finish(st, T->view(), d_voff.p, d_coltmpl.p, voff.back(), d_cdiff.p, d_vother, d_votes.p);
