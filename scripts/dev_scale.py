@@ -6,7 +6,8 @@ import dentist_amd
 from dentist_amd import sim
 scale = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 t = time.time()
-w = sim.Workload(10_000_000 * scale, 100 * scale, 100_000 * scale, 10_000, seed=77)
+rl = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000
+w = sim.Workload(10_000_000 * scale, 100 * scale, 100_000 * scale, rl, seed=77)
 print(f"workload: {len(w.reads.bases)/1e9:.2f} Gbp reads, {w.contigs.n} contigs, {time.time()-t:.1f} s", flush=True)
 ctx = dentist_amd.Context(0)
 A, B = ctx.db(w.contigs), ctx.db(w.reads)
