@@ -269,3 +269,13 @@ def test_larger_run_properties(gpu_ctx):
     A.drop_cache()
     las2, trace2 = gpu_ctx.align_db(A, B, g)
     assert_same_las((las2, trace2), (las, trace))
+
+
+@pytest.mark.parametrize("kw", [dict(k=12), dict(k=16, kmer_mod=3), dict(k=10, hmin=50), dict(band_shift=5),
+                                dict(strands=1), dict(strands=2), dict(tspace=64, min_len=300), dict(pen=4, xdrop=60),
+                                dict(max_cand=2, max_la=1), dict(tcap=1), dict(dmax=200)])
+def test_option_sweep(gpu_ctx, kw):
+    """Every option of dh_align_opts away from its default (short k-mers flood the hit buffers, odd
+    modimer moduli take the rotate-free divisibility test, ...): still bit-exact."""
+    w = sim.Workload(150_000, 2, 250, 3000, seed=61, spacing=15000)
+    run_both(gpu_ctx, w.contigs, w.reads, **kw)
