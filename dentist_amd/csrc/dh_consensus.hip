@@ -268,15 +268,20 @@ k_seg_vote2(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R,
     const uint8_t *qry = (sg.comp ? rrc : R.bases) + R.off[sg.bseq] + sg.b0;
     const int64_t NDP = nseg;
 #define OPB(t) opbuf[(int64_t)(t)*NDP + dp]
-    // colst[x]: base aligned to column x (5 = deleted); icnt[x]: bases inserted before column x;
-    // ibase[x][t]: the first MAXINS of them
+    // colst[x]: base aligned to column x (5 = deleted); ins[x]: bases inserted before column x --
+    // count (0..5, 5 = more than MAXINS) in bits 0-2, bits 3-6 = "base t is one of ACGT";
+    // ibp[x]: the first MAXINS inserted bases, 2 bits each.  3 bytes per column keep 6 blocks of 64
+    // tiles resident per CU.
     uint8_t *colst = smem + threadIdx.x;
-    uint8_t *icnt = smem + (size_t)(ncolmax + 1) * 64 + threadIdx.x;
-    uint8_t *ibase = smem + (size_t)(2 * ncolmax + 3) * 64 + threadIdx.x;
+    uint8_t *ins = smem + (size_t)(ncolmax + 1) * 64 + threadIdx.x;
+    uint8_t *ibp = smem + (size_t)(2 * ncolmax + 3) * 64 + threadIdx.x;
 #define CS(x) colst[(x)*64]
-#define IC(x) icnt[(x)*64]
-#define IB(x, t) ibase[((x)*MAXINS + (t)) * 64]
-    for (int32_t x = 0; x <= rl; x++) IC(x) = 0;
+#define IN(x) ins[(x)*64]
+#define IB(x) ibp[(x)*64]
+    for (int32_t x = 0; x <= rl; x++) {
+        IN(x) = 0;
+        IB(x) = 0;
+    }
     {
         int32_t x = 0, y = 0;
         for (int32_t t = nops - 1; t >= 0; t--) {
@@ -288,9 +293,14 @@ k_seg_vote2(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R,
                 CS(x) = 5;
                 x++;
             } else {
-                const uint8_t n = IC(x);
-                if (n < MAXINS) IB(x, n) = qry[y];
-                if (n < 255) IC(x) = (uint8_t)(n + 1);
+                const uint8_t v = IN(x), n = v & 7, q = qry[y];
+                uint8_t nv = v;
+                if (n < MAXINS) {
+                    IB(x) = (uint8_t)(IB(x) | ((q & 3) << (2 * n)));
+                    if (q < 4) nv = (uint8_t)(nv | (8u << n));
+                }
+                if (n < 5) nv = (uint8_t)((nv & ~7u) | (n + 1));
+                IN(x) = nv;
                 y++;
             }
         }
@@ -300,25 +310,29 @@ k_seg_vote2(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R,
         if (CS(x) != 5) continue;
         const uint8_t c = ref[x];
         int32_t st = x;
-        while (st > 0 && CS(st - 1) == c && ref[st - 1] == c && IC(st) == 0) st--;
+        while (st > 0 && CS(st - 1) == c && ref[st - 1] == c && (IN(st) & 7) == 0) st--;
         if (st < x) {
             CS(st) = 5;
             CS(x) = c;
         }
     }
     for (int32_t x = 1; x <= rl; x++) {
-        const int32_t n = IC(x);
+        const uint8_t v = IN(x);
+        const int32_t n = v & 7;
         if (n == 0 || n > MAXINS) continue;
-        const uint8_t c = IB(x, 0);
-        bool same = c < 4;
-        for (int32_t t = 1; t < n; t++) same = same && IB(x, t) == c;
+        const uint8_t bits = IB(x), c = bits & 3;
+        // all n inserted bases are the same ACGT base
+        const uint8_t want_valid = (uint8_t)(((1u << n) - 1u) << 3);
+        bool same = (v & want_valid) == want_valid;
+        for (int32_t t = 1; t < n; t++) same = same && ((bits >> (2 * t)) & 3) == c;
         if (!same) continue;
         int32_t st = x;
-        while (st > 0 && CS(st - 1) == c && ref[st - 1] == c && IC(st - 1) == 0) st--;
+        while (st > 0 && CS(st - 1) == c && ref[st - 1] == c && (IN(st - 1) & 7) == 0) st--;
         if (st < x) {
-            for (int32_t t = 0; t < n; t++) IB(st, t) = c;
-            IC(st) = (uint8_t)n;
-            IC(x) = 0;
+            IB(st) = bits;
+            IN(st) = v;
+            IN(x) = 0;
+            IB(x) = 0;
         }
     }
     // ---- votes, sparse: a column whose read base equals the template base casts no atomic at
@@ -331,12 +345,11 @@ k_seg_vote2(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R,
     atomicSub(&cdiff[c0 + rl], 1u);
     for (int32_t x = 0; x <= rl; x++) {
         uint32_t *col = v + (int64_t)x * VSTRIDE;
-        const int32_t ic = IC(x);
+        const uint8_t iv = IN(x), bits = IB(x);
+        const int32_t ic = iv & 7;
         const int32_t n = ic < MAXINS ? ic : MAXINS;
-        for (int32_t t = 0; t < n; t++) {
-            const uint8_t c = IB(x, t);
-            if (c < 4) atomicAdd(&col[6 + 4 * t + c], 1u);
-        }
+        for (int32_t t = 0; t < n; t++)
+            if (iv & (8u << t)) atomicAdd(&col[6 + 4 * t + ((bits >> (2 * t)) & 3)], 1u);
         if (x == rl) break;
         const uint8_t cs = CS(x), rc = ref[x];
         if (cs == rc && rc < 4) continue;
@@ -348,7 +361,7 @@ k_seg_vote2(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R,
             atomicAdd(&vother[c0 + x], 1u);
     }
 #undef CS
-#undef IC
+#undef IN
 #undef IB
 #undef OPB
 }
@@ -561,7 +574,7 @@ void dhk_seg_vote(hipStream_t st, const void *segs, int32_t nseg, DbView T, DbVi
     const size_t lds = (size_t)(2 * bandmax + 2) * 64 + ((size_t)(qmax + 7) / 8 + 1) * 256;
     hipLaunchKernelGGL(k_seg_vote, dim3((nseg + 63) / 64), dim3(64), lds, st, (const SegDesc *)segs, nseg,
                        T, R, rrc, voff, dmat, bandmax, opbuf, nops, status);
-    const size_t lds2 = (size_t)((2 * ncolmax + 3) + (ncolmax + 2) * MAXINS) * 64;
+    const size_t lds2 = (size_t)(3 * ncolmax + 5) * 64;
     if (lds2 > 65536)
         (void)hipFuncSetAttribute((const void *)k_seg_vote2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     hipLaunchKernelGGL(k_seg_vote2, dim3((nseg + 63) / 64), dim3(64), lds2, st, (const SegDesc *)segs, nseg, T, R,
