@@ -29,6 +29,9 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 WORKLOADS = {
+    # BASELINE.json configs[2] -- the configuration north_star quotes the target on: 100 Mb assembly,
+    # 1 000 gaps, 1 M x 15 kb PacBio-error reads (15 Gbp, 150x)
+    "cfg2_100Mb_1000gaps_1Mx15kb": dict(genome_len=100_000_000, ngaps=1000, nreads=1_000_000, read_len=15_000),
     # BASELINE.json configs[1]: 10 Mb assembly, 100 gaps, 100 k x 10 kb PacBio-error reads
     "cfg1_10Mb_100gaps_100kx10kb": dict(genome_len=10_000_000, ngaps=100, nreads=100_000, read_len=10_000),
     # reduced shape for quick checks (not a bench line)
@@ -63,11 +66,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cfg1_10Mb_100gaps_100kx10kb")
+    ap.add_argument("--workload", default="cfg2_100Mb_1000gaps_1Mx15kb")
     ap.add_argument("--cpu-sample-reads", type=int, default=3000)
     ap.add_argument("--cpu-sample-gaps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kmer-mod", type=int, default=4)
+    ap.add_argument("--map-k", type=int, default=20, help="k-mer length of the mapping pass (damapper's default)")
     args = ap.parse_args()
 
     import torch
@@ -97,7 +101,7 @@ def main():
     ctx = dentist_amd.Context(local_rank, stream=stream)
     A, B = ctx.db(w.contigs), ctx.db(w.reads)
     # mapping pass: modimer sampling 1/4 (daligner's -%), every other option at its default
-    mopts = dentist_amd.default_align_opts(kmer_mod=args.kmer_mod)
+    mopts = dentist_amd.default_align_opts(kmer_mod=args.kmer_mod, k=args.map_k)
     popts = dentist_amd.default_process_opts()
     read_bp = int(len(w.reads.bases))
 
@@ -184,7 +188,7 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": args.workload, "per_gpu": spec, "mapping_kmer_mod": args.kmer_mod,
+            "config": {"workload": args.workload, "per_gpu": spec, "mapping_kmer_mod": args.kmer_mod, "mapping_k": args.map_k,
                        "read_bp_total": read_all,
                        "pile_ups": npiles_all, "gaps_closed": nclosed_all, "gap_bases_closed": gap_all,
                        "consensus_edit_distance_vs_truth": edits_all, "consensus_truth_bases": truth_all,
@@ -236,7 +240,7 @@ def cpu_baseline(w, last, mopts, popts, args):
     cores = os.cpu_count() or 1
     n = min(args.cpu_sample_reads, w.reads.n)
     sub = sim.SeqDb(w.reads.bases[:w.reads.off[n]], w.reads.off[:n + 1])
-    o = oz.default_opts(width=mopts.width, kmer_mod=mopts.kmer_mod)
+    o = oz.default_opts(width=mopts.width, kmer_mod=mopts.kmer_mod, k=mopts.k)
     t0 = time.perf_counter()
     oz.align_db(w.contigs, sub, o, nthreads=cores)
     t_map = time.perf_counter() - t0

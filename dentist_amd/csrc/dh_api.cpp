@@ -498,10 +498,9 @@ static int build_index(dh_db *A, int32_t k, int32_t sepv, int32_t kmer_mod)
     ix.shift = keybits - pbits;
     // the largest key is ngroups * 4^k - 1, so buckets up to (that >> shift) are addressable
     const int64_t nb = (int64_t)((((uint64_t)A->ngroups << (2 * k)) - 1) >> ix.shift) + 1;
-    ix.n = nk;
+    if (nk >= (1ll << 32)) return fail(DH_EINVAL, "index: more than 2^32 k-mer positions (32-bit bucket offsets)");
     HIPCHK(dh_dev_alloc(&ix.d_dir_alloc, sizeof(uint32_t) * (size_t)(nb + 2)));
     ix.d_dir = ix.d_dir_alloc + 1;
-    HIPCHK(dh_dev_alloc(&ix.d_ent, sizeof(ulonglong2) * (size_t)std::max<int64_t>(nk, 1)));
     HIPCHK(dh_dev_alloc(&ix.d_goff, sizeof(int64_t) * (size_t)(A->n + 1)));
     int2 *d_tiles = nullptr;
     uint32_t *d_sums = nullptr;
@@ -518,6 +517,13 @@ static int build_index(dh_db *A, int32_t k, int32_t sepv, int32_t kmer_mod)
     dhk_kmer_pass(ctx->stream, 0, av, d_tiles, (int32_t)tiles.size(), k, kmer_mod, ix.shift, ix.d_dir, ix.d_ent,
                   ix.d_goff);
     dhk_scan(ctx->stream, ix.d_dir, nb + 1, d_sums);
+    // the entry array is sized by the k-mers that were actually indexed (sampled, unmasked): the
+    // exclusive scan leaves their number in dir[nb]
+    uint32_t nent = 0;
+    HIPCHK(hipMemcpyAsync(&nent, ix.d_dir + nb, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ix.n = (int64_t)nent;
+    HIPCHK(dh_dev_alloc(&ix.d_ent, sizeof(ulonglong2) * (size_t)std::max<int64_t>(ix.n, 1)));
     dhk_kmer_pass(ctx->stream, 1, av, d_tiles, (int32_t)tiles.size(), k, kmer_mod, ix.shift, ix.d_dir, ix.d_ent,
                   ix.d_goff);
     HIPCHK(hipGetLastError());
@@ -663,7 +669,7 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
     if (!ctx || !A || !B || !opts || !out) return fail(DH_EINVAL, "dh_align_db: NULL argument");
     if (A->ctx != ctx || B->ctx != ctx) return fail(DH_EINVAL, "dh_align_db: DB of another context");
     const dh_align_opts &o = *opts;
-    if (o.k < 8 || o.k > 16) return fail(DH_EINVAL, "k must be in [8, 16]");
+    if (o.k < 8 || o.k > 28) return fail(DH_EINVAL, "k must be in [8, 28]");
     if (o.width < 1 || o.width > 62) return fail(DH_EINVAL, "width must be in [1, 62]");
     if (o.tspace < 16 || o.tspace > 32767) return fail(DH_EINVAL, "tspace out of range");
     if (o.max_cand < 1 || o.max_cand > 256) return fail(DH_EINVAL, "max_cand must be in [1, 256]");
@@ -761,8 +767,9 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
     HIPCHK(hipMemsetAsync(d_counters, 0, 2 * sizeof(unsigned long long), st));
 
     // expected hits per (read, strand): random matches + true seeds; pick the LDS hit capacity
-    const double dens = (double)A->ix.n / std::pow(4.0, o.k) / std::max(1, A->ngroups);
-    const double exp_hits = B->max_len * (dens + 0.2 / std::max(1, o.kmer_mod));
+    // (ix.n = indexed k-mers; a sampled k-mer of B meets ix.n / (4^k / kmer_mod) of them by chance)
+    const double dens = (double)A->ix.n * std::max(1, o.kmer_mod) / std::pow(4.0, o.k) / std::max(1, A->ngroups);
+    const double exp_hits = (double)B->max_len / std::max(1, o.kmer_mod) * (dens + 0.2);
     int cap = 1024;
     while (cap < 16384 && exp_hits * 1.5 >= cap) cap *= 2;
     if (A == B && cap < 8192) cap = 8192;  // all-vs-all inside pile-ups: every read overlaps every other

@@ -69,6 +69,15 @@ def test_modimer_sampling(gpu_ctx, mod):
     assert len(set(las["bread"].tolist())) == w.reads.n
 
 
+@pytest.mark.parametrize("k,mod", [(20, 1), (20, 4), (17, 2), (24, 4)])
+def test_long_kmers_like_damapper(gpu_ctx, k, mod):
+    """damapper's own default is -k20 (DENTIST passes no -k, commandline.d:2943-2955): keys beyond
+    32 bits take the wide hash path of the sampler and a deeper directory shift."""
+    w = sim.Workload(300_000, 3, 400, 8000, seed=31, spacing=15000)
+    las, _ = run_both(gpu_ctx, w.contigs, w.reads, k=k, kmer_mod=mod)
+    assert len(set(las["bread"].tolist())) >= 0.99 * w.reads.n
+
+
 def test_long_b_sequences_use_the_hbm_staged_seed_path(gpu_ctx):
     """Contigs as B against an index of the reads (the transposed `damapper -C` file): far more
     than 16384 k-mer hits per sequence -> hits are staged in HBM, results still bit-exact."""
