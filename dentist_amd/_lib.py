@@ -74,6 +74,7 @@ SYMBOLS = [
     "dh_dazz_close", "dh_dazz_nreads", "dh_dazz_first_id", "dh_dazz_bases", "dh_dazz_offsets",
     "dh_dazz_origin", "dh_dazz_fpulse", "dh_dazz_header", "dh_dazz_read_mask", "dh_dazz_write_mask",
     "dh_db_set_mask", "dh_output_fasta", "dh_tile_qv", "dh_consensus", "dh_las_merge",
+    "dh_collect_candidates", "dh_pileups_create", "dh_pileups_select", "dh_align_db_block", "dh_la_set_merge",
 ]
 
 _LIB = None
@@ -117,10 +118,15 @@ def lib():
     L.dh_get_align_stats.argtypes = [vp, ctypes.POINTER(AlignStats)]
     L.dh_get_cum_stats.argtypes = [vp, ctypes.POINTER(CumStats), i32]
     L.dh_align_db.argtypes = [vp, vp, vp, ctypes.POINTER(AlignOpts), i32, ctypes.POINTER(vp)]
+    L.dh_align_db_block.argtypes = [vp, vp, vp, i32, i32, ctypes.POINTER(AlignOpts), i32, ctypes.POINTER(vp)]
+    L.dh_la_set_merge.argtypes = [ctypes.POINTER(vp), i32, ctypes.POINTER(vp)]
     L.dh_las_write.argtypes = [ctypes.c_char_p, vp, i64, vp, i32]
     L.dh_las_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
     L.dh_default_process_opts.argtypes = [ctypes.POINTER(ProcessOpts)]
     L.dh_collect_spanning.argtypes = [vp, i64, vp, i32, ctypes.POINTER(ProcessOpts), ctypes.POINTER(vp)]
+    L.dh_collect_candidates.argtypes = L.dh_collect_spanning.argtypes
+    L.dh_pileups_create.argtypes = [vp, vp, i32, vp, ctypes.POINTER(vp)]
+    L.dh_pileups_select.argtypes = [vp, vp, i64, ctypes.POINTER(ProcessOpts), ctypes.POINTER(vp)]
     L.dh_pileups_destroy.argtypes = [vp]
     L.dh_pileups_count.argtypes = [vp]
     L.dh_pileups_count.restype = i32
@@ -265,6 +271,30 @@ class Context:
         return las, trace
 
 
+    def align_db_block(self, A, B, first, count, opts, select_best=False, raw=False):
+        """`damapper ref reads.<block>`: reads [first, first + count) of B against A.  raw=True
+        returns the library handle (for merge_las) instead of numpy views."""
+        h = ctypes.c_void_p()
+        _check(lib().dh_align_db_block(self._h, A._h, B._h, first, count, ctypes.byref(opts), int(select_best),
+                                       ctypes.byref(h)))
+        if raw:
+            return h
+        las, trace, _ = _take_la_set(h)
+        return las, trace
+
+
+def merge_las(handles):
+    """LAmerge of in-memory block results (handles from align_db_block(raw=True), consumed)."""
+    arr = (ctypes.c_void_p * len(handles))(*[h.value for h in handles])
+    out = ctypes.c_void_p()
+    rc = lib().dh_la_set_merge(arr, len(handles), ctypes.byref(out))
+    for h in handles:
+        lib().dh_la_set_destroy(h)
+    _check(rc)
+    las, trace, _ = _take_la_set(out)
+    return las, trace
+
+
 class Db:
     """Device-resident sequence DB (HBM); built from a dentist_amd.sim.SeqDb-like object."""
 
@@ -330,15 +360,39 @@ def default_process_opts(**kw):
 
 
 class Pileups:
-    """Spanning-read pile-ups per gap (host only): dh_collect_spanning."""
+    """Spanning-read pile-ups per gap (host only): dh_collect_spanning; ``candidates=True`` skips the
+    min/max-reads cut (dh_collect_candidates)."""
 
-    def __init__(self, las, contig_off, opts):
+    def __init__(self, las, contig_off, opts, candidates=False, _handle=None):
+        if _handle is not None:
+            self._h = _handle
+            return
         arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
         off = np.ascontiguousarray(contig_off, dtype=np.int64)
         h = ctypes.c_void_p()
-        _check(lib().dh_collect_spanning(arr.ctypes.data, len(arr), off.ctypes.data, len(off) - 1,
-                                         ctypes.byref(opts), ctypes.byref(h)))
+        fn = lib().dh_collect_candidates if candidates else lib().dh_collect_spanning
+        _check(fn(arr.ctypes.data, len(arr), off.ctypes.data, len(off) - 1, ctypes.byref(opts), ctypes.byref(h)))
         self._h = h
+
+    @classmethod
+    def from_triples(cls, contig_left, triples_per_pile):
+        """dh_pileups_create: gaps ordered by contig_left, one (k, 3) int32 array of
+        (read, left LA index, right LA index) per gap."""
+        cl = np.ascontiguousarray(contig_left, dtype=np.int32)
+        cnt = np.asarray([len(t) for t in triples_per_pile], dtype=np.int32)
+        tri = (np.ascontiguousarray(np.concatenate([np.asarray(t, dtype=np.int32).reshape(-1, 3)
+                                                    for t in triples_per_pile]), dtype=np.int32)
+               if len(triples_per_pile) else np.zeros((0, 3), np.int32))
+        h = ctypes.c_void_p()
+        _check(lib().dh_pileups_create(cl.ctypes.data, cnt.ctypes.data, len(cl), tri.ctypes.data, ctypes.byref(h)))
+        return cls(None, None, None, _handle=h)
+
+    def select(self, las, opts):
+        """dh_pileups_select: the min_reads / max_reads cut."""
+        arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
+        h = ctypes.c_void_p()
+        _check(lib().dh_pileups_select(self._h, arr.ctypes.data, len(arr), ctypes.byref(opts), ctypes.byref(h)))
+        return Pileups(None, None, None, _handle=h)
 
     def __len__(self):
         return lib().dh_pileups_count(self._h)

@@ -657,8 +657,68 @@ extern "C" int dh_align_db(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts 
     return dh_align_db_ex(ctx, A, B, opts, want_best, 1, out);
 }
 
+static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t count, const dh_align_opts *opts,
+                       int32_t want_best, int32_t want_sorted, dh_la_set **out);
+
+// `damapper <ref> <reads>.<block>` (snakemake/Snakefile:1143-1170): the reads [first, first + count)
+// of B against all of A; read ids in the records are those of the whole DB, as in a block's .las
+extern "C" int dh_align_db_block(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t count,
+                                 const dh_align_opts *opts, int32_t want_best, dh_la_set **out)
+{
+    if (!B || first < 0 || count < 0 || (int64_t)first + count > B->n)
+        return fail(DH_EINVAL, "dh_align_db_block: block outside the DB");
+    return align_range(ctx, A, B, first, count, opts, want_best, 1, out);
+}
+
 int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, int32_t want_best,
                    int32_t want_sorted, dh_la_set **out)
+{
+    if (!B) return fail(DH_EINVAL, "dh_align_db: NULL argument");
+    return align_range(ctx, A, B, 0, B->n, opts, want_best, want_sorted, out);
+}
+
+// derived copies (reverse complement, 2-bit packed forward / reverse) of the reads [r0, r1) of B in
+// the context's scratch arena; the returned pointers are shifted so that absolute base offsets of
+// the DB index them, exactly like the DB-owned whole copies
+struct ChunkCopies {
+    const uint8_t *rc = nullptr, *pk = nullptr, *rcpk = nullptr;
+    bool has_n = false;
+};
+static int chunk_copies(dh_ctx *ctx, dh_db *B, int32_t r0, int32_t r1, bool want_packed, ChunkCopies *out)
+{
+    hipStream_t st = ctx->stream;
+    const int64_t o0 = B->h_off[(size_t)r0], o1 = B->h_off[(size_t)r1];
+    const int64_t a0 = o0 & ~31ll;  // packed words hold 32 bases: start the chunk on a word boundary
+    uint8_t *d_rc, *d_pk, *d_rcpk;
+    int32_t *d_flag;
+    if (int rc = dh_scratch(ctx, 26, (size_t)(o1 - a0) + 2 * DB_PAD, (void **)&d_rc)) return rc;
+    // reverse complement: every read mirrored inside its own [off, off + len) range
+    HIPCHK(hipMemsetAsync(d_rc, 4, (size_t)(o1 - a0) + 2 * DB_PAD, st));
+    uint8_t *rc_shift = d_rc + DB_PAD - a0;
+    dhk_revcomp(st, B->d_bases, rc_shift, B->d_off + r0, r1 - r0, B->max_len);
+    HIPCHK(hipGetLastError());
+    out->rc = rc_shift;
+    out->has_n = false;
+    if (!want_packed) return DH_OK;
+    const size_t pbytes = (size_t)((o1 - a0 + 31) / 32) * 8 + 32;
+    if (int rc = dh_scratch(ctx, 27, pbytes, (void **)&d_pk)) return rc;
+    if (int rc = dh_scratch(ctx, 28, pbytes, (void **)&d_rcpk)) return rc;
+    if (int rc = dh_scratch(ctx, 3, 4 * sizeof(int32_t), (void **)&d_flag)) return rc;
+    HIPCHK(hipMemsetAsync(d_flag + 1, 0, 2 * sizeof(int32_t), st));
+    dhk_pack2(st, B->d_bases + a0, o1 - a0, d_pk + 16, d_flag + 1);
+    dhk_pack2(st, d_rc + DB_PAD, o1 - a0, d_rcpk + 16, d_flag + 2);
+    HIPCHK(hipGetLastError());
+    int32_t flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, d_flag + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    out->has_n = flag != 0;
+    out->pk = d_pk + 16 - (a0 >> 2);
+    out->rcpk = d_rcpk + 16 - (a0 >> 2);
+    return DH_OK;
+}
+
+static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t count, const dh_align_opts *opts,
+                       int32_t want_best, int32_t want_sorted, dh_la_set **out)
 {
     auto now_ms = [] {
         return (double)std::chrono::duration_cast<std::chrono::microseconds>(
@@ -682,7 +742,7 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     dh_align_stats stats = {};
-    stats.b_bases = B->total;
+    stats.b_bases = B->h_off[(size_t)first + (size_t)count] - B->h_off[(size_t)first];
     dh_la_set *res = new dh_la_set();
     res->tspace = o.tspace;
     *out = nullptr;
@@ -698,17 +758,32 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
     HIPCHK(hipEventRecord(ctx->ev[0], st));
     const int32_t sepv = ((B->max_len + 64) + 63) & ~63;
     if (int rc = build_index(A, o.k, sepv, o.kmer_mod)) return rc;
-    if (int rc = dh_ensure_rc(B)) return rc;
+    // B's derived copies (reverse complement, 2-bit packed) live with the DB when the whole DB is
+    // one chunk of this call (pile-up and template DBs are re-aligned several times); a block of a
+    // larger DB gets them chunk by chunk in the scratch arena, so the resident footprint of a reads
+    // DB stays at one byte per base however large it is
+    const int64_t nitems_total = 2ll * count;
+    int32_t chunk = 1 << 18;
+    if (const char *e = getenv("DH_ALIGN_CHUNK")) chunk = std::max(2, atoi(e)) & ~1;
+    // symmetric mode writes records into the slots of other items: everything is one chunk
+    if (o.skip_self == 2) {
+        if (first != 0 || count != B->n) return fail(DH_EINVAL, "symmetric mode needs the whole DB");
+        chunk = (int32_t)std::min<int64_t>(std::max<int64_t>(nitems_total, 2), INT32_MAX - 1);
+    }
+    const bool db_copies = A == B || (first == 0 && count == B->n && nitems_total <= chunk);
+    const bool want_packed = !getenv("DH_WAVE_BYTES");
     // the wave kernel slides over 2-bit packed copies unless a DB holds codes outside 0..3
     if (int rc = dh_ensure_packed(A, false)) return rc;
-    if (int rc = dh_ensure_packed(B, true)) return rc;
-    const bool packed = A->has_n == 0 && B->has_n == 0 && !getenv("DH_WAVE_BYTES");
+    if (db_copies) {
+        if (int rc = dh_ensure_rc(B)) return rc;
+        if (int rc = dh_ensure_packed(B, true)) return rc;
+    }
     // up to 30 live diagonals fit a 32-lane half: two alignments per wavefront (k_wave2); its
     // reverse extensions run forward over the reverse complements, so A needs one as well
     const bool dual = o.width <= 30 && !getenv("DH_WAVE_SINGLE");
     if (dual) {
         if (int rc = dh_ensure_rc(A)) return rc;
-        if (packed)
+        if (A->has_n == 0)
             if (int rc = dh_ensure_packed(A, true)) return rc;
     }
     HIPCHK(hipEventRecord(ctx->ev[1], st));
@@ -732,14 +807,8 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
     int32_t slots_per_cu = 32;
     if (o.width <= 30) slots_per_cu = 48;  // k_wave2: 80 VGPRs, 6 waves/SIMD, two slots per wavefront
     if (const char *e = getenv("DH_WAVE_SLOTS_PER_CU")) slots_per_cu = std::max(2, atoi(e)) & ~1;
-    const int64_t nitems_total = 2ll * B->n;
     const int32_t nslots = (int32_t)std::min<int64_t>((int64_t)ctx->ncu * slots_per_cu,
                                                       (std::max<int64_t>(nitems_total, 2) + 1) & ~1ll);
-    int32_t chunk = 1 << 18;
-    if (const char *e = getenv("DH_ALIGN_CHUNK")) chunk = std::max(2, atoi(e)) & ~1;
-    // symmetric mode writes records into the slots of other items: everything is one chunk
-    if (o.skip_self == 2) chunk = (int32_t)std::min<int64_t>(std::max<int64_t>(nitems_total, 2), INT32_MAX - 1);
-
     const int32_t cn = (int32_t)std::min<int64_t>(chunk, std::max<int64_t>(nitems_total, 2));
     DhCand *d_cand;
     int32_t *d_ncand, *d_nhits, *d_status, *d_cdj;
@@ -777,8 +846,18 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
     std::vector<int32_t> h_ncand((size_t)cn), h_nhits((size_t)cn);
     float ms_seed = 0, ms_wave = 0, ms_gather = 0;
 
-    for (int64_t item0 = 0; item0 < nitems_total; item0 += cn) {
-        const int32_t ni = (int32_t)std::min<int64_t>(cn, nitems_total - item0);
+    const int64_t item_first = 2ll * first, item_end = item_first + nitems_total;
+    for (int64_t item0 = item_first; item0 < item_end; item0 += cn) {
+        const int32_t ni = (int32_t)std::min<int64_t>(cn, item_end - item0);
+        ChunkCopies cc;
+        if (db_copies) {
+            cc.rc = B->d_rc;
+            cc.pk = B->d_pk;
+            cc.rcpk = B->d_rcpk;
+            cc.has_n = B->has_n != 0;
+        } else if (int rc = chunk_copies(ctx, B, (int32_t)(item0 >> 1), (int32_t)((item0 + ni) >> 1), want_packed, &cc))
+            return rc;
+        const bool packed = want_packed && A->has_n == 0 && !cc.has_n && cc.pk && cc.rcpk;
         // per-chunk arrays are indexed by absolute item inside the kernels: shift the bases
         DhCand *candbase = d_cand - item0 * o.max_cand;
         DhLa *labase = d_la - item0 * o.max_la;
@@ -787,7 +866,7 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
         int32_t *nlabase = (int32_t *)d_nla - item0, *ntrbase = (int32_t *)d_ntr - item0;
         HIPCHK(hipEventRecord(ctx->ev[2], st));
         HIPCHK(hipMemsetAsync(d_queue, 0, 4 * sizeof(uint32_t), st));
-        dhk_seed(st, cap, bv, B->d_rc, iv, dopt, (int32_t)item0, ni, candbase, ncandbase, nhitsbase, d_status,
+        dhk_seed(st, cap, bv, cc.rc, iv, dopt, (int32_t)item0, ni, candbase, ncandbase, nhitsbase, d_status,
                  d_queue + 1, ctx->ncu);
         HIPCHK(hipGetLastError());
         {
@@ -825,7 +904,7 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
                 for (size_t b0 = 0; b0 < big.size(); b0 += per_launch) {
                     const int32_t cnt = (int32_t)std::min(per_launch, big.size() - b0);
                     HIPCHK(hipMemsetAsync(d_queue + 2, 0, sizeof(uint32_t), st));
-                    dhk_seed_big(st, bv, B->d_rc, iv, dopt, d_list + b0, cnt, d_gbuf, pow2, candbase, ncandbase,
+                    dhk_seed_big(st, bv, cc.rc, iv, dopt, d_list + b0, cnt, d_gbuf, pow2, candbase, ncandbase,
                                  nhitsbase, d_status, d_queue + 2, ctx->ncu);
                     HIPCHK(hipGetLastError());
                 }
@@ -855,13 +934,13 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
         }
         WaveScratch ws{d_pool, d_cdj, d_queue, (const int4 *)d_units, d_queue + 3, poolcap, nbmax};
         if (dual)
-            dhk_wave2(st, nslots / 2, av, bv, A->d_rc, B->d_rc, packed ? A->d_pk : nullptr,
-                      packed ? A->d_rcpk : nullptr, packed ? B->d_pk : nullptr, packed ? B->d_rcpk : nullptr, dopt,
+            dhk_wave2(st, nslots / 2, av, bv, A->d_rc, cc.rc, packed ? A->d_pk : nullptr,
+                      packed ? A->d_rcpk : nullptr, packed ? cc.pk : nullptr, packed ? cc.rcpk : nullptr, dopt,
                       (int32_t)item0, ni, candbase, ncandbase, ws, labase, trbase, trmax, nlabase, ntrbase, d_counters,
                       d_status);
         else
-        dhk_wave(st, nslots, av, bv, B->d_rc, packed ? A->d_pk : nullptr, packed ? B->d_pk : nullptr,
-                 packed ? B->d_rcpk : nullptr, dopt, (int32_t)item0, ni, candbase, ncandbase, ws, labase, trbase,
+        dhk_wave(st, nslots, av, bv, cc.rc, packed ? A->d_pk : nullptr, packed ? cc.pk : nullptr,
+                 packed ? cc.rcpk : nullptr, dopt, (int32_t)item0, ni, candbase, ncandbase, ws, labase, trbase,
                  trmax, nlabase, ntrbase, d_counters, d_status);
         HIPCHK(hipGetLastError());
         stats.wave_launches++;
@@ -897,7 +976,7 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
             if (totals[1] > 0)
                 HIPCHK(hipMemcpyAsync(res->trace.data() + t0, d_trout, sizeof(uint16_t) * (size_t)totals[1],
                                       hipMemcpyDeviceToHost, st));
-            res->d_trace = (t0 == 0 && item0 == 0 && ni == nitems_total) ? d_trout : nullptr;
+            res->d_trace = (t0 == 0 && item0 == item_first && ni == nitems_total) ? d_trout : nullptr;
         }
         HIPCHK(hipEventRecord(ctx->ev[5], st));
         HIPCHK(hipStreamSynchronize(st));
@@ -1056,6 +1135,47 @@ extern "C" int dh_las_read(const char *path, dh_la_set **out)
     }
     fclose(f);
     *out = s;
+    return DH_OK;
+}
+
+// LAmerge in memory: the result sets of the read blocks (dh_align_db_block) merged into one set in
+// LAsort order; traces are concatenated in set order and every record's toff is rebased.
+extern "C" int dh_la_set_merge(const dh_la_set *const *sets, int32_t nsets, dh_la_set **out)
+{
+    if (!sets || nsets < 1 || !out) return fail(DH_EINVAL, "dh_la_set_merge: bad argument");
+    int32_t tspace = -1;
+    size_t nla = 0, ntr = 0;
+    for (int32_t i = 0; i < nsets; i++) {
+        if (!sets[i]) return fail(DH_EINVAL, "dh_la_set_merge: NULL set");
+        if (!sets[i]->la.empty()) {
+            if (tspace >= 0 && sets[i]->tspace != tspace)
+                return fail(DH_EINVAL, "dh_la_set_merge: sets with different trace spacing");
+            tspace = sets[i]->tspace;
+        }
+        nla += sets[i]->la.size();
+        ntr += sets[i]->trace.size();
+    }
+    dh_la_set *res = new dh_la_set();
+    res->tspace = tspace >= 0 ? tspace : sets[0]->tspace;
+    res->la.resize(nla);
+    res->trace.resize(ntr);
+    size_t l0 = 0, t0 = 0;
+    int32_t na = 0;
+    for (int32_t i = 0; i < nsets; i++) {
+        const dh_la_set *x = sets[i];
+        if (!x->trace.empty()) memcpy(res->trace.data() + t0, x->trace.data(), sizeof(uint16_t) * x->trace.size());
+        for (size_t j = 0; j < x->la.size(); j++) {
+            dh_la l = x->la[j];
+            l.toff += (int64_t)t0;
+            na = std::max(na, l.aread + 1);
+            res->la[l0 + j] = l;
+        }
+        l0 += x->la.size();
+        t0 += x->trace.size();
+    }
+    // every input is in LAsort order: a stable sort of the concatenation is the merge
+    std::stable_sort(res->la.begin(), res->la.end(), la_less);
+    *out = res;
     return DH_OK;
 }
 

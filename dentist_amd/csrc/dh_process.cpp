@@ -141,14 +141,20 @@ struct dh_pileups {
     std::vector<std::vector<int32_t>> triples;  // read, left LA, right LA
 };
 
-extern "C" int dh_collect_spanning(const dh_la *las, int64_t n, const int64_t *contig_off,
-                                   int32_t ncontigs, const dh_process_opts *opts, dh_pileups **out)
+// Candidates: for every read and every gap the read spans, ONE (read, left LA, right LA) entry --
+// the qualifying pair with the longest anchors (ties: lowest LA indices) -- grouped by gap, ordered
+// by read id.  No min/max-reads cut yet (the sharded path applies it after the exchange).
+static int collect_candidates(const dh_la *las, int64_t n, const int64_t *contig_off, int32_t ncontigs,
+                              const dh_process_opts &o, dh_pileups **out)
 {
-    if ((n > 0 && !las) || !contig_off || !opts || !out) return dh_fail(DH_EINVAL, "dh_collect_spanning: NULL");
-    const dh_process_opts &o = *opts;
-    // group the LA indices by read (counting sort, keeps the LA order inside a read)
+    if (n >= (1ll << 31)) return dh_fail(DH_EINVAL, "dh_collect_spanning: more than 2^31 - 1 local alignments");
     int32_t nreads = 0;
-    for (int64_t i = 0; i < n; i++) nreads = std::max(nreads, las[i].bread + 1);
+    for (int64_t i = 0; i < n; i++) {
+        if (las[i].bread < 0 || las[i].aread < 0 || las[i].aread >= ncontigs)
+            return dh_fail(DH_EINVAL, "dh_collect_spanning: read or contig id out of range");
+        nreads = std::max(nreads, las[i].bread + 1);
+    }
+    // group the LA indices by read (counting sort, keeps the LA order inside a read)
     std::vector<int64_t> first((size_t)nreads + 1, 0), order((size_t)n);
     for (int64_t i = 0; i < n; i++) first[(size_t)las[i].bread + 1]++;
     for (int32_t r = 0; r < nreads; r++) first[(size_t)r + 1] += first[(size_t)r];
@@ -160,10 +166,11 @@ extern "C" int dh_collect_spanning(const dh_la *las, int64_t n, const int64_t *c
     for (int32_t rd = 0; rd < nreads; rd++) {
         const int64_t *idx = order.data() + first[(size_t)rd], cnt = first[(size_t)rd + 1] - first[(size_t)rd];
         if (cnt < 2) continue;
+        std::map<int32_t, std::pair<int64_t, std::pair<int64_t, int64_t>>> best;  // gap -> (anchor sum, (iL, iR))
         for (int64_t x = 0; x < cnt; x++) {
             const int64_t iL = idx[x];
             const dh_la &L = las[iL];
-            if (L.aread < 0 || L.aread + 1 >= ncontigs) continue;
+            if (L.aread + 1 >= ncontigs) continue;
             const int64_t cl = contig_off[L.aread + 1] - contig_off[L.aread];
             if (L.aepos + o.allowance < cl || L.aepos - L.abpos < o.min_anchor) continue;
             for (int64_t y = 0; y < cnt; y++) {
@@ -172,23 +179,111 @@ extern "C" int dh_collect_spanning(const dh_la *las, int64_t n, const int64_t *c
                 if (R.aread != L.aread + 1 || (R.flags & DH_FLAG_COMP) != (L.flags & DH_FLAG_COMP)) continue;
                 if (R.abpos > o.allowance || R.aepos - R.abpos < o.min_anchor) continue;
                 if (R.bbpos + o.allowance < L.bepos - o.allowance) continue;
-                std::vector<int32_t> &v = piles[L.aread];
-                v.push_back(rd);
-                v.push_back((int32_t)iL);
-                v.push_back((int32_t)iR);
+                const int64_t anchors = (int64_t)(L.aepos - L.abpos) + (R.aepos - R.abpos);
+                auto it = best.find(L.aread);
+                if (it == best.end() || anchors > it->second.first)
+                    best[L.aread] = std::make_pair(anchors, std::make_pair(iL, iR));
             }
+        }
+        for (auto &kv : best) {
+            std::vector<int32_t> &v = piles[kv.first];
+            v.push_back(rd);
+            v.push_back((int32_t)kv.second.second.first);
+            v.push_back((int32_t)kv.second.second.second);
         }
     }
     dh_pileups *p = new dh_pileups();
     for (auto &kv : piles) {
-        if ((int32_t)kv.second.size() / 3 < o.min_reads) continue;
-        std::vector<int32_t> v = kv.second;
-        if ((int32_t)v.size() / 3 > o.max_reads) v.resize((size_t)o.max_reads * 3);
         p->contig_left.push_back(kv.first);
+        p->triples.push_back(std::move(kv.second));
+    }
+    *out = p;
+    return DH_OK;
+}
+
+// min-reads / max-reads cut of one candidate list (ordered by read id): fewer than min_reads
+// distinct reads -> dropped; more than max_reads -> the max_reads entries with the lowest error
+// rate of their two anchoring LAs stay (ties: lower read id), still ordered by read id.
+static bool select_pile(std::vector<int32_t> &v, const dh_la *las, const dh_process_opts &o)
+{
+    const int32_t cnt = (int32_t)v.size() / 3;
+    if (cnt < o.min_reads) return false;
+    if (cnt <= o.max_reads) return true;
+    std::vector<std::pair<int64_t, int32_t>> key((size_t)cnt);
+    for (int32_t e = 0; e < cnt; e++) {
+        const dh_la &L = las[v[(size_t)e * 3 + 1]], &R = las[v[(size_t)e * 3 + 2]];
+        const int64_t len = (int64_t)(L.aepos - L.abpos) + (R.aepos - R.abpos);
+        key[(size_t)e] = std::make_pair(((int64_t)L.diffs + R.diffs) * 1000000 / std::max<int64_t>(len, 1), e);
+    }
+    std::sort(key.begin(), key.end());  // entries are in read-id order, so e breaks ties by read id
+    std::vector<int32_t> keep((size_t)o.max_reads);
+    for (int32_t x = 0; x < o.max_reads; x++) keep[(size_t)x] = key[(size_t)x].second;
+    std::sort(keep.begin(), keep.end());
+    std::vector<int32_t> w;
+    w.reserve((size_t)o.max_reads * 3);
+    for (int32_t e : keep) w.insert(w.end(), v.begin() + (size_t)e * 3, v.begin() + (size_t)e * 3 + 3);
+    v.swap(w);
+    return true;
+}
+
+extern "C" int dh_collect_candidates(const dh_la *las, int64_t n, const int64_t *contig_off, int32_t ncontigs,
+                                     const dh_process_opts *opts, dh_pileups **out)
+{
+    if ((n > 0 && !las) || !contig_off || !opts || !out || ncontigs < 0)
+        return dh_fail(DH_EINVAL, "dh_collect_candidates: bad argument");
+    return collect_candidates(las, n, contig_off, ncontigs, *opts, out);
+}
+
+extern "C" int dh_pileups_select(const dh_pileups *cands, const dh_la *las, int64_t n,
+                                 const dh_process_opts *opts, dh_pileups **out)
+{
+    if (!cands || !opts || !out || (n > 0 && !las)) return dh_fail(DH_EINVAL, "dh_pileups_select: bad argument");
+    dh_pileups *p = new dh_pileups();
+    for (size_t i = 0; i < cands->contig_left.size(); i++) {
+        std::vector<int32_t> v = cands->triples[i];
+        for (size_t e = 0; e < v.size(); e += 3)
+            if (v[e + 1] < 0 || v[e + 1] >= n || v[e + 2] < 0 || v[e + 2] >= n) {
+                delete p;
+                return dh_fail(DH_EINVAL, "dh_pileups_select: LA index out of range");
+            }
+        if (!select_pile(v, las, *opts)) continue;
+        p->contig_left.push_back(cands->contig_left[i]);
         p->triples.push_back(std::move(v));
     }
     *out = p;
     return DH_OK;
+}
+
+extern "C" int dh_pileups_create(const int32_t *contig_left, const int32_t *count, int32_t npiles,
+                                 const int32_t *triples, dh_pileups **out)
+{
+    if (npiles < 0 || !out || (npiles > 0 && (!contig_left || !count || !triples)))
+        return dh_fail(DH_EINVAL, "dh_pileups_create: bad argument");
+    dh_pileups *p = new dh_pileups();
+    int64_t at = 0;
+    for (int32_t i = 0; i < npiles; i++) {
+        if (count[i] < 0 || contig_left[i] < 0 || (i > 0 && contig_left[i] <= contig_left[i - 1])) {
+            delete p;
+            return dh_fail(DH_EINVAL, "dh_pileups_create: pile-ups must be ordered by contig and counts >= 0");
+        }
+        p->contig_left.push_back(contig_left[i]);
+        p->triples.emplace_back(triples + at * 3, triples + (at + count[i]) * 3);
+        at += count[i];
+    }
+    *out = p;
+    return DH_OK;
+}
+
+extern "C" int dh_collect_spanning(const dh_la *las, int64_t n, const int64_t *contig_off,
+                                   int32_t ncontigs, const dh_process_opts *opts, dh_pileups **out)
+{
+    if ((n > 0 && !las) || !contig_off || !opts || !out || ncontigs < 0)
+        return dh_fail(DH_EINVAL, "dh_collect_spanning: bad argument");
+    dh_pileups *c = nullptr;
+    if (int rc = collect_candidates(las, n, contig_off, ncontigs, *opts, &c)) return rc;
+    const int rc = dh_pileups_select(c, las, n, opts, out);
+    delete c;
+    return rc;
 }
 
 extern "C" void dh_pileups_destroy(dh_pileups *p) { delete p; }
@@ -778,7 +873,7 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
         }
         const int32_t cnt = (int32_t)(poff.size() - mark_seqs);
         r.nreads = cnt;
-        if (cnt < 3) {
+        if (cnt < o.min_reads) {
             r.status = DH_PILE_TOO_SMALL;
             parts.resize(mark_parts);
             poff.resize(mark_seqs);

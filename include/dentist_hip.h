@@ -137,6 +137,15 @@ int dh_get_cum_stats(dh_ctx *ctx, dh_cum_stats *out, int32_t reset);
 int dh_align_db(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, int32_t select_best,
                 dh_la_set **out);
 
+/* One read block against the whole reference, the unit the workflow shards the mapping by
+ * (`damapper <ref> <reads>.<block>`, snakemake/Snakefile:1143-1170; blocks = DBsplit ranges of one
+ * DB): reads [first, first + count) of B; bread in the records are ids of the whole DB.  The k-mer
+ * index of A is built once and stays with A between calls.  dh_la_set_merge is LAmerge
+ * (Snakefile:1173-1185) on the in-memory results: one set in LAsort order. */
+int dh_align_db_block(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t count,
+                      const dh_align_opts *opts, int32_t select_best, dh_la_set **out);
+int dh_la_set_merge(const dh_la_set *const *sets, int32_t nsets, dh_la_set **out);
+
 /* ---- .las files: replaces the reader/writer pair of source/dentist/dazzler.d:1665-1834
  *      (LocalAlignmentReader) and :1913-1960, 2130-2170 (writeAlignments/writeDazzlerOverlap). */
 int dh_las_write(const char *path, const dh_la *las, int64_t n, const uint16_t *trace,
@@ -169,9 +178,24 @@ void dh_default_process_opts(dh_process_opts *o);
 typedef struct dh_pileups dh_pileups;
 /* las/trace: read->contig LAs (A = contig, B = read) as returned by dh_align_db.  A read spans
  * the gap between contig c and c+1 when it has an LA reaching the end of c and an LA starting at
- * the begin of c+1, same orientation, in read order, both anchors >= min_anchor. */
+ * the begin of c+1, same orientation, in read order, both anchors >= min_anchor.  Every read
+ * enters a pile-up once (its pair of LAs with the longest anchors); pile-ups with fewer than
+ * min_reads reads are dropped (commandline.d:2125-2187); of more than max_reads the max_reads
+ * reads whose anchoring LAs have the lowest error rate are kept (ties: lower read id).
+ *   dh_collect_spanning   = dh_collect_candidates + dh_pileups_select
+ *   dh_collect_candidates   every spanning read of every gap, no cut (the multi-GPU path exchanges
+ *                           candidates between ranks first)
+ *   dh_pileups_create       pile-ups from explicit arrays: npiles gaps ordered by contig_left,
+ *                           count[i] (read, left LA index, right LA index) triples each
+ *   dh_pileups_select       the min_reads / max_reads cut on a candidate set */
 int dh_collect_spanning(const dh_la *las, int64_t n, const int64_t *contig_off, int32_t ncontigs,
                         const dh_process_opts *opts, dh_pileups **out);
+int dh_collect_candidates(const dh_la *las, int64_t n, const int64_t *contig_off, int32_t ncontigs,
+                          const dh_process_opts *opts, dh_pileups **out);
+int dh_pileups_create(const int32_t *contig_left, const int32_t *count, int32_t npiles,
+                      const int32_t *triples, dh_pileups **out);
+int dh_pileups_select(const dh_pileups *cands, const dh_la *las, int64_t n, const dh_process_opts *opts,
+                      dh_pileups **out);
 void dh_pileups_destroy(dh_pileups *p);
 int32_t dh_pileups_count(const dh_pileups *p);
 /* pile-up i: left contig id (gap lies between it and the next contig), number of reads, and the

@@ -19,16 +19,21 @@ MAX_PILE = 60          # reads kept per pile-up (one wavefront tracks <= 64 alig
 MAX_INS_ERR_PPM = 100000  # commandline.d:1997 maxInsertionError 0.10
 
 
-def collect_spanning(las, trace, contigs, reads, allowance=ALLOWANCE_MAP, min_anchor=MIN_ANCHOR):
+def collect_spanning(las, trace, contigs, reads, allowance=ALLOWANCE_MAP, min_anchor=MIN_ANCHOR, min_reads=3,
+                     max_reads=MAX_PILE):
     """Gap g lies between contig g and g+1.  A read spans it when it has an LA reaching the end of
-    contig g and an LA starting at the begin of contig g+1, same orientation, in read order."""
+    contig g and an LA starting at the begin of contig g+1, same orientation, in read order.  A read
+    enters a pile-up once: with its qualifying pair of the longest anchors (ties: lowest indices)."""
     by_read = {}
     for i, la in enumerate(las):
         by_read.setdefault(int(la["bread"]), []).append(i)
     piles = {}
     for r, idxs in sorted(by_read.items()):
+        best = {}
         for iL in idxs:
             L = las[iL]
+            if int(L["aread"]) + 1 >= contigs.n:
+                continue
             cl = contigs.length(int(L["aread"]))
             if L["aepos"] + allowance < cl or L["aepos"] - L["abpos"] < min_anchor:
                 continue
@@ -40,8 +45,25 @@ def collect_spanning(las, trace, contigs, reads, allowance=ALLOWANCE_MAP, min_an
                     continue
                 if R["bbpos"] + allowance < L["bepos"] - allowance:  # right part must follow the left part
                     continue
-                piles.setdefault(int(L["aread"]), []).append((r, iL, iR))
-    return {g: v[:MAX_PILE] for g, v in piles.items() if len(v) >= 3}  # min-reads-per-pile-up 3
+                anchors = int(L["aepos"] - L["abpos"]) + int(R["aepos"] - R["abpos"])
+                g = int(L["aread"])
+                if g not in best or anchors > best[g][0]:
+                    best[g] = (anchors, iL, iR)
+        for g, (_, iL, iR) in best.items():
+            piles.setdefault(g, []).append((r, iL, iR))
+    out = {}
+    for g, v in piles.items():
+        if len(v) < min_reads:   # min-reads-per-pile-up (commandline.d:2125-2187)
+            continue
+        if len(v) > max_reads:   # keep the reads whose anchoring LAs have the lowest error rate
+            def err(e):
+                L, R = las[e[1]], las[e[2]]
+                ln = int(L["aepos"] - L["abpos"]) + int(R["aepos"] - R["abpos"])
+                return (int(L["diffs"]) + int(R["diffs"])) * 1000000 // max(ln, 1)
+            keep = sorted(range(len(v)), key=lambda x: (err(v[x]), x))[:max_reads]
+            v = [v[x] for x in sorted(keep)]
+        out[g] = v
+    return out
 
 
 def ceil_to(x, m):

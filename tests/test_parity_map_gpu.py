@@ -78,6 +78,24 @@ def test_long_kmers_like_damapper(gpu_ctx, k, mod):
     assert len(set(las["bread"].tolist())) >= 0.99 * w.reads.n
 
 
+def test_read_blocks_merged_equal_the_single_call(gpu_ctx, monkeypatch):
+    """dh_align_db_block per DBsplit-style block + dh_la_set_merge (LAmerge) == dh_align_db of the
+    whole DB; with a small DH_ALIGN_CHUNK the single call runs its own chunk loop, whose derived
+    copies (reverse complement, 2-bit packed) are made per chunk in scratch memory."""
+    w = sim.Workload(300_000, 3, 900, 5000, seed=53, spacing=15000)
+    g, o = both_opts(kmer_mod=2)
+    exp = oz.align_db(w.contigs, w.reads, o, nthreads=os.cpu_count() or 1)
+    A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
+    bounds = [0, 1, 250, 251, 600, 900]
+    hs = [gpu_ctx.align_db_block(A, B, bounds[i], bounds[i + 1] - bounds[i], g, raw=True) for i in range(len(bounds) - 1)]
+    assert_same_las(dentist_amd.merge_las(hs), exp[:2])
+    monkeypatch.setenv("DH_ALIGN_CHUNK", "300")
+    B.drop_cache()
+    assert_same_las(gpu_ctx.align_db(A, B, g), exp[:2])
+    with pytest.raises(dentist_amd.DhError):
+        gpu_ctx.align_db_block(A, B, 800, 200, g)
+
+
 def test_long_b_sequences_use_the_hbm_staged_seed_path(gpu_ctx):
     """Contigs as B against an index of the reads (the transposed `damapper -C` file): far more
     than 16384 k-mer hits per sequence -> hits are staged in HBM, results still bit-exact."""

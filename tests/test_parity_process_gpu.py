@@ -153,3 +153,59 @@ def test_config1_full_size_properties(gpu_ctx):
     assert_same_las((las2, trace2), (las, trace))
     rec2, bases2 = dentist_amd.process_pileups(gpu_ctx, A, B, las2, trace2, dentist_amd.Pileups(las2, w.contigs.off, po), po)
     assert np.array_equal(rec2, rec) and np.array_equal(bases2, bases)
+
+
+def test_config2_full_size_properties(gpu_ctx):
+    """BASELINE configs[2], the headline workload (100 Mb assembly, 1 000 gaps, 1 M x 15 kb reads at
+    13 %, 15.7 Gbp): the mapping runs as a loop over read blocks against the persistent contig index
+    (snakemake/Snakefile:1143-1170) merged in memory (LAmerge, :1173-1185) and must equal the single
+    call bit for bit; then the size-independent properties of the whole hot path: placement of every
+    mapped read, trace invariants, >= 99 % of the gaps closed, consensus <= 0.1 % from the truth,
+    idempotence of the process stage."""
+    from helpers import check_trace_invariants
+    w = sim.Workload(100_000_000, 1000, 1_000_000, 15_000, seed=20260929)
+    A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
+    mo = dentist_amd.default_align_opts(kmer_mod=4, k=20)
+    po = dentist_amd.default_process_opts()
+    nblocks = 8
+    bounds = [w.reads.n * b // nblocks for b in range(nblocks + 1)]
+    handles = [gpu_ctx.align_db_block(A, B, bounds[b], bounds[b + 1] - bounds[b], mo, select_best=True, raw=True)
+               for b in range(nblocks)]
+    las, trace = dentist_amd.merge_las(handles)
+    check_trace_invariants(las[:: max(1, len(las) // 3000)], trace, 100)
+    assert len(set(las["bread"].tolist())) >= 0.995 * w.reads.n
+    key = las["aread"].astype(np.int64) << 32 | las["bread"]
+    assert np.all(np.diff(key) >= 0), "merged blocks are not in LAsort order"
+    s, e = w.read_truth[las["bread"], 0], w.read_truth[las["bread"], 1]
+    cs = w.contig_start[las["aread"]]
+    ok = ((las["flags"] & 1) == w.read_truth[las["bread"], 2]) & (cs + las["abpos"] >= s - 80) & (cs + las["aepos"] <= e + 80)
+    assert ok.mean() > 0.999
+    piles = dentist_amd.Pileups(las, w.contigs.off, po)
+    assert len(piles) == 1000
+    rec, bases = dentist_amd.process_pileups(gpu_ctx, A, B, las, trace, piles, po)
+    closed = rec[rec["status"] == 0]
+    assert len(closed) >= 990
+    edits = total = 0
+    for r in closed:
+        g = int(r["contig_left"])
+        cons = bases[r["cons_off"]:r["cons_off"] + r["cons_len"]]
+        cseq = sim.revcomp(cons) if r["comp"] else cons
+        ins = cseq[r["ins_begin"]:r["ins_end"]]
+        truth = w.truth[w.contig_start[g] + r["left_aepos"]: w.gap_end[g] + r["right_abpos"]]
+        ed, _ = oz.nw(truth, ins)
+        edits += ed
+        total += len(truth)
+    assert edits <= 0.001 * total, (edits, total)
+    # the whole DB in one call (internal chunk loop, every cache dropped) gives the same records
+    A.drop_cache()
+    B.drop_cache()
+    las2, trace2 = gpu_ctx.align_db(A, B, mo, select_best=True)
+    assert len(las2) == len(las)
+    for f in ("tlen", "diffs", "abpos", "bbpos", "aepos", "bepos", "flags", "aread", "bread"):
+        assert np.array_equal(las2[f], las[f]), f
+    idx = np.arange(0, len(las), max(1, len(las) // 20000))
+    for i in idx:
+        a, b = las[i], las2[i]
+        assert np.array_equal(trace[a["toff"]:a["toff"] + a["tlen"]], trace2[b["toff"]:b["toff"] + b["tlen"]])
+    rec2, bases2 = dentist_amd.process_pileups(gpu_ctx, A, B, las2, trace2, dentist_amd.Pileups(las2, w.contigs.off, po), po)
+    assert np.array_equal(rec2, rec) and np.array_equal(bases2, bases)
