@@ -75,6 +75,9 @@ SYMBOLS = [
     "dh_dazz_origin", "dh_dazz_fpulse", "dh_dazz_header", "dh_dazz_read_mask", "dh_dazz_write_mask",
     "dh_db_set_mask", "dh_output_fasta", "dh_tile_qv", "dh_consensus", "dh_las_merge",
     "dh_collect_candidates", "dh_pileups_create", "dh_pileups_select", "dh_align_db_block", "dh_la_set_merge",
+    "dh_crop_pileups", "dh_cropped_create", "dh_cropped_destroy", "dh_cropped_npiles", "dh_cropped_records",
+    "dh_cropped_nreads", "dh_cropped_pile", "dh_cropped_entry", "dh_cropped_read_id", "dh_cropped_offsets",
+    "dh_cropped_bases", "dh_process_cropped",
 ]
 
 _LIB = None
@@ -133,6 +136,17 @@ def lib():
     L.dh_pileups_get.argtypes = [vp, i32, ctypes.POINTER(i32), ctypes.POINTER(vp)]
     L.dh_pileups_get.restype = i32
     L.dh_process_pileups.argtypes = [vp, vp, vp, vp, i64, vp, vp, ctypes.POINTER(ProcessOpts), ctypes.POINTER(vp)]
+    L.dh_crop_pileups.argtypes = [vp, vp, vp, i32, vp, i64, vp, vp, ctypes.POINTER(ProcessOpts), ctypes.POINTER(vp)]
+    L.dh_cropped_create.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, ctypes.POINTER(vp)]
+    L.dh_cropped_destroy.argtypes = [vp]
+    for fn in (L.dh_cropped_npiles, L.dh_cropped_nreads):
+        fn.argtypes = [vp]
+        fn.restype = i32
+    for fn in (L.dh_cropped_records, L.dh_cropped_pile, L.dh_cropped_entry, L.dh_cropped_read_id,
+               L.dh_cropped_offsets, L.dh_cropped_bases):
+        fn.argtypes = [vp]
+        fn.restype = vp
+    L.dh_process_cropped.argtypes = [vp, vp, vp, ctypes.POINTER(ProcessOpts), ctypes.POINTER(vp)]
     L.dh_insertions_destroy.argtypes = [vp]
     L.dh_insertions_count.argtypes = [vp]
     L.dh_insertions_count.restype = i32
@@ -414,6 +428,76 @@ class Pileups:
             self.close()
         except Exception:
             pass
+
+
+class Cropped:
+    """Cropped pile-ups (dh_cropped): per pile-up record + per cropped read (pile, entry, read id, bases)."""
+
+    def __init__(self, h):
+        self._h = h
+
+    @classmethod
+    def crop(cls, ctx, contigs, reads, read_first, las, trace, piles, opts):
+        arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
+        tr = np.ascontiguousarray(trace, dtype=np.uint16)
+        h = ctypes.c_void_p()
+        _check(lib().dh_crop_pileups(ctx._h, contigs._h, reads._h, read_first, arr.ctypes.data, len(arr),
+                                     tr.ctypes.data if len(tr) else None, piles._h, ctypes.byref(opts), ctypes.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def create(cls, rec, pile, entry, read_id, off, bases):
+        r = np.ascontiguousarray(rec, dtype=INSERTION_DTYPE)
+        pi, en, ri = (np.ascontiguousarray(x, dtype=np.int32) for x in (pile, entry, read_id))
+        of = np.ascontiguousarray(off, dtype=np.int64)
+        ba = np.ascontiguousarray(bases, dtype=np.uint8)
+        h = ctypes.c_void_p()
+        _check(lib().dh_cropped_create(r.ctypes.data, len(r), len(pi), pi.ctypes.data, en.ctypes.data, ri.ctypes.data,
+                                       of.ctypes.data, ba.ctypes.data if len(ba) else None, ctypes.byref(h)))
+        return cls(h)
+
+    def arrays(self):
+        """(records, pile, entry, read_id, off, bases) as numpy copies (bases come over PCIe)."""
+        L, h = lib(), self._h
+        npl, nr = L.dh_cropped_npiles(h), L.dh_cropped_nreads(h)
+
+        def arr(ptr, n, dt):
+            return np.frombuffer(ctypes.string_at(ptr, n * np.dtype(dt).itemsize), dtype=dt).copy() if n else np.zeros(0, dt)
+        rec = arr(L.dh_cropped_records(h), npl, INSERTION_DTYPE)
+        off = arr(L.dh_cropped_offsets(h), nr + 1, np.int64) if nr else np.zeros(1, np.int64)
+        bp = L.dh_cropped_bases(h)
+        if not bp:
+            _check(-3)
+        return (rec, arr(L.dh_cropped_pile(h), nr, np.int32), arr(L.dh_cropped_entry(h), nr, np.int32),
+                arr(L.dh_cropped_read_id(h), nr, np.int32), off, arr(bp, int(off[-1]), np.uint8))
+
+    def process(self, ctx, contigs, opts):
+        h = ctypes.c_void_p()
+        _check(lib().dh_process_cropped(ctx._h, contigs._h, self._h, ctypes.byref(opts), ctypes.byref(h)))
+        return _take_insertions(h)
+
+    def close(self):
+        if self._h:
+            lib().dh_cropped_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _take_insertions(h):
+    L = lib()
+    n = L.dh_insertions_count(h)
+    nb = L.dh_insertions_bases_len(h)
+    rec = (np.frombuffer(ctypes.string_at(L.dh_insertions_records(h), n * INSERTION_DTYPE.itemsize),
+                         dtype=INSERTION_DTYPE).copy() if n else np.zeros(0, dtype=INSERTION_DTYPE))
+    bases = (np.frombuffer(ctypes.string_at(L.dh_insertions_bases(h), nb), dtype=np.uint8).copy()
+             if nb else np.zeros(0, dtype=np.uint8))
+    L.dh_insertions_destroy(h)
+    return rec, bases
 
 
 def process_pileups(ctx, contigs, reads, las, trace, piles, opts):

@@ -481,7 +481,7 @@ static int build_index(dh_db *A, int32_t k, int32_t sepv, int32_t kmer_mod)
     for (int32_t s = 0; s < A->n; s++) {
         goff[(size_t)s] = g;
         const int64_t len = A->h_off[(size_t)s + 1] - A->h_off[(size_t)s];
-        g += len + sepv;
+        g += (len + sepv + 4095) & ~4095ll;  // 4096-aligned starts: see sepv in align_range
         if (len >= k) {
             nk += len - k + 1;
             for (int64_t st = 0; st < len - k + 1; st += KM_TILE) tiles.push_back(int2{s, (int32_t)st});
@@ -756,7 +756,10 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     } guard{res};
 
     HIPCHK(hipEventRecord(ctx->ev[0], st));
-    const int32_t sepv = ((B->max_len + 64) + 63) & ~63;
+    // A sequences start at multiples of 4096 on the virtual axis and sepv is one too, so the
+    // position of a hit inside its diagonal band (2^band_shift <= 4096 wide) depends only on the
+    // pair (A sequence, B read) -- never on which other sequences share the DB or the launch
+    const int32_t sepv = (B->max_len + 64 + 4095) & ~4095;
     if (int rc = build_index(A, o.k, sepv, o.kmer_mod)) return rc;
     // B's derived copies (reverse complement, 2-bit packed) live with the DB when the whole DB is
     // one chunk of this call (pile-up and template DBs are re-aligned several times); a block of a

@@ -735,12 +735,254 @@ extern "C" int dh_consensus(dh_ctx *ctx, dh_db *db, const dh_la *las, int64_t n,
     return DH_OK;
 }
 
+// ------------------------------------------------------------------------------------ crop stage
+struct dh_cropped;
+extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop, const dh_process_opts *opts,
+                                  dh_insertions **out);
+
+// What `dentist process` holds after cropPileUp (cropper.d:113-175): per pile-up the common trace
+// points, per cropped read its pile-up, its position in the pile-up's read list, its read id and
+// its bases ([support patch] + read slice + [support patch]).  The bases live on the device
+// (`dev`, an ungrouped DB in (pile, entry) order) and/or on the host.
+struct dh_cropped {
+    dh_ctx *ctx = nullptr;
+    std::vector<dh_insertion> rec;
+    std::vector<int32_t> pile, entry, read_id;
+    std::vector<int64_t> off{0};
+    std::vector<uint8_t> bases;
+    bool host_valid = false;
+    dh_db *dev = nullptr;
+    float ms_crop = 0;
+};
+
+extern "C" void dh_cropped_destroy(dh_cropped *c)
+{
+    if (!c) return;
+    if (c->dev) dh_db_destroy(c->dev);
+    delete c;
+}
+extern "C" int32_t dh_cropped_npiles(const dh_cropped *c) { return c ? (int32_t)c->rec.size() : 0; }
+extern "C" const dh_insertion *dh_cropped_records(const dh_cropped *c) { return c ? c->rec.data() : nullptr; }
+extern "C" int32_t dh_cropped_nreads(const dh_cropped *c) { return c ? (int32_t)c->pile.size() : 0; }
+extern "C" const int32_t *dh_cropped_pile(const dh_cropped *c) { return c ? c->pile.data() : nullptr; }
+extern "C" const int32_t *dh_cropped_entry(const dh_cropped *c) { return c ? c->entry.data() : nullptr; }
+extern "C" const int32_t *dh_cropped_read_id(const dh_cropped *c) { return c ? c->read_id.data() : nullptr; }
+extern "C" const int64_t *dh_cropped_offsets(const dh_cropped *c) { return c ? c->off.data() : nullptr; }
+extern "C" const uint8_t *dh_cropped_bases(dh_cropped *c)
+{
+    if (!c) return nullptr;
+    if (!c->host_valid) {
+        c->bases.resize((size_t)std::max<int64_t>(c->off.back(), 1));
+        if (c->dev && c->off.back() > 0) {
+            if (hipSetDevice(c->ctx->device) != hipSuccess ||
+                hipMemcpyAsync(c->bases.data(), c->dev->d_bases, (size_t)c->off.back(), hipMemcpyDeviceToHost,
+                               c->ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(c->ctx->stream) != hipSuccess) {
+                dh_fail(DH_EHIP, "dh_cropped_bases: device to host copy failed");
+                return nullptr;
+            }
+        }
+        c->host_valid = true;
+    }
+    return c->bases.data();
+}
+
+extern "C" int dh_cropped_create(const dh_insertion *rec, int32_t npiles, int32_t nreads, const int32_t *pile,
+                                 const int32_t *entry, const int32_t *read_id, const int64_t *off,
+                                 const uint8_t *bases, dh_cropped **out)
+{
+    if (npiles < 0 || nreads < 0 || !out || (npiles > 0 && !rec) ||
+        (nreads > 0 && (!pile || !entry || !read_id || !off || !bases)))
+        return dh_fail(DH_EINVAL, "dh_cropped_create: bad argument");
+    dh_cropped *c = new dh_cropped();
+    c->rec.assign(rec, rec + npiles);
+    if (nreads > 0) {
+        if (off[0] != 0) {
+            delete c;
+            return dh_fail(DH_EINVAL, "dh_cropped_create: off[0] must be 0");
+        }
+        for (int32_t i = 0; i < nreads; i++)
+            if (pile[i] < 0 || pile[i] >= npiles || off[i + 1] < off[i] ||
+                (i > 0 && (pile[i] < pile[i - 1] || (pile[i] == pile[i - 1] && entry[i] <= entry[i - 1])))) {
+                delete c;
+                return dh_fail(DH_EINVAL, "dh_cropped_create: reads must be ordered by (pile, entry)");
+            }
+        c->pile.assign(pile, pile + nreads);
+        c->entry.assign(entry, entry + nreads);
+        c->read_id.assign(read_id, read_id + nreads);
+        c->off.assign(off, off + nreads + 1);
+        c->bases.assign(bases, bases + off[nreads]);
+    }
+    c->host_valid = true;
+    *out = c;
+    return DH_OK;
+}
+
+// cropPileUp for a batch (cropper.d:113-175, 446-550): common trace point per flank from ALL entries
+// of a pile-up; bases are cut for the entries whose read is in `reads` -- read ids in the triples
+// are ids of the whole reads DB, `reads` holds [read_first, read_first + reads->n) of it (one rank's
+// share when the mapping is sharded; read_first = 0 and the whole DB otherwise).  LAs of reads that
+// are not held here only need their A intervals (no trace).
+extern "C" int dh_crop_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_t read_first, const dh_la *las,
+                               int64_t n, const uint16_t *trace, const dh_pileups *piles,
+                               const dh_process_opts *opts, dh_cropped **out)
+{
+    if (!ctx || !contigs || !reads || !piles || !opts || !out || (n > 0 && !las))
+        return dh_fail(DH_EINVAL, "dh_crop_pileups: NULL argument");
+    const dh_process_opts &o = *opts;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    hipEvent_t ev[2];
+    for (auto &e : ev) HIPCHK(hipEventCreate(&e));
+    struct EvGuard {
+        hipEvent_t *e;
+        ~EvGuard()
+        {
+            for (int i = 0; i < 2; i++) (void)hipEventDestroy(e[i]);
+        }
+    } evg{ev};
+    HIPCHK(hipEventRecord(ev[0], st));
+    dh_cropped *c = new dh_cropped();
+    c->ctx = ctx;
+    struct CGuard {
+        dh_cropped *&c;
+        bool ok = false;
+        ~CGuard()
+        {
+            if (!ok) dh_cropped_destroy(c);
+        }
+    } cg{c};
+    const int32_t np = (int32_t)piles->contig_left.size();
+    c->rec.resize((size_t)np);
+    const int32_t tsm = o.tspace_map;
+    // every pile-up read = [support patch] + read slice + [support patch]; parts are gathered on
+    // the device from the reads DB (src 0) and the contigs DB (src 1)
+    std::vector<PartDescH> parts;
+    int32_t pile_max_len = 0;
+    for (int32_t p = 0; p < np; p++) {
+        dh_insertion &r = c->rec[(size_t)p];
+        memset(&r, 0, sizeof(r));
+        const int32_t g = piles->contig_left[(size_t)p];
+        if (g < 0 || g + 1 >= contigs->n) return dh_fail(DH_EINVAL, "dh_crop_pileups: gap outside the contigs DB");
+        r.contig_left = g;
+        r.ref_read = r.ref_read_id = -1;
+        r.crop_left = r.crop_right = -1;
+        const std::vector<int32_t> &tr3 = piles->triples[(size_t)p];
+        const int32_t ne = (int32_t)tr3.size() / 3;
+        int32_t llo = 0, lhi = INT32_MAX, rlo = 0, rhi = INT32_MAX;
+        for (int32_t e = 0; e < ne; e++) {
+            const int32_t iL = tr3[(size_t)e * 3 + 1], iR = tr3[(size_t)e * 3 + 2];
+            if (iL < 0 || iL >= n || iR < 0 || iR >= n) return dh_fail(DH_EINVAL, "dh_crop_pileups: LA index out of range");
+            const dh_la &L = las[iL], &R = las[iR];
+            llo = std::max(llo, L.abpos);
+            lhi = std::min(lhi, L.aepos);
+            rlo = std::max(rlo, R.abpos);
+            rhi = std::min(rhi, R.aepos);
+        }
+        const int32_t cll = (int32_t)(contigs->h_off[(size_t)g + 1] - contigs->h_off[(size_t)g]);
+        const int32_t clr = (int32_t)(contigs->h_off[(size_t)g + 2] - contigs->h_off[(size_t)g + 1]);
+        const int32_t cropL = common_trace_point(llo, lhi, cll, tsm, false);
+        const int32_t cropR = common_trace_point(rlo, rhi, clr, tsm, true);
+        r.crop_left = cropL;
+        r.crop_right = cropR;
+        if (cropL < 0 || cropR < 0) {
+            r.status = DH_PILE_NO_COMMON_TRACE_POINT;
+            continue;
+        }
+        // fetchSupportPatches, cropper.d:224-262
+        int32_t lp0 = 0, lp1 = 0, rp0 = 0, rp1 = 0;
+        if (cll - cropL < o.min_anchor) {
+            lp0 = std::max(0, cll - o.min_anchor);
+            lp1 = cropL;
+        }
+        if (cropR < o.min_anchor) {
+            rp0 = cropR;
+            rp1 = std::min(clr, o.min_anchor);
+        }
+        for (int32_t e = 0; e < ne; e++) {
+            const int32_t rd = tr3[(size_t)e * 3];
+            const int64_t lrd = (int64_t)rd - read_first;
+            if (lrd < 0 || lrd >= reads->n) continue;  // held by another rank
+            if (!trace) return dh_fail(DH_EINVAL, "dh_crop_pileups: trace is NULL");
+            const dh_la &L = las[tr3[(size_t)e * 3 + 1]], &R = las[tr3[(size_t)e * 3 + 2]];
+            const int32_t bL = translate_floor_b(L, trace + L.toff, tsm, cropL);
+            const int32_t bR = translate_floor_b(R, trace + R.toff, tsm, cropR);
+            const int32_t rl = (int32_t)(reads->h_off[(size_t)lrd + 1] - reads->h_off[(size_t)lrd]);
+            int32_t b0 = bL, b1 = bR;
+            const bool comp = (L.flags & DH_FLAG_COMP) != 0;
+            if (comp) {  // getCroppingSlice, cropper.d:533-538
+                b0 = rl - bR;
+                b1 = rl - bL;
+            }
+            if (b1 - b0 < 14) continue;  // records shorter than 14 bp are dropped (dazzler.d:150)
+            if (b0 < 0 || b1 > rl) return dh_fail(DH_EINVAL, "dh_crop_pileups: trace does not fit its read");
+            int64_t dst = c->off.back();
+            // getSingleReadPatch, cropper.d:363-378: complement reads get the reverse-complemented
+            // patches in swapped positions
+            const int32_t pre_c = comp ? g + 1 : g, pre0 = comp ? rp0 : lp0, pre1 = comp ? rp1 : lp1;
+            const int32_t post_c = comp ? g : g + 1, post0 = comp ? lp0 : rp0, post1 = comp ? lp1 : rp1;
+            if (pre1 > pre0) {
+                parts.push_back(PartDescH{1, pre_c, pre0, pre1 - pre0, comp ? 1 : 0, 0, dst});
+                dst += pre1 - pre0;
+            }
+            parts.push_back(PartDescH{0, (int32_t)lrd, b0, b1 - b0, 0, 0, dst});
+            dst += b1 - b0;
+            if (post1 > post0) {
+                parts.push_back(PartDescH{1, post_c, post0, post1 - post0, comp ? 1 : 0, 0, dst});
+                dst += post1 - post0;
+            }
+            pile_max_len = std::max<int32_t>(pile_max_len, (int32_t)(dst - c->off.back()));
+            c->off.push_back(dst);
+            c->pile.push_back(p);
+            c->entry.push_back(e);
+            c->read_id.push_back(rd);
+            r.nreads++;
+        }
+    }
+    {
+        uint8_t *d_alloc = nullptr, *d_bases = nullptr;
+        if (int rc = dh_alloc_bases(st, c->off.back(), &d_alloc, &d_bases)) return rc;
+        if (int rc = dh_db_adopt(ctx, d_alloc, d_bases, c->off, std::vector<int32_t>(), &c->dev)) {
+            dh_dev_free(d_alloc);
+            return rc;
+        }
+        if (!parts.empty()) {
+            DevBuf<PartDescH> d_parts;
+            HIPCHK(d_parts.alloc(parts.size()));
+            HIPCHK(hipMemcpyAsync(d_parts.p, parts.data(), sizeof(PartDescH) * parts.size(), hipMemcpyHostToDevice, st));
+            dhk_gather_parts(st, reads->d_bases, reads->d_off, contigs->d_bases, contigs->d_off, d_parts.p,
+                             (int32_t)parts.size(), pile_max_len, d_bases);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(st));
+        }
+    }
+    HIPCHK(hipEventRecord(ev[1], st));
+    HIPCHK(hipEventSynchronize(ev[1]));
+    HIPCHK(hipEventElapsedTime(&c->ms_crop, ev[0], ev[1]));
+    cg.ok = true;
+    *out = c;
+    return DH_OK;
+}
+
 extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, const dh_la *las, int64_t n,
                                   const uint16_t *trace, const dh_pileups *piles,
                                   const dh_process_opts *opts, dh_insertions **out)
 {
     if (!ctx || !contigs || !reads || !piles || !opts || !out || (n > 0 && (!las || !trace)))
         return dh_fail(DH_EINVAL, "dh_process_pileups: NULL argument");
+    dh_cropped *c = nullptr;
+    if (int rc = dh_crop_pileups(ctx, contigs, reads, 0, las, n, trace, piles, opts, &c)) return rc;
+    const int rc = dh_process_cropped(ctx, contigs, c, opts, out);
+    dh_cropped_destroy(c);
+    return rc;
+}
+
+// The pile-up stages of `dentist process` after the crop (package.d:283-374): pile-up alignment ->
+// filter -> tile QV -> reference read -> consensus -> flank re-alignment -> insertion.
+extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop, const dh_process_opts *opts,
+                                  dh_insertions **out)
+{
+    if (!ctx || !contigs || !crop || !opts || !out) return dh_fail(DH_EINVAL, "dh_process_cropped: NULL argument");
     const dh_process_opts &o = *opts;
     if (o.max_reads < 3 || o.max_reads > 60) return dh_fail(DH_EINVAL, "max_reads must be in [3, 60]");
     if (o.rounds < 1 || o.rounds > 8) return dh_fail(DH_EINVAL, "rounds must be in [1, 8]");
@@ -748,6 +990,7 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     ProcStats ps;
+    ps.ms[0] = crop->ms_crop;
     hipEvent_t ev[8];
     for (auto &e : ev) HIPCHK(hipEventCreate(&e));
     struct EvGuard {
@@ -786,129 +1029,69 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
             if (!ok) delete r;
         }
     } rg{res};
-    const int32_t np = (int32_t)piles->contig_left.size();
-    res->rec.resize((size_t)np);
-    const int32_t tsm = o.tspace_map, tsp = o.tspace_pile;
+    const int32_t np = (int32_t)crop->rec.size();
+    res->rec = crop->rec;
+    const int32_t tsp = o.tspace_pile;
 
-    HIPCHK(hipEventRecord(ev[0], st));
-    // ---- 1. crop every pile-up to its common trace points; collect the slices of the reads
-    // every pile-up read = [support patch] + read slice + [support patch]; parts are gathered on
-    // the device from the reads DB (src 0) and the contigs DB (src 1)
-    std::vector<PartDescH> parts;
-    std::vector<int64_t> poff{0};                    // offsets of the pile-up DB sequences
-    std::vector<int32_t> sgroup;
+    // ---- 1. the pile-up DB: the cropped reads of every pile-up that is large enough, grouped by
+    // pile-up (group = index among the active pile-ups)
+    const int32_t ncr = (int32_t)crop->pile.size();
+    std::vector<int32_t> cnt_of((size_t)np, 0);
+    for (int32_t i = 0; i < ncr; i++) cnt_of[(size_t)crop->pile[(size_t)i]]++;
+    std::vector<int32_t> active_of((size_t)np, -1);
     std::vector<int32_t> pile_of_active;             // active index -> pile-up index
     std::vector<int32_t> first_read;                 // active index -> first read in pile-up DB
     std::vector<int32_t> read_id;                    // pile-up DB read -> read id in `reads`
-    int32_t pile_max_len = 0;
+    std::vector<int32_t> sgroup, keep;               // per pile-up DB read: group, index in the crop DB
     for (int32_t p = 0; p < np; p++) {
         dh_insertion &r = res->rec[(size_t)p];
-        memset(&r, 0, sizeof(r));
-        const int32_t g = piles->contig_left[(size_t)p];
-        r.contig_left = g;
-        r.ref_read = r.ref_read_id = -1;
-        r.crop_left = r.crop_right = -1;
-        const std::vector<int32_t> &tr3 = piles->triples[(size_t)p];
-        const int32_t ne = (int32_t)tr3.size() / 3;
-        int32_t llo = 0, lhi = INT32_MAX, rlo = 0, rhi = INT32_MAX;
-        for (int32_t e = 0; e < ne; e++) {
-            const dh_la &L = las[tr3[(size_t)e * 3 + 1]], &R = las[tr3[(size_t)e * 3 + 2]];
-            llo = std::max(llo, L.abpos);
-            lhi = std::min(lhi, L.aepos);
-            rlo = std::max(rlo, R.abpos);
-            rhi = std::min(rhi, R.aepos);
-        }
-        const int32_t cll = (int32_t)(contigs->h_off[(size_t)g + 1] - contigs->h_off[(size_t)g]);
-        const int32_t clr = (int32_t)(contigs->h_off[(size_t)g + 2] - contigs->h_off[(size_t)g + 1]);
-        const int32_t cropL = common_trace_point(llo, lhi, cll, tsm, false);
-        const int32_t cropR = common_trace_point(rlo, rhi, clr, tsm, true);
-        r.crop_left = cropL;
-        r.crop_right = cropR;
-        if (cropL < 0 || cropR < 0) {
-            r.status = DH_PILE_NO_COMMON_TRACE_POINT;
-            continue;
-        }
-        // fetchSupportPatches, cropper.d:224-262
-        int32_t lp0 = 0, lp1 = 0, rp0 = 0, rp1 = 0;
-        if (cll - cropL < o.min_anchor) {
-            lp0 = std::max(0, cll - o.min_anchor);
-            lp1 = cropL;
-        }
-        if (cropR < o.min_anchor) {
-            rp0 = cropR;
-            rp1 = std::min(clr, o.min_anchor);
-        }
-        const size_t mark_parts = parts.size(), mark_seqs = poff.size();
-        for (int32_t e = 0; e < ne; e++) {
-            const int32_t rd = tr3[(size_t)e * 3];
-            const dh_la &L = las[tr3[(size_t)e * 3 + 1]], &R = las[tr3[(size_t)e * 3 + 2]];
-            const int32_t bL = translate_floor_b(L, trace + L.toff, tsm, cropL);
-            const int32_t bR = translate_floor_b(R, trace + R.toff, tsm, cropR);
-            const int32_t rl = (int32_t)(reads->h_off[(size_t)rd + 1] - reads->h_off[(size_t)rd]);
-            int32_t b0 = bL, b1 = bR;
-            const bool comp = (L.flags & DH_FLAG_COMP) != 0;
-            if (comp) {  // getCroppingSlice, cropper.d:533-538
-                b0 = rl - bR;
-                b1 = rl - bL;
-            }
-            if (b1 - b0 < 14) continue;  // records shorter than 14 bp are dropped (dazzler.d:150)
-            int64_t dst = poff.back();
-            // getSingleReadPatch, cropper.d:363-378: complement reads get the reverse-complemented
-            // patches in swapped positions
-            const int32_t pre_c = comp ? g + 1 : g, pre0 = comp ? rp0 : lp0, pre1 = comp ? rp1 : lp1;
-            const int32_t post_c = comp ? g : g + 1, post0 = comp ? lp0 : rp0, post1 = comp ? lp1 : rp1;
-            if (pre1 > pre0) {
-                parts.push_back(PartDescH{1, pre_c, pre0, pre1 - pre0, comp ? 1 : 0, 0, dst});
-                dst += pre1 - pre0;
-            }
-            parts.push_back(PartDescH{0, rd, b0, b1 - b0, 0, 0, dst});
-            dst += b1 - b0;
-            if (post1 > post0) {
-                parts.push_back(PartDescH{1, post_c, post0, post1 - post0, comp ? 1 : 0, 0, dst});
-                dst += post1 - post0;
-            }
-            pile_max_len = std::max<int32_t>(pile_max_len, (int32_t)(dst - poff.back()));
-            poff.push_back(dst);
-            read_id.push_back(rd);
-        }
-        const int32_t cnt = (int32_t)(poff.size() - mark_seqs);
-        r.nreads = cnt;
-        if (cnt < o.min_reads) {
+        r.nreads = cnt_of[(size_t)p];
+        if (r.status != DH_PILE_OK) continue;
+        if (r.contig_left < 0 || r.contig_left + 1 >= contigs->n)
+            return dh_fail(DH_EINVAL, "dh_process_cropped: gap outside the contigs DB");
+        if (cnt_of[(size_t)p] < o.min_reads)
             r.status = DH_PILE_TOO_SMALL;
-            parts.resize(mark_parts);
-            poff.resize(mark_seqs);
-            read_id.resize(mark_seqs - 1);
-            continue;
+        else if (cnt_of[(size_t)p] > o.max_reads)
+            return dh_fail(DH_EINVAL, "dh_process_cropped: pile-up with more than max_reads reads");
+    }
+    for (int32_t i = 0; i < ncr; i++) {
+        const int32_t p = crop->pile[(size_t)i];
+        if (res->rec[(size_t)p].status != DH_PILE_OK) continue;
+        if (active_of[(size_t)p] < 0) {
+            active_of[(size_t)p] = (int32_t)pile_of_active.size();
+            pile_of_active.push_back(p);
+            first_read.push_back((int32_t)keep.size());
         }
-        const int32_t a = (int32_t)pile_of_active.size();
-        pile_of_active.push_back(p);
-        first_read.push_back((int32_t)mark_seqs - 1);
-        for (int32_t x = 0; x < cnt; x++) sgroup.push_back(a);
+        sgroup.push_back(active_of[(size_t)p]);
+        keep.push_back(i);
+        read_id.push_back(crop->read_id[(size_t)i]);
     }
     const int32_t na = (int32_t)pile_of_active.size();
-    first_read.push_back((int32_t)poff.size() - 1);
-    dh_db *pile = nullptr;
-    {
+    first_read.push_back((int32_t)keep.size());
+    HIPCHK(hipEventRecord(ev[0], st));
+    if (!crop->dev) {  // cropped reads came over the host (dh_cropped_create): upload them once
         uint8_t *d_alloc = nullptr, *d_bases = nullptr;
-        if (int rc = dh_alloc_bases(st, poff.back(), &d_alloc, &d_bases)) return rc;
-        if (int rc = dh_db_adopt(ctx, d_alloc, d_bases, poff, sgroup, &pile)) {
+        if (int rc = dh_alloc_bases(st, crop->off.back(), &d_alloc, &d_bases)) return rc;
+        if (int rc = dh_db_adopt(ctx, d_alloc, d_bases, crop->off, std::vector<int32_t>(), &crop->dev)) {
             dh_dev_free(d_alloc);
             return rc;
         }
+        crop->ctx = ctx;
+        if (crop->off.back() > 0)
+            HIPCHK(hipMemcpyAsync(d_bases, crop->bases.data(), (size_t)crop->off.back(), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    dh_db *pile = nullptr;
+    {
+        std::vector<int32_t> sbeg(keep.size(), 0), slen(keep.size());
+        for (size_t x = 0; x < keep.size(); x++)
+            slen[x] = (int32_t)(crop->off[(size_t)keep[x] + 1] - crop->off[(size_t)keep[x]]);
+        if (int rc = dh_db_from_slices(ctx, crop->dev, keep, sbeg, slen, sgroup, &pile)) return rc;
         dbg.dbs.push_back(pile);
-        if (!parts.empty()) {
-            DevBuf<PartDescH> d_parts;
-            HIPCHK(d_parts.alloc(parts.size()));
-            HIPCHK(hipMemcpyAsync(d_parts.p, parts.data(), sizeof(PartDescH) * parts.size(), hipMemcpyHostToDevice, st));
-            dhk_gather_parts(st, reads->d_bases, reads->d_off, contigs->d_bases, contigs->d_off, d_parts.p,
-                             (int32_t)parts.size(), pile_max_len, d_bases);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(st));
-        }
     }
     HIPCHK(hipEventRecord(ev[1], st));
     if (int rc = elapsed(0, 1, ps.ms[0])) return rc;
-    lap("crop + pile DB");
+    lap("pile DB");
 
     std::vector<uint8_t> active_ok((size_t)na, 1);
     dh_db *T = nullptr;
@@ -1162,7 +1345,7 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
         // ---- 7. flank re-alignment: daligner -A -s126 -l126 contigs consensus (commandline.d:2918-2935)
         std::vector<int32_t> fidx, fbeg, flen, fgrp, foff((size_t)na, 0);
         for (int32_t a = 0; a < na; a++) {
-            const int32_t g = piles->contig_left[(size_t)pile_of_active[(size_t)a]];
+            const int32_t g = res->rec[(size_t)pile_of_active[(size_t)a]].contig_left;
             const int32_t cll = (int32_t)(contigs->h_off[(size_t)g + 1] - contigs->h_off[(size_t)g]);
             const int32_t clr = (int32_t)(contigs->h_off[(size_t)g + 2] - contigs->h_off[(size_t)g + 1]);
             const int32_t wl = std::max(0, cll - o.flank_window);

@@ -1,17 +1,252 @@
-"""Multi-GPU layer: one process per GPU, pile-ups / read blocks sharded with no data-path
-collective; the only exchange is the gather of the closed-gap records at the end -- the role of
-`dentist merge-insertions` (source/dentist/commands/mergeInsertions.d:60-164, workflow rule
-snakemake/Snakefile:1347-1358).  Payload is a few MB, so it is latency-bound: one all-gather of
-the sizes, one all-gather of the padded bytes (RCCL over xGMI on GPUs, gloo in the CPU tests).
+"""Multi-GPU layer: one process per GPU, the hot path sharded the way the reference's workflow
+shards it, with the filesystem replaced by two small exchanges over RCCL/xGMI (gloo in CPU tests).
+
+  mapping   read blocks over ranks, contigs + k-mer index replicated -- one `damapper` job per read
+            block (snakemake/Snakefile:1143-1170).  No collective.
+  collect   every rank finds the spanning reads among ITS reads (per-read decision); the candidate
+            entries (gap, read id, the two anchoring LA records; ~100 B each, a few MB in total) are
+            all-gathered in rank order = read-id order, which is what `LAmerge` + `dentist collect`
+            see (Snakefile:1173-1185).  Every rank then applies the same min/max-reads cut and gets
+            identical pile-ups.
+  process   pile-ups are bin-packed over ranks by cost n^2 * L (greedy, largest first) -- the role of
+            `process --batch` (Snakefile:1315-1334).  Each rank crops ITS reads of every pile-up on
+            its GPU (dh_crop_pileups) and sends the cropped reads (gap + anchors, not whole reads) to
+            the pile-up's owner: one all-to-all(v).  Owners run dh_process_cropped.
+  gather    closed-gap records of all ranks, ordered by gap = `dentist merge-insertions`
+            (commands/mergeInsertions.d:60-164, insertions.sort() processPileUps/package.d:156).
+
+The result is bit-identical to the single-GPU run on the same inputs (tests/test_parallel_gloo.py
+for the host logic, tests/test_parity_shard_gpu.py for two shards run on one GPU).
 """
 import numpy as np
 
-from ._lib import INSERTION_DTYPE
+from ._lib import INSERTION_DTYPE, LA_DTYPE
+
+CAND_DTYPE = np.dtype([("gap", "<i4"), ("read", "<i4"), ("L", LA_DTYPE), ("R", LA_DTYPE)])
+CROP_DTYPE = np.dtype([("pile", "<i4"), ("entry", "<i4"), ("read", "<i4"), ("len", "<i4")])
 
 
 def shard_range(n, rank, world):
-    """Contiguous block partition of n units (read blocks / pile-up batches) over the ranks."""
+    """Contiguous block partition of n units (reads) over the ranks: (first, end)."""
     return n * rank // world, n * (rank + 1) // world
+
+
+def assign_owners(costs, world):
+    """Greedy bin-packing (largest cost first, ties by index; least-loaded rank, ties by rank):
+    owner[i] for every unit.  Deterministic, so every rank computes the same assignment."""
+    costs = np.asarray(costs, dtype=np.int64)
+    order = sorted(range(len(costs)), key=lambda i: (-int(costs[i]), i))
+    load = [0] * world
+    owner = np.zeros(len(costs), dtype=np.int32)
+    for i in order:
+        r = min(range(world), key=lambda x: (load[x], x))
+        owner[i] = r
+        load[r] += int(costs[i])
+    return owner
+
+
+# ------------------------------------------------------------------ collectives on byte payloads
+
+def _device(dist):
+    import torch
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def all_gather_bytes(payload, world):
+    """all-gather(v) of one uint8 array per rank: sizes first, then the padded bytes."""
+    import torch
+    import torch.distributed as dist
+    payload = np.ascontiguousarray(payload, dtype=np.uint8)
+    if world == 1 or not dist.is_initialized():
+        return [payload]
+    dev = _device(dist)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([len(payload)], dtype=torch.int64, device=dev))
+    sizes = [int(s.item()) for s in sizes]
+    cap = max(1, max(sizes))
+    mine = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    if len(payload):
+        mine[:len(payload)] = torch.from_numpy(payload.copy()).to(dev)
+    out = [torch.zeros(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(out, mine)
+    return [out[r][:sizes[r]].cpu().numpy() for r in range(world)]
+
+
+def all_to_all_bytes(per_dest, world):
+    """all-to-all(v): per_dest[r] = uint8 array for rank r; returns the arrays received, by source.
+    RCCL: one all_to_all_single with split sizes; gloo has no all-to-all, the CPU tests fall back to
+    an all-gather of everything and pick their own parts."""
+    import torch
+    import torch.distributed as dist
+    per_dest = [np.ascontiguousarray(x, dtype=np.uint8) for x in per_dest]
+    if world == 1 or not dist.is_initialized():
+        return [per_dest[0]]
+    rank = dist.get_rank()
+    dev = _device(dist)
+    if dist.get_backend() != "nccl":
+        head = np.asarray([len(x) for x in per_dest], dtype=np.int64)
+        blobs = all_gather_bytes(np.concatenate([head.view(np.uint8)] + per_dest), world)
+        out = []
+        for src in range(world):
+            h = blobs[src][:8 * world].view(np.int64)
+            start = 8 * world + int(h[:rank].sum())
+            out.append(blobs[src][start:start + int(h[rank])].copy())
+        return out
+    send_sizes = torch.tensor([len(x) for x in per_dest], dtype=torch.int64, device=dev)
+    recv_sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(recv_sizes, send_sizes)
+    rs = [int(x) for x in recv_sizes.tolist()]
+    ss = [len(x) for x in per_dest]
+    send = torch.from_numpy(np.concatenate(per_dest) if sum(ss) else np.zeros(0, np.uint8)).to(dev)
+    recv = torch.zeros(sum(rs), dtype=torch.uint8, device=dev)
+    dist.all_to_all_single(recv, send, output_split_sizes=rs, input_split_sizes=ss)
+    buf = recv.cpu().numpy()
+    out, at = [], 0
+    for n in rs:
+        out.append(buf[at:at + n].copy())
+        at += n
+    return out
+
+
+# ------------------------------------------------------------------ the sharded `collect` + `process`
+
+def pack_candidates(cands, las):
+    """Candidate entries of this rank (dentist_amd.Pileups(..., candidates=True) on its LAs, whose
+    bread are ids of the whole reads DB) as CAND_DTYPE records in (gap, read) order."""
+    rows = []
+    for i in range(len(cands)):
+        gap, tri = cands.get(i)
+        rec = np.zeros(len(tri), dtype=CAND_DTYPE)
+        rec["gap"] = gap
+        rec["read"] = tri[:, 0]
+        rec["L"] = las[tri[:, 1]]
+        rec["R"] = las[tri[:, 2]]
+        rows.append(rec)
+    return np.concatenate(rows) if rows else np.zeros(0, dtype=CAND_DTYPE)
+
+
+def merge_candidates(per_rank):
+    """All ranks' candidates -> (LA array, contig_left list, triples per gap).  Ranks hold ascending
+    read ranges and list their candidates by read, so concatenation in rank order keeps every gap's
+    entries ordered by read id -- the order `dentist collect` sees after LAmerge."""
+    allc = np.concatenate(per_rank) if len(per_rank) else np.zeros(0, dtype=CAND_DTYPE)
+    las = np.zeros(2 * len(allc), dtype=LA_DTYPE)
+    las[0::2] = allc["L"]
+    las[1::2] = allc["R"]
+    order = np.argsort(allc["gap"], kind="stable")
+    gaps, starts = np.unique(allc["gap"][order], return_index=True)
+    bounds = list(starts) + [len(order)]
+    triples = []
+    for x in range(len(gaps)):
+        idx = order[bounds[x]:bounds[x + 1]]
+        triples.append(np.stack([allc["read"][idx], 2 * idx, 2 * idx + 1], axis=1).astype(np.int32))
+    return las, [int(g) for g in gaps], triples
+
+
+def pile_costs(piles, las):
+    """n^2 * L per pile-up: n reads, L = mean read span between the anchors + 1 kb."""
+    costs = []
+    for i in range(len(piles)):
+        _, tri = piles.get(i)
+        span = np.maximum(las["bbpos"][tri[:, 2]] - las["bepos"][tri[:, 1]], 0).mean() + 1000.0
+        costs.append(int(len(tri) ** 2 * span))
+    return costs
+
+
+def sharded_process(ctx, contigs_db, reads_db, read_first, contig_off, las, trace, popts, rank, world):
+    """`collect` + `process` for one rank's share of the reads.  las/trace: this rank's mapping
+    result with bread ALREADY shifted to ids of the whole reads DB; reads_db holds the reads
+    [read_first, read_first + n).  Returns (records, bases, info): the closed-gap records of ALL
+    ranks ordered by gap (identical on every rank) with ref_read_id as whole-DB ids."""
+    gen = sharded_process_steps(ctx, contigs_db, reads_db, read_first, contig_off, las, trace, popts, rank, world)
+    try:
+        req = next(gen)
+        while True:
+            kind, payload = req
+            req = gen.send(all_gather_bytes(payload, world) if kind == "all_gather" else all_to_all_bytes(payload, world))
+    except StopIteration as done:
+        return done.value
+
+
+def emulate_ranks(gens):
+    """Drive one sharded_process_steps generator per emulated rank in lockstep inside ONE process
+    (tests: two shards on one GPU); collectives are served from memory.  Returns their results."""
+    world = len(gens)
+    reqs = [next(g) for g in gens]
+    results = [None] * world
+    while any(r is not None for r in reqs):
+        kinds = {r[0] for r in reqs if r is not None}
+        assert len(kinds) == 1 and all(r is not None for r in reqs), "ranks diverged"
+        if kinds == {"all_gather"}:
+            answers = [[np.asarray(reqs[src][1], dtype=np.uint8).copy() for src in range(world)] for _ in range(world)]
+        else:
+            answers = [[np.asarray(reqs[src][1][dst], dtype=np.uint8).copy() for src in range(world)] for dst in range(world)]
+        nxt = []
+        for r, g in enumerate(gens):
+            try:
+                nxt.append(g.send(answers[r]))
+            except StopIteration as done:
+                results[r] = done.value
+                nxt.append(None)
+        reqs = nxt
+    return results
+
+
+def sharded_process_steps(ctx, contigs_db, reads_db, read_first, contig_off, las, trace, popts, rank, world):
+    """Generator form of sharded_process: yields ("all_gather", bytes) / ("all_to_all", [bytes per
+    destination]) and expects the list of arrays received (by source rank) to be sent back."""
+    from . import Cropped, Pileups
+    cands = Pileups(las, contig_off, popts, candidates=True)
+    mine = pack_candidates(cands, las)
+    blobs = yield ("all_gather", mine.view(np.uint8))
+    per_rank = [np.frombuffer(b.tobytes(), dtype=CAND_DTYPE) for b in blobs]
+    glas, gaps, triples = merge_candidates(per_rank)
+    # the entries of this rank inside glas are copies of its own records: their toff still points
+    # into its own trace array, which is all dh_crop_pileups needs (other ranks' traces stay there)
+    piles = Pileups.from_triples(gaps, triples).select(glas, popts)
+    owner = assign_owners(pile_costs(piles, glas), world)
+    crop = Cropped.crop(ctx, contigs_db, reads_db, read_first, glas, trace, piles, popts)
+    rec, cpile, centry, cread, coff, cbases = crop.arrays()
+    crop.close()
+    # cropped reads to the owners of their pile-ups
+    per_dest = []
+    lens = np.diff(coff).astype(np.int32)
+    dest_of_read = owner[cpile] if len(cpile) else np.zeros(0, np.int32)
+    for r in range(world):
+        sel = np.nonzero(dest_of_read == r)[0]
+        head = np.zeros(len(sel), dtype=CROP_DTYPE)
+        head["pile"], head["entry"], head["read"], head["len"] = cpile[sel], centry[sel], cread[sel], lens[sel]
+        seqs = [cbases[coff[i]:coff[i + 1]] for i in sel]
+        per_dest.append(np.concatenate([np.asarray([len(sel)], dtype=np.int64).view(np.uint8), head.view(np.uint8)] + seqs))
+    got = yield ("all_to_all", per_dest)
+    heads, seqs = [], []
+    for blob in got:
+        k = int(blob[:8].view(np.int64)[0])
+        h = np.frombuffer(blob[8:8 + k * CROP_DTYPE.itemsize].tobytes(), dtype=CROP_DTYPE)
+        heads.append(h)
+        seqs.append(blob[8 + k * CROP_DTYPE.itemsize:])
+    head = np.concatenate(heads)
+    src_off = np.concatenate([[0], np.cumsum(head["len"].astype(np.int64))])
+    allseq = np.concatenate(seqs) if seqs else np.zeros(0, np.uint8)
+    # pile-ups owned here, renumbered 0..; reads ordered by (pile, entry)
+    mine_piles = np.nonzero(owner == rank)[0]
+    renum = np.full(len(rec), -1, dtype=np.int32)
+    renum[mine_piles] = np.arange(len(mine_piles), dtype=np.int32)
+    order = np.lexsort((head["entry"], head["pile"]))
+    o_len = head["len"][order].astype(np.int64)
+    o_off = np.concatenate([[0], np.cumsum(o_len)])
+    o_bases = (np.concatenate([allseq[src_off[i]:src_off[i + 1]] for i in order]) if len(order)
+               else np.zeros(0, np.uint8))
+    own = Cropped.create(rec[mine_piles], renum[head["pile"][order]], head["entry"][order], head["read"][order],
+                         o_off, o_bases)
+    lrec, lbases = own.process(ctx, contigs_db, popts)
+    own.close()
+    blobs = yield ("all_gather", _pack_closed(lrec, lbases))
+    grec, gbases, origin = _unpack_closed(blobs)
+    order = np.argsort(grec["contig_left"], kind="stable")   # insertions.sort(): by start node
+    info = {"piles": len(rec), "owned": len(mine_piles), "candidates": int(sum(len(p) for p in per_rank)),
+            "cropped_bytes_sent": int(sum(len(x) for x in per_dest)), "owner": owner}
+    return grec[order], gbases, info
 
 
 def all_gather_closed_gaps(rec, bases, rank, world, device=None):
@@ -20,33 +255,27 @@ def all_gather_closed_gaps(rec, bases, rank, world, device=None):
     Returns (records, bases, origin): records concatenated in rank order with ``cons_off``
     rebased into the concatenated ``bases``; ``origin[i]`` = rank that produced record i.
     """
-    import torch
     import torch.distributed as dist
 
     if world == 1 or not dist.is_initialized():
         return rec.copy(), bases.copy(), np.zeros(len(rec), dtype=np.int32)
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    return _unpack_closed(all_gather_bytes(_pack_closed(rec, bases), world))
+
+
+def _pack_closed(rec, bases):
     rb = np.frombuffer(np.ascontiguousarray(rec, dtype=INSERTION_DTYPE).tobytes(), dtype=np.uint8)
     bb = np.ascontiguousarray(bases, dtype=np.uint8)
-    sizes = torch.tensor([len(rb), len(bb)], dtype=torch.int64, device=device)
-    all_sizes = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(all_sizes, sizes)
-    all_sizes = [tuple(int(x) for x in s.tolist()) for s in all_sizes]
-    cap = max(1, max(a + b for a, b in all_sizes))
-    payload = torch.zeros(cap, dtype=torch.uint8, device=device)
-    mine = np.concatenate([rb, bb])
-    if len(mine):
-        payload[:len(mine)] = torch.from_numpy(mine.copy()).to(device)
-    gathered = [torch.zeros(cap, dtype=torch.uint8, device=device) for _ in range(world)]
-    dist.all_gather(gathered, payload)
+    return np.concatenate([np.asarray([len(rb)], dtype=np.int64).view(np.uint8), rb, bb])
+
+
+def _unpack_closed(blobs):
     recs, seqs, origin, base_off = [], [], [], 0
-    for r, (nr, nb) in enumerate(all_sizes):
-        buf = gathered[r].cpu().numpy()
-        rr = np.frombuffer(buf[:nr].tobytes(), dtype=INSERTION_DTYPE).copy()
+    for r, buf in enumerate(blobs):
+        nr = int(buf[:8].view(np.int64)[0])
+        rr = np.frombuffer(buf[8:8 + nr].tobytes(), dtype=INSERTION_DTYPE).copy()
         rr["cons_off"] += base_off
         recs.append(rr)
-        seqs.append(buf[nr:nr + nb].copy())
+        seqs.append(buf[8 + nr:].copy())
         origin.append(np.full(len(rr), r, dtype=np.int32))
-        base_off += nb
+        base_off += len(buf) - 8 - nr
     return np.concatenate(recs), np.concatenate(seqs), np.concatenate(origin)

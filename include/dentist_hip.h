@@ -243,6 +243,37 @@ int32_t dh_insertions_count(const dh_insertions *r);
 const dh_insertion *dh_insertions_records(const dh_insertions *r);
 const uint8_t *dh_insertions_bases(const dh_insertions *r);
 int64_t dh_insertions_bases_len(const dh_insertions *r);
+/* The two halves of dh_process_pileups as entry points of their own (dh_process_pileups runs them
+ * back to back with the cropped reads staying on the device):
+ *   dh_crop_pileups     cropPileUp (cropper.d:113-175, 446-550) for a batch: the common trace point of
+ *                       each flank from ALL entries of a pile-up, then [support patch] + read slice +
+ *                       [support patch] for the entries whose read is in `reads`.  Read ids in the
+ *                       triples are ids of the whole reads DB; `reads` holds [read_first, read_first +
+ *                       nreads(reads)) of it -- one rank's share when the mapping is sharded (SURVEY
+ *                       8(e)); LAs of reads held elsewhere only need their A intervals.
+ *   dh_cropped_create   cropped pile-ups assembled from parts received from other ranks: rec = the
+ *                       per-pile-up records of dh_crop_pileups (crop points, status), reads ordered by
+ *                       (pile, entry)
+ *   dh_process_cropped  pile-up alignment -> filter -> tile QV -> reference read -> consensus -> flank
+ *                       re-alignment -> insertion on cropped pile-ups (package.d:283-374 after crop()) */
+typedef struct dh_cropped dh_cropped;
+int dh_crop_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_t read_first, const dh_la *las, int64_t n,
+                    const uint16_t *trace, const dh_pileups *piles, const dh_process_opts *opts,
+                    dh_cropped **out);
+int dh_cropped_create(const dh_insertion *rec, int32_t npiles, int32_t nreads, const int32_t *pile,
+                      const int32_t *entry, const int32_t *read_id, const int64_t *off, const uint8_t *bases,
+                      dh_cropped **out);
+void dh_cropped_destroy(dh_cropped *c);
+int32_t dh_cropped_npiles(const dh_cropped *c);
+const dh_insertion *dh_cropped_records(const dh_cropped *c);
+int32_t dh_cropped_nreads(const dh_cropped *c);
+const int32_t *dh_cropped_pile(const dh_cropped *c);     /* pile-up of every cropped read               */
+const int32_t *dh_cropped_entry(const dh_cropped *c);    /* its position in the pile-up's read list      */
+const int32_t *dh_cropped_read_id(const dh_cropped *c);
+const int64_t *dh_cropped_offsets(const dh_cropped *c);  /* nreads + 1                                   */
+const uint8_t *dh_cropped_bases(dh_cropped *c);          /* copies device -> host on first use           */
+int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop, const dh_process_opts *opts,
+                       dh_insertions **out);
 /* per-stage HIP-event times (ms) of the last dh_process_pileups call on this context:
  * [0] crop+gather [1] pile-up alignment [2] tile QV [3] consensus vote+emit (all rounds)
  * [4] read->consensus re-alignment (rounds > 1) [5] flank re-alignment [6] total;

@@ -165,7 +165,9 @@ static int ent_cmp(const void *x, const void *y)
 
 /* sepv separates the sequences of A on the virtual diagonal axis so that no band of 2^w
  * diagonals is shared by two A sequences; it has to be >= the longest B sequence + 2^w. */
-static int32_t sepv_for(int32_t max_blen) { return ((max_blen + 64) + 63) & ~63; }
+/* both are multiples of 4096 (>= the widest band), and so is every goff: the band of a hit then
+ * depends only on the pair (A sequence, B read), not on the rest of the DB */
+static int32_t sepv_for(int32_t max_blen) { return (max_blen + 64 + 4095) & ~4095; }
 
 static oz_index *index_build(const oz_db *A, const oz_opts *o, int32_t max_blen)
 {
@@ -179,7 +181,7 @@ static oz_index *index_build(const oz_db *A, const oz_opts *o, int32_t max_blen)
     for (int32_t s = 0; s < A->n; s++) {
         ix->goff[s] = g;
         int64_t len = A->off[s + 1] - A->off[s];
-        g += len + ix->sepv;
+        g += (len + ix->sepv + 4095) & ~4095ll;
         if (len >= k) total += len - k + 1;
     }
     ix->goff[A->n] = g;

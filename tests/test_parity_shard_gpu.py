@@ -1,0 +1,79 @@
+"""The sharded (multi-GPU) hot path against the single-GPU path -- bit exact.
+
+`world` shards are emulated inside one process on one GPU (dentist_amd.parallel.emulate_ranks serves
+the collectives from memory): every emulated rank maps its own block of reads, the candidate
+entries are all-gathered, pile-ups are bin-packed over the ranks, cropped reads go to the owners
+(all-to-all) and the closed gaps are gathered -- the result must equal the unsharded run."""
+import numpy as np
+import pytest
+
+import dentist_amd
+from dentist_amd import parallel, sim
+
+pytestmark = pytest.mark.gpu
+
+
+def single(ctx, w, mo, po):
+    A, B = ctx.db(w.contigs), ctx.db(w.reads)
+    las, trace = ctx.align_db(A, B, mo, select_best=True)
+    piles = dentist_amd.Pileups(las, w.contigs.off, po)
+    rec, bases = dentist_amd.process_pileups(ctx, A, B, las, trace, piles, po)
+    return rec, bases
+
+
+def sharded(ctx, w, mo, po, world):
+    A = ctx.db(w.contigs)
+    gens, keep = [], []
+    for rank in range(world):
+        lo, hi = parallel.shard_range(w.reads.n, rank, world)
+        share = sim.SeqDb(w.reads.bases[w.reads.off[lo]:w.reads.off[hi]], w.reads.off[lo:hi + 1] - w.reads.off[lo])
+        B = ctx.db(share)
+        las, trace = ctx.align_db(A, B, mo, select_best=True)
+        las = las.copy()
+        las["bread"] += lo   # ids of the whole reads DB, as in the .las of a block
+        keep.append((B, las, trace))
+        gens.append(parallel.sharded_process_steps(ctx, A, B, lo, w.contigs.off, las, trace, po, rank, world))
+    return parallel.emulate_ranks(gens)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_run_equals_the_single_gpu_run(gpu_ctx, world):
+    w = sim.Workload(800_000, 8, 4000, 6000, seed=61, spacing=20000, gap_max=1500)
+    mo = dentist_amd.default_align_opts(kmer_mod=2)
+    po = dentist_amd.default_process_opts(max_reads=12)   # the quality cut is exercised: ~30 spanning reads per gap
+    rec, bases = single(gpu_ctx, w, mo, po)
+    assert (rec["status"] == 0).sum() >= 6
+    results = sharded(gpu_ctx, w, mo, po, world)
+    owners = results[0][2]["owner"]
+    assert len(set(owners.tolist())) == world, "every emulated rank must own pile-ups"
+    for grec, gbases, info in results:
+        assert len(grec) == len(rec)
+        assert np.array_equal(grec["contig_left"], rec["contig_left"])
+        for f in rec.dtype.names:
+            if f not in ("cons_off", "pad"):
+                assert np.array_equal(grec[f], rec[f]), f
+        for a, b in zip(grec, rec):
+            assert np.array_equal(gbases[a["cons_off"]:a["cons_off"] + a["cons_len"]],
+                                  bases[b["cons_off"]:b["cons_off"] + b["cons_len"]])
+        assert info["cropped_bytes_sent"] > 0
+
+
+def test_crop_then_process_equals_the_fused_call(gpu_ctx):
+    """dh_crop_pileups + dh_process_cropped (also through the host: dh_cropped_create) == dh_process_pileups."""
+    w = sim.Workload(500_000, 5, 2500, 6000, seed=67, spacing=20000, gap_max=1200)
+    mo = dentist_amd.default_align_opts()
+    po = dentist_amd.default_process_opts()
+    A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
+    las, trace = gpu_ctx.align_db(A, B, mo)
+    piles = dentist_amd.Pileups(las, w.contigs.off, po)
+    rec, bases = dentist_amd.process_pileups(gpu_ctx, A, B, las, trace, piles, po)
+    crop = dentist_amd.Cropped.crop(gpu_ctx, A, B, 0, las, trace, piles, po)
+    parts = crop.arrays()
+    rec2, bases2 = crop.process(gpu_ctx, A, po)
+    assert np.array_equal(rec2, rec) and np.array_equal(bases2, bases)
+    rec3, bases3 = dentist_amd.Cropped.create(*parts).process(gpu_ctx, A, po)
+    assert np.array_equal(rec3, rec) and np.array_equal(bases3, bases)
+    # cropped reads are [patch] + slice + [patch] of the reads in (pile, entry) order
+    prec, cpile, centry, cread, coff, cbases = parts
+    assert np.all(np.diff(cpile.astype(np.int64) * 1000 + centry) > 0)
+    assert len(cpile) == sum(len(piles.get(i)[1]) for i in range(len(piles)) if prec[i]["status"] == 0)
