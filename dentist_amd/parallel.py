@@ -153,6 +153,18 @@ def pile_costs(piles, las):
     return costs
 
 
+def _runs(bases, off, idx):
+    """Slices of `bases` covering the sequences idx[0], idx[1], ... (off = their offsets), with runs
+    of consecutive indices merged into one slice."""
+    idx = np.asarray(idx, dtype=np.int64)
+    if len(idx) == 0:
+        return []
+    brk = np.nonzero(np.diff(idx) != 1)[0] + 1
+    starts = np.concatenate([[0], brk])
+    ends = np.concatenate([brk, [len(idx)]])
+    return [bases[off[idx[a]]:off[idx[b - 1] + 1]] for a, b in zip(starts, ends)]
+
+
 def sharded_process(ctx, contigs_db, reads_db, read_first, contig_off, las, trace, popts, rank, world):
     """`collect` + `process` for one rank's share of the reads.  las/trace: this rank's mapping
     result with bread ALREADY shifted to ids of the whole reads DB; reads_db holds the reads
@@ -208,16 +220,17 @@ def sharded_process_steps(ctx, contigs_db, reads_db, read_first, contig_off, las
     crop = Cropped.crop(ctx, contigs_db, reads_db, read_first, glas, trace, piles, popts)
     rec, cpile, centry, cread, coff, cbases = crop.arrays()
     crop.close()
-    # cropped reads to the owners of their pile-ups
-    per_dest = []
+    # cropped reads to the owners of their pile-ups; reads are in (pile, entry) order, so the reads of
+    # one destination form a few contiguous runs of the base array
     lens = np.diff(coff).astype(np.int32)
     dest_of_read = owner[cpile] if len(cpile) else np.zeros(0, np.int32)
+    per_dest = []
     for r in range(world):
         sel = np.nonzero(dest_of_read == r)[0]
         head = np.zeros(len(sel), dtype=CROP_DTYPE)
         head["pile"], head["entry"], head["read"], head["len"] = cpile[sel], centry[sel], cread[sel], lens[sel]
-        seqs = [cbases[coff[i]:coff[i + 1]] for i in sel]
-        per_dest.append(np.concatenate([np.asarray([len(sel)], dtype=np.int64).view(np.uint8), head.view(np.uint8)] + seqs))
+        per_dest.append(np.concatenate([np.asarray([len(sel)], dtype=np.int64).view(np.uint8), head.view(np.uint8)]
+                                       + _runs(cbases, coff, sel)))
     got = yield ("all_to_all", per_dest)
     heads, seqs = [], []
     for blob in got:
@@ -235,8 +248,8 @@ def sharded_process_steps(ctx, contigs_db, reads_db, read_first, contig_off, las
     order = np.lexsort((head["entry"], head["pile"]))
     o_len = head["len"][order].astype(np.int64)
     o_off = np.concatenate([[0], np.cumsum(o_len)])
-    o_bases = (np.concatenate([allseq[src_off[i]:src_off[i + 1]] for i in order]) if len(order)
-               else np.zeros(0, np.uint8))
+    parts = _runs(allseq, src_off, order)
+    o_bases = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
     own = Cropped.create(rec[mine_piles], renum[head["pile"][order]], head["entry"][order], head["read"][order],
                          o_off, o_bases)
     lrec, lbases = own.process(ctx, contigs_db, popts)

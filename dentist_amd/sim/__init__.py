@@ -29,6 +29,11 @@ def _lib():
                                     ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
                                     ctypes.c_void_p]
         lib.dhsim_reads.restype = ctypes.c_int64
+        lib.dhsim_reads_from.argtypes = [ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                         ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                         ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_void_p]
+        lib.dhsim_reads_from.restype = ctypes.c_int64
         _LIB = lib
     return _LIB
 
@@ -93,15 +98,17 @@ def gaps(seed, genome_len, ngaps, minlen=50, maxlen=5000, spacing=20000):
     return b[:n].copy(), e[:n].copy()
 
 
-def reads(seed, genome_codes, nreads, mean_len, sd_len=0, min_len=100, err=0.13, p_ins=0.60, p_del=0.25):
+def reads(seed, genome_codes, nreads, mean_len, sd_len=0, min_len=100, err=0.13, p_ins=0.60, p_del=0.25, first=0):
+    """nreads reads starting with read number `first` of the stream (every read has its own RNG
+    stream, so a share of the reads equals the corresponding reads of the whole set)."""
     g = np.ascontiguousarray(genome_codes, dtype=np.uint8)
     off = np.zeros(nreads + 1, dtype=np.int64)
     truth = np.zeros((nreads, 3), dtype=np.int64)
-    total = _lib().dhsim_reads(seed, g.ctypes.data, len(g), nreads, mean_len, sd_len, min_len, err, p_ins,
-                               p_del, off.ctypes.data, None, truth.ctypes.data)
+    total = _lib().dhsim_reads_from(seed, g.ctypes.data, len(g), first, nreads, mean_len, sd_len, min_len, err,
+                                    p_ins, p_del, off.ctypes.data, None, truth.ctypes.data)
     bases = np.empty(total, dtype=np.uint8)
-    _lib().dhsim_reads(seed, g.ctypes.data, len(g), nreads, mean_len, sd_len, min_len, err, p_ins, p_del,
-                       off.ctypes.data, bases.ctypes.data, truth.ctypes.data)
+    _lib().dhsim_reads_from(seed, g.ctypes.data, len(g), first, nreads, mean_len, sd_len, min_len, err, p_ins,
+                            p_del, off.ctypes.data, bases.ctypes.data, truth.ctypes.data)
     return SeqDb(bases, off), truth
 
 
@@ -117,8 +124,12 @@ class Workload:
     """A BASELINE.json-style synthetic workload (SURVEY.md 8(d) seeds: asm, +1 gaps, +2 reads)."""
 
     def __init__(self, genome_len, ngaps, nreads, read_len, seed=20260929, err=0.13, sd_len=0,
-                 gap_min=50, gap_max=5000, spacing=20000):
+                 gap_min=50, gap_max=5000, spacing=20000, read_range=None):
         self.truth = genome(seed, genome_len)
         self.gap_begin, self.gap_end = gaps(seed + 1, genome_len, ngaps, gap_min, gap_max, spacing)
         self.contigs, self.contig_start = contigs_from_gaps(self.truth, self.gap_begin, self.gap_end)
-        self.reads, self.read_truth = reads(seed + 2, self.truth, nreads, read_len, sd_len, err=err)
+        # read_range = (first, end): only that share of the nreads reads is generated (sharded runs)
+        self.read_first, read_end = read_range if read_range is not None else (0, nreads)
+        self.nreads_total = nreads
+        self.reads, self.read_truth = reads(seed + 2, self.truth, read_end - self.read_first, read_len, sd_len,
+                                            err=err, first=self.read_first)

@@ -83,9 +83,22 @@ int32_t dhsim_gaps(uint64_t seed, int64_t genome_len, int32_t ngaps, int32_t min
 // out_bases must hold nreads * max_out bytes; read r is written at out_off[r] (filled here,
 // contiguous) -- call once with out_bases == NULL to size (returns total bytes needed).
 // truth[r*3+0..2] = start, end, strand.
+int64_t dhsim_reads_from(uint64_t seed, const uint8_t *genome, int64_t glen, int32_t first, int32_t nreads,
+                         int32_t mean_len, int32_t sd_len, int32_t min_len, double err, double p_ins,
+                         double p_del, int64_t *out_off, uint8_t *out_bases, int64_t *truth);
 int64_t dhsim_reads(uint64_t seed, const uint8_t *genome, int64_t glen, int32_t nreads,
                     int32_t mean_len, int32_t sd_len, int32_t min_len, double err, double p_ins,
                     double p_del, int64_t *out_off, uint8_t *out_bases, int64_t *truth)
+{
+    return dhsim_reads_from(seed, genome, glen, 0, nreads, mean_len, sd_len, min_len, err, p_ins, p_del, out_off,
+                            out_bases, truth);
+}
+
+// the reads [first, first + nreads) of the same stream: a rank of a sharded run generates only its
+// share, identical to the corresponding reads of the whole set
+int64_t dhsim_reads_from(uint64_t seed, const uint8_t *genome, int64_t glen, int32_t first, int32_t nreads,
+                         int32_t mean_len, int32_t sd_len, int32_t min_len, double err, double p_ins,
+                         double p_del, int64_t *out_off, uint8_t *out_bases, int64_t *truth)
 {
     // pass 1: lengths of every read's output (sequential prefix sum needs them)
     std::vector<int32_t> outlen((size_t)nreads);
@@ -107,7 +120,7 @@ int64_t dhsim_reads(uint64_t seed, const uint8_t *genome, int64_t glen, int32_t 
         }
 #pragma omp parallel for schedule(dynamic, 256)
         for (int32_t r = 0; r < nreads; r++) {
-            Rng g(seed ^ (0xD1B54A32D192ED03ull * (uint64_t)(r + 1)));
+            Rng g(seed ^ (0xD1B54A32D192ED03ull * (uint64_t)((int64_t)first + r + 1)));
             int64_t len = mean_len;
             if (sd_len > 0) {
                 len = (int64_t)std::exp(mu + sg * g.normal());

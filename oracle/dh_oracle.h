@@ -169,6 +169,25 @@ int32_t oz_rank_reference_reads(const uint8_t *qv, int32_t nreads, const int32_t
 int32_t oz_consensus(const uint8_t *ref, int32_t rlen, const oz_db *reads, const oz_la_set *s,
                      int32_t aidx, int32_t tspace, uint8_t *out, uint32_t *votes_out);
 
+/* ---------- `dentist collect` (spanning reads) + `dentist process` per pile-up (pile.c) ---------- */
+typedef struct {
+    int32_t ts_map, allowance, min_anchor, min_reads, max_reads, ts_pile, rounds, flank_window,
+        max_align_err_ppm, max_ins_err_ppm, bad_fraction_ppm, width;
+} oz_process_opts;
+void oz_default_process_opts(oz_process_opts *o);
+typedef struct {
+    int32_t gap, status /* 0 ok, 1..7 = DH_PILE_* */, nreads, ref_idx, ref_read_id, crop_left, crop_right,
+        left_aepos, right_abpos, ins_begin, ins_end, comp, cons_len, left_diffs, right_diffs, pad;
+    int64_t cons_off;
+} oz_insertion;
+/* malloc'd outputs (free with oz_free): gap[npiles], count[npiles], triples[3 * sum(count)] */
+int oz_collect_spanning(const oz_la *las, int64_t n, const oz_db *contigs, const oz_process_opts *o,
+                        int32_t **gap_out, int32_t **count_out, int32_t **triples_out, int32_t *npiles);
+int oz_process_piles(const oz_db *contigs, const oz_db *reads, const oz_la *las, int64_t n, const uint16_t *trace,
+                     const int32_t *gap, const int32_t *count, const int32_t *triples, int32_t npiles,
+                     const oz_process_opts *o, int nthreads, oz_insertion *out, uint8_t **bases_out, int64_t *nbases);
+void oz_free(void *p);
+
 #ifdef __cplusplus
 }
 #endif

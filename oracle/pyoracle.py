@@ -247,3 +247,80 @@ def valid_pileup_alignment(la, alen, blen, allowance):
     for f, _ in La._fields_:
         setattr(rec, f, int(la[f]))
     return bool(L.oz_valid_pileup_alignment(ctypes.byref(rec), alen, blen, allowance))
+
+
+# ---------------------------------------------------------------- collect + process in C (pile.c)
+class ProcessOpts(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "ts_map", "allowance", "min_anchor", "min_reads", "max_reads", "ts_pile", "rounds", "flank_window",
+        "max_align_err_ppm", "max_ins_err_ppm", "bad_fraction_ppm", "width")]
+
+
+OZ_INSERTION_DTYPE = np.dtype([(n, "<i4") for n in (
+    "gap", "status", "nreads", "ref_idx", "ref_read_id", "crop_left", "crop_right", "left_aepos", "right_abpos",
+    "ins_begin", "ins_end", "comp", "cons_len", "left_diffs", "right_diffs", "pad")] + [("cons_off", "<i8")])
+
+
+def default_process_opts(**kw):
+    o = ProcessOpts()
+    lib().oz_default_process_opts(ctypes.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def collect_spanning_c(las, contigs, popts):
+    """oz_collect_spanning: (gaps, [triples per gap]) -- the C twin of oracle.process.collect_spanning."""
+    L = lib()
+    arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
+    dc = _db(contigs)
+    gp, cp, tp = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    npl = ctypes.c_int32(0)
+    L.oz_collect_spanning.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(Db), ctypes.POINTER(ProcessOpts),
+                                      ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
+                                      ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int32)]
+    L.oz_free.argtypes = [ctypes.c_void_p]
+    L.oz_collect_spanning(arr.ctypes.data, len(arr), ctypes.byref(dc), ctypes.byref(popts), ctypes.byref(gp),
+                          ctypes.byref(cp), ctypes.byref(tp), ctypes.byref(npl))
+    n = npl.value
+    gaps = np.frombuffer(ctypes.string_at(gp, 4 * n), dtype=np.int32).copy() if n else np.zeros(0, np.int32)
+    cnt = np.frombuffer(ctypes.string_at(cp, 4 * n), dtype=np.int32).copy() if n else np.zeros(0, np.int32)
+    tot = int(cnt.sum())
+    tri = (np.frombuffer(ctypes.string_at(tp, 12 * tot), dtype=np.int32).reshape(tot, 3).copy() if tot
+           else np.zeros((0, 3), np.int32))
+    for p in (gp, cp, tp):
+        L.oz_free(p)
+    out, at = [], 0
+    for c in cnt:
+        out.append(tri[at:at + c])
+        at += c
+    return gaps, out
+
+
+def process_piles_c(contigs, reads, las, trace, gaps, triples, popts, nthreads=1):
+    """oz_process_piles: every pile-up through the `process` sequence on the CPU (OpenMP over
+    pile-ups).  Returns (records OZ_INSERTION_DTYPE, consensus bases)."""
+    L = lib()
+    arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
+    tr = np.ascontiguousarray(trace, dtype=np.uint16)
+    g = np.ascontiguousarray(gaps, dtype=np.int32)
+    cnt = np.asarray([len(t) for t in triples], dtype=np.int32)
+    tri = (np.ascontiguousarray(np.concatenate([np.asarray(t, dtype=np.int32).reshape(-1, 3) for t in triples]))
+           if len(triples) else np.zeros((0, 3), np.int32))
+    out = np.zeros(len(g), dtype=OZ_INSERTION_DTYPE)
+    bp = ctypes.c_void_p()
+    nb = ctypes.c_int64(0)
+    dc, dr = _db(contigs), _db(reads)
+    L.oz_process_piles.argtypes = [ctypes.POINTER(Db), ctypes.POINTER(Db), ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
+                                   ctypes.POINTER(ProcessOpts), ctypes.c_int, ctypes.c_void_p,
+                                   ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64)]
+    L.oz_free.argtypes = [ctypes.c_void_p]
+    L.oz_process_piles(ctypes.byref(dc), ctypes.byref(dr), arr.ctypes.data, len(arr), tr.ctypes.data, g.ctypes.data,
+                       cnt.ctypes.data, tri.ctypes.data, len(g), ctypes.byref(popts), nthreads, out.ctypes.data,
+                       ctypes.byref(bp), ctypes.byref(nb))
+    bases = np.frombuffer(ctypes.string_at(bp, nb.value), dtype=np.uint8).copy() if nb.value else np.zeros(0, np.uint8)
+    L.oz_free(bp)
+    return out, bases
