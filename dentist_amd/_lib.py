@@ -77,7 +77,7 @@ SYMBOLS = [
     "dh_collect_candidates", "dh_pileups_create", "dh_pileups_select", "dh_align_db_block", "dh_la_set_merge",
     "dh_crop_pileups", "dh_cropped_create", "dh_cropped_destroy", "dh_cropped_npiles", "dh_cropped_records",
     "dh_cropped_nreads", "dh_cropped_pile", "dh_cropped_entry", "dh_cropped_read_id", "dh_cropped_offsets",
-    "dh_cropped_bases", "dh_process_cropped",
+    "dh_cropped_bases", "dh_process_cropped", "dh_translate_trace_point",
 ]
 
 _LIB = None
@@ -147,6 +147,7 @@ def lib():
         fn.argtypes = [vp]
         fn.restype = vp
     L.dh_process_cropped.argtypes = [vp, vp, vp, ctypes.POINTER(ProcessOpts), ctypes.POINTER(vp)]
+    L.dh_translate_trace_point.argtypes = [vp, vp, i32, i32, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.dh_insertions_destroy.argtypes = [vp]
     L.dh_insertions_count.argtypes = [vp]
     L.dh_insertions_count.restype = i32
@@ -349,6 +350,18 @@ class Db:
             self.close()
         except Exception:
             pass
+
+
+def translate_trace_point(la, trace, tspace, apos, mode="floor"):
+    """Trace.translateTracePoint!"contigA" (base.d:185-244) of the product: (a, b) of the trace point
+    apos is assigned to; raises DhError when apos is outside the LA.  la: one LA_DTYPE record."""
+    rec = np.zeros(1, dtype=LA_DTYPE)
+    rec[0] = la
+    tr = np.ascontiguousarray(trace, dtype=np.uint16)
+    a, b = ctypes.c_int32(), ctypes.c_int32()
+    _check(lib().dh_translate_trace_point(rec.ctypes.data, tr.ctypes.data, tspace, apos,
+                                          {"floor": 0, "ceil": 1}[mode], ctypes.byref(a), ctypes.byref(b)))
+    return a.value, b.value
 
 
 def las_write(path, las, trace, tspace):

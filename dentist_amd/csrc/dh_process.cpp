@@ -316,21 +316,56 @@ static int32_t common_trace_point(int32_t lo, int32_t hi, int32_t contig_len, in
     return -1;
 }
 
-// Trace.translateTracePoint!"contigA"(pos, floor).contigB, base.d:185-237
-static int32_t translate_floor_b(const dh_la &la, const uint16_t *tr, int32_t ts, int32_t apos)
+// Trace.tracePointsUpTo!"contigA" (base.d:207-244): number of trace points up to and including
+// apos under the rounding mode (0 floor, 1 ceil)
+static int32_t trace_points_up_to_a(const dh_la &la, int32_t ts, int32_t apos, int32_t mode)
 {
     const int32_t ntp = la.tlen / 2;
     const int32_t second = la.abpos / ts * ts + ts;
-    int32_t idx;
-    if (apos < second)
-        idx = 0;
-    else if (apos < la.aepos)
-        idx = 1 + (apos - second) / ts;
-    else
-        idx = ntp;
+    if (mode == 0) {
+        if (apos < second) return 0;
+        if (apos < la.aepos) return 1 + (apos - second) / ts;
+        return ntp;
+    }
+    const int32_t second_from_last = (la.aepos - 1) / ts * ts;
+    if (apos == la.abpos) return 0;
+    if (apos <= second) return 1;
+    if (apos <= second_from_last) return 1 + (apos - second + ts - 1) / ts;
+    return ntp;
+}
+
+// Trace.translateTracePoint!"contigA"(pos, mode), base.d:185-203: the position is assigned to a trace
+// point of the LA; returns its coordinates on A and on B
+static void translate_trace_point(const dh_la &la, const uint16_t *tr, int32_t ts, int32_t apos, int32_t mode,
+                                  int32_t *outa, int32_t *outb)
+{
+    const int32_t ntp = la.tlen / 2;
+    const int32_t idx = trace_points_up_to_a(la, ts, apos, mode);
     int32_t b = la.bbpos;
     for (int32_t i = 0; i < idx; i++) b += tr[2 * i + 1];
+    *outb = b;
+    *outa = idx == 0 ? la.abpos : (idx < ntp ? la.abpos / ts * ts + idx * ts : la.aepos);
+}
+
+static int32_t translate_floor_b(const dh_la &la, const uint16_t *tr, int32_t ts, int32_t apos)
+{
+    int32_t a, b;
+    translate_trace_point(la, tr, ts, apos, 0, &a, &b);
     return b;
+}
+
+// the same through the C ABI (the cropper of `dentist process` is built on it: cropper.d:503-550)
+extern "C" int dh_translate_trace_point(const dh_la *la, const uint16_t *trace, int32_t tspace, int32_t apos,
+                                        int32_t mode, int32_t *out_a, int32_t *out_b)
+{
+    if (!la || !trace || !out_a || !out_b || tspace < 1 || (mode != 0 && mode != 1) || la->tlen < 0 || la->tlen % 2)
+        return dh_fail(DH_EINVAL, "dh_translate_trace_point: bad argument");
+    if (apos < la->abpos || apos > la->aepos)  // the reference asserts contigA.begin <= pos <= contigA.end
+        return dh_fail(DH_EINVAL, "dh_translate_trace_point: position outside the local alignment");
+    if (la->tlen / 2 != (la->aepos + tspace - 1) / tspace - la->abpos / tspace)
+        return dh_fail(DH_EINVAL, "dh_translate_trace_point: trace length does not fit the A interval");
+    translate_trace_point(*la, trace + la->toff, tspace, apos, mode, out_a, out_b);
+    return DH_OK;
 }
 
 // isValidPileUpAlignment (flat), dazzler.d:4126-4141

@@ -156,6 +156,14 @@ int dh_las_read(const char *path, dh_la_set **out);
 int dh_las_merge(const char *const *paths, int32_t npaths, const char *out_path);
 
 
+/* ---- trace-point arithmetic of the alignment model (Trace.translateTracePoint!"contigA",
+ *      source/dentist/common/alignments/base.d:185-244; the cropper is built on it, cropper.d:503-550):
+ *      apos is assigned to a trace point of the LA (mode 0 = RoundingMode.floor, 1 = ceil); out_a /
+ *      out_b = that trace point on A and on B.  trace = the u16 array the record's toff indexes.
+ *      DH_EINVAL when apos lies outside [abpos, aepos] (the reference asserts). Host only. */
+int dh_translate_trace_point(const dh_la *la, const uint16_t *trace, int32_t tspace, int32_t apos,
+                             int32_t mode, int32_t *out_a, int32_t *out_b);
+
 /* ---- pile-ups: which reads span which gap.  Host-side stand-in for the part of `dentist collect`
  *      the consensus path needs (spanning reads only; the scaffold-graph builder of
  *      source/dentist/commands/collectPileUps/pileups.d is outside this library). */

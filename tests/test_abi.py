@@ -1,6 +1,7 @@
 """The C-ABI library loads and exports every symbol include/*.h declares (no GPU needed)."""
 import ctypes
 import glob
+import json
 import os
 import re
 
@@ -9,6 +10,8 @@ import pytest
 
 import dentist_amd
 from dentist_amd import _lib
+
+from test_oracle_golden import GOLD, dentist_flags, parse_ladump  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -130,3 +133,64 @@ def test_las_merge_of_block_files(tmp_path):
     assert keys == sorted(keys)
     got = sorted((int(l["aread"]), int(l["bread"]), tr[l["toff"]:l["toff"] + l["tlen"]].tolist()) for l in las)
     assert got == sorted(every)
+
+
+def _golden_la():
+    g = json.load(open(os.path.join(GOLD, "trace_cases.json")))
+    la = g["la"]
+    rec = np.zeros(1, dtype=dentist_amd.LA_DTYPE)
+    tr = np.asarray(la["tp"], dtype=np.uint16).reshape(-1)
+    rec[0]["abpos"], rec[0]["aepos"], rec[0]["bbpos"], rec[0]["bepos"] = la["abpos"], la["aepos"], la["bbpos"], la["bepos"]
+    rec[0]["diffs"], rec[0]["tlen"], rec[0]["toff"] = la["diffs"], len(tr), 0
+    return g, rec[0], tr, la["tspace"]
+
+
+def test_product_trace_translation_matches_the_reference_vectors():
+    """base.d:883-944 / :244-264 (translateTracePoint) applied to the PRODUCT's arithmetic through the
+    C ABI (dh_translate_trace_point is what dh_crop_pileups cuts reads with), not only to the oracle."""
+    g, la, tr, ts = _golden_la()
+    for apos, ea, eb in g["floor_cases"]:
+        assert dentist_amd.translate_trace_point(la, tr, ts, apos, "floor") == (ea, eb)
+    for p1, m1, p2, m2 in g["equal_pairs"]:
+        assert dentist_amd.translate_trace_point(la, tr, ts, p1, m1) == dentist_amd.translate_trace_point(la, tr, ts, p2, m2)
+
+
+def test_product_crop_to_trace_point_cases_of_the_reference():
+    """base.d:993-1129 (cropToTracePoint): a front crop keeps [begin, tp], a back crop [tp, end]; the
+    chain is disabled when nothing is left; positions outside the LA are an error."""
+    g, la, tr, ts = _golden_la()
+
+    def crop(seed, pos, mode):
+        a, b = dentist_amd.translate_trace_point(la, tr, ts, pos, mode)
+        empty = (a == la["abpos"] or b == la["bbpos"]) if seed == "front" else (a == la["aepos"] or b == la["bepos"])
+        return empty, a, b
+    for seed, pos, mode, disabled, ea, eb in g["crop_cases"]:
+        empty, a, b = crop(seed, pos, mode)
+        assert empty == disabled
+        if not disabled:
+            assert (a, b) == (ea, eb)
+    for seed, p1, m1, p2, m2 in g["equal_crop_pairs"]:
+        assert crop(seed, p1, m1) == crop(seed, p2, m2)
+    for pos in g["crop_throws"]:
+        with pytest.raises(dentist_amd.DhError):
+            dentist_amd.translate_trace_point(la, tr, ts, pos, "floor")
+
+
+def test_product_las_filter_roundtrip_of_the_reference(tmp_path):
+    """dazzler.d:3901-3988: read test.las, keep the even ids, write, read back -> the six expected
+    records (product codec on both legs)."""
+    g = json.load(open(os.path.join(GOLD, "las_dump.json")))
+    las, trace, _ = parse_ladump(g["dump"])
+    src = str(tmp_path / "test.las")
+    dentist_amd.las_write(src, las, trace, 100)
+    las1, trace1, ts = dentist_amd.las_read(src)
+    keep = las1[::2].copy()
+    dst = str(tmp_path / "test-filtered.las")
+    dentist_amd.las_write(dst, keep, trace1, ts)
+    las2, trace2, ts2 = dentist_amd.las_read(dst)
+    assert ts2 == 100 and len(las2) == len(g["filtered_even"])
+    for la, exp in zip(las2, g["filtered_even"]):
+        assert [la["aread"] + 1, la["abpos"], la["aepos"]] == exp["a"]
+        assert [la["bread"] + 1, la["bbpos"], la["bepos"]] == exp["b"]
+        assert sorted(dentist_flags(int(la["flags"]))) == sorted(exp["flags"])
+        assert trace2[la["toff"]:la["toff"] + la["tlen"]].reshape(-1, 2).tolist() == exp["tp"]

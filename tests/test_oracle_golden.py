@@ -148,6 +148,16 @@ def test_trace_translation_golden():
         assert translate(apos, "floor") == (ea, eb)
     for p1, m1, p2, m2 in g["equal_pairs"]:
         assert translate(p1, m1) == translate(p2, m2)
+    # cropToTracePoint (base.d:993-1129) in terms of the translation: front keeps [begin, tp], back [tp, end]
+    def crop(seed, pos, mode):
+        a, b = translate(pos, mode)
+        empty = (a == la["abpos"] or b == la["bbpos"]) if seed == "front" else (a == la["aepos"] or b == la["bepos"])
+        return empty, a, b
+    for seed, pos, mode, disabled, ea, eb in g["crop_cases"]:
+        empty, a, b = crop(seed, pos, mode)
+        assert empty == disabled and (disabled or (a, b) == (ea, eb))
+    for seed, p1, m1, p2, m2 in g["equal_crop_pairs"]:
+        assert crop(seed, p1, m1) == crop(seed, p2, m2)
     s = g["second"]
     n = L.oz_trace_points_up_to_a(s["abpos"], s["aepos"], s["tspace"], len(s["tp"]), s["apos"], 1)
     assert 0 <= n <= len(s["tp"])

@@ -108,8 +108,9 @@ def test_process_reference_fixture_gap_is_closed_perfectly(gpu_ctx, tmp_path):
     dentist_amd.output_fasta(path, contigs, [0, 0], [header[1:]], [97], rec, bases, bed_path=bed)
     data = open(path, "rb").read()
     assert data.decode() == f"{header}\tscaffold-1\n" + "\n".join(out[i:i + 50] for i in range(0, len(out), 50)) + "\n"
-    if r["left_aepos"] == 2000 and r["right_abpos"] == 0:
-        assert hashlib.md5(data).hexdigest() == "c3836dc00a3f5e1e2aa8f2a802da4d67"
+    # the flank overlaps reach the contig ends, so exactly the gap [2000, 2097) is inserted (upper case)
+    assert (r["left_aepos"], r["right_abpos"]) == (2000, 0)
+    assert hashlib.md5(data).hexdigest() == "c3836dc00a3f5e1e2aa8f2a802da4d67"   # tests/test-commands.sh:62-65
     b = open(bed).read().split("\t")
     assert b[0] == header[1:] and int(b[1]) == r["left_aepos"] and int(b[2]) == r["left_aepos"] + len(ins)
 
