@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kmer-mod", type=int, default=4)
     ap.add_argument("--map-k", type=int, default=20, help="k-mer length of the mapping pass (damapper's default)")
+    ap.add_argument("--map-width", type=int, default=14,
+                    help="live diagonals of the mapping waves: <= 14 runs four alignments per wavefront")
+    ap.add_argument("--map-xdrop", type=int, default=60, help="score lag that trims the mapping waves")
     ap.add_argument("--dev-share-gpu", action="store_true",
                     help="development only: all ranks on cuda:0 with gloo collectives (exercises the N > 1 "
                          "code path on a 1-GPU box; not a measurement)")
@@ -112,7 +115,8 @@ def main():
     ctx = dentist_amd.Context(local_rank, stream=stream)
     A, B = ctx.db(w.contigs), ctx.db(w.reads)
     # mapping pass: damapper's k-mer length, modimer sampling 1/4, every other option at its default
-    mopts = dentist_amd.default_align_opts(kmer_mod=args.kmer_mod, k=args.map_k)
+    mopts = dentist_amd.default_align_opts(kmer_mod=args.kmer_mod, k=args.map_k, width=args.map_width,
+                                           xdrop=args.map_xdrop)
     popts = dentist_amd.default_process_opts()
     read_bp = int(len(w.reads.bases))
 
@@ -208,7 +212,8 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": args.workload, "shape": spec, "mapping_k": args.map_k,
-                       "mapping_kmer_mod": args.kmer_mod, "parallelism": f"reads and gaps sharded over {world} GPU(s)",
+                       "mapping_kmer_mod": args.kmer_mod, "mapping_width": args.map_width,
+                       "mapping_xdrop": args.map_xdrop, "parallelism": f"reads and gaps sharded over {world} GPU(s)",
                        "read_bp_total": read_all, "pile_ups": int(last["info"]["piles"]),
                        "gaps_closed": nclosed_all, "gap_bases_closed": gap_all,
                        "consensus_edit_distance_vs_truth": edits_all, "consensus_truth_bases": truth_all,
@@ -263,7 +268,7 @@ def cpu_baseline(w, last, mopts, popts, args, gap_bases, read_bp_total):
     from dentist_amd import sim
     from oracle import pyoracle as oz
     cores = os.cpu_count() or 1
-    o = oz.default_opts(width=mopts.width, kmer_mod=mopts.kmer_mod, k=mopts.k)
+    o = oz.default_opts(width=mopts.width, kmer_mod=mopts.kmer_mod, k=mopts.k, xdrop=mopts.xdrop)
 
     def map_reads(n):
         sub = sim.SeqDb(w.reads.bases[:w.reads.off[n]], w.reads.off[:n + 1])

@@ -807,11 +807,14 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     const int32_t poolcap = 96 * nbmax;
     // resident alignment slots: one per wavefront of k_wave (<= 64 VGPRs -> 8 waves/SIMD), one per
     // 32-lane half of k_wave2 (two per wavefront, 6 waves/SIMD)
+    // alignments per wavefront of k_wave2: 2 (32 lanes each, width <= 30) or 4 (16 lanes, width <= 14)
+    const int32_t per_wave = (o.width <= 14 && !getenv("DH_WAVE_G32")) ? 4 : 2;
     int32_t slots_per_cu = 32;
-    if (o.width <= 30) slots_per_cu = 48;  // k_wave2: 80 VGPRs, 6 waves/SIMD, two slots per wavefront
-    if (const char *e = getenv("DH_WAVE_SLOTS_PER_CU")) slots_per_cu = std::max(2, atoi(e)) & ~1;
+    // k_wave2: 80 VGPRs -> 6 waves/SIMD = 24 wavefronts per CU (two per wavefront); 96 VGPRs -> 5 waves/SIMD = 20 (four)
+    if (o.width <= 30) slots_per_cu = per_wave == 4 ? 20 * 4 : 24 * 2;
+    if (const char *e = getenv("DH_WAVE_SLOTS_PER_CU")) slots_per_cu = std::max(4, atoi(e)) & ~3;
     const int32_t nslots = (int32_t)std::min<int64_t>((int64_t)ctx->ncu * slots_per_cu,
-                                                      (std::max<int64_t>(nitems_total, 2) + 1) & ~1ll);
+                                                      (std::max<int64_t>(nitems_total, 4) + 3) & ~3ll);
     const int32_t cn = (int32_t)std::min<int64_t>(chunk, std::max<int64_t>(nitems_total, 2));
     DhCand *d_cand;
     int32_t *d_ncand, *d_nhits, *d_status, *d_cdj;
@@ -937,7 +940,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         }
         WaveScratch ws{d_pool, d_cdj, d_queue, (const int4 *)d_units, d_queue + 3, poolcap, nbmax};
         if (dual)
-            dhk_wave2(st, nslots / 2, av, bv, A->d_rc, cc.rc, packed ? A->d_pk : nullptr,
+            dhk_wave2(st, nslots / per_wave, av, bv, A->d_rc, cc.rc, packed ? A->d_pk : nullptr,
                       packed ? A->d_rcpk : nullptr, packed ? cc.pk : nullptr, packed ? cc.rcpk : nullptr, dopt,
                       (int32_t)item0, ni, candbase, ncandbase, ws, labase, trbase, trmax, nlabase, ntrbase, d_counters,
                       d_status);

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "dh_device.h"
 
@@ -1169,6 +1170,9 @@ __device__ void walk_chain(const DhNode *__restrict__ pool, int32_t head, int32_
     lo = best_k < 0 ? best_k : 0;
     hi = best_k > 0 ? best_k : 0;
     int32_t h = head;
+#ifdef DH_SKIP_WALK
+    return;
+#endif
     for (int32_t m = nb - 1; m >= 0 && h >= 0; m--) {
         const DhNode nd = pool[h];
         cd[m] = nd.d;
@@ -1420,7 +1424,6 @@ k_wave(DbView A, DbView B, const uint8_t *__restrict__ brc, const uint8_t *__res
     }
 }
 
-#define HL_LANES 32
 // ------------------------------------------------------------------------------------ K5b
 //
 // k_wave2: two alignments per wavefront.  On average only ~19 of the 64 diagonals of a wavefront
@@ -1437,41 +1440,63 @@ k_wave(DbView A, DbView B, const uint8_t *__restrict__ brc, const uint8_t *__res
 enum { W2_FETCH = 0, W2_CAND = 1, W2_EXT = 2, W2_EXT_END = 3, W2_DONE = 4, W2_POST_CHAIN = 5, W2_POST_REC1 = 6,
        W2_POST_REC2 = 7 };
 
+// G lanes per alignment (32: two per wavefront, 16: four); hb = first lane of my group
+template <int G>
 __device__ __forceinline__ uint32_t hballot(bool p, int hb)
 {
     const uint64_t m = wballot(p);
-    return hb ? (uint32_t)(m >> 32) : (uint32_t)m;
+    if (G == 32) return hb ? (uint32_t)(m >> 32) : (uint32_t)m;
+    return (uint32_t)(m >> hb) & 0xFFFFu;
 }
-// value of lane `l` (constant) of my half
-template <int L>
+// value of lane `l` (constant) of my group
+template <int G, int L>
 __device__ __forceinline__ int32_t hlane(int32_t v, int hb)
 {
-    const int32_t a = __builtin_amdgcn_readlane(v, L), b = __builtin_amdgcn_readlane(v, 32 + L);
-    return hb ? b : a;
+    if (G == 32) {
+        const int32_t a = __builtin_amdgcn_readlane(v, L), b = __builtin_amdgcn_readlane(v, 32 + L);
+        return hb ? b : a;
+    }
+    // four groups: one trip through the LDS crossbar (the group's lanes are all active wherever this
+    // is used) instead of four readlanes and three selects
+    return __builtin_amdgcn_ds_bpermute((hb | L) << 2, v);
 }
-// value of lane l (half-uniform, 0..31) of my half; every lane of the half must be active
+// value of lane l (group-uniform, 0..G-1) of my group; every lane of the group must be active
 __device__ __forceinline__ int32_t hread(int32_t v, int32_t l, int hb)
 {
     return __builtin_amdgcn_ds_bpermute((hb | l) << 2, v);
 }
-// the same without the LDS crossbar round trip: two readlanes per half on scalar indices (for the
-// serial edge trimming, where the latency of ds_bpermute would sit on the critical path)
+// the same for the serial edge trimming.  Two groups: two readlanes per group on scalar indices
+// (no LDS crossbar round trip on the critical path); four groups: the crossbar after all (eight
+// readlanes plus selects cost more issue slots than the round trip costs latency)
+template <int G>
 __device__ __forceinline__ int32_t hread_fast(int32_t v, int32_t l, int hb)
 {
-    const int32_t l0 = __builtin_amdgcn_readlane(l, 0) & 31, l1 = __builtin_amdgcn_readlane(l, 32) & 31;
-    const int32_t a = __builtin_amdgcn_readlane(v, l0), b = __builtin_amdgcn_readlane(v, 32 + l1);
-    return hb ? b : a;
+    if (G == 32) {
+        const int32_t l0 = __builtin_amdgcn_readlane(l, 0) & 31, l1 = __builtin_amdgcn_readlane(l, 32) & 31;
+        const int32_t a = __builtin_amdgcn_readlane(v, l0), b = __builtin_amdgcn_readlane(v, 32 + l1);
+        return hb ? b : a;
+    }
+    return __builtin_amdgcn_ds_bpermute((hb | (l & 15)) << 2, v);
 }
-// max over the 32 lanes of my half
+// max over the G lanes of my group
+template <int G>
 __device__ __forceinline__ int32_t hmax_i32(int32_t v, int hb)
 {
     v = max(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, false));
     v = max(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, false));
     v = max(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, false));
     v = max(v, __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, false));
+    if (G == 16) return v;  // a DPP row is a group: every lane holds its row's maximum
     const int32_t r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
     const int32_t r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
     return hb ? max(r2, r3) : max(r0, r1);
+}
+// rotate the G-bit group mask right by r (0 <= r < G)
+template <int G>
+__device__ __forceinline__ uint32_t hrotr(uint32_t x, uint32_t r)
+{
+    if (G == 32) return __builtin_rotateright32(x, r);
+    return ((x | (x << 16)) >> r) & 0xFFFFu;
 }
 // forward slide with per-lane base pointers (bytes: p + i; packed: base index 4 * q + r + i,
 // p points at byte q)
@@ -1512,8 +1537,8 @@ struct W2Cold {
     unsigned long long cells, naln;
 };
 
-template <bool SYM, bool PK>
-__global__ void __launch_bounds__(LANES, 6)  // 80 VGPRs: measured best of 4 / 5 / 6 / 8 waves per SIMD
+template <bool SYM, bool PK, int G>
+__global__ void __launch_bounds__(LANES, G == 16 ? 5 : 6)  // G = 32: 80 VGPRs, measured best of 4 / 5 / 6 / 8 waves per SIMD
 k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__restrict__ brc,
         const uint8_t *__restrict__ apk, const uint8_t *__restrict__ arcpk,
         const uint8_t *__restrict__ bpk, const uint8_t *__restrict__ brcpk, DhOpts o, int32_t item0,
@@ -1522,21 +1547,22 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
         int32_t trmax, int32_t *__restrict__ out_nla, int32_t *__restrict__ out_ntr,
         unsigned long long *__restrict__ counters, int32_t *__restrict__ status)
 {
-    const int lane = threadIdx.x, hl = lane & 31, hb = lane & 32;
-    const int64_t slot = (int64_t)blockIdx.x * 2 + (lane >> 5);
+    constexpr int NG = LANES / G;  // alignments per wavefront
+    const int lane = threadIdx.x, hl = lane & (G - 1), hb = lane & (LANES - G), grp = lane / G;
+    const int64_t slot = (int64_t)blockIdx.x * NG + grp;
     DhNode *pool = ws.pool + slot * ws.poolcap;
     const int32_t ts = o.tspace, pen = o.pen, xdrop = o.xdrop, poolcap = ws.poolcap;
-    const int32_t addr_lo = (hb | ((hl - 1) & 31)) << 2, addr_hi = (hb | ((hl + 1) & 31)) << 2;
+    const int32_t addr_lo = (hb | ((hl - 1) & (G - 1))) << 2, addr_hi = (hb | ((hl + 1) & (G - 1))) << 2;
     constexpr int32_t DEAD = -(1 << 30);
 
     int32_t st = W2_FETCH, err = 0;
     // ---- cold state of the half (item, candidate, results, counters): half-uniform values that
     // only the bookkeeping touches live in LDS (every lane of the half writes the same value), so
     // that the stepping loop keeps its registers -- two alignments per wavefront at 8 waves/SIMD
-    __shared__ W2Cold cold_[2];
-    __shared__ int32_t greg_[2][14][HL_LANES];  // regions already aligned: region x in lane x & 31, set x >> 5
-    W2Cold &cs = cold_[lane >> 5];
-    int32_t(*gr)[HL_LANES] = greg_[lane >> 5];
+    __shared__ W2Cold cold_[NG];
+    __shared__ int32_t greg_[NG][7 * NG][G];  // regions already aligned: region x in lane x % G, set x / G
+    W2Cold &cs = cold_[grp];
+    int32_t(*gr)[G] = greg_[grp];
     cs.cells = 0;
     cs.naln = 0;
     // ---- the running extension (hot)
@@ -1610,11 +1636,11 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
             HB = hb0;
             NBB = tpb_first + nbb0 * ts;
         }
-        i0 = hlane<0>(i0, hb);
-        h0 = hlane<0>(h0, hb);
-        nb0 = hlane<0>(nb0, hb);
-        hb0 = hlane<0>(hb0, hb);
-        nbb0 = hlane<0>(nbb0, hb);
+        i0 = hlane<G, 0>(i0, hb);
+        h0 = hlane<G, 0>(h0, hb);
+        nb0 = hlane<G, 0>(nb0, hb);
+        hb0 = hlane<G, 0>(hb0, hb);
+        nbb0 = hlane<G, 0>(nbb0, hb);
         pool_n += nb0 + nbb0;
         best_score = 2 * i0;
         best_i = i0;
@@ -1629,7 +1655,18 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
         st = d <= o.dmax ? W2_EXT : W2_EXT_END;
     };
 
+#ifdef DH_WAVE_GUARD
+    uint32_t guard_ = 0;
+#endif
     for (;;) {
+#ifdef DH_WAVE_GUARD
+        if (++guard_ > (1u << 22)) {  // debug builds: a stuck state machine reports instead of hanging
+            if (hl == 0) printf("k_wave2 guard: block %d grp %d st %d d %d L %d item %d c %d nc %d nd %d\n", (int)blockIdx.x, grp,
+                                st, d, L, cs.item, cs.c, cs.nc, cs.nd);
+            err |= 8;
+            break;
+        }
+#endif
         // the stepping loop proper: left only when a half needs bookkeeping (or both are done)
         if (wballot(st != W2_EXT && st != W2_DONE) == 0ull && wballot(st == W2_EXT) != 0ull) do {
           {
@@ -1638,7 +1675,7 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
             // step is a no-op for it and the loop body needs no divergent region)
             R = st == W2_EXT ? R : DEAD;
             const int32_t nL = L - 1;
-            const int32_t kidx = (hl - nL) & 31;
+            const int32_t kidx = (hl - nL) & (G - 1);
             const int32_t k = nL + kidx;
             const int32_t Rm = __builtin_amdgcn_ds_bpermute(addr_lo, R), Hm = __builtin_amdgcn_ds_bpermute(addr_lo, H),
                           Nm = __builtin_amdgcn_ds_bpermute(addr_lo, NB);
@@ -1690,7 +1727,7 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
                 int32_t nextb = nbp;
                 bool cross = alive && ni >= nextb;
                 for (;;) {
-                    const uint32_t m = hballot(cross, hb);
+                    const uint32_t m = hballot<G>(cross, hb);
                     if (m == 0u) break;
                     if (cross) {
                         const int32_t idx = pool_n + __popc(m & ((1u << hl) - 1u));
@@ -1709,7 +1746,7 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
                 if (SYM) {
                     bool crossb = alive && j >= nextbb;
                     for (;;) {
-                        const uint32_t m = hballot(crossb, hb);
+                        const uint32_t m = hballot<G>(crossb, hb);
                         if (m == 0u) break;
                         if (crossb) {
                             const int32_t idx = pool_n + __popc(m & ((1u << hl) - 1u));
@@ -1735,13 +1772,13 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
                     HB = hbn;
                     NBB = nextbb;
                     const int32_t sc = alive ? 2 * ni - k - pen * d : INT32_MIN;
-                    const int32_t step_best = hmax_i32(sc, hb);
-                    const uint32_t rot = (uint32_t)nL & 31u;
+                    const int32_t step_best = hmax_i32<G>(sc, hb);
+                    const uint32_t rot = (uint32_t)nL & (uint32_t)(G - 1);
                     if (step_best > best_score) {
-                        const uint32_t hm = hballot(alive && sc == step_best, hb);
-                        const uint32_t hr = __builtin_rotateright32(hm, rot);
+                        const uint32_t hm = hballot<G>(alive && sc == step_best, hb);
+                        const uint32_t hr = hrotr<G>(hm, rot);
                         const int32_t step_kidx = __ffs((int)hr) - 1;
-                        const int32_t src = (nL + step_kidx) & 31;
+                        const int32_t src = (nL + step_kidx) & (G - 1);
                         best_score = step_best;
                         best_k = nL + step_kidx;
                         best_i = hread(R, src, hb);
@@ -1757,24 +1794,49 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
                         alive = false;
                         R = DEAD;
                     }
-                    uint32_t lm = hballot(alive, hb);
+                    uint32_t lm = hballot<G>(alive, hb);
                     if (lm == 0u) {
                         ended = true;
                     } else {
-                        uint32_t rm = __builtin_rotateright32(lm, rot);
+                        uint32_t rm = hrotr<G>(lm, rot);
                         int32_t l2 = nL + (__ffs((int)rm) - 1);
                         int32_t u2 = nL + (31 - __clz((int)rm));
+                        if (G == 16 && u2 - l2 + 1 > o.width) {
+                            // Narrow windows trim on most levels.  A level adds at most one diagonal on
+                            // each side, so at most two edges go: fetch the scores of the two lowest and
+                            // the two highest live diagonals in one crossbar round trip and replay the
+                            // rule (drop the lower-scoring edge, ties the low edge) on them.
+                            const uint32_t rml = rm & (rm - 1u);
+                            const int32_t pl0 = __ffs((int)rm) - 1, pu0 = 31 - __clz((int)rm);
+                            const int32_t pl1 = __ffs((int)rml) - 1, pu1 = 31 - __clz((int)(rm & ~(1u << pu0)));
+                            const int32_t val = 2 * R - k;
+                            const int32_t sl0 = hread(val, (nL + pl0) & (G - 1), hb), sl1 = hread(val, (nL + pl1) & (G - 1), hb);
+                            const int32_t su0 = hread(val, (nL + pu0) & (G - 1), hb), su1 = hread(val, (nL + pu1) & (G - 1), hb);
+                            const bool low1 = sl0 <= su0;
+                            const int32_t kill1 = low1 ? pl0 : pu0;
+                            const int32_t nl = low1 ? pl1 : pl0, nu = low1 ? pu0 : pu1;
+                            const bool low2 = (low1 ? sl1 : sl0) <= (low1 ? su0 : su1);
+                            const int32_t kill2 = nu - nl + 1 > o.width ? (low2 ? nl : nu) : -1;
+                            if (kidx == kill1 || kidx == kill2) {
+                                alive = false;
+                                R = DEAD;
+                            }
+                            lm = hballot<G>(alive, hb);
+                            rm = hrotr<G>(lm, rot);
+                            l2 = nL + (__ffs((int)rm) - 1);
+                            u2 = nL + (31 - __clz((int)rm));
+                        }
                         while (u2 - l2 + 1 > o.width) {
                             const int32_t val = 2 * R - k;
-                            const int32_t sl = hread_fast(val, l2, hb);
-                            const int32_t su = hread_fast(val, u2, hb);
+                            const int32_t sl = hread_fast<G>(val, l2, hb);
+                            const int32_t su = hread_fast<G>(val, u2, hb);
                             const int32_t kill = sl <= su ? l2 : u2;
                             if (k == kill) {
                                 alive = false;
                                 R = DEAD;
                             }
-                            lm = hballot(alive, hb);
-                            rm = __builtin_rotateright32(lm, rot);
+                            lm = hballot<G>(alive, hb);
+                            rm = hrotr<G>(lm, rot);
                             l2 = nL + (__ffs((int)rm) - 1);
                             u2 = nL + (31 - __clz((int)rm));
                         }
@@ -1792,7 +1854,7 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
                 if (st == W2_FETCH) {
                     int32_t it = 0;
                     if (hl == 0) it = (int32_t)atomicAdd(ws.queue, 1u);
-                    it = hlane<0>(it, hb);
+                    it = hlane<G, 0>(it, hb);
                     if (it >= (ws.units ? (int32_t)*ws.nunits : nitems)) {
                         st = W2_DONE;
                         break;
@@ -1813,8 +1875,8 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
                     const int64_t bo = B.off[item >> 1];
                     cs.bo = bo;
                     cs.blen = (int32_t)(B.off[(item >> 1) + 1] - bo);
-                    gr[0][hl] = -1;
-                    gr[7][hl] = -1;
+#pragma unroll
+                    for (int sx = 0; sx < NG; sx++) gr[7 * sx][hl] = -1;
                     cs.nd = cs.nacc = cs.ntr = 0;
                     cs.c = c0;
                     st = W2_CAND;
@@ -1825,13 +1887,14 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
                     while (c < nc && (SYM || cs.nacc < o.max_la) && nd < LANES) {
                         const DhCand cd = cand[(int64_t)item * o.max_cand + c];
                         const int32_t sdc = cd.apos - cd.bpos;
-                        const bool cov0 = hl < nd && gr[0][hl] == cd.aseq && cd.apos >= gr[1][hl] && cd.apos < gr[2][hl] &&
-                                          cd.bpos >= gr[3][hl] && cd.bpos < gr[4][hl] && sdc >= gr[5][hl] - 64 &&
-                                          sdc <= gr[6][hl] + 64;
-                        const bool cov1 = hl + 32 < nd && gr[7][hl] == cd.aseq && cd.apos >= gr[8][hl] &&
-                                          cd.apos < gr[9][hl] && cd.bpos >= gr[10][hl] && cd.bpos < gr[11][hl] &&
-                                          sdc >= gr[12][hl] - 64 && sdc <= gr[13][hl] + 64;
-                        if (hballot(cov0 || cov1, hb) != 0u) {
+                        bool covd = false;
+#pragma unroll 1
+                        for (int sx = 0; sx < NG; sx++)
+                            covd = covd || (hl + sx * G < nd && gr[7 * sx][hl] == cd.aseq && cd.apos >= gr[7 * sx + 1][hl] &&
+                                            cd.apos < gr[7 * sx + 2][hl] && cd.bpos >= gr[7 * sx + 3][hl] &&
+                                            cd.bpos < gr[7 * sx + 4][hl] && sdc >= gr[7 * sx + 5][hl] - 64 &&
+                                            sdc <= gr[7 * sx + 6][hl] + 64);
+                        if (hballot<G>(covd, hb) != 0u) {
                             c++;
                             continue;
                         }
@@ -1868,7 +1931,7 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
                     {
                         // sum of the per-lane counts over the half
                         uint32_t tot = ncell;
-                        for (int off = 16; off > 0; off >>= 1) tot += (uint32_t)__shfl_xor((int)tot, off, LANES);
+                        for (int off = G / 2; off > 0; off >>= 1) tot += (uint32_t)__shfl_xor((int)tot, off, LANES);
                         cs.cells += tot;
                     }
                     const int32_t r_nb = (best_nb - tp_first) / ts, r_nbb = SYM ? (best_nbb - tpb_first) / ts : 0;
@@ -1899,7 +1962,7 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
                     st = W2_POST_CHAIN;
                 } else if (st == W2_POST_CHAIN) {
                     // chains: lane 0 forward, lane 1 reverse, lanes 2 / 3 the B-boundary families (SYM)
-                    int32_t *cdj = ws.cdj + ((int64_t)blockIdx.x * 2 + (lane >> 5)) * 8 * ws.nbmax;
+                    int32_t *cdj = ws.cdj + slot * 8 * ws.nbmax;
                     int32_t clo = 0, chi = 0;
                     if (hl < (SYM ? 4 : 2)) {
                         const bool isf = (hl & 1) == 0, isb = hl >= 2;
@@ -1913,16 +1976,16 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
                         walk_chain(pool, head, nb, first, ts, bk, cd, cd + ws.nbmax, clo, chi);
                     }
                     __threadfence_block();
-                    const int32_t flo = hlane<0>(clo, hb), fhi = hlane<0>(chi, hb);
-                    const int32_t rlo = hlane<1>(clo, hb), rhi = hlane<1>(chi, hb);
+                    const int32_t flo = hlane<G, 0>(clo, hb), fhi = hlane<G, 0>(chi, hb);
+                    const int32_t rlo = hlane<G, 1>(clo, hb), rhi = hlane<G, 1>(chi, hb);
                     const int32_t as = cs.as, bs = cs.bs, sd = cs.sd, nd = cs.nd;
                     const int32_t abpos = as - cs.rv_i, bbpos = bs - cs.rv_j, aepos = as + cs.fw_i, bepos = bs + cs.fw_j;
                     const int32_t diffs = cs.fw_d + cs.rv_d;
                     int32_t lo = sd + flo, hi = sd + fhi;
                     lo = (sd - rhi) < lo ? (sd - rhi) : lo;
                     hi = (sd - rlo) > hi ? (sd - rlo) : hi;
-                    if (hl == (nd & 31)) {
-                        const int g0 = nd < 32 ? 0 : 7;
+                    if (hl == (nd & (G - 1))) {
+                        const int g0 = 7 * (nd / G);
                         gr[g0 + 0][hl] = cs.c_aseq;
                         gr[g0 + 1][hl] = abpos;
                         gr[g0 + 2][hl] = aepos;
@@ -1944,13 +2007,13 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
                     st = accept ? W2_POST_REC1 : W2_CAND;
                 } else if (st == W2_POST_REC1) {
                     // ---- the record (a, b): trace on the grid of A
-                    int32_t *cdj = ws.cdj + ((int64_t)blockIdx.x * 2 + (lane >> 5)) * 8 * ws.nbmax;
+                    int32_t *cdj = ws.cdj + slot * 8 * ws.nbmax;
                     const int32_t item = cs.item, strand = cs.strand, c_aseq = cs.c_aseq;
                     const int32_t item_a = SYM ? 2 * c_aseq + strand : item;
                     int32_t s1 = cs.nacc;
                     if (SYM) {
                         if (hl == 0) s1 = atomicAdd(&out_nla[item_a], 1);
-                        s1 = hlane<0>(s1, hb);
+                        s1 = hlane<G, 0>(s1, hb);
                         if (s1 >= o.max_la) {
                             err |= DH_ST_POOL_OVERFLOW;
                             st = W2_DONE;
@@ -1958,7 +2021,7 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
                         }
                     }
                     const int64_t oslot = (int64_t)item_a * o.max_la + s1;
-                    const int32_t npairs = emit_trace(hl, HL_LANES, ts, 0, cs.as, cs.bs, cs.abpos, cs.aepos, cs.bbpos,
+                    const int32_t npairs = emit_trace(hl, G, ts, 0, cs.as, cs.bs, cs.abpos, cs.aepos, cs.bbpos,
                                                       cs.bepos, cs.rv_d, cs.fw_d, cs.rev_first, cs.rv_nb,
                                                       cdj + 2 * (int64_t)ws.nbmax, cdj + 3 * (int64_t)ws.nbmax,
                                                       cs.fwd_first, cs.fw_nb, cdj, cdj + ws.nbmax, false,
@@ -1983,18 +2046,18 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
                     cs.ntr = cs.ntr + 2 * npairs;
                     st = SYM ? W2_POST_REC2 : W2_CAND;
                 } else {  // W2_POST_REC2: the transposed record (b, a), trace on the grid of B
-                    int32_t *cdj = ws.cdj + ((int64_t)blockIdx.x * 2 + (lane >> 5)) * 8 * ws.nbmax;
+                    int32_t *cdj = ws.cdj + slot * 8 * ws.nbmax;
                     const int32_t item = cs.item, strand = cs.strand;
                     int32_t s2 = 0;
                     if (hl == 0) s2 = atomicAdd(&out_nla[item], 1);
-                    s2 = hlane<0>(s2, hb);
+                    s2 = hlane<G, 0>(s2, hb);
                     if (s2 >= o.max_la) {
                         err |= DH_ST_POOL_OVERFLOW;
                         st = W2_DONE;
                         break;
                     }
                     const int64_t slot2 = (int64_t)item * o.max_la + s2;
-                    const int32_t np2 = emit_trace(hl, HL_LANES, ts, cs.resb, cs.bs, cs.as, cs.bbpos, cs.bepos, cs.abpos,
+                    const int32_t np2 = emit_trace(hl, G, ts, cs.resb, cs.bs, cs.as, cs.bbpos, cs.bepos, cs.abpos,
                                                    cs.aepos, cs.rv_d, cs.fw_d, cs.revb_first, cs.rv_nbb,
                                                    cdj + 6 * (int64_t)ws.nbmax, cdj + 7 * (int64_t)ws.nbmax,
                                                    cs.fwdb_first, cs.fw_nbb, cdj + 4 * (int64_t)ws.nbmax,
@@ -2214,8 +2277,9 @@ void dhk_wave(hipStream_t st, int32_t nslots, DbView A, DbView B, const uint8_t 
 #undef WAVE_LAUNCH
 }
 
-// two alignments per wavefront (o.width <= 30): nslots blocks, 2 * nslots scratch slots; needs the
-// reverse complement of A as well (arc, arcpk); apk / arcpk / bpk / brcpk all four or none
+// two (o.width <= 30) or four (o.width <= 14) alignments per wavefront: nslots blocks with 2 or 4
+// scratch slots each; needs the reverse complement of A as well (arc, arcpk); apk / arcpk / bpk /
+// brcpk all four or none
 void dhk_wave2(hipStream_t st, int32_t nslots, DbView A, DbView B, const uint8_t *arc, const uint8_t *brc,
                const uint8_t *apk, const uint8_t *arcpk, const uint8_t *bpk, const uint8_t *brcpk, DhOpts o,
                int32_t item0, int32_t nitems, const DhCand *cand, const int32_t *ncand, WaveScratch ws,
@@ -2225,9 +2289,16 @@ void dhk_wave2(hipStream_t st, int32_t nslots, DbView A, DbView B, const uint8_t
     if (nitems <= 0) return;
     const bool pk = apk && arcpk && bpk && brcpk;
 #define WAVE2_LAUNCH(S, P)                                                                         \
-    hipLaunchKernelGGL((k_wave2<S, P>), dim3(nslots), dim3(LANES), 0, st, A, B, arc, brc, apk, arcpk, bpk, brcpk, o, \
-                       item0, nitems, cand, ncand, ws, out_la, out_trace, trmax, out_nla, out_ntr, counters,  \
-                       status)
+    do {                                                                                           \
+        if (o.width <= 14 && !getenv("DH_WAVE_G32"))                                               \
+            hipLaunchKernelGGL((k_wave2<S, P, 16>), dim3(nslots), dim3(LANES), 0, st, A, B, arc, brc, apk, arcpk, bpk, \
+                               brcpk, o, item0, nitems, cand, ncand, ws, out_la, out_trace, trmax, out_nla, out_ntr,  \
+                               counters, status);                                                  \
+        else                                                                                       \
+            hipLaunchKernelGGL((k_wave2<S, P, 32>), dim3(nslots), dim3(LANES), 0, st, A, B, arc, brc, apk, arcpk, bpk, \
+                               brcpk, o, item0, nitems, cand, ncand, ws, out_la, out_trace, trmax, out_nla, out_ntr,  \
+                               counters, status);                                                  \
+    } while (0)
     if (o.skip_self == 2) {
         if (pk)
             WAVE2_LAUNCH(true, true);

@@ -70,6 +70,7 @@ extern "C" void dh_default_process_opts(dh_process_opts *o)
     o->max_align_err_ppm = 300000;
     o->max_ins_err_ppm = 100000;
     o->bad_fraction_ppm = 80000;
+    o->width = 30;
 }
 
 // ------------------------------------------------------------------------------------ DB helpers
@@ -1067,6 +1068,9 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
     const int32_t np = (int32_t)crop->rec.size();
     res->rec = crop->rec;
     const int32_t tsp = o.tspace_pile;
+    int32_t pwidth = o.width > 0 ? o.width : 30;
+    if (const char *e = getenv("DH_PILE_WIDTH")) pwidth = atoi(e);  // development override
+    if (pwidth < 1 || pwidth > 62) return dh_fail(DH_EINVAL, "process: width must be in [1, 62]");
 
     // ---- 1. the pile-up DB: the cropped reads of every pile-up that is large enough, grouped by
     // pile-up (group = index among the active pile-ups)
@@ -1139,6 +1143,7 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
         ao.skip_self = 2;  // every unordered pair aligned once, both records emitted (as daligner does)
         ao.max_la = 64;
         ao.max_cand = 128;
+        ao.width = pwidth;
         dh_la_set *pset = nullptr;
         HIPCHK(hipEventRecord(ev[0], st));
         if (int rc = dh_align_db_ex(ctx, pile, pile, &ao, 0, 0, &pset)) return rc;
@@ -1349,6 +1354,7 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
             ro.min_len = 500;
             ro.max_la = 4;
             ro.max_cand = 32;
+            ro.width = pwidth;
             dh_la_set *rset = nullptr;
             HIPCHK(hipEventRecord(ev[0], st));
             if (int rc = dh_align_db_ex(ctx, T, pile, &ro, 0, 0, &rset)) return rc;
@@ -1403,6 +1409,7 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
         fo.min_len = 126;
         fo.max_la = 4;
         fo.max_cand = 32;
+        fo.width = pwidth;
         dh_la_set *fset = nullptr;
         HIPCHK(hipEventRecord(ev[0], st));
         if (int rc = dh_align_db_ex(ctx, F, T, &fo, 0, 0, &fset)) return rc;

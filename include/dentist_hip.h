@@ -179,7 +179,7 @@ typedef struct {
     int32_t max_align_err_ppm; /* --max-alignment-error 0.30, commandline.d:1808                    */
     int32_t max_ins_err_ppm;   /* --max-insertion-error 0.10, commandline.d:1997                    */
     int32_t bad_fraction_ppm;  /* --bad-fraction 0.08, commandline.d:1101                           */
-    int32_t reserved;
+    int32_t width;             /* live diagonals of the wave in the pile-up stages (dh_align_opts.width), 0 = 30 */
 } dh_process_opts;
 void dh_default_process_opts(dh_process_opts *o);
 

@@ -240,15 +240,15 @@ def test_chunked_launches_give_identical_results(gpu_ctx, monkeypatch):
 
 @pytest.mark.parametrize("sym", [False, True])
 def test_wide_windows_use_one_alignment_per_wavefront(gpu_ctx, sym):
-    """width <= 30 (default) runs two alignments per wavefront (k_wave2), wider windows one
-    (k_wave): both against the oracle at their own width."""
+    """width <= 14 runs four alignments per wavefront (k_wave2 with 16-lane groups), width <= 30 two
+    (32-lane groups), wider windows one (k_wave): all against the oracle at their own width."""
     w = sim.Workload(200_000, 2, 300, 4000, seed=37, spacing=15000)
     if sym:
         sub = sim.SeqDb.from_list([w.reads.seq(i) for i in range(80)])
-        for width in (62, 30, 12):
+        for width in (62, 30, 14, 12, 5):
             run_both(gpu_ctx, sub, sub, same=True, skip_self=2, tspace=126, max_la=64, max_cand=128, width=width)
     else:
-        for width in (62, 30, 12):
+        for width in (62, 30, 14, 12, 5):
             run_both(gpu_ctx, w.contigs, w.reads, width=width)
 
 
