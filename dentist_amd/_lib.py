@@ -29,10 +29,10 @@ class AlignStats(ctypes.Structure):
                 ("wave_cells", ctypes.c_int64), ("las", ctypes.c_int64), ("b_bases", ctypes.c_int64),
                 ("ms_index", ctypes.c_float), ("ms_seed", ctypes.c_float), ("ms_wave", ctypes.c_float),
                 ("ms_gather", ctypes.c_float), ("ms_total", ctypes.c_float),
-                ("wave_launches", ctypes.c_int32), ("pad", ctypes.c_int32), ("big_items", ctypes.c_int64)]
+                ("wave_launches", ctypes.c_int32), ("overflow_items", ctypes.c_int32), ("big_items", ctypes.c_int64)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_ if n != "pad"}
+        return {n: getattr(self, n) for n, _ in self._fields_}
 
 
 class CumStats(ctypes.Structure):

@@ -838,6 +838,8 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     SCR(10, d_trslots, (size_t)cn * o.max_la * trmax)
     SCR(11, d_counters, 2)
     SCR(12, d_sums, (size_t)cn / 2048 + 4)
+    int32_t *d_ovf;
+    SCR(29, d_ovf, cn)
     HIPCHK(hipMemsetAsync(d_status, 0, sizeof(int32_t), st));
     HIPCHK(hipMemsetAsync(d_counters, 0, 2 * sizeof(unsigned long long), st));
 
@@ -883,12 +885,10 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             HIPCHK(hipMemcpyAsync(h_ncand.data(), d_ncand, sizeof(int32_t) * (size_t)ni, hipMemcpyDeviceToHost, st));
             HIPCHK(hipMemcpyAsync(h_nhits.data(), d_nhits, sizeof(int32_t) * (size_t)ni, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
-            if (status & DH_ST_CAND_OVERFLOW)
-                return fail(DH_EOVERFLOW, "seed filter: more than 256 candidate band pairs for one read");
             std::vector<int32_t> big;
             int32_t gcap = 0;
             for (int32_t it = 0; it < ni; it++)
-                if (h_ncand[(size_t)it] < 0) {
+                if (h_ncand[(size_t)it] == -1) {
                     big.push_back((int32_t)item0 + it);
                     gcap = std::max(gcap, h_nhits[(size_t)it]);
                 }
@@ -916,7 +916,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
                 }
                 HIPCHK(hipMemcpyAsync(&status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
                 HIPCHK(hipStreamSynchronize(st));
-                if (status & (DH_ST_HIT_OVERFLOW | DH_ST_CAND_OVERFLOW))
+                if (status & DH_ST_HIT_OVERFLOW)
                     return fail(DH_EOVERFLOW, "seed filter: capacity exceeded in the HBM-staged pass");
                 stats.big_items += (int64_t)big.size();
             }
@@ -938,7 +938,8 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             dhk_units(st, candbase, ncandbase, (int32_t)item0, ni, o.max_cand, d_units, d_queue + 3);
             HIPCHK(hipGetLastError());
         }
-        WaveScratch ws{d_pool, d_cdj, d_queue, (const int4 *)d_units, d_queue + 3, poolcap, nbmax};
+        HIPCHK(hipMemsetAsync(d_ovf, 0, sizeof(int32_t) * (size_t)ni, st));
+        WaveScratch ws{d_pool, d_cdj, d_queue, (const int4 *)d_units, d_queue + 3, poolcap, nbmax, d_ovf - item0};
         if (dual)
             dhk_wave2(st, nslots / per_wave, av, bv, A->d_rc, cc.rc, packed ? A->d_pk : nullptr,
                       packed ? A->d_rcpk : nullptr, packed ? cc.pk : nullptr, packed ? cc.rcpk : nullptr, dopt,
@@ -966,7 +967,20 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             return fail(DH_EOVERFLOW, "wave: trace-tree pool or boundary capacity exceeded");
         for (int32_t it = 0; it < ni; it++) {
             stats.hits += h_nhits[(size_t)it];
-            stats.cands += h_ncand[(size_t)it];
+            stats.cands += std::max(h_ncand[(size_t)it], 0);
+            if (h_ncand[(size_t)it] == -2) {  // seed filter gave up on the item (> 256 candidate band pairs)
+                stats.overflow_items++;
+                res->ovf_reads.push_back((int32_t)((item0 + it) >> 1));
+            }
+        }
+        if (o.skip_self == 2) {  // records dropped for want of slots (> max_la overlaps of one read and strand)
+            std::vector<int32_t> h_ovf((size_t)ni);
+            HIPCHK(hipMemcpy(h_ovf.data(), d_ovf, sizeof(int32_t) * (size_t)ni, hipMemcpyDeviceToHost));
+            for (int32_t it = 0; it < ni; it++)
+                if (h_ovf[(size_t)it]) {
+                    stats.overflow_items++;
+                    res->ovf_reads.push_back((int32_t)((item0 + it) >> 1));
+                }
         }
         if (totals[0] > 0) {
             SCR(13, d_laout, totals[0])

@@ -57,6 +57,7 @@ struct WaveScratch {
     const int4 *units;        // optional work units (item - item0, first candidate, end candidate, 0)
     const uint32_t *nunits;   // their number (device side)
     int32_t poolcap, nbmax;
+    int32_t *item_ovf;        // per item (absolute index): set when a record of the item was dropped (SYM: > max_la)
 };
 
 #ifdef __cplusplus

@@ -136,6 +136,9 @@ struct dh_la_set {
     // device copy of `trace` left behind by dh_align_db_ex (scratch arena): valid until the next
     // alignment call on the same context, nullptr when the result came in several chunks
     const uint16_t *d_trace = nullptr;
+    // B reads whose items overflowed a per-item capacity (dropped records / no candidates), see
+    // dh_align_stats.overflow_items; the pile-up path skips the pile-ups of such reads
+    std::vector<int32_t> ovf_reads;
 };
 
 template <typename T>

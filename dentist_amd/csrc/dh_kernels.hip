@@ -702,10 +702,9 @@ __device__ void seed_item(const DbView &B, const uint8_t *__restrict__ brc, cons
     SP(3)
     int32_t nc = s_nc;
     if (nc > SEED_CCAP) {
-        if (tid == 0) {
-            atomicOr(status, DH_ST_CAND_OVERFLOW);
-            ncand_out[item] = 0;
-        }
+        // more candidate band pairs than one read can sensibly have (a repeat the -t cap did not
+        // catch): the item yields no alignments and is reported (ncand = -2), the launch goes on
+        if (tid == 0) ncand_out[item] = -2;
         return;
     }
     // ---- rank by (score desc, band asc); bands are distinct so ranks are a permutation.  Symmetric
@@ -1352,9 +1351,13 @@ k_wave(DbView A, DbView B, const uint8_t *__restrict__ brc, const uint8_t *__res
             if (SYM) {
                 if (lane == 0) s1 = atomicAdd(&out_nla[item_a], 1);
                 s1 = __shfl(s1, 0, LANES);
-                if (s1 >= o.max_la) {
-                    err |= DH_ST_POOL_OVERFLOW;
-                    break;
+                if (s1 >= o.max_la) {  // more overlaps than slots: drop the pair, report both items
+                    if (lane == 0) {
+                        atomicSub(&out_nla[item_a], 1);
+                        ws.item_ovf[item_a] = 1;
+                        ws.item_ovf[item] = 1;
+                    }
+                    continue;
                 }
             }
             const int64_t slot = (int64_t)item_a * o.max_la + s1;
@@ -1386,8 +1389,12 @@ k_wave(DbView A, DbView B, const uint8_t *__restrict__ brc, const uint8_t *__res
                 if (lane == 0) s2 = atomicAdd(&out_nla[item2], 1);
                 s2 = __shfl(s2, 0, LANES);
                 if (s2 >= o.max_la) {
-                    err |= DH_ST_POOL_OVERFLOW;
-                    break;
+                    if (lane == 0) {
+                        atomicSub(&out_nla[item2], 1);
+                        ws.item_ovf[item2] = 1;
+                        ws.item_ovf[item_a] = 1;
+                    }
+                    continue;
                 }
                 const int64_t slot2 = (int64_t)item2 * o.max_la + s2;
                 const int32_t np2 = emit_trace(lane, LANES, ts, resb, bs, as, bbpos, bepos, abpos, aepos, rv.d, fw.d,
@@ -2015,9 +2022,15 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
                         if (hl == 0) s1 = atomicAdd(&out_nla[item_a], 1);
                         s1 = hlane<G, 0>(s1, hb);
                         if (s1 >= o.max_la) {
-                            err |= DH_ST_POOL_OVERFLOW;
-                            st = W2_DONE;
-                            break;
+                            // more overlaps than slots: the pair is dropped, both items are reported
+                            // (their pile-up is skipped by the caller), everything else goes on
+                            if (hl == 0) {
+                                atomicSub(&out_nla[item_a], 1);
+                                ws.item_ovf[item_a] = 1;
+                                ws.item_ovf[item] = 1;
+                            }
+                            st = W2_CAND;
+                            continue;
                         }
                     }
                     const int64_t oslot = (int64_t)item_a * o.max_la + s1;
@@ -2052,9 +2065,13 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
                     if (hl == 0) s2 = atomicAdd(&out_nla[item], 1);
                     s2 = hlane<G, 0>(s2, hb);
                     if (s2 >= o.max_la) {
-                        err |= DH_ST_POOL_OVERFLOW;
-                        st = W2_DONE;
-                        break;
+                        if (hl == 0) {
+                            atomicSub(&out_nla[item], 1);
+                            ws.item_ovf[item] = 1;
+                            ws.item_ovf[2 * cs.c_aseq + strand] = 1;
+                        }
+                        st = W2_CAND;
+                        continue;
                     }
                     const int64_t slot2 = (int64_t)item * o.max_la + s2;
                     const int32_t np2 = emit_trace(hl, G, ts, cs.resb, cs.bs, cs.as, cs.bbpos, cs.bepos, cs.abpos,

@@ -163,36 +163,54 @@ static int collect_candidates(const dh_la *las, int64_t n, const int64_t *contig
         std::vector<int64_t> cur(first.begin(), first.end() - 1);
         for (int64_t i = 0; i < n; i++) order[(size_t)cur[(size_t)las[i].bread]++] = i;
     }
-    std::map<int32_t, std::vector<int32_t>> piles;
-    for (int32_t rd = 0; rd < nreads; rd++) {
-        const int64_t *idx = order.data() + first[(size_t)rd], cnt = first[(size_t)rd + 1] - first[(size_t)rd];
-        if (cnt < 2) continue;
-        std::map<int32_t, std::pair<int64_t, std::pair<int64_t, int64_t>>> best;  // gap -> (anchor sum, (iL, iR))
-        for (int64_t x = 0; x < cnt; x++) {
-            const int64_t iL = idx[x];
-            const dh_la &L = las[iL];
-            if (L.aread + 1 >= ncontigs) continue;
-            const int64_t cl = contig_off[L.aread + 1] - contig_off[L.aread];
-            if (L.aepos + o.allowance < cl || L.aepos - L.abpos < o.min_anchor) continue;
-            for (int64_t y = 0; y < cnt; y++) {
-                const int64_t iR = idx[y];
-                const dh_la &R = las[iR];
-                if (R.aread != L.aread + 1 || (R.flags & DH_FLAG_COMP) != (L.flags & DH_FLAG_COMP)) continue;
-                if (R.abpos > o.allowance || R.aepos - R.abpos < o.min_anchor) continue;
-                if (R.bbpos + o.allowance < L.bepos - o.allowance) continue;
-                const int64_t anchors = (int64_t)(L.aepos - L.abpos) + (R.aepos - R.abpos);
-                auto it = best.find(L.aread);
-                if (it == best.end() || anchors > it->second.first)
-                    best[L.aread] = std::make_pair(anchors, std::make_pair(iL, iR));
+    // reads are independent: host threads take runs of reads and list their entries (gap, read, iL,
+    // iR) in read order; the runs are concatenated in order and split by gap afterwards
+    struct Ent {
+        int32_t gap, rd, iL, iR;
+    };
+    const int64_t grain = 16384, nchunks = ((int64_t)nreads + grain - 1) / grain;
+    std::vector<std::vector<Ent>> found((size_t)std::max<int64_t>(nchunks, 1));
+    dh_parallel_for(nchunks, 1, [&](int64_t clo, int64_t chi) {
+        for (int64_t c = clo; c < chi; c++) {
+            std::vector<Ent> &out_c = found[(size_t)c];
+            const int32_t r1 = (int32_t)std::min<int64_t>(nreads, (c + 1) * grain);
+            std::vector<std::pair<int32_t, std::pair<int64_t, std::pair<int64_t, int64_t>>>> best;  // gap -> (anchors, (iL, iR))
+            for (int32_t rd = (int32_t)(c * grain); rd < r1; rd++) {
+                const int64_t *idx = order.data() + first[(size_t)rd], cnt = first[(size_t)rd + 1] - first[(size_t)rd];
+                if (cnt < 2) continue;
+                best.clear();
+                for (int64_t x = 0; x < cnt; x++) {
+                    const int64_t iL = idx[x];
+                    const dh_la &L = las[iL];
+                    if (L.aread + 1 >= ncontigs) continue;
+                    const int64_t cl = contig_off[L.aread + 1] - contig_off[L.aread];
+                    if (L.aepos + o.allowance < cl || L.aepos - L.abpos < o.min_anchor) continue;
+                    for (int64_t y = 0; y < cnt; y++) {
+                        const int64_t iR = idx[y];
+                        const dh_la &R = las[iR];
+                        if (R.aread != L.aread + 1 || (R.flags & DH_FLAG_COMP) != (L.flags & DH_FLAG_COMP)) continue;
+                        if (R.abpos > o.allowance || R.aepos - R.abpos < o.min_anchor) continue;
+                        if (R.bbpos + o.allowance < L.bepos - o.allowance) continue;
+                        const int64_t anchors = (int64_t)(L.aepos - L.abpos) + (R.aepos - R.abpos);
+                        size_t k = 0;
+                        while (k < best.size() && best[k].first != L.aread) k++;
+                        if (k == best.size()) best.push_back(std::make_pair(L.aread, std::make_pair((int64_t)-1, std::make_pair(iL, iR))));
+                        if (anchors > best[k].second.first) best[k].second = std::make_pair(anchors, std::make_pair(iL, iR));
+                    }
+                }
+                for (auto &b : best)
+                    out_c.push_back(Ent{b.first, rd, (int32_t)b.second.second.first, (int32_t)b.second.second.second});
             }
         }
-        for (auto &kv : best) {
-            std::vector<int32_t> &v = piles[kv.first];
-            v.push_back(rd);
-            v.push_back((int32_t)kv.second.second.first);
-            v.push_back((int32_t)kv.second.second.second);
+    });
+    std::map<int32_t, std::vector<int32_t>> piles;
+    for (const std::vector<Ent> &v : found)
+        for (const Ent &e : v) {
+            std::vector<int32_t> &t = piles[e.gap];
+            t.push_back(e.rd);
+            t.push_back(e.iL);
+            t.push_back(e.iR);
         }
-    }
     dh_pileups *p = new dh_pileups();
     for (auto &kv : piles) {
         p->contig_left.push_back(kv.first);
@@ -505,6 +523,12 @@ static int consensus_round(dh_ctx *ctx, dh_db *T, dh_db *R, const LaVec &las,
         std::vector<size_t> soff(1, 0);
         for (size_t i = 0; i < las.size(); i++)
             if (tmpl_of[i] >= 0 && !(las[i].flags & DH_FLAG_DISABLED)) {
+                // an overlap with a tile spanning more than SEG_MAX B bases (a > 100 % local indel
+                // rate) takes no part in the vote
+                const uint16_t *tr = trace.data() + las[i].toff;
+                bool too_long = false;
+                for (int32_t e = 0; e < las[i].tlen / 2; e++) too_long = too_long || tr[2 * e + 1] > SEG_MAX;
+                if (too_long) continue;
                 sel.push_back(i);
                 soff.push_back(soff.back() + (size_t)(las[i].tlen / 2));
             }
@@ -540,7 +564,6 @@ static int consensus_round(dh_ctx *ctx, dh_db *T, dh_db *R, const LaVec &las,
             ncell += nc;
         });
     }
-    if (wmax > SEG_MAX) return dh_fail(DH_EOVERFLOW, "consensus: a trace tile is longer than 250 bases on B");
     *nseg_out = (int64_t)segs.size();
     *ncell_out = ncell;
     const int32_t nt = T->n;
@@ -1164,6 +1187,18 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
         if (int rc = elapsed(0, 1, ps.ms[1])) return rc;
         LaVec &pl = pset->la;
         ps.counters[0] = (int64_t)pl.size();
+        // reads whose overlaps did not fit the per-read slots: their pile-up is skipped with a status
+        // (the reference skips a failing pile-up and carries on, package.d:319-363)
+        for (int32_t r : pset->ovf_reads) {
+            const int32_t a = pile->h_group[(size_t)r];
+            if (active_ok[(size_t)a]) {
+                active_ok[(size_t)a] = 0;
+                res->rec[(size_t)pile_of_active[(size_t)a]].status = DH_PILE_ALIGN_OVERFLOW;
+            }
+        }
+        if (!pset->ovf_reads.empty())
+            for (dh_la &la : pl)
+                if (!active_ok[(size_t)pile->h_group[(size_t)la.aread]]) la.flags |= DH_FLAG_DISABLED;
         lap("group by aread");
         // ---- 3. the alignment funnel of computeQVs (package.d:474-516): averageErrorRate <=
         //         maxAlignmentError -> chainLocalAlignments -> isValidPileUpAlignment with
@@ -1267,7 +1302,7 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
                 if (!(pl[(size_t)i].flags & DH_FLAG_DISABLED)) any = true;
             dh_insertion &rec = res->rec[(size_t)pile_of_active[(size_t)a]];
             if (!any) {
-                rec.status = DH_PILE_EMPTY_ALIGNMENT;
+                if (rec.status == DH_PILE_OK) rec.status = DH_PILE_EMPTY_ALIGNMENT;
                 active_ok[(size_t)a] = 0;
                 continue;
             }

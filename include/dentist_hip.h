@@ -25,7 +25,7 @@ extern "C" {
 #define DH_EINVAL (-1)
 #define DH_ENODEV (-2)
 #define DH_EHIP (-3)
-#define DH_EOVERFLOW (-4) /* a device-side capacity (hit buffer, trace pool) was exceeded */
+#define DH_EOVERFLOW (-4) /* a device-side capacity planned from the input (trace pool, hit slab) was exceeded */
 #define DH_EIO (-5)
 #define DH_ENOMEM (-6)
 
@@ -110,7 +110,13 @@ typedef struct {
     int64_t hits, cands, alignments, wave_cells, las;
     int64_t b_bases;       /* bases of B processed (both strands counted once)               */
     float ms_index, ms_seed, ms_wave, ms_gather, ms_total; /* HIP-event times on ctx stream   */
-    int32_t wave_launches, pad;
+    int32_t wave_launches;
+    int32_t overflow_items; /* (read, strand) items that exceeded a per-item capacity: more than 256
+                             * candidate band pairs (the item yields no alignments) or, in symmetric
+                             * mode, more than max_la overlaps (the excess records are dropped).  The
+                             * call still succeeds; dh_process_pileups skips the pile-ups concerned
+                             * with DH_PILE_ALIGN_OVERFLOW, as the reference skips a failing pile-up
+                             * (processPileUps/package.d:319-363) */
     int64_t big_items;     /* (read, strand) items whose hits were staged in HBM instead of LDS  */
 } dh_align_stats;
 int dh_get_align_stats(dh_ctx *ctx, dh_align_stats *out);
@@ -223,6 +229,7 @@ int32_t dh_pileups_get(const dh_pileups *p, int32_t i, int32_t *contig_left, con
 #define DH_PILE_ORIENTATION 5
 #define DH_PILE_MAX_INSERTION_ERROR 6
 #define DH_PILE_NEGATIVE_INSERTION 7
+#define DH_PILE_ALIGN_OVERFLOW 8 /* a read of the pile-up exceeded a per-read capacity of the aligner */
 typedef struct {
     int32_t contig_left;   /* gap between contig_left and contig_left + 1                          */
     int32_t status;        /* DH_PILE_*                                                             */

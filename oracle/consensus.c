@@ -183,6 +183,12 @@ int32_t oz_consensus(const uint8_t *ref, int32_t rlen, const oz_db *reads, const
             b = rc;
         }
         const uint16_t *tr = s->trace + la->toff;
+        /* an overlap with a tile spanning more than OZ_SEG_MAX B bases (a > 100 % local indel rate)
+         * takes no part in the vote */
+        int too_long = 0;
+        for (int32_t e = 0; e < la->tlen / 2; e++)
+            if (tr[2 * e + 1] > OZ_SEG_MAX) too_long = 1;
+        if (too_long) continue;
         int32_t a0 = la->abpos, b0 = la->bbpos;
         for (int32_t e = 0; e < la->tlen / 2; e++) {
             int32_t a1 = (a0 / tspace + 1) * tspace;

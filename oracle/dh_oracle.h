@@ -160,6 +160,7 @@ uint32_t oz_nw(const uint8_t *ref, int32_t rlen, const uint8_t *qry, int32_t qle
 #define OZ_MAXQV 50
 #define OZ_MAXINS 4
 #define OZ_VOTE_STRIDE (6 + 4 * OZ_MAXINS)
+#define OZ_SEG_MAX 250 /* longest B stretch of one trace tile the consensus vote accepts */
 int oz_valid_pileup_alignment(const oz_la *la, int32_t alen, int32_t blen, int32_t allowance);
 void oz_tile_qv(const oz_la_set *s, int32_t nreads, const int32_t *rlen, int32_t tspace,
                 int32_t cov, uint8_t *qv, int32_t maxtiles);

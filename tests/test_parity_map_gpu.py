@@ -9,7 +9,7 @@ import pytest
 
 import dentist_amd
 from dentist_amd import sim
-from helpers import assert_same_las, check_trace_invariants
+from helpers import assert_same_las, check_trace_invariants, la_rows
 from oracle import pyoracle as oz
 
 pytestmark = pytest.mark.gpu
@@ -306,3 +306,22 @@ def test_option_sweep(gpu_ctx, kw):
     modimer moduli take the rotate-free divisibility test, ...): still bit-exact."""
     w = sim.Workload(150_000, 2, 250, 3000, seed=61, spacing=15000)
     run_both(gpu_ctx, w.contigs, w.reads, **kw)
+
+
+def test_per_item_overflow_is_reported_not_fatal(gpu_ctx):
+    """More overlaps of one read and strand than max_la slots (symmetric mode): the excess pairs are
+    dropped, the items are counted in overflow_items and the call succeeds (one read must not abort
+    a batch -- the reference skips a failing pile-up and carries on, processPileUps/package.d:319-363).
+    Everything that is returned is an alignment the oracle (with room for all) finds too."""
+    p = pile(41, n=40)
+    g, o = both_opts(skip_self=2, tspace=126, max_la=8, max_cand=128)
+    o.max_la = 64
+    exp = oz.align_db(p, p, o, nthreads=os.cpu_count() or 1)
+    d = gpu_ctx.db(p)
+    las, trace = gpu_ctx.align_db(d, d, g)
+    st = gpu_ctx.align_stats()
+    assert st.overflow_items > 0 and 0 < len(las) < len(exp[0])
+    want = set(la_rows(*exp[:2]))
+    assert all(r in want for r in la_rows(las, trace))
+    per_item = np.bincount(las["aread"] * 2 + (las["flags"] & 1))
+    assert per_item.max() <= 8
