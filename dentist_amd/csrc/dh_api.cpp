@@ -36,8 +36,15 @@ extern "C" void dhk_seed_prof_dump();
 #include <unordered_map>
 namespace {
 std::mutex g_alloc_mu;
-std::map<size_t, std::vector<void *>> g_free_lists;
-std::unordered_map<void *, size_t> g_block_size;
+// free blocks per (device, size class): a block is only handed back to the device it lives on
+std::map<std::pair<int, size_t>, std::vector<void *>> g_free_lists;
+std::unordered_map<void *, std::pair<int, size_t>> g_block_size;
+int current_device()
+{
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return d;
+}
 size_t size_class(size_t bytes)
 {
     if (bytes < 4096) return 4096;
@@ -51,9 +58,10 @@ size_t size_class(size_t bytes)
 hipError_t dh_dev_alloc(void **p, size_t bytes)
 {
     const size_t cls = size_class(bytes);
+    const int dev = current_device();
     {
         std::lock_guard<std::mutex> lk(g_alloc_mu);
-        auto it = g_free_lists.find(cls);
+        auto it = g_free_lists.find(std::make_pair(dev, cls));
         if (it != g_free_lists.end() && !it->second.empty()) {
             *p = it->second.back();
             it->second.pop_back();
@@ -67,7 +75,7 @@ hipError_t dh_dev_alloc(void **p, size_t bytes)
     }
     if (e == hipSuccess) {
         std::lock_guard<std::mutex> lk(g_alloc_mu);
-        g_block_size[*p] = cls;
+        g_block_size[*p] = std::make_pair(dev, cls);
     }
     return e;
 }
@@ -182,6 +190,19 @@ extern "C" int dh_ctx_create(int32_t device, void *stream, dh_ctx **out)
     if (device < 0 || device >= ndev) return fail(DH_EINVAL, "dh_ctx_create: bad device index");
     HIPCHK(hipSetDevice(device));
     dh_ctx *c = new dh_ctx();
+    struct CtxCreateGuard {
+        dh_ctx *&c;
+        bool ok = false;
+        ~CtxCreateGuard()
+        {
+            if (!ok && c) {
+                for (auto &e : c->ev)
+                    if (e) (void)hipEventDestroy(e);
+                if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+                delete c;
+            }
+        }
+    } cguard{c};
     c->device = device;
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
@@ -193,6 +214,7 @@ extern "C" int dh_ctx_create(int32_t device, void *stream, dh_ctx **out)
         c->own_stream = true;
     }
     for (auto &e : c->ev) HIPCHK(hipEventCreate(&e));
+    cguard.ok = true;
     *out = c;
     return DH_OK;
 }
@@ -293,36 +315,37 @@ extern "C" int dh_db_create(dh_ctx *ctx, const uint8_t *bases, const int64_t *of
     if (n > 0 && !bases) return fail(DH_EINVAL, "dh_db_create: bases is NULL");
     HIPCHK(hipSetDevice(ctx->device));
     dh_db *db = new dh_db();
+    struct DbCreateGuard {  // releases the half-built DB on any early return
+        dh_db *&d;
+        bool ok = false;
+        ~DbCreateGuard()
+        {
+            if (!ok && d) {
+                dh_dev_free(d->d_bases_alloc);
+                dh_dev_free(d->d_off);
+                dh_dev_free(d->d_group);
+                delete d;
+            }
+        }
+    } guard{db};
     db->ctx = ctx;
     db->n = n;
     db->h_off.assign(off, off + n + 1);
     db->total = off[n] - off[0];
-    if (off[0] != 0) {
-        delete db;
-        return fail(DH_EINVAL, "dh_db_create: off[0] must be 0");
-    }
+    if (off[0] != 0) return fail(DH_EINVAL, "dh_db_create: off[0] must be 0");
     for (int32_t i = 0; i < n; i++) {
         const int64_t l = off[i + 1] - off[i];
-        if (l < 0 || l >= (1 << 24)) {
-            delete db;
-            return fail(DH_EINVAL, "dh_db_create: sequence length must be in [0, 2^24)");
-        }
+        if (l < 0 || l >= (1 << 24)) return fail(DH_EINVAL, "dh_db_create: sequence length must be in [0, 2^24)");
         db->max_len = std::max<int32_t>(db->max_len, (int32_t)l);
     }
     if (group) {
         db->h_group.assign(group, group + n);
         for (int32_t g : db->h_group) {
-            if (g < 0) {
-                delete db;
-                return fail(DH_EINVAL, "dh_db_create: negative group id");
-            }
+            if (g < 0) return fail(DH_EINVAL, "dh_db_create: negative group id");
             db->ngroups = std::max(db->ngroups, g + 1);
         }
     }
-    if (int rc = dh_alloc_bases(ctx->stream, db->total, &db->d_bases_alloc, &db->d_bases)) {
-        delete db;
-        return rc;
-    }
+    if (int rc = dh_alloc_bases(ctx->stream, db->total, &db->d_bases_alloc, &db->d_bases)) return rc;
     HIPCHK(dh_dev_alloc(&db->d_off, sizeof(int64_t) * (size_t)(n + 1)));
     if (db->total > 0)
         HIPCHK(hipMemcpyAsync(db->d_bases, bases, (size_t)db->total, hipMemcpyHostToDevice, ctx->stream));
@@ -334,6 +357,7 @@ extern "C" int dh_db_create(dh_ctx *ctx, const uint8_t *bases, const int64_t *of
                               ctx->stream));
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    guard.ok = true;
     *out = db;
     return DH_OK;
 }

@@ -101,6 +101,11 @@ extern "C" int dh_output_fasta(const char *fasta_path, const char *bed_path, con
             if (last) break;
             if (ci >= 0) {
                 const dh_insertion &in = ins[ci];
+                if (in.ins_begin < 0 || in.ins_begin > in.ins_end || in.ins_end > in.cons_len || in.cons_off < 0) {
+                    fclose(f);
+                    if (bed) fclose(bed);
+                    return dh_fail(DH_EINVAL, "dh_output_fasta: insertion outside its consensus");
+                }
                 const uint8_t *cons = ins_bases + in.cons_off;
                 const int64_t n = (int64_t)in.ins_end - in.ins_begin;
                 for (int64_t x = 0; x < n; x++) {
@@ -110,9 +115,10 @@ extern "C" int dh_output_fasta(const char *fasta_path, const char *bed_path, con
                     if (in.comp && b < 4) b = (uint8_t)(3 - b);
                     w.put((highlight ? UPPER : LOWER)[b < 4 ? b : 4]);
                 }
+                // output.d:879-891: currentScaffoldCoord - 1 and nextScaffoldCoord (= current + length)
                 if (bed)
                     ok = ok && fprintf(bed, "%s\t%lld\t%lld\tcontigs-%d-%d|reads-%d\n", id.c_str(),
-                                       (long long)(coord - 1), (long long)(coord - 1 + n), c + 1, c + 2,
+                                       (long long)(coord - 1), (long long)(coord + n), c + 1, c + 2,
                                        in.ref_read_id + 1) > 0;
                 coord += n;
                 from = in.right_abpos;

@@ -46,6 +46,7 @@ void dhk_emit(hipStream_t st, DbView T, int32_t ntmpl, const int64_t *voff, cons
 #define VSTRIDE (6 + 4 * MAXINS)
 #define MAXQV 50
 #define SEG_MAX 250
+#define FLAG_IMPROPER 0x40u /* internal: fails isValidPileUpAlignment, dropped after the tile QVs */
 
 struct PartDescH {
     int32_t src, sidx, sbeg, len, rc, pad;
@@ -1241,8 +1242,10 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
                         if (la.flags & DH_FLAG_DISABLED) continue;
                         const int32_t alen = (int32_t)(pile->h_off[(size_t)la.aread + 1] - pile->h_off[(size_t)la.aread]);
                         const int32_t blen = (int32_t)(pile->h_off[(size_t)la.bread + 1] - pile->h_off[(size_t)la.bread]);
+                        // improper overlaps still count for the tile QVs: DASqv runs on the chained
+                        // file, filterPileUpAlignments comes after it (package.d:492-512)
                         if (!valid_pileup_alignment(la, la.aread == la.bread, alen, blen, tsp))
-                            la.flags |= DH_FLAG_DISABLED;
+                            la.flags |= FLAG_IMPROPER;
                     }
                 }
             });
@@ -1291,6 +1294,9 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
         }
         HIPCHK(hipEventRecord(ev[1], st));
         if (int rc = elapsed(0, 1, ps.ms[2])) return rc;
+        // filterPileUpAlignments (properAlignmentAllowance), dazzler.d:4043-4094: after the QVs
+        for (dh_la &la : pl)
+            if (la.flags & FLAG_IMPROPER) la.flags = (la.flags & ~FLAG_IMPROPER) | DH_FLAG_DISABLED;
         lap("tile qv");
         // ---- 5. reference read per pile-up: findReferenceReadCandidates (package.d:518-568)
         std::vector<int32_t> ref_of((size_t)na, -1);

@@ -453,6 +453,11 @@ static void process_one(const oz_db *contigs, const oz_db *reads, const oz_la *l
             chain_pair(ps.la, p0, p1, tsp);
             p0 = p1;
         }
+        /* DAScover + DASqv on the chained file, then filterPileUpAlignments (package.d:492-512) */
+        const int32_t maxtiles = (maxlen + tsp - 1) / tsp > 0 ? (maxlen + tsp - 1) / tsp : 1;
+        uint8_t *qv = (uint8_t *)malloc((size_t)pile.n * maxtiles);
+        memset(qv, 255, (size_t)pile.n * maxtiles);
+        oz_tile_qv(&ps, pile.n, rlen, tsp, pile.n, qv, maxtiles);
         int any = 0;
         for (int64_t i = 0; i < ps.n; i++) {
             oz_la *la = &ps.la[i];
@@ -464,14 +469,11 @@ static void process_one(const oz_db *contigs, const oz_db *reads, const oz_la *l
         }
         if (!any) {
             r->status = 3;
+            free(qv);
             oz_la_set_free(&ps);
             free(rlen);
             goto done_pile;
         }
-        const int32_t maxtiles = (maxlen + tsp - 1) / tsp > 0 ? (maxlen + tsp - 1) / tsp : 1;
-        uint8_t *qv = (uint8_t *)malloc((size_t)pile.n * maxtiles);
-        memset(qv, 255, (size_t)pile.n * maxtiles);
-        oz_tile_qv(&ps, pile.n, rlen, tsp, pile.n, qv, maxtiles);
         int32_t *order = (int32_t *)malloc((size_t)pile.n * sizeof(int32_t)), norder = 0;
         oz_rank_reference_reads(qv, pile.n, rlen, tsp, maxtiles, NULL, (double)o->bad_fraction_ppm / 1e6, order, &norder);
         const int32_t ref = order[0];

@@ -132,7 +132,7 @@ def pile_opts():
     return oz.default_opts(tspace=TS_PILE, min_len=500, skip_self=2, max_la=64, max_cand=128, width=WAVE_WIDTH)
 
 
-def filter_pile_las(las, pile, max_err_ppm=300000, allowance=TS_PILE):
+def filter_pile_las(las, pile, max_err_ppm=300000, allowance=TS_PILE, proper=True):
     """computeQVs' alignment funnel (processPileUps/package.d:474-516): filterLocalAlignments
     (averageErrorRate <= maxAlignmentError) -> chainLocalAlignments -> filterPileUpAlignments
     (properAlignmentAllowance, forceFlat; dazzler.d:4066-4094).  Dropped LAs get DISABLED (0x20)."""
@@ -142,6 +142,14 @@ def filter_pile_las(las, pile, max_err_ppm=300000, allowance=TS_PILE):
         if int(la["diffs"]) * 1000000 > max_err_ppm * al:
             la["flags"] |= 0x20
     las = chain_pile_las(las)
+    if proper:
+        las = filter_proper(las, pile, allowance)
+    return las
+
+
+def filter_proper(las, pile, allowance=TS_PILE):
+    """filterPileUpAlignments (dazzler.d:4043-4094); runs AFTER the tile QVs (package.d:492-512)."""
+    las = las.copy()
     for la in las:
         if la["flags"] & 0x20:
             continue
@@ -231,14 +239,16 @@ def process_pile(entries, las, trace, contigs, reads, g, rounds=3, nthreads=1, f
         return res
     o = pile_opts()
     plas, ptrace, _ = oz.align_db(pile, pile, o, nthreads=nthreads)
-    plas = filter_pile_las(plas, pile)
+    # computeQVs (package.d:474-516): error filter -> chain -> DAScover/DASqv -> proper-overlap filter
+    chained = filter_pile_las(plas, pile, proper=False)
+    rlen = np.asarray([pile.length(i) for i in range(pile.n)], dtype=np.int32)
+    cov = pile.n if pile.n >= 4 else pile.n   # max(#allowed reference reads, 4 if pile >= 4) (package.d:498-503)
+    qv = oz.tile_qv(chained, ptrace, rlen, TS_PILE, max(cov, 4) if pile.n >= 4 else cov)
+    plas = filter_proper(chained, pile)
     res.update(pile_las=plas, pile_trace=ptrace)
     if not np.any((plas["flags"] & 0x20) == 0):
         res["status"] = "empty pileup alignment after filtering"
         return res
-    rlen = np.asarray([pile.length(i) for i in range(pile.n)], dtype=np.int32)
-    cov = pile.n if pile.n >= 4 else pile.n   # max(#allowed reference reads, 4 if pile >= 4) (package.d:498-503)
-    qv = oz.tile_qv(plas, ptrace, rlen, TS_PILE, max(cov, 4) if pile.n >= 4 else cov)
     order, badqv = oz.rank_reference_reads(qv, rlen, TS_PILE)
     ref_idx = int(order[0])
     res.update(qv=qv, order=order, ref_idx=ref_idx)

@@ -112,7 +112,8 @@ def test_process_reference_fixture_gap_is_closed_perfectly(gpu_ctx, tmp_path):
     assert (r["left_aepos"], r["right_abpos"]) == (2000, 0)
     assert hashlib.md5(data).hexdigest() == "c3836dc00a3f5e1e2aa8f2a802da4d67"   # tests/test-commands.sh:62-65
     b = open(bed).read().split("\t")
-    assert b[0] == header[1:] and int(b[1]) == r["left_aepos"] and int(b[2]) == r["left_aepos"] + len(ins)
+    # output.d:879-891: start = currentScaffoldCoord - 1, end = nextScaffoldCoord (1-based, one past the 0-based end)
+    assert b[0] == header[1:] and int(b[1]) == r["left_aepos"] and int(b[2]) == r["left_aepos"] + len(ins) + 1
 
 
 def test_config1_full_size_properties(gpu_ctx):
