@@ -48,7 +48,7 @@ class CumStats(ctypes.Structure):
 class ProcessOpts(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "tspace_map", "allowance", "min_anchor", "min_reads", "max_reads", "tspace_pile", "rounds",
-        "flank_window", "max_align_err_ppm", "max_ins_err_ppm", "bad_fraction_ppm", "width")]
+        "flank_window", "max_align_err_ppm", "max_ins_err_ppm", "bad_fraction_ppm", "width", "dust", "reserved")]
 
 
 INSERTION_DTYPE = np.dtype([(n, "<i4") for n in (
@@ -77,7 +77,7 @@ SYMBOLS = [
     "dh_collect_candidates", "dh_pileups_create", "dh_pileups_select", "dh_align_db_block", "dh_la_set_merge",
     "dh_crop_pileups", "dh_cropped_create", "dh_cropped_destroy", "dh_cropped_npiles", "dh_cropped_records",
     "dh_cropped_nreads", "dh_cropped_pile", "dh_cropped_entry", "dh_cropped_read_id", "dh_cropped_offsets",
-    "dh_cropped_bases", "dh_process_cropped", "dh_translate_trace_point",
+    "dh_cropped_bases", "dh_process_cropped", "dh_translate_trace_point", "dh_db_dust", "dh_db_get_mask",
 ]
 
 _LIB = None
@@ -175,6 +175,9 @@ def lib():
     L.dh_dazz_read_mask.restype = i64
     L.dh_dazz_write_mask.argtypes = [ctypes.c_char_p, ctypes.c_char_p, i32, vp, vp]
     L.dh_db_set_mask.argtypes = [vp, vp, vp]
+    L.dh_db_dust.argtypes = [vp]
+    L.dh_db_get_mask.argtypes = [vp, vp, vp, i64]
+    L.dh_db_get_mask.restype = i64
     L.dh_las_merge.argtypes = [ctypes.POINTER(ctypes.c_char_p), i32, ctypes.c_char_p]
     L.dh_tile_qv.argtypes = [vp, vp, vp, i64, vp, i32, i32, vp, i32]
     L.dh_consensus.argtypes = [vp, vp, vp, i64, vp, i32, i32, i32, vp, i64, ctypes.POINTER(i64)]
@@ -338,6 +341,21 @@ class Db:
         p = np.ascontiguousarray(ptr, dtype=np.int64)
         v = np.ascontiguousarray(iv, dtype=np.int32)
         _check(lib().dh_db_set_mask(self._h, p.ctypes.data, v.ctypes.data))
+
+    def dust(self):
+        """DBdust on the device: low-complexity windows are ORed into the soft mask."""
+        _check(lib().dh_db_dust(self._h))
+
+    def get_mask(self):
+        """The soft mask as (ptr int64[n+1], iv int32 (begin, end) pairs)."""
+        n = lib().dh_db_nreads(self._h)
+        ptr = np.zeros(n + 1, dtype=np.int64)
+        m = lib().dh_db_get_mask(self._h, ptr.ctypes.data, None, 0)
+        if m < 0:
+            _check(int(m))
+        iv = np.zeros(max(2 * m, 2), dtype=np.int32)
+        lib().dh_db_get_mask(self._h, ptr.ctypes.data, iv.ctypes.data, m)
+        return ptr, iv[:2 * m]
 
     def close(self):
         if self._h:

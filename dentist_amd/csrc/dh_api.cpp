@@ -176,7 +176,7 @@ void dh_pinned_trim()
 }
 
 extern "C" const char *dh_last_error(void) { return g_err.c_str(); }
-extern "C" int32_t dh_abi_version(void) { return 1; }
+extern "C" int32_t dh_abi_version(void) { return 2; }
 
 // ------------------------------------------------------------------------------------ context
 
@@ -373,27 +373,36 @@ extern "C" void dh_db_destroy(dh_db *db)
     dh_dev_free(db->d_rcpk_alloc);
     dh_dev_free(db->d_off);
     dh_dev_free(db->d_group);
-    dh_dev_free(db->d_mask_ptr);
-    dh_dev_free(db->d_mask_iv);
+    dh_dev_free(db->d_mask_bits);
     if (db->has_ix) db->ix.release();
     delete db;
 }
 
-// soft mask of the DB (union of the daligner -m tracks): per sequence sorted, disjoint intervals.
-// Passing ptr == NULL clears it.  The cached k-mer index is dropped.
+static size_t mask_bytes(const dh_db *db) { return (size_t)((db->total + 31) / 32) * 4 + 16; }
+
+int dh_ensure_mask_bits(dh_db *db)
+{
+    if (db->d_mask_bits) return DH_OK;
+    HIPCHK(dh_dev_alloc(&db->d_mask_bits, mask_bytes(db)));
+    HIPCHK(hipMemsetAsync(db->d_mask_bits, 0, mask_bytes(db), db->ctx->stream));
+    return DH_OK;
+}
+
+// soft mask of the DB (union of the daligner -m tracks): per sequence sorted, disjoint intervals,
+// rasterised into the DB's mask bitmap (ORed with DBdust's bits if dh_db_dust ran before).
+// Passing ptr == NULL clears the whole mask.  The cached k-mer index is dropped.
 extern "C" int dh_db_set_mask(dh_db *db, const int64_t *ptr, const int32_t *iv)
 {
     if (!db) return fail(DH_EINVAL, "db is NULL");
     HIPCHK(hipSetDevice(db->ctx->device));
     HIPCHK(hipStreamSynchronize(db->ctx->stream));
-    dh_dev_free(db->d_mask_ptr);
-    dh_dev_free(db->d_mask_iv);
-    db->d_mask_ptr = nullptr;
-    db->d_mask_iv = nullptr;
     if (db->has_ix) db->ix.release();
     db->has_ix = false;
-    if (!ptr) return DH_OK;
-    const int64_t m = ptr[db->n];
+    if (!ptr) {
+        dh_dev_free(db->d_mask_bits);
+        db->d_mask_bits = nullptr;
+        return DH_OK;
+    }
     for (int32_t s = 0; s < db->n; s++) {
         if (ptr[s] > ptr[s + 1]) return fail(DH_EINVAL, "dh_db_set_mask: pointers must be non-decreasing");
         const int64_t len = db->h_off[(size_t)s + 1] - db->h_off[(size_t)s];
@@ -402,15 +411,89 @@ extern "C" int dh_db_set_mask(dh_db *db, const int64_t *ptr, const int32_t *iv)
                 (j > ptr[s] && iv[2 * j] < iv[2 * j - 1]))
                 return fail(DH_EINVAL, "dh_db_set_mask: intervals must be sorted, disjoint and inside the sequence");
     }
-    HIPCHK(dh_dev_alloc(&db->d_mask_ptr, sizeof(int64_t) * (size_t)(db->n + 1)));
-    HIPCHK(dh_dev_alloc(&db->d_mask_iv, sizeof(int32_t) * (size_t)std::max<int64_t>(2 * m, 2)));
-    HIPCHK(hipMemcpyAsync(db->d_mask_ptr, ptr, sizeof(int64_t) * (size_t)(db->n + 1), hipMemcpyHostToDevice,
-                          db->ctx->stream));
-    if (m > 0)
-        HIPCHK(hipMemcpyAsync(db->d_mask_iv, iv, sizeof(int32_t) * (size_t)(2 * m), hipMemcpyHostToDevice,
-                              db->ctx->stream));
+    std::vector<uint8_t> bits(mask_bytes(db), 0);
+    for (int32_t s = 0; s < db->n; s++)
+        for (int64_t j = ptr[s]; j < ptr[s + 1]; j++)
+            for (int64_t g = db->h_off[(size_t)s] + iv[2 * j]; g < db->h_off[(size_t)s] + iv[2 * j + 1]; g++)
+                bits[(size_t)(g >> 3)] |= (uint8_t)(1u << (g & 7));
+    const bool had = db->d_mask_bits != nullptr;
+    if (int rc = dh_ensure_mask_bits(db)) return rc;
+    if (had) {  // keep what is there (e.g. the dust bits): OR on the host
+        std::vector<uint8_t> cur(bits.size());
+        HIPCHK(hipMemcpy(cur.data(), db->d_mask_bits, cur.size(), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < bits.size(); i++) bits[i] |= cur[i];
+    }
+    HIPCHK(hipMemcpyAsync(db->d_mask_bits, bits.data(), bits.size(), hipMemcpyHostToDevice, db->ctx->stream));
     HIPCHK(hipStreamSynchronize(db->ctx->stream));
     return DH_OK;
+}
+
+int dh_db_dust_impl(dh_db *db)
+{
+    dh_ctx *ctx = db->ctx;
+    if (db->has_ix) db->ix.release();
+    db->has_ix = false;
+    if (int rc = dh_ensure_mask_bits(db)) return rc;
+    const int32_t chunk = db->max_len < 16384 ? 64 : 512;
+    const int64_t tile = 256ll * chunk;
+    std::vector<int2> tiles;
+    for (int32_t s = 0; s < db->n; s++) {
+        const int64_t len = db->h_off[(size_t)s + 1] - db->h_off[(size_t)s];
+        for (int64_t a = 0; a < len - 15; a += tile) tiles.push_back(int2{s, (int32_t)a});
+    }
+    if (tiles.empty()) return DH_OK;
+    DevBuf<int2> d_tiles;
+    HIPCHK(d_tiles.alloc(tiles.size()));
+    HIPCHK(hipMemcpyAsync(d_tiles.p, tiles.data(), sizeof(int2) * tiles.size(), hipMemcpyHostToDevice, ctx->stream));
+    dhk_dust(ctx->stream, db->d_bases, db->d_off, d_tiles.p, (int32_t)tiles.size(), chunk, (uint32_t *)db->d_mask_bits);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return DH_OK;
+}
+
+// DBdust (symmetric DUST, -w64 -t2.0 -m10; the reference runs it on every DB it aligns with -mdust,
+// processPileUps/package.d:476, 655): the low-complexity mask is computed on the device and ORed
+// into the DB's soft mask
+extern "C" int dh_db_dust(dh_db *db)
+{
+    if (!db) return fail(DH_EINVAL, "db is NULL");
+    HIPCHK(hipSetDevice(db->ctx->device));
+    return dh_db_dust_impl(db);
+}
+
+// the mask as intervals (what `DBdust` writes into the `dust` track, dazzler.d:4943-5170): ptr gets
+// n + 1 entries; iv may be NULL to size; returns the number of intervals or a negative error
+extern "C" int64_t dh_db_get_mask(dh_db *db, int64_t *ptr, int32_t *iv, int64_t iv_cap)
+{
+    if (!db || !ptr) return fail(DH_EINVAL, "dh_db_get_mask: NULL argument");
+    std::vector<uint8_t> bits(mask_bytes(db), 0);
+    if (db->d_mask_bits) {
+        if (hipSetDevice(db->ctx->device) != hipSuccess || hipStreamSynchronize(db->ctx->stream) != hipSuccess ||
+            hipMemcpy(bits.data(), db->d_mask_bits, bits.size(), hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(DH_EHIP, "dh_db_get_mask: device to host copy failed");
+    }
+    int64_t m = 0;
+    for (int32_t s = 0; s < db->n; s++) {
+        ptr[s] = m;
+        const int64_t o = db->h_off[(size_t)s], e = db->h_off[(size_t)s + 1];
+        int64_t g = o;
+        while (g < e) {
+            if (!(bits[(size_t)(g >> 3)] >> (g & 7) & 1)) {
+                g++;
+                continue;
+            }
+            int64_t h = g;
+            while (h < e && (bits[(size_t)(h >> 3)] >> (h & 7) & 1)) h++;
+            if (iv && m < iv_cap) {
+                iv[2 * m] = (int32_t)(g - o);
+                iv[2 * m + 1] = (int32_t)(h - o);
+            }
+            m++;
+            g = h;
+        }
+    }
+    ptr[db->n] = m;
+    return m;
 }
 
 extern "C" int32_t dh_db_nreads(const dh_db *db) { return db ? db->n : 0; }

@@ -21,10 +21,9 @@ struct DbView {
     const int64_t *off;    // n + 1 offsets
     const int32_t *group;  // optional
     int32_t n;
-    // optional soft mask (daligner -m): sorted disjoint intervals mask_iv[2j], mask_iv[2j+1] for
-    // j in [mask_ptr[s], mask_ptr[s+1]); k-mers touching one are neither indexed nor looked up
-    const int64_t *mask_ptr;
-    const int32_t *mask_iv;
+    // optional soft mask (daligner -m tracks, DBdust): one bit per base of `bases` (bit g = base g is
+    // masked); k-mers touching a masked base are neither indexed nor looked up
+    const uint8_t *mask_bits;
 };
 
 struct IndexView {
@@ -87,6 +86,10 @@ void dhk_wave2(hipStream_t st, int32_t nslots, DbView A, DbView B, const uint8_t
 void dhk_units(hipStream_t st, const DhCand *cand, const int32_t *ncand, int32_t item0, int32_t nitems,
                int32_t max_cand, void *units, uint32_t *nunits);
 void dhk_pack2(hipStream_t st, const uint8_t *src, int64_t total, uint8_t *dst, int32_t *flag);
+void dhk_dust(hipStream_t st, const uint8_t *bases, const int64_t *off, const int2 *tiles, int32_t ntiles,
+              int32_t chunk, uint32_t *bits);
+void dhk_mask_slices(hipStream_t st, const uint32_t *src_bits, const int64_t *src_off, const int32_t *sidx,
+                     const int32_t *sbeg, const int64_t *dst_off, int32_t n, int32_t max_len, uint32_t *dst_bits);
 void dhk_compact(hipStream_t st, const DhLa *la_slots, const uint16_t *tr_slots, int32_t trmax,
                  int32_t max_la, int32_t ordered, int32_t nitems, const uint32_t *la_off,
                  const uint32_t *tr_off, int64_t tr_base, DhLa *la_out, uint16_t *tr_out);

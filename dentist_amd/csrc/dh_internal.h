@@ -95,9 +95,10 @@ struct dh_db {
     std::vector<int32_t> h_group;
     dh_index ix;
     bool has_ix = false;
-    int64_t *d_mask_ptr = nullptr;
-    int32_t *d_mask_iv = nullptr;
-    DbView view() const { return DbView{d_bases, d_off, d_group, n, d_mask_ptr, d_mask_iv}; }
+    // soft mask: one bit per base of d_bases (bit g of the buffer = base g), 16 bytes of slack at the
+    // end for the kernels' unaligned 8-byte reads; nullptr = nothing masked
+    uint8_t *d_mask_bits = nullptr;
+    DbView view() const { return DbView{d_bases, d_off, d_group, n, d_mask_bits}; }
 };
 
 // Result buffers live in pooled page-locked host memory: device-to-host copies into them run at
@@ -151,11 +152,15 @@ struct DevBuf {
 // build a DB whose bases are slices [beg, beg+len) of sequences of `src` (device-to-device)
 int dh_db_from_slices(dh_ctx *ctx, const dh_db *src, const std::vector<int32_t> &sidx,
                       const std::vector<int32_t> &sbeg, const std::vector<int32_t> &slen,
-                      const std::vector<int32_t> &group, dh_db **out);
+                      const std::vector<int32_t> &group, dh_db **out, bool inherit_mask = false);
 // adopt device bases allocated with dh_alloc_bases (ownership moves to the DB)
 int dh_db_adopt(dh_ctx *ctx, uint8_t *d_alloc, uint8_t *d_bases, const std::vector<int64_t> &off,
                 const std::vector<int32_t> &group, dh_db **out);
 int dh_ensure_rc(dh_db *db);
+// the DB's mask bitmap, allocated and zeroed on first use
+int dh_ensure_mask_bits(dh_db *db);
+// DBdust: ORs the low-complexity mask (k_dust) into the DB's mask bitmap; drops the cached index
+int dh_db_dust_impl(dh_db *db);
 int dh_ensure_packed(dh_db *db, bool with_rc);
 // dh_align_db with the final LAsort made optional (internal callers regroup on their own)
 int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, int32_t want_best,

@@ -65,55 +65,13 @@ __device__ __forceinline__ uint64_t load8(const uint8_t *p)
     return x;
 }
 
-// ---- soft masks: cursor over the sorted intervals of one sequence, optionally mirrored for the
-// reverse-complement strand; positions are visited in increasing order by each thread
-struct MaskCur {
-    const int32_t *iv;
-    int64_t lo, n, cur;
-    int32_t len, rc;
-};
-__device__ __forceinline__ void mask_get(const MaskCur &m, int64_t j, int32_t &b, int32_t &e)
+// ---- soft masks (daligner / damapper -m<track>, DBdust): one bit per base of the concatenated base
+// array (DbView.mask_bits, bit g = base g is masked).  A k-mer is neither indexed nor looked up when
+// it touches a masked base: k <= 28 bits read with one unaligned 8-byte load.
+__device__ __forceinline__ bool mask_touch(const uint8_t *__restrict__ bits, int64_t g, int32_t k)
 {
-    if (!m.rc) {
-        b = m.iv[2 * (m.lo + j)];
-        e = m.iv[2 * (m.lo + j) + 1];
-    } else {
-        const int64_t o = m.lo + m.n - 1 - j;
-        b = m.len - m.iv[2 * o + 1];
-        e = m.len - m.iv[2 * o];
-    }
-}
-__device__ __forceinline__ MaskCur mask_open(const DbView &db, int32_t s, int32_t len, int32_t rc, int32_t p)
-{
-    MaskCur m;
-    m.iv = db.mask_iv;
-    m.lo = db.mask_ptr ? db.mask_ptr[s] : 0;
-    m.n = db.mask_ptr ? db.mask_ptr[s + 1] - m.lo : 0;
-    m.len = len;
-    m.rc = rc;
-    // first interval whose end is > p
-    int64_t lo = 0, hi = m.n;
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        int32_t b, e;
-        mask_get(m, mid, b, e);
-        if (e <= p)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    m.cur = lo;
-    return m;
-}
-__device__ __forceinline__ bool mask_touch(MaskCur &m, int32_t p, int32_t k)
-{
-    int32_t b = 0, e = 0;
-    while (m.cur < m.n) {
-        mask_get(m, m.cur, b, e);
-        if (e > p) break;
-        m.cur++;
-    }
-    return m.cur < m.n && b < p + k;
+    const uint64_t w = load8(bits + (g >> 3)) >> (g & 7);
+    return (w & ((1ull << k) - 1ull)) != 0ull;
 }
 
 // ------------------------------------------------------------------------------------ K1
@@ -200,7 +158,6 @@ k_kmer_pass(DbView A, const int2 *__restrict__ tiles, int32_t ntiles, int32_t k,
     uint64_t km = 0;
     int32_t valid = 0;
     const uint8_t *a = A.bases + o;
-    MaskCur mc = mask_open(A, s, len, 0, p0);
     for (int32_t x = 0; x < KM_TILE / 256 + k - 1; x++) {
         const int32_t p = p0 + x;
         if (p >= len) break;
@@ -213,7 +170,7 @@ k_kmer_pass(DbView A, const int2 *__restrict__ tiles, int32_t ntiles, int32_t k,
             valid = 0;
         }
         if (x >= k - 1 && valid >= k && kmer_sampled(km, smp) &&
-            !(A.mask_ptr && mask_touch(mc, p - k + 1, k))) {
+            !(A.mask_bits && mask_touch(A.mask_bits, o + p - k + 1, k))) {
             const uint64_t key = (grp << (2 * k)) | km;
             const uint32_t b = (uint32_t)(key >> shift);
             if (FILL) {
@@ -390,7 +347,6 @@ __device__ void seed_item(const DbView &B, const uint8_t *__restrict__ brc, cons
         uint64_t km = 0;
         int32_t valid = 0;
         const int32_t pend = q0 < q1 ? q1 + k - 1 : q0;
-        MaskCur mc = mask_open(B, r, blen, strand, q0);
         uint64_t qk[QN];
         int32_t qq[QN];
         int32_t nq = 0;
@@ -482,7 +438,11 @@ __device__ void seed_item(const DbView &B, const uint8_t *__restrict__ brc, cons
                     valid = 0;
                 }
                 bool em = valid >= k && kmer_sampled(km, smp);
-                if (em && B.mask_ptr && mask_touch(mc, pp - k + 1, k)) em = false;
+                // reverse strand: the k-mer at position q of the reverse complement covers the forward
+                // bases [blen - q - k, blen - q)
+                if (em && B.mask_bits &&
+                    mask_touch(B.mask_bits, bo + (strand ? blen - (pp - k + 1) - k : pp - k + 1), k))
+                    em = false;
                 if (em) {
                     const uint64_t key = (grp << (2 * k)) | km;
                     const int32_t q = pp - k + 1;
@@ -2186,6 +2146,81 @@ static int seed_grid(int32_t nitems, int32_t ncu)
     return (int)(g < nitems ? g : nitems);
 }
 
+// ------------------------------------------------------------------------------------ DUST
+// Low-complexity mask (the role of DBdust, symmetric DUST with -w64 -t2.0 -m10): a window of L bases
+// (L = 16, 32, 64) is low-complexity when the triplets inside it repeat too often,
+//     S = sum over triplet codes of c (c - 1) / 2  >  2 (l - 1),   l = L - 2 triplets,
+// i.e. a DUST score above 2.0; the mask is the union of all such windows (windows holding a
+// non-ACGT base are skipped).  The score depends on the multiset of triplets only, so a sequence and
+// its reverse complement get mirrored masks.  One launch per window length; a thread slides its
+// window over a chunk of `chunk` starts (a tile = 256 chunks) with byte counters in LDS ([code][thread]).
+template <int L>
+__global__ void __launch_bounds__(256)
+k_dust(const uint8_t *__restrict__ bases, const int64_t *__restrict__ off, const int2 *__restrict__ tiles,
+       int32_t ntiles, int32_t chunk, uint32_t *__restrict__ bits)
+{
+    __shared__ uint8_t cnt[64][256];
+    const int32_t t = blockIdx.x;
+    if (t >= ntiles) return;
+    const int tid = threadIdx.x;
+    const int32_t s = tiles[t].x;
+    const int64_t o = off[s];
+    const int32_t len = (int32_t)(off[s + 1] - o);
+    const int32_t a0 = tiles[t].y + tid * chunk;      // first window start of this thread
+    const int32_t a1 = min(a0 + chunk, len - L + 1);  // end of its window starts
+    if (a0 >= a1) return;
+    for (int c = 0; c < 64; c++) cnt[c][tid] = 0;
+    const uint8_t *b = bases + o;
+    auto trip = [&](int32_t i) -> int32_t {  // code of the triplet at i, -1 when it holds a non-base
+        const uint32_t x = b[i], y = b[i + 1], z = b[i + 2];
+        return (x | y | z) > 3u ? -1 : (int32_t)(x << 4 | y << 2 | z);
+    };
+    int32_t S = 0, bad = 0;
+    for (int32_t i = a0; i < a0 + L - 2; i++) {
+        const int32_t c = trip(i);
+        if (c < 0)
+            bad++;
+        else
+            S += cnt[c][tid]++;
+    }
+    for (int32_t a = a0; a < a1; a++) {
+        if (bad == 0 && S > 2 * (L - 3)) {
+            const int64_t g0 = o + a, g1 = g0 + L;  // mask [g0, g1)
+            for (int64_t wd = g0 >> 5; wd <= (g1 - 1) >> 5; wd++) {
+                const int64_t lo = max(g0, wd << 5), hi = min(g1, (wd + 1) << 5);
+                const uint32_t m = (hi - lo == 32) ? 0xFFFFFFFFu : (((1u << (hi - lo)) - 1u) << (lo & 31));
+                if ((bits[wd] & m) != m) atomicOr(&bits[wd], m);
+            }
+        }
+        if (a + 1 < a1) {  // slide: triplet a leaves, triplet a + L - 2 enters
+            const int32_t c0 = trip(a), c1 = trip(a + L - 2);
+            if (c0 < 0)
+                bad--;
+            else
+                S -= --cnt[c0][tid];
+            if (c1 < 0)
+                bad++;
+            else
+                S += cnt[c1][tid]++;
+        }
+    }
+}
+
+// mask bits of slices: destination sequence i = source sequence sidx[i] from sbeg[i] on
+__global__ void __launch_bounds__(256)
+k_mask_slices(const uint32_t *__restrict__ src_bits, const int64_t *__restrict__ src_off,
+              const int32_t *__restrict__ sidx, const int32_t *__restrict__ sbeg,
+              const int64_t *__restrict__ dst_off, int32_t n, uint32_t *__restrict__ dst_bits)
+{
+    const int32_t i = blockIdx.y;
+    if (i >= n) return;
+    const int64_t d0 = dst_off[i], len = dst_off[i + 1] - d0, s0 = src_off[sidx[i]] + sbeg[i];
+    for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < len; x += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t g = s0 + x;
+        if (src_bits[g >> 5] >> (g & 31) & 1u) atomicOr(&dst_bits[(d0 + x) >> 5], 1u << ((d0 + x) & 31));
+    }
+}
+
 extern "C" {
 
 void dhk_revcomp(hipStream_t st, const uint8_t *src, uint8_t *dst, const int64_t *off, int32_t n,
@@ -2353,6 +2388,28 @@ void dhk_compact(hipStream_t st, const DhLa *la_slots, const uint16_t *tr_slots,
     if (nitems <= 0) return;
     hipLaunchKernelGGL(k_compact, dim3(nitems), dim3(LANES), 0, st, la_slots, tr_slots, trmax, max_la, ordered,
                        nitems, la_off, tr_off, tr_base, la_out, tr_out);
+}
+
+void dhk_dust(hipStream_t st, const uint8_t *bases, const int64_t *off, const int2 *tiles, int32_t ntiles,
+              int32_t chunk, uint32_t *bits)
+{
+    if (ntiles <= 0) return;
+    hipLaunchKernelGGL(k_dust<16>, dim3(ntiles), dim3(256), 0, st, bases, off, tiles, ntiles, chunk, bits);
+    hipLaunchKernelGGL(k_dust<32>, dim3(ntiles), dim3(256), 0, st, bases, off, tiles, ntiles, chunk, bits);
+    hipLaunchKernelGGL(k_dust<64>, dim3(ntiles), dim3(256), 0, st, bases, off, tiles, ntiles, chunk, bits);
+}
+
+void dhk_mask_slices(hipStream_t st, const uint32_t *src_bits, const int64_t *src_off, const int32_t *sidx,
+                     const int32_t *sbeg, const int64_t *dst_off, int32_t n, int32_t max_len, uint32_t *dst_bits)
+{
+    if (n <= 0) return;
+    int gx = (max_len + 255) / 256;
+    gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+    for (int32_t s0 = 0; s0 < n; s0 += 65535) {
+        const int32_t cnt = n - s0 < 65535 ? n - s0 : 65535;
+        hipLaunchKernelGGL(k_mask_slices, dim3(gx, cnt), dim3(256), 0, st, src_bits, src_off, sidx + s0, sbeg + s0,
+                           dst_off + s0, cnt, dst_bits);
+    }
 }
 
 }  // extern "C"

@@ -72,6 +72,7 @@ extern "C" void dh_default_process_opts(dh_process_opts *o)
     o->max_ins_err_ppm = 100000;
     o->bad_fraction_ppm = 80000;
     o->width = 30;
+    o->dust = 1;
 }
 
 // ------------------------------------------------------------------------------------ DB helpers
@@ -105,7 +106,7 @@ int dh_db_adopt(dh_ctx *ctx, uint8_t *d_alloc, uint8_t *d_bases, const std::vect
 
 int dh_db_from_slices(dh_ctx *ctx, const dh_db *src, const std::vector<int32_t> &sidx,
                       const std::vector<int32_t> &sbeg, const std::vector<int32_t> &slen,
-                      const std::vector<int32_t> &group, dh_db **out)
+                      const std::vector<int32_t> &group, dh_db **out, bool inherit_mask)
 {
     const int32_t n = (int32_t)sidx.size();
     std::vector<int64_t> off((size_t)n + 1, 0);
@@ -130,6 +131,11 @@ int dh_db_from_slices(dh_ctx *ctx, const dh_db *src, const std::vector<int32_t> 
                               ctx->stream));
         dhk_gather_slices(ctx->stream, src->d_bases, src->d_off, d_sidx.p, d_sbeg.p, (*out)->d_off, n,
                           max_len, d_bases);
+        if (inherit_mask && src->d_mask_bits) {  // slices keep the soft mask of their source (the flank DB's -mrep)
+            if (int rc = dh_ensure_mask_bits(*out)) return rc;
+            dhk_mask_slices(ctx->stream, (const uint32_t *)src->d_mask_bits, src->d_off, d_sidx.p, d_sbeg.p, (*out)->d_off, n,
+                            max_len, (uint32_t *)(*out)->d_mask_bits);
+        }
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(ctx->stream));
     }
@@ -1151,6 +1157,8 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
             slen[x] = (int32_t)(crop->off[(size_t)keep[x] + 1] - crop->off[(size_t)keep[x]]);
         if (int rc = dh_db_from_slices(ctx, crop->dev, keep, sbeg, slen, sgroup, &pile)) return rc;
         dbg.dbs.push_back(pile);
+        if (o.dust)  // DBdust pileup.db; daligner ... -mdust (package.d:476-482)
+            if (int rc = dh_db_dust_impl(pile)) return rc;
     }
     HIPCHK(hipEventRecord(ev[1], st));
     if (int rc = elapsed(0, 1, ps.ms[0])) return rc;
@@ -1442,8 +1450,10 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
             fgrp.push_back(a);
         }
         dh_db *F = nullptr;
-        if (int rc = dh_db_from_slices(ctx, contigs, fidx, fbeg, flen, fgrp, &F)) return rc;
+        if (int rc = dh_db_from_slices(ctx, contigs, fidx, fbeg, flen, fgrp, &F, true)) return rc;
         dbg.dbs.push_back(F);
+        if (o.dust)  // DBdust contigs.dam; daligner -A ... -mdust -mrep (package.d:631-667)
+            if (int rc = dh_db_dust_impl(F)) return rc;
         dh_align_opts fo;
         dh_default_align_opts(&fo);
         fo.tspace = tsp;

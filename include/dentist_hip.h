@@ -77,6 +77,14 @@ void dh_db_destroy(dh_db *db);
  * [ptr[s], ptr[s+1]).  k-mers touching a masked interval are neither indexed (A side) nor looked
  * up (B side); alignments still extend through masked sequence.  ptr == NULL clears the mask. */
 int dh_db_set_mask(dh_db *db, const int64_t *ptr, const int32_t *iv);
+/* DBdust (symmetric DUST, -w64 -t2.0 -m10; DENTIST runs it on every DB it aligns with -mdust,
+ * processPileUps/package.d:476-482, 655-667): low-complexity windows are found on the device and
+ * ORed into the DB's soft mask.  A window of L = 16, 32 or 64 bases is masked when its triplets
+ * repeat with a DUST score above 2.0: sum_t c_t (c_t - 1) / 2 > 2 (L - 3).
+ * dh_db_get_mask returns the current soft mask as intervals (what DBdust writes into the `dust`
+ * track): ptr gets n + 1 entries, iv may be NULL to size; returns the interval count or < 0. */
+int dh_db_dust(dh_db *db);
+int64_t dh_db_get_mask(dh_db *db, int64_t *ptr, int32_t *iv, int64_t iv_cap);
 /* drop cached derived data (k-mer index, reverse complement): the next dh_align_db rebuilds it */
 int dh_db_drop_cache(dh_db *db);
 int32_t dh_db_nreads(const dh_db *db);
@@ -186,6 +194,9 @@ typedef struct {
     int32_t max_ins_err_ppm;   /* --max-insertion-error 0.10, commandline.d:1997                    */
     int32_t bad_fraction_ppm;  /* --bad-fraction 0.08, commandline.d:1101                           */
     int32_t width;             /* live diagonals of the wave in the pile-up stages (dh_align_opts.width), 0 = 30 */
+    int32_t dust;              /* 1: DBdust + -mdust on the pile-up DB and the flank DB (package.d:476-482,
+                                * 655-667); the flank DB also inherits the contigs' soft mask (-mrep)       */
+    int32_t reserved;
 } dh_process_opts;
 void dh_default_process_opts(dh_process_opts *o);
 

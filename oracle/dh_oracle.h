@@ -173,7 +173,7 @@ int32_t oz_consensus(const uint8_t *ref, int32_t rlen, const oz_db *reads, const
 /* ---------- `dentist collect` (spanning reads) + `dentist process` per pile-up (pile.c) ---------- */
 typedef struct {
     int32_t ts_map, allowance, min_anchor, min_reads, max_reads, ts_pile, rounds, flank_window,
-        max_align_err_ppm, max_ins_err_ppm, bad_fraction_ppm, width;
+        max_align_err_ppm, max_ins_err_ppm, bad_fraction_ppm, width, dust;
 } oz_process_opts;
 void oz_default_process_opts(oz_process_opts *o);
 typedef struct {
@@ -188,6 +188,9 @@ int oz_process_piles(const oz_db *contigs, const oz_db *reads, const oz_la *las,
                      const int32_t *gap, const int32_t *count, const int32_t *triples, int32_t npiles,
                      const oz_process_opts *o, int nthreads, oz_insertion *out, uint8_t **bases_out, int64_t *nbases);
 void oz_free(void *p);
+
+/* ---------- low-complexity mask, DBdust's role (dust.c) ---------- */
+int64_t oz_dust(const oz_db *db, int64_t *ptr, int32_t **iv_out);
 
 #ifdef __cplusplus
 }

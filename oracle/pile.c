@@ -38,6 +38,7 @@ void oz_default_process_opts(oz_process_opts *o)
     o->max_ins_err_ppm = 100000;
     o->bad_fraction_ppm = 80000;
     o->width = 30;
+    o->dust = 1;
 }
 
 /* ------------------------------------------------------------------ collect ------------- */
@@ -430,6 +431,15 @@ static void process_one(const oz_db *contigs, const oz_db *reads, const oz_la *l
     }
     {
         oz_db pdb = {pile.n, pile.off, pile.bases, NULL, NULL, NULL};
+        /* DBdust pileup.db; daligner ... -mdust (package.d:476-482) */
+        int64_t *dptr = NULL;
+        int32_t *div = NULL;
+        if (o->dust) {
+            dptr = (int64_t *)malloc(((size_t)pile.n + 1) * sizeof(int64_t));
+            oz_dust(&pdb, dptr, &div);
+            pdb.mask_ptr = dptr;
+            pdb.mask_iv = div;
+        }
         int32_t *rlen = (int32_t *)malloc((size_t)pile.n * sizeof(int32_t));
         int32_t maxlen = 0;
         for (int32_t i = 0; i < pile.n; i++) {
@@ -472,6 +482,8 @@ static void process_one(const oz_db *contigs, const oz_db *reads, const oz_la *l
             free(qv);
             oz_la_set_free(&ps);
             free(rlen);
+            free(dptr);
+            free(div);
             goto done_pile;
         }
         int32_t *order = (int32_t *)malloc((size_t)pile.n * sizeof(int32_t)), norder = 0;
@@ -523,6 +535,15 @@ static void process_one(const oz_db *contigs, const oz_db *reads, const oz_la *l
         memcpy(fb + fl_len, cr, (size_t)fr_len);
         int64_t foff[3] = {0, fl_len, (int64_t)fl_len + fr_len};
         oz_db fdb = {2, foff, fb, NULL, NULL, NULL};
+        /* DBdust contigs.dam; daligner -A ... -mdust -mrep (package.d:631-667; no repeat mask here) */
+        int64_t *fdptr = NULL;
+        int32_t *fdiv = NULL;
+        if (o->dust) {
+            fdptr = (int64_t *)malloc(3 * sizeof(int64_t));
+            oz_dust(&fdb, fdptr, &fdiv);
+            fdb.mask_ptr = fdptr;
+            fdb.mask_iv = fdiv;
+        }
         int64_t coff[2] = {0, clen};
         oz_db cdb = {1, coff, cons, NULL, NULL, NULL};
         oz_opts fo;
@@ -565,6 +586,10 @@ static void process_one(const oz_db *contigs, const oz_db *reads, const oz_la *l
         }
         oz_la_set_free(&fs);
         free(fb);
+        free(fdptr);
+        free(fdiv);
+        free(dptr);
+        free(div);
     }
 done_pile:
     free(ids);

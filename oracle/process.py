@@ -225,7 +225,7 @@ def chain_pile_las(las, max_indel=1000, max_gap=10000, max_rel_overlap=0.3, min_
     return las
 
 
-def process_pile(entries, las, trace, contigs, reads, g, rounds=3, nthreads=1, flank_window=20000):
+def process_pile(entries, las, trace, contigs, reads, g, rounds=3, nthreads=1, flank_window=20000, dust=True):
     """One pile-up through the `process` sequence; returns a dict describing the insertion."""
     res = {"gap": g, "status": "ok", "nreads": len(entries)}
     crop = crop_pile(entries, las, trace, contigs, reads, g)
@@ -238,6 +238,9 @@ def process_pile(entries, las, trace, contigs, reads, g, rounds=3, nthreads=1, f
         res["status"] = "pile too small"
         return res
     o = pile_opts()
+    if dust:   # DBdust pileup.db; daligner ... -mdust (package.d:476-482)
+        pile = oz.with_dust(pile)
+        res["pile"] = pile
     plas, ptrace, _ = oz.align_db(pile, pile, o, nthreads=nthreads)
     # computeQVs (package.d:474-516): error filter -> chain -> DAScover/DASqv -> proper-overlap filter
     chained = filter_pile_las(plas, pile, proper=False)
@@ -268,6 +271,8 @@ def process_pile(entries, las, trace, contigs, reads, g, rounds=3, nthreads=1, f
     wl = max(0, len(cl) - flank_window)
     fl, fr = cl[wl:], cr[:flank_window]
     fdb = SeqDb.from_list([fl, fr])
+    if dust:   # DBdust contigs.dam; daligner -A ... -mdust -mrep (package.d:631-667)
+        fdb = oz.with_dust(fdb)
     o3 = oz.default_opts(tspace=TS_PILE, min_len=126, max_la=4, max_cand=32, width=WAVE_WIDTH)
     fl_las, fl_tr, _ = oz.align_db(fdb, SeqDb.from_list([cons]), o3, nthreads=nthreads)
     res.update(flank_las=fl_las, flank_trace=fl_tr, flank_off=wl)

@@ -253,7 +253,7 @@ def valid_pileup_alignment(la, alen, blen, allowance):
 class ProcessOpts(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "ts_map", "allowance", "min_anchor", "min_reads", "max_reads", "ts_pile", "rounds", "flank_window",
-        "max_align_err_ppm", "max_ins_err_ppm", "bad_fraction_ppm", "width")]
+        "max_align_err_ppm", "max_ins_err_ppm", "bad_fraction_ppm", "width", "dust")]
 
 
 OZ_INSERTION_DTYPE = np.dtype([(n, "<i4") for n in (
@@ -324,3 +324,28 @@ def process_piles_c(contigs, reads, las, trace, gaps, triples, popts, nthreads=1
     bases = np.frombuffer(ctypes.string_at(bp, nb.value), dtype=np.uint8).copy() if nb.value else np.zeros(0, np.uint8)
     L.oz_free(bp)
     return out, bases
+
+
+def dust(seqdb):
+    """oz_dust: low-complexity mask of every sequence as (ptr int64[n+1], iv int32 pairs)."""
+    L = lib()
+    d = _db(seqdb)
+    ptr = np.zeros(seqdb.n + 1, dtype=np.int64)
+    ivp = ctypes.c_void_p()
+    L.oz_dust.argtypes = [ctypes.POINTER(Db), ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+    L.oz_dust.restype = ctypes.c_int64
+    L.oz_free.argtypes = [ctypes.c_void_p]
+    m = L.oz_dust(ctypes.byref(d), ptr.ctypes.data, ctypes.byref(ivp))
+    iv = np.frombuffer(ctypes.string_at(ivp, 8 * m), dtype=np.int32).copy() if m else np.zeros(0, np.int32)
+    L.oz_free(ivp)
+    return ptr, iv
+
+
+def with_dust(seqdb):
+    """The same sequences with their dust mask attached (union with an existing mask is not needed
+    by the callers: pile-up and flank DBs carry no other mask in the oracle drivers)."""
+    from dentist_amd.sim import SeqDb
+    out = SeqDb(seqdb.bases, seqdb.off, seqdb.group)
+    ptr, iv = dust(seqdb)
+    out.mask = (ptr, np.concatenate([iv, np.zeros(2, np.int32)]))
+    return out
