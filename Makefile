@@ -6,7 +6,8 @@ CSRC := dentist_amd/csrc
 LIB := dentist_amd/libdentist_hip.so
 SIM := dentist_amd/sim/libdh_sim.so
 
-TOOLS := tools/daligner tools/damapper
+DAZZ_TOOLS := fasta2DB fasta2DAM DBsplit DBrm DBdump DBshow DBdust LAmerge DAScover DASqv computeintrinsicqv daccord
+TOOLS := tools/daligner tools/damapper tools/dazz_tools $(addprefix tools/,$(DAZZ_TOOLS))
 
 all: $(LIB) $(SIM) oracle $(TOOLS)
 
@@ -14,6 +15,12 @@ tools/daligner: tools/aligner_main.cpp include/dentist_hip.h $(LIB)
 	$(HIPCC) -O2 -std=c++17 -o $@ $< -Ldentist_amd -ldentist_hip -Wl,-rpath,'$$ORIGIN/../dentist_amd'
 
 tools/damapper: tools/daligner
+	cp $< $@
+
+tools/dazz_tools: tools/dazz_main.cpp include/dentist_hip.h $(LIB)
+	$(HIPCC) -O2 -std=c++17 -o $@ $< -Ldentist_amd -ldentist_hip -Wl,-rpath,'$$ORIGIN/../dentist_amd'
+
+$(addprefix tools/,$(DAZZ_TOOLS)): tools/dazz_tools
 	cp $< $@
 
 $(LIB): $(CSRC)/dh_kernels.hip $(CSRC)/dh_api.cpp $(CSRC)/dh_device.h include/dentist_hip.h $(wildcard $(CSRC)/*.hip $(CSRC)/*.cpp $(CSRC)/*.h)

@@ -78,6 +78,7 @@ SYMBOLS = [
     "dh_crop_pileups", "dh_cropped_create", "dh_cropped_destroy", "dh_cropped_npiles", "dh_cropped_records",
     "dh_cropped_nreads", "dh_cropped_pile", "dh_cropped_entry", "dh_cropped_read_id", "dh_cropped_offsets",
     "dh_cropped_bases", "dh_process_cropped", "dh_translate_trace_point", "dh_db_dust", "dh_db_get_mask",
+    "dh_dazz_write_track", "dh_dazz_read_track", "dh_dazz_remove", "dh_dazz_flags",
 ]
 
 _LIB = None

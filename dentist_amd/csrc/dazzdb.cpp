@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dirent.h>
 #include <string>
 #include <vector>
 
@@ -238,6 +239,7 @@ extern "C" int dh_dazz_create_db(const char *path, const char *fasta, int64_t n)
         p.stub += ".db";
     }
     std::vector<Rec> recs;
+    std::string prolog;
     int64_t i = 0;
     while (i < n) {
         if (fasta[i] != '>') {
@@ -250,6 +252,7 @@ extern "C" int dh_dazz_create_db(const char *path, const char *fasta, int64_t n)
         Rec r;
         int well = (int)recs.size(), beg = 0, end = 0;
         const size_t s1 = h.find('/');
+        if (recs.empty()) prolog = h.substr(0, std::min(s1, h.find(' ')));  // the movie name: DBdump's H line
         if (s1 != std::string::npos) sscanf(h.c_str() + s1 + 1, "%d/%d_%d", &well, &beg, &end);
         float rq = 0;
         const size_t rqp = h.find("RQ=0.");
@@ -265,7 +268,7 @@ extern "C" int dh_dazz_create_db(const char *path, const char *fasta, int64_t n)
         }
         recs.push_back(r);
     }
-    return write_db(p, recs, "", false, p.root);
+    return write_db(p, recs, "", false, prolog.empty() ? p.root : prolog);
 }
 
 // DBsplit -x<cutoff> [-a] -s<mb>: rewrites the block table of the stub and cutoff/all/treads of
@@ -331,7 +334,7 @@ extern "C" int dh_dazz_split(const char *path, int32_t cutoff, int32_t all, int6
 struct dh_dazz {
     std::vector<uint8_t> bases;
     std::vector<int64_t> off;
-    std::vector<int32_t> origin, fpulse, uid;
+    std::vector<int32_t> origin, fpulse, uid, flags;
     std::vector<std::string> header;  // DAM only: scaffold header of every contig
     int32_t tfirst = 0, cutoff = 0, is_dam = 0, ureads = 0, treads = 0;
     std::string root;
@@ -353,8 +356,13 @@ extern "C" int dh_dazz_open(const char *path, dh_dazz **out)
         fclose(st);
         return dh_fail(DH_EIO, "bad stub " + p.stub);
     }
-    for (int i = 0; i < nfiles; i++)
+    std::vector<std::pair<int, std::string>> prologs;  // (cumulative read count, prolog) per input file
+    for (int i = 0; i < nfiles; i++) {
         if (!fgets(line, sizeof(line), st)) break;
+        int cum = 0;
+        char fname[2048], prolog[2048];
+        if (sscanf(line, " %d %2047s %2047s", &cum, fname, prolog) == 3) prologs.push_back({cum, std::string(prolog)});
+    }
     if (fgets(line, sizeof(line), st)) sscanf(line, "blocks = %d", &nblocks);
     if (nblocks > 0 && fgets(line, sizeof(line), st)) {
         sscanf(line, "size = %lld cutoff = %d all = %d", &size, &cutoff, &all);
@@ -426,10 +434,19 @@ extern "C" int dh_dazz_open(const char *path, dh_dazz **out)
         db->origin.push_back(r.origin);
         db->fpulse.push_back(r.fpulse);
         db->uid.push_back(i);
+        db->flags.push_back(r.flags);
         if (is_dam) {
             size_t e = (size_t)r.coff;
             while (e < hdrs.size() && hdrs[e] != '\n') e++;
             db->header.push_back((size_t)r.coff < hdrs.size() ? hdrs.substr((size_t)r.coff, e - (size_t)r.coff) : std::string());
+        } else {  // .db: the prolog of the file the read came from (the H line of DBdump)
+            std::string pl;
+            for (auto &f : prologs)
+                if (i < f.first) {
+                    pl = f.second;
+                    break;
+                }
+            db->header.push_back(pl);
         }
     }
     fclose(bps);
@@ -444,6 +461,7 @@ extern "C" const uint8_t *dh_dazz_bases(const dh_dazz *db) { return db ? db->bas
 extern "C" const int64_t *dh_dazz_offsets(const dh_dazz *db) { return db ? db->off.data() : nullptr; }
 extern "C" const int32_t *dh_dazz_origin(const dh_dazz *db) { return db ? db->origin.data() : nullptr; }
 extern "C" const int32_t *dh_dazz_fpulse(const dh_dazz *db) { return db ? db->fpulse.data() : nullptr; }
+extern "C" const int32_t *dh_dazz_flags(const dh_dazz *db) { return db ? db->flags.data() : nullptr; }
 extern "C" const char *dh_dazz_header(const dh_dazz *db, int32_t i)
 {
     return (db && i >= 0 && (size_t)i < db->header.size()) ? db->header[(size_t)i].c_str() : "";
@@ -531,4 +549,95 @@ extern "C" int64_t dh_dazz_read_mask(const dh_dazz *db, const char *db_path, con
         ptr[i + 1] = n;
     }
     return n;
+}
+
+
+// ---------------------------------------------------------------------------------- byte tracks
+// Per-read byte vectors (`qual` / `inqual`: one intrinsic QV per trace tile, written by DASqv /
+// computeintrinsicqv and shown by `DBdump -i`, dazzler.d:2877-2897): .anno = int32 nreads, int32 8,
+// int64 byte offsets[nreads + 1]; .data = the bytes.  For the whole trimmed DB.
+extern "C" int dh_dazz_write_track(const char *db_path, const char *name, int32_t nreads, const int64_t *ptr,
+                                   const uint8_t *data)
+{
+    Paths p;
+    if (!db_path || !name || !ptr || !split_path(std::string(db_path), p, true)) return dh_fail(DH_EIO, "DAZZ_DB not found");
+    if (strchr(name, '/') || strchr(name, '.')) return dh_fail(DH_EINVAL, "track name must not contain dots or slashes");
+    FILE *an = fopen(p.hidden((std::string(name) + ".anno").c_str()).c_str(), "wb");
+    FILE *da = fopen(p.hidden((std::string(name) + ".data").c_str()).c_str(), "wb");
+    if (!an || !da) {
+        if (an) fclose(an);
+        if (da) fclose(da);
+        return dh_fail(DH_EIO, "cannot create track files");
+    }
+    const int32_t head[2] = {nreads, 8};
+    fwrite(head, 4, 2, an);
+    fwrite(ptr, 8, (size_t)nreads + 1, an);
+    if (ptr[nreads] > 0) fwrite(data, 1, (size_t)ptr[nreads], da);
+    const bool ok = fclose(an) == 0;
+    return (fclose(da) == 0 && ok) ? DH_OK : dh_fail(DH_EIO, "short write of track files");
+}
+
+// ptr gets nreads(view) + 1 entries; data may be NULL to size; returns the number of bytes or < 0
+extern "C" int64_t dh_dazz_read_track(const dh_dazz *db, const char *db_path, const char *name, int64_t *ptr,
+                                      uint8_t *data, int64_t cap)
+{
+    Paths p;
+    if (!db || !db_path || !name || !ptr || !split_path(std::string(db_path), p, true)) return dh_fail(DH_EIO, "DAZZ_DB not found");
+    FILE *an = fopen(p.hidden((std::string(name) + ".anno").c_str()).c_str(), "rb");
+    FILE *da = fopen(p.hidden((std::string(name) + ".data").c_str()).c_str(), "rb");
+    if (!an || !da) {
+        if (an) fclose(an);
+        if (da) fclose(da);
+        return dh_fail(DH_EIO, std::string("track not found: ") + name);
+    }
+    int32_t head[2] = {0, 0};
+    std::vector<int64_t> offs;
+    bool ok = fread(head, 4, 2, an) == 2 && head[1] == 8 && head[0] >= 0;
+    if (ok) {
+        offs.resize((size_t)head[0] + 1);
+        ok = fread(offs.data(), 8, offs.size(), an) == offs.size();
+    }
+    fclose(an);
+    std::vector<uint8_t> all;
+    if (ok) {
+        uint8_t buf[65536];
+        size_t got;
+        while ((got = fread(buf, 1, sizeof(buf), da)) > 0) all.insert(all.end(), buf, buf + got);
+    }
+    fclose(da);
+    if (!ok) return dh_fail(DH_EIO, std::string("corrupted track: ") + name);
+    const int32_t nview = (int32_t)db->off.size() - 1;
+    int64_t n = 0;
+    ptr[0] = 0;
+    for (int32_t i = 0; i < nview; i++) {
+        const int64_t id = (int64_t)db->tfirst + i;
+        if (id < head[0]) {
+            const int64_t a = offs[(size_t)id], b = offs[(size_t)id + 1];
+            if (a < 0 || a > b || b > (int64_t)all.size()) return dh_fail(DH_EIO, "corrupted track: pointer out of bounds");
+            for (int64_t x = a; x < b; x++) {
+                if (data && n < cap) data[n] = all[(size_t)x];
+                n++;
+            }
+        }
+        ptr[i + 1] = n;
+    }
+    return n;
+}
+
+// DBrm: the stub and every hidden file of the DB
+extern "C" int dh_dazz_remove(const char *db_path)
+{
+    Paths p;
+    if (!db_path || !split_path(std::string(db_path), p, true)) return dh_fail(DH_EIO, std::string("DAZZ_DB not found: ") + (db_path ? db_path : ""));
+    const std::string prefix = p.hidden("");
+    const size_t slash = prefix.find_last_of('/');
+    const std::string dir = slash == std::string::npos ? "." : prefix.substr(0, slash);
+    const std::string base = slash == std::string::npos ? prefix : prefix.substr(slash + 1);
+    if (DIR *d = opendir(dir.c_str())) {
+        while (struct dirent *e = readdir(d))
+            if (strncmp(e->d_name, base.c_str(), base.size()) == 0) remove((dir + "/" + e->d_name).c_str());
+        closedir(d);
+    }
+    remove(p.stub.c_str());
+    return DH_OK;
 }

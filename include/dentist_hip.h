@@ -349,7 +349,8 @@ const uint8_t *dh_dazz_bases(const dh_dazz *db);      /* base codes 0..3, concat
 const int64_t *dh_dazz_offsets(const dh_dazz *db);    /* nreads + 1                                 */
 const int32_t *dh_dazz_origin(const dh_dazz *db);     /* well (DB) / contig number in scaffold (DAM)*/
 const int32_t *dh_dazz_fpulse(const dh_dazz *db);     /* first pulse (DB) / contig start (DAM)      */
-const char *dh_dazz_header(const dh_dazz *db, int32_t i); /* DAM: scaffold header of contig i        */
+const int32_t *dh_dazz_flags(const dh_dazz *db);      /* DAZZ_READ.flags: low 10 bits = RQ * 1000 (DB) */
+const char *dh_dazz_header(const dh_dazz *db, int32_t i); /* DAM: scaffold header of contig i; DB: prolog */
 /* mask tracks `<dir>/.<db>.<name>.anno/.data` (source/dentist/dazzler.d:4870-5170): .anno = int32
  * nreads, int32 size (0), int64 byte offsets[nreads + 1]; .data = int32 (begin, end) pairs.
  * read: intervals of the opened (trimmed) view, ptr has nreads + 1 entries; returns the number of
@@ -358,6 +359,17 @@ int64_t dh_dazz_read_mask(const dh_dazz *db, const char *db_path, const char *na
                           int64_t iv_cap);
 int dh_dazz_write_mask(const char *db_path, const char *name, int32_t nreads, const int64_t *ptr,
                        const int32_t *iv);
+
+/* byte tracks `<dir>/.<db>.<name>.anno/.data` (the `qual` / `inqual` intrinsic-QV tracks DASqv and
+ * computeintrinsicqv write and `DBdump -i` shows, dazzler.d:2877-2897, 6142-6183): .anno = int32 nreads,
+ * int32 8, int64 byte offsets[nreads + 1]; .data = the bytes (one QV per trace tile).  read: bytes of the
+ * opened (trimmed) view, ptr has nreads + 1 entries, data may be NULL to size; returns the byte count. */
+int dh_dazz_write_track(const char *db_path, const char *name, int32_t nreads, const int64_t *ptr,
+                        const uint8_t *data);
+int64_t dh_dazz_read_track(const dh_dazz *db, const char *db_path, const char *name, int64_t *ptr, uint8_t *data,
+                           int64_t cap);
+/* DBrm (dazzler.d:216, 6115-6119): removes the stub and every hidden file of the DB */
+int dh_dazz_remove(const char *db_path);
 
 #ifdef __cplusplus
 }

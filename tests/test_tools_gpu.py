@@ -91,3 +91,67 @@ def test_daligner_pile_up_call(gpu_ctx, tmp_path):
     exp = gpu_ctx.align_db(d, d, dentist_amd.default_align_opts(tspace=126, skip_self=2, max_la=64, max_cand=128))
     assert len(las) % 2 == 0 and len(las) > 0
     assert_same_las((las, trace), exp)
+
+
+def tool(name, *args, cwd=None, stdin=None):
+    r = subprocess.run([os.path.join(ROOT, "tools", name), *args], cwd=cwd, input=stdin, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, (name, args, r.stderr)
+    return r.stdout
+
+
+def test_process_tool_sequence_of_one_pile_up(gpu_ctx, tmp_path):
+    """The literal per-pile-up command lines of `dentist process` (SURVEY Appendix A;
+    processPileUps/package.d:474-516, 600-619): fasta2DB -i | DBsplit | DBdust | daligner -mdust |
+    DAScover | DASqv -c | DBdump -r -i | computeintrinsicqv | daccord --eprofonly |
+    daccord -f -I<i>,<i> | fasta2DAM -i | DBsplit -a -- against the stage-level library calls."""
+    g = sim.genome(41, 12000)
+    g[3000:3060] = np.tile([0, 1], 30)          # a microsatellite for DBdust to find
+    pile, _ = sim.reads(42, g[1000:7000], 18, 6000)
+    p = str(tmp_path / "pileup-3b-4f.db")
+    tool("fasta2DB", "-i", p, stdin=fasta_db(pile))
+    tool("DBsplit", "-x0", "-a", p)
+    tool("DBdust", p)
+    dz = dentist_amd.DazzDb(p)
+    ptr, iv = dz.read_mask("dust")
+    d = gpu_ctx.db(pile)
+    d.dust()
+    eptr, eiv = d.get_mask()
+    assert np.array_equal(ptr, eptr) and np.array_equal(iv, eiv) and len(iv) > 0
+    tool("daligner", "-T1", "-B", "-s126", "-l500", "-e0.7", "-mdust", p, p, cwd=tmp_path)
+    las_path = str(tmp_path / "pileup-3b-4f.pileup-3b-4f.las")
+    las, trace, ts = dentist_amd.las_read(las_path)
+    exp = gpu_ctx.align_db(d, d, dentist_amd.default_align_opts(tspace=126, skip_self=2, max_la=64, max_cand=128))
+    assert_same_las((las, trace), exp)
+    # DAScover / DASqv -c<cov>, then the QVs as DENTIST reads them: DBdump -r -i (dazzler.d:2877-2897)
+    tool("DAScover", "-v", p, las_path)
+    tool("DASqv", "-v", f"-c{pile.n}", p, las_path)
+    maxtiles = max((pile.length(i) + 125) // 126 for i in range(pile.n))
+    qv = dentist_amd.tile_qv(gpu_ctx, d, las, trace, 126, pile.n, maxtiles)
+    lines = [ln.split() for ln in tool("DBdump", "-r", "-i", p).splitlines() if ln and ln[0] in "RI"]
+    dec = lambda c: ord(c) - ord("a") if c.islower() else 26 + ord(c) - ord("A")   # noqa: E731
+    for i in range(pile.n):
+        assert lines[2 * i] == ["R", str(i + 1)]
+        nt = (pile.length(i) + 125) // 126
+        assert int(lines[2 * i + 1][1]) == nt
+        assert [dec(c) for c in lines[2 * i + 1][2]] == [min(int(x), 50) for x in qv[i, :nt]]
+    # consensus of read 2: computeintrinsicqv, error profile pass, then FASTA on stdout into fasta2DAM
+    tool("computeintrinsicqv", f"-d{pile.n}", p, las_path)
+    tool("daccord", "-t1", "-I2,2", "--eprofonly", las_path, p)
+    assert os.path.exists(las_path + ".eprof")
+    fa = tool("daccord", "-f", "-t1", "-I2,2", las_path, p)
+    out_dam = str(tmp_path / "pileup-3b-4f-daccord-I2-2.dam")
+    tool("fasta2DAM", "-i", out_dam, stdin=fa)
+    tool("DBsplit", "-a", out_dam)
+    cons = dentist_amd.DazzDb(out_dam)
+    exp_cons = dentist_amd.consensus(gpu_ctx, d, las, trace, 126, 2, rounds=3)
+    assert cons.n == 1 and np.array_equal(cons.seq(0), exp_cons)
+    # flank re-alignment call: daligner -A ... contigs consensus writes only contigs.consensus.las
+    contigs = sim.SeqDb.from_list([g[:2500], g[5500:]])
+    cdam = str(tmp_path / "contigs-3b-4f.dam")
+    tool("fasta2DAM", "-i", cdam, stdin=fasta_dam(contigs))
+    tool("DBsplit", "-a", cdam)
+    tool("DBdust", cdam)
+    tool("daligner", "-A", "-B", "-s126", "-T1", "-mdust", "-mrep", "-l126", "-e0.7", cdam, out_dam, cwd=tmp_path)
+    fl, _, _ = dentist_amd.las_read(str(tmp_path / "contigs-3b-4f.pileup-3b-4f-daccord-I2-2.las"))
+    assert len(fl) >= 1 and not os.path.exists(tmp_path / "pileup-3b-4f-daccord-I2-2.contigs-3b-4f.las")

@@ -150,7 +150,11 @@ int main(int argc, char **argv)
         case 'C': flagC = true; break;
         case 'v': verbose = true; break;
         case 'm': tracks.push_back(v); break;
-        case 'B': case 'b': case 'p': case 'T': case 'P': case 'M': case 'n': case 'z': case 'H': break;
+        case 'T': case 'P': case 'M': break;  // threads / temp dir / memory: no meaning on the device
+        case 'B': case 'b': case 'p': case 'n': case 'z': case 'H':
+            // accepted for DENTIST's argv, but not implemented: say so instead of silently differing
+            fprintf(stderr, "%s: option %s is accepted but has no effect in this implementation\n", mode.c_str(), a.c_str());
+            break;
         default: die(mode + ": unknown option " + a);
         }
     }
