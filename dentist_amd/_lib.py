@@ -79,6 +79,11 @@ SYMBOLS = [
     "dh_cropped_nreads", "dh_cropped_pile", "dh_cropped_entry", "dh_cropped_read_id", "dh_cropped_offsets",
     "dh_cropped_bases", "dh_process_cropped", "dh_translate_trace_point", "dh_db_dust", "dh_db_get_mask",
     "dh_dazz_write_track", "dh_dazz_read_track", "dh_dazz_remove", "dh_dazz_flags",
+    "dh_pileupdb_write", "dh_pileupdb_read", "dh_insertiondb_write", "dh_insertiondb_read", "dh_chaindb_destroy",
+    "dh_chaindb_npiles", "dh_chaindb_pile_counts", "dh_chaindb_nread_alignments", "dh_chaindb_read_alignment_counts",
+    "dh_chaindb_nseeded", "dh_chaindb_seeded", "dh_chaindb_nlas", "dh_chaindb_las", "dh_chaindb_ntrace",
+    "dh_chaindb_trace", "dh_chaindb_ninsertions", "dh_chaindb_insertions", "dh_chaindb_bases", "dh_chaindb_read_ids",
+    "dh_insertions_write_db", "dh_pileups_write_db",
 ]
 
 _LIB = None
@@ -433,6 +438,17 @@ class Pileups:
         _check(lib().dh_pileups_create(cl.ctypes.data, cnt.ctypes.data, len(cl), tri.ctypes.data, ctypes.byref(h)))
         return cls(None, None, None, _handle=h)
 
+    def write_db(self, path, las, trace, contig_off, read_off, tspace=100):
+        """dh_pileups_write_db: DENTIST's pile-ups.db for these pile-ups."""
+        arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
+        tr = np.ascontiguousarray(trace, dtype=np.uint16)
+        co, ro = np.ascontiguousarray(contig_off, dtype=np.int64), np.ascontiguousarray(read_off, dtype=np.int64)
+        L = lib()
+        L.dh_pileups_write_db.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_char_p]
+        _check(L.dh_pileups_write_db(self._h, arr.ctypes.data, len(arr), tr.ctypes.data, co.ctypes.data, len(co) - 1,
+                                     ro.ctypes.data, len(ro) - 1, tspace, path.encode()))
+
     def select(self, las, opts):
         """dh_pileups_select: the min_reads / max_reads cut."""
         arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
@@ -520,8 +536,17 @@ class Cropped:
             pass
 
 
-def _take_insertions(h):
+def _take_insertions(h, insertions_db=None):
+    """insertions_db = (path, contig_off, tspace): also write the result as DENTIST's insertions.db."""
     L = lib()
+    if insertions_db is not None:
+        path, contig_off, tspace = insertions_db
+        off = np.ascontiguousarray(contig_off, dtype=np.int64)
+        L.dh_insertions_write_db.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_char_p]
+        rc = L.dh_insertions_write_db(h, off.ctypes.data, len(off) - 1, tspace, path.encode())
+        if rc != 0:
+            L.dh_insertions_destroy(h)
+            _check(rc)
     n = L.dh_insertions_count(h)
     nb = L.dh_insertions_bases_len(h)
     rec = (np.frombuffer(ctypes.string_at(L.dh_insertions_records(h), n * INSERTION_DTYPE.itemsize),
@@ -532,22 +557,16 @@ def _take_insertions(h):
     return rec, bases
 
 
-def process_pileups(ctx, contigs, reads, las, trace, piles, opts):
-    """dentist `process` for a batch of pile-ups on the GPU. Returns (records, consensus bases)."""
+def process_pileups(ctx, contigs, reads, las, trace, piles, opts, insertions_db=None):
+    """dentist `process` for a batch of pile-ups on the GPU. Returns (records, consensus bases);
+    insertions_db = (path, contig_off, tspace) also writes DENTIST's insertions.db."""
     L = lib()
     arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
     tr = np.ascontiguousarray(trace, dtype=np.uint16)
     h = ctypes.c_void_p()
     _check(L.dh_process_pileups(ctx._h, contigs._h, reads._h, arr.ctypes.data, len(arr), tr.ctypes.data,
                                 piles._h, ctypes.byref(opts), ctypes.byref(h)))
-    n = L.dh_insertions_count(h)
-    nb = L.dh_insertions_bases_len(h)
-    rec = (np.frombuffer(ctypes.string_at(L.dh_insertions_records(h), n * INSERTION_DTYPE.itemsize),
-                         dtype=INSERTION_DTYPE).copy() if n else np.zeros(0, dtype=INSERTION_DTYPE))
-    bases = (np.frombuffer(ctypes.string_at(L.dh_insertions_bases(h), nb), dtype=np.uint8).copy()
-             if nb else np.zeros(0, dtype=np.uint8))
-    L.dh_insertions_destroy(h)
-    return rec, bases
+    return _take_insertions(h, insertions_db)
 
 
 def output_fasta(fasta_path, contigs, scaffold_of, headers, gap_len, rec, bases, bed_path=None, line_width=50,
@@ -683,3 +702,80 @@ def dazz_write_mask(db_path, name, ptr, iv):
     p = np.ascontiguousarray(ptr, dtype=np.int64)
     v = np.ascontiguousarray(iv, dtype=np.int32)
     _check(lib().dh_dazz_write_mask(db_path.encode(), name.encode(), len(p) - 1, p.ctypes.data, v.ctypes.data))
+
+
+# ---------------------------------------------------------------- pile-ups.db / insertions.db (host only)
+SEEDED_DTYPE = np.dtype([("id", "<i8"), ("contig_a_id", "<u4"), ("contig_a_len", "<u4"), ("contig_b_id", "<u4"),
+                         ("contig_b_len", "<u4"), ("flags", "u1"), ("seed", "u1"), ("tspace", "<u2"), ("nla", "<i4")])
+CHAIN_LA_DTYPE = np.dtype([("a_begin", "<u4"), ("a_end", "<u4"), ("b_begin", "<u4"), ("b_end", "<u4"), ("diffs", "<u4"),
+                           ("ntp", "<i4")])
+INSERTION_REC_DTYPE = np.dtype([("start_contig", "<i8"), ("end_contig", "<i8"), ("start_part", "u1"), ("end_part", "u1"),
+                                ("pad", "u1", (6,)), ("seq_len", "<i8"), ("contig_len", "<i8"), ("noverlaps", "<i4"),
+                                ("nread_ids", "<i4")])
+assert SEEDED_DTYPE.itemsize == 32 and CHAIN_LA_DTYPE.itemsize == 24 and INSERTION_REC_DTYPE.itemsize == 48
+
+
+def _arr(ptr, n, dt):
+    return np.frombuffer(ctypes.string_at(ptr, n * np.dtype(dt).itemsize), dtype=dt).copy() if n else np.zeros(0, dt)
+
+
+def _take_chaindb(h):
+    L = lib()
+    vp = ctypes.c_void_p
+    for fn in ("dh_chaindb_pile_counts", "dh_chaindb_read_alignment_counts", "dh_chaindb_seeded", "dh_chaindb_las",
+               "dh_chaindb_trace", "dh_chaindb_insertions", "dh_chaindb_bases", "dh_chaindb_read_ids"):
+        getattr(L, fn).restype = vp
+        getattr(L, fn).argtypes = [vp]
+    for fn in ("dh_chaindb_nseeded", "dh_chaindb_nlas", "dh_chaindb_ntrace"):
+        getattr(L, fn).restype = ctypes.c_int64
+        getattr(L, fn).argtypes = [vp]
+    for fn in ("dh_chaindb_npiles", "dh_chaindb_nread_alignments", "dh_chaindb_ninsertions"):
+        getattr(L, fn).argtypes = [vp]
+    L.dh_chaindb_destroy.argtypes = [vp]
+    ins = _arr(L.dh_chaindb_insertions(h), L.dh_chaindb_ninsertions(h), INSERTION_REC_DTYPE)
+    out = dict(pile_counts=_arr(L.dh_chaindb_pile_counts(h), L.dh_chaindb_npiles(h), np.int32),
+               ra_counts=_arr(L.dh_chaindb_read_alignment_counts(h), L.dh_chaindb_nread_alignments(h), np.int32),
+               seeded=_arr(L.dh_chaindb_seeded(h), L.dh_chaindb_nseeded(h), SEEDED_DTYPE),
+               las=_arr(L.dh_chaindb_las(h), L.dh_chaindb_nlas(h), CHAIN_LA_DTYPE),
+               trace=_arr(L.dh_chaindb_trace(h), L.dh_chaindb_ntrace(h), np.uint16),
+               insertions=ins, bases=_arr(L.dh_chaindb_bases(h), int(ins["seq_len"].sum()) if len(ins) else 0, np.uint8),
+               read_ids=_arr(L.dh_chaindb_read_ids(h), int(ins["nread_ids"].sum()) if len(ins) else 0, np.uint32))
+    L.dh_chaindb_destroy(h)
+    return out
+
+
+def pileupdb_write(path, pile_counts, ra_counts, seeded, las, trace):
+    pc, rc = (np.ascontiguousarray(x, dtype=np.int32) for x in (pile_counts, ra_counts))
+    sa, la = np.ascontiguousarray(seeded, dtype=SEEDED_DTYPE), np.ascontiguousarray(las, dtype=CHAIN_LA_DTYPE)
+    tr = np.ascontiguousarray(trace, dtype=np.uint16)
+    L = lib()
+    L.dh_pileupdb_write.argtypes = [ctypes.c_char_p, ctypes.c_int32] + [ctypes.c_void_p] * 5
+    _check(L.dh_pileupdb_write(path.encode(), len(pc), pc.ctypes.data, rc.ctypes.data, sa.ctypes.data, la.ctypes.data,
+                               tr.ctypes.data))
+
+
+def pileupdb_read(path):
+    h = ctypes.c_void_p()
+    L = lib()
+    L.dh_pileupdb_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
+    _check(L.dh_pileupdb_read(path.encode(), ctypes.byref(h)))
+    return _take_chaindb(h)
+
+
+def insertiondb_write(path, insertions, bases, read_ids, seeded, las, trace):
+    ins = np.ascontiguousarray(insertions, dtype=INSERTION_REC_DTYPE)
+    b, ids = np.ascontiguousarray(bases, dtype=np.uint8), np.ascontiguousarray(read_ids, dtype=np.uint32)
+    sa, la = np.ascontiguousarray(seeded, dtype=SEEDED_DTYPE), np.ascontiguousarray(las, dtype=CHAIN_LA_DTYPE)
+    tr = np.ascontiguousarray(trace, dtype=np.uint16)
+    L = lib()
+    L.dh_insertiondb_write.argtypes = [ctypes.c_char_p, ctypes.c_int32] + [ctypes.c_void_p] * 6
+    _check(L.dh_insertiondb_write(path.encode(), len(ins), ins.ctypes.data, b.ctypes.data, ids.ctypes.data, sa.ctypes.data,
+                                  la.ctypes.data, tr.ctypes.data))
+
+
+def insertiondb_read(path):
+    h = ctypes.c_void_p()
+    L = lib()
+    L.dh_insertiondb_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
+    _check(L.dh_insertiondb_read(path.encode(), ctypes.byref(h)))
+    return _take_chaindb(h)

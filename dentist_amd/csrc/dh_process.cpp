@@ -312,6 +312,52 @@ extern "C" int dh_collect_spanning(const dh_la *las, int64_t n, const int64_t *c
     return rc;
 }
 
+// pile-ups.db of a collect result (what `dentist collect` hands to `dentist process`,
+// collectPileUps/package.d:88-96 writePileUpsDb): every read of a pile-up is a ReadAlignment of two
+// SeededAlignments -- its chain on the left contig seeded at the back, its chain on the right contig
+// seeded at the front (pileups.d:821-888); chains hold one local alignment with its trace points.
+extern "C" int dh_pileups_write_db(const dh_pileups *p, const dh_la *las, int64_t n, const uint16_t *trace,
+                                   const int64_t *contig_off, int32_t ncontigs, const int64_t *read_off, int32_t nreads,
+                                   int32_t tspace, const char *path)
+{
+    if (!p || !contig_off || !read_off || !path || (n > 0 && (!las || !trace)))
+        return dh_fail(DH_EINVAL, "dh_pileups_write_db: bad argument");
+    std::vector<int32_t> nra, nsa;
+    std::vector<dh_seeded> sa;
+    std::vector<dh_chain_la> la;
+    std::vector<uint16_t> tp;
+    for (size_t i = 0; i < p->contig_left.size(); i++) {
+        const std::vector<int32_t> &t = p->triples[i];
+        nra.push_back((int32_t)t.size() / 3);
+        for (size_t e = 0; e + 2 < t.size(); e += 3) {
+            nsa.push_back(2);
+            for (int side = 0; side < 2; side++) {
+                const int32_t li = t[e + 1 + (size_t)side];
+                if (li < 0 || li >= n) return dh_fail(DH_EINVAL, "dh_pileups_write_db: LA index out of range");
+                const dh_la &x = las[li];
+                if (x.aread < 0 || x.aread >= ncontigs || x.bread < 0 || x.bread >= nreads)
+                    return dh_fail(DH_EINVAL, "dh_pileups_write_db: id out of range");
+                dh_seeded s;
+                memset(&s, 0, sizeof(s));
+                s.id = li;
+                s.contig_a_id = (uint32_t)(x.aread + 1);
+                s.contig_a_len = (uint32_t)(contig_off[x.aread + 1] - contig_off[x.aread]);
+                s.contig_b_id = (uint32_t)(x.bread + 1);
+                s.contig_b_len = (uint32_t)(read_off[x.bread + 1] - read_off[x.bread]);
+                s.flags = (x.flags & DH_FLAG_COMP) ? 1 : 0;
+                s.seed = side == 0 ? 1 : 0;
+                s.tspace = (uint16_t)tspace;
+                s.nla = 1;
+                sa.push_back(s);
+                la.push_back(dh_chain_la{(uint32_t)x.abpos, (uint32_t)x.aepos, (uint32_t)x.bbpos, (uint32_t)x.bepos,
+                                         (uint32_t)x.diffs, x.tlen / 2});
+                tp.insert(tp.end(), trace + x.toff, trace + x.toff + x.tlen);
+            }
+        }
+    }
+    return dh_pileupdb_write(path, (int32_t)nra.size(), nra.data(), nsa.data(), sa.data(), la.data(), tp.data());
+}
+
 extern "C" void dh_pileups_destroy(dh_pileups *p) { delete p; }
 extern "C" int32_t dh_pileups_count(const dh_pileups *p) { return p ? (int32_t)p->contig_left.size() : 0; }
 extern "C" int32_t dh_pileups_get(const dh_pileups *p, int32_t i, int32_t *contig_left,
@@ -490,6 +536,13 @@ static void chain_pair(LaVec &la, size_t first, size_t last, int32_t min_score)
 struct dh_insertions {
     std::vector<dh_insertion> rec;
     std::vector<uint8_t> bases;
+    // what insertions.db stores besides the sequence (insertiondb.d:987-1031): the two flank overlaps
+    // of every closed gap with their trace points (A coordinates on the whole contig) and the read
+    // ids of the pile-up
+    std::vector<dh_la> flank;        // 2 per closed gap: left, right; toff into flank_tr
+    std::vector<uint16_t> flank_tr;
+    std::vector<int32_t> flank_of;   // per record: index of its left overlap in `flank`, -1 if none
+    std::vector<int32_t> ids_off, ids;  // per record [ids_off[i], ids_off[i+1]): read ids of the pile-up
 };
 
 extern "C" void dh_insertions_destroy(dh_insertions *r) { delete r; }
@@ -497,6 +550,62 @@ extern "C" int32_t dh_insertions_count(const dh_insertions *r) { return r ? (int
 extern "C" const dh_insertion *dh_insertions_records(const dh_insertions *r) { return r ? r->rec.data() : nullptr; }
 extern "C" const uint8_t *dh_insertions_bases(const dh_insertions *r) { return r ? r->bases.data() : nullptr; }
 extern "C" int64_t dh_insertions_bases_len(const dh_insertions *r) { return r ? (int64_t)r->bases.size() : 0; }
+
+// insertions.db of a result (what `dentist process` hands to `dentist output`,
+// processPileUps/package.d:156-158, 789-805): one insertion per closed gap -- start = (left contig,
+// end), end = (right contig, begin), the whole consensus as sequence, the two flank overlaps
+// (contig = A, consensus = B, seeds back / front) and the sorted 1-based read ids of the pile-up.
+extern "C" int dh_insertions_write_db(const dh_insertions *r, const int64_t *contig_off, int32_t ncontigs,
+                                      int32_t tspace, const char *path)
+{
+    if (!r || !contig_off || !path || ncontigs < 0) return dh_fail(DH_EINVAL, "dh_insertions_write_db: bad argument");
+    std::vector<dh_insertion_rec> ins;
+    std::vector<uint8_t> bases;
+    std::vector<uint32_t> ids;
+    std::vector<dh_seeded> sa;
+    std::vector<dh_chain_la> la;
+    std::vector<uint16_t> tp;
+    for (size_t i = 0; i < r->rec.size(); i++) {
+        const dh_insertion &x = r->rec[i];
+        if (x.status != DH_PILE_OK || r->flank_of[i] < 0) continue;
+        if (x.contig_left < 0 || x.contig_left + 1 >= ncontigs) return dh_fail(DH_EINVAL, "dh_insertions_write_db: gap outside the contigs");
+        dh_insertion_rec q;
+        memset(&q, 0, sizeof(q));
+        q.start_contig = x.contig_left + 1;
+        q.start_part = 2;  // ContigPart.end
+        q.end_contig = x.contig_left + 2;
+        q.end_part = 1;    // ContigPart.begin
+        q.seq_len = x.cons_len;
+        q.contig_len = 0;
+        q.noverlaps = 2;
+        q.nread_ids = r->ids_off[i + 1] - r->ids_off[i];
+        ins.push_back(q);
+        bases.insert(bases.end(), r->bases.begin() + x.cons_off, r->bases.begin() + x.cons_off + x.cons_len);
+        std::vector<uint32_t> my(r->ids.begin() + r->ids_off[i], r->ids.begin() + r->ids_off[i + 1]);
+        for (uint32_t &v : my) v += 1;
+        std::sort(my.begin(), my.end());
+        ids.insert(ids.end(), my.begin(), my.end());
+        for (int side = 0; side < 2; side++) {
+            const dh_la &f = r->flank[(size_t)r->flank_of[i] + (size_t)side];
+            const int32_t c = x.contig_left + side;
+            dh_seeded s;
+            memset(&s, 0, sizeof(s));
+            s.id = (int64_t)sa.size();
+            s.contig_a_id = (uint32_t)(c + 1);
+            s.contig_a_len = (uint32_t)(contig_off[c + 1] - contig_off[c]);
+            s.contig_b_id = 1;
+            s.contig_b_len = (uint32_t)x.cons_len;
+            s.flags = (f.flags & DH_FLAG_COMP) ? 1 : 0;
+            s.seed = side == 0 ? 1 : 0;  // left flank: the back of the contig; right flank: its front
+            s.tspace = (uint16_t)tspace;
+            s.nla = 1;
+            sa.push_back(s);
+            la.push_back(dh_chain_la{(uint32_t)f.abpos, (uint32_t)f.aepos, (uint32_t)f.bbpos, (uint32_t)f.bepos, (uint32_t)f.diffs, f.tlen / 2});
+            tp.insert(tp.end(), r->flank_tr.begin() + f.toff, r->flank_tr.begin() + f.toff + f.tlen);
+        }
+    }
+    return dh_insertiondb_write(path, (int32_t)ins.size(), ins.data(), bases.data(), ids.data(), sa.data(), la.data(), tp.data());
+}
 
 struct ProcStats {
     float ms[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -1097,6 +1206,16 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
     } rg{res};
     const int32_t np = (int32_t)crop->rec.size();
     res->rec = crop->rec;
+    res->flank_of.assign((size_t)np, -1);
+    res->ids_off.assign((size_t)np + 1, 0);
+    {
+        std::vector<int32_t> cnt((size_t)np, 0);
+        for (int32_t p : crop->pile) cnt[(size_t)p]++;
+        for (int32_t p = 0; p < np; p++) res->ids_off[(size_t)p + 1] = res->ids_off[(size_t)p] + cnt[(size_t)p];
+        res->ids.resize((size_t)res->ids_off.back());
+        std::vector<int32_t> at(res->ids_off.begin(), res->ids_off.end() - 1);
+        for (size_t i = 0; i < crop->pile.size(); i++) res->ids[(size_t)at[(size_t)crop->pile[i]]++] = crop->read_id[i];
+    }
     const int32_t tsp = o.tspace_pile;
     int32_t pwidth = o.width > 0 ? o.width : 30;
     if (const char *e = getenv("DH_PILE_WIDTH")) pwidth = atoi(e);  // development override
@@ -1507,6 +1626,17 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
                 (int64_t)R->diffs * 1000000 > (int64_t)o.max_ins_err_ppm * (R->aepos - R->abpos)) {
                 rec.status = DH_PILE_MAX_INSERTION_ERROR;
                 continue;
+            }
+            for (const dh_la *fl : {L, R}) {  // kept for insertions.db (dh_insertions_write_db)
+                dh_la c = *fl;
+                if (fl == L) {
+                    c.abpos += foff[(size_t)a];
+                    c.aepos += foff[(size_t)a];
+                }
+                c.toff = (int64_t)res->flank_tr.size();
+                res->flank_tr.insert(res->flank_tr.end(), fset->trace.begin() + fl->toff, fset->trace.begin() + fl->toff + fl->tlen);
+                if (fl == L) res->flank_of[(size_t)pile_of_active[(size_t)a]] = (int32_t)res->flank.size();
+                res->flank.push_back(c);
             }
             rec.comp = (L->flags & DH_FLAG_COMP) ? 1 : 0;
             rec.left_aepos = foff[(size_t)a] + L->aepos;   // getCroppingPosition!"contigA", seed back

@@ -360,6 +360,69 @@ int64_t dh_dazz_read_mask(const dh_dazz *db, const char *db_path, const char *na
 int dh_dazz_write_mask(const char *db_path, const char *name, int32_t nreads, const int64_t *ptr,
                        const int32_t *iv);
 
+/* ---- the binary containers between DENTIST's commands (host only):
+ *      pile-ups.db (collect -> process, source/dentist/common/binio/pileupdb.d:400-897) and
+ *      insertions.db (process -> output, binio/insertiondb.d:738-1031), byte-compatible with the D
+ *      structs on x86-64.  Flat description used on both sides of the ABI:
+ *        dh_seeded    one SeededAlignment: alignment chain (id, contig A = reference contig, contig B =
+ *                     read, DENTIST flag bits 1 complement 2 disabled 4 alternateChain 8 chainContinuation
+ *                     16 unchained), trace spacing, seed (0 front, 1 back), nla local alignments
+ *        dh_chain_la  one LocalAlignment with ntp trace points
+ *        tp           (numDiffs, numBasePairs) u16 pairs of all local alignments, in order
+ *      pile-ups.db: npiles pile-ups of nra_of_pile[p] read alignments of nsa_of_ra[r] (1 or 2) seeded
+ *      alignments.  insertions.db: nins insertions, each with its sequence (codes a,c,g,t = 0..3,
+ *      stored 4 per byte as a=0 c=1 t=2 g=3), noverlaps seeded alignments and nread_ids read ids. */
+typedef struct {
+    int64_t id;
+    uint32_t contig_a_id, contig_a_len, contig_b_id, contig_b_len;
+    uint8_t flags, seed;
+    uint16_t tspace;
+    int32_t nla;
+} dh_seeded;
+typedef struct {
+    uint32_t a_begin, a_end, b_begin, b_end, diffs;
+    int32_t ntp;
+} dh_chain_la;
+typedef struct {
+    int64_t start_contig, end_contig; /* ContigNode.contigId (1-based contig ids)                         */
+    uint8_t start_part, end_part;     /* ContigPart: 0 pre, 1 begin, 2 end, 3 post (scaffold.d:77-90)     */
+    uint8_t pad[6];
+    int64_t seq_len, contig_len;
+    int32_t noverlaps, nread_ids;
+} dh_insertion_rec;
+typedef struct dh_chaindb dh_chaindb; /* a parsed container, owned by the library */
+int dh_pileupdb_write(const char *path, int32_t npiles, const int32_t *nra_of_pile, const int32_t *nsa_of_ra,
+                      const dh_seeded *sa, const dh_chain_la *la, const uint16_t *tp);
+int dh_pileupdb_read(const char *path, dh_chaindb **out);
+int dh_insertiondb_write(const char *path, int32_t nins, const dh_insertion_rec *ins, const uint8_t *bases,
+                         const uint32_t *read_ids, const dh_seeded *sa, const dh_chain_la *la, const uint16_t *tp);
+int dh_insertiondb_read(const char *path, dh_chaindb **out);
+/* pile-ups.db of a collect result (collectPileUps/package.d:88-96): every read of a pile-up becomes a
+ * ReadAlignment of two SeededAlignments (left contig seeded at the back, right contig at the front) */
+int dh_pileups_write_db(const dh_pileups *p, const dh_la *las, int64_t n, const uint16_t *trace,
+                        const int64_t *contig_off, int32_t ncontigs, const int64_t *read_off, int32_t nreads,
+                        int32_t tspace, const char *path);
+/* insertions.db of a process result (processPileUps/package.d:156-158, 789-805): one insertion per
+ * closed gap = (left contig, end) -> (right contig, begin), the whole consensus, its two flank overlaps
+ * with trace points (tspace = dh_process_opts.tspace_pile) and the sorted 1-based read ids */
+int dh_insertions_write_db(const dh_insertions *r, const int64_t *contig_off, int32_t ncontigs, int32_t tspace,
+                           const char *path);
+void dh_chaindb_destroy(dh_chaindb *d);
+int32_t dh_chaindb_npiles(const dh_chaindb *d);
+const int32_t *dh_chaindb_pile_counts(const dh_chaindb *d);
+int32_t dh_chaindb_nread_alignments(const dh_chaindb *d);
+const int32_t *dh_chaindb_read_alignment_counts(const dh_chaindb *d);
+int64_t dh_chaindb_nseeded(const dh_chaindb *d);
+const dh_seeded *dh_chaindb_seeded(const dh_chaindb *d);
+int64_t dh_chaindb_nlas(const dh_chaindb *d);
+const dh_chain_la *dh_chaindb_las(const dh_chaindb *d);
+int64_t dh_chaindb_ntrace(const dh_chaindb *d); /* number of u16 values = 2 x trace points */
+const uint16_t *dh_chaindb_trace(const dh_chaindb *d);
+int32_t dh_chaindb_ninsertions(const dh_chaindb *d);
+const dh_insertion_rec *dh_chaindb_insertions(const dh_chaindb *d);
+const uint8_t *dh_chaindb_bases(const dh_chaindb *d);
+const uint32_t *dh_chaindb_read_ids(const dh_chaindb *d);
+
 /* byte tracks `<dir>/.<db>.<name>.anno/.data` (the `qual` / `inqual` intrinsic-QV tracks DASqv and
  * computeintrinsicqv write and `DBdump -i` shows, dazzler.d:2877-2897, 6142-6183): .anno = int32 nreads,
  * int32 8, int64 byte offsets[nreads + 1]; .data = the bytes (one QV per trace tile).  read: bytes of the

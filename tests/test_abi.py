@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(decl):
         assert hasattr(L, name), f"{name} declared in include/ but not exported"
     assert decl == set(_lib.SYMBOLS), "binding list and header disagree"
-    assert L.dh_abi_version() == 1
+    assert L.dh_abi_version() == 2
 
 
 def test_struct_layouts_match_header():

@@ -211,3 +211,53 @@ def test_config2_full_size_properties(gpu_ctx):
         assert np.array_equal(trace[a["toff"]:a["toff"] + a["tlen"]], trace2[b["toff"]:b["toff"] + b["tlen"]])
     rec2, bases2 = dentist_amd.process_pileups(gpu_ctx, A, B, las2, trace2, dentist_amd.Pileups(las2, w.contigs.off, po), po)
     assert np.array_equal(rec2, rec) and np.array_equal(bases2, bases)
+
+
+def test_containers_of_collect_and_process(gpu_ctx, tmp_path):
+    """pile-ups.db of the collect result and insertions.db of the process result (binio/pileupdb.d,
+    insertiondb.d): what an unmodified `dentist process` / `dentist output` would read back."""
+    w = sim.Workload(400_000, 4, 1600, 6000, seed=83, spacing=20000, gap_max=900)
+    g = dentist_amd.default_align_opts()
+    A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
+    las, trace = gpu_ctx.align_db(A, B, g, select_best=True)
+    po = dentist_amd.default_process_opts(rounds=2)
+    piles = dentist_amd.Pileups(las, w.contigs.off, po)
+    pdb = str(tmp_path / "pile-ups.db")
+    piles.write_db(pdb, las, trace, w.contigs.off, w.reads.off)
+    back = dentist_amd.pileupdb_read(pdb)
+    assert len(back["pile_counts"]) == len(piles) and np.all(back["ra_counts"] == 2)
+    at = 0
+    for i in range(len(piles)):
+        gap, tri = piles.get(i)
+        assert back["pile_counts"][i] == len(tri)
+        for read, il, ir in tri.tolist():
+            left, right = back["seeded"][at], back["seeded"][at + 1]
+            at += 2
+            assert (left["contig_a_id"], right["contig_a_id"]) == (gap + 1, gap + 2)
+            assert left["contig_b_id"] == right["contig_b_id"] == read + 1 and (left["seed"], right["seed"]) == (1, 0)
+            assert left["contig_b_len"] == w.reads.length(read) and left["flags"] == (int(las[il]["flags"]) & 1)
+    assert int(back["las"]["ntp"].sum()) * 2 == len(back["trace"])
+    idb = str(tmp_path / "insertions.db")
+    rec, bases = dentist_amd.process_pileups(gpu_ctx, A, B, las, trace, piles, po, insertions_db=(idb, w.contigs.off, 126))
+    ins = dentist_amd.insertiondb_read(idb)
+    closed = rec[rec["status"] == 0]
+    assert len(ins["insertions"]) == len(closed) >= 3
+    boff = ioff = 0
+    for k, r in enumerate(closed):
+        q = ins["insertions"][k]
+        gap = int(r["contig_left"])
+        assert (q["start_contig"], q["start_part"], q["end_contig"], q["end_part"]) == (gap + 1, 2, gap + 2, 1)
+        assert q["seq_len"] == r["cons_len"] and q["noverlaps"] == 2
+        assert np.array_equal(ins["bases"][boff:boff + q["seq_len"]], bases[r["cons_off"]:r["cons_off"] + r["cons_len"]])
+        boff += int(q["seq_len"])
+        ids = ins["read_ids"][ioff:ioff + q["nread_ids"]]
+        ioff += int(q["nread_ids"])
+        assert np.all(np.diff(ids.astype(np.int64)) > 0) and int(r["ref_read_id"]) + 1 in ids.tolist() and len(ids) == r["nreads"]
+        left, right = ins["seeded"][2 * k], ins["seeded"][2 * k + 1]
+        ll, rl = ins["las"][2 * k], ins["las"][2 * k + 1]
+        # the cropping positions `dentist output` derives from the overlaps (insertions.d:230-284):
+        # contig A: end of the left overlap / begin of the right one; contig B likewise
+        assert (ll["a_end"], rl["a_begin"], ll["b_end"], rl["b_begin"]) == \
+               (r["left_aepos"], r["right_abpos"], r["ins_begin"], r["ins_end"])
+        assert left["contig_a_len"] == w.contigs.length(gap) and left["contig_b_len"] == r["cons_len"]
+        assert (left["seed"], right["seed"], left["tspace"]) == (1, 0, 126) and left["flags"] == r["comp"]
