@@ -1,1 +1,1 @@
-timeout -s KILL 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -6
+timeout -s KILL 400 python scripts/dev/pile_seed.py 8192 4096 2048 2>&1 | tail -3
