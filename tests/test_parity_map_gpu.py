@@ -325,3 +325,20 @@ def test_per_item_overflow_is_reported_not_fatal(gpu_ctx):
     assert all(r in want for r in la_rows(las, trace))
     per_item = np.bincount(las["aread"] * 2 + (las["flags"] & 1))
     assert per_item.max() <= 8
+
+
+@pytest.mark.parametrize("err,width,xdrop", [(0.10, 30, 120), (0.15, 14, 60)])
+def test_ont_like_error_profile_of_configs4(gpu_ctx, err, width, xdrop):
+    """BASELINE configs[4] reads: 20 kb, deletion-biased ONT-like errors (ins .3 / del .4 / sub .3,
+    SURVEY 8(d)).  The narrow windows do not break on this profile: every read maps end to end, and the
+    HIP path equals the oracle bit for bit."""
+    g = sim.genome(97, 600_000)
+    gb, ge = sim.gaps(98, len(g), 3, 50, 3000, 20000)
+    contigs, _ = sim.contigs_from_gaps(g, gb, ge)
+    reads, truth = sim.reads(99, g, 240, 20000, 0, err=err, p_ins=0.30, p_del=0.40)
+    las, _ = run_both(gpu_ctx, contigs, reads, k=20, kmer_mod=4, width=width, xdrop=xdrop)
+    assert len(set(las["bread"].tolist())) == reads.n
+    covered = np.zeros(reads.n, dtype=np.int64)
+    np.add.at(covered, las["bread"], las["bepos"] - las["bbpos"])
+    lens = np.diff(reads.off)
+    assert np.mean(covered >= 0.9 * lens) > 0.93   # reads across a gap lose the gap itself
