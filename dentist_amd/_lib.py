@@ -83,7 +83,7 @@ SYMBOLS = [
     "dh_chaindb_npiles", "dh_chaindb_pile_counts", "dh_chaindb_nread_alignments", "dh_chaindb_read_alignment_counts",
     "dh_chaindb_nseeded", "dh_chaindb_seeded", "dh_chaindb_nlas", "dh_chaindb_las", "dh_chaindb_ntrace",
     "dh_chaindb_trace", "dh_chaindb_ninsertions", "dh_chaindb_insertions", "dh_chaindb_bases", "dh_chaindb_read_ids",
-    "dh_insertions_write_db", "dh_pileups_write_db",
+    "dh_insertions_write_db", "dh_pileups_write_db", "dh_pileups_flat",
 ]
 
 _LIB = None
@@ -448,6 +448,27 @@ class Pileups:
                                           ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_char_p]
         _check(L.dh_pileups_write_db(self._h, arr.ctypes.data, len(arr), tr.ctypes.data, co.ctypes.data, len(co) - 1,
                                      ro.ctypes.data, len(ro) - 1, tspace, path.encode()))
+
+    def flat(self):
+        """(contig_left int32[npiles], count int32[npiles], triples int32[total, 3]) in one call."""
+        L = lib()
+        L.dh_pileups_flat.argtypes = [ctypes.c_void_p] * 4
+        L.dh_pileups_flat.restype = ctypes.c_int64
+        n = len(self)
+        cl, cnt = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+        tot = L.dh_pileups_flat(self._h, None, None, None)
+        tri = np.zeros((tot, 3), dtype=np.int32)
+        L.dh_pileups_flat(self._h, cl.ctypes.data, cnt.ctypes.data, tri.ctypes.data)
+        return cl, cnt, tri
+
+    @classmethod
+    def from_flat(cls, contig_left, count, triples):
+        cl = np.ascontiguousarray(contig_left, dtype=np.int32)
+        cnt = np.ascontiguousarray(count, dtype=np.int32)
+        tri = np.ascontiguousarray(triples, dtype=np.int32)
+        h = ctypes.c_void_p()
+        _check(lib().dh_pileups_create(cl.ctypes.data, cnt.ctypes.data, len(cl), tri.ctypes.data, ctypes.byref(h)))
+        return cls(None, None, None, _handle=h)
 
     def select(self, las, opts):
         """dh_pileups_select: the min_reads / max_reads cut."""

@@ -358,6 +358,22 @@ extern "C" int dh_pileups_write_db(const dh_pileups *p, const dh_la *las, int64_
     return dh_pileupdb_write(path, (int32_t)nra.size(), nra.data(), nsa.data(), sa.data(), la.data(), tp.data());
 }
 
+// all pile-ups at once: contig_left[npiles], count[npiles], triples[3 * total]; arrays may be NULL to
+// size; returns the total number of triples
+extern "C" int64_t dh_pileups_flat(const dh_pileups *p, int32_t *contig_left, int32_t *count, int32_t *triples)
+{
+    if (!p) return 0;
+    int64_t at = 0;
+    for (size_t i = 0; i < p->contig_left.size(); i++) {
+        const std::vector<int32_t> &t = p->triples[i];
+        if (contig_left) contig_left[i] = p->contig_left[i];
+        if (count) count[i] = (int32_t)t.size() / 3;
+        if (triples && !t.empty()) memcpy(triples + 3 * at, t.data(), sizeof(int32_t) * t.size());
+        at += (int64_t)t.size() / 3;
+    }
+    return at;
+}
+
 extern "C" void dh_pileups_destroy(dh_pileups *p) { delete p; }
 extern "C" int32_t dh_pileups_count(const dh_pileups *p) { return p ? (int32_t)p->contig_left.size() : 0; }
 extern "C" int32_t dh_pileups_get(const dh_pileups *p, int32_t i, int32_t *contig_left,

@@ -113,44 +113,39 @@ def all_to_all_bytes(per_dest, world):
 def pack_candidates(cands, las):
     """Candidate entries of this rank (dentist_amd.Pileups(..., candidates=True) on its LAs, whose
     bread are ids of the whole reads DB) as CAND_DTYPE records in (gap, read) order."""
-    rows = []
-    for i in range(len(cands)):
-        gap, tri = cands.get(i)
-        rec = np.zeros(len(tri), dtype=CAND_DTYPE)
-        rec["gap"] = gap
-        rec["read"] = tri[:, 0]
-        rec["L"] = las[tri[:, 1]]
-        rec["R"] = las[tri[:, 2]]
-        rows.append(rec)
-    return np.concatenate(rows) if rows else np.zeros(0, dtype=CAND_DTYPE)
+    cl, cnt, tri = cands.flat()
+    rec = np.zeros(len(tri), dtype=CAND_DTYPE)
+    rec["gap"] = np.repeat(cl, cnt)
+    rec["read"] = tri[:, 0]
+    rec["L"] = las[tri[:, 1]]
+    rec["R"] = las[tri[:, 2]]
+    return rec
 
 
 def merge_candidates(per_rank):
-    """All ranks' candidates -> (LA array, contig_left list, triples per gap).  Ranks hold ascending
-    read ranges and list their candidates by read, so concatenation in rank order keeps every gap's
-    entries ordered by read id -- the order `dentist collect` sees after LAmerge."""
+    """All ranks' candidates -> (LA array, contig_left, count, triples).  Ranks hold ascending read
+    ranges and list their candidates by read, so a stable sort by gap of the concatenation in rank
+    order keeps every gap's entries ordered by read id -- the order `dentist collect` sees after
+    LAmerge."""
     allc = np.concatenate(per_rank) if len(per_rank) else np.zeros(0, dtype=CAND_DTYPE)
     las = np.zeros(2 * len(allc), dtype=LA_DTYPE)
     las[0::2] = allc["L"]
     las[1::2] = allc["R"]
     order = np.argsort(allc["gap"], kind="stable")
-    gaps, starts = np.unique(allc["gap"][order], return_index=True)
-    bounds = list(starts) + [len(order)]
-    triples = []
-    for x in range(len(gaps)):
-        idx = order[bounds[x]:bounds[x + 1]]
-        triples.append(np.stack([allc["read"][idx], 2 * idx, 2 * idx + 1], axis=1).astype(np.int32))
-    return las, [int(g) for g in gaps], triples
+    gaps, counts = np.unique(allc["gap"][order], return_counts=True)
+    triples = np.stack([allc["read"][order], 2 * order, 2 * order + 1], axis=1).astype(np.int32)
+    return las, gaps.astype(np.int32), counts.astype(np.int32), triples
 
 
 def pile_costs(piles, las):
     """n^2 * L per pile-up: n reads, L = mean read span between the anchors + 1 kb."""
-    costs = []
-    for i in range(len(piles)):
-        _, tri = piles.get(i)
-        span = np.maximum(las["bbpos"][tri[:, 2]] - las["bepos"][tri[:, 1]], 0).mean() + 1000.0
-        costs.append(int(len(tri) ** 2 * span))
-    return costs
+    _, cnt, tri = piles.flat()
+    if len(cnt) == 0:
+        return np.zeros(0, dtype=np.int64)
+    span = np.maximum(las["bbpos"][tri[:, 2]].astype(np.int64) - las["bepos"][tri[:, 1]], 0)
+    starts = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+    mean = np.add.reduceat(span, starts) / np.maximum(cnt, 1) + 1000.0
+    return (cnt.astype(np.int64) ** 2 * mean).astype(np.int64)
 
 
 def _runs(bases, off, idx):
@@ -212,10 +207,10 @@ def sharded_process_steps(ctx, contigs_db, reads_db, read_first, contig_off, las
     mine = pack_candidates(cands, las)
     blobs = yield ("all_gather", mine.view(np.uint8))
     per_rank = [np.frombuffer(b.tobytes(), dtype=CAND_DTYPE) for b in blobs]
-    glas, gaps, triples = merge_candidates(per_rank)
+    glas, gaps, counts, triples = merge_candidates(per_rank)
     # the entries of this rank inside glas are copies of its own records: their toff still points
     # into its own trace array, which is all dh_crop_pileups needs (other ranks' traces stay there)
-    piles = Pileups.from_triples(gaps, triples).select(glas, popts)
+    piles = Pileups.from_flat(gaps, counts, triples).select(glas, popts)
     owner = assign_owners(pile_costs(piles, glas), world)
     crop = Cropped.crop(ctx, contigs_db, reads_db, read_first, glas, trace, piles, popts)
     rec, cpile, centry, cread, coff, cbases = crop.arrays()

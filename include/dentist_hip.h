@@ -227,6 +227,10 @@ int32_t dh_pileups_count(const dh_pileups *p);
  * (read, left LA index, right LA index) triples */
 int32_t dh_pileups_get(const dh_pileups *p, int32_t i, int32_t *contig_left, const int32_t **triples);
 
+/* all pile-ups at once: contig_left[npiles], count[npiles], triples[3 * total] (any may be NULL);
+ * returns the total number of triples */
+int64_t dh_pileups_flat(const dh_pileups *p, int32_t *contig_left, int32_t *count, int32_t *triples);
+
 /* ---- `dentist process` for a batch of pile-ups: crop -> pile-up alignment -> filter -> tile QV
  *      -> reference read -> consensus -> flank re-alignment -> insertion
  *      (source/dentist/commands/processPileUps/package.d:283-374; cropper.d:446-550;

@@ -115,12 +115,11 @@ def test_owner_assignment_and_candidate_merge_are_deterministic():
         return c
     r0 = np.concatenate([cand(3, 1, 10), cand(7, 0, 20), cand(7, 2, 30)])
     r1 = np.concatenate([cand(7, 5, 40), cand(9, 6, 50)])
-    las, gaps, triples = merge_candidates([r0, r1])
-    assert gaps == [3, 7, 9] and las.dtype == LA_DTYPE
-    assert triples[1][:, 0].tolist() == [0, 2, 5]     # read-id order across the ranks
-    for t in triples:
-        for read, il, ir in t.tolist():
-            assert ir == il + 1 and las[ir]["abpos"] == las[il]["abpos"] + 1
+    las, gaps, counts, triples = merge_candidates([r0, r1])
+    assert gaps.tolist() == [3, 7, 9] and counts.tolist() == [1, 3, 1] and las.dtype == LA_DTYPE
+    assert triples[1:4, 0].tolist() == [0, 2, 5]     # read-id order across the ranks
+    for read, il, ir in triples.tolist():
+        assert ir == il + 1 and las[ir]["abpos"] == las[il]["abpos"] + 1
     # the lockstep driver: two generators exchanging through "collectives"
     def gen(rank):
         got = yield ("all_gather", np.asarray([rank + 1], dtype=np.uint8))
