@@ -10,7 +10,8 @@ A "step" is one pass of the whole hot path over that input, resident in HBM when
   1. every read is aligned to the assembly: k-mer index of the contigs, then a loop over read
      chunks (seed filter, wave alignment with trace points, LAs back on the host)  -- damapper's
      role, one call per read block against the persistent index (snakemake/Snakefile:1143-1170),
-  2. the spanning reads of every gap are collected (host)                       -- `dentist collect`,
+  2. the alignments pass the six filters of `dentist collect` and the spanning reads of every gap are
+     collected (host)                                                           -- `dentist collect`,
   3. every pile-up goes through crop -> pile-up all-vs-all alignment -> filters -> tile QV ->
      reference read -> consensus rounds -> flank re-alignment -> insertion      -- `dentist process`
      with daligner/DASqv/daccord replaced by kernels.
@@ -128,6 +129,9 @@ def main():
         las, trace = ctx.align_db(A, B, mopts, select_best=True)
         ast = ctx.align_stats()
         t1 = time.perf_counter()
+        # the six alignment filters of `dentist collect` (filter.d:122-356): per-read decisions, so
+        # every rank filters the alignments of its own reads
+        las, dropped, _ = dentist_amd.collect_filter(las, w.contigs.off, w.reads.off, popts, inplace=True)
         if world == 1:
             piles = dentist_amd.Pileups(las, w.contigs.off, popts)
             t2 = time.perf_counter()
@@ -140,6 +144,7 @@ def main():
         t3 = time.perf_counter()
         pst = dentist_amd.process_stats(ctx)
         cum = ctx.cum_stats().as_dict()  # every k_wave / k_seed launch of the step
+        info["filtered"] = dropped.tolist()
         return dict(las=las, rec=rec, bases=bases, ast=ast, pst=pst, cum=cum, info=info,
                     t_map=t1 - t0, t_collect=t2 - t1, t_process=t3 - t2)
 
@@ -215,6 +220,8 @@ def main():
                        "mapping_kmer_mod": args.kmer_mod, "mapping_width": args.map_width,
                        "mapping_xdrop": args.map_xdrop, "parallelism": f"reads and gaps sharded over {world} GPU(s)",
                        "read_bp_total": read_all, "pile_ups": int(last["info"]["piles"]),
+                       "collect_filters_dropped_las": dict(zip(("lq", "improper", "weakly_anchored", "contained",
+                                                                "ambiguous", "redundant"), last["info"]["filtered"])),
                        "gaps_closed": nclosed_all, "gap_bases_closed": gap_all,
                        "consensus_edit_distance_vs_truth": edits_all, "consensus_truth_bases": truth_all,
                        "consensus_error_rate": (edits_all / truth_all) if truth_all else None},

@@ -83,7 +83,7 @@ SYMBOLS = [
     "dh_chaindb_npiles", "dh_chaindb_pile_counts", "dh_chaindb_nread_alignments", "dh_chaindb_read_alignment_counts",
     "dh_chaindb_nseeded", "dh_chaindb_seeded", "dh_chaindb_nlas", "dh_chaindb_las", "dh_chaindb_ntrace",
     "dh_chaindb_trace", "dh_chaindb_ninsertions", "dh_chaindb_insertions", "dh_chaindb_bases", "dh_chaindb_read_ids",
-    "dh_insertions_write_db", "dh_pileups_write_db", "dh_pileups_flat",
+    "dh_insertions_write_db", "dh_pileups_write_db", "dh_pileups_flat", "dh_collect_filter",
 ]
 
 _LIB = None
@@ -497,6 +497,29 @@ class Pileups:
             self.close()
         except Exception:
             pass
+
+
+def collect_filter(las, contig_off, read_off, opts, repeat_mask=None, inplace=False):
+    """The six filters of `dentist collect` (filter.d:122-356). Returns (las with DISABLED flags -- a
+    copy unless inplace, dropped-per-stage int64[6], read_used uint8[nreads])."""
+    arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
+    if not inplace or arr is not las or not arr.flags.writeable:
+        arr = arr.copy()
+    co, ro = np.ascontiguousarray(contig_off, dtype=np.int64), np.ascontiguousarray(read_off, dtype=np.int64)
+    dropped = np.zeros(6, dtype=np.int64)
+    used = np.ones(len(ro) - 1, dtype=np.uint8)
+    rp = ri = None
+    if repeat_mask is not None:
+        rp = np.ascontiguousarray(repeat_mask[0], dtype=np.int64)
+        ri = np.ascontiguousarray(np.concatenate([repeat_mask[1], [0, 0]]), dtype=np.int32)
+    L = lib()
+    L.dh_collect_filter.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+                                    ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ProcessOpts),
+                                    ctypes.c_void_p, ctypes.c_void_p]
+    _check(L.dh_collect_filter(arr.ctypes.data, len(arr), co.ctypes.data, len(co) - 1, ro.ctypes.data, len(ro) - 1,
+                               rp.ctypes.data if rp is not None else None, ri.ctypes.data if ri is not None else None,
+                               ctypes.byref(opts), dropped.ctypes.data, used.ctypes.data))
+    return arr, dropped, used
 
 
 class Cropped:

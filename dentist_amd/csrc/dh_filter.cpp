@@ -1,0 +1,176 @@
+// dh_filter.cpp -- the alignment filters of `dentist collect` (host only):
+// source/dentist/commands/collectPileUps/filter.d:122-356, applied in the order of
+// collectPileUps/package.d:130-141 to the read->contig alignments damapper produced:
+//   1 LQ              averageErrorRate > maxAlignmentError                      filter.d:122-139, base.d:695-698
+//   2 Improper        !isProper(properAlignmentAllowance)                       filter.d:142-161, base.d:537-556
+//   3 WeaklyAnchored  <= minAnchorLength unmasked reference bases               filter.d:325-356
+//   4 Contained       inside another alignment on contig AND read, same strand  filter.d:178-211
+//   5 Ambiguous       reads with two alignments that overlap on the read        filter.d:238-322
+//   6 Redundant       reads with an alignment that (extended by the unaligned
+//                     read ends) lies inside one contig                          filter.d:164-175, base.d:562-598
+// Alignment chains are the single-LA chains this library's damapper role emits.  Dropped alignments
+// get DH_FLAG_DISABLED (the reference removes the alignments of ambiguous reads from the array; the
+// effect on every later stage is the same).  Per-alignment predicates run on the host thread pool.
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "dh_internal.h"
+#include "dh_parallel.h"
+
+namespace {
+struct Ctx {
+    const int64_t *coff, *roff;
+    int32_t alen(const dh_la &l) const { return (int32_t)(coff[l.aread + 1] - coff[l.aread]); }
+    int32_t blen(const dh_la &l) const { return (int32_t)(roff[l.bread + 1] - roff[l.bread]); }
+    // toInterval!(ReadInterval, "contigB"), common/package.d:259-288: forward read coordinates
+    int32_t bfwd_begin(const dh_la &l) const { return (l.flags & DH_FLAG_COMP) ? blen(l) - l.bepos : l.bbpos; }
+    int32_t bfwd_end(const dh_la &l) const { return (l.flags & DH_FLAG_COMP) ? blen(l) - l.bbpos : l.bepos; }
+};
+}  // namespace
+
+extern "C" int dh_collect_filter(dh_la *las, int64_t n, const int64_t *contig_off, int32_t ncontigs,
+                                 const int64_t *read_off, int32_t nreads, const int64_t *rep_ptr, const int32_t *rep_iv,
+                                 const dh_process_opts *opts, int64_t *dropped6, uint8_t *read_used)
+{
+    if ((n > 0 && !las) || !contig_off || !read_off || !opts || n < 0) return dh_fail(DH_EINVAL, "dh_collect_filter: bad argument");
+    for (int64_t i = 0; i < n; i++)
+        if (las[i].aread < 0 || las[i].aread >= ncontigs || las[i].bread < 0 || las[i].bread >= nreads)
+            return dh_fail(DH_EINVAL, "dh_collect_filter: id out of range");
+    const dh_process_opts &o = *opts;
+    const Ctx c{contig_off, read_off};
+    int64_t cnt[6] = {0, 0, 0, 0, 0, 0};
+    auto count_disabled = [&] {
+        int64_t d = 0;
+        for (int64_t i = 0; i < n; i++) d += (las[i].flags & DH_FLAG_DISABLED) ? 1 : 0;
+        return d;
+    };
+    int64_t before = count_disabled();
+    auto stage_done = [&](int s) {
+        const int64_t now = count_disabled();
+        cnt[s] = now - before;
+        before = now;
+    };
+    // 1-3: per-alignment predicates
+    dh_parallel_for(n, 4096, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; i++) {
+            dh_la &l = las[i];
+            if (l.flags & DH_FLAG_DISABLED) continue;
+            if ((int64_t)l.diffs * 1000000 > (int64_t)o.max_align_err_ppm * (l.aepos - l.abpos)) l.flags |= DH_FLAG_DISABLED;
+        }
+    });
+    stage_done(0);
+    dh_parallel_for(n, 4096, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; i++) {
+            dh_la &l = las[i];
+            if (l.flags & DH_FLAG_DISABLED) continue;
+            const bool begins = l.abpos <= o.allowance || l.bbpos <= o.allowance;
+            const bool ends = l.aepos + o.allowance >= c.alen(l) || l.bepos + o.allowance >= c.blen(l);
+            if (!(begins && ends)) l.flags |= DH_FLAG_DISABLED;
+        }
+    });
+    stage_done(1);
+    dh_parallel_for(n, 4096, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; i++) {
+            dh_la &l = las[i];
+            if (l.flags & DH_FLAG_DISABLED) continue;
+            int64_t unmasked = l.aepos - l.abpos;
+            if (rep_ptr)
+                for (int64_t j = rep_ptr[l.aread]; j < rep_ptr[l.aread + 1]; j++) {
+                    const int32_t b = std::max(rep_iv[2 * j], l.abpos), e = std::min(rep_iv[2 * j + 1], l.aepos);
+                    if (e > b) unmasked -= e - b;
+                }
+            if (unmasked <= o.min_anchor) l.flags |= DH_FLAG_DISABLED;
+        }
+    });
+    stage_done(2);
+    // 4: contained (AlignmentChain.opCmp order, base.d:766-777; stable).  Alignments of different
+    // contigs never interact, so the contigs are sorted and scanned independently on the host threads.
+    std::vector<int64_t> ord((size_t)n);
+    {
+        std::vector<int64_t> cfirst((size_t)ncontigs + 1, 0);
+        for (int64_t i = 0; i < n; i++) cfirst[(size_t)las[i].aread + 1]++;
+        for (int32_t a = 0; a < ncontigs; a++) cfirst[(size_t)a + 1] += cfirst[(size_t)a];
+        std::vector<int64_t> cur(cfirst.begin(), cfirst.end() - 1);
+        for (int64_t i = 0; i < n; i++) ord[(size_t)cur[(size_t)las[i].aread]++] = i;  // stable by input order
+        dh_parallel_for(ncontigs, 8, [&](int64_t clo, int64_t chi) {
+            for (int64_t a = clo; a < chi; a++) {
+                const auto ob = ord.begin() + cfirst[(size_t)a], oe = ord.begin() + cfirst[(size_t)a + 1];
+                std::stable_sort(ob, oe, [&](int64_t x, int64_t y) {
+                    const dh_la &p = las[x], &q = las[y];
+                    if (p.bread != q.bread) return p.bread < q.bread;
+                    if (p.abpos != q.abpos) return p.abpos < q.abpos;
+                    if (p.bbpos != q.bbpos) return p.bbpos < q.bbpos;
+                    if (p.aepos != q.aepos) return p.aepos < q.aepos;
+                    return p.bepos < q.bepos;
+                });
+                for (auto x = ob; x != oe; ++x) {
+                    const dh_la &a1 = las[*x];
+                    if (a1.flags & DH_FLAG_DISABLED) continue;
+                    for (auto y = x + 1; y != oe; ++y) {
+                        dh_la &a2 = las[*y];
+                        if (!(a1.abpos <= a2.abpos && a2.aepos <= a1.aepos)) break;  // sliceUntil
+                        if ((a2.flags & DH_FLAG_COMP) == (a1.flags & DH_FLAG_COMP) && a2.bread == a1.bread &&
+                            c.bfwd_begin(a1) <= c.bfwd_begin(a2) && c.bfwd_end(a2) <= c.bfwd_end(a1))
+                            a2.flags |= DH_FLAG_DISABLED;
+                    }
+                }
+            }
+        });
+    }
+    stage_done(3);
+    // group by read for 5 and 6
+    std::vector<int64_t> first((size_t)nreads + 1, 0), byread((size_t)n);
+    for (int64_t i = 0; i < n; i++) first[(size_t)las[i].bread + 1]++;
+    for (int32_t r = 0; r < nreads; r++) first[(size_t)r + 1] += first[(size_t)r];
+    {
+        std::vector<int64_t> cur(first.begin(), first.end() - 1);
+        for (int64_t i = 0; i < n; i++) byread[(size_t)cur[(size_t)las[i].bread]++] = i;
+    }
+    std::vector<uint8_t> used((size_t)nreads, 1);
+    // 5: ambiguous -- two enabled alignments of a read that intersect on the read
+    dh_parallel_for(nreads, 2048, [&](int64_t lo, int64_t hi) {
+        for (int64_t r = lo; r < hi; r++) {
+            bool amb = false;
+            for (int64_t x = first[(size_t)r]; x < first[(size_t)r + 1] && !amb; x++) {
+                const dh_la &p = las[byread[(size_t)x]];
+                if (p.flags & DH_FLAG_DISABLED) continue;
+                for (int64_t y = x + 1; y < first[(size_t)r + 1]; y++) {
+                    const dh_la &q = las[byread[(size_t)y]];
+                    if (q.flags & DH_FLAG_DISABLED) continue;
+                    if (c.bfwd_begin(p) < c.bfwd_end(q) && c.bfwd_begin(q) < c.bfwd_end(p)) {
+                        amb = true;
+                        break;
+                    }
+                }
+            }
+            if (amb) {
+                used[(size_t)r] = 0;
+                for (int64_t x = first[(size_t)r]; x < first[(size_t)r + 1]; x++) las[byread[(size_t)x]].flags |= DH_FLAG_DISABLED;
+            }
+        }
+    });
+    stage_done(4);
+    // 6: redundant -- isFullyContained, base.d:562-598
+    dh_parallel_for(nreads, 2048, [&](int64_t lo, int64_t hi) {
+        for (int64_t r = lo; r < hi; r++) {
+            bool red = false;
+            for (int64_t x = first[(size_t)r]; x < first[(size_t)r + 1] && !red; x++) {
+                const dh_la &p = las[byread[(size_t)x]];
+                if (p.flags & DH_FLAG_DISABLED) continue;
+                if (p.bbpos > p.abpos) continue;
+                const int64_t yy = (int64_t)p.aepos + c.blen(p) - p.bepos;
+                red = yy < c.alen(p);
+            }
+            if (red) {
+                used[(size_t)r] = 0;
+                for (int64_t x = first[(size_t)r]; x < first[(size_t)r + 1]; x++) las[byread[(size_t)x]].flags |= DH_FLAG_DISABLED;
+            }
+        }
+    });
+    stage_done(5);
+    if (dropped6) memcpy(dropped6, cnt, sizeof(cnt));
+    if (read_used) memcpy(read_used, used.data(), (size_t)nreads);
+    return DH_OK;
+}

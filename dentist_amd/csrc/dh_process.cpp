@@ -189,12 +189,14 @@ static int collect_candidates(const dh_la *las, int64_t n, const int64_t *contig
                 for (int64_t x = 0; x < cnt; x++) {
                     const int64_t iL = idx[x];
                     const dh_la &L = las[iL];
+                    if (L.flags & DH_FLAG_DISABLED) continue;  // dropped by dh_collect_filter
                     if (L.aread + 1 >= ncontigs) continue;
                     const int64_t cl = contig_off[L.aread + 1] - contig_off[L.aread];
                     if (L.aepos + o.allowance < cl || L.aepos - L.abpos < o.min_anchor) continue;
                     for (int64_t y = 0; y < cnt; y++) {
                         const int64_t iR = idx[y];
                         const dh_la &R = las[iR];
+                        if (R.flags & DH_FLAG_DISABLED) continue;
                         if (R.aread != L.aread + 1 || (R.flags & DH_FLAG_COMP) != (L.flags & DH_FLAG_COMP)) continue;
                         if (R.abpos > o.allowance || R.aepos - R.abpos < o.min_anchor) continue;
                         if (R.bbpos + o.allowance < L.bepos - o.allowance) continue;

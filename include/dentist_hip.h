@@ -227,6 +227,17 @@ int32_t dh_pileups_count(const dh_pileups *p);
  * (read, left LA index, right LA index) triples */
 int32_t dh_pileups_get(const dh_pileups *p, int32_t i, int32_t *contig_left, const int32_t **triples);
 
+/* the six alignment filters of `dentist collect` (collectPileUps/filter.d:122-356, order of
+ * collectPileUps/package.d:130-141) on the read->contig LAs: LQ (averageErrorRate > max_align_err),
+ * Improper (allowance), WeaklyAnchored (<= min_anchor bases outside the repeat mask rep_ptr / rep_iv of
+ * the contigs, may be NULL), Contained, Ambiguous (reads with alignments overlapping on the read),
+ * Redundant (reads that fit inside one contig).  Dropped LAs get DH_FLAG_DISABLED in place;
+ * dropped6[stage] = LAs dropped per stage, read_used[r] = 0 for reads discarded by 5 / 6 (either may be
+ * NULL).  Host only. */
+int dh_collect_filter(dh_la *las, int64_t n, const int64_t *contig_off, int32_t ncontigs, const int64_t *read_off,
+                      int32_t nreads, const int64_t *rep_ptr, const int32_t *rep_iv, const dh_process_opts *opts,
+                      int64_t *dropped6, uint8_t *read_used);
+
 /* all pile-ups at once: contig_left[npiles], count[npiles], triples[3 * total] (any may be NULL);
  * returns the total number of triples */
 int64_t dh_pileups_flat(const dh_pileups *p, int32_t *contig_left, int32_t *count, int32_t *triples);

@@ -94,12 +94,12 @@ int oz_collect_spanning(const oz_la *las, int64_t n, const oz_db *contigs, const
         for (int64_t x = 0; x < c; x++) {
             const oz_la *L = &las[idx[x]];
             const int32_t g = L->aread;
-            if (g < 0 || g + 1 >= nc) continue;
+            if ((L->flags & OZ_FLAG_DISABLED) || g < 0 || g + 1 >= nc) continue;
             const int64_t cl = contigs->off[g + 1] - contigs->off[g];
             if (L->aepos + o->allowance < cl || L->aepos - L->abpos < o->min_anchor) continue;
             for (int64_t y = 0; y < c; y++) {
                 const oz_la *R = &las[idx[y]];
-                if (R->aread != g + 1 || (R->flags & 1u) != (L->flags & 1u)) continue;
+                if ((R->flags & OZ_FLAG_DISABLED) || R->aread != g + 1 || (R->flags & 1u) != (L->flags & 1u)) continue;
                 if (R->abpos > o->allowance || R->aepos - R->abpos < o->min_anchor) continue;
                 if (R->bbpos + o->allowance < L->bepos - o->allowance) continue; /* right part follows the left part */
                 const int64_t anchors = (int64_t)(L->aepos - L->abpos) + (R->aepos - R->abpos);

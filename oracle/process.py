@@ -32,14 +32,14 @@ def collect_spanning(las, trace, contigs, reads, allowance=ALLOWANCE_MAP, min_an
         best = {}
         for iL in idxs:
             L = las[iL]
-            if int(L["aread"]) + 1 >= contigs.n:
+            if L["flags"] & 0x20 or int(L["aread"]) + 1 >= contigs.n:   # 0x20: dropped by the collect filters
                 continue
             cl = contigs.length(int(L["aread"]))
             if L["aepos"] + allowance < cl or L["aepos"] - L["abpos"] < min_anchor:
                 continue
             for iR in idxs:
                 R = las[iR]
-                if R["aread"] != L["aread"] + 1 or (R["flags"] & 1) != (L["flags"] & 1):
+                if R["flags"] & 0x20 or R["aread"] != L["aread"] + 1 or (R["flags"] & 1) != (L["flags"] & 1):
                     continue
                 if R["abpos"] > allowance or R["aepos"] - R["abpos"] < min_anchor:
                     continue

@@ -1,0 +1,96 @@
+"""The six alignment filters of `dentist collect` (filter.d:122-356): unit cases of the reference's
+predicates (base.d:600-640 isFullyContained), the product (dh_collect_filter, host code through the C
+ABI) against the oracle restatement on random alignment sets, and a planted scenario.  CPU only."""
+import numpy as np
+import pytest
+
+import dentist_amd
+from oracle import collect_filters as cf
+
+LA = dentist_amd.LA_DTYPE
+
+
+def la(aread, bread, abpos, aepos, bbpos, bepos, diffs=0, comp=0):
+    r = np.zeros(1, dtype=LA)[0]
+    r["aread"], r["bread"], r["abpos"], r["aepos"], r["bbpos"], r["bepos"], r["diffs"], r["flags"] = \
+        aread, bread, abpos, aepos, bbpos, bepos, diffs, comp
+    return r
+
+
+def test_is_fully_contained_cases_of_the_reference():
+    """base.d:600-640: contig A of 50, read B of 15."""
+    assert cf.is_fully_contained(la(0, 0, 30, 35, 5, 10), 50, 15)        # read with extension on A from 25 to 40
+    assert not cf.is_fully_contained(la(0, 0, 0, 10, 5, 10), 50, 15)     # from -5 to 15
+    assert not cf.is_fully_contained(la(0, 0, 40, 50, 5, 10), 50, 15)    # from 35 to 55
+    # the product agrees: the redundant filter drops exactly the first read
+    las = np.stack([la(0, 0, 30, 35, 5, 10), la(0, 1, 0, 10, 5, 10), la(0, 2, 40, 50, 5, 10)])
+    po = dentist_amd.default_process_opts(allowance=100, min_anchor=0)
+    out, dropped, used = dentist_amd.collect_filter(las, [0, 50], [0, 15, 30, 45], po)
+    assert used.tolist() == [0, 1, 1] and dropped[5] == 1 and (out["flags"] & 0x20 != 0).tolist() == [True, False, False]
+
+
+def random_las(rng, nreads, ncontigs, clen, rlen):
+    """1-3 alignments per read; most are proper (touch a contig or read end), some low quality, some
+    shrunk copies of another alignment (contained), some reads short enough to fit inside a contig."""
+    rows = []
+    for r in range(nreads):
+        for _ in range(int(rng.integers(1, 4))):
+            c, comp = int(rng.integers(0, ncontigs)), int(rng.integers(0, 2))
+            ln = int(rng.integers(600, 5000))
+            kind = rng.random()
+            if kind < 0.35:      # read hangs over the contig begin
+                ab, bb = 0, rlen - ln
+            elif kind < 0.7:     # ... over the contig end
+                ab, bb = clen - ln, 0
+            elif kind < 0.85:    # inside the contig, whole read aligned (short read): redundant
+                ab, bb, ln = int(rng.integers(1000, clen - 7000)), 0, rlen
+            else:                # somewhere: improper
+                ab, bb = int(rng.integers(100, clen - 6000)), int(rng.integers(100, rlen - ln))
+            d = int(ln * rng.choice([0.05, 0.13, 0.2, 0.35]))
+            rows.append(la(c, r, ab, ab + ln, bb, bb + ln, d, comp))
+            if rng.random() < 0.15:   # a contained copy
+                rows.append(la(c, r, ab + 50, ab + ln - 50, bb + 50, bb + ln - 50, d // 2, comp))
+    out = np.stack(rows)
+    return out[rng.permutation(len(out))]
+
+
+def test_product_filters_equal_the_oracle_on_random_sets():
+    total = np.zeros(6, dtype=np.int64)
+    for seed in range(1, 7):
+        rng = np.random.default_rng(seed)
+        nc, nr, clen, rlen = 6, 150, 20000, 6000
+        las = random_las(rng, nr, nc, clen, rlen)
+        coff = np.arange(nc + 1, dtype=np.int64) * clen
+        roff = np.arange(nr + 1, dtype=np.int64) * rlen
+        ptr = np.arange(nc + 1, dtype=np.int64) * 2
+        iv = np.tile(np.asarray([0, 4000, 15000, 19990], dtype=np.int32), nc)
+        po = dentist_amd.default_process_opts()
+        got, gd, gu = dentist_amd.collect_filter(las, coff, roff, po, repeat_mask=(ptr, iv))
+        exp, ed, eu = cf.collect_filter(las, coff, roff, repeat_mask=(ptr, iv))
+        assert np.array_equal(got["flags"], exp["flags"]) and np.array_equal(gd, ed) and np.array_equal(gu, eu)
+        assert (got["flags"] & 0x20 == 0).sum() > 0
+        total += ed
+    assert all(d > 0 for d in total), total     # every stage is exercised
+
+
+def test_planted_scenario():
+    """One contig pair; reads: a clean spanning read, a low-quality one, an improper one, one anchored
+    only in a repeat, one contained alignment, an ambiguous read and a redundant one."""
+    coff, roff = [0, 10000, 20000], [0] + [6000 * (i + 1) for i in range(7)]
+    las = np.stack([
+        la(0, 0, 7000, 10000, 0, 3000, diffs=300), la(1, 0, 0, 2900, 3100, 6000, diffs=300),     # spanning read 0: kept
+        la(0, 1, 7000, 10000, 0, 3000, diffs=1200),                                               # LQ (40 %)
+        la(0, 2, 3000, 5000, 2000, 4000, diffs=100),                                              # improper
+        la(0, 3, 9400, 10000, 0, 600, diffs=50),                                                  # weakly anchored (repeat)
+        la(0, 4, 6000, 10000, 0, 4000, diffs=300), la(0, 4, 6050, 10000, 50, 4000, diffs=290),    # second is contained
+        la(0, 5, 7000, 10000, 0, 3000, diffs=300), la(1, 5, 0, 4000, 2000, 6000, diffs=300),      # overlap on the read: ambiguous
+        la(0, 6, 1000, 7000, 0, 6000, diffs=500),                                                 # fits inside contig 0: redundant
+    ])
+    ptr, iv = np.asarray([0, 1, 1], dtype=np.int64), np.asarray([9300, 10000], dtype=np.int32)
+    po = dentist_amd.default_process_opts()
+    out, dropped, used = dentist_amd.collect_filter(las, coff, roff, po, repeat_mask=(ptr, iv))
+    assert dropped.tolist() == [1, 1, 1, 1, 2, 1]
+    assert (out["flags"] & 0x20 == 0).tolist() == [True, True, False, False, False, True, False, False, False, False]
+    assert used.tolist() == [1, 1, 1, 1, 1, 0, 0]
+    exp, ed, eu = cf.collect_filter(las, np.asarray(coff), np.asarray(roff), repeat_mask=(ptr, iv))
+    assert np.array_equal(out["flags"], exp["flags"]) and np.array_equal(dropped, ed) and np.array_equal(used, eu)
