@@ -595,7 +595,7 @@ static int build_index(dh_db *A, int32_t k, int32_t sepv, int32_t kmer_mod)
         }
     }
     goff[(size_t)A->n] = g;
-    if (g >= (1ll << 40)) return fail(DH_EINVAL, "index: virtual coordinate space exceeds 2^40");
+    if (g >= (1ll << 39)) return fail(DH_EINVAL, "index: virtual coordinate space exceeds 2^39");
     if (A->n >= (1 << 24)) return fail(DH_EINVAL, "index: more than 2^24 sequences");
     const int32_t keybits = 2 * k + ceil_log2((uint64_t)A->ngroups);
     if (keybits > 62) return fail(DH_EINVAL, "index: k-mer key does not fit 62 bits");
@@ -988,7 +988,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         int32_t *nlabase = (int32_t *)d_nla - item0, *ntrbase = (int32_t *)d_ntr - item0;
         HIPCHK(hipEventRecord(ctx->ev[2], st));
         HIPCHK(hipMemsetAsync(d_queue, 0, 4 * sizeof(uint32_t), st));
-        dhk_seed(st, cap, bv, cc.rc, iv, dopt, (int32_t)item0, ni, candbase, ncandbase, nhitsbase, d_status,
+        dhk_seed(st, cap, bv, iv, dopt, (int32_t)item0, ni, candbase, ncandbase, nhitsbase, d_status,
                  d_queue + 1, ctx->ncu);
         HIPCHK(hipGetLastError());
         {
@@ -1001,10 +1001,10 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             HIPCHK(hipStreamSynchronize(st));
             std::vector<int32_t> big;
             int32_t gcap = 0;
-            for (int32_t it = 0; it < ni; it++)
+            for (int32_t it = 0; it + 1 < ni; it += 2)  // a read overflows with both of its strands
                 if (h_ncand[(size_t)it] == -1) {
-                    big.push_back((int32_t)item0 + it);
-                    gcap = std::max(gcap, h_nhits[(size_t)it]);
+                    big.push_back((int32_t)((item0 + it) >> 1));
+                    gcap = std::max(gcap, h_nhits[(size_t)it] + h_nhits[(size_t)it + 1]);
                 }
             if (big.size() > (size_t)ni / 50 + 8 && cap < 16384) {
                 cap *= 2;  // many items overflow the LDS buffer: the next size is cheaper than HBM staging
@@ -1024,7 +1024,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
                 for (size_t b0 = 0; b0 < big.size(); b0 += per_launch) {
                     const int32_t cnt = (int32_t)std::min(per_launch, big.size() - b0);
                     HIPCHK(hipMemsetAsync(d_queue + 2, 0, sizeof(uint32_t), st));
-                    dhk_seed_big(st, bv, cc.rc, iv, dopt, d_list + b0, cnt, d_gbuf, pow2, candbase, ncandbase,
+                    dhk_seed_big(st, bv, iv, dopt, d_list + b0, cnt, d_gbuf, pow2, candbase, ncandbase,
                                  nhitsbase, d_status, d_queue + 2, ctx->ncu);
                     HIPCHK(hipGetLastError());
                 }
@@ -1032,7 +1032,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
                 HIPCHK(hipStreamSynchronize(st));
                 if (status & DH_ST_HIT_OVERFLOW)
                     return fail(DH_EOVERFLOW, "seed filter: capacity exceeded in the HBM-staged pass");
-                stats.big_items += (int64_t)big.size();
+                stats.big_items += 2 * (int64_t)big.size();
             }
         }
         HIPCHK(hipEventRecord(ctx->ev[3], st));

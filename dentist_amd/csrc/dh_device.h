@@ -28,7 +28,7 @@ struct DbView {
 
 struct IndexView {
     const uint32_t *dir;   // dir[b] = end of bucket b (start = dir[b-1])
-    const ulonglong2 *ent;  // x = group * 4^k + kmer (sorted inside every bucket), y = aseq << 40 | virtual position
+    const ulonglong2 *ent;  // x = group * 4^k + canonical k-mer, bit 63: the k-mer of A is its reverse complement; y = aseq << 40 | virtual position
     const int64_t *goff;   // virtual offset of every A sequence
     int64_t n;
     int32_t na, sepv, shift, pbits;
@@ -67,11 +67,11 @@ void dhk_revcomp(hipStream_t st, const uint8_t *src, uint8_t *dst, const int64_t
 void dhk_kmer_pass(hipStream_t st, int fill, DbView A, const int2 *tiles, int32_t ntiles, int32_t k,
                    int32_t kmer_mod, int32_t shift, uint32_t *dir, ulonglong2 *ent, const int64_t *goff);
 void dhk_scan(hipStream_t st, uint32_t *v, int64_t n, uint32_t *sums);
-void dhk_seed(hipStream_t st, int cap, DbView B, const uint8_t *brc, IndexView ix, DhOpts o,
+void dhk_seed(hipStream_t st, int cap, DbView B, IndexView ix, DhOpts o,
               int32_t item0, int32_t nitems, DhCand *cand, int32_t *ncand, int32_t *nhits,
               int32_t *status, uint32_t *queue, int32_t ncu);
-void dhk_seed_big(hipStream_t st, DbView B, const uint8_t *brc, IndexView ix, DhOpts o,
-                  const int32_t *item_list, int32_t nitems, uint64_t *gbuf, int32_t gcap, DhCand *cand,
+void dhk_seed_big(hipStream_t st, DbView B, IndexView ix, DhOpts o,
+                  const int32_t *read_list, int32_t nreads, uint64_t *gbuf, int32_t gcap, DhCand *cand,
                   int32_t *ncand, int32_t *nhits, int32_t *status, uint32_t *queue, int32_t ncu);
 void dhk_wave(hipStream_t st, int32_t nslots, DbView A, DbView B, const uint8_t *brc, const uint8_t *apk,
               const uint8_t *bpk, const uint8_t *brcpk, DhOpts o,

@@ -20,8 +20,10 @@
 
 #define LANES 64
 
-// modimer sampling (daligner -%): the same k-mers are kept on the A and on the B side.
-// Keep a k-mer iff h % mod == 0 with h = bits 32..63 of kmer * 0x9E3779B97F4A7C15.  32-bit integer
+// modimer sampling (daligner -%): the same k-mers are kept on the A and on the B side, decided on the
+// CANONICAL k-mer (the smaller of a k-mer and its reverse complement, both rolled along), so that a
+// k-mer and its reverse complement are sampled together.
+// Keep a k-mer iff h % mod == 0 with h = bits 32..63 of canon * 0x9E3779B97F4A7C15.  32-bit integer
 // multiplies run at quarter rate on CDNA, and this test is evaluated for every base of every
 // read, so it is arranged to need three of them (two when k <= 16):
 //  * h = mulhi(lo, C_lo) + lo * C_hi + hi * C_lo   (lo / hi = halves of the k-mer);
@@ -155,27 +157,34 @@ k_kmer_pass(DbView A, const int2 *__restrict__ tiles, int32_t ntiles, int32_t k,
     const uint64_t mask = (1ull << (2 * k)) - 1;
     const int32_t p0 = tiles[t].y + threadIdx.x * (KM_TILE / 256);
     const KmerSampler smp = kmer_sampler(kmer_mod, k);
-    uint64_t km = 0;
+    uint64_t km = 0, rc = 0;
     int32_t valid = 0;
     const uint8_t *a = A.bases + o;
+    const int rcsh = 2 * (k - 1);
     for (int32_t x = 0; x < KM_TILE / 256 + k - 1; x++) {
         const int32_t p = p0 + x;
         if (p >= len) break;
         const uint8_t c = a[p];
         if (c < 4) {
             km = ((km << 2) | c) & mask;
+            rc = (rc >> 2) | ((uint64_t)(3 - c) << rcsh);
             valid++;
         } else {
             km = 0;
+            rc = 0;
             valid = 0;
         }
-        if (x >= k - 1 && valid >= k && kmer_sampled(km, smp) &&
+        // the index is keyed by the canonical k-mer; bit 63 of the stored key says that the k-mer of A
+        // is the reverse complement of its key (the lookup tells the strands apart with it)
+        const uint64_t canon = km < rc ? km : rc;
+        if (x >= k - 1 && valid >= k && kmer_sampled(canon, smp) &&
             !(A.mask_bits && mask_touch(A.mask_bits, o + p - k + 1, k))) {
-            const uint64_t key = (grp << (2 * k)) | km;
+            const uint64_t key = (grp << (2 * k)) | canon;
             const uint32_t b = (uint32_t)(key >> shift);
             if (FILL) {
                 const uint32_t slot = atomicAdd(&dir[b], 1u);
-                ent[slot] = make_ulonglong2(key, ((uint64_t)s << 40) | (uint64_t)(goff[s] + (p - k + 1)));
+                ent[slot] = make_ulonglong2(key | (km != canon ? 1ull << 63 : 0ull),
+                                            ((uint64_t)s << 40) | (uint64_t)(goff[s] + (p - k + 1)));
             } else
                 atomicAdd(&dir[b], 1u);
         }
@@ -289,24 +298,30 @@ __device__ unsigned long long g_seed_prof[8];
 #else
 #define SP(i)
 #endif
-// One (read, strand) item, processed by the whole block; `work` = index of the item in this
-// launch, `slab` = index of the block's HBM hit slab (LCAP == 0).
+// One READ (both strands), processed by the whole block; `work` = index of the read in this launch,
+// `slab` = index of the block's HBM hit slab (LCAP == 0).  The k-mers are rolled once over the forward
+// read together with their reverse complements; the index is keyed by canonical k-mers with the
+// orientation of the A k-mer in bit 63 of the key, so ONE lookup yields the hits of both strands:
+// equal orientations = the forward read matches A, opposite = its reverse complement does (at
+// position blen - k - q of the reverse-complemented read).  Hits carry the strand in their top bit,
+// the band filter therefore never mixes strands; candidates go to the items 2r (forward) and 2r + 1.
+#define HIT_DBITS 39
 template <int LCAP>
-__device__ void seed_item(const DbView &B, const uint8_t *__restrict__ brc, const IndexView &ix,
-                          const DhOpts &o, int32_t item0, int32_t work, int32_t slab,
+__device__ void seed_item(const DbView &B, const IndexView &ix,
+                          const DhOpts &o, int32_t read0, int32_t work, int32_t slab,
                           DhCand *__restrict__ cand_out, int32_t *__restrict__ ncand_out,
                           int32_t *__restrict__ nhits_out, int32_t *__restrict__ status,
-                          uint64_t *__restrict__ gbuf, int32_t gcap, const int32_t *__restrict__ item_list)
+                          uint64_t *__restrict__ gbuf, int32_t gcap, const int32_t *__restrict__ read_list)
 {
     __shared__ uint64_t lhits[LCAP > 0 ? LCAP : 1];
-    __shared__ DhCand cands[SEED_CCAP];
-    __shared__ int64_t cband[SEED_CCAP];
+    __shared__ DhCand cands[2 * SEED_CCAP];
+    __shared__ int64_t cband[2 * SEED_CCAP];
     __shared__ int32_t s_n, s_nc;
 
-    const int32_t item = LCAP > 0 ? item0 + work : item_list[work];
+    const int32_t r = LCAP > 0 ? read0 + work : read_list[work];
+    const int32_t item = 2 * r;
     uint64_t *hits = LCAP > 0 ? lhits : gbuf + (int64_t)slab * gcap;
     const int32_t CAP = LCAP > 0 ? LCAP : gcap;
-    const int32_t r = item >> 1, strand = item & 1;
     const int tid = threadIdx.x;
 #ifdef DH_SEED_PROF
     unsigned long long tp_ = wall_clock64();
@@ -316,20 +331,14 @@ __device__ void seed_item(const DbView &B, const uint8_t *__restrict__ brc, cons
         s_nc = 0;
     }
     __syncthreads();
-    if (!(o.strands & (1 << strand))) {
-        if (tid == 0) {
-            ncand_out[item] = 0;
-            nhits_out[item] = 0;
-        }
-        return;
-    }
     const int64_t bo = B.off[r];
     const int32_t blen = (int32_t)(B.off[r + 1] - bo);
-    const uint8_t *b = (strand ? brc : B.bases) + bo;
+    const uint8_t *b = B.bases + bo;
     const uint64_t grp = B.group ? (uint64_t)B.group[r] : 0ull;
     const int k = o.k;
     const uint64_t mask = (1ull << (2 * k)) - 1;
     const int32_t npos = blen - k + 1;
+    constexpr uint64_t ORI = 1ull << 63, PAL = 1ull << 62;
 
     // ---- k-mer lookups: thread t rolls over a contiguous chunk of positions.  Sampled k-mers are
     // queued in registers (SEED_QN per lane); when the queue of ANY lane of the wavefront is full
@@ -344,7 +353,7 @@ __device__ void seed_item(const DbView &B, const uint8_t *__restrict__ brc, cons
         const int32_t per = (npos + SEED_LOOKUP_THREADS - 1) / SEED_LOOKUP_THREADS;
         const int32_t q0 = tid * per, q1 = min(npos, q0 + per);
         const KmerSampler smp = kmer_sampler(o.kmer_mod, k);
-        uint64_t km = 0;
+        uint64_t km = 0, rc = 0;
         int32_t valid = 0;
         const int32_t pend = q0 < q1 ? q1 + k - 1 : q0;
         uint64_t qk[QN];
@@ -355,16 +364,18 @@ __device__ void seed_item(const DbView &B, const uint8_t *__restrict__ brc, cons
             qk[u] = 0;
             qq[u] = 0;
         }
-        auto emit = [&](uint64_t v, int32_t q) {
+        auto emit = [&](uint64_t v, int32_t q, int32_t strand) {
+            if (!(o.strands & (1 << strand))) return;
             const int32_t aseq = (int32_t)(v >> 40);
             if (o.skip_self == 1 && aseq == r) return;
             // symmetric: each unordered pair once; which read plays B alternates with the
             // parity of a + b, so every read is B for about half of its partners
             if (o.skip_self == 2 && (aseq == r || ((aseq < r) != (((aseq + r) & 1) == 0)))) return;
             const int64_t gv = (int64_t)(v & ((1ull << 40) - 1));
-            const int64_t D = gv + ix.sepv - q;
+            const int32_t qs = strand ? blen - k - q : q;  // position on the oriented read
+            const int64_t D = gv + ix.sepv - qs;
             const int32_t slot = atomicAdd(&s_n, 1);
-            if (slot < CAP) hits[slot] = ((uint64_t)D << HIT_QBITS) | (uint32_t)q;
+            if (slot < CAP) hits[slot] = ((uint64_t)strand << 63) | ((uint64_t)D << HIT_QBITS) | (uint32_t)qs;
         };
         auto flush = [&]() {
             uint32_t ss[QN], ee[QN];
@@ -372,7 +383,7 @@ __device__ void seed_item(const DbView &B, const uint8_t *__restrict__ brc, cons
             for (int u = 0; u < QN; u++) {
                 // (start, end) of the bucket = dir[bk - 1], dir[bk] in one 8-byte load (dir[-1] == 0)
                 uint64_t se = 0;
-                if (u < nq) se = load8((const uint8_t *)(ix.dir + (uint32_t)(qk[u] >> ix.shift)) - 4);
+                if (u < nq) se = load8((const uint8_t *)(ix.dir + (uint32_t)((qk[u] & ~(ORI | PAL)) >> ix.shift)) - 4);
                 ss[u] = (uint32_t)se;
                 ee[u] = (uint32_t)(se >> 32);
             }
@@ -383,24 +394,41 @@ __device__ void seed_item(const DbView &B, const uint8_t *__restrict__ brc, cons
 #pragma unroll
             for (int u = 0; u < QN; u++) {
                 if (ss[u] >= ee[u]) continue;
-                const uint64_t key = qk[u];
+                const uint64_t key = qk[u] & ~(ORI | PAL);
+                const uint64_t bori = qk[u] & ORI;
+                const bool pal = (qk[u] & PAL) != 0;
                 if (ee[u] - ss[u] == 1u) {
-                    if (e0[u].x == key && o.tcap >= 1) emit(e0[u].y, qq[u]);
+                    if ((e0[u].x & ~ORI) == key && o.tcap >= 1) {
+                        const bool same = (e0[u].x & ORI) == bori;
+                        if (same || pal) emit(e0[u].y, qq[u], 0);
+                        if (!same || pal) emit(e0[u].y, qq[u], 1);
+                    }
                     continue;
                 }
-                // count the entries of the bucket with this key first (-t cap) ...
-                int32_t run = 0;
-                for (uint32_t t = ss[u]; t < ee[u]; t++) run += ix.ent[t].x == key ? 1 : 0;
-                if (run == 0 || run > o.tcap) continue;
+                // count the entries of the bucket with this key first, per orientation (-t cap) ...
+                int32_t runf = 0, runr = 0;
+                for (uint32_t t = ss[u]; t < ee[u]; t++) {
+                    const uint64_t ex = ix.ent[t].x;
+                    if ((ex & ~ORI) != key) continue;
+                    const bool same = (ex & ORI) == bori;
+                    runf += (same || pal) ? 1 : 0;
+                    runr += (!same || pal) ? 1 : 0;
+                }
+                const bool dof = runf > 0 && runf <= o.tcap, dor = runr > 0 && runr <= o.tcap;
+                if (!dof && !dor) continue;
                 // ... then emit its hits
                 for (uint32_t t = ss[u]; t < ee[u]; t++) {
                     const ulonglong2 en = ix.ent[t];
-                    if (en.x == key) emit(en.y, qq[u]);
+                    if ((en.x & ~ORI) != key) continue;
+                    const bool same = (en.x & ORI) == bori;
+                    if (dof && (same || pal)) emit(en.y, qq[u], 0);
+                    if (dor && (!same || pal)) emit(en.y, qq[u], 1);
                 }
             }
             nq = 0;
         };
-        // warm-up: the first k - 1 bases of the chunk only fill the rolling k-mer
+        const int rcsh = 2 * (k - 1);
+        // warm-up: the first k - 1 bases of the chunk only fill the rolling k-mers
         uint64_t w = 0, wnext = q0 < pend ? load8(b + q0) : 0ull;
         for (int32_t t = 0; t < k - 1; t++) {
             const int32_t pp = q0 + t;
@@ -413,9 +441,11 @@ __device__ void seed_item(const DbView &B, const uint8_t *__restrict__ brc, cons
             if (pp < pend) {
                 if (c < 4) {
                     km = ((km << 2) | c) & mask;
+                    rc = (rc >> 2) | ((uint64_t)(3 - c) << rcsh);
                     valid++;
                 } else {
                     km = 0;
+                    rc = 0;
                     valid = 0;
                 }
             }
@@ -432,19 +462,18 @@ __device__ void seed_item(const DbView &B, const uint8_t *__restrict__ brc, cons
             if (pp < pend) {
                 if (c < 4) {
                     km = ((km << 2) | c) & mask;
+                    rc = (rc >> 2) | ((uint64_t)(3 - c) << rcsh);
                     valid++;
                 } else {
                     km = 0;
+                    rc = 0;
                     valid = 0;
                 }
-                bool em = valid >= k && kmer_sampled(km, smp);
-                // reverse strand: the k-mer at position q of the reverse complement covers the forward
-                // bases [blen - q - k, blen - q)
-                if (em && B.mask_bits &&
-                    mask_touch(B.mask_bits, bo + (strand ? blen - (pp - k + 1) - k : pp - k + 1), k))
-                    em = false;
+                const uint64_t canon = km < rc ? km : rc;
+                bool em = valid >= k && kmer_sampled(canon, smp);
+                if (em && B.mask_bits && mask_touch(B.mask_bits, bo + pp - k + 1, k)) em = false;
                 if (em) {
-                    const uint64_t key = (grp << (2 * k)) | km;
+                    const uint64_t key = ((grp << (2 * k)) | canon) | (km != canon ? ORI : 0ull) | (km == rc ? PAL : 0ull);
                     const int32_t q = pp - k + 1;
 #pragma unroll
                     for (int u = 0; u < QN; u++)
@@ -462,18 +491,19 @@ __device__ void seed_item(const DbView &B, const uint8_t *__restrict__ brc, cons
     __syncthreads();
     SP(0)
     int32_t n = s_n;
-    if (tid == 0) nhits_out[item] = n;
     if (n > CAP) {
-        // capacity exceeded: never silently truncated.  LDS variant: hand the item to the HBM
+        // capacity exceeded: never silently truncated.  LDS variant: hand the read to the HBM
         // variant (ncand = -1); HBM variant: report
         if (tid == 0) {
             if (LCAP == 0) atomicOr(status, DH_ST_HIT_OVERFLOW);
-            ncand_out[item] = LCAP > 0 ? -1 : 0;
+            ncand_out[item] = ncand_out[item + 1] = LCAP > 0 ? -1 : 0;
+            nhits_out[item] = n;  // what the HBM slab has to hold (both strands)
+            nhits_out[item + 1] = 0;
         }
         return;
     }
     if (n == 0) {
-        if (tid == 0) ncand_out[item] = 0;
+        if (tid == 0) ncand_out[item] = ncand_out[item + 1] = nhits_out[item] = nhits_out[item + 1] = 0;
         return;
     }
     // ---- bitonic sort of the padded hit buffer (keys are distinct)
@@ -506,6 +536,18 @@ __device__ void seed_item(const DbView &B, const uint8_t *__restrict__ brc, cons
         }
     }
     __syncthreads();
+    if (tid == 0) {  // hits per strand: the forward strand sorts first
+        int32_t lo = 0, hi = n;
+        while (lo < hi) {
+            const int32_t mid = (lo + hi) >> 1;
+            if (hits[mid] >> 63)
+                hi = mid;
+            else
+                lo = mid + 1;
+        }
+        nhits_out[item] = lo;
+        nhits_out[item + 1] = n - lo;
+    }
     SP(1)
     // ---- band pairs.  Small variants (FASTB): one block-wide inclusive scan over
     // (band-head flag << 18 | covered-base contribution) gives every band its coverage as a
@@ -523,7 +565,7 @@ __device__ void seed_item(const DbView &B, const uint8_t *__restrict__ brc, cons
     // seed of a band pair [i, e1): first hit of the same-diagonal run (steps <= k) covering most
     // bases; then the candidate record
     auto emit_cand = [&](int32_t slot, int32_t best_first, int32_t P, int64_t band) {
-        const int64_t D = hitD(hits[best_first]);
+        const int64_t D = hitD(hits[best_first]) & ((1ll << HIT_DBITS) - 1);  // without the strand bit
         const int32_t q = hitQ(hits[best_first]);
         const int64_t gv = D - ix.sepv + q;
         int32_t lo = 0, hi = ix.na;
@@ -605,7 +647,7 @@ __device__ void seed_item(const DbView &B, const uint8_t *__restrict__ brc, cons
             const int32_t P = cov0 + cov1, Pm1 = covm1 + cov0, Pp1 = cov1 + cov2;
             if (P < o.hmin || P < Pm1 || P <= Pp1) continue;
             const int32_t slot = atomicAdd(&s_nc, 1);
-            if (slot >= SEED_CCAP) continue;
+            if (slot >= 2 * SEED_CCAP) continue;
             if (e1 - i > 64) {
                 // long range: the whole block picks the seed below
                 const int32_t bslot = atomicAdd(&s_nbig, 1);
@@ -655,46 +697,54 @@ __device__ void seed_item(const DbView &B, const uint8_t *__restrict__ brc, cons
             const int32_t P = cov0 + cov1, Pm1 = covm1 + cov0, Pp1 = cov1 + cov2;
             if (P < o.hmin || P < Pm1 || P <= Pp1) continue;
             const int32_t slot = atomicAdd(&s_nc, 1);
-            if (slot < SEED_CCAP) emit_cand(slot, serial_seed(i, e1), P, band);
+            if (slot < 2 * SEED_CCAP) emit_cand(slot, serial_seed(i, e1), P, band);
         }
     }
     __syncthreads();
     SP(3)
     int32_t nc = s_nc;
-    if (nc > SEED_CCAP) {
+    if (nc > 2 * SEED_CCAP) {
         // more candidate band pairs than one read can sensibly have (a repeat the -t cap did not
-        // catch): the item yields no alignments and is reported (ncand = -2), the launch goes on
-        if (tid == 0) ncand_out[item] = -2;
+        // catch): the read yields no alignments and is reported (ncand = -2), the launch goes on
+        if (tid == 0) ncand_out[item] = ncand_out[item + 1] = -2;
         return;
     }
-    // ---- rank by (score desc, band asc); bands are distinct so ranks are a permutation.  Symmetric
-    // all-vs-all: the kept candidates (rank < max_cand) are then grouped by A read, rank order inside
-    // a group -- groups are the only candidates that depend on each other (coverage skip), which
-    // makes each of them a separate work unit of the wave kernel (k_units).
-    __shared__ int32_t crank[SEED_CCAP];
+    // ---- rank per strand by (score desc, band asc); bands are distinct so ranks are a permutation
+    // (the strand is the top bit of the band).  Symmetric all-vs-all: the kept candidates
+    // (rank < max_cand) are then grouped by A read, rank order inside a group -- groups are the only
+    // candidates that depend on each other (coverage skip), which makes each of them a separate work
+    // unit of the wave kernel (k_units).
+    __shared__ int32_t crank[2 * SEED_CCAP];
+    __shared__ int32_t s_ncs[2];
+    constexpr int BSTR = HIT_DBITS;  // strand bit of a band = bit HIT_DBITS - band_shift
+    auto strand_of = [&](int32_t c) { return (int32_t)((cband[c] >> (BSTR - bs)) & 1); };
+    if (tid < 2) s_ncs[tid] = 0;
+    __syncthreads();
     for (int32_t c = tid; c < nc; c += SEED_THREADS) {
+        const int32_t st = strand_of(c);
         int32_t rank = 0;
         for (int32_t x = 0; x < nc; x++)
-            if (cands[x].score > cands[c].score ||
-                (cands[x].score == cands[c].score && cband[x] < cband[c]))
+            if (strand_of(x) == st && (cands[x].score > cands[c].score ||
+                                       (cands[x].score == cands[c].score && cband[x] < cband[c])))
                 rank++;
         crank[c] = rank;
+        atomicAdd(&s_ncs[st], 1);
     }
     __syncthreads();
     for (int32_t c = tid; c < nc; c += SEED_THREADS) {
-        const int32_t rank = crank[c];
+        const int32_t rank = crank[c], st = strand_of(c);
         if (rank >= o.max_cand) continue;
         int32_t pos = rank;
         if (o.skip_self == 2) {
             pos = 0;
             for (int32_t x = 0; x < nc; x++)
-                if (crank[x] < o.max_cand &&
+                if (strand_of(x) == st && crank[x] < o.max_cand &&
                     (cands[x].aseq < cands[c].aseq || (cands[x].aseq == cands[c].aseq && crank[x] < rank)))
                     pos++;
         }
-        cand_out[(int64_t)item * o.max_cand + pos] = cands[c];
+        cand_out[(int64_t)(item + st) * o.max_cand + pos] = cands[c];
     }
-    if (tid == 0) ncand_out[item] = nc < o.max_cand ? nc : o.max_cand;
+    if (tid < 2) ncand_out[item + tid] = s_ncs[tid] < o.max_cand ? s_ncs[tid] : o.max_cand;
     SP(4)
 #ifdef DH_SEED_PROF
     if (tid == 0) atomicAdd(&g_seed_prof[7], 1ull);
@@ -704,24 +754,24 @@ __device__ void seed_item(const DbView &B, const uint8_t *__restrict__ brc, cons
 // items from an atomic queue (no per-item block launch, dynamic balance over ragged read lengths).
 template <int LCAP>
 __global__ void __launch_bounds__(SEED_THREADS, (LCAP > 0 && LCAP <= 2048) ? 8 : (LCAP == 16384 ? 2 : 4))
-k_seed(DbView B, const uint8_t *__restrict__ brc, IndexView ix, DhOpts o, int32_t item0,
-       int32_t nitems, DhCand *__restrict__ cand_out, int32_t *__restrict__ ncand_out,
+k_seed(DbView B, IndexView ix, DhOpts o, int32_t read0,
+       int32_t nreads, DhCand *__restrict__ cand_out, int32_t *__restrict__ ncand_out,
        int32_t *__restrict__ nhits_out, int32_t *__restrict__ status, uint64_t *__restrict__ gbuf,
-       int32_t gcap, const int32_t *__restrict__ item_list, uint32_t *__restrict__ queue)
+       int32_t gcap, const int32_t *__restrict__ read_list, uint32_t *__restrict__ queue)
 {
     __shared__ int32_t s_work;
     for (;;) {
-        __syncthreads();  // the previous item is finished by every thread (shared state is reused)
+        __syncthreads();  // the previous read is finished by every thread (shared state is reused)
         if (threadIdx.x == 0) s_work = (int32_t)atomicAdd(queue, 1u);
         __syncthreads();
         const int32_t work = s_work;
-        if (work >= nitems) break;
-        seed_item<LCAP>(B, brc, ix, o, item0, work, (int32_t)blockIdx.x, cand_out, ncand_out, nhits_out,
-                        status, gbuf, gcap, item_list);
+        if (work >= nreads) break;
+        seed_item<LCAP>(B, ix, o, read0, work, (int32_t)blockIdx.x, cand_out, ncand_out, nhits_out,
+                        status, gbuf, gcap, read_list);
     }
 }
 #define SEED_INST(C)                                                                              \
-    template __global__ void k_seed<C>(DbView, const uint8_t *, IndexView, DhOpts, int32_t, int32_t,  \
+    template __global__ void k_seed<C>(DbView, IndexView, DhOpts, int32_t, int32_t,  \
                                        DhCand *, int32_t *, int32_t *, int32_t *, uint64_t *, int32_t, \
                                        const int32_t *, uint32_t *);
 SEED_INST(1024)
@@ -2260,14 +2310,16 @@ void dhk_scan(hipStream_t st, uint32_t *v, int64_t n, uint32_t *sums)
 }
 
 // queue: one zeroed uint32 (work counter of the persistent blocks)
-void dhk_seed(hipStream_t st, int cap, DbView B, const uint8_t *brc, IndexView ix, DhOpts o,
+// item0 / nitems: even (both strands of the reads [item0 / 2, (item0 + nitems) / 2))
+void dhk_seed(hipStream_t st, int cap, DbView B, IndexView ix, DhOpts o,
               int32_t item0, int32_t nitems, DhCand *cand, int32_t *ncand, int32_t *nhits,
               int32_t *status, uint32_t *queue, int32_t ncu)
 {
     if (nitems <= 0) return;
+    const int32_t read0 = item0 / 2, nreads = nitems / 2;
 #define SEED_LAUNCH(C)                                                                            \
-    hipLaunchKernelGGL(k_seed<C>, dim3(seed_grid<C>(nitems, ncu)), dim3(SEED_THREADS), 0, st, B, brc, ix, o, \
-                       item0, nitems, cand, ncand, nhits, status, (uint64_t *)nullptr, 0,         \
+    hipLaunchKernelGGL(k_seed<C>, dim3(seed_grid<C>(nreads, ncu)), dim3(SEED_THREADS), 0, st, B, ix, o, \
+                       read0, nreads, cand, ncand, nhits, status, (uint64_t *)nullptr, 0,         \
                        (const int32_t *)nullptr, queue)
     if (cap <= 1024)
         SEED_LAUNCH(1024);
@@ -2294,13 +2346,13 @@ void dhk_seed_prof_dump()
 #endif
 // the items listed in item_list (absolute ids) with their hits staged in HBM: block x owns the
 // slab gbuf[x * gcap ..]; nslabs bounds the grid
-void dhk_seed_big(hipStream_t st, DbView B, const uint8_t *brc, IndexView ix, DhOpts o,
-                  const int32_t *item_list, int32_t nitems, uint64_t *gbuf, int32_t gcap, DhCand *cand,
+void dhk_seed_big(hipStream_t st, DbView B, IndexView ix, DhOpts o,
+                  const int32_t *read_list, int32_t nreads, uint64_t *gbuf, int32_t gcap, DhCand *cand,
                   int32_t *ncand, int32_t *nhits, int32_t *status, uint32_t *queue, int32_t ncu)
 {
-    if (nitems <= 0) return;
-    hipLaunchKernelGGL(k_seed<0>, dim3(seed_grid<0>(nitems, ncu)), dim3(SEED_THREADS), 0, st, B, brc, ix, o, 0,
-                       nitems, cand, ncand, nhits, status, gbuf, gcap, item_list, queue);
+    if (nreads <= 0) return;
+    hipLaunchKernelGGL(k_seed<0>, dim3(seed_grid<0>(nreads, ncu)), dim3(SEED_THREADS), 0, st, B, ix, o, 0,
+                       nreads, cand, ncand, nhits, status, gbuf, gcap, read_list, queue);
 }
 
 // apk / bpk / brcpk: 2-bit packed copies (all three or none)

@@ -129,10 +129,23 @@ static inline int kmer_masked(const oz_db *db, int32_t s, int64_t p, int k, int6
 }
 
 
-/* modimer sampling: the same k-mers are kept on the A and on the B side */
-static inline int kmer_sampled(uint64_t km, int32_t mod)
+/* modimer sampling: the same k-mers are kept on the A and on the B side.  The decision is taken on
+ * the CANONICAL k-mer (the smaller of the k-mer and its reverse complement), so a k-mer and its
+ * reverse complement are sampled together: one pass over a read then serves both strands. */
+static inline uint64_t kmer_rc(uint64_t km, int k)
 {
-    return mod <= 1 || (uint32_t)((km * 0x9E3779B97F4A7C15ull) >> 32) % (uint32_t)mod == 0;
+    uint64_t r = 0;
+    for (int i = 0; i < k; i++) {
+        r = (r << 2) | (3 - (km & 3));
+        km >>= 2;
+    }
+    return r;
+}
+static inline int kmer_sampled_k(uint64_t km, int32_t mod, int k)
+{
+    if (mod <= 1) return 1;
+    const uint64_t rc = kmer_rc(km, k), c = km < rc ? km : rc;
+    return (uint32_t)((c * 0x9E3779B97F4A7C15ull) >> 32) % (uint32_t)mod == 0;
 }
 
 
@@ -203,7 +216,7 @@ static oz_index *index_build(const oz_db *A, const oz_opts *o, int32_t max_blen)
                 valid = 0;
                 km = 0;
             }
-            if (valid >= k && kmer_sampled(km, o->kmer_mod) && !kmer_masked(A, s, p - k + 1, k, &mcur)) {
+            if (valid >= k && kmer_sampled_k(km, o->kmer_mod, k) && !kmer_masked(A, s, p - k + 1, k, &mcur)) {
                 ix->e[n].key = (grp << (2 * k)) | km;
                 ix->e[n].aseq = s;
                 ix->e[n].apos = (int32_t)(p - k + 1);
@@ -332,7 +345,7 @@ static int seed_candidates(const oz_index *ix, const uint8_t *b, int32_t blen, i
             valid = 0;
             km = 0;
         }
-        if (valid < k || !kmer_sampled(km, o->kmer_mod)) continue;
+        if (valid < k || !kmer_sampled_k(km, o->kmer_mod, k)) continue;
         const int32_t q = p - k + 1;
         if (bmask) {
             while (bcur < nbmask && bmask[2 * bcur + 1] <= q) bcur++;
