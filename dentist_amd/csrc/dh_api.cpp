@@ -950,10 +950,12 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     HIPCHK(hipMemsetAsync(d_status, 0, sizeof(int32_t), st));
     HIPCHK(hipMemsetAsync(d_counters, 0, 2 * sizeof(unsigned long long), st));
 
-    // expected hits per (read, strand): random matches + true seeds; pick the LDS hit capacity
+    // expected hits per read (both strands share the LDS buffer): random matches + true seeds (measured
+    // 0.075 per sampled k-mer for 15 % error reads at k = 20; reads that need more are redone with their
+    // hits in HBM, and a chunk with many of them restarts with the next capacity); pick the LDS hit capacity
     // (ix.n = indexed k-mers; a sampled k-mer of B meets ix.n / (4^k / kmer_mod) of them by chance)
     const double dens = (double)A->ix.n * std::max(1, o.kmer_mod) / std::pow(4.0, o.k) / std::max(1, A->ngroups);
-    const double exp_hits = (double)B->max_len / std::max(1, o.kmer_mod) * (dens + 0.2);
+    const double exp_hits = (double)B->max_len / std::max(1, o.kmer_mod) * (2.0 * dens + 0.1);
     int cap = 1024;
     while (cap < 16384 && exp_hits * 1.5 >= cap) cap *= 2;
     if (A == B) {
@@ -967,10 +969,17 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
 
     std::vector<int32_t> h_ncand((size_t)cn), h_nhits((size_t)cn);
     float ms_seed = 0, ms_wave = 0, ms_gather = 0;
+    double w_g[6] = {0, 0, 0, 0, 0, 0};  // host wall of the chunk loop's phases (DH_TRACE)
 
     const int64_t item_first = 2ll * first, item_end = item_first + nitems_total;
     for (int64_t item0 = item_first; item0 < item_end; item0 += cn) {
         const int32_t ni = (int32_t)std::min<int64_t>(cn, item_end - item0);
+        double w_c = now_ms();
+        auto lap = [&](int i) {
+            const double t = now_ms();
+            w_g[i] += t - w_c;
+            w_c = t;
+        };
         ChunkCopies cc;
         if (db_copies) {
             cc.rc = B->d_rc;
@@ -986,6 +995,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         uint16_t *trbase = d_trslots - item0 * (int64_t)o.max_la * trmax;
         int32_t *ncandbase = d_ncand - item0, *nhitsbase = d_nhits - item0;
         int32_t *nlabase = (int32_t *)d_nla - item0, *ntrbase = (int32_t *)d_ntr - item0;
+        lap(0);
         HIPCHK(hipEventRecord(ctx->ev[2], st));
         HIPCHK(hipMemsetAsync(d_queue, 0, 4 * sizeof(uint32_t), st));
         dhk_seed(st, cap, bv, iv, dopt, (int32_t)item0, ni, candbase, ncandbase, nhitsbase, d_status,
@@ -1035,6 +1045,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
                 stats.big_items += 2 * (int64_t)big.size();
             }
         }
+        lap(1);
         HIPCHK(hipEventRecord(ctx->ev[3], st));
         HIPCHK(hipMemsetAsync(d_queue, 0, sizeof(uint32_t), st));
         // symmetric mode claims slots with atomics: every counter starts at zero
@@ -1077,6 +1088,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         HIPCHK(hipMemcpyAsync(h_ncand.data(), d_ncand, sizeof(int32_t) * (size_t)ni, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(h_nhits.data(), d_nhits, sizeof(int32_t) * (size_t)ni, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        lap(2);
         if (status & DH_ST_POOL_OVERFLOW)
             return fail(DH_EOVERFLOW, "wave: trace-tree pool or boundary capacity exceeded");
         for (int32_t it = 0; it < ni; it++) {
@@ -1096,6 +1108,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
                     res->ovf_reads.push_back((int32_t)((item0 + it) >> 1));
                 }
         }
+        lap(3);
         if (totals[0] > 0) {
             SCR(13, d_laout, totals[0])
             SCR(14, d_trout, totals[1])
@@ -1103,8 +1116,16 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             dhk_compact(st, d_la, d_trslots, trmax, o.max_la, o.skip_self == 2 ? 1 : 0, ni, d_nla, d_ntr, (int64_t)t0,
                         d_laout, d_trout);
             HIPCHK(hipGetLastError());
+            if (l0 == 0 && ni < nitems_total) {
+                // first of several chunks: reserve for the whole call (this chunk's yield + 15 %) so that
+                // the result never moves while it grows
+                const double f = 1.15 * (double)nitems_total / ni;
+                res->la.reserve((size_t)(f * totals[0]) + 1024);
+                res->trace.reserve((size_t)(f * totals[1]) + 65536);
+            }
             res->la.resize(l0 + totals[0]);
             res->trace.resize(t0 + totals[1]);
+            lap(4);
             HIPCHK(hipMemcpyAsync(res->la.data() + l0, d_laout, sizeof(dh_la) * (size_t)totals[0],
                                   hipMemcpyDeviceToHost, st));
             if (totals[1] > 0)
@@ -1114,6 +1135,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         }
         HIPCHK(hipEventRecord(ctx->ev[5], st));
         HIPCHK(hipStreamSynchronize(st));
+        lap(5);
         float t;
         HIPCHK(hipEventElapsedTime(&t, ctx->ev[2], ctx->ev[3]));
         ms_seed += t;
@@ -1163,13 +1185,14 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     if (getenv("DH_TRACE"))
         fprintf(stderr,
                 "[dh_align_db] A=%d seqs/%lld bp B=%d seqs/%lld bp hits=%lld cands=%lld aln=%lld las=%lld cells=%lld | "
-                "index %.2f seed %.2f wave %.2f gather %.2f ms, wall %.2f ms (host: index %.2f loop %.2f post %.2f)\n",
+                "index %.2f seed %.2f wave %.2f gather %.2f ms, wall %.2f ms (host: index %.2f loop %.2f post %.2f; "
+                "loop: copies %.2f seed %.2f wave %.2f stats %.2f resize %.2f d2h %.2f)\n",
                 A->n, (long long)A->total, B->n, (long long)B->total, (long long)stats.hits, (long long)stats.cands,
                 (long long)stats.alignments, (long long)stats.las, (long long)stats.wave_cells, stats.ms_index,
                 stats.ms_seed, stats.ms_wave, stats.ms_gather,
                 ((double)std::chrono::duration_cast<std::chrono::microseconds>(
                      std::chrono::steady_clock::now().time_since_epoch()).count() - wall0) / 1e3,
-                w_index, w_loop, w_post);
+                w_index, w_loop, w_post, w_g[0], w_g[1], w_g[2], w_g[3], w_g[4], w_g[5]);
     guard.ok = true;
     *out = res;
     return DH_OK;

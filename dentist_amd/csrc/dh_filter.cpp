@@ -12,6 +12,7 @@
 // get DH_FLAG_DISABLED (the reference removes the alignments of ambiguous reads from the array; the
 // effect on every later stage is the same).  Per-alignment predicates run on the host thread pool.
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -35,43 +36,51 @@ extern "C" int dh_collect_filter(dh_la *las, int64_t n, const int64_t *contig_of
                                  const dh_process_opts *opts, int64_t *dropped6, uint8_t *read_used)
 {
     if ((n > 0 && !las) || !contig_off || !read_off || !opts || n < 0) return dh_fail(DH_EINVAL, "dh_collect_filter: bad argument");
-    for (int64_t i = 0; i < n; i++)
-        if (las[i].aread < 0 || las[i].aread >= ncontigs || las[i].bread < 0 || las[i].bread >= nreads)
-            return dh_fail(DH_EINVAL, "dh_collect_filter: id out of range");
+    {
+        std::atomic<int> bad{0};
+        dh_parallel_for(n, 16384, [&](int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; i++)
+                if (las[i].aread < 0 || las[i].aread >= ncontigs || las[i].bread < 0 || las[i].bread >= nreads) bad = 1;
+        });
+        if (bad) return dh_fail(DH_EINVAL, "dh_collect_filter: id out of range");
+    }
     const dh_process_opts &o = *opts;
     const Ctx c{contig_off, read_off};
     int64_t cnt[6] = {0, 0, 0, 0, 0, 0};
-    auto count_disabled = [&] {
-        int64_t d = 0;
-        for (int64_t i = 0; i < n; i++) d += (las[i].flags & DH_FLAG_DISABLED) ? 1 : 0;
-        return d;
-    };
-    int64_t before = count_disabled();
-    auto stage_done = [&](int s) {
-        const int64_t now = count_disabled();
-        cnt[s] = now - before;
-        before = now;
-    };
+    // alignments disabled by the running stage (summed over the host threads)
+    std::atomic<int64_t> newly{0};
+    auto stage_done = [&](int s) { cnt[s] = newly.exchange(0); };
     // 1-3: per-alignment predicates
     dh_parallel_for(n, 4096, [&](int64_t lo, int64_t hi) {
+        int64_t local = 0;
         for (int64_t i = lo; i < hi; i++) {
             dh_la &l = las[i];
             if (l.flags & DH_FLAG_DISABLED) continue;
-            if ((int64_t)l.diffs * 1000000 > (int64_t)o.max_align_err_ppm * (l.aepos - l.abpos)) l.flags |= DH_FLAG_DISABLED;
+            if ((int64_t)l.diffs * 1000000 > (int64_t)o.max_align_err_ppm * (l.aepos - l.abpos)) {
+                l.flags |= DH_FLAG_DISABLED;
+                local++;
+            }
         }
+        newly += local;
     });
     stage_done(0);
     dh_parallel_for(n, 4096, [&](int64_t lo, int64_t hi) {
+        int64_t local = 0;
         for (int64_t i = lo; i < hi; i++) {
             dh_la &l = las[i];
             if (l.flags & DH_FLAG_DISABLED) continue;
             const bool begins = l.abpos <= o.allowance || l.bbpos <= o.allowance;
             const bool ends = l.aepos + o.allowance >= c.alen(l) || l.bepos + o.allowance >= c.blen(l);
-            if (!(begins && ends)) l.flags |= DH_FLAG_DISABLED;
+            if (!(begins && ends)) {
+                l.flags |= DH_FLAG_DISABLED;
+                local++;
+            }
         }
+        newly += local;
     });
     stage_done(1);
     dh_parallel_for(n, 4096, [&](int64_t lo, int64_t hi) {
+        int64_t local = 0;
         for (int64_t i = lo; i < hi; i++) {
             dh_la &l = las[i];
             if (l.flags & DH_FLAG_DISABLED) continue;
@@ -81,20 +90,33 @@ extern "C" int dh_collect_filter(dh_la *las, int64_t n, const int64_t *contig_of
                     const int32_t b = std::max(rep_iv[2 * j], l.abpos), e = std::min(rep_iv[2 * j + 1], l.aepos);
                     if (e > b) unmasked -= e - b;
                 }
-            if (unmasked <= o.min_anchor) l.flags |= DH_FLAG_DISABLED;
+            if (unmasked <= o.min_anchor) {
+                l.flags |= DH_FLAG_DISABLED;
+                local++;
+            }
         }
+        newly += local;
     });
     stage_done(2);
     // 4: contained (AlignmentChain.opCmp order, base.d:766-777; stable).  Alignments of different
     // contigs never interact, so the contigs are sorted and scanned independently on the host threads.
     std::vector<int64_t> ord((size_t)n);
+    // the two ids of every alignment as dense arrays: the counting sorts below are serial passes
+    std::vector<int32_t> ka((size_t)n), kb((size_t)n);
+    dh_parallel_for(n, 16384, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; i++) {
+            ka[(size_t)i] = las[i].aread;
+            kb[(size_t)i] = las[i].bread;
+        }
+    });
     {
         std::vector<int64_t> cfirst((size_t)ncontigs + 1, 0);
-        for (int64_t i = 0; i < n; i++) cfirst[(size_t)las[i].aread + 1]++;
+        for (int64_t i = 0; i < n; i++) cfirst[(size_t)ka[(size_t)i] + 1]++;
         for (int32_t a = 0; a < ncontigs; a++) cfirst[(size_t)a + 1] += cfirst[(size_t)a];
         std::vector<int64_t> cur(cfirst.begin(), cfirst.end() - 1);
-        for (int64_t i = 0; i < n; i++) ord[(size_t)cur[(size_t)las[i].aread]++] = i;  // stable by input order
+        for (int64_t i = 0; i < n; i++) ord[(size_t)cur[(size_t)ka[(size_t)i]]++] = i;  // stable by input order
         dh_parallel_for(ncontigs, 8, [&](int64_t clo, int64_t chi) {
+            int64_t local = 0;
             for (int64_t a = clo; a < chi; a++) {
                 const auto ob = ord.begin() + cfirst[(size_t)a], oe = ord.begin() + cfirst[(size_t)a + 1];
                 std::stable_sort(ob, oe, [&](int64_t x, int64_t y) {
@@ -112,25 +134,30 @@ extern "C" int dh_collect_filter(dh_la *las, int64_t n, const int64_t *contig_of
                         dh_la &a2 = las[*y];
                         if (!(a1.abpos <= a2.abpos && a2.aepos <= a1.aepos)) break;  // sliceUntil
                         if ((a2.flags & DH_FLAG_COMP) == (a1.flags & DH_FLAG_COMP) && a2.bread == a1.bread &&
-                            c.bfwd_begin(a1) <= c.bfwd_begin(a2) && c.bfwd_end(a2) <= c.bfwd_end(a1))
+                            c.bfwd_begin(a1) <= c.bfwd_begin(a2) && c.bfwd_end(a2) <= c.bfwd_end(a1) &&
+                            !(a2.flags & DH_FLAG_DISABLED)) {
                             a2.flags |= DH_FLAG_DISABLED;
+                            local++;
+                        }
                     }
                 }
             }
+            newly += local;
         });
     }
     stage_done(3);
     // group by read for 5 and 6
     std::vector<int64_t> first((size_t)nreads + 1, 0), byread((size_t)n);
-    for (int64_t i = 0; i < n; i++) first[(size_t)las[i].bread + 1]++;
+    for (int64_t i = 0; i < n; i++) first[(size_t)kb[(size_t)i] + 1]++;
     for (int32_t r = 0; r < nreads; r++) first[(size_t)r + 1] += first[(size_t)r];
     {
         std::vector<int64_t> cur(first.begin(), first.end() - 1);
-        for (int64_t i = 0; i < n; i++) byread[(size_t)cur[(size_t)las[i].bread]++] = i;
+        for (int64_t i = 0; i < n; i++) byread[(size_t)cur[(size_t)kb[(size_t)i]]++] = i;
     }
     std::vector<uint8_t> used((size_t)nreads, 1);
     // 5: ambiguous -- two enabled alignments of a read that intersect on the read
     dh_parallel_for(nreads, 2048, [&](int64_t lo, int64_t hi) {
+        int64_t local = 0;
         for (int64_t r = lo; r < hi; r++) {
             bool amb = false;
             for (int64_t x = first[(size_t)r]; x < first[(size_t)r + 1] && !amb; x++) {
@@ -147,13 +174,19 @@ extern "C" int dh_collect_filter(dh_la *las, int64_t n, const int64_t *contig_of
             }
             if (amb) {
                 used[(size_t)r] = 0;
-                for (int64_t x = first[(size_t)r]; x < first[(size_t)r + 1]; x++) las[byread[(size_t)x]].flags |= DH_FLAG_DISABLED;
+                for (int64_t x = first[(size_t)r]; x < first[(size_t)r + 1]; x++) {
+                    dh_la &l = las[byread[(size_t)x]];
+                    local += (l.flags & DH_FLAG_DISABLED) ? 0 : 1;
+                    l.flags |= DH_FLAG_DISABLED;
+                }
             }
         }
+        newly += local;
     });
     stage_done(4);
     // 6: redundant -- isFullyContained, base.d:562-598
     dh_parallel_for(nreads, 2048, [&](int64_t lo, int64_t hi) {
+        int64_t local = 0;
         for (int64_t r = lo; r < hi; r++) {
             bool red = false;
             for (int64_t x = first[(size_t)r]; x < first[(size_t)r + 1] && !red; x++) {
@@ -165,9 +198,14 @@ extern "C" int dh_collect_filter(dh_la *las, int64_t n, const int64_t *contig_of
             }
             if (red) {
                 used[(size_t)r] = 0;
-                for (int64_t x = first[(size_t)r]; x < first[(size_t)r + 1]; x++) las[byread[(size_t)x]].flags |= DH_FLAG_DISABLED;
+                for (int64_t x = first[(size_t)r]; x < first[(size_t)r + 1]; x++) {
+                    dh_la &l = las[byread[(size_t)x]];
+                    local += (l.flags & DH_FLAG_DISABLED) ? 0 : 1;
+                    l.flags |= DH_FLAG_DISABLED;
+                }
             }
         }
+        newly += local;
     });
     stage_done(5);
     if (dropped6) memcpy(dropped6, cnt, sizeof(cnt));

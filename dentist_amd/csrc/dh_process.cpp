@@ -156,20 +156,39 @@ static int collect_candidates(const dh_la *las, int64_t n, const int64_t *contig
                               const dh_process_opts &o, dh_pileups **out)
 {
     if (n >= (1ll << 31)) return dh_fail(DH_EINVAL, "dh_collect_spanning: more than 2^31 - 1 local alignments");
+    // the enabled LAs (dh_collect_filter leaves most of a mapping disabled) as (read, LA index), listed
+    // by the host threads over runs of the input and grouped by read with a counting sort that keeps
+    // the LA order inside a read
+    const int64_t lgrain = 1 << 16, lchunks = (n + lgrain - 1) / lgrain;
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> live((size_t)std::max<int64_t>(lchunks, 1));
+    std::atomic<int> bad{0};
+    dh_parallel_for(lchunks, 1, [&](int64_t clo, int64_t chi) {
+        for (int64_t c = clo; c < chi; c++) {
+            auto &v = live[(size_t)c];
+            const int64_t i1 = std::min(n, (c + 1) * lgrain);
+            for (int64_t i = c * lgrain; i < i1; i++) {
+                if (las[i].bread < 0 || las[i].aread < 0 || las[i].aread >= ncontigs) bad = 1;
+                else if (!(las[i].flags & DH_FLAG_DISABLED)) v.emplace_back(las[i].bread, (int32_t)i);
+            }
+        }
+    });
+    if (bad) return dh_fail(DH_EINVAL, "dh_collect_spanning: read or contig id out of range");
     int32_t nreads = 0;
-    for (int64_t i = 0; i < n; i++) {
-        if (las[i].bread < 0 || las[i].aread < 0 || las[i].aread >= ncontigs)
-            return dh_fail(DH_EINVAL, "dh_collect_spanning: read or contig id out of range");
-        nreads = std::max(nreads, las[i].bread + 1);
+    int64_t nlive = 0;
+    for (const auto &v : live) {
+        nlive += (int64_t)v.size();
+        for (const auto &e : v) nreads = std::max(nreads, e.first + 1);
     }
-    // group the LA indices by read (counting sort, keeps the LA order inside a read)
-    std::vector<int64_t> first((size_t)nreads + 1, 0), order((size_t)n);
-    for (int64_t i = 0; i < n; i++) first[(size_t)las[i].bread + 1]++;
+    std::vector<int64_t> first((size_t)nreads + 1, 0), order((size_t)nlive);
+    for (const auto &v : live)
+        for (const auto &e : v) first[(size_t)e.first + 1]++;
     for (int32_t r = 0; r < nreads; r++) first[(size_t)r + 1] += first[(size_t)r];
     {
         std::vector<int64_t> cur(first.begin(), first.end() - 1);
-        for (int64_t i = 0; i < n; i++) order[(size_t)cur[(size_t)las[i].bread]++] = i;
+        for (const auto &v : live)
+            for (const auto &e : v) order[(size_t)cur[(size_t)e.first]++] = e.second;
     }
+    live.clear();
     // reads are independent: host threads take runs of reads and list their entries (gap, read, iL,
     // iR) in read order; the runs are concatenated in order and split by gap afterwards
     struct Ent {
