@@ -911,7 +911,6 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         std::min<int64_t>(A->max_len, (int64_t)B->max_len + (2ll * B->max_len + o.xdrop) / (o.pen - 1) + 1);
     const int32_t nbmax = (int32_t)(maxext / o.tspace + 3);
     const int32_t trmax = 2 * (2 * nbmax + 2);
-    const int32_t poolcap = 96 * nbmax;
     // resident alignment slots: one per wavefront of k_wave (<= 64 VGPRs -> 8 waves/SIMD), one per
     // 32-lane half of k_wave2 (two per wavefront, 6 waves/SIMD)
     // alignments per wavefront of k_wave2: 2 (32 lanes each, width <= 30) or 4 (16 lanes, width <= 14)
@@ -920,6 +919,10 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     // k_wave2: 80 VGPRs -> 6 waves/SIMD = 24 wavefronts per CU (two per wavefront); 96 VGPRs -> 5 waves/SIMD = 20 (four)
     if (o.width <= 30) slots_per_cu = per_wave == 4 ? 20 * 4 : 24 * 2;
     if (const char *e = getenv("DH_WAVE_SLOTS_PER_CU")) slots_per_cu = std::max(4, atoi(e)) & ~3;
+    // trace-node pool of one alignment slot.  k_wave2: every lane of the group owns a stretch (a lane
+    // crosses each boundary of either grid at most once per diagonal it serves; twice that is the
+    // capacity, an overflow is reported); k_wave: one shared pool
+    const int32_t poolcap = dual ? (64 / per_wave) * (4 * nbmax + 8) : 96 * nbmax;
     const int32_t nslots = (int32_t)std::min<int64_t>((int64_t)ctx->ncu * slots_per_cu,
                                                       (std::max<int64_t>(nitems_total, 4) + 3) & ~3ll);
     const int32_t cn = (int32_t)std::min<int64_t>(chunk, std::max<int64_t>(nitems_total, 2));

@@ -1568,7 +1568,10 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
     const int lane = threadIdx.x, hl = lane & (G - 1), hb = lane & (LANES - G), grp = lane / G;
     const int64_t slot = (int64_t)blockIdx.x * NG + grp;
     DhNode *pool = ws.pool + slot * ws.poolcap;
-    const int32_t ts = o.tspace, pen = o.pen, xdrop = o.xdrop, poolcap = ws.poolcap;
+    // every lane pushes its trace nodes into its own stretch of the slot's pool (node = lbase + pn):
+    // no ballot / prefix count per boundary crossing, and a level on which nothing crosses costs
+    // one compare per family
+    const int32_t ts = o.tspace, pen = o.pen, xdrop = o.xdrop, lanecap = ws.poolcap / G, lbase = hl * lanecap;
     const int32_t addr_lo = (hb | ((hl - 1) & (G - 1))) << 2, addr_hi = (hb | ((hl + 1) & (G - 1))) << 2;
     constexpr int32_t DEAD = -(1 << 30);
 
@@ -1586,7 +1589,7 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
     int32_t dir = 0, ra = 0, rb = 0, an = 0, bn = 0, tp_first = 0, tpb_first = 0;
     const uint8_t *pa = nullptr, *pb = nullptr;
     int32_t R = DEAD, H = -1, NB = 0, HB = -1, NBB = 0;  // per lane
-    int32_t L = 0, d = 0, pool_n = 0;
+    int32_t L = 0, d = 0, pn = 0;  // pn: nodes of this lane (per candidate, both extensions)
     int32_t best_score = 0, best_i = 0, best_k = 0, best_d = 0, best_head = -1, best_nb = 0, best_headb = -1,
             best_nbb = 0;
     uint32_t ncell = 0;
@@ -1625,8 +1628,8 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
             slide2<PK>(pa, ra, pb, rb, min(an, bn), i0, j0);
             int32_t cnt = 0;
             for (int32_t nextb = tp_first; nextb <= i0; nextb += ts) {
-                const int32_t idx = pool_n + cnt;
-                if (idx < poolcap) {
+                const int32_t idx = lbase + pn + cnt;
+                if (pn + cnt < lanecap) {
                     pool[idx].parent = h0;
                     pool[idx].d = 0;
                     pool[idx].j = nextb;
@@ -1637,8 +1640,8 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
             }
             if (SYM)
                 for (int32_t nextb = tpb_first; nextb <= i0; nextb += ts) {
-                    const int32_t idx = pool_n + cnt;
-                    if (idx < poolcap) {
+                    const int32_t idx = lbase + pn + cnt;
+                    if (pn + cnt < lanecap) {
                         pool[idx].parent = hb0;
                         pool[idx].d = 0;
                         pool[idx].j = nextb;
@@ -1652,13 +1655,13 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
             NB = tp_first + nb0 * ts;
             HB = hb0;
             NBB = tpb_first + nbb0 * ts;
+            pn += cnt;
         }
         i0 = hlane<G, 0>(i0, hb);
         h0 = hlane<G, 0>(h0, hb);
         nb0 = hlane<G, 0>(nb0, hb);
         hb0 = hlane<G, 0>(hb0, hb);
         nbb0 = hlane<G, 0>(nbb0, hb);
-        pool_n += nb0 + nbb0;
         best_score = 2 * i0;
         best_i = i0;
         best_k = 0;
@@ -1742,47 +1745,32 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
             {
                 // trace nodes for the boundaries crossed in (prev_i, ni]
                 int32_t nextb = nbp;
-                bool cross = alive && ni >= nextb;
-                for (;;) {
-                    const uint32_t m = hballot<G>(cross, hb);
-                    if (m == 0u) break;
-                    if (cross) {
-                        const int32_t idx = pool_n + __popc(m & ((1u << hl) - 1u));
-                        if (idx < poolcap) {
+                if (alive)
+                    while (ni >= nextb) {
+                        const int32_t idx = lbase + pn;
+                        if (pn < lanecap) {
                             pool[idx].parent = hd;
                             pool[idx].d = d;
                             pool[idx].j = nextb - k;
                         }
                         hd = idx;
+                        pn++;
                         nextb += ts;
-                        cross = ni >= nextb;
                     }
-                    pool_n += __popc(m);
-                }
                 int32_t nextbb = nbbp;
-                if (SYM) {
-                    bool crossb = alive && j >= nextbb;
-                    for (;;) {
-                        const uint32_t m = hballot<G>(crossb, hb);
-                        if (m == 0u) break;
-                        if (crossb) {
-                            const int32_t idx = pool_n + __popc(m & ((1u << hl) - 1u));
-                            if (idx < poolcap) {
-                                pool[idx].parent = hbn;
-                                pool[idx].d = d;
-                                pool[idx].j = nextbb + k;
-                            }
-                            hbn = idx;
-                            nextbb += ts;
-                            crossb = j >= nextbb;
+                if (SYM && alive)
+                    while (j >= nextbb) {
+                        const int32_t idx = lbase + pn;
+                        if (pn < lanecap) {
+                            pool[idx].parent = hbn;
+                            pool[idx].d = d;
+                            pool[idx].j = nextbb + k;
                         }
-                        pool_n += __popc(m);
+                        hbn = idx;
+                        pn++;
+                        nextbb += ts;
                     }
-                }
-                if (pool_n > poolcap) {
-                    err |= DH_ST_POOL_OVERFLOW;
-                    ended = true;
-                } else {
+                {
                     R = alive ? ni : DEAD;
                     H = hd;
                     NB = nextb;
@@ -1818,7 +1806,7 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
                         uint32_t rm = hrotr<G>(lm, rot);
                         int32_t l2 = nL + (__ffs((int)rm) - 1);
                         int32_t u2 = nL + (31 - __clz((int)rm));
-                        if (G == 16 && u2 - l2 + 1 > o.width) {
+                        if (u2 - l2 + 1 > o.width) {
                             // Narrow windows trim on most levels.  A level adds at most one diagonal on
                             // each side, so at most two edges go: fetch the scores of the two lowest and
                             // the two highest live diagonals in one crossbar round trip and replay the
@@ -1931,7 +1919,7 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
                         bm = bm < 0 ? bm + ts : bm;
                         cs.fwdb_first = ts - bm;
                         cs.revb_first = bm ? bm : ts;
-                        pool_n = 0;
+                        pn = 0;
                         ext_begin(0);
                         started = true;
                         break;
@@ -1950,6 +1938,9 @@ k_wave2(DbView A, DbView B, const uint8_t *__restrict__ arc, const uint8_t *__re
                         uint32_t tot = ncell;
                         for (int off = G / 2; off > 0; off >>= 1) tot += (uint32_t)__shfl_xor((int)tot, off, LANES);
                         cs.cells += tot;
+                        // a lane that ran out of node slots wrote nothing past its stretch; its chains are
+                        // broken, so the alignment is reported instead of used
+                        if (hballot<G>(pn > lanecap, hb) != 0u) err |= DH_ST_POOL_OVERFLOW;
                     }
                     const int32_t r_nb = (best_nb - tp_first) / ts, r_nbb = SYM ? (best_nbb - tpb_first) / ts : 0;
                     if (dir == 0 && !err) {
