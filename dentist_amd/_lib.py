@@ -84,6 +84,8 @@ SYMBOLS = [
     "dh_chaindb_nseeded", "dh_chaindb_seeded", "dh_chaindb_nlas", "dh_chaindb_las", "dh_chaindb_ntrace",
     "dh_chaindb_trace", "dh_chaindb_ninsertions", "dh_chaindb_insertions", "dh_chaindb_bases", "dh_chaindb_read_ids",
     "dh_insertions_write_db", "dh_pileups_write_db", "dh_pileups_flat", "dh_collect_filter",
+    "dh_default_scaffold_opts", "dh_scaffold_pileups", "dh_scaffold_npiles", "dh_scaffold_nentries", "dh_scaffold_joins",
+    "dh_scaffold_entries", "dh_scaffold_destroy", "dh_scaffold_spanning",
 ]
 
 _LIB = None
@@ -520,6 +522,79 @@ def collect_filter(las, contig_off, read_off, opts, repeat_mask=None, inplace=Fa
                                rp.ctypes.data if rp is not None else None, ri.ctypes.data if ri is not None else None,
                                ctypes.byref(opts), dropped.ctypes.data, used.ctypes.data))
     return arr, dropped, used
+
+
+class ScaffoldOpts(ctypes.Structure):
+    _fields_ = [("min_spanning_reads", ctypes.c_int32), ("merge_extensions", ctypes.c_int32),
+                ("best_pile_up_margin", ctypes.c_double), ("existing_gap_bonus", ctypes.c_double)]
+
+
+JOIN_DTYPE = np.dtype([("contig0", "<i4"), ("part0", "<i4"), ("contig1", "<i4"), ("part1", "<i4"), ("type", "<i4"),
+                       ("count", "<i4"), ("first", "<i8")])
+READ_ALIGNMENT_DTYPE = np.dtype([("read", "<i4"), ("la0", "<i4"), ("la1", "<i4"), ("seed0", "u1"), ("seed1", "u1"),
+                                 ("n", "u1"), ("pad", "u1")])
+
+
+def _scaffold(las, contig_off, read_off, input_gaps, kw):
+    L = lib()
+    o = ScaffoldOpts()
+    L.dh_default_scaffold_opts(ctypes.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise TypeError(f"unknown scaffold option {k}")
+        setattr(o, k, int(v) if k in ("min_spanning_reads", "merge_extensions") else float(v))
+    arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
+    co, ro = np.ascontiguousarray(contig_off, dtype=np.int64), np.ascontiguousarray(read_off, dtype=np.int64)
+    ig = np.ascontiguousarray(input_gaps if input_gaps is not None else np.zeros((0, 2)), dtype=np.int32).reshape(-1, 2)
+    h = ctypes.c_void_p()
+    L.dh_scaffold_pileups.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+                                      ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ScaffoldOpts),
+                                      ctypes.POINTER(ctypes.c_void_p)]
+    _check(L.dh_scaffold_pileups(arr.ctypes.data, len(arr), co.ctypes.data, len(co) - 1, ro.ctypes.data, len(ro) - 1,
+                                 ig.ctypes.data if len(ig) else None, len(ig), ctypes.byref(o), ctypes.byref(h)))
+    return h, arr
+
+
+def scaffold_pileups(las, contig_off, read_off, input_gaps=None, **opts):
+    """dh_scaffold_pileups: the scaffold-graph pile-up builder of `dentist collect`
+    (pileups.d:173-208).  Returns (joins JOIN_DTYPE[npiles], read alignments READ_ALIGNMENT_DTYPE[...])."""
+    L = lib()
+    h, _ = _scaffold(las, contig_off, read_off, input_gaps, opts)
+    try:
+        L.dh_scaffold_npiles.restype = ctypes.c_int32
+        L.dh_scaffold_nentries.restype = ctypes.c_int64
+        L.dh_scaffold_joins.restype = ctypes.c_void_p
+        L.dh_scaffold_entries.restype = ctypes.c_void_p
+        for f in (L.dh_scaffold_npiles, L.dh_scaffold_nentries, L.dh_scaffold_joins, L.dh_scaffold_entries):
+            f.argtypes = [ctypes.c_void_p]
+        nj, ne = L.dh_scaffold_npiles(h), L.dh_scaffold_nentries(h)
+        joins = np.zeros(nj, dtype=JOIN_DTYPE)
+        ent = np.zeros(ne, dtype=READ_ALIGNMENT_DTYPE)
+        if nj:
+            ctypes.memmove(joins.ctypes.data, L.dh_scaffold_joins(h), joins.nbytes)
+        if ne:
+            ctypes.memmove(ent.ctypes.data, L.dh_scaffold_entries(h), ent.nbytes)
+    finally:
+        L.dh_scaffold_destroy.argtypes = [ctypes.c_void_p]
+        L.dh_scaffold_destroy(h)
+    return joins, ent
+
+
+def scaffold_spanning_pileups(las, contig_off, read_off, input_gaps=None, **opts):
+    """The pile-ups of the scaffold graph that dh_process_pileups handles (dh_scaffold_spanning):
+    returns (Pileups, number of pile-ups of other kinds)."""
+    L = lib()
+    h, arr = _scaffold(las, contig_off, read_off, input_gaps, opts)
+    try:
+        ph = ctypes.c_void_p()
+        skipped = ctypes.c_int32(0)
+        L.dh_scaffold_spanning.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                           ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int32)]
+        _check(L.dh_scaffold_spanning(h, arr.ctypes.data, len(arr), ctypes.byref(ph), ctypes.byref(skipped)))
+    finally:
+        L.dh_scaffold_destroy.argtypes = [ctypes.c_void_p]
+        L.dh_scaffold_destroy(h)
+    return Pileups(None, None, None, _handle=ph), int(skipped.value)
 
 
 class Cropped:

@@ -1,0 +1,376 @@
+// dh_scaffold.cpp -- the scaffold-graph pile-up builder of `dentist collect`
+// (collectPileUps/pileups.d:173-208 build): read alignments of every read (pileups.d:821-888
+// collectReadAlignments over base.d:1964-2050 SeededAlignment), one join per read alignment
+// (base.d:2680-2722 makeJoin), the scaffold graph with its four nodes per contig (scaffold.d:75-115,
+// 237-244), multi-edges merged (pileups.d:626-636), forks resolved by read support
+// (pileups.d:1592-1657, 1754-1804), min-spanning-reads (pileups.d:1807-1838), input-gap marks removed
+// (pileups.d:1840-1852), extensions merged into their gap (scaffold.d:789-816) and the pile-ups read
+// off the edges in edge order (pileups.d:435-444).
+//
+// Host code: per-read work runs on the thread pool, the graph itself has 4 nodes per contig and is
+// handled serially.  Where the reference merges equal edges after an unstable sort, the order here is
+// the stable one (read id, then position on the read).  resolveBubbles (pileups.d:1124-1590) re-aligns
+// the skipping reads with the external tools and is not part of this builder: the forks of a bubble go
+// through the read-support rule like any other fork.
+#include <algorithm>
+#include <array>
+#include <atomic>
+#include <cstring>
+#include <vector>
+
+#include "dh_internal.h"
+#include "dh_parallel.h"
+
+namespace {
+enum { FRONT = 0, BACK = 1 };
+enum { PRE = 0, BEGIN = 1, END = 2, POST = 3 };
+enum { T_PILEUP = 1, T_INPUTGAP = 2 };
+
+struct Node {
+    int32_t contig, part;
+    bool operator<(const Node &o) const { return contig != o.contig ? contig < o.contig : part < o.part; }
+    bool operator==(const Node &o) const { return contig == o.contig && part == o.part; }
+};
+inline bool real_part(int32_t p) { return p == BEGIN || p == END; }
+
+struct Edge {
+    Node s, e;
+    uint32_t types = 0;
+    std::vector<dh_read_alignment> ras;
+    bool is_default() const { return s.part == BEGIN && e.part == END && s.contig == e.contig; }
+    bool is_gap() const { return s.contig != e.contig && real_part(s.part) && real_part(e.part); }
+    bool empty_payload() const { return types == 0 && ras.empty(); }
+};
+inline bool key_less(const Edge &a, const Edge &b) { return a.s == b.s ? a.e < b.e : a.s < b.s; }
+inline bool key_eq(const Edge &a, const Edge &b) { return a.s == b.s && a.e == b.e; }
+inline Edge make_edge(Node a, Node b)
+{
+    Edge x;
+    if (b < a) std::swap(a, b);  // undirected: start <= end (math.d:385-398)
+    x.s = a;
+    x.e = b;
+    return x;
+}
+
+void remove_none_joins(std::vector<Edge> &g)
+{
+    g.erase(std::remove_if(g.begin(), g.end(), [](const Edge &x) { return !x.is_default() && x.empty_payload(); }),
+            g.end());
+}
+
+struct SA {
+    int64_t la;
+    int32_t seed, b, e, srel;
+};
+
+struct Ctx {
+    const dh_la *las;
+    const int64_t *coff, *roff;
+    int32_t alen(const dh_la &l) const { return (int32_t)(coff[l.aread + 1] - coff[l.aread]); }
+    int32_t blen(const dh_la &l) const { return (int32_t)(roff[l.bread + 1] - roff[l.bread]); }
+};
+
+// collectReadAlignments for the enabled LAs idx[0..cnt) of one read, appended to `out` as raw joins
+void read_joins(const Ctx &c, const int64_t *idx, int64_t cnt, std::vector<Edge> &out, std::vector<SA> &sa)
+{
+    sa.clear();
+    for (int64_t x = 0; x < cnt; x++) {
+        const dh_la &l = c.las[idx[x]];
+        const bool comp = (l.flags & DH_FLAG_COMP) != 0;
+        const int32_t bl = c.blen(l);
+        const int32_t b = comp ? bl - l.bepos : l.bbpos, e = comp ? bl - l.bbpos : l.bepos;
+        if (l.bbpos > l.abpos) sa.push_back(SA{idx[x], FRONT, b, e, comp ? -FRONT : FRONT});                 // isFrontExtension
+        if (bl - l.bepos > c.alen(l) - l.aepos) sa.push_back(SA{idx[x], BACK, b, e, comp ? -BACK : BACK});  // isBackExtension
+    }
+    if (sa.empty()) return;
+    std::stable_sort(sa.begin(), sa.end(), [](const SA &p, const SA &q) {
+        if (p.b != q.b) return p.b < q.b;
+        if (p.e != q.e) return p.e < q.e;
+        return p.srel < q.srel;
+    });
+    for (size_t i = 0; i + 1 < sa.size(); i++)
+        if (sa[i].e > sa[i + 1].b && !(sa[i].la == sa[i + 1].la && sa[i].seed != sa[i + 1].seed)) return;  // a region of the read used twice
+    const bool start_ext = sa[0].b > 0;
+    // slices [0,1) if the read starts with an extension, then pairs
+    std::vector<std::pair<size_t, size_t>> sl;
+    if (start_ext) sl.emplace_back(0, 1);
+    for (size_t i = start_ext ? 1 : 0; i < sa.size(); i += 2) sl.emplace_back(i, std::min(i + 2, sa.size()));
+    for (auto &p : sl)  // one invalid read alignment discards the read
+        if (p.second - p.first == 2 && c.las[sa[p.first].la].aread == c.las[sa[p.first + 1].la].aread) return;
+    for (auto &p : sl) {
+        dh_read_alignment ra;
+        memset(&ra, 0, sizeof(ra));
+        Edge e;
+        if (p.second - p.first == 2) {
+            SA a = sa[p.first], b = sa[p.first + 1];
+            if (!(c.las[a.la].aread < c.las[b.la].aread)) std::swap(a, b);  // getInOrder
+            ra.n = 2;
+            ra.la0 = (int32_t)a.la;
+            ra.la1 = (int32_t)b.la;
+            ra.seed0 = (uint8_t)a.seed;
+            ra.seed1 = (uint8_t)b.seed;
+            e = make_edge(Node{c.las[a.la].aread, a.seed == FRONT ? BEGIN : END},
+                          Node{c.las[b.la].aread, b.seed == FRONT ? BEGIN : END});
+        } else {
+            const SA a = sa[p.first];
+            ra.n = 1;
+            ra.la0 = (int32_t)a.la;
+            ra.la1 = -1;
+            ra.seed0 = (uint8_t)a.seed;
+            const int32_t ct = c.las[a.la].aread;
+            e = a.seed == FRONT ? make_edge(Node{ct, PRE}, Node{ct, BEGIN}) : make_edge(Node{ct, END}, Node{ct, POST});
+        }
+        ra.read = c.las[ra.la0].bread;
+        e.types = T_PILEUP;
+        e.ras.push_back(ra);
+        out.push_back(std::move(e));
+    }
+}
+
+// sort stably and merge equal edges: types OR-ed, read alignments concatenated (bulkAdd!mergeJoins)
+void merge_multi_edges(std::vector<Edge> &g)
+{
+    std::stable_sort(g.begin(), g.end(), key_less);
+    std::vector<Edge> out;
+    for (size_t i = 0; i < g.size();) {
+        size_t j = i + 1;
+        while (j < g.size() && key_eq(g[i], g[j])) j++;
+        Edge m = std::move(g[i]);
+        if (j - i > 1) {
+            size_t tot = m.ras.size();
+            for (size_t x = i + 1; x < j; x++) tot += g[x].ras.size();
+            m.ras.reserve(tot);
+            for (size_t x = i + 1; x < j; x++) {
+                m.types |= g[x].types;
+                m.ras.insert(m.ras.end(), g[x].ras.begin(), g[x].ras.end());
+            }
+        }
+        out.push_back(std::move(m));
+        i = j;
+    }
+    g.swap(out);
+}
+
+// edges incident to every node: inc[4 * contig + part] = edge indices in edge order
+std::vector<std::vector<int32_t>> incidence(const std::vector<Edge> &g, int32_t ncontigs)
+{
+    std::vector<std::vector<int32_t>> inc((size_t)ncontigs * 4);
+    for (size_t i = 0; i < g.size(); i++) {
+        inc[(size_t)g[i].s.contig * 4 + g[i].s.part].push_back((int32_t)i);
+        if (!(g[i].e == g[i].s)) inc[(size_t)g[i].e.contig * 4 + g[i].e.part].push_back((int32_t)i);
+    }
+    return inc;
+}
+}  // namespace
+
+struct dh_scaffold {
+    std::vector<dh_join> joins;
+    std::vector<dh_read_alignment> entries;
+};
+
+extern "C" void dh_default_scaffold_opts(dh_scaffold_opts *o)
+{
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->min_spanning_reads = 3;     // commandline.d:2125, 2187
+    o->merge_extensions = 1;       // commandline.d:2217-2222
+    o->best_pile_up_margin = 3.0;  // commandline.d:1345
+    o->existing_gap_bonus = 6.0;   // commandline.d:1688
+}
+
+extern "C" int dh_scaffold_pileups(const dh_la *las, int64_t n, const int64_t *contig_off, int32_t ncontigs,
+                                   const int64_t *read_off, int32_t nreads, const int32_t *input_gaps, int32_t ngaps,
+                                   const dh_scaffold_opts *opts, dh_scaffold **out)
+{
+    if ((n > 0 && !las) || !contig_off || !read_off || !opts || !out || ncontigs < 0 || nreads < 0 || n < 0 ||
+        n >= (1ll << 31) || (ngaps > 0 && !input_gaps) || ngaps < 0)
+        return dh_fail(DH_EINVAL, "dh_scaffold_pileups: bad argument");
+    const Ctx c{las, contig_off, read_off};
+    // ---- the enabled LAs grouped by read, input order inside a read
+    std::atomic<int> bad{0};
+    const int64_t lgrain = 1 << 16, lchunks = (n + lgrain - 1) / lgrain;
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> live((size_t)std::max<int64_t>(lchunks, 1));
+    dh_parallel_for(lchunks, 1, [&](int64_t clo, int64_t chi) {
+        for (int64_t ch = clo; ch < chi; ch++) {
+            auto &v = live[(size_t)ch];
+            const int64_t i1 = std::min(n, (ch + 1) * lgrain);
+            for (int64_t i = ch * lgrain; i < i1; i++) {
+                if (las[i].bread < 0 || las[i].bread >= nreads || las[i].aread < 0 || las[i].aread >= ncontigs) bad = 1;
+                else if (!(las[i].flags & DH_FLAG_DISABLED)) v.emplace_back(las[i].bread, (int32_t)i);
+            }
+        }
+    });
+    if (bad) return dh_fail(DH_EINVAL, "dh_scaffold_pileups: read or contig id out of range");
+    for (int32_t g = 0; g < ngaps; g++)
+        if (input_gaps[2 * g] < 0 || input_gaps[2 * g] >= ncontigs || input_gaps[2 * g + 1] < 0 || input_gaps[2 * g + 1] >= ncontigs)
+            return dh_fail(DH_EINVAL, "dh_scaffold_pileups: input gap names a contig out of range");
+    std::vector<int64_t> first((size_t)nreads + 1, 0);
+    int64_t nlive = 0;
+    for (const auto &v : live) {
+        nlive += (int64_t)v.size();
+        for (const auto &e : v) first[(size_t)e.first + 1]++;
+    }
+    for (int32_t r = 0; r < nreads; r++) first[(size_t)r + 1] += first[(size_t)r];
+    std::vector<int64_t> order((size_t)nlive);
+    {
+        std::vector<int64_t> cur(first.begin(), first.end() - 1);
+        for (const auto &v : live)
+            for (const auto &e : v) order[(size_t)cur[(size_t)e.first]++] = e.second;
+    }
+    live.clear();
+    // ---- raw joins of the reads, in read order (collectScaffoldJoins, pileups.d:650-667)
+    const int64_t grain = 8192, nchunks = ((int64_t)nreads + grain - 1) / grain;
+    std::vector<std::vector<Edge>> found((size_t)std::max<int64_t>(nchunks, 1));
+    dh_parallel_for(nchunks, 1, [&](int64_t clo, int64_t chi) {
+        std::vector<SA> sa;
+        for (int64_t ch = clo; ch < chi; ch++) {
+            const int32_t r1 = (int32_t)std::min<int64_t>(nreads, (ch + 1) * grain);
+            for (int32_t rd = (int32_t)(ch * grain); rd < r1; rd++) {
+                const int64_t cnt = first[(size_t)rd + 1] - first[(size_t)rd];
+                if (cnt > 0) read_joins(c, order.data() + first[(size_t)rd], cnt, found[(size_t)ch], sa);
+            }
+        }
+    });
+    // ---- the scaffold: default edges, read joins, input gaps (buildScaffold, scaffold.d:237-244)
+    std::vector<Edge> g;
+    for (int32_t ct = 0; ct < ncontigs; ct++) g.push_back(make_edge(Node{ct, BEGIN}, Node{ct, END}));
+    for (auto &v : found)
+        for (auto &e : v) g.push_back(std::move(e));
+    found.clear();
+    for (int32_t x = 0; x < ngaps; x++) {
+        Edge e = make_edge(Node{input_gaps[2 * x], END}, Node{input_gaps[2 * x + 1], BEGIN});
+        e.types = T_INPUTGAP;
+        g.push_back(std::move(e));
+    }
+    merge_multi_edges(g);
+    remove_none_joins(g);
+    // ---- discardAmbiguousJoins (pileups.d:1592-1657)
+    {
+        const auto inc = incidence(g, ncontigs);
+        std::vector<char> drop(g.size(), 0);
+        for (int32_t ct = 0; ct < ncontigs; ct++)
+            for (int32_t part : {BEGIN, END}) {
+                const auto &in = inc[(size_t)ct * 4 + part];
+                if (in.size() <= 2) continue;
+                std::vector<int32_t> gj;
+                for (int32_t ei : in)
+                    if (g[(size_t)ei].is_gap() && (g[(size_t)ei].types & T_PILEUP)) gj.push_back(ei);
+                if (gj.size() <= 1) continue;
+                // findCorrectGapJoin (pileups.d:1754-1804): the best-supported join wins if it beats the
+                // runner-up by the margin; joins of the input assembly get a bonus
+                std::vector<std::pair<double, size_t>> val;
+                for (size_t x = 0; x < gj.size(); x++) {
+                    const Edge &e = g[(size_t)gj[x]];
+                    val.emplace_back((double)e.ras.size() * ((e.types & T_INPUTGAP) ? opts->existing_gap_bonus : 1.0), x);
+                }
+                std::stable_sort(val.begin(), val.end(), [](const auto &p, const auto &q) { return p.first > q.first; });
+                const size_t keep = val[1].first * opts->best_pile_up_margin < val[0].first ? val[0].second : gj.size();
+                for (size_t x = 0; x < gj.size(); x++)
+                    if (x != keep) drop[(size_t)gj[x]] = 1;
+            }
+        for (size_t i = 0; i < g.size(); i++)
+            if (drop[i]) {
+                g[i].types &= ~(uint32_t)T_PILEUP;
+                g[i].ras.clear();
+            }
+        remove_none_joins(g);
+    }
+    // ---- enforceMinSpanningReads, removeInputGaps (pileups.d:1807-1852)
+    for (Edge &e : g)
+        if ((e.types & T_PILEUP) && e.is_gap() && (int64_t)e.ras.size() < opts->min_spanning_reads) {
+            e.types &= ~(uint32_t)T_PILEUP;
+            e.ras.clear();
+        }
+    remove_none_joins(g);
+    for (Edge &e : g) e.types &= ~(uint32_t)T_INPUTGAP;
+    remove_none_joins(g);
+    // ---- mergeExtensionsWithGaps (scaffold.d:789-816): emptied edges stay until the end
+    if (opts->merge_extensions) {
+        const auto inc = incidence(g, ncontigs);
+        for (int32_t ct = 0; ct < ncontigs; ct++)
+            for (int32_t part : {BEGIN, END}) {
+                const auto &in = inc[(size_t)ct * 4 + part];
+                if (in.size() > 3) return dh_fail(DH_EINVAL, "dh_scaffold_pileups: node degree must be <= 3");
+                if (in.size() != 3) continue;
+                int32_t nd[2], k = 0;
+                for (int32_t ei : in)
+                    if (!g[(size_t)ei].is_default() && k < 2) nd[k++] = ei;
+                if (k != 2) continue;
+                const Node me{ct, part};
+                auto other = [&](const Edge &e) { return e.s == me ? e.e : e.s; };
+                const int gi = real_part(other(g[(size_t)nd[0]]).part) ? 0 : 1;
+                Edge &gap = g[(size_t)nd[gi]], &ext = g[(size_t)nd[1 - gi]];
+                gap.types |= ext.types;
+                gap.ras.insert(gap.ras.end(), ext.ras.begin(), ext.ras.end());
+                ext.types = 0;
+                ext.ras.clear();
+            }
+        remove_none_joins(g);
+    }
+    // ---- collectPileUps (pileups.d:435-444): valid pile-ups in edge order
+    dh_scaffold *res = new dh_scaffold();
+    for (const Edge &e : g) {
+        if (!(e.types & T_PILEUP) || e.ras.empty()) continue;
+        bool any_gap = false, all_front = true, all_back = true;
+        for (const dh_read_alignment &ra : e.ras) {
+            any_gap = any_gap || ra.n == 2;
+            all_front = all_front && ra.n == 1 && ra.seed0 == FRONT;
+            all_back = all_back && ra.n == 1 && ra.seed0 == BACK;
+        }
+        const bool is_ext = all_front || all_back;
+        if (is_ext == any_gap) continue;  // PileUp.isValid, base.d:2755-2790
+        dh_join j;
+        j.contig0 = e.s.contig;
+        j.part0 = e.s.part;
+        j.contig1 = e.e.contig;
+        j.part1 = e.e.part;
+        j.type = any_gap ? 1 : (all_front ? 0 : 2);  // ReadAlignmentType: front, gap, back
+        j.count = (int32_t)e.ras.size();
+        j.first = (int64_t)res->entries.size();
+        res->joins.push_back(j);
+        res->entries.insert(res->entries.end(), e.ras.begin(), e.ras.end());
+    }
+    *out = res;
+    return DH_OK;
+}
+
+extern "C" int32_t dh_scaffold_npiles(const dh_scaffold *s) { return s ? (int32_t)s->joins.size() : 0; }
+extern "C" int64_t dh_scaffold_nentries(const dh_scaffold *s) { return s ? (int64_t)s->entries.size() : 0; }
+extern "C" const dh_join *dh_scaffold_joins(const dh_scaffold *s) { return s ? s->joins.data() : nullptr; }
+extern "C" const dh_read_alignment *dh_scaffold_entries(const dh_scaffold *s) { return s ? s->entries.data() : nullptr; }
+extern "C" void dh_scaffold_destroy(dh_scaffold *s) { delete s; }
+
+// The gap pile-ups the process path handles: joins (c, end) -- (c + 1, begin) whose spanning reads see
+// both contigs in the same orientation; of every such pile-up the spanning read alignments (left LA
+// seeded at the back, right LA at the front) become (read, left LA, right LA) triples ordered by read.
+// Everything else (extension pile-ups, joins between other contig ends, extension reads merged into a
+// gap) is counted in *skipped.
+extern "C" int dh_scaffold_spanning(const dh_scaffold *s, const dh_la *las, int64_t n, dh_pileups **out, int32_t *skipped)
+{
+    if (!s || !out || (n > 0 && !las)) return dh_fail(DH_EINVAL, "dh_scaffold_spanning: bad argument");
+    std::vector<int32_t> cl, cnt, tri;
+    int32_t skip = 0;
+    for (const dh_join &j : s->joins) {
+        if (!(j.type == 1 && j.part0 == END && j.part1 == BEGIN && j.contig1 == j.contig0 + 1)) {
+            skip++;
+            continue;
+        }
+        std::vector<std::array<int32_t, 3>> t;
+        for (int64_t x = j.first; x < j.first + j.count; x++) {
+            const dh_read_alignment &ra = s->entries[(size_t)x];
+            if (ra.n != 2 || ra.la0 < 0 || ra.la0 >= n || ra.la1 < 0 || ra.la1 >= n) continue;
+            if ((las[ra.la0].flags & DH_FLAG_COMP) != (las[ra.la1].flags & DH_FLAG_COMP)) continue;
+            t.push_back({ra.read, ra.la0, ra.la1});
+        }
+        if (t.empty()) {
+            skip++;
+            continue;
+        }
+        std::stable_sort(t.begin(), t.end(), [](const auto &a, const auto &b) { return a[0] < b[0]; });
+        cl.push_back(j.contig0);
+        cnt.push_back((int32_t)t.size());
+        for (auto &x : t) tri.insert(tri.end(), x.begin(), x.end());
+    }
+    if (skipped) *skipped = skip;
+    return dh_pileups_create(cl.data(), cnt.data(), (int32_t)cl.size(), tri.data(), out);
+}

@@ -227,6 +227,46 @@ int32_t dh_pileups_count(const dh_pileups *p);
  * (read, left LA index, right LA index) triples */
 int32_t dh_pileups_get(const dh_pileups *p, int32_t i, int32_t *contig_left, const int32_t **triples);
 
+/* ---- the scaffold-graph pile-up builder of `dentist collect` (collectPileUps/pileups.d:173-208 build;
+ * collectPileUps/package.d:174-184 is the call site).  Nodes are (contig, part) with part 0 = pre,
+ * 1 = begin, 2 = end, 3 = post (scaffold.d:75-90); a read alignment is one seeded LA (an extension over
+ * a contig end) or two (a read spanning a gap), seed 0 = front, 1 = back (base.d:1938-1944).  Steps:
+ * collectReadAlignments per read (pileups.d:821-888), joins merged per edge (pileups.d:626-636), forks
+ * resolved by read support with a bonus for joins of the input assembly (pileups.d:1592-1657,
+ * 1754-1804), min_spanning_reads (pileups.d:1807-1838), extensions merged into their gap
+ * (scaffold.d:789-816), pile-ups in edge order (pileups.d:435-444).  resolveBubbles (pileups.d:1124-1590)
+ * is not included.  DISABLED LAs are ignored.  input_gaps: ngaps pairs (begin contig, end contig) of the
+ * input assembly's scaffolding (pileups.d:796-811).  Host only. */
+typedef struct dh_scaffold_opts {
+    int32_t min_spanning_reads;  /* --min-spanning-reads, default 3 */
+    int32_t merge_extensions;    /* 0 = --no-merge-extension */
+    double best_pile_up_margin;  /* --best-pile-up-margin, default 3.0 */
+    double existing_gap_bonus;   /* --existing-gap-bonus, default 6.0 */
+} dh_scaffold_opts;
+void dh_default_scaffold_opts(dh_scaffold_opts *o);
+typedef struct dh_join {        /* one pile-up = the payload of one edge of the scaffold graph */
+    int32_t contig0, part0, contig1, part1; /* (contig0, part0) <= (contig1, part1) */
+    int32_t type;                /* ReadAlignmentType (base.d:2052-2070): 0 front extension, 1 gap, 2 back extension */
+    int32_t count;               /* read alignments of the pile-up: entries[first .. first + count) */
+    int64_t first;
+} dh_join;
+typedef struct dh_read_alignment {
+    int32_t read, la0, la1;      /* LA indices into the input; la1 = -1 for an extension */
+    uint8_t seed0, seed1, n, pad; /* n = 1 | 2 seeded alignments */
+} dh_read_alignment;
+typedef struct dh_scaffold dh_scaffold;
+int dh_scaffold_pileups(const dh_la *las, int64_t n, const int64_t *contig_off, int32_t ncontigs,
+                        const int64_t *read_off, int32_t nreads, const int32_t *input_gaps, int32_t ngaps,
+                        const dh_scaffold_opts *opts, dh_scaffold **out);
+int32_t dh_scaffold_npiles(const dh_scaffold *s);
+int64_t dh_scaffold_nentries(const dh_scaffold *s);
+const dh_join *dh_scaffold_joins(const dh_scaffold *s);
+const dh_read_alignment *dh_scaffold_entries(const dh_scaffold *s);
+void dh_scaffold_destroy(dh_scaffold *s);
+/* the pile-ups dh_process_pileups handles -- gap joins (c, end)--(c + 1, begin) -- with their spanning
+ * read alignments as (read, left LA, right LA) triples; *skipped = pile-ups of any other kind */
+int dh_scaffold_spanning(const dh_scaffold *s, const dh_la *las, int64_t n, dh_pileups **out, int32_t *skipped);
+
 /* the six alignment filters of `dentist collect` (collectPileUps/filter.d:122-356, order of
  * collectPileUps/package.d:130-141) on the read->contig LAs: LQ (averageErrorRate > max_align_err),
  * Improper (allowance), WeaklyAnchored (<= min_anchor bases outside the repeat mask rep_ptr / rep_iv of

@@ -261,3 +261,38 @@ def test_containers_of_collect_and_process(gpu_ctx, tmp_path):
                (r["left_aepos"], r["right_abpos"], r["ins_begin"], r["ins_end"])
         assert left["contig_a_len"] == w.contigs.length(gap) and left["contig_b_len"] == r["cons_len"]
         assert (left["seed"], right["seed"], left["tspace"]) == (1, 0, 126) and left["flags"] == r["comp"]
+
+
+@pytest.mark.gpu
+def test_scaffold_graph_builder_on_a_mapping(gpu_ctx):
+    """The scaffold-graph builder (pileups.d:173-208) on real mapping output: one gap join per gap of
+    the linear assembly, no forks; its spanning read alignments are a subset of what the spanning
+    collector pairs (the builder follows pileups.d:870 literally: a read whose first alignment starts
+    after read position 0 opens with an extension, so its two alignments become two extension entries
+    of the gap pile-up instead of one spanning entry), and every LA it uses is enabled."""
+    w = sim.Workload(2_000_000, 20, 20_000, 10_000, seed=77)
+    A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
+    mo = dentist_amd.default_align_opts(kmer_mod=4, k=20)
+    po = dentist_amd.default_process_opts()
+    las, trace = gpu_ctx.align_db(A, B, mo, select_best=True)
+    las, dropped, _ = dentist_amd.collect_filter(las, w.contigs.off, w.reads.off, po, inplace=True)
+    cand = dentist_amd.Pileups(las, w.contigs.off, po, candidates=True)
+    ig = np.stack([np.arange(w.contigs.n - 1), np.arange(1, w.contigs.n)], axis=1)
+    joins, ent = dentist_amd.scaffold_pileups(las, w.contigs.off, w.reads.off, ig, min_spanning_reads=po.min_reads)
+    gaps = joins[joins["type"] == 1]
+    assert len(gaps) == 20 and np.array_equal(gaps["contig1"], gaps["contig0"] + 1)
+    assert np.all(gaps["part0"] == 2) and np.all(gaps["part1"] == 1)
+    gp, skipped = dentist_amd.scaffold_spanning_pileups(las, w.contigs.off, w.reads.off, ig, min_spanning_reads=po.min_reads)
+    assert skipped == len(joins) - len(gaps)
+    (cl_a, cnt_a, tri_a), (cl_b, cnt_b, tri_b) = cand.flat(), gp.flat()
+    assert np.array_equal(cl_a, cl_b)
+    sa = set(map(tuple, np.asarray(tri_a).reshape(-1, 3).tolist()))
+    sb = set(map(tuple, np.asarray(tri_b).reshape(-1, 3).tolist()))
+    assert sb and sb <= sa
+    for e in ent:
+        assert not las[e["la0"]]["flags"] & 0x20 and (e["n"] == 1 or not las[e["la1"]]["flags"] & 0x20)
+    # the spanning reads the builder keeps start exactly at read position 0 on the read's strand
+    for rd, il, ir in sb:
+        first = las[il] if not las[il]["flags"] & 1 else las[ir]
+        blen = int(w.reads.off[rd + 1] - w.reads.off[rd])
+        assert (first["bbpos"] == 0) if not first["flags"] & 1 else (first["bepos"] == blen)
