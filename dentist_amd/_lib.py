@@ -84,6 +84,7 @@ SYMBOLS = [
     "dh_chaindb_nseeded", "dh_chaindb_seeded", "dh_chaindb_nlas", "dh_chaindb_las", "dh_chaindb_ntrace",
     "dh_chaindb_trace", "dh_chaindb_ninsertions", "dh_chaindb_insertions", "dh_chaindb_bases", "dh_chaindb_read_ids",
     "dh_insertions_write_db", "dh_pileups_write_db", "dh_pileups_flat", "dh_collect_filter",
+    "dh_db_mask_coverage", "dh_max_coverage_reads", "dh_max_improper_coverage_reads",
     "dh_default_scaffold_opts", "dh_scaffold_pileups", "dh_scaffold_npiles", "dh_scaffold_nentries", "dh_scaffold_joins",
     "dh_scaffold_entries", "dh_scaffold_destroy", "dh_scaffold_spanning",
 ]
@@ -354,6 +355,18 @@ class Db:
         """DBdust on the device: low-complexity windows are ORed into the soft mask."""
         _check(lib().dh_db_dust(self._h))
 
+    def mask_coverage(self, las, lower, upper, read_off=None, improper_only=False, allowance=0):
+        """dh_db_mask_coverage: regions with alignment coverage outside [lower, upper] join the soft mask
+        (maskRepetitiveRegions.d:238-430); improper_only counts improper alignments only."""
+        arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
+        ro = np.ascontiguousarray(read_off, dtype=np.int64) if read_off is not None else None
+        L = lib()
+        L.dh_db_mask_coverage.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32,
+                                          ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+        _check(L.dh_db_mask_coverage(self._h, arr.ctypes.data if len(arr) else None, len(arr),
+                                     ro.ctypes.data if ro is not None else None, len(ro) - 1 if ro is not None else 0,
+                                     int(lower), int(upper), 1 if improper_only else 0, int(allowance)))
+
     def get_mask(self):
         """The soft mask as (ptr int64[n+1], iv int32 (begin, end) pairs)."""
         n = lib().dh_db_nreads(self._h)
@@ -522,6 +535,22 @@ def collect_filter(las, contig_off, read_off, opts, repeat_mask=None, inplace=Fa
                                rp.ctypes.data if rp is not None else None, ri.ctypes.data if ri is not None else None,
                                ctypes.byref(opts), dropped.ctypes.data, used.ctypes.data))
     return arr, dropped, used
+
+
+def max_coverage_reads(read_coverage):
+    """--max-coverage-reads derived from --read-coverage (commandline.d:1876-1889)."""
+    L = lib()
+    L.dh_max_coverage_reads.argtypes = [ctypes.c_double]
+    L.dh_max_coverage_reads.restype = ctypes.c_int32
+    return int(L.dh_max_coverage_reads(float(read_coverage)))
+
+
+def max_improper_coverage_reads(read_coverage):
+    """--max-improper-coverage-reads derived from --read-coverage (commandline.d:1957-1970)."""
+    L = lib()
+    L.dh_max_improper_coverage_reads.argtypes = [ctypes.c_double]
+    L.dh_max_improper_coverage_reads.restype = ctypes.c_int32
+    return int(L.dh_max_improper_coverage_reads(float(read_coverage)))
 
 
 class ScaffoldOpts(ctypes.Structure):

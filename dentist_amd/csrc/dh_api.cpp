@@ -461,6 +461,62 @@ extern "C" int dh_db_dust(dh_db *db)
     return dh_db_dust_impl(db);
 }
 
+// maskRepetitiveRegions (commands/maskRepetitiveRegions.d:129-176, 238-430): sequence regions whose
+// alignment coverage lies outside [lower, upper] are ORed into the DB's soft mask; improper_only
+// restricts the coverage to alignments that are not proper within `allowance` (the second assessor of
+// the reads case, :157-176).  No alignments, no mask (:347-348).  The coverage is computed on the device:
+// +1 / -1 events, one scan, one classification pass.
+extern "C" int dh_db_mask_coverage(dh_db *db, const dh_la *las, int64_t n, const int64_t *read_off, int32_t nreads,
+                                   int32_t lower, int32_t upper, int32_t improper_only, int32_t allowance)
+{
+    if (!db || (n > 0 && !las) || n < 0 || (improper_only && !read_off))
+        return fail(DH_EINVAL, "dh_db_mask_coverage: bad argument");
+    for (int64_t i = 0; i < n; i++) {
+        const dh_la &l = las[i];
+        if (l.aread < 0 || l.aread >= db->n || (improper_only && (l.bread < 0 || l.bread >= nreads)))
+            return fail(DH_EINVAL, "dh_db_mask_coverage: id out of range");
+        const int64_t alen = db->h_off[(size_t)l.aread + 1] - db->h_off[(size_t)l.aread];
+        if (l.abpos < 0 || l.aepos > alen || l.abpos > l.aepos)
+            return fail(DH_EINVAL, "dh_db_mask_coverage: alignment outside its contig");
+    }
+    if (n == 0) return DH_OK;
+    dh_ctx *ctx = db->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    if (db->has_ix) db->ix.release();
+    db->has_ix = false;
+    if (int rc = dh_ensure_mask_bits(db)) return rc;
+    const int64_t nslots = db->total + db->n + 2;
+    DevBuf<uint32_t> d_cov, d_sums;
+    DevBuf<dh_la> d_las;
+    DevBuf<int64_t> d_roff;
+    HIPCHK(d_cov.alloc((size_t)nslots));
+    HIPCHK(d_sums.alloc((size_t)nslots / 2048 + 4));
+    HIPCHK(d_las.alloc((size_t)n));
+    HIPCHK(hipMemsetAsync(d_cov.p, 0, sizeof(uint32_t) * (size_t)nslots, st));
+    HIPCHK(hipMemcpyAsync(d_las.p, las, sizeof(dh_la) * (size_t)n, hipMemcpyHostToDevice, st));
+    if (improper_only) {
+        HIPCHK(d_roff.alloc((size_t)nreads + 1));
+        HIPCHK(hipMemcpyAsync(d_roff.p, read_off, sizeof(int64_t) * ((size_t)nreads + 1), hipMemcpyHostToDevice, st));
+    }
+    dhk_cov_events(st, (const DhLa *)d_las.p, n, db->d_off, d_roff.p, improper_only ? 1 : 0, allowance, d_cov.p);
+    HIPCHK(hipGetLastError());
+    dhk_scan(st, d_cov.p, nslots, d_sums.p);
+    HIPCHK(hipGetLastError());
+    dhk_cov_mask(st, d_cov.p, db->d_off, db->n, db->max_len, lower, upper, (uint32_t *)db->d_mask_bits);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    return DH_OK;
+}
+
+// --max-coverage-reads / --max-improper-coverage-reads from --read-coverage (commandline.d:1876-1889,
+// 1957-1970)
+extern "C" int32_t dh_max_coverage_reads(double x)
+{
+    return (int32_t)(x / std::log(std::log(std::log(0.1650612 * x + 5.9354533) / std::log(1.65))));
+}
+extern "C" int32_t dh_max_improper_coverage_reads(double x) { return (int32_t)(0.5 * x + std::exp(0.1875 * (8.0 - x))); }
+
 // the mask as intervals (what `DBdust` writes into the `dust` track, dazzler.d:4943-5170): ptr gets
 // n + 1 entries; iv may be NULL to size; returns the number of intervals or a negative error
 extern "C" int64_t dh_db_get_mask(dh_db *db, int64_t *ptr, int32_t *iv, int64_t iv_cap)

@@ -2262,6 +2262,55 @@ k_mask_slices(const uint32_t *__restrict__ src_bits, const int64_t *__restrict__
     }
 }
 
+// ---- alignment-coverage mask (maskRepetitiveRegions.d:238-430 BadAlignmentCoverageAssessor): the
+// alignment intervals become +1 / -1 events in a difference array laid out like the DB plus one slot
+// per sequence (an interval may end at the sequence's length); the event of position p sits at slot
+// p + 1, so the exclusive scan leaves the coverage of base p at slot p + 2; coverage drops to zero at every sequence end, so
+// one scan over the whole array serves all sequences.
+__global__ void __launch_bounds__(256)
+k_cov_events(const DhLa *__restrict__ las, int64_t n, const int64_t *__restrict__ off,
+             const int64_t *__restrict__ roff, int32_t improper_only, int32_t allowance,
+             uint32_t *__restrict__ diff)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DhLa l = las[i];
+    const int64_t o = off[l.aread];
+    if (improper_only) {  // AlignmentChain.isProper, base.d:537-557
+        const int32_t alen = (int32_t)(off[l.aread + 1] - o), blen = (int32_t)(roff[l.bread + 1] - roff[l.bread]);
+        const bool proper = (l.abpos <= allowance || l.bbpos <= allowance) &&
+                            (l.aepos + allowance >= alen || l.bepos + allowance >= blen);
+        if (proper) return;
+    }
+    if (l.aepos <= l.abpos) return;
+    const int64_t slot = o - off[0] + l.aread + 1;
+    atomicAdd(&diff[slot + l.abpos], 1u);
+    atomicAdd(&diff[slot + l.aepos], 0xFFFFFFFFu);
+}
+
+// bases whose coverage is outside [lower, upper] get their mask bit (runs of them are the intervals
+// the assessor's event machine emits: it masks from an event entering a bad zone to the next event
+// entering the ok zone, sequence ends closing a run)
+__global__ void __launch_bounds__(256)
+k_cov_mask_at(const uint32_t *__restrict__ cov, const int64_t *__restrict__ off, int32_t s0, int32_t nseq, int32_t lower,
+              int32_t upper, uint32_t *__restrict__ bits)
+{
+    if ((int32_t)blockIdx.y >= nseq) return;
+    const int32_t s = s0 + blockIdx.y;
+    const int64_t o = off[s], e = off[s + 1], slot = o - off[0] + s + 1;
+    // one thread per 32-bit word of the bitmap that the sequence touches
+    const int64_t w0 = o >> 5, w1 = (e + 31) >> 5;
+    for (int64_t w = w0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < w1; w += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t g0 = max(o, w << 5), g1 = min(e, (w << 5) + 32);
+        uint32_t m = 0;
+        for (int64_t g = g0; g < g1; g++) {
+            const int32_t c = (int32_t)cov[slot + (g - o) + 1];  // exclusive scan: events at positions <= g - o
+            if (c < lower || c > upper) m |= 1u << (g & 31);
+        }
+        if (m) atomicOr(&bits[w], m);
+    }
+}
+
 extern "C" {
 
 void dhk_revcomp(hipStream_t st, const uint8_t *src, uint8_t *dst, const int64_t *off, int32_t n,
@@ -2440,6 +2489,27 @@ void dhk_dust(hipStream_t st, const uint8_t *bases, const int64_t *off, const in
     hipLaunchKernelGGL(k_dust<16>, dim3(ntiles), dim3(256), 0, st, bases, off, tiles, ntiles, chunk, bits);
     hipLaunchKernelGGL(k_dust<32>, dim3(ntiles), dim3(256), 0, st, bases, off, tiles, ntiles, chunk, bits);
     hipLaunchKernelGGL(k_dust<64>, dim3(ntiles), dim3(256), 0, st, bases, off, tiles, ntiles, chunk, bits);
+}
+
+void dhk_cov_events(hipStream_t st, const DhLa *las, int64_t n, const int64_t *off, const int64_t *roff,
+                    int32_t improper_only, int32_t allowance, uint32_t *diff)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_cov_events, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, las, n, off, roff, improper_only,
+                       allowance, diff);
+}
+
+void dhk_cov_mask(hipStream_t st, const uint32_t *cov, const int64_t *off, int32_t nseq, int32_t max_len, int32_t lower,
+                  int32_t upper, uint32_t *bits)
+{
+    if (nseq <= 0) return;
+    int gx = (max_len / 32 + 255) / 256;
+    gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+    for (int32_t s0 = 0; s0 < nseq; s0 += 65535) {
+        const int32_t cnt = nseq - s0 < 65535 ? nseq - s0 : 65535;
+        // shifted views keep absolute offsets; the slot formula needs off[0] of the whole DB
+        hipLaunchKernelGGL(k_cov_mask_at, dim3(gx, cnt), dim3(256), 0, st, cov, off, s0, cnt, lower, upper, bits);
+    }
 }
 
 void dhk_mask_slices(hipStream_t st, const uint32_t *src_bits, const int64_t *src_off, const int32_t *sidx,

@@ -227,6 +227,19 @@ int32_t dh_pileups_count(const dh_pileups *p);
  * (read, left LA index, right LA index) triples */
 int32_t dh_pileups_get(const dh_pileups *p, int32_t i, int32_t *contig_left, const int32_t **triples);
 
+/* maskRepetitiveRegions (commands/maskRepetitiveRegions.d:129-176 assessRepeatStructure, :238-430
+ * BadAlignmentCoverageAssessor): ORs into the soft mask of `db` every region whose coverage by the
+ * alignment intervals [abpos, aepos) of `las` is < lower or > upper; improper_only != 0 counts only
+ * alignments that are not proper within `allowance` (base.d:537-557; needs read_off).  The command's mask
+ * is the union of one call over all alignments with --max-coverage-reads and one improper-only call with
+ * --max-improper-coverage-reads; read the result with dh_db_get_mask, write it with dh_dazz_write_mask.
+ * n == 0 masks nothing (:347-348). */
+int dh_db_mask_coverage(dh_db *db, const dh_la *las, int64_t n, const int64_t *read_off, int32_t nreads,
+                        int32_t lower, int32_t upper, int32_t improper_only, int32_t allowance);
+/* the bounds DENTIST derives from --read-coverage (commandline.d:1876-1889, 1957-1970) */
+int32_t dh_max_coverage_reads(double read_coverage);
+int32_t dh_max_improper_coverage_reads(double read_coverage);
+
 /* ---- the scaffold-graph pile-up builder of `dentist collect` (collectPileUps/pileups.d:173-208 build;
  * collectPileUps/package.d:174-184 is the call site).  Nodes are (contig, part) with part 0 = pre,
  * 1 = begin, 2 = end, 3 = post (scaffold.d:75-90); a read alignment is one seeded LA (an extension over

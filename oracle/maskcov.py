@@ -1,0 +1,70 @@
+"""TEST INFRASTRUCTURE -- CPU restatement of DENTIST's alignment-coverage mask.
+
+Only tests/ may import this module.  Restates commands/maskRepetitiveRegions.d:238-430
+(BadAlignmentCoverageAssessor.opCall, coverageZone, Masker) and :432-580 (CoverageChangeRange: events
+sorted by (contig, position), all events of one position folded into one change).  Pinned by the
+reference's unittests: coverageChanges (:591-631) and the assessor with limits (3, 5) (:394-410), both
+on the 33 intervals of :299-333 (tests/test_maskcov.py)."""
+import math
+
+
+def coverage_changes(alignment_intervals, contig_intervals):
+    """(contig, position, current coverage, new coverage) per distinct event position."""
+    if not alignment_intervals:
+        return []
+    ev = []
+    for c, b, e in alignment_intervals:
+        ev.append((c, b, 1))
+        ev.append((c, e, -1))
+    for c, b, e in contig_intervals:
+        ev.append((c, 0, 0))
+        ev.append((c, e - b, 0))
+    ev.sort()
+    out, cur, i = [], 0, 0
+    while i < len(ev):
+        c, p, _ = ev[i]
+        d = 0
+        while i < len(ev) and ev[i][0] == c and ev[i][1] == p:
+            d += ev[i][2]
+            i += 1
+        out.append((c, p, cur, cur + d))
+        cur += d
+    assert cur == 0
+    return out
+
+
+def bad_coverage_mask(alignment_intervals, contig_intervals, lower, upper):
+    """Masked (contig, begin, end) intervals, empty ones dropped (ReferenceRegion normalises)."""
+    changes = coverage_changes(alignment_intervals, contig_intervals)
+    if not changes:
+        return []
+
+    def zone(c):
+        return -1 if c < lower else (1 if c > upper else 0)
+    acc, masking, mc, ms = [], False, 0, 0
+    last = changes[0]
+    for ev in changes:
+        c, p, cur, new = ev
+        zc, zn = zone(cur), zone(new)
+        if masking and c != last[0]:
+            acc.append((mc, ms, last[1]))
+            masking = False
+        if not masking and (zn != 0 or (zc == 0 and zc != zn)):
+            masking, mc, ms = True, c, p
+        elif masking and zc != 0 and zn == 0:
+            acc.append((mc, ms, p))
+            masking = False
+        last = ev
+    if masking:
+        acc.append((mc, ms, last[1]))
+    return [iv for iv in acc if iv[2] > iv[1]]
+
+
+def max_coverage_reads(x):
+    """commandline.d:1876-1884."""
+    return int(x / math.log(math.log(math.log(0.1650612 * x + 5.9354533) / math.log(1.65))))
+
+
+def max_improper_coverage_reads(x):
+    """commandline.d:1957-1965."""
+    return int(0.5 * x + math.exp(0.1875 * (8.0 - x)))

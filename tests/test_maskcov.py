@@ -1,0 +1,95 @@
+"""Alignment-coverage mask of `dentist mask-repetitive-regions`: the reference's unittest
+vectors against the oracle (CPU) and against the product's device path (dh_db_mask_coverage), plus
+product == oracle on seeded random alignments."""
+import numpy as np
+import pytest
+
+import dentist_amd
+from dentist_amd import sim
+from oracle import maskcov as mc
+
+# maskRepetitiveRegions.d:299-333, 336-343
+ALIGNMENTS = [(1, 5, 18), (1, 5, 18), (1, 5, 20), (1, 10, 20), (1, 10, 30), (1, 10, 30), (1, 13, 30), (1, 20, 30),
+              (1, 20, 30), (1, 20, 30), (1, 24, 30), (2, 0, 3), (2, 0, 3), (2, 0, 5), (2, 0, 5), (2, 0, 15), (2, 0, 15),
+              (2, 0, 15), (2, 5, 15), (2, 5, 15), (2, 5, 15), (2, 9, 15), (3, 1, 4), (3, 2, 5), (3, 3, 6), (3, 4, 7),
+              (3, 5, 8), (3, 6, 9), (3, 7, 10), (3, 8, 11), (3, 9, 12), (3, 10, 13), (3, 11, 14)]
+CONTIGS = [(1, 0, 30), (2, 0, 15), (3, 0, 15)]
+# :394-410
+MASK_3_5 = [(1, 0, 5), (1, 10, 18), (1, 20, 30), (2, 0, 3), (2, 5, 15), (3, 0, 3), (3, 12, 15)]
+# :603-631
+CHANGES = [(1, 0, 0, 0), (1, 5, 0, 3), (1, 10, 3, 6), (1, 13, 6, 7), (1, 18, 7, 5), (1, 20, 5, 6), (1, 24, 6, 7),
+           (1, 30, 7, 0), (2, 0, 0, 7), (2, 3, 7, 5), (2, 5, 5, 6), (2, 9, 6, 7), (2, 15, 7, 0), (3, 0, 0, 0), (3, 1, 0, 1),
+           (3, 2, 1, 2), (3, 3, 2, 3), (3, 4, 3, 3), (3, 5, 3, 3), (3, 6, 3, 3), (3, 7, 3, 3), (3, 8, 3, 3), (3, 9, 3, 3),
+           (3, 10, 3, 3), (3, 11, 3, 3), (3, 12, 3, 2), (3, 13, 2, 1), (3, 14, 1, 0), (3, 15, 0, 0)]
+
+
+def test_oracle_coverage_changes_vector():
+    assert mc.coverage_changes(ALIGNMENTS, CONTIGS) == CHANGES
+
+
+def test_oracle_assessor_vector():
+    assert mc.bad_coverage_mask(ALIGNMENTS, CONTIGS, 3, 5) == MASK_3_5
+    assert mc.bad_coverage_mask([], CONTIGS, 3, 5) == []
+
+
+def test_coverage_bounds_from_read_coverage():
+    for x in (10.0, 25.0, 50.0, 87.5, 200.0):
+        assert dentist_amd.max_coverage_reads(x) == mc.max_coverage_reads(x)
+        assert dentist_amd.max_improper_coverage_reads(x) == mc.max_improper_coverage_reads(x)
+    assert mc.max_improper_coverage_reads(50.0) == 25 and mc.max_improper_coverage_reads(4.0) >= 4
+
+
+def _las_of(intervals, rlen=None):
+    las = np.zeros(len(intervals), dtype=dentist_amd.LA_DTYPE)
+    for i, (c, b, e) in enumerate(intervals):
+        las[i]["aread"], las[i]["abpos"], las[i]["aepos"], las[i]["bread"] = c - 1, b, e, i
+        las[i]["bbpos"], las[i]["bepos"] = 0, e - b
+    return las
+
+
+def _product_mask(ctx, lens, las, lower, upper, **kw):
+    db = ctx.db(sim.SeqDb.from_list([np.zeros(n, dtype=np.uint8) for n in lens]))
+    db.mask_coverage(las, lower, upper, **kw)
+    ptr, iv = db.get_mask()
+    iv = np.asarray(iv).reshape(-1, 2)
+    return [(c + 1, int(iv[j][0]), int(iv[j][1])) for c in range(len(lens)) for j in range(ptr[c], ptr[c + 1])]
+
+
+@pytest.mark.gpu
+def test_product_assessor_vector(gpu_ctx):
+    assert _product_mask(gpu_ctx, [30, 15, 15], _las_of(ALIGNMENTS), 3, 5) == MASK_3_5
+    assert _product_mask(gpu_ctx, [30, 15, 15], _las_of([]), 3, 5) == []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,lower,upper", [(1, 0, 8), (2, 2, 6), (3, 0, 3), (4, 5, 40)])
+def test_product_equals_oracle_on_random_alignments(gpu_ctx, seed, lower, upper):
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(50, 6000, 37).tolist()
+    iv = []
+    for _ in range(4000):
+        c = int(rng.integers(0, len(lens)))
+        b = int(rng.integers(0, lens[c]))
+        e = int(min(lens[c], b + rng.integers(1, 1500)))
+        iv.append((c + 1, b, e))
+    contigs = [(c + 1, 0, n) for c, n in enumerate(lens)]
+    assert _product_mask(gpu_ctx, lens, _las_of(iv), lower, upper) == mc.bad_coverage_mask(iv, contigs, lower, upper)
+
+
+@pytest.mark.gpu
+def test_improper_only_counts_improper_alignments(gpu_ctx):
+    """The second assessor of the reads case (maskRepetitiveRegions.d:157-176): only alignments that are
+    not proper within the allowance (base.d:537-557) enter the coverage."""
+    lens, rlen = [1000], 400
+    # (abpos, aepos, bbpos, bepos): proper ones reach a read end or a contig end on both sides
+    rows = [(0, 300, 100, 400), (100, 500, 0, 400), (200, 350, 50, 200), (220, 380, 100, 260), (240, 360, 150, 270),
+            (700, 1000, 0, 300)]
+    las = np.zeros(len(rows), dtype=dentist_amd.LA_DTYPE)
+    for i, (ab, ae, bb, be) in enumerate(rows):
+        las[i]["aread"], las[i]["bread"] = 0, i
+        las[i]["abpos"], las[i]["aepos"], las[i]["bbpos"], las[i]["bepos"] = ab, ae, bb, be
+    ro = np.arange(len(rows) + 1, dtype=np.int64) * rlen
+    got = _product_mask(gpu_ctx, lens, las, 0, 1, read_off=ro, improper_only=True, allowance=0)
+    improper = [(1, ab, ae) for ab, ae, bb, be in rows if not ((ab <= 0 or bb <= 0) and (ae >= 1000 or be >= rlen))]
+    assert improper == [(1, 200, 350), (1, 220, 380), (1, 240, 360)]
+    assert got == mc.bad_coverage_mask(improper, [(1, 0, 1000)], 0, 1) == [(1, 220, 360)]
