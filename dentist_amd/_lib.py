@@ -84,7 +84,7 @@ SYMBOLS = [
     "dh_chaindb_nseeded", "dh_chaindb_seeded", "dh_chaindb_nlas", "dh_chaindb_las", "dh_chaindb_ntrace",
     "dh_chaindb_trace", "dh_chaindb_ninsertions", "dh_chaindb_insertions", "dh_chaindb_bases", "dh_chaindb_read_ids",
     "dh_insertions_write_db", "dh_pileups_write_db", "dh_pileups_flat", "dh_collect_filter",
-    "dh_db_mask_coverage", "dh_max_coverage_reads", "dh_max_improper_coverage_reads",
+    "dh_propagate_mask", "dh_db_mask_coverage", "dh_max_coverage_reads", "dh_max_improper_coverage_reads",
     "dh_default_scaffold_opts", "dh_scaffold_pileups", "dh_scaffold_npiles", "dh_scaffold_nentries", "dh_scaffold_joins",
     "dh_scaffold_entries", "dh_scaffold_destroy", "dh_scaffold_spanning",
 ]
@@ -535,6 +535,30 @@ def collect_filter(las, contig_off, read_off, opts, repeat_mask=None, inplace=Fa
                                rp.ctypes.data if rp is not None else None, ri.ctypes.data if ri is not None else None,
                                ctypes.byref(opts), dropped.ctypes.data, used.ctypes.data))
     return arr, dropped, used
+
+
+def propagate_mask(las, trace, tspace, mask, ncontigs, read_off):
+    """dh_propagate_mask: the contig mask (ptr, iv) carried to the reads (propagateMask.d:136-305).
+    Returns (ptr int64[nreads + 1], iv int32[m, 2])."""
+    arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
+    tr = np.ascontiguousarray(trace, dtype=np.uint16)
+    mp = np.ascontiguousarray(mask[0], dtype=np.int64)
+    mi = np.ascontiguousarray(np.concatenate([np.asarray(mask[1], dtype=np.int32).reshape(-1), [0, 0]]), dtype=np.int32)
+    ro = np.ascontiguousarray(read_off, dtype=np.int64)
+    L = lib()
+    L.dh_propagate_mask.restype = ctypes.c_int64
+    L.dh_propagate_mask.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+                                    ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+                                    ctypes.c_void_p, ctypes.c_int64]
+    ptr = np.zeros(len(ro), dtype=np.int64)
+    args = (arr.ctypes.data if len(arr) else None, len(arr), tr.ctypes.data if len(tr) else None, int(tspace),
+            mp.ctypes.data, mi.ctypes.data, int(ncontigs), ro.ctypes.data, len(ro) - 1, ptr.ctypes.data)
+    m = L.dh_propagate_mask(*args, None, 0)
+    if m < 0:
+        _check(int(m))
+    iv = np.zeros((max(int(m), 1), 2), dtype=np.int32)
+    L.dh_propagate_mask(*args, iv.ctypes.data, int(m))
+    return ptr, iv[:int(m)]
 
 
 def max_coverage_reads(read_coverage):

@@ -1690,3 +1690,90 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
     *out = res;
     return DH_OK;
 }
+
+// ------------------------------------------------------------------------------------ propagate-mask
+// `dentist propagate-mask` (commands/propagateMask.d:136-305): every interval of the contig mask is cut
+// to the local alignments it intersects (:214-262) and carried over to the read through the trace
+// points -- begin rounded down, end rounded up (:264-293, translateTracePoint base.d:185-203) -- and
+// mirrored for complement alignments (:295-300); the union per read is the result (:307-313, Region
+// normalisation util/region.d:776-816: sorted, intersecting or touching intervals merged, empty ones
+// dropped).  Alignments are independent of each other, so they are spread over the host threads.
+// out_ptr gets nreads + 1 entries; out_iv may be NULL to size; returns the number of intervals.
+extern "C" int64_t dh_propagate_mask(const dh_la *las, int64_t n, const uint16_t *trace, int32_t tspace,
+                                     const int64_t *mask_ptr, const int32_t *mask_iv, int32_t ncontigs,
+                                     const int64_t *read_off, int32_t nreads, int64_t *out_ptr, int32_t *out_iv,
+                                     int64_t cap)
+{
+    if ((n > 0 && (!las || !trace)) || n < 0 || !mask_ptr || !read_off || !out_ptr || tspace < 1 || ncontigs < 0 || nreads < 0)
+        return dh_fail(DH_EINVAL, "dh_propagate_mask: bad argument");
+    struct Iv {
+        int32_t rd, b, e;
+    };
+    const int64_t grain = 4096, nchunks = (n + grain - 1) / grain;
+    std::vector<std::vector<Iv>> found((size_t)std::max<int64_t>(nchunks, 1));
+    std::atomic<int> bad{0};
+    dh_parallel_for(nchunks, 1, [&](int64_t clo, int64_t chi) {
+        for (int64_t c = clo; c < chi; c++) {
+            std::vector<Iv> &out = found[(size_t)c];
+            const int64_t i1 = std::min(n, (c + 1) * grain);
+            for (int64_t i = c * grain; i < i1; i++) {
+                const dh_la &l = las[i];
+                if (l.aread < 0 || l.aread >= ncontigs || l.bread < 0 || l.bread >= nreads || l.tlen < 0 || l.tlen % 2 ||
+                    l.tlen / 2 != (l.aepos + tspace - 1) / tspace - l.abpos / tspace) {
+                    bad = 1;
+                    continue;
+                }
+                const int64_t m0 = mask_ptr[l.aread], m1 = mask_ptr[l.aread + 1];
+                if (m1 <= m0) continue;
+                // first mask interval that ends after the alignment begins
+                int64_t lo = m0, hi = m1;
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (mask_iv[2 * mid + 1] <= l.abpos)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                const int32_t blen = (int32_t)(read_off[l.bread + 1] - read_off[l.bread]);
+                for (int64_t j = lo; j < m1 && mask_iv[2 * j] < l.aepos; j++) {
+                    const int32_t ib = std::max(mask_iv[2 * j], l.abpos), ie = std::min(mask_iv[2 * j + 1], l.aepos);
+                    int32_t ta, b0, b1;
+                    translate_trace_point(l, trace + l.toff, tspace, ib, 0, &ta, &b0);
+                    translate_trace_point(l, trace + l.toff, tspace, ie, 1, &ta, &b1);
+                    if (l.flags & DH_FLAG_COMP) {
+                        const int32_t x0 = blen - b1, x1 = blen - b0;
+                        b0 = x0;
+                        b1 = x1;
+                    }
+                    if (b1 > b0) out.push_back(Iv{l.bread, b0, b1});
+                }
+            }
+        }
+    });
+    if (bad) return dh_fail(DH_EINVAL, "dh_propagate_mask: id out of range or trace length does not fit the A interval");
+    std::vector<Iv> all;
+    for (auto &v : found) all.insert(all.end(), v.begin(), v.end());
+    std::sort(all.begin(), all.end(), [](const Iv &x, const Iv &y) {
+        return x.rd != y.rd ? x.rd < y.rd : (x.b != y.b ? x.b < y.b : x.e < y.e);
+    });
+    int64_t m = 0;
+    size_t at = 0;
+    for (int32_t r = 0; r < nreads; r++) {
+        out_ptr[r] = m;
+        while (at < all.size() && all[at].rd == r) {
+            int32_t b = all[at].b, e = all[at].e;
+            at++;
+            while (at < all.size() && all[at].rd == r && all[at].b <= e) {  // intersecting or touching
+                e = std::max(e, all[at].e);
+                at++;
+            }
+            if (out_iv && m < cap) {
+                out_iv[2 * m] = b;
+                out_iv[2 * m + 1] = e;
+            }
+            m++;
+        }
+    }
+    out_ptr[nreads] = m;
+    return m;
+}

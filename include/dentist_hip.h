@@ -240,6 +240,15 @@ int dh_db_mask_coverage(dh_db *db, const dh_la *las, int64_t n, const int64_t *r
 int32_t dh_max_coverage_reads(double read_coverage);
 int32_t dh_max_improper_coverage_reads(double read_coverage);
 
+/* `dentist propagate-mask` (commands/propagateMask.d:136-305): the contig mask (mask_ptr[ncontigs + 1],
+ * mask_iv = sorted disjoint (begin, end) pairs) carried over to the reads through the trace points of the
+ * read->contig LAs -- begin rounded down, end rounded up, mirrored for complement alignments -- and merged
+ * per read.  out_ptr gets nreads + 1 entries, out_iv (begin, end) pairs on the forward read; out_iv may be
+ * NULL to size (cap = pairs it can hold); returns the number of intervals or a negative error.  Host only. */
+int64_t dh_propagate_mask(const dh_la *las, int64_t n, const uint16_t *trace, int32_t tspace, const int64_t *mask_ptr,
+                          const int32_t *mask_iv, int32_t ncontigs, const int64_t *read_off, int32_t nreads,
+                          int64_t *out_ptr, int32_t *out_iv, int64_t cap);
+
 /* ---- the scaffold-graph pile-up builder of `dentist collect` (collectPileUps/pileups.d:173-208 build;
  * collectPileUps/package.d:174-184 is the call site).  Nodes are (contig, part) with part 0 = pre,
  * 1 = begin, 2 = end, 3 = post (scaffold.d:75-90); a read alignment is one seeded LA (an extension over

@@ -68,3 +68,57 @@ def max_coverage_reads(x):
 def max_improper_coverage_reads(x):
     """commandline.d:1957-1965."""
     return int(0.5 * x + math.exp(0.1875 * (8.0 - x)))
+
+
+def propagate_mask(las, trace, tspace, mask_ptr, mask_iv, read_len):
+    """commands/propagateMask.d:136-305 restated literally: per contig the two-pointer walk over the mask
+    intervals and the alignments sorted by their begin on the contig, intervals cut to the alignment and
+    translated through the trace points (floor / ceil, oracle/seq_las_trace.c restating base.d:185-203),
+    mirrored for complement alignments; then the Region union per read (util/region.d:776-816).
+    Returns {read: [(begin, end), ...]}."""
+    import ctypes
+    import numpy as np
+    from . import pyoracle as oz
+
+    def translate(la, pos, mode):
+        a, b = ctypes.c_int32(), ctypes.c_int32()
+        t = np.ascontiguousarray(trace[la["toff"]:la["toff"] + la["tlen"]], dtype=np.uint16)
+        oz.lib().oz_translate_trace_point_a(int(la["abpos"]), int(la["aepos"]), int(la["bbpos"]), tspace, t.ctypes.data,
+                                            len(t) // 2, int(pos), mode, ctypes.byref(a), ctypes.byref(b))
+        return b.value
+    raw = []
+    contigs = sorted(set(int(a) for a in las["aread"]))
+    for c in contigs:
+        mi = [(int(mask_iv[j][0]), int(mask_iv[j][1])) for j in range(mask_ptr[c], mask_ptr[c + 1])]
+        la_c = sorted((la for la in las if la["aread"] == c), key=lambda la: int(la["abpos"]))
+        m = k = 0
+        while m < len(mi) and k < len(la_c):
+            la = la_c[k]
+            if mi[m][1] <= la["abpos"]:
+                m += 1
+            elif la["aepos"] <= mi[m][0]:
+                k += 1
+            else:
+                inter = [iv for iv in mi[m:] if iv[0] < la["aepos"]]
+                for x, (b, e) in enumerate(inter):
+                    if x == 0:
+                        b = max(b, int(la["abpos"]))
+                    if x == len(inter) - 1:
+                        e = min(e, int(la["aepos"]))
+                    pb, pe = translate(la, b, 0), translate(la, e, 1)
+                    if la["flags"] & 1:
+                        bl = int(read_len[la["bread"]])
+                        pb, pe = bl - pe, bl - pb
+                    raw.append((int(la["bread"]), pb, pe))
+                k += 1
+    raw.sort()
+    out = {}
+    for r, b, e in raw:
+        if e <= b:
+            continue
+        ivs = out.setdefault(r, [])
+        if ivs and b <= ivs[-1][1]:
+            ivs[-1] = (ivs[-1][0], max(ivs[-1][1], e))
+        else:
+            ivs.append((b, e))
+    return out

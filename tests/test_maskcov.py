@@ -93,3 +93,44 @@ def test_improper_only_counts_improper_alignments(gpu_ctx):
     improper = [(1, ab, ae) for ab, ae, bb, be in rows if not ((ab <= 0 or bb <= 0) and (ae >= 1000 or be >= rlen))]
     assert improper == [(1, 200, 350), (1, 220, 380), (1, 240, 360)]
     assert got == mc.bad_coverage_mask(improper, [(1, 0, 1000)], 0, 1) == [(1, 220, 360)]
+
+
+@pytest.mark.gpu
+def test_propagate_mask_matches_the_oracle_on_a_mapping(gpu_ctx):
+    """`dentist propagate-mask` (propagateMask.d:136-305): a contig mask carried to the reads through
+    the trace points of a real mapping; product == oracle, and against the truth of the simulation every
+    propagated interval covers the read bases that came from the masked contig bases (within a trace
+    tile on either side)."""
+    w = sim.Workload(400_000, 4, 3000, 6000, seed=5)
+    A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
+    las, trace = gpu_ctx.align_db(A, B, dentist_amd.default_align_opts(kmer_mod=4, k=20), select_best=True)
+    rng = np.random.default_rng(9)
+    ptr, iv = [0], []
+    for c in range(w.contigs.n):
+        n = int(w.contigs.off[c + 1] - w.contigs.off[c])
+        cuts = np.sort(rng.choice(np.arange(1, n), size=24, replace=False))
+        for b, e in cuts.reshape(-1, 2):
+            iv.append((int(b), int(min(e, b + 900))))
+        ptr.append(len(iv))
+    ptr, iv = np.array(ptr, dtype=np.int64), np.array(iv, dtype=np.int32)
+    rlen = np.diff(w.reads.off)
+    optr, oiv = dentist_amd.propagate_mask(las, trace, 100, (ptr, iv), w.contigs.n, w.reads.off)
+    exp = mc.propagate_mask(las, trace, 100, ptr, iv, rlen)
+    got = {r: [tuple(x) for x in oiv[optr[r]:optr[r + 1]].tolist()] for r in range(w.reads.n) if optr[r + 1] > optr[r]}
+    assert got == exp and len(got) > 100
+    # truth: read r covers genome [s, e) on strand st; forward-read position of genome position x is x - s
+    # (st = 0) or e - x (st = 1), up to the indels of the read
+    checked = 0
+    for la in las[:: max(1, len(las) // 400)]:
+        r, c = int(la["bread"]), int(la["aread"])
+        s, e, st = (int(x) for x in w.read_truth[r][:3])
+        for b, en in iv[ptr[c]:ptr[c + 1]]:
+            gb, ge = max(int(w.contig_start[c]) + max(b, la["abpos"]), s), min(int(w.contig_start[c]) + min(en, la["aepos"]), e)
+            if ge - gb < 50:
+                continue
+            mid = (gb + ge) // 2
+            pos = mid - s if st == 0 else e - mid
+            pos = pos * rlen[r] / max(e - s, 1)
+            assert any(x0 - 150 <= pos <= x1 + 150 for x0, x1 in got.get(r, [])), (r, c, b, en)
+            checked += 1
+    assert checked > 50
