@@ -160,10 +160,10 @@ def main():
     t0 = time.perf_counter()
     runs = []
     for _ in range(args.steps):
+        if runs:  # only the last step's results are inspected: the earlier buffers go back to the pools
+            for key in ("las", "rec", "bases"):  # before the next step allocates its own
+                runs[-1].pop(key, None)
         runs.append(step())
-        if len(runs) > 1:  # only the last step's results are inspected: release the earlier buffers
-            for key in ("las", "rec", "bases"):
-                runs[-2].pop(key, None)
     barrier()
     dt = time.perf_counter() - t0
 
