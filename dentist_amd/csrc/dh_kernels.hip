@@ -753,7 +753,7 @@ __device__ void seed_item(const DbView &B, const IndexView &ix,
 // Persistent blocks: the grid is sized to the resident capacity of the chip and every block pulls
 // items from an atomic queue (no per-item block launch, dynamic balance over ragged read lengths).
 template <int LCAP>
-__global__ void __launch_bounds__(SEED_THREADS, (LCAP > 0 && LCAP <= 2048) ? 8 : (LCAP == 16384 ? 2 : 4))
+__global__ void __launch_bounds__(SEED_THREADS, (LCAP > 0 && LCAP <= 2048) ? 6 : (LCAP == 16384 ? 2 : 4))
 k_seed(DbView B, IndexView ix, DhOpts o, int32_t read0,
        int32_t nreads, DhCand *__restrict__ cand_out, int32_t *__restrict__ ncand_out,
        int32_t *__restrict__ nhits_out, int32_t *__restrict__ status, uint64_t *__restrict__ gbuf,
