@@ -201,7 +201,9 @@ def main():
             if tj.get("workload") == args.workload and tj.get("mapping_kmer_mod") == args.kmer_mod and \
                     tj.get("mapping_k") == args.map_k:
                 traffic = tj["hbm_bytes_per_step"] / max(1, cum["wave_launches"])
-        seed_bytes = 2.0 * read_bp * (1.0 + 64.0 / max(1, args.kmer_mod))
+        # one rolling pass per read serves both strands (canonical k-mers): 1 B per read base + one
+        # 64 B directory line per sampled k-mer
+        seed_bytes = 1.0 * read_bp * (1.0 + 64.0 / max(1, args.kmer_mod))
         seed_ms = mean(lambda r: r["ast"].ms_seed)
         out = {
             "metric": "gap-bases closed/sec",
@@ -287,7 +289,7 @@ def cpu_baseline(w, last, mopts, popts, args, gap_bases, read_bp_total):
     t_index, _ = map_reads(1)
     t_probe, bp_probe = map_reads(min(w.reads.n, 4 * cores))
     rate = bp_probe / max(t_probe - t_index, 1e-3)
-    n_map = int(min(w.reads.n, max(4 * cores, 0.4 * args.cpu_seconds * rate / (read_bp_total / max(w.nreads_total, 1)))))
+    n_map = int(min(w.reads.n, max(4 * cores, 0.15 * args.cpu_seconds * rate / (read_bp_total / max(w.nreads_total, 1)))))
     t_map, bp_map = map_reads(n_map)
     map_bp_s = bp_map / max(t_map - t_index, 1e-3)   # marginal rate, index build excluded
 
