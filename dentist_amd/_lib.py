@@ -84,7 +84,7 @@ SYMBOLS = [
     "dh_chaindb_nseeded", "dh_chaindb_seeded", "dh_chaindb_nlas", "dh_chaindb_las", "dh_chaindb_ntrace",
     "dh_chaindb_trace", "dh_chaindb_ninsertions", "dh_chaindb_insertions", "dh_chaindb_bases", "dh_chaindb_read_ids",
     "dh_insertions_write_db", "dh_pileups_write_db", "dh_pileups_flat", "dh_collect_filter",
-    "dh_propagate_mask", "dh_db_mask_coverage", "dh_max_coverage_reads", "dh_max_improper_coverage_reads",
+    "dh_validate_regions", "dh_propagate_mask", "dh_db_mask_coverage", "dh_max_coverage_reads", "dh_max_improper_coverage_reads",
     "dh_default_scaffold_opts", "dh_scaffold_pileups", "dh_scaffold_npiles", "dh_scaffold_nentries", "dh_scaffold_joins",
     "dh_scaffold_entries", "dh_scaffold_destroy", "dh_scaffold_spanning",
 ]
@@ -559,6 +559,37 @@ def propagate_mask(las, trace, tspace, mask, ncontigs, read_off):
     iv = np.zeros((max(int(m), 1), 2), dtype=np.int32)
     L.dh_propagate_mask(*args, iv.ctypes.data, int(m))
     return ptr, iv[:int(m)]
+
+
+REGION_DTYPE = np.dtype([("contig", "<i4"), ("begin", "<i4"), ("end", "<i4")])
+REGION_REPORT_DTYPE = np.dtype([("num_spanning_reads", "<i4"), ("weak_bp", "<i4"), ("is_valid", "<i4"),
+                                ("ctx_begin", "<i4"), ("ctx_end", "<i4")])
+
+
+def validate_regions(las, contig_off, regions, min_coverage_reads, min_spanning_reads=3, region_context=1000,
+                     weak_coverage_window=500):
+    """dh_validate_regions (`dentist validate-regions`, validateRegions.d:325-512).  regions: (contig,
+    begin, end) rows.  Returns (reports REGION_REPORT_DTYPE[nregions], weak (contig, begin, end) int32[m, 3])."""
+    arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
+    co = np.ascontiguousarray(contig_off, dtype=np.int64)
+    rg = np.zeros(len(regions), dtype=REGION_DTYPE)
+    r = np.asarray(regions, dtype=np.int32).reshape(-1, 3)
+    rg["contig"], rg["begin"], rg["end"] = r[:, 0], r[:, 1], r[:, 2]
+    rep = np.zeros(len(rg), dtype=REGION_REPORT_DTYPE)
+    L = lib()
+    L.dh_validate_regions.restype = ctypes.c_int64
+    L.dh_validate_regions.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+                                      ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+    args = (arr.ctypes.data if len(arr) else None, len(arr), co.ctypes.data, len(co) - 1, rg.ctypes.data if len(rg) else None,
+            len(rg), int(region_context), int(weak_coverage_window), int(min_coverage_reads), int(min_spanning_reads),
+            rep.ctypes.data if len(rg) else None)
+    m = L.dh_validate_regions(*args, None, 0)
+    if m < 0:
+        _check(int(m))
+    weak = np.zeros((max(int(m), 1), 3), dtype=np.int32)
+    L.dh_validate_regions(*args, weak.ctypes.data, int(m))
+    return rep, weak[:int(m)]
 
 
 def max_coverage_reads(read_coverage):

@@ -212,3 +212,96 @@ extern "C" int dh_collect_filter(dh_la *las, int64_t n, const int64_t *contig_of
     if (read_used) memcpy(read_used, used.data(), (size_t)nreads);
     return DH_OK;
 }
+
+// ------------------------------------------------------------------------------------ validate-regions
+// `dentist validate-regions` (commands/validateRegions.d:141-203, 274-312, 325-512): a region -- a closed
+// gap on the gap-closed assembly -- extended by `region_context` on both sides (clipped to the contig)
+// is valid iff (a) every sliding window of `weak_coverage_window` bases inside it is spanned by at least
+// `min_coverage_reads` local alignments (:423-505) and (b) at least `min_spanning_reads` alignments span
+// the whole extended region (:409-420).  `las` = the reads aligned to that assembly, grouped by aread
+// (the command insists on the sort, :165-168).  An alignment spans the window [w, w + W) iff
+// abpos <= w and w + W <= aepos (it opened at or before w and has not closed before the window's end),
+// so the count per window start is a prefix sum over +1 at abpos, -1 at aepos - W + 1.  Regions are
+// independent: host threads take one each.  weak_iv (may be NULL; cap pairs) receives the weak-coverage
+// mask of all regions as (contig, begin, end) triples in region order (the command's union is left to the
+// caller, e.g. dh_db_set_mask); returns the number of triples or a negative error.
+extern "C" int64_t dh_validate_regions(const dh_la *las, int64_t n, const int64_t *contig_off, int32_t ncontigs,
+                                       const dh_region *regions, int32_t nregions, int32_t region_context,
+                                       int32_t weak_coverage_window, int32_t min_coverage_reads,
+                                       int32_t min_spanning_reads, dh_region_report *reports, int32_t *weak_iv,
+                                       int64_t cap)
+{
+    if ((n > 0 && !las) || !contig_off || (nregions > 0 && (!regions || !reports)) || n < 0 || nregions < 0 ||
+        region_context < 0 || weak_coverage_window < 1)
+        return dh_fail(DH_EINVAL, "dh_validate_regions: bad argument");
+    for (int64_t i = 0; i < n; i++) {
+        if (las[i].aread < 0 || las[i].aread >= ncontigs) return dh_fail(DH_EINVAL, "dh_validate_regions: contig id out of range");
+        if (i > 0 && las[i].aread < las[i - 1].aread)
+            return dh_fail(DH_EINVAL, "dh_validate_regions: reads-alignment must be sorted at least by a-read ID");
+    }
+    std::vector<int64_t> first((size_t)ncontigs + 1, 0);
+    for (int64_t i = 0; i < n; i++) first[(size_t)las[i].aread + 1]++;
+    for (int32_t c = 0; c < ncontigs; c++) first[(size_t)c + 1] += first[(size_t)c];
+    for (int32_t r = 0; r < nregions; r++)
+        if (regions[r].contig < 0 || regions[r].contig >= ncontigs || regions[r].begin < 0 || regions[r].end < regions[r].begin)
+            return dh_fail(DH_EINVAL, "dh_validate_regions: bad region");
+    std::vector<std::vector<int32_t>> weak((size_t)std::max(nregions, 1));
+    const int32_t W = weak_coverage_window;
+    dh_parallel_for(nregions, 1, [&](int64_t rlo, int64_t rhi) {
+        std::vector<int32_t> diff;
+        for (int64_t r = rlo; r < rhi; r++) {
+            const dh_region &rg = regions[r];
+            const int32_t clen = (int32_t)(contig_off[rg.contig + 1] - contig_off[rg.contig]);
+            const int32_t cb = rg.begin > region_context ? rg.begin - region_context : 0;
+            const int32_t ce = std::min(rg.end + region_context, clen);
+            dh_region_report &rep = reports[r];
+            rep.ctx_begin = cb;
+            rep.ctx_end = ce;
+            rep.num_spanning_reads = 0;
+            rep.weak_bp = 0;
+            const int64_t l0 = first[(size_t)rg.contig], l1 = first[(size_t)rg.contig + 1];
+            // (b) alignments spanning the extended region
+            for (int64_t i = l0; i < l1; i++)
+                if (las[i].abpos < cb && ce < las[i].aepos) rep.num_spanning_reads++;
+            // (a) windows [w, w + W) for w = cb .. ce - W (window clipped to the extended region)
+            const int32_t wlen = std::min(W, ce - cb), nw = (ce - cb) - wlen + 1;
+            std::vector<int32_t> &wk = weak[(size_t)r];
+            bool any = false;
+            for (int64_t i = l0; i < l1 && !any; i++) any = las[i].abpos < ce && cb < las[i].aepos;
+            if (any && nw > 0 && wlen > 0) {  // no alignment bound in sight: the command's loop does not run (:471)
+                diff.assign((size_t)nw + 1, 0);
+                for (int64_t i = l0; i < l1; i++) {
+                    if (!(las[i].abpos < ce && cb < las[i].aepos)) continue;
+                    const int32_t w0 = std::max(las[i].abpos, cb) - cb, w1 = las[i].aepos - wlen - cb;  // last spanned start
+                    if (w1 < w0 || w0 >= nw) continue;
+                    diff[(size_t)w0]++;
+                    diff[(size_t)std::min(w1 + 1, nw)]--;
+                }
+                int32_t cov = 0;
+                for (int32_t w = 0; w < nw; w++) {
+                    cov += diff[(size_t)w];
+                    if (cov >= min_coverage_reads) continue;
+                    const int32_t b = cb + w, e = cb + w + wlen;
+                    if (wk.empty() || wk[wk.size() - 1] < b) {
+                        wk.push_back(b);
+                        wk.push_back(e);
+                    } else
+                        wk[wk.size() - 1] = e;
+                }
+                for (size_t x = 0; x + 1 < wk.size(); x += 2) rep.weak_bp += wk[x + 1] - wk[x];
+            }
+            rep.is_valid = rep.num_spanning_reads >= min_spanning_reads && rep.weak_bp == 0;
+        }
+    });
+    int64_t m = 0;
+    for (int32_t r = 0; r < nregions; r++)
+        for (size_t x = 0; x + 1 < weak[(size_t)r].size(); x += 2) {
+            if (weak_iv && m < cap) {
+                weak_iv[3 * m] = regions[r].contig;
+                weak_iv[3 * m + 1] = weak[(size_t)r][x];
+                weak_iv[3 * m + 2] = weak[(size_t)r][x + 1];
+            }
+            m++;
+        }
+    return m;
+}

@@ -249,6 +249,20 @@ int64_t dh_propagate_mask(const dh_la *las, int64_t n, const uint16_t *trace, in
                           const int32_t *mask_iv, int32_t ncontigs, const int64_t *read_off, int32_t nreads,
                           int64_t *out_ptr, int32_t *out_iv, int64_t cap);
 
+/* `dentist validate-regions` (commands/validateRegions.d:141-203 region context, :325-512 RegionValidator):
+ * every region (closed gap on the gap-closed assembly) extended by region_context (default 1000,
+ * commandline.d:2411) is valid iff every window of weak_coverage_window bases (default 500, :2497) inside
+ * it is spanned by >= min_coverage_reads alignments (from --read-coverage: 0.5 * x / ploidy, :2080-2085)
+ * and >= min_spanning_reads alignments span the whole extended region.  las: reads aligned to that
+ * assembly, grouped by aread.  reports[nregions]; weak_iv (may be NULL, cap triples) = weakly covered
+ * (contig, begin, end) per region in region order (--weak-coverage-mask); returns their number.  Host only. */
+typedef struct dh_region { int32_t contig, begin, end; } dh_region;
+typedef struct dh_region_report { int32_t num_spanning_reads, weak_bp, is_valid, ctx_begin, ctx_end; } dh_region_report;
+int64_t dh_validate_regions(const dh_la *las, int64_t n, const int64_t *contig_off, int32_t ncontigs,
+                            const dh_region *regions, int32_t nregions, int32_t region_context,
+                            int32_t weak_coverage_window, int32_t min_coverage_reads, int32_t min_spanning_reads,
+                            dh_region_report *reports, int32_t *weak_iv, int64_t cap);
+
 /* ---- the scaffold-graph pile-up builder of `dentist collect` (collectPileUps/pileups.d:173-208 build;
  * collectPileUps/package.d:174-184 is the call site).  Nodes are (contig, part) with part 0 = pre,
  * 1 = begin, 2 = end, 3 = post (scaffold.d:75-90); a read alignment is one seeded LA (an extension over

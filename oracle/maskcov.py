@@ -122,3 +122,42 @@ def propagate_mask(las, trace, tspace, mask_ptr, mask_iv, read_len):
         else:
             ivs.append((b, e))
     return out
+
+
+def validate_region(alignments, region, contig_len, region_context, window, min_coverage_reads, min_spanning_reads):
+    """commands/validateRegions.d:325-512 (RegionValidator) restated literally for one region.
+    alignments: (abpos, aepos) of the local alignments on the region's contig; region = (begin, end).
+    Returns (numSpanningReads, weak-coverage intervals, isValid, regionWithContext)."""
+    cb = region[0] - region_context if region[0] > region_context else 0      # :178-190
+    ce = min(region[1] + region_context, contig_len)
+    spanning = sum(1 for b, e in alignments if b < cb and ce < e)                # :409-420
+    bounds = []                                                                  # :440-454
+    for idx, (b, e) in enumerate(alignments):
+        if b < ce and cb < e:
+            bounds.append((b, 1, idx))
+            bounds.append((e, -1, idx))
+    bounds.sort(key=lambda t: (t[0], t[1], t[2]))
+    weak, begins = [], {}
+    wb, we = cb, min(cb + window, ce)                                            # window & regionWithContext
+    while we <= ce and bounds:                                                   # :471-502
+        trimmed = False
+        for i, (pos, kind, idx) in enumerate(bounds):
+            if pos < we:
+                if kind == 1:
+                    begins[idx] = pos
+                else:
+                    begins.pop(idx, None)
+            else:
+                bounds = bounds[i:]
+                trimmed = True
+                break
+        n_span = sum(1 for p in begins.values() if p <= wb)
+        if n_span < min_coverage_reads:
+            if not weak or weak[-1][1] < wb:
+                weak.append([wb, we])
+            else:
+                weak[-1][1] = we
+        wb += 1
+        we += 1
+    weak = [tuple(x) for x in weak]
+    return spanning, weak, spanning >= min_spanning_reads and not weak, (cb, ce)

@@ -134,3 +134,51 @@ def test_propagate_mask_matches_the_oracle_on_a_mapping(gpu_ctx):
             assert any(x0 - 150 <= pos <= x1 + 150 for x0, x1 in got.get(r, [])), (r, c, b, en)
             checked += 1
     assert checked > 50
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_validate_regions_matches_the_literal_restatement(seed):
+    """`dentist validate-regions` (validateRegions.d:325-512): the prefix-sum formulation of the product
+    against the literal window loop of the oracle on random alignments around random regions."""
+    rng = np.random.default_rng(seed)
+    lens = [9000, 400, 15000, 2500]
+    co = np.concatenate([[0], np.cumsum(lens)])
+    rows = []
+    for c, n in enumerate(lens):
+        for _ in range(int(rng.integers(0, 120))):
+            b = int(rng.integers(0, n))
+            rows.append((c, b, int(min(n, b + rng.integers(1, 6000)))))
+    rows.sort(key=lambda r: r[0])
+    las = np.zeros(len(rows), dtype=dentist_amd.LA_DTYPE)
+    for i, (c, b, e) in enumerate(rows):
+        las[i]["aread"], las[i]["abpos"], las[i]["aepos"], las[i]["bread"] = c, b, e, i
+    regions = []
+    for c, n in enumerate(lens):
+        for _ in range(4):
+            b = int(rng.integers(0, n))
+            regions.append((c, b, int(min(n, b + rng.integers(0, 800)))))
+    for ctx, win, mincov, minspan in [(1000, 500, 3, 3), (200, 50, 1, 1), (0, 700, 5, 2), (300, 5000, 2, 1)]:
+        rep, weak = dentist_amd.validate_regions(las, co, regions, mincov, min_spanning_reads=minspan, region_context=ctx,
+                                                 weak_coverage_window=win)
+        exp_weak = []
+        for r, (c, b, e) in enumerate(regions):
+            al = [(x[1], x[2]) for x in rows if x[0] == c]
+            sp, wk, ok, (cb, ce) = mc.validate_region(al, (b, e), lens[c], ctx, win, mincov, minspan)
+            assert (rep[r]["num_spanning_reads"], bool(rep[r]["is_valid"]), rep[r]["ctx_begin"], rep[r]["ctx_end"]) == (sp, ok, cb, ce)
+            assert rep[r]["weak_bp"] == sum(y - x for x, y in wk)
+            exp_weak += [(c, x, y) for x, y in wk]
+        assert [tuple(x) for x in weak.tolist()] == exp_weak
+
+
+def test_validate_regions_on_a_closed_gap_layout():
+    """A well covered closed gap is valid; a gap that only two reads cross is not (too few spanning reads
+    and a weakly covered stretch that contains the gap)."""
+    co = np.array([0, 20000], dtype=np.int64)
+    good = [(0, 500 * i, 500 * i + 9000) for i in range(12)]
+    las = np.zeros(len(good) + 2, dtype=dentist_amd.LA_DTYPE)
+    for i, (c, b, e) in enumerate(good + [(0, 11000, 19000), (0, 11500, 19500)]):
+        las[i]["aread"], las[i]["abpos"], las[i]["aepos"], las[i]["bread"] = c, b, e, i
+    rep, weak = dentist_amd.validate_regions(las, co, [(0, 6000, 6100), (0, 17000, 17100)], 3)
+    assert rep[0]["is_valid"] == 1 and rep[0]["num_spanning_reads"] >= 3 and rep[0]["weak_bp"] == 0
+    assert rep[1]["is_valid"] == 0 and rep[1]["num_spanning_reads"] == 2 and rep[1]["weak_bp"] > 0
+    assert all(c == 0 and b <= 17000 and e >= 17100 for c, b, e in weak.tolist())
