@@ -126,12 +126,12 @@ def main():
         B.drop_cache()
         ctx.cum_stats(reset=True)
         t0 = time.perf_counter()
-        las, trace = ctx.align_db(A, B, mopts, select_best=True)
+        # mapping + the six alignment filters of `dentist collect` (filter.d:122-356): per-read decisions,
+        # so every rank filters the alignments of its own reads, chunk by chunk on the host while the
+        # device maps the next chunk (dh_map_reads)
+        las, trace, dropped = ctx.map_reads(A, B, mopts, popts)
         ast = ctx.align_stats()
         t1 = time.perf_counter()
-        # the six alignment filters of `dentist collect` (filter.d:122-356): per-read decisions, so
-        # every rank filters the alignments of its own reads
-        las, dropped, _ = dentist_amd.collect_filter(las, w.contigs.off, w.reads.off, popts, inplace=True)
         if world == 1:
             piles = dentist_amd.Pileups(las, w.contigs.off, popts)
             t2 = time.perf_counter()

@@ -84,7 +84,7 @@ SYMBOLS = [
     "dh_chaindb_nseeded", "dh_chaindb_seeded", "dh_chaindb_nlas", "dh_chaindb_las", "dh_chaindb_ntrace",
     "dh_chaindb_trace", "dh_chaindb_ninsertions", "dh_chaindb_insertions", "dh_chaindb_bases", "dh_chaindb_read_ids",
     "dh_insertions_write_db", "dh_pileups_write_db", "dh_pileups_flat", "dh_collect_filter",
-    "dh_validate_regions", "dh_propagate_mask", "dh_db_mask_coverage", "dh_max_coverage_reads", "dh_max_improper_coverage_reads",
+    "dh_map_reads", "dh_validate_regions", "dh_propagate_mask", "dh_db_mask_coverage", "dh_max_coverage_reads", "dh_max_improper_coverage_reads",
     "dh_default_scaffold_opts", "dh_scaffold_pileups", "dh_scaffold_npiles", "dh_scaffold_nentries", "dh_scaffold_joins",
     "dh_scaffold_entries", "dh_scaffold_destroy", "dh_scaffold_spanning",
 ]
@@ -298,6 +298,11 @@ class Context:
         return las, trace
 
 
+    def map_reads(self, A, B, opts, popts, first=0, count=None, repeat_mask=None):
+        """dh_map_reads: the mapping pass (chain flags as with select_best) with the six `collect` filters
+        applied chunk by chunk on the host while the device maps on.  Returns (las, trace, dropped[6])."""
+        return _map_reads(self, A, B, opts, popts, first, count, repeat_mask)
+
     def align_db_block(self, A, B, first, count, opts, select_best=False, raw=False):
         """`damapper ref reads.<block>`: reads [first, first + count) of B against A.  raw=True
         returns the library handle (for merge_las) instead of numpy views."""
@@ -308,6 +313,26 @@ class Context:
             return h
         las, trace, _ = _take_la_set(h)
         return las, trace
+
+
+def _map_reads(ctx, A, B, opts, popts, first=0, count=None, repeat_mask=None):
+    rp = ri = None
+    if repeat_mask is not None:
+        rp = np.ascontiguousarray(repeat_mask[0], dtype=np.int64)
+        ri = np.ascontiguousarray(np.concatenate([repeat_mask[1], [0, 0]]), dtype=np.int32)
+    L = lib()
+    n = L.dh_db_nreads(B._h)
+    count = n - first if count is None else count
+    dropped = np.zeros(6, dtype=np.int64)
+    h = ctypes.c_void_p()
+    L.dh_map_reads.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                               ctypes.POINTER(AlignOpts), ctypes.POINTER(ProcessOpts), ctypes.c_void_p, ctypes.c_void_p,
+                               ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+    _check(L.dh_map_reads(ctx._h, A._h, B._h, int(first), int(count), ctypes.byref(opts), ctypes.byref(popts),
+                          rp.ctypes.data if rp is not None else None, ri.ctypes.data if ri is not None else None,
+                          dropped.ctypes.data, ctypes.byref(h)))
+    las, trace, _ = _take_la_set(h)
+    return las, trace, dropped
 
 
 def merge_las(handles):

@@ -820,8 +820,11 @@ extern "C" int dh_align_db(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts 
     return dh_align_db_ex(ctx, A, B, opts, want_best, 1, out);
 }
 
+// per-chunk hook: called on a host thread of its own with the records of a finished chunk (B-major,
+// whole reads) while the device works on the next chunk; the records may be modified in place
+typedef std::function<void(dh_la *, int64_t)> ChunkHook;
 static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t count, const dh_align_opts *opts,
-                       int32_t want_best, int32_t want_sorted, dh_la_set **out);
+                       int32_t want_best, int32_t want_sorted, dh_la_set **out, const ChunkHook *hook = nullptr);
 
 // `damapper <ref> <reads>.<block>` (snakemake/Snakefile:1143-1170): the reads [first, first + count)
 // of B against all of A; read ids in the records are those of the whole DB, as in a block's .las
@@ -831,6 +834,39 @@ extern "C" int dh_align_db_block(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first,
     if (!B || first < 0 || count < 0 || (int64_t)first + count > B->n)
         return fail(DH_EINVAL, "dh_align_db_block: block outside the DB");
     return align_range(ctx, A, B, first, count, opts, want_best, 1, out);
+}
+
+// The mapping pass with the alignment filters of `dentist collect` applied on the way
+// (damapper per read block, Snakefile:1143-1170, + collectPileUps/filter.d:122-356): all six filters
+// decide per read, so the records of a finished chunk of reads are filtered on a host thread while the
+// device maps the next chunk.  Same records and flags as dh_align_db_block(want_best = 1) followed by
+// dh_collect_filter.  rep_ptr / rep_iv: repeat mask of the contigs for WeaklyAnchored (may be NULL).
+extern "C" int dh_map_reads(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_t first, int32_t count,
+                            const dh_align_opts *opts, const dh_process_opts *popts, const int64_t *rep_ptr,
+                            const int32_t *rep_iv, int64_t *dropped6, dh_la_set **out)
+{
+    if (!contigs || !reads || !popts || first < 0 || count < 0 || (int64_t)first + count > reads->n)
+        return fail(DH_EINVAL, "dh_map_reads: bad argument");
+    std::mutex mu;
+    int64_t dropped[6] = {0, 0, 0, 0, 0, 0};
+    int hook_rc = DH_OK;
+    const ChunkHook hook = [&](dh_la *las, int64_t n) {
+        int64_t d[6];
+        const int rc = dh_collect_filter(las, n, contigs->h_off.data(), contigs->n, reads->h_off.data(), reads->n, rep_ptr,
+                                         rep_iv, popts, d, nullptr);
+        std::lock_guard<std::mutex> lk(mu);
+        if (rc != DH_OK) hook_rc = rc;
+        for (int k = 0; k < 6; k++) dropped[k] += d[k];
+    };
+    const int rc = align_range(ctx, contigs, reads, first, count, opts, 1, 1, out, &hook);
+    if (rc != DH_OK) return rc;
+    if (hook_rc != DH_OK) {
+        dh_la_set_destroy(*out);
+        *out = nullptr;
+        return hook_rc;
+    }
+    if (dropped6) memcpy(dropped6, dropped, sizeof(dropped));
+    return DH_OK;
 }
 
 int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, int32_t want_best,
@@ -881,7 +917,7 @@ static int chunk_copies(dh_ctx *ctx, dh_db *B, int32_t r0, int32_t r1, bool want
 }
 
 static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t count, const dh_align_opts *opts,
-                       int32_t want_best, int32_t want_sorted, dh_la_set **out)
+                       int32_t want_best, int32_t want_sorted, dh_la_set **out, const ChunkHook *hook)
 {
     auto now_ms = [] {
         return (double)std::chrono::duration_cast<std::chrono::microseconds>(
@@ -917,6 +953,17 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             if (!ok) delete r;
         }
     } guard{res};
+    // hook tasks in flight; joined before the result can move or is handed out (also on error paths)
+    struct Tasks {
+        std::vector<std::thread> v;
+        void join()
+        {
+            for (auto &t : v)
+                if (t.joinable()) t.join();
+            v.clear();
+        }
+        ~Tasks() { join(); }
+    } tasks;
 
     HIPCHK(hipEventRecord(ctx->ev[0], st));
     // A sequences start at multiples of 4096 on the virtual axis and sepv is one too, so the
@@ -1182,6 +1229,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
                 res->la.reserve((size_t)(f * totals[0]) + 1024);
                 res->trace.reserve((size_t)(f * totals[1]) + 65536);
             }
+            if (l0 + totals[0] > res->la.capacity()) tasks.join();  // the records are about to move
             res->la.resize(l0 + totals[0]);
             res->trace.resize(t0 + totals[1]);
             lap(4);
@@ -1195,6 +1243,12 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         HIPCHK(hipEventRecord(ctx->ev[5], st));
         HIPCHK(hipStreamSynchronize(st));
         lap(5);
+        if (hook && totals[0] > 0) {
+            dh_la *p = res->la.data() + (res->la.size() - totals[0]);
+            const int64_t cnt = (int64_t)totals[0];
+            const ChunkHook h = *hook;
+            tasks.v.emplace_back([h, p, cnt] { h(p, cnt); });
+        }
         float t;
         HIPCHK(hipEventElapsedTime(&t, ctx->ev[2], ctx->ev[3]));
         ms_seed += t;
@@ -1211,6 +1265,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     stats.wave_cells = (int64_t)counters[0];
     stats.alignments = (int64_t)counters[1];
 
+    tasks.join();
     if (want_best) select_best(res->la);
     if (want_sorted) lasort(res, A->n);
     w_post = now_ms() - w_a;

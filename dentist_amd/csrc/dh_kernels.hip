@@ -1499,10 +1499,10 @@ __device__ __forceinline__ int32_t hread_fast(int32_t v, int32_t l, int hb)
 template <int G>
 __device__ __forceinline__ int32_t hmax_i32(int32_t v, int hb)
 {
-    v = max(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, false));
-    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, false));
-    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, false));
-    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true));
     if (G == 16) return v;  // a DPP row is a group: every lane holds its row's maximum
     const int32_t r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
     const int32_t r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);

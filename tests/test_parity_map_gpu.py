@@ -342,3 +342,32 @@ def test_ont_like_error_profile_of_configs4(gpu_ctx, err, width, xdrop):
     np.add.at(covered, las["bread"], las["bepos"] - las["bbpos"])
     lens = np.diff(reads.off)
     assert np.mean(covered >= 0.9 * lens) > 0.93   # reads across a gap lose the gap itself
+
+
+@pytest.mark.gpu
+def test_map_reads_equals_mapping_followed_by_the_collect_filters(gpu_ctx, monkeypatch):
+    """dh_map_reads filters the records of every finished chunk on a host thread while the device maps
+    the next chunk; records, flags, traces and per-stage counts equal dh_align_db(select_best) followed
+    by dh_collect_filter, however the reads are chunked."""
+    w = sim.Workload(1_500_000, 12, 6000, 8000, seed=31)
+    A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
+    mo = dentist_amd.default_align_opts(kmer_mod=4, k=20, width=14, xdrop=60)
+    po = dentist_amd.default_process_opts()
+    las, trace = gpu_ctx.align_db(A, B, mo, select_best=True)
+    exp, exp_dropped, _ = dentist_amd.collect_filter(las, w.contigs.off, w.reads.off, po)
+    assert exp_dropped.sum() > 0
+    for chunk in ("512", "3000", None):
+        if chunk is None:
+            monkeypatch.delenv("DH_ALIGN_CHUNK", raising=False)
+        else:
+            monkeypatch.setenv("DH_ALIGN_CHUNK", chunk)
+        got, gtrace, dropped = gpu_ctx.map_reads(A, B, mo, po)
+        assert np.array_equal(dropped, exp_dropped)
+        assert np.array_equal(got, exp) and np.array_equal(gtrace, trace)
+    # a block of the reads: ids of the whole DB, filters see the whole DB's read lengths
+    monkeypatch.setenv("DH_ALIGN_CHUNK", "1024")
+    first, count = 1500, 2500
+    got, gtrace, dropped = gpu_ctx.map_reads(A, B, mo, po, first=first, count=count)
+    sel = (exp["bread"] >= first) & (exp["bread"] < first + count)
+    for f in ("aread", "bread", "abpos", "aepos", "bbpos", "bepos", "diffs", "flags", "tlen"):
+        assert np.array_equal(got[f], exp[f][sel]), f
