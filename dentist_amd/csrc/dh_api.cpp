@@ -198,6 +198,9 @@ extern "C" int dh_ctx_create(int32_t device, void *stream, dh_ctx **out)
             if (!ok && c) {
                 for (auto &e : c->ev)
                     if (e) (void)hipEventDestroy(e);
+                for (auto &e : c->cev)
+                    if (e) (void)hipEventDestroy(e);
+                if (c->cstream) (void)hipStreamDestroy(c->cstream);
                 if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
                 delete c;
             }
@@ -214,6 +217,8 @@ extern "C" int dh_ctx_create(int32_t device, void *stream, dh_ctx **out)
         c->own_stream = true;
     }
     for (auto &e : c->ev) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
+    for (auto &e : c->cev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     cguard.ok = true;
     *out = c;
     return DH_OK;
@@ -224,8 +229,12 @@ extern "C" void dh_ctx_destroy(dh_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->cstream) (void)hipStreamSynchronize(c->cstream);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->cev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->cstream) (void)hipStreamDestroy(c->cstream);
     for (auto &a : c->arena)
         if (a.p) dh_dev_free(a.p);
     dh_dev_trim();
@@ -955,15 +964,18 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     } guard{res};
     // hook tasks in flight; joined before the result can move or is handed out (also on error paths)
     struct Tasks {
+        hipStream_t cs;
         std::vector<std::thread> v;
         void join()
         {
+            (void)hipStreamSynchronize(cs);  // copies in flight land first
             for (auto &t : v)
                 if (t.joinable()) t.join();
             v.clear();
         }
         ~Tasks() { join(); }
-    } tasks;
+    } tasks{ctx->cstream, {}};
+    int64_t nchunk_done = 0;
 
     HIPCHK(hipEventRecord(ctx->ev[0], st));
     // A sequences start at multiples of 4096 on the virtual axis and sepv is one too, so the
@@ -1215,7 +1227,10 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
                 }
         }
         lap(3);
+        hipEvent_t copied = nullptr;
         if (totals[0] > 0) {
+            // the compacted buffers are reused: the previous chunk's copies must have left them
+            HIPCHK(hipStreamSynchronize(ctx->cstream));
             SCR(13, d_laout, totals[0])
             SCR(14, d_trout, totals[1])
             const size_t l0 = res->la.size(), t0 = res->trace.size();
@@ -1229,25 +1244,38 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
                 res->la.reserve((size_t)(f * totals[0]) + 1024);
                 res->trace.reserve((size_t)(f * totals[1]) + 65536);
             }
-            if (l0 + totals[0] > res->la.capacity()) tasks.join();  // the records are about to move
+            if (l0 + totals[0] > res->la.capacity() || t0 + totals[1] > res->trace.capacity())
+                tasks.join();  // the records are about to move: copies and hooks in flight finish first
             res->la.resize(l0 + totals[0]);
             res->trace.resize(t0 + totals[1]);
             lap(4);
+            // device-to-host on the copy stream: it overlaps the next chunk's kernels
+            hipEvent_t compacted = ctx->cev[nchunk_done & 1];
+            copied = ctx->cev[2 + (nchunk_done & 1)];
+            HIPCHK(hipEventRecord(compacted, st));
+            HIPCHK(hipStreamWaitEvent(ctx->cstream, compacted, 0));
             HIPCHK(hipMemcpyAsync(res->la.data() + l0, d_laout, sizeof(dh_la) * (size_t)totals[0],
-                                  hipMemcpyDeviceToHost, st));
+                                  hipMemcpyDeviceToHost, ctx->cstream));
             if (totals[1] > 0)
                 HIPCHK(hipMemcpyAsync(res->trace.data() + t0, d_trout, sizeof(uint16_t) * (size_t)totals[1],
-                                      hipMemcpyDeviceToHost, st));
+                                      hipMemcpyDeviceToHost, ctx->cstream));
+            HIPCHK(hipEventRecord(copied, ctx->cstream));
             res->d_trace = (t0 == 0 && item0 == item_first && ni == nitems_total) ? d_trout : nullptr;
         }
         HIPCHK(hipEventRecord(ctx->ev[5], st));
         HIPCHK(hipStreamSynchronize(st));
         lap(5);
+        nchunk_done++;
         if (hook && totals[0] > 0) {
             dh_la *p = res->la.data() + (res->la.size() - totals[0]);
             const int64_t cnt = (int64_t)totals[0];
             const ChunkHook h = *hook;
-            tasks.v.emplace_back([h, p, cnt] { h(p, cnt); });
+            const int dev = ctx->device;
+            tasks.v.emplace_back([h, p, cnt, copied, dev] {
+                (void)hipSetDevice(dev);
+                (void)hipEventSynchronize(copied);  // the records of this chunk have arrived
+                h(p, cnt);
+            });
         }
         float t;
         HIPCHK(hipEventElapsedTime(&t, ctx->ev[2], ctx->ev[3]));

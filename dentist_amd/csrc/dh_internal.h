@@ -46,6 +46,10 @@ struct dh_ctx {
     bool own_stream = false;
     int ncu = 0;
     hipEvent_t ev[6] = {};
+    // second stream for the device-to-host copies of a chunk's records (they overlap the next chunk's
+    // kernels); cev[0..1]: compaction done (main stream), cev[2..3]: copy done (copy stream), by chunk parity
+    hipStream_t cstream = nullptr;
+    hipEvent_t cev[4] = {};
     dh_align_stats stats = {};
     dh_cum_stats cum = {};
     // grow-only device scratch buffers reused across calls (hipMalloc/hipFree of GB-sized
