@@ -1071,74 +1071,120 @@ extern "C" int dh_crop_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_
     // the device from the reads DB (src 0) and the contigs DB (src 1)
     std::vector<PartDescH> parts;
     int32_t pile_max_len = 0;
-    for (int32_t p = 0; p < np; p++) {
-        dh_insertion &r = c->rec[(size_t)p];
-        memset(&r, 0, sizeof(r));
-        const int32_t g = piles->contig_left[(size_t)p];
-        if (g < 0 || g + 1 >= contigs->n) return dh_fail(DH_EINVAL, "dh_crop_pileups: gap outside the contigs DB");
-        r.contig_left = g;
-        r.ref_read = r.ref_read_id = -1;
-        r.crop_left = r.crop_right = -1;
-        const std::vector<int32_t> &tr3 = piles->triples[(size_t)p];
-        const int32_t ne = (int32_t)tr3.size() / 3;
-        int32_t llo = 0, lhi = INT32_MAX, rlo = 0, rhi = INT32_MAX;
-        for (int32_t e = 0; e < ne; e++) {
-            const int32_t iL = tr3[(size_t)e * 3 + 1], iR = tr3[(size_t)e * 3 + 2];
-            if (iL < 0 || iL >= n || iR < 0 || iR >= n) return dh_fail(DH_EINVAL, "dh_crop_pileups: LA index out of range");
-            const dh_la &L = las[iL], &R = las[iR];
-            llo = std::max(llo, L.abpos);
-            lhi = std::min(lhi, L.aepos);
-            rlo = std::max(rlo, R.abpos);
-            rhi = std::min(rhi, R.aepos);
-        }
-        const int32_t cll = (int32_t)(contigs->h_off[(size_t)g + 1] - contigs->h_off[(size_t)g]);
-        const int32_t clr = (int32_t)(contigs->h_off[(size_t)g + 2] - contigs->h_off[(size_t)g + 1]);
-        const int32_t cropL = common_trace_point(llo, lhi, cll, tsm, false);
-        const int32_t cropR = common_trace_point(rlo, rhi, clr, tsm, true);
-        r.crop_left = cropL;
-        r.crop_right = cropR;
-        if (cropL < 0 || cropR < 0) {
-            r.status = DH_PILE_NO_COMMON_TRACE_POINT;
-            continue;
-        }
-        // fetchSupportPatches, cropper.d:224-262
+    // pile-ups are independent: host threads compute crop points and read slices (the trace walks are
+    // cache misses into the mapping's trace array), the parts are laid out serially afterwards
+    struct Slice {
+        int32_t e, rd, lrd, b0, b1, comp;
+    };
+    struct PileCrop {
         int32_t lp0 = 0, lp1 = 0, rp0 = 0, rp1 = 0;
-        if (cll - cropL < o.min_anchor) {
-            lp0 = std::max(0, cll - o.min_anchor);
-            lp1 = cropL;
-        }
-        if (cropR < o.min_anchor) {
-            rp0 = cropR;
-            rp1 = std::min(clr, o.min_anchor);
-        }
-        for (int32_t e = 0; e < ne; e++) {
-            const int32_t rd = tr3[(size_t)e * 3];
-            const int64_t lrd = (int64_t)rd - read_first;
-            if (lrd < 0 || lrd >= reads->n) continue;  // held by another rank
-            if (!trace) return dh_fail(DH_EINVAL, "dh_crop_pileups: trace is NULL");
-            const dh_la &L = las[tr3[(size_t)e * 3 + 1]], &R = las[tr3[(size_t)e * 3 + 2]];
-            const int32_t bL = translate_floor_b(L, trace + L.toff, tsm, cropL);
-            const int32_t bR = translate_floor_b(R, trace + R.toff, tsm, cropR);
-            const int32_t rl = (int32_t)(reads->h_off[(size_t)lrd + 1] - reads->h_off[(size_t)lrd]);
-            int32_t b0 = bL, b1 = bR;
-            const bool comp = (L.flags & DH_FLAG_COMP) != 0;
-            if (comp) {  // getCroppingSlice, cropper.d:533-538
-                b0 = rl - bR;
-                b1 = rl - bL;
+        std::vector<Slice> sl;
+    };
+    std::vector<PileCrop> pc((size_t)np);
+    std::atomic<int> err{0};  // 1 gap outside, 2 LA index, 3 trace NULL, 4 trace does not fit
+    dh_parallel_for(np, 4, [&](int64_t plo, int64_t phi) {
+        for (int64_t p = plo; p < phi; p++) {
+            dh_insertion &r = c->rec[(size_t)p];
+            memset(&r, 0, sizeof(r));
+            const int32_t g = piles->contig_left[(size_t)p];
+            if (g < 0 || g + 1 >= contigs->n) {
+                err = 1;
+                continue;
             }
-            if (b1 - b0 < 14) continue;  // records shorter than 14 bp are dropped (dazzler.d:150)
-            if (b0 < 0 || b1 > rl) return dh_fail(DH_EINVAL, "dh_crop_pileups: trace does not fit its read");
+            r.contig_left = g;
+            r.ref_read = r.ref_read_id = -1;
+            r.crop_left = r.crop_right = -1;
+            const std::vector<int32_t> &tr3 = piles->triples[(size_t)p];
+            const int32_t ne = (int32_t)tr3.size() / 3;
+            int32_t llo = 0, lhi = INT32_MAX, rlo = 0, rhi = INT32_MAX;
+            bool bad = false;
+            for (int32_t e = 0; e < ne; e++) {
+                const int32_t iL = tr3[(size_t)e * 3 + 1], iR = tr3[(size_t)e * 3 + 2];
+                if (iL < 0 || iL >= n || iR < 0 || iR >= n) {
+                    bad = true;
+                    break;
+                }
+                const dh_la &L = las[iL], &R = las[iR];
+                llo = std::max(llo, L.abpos);
+                lhi = std::min(lhi, L.aepos);
+                rlo = std::max(rlo, R.abpos);
+                rhi = std::min(rhi, R.aepos);
+            }
+            if (bad) {
+                err = 2;
+                continue;
+            }
+            const int32_t cll = (int32_t)(contigs->h_off[(size_t)g + 1] - contigs->h_off[(size_t)g]);
+            const int32_t clr = (int32_t)(contigs->h_off[(size_t)g + 2] - contigs->h_off[(size_t)g + 1]);
+            const int32_t cropL = common_trace_point(llo, lhi, cll, tsm, false);
+            const int32_t cropR = common_trace_point(rlo, rhi, clr, tsm, true);
+            r.crop_left = cropL;
+            r.crop_right = cropR;
+            if (cropL < 0 || cropR < 0) {
+                r.status = DH_PILE_NO_COMMON_TRACE_POINT;
+                continue;
+            }
+            PileCrop &q = pc[(size_t)p];
+            // fetchSupportPatches, cropper.d:224-262
+            if (cll - cropL < o.min_anchor) {
+                q.lp0 = std::max(0, cll - o.min_anchor);
+                q.lp1 = cropL;
+            }
+            if (cropR < o.min_anchor) {
+                q.rp0 = cropR;
+                q.rp1 = std::min(clr, o.min_anchor);
+            }
+            for (int32_t e = 0; e < ne; e++) {
+                const int32_t rd = tr3[(size_t)e * 3];
+                const int64_t lrd = (int64_t)rd - read_first;
+                if (lrd < 0 || lrd >= reads->n) continue;  // held by another rank
+                if (!trace) {
+                    err = 3;
+                    break;
+                }
+                const dh_la &L = las[tr3[(size_t)e * 3 + 1]], &R = las[tr3[(size_t)e * 3 + 2]];
+                const int32_t bL = translate_floor_b(L, trace + L.toff, tsm, cropL);
+                const int32_t bR = translate_floor_b(R, trace + R.toff, tsm, cropR);
+                const int32_t rl = (int32_t)(reads->h_off[(size_t)lrd + 1] - reads->h_off[(size_t)lrd]);
+                int32_t b0 = bL, b1 = bR;
+                const bool comp = (L.flags & DH_FLAG_COMP) != 0;
+                if (comp) {  // getCroppingSlice, cropper.d:533-538
+                    b0 = rl - bR;
+                    b1 = rl - bL;
+                }
+                if (b1 - b0 < 14) continue;  // records shorter than 14 bp are dropped (dazzler.d:150)
+                if (b0 < 0 || b1 > rl) {
+                    err = 4;
+                    break;
+                }
+                q.sl.push_back(Slice{e, rd, (int32_t)lrd, b0, b1, comp ? 1 : 0});
+            }
+        }
+    });
+    switch (err.load()) {
+        case 1: return dh_fail(DH_EINVAL, "dh_crop_pileups: gap outside the contigs DB");
+        case 2: return dh_fail(DH_EINVAL, "dh_crop_pileups: LA index out of range");
+        case 3: return dh_fail(DH_EINVAL, "dh_crop_pileups: trace is NULL");
+        case 4: return dh_fail(DH_EINVAL, "dh_crop_pileups: trace does not fit its read");
+        default: break;
+    }
+    for (int32_t p = 0; p < np; p++) {
+        const PileCrop &q = pc[(size_t)p];
+        const int32_t g = piles->contig_left[(size_t)p];
+        dh_insertion &r = c->rec[(size_t)p];
+        for (const Slice &x : q.sl) {
+            const bool comp = x.comp != 0;
             int64_t dst = c->off.back();
             // getSingleReadPatch, cropper.d:363-378: complement reads get the reverse-complemented
             // patches in swapped positions
-            const int32_t pre_c = comp ? g + 1 : g, pre0 = comp ? rp0 : lp0, pre1 = comp ? rp1 : lp1;
-            const int32_t post_c = comp ? g : g + 1, post0 = comp ? lp0 : rp0, post1 = comp ? lp1 : rp1;
+            const int32_t pre_c = comp ? g + 1 : g, pre0 = comp ? q.rp0 : q.lp0, pre1 = comp ? q.rp1 : q.lp1;
+            const int32_t post_c = comp ? g : g + 1, post0 = comp ? q.lp0 : q.rp0, post1 = comp ? q.lp1 : q.rp1;
             if (pre1 > pre0) {
                 parts.push_back(PartDescH{1, pre_c, pre0, pre1 - pre0, comp ? 1 : 0, 0, dst});
                 dst += pre1 - pre0;
             }
-            parts.push_back(PartDescH{0, (int32_t)lrd, b0, b1 - b0, 0, 0, dst});
-            dst += b1 - b0;
+            parts.push_back(PartDescH{0, x.lrd, x.b0, x.b1 - x.b0, 0, 0, dst});
+            dst += x.b1 - x.b0;
             if (post1 > post0) {
                 parts.push_back(PartDescH{1, post_c, post0, post1 - post0, comp ? 1 : 0, 0, dst});
                 dst += post1 - post0;
@@ -1146,8 +1192,8 @@ extern "C" int dh_crop_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_
             pile_max_len = std::max<int32_t>(pile_max_len, (int32_t)(dst - c->off.back()));
             c->off.push_back(dst);
             c->pile.push_back(p);
-            c->entry.push_back(e);
-            c->read_id.push_back(rd);
+            c->entry.push_back(x.e);
+            c->read_id.push_back(x.rd);
             r.nreads++;
         }
     }
