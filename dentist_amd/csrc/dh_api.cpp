@@ -665,7 +665,9 @@ static int build_index(dh_db *A, int32_t k, int32_t sepv, int32_t kmer_mod)
     const int32_t keybits = 2 * k + ceil_log2((uint64_t)A->ngroups);
     if (keybits > 62) return fail(DH_EINVAL, "index: k-mer key does not fit 62 bits");
     int32_t pbits = ceil_log2((uint64_t)std::max<int64_t>(nk, 1));
-    pbits = std::max(10, std::min(pbits, std::min(keybits, 27)));
+    int32_t pmax = 27;
+    if (const char *e = getenv("DH_INDEX_PBITS")) pmax = std::max(10, std::min(30, atoi(e)));  // development
+    pbits = std::max(10, std::min(pbits, std::min(keybits, pmax)));
     ix.pbits = pbits;
     ix.shift = keybits - pbits;
     // the largest key is ngroups * 4^k - 1, so buckets up to (that >> shift) are addressable
