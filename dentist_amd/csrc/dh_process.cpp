@@ -1351,6 +1351,7 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
         if (crop->off.back() > 0)
             HIPCHK(hipMemcpyAsync(d_bases, crop->bases.data(), (size_t)crop->off.back(), hipMemcpyHostToDevice, st));
         HIPCHK(hipStreamSynchronize(st));
+        lap("cropped reads upload");
     }
     dh_db *pile = nullptr;
     {
@@ -1359,6 +1360,7 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
             slen[x] = (int32_t)(crop->off[(size_t)keep[x] + 1] - crop->off[(size_t)keep[x]]);
         if (int rc = dh_db_from_slices(ctx, crop->dev, keep, sbeg, slen, sgroup, &pile)) return rc;
         dbg.dbs.push_back(pile);
+        lap("pile DB slices");
         if (o.dust)  // DBdust pileup.db; daligner ... -mdust (package.d:476-482)
             if (int rc = dh_db_dust_impl(pile)) return rc;
     }

@@ -202,19 +202,36 @@ def emulate_ranks(gens):
 def sharded_process_steps(ctx, contigs_db, reads_db, read_first, contig_off, las, trace, popts, rank, world):
     """Generator form of sharded_process: yields ("all_gather", bytes) / ("all_to_all", [bytes per
     destination]) and expects the list of arrays received (by source rank) to be sent back."""
+    import os
+    import time
     from . import Cropped, Pileups
+    _t = [time.perf_counter()]
+    _laps = []
+
+    def lap(what):
+        if os.environ.get("DH_TRACE"):
+            t = time.perf_counter()
+            _laps.append("%s %.1f" % (what, (t - _t[0]) * 1e3))
+            _t[0] = t
     cands = Pileups(las, contig_off, popts, candidates=True)
     mine = pack_candidates(cands, las)
+    lap("candidates")
     blobs = yield ("all_gather", mine.view(np.uint8))
     per_rank = [np.frombuffer(b.tobytes(), dtype=CAND_DTYPE) for b in blobs]
+    _t[0] = time.perf_counter()
     glas, gaps, counts, triples = merge_candidates(per_rank)
+    lap("merge")
     # the entries of this rank inside glas are copies of its own records: their toff still points
     # into its own trace array, which is all dh_crop_pileups needs (other ranks' traces stay there)
     piles = Pileups.from_flat(gaps, counts, triples).select(glas, popts)
+    lap("select")
     owner = assign_owners(pile_costs(piles, glas), world)
+    lap("owners")
     crop = Cropped.crop(ctx, contigs_db, reads_db, read_first, glas, trace, piles, popts)
+    lap("crop")
     rec, cpile, centry, cread, coff, cbases = crop.arrays()
     crop.close()
+    lap("crop arrays")
     # cropped reads to the owners of their pile-ups; reads are in (pile, entry) order, so the reads of
     # one destination form a few contiguous runs of the base array
     lens = np.diff(coff).astype(np.int32)
@@ -226,7 +243,9 @@ def sharded_process_steps(ctx, contigs_db, reads_db, read_first, contig_off, las
         head["pile"], head["entry"], head["read"], head["len"] = cpile[sel], centry[sel], cread[sel], lens[sel]
         per_dest.append(np.concatenate([np.asarray([len(sel)], dtype=np.int64).view(np.uint8), head.view(np.uint8)]
                                        + _runs(cbases, coff, sel)))
+    lap("pack per dest")
     got = yield ("all_to_all", per_dest)
+    _t[0] = time.perf_counter()
     heads, seqs = [], []
     for blob in got:
         k = int(blob[:8].view(np.int64)[0])
@@ -247,10 +266,15 @@ def sharded_process_steps(ctx, contigs_db, reads_db, read_first, contig_off, las
     o_bases = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
     own = Cropped.create(rec[mine_piles], renum[head["pile"][order]], head["entry"][order], head["read"][order],
                          o_off, o_bases)
+    lap("unpack + create")
     lrec, lbases = own.process(ctx, contigs_db, popts)
+    lap("process")
     own.close()
     blobs = yield ("all_gather", _pack_closed(lrec, lbases))
     grec, gbases, origin = _unpack_closed(blobs)
+    if _laps and rank == 0:
+        import sys
+        print("[sharded rank 0] " + ", ".join(_laps), file=sys.stderr)
     order = np.argsort(grec["contig_left"], kind="stable")   # insertions.sort(): by start node
     info = {"piles": len(rec), "owned": len(mine_piles), "candidates": int(sum(len(p) for p in per_rank)),
             "cropped_bytes_sent": int(sum(len(x) for x in per_dest)), "owner": owner}
