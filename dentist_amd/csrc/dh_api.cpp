@@ -894,29 +894,36 @@ struct ChunkCopies {
     const uint8_t *rc = nullptr, *pk = nullptr, *rcpk = nullptr;
     bool has_n = false;
 };
-static int chunk_copies(dh_ctx *ctx, dh_db *B, int32_t r0, int32_t r1, bool want_packed, ChunkCopies *out)
+static int chunk_copies(dh_ctx *ctx, dh_db *B, int32_t r0, int32_t r1, bool want_packed, bool need_bytes,
+                        ChunkCopies *out)
 {
     hipStream_t st = ctx->stream;
     const int64_t o0 = B->h_off[(size_t)r0], o1 = B->h_off[(size_t)r1];
     const int64_t a0 = o0 & ~31ll;  // packed words hold 32 bases: start the chunk on a word boundary
     uint8_t *d_rc, *d_pk, *d_rcpk;
     int32_t *d_flag;
-    if (int rc = dh_scratch(ctx, 26, (size_t)(o1 - a0) + 2 * DB_PAD, (void **)&d_rc)) return rc;
-    // reverse complement: every read mirrored inside its own [off, off + len) range
-    HIPCHK(hipMemsetAsync(d_rc, 4, (size_t)(o1 - a0) + 2 * DB_PAD, st));
-    uint8_t *rc_shift = d_rc + DB_PAD - a0;
-    dhk_revcomp(st, B->d_bases, rc_shift, B->d_off + r0, r1 - r0, B->max_len);
-    HIPCHK(hipGetLastError());
-    out->rc = rc_shift;
     out->has_n = false;
-    if (!want_packed) return DH_OK;
+    auto rc_bytes = [&]() -> int {
+        // reverse complement as bytes (only the wave kernels' byte path reads it): every read mirrored
+        // inside its own [off, off + len) range
+        if (int rc = dh_scratch(ctx, 26, (size_t)(o1 - a0) + 2 * DB_PAD, (void **)&d_rc)) return rc;
+        HIPCHK(hipMemsetAsync(d_rc, 4, (size_t)(o1 - a0) + 2 * DB_PAD, st));
+        uint8_t *rc_shift = d_rc + DB_PAD - a0;
+        dhk_revcomp(st, B->d_bases, rc_shift, B->d_off + r0, r1 - r0, B->max_len);
+        HIPCHK(hipGetLastError());
+        out->rc = rc_shift;
+        return DH_OK;
+    };
+    if (!want_packed) return rc_bytes();
+    // 2-bit packed forward copy and, straight from the forward bytes, the packed reverse complements
     const size_t pbytes = (size_t)((o1 - a0 + 31) / 32) * 8 + 32;
     if (int rc = dh_scratch(ctx, 27, pbytes, (void **)&d_pk)) return rc;
     if (int rc = dh_scratch(ctx, 28, pbytes, (void **)&d_rcpk)) return rc;
     if (int rc = dh_scratch(ctx, 3, 4 * sizeof(int32_t), (void **)&d_flag)) return rc;
     HIPCHK(hipMemsetAsync(d_flag + 1, 0, 2 * sizeof(int32_t), st));
+    HIPCHK(hipMemsetAsync(d_rcpk, 0, pbytes, st));
     dhk_pack2(st, B->d_bases + a0, o1 - a0, d_pk + 16, d_flag + 1);
-    dhk_pack2(st, d_rc + DB_PAD, o1 - a0, d_rcpk + 16, d_flag + 2);
+    dhk_pack2_rc(st, B->d_bases, B->d_off + r0, r1 - r0, B->max_len, a0, d_rcpk + 16);
     HIPCHK(hipGetLastError());
     int32_t flag = 0;
     HIPCHK(hipMemcpyAsync(&flag, d_flag + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -924,6 +931,8 @@ static int chunk_copies(dh_ctx *ctx, dh_db *B, int32_t r0, int32_t r1, bool want
     out->has_n = flag != 0;
     out->pk = d_pk + 16 - (a0 >> 2);
     out->rcpk = d_rcpk + 16 - (a0 >> 2);
+    // codes outside 0..3 (here or in A): the wave kernels slide over the byte arrays
+    if (out->has_n || need_bytes) return rc_bytes();
     return DH_OK;
 }
 
@@ -1106,7 +1115,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             cc.pk = B->d_pk;
             cc.rcpk = B->d_rcpk;
             cc.has_n = B->has_n != 0;
-        } else if (int rc = chunk_copies(ctx, B, (int32_t)(item0 >> 1), (int32_t)((item0 + ni) >> 1), want_packed, &cc))
+        } else if (int rc = chunk_copies(ctx, B, (int32_t)(item0 >> 1), (int32_t)((item0 + ni) >> 1), want_packed, A->has_n != 0, &cc))
             return rc;
         const bool packed = want_packed && A->has_n == 0 && !cc.has_n && cc.pk && cc.rcpk;
         // per-chunk arrays are indexed by absolute item inside the kernels: shift the bases

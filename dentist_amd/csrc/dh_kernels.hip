@@ -139,6 +139,46 @@ k_pack2(const uint8_t *__restrict__ src, int64_t total, uint64_t *__restrict__ d
     if (bad) atomicOr(flag, 1);
 }
 
+// 2-bit packed reverse complements straight from the forward bytes: sequence s occupies the same base
+// range [off[s], off[s+1]) in the packed copy, mirrored inside it.  One thread per 16-base word of the
+// destination that the sequence touches: whole words are stored, the (at most two) words a sequence
+// shares with its neighbours are ORed into the zeroed buffer.  `a0` (multiple of 32) = base position of
+// dst word 0.  Codes outside 0..3 pack as (c ^ 3) & 3; such DBs are not aligned from the packed copies.
+__device__ __forceinline__ uint32_t pack8_rc(uint64_t y)
+{
+    uint64_t t = (y ^ 0x0303030303030303ull) & 0x0303030303030303ull;
+    t = (t | (t >> 6)) & 0x000F000F000F000Full;
+    t = (t | (t >> 12)) & 0x000000FF000000FFull;
+    t = (t | (t >> 24)) & 0xFFFFull;
+    return (uint32_t)t;
+}
+__global__ void __launch_bounds__(256)
+k_pack2_rc(const uint8_t *__restrict__ src, const int64_t *__restrict__ off, int32_t n, int64_t a0,
+           uint32_t *__restrict__ dst)
+{
+    const int32_t s = blockIdx.y;
+    if (s >= n) return;
+    const int64_t o = off[s], len = off[s + 1] - o;
+    if (len <= 0) return;
+    const int64_t w0 = (o - a0) >> 4, w1 = (o + len - 1 - a0) >> 4;  // first / last destination word
+    const int64_t sbase = 2 * o + len - 1;                           // source of base g is src[sbase - g]
+    for (int64_t w = w0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w <= w1; w += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t gw = a0 + (w << 4);
+        if (gw >= o && gw + 16 <= o + len) {
+            const uint8_t *A = src + (sbase - gw - 15);
+            uint64_t x0, x1;
+            __builtin_memcpy(&x0, A, 8);      // positions 15 .. 8
+            __builtin_memcpy(&x1, A + 8, 8);  // positions 7 .. 0
+            dst[w] = pack8_rc(__builtin_bswap64(x1)) | (pack8_rc(__builtin_bswap64(x0)) << 16);
+        } else {
+            const int64_t g0 = gw > o ? gw : o, g1 = gw + 16 < o + len ? gw + 16 : o + len;
+            uint32_t out = 0;
+            for (int64_t g = g0; g < g1; g++) out |= (uint32_t)((src[sbase - g] ^ 3u) & 3u) << (2 * (int)(g - gw));
+            atomicOr(&dst[w], out);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ K2
 
 // tiles: (sequence, start) pairs, KM_TILE positions each; 256 threads x 16 positions.
@@ -2471,6 +2511,18 @@ void dhk_pack2(hipStream_t st, const uint8_t *src, int64_t total, uint8_t *dst, 
     if (nw <= 0) return;
     hipLaunchKernelGGL(k_pack2, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, src, total, (uint64_t *)dst,
                        flag);
+}
+
+void dhk_pack2_rc(hipStream_t st, const uint8_t *src, const int64_t *off, int32_t n, int32_t max_len, int64_t a0,
+                  uint8_t *dst)
+{
+    if (n <= 0) return;
+    int gx = (max_len / 16 + 255) / 256;
+    gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+    for (int32_t s0 = 0; s0 < n; s0 += 65535) {
+        const int32_t cnt = n - s0 < 65535 ? n - s0 : 65535;
+        hipLaunchKernelGGL(k_pack2_rc, dim3(gx, cnt), dim3(256), 0, st, src, off + s0, cnt, a0, (uint32_t *)dst);
+    }
 }
 
 void dhk_compact(hipStream_t st, const DhLa *la_slots, const uint16_t *tr_slots, int32_t trmax,
