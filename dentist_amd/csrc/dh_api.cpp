@@ -1330,7 +1330,14 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         c.hits += stats.hits;
         c.b_bases += stats.b_bases;
         c.trace_values += (int64_t)res->trace.size();
-        for (const dh_la &l : res->la) c.aligned_bp += l.aepos - l.abpos;
+        std::atomic<int64_t> abp{0};
+        const dh_la *lp = res->la.data();
+        dh_parallel_for((int64_t)res->la.size(), 1 << 16, [&](int64_t lo, int64_t hi) {
+            int64_t sum = 0;
+            for (int64_t i = lo; i < hi; i++) sum += lp[i].aepos - lp[i].abpos;
+            abp += sum;
+        });
+        c.aligned_bp += abp.load();
     }
 #ifdef DH_SEED_PROF
     if (getenv("DH_TRACE")) dhk_seed_prof_dump();

@@ -1386,8 +1386,18 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
         sg.sets.push_back(pset);
         lap("pile align call");
         bool grouped = true;  // the symmetric wave kernel already emits grouped by A read
-        for (size_t i = 1; i < pset->la.size() && grouped; i++)
-            grouped = pset->la[i - 1].aread <= pset->la[i].aread;
+        {
+            std::atomic<int> out_of_order{0};
+            const dh_la *lp = pset->la.data();
+            dh_parallel_for((int64_t)pset->la.size(), 1 << 16, [&](int64_t lo, int64_t hi) {
+                for (int64_t i = std::max<int64_t>(lo, 1); i < hi; i++)
+                    if (lp[i - 1].aread > lp[i].aread) {
+                        out_of_order = 1;
+                        break;
+                    }
+            });
+            grouped = out_of_order.load() == 0;
+        }
         if (!grouped) {  // group by aread (counting sort, stable); traces stay where they are
             std::vector<int32_t> cnt((size_t)pile->n + 1, 0);
             for (const dh_la &la : pset->la) cnt[(size_t)la.aread + 1]++;
@@ -1416,17 +1426,28 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
         // ---- 3. the alignment funnel of computeQVs (package.d:474-516): averageErrorRate <=
         //         maxAlignmentError -> chainLocalAlignments -> isValidPileUpAlignment with
         //         allowance = trace spacing (dazzler.d:4066-4141)
+        std::vector<int32_t> la_first;
         {
             // the funnel of one A read is independent of the others: host threads take read groups
             // (LAs are grouped by aread; inside a group order by bread to get (A, B) pairs)
-            std::vector<size_t> gstart;
-            for (size_t i = 0; i < pl.size(); i++)
-                if (i == 0 || pl[i].aread != pl[i - 1].aread) gstart.push_back(i);
-            gstart.push_back(pl.size());
-            const int64_t ngroups = (int64_t)gstart.size() - 1;
-            dh_parallel_for(ngroups, 64, [&](int64_t glo, int64_t ghi) {
+            // la_first[r] = first LA of A read r (the LAs are grouped by aread): boundaries found in parallel
+            la_first.assign((size_t)pile->n + 1, 0);
+            {
+                const int64_t nl = (int64_t)pl.size();
+                const dh_la *lp = pl.data();
+                int32_t *lf = la_first.data();
+                const int32_t npr_ = pile->n;
+                dh_parallel_for(nl + 1, 1 << 16, [&](int64_t lo, int64_t hi) {
+                    for (int64_t i = lo; i < hi; i++) {
+                        const int32_t prev = i == 0 ? -1 : lp[i - 1].aread, cur = i == nl ? npr_ : lp[i].aread;
+                        for (int32_t r = prev + 1; r <= cur; r++) lf[r] = (int32_t)i;
+                    }
+                });
+            }
+            dh_parallel_for(pile->n, 64, [&](int64_t glo, int64_t ghi) {
                 for (int64_t g = glo; g < ghi; g++) {
-                    const size_t g0 = gstart[(size_t)g], g1 = gstart[(size_t)g + 1];
+                    const size_t g0 = (size_t)la_first[(size_t)g], g1 = (size_t)la_first[(size_t)g + 1];
+                    if (g1 <= g0) continue;
                     for (size_t i = g0; i < g1; i++) {
                         dh_la &la = pl[i];
                         if ((int64_t)la.diffs * 1000000 > (int64_t)o.max_align_err_ppm * (la.aepos - la.abpos))
@@ -1466,9 +1487,6 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
         // ---- 4. tile QVs on the device (LAs are sorted by aread)
         HIPCHK(hipEventRecord(ev[0], st));
         const int32_t npr = pile->n;
-        std::vector<int32_t> la_first((size_t)npr + 1, 0);
-        for (const dh_la &la : pl) la_first[(size_t)la.aread + 1]++;
-        for (int32_t r = 0; r < npr; r++) la_first[(size_t)r + 1] += la_first[(size_t)r];
         const int32_t maxtiles = std::max(1, (pile->max_len + tsp - 1) / tsp);
         std::vector<uint8_t> qv((size_t)npr * maxtiles, 255);
         {
