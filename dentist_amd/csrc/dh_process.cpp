@@ -674,17 +674,30 @@ static int consensus_round(dh_ctx *ctx, dh_db *T, dh_db *R, const LaVec &las,
         // the selected overlaps and where their tiles go; host threads then fill the tiles
         std::vector<size_t> sel;
         std::vector<size_t> soff(1, 0);
-        for (size_t i = 0; i < las.size(); i++)
-            if (tmpl_of[i] >= 0 && !(las[i].flags & DH_FLAG_DISABLED)) {
-                // an overlap with a tile spanning more than SEG_MAX B bases (a > 100 % local indel
-                // rate) takes no part in the vote
-                const uint16_t *tr = trace.data() + las[i].toff;
-                bool too_long = false;
-                for (int32_t e = 0; e < las[i].tlen / 2; e++) too_long = too_long || tr[2 * e + 1] > SEG_MAX;
-                if (too_long) continue;
-                sel.push_back(i);
-                soff.push_back(soff.back() + (size_t)(las[i].tlen / 2));
-            }
+        {
+            // selection in input order: host threads scan runs of the LAs, the runs are concatenated
+            const int64_t grain = 1 << 16, nch = ((int64_t)las.size() + grain - 1) / grain;
+            std::vector<std::vector<size_t>> part((size_t)std::max<int64_t>(nch, 1));
+            dh_parallel_for(nch, 1, [&](int64_t clo, int64_t chi) {
+                for (int64_t c = clo; c < chi; c++) {
+                    const size_t i1 = std::min(las.size(), (size_t)(c + 1) * (size_t)grain);
+                    for (size_t i = (size_t)c * (size_t)grain; i < i1; i++)
+                        if (tmpl_of[i] >= 0 && !(las[i].flags & DH_FLAG_DISABLED)) {
+                            // an overlap with a tile spanning more than SEG_MAX B bases (a > 100 % local
+                            // indel rate) takes no part in the vote
+                            const uint16_t *tr = trace.data() + las[i].toff;
+                            bool too_long = false;
+                            for (int32_t e = 0; e < las[i].tlen / 2; e++) too_long = too_long || tr[2 * e + 1] > SEG_MAX;
+                            if (!too_long) part[(size_t)c].push_back(i);
+                        }
+                }
+            });
+            for (const auto &v : part)
+                for (size_t i : v) {
+                    sel.push_back(i);
+                    soff.push_back(soff.back() + (size_t)(las[i].tlen / 2));
+                }
+        }
         segs.resize(soff.back());
         std::mutex red;
         dh_parallel_for((int64_t)sel.size(), 256, [&](int64_t lo_, int64_t hi_) {
@@ -1525,13 +1538,18 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
         HIPCHK(hipEventRecord(ev[1], st));
         if (int rc = elapsed(0, 1, ps.ms[2])) return rc;
         // filterPileUpAlignments (properAlignmentAllowance), dazzler.d:4043-4094: after the QVs
-        for (dh_la &la : pl)
-            if (la.flags & FLAG_IMPROPER) la.flags = (la.flags & ~FLAG_IMPROPER) | DH_FLAG_DISABLED;
+        dh_parallel_for((int64_t)pl.size(), 1 << 16, [&](int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; i++) {
+                dh_la &la = pl[(size_t)i];
+                if (la.flags & FLAG_IMPROPER) la.flags = (la.flags & ~FLAG_IMPROPER) | DH_FLAG_DISABLED;
+            }
+        });
         lap("tile qv");
         // ---- 5. reference read per pile-up: findReferenceReadCandidates (package.d:518-568)
         std::vector<int32_t> ref_of((size_t)na, -1);
         const double bad_fraction = (double)o.bad_fraction_ppm / 1e6;
-        for (int32_t a = 0; a < na; a++) {
+        dh_parallel_for(na, 8, [&](int64_t alo, int64_t ahi) {
+          for (int32_t a = (int32_t)alo; a < (int32_t)ahi; a++) {  // pile-ups are independent
             const int32_t r0 = first_read[(size_t)a], r1 = first_read[(size_t)a + 1];
             bool any = false;
             for (int32_t i = la_first[(size_t)r0]; i < la_first[(size_t)r1]; i++)
@@ -1588,7 +1606,8 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
             ref_of[(size_t)a] = best;
             rec.ref_read = best - r0;
             rec.ref_read_id = read_id[(size_t)best];
-        }
+          }
+        });
         lap("rank reference reads");
         // ---- 6. consensus rounds.  Templates are indexed by active pile-up (group = active idx)
         std::vector<int32_t> tidx, tbeg, tlen, tgrp;
@@ -1602,11 +1621,13 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
         if (int rc = dh_db_from_slices(ctx, pile, tidx, tbeg, tlen, tgrp, &T)) return rc;
         dbg.dbs.push_back(T);
         {
-            std::vector<int32_t> tmpl_of(pl.size(), -1);
-            for (size_t i = 0; i < pl.size(); i++) {
-                const int32_t a = pile->h_group[(size_t)pl[i].aread];
-                if (active_ok[(size_t)a] && pl[i].aread == ref_of[(size_t)a]) tmpl_of[i] = a;
-            }
+            std::vector<int32_t> tmpl_of(pl.size());
+            dh_parallel_for((int64_t)pl.size(), 1 << 16, [&](int64_t lo, int64_t hi) {
+                for (int64_t i = lo; i < hi; i++) {
+                    const int32_t a = pile->h_group[(size_t)pl[(size_t)i].aread];
+                    tmpl_of[(size_t)i] = (active_ok[(size_t)a] && pl[(size_t)i].aread == ref_of[(size_t)a]) ? a : -1;
+                }
+            });
             HIPCHK(hipEventRecord(ev[0], st));
             dh_db *nT = nullptr;
             int64_t nseg = 0, ncell = 0;
