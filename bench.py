@@ -129,18 +129,19 @@ def main():
         # mapping + the six alignment filters of `dentist collect` (filter.d:122-356): per-read decisions,
         # so every rank filters the alignments of its own reads, chunk by chunk on the host while the
         # device maps the next chunk (dh_map_reads)
-        las, trace, dropped = ctx.map_reads(A, B, mopts, popts)
+        # and lists the spanning-read candidates of the chunk; records stay in mapping order (by read)
+        las, trace, dropped, cands = ctx.map_reads(A, B, mopts, popts, sorted=False, candidates=True)
         ast = ctx.align_stats()
         t1 = time.perf_counter()
         if world == 1:
-            piles = dentist_amd.Pileups(las, w.contigs.off, popts)
+            piles = cands.select(las, popts)   # min / max reads per pile-up (choice by alignment quality)
             t2 = time.perf_counter()
             rec, bases = dentist_amd.process_pileups(ctx, A, B, las, trace, piles, popts)
             info = {"piles": len(piles)}
         else:
             las["bread"] += lo   # read ids of the whole reads DB, as in the .las of a block
             t2 = t1
-            rec, bases, info = sharded_process(ctx, A, B, lo, w.contigs.off, las, trace, popts, rank, world)
+            rec, bases, info = sharded_process(ctx, A, B, lo, w.contigs.off, las, trace, popts, rank, world, cands=cands)
         t3 = time.perf_counter()
         pst = dentist_amd.process_stats(ctx)
         cum = ctx.cum_stats().as_dict()  # every k_wave / k_seed launch of the step

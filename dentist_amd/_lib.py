@@ -298,10 +298,11 @@ class Context:
         return las, trace
 
 
-    def map_reads(self, A, B, opts, popts, first=0, count=None, repeat_mask=None):
+    def map_reads(self, A, B, opts, popts, first=0, count=None, repeat_mask=None, sorted=True, candidates=False):
         """dh_map_reads: the mapping pass (chain flags as with select_best) with the six `collect` filters
-        applied chunk by chunk on the host while the device maps on.  Returns (las, trace, dropped[6])."""
-        return _map_reads(self, A, B, opts, popts, first, count, repeat_mask)
+        applied chunk by chunk on the host while the device maps on.  Returns (las, trace, dropped[6]);
+        with sorted=False, candidates=True also the spanning-read candidates (Pileups, not yet cut)."""
+        return _map_reads(self, A, B, opts, popts, first, count, repeat_mask, sorted, candidates)
 
     def align_db_block(self, A, B, first, count, opts, select_best=False, raw=False):
         """`damapper ref reads.<block>`: reads [first, first + count) of B against A.  raw=True
@@ -315,7 +316,7 @@ class Context:
         return las, trace
 
 
-def _map_reads(ctx, A, B, opts, popts, first=0, count=None, repeat_mask=None):
+def _map_reads(ctx, A, B, opts, popts, first=0, count=None, repeat_mask=None, sorted=True, candidates=False):
     rp = ri = None
     if repeat_mask is not None:
         rp = np.ascontiguousarray(repeat_mask[0], dtype=np.int64)
@@ -324,14 +325,18 @@ def _map_reads(ctx, A, B, opts, popts, first=0, count=None, repeat_mask=None):
     n = L.dh_db_nreads(B._h)
     count = n - first if count is None else count
     dropped = np.zeros(6, dtype=np.int64)
-    h = ctypes.c_void_p()
+    h, ph = ctypes.c_void_p(), ctypes.c_void_p()
     L.dh_map_reads.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                ctypes.POINTER(AlignOpts), ctypes.POINTER(ProcessOpts), ctypes.c_void_p, ctypes.c_void_p,
-                               ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+                               ctypes.c_int32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p),
+                               ctypes.POINTER(ctypes.c_void_p)]
     _check(L.dh_map_reads(ctx._h, A._h, B._h, int(first), int(count), ctypes.byref(opts), ctypes.byref(popts),
                           rp.ctypes.data if rp is not None else None, ri.ctypes.data if ri is not None else None,
-                          dropped.ctypes.data, ctypes.byref(h)))
+                          1 if sorted else 0, dropped.ctypes.data, ctypes.byref(h),
+                          ctypes.byref(ph) if candidates else None))
     las, trace, _ = _take_la_set(h)
+    if candidates:
+        return las, trace, dropped, Pileups(None, None, None, _handle=ph)
     return las, trace, dropped
 
 

@@ -736,13 +736,13 @@ static bool la_less(const dh_la &p, const dh_la &q)
 // unless a higher-scoring LA of the same read and orientation covers more than half of it on B
 // (consumer: dazzler.d:1728-1758 reads START without BEST as alternateChain).
 // `la` must be grouped by bread (the kernels emit it that way).
-static void select_best(LaVec &la)
+static void select_best_range(dh_la *la, size_t nla)
 {
     // groups of equal bread are independent: host threads take runs of groups
     std::vector<size_t> gstart;
-    for (size_t i = 0; i < la.size(); i++)
+    for (size_t i = 0; i < nla; i++)
         if (i == 0 || la[i].bread != la[i - 1].bread) gstart.push_back(i);
-    gstart.push_back(la.size());
+    gstart.push_back(nla);
     dh_parallel_for((int64_t)gstart.size() - 1, 2048, [&](int64_t glo, int64_t ghi) {
         for (int64_t g = glo; g < ghi; g++) {
             const size_t g0 = gstart[(size_t)g], g1 = gstart[(size_t)g + 1];
@@ -833,7 +833,8 @@ extern "C" int dh_align_db(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts 
 
 // per-chunk hook: called on a host thread of its own with the records of a finished chunk (B-major,
 // whole reads) while the device works on the next chunk; the records may be modified in place
-typedef std::function<void(dh_la *, int64_t)> ChunkHook;
+// (records of the chunk, their number, their offset in the result, number of the chunk)
+typedef std::function<void(dh_la *, int64_t, int64_t, int64_t)> ChunkHook;
 static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t count, const dh_align_opts *opts,
                        int32_t want_best, int32_t want_sorted, dh_la_set **out, const ChunkHook *hook = nullptr);
 
@@ -854,27 +855,51 @@ extern "C" int dh_align_db_block(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first,
 // dh_collect_filter.  rep_ptr / rep_iv: repeat mask of the contigs for WeaklyAnchored (may be NULL).
 extern "C" int dh_map_reads(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_t first, int32_t count,
                             const dh_align_opts *opts, const dh_process_opts *popts, const int64_t *rep_ptr,
-                            const int32_t *rep_iv, int64_t *dropped6, dh_la_set **out)
+                            const int32_t *rep_iv, int32_t want_sorted, int64_t *dropped6, dh_la_set **out,
+                            dh_pileups **cands)
 {
     if (!contigs || !reads || !popts || first < 0 || count < 0 || (int64_t)first + count > reads->n)
         return fail(DH_EINVAL, "dh_map_reads: bad argument");
+    if (cands && want_sorted)
+        return fail(DH_EINVAL, "dh_map_reads: candidates index the records in mapping order (want_sorted = 0)");
+    if (cands) *cands = nullptr;
     std::mutex mu;
     int64_t dropped[6] = {0, 0, 0, 0, 0, 0};
     int hook_rc = DH_OK;
-    const ChunkHook hook = [&](dh_la *las, int64_t n) {
+    std::vector<dh_pileups *> per_chunk;  // spanning-read candidates of every chunk, LA indices of the result
+    struct CandGuard {
+        std::vector<dh_pileups *> &v;
+        ~CandGuard()
+        {
+            for (dh_pileups *p : v) dh_pileups_destroy(p);
+        }
+    } cguard{per_chunk};
+    const ChunkHook hook = [&](dh_la *las, int64_t n, int64_t l0, int64_t chunk_no) {
         int64_t d[6];
-        const int rc = dh_collect_filter(las, n, contigs->h_off.data(), contigs->n, reads->h_off.data(), reads->n, rep_ptr,
-                                         rep_iv, popts, d, nullptr);
+        int rc = dh_collect_filter(las, n, contigs->h_off.data(), contigs->n, reads->h_off.data(), reads->n, rep_ptr,
+                                   rep_iv, popts, d, nullptr);
+        dh_pileups *pc = nullptr;
+        if (rc == DH_OK && cands) rc = dh_collect_candidates(las, n, contigs->h_off.data(), contigs->n, popts, &pc);
+        if (pc && l0 != 0) dh_pileups_shift(pc, (int32_t)l0);
         std::lock_guard<std::mutex> lk(mu);
         if (rc != DH_OK) hook_rc = rc;
         for (int k = 0; k < 6; k++) dropped[k] += d[k];
+        if ((size_t)chunk_no >= per_chunk.size()) per_chunk.resize((size_t)chunk_no + 1, nullptr);
+        per_chunk[(size_t)chunk_no] = pc;
     };
-    const int rc = align_range(ctx, contigs, reads, first, count, opts, 1, 1, out, &hook);
+    const int rc = align_range(ctx, contigs, reads, first, count, opts, 1, want_sorted, out, &hook);
     if (rc != DH_OK) return rc;
     if (hook_rc != DH_OK) {
         dh_la_set_destroy(*out);
         *out = nullptr;
         return hook_rc;
+    }
+    if (cands) {  // chunks hold ascending read ranges: concatenating per gap keeps every gap ordered by read
+        if (int rc2 = dh_pileups_concat(per_chunk.data(), (int32_t)per_chunk.size(), cands)) {
+            dh_la_set_destroy(*out);
+            *out = nullptr;
+            return rc2;
+        }
     }
     if (dropped6) memcpy(dropped6, dropped, sizeof(dropped));
     return DH_OK;
@@ -1282,10 +1307,13 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             const int64_t cnt = (int64_t)totals[0];
             const ChunkHook h = *hook;
             const int dev = ctx->device;
-            tasks.v.emplace_back([h, p, cnt, copied, dev] {
+            const int64_t l0h = (int64_t)(res->la.size() - totals[0]), chunk_no = nchunk_done - 1;
+            const bool best = want_best != 0;
+            tasks.v.emplace_back([h, p, cnt, copied, dev, l0h, chunk_no, best] {
                 (void)hipSetDevice(dev);
                 (void)hipEventSynchronize(copied);  // the records of this chunk have arrived
-                h(p, cnt);
+                if (best) select_best_range(p, (size_t)cnt);  // chain flags: a per-read decision too
+                h(p, cnt, l0h, chunk_no);
             });
         }
         float t;
@@ -1305,7 +1333,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     stats.alignments = (int64_t)counters[1];
 
     tasks.join();
-    if (want_best) select_best(res->la);
+    if (want_best && !hook) select_best_range(res->la.data(), res->la.size());
     if (want_sorted) lasort(res, A->n);
     w_post = now_ms() - w_a;
     stats.las = (int64_t)res->la.size();

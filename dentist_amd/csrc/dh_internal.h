@@ -146,6 +146,9 @@ struct dh_la_set {
     std::vector<int32_t> ovf_reads;
 };
 
+void dh_pileups_shift(dh_pileups *p, int32_t by);
+int dh_pileups_concat(dh_pileups *const *parts, int32_t nparts, dh_pileups **out);
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;

@@ -285,17 +285,61 @@ extern "C" int dh_pileups_select(const dh_pileups *cands, const dh_la *las, int6
                                  const dh_process_opts *opts, dh_pileups **out)
 {
     if (!cands || !opts || !out || (n > 0 && !las)) return dh_fail(DH_EINVAL, "dh_pileups_select: bad argument");
-    dh_pileups *p = new dh_pileups();
-    for (size_t i = 0; i < cands->contig_left.size(); i++) {
-        std::vector<int32_t> v = cands->triples[i];
-        for (size_t e = 0; e < v.size(); e += 3)
-            if (v[e + 1] < 0 || v[e + 1] >= n || v[e + 2] < 0 || v[e + 2] >= n) {
-                delete p;
-                return dh_fail(DH_EINVAL, "dh_pileups_select: LA index out of range");
+    // pile-ups are independent (the cut reads the anchoring LAs: cache misses into the mapping's records)
+    const size_t np = cands->contig_left.size();
+    std::vector<std::vector<int32_t>> sel(np);
+    std::vector<char> keep(np, 0);
+    std::atomic<int> bad{0};
+    dh_parallel_for((int64_t)np, 4, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; i++) {
+            std::vector<int32_t> v = cands->triples[(size_t)i];
+            bool ok = true;
+            for (size_t e = 0; e < v.size() && ok; e += 3)
+                ok = !(v[e + 1] < 0 || v[e + 1] >= n || v[e + 2] < 0 || v[e + 2] >= n);
+            if (!ok) {
+                bad = 1;
+                continue;
             }
-        if (!select_pile(v, las, *opts)) continue;
-        p->contig_left.push_back(cands->contig_left[i]);
-        p->triples.push_back(std::move(v));
+            if (!select_pile(v, las, *opts)) continue;
+            keep[(size_t)i] = 1;
+            sel[(size_t)i] = std::move(v);
+        }
+    });
+    if (bad) return dh_fail(DH_EINVAL, "dh_pileups_select: LA index out of range");
+    dh_pileups *p = new dh_pileups();
+    for (size_t i = 0; i < np; i++)
+        if (keep[i]) {
+            p->contig_left.push_back(cands->contig_left[i]);
+            p->triples.push_back(std::move(sel[i]));
+        }
+    *out = p;
+    return DH_OK;
+}
+
+// internal helpers of dh_map_reads: LA indices shifted by a constant; pile-ups of several parts (ascending
+// read ranges) concatenated gap by gap
+void dh_pileups_shift(dh_pileups *p, int32_t by)
+{
+    for (auto &t : p->triples)
+        for (size_t e = 0; e + 2 < t.size(); e += 3) {
+            t[e + 1] += by;
+            t[e + 2] += by;
+        }
+}
+int dh_pileups_concat(dh_pileups *const *parts, int32_t nparts, dh_pileups **out)
+{
+    std::map<int32_t, std::vector<int32_t>> m;
+    for (int32_t i = 0; i < nparts; i++) {
+        if (!parts[i]) continue;
+        for (size_t g = 0; g < parts[i]->contig_left.size(); g++) {
+            std::vector<int32_t> &t = m[parts[i]->contig_left[g]];
+            t.insert(t.end(), parts[i]->triples[g].begin(), parts[i]->triples[g].end());
+        }
+    }
+    dh_pileups *p = new dh_pileups();
+    for (auto &kv : m) {
+        p->contig_left.push_back(kv.first);
+        p->triples.push_back(std::move(kv.second));
     }
     *out = p;
     return DH_OK;

@@ -110,13 +110,14 @@ def all_to_all_bytes(per_dest, world):
 
 # ------------------------------------------------------------------ the sharded `collect` + `process`
 
-def pack_candidates(cands, las):
+def pack_candidates(cands, las, read_shift=0):
     """Candidate entries of this rank (dentist_amd.Pileups(..., candidates=True) on its LAs, whose
-    bread are ids of the whole reads DB) as CAND_DTYPE records in (gap, read) order."""
+    bread are ids of the whole reads DB) as CAND_DTYPE records in (gap, read) order.  read_shift: added
+    to the read ids of candidates that were collected before the LAs got their whole-DB ids."""
     cl, cnt, tri = cands.flat()
     rec = np.zeros(len(tri), dtype=CAND_DTYPE)
     rec["gap"] = np.repeat(cl, cnt)
-    rec["read"] = tri[:, 0]
+    rec["read"] = tri[:, 0] + read_shift
     rec["L"] = las[tri[:, 1]]
     rec["R"] = las[tri[:, 2]]
     return rec
@@ -160,12 +161,12 @@ def _runs(bases, off, idx):
     return [bases[off[idx[a]]:off[idx[b - 1] + 1]] for a, b in zip(starts, ends)]
 
 
-def sharded_process(ctx, contigs_db, reads_db, read_first, contig_off, las, trace, popts, rank, world):
+def sharded_process(ctx, contigs_db, reads_db, read_first, contig_off, las, trace, popts, rank, world, cands=None):
     """`collect` + `process` for one rank's share of the reads.  las/trace: this rank's mapping
     result with bread ALREADY shifted to ids of the whole reads DB; reads_db holds the reads
     [read_first, read_first + n).  Returns (records, bases, info): the closed-gap records of ALL
     ranks ordered by gap (identical on every rank) with ref_read_id as whole-DB ids."""
-    gen = sharded_process_steps(ctx, contigs_db, reads_db, read_first, contig_off, las, trace, popts, rank, world)
+    gen = sharded_process_steps(ctx, contigs_db, reads_db, read_first, contig_off, las, trace, popts, rank, world, cands)
     try:
         req = next(gen)
         while True:
@@ -199,7 +200,7 @@ def emulate_ranks(gens):
     return results
 
 
-def sharded_process_steps(ctx, contigs_db, reads_db, read_first, contig_off, las, trace, popts, rank, world):
+def sharded_process_steps(ctx, contigs_db, reads_db, read_first, contig_off, las, trace, popts, rank, world, cands=None):
     """Generator form of sharded_process: yields ("all_gather", bytes) / ("all_to_all", [bytes per
     destination]) and expects the list of arrays received (by source rank) to be sent back."""
     import os
@@ -213,8 +214,11 @@ def sharded_process_steps(ctx, contigs_db, reads_db, read_first, contig_off, las
             t = time.perf_counter()
             _laps.append("%s %.1f" % (what, (t - _t[0]) * 1e3))
             _t[0] = t
-    cands = Pileups(las, contig_off, popts, candidates=True)
-    mine = pack_candidates(cands, las)
+    # cands: candidates dh_map_reads collected on the way (read ids still local to this rank's reads DB)
+    shift = 0 if cands is None else read_first
+    if cands is None:
+        cands = Pileups(las, contig_off, popts, candidates=True)
+    mine = pack_candidates(cands, las, shift)
     lap("candidates")
     blobs = yield ("all_gather", mine.view(np.uint8))
     per_rank = [np.frombuffer(b.tobytes(), dtype=CAND_DTYPE) for b in blobs]

@@ -265,12 +265,14 @@ int64_t dh_validate_regions(const dh_la *las, int64_t n, const int64_t *contig_o
 
 /* The mapping pass with the six filters of `dentist collect` applied on the way: `damapper` per read block
  * (snakemake/Snakefile:1143-1170) + collectPileUps/filter.d:122-356.  Every filter decides per read, so
- * the records of a finished chunk of reads are filtered on a host thread while the device maps the next
- * chunk.  Result = dh_align_db_block(want_best = 1) followed by dh_collect_filter (same records, flags
- * and dropped6 counts). */
+ * the records of a finished chunk of reads get their chain flags and are filtered on a host thread while
+ * the device maps the next chunk.  want_sorted != 0: result = dh_align_db_block(want_best = 1) followed by
+ * dh_collect_filter (same records, flags and dropped6 counts, LAsort order).  want_sorted == 0: the same
+ * records in mapping order (by read, strand); then `cands` (may be NULL) receives the spanning-read
+ * candidates of dh_collect_candidates, collected chunk by chunk as well (indices into the result). */
 int dh_map_reads(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_t first, int32_t count, const dh_align_opts *opts,
-                 const dh_process_opts *popts, const int64_t *rep_ptr, const int32_t *rep_iv, int64_t *dropped6,
-                 dh_la_set **out);
+                 const dh_process_opts *popts, const int64_t *rep_ptr, const int32_t *rep_iv, int32_t want_sorted,
+                 int64_t *dropped6, dh_la_set **out, dh_pileups **cands);
 
 /* ---- the scaffold-graph pile-up builder of `dentist collect` (collectPileUps/pileups.d:173-208 build;
  * collectPileUps/package.d:174-184 is the call site).  Nodes are (contig, part) with part 0 = pre,

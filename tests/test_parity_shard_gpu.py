@@ -77,3 +77,42 @@ def test_crop_then_process_equals_the_fused_call(gpu_ctx):
     prec, cpile, centry, cread, coff, cbases = parts
     assert np.all(np.diff(cpile.astype(np.int64) * 1000 + centry) > 0)
     assert len(cpile) == sum(len(piles.get(i)[1]) for i in range(len(piles)) if prec[i]["status"] == 0)
+
+
+def test_sharded_run_with_candidates_collected_while_mapping(gpu_ctx, monkeypatch):
+    """bench.py's flow: dh_map_reads (filters and spanning-read candidates per chunk, records in mapping
+    order) on every rank, candidates handed to the sharded collect + process; equal to the single-GPU
+    flow mapping -> dh_collect_filter -> collect -> process, whatever the chunking."""
+    w = sim.Workload(800_000, 8, 4000, 6000, seed=71, spacing=20000, gap_max=1500)
+    mo = dentist_amd.default_align_opts(kmer_mod=2)
+    po = dentist_amd.default_process_opts(max_reads=12)
+    A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
+    las, trace = gpu_ctx.align_db(A, B, mo, select_best=True)
+    las, _, _ = dentist_amd.collect_filter(las, w.contigs.off, w.reads.off, po)
+    rec, bases = dentist_amd.process_pileups(gpu_ctx, A, B, las, trace, dentist_amd.Pileups(las, w.contigs.off, po), po)
+    assert (rec["status"] == 0).sum() >= 6
+    monkeypatch.setenv("DH_ALIGN_CHUNK", "700")
+    # one rank: candidates of dh_map_reads + the min / max reads cut == collect on the filtered records
+    l1, t1, _, c1 = gpu_ctx.map_reads(A, B, mo, po, sorted=False, candidates=True)
+    rec1, bases1 = dentist_amd.process_pileups(gpu_ctx, A, B, l1, t1, c1.select(l1, po), po)
+    for f in rec.dtype.names:
+        if f not in ("cons_off", "pad"):
+            assert np.array_equal(rec1[f], rec[f]), f
+    assert np.array_equal(bases1, bases)
+    world, gens, keep = 3, [], []
+    for rank in range(world):
+        lo, hi = parallel.shard_range(w.reads.n, rank, world)
+        share = sim.SeqDb(w.reads.bases[w.reads.off[lo]:w.reads.off[hi]], w.reads.off[lo:hi + 1] - w.reads.off[lo])
+        Br = gpu_ctx.db(share)
+        lr, tr, _, cr = gpu_ctx.map_reads(A, Br, mo, po, sorted=False, candidates=True)
+        lr = lr.copy()
+        lr["bread"] += lo
+        keep.append((Br, lr, tr, cr))
+        gens.append(parallel.sharded_process_steps(gpu_ctx, A, Br, lo, w.contigs.off, lr, tr, po, rank, world, cr))
+    for grec, gbases, info in parallel.emulate_ranks(gens):
+        for f in rec.dtype.names:
+            if f not in ("cons_off", "pad"):
+                assert np.array_equal(grec[f], rec[f]), f
+        for a, b in zip(grec, rec):
+            assert np.array_equal(gbases[a["cons_off"]:a["cons_off"] + a["cons_len"]],
+                                  bases[b["cons_off"]:b["cons_off"] + b["cons_len"]])
