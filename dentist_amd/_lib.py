@@ -742,8 +742,11 @@ class Cropped:
         L, h = lib(), self._h
         npl, nr = L.dh_cropped_npiles(h), L.dh_cropped_nreads(h)
 
-        def arr(ptr, n, dt):
-            return np.frombuffer(ctypes.string_at(ptr, n * np.dtype(dt).itemsize), dtype=dt).copy() if n else np.zeros(0, dt)
+        def arr(ptr, n, dt):  # one copy out of the library's buffer
+            if not n:
+                return np.zeros(0, dt)
+            buf = (ctypes.c_uint8 * (n * np.dtype(dt).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dt).copy()
         rec = arr(L.dh_cropped_records(h), npl, INSERTION_DTYPE)
         off = arr(L.dh_cropped_offsets(h), nr + 1, np.int64) if nr else np.zeros(1, np.int64)
         bp = L.dh_cropped_bases(h)

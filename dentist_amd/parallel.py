@@ -129,9 +129,9 @@ def merge_candidates(per_rank):
     order keeps every gap's entries ordered by read id -- the order `dentist collect` sees after
     LAmerge."""
     allc = np.concatenate(per_rank) if len(per_rank) else np.zeros(0, dtype=CAND_DTYPE)
-    las = np.zeros(2 * len(allc), dtype=LA_DTYPE)
-    las[0::2] = allc["L"]
-    las[1::2] = allc["R"]
+    # the two LA records of an entry are adjacent in the packed record: one strided copy gives L0 R0 L1 R1 ...
+    raw = np.ascontiguousarray(allc).view(np.uint8).reshape(len(allc), CAND_DTYPE.itemsize)
+    las = np.ascontiguousarray(raw[:, 8:8 + 2 * LA_DTYPE.itemsize]).reshape(-1).view(LA_DTYPE)
     order = np.argsort(allc["gap"], kind="stable")
     gaps, counts = np.unique(allc["gap"][order], return_counts=True)
     triples = np.stack([allc["read"][order], 2 * order, 2 * order + 1], axis=1).astype(np.int32)
