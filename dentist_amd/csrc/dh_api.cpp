@@ -1152,8 +1152,11 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         lap(0);
         HIPCHK(hipEventRecord(ctx->ev[2], st));
         HIPCHK(hipMemsetAsync(d_queue, 0, 4 * sizeof(uint32_t), st));
+        uint64_t *d_fscr = nullptr;
+        if (cap > 4096 && cap <= 8192)
+            SCR(30, d_fscr, (size_t)ctx->ncu * DH_SEED_FSCR_BLOCKS_PER_CU * DH_SEED_FSCR_WORDS)
         dhk_seed(st, cap, bv, iv, dopt, (int32_t)item0, ni, candbase, ncandbase, nhitsbase, d_status,
-                 d_queue + 1, ctx->ncu);
+                 d_queue + 1, ctx->ncu, d_fscr);
         HIPCHK(hipGetLastError());
         {
             // items whose hits did not fit the LDS buffer (ncand == -1) are redone with their hits

@@ -69,7 +69,11 @@ void dhk_kmer_pass(hipStream_t st, int fill, DbView A, const int2 *tiles, int32_
 void dhk_scan(hipStream_t st, uint32_t *v, int64_t n, uint32_t *sums);
 void dhk_seed(hipStream_t st, int cap, DbView B, IndexView ix, DhOpts o,
               int32_t item0, int32_t nitems, DhCand *cand, int32_t *ncand, int32_t *nhits,
-              int32_t *status, uint32_t *queue, int32_t ncu);
+              int32_t *status, uint32_t *queue, int32_t ncu, uint64_t *fscr);
+// scratch of the 8192-entry seed variant: DH_SEED_FSCR_WORDS 8-byte words per resident block
+// (prefix sums u32[8192] + band heads u16[8192]), DH_SEED_FSCR_BLOCKS_PER_CU blocks per CU at most
+#define DH_SEED_FSCR_WORDS 6144
+#define DH_SEED_FSCR_BLOCKS_PER_CU 4
 void dhk_seed_big(hipStream_t st, DbView B, IndexView ix, DhOpts o,
                   const int32_t *read_list, int32_t nreads, uint64_t *gbuf, int32_t gcap, DhCand *cand,
                   int32_t *ncand, int32_t *nhits, int32_t *status, uint32_t *queue, int32_t ncu);

@@ -594,13 +594,20 @@ __device__ void seed_item(const DbView &B, const IndexView &ix,
     // difference of two prefix sums and the compacted list of band heads, so the work is spread
     // over all threads instead of one serial walk per band; large variants (no LDS to spare) walk
     // the four bands from every band head.
-    constexpr bool FASTB = LCAP > 0 && LCAP <= 4096;
-    __shared__ uint32_t bsum[FASTB ? LCAP : 1];   // inclusive prefix sums
-    __shared__ uint16_t bhead[FASTB ? LCAP : 1];  // positions of the band heads
+    // The 8192-entry variant has no LDS to spare either, but its two arrays fit a per-block slab of
+    // global scratch (48 KB, L2 resident since the persistent block reuses it): the parallel scan beats
+    // the serial walks by far (pile-up all-vs-all: 183 -> about 30 us per read).  18 bits of coverage and
+    // 14 bits of head count hold up to 8192 hits of k <= 28.
+    constexpr bool FASTB = LCAP > 0 && LCAP <= 8192;
+    constexpr bool FB_LDS = LCAP > 0 && LCAP <= 4096;
+    __shared__ uint32_t bsum_l[FB_LDS ? LCAP : 1];   // inclusive prefix sums
+    __shared__ uint16_t bhead_l[FB_LDS ? LCAP : 1];  // positions of the band heads
+    uint32_t *bsum = FB_LDS ? bsum_l : (uint32_t *)(gbuf + (int64_t)slab * gcap);
+    uint16_t *bhead = FB_LDS ? bhead_l : (uint16_t *)(bsum + (LCAP > 0 ? LCAP : 1));
     __shared__ uint32_t s_wsum[SEED_THREADS / LANES];
     __shared__ int32_t s_nbig;
     __shared__ int32_t bigc[64][4];  // candidate band pairs with long hit ranges: (first, end, P, slot)
-    __shared__ unsigned long long s_bestkey;
+    __shared__ unsigned long long s_bestkeys[64];
     const int bs = o.band_shift;
     // seed of a band pair [i, e1): first hit of the same-diagonal run (steps <= k) covering most
     // bases; then the candidate record
@@ -702,13 +709,15 @@ __device__ void seed_item(const DbView &B, const IndexView &ix,
             emit_cand(slot, serial_seed(i, e1), P, band);
         }
         __syncthreads();
+        // long ranges: one wavefront per candidate (no block barrier inside), lanes stride over its hits
         const int32_t nbig = min(s_nbig, 64);
-        for (int32_t bc = 0; bc < nbig; bc++) {
+        for (int32_t bc = tid; bc < nbig; bc += SEED_THREADS) s_bestkeys[bc] = 0ull;
+        __syncthreads();
+        for (int32_t bc = tid / LANES; bc < nbig; bc += SEED_THREADS / LANES) {
             const int32_t i = bigc[bc][0], e1 = bigc[bc][1];
-            if (tid == 0) s_bestkey = 0ull;
-            __syncthreads();
+            unsigned long long best = 0ull;
             // a run ends where the next hit is not linked; its coverage is the largest of the run
-            for (int32_t x = i + tid; x < e1; x += SEED_THREADS) {
+            for (int32_t x = i + (tid & (LANES - 1)); x < e1; x += LANES) {
                 const bool last = x + 1 >= e1 || hitD(hits[x + 1]) != hitD(hits[x]) ||
                                   (hitQ(hits[x + 1]) - hitQ(hits[x])) > k;
                 if (!last) continue;
@@ -716,12 +725,14 @@ __device__ void seed_item(const DbView &B, const IndexView &ix,
                 while (rf > i && hitD(hits[rf]) == hitD(hits[rf - 1]) && (hitQ(hits[rf]) - hitQ(hits[rf - 1])) <= k) rf--;
                 const uint32_t cov = (uint32_t)(k + hitQ(hits[x]) - hitQ(hits[rf]));
                 // largest coverage, then the earliest run
-                atomicMax(&s_bestkey, ((unsigned long long)cov << 32) | (uint32_t)(0x7FFFFFFF - rf));
+                const unsigned long long key = ((unsigned long long)cov << 32) | (uint32_t)(0x7FFFFFFF - rf);
+                best = key > best ? key : best;
             }
-            __syncthreads();
-            if (tid == 0)
-                emit_cand(bigc[bc][3], 0x7FFFFFFF - (int32_t)(uint32_t)s_bestkey, bigc[bc][2], hitD(hits[i]) >> bs);
+            if (best) atomicMax(&s_bestkeys[bc], best);
         }
+        __syncthreads();
+        for (int32_t bc = tid; bc < nbig; bc += SEED_THREADS)
+            emit_cand(bigc[bc][3], 0x7FFFFFFF - (int32_t)(uint32_t)s_bestkeys[bc], bigc[bc][2], hitD(hits[bigc[bc][0]]) >> bs);
     } else {
         for (int32_t i = tid; i < n; i += SEED_THREADS) {
             const int64_t band = hitD(hits[i]) >> bs;
@@ -2393,14 +2404,14 @@ void dhk_scan(hipStream_t st, uint32_t *v, int64_t n, uint32_t *sums)
 // item0 / nitems: even (both strands of the reads [item0 / 2, (item0 + nitems) / 2))
 void dhk_seed(hipStream_t st, int cap, DbView B, IndexView ix, DhOpts o,
               int32_t item0, int32_t nitems, DhCand *cand, int32_t *ncand, int32_t *nhits,
-              int32_t *status, uint32_t *queue, int32_t ncu)
+              int32_t *status, uint32_t *queue, int32_t ncu, uint64_t *fscr)
 {
     if (nitems <= 0) return;
     const int32_t read0 = item0 / 2, nreads = nitems / 2;
 #define SEED_LAUNCH(C)                                                                            \
     hipLaunchKernelGGL(k_seed<C>, dim3(seed_grid<C>(nreads, ncu)), dim3(SEED_THREADS), 0, st, B, ix, o, \
-                       read0, nreads, cand, ncand, nhits, status, (uint64_t *)nullptr, 0,         \
-                       (const int32_t *)nullptr, queue)
+                       read0, nreads, cand, ncand, nhits, status, C == 8192 ? fscr : (uint64_t *)nullptr,    \
+                       C == 8192 ? DH_SEED_FSCR_WORDS : 0, (const int32_t *)nullptr, queue)
     if (cap <= 1024)
         SEED_LAUNCH(1024);
     else if (cap <= 2048)
