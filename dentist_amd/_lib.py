@@ -21,7 +21,7 @@ class DhError(RuntimeError):
 class AlignOpts(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "k", "hmin", "band_shift", "tspace", "min_len", "pen", "xdrop", "max_err_ppm", "max_cand",
-        "max_la", "tcap", "strands", "skip_self", "dmax", "width", "kmer_mod")]
+        "max_la", "tcap", "strands", "skip_self", "dmax", "width", "kmer_mod", "algo")]
 
 
 class AlignStats(ctypes.Structure):

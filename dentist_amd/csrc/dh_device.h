@@ -13,7 +13,7 @@
 
 struct DhOpts {  // == dh_align_opts
     int32_t k, hmin, band_shift, tspace, min_len, pen, xdrop, max_err_ppm, max_cand, max_la, tcap,
-        strands, skip_self, dmax, width, kmer_mod;
+        strands, skip_self, dmax, width, kmer_mod, algo;
 };
 
 struct DbView {

@@ -61,6 +61,9 @@ typedef struct {
     int32_t dmax;        /* cap on differences per extension                                 */
     int32_t width;       /* live diagonals of the wave, <= 62 (one 64-lane wavefront)        */
     int32_t kmer_mod;    /* -%  modimer sampling: only k-mers with hash % kmer_mod == 0; 1 = all     */
+    int32_t algo;        /* extension algorithm: 0 = DH-1, the O(ND) furthest-reaching wave (k_wave2);
+                          * 1 = DH-2, tile-by-tile banded bit-parallel DP, one alignment per lane (k_tile);
+                          *     band = width, which must be 32 or 64; not available with skip_self = 2 */
 } dh_align_opts;
 void dh_default_align_opts(dh_align_opts *o);
 

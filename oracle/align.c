@@ -691,6 +691,134 @@ static int extend(const uint8_t *ap, int astep, int32_t an, const uint8_t *bp, i
     return nb;
 }
 
+/*
+ * DH-2: tile-by-tile banded extension (selected by oz_opts.algo == 1; band = o->width rows, 32 or 64).
+ *
+ * The extension advances through A' one trace tile at a time (the first tile ends at tp_first, the
+ * others are `tspace` columns; the last one ends with A').  A tile that starts at (a0, b0) is a banded
+ * edit-distance DP over its columns c = 0..cols and the rows j (B' bases consumed since b0) with
+ *   c - W/2 <= j <= c + W/2 - 1                         (the band slides down one row per column)
+ *   D[0][j] = |j|
+ *   D[c][j] = min(D[c-1][j-1] + !eq(c, j), left + 1, up + 1)
+ * where up = D[c][j-1] is missing for the top row of the band, and left = D[c-1][j] is, for the
+ * bottom row of the band, the value V[c-1] of a virtual row beneath the band that never matches:
+ *   V[0] = D[0][W/2 - 1] + 1,  V[c] = min(D[c][bottom] + 1, V[c-1] + 1)
+ * (this is exactly what Hyyro's diagonal-band bit-vector recurrence computes; the device kernel is
+ * that recurrence, one alignment per lane).  eq(c, j): rows j <= 0 (before the tile) never match; rows
+ * j > bnr = bn - b0 (past the end of B') match everything, so that D[c][bnr + t] = D[c - t][bnr]:
+ * the cells beneath the end of B' in the last column are the history of B's last row.
+ * At the last column the row with the smallest D wins (ties: closest to the tile's diagonal, then
+ * the lower row).  A row past the end of B' stands for the end point (a0 + cols - t, bn) and ends
+ * the extension, so does the end of A'.  Otherwise the tile's (diffs, b-bases) is a trace point, the
+ * next tile starts at the chosen cell with the band centred on it, and the running score
+ * a + b - pen * diffs decides as in DH-1: the best boundary is remembered, a boundary scoring less
+ * than best - xdrop stops the extension, which then ends at the best boundary.  An end point inside
+ * the last tile replaces the best boundary only if it scores higher.
+ * Same outputs as extend(): best point, crossings (cd[m], cj[m]) = (diffs, j) at A'-offset
+ * tp_first + m*ts for m < nbound(best i), diagonal excursion, cells (= band cells computed).
+ */
+#define T2_WMAX 64
+static int extend_tiled(const uint8_t *ap, int astep, int32_t an, const uint8_t *bp, int bstep,
+                        int32_t bn, int32_t tp_first, const oz_opts *o, int32_t *bi, int32_t *bj,
+                        int32_t *bd_, int32_t *cd, int32_t *cj, int32_t *dlo, int32_t *dhi,
+                        int64_t *cells)
+{
+    const int32_t W = o->width, lo = -(W / 2), ts = o->tspace, pen = o->pen, xdrop = o->xdrop;
+    int32_t a0 = 0, b0 = 0, dsum = 0, ntp = 0;
+    int32_t best_s = 0, best_a = 0, best_b = 0, best_d = 0;
+    int64_t ncell = 0;
+    int32_t D[2][T2_WMAX];
+    if (W != 32 && W != 64) {
+        fprintf(stderr, "oracle: DH-2 needs width 32 or 64\n");
+        abort();
+    }
+    while (a0 < an && b0 < bn) {
+        const int32_t T = ntp == 0 ? tp_first : ts;
+        const int32_t anr = an - a0, bnr = bn - b0;
+        const int32_t cols = T < anr ? T : anr;
+        int cur = 0;
+        int32_t V = W / 2;
+        for (int32_t i = 0; i < W; i++) D[0][i] = lo + i < 0 ? -(lo + i) : lo + i;
+        for (int32_t c = 1; c <= cols; c++) {
+            const int prv = cur;
+            cur ^= 1;
+            const uint8_t ach = ap[(int64_t)(a0 + c - 1) * astep];
+            for (int32_t i = 0; i < W; i++) {
+                const int32_t j = c + lo + i;
+                int eq;
+                if (j <= 0)
+                    eq = 0;
+                else if (j > bnr)
+                    eq = 1;
+                else
+                    eq = ach == bp[(int64_t)(b0 + j - 1) * bstep];
+                int32_t v = D[prv][i] + !eq;
+                const int32_t left = (i + 1 < W ? D[prv][i + 1] : V) + 1;
+                if (left < v) v = left;
+                if (i > 0 && D[cur][i - 1] + 1 < v) v = D[cur][i - 1] + 1;
+                D[cur][i] = v;
+            }
+            V = (D[cur][W - 1] < V ? D[cur][W - 1] : V) + 1;
+            ncell += W;
+        }
+        /* the row of the last column to go on from (or to end at) */
+        uint32_t key = UINT32_MAX;
+        for (int32_t i = 0; i < W; i++) {
+            const int32_t j = cols + lo + i;
+            if (j < 0 || j - bnr > cols) continue;
+            const int32_t off = lo + i < 0 ? -(lo + i) : lo + i;
+            const uint32_t kk = ((uint32_t)D[cur][i] << 16) | ((uint32_t)off << 8) | (uint32_t)(W - 1 - i);
+            if (kk < key) key = kk;
+        }
+        if (key == UINT32_MAX) break; /* (cannot happen: row max(0, ..) of the band is always eligible) */
+        const int32_t ci = W - 1 - (int32_t)(key & 255), dt = (int32_t)(key >> 16);
+        const int32_t j = cols + lo + ci, t = j > bnr ? j - bnr : 0;
+        if (t > 0 || cols < T) {
+            /* the end of B' or of A': an end point inside (or at the end of) this tile */
+            const int32_t ea = a0 + cols - t, eb = b0 + j - t, ed = dsum + dt;
+            const int32_t sc = ea + eb - pen * ed;
+            if (sc > best_s) {
+                best_s = sc;
+                best_a = ea;
+                best_b = eb;
+                best_d = ed;
+            }
+            break;
+        }
+        a0 += T;
+        b0 += j;
+        dsum += dt;
+        cd[ntp] = dsum;
+        cj[ntp] = b0;
+        ntp++;
+        const int32_t sc = a0 + b0 - pen * dsum;
+        if (sc > best_s) {
+            best_s = sc;
+            best_a = a0;
+            best_b = b0;
+            best_d = dsum;
+        } else if (sc < best_s - xdrop)
+            break;
+    }
+    *bi = best_a;
+    *bj = best_b;
+    *bd_ = best_d;
+    const int32_t nb = nbound(best_a, tp_first, ts);
+    int32_t klo = 0, khi = 0;
+    const int32_t bk = best_a - best_b;
+    if (bk < klo) klo = bk;
+    if (bk > khi) khi = bk;
+    for (int32_t m = 0; m < nb; m++) {
+        const int32_t kk = tp_first + m * ts - cj[m];
+        if (kk < klo) klo = kk;
+        if (kk > khi) khi = kk;
+    }
+    *dlo = klo;
+    *dhi = khi;
+    if (cells) *cells += ncell;
+    return nb;
+}
+
 /* trace pairs (delta diffs, delta other) between consecutive grid boundaries, in increasing grid
  * coordinate: grid = the coordinate the trace spacing refers to, other = the opposite sequence.
  * gs/os = seed on the grid / other axis; res = residue of the boundaries (grid = res mod ts). */
@@ -751,10 +879,22 @@ static int local_align2(const uint8_t *a, int32_t alen, const uint8_t *b, int32_
     int32_t *fd = buf, *fj = fd + maxb, *rd = fj + maxb, *rj = rd + maxb;
     int32_t *fdb = rj + maxb, *fib = fdb + maxb, *rdb = fib + maxb, *rib = rdb + maxb;
     int32_t fi, fjv, fdv, ri, rjv, rdv, flo, fhi, rlo, rhi, nfb = 0, nrb = 0;
-    int32_t nf = extend(a + as, 1, alen - as, b + bs, 1, blen - bs, fwd_first, fwdb_first, o, &fi,
-                        &fjv, &fdv, fd, fj, fdb, fib, &nfb, &flo, &fhi, cells);
-    int32_t nr = extend(a + as - 1, -1, as, b + bs - 1, -1, bs, rev_first, revb_first, o, &ri, &rjv,
-                        &rdv, rd, rj, rdb, rib, &nrb, &rlo, &rhi, cells);
+    int32_t nf, nr;
+    if (o->algo == 1) {
+        if (la2) {
+            fprintf(stderr, "oracle: DH-2 has no symmetric mode\n");
+            abort();
+        }
+        nf = extend_tiled(a + as, 1, alen - as, b + bs, 1, blen - bs, fwd_first, o, &fi, &fjv, &fdv, fd, fj,
+                          &flo, &fhi, cells);
+        nr = extend_tiled(a + as - 1, -1, as, b + bs - 1, -1, bs, rev_first, o, &ri, &rjv, &rdv, rd, rj, &rlo,
+                          &rhi, cells);
+    } else {
+        nf = extend(a + as, 1, alen - as, b + bs, 1, blen - bs, fwd_first, fwdb_first, o, &fi, &fjv, &fdv, fd,
+                    fj, fdb, fib, &nfb, &flo, &fhi, cells);
+        nr = extend(a + as - 1, -1, as, b + bs - 1, -1, bs, rev_first, revb_first, o, &ri, &rjv, &rdv, rd, rj,
+                    rdb, rib, &nrb, &rlo, &rhi, cells);
+    }
     la->abpos = as - ri;
     la->bbpos = bs - rjv;
     la->aepos = as + fi;

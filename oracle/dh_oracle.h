@@ -70,6 +70,7 @@ typedef struct {
     int32_t dmax;        /* hard cap on differences per extension                          */
     int32_t width;       /* max live diagonals of the wave (64 = one wavefront)            */
     int32_t kmer_mod;    /* modimer sampling (daligner -%): only k-mers with hash % kmer_mod == 0, 1 = all */
+    int32_t algo;        /* extension: 0 = DH-1 (O(ND) wave), 1 = DH-2 (tiled banded DP, band = width in {32, 64}) */
 } oz_opts;
 
 void oz_default_opts(oz_opts *o);

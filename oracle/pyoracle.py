@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 class Opts(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "k", "hmin", "band_shift", "tspace", "min_len", "pen", "xdrop", "max_err_ppm", "max_cand",
-        "max_la", "tcap", "strands", "skip_self", "dmax", "width", "kmer_mod")]
+        "max_la", "tcap", "strands", "skip_self", "dmax", "width", "kmer_mod", "algo")]
 
 
 class La(ctypes.Structure):

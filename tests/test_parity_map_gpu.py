@@ -15,7 +15,7 @@ from oracle import pyoracle as oz
 pytestmark = pytest.mark.gpu
 
 OPT_FIELDS = ("k", "hmin", "band_shift", "tspace", "min_len", "pen", "xdrop", "max_err_ppm", "max_cand",
-              "max_la", "tcap", "strands", "skip_self", "dmax", "width", "kmer_mod")
+              "max_la", "tcap", "strands", "skip_self", "dmax", "width", "kmer_mod", "algo")
 
 
 def both_opts(**kw):
