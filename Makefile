@@ -36,3 +36,7 @@ clean:
 	rm -f $(LIB) $(SIM) $(TOOLS); $(MAKE) -C oracle clean
 
 .PHONY: all oracle clean
+
+# the DH-2 lane code (dentist_amd/csrc/dh_tile.h) compiled for the CPU: test infrastructure
+tests/native/libdh_tile_host.so: tests/native/tile_host.cpp dentist_amd/csrc/dh_tile.h dentist_amd/csrc/dh_device.h
+	g++ -O2 -g -shared -fPIC -std=c++17 -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -Wno-unknown-pragmas -o $@ $<

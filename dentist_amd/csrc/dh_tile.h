@@ -1,0 +1,440 @@
+// dh_tile.h -- DH-2, the tile-by-tile banded bit-parallel extension: one alignment per LANE.
+//
+// Role: the local-alignment arithmetic of `damapper` / `daligner -A` (call sites
+// source/dentist/dazzler.d:6121-6170; argv source/dentist/commandline.d:2918-2955), selected with
+// dh_align_opts.algo = 1.  DESIGN.md section 3 ("DH-2") states the algorithm; oracle/align.c
+// (extend_tiled) is its plain-DP restatement and the parity fence.
+//
+// This header is the whole per-lane state machine -- work fetch, candidate loop, tile set-up, the
+// column step (Hyyro's diagonal-band form of Myers' bit-vector recurrence on one 64-bit word), the
+// choice of the next tile's origin, trace pairs, records -- written once as host/device code:
+//   * k_tile (dh_tile.hip) runs it with 64 lanes per wavefront, the column loop in lock step;
+//   * tests/native/tile_host.cpp compiles the same functions for the CPU, so that `-m "not gpu"`
+//     tests compare this very code with the oracle (no GPU needed to find an arithmetic slip).
+#ifndef DH_TILE_H
+#define DH_TILE_H
+
+#include <stdint.h>
+
+#include "dh_device.h"
+
+#if defined(__HIPCC__)
+#define DH_HD __host__ __device__ __forceinline__
+#else
+#define DH_HD inline
+#endif
+
+namespace dhtile {
+
+constexpr int W = 64;        // band rows = bits of one vector
+constexpr int TS_MAX = 128;  // longest tile (trace spacing) the per-tile buffers hold
+constexpr int NQ = 7;        // plane words of a tile: window bits [0, 224) >= (TS_MAX - 1) + 64 + 31
+constexpr int NAW = 9;       // raw packed-A words of a tile: 2 * TS_MAX bits + 30 bits of misalignment
+constexpr int MAXREG = 64;   // aligned regions remembered per (read, strand) item (as DH-1)
+constexpr int REGF = 8;      // ints per region (7 used)
+
+enum { L_FETCH = 0, L_CAND = 1, L_RUN = 2, L_EXT_END = 3, L_DONE = 4 };
+
+struct PlanePair {  // 32 bases of a plane-packed copy: bit g & 31 of .x / .y = low / high bit of base g
+    uint32_t x, y;
+};
+
+struct Params {
+    const int64_t *aoff, *boff;       // offsets of the A / B sequences (bases)
+    const uint32_t *apk, *arcpk;      // 2-bit packed A, forward / reverse complement: base g in dword g >> 4, bits 2 (g & 15)
+    const PlanePair *bpp, *brcpp;     // plane-packed B, forward / reverse complement (indexed by absolute base >> 5)
+    DhOpts o;
+    int32_t item0, nitems;            // items (read * 2 + strand) [item0, item0 + nitems)
+    const DhCand *cand;               // max_cand per item, indexed by absolute item
+    const int32_t *ncand;
+    uint32_t *queue;                  // work counter
+    int32_t *regs;                    // nlanes * MAXREG * REGF
+    int32_t nbmax, trmax;             // pairs a direction can yield; u16 values per output slot (>= 2 * (2 * nbmax + 2))
+    DhLa *out_la;                     // max_la records per item (absolute item index)
+    uint16_t *out_trace;              // trmax values per record slot
+    int32_t *out_nla, *out_ntr;       // per item
+    unsigned long long *counters;     // [0] band cells computed, [1] candidates aligned
+    int32_t *status;
+};
+
+// one running extension
+struct Ext {
+    int64_t ga, gb;           // absolute base index of A'[0] / B'[0] in the copies of this direction
+    const uint32_t *apk;
+    const PlanePair *bpp;
+    int32_t an, bn, tp_first;
+    int32_t a0, b0, dsum, ntp;
+    int32_t best_s, best_a, best_b, best_d, best_nseg;  // best end so far; nseg = trace segments up to it
+    int32_t klo, khi, bklo, bkhi;                       // diagonal excursion: path so far / up to the best end
+    uint32_t pair1, best_pair1;                         // first segment (diffs << 16 | bbases): as computed / of the best end
+};
+
+struct Lane {
+    int32_t st;
+    // item
+    int32_t item, strand, nc, c, blen, nd, nacc, ntr;
+    int64_t bo;
+    // candidate
+    int32_t c_aseq, as, bs, alen, roff;
+    int64_t ao;
+    int32_t dir;  // 1 = reverse extension (runs first), 0 = forward
+    // result of the reverse extension
+    int32_t rv_i, rv_j, rv_d, rv_nseg, rv_klo, rv_khi;
+    uint32_t rv_pair1;
+    Ext e;
+    uint64_t cells;
+    uint32_t naln;
+    int32_t slot;  // lane slot (scratch index)
+    int32_t err;
+};
+
+// the tile in flight
+struct Tile {
+    uint64_t Pv, Mv, lv, wild;
+    int32_t z, dbot, cols, bnr, T;
+    uint32_t q0[NQ], q1[NQ];  // plane windows: bit x of the 224-bit string = B'[b0 - 32 + x]
+    uint32_t aw[NAW - 1];     // A'[a0 + x] at bits 2x of the 256-bit string
+};
+
+DH_HD uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t sh)  // ({hi, lo} >> sh)[31:0], sh in [0, 31]
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31u));
+#endif
+}
+
+DH_HD int32_t nbound(int32_t x, int32_t first, int32_t ts) { return x >= first ? (x - first) / ts + 1 : 0; }
+
+// ------------------------------------------------------------------------------ extension
+
+DH_HD void ext_begin(Lane &l, const Params &P, int32_t dir)
+{
+    Ext &e = l.e;
+    l.dir = dir;
+    const int32_t ts = P.o.tspace, as = l.as, bs = l.bs;
+    // the reverse extension is a forward extension over the reverse-complemented copies
+    e.ga = l.ao + (dir ? l.alen - as : as);
+    e.gb = l.bo + (dir ? l.blen - bs : bs);
+    e.an = dir ? as : l.alen - as;
+    e.bn = dir ? bs : l.blen - bs;
+    const bool brc_side = (l.strand != 0) != (dir != 0);
+    e.apk = dir ? P.arcpk : P.apk;
+    e.bpp = brc_side ? P.brcpp : P.bpp;
+    e.tp_first = dir ? ((as % ts) ? (as % ts) : ts) : ts - (as % ts);
+    e.a0 = e.b0 = e.dsum = e.ntp = 0;
+    e.best_s = e.best_a = e.best_b = e.best_d = e.best_nseg = 0;
+    e.klo = e.khi = e.bklo = e.bkhi = 0;
+    e.pair1 = e.best_pair1 = 0;
+    l.st = (e.an > 0 && e.bn > 0) ? L_RUN : L_EXT_END;
+}
+
+DH_HD void tile_setup(const Lane &l, const Params &P, Tile &t)
+{
+    const Ext &e = l.e;
+    t.T = e.ntp == 0 ? e.tp_first : P.o.tspace;
+    const int32_t anr = e.an - e.a0;
+    t.bnr = e.bn - e.b0;
+    t.cols = t.T < anr ? t.T : anr;
+    // column 0: D[0][j] = |j| for the band rows j = i - W/2; vectors aligned for column 1
+    t.Pv = ~0ull << (W / 2);
+    t.Mv = ~t.Pv;
+    t.dbot = W / 2 - 1;
+    t.lv = ~0ull << (W / 2 + 1);  // rows j >= 1 of column 0
+    const int32_t th = t.bnr + W / 2 + 1;  // first bit of column 0 past the end of B'
+    t.wild = th >= 64 ? 0ull : ~0ull << th;
+    t.z = t.bnr - W / 2 + 1;
+    // B planes: bit x of the window string = base (gb + b0 - W/2 + x)
+    {
+        const int64_t g = e.gb + e.b0 - W / 2;
+        const PlanePair *p = e.bpp + (g >> 5);
+        const uint32_t s = (uint32_t)(g & 31);
+        PlanePair r[NQ + 1];
+#pragma unroll
+        for (int i = 0; i <= NQ; i++) r[i] = p[i];
+#pragma unroll
+        for (int i = 0; i < NQ; i++) {
+            t.q0[i] = funnel(r[i + 1].x, r[i].x, s);
+            t.q1[i] = funnel(r[i + 1].y, r[i].y, s);
+        }
+    }
+    // A: base x of the tile = base (ga + a0 + x)
+    {
+        const int64_t g = e.ga + e.a0;
+        const uint32_t *p = e.apk + (g >> 4);
+        const uint32_t s = (uint32_t)(g & 15) << 1;
+        uint32_t r[NAW];
+#pragma unroll
+        for (int i = 0; i < NAW; i++) r[i] = p[i];
+#pragma unroll
+        for (int i = 0; i < NAW - 1; i++) t.aw[i] = funnel(r[i + 1], r[i], s);
+    }
+}
+
+// one column of the band: c = 1 .. cols.  (p0, p1) = plane windows of the column: bit i = low / high bit
+// of base B'[b0 + c + i - W/2 - 1], the base a path consumes to reach row i of the column; x = A'[a0 + c - 1]
+DH_HD void tile_col(Tile &t, uint64_t p0, uint64_t p1, uint32_t x)
+{
+    const uint64_t x0 = 0ull - (uint64_t)(x & 1u), x1 = 0ull - (uint64_t)((x >> 1) & 1u);
+    // rows before the tile's origin never match (lv), rows past the end of B' match everything (wild)
+    t.lv = (uint64_t)((int64_t)t.lv >> 1);
+    t.z -= 1;
+    t.wild = (uint64_t)((int64_t)t.wild >> 1) | ((uint64_t)((uint32_t)t.z & 0x80000000u) << 32);
+    const uint64_t Eq = (~((p0 ^ x0) | (p1 ^ x1)) & t.lv) | t.wild;
+    const uint64_t Pv = t.Pv, Mv = t.Mv;
+    const uint64_t D0 = (((Eq & Pv) + Pv) ^ Pv) | Eq | Mv;
+    const uint64_t HP = Mv | ~(D0 | Pv), HN = Pv & D0;
+    const uint64_t Xv = D0 >> 1;
+    t.Pv = HN | ~(Xv | HP);
+    t.Mv = HP & Xv;
+    t.dbot += 1 - (int32_t)(D0 >> 63);
+}
+
+// the columns of a tile in sequence (host; the device kernel runs the same steps in lock step)
+DH_HD void tile_window(const Tile &t, int32_t c, uint64_t &p0, uint64_t &p1, uint32_t &x)
+{
+    const int32_t cm = c - 1, k = cm >> 5;
+    const uint32_t sh = (uint32_t)(cm & 31);
+    p0 = (uint64_t)funnel(t.q0[k + 1], t.q0[k], sh) | ((uint64_t)funnel(t.q0[k + 2], t.q0[k + 1], sh) << 32);
+    p1 = (uint64_t)funnel(t.q1[k + 1], t.q1[k], sh) | ((uint64_t)funnel(t.q1[k + 2], t.q1[k + 1], sh) << 32);
+    x = (t.aw[cm >> 4] >> ((cm & 15) << 1)) & 3u;
+}
+
+// the last column: the row to go on from / to end at.  Returns the key (D << 16 | |row - diagonal| << 8 | W-1-i)
+DH_HD uint32_t tile_scan(const Tile &t)
+{
+    // eligible rows: j = cols - W/2 + i >= 0 and j - bnr <= cols
+    const int32_t imin = W / 2 - t.cols, imax = t.bnr + W / 2;
+    uint32_t key = 0xFFFFFFFFu;
+    int32_t d = t.dbot;
+#pragma unroll
+    for (int i = W - 1; i >= 0; i--) {
+        if (i < W - 1) d += (int32_t)((t.Mv >> i) & 1u) - (int32_t)((t.Pv >> i) & 1u);
+        const uint32_t off = (uint32_t)(i >= W / 2 ? i - W / 2 : W / 2 - i);
+        uint32_t kk = ((uint32_t)d << 16) | (off << 8) | (uint32_t)(W - 1 - i);
+        kk = (i >= imin && i <= imax) ? kk : 0xFFFFFFFFu;
+        key = kk < key ? kk : key;
+    }
+    return key;
+}
+
+// a tile is done: trace pair, next origin or end of the extension.  `pairs` = trace slot of the candidate
+DH_HD void tile_end(Lane &l, const Params &P, const Tile &t, uint16_t *pairs)
+{
+    Ext &e = l.e;
+    const int32_t ts = P.o.tspace, pen = P.o.pen, nbmax = P.nbmax;
+    l.cells += (uint64_t)t.cols * W;
+    const uint32_t key = tile_scan(t);
+    const int32_t ci = W - 1 - (int32_t)(key & 255u), dt = (int32_t)(key >> 16);
+    const int32_t j = t.cols - W / 2 + ci, tw = j > t.bnr ? j - t.bnr : 0;
+    // pair index of this tile in the candidate's slot: interval (floor(as / ts) +- ...) -> nbmax +- ...
+    const int32_t kt = e.ntp + 1;  // 1-based tile number
+    const int32_t pidx = l.dir ? nbmax - kt + l.roff : nbmax + kt - 1;
+    if (pidx < 0 || 2 * pidx + 1 >= P.trmax) {
+        l.err |= DH_ST_POOL_OVERFLOW;
+        l.st = L_EXT_END;
+        return;
+    }
+    if (tw > 0 || t.cols < t.T) {
+        // the end of B' (a row past it stands for the cell (cols - tw, bnr)) or of A'
+        const int32_t ea = e.a0 + t.cols - tw, eb = e.b0 + j - tw, ed = e.dsum + dt;
+        const int32_t sc = ea + eb - pen * ed;
+        if (sc > e.best_s) {
+            const int32_t k = ea - eb;
+            e.best_s = sc;
+            e.best_a = ea;
+            e.best_b = eb;
+            e.best_d = ed;
+            e.bklo = k < e.klo ? k : e.klo;
+            e.bkhi = k > e.khi ? k : e.khi;
+            const uint32_t pr = ((uint32_t)dt << 16) | (uint32_t)(j - tw);
+            // a last segment without A bases (the end sits on the previous boundary) adds no pair
+            const bool seg = ea > e.a0;
+            e.best_nseg = e.ntp + (seg ? 1 : 0);
+            e.best_pair1 = kt == 1 ? (seg ? pr : 0u) : e.pair1;
+            if (seg && kt > 1) {
+                pairs[2 * pidx] = (uint16_t)dt;
+                pairs[2 * pidx + 1] = (uint16_t)(j - tw);
+            }
+        }
+        l.st = L_EXT_END;
+        return;
+    }
+    e.a0 += t.T;
+    e.b0 += j;
+    e.dsum += dt;
+    e.ntp = kt;
+    if (kt == 1)
+        e.pair1 = ((uint32_t)dt << 16) | (uint32_t)j;
+    else {
+        pairs[2 * pidx] = (uint16_t)dt;
+        pairs[2 * pidx + 1] = (uint16_t)j;
+    }
+    const int32_t k = e.a0 - e.b0;
+    e.klo = k < e.klo ? k : e.klo;
+    e.khi = k > e.khi ? k : e.khi;
+    const int32_t sc = e.a0 + e.b0 - pen * e.dsum;
+    if (sc > e.best_s) {
+        e.best_s = sc;
+        e.best_a = e.a0;
+        e.best_b = e.b0;
+        e.best_d = e.dsum;
+        e.best_nseg = kt;
+        e.best_pair1 = e.pair1;
+        e.bklo = e.klo;
+        e.bkhi = e.khi;
+    } else if (sc < e.best_s - P.o.xdrop) {
+        l.st = L_EXT_END;
+        return;
+    }
+    if (e.a0 >= e.an || e.b0 >= e.bn) l.st = L_EXT_END;
+    (void)ts;
+}
+
+// ------------------------------------------------------------------------------ bookkeeping
+
+DH_HD void lane_init(Lane &l, int32_t slot)
+{
+    l.st = L_FETCH;
+    l.cells = 0;
+    l.naln = 0;
+    l.slot = slot;
+    l.err = 0;
+    l.item = l.strand = l.nc = l.c = l.blen = l.nd = l.nacc = l.ntr = 0;
+    l.bo = 0;
+    l.c_aseq = l.as = l.bs = l.alen = l.roff = 0;
+    l.ao = 0;
+    l.dir = 0;
+    l.rv_i = l.rv_j = l.rv_d = l.rv_nseg = l.rv_klo = l.rv_khi = 0;
+    l.rv_pair1 = 0;
+}
+
+// `it` = work item index in [0, nitems)
+DH_HD void lane_fetch(Lane &l, const Params &P, int32_t it)
+{
+    const int32_t item = P.item0 + it;
+    l.item = item;
+    l.strand = item & 1;
+    const int32_t nc = P.ncand[item];
+    l.nc = nc > 0 ? nc : 0;
+    const int64_t bo = P.boff[item >> 1];
+    l.bo = bo;
+    l.blen = (int32_t)(P.boff[(item >> 1) + 1] - bo);
+    l.nd = l.nacc = l.ntr = 0;
+    l.c = 0;
+    l.st = L_CAND;
+}
+
+// next candidate of the item that no aligned region covers -> its reverse extension; none -> item done
+DH_HD void lane_next_cand(Lane &l, const Params &P)
+{
+    const int32_t *rg = P.regs + (int64_t)l.slot * MAXREG * REGF;
+    while (l.c < l.nc && l.nacc < P.o.max_la && l.nd < MAXREG) {
+        const DhCand cd = P.cand[(int64_t)l.item * P.o.max_cand + l.c];
+        const int32_t sdc = cd.apos - cd.bpos;
+        bool covd = false;
+        for (int32_t x = 0; x < l.nd; x++) {
+            const int32_t *g = rg + x * REGF;
+            covd = covd || (g[0] == cd.aseq && cd.apos >= g[1] && cd.apos < g[2] && cd.bpos >= g[3] && cd.bpos < g[4] &&
+                            sdc >= g[5] - 64 && sdc <= g[6] + 64);
+        }
+        if (covd) {
+            l.c++;
+            continue;
+        }
+        l.c_aseq = cd.aseq;
+        l.as = cd.apos;
+        l.bs = cd.bpos;
+        const int64_t ao = P.aoff[cd.aseq];
+        l.ao = ao;
+        l.alen = (int32_t)(P.aoff[cd.aseq + 1] - ao);
+        l.roff = (cd.apos % P.o.tspace) != 0 ? 1 : 0;
+        ext_begin(l, P, 1);
+        return;
+    }
+    P.out_nla[l.item] = l.nacc;
+    P.out_ntr[l.item] = l.ntr;
+    l.st = L_FETCH;
+}
+
+// an extension ended: after the reverse one the forward one starts, after the forward one the candidate
+// becomes a region and, if it passes, a record
+DH_HD void lane_ext_end(Lane &l, const Params &P)
+{
+    Ext &e = l.e;
+    if (l.err) {
+        l.st = L_DONE;
+        return;
+    }
+    if (l.dir == 1) {
+        l.rv_i = e.best_a;
+        l.rv_j = e.best_b;
+        l.rv_d = e.best_d;
+        l.rv_nseg = e.best_nseg;
+        l.rv_klo = e.bklo;
+        l.rv_khi = e.bkhi;
+        l.rv_pair1 = e.best_pair1;
+        ext_begin(l, P, 0);
+        return;
+    }
+    l.naln += 1;
+    const int32_t as = l.as, bs = l.bs, sd = as - bs;
+    const int32_t abpos = as - l.rv_i, bbpos = bs - l.rv_j, aepos = as + e.best_a, bepos = bs + e.best_b;
+    const int32_t diffs = l.rv_d + e.best_d;
+    int32_t lo = sd + e.bklo, hi = sd + e.bkhi;
+    lo = (sd - l.rv_khi) < lo ? (sd - l.rv_khi) : lo;
+    hi = (sd - l.rv_klo) > hi ? (sd - l.rv_klo) : hi;
+    int32_t *g = P.regs + ((int64_t)l.slot * MAXREG + l.nd) * REGF;
+    g[0] = l.c_aseq;
+    g[1] = abpos;
+    g[2] = aepos;
+    g[3] = bbpos;
+    g[4] = bepos;
+    g[5] = lo;
+    g[6] = hi;
+    l.nd += 1;
+    l.c += 1;
+    const int64_t al = aepos - abpos, bl = bepos - bbpos;
+    const bool accept = al >= P.o.min_len && (int64_t)2 * diffs * 1000000ll <= (int64_t)P.o.max_err_ppm * (al + bl);
+    if (accept) {
+        const int64_t oslot = (int64_t)l.item * P.o.max_la + l.nacc;
+        uint16_t *pairs = P.out_trace + oslot * P.trmax;
+        const int32_t nbmax = P.nbmax, nr = l.rv_nseg, nf = e.best_nseg;
+        // the pair of the seed's interval: the forward tile 1 plus, when the seed is not on a boundary,
+        // the reverse tile 1 (the two are the halves of one trace interval)
+        const uint32_t seedp = (nf >= 1 ? e.best_pair1 : 0u) + ((l.roff && nr >= 1) ? l.rv_pair1 : 0u);
+        const bool seedslot = nf >= 1 || (l.roff && nr >= 1);
+        if (seedslot) {
+            pairs[2 * nbmax] = (uint16_t)(seedp >> 16);
+            pairs[2 * nbmax + 1] = (uint16_t)(seedp & 0xFFFFu);
+        }
+        if (!l.roff && nr >= 1) {  // the reverse tile 1 is an interval of its own
+            pairs[2 * (nbmax - 1)] = (uint16_t)(l.rv_pair1 >> 16);
+            pairs[2 * (nbmax - 1) + 1] = (uint16_t)(l.rv_pair1 & 0xFFFFu);
+        }
+        const int32_t lo_idx = nbmax - nr + l.roff;
+        const int32_t hi_idx = nbmax + (nf > (seedslot ? 1 : 0) ? nf : (seedslot ? 1 : 0));
+        const int32_t first = (nr == 0 && l.roff) ? nbmax : lo_idx;  // no reverse segment: the range starts at the seed slot
+        const int32_t npairs = hi_idx - first;
+        DhLa la;
+        la.tlen = 2 * npairs;
+        la.diffs = diffs;
+        la.abpos = abpos;
+        la.bbpos = bbpos;
+        la.aepos = aepos;
+        la.bepos = bepos;
+        la.flags = l.strand ? 1u : 0u;
+        la.aread = l.c_aseq;
+        la.bread = l.item >> 1;
+        la.pad = 0;
+        la.toff = 2 * (int64_t)first;  // where the pairs start inside the slot (k_compact honours it)
+        P.out_la[oslot] = la;
+        l.nacc += 1;
+        l.ntr += 2 * npairs;
+    }
+    l.st = L_CAND;
+}
+
+}  // namespace dhtile
+#endif

@@ -349,3 +349,36 @@ def with_dust(seqdb):
     ptr, iv = dust(seqdb)
     out.mask = (ptr, np.concatenate([iv, np.zeros(2, np.int32)]))
     return out
+
+
+# ---------------------------------------------------------------- seed candidates of every item
+CAND_DTYPE = np.dtype([("score", "<i4"), ("aseq", "<i4"), ("apos", "<i4"), ("bpos", "<i4"), ("band", "<i8")])
+
+
+def seed_candidates_all(A, B, opts):
+    """Candidates of every (read, strand) item of B, in item order (item = 2 * read + strand):
+    (cand[nitems, max_cand] CAND_DTYPE, ncand[nitems]) -- what the seed stage hands to the extension."""
+    from dentist_amd.sim import revcomp
+    L = lib()
+    L.oz_index_build.restype = ctypes.c_void_p
+    L.oz_index_build.argtypes = [ctypes.POINTER(Db), ctypes.POINTER(Opts)]
+    L.oz_index_free.argtypes = [ctypes.c_void_p]
+    L.oz_seed_candidates.restype = ctypes.c_int
+    L.oz_seed_candidates.argtypes = [ctypes.c_void_p, ctypes.POINTER(Db), ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                     ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(Opts), ctypes.c_void_p, ctypes.c_void_p]
+    da = _db(A)
+    ix = L.oz_index_build(ctypes.byref(da), ctypes.byref(opts))
+    cand = np.zeros((2 * B.n, opts.max_cand + 1), dtype=CAND_DTYPE)
+    ncand = np.zeros(2 * B.n, dtype=np.int32)
+    nh = ctypes.c_int32(0)
+    for r in range(B.n):
+        for s in range(2):
+            if not opts.strands & (1 << s):
+                continue
+            b = np.ascontiguousarray(B.seq(r) if s == 0 else revcomp(B.seq(r)))
+            row = cand[2 * r + s]
+            ncand[2 * r + s] = L.oz_seed_candidates(ix, ctypes.byref(da), b.ctypes.data, len(b),
+                                                    int(B.group[r]) if B.group is not None else 0, r, 0,
+                                                    ctypes.byref(opts), row.ctypes.data, ctypes.byref(nh))
+    L.oz_index_free(ix)
+    return cand[:, :opts.max_cand], ncand

@@ -1,0 +1,85 @@
+"""DH-2 without a GPU: the lane state machine of dentist_amd/csrc/dh_tile.h (the code k_tile runs --
+tile set-up, bit-vector column step, scan, trace pairs, candidate loop, records) compiled for the CPU
+(tests/native/tile_host.cpp) against the oracle's plain-DP restatement (oracle/align.c: extend_tiled).
+Bit-exact: every record field and every trace value."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from dentist_amd import sim
+from helpers import assert_same_las, check_trace_invariants
+from oracle import pyoracle as oz
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DHCAND = np.dtype([("score", "<i4"), ("aseq", "<i4"), ("apos", "<i4"), ("bpos", "<i4")])
+
+
+@pytest.fixture(scope="module")
+def host_lib():
+    path = os.path.join(ROOT, "tests", "native", "libdh_tile_host.so")
+    if not os.path.exists(path):
+        subprocess.run(["make", "-C", ROOT, "tests/native/libdh_tile_host.so"], check=True)
+    L = ctypes.CDLL(path)
+    L.dh_tile_host_align.restype = ctypes.c_long
+    L.dh_tile_host_align.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_int32, ctypes.POINTER(oz.Opts), ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]
+    return L
+
+
+def run_host(L, A, B, o):
+    cand, ncand = oz.seed_candidates_all(A, B, o)
+    dc = np.zeros(cand.shape, dtype=DHCAND)
+    for f in ("score", "aseq", "apos", "bpos"):
+        dc[f] = cand[f]
+    dc = np.ascontiguousarray(dc)
+    maxlen = int(max((A.off[1:] - A.off[:-1]).max(), (B.off[1:] - B.off[:-1]).max()))
+    nbmax = maxlen // o.tspace + 3
+    las = np.zeros(2 * B.n * o.max_la, dtype=oz.LA_DTYPE)
+    cap = int(2 * B.n * o.max_la * 2 * (2 * nbmax + 2))
+    trace = np.zeros(cap, dtype=np.uint16)
+    counters = np.zeros(2, dtype=np.uint64)
+    n = L.dh_tile_host_align(A.bases.ctypes.data, A.off.ctypes.data, A.n, B.bases.ctypes.data, B.off.ctypes.data, B.n,
+                             ctypes.byref(o), dc.ctypes.data, ncand.ctypes.data, nbmax, las.ctypes.data,
+                             trace.ctypes.data, cap, counters.ctypes.data)
+    assert n >= 0, n
+    return las[:n], trace, counters
+
+
+@pytest.mark.parametrize("kw", [
+    dict(seed=3, tspace=100, err=0.13),
+    dict(seed=4, tspace=126, err=0.13),
+    dict(seed=5, tspace=100, err=0.20, xdrop=60),
+    dict(seed=6, tspace=64, err=0.05),
+    dict(seed=7, tspace=128, err=0.13, min_len=100),
+])
+def test_lane_state_machine_equals_oracle(host_lib, kw):
+    w = sim.Workload(300_000, 4, 500, 5000, seed=kw["seed"], err=kw["err"], spacing=20000, gap_max=800)
+    o = oz.default_opts(algo=1, width=64, k=16, kmer_mod=2, tspace=kw["tspace"], xdrop=kw.get("xdrop", 120),
+                        min_len=kw.get("min_len", 500))
+    exp_las, exp_trace, stats = oz.align_db(w.contigs, w.reads, o, nthreads=4, sort=False)
+    las, trace, counters = run_host(host_lib, w.contigs, w.reads, o)
+    assert len(exp_las) >= 450
+    assert_same_las((las, trace), (exp_las, exp_trace))
+    check_trace_invariants(las, trace, o.tspace)
+    assert int(counters[0]) == stats[3] and int(counters[1]) == stats[2]
+
+
+def test_short_and_ragged_inputs(host_lib):
+    """Reads shorter than a tile / than the band, reads hanging over both contig ends, a read equal to
+    its contig, tiny contigs: the ends of A' and B' inside the first tile on either side of the seed."""
+    rng = np.random.default_rng(11)
+    g = rng.integers(0, 4, 6000).astype(np.uint8)
+    contigs = sim.SeqDb.from_list([g[:3000], g[3100:3160], g[3200:6000], g[100:140]])
+    reads = [g[2900:3000], g[2950:3160], g[0:3000], g[3150:3300], g[10:70], sim.revcomp(g[3300:5900]), g[3100:3160],
+             g[2990:3110], g[20:52]]
+    o = oz.default_opts(algo=1, width=64, k=12, hmin=20, min_len=20, tspace=100)
+    B = sim.SeqDb.from_list(reads)
+    exp_las, exp_trace, _ = oz.align_db(contigs, B, o, nthreads=1, sort=False)
+    las, trace, _ = run_host(host_lib, contigs, B, o)
+    assert len(exp_las) >= 8
+    assert_same_las((las, trace), (exp_las, exp_trace))
+    check_trace_invariants(las, trace, 100)
