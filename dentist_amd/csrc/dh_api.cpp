@@ -12,6 +12,7 @@
 #include <numeric>
 
 #include "dh_internal.h"
+#include "dh_tile.h"
 #include "dh_parallel.h"
 
 static_assert(sizeof(dh_align_opts) == sizeof(DhOpts), "opts layout");
@@ -596,12 +597,12 @@ int dh_ensure_packed(dh_db *db, bool with_rc)
 {
     if (db->has_n == 1) return DH_OK;
     hipStream_t st = db->ctx->stream;
-    const size_t bytes = (size_t)((db->total + 31) / 32) * 8 + 32;
+    const size_t bytes = (size_t)((db->total + 31) / 32) * 8 + 2 * PK_PAD;
     if (!db->d_pk) {
         int32_t *d_flag;
         if (int rc = dh_scratch(db->ctx, 3, 4 * sizeof(int32_t), (void **)&d_flag)) return rc;
         HIPCHK(dh_dev_alloc((void **)&db->d_pk_alloc, bytes));
-        db->d_pk = db->d_pk_alloc + 16;
+        db->d_pk = db->d_pk_alloc + PK_PAD;
         HIPCHK(hipMemsetAsync(d_flag + 1, 0, sizeof(int32_t), st));
         dhk_pack2(st, db->d_bases, db->total, db->d_pk, d_flag + 1);
         HIPCHK(hipGetLastError());
@@ -620,7 +621,7 @@ int dh_ensure_packed(dh_db *db, bool with_rc)
         int32_t *d_flag;
         if (int rc = dh_scratch(db->ctx, 3, 4 * sizeof(int32_t), (void **)&d_flag)) return rc;
         HIPCHK(dh_dev_alloc((void **)&db->d_rcpk_alloc, bytes));
-        db->d_rcpk = db->d_rcpk_alloc + 16;
+        db->d_rcpk = db->d_rcpk_alloc + PK_PAD;
         dhk_pack2(st, db->d_rc, db->total, db->d_rcpk, d_flag + 2);
         HIPCHK(hipGetLastError());
     }
@@ -918,6 +919,9 @@ int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, i
 struct ChunkCopies {
     const uint8_t *rc = nullptr, *pk = nullptr, *rcpk = nullptr;
     bool has_n = false;
+    // the packed words of the chunk themselves (unshifted) -- k_tile turns them into plane words in place
+    uint8_t *pk_w0 = nullptr, *rcpk_w0 = nullptr;
+    int64_t pk_words = 0;
 };
 static int chunk_copies(dh_ctx *ctx, dh_db *B, int32_t r0, int32_t r1, bool want_packed, bool need_bytes,
                         ChunkCopies *out)
@@ -941,21 +945,24 @@ static int chunk_copies(dh_ctx *ctx, dh_db *B, int32_t r0, int32_t r1, bool want
     };
     if (!want_packed) return rc_bytes();
     // 2-bit packed forward copy and, straight from the forward bytes, the packed reverse complements
-    const size_t pbytes = (size_t)((o1 - a0 + 31) / 32) * 8 + 32;
+    const size_t pbytes = (size_t)((o1 - a0 + 31) / 32) * 8 + 2 * PK_PAD;
     if (int rc = dh_scratch(ctx, 27, pbytes, (void **)&d_pk)) return rc;
     if (int rc = dh_scratch(ctx, 28, pbytes, (void **)&d_rcpk)) return rc;
     if (int rc = dh_scratch(ctx, 3, 4 * sizeof(int32_t), (void **)&d_flag)) return rc;
     HIPCHK(hipMemsetAsync(d_flag + 1, 0, 2 * sizeof(int32_t), st));
     HIPCHK(hipMemsetAsync(d_rcpk, 0, pbytes, st));
-    dhk_pack2(st, B->d_bases + a0, o1 - a0, d_pk + 16, d_flag + 1);
-    dhk_pack2_rc(st, B->d_bases, B->d_off + r0, r1 - r0, B->max_len, a0, d_rcpk + 16);
+    dhk_pack2(st, B->d_bases + a0, o1 - a0, d_pk + PK_PAD, d_flag + 1);
+    dhk_pack2_rc(st, B->d_bases, B->d_off + r0, r1 - r0, B->max_len, a0, d_rcpk + PK_PAD);
     HIPCHK(hipGetLastError());
     int32_t flag = 0;
     HIPCHK(hipMemcpyAsync(&flag, d_flag + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     out->has_n = flag != 0;
-    out->pk = d_pk + 16 - (a0 >> 2);
-    out->rcpk = d_rcpk + 16 - (a0 >> 2);
+    out->pk = d_pk + PK_PAD - (a0 >> 2);
+    out->rcpk = d_rcpk + PK_PAD - (a0 >> 2);
+    out->pk_words = (o1 - a0 + 31) / 32;
+    out->pk_w0 = d_pk + PK_PAD;
+    out->rcpk_w0 = d_rcpk + PK_PAD;
     // codes outside 0..3 (here or in A): the wave kernels slide over the byte arrays
     if (out->has_n || need_bytes) return rc_bytes();
     return DH_OK;
@@ -974,7 +981,14 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     if (A->ctx != ctx || B->ctx != ctx) return fail(DH_EINVAL, "dh_align_db: DB of another context");
     const dh_align_opts &o = *opts;
     if (o.k < 8 || o.k > 28) return fail(DH_EINVAL, "k must be in [8, 28]");
-    if (o.width < 1 || o.width > 62) return fail(DH_EINVAL, "width must be in [1, 62]");
+    if (o.algo != 0 && o.algo != 1) return fail(DH_EINVAL, "algo must be 0 (DH-1, wave) or 1 (DH-2, tiled band)");
+    const bool tiled = o.algo == 1;
+    if (tiled) {
+        if (o.width != dhtile::W) return fail(DH_EINVAL, "algo 1 (DH-2): width is the band, it must be 64");
+        if (o.skip_self == 2) return fail(DH_EINVAL, "algo 1 (DH-2) has no symmetric mode");
+        if (o.tspace > dhtile::TS_MAX) return fail(DH_EINVAL, "algo 1 (DH-2): tspace must be <= 128");
+    } else if (o.width < 1 || o.width > 62)
+        return fail(DH_EINVAL, "width must be in [1, 62]");
     if (o.tspace < 16 || o.tspace > 32767) return fail(DH_EINVAL, "tspace out of range");
     if (o.max_cand < 1 || o.max_cand > 256) return fail(DH_EINVAL, "max_cand must be in [1, 256]");
     if (o.max_la < 1 || o.max_la > 64) return fail(DH_EINVAL, "max_la must be in [1, 64]");
@@ -1031,7 +1045,8 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         if (first != 0 || count != B->n) return fail(DH_EINVAL, "symmetric mode needs the whole DB");
         chunk = (int32_t)std::min<int64_t>(std::max<int64_t>(nitems_total, 2), INT32_MAX - 1);
     }
-    const bool db_copies = A == B || (first == 0 && count == B->n && nitems_total <= chunk);
+    // (DH-2 reads B from plane-packed copies made chunk by chunk in the scratch arena)
+    const bool db_copies = !tiled && (A == B || (first == 0 && count == B->n && nitems_total <= chunk));
     const bool want_packed = !getenv("DH_WAVE_BYTES");
     // the wave kernel slides over 2-bit packed copies unless a DB holds codes outside 0..3
     if (int rc = dh_ensure_packed(A, false)) return rc;
@@ -1041,12 +1056,14 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     }
     // up to 30 live diagonals fit a 32-lane half: two alignments per wavefront (k_wave2); its
     // reverse extensions run forward over the reverse complements, so A needs one as well
-    const bool dual = o.width <= 30 && !getenv("DH_WAVE_SINGLE");
+    const bool dual = tiled || (o.width <= 30 && !getenv("DH_WAVE_SINGLE"));
     if (dual) {
         if (int rc = dh_ensure_rc(A)) return rc;
         if (A->has_n == 0)
             if (int rc = dh_ensure_packed(A, true)) return rc;
     }
+    if (tiled && (A->has_n != 0 || !A->d_pk || !A->d_rcpk))
+        return fail(DH_EINVAL, "algo 1 (DH-2) needs sequences of a, c, g, t only (2-bit copies), A holds other codes");
     HIPCHK(hipEventRecord(ctx->ev[1], st));
     w_index = now_ms() - w_a;
     w_a = now_ms();
@@ -1074,8 +1091,15 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     // crosses each boundary of either grid at most once per diagonal it serves; twice that is the
     // capacity, an overflow is reported); k_wave: one shared pool
     const int32_t poolcap = dual ? (64 / per_wave) * (4 * nbmax + 8) : 96 * nbmax;
-    const int32_t nslots = (int32_t)std::min<int64_t>((int64_t)ctx->ncu * slots_per_cu,
+    const int32_t nslots = tiled ? 4 : (int32_t)std::min<int64_t>((int64_t)ctx->ncu * slots_per_cu,
                                                       (std::max<int64_t>(nitems_total, 4) + 3) & ~3ll);
+    // DH-2: one alignment per lane; wavefronts resident = CUs x waves per CU, no more than the items need
+    int32_t tile_waves = 0;
+    if (tiled) {
+        int32_t per_cu = dhk_tile_waves_per_cu();
+        if (const char *e = getenv("DH_TILE_WAVES_PER_CU")) per_cu = std::max(1, atoi(e));
+        tile_waves = (int32_t)std::min<int64_t>((int64_t)ctx->ncu * per_cu, (std::max<int64_t>(nitems_total, 1) + 63) / 64);
+    }
     const int32_t cn = (int32_t)std::min<int64_t>(chunk, std::max<int64_t>(nitems_total, 2));
     DhCand *d_cand;
     int32_t *d_ncand, *d_nhits, *d_status, *d_cdj;
@@ -1101,6 +1125,8 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     SCR(12, d_sums, (size_t)cn / 2048 + 4)
     int32_t *d_ovf;
     SCR(29, d_ovf, cn)
+    int32_t *d_regs = nullptr;
+    if (tiled) SCR(32, d_regs, (size_t)tile_waves * 64 * dhtile::MAXREG * dhtile::REGF)
     HIPCHK(hipMemsetAsync(d_status, 0, sizeof(int32_t), st));
     HIPCHK(hipMemsetAsync(d_counters, 0, 2 * sizeof(unsigned long long), st));
 
@@ -1143,6 +1169,12 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         } else if (int rc = chunk_copies(ctx, B, (int32_t)(item0 >> 1), (int32_t)((item0 + ni) >> 1), want_packed, A->has_n != 0, &cc))
             return rc;
         const bool packed = want_packed && A->has_n == 0 && !cc.has_n && cc.pk && cc.rcpk;
+        if (tiled) {
+            if (!packed) return fail(DH_EINVAL, "algo 1 (DH-2) needs sequences of a, c, g, t only (2-bit copies), B holds other codes");
+            dhk_pk2planes(st, cc.pk_w0, cc.pk_words);
+            dhk_pk2planes(st, cc.rcpk_w0, cc.pk_words);
+            HIPCHK(hipGetLastError());
+        }
         // per-chunk arrays are indexed by absolute item inside the kernels: shift the bases
         DhCand *candbase = d_cand - item0 * o.max_cand;
         DhLa *labase = d_la - item0 * o.max_la;
@@ -1222,7 +1254,31 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         }
         HIPCHK(hipMemsetAsync(d_ovf, 0, sizeof(int32_t) * (size_t)ni, st));
         WaveScratch ws{d_pool, d_cdj, d_queue, (const int4 *)d_units, d_queue + 3, poolcap, nbmax, d_ovf - item0};
-        if (dual)
+        if (tiled) {
+            dhtile::Params tp;
+            tp.aoff = A->d_off;
+            tp.boff = B->d_off;
+            tp.apk = (const uint32_t *)A->d_pk;
+            tp.arcpk = (const uint32_t *)A->d_rcpk;
+            tp.bpp = (const dhtile::PlanePair *)cc.pk;
+            tp.brcpp = (const dhtile::PlanePair *)cc.rcpk;
+            tp.o = dopt;
+            tp.item0 = (int32_t)item0;
+            tp.nitems = ni;
+            tp.cand = candbase;
+            tp.ncand = ncandbase;
+            tp.queue = d_queue;
+            tp.regs = d_regs;
+            tp.nbmax = nbmax;
+            tp.trmax = trmax;
+            tp.out_la = labase;
+            tp.out_trace = trbase;
+            tp.out_nla = nlabase;
+            tp.out_ntr = ntrbase;
+            tp.counters = d_counters;
+            tp.status = d_status;
+            dhk_tile(st, tile_waves, &tp);
+        } else if (dual)
             dhk_wave2(st, nslots / per_wave, av, bv, A->d_rc, cc.rc, packed ? A->d_pk : nullptr,
                       packed ? A->d_rcpk : nullptr, packed ? cc.pk : nullptr, packed ? cc.rcpk : nullptr, dopt,
                       (int32_t)item0, ni, candbase, ncandbase, ws, labase, trbase, trmax, nlabase, ntrbase, d_counters,

@@ -15,6 +15,7 @@
 #include "dh_device.h"
 
 #define DB_PAD 64
+#define PK_PAD 128 /* bytes of padding on both sides of a packed copy (k_tile reads 64 bytes past a window origin) */
 
 // Caching device allocator: hipMalloc / hipFree synchronise the device and cost 0.1-1 ms each;
 // the same buffer sizes recur on every call, so freed blocks are kept in size-class free lists and
@@ -57,7 +58,7 @@ struct dh_ctx {
     struct Arena {
         void *p = nullptr;
         size_t cap = 0;
-    } arena[32];
+    } arena[48];
 };
 // slot `id` of the context's scratch arena, at least `bytes` large
 int dh_scratch(dh_ctx *ctx, int id, size_t bytes, void **out);

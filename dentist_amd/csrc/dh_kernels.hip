@@ -2200,9 +2200,10 @@ k_compact(const DhLa *__restrict__ la_slots, const uint16_t *__restrict__ tr_slo
             la.toff = tr_base + t + toff;
             la_out[l0 + rank] = la;
         }
+        const int32_t so = (uint32_t)lane < n ? (int32_t)la.toff : 0;  // where the pairs start inside the slot (k_tile)
         for (uint32_t x = 0; x < n; x++) {
             const int32_t xl = __shfl(tl, (int)x, LANES);
-            const uint16_t *src = tr_slots + ((int64_t)it * max_la + x) * trmax;
+            const uint16_t *src = tr_slots + ((int64_t)it * max_la + x) * trmax + __shfl(so, (int)x, LANES);
             for (int32_t e = lane; e < xl; e += LANES) tr_out[t + e] = src[e];
             t += xl;
         }
@@ -2211,7 +2212,7 @@ k_compact(const DhLa *__restrict__ la_slots, const uint16_t *__restrict__ tr_slo
     for (uint32_t x = 0; x < n; x++) {
         const int64_t slot = (int64_t)it * max_la + x;
         DhLa la = la_slots[slot];
-        const uint16_t *src = tr_slots + slot * trmax;
+        const uint16_t *src = tr_slots + slot * trmax + la.toff;
         for (int32_t e = lane; e < la.tlen; e += LANES) tr_out[t + e] = src[e];
         if (lane == 0) {
             la.toff = tr_base + t;

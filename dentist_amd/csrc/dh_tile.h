@@ -437,4 +437,16 @@ DH_HD void lane_ext_end(Lane &l, const Params &P)
 }
 
 }  // namespace dhtile
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+// nwaves wavefronts (64 lanes = 64 alignments each) over the items of P; regs holds nwaves * 64 lane slots
+void dhk_tile(hipStream_t st, int32_t nwaves, const dhtile::Params *P);
+int32_t dhk_tile_waves_per_cu(void);
+// 2-bit packed words (32 bases each) -> plane-packed words, in place
+void dhk_pk2planes(hipStream_t st, void *words, int64_t nwords);
+#ifdef __cplusplus
+}
+#endif
 #endif

@@ -1,0 +1,114 @@
+// dh_tile.hip -- k_tile: DH-2 on gfx950, one alignment per lane (dh_tile.h holds the lane code).
+//
+// A wavefront = 64 independent alignments.  The only wave-level structure is time: every lane that is
+// extending runs one trace tile per round, column by column in lock step (the column counter and the
+// funnel-shift amounts are scalars), lanes that need bookkeeping (next candidate, end of an extension,
+// a record, the next read) do it between rounds, and a lane whose read is done pulls the next one from
+// the queue -- no lane waits for another lane's alignment.  Per column and lane: two 64-bit plane
+// windows cut from the tile's registers with four v_alignbit, the match vector, Hyyro's eleven
+// bit-vector operations on one 64-bit word and the score of the band's bottom cell; per tile: eight
+// 8-byte pairs of the plane-packed read and nine dwords of the 2-bit packed contig, one 4-byte trace
+// pair out.  Nothing is staged in LDS -- the working set of a lane is its registers.
+#include <hip/hip_runtime.h>
+
+#include "dh_tile.h"
+
+using namespace dhtile;
+
+#define TILE_WAVES_PER_SIMD 4
+
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
+__device__ __forceinline__ int32_t wave_max_i32(int32_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int32_t o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
+{
+    Lane l;
+    lane_init(l, (int32_t)(blockIdx.x * 64 + threadIdx.x));
+    Tile t;
+    for (;;) {
+        // ---- bookkeeping until every lane extends or is out of work
+        while (wave_any(l.st != L_RUN && l.st != L_DONE)) {
+            if (l.st == L_EXT_END)
+                lane_ext_end(l, P);
+            else if (l.st == L_CAND)
+                lane_next_cand(l, P);
+            else if (l.st == L_FETCH) {
+                const int32_t it = (int32_t)atomicAdd(P.queue, 1u);
+                if (it >= P.nitems)
+                    l.st = L_DONE;
+                else
+                    lane_fetch(l, P, it);
+            }
+        }
+        const bool run = l.st == L_RUN;
+        if (!wave_any(run)) break;
+        // ---- one tile of every extending lane
+        if (run) tile_setup(l, P, t);
+        const int32_t cmax = wave_max_i32(run ? t.cols : 0);
+#pragma unroll
+        for (int blk = 0; blk < TS_MAX / 32; blk++) {
+            if (32 * blk >= cmax) break;
+            // the registers this block of 32 columns cuts its windows from
+            const uint32_t a0 = t.q0[blk], a1 = t.q0[blk + 1], a2 = t.q0[blk + 2];
+            const uint32_t b0 = t.q1[blk], b1 = t.q1[blk + 1], b2 = t.q1[blk + 2];
+            const uint64_t ab = (uint64_t)t.aw[2 * blk] | ((uint64_t)t.aw[2 * blk + 1] << 32);
+            const int32_t nsh = cmax - 32 * blk < 32 ? cmax - 32 * blk : 32;
+            for (int32_t sh = 0; sh < nsh; sh++) {
+                const int32_t c = 32 * blk + sh + 1;
+                if (run && c <= t.cols) {
+                    const uint64_t p0 = (uint64_t)funnel(a1, a0, (uint32_t)sh) | ((uint64_t)funnel(a2, a1, (uint32_t)sh) << 32);
+                    const uint64_t p1 = (uint64_t)funnel(b1, b0, (uint32_t)sh) | ((uint64_t)funnel(b2, b1, (uint32_t)sh) << 32);
+                    const uint32_t x = (uint32_t)(ab >> (2 * sh)) & 3u;
+                    tile_col(t, p0, p1, x);
+                }
+            }
+        }
+        if (run) tile_end(l, P, t, P.out_trace + ((int64_t)l.item * P.o.max_la + l.nacc) * P.trmax);
+    }
+    if (l.cells) atomicAdd(&P.counters[0], (unsigned long long)l.cells);
+    if (l.naln) atomicAdd(&P.counters[1], (unsigned long long)l.naln);
+    if (l.err) atomicOr(P.status, l.err);
+}
+
+// plane-packed copy from the 2-bit packed one, in place: word w (32 bases, base b at bits 2b) becomes
+// (low bits of the 32 bases, high bits of the 32 bases)
+__device__ __forceinline__ uint32_t squeeze_even(uint64_t x)
+{
+    x &= 0x5555555555555555ull;
+    x = (x | (x >> 1)) & 0x3333333333333333ull;
+    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+    return (uint32_t)x;
+}
+__global__ void __launch_bounds__(256) k_pk2planes(uint64_t *__restrict__ w, int64_t nwords)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nwords) return;
+    const uint64_t x = w[i];
+    w[i] = (uint64_t)squeeze_even(x) | ((uint64_t)squeeze_even(x >> 1) << 32);
+}
+
+extern "C" {
+void dhk_tile(hipStream_t st, int32_t nwaves, const Params *P)
+{
+    if (P->nitems <= 0 || nwaves <= 0) return;
+    hipLaunchKernelGGL(k_tile, dim3(nwaves), dim3(64), 0, st, *P);
+}
+int32_t dhk_tile_waves_per_cu(void) { return 4 * TILE_WAVES_PER_SIMD; }
+void dhk_pk2planes(hipStream_t st, void *words, int64_t nwords)
+{
+    if (nwords <= 0) return;
+    hipLaunchKernelGGL(k_pk2planes, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, st, (uint64_t *)words, nwords);
+}
+}

@@ -1,0 +1,103 @@
+"""DH-2 (dh_align_opts.algo = 1: tile-by-tile banded bit-parallel extension, one alignment per lane,
+k_tile) against the oracle's plain-DP restatement (oracle/align.c: extend_tiled).  Bit-exact: every
+record field, every trace value, the hit / candidate / alignment / cell counters.  The reference's
+call sites for this arithmetic: damapper (dazzler.d:6158-6170, Snakefile:1143-1170), daligner -A
+(processPileUps/package.d:655-667)."""
+import os
+
+import numpy as np
+import pytest
+
+import dentist_amd
+from dentist_amd import sim
+from helpers import assert_same_las, check_trace_invariants
+from oracle import pyoracle as oz
+from test_parity_map_gpu import run_both
+
+pytestmark = pytest.mark.gpu
+
+T = dict(algo=1, width=64)
+
+
+def test_mapping_reads_to_contigs(gpu_ctx):
+    w = sim.Workload(400_000, 4, 800, 5000, seed=7, spacing=20000)
+    las, _ = run_both(gpu_ctx, w.contigs, w.reads, **T)
+    assert len(set(las["bread"].tolist())) == w.reads.n
+
+
+@pytest.mark.parametrize("seed,rl,err,ts", [(3, 2500, 0.13, 100), (5, 9000, 0.13, 126), (9, 6000, 0.05, 100),
+                                            (13, 4000, 0.20, 100), (17, 3000, 0.13, 64), (19, 3000, 0.13, 128)])
+def test_lengths_error_rates_and_trace_spacings(gpu_ctx, seed, rl, err, ts):
+    w = sim.Workload(250_000, 3, 250, rl, seed=seed, err=err, spacing=15000)
+    run_both(gpu_ctx, w.contigs, w.reads, tspace=ts, **T)
+
+
+def test_bench_options_of_the_mapping_pass(gpu_ctx):
+    """k = 20, modimers, x-drop 60: the options bench.py maps configs[2] with."""
+    w = sim.Workload(1_000_000, 8, 3000, 10_000, seed=23)
+    las, _ = run_both(gpu_ctx, w.contigs, w.reads, k=20, kmer_mod=4, xdrop=60, **T)
+    s, e = w.read_truth[las["bread"], 0], w.read_truth[las["bread"], 1]
+    cs = w.contig_start[las["aread"]]
+    ok = ((las["flags"] & 1) == w.read_truth[las["bread"], 2]) & (cs + las["abpos"] >= s - 80) & (cs + las["aepos"] <= e + 80)
+    assert ok.mean() > 0.999 and len(set(las["bread"].tolist())) == w.reads.n
+
+
+def test_short_and_ragged_inputs(gpu_ctx):
+    """Reads shorter than a tile / than the band, reads hanging over both contig ends, a read equal to
+    its contig, tiny contigs, an empty read."""
+    rng = np.random.default_rng(11)
+    g = rng.integers(0, 4, 6000).astype(np.uint8)
+    contigs = sim.SeqDb.from_list([g[:3000], g[3100:3160], g[3200:6000], g[100:140]])
+    reads = sim.SeqDb.from_list([g[2900:3000], g[2950:3160], g[0:3000], g[3150:3300], g[10:70], sim.revcomp(g[3300:5900]),
+                                 g[3100:3160], g[2990:3110], g[20:52], g[0:0], g[5:12]])
+    las, _ = run_both(gpu_ctx, contigs, reads, k=12, hmin=20, min_len=20, **T)
+    assert len(las) >= 8
+
+
+@pytest.mark.parametrize("kw", [dict(strands=1), dict(strands=2), dict(pen=4, xdrop=60), dict(max_cand=2, max_la=1),
+                                dict(min_len=2000), dict(max_err_ppm=200000), dict(k=12, tcap=8)])
+def test_option_sweep(gpu_ctx, kw):
+    w = sim.Workload(150_000, 2, 250, 3000, seed=61, spacing=15000)
+    run_both(gpu_ctx, w.contigs, w.reads, **kw, **T)
+
+
+def test_ont_like_error_profile(gpu_ctx):
+    g = sim.genome(97, 600_000)
+    gb, ge = sim.gaps(98, len(g), 3, 50, 3000, 20000)
+    contigs, _ = sim.contigs_from_gaps(g, gb, ge)
+    reads, truth = sim.reads(99, g, 240, 20000, 0, err=0.10, p_ins=0.30, p_del=0.40)
+    las, _ = run_both(gpu_ctx, contigs, reads, k=20, kmer_mod=4, **T)
+    assert len(set(las["bread"].tolist())) == reads.n
+
+
+def test_blocks_and_chunks_give_the_same_bits(gpu_ctx, monkeypatch):
+    """One call, a loop over read blocks (`damapper <ref> <reads>.<block>`, Snakefile:1143-1170) and a
+    small internal chunk size: the same records."""
+    w = sim.Workload(600_000, 5, 2400, 6000, seed=29)
+    A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
+    g = dentist_amd.default_align_opts(k=20, kmer_mod=4, **T)
+    las, trace = gpu_ctx.align_db(A, B, g, select_best=True)
+    handles = [gpu_ctx.align_db_block(A, B, f, 800, g, select_best=True, raw=True) for f in (0, 800, 1600)]
+    las2, trace2 = dentist_amd.merge_las(handles)
+    assert_same_las((las2, trace2), (las, trace))
+    monkeypatch.setenv("DH_ALIGN_CHUNK", "700")
+    las3, trace3 = gpu_ctx.align_db(A, B, g, select_best=True)
+    assert_same_las((las3, trace3), (las, trace))
+    monkeypatch.setenv("DH_TILE_WAVES_PER_CU", "1")
+    las4, trace4 = gpu_ctx.align_db(A, B, g, select_best=True)
+    assert_same_las((las4, trace4), (las, trace))
+
+
+def test_rejections(gpu_ctx):
+    """DH-2 has no symmetric mode, one band width, tiles of at most 128 columns, 2-bit sequences only."""
+    rng = np.random.default_rng(5)
+    g = rng.integers(0, 4, 4000).astype(np.uint8)
+    db = gpu_ctx.db(sim.SeqDb.from_list([g, g[100:3000]]))
+    for kw in (dict(width=30), dict(skip_self=2), dict(tspace=200)):
+        with pytest.raises(dentist_amd.DhError):
+            gpu_ctx.align_db(db, db, dentist_amd.default_align_opts(**{**T, **kw}))
+    gn = g.copy()
+    gn[50] = 4
+    dn = gpu_ctx.db(sim.SeqDb.from_list([gn]))
+    with pytest.raises(dentist_amd.DhError):
+        gpu_ctx.align_db(dn, db, dentist_amd.default_align_opts(**T))
