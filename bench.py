@@ -75,8 +75,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kmer-mod", type=int, default=4)
     ap.add_argument("--map-k", type=int, default=20, help="k-mer length of the mapping pass (damapper's default)")
-    ap.add_argument("--map-width", type=int, default=14,
-                    help="live diagonals of the mapping waves: <= 14 runs four alignments per wavefront")
+    ap.add_argument("--map-algo", type=int, default=1,
+                    help="extension algorithm of the mapping pass: 1 = DH-2 (tiled banded bit-parallel DP, one "
+                         "alignment per lane, k_tile), 0 = DH-1 (O(ND) wave, k_wave2)")
+    ap.add_argument("--map-width", type=int, default=None,
+                    help="DH-2: the band (64); DH-1: live diagonals of the wave (default 14: four alignments per wavefront)")
     ap.add_argument("--map-xdrop", type=int, default=60, help="score lag that trims the mapping waves")
     ap.add_argument("--dev-share-gpu", action="store_true",
                     help="development only: all ranks on cuda:0 with gloo collectives (exercises the N > 1 "
@@ -116,8 +119,10 @@ def main():
     ctx = dentist_amd.Context(local_rank, stream=stream)
     A, B = ctx.db(w.contigs), ctx.db(w.reads)
     # mapping pass: damapper's k-mer length, modimer sampling 1/4, every other option at its default
+    if args.map_width is None:
+        args.map_width = 64 if args.map_algo == 1 else 14
     mopts = dentist_amd.default_align_opts(kmer_mod=args.kmer_mod, k=args.map_k, width=args.map_width,
-                                           xdrop=args.map_xdrop)
+                                           xdrop=args.map_xdrop, algo=args.map_algo)
     popts = dentist_amd.default_process_opts()
     read_bp = int(len(w.reads.bases))
 
@@ -220,7 +225,8 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": args.workload, "shape": spec, "mapping_k": args.map_k,
-                       "mapping_kmer_mod": args.kmer_mod, "mapping_width": args.map_width,
+                       "mapping_kmer_mod": args.kmer_mod, "mapping_algo": "DH-2 tiled band (k_tile)" if args.map_algo == 1 else "DH-1 wave (k_wave2)",
+                       "mapping_width": args.map_width,
                        "mapping_xdrop": args.map_xdrop, "parallelism": f"reads and gaps sharded over {world} GPU(s)",
                        "read_bp_total": read_all, "pile_ups": int(last["info"]["piles"]),
                        "collect_filters_dropped_las": dict(zip(("lq", "improper", "weakly_anchored", "contained",
@@ -278,7 +284,7 @@ def cpu_baseline(w, last, mopts, popts, args, gap_bases, read_bp_total):
     from dentist_amd import sim
     from oracle import pyoracle as oz
     cores = os.cpu_count() or 1
-    o = oz.default_opts(width=mopts.width, kmer_mod=mopts.kmer_mod, k=mopts.k, xdrop=mopts.xdrop)
+    o = oz.default_opts(width=mopts.width, kmer_mod=mopts.kmer_mod, k=mopts.k, xdrop=mopts.xdrop, algo=mopts.algo)
 
     def map_reads(n):
         sub = sim.SeqDb(w.reads.bases[:w.reads.off[n]], w.reads.off[:n + 1])

@@ -1038,7 +1038,11 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     // larger DB gets them chunk by chunk in the scratch arena, so the resident footprint of a reads
     // DB stays at one byte per base however large it is
     const int64_t nitems_total = 2ll * count;
-    int32_t chunk = 1 << 18;
+    // items per launch.  k_tile runs one alignment per lane: a launch needs several alignments per
+    // resident lane (262 144 of them) to keep the wavefronts full until the queue drains -- measured on
+    // configs[2]: 2^18 items per launch 70 ms of k_tile per step, 2^20 37 ms (the host filters of a chunk
+    // still overlap the next chunk's kernels)
+    int32_t chunk = o.algo == 1 ? 1 << 20 : 1 << 18;
     if (const char *e = getenv("DH_ALIGN_CHUNK")) chunk = std::max(2, atoi(e)) & ~1;
     // symmetric mode writes records into the slots of other items: everything is one chunk
     if (o.skip_self == 2) {

@@ -2180,9 +2180,10 @@ k_compact(const DhLa *__restrict__ la_slots, const uint16_t *__restrict__ tr_slo
     if (ordered && n <= LANES) {
         DhLa la;
         uint64_t k1 = ~0ull, k2 = ~0ull;
-        int32_t tl = 0;
+        int32_t tl = 0, so = 0;  // so: where the pairs start inside the slot (k_tile; 0 for the wave kernels)
         if ((uint32_t)lane < n) {
             la = la_slots[(int64_t)it * max_la + lane];
+            so = (int32_t)la.toff;
             k1 = ((uint64_t)(uint32_t)la.bread << 32) | ((uint64_t)(la.flags & 1u) << 31) | (uint32_t)la.abpos;
             k2 = ((uint64_t)(uint32_t)la.bbpos << 32) | (uint32_t)la.aepos;
             tl = la.tlen;
@@ -2200,7 +2201,6 @@ k_compact(const DhLa *__restrict__ la_slots, const uint16_t *__restrict__ tr_slo
             la.toff = tr_base + t + toff;
             la_out[l0 + rank] = la;
         }
-        const int32_t so = (uint32_t)lane < n ? (int32_t)la.toff : 0;  // where the pairs start inside the slot (k_tile)
         for (uint32_t x = 0; x < n; x++) {
             const int32_t xl = __shfl(tl, (int)x, LANES);
             const uint16_t *src = tr_slots + ((int64_t)it * max_la + x) * trmax + __shfl(so, (int)x, LANES);

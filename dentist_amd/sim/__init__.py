@@ -34,6 +34,13 @@ def _lib():
                                          ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_void_p,
                                          ctypes.c_void_p, ctypes.c_void_p]
         lib.dhsim_reads_from.restype = ctypes.c_int64
+        lib.dhsim_reads_sel.argtypes = [ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32,
+                                        ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_double,
+                                        ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_void_p,
+                                        ctypes.c_void_p, ctypes.c_void_p]
+        lib.dhsim_reads_sel.restype = ctypes.c_int64
+        lib.dhsim_read_truth.argtypes = [ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
+                                         ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
         _LIB = lib
     return _LIB
 
@@ -98,18 +105,32 @@ def gaps(seed, genome_len, ngaps, minlen=50, maxlen=5000, spacing=20000):
     return b[:n].copy(), e[:n].copy()
 
 
-def reads(seed, genome_codes, nreads, mean_len, sd_len=0, min_len=100, err=0.13, p_ins=0.60, p_del=0.25, first=0):
+def reads(seed, genome_codes, nreads, mean_len, sd_len=0, min_len=100, err=0.13, p_ins=0.60, p_del=0.25, first=0,
+          hp_bias=0.0, ids=None):
     """nreads reads starting with read number `first` of the stream (every read has its own RNG
-    stream, so a share of the reads equals the corresponding reads of the whole set)."""
+    stream, so a share of the reads equals the corresponding reads of the whole set); ``ids`` = the
+    reads with these numbers instead.  ``hp_bias`` > 0: homopolymer-biased indels (ONT-like profile,
+    SURVEY 8(d), BASELINE configs[4])."""
     g = np.ascontiguousarray(genome_codes, dtype=np.uint8)
+    idp = None
+    if ids is not None:
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        nreads, idp = len(ids), ids.ctypes.data
     off = np.zeros(nreads + 1, dtype=np.int64)
     truth = np.zeros((nreads, 3), dtype=np.int64)
-    total = _lib().dhsim_reads_from(seed, g.ctypes.data, len(g), first, nreads, mean_len, sd_len, min_len, err,
-                                    p_ins, p_del, off.ctypes.data, None, truth.ctypes.data)
+    total = _lib().dhsim_reads_sel(seed, g.ctypes.data, len(g), idp, first, nreads, mean_len, sd_len, min_len, err,
+                                   p_ins, p_del, hp_bias, off.ctypes.data, None, truth.ctypes.data)
     bases = np.empty(total, dtype=np.uint8)
-    _lib().dhsim_reads_from(seed, g.ctypes.data, len(g), first, nreads, mean_len, sd_len, min_len, err, p_ins,
-                            p_del, off.ctypes.data, bases.ctypes.data, truth.ctypes.data)
+    _lib().dhsim_reads_sel(seed, g.ctypes.data, len(g), idp, first, nreads, mean_len, sd_len, min_len, err, p_ins,
+                           p_del, hp_bias, off.ctypes.data, bases.ctypes.data, truth.ctypes.data)
     return SeqDb(bases, off), truth
+
+
+def read_truth(seed, genome_len, nreads, mean_len, sd_len=0, min_len=100, first=0):
+    """(start, end, strand) of reads [first, first + nreads) of the stream, without their bases."""
+    truth = np.zeros((nreads, 3), dtype=np.int64)
+    _lib().dhsim_read_truth(seed, genome_len, first, nreads, mean_len, sd_len, min_len, truth.ctypes.data)
+    return truth
 
 
 def contigs_from_gaps(genome_codes, gap_begin, gap_end):
@@ -124,7 +145,7 @@ class Workload:
     """A BASELINE.json-style synthetic workload (SURVEY.md 8(d) seeds: asm, +1 gaps, +2 reads)."""
 
     def __init__(self, genome_len, ngaps, nreads, read_len, seed=20260929, err=0.13, sd_len=0,
-                 gap_min=50, gap_max=5000, spacing=20000, read_range=None):
+                 gap_min=50, gap_max=5000, spacing=20000, read_range=None, p_ins=0.60, p_del=0.25, hp_bias=0.0):
         self.truth = genome(seed, genome_len)
         self.gap_begin, self.gap_end = gaps(seed + 1, genome_len, ngaps, gap_min, gap_max, spacing)
         self.contigs, self.contig_start = contigs_from_gaps(self.truth, self.gap_begin, self.gap_end)
@@ -132,4 +153,41 @@ class Workload:
         self.read_first, read_end = read_range if read_range is not None else (0, nreads)
         self.nreads_total = nreads
         self.reads, self.read_truth = reads(seed + 2, self.truth, read_end - self.read_first, read_len, sd_len,
-                                            err=err, first=self.read_first)
+                                            err=err, first=self.read_first, p_ins=p_ins, p_del=p_del, hp_bias=hp_bias)
+        self.read_profile = dict(err=err, p_ins=p_ins, p_del=p_del, hp_bias=hp_bias, sd_len=sd_len, read_len=read_len,
+                                 seed=seed + 2)
+
+
+class RankShare:
+    """What ONE rank of ``world`` holds of a workload too large to build on one box (BASELINE configs[4]:
+    3 Gb assembly, 10 000 gaps, 10 M x 20 kb reads on 8 GPUs): the whole assembly (contigs and index are
+    replicated), its block of the reads (``reads``: reads [lo, hi) of the stream) and -- what
+    the all-to-all of cropped reads would hand it -- the reads of ALL ranks that span the gaps it owns
+    (``pile_reads``; emulation: rank r owns every world-th gap starting with gap r, and the spanning reads
+    are picked by their true origin, margin 1 kb on both sides).  Reads are generated from per-read RNG
+    streams, so both sets equal the corresponding reads of the full workload."""
+
+    def __init__(self, genome_len, ngaps, nreads, read_len, rank=0, world=8, seed=20260929, err=0.10, sd_len=0,
+                 p_ins=0.30, p_del=0.40, hp_bias=0.5, gap_min=50, gap_max=5000, spacing=20000, margin=1000):
+        self.truth = genome(seed, genome_len)
+        self.gap_begin, self.gap_end = gaps(seed + 1, genome_len, ngaps, gap_min, gap_max, spacing)
+        self.contigs, self.contig_start = contigs_from_gaps(self.truth, self.gap_begin, self.gap_end)
+        self.rank, self.world, self.nreads_total = rank, world, nreads
+        self.read_first, read_end = nreads * rank // world, nreads * (rank + 1) // world
+        prof = dict(err=err, p_ins=p_ins, p_del=p_del, hp_bias=hp_bias)
+        self.reads, self.read_truth = reads(seed + 2, self.truth, read_end - self.read_first, read_len, sd_len,
+                                            first=self.read_first, **prof)
+        # the reads of the whole workload that span the owned gaps
+        tr = read_truth(seed + 2, genome_len, nreads, read_len, sd_len)
+        order = np.argsort(tr[:, 0], kind="stable")
+        starts = tr[order, 0]
+        maxlen = int((tr[:, 1] - tr[:, 0]).max()) if nreads else 0
+        self.owned_gaps = np.arange(rank, len(self.gap_begin), world)
+        ids = []
+        for g in self.owned_gaps:
+            lo = np.searchsorted(starts, self.gap_end[g] + margin - maxlen, side="left")
+            hi = np.searchsorted(starts, self.gap_begin[g] - margin, side="right")
+            cand = order[lo:hi]
+            ids.append(cand[tr[cand, 1] >= self.gap_end[g] + margin])
+        self.pile_read_ids = np.unique(np.concatenate(ids)) if ids else np.zeros(0, np.int64)
+        self.pile_reads, self.pile_truth = reads(seed + 2, self.truth, 0, read_len, sd_len, ids=self.pile_read_ids, **prof)

@@ -86,6 +86,9 @@ int32_t dhsim_gaps(uint64_t seed, int64_t genome_len, int32_t ngaps, int32_t min
 int64_t dhsim_reads_from(uint64_t seed, const uint8_t *genome, int64_t glen, int32_t first, int32_t nreads,
                          int32_t mean_len, int32_t sd_len, int32_t min_len, double err, double p_ins,
                          double p_del, int64_t *out_off, uint8_t *out_bases, int64_t *truth);
+int64_t dhsim_reads_sel(uint64_t seed, const uint8_t *genome, int64_t glen, const int64_t *ids, int32_t first,
+                        int32_t nreads, int32_t mean_len, int32_t sd_len, int32_t min_len, double err, double p_ins,
+                        double p_del, double hp_bias, int64_t *out_off, uint8_t *out_bases, int64_t *truth);
 int64_t dhsim_reads(uint64_t seed, const uint8_t *genome, int64_t glen, int32_t nreads,
                     int32_t mean_len, int32_t sd_len, int32_t min_len, double err, double p_ins,
                     double p_del, int64_t *out_off, uint8_t *out_bases, int64_t *truth)
@@ -100,6 +103,48 @@ int64_t dhsim_reads_from(uint64_t seed, const uint8_t *genome, int64_t glen, int
                          int32_t mean_len, int32_t sd_len, int32_t min_len, double err, double p_ins,
                          double p_del, int64_t *out_off, uint8_t *out_bases, int64_t *truth)
 {
+    return dhsim_reads_sel(seed, genome, glen, nullptr, first, nreads, mean_len, sd_len, min_len, err, p_ins, p_del, 0.0,
+                           out_off, out_bases, truth);
+}
+
+// where every read of the stream comes from (start, end, strand) without generating its bases: the
+// first draws of a read's RNG stream.  Lets a sharded run find the reads of other shards that reach
+// its gaps (they are then generated with dhsim_reads_sel).
+void dhsim_read_truth(uint64_t seed, int64_t glen, int64_t first, int64_t nreads, int32_t mean_len, int32_t sd_len,
+                      int32_t min_len, int64_t *truth)
+{
+    const double mu = sd_len > 0 ? std::log((double)mean_len * mean_len /
+                                            std::sqrt((double)mean_len * mean_len + (double)sd_len * sd_len))
+                                 : 0.0;
+    const double sg = sd_len > 0 ? std::sqrt(std::log(1.0 + ((double)sd_len * sd_len) / ((double)mean_len * mean_len))) : 0.0;
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < nreads; r++) {
+        Rng g(seed ^ (0xD1B54A32D192ED03ull * (uint64_t)(first + r + 1)));
+        int64_t len = mean_len;
+        if (sd_len > 0) {
+            len = (int64_t)std::exp(mu + sg * g.normal());
+            if (len < min_len) len = min_len;
+        }
+        if (len > glen) len = glen;
+        const int64_t start = (int64_t)g.below((uint64_t)(glen - len + 1));
+        truth[r * 3 + 0] = start;
+        truth[r * 3 + 1] = start + len;
+        truth[r * 3 + 2] = (int64_t)(g.next() & 1);
+    }
+}
+
+// the general form: reads ids[0 .. nreads) of the stream (ids == NULL: first .. first + nreads), and
+// hp_bias > 0 = homopolymer-biased indels (the ONT-like profile of BASELINE configs[4]):
+// inside a homopolymer run of the template the insertion and deletion rates grow by hp_bias per base
+// of the run so far (capped at 5), half of the inserted bases there repeat the run's base, and the
+// rates are scaled so that the expected error rate stays `err` on an i.i.d. template.
+int64_t dhsim_reads_sel(uint64_t seed, const uint8_t *genome, int64_t glen, const int64_t *ids, int32_t first,
+                        int32_t nreads, int32_t mean_len, int32_t sd_len, int32_t min_len, double err, double p_ins,
+                        double p_del, double hp_bias, int64_t *out_off, uint8_t *out_bases, int64_t *truth)
+{
+    // E[min(run - 1, 5)] of an i.i.d. 4-letter template = sum_{k>=1} P(run >= k + 1) for k <= 5
+    const double hp_mean = 0.25 + 0.0625 + 0.015625 + 0.00390625 + 0.0009765625;
+    const double hp_norm = hp_bias > 0 ? 1.0 / (1.0 + hp_bias * hp_mean * (p_ins + p_del)) : 1.0;
     // pass 1: lengths of every read's output (sequential prefix sum needs them)
     std::vector<int32_t> outlen((size_t)nreads);
     const double mu = sd_len > 0 ? std::log((double)mean_len * mean_len /
@@ -120,7 +165,7 @@ int64_t dhsim_reads_from(uint64_t seed, const uint8_t *genome, int64_t glen, int
         }
 #pragma omp parallel for schedule(dynamic, 256)
         for (int32_t r = 0; r < nreads; r++) {
-            Rng g(seed ^ (0xD1B54A32D192ED03ull * (uint64_t)((int64_t)first + r + 1)));
+            Rng g(seed ^ (0xD1B54A32D192ED03ull * (uint64_t)((ids ? ids[r] : (int64_t)first + r) + 1)));
             int64_t len = mean_len;
             if (sd_len > 0) {
                 len = (int64_t)std::exp(mu + sg * g.normal());
@@ -132,17 +177,34 @@ int64_t dhsim_reads_from(uint64_t seed, const uint8_t *genome, int64_t glen, int
             uint8_t *dst = (pass == 1) ? out_bases + out_off[r] : nullptr;
             int32_t n = 0;
             int64_t p = 0;
+            int32_t run = 0;
+            uint8_t prev = 255;
+            int64_t prev_p = -1;
             while (p < len) {
                 // true base in read orientation
                 const uint8_t tb = strand ? (uint8_t)(3 - genome[start + len - 1 - p]) : genome[start + p];
+                double e_ins = err * p_ins, e_indel = err * (p_ins + p_del), e_all = err;
+                bool in_run = false;
+                if (hp_bias > 0) {
+                    if (p != prev_p) {  // a new template position: length of the homopolymer run ending here
+                        run = tb == prev ? run + 1 : 1;
+                        prev = tb;
+                        prev_p = p;
+                    }
+                    const double m = 1.0 + hp_bias * (double)(run - 1 < 5 ? run - 1 : 5);
+                    in_run = run > 1;
+                    e_ins = err * hp_norm * p_ins * m;
+                    e_indel = e_ins + err * hp_norm * p_del * m;
+                    e_all = e_indel + err * hp_norm * (1.0 - p_ins - p_del);
+                }
                 const double u = g.uni();
-                if (u < err * p_ins) {  // insertion: emit a random base, do not consume
-                    const uint8_t b = (uint8_t)(g.next() & 3);
+                if (u < e_ins) {  // insertion: emit a random base (inside a run: every other time the run's base), do not consume
+                    const uint8_t b = (in_run && g.uni() < 0.5) ? tb : (uint8_t)(g.next() & 3);
                     if (dst) dst[n] = b;
                     n++;
-                } else if (u < err * (p_ins + p_del)) {  // deletion
+                } else if (u < e_indel) {  // deletion
                     p++;
-                } else if (u < err) {  // substitution by one of the three other bases
+                } else if (u < e_all) {  // substitution by one of the three other bases
                     const uint8_t b = (uint8_t)((tb + 1 + g.below(3)) & 3);
                     if (dst) dst[n] = b;
                     n++;

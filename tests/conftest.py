@@ -18,3 +18,11 @@ def gpu_ctx():
     ctx = dentist_amd.Context(0)
     yield ctx
     ctx.close()
+
+
+@pytest.fixture(scope="session")
+def cfg2_workload():
+    """BASELINE configs[2] / [3]: 100 Mb assembly, 1 000 gaps, 1 M x 15 kb reads at 13 % (15.7 Gbp) -- built
+    once per session (about a minute of host time), shared by the full-size tests."""
+    from dentist_amd import sim
+    return sim.Workload(100_000_000, 1000, 1_000_000, 15_000, seed=20260929)

@@ -1,0 +1,142 @@
+"""BASELINE.json configs[3] and configs[4] on the one GPU a test box has.
+
+configs[3]: the configs[2] workload (100 Mb / 1 000 gaps / 1 M x 15 kb) sharded over 8 ranks -- here 8
+emulated ranks on one GPU (collectives served from memory), every rank running bench.py's exact call
+sequence (dh_map_reads with DH-2 mapping, candidates, sharded collect + process); the gathered result
+must equal the single-rank run bit for bit.  Reference: one damapper job per read block against the
+whole reference (snakemake/Snakefile:1143-1170), `process --batch` per pile-up batch (:1315-1334),
+merge-insertions (commands/mergeInsertions.d:60-164).
+
+configs[4]: 3 Gb assembly, 10 000 gaps, 10 M x 20 kb ONT-like reads on 8 GPUs -- one rank's share
+(dentist_amd.sim.RankShare): the whole assembly and its 12 GB k-mer index, a 1.25 M read block
+(25 Gbp) mapped against it, and the 1 250 pile-ups the rank owns processed with the spanning reads of
+all ranks.  Size-independent properties only (no oracle at this size)."""
+import time
+
+import numpy as np
+import pytest
+
+import dentist_amd
+from dentist_amd import parallel, sim
+from helpers import check_trace_invariants
+from oracle import pyoracle as oz
+
+pytestmark = pytest.mark.gpu
+
+MAP = dict(kmer_mod=4, k=20, width=64, xdrop=60, algo=1)   # bench.py's mapping options
+
+
+def consensus_edits(truth, contig_start, gap_end, rec, bases):
+    edits = total = 0
+    for r in rec:
+        g = int(r["contig_left"])
+        cons = bases[r["cons_off"]:r["cons_off"] + r["cons_len"]]
+        cseq = sim.revcomp(cons) if r["comp"] else cons
+        ins = cseq[r["ins_begin"]:r["ins_end"]]
+        t = truth[contig_start[g] + r["left_aepos"]: gap_end[g] + r["right_abpos"]]
+        ed, _ = oz.nw(t, ins)
+        edits += ed
+        total += len(t)
+    return edits, total
+
+
+def test_config3_eight_emulated_ranks_equal_the_single_rank_run(gpu_ctx, cfg2_workload, capsys):
+    w = cfg2_workload
+    mo = dentist_amd.default_align_opts(**MAP)
+    po = dentist_amd.default_process_opts()
+    A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
+    # ---- one rank: bench.py's sequence
+    las, trace, dropped, cands = gpu_ctx.map_reads(A, B, mo, po, sorted=False, candidates=True)
+    piles = cands.select(las, po)
+    rec, bases = dentist_amd.process_pileups(gpu_ctx, A, B, las, trace, piles, po)
+    closed = rec[rec["status"] == 0]
+    assert len(piles) == 1000 and len(closed) >= 990
+    edits, total = consensus_edits(w.truth, w.contig_start, w.gap_end, closed, bases)
+    assert edits <= 0.001 * total, (edits, total)
+    s, e = w.read_truth[las["bread"], 0], w.read_truth[las["bread"], 1]
+    cs = w.contig_start[las["aread"]]
+    ok = ((las["flags"] & 1) == w.read_truth[las["bread"], 2]) & (cs + las["abpos"] >= s - 80) & (cs + las["aepos"] <= e + 80)
+    assert ok.mean() > 0.999
+    check_trace_invariants(las[:: max(1, len(las) // 3000)], trace, 100)
+    del B
+    # ---- eight ranks, one after the other on this GPU
+    world, gens, keep, t_map = 8, [], [], []
+    for rank in range(world):
+        lo, hi = parallel.shard_range(w.reads.n, rank, world)
+        share = sim.SeqDb(w.reads.bases[w.reads.off[lo]:w.reads.off[hi]], w.reads.off[lo:hi + 1] - w.reads.off[lo])
+        Br = gpu_ctx.db(share)
+        gpu_ctx.map_reads(A, Br, mo, po, sorted=False, candidates=True)   # warm: buffers of this size exist
+        t0 = time.perf_counter()
+        lr, tr, _, cr = gpu_ctx.map_reads(A, Br, mo, po, sorted=False, candidates=True)
+        t_map.append(time.perf_counter() - t0)
+        lr = lr.copy()
+        lr["bread"] += lo
+        keep.append((Br, lr, tr, cr))
+        gens.append(parallel.sharded_process_steps(gpu_ctx, A, Br, lo, w.contigs.off, lr, tr, po, rank, world, cr))
+    t0 = time.perf_counter()
+    results = parallel.emulate_ranks(gens)
+    t_rest = (time.perf_counter() - t0) / world
+    owners = results[0][2]["owner"]
+    assert len(set(owners.tolist())) == world
+    for grec, gbases, info in results:
+        assert len(grec) == len(rec)
+        for f in rec.dtype.names:
+            if f not in ("cons_off", "pad"):
+                assert np.array_equal(grec[f], rec[f]), f
+    grec, gbases, _ = results[0]
+    for a, b in zip(grec, rec):
+        assert np.array_equal(gbases[a["cons_off"]:a["cons_off"] + a["cons_len"]], bases[b["cons_off"]:b["cons_off"] + b["cons_len"]])
+    with capsys.disabled():
+        print(f"\n[configs[3], 8 emulated ranks on one GPU] per rank: mapping + filters + candidates "
+              f"{np.mean(t_map) * 1e3:.1f} ms (max {np.max(t_map) * 1e3:.1f}), collect + crop + exchange + process + gather "
+              f"{t_rest * 1e3:.1f} ms (the ranks' steps run one after the other here)")
+
+
+def test_config4_one_rank_of_eight(gpu_ctx, capsys):
+    t0 = time.perf_counter()
+    s = sim.RankShare(3_000_000_000, 10_000, 10_000_000, 20_000, rank=0, world=8, seed=20260929)
+    t_sim = time.perf_counter() - t0
+    mo = dentist_amd.default_align_opts(**MAP)
+    po = dentist_amd.default_process_opts()
+    A, B = gpu_ctx.db(s.contigs), gpu_ctx.db(s.reads)
+    assert s.reads.n == 1_250_000 and len(s.owned_gaps) == 1250
+    # ---- mapping of the rank's read block against the whole assembly
+    t0 = time.perf_counter()
+    las, trace, dropped, cands = gpu_ctx.map_reads(A, B, mo, po, sorted=False, candidates=True)
+    t_first = time.perf_counter() - t0
+    st = gpu_ctx.align_stats()
+    assert len(set(las["bread"].tolist())) >= 0.995 * s.reads.n
+    t, e = s.read_truth[las["bread"], 0], s.read_truth[las["bread"], 1]
+    cs = s.contig_start[las["aread"]]
+    ok = ((las["flags"] & 1) == s.read_truth[las["bread"], 2]) & (cs + las["abpos"] >= t - 80) & (cs + las["aepos"] <= e + 80)
+    assert ok.mean() > 0.999
+    check_trace_invariants(las[:: max(1, len(las) // 3000)], trace, 100)
+    # a second pass (index kept) gives the same bits
+    t0 = time.perf_counter()
+    las2, trace2, dropped2, _ = gpu_ctx.map_reads(A, B, mo, po, sorted=False, candidates=True)
+    t_second = time.perf_counter() - t0
+    st2 = gpu_ctx.align_stats()
+    assert np.array_equal(las2, las) and np.array_equal(trace2, trace) and np.array_equal(dropped2, dropped)
+    del las2, trace2, B
+    # ---- the pile-ups this rank owns, with the spanning reads of all ranks
+    P = gpu_ctx.db(s.pile_reads)
+    pl, pt, _, pc = gpu_ctx.map_reads(A, P, mo, po, sorted=False, candidates=True)
+    piles = pc.select(pl, po)
+    gaps = np.asarray([piles.get(i)[0] for i in range(len(piles))])
+    assert set(s.owned_gaps.tolist()) <= set(gaps.tolist())
+    t0 = time.perf_counter()
+    rec, bases = dentist_amd.process_pileups(gpu_ctx, A, P, pl, pt, piles, po)
+    t_proc = time.perf_counter() - t0
+    mine = rec[np.isin(rec["contig_left"], s.owned_gaps)]
+    closed = mine[mine["status"] == 0]
+    assert len(closed) >= 0.99 * len(s.owned_gaps), (len(closed), len(s.owned_gaps))
+    edits, total = consensus_edits(s.truth, s.contig_start, s.gap_end, closed, bases)
+    assert edits <= 0.001 * total, (edits, total)
+    rec2, bases2 = dentist_amd.process_pileups(gpu_ctx, A, P, pl, pt, piles, po)
+    assert np.array_equal(rec2, rec) and np.array_equal(bases2, bases)
+    with capsys.disabled():
+        print(f"\n[configs[4], rank 0 of 8] workload built in {t_sim:.0f} s; mapping of 1.25 M x 20 kb ONT-like reads "
+              f"({int(s.reads.off[-1]) / 1e9:.1f} Gbp) against 3 Gb: first call {t_first * 1e3:.0f} ms (index {st.ms_index:.0f}), "
+              f"steady {t_second * 1e3:.0f} ms (seeds {st2.ms_seed:.0f}, k_tile {st2.ms_wave:.0f}); {len(las)} LAs, placed "
+              f"{ok.mean():.5f}; {len(closed)} of {len(s.owned_gaps)} owned gaps closed in {t_proc * 1e3:.0f} ms, consensus "
+              f"{edits} / {total} = {edits / max(total, 1):.5f} from the truth")

@@ -157,7 +157,7 @@ def test_config1_full_size_properties(gpu_ctx):
     assert np.array_equal(rec2, rec) and np.array_equal(bases2, bases)
 
 
-def test_config2_full_size_properties(gpu_ctx):
+def test_config2_full_size_properties(gpu_ctx, cfg2_workload):
     """BASELINE configs[2], the headline workload (100 Mb assembly, 1 000 gaps, 1 M x 15 kb reads at
     13 %, 15.7 Gbp): the mapping runs as a loop over read blocks against the persistent contig index
     (snakemake/Snakefile:1143-1170) merged in memory (LAmerge, :1173-1185) and must equal the single
@@ -165,7 +165,7 @@ def test_config2_full_size_properties(gpu_ctx):
     mapped read, trace invariants, >= 99 % of the gaps closed, consensus <= 0.1 % from the truth,
     idempotence of the process stage."""
     from helpers import check_trace_invariants
-    w = sim.Workload(100_000_000, 1000, 1_000_000, 15_000, seed=20260929)
+    w = cfg2_workload
     A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
     mo = dentist_amd.default_align_opts(kmer_mod=4, k=20)
     po = dentist_amd.default_process_opts()
