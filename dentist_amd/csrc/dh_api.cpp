@@ -177,7 +177,7 @@ void dh_pinned_trim()
 }
 
 extern "C" const char *dh_last_error(void) { return g_err.c_str(); }
-extern "C" int32_t dh_abi_version(void) { return 2; }
+extern "C" int32_t dh_abi_version(void) { return 3; }  // 3: dh_align_opts.algo
 
 // ------------------------------------------------------------------------------------ context
 

@@ -31,15 +31,19 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(decl):
         assert hasattr(L, name), f"{name} declared in include/ but not exported"
     assert decl == set(_lib.SYMBOLS), "binding list and header disagree"
-    assert L.dh_abi_version() == 2
+    assert L.dh_abi_version() == 3
+
+
+def o_algo_default():
+    return dentist_amd.default_align_opts().algo
 
 
 def test_struct_layouts_match_header():
-    assert ctypes.sizeof(_lib.AlignOpts) == 64
+    assert ctypes.sizeof(_lib.AlignOpts) == 68 and o_algo_default() == 0
     assert _lib.LA_DTYPE.itemsize == 48
     o = dentist_amd.default_align_opts()
     assert (o.k, o.hmin, o.band_shift, o.tspace, o.min_len, o.pen) == (14, 35, 6, 100, 500, 6)
-    assert o.width <= 62
+    assert o.width <= 62 and o.algo == 0
 
 
 def test_no_silent_cpu_fallback_without_gpu():
