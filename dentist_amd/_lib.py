@@ -373,7 +373,9 @@ class Db:
         _check(lib().dh_db_drop_cache(self._h))
 
     def set_mask(self, ptr, iv):
-        """Soft mask (union of -m tracks): ptr int64[n+1], iv int32 (begin, end) pairs; None clears."""
+        """Soft mask (union of -m tracks): ptr int64[n+1], iv int32 (begin, end) pairs.  Replaces the tracks
+        of an earlier call; the bits of dust() / mask_coverage() are a layer of their own and stay (the
+        effective mask is the OR).  None clears everything."""
         if ptr is None:
             _check(lib().dh_db_set_mask(self._h, None, None))
             return

@@ -383,24 +383,59 @@ extern "C" void dh_db_destroy(dh_db *db)
     dh_dev_free(db->d_rcpk_alloc);
     dh_dev_free(db->d_off);
     dh_dev_free(db->d_group);
-    dh_dev_free(db->d_mask_bits);
+    dh_mask_free(db);
     if (db->has_ix) db->ix.release();
     delete db;
 }
 
 static size_t mask_bytes(const dh_db *db) { return (size_t)((db->total + 31) / 32) * 4 + 16; }
 
-int dh_ensure_mask_bits(dh_db *db)
+void dh_mask_free(dh_db *db)
 {
-    if (db->d_mask_bits) return DH_OK;
-    HIPCHK(dh_dev_alloc(&db->d_mask_bits, mask_bytes(db)));
-    HIPCHK(hipMemsetAsync(db->d_mask_bits, 0, mask_bytes(db), db->ctx->stream));
+    if (db->d_mask_bits != db->d_mask_user && db->d_mask_bits != db->d_mask_derived) dh_dev_free(db->d_mask_bits);
+    dh_dev_free(db->d_mask_user);
+    dh_dev_free(db->d_mask_derived);
+    db->d_mask_bits = db->d_mask_user = db->d_mask_derived = nullptr;
+}
+
+int dh_ensure_mask_layer(dh_db *db, int derived, uint8_t **out)
+{
+    uint8_t *&layer = derived ? db->d_mask_derived : db->d_mask_user;
+    if (!layer) {
+        HIPCHK(dh_dev_alloc(&layer, mask_bytes(db)));
+        HIPCHK(hipMemsetAsync(layer, 0, mask_bytes(db), db->ctx->stream));
+    }
+    *out = layer;
     return DH_OK;
 }
 
-// soft mask of the DB (union of the daligner -m tracks): per sequence sorted, disjoint intervals,
-// rasterised into the DB's mask bitmap (ORed with DBdust's bits if dh_db_dust ran before).
-// Passing ptr == NULL clears the whole mask.  The cached k-mer index is dropped.
+// d_mask_bits = the only layer there is, or the OR of the two in a buffer of its own
+int dh_mask_recompose(dh_db *db)
+{
+    uint8_t *u = db->d_mask_user, *d = db->d_mask_derived;
+    const bool own = db->d_mask_bits && db->d_mask_bits != u && db->d_mask_bits != d;
+    if (u && d) {
+        if (!own) {
+            db->d_mask_bits = nullptr;
+            HIPCHK(dh_dev_alloc(&db->d_mask_bits, mask_bytes(db)));
+        }
+        dhk_or_words(db->ctx->stream, (uint32_t *)db->d_mask_bits, (const uint32_t *)u, (const uint32_t *)d,
+                     (int64_t)(mask_bytes(db) / 4));
+        HIPCHK(hipGetLastError());
+        return DH_OK;
+    }
+    if (own) {
+        HIPCHK(hipStreamSynchronize(db->ctx->stream));
+        dh_dev_free(db->d_mask_bits);
+    }
+    db->d_mask_bits = u ? u : d;
+    return DH_OK;
+}
+
+// soft mask of the DB (union of the daligner -m tracks): per sequence sorted, disjoint intervals.
+// SET semantics: the call replaces the tracks of an earlier call; what the library derived itself
+// (dh_db_dust, dh_db_mask_coverage) is a layer of its own and stays -- the effective mask is the OR
+// of the two.  Passing ptr == NULL clears the whole mask, both layers.  The cached k-mer index is dropped.
 extern "C" int dh_db_set_mask(dh_db *db, const int64_t *ptr, const int32_t *iv)
 {
     if (!db) return fail(DH_EINVAL, "db is NULL");
@@ -409,8 +444,7 @@ extern "C" int dh_db_set_mask(dh_db *db, const int64_t *ptr, const int32_t *iv)
     if (db->has_ix) db->ix.release();
     db->has_ix = false;
     if (!ptr) {
-        dh_dev_free(db->d_mask_bits);
-        db->d_mask_bits = nullptr;
+        dh_mask_free(db);
         return DH_OK;
     }
     for (int32_t s = 0; s < db->n; s++) {
@@ -426,14 +460,10 @@ extern "C" int dh_db_set_mask(dh_db *db, const int64_t *ptr, const int32_t *iv)
         for (int64_t j = ptr[s]; j < ptr[s + 1]; j++)
             for (int64_t g = db->h_off[(size_t)s] + iv[2 * j]; g < db->h_off[(size_t)s] + iv[2 * j + 1]; g++)
                 bits[(size_t)(g >> 3)] |= (uint8_t)(1u << (g & 7));
-    const bool had = db->d_mask_bits != nullptr;
-    if (int rc = dh_ensure_mask_bits(db)) return rc;
-    if (had) {  // keep what is there (e.g. the dust bits): OR on the host
-        std::vector<uint8_t> cur(bits.size());
-        HIPCHK(hipMemcpy(cur.data(), db->d_mask_bits, cur.size(), hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < bits.size(); i++) bits[i] |= cur[i];
-    }
-    HIPCHK(hipMemcpyAsync(db->d_mask_bits, bits.data(), bits.size(), hipMemcpyHostToDevice, db->ctx->stream));
+    uint8_t *layer;
+    if (int rc = dh_ensure_mask_layer(db, 0, &layer)) return rc;
+    HIPCHK(hipMemcpyAsync(layer, bits.data(), bits.size(), hipMemcpyHostToDevice, db->ctx->stream));
+    if (int rc = dh_mask_recompose(db)) return rc;
     HIPCHK(hipStreamSynchronize(db->ctx->stream));
     return DH_OK;
 }
@@ -443,7 +473,8 @@ int dh_db_dust_impl(dh_db *db)
     dh_ctx *ctx = db->ctx;
     if (db->has_ix) db->ix.release();
     db->has_ix = false;
-    if (int rc = dh_ensure_mask_bits(db)) return rc;
+    uint8_t *layer;
+    if (int rc = dh_ensure_mask_layer(db, 1, &layer)) return rc;
     const int32_t chunk = db->max_len < 16384 ? 64 : 512;
     const int64_t tile = 256ll * chunk;
     std::vector<int2> tiles;
@@ -451,12 +482,13 @@ int dh_db_dust_impl(dh_db *db)
         const int64_t len = db->h_off[(size_t)s + 1] - db->h_off[(size_t)s];
         for (int64_t a = 0; a < len - 15; a += tile) tiles.push_back(int2{s, (int32_t)a});
     }
-    if (tiles.empty()) return DH_OK;
+    if (tiles.empty()) return dh_mask_recompose(db);
     DevBuf<int2> d_tiles;
     HIPCHK(d_tiles.alloc(tiles.size()));
     HIPCHK(hipMemcpyAsync(d_tiles.p, tiles.data(), sizeof(int2) * tiles.size(), hipMemcpyHostToDevice, ctx->stream));
-    dhk_dust(ctx->stream, db->d_bases, db->d_off, d_tiles.p, (int32_t)tiles.size(), chunk, (uint32_t *)db->d_mask_bits);
+    dhk_dust(ctx->stream, db->d_bases, db->d_off, d_tiles.p, (int32_t)tiles.size(), chunk, (uint32_t *)layer);
     HIPCHK(hipGetLastError());
+    if (int rc = dh_mask_recompose(db)) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return DH_OK;
 }
@@ -495,7 +527,8 @@ extern "C" int dh_db_mask_coverage(dh_db *db, const dh_la *las, int64_t n, const
     hipStream_t st = ctx->stream;
     if (db->has_ix) db->ix.release();
     db->has_ix = false;
-    if (int rc = dh_ensure_mask_bits(db)) return rc;
+    uint8_t *layer;
+    if (int rc = dh_ensure_mask_layer(db, 1, &layer)) return rc;
     const int64_t nslots = db->total + db->n + 2;
     DevBuf<uint32_t> d_cov, d_sums;
     DevBuf<dh_la> d_las;
@@ -513,8 +546,9 @@ extern "C" int dh_db_mask_coverage(dh_db *db, const dh_la *las, int64_t n, const
     HIPCHK(hipGetLastError());
     dhk_scan(st, d_cov.p, nslots, d_sums.p);
     HIPCHK(hipGetLastError());
-    dhk_cov_mask(st, d_cov.p, db->d_off, db->n, db->max_len, lower, upper, (uint32_t *)db->d_mask_bits);
+    dhk_cov_mask(st, d_cov.p, db->d_off, db->n, db->max_len, lower, upper, (uint32_t *)layer);
     HIPCHK(hipGetLastError());
+    if (int rc = dh_mask_recompose(db)) return rc;
     HIPCHK(hipStreamSynchronize(st));
     return DH_OK;
 }
@@ -661,7 +695,9 @@ static int build_index(dh_db *A, int32_t k, int32_t sepv, int32_t kmer_mod)
         }
     }
     goff[(size_t)A->n] = g;
-    if (g >= (1ll << 39)) return fail(DH_EINVAL, "index: virtual coordinate space exceeds 2^39");
+    if (g >= (1ll << 39))
+        return fail(DH_EINVAL, "index: virtual coordinate space exceeds 2^39 (every sequence takes its length + the longest "
+                               "B read + 64, rounded up to 4096)");
     if (A->n >= (1 << 24)) return fail(DH_EINVAL, "index: more than 2^24 sequences");
     const int32_t keybits = 2 * k + ceil_log2((uint64_t)A->ngroups);
     if (keybits > 62) return fail(DH_EINVAL, "index: k-mer key does not fit 62 bits");
@@ -673,7 +709,10 @@ static int build_index(dh_db *A, int32_t k, int32_t sepv, int32_t kmer_mod)
     ix.shift = keybits - pbits;
     // the largest key is ngroups * 4^k - 1, so buckets up to (that >> shift) are addressable
     const int64_t nb = (int64_t)((((uint64_t)A->ngroups << (2 * k)) - 1) >> ix.shift) + 1;
-    if (nk >= (1ll << 32)) return fail(DH_EINVAL, "index: more than 2^32 k-mer positions (32-bit bucket offsets)");
+    // bucket offsets are 32 bits wide: the k-mers actually indexed (about nk / kmer_mod of the positions: the
+    // modimer hash samples evenly) have to stay below 2^32, with 1/16 of headroom for the sampling's spread
+    if (nk / std::max(1, kmer_mod) >= (1ll << 32) - (1ll << 28))
+        return fail(DH_EINVAL, "index: more than 2^32 indexed k-mers (32-bit bucket offsets); raise kmer_mod");
     HIPCHK(dh_dev_alloc(&ix.d_dir_alloc, sizeof(uint32_t) * (size_t)(nb + 2)));
     ix.d_dir = ix.d_dir_alloc + 1;
     HIPCHK(dh_dev_alloc(&ix.d_goff, sizeof(int64_t) * (size_t)(A->n + 1)));
@@ -867,6 +906,7 @@ extern "C" int dh_map_reads(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_t f
     std::mutex mu;
     int64_t dropped[6] = {0, 0, 0, 0, 0, 0};
     int hook_rc = DH_OK;
+    std::string hook_msg;  // dh_last_error() is per thread: the hook thread's message travels with its code
     std::vector<dh_pileups *> per_chunk;  // spanning-read candidates of every chunk, LA indices of the result
     struct CandGuard {
         std::vector<dh_pileups *> &v;
@@ -876,14 +916,17 @@ extern "C" int dh_map_reads(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_t f
         }
     } cguard{per_chunk};
     const ChunkHook hook = [&](dh_la *las, int64_t n, int64_t l0, int64_t chunk_no) {
-        int64_t d[6];
+        int64_t d[6] = {0, 0, 0, 0, 0, 0};
         int rc = dh_collect_filter(las, n, contigs->h_off.data(), contigs->n, reads->h_off.data(), reads->n, rep_ptr,
                                    rep_iv, popts, d, nullptr);
         dh_pileups *pc = nullptr;
         if (rc == DH_OK && cands) rc = dh_collect_candidates(las, n, contigs->h_off.data(), contigs->n, popts, &pc);
         if (pc && l0 != 0) dh_pileups_shift(pc, (int32_t)l0);
         std::lock_guard<std::mutex> lk(mu);
-        if (rc != DH_OK) hook_rc = rc;
+        if (rc != DH_OK && hook_rc == DH_OK) {
+            hook_rc = rc;
+            hook_msg = dh_last_error();
+        }
         for (int k = 0; k < 6; k++) dropped[k] += d[k];
         if ((size_t)chunk_no >= per_chunk.size()) per_chunk.resize((size_t)chunk_no + 1, nullptr);
         per_chunk[(size_t)chunk_no] = pc;
@@ -893,7 +936,7 @@ extern "C" int dh_map_reads(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_t f
     if (hook_rc != DH_OK) {
         dh_la_set_destroy(*out);
         *out = nullptr;
-        return hook_rc;
+        return fail(hook_rc, hook_msg.empty() ? "dh_map_reads: a chunk's filters failed" : hook_msg);
     }
     if (cands) {  // chunks hold ascending read ranges: concatenating per gap keeps every gap ordered by read
         if (int rc2 = dh_pileups_concat(per_chunk.data(), (int32_t)per_chunk.size(), cands)) {

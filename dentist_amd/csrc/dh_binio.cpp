@@ -246,7 +246,9 @@ extern "C" int dh_pileupdb_read(const char *path, dh_chaindb **out)
     uint64_t ix[6];
     if (b.size() < sizeof(ix)) return dh_fail(DH_EIO, "pile-ups db: unexpected end of file (index)");
     memcpy(ix, b.data(), sizeof(ix));
-    if (ix[0] != sizeof(ix) || ix[5] != b.size() || ix[1] < ix[0] || ix[2] < ix[1] || (ix[1] - ix[0]) % 16 || (ix[2] - ix[1]) % 16)
+    // every array begins where the previous one ends and all of them lie inside the file
+    if (ix[0] != sizeof(ix) || ix[5] != b.size() || ix[1] < ix[0] || ix[2] < ix[1] || ix[3] < ix[2] || ix[4] < ix[3] ||
+        ix[5] < ix[4] || (ix[1] - ix[0]) % 16 || (ix[2] - ix[1]) % 16)
         return dh_fail(DH_EIO, "pile-ups db: corrupted index");
     dh_chaindb *d = new dh_chaindb();
     const size_t npiles = (ix[1] - ix[0]) / 16, nra = (ix[2] - ix[1]) / 16;
@@ -292,10 +294,11 @@ extern "C" int dh_insertiondb_write(const char *path, int32_t nins, const dh_ins
         nsa += ins[i].noverlaps;
         nids += ins[i].nread_ids;
     }
+    if ((nbases > 0 && !bases) || (nids > 0 && !read_ids) || (nsa > 0 && (!sa || !la)))
+        return dh_fail(DH_EINVAL, "dh_insertiondb_write: NULL array");
     for (int64_t s = 0; s < nsa; s++) nla += sa[s].nla;
     for (int64_t l = 0; l < nla; l++) ntp += la[l].ntp;
-    if ((nbases > 0 && !bases) || (nids > 0 && !read_ids) || (nsa > 0 && (!sa || !la)) || (ntp > 0 && !tp))
-        return dh_fail(DH_EINVAL, "dh_insertiondb_write: NULL array");
+    if (ntp > 0 && !tp) return dh_fail(DH_EINVAL, "dh_insertiondb_write: NULL array");
     uint64_t ix[7];
     ix[0] = sizeof(ix);
     ix[1] = ix[0] + sizeof(InsertionSt) * (uint64_t)nins;
@@ -357,7 +360,7 @@ extern "C" int dh_insertiondb_read(const char *path, dh_chaindb **out)
     if (b.size() < sizeof(ix)) return dh_fail(DH_EIO, "insertions db: unexpected end of file (index)");
     memcpy(ix, b.data(), sizeof(ix));
     if (ix[0] != sizeof(ix) || ix[6] != b.size() || ix[1] < ix[0] || (ix[1] - ix[0]) % sizeof(InsertionSt) || ix[2] < ix[1] ||
-        ix[5] > ix[6] || (ix[6] - ix[5]) % 4)
+        ix[3] < ix[2] || ix[4] < ix[3] || ix[5] < ix[4] || ix[5] > ix[6] || (ix[6] - ix[5]) % 4)
         return dh_fail(DH_EIO, "insertions db: corrupted index");
     dh_chaindb *d = new dh_chaindb();
     const size_t nins = (ix[1] - ix[0]) / sizeof(InsertionSt);

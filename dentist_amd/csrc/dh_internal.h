@@ -103,6 +103,10 @@ struct dh_db {
     // soft mask: one bit per base of d_bases (bit g of the buffer = base g), 16 bytes of slack at the
     // end for the kernels' unaligned 8-byte reads; nullptr = nothing masked
     uint8_t *d_mask_bits = nullptr;
+    // the two layers behind it: the caller's tracks (dh_db_set_mask replaces this layer only; slices
+    // inherit into it) and what the library derived (DBdust, alignment coverage).  d_mask_bits is the
+    // layer itself while only one exists, their OR in a buffer of its own when both do.
+    uint8_t *d_mask_user = nullptr, *d_mask_derived = nullptr;
     DbView view() const { return DbView{d_bases, d_off, d_group, n, d_mask_bits}; }
 };
 
@@ -165,8 +169,11 @@ int dh_db_from_slices(dh_ctx *ctx, const dh_db *src, const std::vector<int32_t> 
 int dh_db_adopt(dh_ctx *ctx, uint8_t *d_alloc, uint8_t *d_bases, const std::vector<int64_t> &off,
                 const std::vector<int32_t> &group, dh_db **out);
 int dh_ensure_rc(dh_db *db);
-// the DB's mask bitmap, allocated and zeroed on first use
-int dh_ensure_mask_bits(dh_db *db);
+// a layer of the DB's mask bitmap (derived != 0: the library's own bits, else the caller's / inherited
+// tracks), allocated and zeroed on first use; write into it, then call dh_mask_recompose
+int dh_ensure_mask_layer(dh_db *db, int derived, uint8_t **out);
+int dh_mask_recompose(dh_db *db);
+void dh_mask_free(dh_db *db);
 // DBdust: ORs the low-complexity mask (k_dust) into the DB's mask bitmap; drops the cached index
 int dh_db_dust_impl(dh_db *db);
 int dh_ensure_packed(dh_db *db, bool with_rc);

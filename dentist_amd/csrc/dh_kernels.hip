@@ -2546,6 +2546,18 @@ void dhk_compact(hipStream_t st, const DhLa *la_slots, const uint16_t *tr_slots,
                        nitems, la_off, tr_off, tr_base, la_out, tr_out);
 }
 
+__global__ void __launch_bounds__(256) k_or_words(uint32_t *__restrict__ dst, const uint32_t *__restrict__ a,
+                                                    const uint32_t *__restrict__ b, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = a[i] | b[i];
+}
+void dhk_or_words(hipStream_t st, uint32_t *dst, const uint32_t *a, const uint32_t *b, int64_t n)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_or_words, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dst, a, b, n);
+}
+
 void dhk_dust(hipStream_t st, const uint8_t *bases, const int64_t *off, const int2 *tiles, int32_t ntiles,
               int32_t chunk, uint32_t *bits)
 {

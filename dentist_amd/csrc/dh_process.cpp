@@ -132,9 +132,11 @@ int dh_db_from_slices(dh_ctx *ctx, const dh_db *src, const std::vector<int32_t> 
         dhk_gather_slices(ctx->stream, src->d_bases, src->d_off, d_sidx.p, d_sbeg.p, (*out)->d_off, n,
                           max_len, d_bases);
         if (inherit_mask && src->d_mask_bits) {  // slices keep the soft mask of their source (the flank DB's -mrep)
-            if (int rc = dh_ensure_mask_bits(*out)) return rc;
+            uint8_t *layer;
+            if (int rc = dh_ensure_mask_layer(*out, 0, &layer)) return rc;
             dhk_mask_slices(ctx->stream, (const uint32_t *)src->d_mask_bits, src->d_off, d_sidx.p, d_sbeg.p, (*out)->d_off, n,
-                            max_len, (uint32_t *)(*out)->d_mask_bits);
+                            max_len, (uint32_t *)layer);
+            if (int rc = dh_mask_recompose(*out)) return rc;
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -78,7 +78,10 @@ void dh_db_destroy(dh_db *db);
 /* soft mask = union of the daligner/damapper -m tracks (commandline.d:2886-2955 passes -mdust,
  * -mdentist-self, -mtan, -mrep): per sequence sorted disjoint intervals iv[2j], iv[2j+1] for j in
  * [ptr[s], ptr[s+1]).  k-mers touching a masked interval are neither indexed (A side) nor looked
- * up (B side); alignments still extend through masked sequence.  ptr == NULL clears the mask. */
+ * up (B side); alignments still extend through masked sequence.  The call REPLACES the tracks of an
+ * earlier dh_db_set_mask; the bits the library derived itself (dh_db_dust, dh_db_mask_coverage) are a
+ * layer of their own and stay -- the effective mask is the OR of the two layers.  ptr == NULL clears
+ * the whole mask, both layers. */
 int dh_db_set_mask(dh_db *db, const int64_t *ptr, const int32_t *iv);
 /* DBdust (symmetric DUST, -w64 -t2.0 -m10; DENTIST runs it on every DB it aligns with -mdust,
  * processPileUps/package.d:476-482, 655-667): low-complexity windows are found on the device and

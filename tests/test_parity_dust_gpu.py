@@ -53,12 +53,27 @@ def test_dust_mask_matches_the_oracle(gpu_ctx):
     fwd = iv[2 * ptr[0]:2 * ptr[1]].reshape(-1, 2)
     rev = iv[2 * ptr[5]:2 * ptr[6]].reshape(-1, 2)
     assert np.array_equal(np.sort(n0 - fwd[:, ::-1], axis=0), np.sort(rev, axis=0))
-    # an explicit track is ORed with the dust bits
+    # an explicit track is a layer of its own: the effective mask is its OR with the dust bits ...
     extra_ptr = np.zeros(db.n + 1, dtype=np.int64)
     extra_ptr[1:] = 1
     d.set_mask(extra_ptr, np.asarray([20_000, 20_500], dtype=np.int32))
     p2, i2 = d.get_mask()
     assert p2[-1] >= ptr[-1] and any(b <= 20_000 and e >= 20_500 for b, e in i2[:2 * p2[1]].reshape(-1, 2))
+    # ... and a second dh_db_set_mask REPLACES the first track (set semantics), the dust layer stays
+    d.set_mask(extra_ptr, np.asarray([30_000, 30_100], dtype=np.int32))
+    p3, i3 = d.get_mask()
+    first = i3[:2 * p3[1]].reshape(-1, 2)
+    assert any(b <= 30_000 and e >= 30_100 for b, e in first)
+    dust0 = iv[2 * ptr[0]:2 * ptr[1]].reshape(-1, 2)
+    if not any(b < 20_500 and e > 20_000 for b, e in dust0):   # the old track is gone unless dust covers it anyway
+        assert not any(b < 20_500 and e > 20_000 for b, e in first)
+    empty = np.zeros(db.n + 1, dtype=np.int64)
+    d.set_mask(empty, np.zeros(0, dtype=np.int32))
+    p4, i4 = d.get_mask()
+    assert np.array_equal(p4, ptr) and np.array_equal(i4, iv)   # only the dust layer is left
+    d.set_mask(None, None)
+    p5, _ = d.get_mask()
+    assert p5[-1] == 0
 
 
 def test_alignment_with_dust_masks_matches_the_oracle(gpu_ctx):
