@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--map-width", type=int, default=None,
                     help="DH-2: the band (64); DH-1: live diagonals of the wave (default 14: four alignments per wavefront)")
     ap.add_argument("--map-xdrop", type=int, default=60, help="score lag that trims the mapping waves")
+    ap.add_argument("--process-algo", type=int, default=1,
+                    help="alignments of the process stages (pile-up all-vs-all, re-alignment, flanks): 1 = DH-2, 0 = DH-1")
+    ap.add_argument("--max-reads", type=int, default=None, help="reads kept per pile-up (default: dh_default_process_opts)")
     ap.add_argument("--dev-share-gpu", action="store_true",
                     help="development only: all ranks on cuda:0 with gloo collectives (exercises the N > 1 "
                          "code path on a 1-GPU box; not a measurement)")
@@ -123,7 +126,9 @@ def main():
         args.map_width = 64 if args.map_algo == 1 else 14
     mopts = dentist_amd.default_align_opts(kmer_mod=args.kmer_mod, k=args.map_k, width=args.map_width,
                                            xdrop=args.map_xdrop, algo=args.map_algo)
-    popts = dentist_amd.default_process_opts()
+    popts = dentist_amd.default_process_opts(algo=args.process_algo)
+    if args.max_reads is not None:
+        popts.max_reads = args.max_reads
     read_bp = int(len(w.reads.bases))
 
     def step():
@@ -227,7 +232,12 @@ def main():
             "config": {"workload": args.workload, "shape": spec, "mapping_k": args.map_k,
                        "mapping_kmer_mod": args.kmer_mod, "mapping_algo": "DH-2 tiled band (k_tile)" if args.map_algo == 1 else "DH-1 wave (k_wave2)",
                        "mapping_width": args.map_width,
-                       "mapping_xdrop": args.map_xdrop, "parallelism": f"reads and gaps sharded over {world} GPU(s)",
+                       "mapping_xdrop": args.map_xdrop,
+                       "process": {"algo": "DH-2 tiled band (k_tile)" if popts.algo == 1 else "DH-1 wave (k_wave2)",
+                                   "max_reads_per_pile_up": popts.max_reads, "min_reads_per_pile_up": popts.min_reads,
+                                   "consensus_rounds": popts.rounds, "width": 64 if popts.algo == 1 else (popts.width or 30),
+                                   "xdrop": 120, "tspace": popts.tspace_pile, "dust": popts.dust},
+                       "parallelism": f"reads and gaps sharded over {world} GPU(s)",
                        "read_bp_total": read_all, "pile_ups": int(last["info"]["piles"]),
                        "collect_filters_dropped_las": dict(zip(("lq", "improper", "weakly_anchored", "contained",
                                                                 "ambiguous", "redundant"), last["info"]["filtered"])),
@@ -302,7 +312,7 @@ def cpu_baseline(w, last, mopts, popts, args, gap_bases, read_bp_total):
 
     rec, las_all = last["rec"], last["las"]
     npiles = int(last["info"]["piles"])
-    po = oz.default_process_opts(rounds=popts.rounds, max_reads=popts.max_reads, min_reads=popts.min_reads)
+    po = oz.default_process_opts(rounds=popts.rounds, max_reads=popts.max_reads, min_reads=popts.min_reads, algo=popts.algo)
     gaps_sorted = [int(r["contig_left"]) for r in rec]
     budget, batch = 0.5 * args.cpu_seconds, max(cores // 4, 8)
     done, t_proc, used = 0, 0.0, 0

@@ -1028,7 +1028,6 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     const bool tiled = o.algo == 1;
     if (tiled) {
         if (o.width != dhtile::W) return fail(DH_EINVAL, "algo 1 (DH-2): width is the band, it must be 64");
-        if (o.skip_self == 2) return fail(DH_EINVAL, "algo 1 (DH-2) has no symmetric mode");
         if (o.tspace > dhtile::TS_MAX) return fail(DH_EINVAL, "algo 1 (DH-2): tspace must be <= 128");
     } else if (o.width < 1 || o.width > 62)
         return fail(DH_EINVAL, "width must be in [1, 62]");
@@ -1173,7 +1172,9 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     int32_t *d_ovf;
     SCR(29, d_ovf, cn)
     int32_t *d_regs = nullptr;
+    uint16_t *d_tscr = nullptr;
     if (tiled) SCR(32, d_regs, (size_t)tile_waves * 64 * dhtile::MAXREG * dhtile::REGF)
+    if (tiled && o.skip_self == 2) SCR(33, d_tscr, (size_t)tile_waves * 64 * trmax)
     HIPCHK(hipMemsetAsync(d_status, 0, sizeof(int32_t), st));
     HIPCHK(hipMemsetAsync(d_counters, 0, 2 * sizeof(unsigned long long), st));
 
@@ -1315,6 +1316,10 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             tp.cand = candbase;
             tp.ncand = ncandbase;
             tp.queue = d_queue;
+            tp.units = (const int4 *)d_units;
+            tp.nunits = d_queue + 3;
+            tp.item_ovf = d_ovf - item0;
+            tp.tscr = d_tscr;
             tp.regs = d_regs;
             tp.nbmax = nbmax;
             tp.trmax = trmax;

@@ -1362,6 +1362,9 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
     int32_t pwidth = o.width > 0 ? o.width : 30;
     if (const char *e = getenv("DH_PILE_WIDTH")) pwidth = atoi(e);  // development override
     if (pwidth < 1 || pwidth > 62) return dh_fail(DH_EINVAL, "process: width must be in [1, 62]");
+    if (o.algo != 0 && o.algo != 1) return dh_fail(DH_EINVAL, "process: algo must be 0 (DH-1) or 1 (DH-2)");
+    const int32_t palgo = o.algo;
+    if (palgo == 1) pwidth = 64;  // DH-2: the band
 
     // ---- 1. the pile-up DB: the cropped reads of every pile-up that is large enough, grouped by
     // pile-up (group = index among the active pile-ups)
@@ -1439,6 +1442,7 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
         ao.max_la = 64;
         ao.max_cand = 128;
         ao.width = pwidth;
+        ao.algo = palgo;
         dh_la_set *pset = nullptr;
         HIPCHK(hipEventRecord(ev[0], st));
         if (int rc = dh_align_db_ex(ctx, pile, pile, &ao, 0, 0, &pset)) return rc;
@@ -1693,6 +1697,7 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
             ro.max_la = 4;
             ro.max_cand = 32;
             ro.width = pwidth;
+            ro.algo = palgo;
             dh_la_set *rset = nullptr;
             HIPCHK(hipEventRecord(ev[0], st));
             if (int rc = dh_align_db_ex(ctx, T, pile, &ro, 0, 0, &rset)) return rc;
@@ -1750,6 +1755,7 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
         fo.max_la = 4;
         fo.max_cand = 32;
         fo.width = pwidth;
+        fo.algo = palgo;
         dh_la_set *fset = nullptr;
         HIPCHK(hipEventRecord(ev[0], st));
         if (int rc = dh_align_db_ex(ctx, F, T, &fo, 0, 0, &fset)) return rc;

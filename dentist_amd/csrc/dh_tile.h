@@ -48,6 +48,10 @@ struct Params {
     const DhCand *cand;               // max_cand per item, indexed by absolute item
     const int32_t *ncand;
     uint32_t *queue;                  // work counter
+    const int4 *units;                // optional work units (item - item0, first candidate, end candidate, 0), else NULL
+    const uint32_t *nunits;           // their number (device side)
+    int32_t *item_ovf;                // symmetric mode: per item (absolute), set when a record was dropped for want of slots
+    uint16_t *tscr;                   // symmetric mode: nlanes * trmax, the trace pairs of the alignment in flight
     int32_t *regs;                    // nlanes * MAXREG * REGF
     int32_t nbmax, trmax;             // pairs a direction can yield; u16 values per output slot (>= 2 * (2 * nbmax + 2))
     DhLa *out_la;                     // max_la records per item (absolute item index)
@@ -78,6 +82,10 @@ struct Lane {
     int32_t c_aseq, as, bs, alen, roff;
     int64_t ao;
     int32_t dir;  // 1 = reverse extension (runs first), 0 = forward
+    // the alignment in flight: mode 0 = the candidate as seeded, 1 = the transposed pair (symmetric mode);
+    // g_*: its A / B sequences (offset, length) and seed point
+    int32_t mode, g_alen, g_as, g_blen, g_bs;
+    int64_t g_ao, g_bo;
     // result of the reverse extension
     int32_t rv_i, rv_j, rv_d, rv_nseg, rv_klo, rv_khi;
     uint32_t rv_pair1;
@@ -113,12 +121,12 @@ DH_HD void ext_begin(Lane &l, const Params &P, int32_t dir)
 {
     Ext &e = l.e;
     l.dir = dir;
-    const int32_t ts = P.o.tspace, as = l.as, bs = l.bs;
+    const int32_t ts = P.o.tspace, as = l.g_as, bs = l.g_bs;
     // the reverse extension is a forward extension over the reverse-complemented copies
-    e.ga = l.ao + (dir ? l.alen - as : as);
-    e.gb = l.bo + (dir ? l.blen - bs : bs);
-    e.an = dir ? as : l.alen - as;
-    e.bn = dir ? bs : l.blen - bs;
+    e.ga = l.g_ao + (dir ? l.g_alen - as : as);
+    e.gb = l.g_bo + (dir ? l.g_blen - bs : bs);
+    e.an = dir ? as : l.g_alen - as;
+    e.bn = dir ? bs : l.g_blen - bs;
     const bool brc_side = (l.strand != 0) != (dir != 0);
     e.apk = dir ? P.arcpk : P.apk;
     e.bpp = brc_side ? P.brcpp : P.bpp;
@@ -294,6 +302,18 @@ DH_HD void tile_end(Lane &l, const Params &P, const Tile &t, uint16_t *pairs)
 
 // ------------------------------------------------------------------------------ bookkeeping
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DH_ATOMIC_ADD(p, v) atomicAdd((p), (v))
+#else
+static inline int32_t dh_host_fetch_add(int32_t *p, int32_t v)
+{
+    const int32_t old = *p;
+    *p = old + v;
+    return old;
+}
+#define DH_ATOMIC_ADD(p, v) dh_host_fetch_add((p), (v))
+#endif
+
 DH_HD void lane_init(Lane &l, int32_t slot)
 {
     l.st = L_FETCH;
@@ -306,23 +326,66 @@ DH_HD void lane_init(Lane &l, int32_t slot)
     l.c_aseq = l.as = l.bs = l.alen = l.roff = 0;
     l.ao = 0;
     l.dir = 0;
+    l.mode = 0;
+    l.g_ao = l.g_bo = 0;
+    l.g_alen = l.g_as = l.g_blen = l.g_bs = 0;
     l.rv_i = l.rv_j = l.rv_d = l.rv_nseg = l.rv_klo = l.rv_khi = 0;
     l.rv_pair1 = 0;
 }
 
-// `it` = work item index in [0, nitems)
+// where the trace pairs of the running candidate go: straight into its output slot, or -- symmetric
+// mode, where the slot is claimed only when the record is accepted -- into the lane's own scratch slot
+DH_HD uint16_t *lane_pairs(const Lane &l, const Params &P)
+{
+    if (P.o.skip_self == 2) return P.tscr + (int64_t)l.slot * P.trmax;
+    return P.out_trace + ((int64_t)l.item * P.o.max_la + l.nacc) * P.trmax;
+}
+
+// geometry of the alignment to run for the current candidate.  mode 0: A = the candidate's A sequence,
+// B = the item's read in the item's orientation.  mode 1 (symmetric mode, second record): the
+// transposed pair through the same seed -- A'' = the item's read on its forward strand, B'' = the A
+// sequence, complemented when the item is (both axes mirrored then)
+DH_HD void cand_geometry(Lane &l, const Params &P, int32_t mode)
+{
+    l.mode = mode;
+    if (!mode) {
+        l.g_ao = l.ao;
+        l.g_alen = l.alen;
+        l.g_as = l.as;
+        l.g_bo = l.bo;
+        l.g_blen = l.blen;
+        l.g_bs = l.bs;
+    } else {
+        l.g_ao = l.bo;
+        l.g_alen = l.blen;
+        l.g_as = l.strand ? l.blen - l.bs : l.bs;
+        l.g_bo = l.ao;
+        l.g_blen = l.alen;
+        l.g_bs = l.strand ? l.alen - l.as : l.as;
+    }
+    l.roff = (l.g_as % P.o.tspace) != 0 ? 1 : 0;
+}
+
+// `it` = work unit index: an item, or (P.units) one group of candidates of an item
 DH_HD void lane_fetch(Lane &l, const Params &P, int32_t it)
 {
-    const int32_t item = P.item0 + it;
+    int32_t ui = it, c0 = 0, c1 = 0x7FFFFFFF;
+    if (P.units) {
+        const int4 u = P.units[it];
+        ui = u.x;
+        c0 = u.y;
+        c1 = u.z;
+    }
+    const int32_t item = P.item0 + ui;
     l.item = item;
     l.strand = item & 1;
     const int32_t nc = P.ncand[item];
-    l.nc = nc > 0 ? nc : 0;
+    l.nc = nc > 0 ? (nc < c1 ? nc : c1) : 0;
     const int64_t bo = P.boff[item >> 1];
     l.bo = bo;
     l.blen = (int32_t)(P.boff[(item >> 1) + 1] - bo);
     l.nd = l.nacc = l.ntr = 0;
-    l.c = 0;
+    l.c = c0;
     l.st = L_CAND;
 }
 
@@ -330,7 +393,8 @@ DH_HD void lane_fetch(Lane &l, const Params &P, int32_t it)
 DH_HD void lane_next_cand(Lane &l, const Params &P)
 {
     const int32_t *rg = P.regs + (int64_t)l.slot * MAXREG * REGF;
-    while (l.c < l.nc && l.nacc < P.o.max_la && l.nd < MAXREG) {
+    const bool sym = P.o.skip_self == 2;
+    while (l.c < l.nc && (sym || l.nacc < P.o.max_la) && l.nd < MAXREG) {
         const DhCand cd = P.cand[(int64_t)l.item * P.o.max_cand + l.c];
         const int32_t sdc = cd.apos - cd.bpos;
         bool covd = false;
@@ -349,17 +413,65 @@ DH_HD void lane_next_cand(Lane &l, const Params &P)
         const int64_t ao = P.aoff[cd.aseq];
         l.ao = ao;
         l.alen = (int32_t)(P.aoff[cd.aseq + 1] - ao);
-        l.roff = (cd.apos % P.o.tspace) != 0 ? 1 : 0;
+        cand_geometry(l, P, 0);
         ext_begin(l, P, 1);
         return;
     }
-    P.out_nla[l.item] = l.nacc;
-    P.out_ntr[l.item] = l.ntr;
+    if (!sym) {
+        P.out_nla[l.item] = l.nacc;
+        P.out_ntr[l.item] = l.ntr;
+    }
     l.st = L_FETCH;
 }
 
+// the record of the alignment that just ended (both extensions), its pairs completed in `pairs`;
+// returns the number of pairs and where they start inside the slot
+DH_HD int32_t finish_pairs(const Lane &l, const Params &P, uint16_t *pairs, int32_t *first_out)
+{
+    const Ext &e = l.e;
+    const int32_t nbmax = P.nbmax, nr = l.rv_nseg, nf = e.best_nseg;
+    // the pair of the seed's interval: the forward tile 1 plus, when the seed is not on a boundary,
+    // the reverse tile 1 (the two are the halves of one trace interval)
+    const uint32_t seedp = (nf >= 1 ? e.best_pair1 : 0u) + ((l.roff && nr >= 1) ? l.rv_pair1 : 0u);
+    const bool seedslot = nf >= 1 || (l.roff && nr >= 1);
+    if (seedslot) {
+        pairs[2 * nbmax] = (uint16_t)(seedp >> 16);
+        pairs[2 * nbmax + 1] = (uint16_t)(seedp & 0xFFFFu);
+    }
+    if (!l.roff && nr >= 1) {  // the reverse tile 1 is an interval of its own
+        pairs[2 * (nbmax - 1)] = (uint16_t)(l.rv_pair1 >> 16);
+        pairs[2 * (nbmax - 1) + 1] = (uint16_t)(l.rv_pair1 & 0xFFFFu);
+    }
+    const int32_t lo_idx = nbmax - nr + l.roff;
+    const int32_t hi_idx = nbmax + (nf > (seedslot ? 1 : 0) ? nf : (seedslot ? 1 : 0));
+    const int32_t first = (nr == 0 && l.roff) ? nbmax : lo_idx;  // no reverse segment: the range starts at the seed slot
+    *first_out = first;
+    return hi_idx - first;
+}
+
+// symmetric mode: claim a record slot of item `it` and move the pairs from the lane's scratch into it
+DH_HD void emit_claimed(Lane &l, const Params &P, int32_t it, int32_t other_item, DhLa la, const uint16_t *pairs,
+                        int32_t first, int32_t npairs)
+{
+    const int32_t s = DH_ATOMIC_ADD(&P.out_nla[it], 1);
+    if (s >= P.o.max_la) {
+        // more overlaps than slots: the record is dropped, both items are reported (as k_wave2 does)
+        DH_ATOMIC_ADD(&P.out_nla[it], -1);
+        P.item_ovf[it] = 1;
+        P.item_ovf[other_item] = 1;
+        return;
+    }
+    const int64_t oslot = (int64_t)it * P.o.max_la + s;
+    uint16_t *dst = P.out_trace + oslot * P.trmax;
+    for (int32_t x = 0; x < 2 * npairs; x++) dst[x] = pairs[2 * first + x];
+    la.toff = 0;
+    P.out_la[oslot] = la;
+    DH_ATOMIC_ADD(&P.out_ntr[it], 2 * npairs);
+}
+
 // an extension ended: after the reverse one the forward one starts, after the forward one the candidate
-// becomes a region and, if it passes, a record
+// becomes a region and, if it passes, a record (symmetric mode: then the transposed pair is aligned
+// for the second record)
 DH_HD void lane_ext_end(Lane &l, const Params &P)
 {
     Ext &e = l.e;
@@ -378,45 +490,31 @@ DH_HD void lane_ext_end(Lane &l, const Params &P)
         ext_begin(l, P, 0);
         return;
     }
-    l.naln += 1;
-    const int32_t as = l.as, bs = l.bs, sd = as - bs;
+    const bool sym = P.o.skip_self == 2;
+    const int32_t as = l.g_as, bs = l.g_bs, sd = as - bs;
     const int32_t abpos = as - l.rv_i, bbpos = bs - l.rv_j, aepos = as + e.best_a, bepos = bs + e.best_b;
     const int32_t diffs = l.rv_d + e.best_d;
-    int32_t lo = sd + e.bklo, hi = sd + e.bkhi;
-    lo = (sd - l.rv_khi) < lo ? (sd - l.rv_khi) : lo;
-    hi = (sd - l.rv_klo) > hi ? (sd - l.rv_klo) : hi;
-    int32_t *g = P.regs + ((int64_t)l.slot * MAXREG + l.nd) * REGF;
-    g[0] = l.c_aseq;
-    g[1] = abpos;
-    g[2] = aepos;
-    g[3] = bbpos;
-    g[4] = bepos;
-    g[5] = lo;
-    g[6] = hi;
-    l.nd += 1;
-    l.c += 1;
+    if (l.mode == 0) {
+        l.naln += 1;
+        int32_t lo = sd + e.bklo, hi = sd + e.bkhi;
+        lo = (sd - l.rv_khi) < lo ? (sd - l.rv_khi) : lo;
+        hi = (sd - l.rv_klo) > hi ? (sd - l.rv_klo) : hi;
+        int32_t *g = P.regs + ((int64_t)l.slot * MAXREG + l.nd) * REGF;
+        g[0] = l.c_aseq;
+        g[1] = abpos;
+        g[2] = aepos;
+        g[3] = bbpos;
+        g[4] = bepos;
+        g[5] = lo;
+        g[6] = hi;
+        l.nd += 1;
+    }
     const int64_t al = aepos - abpos, bl = bepos - bbpos;
     const bool accept = al >= P.o.min_len && (int64_t)2 * diffs * 1000000ll <= (int64_t)P.o.max_err_ppm * (al + bl);
     if (accept) {
-        const int64_t oslot = (int64_t)l.item * P.o.max_la + l.nacc;
-        uint16_t *pairs = P.out_trace + oslot * P.trmax;
-        const int32_t nbmax = P.nbmax, nr = l.rv_nseg, nf = e.best_nseg;
-        // the pair of the seed's interval: the forward tile 1 plus, when the seed is not on a boundary,
-        // the reverse tile 1 (the two are the halves of one trace interval)
-        const uint32_t seedp = (nf >= 1 ? e.best_pair1 : 0u) + ((l.roff && nr >= 1) ? l.rv_pair1 : 0u);
-        const bool seedslot = nf >= 1 || (l.roff && nr >= 1);
-        if (seedslot) {
-            pairs[2 * nbmax] = (uint16_t)(seedp >> 16);
-            pairs[2 * nbmax + 1] = (uint16_t)(seedp & 0xFFFFu);
-        }
-        if (!l.roff && nr >= 1) {  // the reverse tile 1 is an interval of its own
-            pairs[2 * (nbmax - 1)] = (uint16_t)(l.rv_pair1 >> 16);
-            pairs[2 * (nbmax - 1) + 1] = (uint16_t)(l.rv_pair1 & 0xFFFFu);
-        }
-        const int32_t lo_idx = nbmax - nr + l.roff;
-        const int32_t hi_idx = nbmax + (nf > (seedslot ? 1 : 0) ? nf : (seedslot ? 1 : 0));
-        const int32_t first = (nr == 0 && l.roff) ? nbmax : lo_idx;  // no reverse segment: the range starts at the seed slot
-        const int32_t npairs = hi_idx - first;
+        uint16_t *pairs = lane_pairs(l, P);
+        int32_t first;
+        const int32_t npairs = finish_pairs(l, P, pairs, &first);
         DhLa la;
         la.tlen = 2 * npairs;
         la.diffs = diffs;
@@ -425,14 +523,25 @@ DH_HD void lane_ext_end(Lane &l, const Params &P)
         la.aepos = aepos;
         la.bepos = bepos;
         la.flags = l.strand ? 1u : 0u;
-        la.aread = l.c_aseq;
-        la.bread = l.item >> 1;
+        la.aread = l.mode ? (l.item >> 1) : l.c_aseq;
+        la.bread = l.mode ? l.c_aseq : (l.item >> 1);
         la.pad = 0;
         la.toff = 2 * (int64_t)first;  // where the pairs start inside the slot (k_compact honours it)
-        P.out_la[oslot] = la;
-        l.nacc += 1;
-        l.ntr += 2 * npairs;
+        if (!sym) {
+            P.out_la[(int64_t)l.item * P.o.max_la + l.nacc] = la;
+            l.ntr += 2 * npairs;
+        } else {
+            const int32_t item_a = 2 * l.c_aseq + l.strand;
+            emit_claimed(l, P, l.mode ? l.item : item_a, l.mode ? item_a : l.item, la, pairs, first, npairs);
+        }
+        if (l.mode == 0) l.nacc += 1;
+        if (sym && l.mode == 0) {  // the second record: the transposed pair, aligned on its own
+            cand_geometry(l, P, 1);
+            ext_begin(l, P, 1);
+            return;
+        }
     }
+    l.c += 1;
     l.st = L_CAND;
 }
 

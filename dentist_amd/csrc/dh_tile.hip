@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
                 lane_next_cand(l, P);
             else if (l.st == L_FETCH) {
                 const int32_t it = (int32_t)atomicAdd(P.queue, 1u);
-                if (it >= P.nitems)
+                if (it >= (P.units ? (int32_t)*P.nunits : P.nitems))
                     l.st = L_DONE;
                 else
                     lane_fetch(l, P, it);
@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
                 }
             }
         }
-        if (run) tile_end(l, P, t, P.out_trace + ((int64_t)l.item * P.o.max_la + l.nacc) * P.trmax);
+        if (run) tile_end(l, P, t, lane_pairs(l, P));
     }
     if (l.cells) atomicAdd(&P.counters[0], (unsigned long long)l.cells);
     if (l.naln) atomicAdd(&P.counters[1], (unsigned long long)l.naln);

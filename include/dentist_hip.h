@@ -63,7 +63,8 @@ typedef struct {
     int32_t kmer_mod;    /* -%  modimer sampling: only k-mers with hash % kmer_mod == 0; 1 = all     */
     int32_t algo;        /* extension algorithm: 0 = DH-1, the O(ND) furthest-reaching wave (k_wave2);
                           * 1 = DH-2, tile-by-tile banded bit-parallel DP, one alignment per lane (k_tile);
-                          *     band = width, which must be 32 or 64; not available with skip_self = 2 */
+                          *     band = width, which must be 64; with skip_self = 2 the second record of a pair is the
+                          *     tiled alignment of the transposed pair through the same seed */
 } dh_align_opts;
 void dh_default_align_opts(dh_align_opts *o);
 
@@ -202,7 +203,8 @@ typedef struct {
     int32_t width;             /* live diagonals of the wave in the pile-up stages (dh_align_opts.width), 0 = 30 */
     int32_t dust;              /* 1: DBdust + -mdust on the pile-up DB and the flank DB (package.d:476-482,
                                 * 655-667); the flank DB also inherits the contigs' soft mask (-mrep)       */
-    int32_t reserved;
+    int32_t algo;              /* alignments of the process stages (pile-up all-vs-all, re-alignment to the template,
+                                * flanks): 0 = DH-1 (wave, `width` live diagonals), 1 = DH-2 (tiled band of 64, k_tile) */
 } dh_process_opts;
 void dh_default_process_opts(dh_process_opts *o);
 

@@ -1013,9 +1013,11 @@ static void align_read(const oz_index *ix, const oz_db *A, const oz_db *B, int32
             memset(&la, 0, sizeof(la));
             memset(&la2, 0, sizeof(la2));
             int32_t dlo, dhi;
-            const int sym = o->skip_self == 2;
-            local_align2(a, alen, b, blen, cd->apos, cd->bpos, o, &la, trace, sym ? &la2 : NULL,
-                         sym ? trace2 : NULL, strand, &dlo, &dhi, &stats[3]);
+            const int sym = o->skip_self == 2, tiled = o->algo == 1;
+            /* DH-1 derives the transposed record from the same path (second trace grid); DH-2 aligns the
+             * transposed pair on its own, below, once the first record is in */
+            local_align2(a, alen, b, blen, cd->apos, cd->bpos, o, &la, trace, sym && !tiled ? &la2 : NULL,
+                         sym && !tiled ? trace2 : NULL, strand, &dlo, &dhi, &stats[3]);
             stats[2]++;
             done[nd].aseq = cd->aseq;
             done[nd].abpos = la.abpos;
@@ -1030,7 +1032,31 @@ static void align_read(const oz_index *ix, const oz_db *A, const oz_db *B, int32
             la.bread = r;
             la.flags = strand ? OZ_FLAG_COMP : 0;
             la_set_push(out, &la, trace);
-            if (sym) { /* the transposed record of the same alignment: A and B swapped */
+            if (sym && tiled) {
+                /* DH-2, symmetric: the record (b, a) is the tiled alignment of the transposed pair through the
+                 * same seed -- A'' = the read behind B on its forward strand (the trace grid of that record),
+                 * B'' = the A read, complemented when B is (then both axes are mirrored: the seed point
+                 * (as, bs) becomes (blen - bs, alen - as)).  It is accepted on its own length and error. */
+                uint8_t *a2 = (uint8_t *)malloc((size_t)blen + 1), *b2 = (uint8_t *)malloc((size_t)alen + 1);
+                if (strand) {
+                    oz_revcomp(b, blen, a2);
+                    oz_revcomp(a, alen, b2);
+                } else {
+                    memcpy(a2, b, (size_t)blen);
+                    memcpy(b2, a, (size_t)alen);
+                }
+                int32_t d2lo, d2hi;
+                local_align2(a2, blen, b2, alen, strand ? blen - cd->bpos : cd->bpos, strand ? alen - cd->apos : cd->apos,
+                             o, &la2, trace2, NULL, NULL, 0, &d2lo, &d2hi, &stats[3]);
+                free(a2);
+                free(b2);
+                if (la_accept(&la2, o)) {
+                    la2.aread = r;
+                    la2.bread = cd->aseq;
+                    la2.flags = la.flags;
+                    la_set_push(out, &la2, trace2);
+                }
+            } else if (sym) { /* the transposed record of the same alignment: A and B swapped */
                 la2.aread = r;
                 la2.bread = cd->aseq;
                 la2.flags = la.flags;

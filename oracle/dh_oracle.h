@@ -174,7 +174,8 @@ int32_t oz_consensus(const uint8_t *ref, int32_t rlen, const oz_db *reads, const
 /* ---------- `dentist collect` (spanning reads) + `dentist process` per pile-up (pile.c) ---------- */
 typedef struct {
     int32_t ts_map, allowance, min_anchor, min_reads, max_reads, ts_pile, rounds, flank_window,
-        max_align_err_ppm, max_ins_err_ppm, bad_fraction_ppm, width, dust;
+        max_align_err_ppm, max_ins_err_ppm, bad_fraction_ppm, width, dust,
+        algo; /* alignments of the process stages: 0 = DH-1 (wave, `width` live diagonals), 1 = DH-2 (tiled band of 64) */
 } oz_process_opts;
 void oz_default_process_opts(oz_process_opts *o);
 typedef struct {

@@ -331,7 +331,7 @@ static void chain_pair(oz_la *la, int64_t first, int64_t last, int32_t min_score
 /* ------------------------------------------------------------------ one pile-up ---------- */
 
 static void set_opts(oz_opts *a, int32_t tspace, int32_t min_len, int32_t skip_self, int32_t max_la,
-                     int32_t max_cand, int32_t width)
+                     int32_t max_cand, int32_t width, int32_t algo)
 {
     oz_default_opts(a);
     a->tspace = tspace;
@@ -339,7 +339,8 @@ static void set_opts(oz_opts *a, int32_t tspace, int32_t min_len, int32_t skip_s
     a->skip_self = skip_self;
     a->max_la = max_la;
     a->max_cand = max_cand;
-    a->width = width;
+    a->width = algo == 1 ? 64 : width;
+    a->algo = algo;
 }
 
 static void process_one(const oz_db *contigs, const oz_db *reads, const oz_la *las, const uint16_t *trace,
@@ -447,7 +448,7 @@ static void process_one(const oz_db *contigs, const oz_db *reads, const oz_la *l
             if (rlen[i] > maxlen) maxlen = rlen[i];
         }
         oz_opts po;
-        set_opts(&po, tsp, 500, 2, 64, 128, o->width);
+        set_opts(&po, tsp, 500, 2, 64, 128, o->width, o->algo);
         oz_la_set ps;
         oz_la_set_init(&ps);
         int64_t st[4];
@@ -507,7 +508,7 @@ static void process_one(const oz_db *contigs, const oz_db *reads, const oz_la *l
             int64_t toff[2] = {0, clen};
             oz_db tdb = {1, toff, cons, NULL, NULL, NULL};
             oz_opts ro;
-            set_opts(&ro, tsp, 500, 0, 4, 32, o->width);
+            set_opts(&ro, tsp, 500, 0, 4, 32, o->width, o->algo);
             oz_la_set rs;
             oz_la_set_init(&rs);
             oz_align_db(&tdb, &pdb, &ro, 1, &rs, st);
@@ -547,7 +548,7 @@ static void process_one(const oz_db *contigs, const oz_db *reads, const oz_la *l
         int64_t coff[2] = {0, clen};
         oz_db cdb = {1, coff, cons, NULL, NULL, NULL};
         oz_opts fo;
-        set_opts(&fo, tsp, 126, 0, 4, 32, o->width);
+        set_opts(&fo, tsp, 126, 0, 4, 32, o->width, o->algo);
         oz_la_set fs;
         oz_la_set_init(&fs);
         oz_align_db(&fdb, &cdb, &fo, 1, &fs, st);

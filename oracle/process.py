@@ -127,9 +127,15 @@ def crop_pile(entries, las, trace, contigs, reads, g, ts_map=100):
     return cropL, cropR, SeqDb.from_list(seqs), ids
 
 
-def pile_opts():
+def stage_width(algo):
+    """DH-2 (algo 1): the band of 64; DH-1: the product's default wave width."""
+    return 64 if algo == 1 else WAVE_WIDTH
+
+
+def pile_opts(algo=0):
     # skip_self = 2: every unordered pair aligned once, both records emitted (what daligner does)
-    return oz.default_opts(tspace=TS_PILE, min_len=500, skip_self=2, max_la=64, max_cand=128, width=WAVE_WIDTH)
+    return oz.default_opts(tspace=TS_PILE, min_len=500, skip_self=2, max_la=64, max_cand=128, width=stage_width(algo),
+                           algo=algo)
 
 
 def filter_pile_las(las, pile, max_err_ppm=300000, allowance=TS_PILE, proper=True):
@@ -225,7 +231,7 @@ def chain_pile_las(las, max_indel=1000, max_gap=10000, max_rel_overlap=0.3, min_
     return las
 
 
-def process_pile(entries, las, trace, contigs, reads, g, rounds=3, nthreads=1, flank_window=20000, dust=True):
+def process_pile(entries, las, trace, contigs, reads, g, rounds=3, nthreads=1, flank_window=20000, dust=True, algo=0):
     """One pile-up through the `process` sequence; returns a dict describing the insertion."""
     res = {"gap": g, "status": "ok", "nreads": len(entries)}
     crop = crop_pile(entries, las, trace, contigs, reads, g)
@@ -237,7 +243,7 @@ def process_pile(entries, las, trace, contigs, reads, g, rounds=3, nthreads=1, f
     if pile.n < 3:
         res["status"] = "pile too small"
         return res
-    o = pile_opts()
+    o = pile_opts(algo)
     if dust:   # DBdust pileup.db; daligner ... -mdust (package.d:476-482)
         pile = oz.with_dust(pile)
         res["pile"] = pile
@@ -258,7 +264,7 @@ def process_pile(entries, las, trace, contigs, reads, g, rounds=3, nthreads=1, f
     cons = oz.consensus(pile.seq(ref_idx), pile, plas, ptrace, ref_idx, TS_PILE)
     for _ in range(1, rounds):
         tdb = SeqDb.from_list([cons])
-        o2 = oz.default_opts(tspace=TS_PILE, min_len=500, max_la=4, max_cand=32, width=WAVE_WIDTH)
+        o2 = oz.default_opts(tspace=TS_PILE, min_len=500, max_la=4, max_cand=32, width=stage_width(algo), algo=algo)
         rl, rt, _ = oz.align_db(tdb, pile, o2, nthreads=nthreads)
         for la in rl:   # proper overlaps only
             if not oz.valid_pileup_alignment({**{f: la[f] for f in la.dtype.names}, "aread": -1},
@@ -273,7 +279,7 @@ def process_pile(entries, las, trace, contigs, reads, g, rounds=3, nthreads=1, f
     fdb = SeqDb.from_list([fl, fr])
     if dust:   # DBdust contigs.dam; daligner -A ... -mdust -mrep (package.d:631-667)
         fdb = oz.with_dust(fdb)
-    o3 = oz.default_opts(tspace=TS_PILE, min_len=126, max_la=4, max_cand=32, width=WAVE_WIDTH)
+    o3 = oz.default_opts(tspace=TS_PILE, min_len=126, max_la=4, max_cand=32, width=stage_width(algo), algo=algo)
     fl_las, fl_tr, _ = oz.align_db(fdb, SeqDb.from_list([cons]), o3, nthreads=nthreads)
     res.update(flank_las=fl_las, flank_trace=fl_tr, flank_off=wl)
     allow = TS_PILE

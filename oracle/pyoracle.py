@@ -253,7 +253,7 @@ def valid_pileup_alignment(la, alen, blen, allowance):
 class ProcessOpts(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "ts_map", "allowance", "min_anchor", "min_reads", "max_reads", "ts_pile", "rounds", "flank_window",
-        "max_align_err_ppm", "max_ins_err_ppm", "bad_fraction_ppm", "width", "dust")]
+        "max_align_err_ppm", "max_ins_err_ppm", "bad_fraction_ppm", "width", "dust", "algo")]
 
 
 OZ_INSERTION_DTYPE = np.dtype([(n, "<i4") for n in (

@@ -70,6 +70,12 @@ extern "C" long dh_tile_host_align(const uint8_t *abases, const int64_t *aoff, i
     P.cand = cand;
     P.ncand = ncand;
     P.queue = &queue;
+    P.units = nullptr;
+    P.nunits = nullptr;
+    std::vector<int32_t> ovf((size_t)nitems, 0);
+    std::vector<uint16_t> tscr((size_t)trmax, 0);
+    P.item_ovf = ovf.data();
+    P.tscr = tscr.data();
     P.regs = regs.data();
     P.nbmax = nbmax;
     P.trmax = trmax;
@@ -104,7 +110,7 @@ extern "C" long dh_tile_host_align(const uint8_t *abases, const int64_t *aoff, i
             tile_window(t, c, p0, p1, x);
             tile_col(t, p0, p1, x);
         }
-        tile_end(l, P, t, P.out_trace + ((int64_t)l.item * o->max_la + l.nacc) * trmax);
+        tile_end(l, P, t, lane_pairs(l, P));
     }
     if (l.err) return -(long)l.err;
     counters[0] = l.cells;

@@ -88,12 +88,26 @@ def test_blocks_and_chunks_give_the_same_bits(gpu_ctx, monkeypatch):
     assert_same_las((las4, trace4), (las, trace))
 
 
+@pytest.mark.parametrize("seed,grouped", [(21, False), (57, True), (33, True)])
+def test_symmetric_all_vs_all(gpu_ctx, seed, grouped):
+    """skip_self = 2 (daligner -s126 pile x pile, processPileUps/package.d:478-482): every unordered pair
+    seeded once, DH-2 aligns the pair and the transposed pair through the same seed; both records."""
+    g = sim.genome(seed, 20000)
+    reads, _ = sim.reads(seed + 1, g, 30, 6000)
+    if grouped:
+        reads = sim.SeqDb(reads.bases, reads.off, group=np.arange(reads.n) % 3)
+    las, trace = run_both(gpu_ctx, reads, reads, same=True, tspace=126, skip_self=2, min_len=500, max_la=64, max_cand=128, **T)
+    assert len(las) > reads.n and not np.any(las["aread"] == las["bread"])
+    key = set(zip(las["aread"].tolist(), las["bread"].tolist(), (las["flags"] & 1).tolist()))
+    assert all((b, a, c) in key for a, b, c in key)
+
+
 def test_rejections(gpu_ctx):
-    """DH-2 has no symmetric mode, one band width, tiles of at most 128 columns, 2-bit sequences only."""
+    """DH-2 has one band width, tiles of at most 128 columns, 2-bit sequences only."""
     rng = np.random.default_rng(5)
     g = rng.integers(0, 4, 4000).astype(np.uint8)
     db = gpu_ctx.db(sim.SeqDb.from_list([g, g[100:3000]]))
-    for kw in (dict(width=30), dict(skip_self=2), dict(tspace=200)):
+    for kw in (dict(width=30), dict(tspace=200)):
         with pytest.raises(dentist_amd.DhError):
             gpu_ctx.align_db(db, db, dentist_amd.default_align_opts(**{**T, **kw}))
     gn = g.copy()

@@ -83,3 +83,25 @@ def test_short_and_ragged_inputs(host_lib):
     assert len(exp_las) >= 8
     assert_same_las((las, trace), (exp_las, exp_trace))
     check_trace_invariants(las, trace, 100)
+
+
+@pytest.mark.parametrize("seed,grouped", [(21, False), (57, True)])
+def test_symmetric_all_vs_all(host_lib, seed, grouped):
+    """skip_self = 2 (the pile-up stage, daligner -s126 pile x pile): every unordered pair is seeded once;
+    DH-2 then aligns the pair and, for the second record, the transposed pair through the same seed (trace
+    on the other read's grid, both axes mirrored for complemented overlaps).  Records land in slots claimed
+    at acceptance, so only their set is compared."""
+    from helpers import la_rows
+    g = sim.genome(seed, 20000)
+    reads, _ = sim.reads(seed + 1, g, 30, 6000)
+    if grouped:
+        reads = sim.SeqDb(reads.bases, reads.off, group=np.arange(reads.n) % 2)
+    o = oz.default_opts(algo=1, width=64, tspace=126, skip_self=2, min_len=500, max_la=64, max_cand=128)
+    exp_las, exp_trace, stats = oz.align_db(reads, reads, o, nthreads=4, sort=False)
+    las, trace, counters = run_host(host_lib, reads, reads, o)
+    assert len(exp_las) > reads.n
+    assert sorted(la_rows(las, trace)) == sorted(la_rows(exp_las, exp_trace))
+    check_trace_invariants(las, trace, 126)
+    assert int(counters[0]) == stats[3] and int(counters[1]) == stats[2]
+    comp = las[(las["flags"] & 1) != 0]
+    assert len(comp) > 0 and len(las) % 2 == 0
