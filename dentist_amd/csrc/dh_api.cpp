@@ -1175,6 +1175,8 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     uint16_t *d_tscr = nullptr;
     if (tiled) SCR(32, d_regs, (size_t)tile_waves * 64 * dhtile::MAXREG * dhtile::REGF)
     if (tiled && o.skip_self == 2) SCR(33, d_tscr, (size_t)tile_waves * 64 * trmax)
+    dhtile::Cold *d_cold = nullptr;
+    if (tiled) SCR(34, d_cold, (size_t)tile_waves * 64)
     HIPCHK(hipMemsetAsync(d_status, 0, sizeof(int32_t), st));
     HIPCHK(hipMemsetAsync(d_counters, 0, 2 * sizeof(unsigned long long), st));
 
@@ -1321,6 +1323,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             tp.item_ovf = d_ovf - item0;
             tp.tscr = d_tscr;
             tp.regs = d_regs;
+            tp.cold = d_cold;
             tp.nbmax = nbmax;
             tp.trmax = trmax;
             tp.out_la = labase;

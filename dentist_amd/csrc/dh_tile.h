@@ -39,6 +39,8 @@ struct PlanePair {  // 32 bases of a plane-packed copy: bit g & 31 of .x / .y = 
     uint32_t x, y;
 };
 
+struct Cold;
+
 struct Params {
     const int64_t *aoff, *boff;       // offsets of the A / B sequences (bases)
     const uint32_t *apk, *arcpk;      // 2-bit packed A, forward / reverse complement: base g in dword g >> 4, bits 2 (g & 15)
@@ -53,6 +55,7 @@ struct Params {
     int32_t *item_ovf;                // symmetric mode: per item (absolute), set when a record was dropped for want of slots
     uint16_t *tscr;                   // symmetric mode: nlanes * trmax, the trace pairs of the alignment in flight
     int32_t *regs;                    // nlanes * MAXREG * REGF
+    Cold *cold;                       // nlanes: the lanes' cold state
     int32_t nbmax, trmax;             // pairs a direction can yield; u16 values per output slot (>= 2 * (2 * nbmax + 2))
     DhLa *out_la;                     // max_la records per item (absolute item index)
     uint16_t *out_trace;              // trmax values per record slot
@@ -61,27 +64,27 @@ struct Params {
     int32_t *status;
 };
 
-// one running extension
+// one running extension (registers)
 struct Ext {
     int64_t ga, gb;           // absolute base index of A'[0] / B'[0] in the copies of this direction
-    const uint32_t *apk;
-    const PlanePair *bpp;
+    int32_t src;              // bit 0: A' from the reverse-complement copy, bit 1: B' from the reverse-complement copy
     int32_t an, bn, tp_first;
     int32_t a0, b0, dsum, ntp;
     int32_t best_s, best_a, best_b, best_d, best_nseg;  // best end so far; nseg = trace segments up to it
     int32_t klo, khi, bklo, bkhi;                       // diagonal excursion: path so far / up to the best end
     uint32_t pair1, best_pair1;                         // first segment (diffs << 16 | bbases): as computed / of the best end
+    uint16_t *pairs;                                    // where the trace pairs of the alignment in flight go
 };
 
-struct Lane {
-    int32_t st;
+// what a lane touches only between extensions (next candidate, end of an extension, records): it lives
+// in memory -- one record per lane slot -- so that the tile loop keeps its registers
+struct Cold {
     // item
     int32_t item, strand, nc, c, blen, nd, nacc, ntr;
     int64_t bo;
     // candidate
-    int32_t c_aseq, as, bs, alen, roff;
+    int32_t c_aseq, as, bs, alen;
     int64_t ao;
-    int32_t dir;  // 1 = reverse extension (runs first), 0 = forward
     // the alignment in flight: mode 0 = the candidate as seeded, 1 = the transposed pair (symmetric mode);
     // g_*: its A / B sequences (offset, length) and seed point
     int32_t mode, g_alen, g_as, g_blen, g_bs;
@@ -89,20 +92,31 @@ struct Lane {
     // result of the reverse extension
     int32_t rv_i, rv_j, rv_d, rv_nseg, rv_klo, rv_khi;
     uint32_t rv_pair1;
-    Ext e;
-    uint64_t cells;
-    uint32_t naln;
+    int32_t pad_;
+};
+
+struct Lane {
+    int32_t st;
+    int32_t dir;   // 1 = reverse extension (runs first), 0 = forward
+    int32_t roff;  // 1: the seed is not on a trace boundary (the two first tiles share a trace interval)
     int32_t slot;  // lane slot (scratch index)
     int32_t err;
+    uint32_t naln;
+    uint64_t cells;
+    Ext e;
+    Cold *c;
 };
 
 // the tile in flight
 struct Tile {
     uint64_t Pv, Mv, lv, wild;
     int32_t z, dbot, cols, bnr, T;
-    uint32_t q0[NQ], q1[NQ];  // plane windows: bit x of the 224-bit string = B'[b0 - 32 + x]
-    uint32_t aw[NAW - 1];     // A'[a0 + x] at bits 2x of the 256-bit string
 };
+// the sequence words of a tile, NTW dwords per lane (registers on the host, LDS on the device):
+//   [0, NQ)        low-bit plane of B': bit x of the 224-bit string = B'[b0 - 32 + x]
+//   [NQ, 2 NQ)     high-bit plane
+//   [2 NQ, NTW)    A'[a0 + x] at bits 2x of the 256-bit string
+constexpr int NTW = 2 * NQ + NAW - 1;
 
 DH_HD uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t sh)  // ({hi, lo} >> sh)[31:0], sh in [0, 31]
 {
@@ -117,28 +131,31 @@ DH_HD int32_t nbound(int32_t x, int32_t first, int32_t ts) { return x >= first ?
 
 // ------------------------------------------------------------------------------ extension
 
+DH_HD uint16_t *lane_pairs(const Lane &l, const Params &P);
+
 DH_HD void ext_begin(Lane &l, const Params &P, int32_t dir)
 {
     Ext &e = l.e;
+    const Cold &c = *l.c;
     l.dir = dir;
-    const int32_t ts = P.o.tspace, as = l.g_as, bs = l.g_bs;
+    const int32_t ts = P.o.tspace, as = c.g_as, bs = c.g_bs;
     // the reverse extension is a forward extension over the reverse-complemented copies
-    e.ga = l.g_ao + (dir ? l.g_alen - as : as);
-    e.gb = l.g_bo + (dir ? l.g_blen - bs : bs);
-    e.an = dir ? as : l.g_alen - as;
-    e.bn = dir ? bs : l.g_blen - bs;
-    const bool brc_side = (l.strand != 0) != (dir != 0);
-    e.apk = dir ? P.arcpk : P.apk;
-    e.bpp = brc_side ? P.brcpp : P.bpp;
+    e.ga = c.g_ao + (dir ? c.g_alen - as : as);
+    e.gb = c.g_bo + (dir ? c.g_blen - bs : bs);
+    e.an = dir ? as : c.g_alen - as;
+    e.bn = dir ? bs : c.g_blen - bs;
+    const bool brc_side = (c.strand != 0) != (dir != 0);
+    e.src = (dir ? 1 : 0) | (brc_side ? 2 : 0);
     e.tp_first = dir ? ((as % ts) ? (as % ts) : ts) : ts - (as % ts);
     e.a0 = e.b0 = e.dsum = e.ntp = 0;
     e.best_s = e.best_a = e.best_b = e.best_d = e.best_nseg = 0;
     e.klo = e.khi = e.bklo = e.bkhi = 0;
     e.pair1 = e.best_pair1 = 0;
+    e.pairs = lane_pairs(l, P);
     l.st = (e.an > 0 && e.bn > 0) ? L_RUN : L_EXT_END;
 }
 
-DH_HD void tile_setup(const Lane &l, const Params &P, Tile &t)
+DH_HD void tile_setup(const Lane &l, const Params &P, Tile &t, uint32_t *q)
 {
     const Ext &e = l.e;
     t.T = e.ntp == 0 ? e.tp_first : P.o.tspace;
@@ -156,27 +173,27 @@ DH_HD void tile_setup(const Lane &l, const Params &P, Tile &t)
     // B planes: bit x of the window string = base (gb + b0 - W/2 + x)
     {
         const int64_t g = e.gb + e.b0 - W / 2;
-        const PlanePair *p = e.bpp + (g >> 5);
+        const PlanePair *p = ((e.src & 2) ? P.brcpp : P.bpp) + (g >> 5);
         const uint32_t s = (uint32_t)(g & 31);
         PlanePair r[NQ + 1];
 #pragma unroll
         for (int i = 0; i <= NQ; i++) r[i] = p[i];
 #pragma unroll
         for (int i = 0; i < NQ; i++) {
-            t.q0[i] = funnel(r[i + 1].x, r[i].x, s);
-            t.q1[i] = funnel(r[i + 1].y, r[i].y, s);
+            q[i] = funnel(r[i + 1].x, r[i].x, s);
+            q[NQ + i] = funnel(r[i + 1].y, r[i].y, s);
         }
     }
     // A: base x of the tile = base (ga + a0 + x)
     {
         const int64_t g = e.ga + e.a0;
-        const uint32_t *p = e.apk + (g >> 4);
+        const uint32_t *p = ((e.src & 1) ? P.arcpk : P.apk) + (g >> 4);
         const uint32_t s = (uint32_t)(g & 15) << 1;
         uint32_t r[NAW];
 #pragma unroll
         for (int i = 0; i < NAW; i++) r[i] = p[i];
 #pragma unroll
-        for (int i = 0; i < NAW - 1; i++) t.aw[i] = funnel(r[i + 1], r[i], s);
+        for (int i = 0; i < NAW - 1; i++) q[2 * NQ + i] = funnel(r[i + 1], r[i], s);
     }
 }
 
@@ -200,13 +217,14 @@ DH_HD void tile_col(Tile &t, uint64_t p0, uint64_t p1, uint32_t x)
 }
 
 // the columns of a tile in sequence (host; the device kernel runs the same steps in lock step)
-DH_HD void tile_window(const Tile &t, int32_t c, uint64_t &p0, uint64_t &p1, uint32_t &x)
+DH_HD void tile_window(const uint32_t *q, int32_t c, uint64_t &p0, uint64_t &p1, uint32_t &x)
 {
     const int32_t cm = c - 1, k = cm >> 5;
     const uint32_t sh = (uint32_t)(cm & 31);
-    p0 = (uint64_t)funnel(t.q0[k + 1], t.q0[k], sh) | ((uint64_t)funnel(t.q0[k + 2], t.q0[k + 1], sh) << 32);
-    p1 = (uint64_t)funnel(t.q1[k + 1], t.q1[k], sh) | ((uint64_t)funnel(t.q1[k + 2], t.q1[k + 1], sh) << 32);
-    x = (t.aw[cm >> 4] >> ((cm & 15) << 1)) & 3u;
+    const uint32_t *q0 = q, *q1 = q + NQ, *aw = q + 2 * NQ;
+    p0 = (uint64_t)funnel(q0[k + 1], q0[k], sh) | ((uint64_t)funnel(q0[k + 2], q0[k + 1], sh) << 32);
+    p1 = (uint64_t)funnel(q1[k + 1], q1[k], sh) | ((uint64_t)funnel(q1[k + 2], q1[k + 1], sh) << 32);
+    x = (aw[cm >> 4] >> ((cm & 15) << 1)) & 3u;
 }
 
 // the last column: the row to go on from / to end at.  Returns the key (D << 16 | |row - diagonal| << 8 | W-1-i)
@@ -216,7 +234,7 @@ DH_HD uint32_t tile_scan(const Tile &t)
     const int32_t imin = W / 2 - t.cols, imax = t.bnr + W / 2;
     uint32_t key = 0xFFFFFFFFu;
     int32_t d = t.dbot;
-#pragma unroll
+#pragma unroll 8
     for (int i = W - 1; i >= 0; i--) {
         if (i < W - 1) d += (int32_t)((t.Mv >> i) & 1u) - (int32_t)((t.Pv >> i) & 1u);
         const uint32_t off = (uint32_t)(i >= W / 2 ? i - W / 2 : W / 2 - i);
@@ -227,10 +245,11 @@ DH_HD uint32_t tile_scan(const Tile &t)
     return key;
 }
 
-// a tile is done: trace pair, next origin or end of the extension.  `pairs` = trace slot of the candidate
-DH_HD void tile_end(Lane &l, const Params &P, const Tile &t, uint16_t *pairs)
+// a tile is done: trace pair, next origin or end of the extension
+DH_HD void tile_end(Lane &l, const Params &P, const Tile &t)
 {
     Ext &e = l.e;
+    uint16_t *pairs = e.pairs;
     const int32_t ts = P.o.tspace, pen = P.o.pen, nbmax = P.nbmax;
     l.cells += (uint64_t)t.cols * W;
     const uint32_t key = tile_scan(t);
@@ -314,23 +333,17 @@ static inline int32_t dh_host_fetch_add(int32_t *p, int32_t v)
 #define DH_ATOMIC_ADD(p, v) dh_host_fetch_add((p), (v))
 #endif
 
-DH_HD void lane_init(Lane &l, int32_t slot)
+DH_HD void lane_init(Lane &l, int32_t slot, Cold *cold)
 {
     l.st = L_FETCH;
     l.cells = 0;
     l.naln = 0;
     l.slot = slot;
     l.err = 0;
-    l.item = l.strand = l.nc = l.c = l.blen = l.nd = l.nacc = l.ntr = 0;
-    l.bo = 0;
-    l.c_aseq = l.as = l.bs = l.alen = l.roff = 0;
-    l.ao = 0;
     l.dir = 0;
-    l.mode = 0;
-    l.g_ao = l.g_bo = 0;
-    l.g_alen = l.g_as = l.g_blen = l.g_bs = 0;
-    l.rv_i = l.rv_j = l.rv_d = l.rv_nseg = l.rv_klo = l.rv_khi = 0;
-    l.rv_pair1 = 0;
+    l.roff = 0;
+    l.c = cold;
+    l.e.pairs = nullptr;
 }
 
 // where the trace pairs of the running candidate go: straight into its output slot, or -- symmetric
@@ -338,7 +351,7 @@ DH_HD void lane_init(Lane &l, int32_t slot)
 DH_HD uint16_t *lane_pairs(const Lane &l, const Params &P)
 {
     if (P.o.skip_self == 2) return P.tscr + (int64_t)l.slot * P.trmax;
-    return P.out_trace + ((int64_t)l.item * P.o.max_la + l.nacc) * P.trmax;
+    return P.out_trace + ((int64_t)l.c->item * P.o.max_la + l.c->nacc) * P.trmax;
 }
 
 // geometry of the alignment to run for the current candidate.  mode 0: A = the candidate's A sequence,
@@ -347,28 +360,30 @@ DH_HD uint16_t *lane_pairs(const Lane &l, const Params &P)
 // sequence, complemented when the item is (both axes mirrored then)
 DH_HD void cand_geometry(Lane &l, const Params &P, int32_t mode)
 {
-    l.mode = mode;
+    Cold &c = *l.c;
+    c.mode = mode;
     if (!mode) {
-        l.g_ao = l.ao;
-        l.g_alen = l.alen;
-        l.g_as = l.as;
-        l.g_bo = l.bo;
-        l.g_blen = l.blen;
-        l.g_bs = l.bs;
+        c.g_ao = c.ao;
+        c.g_alen = c.alen;
+        c.g_as = c.as;
+        c.g_bo = c.bo;
+        c.g_blen = c.blen;
+        c.g_bs = c.bs;
     } else {
-        l.g_ao = l.bo;
-        l.g_alen = l.blen;
-        l.g_as = l.strand ? l.blen - l.bs : l.bs;
-        l.g_bo = l.ao;
-        l.g_blen = l.alen;
-        l.g_bs = l.strand ? l.alen - l.as : l.as;
+        c.g_ao = c.bo;
+        c.g_alen = c.blen;
+        c.g_as = c.strand ? c.blen - c.bs : c.bs;
+        c.g_bo = c.ao;
+        c.g_blen = c.alen;
+        c.g_bs = c.strand ? c.alen - c.as : c.as;
     }
-    l.roff = (l.g_as % P.o.tspace) != 0 ? 1 : 0;
+    l.roff = (c.g_as % P.o.tspace) != 0 ? 1 : 0;
 }
 
 // `it` = work unit index: an item, or (P.units) one group of candidates of an item
 DH_HD void lane_fetch(Lane &l, const Params &P, int32_t it)
 {
+    Cold &c = *l.c;
     int32_t ui = it, c0 = 0, c1 = 0x7FFFFFFF;
     if (P.units) {
         const int4 u = P.units[it];
@@ -377,49 +392,54 @@ DH_HD void lane_fetch(Lane &l, const Params &P, int32_t it)
         c1 = u.z;
     }
     const int32_t item = P.item0 + ui;
-    l.item = item;
-    l.strand = item & 1;
+    c.item = item;
+    c.strand = item & 1;
     const int32_t nc = P.ncand[item];
-    l.nc = nc > 0 ? (nc < c1 ? nc : c1) : 0;
+    c.nc = nc > 0 ? (nc < c1 ? nc : c1) : 0;
     const int64_t bo = P.boff[item >> 1];
-    l.bo = bo;
-    l.blen = (int32_t)(P.boff[(item >> 1) + 1] - bo);
-    l.nd = l.nacc = l.ntr = 0;
-    l.c = c0;
+    c.bo = bo;
+    c.blen = (int32_t)(P.boff[(item >> 1) + 1] - bo);
+    c.nd = c.nacc = c.ntr = 0;
+    c.c = c0;
     l.st = L_CAND;
 }
 
 // next candidate of the item that no aligned region covers -> its reverse extension; none -> item done
 DH_HD void lane_next_cand(Lane &l, const Params &P)
 {
+    Cold &c = *l.c;
     const int32_t *rg = P.regs + (int64_t)l.slot * MAXREG * REGF;
     const bool sym = P.o.skip_self == 2;
-    while (l.c < l.nc && (sym || l.nacc < P.o.max_la) && l.nd < MAXREG) {
-        const DhCand cd = P.cand[(int64_t)l.item * P.o.max_cand + l.c];
+    int32_t ci = c.c;
+    const int32_t nc = c.nc, nd = c.nd, item = c.item;
+    while (ci < nc && (sym || c.nacc < P.o.max_la) && nd < MAXREG) {
+        const DhCand cd = P.cand[(int64_t)item * P.o.max_cand + ci];
         const int32_t sdc = cd.apos - cd.bpos;
         bool covd = false;
-        for (int32_t x = 0; x < l.nd; x++) {
+        for (int32_t x = 0; x < nd; x++) {
             const int32_t *g = rg + x * REGF;
             covd = covd || (g[0] == cd.aseq && cd.apos >= g[1] && cd.apos < g[2] && cd.bpos >= g[3] && cd.bpos < g[4] &&
                             sdc >= g[5] - 64 && sdc <= g[6] + 64);
         }
         if (covd) {
-            l.c++;
+            ci++;
             continue;
         }
-        l.c_aseq = cd.aseq;
-        l.as = cd.apos;
-        l.bs = cd.bpos;
+        c.c = ci;
+        c.c_aseq = cd.aseq;
+        c.as = cd.apos;
+        c.bs = cd.bpos;
         const int64_t ao = P.aoff[cd.aseq];
-        l.ao = ao;
-        l.alen = (int32_t)(P.aoff[cd.aseq + 1] - ao);
+        c.ao = ao;
+        c.alen = (int32_t)(P.aoff[cd.aseq + 1] - ao);
         cand_geometry(l, P, 0);
         ext_begin(l, P, 1);
         return;
     }
+    c.c = ci;
     if (!sym) {
-        P.out_nla[l.item] = l.nacc;
-        P.out_ntr[l.item] = l.ntr;
+        P.out_nla[item] = c.nacc;
+        P.out_ntr[item] = c.ntr;
     }
     l.st = L_FETCH;
 }
@@ -429,18 +449,19 @@ DH_HD void lane_next_cand(Lane &l, const Params &P)
 DH_HD int32_t finish_pairs(const Lane &l, const Params &P, uint16_t *pairs, int32_t *first_out)
 {
     const Ext &e = l.e;
-    const int32_t nbmax = P.nbmax, nr = l.rv_nseg, nf = e.best_nseg;
+    const Cold &c = *l.c;
+    const int32_t nbmax = P.nbmax, nr = c.rv_nseg, nf = e.best_nseg;
     // the pair of the seed's interval: the forward tile 1 plus, when the seed is not on a boundary,
     // the reverse tile 1 (the two are the halves of one trace interval)
-    const uint32_t seedp = (nf >= 1 ? e.best_pair1 : 0u) + ((l.roff && nr >= 1) ? l.rv_pair1 : 0u);
+    const uint32_t seedp = (nf >= 1 ? e.best_pair1 : 0u) + ((l.roff && nr >= 1) ? c.rv_pair1 : 0u);
     const bool seedslot = nf >= 1 || (l.roff && nr >= 1);
     if (seedslot) {
         pairs[2 * nbmax] = (uint16_t)(seedp >> 16);
         pairs[2 * nbmax + 1] = (uint16_t)(seedp & 0xFFFFu);
     }
     if (!l.roff && nr >= 1) {  // the reverse tile 1 is an interval of its own
-        pairs[2 * (nbmax - 1)] = (uint16_t)(l.rv_pair1 >> 16);
-        pairs[2 * (nbmax - 1) + 1] = (uint16_t)(l.rv_pair1 & 0xFFFFu);
+        pairs[2 * (nbmax - 1)] = (uint16_t)(c.rv_pair1 >> 16);
+        pairs[2 * (nbmax - 1) + 1] = (uint16_t)(c.rv_pair1 & 0xFFFFu);
     }
     const int32_t lo_idx = nbmax - nr + l.roff;
     const int32_t hi_idx = nbmax + (nf > (seedslot ? 1 : 0) ? nf : (seedslot ? 1 : 0));
@@ -450,8 +471,8 @@ DH_HD int32_t finish_pairs(const Lane &l, const Params &P, uint16_t *pairs, int3
 }
 
 // symmetric mode: claim a record slot of item `it` and move the pairs from the lane's scratch into it
-DH_HD void emit_claimed(Lane &l, const Params &P, int32_t it, int32_t other_item, DhLa la, const uint16_t *pairs,
-                        int32_t first, int32_t npairs)
+DH_HD void emit_claimed(const Params &P, int32_t it, int32_t other_item, DhLa la, const uint16_t *pairs, int32_t first,
+                        int32_t npairs)
 {
     const int32_t s = DH_ATOMIC_ADD(&P.out_nla[it], 1);
     if (s >= P.o.max_la) {
@@ -475,44 +496,46 @@ DH_HD void emit_claimed(Lane &l, const Params &P, int32_t it, int32_t other_item
 DH_HD void lane_ext_end(Lane &l, const Params &P)
 {
     Ext &e = l.e;
+    Cold &c = *l.c;
     if (l.err) {
         l.st = L_DONE;
         return;
     }
     if (l.dir == 1) {
-        l.rv_i = e.best_a;
-        l.rv_j = e.best_b;
-        l.rv_d = e.best_d;
-        l.rv_nseg = e.best_nseg;
-        l.rv_klo = e.bklo;
-        l.rv_khi = e.bkhi;
-        l.rv_pair1 = e.best_pair1;
+        c.rv_i = e.best_a;
+        c.rv_j = e.best_b;
+        c.rv_d = e.best_d;
+        c.rv_nseg = e.best_nseg;
+        c.rv_klo = e.bklo;
+        c.rv_khi = e.bkhi;
+        c.rv_pair1 = e.best_pair1;
         ext_begin(l, P, 0);
         return;
     }
     const bool sym = P.o.skip_self == 2;
-    const int32_t as = l.g_as, bs = l.g_bs, sd = as - bs;
-    const int32_t abpos = as - l.rv_i, bbpos = bs - l.rv_j, aepos = as + e.best_a, bepos = bs + e.best_b;
-    const int32_t diffs = l.rv_d + e.best_d;
-    if (l.mode == 0) {
+    const int32_t mode = c.mode, item = c.item, c_aseq = c.c_aseq, strand = c.strand;
+    const int32_t as = c.g_as, bs = c.g_bs, sd = as - bs;
+    const int32_t abpos = as - c.rv_i, bbpos = bs - c.rv_j, aepos = as + e.best_a, bepos = bs + e.best_b;
+    const int32_t diffs = c.rv_d + e.best_d;
+    if (mode == 0) {
         l.naln += 1;
         int32_t lo = sd + e.bklo, hi = sd + e.bkhi;
-        lo = (sd - l.rv_khi) < lo ? (sd - l.rv_khi) : lo;
-        hi = (sd - l.rv_klo) > hi ? (sd - l.rv_klo) : hi;
-        int32_t *g = P.regs + ((int64_t)l.slot * MAXREG + l.nd) * REGF;
-        g[0] = l.c_aseq;
+        lo = (sd - c.rv_khi) < lo ? (sd - c.rv_khi) : lo;
+        hi = (sd - c.rv_klo) > hi ? (sd - c.rv_klo) : hi;
+        int32_t *g = P.regs + ((int64_t)l.slot * MAXREG + c.nd) * REGF;
+        g[0] = c_aseq;
         g[1] = abpos;
         g[2] = aepos;
         g[3] = bbpos;
         g[4] = bepos;
         g[5] = lo;
         g[6] = hi;
-        l.nd += 1;
+        c.nd += 1;
     }
     const int64_t al = aepos - abpos, bl = bepos - bbpos;
     const bool accept = al >= P.o.min_len && (int64_t)2 * diffs * 1000000ll <= (int64_t)P.o.max_err_ppm * (al + bl);
     if (accept) {
-        uint16_t *pairs = lane_pairs(l, P);
+        uint16_t *pairs = e.pairs;
         int32_t first;
         const int32_t npairs = finish_pairs(l, P, pairs, &first);
         DhLa la;
@@ -522,26 +545,26 @@ DH_HD void lane_ext_end(Lane &l, const Params &P)
         la.bbpos = bbpos;
         la.aepos = aepos;
         la.bepos = bepos;
-        la.flags = l.strand ? 1u : 0u;
-        la.aread = l.mode ? (l.item >> 1) : l.c_aseq;
-        la.bread = l.mode ? l.c_aseq : (l.item >> 1);
+        la.flags = strand ? 1u : 0u;
+        la.aread = mode ? (item >> 1) : c_aseq;
+        la.bread = mode ? c_aseq : (item >> 1);
         la.pad = 0;
         la.toff = 2 * (int64_t)first;  // where the pairs start inside the slot (k_compact honours it)
         if (!sym) {
-            P.out_la[(int64_t)l.item * P.o.max_la + l.nacc] = la;
-            l.ntr += 2 * npairs;
+            P.out_la[(int64_t)item * P.o.max_la + c.nacc] = la;
+            c.ntr += 2 * npairs;
         } else {
-            const int32_t item_a = 2 * l.c_aseq + l.strand;
-            emit_claimed(l, P, l.mode ? l.item : item_a, l.mode ? item_a : l.item, la, pairs, first, npairs);
+            const int32_t item_a = 2 * c_aseq + strand;
+            emit_claimed(P, mode ? item : item_a, mode ? item_a : item, la, pairs, first, npairs);
         }
-        if (l.mode == 0) l.nacc += 1;
-        if (sym && l.mode == 0) {  // the second record: the transposed pair, aligned on its own
+        if (mode == 0) c.nacc += 1;
+        if (sym && mode == 0) {  // the second record: the transposed pair, aligned on its own
             cand_geometry(l, P, 1);
             ext_begin(l, P, 1);
             return;
         }
     }
-    l.c += 1;
+    c.c += 1;
     l.st = L_CAND;
 }
 

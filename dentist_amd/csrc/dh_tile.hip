@@ -31,8 +31,10 @@ __device__ __forceinline__ int32_t wave_max_i32(int32_t v)
 
 __global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
 {
+    __shared__ uint32_t s_q[NTW][64];
     Lane l;
-    lane_init(l, (int32_t)(blockIdx.x * 64 + threadIdx.x));
+    const int32_t slot = (int32_t)(blockIdx.x * 64 + threadIdx.x);
+    lane_init(l, slot, P.cold + slot);
     Tile t;
     for (;;) {
         // ---- bookkeeping until every lane extends or is out of work
@@ -51,16 +53,19 @@ __global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
         }
         const bool run = l.st == L_RUN;
         if (!wave_any(run)) break;
-        // ---- one tile of every extending lane
-        if (run) tile_setup(l, P, t);
-        const int32_t cmax = wave_max_i32(run ? t.cols : 0);
+        // ---- one tile of every extending lane.  Its sequence words go to LDS, [word][lane]: the column loop
+        // keeps three words of either plane and two of A in registers per block of 32 columns
+        if (run) {
+            uint32_t q[NTW];
+            tile_setup(l, P, t, q);
 #pragma unroll
-        for (int blk = 0; blk < TS_MAX / 32; blk++) {
-            if (32 * blk >= cmax) break;
-            // the registers this block of 32 columns cuts its windows from
-            const uint32_t a0 = t.q0[blk], a1 = t.q0[blk + 1], a2 = t.q0[blk + 2];
-            const uint32_t b0 = t.q1[blk], b1 = t.q1[blk + 1], b2 = t.q1[blk + 2];
-            const uint64_t ab = (uint64_t)t.aw[2 * blk] | ((uint64_t)t.aw[2 * blk + 1] << 32);
+            for (int i = 0; i < NTW; i++) s_q[i][threadIdx.x] = q[i];
+        }
+        const int32_t cmax = wave_max_i32(run ? t.cols : 0);
+        for (int32_t blk = 0; 32 * blk < cmax; blk++) {
+            const uint32_t a0 = s_q[blk][threadIdx.x], a1 = s_q[blk + 1][threadIdx.x], a2 = s_q[blk + 2][threadIdx.x];
+            const uint32_t b0 = s_q[NQ + blk][threadIdx.x], b1 = s_q[NQ + blk + 1][threadIdx.x], b2 = s_q[NQ + blk + 2][threadIdx.x];
+            const uint64_t ab = (uint64_t)s_q[2 * NQ + 2 * blk][threadIdx.x] | ((uint64_t)s_q[2 * NQ + 2 * blk + 1][threadIdx.x] << 32);
             const int32_t nsh = cmax - 32 * blk < 32 ? cmax - 32 * blk : 32;
             for (int32_t sh = 0; sh < nsh; sh++) {
                 const int32_t c = 32 * blk + sh + 1;
@@ -72,7 +77,7 @@ __global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
                 }
             }
         }
-        if (run) tile_end(l, P, t, lane_pairs(l, P));
+        if (run) tile_end(l, P, t);
     }
     if (l.cells) atomicAdd(&P.counters[0], (unsigned long long)l.cells);
     if (l.naln) atomicAdd(&P.counters[1], (unsigned long long)l.naln);
@@ -105,7 +110,9 @@ void dhk_tile(hipStream_t st, int32_t nwaves, const Params *P)
     if (P->nitems <= 0 || nwaves <= 0) return;
     hipLaunchKernelGGL(k_tile, dim3(nwaves), dim3(64), 0, st, *P);
 }
-int32_t dhk_tile_waves_per_cu(void) { return 4 * TILE_WAVES_PER_SIMD; }
+// resident wavefronts per CU the host launches: 12 of the 16 the registers allow measured best on configs[2]
+// (mapping pass 31.3 ms against 33.6 with 16: fewer lanes share the queue's tail and the caches)
+int32_t dhk_tile_waves_per_cu(void) { return 12; }
 void dhk_pk2planes(hipStream_t st, void *words, int64_t nwords)
 {
     if (nwords <= 0) return;

@@ -86,7 +86,10 @@ extern "C" long dh_tile_host_align(const uint8_t *abases, const int64_t *aoff, i
     P.counters = counters;
     P.status = &status;
     Lane l;
-    lane_init(l, 0);
+    Cold cold;
+    memset(&cold, 0, sizeof(cold));
+    P.cold = &cold;
+    lane_init(l, 0, &cold);
     Tile t;
     for (;;) {
         while (l.st != L_RUN && l.st != L_DONE) {
@@ -103,14 +106,15 @@ extern "C" long dh_tile_host_align(const uint8_t *abases, const int64_t *aoff, i
             }
         }
         if (l.st == L_DONE) break;
-        tile_setup(l, P, t);
+        uint32_t q[NTW];
+        tile_setup(l, P, t, q);
         for (int32_t c = 1; c <= t.cols; c++) {
             uint64_t p0, p1;
             uint32_t x;
-            tile_window(t, c, p0, p1, x);
+            tile_window(q, c, p0, p1, x);
             tile_col(t, p0, p1, x);
         }
-        tile_end(l, P, t, lane_pairs(l, P));
+        tile_end(l, P, t);
     }
     if (l.err) return -(long)l.err;
     counters[0] = l.cells;
