@@ -86,7 +86,8 @@ SYMBOLS = [
     "dh_insertions_write_db", "dh_pileups_write_db", "dh_pileups_flat", "dh_collect_filter",
     "dh_map_reads", "dh_validate_regions", "dh_propagate_mask", "dh_db_mask_coverage", "dh_max_coverage_reads", "dh_max_improper_coverage_reads",
     "dh_default_scaffold_opts", "dh_scaffold_pileups", "dh_scaffold_npiles", "dh_scaffold_nentries", "dh_scaffold_joins",
-    "dh_scaffold_entries", "dh_scaffold_destroy", "dh_scaffold_spanning",
+    "dh_scaffold_entries", "dh_scaffold_destroy", "dh_scaffold_spanning", "dh_scaffold_gap_pileups", "dh_cropped_create2",
+    "dh_cropped_kind",
 ]
 
 _LIB = None
@@ -147,6 +148,9 @@ def lib():
     L.dh_process_pileups.argtypes = [vp, vp, vp, vp, i64, vp, vp, ctypes.POINTER(ProcessOpts), ctypes.POINTER(vp)]
     L.dh_crop_pileups.argtypes = [vp, vp, vp, i32, vp, i64, vp, vp, ctypes.POINTER(ProcessOpts), ctypes.POINTER(vp)]
     L.dh_cropped_create.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, ctypes.POINTER(vp)]
+    L.dh_cropped_create2.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, ctypes.POINTER(vp)]
+    L.dh_cropped_kind.argtypes = [vp]
+    L.dh_cropped_kind.restype = vp
     L.dh_cropped_destroy.argtypes = [vp]
     for fn in (L.dh_cropped_npiles, L.dh_cropped_nreads):
         fn.argtypes = [vp]
@@ -696,17 +700,21 @@ def scaffold_pileups(las, contig_off, read_off, input_gaps=None, **opts):
     return joins, ent
 
 
-def scaffold_spanning_pileups(las, contig_off, read_off, input_gaps=None, **opts):
-    """The pile-ups of the scaffold graph that dh_process_pileups handles (dh_scaffold_spanning):
-    returns (Pileups, number of pile-ups of other kinds)."""
+def scaffold_spanning_pileups(las, contig_off, read_off, input_gaps=None, with_extensions=False, **opts):
+    """The gap pile-ups of the scaffold graph (collectPileUps/pileups.d:173-208): returns (Pileups, number of
+    pile-ups of other kinds).  with_extensions = False: the spanning reads only (dh_scaffold_spanning);
+    True: every read alignment of the pile-up, i.e. also the extension entries mergeExtensionsWithGaps moved
+    into the gap, as (read, LA, -1) / (read, -1, LA) triples (dh_scaffold_gap_pileups) -- what the reference's
+    `dentist process` is handed."""
     L = lib()
     h, arr = _scaffold(las, contig_off, read_off, input_gaps, opts)
     try:
         ph = ctypes.c_void_p()
         skipped = ctypes.c_int32(0)
-        L.dh_scaffold_spanning.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
-                                           ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int32)]
-        _check(L.dh_scaffold_spanning(h, arr.ctypes.data, len(arr), ctypes.byref(ph), ctypes.byref(skipped)))
+        fn = L.dh_scaffold_gap_pileups if with_extensions else L.dh_scaffold_spanning
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                       ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int32)]
+        _check(fn(h, arr.ctypes.data, len(arr), ctypes.byref(ph), ctypes.byref(skipped)))
     finally:
         L.dh_scaffold_destroy.argtypes = [ctypes.c_void_p]
         L.dh_scaffold_destroy(h)
@@ -729,15 +737,26 @@ class Cropped:
         return cls(h)
 
     @classmethod
-    def create(cls, rec, pile, entry, read_id, off, bases):
+    def create(cls, rec, pile, entry, read_id, off, bases, kind=None):
         r = np.ascontiguousarray(rec, dtype=INSERTION_DTYPE)
         pi, en, ri = (np.ascontiguousarray(x, dtype=np.int32) for x in (pile, entry, read_id))
         of = np.ascontiguousarray(off, dtype=np.int64)
         ba = np.ascontiguousarray(bases, dtype=np.uint8)
+        ki = None if kind is None else np.ascontiguousarray(kind, dtype=np.uint8)
         h = ctypes.c_void_p()
-        _check(lib().dh_cropped_create(r.ctypes.data, len(r), len(pi), pi.ctypes.data, en.ctypes.data, ri.ctypes.data,
-                                       of.ctypes.data, ba.ctypes.data if len(ba) else None, ctypes.byref(h)))
+        _check(lib().dh_cropped_create2(r.ctypes.data, len(r), len(pi), pi.ctypes.data, en.ctypes.data, ri.ctypes.data,
+                                        ki.ctypes.data if ki is not None and len(ki) else None,
+                                        of.ctypes.data, ba.ctypes.data if len(ba) else None, ctypes.byref(h)))
         return cls(h)
+
+    def kind(self):
+        """Per cropped read: 0 spans the gap, 1 / 2 extension entry of the left / right contig."""
+        L, h = lib(), self._h
+        nr = L.dh_cropped_nreads(h)
+        if not nr:
+            return np.zeros(0, np.uint8)
+        buf = (ctypes.c_uint8 * nr).from_address(L.dh_cropped_kind(h))
+        return np.frombuffer(buf, dtype=np.uint8).copy()
 
     def arrays(self):
         """(records, pile, entry, read_id, off, bases) as numpy copies (bases come over PCIe)."""

@@ -1033,7 +1033,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         return fail(DH_EINVAL, "width must be in [1, 62]");
     if (o.tspace < 16 || o.tspace > 32767) return fail(DH_EINVAL, "tspace out of range");
     if (o.max_cand < 1 || o.max_cand > 256) return fail(DH_EINVAL, "max_cand must be in [1, 256]");
-    if (o.max_la < 1 || o.max_la > 64) return fail(DH_EINVAL, "max_la must be in [1, 64]");
+    if (o.max_la < 1 || o.max_la > 256) return fail(DH_EINVAL, "max_la must be in [1, 256]");
     if (o.pen < 2) return fail(DH_EINVAL, "pen must be >= 2");
     if (o.band_shift < 1 || o.band_shift > 12) return fail(DH_EINVAL, "band_shift out of range");
     if (o.skip_self && A != B) return fail(DH_EINVAL, "skip_self needs A == B");

@@ -65,21 +65,31 @@ k_gather_parts(const uint8_t *__restrict__ src0, const int64_t *__restrict__ off
 // las sorted by aread; la_first[r] .. la_first[r+1] are the LAs with aread == r.
 // qv[r * maxtiles + t]; tile value = floor(200 * diffs / (tile_len + bbases)), the QV is the mean
 // of the lowest min(cov, m) values, capped at MAXQV; MAXQV when no overlap covers the tile.
+// One wavefront per read.  Per tile the lanes share the overlaps of the read (lane l takes the overlaps
+// l, l + 64, ...), the tile values -- at most 200, since a tile's diffs cannot exceed the longer of its
+// two sides -- are counted into 256 LDS bins, and the sum of the lowest `cov` of them is one wave-wide
+// scan over the bins (four bins per lane).  No per-thread arrays (the round-2 kernel kept 64 sorted values
+// per thread in scratch: 15 GB of traffic for 1 MB of output), any number of overlaps, any cov.
 __global__ void __launch_bounds__(64)
 k_tile_qv(const DhLa *__restrict__ las, const uint16_t *__restrict__ trace,
           const int32_t *__restrict__ la_first, const int64_t *__restrict__ roff, int32_t nreads,
           int32_t tspace, const int32_t *__restrict__ cov_of, int32_t maxtiles, uint8_t *__restrict__ qv)
 {
+    __shared__ int32_t hist[256];
     const int32_t r = blockIdx.x;
     if (r >= nreads) return;
+    const int lane = threadIdx.x;
     const int32_t cov = cov_of[r];
     const int32_t rlen = (int32_t)(roff[r + 1] - roff[r]);
     const int32_t nt = (rlen + tspace - 1) / tspace;
-    for (int32_t t = threadIdx.x; t < nt && t < maxtiles; t += blockDim.x) {
+    const int32_t l0 = la_first[r], l1 = la_first[r + 1];
+    for (int32_t t = 0; t < nt && t < maxtiles; t++) {
         const int32_t t0 = t * tspace, t1 = (t0 + tspace < rlen) ? t0 + tspace : rlen;
-        int32_t vals[64];
-        int32_t m = 0;
-        for (int32_t i = la_first[r]; i < la_first[r + 1]; i++) {
+#pragma unroll
+        for (int x = 0; x < 4; x++) hist[4 * lane + x] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        for (int32_t i = l0 + lane; i < l1; i += 64) {
             const DhLa la = las[i];
             if (la.flags & 0x20u) continue;
             if (la.abpos > t0 || la.aepos < t1) continue;
@@ -89,25 +99,42 @@ k_tile_qv(const DhLa *__restrict__ las, const uint16_t *__restrict__ trace,
             if (seg0 != t0 || seg1 != t1) continue;
             const uint16_t *tr = trace + la.toff;
             const int32_t val = 200 * (int32_t)tr[2 * e] / ((t1 - t0) + (int32_t)tr[2 * e + 1]);
-            // insertion into the sorted prefix; only the lowest 64 matter (cov <= 64)
-            int32_t p = m < 64 ? m : 63;
-            if (m >= 64 && val >= vals[63]) continue;
-            while (p > 0 && vals[p - 1] > val) {
-                vals[p] = vals[p - 1];
-                p--;
-            }
-            vals[p] = val;
-            if (m < 64) m++;
+            atomicAdd(&hist[val < 255 ? val : 255], 1);
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        int32_t c[4], mine = 0;
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            c[x] = hist[4 * lane + x];
+            mine += c[x];
+        }
+        // exclusive scan of the lanes' counts
+        int32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int32_t v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        const int32_t m = __shfl(incl, 63, 64);
         int32_t q = MAXQV;
         if (m > 0) {
             const int32_t use = m < cov ? m : cov;
-            int64_t sum = 0;
-            for (int32_t x = 0; x < use; x++) sum += vals[x];
-            q = (int32_t)(sum / use);
+            int32_t before = incl - mine, part = 0;
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                int32_t take = use - before;
+                take = take < 0 ? 0 : (take > c[x] ? c[x] : take);
+                part += take * (4 * lane + x);
+                before += c[x];
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+            q = part / use;
             if (q > MAXQV) q = MAXQV;
         }
-        qv[(int64_t)r * maxtiles + t] = (uint8_t)q;
+        if (lane == 0) qv[(int64_t)r * maxtiles + t] = (uint8_t)q;
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

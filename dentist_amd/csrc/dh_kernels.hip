@@ -2177,33 +2177,35 @@ k_compact(const DhLa *__restrict__ la_slots, const uint16_t *__restrict__ tr_slo
     const int lane = threadIdx.x;
     const uint32_t l0 = la_off[it], n = la_off[it + 1] - l0;
     uint32_t t = tr_off[it];
-    if (ordered && n <= LANES) {
-        DhLa la;
-        uint64_t k1 = ~0ull, k2 = ~0ull;
-        int32_t tl = 0, so = 0;  // so: where the pairs start inside the slot (k_tile; 0 for the wave kernels)
-        if ((uint32_t)lane < n) {
-            la = la_slots[(int64_t)it * max_la + lane];
-            so = (int32_t)la.toff;
-            k1 = ((uint64_t)(uint32_t)la.bread << 32) | ((uint64_t)(la.flags & 1u) << 31) | (uint32_t)la.abpos;
-            k2 = ((uint64_t)(uint32_t)la.bbpos << 32) | (uint32_t)la.aepos;
-            tl = la.tlen;
+    if (ordered && n <= 256u) {
+        // keys of the item's records in LDS; lane l ranks the records l, l + 64, ...
+        __shared__ uint64_t sk1[256], sk2[256];
+        __shared__ int32_t stl[256], sso[256];
+        for (uint32_t x = (uint32_t)lane; x < n; x += LANES) {
+            const DhLa la = la_slots[(int64_t)it * max_la + x];
+            sk1[x] = ((uint64_t)(uint32_t)la.bread << 32) | ((uint64_t)(la.flags & 1u) << 31) | (uint32_t)la.abpos;
+            sk2[x] = ((uint64_t)(uint32_t)la.bbpos << 32) | (uint32_t)la.aepos;
+            stl[x] = la.tlen;
+            sso[x] = (int32_t)la.toff;  // where the pairs start inside the slot (k_tile; 0 for the wave kernels)
         }
+        __syncthreads();
         // rank among the records of the item, trace offset = prefix sum of the slot order
-        int32_t rank = 0, toff = 0;
-        for (uint32_t y = 0; y < n; y++) {
-            const uint64_t y1 = __shfl(k1, (int)y, LANES), y2 = __shfl(k2, (int)y, LANES);
-            const int32_t yt = __shfl(tl, (int)y, LANES);
-            const bool less = y1 < k1 || (y1 == k1 && (y2 < k2 || (y2 == k2 && (int)y < lane)));
-            rank += less ? 1 : 0;
-            toff += (int)y < lane ? yt : 0;
-        }
-        if ((uint32_t)lane < n) {
+        for (uint32_t x = (uint32_t)lane; x < n; x += LANES) {
+            const uint64_t k1 = sk1[x], k2 = sk2[x];
+            int32_t rank = 0, toff = 0;
+            for (uint32_t y = 0; y < n; y++) {
+                const uint64_t y1 = sk1[y], y2 = sk2[y];
+                const bool less = y1 < k1 || (y1 == k1 && (y2 < k2 || (y2 == k2 && y < x)));
+                rank += less ? 1 : 0;
+                toff += y < x ? stl[y] : 0;
+            }
+            DhLa la = la_slots[(int64_t)it * max_la + x];
             la.toff = tr_base + t + toff;
             la_out[l0 + rank] = la;
         }
         for (uint32_t x = 0; x < n; x++) {
-            const int32_t xl = __shfl(tl, (int)x, LANES);
-            const uint16_t *src = tr_slots + ((int64_t)it * max_la + x) * trmax + __shfl(so, (int)x, LANES);
+            const int32_t xl = stl[x];
+            const uint16_t *src = tr_slots + ((int64_t)it * max_la + x) * trmax + sso[x];
             for (int32_t e = lane; e < xl; e += LANES) tr_out[t + e] = src[e];
             t += xl;
         }

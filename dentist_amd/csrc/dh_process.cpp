@@ -257,12 +257,21 @@ static bool select_pile(std::vector<int32_t> &v, const dh_la *las, const dh_proc
 {
     const int32_t cnt = (int32_t)v.size() / 3;
     if (cnt < o.min_reads) return false;
-    if (cnt <= o.max_reads) return true;
+    if (o.max_reads <= 0 || cnt <= o.max_reads) return true;  // max_reads 0 = no cap (the reference has none)
     std::vector<std::pair<int64_t, int32_t>> key((size_t)cnt);
     for (int32_t e = 0; e < cnt; e++) {
-        const dh_la &L = las[v[(size_t)e * 3 + 1]], &R = las[v[(size_t)e * 3 + 2]];
-        const int64_t len = (int64_t)(L.aepos - L.abpos) + (R.aepos - R.abpos);
-        key[(size_t)e] = std::make_pair(((int64_t)L.diffs + R.diffs) * 1000000 / std::max<int64_t>(len, 1), e);
+        // an extension entry (one index is -1) is judged by the one alignment it has
+        const int32_t iL = v[(size_t)e * 3 + 1], iR = v[(size_t)e * 3 + 2];
+        int64_t len = 0, diffs = 0;
+        if (iL >= 0) {
+            len += las[iL].aepos - las[iL].abpos;
+            diffs += las[iL].diffs;
+        }
+        if (iR >= 0) {
+            len += las[iR].aepos - las[iR].abpos;
+            diffs += las[iR].diffs;
+        }
+        key[(size_t)e] = std::make_pair(diffs * 1000000 / std::max<int64_t>(len, 1), e);
     }
     std::sort(key.begin(), key.end());  // entries are in read-id order, so e breaks ties by read id
     std::vector<int32_t> keep((size_t)o.max_reads);
@@ -296,8 +305,8 @@ extern "C" int dh_pileups_select(const dh_pileups *cands, const dh_la *las, int6
         for (int64_t i = lo; i < hi; i++) {
             std::vector<int32_t> v = cands->triples[(size_t)i];
             bool ok = true;
-            for (size_t e = 0; e < v.size() && ok; e += 3)
-                ok = !(v[e + 1] < 0 || v[e + 1] >= n || v[e + 2] < 0 || v[e + 2] >= n);
+            for (size_t e = 0; e < v.size() && ok; e += 3)  // -1 = no alignment on that side (extension entry)
+                ok = v[e + 1] >= -1 && v[e + 1] < n && v[e + 2] >= -1 && v[e + 2] < n && (v[e + 1] >= 0 || v[e + 2] >= 0);
             if (!ok) {
                 bad = 1;
                 continue;
@@ -324,8 +333,8 @@ void dh_pileups_shift(dh_pileups *p, int32_t by)
 {
     for (auto &t : p->triples)
         for (size_t e = 0; e + 2 < t.size(); e += 3) {
-            t[e + 1] += by;
-            t[e + 2] += by;
+            if (t[e + 1] >= 0) t[e + 1] += by;
+            if (t[e + 2] >= 0) t[e + 2] += by;
         }
 }
 int dh_pileups_concat(dh_pileups *const *parts, int32_t nparts, dh_pileups **out)
@@ -397,9 +406,10 @@ extern "C" int dh_pileups_write_db(const dh_pileups *p, const dh_la *las, int64_
         const std::vector<int32_t> &t = p->triples[i];
         nra.push_back((int32_t)t.size() / 3);
         for (size_t e = 0; e + 2 < t.size(); e += 3) {
-            nsa.push_back(2);
+            nsa.push_back((t[e + 1] >= 0 ? 1 : 0) + (t[e + 2] >= 0 ? 1 : 0));
             for (int side = 0; side < 2; side++) {
                 const int32_t li = t[e + 1 + (size_t)side];
+                if (li == -1 && t[e + 2 - (size_t)side] >= 0) continue;  // extension entry: one seeded alignment
                 if (li < 0 || li >= n) return dh_fail(DH_EINVAL, "dh_pileups_write_db: LA index out of range");
                 const dh_la &x = las[li];
                 if (x.aread < 0 || x.aread >= ncontigs || x.bread < 0 || x.bread >= nreads)
@@ -1019,6 +1029,7 @@ struct dh_cropped {
     dh_ctx *ctx = nullptr;
     std::vector<dh_insertion> rec;
     std::vector<int32_t> pile, entry, read_id;
+    std::vector<uint8_t> kind;  // per cropped read: 0 = spans the gap, 1 = back extension of the left contig, 2 = front extension of the right one
     std::vector<int64_t> off{0};
     std::vector<uint8_t> bases;
     bool host_valid = false;
@@ -1038,6 +1049,7 @@ extern "C" int32_t dh_cropped_nreads(const dh_cropped *c) { return c ? (int32_t)
 extern "C" const int32_t *dh_cropped_pile(const dh_cropped *c) { return c ? c->pile.data() : nullptr; }
 extern "C" const int32_t *dh_cropped_entry(const dh_cropped *c) { return c ? c->entry.data() : nullptr; }
 extern "C" const int32_t *dh_cropped_read_id(const dh_cropped *c) { return c ? c->read_id.data() : nullptr; }
+extern "C" const uint8_t *dh_cropped_kind(const dh_cropped *c) { return c ? c->kind.data() : nullptr; }
 extern "C" const int64_t *dh_cropped_offsets(const dh_cropped *c) { return c ? c->off.data() : nullptr; }
 extern "C" const uint8_t *dh_cropped_bases(dh_cropped *c)
 {
@@ -1058,9 +1070,20 @@ extern "C" const uint8_t *dh_cropped_bases(dh_cropped *c)
     return c->bases.data();
 }
 
+extern "C" int dh_cropped_create2(const dh_insertion *rec, int32_t npiles, int32_t nreads, const int32_t *pile,
+                                  const int32_t *entry, const int32_t *read_id, const uint8_t *kind, const int64_t *off,
+                                  const uint8_t *bases, dh_cropped **out);
 extern "C" int dh_cropped_create(const dh_insertion *rec, int32_t npiles, int32_t nreads, const int32_t *pile,
                                  const int32_t *entry, const int32_t *read_id, const int64_t *off,
                                  const uint8_t *bases, dh_cropped **out)
+{
+    return dh_cropped_create2(rec, npiles, nreads, pile, entry, read_id, nullptr, off, bases, out);
+}
+
+// kind: per read 0 / 1 / 2 (see dh_cropped_kind), NULL = every read spans its gap
+extern "C" int dh_cropped_create2(const dh_insertion *rec, int32_t npiles, int32_t nreads, const int32_t *pile,
+                                  const int32_t *entry, const int32_t *read_id, const uint8_t *kind, const int64_t *off,
+                                  const uint8_t *bases, dh_cropped **out)
 {
     if (npiles < 0 || nreads < 0 || !out || (npiles > 0 && !rec) ||
         (nreads > 0 && (!pile || !entry || !read_id || !off || !bases)))
@@ -1081,6 +1104,15 @@ extern "C" int dh_cropped_create(const dh_insertion *rec, int32_t npiles, int32_
         c->pile.assign(pile, pile + nreads);
         c->entry.assign(entry, entry + nreads);
         c->read_id.assign(read_id, read_id + nreads);
+        if (kind)
+            c->kind.assign(kind, kind + nreads);
+        else
+            c->kind.assign((size_t)nreads, 0);
+        for (uint8_t k : c->kind)
+            if (k > 2) {
+                delete c;
+                return dh_fail(DH_EINVAL, "dh_cropped_create: kind must be 0, 1 or 2");
+            }
         c->off.assign(off, off + nreads + 1);
         c->bases.assign(bases, bases + off[nreads]);
     }
@@ -1133,7 +1165,7 @@ extern "C" int dh_crop_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_
     // pile-ups are independent: host threads compute crop points and read slices (the trace walks are
     // cache misses into the mapping's trace array), the parts are laid out serially afterwards
     struct Slice {
-        int32_t e, rd, lrd, b0, b1, comp;
+        int32_t e, rd, lrd, b0, b1, comp, kind;
     };
     struct PileCrop {
         int32_t lp0 = 0, lp1 = 0, rp0 = 0, rp1 = 0;
@@ -1158,16 +1190,21 @@ extern "C" int dh_crop_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_
             int32_t llo = 0, lhi = INT32_MAX, rlo = 0, rhi = INT32_MAX;
             bool bad = false;
             for (int32_t e = 0; e < ne; e++) {
+                // an entry is a read spanning the gap (two alignments) or an extension over one contig end
+                // merged into the gap's pile-up (one alignment, the other index is -1: scaffold.d:789-816)
                 const int32_t iL = tr3[(size_t)e * 3 + 1], iR = tr3[(size_t)e * 3 + 2];
-                if (iL < 0 || iL >= n || iR < 0 || iR >= n) {
+                if (iL < -1 || iL >= n || iR < -1 || iR >= n || (iL < 0 && iR < 0)) {
                     bad = true;
                     break;
                 }
-                const dh_la &L = las[iL], &R = las[iR];
-                llo = std::max(llo, L.abpos);
-                lhi = std::min(lhi, L.aepos);
-                rlo = std::max(rlo, R.abpos);
-                rhi = std::min(rhi, R.aepos);
+                if (iL >= 0) {
+                    llo = std::max(llo, las[iL].abpos);
+                    lhi = std::min(lhi, las[iL].aepos);
+                }
+                if (iR >= 0) {
+                    rlo = std::max(rlo, las[iR].abpos);
+                    rhi = std::min(rhi, las[iR].aepos);
+                }
             }
             if (bad) {
                 err = 2;
@@ -1201,12 +1238,14 @@ extern "C" int dh_crop_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_
                     err = 3;
                     break;
                 }
-                const dh_la &L = las[tr3[(size_t)e * 3 + 1]], &R = las[tr3[(size_t)e * 3 + 2]];
-                const int32_t bL = translate_floor_b(L, trace + L.toff, tsm, cropL);
-                const int32_t bR = translate_floor_b(R, trace + R.toff, tsm, cropR);
+                const int32_t iL = tr3[(size_t)e * 3 + 1], iR = tr3[(size_t)e * 3 + 2];
                 const int32_t rl = (int32_t)(reads->h_off[(size_t)lrd + 1] - reads->h_off[(size_t)lrd]);
+                // getCroppingSlice per alignment, intersected (cropper.d:339-348, 503-550): the back-seeded
+                // one keeps [crop point, read end), the front-seeded one [0, crop point)
+                const int32_t bL = iL >= 0 ? translate_floor_b(las[iL], trace + las[iL].toff, tsm, cropL) : 0;
+                const int32_t bR = iR >= 0 ? translate_floor_b(las[iR], trace + las[iR].toff, tsm, cropR) : rl;
                 int32_t b0 = bL, b1 = bR;
-                const bool comp = (L.flags & DH_FLAG_COMP) != 0;
+                const bool comp = (las[iL >= 0 ? iL : iR].flags & DH_FLAG_COMP) != 0;
                 if (comp) {  // getCroppingSlice, cropper.d:533-538
                     b0 = rl - bR;
                     b1 = rl - bL;
@@ -1216,7 +1255,7 @@ extern "C" int dh_crop_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_
                     err = 4;
                     break;
                 }
-                q.sl.push_back(Slice{e, rd, (int32_t)lrd, b0, b1, comp ? 1 : 0});
+                q.sl.push_back(Slice{e, rd, (int32_t)lrd, b0, b1, comp ? 1 : 0, iR < 0 ? 1 : (iL < 0 ? 2 : 0)});
             }
         }
     });
@@ -1236,8 +1275,11 @@ extern "C" int dh_crop_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_
             int64_t dst = c->off.back();
             // getSingleReadPatch, cropper.d:363-378: complement reads get the reverse-complemented
             // patches in swapped positions
-            const int32_t pre_c = comp ? g + 1 : g, pre0 = comp ? q.rp0 : q.lp0, pre1 = comp ? q.rp1 : q.lp1;
-            const int32_t post_c = comp ? g : g + 1, post0 = comp ? q.lp0 : q.rp0, post1 = comp ? q.lp1 : q.rp1;
+            // (an extension entry gets the patch of its own contig only: getReadPatches, cropper.d:351-361)
+            const int32_t lp0 = x.kind == 2 ? 0 : q.lp0, lp1 = x.kind == 2 ? 0 : q.lp1;
+            const int32_t rp0 = x.kind == 1 ? 0 : q.rp0, rp1 = x.kind == 1 ? 0 : q.rp1;
+            const int32_t pre_c = comp ? g + 1 : g, pre0 = comp ? rp0 : lp0, pre1 = comp ? rp1 : lp1;
+            const int32_t post_c = comp ? g : g + 1, post0 = comp ? lp0 : rp0, post1 = comp ? lp1 : rp1;
             if (pre1 > pre0) {
                 parts.push_back(PartDescH{1, pre_c, pre0, pre1 - pre0, comp ? 1 : 0, 0, dst});
                 dst += pre1 - pre0;
@@ -1253,6 +1295,7 @@ extern "C" int dh_crop_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_
             c->pile.push_back(p);
             c->entry.push_back(x.e);
             c->read_id.push_back(x.rd);
+            c->kind.push_back((uint8_t)x.kind);
             r.nreads++;
         }
     }
@@ -1301,7 +1344,8 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
 {
     if (!ctx || !contigs || !crop || !opts || !out) return dh_fail(DH_EINVAL, "dh_process_cropped: NULL argument");
     const dh_process_opts &o = *opts;
-    if (o.max_reads < 3 || o.max_reads > 60) return dh_fail(DH_EINVAL, "max_reads must be in [3, 60]");
+    if (o.max_reads != 0 && (o.max_reads < 3 || o.max_reads > 250))
+        return dh_fail(DH_EINVAL, "max_reads must be 0 (no cap) or in [3, 250]");
     if (o.rounds < 1 || o.rounds > 8) return dh_fail(DH_EINVAL, "rounds must be in [1, 8]");
     if (o.tspace_pile < 16 || o.tspace_pile > SEG_MAX) return dh_fail(DH_EINVAL, "tspace_pile out of range");
     HIPCHK(hipSetDevice(ctx->device));
@@ -1375,6 +1419,7 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
     std::vector<int32_t> pile_of_active;             // active index -> pile-up index
     std::vector<int32_t> first_read;                 // active index -> first read in pile-up DB
     std::vector<int32_t> read_id;                    // pile-up DB read -> read id in `reads`
+    std::vector<uint8_t> rkind;                      // pile-up DB read -> 0 spans the gap, 1 / 2 extension entry
     std::vector<int32_t> sgroup, keep;               // per pile-up DB read: group, index in the crop DB
     for (int32_t p = 0; p < np; p++) {
         dh_insertion &r = res->rec[(size_t)p];
@@ -1384,7 +1429,7 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
             return dh_fail(DH_EINVAL, "dh_process_cropped: gap outside the contigs DB");
         if (cnt_of[(size_t)p] < o.min_reads)
             r.status = DH_PILE_TOO_SMALL;
-        else if (cnt_of[(size_t)p] > o.max_reads)
+        else if (o.max_reads > 0 && cnt_of[(size_t)p] > o.max_reads)
             return dh_fail(DH_EINVAL, "dh_process_cropped: pile-up with more than max_reads reads");
     }
     for (int32_t i = 0; i < ncr; i++) {
@@ -1398,6 +1443,7 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
         sgroup.push_back(active_of[(size_t)p]);
         keep.push_back(i);
         read_id.push_back(crop->read_id[(size_t)i]);
+        rkind.push_back(crop->kind.empty() ? 0 : crop->kind[(size_t)i]);
     }
     const int32_t na = (int32_t)pile_of_active.size();
     first_read.push_back((int32_t)keep.size());
@@ -1439,8 +1485,15 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
         ao.tspace = tsp;
         ao.min_len = 500;
         ao.skip_self = 2;  // every unordered pair aligned once, both records emitted (as daligner does)
-        ao.max_la = 64;
-        ao.max_cand = 128;
+        // record slots per (read, strand): a read overlaps at most every other read of its pile-up
+        {
+            int32_t most = 0;
+            for (int32_t a = 0; a < na; a++) most = std::max(most, first_read[(size_t)a + 1] - first_read[(size_t)a]);
+            if (most > 252)
+                return dh_fail(DH_EOVERFLOW, "process: a pile-up with more than 252 reads (set max_reads)");
+            ao.max_la = most <= 60 ? 64 : (most <= 124 ? 128 : 256);
+            ao.max_cand = std::min(256, 2 * ao.max_la);
+        }
         ao.width = pwidth;
         ao.algo = palgo;
         dh_la_set *pset = nullptr;
@@ -1573,10 +1626,15 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
                                   hipMemcpyHostToDevice, st));
             HIPCHK(hipMemsetAsync(d_qv.p, 255, qv.size(), st));
             // cov = max(#allowed reference reads, 4 if pile >= 4) == pile size here (package.d:498-503)
+            // (allowed reference reads = the reads that span the gap, selectAllowedReferenceReadIds :461-472)
             std::vector<int32_t> cov_of((size_t)npr, 1);
-            for (int32_t a = 0; a < na; a++)
-                for (int32_t r = first_read[(size_t)a]; r < first_read[(size_t)a + 1]; r++)
-                    cov_of[(size_t)r] = first_read[(size_t)a + 1] - first_read[(size_t)a];
+            for (int32_t a = 0; a < na; a++) {
+                const int32_t r0 = first_read[(size_t)a], r1 = first_read[(size_t)a + 1];
+                int32_t cov = 0;
+                for (int32_t r = r0; r < r1; r++) cov += rkind[(size_t)r] == 0 ? 1 : 0;
+                if (cov < 4 && r1 - r0 >= 4) cov = 4;
+                for (int32_t r = r0; r < r1; r++) cov_of[(size_t)r] = std::max(cov, 1);
+            }
             DevBuf<int32_t> d_cov;
             HIPCHK(d_cov.alloc(cov_of.size()));
             HIPCHK(hipMemcpyAsync(d_cov.p, cov_of.data(), sizeof(int32_t) * cov_of.size(), hipMemcpyHostToDevice, st));
@@ -1613,6 +1671,7 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
             int64_t hist[MAXQV] = {0};
             int64_t total = 0;
             for (int32_t r = r0; r < r1; r++) {
+                if (rkind[(size_t)r] != 0) continue;  // only allowed reference reads enter the histogram and the ranking
                 const int32_t len = (int32_t)(pile->h_off[(size_t)r + 1] - pile->h_off[(size_t)r]);
                 const int32_t nt = (len + tsp - 1) / tsp;
                 for (int32_t t = 0; t < nt; t++) {
@@ -1638,6 +1697,7 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
             int64_t best_nbad = 0;
             double best_mean = 0;
             for (int32_t r = r0; r < r1; r++) {
+                if (rkind[(size_t)r] != 0) continue;
                 const int32_t len = (int32_t)(pile->h_off[(size_t)r + 1] - pile->h_off[(size_t)r]);
                 const int32_t nt = (len + tsp - 1) / tsp;
                 int64_t nb = 0, sum = 0;
@@ -1652,6 +1712,11 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
                     best_nbad = nb;
                     best_mean = mean;
                 }
+            }
+            if (best < 0) {  // no read spans the gap: "no valid reference read found" (package.d:335-343)
+                if (rec.status == DH_PILE_OK) rec.status = DH_PILE_TOO_SMALL;
+                active_ok[(size_t)a] = 0;
+                continue;
             }
             ref_of[(size_t)a] = best;
             rec.ref_read = best - r0;

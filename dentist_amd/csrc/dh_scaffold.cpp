@@ -374,3 +374,45 @@ extern "C" int dh_scaffold_spanning(const dh_scaffold *s, const dh_la *las, int6
     if (skipped) *skipped = skip;
     return dh_pileups_create(cl.data(), cnt.data(), (int32_t)cl.size(), tri.data(), out);
 }
+
+// The pile-ups of the gap joins (c, end)--(c + 1, begin) with EVERY read alignment the builder put into
+// them: reads spanning the gap as (read, left LA, right LA) and the extension-type read alignments that
+// mergeExtensionsWithGaps (scaffold.d:789-816) moved into the gap -- (read, LA, -1) for a back extension
+// of the left contig, (read, -1, LA) for a front extension of the right one -- which the reference crops
+// and aligns like any other member of the pile-up (cropper.d:113-175, 339-361).  Entries are ordered by
+// read, then by their position in the builder's list.  *skipped = pile-ups of any other kind.
+extern "C" int dh_scaffold_gap_pileups(const dh_scaffold *s, const dh_la *las, int64_t n, dh_pileups **out, int32_t *skipped)
+{
+    if (!s || !out || (n > 0 && !las)) return dh_fail(DH_EINVAL, "dh_scaffold_gap_pileups: bad argument");
+    std::vector<int32_t> cl, cnt, tri;
+    int32_t skip = 0;
+    for (const dh_join &j : s->joins) {
+        if (!(j.type == 1 && j.part0 == END && j.part1 == BEGIN && j.contig1 == j.contig0 + 1)) {
+            skip++;
+            continue;
+        }
+        std::vector<std::array<int32_t, 3>> t;
+        for (int64_t x = j.first; x < j.first + j.count; x++) {
+            const dh_read_alignment &ra = s->entries[(size_t)x];
+            if (ra.la0 < 0 || ra.la0 >= n) continue;
+            if (ra.n == 2) {
+                if (ra.la1 < 0 || ra.la1 >= n) continue;
+                if ((las[ra.la0].flags & DH_FLAG_COMP) != (las[ra.la1].flags & DH_FLAG_COMP)) continue;
+                t.push_back({ra.read, ra.la0, ra.la1});
+            } else if (las[ra.la0].aread == j.contig0 && ra.seed0 == BACK)
+                t.push_back({ra.read, ra.la0, -1});
+            else if (las[ra.la0].aread == j.contig1 && ra.seed0 == FRONT)
+                t.push_back({ra.read, -1, ra.la0});
+        }
+        if (t.empty()) {
+            skip++;
+            continue;
+        }
+        std::stable_sort(t.begin(), t.end(), [](const auto &a, const auto &b) { return a[0] < b[0]; });
+        cl.push_back(j.contig0);
+        cnt.push_back((int32_t)t.size());
+        for (auto &x : t) tri.insert(tri.end(), x.begin(), x.end());
+    }
+    if (skipped) *skipped = skip;
+    return dh_pileups_create(cl.data(), cnt.data(), (int32_t)cl.size(), tri.data(), out);
+}

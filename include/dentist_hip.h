@@ -193,7 +193,8 @@ typedef struct {
     int32_t allowance;         /* proper-alignment-allowance of the mapping LAs (= tspace_map)      */
     int32_t min_anchor;        /* --min-anchor-length, commandline.d:2036 (500)                     */
     int32_t min_reads;         /* --min-reads-per-pile-up, commandline.d:2125-2187 (3)              */
-    int32_t max_reads;         /* reads kept per pile-up (<= 60)                                    */
+    int32_t max_reads;         /* reads kept per pile-up (default 60); 0 = every read, as the reference
+                                * (commandline.d:2125-2187 knows minimum counts only)                */
     int32_t tspace_pile;       /* -s126 of the pile-up daligner call, commandline.d:2886-2902       */
     int32_t rounds;            /* consensus rounds (1 = reference read + its overlaps only)         */
     int32_t flank_window;      /* bases of each flanking contig given to the flank re-alignment     */
@@ -321,6 +322,13 @@ void dh_scaffold_destroy(dh_scaffold *s);
 /* the pile-ups dh_process_pileups handles -- gap joins (c, end)--(c + 1, begin) -- with their spanning
  * read alignments as (read, left LA, right LA) triples; *skipped = pile-ups of any other kind */
 int dh_scaffold_spanning(const dh_scaffold *s, const dh_la *las, int64_t n, dh_pileups **out, int32_t *skipped);
+/* the same pile-ups with EVERY read alignment the builder put into them, as `dentist process` gets them
+ * (pile-ups.db): besides the spanning reads the extension-type read alignments that mergeExtensionsWithGaps
+ * (scaffold.d:789-816) moved into the gap -- (read, LA, -1): back extension of the left contig, (read, -1, LA):
+ * front extension of the right one.  The cropper cuts them from their crop point to the read's end
+ * (cropper.d:339-361, 503-550); they are members of the pile-up but never its reference read
+ * (processPileUps/package.d:461-472). */
+int dh_scaffold_gap_pileups(const dh_scaffold *s, const dh_la *las, int64_t n, dh_pileups **out, int32_t *skipped);
 
 /* the six alignment filters of `dentist collect` (collectPileUps/filter.d:122-356, order of
  * collectPileUps/package.d:130-141) on the read->contig LAs: LQ (averageErrorRate > max_align_err),
@@ -399,8 +407,15 @@ int dh_crop_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_t read_firs
 int dh_cropped_create(const dh_insertion *rec, int32_t npiles, int32_t nreads, const int32_t *pile,
                       const int32_t *entry, const int32_t *read_id, const int64_t *off, const uint8_t *bases,
                       dh_cropped **out);
+/* the same with the kind of every read (dh_cropped_kind); kind == NULL: every read spans its gap */
+int dh_cropped_create2(const dh_insertion *rec, int32_t npiles, int32_t nreads, const int32_t *pile,
+                       const int32_t *entry, const int32_t *read_id, const uint8_t *kind, const int64_t *off,
+                       const uint8_t *bases, dh_cropped **out);
 void dh_cropped_destroy(dh_cropped *c);
 int32_t dh_cropped_npiles(const dh_cropped *c);
+/* per cropped read: 0 = it spans the gap, 1 = back extension of the left contig, 2 = front extension of the
+ * right contig (entries with one alignment, see dh_scaffold_gap_pileups) */
+const uint8_t *dh_cropped_kind(const dh_cropped *c);
 const dh_insertion *dh_cropped_records(const dh_cropped *c);
 int32_t dh_cropped_nreads(const dh_cropped *c);
 const int32_t *dh_cropped_pile(const dh_cropped *c);     /* pile-up of every cropped read               */

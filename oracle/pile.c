@@ -135,7 +135,7 @@ int oz_collect_spanning(const oz_la *las, int64_t n, const oz_db *contigs, const
     for (int32_t g = 0; g < nc; g++)
         if (cnt[g] >= o->min_reads) {
             np++;
-            ntri += cnt[g] < o->max_reads ? cnt[g] : o->max_reads;
+            ntri += (o->max_reads <= 0 || cnt[g] < o->max_reads) ? cnt[g] : o->max_reads; /* max_reads 0: no cap */
         }
     int32_t *gap = (int32_t *)malloc((size_t)(np ? np : 1) * sizeof(int32_t));
     int32_t *count = (int32_t *)malloc((size_t)(np ? np : 1) * sizeof(int32_t));
@@ -145,7 +145,7 @@ int oz_collect_spanning(const oz_la *las, int64_t n, const oz_db *contigs, const
     for (int32_t g = 0; g < nc; g++) {
         if (cnt[g] < o->min_reads) continue;
         gap[p] = g;
-        if (cnt[g] <= o->max_reads) {
+        if (o->max_reads <= 0 || cnt[g] <= o->max_reads) {
             memcpy(tri + 3 * at, lst[g], (size_t)cnt[g] * 3 * sizeof(int32_t));
             count[p] = cnt[g];
         } else {
@@ -448,7 +448,8 @@ static void process_one(const oz_db *contigs, const oz_db *reads, const oz_la *l
             if (rlen[i] > maxlen) maxlen = rlen[i];
         }
         oz_opts po;
-        set_opts(&po, tsp, 500, 2, 64, 128, o->width, o->algo);
+        const int32_t pla = pile.n <= 60 ? 64 : (pile.n <= 124 ? 128 : 256);
+        set_opts(&po, tsp, 500, 2, pla, pla * 2 < 256 ? pla * 2 : 256, o->width, o->algo);
         oz_la_set ps;
         oz_la_set_init(&ps);
         int64_t st[4];

@@ -96,9 +96,14 @@ def translate_floor(la, tr, apos, ts):
 
 
 def crop_pile(entries, las, trace, contigs, reads, g, ts_map=100):
-    """cropPileUp: returns (cropL, cropR, SeqDb of cropped reads in read orientation, read ids)."""
-    left = [las[iL] for _, iL, _ in entries]
-    right = [las[iR] for _, _, iR in entries]
+    """cropPileUp: returns (cropL, cropR, SeqDb of cropped reads in read orientation, read ids, kinds).
+    An entry is (read, left LA, right LA); an extension-type read alignment merged into the gap
+    (scaffold.d:789-816) has None / -1 in place of the alignment it lacks: it is cut from its crop point to
+    the end of the read (getCroppingSlice per alignment, cropper.d:339-348, 503-550) and gets the support
+    patch of its own contig only (getReadPatches, cropper.d:351-361).  kind: 0 spans, 1 left only, 2 right only."""
+    has = lambda i: i is not None and i >= 0   # noqa: E731
+    left = [las[iL] for _, iL, _ in entries if has(iL)]
+    right = [las[iR] for _, _, iR in entries if has(iR)]
     cropL = common_trace_point([(int(l["abpos"]), int(l["aepos"])) for l in left], contigs.length(g), ts_map, False)
     cropR = common_trace_point([(int(r["abpos"]), int(r["aepos"])) for r in right], contigs.length(g + 1), ts_map, True)
     if cropL < 0 or cropR < 0:
@@ -108,23 +113,30 @@ def crop_pile(entries, las, trace, contigs, reads, g, ts_map=100):
     cl, cr = contigs.seq(g), contigs.seq(g + 1)
     left_patch = cl[max(0, len(cl) - MIN_ANCHOR):cropL] if len(cl) - cropL < MIN_ANCHOR else cl[0:0]
     right_patch = cr[cropR:MIN_ANCHOR] if cropR < MIN_ANCHOR else cr[0:0]
-    seqs, ids = [], []
+    seqs, ids, kinds = [], [], []
     for (r, iL, iR) in entries:
-        L, R = las[iL], las[iR]
-        _, bL = translate_floor(L, trace[L["toff"]:L["toff"] + L["tlen"]], cropL, ts_map)
-        _, bR = translate_floor(R, trace[R["toff"]:R["toff"] + R["tlen"]], cropR, ts_map)
         rl = reads.length(r)
-        if L["flags"] & 1:          # getCroppingSlice: complement -> swap and mirror (cropper.d:533-538)
+        bL, bR = 0, rl
+        if has(iL):
+            L = las[iL]
+            _, bL = translate_floor(L, trace[L["toff"]:L["toff"] + L["tlen"]], cropL, ts_map)
+        if has(iR):
+            R = las[iR]
+            _, bR = translate_floor(R, trace[R["toff"]:R["toff"] + R["tlen"]], cropR, ts_map)
+        lp = left_patch if has(iL) else left_patch[0:0]
+        rp = right_patch if has(iR) else right_patch[0:0]
+        if las[iL if has(iL) else iR]["flags"] & 1:   # getCroppingSlice: complement -> swap and mirror (cropper.d:533-538)
             b0, b1 = rl - bR, rl - bL
-            pre, post = revcomp(right_patch), revcomp(left_patch)   # getSingleReadPatch, cropper.d:363-378
+            pre, post = revcomp(rp), revcomp(lp)   # getSingleReadPatch, cropper.d:363-378
         else:
             b0, b1 = bL, bR
-            pre, post = left_patch, right_patch
+            pre, post = lp, rp
         if b1 - b0 < 14:
             continue
         seqs.append(np.concatenate([pre, reads.seq(r)[b0:b1], post]).astype(np.uint8))
         ids.append(r)
-    return cropL, cropR, SeqDb.from_list(seqs), ids
+        kinds.append(0 if has(iL) and has(iR) else (1 if has(iL) else 2))
+    return cropL, cropR, SeqDb.from_list(seqs), ids, kinds
 
 
 def stage_width(algo):
@@ -132,10 +144,12 @@ def stage_width(algo):
     return 64 if algo == 1 else WAVE_WIDTH
 
 
-def pile_opts(algo=0):
-    # skip_self = 2: every unordered pair aligned once, both records emitted (what daligner does)
-    return oz.default_opts(tspace=TS_PILE, min_len=500, skip_self=2, max_la=64, max_cand=128, width=stage_width(algo),
-                           algo=algo)
+def pile_opts(algo=0, nreads=0):
+    # skip_self = 2: every unordered pair aligned once, both records emitted (what daligner does);
+    # record slots / candidates per (read, strand) grow with the pile-up (a read overlaps every other read)
+    max_la = 64 if nreads <= 60 else (128 if nreads <= 124 else 256)
+    return oz.default_opts(tspace=TS_PILE, min_len=500, skip_self=2, max_la=max_la, max_cand=min(256, 2 * max_la),
+                           width=stage_width(algo), algo=algo)
 
 
 def filter_pile_las(las, pile, max_err_ppm=300000, allowance=TS_PILE, proper=True):
@@ -238,12 +252,12 @@ def process_pile(entries, las, trace, contigs, reads, g, rounds=3, nthreads=1, f
     if crop is None:
         res["status"] = "no common trace point"
         return res
-    cropL, cropR, pile, ids = crop
-    res.update(cropL=cropL, cropR=cropR, pile=pile, read_ids=ids)
+    cropL, cropR, pile, ids, kinds = crop
+    res.update(cropL=cropL, cropR=cropR, pile=pile, read_ids=ids, kinds=kinds)
     if pile.n < 3:
         res["status"] = "pile too small"
         return res
-    o = pile_opts(algo)
+    o = pile_opts(algo, pile.n)
     if dust:   # DBdust pileup.db; daligner ... -mdust (package.d:476-482)
         pile = oz.with_dust(pile)
         res["pile"] = pile
@@ -251,14 +265,22 @@ def process_pile(entries, las, trace, contigs, reads, g, rounds=3, nthreads=1, f
     # computeQVs (package.d:474-516): error filter -> chain -> DAScover/DASqv -> proper-overlap filter
     chained = filter_pile_las(plas, pile, proper=False)
     rlen = np.asarray([pile.length(i) for i in range(pile.n)], dtype=np.int32)
-    cov = pile.n if pile.n >= 4 else pile.n   # max(#allowed reference reads, 4 if pile >= 4) (package.d:498-503)
-    qv = oz.tile_qv(chained, ptrace, rlen, TS_PILE, max(cov, 4) if pile.n >= 4 else cov)
+    # allowed reference reads = the reads that span the gap (selectAllowedReferenceReadIds, package.d:461-472);
+    # coverage = max(their number, 4 if pile >= 4) (package.d:498-503)
+    allowed = np.asarray([1 if k == 0 else 0 for k in kinds], dtype=np.uint8)
+    cov = int(allowed.sum())
+    if cov < 4 and pile.n >= 4:
+        cov = 4
+    qv = oz.tile_qv(chained, ptrace, rlen, TS_PILE, max(cov, 1))
     plas = filter_proper(chained, pile)
     res.update(pile_las=plas, pile_trace=ptrace)
     if not np.any((plas["flags"] & 0x20) == 0):
         res["status"] = "empty pileup alignment after filtering"
         return res
-    order, badqv = oz.rank_reference_reads(qv, rlen, TS_PILE)
+    order, badqv = oz.rank_reference_reads(qv, rlen, TS_PILE, allowed=allowed)
+    if len(order) == 0:
+        res["status"] = "pile too small"   # no valid reference read (package.d:335-343)
+        return res
     ref_idx = int(order[0])
     res.update(qv=qv, order=order, ref_idx=ref_idx)
     cons = oz.consensus(pile.seq(ref_idx), pile, plas, ptrace, ref_idx, TS_PILE)

@@ -307,3 +307,71 @@ def test_scaffold_graph_builder_on_a_mapping(gpu_ctx):
         first = las[il] if not las[il]["flags"] & 1 else las[ir]
         blen = int(w.reads.off[rd + 1] - w.reads.off[rd])
         assert (first["bbpos"] == 0) if not first["flags"] & 1 else (first["bepos"] == blen)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("algo", [0, 1])
+def test_pile_ups_of_the_graph_builder_with_extension_entries(gpu_ctx, algo):
+    """Read-id parity on the path bench.py runs: mapping -> six collect filters -> scaffold-graph builder
+    (pileups.d:173-208) -> gap pile-ups WITH the extension-type read alignments mergeExtensionsWithGaps put
+    into them (scaffold.d:789-816; pileups.d:870 makes a read whose first alignment starts after read
+    position 0 open with an extension) -> crop -> process.  Membership equals oracle/scaffold.py:build() on
+    the same alignments; crop points, pile-up reads, reference read (a spanning read: package.d:461-472),
+    consensus and splice coordinates equal oracle/process.py with the same entries."""
+    from oracle import scaffold as sc
+    w = sim.Workload(1_000_000, 10, 8000, 8000, seed=43)
+    mo = dentist_amd.default_align_opts(kmer_mod=4, k=20, **(dict(algo=1, width=64) if algo else {}))
+    po = dentist_amd.default_process_opts(rounds=2, algo=algo, max_reads=0)
+    A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
+    las, trace = gpu_ctx.align_db(A, B, mo, select_best=True)
+    las, dropped, _ = dentist_amd.collect_filter(las, w.contigs.off, w.reads.off, po, inplace=True)
+    gaps_in = np.stack([np.arange(w.contigs.n - 1), np.arange(1, w.contigs.n)], axis=1)
+    piles, skipped = dentist_amd.scaffold_spanning_pileups(las, w.contigs.off, w.reads.off, gaps_in, with_extensions=True,
+                                                           min_spanning_reads=po.min_reads)
+    # ---- membership against the oracle's builder
+    chains = [sc.chain(i, int(l["aread"]) + 1, w.contigs.length(int(l["aread"])), int(l["bread"]) + 1,
+                       w.reads.length(int(l["bread"])), bool(l["flags"] & 1), int(l["abpos"]), int(l["aepos"]),
+                       int(l["bbpos"]), int(l["bepos"]), disabled=bool(l["flags"] & 0x20)) for i, l in enumerate(las)]
+    exp = {}
+    for e, ras in sc.build(w.contigs.n, chains, [(int(a) + 1, int(b) + 1) for a, b in gaps_in], min_spanning_reads=po.min_reads):
+        (c0, p0), (c1, p1) = e["start"], e["end"]
+        if not (p0 == sc.END and p1 == sc.BEGIN and c1 == c0 + 1):
+            continue
+        ent = []
+        for ra in ras:
+            if len(ra) == 2:
+                a, b = sorted(ra, key=lambda s: s[0]["a_id"])
+                ent.append((a[0]["b_id"] - 1, a[0]["id"], b[0]["id"]))
+            elif ra[0][0]["a_id"] == c0:
+                ent.append((ra[0][0]["b_id"] - 1, ra[0][0]["id"], -1))
+            else:
+                ent.append((ra[0][0]["b_id"] - 1, -1, ra[0][0]["id"]))
+        exp[c0 - 1] = sorted(ent, key=lambda t: t[0])   # stable: by read, then the builder's order
+    got = {}
+    for i in range(len(piles)):
+        g, tri = piles.get(i)
+        got[int(g)] = [tuple(int(x) for x in t) for t in tri.tolist()]
+    assert set(got) == set(exp) and len(got) == 10
+    for g in got:
+        assert sorted(got[g]) == sorted(exp[g]), g
+    next_ = sum(1 for v in got.values() for t in v if t[1] < 0 or t[2] < 0)
+    assert next_ > 0, "the case must contain extension entries"
+    # ---- process with these pile-ups against the oracle's driver
+    rec, bases = dentist_amd.process_pileups(gpu_ctx, A, B, las, trace, piles, po)
+    closed = 0
+    for i in range(len(piles)):
+        g, tri = piles.get(i)
+        ex = pr.process_pile([tuple(int(x) for x in t) for t in tri.tolist()], las, trace, w.contigs, w.reads, int(g),
+                             rounds=po.rounds, nthreads=os.cpu_count() or 1, algo=algo)
+        r = rec[i]
+        assert (r["status"] == 0) == (ex["status"] == "ok"), (g, int(r["status"]), ex["status"])
+        if r["status"] != 0:
+            continue
+        assert (r["crop_left"], r["crop_right"], r["nreads"]) == (ex["cropL"], ex["cropR"], ex["pile"].n)
+        assert r["ref_read"] == ex["ref_idx"] and ex["kinds"][ex["ref_idx"]] == 0
+        cons = bases[r["cons_off"]:r["cons_off"] + r["cons_len"]]
+        assert np.array_equal(cons, ex["consensus"]), f"gap {g}: consensus differs"
+        assert (r["left_aepos"], r["right_abpos"], r["ins_begin"], r["ins_end"]) == \
+               (ex["left_aepos"], ex["right_abpos"], ex["ins_begin"], ex["ins_end"])
+        closed += 1
+    assert closed >= 9
