@@ -83,7 +83,12 @@ def main():
     ap.add_argument("--map-xdrop", type=int, default=60, help="score lag that trims the mapping waves")
     ap.add_argument("--process-algo", type=int, default=1,
                     help="alignments of the process stages (pile-up all-vs-all, re-alignment, flanks): 1 = DH-2, 0 = DH-1")
-    ap.add_argument("--max-reads", type=int, default=None, help="reads kept per pile-up (default: dh_default_process_opts)")
+    ap.add_argument("--max-reads", type=int, default=None,
+                    help="reads kept per pile-up (default: dh_default_process_opts = 60; 0 = no cap, the reference's behaviour)")
+    ap.add_argument("--collect", choices=("graph", "spanning"), default=None,
+                    help="pile-up membership: 'graph' = the scaffold-graph builder of `dentist collect` with the extension "
+                         "entries it merges into a gap (pileups.d:173-208; N = 1 default), 'spanning' = one entry per "
+                         "spanning read, collected per chunk while mapping (the sharded path; N > 1 default)")
     ap.add_argument("--dev-share-gpu", action="store_true",
                     help="development only: all ranks on cuda:0 with gloo collectives (exercises the N > 1 "
                          "code path on a 1-GPU box; not a measurement)")
@@ -130,6 +135,11 @@ def main():
     if args.max_reads is not None:
         popts.max_reads = args.max_reads
     read_bp = int(len(w.reads.bases))
+    if args.collect is None:
+        args.collect = "graph" if world == 1 else "spanning"
+    if args.collect == "graph" and world > 1:
+        raise SystemExit("--collect graph is a single-process step (the scaffold graph is global); use spanning for N > 1")
+    input_gaps = np.stack([np.arange(w.contigs.n - 1), np.arange(1, w.contigs.n)], axis=1).astype(np.int32)
 
     def step():
         A.drop_cache()  # the k-mer index and the derived copies are rebuilt every step
@@ -144,10 +154,17 @@ def main():
         ast = ctx.align_stats()
         t1 = time.perf_counter()
         if world == 1:
-            piles = cands.select(las, popts)   # min / max reads per pile-up (choice by alignment quality)
+            if args.collect == "graph":
+                # `dentist collect` on the filtered alignments: scaffold graph, forks by read support, min spanning
+                # reads, extensions merged into their gap; then the optional read cap (by alignment quality)
+                gp, _ = dentist_amd.scaffold_spanning_pileups(las, w.contigs.off, w.reads.off, input_gaps,
+                                                              with_extensions=True, min_spanning_reads=popts.min_reads)
+                piles = gp.select(las, popts)
+            else:
+                piles = cands.select(las, popts)   # min / max reads per pile-up (choice by alignment quality)
             t2 = time.perf_counter()
             rec, bases = dentist_amd.process_pileups(ctx, A, B, las, trace, piles, popts)
-            info = {"piles": len(piles)}
+            info = {"piles": len(piles), "entries": int(piles.flat()[1].sum())}
         else:
             las["bread"] += lo   # read ids of the whole reads DB, as in the .las of a block
             t2 = t1
@@ -233,6 +250,9 @@ def main():
                        "mapping_kmer_mod": args.kmer_mod, "mapping_algo": "DH-2 tiled band (k_tile)" if args.map_algo == 1 else "DH-1 wave (k_wave2)",
                        "mapping_width": args.map_width,
                        "mapping_xdrop": args.map_xdrop,
+                       "collect": "scaffold-graph builder, extension entries merged into the gap pile-ups" if args.collect == "graph"
+                                  else "spanning reads, one entry per read",
+                       "pile_up_entries": int(last["info"].get("entries", 0)),
                        "process": {"algo": "DH-2 tiled band (k_tile)" if popts.algo == 1 else "DH-1 wave (k_wave2)",
                                    "max_reads_per_pile_up": popts.max_reads, "min_reads_per_pile_up": popts.min_reads,
                                    "consensus_rounds": popts.rounds, "width": 64 if popts.algo == 1 else (popts.width or 30),
