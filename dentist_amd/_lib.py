@@ -87,7 +87,7 @@ SYMBOLS = [
     "dh_map_reads", "dh_validate_regions", "dh_propagate_mask", "dh_db_mask_coverage", "dh_max_coverage_reads", "dh_max_improper_coverage_reads",
     "dh_default_scaffold_opts", "dh_scaffold_pileups", "dh_scaffold_npiles", "dh_scaffold_nentries", "dh_scaffold_joins",
     "dh_scaffold_entries", "dh_scaffold_destroy", "dh_scaffold_spanning", "dh_scaffold_gap_pileups", "dh_cropped_create2",
-    "dh_cropped_kind",
+    "dh_cropped_kind", "dh_insertions_read_ids", "dh_insertions_read_ids_off", "dh_output_assembly", "dh_default_output_opts",
 ]
 
 _LIB = None
@@ -793,8 +793,9 @@ class Cropped:
             pass
 
 
-def _take_insertions(h, insertions_db=None):
-    """insertions_db = (path, contig_off, tspace): also write the result as DENTIST's insertions.db."""
+def _take_insertions(h, insertions_db=None, read_ids=False):
+    """insertions_db = (path, contig_off, tspace): also write the result as DENTIST's insertions.db.
+    read_ids: also return (ids, off): the 0-based read ids of every record's pile-up."""
     L = lib()
     if insertions_db is not None:
         path, contig_off, tspace = insertions_db
@@ -810,20 +811,86 @@ def _take_insertions(h, insertions_db=None):
                          dtype=INSERTION_DTYPE).copy() if n else np.zeros(0, dtype=INSERTION_DTYPE))
     bases = (np.frombuffer(ctypes.string_at(L.dh_insertions_bases(h), nb), dtype=np.uint8).copy()
              if nb else np.zeros(0, dtype=np.uint8))
+    ids = None
+    if read_ids:
+        L.dh_insertions_read_ids.restype = ctypes.c_void_p
+        L.dh_insertions_read_ids_off.restype = ctypes.c_void_p
+        L.dh_insertions_read_ids.argtypes = L.dh_insertions_read_ids_off.argtypes = [ctypes.c_void_p]
+        po = L.dh_insertions_read_ids_off(h)
+        if po and n:
+            off = np.frombuffer(ctypes.string_at(po, 4 * (n + 1)), dtype=np.int32).astype(np.int64)
+            tot = int(off[-1])
+            idv = (np.frombuffer(ctypes.string_at(L.dh_insertions_read_ids(h), 4 * tot), dtype=np.int32).copy()
+                   if tot else np.zeros(0, np.int32))
+            ids = (idv, off)
+        else:
+            ids = (np.zeros(0, np.int32), np.zeros(n + 1, np.int64))
     L.dh_insertions_destroy(h)
-    return rec, bases
+    return (rec, bases, ids) if read_ids else (rec, bases)
 
 
-def process_pileups(ctx, contigs, reads, las, trace, piles, opts, insertions_db=None):
+def process_pileups(ctx, contigs, reads, las, trace, piles, opts, insertions_db=None, read_ids=False):
     """dentist `process` for a batch of pile-ups on the GPU. Returns (records, consensus bases);
-    insertions_db = (path, contig_off, tspace) also writes DENTIST's insertions.db."""
+    insertions_db = (path, contig_off, tspace) also writes DENTIST's insertions.db; read_ids = True adds
+    (ids, off): the read ids of every record's pile-up (what `dentist output` lists in its BED / AGP)."""
     L = lib()
     arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
     tr = np.ascontiguousarray(trace, dtype=np.uint16)
     h = ctypes.c_void_p()
     _check(L.dh_process_pileups(ctx._h, contigs._h, reads._h, arr.ctypes.data, len(arr), tr.ctypes.data,
                                 piles._h, ctypes.byref(opts), ctypes.byref(h)))
-    return _take_insertions(h, insertions_db)
+    return _take_insertions(h, insertions_db, read_ids)
+
+
+class OutputOpts(ctypes.Structure):
+    _fields_ = [("line_width", ctypes.c_int32), ("highlight", ctypes.c_int32), ("join_policy", ctypes.c_int32),
+                ("agp_dazzler", ctypes.c_int32), ("agp_skip_read_ids", ctypes.c_int32), ("pad", ctypes.c_int32),
+                ("agp_version", ctypes.c_char_p), ("tool", ctypes.c_char_p), ("input_assembly", ctypes.c_char_p)]
+
+
+JOIN_POLICIES = {"scaffoldGaps": 0, "scaffolds": 1, "contigs": 2}
+
+
+def output_assembly(fasta_path, contigs, scaffold_of, headers, gap_len, rec, bases, read_ids=None, bed_path=None,
+                    agp_path=None, join_policy="scaffoldGaps", agp_dazzler=False, agp_skip_read_ids=False, read_names=None,
+                    line_width=50, highlight=True, tool=None, input_assembly=None):
+    """`dentist output` (host only): assembly graph with the join policy, fixCropping, FASTA, AGP and closed-gaps
+    BED (dh_output_assembly).  read_ids = (ids, off) from process_pileups(read_ids=True).  Returns the number of
+    insertions the join policy dropped."""
+    L = lib()
+    o = OutputOpts()
+    L.dh_default_output_opts.argtypes = [ctypes.POINTER(OutputOpts)]
+    L.dh_default_output_opts(ctypes.byref(o))
+    o.line_width, o.highlight, o.join_policy = line_width, int(bool(highlight)), JOIN_POLICIES[join_policy]
+    o.agp_dazzler, o.agp_skip_read_ids = int(bool(agp_dazzler)), int(bool(agp_skip_read_ids))
+    if tool is not None:
+        o.tool = tool.encode()
+    if input_assembly is not None:
+        o.input_assembly = input_assembly.encode()
+    cb = np.ascontiguousarray(contigs.bases, dtype=np.uint8)
+    co = np.ascontiguousarray(contigs.off, dtype=np.int64)
+    so = np.ascontiguousarray(scaffold_of, dtype=np.int32)
+    gl = np.ascontiguousarray(gap_len, dtype=np.int32) if gap_len is not None else None
+    r = np.ascontiguousarray(rec, dtype=INSERTION_DTYPE)
+    b = np.ascontiguousarray(bases, dtype=np.uint8)
+    hs = (ctypes.c_char_p * len(headers))(*[h.encode() for h in headers])
+    ids = off = None
+    if read_ids is not None:
+        ids = np.ascontiguousarray(read_ids[0], dtype=np.int32)
+        off = np.ascontiguousarray(read_ids[1], dtype=np.int64)
+    rn = (ctypes.c_char_p * len(read_names))(*[x.encode() for x in read_names]) if read_names is not None else None
+    dropped = ctypes.c_int32(0)
+    vp = ctypes.c_void_p
+    L.dh_output_assembly.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, vp, vp, ctypes.c_int32, vp, vp, vp, vp,
+                                     ctypes.c_int32, vp, vp, vp, vp, ctypes.POINTER(OutputOpts), ctypes.POINTER(ctypes.c_int32)]
+    _check(L.dh_output_assembly(fasta_path.encode(), bed_path.encode() if bed_path else None,
+                                agp_path.encode() if agp_path else None, cb.ctypes.data, co.ctypes.data, len(co) - 1,
+                                so.ctypes.data, ctypes.cast(hs, vp), gl.ctypes.data if gl is not None else None,
+                                r.ctypes.data, len(r), b.ctypes.data if len(b) else None,
+                                ids.ctypes.data if ids is not None and len(ids) else (ids.ctypes.data if ids is not None else None),
+                                off.ctypes.data if off is not None else None, ctypes.cast(rn, vp) if rn is not None else None,
+                                ctypes.byref(o), ctypes.byref(dropped)))
+    return int(dropped.value)
 
 
 def output_fasta(fasta_path, contigs, scaffold_of, headers, gap_len, rec, bases, bed_path=None, line_width=50,

@@ -643,6 +643,13 @@ extern "C" int32_t dh_insertions_count(const dh_insertions *r) { return r ? (int
 extern "C" const dh_insertion *dh_insertions_records(const dh_insertions *r) { return r ? r->rec.data() : nullptr; }
 extern "C" const uint8_t *dh_insertions_bases(const dh_insertions *r) { return r ? r->bases.data() : nullptr; }
 extern "C" int64_t dh_insertions_bases_len(const dh_insertions *r) { return r ? (int64_t)r->bases.size() : 0; }
+// read ids (0-based) of every record's pile-up: ids[off[i] .. off[i + 1]); off has count + 1 entries (all 0 when the
+// result carries no ids)
+extern "C" const int32_t *dh_insertions_read_ids(const dh_insertions *r) { return r ? r->ids.data() : nullptr; }
+extern "C" const int32_t *dh_insertions_read_ids_off(const dh_insertions *r)
+{
+    return r && r->ids_off.size() == r->rec.size() + 1 ? r->ids_off.data() : nullptr;
+}
 
 // insertions.db of a result (what `dentist process` hands to `dentist output`,
 // processPileUps/package.d:156-158, 789-805): one insertion per closed gap -- start = (left contig,

@@ -387,6 +387,10 @@ int32_t dh_insertions_count(const dh_insertions *r);
 const dh_insertion *dh_insertions_records(const dh_insertions *r);
 const uint8_t *dh_insertions_bases(const dh_insertions *r);
 int64_t dh_insertions_bases_len(const dh_insertions *r);
+/* read ids (0-based) of every record's pile-up, the Insertion.readIds of makeInsertion (processPileUps/
+ * package.d:789-798): ids[off[i] .. off[i + 1]), off has count + 1 entries; NULL when the result carries none */
+const int32_t *dh_insertions_read_ids(const dh_insertions *r);
+const int32_t *dh_insertions_read_ids_off(const dh_insertions *r);
 /* The two halves of dh_process_pileups as entry points of their own (dh_process_pileups runs them
  * back to back with the cropped reads staying on the device):
  *   dh_crop_pileups     cropPileUp (cropper.d:113-175, 446-550) for a batch: the common trace point of
@@ -456,6 +460,24 @@ int dh_output_fasta(const char *fasta_path, const char *bed_path, const uint8_t 
                     const int64_t *contig_off, int32_t ncontigs, const int32_t *scaffold_of,
                     const char *const *headers, const int32_t *gap_len, const dh_insertion *ins,
                     int32_t nins, const uint8_t *ins_bases, int32_t line_width, int32_t highlight);
+/* `dentist output` with its graph step and all three writers (output.d:305-348 buildAssemblyGraph with
+ * enforceJoinPolicy common/scaffold.d:642-715, fixCropping :931-1003; FASTA :782-925; AGP :454-573; BED
+ * :879-891 with every read id of the pile-up).  join_policy: 0 scaffoldGaps (insertions between input
+ * scaffolds are dropped, *dropped counts them), 1 scaffolds, 2 contigs (they join the two scaffolds into one
+ * record).  agp_dazzler: component ids are contig numbers / "reads-<ids>"; otherwise scaffold header ids and
+ * read_names[id - 1]; agp_skip_read_ids: "<n> reads".  read_ids / read_ids_off[nins + 1]: 0-based read ids of
+ * every insertion's pile-up (NULL: the reference read alone). */
+typedef struct {
+    int32_t line_width, highlight, join_policy, agp_dazzler, agp_skip_read_ids, pad;
+    const char *agp_version, *tool, *input_assembly;
+} dh_output_opts;
+void dh_default_output_opts(dh_output_opts *o);
+int dh_output_assembly(const char *fasta_path, const char *bed_path, const char *agp_path,
+                       const uint8_t *contig_bases, const int64_t *contig_off, int32_t ncontigs,
+                       const int32_t *scaffold_of, const char *const *headers, const int32_t *gap_len,
+                       const dh_insertion *ins, int32_t nins, const uint8_t *ins_bases, const int32_t *read_ids,
+                       const int64_t *read_ids_off, const char *const *read_names, const dh_output_opts *opts,
+                       int32_t *dropped);
 
 /* ---- DAZZ_DB files on disk (.db / .dam stub + hidden .idx / .bps / .hdr), host only.
  *      Replaces what DENTIST obtains by spawning fasta2DB / fasta2DAM / DBsplit

@@ -125,6 +125,22 @@ def test_process_reference_fixture_gap_is_closed_perfectly(gpu_ctx, tmp_path):
     b = open(bed).read().split("\t")
     # output.d:879-891: start = currentScaffoldCoord - 1, end = nextScaffoldCoord (1-based, one past the 0-based end)
     assert b[0] == header[1:] and int(b[1]) == r["left_aepos"] and int(b[2]) == r["left_aepos"] + len(ins) + 1
+    # the full writer: same FASTA bytes, the AGP of the reference's layout (output.d:454-573) and a BED line that
+    # lists every read of the pile-up (`%(%d-%)`, output.d:879-891)
+    rec2, bases2, ids = dentist_amd.process_pileups(gpu_ctx, A, B, las, trace, piles, po, read_ids=True)
+    assert np.array_equal(rec2, rec) and len(ids[0]) == r["nreads"]
+    path2, bed2, agp = (str(tmp_path / n) for n in ("gap-closed2.fasta", "closed-gaps2.bed", "gap-closed.agp"))
+    assert dentist_amd.output_assembly(path2, contigs, [0, 0], [header[1:]], [97], rec2, bases2, read_ids=ids, bed_path=bed2,
+                                       agp_path=agp, agp_dazzler=True, input_assembly="reference.dam") == 0
+    assert open(path2, "rb").read() == data
+    idlist = "-".join(str(int(x) + 1) for x in sorted(ids[0].tolist()))
+    assert open(bed2).read() == f"chr3R\t2000\t2098\tcontigs-1-2|reads-{idlist}\n"
+    sb, se = (r["cons_len"] - r["ins_end"], r["cons_len"] - r["ins_begin"]) if r["comp"] else (r["ins_begin"], r["ins_end"])
+    assert [ln for ln in open(agp).read().split("\n") if ln and not ln.startswith("#")] == [
+        "chr3R\t1\t2000\t1\tW\t1\t0\t2000\t-\tna",
+        f"chr3R\t2001\t2097\t2\tO\treads-{idlist}\t{sb}\t{se}\t{'+' if r['comp'] else '-'}\tclone_contig",
+        "chr3R\t2098\t4097\t3\tW\t2\t2097\t4097\t-\tna",
+    ]
 
 
 def test_config1_full_size_properties(gpu_ctx):
