@@ -87,7 +87,9 @@ SYMBOLS = [
     "dh_map_reads", "dh_validate_regions", "dh_propagate_mask", "dh_db_mask_coverage", "dh_max_coverage_reads", "dh_max_improper_coverage_reads",
     "dh_default_scaffold_opts", "dh_scaffold_pileups", "dh_scaffold_npiles", "dh_scaffold_nentries", "dh_scaffold_joins",
     "dh_scaffold_entries", "dh_scaffold_destroy", "dh_scaffold_spanning", "dh_scaffold_gap_pileups", "dh_cropped_create2",
-    "dh_cropped_kind", "dh_insertions_read_ids", "dh_insertions_read_ids_off", "dh_output_assembly", "dh_default_output_opts",
+    "dh_cropped_kind", "dh_shard_free", "dh_shard_pack_candidates", "dh_shard_plan_create", "dh_shard_plan_destroy",
+    "dh_shard_plan_las", "dh_shard_plan_nlas", "dh_shard_plan_pileups", "dh_shard_plan_owner", "dh_shard_pack_cropped",
+    "dh_shard_unpack_cropped", "dh_insertions_read_ids", "dh_insertions_read_ids_off", "dh_output_assembly", "dh_default_output_opts",
 ]
 
 _LIB = None
@@ -465,7 +467,8 @@ class Pileups:
     """Spanning-read pile-ups per gap (host only): dh_collect_spanning; ``candidates=True`` skips the
     min/max-reads cut (dh_collect_candidates)."""
 
-    def __init__(self, las, contig_off, opts, candidates=False, _handle=None):
+    def __init__(self, las, contig_off, opts, candidates=False, _handle=None, _keep=None):
+        self._keep = _keep   # a borrowed handle (owned by _keep, e.g. a ShardPlan): never destroyed here
         if _handle is not None:
             self._h = _handle
             return
@@ -540,7 +543,75 @@ class Pileups:
 
     def close(self):
         if self._h:
-            lib().dh_pileups_destroy(self._h)
+            if getattr(self, "_keep", None) is None:
+                lib().dh_pileups_destroy(self._h)
+            self._h = None
+            self._keep = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------- sharded path: the host work between the collectives
+def _blob(ptr, n):
+    """numpy copy of a malloc'd blob of the library."""
+    if not n:
+        return np.zeros(0, np.uint8)
+    return np.frombuffer(ctypes.string_at(ptr, n), dtype=np.uint8).copy()
+
+
+def shard_pack_candidates(cands, las, read_shift=0):
+    """dh_shard_pack_candidates: this rank's candidate entries as the blob of the candidate all-gather."""
+    L = lib()
+    arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
+    out, nb = ctypes.c_void_p(), ctypes.c_int64(0)
+    L.dh_shard_pack_candidates.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                           ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64)]
+    L.dh_shard_free.argtypes = [ctypes.c_void_p]
+    _check(L.dh_shard_pack_candidates(cands._h, arr.ctypes.data, len(arr), read_shift, ctypes.byref(out), ctypes.byref(nb)))
+    b = _blob(out, nb.value)
+    L.dh_shard_free(out)
+    return b
+
+
+class ShardPlan:
+    """dh_shard_plan: the pile-ups every rank derives from the gathered candidates, and who processes them."""
+
+    def __init__(self, blobs, opts):
+        L = lib()
+        self._blobs = [np.ascontiguousarray(b, dtype=np.uint8) for b in blobs]
+        n = len(self._blobs)
+        ptrs = (ctypes.c_void_p * n)(*[b.ctypes.data for b in self._blobs])
+        sizes = (ctypes.c_int64 * n)(*[len(b) for b in self._blobs])
+        h = ctypes.c_void_p()
+        L.dh_shard_plan_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ProcessOpts),
+                                           ctypes.POINTER(ctypes.c_void_p)]
+        _check(L.dh_shard_plan_create(ptrs, sizes, n, ctypes.byref(opts), ctypes.byref(h)))
+        self._h = h
+        for fn in (L.dh_shard_plan_las, L.dh_shard_plan_pileups, L.dh_shard_plan_owner):
+            fn.argtypes = [ctypes.c_void_p]
+            fn.restype = ctypes.c_void_p
+        L.dh_shard_plan_nlas.argtypes = [ctypes.c_void_p]
+        L.dh_shard_plan_nlas.restype = ctypes.c_int64
+        nl = L.dh_shard_plan_nlas(h)
+        # a view of the plan's records (kept alive by this object)
+        self.las = (np.frombuffer((ctypes.c_uint8 * (nl * LA_DTYPE.itemsize)).from_address(L.dh_shard_plan_las(h)), dtype=LA_DTYPE)
+                    if nl else np.zeros(0, dtype=LA_DTYPE))
+        self.piles = Pileups(None, None, None, _handle=ctypes.c_void_p(L.dh_shard_plan_pileups(h)), _keep=self)
+        npl = len(self.piles)
+        self.owner = (np.frombuffer((ctypes.c_uint8 * (4 * npl)).from_address(L.dh_shard_plan_owner(h)), dtype=np.int32).copy()
+                      if npl else np.zeros(0, np.int32))
+
+    def close(self):
+        if self._h:
+            self.piles._h = None
+            self.las = None
+            L = lib()
+            L.dh_shard_plan_destroy.argtypes = [ctypes.c_void_p]
+            L.dh_shard_plan_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -548,6 +619,36 @@ class Pileups:
             self.close()
         except Exception:
             pass
+
+
+def shard_pack_cropped(crop, owner, world):
+    """dh_shard_pack_cropped: the reads this rank cropped, one blob per owner rank."""
+    L = lib()
+    ow = np.ascontiguousarray(owner, dtype=np.int32)
+    ptrs = (ctypes.c_void_p * world)()
+    sizes = (ctypes.c_int64 * world)()
+    L.dh_shard_pack_cropped.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    L.dh_shard_free.argtypes = [ctypes.c_void_p]
+    _check(L.dh_shard_pack_cropped(crop._h, ow.ctypes.data, world, ptrs, sizes))
+    out = [_blob(ptrs[r], sizes[r]) for r in range(world)]
+    L.dh_shard_free(ptrs[0])
+    return out
+
+
+def shard_unpack_cropped(blobs, rec, owner, rank):
+    """dh_shard_unpack_cropped: what an owner received -> Cropped for dh_process_cropped."""
+    L = lib()
+    bl = [np.ascontiguousarray(b, dtype=np.uint8) for b in blobs]
+    n = len(bl)
+    ptrs = (ctypes.c_void_p * n)(*[b.ctypes.data for b in bl])
+    sizes = (ctypes.c_int64 * n)(*[len(b) for b in bl])
+    r = np.ascontiguousarray(rec, dtype=INSERTION_DTYPE)
+    ow = np.ascontiguousarray(owner, dtype=np.int32)
+    h = ctypes.c_void_p()
+    L.dh_shard_unpack_cropped.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+                                          ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]
+    _check(L.dh_shard_unpack_cropped(ptrs, sizes, n, r.ctypes.data, len(r), ow.ctypes.data, rank, ctypes.byref(h)))
+    return Cropped(h)
 
 
 def collect_filter(las, contig_off, read_off, opts, repeat_mask=None, inplace=False):

@@ -1988,3 +1988,242 @@ extern "C" int64_t dh_propagate_mask(const dh_la *las, int64_t n, const uint16_t
     out_ptr[nreads] = m;
     return m;
 }
+
+// ------------------------------------------------------------------------------------ sharded collect + process
+//
+// The host work of one rank between the collectives of the sharded path (dentist_amd/parallel.py): what
+// `LAmerge` + `dentist collect` + `process --batch` + `merge-insertions` do through the file system in the
+// reference (snakemake/Snakefile:1173-1185, 1315-1334; commands/mergeInsertions.d:60-164).  Payloads are byte
+// blobs the caller hands to RCCL as they are:
+//   candidates  records of 104 bytes: int32 gap, int32 read, dh_la left, dh_la right, in (gap, read) order
+//   cropped     int64 k, k x {int32 pile, entry, read, len}, then the k cropped reads' bases back to back
+namespace {
+#pragma pack(push, 1)
+struct CandRec {
+    int32_t gap, read;
+    dh_la L, R;
+};
+struct CropHead {
+    int32_t pile, entry, read, len;
+};
+#pragma pack(pop)
+static_assert(sizeof(CandRec) == 104 && sizeof(CropHead) == 16, "blob layouts");
+}  // namespace
+
+struct dh_shard_plan {
+    std::vector<dh_la> las;        // L0 R0 L1 R1 ... of every gathered candidate, in gather order
+    dh_pileups *piles = nullptr;   // after the min / max reads cut; LA indices into `las`
+    std::vector<int32_t> owner;    // rank that processes each pile-up
+    ~dh_shard_plan() { delete piles; }
+};
+
+extern "C" void dh_shard_free(void *p) { free(p); }
+
+// this rank's candidates as a blob (malloc'd; dh_shard_free).  read_shift is added to the read ids (candidates
+// collected before the alignments got their whole-DB ids)
+extern "C" int dh_shard_pack_candidates(const dh_pileups *cands, const dh_la *las, int64_t n, int32_t read_shift,
+                                        uint8_t **out, int64_t *nbytes)
+{
+    if (!cands || !out || !nbytes || (n > 0 && !las)) return dh_fail(DH_EINVAL, "dh_shard_pack_candidates: bad argument");
+    int64_t tot = 0;
+    for (const auto &t : cands->triples) tot += (int64_t)t.size() / 3;
+    CandRec *rec = (CandRec *)malloc(std::max<size_t>((size_t)tot * sizeof(CandRec), 1));
+    if (!rec) return dh_fail(DH_EINVAL, "dh_shard_pack_candidates: out of memory");
+    int64_t at = 0;
+    for (size_t g = 0; g < cands->contig_left.size(); g++) {
+        const std::vector<int32_t> &t = cands->triples[g];
+        for (size_t e = 0; e + 2 < t.size(); e += 3) {
+            if (t[e + 1] < 0 || t[e + 1] >= n || t[e + 2] < 0 || t[e + 2] >= n) {
+                free(rec);
+                return dh_fail(DH_EINVAL, "dh_shard_pack_candidates: LA index out of range");
+            }
+            CandRec &r = rec[at++];
+            r.gap = cands->contig_left[g];
+            r.read = t[e] + read_shift;
+            r.L = las[t[e + 1]];
+            r.R = las[t[e + 2]];
+        }
+    }
+    *out = (uint8_t *)rec;
+    *nbytes = tot * (int64_t)sizeof(CandRec);
+    return DH_OK;
+}
+
+// every rank's candidates (rank order = read order) -> the same pile-ups on every rank: entries of a gap ordered by
+// read id (stable sort by gap of the concatenation), the min / max reads cut, owners by greedy bin-packing of
+// n^2 * (mean read span between the anchors + 1 kb), largest first (ties: lower index; least-loaded rank, ties: lower rank)
+extern "C" int dh_shard_plan_create(const uint8_t *const *blobs, const int64_t *sizes, int32_t world,
+                                    const dh_process_opts *opts, dh_shard_plan **out)
+{
+    if (!blobs || !sizes || !opts || !out || world < 1) return dh_fail(DH_EINVAL, "dh_shard_plan_create: bad argument");
+    int64_t tot = 0;
+    for (int32_t r = 0; r < world; r++) {
+        if (sizes[r] < 0 || sizes[r] % (int64_t)sizeof(CandRec)) return dh_fail(DH_EINVAL, "dh_shard_plan_create: blob size");
+        tot += sizes[r] / (int64_t)sizeof(CandRec);
+    }
+    if (2 * tot >= (1ll << 31)) return dh_fail(DH_EINVAL, "dh_shard_plan_create: too many candidates");
+    dh_shard_plan *p = new dh_shard_plan();
+    p->las.resize((size_t)(2 * tot));
+    std::vector<std::pair<int32_t, int32_t>> key((size_t)tot);  // (gap, position in the concatenation)
+    std::vector<int32_t> rd((size_t)tot);
+    int64_t at = 0;
+    for (int32_t r = 0; r < world; r++) {
+        const CandRec *rec = (const CandRec *)blobs[r];
+        for (int64_t i = 0; i < sizes[r] / (int64_t)sizeof(CandRec); i++, at++) {
+            p->las[(size_t)(2 * at)] = rec[i].L;
+            p->las[(size_t)(2 * at + 1)] = rec[i].R;
+            key[(size_t)at] = std::make_pair(rec[i].gap, (int32_t)at);
+            rd[(size_t)at] = rec[i].read;
+        }
+    }
+    std::sort(key.begin(), key.end());  // by gap, then gather order: the stable sort by gap
+    dh_pileups all;
+    for (int64_t i = 0; i < tot; i++) {
+        if (all.contig_left.empty() || all.contig_left.back() != key[(size_t)i].first) {
+            all.contig_left.push_back(key[(size_t)i].first);
+            all.triples.emplace_back();
+        }
+        const int32_t x = key[(size_t)i].second;
+        std::vector<int32_t> &t = all.triples.back();
+        t.push_back(rd[(size_t)x]);
+        t.push_back(2 * x);
+        t.push_back(2 * x + 1);
+    }
+    if (int rc = dh_pileups_select(&all, p->las.data(), (int64_t)p->las.size(), opts, &p->piles)) {
+        delete p;
+        return rc;
+    }
+    const size_t np = p->piles->contig_left.size();
+    std::vector<int64_t> cost(np);
+    for (size_t g = 0; g < np; g++) {
+        const std::vector<int32_t> &t = p->piles->triples[g];
+        const int64_t cnt = (int64_t)t.size() / 3;
+        int64_t span = 0;
+        for (size_t e = 0; e + 2 < t.size(); e += 3)
+            span += std::max<int64_t>((int64_t)p->las[(size_t)t[e + 2]].bbpos - p->las[(size_t)t[e + 1]].bepos, 0);
+        const double mean = (double)span / (double)std::max<int64_t>(cnt, 1) + 1000.0;
+        cost[g] = (int64_t)((double)(cnt * cnt) * mean);
+    }
+    std::vector<int32_t> order(np);
+    for (size_t g = 0; g < np; g++) order[g] = (int32_t)g;
+    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return cost[(size_t)a] != cost[(size_t)b] ? cost[(size_t)a] > cost[(size_t)b] : a < b; });
+    std::vector<int64_t> load((size_t)world, 0);
+    p->owner.assign(np, 0);
+    for (int32_t g : order) {
+        int32_t best = 0;
+        for (int32_t r = 1; r < world; r++)
+            if (load[(size_t)r] < load[(size_t)best]) best = r;
+        p->owner[(size_t)g] = best;
+        load[(size_t)best] += cost[(size_t)g];
+    }
+    *out = p;
+    return DH_OK;
+}
+extern "C" void dh_shard_plan_destroy(dh_shard_plan *p) { delete p; }
+extern "C" const dh_la *dh_shard_plan_las(const dh_shard_plan *p) { return p ? p->las.data() : nullptr; }
+extern "C" int64_t dh_shard_plan_nlas(const dh_shard_plan *p) { return p ? (int64_t)p->las.size() : 0; }
+extern "C" const dh_pileups *dh_shard_plan_pileups(const dh_shard_plan *p) { return p ? p->piles : nullptr; }
+extern "C" const int32_t *dh_shard_plan_owner(const dh_shard_plan *p) { return p ? p->owner.data() : nullptr; }
+
+// the cropped reads of this rank for the owners of their pile-ups: one blob per destination rank (malloc'd as ONE block,
+// blobs[r] point into it; release blobs[0] with dh_shard_free)
+extern "C" int dh_shard_pack_cropped(dh_cropped *crop, const int32_t *owner, int32_t world, uint8_t **blobs, int64_t *sizes)
+{
+    if (!crop || !owner || !blobs || !sizes || world < 1) return dh_fail(DH_EINVAL, "dh_shard_pack_cropped: bad argument");
+    const size_t nr = crop->pile.size();
+    const uint8_t *bases = nr ? dh_cropped_bases(crop) : nullptr;
+    if (nr && !bases) return DH_EHIP;
+    std::vector<int64_t> cnt((size_t)world, 0), nb((size_t)world, 0);
+    for (size_t i = 0; i < nr; i++) {
+        const int32_t d = owner[crop->pile[i]];
+        if (d < 0 || d >= world) return dh_fail(DH_EINVAL, "dh_shard_pack_cropped: owner out of range");
+        cnt[(size_t)d]++;
+        nb[(size_t)d] += crop->off[i + 1] - crop->off[i];
+    }
+    int64_t total = 0;
+    std::vector<int64_t> start((size_t)world);
+    for (int32_t r = 0; r < world; r++) {
+        start[(size_t)r] = total;
+        sizes[r] = 8 + cnt[(size_t)r] * (int64_t)sizeof(CropHead) + nb[(size_t)r];
+        total += sizes[r];
+    }
+    uint8_t *blk = (uint8_t *)malloc((size_t)std::max<int64_t>(total, 1));
+    if (!blk) return dh_fail(DH_EINVAL, "dh_shard_pack_cropped: out of memory");
+    std::vector<int64_t> hat((size_t)world), bat((size_t)world);
+    for (int32_t r = 0; r < world; r++) {
+        blobs[r] = blk + start[(size_t)r];
+        memcpy(blobs[r], &cnt[(size_t)r], 8);
+        hat[(size_t)r] = 8;
+        bat[(size_t)r] = 8 + cnt[(size_t)r] * (int64_t)sizeof(CropHead);
+    }
+    for (size_t i = 0; i < nr; i++) {
+        const int32_t d = owner[crop->pile[i]];
+        const int64_t len = crop->off[i + 1] - crop->off[i];
+        const CropHead h{crop->pile[i], crop->entry[i], crop->read_id[i], (int32_t)len};
+        memcpy(blobs[d] + hat[(size_t)d], &h, sizeof(h));
+        hat[(size_t)d] += (int64_t)sizeof(h);
+        memcpy(blobs[d] + bat[(size_t)d], bases + crop->off[i], (size_t)len);
+        bat[(size_t)d] += len;
+    }
+    return DH_OK;
+}
+
+// what the owners received (one blob per source rank) -> the cropped pile-ups this rank processes: its pile-ups
+// renumbered 0.., their reads ordered by (pile, entry); rec = the crop records of ALL pile-ups (same on every rank)
+extern "C" int dh_shard_unpack_cropped(const uint8_t *const *blobs, const int64_t *sizes, int32_t world, const dh_insertion *rec,
+                                       int32_t npiles, const int32_t *owner, int32_t rank, dh_cropped **out)
+{
+    if (!blobs || !sizes || !out || world < 1 || npiles < 0 || (npiles > 0 && (!rec || !owner)))
+        return dh_fail(DH_EINVAL, "dh_shard_unpack_cropped: bad argument");
+    struct Src {
+        CropHead h;
+        const uint8_t *b;
+    };
+    std::vector<Src> all;
+    for (int32_t r = 0; r < world; r++) {
+        if (sizes[r] < 8) return dh_fail(DH_EINVAL, "dh_shard_unpack_cropped: short blob");
+        int64_t k;
+        memcpy(&k, blobs[r], 8);
+        if (k < 0 || 8 + k * (int64_t)sizeof(CropHead) > sizes[r]) return dh_fail(DH_EINVAL, "dh_shard_unpack_cropped: corrupt blob");
+        const uint8_t *hb = blobs[r] + 8, *bb = hb + k * (int64_t)sizeof(CropHead);
+        for (int64_t i = 0; i < k; i++) {
+            Src s;
+            memcpy(&s.h, hb + i * (int64_t)sizeof(CropHead), sizeof(CropHead));
+            s.b = bb;
+            if (s.h.len < 0 || bb + s.h.len > blobs[r] + sizes[r] || s.h.pile < 0 || s.h.pile >= npiles)
+                return dh_fail(DH_EINVAL, "dh_shard_unpack_cropped: corrupt blob");
+            bb += s.h.len;
+            all.push_back(s);
+        }
+    }
+    std::stable_sort(all.begin(), all.end(), [](const Src &a, const Src &b) {
+        return a.h.pile != b.h.pile ? a.h.pile < b.h.pile : a.h.entry < b.h.entry;
+    });
+    std::vector<int32_t> renum((size_t)npiles, -1);
+    dh_cropped *c = new dh_cropped();
+    for (int32_t p = 0; p < npiles; p++)
+        if (owner[p] == rank) {
+            renum[(size_t)p] = (int32_t)c->rec.size();
+            c->rec.push_back(rec[p]);
+        }
+    int64_t nbases = 0;
+    for (const Src &s : all) nbases += s.h.len;
+    c->bases.resize((size_t)nbases);
+    int64_t at = 0;
+    for (const Src &s : all) {
+        if (renum[(size_t)s.h.pile] < 0) {
+            delete c;
+            return dh_fail(DH_EINVAL, "dh_shard_unpack_cropped: a read of a pile-up this rank does not own");
+        }
+        c->pile.push_back(renum[(size_t)s.h.pile]);
+        c->entry.push_back(s.h.entry);
+        c->read_id.push_back(s.h.read);
+        c->kind.push_back(0);
+        memcpy(c->bases.data() + at, s.b, (size_t)s.h.len);
+        at += s.h.len;
+        c->off.push_back(at);
+    }
+    c->host_valid = true;
+    *out = c;
+    return DH_OK;
+}

@@ -18,9 +18,11 @@ shards it, with the filesystem replaced by two small exchanges over RCCL/xGMI (g
 The result is bit-identical to the single-GPU run on the same inputs (tests/test_parallel_gloo.py
 for the host logic, tests/test_parity_shard_gpu.py for two shards run on one GPU).
 """
+import ctypes
+
 import numpy as np
 
-from ._lib import INSERTION_DTYPE, LA_DTYPE
+from ._lib import INSERTION_DTYPE, LA_DTYPE, lib
 
 CAND_DTYPE = np.dtype([("gap", "<i4"), ("read", "<i4"), ("L", LA_DTYPE), ("R", LA_DTYPE)])
 CROP_DTYPE = np.dtype([("pile", "<i4"), ("entry", "<i4"), ("read", "<i4"), ("len", "<i4")])
@@ -214,62 +216,36 @@ def sharded_process_steps(ctx, contigs_db, reads_db, read_first, contig_off, las
             t = time.perf_counter()
             _laps.append("%s %.1f" % (what, (t - _t[0]) * 1e3))
             _t[0] = t
-    # cands: candidates dh_map_reads collected on the way (read ids still local to this rank's reads DB)
+    # cands: candidates dh_map_reads collected on the way (read ids still local to this rank's reads DB).
+    # The host work between the collectives is C++ behind dh_shard_* (the numpy restatement of it -- pack_candidates,
+    # merge_candidates, assign_owners, pile_costs above -- is what tests/test_parallel_gloo.py checks it against)
+    from ._lib import ShardPlan, shard_pack_candidates, shard_pack_cropped, shard_unpack_cropped
     shift = 0 if cands is None else read_first
     if cands is None:
         cands = Pileups(las, contig_off, popts, candidates=True)
-    mine = pack_candidates(cands, las, shift)
+    mine = shard_pack_candidates(cands, las, shift)
     lap("candidates")
-    blobs = yield ("all_gather", mine.view(np.uint8))
-    per_rank = [np.frombuffer(b.tobytes(), dtype=CAND_DTYPE) for b in blobs]
+    blobs = yield ("all_gather", mine)
     _t[0] = time.perf_counter()
-    glas, gaps, counts, triples = merge_candidates(per_rank)
-    lap("merge")
+    ncand = sum(len(b) for b in blobs) // CAND_DTYPE.itemsize
+    plan = ShardPlan(blobs, popts)
+    glas, piles, owner = plan.las, plan.piles, plan.owner
+    lap("plan (merge, cut, owners)")
     # the entries of this rank inside glas are copies of its own records: their toff still points
     # into its own trace array, which is all dh_crop_pileups needs (other ranks' traces stay there)
-    piles = Pileups.from_flat(gaps, counts, triples).select(glas, popts)
-    lap("select")
-    owner = assign_owners(pile_costs(piles, glas), world)
-    lap("owners")
     crop = Cropped.crop(ctx, contigs_db, reads_db, read_first, glas, trace, piles, popts)
     lap("crop")
-    rec, cpile, centry, cread, coff, cbases = crop.arrays()
+    L = lib()
+    npl = L.dh_cropped_npiles(crop._h)
+    rec = (np.frombuffer(ctypes.string_at(L.dh_cropped_records(crop._h), npl * INSERTION_DTYPE.itemsize),
+                         dtype=INSERTION_DTYPE).copy() if npl else np.zeros(0, dtype=INSERTION_DTYPE))
+    per_dest = shard_pack_cropped(crop, owner, world)
     crop.close()
-    lap("crop arrays")
-    # cropped reads to the owners of their pile-ups; reads are in (pile, entry) order, so the reads of
-    # one destination form a few contiguous runs of the base array
-    lens = np.diff(coff).astype(np.int32)
-    dest_of_read = owner[cpile] if len(cpile) else np.zeros(0, np.int32)
-    per_dest = []
-    for r in range(world):
-        sel = np.nonzero(dest_of_read == r)[0]
-        head = np.zeros(len(sel), dtype=CROP_DTYPE)
-        head["pile"], head["entry"], head["read"], head["len"] = cpile[sel], centry[sel], cread[sel], lens[sel]
-        per_dest.append(np.concatenate([np.asarray([len(sel)], dtype=np.int64).view(np.uint8), head.view(np.uint8)]
-                                       + _runs(cbases, coff, sel)))
     lap("pack per dest")
     got = yield ("all_to_all", per_dest)
     _t[0] = time.perf_counter()
-    heads, seqs = [], []
-    for blob in got:
-        k = int(blob[:8].view(np.int64)[0])
-        h = np.frombuffer(blob[8:8 + k * CROP_DTYPE.itemsize].tobytes(), dtype=CROP_DTYPE)
-        heads.append(h)
-        seqs.append(blob[8 + k * CROP_DTYPE.itemsize:])
-    head = np.concatenate(heads)
-    src_off = np.concatenate([[0], np.cumsum(head["len"].astype(np.int64))])
-    allseq = np.concatenate(seqs) if seqs else np.zeros(0, np.uint8)
-    # pile-ups owned here, renumbered 0..; reads ordered by (pile, entry)
     mine_piles = np.nonzero(owner == rank)[0]
-    renum = np.full(len(rec), -1, dtype=np.int32)
-    renum[mine_piles] = np.arange(len(mine_piles), dtype=np.int32)
-    order = np.lexsort((head["entry"], head["pile"]))
-    o_len = head["len"][order].astype(np.int64)
-    o_off = np.concatenate([[0], np.cumsum(o_len)])
-    parts = _runs(allseq, src_off, order)
-    o_bases = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
-    own = Cropped.create(rec[mine_piles], renum[head["pile"][order]], head["entry"][order], head["read"][order],
-                         o_off, o_bases)
+    own = shard_unpack_cropped(got, rec, owner, rank)
     lap("unpack + create")
     lrec, lbases = own.process(ctx, contigs_db, popts)
     lap("process")
@@ -280,7 +256,8 @@ def sharded_process_steps(ctx, contigs_db, reads_db, read_first, contig_off, las
         import sys
         print("[sharded rank 0] " + ", ".join(_laps), file=sys.stderr)
     order = np.argsort(grec["contig_left"], kind="stable")   # insertions.sort(): by start node
-    info = {"piles": len(rec), "owned": len(mine_piles), "candidates": int(sum(len(p) for p in per_rank)),
+    plan.close()
+    info = {"piles": len(rec), "owned": len(mine_piles), "candidates": int(ncand),
             "cropped_bytes_sent": int(sum(len(x) for x in per_dest)), "owner": owner}
     return grec[order], gbases, info
 

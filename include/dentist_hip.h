@@ -420,6 +420,31 @@ int32_t dh_cropped_npiles(const dh_cropped *c);
 /* per cropped read: 0 = it spans the gap, 1 = back extension of the left contig, 2 = front extension of the
  * right contig (entries with one alignment, see dh_scaffold_gap_pileups) */
 const uint8_t *dh_cropped_kind(const dh_cropped *c);
+
+/* ---- the host work of one rank between the collectives of the sharded path (one process per GPU): what LAmerge +
+ *      `dentist collect` + `process --batch` do through the file system in the reference (snakemake/Snakefile:
+ *      1173-1185, 1315-1334).  Blobs are what the caller hands to the collective as they are:
+ *        candidates  records of 104 bytes {int32 gap, int32 read, dh_la left, dh_la right} in (gap, read) order
+ *        cropped     int64 k, k x {int32 pile, entry, read, len}, then the k reads' bases back to back
+ *      dh_shard_pack_candidates  this rank's candidates (dh_collect_candidates / dh_map_reads) -> blob
+ *      dh_shard_plan_create      all ranks' blobs (rank order) -> the same pile-ups on every rank (entries of a gap by
+ *                                read id, min / max reads cut) and their owners (greedy bin-packing of n^2 L)
+ *      dh_shard_pack_cropped     the reads this rank cropped -> one blob per owner (one malloc, free blobs[0])
+ *      dh_shard_unpack_cropped   the blobs an owner received -> its cropped pile-ups for dh_process_cropped */
+typedef struct dh_shard_plan dh_shard_plan;
+void dh_shard_free(void *p);
+int dh_shard_pack_candidates(const dh_pileups *cands, const dh_la *las, int64_t n, int32_t read_shift, uint8_t **out,
+                             int64_t *nbytes);
+int dh_shard_plan_create(const uint8_t *const *blobs, const int64_t *sizes, int32_t world, const dh_process_opts *opts,
+                         dh_shard_plan **out);
+void dh_shard_plan_destroy(dh_shard_plan *p);
+const dh_la *dh_shard_plan_las(const dh_shard_plan *p);
+int64_t dh_shard_plan_nlas(const dh_shard_plan *p);
+const dh_pileups *dh_shard_plan_pileups(const dh_shard_plan *p);   /* owned by the plan */
+const int32_t *dh_shard_plan_owner(const dh_shard_plan *p);         /* one per pile-up of dh_shard_plan_pileups */
+int dh_shard_pack_cropped(dh_cropped *crop, const int32_t *owner, int32_t world, uint8_t **blobs, int64_t *sizes);
+int dh_shard_unpack_cropped(const uint8_t *const *blobs, const int64_t *sizes, int32_t world, const dh_insertion *rec,
+                            int32_t npiles, const int32_t *owner, int32_t rank, dh_cropped **out);
 const dh_insertion *dh_cropped_records(const dh_cropped *c);
 int32_t dh_cropped_nreads(const dh_cropped *c);
 const int32_t *dh_cropped_pile(const dh_cropped *c);     /* pile-up of every cropped read               */

@@ -127,3 +127,86 @@ def test_owner_assignment_and_candidate_merge_are_deterministic():
         got = yield ("all_to_all", [np.asarray([10 * rank + d], dtype=np.uint8) for d in range(2)])
         return s, [int(g[0]) for g in got]
     assert emulate_ranks([gen(0), gen(1)]) == [(3, [0, 10]), (3, [1, 11])]
+
+
+def test_cxx_shard_glue_equals_the_numpy_restatement():
+    """dh_shard_pack_candidates / dh_shard_plan_create / dh_shard_pack_cropped / dh_shard_unpack_cropped (the host
+    work of a rank between the collectives, C++) against pack_candidates / merge_candidates / select / pile_costs /
+    assign_owners and the Python packing (the restatement in dentist_amd/parallel.py) on random mappings."""
+    import dentist_amd
+    from dentist_amd import INSERTION_DTYPE, LA_DTYPE, Cropped, Pileups
+    from dentist_amd._lib import ShardPlan, shard_pack_candidates, shard_pack_cropped, shard_unpack_cropped
+    from dentist_amd.parallel import (CAND_DTYPE, CROP_DTYPE, assign_owners, merge_candidates, pack_candidates, pile_costs)
+    rng = np.random.default_rng(7)
+    ncontigs, world = 9, 3
+    clen = rng.integers(20000, 40000, ncontigs)
+    coff = np.concatenate([[0], np.cumsum(clen)]).astype(np.int64)
+    po = dentist_amd.default_process_opts(max_reads=5)
+    per_rank, blobs = [], []
+    for rank in range(world):
+        las = []
+        for rd in range(40):
+            g = int(rng.integers(0, ncontigs - 1))
+            comp = int(rng.integers(0, 2))
+            anchor = int(rng.integers(600, 5000))
+            L = np.zeros(1, dtype=LA_DTYPE)
+            R = np.zeros(1, dtype=LA_DTYPE)
+            L["aread"], L["bread"], L["flags"] = g, rd, comp
+            L["abpos"], L["aepos"] = clen[g] - anchor, clen[g] - int(rng.integers(0, 50))
+            L["bbpos"], L["bepos"], L["diffs"] = 10, 10 + anchor, int(rng.integers(0, anchor // 5))
+            R["aread"], R["bread"], R["flags"] = g + 1, rd, comp
+            R["abpos"], R["aepos"] = int(rng.integers(0, 50)), anchor
+            R["bbpos"], R["bepos"], R["diffs"] = 10 + anchor + int(rng.integers(0, 3000)), 30000, int(rng.integers(0, anchor // 5))
+            las += [L, R]
+        las = np.concatenate(las)
+        c = Pileups(las, coff, po, candidates=True)
+        shift = 40 * rank
+        exp = pack_candidates(c, las, shift)
+        got = shard_pack_candidates(c, las, shift)
+        assert got.tobytes() == exp.view(np.uint8).tobytes() and len(exp) > 20
+        per_rank.append(exp)
+        blobs.append(got)
+    glas, gaps, counts, triples = merge_candidates(per_rank)
+    piles = Pileups.from_flat(gaps, counts, triples).select(glas, po)
+    owner = assign_owners(pile_costs(piles, glas), world)
+    plan = ShardPlan(blobs, po)
+    assert np.array_equal(plan.las, glas) and np.array_equal(plan.owner, owner) and len(set(owner.tolist())) == world
+    a, b = plan.piles.flat(), piles.flat()
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and a[1].max() == 5
+    # cropped reads to their owners and back: every owner ends up with its pile-ups' reads in (pile, entry) order
+    npl = len(piles)
+    rec = np.zeros(npl, dtype=INSERTION_DTYPE)
+    rec["contig_left"] = a[0]
+    crops = []
+    for rank in range(world):   # rank r "cropped" the entries whose read id falls into its range
+        pile, entry, read, seqs = [], [], [], []
+        at = 0
+        for p_, n in enumerate(a[1]):
+            for e in range(n):
+                rd = int(a[2][at + e][0])
+                if rd // 40 == rank:
+                    pile.append(p_)
+                    entry.append(e)
+                    read.append(rd)
+                    seqs.append(rng.integers(0, 4, int(rng.integers(20, 60))).astype(np.uint8))
+            at += n
+        off = np.concatenate([[0], np.cumsum([len(x) for x in seqs])]).astype(np.int64)
+        crops.append((Cropped.create(rec, pile, entry, read, off, np.concatenate(seqs)), pile, entry, read, seqs))
+    sent = [shard_pack_cropped(c[0], owner, world) for c in crops]
+    for src, (c, pile, entry, read, seqs) in enumerate(crops):   # blob format = the Python packing
+        for dst in range(world):
+            sel = [i for i in range(len(pile)) if owner[pile[i]] == dst]
+            head = np.zeros(len(sel), dtype=CROP_DTYPE)
+            head["pile"], head["entry"], head["read"] = [pile[i] for i in sel], [entry[i] for i in sel], [read[i] for i in sel]
+            head["len"] = [len(seqs[i]) for i in sel]
+            exp = np.concatenate([np.asarray([len(sel)], dtype=np.int64).view(np.uint8), head.view(np.uint8)] + [seqs[i] for i in sel])
+            assert sent[src][dst].tobytes() == exp.tobytes()
+    for dst in range(world):
+        own = shard_unpack_cropped([sent[src][dst] for src in range(world)], rec, owner, dst)
+        orec, opile, oentry, oread, ooff, obases = own.arrays()
+        mine = np.nonzero(owner == dst)[0]
+        assert np.array_equal(orec["contig_left"], rec["contig_left"][mine])
+        assert np.all(np.diff(opile.astype(np.int64) * 1000 + oentry) > 0)
+        want = sum(int(a[1][p_]) for p_ in mine)
+        assert len(opile) == want and ooff[-1] == len(obases)
+    plan.close()
