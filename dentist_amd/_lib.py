@@ -556,11 +556,15 @@ class Pileups:
 
 
 # ---------------------------------------------------------------- sharded path: the host work between the collectives
+_KEEP = {}
+
+
 def _blob(ptr, n):
     """numpy copy of a malloc'd blob of the library."""
     if not n:
         return np.zeros(0, np.uint8)
-    return np.frombuffer(ctypes.string_at(ptr, n), dtype=np.uint8).copy()
+    addr = ptr.value if isinstance(ptr, ctypes.c_void_p) else int(ptr)
+    return np.frombuffer((ctypes.c_uint8 * n).from_address(addr), dtype=np.uint8).copy()   # one copy
 
 
 def shard_pack_candidates(cands, las, read_shift=0):
@@ -630,8 +634,27 @@ def shard_pack_cropped(crop, owner, world):
     L.dh_shard_pack_cropped.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
     L.dh_shard_free.argtypes = [ctypes.c_void_p]
     _check(L.dh_shard_pack_cropped(crop._h, ow.ctypes.data, world, ptrs, sizes))
-    out = [_blob(ptrs[r], sizes[r]) for r in range(world)]
-    L.dh_shard_free(ptrs[0])
+
+    class _Block:   # the one malloc'd block behind all the blobs: released with the last view
+        def __init__(self, p):
+            self.p = p
+
+        def __del__(self):
+            try:
+                lib().dh_shard_free(self.p)
+            except Exception:
+                pass
+    total = sum(int(sizes[r]) for r in range(world))
+    block = _Block(ptrs[0])
+    whole = np.frombuffer((ctypes.c_uint8 * max(total, 1)).from_address(ptrs[0]), dtype=np.uint8)
+    out, at = [], 0
+    for r in range(world):   # views, no copy: the collective (or torch.from_numpy) reads them in place
+        v = whole[at:at + int(sizes[r])]
+        at += int(sizes[r])
+        out.append(v)
+    _KEEP[id(whole)] = block
+    import weakref
+    weakref.finalize(whole, _KEEP.pop, id(whole), None)
     return out
 
 

@@ -1144,7 +1144,10 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     if (tiled) {
         int32_t per_cu = dhk_tile_waves_per_cu();
         if (const char *e = getenv("DH_TILE_WAVES_PER_CU")) per_cu = std::max(1, atoi(e));
-        tile_waves = (int32_t)std::min<int64_t>((int64_t)ctx->ncu * per_cu, (std::max<int64_t>(nitems_total, 1) + 63) / 64);
+        // (symmetric mode: the work units are groups of candidates, many per item -- a pile-up read meets every other
+        // read of its pile-up -- so the items do not bound the lanes that find work)
+        const int64_t lanes_wanted = o.skip_self == 2 ? nitems_total * (int64_t)o.max_cand : nitems_total;
+        tile_waves = (int32_t)std::min<int64_t>((int64_t)ctx->ncu * per_cu, (std::max<int64_t>(lanes_wanted, 1) + 63) / 64);
     }
     const int32_t cn = (int32_t)std::min<int64_t>(chunk, std::max<int64_t>(nitems_total, 2));
     DhCand *d_cand;
@@ -1322,6 +1325,8 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             tp.nunits = d_queue + 3;
             tp.item_ovf = d_ovf - item0;
             tp.tscr = d_tscr;
+            tp.book_min = 1;
+            if (const char *e = getenv("DH_TILE_BOOK_MIN")) tp.book_min = std::max(1, std::min(64, atoi(e)));
             tp.regs = d_regs;
             tp.cold = d_cold;
             tp.nbmax = nbmax;

@@ -56,6 +56,7 @@ struct Params {
     uint16_t *tscr;                   // symmetric mode: nlanes * trmax, the trace pairs of the alignment in flight
     int32_t *regs;                    // nlanes * MAXREG * REGF
     Cold *cold;                       // nlanes: the lanes' cold state
+    int32_t book_min;                 // lanes that must be waiting before a wavefront does a bookkeeping pass (k_tile)
     int32_t nbmax, trmax;             // pairs a direction can yield; u16 values per output slot (>= 2 * (2 * nbmax + 2))
     DhLa *out_la;                     // max_la records per item (absolute item index)
     uint16_t *out_trace;              // trmax values per record slot

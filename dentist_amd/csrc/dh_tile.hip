@@ -37,7 +37,11 @@ __global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
     lane_init(l, slot, P.cold + slot);
     Tile t;
     for (;;) {
-        // ---- bookkeeping until every lane extends or is out of work
+        // ---- bookkeeping until every lane extends or is out of work.  A pass costs a handful of dependent memory
+        // round trips whatever the number of lanes in it, so it waits until P.book_min lanes want one (or nothing
+        // else can run): short extensions (pile-up reads) would otherwise pay a pass on every round
+        const unsigned long long want = __builtin_amdgcn_ballot_w64(l.st != L_RUN && l.st != L_DONE);
+        if (want != 0ull && (__builtin_popcountll(want) >= P.book_min || !wave_any(l.st == L_RUN)))
         while (wave_any(l.st != L_RUN && l.st != L_DONE)) {
             if (l.st == L_EXT_END)
                 lane_ext_end(l, P);

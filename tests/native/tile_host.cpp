@@ -70,6 +70,7 @@ extern "C" long dh_tile_host_align(const uint8_t *abases, const int64_t *aoff, i
     P.cand = cand;
     P.ncand = ncand;
     P.queue = &queue;
+    P.book_min = 1;
     P.units = nullptr;
     P.nunits = nullptr;
     std::vector<int32_t> ovf((size_t)nitems, 0);
