@@ -216,21 +216,18 @@ def main():
         # the closed-gap records are the gathered result of all ranks (identical on every rank)
         gap_all, nclosed_all, edits_all, truth_all = closed_gap_stats(w, last["rec"], last["bases"])
         ms_step = dt / args.steps * 1e3
-        # dominant kernel of the step: the wave kernel (k_wave2; mapping launches + pile-up all-vs-all
-        # launch + the small re-alignment and flank launches).  Algorithmic bytes of a launch = both
-        # sequences of every alignment it emits streamed once (2 B per aligned A base at one byte per
-        # base) + its trace (2 B per trace value); summed over the step's launches and divided by
-        # their summed HIP-event durations, i.e. the per-launch average weighted by work
+        # extension kernels of the step (k_tile: mapping launches, pile-up all-vs-all, re-alignment, flanks; k_wave2 when
+        # an algo is 0).  Algorithmic bytes of a launch = both sequences of every alignment it emits streamed once
+        # (2 B per aligned A base at one byte per base) + its trace (2 B per trace value)
         achieved = alg_bytes / (wave_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "k_wave_traffic.json")
+        traffic = seed_traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r03_kernel_traffic.json")
         if os.path.exists(tpath) and world == 1:
             tj = json.load(open(tpath))
             if tj.get("workload") == args.workload and tj.get("mapping_kmer_mod") == args.kmer_mod and \
-                    tj.get("mapping_k") == args.map_k:
-                traffic = tj["hbm_bytes_per_step"] / max(1, cum["wave_launches"])
-        # one rolling pass per read serves both strands (canonical k-mers): 1 B per read base + one
-        # 64 B directory line per sampled k-mer
+                    tj.get("mapping_k") == args.map_k and tj.get("mapping_algo") == args.map_algo:
+                traffic = tj.get("k_tile_hbm_bytes_per_launch")
+                seed_traffic = tj.get("k_seed_hbm_bytes_per_launch")
         seed_bytes = 1.0 * read_bp * (1.0 + 64.0 / max(1, args.kmer_mod))
         seed_ms = mean(lambda r: r["ast"].ms_seed)
         out = {
@@ -266,23 +263,27 @@ def main():
                        "consensus_error_rate": (edits_all / truth_all) if truth_all else None},
             "read_bp_aligned_per_sec": aligned_all * args.steps / dt,
             "read_bp_aligned_per_sec_mapping_stage": aligned_all / mean(lambda r: r["t_map"]),
-            "roofline": {"bound": "hbm", "kernel": "k_wave2", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "launches_per_step": cum["wave_launches"], "kernel_ms_per_step": wave_ms,
-                         "avg_launch_ms": wave_ms / max(1, cum["wave_launches"]),
-                         "algorithmic_bytes_per_step": alg_bytes,
-                         "wave_cells_per_s": cum["wave_cells"] / (wave_ms * 1e-3),
-                         "note": "rank 0's launches; integer VALU-issue bound by nature (SURVEY 7d): DP cell "
-                                 "updates/s is the honest secondary"},
-            # second kernel of the step: the seed filter of the mapping launches is bound by random
-            # 64-byte directory lines: per read base and strand 1 B of sequence
-            # + one 64 B line per sampled k-mer; the measured ceiling of random 64 B lines on this
-            # part is ~3.0-3.5 TB/s at working sets of 1-16 GB (scripts/rand_access_probe.cpp)
-            "roofline_seed": {"bound": "hbm", "kernel": "k_seed (mapping launches)",
-                              "achieved": seed_bytes / (seed_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": seed_bytes / (seed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                              "algorithmic_bytes_per_step": seed_bytes, "kernel_ms_per_step": seed_ms,
-                              "measured_random_line_ceiling_GBs": 3200.0},
+            # dominant kernel of the step: the seed filter (k_seed) of the mapping launches.  It is bound by random
+            # 64-byte lines: per read base 1 B of sequence, per sampled canonical k-mer one 64 B
+            # directory line, one pass for both strands; the ceiling of random 64 B lines measured on this part is
+            # 3.0-3.2 TB/s at working sets of 1-16 GB (scripts/rand_access_probe.cpp)
+            "roofline": {"bound": "hbm", "kernel": "k_seed (mapping launches)",
+                         "achieved": seed_bytes / (seed_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": seed_bytes / (seed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": seed_traffic,
+                         "launches_per_step": int(last["ast"].wave_launches), "kernel_ms_per_step": seed_ms,
+                         "avg_launch_ms": seed_ms / max(1, int(last["ast"].wave_launches)),
+                         "algorithmic_bytes_per_step": seed_bytes,
+                         "measured_random_line_ceiling_GBs": 3200.0},
+            # second: the extension kernel, one alignment per lane.  VALU bound (scripts/valu_probe.cpp: 2-cycle class
+            # 0.90-0.94, 4-cycle class 0.56-0.58 G wave-instructions/s per SIMD); the HBM fraction is reported as asked
+            "roofline_tile": {"bound": "hbm", "kernel": "k_tile" if args.map_algo == 1 else "k_wave2", "achieved": achieved,
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                              "launches_per_step": cum["wave_launches"], "kernel_ms_per_step": wave_ms,
+                              "avg_launch_ms": wave_ms / max(1, cum["wave_launches"]),
+                              "algorithmic_bytes_per_step": alg_bytes,
+                              "band_cells_per_s": cum["wave_cells"] / (wave_ms * 1e-3),
+                              "note": "rank 0's launches; integer VALU-issue bound: 70 wave-instructions per 64 band "
+                                      "columns, DP cell updates/s is the honest secondary"},
             "stages_ms": {"map_wall": mean(lambda r: r["t_map"]) * 1e3,
                           "map_index": mean(lambda r: r["ast"].ms_index),
                           "map_seed": seed_ms,
@@ -329,6 +330,12 @@ def cpu_baseline(w, last, mopts, popts, args, gap_bases, read_bp_total):
     n_map = int(min(w.reads.n, max(4 * cores, 0.15 * args.cpu_seconds * rate / (read_bp_total / max(w.nreads_total, 1)))))
     t_map, bp_map = map_reads(n_map)
     map_bp_s = bp_map / max(t_map - t_index, 1e-3)   # marginal rate, index build excluded
+    # spread of the mapping rate: two more samples of a third of the size (different reads would need another DB:
+    # the same reads are re-mapped, so this is the timing noise of the box, not of the data)
+    rates = [map_bp_s]
+    for _ in range(2):
+        t_s, bp_s = map_reads(max(4 * cores, n_map // 3))
+        rates.append(bp_s / max(t_s - t_index, 1e-3))
 
     rec, las_all = last["rec"], last["las"]
     npiles = int(last["info"]["piles"])
@@ -354,7 +361,9 @@ def cpu_baseline(w, last, mopts, popts, args, gap_bases, read_bp_total):
     est_map, est_proc = t_index + read_bp_total / map_bp_s, per_pile * npiles
     return {"value": gap_bases / (est_map + est_proc), "unit": "gap-bp/s", "cores": cores, "kind": "port",
             "label": "CPU restatement of the same algorithm (C + OpenMP) -- not the reference binaries",
-            "read_bp_mapped_per_sec": map_bp_s, "index_build_s": t_index,
+            "read_bp_mapped_per_sec": map_bp_s, "read_bp_mapped_per_sec_per_core": map_bp_s / cores,
+            "read_bp_mapped_per_sec_samples": rates, "pile_ups_per_sec_per_core": 1.0 / max(per_pile, 1e-9) / cores,
+            "index_build_s": t_index,
             "pile_ups_per_sec": 1.0 / max(per_pile, 1e-9),
             "estimated_seconds": {"mapping": est_map, "process": est_proc},
             "sample": f"index of the whole assembly ({t_index:.1f} s); {n_map} reads / {bp_map} bp mapped in "
