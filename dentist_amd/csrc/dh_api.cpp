@@ -776,6 +776,23 @@ static bool la_less(const dh_la &p, const dh_la &q)
 // unless a higher-scoring LA of the same read and orientation covers more than half of it on B
 // (consumer: dazzler.d:1728-1758 reads START without BEST as alternateChain).
 // `la` must be grouped by bread (the kernels emit it that way).
+// damapper's chain flags (consumer: source/dentist/dazzler.d:1728-1758, 1991-1998).  Per read:
+//   1. the local alignments on one contig and strand, ordered by their A interval, are linked into chains: an LA
+//      continues the chain of its predecessor when it lies after it on both sequences (up to CHAIN_OVERLAP bases of
+//      overlap), the gaps are at most CHAIN_GAP on either sequence and differ by at most CHAIN_INDEL (a read that
+//      carries a long indel maps as two collinear LAs -- SURVEY section 7, K6);
+//   2. score of a chain = sum of (A length - 2 * diffs) of its LAs;
+//   3. a chain is the BEST one of its stretch of the read unless a higher-scoring chain of the same strand (ties:
+//      the one whose first LA sorts later in LAsort order) covers more than half of its B span;
+//   4. flags: START on the first LA of a chain, NEXT on the others, BEST on every LA of a best chain; START without
+//      BEST reads as `alternateChain`.  near_best_ppm > 0 (damapper -n): an alternate chain scoring less than that
+//      fraction of the chain that beats it is DISABLED (damapper does not report it).
+#define CHAIN_GAP 10000
+#define CHAIN_INDEL 6000
+#define CHAIN_OVERLAP 100
+static int32_t g_near_best_ppm = 0;
+extern "C" void dh_set_near_best(int32_t ppm) { g_near_best_ppm = ppm < 0 ? 0 : ppm; }
+
 static void select_best_range(dh_la *la, size_t nla)
 {
     // groups of equal bread are independent: host threads take runs of groups
@@ -783,22 +800,61 @@ static void select_best_range(dh_la *la, size_t nla)
     for (size_t i = 0; i < nla; i++)
         if (i == 0 || la[i].bread != la[i - 1].bread) gstart.push_back(i);
     gstart.push_back(nla);
+    const int32_t near_ppm = g_near_best_ppm;
     dh_parallel_for((int64_t)gstart.size() - 1, 2048, [&](int64_t glo, int64_t ghi) {
+        struct Chain {
+            int64_t score;
+            int32_t bb, be, comp;
+            size_t first;
+            std::vector<size_t> members;
+        };
+        std::vector<size_t> ord;
+        std::vector<Chain> chains;
         for (int64_t g = glo; g < ghi; g++) {
             const size_t g0 = gstart[(size_t)g], g1 = gstart[(size_t)g + 1];
-            for (size_t x = g0; x < g1; x++) la[x].flags |= DH_FLAG_START | DH_FLAG_BEST;
-            for (size_t x = g0; x < g1; x++) {
-                dh_la &p = la[x];
-                const int64_t ps = (int64_t)(p.aepos - p.abpos) - 2 * (int64_t)p.diffs;
-                for (size_t y = g0; y < g1; y++) {
+            ord.clear();
+            for (size_t x = g0; x < g1; x++) ord.push_back(x);
+            std::sort(ord.begin(), ord.end(), [&](size_t x, size_t y) { return la_less(la[x], la[y]); });  // (a, b, comp, abpos, ...)
+            chains.clear();
+            for (size_t k = 0; k < ord.size(); k++) {
+                const dh_la &q = la[ord[k]];
+                bool linked = false;
+                if (!chains.empty()) {
+                    Chain &c = chains.back();
+                    const dh_la &p = la[c.members.back()];
+                    const int64_t ga = (int64_t)q.abpos - p.aepos, gb = (int64_t)q.bbpos - p.bepos;
+                    linked = p.aread == q.aread && (p.flags & DH_FLAG_COMP) == (q.flags & DH_FLAG_COMP) && ga >= -CHAIN_OVERLAP &&
+                             gb >= -CHAIN_OVERLAP && ga <= CHAIN_GAP && gb <= CHAIN_GAP && std::llabs(ga - gb) <= CHAIN_INDEL &&
+                             q.aepos > p.aepos && q.bepos > p.bepos;
+                    if (linked) {
+                        c.members.push_back(ord[k]);
+                        c.score += (int64_t)(q.aepos - q.abpos) - 2 * (int64_t)q.diffs;
+                        c.be = q.bepos;
+                    }
+                }
+                if (!linked)
+                    chains.push_back(Chain{(int64_t)(q.aepos - q.abpos) - 2 * (int64_t)q.diffs, q.bbpos, q.bepos,
+                                           (int32_t)(q.flags & DH_FLAG_COMP), ord[k], {ord[k]}});
+            }
+            for (size_t x = 0; x < chains.size(); x++) {
+                const Chain &p = chains[x];
+                bool best = true, drop = false;
+                for (size_t y = 0; y < chains.size(); y++) {
                     if (x == y) continue;
-                    const dh_la &q = la[y];
-                    const int64_t qs = (int64_t)(q.aepos - q.abpos) - 2 * (int64_t)q.diffs;
-                    // ties: the LA that sorts later (LAsort order) wins
-                    if (qs < ps || (qs == ps && la_less(q, p))) continue;
-                    if ((q.flags & DH_FLAG_COMP) != (p.flags & DH_FLAG_COMP)) continue;
-                    const int32_t lo = std::max(p.bbpos, q.bbpos), hi = std::min(p.bepos, q.bepos);
-                    if (hi - lo > (p.bepos - p.bbpos) / 2) p.flags &= ~DH_FLAG_BEST;
+                    const Chain &q = chains[y];
+                    // ties: the chain whose first LA sorts later (LAsort order) wins
+                    if (q.score < p.score || (q.score == p.score && la_less(la[q.first], la[p.first]))) continue;
+                    if (q.comp != p.comp) continue;
+                    const int32_t lo = std::max(p.bb, q.bb), hi = std::min(p.be, q.be);
+                    if (hi - lo > (p.be - p.bb) / 2) {
+                        best = false;
+                        if (near_ppm > 0 && p.score * 1000000ll < (int64_t)near_ppm * q.score) drop = true;
+                    }
+                }
+                for (size_t m = 0; m < p.members.size(); m++) {
+                    dh_la &l = la[p.members[m]];
+                    l.flags &= ~(DH_FLAG_START | DH_FLAG_NEXT | DH_FLAG_BEST);
+                    l.flags |= (m == 0 ? DH_FLAG_START : DH_FLAG_NEXT) | (best ? DH_FLAG_BEST : 0u) | (drop ? DH_FLAG_DISABLED : 0u);
                 }
             }
         }

@@ -157,6 +157,12 @@ int dh_get_cum_stats(dh_ctx *ctx, dh_cum_stats *out, int32_t reset);
  */
 int dh_align_db(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, int32_t select_best,
                 dh_la_set **out);
+/* select_best: damapper's chains.  The LAs of a read on one contig and strand that follow each other (gaps <= 10 kb,
+ * gap difference <= 6 kb: a long indel splits a mapping into collinear LAs) form a chain: START (0x4) on its first
+ * LA, NEXT (0x8) on the others, BEST (0x10) on the LAs of the chain that no higher-scoring chain of the strand covers
+ * by more than half (consumer: dazzler.d:1728-1758).  dh_set_near_best(ppm) is damapper's -n: alternate chains scoring
+ * less than that fraction of the chain that beats them are DISABLED; 0 (default) keeps every chain. */
+void dh_set_near_best(int32_t ppm);
 
 /* One read block against the whole reference, the unit the workflow shards the mapping by
  * (`damapper <ref> <reads>.<block>`, snakemake/Snakefile:1143-1170; blocks = DBsplit ranges of one

@@ -1122,31 +1122,98 @@ int oz_align_db(const oz_db *A, const oz_db *B, const oz_opts *o, int nthreads, 
 }
 
 /*
- * damapper-style selection per B read: every LA is a chain of its own (START); the LA is the
- * BEST chain of its read segment unless a higher-scoring LA of the same read overlaps more than
- * half of it on B.  Consumer semantics: source/dentist/dazzler.d:1728-1758 (START without BEST
- * is read as `alternateChain`).  Expects LAs grouped by bread (any order inside the group).
+ * damapper's chain flags per B read (consumer semantics: source/dentist/dazzler.d:1728-1758, flags :1991-1998).
+ * The LAs of a read on one contig and strand, ordered as LAsort orders them, are linked into chains: an LA continues
+ * its predecessor's chain when it follows it on both sequences (at most 100 bases of overlap, both ends further on),
+ * the gaps are at most 10 000 on either sequence and differ by at most 6 000 (a long indel splits a mapping into
+ * collinear LAs).  Chain score = sum(alen - 2 diffs).  A chain is BEST unless a higher-scoring chain of the same strand
+ * (ties: the one whose first LA sorts later) covers more than half of its B span.  START on the first LA, NEXT on the
+ * others, BEST on all LAs of a best chain; near_best_ppm > 0 (damapper -n): an alternate chain below that fraction of
+ * the chain that beats it is DISABLED.  Expects LAs grouped by bread (any order inside the group).
  */
+static int32_t oz_near_best_ppm = 0;
+void oz_set_near_best(int32_t ppm) { oz_near_best_ppm = ppm < 0 ? 0 : ppm; }
+
+typedef struct {
+    int64_t score;
+    int32_t bb, be, comp, n;
+    int64_t first, last;
+    int64_t mem0; /* index of the first member in the members array */
+} oz_chain;
+
+static const oz_la *cmp_base_;
+static int idx_cmp_(const void *x, const void *y)
+{
+    return la_cmp(&cmp_base_[*(const int64_t *)x], &cmp_base_[*(const int64_t *)y]);
+}
+
 void oz_select_best(oz_la_set *s)
 {
-    for (int64_t i = 0; i < s->n; i++) s->la[i].flags |= OZ_FLAG_START | OZ_FLAG_BEST;
-    for (int64_t i = 0; i < s->n; i++) {
-        const oz_la *p = &s->la[i];
-        const int64_t pscore = (int64_t)(p->aepos - p->abpos) - 2 * (int64_t)p->diffs;
-        /* B coordinates of complemented LAs are relative to the reverse complement */
-        for (int64_t j = 0; j < s->n; j++) {
-            if (i == j) continue;
-            const oz_la *q = &s->la[j];
-            if (q->bread != p->bread) continue;
-            const int64_t qscore = (int64_t)(q->aepos - q->abpos) - 2 * (int64_t)q->diffs;
-            /* ties: the LA that sorts later in LAsort order wins */
-            if (qscore < pscore || (qscore == pscore && la_cmp(q, p) < 0)) continue;
-            /* compare on the forward strand of B: need read length -> not available here, so
-             * only LAs of the same orientation compete (different orientation = other locus) */
-            if ((q->flags & OZ_FLAG_COMP) != (p->flags & OZ_FLAG_COMP)) continue;
-            int32_t lo = p->bbpos > q->bbpos ? p->bbpos : q->bbpos;
-            int32_t hi = p->bepos < q->bepos ? p->bepos : q->bepos;
-            if (hi - lo > (p->bepos - p->bbpos) / 2) s->la[i].flags &= ~OZ_FLAG_BEST;
+    int64_t g0 = 0;
+    while (g0 < s->n) {
+        int64_t g1 = g0;
+        while (g1 < s->n && s->la[g1].bread == s->la[g0].bread) g1++;
+        const int64_t m = g1 - g0;
+        int64_t *ord = (int64_t *)malloc((size_t)m * sizeof(int64_t));
+        int64_t *mem = (int64_t *)malloc((size_t)m * sizeof(int64_t));
+        oz_chain *ch = (oz_chain *)malloc((size_t)m * sizeof(oz_chain));
+        for (int64_t x = 0; x < m; x++) ord[x] = g0 + x;
+        cmp_base_ = s->la;
+        qsort(ord, (size_t)m, sizeof(int64_t), idx_cmp_);
+        int64_t nc = 0, nm = 0;
+        for (int64_t k = 0; k < m; k++) {
+            const oz_la *q = &s->la[ord[k]];
+            int linked = 0;
+            if (nc > 0) {
+                oz_chain *c = &ch[nc - 1];
+                const oz_la *p = &s->la[c->last];
+                const int64_t ga = (int64_t)q->abpos - p->aepos, gb = (int64_t)q->bbpos - p->bepos;
+                const int64_t dg = ga > gb ? ga - gb : gb - ga;
+                linked = p->aread == q->aread && (p->flags & OZ_FLAG_COMP) == (q->flags & OZ_FLAG_COMP) && ga >= -100 &&
+                         gb >= -100 && ga <= 10000 && gb <= 10000 && dg <= 6000 && q->aepos > p->aepos && q->bepos > p->bepos;
+                if (linked) {
+                    mem[nm++] = ord[k];
+                    c->n++;
+                    c->last = ord[k];
+                    c->score += (int64_t)(q->aepos - q->abpos) - 2 * (int64_t)q->diffs;
+                    c->be = q->bepos;
+                }
+            }
+            if (!linked) {
+                oz_chain *c = &ch[nc++];
+                c->score = (int64_t)(q->aepos - q->abpos) - 2 * (int64_t)q->diffs;
+                c->bb = q->bbpos;
+                c->be = q->bepos;
+                c->comp = (int32_t)(q->flags & OZ_FLAG_COMP);
+                c->n = 1;
+                c->first = c->last = ord[k];
+                c->mem0 = nm;
+                mem[nm++] = ord[k];
+            }
         }
+        for (int64_t x = 0; x < nc; x++) {
+            const oz_chain *p = &ch[x];
+            int best = 1, drop = 0;
+            for (int64_t y = 0; y < nc; y++) {
+                if (x == y) continue;
+                const oz_chain *q = &ch[y];
+                if (q->score < p->score || (q->score == p->score && la_cmp(&s->la[q->first], &s->la[p->first]) < 0)) continue;
+                if (q->comp != p->comp) continue;
+                const int32_t lo = p->bb > q->bb ? p->bb : q->bb, hi = p->be < q->be ? p->be : q->be;
+                if (hi - lo > (p->be - p->bb) / 2) {
+                    best = 0;
+                    if (oz_near_best_ppm > 0 && p->score * 1000000ll < (int64_t)oz_near_best_ppm * q->score) drop = 1;
+                }
+            }
+            for (int32_t k = 0; k < p->n; k++) {
+                oz_la *l = &s->la[mem[p->mem0 + k]];
+                l->flags &= ~(OZ_FLAG_START | OZ_FLAG_NEXT | OZ_FLAG_BEST);
+                l->flags |= (k == 0 ? OZ_FLAG_START : OZ_FLAG_NEXT) | (best ? OZ_FLAG_BEST : 0u) | (drop ? OZ_FLAG_DISABLED : 0u);
+            }
+        }
+        free(ord);
+        free(mem);
+        free(ch);
+        g0 = g1;
     }
 }

@@ -133,6 +133,7 @@ int oz_align_db(const oz_db *A, const oz_db *B, const oz_opts *o, int nthreads, 
 
 /* damapper-style per-read selection: sets START/BEST flags (dazzler.d:1728-1758 consumer) */
 void oz_select_best(oz_la_set *s);
+void oz_set_near_best(int32_t ppm); /* damapper -n as parts per million, 0 = keep every chain */
 
 /* ---------- .las codec ---------- */
 int oz_las_write(const char *path, const oz_la_set *s, int32_t tspace);

@@ -115,3 +115,51 @@ def test_rejections(gpu_ctx):
     dn = gpu_ctx.db(sim.SeqDb.from_list([gn]))
     with pytest.raises(dentist_amd.DhError):
         gpu_ctx.align_db(dn, db, dentist_amd.default_align_opts(**T))
+
+
+def test_damapper_chains_of_reads_with_a_long_indel(gpu_ctx):
+    """damapper's chain flags (dazzler.d:1728-1758, 1991-1998): a read that carries a 2-5 kb indel against its contig
+    maps as two collinear local alignments -- one chain: START|BEST on the first, NEXT on the second; an alternate
+    placement of a read is a chain of its own (START without BEST = alternateChain); -n (dh_set_near_best) disables
+    alternates far below the best chain.  Product == oracle."""
+    rng = np.random.default_rng(77)
+    g = sim.genome(101, 400_000)
+    contigs = sim.SeqDb.from_list([g[:200_000], g[200_000:]])
+    reads, truth = sim.reads(102, g, 60, 12_000)
+    seqs = [reads.seq(i) for i in range(reads.n)]
+    planted = []
+    for i in range(0, 24, 2):      # deletions in the read (contig bases missing) and insertions (foreign bases in the read)
+        s = seqs[i]
+        cut, ln = len(s) // 2, int(rng.integers(2000, 5000))
+        if i % 4 == 0 and len(s) > cut + ln + 3000:
+            seqs[i] = np.concatenate([s[:cut], s[cut + ln:]])
+        else:
+            seqs[i] = np.concatenate([s[:cut], rng.integers(0, 4, ln).astype(np.uint8), s[cut:]])
+        planted.append(i)
+    reads2 = sim.SeqDb.from_list(seqs)
+    g_, o = __import__("test_parity_map_gpu").both_opts(k=20, kmer_mod=2, **T)
+    A, B = gpu_ctx.db(contigs), gpu_ctx.db(reads2)
+    for ppm in (0, 850000):
+        lib = dentist_amd.lib()
+        lib.dh_set_near_best(ppm)
+        oz.lib().oz_set_near_best(ppm)
+        try:
+            las, trace = gpu_ctx.align_db(A, B, g_, select_best=True)
+            exp = oz.align_db(contigs, reads2, o, nthreads=os.cpu_count() or 1, select_best=True)
+        finally:
+            lib.dh_set_near_best(0)
+            oz.lib().oz_set_near_best(0)
+        assert_same_las((las, trace), exp[:2])
+        chained = 0
+        for i in planted:
+            mine = las[las["bread"] == i]
+            st = mine[(mine["flags"] & 0x4) != 0]
+            nx = mine[(mine["flags"] & 0x8) != 0]
+            if truth[i][0] < 200_000 - 12_000 or truth[i][0] > 200_000:   # the read lies inside one contig
+                if len(nx) >= 1:
+                    chained += 1
+                    assert np.all((nx["flags"] & 0x10) != 0) and np.any((st["flags"] & 0x10) != 0)
+                    assert np.all((mine["flags"] & (0x4 | 0x8)) != (0x4 | 0x8))
+        assert chained >= 6
+        plain = las[~np.isin(las["bread"], planted)]
+        assert np.all((plain["flags"] & 0x4) != 0) or np.any((plain["flags"] & 0x8) != 0)

@@ -44,8 +44,18 @@ def test_damapper_executable_matches_the_library(gpu_ctx, tmp_path):
     las, trace, ts = dentist_amd.las_read(str(tmp_path / "ref.reads.1.las"))
     assert ts == 100
     A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
-    exp = gpu_ctx.align_db(A, B, dentist_amd.default_align_opts(), select_best=True)
+
+    def library(Adb):
+        """What the executable runs: DH-2 (tiled band), chains with damapper's default -n.85, discarded chains not written."""
+        dentist_amd.lib().dh_set_near_best(850000)
+        try:
+            el, et = gpu_ctx.align_db(Adb, B, dentist_amd.default_align_opts(algo=1, width=64), select_best=True)
+        finally:
+            dentist_amd.lib().dh_set_near_best(0)
+        return el[(el["flags"] & 0x20) == 0], et
+    exp = library(A)
     assert_same_las((las, trace), exp)
+    assert np.all((las["flags"] & (0x4 | 0x8)) != 0)   # every record is part of a chain
     assert os.path.exists(tmp_path / "reads.1.ref.las")
     back, _, _ = dentist_amd.las_read(str(tmp_path / "reads.1.ref.las"))
     assert len(back) > 0 and set(back["aread"].tolist()) <= set(range(w.reads.n))
@@ -63,7 +73,7 @@ def test_damapper_executable_matches_the_library(gpu_ctx, tmp_path):
     assert "`tan` not found for ref" in r.stderr and "`dentist-self` not found for ref" not in r.stderr, r.stderr
     w.contigs.mask = (ptr, np.asarray(iv, dtype=np.int32))
     Am = gpu_ctx.db(w.contigs)
-    expm = gpu_ctx.align_db(Am, B, dentist_amd.default_align_opts(), select_best=True)
+    expm = library(Am)
     lasm, tracem, _ = dentist_amd.las_read(str(tmp_path / "ref.reads.1.las"))
     assert_same_las((lasm, tracem), expm)
     # a missing DB is an error with a non-zero exit status (DazzlerCommandException, dazzler.d:6586-6591)

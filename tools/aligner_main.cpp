@@ -107,12 +107,17 @@ static OpenDb open_db(dh_ctx *ctx, const std::string &arg, const std::vector<std
 static void write_las(const std::string &path, dh_la_set *set, int afirst, int bfirst, int tspace)
 {
     const int64_t n = dh_la_set_count(set);
-    std::vector<dh_la> las(dh_la_set_records(set), dh_la_set_records(set) + n);
-    for (dh_la &l : las) {
+    // chains that damapper's -n rule discards come back DISABLED: they are not written
+    std::vector<dh_la> las;
+    las.reserve((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        dh_la l = dh_la_set_records(set)[i];
+        if (l.flags & DH_FLAG_DISABLED) continue;
         l.aread += afirst;
         l.bread += bfirst;
+        las.push_back(l);
     }
-    CHK(dh_las_write(path.c_str(), las.data(), n, dh_la_set_trace(set), tspace));
+    CHK(dh_las_write(path.c_str(), las.data(), (int64_t)las.size(), dh_la_set_trace(set), tspace));
 }
 
 int main(int argc, char **argv)
@@ -123,7 +128,7 @@ int main(int argc, char **argv)
     dh_align_opts o;
     dh_default_align_opts(&o);
     bool flagA = false, flagI = false, flagC = false, verbose = false;
-    double e = 0.7;
+    double e = 0.7, near_best = 0.85;  // damapper -n default
     std::vector<std::string> dbs, tracks;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
@@ -151,7 +156,8 @@ int main(int argc, char **argv)
         case 'v': verbose = true; break;
         case 'm': tracks.push_back(v); break;
         case 'T': case 'P': case 'M': break;  // threads / temp dir / memory: no meaning on the device
-        case 'B': case 'b': case 'p': case 'n': case 'z': case 'H':
+        case 'n': near_best = atof(v); break;
+        case 'B': case 'b': case 'p': case 'z': case 'H':
             // accepted for DENTIST's argv, but not implemented: say so instead of silently differing
             fprintf(stderr, "%s: option %s is accepted but has no effect in this implementation\n", mode.c_str(), a.c_str());
             break;
@@ -164,6 +170,13 @@ int main(int argc, char **argv)
     o.max_err_ppm = (int)llround((1.0 - e) * 1e6);
     const bool mapper = mode.find("damapper") != std::string::npos;
     if (mapper && o.min_len == 500 && o.tspace == 100) o.min_len = 500;
+    if (mapper) {
+        // damapper: the tiled band extension (one alignment per lane) and chains with the -n near-best rule
+        o.algo = 1;
+        o.width = 64;
+        if (near_best < 0 || near_best > 1) die(mode + ": -n must be in [0, 1]");
+        dh_set_near_best((int32_t)llround(near_best * 1e6));
+    }
 
     dh_ctx *ctx = nullptr;
     CHK(dh_ctx_create(0, nullptr, &ctx));
