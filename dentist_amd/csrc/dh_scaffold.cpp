@@ -13,6 +13,9 @@
 // the skipping reads with the external tools and is not part of this builder: the forks of a bubble go
 // through the read-support rule like any other fork.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <array>
 #include <atomic>
 #include <cstring>
@@ -70,8 +73,16 @@ struct Ctx {
     int32_t blen(const dh_la &l) const { return (int32_t)(roff[l.bread + 1] - roff[l.bread]); }
 };
 
+// one read alignment with the edge it contributes to: plain data, so that a run of reads yields one flat array
+// (no allocation per join); runs are turned into edges by raw_to_edges
+struct RawJoin {
+    Node s, e;
+    dh_read_alignment ra;
+};
+
 // collectReadAlignments for the enabled LAs idx[0..cnt) of one read, appended to `out` as raw joins
-void read_joins(const Ctx &c, const int64_t *idx, int64_t cnt, std::vector<Edge> &out, std::vector<SA> &sa)
+void read_joins(const Ctx &c, const int64_t *idx, int64_t cnt, std::vector<RawJoin> &out, std::vector<SA> &sa,
+                std::vector<std::pair<size_t, size_t>> &sl)
 {
     sa.clear();
     for (int64_t x = 0; x < cnt; x++) {
@@ -92,7 +103,7 @@ void read_joins(const Ctx &c, const int64_t *idx, int64_t cnt, std::vector<Edge>
         if (sa[i].e > sa[i + 1].b && !(sa[i].la == sa[i + 1].la && sa[i].seed != sa[i + 1].seed)) return;  // a region of the read used twice
     const bool start_ext = sa[0].b > 0;
     // slices [0,1) if the read starts with an extension, then pairs
-    std::vector<std::pair<size_t, size_t>> sl;
+    sl.clear();
     if (start_ext) sl.emplace_back(0, 1);
     for (size_t i = start_ext ? 1 : 0; i < sa.size(); i += 2) sl.emplace_back(i, std::min(i + 2, sa.size()));
     for (auto &p : sl)  // one invalid read alignment discards the read
@@ -121,9 +132,25 @@ void read_joins(const Ctx &c, const int64_t *idx, int64_t cnt, std::vector<Edge>
             e = a.seed == FRONT ? make_edge(Node{ct, PRE}, Node{ct, BEGIN}) : make_edge(Node{ct, END}, Node{ct, POST});
         }
         ra.read = c.las[ra.la0].bread;
-        e.types = T_PILEUP;
-        e.ras.push_back(ra);
-        out.push_back(std::move(e));
+        out.push_back(RawJoin{e.s, e.e, ra});
+    }
+}
+
+// the raw joins of a run of reads as edges: equal edges merged, their read alignments in input (= read) order
+void raw_to_edges(std::vector<RawJoin> &raw, std::vector<Edge> &out)
+{
+    std::stable_sort(raw.begin(), raw.end(), [](const RawJoin &a, const RawJoin &b) { return a.s == b.s ? a.e < b.e : a.s < b.s; });
+    for (size_t i = 0; i < raw.size();) {
+        size_t j = i + 1;
+        while (j < raw.size() && raw[j].s == raw[i].s && raw[j].e == raw[i].e) j++;
+        Edge m;
+        m.s = raw[i].s;
+        m.e = raw[i].e;
+        m.types = T_PILEUP;
+        m.ras.reserve(j - i);
+        for (size_t x = i; x < j; x++) m.ras.push_back(raw[x].ra);
+        out.push_back(std::move(m));
+        i = j;
     }
 }
 
@@ -186,6 +213,8 @@ extern "C" int dh_scaffold_pileups(const dh_la *las, int64_t n, const int64_t *c
         n >= (1ll << 31) || (ngaps > 0 && !input_gaps) || ngaps < 0)
         return dh_fail(DH_EINVAL, "dh_scaffold_pileups: bad argument");
     const Ctx c{las, contig_off, read_off};
+    auto T0_ = std::chrono::steady_clock::now();
+    auto LAP_ = [&](const char *w) { if (getenv("DH_TRACE")) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[scaffold] %-24s %.2f ms\n", w, std::chrono::duration<double, std::milli>(t - T0_).count()); T0_ = t; } };
     // ---- the enabled LAs grouped by read, input order inside a read
     std::atomic<int> bad{0};
     const int64_t lgrain = 1 << 16, lchunks = (n + lgrain - 1) / lgrain;
@@ -218,19 +247,27 @@ extern "C" int dh_scaffold_pileups(const dh_la *las, int64_t n, const int64_t *c
             for (const auto &e : v) order[(size_t)cur[(size_t)e.first]++] = e.second;
     }
     live.clear();
+    LAP_("group by read");
     // ---- raw joins of the reads, in read order (collectScaffoldJoins, pileups.d:650-667)
-    const int64_t grain = 8192, nchunks = ((int64_t)nreads + grain - 1) / grain;
+    // (every host thread also merges the equal edges of its run of reads: the stable sort keeps the reads of an
+    // edge in read order, and the serial merge below then handles a few thousand edges instead of one per read)
+    const int64_t grain = std::max<int64_t>(8192, ((int64_t)nreads + 15) / 16), nchunks = ((int64_t)nreads + grain - 1) / grain;
     std::vector<std::vector<Edge>> found((size_t)std::max<int64_t>(nchunks, 1));
     dh_parallel_for(nchunks, 1, [&](int64_t clo, int64_t chi) {
         std::vector<SA> sa;
+        std::vector<std::pair<size_t, size_t>> sl;
+        std::vector<RawJoin> raw;
         for (int64_t ch = clo; ch < chi; ch++) {
             const int32_t r1 = (int32_t)std::min<int64_t>(nreads, (ch + 1) * grain);
+            raw.clear();
             for (int32_t rd = (int32_t)(ch * grain); rd < r1; rd++) {
                 const int64_t cnt = first[(size_t)rd + 1] - first[(size_t)rd];
-                if (cnt > 0) read_joins(c, order.data() + first[(size_t)rd], cnt, found[(size_t)ch], sa);
+                if (cnt > 0) read_joins(c, order.data() + first[(size_t)rd], cnt, raw, sa, sl);
             }
+            raw_to_edges(raw, found[(size_t)ch]);
         }
     });
+    LAP_("read joins");
     // ---- the scaffold: default edges, read joins, input gaps (buildScaffold, scaffold.d:237-244)
     std::vector<Edge> g;
     for (int32_t ct = 0; ct < ncontigs; ct++) g.push_back(make_edge(Node{ct, BEGIN}, Node{ct, END}));
@@ -244,6 +281,7 @@ extern "C" int dh_scaffold_pileups(const dh_la *las, int64_t n, const int64_t *c
     }
     merge_multi_edges(g);
     remove_none_joins(g);
+    LAP_("graph merge");
     // ---- discardAmbiguousJoins (pileups.d:1592-1657)
     {
         const auto inc = incidence(g, ncontigs);
@@ -330,6 +368,7 @@ extern "C" int dh_scaffold_pileups(const dh_la *las, int64_t n, const int64_t *c
         res->joins.push_back(j);
         res->entries.insert(res->entries.end(), e.ras.begin(), e.ras.end());
     }
+    LAP_("rest");
     *out = res;
     return DH_OK;
 }

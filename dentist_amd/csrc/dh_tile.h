@@ -484,8 +484,18 @@ DH_HD void emit_claimed(const Params &P, int32_t it, int32_t other_item, DhLa la
         return;
     }
     const int64_t oslot = (int64_t)it * P.o.max_la + s;
-    uint16_t *dst = P.out_trace + oslot * P.trmax;
-    for (int32_t x = 0; x < 2 * npairs; x++) dst[x] = pairs[2 * first + x];
+    // pairs are moved as 4-byte words, eight loads in flight before the stores (a load-store chain per value would
+    // cost a memory round trip each: dst and pairs are both global memory)
+    uint32_t *__restrict__ dst = (uint32_t *)(P.out_trace + oslot * P.trmax);
+    const uint32_t *__restrict__ src = (const uint32_t *)(pairs + 2 * first);
+    for (int32_t x = 0; x < npairs; x += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = x + u < npairs ? src[x + u] : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (x + u < npairs) dst[x + u] = v[u];
+    }
     la.toff = 0;
     P.out_la[oslot] = la;
     DH_ATOMIC_ADD(&P.out_ntr[it], 2 * npairs);
