@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch of the seed and extension kernels of one bench step, from the two
+rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; one counter per pass) of scripts/profile_round.sh.
+
+usage: traffic_json.py <fetch-dir> <write-dir> <out.json> workload kmer_mod k algo
+
+Written as profiles/<round>_kernel_traffic.json, which bench.py reads for `roofline.traffic` when its
+configuration matches.  The counters are taken as rocprofv3 reports them (KB); the x2 correction of the
+microarchitecture guide applies to wide coalesced streaming reads only and is NOT applied: k_seed reads
+8-byte directory entries at random, k_tile 4/8-byte words per lane.  Mapping launches = the dispatches
+before the first crop kernel (k_gather_parts) of the step.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def rows(d):
+    out = []
+    for path in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                name = (row.get("Kernel_Name") or row.get("kernel_name") or "?").split("(")[0]
+                val = float(row.get("Counter_Value") or row.get("counter_value") or 0)
+                did = int(row.get("Dispatch_Id") or row.get("dispatch_id") or 0)
+                out.append((did, name, val))
+    return out
+
+
+def per_kernel(d):
+    per = {}
+    for did, name, val in rows(d):
+        per.setdefault(did, [name, 0.0])[1] += val
+    order = sorted(per)
+    first_crop = next((i for i in order if per[i][0].strip() == "k_gather_parts"), None)
+    res = {}
+    for i in order:
+        name, kb = per[i]
+        fam = "k_seed" if "k_seed<" in name and "k_seed<0>" not in name else ("k_tile" if name.strip() == "k_tile" else
+                                                                               ("k_seed_redo" if "k_seed<0>" in name else None))
+        if fam is None:
+            continue
+        stage = "mapping" if first_crop is None or i < first_crop else "process"
+        r = res.setdefault((fam, stage), [0, 0.0])
+        r[0] += 1
+        r[1] += kb * 1024.0
+    return res
+
+
+def main(fetch_dir, write_dir, out, workload, kmer_mod, k, algo):
+    f, w = per_kernel(fetch_dir), per_kernel(write_dir)
+    j = {"workload": workload, "mapping_kmer_mod": int(kmer_mod), "mapping_k": int(k), "mapping_algo": int(algo),
+         "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, as reported (no x2 correction: no wide "
+                   "coalesced streams in these kernels)", "launches": {}}
+    for key in sorted(set(f) | set(w)):
+        n = (f.get(key) or w.get(key))[0]
+        fb, wb = (f.get(key) or [0, 0.0])[1], (w.get(key) or [0, 0.0])[1]
+        j["launches"]["%s/%s" % key] = {"launches": n, "fetch_bytes": fb, "write_bytes": wb}
+    def per_launch(fam):
+        n = sum(v["launches"] for k_, v in j["launches"].items() if k_.startswith(fam + "/mapping"))
+        b = sum(v["fetch_bytes"] + v["write_bytes"] for k_, v in j["launches"].items()
+                if k_.startswith(fam + "/mapping") or k_.startswith(fam + "_redo/mapping"))
+        return b / n if n else None
+    j["k_seed_hbm_bytes_per_launch"] = per_launch("k_seed")
+    nt = sum(v["launches"] for k_, v in j["launches"].items() if k_.startswith("k_tile/"))
+    bt = sum(v["fetch_bytes"] + v["write_bytes"] for k_, v in j["launches"].items() if k_.startswith("k_tile/"))
+    j["k_tile_hbm_bytes_per_launch"] = bt / nt if nt else None      # all k_tile launches of the step, like roofline_tile
+    with open(out, "w") as fo:
+        json.dump(j, fo, indent=1)
+        fo.write("\n")
+    print(json.dumps({k_: j[k_] for k_ in ("k_seed_hbm_bytes_per_launch", "k_tile_hbm_bytes_per_launch")}))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:8])
