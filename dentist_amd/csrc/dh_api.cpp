@@ -741,9 +741,16 @@ static int build_index(dh_db *A, int32_t k, int32_t sepv, int32_t kmer_mod)
     dhk_kmer_pass(ctx->stream, 1, av, d_tiles, (int32_t)tiles.size(), k, kmer_mod, ix.shift, ix.d_dir, ix.d_ent,
                   ix.d_goff);
     HIPCHK(hipGetLastError());
+    // the directory the seed kernel reads: 16 bytes per bucket that hold the bucket's only entry itself, so that a
+    // looked-up k-mer costs one random line unless its bucket holds several entries
+    HIPCHK(dh_dev_alloc(&ix.d_fat, sizeof(ulonglong2) * (size_t)nb));
+    dhk_fat_dir(ctx->stream, ix.d_dir, ix.d_ent, nb, ix.d_fat);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));  // tiles vector goes out of scope
     dh_dev_free(d_tiles);
     dh_dev_free(d_sums);
+    dh_dev_free(ix.d_dir_alloc);
+    ix.d_dir_alloc = ix.d_dir = nullptr;
     A->has_ix = true;
     return DH_OK;
 }
@@ -1172,7 +1179,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
 
     DhOpts dopt;
     memcpy(&dopt, &o, sizeof(dopt));
-    IndexView iv{A->ix.d_dir, A->ix.d_ent, A->ix.d_goff, A->ix.n,
+    IndexView iv{A->ix.d_fat, A->ix.d_ent, A->ix.d_goff, A->ix.n,
                  A->ix.na,    A->ix.sepv,   A->ix.shift,  A->ix.pbits};
     const DbView av = A->view(), bv = B->view();
 

@@ -26,8 +26,13 @@ struct DbView {
     const uint8_t *mask_bits;
 };
 
+// fat directory word of a bucket (16 bytes, one load per looked-up k-mer):
+//   x == ~0            empty bucket
+//   x >> 62 == 1       several entries: y = first entry | count << 32
+//   else               the bucket's only entry itself, (x, y) as in `ent` -- no second line to fetch
+#define DH_FAT_EMPTY (~0ull)
 struct IndexView {
-    const uint32_t *dir;   // dir[b] = end of bucket b (start = dir[b-1])
+    const ulonglong2 *fat;  // one word per bucket
     const ulonglong2 *ent;  // x = group * 4^k + canonical k-mer, bit 63: the k-mer of A is its reverse complement; y = aseq << 40 | virtual position
     const int64_t *goff;   // virtual offset of every A sequence
     int64_t n;
@@ -67,6 +72,8 @@ void dhk_revcomp(hipStream_t st, const uint8_t *src, uint8_t *dst, const int64_t
 void dhk_kmer_pass(hipStream_t st, int fill, DbView A, const int2 *tiles, int32_t ntiles, int32_t k,
                    int32_t kmer_mod, int32_t shift, uint32_t *dir, ulonglong2 *ent, const int64_t *goff);
 void dhk_scan(hipStream_t st, uint32_t *v, int64_t n, uint32_t *sums);
+// dir[b] = end of bucket b (dir[-1] == 0) -> the fat directory
+void dhk_fat_dir(hipStream_t st, const uint32_t *dir, const ulonglong2 *ent, int64_t nb, ulonglong2 *fat);
 void dhk_seed(hipStream_t st, int cap, DbView B, IndexView ix, DhOpts o,
               int32_t item0, int32_t nitems, DhCand *cand, int32_t *ncand, int32_t *nhits,
               int32_t *status, uint32_t *queue, int32_t ncu, uint64_t *fscr);

@@ -64,9 +64,10 @@ struct dh_ctx {
 int dh_scratch(dh_ctx *ctx, int id, size_t bytes, void **out);
 
 struct dh_index {
-    // d_dir points one word into its allocation: d_dir[-1] == 0, so that (start, end) of bucket b
-    // is the 8-byte word at d_dir + b - 1 for every b (one load instead of two in the seed kernel)
+    // d_dir (build only, released afterwards) points one word into its allocation: d_dir[-1] == 0, so that
+    // bucket b is [d_dir[b - 1], d_dir[b]) for every b; the seed kernel reads d_fat (dh_device.h)
     uint32_t *d_dir = nullptr, *d_dir_alloc = nullptr;
+    ulonglong2 *d_fat = nullptr;
     ulonglong2 *d_ent = nullptr;
     int64_t *d_goff = nullptr;
     int64_t n = 0;
@@ -77,6 +78,8 @@ struct dh_index {
         d_dir_alloc = nullptr;
         dh_dev_free(d_ent);
         dh_dev_free(d_goff);
+        dh_dev_free(d_fat);
+        d_fat = nullptr;
         d_dir = nullptr;
         d_ent = nullptr;
         d_goff = nullptr;

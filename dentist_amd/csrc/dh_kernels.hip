@@ -230,6 +230,26 @@ k_kmer_pass(DbView A, const int2 *__restrict__ tiles, int32_t ntiles, int32_t k,
         }
     }
 }
+// fat directory (dh_device.h): thread per bucket
+__global__ void __launch_bounds__(256)
+k_fat_dir(const uint32_t *__restrict__ dir, const ulonglong2 *__restrict__ ent, int64_t nb, ulonglong2 *__restrict__ fat)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const uint32_t s0 = dir[b - 1], e0 = dir[b];
+    ulonglong2 f;
+    if (e0 == s0) {
+        f.x = DH_FAT_EMPTY;
+        f.y = 0;
+    } else if (e0 - s0 == 1u)
+        f = ent[s0];
+    else {
+        f.x = 1ull << 62;
+        f.y = (unsigned long long)s0 | ((unsigned long long)(e0 - s0) << 32);
+    }
+    fat[b] = f;
+}
+
 template __global__ void k_kmer_pass<false>(DbView, const int2 *, int32_t, int32_t, int32_t, int32_t,
                                             uint32_t *, ulonglong2 *, const int64_t *);
 template __global__ void k_kmer_pass<true>(DbView, const int2 *, int32_t, int32_t, int32_t, int32_t,
@@ -418,36 +438,32 @@ __device__ void seed_item(const DbView &B, const IndexView &ix,
             if (slot < CAP) hits[slot] = ((uint64_t)strand << 63) | ((uint64_t)D << HIT_QBITS) | (uint32_t)qs;
         };
         auto flush = [&]() {
-            uint32_t ss[QN], ee[QN];
+            // the fat directory word of every queued k-mer: one 16-byte load, one memory round trip per flush
+            ulonglong2 f[QN];
 #pragma unroll
             for (int u = 0; u < QN; u++) {
-                // (start, end) of the bucket = dir[bk - 1], dir[bk] in one 8-byte load (dir[-1] == 0)
-                uint64_t se = 0;
-                if (u < nq) se = load8((const uint8_t *)(ix.dir + (uint32_t)((qk[u] & ~(ORI | PAL)) >> ix.shift)) - 4);
-                ss[u] = (uint32_t)se;
-                ee[u] = (uint32_t)(se >> 32);
+                f[u].x = DH_FAT_EMPTY;
+                f[u].y = 0;
+                if (u < nq) f[u] = ix.fat[(uint32_t)((qk[u] & ~(ORI | PAL)) >> ix.shift)];
             }
-            ulonglong2 e0[QN];
-#pragma unroll
-            for (int u = 0; u < QN; u++)
-                if (ss[u] < ee[u]) e0[u] = ix.ent[ss[u]];
 #pragma unroll
             for (int u = 0; u < QN; u++) {
-                if (ss[u] >= ee[u]) continue;
+                if (f[u].x == DH_FAT_EMPTY) continue;
                 const uint64_t key = qk[u] & ~(ORI | PAL);
                 const uint64_t bori = qk[u] & ORI;
                 const bool pal = (qk[u] & PAL) != 0;
-                if (ee[u] - ss[u] == 1u) {
-                    if ((e0[u].x & ~ORI) == key && o.tcap >= 1) {
-                        const bool same = (e0[u].x & ORI) == bori;
-                        if (same || pal) emit(e0[u].y, qq[u], 0);
-                        if (!same || pal) emit(e0[u].y, qq[u], 1);
+                if ((f[u].x >> 62) != 1ull) {  // the bucket's only entry
+                    if ((f[u].x & ~ORI) == key && o.tcap >= 1) {
+                        const bool same = (f[u].x & ORI) == bori;
+                        if (same || pal) emit(f[u].y, qq[u], 0);
+                        if (!same || pal) emit(f[u].y, qq[u], 1);
                     }
                     continue;
                 }
+                const uint32_t ss_u = (uint32_t)f[u].y, ee_u = ss_u + (uint32_t)(f[u].y >> 32);
                 // count the entries of the bucket with this key first, per orientation (-t cap) ...
                 int32_t runf = 0, runr = 0;
-                for (uint32_t t = ss[u]; t < ee[u]; t++) {
+                for (uint32_t t = ss_u; t < ee_u; t++) {
                     const uint64_t ex = ix.ent[t].x;
                     if ((ex & ~ORI) != key) continue;
                     const bool same = (ex & ORI) == bori;
@@ -457,7 +473,7 @@ __device__ void seed_item(const DbView &B, const IndexView &ix,
                 const bool dof = runf > 0 && runf <= o.tcap, dor = runr > 0 && runr <= o.tcap;
                 if (!dof && !dor) continue;
                 // ... then emit its hits
-                for (uint32_t t = ss[u]; t < ee[u]; t++) {
+                for (uint32_t t = ss_u; t < ee_u; t++) {
                     const ulonglong2 en = ix.ent[t];
                     if ((en.x & ~ORI) != key) continue;
                     const bool same = (en.x & ORI) == bori;
@@ -2392,6 +2408,12 @@ void dhk_kmer_pass(hipStream_t st, int fill, DbView A, const int2 *tiles, int32_
     else
         hipLaunchKernelGGL(k_kmer_pass<false>, dim3(ntiles), dim3(256), 0, st, A, tiles, ntiles, k,
                            kmer_mod, shift, dir, ent, goff);
+}
+
+void dhk_fat_dir(hipStream_t st, const uint32_t *dir, const ulonglong2 *ent, int64_t nb, ulonglong2 *fat)
+{
+    if (nb <= 0) return;
+    hipLaunchKernelGGL(k_fat_dir, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, dir, ent, nb, fat);
 }
 
 // exclusive scan in place; sums must hold ceil(n / 2048) uint32

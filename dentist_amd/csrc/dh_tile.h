@@ -484,16 +484,17 @@ DH_HD void emit_claimed(const Params &P, int32_t it, int32_t other_item, DhLa la
         return;
     }
     const int64_t oslot = (int64_t)it * P.o.max_la + s;
-    // pairs are moved as 4-byte words, eight loads in flight before the stores (a load-store chain per value would
+    // pairs are moved as 4-byte words, 24 loads in flight before the stores (a load-store chain per value would
     // cost a memory round trip each: dst and pairs are both global memory)
     uint32_t *__restrict__ dst = (uint32_t *)(P.out_trace + oslot * P.trmax);
     const uint32_t *__restrict__ src = (const uint32_t *)(pairs + 2 * first);
-    for (int32_t x = 0; x < npairs; x += 8) {
-        uint32_t v[8];
+    constexpr int NV = 24;  // a pile-up overlap has about 21 pairs: one round trip for most records
+    for (int32_t x = 0; x < npairs; x += NV) {
+        uint32_t v[NV];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = x + u < npairs ? src[x + u] : 0u;
+        for (int u = 0; u < NV; u++) v[u] = x + u < npairs ? src[x + u] : 0u;
 #pragma unroll
-        for (int u = 0; u < 8; u++)
+        for (int u = 0; u < NV; u++)
             if (x + u < npairs) dst[x + u] = v[u];
     }
     la.toff = 0;

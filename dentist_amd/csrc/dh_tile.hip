@@ -42,18 +42,20 @@ __global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
         // else can run): short extensions (pile-up reads) would otherwise pay a pass on every round
         const unsigned long long want = __builtin_amdgcn_ballot_w64(l.st != L_RUN && l.st != L_DONE);
         if (want != 0ull && (__builtin_popcountll(want) >= P.book_min || !wave_any(l.st == L_RUN)))
+        // the states are visited in the order a lane moves through them (end of an extension -> next candidate ->
+        // next work unit -> its first candidate), so that one pass takes a lane all the way to its next extension:
+        // as exclusive branches this chain took four passes, each paying the round trips of every branch in it
         while (wave_any(l.st != L_RUN && l.st != L_DONE)) {
-            if (l.st == L_EXT_END)
-                lane_ext_end(l, P);
-            else if (l.st == L_CAND)
-                lane_next_cand(l, P);
-            else if (l.st == L_FETCH) {
+            if (l.st == L_EXT_END) lane_ext_end(l, P);
+            if (l.st == L_CAND) lane_next_cand(l, P);
+            if (l.st == L_FETCH) {
                 const int32_t it = (int32_t)atomicAdd(P.queue, 1u);
                 if (it >= (P.units ? (int32_t)*P.nunits : P.nitems))
                     l.st = L_DONE;
                 else
                     lane_fetch(l, P, it);
             }
+            if (l.st == L_CAND) lane_next_cand(l, P);
         }
         const bool run = l.st == L_RUN;
         if (!wave_any(run)) break;

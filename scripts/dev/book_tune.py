@@ -24,8 +24,9 @@ for bm, wpc in [(1, 12)]:
         rec, bases = dentist_amd.process_pileups(ctx, A, B, las, trace, piles, po)
         t2 = time.perf_counter()
         pst = dentist_amd.process_stats(ctx)
+        cum = ctx.cum_stats().as_dict()
     if ref is None:
         ref = (rec.copy(), bases.copy())
     same = np.array_equal(ref[0], rec) and np.array_equal(ref[1], bases)
-    print(f"book_min {bm:2d} waves/CU {wpc:2d}: map {1e3*(t1-t0):6.1f} (k_tile {st.ms_wave:5.1f}) process {1e3*(t2-t1):6.1f} "
-          f"(pile align {pst['ms_pile_align']:6.1f} realign {pst['ms_realign']:5.1f} flank {pst['ms_flank_align']:4.1f}) same {same}", flush=True)
+    print(f"book_min {bm:2d} waves/CU {wpc:2d}: map {1e3*(t1-t0):6.1f} (index {st.ms_index:4.1f} seeds {st.ms_seed:5.1f} k_tile {st.ms_wave:5.1f}) process {1e3*(t2-t1):6.1f} "
+          f"(pile align {pst['ms_pile_align']:6.1f} [{' '.join('%s=%.1f' % (k[3:], v) for k, v in pst.items() if k.startswith('ms_pa_'))}] realign {pst['ms_realign']:5.1f} flank {pst['ms_flank_align']:4.1f}) all k_tile {cum['ms_wave']:5.1f} all seeds {cum['ms_seed']:5.1f} same {same}", flush=True)
