@@ -87,8 +87,9 @@ def main():
                     help="reads kept per pile-up (default: dh_default_process_opts = 60; 0 = no cap, the reference's behaviour)")
     ap.add_argument("--collect", choices=("graph", "spanning"), default=None,
                     help="pile-up membership: 'graph' = the scaffold-graph builder of `dentist collect` with the extension "
-                         "entries it merges into a gap (pileups.d:173-208; N = 1 default), 'spanning' = one entry per "
-                         "spanning read, collected per chunk while mapping (the sharded path; N > 1 default)")
+                         "entries it merges into a gap (pileups.d:173-208; the default for every N: at N > 1 the raw joins "
+                         "of each rank's reads are all-gathered), 'spanning' = one entry per spanning read, collected per "
+                         "chunk while mapping")
     ap.add_argument("--dev-share-gpu", action="store_true",
                     help="development only: all ranks on cuda:0 with gloo collectives (exercises the N > 1 "
                          "code path on a 1-GPU box; not a measurement)")
@@ -136,9 +137,7 @@ def main():
         popts.max_reads = args.max_reads
     read_bp = int(len(w.reads.bases))
     if args.collect is None:
-        args.collect = "graph" if world == 1 else "spanning"
-    if args.collect == "graph" and world > 1:
-        raise SystemExit("--collect graph is a single-process step (the scaffold graph is global); use spanning for N > 1")
+        args.collect = "graph"
     input_gaps = np.stack([np.arange(w.contigs.n - 1), np.arange(1, w.contigs.n)], axis=1).astype(np.int32)
 
     def step():
@@ -168,7 +167,10 @@ def main():
         else:
             las["bread"] += lo   # read ids of the whole reads DB, as in the .las of a block
             t2 = t1
-            rec, bases, info = sharded_process(ctx, A, B, lo, w.contigs.off, las, trace, popts, rank, world, cands=cands)
+            # graph collector: the raw joins of a rank's reads are all-gathered and every rank builds the same scaffold
+            graph = dict(read_off=w.reads.off, input_gaps=input_gaps) if args.collect == "graph" else None
+            rec, bases, info = sharded_process(ctx, A, B, lo, w.contigs.off, las, trace, popts, rank, world, cands=cands,
+                                               graph=graph)
         t3 = time.perf_counter()
         pst = dentist_amd.process_stats(ctx)
         cum = ctx.cum_stats().as_dict()  # every k_wave / k_seed launch of the step

@@ -87,7 +87,7 @@ SYMBOLS = [
     "dh_map_reads", "dh_validate_regions", "dh_propagate_mask", "dh_db_mask_coverage", "dh_max_coverage_reads", "dh_max_improper_coverage_reads",
     "dh_default_scaffold_opts", "dh_scaffold_pileups", "dh_scaffold_npiles", "dh_scaffold_nentries", "dh_scaffold_joins",
     "dh_scaffold_entries", "dh_scaffold_destroy", "dh_scaffold_spanning", "dh_scaffold_gap_pileups", "dh_cropped_create2",
-    "dh_cropped_kind", "dh_set_near_best", "dh_shard_free", "dh_shard_pack_candidates", "dh_shard_plan_create", "dh_shard_plan_destroy",
+    "dh_cropped_kind", "dh_set_near_best", "dh_shard_free", "dh_shard_pack_candidates", "dh_shard_plan_create", "dh_shard_read_joins", "dh_shard_graph_plan_create", "dh_shard_plan_destroy",
     "dh_shard_plan_las", "dh_shard_plan_nlas", "dh_shard_plan_pileups", "dh_shard_plan_owner", "dh_shard_pack_cropped",
     "dh_shard_unpack_cropped", "dh_insertions_read_ids", "dh_insertions_read_ids_off", "dh_output_assembly", "dh_default_output_opts",
 ]
@@ -581,19 +581,52 @@ def shard_pack_candidates(cands, las, read_shift=0):
     return b
 
 
-class ShardPlan:
-    """dh_shard_plan: the pile-ups every rank derives from the gathered candidates, and who processes them."""
+def shard_read_joins(las, contig_off, read_off, read_first=0):
+    """dh_shard_read_joins: the raw scaffold joins of this rank's reads (global read ids in las["bread"], read_off =
+    offsets of the rank's reads [read_first, read_first + len(read_off) - 1)) as the blob of the join all-gather."""
+    L = lib()
+    arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
+    co, ro = np.ascontiguousarray(contig_off, dtype=np.int64), np.ascontiguousarray(read_off, dtype=np.int64)
+    out, nb = ctypes.c_void_p(), ctypes.c_int64(0)
+    L.dh_shard_read_joins.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+                                      ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64)]
+    L.dh_shard_free.argtypes = [ctypes.c_void_p]
+    _check(L.dh_shard_read_joins(arr.ctypes.data, len(arr), co.ctypes.data, len(co) - 1, ro.ctypes.data, int(read_first),
+                                 len(ro) - 1, ctypes.byref(out), ctypes.byref(nb)))
+    b = _blob(out, nb.value)
+    L.dh_shard_free(out)
+    return b
 
-    def __init__(self, blobs, opts):
+
+class ShardPlan:
+    """dh_shard_plan: the pile-ups every rank derives from the gathered candidates (or, graph = (ncontigs, input_gaps,
+    scaffold options): from the gathered scaffold joins), and who processes them."""
+
+    def __init__(self, blobs, opts, graph=None):
         L = lib()
         self._blobs = [np.ascontiguousarray(b, dtype=np.uint8) for b in blobs]
         n = len(self._blobs)
         ptrs = (ctypes.c_void_p * n)(*[b.ctypes.data for b in self._blobs])
         sizes = (ctypes.c_int64 * n)(*[len(b) for b in self._blobs])
         h = ctypes.c_void_p()
-        L.dh_shard_plan_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ProcessOpts),
-                                           ctypes.POINTER(ctypes.c_void_p)]
-        _check(L.dh_shard_plan_create(ptrs, sizes, n, ctypes.byref(opts), ctypes.byref(h)))
+        if graph is not None:
+            ncontigs, input_gaps, kw = graph
+            so = ScaffoldOpts()
+            L.dh_default_scaffold_opts(ctypes.byref(so))
+            for k, v in (kw or {}).items():
+                if not hasattr(so, k):
+                    raise TypeError(f"unknown scaffold option {k}")
+                setattr(so, k, int(v) if k in ("min_spanning_reads", "merge_extensions") else float(v))
+            ig = np.ascontiguousarray(input_gaps if input_gaps is not None else np.zeros((0, 2)), dtype=np.int32).reshape(-1, 2)
+            L.dh_shard_graph_plan_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                                     ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ScaffoldOpts),
+                                                     ctypes.POINTER(ProcessOpts), ctypes.POINTER(ctypes.c_void_p)]
+            _check(L.dh_shard_graph_plan_create(ptrs, sizes, n, int(ncontigs), ig.ctypes.data if len(ig) else None, len(ig),
+                                                ctypes.byref(so), ctypes.byref(opts), ctypes.byref(h)))
+        else:
+            L.dh_shard_plan_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ProcessOpts),
+                                               ctypes.POINTER(ctypes.c_void_p)]
+            _check(L.dh_shard_plan_create(ptrs, sizes, n, ctypes.byref(opts), ctypes.byref(h)))
         self._h = h
         for fn in (L.dh_shard_plan_las, L.dh_shard_plan_pileups, L.dh_shard_plan_owner):
             fn.argtypes = [ctypes.c_void_p]

@@ -31,6 +31,12 @@ inline hipError_t dh_dev_alloc(T **p, size_t bytes)
 }
 
 int dh_fail(int code, const std::string &msg);
+#include <vector>
+struct dh_scaffold;
+// dh_scaffold.cpp: the scaffold of the gathered join blobs of the sharded collector (glas: two LA records per join)
+int dh_scaffold_from_join_blobs(const uint8_t *const *blobs, const int64_t *sizes, int32_t world, int32_t ncontigs,
+                                const int32_t *input_gaps, int32_t ngaps, const struct dh_scaffold_opts *opts,
+                                std::vector<dh_la> &glas, dh_scaffold **out);
 // allocate total + 2 * DB_PAD bytes filled with code 4; *base = alloc + DB_PAD
 int dh_alloc_bases(hipStream_t st, int64_t total, uint8_t **alloc, uint8_t **base);
 

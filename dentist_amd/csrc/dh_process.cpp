@@ -2049,6 +2049,67 @@ extern "C" int dh_shard_pack_candidates(const dh_pileups *cands, const dh_la *la
     return DH_OK;
 }
 
+// owners by greedy bin-packing of n^2 * (mean read span between the anchors + 1 kb), largest first (ties: lower index;
+// least-loaded rank, ties: lower rank); the span is taken over the entries that span the gap
+static void plan_owners(dh_shard_plan *p, int32_t world)
+{
+    const size_t np = p->piles->contig_left.size();
+    std::vector<int64_t> cost(np);
+    for (size_t g = 0; g < np; g++) {
+        const std::vector<int32_t> &t = p->piles->triples[g];
+        const int64_t cnt = (int64_t)t.size() / 3;
+        int64_t span = 0;
+        int64_t nspan = 0;
+        for (size_t e = 0; e + 2 < t.size(); e += 3)
+            if (t[e + 1] >= 0 && t[e + 2] >= 0) {
+                span += std::max<int64_t>((int64_t)p->las[(size_t)t[e + 2]].bbpos - p->las[(size_t)t[e + 1]].bepos, 0);
+                nspan++;
+            }
+        const double mean = (double)span / (double)std::max<int64_t>(nspan, 1) + 1000.0;
+        cost[g] = (int64_t)((double)(cnt * cnt) * mean);
+    }
+    std::vector<int32_t> order(np);
+    for (size_t g = 0; g < np; g++) order[g] = (int32_t)g;
+    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return cost[(size_t)a] != cost[(size_t)b] ? cost[(size_t)a] > cost[(size_t)b] : a < b; });
+    std::vector<int64_t> load((size_t)world, 0);
+    p->owner.assign(np, 0);
+    for (int32_t g : order) {
+        int32_t best = 0;
+        for (int32_t r = 1; r < world; r++)
+            if (load[(size_t)r] < load[(size_t)best]) best = r;
+        p->owner[(size_t)g] = best;
+        load[(size_t)best] += cost[(size_t)g];
+    }
+}
+
+// the sharded scaffold-graph collector: all ranks' join blobs (dh_shard_read_joins, rank order = read order) -> the
+// scaffold, its gap pile-ups with the extension entries (dh_scaffold_gap_pileups), the min / max reads cut, owners
+extern "C" int dh_shard_graph_plan_create(const uint8_t *const *blobs, const int64_t *sizes, int32_t world, int32_t ncontigs,
+                                          const int32_t *input_gaps, int32_t ngaps, const dh_scaffold_opts *sopts,
+                                          const dh_process_opts *opts, dh_shard_plan **out)
+{
+    if (!opts || !out) return dh_fail(DH_EINVAL, "dh_shard_graph_plan_create: bad argument");
+    dh_shard_plan *p = new dh_shard_plan();
+    dh_scaffold *sc = nullptr;
+    if (int rc = dh_scaffold_from_join_blobs(blobs, sizes, world, ncontigs, input_gaps, ngaps, sopts, p->las, &sc)) {
+        delete p;
+        return rc;
+    }
+    dh_pileups *all = nullptr;
+    int32_t skipped = 0;
+    int rc = dh_scaffold_gap_pileups(sc, p->las.data(), (int64_t)p->las.size(), &all, &skipped);
+    dh_scaffold_destroy(sc);
+    if (!rc) rc = dh_pileups_select(all, p->las.data(), (int64_t)p->las.size(), opts, &p->piles);
+    delete all;
+    if (rc) {
+        delete p;
+        return rc;
+    }
+    plan_owners(p, world);
+    *out = p;
+    return DH_OK;
+}
+
 // every rank's candidates (rank order = read order) -> the same pile-ups on every rank: entries of a gap ordered by
 // read id (stable sort by gap of the concatenation), the min / max reads cut, owners by greedy bin-packing of
 // n^2 * (mean read span between the anchors + 1 kb), largest first (ties: lower index; least-loaded rank, ties: lower rank)
@@ -2093,29 +2154,7 @@ extern "C" int dh_shard_plan_create(const uint8_t *const *blobs, const int64_t *
         delete p;
         return rc;
     }
-    const size_t np = p->piles->contig_left.size();
-    std::vector<int64_t> cost(np);
-    for (size_t g = 0; g < np; g++) {
-        const std::vector<int32_t> &t = p->piles->triples[g];
-        const int64_t cnt = (int64_t)t.size() / 3;
-        int64_t span = 0;
-        for (size_t e = 0; e + 2 < t.size(); e += 3)
-            span += std::max<int64_t>((int64_t)p->las[(size_t)t[e + 2]].bbpos - p->las[(size_t)t[e + 1]].bepos, 0);
-        const double mean = (double)span / (double)std::max<int64_t>(cnt, 1) + 1000.0;
-        cost[g] = (int64_t)((double)(cnt * cnt) * mean);
-    }
-    std::vector<int32_t> order(np);
-    for (size_t g = 0; g < np; g++) order[g] = (int32_t)g;
-    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return cost[(size_t)a] != cost[(size_t)b] ? cost[(size_t)a] > cost[(size_t)b] : a < b; });
-    std::vector<int64_t> load((size_t)world, 0);
-    p->owner.assign(np, 0);
-    for (int32_t g : order) {
-        int32_t best = 0;
-        for (int32_t r = 1; r < world; r++)
-            if (load[(size_t)r] < load[(size_t)best]) best = r;
-        p->owner[(size_t)g] = best;
-        load[(size_t)best] += cost[(size_t)g];
-    }
+    plan_owners(p, world);
     *out = p;
     return DH_OK;
 }
@@ -2159,7 +2198,8 @@ extern "C" int dh_shard_pack_cropped(dh_cropped *crop, const int32_t *owner, int
     for (size_t i = 0; i < nr; i++) {
         const int32_t d = owner[crop->pile[i]];
         const int64_t len = crop->off[i + 1] - crop->off[i];
-        const CropHead h{crop->pile[i], crop->entry[i], crop->read_id[i], (int32_t)len};
+        // the entry's kind (0 spanning, 1 / 2 extension) rides in the top bits of `entry` (entries < 2^28)
+        const CropHead h{crop->pile[i], crop->entry[i] | ((int32_t)(i < crop->kind.size() ? crop->kind[i] : 0) << 28), crop->read_id[i], (int32_t)len};
         memcpy(blobs[d] + hat[(size_t)d], &h, sizeof(h));
         hat[(size_t)d] += (int64_t)sizeof(h);
         memcpy(blobs[d] + bat[(size_t)d], bases + crop->off[i], (size_t)len);
@@ -2178,6 +2218,7 @@ extern "C" int dh_shard_unpack_cropped(const uint8_t *const *blobs, const int64_
     struct Src {
         CropHead h;
         const uint8_t *b;
+        uint8_t kind;
     };
     std::vector<Src> all;
     for (int32_t r = 0; r < world; r++) {
@@ -2189,6 +2230,8 @@ extern "C" int dh_shard_unpack_cropped(const uint8_t *const *blobs, const int64_
         for (int64_t i = 0; i < k; i++) {
             Src s;
             memcpy(&s.h, hb + i * (int64_t)sizeof(CropHead), sizeof(CropHead));
+            s.kind = (uint8_t)((uint32_t)s.h.entry >> 28);
+            s.h.entry &= 0x0FFFFFFF;
             s.b = bb;
             if (s.h.len < 0 || bb + s.h.len > blobs[r] + sizes[r] || s.h.pile < 0 || s.h.pile >= npiles)
                 return dh_fail(DH_EINVAL, "dh_shard_unpack_cropped: corrupt blob");
@@ -2218,7 +2261,7 @@ extern "C" int dh_shard_unpack_cropped(const uint8_t *const *blobs, const int64_
         c->pile.push_back(renum[(size_t)s.h.pile]);
         c->entry.push_back(s.h.entry);
         c->read_id.push_back(s.h.read);
-        c->kind.push_back(0);
+        c->kind.push_back(s.kind);
         memcpy(c->bases.data() + at, s.b, (size_t)s.h.len);
         at += s.h.len;
         c->off.push_back(at);

@@ -205,14 +205,25 @@ extern "C" void dh_default_scaffold_opts(dh_scaffold_opts *o)
     o->existing_gap_bonus = 6.0;   // commandline.d:1688
 }
 
-extern "C" int dh_scaffold_pileups(const dh_la *las, int64_t n, const int64_t *contig_off, int32_t ncontigs,
-                                   const int64_t *read_off, int32_t nreads, const int32_t *input_gaps, int32_t ngaps,
-                                   const dh_scaffold_opts *opts, dh_scaffold **out)
+namespace {
+// blob record of the sharded collector (dh_shard_read_joins): one raw join with copies of the LA records it names
+#pragma pack(push, 1)
+struct JoinRec {
+    Node s, e;
+    int32_t read;
+    uint8_t seed0, seed1, n, pad;
+    dh_la la0, la1;  // la1 zeroed for an extension
+};
+#pragma pack(pop)
+static_assert(sizeof(JoinRec) == 24 + 2 * sizeof(dh_la), "join blob layout");
+
+// The raw joins of the reads [read_first, read_first + nreads) named by `las` (bread = global read id), in read
+// order: runs of reads per host thread, each run either kept raw (`raws`) or turned into edges (`edges`).
+int collect_raw_joins(const char *who, const dh_la *las, int64_t n, const int64_t *contig_off, int32_t ncontigs,
+                      const int64_t *read_off, int32_t read_first, int32_t nreads, std::vector<std::vector<RawJoin>> *raws,
+                      std::vector<std::vector<Edge>> *edges)
 {
-    if ((n > 0 && !las) || !contig_off || !read_off || !opts || !out || ncontigs < 0 || nreads < 0 || n < 0 ||
-        n >= (1ll << 31) || (ngaps > 0 && !input_gaps) || ngaps < 0)
-        return dh_fail(DH_EINVAL, "dh_scaffold_pileups: bad argument");
-    const Ctx c{las, contig_off, read_off};
+    const Ctx c{las, contig_off, read_off - read_first};
     auto T0_ = std::chrono::steady_clock::now();
     auto LAP_ = [&](const char *w) { if (getenv("DH_TRACE")) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[scaffold] %-24s %.2f ms\n", w, std::chrono::duration<double, std::milli>(t - T0_).count()); T0_ = t; } };
     // ---- the enabled LAs grouped by read, input order inside a read
@@ -224,15 +235,13 @@ extern "C" int dh_scaffold_pileups(const dh_la *las, int64_t n, const int64_t *c
             auto &v = live[(size_t)ch];
             const int64_t i1 = std::min(n, (ch + 1) * lgrain);
             for (int64_t i = ch * lgrain; i < i1; i++) {
-                if (las[i].bread < 0 || las[i].bread >= nreads || las[i].aread < 0 || las[i].aread >= ncontigs) bad = 1;
-                else if (!(las[i].flags & DH_FLAG_DISABLED)) v.emplace_back(las[i].bread, (int32_t)i);
+                const int64_t rd = (int64_t)las[i].bread - read_first;
+                if (rd < 0 || rd >= nreads || las[i].aread < 0 || las[i].aread >= ncontigs) bad = 1;
+                else if (!(las[i].flags & DH_FLAG_DISABLED)) v.emplace_back((int32_t)rd, (int32_t)i);
             }
         }
     });
-    if (bad) return dh_fail(DH_EINVAL, "dh_scaffold_pileups: read or contig id out of range");
-    for (int32_t g = 0; g < ngaps; g++)
-        if (input_gaps[2 * g] < 0 || input_gaps[2 * g] >= ncontigs || input_gaps[2 * g + 1] < 0 || input_gaps[2 * g + 1] >= ncontigs)
-            return dh_fail(DH_EINVAL, "dh_scaffold_pileups: input gap names a contig out of range");
+    if (bad) return dh_fail(DH_EINVAL, std::string(who) + ": read or contig id out of range");
     std::vector<int64_t> first((size_t)nreads + 1, 0);
     int64_t nlive = 0;
     for (const auto &v : live) {
@@ -252,22 +261,150 @@ extern "C" int dh_scaffold_pileups(const dh_la *las, int64_t n, const int64_t *c
     // (every host thread also merges the equal edges of its run of reads: the stable sort keeps the reads of an
     // edge in read order, and the serial merge below then handles a few thousand edges instead of one per read)
     const int64_t grain = std::max<int64_t>(8192, ((int64_t)nreads + 15) / 16), nchunks = ((int64_t)nreads + grain - 1) / grain;
-    std::vector<std::vector<Edge>> found((size_t)std::max<int64_t>(nchunks, 1));
+    if (raws) raws->assign((size_t)std::max<int64_t>(nchunks, 1), {});
+    if (edges) edges->assign((size_t)std::max<int64_t>(nchunks, 1), {});
     dh_parallel_for(nchunks, 1, [&](int64_t clo, int64_t chi) {
         std::vector<SA> sa;
         std::vector<std::pair<size_t, size_t>> sl;
-        std::vector<RawJoin> raw;
+        std::vector<RawJoin> local;
         for (int64_t ch = clo; ch < chi; ch++) {
+            std::vector<RawJoin> &raw = raws ? (*raws)[(size_t)ch] : local;
             const int32_t r1 = (int32_t)std::min<int64_t>(nreads, (ch + 1) * grain);
             raw.clear();
             for (int32_t rd = (int32_t)(ch * grain); rd < r1; rd++) {
                 const int64_t cnt = first[(size_t)rd + 1] - first[(size_t)rd];
                 if (cnt > 0) read_joins(c, order.data() + first[(size_t)rd], cnt, raw, sa, sl);
             }
-            raw_to_edges(raw, found[(size_t)ch]);
+            if (edges) raw_to_edges(raw, (*edges)[(size_t)ch]);
         }
     });
     LAP_("read joins");
+    return DH_OK;
+}
+
+int scaffold_from_edges(std::vector<std::vector<Edge>> &found, int32_t ncontigs, const int32_t *input_gaps, int32_t ngaps,
+                        const dh_scaffold_opts *opts, dh_scaffold **out);
+}  // namespace
+
+extern "C" int dh_scaffold_pileups(const dh_la *las, int64_t n, const int64_t *contig_off, int32_t ncontigs,
+                                   const int64_t *read_off, int32_t nreads, const int32_t *input_gaps, int32_t ngaps,
+                                   const dh_scaffold_opts *opts, dh_scaffold **out)
+{
+    if ((n > 0 && !las) || !contig_off || !read_off || !opts || !out || ncontigs < 0 || nreads < 0 || n < 0 ||
+        n >= (1ll << 31) || (ngaps > 0 && !input_gaps) || ngaps < 0)
+        return dh_fail(DH_EINVAL, "dh_scaffold_pileups: bad argument");
+    for (int32_t g = 0; g < ngaps; g++)
+        if (input_gaps[2 * g] < 0 || input_gaps[2 * g] >= ncontigs || input_gaps[2 * g + 1] < 0 || input_gaps[2 * g + 1] >= ncontigs)
+            return dh_fail(DH_EINVAL, "dh_scaffold_pileups: input gap names a contig out of range");
+    std::vector<std::vector<Edge>> found;
+    if (int rc = collect_raw_joins("dh_scaffold_pileups", las, n, contig_off, ncontigs, read_off, 0, nreads, nullptr, &found)) return rc;
+    return scaffold_from_edges(found, ncontigs, input_gaps, ngaps, opts, out);
+}
+
+// ---- the sharded collector: every rank turns the alignments of ITS reads into raw joins (a per-read computation),
+// the joins are all-gathered in rank order (= read order), and every rank builds the same scaffold from them
+extern "C" int dh_shard_read_joins(const dh_la *las, int64_t n, const int64_t *contig_off, int32_t ncontigs,
+                                   const int64_t *read_off, int32_t read_first, int32_t nreads, uint8_t **blob, int64_t *nbytes)
+{
+    if ((n > 0 && !las) || !contig_off || !read_off || !blob || !nbytes || ncontigs < 0 || nreads < 0 || n < 0 || n >= (1ll << 31) ||
+        read_first < 0)
+        return dh_fail(DH_EINVAL, "dh_shard_read_joins: bad argument");
+    std::vector<std::vector<RawJoin>> raws;
+    if (int rc = collect_raw_joins("dh_shard_read_joins", las, n, contig_off, ncontigs, read_off, read_first, nreads, &raws, nullptr)) return rc;
+    size_t tot = 0;
+    std::vector<size_t> at(raws.size());
+    for (size_t i = 0; i < raws.size(); i++) {
+        at[i] = tot;
+        tot += raws[i].size();
+    }
+    JoinRec *out = (JoinRec *)malloc(std::max<size_t>(tot, 1) * sizeof(JoinRec));
+    if (!out) return dh_fail(DH_EINVAL, "dh_shard_read_joins: out of memory");
+    dh_parallel_for((int64_t)raws.size(), 1, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; i++)
+            for (size_t x = 0; x < raws[(size_t)i].size(); x++) {
+                const RawJoin &r = raws[(size_t)i][x];
+                JoinRec &j = out[at[(size_t)i] + x];
+                j.s = r.s;
+                j.e = r.e;
+                j.read = r.ra.read;
+                j.seed0 = r.ra.seed0;
+                j.seed1 = r.ra.seed1;
+                j.n = r.ra.n;
+                j.pad = 0;
+                j.la0 = las[r.ra.la0];
+                if (r.ra.la1 >= 0)
+                    j.la1 = las[r.ra.la1];
+                else
+                    memset(&j.la1, 0, sizeof(dh_la));
+            }
+    });
+    *blob = (uint8_t *)out;
+    *nbytes = (int64_t)(tot * sizeof(JoinRec));
+    return DH_OK;
+}
+
+// the gathered join blobs -> the scaffold every rank derives; glas = the LA records of the joins (two per join, the
+// second unused for an extension), which the entries of the scaffold index
+int dh_scaffold_from_join_blobs(const uint8_t *const *blobs, const int64_t *sizes, int32_t world, int32_t ncontigs,
+                                const int32_t *input_gaps, int32_t ngaps, const dh_scaffold_opts *opts,
+                                std::vector<dh_la> &glas, dh_scaffold **out)
+{
+    if (!blobs || !sizes || world < 1 || !opts || !out || ncontigs < 0 || (ngaps > 0 && !input_gaps) || ngaps < 0)
+        return dh_fail(DH_EINVAL, "dh_shard_graph_plan_create: bad argument");
+    int64_t tot = 0;
+    for (int32_t r = 0; r < world; r++) {
+        if (sizes[r] < 0 || sizes[r] % (int64_t)sizeof(JoinRec)) return dh_fail(DH_EINVAL, "dh_shard_graph_plan_create: blob size");
+        tot += sizes[r] / (int64_t)sizeof(JoinRec);
+    }
+    if (2 * tot >= (1ll << 31)) return dh_fail(DH_EINVAL, "dh_shard_graph_plan_create: too many joins");
+    for (int32_t g = 0; g < ngaps; g++)
+        if (input_gaps[2 * g] < 0 || input_gaps[2 * g] >= ncontigs || input_gaps[2 * g + 1] < 0 || input_gaps[2 * g + 1] >= ncontigs)
+            return dh_fail(DH_EINVAL, "dh_shard_graph_plan_create: input gap names a contig out of range");
+    glas.resize((size_t)(2 * tot));
+    // runs of the concatenation (rank order = read order) become edges on the host threads, as in the single-rank builder
+    std::vector<int64_t> start((size_t)world + 1, 0);
+    for (int32_t r = 0; r < world; r++) start[(size_t)r + 1] = start[(size_t)r] + sizes[r] / (int64_t)sizeof(JoinRec);
+    const int64_t grain = 16384, nruns = (tot + grain - 1) / grain;
+    std::vector<std::vector<Edge>> found((size_t)std::max<int64_t>(nruns, 1));
+    std::atomic<int> bad{0};
+    dh_parallel_for(nruns, 1, [&](int64_t lo, int64_t hi) {
+        std::vector<RawJoin> raw;
+        for (int64_t run = lo; run < hi; run++) {
+            const int64_t a0 = run * grain, a1 = std::min(tot, a0 + grain);
+            raw.resize((size_t)(a1 - a0));
+            int32_t r = (int32_t)(std::upper_bound(start.begin(), start.end(), a0) - start.begin()) - 1;
+            for (int64_t at = a0; at < a1; at++) {
+                while (at >= start[(size_t)r + 1]) r++;
+                const JoinRec &j = ((const JoinRec *)blobs[r])[at - start[(size_t)r]];
+                if (j.s.contig < 0 || j.s.contig >= ncontigs || j.e.contig < 0 || j.e.contig >= ncontigs || j.s.part < 0 || j.s.part > 3 ||
+                    j.e.part < 0 || j.e.part > 3 || (j.n != 1 && j.n != 2))
+                    bad = 1;
+                glas[(size_t)(2 * at)] = j.la0;
+                glas[(size_t)(2 * at + 1)] = j.la1;
+                RawJoin &q = raw[(size_t)(at - a0)];
+                q.s = j.s;
+                q.e = j.e;
+                memset(&q.ra, 0, sizeof(q.ra));
+                q.ra.read = j.read;
+                q.ra.la0 = (int32_t)(2 * at);
+                q.ra.la1 = j.n == 2 ? (int32_t)(2 * at + 1) : -1;
+                q.ra.seed0 = j.seed0;
+                q.ra.seed1 = j.seed1;
+                q.ra.n = j.n;
+            }
+            if (!bad) raw_to_edges(raw, found[(size_t)run]);
+        }
+    });
+    if (bad) return dh_fail(DH_EINVAL, "dh_shard_graph_plan_create: malformed join record");
+    return scaffold_from_edges(found, ncontigs, input_gaps, ngaps, opts, out);
+}
+
+namespace {
+int scaffold_from_edges(std::vector<std::vector<Edge>> &found, int32_t ncontigs, const int32_t *input_gaps, int32_t ngaps,
+                        const dh_scaffold_opts *opts, dh_scaffold **out)
+{
+    auto T0_ = std::chrono::steady_clock::now();
+    auto LAP_ = [&](const char *w) { if (getenv("DH_TRACE")) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[scaffold] %-24s %.2f ms\n", w, std::chrono::duration<double, std::milli>(t - T0_).count()); T0_ = t; } };
     // ---- the scaffold: default edges, read joins, input gaps (buildScaffold, scaffold.d:237-244)
     std::vector<Edge> g;
     for (int32_t ct = 0; ct < ncontigs; ct++) g.push_back(make_edge(Node{ct, BEGIN}, Node{ct, END}));
@@ -372,6 +509,7 @@ extern "C" int dh_scaffold_pileups(const dh_la *las, int64_t n, const int64_t *c
     *out = res;
     return DH_OK;
 }
+}  // namespace
 
 extern "C" int32_t dh_scaffold_npiles(const dh_scaffold *s) { return s ? (int32_t)s->joins.size() : 0; }
 extern "C" int64_t dh_scaffold_nentries(const dh_scaffold *s) { return s ? (int64_t)s->entries.size() : 0; }

@@ -163,12 +163,12 @@ def _runs(bases, off, idx):
     return [bases[off[idx[a]]:off[idx[b - 1] + 1]] for a, b in zip(starts, ends)]
 
 
-def sharded_process(ctx, contigs_db, reads_db, read_first, contig_off, las, trace, popts, rank, world, cands=None):
+def sharded_process(ctx, contigs_db, reads_db, read_first, contig_off, las, trace, popts, rank, world, cands=None, graph=None):
     """`collect` + `process` for one rank's share of the reads.  las/trace: this rank's mapping
     result with bread ALREADY shifted to ids of the whole reads DB; reads_db holds the reads
     [read_first, read_first + n).  Returns (records, bases, info): the closed-gap records of ALL
     ranks ordered by gap (identical on every rank) with ref_read_id as whole-DB ids."""
-    gen = sharded_process_steps(ctx, contigs_db, reads_db, read_first, contig_off, las, trace, popts, rank, world, cands)
+    gen = sharded_process_steps(ctx, contigs_db, reads_db, read_first, contig_off, las, trace, popts, rank, world, cands, graph)
     try:
         req = next(gen)
         while True:
@@ -202,9 +202,15 @@ def emulate_ranks(gens):
     return results
 
 
-def sharded_process_steps(ctx, contigs_db, reads_db, read_first, contig_off, las, trace, popts, rank, world, cands=None):
+def sharded_process_steps(ctx, contigs_db, reads_db, read_first, contig_off, las, trace, popts, rank, world, cands=None,
+                          graph=None):
     """Generator form of sharded_process: yields ("all_gather", bytes) / ("all_to_all", [bytes per
-    destination]) and expects the list of arrays received (by source rank) to be sent back."""
+    destination]) and expects the list of arrays received (by source rank) to be sent back.
+
+    graph = None: the spanning-read collector (candidates).  graph = dict(read_off=offsets of this rank's reads,
+    input_gaps=..., plus scaffold options): the scaffold-graph collector of `dentist collect` -- the raw joins of a
+    rank's reads are a per-read computation (collectReadAlignments), they are all-gathered instead of the
+    candidates, and every rank builds the same scaffold and the same gap pile-ups (extension entries included)."""
     import os
     import time
     from . import Cropped, Pileups
@@ -219,16 +225,27 @@ def sharded_process_steps(ctx, contigs_db, reads_db, read_first, contig_off, las
     # cands: candidates dh_map_reads collected on the way (read ids still local to this rank's reads DB).
     # The host work between the collectives is C++ behind dh_shard_* (the numpy restatement of it -- pack_candidates,
     # merge_candidates, assign_owners, pile_costs above -- is what tests/test_parallel_gloo.py checks it against)
-    from ._lib import ShardPlan, shard_pack_candidates, shard_pack_cropped, shard_unpack_cropped
-    shift = 0 if cands is None else read_first
-    if cands is None:
-        cands = Pileups(las, contig_off, popts, candidates=True)
-    mine = shard_pack_candidates(cands, las, shift)
-    lap("candidates")
-    blobs = yield ("all_gather", mine)
-    _t[0] = time.perf_counter()
-    ncand = sum(len(b) for b in blobs) // CAND_DTYPE.itemsize
-    plan = ShardPlan(blobs, popts)
+    from ._lib import ShardPlan, shard_pack_candidates, shard_pack_cropped, shard_read_joins, shard_unpack_cropped
+    if graph is not None:
+        g = dict(graph)
+        read_off, input_gaps = g.pop("read_off"), g.pop("input_gaps", None)
+        g.setdefault("min_spanning_reads", popts.min_reads)
+        mine = shard_read_joins(las, contig_off, read_off, read_first)
+        lap("read joins")
+        blobs = yield ("all_gather", mine)
+        _t[0] = time.perf_counter()
+        ncand = sum(len(b) for b in blobs) // 120
+        plan = ShardPlan(blobs, popts, graph=(len(contig_off) - 1, input_gaps, g))
+    else:
+        shift = 0 if cands is None else read_first
+        if cands is None:
+            cands = Pileups(las, contig_off, popts, candidates=True)
+        mine = shard_pack_candidates(cands, las, shift)
+        lap("candidates")
+        blobs = yield ("all_gather", mine)
+        _t[0] = time.perf_counter()
+        ncand = sum(len(b) for b in blobs) // CAND_DTYPE.itemsize
+        plan = ShardPlan(blobs, popts)
     glas, piles, owner = plan.las, plan.piles, plan.owner
     lap("plan (merge, cut, owners)")
     # the entries of this rank inside glas are copies of its own records: their toff still points
@@ -256,8 +273,9 @@ def sharded_process_steps(ctx, contigs_db, reads_db, read_first, contig_off, las
         import sys
         print("[sharded rank 0] " + ", ".join(_laps), file=sys.stderr)
     order = np.argsort(grec["contig_left"], kind="stable")   # insertions.sort(): by start node
+    nentries = int(piles.flat()[1].sum())
     plan.close()
-    info = {"piles": len(rec), "owned": len(mine_piles), "candidates": int(ncand),
+    info = {"piles": len(rec), "owned": len(mine_piles), "candidates": int(ncand), "entries": nentries,
             "cropped_bytes_sent": int(sum(len(x) for x in per_dest)), "owner": owner}
     return grec[order], gbases, info
 

@@ -435,6 +435,14 @@ const uint8_t *dh_cropped_kind(const dh_cropped *c);
  *      dh_shard_pack_candidates  this rank's candidates (dh_collect_candidates / dh_map_reads) -> blob
  *      dh_shard_plan_create      all ranks' blobs (rank order) -> the same pile-ups on every rank (entries of a gap by
  *                                read id, min / max reads cut) and their owners (greedy bin-packing of n^2 L)
+ *      dh_shard_read_joins       (scaffold-graph collector) the raw joins of this rank's reads -- collectReadAlignments,
+ *                                pileups.d:821-888, a per-read computation -- as a blob of 120-byte records {4 x int32
+ *                                edge (contig, part) x 2, int32 read, u8 seed0, seed1, n, pad, dh_la, dh_la}; las[].bread
+ *                                are global read ids, read_off the offsets of the rank's reads [read_first, +nreads)
+ *      dh_shard_graph_plan_create  all ranks' join blobs (rank order) -> the scaffold every rank derives (forks, min
+ *                                spanning reads, extensions merged into gaps), its gap pile-ups incl. extension entries,
+ *                                the min / max reads cut, owners -- the pile-ups are those of dh_scaffold_pileups +
+ *                                dh_scaffold_gap_pileups + dh_pileups_select on the merged alignments
  *      dh_shard_pack_cropped     the reads this rank cropped -> one blob per owner (one malloc, free blobs[0])
  *      dh_shard_unpack_cropped   the blobs an owner received -> its cropped pile-ups for dh_process_cropped */
 typedef struct dh_shard_plan dh_shard_plan;
@@ -443,6 +451,11 @@ int dh_shard_pack_candidates(const dh_pileups *cands, const dh_la *las, int64_t 
                              int64_t *nbytes);
 int dh_shard_plan_create(const uint8_t *const *blobs, const int64_t *sizes, int32_t world, const dh_process_opts *opts,
                          dh_shard_plan **out);
+int dh_shard_read_joins(const dh_la *las, int64_t n, const int64_t *contig_off, int32_t ncontigs, const int64_t *read_off,
+                        int32_t read_first, int32_t nreads, uint8_t **blob, int64_t *nbytes);
+int dh_shard_graph_plan_create(const uint8_t *const *blobs, const int64_t *sizes, int32_t world, int32_t ncontigs,
+                               const int32_t *input_gaps, int32_t ngaps, const dh_scaffold_opts *sopts,
+                               const dh_process_opts *opts, dh_shard_plan **out);
 void dh_shard_plan_destroy(dh_shard_plan *p);
 const dh_la *dh_shard_plan_las(const dh_shard_plan *p);
 int64_t dh_shard_plan_nlas(const dh_shard_plan *p);

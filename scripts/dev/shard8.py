@@ -27,7 +27,11 @@ for r in range(N):
     las["bread"] += lo
     ranks.append(dict(lo=lo, B=B, las=las, trace=trace, w=w, t_map=t1 - t0))
     print('rank', r, 'map+filter %.1f ms, las %d' % ((t1 - t0) * 1e3, len(las)), flush=True)
-gens = [sharded_process_steps(ctx, A, R["B"], R["lo"], R["w"].contigs.off, R["las"], R["trace"], po, r, N) for r, R in enumerate(ranks)]
+ncg = ranks[0]["w"].contigs.n
+gaps = np.stack([np.arange(ncg - 1), np.arange(1, ncg)], axis=1).astype(np.int32)
+graph = len(sys.argv) <= 2 or sys.argv[2] != "spanning"
+gens = [sharded_process_steps(ctx, A, R["B"], R["lo"], R["w"].contigs.off, R["las"], R["trace"], po, r, N,
+                              graph=dict(read_off=R["w"].reads.off, input_gaps=gaps) if graph else None) for r, R in enumerate(ranks)]
 phase_t = [[] for _ in range(N)]
 reqs = []
 for r, g in enumerate(gens):

@@ -47,7 +47,10 @@ def test_config3_eight_emulated_ranks_equal_the_single_rank_run(gpu_ctx, cfg2_wo
     A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
     # ---- one rank: bench.py's sequence
     las, trace, dropped, cands = gpu_ctx.map_reads(A, B, mo, po, sorted=False, candidates=True)
-    piles = cands.select(las, po)
+    gaps = np.stack([np.arange(w.contigs.n - 1), np.arange(1, w.contigs.n)], axis=1).astype(np.int32)
+    gp, _ = dentist_amd.scaffold_spanning_pileups(las, w.contigs.off, w.reads.off, gaps, with_extensions=True,
+                                                  min_spanning_reads=po.min_reads)
+    piles = gp.select(las, po)     # the scaffold-graph collector with extension entries, cap 60: bench.py's default
     rec, bases = dentist_amd.process_pileups(gpu_ctx, A, B, las, trace, piles, po)
     closed = rec[rec["status"] == 0]
     assert len(piles) == 1000 and len(closed) >= 990
@@ -72,7 +75,8 @@ def test_config3_eight_emulated_ranks_equal_the_single_rank_run(gpu_ctx, cfg2_wo
         lr = lr.copy()
         lr["bread"] += lo
         keep.append((Br, lr, tr, cr))
-        gens.append(parallel.sharded_process_steps(gpu_ctx, A, Br, lo, w.contigs.off, lr, tr, po, rank, world, cr))
+        gens.append(parallel.sharded_process_steps(gpu_ctx, A, Br, lo, w.contigs.off, lr, tr, po, rank, world,
+                                                   graph=dict(read_off=share.off, input_gaps=gaps)))
     t0 = time.perf_counter()
     results = parallel.emulate_ranks(gens)
     t_rest = (time.perf_counter() - t0) / world
@@ -87,8 +91,8 @@ def test_config3_eight_emulated_ranks_equal_the_single_rank_run(gpu_ctx, cfg2_wo
     for a, b in zip(grec, rec):
         assert np.array_equal(gbases[a["cons_off"]:a["cons_off"] + a["cons_len"]], bases[b["cons_off"]:b["cons_off"] + b["cons_len"]])
     with capsys.disabled():
-        print(f"\n[configs[3], 8 emulated ranks on one GPU] per rank: mapping + filters + candidates "
-              f"{np.mean(t_map) * 1e3:.1f} ms (max {np.max(t_map) * 1e3:.1f}), collect + crop + exchange + process + gather "
+        print(f"\n[configs[3], 8 emulated ranks on one GPU] per rank: mapping + filters "
+              f"{np.mean(t_map) * 1e3:.1f} ms (max {np.max(t_map) * 1e3:.1f}), read joins + scaffold + crop + exchange + process + gather "
               f"{t_rest * 1e3:.1f} ms (the ranks' steps run one after the other here)")
 
 

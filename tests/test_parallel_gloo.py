@@ -191,13 +191,15 @@ def test_cxx_shard_glue_equals_the_numpy_restatement():
                     seqs.append(rng.integers(0, 4, int(rng.integers(20, 60))).astype(np.uint8))
             at += n
         off = np.concatenate([[0], np.cumsum([len(x) for x in seqs])]).astype(np.int64)
-        crops.append((Cropped.create(rec, pile, entry, read, off, np.concatenate(seqs)), pile, entry, read, seqs))
+        kind = [(p_ + e + r_) % 3 for p_, e, r_ in zip(pile, entry, read)]      # 0 spanning, 1 / 2 extension entries
+        crops.append((Cropped.create(rec, pile, entry, read, off, np.concatenate(seqs), kind=kind), pile, entry, read, seqs, kind))
     sent = [shard_pack_cropped(c[0], owner, world) for c in crops]
-    for src, (c, pile, entry, read, seqs) in enumerate(crops):   # blob format = the Python packing
+    for src, (c, pile, entry, read, seqs, kind) in enumerate(crops):   # blob format = the Python packing
         for dst in range(world):
             sel = [i for i in range(len(pile)) if owner[pile[i]] == dst]
             head = np.zeros(len(sel), dtype=CROP_DTYPE)
-            head["pile"], head["entry"], head["read"] = [pile[i] for i in sel], [entry[i] for i in sel], [read[i] for i in sel]
+            head["pile"], head["read"] = [pile[i] for i in sel], [read[i] for i in sel]
+            head["entry"] = [entry[i] | (kind[i] << 28) for i in sel]        # the entry's kind rides in the top bits
             head["len"] = [len(seqs[i]) for i in sel]
             exp = np.concatenate([np.asarray([len(sel)], dtype=np.int64).view(np.uint8), head.view(np.uint8)] + [seqs[i] for i in sel])
             assert sent[src][dst].tobytes() == exp.tobytes()
@@ -209,4 +211,41 @@ def test_cxx_shard_glue_equals_the_numpy_restatement():
         assert np.all(np.diff(opile.astype(np.int64) * 1000 + oentry) > 0)
         want = sum(int(a[1][p_]) for p_ in mine)
         assert len(opile) == want and ooff[-1] == len(obases)
+        assert np.array_equal(own.kind(), (mine[opile] + oentry + oread) % 3)
     plan.close()
+
+
+def test_sharded_scaffold_collector_equals_the_single_rank_builder():
+    """dh_shard_read_joins per rank + dh_shard_graph_plan_create on the gathered joins against dh_scaffold_pileups +
+    dh_scaffold_gap_pileups + dh_pileups_select on the merged alignments (the N = 1 path of bench.py): the same pile-ups,
+    entry by entry (read id, kind of entry, the LA records behind it), and kinds survive the cropped-read blobs."""
+    import dentist_amd
+    from dentist_amd import sim
+    from dentist_amd._lib import ShardPlan, shard_read_joins
+    from oracle import pyoracle as oz
+    w = sim.Workload(160_000, 6, 420, 5000, seed=77, spacing=20000, gap_min=50, gap_max=1500)
+    o = oz.default_opts(k=14, kmer_mod=1)
+    las, _, _ = oz.align_db(w.contigs, w.reads, o, nthreads=4, sort=False, select_best=True)
+    las = np.ascontiguousarray(las[np.argsort(las["bread"], kind="stable")])
+    coff, roff = w.contigs.off, w.reads.off
+    gaps = np.stack([np.arange(w.contigs.n - 1), np.arange(1, w.contigs.n)], axis=1).astype(np.int32)
+    for max_reads in (0, 6):
+        po = dentist_amd.default_process_opts(max_reads=max_reads)
+        gp, _ = dentist_amd.scaffold_spanning_pileups(las, coff, roff, gaps, with_extensions=True, min_spanning_reads=po.min_reads)
+        ecl, ecnt, etri = gp.select(las, po).flat()
+        assert len(ecl) >= 4 and (etri[:, 1] < 0).any() and (etri[:, 2] < 0).any()   # extension entries of both kinds
+        for world in (1, 2, 3):
+            blobs = []
+            for r in range(world):
+                lo, hi = w.reads.n * r // world, w.reads.n * (r + 1) // world
+                mine = las[(las["bread"] >= lo) & (las["bread"] < hi)]
+                blobs.append(shard_read_joins(mine, coff, roff[lo:hi + 1] - roff[lo], lo))
+            plan = ShardPlan(blobs, po, graph=(w.contigs.n, gaps, {"min_spanning_reads": po.min_reads}))
+            cl, cnt, tri = plan.piles.flat()
+            assert np.array_equal(cl, ecl) and np.array_equal(cnt, ecnt) and np.array_equal(tri[:, 0], etri[:, 0])
+            for col in (1, 2):
+                assert np.array_equal(tri[:, col] < 0, etri[:, col] < 0)
+                m = tri[:, col] >= 0
+                assert np.array_equal(plan.las[tri[m, col]], las[etri[m, col]])
+            assert len(plan.owner) == len(cl) and set(plan.owner.tolist()) <= set(range(world))
+            plan.close()

@@ -116,3 +116,45 @@ def test_sharded_run_with_candidates_collected_while_mapping(gpu_ctx, monkeypatc
         for a, b in zip(grec, rec):
             assert np.array_equal(gbases[a["cons_off"]:a["cons_off"] + a["cons_len"]],
                                   bases[b["cons_off"]:b["cons_off"] + b["cons_len"]])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_scaffold_graph_collector_equals_the_single_gpu_run(gpu_ctx, world):
+    """bench.py's default flow for every N: mapping + filters per rank (dh_map_reads), the raw scaffold joins of a
+    rank's reads all-gathered (dh_shard_read_joins), the same scaffold / gap pile-ups with extension entries on every
+    rank (dh_shard_graph_plan_create), crop, all-to-all, process -- against the N = 1 flow (dh_scaffold_pileups +
+    dh_scaffold_gap_pileups + select + dh_process_pileups).  DH-2 in every stage."""
+    w = sim.Workload(800_000, 8, 4000, 6000, seed=73, spacing=20000, gap_max=1500)
+    mo = dentist_amd.default_align_opts(kmer_mod=2, k=20, algo=1, width=64)
+    po = dentist_amd.default_process_opts(max_reads=14, algo=1)
+    gaps = np.stack([np.arange(w.contigs.n - 1), np.arange(1, w.contigs.n)], axis=1).astype(np.int32)
+    A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
+    las, trace, _, _ = gpu_ctx.map_reads(A, B, mo, po, sorted=False, candidates=True)
+    gp, _ = dentist_amd.scaffold_spanning_pileups(las, w.contigs.off, w.reads.off, gaps, with_extensions=True,
+                                                  min_spanning_reads=po.min_reads)
+    piles = gp.select(las, po)
+    tri = piles.flat()[2]
+    assert (tri[:, 1] < 0).any() and (tri[:, 2] < 0).any()
+    rec, bases = dentist_amd.process_pileups(gpu_ctx, A, B, las, trace, piles, po)
+    assert (rec["status"] == 0).sum() >= 6
+    gens, keep = [], []
+    for rank in range(world):
+        lo, hi = parallel.shard_range(w.reads.n, rank, world)
+        share = sim.SeqDb(w.reads.bases[w.reads.off[lo]:w.reads.off[hi]], w.reads.off[lo:hi + 1] - w.reads.off[lo])
+        Br = gpu_ctx.db(share)
+        lr, tr, _, _ = gpu_ctx.map_reads(A, Br, mo, po, sorted=False, candidates=True)
+        lr = lr.copy()
+        lr["bread"] += lo
+        keep.append((Br, lr, tr))
+        gens.append(parallel.sharded_process_steps(gpu_ctx, A, Br, lo, w.contigs.off, lr, tr, po, rank, world,
+                                                   graph=dict(read_off=share.off, input_gaps=gaps)))
+    results = parallel.emulate_ranks(gens)
+    assert len(set(results[0][2]["owner"].tolist())) == world
+    for grec, gbases, info in results:
+        assert info["entries"] == len(tri)
+        for f in rec.dtype.names:
+            if f not in ("cons_off", "pad"):
+                assert np.array_equal(grec[f], rec[f]), f
+        for a, b in zip(grec, rec):
+            assert np.array_equal(gbases[a["cons_off"]:a["cons_off"] + a["cons_len"]],
+                                  bases[b["cons_off"]:b["cons_off"] + b["cons_len"]])
