@@ -1205,7 +1205,9 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     // DH-2: one alignment per lane; wavefronts resident = CUs x waves per CU, no more than the items need
     int32_t tile_waves = 0;
     if (tiled) {
-        int32_t per_cu = dhk_tile_waves_per_cu();
+        // symmetric launches spend most of a wavefront's time waiting on the records and scratch of short alignments:
+        // all 16 wavefronts the registers allow (configs[2]: pile-up launch -2.5 ms against 12; mapping +1 ms with 16)
+        int32_t per_cu = o.skip_self == 2 ? 16 : dhk_tile_waves_per_cu();
         if (const char *e = getenv("DH_TILE_WAVES_PER_CU")) per_cu = std::max(1, atoi(e));
         // (symmetric mode: the work units are groups of candidates, many per item -- a pile-up read meets every other
         // read of its pile-up -- so the items do not bound the lanes that find work)
@@ -1362,10 +1364,17 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         // item (k_units); d_queue[3] counts them
         void *d_units = nullptr;
         if (o.skip_self == 2 && ni > 1) {
-            int4 *d_u;
-            SCR(24, d_u, (size_t)ni * (size_t)o.max_cand)  // at most one unit per candidate
-            d_units = d_u;
-            dhk_units(st, candbase, ncandbase, (int32_t)item0, ni, o.max_cand, d_units, d_queue + 3);
+            if (tiled) {
+                dhtile::Unit *d_u;
+                SCR(24, d_u, (size_t)ni * (size_t)o.max_cand)  // at most one unit per candidate
+                d_units = d_u;
+                dhk_tile_units(st, candbase, ncandbase, (int32_t)item0, ni, o.max_cand, A->d_off, B->d_off, d_u, d_queue + 3);
+            } else {
+                int4 *d_u;
+                SCR(24, d_u, (size_t)ni * (size_t)o.max_cand)
+                d_units = d_u;
+                dhk_units(st, candbase, ncandbase, (int32_t)item0, ni, o.max_cand, d_units, d_queue + 3);
+            }
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipMemsetAsync(d_ovf, 0, sizeof(int32_t) * (size_t)ni, st));
@@ -1384,7 +1393,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             tp.cand = candbase;
             tp.ncand = ncandbase;
             tp.queue = d_queue;
-            tp.units = (const int4 *)d_units;
+            tp.units = (const dhtile::Unit *)d_units;
             tp.nunits = d_queue + 3;
             tp.item_ovf = d_ovf - item0;
             tp.tscr = d_tscr;

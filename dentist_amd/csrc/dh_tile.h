@@ -41,6 +41,16 @@ struct PlanePair {  // 32 bases of a plane-packed copy: bit g & 31 of .x / .y = 
 
 struct Cold;
 
+// work unit of a symmetric launch (k_units_fat): one group of candidates of an item, with everything the lane needs to
+// start on the first of them -- fetching a unit is ONE memory round trip (four 16-byte loads) instead of the chain
+// unit -> item -> candidate -> A offsets
+struct Unit {
+    int32_t it, c0, c1, blen;      // item - item0, candidates [c0, c1) of it, length of the item's read
+    int64_t bo, ao;                // base offsets of the read and of the first candidate's A sequence
+    int32_t aseq, apos, bpos, alen;  // the first candidate and the length of its A sequence
+    int32_t pad_[4];
+};
+
 struct Params {
     const int64_t *aoff, *boff;       // offsets of the A / B sequences (bases)
     const uint32_t *apk, *arcpk;      // 2-bit packed A, forward / reverse complement: base g in dword g >> 4, bits 2 (g & 15)
@@ -50,7 +60,7 @@ struct Params {
     const DhCand *cand;               // max_cand per item, indexed by absolute item
     const int32_t *ncand;
     uint32_t *queue;                  // work counter
-    const int4 *units;                // optional work units (item - item0, first candidate, end candidate, 0), else NULL
+    const Unit *units;                // optional work units (symmetric launches), else NULL: the items are the units
     const uint32_t *nunits;           // their number (device side)
     int32_t *item_ovf;                // symmetric mode: per item (absolute), set when a record was dropped for want of slots
     uint16_t *tscr;                   // symmetric mode: nlanes * trmax, the trace pairs of the alignment in flight
@@ -385,23 +395,37 @@ DH_HD void cand_geometry(Lane &l, const Params &P, int32_t mode)
 DH_HD void lane_fetch(Lane &l, const Params &P, int32_t it)
 {
     Cold &c = *l.c;
-    int32_t ui = it, c0 = 0, c1 = 0x7FFFFFFF;
     if (P.units) {
-        const int4 u = P.units[it];
-        ui = u.x;
-        c0 = u.y;
-        c1 = u.z;
+        // a unit has at least one candidate and the lane no aligned region yet: the first candidate runs as it is
+        // (what lane_next_cand would decide), from the unit record alone
+        const Unit u = P.units[it];
+        const int32_t item = P.item0 + u.it;
+        c.item = item;
+        c.strand = item & 1;
+        c.nc = u.c1;
+        c.bo = u.bo;
+        c.blen = u.blen;
+        c.nd = c.nacc = c.ntr = 0;
+        c.c = u.c0;
+        c.c_aseq = u.aseq;
+        c.as = u.apos;
+        c.bs = u.bpos;
+        c.ao = u.ao;
+        c.alen = u.alen;
+        cand_geometry(l, P, 0);
+        ext_begin(l, P, 1);
+        return;
     }
-    const int32_t item = P.item0 + ui;
+    const int32_t item = P.item0 + it;
     c.item = item;
     c.strand = item & 1;
     const int32_t nc = P.ncand[item];
-    c.nc = nc > 0 ? (nc < c1 ? nc : c1) : 0;
+    c.nc = nc > 0 ? nc : 0;
     const int64_t bo = P.boff[item >> 1];
     c.bo = bo;
     c.blen = (int32_t)(P.boff[(item >> 1) + 1] - bo);
     c.nd = c.nacc = c.ntr = 0;
-    c.c = c0;
+    c.c = 0;
     l.st = L_CAND;
 }
 
@@ -475,6 +499,13 @@ DH_HD int32_t finish_pairs(const Lane &l, const Params &P, uint16_t *pairs, int3
 DH_HD void emit_claimed(const Params &P, int32_t it, int32_t other_item, DhLa la, const uint16_t *pairs, int32_t first,
                         int32_t npairs)
 {
+    // pairs are moved as 4-byte words; the first 24 (a pile-up overlap has about 21) are loaded before the slot is
+    // claimed, so that the claim and the loads are one memory round trip, not two (dst and pairs are global memory)
+    constexpr int NV = 24;
+    const uint32_t *__restrict__ src = (const uint32_t *)(pairs + 2 * first);
+    uint32_t v[NV];
+#pragma unroll
+    for (int u = 0; u < NV; u++) v[u] = u < npairs ? src[u] : 0u;
     const int32_t s = DH_ATOMIC_ADD(&P.out_nla[it], 1);
     if (s >= P.o.max_la) {
         // more overlaps than slots: the record is dropped, both items are reported (as k_wave2 does)
@@ -484,13 +515,11 @@ DH_HD void emit_claimed(const Params &P, int32_t it, int32_t other_item, DhLa la
         return;
     }
     const int64_t oslot = (int64_t)it * P.o.max_la + s;
-    // pairs are moved as 4-byte words, 24 loads in flight before the stores (a load-store chain per value would
-    // cost a memory round trip each: dst and pairs are both global memory)
     uint32_t *__restrict__ dst = (uint32_t *)(P.out_trace + oslot * P.trmax);
-    const uint32_t *__restrict__ src = (const uint32_t *)(pairs + 2 * first);
-    constexpr int NV = 24;  // a pile-up overlap has about 21 pairs: one round trip for most records
-    for (int32_t x = 0; x < npairs; x += NV) {
-        uint32_t v[NV];
+#pragma unroll
+    for (int u = 0; u < NV; u++)
+        if (u < npairs) dst[u] = v[u];
+    for (int32_t x = NV; x < npairs; x += NV) {
 #pragma unroll
         for (int u = 0; u < NV; u++) v[u] = x + u < npairs ? src[x + u] : 0u;
 #pragma unroll
@@ -590,6 +619,10 @@ void dhk_tile(hipStream_t st, int32_t nwaves, const dhtile::Params *P);
 int32_t dhk_tile_waves_per_cu(void);
 // 2-bit packed words (32 bases each) -> plane-packed words, in place
 void dhk_pk2planes(hipStream_t st, void *words, int64_t nwords);
+// work units of a symmetric launch: the candidates of every item grouped by A read (items with more than 64
+// candidates stay whole); units must hold nitems * max_cand records, *nunits counts them (zeroed by the caller)
+void dhk_tile_units(hipStream_t st, const DhCand *cand, const int32_t *ncand, int32_t item0, int32_t nitems, int32_t max_cand,
+                    const int64_t *aoff, const int64_t *boff, dhtile::Unit *units, uint32_t *nunits);
 #ifdef __cplusplus
 }
 #endif

@@ -110,7 +110,52 @@ __global__ void __launch_bounds__(256) k_pk2planes(uint64_t *__restrict__ w, int
     w[i] = (uint64_t)squeeze_even(x) | ((uint64_t)squeeze_even(x >> 1) << 32);
 }
 
+// one thread per item: its candidates (grouped by A read by the seed kernel) become units; an item with more than 64
+// candidates stays one unit (the cap of attempted alignments per item must see them in order), as in k_units
+__global__ void __launch_bounds__(256)
+k_units_fat(const DhCand *__restrict__ cand, const int32_t *__restrict__ ncand, int32_t item0, int32_t nitems, int32_t max_cand,
+            const int64_t *__restrict__ aoff, const int64_t *__restrict__ boff, Unit *__restrict__ units, uint32_t *__restrict__ nunits)
+{
+    const int32_t it = blockIdx.x * blockDim.x + threadIdx.x;
+    if (it >= nitems) return;
+    const int32_t item = item0 + it;
+    const int32_t nc = max(ncand[item], 0);
+    if (nc == 0) return;
+    const DhCand *cl = cand + (int64_t)item * max_cand;
+    const int64_t bo = boff[item >> 1];
+    const int32_t blen = (int32_t)(boff[(item >> 1) + 1] - bo);
+    int32_t c0 = 0;
+    while (c0 < nc) {
+        int32_t c1 = c0 + 1;
+        if (nc > 64)
+            c1 = nc;
+        else
+            while (c1 < nc && cl[c1].aseq == cl[c0].aseq) c1++;
+        Unit u;
+        u.it = it;
+        u.c0 = c0;
+        u.c1 = c1;
+        u.blen = blen;
+        u.bo = bo;
+        u.aseq = cl[c0].aseq;
+        u.apos = cl[c0].apos;
+        u.bpos = cl[c0].bpos;
+        u.ao = aoff[u.aseq];
+        u.alen = (int32_t)(aoff[u.aseq + 1] - u.ao);
+        u.pad_[0] = u.pad_[1] = u.pad_[2] = u.pad_[3] = 0;
+        units[atomicAdd(nunits, 1u)] = u;
+        c0 = c1;
+    }
+}
+
 extern "C" {
+void dhk_tile_units(hipStream_t st, const DhCand *cand, const int32_t *ncand, int32_t item0, int32_t nitems, int32_t max_cand,
+                    const int64_t *aoff, const int64_t *boff, Unit *units, uint32_t *nunits)
+{
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL(k_units_fat, dim3((nitems + 255) / 256), dim3(256), 0, st, cand, ncand, item0, nitems, max_cand, aoff, boff,
+                       units, nunits);
+}
 void dhk_tile(hipStream_t st, int32_t nwaves, const Params *P)
 {
     if (P->nitems <= 0 || nwaves <= 0) return;

@@ -10,7 +10,7 @@ A, B = ctx.db(w.contigs), ctx.db(w.reads)
 mo = dentist_amd.default_align_opts(kmer_mod=4, k=20, width=64, xdrop=60, algo=1)
 po = dentist_amd.default_process_opts(algo=1)
 ref = None
-for bm, wpc in [(1, 12)]:
+for bm, wpc in [(1, 12), (1, 16)]:
     os.environ["DH_TILE_BOOK_MIN"] = str(bm)
     os.environ["DH_TILE_WAVES_PER_CU"] = str(wpc)
     for rep in range(2):
