@@ -2089,23 +2089,34 @@ extern "C" int dh_shard_graph_plan_create(const uint8_t *const *blobs, const int
                                           const dh_process_opts *opts, dh_shard_plan **out)
 {
     if (!opts || !out) return dh_fail(DH_EINVAL, "dh_shard_graph_plan_create: bad argument");
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *w) {
+        if (!getenv("DH_TRACE")) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[graph plan] %-20s %.2f ms\n", w, std::chrono::duration<double, std::milli>(t - t0).count());
+        t0 = t;
+    };
     dh_shard_plan *p = new dh_shard_plan();
     dh_scaffold *sc = nullptr;
     if (int rc = dh_scaffold_from_join_blobs(blobs, sizes, world, ncontigs, input_gaps, ngaps, sopts, p->las, &sc)) {
         delete p;
         return rc;
     }
+    lap("scaffold");
     dh_pileups *all = nullptr;
     int32_t skipped = 0;
     int rc = dh_scaffold_gap_pileups(sc, p->las.data(), (int64_t)p->las.size(), &all, &skipped);
     dh_scaffold_destroy(sc);
+    lap("gap pile-ups");
     if (!rc) rc = dh_pileups_select(all, p->las.data(), (int64_t)p->las.size(), opts, &p->piles);
     delete all;
     if (rc) {
         delete p;
         return rc;
     }
+    lap("select");
     plan_owners(p, world);
+    lap("owners");
     *out = p;
     return DH_OK;
 }

@@ -561,34 +561,44 @@ extern "C" int dh_scaffold_spanning(const dh_scaffold *s, const dh_la *las, int6
 extern "C" int dh_scaffold_gap_pileups(const dh_scaffold *s, const dh_la *las, int64_t n, dh_pileups **out, int32_t *skipped)
 {
     if (!s || !out || (n > 0 && !las)) return dh_fail(DH_EINVAL, "dh_scaffold_gap_pileups: bad argument");
+    // joins are independent: host threads fill one triple list per join, the lists are concatenated in join order
+    const int64_t nj = (int64_t)s->joins.size();
+    std::vector<std::vector<std::array<int32_t, 3>>> per((size_t)nj);
+    dh_parallel_for(nj, 16, [&](int64_t lo, int64_t hi) {
+        for (int64_t ji = lo; ji < hi; ji++) {
+            const dh_join &j = s->joins[(size_t)ji];
+            if (!(j.type == 1 && j.part0 == END && j.part1 == BEGIN && j.contig1 == j.contig0 + 1)) continue;
+            std::vector<std::array<int32_t, 3>> &t = per[(size_t)ji];
+            t.reserve((size_t)j.count);
+            for (int64_t x = j.first; x < j.first + j.count; x++) {
+                const dh_read_alignment &ra = s->entries[(size_t)x];
+                if (ra.la0 < 0 || ra.la0 >= n) continue;
+                if (ra.n == 2) {
+                    if (ra.la1 < 0 || ra.la1 >= n) continue;
+                    if ((las[ra.la0].flags & DH_FLAG_COMP) != (las[ra.la1].flags & DH_FLAG_COMP)) continue;
+                    t.push_back({ra.read, ra.la0, ra.la1});
+                } else if (las[ra.la0].aread == j.contig0 && ra.seed0 == BACK)
+                    t.push_back({ra.read, ra.la0, -1});
+                else if (las[ra.la0].aread == j.contig1 && ra.seed0 == FRONT)
+                    t.push_back({ra.read, -1, ra.la0});
+            }
+            std::stable_sort(t.begin(), t.end(), [](const auto &a, const auto &b) { return a[0] < b[0]; });
+        }
+    });
     std::vector<int32_t> cl, cnt, tri;
     int32_t skip = 0;
-    for (const dh_join &j : s->joins) {
-        if (!(j.type == 1 && j.part0 == END && j.part1 == BEGIN && j.contig1 == j.contig0 + 1)) {
-            skip++;
-            continue;
-        }
-        std::vector<std::array<int32_t, 3>> t;
-        for (int64_t x = j.first; x < j.first + j.count; x++) {
-            const dh_read_alignment &ra = s->entries[(size_t)x];
-            if (ra.la0 < 0 || ra.la0 >= n) continue;
-            if (ra.n == 2) {
-                if (ra.la1 < 0 || ra.la1 >= n) continue;
-                if ((las[ra.la0].flags & DH_FLAG_COMP) != (las[ra.la1].flags & DH_FLAG_COMP)) continue;
-                t.push_back({ra.read, ra.la0, ra.la1});
-            } else if (las[ra.la0].aread == j.contig0 && ra.seed0 == BACK)
-                t.push_back({ra.read, ra.la0, -1});
-            else if (las[ra.la0].aread == j.contig1 && ra.seed0 == FRONT)
-                t.push_back({ra.read, -1, ra.la0});
-        }
+    size_t total = 0;
+    for (const auto &t : per) total += t.size();
+    tri.reserve(3 * total);
+    for (int64_t ji = 0; ji < nj; ji++) {
+        const auto &t = per[(size_t)ji];
         if (t.empty()) {
             skip++;
             continue;
         }
-        std::stable_sort(t.begin(), t.end(), [](const auto &a, const auto &b) { return a[0] < b[0]; });
-        cl.push_back(j.contig0);
+        cl.push_back(s->joins[(size_t)ji].contig0);
         cnt.push_back((int32_t)t.size());
-        for (auto &x : t) tri.insert(tri.end(), x.begin(), x.end());
+        for (const auto &x : t) tri.insert(tri.end(), x.begin(), x.end());
     }
     if (skipped) *skipped = skip;
     return dh_pileups_create(cl.data(), cnt.data(), (int32_t)cl.size(), tri.data(), out);

@@ -49,6 +49,8 @@ while any(q is not None for q in reqs):
         t = time.perf_counter()
         try:
             nxt.append(g.send(answers[r]))
+            if kind == "all_to_all":
+                print('rank', r, 'process stages', {k: round(v, 1) for k, v in dentist_amd.process_stats(ctx).items() if k.startswith('ms_')}, flush=True)
         except StopIteration as done:
             results[r] = done.value; nxt.append(None)
         phase_t[r].append(time.perf_counter() - t)
