@@ -939,7 +939,8 @@ extern "C" int dh_align_db(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts 
 // (records of the chunk, their number, their offset in the result, number of the chunk)
 typedef std::function<void(dh_la *, int64_t, int64_t, int64_t)> ChunkHook;
 static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t count, const dh_align_opts *opts,
-                       int32_t want_best, int32_t want_sorted, dh_la_set **out, const ChunkHook *hook = nullptr);
+                       int32_t want_best, int32_t want_sorted, dh_la_set **out, const ChunkHook *hook = nullptr,
+                       dh_la_set **out_tr = nullptr);
 
 // `damapper <ref> <reads>.<block>` (snakemake/Snakefile:1143-1170): the reads [first, first + count)
 // of B against all of A; read ids in the records are those of the whole DB, as in a block's .las
@@ -1075,7 +1076,7 @@ static int chunk_copies(dh_ctx *ctx, dh_db *B, int32_t r0, int32_t r1, bool want
 }
 
 static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t count, const dh_align_opts *opts,
-                       int32_t want_best, int32_t want_sorted, dh_la_set **out, const ChunkHook *hook)
+                       int32_t want_best, int32_t want_sorted, dh_la_set **out, const ChunkHook *hook, dh_la_set **out_tr)
 {
     auto now_ms = [] {
         return (double)std::chrono::duration_cast<std::chrono::microseconds>(
@@ -1100,6 +1101,8 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     if (o.pen < 2) return fail(DH_EINVAL, "pen must be >= 2");
     if (o.band_shift < 1 || o.band_shift > 12) return fail(DH_EINVAL, "band_shift out of range");
     if (o.skip_self && A != B) return fail(DH_EINVAL, "skip_self needs A == B");
+    if (out_tr && (o.algo != 1 || A == B || hook))
+        return fail(DH_EINVAL, "the transposed file is defined for DH-2 (algo 1) mappings of one DB onto another");
     if (o.skip_self < 0 || o.skip_self > 2) return fail(DH_EINVAL, "skip_self must be 0, 1 or 2");
     if (o.kmer_mod < 1 || o.kmer_mod > 64) return fail(DH_EINVAL, "kmer_mod must be in [1, 64]");
     HIPCHK(hipSetDevice(ctx->device));
@@ -1117,6 +1120,18 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             if (!ok) delete r;
         }
     } guard{res};
+    // the transposed file of a mapping (`damapper -C`): records (read, contig) of the transposed pairs
+    dh_la_set *res2 = out_tr ? new dh_la_set() : nullptr;
+    struct Guard2 {
+        dh_la_set *p;
+        bool ok = false;
+        ~Guard2()
+        {
+            if (!ok) delete p;
+        }
+    } guard2{res2};
+    if (res2) res2->tspace = o.tspace;
+    if (out_tr) *out_tr = nullptr;
     // hook tasks in flight; joined before the result can move or is handed out (also on error paths)
     struct Tasks {
         hipStream_t cs;
@@ -1245,6 +1260,24 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     if (tiled && o.skip_self == 2) SCR(33, d_tscr, (size_t)tile_waves * 64 * trmax)
     dhtile::Cold *d_cold = nullptr;
     if (tiled) SCR(34, d_cold, (size_t)tile_waves * 64)
+    DhLa *d_la2 = nullptr, *d_laout2 = nullptr;
+    uint16_t *d_trslots2 = nullptr, *d_trout2 = nullptr;
+    uint32_t *d_nla2 = nullptr, *d_ntr2 = nullptr;
+    uint8_t *d_app = nullptr, *d_arcpp = nullptr;  // plane-packed copies of A (B'' of the transposed pairs)
+    if (res2) {
+        SCR(35, d_la2, (size_t)cn * o.max_la)
+        SCR(36, d_trslots2, (size_t)cn * o.max_la * trmax)
+        SCR(37, d_nla2, cn + 1)
+        SCR(38, d_ntr2, cn + 1)
+        const size_t awords = (size_t)((A->total + 31) / 32), abytes = awords * 8 + 2 * PK_PAD;
+        SCR(39, d_app, abytes)
+        SCR(40, d_arcpp, abytes)
+        HIPCHK(hipMemcpyAsync(d_app, A->d_pk_alloc, abytes, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_arcpp, A->d_rcpk_alloc, abytes, hipMemcpyDeviceToDevice, st));
+        dhk_pk2planes(st, d_app + PK_PAD, (int64_t)awords);
+        dhk_pk2planes(st, d_arcpp + PK_PAD, (int64_t)awords);
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipMemsetAsync(d_status, 0, sizeof(int32_t), st));
     HIPCHK(hipMemsetAsync(d_counters, 0, 2 * sizeof(unsigned long long), st));
 
@@ -1279,6 +1312,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             w_c = t;
         };
         ChunkCopies cc;
+        uint8_t *d_bpk2 = nullptr, *d_brcpk2 = nullptr;
         if (db_copies) {
             cc.rc = B->d_rc;
             cc.pk = B->d_pk;
@@ -1289,6 +1323,14 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         const bool packed = want_packed && A->has_n == 0 && !cc.has_n && cc.pk && cc.rcpk;
         if (tiled) {
             if (!packed) return fail(DH_EINVAL, "algo 1 (DH-2) needs sequences of a, c, g, t only (2-bit copies), B holds other codes");
+            if (res2) {
+                // the transposed pairs read this chunk of B as their A'': keep its 2-bit copies
+                const size_t pbytes = (size_t)cc.pk_words * 8 + 2 * PK_PAD;
+                SCR(41, d_bpk2, pbytes)
+                SCR(42, d_brcpk2, pbytes)
+                HIPCHK(hipMemcpyAsync(d_bpk2, cc.pk_w0 - PK_PAD, pbytes, hipMemcpyDeviceToDevice, st));
+                HIPCHK(hipMemcpyAsync(d_brcpk2, cc.rcpk_w0 - PK_PAD, pbytes, hipMemcpyDeviceToDevice, st));
+            }
             dhk_pk2planes(st, cc.pk_w0, cc.pk_words);
             dhk_pk2planes(st, cc.rcpk_w0, cc.pk_words);
             HIPCHK(hipGetLastError());
@@ -1387,6 +1429,26 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             tp.arcpk = (const uint32_t *)A->d_rcpk;
             tp.bpp = (const dhtile::PlanePair *)cc.pk;
             tp.brcpp = (const dhtile::PlanePair *)cc.rcpk;
+            // transposed pairs: a symmetric launch (A == B) reads the same copies in both roles
+            tp.apk1 = tp.apk;
+            tp.arcpk1 = tp.arcpk;
+            tp.bpp1 = tp.bpp;
+            tp.brcpp1 = tp.brcpp;
+            tp.out_la2 = nullptr;
+            tp.out_trace2 = nullptr;
+            tp.out_nla2 = tp.out_ntr2 = nullptr;
+            if (res2) {
+                tp.apk1 = (const uint32_t *)(d_bpk2 + PK_PAD + (cc.pk - cc.pk_w0));
+                tp.arcpk1 = (const uint32_t *)(d_brcpk2 + PK_PAD + (cc.rcpk - cc.rcpk_w0));
+                tp.bpp1 = (const dhtile::PlanePair *)(d_app + PK_PAD);
+                tp.brcpp1 = (const dhtile::PlanePair *)(d_arcpp + PK_PAD);
+                tp.out_la2 = d_la2 - item0 * o.max_la;
+                tp.out_trace2 = d_trslots2 - item0 * (int64_t)o.max_la * trmax;
+                tp.out_nla2 = (int32_t *)d_nla2 - item0;
+                tp.out_ntr2 = (int32_t *)d_ntr2 - item0;
+                HIPCHK(hipMemsetAsync(d_nla2, 0, sizeof(uint32_t) * (size_t)(ni + 1), st));
+                HIPCHK(hipMemsetAsync(d_ntr2, 0, sizeof(uint32_t) * (size_t)(ni + 1), st));
+            }
             tp.o = dopt;
             tp.item0 = (int32_t)item0;
             tp.nitems = ni;
@@ -1489,6 +1551,28 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             HIPCHK(hipEventRecord(copied, ctx->cstream));
             res->d_trace = (t0 == 0 && item0 == item_first && ni == nitems_total) ? d_trout : nullptr;
         }
+        if (res2) {
+            // the transposed records of the chunk: same compaction, copied on this stream (not the benched path)
+            dhk_scan(st, d_nla2, (int64_t)ni + 1, d_sums);
+            dhk_scan(st, d_ntr2, (int64_t)ni + 1, d_sums);
+            uint32_t tot2[2] = {0, 0};
+            HIPCHK(hipMemcpyAsync(&tot2[0], d_nla2 + ni, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(&tot2[1], d_ntr2 + ni, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (tot2[0] > 0) {
+                SCR(43, d_laout2, tot2[0])
+                SCR(44, d_trout2, tot2[1])
+                const size_t l2 = res2->la.size(), t2 = res2->trace.size();
+                dhk_compact(st, d_la2, d_trslots2, trmax, o.max_la, 0, ni, d_nla2, d_ntr2, (int64_t)t2, d_laout2, d_trout2);
+                HIPCHK(hipGetLastError());
+                res2->la.resize(l2 + tot2[0]);
+                res2->trace.resize(t2 + tot2[1]);
+                HIPCHK(hipMemcpyAsync(res2->la.data() + l2, d_laout2, sizeof(dh_la) * (size_t)tot2[0], hipMemcpyDeviceToHost, st));
+                if (tot2[1] > 0)
+                    HIPCHK(hipMemcpyAsync(res2->trace.data() + t2, d_trout2, sizeof(uint16_t) * (size_t)tot2[1],
+                                          hipMemcpyDeviceToHost, st));
+            }
+        }
         HIPCHK(hipEventRecord(ctx->ev[5], st));
         HIPCHK(hipStreamSynchronize(st));
         lap(5);
@@ -1526,6 +1610,23 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     tasks.join();
     if (want_best && !hook) select_best_range(res->la.data(), res->la.size());
     if (want_sorted) lasort(res, A->n);
+    if (res2) {
+        // chain flags of the transposed set: the same rule with the roles of the sequences exchanged (chains of a read
+        // on one contig, ordered along the read); then LAsort order
+        auto swap_roles = [&]() {
+            for (dh_la &l : res2->la) {
+                std::swap(l.aread, l.bread);
+                std::swap(l.abpos, l.bbpos);
+                std::swap(l.aepos, l.bepos);
+            }
+        };
+        if (want_best) {
+            swap_roles();  // grouped by read already (items are (read, strand) in order)
+            select_best_range(res2->la.data(), res2->la.size());
+            swap_roles();
+        }
+        std::sort(res2->la.begin(), res2->la.end(), la_less);
+    }
     w_post = now_ms() - w_a;
     stats.las = (int64_t)res->la.size();
     float t;
@@ -1574,7 +1675,23 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
                 w_index, w_loop, w_post, w_g[0], w_g[1], w_g[2], w_g[3], w_g[4], w_g[5]);
     guard.ok = true;
     *out = res;
+    if (out_tr) {
+        guard2.ok = true;
+        *out_tr = res2;
+    }
     return DH_OK;
+}
+
+// `damapper -C <ref> <reads>`: the mapping and, as a second set, the records of the transposed pairs (read, contig) --
+// for every accepted local alignment the tiled alignment (DH-2) of A'' = the read on its forward strand against B'' = the
+// contig (complemented for a reverse-strand mapping) through the same seed, accepted on its own; one pass over the reads
+// (the reference's tools write <reads>.<ref>.las from the same alignments: source/dentist/dazzler.d:6158-6170,
+// getLasFile :4339-4354).  opts->algo must be 1.
+extern "C" int dh_align_db_transposed(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, int32_t want_best,
+                                      dh_la_set **out, dh_la_set **out_transposed)
+{
+    if (!B || !out_transposed) return fail(DH_EINVAL, "dh_align_db_transposed: NULL argument");
+    return align_range(ctx, A, B, 0, B->n, opts, want_best, 1, out, nullptr, out_transposed);
 }
 
 // ------------------------------------------------------------------------------------ .las

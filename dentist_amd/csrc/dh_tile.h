@@ -55,6 +55,11 @@ struct Params {
     const int64_t *aoff, *boff;       // offsets of the A / B sequences (bases)
     const uint32_t *apk, *arcpk;      // 2-bit packed A, forward / reverse complement: base g in dword g >> 4, bits 2 (g & 15)
     const PlanePair *bpp, *brcpp;     // plane-packed B, forward / reverse complement (indexed by absolute base >> 5)
+    // the transposed pair (mode 1: A'' = a B sequence, B'' = an A sequence): 2-bit packed B, plane-packed A.  A symmetric
+    // launch (A == B) passes the same copies here; a mapping with the transposed file (`damapper -C`) passes the second
+    // set of copies and the second set of outputs below; otherwise NULL
+    const uint32_t *apk1, *arcpk1;
+    const PlanePair *bpp1, *brcpp1;
     DhOpts o;
     int32_t item0, nitems;            // items (read * 2 + strand) [item0, item0 + nitems)
     const DhCand *cand;               // max_cand per item, indexed by absolute item
@@ -71,6 +76,9 @@ struct Params {
     DhLa *out_la;                     // max_la records per item (absolute item index)
     uint16_t *out_trace;              // trmax values per record slot
     int32_t *out_nla, *out_ntr;       // per item
+    DhLa *out_la2;                    // transposed records of a mapping (not symmetric mode), laid out like out_la; or NULL
+    uint16_t *out_trace2;
+    int32_t *out_nla2, *out_ntr2;
     unsigned long long *counters;     // [0] band cells computed, [1] candidates aligned
     int32_t *status;
 };
@@ -78,7 +86,7 @@ struct Params {
 // one running extension (registers)
 struct Ext {
     int64_t ga, gb;           // absolute base index of A'[0] / B'[0] in the copies of this direction
-    int32_t src;              // bit 0: A' from the reverse-complement copy, bit 1: B' from the reverse-complement copy
+    int32_t src;              // bit 0: A' from the reverse-complement copy, bit 1: B' from the reverse-complement copy, bit 2: transposed pair
     int32_t an, bn, tp_first;
     int32_t a0, b0, dsum, ntp;
     int32_t best_s, best_a, best_b, best_d, best_nseg;  // best end so far; nseg = trace segments up to it
@@ -103,7 +111,7 @@ struct Cold {
     // result of the reverse extension
     int32_t rv_i, rv_j, rv_d, rv_nseg, rv_klo, rv_khi;
     uint32_t rv_pair1;
-    int32_t pad_;
+    int32_t nacc2, ntr2, pad_;  // transposed records of the item (mapping with the transposed file)
 };
 
 struct Lane {
@@ -156,7 +164,7 @@ DH_HD void ext_begin(Lane &l, const Params &P, int32_t dir)
     e.an = dir ? as : c.g_alen - as;
     e.bn = dir ? bs : c.g_blen - bs;
     const bool brc_side = (c.strand != 0) != (dir != 0);
-    e.src = (dir ? 1 : 0) | (brc_side ? 2 : 0);
+    e.src = (dir ? 1 : 0) | (brc_side ? 2 : 0) | (c.mode ? 4 : 0);
     e.tp_first = dir ? ((as % ts) ? (as % ts) : ts) : ts - (as % ts);
     e.a0 = e.b0 = e.dsum = e.ntp = 0;
     e.best_s = e.best_a = e.best_b = e.best_d = e.best_nseg = 0;
@@ -184,7 +192,7 @@ DH_HD void tile_setup(const Lane &l, const Params &P, Tile &t, uint32_t *q)
     // B planes: bit x of the window string = base (gb + b0 - W/2 + x)
     {
         const int64_t g = e.gb + e.b0 - W / 2;
-        const PlanePair *p = ((e.src & 2) ? P.brcpp : P.bpp) + (g >> 5);
+        const PlanePair *p = ((e.src & 4) ? ((e.src & 2) ? P.brcpp1 : P.bpp1) : ((e.src & 2) ? P.brcpp : P.bpp)) + (g >> 5);
         const uint32_t s = (uint32_t)(g & 31);
         PlanePair r[NQ + 1];
 #pragma unroll
@@ -198,7 +206,7 @@ DH_HD void tile_setup(const Lane &l, const Params &P, Tile &t, uint32_t *q)
     // A: base x of the tile = base (ga + a0 + x)
     {
         const int64_t g = e.ga + e.a0;
-        const uint32_t *p = ((e.src & 1) ? P.arcpk : P.apk) + (g >> 4);
+        const uint32_t *p = ((e.src & 4) ? ((e.src & 1) ? P.arcpk1 : P.apk1) : ((e.src & 1) ? P.arcpk : P.apk)) + (g >> 4);
         const uint32_t s = (uint32_t)(g & 15) << 1;
         uint32_t r[NAW];
 #pragma unroll
@@ -362,6 +370,7 @@ DH_HD void lane_init(Lane &l, int32_t slot, Cold *cold)
 DH_HD uint16_t *lane_pairs(const Lane &l, const Params &P)
 {
     if (P.o.skip_self == 2) return P.tscr + (int64_t)l.slot * P.trmax;
+    if (l.c->mode) return P.out_trace2 + ((int64_t)l.c->item * P.o.max_la + l.c->nacc2) * P.trmax;
     return P.out_trace + ((int64_t)l.c->item * P.o.max_la + l.c->nacc) * P.trmax;
 }
 
@@ -405,7 +414,7 @@ DH_HD void lane_fetch(Lane &l, const Params &P, int32_t it)
         c.nc = u.c1;
         c.bo = u.bo;
         c.blen = u.blen;
-        c.nd = c.nacc = c.ntr = 0;
+        c.nd = c.nacc = c.ntr = c.nacc2 = c.ntr2 = 0;
         c.c = u.c0;
         c.c_aseq = u.aseq;
         c.as = u.apos;
@@ -424,7 +433,7 @@ DH_HD void lane_fetch(Lane &l, const Params &P, int32_t it)
     const int64_t bo = P.boff[item >> 1];
     c.bo = bo;
     c.blen = (int32_t)(P.boff[(item >> 1) + 1] - bo);
-    c.nd = c.nacc = c.ntr = 0;
+    c.nd = c.nacc = c.ntr = c.nacc2 = c.ntr2 = 0;
     c.c = 0;
     l.st = L_CAND;
 }
@@ -465,6 +474,10 @@ DH_HD void lane_next_cand(Lane &l, const Params &P)
     if (!sym) {
         P.out_nla[item] = c.nacc;
         P.out_ntr[item] = c.ntr;
+        if (P.out_la2) {
+            P.out_nla2[item] = c.nacc2;
+            P.out_ntr2[item] = c.ntr2;
+        }
     }
     l.st = L_FETCH;
 }
@@ -591,7 +604,11 @@ DH_HD void lane_ext_end(Lane &l, const Params &P)
         la.bread = mode ? c_aseq : (item >> 1);
         la.pad = 0;
         la.toff = 2 * (int64_t)first;  // where the pairs start inside the slot (k_compact honours it)
-        if (!sym) {
+        if (!sym && mode) {  // the transposed record of a mapping: at most one per accepted record, so nacc2 <= nacc
+            P.out_la2[(int64_t)item * P.o.max_la + c.nacc2] = la;
+            c.ntr2 += 2 * npairs;
+            c.nacc2 += 1;
+        } else if (!sym) {
             P.out_la[(int64_t)item * P.o.max_la + c.nacc] = la;
             c.ntr += 2 * npairs;
         } else {
@@ -599,7 +616,7 @@ DH_HD void lane_ext_end(Lane &l, const Params &P)
             emit_claimed(P, mode ? item : item_a, mode ? item_a : item, la, pairs, first, npairs);
         }
         if (mode == 0) c.nacc += 1;
-        if (sym && mode == 0) {  // the second record: the transposed pair, aligned on its own
+        if ((sym || P.out_la2) && mode == 0) {  // the second record: the transposed pair, aligned on its own
             cand_geometry(l, P, 1);
             ext_begin(l, P, 1);
             return;

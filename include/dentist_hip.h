@@ -171,6 +171,14 @@ void dh_set_near_best(int32_t ppm);
  * (Snakefile:1173-1185) on the in-memory results: one set in LAsort order. */
 int dh_align_db_block(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t count,
                       const dh_align_opts *opts, int32_t select_best, dh_la_set **out);
+/* `damapper -C`: the mapping of B onto A and, in one pass, the set of its transposed records (aread = B read, bread = A
+ * sequence; source/dentist/dazzler.d:6158-6170 writes them as <B>.<A>.las, getLasFile :4339-4354).  DH-2 only
+ * (opts->algo = 1, A != B): for every accepted local alignment the transposed pair -- A'' = the read on its forward
+ * strand, B'' = the contig, complemented for a reverse-strand mapping -- is aligned through the same seed and accepted
+ * on its own (min_len, max_err_ppm); its trace lies on the read's grid.  want_best: chain flags on both sets (the
+ * transposed set with the roles of the sequences exchanged).  Both sets in LAsort order. */
+int dh_align_db_transposed(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, int32_t want_best,
+                           dh_la_set **out, dh_la_set **out_transposed);
 int dh_la_set_merge(const dh_la_set *const *sets, int32_t nsets, dh_la_set **out);
 
 /* ---- .las files: replaces the reader/writer pair of source/dentist/dazzler.d:1665-1834

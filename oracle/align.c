@@ -959,8 +959,9 @@ static int la_accept(const oz_la *la, const oz_opts *o)
     return (int64_t)2 * la->diffs * 1000000 <= (int64_t)o->max_err_ppm * (al + bl);
 }
 
+/* out2 (optional, DH-2 and A != B only): the records of the transposed pairs -- `damapper -C`'s second file */
 static void align_read(const oz_index *ix, const oz_db *A, const oz_db *B, int32_t r,
-                       const oz_opts *o, oz_la_set *out, int64_t *stats, oz_cand *cands,
+                       const oz_opts *o, oz_la_set *out, oz_la_set *out2, int64_t *stats, oz_cand *cands,
                        uint8_t *rc, uint16_t *trace, uint16_t *trace2)
 {
     const uint8_t *bf = B->bases + B->off[r];
@@ -1032,8 +1033,8 @@ static void align_read(const oz_index *ix, const oz_db *A, const oz_db *B, int32
             la.bread = r;
             la.flags = strand ? OZ_FLAG_COMP : 0;
             la_set_push(out, &la, trace);
-            if (sym && tiled) {
-                /* DH-2, symmetric: the record (b, a) is the tiled alignment of the transposed pair through the
+            if ((sym || out2) && tiled) {
+                /* DH-2, symmetric (or the transposed file of a mapping): the record (b, a) is the tiled alignment of the transposed pair through the
                  * same seed -- A'' = the read behind B on its forward strand (the trace grid of that record),
                  * B'' = the A read, complemented when B is (then both axes are mirrored: the seed point
                  * (as, bs) becomes (blen - bs, alen - as)).  It is accepted on its own length and error. */
@@ -1054,7 +1055,7 @@ static void align_read(const oz_index *ix, const oz_db *A, const oz_db *B, int32
                     la2.aread = r;
                     la2.bread = cd->aseq;
                     la2.flags = la.flags;
-                    la_set_push(out, &la2, trace2);
+                    la_set_push(sym ? out : out2, &la2, trace2);
                 }
             } else if (sym) { /* the transposed record of the same alignment: A and B swapped */
                 la2.aread = r;
@@ -1070,6 +1071,13 @@ static void align_read(const oz_index *ix, const oz_db *A, const oz_db *B, int32
 int oz_align_db(const oz_db *A, const oz_db *B, const oz_opts *o, int nthreads, oz_la_set *out,
                 int64_t *stats)
 {
+    return oz_align_db2(A, B, o, nthreads, out, NULL, stats);
+}
+
+int oz_align_db2(const oz_db *A, const oz_db *B, const oz_opts *o, int nthreads, oz_la_set *out, oz_la_set *out2,
+                 int64_t *stats)
+{
+    if (out2 && (o->algo != 1 || o->skip_self == 2)) return -1; /* the transposed file is defined for DH-2 mappings */
     int32_t max_blen = 0, max_alen = 0;
     for (int32_t r = 0; r < B->n; r++) {
         int32_t l = (int32_t)(B->off[r + 1] - B->off[r]);
@@ -1083,6 +1091,7 @@ int oz_align_db(const oz_db *A, const oz_db *B, const oz_opts *o, int nthreads, 
     int64_t st[4] = {0, 0, 0, 0};
     if (nthreads < 1) nthreads = 1;
     oz_la_set *parts = (oz_la_set *)calloc((size_t)nthreads, sizeof(oz_la_set));
+    oz_la_set *parts2 = (oz_la_set *)calloc((size_t)nthreads, sizeof(oz_la_set));
     int64_t(*pst)[4] = (int64_t(*)[4])calloc((size_t)nthreads, sizeof(int64_t[4]));
 #ifdef _OPENMP
 #pragma omp parallel num_threads(nthreads)
@@ -1101,7 +1110,7 @@ int oz_align_db(const oz_db *A, const oz_db *B, const oz_opts *o, int nthreads, 
         /* contiguous read ranges per thread keep the merged output in read order */
         const int64_t lo = (int64_t)B->n * tid / nt, hi = (int64_t)B->n * (tid + 1) / nt;
         for (int64_t r = lo; r < hi; r++)
-            align_read(ix, A, B, (int32_t)r, o, &parts[tid], pst[tid], cands, rc, trace, trace2);
+            align_read(ix, A, B, (int32_t)r, o, &parts[tid], out2 ? &parts2[tid] : NULL, pst[tid], cands, rc, trace, trace2);
         free(cands);
         free(rc);
         free(trace);
@@ -1110,10 +1119,14 @@ int oz_align_db(const oz_db *A, const oz_db *B, const oz_opts *o, int nthreads, 
     for (int t = 0; t < nthreads; t++) {
         for (int64_t i = 0; i < parts[t].n; i++)
             la_set_push(out, &parts[t].la[i], parts[t].trace + parts[t].la[i].toff);
+        for (int64_t i = 0; out2 && i < parts2[t].n; i++)
+            la_set_push(out2, &parts2[t].la[i], parts2[t].trace + parts2[t].la[i].toff);
         for (int q = 0; q < 4; q++) st[q] += pst[t][q];
         oz_la_set_free(&parts[t]);
+        oz_la_set_free(&parts2[t]);
     }
     free(parts);
+    free(parts2);
     free(pst);
     if (stats)
         for (int q = 0; q < 4; q++) stats[q] = st[q];

@@ -130,6 +130,12 @@ int oz_local_align(const uint8_t *a, int32_t alen, const uint8_t *b, int32_t ble
 /* whole pass: every B read against the index of A (daligner / damapper role) */
 int oz_align_db(const oz_db *A, const oz_db *B, const oz_opts *o, int nthreads, oz_la_set *out,
                 int64_t *stats /* [0]=hits [1]=cands [2]=alignments [3]=wave cells */);
+/* + out2 (may be NULL): for DH-2 mappings (algo 1, A != B) the records of the transposed pairs, (aread = read,
+ * bread = contig): the tiled alignment of A'' = the read on its forward strand, B'' = the contig (complemented for a
+ * reverse-strand mapping) through the same seed, accepted on its own -- the second file of `damapper -C`
+ * (source/dentist/dazzler.d:6158-6170, getLasFile :4339-4354) */
+int oz_align_db2(const oz_db *A, const oz_db *B, const oz_opts *o, int nthreads, oz_la_set *out, oz_la_set *out2,
+                 int64_t *stats);
 
 /* damapper-style per-read selection: sets START/BEST flags (dazzler.d:1728-1758 consumer) */
 void oz_select_best(oz_la_set *s);

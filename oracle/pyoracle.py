@@ -53,6 +53,8 @@ def lib():
         L.oz_default_opts.argtypes = [ctypes.POINTER(Opts)]
         L.oz_align_db.argtypes = [ctypes.POINTER(Db), ctypes.POINTER(Db), ctypes.POINTER(Opts),
                                   ctypes.c_int, ctypes.POINTER(LaSet), ctypes.c_void_p]
+        L.oz_align_db2.argtypes = [ctypes.POINTER(Db), ctypes.POINTER(Db), ctypes.POINTER(Opts), ctypes.c_int,
+                                   ctypes.POINTER(LaSet), ctypes.POINTER(LaSet), ctypes.c_void_p]
         L.oz_la_set_init.argtypes = [ctypes.POINTER(LaSet)]
         L.oz_la_set_free.argtypes = [ctypes.POINTER(LaSet)]
         L.oz_la_set_sort.argtypes = [ctypes.POINTER(LaSet)]
@@ -134,6 +136,24 @@ def align_db(A, B, opts, nthreads=1, sort=True, select_best=False):
         L.oz_la_set_sort(ctypes.byref(ls))
     las, trace = _take(ls)
     return las, trace, stats
+
+
+def align_db_transposed(A, B, opts, nthreads=1):
+    """oz_align_db2: a DH-2 mapping and the records of its transposed pairs (`damapper -C`).  Returns
+    ((records, trace), (transposed records, trace)), both in LAsort order; chain flags are not set."""
+    L = lib()
+    ls, ls2 = LaSet(), LaSet()
+    L.oz_la_set_init(ctypes.byref(ls))
+    L.oz_la_set_init(ctypes.byref(ls2))
+    stats = np.zeros(4, dtype=np.int64)
+    da, dbb = _db(A), _db(B)
+    rc = L.oz_align_db2(ctypes.byref(da), ctypes.byref(dbb), ctypes.byref(opts), nthreads, ctypes.byref(ls), ctypes.byref(ls2),
+                        stats.ctypes.data)
+    if rc != 0:
+        raise ValueError("oz_align_db2: the transposed file is defined for algo = 1 and skip_self != 2")
+    L.oz_la_set_sort(ctypes.byref(ls))
+    L.oz_la_set_sort(ctypes.byref(ls2))
+    return _take(ls), _take(ls2)
 
 
 def nw(ref, qry, indel=1, free_shift=False):

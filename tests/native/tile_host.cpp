@@ -36,10 +36,12 @@ static void revcomp_all(const uint8_t *src, const int64_t *off, int32_t n, std::
 
 // every item (read * 2 + strand) of B against its candidates; results compacted in item order.
 // out_la: capacity nitems * max_la; out_trace: capacity cap_trace u16; returns the number of records or < 0
-extern "C" long dh_tile_host_align(const uint8_t *abases, const int64_t *aoff, int32_t na, const uint8_t *bbases,
-                                   const int64_t *boff, int32_t nb, const DhOpts *o, const DhCand *cand,
-                                   const int32_t *ncand, int32_t nbmax, DhLa *out_la, uint16_t *out_trace,
-                                   long cap_trace, unsigned long long *counters)
+// out_la2 / out_trace2 / n2 (optional): the transposed records of the mapping (`damapper -C`), compacted in item order
+extern "C" long dh_tile_host_align2(const uint8_t *abases, const int64_t *aoff, int32_t na, const uint8_t *bbases,
+                                    const int64_t *boff, int32_t nb, const DhOpts *o, const DhCand *cand,
+                                    const int32_t *ncand, int32_t nbmax, DhLa *out_la, uint16_t *out_trace,
+                                    long cap_trace, unsigned long long *counters, DhLa *out_la2, uint16_t *out_trace2,
+                                    long *n2)
 {
     const int64_t PADW = 8;
     std::vector<uint8_t> arc, brc;
@@ -51,6 +53,13 @@ extern "C" long dh_tile_host_align(const uint8_t *abases, const int64_t *aoff, i
     pack2(arc.data(), aoff[na], arcpk, PADW);
     planes(bbases, boff[nb], bpp, PADW);
     planes(brc.data(), boff[nb], brcpp, PADW);
+    // the copies of the transposed pairs: 2-bit packed B, plane-packed A
+    std::vector<uint32_t> bpk, brcpk;
+    std::vector<PlanePair> app, arcpp;
+    pack2(bbases, boff[nb], bpk, PADW);
+    pack2(brc.data(), boff[nb], brcpk, PADW);
+    planes(abases, aoff[na], app, PADW);
+    planes(arc.data(), aoff[na], arcpp, PADW);
     const int32_t nitems = 2 * nb, trmax = 2 * (2 * nbmax + 2);
     std::vector<DhLa> slots((size_t)nitems * o->max_la);
     std::vector<uint16_t> tr((size_t)nitems * o->max_la * trmax, 0);
@@ -64,6 +73,17 @@ extern "C" long dh_tile_host_align(const uint8_t *abases, const int64_t *aoff, i
     P.arcpk = arcpk.data() + PADW;
     P.bpp = bpp.data() + PADW;
     P.brcpp = brcpp.data() + PADW;
+    P.apk1 = bpk.data() + PADW;
+    P.arcpk1 = brcpk.data() + PADW;
+    P.bpp1 = app.data() + PADW;
+    P.brcpp1 = arcpp.data() + PADW;
+    std::vector<DhLa> slots2(out_la2 ? (size_t)2 * nb * o->max_la : 0);
+    std::vector<uint16_t> tr2(out_la2 ? (size_t)2 * nb * o->max_la * (2 * (2 * nbmax + 2)) : 0, 0);
+    std::vector<int32_t> nla2((size_t)2 * nb, 0), ntr2((size_t)2 * nb, 0);
+    P.out_la2 = out_la2 ? slots2.data() : nullptr;
+    P.out_trace2 = out_la2 ? tr2.data() : nullptr;
+    P.out_nla2 = nla2.data();
+    P.out_ntr2 = ntr2.data();
     P.o = *o;
     P.item0 = 0;
     P.nitems = nitems;
@@ -131,5 +151,28 @@ extern "C" long dh_tile_host_align(const uint8_t *abases, const int64_t *aoff, i
             tn += la.tlen;
             out_la[n++] = la;
         }
+    if (out_la2) {
+        long m = 0, tm = 0;
+        for (int32_t it = 0; it < nitems; it++)
+            for (int32_t s = 0; s < nla2[(size_t)it]; s++) {
+                DhLa la = slots2[(size_t)it * o->max_la + s];
+                const uint16_t *src = tr2.data() + ((size_t)it * o->max_la + s) * trmax + la.toff;
+                if (tm + la.tlen > cap_trace) return -100;
+                memcpy(out_trace2 + tm, src, sizeof(uint16_t) * (size_t)la.tlen);
+                la.toff = tm;
+                tm += la.tlen;
+                out_la2[m++] = la;
+            }
+        *n2 = m;
+    }
     return n;
+}
+
+extern "C" long dh_tile_host_align(const uint8_t *abases, const int64_t *aoff, int32_t na, const uint8_t *bbases,
+                                   const int64_t *boff, int32_t nb, const DhOpts *o, const DhCand *cand,
+                                   const int32_t *ncand, int32_t nbmax, DhLa *out_la, uint16_t *out_trace,
+                                   long cap_trace, unsigned long long *counters)
+{
+    return dh_tile_host_align2(abases, aoff, na, bbases, boff, nb, o, cand, ncand, nbmax, out_la, out_trace, cap_trace, counters,
+                               nullptr, nullptr, nullptr);
 }

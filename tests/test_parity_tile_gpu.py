@@ -163,3 +163,31 @@ def test_damapper_chains_of_reads_with_a_long_indel(gpu_ctx):
         assert chained >= 6
         plain = las[~np.isin(las["bread"], planted)]
         assert np.all((plain["flags"] & 0x4) != 0) or np.any((plain["flags"] & 0x8) != 0)
+
+
+@pytest.mark.parametrize("chunk", [None, "300"])
+def test_transposed_records_of_a_mapping(gpu_ctx, monkeypatch, chunk):
+    """dh_align_db_transposed (`damapper -C`): the mapping and, from the same pass, the records (read, contig) of the
+    transposed pairs -- A'' = the read forward, B'' = the contig (complemented for reverse-strand mappings), through
+    the same seed, accepted on its own, trace on the read's grid -- against oz_align_db2, bit-exact, also when the reads
+    come in several chunks; the first set equals the plain call."""
+    if chunk:
+        monkeypatch.setenv("DH_ALIGN_CHUNK", chunk)
+    w = sim.Workload(500_000, 5, 900, 6000, seed=29, spacing=20000, gap_max=1200)
+    o = dentist_amd.default_align_opts(k=16, kmer_mod=2, **T)
+    A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
+    (las, trace), (las2, trace2) = gpu_ctx.align_db_transposed(A, B, o)
+    plain = gpu_ctx.align_db(A, B, o)
+    assert_same_las((las, trace), plain)
+    oo = oz.default_opts(k=16, kmer_mod=2, **T)
+    (exp, exp_t), (exp2, exp2_t) = oz.align_db_transposed(w.contigs, w.reads, oo, nthreads=8)
+    assert len(exp) > 800 and len(exp2) > 0.95 * len(exp) and ((exp2["flags"] & 1) != 0).any()
+    assert_same_las((las, trace), (exp, exp_t))
+    assert_same_las((las2, trace2), (exp2, exp2_t))
+    check_trace_invariants(las2, trace2, o.tspace)
+    # chain flags on both sets; every transposed record belongs to a chain of its read
+    (_, _), (best2, _) = gpu_ctx.align_db_transposed(A, B, o, select_best=True)
+    assert len(best2) == len(las2) and np.all((best2["flags"] & (0x4 | 0x8)) != 0) and ((best2["flags"] & 0x10) != 0).any()
+    # refused where it is not defined
+    with pytest.raises(dentist_amd.DhError):
+        gpu_ctx.align_db_transposed(A, B, dentist_amd.default_align_opts(k=16, kmer_mod=2))   # DH-1

@@ -105,3 +105,46 @@ def test_symmetric_all_vs_all(host_lib, seed, grouped):
     assert int(counters[0]) == stats[3] and int(counters[1]) == stats[2]
     comp = las[(las["flags"] & 1) != 0]
     assert len(comp) > 0 and len(las) % 2 == 0
+
+
+def test_transposed_records_of_a_mapping(host_lib):
+    """`damapper -C`: next to every record (contig, read) the record (read, contig) of the transposed pair -- A'' = the
+    read on its forward strand, B'' = the contig (complemented for reverse-strand mappings), through the same seed,
+    accepted on its own; trace on the read's grid.  Lane code (mode 1 of a plain launch) against oz_align_db2."""
+    w = sim.Workload(300_000, 4, 400, 5000, seed=9, err=0.13, spacing=20000, gap_max=800)
+    o = oz.default_opts(algo=1, width=64, k=16, kmer_mod=2, tspace=100)
+    (exp, exp_t), (exp2, exp2_t) = oz.align_db_transposed(w.contigs, w.reads, o, nthreads=4)
+    L = host_lib
+    L.dh_tile_host_align2.restype = ctypes.c_long
+    L.dh_tile_host_align2.argtypes = L.dh_tile_host_align.argtypes + [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_long)]
+    A, B = w.contigs, w.reads
+    cand, ncand = oz.seed_candidates_all(A, B, o)
+    dc = np.zeros(cand.shape, dtype=DHCAND)
+    for f in ("score", "aseq", "apos", "bpos"):
+        dc[f] = cand[f]
+    dc = np.ascontiguousarray(dc)
+    maxlen = int(max((A.off[1:] - A.off[:-1]).max(), (B.off[1:] - B.off[:-1]).max()))
+    nbmax = maxlen // o.tspace + 3
+    cap = int(2 * B.n * o.max_la * 2 * (2 * nbmax + 2))
+    las, las2 = (np.zeros(2 * B.n * o.max_la, dtype=oz.LA_DTYPE) for _ in range(2))
+    trace, trace2 = (np.zeros(cap, dtype=np.uint16) for _ in range(2))
+    counters = np.zeros(2, dtype=np.uint64)
+    n2 = ctypes.c_long(0)
+    n = L.dh_tile_host_align2(A.bases.ctypes.data, A.off.ctypes.data, A.n, B.bases.ctypes.data, B.off.ctypes.data, B.n,
+                              ctypes.byref(o), dc.ctypes.data, ncand.ctypes.data, nbmax, las.ctypes.data, trace.ctypes.data,
+                              cap, counters.ctypes.data, las2.ctypes.data, trace2.ctypes.data, ctypes.byref(n2))
+    assert n >= 0 and len(exp) >= 350 and len(exp2) >= 0.95 * len(exp)
+    from helpers import la_rows
+    assert sorted(la_rows(las[:n], trace)) == sorted(la_rows(exp, exp_t))
+    assert sorted(la_rows(las2[:n2.value], trace2)) == sorted(la_rows(exp2, exp2_t))
+    check_trace_invariants(las2[:n2.value], trace2, o.tspace)
+    t2 = las2[:n2.value]
+    assert np.all(t2["aread"] < w.reads.n) and np.all(t2["bread"] < w.contigs.n) and ((t2["flags"] & 1) != 0).any()
+    # the two records of a pair describe the same overlap: equal spans up to the slack of independent band paths
+    key = {(int(r["bread"]), int(r["aread"]), int(r["flags"]) & 1): r for r in las[:n]}
+    close = 0
+    for r in t2:
+        f = key.get((int(r["aread"]), int(r["bread"]), int(r["flags"]) & 1))
+        if f is not None and abs((r["aepos"] - r["abpos"]) - (f["bepos"] - f["bbpos"])) <= 64:
+            close += 1
+    assert close >= 0.9 * len(t2)

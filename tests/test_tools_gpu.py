@@ -56,9 +56,15 @@ def test_damapper_executable_matches_the_library(gpu_ctx, tmp_path):
     exp = library(A)
     assert_same_las((las, trace), exp)
     assert np.all((las["flags"] & (0x4 | 0x8)) != 0)   # every record is part of a chain
-    assert os.path.exists(tmp_path / "reads.1.ref.las")
-    back, _, _ = dentist_amd.las_read(str(tmp_path / "reads.1.ref.las"))
-    assert len(back) > 0 and set(back["aread"].tolist()) <= set(range(w.reads.n))
+    # -C: the transposed file of the same pass (dh_align_db_transposed), chains with -n.85 applied to it as well
+    back, btrace, _ = dentist_amd.las_read(str(tmp_path / "reads.1.ref.las"))
+    dentist_amd.lib().dh_set_near_best(850000)
+    try:
+        (_, _), (bl, bt) = gpu_ctx.align_db_transposed(A, B, dentist_amd.default_align_opts(algo=1, width=64), select_best=True)
+    finally:
+        dentist_amd.lib().dh_set_near_best(0)
+    assert_same_las((back, btrace), (bl[(bl["flags"] & 0x20) == 0], bt))
+    assert len(back) > 0.9 * len(las) and set(back["aread"].tolist()) <= set(range(w.reads.n))
     # -m<track>: an existing track is applied (fewer seeds, same reads mapped), a missing one is reported
     db = dentist_amd.DazzDb(ref)
     ptr = np.zeros(db.n + 1, dtype=np.int64)

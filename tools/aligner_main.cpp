@@ -192,15 +192,19 @@ int main(int argc, char **argv)
             oo.max_la = std::max(oo.max_la, 64);
             oo.max_cand = std::max(oo.max_cand, 128);
         }
-        dh_la_set *ab = nullptr;
-        CHK(dh_align_db(ctx, A.dev, B.dev, &oo, mapper ? 1 : 0, &ab));
+        dh_la_set *ab = nullptr, *ba = nullptr;
+        // damapper -C: the transposed file comes out of the same pass (the transposed pair of every alignment, through
+        // its seed); daligner without -A aligns the DBs in exchanged roles for its second file
+        const bool transposed = !same && mapper && flagC;
+        if (transposed)
+            CHK(dh_align_db_transposed(ctx, A.dev, B.dev, &oo, 1, &ab, &ba));
+        else
+            CHK(dh_align_db(ctx, A.dev, B.dev, &oo, mapper ? 1 : 0, &ab));
         write_las(A.name + "." + B.name + ".las", ab, dh_dazz_first_id(A.dz), dh_dazz_first_id(B.dz), o.tspace);
         if (verbose) fprintf(stderr, "%s: %lld local alignments -> %s.%s.las\n", mode.c_str(), (long long)dh_la_set_count(ab), A.name.c_str(), B.name.c_str());
         dh_la_set_destroy(ab);
-        // the symmetric file: daligner writes B.A.las unless -A (or A == B), damapper only with -C
-        if (!same && ((!mapper && !flagA) || (mapper && flagC))) {
-            dh_la_set *ba = nullptr;
-            CHK(dh_align_db(ctx, B.dev, A.dev, &oo, mapper ? 1 : 0, &ba));
+        if (!same && !mapper && !flagA) CHK(dh_align_db(ctx, B.dev, A.dev, &oo, 0, &ba));
+        if (ba) {
             write_las(B.name + "." + A.name + ".las", ba, dh_dazz_first_id(B.dz), dh_dazz_first_id(A.dz), o.tspace);
             dh_la_set_destroy(ba);
         }
