@@ -87,7 +87,7 @@ SYMBOLS = [
     "dh_map_reads", "dh_validate_regions", "dh_propagate_mask", "dh_db_mask_coverage", "dh_max_coverage_reads", "dh_max_improper_coverage_reads",
     "dh_default_scaffold_opts", "dh_scaffold_pileups", "dh_scaffold_npiles", "dh_scaffold_nentries", "dh_scaffold_joins",
     "dh_scaffold_entries", "dh_scaffold_destroy", "dh_scaffold_spanning", "dh_scaffold_gap_pileups", "dh_cropped_create2",
-    "dh_cropped_kind", "dh_set_near_best", "dh_shard_free", "dh_shard_pack_candidates", "dh_shard_plan_create", "dh_shard_read_joins", "dh_align_db_transposed", "dh_shard_graph_plan_create", "dh_shard_plan_destroy",
+    "dh_cropped_kind", "dh_set_near_best", "dh_shard_free", "dh_shard_pack_candidates", "dh_shard_plan_create", "dh_shard_read_joins", "dh_align_db_transposed", "dh_remap_skipping_reads", "dh_shard_graph_plan_create", "dh_shard_plan_destroy",
     "dh_shard_plan_las", "dh_shard_plan_nlas", "dh_shard_plan_pileups", "dh_shard_plan_owner", "dh_shard_pack_cropped",
     "dh_shard_unpack_cropped", "dh_insertions_read_ids", "dh_insertions_read_ids_off", "dh_output_assembly", "dh_default_output_opts",
 ]
@@ -295,6 +295,20 @@ class Context:
         st = CumStats()
         _check(lib().dh_get_cum_stats(self._h, ctypes.byref(st), int(reset)))
         return st
+
+    def remap_skipping_reads(self, contigs, reads, contig_ids, read_ids, opts, allowance):
+        """dh_remap_skipping_reads: the re-mapping call of `resolveBubbles` (pileups.d:1316-1385)."""
+        ci = np.ascontiguousarray(contig_ids, dtype=np.int32)
+        ri = np.ascontiguousarray(read_ids, dtype=np.int32)
+        h = ctypes.c_void_p()
+        L = lib()
+        L.dh_remap_skipping_reads.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
+                                              ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+                                              ctypes.POINTER(ctypes.c_void_p)]
+        _check(L.dh_remap_skipping_reads(self._h, contigs._h, reads._h, ci.ctypes.data, len(ci), ri.ctypes.data, len(ri),
+                                         ctypes.byref(opts), int(allowance), ctypes.byref(h)))
+        las, trace, _ = _take_la_set(h)
+        return las, trace
 
     def align_db_transposed(self, A, B, opts, select_best=False):
         """dh_align_db_transposed (`damapper -C`): ((records, trace), (transposed records, trace)), LAsort order."""

@@ -2281,3 +2281,55 @@ extern "C" int dh_shard_unpack_cropped(const uint8_t *const *blobs, const int64_
     *out = c;
     return DH_OK;
 }
+
+// ------------------------------------------------------------------------------------ bubbles
+// getReadAlignmentsOnContigs of `resolveBubbles` (collectPileUps/pileups.d:1316-1385): the reads of a pile-up whose
+// join skips contigs are mapped again, without any mask, onto just those intermediate contigs (the reference builds
+// two DB subsets and spawns damapper on them, :1337-1366); chains that do not cover their contig completely within
+// `allowance` (AlignmentChain.completelyCovers!"contigA", common/alignments/base.d:562-566) are disabled, ids are
+// those of the full DBs again (:1373-1380).  The graph surgery around it (BubbleResolver) stays with the caller.
+extern "C" int dh_remap_skipping_reads(dh_ctx *ctx, dh_db *contigs, dh_db *reads, const int32_t *contig_ids, int32_t ncontig_ids,
+                                       const int32_t *read_ids, int32_t nread_ids, const dh_align_opts *opts, int32_t allowance,
+                                       dh_la_set **out)
+{
+    if (!ctx || !contigs || !reads || !contig_ids || !read_ids || !opts || !out || ncontig_ids < 1 || nread_ids < 1 || allowance < 0)
+        return dh_fail(DH_EINVAL, "dh_remap_skipping_reads: bad argument");
+    auto subset = [&](dh_db *src, const int32_t *ids, int32_t n, dh_db **sub) -> int {
+        std::vector<int32_t> sidx((size_t)n), sbeg((size_t)n, 0), slen((size_t)n);
+        for (int32_t i = 0; i < n; i++) {
+            if (ids[i] < 0 || ids[i] >= src->n || (i > 0 && ids[i] <= ids[i - 1]))
+                return dh_fail(DH_EINVAL, "dh_remap_skipping_reads: ids must be ascending, distinct and inside the DB");
+            sidx[(size_t)i] = ids[i];
+            slen[(size_t)i] = (int32_t)(src->h_off[(size_t)ids[i] + 1] - src->h_off[(size_t)ids[i]]);
+        }
+        return dh_db_from_slices(ctx, src, sidx, sbeg, slen, {}, sub);  // no mask: "align without any mask"
+    };
+    dh_db *sa = nullptr, *sb = nullptr;
+    if (int rc = subset(contigs, contig_ids, ncontig_ids, &sa)) return rc;
+    if (int rc = subset(reads, read_ids, nread_ids, &sb)) {
+        dh_db_destroy(sa);
+        return rc;
+    }
+    dh_la_set *set = nullptr;
+    const int rc = dh_align_db(ctx, sa, sb, opts, 1, &set);
+    if (!rc) {
+        // chains in file order: START, then its NEXT records (how the reference reads them, dazzler.d:1728-1758)
+        LaVec &la = set->la;
+        for (size_t i = 0; i < la.size();) {
+            size_t j = i + 1;
+            while (j < la.size() && (la[j].flags & DH_FLAG_NEXT) && !(la[j].flags & DH_FLAG_START)) j++;
+            const int32_t alen = (int32_t)(sa->h_off[(size_t)la[i].aread + 1] - sa->h_off[(size_t)la[i].aread]);
+            const bool covers = la[i].abpos <= allowance && la[j - 1].aepos >= alen - allowance;
+            for (size_t x = i; x < j; x++) {
+                if (!covers) la[x].flags |= DH_FLAG_DISABLED;
+                la[x].aread = contig_ids[la[x].aread];
+                la[x].bread = read_ids[la[x].bread];
+            }
+            i = j;
+        }
+        *out = set;
+    }
+    dh_db_destroy(sa);
+    dh_db_destroy(sb);
+    return rc;
+}

@@ -335,6 +335,15 @@ const dh_read_alignment *dh_scaffold_entries(const dh_scaffold *s);
 void dh_scaffold_destroy(dh_scaffold *s);
 /* the pile-ups dh_process_pileups handles -- gap joins (c, end)--(c + 1, begin) -- with their spanning
  * read alignments as (read, left LA, right LA) triples; *skipped = pile-ups of any other kind */
+/* The re-mapping call of `resolveBubbles` (getReadAlignmentsOnContigs, collectPileUps/pileups.d:1316-1385): the reads
+ * read_ids[] (those of a pile-up whose join skips contigs) are mapped, without any mask, onto the intermediate contigs
+ * contig_ids[] alone -- the reference builds two DB subsets and spawns damapper on them (:1337-1366); here the subsets
+ * are gathered on the device.  Chains that do not cover their contig completely within `allowance`
+ * (completelyCovers!"contigA", common/alignments/base.d:562-566) come back DISABLED; ids are those of the full DBs
+ * (:1373-1380).  Ids 0-based, ascending, distinct.  The graph surgery of BubbleResolver stays with the caller. */
+int dh_remap_skipping_reads(dh_ctx *ctx, dh_db *contigs, dh_db *reads, const int32_t *contig_ids, int32_t ncontig_ids,
+                            const int32_t *read_ids, int32_t nread_ids, const dh_align_opts *opts, int32_t allowance,
+                            dh_la_set **out);
 int dh_scaffold_spanning(const dh_scaffold *s, const dh_la *las, int64_t n, dh_pileups **out, int32_t *skipped);
 /* the same pile-ups with EVERY read alignment the builder put into them, as `dentist process` gets them
  * (pile-ups.db): besides the spanning reads the extension-type read alignments that mergeExtensionsWithGaps

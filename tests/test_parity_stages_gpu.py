@@ -78,3 +78,50 @@ def test_consensus_known_answer_of_the_reference(gpu_ctx):
         for rounds in (1, 3):
             cons = dentist_amd.consensus(gpu_ctx, dd, las, trace, 100, ref, rounds=rounds)
             assert sim.decode(cons) == d["expected_consensus"].lower()
+
+
+def test_remapping_call_of_the_bubble_resolver(gpu_ctx):
+    """dh_remap_skipping_reads = getReadAlignmentsOnContigs of resolveBubbles (collectPileUps/pileups.d:1316-1385):
+    the skipping reads against the intermediate contigs alone, no mask, chains that do not cover their contig within the
+    allowance disabled, ids of the full DBs -- against the same steps done by hand (host subsets, dh_align_db with chain
+    flags, the completelyCovers rule of base.d:562-566)."""
+    import dentist_amd
+    from dentist_amd import sim
+    from helpers import assert_same_las
+    g = sim.genome(5, 60000)
+    contigs = sim.SeqDb.from_list([g[:20000], g[20080:20700], g[20780:45000], g[45060:45900], g[46000:60000]])
+    reads, truth = sim.reads(6, g, 260, 6000)
+    # reads that touch one of the two short intermediate contigs (1 and 3)
+    touch = lambda s, e: (truth[:, 0] < e - 100) & (truth[:, 1] > s + 100)   # noqa: E731
+    read_ids = np.nonzero(touch(20080, 20700) | touch(45060, 45900))[0].astype(np.int32)
+    contig_ids = np.asarray([1, 3], dtype=np.int32)
+    assert len(read_ids) >= 20
+    A, B = gpu_ctx.db(contigs), gpu_ctx.db(reads)
+    o = dentist_amd.default_align_opts(algo=1, width=64, k=14, min_len=300)
+    allowance = 100
+    las, trace = gpu_ctx.remap_skipping_reads(A, B, contig_ids, read_ids, o, allowance)
+    subA = sim.SeqDb.from_list([contigs.seq(int(c)) for c in contig_ids])
+    subB = sim.SeqDb.from_list([reads.seq(int(r)) for r in read_ids])
+    el, et = gpu_ctx.align_db(gpu_ctx.db(subA), gpu_ctx.db(subB), o, select_best=True)
+    el = el.copy()
+    i = 0
+    while i < len(el):
+        j = i + 1
+        while j < len(el) and (el["flags"][j] & 0x8) and not (el["flags"][j] & 0x4):
+            j += 1
+        alen = subA.length(int(el["aread"][i]))
+        if not (el["abpos"][i] <= allowance and el["aepos"][j - 1] >= alen - allowance):
+            el["flags"][i:j] |= 0x20
+        i = j
+    el["aread"] = contig_ids[el["aread"]]
+    el["bread"] = read_ids[el["bread"]]
+    assert_same_las((las, trace), (el, et))
+    on = las[(las["flags"] & 0x20) == 0]
+    assert len(on) >= 10 and len(on) < len(las) and set(on["aread"].tolist()) == {1, 3}
+    # what stays enabled really spans its contig in the read's truth
+    cs = np.asarray([0, 20080, 20780, 45060, 46000])
+    for r in on:
+        s, e = truth[r["bread"], 0], truth[r["bread"], 1]
+        assert s <= cs[r["aread"]] + allowance + 60 and e >= cs[r["aread"]] + contigs.length(int(r["aread"])) - allowance - 60
+    with pytest.raises(dentist_amd.DhError):
+        gpu_ctx.remap_skipping_reads(A, B, [3, 1], read_ids, o, allowance)   # ids must ascend
