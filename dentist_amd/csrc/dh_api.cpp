@@ -723,6 +723,12 @@ static int build_index(dh_db *A, int32_t k, int32_t sepv, int32_t kmer_mod)
     HIPCHK(dh_dev_alloc(&d_sums, sizeof(uint32_t) * (size_t)nsum));
     HIPCHK(hipMemcpyAsync(ix.d_goff, goff.data(), sizeof(int64_t) * goff.size(), hipMemcpyHostToDevice,
                           ctx->stream));
+    // sequence of every page of the virtual axis: one load instead of a binary search over goff per candidate
+    std::vector<int32_t> page_seq((size_t)(g >> 12) + 1, A->n > 0 ? A->n - 1 : 0);
+    for (int32_t s2 = 0; s2 < A->n; s2++)
+        for (int64_t pg = goff[(size_t)s2] >> 12; pg < (goff[(size_t)s2 + 1] >> 12); pg++) page_seq[(size_t)pg] = s2;
+    HIPCHK(dh_dev_alloc(&ix.d_page_seq, sizeof(int32_t) * page_seq.size()));
+    HIPCHK(hipMemcpyAsync(ix.d_page_seq, page_seq.data(), sizeof(int32_t) * page_seq.size(), hipMemcpyHostToDevice, ctx->stream));
     if (!tiles.empty())
         HIPCHK(hipMemcpyAsync(d_tiles, tiles.data(), sizeof(int2) * tiles.size(), hipMemcpyHostToDevice,
                               ctx->stream));
@@ -1194,7 +1200,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
 
     DhOpts dopt;
     memcpy(&dopt, &o, sizeof(dopt));
-    IndexView iv{A->ix.d_fat, A->ix.d_ent, A->ix.d_goff, A->ix.n,
+    IndexView iv{A->ix.d_fat, A->ix.d_ent, A->ix.d_goff, A->ix.d_page_seq, A->ix.n,
                  A->ix.na,    A->ix.sepv,   A->ix.shift,  A->ix.pbits};
     const DbView av = A->view(), bv = B->view();
 

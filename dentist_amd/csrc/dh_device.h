@@ -35,6 +35,7 @@ struct IndexView {
     const ulonglong2 *fat;  // one word per bucket
     const ulonglong2 *ent;  // x = group * 4^k + canonical k-mer, bit 63: the k-mer of A is its reverse complement; y = aseq << 40 | virtual position
     const int64_t *goff;   // virtual offset of every A sequence
+    const int32_t *page_seq;  // A sequence of every 4096-base page of the virtual axis (sequences start on page boundaries)
     int64_t n;
     int32_t na, sepv, shift, pbits;
 };

@@ -76,6 +76,7 @@ struct dh_index {
     ulonglong2 *d_fat = nullptr;
     ulonglong2 *d_ent = nullptr;
     int64_t *d_goff = nullptr;
+    int32_t *d_page_seq = nullptr;  // virtual page (4096 bases) -> sequence
     int64_t n = 0;
     int32_t k = 0, sepv = 0, shift = 0, pbits = 0, na = 0, kmer_mod = 1;
     void release()
@@ -86,6 +87,8 @@ struct dh_index {
         dh_dev_free(d_goff);
         dh_dev_free(d_fat);
         d_fat = nullptr;
+        dh_dev_free(d_page_seq);
+        d_page_seq = nullptr;
         d_dir = nullptr;
         d_ent = nullptr;
         d_goff = nullptr;

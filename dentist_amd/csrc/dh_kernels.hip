@@ -438,6 +438,10 @@ __device__ void seed_item(const DbView &B, const IndexView &ix,
             if (slot < CAP) hits[slot] = ((uint64_t)strand << 63) | ((uint64_t)D << HIT_QBITS) | (uint32_t)qs;
         };
         auto flush = [&]() {
+#ifdef DH_SEED_NOLOAD
+            nq = 0;  // development: the rolling alone (no lookups), for the split of the lookup phase
+            return;
+#endif
             // the fat directory word of every queued k-mer: one 16-byte load, one memory round trip per flush
             ulonglong2 f[QN];
 #pragma unroll
@@ -631,14 +635,9 @@ __device__ void seed_item(const DbView &B, const IndexView &ix,
         const int64_t D = hitD(hits[best_first]) & ((1ll << HIT_DBITS) - 1);  // without the strand bit
         const int32_t q = hitQ(hits[best_first]);
         const int64_t gv = D - ix.sepv + q;
-        int32_t lo = 0, hi = ix.na;
-        while (hi - lo > 1) {
-            const int32_t mid = (lo + hi) >> 1;
-            if (ix.goff[mid] <= gv)
-                lo = mid;
-            else
-                hi = mid;
-        }
+        // sequences start on 4096-base pages of the virtual axis: the page names the sequence (the binary search
+        // over goff this replaces was a chain of ten dependent loads per candidate)
+        const int32_t lo = ix.page_seq[gv >> 12];
         cands[slot].score = P;
         cands[slot].aseq = lo;
         cands[slot].apos = (int32_t)(gv - ix.goff[lo]);
