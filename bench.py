@@ -268,14 +268,14 @@ def main():
             # dominant kernel of the step: the seed filter (k_seed) of the mapping launches.  It is bound by random
             # 64-byte lines: per read base 1 B of sequence, per sampled canonical k-mer one 64 B
             # directory line, one pass for both strands; the ceiling of random 64 B lines measured on this part is
-            # 3.0-3.2 TB/s at working sets of 1-16 GB (scripts/rand_access_probe.cpp)
+            # 55 G lines/s = 3.5 TB/s at working sets of 128 MB - 2 GB, 3.2 at 4 GB, 3.06 at 16 GB (scripts/rand_access_probe.cpp)
             "roofline": {"bound": "hbm", "kernel": "k_seed (mapping launches)",
                          "achieved": seed_bytes / (seed_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": seed_bytes / (seed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": seed_traffic,
                          "launches_per_step": int(last["ast"].wave_launches), "kernel_ms_per_step": seed_ms,
                          "avg_launch_ms": seed_ms / max(1, int(last["ast"].wave_launches)),
                          "algorithmic_bytes_per_step": seed_bytes,
-                         "measured_random_line_ceiling_GBs": 3200.0},
+                         "measured_random_line_ceiling_GBs": 3500.0},
             # second: the extension kernel, one alignment per lane.  VALU bound (scripts/valu_probe.cpp: 2-cycle class
             # 0.90-0.94, 4-cycle class 0.56-0.58 G wave-instructions/s per SIMD); the HBM fraction is reported as asked
             "roofline_tile": {"bound": "hbm", "kernel": "k_tile" if args.map_algo == 1 else "k_wave2", "achieved": achieved,
