@@ -274,6 +274,203 @@ k_seg_vote(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R,
 #undef OPB
 }
 
+// K8a, bit-parallel fill: the same Needleman-Wunsch tile and the same traceback rule as k_seg_vote, for tiles whose band
+// (trace diffs + 1) is at most 31 (NW = 1) or 63 (NW = 2).  The banded fill is Hyyro's diagonal-band form of Myers'
+// bit-vector recurrence -- the column step of DH-2 (dh_tile.h: tile_col) with the same conventions: band row R of matrix
+// row i is query index j = i - 32 NW + R, D[0][j] = |j| and rows j <= 0 never match (which yields F[i][0] = i), the row
+// above the band is missing, the row below it is a never-matching virtual row.  Computed scores are never below the true
+// ones and exact wherever the true score is at most the band's half-width, which is all the argument in k_seg_vote needs:
+// the traceback only ever selects neighbours scoring <= D <= diffs < band.  The 2-bit decision of every band cell
+// (smallest neighbour; diagonal > insertion > deletion, util/string.d:775-831) depends on the three neighbours only
+// through differences the step has as bit vectors:
+//     left - diag = h(R - 1)   horizontal delta (HP / HN) of the row above         [left  = F[i][j-1]]
+//     up   - diag = dd(R) - h(R)   with dd = 1 - D0                                 [up    = F[i-1][j]]
+// so  op0 = (diag <= left) & (diag <= up) = ~HN' & ~(D0 & HP)   (X' = X << 1, the top row has no left: op0 bit 0 = B)
+//     L   = (left <= up)  = [h(R - 1) + h(R) <= dd(R)]          (top row: 0)
+// Two words per matrix row and plane are stored (op0, L), 64 NW cells each; about 90 (NW = 1) / 170 (NW = 2)
+// instructions per matrix row instead of ~15 per band cell.
+template <int NW>
+struct BV {
+    uint64_t w[NW];
+};
+template <int NW>
+__device__ __forceinline__ BV<NW> bv_shl1(const BV<NW> &a)
+{
+    BV<NW> r;
+#pragma unroll
+    for (int k = NW - 1; k > 0; k--) r.w[k] = (a.w[k] << 1) | (a.w[k - 1] >> 63);
+    r.w[0] = a.w[0] << 1;
+    return r;
+}
+template <int NW>
+__device__ __forceinline__ BV<NW> bv_shr1(const BV<NW> &a, uint64_t top)  // logical; `top` enters at the highest bit
+{
+    BV<NW> r;
+#pragma unroll
+    for (int k = 0; k < NW - 1; k++) r.w[k] = (a.w[k] >> 1) | (a.w[k + 1] << 63);
+    r.w[NW - 1] = (a.w[NW - 1] >> 1) | (top << 63);
+    return r;
+}
+
+template <int NW>
+__global__ void __launch_bounds__(64)
+k_seg_vote_bp(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R, const uint8_t *__restrict__ rrc,
+              uint64_t *__restrict__ dmat, uint8_t *__restrict__ opbuf, uint16_t *__restrict__ nops_out,
+              int32_t *__restrict__ status)
+{
+    constexpr int HALF = 32 * NW;         // band rows above the diagonal
+    constexpr int QW = (SEG_MAX + 63) / 64 + 1 + NW;  // plane words per tile: HALF bits of lead-in + the query
+    __shared__ uint64_t s_pl[3][QW][64];  // planes of the query codes (bits 0, 1, 2), [word][lane]
+    const int32_t dp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (dp >= nseg) return;
+    const SegDesc sg = segs[dp];
+    const int32_t rl = sg.a1 - sg.a0, ql = sg.b1 - sg.b0;
+    if (rl > SEG_MAX || ql > SEG_MAX || sg.band > HALF - 1 || rl - ql >= sg.band || ql - rl >= sg.band) {
+        atomicOr(status, DH_ST_POOL_OVERFLOW);
+        nops_out[dp] = 0;
+        return;
+    }
+    const uint8_t *ref = T.bases + T.off[sg.tmpl] + sg.a0;
+    const uint8_t *qry = (sg.comp ? rrc : R.bases) + R.off[sg.bseq] + sg.b0;
+    const int64_t NDP = nseg;
+    const int lane = threadIdx.x;
+    // ---- planes: bit (HALF + j - 1) of the plane string = bit of the code of query base j (1-based)
+    {
+        uint64_t a0 = 0, a1 = 0, a2 = 0;
+        int32_t wi = HALF / 64, bi = HALF % 64;  // (NW = 1: word 0, bit 32; NW = 2: word 1, bit 0)
+#pragma unroll
+        for (int k = 0; k < QW; k++) s_pl[0][k][lane] = s_pl[1][k][lane] = s_pl[2][k][lane] = 0;
+        for (int32_t j = 0; j < ql; j++) {
+            const uint64_t c = qry[j] & 7u;
+            a0 |= (c & 1u) << bi;
+            a1 |= ((c >> 1) & 1u) << bi;
+            a2 |= ((c >> 2) & 1u) << bi;
+            if (++bi == 64 || j + 1 == ql) {
+                s_pl[0][wi][lane] = a0;
+                s_pl[1][wi][lane] = a1;
+                s_pl[2][wi][lane] = a2;
+                a0 = a1 = a2 = 0;
+                bi = 0;
+                wi++;
+            }
+        }
+    }
+    // window of matrix row i: bit R <-> j = i - HALF + R <-> plane string bit (i + R - 1); row 0 would start at bit -1,
+    // the loop starts with row 1 at bit 0: the first NW words, and one new bit per row from the feed words
+    BV<NW> p0, p1, p2;
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+        p0.w[k] = s_pl[0][k][lane];
+        p1.w[k] = s_pl[1][k][lane];
+        p2.w[k] = s_pl[2][k][lane];
+    }
+    uint64_t f0 = s_pl[0][NW][lane], f1 = s_pl[1][NW][lane], f2 = s_pl[2][NW][lane];
+    int32_t fword = NW, fleft = 64;
+    // column 0 (dh_tile.h: tile_setup): vertical deltas aligned for row 1
+    BV<NW> Pv, Mv, lv;
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+        const uint64_t hi = k * 64 >= HALF ? ~0ull : (k * 64 + 64 <= HALF ? 0ull : ~0ull << (HALF - k * 64));
+        Pv.w[k] = hi;
+        Mv.w[k] = ~hi;
+        const int hb = HALF + 1;  // lv of column 0: rows j >= 1
+        lv.w[k] = k * 64 >= hb ? ~0ull : (k * 64 + 64 <= hb ? 0ull : ~0ull << (hb - k * 64));
+    }
+#define DMW(i, k) dmat[((int64_t)(i) * (2 * NW) + (k)) * NDP + dp]
+    for (int32_t i = 1; i <= rl; i++) {
+        const uint32_t rc = ref[i - 1] & 7u;
+        const uint64_t x0 = 0ull - (uint64_t)(rc & 1u), x1 = 0ull - (uint64_t)((rc >> 1) & 1u), x2 = 0ull - (uint64_t)((rc >> 2) & 1u);
+        // rows j >= 1 of this matrix row: arithmetic shift of the 64 NW-bit mask
+        {
+            const uint64_t top = lv.w[NW - 1] >> 63;
+            lv = bv_shr1<NW>(lv, top);
+        }
+        BV<NW> Eq, D0, HP, HN;
+        uint64_t carry = 0;
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            Eq.w[k] = ~((p0.w[k] ^ x0) | (p1.w[k] ^ x1) | (p2.w[k] ^ x2)) & lv.w[k];
+            const uint64_t x = Eq.w[k] & Pv.w[k];
+            const uint64_t s1 = x + Pv.w[k];
+            const uint64_t c1 = s1 < x ? 1ull : 0ull;
+            const uint64_t s2 = s1 + carry;
+            const uint64_t c2 = s2 < s1 ? 1ull : 0ull;
+            carry = c1 | c2;
+            D0.w[k] = (s2 ^ Pv.w[k]) | Eq.w[k] | Mv.w[k];
+            HP.w[k] = Mv.w[k] | ~(D0.w[k] | Pv.w[k]);
+            HN.w[k] = Pv.w[k] & D0.w[k];
+        }
+        // decisions of the band cells of this row
+        const BV<NW> HPs = bv_shl1<NW>(HP), HNs = bv_shl1<NW>(HN);
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            uint64_t A = ~HNs.w[k];
+            const uint64_t B = ~(D0.w[k] & HP.w[k]);
+            const uint64_t t2 = HPs.w[k] & HP.w[k];
+            const uint64_t t1 = (HPs.w[k] & ~HP.w[k] & ~HN.w[k]) | (~HPs.w[k] & ~HNs.w[k] & HP.w[k]);
+            uint64_t L = ~t2 & ~(t1 & D0.w[k]);
+            if (k == 0) {
+                A |= 1ull;
+                L &= ~1ull;
+            }
+            DMW(i, k) = A & B;
+            DMW(i, NW + k) = L;
+        }
+        // next row: vertical deltas one band row further down
+        const BV<NW> Xv = bv_shr1<NW>(D0, 0ull);
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            Pv.w[k] = HN.w[k] | ~(Xv.w[k] | HP.w[k]);
+            Mv.w[k] = HP.w[k] & Xv.w[k];
+        }
+        // slide the query window by one base
+        p0 = bv_shr1<NW>(p0, f0 & 1ull);
+        p1 = bv_shr1<NW>(p1, f1 & 1ull);
+        p2 = bv_shr1<NW>(p2, f2 & 1ull);
+        f0 >>= 1;
+        f1 >>= 1;
+        f2 >>= 1;
+        if (--fleft == 0) {
+            fword++;
+            f0 = fword < QW ? s_pl[0][fword][lane] : 0ull;
+            f1 = fword < QW ? s_pl[1][fword][lane] : 0ull;
+            f2 = fword < QW ? s_pl[2][fword][lane] : 0ull;
+            fleft = 64;
+        }
+    }
+    // ---- traceback (as k_seg_vote): ops back to front into the interleaved op buffer
+#define OPB(t) opbuf[(int64_t)(t)*NDP + dp]
+    int32_t i = rl, j = ql, nops = 0;
+    while (i > 0 && j > 0) {
+        const int32_t Rr = j - i + HALF;
+        const uint64_t z = DMW(i, Rr >> 6), l = DMW(i, NW + (Rr >> 6));
+        const uint8_t op = ((z >> (Rr & 63)) & 1ull) ? 0 : (((l >> (Rr & 63)) & 1ull) ? 2 : 1);
+        if (op == 0) {
+            --i;
+            --j;
+        } else if (op == 2) {
+            --j;
+        } else {
+            --i;
+        }
+        OPB(nops) = op;
+        nops++;
+    }
+    while (i > 0) {
+        OPB(nops) = 1;
+        nops++;
+        --i;
+    }
+    while (j > 0) {
+        OPB(nops) = 2;
+        nops++;
+        --j;
+    }
+    nops_out[dp] = (uint16_t)nops;
+#undef DMW
+#undef OPB
+}
+
 // K8a (second half): per-column view of every tile from its op list, canonical indel placement,
 // votes.  The per-thread column arrays live in LDS ([column][lane], one byte per entry:
 // conflict-free) -- as private arrays they sat in scratch memory and every one of the ~700
@@ -595,12 +792,21 @@ void dhk_tile_qv(hipStream_t st, const DhLa *las, const uint16_t *trace, const i
 void dhk_seg_vote(hipStream_t st, const void *segs, int32_t nseg, DbView T, DbView R,
                   const uint8_t *rrc, const int64_t *voff, uint32_t *dmat, int32_t bandmax, int32_t qmax,
                   int32_t ncolmax, uint8_t *opbuf, uint16_t *nops, uint32_t *votes, uint32_t *cdiff,
-                  uint32_t *vother, int32_t *status)
+                  uint32_t *vother, int32_t *status, int32_t mode)
 {
     if (nseg <= 0) return;
-    const size_t lds = (size_t)(2 * bandmax + 2) * 64 + ((size_t)(qmax + 7) / 8 + 1) * 256;
-    hipLaunchKernelGGL(k_seg_vote, dim3((nseg + 63) / 64), dim3(64), lds, st, (const SegDesc *)segs, nseg,
-                       T, R, rrc, voff, dmat, bandmax, opbuf, nops, status);
+    // mode 1 / 2: bit-parallel fill with one / two 64-cell words per matrix row (bands up to 31 / 63); 0: scalar fill
+    if (mode == 1)
+        hipLaunchKernelGGL(k_seg_vote_bp<1>, dim3((nseg + 63) / 64), dim3(64), 0, st, (const SegDesc *)segs, nseg, T, R, rrc,
+                           (uint64_t *)dmat, opbuf, nops, status);
+    else if (mode == 2)
+        hipLaunchKernelGGL(k_seg_vote_bp<2>, dim3((nseg + 63) / 64), dim3(64), 0, st, (const SegDesc *)segs, nseg, T, R, rrc,
+                           (uint64_t *)dmat, opbuf, nops, status);
+    else {
+        const size_t lds = (size_t)(2 * bandmax + 2) * 64 + ((size_t)(qmax + 7) / 8 + 1) * 256;
+        hipLaunchKernelGGL(k_seg_vote, dim3((nseg + 63) / 64), dim3(64), lds, st, (const SegDesc *)segs, nseg,
+                           T, R, rrc, voff, dmat, bandmax, opbuf, nops, status);
+    }
     const size_t lds2 = (size_t)(3 * ncolmax + 5) * 64;
     if (lds2 > 65536)
         (void)hipFuncSetAttribute((const void *)k_seg_vote2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);

@@ -9,6 +9,7 @@
 //   daccord (dazzler.d:6185-6231)                -> k_seg_vote + k_emit, `rounds` times
 //   daligner -A flanks vs consensus (:655-667)   -> dh_align_db
 //   insertion (package.d:699-805, insertions.d:110-146) -> host
+#include <array>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -32,7 +33,7 @@ void dhk_tile_qv(hipStream_t st, const DhLa *las, const uint16_t *trace, const i
 void dhk_seg_vote(hipStream_t st, const void *segs, int32_t nseg, DbView T, DbView R,
                   const uint8_t *rrc, const int64_t *voff, uint32_t *dmat, int32_t bandmax, int32_t qmax,
                   int32_t ncolmax, uint8_t *opbuf, uint16_t *nops, uint32_t *votes, uint32_t *cdiff,
-                  uint32_t *vother, int32_t *status);
+                  uint32_t *vother, int32_t *status, int32_t mode);
 void dhk_votes_finish(hipStream_t st, DbView T, const int64_t *voff, const int32_t *col_tmpl, int64_t ncols_total,
                       const uint32_t *cexcl, const uint32_t *vother, uint32_t *votes);
 void dhk_scan(hipStream_t st, uint32_t *v, int64_t n, uint32_t *sums);
@@ -733,6 +734,7 @@ static int consensus_round(dh_ctx *ctx, dh_db *T, dh_db *R, const LaVec &las,
     std::vector<SegDescH, PinnedAlloc<SegDescH>> segs;  // page-locked: uploaded every round
     int32_t wmax = 1, bandmax = 1;
     int64_t ncell = 0;
+    size_t class_end[3] = {0, 0, 0};  // tiles of the overlaps of each band class end here (classes are contiguous)
     {
         // the selected overlaps and where their tiles go; host threads then fill the tiles
         std::vector<size_t> sel;
@@ -740,7 +742,9 @@ static int consensus_round(dh_ctx *ctx, dh_db *T, dh_db *R, const LaVec &las,
         {
             // selection in input order: host threads scan runs of the LAs, the runs are concatenated
             const int64_t grain = 1 << 16, nch = ((int64_t)las.size() + grain - 1) / grain;
-            std::vector<std::vector<size_t>> part((size_t)std::max<int64_t>(nch, 1));
+            // overlaps are grouped by the widest band of their tiles (tile diffs + 1): up to 31 / up to 63 cells take
+            // the bit-parallel fill with one / two words per matrix row, wider ones the scalar fill (dhk_seg_vote)
+            std::vector<std::array<std::vector<size_t>, 3>> part((size_t)std::max<int64_t>(nch, 1));
             dh_parallel_for(nch, 1, [&](int64_t clo, int64_t chi) {
                 for (int64_t c = clo; c < chi; c++) {
                     const size_t i1 = std::min(las.size(), (size_t)(c + 1) * (size_t)grain);
@@ -750,16 +754,23 @@ static int consensus_round(dh_ctx *ctx, dh_db *T, dh_db *R, const LaVec &las,
                             // indel rate) takes no part in the vote
                             const uint16_t *tr = trace.data() + las[i].toff;
                             bool too_long = false;
-                            for (int32_t e = 0; e < las[i].tlen / 2; e++) too_long = too_long || tr[2 * e + 1] > SEG_MAX;
-                            if (!too_long) part[(size_t)c].push_back(i);
+                            int32_t dmax = 0;
+                            for (int32_t e = 0; e < las[i].tlen / 2; e++) {
+                                too_long = too_long || tr[2 * e + 1] > SEG_MAX;
+                                dmax = std::max<int32_t>(dmax, tr[2 * e]);
+                            }
+                            if (!too_long) part[(size_t)c][dmax + 1 <= 31 ? 0 : (dmax + 1 <= 63 ? 1 : 2)].push_back(i);
                         }
                 }
             });
-            for (const auto &v : part)
-                for (size_t i : v) {
-                    sel.push_back(i);
-                    soff.push_back(soff.back() + (size_t)(las[i].tlen / 2));
-                }
+            for (int cls = 0; cls < 3; cls++) {
+                for (const auto &v : part)
+                    for (size_t i : v[(size_t)cls]) {
+                        sel.push_back(i);
+                        soff.push_back(soff.back() + (size_t)(las[i].tlen / 2));
+                    }
+                class_end[cls] = soff.back();
+            }
         }
         segs.resize(soff.back());
         std::mutex red;
@@ -832,23 +843,29 @@ static int consensus_round(dh_ctx *ctx, dh_db *T, dh_db *R, const LaVec &las,
     uint32_t *d_vother = d_cdiff.p + ncolp, *d_csums = d_vother + ncolp;
     HIPCHK(hipMemsetAsync(d_cdiff.p, 0, sizeof(uint32_t) * 2 * ncolp, st));
     if (int rc = dh_ensure_rc(R)) return rc;
-    // the score matrices of one launch live interleaved in HBM: bound the launch to ~6 GB
-    const size_t mrow = 4 * (size_t)((2 * bandmax + 16) >> 4);  // bytes of 2-bit decisions per matrix row
-    const int64_t per_dp = (int64_t)(ts + 1) * (int64_t)mrow + 2 * SEG_MAX;
-    const int64_t max_dp = std::max<int64_t>(4096, (6ll << 30) / per_dp);
-    for (size_t s0 = 0; s0 < segs.size(); s0 += (size_t)max_dp) {
-        const int32_t cnt = (int32_t)std::min<size_t>((size_t)max_dp, segs.size() - s0);
-        struct { SegDescH *p; } ds;
-        struct { uint8_t *p; } fm, ob;
-        SCRP(22, ds, (size_t)cnt)
-        SCRP(23, fm, (size_t)cnt * (size_t)(ts + 1) * mrow + (size_t)cnt * 2 * SEG_MAX + (size_t)cnt * 2 + 16)
-        ob.p = fm.p + (size_t)cnt * (size_t)(ts + 1) * mrow;
-        uint16_t *d_nops = (uint16_t *)(ob.p + (((size_t)cnt * 2 * SEG_MAX + 7) & ~(size_t)7));
-        HIPCHK(hipMemcpyAsync(ds.p, segs.data() + s0, sizeof(SegDescH) * (size_t)cnt, hipMemcpyHostToDevice, st));
-        dhk_seg_vote(st, ds.p, cnt, T->view(), R->view(), R->d_rc, d_voff.p, (uint32_t *)fm.p, bandmax, wmax, ts,
-                     ob.p, d_nops, d_votes.p, d_cdiff.p, d_vother, d_status.p);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(st));
+    // the decision matrices of one launch live interleaved in HBM: bound the launch to ~6 GB
+    for (int cls = 0; cls < 3; cls++) {
+        const size_t c0 = cls ? class_end[cls - 1] : 0, c1 = class_end[cls];
+        if (c1 <= c0) continue;
+        const int32_t mode = getenv("DH_CONS_SCALAR") ? 0 : (cls == 0 ? 1 : (cls == 1 ? 2 : 0));  // (development: scalar fill for everything)
+        // bytes of decisions per matrix row: two bit planes of 64 cells per word, or 2 bits per band cell
+        const size_t mrow = mode ? (size_t)16 * (size_t)mode : 4 * (size_t)((2 * bandmax + 16) >> 4);
+        const int64_t per_dp = (int64_t)(ts + 1) * (int64_t)mrow + 2 * SEG_MAX;
+        const int64_t max_dp = std::max<int64_t>(4096, (6ll << 30) / per_dp);
+        for (size_t s0 = c0; s0 < c1; s0 += (size_t)max_dp) {
+            const int32_t cnt = (int32_t)std::min<size_t>((size_t)max_dp, c1 - s0);
+            struct { SegDescH *p; } ds;
+            struct { uint8_t *p; } fm, ob;
+            SCRP(22, ds, (size_t)cnt)
+            SCRP(23, fm, (size_t)cnt * (size_t)(ts + 1) * mrow + (size_t)cnt * 2 * SEG_MAX + (size_t)cnt * 2 + 16)
+            ob.p = fm.p + (size_t)cnt * (size_t)(ts + 1) * mrow;
+            uint16_t *d_nops = (uint16_t *)(ob.p + (((size_t)cnt * 2 * SEG_MAX + 7) & ~(size_t)7));
+            HIPCHK(hipMemcpyAsync(ds.p, segs.data() + s0, sizeof(SegDescH) * (size_t)cnt, hipMemcpyHostToDevice, st));
+            dhk_seg_vote(st, ds.p, cnt, T->view(), R->view(), R->d_rc, d_voff.p, (uint32_t *)fm.p, bandmax, wmax, ts,
+                         ob.p, d_nops, d_votes.p, d_cdiff.p, d_vother, d_status.p, mode);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(st));
+        }
     }
     {
         // column -> template map of the vote space (-1 for the spare column after each template)
