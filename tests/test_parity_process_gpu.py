@@ -18,7 +18,7 @@ STATUS = {0: "ok", 1: "no common trace point", 2: "pile too small",
           3: "empty pileup alignment after filtering"}
 
 
-def run_case(ctx, w, rounds, algo=0):
+def run_case(ctx, w, rounds, algo=0, truth_slack=1.0):
     """algo: 0 = DH-1 (waves) everywhere, 1 = DH-2 (tiled band) for the mapping and every process stage."""
     g = dentist_amd.default_align_opts(**(dict(algo=1, width=64) if algo else {}))
     A, B = ctx.db(w.contigs), ctx.db(w.reads)
@@ -59,7 +59,7 @@ def run_case(ctx, w, rounds, algo=0):
         # against the truth: the spliced region must be close to what was cut out
         truth = w.truth[w.contig_start[gap] + r["left_aepos"]: w.gap_end[gap] + r["right_abpos"]]
         ed, _ = oz.nw(truth, ins)
-        assert ed <= max(3, (0.05 if rounds == 1 else 0.02) * len(truth)), (gap, ed, len(truth))
+        assert ed <= truth_slack * max(3, (0.05 if rounds == 1 else 0.02) * len(truth)), (gap, ed, len(truth))
         closed += 1
     assert closed >= 1
     return rec
@@ -391,3 +391,17 @@ def test_pile_ups_of_the_graph_builder_with_extension_entries(gpu_ctx, algo):
                (ex["left_aepos"], ex["right_abpos"], ex["ins_begin"], ex["ins_end"])
         closed += 1
     assert closed >= 9
+
+
+def test_consensus_band_classes_and_scalar_fill_agree(gpu_ctx, monkeypatch):
+    """The three fills of the per-tile Needleman-Wunsch (bit-parallel with one / two 64-cell words per matrix row, scalar
+    for bands above 63) against the oracle's full-matrix NW on noisy reads (20 % error: read-read tiles reach 60+
+    differences, so all three classes occur), and the scalar fill forced for everything (DH_CONS_SCALAR) gives the
+    same bits."""
+    w = sim.Workload(150_000, 2, 700, 4000, seed=47, err=0.20, spacing=15000, gap_max=700)
+    rec = run_case(gpu_ctx, w, 2, algo=1, truth_slack=4.0)     # 20 % reads: parity is the point, not the polish
+    monkeypatch.setenv("DH_CONS_SCALAR", "1")
+    rec2 = run_case(gpu_ctx, w, 2, algo=1, truth_slack=4.0)
+    for f in rec.dtype.names:
+        if f != "pad":
+            assert np.array_equal(rec[f], rec2[f]), f
