@@ -1258,6 +1258,8 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     SCR(10, d_trslots, (size_t)cn * o.max_la * trmax)
     SCR(11, d_counters, 2)
     SCR(12, d_sums, (size_t)cn / 2048 + 4)
+    unsigned long long *d_summary;
+    SCR(31, d_summary, 4)
     int32_t *d_ovf;
     SCR(29, d_ovf, cn)
     int32_t *d_regs = nullptr;
@@ -1360,17 +1362,23 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             // items whose hits did not fit the LDS buffer (ncand == -1) are redone with their hits
             // staged in HBM: same kernel code, capacity = the item's own hit count
             int32_t status = 0;
+            unsigned long long sm[4] = {0, 0, 0, 0};
+            dhk_seed_summary(st, d_ncand, d_nhits, ni, d_summary);
             HIPCHK(hipMemcpyAsync(&status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipMemcpyAsync(h_ncand.data(), d_ncand, sizeof(int32_t) * (size_t)ni, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipMemcpyAsync(h_nhits.data(), d_nhits, sizeof(int32_t) * (size_t)ni, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(sm, d_summary, sizeof(sm), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             std::vector<int32_t> big;
             int32_t gcap = 0;
-            for (int32_t it = 0; it + 1 < ni; it += 2)  // a read overflows with both of its strands
-                if (h_ncand[(size_t)it] == -1) {
-                    big.push_back((int32_t)((item0 + it) >> 1));
-                    gcap = std::max(gcap, h_nhits[(size_t)it] + h_nhits[(size_t)it + 1]);
-                }
+            if (sm[2] > 0) {  // the per-item arrays travel only when some item overflowed its LDS buffer
+                HIPCHK(hipMemcpyAsync(h_ncand.data(), d_ncand, sizeof(int32_t) * (size_t)ni, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipMemcpyAsync(h_nhits.data(), d_nhits, sizeof(int32_t) * (size_t)ni, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                for (int32_t it = 0; it + 1 < ni; it += 2)  // a read overflows with both of its strands
+                    if (h_ncand[(size_t)it] == -1) {
+                        big.push_back((int32_t)((item0 + it) >> 1));
+                        gcap = std::max(gcap, h_nhits[(size_t)it] + h_nhits[(size_t)it + 1]);
+                    }
+            }
             if (big.size() > (size_t)ni / 50 + 8 && cap < 16384) {
                 cap *= 2;  // many items overflow the LDS buffer: the next size is cheaper than HBM staging
                 item0 -= cn;
@@ -1498,19 +1506,22 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         HIPCHK(hipMemcpyAsync(&totals[0], d_nla + ni, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(&totals[1], d_ntr + ni, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(&status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(h_ncand.data(), d_ncand, sizeof(int32_t) * (size_t)ni, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(h_nhits.data(), d_nhits, sizeof(int32_t) * (size_t)ni, hipMemcpyDeviceToHost, st));
+        unsigned long long sm2[4] = {0, 0, 0, 0};
+        dhk_seed_summary(st, d_ncand, d_nhits, ni, d_summary);
+        HIPCHK(hipMemcpyAsync(sm2, d_summary, sizeof(sm2), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         lap(2);
         if (status & DH_ST_POOL_OVERFLOW)
             return fail(DH_EOVERFLOW, "wave: trace-tree pool or boundary capacity exceeded");
-        for (int32_t it = 0; it < ni; it++) {
-            stats.hits += h_nhits[(size_t)it];
-            stats.cands += std::max(h_ncand[(size_t)it], 0);
-            if (h_ncand[(size_t)it] == -2) {  // seed filter gave up on the item (> 256 candidate band pairs)
-                stats.overflow_items++;
-                res->ovf_reads.push_back((int32_t)((item0 + it) >> 1));
-            }
+        stats.hits += (int64_t)sm2[0];
+        stats.cands += (int64_t)sm2[1];
+        if (sm2[3] > 0) {  // the seed filter gave up on some items (> 256 candidate band pairs): which reads
+            HIPCHK(hipMemcpy(h_ncand.data(), d_ncand, sizeof(int32_t) * (size_t)ni, hipMemcpyDeviceToHost));
+            for (int32_t it = 0; it < ni; it++)
+                if (h_ncand[(size_t)it] == -2) {
+                    stats.overflow_items++;
+                    res->ovf_reads.push_back((int32_t)((item0 + it) >> 1));
+                }
         }
         if (o.skip_self == 2) {  // records dropped for want of slots (> max_la overlaps of one read and strand)
             std::vector<int32_t> h_ovf((size_t)ni);

@@ -12,6 +12,7 @@
 // The arithmetic specification these kernels implement is written down in DESIGN.md
 // ("Algorithm DH-1"); reference call sites: source/dentist/dazzler.d:6121-6170.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -2407,6 +2408,41 @@ void dhk_kmer_pass(hipStream_t st, int fill, DbView A, const int2 *tiles, int32_
     else
         hipLaunchKernelGGL(k_kmer_pass<false>, dim3(ntiles), dim3(256), 0, st, A, tiles, ntiles, k,
                            kmer_mod, shift, dir, ent, goff);
+}
+
+// per-chunk summary of the seed filter's per-item results, so that the host fetches the per-item arrays only when it
+// has to: out[0] = sum of hits, out[1] = sum of candidates, out[2] = items handed to the HBM variant (-1),
+// out[3] = items the filter gave up on (-2)
+__global__ void __launch_bounds__(256)
+k_seed_summary(const int32_t *__restrict__ ncand, const int32_t *__restrict__ nhits, int32_t n, unsigned long long *__restrict__ out)
+{
+    unsigned long long h = 0, c = 0, big = 0, gave = 0;
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int32_t nc = ncand[i];
+        h += (unsigned long long)max(nhits[i], 0);
+        c += (unsigned long long)max(nc, 0);
+        big += nc == -1 ? 1ull : 0ull;
+        gave += nc == -2 ? 1ull : 0ull;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        h += __shfl_xor(h, off, 64);
+        c += __shfl_xor(c, off, 64);
+        big += __shfl_xor(big, off, 64);
+        gave += __shfl_xor(gave, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (h) atomicAdd(&out[0], h);
+        if (c) atomicAdd(&out[1], c);
+        if (big) atomicAdd(&out[2], big);
+        if (gave) atomicAdd(&out[3], gave);
+    }
+}
+
+void dhk_seed_summary(hipStream_t st, const int32_t *ncand, const int32_t *nhits, int32_t n, unsigned long long *out)
+{
+    (void)hipMemsetAsync(out, 0, 4 * sizeof(unsigned long long), st);
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_seed_summary, dim3(std::min((n + 255) / 256, 1024)), dim3(256), 0, st, ncand, nhits, n, out);
 }
 
 void dhk_fat_dir(hipStream_t st, const uint32_t *dir, const ulonglong2 *ent, int64_t nb, ulonglong2 *fat)
