@@ -411,7 +411,6 @@ __device__ void seed_item(const DbView &B, const IndexView &ix,
     // of rolling threads makes it 40 % slower), so every thread of the block takes a chunk.
     if (npos > 0 && tid < SEED_LOOKUP_THREADS) {
         constexpr int QN = 4;
-        constexpr bool MULTI4 = LCAP == 0 || LCAP >= 4096;  // register budget of the large variants (4 waves per SIMD)
         const int32_t per = (npos + SEED_LOOKUP_THREADS - 1) / SEED_LOOKUP_THREADS;
         const int32_t q0 = tid * per, q1 = min(npos, q0 + per);
         const KmerSampler smp = kmer_sampler(o.kmer_mod, k);
@@ -467,25 +466,13 @@ __device__ void seed_item(const DbView &B, const IndexView &ix,
                     continue;
                 }
                 const uint32_t ss_u = (uint32_t)f[u].y, ee_u = ss_u + (uint32_t)(f[u].y >> 32);
-                // count the entries of the bucket with this key first, per orientation (-t cap) ...
-                int32_t runf = 0, runr = 0;
-                if (MULTI4 && ee_u - ss_u <= 4u) {
-                    // a short bucket (the usual case of an unsampled index, e.g. the pile-up stage's): its keys in one
-                    // round trip (the loop below pays a dependent load per entry), the emission loop then hits L1
-                    uint64_t kx[4];
-#pragma unroll
-                    for (int x = 0; x < 4; x++) {
-                        kx[x] = ~0ull;  // never equal to a key (keys have bit 62 clear)
-                        if (ss_u + (uint32_t)x < ee_u) kx[x] = ix.ent[ss_u + (uint32_t)x].x;
-                    }
-#pragma unroll
-                    for (int x = 0; x < 4; x++) {
-                        const bool hit = (kx[x] & ~ORI) == key;
-                        const bool same = (kx[x] & ORI) == bori;
-                        runf += (hit && (same || pal)) ? 1 : 0;
-                        runr += (hit && (!same || pal)) ? 1 : 0;
-                    }
-                } else
+                // -t cap: a k-mer occurring more than tcap times (per orientation) is skipped.  A bucket with at most
+                // tcap entries cannot hold such a k-mer, so only larger buckets are counted first -- the count pass costs
+                // one dependent load per entry, which for an unsampled index (the pile-up stage's: every intact k-mer of
+                // a pile-up shares a bucket with its ~coverage copies) was half of the lookup phase
+                bool dof = true, dor = true;
+                if (ee_u - ss_u > (uint32_t)max(o.tcap, 0)) {
+                    int32_t runf = 0, runr = 0;
                     for (uint32_t t = ss_u; t < ee_u; t++) {
                         const uint64_t ex = ix.ent[t].x;
                         if ((ex & ~ORI) != key) continue;
@@ -493,8 +480,10 @@ __device__ void seed_item(const DbView &B, const IndexView &ix,
                         runf += (same || pal) ? 1 : 0;
                         runr += (!same || pal) ? 1 : 0;
                     }
-                const bool dof = runf > 0 && runf <= o.tcap, dor = runr > 0 && runr <= o.tcap;
-                if (!dof && !dor) continue;
+                    dof = runf > 0 && runf <= o.tcap;
+                    dor = runr > 0 && runr <= o.tcap;
+                    if (!dof && !dor) continue;
+                }
                 // ... then emit its hits
                 for (uint32_t t = ss_u; t < ee_u; t++) {
                     const ulonglong2 en = ix.ent[t];
