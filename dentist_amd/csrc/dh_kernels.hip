@@ -484,9 +484,11 @@ __device__ void seed_item(const DbView &B, const IndexView &ix,
                     dor = runr > 0 && runr <= o.tcap;
                     if (!dof && !dor) continue;
                 }
-                // ... then emit its hits
+                // ... then emit its hits (the next entry is on its way while this one is handled)
+                ulonglong2 nx = ix.ent[ss_u];
                 for (uint32_t t = ss_u; t < ee_u; t++) {
-                    const ulonglong2 en = ix.ent[t];
+                    const ulonglong2 en = nx;
+                    if (t + 1 < ee_u) nx = ix.ent[t + 1];
                     if ((en.x & ~ORI) != key) continue;
                     const bool same = (en.x & ORI) == bori;
                     if (dof && (same || pal)) emit(en.y, qq[u], 0);
