@@ -364,7 +364,7 @@ int dh_scaffold_from_join_blobs(const uint8_t *const *blobs, const int64_t *size
     // runs of the concatenation (rank order = read order) become edges on the host threads, as in the single-rank builder
     std::vector<int64_t> start((size_t)world + 1, 0);
     for (int32_t r = 0; r < world; r++) start[(size_t)r + 1] = start[(size_t)r] + sizes[r] / (int64_t)sizeof(JoinRec);
-    const int64_t grain = 16384, nruns = (tot + grain - 1) / grain;
+    const int64_t grain = 4096, nruns = (tot + grain - 1) / grain;
     std::vector<std::vector<Edge>> found((size_t)std::max<int64_t>(nruns, 1));
     std::atomic<int> bad{0};
     dh_parallel_for(nruns, 1, [&](int64_t lo, int64_t hi) {
