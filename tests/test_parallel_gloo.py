@@ -249,3 +249,31 @@ def test_sharded_scaffold_collector_equals_the_single_rank_builder():
                 assert np.array_equal(plan.las[tri[m, col]], las[etri[m, col]])
             assert len(plan.owner) == len(cl) and set(plan.owner.tolist()) <= set(range(world))
             plan.close()
+
+
+def test_shard_graph_glue_rejects_malformed_input():
+    import pytest
+    """Error behaviour of the sharded collector's entry points: bad read ranges, truncated or corrupt join blobs."""
+    import dentist_amd
+    from dentist_amd import LA_DTYPE
+    from dentist_amd._lib import ShardPlan, shard_read_joins
+    coff = np.asarray([0, 5000, 9000], dtype=np.int64)
+    roff = np.asarray([0, 3000, 6000], dtype=np.int64)
+    la = np.zeros(2, dtype=LA_DTYPE)
+    la["aread"], la["bread"] = [0, 1], [7, 7]           # read 7 of a rank that holds reads [5, 7)
+    la["abpos"], la["aepos"], la["bbpos"], la["bepos"] = [4000, 0], [5000, 1200], [0, 1500], [1000, 2700]
+    with pytest.raises(dentist_amd.DhError):
+        shard_read_joins(la, coff, roff, 5)
+    la["bread"] = 6
+    blob = shard_read_joins(la, coff, roff, 5)
+    assert len(blob) % 120 == 0 and len(blob) > 0
+    po = dentist_amd.default_process_opts()
+    with pytest.raises(dentist_amd.DhError):
+        ShardPlan([blob[:-8]], po, graph=(2, None, {}))             # not a whole number of records
+    bad = blob.copy()
+    bad[0:4] = np.asarray([99], dtype=np.int32).view(np.uint8)      # edge names a contig outside the assembly
+    with pytest.raises(dentist_amd.DhError):
+        ShardPlan([bad], po, graph=(2, None, {}))
+    plan = ShardPlan([blob], po, graph=(2, None, {"min_spanning_reads": 1}))
+    assert len(plan.piles) <= 1
+    plan.close()
