@@ -1,0 +1,21 @@
+"""dev: DH_TRACE output of one process stage of configs[2] (run with DH_TRACE=1)."""
+import sys
+sys.path.insert(0, ".")
+import numpy as np
+import dentist_amd
+from dentist_amd import sim
+import bench
+spec = bench.WORKLOADS["cfg2_100Mb_1000gaps_1Mx15kb"]
+w = sim.Workload(seed=20260929, **spec)
+ctx = dentist_amd.Context(0)
+A, B = ctx.db(w.contigs), ctx.db(w.reads)
+mo = dentist_amd.default_align_opts(kmer_mod=4, k=20, width=64, xdrop=60, algo=1)
+po = dentist_amd.default_process_opts(algo=1)
+gaps = np.stack([np.arange(w.contigs.n - 1), np.arange(1, w.contigs.n)], axis=1).astype(np.int32)
+for rep in range(2):
+    las, trace, dropped, cands = ctx.map_reads(A, B, mo, po, sorted=False, candidates=True)
+    gp, _ = dentist_amd.scaffold_spanning_pileups(las, w.contigs.off, w.reads.off, gaps, with_extensions=True, min_spanning_reads=po.min_reads)
+    piles = gp.select(las, po)
+    print("PROCESS", rep, flush=True)
+    rec, bases = dentist_amd.process_pileups(ctx, A, B, las, trace, piles, po)
+    print({k: round(v, 1) for k, v in dentist_amd.process_stats(ctx).items() if k.startswith("ms_")}, flush=True)
