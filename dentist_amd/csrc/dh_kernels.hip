@@ -13,6 +13,7 @@
 // ("Algorithm DH-1"); reference call sites: source/dentist/dazzler.d:6121-6170.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdlib>
 #include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -2262,7 +2263,9 @@ static int seed_grid(int32_t nitems, int32_t ncu)
             nb = 1;
         per_cu = nb;
     }
-    const int64_t g = (int64_t)per_cu * ncu;
+    int use = per_cu;
+    if (const char *e = getenv("DH_SEED_BLOCKS_PER_CU")) use = std::max(1, std::min(per_cu, atoi(e)));  // development
+    const int64_t g = (int64_t)use * ncu;
     return (int)(g < nitems ? g : nitems);
 }
 
