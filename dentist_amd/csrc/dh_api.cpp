@@ -703,6 +703,11 @@ static int build_index(dh_db *A, int32_t k, int32_t sepv, int32_t kmer_mod)
     if (keybits > 62) return fail(DH_EINVAL, "index: k-mer key does not fit 62 bits");
     int32_t pbits = ceil_log2((uint64_t)std::max<int64_t>(nk, 1));
     int32_t pmax = 27;
+    // more indexed k-mers than 2^27 buckets can keep apart (a 3 Gb assembly at kmer_mod 4: 750 M): about one bucket per
+    // entry, up to 2^30 -- at 5.6 entries per bucket every lookup walked a chain of dependent loads (configs[4]: seeds
+    // 631 -> 223 ms per 25 Gbp of reads, index build 81 -> 128 ms; 17 GB of directory, the part has 288)
+    const int64_t expect = nk / std::max(1, kmer_mod);
+    if (expect > (1ll << 27)) pmax = std::min(30, ceil_log2((uint64_t)expect) + 1);
     if (const char *e = getenv("DH_INDEX_PBITS")) pmax = std::max(10, std::min(30, atoi(e)));  // development
     pbits = std::max(10, std::min(pbits, std::min(keybits, pmax)));
     ix.pbits = pbits;

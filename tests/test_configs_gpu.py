@@ -43,7 +43,7 @@ def consensus_edits(truth, contig_start, gap_end, rec, bases):
 def test_config3_eight_emulated_ranks_equal_the_single_rank_run(gpu_ctx, cfg2_workload, capsys):
     w = cfg2_workload
     mo = dentist_amd.default_align_opts(**MAP)
-    po = dentist_amd.default_process_opts()
+    po = dentist_amd.default_process_opts(algo=1)   # DH-2 in every process stage, as bench.py
     A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
     # ---- one rank: bench.py's sequence
     las, trace, dropped, cands = gpu_ctx.map_reads(A, B, mo, po, sorted=False, candidates=True)
@@ -101,7 +101,7 @@ def test_config4_one_rank_of_eight(gpu_ctx, capsys):
     s = sim.RankShare(3_000_000_000, 10_000, 10_000_000, 20_000, rank=0, world=8, seed=20260929)
     t_sim = time.perf_counter() - t0
     mo = dentist_amd.default_align_opts(**MAP)
-    po = dentist_amd.default_process_opts()
+    po = dentist_amd.default_process_opts(algo=1)   # DH-2 in every process stage, as bench.py
     A, B = gpu_ctx.db(s.contigs), gpu_ctx.db(s.reads)
     assert s.reads.n == 1_250_000 and len(s.owned_gaps) == 1250
     # ---- mapping of the rank's read block against the whole assembly
