@@ -3,8 +3,8 @@
 as a measured line for profiles/ (not the headline): the whole assembly and its index, the rank's block of 1.25 M reads
 mapped against it (dh_map_reads, bench.py's options), and the 1 250 pile-ups it owns processed with the spanning reads of
 all ranks.  Prints one JSON line.  tests/test_configs_gpu.py::test_config4_one_rank_of_eight checks the properties."""
-import json, sys, time
-sys.path.insert(0, ".")
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import dentist_amd
 from dentist_amd import sim
