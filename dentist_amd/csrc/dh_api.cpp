@@ -1384,8 +1384,15 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
                         gcap = std::max(gcap, h_nhits[(size_t)it] + h_nhits[(size_t)it + 1]);
                     }
             }
-            if (big.size() > (size_t)ni / 50 + 8 && cap < 16384) {
-                cap *= 2;  // many items overflow the LDS buffer: the next size is cheaper than HBM staging
+            // many items overflow the LDS buffer: the next size is cheaper than HBM staging -- up to 8192; the 16384-entry
+            // variant keeps one block per CU resident and pays off only when most items need it
+            size_t redo_all = (size_t)ni / 50 + 8;
+            if (cap >= 8192) redo_all = (size_t)ni / 4;
+            if (const char *e = getenv("DH_SEED_BIG_PCT")) redo_all = (size_t)((double)ni * atof(e) / 200.0);  // development (reads = ni / 2)
+            if (getenv("DH_TRACE") && !big.empty())
+                fprintf(stderr, "[seeds] cap %d: %zu of %d reads overflow (whole chunk again above %zu)\n", cap, big.size(), ni / 2, redo_all);
+            if (big.size() > redo_all && cap < 16384) {
+                cap *= 2;
                 item0 -= cn;
                 continue;
             }
