@@ -284,6 +284,10 @@ def main():
                               "avg_launch_ms": wave_ms / max(1, cum["wave_launches"]),
                               "algorithmic_bytes_per_step": alg_bytes,
                               "band_cells_per_s": cum["wave_cells"] / (wave_ms * 1e-3),
+                              # VALU issue: 74 wave-instructions per 64 lanes x 64 band cells (SQ_INSTS_VALU of the mapping
+                              # launches, profiles/r03_final_pmc_sq_counters.txt) against the measured ceiling of
+                              # 0.57 G wave-instructions/s per SIMD (scripts/valu_probe.cpp), 1024 SIMDs
+                              "valu_frac": (74.0 * cum["wave_cells"] / 4096.0) / (wave_ms * 1e-3) / (1024 * 0.57e9),
                               "note": "rank 0's launches; integer VALU-issue bound: 70 wave-instructions per 64 band "
                                       "columns, DP cell updates/s is the honest secondary"},
             "stages_ms": {"map_wall": mean(lambda r: r["t_map"]) * 1e3,
