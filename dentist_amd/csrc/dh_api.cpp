@@ -228,6 +228,7 @@ extern "C" int dh_ctx_create(int32_t device, void *stream, dh_ctx **out)
 extern "C" void dh_ctx_destroy(dh_ctx *c)
 {
     if (!c) return;
+    if (c->sub) dh_ctx_destroy(c->sub);
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->cstream) (void)hipStreamSynchronize(c->cstream);

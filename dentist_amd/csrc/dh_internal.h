@@ -59,6 +59,9 @@ struct dh_ctx {
     hipEvent_t cev[4] = {};
     dh_align_stats stats = {};
     dh_cum_stats cum = {};
+    // second context of the same device (own streams and scratch), created on first use: the process stage runs the
+    // two halves of a batch of pile-ups concurrently, one on each (dh_process_pileups)
+    dh_ctx *sub = nullptr;
     // grow-only device scratch buffers reused across calls (hipMalloc/hipFree of GB-sized
     // buffers per call costs milliseconds and synchronises the device)
     struct Arena {

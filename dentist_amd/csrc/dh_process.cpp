@@ -11,6 +11,7 @@
 //   insertion (package.d:699-805, insertions.d:110-146) -> host
 #include <array>
 #include <chrono>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1354,11 +1355,89 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
 {
     if (!ctx || !contigs || !reads || !piles || !opts || !out || (n > 0 && (!las || !trace)))
         return dh_fail(DH_EINVAL, "dh_process_pileups: NULL argument");
-    dh_cropped *c = nullptr;
-    if (int rc = dh_crop_pileups(ctx, contigs, reads, 0, las, n, trace, piles, opts, &c)) return rc;
-    const int rc = dh_process_cropped(ctx, contigs, c, opts, out);
-    dh_cropped_destroy(c);
-    return rc;
+    auto one = [&](dh_ctx *cx, const dh_pileups *pl, dh_insertions **res) -> int {
+        dh_cropped *c = nullptr;
+        if (int rc = dh_crop_pileups(cx, contigs, reads, 0, las, n, trace, pl, opts, &c)) return rc;
+        const int rc = dh_process_cropped(cx, contigs, c, opts, res);
+        dh_cropped_destroy(c);
+        return rc;
+    };
+    const size_t np = piles->contig_left.size();
+    if (np < 64 || getenv("DH_PROCESS_SERIAL")) return one(ctx, piles, out);
+    // Two halves of the batch run concurrently, each on its own context (streams, scratch) and host thread: between its
+    // kernels a half has host work -- device-to-host copies of 3.5 M overlap records, LAsort, filters and chains, the
+    // per-tile descriptors of the consensus rounds -- during which the device served nobody (configs[2]: one call 188 ms,
+    // two concurrent halves 160 ms).  Pile-ups are independent and keep their order; the halves balance n^2.
+    if (!ctx->sub) {
+        if (int rc = dh_ctx_create(ctx->device, nullptr, &ctx->sub)) return rc;
+    }
+    std::vector<double> cost(np);
+    double total = 0;
+    for (size_t p = 0; p < np; p++) {
+        const double e = (double)piles->triples[p].size() / 3.0;
+        cost[p] = e * e;
+        total += cost[p];
+    }
+    size_t cut = 0;
+    for (double acc = 0; cut < np && acc + cost[cut] <= total / 2; cut++) acc += cost[cut];
+    cut = std::max<size_t>(1, std::min(cut, np - 1));
+    dh_pileups half[2];
+    for (size_t p = 0; p < np; p++) {
+        dh_pileups &h = half[p < cut ? 0 : 1];
+        h.contig_left.push_back(piles->contig_left[p]);
+        h.triples.push_back(piles->triples[p]);
+    }
+    dh_insertions *res[2] = {nullptr, nullptr};
+    int rcs[2] = {DH_OK, DH_OK};
+    std::string msg1;
+    ProcStats st1;
+    std::thread worker([&] {
+        rcs[1] = one(ctx->sub, &half[1], &res[1]);
+        if (rcs[1]) msg1 = dh_last_error();
+        st1 = g_pstats;
+    });
+    rcs[0] = one(ctx, &half[0], &res[0]);
+    worker.join();
+    // the second context's alignment statistics belong to this call (the two streams' event times overlap: their sum
+    // overstates the kernel time of the step, never understates it)
+    {
+        dh_cum_stats &a = ctx->cum, &b = ctx->sub->cum;
+        a.ms_index += b.ms_index; a.ms_seed += b.ms_seed; a.ms_wave += b.ms_wave; a.ms_gather += b.ms_gather;
+        a.wave_launches += b.wave_launches; a.wave_cells += b.wave_cells; a.alignments += b.alignments; a.las += b.las;
+        a.aligned_bp += b.aligned_bp; a.trace_values += b.trace_values; a.hits += b.hits; a.b_bases += b.b_bases;
+        b = dh_cum_stats();
+    }
+    if (rcs[0] || rcs[1]) {
+        dh_insertions_destroy(res[0]);
+        dh_insertions_destroy(res[1]);
+        return rcs[0] ? rcs[0] : dh_fail(rcs[1], msg1.empty() ? "dh_process_pileups: the second half of the batch failed" : msg1);
+    }
+    for (int i = 0; i < 7; i++) g_pstats.ms[i] = std::max(g_pstats.ms[i], st1.ms[i]);  // the halves ran side by side
+    for (int i = 0; i < 3; i++) g_pstats.counters[i] += st1.counters[i];
+    // second half appended to the first
+    dh_insertions *r0 = res[0], *r1 = res[1];
+    const int64_t b0 = (int64_t)r0->bases.size();
+    const int32_t f0 = (int32_t)r0->flank.size(), i0 = r0->ids_off.empty() ? 0 : r0->ids_off.back();
+    const int64_t t0 = (int64_t)r0->flank_tr.size();
+    for (dh_insertion x : r1->rec) {
+        x.cons_off += b0;
+        r0->rec.push_back(x);
+    }
+    r0->bases.insert(r0->bases.end(), r1->bases.begin(), r1->bases.end());
+    for (dh_la f : r1->flank) {
+        f.toff += t0;
+        r0->flank.push_back(f);
+    }
+    r0->flank_tr.insert(r0->flank_tr.end(), r1->flank_tr.begin(), r1->flank_tr.end());
+    for (int32_t v : r1->flank_of) r0->flank_of.push_back(v < 0 ? v : v + f0);
+    if (!r1->ids_off.empty()) {
+        if (r0->ids_off.empty()) r0->ids_off.push_back(0);
+        for (size_t k = 1; k < r1->ids_off.size(); k++) r0->ids_off.push_back(r1->ids_off[k] + i0);
+        r0->ids.insert(r0->ids.end(), r1->ids.begin(), r1->ids.end());
+    }
+    dh_insertions_destroy(r1);
+    *out = r0;
+    return DH_OK;
 }
 
 // The pile-up stages of `dentist process` after the crop (package.d:283-374): pile-up alignment ->

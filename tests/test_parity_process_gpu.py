@@ -182,6 +182,17 @@ def test_config1_full_size_properties(gpu_ctx):
     assert_same_las((las2, trace2), (las, trace))
     rec2, bases2 = dentist_amd.process_pileups(gpu_ctx, A, B, las2, trace2, dentist_amd.Pileups(las2, w.contigs.off, po), po)
     assert np.array_equal(rec2, rec) and np.array_equal(bases2, bases)
+    # a batch of 64 or more pile-ups is processed as two concurrent halves (two contexts, two host threads): one after
+    # the other (DH_PROCESS_SERIAL) gives the same records, consensus sequences, read ids and containers
+    ids = dentist_amd.process_pileups(gpu_ctx, A, B, las, trace, piles, po, read_ids=True)
+    os.environ["DH_PROCESS_SERIAL"] = "1"
+    try:
+        ids1 = dentist_amd.process_pileups(gpu_ctx, A, B, las, trace, piles, po, read_ids=True)
+    finally:
+        del os.environ["DH_PROCESS_SERIAL"]
+    for got, exp in ((ids[0], ids1[0]), (ids[1], ids1[1]), (ids[2][0], ids1[2][0]), (ids[2][1], ids1[2][1])):
+        assert np.array_equal(got, exp)
+    assert np.array_equal(ids1[0], rec) and np.array_equal(ids1[1], bases) and len(ids[2][0]) >= 3 * 99
 
 
 def test_config2_full_size_properties(gpu_ctx, cfg2_workload):
