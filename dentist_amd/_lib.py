@@ -79,7 +79,7 @@ SYMBOLS = [
     "dh_cropped_nreads", "dh_cropped_pile", "dh_cropped_entry", "dh_cropped_read_id", "dh_cropped_offsets",
     "dh_cropped_bases", "dh_process_cropped", "dh_translate_trace_point", "dh_db_dust", "dh_db_get_mask",
     "dh_dazz_write_track", "dh_dazz_read_track", "dh_dazz_remove", "dh_dazz_flags",
-    "dh_pileupdb_write", "dh_pileupdb_read", "dh_insertiondb_write", "dh_insertiondb_read", "dh_chaindb_destroy",
+    "dh_pileupdb_write", "dh_pileupdb_read", "dh_insertiondb_write", "dh_insertiondb_read", "dh_insertiondb_merge", "dh_chaindb_destroy",
     "dh_chaindb_npiles", "dh_chaindb_pile_counts", "dh_chaindb_nread_alignments", "dh_chaindb_read_alignment_counts",
     "dh_chaindb_nseeded", "dh_chaindb_seeded", "dh_chaindb_nlas", "dh_chaindb_las", "dh_chaindb_ntrace",
     "dh_chaindb_trace", "dh_chaindb_ninsertions", "dh_chaindb_insertions", "dh_chaindb_bases", "dh_chaindb_read_ids",
@@ -1283,3 +1283,15 @@ def insertiondb_read(path):
     L.dh_insertiondb_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
     _check(L.dh_insertiondb_read(path.encode(), ctypes.byref(h)))
     return _take_chaindb(h)
+
+
+def insertiondb_merge(paths, out_path):
+    """`dentist merge-insertions` (commands/mergeInsertions.d:42-164): k-way merge of insertions.db files by
+    (start contig, start part, end contig, end part); returns the number of insertions written."""
+    L = lib()
+    arr = (ctypes.c_char_p * max(1, len(paths)))(*[p.encode() for p in paths])
+    n = ctypes.c_int64(0)
+    L.dh_insertiondb_merge.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.c_int32, ctypes.c_char_p,
+                                       ctypes.POINTER(ctypes.c_int64)]
+    _check(L.dh_insertiondb_merge(arr, len(paths), out_path.encode(), ctypes.byref(n)))
+    return n.value

@@ -18,6 +18,8 @@
 //   sequence bytes: 4 bases per byte, a=0 c=1 t=2 g=3, first base in the low bits (common.d:324-345)
 // (pileupdb.d:710-897, insertiondb.d:738-1031; sizes asserted by the reference's own unit tests as
 // sums of T.sizeof, pileupdb.d:439-446.)
+#include <algorithm>
+#include <climits>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -405,4 +407,92 @@ extern "C" int dh_insertiondb_read(const char *path, dh_chaindb **out)
     }
     *out = d;
     return DH_OK;
+}
+
+// `dentist merge-insertions` (commands/mergeInsertions.d:42-164): the insertions of several insertions.db
+// files (one per `process --batch`, snakemake/Snakefile:1315-1334) merged into one, ordered like the
+// reference's Insertion.opCmp (util/math.d:527-545 on ContigNode tuples: start contig, start part, end
+// contig, end part).  A file that is not sorted is sorted first (ensureSorted :66-72); equal keys keep the
+// order of the files (the merger takes the first source whose head is strictly smallest, :120-138).
+namespace {
+struct InsRef {
+    int32_t file, idx;
+    int64_t base_off, id_off, sa_off;
+};
+inline bool ins_less(const dh_insertion_rec &a, const dh_insertion_rec &b)
+{
+    if (a.start_contig != b.start_contig) return a.start_contig < b.start_contig;
+    if (a.start_part != b.start_part) return a.start_part < b.start_part;
+    if (a.end_contig != b.end_contig) return a.end_contig < b.end_contig;
+    return a.end_part < b.end_part;
+}
+} // namespace
+
+extern "C" int dh_insertiondb_merge(const char *const *paths, int32_t npaths, const char *out_path, int64_t *ntotal)
+{
+    if (!out_path || npaths < 0 || (npaths > 0 && !paths)) return dh_fail(DH_EINVAL, "dh_insertiondb_merge: bad argument");
+    std::vector<dh_chaindb *> dbs(npaths, nullptr);
+    auto cleanup = [&]() { for (auto *d : dbs) delete d; };
+    std::vector<std::vector<InsRef>> refs(npaths);
+    std::vector<std::vector<int64_t>> la_off(npaths), tp_off(npaths); // per seeded alignment of a file
+    int64_t total = 0;
+    for (int32_t f = 0; f < npaths; f++) {
+        if (!paths[f]) { cleanup(); return dh_fail(DH_EINVAL, "dh_insertiondb_merge: NULL path"); }
+        int rc = dh_insertiondb_read(paths[f], &dbs[f]);
+        if (rc != DH_OK) { cleanup(); return rc; }
+        const dh_chaindb *d = dbs[f];
+        int64_t lo = 0, to = 0;
+        la_off[f].reserve(d->sa.size() + 1);
+        tp_off[f].reserve(d->sa.size() + 1);
+        for (size_t s = 0; s < d->sa.size(); s++) {
+            la_off[f].push_back(lo);
+            tp_off[f].push_back(to);
+            for (int32_t l = 0; l < d->sa[s].nla; l++) to += 2ll * d->la[lo + l].ntp;
+            lo += d->sa[s].nla;
+        }
+        la_off[f].push_back(lo);
+        tp_off[f].push_back(to);
+        int64_t bo = 0, io = 0, so = 0;
+        for (size_t i = 0; i < d->ins.size(); i++) {
+            refs[f].push_back({f, (int32_t)i, bo, io, so});
+            bo += d->ins[i].seq_len;
+            io += d->ins[i].nread_ids;
+            so += d->ins[i].noverlaps;
+        }
+        auto less = [d](const InsRef &a, const InsRef &b) { return ins_less(d->ins[a.idx], d->ins[b.idx]); };
+        if (!std::is_sorted(refs[f].begin(), refs[f].end(), less)) std::stable_sort(refs[f].begin(), refs[f].end(), less);
+        total += (int64_t)d->ins.size();
+    }
+    if (total > INT32_MAX) { cleanup(); return dh_fail(DH_EINVAL, "dh_insertiondb_merge: more than 2^31 insertions"); }
+    std::vector<dh_insertion_rec> ins;
+    std::vector<uint8_t> bases;
+    std::vector<uint32_t> ids;
+    std::vector<dh_seeded> sa;
+    std::vector<dh_chain_la> la;
+    std::vector<uint16_t> tp;
+    ins.reserve(total);
+    std::vector<size_t> head(npaths, 0);
+    for (;;) {
+        int32_t best = -1;
+        for (int32_t f = 0; f < npaths; f++) {
+            if (head[f] >= refs[f].size()) continue;
+            if (best < 0 || ins_less(dbs[f]->ins[refs[f][head[f]].idx], dbs[best]->ins[refs[best][head[best]].idx])) best = f;
+        }
+        if (best < 0) break;
+        const InsRef &r = refs[best][head[best]++];
+        const dh_chaindb *d = dbs[best];
+        const dh_insertion_rec &rec = d->ins[r.idx];
+        ins.push_back(rec);
+        bases.insert(bases.end(), d->ins_bases.begin() + r.base_off, d->ins_bases.begin() + r.base_off + rec.seq_len);
+        ids.insert(ids.end(), d->read_ids.begin() + r.id_off, d->read_ids.begin() + r.id_off + rec.nread_ids);
+        sa.insert(sa.end(), d->sa.begin() + r.sa_off, d->sa.begin() + r.sa_off + rec.noverlaps);
+        const int64_t l0 = la_off[best][r.sa_off], l1 = la_off[best][r.sa_off + rec.noverlaps];
+        const int64_t t0 = tp_off[best][r.sa_off], t1 = tp_off[best][r.sa_off + rec.noverlaps];
+        la.insert(la.end(), d->la.begin() + l0, d->la.begin() + l1);
+        tp.insert(tp.end(), d->tp.begin() + t0, d->tp.begin() + t1);
+    }
+    cleanup();
+    if (ntotal) *ntotal = total;
+    return dh_insertiondb_write(out_path, (int32_t)ins.size(), ins.data(), bases.data(), ids.data(), sa.data(), la.data(),
+                                tp.data());
 }

@@ -605,6 +605,11 @@ int dh_pileupdb_read(const char *path, dh_chaindb **out);
 int dh_insertiondb_write(const char *path, int32_t nins, const dh_insertion_rec *ins, const uint8_t *bases,
                          const uint32_t *read_ids, const dh_seeded *sa, const dh_chain_la *la, const uint16_t *tp);
 int dh_insertiondb_read(const char *path, dh_chaindb **out);
+/* `dentist merge-insertions` (commands/mergeInsertions.d:42-164): the insertions.db files of the process batches
+ * (snakemake/Snakefile:1315-1334) merged into one file, ordered by (start contig, start part, end contig, end
+ * part) like Insertion.opCmp (util/math.d:527-545); an unsorted input is sorted first (:66-72), equal keys keep
+ * the order of the inputs (:120-138).  *ntotal (may be NULL) = insertions written. */
+int dh_insertiondb_merge(const char *const *paths, int32_t npaths, const char *out_path, int64_t *ntotal);
 /* pile-ups.db of a collect result (collectPileUps/package.d:88-96): every read of a pile-up becomes a
  * ReadAlignment of two SeededAlignments (left contig seeded at the back, right contig at the front) */
 int dh_pileups_write_db(const dh_pileups *p, const dh_la *las, int64_t n, const uint16_t *trace,

@@ -125,3 +125,68 @@ def test_insertiondb_round_trip_and_base_packing(tmp_path):
     assert np.array_equal(back["seeded"], overlaps) and np.array_equal(back["las"], las) and np.array_equal(back["trace"], trace)
     with pytest.raises(dentist_amd.DhError):
         dentist_amd.insertiondb_write(path, ins, np.full(48, 4, np.uint8), [5, 9, 1539, 77], overlaps, las, trace)
+
+
+def test_merge_insertions_is_a_keyed_merge_of_the_batch_files(tmp_path):
+    """`dentist merge-insertions` (commands/mergeInsertions.d:42-164): batch files merged by (start, end) node; a batch
+    that is not sorted is sorted first (:66-72); equal keys keep the order of the files (:120-138, the unittest's
+    [1,3,5] + [2,3,4] + [3,5,6] -> [1,2,3,3,3,4,5,5,6] with contig ids as keys)."""
+    g, pc, rc, sa, la, tp = load_fixture()
+    rng = np.random.default_rng(3)
+    sa_la0 = np.concatenate([[0], np.cumsum(sa["nla"])]).astype(np.int64)
+    la_tp0 = np.concatenate([[0], np.cumsum(la["ntp"])]).astype(np.int64) * 2
+
+    def batch(keys, tag):
+        n = len(keys)
+        ins = np.zeros(n, dtype=dentist_amd.INSERTION_REC_DTYPE)
+        bases, ids, ov, las, trace = [], [], [], [], []
+        for i, k in enumerate(keys):
+            ins[i]["start_contig"], ins[i]["start_part"], ins[i]["end_contig"], ins[i]["end_part"] = k, 2, k + 1, 1
+            L = int(rng.integers(1, 40))
+            ins[i]["seq_len"], ins[i]["noverlaps"], ins[i]["nread_ids"] = L, 1 + (i & 1), 1 + i % 3
+            bases.append(rng.integers(0, 4, L).astype(np.uint8))
+            ids.append(np.asarray([tag * 1000 + k * 10 + j for j in range(1 + i % 3)], dtype=np.uint32))
+            for j in range(1 + (i & 1)):
+                s = int(rng.integers(0, len(sa)))
+                ov.append(sa[s:s + 1])
+                las.append(la[sa_la0[s]:sa_la0[s + 1]])
+                trace.append(tp[la_tp0[sa_la0[s]]:la_tp0[sa_la0[s + 1]]])
+        path = str(tmp_path / f"batch.{tag}.db")
+        cat = lambda xs, like: np.concatenate(xs) if xs else like[:0]
+        dentist_amd.insertiondb_write(path, ins, cat(bases, np.zeros(0, np.uint8)), cat(ids, np.zeros(0, np.uint32)),
+                                      cat(ov, sa), cat(las, la), cat(trace, tp))
+        return path, [(int(k), tag) for k in keys]
+
+    files = [batch([1, 3, 5], 1), batch([4, 2, 3], 2), batch([3, 5, 6], 3), batch([], 4)]   # batch 2 is unsorted
+    out = str(tmp_path / "insertions.db")
+    assert dentist_amd.insertiondb_merge([f[0] for f in files], out) == 9
+    m = dentist_amd.insertiondb_read(out)
+    assert m["insertions"]["start_contig"].tolist() == [1, 2, 3, 3, 3, 4, 5, 5, 6]
+    # every merged insertion carries its own payload: look each one up in its source file
+    src = {f[0]: dentist_amd.insertiondb_read(f[0]) for f in files}
+    got_tags = [int(m["read_ids"][o]) // 1000 for o in np.concatenate([[0], np.cumsum(m["insertions"]["nread_ids"])])[:-1]]
+    assert got_tags == [1, 2, 1, 2, 3, 2, 1, 3, 3]          # ties in file order
+
+    def payloads(d):
+        ins = d["insertions"]
+        bo = np.concatenate([[0], np.cumsum(ins["seq_len"])])
+        io = np.concatenate([[0], np.cumsum(ins["nread_ids"])])
+        so = np.concatenate([[0], np.cumsum(ins["noverlaps"])])
+        lo = np.concatenate([[0], np.cumsum(d["seeded"]["nla"])])
+        to = np.concatenate([[0], np.cumsum(d["las"]["ntp"])]) * 2
+        res = {}
+        for i in range(len(ins)):
+            l0, l1 = lo[so[i]], lo[so[i + 1]]
+            key = (int(ins[i]["start_contig"]), int(d["read_ids"][io[i]]) // 1000)
+            res[key] = (ins[i].tobytes(), d["bases"][bo[i]:bo[i + 1]].tobytes(), d["read_ids"][io[i]:io[i + 1]].tobytes(),
+                        d["seeded"][so[i]:so[i + 1]].tobytes(), d["las"][l0:l1].tobytes(), d["trace"][to[l0]:to[l1]].tobytes())
+        return res
+    want = {}
+    for d in src.values():
+        want.update(payloads(d))
+    assert payloads(m) == want and len(want) == 9
+    # no inputs: an empty container; a missing file: an error, nothing written over the old result
+    assert dentist_amd.insertiondb_merge([], str(tmp_path / "empty.db")) == 0
+    assert len(dentist_amd.insertiondb_read(str(tmp_path / "empty.db"))["insertions"]) == 0
+    with pytest.raises(dentist_amd.DhError):
+        dentist_amd.insertiondb_merge([files[0][0], str(tmp_path / "nope.db")], out)

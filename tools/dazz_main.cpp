@@ -12,6 +12,9 @@
 //   computeintrinsicqv -d<depth> <db> <las>             `inqual` track  dazzler.d:6172-6183
 //   daccord [-t<n>] [-I<i>,<j>] [-f] [--eprofonly] <las> <db>           dazzler.d:6185-6231
 //                                    consensus FASTA on stdout; --eprofonly writes <las>.eprof
+//   merge-insertions <merged.db> <batch.db>...   (DENTIST's own sub-command, commands/mergeInsertions.d:42-164,
+//                                    snakemake/Snakefile:1315-1334; here so that batches written by this library
+//                                    can be merged without the D binary)
 // DENTIST only sees exit codes, files and stdout of these tools; flags it never emits are rejected.
 #include <algorithm>
 #include <cmath>
@@ -455,6 +458,25 @@ static int tool_lamerge(const std::vector<std::string> &args)
     return 0;
 }
 
+static int tool_merge_insertions(const std::vector<std::string> &args)
+{
+    std::vector<const char *> in;
+    std::string out;
+    for (const std::string &a : args) {
+        if (a == "-v" || a == "-vv" || a == "-vvv") continue;
+        if (a[0] == '-') die("unknown option " + a);
+        if (out.empty())
+            out = a;
+        else
+            in.push_back(a.c_str());
+    }
+    if (out.empty() || in.empty()) die("usage: merge-insertions <merged-insertions:db> <insertions:db> ...");
+    int64_t n = 0;
+    CHK(dh_insertiondb_merge(in.data(), (int32_t)in.size(), out.c_str(), &n));
+    fprintf(stderr, "{\"numInputFiles\":%zu,\"totalNumInsertions\":%lld}\n", in.size(), (long long)n);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     g_tool = argv[0];
@@ -478,7 +500,8 @@ int main(int argc, char **argv)
     if (g_tool == "DASqv") return tool_qv("qual", args, true);
     if (g_tool == "computeintrinsicqv") return tool_qv("inqual", args, true);
     if (g_tool == "daccord") return tool_daccord(args);
+    if (g_tool == "merge-insertions") return tool_merge_insertions(args);
     die("unknown tool (expected fasta2DB fasta2DAM DBsplit DBrm DBdump DBshow DBdust LAmerge DAScover DASqv "
-        "computeintrinsicqv daccord)");
+        "computeintrinsicqv daccord merge-insertions)");
     return 1;
 }
