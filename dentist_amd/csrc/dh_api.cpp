@@ -228,7 +228,8 @@ extern "C" int dh_ctx_create(int32_t device, void *stream, dh_ctx **out)
 extern "C" void dh_ctx_destroy(dh_ctx *c)
 {
     if (!c) return;
-    if (c->sub) dh_ctx_destroy(c->sub);
+    for (dh_ctx *s : c->sub)
+        if (s) dh_ctx_destroy(s);
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->cstream) (void)hipStreamSynchronize(c->cstream);
@@ -1150,10 +1151,10 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         std::vector<std::thread> v;
         void join()
         {
-            (void)hipStreamSynchronize(cs);  // copies in flight land first
             for (auto &t : v)
                 if (t.joinable()) t.join();
             v.clear();
+            (void)hipStreamSynchronize(cs);  // copies in flight have landed
         }
         ~Tasks() { join(); }
     } tasks{ctx->cstream, {}};
@@ -1575,10 +1576,13 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             HIPCHK(hipStreamWaitEvent(ctx->cstream, compacted, 0));
             HIPCHK(hipMemcpyAsync(res->la.data() + l0, d_laout, sizeof(dh_la) * (size_t)totals[0],
                                   hipMemcpyDeviceToHost, ctx->cstream));
+            // the chunk's hook (chain flags, filters, candidates) reads the records only: it starts when they have
+            // arrived, while the trace values -- ten times the bytes -- are still on their way (Tasks::join waits
+            // for the stream before anybody sees the result)
+            HIPCHK(hipEventRecord(copied, ctx->cstream));
             if (totals[1] > 0)
                 HIPCHK(hipMemcpyAsync(res->trace.data() + t0, d_trout, sizeof(uint16_t) * (size_t)totals[1],
                                       hipMemcpyDeviceToHost, ctx->cstream));
-            HIPCHK(hipEventRecord(copied, ctx->cstream));
             res->d_trace = (t0 == 0 && item0 == item_first && ni == nitems_total) ? d_trout : nullptr;
         }
         if (res2) {

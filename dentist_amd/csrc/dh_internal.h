@@ -61,7 +61,7 @@ struct dh_ctx {
     dh_cum_stats cum = {};
     // second context of the same device (own streams and scratch), created on first use: the process stage runs the
     // two halves of a batch of pile-ups concurrently, one on each (dh_process_pileups)
-    dh_ctx *sub = nullptr;
+    dh_ctx *sub[3] = {nullptr, nullptr, nullptr};  // contexts of the concurrent parts of dh_process_pileups
     // grow-only device scratch buffers reused across calls (hipMalloc/hipFree of GB-sized
     // buffers per call costs milliseconds and synchronises the device)
     struct Arena {

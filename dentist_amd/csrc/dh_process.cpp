@@ -1364,13 +1364,17 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
     };
     const size_t np = piles->contig_left.size();
     if (np < 64 || getenv("DH_PROCESS_SERIAL")) return one(ctx, piles, out);
-    // Two halves of the batch run concurrently, each on its own context (streams, scratch) and host thread: between its
-    // kernels a half has host work -- device-to-host copies of 3.5 M overlap records, LAsort, filters and chains, the
+    // Parts of the batch run concurrently, each on its own context (streams, scratch) and host thread: between its
+    // kernels a part has host work -- device-to-host copies of 3.5 M overlap records, LAsort, filters and chains, the
     // per-tile descriptors of the consensus rounds -- during which the device served nobody (configs[2]: one call 188 ms,
-    // two concurrent halves 160 ms).  Pile-ups are independent and keep their order; the halves balance n^2.
-    if (!ctx->sub) {
-        if (int rc = dh_ctx_create(ctx->device, nullptr, &ctx->sub)) return rc;
-    }
+    // two concurrent halves 160 ms).  Pile-ups are independent and keep their order; the parts balance n^2.
+    int32_t nparts = 2;
+    if (const char *e = getenv("DH_PROCESS_PARTS")) nparts = std::max(1, std::min(4, atoi(e)));
+    nparts = (int32_t)std::min<size_t>((size_t)nparts, np / 16);
+    if (nparts < 2) return one(ctx, piles, out);
+    for (int32_t k = 1; k < nparts; k++)
+        if (!ctx->sub[k - 1])
+            if (int rc = dh_ctx_create(ctx->device, nullptr, &ctx->sub[k - 1])) return rc;
     std::vector<double> cost(np);
     double total = 0;
     for (size_t p = 0; p < np; p++) {
@@ -1378,64 +1382,82 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
         cost[p] = e * e;
         total += cost[p];
     }
-    size_t cut = 0;
-    for (double acc = 0; cut < np && acc + cost[cut] <= total / 2; cut++) acc += cost[cut];
-    cut = std::max<size_t>(1, std::min(cut, np - 1));
-    dh_pileups half[2];
-    for (size_t p = 0; p < np; p++) {
-        dh_pileups &h = half[p < cut ? 0 : 1];
-        h.contig_left.push_back(piles->contig_left[p]);
-        h.triples.push_back(piles->triples[p]);
-    }
-    dh_insertions *res[2] = {nullptr, nullptr};
-    int rcs[2] = {DH_OK, DH_OK};
-    std::string msg1;
-    ProcStats st1;
-    std::thread worker([&] {
-        rcs[1] = one(ctx->sub, &half[1], &res[1]);
-        if (rcs[1]) msg1 = dh_last_error();
-        st1 = g_pstats;
-    });
-    rcs[0] = one(ctx, &half[0], &res[0]);
-    worker.join();
-    // the second context's alignment statistics belong to this call (the two streams' event times overlap: their sum
-    // overstates the kernel time of the step, never understates it)
+    // contiguous runs of pile-ups of about total / nparts each, none empty
+    std::vector<size_t> cut((size_t)nparts + 1, np);
+    cut[0] = 0;
     {
-        dh_cum_stats &a = ctx->cum, &b = ctx->sub->cum;
+        size_t p = 0;
+        double acc = 0;
+        for (int32_t k = 1; k < nparts; k++) {
+            while (p < np && acc + cost[p] <= total * k / nparts) acc += cost[p++];
+            while (p < cut[(size_t)k - 1] + 1) acc += cost[p++];
+            p = std::min(p, np - (size_t)(nparts - k));
+            cut[(size_t)k] = p;
+        }
+    }
+    std::vector<dh_pileups> part((size_t)nparts);
+    for (int32_t k = 0; k < nparts; k++)
+        for (size_t p = cut[(size_t)k]; p < cut[(size_t)k + 1]; p++) {
+            part[(size_t)k].contig_left.push_back(piles->contig_left[p]);
+            part[(size_t)k].triples.push_back(piles->triples[p]);
+        }
+    std::vector<dh_insertions *> res((size_t)nparts, nullptr);
+    std::vector<int> rcs((size_t)nparts, DH_OK);
+    std::vector<std::string> msgs((size_t)nparts);
+    std::vector<ProcStats> sts((size_t)nparts);
+    std::vector<std::thread> workers;
+    for (int32_t k = 1; k < nparts; k++)
+        workers.emplace_back([&, k] {
+            rcs[(size_t)k] = one(ctx->sub[k - 1], &part[(size_t)k], &res[(size_t)k]);
+            if (rcs[(size_t)k]) msgs[(size_t)k] = dh_last_error();
+            sts[(size_t)k] = g_pstats;
+        });
+    rcs[0] = one(ctx, &part[0], &res[0]);
+    for (std::thread &w : workers) w.join();
+    // the other contexts' alignment statistics belong to this call (the streams' event times overlap: their sum
+    // overstates the kernel time of the step, never understates it)
+    for (int32_t k = 1; k < nparts; k++) {
+        dh_cum_stats &a = ctx->cum, &b = ctx->sub[k - 1]->cum;
         a.ms_index += b.ms_index; a.ms_seed += b.ms_seed; a.ms_wave += b.ms_wave; a.ms_gather += b.ms_gather;
         a.wave_launches += b.wave_launches; a.wave_cells += b.wave_cells; a.alignments += b.alignments; a.las += b.las;
         a.aligned_bp += b.aligned_bp; a.trace_values += b.trace_values; a.hits += b.hits; a.b_bases += b.b_bases;
         b = dh_cum_stats();
     }
-    if (rcs[0] || rcs[1]) {
-        dh_insertions_destroy(res[0]);
-        dh_insertions_destroy(res[1]);
-        return rcs[0] ? rcs[0] : dh_fail(rcs[1], msg1.empty() ? "dh_process_pileups: the second half of the batch failed" : msg1);
+    for (int32_t k = 0; k < nparts; k++)
+        if (rcs[(size_t)k]) {
+            for (dh_insertions *r : res) dh_insertions_destroy(r);
+            if (k == 0) return rcs[0];
+            return dh_fail(rcs[(size_t)k], msgs[(size_t)k].empty() ? "dh_process_pileups: a concurrent part of the batch failed" : msgs[(size_t)k]);
+        }
+    for (int32_t k = 1; k < nparts; k++) {
+        for (int i = 0; i < 7; i++) g_pstats.ms[i] = std::max(g_pstats.ms[i], sts[(size_t)k].ms[i]);  // side by side
+        for (int i = 0; i < 3; i++) g_pstats.counters[i] += sts[(size_t)k].counters[i];
     }
-    for (int i = 0; i < 7; i++) g_pstats.ms[i] = std::max(g_pstats.ms[i], st1.ms[i]);  // the halves ran side by side
-    for (int i = 0; i < 3; i++) g_pstats.counters[i] += st1.counters[i];
-    // second half appended to the first
-    dh_insertions *r0 = res[0], *r1 = res[1];
-    const int64_t b0 = (int64_t)r0->bases.size();
-    const int32_t f0 = (int32_t)r0->flank.size(), i0 = r0->ids_off.empty() ? 0 : r0->ids_off.back();
-    const int64_t t0 = (int64_t)r0->flank_tr.size();
-    for (dh_insertion x : r1->rec) {
-        x.cons_off += b0;
-        r0->rec.push_back(x);
+    // later parts appended to the first
+    dh_insertions *r0 = res[0];
+    for (int32_t k = 1; k < nparts; k++) {
+        dh_insertions *r1 = res[(size_t)k];
+        const int64_t b0 = (int64_t)r0->bases.size();
+        const int32_t f0 = (int32_t)r0->flank.size(), i0 = r0->ids_off.empty() ? 0 : r0->ids_off.back();
+        const int64_t t0 = (int64_t)r0->flank_tr.size();
+        for (dh_insertion x : r1->rec) {
+            x.cons_off += b0;
+            r0->rec.push_back(x);
+        }
+        r0->bases.insert(r0->bases.end(), r1->bases.begin(), r1->bases.end());
+        for (dh_la f : r1->flank) {
+            f.toff += t0;
+            r0->flank.push_back(f);
+        }
+        r0->flank_tr.insert(r0->flank_tr.end(), r1->flank_tr.begin(), r1->flank_tr.end());
+        for (int32_t v : r1->flank_of) r0->flank_of.push_back(v < 0 ? v : v + f0);
+        if (!r1->ids_off.empty()) {
+            if (r0->ids_off.empty()) r0->ids_off.push_back(0);
+            for (size_t j = 1; j < r1->ids_off.size(); j++) r0->ids_off.push_back(r1->ids_off[j] + i0);
+            r0->ids.insert(r0->ids.end(), r1->ids.begin(), r1->ids.end());
+        }
+        dh_insertions_destroy(r1);
     }
-    r0->bases.insert(r0->bases.end(), r1->bases.begin(), r1->bases.end());
-    for (dh_la f : r1->flank) {
-        f.toff += t0;
-        r0->flank.push_back(f);
-    }
-    r0->flank_tr.insert(r0->flank_tr.end(), r1->flank_tr.begin(), r1->flank_tr.end());
-    for (int32_t v : r1->flank_of) r0->flank_of.push_back(v < 0 ? v : v + f0);
-    if (!r1->ids_off.empty()) {
-        if (r0->ids_off.empty()) r0->ids_off.push_back(0);
-        for (size_t k = 1; k < r1->ids_off.size(); k++) r0->ids_off.push_back(r1->ids_off[k] + i0);
-        r0->ids.insert(r0->ids.end(), r1->ids.begin(), r1->ids.end());
-    }
-    dh_insertions_destroy(r1);
     *out = r0;
     return DH_OK;
 }

@@ -9,7 +9,7 @@ import bench
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 spec = bench.WORKLOADS["cfg2_100Mb_1000gaps_1Mx15kb"]
 ctx = dentist_amd.Context(0)
-mo = dentist_amd.default_align_opts(kmer_mod=4, k=20, width=64, xdrop=60, algo=1)
+mo = dentist_amd.default_align_opts(kmer_mod=8, k=20, width=64, xdrop=60, algo=1)
 po = dentist_amd.default_process_opts(algo=1)
 ranks = []
 A = None

@@ -23,7 +23,8 @@ from oracle import pyoracle as oz
 
 pytestmark = pytest.mark.gpu
 
-MAP = dict(kmer_mod=4, k=20, width=64, xdrop=60, algo=1)   # bench.py's mapping options
+MAP = dict(kmer_mod=8, k=20, width=64, xdrop=60, algo=1)   # bench.py's mapping options
+MAP4 = dict(MAP, kmer_mod=4)   # configs[4], the HBM-bound stress configuration: twice the lookups per read
 
 
 def consensus_edits(truth, contig_start, gap_end, rec, bases):
@@ -100,7 +101,7 @@ def test_config4_one_rank_of_eight(gpu_ctx, capsys):
     t0 = time.perf_counter()
     s = sim.RankShare(3_000_000_000, 10_000, 10_000_000, 20_000, rank=0, world=8, seed=20260929)
     t_sim = time.perf_counter() - t0
-    mo = dentist_amd.default_align_opts(**MAP)
+    mo = dentist_amd.default_align_opts(**MAP4)
     po = dentist_amd.default_process_opts(algo=1)   # DH-2 in every process stage, as bench.py
     A, B = gpu_ctx.db(s.contigs), gpu_ctx.db(s.reads)
     assert s.reads.n == 1_250_000 and len(s.owned_gaps) == 1250

@@ -193,6 +193,14 @@ def test_config1_full_size_properties(gpu_ctx):
     for got, exp in ((ids[0], ids1[0]), (ids[1], ids1[1]), (ids[2][0], ids1[2][0]), (ids[2][1], ids1[2][1])):
         assert np.array_equal(got, exp)
     assert np.array_equal(ids1[0], rec) and np.array_equal(ids1[1], bases) and len(ids[2][0]) >= 3 * 99
+    # four concurrent parts (DH_PROCESS_PARTS, at least 16 pile-ups each): the same bits again
+    os.environ["DH_PROCESS_PARTS"] = "4"
+    try:
+        ids3 = dentist_amd.process_pileups(gpu_ctx, A, B, las, trace, piles, po, read_ids=True)
+    finally:
+        del os.environ["DH_PROCESS_PARTS"]
+    for got, exp in ((ids3[0], ids1[0]), (ids3[1], ids1[1]), (ids3[2][0], ids1[2][0]), (ids3[2][1], ids1[2][1])):
+        assert np.array_equal(got, exp)
 
 
 def test_config2_full_size_properties(gpu_ctx, cfg2_workload):
