@@ -577,10 +577,30 @@ __device__ void seed_item(const DbView &B, const IndexView &ix,
         if (tid == 0) ncand_out[item] = ncand_out[item + 1] = nhits_out[item] = nhits_out[item + 1] = 0;
         return;
     }
-    // ---- bitonic sort of the padded hit buffer (keys are distinct)
+    // ---- sort of the hit buffer (keys are distinct: a hit is (strand, diagonal, read position))
     int32_t N = 1;
     while (N < n) N <<= 1;
-    for (int32_t i = n + tid; i < N; i += SEED_THREADS) hits[i] = ~0ull;
+    if (LCAP > 0 && n <= SEED_THREADS) {
+        // at most one hit per thread (the mapping launches: 140 hits per read at kmer_mod 8): every thread counts the
+        // keys below its own -- n broadcast reads that do not depend on each other -- and stores its key at that rank.
+        // The bitonic network below takes log^2 N dependent LDS round trips (36 for N = 256: 8.6 of the 50 us a block
+        // spent per read)
+        uint64_t key = 0;
+        int32_t rk = 0;
+        if (tid < n) {
+            key = hits[tid];
+#pragma unroll 4
+            for (int32_t x = 0; x < n; x++) rk += hits[x] < key ? 1 : 0;
+        }
+        __syncthreads();
+        if (tid < n)
+            hits[rk] = key;
+        else if (tid < N)
+            hits[tid] = ~0ull;
+        N = 1;  // the network below has nothing left to do
+    } else {
+        for (int32_t i = n + tid; i < N; i += SEED_THREADS) hits[i] = ~0ull;
+    }
     __syncthreads();
     // Pair p exchanges elements i = insert-zero-bit(p, j) and i | j.  Pairs are dealt to threads in
     // runs of 64, so for strides j < 128 both elements of every pair of a wavefront live in that
