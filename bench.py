@@ -151,7 +151,10 @@ def main():
         # so every rank filters the alignments of its own reads, chunk by chunk on the host while the
         # device maps the next chunk (dh_map_reads)
         # and lists the spanning-read candidates of the chunk; records stay in mapping order (by read)
-        las, trace, dropped, cands = ctx.map_reads(A, B, mopts, popts, sorted=False, candidates=True)
+        # (the spanning-read candidates only when that collector is asked for: the scaffold graph does not use them)
+        mapped = ctx.map_reads(A, B, mopts, popts, sorted=False, candidates=args.collect != "graph")
+        las, trace, dropped = mapped[:3]
+        cands = mapped[3] if len(mapped) > 3 else None
         ast = ctx.align_stats()
         t1 = time.perf_counter()
         if world == 1:

@@ -741,8 +741,35 @@ static int build_index(dh_db *A, int32_t k, int32_t sepv, int32_t kmer_mod)
                               ctx->stream));
     HIPCHK(hipMemsetAsync(ix.d_dir_alloc, 0, sizeof(uint32_t) * (size_t)(nb + 2), ctx->stream));
     const DbView av = A->view();
-    dhk_kmer_pass(ctx->stream, 0, av, d_tiles, (int32_t)tiles.size(), k, kmer_mod, ix.shift, ix.d_dir, ix.d_ent,
-                  ix.d_goff);
+    // grouped DB (pile-ups): a group's keys share their top bits, i.e. its buckets are one contiguous range; when the
+    // sequences come group by group and a group is cut into few slices, the passes count in LDS (k_group_index)
+    // instead of 2 x nk device-scope atomics on random counters (configs[2]: see DESIGN 8)
+    int32_t *d_gtile = nullptr;
+    int32_t gi_slices = 0, gi_slice = 0;
+    struct GtGuard {
+        int32_t *&p;
+        ~GtGuard() { dh_dev_free(p); }
+    } gtg{d_gtile};
+    if (A->d_group && A->ngroups > 1 && ix.shift <= 2 * k && !getenv("DH_INDEX_ATOMICS")) {
+        const int64_t nbg = 1ll << (2 * k - ix.shift);
+        gi_slice = (int32_t)std::min<int64_t>(nbg, DH_GI_SLICE);
+        gi_slices = (int32_t)(nbg / gi_slice);
+        bool ordered = true;
+        for (int32_t s2 = 1; s2 < A->n && ordered; s2++) ordered = A->h_group[(size_t)s2] >= A->h_group[(size_t)s2 - 1];
+        if (!ordered || gi_slices > 16 || (int64_t)A->ngroups * gi_slices > (1ll << 30)) gi_slices = 0;
+    }
+    std::vector<int32_t> gtile;  // tiles of group g: [gtile[g], gtile[g + 1]); alive until the stream is synchronised below
+    if (gi_slices > 0) {
+        gtile.assign((size_t)A->ngroups + 1, 0);
+        for (const int2 &t : tiles) gtile[(size_t)A->h_group[(size_t)t.x] + 1]++;
+        for (int32_t g2 = 0; g2 < A->ngroups; g2++) gtile[(size_t)g2 + 1] += gtile[(size_t)g2];
+        HIPCHK(dh_dev_alloc(&d_gtile, sizeof(int32_t) * gtile.size()));
+        HIPCHK(hipMemcpyAsync(d_gtile, gtile.data(), sizeof(int32_t) * gtile.size(), hipMemcpyHostToDevice, ctx->stream));
+        dhk_group_index(ctx->stream, 0, av, d_tiles, d_gtile, A->ngroups, gi_slices, gi_slice, k, kmer_mod, ix.shift,
+                        ix.d_dir, ix.d_ent, ix.d_goff);
+    } else
+        dhk_kmer_pass(ctx->stream, 0, av, d_tiles, (int32_t)tiles.size(), k, kmer_mod, ix.shift, ix.d_dir, ix.d_ent,
+                      ix.d_goff);
     dhk_scan(ctx->stream, ix.d_dir, nb + 1, d_sums);
     // the entry array is sized by the k-mers that were actually indexed (sampled, unmasked): the
     // exclusive scan leaves their number in dir[nb]
@@ -751,8 +778,12 @@ static int build_index(dh_db *A, int32_t k, int32_t sepv, int32_t kmer_mod)
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ix.n = (int64_t)nent;
     HIPCHK(dh_dev_alloc(&ix.d_ent, sizeof(ulonglong2) * (size_t)std::max<int64_t>(ix.n, 1)));
-    dhk_kmer_pass(ctx->stream, 1, av, d_tiles, (int32_t)tiles.size(), k, kmer_mod, ix.shift, ix.d_dir, ix.d_ent,
-                  ix.d_goff);
+    if (gi_slices > 0)
+        dhk_group_index(ctx->stream, 1, av, d_tiles, d_gtile, A->ngroups, gi_slices, gi_slice, k, kmer_mod, ix.shift,
+                        ix.d_dir, ix.d_ent, ix.d_goff);
+    else
+        dhk_kmer_pass(ctx->stream, 1, av, d_tiles, (int32_t)tiles.size(), k, kmer_mod, ix.shift, ix.d_dir, ix.d_ent,
+                      ix.d_goff);
     HIPCHK(hipGetLastError());
     // the directory the seed kernel reads: 16 bytes per bucket that hold the bucket's only entry itself, so that a
     // looked-up k-mer costs one random line unless its bucket holds several entries
@@ -816,10 +847,7 @@ extern "C" void dh_set_near_best(int32_t ppm) { g_near_best_ppm = ppm < 0 ? 0 : 
 static void select_best_range(dh_la *la, size_t nla)
 {
     // groups of equal bread are independent: host threads take runs of groups
-    std::vector<size_t> gstart;
-    for (size_t i = 0; i < nla; i++)
-        if (i == 0 || la[i].bread != la[i - 1].bread) gstart.push_back(i);
-    gstart.push_back(nla);
+    const std::vector<int64_t> gstart = dh_run_starts((int64_t)nla, [la](int64_t i) { return la[i].bread; });
     const int32_t near_ppm = g_near_best_ppm;
     dh_parallel_for((int64_t)gstart.size() - 1, 2048, [&](int64_t glo, int64_t ghi) {
         struct Chain {
@@ -831,7 +859,7 @@ static void select_best_range(dh_la *la, size_t nla)
         std::vector<size_t> ord;
         std::vector<Chain> chains;
         for (int64_t g = glo; g < ghi; g++) {
-            const size_t g0 = gstart[(size_t)g], g1 = gstart[(size_t)g + 1];
+            const size_t g0 = (size_t)gstart[(size_t)g], g1 = (size_t)gstart[(size_t)g + 1];
             ord.clear();
             for (size_t x = g0; x < g1; x++) ord.push_back(x);
             std::sort(ord.begin(), ord.end(), [&](size_t x, size_t y) { return la_less(la[x], la[y]); });  // (a, b, comp, abpos, ...)
@@ -1149,12 +1177,18 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     struct Tasks {
         hipStream_t cs;
         std::vector<std::thread> v;
+        double ms_hooks = 0, ms_copies = 0;  // of the last join: waiting for the hook threads, then for the copy stream
         void join()
         {
+            const auto t0 = std::chrono::steady_clock::now();
             for (auto &t : v)
                 if (t.joinable()) t.join();
             v.clear();
+            const auto t1 = std::chrono::steady_clock::now();
             (void)hipStreamSynchronize(cs);  // copies in flight have landed
+            const auto t2 = std::chrono::steady_clock::now();
+            ms_hooks = std::chrono::duration<double, std::milli>(t1 - t0).count();
+            ms_copies = std::chrono::duration<double, std::milli>(t2 - t1).count();
         }
         ~Tasks() { join(); }
     } tasks{ctx->cstream, {}};
@@ -1620,9 +1654,17 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             const bool best = want_best != 0;
             tasks.v.emplace_back([h, p, cnt, copied, dev, l0h, chunk_no, best] {
                 (void)hipSetDevice(dev);
+                const auto t0 = std::chrono::steady_clock::now();
                 (void)hipEventSynchronize(copied);  // the records of this chunk have arrived
+                const auto t1 = std::chrono::steady_clock::now();
                 if (best) select_best_range(p, (size_t)cnt);  // chain flags: a per-read decision too
+                const auto t2 = std::chrono::steady_clock::now();
                 h(p, cnt, l0h, chunk_no);
+                if (getenv("DH_TRACE"))
+                    fprintf(stderr, "[chunk hook %lld] %lld records: wait %.2f chains %.2f filters + candidates %.2f ms\n",
+                            (long long)chunk_no, (long long)cnt, std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                            std::chrono::duration<double, std::milli>(t2 - t1).count(),
+                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count());
             });
         }
         float t;
@@ -1642,6 +1684,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     stats.alignments = (int64_t)counters[1];
 
     tasks.join();
+    const double tail_hooks = tasks.ms_hooks, tail_copies = tasks.ms_copies;
     if (want_best && !hook) select_best_range(res->la.data(), res->la.size());
     if (want_sorted) lasort(res, A->n);
     if (res2) {
@@ -1700,13 +1743,13 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         fprintf(stderr,
                 "[dh_align_db] A=%d seqs/%lld bp B=%d seqs/%lld bp hits=%lld cands=%lld aln=%lld las=%lld cells=%lld | "
                 "index %.2f seed %.2f wave %.2f gather %.2f ms, wall %.2f ms (host: index %.2f loop %.2f post %.2f; "
-                "loop: copies %.2f seed %.2f wave %.2f stats %.2f resize %.2f d2h %.2f)\n",
+                "loop: copies %.2f seed %.2f wave %.2f stats %.2f resize %.2f d2h %.2f; tail: hooks %.2f copies %.2f)\n",
                 A->n, (long long)A->total, B->n, (long long)B->total, (long long)stats.hits, (long long)stats.cands,
                 (long long)stats.alignments, (long long)stats.las, (long long)stats.wave_cells, stats.ms_index,
                 stats.ms_seed, stats.ms_wave, stats.ms_gather,
                 ((double)std::chrono::duration_cast<std::chrono::microseconds>(
                      std::chrono::steady_clock::now().time_since_epoch()).count() - wall0) / 1e3,
-                w_index, w_loop, w_post, w_g[0], w_g[1], w_g[2], w_g[3], w_g[4], w_g[5]);
+                w_index, w_loop, w_post, w_g[0], w_g[1], w_g[2], w_g[3], w_g[4], w_g[5], tail_hooks, tail_copies);
     guard.ok = true;
     *out = res;
     if (out_tr) {

@@ -72,6 +72,11 @@ void dhk_revcomp(hipStream_t st, const uint8_t *src, uint8_t *dst, const int64_t
                  int32_t max_len);
 void dhk_kmer_pass(hipStream_t st, int fill, DbView A, const int2 *tiles, int32_t ntiles, int32_t k,
                    int32_t kmer_mod, int32_t shift, uint32_t *dir, ulonglong2 *ent, const int64_t *goff);
+/* the two passes for a grouped DB whose groups own contiguous bucket ranges: LDS counters, no global atomics */
+#define DH_GI_SLICE 32768
+void dhk_group_index(hipStream_t st, int fill, DbView A, const int2 *tiles, const int32_t *gtile, int32_t ngroups,
+                     int32_t slices_per_group, int32_t slice, int32_t k, int32_t kmer_mod, int32_t shift, uint32_t *dir,
+                     ulonglong2 *ent, const int64_t *goff);
 void dhk_scan(hipStream_t st, uint32_t *v, int64_t n, uint32_t *sums);
 void dhk_seed_summary(hipStream_t st, const int32_t *ncand, const int32_t *nhits, int32_t n, unsigned long long *out4);
 // dir[b] = end of bucket b (dir[-1] == 0) -> the fat directory

@@ -98,6 +98,99 @@ extern "C" int dh_collect_filter(dh_la *las, int64_t n, const int64_t *contig_of
         newly += local;
     });
     stage_done(2);
+    // Records grouped by read (what the aligner emits, and what the chunk hook of dh_map_reads hands over): the three
+    // remaining stages are decisions per read -- `contained` relates alignments of one read on one contig (in the
+    // sorted order of stage 4 below the alignments of a read on a contig are neighbours, and the scan leaves a1's
+    // range at the first alignment that is not inside it on the contig: alignments of other reads cannot change
+    // the outcome), `ambiguous` and `redundant` are per read by definition -- so the host threads take runs of reads
+    // and no global regrouping (two counting sorts, five serial passes over the records) is needed.
+    std::atomic<int> ungrouped{0};
+    dh_parallel_for(n, 16384, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = std::max<int64_t>(lo, 1); i < hi; i++)
+            if (las[i].bread < las[i - 1].bread) ungrouped = 1;
+    });
+    if (!ungrouped) {
+        const std::vector<int64_t> rs = dh_run_starts(n, [las](int64_t i) { return las[i].bread; });
+        std::vector<uint8_t> used((size_t)nreads, 1);
+        std::atomic<int64_t> c3{0}, c4{0}, c5{0};
+        dh_parallel_for((int64_t)rs.size() - 1, 1024, [&](int64_t rlo, int64_t rhi) {
+            int64_t l3 = 0, l4 = 0, l5 = 0;
+            std::vector<int64_t> idx;
+            for (int64_t run = rlo; run < rhi; run++) {
+                const int64_t i0 = rs[(size_t)run], i1 = rs[(size_t)run + 1];
+                const int32_t r = las[i0].bread;
+                if (i1 - i0 > 1) {  // 4: contained
+                    idx.resize((size_t)(i1 - i0));
+                    std::iota(idx.begin(), idx.end(), i0);
+                    std::stable_sort(idx.begin(), idx.end(), [&](int64_t x, int64_t y) {
+                        const dh_la &p = las[x], &q = las[y];
+                        if (p.aread != q.aread) return p.aread < q.aread;
+                        if (p.abpos != q.abpos) return p.abpos < q.abpos;
+                        if (p.bbpos != q.bbpos) return p.bbpos < q.bbpos;
+                        if (p.aepos != q.aepos) return p.aepos < q.aepos;
+                        return p.bepos < q.bepos;
+                    });
+                    for (size_t x = 0; x < idx.size(); x++) {
+                        const dh_la &a1 = las[idx[x]];
+                        if (a1.flags & DH_FLAG_DISABLED) continue;
+                        for (size_t y = x + 1; y < idx.size(); y++) {
+                            dh_la &a2 = las[idx[y]];
+                            if (a2.aread != a1.aread || !(a1.abpos <= a2.abpos && a2.aepos <= a1.aepos)) break;
+                            if ((a2.flags & DH_FLAG_COMP) == (a1.flags & DH_FLAG_COMP) && c.bfwd_begin(a1) <= c.bfwd_begin(a2) &&
+                                c.bfwd_end(a2) <= c.bfwd_end(a1) && !(a2.flags & DH_FLAG_DISABLED)) {
+                                a2.flags |= DH_FLAG_DISABLED;
+                                l3++;
+                            }
+                        }
+                    }
+                }
+                bool amb = false;  // 5: ambiguous
+                for (int64_t x = i0; x < i1 && !amb; x++) {
+                    const dh_la &p = las[x];
+                    if (p.flags & DH_FLAG_DISABLED) continue;
+                    for (int64_t y = x + 1; y < i1; y++) {
+                        const dh_la &q = las[y];
+                        if (q.flags & DH_FLAG_DISABLED) continue;
+                        if (c.bfwd_begin(p) < c.bfwd_end(q) && c.bfwd_begin(q) < c.bfwd_end(p)) {
+                            amb = true;
+                            break;
+                        }
+                    }
+                }
+                if (amb) {
+                    used[(size_t)r] = 0;
+                    for (int64_t x = i0; x < i1; x++) {
+                        l4 += (las[x].flags & DH_FLAG_DISABLED) ? 0 : 1;
+                        las[x].flags |= DH_FLAG_DISABLED;
+                    }
+                }
+                bool red = false;  // 6: redundant -- isFullyContained, base.d:562-598
+                for (int64_t x = i0; x < i1 && !red; x++) {
+                    const dh_la &p = las[x];
+                    if (p.flags & DH_FLAG_DISABLED) continue;
+                    if (p.bbpos > p.abpos) continue;
+                    const int64_t yy = (int64_t)p.aepos + c.blen(p) - p.bepos;
+                    red = yy < c.alen(p);
+                }
+                if (red) {
+                    used[(size_t)r] = 0;
+                    for (int64_t x = i0; x < i1; x++) {
+                        l5 += (las[x].flags & DH_FLAG_DISABLED) ? 0 : 1;
+                        las[x].flags |= DH_FLAG_DISABLED;
+                    }
+                }
+            }
+            c3 += l3;
+            c4 += l4;
+            c5 += l5;
+        });
+        cnt[3] = c3.load();
+        cnt[4] = c4.load();
+        cnt[5] = c5.load();
+        if (dropped6) memcpy(dropped6, cnt, sizeof(cnt));
+        if (read_used) memcpy(read_used, used.data(), (size_t)nreads);
+        return DH_OK;
+    }
     // 4: contained (AlignmentChain.opCmp order, base.d:766-777; stable).  Alignments of different
     // contigs never interact, so the contigs are sorted and scanned independently on the host threads.
     std::vector<int64_t> ord((size_t)n);

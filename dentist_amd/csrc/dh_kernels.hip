@@ -232,6 +232,84 @@ k_kmer_pass(DbView A, const int2 *__restrict__ tiles, int32_t ntiles, int32_t k,
         }
     }
 }
+// The same two passes for a GROUPED DB (the pile-up stage: group = pile-up) without global atomics.  Keys carry the
+// group in their top bits, so a group owns the contiguous bucket range [g * nbg, (g + 1) * nbg), nbg = 4^k >> shift.
+// A block takes (group, slice of `slice` <= GI_SLICE buckets), rolls every k-mer of the group -- its tiles are
+// tiles[gtile[g] .. gtile[g + 1]) -- and counts (FILL: places) those of its slice with LDS atomics; the counts / the
+// advanced cursors go to dir[] in one coalesced pass.  170 M device-scope atomics on random counters took 19 ms per
+// step (configs[2], 1 000 pile-ups); the price here is that a group's k-mers are rolled once per slice (8 times at
+// k = 14 with 2^27 buckets), which is VALU work of about a millisecond.
+#define GI_SLICE 32768
+#define GI_THREADS 1024
+template <bool FILL>
+__global__ void __launch_bounds__(GI_THREADS)
+k_group_index(DbView A, const int2 *__restrict__ tiles, const int32_t *__restrict__ gtile, int32_t slices_per_group,
+              int32_t slice, int32_t k, int32_t kmer_mod, int32_t shift, uint32_t *__restrict__ dir,
+              ulonglong2 *__restrict__ ent, const int64_t *__restrict__ goff)
+{
+    __shared__ uint32_t cnt[GI_SLICE];
+    const int32_t g = blockIdx.x / slices_per_group, sl = blockIdx.x % slices_per_group;
+    const int tid = threadIdx.x;
+    const uint32_t b0 = (uint32_t)((((uint64_t)g) << (2 * k)) >> shift) + (uint32_t)sl * (uint32_t)slice;
+    for (int32_t i = tid; i < slice; i += GI_THREADS) cnt[i] = FILL ? dir[b0 + i] : 0u;
+    __syncthreads();
+    const uint64_t grp = (uint64_t)g;
+    const uint64_t mask = (1ull << (2 * k)) - 1;
+    const KmerSampler smp = kmer_sampler(kmer_mod, k);
+    const int rcsh = 2 * (k - 1);
+    for (int32_t t = gtile[g] + (tid >> 8); t < gtile[g + 1]; t += GI_THREADS / 256) {
+        const int32_t s = tiles[t].x;
+        const int64_t o = A.off[s];
+        const int32_t len = (int32_t)(A.off[s + 1] - o);
+        const int32_t p0 = tiles[t].y + (tid & 255) * (KM_TILE / 256);
+        const uint8_t *a = A.bases + o;
+        uint64_t km = 0, rc = 0;
+        int32_t valid = 0;
+        // the thread's 16 + k - 1 <= 43 bases as six 8-byte words, all in flight at once (a byte load per base made the
+        // roll a chain of dependent memory round trips: 8 slices x that was slower than the atomics it replaces)
+        constexpr int NW = (KM_TILE / 256 + 27 + 7) / 8;
+        uint64_t wq[NW];
+        const int32_t nroll = KM_TILE / 256 + k - 1;
+#pragma unroll
+        for (int q = 0; q < NW; q++) wq[q] = (8 * q < nroll && p0 + 8 * q < len) ? load8(a + p0 + 8 * q) : 0ull;
+        // the soft-mask bits of the thread's k-mers (starts p0 .. p0 + 15, 15 + k <= 43 bits) in one load as well: a
+        // mask_touch per k-mer put a dependent global load into nearly every step of the roll
+        const uint64_t mw = (A.mask_bits && p0 < len) ? load8(A.mask_bits + ((o + p0) >> 3)) >> ((o + p0) & 7) : 0ull;
+        const uint64_t kones = (1ull << k) - 1ull;
+#pragma unroll
+        for (int32_t x = 0; x < NW * 8; x++) {
+            const int32_t p = p0 + x;
+            if (x >= nroll || p >= len) break;
+            const uint8_t c = (uint8_t)(wq[x >> 3] >> (8 * (x & 7)));
+            if (c < 4) {
+                km = ((km << 2) | c) & mask;
+                rc = (rc >> 2) | ((uint64_t)(3 - c) << rcsh);
+                valid++;
+            } else {
+                km = 0;
+                rc = 0;
+                valid = 0;
+            }
+            const uint64_t canon = km < rc ? km : rc;
+            if (x < k - 1 || valid < k) continue;
+            const uint64_t key = (grp << (2 * k)) | canon;
+            const uint32_t rel = (uint32_t)(key >> shift) - b0;
+            if (rel >= (uint32_t)slice) continue;  // another slice's bucket
+            if (!kmer_sampled(canon, smp) || ((mw >> (x - (k - 1))) & kones) != 0ull) continue;
+            const uint32_t slot = atomicAdd(&cnt[rel], 1u);
+            if (FILL)
+                ent[slot] = make_ulonglong2(key | (km != canon ? 1ull << 63 : 0ull),
+                                            ((uint64_t)s << 40) | (uint64_t)(goff[s] + (p - k + 1)));
+        }
+    }
+    __syncthreads();
+    for (int32_t i = tid; i < slice; i += GI_THREADS) dir[b0 + i] = cnt[i];
+}
+template __global__ void k_group_index<false>(DbView, const int2 *, const int32_t *, int32_t, int32_t, int32_t, int32_t,
+                                              int32_t, uint32_t *, ulonglong2 *, const int64_t *);
+template __global__ void k_group_index<true>(DbView, const int2 *, const int32_t *, int32_t, int32_t, int32_t, int32_t,
+                                             int32_t, uint32_t *, ulonglong2 *, const int64_t *);
+
 // fat directory (dh_device.h): thread per bucket
 __global__ void __launch_bounds__(256)
 k_fat_dir(const uint32_t *__restrict__ dir, const ulonglong2 *__restrict__ ent, int64_t nb, ulonglong2 *__restrict__ fat)
@@ -610,14 +688,33 @@ __device__ void seed_item(const DbView &B, const IndexView &ix,
         for (int32_t j = kk >> 1; j > 0; j >>= 1) {
             const bool cross = j >= 128;
             if (cross) __syncthreads();
-            for (int32_t p = tid; p < (N >> 1); p += SEED_THREADS) {
-                const int32_t i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
-                const int32_t ixj = i | j;
-                const uint64_t x = hits[i], y = hits[ixj];
-                const bool up = (i & kk) == 0;
-                if ((x > y) == up) {
-                    hits[i] = y;
-                    hits[ixj] = x;
+            // pairs in batches of SORT_U: all loads of a batch are issued before the first exchange is stored (the pairs
+            // of a round are disjoint).  One pair at a time made every pair a full memory round trip -- 64 of them in a
+            // row per thread and round when 50 000 hits of a repeat-rich read are sorted in the HBM slab (17 ms for the
+            // 27 such reads of a configs[2] half)
+            constexpr int SORT_U = (LCAP == 0 || LCAP >= 4096) ? 8 : 4;
+            for (int32_t p0 = tid; p0 < (N >> 1); p0 += SEED_THREADS * SORT_U) {
+                uint64_t xs[SORT_U], ys[SORT_U];
+#pragma unroll
+                for (int u = 0; u < SORT_U; u++) {
+                    const int32_t p = p0 + u * SEED_THREADS;
+                    if (p < (N >> 1)) {
+                        const int32_t i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                        xs[u] = hits[i];
+                        ys[u] = hits[i | j];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < SORT_U; u++) {
+                    const int32_t p = p0 + u * SEED_THREADS;
+                    if (p < (N >> 1)) {
+                        const int32_t i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                        const bool up = (i & kk) == 0;
+                        if ((xs[u] > ys[u]) == up) {
+                            hits[i] = ys[u];
+                            hits[i | j] = xs[u];
+                        }
+                    }
                 }
             }
             if (cross)
@@ -2439,6 +2536,20 @@ void dhk_kmer_pass(hipStream_t st, int fill, DbView A, const int2 *tiles, int32_
                            kmer_mod, shift, dir, ent, goff);
     else
         hipLaunchKernelGGL(k_kmer_pass<false>, dim3(ntiles), dim3(256), 0, st, A, tiles, ntiles, k,
+                           kmer_mod, shift, dir, ent, goff);
+}
+
+void dhk_group_index(hipStream_t st, int fill, DbView A, const int2 *tiles, const int32_t *gtile, int32_t ngroups,
+                     int32_t slices_per_group, int32_t slice, int32_t k, int32_t kmer_mod, int32_t shift, uint32_t *dir,
+                     ulonglong2 *ent, const int64_t *goff)
+{
+    if (ngroups <= 0) return;
+    const dim3 grid((uint32_t)ngroups * (uint32_t)slices_per_group);
+    if (fill)
+        hipLaunchKernelGGL(k_group_index<true>, grid, dim3(GI_THREADS), 0, st, A, tiles, gtile, slices_per_group, slice, k,
+                           kmer_mod, shift, dir, ent, goff);
+    else
+        hipLaunchKernelGGL(k_group_index<false>, grid, dim3(GI_THREADS), 0, st, A, tiles, gtile, slices_per_group, slice, k,
                            kmer_mod, shift, dir, ent, goff);
 }
 

@@ -108,3 +108,27 @@ inline void dh_parallel_for(int64_t n, int64_t grain, F &&fn)
     const std::function<void(int64_t, int64_t)> f = std::forward<F>(fn);
     DhPool::get().run(n, grain, f);
 }
+
+// Starts of the runs of equal key(i) in [0, n), plus n at the end -- found by the host threads over slices of
+// the index range and concatenated in order (a serial pass over a million records is a millisecond nobody hides).
+template <class K>
+inline std::vector<int64_t> dh_run_starts(int64_t n, K &&key)
+{
+    const int64_t grain = 1 << 15, nchunks = (n + grain - 1) / grain;
+    std::vector<std::vector<int64_t>> part((size_t)(nchunks > 0 ? nchunks : 1));
+    dh_parallel_for(nchunks, 1, [&](int64_t clo, int64_t chi) {
+        for (int64_t c = clo; c < chi; c++) {
+            std::vector<int64_t> &v = part[(size_t)c];
+            const int64_t i1 = (c + 1) * grain < n ? (c + 1) * grain : n;
+            for (int64_t i = c * grain; i < i1; i++)
+                if (i == 0 || key(i) != key(i - 1)) v.push_back(i);
+        }
+    });
+    std::vector<int64_t> out;
+    size_t total = 1;
+    for (const auto &v : part) total += v.size();
+    out.reserve(total);
+    for (const auto &v : part) out.insert(out.end(), v.begin(), v.end());
+    out.push_back(n);
+    return out;
+}

@@ -70,6 +70,13 @@ def test_product_filters_equal_the_oracle_on_random_sets():
         assert np.array_equal(got["flags"], exp["flags"]) and np.array_equal(gd, ed) and np.array_equal(gu, eu)
         assert (got["flags"] & 0x20 == 0).sum() > 0
         total += ed
+        # the same records grouped by read, as the aligner emits them: the product takes its per-read path (no global
+        # regrouping), the oracle does not care
+        byread = las[np.argsort(las["bread"], kind="stable")]
+        got2, gd2, gu2 = dentist_amd.collect_filter(byread, coff, roff, po, repeat_mask=(ptr, iv))
+        exp2, ed2, eu2 = cf.collect_filter(byread, coff, roff, repeat_mask=(ptr, iv))
+        assert np.array_equal(got2["flags"], exp2["flags"]) and np.array_equal(gd2, ed2) and np.array_equal(gu2, eu2)
+        assert np.array_equal(gd2, gd) and np.array_equal(gu2, gu)
     assert all(d > 0 for d in total), total     # every stage is exercised
 
 

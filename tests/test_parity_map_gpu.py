@@ -195,6 +195,26 @@ def test_grouped_piles_never_cross_groups(gpu_ctx):
         assert np.array_equal(sel[f], l1[f])
 
 
+@pytest.mark.parametrize("k,mod", [(14, 1), (12, 1), (16, 2)])
+def test_grouped_index_counted_in_lds_equals_the_atomic_passes(gpu_ctx, monkeypatch, k, mod):
+    """The index of a grouped DB is built group by group with LDS counters (k_group_index); the generic passes with
+    global atomics (DH_INDEX_ATOMICS=1) and the oracle give the same hits, candidates and records.  Group ids with no
+    sequence (2) and a group of one short read are part of the input."""
+    ps = [pile(51, n=10), pile(52, n=7), pile(53, n=14), pile(54, n=1)]
+    gid = [0, 1, 3, 4]
+    off = [np.zeros(1, dtype=np.int64)]
+    for p in ps:
+        off.append(p.off[1:] + off[-1][-1])
+    both = sim.SeqDb(np.concatenate([p.bases for p in ps]), np.concatenate(off),
+                     group=np.concatenate([np.full(p.n, g, dtype=np.int32) for p, g in zip(ps, gid)]))
+    kw = dict(tspace=126, skip_self=2, min_len=500, max_la=64, max_cand=128, k=k, kmer_mod=mod)
+    las, trace = run_both(gpu_ctx, both, both, same=True, **kw)
+    assert len(las) > 0 and np.all(both.group[las["aread"]] == both.group[las["bread"]])
+    monkeypatch.setenv("DH_INDEX_ATOMICS", "1")
+    las2, trace2 = run_both(gpu_ctx, both, both, same=True, **kw)
+    assert_same_las((las2, trace2), (las, trace))
+
+
 def test_edge_cases_empty_short_and_n_reads(gpu_ctx):
     g = sim.genome(5, 30000)
     rd, _ = sim.reads(6, g, 20, 3000)
