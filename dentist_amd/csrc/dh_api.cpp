@@ -1436,11 +1436,13 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
                 if (gcap > (1 << 22)) return fail(DH_EOVERFLOW, "seed filter: more than 4M k-mer hits for one sequence; lower -t");
                 int32_t pow2 = 1;
                 while (pow2 < gcap) pow2 <<= 1;  // the bitonic sort pads to a power of two
-                const size_t per_launch = std::max<size_t>(1, (size_t)(2ull << 30) / ((size_t)pow2 * 8));
+                // per block: pow2 hits, pow2 64-bit prefix sums, pow2 32-bit band-head positions (k_seed<0>)
+                const size_t slab_words = 2 * (size_t)pow2 + ((size_t)pow2 + 1) / 2;
+                const size_t per_launch = std::max<size_t>(1, (size_t)(2ull << 30) / (slab_words * 8));
                 int32_t *d_list;
                 uint64_t *d_gbuf;
                 SCR(15, d_list, big.size())
-                SCR(16, d_gbuf, std::min(per_launch, big.size()) * (size_t)pow2)
+                SCR(16, d_gbuf, std::min(per_launch, big.size()) * slab_words)
                 HIPCHK(hipMemcpyAsync(d_list, big.data(), sizeof(int32_t) * big.size(), hipMemcpyHostToDevice, st));
                 for (size_t b0 = 0; b0 < big.size(); b0 += per_launch) {
                     const int32_t cnt = (int32_t)std::min(per_launch, big.size() - b0);

@@ -12,6 +12,7 @@
 // The arithmetic specification these kernels implement is written down in DESIGN.md
 // ("Algorithm DH-1"); reference call sites: source/dentist/dazzler.d:6121-6170.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <algorithm>
 #include <cstdlib>
 #include <stdio.h>
@@ -460,7 +461,8 @@ __device__ void seed_item(const DbView &B, const IndexView &ix,
 
     const int32_t r = LCAP > 0 ? read0 + work : read_list[work];
     const int32_t item = 2 * r;
-    uint64_t *hits = LCAP > 0 ? lhits : gbuf + (int64_t)slab * gcap;
+    // HBM variant: the block's slab holds gcap hits, gcap 64-bit prefix sums and gcap 32-bit head positions
+    uint64_t *hits = LCAP > 0 ? lhits : gbuf + (int64_t)slab * (2 * (int64_t)gcap + (gcap + 1) / 2);
     const int32_t CAP = LCAP > 0 ? LCAP : gcap;
     const int tid = threadIdx.x;
 #ifdef DH_SEED_PROF
@@ -746,13 +748,23 @@ __device__ void seed_item(const DbView &B, const IndexView &ix,
     // global scratch (48 KB, L2 resident since the persistent block reuses it): the parallel scan beats
     // the serial walks by far (pile-up all-vs-all: 183 -> about 30 us per read).  18 bits of coverage and
     // 14 bits of head count hold up to 8192 hits of k <= 28.
-    constexpr bool FASTB = LCAP > 0 && LCAP <= 8192;
+    // The HBM variant (LCAP == 0: the few reads whose hits -- tens of thousands for a repeat-rich read -- overflow the
+    // LDS buffer) scans as well, with 64-bit sums (32 bits of coverage, 32 of head count) and 32-bit head positions in
+    // the block's slab behind the hits: the serial walks cost a chain of dependent L2 round trips per hit of a band,
+    // 5 - 21 ms for the 27 such reads of a configs[2] half (one block each).
+    constexpr bool FASTB = LCAP <= 8192;
     constexpr bool FB_LDS = LCAP > 0 && LCAP <= 4096;
+    constexpr bool FB_BIG = LCAP == 0;
+    using bsum_t = typename std::conditional<FB_BIG, uint64_t, uint32_t>::type;
+    using bhead_t = typename std::conditional<FB_BIG, uint32_t, uint16_t>::type;
+    constexpr int HSH = FB_BIG ? 32 : 18;
+    constexpr bsum_t CMASK = ((bsum_t)1 << HSH) - 1;
     __shared__ uint32_t bsum_l[FB_LDS ? LCAP : 1];   // inclusive prefix sums
     __shared__ uint16_t bhead_l[FB_LDS ? LCAP : 1];  // positions of the band heads
-    uint32_t *bsum = FB_LDS ? bsum_l : (uint32_t *)(gbuf + (int64_t)slab * gcap);
-    uint16_t *bhead = FB_LDS ? bhead_l : (uint16_t *)(bsum + (LCAP > 0 ? LCAP : 1));
-    __shared__ uint32_t s_wsum[SEED_THREADS / LANES];
+    bsum_t *bsum = FB_LDS ? (bsum_t *)bsum_l
+                          : (FB_BIG ? (bsum_t *)(hits + gcap) : (bsum_t *)(gbuf + (int64_t)slab * gcap));
+    bhead_t *bhead = FB_LDS ? (bhead_t *)bhead_l : (bhead_t *)(bsum + (LCAP > 0 ? LCAP : gcap));
+    __shared__ bsum_t s_wsum[SEED_THREADS / LANES];
     __shared__ int32_t s_nbig;
     __shared__ int32_t bigc[64][4];  // candidate band pairs with long hit ranges: (first, end, P, slot)
     __shared__ unsigned long long s_bestkeys[64];
@@ -792,33 +804,33 @@ __device__ void seed_item(const DbView &B, const IndexView &ix,
         // -- scan: thread t owns the elements [t * per, t * per + per)
         const int32_t per = (n + SEED_THREADS - 1) / SEED_THREADS;
         const int32_t x0 = tid * per, x1 = min(n, x0 + per);
-        uint32_t acc = 0;
+        bsum_t acc = 0;
         for (int32_t i = x0; i < x1; i++) {
             const bool head = i == 0 || (hitD(hits[i - 1]) >> bs) != (hitD(hits[i]) >> bs);
-            acc += ((head ? 1u : 0u) << 18) | (uint32_t)hit_cov(hits, i, k);
+            acc += ((bsum_t)(head ? 1u : 0u) << HSH) | (bsum_t)hit_cov(hits, i, k);
             bsum[i] = acc;
         }
-        uint32_t incl = acc;  // inclusive scan of the per-thread totals: inside the wavefront ...
+        bsum_t incl = acc;  // inclusive scan of the per-thread totals: inside the wavefront ...
         for (int off = 1; off < LANES; off <<= 1) {
-            const uint32_t up = __shfl_up(incl, off, LANES);
+            const bsum_t up = __shfl_up(incl, off, LANES);
             if ((tid & (LANES - 1)) >= off) incl += up;
         }
         if ((tid & (LANES - 1)) == LANES - 1) s_wsum[tid / LANES] = incl;
         __syncthreads();
-        uint32_t base = incl - acc;  // ... plus the wavefronts before this one
+        bsum_t base = incl - acc;  // ... plus the wavefronts before this one
         for (int wv = 0; wv < tid / LANES; wv++) base += s_wsum[wv];
         for (int32_t i = x0; i < x1; i++) {
-            const uint32_t v = bsum[i] + base;
+            const bsum_t v = bsum[i] + base;
             bsum[i] = v;
             const bool head = i == 0 || (hitD(hits[i - 1]) >> bs) != (hitD(hits[i]) >> bs);
-            if (head) bhead[(v >> 18) - 1] = (uint16_t)i;
+            if (head) bhead[(v >> HSH) - 1] = (bhead_t)i;
         }
         __syncthreads();
         SP(2)
-        const int32_t nheads = (int32_t)(bsum[n - 1] >> 18);
+        const int32_t nheads = (int32_t)(bsum[n - 1] >> HSH);
         auto band_cov = [&](int32_t rnk) {  // coverage of the band with head number rnk
             const int32_t st_ = bhead[rnk], en_ = rnk + 1 < nheads ? bhead[rnk + 1] : n;
-            return (int32_t)((bsum[en_ - 1] & 0x3FFFFu) - (st_ ? (bsum[st_ - 1] & 0x3FFFFu) : 0u));
+            return (int32_t)((bsum[en_ - 1] & CMASK) - (st_ ? (bsum[st_ - 1] & CMASK) : (bsum_t)0));
         };
         for (int32_t rnk = tid; rnk < nheads; rnk += SEED_THREADS) {
             const int32_t i = bhead[rnk];
