@@ -242,7 +242,10 @@ k_kmer_pass(DbView A, const int2 *__restrict__ tiles, int32_t ntiles, int32_t k,
 // k = 14 with 2^27 buckets), which is VALU work of about a millisecond.
 #define GI_SLICE 32768
 #define GI_THREADS 1024
-template <bool FILL>
+// KT = the rolling k-mers' word: uint32_t when k <= 16 (the pile-up stage's k = 14: half the instructions of the
+// 64-bit roll), uint64_t otherwise.  The bucket of a k-mer relative to the slice needs no group bits: the group's
+// first bucket is ((g << 2k) >> shift) exactly (shift <= 2k), so rel = (canon >> shift) - sl * slice.
+template <bool FILL, typename KT>
 __global__ void __launch_bounds__(GI_THREADS)
 k_group_index(DbView A, const int2 *__restrict__ tiles, const int32_t *__restrict__ gtile, int32_t slices_per_group,
               int32_t slice, int32_t k, int32_t kmer_mod, int32_t shift, uint32_t *__restrict__ dir,
@@ -251,65 +254,82 @@ k_group_index(DbView A, const int2 *__restrict__ tiles, const int32_t *__restric
     __shared__ uint32_t cnt[GI_SLICE];
     const int32_t g = blockIdx.x / slices_per_group, sl = blockIdx.x % slices_per_group;
     const int tid = threadIdx.x;
-    const uint32_t b0 = (uint32_t)((((uint64_t)g) << (2 * k)) >> shift) + (uint32_t)sl * (uint32_t)slice;
+    const uint32_t sl0 = (uint32_t)sl * (uint32_t)slice;
+    const uint32_t b0 = (uint32_t)((((uint64_t)g) << (2 * k)) >> shift) + sl0;
     for (int32_t i = tid; i < slice; i += GI_THREADS) cnt[i] = FILL ? dir[b0 + i] : 0u;
     __syncthreads();
     const uint64_t grp = (uint64_t)g;
-    const uint64_t mask = (1ull << (2 * k)) - 1;
+    const KT mask = (KT)(((uint64_t)1 << (2 * k)) - 1);  // 2k == 32 with a 32-bit word: all ones
     const KmerSampler smp = kmer_sampler(kmer_mod, k);
     const int rcsh = 2 * (k - 1);
-    for (int32_t t = gtile[g] + (tid >> 8); t < gtile[g + 1]; t += GI_THREADS / 256) {
+    // a wavefront per tile (16 tiles of the group in flight), a lane per 64 positions: 64 + k - 1 roll steps yield 64
+    // k-mers (a thread per 16 positions spent 16 + k - 1 on 16), and the chain tile -> offsets -> bases is walked a
+    // quarter as often.  Bases stream through one 8-byte word per 8 steps, the next word in flight.
+    constexpr int32_t PER = KM_TILE / LANES;
+    const int32_t nroll = PER + k - 1;
+    const uint64_t kones = (1ull << k) - 1ull;
+    for (int32_t t = gtile[g] + (tid / LANES); t < gtile[g + 1]; t += GI_THREADS / LANES) {
         const int32_t s = tiles[t].x;
         const int64_t o = A.off[s];
         const int32_t len = (int32_t)(A.off[s + 1] - o);
-        const int32_t p0 = tiles[t].y + (tid & 255) * (KM_TILE / 256);
+        const int32_t p0 = tiles[t].y + (tid & (LANES - 1)) * PER;
+        if (p0 >= len) continue;
         const uint8_t *a = A.bases + o;
-        uint64_t km = 0, rc = 0;
+        KT km = 0, rc = 0;
         int32_t valid = 0;
-        // the thread's 16 + k - 1 <= 43 bases as six 8-byte words, all in flight at once (a byte load per base made the
-        // roll a chain of dependent memory round trips: 8 slices x that was slower than the atomics it replaces)
-        constexpr int NW = (KM_TILE / 256 + 27 + 7) / 8;
-        uint64_t wq[NW];
-        const int32_t nroll = KM_TILE / 256 + k - 1;
+        // soft-mask bits of the lane's k-mers (starts p0 .. p0 + 63, up to 64 + k - 1 <= 91 bits) in two words
+        uint64_t mw0 = 0, mw1 = 0;
+        if (A.mask_bits) {
+            const int64_t gb = o + p0;
+            mw0 = load8(A.mask_bits + (gb >> 3)) >> (gb & 7);
+            const uint64_t hi = load8(A.mask_bits + (gb >> 3) + 8);
+            if (gb & 7) mw0 |= hi << (64 - (gb & 7));
+            mw1 = hi >> (gb & 7);  // bits 64 .. 64 + 56 of the window: k - 1 <= 27 are needed
+        }
+        uint64_t cur = load8(a + p0);
+        for (int32_t wi = 0; wi * 8 < nroll; wi++) {
+            const int32_t pn = p0 + 8 * (wi + 1);
+            const uint64_t nxt = (8 * (wi + 1) < nroll && pn < len) ? load8(a + pn) : 0ull;
 #pragma unroll
-        for (int q = 0; q < NW; q++) wq[q] = (8 * q < nroll && p0 + 8 * q < len) ? load8(a + p0 + 8 * q) : 0ull;
-        // the soft-mask bits of the thread's k-mers (starts p0 .. p0 + 15, 15 + k <= 43 bits) in one load as well: a
-        // mask_touch per k-mer put a dependent global load into nearly every step of the roll
-        const uint64_t mw = (A.mask_bits && p0 < len) ? load8(A.mask_bits + ((o + p0) >> 3)) >> ((o + p0) & 7) : 0ull;
-        const uint64_t kones = (1ull << k) - 1ull;
-#pragma unroll
-        for (int32_t x = 0; x < NW * 8; x++) {
-            const int32_t p = p0 + x;
-            if (x >= nroll || p >= len) break;
-            const uint8_t c = (uint8_t)(wq[x >> 3] >> (8 * (x & 7)));
-            if (c < 4) {
-                km = ((km << 2) | c) & mask;
-                rc = (rc >> 2) | ((uint64_t)(3 - c) << rcsh);
-                valid++;
-            } else {
-                km = 0;
-                rc = 0;
-                valid = 0;
+            for (int u = 0; u < 8; u++) {
+                const int32_t x = wi * 8 + u, p = p0 + x;
+                if (x >= nroll || p >= len) continue;
+                const uint32_t c = (uint32_t)(cur >> (8 * u)) & 0xFFu;
+                if (c < 4u) {
+                    km = ((km << 2) | (KT)c) & mask;
+                    rc = (rc >> 2) | ((KT)(3u - c) << rcsh);
+                    valid++;
+                } else {
+                    km = 0;
+                    rc = 0;
+                    valid = 0;
+                }
+                const KT canon = km < rc ? km : rc;
+                if (x < k - 1 || valid < k) continue;
+                const uint32_t rel = (uint32_t)(canon >> shift) - sl0;
+                if (rel >= (uint32_t)slice) continue;  // another slice's bucket
+                const int32_t d = x - (k - 1);         // offset of the k-mer's first base in the lane's window
+                const uint64_t mb = d == 0 ? mw0 : ((mw0 >> d) | (mw1 << (64 - d)));
+                if (!kmer_sampled((uint64_t)canon, smp) || (mb & kones) != 0ull) continue;
+                const uint32_t slot = atomicAdd(&cnt[rel], 1u);
+                if (FILL)
+                    ent[slot] = make_ulonglong2(((grp << (2 * k)) | (uint64_t)canon) | (km != canon ? 1ull << 63 : 0ull),
+                                                ((uint64_t)s << 40) | (uint64_t)(goff[s] + (p - k + 1)));
             }
-            const uint64_t canon = km < rc ? km : rc;
-            if (x < k - 1 || valid < k) continue;
-            const uint64_t key = (grp << (2 * k)) | canon;
-            const uint32_t rel = (uint32_t)(key >> shift) - b0;
-            if (rel >= (uint32_t)slice) continue;  // another slice's bucket
-            if (!kmer_sampled(canon, smp) || ((mw >> (x - (k - 1))) & kones) != 0ull) continue;
-            const uint32_t slot = atomicAdd(&cnt[rel], 1u);
-            if (FILL)
-                ent[slot] = make_ulonglong2(key | (km != canon ? 1ull << 63 : 0ull),
-                                            ((uint64_t)s << 40) | (uint64_t)(goff[s] + (p - k + 1)));
+            cur = nxt;
         }
     }
     __syncthreads();
     for (int32_t i = tid; i < slice; i += GI_THREADS) dir[b0 + i] = cnt[i];
 }
-template __global__ void k_group_index<false>(DbView, const int2 *, const int32_t *, int32_t, int32_t, int32_t, int32_t,
-                                              int32_t, uint32_t *, ulonglong2 *, const int64_t *);
-template __global__ void k_group_index<true>(DbView, const int2 *, const int32_t *, int32_t, int32_t, int32_t, int32_t,
-                                             int32_t, uint32_t *, ulonglong2 *, const int64_t *);
+#define GI_INST(F, T)                                                                                               \
+    template __global__ void k_group_index<F, T>(DbView, const int2 *, const int32_t *, int32_t, int32_t, int32_t, int32_t, \
+                                                 int32_t, uint32_t *, ulonglong2 *, const int64_t *);
+GI_INST(false, uint32_t)
+GI_INST(true, uint32_t)
+GI_INST(false, uint64_t)
+GI_INST(true, uint64_t)
+#undef GI_INST
 
 // fat directory (dh_device.h): thread per bucket
 __global__ void __launch_bounds__(256)
@@ -2557,12 +2577,21 @@ void dhk_group_index(hipStream_t st, int fill, DbView A, const int2 *tiles, cons
 {
     if (ngroups <= 0) return;
     const dim3 grid((uint32_t)ngroups * (uint32_t)slices_per_group);
-    if (fill)
-        hipLaunchKernelGGL(k_group_index<true>, grid, dim3(GI_THREADS), 0, st, A, tiles, gtile, slices_per_group, slice, k,
-                           kmer_mod, shift, dir, ent, goff);
-    else
-        hipLaunchKernelGGL(k_group_index<false>, grid, dim3(GI_THREADS), 0, st, A, tiles, gtile, slices_per_group, slice, k,
-                           kmer_mod, shift, dir, ent, goff);
+#define GI_LAUNCH(F, T)                                                                                              \
+    hipLaunchKernelGGL((k_group_index<F, T>), grid, dim3(GI_THREADS), 0, st, A, tiles, gtile, slices_per_group, slice, k, \
+                       kmer_mod, shift, dir, ent, goff)
+    if (k <= 16 && shift < 32) {  // (a 32-bit word shifted by 32 would be undefined)
+        if (fill)
+            GI_LAUNCH(true, uint32_t);
+        else
+            GI_LAUNCH(false, uint32_t);
+    } else {
+        if (fill)
+            GI_LAUNCH(true, uint64_t);
+        else
+            GI_LAUNCH(false, uint64_t);
+    }
+#undef GI_LAUNCH
 }
 
 // per-chunk summary of the seed filter's per-item results, so that the host fetches the per-item arrays only when it
