@@ -13,7 +13,8 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 rebuild = len(sys.argv) > 2 and sys.argv[2] == "rebuild"   # the index is dropped and rebuilt in every pass (as bench.py does)
 s = sim.RankShare(3_000_000_000, 10_000, 10_000_000, 20_000, rank=0, world=8, seed=20260929)
 ctx = dentist_amd.Context(0)
-mo = dentist_amd.default_align_opts(kmer_mod=4, k=20, width=64, xdrop=60, algo=1)
+KMER_MOD = int(os.environ.get("KMER_MOD", "4"))   # the stress configuration samples 1/4; 8 = bench.py's configs[2] default
+mo = dentist_amd.default_align_opts(kmer_mod=KMER_MOD, k=20, width=64, xdrop=60, algo=1)
 po = dentist_amd.default_process_opts(algo=1)
 A, B, P = ctx.db(s.contigs), ctx.db(s.reads), ctx.db(s.pile_reads)
 rows = []
@@ -37,8 +38,16 @@ mine = rec[np.isin(rec["contig_left"], s.owned_gaps)]
 read_bp = int(s.reads.off[-1])
 steady = rows[1:]
 mean = lambda k: float(np.mean([r[k] for r in steady]))  # noqa: E731
-seed_bytes = read_bp * (1.0 + 64.0 / 4)
+seed_bytes = read_bp * (1.0 + 64.0 / KMER_MOD)
+placed = None
+if hasattr(s, "read_truth"):   # fraction of the records inside their read's true interval (+- 80 bp), right strand
+    las, _, _, _ = ctx.map_reads(A, B, mo, po, sorted=False, candidates=True)
+    t, e = s.read_truth[las["bread"], 0], s.read_truth[las["bread"], 1]
+    cs = s.contig_start[las["aread"]]
+    ok = ((las["flags"] & 1) == s.read_truth[las["bread"], 2]) & (cs + las["abpos"] >= t - 80) & (cs + las["aepos"] <= e + 80)
+    placed = [float(ok.mean()), int(len(las)), int(len(set(las["bread"].tolist())))]
 print(json.dumps({"workload": "cfg4_3Gb_10000gaps_10Mx20kb_ONT, rank 0 of 8 on one GPU", "read_bp_mapped": read_bp,
+                  "mapping_kmer_mod": KMER_MOD, "placed_frac_records_reads": placed,
                   "first_pass": rows[0], "steady": {k: mean(k) for k in steady[0]},
                   "read_bp_mapped_per_sec": read_bp / (mean("map_ms") * 1e-3),
                   "owned_gaps": int(len(s.owned_gaps)), "closed": int((mine["status"] == 0).sum()),
