@@ -23,8 +23,18 @@ tools/dazz_tools: tools/dazz_main.cpp include/dentist_hip.h $(LIB)
 $(addprefix tools/,$(DAZZ_TOOLS)): tools/dazz_tools
 	cp $< $@
 
-$(LIB): $(CSRC)/dh_kernels.hip $(CSRC)/dh_api.cpp $(CSRC)/dh_device.h include/dentist_hip.h $(wildcard $(CSRC)/*.hip $(CSRC)/*.cpp $(CSRC)/*.h)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(wildcard $(CSRC)/*.hip) $(wildcard $(CSRC)/*.cpp)
+# one object per translation unit (build/ is git-ignored): `make -j8` rebuilds only what changed
+OBJDIR := build/obj
+SRCS := $(wildcard $(CSRC)/*.hip) $(wildcard $(CSRC)/*.cpp)
+OBJS := $(patsubst $(CSRC)/%,$(OBJDIR)/%.o,$(SRCS))
+HDRS := $(wildcard $(CSRC)/*.h) include/dentist_hip.h
+
+$(OBJDIR)/%.o: $(CSRC)/% $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+$(LIB): $(OBJS)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(OBJS)
 
 $(SIM): dentist_amd/sim/sim.cpp
 	g++ -O2 -fPIC -shared -fopenmp -o $@ $<

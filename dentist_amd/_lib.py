@@ -1057,18 +1057,19 @@ def output_assembly(fasta_path, contigs, scaffold_of, headers, gap_len, rec, bas
     ids = off = None
     if read_ids is not None:
         ids = np.ascontiguousarray(read_ids[0], dtype=np.int32)
-        off = np.ascontiguousarray(read_ids[1], dtype=np.int64)
+        off = np.ascontiguousarray(read_ids[1], dtype=np.int32)
     rn = (ctypes.c_char_p * len(read_names))(*[x.encode() for x in read_names]) if read_names is not None else None
     dropped = ctypes.c_int32(0)
     vp = ctypes.c_void_p
     L.dh_output_assembly.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, vp, vp, ctypes.c_int32, vp, vp, vp, vp,
-                                     ctypes.c_int32, vp, vp, vp, vp, ctypes.POINTER(OutputOpts), ctypes.POINTER(ctypes.c_int32)]
+                                     ctypes.c_int32, vp, vp, vp, ctypes.c_int32, vp, ctypes.POINTER(OutputOpts), ctypes.POINTER(ctypes.c_int32)]
     _check(L.dh_output_assembly(fasta_path.encode(), bed_path.encode() if bed_path else None,
                                 agp_path.encode() if agp_path else None, cb.ctypes.data, co.ctypes.data, len(co) - 1,
                                 so.ctypes.data, ctypes.cast(hs, vp), gl.ctypes.data if gl is not None else None,
                                 r.ctypes.data, len(r), b.ctypes.data if len(b) else None,
                                 ids.ctypes.data if ids is not None and len(ids) else (ids.ctypes.data if ids is not None else None),
-                                off.ctypes.data if off is not None else None, ctypes.cast(rn, vp) if rn is not None else None,
+                                off.ctypes.data if off is not None else None, len(read_names) if read_names is not None else -1,
+                                ctypes.cast(rn, vp) if rn is not None else None,
                                 ctypes.byref(o), ctypes.byref(dropped)))
     return int(dropped.value)
 

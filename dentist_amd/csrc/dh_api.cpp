@@ -841,14 +841,21 @@ static bool la_less(const dh_la &p, const dh_la &q)
 #define CHAIN_GAP 10000
 #define CHAIN_INDEL 6000
 #define CHAIN_OVERLAP 100
-static int32_t g_near_best_ppm = 0;
-extern "C" void dh_set_near_best(int32_t ppm) { g_near_best_ppm = ppm < 0 ? 0 : ppm; }
+// process-wide default (dh_set_near_best) and the per-context override (dh_ctx_set_near_best, -1 = use the default):
+// a library user who never asked for -n is not affected by another context's setting
+static std::atomic<int32_t> g_near_best_ppm{0};
+extern "C" void dh_set_near_best(int32_t ppm) { g_near_best_ppm.store(ppm < 0 ? 0 : ppm); }
+extern "C" int dh_ctx_set_near_best(dh_ctx *ctx, int32_t ppm)
+{
+    if (!ctx) return fail(DH_EINVAL, "dh_ctx_set_near_best: NULL context");
+    ctx->near_best_ppm = ppm < 0 ? -1 : ppm;
+    return DH_OK;
+}
 
-static void select_best_range(dh_la *la, size_t nla)
+static void select_best_range(dh_la *la, size_t nla, int32_t near_ppm)
 {
     // groups of equal bread are independent: host threads take runs of groups
     const std::vector<int64_t> gstart = dh_run_starts((int64_t)nla, [la](int64_t i) { return la[i].bread; });
-    const int32_t near_ppm = g_near_best_ppm;
     dh_parallel_for((int64_t)gstart.size() - 1, 2048, [&](int64_t glo, int64_t ghi) {
         struct Chain {
             int64_t score;
@@ -1128,6 +1135,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     if (!ctx || !A || !B || !opts || !out) return fail(DH_EINVAL, "dh_align_db: NULL argument");
     if (A->ctx != ctx || B->ctx != ctx) return fail(DH_EINVAL, "dh_align_db: DB of another context");
     const dh_align_opts &o = *opts;
+    const int32_t near_ppm = ctx->near_best_ppm >= 0 ? ctx->near_best_ppm : g_near_best_ppm.load();
     if (o.k < 8 || o.k > 28) return fail(DH_EINVAL, "k must be in [8, 28]");
     if (o.algo != 0 && o.algo != 1) return fail(DH_EINVAL, "algo must be 0 (DH-1, wave) or 1 (DH-2, tiled band)");
     const bool tiled = o.algo == 1;
@@ -1654,12 +1662,12 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             const int dev = ctx->device;
             const int64_t l0h = (int64_t)(res->la.size() - totals[0]), chunk_no = nchunk_done - 1;
             const bool best = want_best != 0;
-            tasks.v.emplace_back([h, p, cnt, copied, dev, l0h, chunk_no, best] {
+            tasks.v.emplace_back([h, p, cnt, copied, dev, l0h, chunk_no, best, near_ppm] {
                 (void)hipSetDevice(dev);
                 const auto t0 = std::chrono::steady_clock::now();
                 (void)hipEventSynchronize(copied);  // the records of this chunk have arrived
                 const auto t1 = std::chrono::steady_clock::now();
-                if (best) select_best_range(p, (size_t)cnt);  // chain flags: a per-read decision too
+                if (best) select_best_range(p, (size_t)cnt, near_ppm);  // chain flags: a per-read decision too
                 const auto t2 = std::chrono::steady_clock::now();
                 h(p, cnt, l0h, chunk_no);
                 if (getenv("DH_TRACE"))
@@ -1687,7 +1695,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
 
     tasks.join();
     const double tail_hooks = tasks.ms_hooks, tail_copies = tasks.ms_copies;
-    if (want_best && !hook) select_best_range(res->la.data(), res->la.size());
+    if (want_best && !hook) select_best_range(res->la.data(), res->la.size(), near_ppm);
     if (want_sorted) lasort(res, A->n);
     if (res2) {
         // chain flags of the transposed set: the same rule with the roles of the sequences exchanged (chains of a read
@@ -1701,7 +1709,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         };
         if (want_best) {
             swap_roles();  // grouped by read already (items are (read, strand) in order)
-            select_best_range(res2->la.data(), res2->la.size());
+            select_best_range(res2->la.data(), res2->la.size(), near_ppm);
             swap_roles();
         }
         std::sort(res2->la.begin(), res2->la.end(), la_less);

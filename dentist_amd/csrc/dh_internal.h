@@ -59,6 +59,7 @@ struct dh_ctx {
     hipEvent_t cev[4] = {};
     dh_align_stats stats = {};
     dh_cum_stats cum = {};
+    int32_t near_best_ppm = -1;  // damapper -n of this context (dh_ctx_set_near_best); -1 = the process default
     // second context of the same device (own streams and scratch), created on first use: the process stage runs the
     // two halves of a batch of pile-ups concurrently, one on each (dh_process_pileups)
     dh_ctx *sub[3] = {nullptr, nullptr, nullptr};  // contexts of the concurrent parts of dh_process_pileups

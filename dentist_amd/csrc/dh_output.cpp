@@ -53,14 +53,15 @@ const char UPPER[5] = {'A', 'C', 'G', 'T', 'N'};
 //     object coordinates 1-based inclusive, components as the reference writes them (contig begin in its
 //     input scaffold + crop begin, ... + crop end; the orientation column follows :534 literally).
 //   * closed-gaps BED (:879-891): every read id of the pile-up (`%(%d-%)`, ids 1-based).
-// read_ids / read_ids_off: the read ids (0-based) of every insertion's pile-up (dh_insertions_read_ids);
-// NULL = the reference read alone.  read_names: FASTA ids of the reads for the AGP (NULL with agp_dazzler).
+// read_ids / read_ids_off[nins + 1] (int32, as dh_insertions_read_ids_off hands them out): the read ids (0-based) of
+// every insertion's pile-up; NULL = the reference read alone.  nreads = entries of read_names (ids are checked against
+// it; -1 = unknown, allowed without a name table).  read_names: FASTA ids of the reads for the AGP (NULL with agp_dazzler).
 extern "C" int dh_output_assembly(const char *fasta_path, const char *bed_path, const char *agp_path,
                                   const uint8_t *contig_bases, const int64_t *contig_off, int32_t ncontigs,
                                   const int32_t *scaffold_of, const char *const *headers, const int32_t *gap_len,
                                   const dh_insertion *ins, int32_t nins, const uint8_t *ins_bases,
-                                  const int32_t *read_ids, const int64_t *read_ids_off, const char *const *read_names,
-                                  const dh_output_opts *opts, int32_t *dropped)
+                                  const int32_t *read_ids, const int32_t *read_ids_off, int32_t nreads,
+                                  const char *const *read_names, const dh_output_opts *opts, int32_t *dropped)
 {
     if (!fasta_path || !contig_bases || !contig_off || !scaffold_of || !headers || !opts ||
         (nins > 0 && (!ins || !ins_bases)) || ncontigs < 0 || (read_ids && !read_ids_off))
@@ -69,6 +70,27 @@ extern "C" int dh_output_assembly(const char *fasta_path, const char *bed_path, 
     if (o.join_policy < 0 || o.join_policy > 2) return dh_fail(DH_EINVAL, "dh_output_assembly: join_policy must be 0, 1 or 2");
     if (agp_path && !o.agp_dazzler && !o.agp_skip_read_ids && !read_names)
         return dh_fail(DH_EINVAL, "dh_output_assembly: the AGP needs read names, agp_dazzler or agp_skip_read_ids");
+    // read ids index read_names[]: offsets monotone, ids inside [0, nreads), names present (nreads < 0: ids unchecked,
+    // legal only when no name table is consulted)
+    const bool names_used = agp_path && !o.agp_dazzler && !o.agp_skip_read_ids;
+    if (names_used && nreads < 0) return dh_fail(DH_EINVAL, "dh_output_assembly: read names need nreads");
+    if (read_ids) {
+        if (read_ids_off[0] < 0) return dh_fail(DH_EINVAL, "dh_output_assembly: negative read id offset");
+        for (int32_t i = 0; i < nins; i++)
+            if (read_ids_off[i + 1] < read_ids_off[i])
+                return dh_fail(DH_EINVAL, "dh_output_assembly: read id offsets are not monotone");
+        if (nreads >= 0)
+            for (int32_t x = read_ids_off[0]; x < read_ids_off[nins]; x++)
+                if (read_ids[x] < 0 || read_ids[x] >= nreads)
+                    return dh_fail(DH_EINVAL, "dh_output_assembly: read id outside [0, nreads)");
+    }
+    if (names_used) {
+        for (int32_t i = 0; i < nins; i++)
+            if (!read_ids && ins[i].status == DH_PILE_OK && (ins[i].ref_read_id < 0 || ins[i].ref_read_id >= nreads))
+                return dh_fail(DH_EINVAL, "dh_output_assembly: reference read id outside [0, nreads)");
+        for (int32_t r = 0; r < nreads; r++)
+            if (!read_names[r]) return dh_fail(DH_EINVAL, "dh_output_assembly: NULL read name");
+    }
     std::vector<int32_t> closing((size_t)std::max(ncontigs, 1), -1);
     int32_t ndropped = 0;
     for (int32_t i = 0; i < nins; i++) {
@@ -172,7 +194,7 @@ extern "C" int dh_output_assembly(const char *fasta_path, const char *bed_path, 
                 // the read ids of the pile-up, 1-based, ascending (makeInsertion, processPileUps/package.d:789-798)
                 std::vector<int32_t> ids;
                 if (read_ids)
-                    for (int64_t x = read_ids_off[ci]; x < read_ids_off[ci + 1]; x++) ids.push_back(read_ids[x] + 1);
+                    for (int32_t x = read_ids_off[ci]; x < read_ids_off[ci + 1]; x++) ids.push_back(read_ids[x] + 1);
                 else
                     ids.push_back(in.ref_read_id + 1);
                 std::sort(ids.begin(), ids.end());
@@ -243,5 +265,5 @@ extern "C" int dh_output_fasta(const char *fasta_path, const char *bed_path, con
             scaffold_of && scaffold_of[ins[i].contig_left] != scaffold_of[ins[i].contig_left + 1])
             return dh_fail(DH_EINVAL, "dh_output_fasta: insertion does not join two contigs of one scaffold");
     return dh_output_assembly(fasta_path, bed_path, nullptr, contig_bases, contig_off, ncontigs, scaffold_of, headers, gap_len,
-                              ins, nins, ins_bases, nullptr, nullptr, nullptr, &o, nullptr);
+                              ins, nins, ins_bases, nullptr, nullptr, -1, nullptr, &o, nullptr);
 }

@@ -161,8 +161,12 @@ int dh_align_db(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, int3
  * gap difference <= 6 kb: a long indel splits a mapping into collinear LAs) form a chain: START (0x4) on its first
  * LA, NEXT (0x8) on the others, BEST (0x10) on the LAs of the chain that no higher-scoring chain of the strand covers
  * by more than half (consumer: dazzler.d:1728-1758).  dh_set_near_best(ppm) is damapper's -n: alternate chains scoring
- * less than that fraction of the chain that beats them are DISABLED; 0 (default) keeps every chain. */
+ * less than that fraction of the chain that beats them are DISABLED; 0 (default) keeps every chain.  dh_set_near_best sets
+ * the process-wide default, dh_ctx_set_near_best the value of one context (-1: back to the process default) -- a library
+ * user who never asked for -n is not affected by what another context set.  (damapper's own default is -n1.00,
+ * commandline.d:2943-2955 always passes -n.7.) */
 void dh_set_near_best(int32_t ppm);
+int dh_ctx_set_near_best(dh_ctx *ctx, int32_t ppm);
 
 /* One read block against the whole reference, the unit the workflow shards the mapping by
  * (`damapper <ref> <reads>.<block>`, snakemake/Snakefile:1143-1170; blocks = DBsplit ranges of one
@@ -527,7 +531,8 @@ int dh_output_fasta(const char *fasta_path, const char *bed_path, const uint8_t 
  * scaffolds are dropped, *dropped counts them), 1 scaffolds, 2 contigs (they join the two scaffolds into one
  * record).  agp_dazzler: component ids are contig numbers / "reads-<ids>"; otherwise scaffold header ids and
  * read_names[id - 1]; agp_skip_read_ids: "<n> reads".  read_ids / read_ids_off[nins + 1]: 0-based read ids of
- * every insertion's pile-up (NULL: the reference read alone). */
+ * every insertion's pile-up, offsets int32 exactly as dh_insertions_read_ids_off returns them (NULL: the reference read
+ * alone); nreads = length of read_names, every id is checked against it (-1: unknown, only without a name table). */
 typedef struct {
     int32_t line_width, highlight, join_policy, agp_dazzler, agp_skip_read_ids, pad;
     const char *agp_version, *tool, *input_assembly;
@@ -537,8 +542,8 @@ int dh_output_assembly(const char *fasta_path, const char *bed_path, const char 
                        const uint8_t *contig_bases, const int64_t *contig_off, int32_t ncontigs,
                        const int32_t *scaffold_of, const char *const *headers, const int32_t *gap_len,
                        const dh_insertion *ins, int32_t nins, const uint8_t *ins_bases, const int32_t *read_ids,
-                       const int64_t *read_ids_off, const char *const *read_names, const dh_output_opts *opts,
-                       int32_t *dropped);
+                       const int32_t *read_ids_off, int32_t nreads, const char *const *read_names,
+                       const dh_output_opts *opts, int32_t *dropped);
 
 /* ---- DAZZ_DB files on disk (.db / .dam stub + hidden .idx / .bps / .hdr), host only.
  *      Replaces what DENTIST obtains by spawning fasta2DB / fasta2DAM / DBsplit

@@ -128,7 +128,7 @@ int main(int argc, char **argv)
     dh_align_opts o;
     dh_default_align_opts(&o);
     bool flagA = false, flagI = false, flagC = false, verbose = false;
-    double e = 0.7, near_best = 0.85;  // damapper -n default
+    double e = 0.7, near_best = 1.0;  // damapper's own -n default is 1.00 (best chains only); DENTIST always passes -n.7
     std::vector<std::string> dbs, tracks;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
@@ -175,11 +175,11 @@ int main(int argc, char **argv)
         o.algo = 1;
         o.width = 64;
         if (near_best < 0 || near_best > 1) die(mode + ": -n must be in [0, 1]");
-        dh_set_near_best((int32_t)llround(near_best * 1e6));
     }
 
     dh_ctx *ctx = nullptr;
     CHK(dh_ctx_create(0, nullptr, &ctx));
+    if (mapper) CHK(dh_ctx_set_near_best(ctx, (int32_t)llround(near_best * 1e6)));
     OpenDb A = open_db(ctx, dbs[0], tracks);
     for (size_t bi = 1; bi < dbs.size(); bi++) {
         const bool same = las_name_part(dbs[bi]) == A.name;
