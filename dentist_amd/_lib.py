@@ -87,7 +87,7 @@ SYMBOLS = [
     "dh_map_reads", "dh_validate_regions", "dh_propagate_mask", "dh_db_mask_coverage", "dh_max_coverage_reads", "dh_max_improper_coverage_reads",
     "dh_default_scaffold_opts", "dh_scaffold_pileups", "dh_scaffold_npiles", "dh_scaffold_nentries", "dh_scaffold_joins",
     "dh_scaffold_entries", "dh_scaffold_destroy", "dh_scaffold_spanning", "dh_scaffold_gap_pileups", "dh_cropped_create2",
-    "dh_cropped_kind", "dh_set_near_best", "dh_shard_free", "dh_shard_pack_candidates", "dh_shard_plan_create", "dh_shard_read_joins", "dh_align_db_transposed", "dh_remap_skipping_reads", "dh_shard_graph_plan_create", "dh_shard_plan_destroy",
+    "dh_cropped_kind", "dh_set_near_best", "dh_ctx_set_near_best", "dh_shard_free", "dh_shard_pack_candidates", "dh_shard_plan_create", "dh_shard_read_joins", "dh_align_db_transposed", "dh_remap_skipping_reads", "dh_shard_graph_plan_create", "dh_shard_plan_destroy",
     "dh_shard_plan_las", "dh_shard_plan_nlas", "dh_shard_plan_pileups", "dh_shard_plan_owner", "dh_shard_pack_cropped",
     "dh_shard_unpack_cropped", "dh_insertions_read_ids", "dh_insertions_read_ids_off", "dh_output_assembly", "dh_default_output_opts",
 ]
