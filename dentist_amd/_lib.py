@@ -9,7 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path():
-    return os.path.join(_HERE, "libdentist_hip.so")
+    # DH_DEV_LIB: development builds of the same library (profiling counters compiled in), never a fallback
+    return os.environ.get("DH_DEV_LIB") or os.path.join(_HERE, "libdentist_hip.so")
 
 
 class DhError(RuntimeError):

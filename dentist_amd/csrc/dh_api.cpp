@@ -12,6 +12,7 @@
 #include <numeric>
 
 #include "dh_internal.h"
+#include "dh_join.h"
 #include "dh_tile.h"
 #include "dh_parallel.h"
 
@@ -30,6 +31,7 @@ int dh_fail(int code, const std::string &msg)
 
 #ifdef DH_SEED_PROF
 extern "C" void dhk_seed_prof_dump();
+extern "C" void dhk_join_prof_dump();
 #endif
 // ------------------------------------------------------------------------------------ allocator
 #include <map>
@@ -671,10 +673,12 @@ static int32_t ceil_log2(uint64_t x)
     return b;
 }
 
-static int build_index(dh_db *A, int32_t k, int32_t sepv, int32_t kmer_mod)
+// light: only the virtual axis (goff, page table) -- what the seed filter's back end needs when the hits come from the
+// per-pile-up k-mer join (dh_join.hip) instead of directory lookups
+static int build_index(dh_db *A, int32_t k, int32_t sepv, int32_t kmer_mod, bool light = false)
 {
     dh_ctx *ctx = A->ctx;
-    if (A->has_ix && A->ix.k == k && A->ix.sepv == sepv && A->ix.kmer_mod == kmer_mod) return DH_OK;
+    if (A->has_ix && A->ix.k == k && A->ix.sepv == sepv && A->ix.kmer_mod == kmer_mod && (light || !A->ix.light)) return DH_OK;
     if (A->has_ix) A->ix.release();
     A->has_ix = false;
     dh_index &ix = A->ix;
@@ -683,6 +687,7 @@ static int build_index(dh_db *A, int32_t k, int32_t sepv, int32_t kmer_mod)
     ix.sepv = sepv;
     ix.kmer_mod = kmer_mod;
     ix.na = A->n;
+    ix.light = light;
     // virtual offsets and tile table
     std::vector<int64_t> goff((size_t)A->n + 1);
     std::vector<int2> tiles;
@@ -691,7 +696,7 @@ static int build_index(dh_db *A, int32_t k, int32_t sepv, int32_t kmer_mod)
         goff[(size_t)s] = g;
         const int64_t len = A->h_off[(size_t)s + 1] - A->h_off[(size_t)s];
         g += (len + sepv + 4095) & ~4095ll;  // 4096-aligned starts: see sepv in align_range
-        if (len >= k) {
+        if (len >= k && !light) {
             nk += len - k + 1;
             for (int64_t st = 0; st < len - k + 1; st += KM_TILE) tiles.push_back(int2{s, (int32_t)st});
         }
@@ -701,6 +706,18 @@ static int build_index(dh_db *A, int32_t k, int32_t sepv, int32_t kmer_mod)
         return fail(DH_EINVAL, "index: virtual coordinate space exceeds 2^39 (every sequence takes its length + the longest "
                                "B read + 64, rounded up to 4096)");
     if (A->n >= (1 << 24)) return fail(DH_EINVAL, "index: more than 2^24 sequences");
+    if (light) {
+        HIPCHK(dh_dev_alloc(&ix.d_goff, sizeof(int64_t) * (size_t)(A->n + 1)));
+        HIPCHK(hipMemcpyAsync(ix.d_goff, goff.data(), sizeof(int64_t) * goff.size(), hipMemcpyHostToDevice, ctx->stream));
+        std::vector<int32_t> page_seq((size_t)(g >> 12) + 1, A->n > 0 ? A->n - 1 : 0);
+        for (int32_t s2 = 0; s2 < A->n; s2++)
+            for (int64_t pg = goff[(size_t)s2] >> 12; pg < (goff[(size_t)s2 + 1] >> 12); pg++) page_seq[(size_t)pg] = s2;
+        HIPCHK(dh_dev_alloc(&ix.d_page_seq, sizeof(int32_t) * page_seq.size()));
+        HIPCHK(hipMemcpyAsync(ix.d_page_seq, page_seq.data(), sizeof(int32_t) * page_seq.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));  // the vectors go out of scope
+        A->has_ix = true;
+        return DH_OK;
+    }
     const int32_t keybits = 2 * k + ceil_log2((uint64_t)A->ngroups);
     if (keybits > 62) return fail(DH_EINVAL, "index: k-mer key does not fit 62 bits");
     int32_t pbits = ceil_log2((uint64_t)std::max<int64_t>(nk, 1));
@@ -1207,7 +1224,59 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     // position of a hit inside its diagonal band (2^band_shift <= 4096 wide) depends only on the
     // pair (A sequence, B read) -- never on which other sequences share the DB or the launch
     const int32_t sepv = (B->max_len + 64 + 4095) & ~4095;
-    if (int rc = build_index(A, o.k, sepv, o.kmer_mod)) return rc;
+    // ---- a grouped DB against itself (the pile-up all-vs-all): the seeds come from the per-pile-up k-mer join
+    // (dh_join.hip) -- no k-mer directory is built, no line of HBM is looked up at random; bit-identical hits.
+    // Plan: slices per group (about JOIN_FILL entries each), part blocks (JP_THREADS chunks of one group each), the
+    // rows of the two tables.  DH_NO_JOIN=1 forces the directory path (tests compare the two).
+    struct JoinPlan {
+        std::vector<int32_t> gfirst, gns, pfirst;
+        std::vector<int2> pblk, jblk;
+        std::vector<int64_t> psubrow, segrow;
+        int64_t npsub = 0, nseg = 0;
+    } jp;
+    bool use_join = A == B && A->d_group && A->ngroups >= 1 && o.k <= 16 && B->max_len < JOIN_MAX_LEN && first == 0 &&
+                    count == B->n && B->n > 0 && !getenv("DH_NO_JOIN");
+    if (use_join) {
+        const int32_t ng = A->ngroups;
+        jp.gfirst.assign((size_t)ng + 1, 0);
+        for (int32_t s2 = 0; s2 < A->n && use_join; s2++) {
+            if (s2 > 0 && A->h_group[(size_t)s2] < A->h_group[(size_t)s2 - 1]) use_join = false;  // groups must be contiguous
+            jp.gfirst[(size_t)A->h_group[(size_t)s2] + 1]++;
+        }
+        for (int32_t g2 = 0; g2 < ng; g2++) jp.gfirst[(size_t)g2 + 1] += jp.gfirst[(size_t)g2];
+        jp.gns.assign((size_t)ng, 1);
+        jp.pfirst.assign((size_t)ng + 1, 0);
+        jp.segrow.assign((size_t)A->n, 0);
+        for (int32_t g2 = 0; g2 < ng && use_join; g2++) {
+            const int32_t r0 = jp.gfirst[(size_t)g2], r1 = jp.gfirst[(size_t)g2 + 1];
+            if (r1 - r0 > JOIN_MAX_READS) use_join = false;
+            int64_t nkm = 0, nch = 0;
+            for (int32_t r = r0; r < r1; r++) {
+                const int64_t np_ = A->h_off[(size_t)r + 1] - A->h_off[(size_t)r] - o.k + 1;
+                if (np_ > 0) {
+                    nkm += np_;
+                    nch += (np_ + JP_PER - 1) / JP_PER;
+                }
+            }
+            const int64_t ns = std::max<int64_t>(1, (nkm / std::max(1, o.kmer_mod) + JOIN_FILL - 1) / JOIN_FILL);
+            if (ns > JOIN_MAX_SLICES) use_join = false;
+            jp.gns[(size_t)g2] = (int32_t)ns;
+            for (int64_t c0 = 0; c0 < nch; c0 += JP_THREADS) {
+                jp.pblk.push_back(int2{g2, (int32_t)c0});
+                jp.psubrow.push_back(jp.npsub);
+                jp.npsub += ns;
+            }
+            jp.pfirst[(size_t)g2 + 1] = (int32_t)jp.pblk.size();
+            if (nch > 0)
+                for (int32_t s2 = 0; s2 < (int32_t)ns; s2++) jp.jblk.push_back(int2{g2, s2});
+            for (int32_t r = r0; r < r1; r++) {
+                jp.segrow[(size_t)r] = jp.nseg;
+                jp.nseg += ns;
+            }
+        }
+        if (jp.pblk.size() > (size_t)INT32_MAX / 2 || jp.jblk.size() > (size_t)INT32_MAX / 2) use_join = false;
+    }
+    if (int rc = build_index(A, o.k, sepv, o.kmer_mod, use_join)) return rc;
     // B's derived copies (reverse complement, 2-bit packed) live with the DB when the whole DB is
     // one chunk of this call (pile-up and template DBs are re-aligned several times); a block of a
     // larger DB gets them chunk by chunk in the scratch arena, so the resident footprint of a reads
@@ -1249,8 +1318,11 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
 
     DhOpts dopt;
     memcpy(&dopt, &o, sizeof(dopt));
-    IndexView iv{A->ix.d_fat, A->ix.d_ent, A->ix.d_goff, A->ix.d_page_seq, A->ix.n,
-                 A->ix.na,    A->ix.sepv,   A->ix.shift,  A->ix.pbits};
+    auto index_view = [&]() {
+        return IndexView{A->ix.d_fat, A->ix.d_ent, A->ix.d_goff, A->ix.d_page_seq, A->ix.n,
+                         A->ix.na,    A->ix.sepv,   A->ix.shift,  A->ix.pbits};
+    };
+    IndexView iv = index_view();
     const DbView av = A->view(), bv = B->view();
 
     // capacity planning
@@ -1338,6 +1410,100 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     HIPCHK(hipMemsetAsync(d_status, 0, sizeof(int32_t), st));
     HIPCHK(hipMemsetAsync(d_counters, 0, 2 * sizeof(unsigned long long), st));
 
+    JoinView jv = {};
+    int64_t join_hits = 0;
+    float ms_join = 0;
+    unsigned int jhist[4] = {0, 0, 0, 0};  // reads with more than 2048 / 4096 / 8192 hits, the largest count
+    if (use_join) {
+        // one upload of the plan tables; device buffers from the scratch arena
+        const size_t ng = (size_t)A->ngroups;
+        size_t blob_bytes = 0;
+        auto place = [&](size_t bytes) {
+            const size_t at = blob_bytes;
+            blob_bytes += (bytes + 15) & ~(size_t)15;
+            return at;
+        };
+        const size_t o_gfirst = place(sizeof(int32_t) * (ng + 1)), o_gns = place(sizeof(int32_t) * ng),
+                     o_pfirst = place(sizeof(int32_t) * (ng + 1)), o_pblk = place(sizeof(int2) * jp.pblk.size()),
+                     o_psubrow = place(sizeof(int64_t) * jp.psubrow.size()), o_jblk = place(sizeof(int2) * jp.jblk.size()),
+                     o_segrow = place(sizeof(int64_t) * jp.segrow.size());
+        std::vector<uint8_t, PinnedAlloc<uint8_t>> blob(blob_bytes);
+        memcpy(blob.data() + o_gfirst, jp.gfirst.data(), sizeof(int32_t) * (ng + 1));
+        memcpy(blob.data() + o_gns, jp.gns.data(), sizeof(int32_t) * ng);
+        memcpy(blob.data() + o_pfirst, jp.pfirst.data(), sizeof(int32_t) * (ng + 1));
+        if (!jp.pblk.empty()) memcpy(blob.data() + o_pblk, jp.pblk.data(), sizeof(int2) * jp.pblk.size());
+        if (!jp.psubrow.empty()) memcpy(blob.data() + o_psubrow, jp.psubrow.data(), sizeof(int64_t) * jp.psubrow.size());
+        if (!jp.jblk.empty()) memcpy(blob.data() + o_jblk, jp.jblk.data(), sizeof(int2) * jp.jblk.size());
+        memcpy(blob.data() + o_segrow, jp.segrow.data(), sizeof(int64_t) * jp.segrow.size());
+        uint8_t *d_blob;
+        uint32_t *d_psub;
+        uint64_t *d_entries, *d_segtab, *d_hits;
+        unsigned long long *d_cursor;
+        SCR(45, d_blob, blob_bytes)
+        SCR(46, d_psub, (size_t)jp.npsub)
+        SCR(47, d_entries, jp.pblk.size() * (size_t)JP_POS)
+        SCR(48, d_segtab, (size_t)jp.nseg)
+        SCR(49, d_cursor, 4)  // [0] the hit cursor; [1..2] = four 32-bit counters of k_join_hist
+        HIPCHK(hipMemcpyAsync(d_blob, blob.data(), blob_bytes, hipMemcpyHostToDevice, st));
+        jv.gfirst = (const int32_t *)(d_blob + o_gfirst);
+        jv.gns = (const int32_t *)(d_blob + o_gns);
+        jv.pfirst = (const int32_t *)(d_blob + o_pfirst);
+        jv.pblk = (const int2 *)(d_blob + o_pblk);
+        jv.psubrow = (const int64_t *)(d_blob + o_psubrow);
+        jv.jblk = (const int2 *)(d_blob + o_jblk);
+        jv.segrow = (const int64_t *)(d_blob + o_segrow);
+        jv.psub = d_psub;
+        jv.entries = d_entries;
+        jv.segtab = d_segtab;
+        jv.cursor = d_cursor;
+        jv.status = d_status;
+        jv.npart = (int32_t)jp.pblk.size();
+        jv.njoin = (int32_t)jp.jblk.size();
+        // reads of groups without k-mers have no join block: their rows read as "no hits"
+        HIPCHK(hipMemsetAsync(d_segtab, 0, sizeof(uint64_t) * (size_t)std::max<int64_t>(jp.nseg, 1), st));
+        HIPCHK(hipEventRecord(ctx->ev[6], st));
+        dhk_join_part(st, jv, bv, o.k, o.kmer_mod);
+        HIPCHK(hipGetLastError());
+        // hit buffer: measured 0.77 hits per base for pile-ups of 60 reads at 13 % error; a rerun sizes it exactly
+        int64_t hcap = std::max<int64_t>(1 << 20, (int64_t)(1.25 * (double)A->total));
+        if (const char *e = getenv("DH_JOIN_HITCAP")) hcap = std::max<int64_t>(1, atoll(e));  // development / tests
+        for (int attempt = 0;; attempt++) {
+            SCR(50, d_hits, (size_t)hcap)
+            jv.hits = d_hits;
+            jv.hits_cap = hcap;
+            HIPCHK(hipMemsetAsync(d_cursor, 0, sizeof(unsigned long long), st));
+            dhk_join(st, jv, bv, dopt, A->ix.d_goff, sepv);
+            HIPCHK(hipGetLastError());
+            unsigned long long cur = 0;
+            int32_t jstatus = 0;
+            HIPCHK(hipMemcpyAsync(&cur, d_cursor, sizeof(cur), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(&jstatus, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            join_hits = (int64_t)cur;
+            if (jstatus & DH_ST_JOIN_OVERFLOW) {  // a slice did not fit its LDS table: directory path for this call
+                use_join = false;
+                break;
+            }
+            if (!(jstatus & DH_ST_JOIN_HITCAP)) break;
+            if (attempt >= 2) return fail(DH_EOVERFLOW, "k-mer join: hit buffer capacity exceeded twice");
+            hcap = (int64_t)cur + 1024;
+            HIPCHK(hipMemsetAsync(d_status, 0, sizeof(int32_t), st));
+        }
+        if (use_join) {
+            dhk_join_hist(st, jv, B->d_group, B->n, (unsigned int *)(d_cursor + 1));
+            HIPCHK(hipMemcpyAsync(jhist, d_cursor + 1, sizeof(unsigned int) * 4, hipMemcpyDeviceToHost, st));
+        }
+        HIPCHK(hipEventRecord(ctx->ev[7], st));
+        HIPCHK(hipEventSynchronize(ctx->ev[7]));
+        HIPCHK(hipEventElapsedTime(&ms_join, ctx->ev[6], ctx->ev[7]));
+        if (!use_join) {
+            if (getenv("DH_TRACE")) fprintf(stderr, "[join] a slice overflowed its table: falling back to the k-mer directory\n");
+            HIPCHK(hipMemsetAsync(d_status, 0, sizeof(int32_t), st));
+            if (int rc = build_index(A, o.k, sepv, o.kmer_mod, false)) return rc;
+            iv = index_view();
+        }
+    }
+
     // expected hits per read (both strands share the LDS buffer): random matches + true seeds (measured
     // 0.075 per sampled k-mer for 15 % error reads at k = 20; reads that need more are redone with their
     // hits in HBM, and a chunk with many of them restarts with the next capacity); pick the LDS hit capacity
@@ -1352,6 +1518,12 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         // HBM beats the 8192-entry one by 40 %
         cap = 1024;
         while (cap < 8192 && 0.6 * B->max_len > cap) cap *= 2;
+    }
+    if (use_join) {
+        // the hits are counted already: the smallest LDS capacity that leaves at most 1 % of the reads to the HBM-staged
+        // variant (a whole second pass with the next size cost 9.5 ms at configs[2] when the guess was one size short)
+        const unsigned int tol = (unsigned int)(B->n / 100);
+        cap = jhist[0] <= tol ? 2048 : (jhist[1] <= tol ? 4096 : 8192);
     }
     if (const char *e = getenv("DH_SEED_CAP")) cap = atoi(e);  // development: 1024 .. 16384, power of two
 
@@ -1404,8 +1576,12 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         uint64_t *d_fscr = nullptr;
         if (cap > 4096 && cap <= 8192)
             SCR(30, d_fscr, (size_t)ctx->ncu * DH_SEED_FSCR_BLOCKS_PER_CU * DH_SEED_FSCR_WORDS)
-        dhk_seed(st, cap, bv, iv, dopt, (int32_t)item0, ni, candbase, ncandbase, nhitsbase, d_status,
-                 d_queue + 1, ctx->ncu, d_fscr);
+        if (use_join)
+            dhk_seed_join(st, cap, bv, iv, dopt, jv, (int32_t)item0, ni, candbase, ncandbase, nhitsbase, d_status,
+                          d_queue + 1, ctx->ncu, d_fscr);
+        else
+            dhk_seed(st, cap, bv, iv, dopt, (int32_t)item0, ni, candbase, ncandbase, nhitsbase, d_status,
+                     d_queue + 1, ctx->ncu, d_fscr);
         HIPCHK(hipGetLastError());
         {
             // items whose hits did not fit the LDS buffer (ncand == -1) are redone with their hits
@@ -1435,7 +1611,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             if (const char *e = getenv("DH_SEED_BIG_PCT")) redo_all = (size_t)((double)ni * atof(e) / 200.0);  // development (reads = ni / 2)
             if (getenv("DH_TRACE") && !big.empty())
                 fprintf(stderr, "[seeds] cap %d: %zu of %d reads overflow (whole chunk again above %zu)\n", cap, big.size(), ni / 2, redo_all);
-            if (big.size() > redo_all && cap < 16384) {
+            if (big.size() > redo_all && cap < (use_join ? 8192 : 16384)) {
                 cap *= 2;
                 item0 -= cn;
                 continue;
@@ -1455,8 +1631,12 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
                 for (size_t b0 = 0; b0 < big.size(); b0 += per_launch) {
                     const int32_t cnt = (int32_t)std::min(per_launch, big.size() - b0);
                     HIPCHK(hipMemsetAsync(d_queue + 2, 0, sizeof(uint32_t), st));
-                    dhk_seed_big(st, bv, iv, dopt, d_list + b0, cnt, d_gbuf, pow2, candbase, ncandbase,
-                                 nhitsbase, d_status, d_queue + 2, ctx->ncu);
+                    if (use_join)
+                        dhk_seed_big_join(st, bv, iv, dopt, jv, d_list + b0, cnt, d_gbuf, pow2, candbase, ncandbase,
+                                          nhitsbase, d_status, d_queue + 2, ctx->ncu);
+                    else
+                        dhk_seed_big(st, bv, iv, dopt, d_list + b0, cnt, d_gbuf, pow2, candbase, ncandbase,
+                                     nhitsbase, d_status, d_queue + 2, ctx->ncu);
                     HIPCHK(hipGetLastError());
                 }
                 HIPCHK(hipMemcpyAsync(&status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -1611,7 +1791,8 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             if (l0 + totals[0] > res->la.capacity() || t0 + totals[1] > res->trace.capacity())
                 tasks.join();  // the records are about to move: copies and hooks in flight finish first
             res->la.resize(l0 + totals[0]);
-            res->trace.resize(t0 + totals[1]);
+            const bool dev_only = (want_sorted & 2) && t0 == 0 && item0 == item_first && ni == nitems_total;
+            if (!dev_only) res->trace.resize(t0 + totals[1]);
             lap(4);
             // device-to-host on the copy stream: it overlaps the next chunk's kernels
             hipEvent_t compacted = ctx->cev[nchunk_done & 1];
@@ -1624,10 +1805,14 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             // arrived, while the trace values -- ten times the bytes -- are still on their way (Tasks::join waits
             // for the stream before anybody sees the result)
             HIPCHK(hipEventRecord(copied, ctx->cstream));
-            if (totals[1] > 0)
+            res->d_trace = (t0 == 0 && item0 == item_first && ni == nitems_total) ? d_trout : nullptr;
+            // (want_sorted & 2: the caller reads the trace from the device copy -- the pile-up all-vs-all, whose host
+            // side needs 1 / n of the values: the overlaps of the reference reads -- so the 2 x 160 MB of configs[2] stay)
+            if (totals[1] > 0 && !dev_only)
                 HIPCHK(hipMemcpyAsync(res->trace.data() + t0, d_trout, sizeof(uint16_t) * (size_t)totals[1],
                                       hipMemcpyDeviceToHost, ctx->cstream));
-            res->d_trace = (t0 == 0 && item0 == item_first && ni == nitems_total) ? d_trout : nullptr;
+            else if (totals[1] > 0)
+                res->d_trace_len = (int64_t)totals[1];
         }
         if (res2) {
             // the transposed records of the chunk: same compaction, copied on this stream (not the benched path)
@@ -1696,7 +1881,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     tasks.join();
     const double tail_hooks = tasks.ms_hooks, tail_copies = tasks.ms_copies;
     if (want_best && !hook) select_best_range(res->la.data(), res->la.size(), near_ppm);
-    if (want_sorted) lasort(res, A->n);
+    if (want_sorted & 1) lasort(res, A->n);
     if (res2) {
         // chain flags of the transposed set: the same rule with the roles of the sequences exchanged (chains of a read
         // on one contig, ordered along the read); then LAsort order
@@ -1719,7 +1904,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     float t;
     HIPCHK(hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[1]));
     stats.ms_index = t;
-    stats.ms_seed = ms_seed;
+    stats.ms_seed = ms_seed + ms_join;  // the k-mer join is seeding work
     stats.ms_wave = ms_wave;
     stats.ms_gather = ms_gather;
     stats.ms_total = stats.ms_index + ms_seed + ms_wave + ms_gather;
@@ -1736,7 +1921,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         c.las += stats.las;
         c.hits += stats.hits;
         c.b_bases += stats.b_bases;
-        c.trace_values += (int64_t)res->trace.size();
+        c.trace_values += res->d_trace_len > 0 ? res->d_trace_len : (int64_t)res->trace.size();
         std::atomic<int64_t> abp{0};
         const dh_la *lp = res->la.data();
         dh_parallel_for((int64_t)res->la.size(), 1 << 16, [&](int64_t lo, int64_t hi) {
@@ -1747,16 +1932,19 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         c.aligned_bp += abp.load();
     }
 #ifdef DH_SEED_PROF
-    if (getenv("DH_TRACE")) dhk_seed_prof_dump();
+    if (getenv("DH_TRACE")) {
+        dhk_seed_prof_dump();
+        dhk_join_prof_dump();
+    }
 #endif
     if (getenv("DH_TRACE"))
         fprintf(stderr,
                 "[dh_align_db] A=%d seqs/%lld bp B=%d seqs/%lld bp hits=%lld cands=%lld aln=%lld las=%lld cells=%lld | "
-                "index %.2f seed %.2f wave %.2f gather %.2f ms, wall %.2f ms (host: index %.2f loop %.2f post %.2f; "
+                "index %.2f seed %.2f (join %.2f: %lld hits) wave %.2f gather %.2f ms, wall %.2f ms (host: index %.2f loop %.2f post %.2f; "
                 "loop: copies %.2f seed %.2f wave %.2f stats %.2f resize %.2f d2h %.2f; tail: hooks %.2f copies %.2f)\n",
                 A->n, (long long)A->total, B->n, (long long)B->total, (long long)stats.hits, (long long)stats.cands,
                 (long long)stats.alignments, (long long)stats.las, (long long)stats.wave_cells, stats.ms_index,
-                stats.ms_seed, stats.ms_wave, stats.ms_gather,
+                stats.ms_seed, ms_join, (long long)join_hits, stats.ms_wave, stats.ms_gather,
                 ((double)std::chrono::duration_cast<std::chrono::microseconds>(
                      std::chrono::steady_clock::now().time_since_epoch()).count() - wall0) / 1e3,
                 w_index, w_loop, w_post, w_g[0], w_g[1], w_g[2], w_g[3], w_g[4], w_g[5], tail_hooks, tail_copies);

@@ -764,6 +764,22 @@ void dhk_gather_slices(hipStream_t st, const uint8_t *src, const int64_t *src_of
     }
 }
 
+// ranges of 16-bit trace values copied into one compact array: a wavefront per range (desc = src offset, dst offset, length)
+__global__ void __launch_bounds__(256)
+k_gather_ranges16(const uint16_t *__restrict__ src, const int64_t *__restrict__ desc, int32_t n, uint16_t *__restrict__ dst)
+{
+    const int32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int64_t so = desc[3 * (int64_t)r], d0 = desc[3 * (int64_t)r + 1], len = desc[3 * (int64_t)r + 2];
+    for (int64_t e = threadIdx.x & 63; e < len; e += 64) dst[d0 + e] = src[so + e];
+}
+
+void dhk_gather_ranges16(hipStream_t st, const uint16_t *src, const int64_t *desc, int32_t n, uint16_t *dst)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_gather_ranges16, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, st, src, desc, n, dst);
+}
+
 void dhk_gather_parts(hipStream_t st, const uint8_t *src0, const int64_t *off0, const uint8_t *src1,
                       const int64_t *off1, const void *parts, int32_t n, int32_t max_len, uint8_t *dst)
 {

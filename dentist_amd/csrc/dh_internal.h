@@ -52,7 +52,7 @@ struct dh_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int ncu = 0;
-    hipEvent_t ev[6] = {};
+    hipEvent_t ev[8] = {};
     // second stream for the device-to-host copies of a chunk's records (they overlap the next chunk's
     // kernels); cev[0..1]: compaction done (main stream), cev[2..3]: copy done (copy stream), by chunk parity
     hipStream_t cstream = nullptr;
@@ -68,7 +68,7 @@ struct dh_ctx {
     struct Arena {
         void *p = nullptr;
         size_t cap = 0;
-    } arena[48];
+    } arena[64];
 };
 // slot `id` of the context's scratch arena, at least `bytes` large
 int dh_scratch(dh_ctx *ctx, int id, size_t bytes, void **out);
@@ -83,6 +83,7 @@ struct dh_index {
     int32_t *d_page_seq = nullptr;  // virtual page (4096 bases) -> sequence
     int64_t n = 0;
     int32_t k = 0, sepv = 0, shift = 0, pbits = 0, na = 0, kmer_mod = 1;
+    bool light = false;  // virtual axis only (no directory): the hits come from the k-mer join (dh_join.hip)
     void release()
     {
         dh_dev_free(d_dir_alloc);
@@ -162,6 +163,7 @@ struct dh_la_set {
     // device copy of `trace` left behind by dh_align_db_ex (scratch arena): valid until the next
     // alignment call on the same context, nullptr when the result came in several chunks
     const uint16_t *d_trace = nullptr;
+    int64_t d_trace_len = 0;  // > 0: `trace` was left on the device on request (dh_align_db_ex want_sorted & 2), the host vector is empty
     // B reads whose items overflowed a per-item capacity (dropped records / no candidates), see
     // dh_align_stats.overflow_items; the pile-up path skips the pile-ups of such reads
     std::vector<int32_t> ovf_reads;
@@ -193,7 +195,8 @@ void dh_mask_free(dh_db *db);
 // DBdust: ORs the low-complexity mask (k_dust) into the DB's mask bitmap; drops the cached index
 int dh_db_dust_impl(dh_db *db);
 int dh_ensure_packed(dh_db *db, bool with_rc);
-// dh_align_db with the final LAsort made optional (internal callers regroup on their own)
+// dh_align_db with the final LAsort made optional (internal callers regroup on their own): want_sorted bit 0 = LAsort,
+// bit 1 = leave the trace values on the device (dh_la_set.d_trace / d_trace_len) when the call is one chunk
 int dh_align_db_ex(dh_ctx *ctx, dh_db *A, dh_db *B, const dh_align_opts *opts, int32_t want_best,
                    int32_t want_sorted, dh_la_set **out);
 

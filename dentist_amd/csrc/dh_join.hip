@@ -1,0 +1,374 @@
+// dh_join.hip -- gfx950 kernels of the per-pile-up k-mer join (see dh_join.h for the design).
+// Replaces, for the pile-up all-vs-all of `dentist process` (processPileUps/package.d:474-485), the k-mer
+// directory of the grouped DB (k_group_index) and the directory lookups of the seed filter (k_seed):
+// the hits a read gets are the same multiset, produced without leaving the CU.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "dh_join.h"
+#include "dh_kmer.h"
+
+#define LANES 64
+
+#ifdef DH_SEED_PROF
+__device__ unsigned long long g_join_prof[8];
+#define JP(i) if (tid == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_join_prof[i], t_ - tp_); tp_ = t_; }
+extern "C" void dhk_join_prof_dump()
+{
+    unsigned long long h[8];
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_join_prof), sizeof(h));
+    if (h[7])
+        fprintf(stderr, "[join prof] blocks %llu: gather %.1f chain %.1f count %.1f reserve %.1f emit %.1f us/block\n", h[7],
+                h[0] / 100.0 / h[7], h[1] / 100.0 / h[7], h[2] / 100.0 / h[7], h[3] / 100.0 / h[7], h[4] / 100.0 / h[7]);
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_join_prof), z, sizeof(z));
+}
+#else
+#define JP(i)
+#endif
+
+namespace {
+
+// slice of a canonical k-mer inside its group (ns slices) and bucket inside the slice's LDS table: two different
+// multiplicative hashes of the k-mer, so that the entries of one slice spread over all buckets
+__device__ __forceinline__ uint32_t join_slice(uint32_t canon, uint32_t ns) { return __umulhi(canon * 0x9E3779B1u, ns); }
+template <int CAP>
+__device__ __forceinline__ uint32_t join_bucket(uint32_t canon)
+{
+    return ((canon ^ (canon >> 15)) * 0x85EBCA6Bu) >> (32 - __builtin_ctz((unsigned)CAP));
+}
+
+// exclusive prefix sum over the block's threads (one value each); *total = sum.  s_w: one word per wavefront.
+template <int THREADS>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, int tid, uint32_t *s_w, uint32_t *total)
+{
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < LANES; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off, LANES);
+        if ((tid & (LANES - 1)) >= off) incl += up;
+    }
+    __syncthreads();  // s_w may still be read from a previous scan
+    if ((tid & (LANES - 1)) == LANES - 1) s_w[tid / LANES] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < THREADS / LANES; w++) {
+        const uint32_t x = s_w[w];
+        if (w < tid / LANES) base += x;
+        tot += x;
+    }
+    *total = tot;
+    return base + incl - v;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------ partition
+// Block pb covers the chunks [c0, c0 + JP_THREADS) of group g's chunk space (the reads of the group one after the
+// other, JP_PER k-mer start positions per chunk); thread t rolls chunk c0 + t.
+__global__ void __launch_bounds__(JP_THREADS)
+k_join_part(JoinView jv, DbView B, int32_t k, int32_t kmer_mod)
+{
+    __shared__ uint64_t stage[JP_POS];
+    __shared__ uint32_t scnt[JOIN_MAX_SLICES], sstart[JOIN_MAX_SLICES];
+    __shared__ uint32_t cpre[JOIN_MAX_READS + 1];
+    __shared__ uint32_t s_w[JP_THREADS / LANES];
+    const int tid = threadIdx.x;
+    const int32_t pb = blockIdx.x;
+    const int32_t g = jv.pblk[pb].x, c0 = jv.pblk[pb].y;
+    const int32_t r0 = jv.gfirst[g], nr = jv.gfirst[g + 1] - r0;
+    const uint32_t ns = (uint32_t)jv.gns[g];
+    // chunks of every read of the group (prefix sums)
+    uint32_t nch = 0;
+    if (tid < nr) {
+        const int32_t len = (int32_t)(B.off[r0 + tid + 1] - B.off[r0 + tid]);
+        const int32_t npos = len - k + 1;
+        nch = npos > 0 ? (uint32_t)(npos + JP_PER - 1) / JP_PER : 0u;
+    }
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan<JP_THREADS>(nch, tid, s_w, &tot);
+    if (tid < nr) cpre[tid] = ex;
+    if (tid == 0) cpre[nr] = tot;
+    scnt[tid] = 0;  // JP_THREADS == JOIN_MAX_SLICES
+    __syncthreads();
+    const uint32_t c = (uint32_t)c0 + (uint32_t)tid;
+    bool live = c < tot;
+    int32_t rl = 0, p0 = 0, len = 0;
+    int64_t o = 0;
+    if (live) {
+        // read of the chunk: the last rl with cpre[rl] <= c (reads without k-mers have empty ranges)
+        int32_t lo = 0, hi = nr - 1;
+        while (lo < hi) {
+            const int32_t mid = (lo + hi + 1) >> 1;
+            if (cpre[mid] <= c)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        rl = lo;
+        p0 = (int32_t)(c - cpre[rl]) * JP_PER;
+        o = B.off[r0 + rl];
+        len = (int32_t)(B.off[r0 + rl + 1] - o);
+    }
+    const KmerSampler smp = kmer_sampler(kmer_mod, k);
+    const uint32_t mask = k == 16 ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u);
+    const int rcsh = 2 * (k - 1);
+    const uint64_t kones = (1ull << k) - 1ull;
+    uint64_t w[4] = {0, 0, 0, 0};
+    uint64_t mw = 0;
+    if (live) {
+        const uint8_t *a = B.bases + o + p0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) w[u] = load8(a + 8 * u);  // JP_PER + k - 1 <= 31 bases (buffers are padded)
+        if (B.mask_bits) {
+            const int64_t gb = o + p0;
+            mw = load8(B.mask_bits + (gb >> 3)) >> (gb & 7);  // >= 57 bits of the window, JP_PER + k - 1 <= 31 are used
+        }
+    }
+    uint32_t km = 0, rc = 0;
+    int32_t valid = 0;
+#pragma unroll
+    for (int x = 0; x < JP_PER + 15; x++) {  // k <= 16; steps past JP_PER + k - 2 are predicated off (no break: the loop must unroll, w[] stays in registers)
+        const bool act = x < JP_PER + k - 1;
+        const int32_t p = p0 + x;
+        uint32_t cc = (uint32_t)(w[x >> 3] >> (8 * (x & 7))) & 0xFFu;
+        if (!live || p >= len) cc = 4u;
+        if (cc < 4u) {
+            km = ((km << 2) | cc) & mask;
+            rc = (rc >> 2) | ((3u - cc) << rcsh);
+            valid++;
+        } else {
+            km = 0;
+            rc = 0;
+            valid = 0;
+        }
+        const int j = x - (k - 1);  // k-mer start p0 + j
+        if (act && j >= 0) {
+            const uint32_t canon = km < rc ? km : rc;
+            const bool ok = valid >= k && kmer_sampled((uint64_t)canon, smp) && ((mw >> j) & kones) == 0ull;
+            uint64_t e = ~0ull;
+            if (ok) {
+                e = ((uint64_t)canon << 32) | (km != canon ? 1ull << 31 : 0ull) | (km == rc ? 1ull << 30 : 0ull) |
+                    ((uint64_t)rl << 21) | (uint64_t)(p0 + j);
+                atomicAdd(&scnt[join_slice(canon, ns)], 1u);
+            }
+            stage[j * JP_THREADS + tid] = e;
+        }
+    }
+    __syncthreads();
+    // the slices' ranges inside the block's region; scnt becomes the cursors
+    const uint32_t mine = scnt[tid];
+    uint32_t tot2;
+    const uint32_t st = block_excl_scan<JP_THREADS>(mine, tid, s_w, &tot2);
+    sstart[tid] = st;
+    scnt[tid] = 0;
+    if ((uint32_t)tid < ns) jv.psub[jv.psubrow[pb] + tid] = (st << 16) | mine;
+    __syncthreads();
+    uint64_t *out = jv.entries + (int64_t)pb * JP_POS;
+#pragma unroll 4
+    for (int j = 0; j < JP_PER; j++) {
+        const uint64_t e = stage[j * JP_THREADS + tid];
+        if (e == ~0ull) continue;
+        const uint32_t s = join_slice((uint32_t)(e >> 32), ns);
+        const uint32_t rank = atomicAdd(&scnt[s], 1u);
+        out[sstart[s] + rank] = e;
+    }
+}
+
+// ------------------------------------------------------------------------------------ join
+template <int CAP>
+__global__ void __launch_bounds__(JOIN_THREADS)
+k_join(JoinView jv, DbView B, DhOpts o, const int64_t *__restrict__ goff, int32_t sepv)
+{
+    __shared__ uint64_t keys[CAP];
+    __shared__ uint32_t head[CAP];  // bucket -> last inserted entry + 1 (0 = empty)
+    __shared__ uint16_t nxt[CAP];   // entry -> previous entry of its bucket + 1
+    __shared__ int64_t lgoff[JOIN_MAX_READS];
+    __shared__ int32_t llen[JOIN_MAX_READS];
+    __shared__ uint32_t cnt[JOIN_MAX_READS], roff[JOIN_MAX_READS];
+    __shared__ uint32_t s_w[JOIN_THREADS / LANES];
+    __shared__ int32_t s_n;
+    __shared__ unsigned long long s_base;
+    const int tid = threadIdx.x, lane = tid & (LANES - 1), wv = tid / LANES;
+    const int32_t jb = blockIdx.x;
+    const int32_t g = jv.jblk[jb].x, sl = jv.jblk[jb].y;
+    const int32_t r0 = jv.gfirst[g], nr = jv.gfirst[g + 1] - r0;
+    for (int i = tid; i < CAP; i += JOIN_THREADS) head[i] = 0u;
+    if (tid < nr) {
+        lgoff[tid] = goff[r0 + tid];
+        llen[tid] = (int32_t)(B.off[r0 + tid + 1] - B.off[r0 + tid]);
+    }
+    cnt[tid] = 0u;  // JOIN_THREADS == JOIN_MAX_READS
+    if (tid == 0) s_n = 0;
+#ifdef DH_SEED_PROF
+    unsigned long long tp_ = wall_clock64();
+#endif
+    __syncthreads();
+    // ---- gather the slice's entries from the group's part blocks: a wavefront per part block
+    for (int32_t pb = jv.pfirst[g] + wv; pb < jv.pfirst[g + 1]; pb += JOIN_THREADS / LANES) {
+        const uint32_t u = jv.psub[jv.psubrow[pb] + sl];
+        const int32_t c = (int32_t)(u & 0xFFFFu), st = (int32_t)(u >> 16);
+        if (c == 0) continue;
+        int32_t base = 0;
+        if (lane == 0) base = atomicAdd(&s_n, c);
+        base = __shfl(base, 0, LANES);
+        if (base + c <= CAP) {
+            const uint64_t *src = jv.entries + (int64_t)pb * JP_POS + st;
+            for (int32_t e = lane; e < c; e += LANES) keys[base + e] = src[e];
+        }
+    }
+    __syncthreads();
+    JP(0)
+    const int32_t n = s_n;
+    if (n > CAP) {  // a k-mer with thousands of copies landed here: the whole call takes the directory path
+        if (tid == 0) atomicOr(jv.status, DH_ST_JOIN_OVERFLOW);
+        return;
+    }
+    // ---- chain the entries by bucket
+    for (int32_t i = tid; i < n; i += JOIN_THREADS) {
+        const uint32_t hb = join_bucket<CAP>((uint32_t)(keys[i] >> 32));
+        nxt[i] = (uint16_t)atomicExch(&head[hb], (uint32_t)i + 1u);
+    }
+    __syncthreads();
+    JP(1)
+    const int32_t tcap = o.tcap;
+    const int32_t k = o.k;
+    // walk of entry i taken as the B side: fn(a key) for every entry of the same canonical k-mer (itself included)
+    // ---- pass 1: orientation classes of every entry's k-mer (-t cap), hits per B read
+    uint32_t dmask = 0;  // (forward ok, reverse ok) of this thread's entries, two bits each
+    {
+        int slot = 0;
+        for (int32_t i = tid; i < n; i += JOIN_THREADS, slot++) {
+            const uint64_t key = keys[i];
+            const uint32_t canon = (uint32_t)(key >> 32);
+            const uint32_t ori = (uint32_t)(key >> 31) & 1u;
+            const bool pal = ((key >> 30) & 1ull) != 0;
+            const int32_t brl = (int32_t)(key >> 21) & (JOIN_MAX_READS - 1);
+            const int32_t R = r0 + brl;
+            int32_t n_same = 0, n_opp = 0, k_same = 0, k_opp = 0;
+            for (uint32_t j = head[join_bucket<CAP>(canon)]; j; j = nxt[j - 1]) {
+                const uint64_t ka = keys[j - 1];
+                if ((uint32_t)(ka >> 32) != canon) continue;
+                const bool same = ((uint32_t)(ka >> 31) & 1u) == ori;
+                const int32_t Aq = r0 + ((int32_t)(ka >> 21) & (JOIN_MAX_READS - 1));
+                bool keep = true;
+                if (o.skip_self == 1) keep = Aq != R;
+                if (o.skip_self == 2) keep = Aq != R && ((Aq < R) == (((Aq + R) & 1) == 0));
+                if (same) {
+                    n_same++;
+                    k_same += keep ? 1 : 0;
+                } else {
+                    n_opp++;
+                    k_opp += keep ? 1 : 0;
+                }
+            }
+            // a k-mer occurring more than tcap times in an orientation class yields no hits of that class (its own
+            // occurrence counts, as an index entry does)
+            const bool dof = n_same <= tcap && (o.strands & 1);
+            const bool dor = (pal ? n_same <= tcap : (n_opp >= 1 && n_opp <= tcap)) && (o.strands & 2);
+            const int32_t nh = (dof ? k_same : 0) + (dor ? (pal ? k_same : k_opp) : 0);
+            dmask |= ((dof ? 1u : 0u) | (dor ? 2u : 0u)) << (2 * slot);
+            if (nh) atomicAdd(&cnt[brl], (uint32_t)nh);
+        }
+    }
+    __syncthreads();
+    JP(2)
+    // ---- the block's range of the hit buffer, one segment per B read
+    const uint32_t mine = cnt[tid];
+    uint32_t total;
+    const uint32_t ro = block_excl_scan<JOIN_THREADS>(mine, tid, s_w, &total);
+    roff[tid] = ro;
+    if (tid == 0) s_base = total ? atomicAdd(jv.cursor, (unsigned long long)total) : 0ull;
+    __syncthreads();
+    const unsigned long long base = s_base;
+    if (tid < nr) jv.segtab[jv.segrow[r0 + tid] + sl] = ((uint64_t)(base + ro) << 24) | (uint64_t)mine;
+    if (total == 0) return;
+    if (base + total > (unsigned long long)jv.hits_cap) {  // the host reruns this kernel with a buffer of cursor entries
+        if (tid == 0) atomicOr(jv.status, DH_ST_JOIN_HITCAP);
+        return;
+    }
+    cnt[tid] = 0u;  // now the cursors of the segments
+    __syncthreads();
+    JP(3)
+    // ---- pass 2: the hits
+    {
+        int slot = 0;
+        for (int32_t i = tid; i < n; i += JOIN_THREADS, slot++) {
+            const uint32_t dm = (dmask >> (2 * slot)) & 3u;
+            if (!dm) continue;
+            const bool dof = (dm & 1u) != 0, dor = (dm & 2u) != 0;
+            const uint64_t key = keys[i];
+            const uint32_t canon = (uint32_t)(key >> 32);
+            const uint32_t ori = (uint32_t)(key >> 31) & 1u;
+            const bool pal = ((key >> 30) & 1ull) != 0;
+            const int32_t brl = (int32_t)(key >> 21) & (JOIN_MAX_READS - 1);
+            const int32_t q = (int32_t)(key & (JOIN_MAX_LEN - 1));
+            const int32_t R = r0 + brl;
+            const int32_t qrev = llen[brl] - k - q;  // position on the reverse-complemented read
+            uint64_t *dst = jv.hits + base + roff[brl];
+            for (uint32_t j = head[join_bucket<CAP>(canon)]; j; j = nxt[j - 1]) {
+                const uint64_t ka = keys[j - 1];
+                if ((uint32_t)(ka >> 32) != canon) continue;
+                const bool same = ((uint32_t)(ka >> 31) & 1u) == ori;
+                const int32_t arl = (int32_t)(ka >> 21) & (JOIN_MAX_READS - 1);
+                const int32_t Aq = r0 + arl;
+                if (o.skip_self == 1 && Aq == R) continue;
+                if (o.skip_self == 2 && (Aq == R || ((Aq < R) != (((Aq + R) & 1) == 0)))) continue;
+                const int64_t gv = lgoff[arl] + (int64_t)(ka & (JOIN_MAX_LEN - 1));
+                if (dof && (same || pal)) {
+                    const int64_t D = gv + sepv - q;
+                    dst[atomicAdd(&cnt[brl], 1u)] = ((uint64_t)D << 24) | (uint32_t)q;
+                }
+                if (dor && (!same || pal)) {
+                    const int64_t D = gv + sepv - qrev;
+                    dst[atomicAdd(&cnt[brl], 1u)] = (1ull << 63) | ((uint64_t)D << 24) | (uint32_t)qrev;
+                }
+            }
+        }
+    }
+#ifdef DH_SEED_PROF
+    __syncthreads();
+    JP(4)
+    if (tid == 0) atomicAdd(&g_join_prof[7], 1ull);
+#endif
+}
+
+template __global__ void k_join<JOIN_CAP>(JoinView, DbView, DhOpts, const int64_t *, int32_t);
+
+// reads whose hits exceed 2048 / 4096 / 8192 entries (out[0..2]) and the largest count (out[3]): the host picks the LDS
+// capacity of the seed filter's back end from them
+__global__ void __launch_bounds__(256)
+k_join_hist(JoinView jv, const int32_t *__restrict__ group, int32_t nreads, unsigned int *__restrict__ out)
+{
+    const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nreads) return;
+    const int32_t ns = jv.gns[group[r]];
+    const uint64_t *row = jv.segtab + jv.segrow[r];
+    uint32_t n = 0;
+    for (int32_t s = 0; s < ns; s++) n += (uint32_t)(row[s] & 0xFFFFFFull);
+    if (n > 2048u) atomicAdd(&out[0], 1u);
+    if (n > 4096u) atomicAdd(&out[1], 1u);
+    if (n > 8192u) atomicAdd(&out[2], 1u);
+    atomicMax(&out[3], n);
+}
+
+extern "C" void dhk_join_hist(hipStream_t st, JoinView jv, const int32_t *group, int32_t nreads, unsigned int *out4)
+{
+    (void)hipMemsetAsync(out4, 0, 4 * sizeof(unsigned int), st);
+    if (nreads <= 0) return;
+    hipLaunchKernelGGL(k_join_hist, dim3((uint32_t)((nreads + 255) / 256)), dim3(256), 0, st, jv, group, nreads, out4);
+}
+
+extern "C" void dhk_join_part(hipStream_t st, JoinView jv, DbView B, int32_t k, int32_t kmer_mod)
+{
+    if (jv.npart <= 0) return;
+    hipLaunchKernelGGL(k_join_part, dim3((uint32_t)jv.npart), dim3(JP_THREADS), 0, st, jv, B, k, kmer_mod);
+}
+
+extern "C" void dhk_join(hipStream_t st, JoinView jv, DbView B, DhOpts o, const int64_t *goff, int32_t sepv)
+{
+    if (jv.njoin <= 0) return;
+    hipLaunchKernelGGL(k_join<JOIN_CAP>, dim3((uint32_t)jv.njoin), dim3(JOIN_THREADS), 0, st, jv, B, o, goff, sepv);
+}

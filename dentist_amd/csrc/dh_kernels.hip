@@ -20,64 +20,11 @@
 #include <stdlib.h>
 
 #include "dh_device.h"
+#include "dh_join.h"
 
 #define LANES 64
 
-// modimer sampling (daligner -%): the same k-mers are kept on the A and on the B side, decided on the
-// CANONICAL k-mer (the smaller of a k-mer and its reverse complement, both rolled along), so that a
-// k-mer and its reverse complement are sampled together.
-// Keep a k-mer iff h % mod == 0 with h = bits 32..63 of canon * 0x9E3779B97F4A7C15.  32-bit integer
-// multiplies run at quarter rate on CDNA, and this test is evaluated for every base of every
-// read, so it is arranged to need three of them (two when k <= 16):
-//  * h = mulhi(lo, C_lo) + lo * C_hi + hi * C_lo   (lo / hi = halves of the k-mer);
-//  * h % mod == 0  <=>  rotr(h * inv(mod'), e) <= (2^32 - 1) / mod   for mod = mod' * 2^e, mod'
-//    odd, inv = inverse of mod' modulo 2^32 (test for zero remainder, Hacker's Delight 10-17).
-struct KmerSampler {
-    uint32_t inv, thresh, rot;
-    bool all, small_k;
-};
-__device__ __forceinline__ KmerSampler kmer_sampler(int32_t mod, int32_t k)
-{
-    KmerSampler s;
-    s.all = mod <= 1;
-    s.small_k = k <= 16;
-    uint32_t d = s.all ? 1u : (uint32_t)mod, e = 0;
-    while ((d & 1u) == 0u) {
-        d >>= 1;
-        e++;
-    }
-    uint32_t x = d;  // Newton: x <- x * (2 - d * x) doubles the number of correct low bits
-    for (int it = 0; it < 5; it++) x *= 2u - d * x;
-    s.inv = x;
-    s.rot = e;
-    s.thresh = s.all ? 0xFFFFFFFFu : 0xFFFFFFFFu / (uint32_t)mod;
-    return s;
-}
-__device__ __forceinline__ bool kmer_sampled(uint64_t km, const KmerSampler &s)
-{
-    const uint32_t lo = (uint32_t)km, hi = (uint32_t)(km >> 32);
-    uint32_t h = __umulhi(lo, 0x7F4A7C15u) + lo * 0x9E3779B9u;
-    if (!s.small_k) h += hi * 0x7F4A7C15u;
-    const uint32_t t = h * s.inv;
-    const uint32_t r = s.rot ? ((t >> s.rot) | (t << (32u - s.rot))) : t;
-    return s.all || r <= s.thresh;
-}
-
-__device__ __forceinline__ uint64_t load8(const uint8_t *p)
-{
-    uint64_t x;
-    __builtin_memcpy(&x, p, 8);  // unaligned global_load_dwordx2 (DB buffers are padded)
-    return x;
-}
-
-// ---- soft masks (daligner / damapper -m<track>, DBdust): one bit per base of the concatenated base
-// array (DbView.mask_bits, bit g = base g is masked).  A k-mer is neither indexed nor looked up when
-// it touches a masked base: k <= 28 bits read with one unaligned 8-byte load.
-__device__ __forceinline__ bool mask_touch(const uint8_t *__restrict__ bits, int64_t g, int32_t k)
-{
-    const uint64_t w = load8(bits + (g >> 3)) >> (g & 7);
-    return (w & ((1ull << k) - 1ull)) != 0ull;
-}
+#include "dh_kmer.h"
 
 // ------------------------------------------------------------------------------------ K1
 
@@ -467,8 +414,10 @@ __device__ unsigned long long g_seed_prof[8];
 // position blen - k - q of the reverse-complemented read).  Hits carry the strand in their top bit,
 // the band filter therefore never mixes strands; candidates go to the items 2r (forward) and 2r + 1.
 #define HIT_DBITS 39
-template <int LCAP>
-__device__ void seed_item(const DbView &B, const IndexView &ix,
+// JOIN: the hits come from the per-pile-up k-mer join (dh_join.hip) -- the read's segments of the hit buffer are
+// gathered instead of looking its k-mers up; everything after the hit buffer is filled is the same code.
+template <int LCAP, bool JOIN>
+__device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &jv,
                           const DhOpts &o, int32_t read0, int32_t work, int32_t slab,
                           DhCand *__restrict__ cand_out, int32_t *__restrict__ ncand_out,
                           int32_t *__restrict__ nhits_out, int32_t *__restrict__ status,
@@ -510,7 +459,50 @@ __device__ void seed_item(const DbView &B, const IndexView &ix,
     // directory has ~8 buckets per indexed k-mer); longer ones take the generic loop.
     // The phase is bound by the latency of each lane's serial chain (measured: halving the number
     // of rolling threads makes it 40 % slower), so every thread of the block takes a chunk.
-    if (npos > 0 && tid < SEED_LOOKUP_THREADS) {
+    if (JOIN) {
+        // the read's segments: one per slice of its group (segtab row), first hit << 24 | count.  Their prefix sums
+        // and first hits overlay the candidate arrays, which are not in use yet.
+        uint64_t *segb = (uint64_t *)cands;                     // [SEED_THREADS] first hit of segment s
+        uint32_t *sego = (uint32_t *)(cands + SEED_CCAP) + 1;   // [-1 .. SEED_THREADS) exclusive prefix sums of the counts
+        __shared__ uint32_t s_jw[SEED_THREADS / LANES];
+        const int32_t ns = jv.gns[B.group[r]];
+        uint32_t c = 0;
+        if (tid < ns) {
+            const uint64_t sg = jv.segtab[jv.segrow[r] + tid];
+            c = (uint32_t)(sg & 0xFFFFFFull);
+            segb[tid] = sg >> 24;
+        }
+        uint32_t incl = c;
+        for (int off = 1; off < LANES; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off, LANES);
+            if ((tid & (LANES - 1)) >= off) incl += up;
+        }
+        if ((tid & (LANES - 1)) == LANES - 1) s_jw[tid / LANES] = incl;
+        __syncthreads();
+        uint32_t base = 0, tot = 0;
+        for (int wv = 0; wv < SEED_THREADS / LANES; wv++) {
+            if (wv < tid / LANES) base += s_jw[wv];
+            tot += s_jw[wv];
+        }
+        sego[tid] = base + incl;  // inclusive: sego[s - 1] = hits before segment s
+        if (tid == 0) {
+            sego[-1] = 0;
+            s_n = (int32_t)tot;
+        }
+        __syncthreads();
+        if ((int32_t)tot <= CAP)
+            for (int32_t e = tid; e < (int32_t)tot; e += SEED_THREADS) {
+                int32_t lo = 0, hi = ns - 1;  // the segment of hit e: the first s with sego[s] > e
+                while (lo < hi) {
+                    const int32_t mid = (lo + hi) >> 1;
+                    if (sego[mid] > (uint32_t)e)
+                        hi = mid;
+                    else
+                        lo = mid + 1;
+                }
+                hits[e] = jv.hits[segb[lo] + ((uint32_t)e - sego[lo - 1])];
+            }
+    } else if (npos > 0 && tid < SEED_LOOKUP_THREADS) {
         constexpr int QN = 4;
         const int32_t per = (npos + SEED_LOOKUP_THREADS - 1) / SEED_LOOKUP_THREADS;
         const int32_t q0 = tid * per, q1 = min(npos, q0 + per);
@@ -978,9 +970,9 @@ __device__ void seed_item(const DbView &B, const IndexView &ix,
 }
 // Persistent blocks: the grid is sized to the resident capacity of the chip and every block pulls
 // items from an atomic queue (no per-item block launch, dynamic balance over ragged read lengths).
-template <int LCAP>
+template <int LCAP, bool JOIN>
 __global__ void __launch_bounds__(SEED_THREADS, (LCAP > 0 && LCAP <= 2048) ? 6 : (LCAP == 16384 ? 2 : 4))
-k_seed(DbView B, IndexView ix, DhOpts o, int32_t read0,
+k_seed(DbView B, IndexView ix, JoinView jv, DhOpts o, int32_t read0,
        int32_t nreads, DhCand *__restrict__ cand_out, int32_t *__restrict__ ncand_out,
        int32_t *__restrict__ nhits_out, int32_t *__restrict__ status, uint64_t *__restrict__ gbuf,
        int32_t gcap, const int32_t *__restrict__ read_list, uint32_t *__restrict__ queue)
@@ -992,20 +984,24 @@ k_seed(DbView B, IndexView ix, DhOpts o, int32_t read0,
         __syncthreads();
         const int32_t work = s_work;
         if (work >= nreads) break;
-        seed_item<LCAP>(B, ix, o, read0, work, (int32_t)blockIdx.x, cand_out, ncand_out, nhits_out,
-                        status, gbuf, gcap, read_list);
+        seed_item<LCAP, JOIN>(B, ix, jv, o, read0, work, (int32_t)blockIdx.x, cand_out, ncand_out, nhits_out,
+                              status, gbuf, gcap, read_list);
     }
 }
-#define SEED_INST(C)                                                                              \
-    template __global__ void k_seed<C>(DbView, IndexView, DhOpts, int32_t, int32_t,  \
-                                       DhCand *, int32_t *, int32_t *, int32_t *, uint64_t *, int32_t, \
-                                       const int32_t *, uint32_t *);
-SEED_INST(1024)
-SEED_INST(2048)
-SEED_INST(4096)
-SEED_INST(8192)
-SEED_INST(16384)
-SEED_INST(0)
+#define SEED_INST(C, J)                                                                           \
+    template __global__ void k_seed<C, J>(DbView, IndexView, JoinView, DhOpts, int32_t, int32_t,  \
+                                          DhCand *, int32_t *, int32_t *, int32_t *, uint64_t *, int32_t, \
+                                          const int32_t *, uint32_t *);
+SEED_INST(1024, false)
+SEED_INST(2048, false)
+SEED_INST(4096, false)
+SEED_INST(8192, false)
+SEED_INST(16384, false)
+SEED_INST(0, false)
+SEED_INST(2048, true)
+SEED_INST(4096, true)
+SEED_INST(8192, true)
+SEED_INST(0, true)
 
 // ------------------------------------------------------------------------------------ K4b
 // Work units of the symmetric wave launch: the candidates of an item are grouped by A read
@@ -2402,13 +2398,13 @@ k_compact(const DhLa *__restrict__ la_slots, const uint16_t *__restrict__ tr_slo
 // ------------------------------------------------------------------------------------ launchers
 
 // resident blocks of a seed variant on the whole chip (persistent grid size)
-template <int C>
+template <int C, bool J = false>
 static int seed_grid(int32_t nitems, int32_t ncu)
 {
     static int per_cu = 0;
     if (per_cu == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_seed<C>, SEED_THREADS, 0) != hipSuccess || nb < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_seed<C, J>, SEED_THREADS, 0) != hipSuccess || nb < 1)
             nb = 1;
         per_cu = nb;
     }
@@ -2652,8 +2648,9 @@ void dhk_seed(hipStream_t st, int cap, DbView B, IndexView ix, DhOpts o,
 {
     if (nitems <= 0) return;
     const int32_t read0 = item0 / 2, nreads = nitems / 2;
+    const JoinView jv = {};
 #define SEED_LAUNCH(C)                                                                            \
-    hipLaunchKernelGGL(k_seed<C>, dim3(seed_grid<C>(nreads, ncu)), dim3(SEED_THREADS), 0, st, B, ix, o, \
+    hipLaunchKernelGGL((k_seed<C, false>), dim3(seed_grid<C>(nreads, ncu)), dim3(SEED_THREADS), 0, st, B, ix, jv, o, \
                        read0, nreads, cand, ncand, nhits, status, C == 8192 ? fscr : (uint64_t *)nullptr,    \
                        C == 8192 ? DH_SEED_FSCR_WORDS : 0, (const int32_t *)nullptr, queue)
     if (cap <= 1024)
@@ -2686,7 +2683,37 @@ void dhk_seed_big(hipStream_t st, DbView B, IndexView ix, DhOpts o,
                   int32_t *ncand, int32_t *nhits, int32_t *status, uint32_t *queue, int32_t ncu)
 {
     if (nreads <= 0) return;
-    hipLaunchKernelGGL(k_seed<0>, dim3(seed_grid<0>(nreads, ncu)), dim3(SEED_THREADS), 0, st, B, ix, o, 0,
+    const JoinView jv = {};
+    hipLaunchKernelGGL((k_seed<0, false>), dim3(seed_grid<0>(nreads, ncu)), dim3(SEED_THREADS), 0, st, B, ix, jv, o, 0,
+                       nreads, cand, ncand, nhits, status, gbuf, gcap, read_list, queue);
+}
+
+// the same back end fed from the hit segments of the per-pile-up k-mer join (dh_join.hip)
+void dhk_seed_join(hipStream_t st, int cap, DbView B, IndexView ix, DhOpts o, JoinView jv, int32_t item0, int32_t nitems,
+                   DhCand *cand, int32_t *ncand, int32_t *nhits, int32_t *status, uint32_t *queue, int32_t ncu,
+                   uint64_t *fscr)
+{
+    if (nitems <= 0) return;
+    const int32_t read0 = item0 / 2, nreads = nitems / 2;
+#define SEED_LAUNCH_J(C)                                                                          \
+    hipLaunchKernelGGL((k_seed<C, true>), dim3(seed_grid<C, true>(nreads, ncu)), dim3(SEED_THREADS), 0, st, B, ix, jv, o, \
+                       read0, nreads, cand, ncand, nhits, status, C == 8192 ? fscr : (uint64_t *)nullptr,    \
+                       C == 8192 ? DH_SEED_FSCR_WORDS : 0, (const int32_t *)nullptr, queue)
+    if (cap <= 2048)
+        SEED_LAUNCH_J(2048);
+    else if (cap <= 4096)
+        SEED_LAUNCH_J(4096);
+    else
+        SEED_LAUNCH_J(8192);
+#undef SEED_LAUNCH_J
+}
+
+void dhk_seed_big_join(hipStream_t st, DbView B, IndexView ix, DhOpts o, JoinView jv, const int32_t *read_list,
+                       int32_t nreads, uint64_t *gbuf, int32_t gcap, DhCand *cand, int32_t *ncand, int32_t *nhits,
+                       int32_t *status, uint32_t *queue, int32_t ncu)
+{
+    if (nreads <= 0) return;
+    hipLaunchKernelGGL((k_seed<0, true>), dim3(seed_grid<0, true>(nreads, ncu)), dim3(SEED_THREADS), 0, st, B, ix, jv, o, 0,
                        nreads, cand, ncand, nhits, status, gbuf, gcap, read_list, queue);
 }
 

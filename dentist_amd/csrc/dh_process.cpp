@@ -28,6 +28,7 @@ void dhk_gather_slices(hipStream_t st, const uint8_t *src, const int64_t *src_of
                        uint8_t *dst);
 void dhk_gather_parts(hipStream_t st, const uint8_t *src0, const int64_t *off0, const uint8_t *src1,
                       const int64_t *off1, const void *parts, int32_t n, int32_t max_len, uint8_t *dst);
+void dhk_gather_ranges16(hipStream_t st, const uint16_t *src, const int64_t *desc, int32_t n, uint16_t *dst);
 void dhk_tile_qv(hipStream_t st, const DhLa *las, const uint16_t *trace, const int32_t *la_first,
                  const int64_t *roff, int32_t nreads, int32_t tspace, const int32_t *cov, int32_t maxtiles,
                  uint8_t *qv);
@@ -1625,7 +1626,9 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
         ao.algo = palgo;
         dh_la_set *pset = nullptr;
         HIPCHK(hipEventRecord(ev[0], st));
-        if (int rc = dh_align_db_ex(ctx, pile, pile, &ao, 0, 0, &pset)) return rc;
+        // (2: the trace values stay on the device -- the tile QVs read them there, the first consensus round fetches the
+        // overlaps of the reference reads only, 1 / n of them)
+        if (int rc = dh_align_db_ex(ctx, pile, pile, &ao, 0, 2, &pset)) return rc;
         sg.sets.push_back(pset);
         lap("pile align call");
         bool grouped = true;  // the symmetric wave kernel already emits grouped by A read
@@ -1873,7 +1876,41 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
             HIPCHK(hipEventRecord(ev[0], st));
             dh_db *nT = nullptr;
             int64_t nseg = 0, ncell = 0;
-            if (int rc = consensus_round(ctx, T, pile, pl, pset->trace, tmpl_of, tsp, &nT, &nseg, &ncell)) return rc;
+            if (pset->d_trace_len > 0) {
+                // the overlaps of the reference reads and their trace values, gathered on the device
+                std::vector<size_t> tsel;
+                for (size_t i = 0; i < pl.size(); i++)
+                    if (tmpl_of[i] >= 0) tsel.push_back(i);
+                LaVec tl(tsel.size());
+                std::vector<int32_t> ttm(tsel.size());
+                std::vector<int64_t, PinnedAlloc<int64_t>> desc(3 * tsel.size());
+                int64_t tot = 0;
+                for (size_t q = 0; q < tsel.size(); q++) {
+                    tl[q] = pl[tsel[q]];
+                    ttm[q] = tmpl_of[tsel[q]];
+                    desc[3 * q] = tl[q].toff;
+                    desc[3 * q + 1] = tot;
+                    desc[3 * q + 2] = tl[q].tlen;
+                    if (tl[q].toff < 0 || tl[q].toff + tl[q].tlen > pset->d_trace_len)
+                        return dh_fail(DH_EINVAL, "process: trace range outside the pile-up alignment's trace");
+                    tl[q].toff = tot;
+                    tot += tl[q].tlen;
+                }
+                TraceVec ttrace((size_t)tot);
+                DevBuf<int64_t> d_desc;
+                DevBuf<uint16_t> d_tt;
+                HIPCHK(d_desc.alloc(desc.size()));
+                HIPCHK(d_tt.alloc((size_t)tot));
+                if (!tsel.empty()) {
+                    HIPCHK(hipMemcpyAsync(d_desc.p, desc.data(), sizeof(int64_t) * desc.size(), hipMemcpyHostToDevice, st));
+                    dhk_gather_ranges16(st, pset->d_trace, d_desc.p, (int32_t)tsel.size(), d_tt.p);
+                    HIPCHK(hipGetLastError());
+                    HIPCHK(hipMemcpyAsync(ttrace.data(), d_tt.p, sizeof(uint16_t) * (size_t)tot, hipMemcpyDeviceToHost, st));
+                }
+                HIPCHK(hipStreamSynchronize(st));
+                if (int rc = consensus_round(ctx, T, pile, tl, ttrace, ttm, tsp, &nT, &nseg, &ncell)) return rc;
+            } else if (int rc = consensus_round(ctx, T, pile, pl, pset->trace, tmpl_of, tsp, &nT, &nseg, &ncell))
+                return rc;
             dbg.dbs.push_back(nT);
             T = nT;
             ps.counters[1] += nseg;

@@ -215,6 +215,77 @@ def test_grouped_index_counted_in_lds_equals_the_atomic_passes(gpu_ctx, monkeypa
     assert_same_las((las2, trace2), (las, trace))
 
 
+def grouped_piles(seeds=(51, 52, 53, 54), sizes=(10, 7, 14, 1), gid=(0, 1, 3, 4), extra=None):
+    ps = [pile(sd, n=n) for sd, n in zip(seeds, sizes)]
+    if extra is not None:
+        ps.append(extra[0])
+        gid = tuple(gid) + (extra[1],)
+    off = [np.zeros(1, dtype=np.int64)]
+    for p in ps:
+        off.append(p.off[1:] + off[-1][-1])
+    return sim.SeqDb(np.concatenate([p.bases for p in ps]), np.concatenate(off),
+                     group=np.concatenate([np.full(p.n, g, dtype=np.int32) for p, g in zip(ps, gid)]))
+
+
+@pytest.mark.parametrize("k,mod,ss", [(14, 1, 2), (12, 1, 2), (16, 2, 2), (14, 1, 1), (14, 3, 0), (9, 1, 2)])
+def test_pile_up_kmer_join_equals_the_directory_lookups(gpu_ctx, monkeypatch, k, mod, ss):
+    """A grouped DB against itself is seeded by the per-pile-up k-mer join (k_join_part / k_join: entries binned per
+    group and slice, chained in an LDS table, hits written per B read) -- the same multiset of hits as the directory
+    lookups (DH_NO_JOIN=1) and as the oracle: hit / candidate / cell counters and every record and trace value.
+    skip_self 0 / 1 / 2, sampled k-mers, k = 16 (32-bit k-mers filled), empty group ids, a group of one read."""
+    both = grouped_piles()
+    kw = dict(tspace=126, skip_self=ss, min_len=500, max_la=64, max_cand=128, k=k, kmer_mod=mod)
+    if k == 9:
+        kw["tcap"] = 20  # short k-mers repeat inside a pile-up: the -t cap decides per orientation class
+    las, trace = run_both(gpu_ctx, both, both, same=True, **kw)
+    assert len(las) > 0 and np.all(both.group[las["aread"]] == both.group[las["bread"]])
+    monkeypatch.setenv("DH_NO_JOIN", "1")
+    las2, trace2 = run_both(gpu_ctx, both, both, same=True, **kw)
+    assert_same_las((las2, trace2), (las, trace))
+
+
+def test_kmer_join_reruns_with_a_larger_hit_buffer_and_masks_and_strands(gpu_ctx, monkeypatch):
+    """The hit buffer is sized from an estimate; when it is too small the join reports the size it needs and runs
+    again (DH_JOIN_HITCAP forces that).  Soft masks (DBdust's role) exclude k-mers on both sides; strands = 1 / 2
+    restrict the hits to one orientation class."""
+    both = grouped_piles()
+    rng = np.random.default_rng(11)
+    ptr, iv = [0], []
+    for i in range(both.n):
+        n, pos = both.length(i), 0
+        while True:
+            pos += int(rng.integers(100, 1500))
+            ln = int(rng.integers(5, 200))
+            if pos + ln >= n:
+                break
+            iv += [pos, pos + ln]
+            pos += ln
+        ptr.append(len(iv) // 2)
+    both.mask = (np.asarray(ptr, dtype=np.int64), np.asarray(iv + [0, 0], dtype=np.int32))
+    monkeypatch.setenv("DH_JOIN_HITCAP", "1000")
+    for strands in (3, 1, 2):
+        run_both(gpu_ctx, both, both, same=True, tspace=126, skip_self=2, min_len=500, max_la=64, max_cand=128,
+                 strands=strands)
+
+
+def test_kmer_join_falls_back_when_a_slice_overflows(gpu_ctx, monkeypatch, capfd):
+    """A k-mer with thousands of copies in one pile-up (a satellite the low-complexity mask does not catch) lands in
+    ONE slice and overflows its LDS table: the call takes the directory path, results as the oracle's."""
+    rng = np.random.default_rng(3)
+    unit = np.asarray([0, 1, 2, 3, 1, 0, 2, 2, 3, 0, 1], dtype=np.uint8)
+    sat = np.tile(unit, 560)  # 6 160 bases of period 11: every one of its 11 k-mers 560 times per read, 4 480 per pile-up
+    reads = []
+    for i in range(8):
+        r = rng.integers(0, 4, 9000).astype(np.uint8)
+        r[1000:1000 + len(sat)] = sat
+        reads.append(r)
+    extra = sim.SeqDb.from_list(reads)
+    both = grouped_piles(seeds=(61,), sizes=(6,), gid=(0,), extra=(extra, 1))
+    monkeypatch.setenv("DH_TRACE", "1")
+    run_both(gpu_ctx, both, both, same=True, tspace=126, skip_self=2, min_len=500, max_la=64, max_cand=128, tcap=64)
+    assert "falling back to the k-mer directory" in capfd.readouterr().err
+
+
 def test_edge_cases_empty_short_and_n_reads(gpu_ctx):
     g = sim.genome(5, 30000)
     rd, _ = sim.reads(6, g, 20, 3000)
