@@ -32,6 +32,7 @@ int dh_fail(int code, const std::string &msg)
 #ifdef DH_SEED_PROF
 extern "C" void dhk_seed_prof_dump();
 extern "C" void dhk_join_prof_dump();
+extern "C" void dhk_tile_prof_dump();
 #endif
 // ------------------------------------------------------------------------------------ allocator
 #include <map>
@@ -1935,6 +1936,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     if (getenv("DH_TRACE")) {
         dhk_seed_prof_dump();
         dhk_join_prof_dump();
+        dhk_tile_prof_dump();
     }
 #endif
     if (getenv("DH_TRACE"))

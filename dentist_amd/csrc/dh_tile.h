@@ -115,6 +115,16 @@ struct Cold {
 };
 
 struct Lane {
+#if defined(DH_SEED_PROF) && defined(__HIPCC__)
+    unsigned long long pt[6];  // development: cycles inside the sections of lane_ext_end
+#endif
+#if defined(DH_SEED_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#define LP_BEGIN unsigned long long lp_ = clock64();
+#define LP(i) { const unsigned long long t_ = clock64(); l.pt[i] += t_ - lp_; lp_ = t_; }
+#else
+#define LP_BEGIN
+#define LP(i)
+#endif
     int32_t st;
     int32_t dir;   // 1 = reverse extension (runs first), 0 = forward
     int32_t roff;  // 1: the seed is not on a trace boundary (the two first tiles share a trace interval)
@@ -551,6 +561,7 @@ DH_HD void lane_ext_end(Lane &l, const Params &P)
 {
     Ext &e = l.e;
     Cold &c = *l.c;
+    LP_BEGIN
     if (l.err) {
         l.st = L_DONE;
         return;
@@ -564,6 +575,7 @@ DH_HD void lane_ext_end(Lane &l, const Params &P)
         c.rv_khi = e.bkhi;
         c.rv_pair1 = e.best_pair1;
         ext_begin(l, P, 0);
+        LP(0)
         return;
     }
     const bool sym = P.o.skip_self == 2;
@@ -586,12 +598,14 @@ DH_HD void lane_ext_end(Lane &l, const Params &P)
         g[6] = hi;
         c.nd += 1;
     }
+    LP(1)
     const int64_t al = aepos - abpos, bl = bepos - bbpos;
     const bool accept = al >= P.o.min_len && (int64_t)2 * diffs * 1000000ll <= (int64_t)P.o.max_err_ppm * (al + bl);
     if (accept) {
         uint16_t *pairs = e.pairs;
         int32_t first;
         const int32_t npairs = finish_pairs(l, P, pairs, &first);
+        LP(2)
         DhLa la;
         la.tlen = 2 * npairs;
         la.diffs = diffs;
@@ -615,15 +629,18 @@ DH_HD void lane_ext_end(Lane &l, const Params &P)
             const int32_t item_a = 2 * c_aseq + strand;
             emit_claimed(P, mode ? item : item_a, mode ? item_a : item, la, pairs, first, npairs);
         }
+        LP(3)
         if (mode == 0) c.nacc += 1;
         if ((sym || P.out_la2) && mode == 0) {  // the second record: the transposed pair, aligned on its own
             cand_geometry(l, P, 1);
             ext_begin(l, P, 1);
+            LP(4)
             return;
         }
     }
     c.c += 1;
     l.st = L_CAND;
+    LP(5)
 }
 
 }  // namespace dhtile

@@ -10,6 +10,7 @@
 // 8-byte pairs of the plane-packed read and nine dwords of the 2-bit packed contig, one 4-byte trace
 // pair out.  Nothing is staged in LDS -- the working set of a lane is its registers.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 
 #include "dh_tile.h"
 
@@ -29,25 +30,72 @@ __device__ __forceinline__ int32_t wave_max_i32(int32_t v)
     return v;
 }
 
+#ifdef DH_SEED_PROF
+// development: where a wavefront's time goes -- [0] bookkeeping passes (wall), [1] tile set-up, [2] column loops,
+// [3] tile ends, [4] passes, [5] rounds, [6] lanes in the rounds, [7] lane-passes (lanes wanting a pass, summed)
+__device__ unsigned long long g_tile_prof[18];
+#define TP(i) { const unsigned long long t_ = clock64(); pacc_[i] += t_ - tp_; tp_ = t_; }
+#define TPC(i, v) pacc_[i] += (unsigned long long)(v);
+extern "C" void dhk_tile_prof_dump()
+{
+    unsigned long long h[18];
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tile_prof), sizeof(h));
+    if (h[5])
+        fprintf(stderr, "[tile prof] ext_end sections (G cycles, max lane per wave): rev->fwd %.2f region %.2f finish_pairs %.2f emit %.2f second %.2f tail %.2f\n",
+                h[12] / 1e9, h[13] / 1e9, h[14] / 1e9, h[15] / 1e9, h[16] / 1e9, h[17] / 1e9);
+    if (h[5])
+        fprintf(stderr, "[tile prof] pass split (G wave cycles): ext_end %.2f next_cand %.2f fetch %.2f next_cand2 %.2f\n", h[8] / 1e9, h[9] / 1e9, h[10] / 1e9, h[11] / 1e9);
+    if (h[5])
+        fprintf(stderr, "[tile prof] wave cycles (G, summed over waves): book %.2f setup %.2f columns %.2f ends %.2f; passes %llu rounds %llu "
+                        "lanes/round %.1f lanes/pass %.1f; per pass %.0f cycles, per round %.0f cycles\n",
+                h[0] / 1e9, h[1] / 1e9, h[2] / 1e9, h[3] / 1e9, h[4], h[5], (double)h[6] / h[5], (double)h[7] / (h[4] ? h[4] : 1),
+                (double)h[0] / (h[4] ? h[4] : 1), (double)(h[1] + h[2] + h[3]) / h[5]);
+    unsigned long long z[18] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tile_prof), z, sizeof(z));
+}
+#else
+#define TP(i)
+#define TPC(i, v)
+#endif
+
 __global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
 {
     __shared__ uint32_t s_q[NTW][64];
+#ifdef DH_SEED_PROF
+    unsigned long long pacc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tp_ = clock64();
+#endif
     Lane l;
     const int32_t slot = (int32_t)(blockIdx.x * 64 + threadIdx.x);
     lane_init(l, slot, P.cold + slot);
+#ifdef DH_SEED_PROF
+    for (int i = 0; i < 6; i++) l.pt[i] = 0;
+#endif
     Tile t;
     for (;;) {
         // ---- bookkeeping until every lane extends or is out of work.  A pass costs a handful of dependent memory
         // round trips whatever the number of lanes in it, so it waits until P.book_min lanes want one (or nothing
         // else can run): short extensions (pile-up reads) would otherwise pay a pass on every round
         const unsigned long long want = __builtin_amdgcn_ballot_w64(l.st != L_RUN && l.st != L_DONE);
+        if (want != 0ull) { TPC(4, 1) TPC(7, __builtin_popcountll(want)) }
+#ifdef DH_SEED_PROF
+        tp_ = clock64();
+#endif
         if (want != 0ull && (__builtin_popcountll(want) >= P.book_min || !wave_any(l.st == L_RUN)))
         // the states are visited in the order a lane moves through them (end of an extension -> next candidate ->
         // next work unit -> its first candidate), so that one pass takes a lane all the way to its next extension:
         // as exclusive branches this chain took four passes, each paying the round trips of every branch in it
         while (wave_any(l.st != L_RUN && l.st != L_DONE)) {
+#ifdef DH_SEED_PROF
+            unsigned long long tq_ = clock64();
+#define TQ(i) { const unsigned long long t_ = clock64(); pacc_[i] += t_ - tq_; tq_ = t_; }
+#else
+#define TQ(i)
+#endif
             if (l.st == L_EXT_END) lane_ext_end(l, P);
+            TQ(8)
             if (l.st == L_CAND) lane_next_cand(l, P);
+            TQ(9)
             if (l.st == L_FETCH) {
                 const int32_t it = (int32_t)atomicAdd(P.queue, 1u);
                 if (it >= (P.units ? (int32_t)*P.nunits : P.nitems))
@@ -55,10 +103,14 @@ __global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
                 else
                     lane_fetch(l, P, it);
             }
+            TQ(10)
             if (l.st == L_CAND) lane_next_cand(l, P);
+            TQ(11)
         }
         const bool run = l.st == L_RUN;
+        TP(0)
         if (!wave_any(run)) break;
+        TPC(5, 1) TPC(6, __builtin_popcountll(__builtin_amdgcn_ballot_w64(run)))
         // ---- one tile of every extending lane.  Its sequence words go to LDS, [word][lane]: the column loop
         // keeps three words of either plane and two of A in registers per block of 32 columns
         if (run) {
@@ -68,6 +120,7 @@ __global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
             for (int i = 0; i < NTW; i++) s_q[i][threadIdx.x] = q[i];
         }
         const int32_t cmax = wave_max_i32(run ? t.cols : 0);
+        TP(1)
         for (int32_t blk = 0; 32 * blk < cmax; blk++) {
             const uint32_t a0 = s_q[blk][threadIdx.x], a1 = s_q[blk + 1][threadIdx.x], a2 = s_q[blk + 2][threadIdx.x];
             const uint32_t b0 = s_q[NQ + blk][threadIdx.x], b1 = s_q[NQ + blk + 1][threadIdx.x], b2 = s_q[NQ + blk + 2][threadIdx.x];
@@ -83,8 +136,22 @@ __global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
                 }
             }
         }
+        TP(2)
         if (run) tile_end(l, P, t);
+        TP(3)
     }
+#ifdef DH_SEED_PROF
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 12; i++) atomicAdd(&g_tile_prof[i], pacc_[i]);
+    for (int i = 0; i < 6; i++) {  // sections of lane_ext_end: the lanes of a pass run them together, so the largest lane total ~ the wavefront's
+        unsigned long long v = l.pt[i];
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o2 = __shfl_xor(v, off, 64);
+            v = o2 > v ? o2 : v;
+        }
+        if (threadIdx.x == 0) atomicAdd(&g_tile_prof[12 + i], v);
+    }
+#endif
     if (l.cells) atomicAdd(&P.counters[0], (unsigned long long)l.cells);
     if (l.naln) atomicAdd(&P.counters[1], (unsigned long long)l.naln);
     if (l.err) atomicOr(P.status, l.err);
