@@ -1376,8 +1376,13 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     SCR(6, d_pool, (size_t)nslots * poolcap)
     SCR(7, d_cdj, (size_t)nslots * 8 * nbmax)
     SCR(8, d_queue, 4)
-    SCR(9, d_la, (size_t)cn * o.max_la)
-    SCR(10, d_trslots, (size_t)cn * o.max_la * trmax)
+    // (symmetric DH-2 launches keep their records in candidate-indexed slots, sized once the candidates are counted)
+    const bool sym_tiled = tiled && o.skip_self == 2;
+    if (!sym_tiled) {
+        SCR(9, d_la, (size_t)cn * o.max_la)
+        SCR(10, d_trslots, (size_t)cn * o.max_la * trmax)
+    } else
+        d_la = nullptr, d_trslots = nullptr;
     SCR(11, d_counters, 2)
     SCR(12, d_sums, (size_t)cn / 2048 + 4)
     unsigned long long *d_summary;
@@ -1385,9 +1390,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     int32_t *d_ovf;
     SCR(29, d_ovf, cn)
     int32_t *d_regs = nullptr;
-    uint16_t *d_tscr = nullptr;
     if (tiled) SCR(32, d_regs, (size_t)tile_waves * 64 * dhtile::MAXREG * dhtile::REGF)
-    if (tiled && o.skip_self == 2) SCR(33, d_tscr, (size_t)tile_waves * 64 * trmax)
     dhtile::Cold *d_cold = nullptr;
     if (tiled) SCR(34, d_cold, (size_t)tile_waves * 64)
     DhLa *d_la2 = nullptr, *d_laout2 = nullptr;
@@ -1567,8 +1570,8 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         }
         // per-chunk arrays are indexed by absolute item inside the kernels: shift the bases
         DhCand *candbase = d_cand - item0 * o.max_cand;
-        DhLa *labase = d_la - item0 * o.max_la;
-        uint16_t *trbase = d_trslots - item0 * (int64_t)o.max_la * trmax;
+        DhLa *labase = d_la ? d_la - item0 * o.max_la : nullptr;
+        uint16_t *trbase = d_trslots ? d_trslots - item0 * (int64_t)o.max_la * trmax : nullptr;
         int32_t *ncandbase = d_ncand - item0, *nhitsbase = d_nhits - item0;
         int32_t *nlabase = (int32_t *)d_nla - item0, *ntrbase = (int32_t *)d_ntr - item0;
         lap(0);
@@ -1658,12 +1661,31 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         // symmetric all-vs-all: one work unit per (item, A read) group of candidates instead of per
         // item (k_units); d_queue[3] counts them
         void *d_units = nullptr;
+        uint32_t *d_candoff = nullptr;
+        int32_t *d_reclist = nullptr;
+        int64_t nrec_slots = 0;
+        if (sym_tiled) {
+            // candidate slots: exclusive prefix sums of the items' candidate counts; two record slots per candidate
+            SCR(51, d_candoff, (size_t)ni + 1)
+            dhk_cand_counts(st, d_ncand, ni, d_candoff);
+            dhk_scan(st, d_candoff, (int64_t)ni + 1, d_sums);
+            uint32_t ncand_total = 0;
+            HIPCHK(hipMemcpyAsync(&ncand_total, d_candoff + ni, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            nrec_slots = 2 * (int64_t)ncand_total;
+            if (nrec_slots >= INT32_MAX) return fail(DH_EOVERFLOW, "symmetric alignment: more than 2^30 candidates in one call");
+            SCR(9, d_la, (size_t)nrec_slots)
+            SCR(10, d_trslots, (size_t)nrec_slots * trmax)
+            SCR(52, d_reclist, (size_t)nrec_slots)
+            HIPCHK(hipMemsetAsync(d_la, 0, sizeof(DhLa) * (size_t)std::max<int64_t>(nrec_slots, 1), st));
+        }
         if (o.skip_self == 2 && ni > 1) {
             if (tiled) {
                 dhtile::Unit *d_u;
                 SCR(24, d_u, (size_t)ni * (size_t)o.max_cand)  // at most one unit per candidate
                 d_units = d_u;
-                dhk_tile_units(st, candbase, ncandbase, (int32_t)item0, ni, o.max_cand, A->d_off, B->d_off, d_u, d_queue + 3);
+                dhk_tile_units(st, candbase, ncandbase, (const int32_t *)d_candoff - item0, (int32_t)item0, ni, o.max_cand, A->d_off,
+                               B->d_off, d_u, d_queue + 3);
             } else {
                 int4 *d_u;
                 SCR(24, d_u, (size_t)ni * (size_t)o.max_cand)
@@ -1710,16 +1732,15 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             tp.queue = d_queue;
             tp.units = (const dhtile::Unit *)d_units;
             tp.nunits = d_queue + 3;
-            tp.item_ovf = d_ovf - item0;
-            tp.tscr = d_tscr;
+            tp.candoff = sym_tiled ? (const int32_t *)d_candoff - item0 : nullptr;
             tp.book_min = 1;
             if (const char *e = getenv("DH_TILE_BOOK_MIN")) tp.book_min = std::max(1, std::min(64, atoi(e)));
             tp.regs = d_regs;
             tp.cold = d_cold;
             tp.nbmax = nbmax;
             tp.trmax = trmax;
-            tp.out_la = labase;
-            tp.out_trace = trbase;
+            tp.out_la = sym_tiled ? d_la : labase;
+            tp.out_trace = sym_tiled ? d_trslots : trbase;
             tp.out_nla = nlabase;
             tp.out_ntr = ntrbase;
             tp.counters = d_counters;
@@ -1738,6 +1759,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         stats.wave_launches++;
         HIPCHK(hipEventRecord(ctx->ev[4], st));
         // compaction on the device: exclusive scans of the per-item counts, then one copy kernel
+        if (sym_tiled) dhk_rec_count(st, d_la, nrec_slots, (int32_t)item0, d_nla, d_ntr);  // records per A-read item
         dhk_scan(st, d_nla, (int64_t)ni + 1, d_sums);
         dhk_scan(st, d_ntr, (int64_t)ni + 1, d_sums);
         uint32_t totals[2] = {0, 0};
@@ -1762,7 +1784,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
                     res->ovf_reads.push_back((int32_t)((item0 + it) >> 1));
                 }
         }
-        if (o.skip_self == 2) {  // records dropped for want of slots (> max_la overlaps of one read and strand)
+        auto read_ovf = [&]() -> int {  // items whose records did not fit (DH-1: > max_la slots; DH-2: > 512 per read and strand)
             std::vector<int32_t> h_ovf((size_t)ni);
             HIPCHK(hipMemcpy(h_ovf.data(), d_ovf, sizeof(int32_t) * (size_t)ni, hipMemcpyDeviceToHost));
             for (int32_t it = 0; it < ni; it++)
@@ -1770,7 +1792,10 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
                     stats.overflow_items++;
                     res->ovf_reads.push_back((int32_t)((item0 + it) >> 1));
                 }
-        }
+            return DH_OK;
+        };
+        if (o.skip_self == 2 && !sym_tiled)
+            if (int rc = read_ovf()) return rc;
         lap(3);
         hipEvent_t copied = nullptr;
         if (totals[0] > 0) {
@@ -1779,8 +1804,15 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             SCR(13, d_laout, totals[0])
             SCR(14, d_trout, totals[1])
             const size_t l0 = res->la.size(), t0 = res->trace.size();
-            dhk_compact(st, d_la, d_trslots, trmax, o.max_la, o.skip_self == 2 ? 1 : 0, ni, d_nla, d_ntr, (int64_t)t0,
-                        d_laout, d_trout);
+            if (sym_tiled) {
+                uint32_t *d_cur;
+                SCR(53, d_cur, (size_t)ni)
+                HIPCHK(hipMemsetAsync(d_cur, 0, sizeof(uint32_t) * (size_t)ni, st));
+                dhk_rec_scatter(st, d_la, nrec_slots, (int32_t)item0, d_nla, d_cur, d_reclist);
+                dhk_compact_sym(st, d_la, d_trslots, trmax, d_reclist, ni, d_nla, d_ntr, (int64_t)t0, d_laout, d_trout, d_ovf);
+            } else
+                dhk_compact(st, d_la, d_trslots, trmax, o.max_la, o.skip_self == 2 ? 1 : 0, ni, d_nla, d_ntr, (int64_t)t0,
+                            d_laout, d_trout);
             HIPCHK(hipGetLastError());
             if (l0 == 0 && ni < nitems_total) {
                 // first of several chunks: reserve for the whole call (this chunk's yield + 15 %) so that
@@ -1839,6 +1871,8 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         }
         HIPCHK(hipEventRecord(ctx->ev[5], st));
         HIPCHK(hipStreamSynchronize(st));
+        if (sym_tiled && totals[0] > 0)  // (set by the compaction)
+            if (int rc = read_ovf()) return rc;
         lap(5);
         nchunk_done++;
         if (hook && totals[0] > 0) {

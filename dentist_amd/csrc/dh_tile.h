@@ -48,7 +48,8 @@ struct Unit {
     int32_t it, c0, c1, blen;      // item - item0, candidates [c0, c1) of it, length of the item's read
     int64_t bo, ao;                // base offsets of the read and of the first candidate's A sequence
     int32_t aseq, apos, bpos, alen;  // the first candidate and the length of its A sequence
-    int32_t pad_[4];
+    int32_t cbase;                   // first candidate slot of the item (Params.candoff[item])
+    int32_t pad_[3];
 };
 
 struct Params {
@@ -67,15 +68,22 @@ struct Params {
     uint32_t *queue;                  // work counter
     const Unit *units;                // optional work units (symmetric launches), else NULL: the items are the units
     const uint32_t *nunits;           // their number (device side)
-    int32_t *item_ovf;                // symmetric mode: per item (absolute), set when a record was dropped for want of slots
-    uint16_t *tscr;                   // symmetric mode: nlanes * trmax, the trace pairs of the alignment in flight
+    // symmetric mode: RECORDS IN PLACE.  Candidate c of item i owns the two record slots 2 (candoff[i] + c) + mode
+    // (mode 0: the pair as seeded, 1: the transposed pair) of out_la / out_trace: the trace pairs are written where
+    // the compaction reads them while the alignment runs, the record is one plain store (pad = 1 marks it valid,
+    // the slots are zeroed before the launch).  No slot is claimed, nothing is copied, no atomic sits in a lane's
+    // way -- the claims were returning device-scope atomics on the counter of one read, hit by every lane that
+    // aligned a partner of that read at about the same time, and with in-order vmcnt every later load of the
+    // wavefront queued behind them: 64 % of the wave cycles of the pile-up launch (clocks: profiles/r04_*).
+    // The records are counted and grouped by A read afterwards (k_rec_count / k_rec_scatter / k_compact_sym).
+    const int32_t *candoff;           // per item (absolute): exclusive prefix sum of max(ncand, 0); NULL otherwise
     int32_t *regs;                    // nlanes * MAXREG * REGF
     Cold *cold;                       // nlanes: the lanes' cold state
     int32_t book_min;                 // lanes that must be waiting before a wavefront does a bookkeeping pass (k_tile)
     int32_t nbmax, trmax;             // pairs a direction can yield; u16 values per output slot (>= 2 * (2 * nbmax + 2))
-    DhLa *out_la;                     // max_la records per item (absolute item index)
+    DhLa *out_la;                     // max_la records per item (absolute item index); symmetric mode: two per candidate
     uint16_t *out_trace;              // trmax values per record slot
-    int32_t *out_nla, *out_ntr;       // per item
+    int32_t *out_nla, *out_ntr;       // per item (not used by symmetric launches)
     DhLa *out_la2;                    // transposed records of a mapping (not symmetric mode), laid out like out_la; or NULL
     uint16_t *out_trace2;
     int32_t *out_nla2, *out_ntr2;
@@ -111,7 +119,8 @@ struct Cold {
     // result of the reverse extension
     int32_t rv_i, rv_j, rv_d, rv_nseg, rv_klo, rv_khi;
     uint32_t rv_pair1;
-    int32_t nacc2, ntr2, pad_;  // transposed records of the item (mapping with the transposed file)
+    int32_t nacc2, ntr2;  // transposed records of the item (mapping with the transposed file)
+    int32_t cbase;        // symmetric mode: first candidate slot of the item
 };
 
 struct Lane {
@@ -375,11 +384,11 @@ DH_HD void lane_init(Lane &l, int32_t slot, Cold *cold)
     l.e.pairs = nullptr;
 }
 
-// where the trace pairs of the running candidate go: straight into its output slot, or -- symmetric
-// mode, where the slot is claimed only when the record is accepted -- into the lane's own scratch slot
+// where the trace pairs of the running candidate go: straight into its output slot (symmetric mode: the slot of
+// (candidate, mode))
 DH_HD uint16_t *lane_pairs(const Lane &l, const Params &P)
 {
-    if (P.o.skip_self == 2) return P.tscr + (int64_t)l.slot * P.trmax;
+    if (P.o.skip_self == 2) return P.out_trace + (2 * ((int64_t)l.c->cbase + l.c->c) + l.c->mode) * P.trmax;
     if (l.c->mode) return P.out_trace2 + ((int64_t)l.c->item * P.o.max_la + l.c->nacc2) * P.trmax;
     return P.out_trace + ((int64_t)l.c->item * P.o.max_la + l.c->nacc) * P.trmax;
 }
@@ -426,6 +435,7 @@ DH_HD void lane_fetch(Lane &l, const Params &P, int32_t it)
         c.blen = u.blen;
         c.nd = c.nacc = c.ntr = c.nacc2 = c.ntr2 = 0;
         c.c = u.c0;
+        c.cbase = u.cbase;
         c.c_aseq = u.aseq;
         c.as = u.apos;
         c.bs = u.bpos;
@@ -445,6 +455,7 @@ DH_HD void lane_fetch(Lane &l, const Params &P, int32_t it)
     c.blen = (int32_t)(P.boff[(item >> 1) + 1] - bo);
     c.nd = c.nacc = c.ntr = c.nacc2 = c.ntr2 = 0;
     c.c = 0;
+    c.cbase = P.candoff ? P.candoff[item] : 0;
     l.st = L_CAND;
 }
 
@@ -516,42 +527,6 @@ DH_HD int32_t finish_pairs(const Lane &l, const Params &P, uint16_t *pairs, int3
     const int32_t first = (nr == 0 && l.roff) ? nbmax : lo_idx;  // no reverse segment: the range starts at the seed slot
     *first_out = first;
     return hi_idx - first;
-}
-
-// symmetric mode: claim a record slot of item `it` and move the pairs from the lane's scratch into it
-DH_HD void emit_claimed(const Params &P, int32_t it, int32_t other_item, DhLa la, const uint16_t *pairs, int32_t first,
-                        int32_t npairs)
-{
-    // pairs are moved as 4-byte words; the first 24 (a pile-up overlap has about 21) are loaded before the slot is
-    // claimed, so that the claim and the loads are one memory round trip, not two (dst and pairs are global memory)
-    constexpr int NV = 24;
-    const uint32_t *__restrict__ src = (const uint32_t *)(pairs + 2 * first);
-    uint32_t v[NV];
-#pragma unroll
-    for (int u = 0; u < NV; u++) v[u] = u < npairs ? src[u] : 0u;
-    const int32_t s = DH_ATOMIC_ADD(&P.out_nla[it], 1);
-    if (s >= P.o.max_la) {
-        // more overlaps than slots: the record is dropped, both items are reported (as k_wave2 does)
-        DH_ATOMIC_ADD(&P.out_nla[it], -1);
-        P.item_ovf[it] = 1;
-        P.item_ovf[other_item] = 1;
-        return;
-    }
-    const int64_t oslot = (int64_t)it * P.o.max_la + s;
-    uint32_t *__restrict__ dst = (uint32_t *)(P.out_trace + oslot * P.trmax);
-#pragma unroll
-    for (int u = 0; u < NV; u++)
-        if (u < npairs) dst[u] = v[u];
-    for (int32_t x = NV; x < npairs; x += NV) {
-#pragma unroll
-        for (int u = 0; u < NV; u++) v[u] = x + u < npairs ? src[x + u] : 0u;
-#pragma unroll
-        for (int u = 0; u < NV; u++)
-            if (x + u < npairs) dst[x + u] = v[u];
-    }
-    la.toff = 0;
-    P.out_la[oslot] = la;
-    DH_ATOMIC_ADD(&P.out_ntr[it], 2 * npairs);
 }
 
 // an extension ended: after the reverse one the forward one starts, after the forward one the candidate
@@ -626,8 +601,8 @@ DH_HD void lane_ext_end(Lane &l, const Params &P)
             P.out_la[(int64_t)item * P.o.max_la + c.nacc] = la;
             c.ntr += 2 * npairs;
         } else {
-            const int32_t item_a = 2 * c_aseq + strand;
-            emit_claimed(P, mode ? item : item_a, mode ? item_a : item, la, pairs, first, npairs);
+            la.pad = 1;  // valid (the slots start zeroed); grouped by A read after the launch
+            P.out_la[2 * ((int64_t)c.cbase + c.c) + mode] = la;
         }
         LP(3)
         if (mode == 0) c.nacc += 1;
@@ -655,8 +630,16 @@ int32_t dhk_tile_waves_per_cu(void);
 void dhk_pk2planes(hipStream_t st, void *words, int64_t nwords);
 // work units of a symmetric launch: the candidates of every item grouped by A read (items with more than 64
 // candidates stay whole); units must hold nitems * max_cand records, *nunits counts them (zeroed by the caller)
-void dhk_tile_units(hipStream_t st, const DhCand *cand, const int32_t *ncand, int32_t item0, int32_t nitems, int32_t max_cand,
-                    const int64_t *aoff, const int64_t *boff, dhtile::Unit *units, uint32_t *nunits);
+void dhk_tile_units(hipStream_t st, const DhCand *cand, const int32_t *ncand, const int32_t *candoff, int32_t item0, int32_t nitems,
+                    int32_t max_cand, const int64_t *aoff, const int64_t *boff, dhtile::Unit *units, uint32_t *nunits);
+// symmetric launches (records in candidate-indexed slots): out[i] = max(ncand[i], 0) for the exclusive scan that yields
+// candoff; records per A-read item; their slot ids grouped by item; ordered compaction
+void dhk_cand_counts(hipStream_t st, const int32_t *ncand, int32_t nitems, uint32_t *out);
+void dhk_rec_count(hipStream_t st, const DhLa *slots, int64_t nslots, int32_t item0, uint32_t *nla, uint32_t *ntr);
+void dhk_rec_scatter(hipStream_t st, const DhLa *slots, int64_t nslots, int32_t item0, const uint32_t *la_off, uint32_t *cursor,
+                     int32_t *list);
+void dhk_compact_sym(hipStream_t st, const DhLa *slots, const uint16_t *tr_slots, int32_t trmax, const int32_t *list, int32_t nitems,
+                     const uint32_t *la_off, const uint32_t *tr_off, int64_t tr_base, DhLa *la_out, uint16_t *tr_out, int32_t *item_ovf);
 #ifdef __cplusplus
 }
 #endif

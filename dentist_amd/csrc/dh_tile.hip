@@ -96,12 +96,23 @@ __global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
             TQ(8)
             if (l.st == L_CAND) lane_next_cand(l, P);
             TQ(9)
-            if (l.st == L_FETCH) {
-                const int32_t it = (int32_t)atomicAdd(P.queue, 1u);
-                if (it >= (P.units ? (int32_t)*P.nunits : P.nitems))
-                    l.st = L_DONE;
-                else
-                    lane_fetch(l, P, it);
+            {
+                // one atomic per wavefront and pass for all lanes that want a work unit (every lane on its own made
+                // 1.75 M returning atomics on one address per pile-up launch)
+                const unsigned long long fm = __builtin_amdgcn_ballot_w64(l.st == L_FETCH);
+                if (fm != 0ull) {
+                    const int first = __builtin_ctzll(fm);
+                    uint32_t base = 0;
+                    if ((int)threadIdx.x == first) base = atomicAdd(P.queue, (uint32_t)__builtin_popcountll(fm));
+                    base = (uint32_t)__shfl((int)base, first, 64);
+                    if (l.st == L_FETCH) {
+                        const int32_t it = (int32_t)(base + (uint32_t)__builtin_popcountll(fm & ((1ull << threadIdx.x) - 1ull)));
+                        if (it >= (P.units ? (int32_t)*P.nunits : P.nitems))
+                            l.st = L_DONE;
+                        else
+                            lane_fetch(l, P, it);
+                    }
+                }
             }
             TQ(10)
             if (l.st == L_CAND) lane_next_cand(l, P);
@@ -180,8 +191,9 @@ __global__ void __launch_bounds__(256) k_pk2planes(uint64_t *__restrict__ w, int
 // one thread per item: its candidates (grouped by A read by the seed kernel) become units; an item with more than 64
 // candidates stays one unit (the cap of attempted alignments per item must see them in order), as in k_units
 __global__ void __launch_bounds__(256)
-k_units_fat(const DhCand *__restrict__ cand, const int32_t *__restrict__ ncand, int32_t item0, int32_t nitems, int32_t max_cand,
-            const int64_t *__restrict__ aoff, const int64_t *__restrict__ boff, Unit *__restrict__ units, uint32_t *__restrict__ nunits)
+k_units_fat(const DhCand *__restrict__ cand, const int32_t *__restrict__ ncand, const int32_t *__restrict__ candoff, int32_t item0,
+            int32_t nitems, int32_t max_cand, const int64_t *__restrict__ aoff, const int64_t *__restrict__ boff,
+            Unit *__restrict__ units, uint32_t *__restrict__ nunits)
 {
     const int32_t it = blockIdx.x * blockDim.x + threadIdx.x;
     if (it >= nitems) return;
@@ -209,19 +221,143 @@ k_units_fat(const DhCand *__restrict__ cand, const int32_t *__restrict__ ncand, 
         u.bpos = cl[c0].bpos;
         u.ao = aoff[u.aseq];
         u.alen = (int32_t)(aoff[u.aseq + 1] - u.ao);
-        u.pad_[0] = u.pad_[1] = u.pad_[2] = u.pad_[3] = 0;
+        u.cbase = candoff[item];
+        u.pad_[0] = u.pad_[1] = u.pad_[2] = 0;
         units[atomicAdd(nunits, 1u)] = u;
         c0 = c1;
     }
 }
 
+// ---- symmetric launches: the records sit in candidate-indexed slots (dh_tile.h, Params.candoff); three streaming
+// kernels group them by A read for the compaction -- their atomics run at full occupancy, no lane of k_tile waits on one.
+__global__ void __launch_bounds__(256) k_cand_counts(const int32_t *__restrict__ ncand, int32_t nitems, uint32_t *__restrict__ out)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > nitems) return;
+    out[i] = i < nitems ? (uint32_t)max(ncand[i], 0) : 0u;  // out[nitems] receives the total from the exclusive scan
+}
+// item (relative to item0) that lists a record: the A read's item of the record's strand
+__device__ __forceinline__ int32_t rec_item(const DhLa &la, int32_t item0) { return 2 * la.aread + (int32_t)(la.flags & 1u) - item0; }
+__global__ void __launch_bounds__(256)
+k_rec_count(const DhLa *__restrict__ slots, int64_t nslots, int32_t item0, uint32_t *__restrict__ nla, uint32_t *__restrict__ ntr)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nslots) return;
+    const DhLa la = slots[s];
+    if (la.pad != 1) return;
+    const int32_t it = rec_item(la, item0);
+    atomicAdd(&nla[it], 1u);
+    atomicAdd(&ntr[it], (uint32_t)la.tlen);
+}
+__global__ void __launch_bounds__(256)
+k_rec_scatter(const DhLa *__restrict__ slots, int64_t nslots, int32_t item0, const uint32_t *__restrict__ la_off,
+              uint32_t *__restrict__ cursor, int32_t *__restrict__ list)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nslots) return;
+    const DhLa la = slots[s];
+    if (la.pad != 1) return;
+    const int32_t it = rec_item(la, item0);
+    list[la_off[it] + atomicAdd(&cursor[it], 1u)] = (int32_t)s;
+}
+// a wavefront per item: its records (slot ids in list[la_off[it] ..)) ordered by (bread, abpos, bbpos, aepos, slot) --
+// the order the host's (A, B) pair logic expects, deterministic whatever order the scatter listed them in -- and their
+// trace pairs copied in that order.  More than CS_MAX records of one (read, strand): reported (item_ovf), written unordered.
+#define CS_MAX 512
+__global__ void __launch_bounds__(64)
+k_compact_sym(const DhLa *__restrict__ slots, const uint16_t *__restrict__ tr_slots, int32_t trmax, const int32_t *__restrict__ list,
+              const uint32_t *__restrict__ la_off, const uint32_t *__restrict__ tr_off, int64_t tr_base, DhLa *__restrict__ la_out,
+              uint16_t *__restrict__ tr_out, int32_t *__restrict__ item_ovf)
+{
+    __shared__ uint64_t sk1[CS_MAX], sk2[CS_MAX];
+    __shared__ int32_t stl[CS_MAX], sso[CS_MAX], ssl[CS_MAX], sto[CS_MAX];
+    const int32_t it = blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint32_t l0 = la_off[it], n = la_off[it + 1] - l0;
+    if (n == 0) return;
+    const uint32_t t0 = tr_off[it];
+    if (n > CS_MAX) {
+        if (lane == 0) item_ovf[it] = 1;
+        uint32_t t = t0;
+        for (uint32_t x = 0; x < n; x++) {
+            const int64_t slot = list[l0 + x];
+            DhLa la = slots[slot];
+            const uint16_t *src = tr_slots + slot * trmax + la.toff;
+            for (int32_t e = lane; e < la.tlen; e += 64) tr_out[t + e] = src[e];
+            if (lane == 0) {
+                la.toff = tr_base + t;
+                la.pad = 0;
+                la_out[l0 + x] = la;
+            }
+            t += la.tlen;
+        }
+        return;
+    }
+    for (uint32_t x = (uint32_t)lane; x < n; x += 64) {
+        const int32_t slot = list[l0 + x];
+        const DhLa la = slots[slot];
+        sk1[x] = ((uint64_t)(uint32_t)la.bread << 32) | (uint32_t)la.abpos;
+        sk2[x] = ((uint64_t)(uint32_t)la.bbpos << 32) | (uint32_t)la.aepos;
+        stl[x] = la.tlen;
+        sso[x] = (int32_t)la.toff;
+        ssl[x] = slot;
+    }
+    __syncthreads();
+    for (uint32_t x = (uint32_t)lane; x < n; x += 64) {
+        const uint64_t k1 = sk1[x], k2 = sk2[x];
+        const int32_t sx = ssl[x];
+        int32_t rank = 0, toff = 0;
+        for (uint32_t y = 0; y < n; y++) {
+            const uint64_t y1 = sk1[y], y2 = sk2[y];
+            const bool less = y1 < k1 || (y1 == k1 && (y2 < k2 || (y2 == k2 && ssl[y] < sx)));
+            rank += less ? 1 : 0;
+            toff += less ? stl[y] : 0;
+        }
+        sto[x] = toff;
+        DhLa la = slots[sx];
+        la.toff = tr_base + t0 + toff;
+        la.pad = 0;
+        la_out[l0 + rank] = la;
+    }
+    __syncthreads();
+    for (uint32_t x = 0; x < n; x++) {
+        const int32_t xl = stl[x];
+        const uint16_t *src = tr_slots + (int64_t)ssl[x] * trmax + sso[x];
+        uint16_t *dst = tr_out + t0 + sto[x];
+        for (int32_t e = lane; e < xl; e += 64) dst[e] = src[e];
+    }
+}
+
 extern "C" {
-void dhk_tile_units(hipStream_t st, const DhCand *cand, const int32_t *ncand, int32_t item0, int32_t nitems, int32_t max_cand,
-                    const int64_t *aoff, const int64_t *boff, Unit *units, uint32_t *nunits)
+void dhk_tile_units(hipStream_t st, const DhCand *cand, const int32_t *ncand, const int32_t *candoff, int32_t item0, int32_t nitems,
+                    int32_t max_cand, const int64_t *aoff, const int64_t *boff, Unit *units, uint32_t *nunits)
 {
     if (nitems <= 0) return;
-    hipLaunchKernelGGL(k_units_fat, dim3((nitems + 255) / 256), dim3(256), 0, st, cand, ncand, item0, nitems, max_cand, aoff, boff,
-                       units, nunits);
+    hipLaunchKernelGGL(k_units_fat, dim3((nitems + 255) / 256), dim3(256), 0, st, cand, ncand, candoff, item0, nitems, max_cand, aoff,
+                       boff, units, nunits);
+}
+void dhk_cand_counts(hipStream_t st, const int32_t *ncand, int32_t nitems, uint32_t *out)
+{
+    hipLaunchKernelGGL(k_cand_counts, dim3((nitems + 1 + 255) / 256), dim3(256), 0, st, ncand, nitems, out);
+}
+void dhk_rec_count(hipStream_t st, const DhLa *slots, int64_t nslots, int32_t item0, uint32_t *nla, uint32_t *ntr)
+{
+    if (nslots <= 0) return;
+    hipLaunchKernelGGL(k_rec_count, dim3((uint32_t)((nslots + 255) / 256)), dim3(256), 0, st, slots, nslots, item0, nla, ntr);
+}
+void dhk_rec_scatter(hipStream_t st, const DhLa *slots, int64_t nslots, int32_t item0, const uint32_t *la_off, uint32_t *cursor,
+                     int32_t *list)
+{
+    if (nslots <= 0) return;
+    hipLaunchKernelGGL(k_rec_scatter, dim3((uint32_t)((nslots + 255) / 256)), dim3(256), 0, st, slots, nslots, item0, la_off, cursor,
+                       list);
+}
+void dhk_compact_sym(hipStream_t st, const DhLa *slots, const uint16_t *tr_slots, int32_t trmax, const int32_t *list, int32_t nitems,
+                     const uint32_t *la_off, const uint32_t *tr_off, int64_t tr_base, DhLa *la_out, uint16_t *tr_out, int32_t *item_ovf)
+{
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL(k_compact_sym, dim3((uint32_t)nitems), dim3(64), 0, st, slots, tr_slots, trmax, list, la_off, tr_off, tr_base,
+                       la_out, tr_out, item_ovf);
 }
 void dhk_tile(hipStream_t st, int32_t nwaves, const Params *P)
 {

@@ -61,8 +61,14 @@ extern "C" long dh_tile_host_align2(const uint8_t *abases, const int64_t *aoff, 
     planes(abases, aoff[na], app, PADW);
     planes(arc.data(), aoff[na], arcpp, PADW);
     const int32_t nitems = 2 * nb, trmax = 2 * (2 * nbmax + 2);
-    std::vector<DhLa> slots((size_t)nitems * o->max_la);
-    std::vector<uint16_t> tr((size_t)nitems * o->max_la * trmax, 0);
+    // symmetric mode: records in candidate-indexed slots (two per candidate), as on the device
+    const bool sym = o->skip_self == 2;
+    std::vector<int32_t> candoff((size_t)nitems + 1, 0);
+    for (int32_t it = 0; it < nitems; it++) candoff[(size_t)it + 1] = candoff[(size_t)it] + (ncand[it] > 0 ? ncand[it] : 0);
+    const size_t nslots = sym ? 2 * (size_t)candoff[(size_t)nitems] : (size_t)nitems * o->max_la;
+    std::vector<DhLa> slots(nslots);
+    memset(slots.data(), 0, sizeof(DhLa) * nslots);
+    std::vector<uint16_t> tr(nslots * trmax, 0);
     std::vector<int32_t> nla((size_t)nitems, 0), ntr((size_t)nitems, 0), regs((size_t)MAXREG * REGF, 0);
     uint32_t queue = 0;
     int32_t status = 0;
@@ -93,10 +99,7 @@ extern "C" long dh_tile_host_align2(const uint8_t *abases, const int64_t *aoff, 
     P.book_min = 1;
     P.units = nullptr;
     P.nunits = nullptr;
-    std::vector<int32_t> ovf((size_t)nitems, 0);
-    std::vector<uint16_t> tscr((size_t)trmax, 0);
-    P.item_ovf = ovf.data();
-    P.tscr = tscr.data();
+    P.candoff = sym ? candoff.data() : nullptr;
     P.regs = regs.data();
     P.nbmax = nbmax;
     P.trmax = trmax;
@@ -141,6 +144,19 @@ extern "C" long dh_tile_host_align2(const uint8_t *abases, const int64_t *aoff, 
     counters[0] = l.cells;
     counters[1] = l.naln;
     long n = 0, tn = 0;
+    if (sym) {
+        for (size_t x = 0; x < nslots; x++) {
+            DhLa la = slots[x];
+            if (la.pad != 1) continue;
+            const uint16_t *src = tr.data() + x * trmax + la.toff;
+            if (tn + la.tlen > cap_trace) return -100;
+            memcpy(out_trace + tn, src, sizeof(uint16_t) * (size_t)la.tlen);
+            la.toff = tn;
+            la.pad = 0;
+            tn += la.tlen;
+            out_la[n++] = la;
+        }
+    } else
     for (int32_t it = 0; it < nitems; it++)
         for (int32_t s = 0; s < nla[(size_t)it]; s++) {
             DhLa la = slots[(size_t)it * o->max_la + s];
