@@ -768,7 +768,12 @@ static int build_index(dh_db *A, int32_t k, int32_t sepv, int32_t kmer_mod, bool
         int32_t *&p;
         ~GtGuard() { dh_dev_free(p); }
     } gtg{d_gtile};
-    if (A->d_group && A->ngroups > 1 && ix.shift <= 2 * k && !getenv("DH_INDEX_ATOMICS")) {
+    // (a small grouped DB -- the templates of a consensus round: 500 sequences -- takes the generic passes: a block per
+    // group and slice that zeroes and writes back 128 KB of LDS counters cost 8.6 ms per step at configs[2] for 1.3 M
+    // k-mers; DH_INDEX_LDS_MIN overrides the threshold, tests run both paths)
+    int64_t gi_min = 1 << 24;
+    if (const char *e = getenv("DH_INDEX_LDS_MIN")) gi_min = atoll(e);
+    if (A->d_group && A->ngroups > 1 && ix.shift <= 2 * k && nk >= gi_min && !getenv("DH_INDEX_ATOMICS")) {
         const int64_t nbg = 1ll << (2 * k - ix.shift);
         gi_slice = (int32_t)std::min<int64_t>(nbg, DH_GI_SLICE);
         gi_slices = (int32_t)(nbg / gi_slice);
@@ -1524,9 +1529,11 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         while (cap < 8192 && 0.6 * B->max_len > cap) cap *= 2;
     }
     if (use_join) {
-        // the hits are counted already: the smallest LDS capacity that leaves at most 1 % of the reads to the HBM-staged
-        // variant (a whole second pass with the next size cost 9.5 ms at configs[2] when the guess was one size short)
-        const unsigned int tol = (unsigned int)(B->n / 100);
+        // the hits are counted already (a whole second pass with the next size cost 9.5 ms at configs[2] when the guess
+        // was one size short)
+        // (tiers: reads above the first capacity are redone by the 8192-entry variant, reads above that from HBM -- so
+        // the first tier is the smallest one that serves at least 70 % of the reads)
+        const unsigned int tol = (unsigned int)(0.3 * B->n);
         cap = jhist[0] <= tol ? 2048 : (jhist[1] <= tol ? 4096 : 8192);
     }
     if (const char *e = getenv("DH_SEED_CAP")) cap = atoi(e);  // development: 1024 .. 16384, power of two
@@ -1582,7 +1589,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             SCR(30, d_fscr, (size_t)ctx->ncu * DH_SEED_FSCR_BLOCKS_PER_CU * DH_SEED_FSCR_WORDS)
         if (use_join)
             dhk_seed_join(st, cap, bv, iv, dopt, jv, (int32_t)item0, ni, candbase, ncandbase, nhitsbase, d_status,
-                          d_queue + 1, ctx->ncu, d_fscr);
+                          d_queue + 1, ctx->ncu, d_fscr, nullptr, 0);
         else
             dhk_seed(st, cap, bv, iv, dopt, (int32_t)item0, ni, candbase, ncandbase, nhitsbase, d_status,
                      d_queue + 1, ctx->ncu, d_fscr);
@@ -1615,10 +1622,41 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             if (const char *e = getenv("DH_SEED_BIG_PCT")) redo_all = (size_t)((double)ni * atof(e) / 200.0);  // development (reads = ni / 2)
             if (getenv("DH_TRACE") && !big.empty())
                 fprintf(stderr, "[seeds] cap %d: %zu of %d reads overflow (whole chunk again above %zu)\n", cap, big.size(), ni / 2, redo_all);
-            if (big.size() > redo_all && cap < (use_join ? 8192 : 16384)) {
+            if (!use_join && big.size() > redo_all && cap < 16384) {
                 cap *= 2;
                 item0 -= cn;
                 continue;
+            }
+            if (use_join && cap < 8192 && !big.empty()) {
+                // second tier of the join path: the reads above the first capacity that fit the 8192-entry variant
+                std::vector<int32_t> mid, huge;
+                int32_t gcap2 = 0;
+                for (int32_t r : big) {
+                    const size_t it = (size_t)(2 * (int64_t)r - item0);
+                    const int32_t nh = h_nhits[it] + h_nhits[it + 1];
+                    if (nh <= 8192)
+                        mid.push_back(r);
+                    else {
+                        huge.push_back(r);
+                        gcap2 = std::max(gcap2, nh);
+                    }
+                }
+                if (!mid.empty()) {
+                    int32_t *d_mid;
+                    uint64_t *d_fscr2;
+                    SCR(54, d_mid, mid.size())
+                    SCR(30, d_fscr2, (size_t)ctx->ncu * DH_SEED_FSCR_BLOCKS_PER_CU * DH_SEED_FSCR_WORDS)
+                    HIPCHK(hipMemcpyAsync(d_mid, mid.data(), sizeof(int32_t) * mid.size(), hipMemcpyHostToDevice, st));
+                    HIPCHK(hipMemsetAsync(d_queue + 1, 0, sizeof(uint32_t), st));
+                    dhk_seed_join(st, 8192, bv, iv, dopt, jv, (int32_t)item0, ni, candbase, ncandbase, nhitsbase, d_status,
+                                  d_queue + 1, ctx->ncu, d_fscr2, d_mid, (int32_t)mid.size());
+                    HIPCHK(hipGetLastError());
+                    HIPCHK(hipStreamSynchronize(st));  // mid goes out of scope
+                }
+                if (getenv("DH_TRACE"))
+                    fprintf(stderr, "[seeds] join tiers: %zu reads redone with 8192 entries, %zu from HBM\n", mid.size(), huge.size());
+                big.swap(huge);
+                gcap = gcap2;
             }
             if (!big.empty()) {
                 if (gcap > (1 << 22)) return fail(DH_EOVERFLOW, "seed filter: more than 4M k-mer hits for one sequence; lower -t");

@@ -76,7 +76,7 @@ void dhk_join_hist(hipStream_t st, JoinView jv, const int32_t *group, int32_t nr
 /* the seed filter's back end fed from the join's hit segments (cap: LDS hit capacity as in dhk_seed) */
 void dhk_seed_join(hipStream_t st, int cap, DbView B, IndexView ix, DhOpts o, JoinView jv, int32_t item0, int32_t nitems,
                    DhCand *cand, int32_t *ncand, int32_t *nhits, int32_t *status, uint32_t *queue, int32_t ncu,
-                   uint64_t *fscr);
+                   uint64_t *fscr, const int32_t *read_list, int32_t nlist);
 void dhk_seed_big_join(hipStream_t st, DbView B, IndexView ix, DhOpts o, JoinView jv, const int32_t *read_list,
                        int32_t nreads, uint64_t *gbuf, int32_t gcap, DhCand *cand, int32_t *ncand, int32_t *nhits,
                        int32_t *status, uint32_t *queue, int32_t ncu);

@@ -428,7 +428,7 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
     __shared__ int64_t cband[2 * SEED_CCAP];
     __shared__ int32_t s_n, s_nc;
 
-    const int32_t r = LCAP > 0 ? read0 + work : read_list[work];
+    const int32_t r = read_list ? read_list[work] : read0 + work;  // (the HBM variant always works from a list)
     const int32_t item = 2 * r;
     // HBM variant: the block's slab holds gcap hits, gcap 64-bit prefix sums and gcap 32-bit head positions
     uint64_t *hits = LCAP > 0 ? lhits : gbuf + (int64_t)slab * (2 * (int64_t)gcap + (gcap + 1) / 2);
@@ -2691,14 +2691,16 @@ void dhk_seed_big(hipStream_t st, DbView B, IndexView ix, DhOpts o,
 // the same back end fed from the hit segments of the per-pile-up k-mer join (dh_join.hip)
 void dhk_seed_join(hipStream_t st, int cap, DbView B, IndexView ix, DhOpts o, JoinView jv, int32_t item0, int32_t nitems,
                    DhCand *cand, int32_t *ncand, int32_t *nhits, int32_t *status, uint32_t *queue, int32_t ncu,
-                   uint64_t *fscr)
+                   uint64_t *fscr, const int32_t *read_list, int32_t nlist)
 {
-    if (nitems <= 0) return;
-    const int32_t read0 = item0 / 2, nreads = nitems / 2;
+    if (nitems <= 0 || (read_list && nlist <= 0)) return;
+    // read_list (device, nlist absolute read ids): only those reads -- the second tier of the join path, the reads whose
+    // hits overflowed the first tier's LDS buffer
+    const int32_t read0 = item0 / 2, nreads = read_list ? nlist : nitems / 2;
 #define SEED_LAUNCH_J(C)                                                                          \
     hipLaunchKernelGGL((k_seed<C, true>), dim3(seed_grid<C, true>(nreads, ncu)), dim3(SEED_THREADS), 0, st, B, ix, jv, o, \
                        read0, nreads, cand, ncand, nhits, status, C == 8192 ? fscr : (uint64_t *)nullptr,    \
-                       C == 8192 ? DH_SEED_FSCR_WORDS : 0, (const int32_t *)nullptr, queue)
+                       C == 8192 ? DH_SEED_FSCR_WORDS : 0, read_list, queue)
     if (cap <= 2048)
         SEED_LAUNCH_J(2048);
     else if (cap <= 4096)

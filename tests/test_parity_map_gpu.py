@@ -208,6 +208,8 @@ def test_grouped_index_counted_in_lds_equals_the_atomic_passes(gpu_ctx, monkeypa
     both = sim.SeqDb(np.concatenate([p.bases for p in ps]), np.concatenate(off),
                      group=np.concatenate([np.full(p.n, g, dtype=np.int32) for p, g in zip(ps, gid)]))
     kw = dict(tspace=126, skip_self=2, min_len=500, max_la=64, max_cand=128, k=k, kmer_mod=mod)
+    monkeypatch.setenv("DH_NO_JOIN", "1")         # the directory path (a grouped DB against itself takes the k-mer join otherwise)
+    monkeypatch.setenv("DH_INDEX_LDS_MIN", "0")   # ... with the LDS-counted passes whatever the size of the DB
     las, trace = run_both(gpu_ctx, both, both, same=True, **kw)
     assert len(las) > 0 and np.all(both.group[las["aread"]] == both.group[las["bread"]])
     monkeypatch.setenv("DH_INDEX_ATOMICS", "1")
