@@ -42,7 +42,39 @@ WORKLOADS = {
     # reduced shape for quick checks (not a bench line)
     "dev_1Mb_10gaps_5kx10kb": dict(genome_len=1_000_000, ngaps=10, nreads=5_000, read_len=10_000),
 }
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+def load_constants():
+    """Ceilings the roofline entries are priced against, with the run each one comes from (profiles/constants.json)."""
+    with open(os.path.join(ROOT, "profiles", "constants.json")) as f:
+        return {k: v["value"] for k, v in json.load(f).items() if isinstance(v, dict)}
+
+
+CONST = load_constants()
+HBM_PEAK_GBS = CONST["hbm_peak_GBs"]  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def kernel_traffic(args, world):
+    """Measured HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE, scripts/profile_round.sh) of THIS build of
+    the kernels on THIS configuration, or (None, None, reason): the newest profiles/*_kernel_traffic.json whose build
+    id (sha1 of the kernel sources) and configuration match.  A figure of another build is never reported."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from traffic_json import kernel_build_id
+    bid = kernel_build_id()
+    if world != 1:
+        return None, None, "N > 1"
+    cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_kernel_traffic.json"))
+    stale = []
+    for name in reversed(cands):
+        tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+        if not (tj.get("workload") == args.workload and tj.get("mapping_kmer_mod") == args.kmer_mod and
+                tj.get("mapping_k") == args.map_k and tj.get("mapping_algo") == args.map_algo):
+            continue
+        if tj.get("kernel_build_id") == bid:
+            return tj.get("k_seed_hbm_bytes_per_launch"), tj.get("k_tile_hbm_bytes_per_launch"), "profiles/" + name
+        stale.append(name)
+    msg = f"no HBM-counter profile of kernel build {bid} for this configuration" + (f" (stale: {', '.join(stale)})" if stale else "")
+    print("bench.py: roofline.traffic = null: " + msg + "; run scripts/profile_round.sh and commit its kernel_traffic.json",
+          file=sys.stderr)
+    return None, None, msg
 
 
 def closed_gap_stats(w, rec, bases):
@@ -71,7 +103,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg2_100Mb_1000gaps_1Mx15kb")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU time budget of the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=40.0, help="CPU time budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kmer-mod", type=int, default=8,
                     help="modimer sampling of the mapping index: one canonical k-mer in kmer_mod is indexed / looked up "
@@ -227,14 +259,7 @@ def main():
         # an algo is 0).  Algorithmic bytes of a launch = both sequences of every alignment it emits streamed once
         # (2 B per aligned A base at one byte per base) + its trace (2 B per trace value)
         achieved = alg_bytes / (wave_ms * 1e-3) / 1e9
-        traffic = seed_traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r03_kernel_traffic.json")
-        if os.path.exists(tpath) and world == 1:
-            tj = json.load(open(tpath))
-            if tj.get("workload") == args.workload and tj.get("mapping_kmer_mod") == args.kmer_mod and \
-                    tj.get("mapping_k") == args.map_k and tj.get("mapping_algo") == args.map_algo:
-                traffic = tj.get("k_tile_hbm_bytes_per_launch")
-                seed_traffic = tj.get("k_seed_hbm_bytes_per_launch")
+        seed_traffic, traffic, traffic_src = kernel_traffic(args, world)
         seed_bytes = 1.0 * read_bp * (1.0 + 64.0 / max(1, args.kmer_mod))
         seed_ms = mean(lambda r: r["ast"].ms_seed)
         out = {
@@ -279,8 +304,8 @@ def main():
                          "frac": seed_bytes / (seed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": seed_traffic,
                          "launches_per_step": int(last["ast"].wave_launches), "kernel_ms_per_step": seed_ms,
                          "avg_launch_ms": seed_ms / max(1, int(last["ast"].wave_launches)),
-                         "algorithmic_bytes_per_step": seed_bytes,
-                         "measured_random_line_ceiling_GBs": 3500.0},
+                         "algorithmic_bytes_per_step": seed_bytes, "traffic_source": traffic_src,
+                         "measured_random_line_ceiling_GBs": CONST["random_line_ceiling_GBs"]},
             # second: the extension kernel, one alignment per lane.  VALU bound (scripts/valu_probe.cpp: 2-cycle class
             # 0.90-0.94, 4-cycle class 0.56-0.58 G wave-instructions/s per SIMD); the HBM fraction is reported as asked
             "roofline_tile": {"bound": "hbm", "kernel": "k_tile" if args.map_algo == 1 else "k_wave2", "achieved": achieved,
@@ -292,9 +317,28 @@ def main():
                               # VALU issue: 74 wave-instructions per 64 lanes x 64 band cells (SQ_INSTS_VALU of the mapping
                               # launches, profiles/r03_final_pmc_sq_counters.txt) against the measured ceiling of
                               # 0.57 G wave-instructions/s per SIMD (scripts/valu_probe.cpp), 1024 SIMDs
-                              "valu_frac": (74.0 * cum["wave_cells"] / 4096.0) / (wave_ms * 1e-3) / (1024 * 0.57e9),
+                              "valu_frac": (CONST["k_tile_valu_wave_instr_per_4096_cells"] * cum["wave_cells"] / 4096.0) /
+                                           (wave_ms * 1e-3) / (CONST["simds"] * CONST["valu_wave_instr_per_s_per_simd"]),
                               "note": "rank 0's launches; integer VALU-issue bound: 70 wave-instructions per 64 band "
                                       "columns, DP cell updates/s is the honest secondary"},
+            # third: the stage the metric is named after.  SURVEY 8(d): per closed gap with n reads of mean cropped length L
+            # the pile-up alignment reads every read once per partner (n (n - 1) L), the consensus once (n L), flanks and
+            # output 2 L -- (n^2 + 2) L bytes; summed over the pile-ups by the library (dh_get_process_work) and divided by
+            # the wall time of the whole stage (crop .. insertions, host phases included).  The stage is integer-VALU work
+            # (k_tile, the seed back end, the bit-parallel consensus NW): the HBM fraction is reported as asked, cells/s
+            # of its k_tile launches is the honest secondary
+            "roofline_process": (lambda pw, pb: {
+                "bound": "hbm", "kernel": "process stage (k_join, k_seed back end, k_tile symmetric, k_seg_vote*)",
+                "achieved": pb / (pw * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": pb / (pw * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_step": pb, "wall_ms_per_step": pw,
+                "pile_ups": last["pst"]["pile_ups"], "entries": last["pst"]["entries"],
+                "mean_entries_per_pile_up": last["pst"]["entries"] / max(1, last["pst"]["pile_ups"]),
+                "mean_cropped_length": last["pst"]["cropped_bases"] / max(1, last["pst"]["entries"]),
+                "k_tile_process_band_cells_per_s": (cum["wave_cells"] - last["ast"].wave_cells) /
+                                                   max(1e-9, (wave_ms - mean(lambda r: r["ast"].ms_wave)) * 1e-3),
+                "note": "rank 0's pile-ups; k_tile time of the two concurrent halves is summed (it overstates the time)"})(
+                    mean(lambda r: r["t_process"]) * 1e3, float(last["pst"]["algorithmic_bytes"])),
             "stages_ms": {"map_wall": mean(lambda r: r["t_map"]) * 1e3,
                           "map_index": mean(lambda r: r["ast"].ms_index),
                           "map_seed": seed_ms,
@@ -305,6 +349,11 @@ def main():
                           "process_wall": mean(lambda r: r["t_process"]) * 1e3,
                           **{"process_" + k[3:]: mean(lambda r, k=k: r["pst"][k]) for k in last["pst"] if k.startswith("ms_")}},
         }
+        # the headline uses two work-reducing knobs the reference does not apply (read cap, modimer sampling): the same
+        # workload at the reference's behaviour, measured by scripts/ref_behaviour.sh on the build named in the file
+        rb = os.path.join(ROOT, "profiles", "reference_behaviour.json")
+        if os.path.exists(rb):
+            out["reference_behaviour"] = json.load(open(rb))
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(w, last, mopts, popts, args, gap_all, read_all)
         print(json.dumps(out))
@@ -352,7 +401,7 @@ def cpu_baseline(w, last, mopts, popts, args, gap_bases, read_bp_total):
     npiles = int(last["info"]["piles"])
     po = oz.default_process_opts(rounds=popts.rounds, max_reads=popts.max_reads, min_reads=popts.min_reads, algo=popts.algo)
     gaps_sorted = [int(r["contig_left"]) for r in rec]
-    budget, batch = 0.5 * args.cpu_seconds, max(cores // 4, 8)
+    budget, batch = 0.5 * args.cpu_seconds, max(cores, 8)   # a pile-up per OpenMP thread and batch
     done, t_proc, used = 0, 0.0, 0
     while done < len(gaps_sorted) and t_proc < budget:
         gs = gaps_sorted[done:done + batch]

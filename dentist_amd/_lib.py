@@ -88,7 +88,7 @@ SYMBOLS = [
     "dh_map_reads", "dh_validate_regions", "dh_propagate_mask", "dh_db_mask_coverage", "dh_max_coverage_reads", "dh_max_improper_coverage_reads",
     "dh_default_scaffold_opts", "dh_scaffold_pileups", "dh_scaffold_npiles", "dh_scaffold_nentries", "dh_scaffold_joins",
     "dh_scaffold_entries", "dh_scaffold_destroy", "dh_scaffold_spanning", "dh_scaffold_gap_pileups", "dh_cropped_create2",
-    "dh_cropped_kind", "dh_set_near_best", "dh_ctx_set_near_best", "dh_shard_free", "dh_shard_pack_candidates", "dh_shard_plan_create", "dh_shard_read_joins", "dh_align_db_transposed", "dh_remap_skipping_reads", "dh_shard_graph_plan_create", "dh_shard_plan_destroy",
+    "dh_cropped_kind", "dh_get_process_work", "dh_set_near_best", "dh_ctx_set_near_best", "dh_shard_free", "dh_shard_pack_candidates", "dh_shard_plan_create", "dh_shard_read_joins", "dh_align_db_transposed", "dh_remap_skipping_reads", "dh_shard_graph_plan_create", "dh_shard_plan_destroy",
     "dh_shard_plan_las", "dh_shard_plan_nlas", "dh_shard_plan_pileups", "dh_shard_plan_owner", "dh_shard_pack_cropped",
     "dh_shard_unpack_cropped", "dh_insertions_read_ids", "dh_insertions_read_ids_off", "dh_output_assembly", "dh_default_output_opts",
 ]
@@ -1133,6 +1133,9 @@ def process_stats(ctx):
     names = ("crop", "pile_align", "tile_qv", "consensus", "realign", "flank_align", "total")
     d = {f"ms_{n}": float(ms[i]) for i, n in enumerate(names)}
     d.update(pile_las=int(cnt[0]), tiles=int(cnt[1]), nw_cells=int(cnt[2]))
+    wk = (ctypes.c_int64 * 4)()
+    _check(lib().dh_get_process_work(ctx._h, wk))
+    d.update(pile_ups=int(wk[0]), entries=int(wk[1]), cropped_bases=int(wk[2]), algorithmic_bytes=int(wk[3]))
     return d
 
 

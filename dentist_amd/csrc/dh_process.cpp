@@ -713,8 +713,18 @@ extern "C" int dh_insertions_write_db(const dh_insertions *r, const int64_t *con
 struct ProcStats {
     float ms[7] = {0, 0, 0, 0, 0, 0, 0};
     int64_t counters[3] = {0, 0, 0};
+    // the work of the call: [0] pile-ups processed, [1] their entries (cropped reads), [2] cropped bases,
+    // [3] algorithmic bytes = sum over pile-ups of (n^2 + 2) L, n entries of mean cropped length L
+    int64_t work[4] = {0, 0, 0, 0};
 };
 static thread_local ProcStats g_pstats;
+
+extern "C" int dh_get_process_work(dh_ctx *ctx, int64_t *work4)
+{
+    if (!ctx || !work4) return dh_fail(DH_EINVAL, "dh_get_process_work: NULL argument");
+    memcpy(work4, g_pstats.work, sizeof(g_pstats.work));
+    return DH_OK;
+}
 
 extern "C" int dh_get_process_stats(dh_ctx *ctx, float *ms7, int64_t *counters3)
 {
@@ -1435,6 +1445,7 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
     for (int32_t k = 1; k < nparts; k++) {
         for (int i = 0; i < 7; i++) g_pstats.ms[i] = std::max(g_pstats.ms[i], sts[(size_t)k].ms[i]);  // side by side
         for (int i = 0; i < 3; i++) g_pstats.counters[i] += sts[(size_t)k].counters[i];
+        for (int i = 0; i < 4; i++) g_pstats.work[i] += sts[(size_t)k].work[i];
     }
     // later parts appended to the first
     dh_insertions *r0 = res[0];
@@ -1575,6 +1586,16 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
     }
     const int32_t na = (int32_t)pile_of_active.size();
     first_read.push_back((int32_t)keep.size());
+    for (int32_t a = 0; a < na; a++) {
+        const int64_t n_ = first_read[(size_t)a + 1] - first_read[(size_t)a];
+        int64_t lsum = 0;
+        for (int32_t x = first_read[(size_t)a]; x < first_read[(size_t)a + 1]; x++)
+            lsum += crop->off[(size_t)keep[(size_t)x] + 1] - crop->off[(size_t)keep[(size_t)x]];
+        ps.work[0] += 1;
+        ps.work[1] += n_;
+        ps.work[2] += lsum;
+        ps.work[3] += n_ * lsum + 2 * lsum / std::max<int64_t>(n_, 1);  // (n^2 + 2) L with L = lsum / n
+    }
     HIPCHK(hipEventRecord(ev[0], st));
     if (!crop->dev) {  // cropped reads came over the host (dh_cropped_create): upload them once
         uint8_t *d_alloc = nullptr, *d_bases = nullptr;

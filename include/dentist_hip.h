@@ -499,6 +499,10 @@ int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop, const dh_p
  * [4] read->consensus re-alignment (rounds > 1) [5] flank re-alignment [6] total;
  * counters: [0] pile LAs [1] tiles aligned (NW) [2] NW cells */
 int dh_get_process_stats(dh_ctx *ctx, float *ms7, int64_t *counters3);
+/* the work of the same call: [0] pile-ups processed [1] their entries (cropped reads) [2] cropped bases [3] algorithmic
+ * bytes, sum over pile-ups of (n^2 + 2) L for n entries of mean cropped length L (the process stage's roofline figure:
+ * every read streamed once per partner, once for the consensus, the flanks and the output) */
+int dh_get_process_work(dh_ctx *ctx, int64_t *work4);
 
 
 /* ---- stage-level entry points (the fused dh_process_pileups runs the same code):

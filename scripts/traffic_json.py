@@ -12,9 +12,24 @@ before the first crop kernel (k_gather_parts) of the step.
 """
 import csv
 import glob
+import hashlib
 import json
 import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_build_id():
+    """sha1 over the kernel sources: bench.py compares it with the tree it runs from, so that a traffic figure taken on
+    another build of the kernels is never reported as this build's."""
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "dentist_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def rows(d):
@@ -52,6 +67,7 @@ def per_kernel(d):
 def main(fetch_dir, write_dir, out, workload, kmer_mod, k, algo):
     f, w = per_kernel(fetch_dir), per_kernel(write_dir)
     j = {"workload": workload, "mapping_kmer_mod": int(kmer_mod), "mapping_k": int(k), "mapping_algo": int(algo),
+         "kernel_build_id": kernel_build_id(),
          "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, as reported (no x2 correction: no wide "
                    "coalesced streams in these kernels)", "launches": {}}
     for key in sorted(set(f) | set(w)):
