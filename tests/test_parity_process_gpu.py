@@ -412,6 +412,96 @@ def test_pile_ups_of_the_graph_builder_with_extension_entries(gpu_ctx, algo):
     assert closed >= 9
 
 
+def test_the_benched_chain_against_the_oracle(gpu_ctx):
+    """bench.py's exact call chain and options on a workload the oracle finishes in seconds: k = 20, modimer sampling
+    1 / 8, band 64, x-drop 60, DH-2 through dh_map_reads (chain flags + the six collect filters on the way) ->
+    dh_scaffold_gap_pileups (graph builder with extension entries) -> select with the default read cap (60: 100x
+    coverage puts more entries than that into every gap) -> dh_process_pileups with its defaults (3 rounds, dust, two
+    concurrent halves need >= 64 pile-ups, so this runs them in one piece).  Oracle side: oz.align_db with the same
+    options and chain flags, oracle/collect_filters.py, oracle/scaffold.py:build, the cap restated below,
+    oracle/process.py.  Bit-exact: records and traces of the mapping, filter counts, pile-up entries, crop points,
+    reference read, consensus bases, splice coordinates."""
+    from oracle import collect_filters as cf
+    from oracle import scaffold as sc
+    w = sim.Workload(2_000_000, 20, 20_000, 10_000, seed=20260929)
+    mo = dentist_amd.default_align_opts(kmer_mod=8, k=20, width=64, xdrop=60, algo=1)
+    po = dentist_amd.default_process_opts(algo=1)
+    assert po.max_reads == 60 and po.rounds == 3
+    A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
+    las, trace, dropped = gpu_ctx.map_reads(A, B, mo, po, sorted=False, candidates=False)[:3]
+    # ---- mapping + filters
+    oo = oz.default_opts(kmer_mod=8, k=20, width=64, xdrop=60, algo=1)
+    olas, otrace, _ = oz.align_db(w.contigs, w.reads, oo, nthreads=os.cpu_count() or 1, sort=False, select_best=True)
+    flas, odropped, _ = cf.collect_filter(olas, w.contigs.off, w.reads.off)
+    assert [int(x) for x in dropped] == [int(x) for x in odropped]
+    assert_same_las((las, trace), (flas, otrace))
+    # ---- pile-ups of the graph builder, then the cap
+    gaps_in = np.stack([np.arange(w.contigs.n - 1), np.arange(1, w.contigs.n)], axis=1).astype(np.int32)
+    gp, _ = dentist_amd.scaffold_spanning_pileups(las, w.contigs.off, w.reads.off, gaps_in, with_extensions=True,
+                                                  min_spanning_reads=po.min_reads)
+    piles = gp.select(las, po)
+    chains = [sc.chain(i, int(l["aread"]) + 1, w.contigs.length(int(l["aread"])), int(l["bread"]) + 1,
+                       w.reads.length(int(l["bread"])), bool(l["flags"] & 1), int(l["abpos"]), int(l["aepos"]),
+                       int(l["bbpos"]), int(l["bepos"]), disabled=bool(l["flags"] & 0x20)) for i, l in enumerate(flas)]
+    exp = {}
+    for e, ras in sc.build(w.contigs.n, chains, [(int(a) + 1, int(b) + 1) for a, b in gaps_in], min_spanning_reads=po.min_reads):
+        (c0, p0), (c1, p1) = e["start"], e["end"]
+        if not (p0 == sc.END and p1 == sc.BEGIN and c1 == c0 + 1):
+            continue
+        ent = []
+        for ra in ras:
+            if len(ra) == 2:
+                a, b = sorted(ra, key=lambda s_: s_[0]["a_id"])
+                ent.append((a[0]["b_id"] - 1, a[0]["id"], b[0]["id"]))
+            elif ra[0][0]["a_id"] == c0:
+                ent.append((ra[0][0]["b_id"] - 1, ra[0][0]["id"], -1))
+            else:
+                ent.append((ra[0][0]["b_id"] - 1, -1, ra[0][0]["id"]))
+        ent.sort(key=lambda t: (t[0], t[1] < 0))   # read order; the halves of a spanning read that opens with an extension: left one first
+        if len(ent) > po.max_reads:   # the cap: the entries whose anchoring alignments have the lowest error rate
+            def err(t):
+                ln = sum(int(flas[i]["aepos"] - flas[i]["abpos"]) for i in t[1:] if i >= 0)
+                df = sum(int(flas[i]["diffs"]) for i in t[1:] if i >= 0)
+                return df * 1000000 // max(ln, 1)
+            order = sorted(range(len(ent)), key=lambda x: (err(ent[x]), x))[:po.max_reads]
+            ent = [ent[x] for x in sorted(order)]
+        exp[c0 - 1] = ent
+    got = {}
+    for i in range(len(piles)):
+        g, tri = piles.get(i)
+        got[int(g)] = [tuple(int(x) for x in t) for t in tri.tolist()]
+    assert set(got) == set(exp) and len(got) == 20
+    capped = 0
+    for g in got:
+        assert got[g] == exp[g], g
+        capped += len(got[g]) == po.max_reads
+    assert capped >= 10, "the cap must bite in this case"
+    # ---- process
+    rec, bases = dentist_amd.process_pileups(gpu_ctx, A, B, las, trace, piles, po)
+    closed = edits = tb = 0
+    for i in range(len(piles)):
+        g, tri = piles.get(i)
+        ex = pr.process_pile(got[int(g)], flas, otrace, w.contigs, w.reads, int(g), rounds=po.rounds,
+                             nthreads=os.cpu_count() or 1, algo=1)
+        r = rec[i]
+        assert (r["status"] == 0) == (ex["status"] == "ok"), (g, int(r["status"]), ex["status"])
+        if r["status"] != 0:
+            continue
+        assert (r["crop_left"], r["crop_right"], r["nreads"]) == (ex["cropL"], ex["cropR"], ex["pile"].n)
+        assert r["ref_read"] == ex["ref_idx"]
+        cons = bases[r["cons_off"]:r["cons_off"] + r["cons_len"]]
+        assert np.array_equal(cons, ex["consensus"]), f"gap {g}: consensus differs"
+        assert (r["left_aepos"], r["right_abpos"], r["ins_begin"], r["ins_end"]) == \
+               (ex["left_aepos"], ex["right_abpos"], ex["ins_begin"], ex["ins_end"])
+        cseq = sim.revcomp(cons) if r["comp"] else cons
+        truth = w.truth[w.contig_start[int(g)] + r["left_aepos"]: w.gap_end[int(g)] + r["right_abpos"]]
+        ed, _ = oz.nw(truth, cseq[r["ins_begin"]:r["ins_end"]])
+        edits += ed
+        tb += len(truth)
+        closed += 1
+    assert closed == 20 and edits <= 0.002 * tb, (closed, edits, tb)
+
+
 def test_consensus_band_classes_and_scalar_fill_agree(gpu_ctx, monkeypatch):
     """The three fills of the per-tile Needleman-Wunsch (bit-parallel with one / two 64-cell words per matrix row, scalar
     for bands above 63) against the oracle's full-matrix NW on noisy reads (20 % error: read-read tiles reach 60+

@@ -32,10 +32,12 @@ def test_lengths_error_rates_and_trace_spacings(gpu_ctx, seed, rl, err, ts):
     run_both(gpu_ctx, w.contigs, w.reads, tspace=ts, **T)
 
 
-def test_bench_options_of_the_mapping_pass(gpu_ctx):
-    """k = 20, modimers, x-drop 60: the options bench.py maps configs[2] with."""
+@pytest.mark.parametrize("mod", [8, 4])
+def test_bench_options_of_the_mapping_pass(gpu_ctx, mod):
+    """k = 20, modimer sampling 1 / 8 (bench.py's default) and 1 / 4 (its --kmer-mod 4 line), x-drop 60: the options
+    bench.py maps configs[2] with, HIP against the oracle bit for bit and against the truth placement."""
     w = sim.Workload(1_000_000, 8, 3000, 10_000, seed=23)
-    las, _ = run_both(gpu_ctx, w.contigs, w.reads, k=20, kmer_mod=4, xdrop=60, **T)
+    las, _ = run_both(gpu_ctx, w.contigs, w.reads, k=20, kmer_mod=mod, xdrop=60, **T)
     s, e = w.read_truth[las["bread"], 0], w.read_truth[las["bread"], 1]
     cs = w.contig_start[las["aread"]]
     ok = ((las["flags"] & 1) == w.read_truth[las["bread"], 2]) & (cs + las["abpos"] >= s - 80) & (cs + las["aepos"] <= e + 80)
