@@ -88,7 +88,8 @@ SYMBOLS = [
     "dh_map_reads", "dh_validate_regions", "dh_propagate_mask", "dh_db_mask_coverage", "dh_max_coverage_reads", "dh_max_improper_coverage_reads",
     "dh_default_scaffold_opts", "dh_scaffold_pileups", "dh_scaffold_npiles", "dh_scaffold_nentries", "dh_scaffold_joins",
     "dh_scaffold_entries", "dh_scaffold_destroy", "dh_scaffold_spanning", "dh_scaffold_gap_pileups", "dh_cropped_create2",
-    "dh_cropped_kind", "dh_get_process_work", "dh_set_near_best", "dh_ctx_set_near_best", "dh_shard_free", "dh_shard_pack_candidates", "dh_shard_plan_create", "dh_shard_read_joins", "dh_align_db_transposed", "dh_remap_skipping_reads", "dh_shard_graph_plan_create", "dh_shard_plan_destroy",
+    "dh_cropped_kind", "dh_get_process_work", "dh_comm_unique_id", "dh_comm_create", "dh_comm_create_local", "dh_comm_destroy",
+    "dh_comm_rank", "dh_comm_world", "dh_comm_all_gather", "dh_comm_all_to_all", "dh_shard_run", "dh_set_near_best", "dh_ctx_set_near_best", "dh_shard_free", "dh_shard_pack_candidates", "dh_shard_plan_create", "dh_shard_read_joins", "dh_align_db_transposed", "dh_remap_skipping_reads", "dh_shard_graph_plan_create", "dh_shard_plan_destroy",
     "dh_shard_plan_las", "dh_shard_plan_nlas", "dh_shard_plan_pileups", "dh_shard_plan_owner", "dh_shard_pack_cropped",
     "dh_shard_unpack_cropped", "dh_insertions_read_ids", "dh_insertions_read_ids_off", "dh_output_assembly", "dh_default_output_opts",
 ]
@@ -680,6 +681,124 @@ class ShardPlan:
             self.close()
         except Exception:
             pass
+
+
+class Comm:
+    """dh_comm: the communicator of the sharded path behind the C ABI -- RCCL between processes (Comm.create) or the
+    in-process hub between host threads (Comm.local)."""
+
+    def __init__(self, h):
+        self._h = h
+
+    @staticmethod
+    def unique_id():
+        buf = (ctypes.c_uint8 * 128)()
+        _check(lib().dh_comm_unique_id(buf))
+        return bytes(buf)
+
+    @staticmethod
+    def create(ctx, rank, world, uid):
+        L = lib()
+        L.dh_comm_create.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+        h = ctypes.c_void_p()
+        _check(L.dh_comm_create(uid, rank, world, ctx._h, ctypes.byref(h)))
+        return Comm(h)
+
+    @staticmethod
+    def local(world, ctxs=None):
+        L = lib()
+        hs = (ctypes.c_void_p * world)()
+        cp = (ctypes.c_void_p * world)(*[c._h for c in ctxs]) if ctxs is not None else None
+        L.dh_comm_create_local.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+        _check(L.dh_comm_create_local(world, cp, hs))
+        return [Comm(ctypes.c_void_p(hs[r])) for r in range(world)]
+
+    @property
+    def world(self):
+        L = lib()
+        L.dh_comm_world.argtypes = [ctypes.c_void_p]
+        return int(L.dh_comm_world(self._h))
+
+    def _take(self, ptr, sizes):
+        L = lib()
+        L.dh_shard_free.argtypes = [ctypes.c_void_p]
+        tot = int(sum(sizes))
+        whole = np.frombuffer(ctypes.string_at(ptr, tot), dtype=np.uint8) if tot else np.zeros(0, np.uint8)
+        L.dh_shard_free(ptr)
+        out, at = [], 0
+        for n in sizes:
+            out.append(whole[at:at + int(n)].copy())
+            at += int(n)
+        return out
+
+    def all_gather(self, payload):
+        L = lib()
+        p = np.ascontiguousarray(payload, dtype=np.uint8)
+        W = self.world
+        sizes = (ctypes.c_int64 * W)()
+        out = ctypes.c_void_p()
+        L.dh_comm_all_gather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]
+        _check(L.dh_comm_all_gather(self._h, p.ctypes.data if len(p) else None, len(p), ctypes.byref(out), sizes))
+        return self._take(out, list(sizes))
+
+    def all_to_all(self, per_dest):
+        L = lib()
+        W = self.world
+        bl = [np.ascontiguousarray(x, dtype=np.uint8) for x in per_dest]
+        ptrs = (ctypes.c_void_p * W)(*[b.ctypes.data if len(b) else None for b in bl])
+        ss = (ctypes.c_int64 * W)(*[len(b) for b in bl])
+        rs = (ctypes.c_int64 * W)()
+        out = ctypes.c_void_p()
+        L.dh_comm_all_to_all.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]
+        _check(L.dh_comm_all_to_all(self._h, ptrs, ss, ctypes.byref(out), rs))
+        return self._take(out, list(rs))
+
+    def close(self):
+        if self._h:
+            L = lib()
+            L.dh_comm_destroy.argtypes = [ctypes.c_void_p]
+            L.dh_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def shard_run(comm, contigs_db, reads_db, read_first, contig_off, las, trace, opts, cands=None, graph=None):
+    """dh_shard_run: `collect` + `process` of one rank's share with its three exchanges behind the C ABI.  graph =
+    dict(read_off=..., input_gaps=..., scaffold options) selects the scaffold-graph collector, cands the spanning-read
+    one.  Returns (records of all ranks by gap, consensus bases, info)."""
+    L = lib()
+    arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
+    tr = np.ascontiguousarray(trace, dtype=np.uint16)
+    co = np.ascontiguousarray(contig_off, dtype=np.int64)
+    ro = ig = so = None
+    if cands is None:
+        g = dict(graph or {})
+        ro = np.ascontiguousarray(g.pop("read_off"), dtype=np.int64)
+        gaps = g.pop("input_gaps", None)
+        ig = np.ascontiguousarray(gaps if gaps is not None else np.zeros((0, 2)), dtype=np.int32).reshape(-1, 2)
+        so = ScaffoldOpts()
+        L.dh_default_scaffold_opts(ctypes.byref(so))
+        g.setdefault("min_spanning_reads", opts.min_reads)
+        for k, v in g.items():
+            if not hasattr(so, k):
+                raise TypeError(f"unknown scaffold option {k}")
+            setattr(so, k, int(v) if k in ("min_spanning_reads", "merge_extensions") else float(v))
+    h = ctypes.c_void_p()
+    info = (ctypes.c_int64 * 4)()
+    vp = ctypes.c_void_p
+    L.dh_shard_run.argtypes = [vp, vp, vp, ctypes.c_int32, vp, ctypes.c_int32, vp, ctypes.c_int64, vp, ctypes.POINTER(ProcessOpts),
+                               vp, vp, vp, ctypes.c_int32, vp, ctypes.POINTER(vp), vp]
+    _check(L.dh_shard_run(comm._h, contigs_db._h, reads_db._h, read_first, co.ctypes.data, len(co) - 1, arr.ctypes.data, len(arr),
+                          tr.ctypes.data, ctypes.byref(opts), cands._h if cands is not None else None,
+                          ro.ctypes.data if ro is not None else None, ig.ctypes.data if ig is not None and len(ig) else None,
+                          len(ig) if ig is not None else 0, ctypes.byref(so) if so is not None else None, ctypes.byref(h), info))
+    rec, bases = _take_insertions(h, None, False)
+    return rec, bases, {"piles": int(info[0]), "owned": int(info[1]), "entries": int(info[2]), "cropped_bytes_sent": int(info[3])}
 
 
 def shard_pack_cropped(crop, owner, world):

@@ -169,6 +169,19 @@ struct dh_la_set {
     std::vector<int32_t> ovf_reads;
 };
 
+// result of the process stage (dh_process.cpp; dh_comm.cpp assembles the gathered result of all ranks)
+struct dh_insertions {
+    std::vector<dh_insertion> rec;
+    std::vector<uint8_t> bases;
+    // what insertions.db stores besides the sequence (insertiondb.d:987-1031): the two flank overlaps
+    // of every closed gap with their trace points (A coordinates on the whole contig) and the read
+    // ids of the pile-up
+    std::vector<dh_la> flank;        // 2 per closed gap: left, right; toff into flank_tr
+    std::vector<uint16_t> flank_tr;
+    std::vector<int32_t> flank_of;   // per record: index of its left overlap in `flank`, -1 if none
+    std::vector<int32_t> ids_off, ids;  // per record [ids_off[i], ids_off[i+1]): read ids of the pile-up
+};
+
 void dh_pileups_shift(dh_pileups *p, int32_t by);
 int dh_pileups_concat(dh_pileups *const *parts, int32_t nparts, dh_pileups **out);
 

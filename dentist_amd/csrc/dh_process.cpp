@@ -629,17 +629,7 @@ static void chain_pair(LaVec &la, size_t first, size_t last, int32_t min_score)
 
 // ------------------------------------------------------------------------------------ results
 
-struct dh_insertions {
-    std::vector<dh_insertion> rec;
-    std::vector<uint8_t> bases;
-    // what insertions.db stores besides the sequence (insertiondb.d:987-1031): the two flank overlaps
-    // of every closed gap with their trace points (A coordinates on the whole contig) and the read
-    // ids of the pile-up
-    std::vector<dh_la> flank;        // 2 per closed gap: left, right; toff into flank_tr
-    std::vector<uint16_t> flank_tr;
-    std::vector<int32_t> flank_of;   // per record: index of its left overlap in `flank`, -1 if none
-    std::vector<int32_t> ids_off, ids;  // per record [ids_off[i], ids_off[i+1]): read ids of the pile-up
-};
+// (struct dh_insertions: dh_internal.h)
 
 extern "C" void dh_insertions_destroy(dh_insertions *r) { delete r; }
 extern "C" int32_t dh_insertions_count(const dh_insertions *r) { return r ? (int32_t)r->rec.size() : 0; }

@@ -163,11 +163,34 @@ def _runs(bases, off, idx):
     return [bases[off[idx[a]]:off[idx[b - 1] + 1]] for a, b in zip(starts, ends)]
 
 
+_COMM = {}
+
+
+def rccl_comm(ctx, rank, world):
+    """The communicator of the C ABI (dh_comm_create) for this process, created once: rank 0 draws the RCCL unique id
+    (dh_comm_unique_id), torch.distributed only carries those 128 bytes to the other processes -- what a D host would do
+    with a file or MPI."""
+    import torch.distributed as dist
+    from ._lib import Comm
+    key = (id(ctx), rank, world)
+    if key not in _COMM:
+        box = [Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        _COMM[key] = Comm.create(ctx, rank, world, box[0])
+    return _COMM[key]
+
+
 def sharded_process(ctx, contigs_db, reads_db, read_first, contig_off, las, trace, popts, rank, world, cands=None, graph=None):
     """`collect` + `process` for one rank's share of the reads.  las/trace: this rank's mapping
     result with bread ALREADY shifted to ids of the whole reads DB; reads_db holds the reads
     [read_first, read_first + n).  Returns (records, bases, info): the closed-gap records of ALL
     ranks ordered by gap (identical on every rank) with ref_read_id as whole-DB ids."""
+    import torch.distributed as dist
+    if world > 1 and dist.is_initialized() and dist.get_backend() == "nccl":
+        # one process per GPU over RCCL: the whole sequence behind the C ABI (dh_shard_run); this module is a thin caller
+        from ._lib import shard_run
+        return shard_run(rccl_comm(ctx, rank, world), contigs_db, reads_db, read_first, contig_off, las, trace, popts,
+                         cands=cands, graph=graph)
     gen = sharded_process_steps(ctx, contigs_db, reads_db, read_first, contig_off, las, trace, popts, rank, world, cands, graph)
     try:
         req = next(gen)

@@ -486,6 +486,38 @@ int dh_shard_pack_cropped(dh_cropped *crop, const int32_t *owner, int32_t world,
 int dh_shard_unpack_cropped(const uint8_t *const *blobs, const int64_t *sizes, int32_t world, const dh_insertion *rec,
                             int32_t npiles, const int32_t *owner, int32_t rank, dh_cropped **out);
 const dh_insertion *dh_cropped_records(const dh_cropped *c);
+/* ---- the multi-GPU entry (dh_comm.cpp): one process per GPU, the exchanges over RCCL / xGMI.  Replaces the file system
+ *      between the workflow's jobs: LAmerge of the per-block mappings (snakemake/Snakefile:1173-1185), the
+ *      `dentist process --batch` jobs (:1315-1358) and `dentist merge-insertions` (commands/mergeInsertions.d:60-164).
+ *      Rank 0 calls dh_comm_unique_id and hands the 128 bytes to the other processes (file, socket, MPI ...); every
+ *      process calls dh_comm_create(id, rank, world, its context) once and dh_shard_run per batch.  RCCL is loaded on
+ *      first use (dlopen); without it these calls fail with DH_ENODEV, everything else works.
+ *      dh_comm_create_local: `world` communicators inside ONE process that exchange through memory -- one per host
+ *      thread and context (tests, the N-rank emulation on one GPU); same calls, same dh_shard_run.
+ *      dh_comm_all_gather / dh_comm_all_to_all: the two collectives on host blobs (staged through page-locked memory and
+ *      the context's device scratch); *out = one malloc'd block with the blobs in rank order, release with dh_shard_free.
+ *      dh_shard_run: `collect` + `process` of this rank's share of the reads (reads = the reads [read_first, read_first +
+ *      nreads(reads)) of the whole DB; las / trace its mapping, bread = ids of the whole DB).  cands != NULL: the
+ *      spanning-read collector on the candidates dh_map_reads listed; cands == NULL: the scaffold-graph collector of
+ *      `dentist collect` (read_off = offsets of this rank's reads, input_gaps / ngaps / sopts as dh_scaffold_pileups; sopts
+ *      NULL = defaults with min_spanning_reads = opts->min_reads).  *out = the closed-gap records of ALL ranks ordered by
+ *      gap, identical on every rank and bit-identical to the single-GPU result; info4 (optional) = pile-ups, pile-ups
+ *      owned by this rank, entries, bytes of cropped reads sent. */
+typedef struct dh_comm dh_comm;
+int dh_comm_unique_id(uint8_t *id128);
+int dh_comm_create(const uint8_t *id128, int32_t rank, int32_t world, dh_ctx *ctx, dh_comm **out);
+int dh_comm_create_local(int32_t world, dh_ctx *const *ctxs, dh_comm **out);
+void dh_comm_destroy(dh_comm *c);
+int32_t dh_comm_rank(const dh_comm *c);
+int32_t dh_comm_world(const dh_comm *c);
+int dh_comm_all_gather(dh_comm *c, const uint8_t *payload, int64_t nbytes, uint8_t **out, int64_t *sizes);
+int dh_comm_all_to_all(dh_comm *c, const uint8_t *const *per_dest, const int64_t *send_sizes, uint8_t **out,
+                       int64_t *recv_sizes);
+int dh_shard_run(dh_comm *c, dh_db *contigs, dh_db *reads, int32_t read_first, const int64_t *contig_off, int32_t ncontigs,
+                 const dh_la *las, int64_t n, const uint16_t *trace, const dh_process_opts *opts, const dh_pileups *cands,
+                 const int64_t *read_off, const int32_t *input_gaps, int32_t ngaps, const struct dh_scaffold_opts *sopts,
+                 dh_insertions **out, int64_t *info4);
+
 int32_t dh_cropped_nreads(const dh_cropped *c);
 const int32_t *dh_cropped_pile(const dh_cropped *c);     /* pile-up of every cropped read               */
 const int32_t *dh_cropped_entry(const dh_cropped *c);    /* its position in the pile-up's read list      */

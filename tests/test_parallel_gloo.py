@@ -277,3 +277,32 @@ def test_shard_graph_glue_rejects_malformed_input():
     plan = ShardPlan([blob], po, graph=(2, None, {"min_spanning_reads": 1}))
     assert len(plan.piles) <= 1
     plan.close()
+
+
+def test_in_process_hub_collectives_of_the_c_abi():
+    """dh_comm_create_local: the communicator of the C ABI between host threads (no GPU, no RCCL): ragged all-gather(v)
+    and all-to-all(v) of byte blobs, empty payloads included -- the exchange code dh_shard_run runs on."""
+    import threading
+    import dentist_amd
+    world = 3
+    comms = dentist_amd.Comm.local(world)
+    rng = np.random.default_rng(5)
+    payload = [rng.integers(0, 256, n, dtype=np.uint8) for n in (1000, 0, 37)]
+    per_dest = [[rng.integers(0, 256, (src * 7 + dst * 13) % 50 * (src != dst), dtype=np.uint8) for dst in range(world)]
+                for src in range(world)]
+    got_g, got_a = [None] * world, [None] * world
+
+    def run(r):
+        for _ in range(3):   # the hub is reusable
+            got_g[r] = comms[r].all_gather(payload[r])
+            got_a[r] = comms[r].all_to_all(per_dest[r])
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=60)
+    for r in range(world):
+        assert all(np.array_equal(got_g[r][s], payload[s]) for s in range(world))
+        assert all(np.array_equal(got_a[r][s], per_dest[s][r]) for s in range(world))
+    for c in comms:
+        c.close()

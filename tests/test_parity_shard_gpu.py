@@ -158,3 +158,98 @@ def test_sharded_scaffold_graph_collector_equals_the_single_gpu_run(gpu_ctx, wor
         for a, b in zip(grec, rec):
             assert np.array_equal(gbases[a["cons_off"]:a["cons_off"] + a["cons_len"]],
                                   bases[b["cons_off"]:b["cons_off"] + b["cons_len"]])
+
+
+def _same(results, rec, bases):
+    for grec, gbases, info in results:
+        assert len(grec) == len(rec) and np.array_equal(grec["contig_left"], rec["contig_left"])
+        for f in rec.dtype.names:
+            if f not in ("cons_off", "pad"):
+                assert np.array_equal(grec[f], rec[f]), f
+        for a, b in zip(grec, rec):
+            assert np.array_equal(gbases[a["cons_off"]:a["cons_off"] + a["cons_len"]],
+                                  bases[b["cons_off"]:b["cons_off"] + b["cons_len"]])
+
+
+def _graph_single(ctx, w, mo, po, gaps_in):
+    A, B = ctx.db(w.contigs), ctx.db(w.reads)
+    las, trace, _ = ctx.map_reads(A, B, mo, po, sorted=False, candidates=False)[:3]
+    gp, _ = dentist_amd.scaffold_spanning_pileups(las, w.contigs.off, w.reads.off, gaps_in, with_extensions=True,
+                                                  min_spanning_reads=po.min_reads)
+    return dentist_amd.process_pileups(ctx, A, B, las, trace, gp.select(las, po), po)
+
+
+@pytest.mark.parametrize("world,collector", [(2, "graph"), (3, "graph"), (2, "spanning")])
+def test_dh_shard_run_between_host_threads_equals_the_single_gpu_run(world, collector):
+    """The C-ABI entry of the multi-GPU path (dh_comm_create_local + dh_shard_run): every rank is a host thread with its
+    own context on the one GPU, the exchanges go through the in-process hub -- the same dh_shard_run code that runs over
+    RCCL between processes.  Scaffold-graph collector (the benched one) and spanning-read collector."""
+    import threading
+    w = sim.Workload(800_000, 8, 4000, 6000, seed=61, spacing=20000, gap_max=1500)
+    mo = dentist_amd.default_align_opts(kmer_mod=4, k=20, width=64, xdrop=60, algo=1)
+    po = dentist_amd.default_process_opts(max_reads=12, algo=1)
+    gaps_in = np.stack([np.arange(w.contigs.n - 1), np.arange(1, w.contigs.n)], axis=1).astype(np.int32)
+    ctx0 = dentist_amd.Context(0)
+    if collector == "graph":
+        rec, bases = _graph_single(ctx0, w, mo, po, gaps_in)
+    else:
+        A, B = ctx0.db(w.contigs), ctx0.db(w.reads)
+        las, trace, _, cands = ctx0.map_reads(A, B, mo, po, sorted=False, candidates=True)
+        rec, bases = dentist_amd.process_pileups(ctx0, A, B, las, trace, cands.select(las, po), po)
+    assert (rec["status"] == 0).sum() >= 6
+    ctxs = [dentist_amd.Context(0) for _ in range(world)]
+    comms = dentist_amd.Comm.local(world, ctxs)
+    results, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            ctx = ctxs[rank]
+            lo, hi = parallel.shard_range(w.reads.n, rank, world)
+            share = sim.SeqDb(w.reads.bases[w.reads.off[lo]:w.reads.off[hi]], w.reads.off[lo:hi + 1] - w.reads.off[lo])
+            A, B = ctx.db(w.contigs), ctx.db(share)
+            m = ctx.map_reads(A, B, mo, po, sorted=False, candidates=collector != "graph")
+            las, trace = m[0].copy(), m[1]
+            las["bread"] += lo
+            if collector == "graph":
+                results[rank] = dentist_amd.shard_run(comms[rank], A, B, lo, w.contigs.off, las, trace, po,
+                                                      graph=dict(read_off=share.off, input_gaps=gaps_in))
+            else:
+                results[rank] = dentist_amd.shard_run(comms[rank], A, B, lo, w.contigs.off, las, trace, po, cands=m[3])
+        except Exception as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+            raise
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    _same(results, rec, bases)
+    assert sum(r[2]["owned"] for r in results) == results[0][2]["piles"] and all(r[2]["owned"] > 0 for r in results)
+    for c in comms:
+        c.close()
+
+
+def test_dh_shard_run_over_rccl_at_world_one(gpu_ctx):
+    """The RCCL back end of the same entry, executable on a one-GPU box: a communicator of one rank (ncclCommInitRank
+    with world 1) -- ncclAllGather of the sizes and of the padded blobs, grouped ncclSend / ncclRecv to itself -- must
+    give the single-GPU result.  (World sizes above one run this code only on a multi-GPU node: the driver's SCALE
+    run; the exchange logic above one rank is what the host-thread test covers.)"""
+    w = sim.Workload(600_000, 6, 3000, 6000, seed=67, spacing=20000, gap_max=1500)
+    mo = dentist_amd.default_align_opts(kmer_mod=4, k=20, width=64, xdrop=60, algo=1)
+    po = dentist_amd.default_process_opts(algo=1)
+    gaps_in = np.stack([np.arange(w.contigs.n - 1), np.arange(1, w.contigs.n)], axis=1).astype(np.int32)
+    rec, bases = _graph_single(gpu_ctx, w, mo, po, gaps_in)
+    comm = dentist_amd.Comm.create(gpu_ctx, 0, 1, dentist_amd.Comm.unique_id())
+    # the collectives on ragged payloads first
+    got = comm.all_gather(np.arange(1000, dtype=np.uint8))
+    assert len(got) == 1 and np.array_equal(got[0], np.arange(1000, dtype=np.uint8))
+    got = comm.all_to_all([np.arange(77, dtype=np.uint8)])
+    assert len(got) == 1 and np.array_equal(got[0], np.arange(77, dtype=np.uint8))
+    assert len(comm.all_gather(np.zeros(0, np.uint8))[0]) == 0
+    A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
+    las, trace, _ = gpu_ctx.map_reads(A, B, mo, po, sorted=False, candidates=False)[:3]
+    res = dentist_amd.shard_run(comm, A, B, 0, w.contigs.off, las, trace, po, graph=dict(read_off=w.reads.off, input_gaps=gaps_in))
+    _same([res], rec, bases)
+    assert res[2]["owned"] == res[2]["piles"] == len(rec)
+    comm.close()
