@@ -88,7 +88,7 @@ SYMBOLS = [
     "dh_map_reads", "dh_validate_regions", "dh_propagate_mask", "dh_db_mask_coverage", "dh_max_coverage_reads", "dh_max_improper_coverage_reads",
     "dh_default_scaffold_opts", "dh_scaffold_pileups", "dh_scaffold_npiles", "dh_scaffold_nentries", "dh_scaffold_joins",
     "dh_scaffold_entries", "dh_scaffold_destroy", "dh_scaffold_spanning", "dh_scaffold_gap_pileups", "dh_cropped_create2",
-    "dh_cropped_kind", "dh_get_process_work", "dh_comm_unique_id", "dh_comm_create", "dh_comm_create_local", "dh_comm_destroy",
+    "dh_cropped_kind", "dh_get_process_work", "dh_scaffold_pileups_cb", "dh_scaffold_pileups_resolved", "dh_comm_unique_id", "dh_comm_create", "dh_comm_create_local", "dh_comm_destroy",
     "dh_comm_rank", "dh_comm_world", "dh_comm_all_gather", "dh_comm_all_to_all", "dh_shard_run", "dh_set_near_best", "dh_ctx_set_near_best", "dh_shard_free", "dh_shard_pack_candidates", "dh_shard_plan_create", "dh_shard_read_joins", "dh_align_db_transposed", "dh_remap_skipping_reads", "dh_shard_graph_plan_create", "dh_shard_plan_destroy",
     "dh_shard_plan_las", "dh_shard_plan_nlas", "dh_shard_plan_pileups", "dh_shard_plan_owner", "dh_shard_pack_cropped",
     "dh_shard_unpack_cropped", "dh_insertions_read_ids", "dh_insertions_read_ids_off", "dh_output_assembly", "dh_default_output_opts",
@@ -955,31 +955,90 @@ READ_ALIGNMENT_DTYPE = np.dtype([("read", "<i4"), ("la0", "<i4"), ("la1", "<i4")
                                  ("n", "u1"), ("pad", "u1")])
 
 
-def _scaffold(las, contig_off, read_off, input_gaps, kw):
+REMAP_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32,
+                            ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p),
+                            ctypes.POINTER(ctypes.c_int64))
+
+
+def _scaffold(las, contig_off, read_off, input_gaps, kw, resolve=None):
+    """The scaffold handle and the LA array it indexes.  resolve = None: dh_scaffold_pileups.  resolve = dict(ctx=, contigs=,
+    reads=, map_opts=, trace=, allowance=100): dh_scaffold_pileups_resolved (resolveBubbles, the device re-maps the skipping
+    reads); resolve = dict(remap=callable(contig_ids, read_ids) -> LA_DTYPE array): dh_scaffold_pileups_cb.  With resolve the
+    result carries (las incl. the added alignments, trace incl. theirs or None, bubbles resolved) in the handle's slot 2."""
     L = lib()
     o = ScaffoldOpts()
     L.dh_default_scaffold_opts(ctypes.byref(o))
+    kw = dict(kw)
+    mbs, mit = int(kw.pop("max_bubble_size", 0)), int(kw.pop("max_bubble_iterations", 0))
     for k, v in kw.items():
         if not hasattr(o, k):
             raise TypeError(f"unknown scaffold option {k}")
         setattr(o, k, int(v) if k in ("min_spanning_reads", "merge_extensions") else float(v))
     arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
-    co, ro = np.ascontiguousarray(contig_off, dtype=np.int64), np.ascontiguousarray(read_off, dtype=np.int64)
     ig = np.ascontiguousarray(input_gaps if input_gaps is not None else np.zeros((0, 2)), dtype=np.int32).reshape(-1, 2)
     h = ctypes.c_void_p()
-    L.dh_scaffold_pileups.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
-                                      ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ScaffoldOpts),
-                                      ctypes.POINTER(ctypes.c_void_p)]
-    _check(L.dh_scaffold_pileups(arr.ctypes.data, len(arr), co.ctypes.data, len(co) - 1, ro.ctypes.data, len(ro) - 1,
-                                 ig.ctypes.data if len(ig) else None, len(ig), ctypes.byref(o), ctypes.byref(h)))
-    return h, arr
+    vp = ctypes.c_void_p
+    if resolve is None:
+        co, ro = np.ascontiguousarray(contig_off, dtype=np.int64), np.ascontiguousarray(read_off, dtype=np.int64)
+        L.dh_scaffold_pileups.argtypes = [vp, ctypes.c_int64, vp, ctypes.c_int32, vp, ctypes.c_int32, vp, ctypes.c_int32,
+                                          ctypes.POINTER(ScaffoldOpts), ctypes.POINTER(vp)]
+        _check(L.dh_scaffold_pileups(arr.ctypes.data, len(arr), co.ctypes.data, len(co) - 1, ro.ctypes.data, len(ro) - 1,
+                                     ig.ctypes.data if len(ig) else None, len(ig), ctypes.byref(o), ctypes.byref(h)))
+        return h, arr
+    ex = vp()
+    nres = ctypes.c_int32(0)
+    if "remap" in resolve:
+        co, ro = np.ascontiguousarray(contig_off, dtype=np.int64), np.ascontiguousarray(read_off, dtype=np.int64)
+        fn = resolve["remap"]
+        libc = ctypes.CDLL(None)
+        libc.malloc.restype = vp
+        libc.malloc.argtypes = [ctypes.c_size_t]
+
+        def cb(user, cids, nc, rids, nr, out, nout):
+            try:
+                got = np.ascontiguousarray(fn([cids[i] for i in range(nc)], [rids[i] for i in range(nr)]), dtype=LA_DTYPE)
+                p = libc.malloc(max(1, got.nbytes))
+                if got.nbytes:
+                    ctypes.memmove(p, got.ctypes.data, got.nbytes)
+                out[0] = p
+                nout[0] = len(got)
+                return 0
+            except Exception:  # noqa: BLE001
+                return -1
+        cfn = REMAP_FN(cb)
+        L.dh_scaffold_pileups_cb.argtypes = [vp, ctypes.c_int64, vp, ctypes.c_int32, vp, ctypes.c_int32, vp, ctypes.c_int32,
+                                             ctypes.POINTER(ScaffoldOpts), ctypes.c_int32, ctypes.c_int32, REMAP_FN, vp,
+                                             ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int32)]
+        _check(L.dh_scaffold_pileups_cb(arr.ctypes.data, len(arr), co.ctypes.data, len(co) - 1, ro.ctypes.data, len(ro) - 1,
+                                        ig.ctypes.data if len(ig) else None, len(ig), ctypes.byref(o), mbs, mit, cfn, None,
+                                        ctypes.byref(h), ctypes.byref(ex), ctypes.byref(nres)))
+        trace = None
+    else:
+        L.dh_scaffold_pileups_resolved.argtypes = [vp, vp, vp, vp, ctypes.c_int64, vp, ctypes.c_int32, ctypes.POINTER(ScaffoldOpts),
+                                                   ctypes.POINTER(AlignOpts), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                   ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int32)]
+        _check(L.dh_scaffold_pileups_resolved(resolve["ctx"]._h, resolve["contigs"]._h, resolve["reads"]._h, arr.ctypes.data, len(arr),
+                                              ig.ctypes.data if len(ig) else None, len(ig), ctypes.byref(o),
+                                              ctypes.byref(resolve["map_opts"]), int(resolve.get("allowance", 100)), mbs, mit,
+                                              ctypes.byref(h), ctypes.byref(ex), ctypes.byref(nres)))
+        trace = np.ascontiguousarray(resolve["trace"], dtype=np.uint16)
+    xl, xt, _ = _take_la_set(ex)
+    if len(xl):
+        xl = xl.copy()
+        if trace is not None:
+            xl["toff"] += len(trace)
+            trace = np.concatenate([trace, xt])
+        arr = np.concatenate([arr, xl])
+    return h, arr, trace, int(nres.value)
 
 
-def scaffold_pileups(las, contig_off, read_off, input_gaps=None, **opts):
+def scaffold_pileups(las, contig_off, read_off, input_gaps=None, resolve=None, **opts):
     """dh_scaffold_pileups: the scaffold-graph pile-up builder of `dentist collect`
-    (pileups.d:173-208).  Returns (joins JOIN_DTYPE[npiles], read alignments READ_ALIGNMENT_DTYPE[...])."""
+    (pileups.d:173-208).  Returns (joins JOIN_DTYPE[npiles], read alignments READ_ALIGNMENT_DTYPE[...]); with
+    resolve (see _scaffold: resolveBubbles) also (las incl. the added alignments, trace or None, bubbles resolved)."""
     L = lib()
-    h, _ = _scaffold(las, contig_off, read_off, input_gaps, opts)
+    sc = _scaffold(las, contig_off, read_off, input_gaps, opts, resolve)
+    h = sc[0]
     try:
         L.dh_scaffold_npiles.restype = ctypes.c_int32
         L.dh_scaffold_nentries.restype = ctypes.c_int64
@@ -997,17 +1056,18 @@ def scaffold_pileups(las, contig_off, read_off, input_gaps=None, **opts):
     finally:
         L.dh_scaffold_destroy.argtypes = [ctypes.c_void_p]
         L.dh_scaffold_destroy(h)
-    return joins, ent
+    return (joins, ent) if resolve is None else (joins, ent, sc[1], sc[2], sc[3])
 
 
-def scaffold_spanning_pileups(las, contig_off, read_off, input_gaps=None, with_extensions=False, **opts):
+def scaffold_spanning_pileups(las, contig_off, read_off, input_gaps=None, with_extensions=False, resolve=None, **opts):
     """The gap pile-ups of the scaffold graph (collectPileUps/pileups.d:173-208): returns (Pileups, number of
     pile-ups of other kinds).  with_extensions = False: the spanning reads only (dh_scaffold_spanning);
     True: every read alignment of the pile-up, i.e. also the extension entries mergeExtensionsWithGaps moved
     into the gap, as (read, LA, -1) / (read, -1, LA) triples (dh_scaffold_gap_pileups) -- what the reference's
     `dentist process` is handed."""
     L = lib()
-    h, arr = _scaffold(las, contig_off, read_off, input_gaps, opts)
+    sc = _scaffold(las, contig_off, read_off, input_gaps, opts, resolve)
+    h, arr = sc[0], sc[1]
     try:
         ph = ctypes.c_void_p()
         skipped = ctypes.c_int32(0)
@@ -1018,6 +1078,8 @@ def scaffold_spanning_pileups(las, contig_off, read_off, input_gaps=None, with_e
     finally:
         L.dh_scaffold_destroy.argtypes = [ctypes.c_void_p]
         L.dh_scaffold_destroy(h)
+    if resolve is not None:   # + the LA / trace arrays the pile-ups index, bubbles resolved
+        return Pileups(None, None, None, _handle=ph), int(skipped.value), sc[1], sc[2], sc[3]
     return Pileups(None, None, None, _handle=ph), int(skipped.value)
 
 

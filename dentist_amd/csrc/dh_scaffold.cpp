@@ -9,9 +9,11 @@
 //
 // Host code: per-read work runs on the thread pool, the graph itself has 4 nodes per contig and is
 // handled serially.  Where the reference merges equal edges after an unstable sort, the order here is
-// the stable one (read id, then position on the read).  resolveBubbles (pileups.d:1124-1590) re-aligns
-// the skipping reads with the external tools and is not part of this builder: the forks of a bubble go
-// through the read-support rule like any other fork.
+// the stable one (read id, then position on the read).  resolveBubbles (pileups.d:1100-1590) is the Resolver below
+// (Paton's cycle base as util/math.d:2380-2480 walks it, simple bubbles, skipped path, collectFixedSimpleBubbles,
+// graph surgery); the re-mapping of the skipping reads is a callback -- dh_remap_skipping_reads on the device
+// (dh_scaffold_pileups_resolved) or the caller's (dh_scaffold_pileups_cb).  dh_scaffold_pileups itself runs without
+// it: the forks of a bubble then go through the read-support rule like any other fork.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -19,6 +21,7 @@
 #include <array>
 #include <atomic>
 #include <cstring>
+#include <functional>
 #include <vector>
 
 #include "dh_internal.h"
@@ -69,6 +72,10 @@ struct SA {
 struct Ctx {
     const dh_la *las;
     const int64_t *coff, *roff;
+    // the bubble resolver adds alignments: LA i >= n is (*extra)[i - n]
+    int64_t n = INT64_MAX;
+    const std::vector<dh_la> *extra = nullptr;
+    const dh_la &L(int64_t i) const { return i < n ? las[i] : (*extra)[(size_t)(i - n)]; }
     int32_t alen(const dh_la &l) const { return (int32_t)(coff[l.aread + 1] - coff[l.aread]); }
     int32_t blen(const dh_la &l) const { return (int32_t)(roff[l.bread + 1] - roff[l.bread]); }
 };
@@ -81,12 +88,13 @@ struct RawJoin {
 };
 
 // collectReadAlignments for the enabled LAs idx[0..cnt) of one read, appended to `out` as raw joins
+// (sa, on return: the seeded alignments of the read in read order -- what the bubble resolver checks against the skipped path)
 void read_joins(const Ctx &c, const int64_t *idx, int64_t cnt, std::vector<RawJoin> &out, std::vector<SA> &sa,
                 std::vector<std::pair<size_t, size_t>> &sl)
 {
     sa.clear();
     for (int64_t x = 0; x < cnt; x++) {
-        const dh_la &l = c.las[idx[x]];
+        const dh_la &l = c.L(idx[x]);
         const bool comp = (l.flags & DH_FLAG_COMP) != 0;
         const int32_t bl = c.blen(l);
         const int32_t b = comp ? bl - l.bepos : l.bbpos, e = comp ? bl - l.bbpos : l.bepos;
@@ -107,31 +115,31 @@ void read_joins(const Ctx &c, const int64_t *idx, int64_t cnt, std::vector<RawJo
     if (start_ext) sl.emplace_back(0, 1);
     for (size_t i = start_ext ? 1 : 0; i < sa.size(); i += 2) sl.emplace_back(i, std::min(i + 2, sa.size()));
     for (auto &p : sl)  // one invalid read alignment discards the read
-        if (p.second - p.first == 2 && c.las[sa[p.first].la].aread == c.las[sa[p.first + 1].la].aread) return;
+        if (p.second - p.first == 2 && c.L(sa[p.first].la).aread == c.L(sa[p.first + 1].la).aread) return;
     for (auto &p : sl) {
         dh_read_alignment ra;
         memset(&ra, 0, sizeof(ra));
         Edge e;
         if (p.second - p.first == 2) {
             SA a = sa[p.first], b = sa[p.first + 1];
-            if (!(c.las[a.la].aread < c.las[b.la].aread)) std::swap(a, b);  // getInOrder
+            if (!(c.L(a.la).aread < c.L(b.la).aread)) std::swap(a, b);  // getInOrder
             ra.n = 2;
             ra.la0 = (int32_t)a.la;
             ra.la1 = (int32_t)b.la;
             ra.seed0 = (uint8_t)a.seed;
             ra.seed1 = (uint8_t)b.seed;
-            e = make_edge(Node{c.las[a.la].aread, a.seed == FRONT ? BEGIN : END},
-                          Node{c.las[b.la].aread, b.seed == FRONT ? BEGIN : END});
+            e = make_edge(Node{c.L(a.la).aread, a.seed == FRONT ? BEGIN : END},
+                          Node{c.L(b.la).aread, b.seed == FRONT ? BEGIN : END});
         } else {
             const SA a = sa[p.first];
             ra.n = 1;
             ra.la0 = (int32_t)a.la;
             ra.la1 = -1;
             ra.seed0 = (uint8_t)a.seed;
-            const int32_t ct = c.las[a.la].aread;
+            const int32_t ct = c.L(a.la).aread;
             e = a.seed == FRONT ? make_edge(Node{ct, PRE}, Node{ct, BEGIN}) : make_edge(Node{ct, END}, Node{ct, POST});
         }
-        ra.read = c.las[ra.la0].bread;
+        ra.read = c.L(ra.la0).bread;
         out.push_back(RawJoin{e.s, e.e, ra});
     }
 }
@@ -223,7 +231,7 @@ int collect_raw_joins(const char *who, const dh_la *las, int64_t n, const int64_
                       const int64_t *read_off, int32_t read_first, int32_t nreads, std::vector<std::vector<RawJoin>> *raws,
                       std::vector<std::vector<Edge>> *edges)
 {
-    const Ctx c{las, contig_off, read_off - read_first};
+    Ctx c{las, contig_off, read_off - read_first};
     auto T0_ = std::chrono::steady_clock::now();
     auto LAP_ = [&](const char *w) { if (getenv("DH_TRACE")) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[scaffold] %-24s %.2f ms\n", w, std::chrono::duration<double, std::milli>(t - T0_).count()); T0_ = t; } };
     // ---- the enabled LAs grouped by read, input order inside a read
@@ -282,8 +290,9 @@ int collect_raw_joins(const char *who, const dh_la *las, int64_t n, const int64_
     return DH_OK;
 }
 
+struct Resolver;
 int scaffold_from_edges(std::vector<std::vector<Edge>> &found, int32_t ncontigs, const int32_t *input_gaps, int32_t ngaps,
-                        const dh_scaffold_opts *opts, dh_scaffold **out);
+                        const dh_scaffold_opts *opts, dh_scaffold **out, Resolver *rs = nullptr);
 }  // namespace
 
 extern "C" int dh_scaffold_pileups(const dh_la *las, int64_t n, const int64_t *contig_off, int32_t ncontigs,
@@ -400,8 +409,186 @@ int dh_scaffold_from_join_blobs(const uint8_t *const *blobs, const int64_t *size
 }
 
 namespace {
+// ---- resolveBubbles (pileups.d:1100-1590).  A bubble: a cycle of at most max_bubble_size nodes with exactly two nodes of
+// degree >= 3 (extension joins not counted) that are joined by an edge carrying a pile-up -- the reads of that pile-up
+// SKIP the contigs on the other side of the cycle (their alignments there were masked or filtered away).  The skipping
+// reads are mapped onto the intermediate contigs once more, without any mask (remap = getReadAlignmentsOnContigs,
+// :1316-1385: dh_remap_skipping_reads on the device), their read alignments are collected again from the old and the
+// new alignments together, kept iff they walk the skipped path in order (collectFixedSimpleBubbles :1414-1491), and
+// replace the pile-up of the skipping edge.
+struct Resolver {
+    Ctx c;                       // LA access incl. the alignments added so far
+    std::vector<dh_la> *extra;   // the added alignments (LA index n + i)
+    // contig ids, read ids (ascending, distinct) -> alignments with ids of the full DBs, DISABLED unless they cover their contig
+    std::function<int(const std::vector<int32_t> &, const std::vector<int32_t> &, std::vector<dh_la> &)> remap;
+    int32_t max_bubble_size = 8, max_iterations = 4;  // commandline.d:1826-1837
+    int32_t resolved = 0;
+};
+
+inline bool is_ext_join(const Edge &e)
+{
+    return e.s.contig == e.e.contig && ((e.s.part == PRE && e.e.part == BEGIN) || (e.s.part == END && e.e.part == POST));
+}
+
+// Paton's cycle base exactly as util/math.d:2380-2480 walks it (roots in node order, LIFO, incident edges in edge order)
+std::vector<std::vector<int32_t>> cycle_base(const std::vector<Edge> &g, const std::vector<std::vector<int32_t>> &inc)
+{
+    const size_t nn = inc.size();
+    std::vector<std::vector<int32_t>> used(nn), cycles;
+    std::vector<int32_t> parent(nn, -1), stack;
+    auto has = [&](int32_t node, int32_t x) { return std::find(used[(size_t)node].begin(), used[(size_t)node].end(), x) != used[(size_t)node].end(); };
+    for (int32_t root = 0; root < (int32_t)nn; root++) {
+        if (parent[(size_t)root] >= 0 || inc[(size_t)root].empty()) continue;  // (isolated nodes yield nothing)
+        parent[(size_t)root] = root;
+        used[(size_t)root].push_back(root);
+        stack.push_back(root);
+        while (!stack.empty()) {
+            const int32_t cur = stack.back();
+            stack.pop_back();
+            const Node me{cur / 4, cur % 4};
+            for (int32_t ei : inc[(size_t)cur]) {
+                const Edge &e = g[(size_t)ei];
+                const Node o = e.s == me ? e.e : e.s;
+                const int32_t nb = o.contig * 4 + o.part;
+                if (used[(size_t)nb].empty()) {
+                    parent[(size_t)nb] = cur;
+                    used[(size_t)nb].push_back(cur);
+                    stack.push_back(nb);
+                } else if (nb == cur)
+                    cycles.push_back({cur});
+                else if (!has(cur, nb)) {
+                    std::vector<int32_t> cyc{nb, cur};
+                    int32_t p = parent[(size_t)cur];
+                    for (; !has(nb, p); p = parent[(size_t)p]) cyc.push_back(p);
+                    cyc.push_back(p);
+                    cycles.push_back(std::move(cyc));
+                    used[(size_t)nb].push_back(cur);
+                }
+            }
+        }
+    }
+    return cycles;
+}
+
+int resolve_bubbles(std::vector<Edge> &g, int32_t ncontigs, Resolver &rs)
+{
+    auto find_edge = [&](Node a, Node b) -> Edge * {
+        const Edge key = make_edge(a, b);
+        auto it = std::lower_bound(g.begin(), g.end(), key, key_less);
+        return it != g.end() && key_eq(*it, key) ? &*it : nullptr;
+    };
+    std::vector<SA> sa;
+    std::vector<std::pair<size_t, size_t>> sl;
+    for (int32_t iter = 0; iter < rs.max_iterations; iter++) {
+        const auto inc = incidence(g, ncontigs);
+        std::vector<int32_t> deg(inc.size(), 0);
+        for (size_t v = 0; v < inc.size(); v++)
+            for (int32_t ei : inc[v]) deg[v] += is_ext_join(g[(size_t)ei]) ? 0 : 1;
+        auto node_of = [](int32_t v) { return Node{v / 4, v % 4}; };
+        std::vector<std::vector<int32_t>> bubbles;
+        for (auto &cyc : cycle_base(g, inc)) {
+            if ((int32_t)cyc.size() > rs.max_bubble_size) continue;
+            int32_t esc[2], ne = 0;
+            bool ok = true;
+            for (int32_t v : cyc) {
+                if (deg[(size_t)v] >= 3) {
+                    if (ne < 2) esc[ne] = v;
+                    ne++;
+                } else if (deg[(size_t)v] < 2)
+                    ok = false;
+            }
+            if (!ok || ne != 2) continue;
+            const Edge *sk = find_edge(node_of(esc[0]), node_of(esc[1]));
+            if (sk && (sk->types & T_PILEUP)) bubbles.push_back(cyc);
+        }
+        if (bubbles.empty()) break;
+        for (const auto &cyc : bubbles) {
+            int32_t esc[2], ne = 0;
+            for (int32_t v : cyc)
+                if (deg[(size_t)v] >= 3 && ne < 2) esc[ne++] = v;
+            Edge *sk = find_edge(node_of(esc[0]), node_of(esc[1]));
+            if (!sk || !(sk->types & T_PILEUP)) continue;  // resolved through another bubble of this iteration
+            // the skipping reads and the contigs they skip
+            std::vector<int32_t> inter, rids;
+            for (int32_t v : cyc)
+                if (deg[(size_t)v] == 2) inter.push_back(v / 4);
+            std::sort(inter.begin(), inter.end());
+            inter.erase(std::unique(inter.begin(), inter.end()), inter.end());
+            for (const dh_read_alignment &ra : sk->ras) rids.push_back(ra.read);
+            std::sort(rids.begin(), rids.end());
+            rids.erase(std::unique(rids.begin(), rids.end()), rids.end());
+            std::vector<dh_la> fresh;
+            if (int rc = rs.remap(inter, rids, fresh)) return rc;
+            const int64_t first_new = rs.c.n + (int64_t)rs.extra->size();
+            rs.extra->insert(rs.extra->end(), fresh.begin(), fresh.end());
+            // the skipped path: from the skipping edge's start around the cycle to its end (the long way)
+            const int32_t v0 = sk->s.contig * 4 + sk->s.part, v1 = sk->e.contig * 4 + sk->e.part;
+            const int32_t L = (int32_t)cyc.size();
+            const int32_t i0 = (int32_t)(std::find(cyc.begin(), cyc.end(), v0) - cyc.begin()),
+                          i1 = (int32_t)(std::find(cyc.begin(), cyc.end(), v1) - cyc.begin());
+            auto walk = [&](int32_t a, int32_t b) {
+                std::vector<Node> p;
+                for (int32_t x = 0; x <= ((b - a) % L + L) % L; x++) p.push_back(node_of(cyc[(size_t)((a + x) % L)]));
+                return p;
+            };
+            std::vector<Node> path = walk(i0, i1);
+            if (path.size() == 2) path = walk(i1, i0);
+            if (path.size() <= 2) return dh_fail(DH_EINVAL, "resolveBubbles: skipped path is too short");
+            // old and new alignments of every skipping read, in that order (pileups.d:1262-1266), enabled ones only
+            std::vector<std::pair<int32_t, int64_t>> al;  // (read, LA)
+            for (const dh_read_alignment &ra : sk->ras) {
+                al.emplace_back(ra.read, (int64_t)ra.la0);
+                if (ra.n == 2) al.emplace_back(ra.read, (int64_t)ra.la1);
+            }
+            for (size_t x = 0; x < fresh.size(); x++)
+                if (!(fresh[x].flags & DH_FLAG_DISABLED)) al.emplace_back(fresh[x].bread, first_new + (int64_t)x);
+            std::stable_sort(al.begin(), al.end(), [](const auto &p, const auto &q) { return p.first < q.first; });
+            std::vector<RawJoin> raw;
+            for (size_t i = 0; i < al.size();) {
+                size_t j = i;
+                std::vector<int64_t> idx;
+                while (j < al.size() && al[j].first == al[i].first) idx.push_back(al[j++].second);
+                const size_t r0 = raw.size();
+                read_joins(rs.c, idx.data(), (int64_t)idx.size(), raw, sa, sl);
+                if (raw.size() > r0) {
+                    // collectFixedSimpleBubbles: the seeded alignments (read order) must walk the skipped path
+                    auto matches = [&](const Node &nd, const SA &x) {
+                        return nd.contig == rs.c.L(x.la).aread && ((nd.part == BEGIN && x.seed == FRONT) || (nd.part == END && x.seed == BACK));
+                    };
+                    const bool rev = path[0].contig != rs.c.L(sa[0].la).aread;
+                    bool good = true;
+                    size_t at = 0;
+                    auto pnode = [&](size_t x) { return rev ? path[path.size() - 1 - x] : path[x]; };
+                    while (at < sa.size() && !matches(pnode(0), sa[at])) at++;
+                    if (at == sa.size() || path.size() > sa.size() - at) good = false;
+                    for (size_t x = 0; good && x < path.size(); x++) good = matches(pnode(x), sa[at + x]);
+                    if (!good) raw.resize(r0);
+                }
+                i = j;
+            }
+            sk->types &= ~(uint32_t)T_PILEUP;
+            sk->ras.clear();
+            std::vector<Edge> add;
+            // one edge per read alignment, merged by the stable multi-edge merge (bulkAdd!mergeJoins)
+            for (const RawJoin &r : raw) {
+                Edge e;
+                e.s = r.s;
+                e.e = r.e;
+                e.types = T_PILEUP;
+                e.ras.push_back(r.ra);
+                add.push_back(std::move(e));
+            }
+            for (Edge &e : add) g.push_back(std::move(e));
+            merge_multi_edges(g);
+            rs.resolved++;
+        }
+        remove_none_joins(g);
+    }
+    return DH_OK;
+}
+
 int scaffold_from_edges(std::vector<std::vector<Edge>> &found, int32_t ncontigs, const int32_t *input_gaps, int32_t ngaps,
-                        const dh_scaffold_opts *opts, dh_scaffold **out)
+                        const dh_scaffold_opts *opts, dh_scaffold **out, Resolver *rs)
 {
     auto T0_ = std::chrono::steady_clock::now();
     auto LAP_ = [&](const char *w) { if (getenv("DH_TRACE")) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[scaffold] %-24s %.2f ms\n", w, std::chrono::duration<double, std::milli>(t - T0_).count()); T0_ = t; } };
@@ -419,6 +606,10 @@ int scaffold_from_edges(std::vector<std::vector<Edge>> &found, int32_t ncontigs,
     merge_multi_edges(g);
     remove_none_joins(g);
     LAP_("graph merge");
+    if (rs) {
+        if (int rc = resolve_bubbles(g, ncontigs, *rs)) return rc;
+        LAP_("resolve bubbles");
+    }
     // ---- discardAmbiguousJoins (pileups.d:1592-1657)
     {
         const auto inc = incidence(g, ncontigs);
@@ -603,3 +794,108 @@ extern "C" int dh_scaffold_gap_pileups(const dh_scaffold *s, const dh_la *las, i
     if (skipped) *skipped = skip;
     return dh_pileups_create(cl.data(), cnt.data(), (int32_t)cl.size(), tri.data(), out);
 }
+
+// dh_scaffold_pileups with resolveBubbles (pileups.d:1124-1315) between the raw scaffold and discardAmbiguousJoins, as
+// build() runs it (pileups.d:186).  The alignments the resolver adds are returned in *extra: LA index n + i of the
+// result's read alignments = record i of *extra (ids of the full DBs; traces for the cropper when the device maps).
+static int scaffold_resolved(const dh_la *las, int64_t n, const int64_t *contig_off, int32_t ncontigs, const int64_t *read_off,
+                             int32_t nreads, const int32_t *input_gaps, int32_t ngaps, const dh_scaffold_opts *opts,
+                             int32_t max_bubble_size, int32_t max_iterations,
+                             std::function<int(const std::vector<int32_t> &, const std::vector<int32_t> &, std::vector<dh_la> &)> remap,
+                             std::vector<dh_la> &extra, dh_scaffold **out, int32_t *resolved)
+{
+    for (int32_t g = 0; g < ngaps; g++)
+        if (input_gaps[2 * g] < 0 || input_gaps[2 * g] >= ncontigs || input_gaps[2 * g + 1] < 0 || input_gaps[2 * g + 1] >= ncontigs)
+            return dh_fail(DH_EINVAL, "dh_scaffold_pileups: input gap names a contig out of range");
+    std::vector<std::vector<Edge>> found;
+    if (int rc = collect_raw_joins("dh_scaffold_pileups", las, n, contig_off, ncontigs, read_off, 0, nreads, nullptr, &found)) return rc;
+    Resolver rs;
+    rs.c = Ctx{las, contig_off, read_off};
+    rs.c.n = n;
+    rs.c.extra = &extra;
+    rs.extra = &extra;
+    rs.remap = [&](const std::vector<int32_t> &cids, const std::vector<int32_t> &rids, std::vector<dh_la> &fresh) -> int {
+        if (int rc = remap(cids, rids, fresh)) return rc;
+        for (const dh_la &l : fresh)
+            if (l.aread < 0 || l.aread >= ncontigs || l.bread < 0 || l.bread >= nreads)
+                return dh_fail(DH_EINVAL, "resolveBubbles: the re-mapping returned an id outside the DBs");
+        return DH_OK;
+    };
+    rs.max_bubble_size = max_bubble_size > 0 ? max_bubble_size : 8;
+    rs.max_iterations = max_iterations > 0 ? max_iterations : 4;
+    const int rc = scaffold_from_edges(found, ncontigs, input_gaps, ngaps, opts, out, &rs);
+    if (resolved) *resolved = rs.resolved;
+    return rc;
+}
+
+// host only: the re-mapping is the caller's (tests feed the oracle's alignments; a D host could spawn damapper)
+extern "C" int dh_scaffold_pileups_cb(const dh_la *las, int64_t n, const int64_t *contig_off, int32_t ncontigs, const int64_t *read_off,
+                                      int32_t nreads, const int32_t *input_gaps, int32_t ngaps, const dh_scaffold_opts *opts,
+                                      int32_t max_bubble_size, int32_t max_iterations, dh_remap_fn remap, void *user,
+                                      dh_scaffold **out, dh_la_set **extra, int32_t *resolved)
+{
+    if ((n > 0 && !las) || !contig_off || !read_off || !opts || !out || !extra || !remap || ncontigs < 0 || nreads < 0 || n < 0 ||
+        n >= (1ll << 30) || (ngaps > 0 && !input_gaps) || ngaps < 0)
+        return dh_fail(DH_EINVAL, "dh_scaffold_pileups_cb: bad argument");
+    dh_la_set *ex = new dh_la_set();
+    std::vector<dh_la> added;
+    const int rc = scaffold_resolved(las, n, contig_off, ncontigs, read_off, nreads, input_gaps, ngaps, opts, max_bubble_size,
+                                     max_iterations,
+                                     [&](const std::vector<int32_t> &cids, const std::vector<int32_t> &rids, std::vector<dh_la> &fresh) -> int {
+                                         dh_la *p = nullptr;
+                                         int64_t cnt = 0;
+                                         if (int rc2 = remap(user, cids.data(), (int32_t)cids.size(), rids.data(), (int32_t)rids.size(), &p, &cnt)) {
+                                             free(p);
+                                             return dh_fail(rc2, "resolveBubbles: the re-mapping callback failed");
+                                         }
+                                         if (cnt < 0 || (cnt > 0 && !p)) return dh_fail(DH_EINVAL, "resolveBubbles: bad callback result");
+                                         fresh.assign(p, p + cnt);
+                                         free(p);
+                                         return DH_OK;
+                                     },
+                                     added, out, resolved);
+    if (rc) {
+        delete ex;
+        return rc;
+    }
+    ex->la.assign(added.begin(), added.end());
+    *extra = ex;
+    return DH_OK;
+}
+
+// the device maps: dh_remap_skipping_reads with the mapping options of the caller, no mask
+extern "C" int dh_scaffold_pileups_resolved(dh_ctx *ctx, dh_db *contigs, dh_db *reads, const dh_la *las, int64_t n,
+                                            const int32_t *input_gaps, int32_t ngaps, const dh_scaffold_opts *opts,
+                                            const dh_align_opts *map_opts, int32_t allowance, int32_t max_bubble_size,
+                                            int32_t max_iterations, dh_scaffold **out, dh_la_set **extra, int32_t *resolved)
+{
+    if (!ctx || !contigs || !reads || (n > 0 && !las) || !opts || !map_opts || !out || !extra || n < 0 || n >= (1ll << 30) ||
+        (ngaps > 0 && !input_gaps) || ngaps < 0 || allowance < 0)
+        return dh_fail(DH_EINVAL, "dh_scaffold_pileups_resolved: bad argument");
+    dh_la_set *ex = new dh_la_set();
+    ex->tspace = map_opts->tspace;
+    std::vector<dh_la> added;
+    const int rc = scaffold_resolved(
+        las, n, contigs->h_off.data(), contigs->n, reads->h_off.data(), reads->n, input_gaps, ngaps, opts, max_bubble_size, max_iterations,
+        [&](const std::vector<int32_t> &cids, const std::vector<int32_t> &rids, std::vector<dh_la> &fresh) -> int {
+            dh_la_set *set = nullptr;
+            if (int rc2 = dh_remap_skipping_reads(ctx, contigs, reads, cids.data(), (int32_t)cids.size(), rids.data(), (int32_t)rids.size(),
+                                                  map_opts, allowance, &set))
+                return rc2;
+            const int64_t t0 = (int64_t)ex->trace.size();
+            fresh.assign(set->la.begin(), set->la.end());
+            for (dh_la &l : fresh) l.toff += t0;
+            ex->trace.insert(ex->trace.end(), set->trace.begin(), set->trace.end());
+            dh_la_set_destroy(set);
+            return DH_OK;
+        },
+        added, out, resolved);
+    if (rc) {
+        delete ex;
+        return rc;
+    }
+    ex->la.assign(added.begin(), added.end());
+    *extra = ex;
+    return DH_OK;
+}
+

@@ -308,8 +308,8 @@ int dh_map_reads(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_t first, int32
  * collectReadAlignments per read (pileups.d:821-888), joins merged per edge (pileups.d:626-636), forks
  * resolved by read support with a bonus for joins of the input assembly (pileups.d:1592-1657,
  * 1754-1804), min_spanning_reads (pileups.d:1807-1838), extensions merged into their gap
- * (scaffold.d:789-816), pile-ups in edge order (pileups.d:435-444).  resolveBubbles (pileups.d:1124-1590)
- * is not included.  DISABLED LAs are ignored.  input_gaps: ngaps pairs (begin contig, end contig) of the
+ * (scaffold.d:789-816), pile-ups in edge order (pileups.d:435-444).  resolveBubbles (pileups.d:1124-1590): see
+ * dh_scaffold_pileups_resolved below.  DISABLED LAs are ignored.  input_gaps: ngaps pairs (begin contig, end contig) of the
  * input assembly's scaffolding (pileups.d:796-811).  Host only. */
 typedef struct dh_scaffold_opts {
     int32_t min_spanning_reads;  /* --min-spanning-reads, default 3 */
@@ -332,6 +332,28 @@ typedef struct dh_scaffold dh_scaffold;
 int dh_scaffold_pileups(const dh_la *las, int64_t n, const int64_t *contig_off, int32_t ncontigs,
                         const int64_t *read_off, int32_t nreads, const int32_t *input_gaps, int32_t ngaps,
                         const dh_scaffold_opts *opts, dh_scaffold **out);
+/* The same builder WITH resolveBubbles (pileups.d:1100-1315, 1387-1590; position in build(): pileups.d:186): cycles of
+ * at most max_bubble_size nodes (0 = the reference's 8, commandline.d:1826-1833) with exactly two nodes of degree >= 3
+ * joined by an edge that carries a pile-up -- its reads skip the contigs on the other side of the cycle, whose
+ * alignments a mask or a filter removed -- are linearised: the skipping reads are mapped onto the intermediate contigs
+ * again without any mask (getReadAlignmentsOnContigs :1316-1385), their read alignments are collected from old and new
+ * alignments together, kept iff they walk the skipped path in order (collectFixedSimpleBubbles :1414-1491), and replace
+ * the skipping pile-up; at most max_iterations sweeps (0 = 4, :1835-1837).  The alignments added on the way come back in
+ * *extra: LA index n + i in the result's read alignments = record i of *extra.  *resolved (optional) = bubbles handled.
+ *   dh_scaffold_pileups_resolved  the device maps (dh_remap_skipping_reads with map_opts; chains must cover their contig
+ *                                 within `allowance`); contig / read offsets are those of the DBs; *extra carries the traces
+ *   dh_scaffold_pileups_cb        host only: `remap` supplies the alignments (las_out malloc'd by the callback, freed here;
+ *                                 ids of the full DBs, DISABLED unless the chain covers its contig) */
+typedef int (*dh_remap_fn)(void *user, const int32_t *contig_ids, int32_t ncontig_ids, const int32_t *read_ids, int32_t nread_ids,
+                           dh_la **las_out, int64_t *n_out);
+int dh_scaffold_pileups_cb(const dh_la *las, int64_t n, const int64_t *contig_off, int32_t ncontigs, const int64_t *read_off,
+                           int32_t nreads, const int32_t *input_gaps, int32_t ngaps, const dh_scaffold_opts *opts,
+                           int32_t max_bubble_size, int32_t max_iterations, dh_remap_fn remap, void *user, dh_scaffold **out,
+                           dh_la_set **extra, int32_t *resolved);
+int dh_scaffold_pileups_resolved(dh_ctx *ctx, dh_db *contigs, dh_db *reads, const dh_la *las, int64_t n, const int32_t *input_gaps,
+                                 int32_t ngaps, const dh_scaffold_opts *opts, const dh_align_opts *map_opts, int32_t allowance,
+                                 int32_t max_bubble_size, int32_t max_iterations, dh_scaffold **out, dh_la_set **extra,
+                                 int32_t *resolved);
 int32_t dh_scaffold_npiles(const dh_scaffold *s);
 int64_t dh_scaffold_nentries(const dh_scaffold *s);
 const dh_join *dh_scaffold_joins(const dh_scaffold *s);

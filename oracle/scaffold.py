@@ -18,8 +18,9 @@ Pinned by the reference's own unittests (tests/test_scaffold.py): collectReadAli
 
 Where the reference sorts with an unstable sort and then merges equal elements (bulkAdd, findCorrectGapJoin)
 this restatement sorts stably, i.e. it fixes the order the reference leaves open.  resolveBubbles
-(pileups.d:1124-1590) re-aligns reads with the external tools and is not restated: cyclic subgraphs
-are left to discardAmbiguousJoins, which removes their forks.
+(pileups.d:1124-1590) is restated below (find_cyclic_subgraphs = Paton's cycle base, util/math.d:2362-2480, pinned by
+its unittest :2488-2535; the BubbleResolver's graph surgery); the re-mapping of the skipping reads onto the
+intermediate contigs (getReadAlignmentsOnContigs, :1316-1385: the external aligner) is a callback.
 
 An alignment chain is a dict: id, contigA (id, length), contigB (id, length), complement, disabled and
 first/last local alignment coordinates: a_begin, a_end, b_begin, b_end (b on the oriented read).
@@ -311,12 +312,143 @@ def collect_pile_ups(edges):
     return [(e, e["ras"]) for e in edges if e["types"] & T_PILEUP and e["ras"] and pile_is_valid(e["ras"])]
 
 
+# ---------------------------------------------------------------- resolveBubbles, pileups.d:1100-1590
+def incident_edges(edges, nodes):
+    """IncidentEdgesCache (math.d:1080-1130): per node the incident edges in edge order (a self loop once)."""
+    idx = {n: i for i, n in enumerate(nodes)}
+    inc = [[] for _ in nodes]
+    for e in edges:
+        inc[idx[e["start"]]].append(e)
+        if e["end"] != e["start"]:
+            inc[idx[e["end"]]].append(e)
+    return inc
+
+
+def find_cyclic_subgraphs(nodes, edges, inc=None):
+    """Paton's cycle base as util/math.d:2380-2480 walks it: roots in node order, a LIFO of discovered nodes, the
+    incident edges of a node in edge order.  Returns cycles as lists of node indices."""
+    idx = {n: i for i, n in enumerate(nodes)}
+    if inc is None:
+        inc = incident_edges(edges, nodes)
+    n = len(nodes)
+    used = [set() for _ in range(n)]
+    parent = [-1] * n
+    cycles = []
+    for root in range(n):
+        if parent[root] >= 0:
+            continue
+        parent[root] = root
+        used[root].add(root)
+        stack = [root]
+        while stack:
+            cur = stack.pop()
+            for e in inc[cur]:
+                nb = idx[e["end"] if e["start"] == nodes[cur] else e["start"]]
+                if not used[nb]:
+                    parent[nb] = cur
+                    used[nb].add(cur)
+                    stack.append(nb)
+                elif nb == cur:
+                    cycles.append([cur])
+                elif nb not in used[cur]:
+                    cyc = [nb, cur]
+                    p = parent[cur]
+                    while p not in used[nb]:
+                        cyc.append(p)
+                        p = parent[p]
+                    cyc.append(p)
+                    cycles.append(cyc)
+                    used[nb].add(cur)
+    return cycles
+
+
+def is_extension_join(e):
+    return is_front_ext_join(e) or is_back_ext_join(e)
+
+
+def _node_matches(node, sa):
+    """contigNodeMatchesReadAlignment (pileups.d:1493-1510)."""
+    return node[0] == sa[0]["a_id"] and ((node[1] == BEGIN and sa[1] == FRONT) or (node[1] == END and sa[1] == BACK))
+
+
+def collect_fixed_simple_bubbles(same_read, skipped_path):
+    """pileups.d:1414-1491: the read alignments of one skipping read after the re-mapping, valid iff they walk the
+    skipped path in order."""
+    ras = collect_read_alignments(same_read)
+    if not ras:
+        return []
+    path = skipped_path[::-1] if skipped_path[0][0] != ras[0][0][0]["a_id"] else skipped_path
+    flat = [sa for ra in ras for sa in ra]
+    at = next((i for i, sa in enumerate(flat) if _node_matches(path[0], sa)), None)
+    if at is None or len(path) > len(flat) - at:
+        return []
+    if any(not _node_matches(nd, sa) for nd, sa in zip(path, flat[at:])):
+        return []
+    return ras
+
+
+def resolve_bubbles(edges, num_contigs, remap, max_bubble_size=8, max_iterations=4):
+    """BubbleResolver.run (pileups.d:1124-1315).  remap(skipping pile-up, intermediate contig ids) -> alignment chains of
+    the skipping reads on the intermediate contigs (disabled unless they cover their contig completely)."""
+    nodes = nodes_of(num_contigs)
+    idx = {n: i for i, n in enumerate(nodes)}
+    for _ in range(max_iterations):
+        inc = incident_edges(edges, nodes)
+        deg = [sum(1 for e in ie if not is_extension_join(e)) for ie in inc]
+        find = lambda a, b: next((e for e in edges if _key(e) == _key(edge(a, b))), None)  # noqa: E731
+
+        def simple(cyc):
+            esc = [nodes[i] for i in cyc if deg[i] >= 3]
+            if len(esc) != 2 or any(deg[i] < 2 for i in cyc):
+                return False
+            sk = find(esc[0], esc[1])
+            return sk is not None and bool(sk["types"] & T_PILEUP)
+        bubbles = [c for c in find_cyclic_subgraphs(nodes, edges, inc) if len(c) <= max_bubble_size and simple(c)]
+        if not bubbles:
+            break
+        for cyc in bubbles:
+            esc = [nodes[i] for i in cyc if deg[i] >= 3]
+            sk = find(esc[0], esc[1])
+            if not sk["types"] & T_PILEUP:
+                continue   # resolved through another bubble of this iteration
+            pile = sk["ras"]
+            inter = sorted({nodes[i][0] for i in cyc if deg[i] == 2})
+            new = remap(pile, inter)
+            augmented = [sa[0] for ra in pile for sa in ra] + list(new)
+            i0, i1 = cyc.index(idx[sk["start"]]), cyc.index(idx[sk["end"]])
+            walk = lambda a, b: [cyc[(a + x) % len(cyc)] for x in range((b - a) % len(cyc) + 1)]  # noqa: E731
+            path = walk(i0, i1)
+            if len(path) == 2:
+                path = walk(i1, i0)
+            assert len(path) > 2, "skipped path is too short"
+            path = [nodes[i] for i in path]
+            al = sorted([a for a in augmented], key=lambda a: a["b_id"])
+            al = [a for a in al if not a["disabled"]]
+            joins, i = [], 0
+            while i < len(al):
+                j = i
+                while j < len(al) and al[j]["b_id"] == al[i]["b_id"]:
+                    j += 1
+                for ra in collect_fixed_simple_bubbles(al[i:j], path):
+                    if ra_is_valid(ra):
+                        joins.append(make_join(ra_in_order(ra)))
+                i = j
+            sk["types"] &= ~T_PILEUP
+            sk["ras"] = []
+            edges = bulk_add(edges, joins, merge_joins)
+        edges = remove_none_joins(edges)
+    return edges
+
+
 def build(num_contigs, alignments, input_gaps, min_spanning_reads=3, best_pile_up_margin=3.0,
-          existing_gap_bonus=6.0, merge_extensions=True):
-    """pileups.d:173-208 without resolveBubbles.  input_gaps: (begin contig id, end contig id)."""
+          existing_gap_bonus=6.0, merge_extensions=True, remap=None, max_bubble_size=8, max_bubble_iterations=4):
+    """pileups.d:173-208.  input_gaps: (begin contig id, end contig id); remap: the re-mapping callback of
+    resolve_bubbles (None: resolveBubbles is skipped, cyclic subgraphs are left to discardAmbiguousJoins)."""
     joins = collect_scaffold_joins(alignments)
     joins += [edge((b, END), (e, BEGIN), T_INPUTGAP) for b, e in input_gaps]
     sc = build_scaffold(num_contigs, joins)
+    if remap is not None:
+        sc = resolve_bubbles(sc, num_contigs, remap, max_bubble_size, max_bubble_iterations)
     sc = discard_ambiguous_joins(sc, num_contigs, best_pile_up_margin, existing_gap_bonus)
     sc = enforce_min_spanning_reads(sc, min_spanning_reads)
     sc = remove_input_gaps(sc)

@@ -514,3 +514,108 @@ def test_consensus_band_classes_and_scalar_fill_agree(gpu_ctx, monkeypatch):
     for f in rec.dtype.names:
         if f != "pad":
             assert np.array_equal(rec[f], rec2[f]), f
+
+
+def test_bubble_resolver_on_a_mapping_with_a_masked_contig(gpu_ctx):
+    """resolveBubbles end to end (pileups.d:1100-1590): a 3 kb contig is covered by the repeat mask, so the mapping seeds
+    nothing on it and the reads that cross it SKIP it -- their join (left contig end -> right contig begin) closes a cycle
+    with the input-gap joins around the masked contig.  dh_scaffold_pileups_resolved maps the skipping reads onto that
+    contig again without the mask on the device (dh_remap_skipping_reads), collects their read alignments from old + new
+    alignments and replaces the skipping pile-up by the two gap pile-ups.  Membership equals oracle/scaffold.py's
+    BubbleResolver driven by the oracle's own re-mapping (oz.align_db on the same subsets); the process stage then closes
+    both gaps from the augmented alignments."""
+    from oracle import collect_filters as cf
+    from oracle import scaffold as sc
+    rng = np.random.default_rng(99)
+    g = sim.genome(4242, 60000)
+    cuts = [(0, 16000), (16300, 19300), (19600, 38000), (38400, 60000)]
+    contigs = sim.SeqDb.from_list([g[a:b].copy() for a, b in cuts])
+    reads, _ = sim.reads(777, g, 240, 11000)
+    # the repeat mask: all of contig 1
+    contigs.mask = (np.asarray([0, 0, 1, 1, 1], dtype=np.int64), np.asarray([0, 3000, 0, 0], dtype=np.int32))
+    mo = dentist_amd.default_align_opts(k=20, kmer_mod=2, width=64, xdrop=60, algo=1)
+    po = dentist_amd.default_process_opts(algo=1, rounds=2)
+    A, B = gpu_ctx.db(contigs), gpu_ctx.db(reads)
+    las, trace = gpu_ctx.align_db(A, B, mo, select_best=True)
+    las, dropped, _ = dentist_amd.collect_filter(las, contigs.off, reads.off, po, inplace=True)
+    assert not np.any(las["aread"] == 1), "the masked contig must not be seeded"
+    gaps_in = np.asarray([[0, 1], [1, 2], [2, 3]], dtype=np.int32)
+    plain, _ = dentist_amd.scaffold_spanning_pileups(las, contigs.off, reads.off, gaps_in, with_extensions=True,
+                                                     min_spanning_reads=po.min_reads)
+    assert sorted(int(plain.get(i)[0]) for i in range(len(plain))) == [2], "without the resolver only the last gap has a pile-up"
+    piles, skipped, las_all, trace_all, resolved = dentist_amd.scaffold_spanning_pileups(
+        las, contigs.off, reads.off, gaps_in, with_extensions=True, min_spanning_reads=po.min_reads,
+        resolve=dict(ctx=gpu_ctx, contigs=A, reads=B, map_opts=mo, trace=trace, allowance=100))
+    assert resolved == 1 and len(las_all) > len(las)
+    # ---- oracle: same mapping (checked bit-exact elsewhere), its own re-mapping, its own resolver
+    oo = oz.default_opts(k=20, kmer_mod=2, width=64, xdrop=60, algo=1)
+    n = len(las)
+
+    def chains_of(arr, first_id):
+        return [sc.chain(first_id + i, int(l["aread"]) + 1, contigs.length(int(l["aread"])), int(l["bread"]) + 1,
+                         reads.length(int(l["bread"])), bool(l["flags"] & 1), int(l["abpos"]), int(l["aepos"]),
+                         int(l["bbpos"]), int(l["bepos"]), disabled=bool(l["flags"] & 0x20)) for i, l in enumerate(arr)]
+    added = []
+
+    def remap(pile, inter):
+        rids = sorted({sa[0]["b_id"] - 1 for ra in pile for sa in ra})
+        cids = [c - 1 for c in inter]
+        sa_ = sim.SeqDb.from_list([contigs.seq(c) for c in cids])
+        sb_ = sim.SeqDb.from_list([reads.seq(r) for r in rids])
+        ol, ot, _ = oz.align_db(sa_, sb_, oo, nthreads=os.cpu_count() or 1, sort=True, select_best=True)
+        ol = ol.copy()
+        i = 0
+        while i < len(ol):   # chains: START then its NEXT records; enabled iff the chain covers its contig (allowance 100)
+            j = i + 1
+            while j < len(ol) and (ol[j]["flags"] & 0x8) and not (ol[j]["flags"] & 0x4):
+                j += 1
+            alen = sa_.length(int(ol[i]["aread"]))
+            if not (ol[i]["abpos"] <= 100 and ol[j - 1]["aepos"] >= alen - 100):
+                ol["flags"][i:j] |= 0x20
+            i = j
+        ol["aread"] = np.asarray(cids, dtype=np.int32)[ol["aread"]]
+        ol["bread"] = np.asarray(rids, dtype=np.int32)[ol["bread"]]
+        new = chains_of(ol, n + len(added))
+        added.extend(new)
+        return new
+    exp = {}
+    for e, ras in sc.build(contigs.n, chains_of(las, 0), [(int(a) + 1, int(b) + 1) for a, b in gaps_in],
+                           min_spanning_reads=po.min_reads, remap=remap):
+        (c0, p0), (c1, p1) = e["start"], e["end"]
+        if not (p0 == sc.END and p1 == sc.BEGIN and c1 == c0 + 1):
+            continue
+        ent = []
+        for ra in ras:
+            if len(ra) == 2:
+                a, b = sorted(ra, key=lambda s_: s_[0]["a_id"])
+                ent.append((a[0]["b_id"] - 1, a[0]["id"], b[0]["id"]))
+            elif ra[0][0]["a_id"] == c0:
+                ent.append((ra[0][0]["b_id"] - 1, ra[0][0]["id"], -1))
+            else:
+                ent.append((ra[0][0]["b_id"] - 1, -1, ra[0][0]["id"]))
+        exp[c0 - 1] = sorted(ent, key=lambda t: (t[0], t[1] < 0))
+    got = {}
+    for i in range(len(piles)):
+        gg, tri = piles.get(i)
+        got[int(gg)] = [tuple(int(x) for x in t) for t in tri.tolist()]
+    assert set(got) == set(exp) == {0, 1, 2}
+    assert len(las_all) == n + len(added)
+    for gg in got:
+        assert got[gg] == exp[gg], gg
+    assert any(t[2] >= n for t in got[0]) and any(t[1] >= n for t in got[1]), "the new pile-ups use the re-mapped alignments"
+    # ---- the process stage on the augmented alignments closes the gaps around the masked contig
+    # (with the mask on the contigs DB the flank re-alignment -- daligner -mrep -- cannot seed on the masked contig and the
+    # two gaps end as DH_PILE_FLANKS_NOT_UNIQUE; `process` without that mask closes them)
+    rec, bases = dentist_amd.process_pileups(gpu_ctx, A, B, las_all, trace_all, piles.select(las_all, po), po)
+    assert [int(r["status"]) for r in rec] == [4, 4, 0]
+    contigs.mask = None
+    A2 = gpu_ctx.db(contigs)
+    rec, bases = dentist_amd.process_pileups(gpu_ctx, A2, B, las_all, trace_all, piles.select(las_all, po), po)
+    assert [int(r["contig_left"]) for r in rec] == [0, 1, 2] and int((rec["status"] == 0).sum()) == 3
+    for r in rec:
+        gq = int(r["contig_left"])
+        cons = bases[r["cons_off"]:r["cons_off"] + r["cons_len"]]
+        ins = (sim.revcomp(cons) if r["comp"] else cons)[r["ins_begin"]:r["ins_end"]]
+        truth = g[cuts[gq][0] + r["left_aepos"]: cuts[gq + 1][0] + r["right_abpos"]]
+        ed, _ = oz.nw(truth, ins)
+        assert ed <= max(3, 0.02 * len(truth)), (gq, ed, len(truth))

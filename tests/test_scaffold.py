@@ -177,7 +177,8 @@ def test_product_collect_read_alignments_cases():
         assert ras == exp
 
 
-def _random_mapping(seed, nc=12, nreads=300):
+def _random_mapping(seed, nc=12, nreads=300, drop=0.05, truth=None):
+    """truth (optional dict): filled with (read, contig) -> the chain the read has on that contig, dropped or not"""
     rng = np.random.default_rng(seed)
     clen = rng.integers(3000, 9000, nc)
     gaps = rng.integers(50, 1500, nc - 1)
@@ -193,12 +194,15 @@ def _random_mapping(seed, nc=12, nreads=300):
             lo, hi = max(p, int(start[c])), min(p + rl, int(start[c] + clen[c]))
             if hi - lo < 300:
                 continue
-            if which < 0.05 and rng.random() < 0.5:
-                continue  # a dropped alignment: the read may then skip a contig
+            dropped = which < drop and rng.random() < 0.5  # a dropped alignment: the read may then skip a contig
             ab, ae = lo - int(start[c]), hi - int(start[c])
             bb, be = lo - p, hi - p
             if comp:
                 ab, ae, bb, be = int(clen[c]) - ae, int(clen[c]) - ab, rl - be, rl - bb
+            if truth is not None:
+                truth[(r, c + 1)] = (int(clen[c]), rl, comp, ab, ae, bb, be)
+            if dropped:
+                continue
             jit = int(rng.integers(0, 3))
             chains.append(sc.chain(cid, c + 1, int(clen[c]), r, rl, comp, ab, ae, bb + (jit if bb > 0 else 0), be,
                                    disabled=bool(rng.random() < 0.03)))
@@ -237,3 +241,120 @@ def test_spanning_subset_feeds_the_process_path():
         for rd, il, ir in tri[at:at + n]:
             assert las[il]["aread"] == c and las[ir]["aread"] == c + 1 and las[il]["bread"] == rd == las[ir]["bread"]
         at += n
+
+
+# ------------------------------------------------------------------ resolveBubbles (pileups.d:1100-1590)
+def test_oracle_cycle_base_reference_vector():
+    """util/math.d:2488-2535: Paton's cycle base on the unittest graph."""
+    E = [(0, 0), (0, 1), (0, 4), (1, 2), (2, 3), (2, 5), (2, 6), (3, 7), (4, 5), (5, 6)]
+    edges = [dict(start=a, end=b, types=0, ras=[]) for a, b in E]
+    assert sc.find_cyclic_subgraphs(list(range(8)), edges) == [[0], [2, 6, 5], [1, 2, 5, 4, 0]]
+
+
+def test_oracle_make_scaffold_join_vector():
+    """pileups.d:679-793: front extension, back extension, gap and input gap as joins."""
+    fe = sc.chain(3, 1, 100, 1, 10, False, 2, 6, 5, 10)
+    be = sc.chain(5, 1, 100, 1, 10, False, 94, 98, 0, 5)
+    g1 = sc.chain(11, 1, 100, 1, 10, True, 94, 98, 0, 5)
+    g2 = sc.chain(12, 2, 100, 1, 10, False, 94, 98, 0, 5)
+    j1 = sc.make_join([sc.seeded_from(fe)[0]])
+    j2 = sc.make_join([sc.seeded_from(be)[0]])
+    j3 = sc.make_join([sc.seeded_from(g1)[0], sc.seeded_from(g2)[0]])
+    assert (j1["start"], j1["end"]) == ((1, PRE), (1, BEGIN))
+    assert (j2["start"], j2["end"]) == ((1, END), (1, POST))
+    assert (j3["start"], j3["end"]) == ((1, END), (2, END))
+    j4 = sc.edge((1, END), (2, BEGIN), sc.T_INPUTGAP)
+    assert (j4["start"], j4["end"], j4["types"]) == ((1, END), (2, BEGIN), sc.T_INPUTGAP)
+
+
+def _clean_mapping(seed, truth, nc=10, nreads=600):
+    """A linear assembly with reads of both strands in the DAZZ convention (A coordinates forward, B coordinates on the
+    complemented read); a third of the reads lose their alignments on the contigs they cover completely -- they skip them."""
+    rng = np.random.default_rng(seed)
+    clen = rng.integers(4000, 7000, nc)
+    gaps = rng.integers(50, 800, nc - 1)
+    start = np.concatenate([[0], np.cumsum(clen[:-1] + gaps)])
+    total = int(start[-1] + clen[-1])
+    chains = []
+    for r in range(1, nreads + 1):
+        rl = int(rng.integers(6000, 13000))
+        p = int(rng.integers(-rl // 2, total - rl // 2))
+        comp = bool(rng.integers(0, 2))
+        dropper = rng.random() < 0.5
+        for c in range(nc):
+            lo, hi = max(p, int(start[c])), min(p + rl, int(start[c] + clen[c]))
+            if hi - lo < 300:
+                continue
+            ab, ae, bb, be = lo - int(start[c]), hi - int(start[c]), lo - p, hi - p   # (B on the complemented read when comp)
+            truth[(r, c + 1)] = (int(clen[c]), rl, comp, ab, ae, bb, be)
+            if dropper and ab == 0 and ae == int(clen[c]) and (c + 1) in (3, 7) and rng.random() < 0.8:   # (adjacent bubbles would not be simple)
+                continue
+            chains.append(sc.chain(len(chains), c + 1, int(clen[c]), r, rl, comp, ab, ae, bb, be))
+    return chains, [(c, c + 1) for c in range(1, nc)], nc
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_bubble_resolver_product_equals_oracle(seed):
+    """Reads that lost their alignment on a contig in the middle skip it: their join and the joins of the complete reads
+    form a cycle.  The product's resolver (dh_scaffold_pileups_cb: cycle base, simple bubbles, skipped path, read
+    alignments collected again from old + re-mapped alignments, order check, graph surgery) against oracle/scaffold.py's
+    restatement of the BubbleResolver, both fed the same re-mapping results.  Every fourth re-mapped alignment comes back
+    DISABLED (it does not cover its contig), the complement flag of some is flipped (the order check must refuse them)."""
+    truth = {}
+    chains, input_gaps, nc = _clean_mapping(seed, truth)
+    n = len(chains)
+    calls = []
+
+    def fresh(contig_ids, read_ids):   # 1-based ids, ascending
+        out = []
+        for c in contig_ids:
+            for r in read_ids:
+                if (r, c) in truth:
+                    cl, rl, comp, ab, ae, bb, be = truth[(r, c)]
+                    k = len(out) + 7 * c + r
+                    covers = ab <= 100 and ae >= cl - 100
+                    out.append(dict(a_id=c, a_len=cl, b_id=r, b_len=rl, complement=comp != (k % 11 == 0), a_begin=ab, a_end=ae,
+                                    b_begin=bb, b_end=be, disabled=(not covers) or k % 4 == 0))
+        return out
+    added = [0]
+
+    def remap_oracle(pile, inter):
+        rids = sorted({sa[0]["b_id"] for ra in pile for sa in ra})
+        calls.append((tuple(inter), tuple(rids)))
+        new = fresh(inter, rids)
+        for x in new:
+            x["id"] = n + added[0]
+            added[0] += 1
+        return new
+    kw = dict(min_spanning_reads=2)
+    exp = [((e["start"], e["end"]), [[(sa[0]["id"], sa[1]) for sa in ra] for ra in ras])
+           for e, ras in sc.build(nc, chains, input_gaps, remap=remap_oracle, **kw)]
+    assert calls, "the case must contain bubbles"
+    pcalls = []
+
+    def remap_product(cids, rids):   # 0-based
+        pcalls.append((tuple(c + 1 for c in cids), tuple(r + 1 for r in rids)))
+        new = fresh([c + 1 for c in cids], [r + 1 for r in rids])
+        la = np.zeros(len(new), dtype=dentist_amd.LA_DTYPE)
+        for i, c in enumerate(new):
+            la[i]["aread"], la[i]["bread"] = c["a_id"] - 1, c["b_id"] - 1
+            la[i]["abpos"], la[i]["aepos"], la[i]["bbpos"], la[i]["bepos"] = c["a_begin"], c["a_end"], c["b_begin"], c["b_end"]
+            la[i]["flags"] = (1 if c["complement"] else 0) | (0x20 if c["disabled"] else 0)
+        return la
+    las, co, ro = _to_arrays(chains)
+    joins, ent, las_all, _, resolved = dentist_amd.scaffold_pileups(
+        las, co, ro, np.array(input_gaps, dtype=np.int32).reshape(-1, 2) - 1, resolve=dict(remap=remap_product), **kw)
+    got = []
+    for j in joins:
+        ras = []
+        for e in ent[j["first"]:j["first"] + j["count"]]:
+            ra = [(int(e["la0"]), int(e["seed0"]))]
+            if e["n"] == 2:
+                ra.append((int(e["la1"]), int(e["seed1"])))
+            ras.append(ra)
+        got.append((((int(j["contig0"]) + 1, int(j["part0"])), (int(j["contig1"]) + 1, int(j["part1"]))), ras))
+    assert pcalls == calls and resolved == len(calls)
+    assert len(las_all) == n + added[0]
+    assert got == exp
+    # without the resolver the skipping joins fall to the fork rule: a different result
+    assert got != _product_piles(chains, input_gaps, nc=nc, **kw)
