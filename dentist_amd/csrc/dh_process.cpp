@@ -261,7 +261,12 @@ static bool select_pile(std::vector<int32_t> &v, const dh_la *las, const dh_proc
     const int32_t cnt = (int32_t)v.size() / 3;
     if (cnt < o.min_reads) return false;
     if (o.max_reads <= 0 || cnt <= o.max_reads) return true;  // max_reads 0 = no cap (the reference has none)
-    std::vector<std::pair<int64_t, int32_t>> key((size_t)cnt);
+    // key = (class, error rate, entry); class = 2 x (extension entry) + (a further entry of its read).  A spanning read that opens with an extension enters the
+    // pile-up as TWO extension entries (pileups.d:870) cropped from the same bases -- read[cropL, end) and read[0, cropR)
+    // overlap in the gap -- so both of them in the vote count that read's errors twice.  With more entries than the cap
+    // there are enough distinct reads: a read's second entry is considered only after every read's best one
+    // (configs[2]: consensus error 0.091 % -> the spanning collector's level with the same 60 entries).
+    std::vector<std::array<int64_t, 3>> key((size_t)cnt);
     for (int32_t e = 0; e < cnt; e++) {
         // an extension entry (one index is -1) is judged by the one alignment it has
         const int32_t iL = v[(size_t)e * 3 + 1], iR = v[(size_t)e * 3 + 2];
@@ -274,11 +279,22 @@ static bool select_pile(std::vector<int32_t> &v, const dh_la *las, const dh_proc
             len += las[iR].aepos - las[iR].abpos;
             diffs += las[iR].diffs;
         }
-        key[(size_t)e] = std::make_pair(diffs * 1000000 / std::max<int64_t>(len, 1), e);
+        key[(size_t)e] = {0, diffs * 1000000 / std::max<int64_t>(len, 1), e};
+    }
+    for (int32_t e = 0; e < cnt;) {  // entries of one read are adjacent: all but its best one rank behind
+        int32_t f = e + 1, best = e;
+        while (f < cnt && v[(size_t)f * 3] == v[(size_t)e * 3]) f++;
+        for (int32_t x = e + 1; x < f; x++)
+            if (key[(size_t)x][1] < key[(size_t)best][1]) best = x;
+        for (int32_t x = e; x < f; x++) key[(size_t)x][0] = x == best ? 0 : 1;
+        // ... and an extension entry (it covers the gap as far as its read goes) only after the reads that span the gap
+        for (int32_t x = e; x < f; x++)
+            if (v[(size_t)x * 3 + 1] < 0 || v[(size_t)x * 3 + 2] < 0) key[(size_t)x][0] += 2;
+        e = f;
     }
     std::sort(key.begin(), key.end());  // entries are in read-id order, so e breaks ties by read id
     std::vector<int32_t> keep((size_t)o.max_reads);
-    for (int32_t x = 0; x < o.max_reads; x++) keep[(size_t)x] = key[(size_t)x].second;
+    for (int32_t x = 0; x < o.max_reads; x++) keep[(size_t)x] = (int32_t)key[(size_t)x][2];
     std::sort(keep.begin(), keep.end());
     std::vector<int32_t> w;
     w.reserve((size_t)o.max_reads * 3);

@@ -56,7 +56,8 @@ def test_config3_eight_emulated_ranks_equal_the_single_rank_run(gpu_ctx, cfg2_wo
     closed = rec[rec["status"] == 0]
     assert len(piles) == 1000 and len(closed) >= 990
     edits, total = consensus_edits(w.truth, w.contig_start, w.gap_end, closed, bases)
-    assert edits <= 0.001 * total, (edits, total)
+    # north_star's tolerance is 0.1 %; measured 0.067 % with the spanning-first read cap (0.091 % before it): asserted with margin
+    assert edits <= 0.0008 * total, (edits, total)
     s, e = w.read_truth[las["bread"], 0], w.read_truth[las["bread"], 1]
     cs = w.contig_start[las["aread"]]
     ok = ((las["flags"] & 1) == w.read_truth[las["bread"], 2]) & (cs + las["abpos"] >= s - 80) & (cs + las["aepos"] <= e + 80)

@@ -458,12 +458,23 @@ def test_the_benched_chain_against_the_oracle(gpu_ctx):
             else:
                 ent.append((ra[0][0]["b_id"] - 1, -1, ra[0][0]["id"]))
         ent.sort(key=lambda t: (t[0], t[1] < 0))   # read order; the halves of a spanning read that opens with an extension: left one first
-        if len(ent) > po.max_reads:   # the cap: the entries whose anchoring alignments have the lowest error rate
+        if len(ent) > po.max_reads:   # the cap: distinct reads first, then the lowest error rate of the anchoring alignments
             def err(t):
                 ln = sum(int(flas[i]["aepos"] - flas[i]["abpos"]) for i in t[1:] if i >= 0)
                 df = sum(int(flas[i]["diffs"]) for i in t[1:] if i >= 0)
                 return df * 1000000 // max(ln, 1)
-            order = sorted(range(len(ent)), key=lambda x: (err(ent[x]), x))[:po.max_reads]
+            second = [False] * len(ent)   # every entry of a read but its best one ranks behind all first entries
+            x0 = 0
+            while x0 < len(ent):
+                x1 = x0
+                while x1 < len(ent) and ent[x1][0] == ent[x0][0]:
+                    x1 += 1
+                best = min(range(x0, x1), key=lambda x: (err(ent[x]), x))
+                for x in range(x0, x1):
+                    second[x] = x != best
+                x0 = x1
+            ext = [t[1] < 0 or t[2] < 0 for t in ent]   # ... and extension entries behind the reads that span the gap
+            order = sorted(range(len(ent)), key=lambda x: (2 * ext[x] + second[x], err(ent[x]), x))[:po.max_reads]
             ent = [ent[x] for x in sorted(order)]
         exp[c0 - 1] = ent
     got = {}
