@@ -1988,7 +1988,10 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
             const int32_t g = res->rec[(size_t)pile_of_active[(size_t)a]].contig_left;
             const int32_t cll = (int32_t)(contigs->h_off[(size_t)g + 1] - contigs->h_off[(size_t)g]);
             const int32_t clr = (int32_t)(contigs->h_off[(size_t)g + 2] - contigs->h_off[(size_t)g + 1]);
-            const int32_t wl = std::max(0, cll - o.flank_window);
+            // flank_window <= 0: the whole contigs, as the reference hands them to daligner (commandline.d:2918-2935)
+            const int32_t fw = o.flank_window > 0 ? o.flank_window : INT32_MAX;
+            // (the window starts on the trace grid of the contig: tiles, and with them the alignment, are those of the whole contig)
+            const int32_t wl = std::max(0, cll - std::min(cll, fw)) / tsp * tsp;
             foff[(size_t)a] = wl;
             fidx.push_back(g);
             fbeg.push_back(wl);
@@ -1996,7 +1999,7 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
             fgrp.push_back(a);
             fidx.push_back(g + 1);
             fbeg.push_back(0);
-            flen.push_back(std::min(clr, o.flank_window));
+            flen.push_back(std::min(clr, fw));
             fgrp.push_back(a);
         }
         dh_db *F = nullptr;

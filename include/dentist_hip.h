@@ -215,7 +215,8 @@ typedef struct {
                                 * (commandline.d:2125-2187 knows minimum counts only)                */
     int32_t tspace_pile;       /* -s126 of the pile-up daligner call, commandline.d:2886-2902       */
     int32_t rounds;            /* consensus rounds (1 = reference read + its overlaps only)         */
-    int32_t flank_window;      /* bases of each flanking contig given to the flank re-alignment     */
+    int32_t flank_window;      /* bases of each flanking contig given to the flank re-alignment (default 20 000);
+                                * 0 = the whole contigs, as the reference does (commandline.d:2918-2935) */
     int32_t max_align_err_ppm; /* --max-alignment-error 0.30, commandline.d:1808                    */
     int32_t max_ins_err_ppm;   /* --max-insertion-error 0.10, commandline.d:1997                    */
     int32_t bad_fraction_ppm;  /* --bad-fraction 0.08, commandline.d:1101                           */

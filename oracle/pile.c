@@ -530,8 +530,9 @@ static void process_one(const oz_db *contigs, const oz_db *reads, const oz_la *l
         r->cons_len = clen;
         *cons_out = cons;
         /* flank re-alignment: daligner -A -s126 -l126 contigs consensus (commandline.d:2918-2935) */
-        const int32_t wl = cll - o->flank_window > 0 ? cll - o->flank_window : 0;
-        const int32_t fl_len = cll - wl, fr_len = clr < o->flank_window ? clr : o->flank_window;
+        const int32_t fw = o->flank_window > 0 ? o->flank_window : INT32_MAX; /* 0 = the whole contigs */
+        const int32_t wl = (cll > fw ? cll - fw : 0) / o->ts_pile * o->ts_pile; /* on the contig's trace grid */
+        const int32_t fl_len = cll - wl, fr_len = clr < fw ? clr : fw;
         uint8_t *fb = (uint8_t *)malloc((size_t)fl_len + fr_len + 1);
         memcpy(fb, cl + wl, (size_t)fl_len);
         memcpy(fb + fl_len, cr, (size_t)fr_len);

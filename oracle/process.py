@@ -296,8 +296,9 @@ def process_pile(entries, las, trace, contigs, reads, g, rounds=3, nthreads=1, f
     res["consensus"] = cons
     # flank re-alignment: daligner -A -s126 -l126 contigs consensus (commandline.d:2918-2935)
     cl, cr = contigs.seq(g), contigs.seq(g + 1)
-    wl = max(0, len(cl) - flank_window)
-    fl, fr = cl[wl:], cr[:flank_window]
+    fw = flank_window if flank_window > 0 else max(len(cl), len(cr))   # 0 = the whole contigs (commandline.d:2918-2935)
+    wl = max(0, len(cl) - fw) // TS_PILE * TS_PILE   # on the contig's trace grid
+    fl, fr = cl[wl:], cr[:fw]
     fdb = SeqDb.from_list([fl, fr])
     if dust:   # DBdust contigs.dam; daligner -A ... -mdust -mrep (package.d:631-667)
         fdb = oz.with_dust(fdb)

@@ -630,3 +630,45 @@ def test_bubble_resolver_on_a_mapping_with_a_masked_contig(gpu_ctx):
         truth = g[cuts[gq][0] + r["left_aepos"]: cuts[gq + 1][0] + r["right_abpos"]]
         ed, _ = oz.nw(truth, ins)
         assert ed <= max(3, 0.02 * len(truth)), (gq, ed, len(truth))
+
+
+def test_flank_window_equals_whole_contig_flanks_with_a_repeat_outside_the_window(gpu_ctx):
+    """`dentist process` aligns the consensus against the WHOLE flanking contigs (commandline.d:2918-2935); this build hands
+    the aligner the last / first flank_window (20 kb) bases by default.  Contigs of 100 kb+, and 2 kb next to a gap planted
+    a second time 57 kb further inside the contig (outside the window, inside the whole contig): the copy yields a second
+    overlap of consensus and contig, which is not a flank overlap (it does not reach the contig's end) -- crop points,
+    reference read, consensus and splice coordinates are identical for flank_window = 20 000 and 0 (whole contigs), and
+    the whole-contig run equals the oracle's."""
+    g = sim.genome(31337, 330_000).copy()
+    g[40_000:42_000] = g[97_500:99_500]
+    cuts = [(0, 100_000), (100_400, 215_000), (215_300, 330_000)]
+    contigs = sim.SeqDb.from_list([g[a:b].copy() for a, b in cuts])
+    reads, _ = sim.reads(4711, g, 1300, 10_000)
+    mo = dentist_amd.default_align_opts(k=20, kmer_mod=4, width=64, xdrop=60, algo=1)
+    A, B = gpu_ctx.db(contigs), gpu_ctx.db(reads)
+    las, trace = gpu_ctx.align_db(A, B, mo, select_best=True)
+    res = {}
+    for fw in (20_000, 0):
+        po = dentist_amd.default_process_opts(algo=1, rounds=2, flank_window=fw)
+        piles = dentist_amd.Pileups(las, contigs.off, po)
+        assert len(piles) == 2
+        res[fw] = dentist_amd.process_pileups(gpu_ctx, A, B, las, trace, piles, po)
+    (r1, b1), (r0, b0) = res[20_000], res[0]
+    assert np.all(r1["status"] == 0) and np.all(r0["status"] == 0)
+    for f in r1.dtype.names:
+        if f != "pad":
+            assert np.array_equal(r1[f], r0[f]), f
+    assert np.array_equal(b1, b0)
+    # the oracle with whole contigs
+    olas, otrace, _ = oz.align_db(contigs, reads, oz.default_opts(k=20, kmer_mod=4, width=64, xdrop=60, algo=1),
+                                  nthreads=os.cpu_count() or 1, select_best=True)
+    assert_same_las((las, trace), (olas, otrace))
+    exp_piles = pr.collect_spanning(olas, otrace, contigs, reads)
+    for i, r in enumerate(r0):
+        gq = int(r["contig_left"])
+        ex = pr.process_pile(exp_piles[gq], olas, otrace, contigs, reads, gq, rounds=2, nthreads=os.cpu_count() or 1, algo=1,
+                             flank_window=0)
+        assert ex["status"] == "ok"
+        assert np.array_equal(b0[r["cons_off"]:r["cons_off"] + r["cons_len"]], ex["consensus"])
+        assert (r["left_aepos"], r["right_abpos"], r["ins_begin"], r["ins_end"]) == \
+               (ex["left_aepos"], ex["right_abpos"], ex["ins_begin"], ex["ins_end"])

@@ -126,7 +126,7 @@ def test_sharded_scaffold_graph_collector_equals_the_single_gpu_run(gpu_ctx, wor
     dh_scaffold_gap_pileups + select + dh_process_pileups).  DH-2 in every stage."""
     w = sim.Workload(800_000, 8, 4000, 6000, seed=73, spacing=20000, gap_max=1500)
     mo = dentist_amd.default_align_opts(kmer_mod=2, k=20, algo=1, width=64)
-    po = dentist_amd.default_process_opts(max_reads=14, algo=1)
+    po = dentist_amd.default_process_opts(max_reads=30, algo=1)   # (the cap takes spanning reads first: 30 keeps extension entries in)
     gaps = np.stack([np.arange(w.contigs.n - 1), np.arange(1, w.contigs.n)], axis=1).astype(np.int32)
     A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
     las, trace, _, _ = gpu_ctx.map_reads(A, B, mo, po, sorted=False, candidates=True)
