@@ -935,6 +935,14 @@ static void select_best_range(dh_la *la, size_t nla, int32_t near_ppm)
                     l.flags |= (m == 0 ? DH_FLAG_START : DH_FLAG_NEXT) | (best ? DH_FLAG_BEST : 0u) | (drop ? DH_FLAG_DISABLED : 0u);
                 }
             }
+            // the records of the read in LAsort order: a chain's members are then neighbours (a chain only ever continues the
+            // chain before it), START followed by its NEXT records -- how damapper writes them and how every consumer
+            // rebuilds the chains (dazzler.d:1728-1758); the trace values stay where they are (toff)
+            if (!std::is_sorted(ord.begin(), ord.end())) {
+                std::vector<dh_la> tmp(ord.size());
+                for (size_t k = 0; k < ord.size(); k++) tmp[k] = la[ord[k]];
+                for (size_t k = 0; k < ord.size(); k++) la[g0 + k] = tmp[k];
+            }
         }
     });
 }

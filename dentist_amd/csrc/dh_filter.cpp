@@ -8,9 +8,11 @@
 //   5 Ambiguous       reads with two alignments that overlap on the read        filter.d:238-322
 //   6 Redundant       reads with an alignment that (extended by the unaligned
 //                     read ends) lies inside one contig                          filter.d:164-175, base.d:562-598
-// Alignment chains are the single-LA chains this library's damapper role emits.  Dropped alignments
-// get DH_FLAG_DISABLED (the reference removes the alignments of ambiguous reads from the array; the
-// effect on every later stage is the same).  Per-alignment predicates run on the host thread pool.
+// The unit of every filter is the alignment CHAIN (base.d:306-421): records linked by the START / NEXT flags damapper
+// sets (dazzler.d:1728-1758) are judged together -- first.begin .. last.end, totalDiffs over coveredBases, the union
+// of the members' A intervals minus the mask -- and dropped together (dh_chain_view).  Dropped alignments get
+// DH_FLAG_DISABLED (the reference removes the alignments of ambiguous reads from the array; the effect on every later
+// stage is the same); the counts are chains.  Per-alignment predicates run on the host thread pool.
 #include <algorithm>
 #include <atomic>
 #include <cstring>
@@ -31,11 +33,109 @@ struct Ctx {
 };
 }  // namespace
 
+void dh_chain_view_build(const dh_la *las, int64_t n, dh_chain_view &v)
+{
+    v = dh_chain_view();
+    std::atomic<int> any{0};
+    dh_parallel_for(n, 1 << 16, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = std::max<int64_t>(lo, 1); i < hi; i++)
+            if (dh_continues_chain(las[i - 1], las[i])) {
+                any = 1;
+                break;
+            }
+    });
+    if (!any) return;
+    v.trivial = false;
+    for (int64_t i = 0; i < n;) {
+        int64_t j = i + 1;
+        dh_la u = las[i];
+        int64_t cov = u.aepos - u.abpos;
+        while (j < n && dh_continues_chain(las[j - 1], las[j])) {
+            u.aepos = las[j].aepos;
+            u.bepos = las[j].bepos;
+            u.diffs += las[j].diffs;
+            u.flags |= las[j].flags & DH_FLAG_DISABLED;  // a chain with a disabled member is disabled
+            cov += las[j].aepos - las[j].abpos;
+            j++;
+        }
+        v.first.push_back(i);
+        v.unit.push_back(u);
+        v.covered.push_back(cov);
+        i = j;
+    }
+    v.first.push_back(n);
+}
+
+static int collect_filter_units(dh_la *las, int64_t n, const int64_t *contig_off, int32_t ncontigs, const int64_t *read_off,
+                                int32_t nreads, const int64_t *rep_ptr, const int32_t *rep_iv, const dh_process_opts *opts,
+                                int64_t *dropped6, uint8_t *read_used, const int64_t *covered, const int64_t *unmasked);
+
 extern "C" int dh_collect_filter(dh_la *las, int64_t n, const int64_t *contig_off, int32_t ncontigs,
                                  const int64_t *read_off, int32_t nreads, const int64_t *rep_ptr, const int32_t *rep_iv,
                                  const dh_process_opts *opts, int64_t *dropped6, uint8_t *read_used)
 {
     if ((n > 0 && !las) || !contig_off || !read_off || !opts || n < 0) return dh_fail(DH_EINVAL, "dh_collect_filter: bad argument");
+    dh_chain_view cv;
+    dh_chain_view_build(las, n, cv);
+    if (cv.trivial)
+        return collect_filter_units(las, n, contig_off, ncontigs, read_off, nreads, rep_ptr, rep_iv, opts, dropped6, read_used,
+                                    nullptr, nullptr);
+    // multi-record chains: the filters see one unit per chain
+    const int64_t nc = (int64_t)cv.unit.size();
+    std::vector<int64_t> unmasked;
+    if (rep_ptr) {
+        // size of (union of the members' A intervals) - mask; members are ordered along A and may overlap by a few bases
+        unmasked.assign((size_t)nc, 0);
+        dh_parallel_for(nc, 4096, [&](int64_t lo, int64_t hi) {
+            for (int64_t c = lo; c < hi; c++) {
+                int64_t sum = 0;
+                int32_t done = -1;  // A positions below `done` are accounted for
+                for (int64_t i = cv.first[(size_t)c]; i < cv.first[(size_t)c + 1]; i++) {
+                    const dh_la &l = las[i];
+                    if (l.aread < 0 || l.aread >= ncontigs) continue;  // (reported by the unit pass)
+                    const int32_t b0 = std::max(l.abpos, done), e0 = l.aepos;
+                    if (e0 <= b0) continue;
+                    int64_t un = e0 - b0;
+                    for (int64_t j = rep_ptr[l.aread]; j < rep_ptr[l.aread + 1]; j++) {
+                        const int32_t b = std::max(rep_iv[2 * j], b0), e = std::min(rep_iv[2 * j + 1], e0);
+                        if (e > b) un -= e - b;
+                    }
+                    sum += un;
+                    done = e0;
+                }
+                unmasked[(size_t)c] = sum;
+            }
+        });
+    } else {
+        unmasked.assign((size_t)nc, 0);
+        for (int64_t c = 0; c < nc; c++) {  // union of the members' A intervals
+            int32_t done = -1;
+            int64_t sum = 0;
+            for (int64_t i = cv.first[(size_t)c]; i < cv.first[(size_t)c + 1]; i++) {
+                const int32_t b0 = std::max(las[i].abpos, done);
+                if (las[i].aepos > b0) sum += las[i].aepos - b0;
+                done = std::max(done, las[i].aepos);
+            }
+            unmasked[(size_t)c] = sum;
+        }
+    }
+    if (int rc = collect_filter_units(cv.unit.data(), nc, contig_off, ncontigs, read_off, nreads, rep_ptr, rep_iv, opts, dropped6,
+                                      read_used, cv.covered.data(), unmasked.data()))
+        return rc;
+    dh_parallel_for(nc, 4096, [&](int64_t lo, int64_t hi) {
+        for (int64_t c = lo; c < hi; c++)
+            if (cv.unit[(size_t)c].flags & DH_FLAG_DISABLED)
+                for (int64_t i = cv.first[(size_t)c]; i < cv.first[(size_t)c + 1]; i++) las[i].flags |= DH_FLAG_DISABLED;
+    });
+    return DH_OK;
+}
+
+// the six filters on units (one record each: a chain's pseudo record, or the records themselves when every chain is one
+// record).  covered / unmasked (optional, per unit): A bases covered by the unit's members / of their union outside the mask
+static int collect_filter_units(dh_la *las, int64_t n, const int64_t *contig_off, int32_t ncontigs, const int64_t *read_off,
+                                int32_t nreads, const int64_t *rep_ptr, const int32_t *rep_iv, const dh_process_opts *opts,
+                                int64_t *dropped6, uint8_t *read_used, const int64_t *covered, const int64_t *unmasked_in)
+{
     {
         std::atomic<int> bad{0};
         dh_parallel_for(n, 16384, [&](int64_t lo, int64_t hi) {
@@ -56,7 +156,7 @@ extern "C" int dh_collect_filter(dh_la *las, int64_t n, const int64_t *contig_of
         for (int64_t i = lo; i < hi; i++) {
             dh_la &l = las[i];
             if (l.flags & DH_FLAG_DISABLED) continue;
-            if ((int64_t)l.diffs * 1000000 > (int64_t)o.max_align_err_ppm * (l.aepos - l.abpos)) {
+            if ((int64_t)l.diffs * 1000000 > (int64_t)o.max_align_err_ppm * (covered ? covered[i] : (int64_t)(l.aepos - l.abpos))) {
                 l.flags |= DH_FLAG_DISABLED;
                 local++;
             }
@@ -85,7 +185,9 @@ extern "C" int dh_collect_filter(dh_la *las, int64_t n, const int64_t *contig_of
             dh_la &l = las[i];
             if (l.flags & DH_FLAG_DISABLED) continue;
             int64_t unmasked = l.aepos - l.abpos;
-            if (rep_ptr)
+            if (unmasked_in)
+                unmasked = unmasked_in[i];
+            else if (rep_ptr)
                 for (int64_t j = rep_ptr[l.aread]; j < rep_ptr[l.aread + 1]; j++) {
                     const int32_t b = std::max(rep_iv[2 * j], l.abpos), e = std::min(rep_iv[2 * j + 1], l.aepos);
                     if (e > b) unmasked -= e - b;

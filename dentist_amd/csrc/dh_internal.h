@@ -182,6 +182,24 @@ struct dh_insertions {
     std::vector<int32_t> ids_off, ids;  // per record [ids_off[i], ids_off[i+1]): read ids of the pile-up
 };
 
+// Alignment chains as units (base.d:306-421; chain flags dazzler.d:1728-1758, 1991-1998): a record with NEXT (and not
+// START) continues the chain of the record before it (same contig, read and strand).  The view holds one pseudo record
+// per chain -- the first member's fields with aepos / bepos of the last member and diffs summed, i.e. what
+// first.contigX.begin / last.contigX.end / totalDiffs read -- plus the A bases its members cover (coveredBases!"contigA")
+// and where the chain's members are.  `trivial`: every chain is one record (the view is not filled).
+struct dh_chain_view {
+    bool trivial = true;
+    std::vector<dh_la> unit;       // one per chain
+    std::vector<int64_t> first;    // chain -> index of its first record; first[nchains] = n
+    std::vector<int64_t> covered;  // chain -> sum of (aepos - abpos) over its members
+};
+void dh_chain_view_build(const dh_la *las, int64_t n, dh_chain_view &v);
+inline bool dh_continues_chain(const dh_la &prev, const dh_la &cur)
+{
+    return (cur.flags & DH_FLAG_NEXT) && !(cur.flags & DH_FLAG_START) && cur.aread == prev.aread && cur.bread == prev.bread &&
+           (cur.flags & DH_FLAG_COMP) == (prev.flags & DH_FLAG_COMP);
+}
+
 void dh_pileups_shift(dh_pileups *p, int32_t by);
 int dh_pileups_concat(dh_pileups *const *parts, int32_t nparts, dh_pileups **out);
 

@@ -1224,6 +1224,13 @@ void oz_select_best(oz_la_set *s)
                 l->flags |= (k == 0 ? OZ_FLAG_START : OZ_FLAG_NEXT) | (best ? OZ_FLAG_BEST : 0u) | (drop ? OZ_FLAG_DISABLED : 0u);
             }
         }
+        {
+            /* the records of the read in LAsort order: chain members become neighbours (START, then its NEXT records) */
+            oz_la *tmp = (oz_la *)malloc((size_t)m * sizeof(oz_la));
+            for (int64_t x = 0; x < m; x++) tmp[x] = s->la[ord[x]];
+            memcpy(s->la + g0, tmp, (size_t)m * sizeof(oz_la));
+            free(tmp);
+        }
         free(ord);
         free(mem);
         free(ch);

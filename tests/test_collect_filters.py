@@ -101,3 +101,82 @@ def test_planted_scenario():
     assert used.tolist() == [1, 1, 1, 1, 1, 0, 0]
     exp, ed, eu = cf.collect_filter(las, np.asarray(coff), np.asarray(roff), repeat_mask=(ptr, iv))
     assert np.array_equal(out["flags"], exp["flags"]) and np.array_equal(dropped, ed) and np.array_equal(used, eu)
+
+
+# ------------------------------------------------------------------ alignment chains as the unit (base.d:306-421)
+def chained(rows):
+    """rows of one chain, in order: START on the first, NEXT on the others (dazzler.d:1728-1758)."""
+    out = np.stack(rows)
+    out["flags"] |= 0x8
+    out["flags"][0] = (int(out["flags"][0]) & 0xFFFFFFF7) | 0x4
+    return out
+
+
+def test_chain_predicates_of_the_reference():
+    """base.d:608-660 isFullyContained on chains of two, :662-680 coveredBases, :683-715 totalDiffs / averageErrorRate."""
+    two = chained([la(0, 0, 10, 20, 5, 10, 1), la(0, 0, 30, 40, 5, 10, 1)])       # read with extension on A from 5 to 45
+    u, cov, _ = cf.chain_units(two)
+    assert len(u) == 1 and cf.is_fully_contained(u[0], 50, 15)
+    wide = chained([la(0, 0, 0, 20, 5, 10, 1), la(0, 0, 30, 50, 5, 10, 1)])       # from -5 to 55
+    assert not cf.is_fully_contained(cf.chain_units(wide)[0][0], 50, 15)
+    c3 = chained([la(0, 0, 1, 3, 1, 3, 1), la(0, 0, 5, 10, 5, 10, 2)])
+    u, cov, _ = cf.chain_units(c3)
+    assert cov == [7] and int(u[0]["diffs"]) == 3                                  # averageErrorRate = 3 / 7
+    # the product: the redundant filter judges the chain (members 10..20 and 30..40 of a read of 15: inside the contig of 50)
+    po = dentist_amd.default_process_opts(allowance=100, min_anchor=0)
+    out, dropped, used = dentist_amd.collect_filter(np.concatenate([two, wide.copy()]), [0, 50], [0, 15], po)
+    exp, ed, eu = cf.collect_filter(np.concatenate([two, wide.copy()]), np.asarray([0, 50]), np.asarray([0, 15]), min_anchor=0)
+    assert np.array_equal(out["flags"], exp["flags"]) and np.array_equal(dropped, ed) and np.array_equal(used, eu)
+
+
+def test_chains_are_the_unit_of_every_filter():
+    """A read with a 3 kb insertion maps as two collinear records: as ONE chain it is a proper alignment with the error
+    rate of both parts together and it is dropped or kept as a whole; judged record by record (NEXT flags cleared) either
+    part would be improper (it ends or begins in the middle of read and contig).  Product == oracle on random chained sets."""
+    coff, roff = np.asarray([0, 20000]), np.asarray([0, 12000, 24000])
+    a = la(0, 0, 12000, 15000, 0, 3000, diffs=300)      # read 0 enters the contig at 12000 ...
+    b = la(0, 0, 15050, 20000, 6050, 11000, diffs=500)  # ... skips 3 kb of its own and runs to the contig's end
+    las = np.concatenate([chained([a, b]), np.stack([la(0, 1, 14000, 20000, 0, 6000, diffs=600)])])
+    po = dentist_amd.default_process_opts()
+    out, dropped, used = dentist_amd.collect_filter(las, coff, roff, po)
+    assert dropped.tolist() == [0, 0, 0, 0, 0, 0] and not np.any(out["flags"] & 0x20)
+    single = las.copy()
+    single["flags"] &= ~np.uint32(0xC)
+    out1, dropped1, _ = dentist_amd.collect_filter(single, coff, roff, po)
+    assert dropped1[1] == 2 and bool(out1["flags"][0] & 0x20) and bool(out1["flags"][1] & 0x20)   # either part alone is improper
+    # low quality is decided on totalDiffs / coveredBases: 2400 + 100 differences over 3000 + 4950 bases = 31 %
+    lq = np.concatenate([chained([la(0, 0, 12000, 15000, 0, 3000, diffs=2400), la(0, 0, 15050, 20000, 6050, 11000, diffs=100)])])
+    out2, dropped2, _ = dentist_amd.collect_filter(lq, coff, roff, po)
+    assert dropped2[0] == 1 and np.all(out2["flags"] & 0x20)
+    total = np.zeros(6, dtype=np.int64)
+    for seed in range(1, 7):
+        rng = np.random.default_rng(100 + seed)
+        nc, nr, clen, rlen = 5, 120, 20000, 9000
+        base = random_las(rng, nr, nc, clen, rlen)
+        base = base[np.argsort(base["bread"], kind="stable")]
+        rows = []
+        for r in base:   # a third of the records are split into a chain of two around a gap of 0 .. 2 kb
+            ln = int(r["aepos"] - r["abpos"])
+            if rng.random() < 0.33 and ln > 1500:
+                cut, gap = int(rng.integers(500, ln - 500)), int(rng.integers(0, 2000))
+                p, q = r.copy(), r.copy()
+                p["aepos"], p["bepos"], p["diffs"] = r["abpos"] + cut, r["bbpos"] + cut, r["diffs"] // 2
+                q["abpos"], q["bbpos"], q["diffs"] = r["abpos"] + cut + 20, min(int(r["bepos"]) - 10, int(r["bbpos"]) + cut + 20 + gap), r["diffs"] - r["diffs"] // 2
+                if q["abpos"] < q["aepos"] and q["bbpos"] < q["bepos"]:
+                    rows += list(chained([p, q]))
+                    continue
+            r = r.copy()
+            r["flags"] |= 0x4
+            rows.append(r)
+        las = np.stack(rows)
+        coff2 = np.arange(nc + 1, dtype=np.int64) * clen
+        roff2 = np.arange(nr + 1, dtype=np.int64) * rlen
+        ptr = np.arange(nc + 1, dtype=np.int64) * 2
+        iv = np.tile(np.asarray([0, 4000, 15000, 19990], dtype=np.int32), nc)
+        got, gd, gu = dentist_amd.collect_filter(las, coff2, roff2, po, repeat_mask=(ptr, iv))
+        exp, ed, eu = cf.collect_filter(las, coff2, roff2, repeat_mask=(ptr, iv))
+        assert np.array_equal(got["flags"], exp["flags"]) and np.array_equal(gd, ed) and np.array_equal(gu, eu)
+        for i, j in cf.chain_ranges(las):   # a chain is kept or dropped as a whole
+            assert len(set((got["flags"][i:j] & 0x20).tolist())) == 1
+        total += ed
+    assert all(d > 0 for d in total), total
