@@ -92,6 +92,7 @@ SYMBOLS = [
     "dh_comm_rank", "dh_comm_world", "dh_comm_all_gather", "dh_comm_all_to_all", "dh_shard_run", "dh_set_near_best", "dh_ctx_set_near_best", "dh_shard_free", "dh_shard_pack_candidates", "dh_shard_plan_create", "dh_shard_read_joins", "dh_align_db_transposed", "dh_remap_skipping_reads", "dh_shard_graph_plan_create", "dh_shard_plan_destroy",
     "dh_shard_plan_las", "dh_shard_plan_nlas", "dh_shard_plan_pileups", "dh_shard_plan_owner", "dh_shard_pack_cropped",
     "dh_shard_unpack_cropped", "dh_insertions_read_ids", "dh_insertions_read_ids_off", "dh_output_assembly", "dh_default_output_opts",
+    "dh_common_trace_point",
 ]
 
 _LIB = None
@@ -464,6 +465,22 @@ def translate_trace_point(la, trace, tspace, apos, mode="floor"):
     _check(lib().dh_translate_trace_point(rec.ctypes.data, tr.ctypes.data, tspace, apos,
                                           {"floor": 0, "ceil": 1}[mode], ctypes.byref(a), ctypes.byref(b)))
     return a.value, b.value
+
+
+def common_trace_point(las, first, contig_len, tspace, seed_front, mask=None):
+    """getCommonTracePoint (cropper.d:446-500) of the product for one flank: first = the first records of the flank's
+    alignment chains in las; mask = [(begin, end), ...] of the contig's repeat mask.  -1 when there is none."""
+    arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
+    fi = np.ascontiguousarray(first, dtype=np.int32)
+    mk = np.ascontiguousarray(mask if mask is not None else [], dtype=np.int32).reshape(-1)
+    out = ctypes.c_int32()
+    L = lib()
+    L.dh_common_trace_point.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                        ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64,
+                                        ctypes.POINTER(ctypes.c_int32)]
+    _check(L.dh_common_trace_point(arr.ctypes.data, len(arr), fi.ctypes.data, len(fi), contig_len, tspace,
+                                   int(bool(seed_front)), mk.ctypes.data if len(mk) else None, len(mk) // 2, ctypes.byref(out)))
+    return out.value
 
 
 def las_write(path, las, trace, tspace):

@@ -485,23 +485,105 @@ extern "C" int32_t dh_pileups_get(const dh_pileups *p, int32_t i, int32_t *conti
 
 static int32_t ceil_to(int32_t x, int32_t m) { return (x + m - 1) / m * m; }
 
-// getCommonTracePoint, cropper.d:446-500, with an empty repeat mask: candidates are the trace
-// points of the common A interval (plus the contig end), innermost first for `front` seeds.
-static int32_t common_trace_point(int32_t lo, int32_t hi, int32_t contig_len, int32_t ts, bool seed_front)
+// Alignment chains (base.d:306-421) in the cropper: an entry names the FIRST record of its chain, the members follow it
+// (dh_continues_chain).  to!(ReferenceRegion, "contigA") of a chain = the union of its members' A intervals
+// (common/package.d:228-241); the common alignment region of a flank = the intersection of the entries' regions.
+typedef std::vector<std::pair<int32_t, int32_t>> Region;
+static int64_t chain_end(const dh_la *las, int64_t n, int64_t i)
 {
-    if (lo >= hi) return -1;
+    int64_t j = i + 1;
+    while (j < n && dh_continues_chain(las[j - 1], las[j])) j++;
+    return j;
+}
+static void intersect_chain(Region &reg, const dh_la *las, int64_t n, int64_t i)
+{
+    const int64_t j = chain_end(las, n, i);
+    Region mine;
+    for (int64_t x = i; x < j; x++) mine.emplace_back(las[x].abpos, las[x].aepos);
+    if (j - i > 1) {
+        std::sort(mine.begin(), mine.end());
+        Region m2;
+        for (const auto &iv : mine)
+            if (!m2.empty() && iv.first <= m2.back().second)
+                m2.back().second = std::max(m2.back().second, iv.second);
+            else
+                m2.push_back(iv);
+        mine.swap(m2);
+    }
+    Region out;
+    for (const auto &a : reg)
+        for (const auto &b : mine) {
+            const int32_t lo = std::max(a.first, b.first), hi = std::min(a.second, b.second);
+            if (lo < hi) out.emplace_back(lo, hi);
+        }
+    reg.swap(out);
+}
+// the first member of the chain at record i that covers apos (AlignmentChain.translateTracePoint, base.d:866-880)
+static int64_t covering_member(const dh_la *las, int64_t n, int64_t i, int32_t apos)
+{
+    const int64_t j = chain_end(las, n, i);
+    for (int64_t x = i; x < j; x++)
+        if (las[x].abpos <= apos && apos <= las[x].aepos) return x;
+    return -1;
+}
+
+// getCommonTracePoint, cropper.d:446-500: candidates are the trace points of the region (plus the contig end),
+// innermost first for `front` seeds; the common A region minus the repeat mask is tried first, then the region itself.
+static int32_t common_trace_point_in(const Region &reg, int32_t contig_len, int32_t ts, bool seed_front)
+{
+    if (reg.empty()) return -1;
+    const int32_t lo = reg.front().first, hi = reg.back().second;
     const int32_t tp_min = ceil_to(lo, ts), tp_sup = ceil_to(hi, ts);
     std::vector<int32_t> cands;
     for (int32_t c = tp_min; c < tp_sup; c += ts) cands.push_back(c);
     if (tp_sup > contig_len) cands.push_back(contig_len);
     if (seed_front) std::reverse(cands.begin(), cands.end());
-    for (int32_t c : cands)
-        if ((lo <= c && c < hi) || c == hi) return c;
+    for (int32_t c : cands) {
+        bool in = c == hi;
+        for (size_t x = 0; x < reg.size() && !in; x++) in = reg[x].first <= c && c < reg[x].second;
+        if (in) return c;
+    }
     return -1;
 }
+// mask: sorted disjoint (begin, end) pairs of this contig, nmask of them (may be 0 / NULL)
+static int32_t common_trace_point(const Region &reg, int32_t contig_len, int32_t ts, bool seed_front,
+                                  const int32_t *mask = nullptr, int64_t nmask = 0)
+{
+    if (nmask > 0 && !reg.empty()) {
+        Region un;  // reg - mask
+        for (const auto &iv : reg) {
+            int32_t b = iv.first;
+            for (int64_t m = 0; m < nmask && b < iv.second; m++) {
+                const int32_t mb = mask[2 * m], me = mask[2 * m + 1];
+                if (me <= b) continue;
+                if (mb >= iv.second) break;
+                if (mb > b) un.emplace_back(b, mb);
+                b = std::max(b, me);
+            }
+            if (b < iv.second) un.emplace_back(b, iv.second);
+        }
+        const int32_t c = common_trace_point_in(un, contig_len, ts, seed_front);
+        if (c >= 0) return c;
+    }
+    return common_trace_point_in(reg, contig_len, ts, seed_front);
+}
 
-// Trace.tracePointsUpTo!"contigA" (base.d:207-244): number of trace points up to and including
-// apos under the rounding mode (0 floor, 1 ceil)
+// the cropper's common trace point as an entry of its own: first[] names the first record of each alignment chain of
+// one flank (all on the same contig, all with the same seed)
+extern "C" int dh_common_trace_point(const dh_la *las, int64_t n, const int32_t *first, int32_t count, int32_t contig_len,
+                                     int32_t tspace, int32_t seed_front, const int32_t *mask_iv, int64_t nmask, int32_t *out)
+{
+    if (!out || count < 0 || (count > 0 && (!las || !first)) || tspace < 1 || nmask < 0 || (nmask > 0 && !mask_iv))
+        return dh_fail(DH_EINVAL, "dh_common_trace_point: bad argument");
+    Region reg{{0, INT32_MAX}};
+    for (int32_t x = 0; x < count; x++) {
+        if (first[x] < 0 || first[x] >= n) return dh_fail(DH_EINVAL, "dh_common_trace_point: record index out of range");
+        intersect_chain(reg, las, n, first[x]);
+    }
+    *out = count > 0 ? common_trace_point(reg, contig_len, tspace, seed_front != 0, mask_iv, nmask) : -1;
+    return DH_OK;
+}
+
 static int32_t trace_points_up_to_a(const dh_la &la, int32_t ts, int32_t apos, int32_t mode)
 {
     const int32_t ntp = la.tlen / 2;
@@ -1231,7 +1313,7 @@ extern "C" int dh_crop_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_
             r.crop_left = r.crop_right = -1;
             const std::vector<int32_t> &tr3 = piles->triples[(size_t)p];
             const int32_t ne = (int32_t)tr3.size() / 3;
-            int32_t llo = 0, lhi = INT32_MAX, rlo = 0, rhi = INT32_MAX;
+            Region lreg{{0, INT32_MAX}}, rreg{{0, INT32_MAX}};
             bool bad = false;
             for (int32_t e = 0; e < ne; e++) {
                 // an entry is a read spanning the gap (two alignments) or an extension over one contig end
@@ -1241,14 +1323,8 @@ extern "C" int dh_crop_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_
                     bad = true;
                     break;
                 }
-                if (iL >= 0) {
-                    llo = std::max(llo, las[iL].abpos);
-                    lhi = std::min(lhi, las[iL].aepos);
-                }
-                if (iR >= 0) {
-                    rlo = std::max(rlo, las[iR].abpos);
-                    rhi = std::min(rhi, las[iR].aepos);
-                }
+                if (iL >= 0) intersect_chain(lreg, las, n, iL);
+                if (iR >= 0) intersect_chain(rreg, las, n, iR);
             }
             if (bad) {
                 err = 2;
@@ -1256,8 +1332,8 @@ extern "C" int dh_crop_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_
             }
             const int32_t cll = (int32_t)(contigs->h_off[(size_t)g + 1] - contigs->h_off[(size_t)g]);
             const int32_t clr = (int32_t)(contigs->h_off[(size_t)g + 2] - contigs->h_off[(size_t)g + 1]);
-            const int32_t cropL = common_trace_point(llo, lhi, cll, tsm, false);
-            const int32_t cropR = common_trace_point(rlo, rhi, clr, tsm, true);
+            const int32_t cropL = common_trace_point(lreg, cll, tsm, false);
+            const int32_t cropR = common_trace_point(rreg, clr, tsm, true);
             r.crop_left = cropL;
             r.crop_right = cropR;
             if (cropL < 0 || cropR < 0) {
@@ -1286,8 +1362,14 @@ extern "C" int dh_crop_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_
                 const int32_t rl = (int32_t)(reads->h_off[(size_t)lrd + 1] - reads->h_off[(size_t)lrd]);
                 // getCroppingSlice per alignment, intersected (cropper.d:339-348, 503-550): the back-seeded
                 // one keeps [crop point, read end), the front-seeded one [0, crop point)
-                const int32_t bL = iL >= 0 ? translate_floor_b(las[iL], trace + las[iL].toff, tsm, cropL) : 0;
-                const int32_t bR = iR >= 0 ? translate_floor_b(las[iR], trace + las[iR].toff, tsm, cropR) : rl;
+                // (a chain translates through the first of its members that covers the crop point)
+                const int64_t mL = iL >= 0 ? covering_member(las, n, iL, cropL) : -1, mR = iR >= 0 ? covering_member(las, n, iR, cropR) : -1;
+                if ((iL >= 0 && mL < 0) || (iR >= 0 && mR < 0)) {
+                    err = 4;
+                    break;
+                }
+                const int32_t bL = iL >= 0 ? translate_floor_b(las[mL], trace + las[mL].toff, tsm, cropL) : 0;
+                const int32_t bR = iR >= 0 ? translate_floor_b(las[mR], trace + las[mR].toff, tsm, cropR) : rl;
                 int32_t b0 = bL, b1 = bR;
                 const bool comp = (las[iL >= 0 ? iL : iR].flags & DH_FLAG_COMP) != 0;
                 if (comp) {  // getCroppingSlice, cropper.d:533-538

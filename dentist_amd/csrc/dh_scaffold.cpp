@@ -305,9 +305,21 @@ extern "C" int dh_scaffold_pileups(const dh_la *las, int64_t n, const int64_t *c
     for (int32_t g = 0; g < ngaps; g++)
         if (input_gaps[2 * g] < 0 || input_gaps[2 * g] >= ncontigs || input_gaps[2 * g + 1] < 0 || input_gaps[2 * g + 1] >= ncontigs)
             return dh_fail(DH_EINVAL, "dh_scaffold_pileups: input gap names a contig out of range");
+    // alignment chains are the unit (SeededAlignment.from(AlignmentChain), base.d:1964-2050: first.begin .. last.end): the
+    // builder runs on one pseudo record per chain, the read alignments then name the chain's first record
+    dh_chain_view cv;
+    dh_chain_view_build(las, n, cv);
+    const dh_la *u = cv.trivial ? las : cv.unit.data();
+    const int64_t nu = cv.trivial ? n : (int64_t)cv.unit.size();
     std::vector<std::vector<Edge>> found;
-    if (int rc = collect_raw_joins("dh_scaffold_pileups", las, n, contig_off, ncontigs, read_off, 0, nreads, nullptr, &found)) return rc;
-    return scaffold_from_edges(found, ncontigs, input_gaps, ngaps, opts, out);
+    if (int rc = collect_raw_joins("dh_scaffold_pileups", u, nu, contig_off, ncontigs, read_off, 0, nreads, nullptr, &found)) return rc;
+    if (int rc = scaffold_from_edges(found, ncontigs, input_gaps, ngaps, opts, out)) return rc;
+    if (!cv.trivial)
+        for (dh_read_alignment &ra : (*out)->entries) {
+            ra.la0 = (int32_t)cv.first[(size_t)ra.la0];
+            if (ra.n == 2) ra.la1 = (int32_t)cv.first[(size_t)ra.la1];
+        }
+    return DH_OK;
 }
 
 // ---- the sharded collector: every rank turns the alignments of ITS reads into raw joins (a per-read computation),
@@ -807,11 +819,17 @@ static int scaffold_resolved(const dh_la *las, int64_t n, const int64_t *contig_
     for (int32_t g = 0; g < ngaps; g++)
         if (input_gaps[2 * g] < 0 || input_gaps[2 * g] >= ncontigs || input_gaps[2 * g + 1] < 0 || input_gaps[2 * g + 1] >= ncontigs)
             return dh_fail(DH_EINVAL, "dh_scaffold_pileups: input gap names a contig out of range");
+    // (chains as units for the mapping's alignments, as in dh_scaffold_pileups; the re-mapped alignments are taken
+    // record by record: they cover a whole intermediate contig)
+    dh_chain_view cv;
+    dh_chain_view_build(las, n, cv);
+    const dh_la *u = cv.trivial ? las : cv.unit.data();
+    const int64_t nu = cv.trivial ? n : (int64_t)cv.unit.size();
     std::vector<std::vector<Edge>> found;
-    if (int rc = collect_raw_joins("dh_scaffold_pileups", las, n, contig_off, ncontigs, read_off, 0, nreads, nullptr, &found)) return rc;
+    if (int rc = collect_raw_joins("dh_scaffold_pileups", u, nu, contig_off, ncontigs, read_off, 0, nreads, nullptr, &found)) return rc;
     Resolver rs;
-    rs.c = Ctx{las, contig_off, read_off};
-    rs.c.n = n;
+    rs.c = Ctx{u, contig_off, read_off};
+    rs.c.n = nu;
     rs.c.extra = &extra;
     rs.extra = &extra;
     rs.remap = [&](const std::vector<int32_t> &cids, const std::vector<int32_t> &rids, std::vector<dh_la> &fresh) -> int {
@@ -825,6 +843,14 @@ static int scaffold_resolved(const dh_la *las, int64_t n, const int64_t *contig_
     rs.max_iterations = max_iterations > 0 ? max_iterations : 4;
     const int rc = scaffold_from_edges(found, ncontigs, input_gaps, ngaps, opts, out, &rs);
     if (resolved) *resolved = rs.resolved;
+    if (!rc) {
+        // unit index -> record index: the first record of the chain; the added alignments follow the n records
+        auto rec_of = [&](int32_t x) { return x < nu ? (int32_t)(cv.trivial ? x : cv.first[(size_t)x]) : (int32_t)(n + (x - nu)); };
+        for (dh_read_alignment &ra : (*out)->entries) {
+            ra.la0 = rec_of(ra.la0);
+            if (ra.n == 2) ra.la1 = rec_of(ra.la1);
+        }
+    }
     return rc;
 }
 

@@ -203,6 +203,15 @@ int dh_las_merge(const char *const *paths, int32_t npaths, const char *out_path)
 int dh_translate_trace_point(const dh_la *la, const uint16_t *trace, int32_t tspace, int32_t apos,
                              int32_t mode, int32_t *out_a, int32_t *out_b);
 
+/* getCommonTracePoint (commands/processPileUps/cropper.d:446-500) of one flank of a pile-up as an entry of its own:
+ * first[count] names the first record of every alignment chain of the flank (same contig, same seed; chain members
+ * follow their first record, dazzler.d:1728-1758); the common region is the intersection of the chains' A regions
+ * (union of the members' A intervals, common/package.d:228-241).  Candidates are the trace points of the region plus
+ * the contig end, taken from the inner side for seed_front != 0; the region minus the repeat mask (mask_iv = nmask
+ * sorted disjoint (begin, end) pairs of this contig) is tried first, then the region itself.  *out = -1: none. Host only. */
+int dh_common_trace_point(const dh_la *las, int64_t n, const int32_t *first, int32_t count, int32_t contig_len,
+                          int32_t tspace, int32_t seed_front, const int32_t *mask_iv, int64_t nmask, int32_t *out);
+
 /* ---- pile-ups: which reads span which gap.  Host-side stand-in for the part of `dentist collect`
  *      the consensus path needs (spanning reads only; the scaffold-graph builder of
  *      source/dentist/commands/collectPileUps/pileups.d is outside this library). */

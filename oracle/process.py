@@ -70,19 +70,74 @@ def ceil_to(x, m):
     return -(-x // m) * m
 
 
-def common_trace_point(intervals, contig_len, ts, seed_front):
-    """getCommonTracePoint, cropper.d:446-500, with an empty repeat mask."""
-    lo = max(a for a, _ in intervals)
-    hi = min(e for _, e in intervals)
-    if lo >= hi:
-        return -1
-    tp_min, tp_sup = ceil_to(lo, ts), ceil_to(hi, ts)
-    cands = list(range(tp_min, tp_sup, ts)) + ([contig_len] if tp_sup > contig_len else [])
-    if seed_front:
-        cands = cands[::-1]
-    for c in cands:
-        if lo <= c < hi or c == hi:
-            return c
+def chain_members(las, i):
+    """Records of the alignment chain that starts at record i: NEXT without START continues it (dazzler.d:1728-1758)."""
+    j = i + 1
+    while j < len(las) and (las[j]["flags"] & 0x8) and not (las[j]["flags"] & 0x4) and las[j]["aread"] == las[j - 1]["aread"] \
+            and las[j]["bread"] == las[j - 1]["bread"] and (las[j]["flags"] & 1) == (las[j - 1]["flags"] & 1):
+        j += 1
+    return list(range(i, j))
+
+
+def region_of(las, i):
+    """to!(ReferenceRegion, "contigA") of a chain (common/package.d:228-241): the union of its members' A intervals."""
+    iv = sorted((int(las[x]["abpos"]), int(las[x]["aepos"])) for x in chain_members(las, i))
+    out = []
+    for b, e in iv:
+        if out and b <= out[-1][1]:
+            out[-1][1] = max(out[-1][1], e)
+        else:
+            out.append([b, e])
+    return out
+
+
+def intersect_regions(regs):
+    cur = regs[0]
+    for r in regs[1:]:
+        nxt = []
+        for b0, e0 in cur:
+            for b1, e1 in r:
+                b, e = max(b0, b1), min(e0, e1)
+                if b < e:
+                    nxt.append([b, e])
+        cur = nxt
+    return cur
+
+
+def subtract_mask(reg, mask):
+    """Region - mask (util/region.d opBinary!"-"): mask = sorted disjoint (begin, end) pairs."""
+    out = []
+    for b, e in reg:
+        for mb, me in mask:
+            if me <= b:
+                continue
+            if mb >= e:
+                break
+            if mb > b:
+                out.append([b, mb])
+            b = max(b, me)
+        if b < e:
+            out.append([b, e])
+    return out
+
+
+def common_trace_point(regions, contig_len, ts, seed_front, mask=None):
+    """getCommonTracePoint, cropper.d:446-500.  regions: one list of [begin, end) per alignment chain (a plain
+    (begin, end) pair counts as one interval); mask: the contig's repeat mask -- the region outside it is tried
+    first, then the common region itself."""
+    regs = [[list(r)] if not isinstance(r[0], (list, tuple)) else [list(x) for x in r] for r in regions]
+    common = intersect_regions(regs)
+    for reg in ([subtract_mask(common, mask)] if mask else []) + [common]:
+        if not reg:
+            continue
+        lo, hi = reg[0][0], reg[-1][1]
+        tp_min, tp_sup = ceil_to(lo, ts), ceil_to(hi, ts)
+        cands = list(range(tp_min, tp_sup, ts)) + ([contig_len] if tp_sup > contig_len else [])
+        if seed_front:
+            cands = cands[::-1]
+        for c in cands:
+            if any(b <= c < e for b, e in reg) or c == hi:
+                return c
     return -1
 
 
@@ -104,8 +159,8 @@ def crop_pile(entries, las, trace, contigs, reads, g, ts_map=100):
     has = lambda i: i is not None and i >= 0   # noqa: E731
     left = [las[iL] for _, iL, _ in entries if has(iL)]
     right = [las[iR] for _, _, iR in entries if has(iR)]
-    cropL = common_trace_point([(int(l["abpos"]), int(l["aepos"])) for l in left], contigs.length(g), ts_map, False)
-    cropR = common_trace_point([(int(r["abpos"]), int(r["aepos"])) for r in right], contigs.length(g + 1), ts_map, True)
+    cropL = common_trace_point([region_of(las, iL) for _, iL, _ in entries if has(iL)], contigs.length(g), ts_map, False)
+    cropR = common_trace_point([region_of(las, iR) for _, _, iR in entries if has(iR)], contigs.length(g + 1), ts_map, True)
     if cropL < 0 or cropR < 0:
         return None
     # fetchSupportPatches (cropper.d:224-262): if less than minAnchorLength of a flank remains after
@@ -117,11 +172,12 @@ def crop_pile(entries, las, trace, contigs, reads, g, ts_map=100):
     for (r, iL, iR) in entries:
         rl = reads.length(r)
         bL, bR = 0, rl
+        # AlignmentChain.translateTracePoint (base.d:866-880): the FIRST member that covers the position translates it
         if has(iL):
-            L = las[iL]
+            L = las[next(x for x in chain_members(las, iL) if las[x]["abpos"] <= cropL <= las[x]["aepos"])]
             _, bL = translate_floor(L, trace[L["toff"]:L["toff"] + L["tlen"]], cropL, ts_map)
         if has(iR):
-            R = las[iR]
+            R = las[next(x for x in chain_members(las, iR) if las[x]["abpos"] <= cropR <= las[x]["aepos"])]
             _, bR = translate_floor(R, trace[R["toff"]:R["toff"] + R["tlen"]], cropR, ts_map)
         lp = left_patch if has(iL) else left_patch[0:0]
         rp = right_patch if has(iR) else right_patch[0:0]

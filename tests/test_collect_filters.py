@@ -180,3 +180,58 @@ def test_chains_are_the_unit_of_every_filter():
             assert len(set((got["flags"][i:j] & 0x20).tolist())) == 1
         total += ed
     assert all(d > 0 for d in total), total
+
+
+def test_common_trace_point_over_regions_with_holes_and_a_mask():
+    """getCommonTracePoint (cropper.d:446-500) on alignment chains: the common region of a flank is the intersection of
+    the chains' A regions (a chain = the union of its members' A intervals, common/package.d:228-241), so it has a hole
+    where a chained read misses contig bases; candidates come from the inner side for front seeds; trace points inside
+    the repeat mask are avoided as long as one outside exists.  Product (dh_common_trace_point) == oracle on hand-made
+    and on random cases."""
+    from oracle import process as pr
+    plain = np.stack([la(0, 0, 1000, 5000, 0, 4000), la(0, 1, 1250, 4800, 0, 3550)])
+    hole = chained([la(0, 2, 900, 2030, 0, 1130), la(0, 2, 3170, 5000, 1130, 2960)])
+    las = np.concatenate([plain, hole])
+    reg = pr.intersect_regions([pr.region_of(las, i) for i in (0, 1, 2)])
+    assert reg == [[1250, 2030], [3170, 4800]]
+    for front, exp in ((False, 1300), (True, 4700)):   # candidates: iota(ceil(min), ceil(sup), 100) -- 4800 is not one
+        assert pr.common_trace_point([pr.region_of(las, i) for i in (0, 1, 2)], 5000, 100, front) == exp
+        assert dentist_amd.common_trace_point(las, [0, 1, 2], 5000, 100, front) == exp
+    # a candidate inside the hole is skipped: only chain 2 and the back seed -> 900 .. 2030 | 3170 .. 5000
+    assert dentist_amd.common_trace_point(las, [2], 5000, 100, True) == 4900
+    assert dentist_amd.common_trace_point(las, [2], 4950, 100, True) == 4950   # the contig end is a candidate when ceil(sup) lies beyond it
+    only_tail = np.concatenate([np.stack([la(0, 0, 2000, 3200, 0, 1200)]), hole])
+    assert pr.intersect_regions([pr.region_of(only_tail, i) for i in (0, 1)]) == [[2000, 2030], [3170, 3200]]
+    assert dentist_amd.common_trace_point(only_tail, [0, 1], 5000, 100, False) == 2000
+    assert dentist_amd.common_trace_point(only_tail, [0, 1], 5000, 100, True) == 2000   # 3100 .. 2100 lie in the hole
+    # the mask: outside first, inside when nothing else is left
+    assert dentist_amd.common_trace_point(las, [0, 1, 2], 5000, 100, False, mask=[(1200, 1950)]) == 2000
+    assert dentist_amd.common_trace_point(las, [0, 1, 2], 5000, 100, False, mask=[(0, 5000)]) == 1300
+    assert dentist_amd.common_trace_point(las, [0], 5000, 100, False, mask=[(900, 1000), (1000 + 1, 4950)]) == 1000
+    # no common region at all
+    far = np.concatenate([plain, np.stack([la(0, 3, 4900, 5000, 0, 100)])])
+    assert dentist_amd.common_trace_point(far, [0, 1, 2], 5000, 100, False) == -1
+    rng = np.random.default_rng(8)
+    for _ in range(300):
+        rows, firsts = [], []
+        clen = int(rng.integers(3000, 9000))
+        for r in range(int(rng.integers(1, 6))):
+            b = int(rng.integers(0, clen // 2))
+            e = int(rng.integers(b + 200, clen + 1))
+            firsts.append(len(rows))
+            if rng.random() < 0.5 and e - b > 900:
+                m = int(rng.integers(b + 200, e - 400))
+                rows += list(chained([la(0, r, b, m, 0, m - b), la(0, r, m + int(rng.integers(0, 300)), e, m - b, e - b)]))
+            else:
+                rows.append(la(0, r, b, e, 0, e - b))
+        arr = np.stack(rows)
+        mask = []
+        x = 0
+        while rng.random() < 0.6 and x < clen - 50:
+            b = int(rng.integers(x, clen - 10))
+            e = int(rng.integers(b + 1, min(clen, b + 2500) + 1))
+            mask.append((b, e))
+            x = e + 1
+        for front in (False, True):
+            exp = pr.common_trace_point([pr.region_of(arr, i) for i in firsts], clen, 100, front, mask=mask)
+            assert dentist_amd.common_trace_point(arr, firsts, clen, 100, front, mask=mask) == exp

@@ -513,6 +513,124 @@ def test_the_benched_chain_against_the_oracle(gpu_ctx):
     assert closed == 20 and edits <= 0.002 * tb, (closed, edits, tb)
 
 
+def test_chains_with_a_long_indel_next_to_a_gap(gpu_ctx):
+    """Alignment chains as the unit from the mapping to the cropper (dazzler.d:1728-1758 builds them from START / NEXT;
+    base.d:306-421; SeededAlignment.from(chain) base.d:1964-2050; getCommonTracePoint over ReferenceRegions
+    cropper.d:446-500; AlignmentChain.translateTracePoint base.d:866-880): reads that span a gap get a 2-5 kb insertion of
+    foreign bases, or lose 2-5 kb of contig bases, 1.5-3.5 kb away from the gap -- each maps as two collinear records on
+    that flank, ONE chain.  As single records the part next to the gap would be improper (it begins in the middle of
+    read and contig) and the read lost; as a chain the read enters the gap's pile-up, its A region is the union of the
+    members' intervals, and the crop position is translated through the member that covers it (regions with holes
+    and the repeat mask: tests/test_collect_filters.py, CPU).  Product (dh_map_reads -> dh_scaffold_gap_pileups -> dh_process_pileups) == oracle (collect_filters on
+    chains, scaffold.build on one chain() per unit, process.crop_pile on regions), bit for bit."""
+    from oracle import collect_filters as cf
+    from oracle import scaffold as sc
+    w = sim.Workload(600_000, 6, 1500, 12_000, seed=20260930, spacing=60000, gap_max=1500)
+    rng = np.random.default_rng(5)
+    seqs = [w.reads.seq(i) for i in range(w.reads.n)]
+    planted, eligible = [], 0
+    for i, (s0, e0, strand) in enumerate(w.read_truth):
+        for g in range(len(w.gap_begin)):
+            gb, ge = int(w.gap_begin[g]), int(w.gap_end[g])
+            if not (s0 + 1500 < gb and ge + 1500 < e0):
+                continue
+            left = gb - s0 >= e0 - ge          # the longer flank part of the read gets the indel
+            if (gb - s0 if left else e0 - ge) < 7000:
+                continue
+            eligible += 1
+            if eligible % 2:
+                continue
+            # a position 1.5-3.5 kb away from the gap, in read coordinates (reads are ~ (1 + ins - del) longer than the truth)
+            d = int(rng.integers(1500, 3500))
+            gpos = gb - d if left else ge + d
+            scale = len(seqs[i]) / float(e0 - s0)
+            at = int((gpos - s0) * scale) if not strand else int((e0 - gpos) * scale)
+            ln = int(rng.integers(2000, 5000))
+            s = seqs[i]
+            if len(planted) % 2 == 0:    # foreign bases in the read
+                seqs[i] = np.concatenate([s[:at], rng.integers(0, 4, ln).astype(np.uint8), s[at:]])
+            else:                        # contig bases missing from the read: cut away from the gap
+                lo, hi = (at - ln, at) if left != bool(strand) else (at, at + ln)
+                if lo < 1000 or hi > len(s) - 1000:
+                    continue
+                seqs[i] = np.concatenate([s[:lo], s[hi:]])
+            planted.append(i)
+            break
+    assert len(planted) >= 12
+    reads = sim.SeqDb.from_list(seqs)
+    mo = dentist_amd.default_align_opts(kmer_mod=4, k=20, width=64, xdrop=60, algo=1)
+    po = dentist_amd.default_process_opts(algo=1, rounds=2, max_reads=0)
+    A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(reads)
+    las, trace, dropped = gpu_ctx.map_reads(A, B, mo, po, sorted=False, candidates=False)[:3]
+    oo = oz.default_opts(kmer_mod=4, k=20, width=64, xdrop=60, algo=1)
+    olas, otrace, _ = oz.align_db(w.contigs, reads, oo, nthreads=os.cpu_count() or 1, sort=False, select_best=True)
+    flas, odropped, _ = cf.collect_filter(olas, w.contigs.off, reads.off)
+    assert [int(x) for x in dropped] == [int(x) for x in odropped]
+    assert_same_las((las, trace), (flas, otrace))
+    # ---- pile-ups: one chain() per unit for the oracle's builder, ids = the first record of the chain
+    gaps_in = np.stack([np.arange(w.contigs.n - 1), np.arange(1, w.contigs.n)], axis=1).astype(np.int32)
+    piles, _ = dentist_amd.scaffold_spanning_pileups(las, w.contigs.off, reads.off, gaps_in, with_extensions=True,
+                                                     min_spanning_reads=po.min_reads)
+    units, _, ranges = cf.chain_units(flas)
+    multi = {i for i, j in ranges if j - i > 1}
+    assert len(multi) >= 10
+    chains = [sc.chain(ranges[c][0], int(l["aread"]) + 1, w.contigs.length(int(l["aread"])), int(l["bread"]) + 1,
+                       reads.length(int(l["bread"])), bool(l["flags"] & 1), int(l["abpos"]), int(l["aepos"]),
+                       int(l["bbpos"]), int(l["bepos"]), disabled=bool(l["flags"] & 0x20)) for c, l in enumerate(units)]
+    exp = {}
+    for e, ras in sc.build(w.contigs.n, chains, [(int(a) + 1, int(b) + 1) for a, b in gaps_in], min_spanning_reads=po.min_reads):
+        (c0, p0), (c1, p1) = e["start"], e["end"]
+        if not (p0 == sc.END and p1 == sc.BEGIN and c1 == c0 + 1):
+            continue
+        ent = []
+        for ra in ras:
+            if len(ra) == 2:
+                a, b = sorted(ra, key=lambda s_: s_[0]["a_id"])
+                ent.append((a[0]["b_id"] - 1, a[0]["id"], b[0]["id"]))
+            elif ra[0][0]["a_id"] == c0:
+                ent.append((ra[0][0]["b_id"] - 1, ra[0][0]["id"], -1))
+            else:
+                ent.append((ra[0][0]["b_id"] - 1, -1, ra[0][0]["id"]))
+        ent.sort(key=lambda t: (t[0], t[1] < 0))
+        exp[c0 - 1] = ent
+    got = {}
+    for i in range(len(piles)):
+        g, tri = piles.get(i)
+        got[int(g)] = [tuple(int(x) for x in t) for t in tri.tolist()]
+    assert set(got) == set(exp) and len(got) == 6
+    chained_entries = 0
+    for g in got:
+        assert got[g] == exp[g], g
+        chained_entries += sum(1 for t in got[g] if t[1] in multi or t[2] in multi)
+    assert chained_entries >= 10, "the planted reads must enter the pile-ups as chains"
+    in_piles = {t[0] for v in got.values() for t in v}
+    assert len(in_piles & set(planted)) >= 10
+    # ---- crop + process
+    rec, bases = dentist_amd.process_pileups(gpu_ctx, A, B, las, trace, piles, po)
+    closed = through_later_member = 0
+    for i in range(len(piles)):
+        g, tri = piles.get(i)
+        ex = pr.process_pile(got[int(g)], flas, otrace, w.contigs, reads, int(g), rounds=po.rounds,
+                             nthreads=os.cpu_count() or 1, algo=1)
+        r = rec[i]
+        assert (r["status"] == 0) == (ex["status"] == "ok"), (g, int(r["status"]), ex["status"])
+        if r["status"] != 0:
+            continue
+        assert (r["crop_left"], r["crop_right"], r["nreads"]) == (ex["cropL"], ex["cropR"], ex["pile"].n)
+        assert r["ref_read"] == ex["ref_idx"]
+        cons = bases[r["cons_off"]:r["cons_off"] + r["cons_len"]]
+        assert np.array_equal(cons, ex["consensus"]), f"gap {g}: consensus differs"
+        assert (r["left_aepos"], r["right_abpos"], r["ins_begin"], r["ins_end"]) == \
+               (ex["left_aepos"], ex["right_abpos"], ex["ins_begin"], ex["ins_end"])
+        # chained entries whose crop position lies on a later member of the chain (the part next to the gap)
+        for t in got[int(g)]:
+            for i0, pos in ((t[1], ex["cropL"]), (t[2], ex["cropR"])):
+                if i0 in multi and not (flas[i0]["abpos"] <= pos <= flas[i0]["aepos"]):
+                    through_later_member += 1
+        closed += 1
+    assert closed >= 5 and through_later_member >= 5, (closed, through_later_member)
+
+
 def test_consensus_band_classes_and_scalar_fill_agree(gpu_ctx, monkeypatch):
     """The three fills of the per-tile Needleman-Wunsch (bit-parallel with one / two 64-cell words per matrix row, scalar
     for bands above 63) against the oracle's full-matrix NW on noisy reads (20 % error: read-read tiles reach 60+
