@@ -54,8 +54,8 @@ class ProcessOpts(ctypes.Structure):
 
 INSERTION_DTYPE = np.dtype([(n, "<i4") for n in (
     "contig_left", "status", "nreads", "ref_read", "ref_read_id", "crop_left", "crop_right", "left_aepos",
-    "right_abpos", "ins_begin", "ins_end", "comp", "cons_len", "left_diffs", "right_diffs", "pad")]
-    + [("cons_off", "<i8")])
+    "right_abpos", "ins_begin", "ins_end", "comp", "cons_len", "left_diffs", "right_diffs", "join")]
+    + [("cons_off", "<i8"), ("contig_right", "<i4"), ("pad", "<i4")])
 
 LA_DTYPE = np.dtype([("tlen", "<i4"), ("diffs", "<i4"), ("abpos", "<i4"), ("bbpos", "<i4"),
                      ("aepos", "<i4"), ("bepos", "<i4"), ("flags", "<u4"), ("aread", "<i4"),
@@ -92,7 +92,8 @@ SYMBOLS = [
     "dh_comm_rank", "dh_comm_world", "dh_comm_all_gather", "dh_comm_all_to_all", "dh_shard_run", "dh_set_near_best", "dh_ctx_set_near_best", "dh_shard_free", "dh_shard_pack_candidates", "dh_shard_plan_create", "dh_shard_read_joins", "dh_align_db_transposed", "dh_remap_skipping_reads", "dh_shard_graph_plan_create", "dh_shard_plan_destroy",
     "dh_shard_plan_las", "dh_shard_plan_nlas", "dh_shard_plan_pileups", "dh_shard_plan_owner", "dh_shard_pack_cropped",
     "dh_shard_unpack_cropped", "dh_insertions_read_ids", "dh_insertions_read_ids_off", "dh_output_assembly", "dh_default_output_opts",
-    "dh_common_trace_point",
+    "dh_common_trace_point", "dh_pileups_create_joins", "dh_pileups_get_join", "dh_scaffold_all_pileups",
+    "dh_crop_pileups_masked", "dh_process_pileups_masked", "dh_scaffold_graph_probe",
 ]
 
 _LIB = None
@@ -533,6 +534,29 @@ class Pileups:
         h = ctypes.c_void_p()
         _check(lib().dh_pileups_create(cl.ctypes.data, cnt.ctypes.data, len(cl), tri.ctypes.data, ctypes.byref(h)))
         return cls(None, None, None, _handle=h)
+
+    @classmethod
+    def from_joins(cls, nodes4, triples_per_pile):
+        """dh_pileups_create_joins: pile-ups of any join -- nodes4[i] = (contig0, seed0, contig1, seed1), seed 0 = front,
+        1 = back, contig1 = -1 for an extension pile-up; ordered by their nodes."""
+        nd = np.ascontiguousarray(nodes4, dtype=np.int32).reshape(-1, 4)
+        cnt = np.asarray([len(t) for t in triples_per_pile], dtype=np.int32)
+        tri = (np.ascontiguousarray(np.concatenate([np.asarray(t, dtype=np.int32).reshape(-1, 3)
+                                                    for t in triples_per_pile]), dtype=np.int32)
+               if len(triples_per_pile) else np.zeros((0, 3), np.int32))
+        h = ctypes.c_void_p()
+        L = lib()
+        L.dh_pileups_create_joins.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+        _check(L.dh_pileups_create_joins(nd.ctypes.data, cnt.ctypes.data, len(nd), tri.ctypes.data, ctypes.byref(h)))
+        return cls(None, None, None, _handle=h)
+
+    def get_join(self, i):
+        """(contig0, seed0, contig1, seed1) of pile-up i."""
+        nd = np.zeros(4, dtype=np.int32)
+        L = lib()
+        L.dh_pileups_get_join.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+        _check(L.dh_pileups_get_join(self._h, i, nd.ctypes.data))
+        return tuple(int(x) for x in nd)
 
     def write_db(self, path, las, trace, contig_off, read_off, tspace=100):
         """dh_pileups_write_db: DENTIST's pile-ups.db for these pile-ups."""
@@ -1100,6 +1124,27 @@ def scaffold_spanning_pileups(las, contig_off, read_off, input_gaps=None, with_e
     return Pileups(None, None, None, _handle=ph), int(skipped.value)
 
 
+def scaffold_all_pileups(las, contig_off, read_off, input_gaps=None, only="both", resolve=None, **opts):
+    """Every pile-up of the scaffold graph the process stage can take (dh_scaffold_all_pileups): only = "spanning" (gap
+    joins of any two contig ends), "extending" (extension joins) or "both".  Returns (Pileups with joins, skipped)."""
+    L = lib()
+    sc = _scaffold(las, contig_off, read_off, input_gaps, opts, resolve)
+    h, arr = sc[0], sc[1]
+    try:
+        ph = ctypes.c_void_p()
+        skipped = ctypes.c_int32(0)
+        L.dh_scaffold_all_pileups.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                              ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int32)]
+        _check(L.dh_scaffold_all_pileups(h, arr.ctypes.data, len(arr), {"spanning": 1, "extending": 2, "both": 3}[only],
+                                         ctypes.byref(ph), ctypes.byref(skipped)))
+    finally:
+        L.dh_scaffold_destroy.argtypes = [ctypes.c_void_p]
+        L.dh_scaffold_destroy(h)
+    if resolve is not None:
+        return Pileups(None, None, None, _handle=ph), int(skipped.value), sc[1], sc[2], sc[3]
+    return Pileups(None, None, None, _handle=ph), int(skipped.value)
+
+
 class Cropped:
     """Cropped pile-ups (dh_cropped): per pile-up record + per cropped read (pile, entry, read id, bases)."""
 
@@ -1107,12 +1152,15 @@ class Cropped:
         self._h = h
 
     @classmethod
-    def crop(cls, ctx, contigs, reads, read_first, las, trace, piles, opts):
+    def crop(cls, ctx, contigs, reads, read_first, las, trace, piles, opts, repeat_mask=None):
         arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
         tr = np.ascontiguousarray(trace, dtype=np.uint16)
         h = ctypes.c_void_p()
-        _check(lib().dh_crop_pileups(ctx._h, contigs._h, reads._h, read_first, arr.ctypes.data, len(arr),
-                                     tr.ctypes.data if len(tr) else None, piles._h, ctypes.byref(opts), ctypes.byref(h)))
+        keep, rp, ri = _mask_args(repeat_mask)
+        L = lib()
+        L.dh_crop_pileups_masked.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 6
+        _check(L.dh_crop_pileups_masked(ctx._h, contigs._h, reads._h, read_first, arr.ctypes.data, len(arr),
+                                        tr.ctypes.data if len(tr) else None, piles._h, rp, ri, ctypes.byref(opts), ctypes.byref(h)))
         return cls(h)
 
     @classmethod
@@ -1208,23 +1256,36 @@ def _take_insertions(h, insertions_db=None, read_ids=False):
     return (rec, bases, ids) if read_ids else (rec, bases)
 
 
-def process_pileups(ctx, contigs, reads, las, trace, piles, opts, insertions_db=None, read_ids=False):
+def _mask_args(repeat_mask):
+    """(ptr int64[ncontigs + 1], intervals int32[2 * total]) -> the two pointers of the *_masked entries (None, None without a mask)."""
+    if repeat_mask is None:
+        return None, None, None
+    rp = np.ascontiguousarray(repeat_mask[0], dtype=np.int64)
+    ri = np.ascontiguousarray(np.concatenate([np.asarray(repeat_mask[1]).reshape(-1), [0, 0]]), dtype=np.int32)
+    return (rp, ri), rp.ctypes.data, ri.ctypes.data
+
+
+def process_pileups(ctx, contigs, reads, las, trace, piles, opts, insertions_db=None, read_ids=False, repeat_mask=None):
     """dentist `process` for a batch of pile-ups on the GPU. Returns (records, consensus bases);
     insertions_db = (path, contig_off, tspace) also writes DENTIST's insertions.db; read_ids = True adds
-    (ids, off): the read ids of every record's pile-up (what `dentist output` lists in its BED / AGP)."""
+    (ids, off): the read ids of every record's pile-up (what `dentist output` lists in its BED / AGP);
+    repeat_mask = (ptr, intervals): the contigs' repeat mask for the cropper (dh_process_pileups_masked)."""
     L = lib()
     arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
     tr = np.ascontiguousarray(trace, dtype=np.uint16)
     h = ctypes.c_void_p()
-    _check(L.dh_process_pileups(ctx._h, contigs._h, reads._h, arr.ctypes.data, len(arr), tr.ctypes.data,
-                                piles._h, ctypes.byref(opts), ctypes.byref(h)))
+    keep, rp, ri = _mask_args(repeat_mask)
+    L.dh_process_pileups_masked.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int64] + [ctypes.c_void_p] * 6
+    _check(L.dh_process_pileups_masked(ctx._h, contigs._h, reads._h, arr.ctypes.data, len(arr), tr.ctypes.data,
+                                       piles._h, rp, ri, ctypes.byref(opts), ctypes.byref(h)))
     return _take_insertions(h, insertions_db, read_ids)
 
 
 class OutputOpts(ctypes.Structure):
     _fields_ = [("line_width", ctypes.c_int32), ("highlight", ctypes.c_int32), ("join_policy", ctypes.c_int32),
-                ("agp_dazzler", ctypes.c_int32), ("agp_skip_read_ids", ctypes.c_int32), ("pad", ctypes.c_int32),
-                ("agp_version", ctypes.c_char_p), ("tool", ctypes.c_char_p), ("input_assembly", ctypes.c_char_p)]
+                ("agp_dazzler", ctypes.c_int32), ("agp_skip_read_ids", ctypes.c_int32), ("only", ctypes.c_int32),
+                ("agp_version", ctypes.c_char_p), ("tool", ctypes.c_char_p), ("input_assembly", ctypes.c_char_p),
+                ("min_extension_length", ctypes.c_int32), ("pad", ctypes.c_int32)]
 
 
 JOIN_POLICIES = {"scaffoldGaps": 0, "scaffolds": 1, "contigs": 2}
@@ -1232,7 +1293,7 @@ JOIN_POLICIES = {"scaffoldGaps": 0, "scaffolds": 1, "contigs": 2}
 
 def output_assembly(fasta_path, contigs, scaffold_of, headers, gap_len, rec, bases, read_ids=None, bed_path=None,
                     agp_path=None, join_policy="scaffoldGaps", agp_dazzler=False, agp_skip_read_ids=False, read_names=None,
-                    line_width=50, highlight=True, tool=None, input_assembly=None):
+                    line_width=50, highlight=True, tool=None, input_assembly=None, only="spanning", min_extension_length=100):
     """`dentist output` (host only): assembly graph with the join policy, fixCropping, FASTA, AGP and closed-gaps
     BED (dh_output_assembly).  read_ids = (ids, off) from process_pileups(read_ids=True).  Returns the number of
     insertions the join policy dropped."""
@@ -1242,6 +1303,7 @@ def output_assembly(fasta_path, contigs, scaffold_of, headers, gap_len, rec, bas
     L.dh_default_output_opts(ctypes.byref(o))
     o.line_width, o.highlight, o.join_policy = line_width, int(bool(highlight)), JOIN_POLICIES[join_policy]
     o.agp_dazzler, o.agp_skip_read_ids = int(bool(agp_dazzler)), int(bool(agp_skip_read_ids))
+    o.only, o.min_extension_length = {"spanning": 1, "extending": 2, "both": 3}[only], int(min_extension_length)
     if tool is not None:
         o.tool = tool.encode()
     if input_assembly is not None:

@@ -316,7 +316,7 @@ int dh_alloc_bases(hipStream_t st, int64_t total, uint8_t **alloc, uint8_t **bas
 {
     const size_t nb = (size_t)std::max<int64_t>(total, 0) + 2 * DB_PAD;
     HIPCHK(dh_dev_alloc(alloc, nb));
-    HIPCHK(hipMemsetAsync(*alloc, 4, nb, st));
+    HIPCHK(dhk_memset(st, *alloc, 4, nb));
     *base = *alloc + DB_PAD;
     return DH_OK;
 }
@@ -408,7 +408,7 @@ int dh_ensure_mask_layer(dh_db *db, int derived, uint8_t **out)
     uint8_t *&layer = derived ? db->d_mask_derived : db->d_mask_user;
     if (!layer) {
         HIPCHK(dh_dev_alloc(&layer, mask_bytes(db)));
-        HIPCHK(hipMemsetAsync(layer, 0, mask_bytes(db), db->ctx->stream));
+        HIPCHK(dhk_memset(db->ctx->stream, layer, 0, mask_bytes(db)));
     }
     *out = layer;
     return DH_OK;
@@ -541,7 +541,7 @@ extern "C" int dh_db_mask_coverage(dh_db *db, const dh_la *las, int64_t n, const
     HIPCHK(d_cov.alloc((size_t)nslots));
     HIPCHK(d_sums.alloc((size_t)nslots / 2048 + 4));
     HIPCHK(d_las.alloc((size_t)n));
-    HIPCHK(hipMemsetAsync(d_cov.p, 0, sizeof(uint32_t) * (size_t)nslots, st));
+    HIPCHK(dhk_memset(st, d_cov.p, 0, sizeof(uint32_t) * (size_t)nslots));
     HIPCHK(hipMemcpyAsync(d_las.p, las, sizeof(dh_la) * (size_t)n, hipMemcpyHostToDevice, st));
     if (improper_only) {
         HIPCHK(d_roff.alloc((size_t)nreads + 1));
@@ -757,7 +757,7 @@ static int build_index(dh_db *A, int32_t k, int32_t sepv, int32_t kmer_mod, bool
     if (!tiles.empty())
         HIPCHK(hipMemcpyAsync(d_tiles, tiles.data(), sizeof(int2) * tiles.size(), hipMemcpyHostToDevice,
                               ctx->stream));
-    HIPCHK(hipMemsetAsync(ix.d_dir_alloc, 0, sizeof(uint32_t) * (size_t)(nb + 2), ctx->stream));
+    HIPCHK(dhk_memset(ctx->stream, ix.d_dir_alloc, 0, sizeof(uint32_t) * (size_t)(nb + 2)));
     const DbView av = A->view();
     // grouped DB (pile-ups): a group's keys share their top bits, i.e. its buckets are one contiguous range; when the
     // sequences come group by group and a group is cut into few slices, the passes count in LDS (k_group_index)
@@ -1122,7 +1122,7 @@ static int chunk_copies(dh_ctx *ctx, dh_db *B, int32_t r0, int32_t r1, bool want
         // reverse complement as bytes (only the wave kernels' byte path reads it): every read mirrored
         // inside its own [off, off + len) range
         if (int rc = dh_scratch(ctx, 26, (size_t)(o1 - a0) + 2 * DB_PAD, (void **)&d_rc)) return rc;
-        HIPCHK(hipMemsetAsync(d_rc, 4, (size_t)(o1 - a0) + 2 * DB_PAD, st));
+        HIPCHK(dhk_memset(st, d_rc, 4, (size_t)(o1 - a0) + 2 * DB_PAD));
         uint8_t *rc_shift = d_rc + DB_PAD - a0;
         dhk_revcomp(st, B->d_bases, rc_shift, B->d_off + r0, r1 - r0, B->max_len);
         HIPCHK(hipGetLastError());
@@ -1136,7 +1136,7 @@ static int chunk_copies(dh_ctx *ctx, dh_db *B, int32_t r0, int32_t r1, bool want
     if (int rc = dh_scratch(ctx, 28, pbytes, (void **)&d_rcpk)) return rc;
     if (int rc = dh_scratch(ctx, 3, 4 * sizeof(int32_t), (void **)&d_flag)) return rc;
     HIPCHK(hipMemsetAsync(d_flag + 1, 0, 2 * sizeof(int32_t), st));
-    HIPCHK(hipMemsetAsync(d_rcpk, 0, pbytes, st));
+    HIPCHK(dhk_memset(st, d_rcpk, 0, pbytes));
     dhk_pack2(st, B->d_bases + a0, o1 - a0, d_pk + PK_PAD, d_flag + 1);
     dhk_pack2_rc(st, B->d_bases, B->d_off + r0, r1 - r0, B->max_len, a0, d_rcpk + PK_PAD);
     HIPCHK(hipGetLastError());
@@ -1477,7 +1477,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         jv.npart = (int32_t)jp.pblk.size();
         jv.njoin = (int32_t)jp.jblk.size();
         // reads of groups without k-mers have no join block: their rows read as "no hits"
-        HIPCHK(hipMemsetAsync(d_segtab, 0, sizeof(uint64_t) * (size_t)std::max<int64_t>(jp.nseg, 1), st));
+        HIPCHK(dhk_memset(st, d_segtab, 0, sizeof(uint64_t) * (size_t)std::max<int64_t>(jp.nseg, 1)));
         HIPCHK(hipEventRecord(ctx->ev[6], st));
         dhk_join_part(st, jv, bv, o.k, o.kmer_mod);
         HIPCHK(hipGetLastError());
@@ -1723,7 +1723,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             SCR(9, d_la, (size_t)nrec_slots)
             SCR(10, d_trslots, (size_t)nrec_slots * trmax)
             SCR(52, d_reclist, (size_t)nrec_slots)
-            HIPCHK(hipMemsetAsync(d_la, 0, sizeof(DhLa) * (size_t)std::max<int64_t>(nrec_slots, 1), st));
+            HIPCHK(dhk_memset(st, d_la, 0, sizeof(DhLa) * (size_t)std::max<int64_t>(nrec_slots, 1)));
         }
         if (o.skip_self == 2 && ni > 1) {
             if (tiled) {
@@ -1740,7 +1740,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             }
             HIPCHK(hipGetLastError());
         }
-        HIPCHK(hipMemsetAsync(d_ovf, 0, sizeof(int32_t) * (size_t)ni, st));
+        HIPCHK(dhk_memset(st, d_ovf, 0, sizeof(int32_t) * (size_t)ni));
         WaveScratch ws{d_pool, d_cdj, d_queue, (const int4 *)d_units, d_queue + 3, poolcap, nbmax, d_ovf - item0};
         if (tiled) {
             dhtile::Params tp;
@@ -1853,7 +1853,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             if (sym_tiled) {
                 uint32_t *d_cur;
                 SCR(53, d_cur, (size_t)ni)
-                HIPCHK(hipMemsetAsync(d_cur, 0, sizeof(uint32_t) * (size_t)ni, st));
+                HIPCHK(dhk_memset(st, d_cur, 0, sizeof(uint32_t) * (size_t)ni));
                 dhk_rec_scatter(st, d_la, nrec_slots, (int32_t)item0, d_nla, d_cur, d_reclist);
                 dhk_compact_sym(st, d_la, d_trslots, trmax, d_reclist, ni, d_nla, d_ntr, (int64_t)t0, d_laout, d_trout, d_ovf);
             } else

@@ -30,6 +30,9 @@ inline hipError_t dh_dev_alloc(T **p, size_t bytes)
     return dh_dev_alloc((void **)p, bytes);
 }
 
+// memset that fills the chip for large buffers (dh_kernels.hip: k_fill16); small ones go to the runtime
+extern "C" hipError_t dhk_memset(hipStream_t st, void *ptr, int value, size_t nbytes);
+
 int dh_fail(int code, const std::string &msg);
 #include <vector>
 struct dh_scaffold;

@@ -152,7 +152,18 @@ int dh_db_from_slices(dh_ctx *ctx, const dh_db *src, const std::vector<int32_t> 
 struct dh_pileups {
     std::vector<int32_t> contig_left;
     std::vector<std::vector<int32_t>> triples;  // read, left LA, right LA
+    // general joins (dh_pileups_create_joins): (contig0, seed0, contig1, seed1) per pile-up, contig1 = -1 for an
+    // extension pile-up; empty = every pile-up is the gap (contig_left, BACK) -> (contig_left + 1, FRONT)
+    std::vector<std::array<int32_t, 4>> join;
+    std::array<int32_t, 4> join_of(size_t i) const
+    {
+        return join.empty() ? std::array<int32_t, 4>{contig_left[i], DH_SEED_BACK, contig_left[i] + 1, DH_SEED_FRONT} : join[i];
+    }
 };
+static int refuse_general(const dh_pileups *p, const char *who)
+{
+    return p && !p->join.empty() ? dh_fail(DH_EINVAL, std::string(who) + ": pile-ups of general joins are not handled here") : DH_OK;
+}
 
 // Candidates: for every read and every gap the read spans, ONE (read, left LA, right LA) entry --
 // the qualifying pair with the longest anchors (ties: lowest LA indices) -- grouped by gap, ordered
@@ -340,6 +351,7 @@ extern "C" int dh_pileups_select(const dh_pileups *cands, const dh_la *las, int6
     for (size_t i = 0; i < np; i++)
         if (keep[i]) {
             p->contig_left.push_back(cands->contig_left[i]);
+            if (!cands->join.empty()) p->join.push_back(cands->join[i]);
             p->triples.push_back(std::move(sel[i]));
         }
     *out = p;
@@ -358,6 +370,8 @@ void dh_pileups_shift(dh_pileups *p, int32_t by)
 }
 int dh_pileups_concat(dh_pileups *const *parts, int32_t nparts, dh_pileups **out)
 {
+    for (int32_t i = 0; i < nparts; i++)
+        if (int rc = refuse_general(parts[i], "dh_pileups_concat")) return rc;
     std::map<int32_t, std::vector<int32_t>> m;
     for (int32_t i = 0; i < nparts; i++) {
         if (!parts[i]) continue;
@@ -395,6 +409,40 @@ extern "C" int dh_pileups_create(const int32_t *contig_left, const int32_t *coun
     return DH_OK;
 }
 
+extern "C" int dh_pileups_create_joins(const int32_t *nodes4, const int32_t *count, int32_t npiles, const int32_t *triples,
+                                       dh_pileups **out)
+{
+    if (npiles < 0 || !out || (npiles > 0 && (!nodes4 || !count || !triples)))
+        return dh_fail(DH_EINVAL, "dh_pileups_create_joins: bad argument");
+    dh_pileups *p = new dh_pileups();
+    int64_t at = 0;
+    for (int32_t i = 0; i < npiles; i++) {
+        const int32_t *q = nodes4 + 4 * (size_t)i;
+        const bool ext = q[2] < 0;
+        // node order of the scaffold graph: (contig, part) with begin < end, i.e. seed front < seed back
+        auto key = [](const int32_t *x) { return std::array<int64_t, 4>{x[0], x[1], x[2] < 0 ? INT32_MAX : x[2], x[3]}; };
+        if (count[i] < 0 || q[0] < 0 || (q[1] != DH_SEED_FRONT && q[1] != DH_SEED_BACK) || (!ext && (q[3] != DH_SEED_FRONT && q[3] != DH_SEED_BACK)) ||
+            (!ext && q[2] <= q[0]) || (i > 0 && !(key(q - 4) < key(q)))) {
+            delete p;
+            return dh_fail(DH_EINVAL, "dh_pileups_create_joins: joins must be ordered by their nodes, contig0 < contig1, seeds 0 / 1, counts >= 0");
+        }
+        p->contig_left.push_back(q[0]);
+        p->join.push_back({q[0], q[1], ext ? -1 : q[2], ext ? 0 : q[3]});
+        p->triples.emplace_back(triples + at * 3, triples + (at + count[i]) * 3);
+        at += count[i];
+    }
+    *out = p;
+    return DH_OK;
+}
+
+extern "C" int dh_pileups_get_join(const dh_pileups *p, int32_t i, int32_t *nodes4)
+{
+    if (!p || !nodes4 || i < 0 || i >= (int32_t)p->contig_left.size()) return dh_fail(DH_EINVAL, "dh_pileups_get_join: bad argument");
+    const std::array<int32_t, 4> j = p->join_of((size_t)i);
+    memcpy(nodes4, j.data(), sizeof(int32_t) * 4);
+    return DH_OK;
+}
+
 extern "C" int dh_collect_spanning(const dh_la *las, int64_t n, const int64_t *contig_off,
                                    int32_t ncontigs, const dh_process_opts *opts, dh_pileups **out)
 {
@@ -423,6 +471,7 @@ extern "C" int dh_pileups_write_db(const dh_pileups *p, const dh_la *las, int64_
     std::vector<uint16_t> tp;
     for (size_t i = 0; i < p->contig_left.size(); i++) {
         const std::vector<int32_t> &t = p->triples[i];
+        const std::array<int32_t, 4> jn = p->join_of(i);
         nra.push_back((int32_t)t.size() / 3);
         for (size_t e = 0; e + 2 < t.size(); e += 3) {
             nsa.push_back((t[e + 1] >= 0 ? 1 : 0) + (t[e + 2] >= 0 ? 1 : 0));
@@ -441,7 +490,7 @@ extern "C" int dh_pileups_write_db(const dh_pileups *p, const dh_la *las, int64_
                 s.contig_b_id = (uint32_t)(x.bread + 1);
                 s.contig_b_len = (uint32_t)(read_off[x.bread + 1] - read_off[x.bread]);
                 s.flags = (x.flags & DH_FLAG_COMP) ? 1 : 0;
-                s.seed = side == 0 ? 1 : 0;
+                s.seed = (uint8_t)jn[1 + 2 * (size_t)side];  // AlignmentLocationSeed of the flank (plain gap: back, front)
                 s.tspace = (uint16_t)tspace;
                 s.nla = 1;
                 sa.push_back(s);
@@ -759,16 +808,28 @@ extern "C" int dh_insertions_write_db(const dh_insertions *r, const int64_t *con
     for (size_t i = 0; i < r->rec.size(); i++) {
         const dh_insertion &x = r->rec[i];
         if (x.status != DH_PILE_OK || r->flank_of[i] < 0) continue;
-        if (x.contig_left < 0 || x.contig_left + 1 >= ncontigs) return dh_fail(DH_EINVAL, "dh_insertions_write_db: gap outside the contigs");
+        const bool ext = (x.join & DH_JOIN_EXTENSION) != 0;
+        const int32_t nf = ext ? 1 : 2;
+        const int32_t fcontig[2] = {x.contig_left, ext ? x.contig_left : (x.join == 0 && x.contig_right == 0 ? x.contig_left + 1 : x.contig_right)};
+        const bool front[2] = {(x.join & DH_JOIN_FLANK0_FRONT) != 0, (x.join & DH_JOIN_FLANK1_BACK) == 0};
+        if (fcontig[0] < 0 || fcontig[0] >= ncontigs || fcontig[1] < 0 || fcontig[1] >= ncontigs)
+            return dh_fail(DH_EINVAL, "dh_insertions_write_db: gap outside the contigs");
         dh_insertion_rec q;
         memset(&q, 0, sizeof(q));
-        q.start_contig = x.contig_left + 1;
-        q.start_part = 2;  // ContigPart.end
-        q.end_contig = x.contig_left + 2;
-        q.end_part = 1;    // ContigPart.begin
+        // makeJoin (base.d:2680-2722): a gap joins the seeded parts of its two contigs (begin = 1, end = 2); a front
+        // extension is (contig, pre = 0) -> (contig, begin), a back extension (contig, end) -> (contig, post = 3)
+        q.start_contig = fcontig[0] + 1;
+        q.end_contig = fcontig[1] + 1;
+        if (ext) {
+            q.start_part = front[0] ? 0 : 2;
+            q.end_part = front[0] ? 1 : 3;
+        } else {
+            q.start_part = front[0] ? 1 : 2;
+            q.end_part = front[1] ? 1 : 2;
+        }
         q.seq_len = x.cons_len;
         q.contig_len = 0;
-        q.noverlaps = 2;
+        q.noverlaps = nf;
         q.nread_ids = r->ids_off[i + 1] - r->ids_off[i];
         ins.push_back(q);
         bases.insert(bases.end(), r->bases.begin() + x.cons_off, r->bases.begin() + x.cons_off + x.cons_len);
@@ -776,9 +837,9 @@ extern "C" int dh_insertions_write_db(const dh_insertions *r, const int64_t *con
         for (uint32_t &v : my) v += 1;
         std::sort(my.begin(), my.end());
         ids.insert(ids.end(), my.begin(), my.end());
-        for (int side = 0; side < 2; side++) {
+        for (int side = 0; side < nf; side++) {
             const dh_la &f = r->flank[(size_t)r->flank_of[i] + (size_t)side];
-            const int32_t c = x.contig_left + side;
+            const int32_t c = fcontig[side];
             dh_seeded s;
             memset(&s, 0, sizeof(s));
             s.id = (int64_t)sa.size();
@@ -787,7 +848,7 @@ extern "C" int dh_insertions_write_db(const dh_insertions *r, const int64_t *con
             s.contig_b_id = 1;
             s.contig_b_len = (uint32_t)x.cons_len;
             s.flags = (f.flags & DH_FLAG_COMP) ? 1 : 0;
-            s.seed = side == 0 ? 1 : 0;  // left flank: the back of the contig; right flank: its front
+            s.seed = front[side] ? 0 : 1;  // AlignmentLocationSeed: front = 0, back = 1 (plain gap: the back of the left contig, the front of the right one)
             s.tspace = (uint16_t)tspace;
             s.nla = 1;
             sa.push_back(s);
@@ -934,14 +995,14 @@ static int consensus_round(dh_ctx *ctx, dh_db *T, dh_db *R, const LaVec &las,
     d_cnt.p = d_stage.p + (size_t)voff.back() * (1 + 2 * MAXINS);
     HIPCHK(hipMemcpyAsync(d_voff.p, voff.data(), sizeof(int64_t) * voff.size(), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_ooff.p, ooff.data(), sizeof(int64_t) * ooff.size(), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(d_votes.p, 0, sizeof(uint32_t) * (size_t)voff.back() * VSTRIDE, st));
+    HIPCHK(dhk_memset(st, d_votes.p, 0, sizeof(uint32_t) * (size_t)voff.back() * VSTRIDE));
     HIPCHK(hipMemsetAsync(d_status.p, 0, sizeof(int32_t), st));
     // sparse votes: cover difference array and "other code" counts per column, scan partial sums
     const size_t ncolp = (size_t)voff.back() + 2;
     struct { uint32_t *p; } d_cdiff;
     SCRP(25, d_cdiff, 2 * ncolp + ncolp / 2048 + 8)
     uint32_t *d_vother = d_cdiff.p + ncolp, *d_csums = d_vother + ncolp;
-    HIPCHK(hipMemsetAsync(d_cdiff.p, 0, sizeof(uint32_t) * 2 * ncolp, st));
+    HIPCHK(dhk_memset(st, d_cdiff.p, 0, sizeof(uint32_t) * 2 * ncolp));
     if (int rc = dh_ensure_rc(R)) return rc;
     // the decision matrices of one launch live interleaved in HBM: bound the launch to ~6 GB
     for (int cls = 0; cls < 3; cls++) {
@@ -970,7 +1031,7 @@ static int consensus_round(dh_ctx *ctx, dh_db *T, dh_db *R, const LaVec &las,
     {
         // column -> template map of the vote space (-1 for the spare column after each template)
         dhk_col_tmpl(st, d_voff.p, nt, voff.back(), d_coltmpl.p);
-        HIPCHK(hipMemsetAsync(d_cnt.p, 0, (size_t)voff.back(), st));
+        HIPCHK(dhk_memset(st, d_cnt.p, 0, (size_t)voff.back()));
         dhk_scan(st, d_cdiff.p, (int64_t)ncolp, d_csums);  // exclusive: cover of column x = [x + 1]
         dhk_votes_finish(st, T->view(), d_voff.p, d_coltmpl.p, voff.back(), d_cdiff.p, d_vother, d_votes.p);
         dhk_emit(st, T->view(), nt, d_voff.p, d_votes.p, d_coltmpl.p, voff.back(), d_stage.p, d_cnt.p, d_ooff.p,
@@ -1142,6 +1203,12 @@ extern "C" int dh_consensus(dh_ctx *ctx, dh_db *db, const dh_la *las, int64_t n,
 
 // ------------------------------------------------------------------------------------ crop stage
 struct dh_cropped;
+extern "C" int dh_process_pileups_masked(dh_ctx *ctx, dh_db *contigs, dh_db *reads, const dh_la *las, int64_t n,
+                                         const uint16_t *trace, const dh_pileups *piles, const int64_t *rep_ptr,
+                                         const int32_t *rep_iv, const dh_process_opts *opts, dh_insertions **out);
+extern "C" int dh_crop_pileups_masked(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_t read_first, const dh_la *las,
+                                      int64_t n, const uint16_t *trace, const dh_pileups *piles, const int64_t *rep_ptr,
+                                      const int32_t *rep_iv, const dh_process_opts *opts, dh_cropped **out);
 extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop, const dh_process_opts *opts,
                                   dh_insertions **out);
 
@@ -1153,12 +1220,14 @@ struct dh_cropped {
     dh_ctx *ctx = nullptr;
     std::vector<dh_insertion> rec;
     std::vector<int32_t> pile, entry, read_id;
-    std::vector<uint8_t> kind;  // per cropped read: 0 = spans the gap, 1 = back extension of the left contig, 2 = front extension of the right one
+    std::vector<uint8_t> kind;  // per cropped read, bits 0-1: 0 = alignments on both flanks (spans the gap), 1 = on flank 0 only, 2 = on flank 1 only;
+                                // bit 2 / 3: its alignment on flank 0 / 1 is a complement one
     std::vector<int64_t> off{0};
     // page-locked and not zero-filled on resize(): the cropped reads travel device -> host -> (collective) -> host -> device
     // in the sharded path, 21 MB per rank at N = 8
     std::vector<uint8_t, PinnedAlloc<uint8_t>> bases;
     bool host_valid = false;
+    bool comp_known = true;  // false: made without kinds (dh_cropped_create): the complement bits are not there
     dh_db *dev = nullptr;
     float ms_crop = 0;
 };
@@ -1232,12 +1301,14 @@ extern "C" int dh_cropped_create2(const dh_insertion *rec, int32_t npiles, int32
         c->read_id.assign(read_id, read_id + nreads);
         if (kind)
             c->kind.assign(kind, kind + nreads);
-        else
+        else {
             c->kind.assign((size_t)nreads, 0);
+            c->comp_known = false;
+        }
         for (uint8_t k : c->kind)
-            if (k > 2) {
+            if ((k & 3) > 2 || k > 15) {
                 delete c;
-                return dh_fail(DH_EINVAL, "dh_cropped_create: kind must be 0, 1 or 2");
+                return dh_fail(DH_EINVAL, "dh_cropped_create: kind must be 0, 1 or 2 (| 4, 8: complement alignment on flank 0, 1)");
             }
         c->off.assign(off, off + nreads + 1);
         c->bases.assign(bases, bases + off[nreads]);
@@ -1256,7 +1327,16 @@ extern "C" int dh_crop_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_
                                int64_t n, const uint16_t *trace, const dh_pileups *piles,
                                const dh_process_opts *opts, dh_cropped **out)
 {
-    if (!ctx || !contigs || !reads || !piles || !opts || !out || (n > 0 && !las))
+    return dh_crop_pileups_masked(ctx, contigs, reads, read_first, las, n, trace, piles, nullptr, nullptr, opts, out);
+}
+
+// rep_ptr[ncontigs + 1] / rep_iv: the repeat mask (sorted disjoint (begin, end) pairs per contig) the common trace points
+// keep out of when they can (cropper.d:446-500); NULL = no mask
+extern "C" int dh_crop_pileups_masked(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_t read_first, const dh_la *las,
+                                      int64_t n, const uint16_t *trace, const dh_pileups *piles, const int64_t *rep_ptr,
+                                      const int32_t *rep_iv, const dh_process_opts *opts, dh_cropped **out)
+{
+    if (!ctx || !contigs || !reads || !piles || !opts || !out || (n > 0 && !las) || (rep_ptr && !rep_iv && rep_ptr[contigs->n] > 0))
         return dh_fail(DH_EINVAL, "dh_crop_pileups: NULL argument");
     const dh_process_opts &o = *opts;
     HIPCHK(hipSetDevice(ctx->device));
@@ -1291,10 +1371,10 @@ extern "C" int dh_crop_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_
     // pile-ups are independent: host threads compute crop points and read slices (the trace walks are
     // cache misses into the mapping's trace array), the parts are laid out serially afterwards
     struct Slice {
-        int32_t e, rd, lrd, b0, b1, comp, kind;
+        int32_t e, rd, lrd, b0, b1, kind;  // kind: 0 / 1 / 2 | complement of the alignment on flank 0 << 2 | on flank 1 << 3
     };
     struct PileCrop {
-        int32_t lp0 = 0, lp1 = 0, rp0 = 0, rp1 = 0;
+        int32_t pc[2] = {-1, -1}, p0[2] = {0, 0}, p1[2] = {0, 0};  // support patch of flank f: contig pc[f], [p0, p1)
         std::vector<Slice> sl;
     };
     std::vector<PileCrop> pc((size_t)np);
@@ -1303,52 +1383,74 @@ extern "C" int dh_crop_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_
         for (int64_t p = plo; p < phi; p++) {
             dh_insertion &r = c->rec[(size_t)p];
             memset(&r, 0, sizeof(r));
-            const int32_t g = piles->contig_left[(size_t)p];
-            if (g < 0 || g + 1 >= contigs->n) {
+            // the two flanks (cropper.d:113-175 treats every pile-up alike: one common trace point per involved
+            // contig, taken from the alignments seeded there)
+            const std::array<int32_t, 4> jn = piles->join_of((size_t)p);
+            const int32_t nf = jn[2] < 0 ? 1 : 2;
+            const int32_t fc[2] = {jn[0], jn[2]};
+            const bool front[2] = {jn[1] == DH_SEED_FRONT, jn[3] == DH_SEED_FRONT};
+            if (fc[0] < 0 || fc[0] >= contigs->n || (nf == 2 && fc[1] >= contigs->n)) {
                 err = 1;
                 continue;
             }
-            r.contig_left = g;
+            r.contig_left = fc[0];
+            r.contig_right = nf == 2 ? fc[1] : -1;
+            r.join = (front[0] ? DH_JOIN_FLANK0_FRONT : 0) | (nf == 2 && !front[1] ? DH_JOIN_FLANK1_BACK : 0) | (nf == 1 ? DH_JOIN_EXTENSION : 0);
             r.ref_read = r.ref_read_id = -1;
             r.crop_left = r.crop_right = -1;
+            if (nf == 2 && fc[0] == fc[1]) {
+                r.status = DH_PILE_UNSUPPORTED_JOIN;
+                continue;
+            }
             const std::vector<int32_t> &tr3 = piles->triples[(size_t)p];
             const int32_t ne = (int32_t)tr3.size() / 3;
-            Region lreg{{0, INT32_MAX}}, rreg{{0, INT32_MAX}};
+            Region reg[2] = {Region{{0, INT32_MAX}}, Region{{0, INT32_MAX}}};
             bool bad = false;
-            for (int32_t e = 0; e < ne; e++) {
+            for (int32_t e = 0; e < ne && !bad; e++) {
                 // an entry is a read spanning the gap (two alignments) or an extension over one contig end
                 // merged into the gap's pile-up (one alignment, the other index is -1: scaffold.d:789-816)
-                const int32_t iL = tr3[(size_t)e * 3 + 1], iR = tr3[(size_t)e * 3 + 2];
-                if (iL < -1 || iL >= n || iR < -1 || iR >= n || (iL < 0 && iR < 0)) {
+                const int32_t ix[2] = {tr3[(size_t)e * 3 + 1], tr3[(size_t)e * 3 + 2]};
+                if (ix[0] < -1 || ix[0] >= n || ix[1] < -1 || ix[1] >= n || (ix[0] < 0 && ix[1] < 0) || (nf == 1 && ix[1] >= 0)) {
                     bad = true;
                     break;
                 }
-                if (iL >= 0) intersect_chain(lreg, las, n, iL);
-                if (iR >= 0) intersect_chain(rreg, las, n, iR);
+                for (int f = 0; f < nf; f++)
+                    if (ix[f] >= 0) {
+                        if (las[ix[f]].aread != fc[f])
+                            bad = true;
+                        else
+                            intersect_chain(reg[f], las, n, ix[f]);
+                    }
             }
             if (bad) {
                 err = 2;
                 continue;
             }
-            const int32_t cll = (int32_t)(contigs->h_off[(size_t)g + 1] - contigs->h_off[(size_t)g]);
-            const int32_t clr = (int32_t)(contigs->h_off[(size_t)g + 2] - contigs->h_off[(size_t)g + 1]);
-            const int32_t cropL = common_trace_point(lreg, cll, tsm, false);
-            const int32_t cropR = common_trace_point(rreg, clr, tsm, true);
-            r.crop_left = cropL;
-            r.crop_right = cropR;
-            if (cropL < 0 || cropR < 0) {
+            int32_t clen[2] = {0, 0}, crop[2] = {-1, -1};
+            for (int f = 0; f < nf; f++) {
+                clen[f] = (int32_t)(contigs->h_off[(size_t)fc[f] + 1] - contigs->h_off[(size_t)fc[f]]);
+                const int64_t m0 = rep_ptr ? rep_ptr[fc[f]] : 0, m1 = rep_ptr ? rep_ptr[fc[f] + 1] : 0;
+                crop[f] = common_trace_point(reg[f], clen[f], tsm, front[f], rep_iv ? rep_iv + 2 * m0 : nullptr, m1 - m0);
+            }
+            r.crop_left = crop[0];
+            r.crop_right = crop[1];
+            if (crop[0] < 0 || (nf == 2 && crop[1] < 0)) {
                 r.status = DH_PILE_NO_COMMON_TRACE_POINT;
                 continue;
             }
             PileCrop &q = pc[(size_t)p];
             // fetchSupportPatches, cropper.d:224-262
-            if (cll - cropL < o.min_anchor) {
-                q.lp0 = std::max(0, cll - o.min_anchor);
-                q.lp1 = cropL;
-            }
-            if (cropR < o.min_anchor) {
-                q.rp0 = cropR;
-                q.rp1 = std::min(clr, o.min_anchor);
+            for (int f = 0; f < nf; f++) {
+                q.pc[f] = fc[f];
+                if (front[f]) {
+                    if (crop[f] < o.min_anchor) {
+                        q.p0[f] = crop[f];
+                        q.p1[f] = std::min(clen[f], o.min_anchor);
+                    }
+                } else if (clen[f] - crop[f] < o.min_anchor) {
+                    q.p0[f] = std::max(0, clen[f] - o.min_anchor);
+                    q.p1[f] = crop[f];
+                }
             }
             for (int32_t e = 0; e < ne; e++) {
                 const int32_t rd = tr3[(size_t)e * 3];
@@ -1358,63 +1460,81 @@ extern "C" int dh_crop_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_
                     err = 3;
                     break;
                 }
-                const int32_t iL = tr3[(size_t)e * 3 + 1], iR = tr3[(size_t)e * 3 + 2];
+                const int32_t ix[2] = {tr3[(size_t)e * 3 + 1], tr3[(size_t)e * 3 + 2]};
                 const int32_t rl = (int32_t)(reads->h_off[(size_t)lrd + 1] - reads->h_off[(size_t)lrd]);
-                // getCroppingSlice per alignment, intersected (cropper.d:339-348, 503-550): the back-seeded
-                // one keeps [crop point, read end), the front-seeded one [0, crop point)
+                // getCroppingSlice per alignment, intersected (cropper.d:339-348, 503-550): a back-seeded alignment
+                // keeps [crop point, read end), a front-seeded one [0, crop point) of the read as the alignment sees it
+                // -- mirrored for a complement alignment (:533-538)
                 // (a chain translates through the first of its members that covers the crop point)
-                const int64_t mL = iL >= 0 ? covering_member(las, n, iL, cropL) : -1, mR = iR >= 0 ? covering_member(las, n, iR, cropR) : -1;
-                if ((iL >= 0 && mL < 0) || (iR >= 0 && mR < 0)) {
+                int32_t b0 = 0, b1 = rl, kind = ix[1] < 0 ? 1 : (ix[0] < 0 ? 2 : 0);
+                bool fail = false;
+                for (int f = 0; f < nf && !fail; f++) {
+                    if (ix[f] < 0) continue;
+                    const int64_t m = covering_member(las, n, ix[f], crop[f]);
+                    if (m < 0) {
+                        fail = true;
+                        break;
+                    }
+                    const int32_t b = translate_floor_b(las[m], trace + las[m].toff, tsm, crop[f]);
+                    int32_t lo = front[f] ? 0 : b, hi = front[f] ? b : rl;
+                    if (las[ix[f]].flags & DH_FLAG_COMP) {
+                        const int32_t t = lo;
+                        lo = rl - hi;
+                        hi = rl - t;
+                        kind |= 4 << f;
+                    }
+                    b0 = std::max(b0, lo);
+                    b1 = std::min(b1, hi);
+                }
+                if (fail) {
                     err = 4;
                     break;
-                }
-                const int32_t bL = iL >= 0 ? translate_floor_b(las[mL], trace + las[mL].toff, tsm, cropL) : 0;
-                const int32_t bR = iR >= 0 ? translate_floor_b(las[mR], trace + las[mR].toff, tsm, cropR) : rl;
-                int32_t b0 = bL, b1 = bR;
-                const bool comp = (las[iL >= 0 ? iL : iR].flags & DH_FLAG_COMP) != 0;
-                if (comp) {  // getCroppingSlice, cropper.d:533-538
-                    b0 = rl - bR;
-                    b1 = rl - bL;
                 }
                 if (b1 - b0 < 14) continue;  // records shorter than 14 bp are dropped (dazzler.d:150)
                 if (b0 < 0 || b1 > rl) {
                     err = 4;
                     break;
                 }
-                q.sl.push_back(Slice{e, rd, (int32_t)lrd, b0, b1, comp ? 1 : 0, iR < 0 ? 1 : (iL < 0 ? 2 : 0)});
+                q.sl.push_back(Slice{e, rd, (int32_t)lrd, b0, b1, kind});
             }
         }
     });
     switch (err.load()) {
         case 1: return dh_fail(DH_EINVAL, "dh_crop_pileups: gap outside the contigs DB");
-        case 2: return dh_fail(DH_EINVAL, "dh_crop_pileups: LA index out of range");
+        case 2: return dh_fail(DH_EINVAL, "dh_crop_pileups: LA index out of range, or an alignment that is not on its flank's contig");
         case 3: return dh_fail(DH_EINVAL, "dh_crop_pileups: trace is NULL");
         case 4: return dh_fail(DH_EINVAL, "dh_crop_pileups: trace does not fit its read");
         default: break;
     }
     for (int32_t p = 0; p < np; p++) {
         const PileCrop &q = pc[(size_t)p];
-        const int32_t g = piles->contig_left[(size_t)p];
+        const std::array<int32_t, 4> jn = piles->join_of((size_t)p);
+        const bool front[2] = {jn[1] == DH_SEED_FRONT, jn[3] == DH_SEED_FRONT};
         dh_insertion &r = c->rec[(size_t)p];
         for (const Slice &x : q.sl) {
-            const bool comp = x.comp != 0;
             int64_t dst = c->off.back();
-            // getSingleReadPatch, cropper.d:363-378: complement reads get the reverse-complemented
-            // patches in swapped positions
-            // (an extension entry gets the patch of its own contig only: getReadPatches, cropper.d:351-361)
-            const int32_t lp0 = x.kind == 2 ? 0 : q.lp0, lp1 = x.kind == 2 ? 0 : q.lp1;
-            const int32_t rp0 = x.kind == 1 ? 0 : q.rp0, rp1 = x.kind == 1 ? 0 : q.rp1;
-            const int32_t pre_c = comp ? g + 1 : g, pre0 = comp ? rp0 : lp0, pre1 = comp ? rp1 : lp1;
-            const int32_t post_c = comp ? g : g + 1, post0 = comp ? lp0 : rp0, post1 = comp ? lp1 : rp1;
-            if (pre1 > pre0) {
-                parts.push_back(PartDescH{1, pre_c, pre0, pre1 - pre0, comp ? 1 : 0, 0, dst});
-                dst += pre1 - pre0;
+            // getSingleReadPatch / getReadPatches, cropper.d:351-378: the patch of an alignment goes to the read's front
+            // when (contig seed == front) == complement, else to its back, reverse-complemented for a complement
+            // alignment; an extension entry gets the patch of its own contig only
+            int pre = -1, post = -1;
+            for (int f = 0; f < 2; f++) {
+                const bool has = f == 0 ? (x.kind & 3) != 2 : ((x.kind & 3) != 1 && q.pc[1] >= 0);
+                if (!has || q.p1[f] <= q.p0[f]) continue;
+                const bool comp = (x.kind & (4 << f)) != 0;
+                if (front[f] == comp)
+                    pre = f;
+                else
+                    post = f;
+            }
+            if (pre >= 0) {
+                parts.push_back(PartDescH{1, q.pc[pre], q.p0[pre], q.p1[pre] - q.p0[pre], (x.kind & (4 << pre)) ? 1 : 0, 0, dst});
+                dst += q.p1[pre] - q.p0[pre];
             }
             parts.push_back(PartDescH{0, x.lrd, x.b0, x.b1 - x.b0, 0, 0, dst});
             dst += x.b1 - x.b0;
-            if (post1 > post0) {
-                parts.push_back(PartDescH{1, post_c, post0, post1 - post0, comp ? 1 : 0, 0, dst});
-                dst += post1 - post0;
+            if (post >= 0) {
+                parts.push_back(PartDescH{1, q.pc[post], q.p0[post], q.p1[post] - q.p0[post], (x.kind & (4 << post)) ? 1 : 0, 0, dst});
+                dst += q.p1[post] - q.p0[post];
             }
             pile_max_len = std::max<int32_t>(pile_max_len, (int32_t)(dst - c->off.back()));
             c->off.push_back(dst);
@@ -1454,11 +1574,19 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
                                   const uint16_t *trace, const dh_pileups *piles,
                                   const dh_process_opts *opts, dh_insertions **out)
 {
+    return dh_process_pileups_masked(ctx, contigs, reads, las, n, trace, piles, nullptr, nullptr, opts, out);
+}
+
+// with the repeat mask of the contigs (--mask of `dentist process`: the cropper keeps its trace points out of it)
+extern "C" int dh_process_pileups_masked(dh_ctx *ctx, dh_db *contigs, dh_db *reads, const dh_la *las, int64_t n,
+                                         const uint16_t *trace, const dh_pileups *piles, const int64_t *rep_ptr,
+                                         const int32_t *rep_iv, const dh_process_opts *opts, dh_insertions **out)
+{
     if (!ctx || !contigs || !reads || !piles || !opts || !out || (n > 0 && (!las || !trace)))
         return dh_fail(DH_EINVAL, "dh_process_pileups: NULL argument");
     auto one = [&](dh_ctx *cx, const dh_pileups *pl, dh_insertions **res) -> int {
         dh_cropped *c = nullptr;
-        if (int rc = dh_crop_pileups(cx, contigs, reads, 0, las, n, trace, pl, opts, &c)) return rc;
+        if (int rc = dh_crop_pileups_masked(cx, contigs, reads, 0, las, n, trace, pl, rep_ptr, rep_iv, opts, &c)) return rc;
         const int rc = dh_process_cropped(cx, contigs, c, opts, res);
         dh_cropped_destroy(c);
         return rc;
@@ -1501,6 +1629,7 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
         for (size_t p = cut[(size_t)k]; p < cut[(size_t)k + 1]; p++) {
             part[(size_t)k].contig_left.push_back(piles->contig_left[p]);
             part[(size_t)k].triples.push_back(piles->triples[p]);
+            if (!piles->join.empty()) part[(size_t)k].join.push_back(piles->join[p]);
         }
     std::vector<dh_insertions *> res((size_t)nparts, nullptr);
     std::vector<int> rcs((size_t)nparts, DH_OK);
@@ -1646,13 +1775,16 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
     std::vector<int32_t> pile_of_active;             // active index -> pile-up index
     std::vector<int32_t> first_read;                 // active index -> first read in pile-up DB
     std::vector<int32_t> read_id;                    // pile-up DB read -> read id in `reads`
-    std::vector<uint8_t> rkind;                      // pile-up DB read -> 0 spans the gap, 1 / 2 extension entry
+    std::vector<uint8_t> rkind;                      // pile-up DB read -> 0 = it may serve as reference read (alignments on every flank of its pile-up:
+                                                     // selectAllowedReferenceReadIds, package.d:461-472), else 1 / 2 = on flank 0 / 1 only
+    std::vector<uint8_t> rcomp;                      // pile-up DB read -> bit f: its alignment on flank f is a complement one
     std::vector<int32_t> sgroup, keep;               // per pile-up DB read: group, index in the crop DB
     for (int32_t p = 0; p < np; p++) {
         dh_insertion &r = res->rec[(size_t)p];
         r.nreads = cnt_of[(size_t)p];
         if (r.status != DH_PILE_OK) continue;
-        if (r.contig_left < 0 || r.contig_left + 1 >= contigs->n)
+        if (r.join == 0 && r.contig_right == 0 && r.contig_left + 1 < contigs->n) r.contig_right = r.contig_left + 1;  // records made by hand before the field existed
+        if (r.contig_left < 0 || r.contig_left >= contigs->n || ((r.join & DH_JOIN_EXTENSION) ? r.contig_right != -1 : (r.contig_right <= r.contig_left || r.contig_right >= contigs->n)))
             return dh_fail(DH_EINVAL, "dh_process_cropped: gap outside the contigs DB");
         if (cnt_of[(size_t)p] < o.min_reads)
             r.status = DH_PILE_TOO_SMALL;
@@ -1670,7 +1802,12 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
         sgroup.push_back(active_of[(size_t)p]);
         keep.push_back(i);
         read_id.push_back(crop->read_id[(size_t)i]);
-        rkind.push_back(crop->kind.empty() ? 0 : crop->kind[(size_t)i]);
+        {
+            const uint8_t kd = crop->kind.empty() ? 0 : crop->kind[(size_t)i];
+            // (an extension pile-up has one flank: every read of it has its alignment there)
+            rkind.push_back((res->rec[(size_t)p].join & DH_JOIN_EXTENSION) ? ((kd & 3) == 1 ? 0 : 2) : (kd & 3));
+            rcomp.push_back(kd >> 2);
+        }
     }
     const int32_t na = (int32_t)pile_of_active.size();
     first_read.push_back((int32_t)keep.size());
@@ -2065,25 +2202,28 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
         }
         lap("consensus rounds");
         // ---- 7. flank re-alignment: daligner -A -s126 -l126 contigs consensus (commandline.d:2918-2935)
-        std::vector<int32_t> fidx, fbeg, flen, fgrp, foff((size_t)na, 0);
+        // one slice of the flank DB per flank of a pile-up (package.d:631-667 builds the DB from the croppingPositions'
+        // contigs): the contig's tail for a back-seeded flank, its head for a front-seeded one
+        std::vector<int32_t> fidx, fbeg, flen, fgrp, fbase((size_t)na + 1, 0);
         for (int32_t a = 0; a < na; a++) {
-            const int32_t g = res->rec[(size_t)pile_of_active[(size_t)a]].contig_left;
-            const int32_t cll = (int32_t)(contigs->h_off[(size_t)g + 1] - contigs->h_off[(size_t)g]);
-            const int32_t clr = (int32_t)(contigs->h_off[(size_t)g + 2] - contigs->h_off[(size_t)g + 1]);
+            const dh_insertion &rec = res->rec[(size_t)pile_of_active[(size_t)a]];
+            const int32_t nf = (rec.join & DH_JOIN_EXTENSION) ? 1 : 2;
             // flank_window <= 0: the whole contigs, as the reference hands them to daligner (commandline.d:2918-2935)
             const int32_t fw = o.flank_window > 0 ? o.flank_window : INT32_MAX;
-            // (the window starts on the trace grid of the contig: tiles, and with them the alignment, are those of the whole contig)
-            const int32_t wl = std::max(0, cll - std::min(cll, fw)) / tsp * tsp;
-            foff[(size_t)a] = wl;
-            fidx.push_back(g);
-            fbeg.push_back(wl);
-            flen.push_back(cll - wl);
-            fgrp.push_back(a);
-            fidx.push_back(g + 1);
-            fbeg.push_back(0);
-            flen.push_back(std::min(clr, fw));
-            fgrp.push_back(a);
+            fbase[(size_t)a] = (int32_t)fidx.size();
+            for (int32_t f = 0; f < nf; f++) {
+                const int32_t g = f == 0 ? rec.contig_left : rec.contig_right;
+                const bool front = f == 0 ? (rec.join & DH_JOIN_FLANK0_FRONT) != 0 : (rec.join & DH_JOIN_FLANK1_BACK) == 0;
+                const int32_t cl = (int32_t)(contigs->h_off[(size_t)g + 1] - contigs->h_off[(size_t)g]);
+                // (a tail window starts on the trace grid of the contig: tiles, and with them the alignment, are those of the whole contig)
+                const int32_t wl = front ? 0 : std::max(0, cl - std::min(cl, fw)) / tsp * tsp;
+                fidx.push_back(g);
+                fbeg.push_back(wl);
+                flen.push_back(front ? std::min(cl, fw) : cl - wl);
+                fgrp.push_back(a);
+            }
         }
+        fbase[(size_t)na] = (int32_t)fidx.size();
         dh_db *F = nullptr;
         if (int rc = dh_db_from_slices(ctx, contigs, fidx, fbeg, flen, fgrp, &F, true)) return rc;
         dbg.dbs.push_back(F);
@@ -2107,6 +2247,10 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
         // ---- 8. consensus bases to the host, insertion per pile-up
         std::vector<uint8_t> cons((size_t)std::max<int64_t>(T->total, 1));
         if (T->total > 0) HIPCHK(hipMemcpy(cons.data(), T->d_bases, (size_t)T->total, hipMemcpyDeviceToHost));
+        // the flank overlaps of a pile-up: B = its consensus; records are grouped by B read or not -- index them once
+        std::vector<std::vector<int32_t>> fl_of((size_t)na);
+        for (size_t i = 0; i < fset->la.size(); i++)
+            if (fset->la[i].bread >= 0 && fset->la[i].bread < na) fl_of[(size_t)fset->la[i].bread].push_back((int32_t)i);
         for (int32_t a = 0; a < na; a++) {
             dh_insertion &rec = res->rec[(size_t)pile_of_active[(size_t)a]];
             if (!active_ok[(size_t)a]) continue;
@@ -2114,52 +2258,77 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
             rec.cons_off = (int64_t)res->bases.size();
             rec.cons_len = (int32_t)(c1 - c0);
             res->bases.insert(res->bases.end(), cons.begin() + c0, cons.begin() + c1);
-            const int32_t fl_len = flen[(size_t)2 * a], clen = rec.cons_len;
-            const dh_la *L = nullptr, *R = nullptr;
-            int nL = 0, nR = 0;
-            for (const dh_la &la : fset->la) {
-                if (la.bread != a) continue;
-                if (la.aread == 2 * a && la.aepos + tsp >= fl_len && la.bbpos <= tsp) {
-                    L = &la;
-                    nL++;
-                }
-                if (la.aread == 2 * a + 1 && la.abpos <= tsp && la.bepos + tsp >= clen) {
-                    R = &la;
-                    nR++;
+            const int32_t clen = rec.cons_len;
+            const int32_t nf = (rec.join & DH_JOIN_EXTENSION) ? 1 : 2;
+            const bool front[2] = {(rec.join & DH_JOIN_FLANK0_FRONT) != 0, (rec.join & DH_JOIN_FLANK1_BACK) == 0};
+            // the consensus has the orientation of the reference read: an overlap whose complement flag differs from the
+            // reference read's alignment on that contig is disabled (package.d:669-690); of the others exactly one per
+            // flank must be a proper insertion overlap (:707-745)
+            const uint8_t refc = ref_of[(size_t)a] >= 0 ? rcomp[(size_t)ref_of[(size_t)a]] : 0;
+            const bool refc_known = crop->comp_known && ref_of[(size_t)a] >= 0;
+            const dh_la *ov[2] = {nullptr, nullptr};
+            int cnt[2] = {0, 0};
+            for (int32_t i : fl_of[(size_t)a]) {
+                const dh_la &la = fset->la[(size_t)i];
+                const int32_t f = la.aread - fbase[(size_t)a];
+                if (f < 0 || f >= nf) continue;
+                if (refc_known && ((la.flags & DH_FLAG_COMP) != 0) != (((refc >> f) & 1) != 0)) continue;
+                const int32_t fl_len = flen[(size_t)la.aread];
+                const bool proper = front[f] ? (la.abpos <= tsp && la.bepos + tsp >= clen) : (la.aepos + tsp >= fl_len && la.bbpos <= tsp);
+                if (proper) {
+                    ov[f] = &la;
+                    cnt[f]++;
                 }
             }
-            if (nL != 1 || nR != 1) {
+            if (cnt[0] != 1 || (nf == 2 && cnt[1] != 1)) {
                 rec.status = DH_PILE_FLANKS_NOT_UNIQUE;
                 continue;
             }
-            if ((L->flags & DH_FLAG_COMP) != (R->flags & DH_FLAG_COMP)) {
+            const dh_la *L = ov[0], *R = ov[1];
+            // insertionAlignment.isParallel == referenceRead.isParallel (package.d:757-773): seeds differ <=> complements equal
+            if (nf == 2 && ((L->flags & DH_FLAG_COMP) == (R->flags & DH_FLAG_COMP)) != (front[0] != front[1])) {
                 rec.status = DH_PILE_ORIENTATION;
                 continue;
             }
             rec.left_diffs = L->diffs;
-            rec.right_diffs = R->diffs;
+            rec.right_diffs = R ? R->diffs : 0;
             // ensureHighQualityConsensus, output.d:388-410
-            if ((int64_t)L->diffs * 1000000 > (int64_t)o.max_ins_err_ppm * (L->aepos - L->abpos) ||
-                (int64_t)R->diffs * 1000000 > (int64_t)o.max_ins_err_ppm * (R->aepos - R->abpos)) {
+            bool bad_q = false;
+            for (int32_t f = 0; f < nf; f++)
+                if ((int64_t)ov[f]->diffs * 1000000 > (int64_t)o.max_ins_err_ppm * (ov[f]->aepos - ov[f]->abpos)) bad_q = true;
+            if (bad_q) {
                 rec.status = DH_PILE_MAX_INSERTION_ERROR;
                 continue;
             }
-            for (const dh_la *fl : {L, R}) {  // kept for insertions.db (dh_insertions_write_db)
-                dh_la c = *fl;
-                if (fl == L) {
-                    c.abpos += foff[(size_t)a];
-                    c.aepos += foff[(size_t)a];
-                }
+            for (int32_t f = 0; f < nf; f++) {  // kept for insertions.db (dh_insertions_write_db)
+                dh_la c = *ov[f];
+                const int32_t shift = fbeg[(size_t)(fbase[(size_t)a] + f)];
+                c.abpos += shift;
+                c.aepos += shift;
                 c.toff = (int64_t)res->flank_tr.size();
-                res->flank_tr.insert(res->flank_tr.end(), fset->trace.begin() + fl->toff, fset->trace.begin() + fl->toff + fl->tlen);
-                if (fl == L) res->flank_of[(size_t)pile_of_active[(size_t)a]] = (int32_t)res->flank.size();
+                res->flank_tr.insert(res->flank_tr.end(), fset->trace.begin() + ov[f]->toff, fset->trace.begin() + ov[f]->toff + ov[f]->tlen);
+                if (f == 0) res->flank_of[(size_t)pile_of_active[(size_t)a]] = (int32_t)res->flank.size();
                 res->flank.push_back(c);
             }
             rec.comp = (L->flags & DH_FLAG_COMP) ? 1 : 0;
-            rec.left_aepos = foff[(size_t)a] + L->aepos;   // getCroppingPosition!"contigA", seed back
-            rec.right_abpos = R->abpos;                    //                                seed front
-            rec.ins_begin = L->bepos;                      // getCroppingPosition!"contigB"
-            rec.ins_end = R->bbpos;
+            // getCroppingPosition!"contigA" (insertions.d:110-121): front seed = begin of the overlap, back seed = its end
+            const int32_t sh0 = fbeg[(size_t)fbase[(size_t)a]];
+            rec.left_aepos = sh0 + (front[0] ? L->abpos : L->aepos);
+            // getCroppingPosition!"contigB" (:124-146) in the frame of the flank-0 overlap
+            const int32_t p0 = front[0] ? L->bbpos : L->bepos;
+            if (nf == 2) {
+                const int32_t sh1 = fbeg[(size_t)fbase[(size_t)a] + 1];
+                rec.right_abpos = sh1 + (front[1] ? R->abpos : R->aepos);
+                int32_t p1 = front[1] ? R->bbpos : R->bepos;
+                if ((R->flags & DH_FLAG_COMP) != (L->flags & DH_FLAG_COMP)) p1 = clen - p1;
+                // walking away from flank 0: past the end of a back-seeded overlap, before the begin of a front-seeded one
+                rec.ins_begin = front[0] ? p1 : p0;
+                rec.ins_end = front[0] ? p0 : p1;
+            } else {
+                rec.right_abpos = -1;
+                rec.ins_begin = front[0] ? 0 : p0;
+                rec.ins_end = front[0] ? p0 : clen;
+            }
             if (rec.ins_end < rec.ins_begin) rec.status = DH_PILE_NEGATIVE_INSERTION;
         }
     }
@@ -2294,6 +2463,7 @@ extern "C" int dh_shard_pack_candidates(const dh_pileups *cands, const dh_la *la
                                         uint8_t **out, int64_t *nbytes)
 {
     if (!cands || !out || !nbytes || (n > 0 && !las)) return dh_fail(DH_EINVAL, "dh_shard_pack_candidates: bad argument");
+    if (int rc = refuse_general(cands, "dh_shard_pack_candidates")) return rc;
     int64_t tot = 0;
     for (const auto &t : cands->triples) tot += (int64_t)t.size() / 3;
     CandRec *rec = (CandRec *)malloc(std::max<size_t>((size_t)tot * sizeof(CandRec), 1));
@@ -2479,7 +2649,7 @@ extern "C" int dh_shard_pack_cropped(dh_cropped *crop, const int32_t *owner, int
         const int32_t d = owner[crop->pile[i]];
         const int64_t len = crop->off[i + 1] - crop->off[i];
         // the entry's kind (0 spanning, 1 / 2 extension) rides in the top bits of `entry` (entries < 2^28)
-        const CropHead h{crop->pile[i], crop->entry[i] | ((int32_t)(i < crop->kind.size() ? crop->kind[i] : 0) << 28), crop->read_id[i], (int32_t)len};
+        const CropHead h{crop->pile[i], (int32_t)((uint32_t)crop->entry[i] | ((uint32_t)(i < crop->kind.size() ? crop->kind[i] : 0) << 28)), crop->read_id[i], (int32_t)len};
         memcpy(blobs[d] + hat[(size_t)d], &h, sizeof(h));
         hat[(size_t)d] += (int64_t)sizeof(h);
         memcpy(blobs[d] + bat[(size_t)d], bases + crop->off[i], (size_t)len);

@@ -807,6 +807,82 @@ extern "C" int dh_scaffold_gap_pileups(const dh_scaffold *s, const dh_la *las, i
     return dh_pileups_create(cl.data(), cnt.data(), (int32_t)cl.size(), tri.data(), out);
 }
 
+// Every pile-up of the scaffold the process stage can take (`dentist process` is handed all of them; `--only` of
+// `dentist output`, commandline.d:2230-2250, decides later which insertions are used): only & 1 = the gap joins of
+// any two contig ends -- same orientation, anti-parallel ((c, end) -> (d, end), (c, begin) -> (d, begin)), contig-
+// skipping --, only & 2 = the extension joins ((c, pre) -> (c, begin), (c, end) -> (c, post)).  Pile-ups come with
+// their nodes (dh_pileups_create_joins); entries are (read, LA on flank 0, LA on flank 1), extension-type read
+// alignments merged into a gap have one of the two.  A read alignment whose two complement flags do not fit the
+// join (parallel: equal, anti-parallel: different) is left out, as dh_scaffold_gap_pileups does.  *skipped = joins
+// without entries, joins of a contig with itself.
+extern "C" int dh_scaffold_all_pileups(const dh_scaffold *s, const dh_la *las, int64_t n, int32_t only, dh_pileups **out,
+                                       int32_t *skipped)
+{
+    if (!s || !out || (n > 0 && !las) || (only & ~3) || !only) return dh_fail(DH_EINVAL, "dh_scaffold_all_pileups: bad argument");
+    const int64_t nj = (int64_t)s->joins.size();
+    std::vector<std::vector<std::array<int32_t, 3>>> per((size_t)nj);
+    std::vector<std::array<int32_t, 4>> node((size_t)nj);
+    dh_parallel_for(nj, 16, [&](int64_t lo, int64_t hi) {
+        for (int64_t ji = lo; ji < hi; ji++) {
+            const dh_join &j = s->joins[(size_t)ji];
+            const bool gap = (j.part0 == BEGIN || j.part0 == END) && (j.part1 == BEGIN || j.part1 == END) && j.contig0 != j.contig1;
+            const bool fext = j.contig0 == j.contig1 && j.part0 == PRE && j.part1 == BEGIN;
+            const bool bext = j.contig0 == j.contig1 && j.part0 == END && j.part1 == POST;
+            if (!((gap && (only & 1)) || ((fext || bext) && (only & 2)))) continue;
+            const int32_t c0 = j.contig0, c1 = gap ? j.contig1 : -1;
+            const int32_t s0 = gap ? (j.part0 == BEGIN ? FRONT : BACK) : (fext ? FRONT : BACK), s1 = gap ? (j.part1 == BEGIN ? FRONT : BACK) : 0;
+            node[(size_t)ji] = {c0, s0 == FRONT ? DH_SEED_FRONT : DH_SEED_BACK, c1, gap && s1 == BACK ? DH_SEED_BACK : DH_SEED_FRONT};
+            std::vector<std::array<int32_t, 3>> &t = per[(size_t)ji];
+            t.reserve((size_t)j.count);
+            auto flank_of = [&](int32_t la, int32_t seed) {
+                if (las[la].aread == c0 && seed == s0) return 0;
+                if (gap && las[la].aread == c1 && seed == s1) return 1;
+                return -1;
+            };
+            for (int64_t x = j.first; x < j.first + j.count; x++) {
+                const dh_read_alignment &ra = s->entries[(size_t)x];
+                if (ra.la0 < 0 || ra.la0 >= n) continue;
+                const int f0 = flank_of(ra.la0, ra.seed0);
+                if (ra.n == 2) {
+                    if (ra.la1 < 0 || ra.la1 >= n) continue;
+                    const int f1 = flank_of(ra.la1, ra.seed1);
+                    if (f0 < 0 || f1 < 0 || f0 == f1) continue;
+                    const bool same = (las[ra.la0].flags & DH_FLAG_COMP) == (las[ra.la1].flags & DH_FLAG_COMP);
+                    if (same != (s0 != s1)) continue;
+                    t.push_back({ra.read, f0 == 0 ? ra.la0 : ra.la1, f0 == 0 ? ra.la1 : ra.la0});
+                } else if (f0 == 0)
+                    t.push_back({ra.read, ra.la0, -1});
+                else if (f0 == 1)
+                    t.push_back({ra.read, -1, ra.la0});
+            }
+            std::stable_sort(t.begin(), t.end(), [](const auto &a, const auto &b) { return a[0] < b[0]; });
+        }
+    });
+    // dh_pileups_create_joins wants the pile-ups in node order: (contig0, seed0, contig1 or "none" last, seed1)
+    std::vector<int64_t> order;
+    int32_t skip = 0;
+    for (int64_t ji = 0; ji < nj; ji++) {
+        if (per[(size_t)ji].empty()) {
+            skip++;
+            continue;
+        }
+        order.push_back(ji);
+    }
+    auto key = [&](int64_t ji) {
+        const auto &q = node[(size_t)ji];
+        return std::array<int64_t, 4>{q[0], q[1], q[2] < 0 ? INT32_MAX : q[2], q[3]};
+    };
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return key(a) < key(b); });
+    std::vector<int32_t> nd, cnt, tri;
+    for (int64_t ji : order) {
+        nd.insert(nd.end(), node[(size_t)ji].begin(), node[(size_t)ji].end());
+        cnt.push_back((int32_t)per[(size_t)ji].size());
+        for (const auto &x : per[(size_t)ji]) tri.insert(tri.end(), x.begin(), x.end());
+    }
+    if (skipped) *skipped = skip;
+    return dh_pileups_create_joins(nd.data(), cnt.data(), (int32_t)cnt.size(), tri.data(), out);
+}
+
 // dh_scaffold_pileups with resolveBubbles (pileups.d:1124-1315) between the raw scaffold and discardAmbiguousJoins, as
 // build() runs it (pileups.d:186).  The alignments the resolver adds are returned in *extra: LA index n + i of the
 // result's read alignments = record i of *extra (ids of the full DBs; traces for the cropper when the device maps).

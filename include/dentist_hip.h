@@ -263,6 +263,19 @@ int32_t dh_pileups_count(const dh_pileups *p);
 /* pile-up i: left contig id (gap lies between it and the next contig), number of reads, and the
  * (read, left LA index, right LA index) triples */
 int32_t dh_pileups_get(const dh_pileups *p, int32_t i, int32_t *contig_left, const int32_t **triples);
+/* Pile-ups of ANY join of the scaffold graph (ReadAlignment types of common/alignments/base.d:2160-2330; PileUp types
+ * :2725-2805; cropper.d:113-175 crops them all the same way): nodes4[4 * i ..] = (contig0, seed0, contig1, seed1) of
+ * pile-up i -- flank 0 = contig0 cropped at its seed0 side (DH_SEED_FRONT: the reads hang over the contig's begin,
+ * DH_SEED_BACK: over its end), flank 1 likewise; contig1 = -1: an extension pile-up (one flank).  The gap between
+ * contig c and c + 1 of dh_pileups_create is (c, DH_SEED_BACK, c + 1, DH_SEED_FRONT); (c, BACK, d, BACK) and
+ * (c, FRONT, d, FRONT) are anti-parallel joins, d > c + 1 skips contigs.  contig0 < contig1 (a contig joined with
+ * itself is refused), pile-ups ordered by their nodes, triples = (read, LA on flank 0 or -1, LA on flank 1 or -1).
+ * dh_pileups_get_join returns the four values of pile-up i (also for pile-ups made by the other creators). */
+#define DH_SEED_FRONT 0
+#define DH_SEED_BACK 1
+int dh_pileups_create_joins(const int32_t *nodes4, const int32_t *count, int32_t npiles, const int32_t *triples,
+                            dh_pileups **out);
+int dh_pileups_get_join(const dh_pileups *p, int32_t i, int32_t *nodes4);
 
 /* maskRepetitiveRegions (commands/maskRepetitiveRegions.d:129-176 assessRepeatStructure, :238-430
  * BadAlignmentCoverageAssessor): ORs into the soft mask of `db` every region whose coverage by the
@@ -388,6 +401,13 @@ int dh_scaffold_spanning(const dh_scaffold *s, const dh_la *las, int64_t n, dh_p
  * (cropper.d:339-361, 503-550); they are members of the pile-up but never its reference read
  * (processPileUps/package.d:461-472). */
 int dh_scaffold_gap_pileups(const dh_scaffold *s, const dh_la *las, int64_t n, dh_pileups **out, int32_t *skipped);
+/* Every pile-up of the scaffold `dentist process` is handed (collectPileUps/package.d:88-96 writes them all; which
+ * insertions are used is `dentist output`'s --only, commandline.d:2230-2250): only & 1 = the gap joins of any two
+ * contig ends (same orientation, anti-parallel, contig-skipping), only & 2 = the extension joins.  The pile-ups carry
+ * their nodes (dh_pileups_create_joins / dh_pileups_get_join); entries as in dh_scaffold_gap_pileups with flank 0 / 1
+ * in place of left / right.  *skipped = joins without entries. */
+int dh_scaffold_all_pileups(const dh_scaffold *s, const dh_la *las, int64_t n, int32_t only, dh_pileups **out,
+                            int32_t *skipped);
 
 /* the six alignment filters of `dentist collect` (collectPileUps/filter.d:122-356, order of
  * collectPileUps/package.d:130-141) on the read->contig LAs: LQ (averageErrorRate > max_align_err),
@@ -418,23 +438,33 @@ int64_t dh_pileups_flat(const dh_pileups *p, int32_t *contig_left, int32_t *coun
 #define DH_PILE_MAX_INSERTION_ERROR 6
 #define DH_PILE_NEGATIVE_INSERTION 7
 #define DH_PILE_ALIGN_OVERFLOW 8 /* a read of the pile-up exceeded a per-read capacity of the aligner */
+#define DH_PILE_UNSUPPORTED_JOIN 9 /* a contig joined with itself */
+/* dh_insertion.join: 0 = the gap between contig_left and contig_left + 1 in the same orientation
+ * ((contig_left, end) -> (contig_right, begin)); otherwise bits */
+#define DH_JOIN_FLANK0_FRONT 1 /* flank 0 is the BEGIN of contig_left (seed front) instead of its end     */
+#define DH_JOIN_FLANK1_BACK 2  /* flank 1 is the END of contig_right (seed back) instead of its begin     */
+#define DH_JOIN_EXTENSION 4    /* no flank 1: the consensus extends contig_left over the flank-0 side     */
 typedef struct {
-    int32_t contig_left;   /* gap between contig_left and contig_left + 1                          */
+    int32_t contig_left;   /* flank 0 (the `left` fields below); the contig with the smaller id                */
     int32_t status;        /* DH_PILE_*                                                             */
     int32_t nreads;        /* reads in the cropped pile-up                                          */
     int32_t ref_read;      /* index of the reference read inside the pile-up, -1 if none            */
     int32_t ref_read_id;   /* its read id in the reads DB                                           */
-    int32_t crop_left;     /* common trace point on the left contig                                 */
-    int32_t crop_right;    /* common trace point on the right contig                                */
-    int32_t left_aepos;    /* left contig is kept up to here  (insertions.d:110-118, seed back)    */
-    int32_t right_abpos;   /* right contig is kept from here (seed front)                           */
-    int32_t ins_begin;     /* insertion = oriented consensus [ins_begin, ins_end)                   */
-    int32_t ins_end;
-    int32_t comp;          /* 1: the consensus is reverse-complemented relative to the contigs      */
+    int32_t crop_left;     /* common trace point on the flank-0 contig                              */
+    int32_t crop_right;    /* common trace point on the flank-1 contig (-1 for an extension)        */
+    int32_t left_aepos;    /* getCroppingPosition!"contigA" of the flank-0 overlap (insertions.d:110-121): the
+                            * contig is kept up to here for seed back, from here for seed front       */
+    int32_t right_abpos;   /* the same for flank 1                                                  */
+    int32_t ins_begin;     /* insertion = oriented consensus [ins_begin, ins_end) (the slice of        */
+    int32_t ins_end;       /* getInfoForNewSequenceInsertion, insertions.d:230-284, in the frame of `comp`) */
+    int32_t comp;          /* 1: the flank-0 overlap is a complement one -- walking from flank 0 to flank 1 (a
+                            * front-seeded flank 0: from flank 1 to flank 0) the consensus is reverse-complemented */
     int32_t cons_len;
     int32_t left_diffs, right_diffs; /* of the two flank overlaps                                   */
-    int32_t pad;
+    int32_t join;          /* DH_JOIN_* bits, 0 for the plain gap                                   */
     int64_t cons_off;      /* consensus bases (read orientation) in the result's sequence buffer    */
+    int32_t contig_right;  /* flank 1: its contig (contig_left + 1 for the plain gap, -1 for an extension) */
+    int32_t pad;
 } dh_insertion;
 
 typedef struct dh_insertions dh_insertions;
@@ -467,6 +497,15 @@ typedef struct dh_cropped dh_cropped;
 int dh_crop_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_t read_first, const dh_la *las, int64_t n,
                     const uint16_t *trace, const dh_pileups *piles, const dh_process_opts *opts,
                     dh_cropped **out);
+/* the same with the repeat mask of the contigs (`dentist process --mask`): rep_ptr[ncontigs + 1] / rep_iv = sorted
+ * disjoint (begin, end) pairs per contig, as dh_map_reads takes them; the common trace point of a flank is taken
+ * outside the mask when one exists there (cropper.d:446-500).  NULL = no mask. */
+int dh_crop_pileups_masked(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_t read_first, const dh_la *las, int64_t n,
+                           const uint16_t *trace, const dh_pileups *piles, const int64_t *rep_ptr, const int32_t *rep_iv,
+                           const dh_process_opts *opts, dh_cropped **out);
+int dh_process_pileups_masked(dh_ctx *ctx, dh_db *contigs, dh_db *reads, const dh_la *las, int64_t n,
+                              const uint16_t *trace, const dh_pileups *piles, const int64_t *rep_ptr, const int32_t *rep_iv,
+                              const dh_process_opts *opts, dh_insertions **out);
 int dh_cropped_create(const dh_insertion *rec, int32_t npiles, int32_t nreads, const int32_t *pile,
                       const int32_t *entry, const int32_t *read_id, const int64_t *off, const uint8_t *bases,
                       dh_cropped **out);
@@ -476,8 +515,10 @@ int dh_cropped_create2(const dh_insertion *rec, int32_t npiles, int32_t nreads, 
                        const uint8_t *bases, dh_cropped **out);
 void dh_cropped_destroy(dh_cropped *c);
 int32_t dh_cropped_npiles(const dh_cropped *c);
-/* per cropped read: 0 = it spans the gap, 1 = back extension of the left contig, 2 = front extension of the
- * right contig (entries with one alignment, see dh_scaffold_gap_pileups) */
+/* per cropped read, bits 0-1: 0 = it has alignments on both flanks (spans the gap), 1 = on flank 0 only (plain gap: back
+ * extension of the left contig), 2 = on flank 1 only (front extension of the right contig) -- entries with one
+ * alignment, see dh_scaffold_gap_pileups; bit 2 / 3: its alignment on flank 0 / 1 is a complement one (the flank
+ * overlaps of the consensus are checked against the reference read's, package.d:669-690) */
 const uint8_t *dh_cropped_kind(const dh_cropped *c);
 
 /* ---- the host work of one rank between the collectives of the sharded path (one process per GPU): what LAmerge +
@@ -594,18 +635,30 @@ int dh_output_fasta(const char *fasta_path, const char *bed_path, const uint8_t 
                     const char *const *headers, const int32_t *gap_len, const dh_insertion *ins,
                     int32_t nins, const uint8_t *ins_bases, int32_t line_width, int32_t highlight);
 /* `dentist output` with its graph step and all three writers (output.d:305-348 buildAssemblyGraph with
- * enforceJoinPolicy common/scaffold.d:642-715, fixCropping :931-1003; FASTA :782-925; AGP :454-573; BED
- * :879-891 with every read id of the pile-up).  join_policy: 0 scaffoldGaps (insertions between input
- * scaffolds are dropped, *dropped counts them), 1 scaffolds, 2 contigs (they join the two scaffolds into one
- * record).  agp_dazzler: component ids are contig numbers / "reads-<ids>"; otherwise scaffold header ids and
+ * enforceJoinPolicy common/scaffold.d:642-723, normalizeUnkownJoins :373-451, fixCropping :931-1003; scaffoldStarts +
+ * linearWalk scaffold.d:1021-1295; FASTA :782-925; AGP :454-573; BED :879-891 with every read id of the pile-up) for
+ * insertions of any join (dh_insertion.join: gaps between any two contig ends, extensions).  join_policy: 0
+ * scaffoldGaps (gap joins that do not sit on a gap of an input scaffold are dropped, *dropped counts them), 1 scaffolds
+ * (they come back where both contig ends are still free), 2 contigs (all stay).  agp_dazzler: component ids are contig numbers / "reads-<ids>"; otherwise scaffold header ids and
  * read_names[id - 1]; agp_skip_read_ids: "<n> reads".  read_ids / read_ids_off[nins + 1]: 0-based read ids of
  * every insertion's pile-up, offsets int32 exactly as dh_insertions_read_ids_off returns them (NULL: the reference read
  * alone); nreads = length of read_names, every id is checked against it (-1: unknown, only without a name table). */
 typedef struct {
-    int32_t line_width, highlight, join_policy, agp_dazzler, agp_skip_read_ids, pad;
+    int32_t line_width, highlight, join_policy, agp_dazzler, agp_skip_read_ids;
+    int32_t only;                 /* --only (commandline.d:2230-2250): 1 spanning (default; 0 means the same), 2 extending, 3 both */
     const char *agp_version, *tool, *input_assembly;
+    int32_t min_extension_length; /* --min-extension-length (commandline.d:2098-2100, default 100): shorter extensions are skipped */
+    int32_t pad;
 } dh_output_opts;
 void dh_default_output_opts(dh_output_opts *o);
+/* Test surface of the writer's graph code (normalizeUnkownJoins common/scaffold.d:373-451, linearWalk :1021-1170,
+ * scaffoldStarts :1209-1295 -- the reference's unit vectors run against it): the default edges of `ncontigs` contigs plus
+ * joins4 = (contig0, part0, contig1, part1) per join, parts 0 pre, 1 begin, 2 end, 3 post, contigs 0-based; normalize != 0
+ * runs normalizeUnkownJoins.  Out (each optional, `cap` entries each): the edges, the scaffold starts as (contig, part), and
+ * the linear walk from walk_start2 (through the join walk_first4 when not NULL) as node pairs in walking direction. */
+int dh_scaffold_graph_probe(int32_t ncontigs, const int32_t *joins4, int32_t njoins, int32_t normalize, int32_t *edges4,
+                            int32_t *nedges, int32_t *starts2, int32_t *nstarts, const int32_t *walk_start2,
+                            const int32_t *walk_first4, int32_t *walk4, int32_t *walk_len, int32_t *cyclic, int32_t cap);
 int dh_output_assembly(const char *fasta_path, const char *bed_path, const char *agp_path,
                        const uint8_t *contig_bases, const int64_t *contig_off, int32_t ncontigs,
                        const int32_t *scaffold_of, const char *const *headers, const int32_t *gap_len,

@@ -150,49 +150,73 @@ def translate_floor(la, tr, apos, ts):
     return a.value, b.value
 
 
-def crop_pile(entries, las, trace, contigs, reads, g, ts_map=100):
-    """cropPileUp: returns (cropL, cropR, SeqDb of cropped reads in read orientation, read ids, kinds).
-    An entry is (read, left LA, right LA); an extension-type read alignment merged into the gap
-    (scaffold.d:789-816) has None / -1 in place of the alignment it lacks: it is cut from its crop point to
-    the end of the read (getCroppingSlice per alignment, cropper.d:339-348, 503-550) and gets the support
-    patch of its own contig only (getReadPatches, cropper.d:351-361).  kind: 0 spans, 1 left only, 2 right only."""
+FRONT, BACK = 0, 1   # AlignmentLocationSeed
+
+
+def join_of(g):
+    """A pile-up's join as (contig0, seed0, contig1, seed1): an int g is the gap between contig g and g + 1 in the
+    same orientation, (g, BACK, g + 1, FRONT); contig1 = -1 is an extension pile-up (one flank)."""
+    return (int(g), BACK, int(g) + 1, FRONT) if not isinstance(g, (tuple, list)) else tuple(int(x) for x in g)
+
+
+def crop_pile(entries, las, trace, contigs, reads, g, ts_map=100, mask=None):
+    """cropPileUp (cropper.d:113-175) for any join: returns (crop0, crop1, SeqDb of cropped reads in read orientation,
+    read ids, kinds).  An entry is (read, LA on flank 0, LA on flank 1); an extension-type read alignment merged into
+    a gap (scaffold.d:789-816) has None / -1 in place of the alignment it lacks.  Per alignment getCroppingSlice
+    (cropper.d:339-348, 503-550): a back-seeded one keeps [crop point, end), a front-seeded one [0, crop point) of the
+    read as the alignment sees it, mirrored for a complement alignment; the slices of an entry are intersected.
+    Support patches per alignment (getSingleReadPatch / getReadPatches, cropper.d:351-378): to the read's front when
+    (contig seed == front) == complement, else to its back.  kind: 0 both flanks, 1 flank 0 only, 2 flank 1 only,
+    | 4 / 8: the alignment on flank 0 / 1 is a complement one.  mask: {contig: [(begin, end), ...]} repeat mask."""
     has = lambda i: i is not None and i >= 0   # noqa: E731
-    left = [las[iL] for _, iL, _ in entries if has(iL)]
-    right = [las[iR] for _, _, iR in entries if has(iR)]
-    cropL = common_trace_point([region_of(las, iL) for _, iL, _ in entries if has(iL)], contigs.length(g), ts_map, False)
-    cropR = common_trace_point([region_of(las, iR) for _, _, iR in entries if has(iR)], contigs.length(g + 1), ts_map, True)
-    if cropL < 0 or cropR < 0:
+    c0, s0, c1, s1 = join_of(g)
+    flanks = [(c0, s0)] + ([(c1, s1)] if c1 >= 0 else [])
+    crops = []
+    for f, (c, sd) in enumerate(flanks):
+        regs = [region_of(las, e[1 + f]) for e in entries if has(e[1 + f])]
+        crops.append(common_trace_point(regs, contigs.length(c), ts_map, sd == FRONT, mask=(mask or {}).get(c)) if regs else -1)
+    if any(c < 0 for c in crops):
         return None
     # fetchSupportPatches (cropper.d:224-262): if less than minAnchorLength of a flank remains after
     # cropping, the missing piece of the contig is glued to every cropped read
-    cl, cr = contigs.seq(g), contigs.seq(g + 1)
-    left_patch = cl[max(0, len(cl) - MIN_ANCHOR):cropL] if len(cl) - cropL < MIN_ANCHOR else cl[0:0]
-    right_patch = cr[cropR:MIN_ANCHOR] if cropR < MIN_ANCHOR else cr[0:0]
-    seqs, ids, kinds = [], [], []
-    for (r, iL, iR) in entries:
-        rl = reads.length(r)
-        bL, bR = 0, rl
-        # AlignmentChain.translateTracePoint (base.d:866-880): the FIRST member that covers the position translates it
-        if has(iL):
-            L = las[next(x for x in chain_members(las, iL) if las[x]["abpos"] <= cropL <= las[x]["aepos"])]
-            _, bL = translate_floor(L, trace[L["toff"]:L["toff"] + L["tlen"]], cropL, ts_map)
-        if has(iR):
-            R = las[next(x for x in chain_members(las, iR) if las[x]["abpos"] <= cropR <= las[x]["aepos"])]
-            _, bR = translate_floor(R, trace[R["toff"]:R["toff"] + R["tlen"]], cropR, ts_map)
-        lp = left_patch if has(iL) else left_patch[0:0]
-        rp = right_patch if has(iR) else right_patch[0:0]
-        if las[iL if has(iL) else iR]["flags"] & 1:   # getCroppingSlice: complement -> swap and mirror (cropper.d:533-538)
-            b0, b1 = rl - bR, rl - bL
-            pre, post = revcomp(rp), revcomp(lp)   # getSingleReadPatch, cropper.d:363-378
+    patches = []
+    for (c, sd), pos in zip(flanks, crops):
+        cs = contigs.seq(c)
+        if sd == FRONT:
+            patches.append(cs[pos:MIN_ANCHOR] if pos < MIN_ANCHOR else cs[0:0])
         else:
-            b0, b1 = bL, bR
-            pre, post = lp, rp
+            patches.append(cs[max(0, len(cs) - MIN_ANCHOR):pos] if len(cs) - pos < MIN_ANCHOR else cs[0:0])
+    seqs, ids, kinds = [], [], []
+    for e in entries:
+        r = e[0]
+        rl = reads.length(r)
+        b0, b1 = 0, rl
+        pre, post = patches[0][0:0], patches[0][0:0]
+        kind = 0 if has(e[1]) and has(e[2]) else (1 if has(e[1]) else 2)
+        for f, ((c, sd), pos) in enumerate(zip(flanks, crops)):
+            i = e[1 + f]
+            if not has(i):
+                continue
+            # AlignmentChain.translateTracePoint (base.d:866-880): the FIRST member that covers the position translates it
+            M = las[next(x for x in chain_members(las, i) if las[x]["abpos"] <= pos <= las[x]["aepos"])]
+            _, b = translate_floor(M, trace[M["toff"]:M["toff"] + M["tlen"]], pos, ts_map)
+            lo, hi = (0, b) if sd == FRONT else (b, rl)
+            comp = bool(las[i]["flags"] & 1)
+            if comp:   # complement -> swap and mirror (cropper.d:533-538)
+                lo, hi = rl - hi, rl - lo
+                kind |= 4 << f
+            b0, b1 = max(b0, lo), min(b1, hi)
+            patch = revcomp(patches[f]) if comp else patches[f]
+            if (sd == FRONT) == comp:
+                pre = patch
+            else:
+                post = patch
         if b1 - b0 < 14:
             continue
         seqs.append(np.concatenate([pre, reads.seq(r)[b0:b1], post]).astype(np.uint8))
         ids.append(r)
-        kinds.append(0 if has(iL) and has(iR) else (1 if has(iL) else 2))
-    return cropL, cropR, SeqDb.from_list(seqs), ids, kinds
+        kinds.append(kind)
+    return crops[0], (crops[1] if len(crops) > 1 else -1), SeqDb.from_list(seqs), ids, kinds
 
 
 def stage_width(algo):
@@ -301,10 +325,16 @@ def chain_pile_las(las, max_indel=1000, max_gap=10000, max_rel_overlap=0.3, min_
     return las
 
 
-def process_pile(entries, las, trace, contigs, reads, g, rounds=3, nthreads=1, flank_window=20000, dust=True, algo=0):
-    """One pile-up through the `process` sequence; returns a dict describing the insertion."""
+def process_pile(entries, las, trace, contigs, reads, g, rounds=3, nthreads=1, flank_window=20000, dust=True, algo=0, mask=None):
+    """One pile-up through the `process` sequence; returns a dict describing the insertion.  g: the left contig of a
+    plain gap, or any join (contig0, seed0, contig1, seed1) -- see join_of."""
     res = {"gap": g, "status": "ok", "nreads": len(entries)}
-    crop = crop_pile(entries, las, trace, contigs, reads, g)
+    c0, s0, c1, s1 = join_of(g)
+    flanks = [(c0, s0)] + ([(c1, s1)] if c1 >= 0 else [])
+    if c1 == c0:
+        res["status"] = "unsupported join"
+        return res
+    crop = crop_pile(entries, las, trace, contigs, reads, g, mask=mask)
     if crop is None:
         res["status"] = "no common trace point"
         return res
@@ -323,7 +353,8 @@ def process_pile(entries, las, trace, contigs, reads, g, rounds=3, nthreads=1, f
     rlen = np.asarray([pile.length(i) for i in range(pile.n)], dtype=np.int32)
     # allowed reference reads = the reads that span the gap (selectAllowedReferenceReadIds, package.d:461-472);
     # coverage = max(their number, 4 if pile >= 4) (package.d:498-503)
-    allowed = np.asarray([1 if k == 0 else 0 for k in kinds], dtype=np.uint8)
+    # (an extension pile-up has one flank: every read has its alignment there)
+    allowed = np.asarray([1 if (k & 3) == (0 if c1 >= 0 else 1) else 0 for k in kinds], dtype=np.uint8)
     cov = int(allowed.sum())
     if cov < 4 and pile.n >= 4:
         cov = 4
@@ -350,34 +381,61 @@ def process_pile(entries, las, trace, contigs, reads, g, rounds=3, nthreads=1, f
                 la["flags"] |= 0x20
         cons = oz.consensus(cons, pile, rl, rt, 0, TS_PILE)
     res["consensus"] = cons
-    # flank re-alignment: daligner -A -s126 -l126 contigs consensus (commandline.d:2918-2935)
-    cl, cr = contigs.seq(g), contigs.seq(g + 1)
-    fw = flank_window if flank_window > 0 else max(len(cl), len(cr))   # 0 = the whole contigs (commandline.d:2918-2935)
-    wl = max(0, len(cl) - fw) // TS_PILE * TS_PILE   # on the contig's trace grid
-    fl, fr = cl[wl:], cr[:fw]
-    fdb = SeqDb.from_list([fl, fr])
+    # flank re-alignment: daligner -A -s126 -l126 contigs consensus (commandline.d:2918-2935); one slice per flank:
+    # the contig's tail for a back-seeded flank (starting on the contig's trace grid), its head for a front-seeded one
+    fw = flank_window if flank_window > 0 else max(contigs.length(c) for c, _ in flanks)   # 0 = the whole contigs
+    offs, slices = [], []
+    for c, sd in flanks:
+        cs = contigs.seq(c)
+        wl = 0 if sd == FRONT else max(0, len(cs) - fw) // TS_PILE * TS_PILE
+        offs.append(wl)
+        slices.append(cs[:fw] if sd == FRONT else cs[wl:])
+    fdb = SeqDb.from_list(slices)
     if dust:   # DBdust contigs.dam; daligner -A ... -mdust -mrep (package.d:631-667)
         fdb = oz.with_dust(fdb)
     o3 = oz.default_opts(tspace=TS_PILE, min_len=126, max_la=4, max_cand=32, width=stage_width(algo), algo=algo)
     fl_las, fl_tr, _ = oz.align_db(fdb, SeqDb.from_list([cons]), o3, nthreads=nthreads)
-    res.update(flank_las=fl_las, flank_trace=fl_tr, flank_off=wl)
+    res.update(flank_las=fl_las, flank_trace=fl_tr, flank_off=offs[0], flank_offs=offs)
     allow = TS_PILE
-    L = [la for la in fl_las if la["aread"] == 0 and la["aepos"] + allow >= len(fl) and la["bbpos"] <= allow]
-    R = [la for la in fl_las if la["aread"] == 1 and la["abpos"] <= allow and la["bepos"] + allow >= len(cons)]
-    if len(L) != 1 or len(R) != 1:
-        res["status"] = f"consensus does not align uniquely to the flanks ({len(L)},{len(R)})"
+    refk = kinds[ref_idx] >> 2   # complement flags of the reference read's alignments: the consensus has its orientation
+    ov = []
+    for f, (c, sd) in enumerate(flanks):
+        # an overlap whose complement flag differs from the reference read's on that contig is disabled
+        # (package.d:669-690); exactly one proper insertion overlap per flank (:707-745)
+        cand = [la for la in fl_las if la["aread"] == f and bool(la["flags"] & 1) == bool((refk >> f) & 1)]
+        if sd == FRONT:
+            cand = [la for la in cand if la["abpos"] <= allow and la["bepos"] + allow >= len(cons)]
+        else:
+            cand = [la for la in cand if la["aepos"] + allow >= len(slices[f]) and la["bbpos"] <= allow]
+        ov.append(cand)
+    if any(len(x) != 1 for x in ov):
+        res["status"] = "consensus does not align uniquely to the flanks (%s)" % ",".join(str(len(x)) for x in ov)
         return res
-    L, R = L[0], R[0]
-    if (L["flags"] & 1) != (R["flags"] & 1):
+    ov = [x[0] for x in ov]
+    L = ov[0]
+    if len(ov) == 2 and ((L["flags"] & 1) == (ov[1]["flags"] & 1)) != (s0 != s1):   # isParallel as the reference read (package.d:757-773)
         res["status"] = "flank orientation mismatch"
         return res
-    for la in (L, R):
+    for la in ov:
         if int(la["diffs"]) * 1000000 > MAX_INS_ERR_PPM * int(la["aepos"] - la["abpos"]):   # ensureHighQualityConsensus output.d:388-410
             res["status"] = "maxInsertionError"
             return res
     cseq = revcomp(cons) if (L["flags"] & 1) else cons
-    b0, b1 = int(L["bepos"]), int(R["bbpos"])
-    res.update(left_aepos=wl + int(L["aepos"]), right_abpos=int(R["abpos"]), ins_begin=b0, ins_end=b1)
+    # getCroppingPosition (insertions.d:110-146): contigA -- front seed: begin of the overlap, back seed: its end;
+    # contigB likewise, here in the frame of the flank-0 overlap
+    res["left_aepos"] = offs[0] + int(L["abpos"] if s0 == FRONT else L["aepos"])
+    p0 = int(L["bbpos"] if s0 == FRONT else L["bepos"])
+    if len(ov) == 2:
+        R = ov[1]
+        res["right_abpos"] = offs[1] + int(R["abpos"] if s1 == FRONT else R["aepos"])
+        p1 = int(R["bbpos"] if s1 == FRONT else R["bepos"])
+        if (R["flags"] & 1) != (L["flags"] & 1):
+            p1 = len(cons) - p1
+        b0, b1 = (p1, p0) if s0 == FRONT else (p0, p1)
+    else:
+        res["right_abpos"] = -1
+        b0, b1 = (0, p0) if s0 == FRONT else (p0, len(cons))
+    res.update(ins_begin=b0, ins_end=b1, comp=int(L["flags"] & 1))
     if b1 < b0:
         res["status"] = "negative insertion"
         return res

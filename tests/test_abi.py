@@ -87,8 +87,8 @@ def test_output_fasta_writer_unclosed_gaps_and_wrapping(tmp_path):
     cons = rng.integers(0, 4, 30).astype(np.uint8)
     rec = np.zeros(2, dtype=INSERTION_DTYPE)
     # gap 0|1 closed with the reverse complement of cons[5:25]; gap 1|2 skipped (status != 0)
-    rec[0] = (0, 0, 5, 0, 7, 0, 0, 110, 4, 5, 25, 1, 30, 0, 0, 0, 0)
-    rec[1] = (1, 4, 5, -1, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+    rec[0] = (0, 0, 5, 0, 7, 0, 0, 110, 4, 5, 25, 1, 30, 0, 0, 0, 0, 1, 0)
+    rec[1] = (1, 4, 5, -1, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 0)
     path = str(tmp_path / "o.fasta")
     dentist_amd.output_fasta(path, contigs, [0, 0, 0, 1], ["chrA\tfoo", "chrB"], [33, 17, 0], rec, cons)
     txt = open(path).read().split(">")[1:]
