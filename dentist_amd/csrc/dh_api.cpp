@@ -793,12 +793,25 @@ static int build_index(dh_db *A, int32_t k, int32_t sepv, int32_t kmer_mod, bool
     } else
         dhk_kmer_pass(ctx->stream, 0, av, d_tiles, (int32_t)tiles.size(), k, kmer_mod, ix.shift, ix.d_dir, ix.d_ent,
                       ix.d_goff);
-    dhk_scan(ctx->stream, ix.d_dir, nb + 1, d_sums);
+    // (the k-mers actually indexed are known only now -- modimer sampling is not even on repetitive sequence --: the scan
+    // also sums them in 64 bits, a total that does not fit the 32-bit bucket offsets is an error, never a wrapped directory)
+    unsigned long long *d_total = nullptr;
+    struct TotGuard {
+        unsigned long long *&p;
+        ~TotGuard() { dh_dev_free(p); }
+    } totg{d_total};
+    HIPCHK(dh_dev_alloc(&d_total, sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(d_total, 0, sizeof(unsigned long long), ctx->stream));
+    dhk_scan_total(ctx->stream, ix.d_dir, nb + 1, d_sums, d_total);
     // the entry array is sized by the k-mers that were actually indexed (sampled, unmasked): the
     // exclusive scan leaves their number in dir[nb]
     uint32_t nent = 0;
+    unsigned long long total = 0;
     HIPCHK(hipMemcpyAsync(&nent, ix.d_dir + nb, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&total, d_total, sizeof(total), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (total != (unsigned long long)nent || total >= (1ull << 32) - 16)
+        return fail(DH_EOVERFLOW, "index: more than 2^32 indexed k-mers (32-bit bucket offsets); raise kmer_mod");
     ix.n = (int64_t)nent;
     HIPCHK(dh_dev_alloc(&ix.d_ent, sizeof(ulonglong2) * (size_t)std::max<int64_t>(ix.n, 1)));
     if (gi_slices > 0)

@@ -78,6 +78,7 @@ void dhk_group_index(hipStream_t st, int fill, DbView A, const int2 *tiles, cons
                      int32_t slices_per_group, int32_t slice, int32_t k, int32_t kmer_mod, int32_t shift, uint32_t *dir,
                      ulonglong2 *ent, const int64_t *goff);
 void dhk_scan(hipStream_t st, uint32_t *v, int64_t n, uint32_t *sums);
+void dhk_scan_total(hipStream_t st, uint32_t *v, int64_t n, uint32_t *sums, unsigned long long *total64);
 void dhk_seed_summary(hipStream_t st, const int32_t *ncand, const int32_t *nhits, int32_t n, unsigned long long *out4);
 // dir[b] = end of bucket b (dir[-1] == 0) -> the fat directory
 void dhk_fat_dir(hipStream_t st, const uint32_t *dir, const ulonglong2 *ent, int64_t nb, ulonglong2 *fat);

@@ -322,14 +322,20 @@ __global__ void __launch_bounds__(256) k_scan_sums(const uint32_t *__restrict__ 
     if (threadIdx.x == 0) sums[blockIdx.x] = red[0];
 }
 
-__global__ void __launch_bounds__(1024) k_scan_top(uint32_t *__restrict__ sums, int32_t nb)
+// total64 (optional): the sum of all elements in 64 bits -- the caller's check that the 32-bit prefix sums did not wrap
+__global__ void __launch_bounds__(1024) k_scan_top(uint32_t *__restrict__ sums, int32_t nb, unsigned long long *__restrict__ total64)
 {
     // single block: serial chunks per thread then a block scan of the 1024 partials
     __shared__ uint32_t part[1024];
     const int32_t per = (nb + 1023) / 1024;
     const int32_t lo = threadIdx.x * per, hi = min(nb, lo + per);
     uint32_t acc = 0;
-    for (int32_t i = lo; i < hi; i++) acc += sums[i];
+    unsigned long long acc64 = 0;
+    for (int32_t i = lo; i < hi; i++) {
+        acc += sums[i];
+        acc64 += sums[i];
+    }
+    if (total64 && acc64) atomicAdd(total64, acc64);
     part[threadIdx.x] = acc;
     __syncthreads();
     // Hillis-Steele inclusive scan
@@ -2664,7 +2670,17 @@ void dhk_scan(hipStream_t st, uint32_t *v, int64_t n, uint32_t *sums)
 {
     const int32_t nb = (int32_t)((n + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
     hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(256), 0, st, v, n, sums);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, sums, nb);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, sums, nb, (unsigned long long *)nullptr);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, v, n, sums);
+}
+
+// the same, adding the 64-bit total of the elements to *total64 (zeroed by the caller): a block's sum of SCAN_PER_BLOCK
+// counters fits 32 bits as long as the counters themselves did not wrap, so the total tells whether the prefix sums did
+void dhk_scan_total(hipStream_t st, uint32_t *v, int64_t n, uint32_t *sums, unsigned long long *total64)
+{
+    const int32_t nb = (int32_t)((n + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
+    hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(256), 0, st, v, n, sums);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, sums, nb, total64);
     hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, v, n, sums);
 }
 

@@ -1228,6 +1228,8 @@ struct dh_cropped {
     std::vector<uint8_t, PinnedAlloc<uint8_t>> bases;
     bool host_valid = false;
     bool comp_known = true;  // false: made without kinds (dh_cropped_create): the complement bits are not there
+    int32_t batch_most = 0;  // largest pile-up of the batch this crop is a part of (dh_process_pileups splits a batch): the
+                             // record slots of the pile-up alignment are sized by it, so that the split does not show
     dh_db *dev = nullptr;
     float ms_crop = 0;
 };
@@ -1584,9 +1586,12 @@ extern "C" int dh_process_pileups_masked(dh_ctx *ctx, dh_db *contigs, dh_db *rea
 {
     if (!ctx || !contigs || !reads || !piles || !opts || !out || (n > 0 && (!las || !trace)))
         return dh_fail(DH_EINVAL, "dh_process_pileups: NULL argument");
+    int32_t batch_most = 0;
+    for (const auto &t : piles->triples) batch_most = std::max(batch_most, (int32_t)(t.size() / 3));
     auto one = [&](dh_ctx *cx, const dh_pileups *pl, dh_insertions **res) -> int {
         dh_cropped *c = nullptr;
         if (int rc = dh_crop_pileups_masked(cx, contigs, reads, 0, las, n, trace, pl, rep_ptr, rep_iv, opts, &c)) return rc;
+        c->batch_most = batch_most;
         const int rc = dh_process_cropped(cx, contigs, c, opts, res);
         dh_cropped_destroy(c);
         return rc;
@@ -1638,8 +1643,13 @@ extern "C" int dh_process_pileups_masked(dh_ctx *ctx, dh_db *contigs, dh_db *rea
     std::vector<std::thread> workers;
     for (int32_t k = 1; k < nparts; k++)
         workers.emplace_back([&, k] {
-            rcs[(size_t)k] = one(ctx->sub[k - 1], &part[(size_t)k], &res[(size_t)k]);
-            if (rcs[(size_t)k]) msgs[(size_t)k] = dh_last_error();
+            try {
+                rcs[(size_t)k] = one(ctx->sub[k - 1], &part[(size_t)k], &res[(size_t)k]);
+                if (rcs[(size_t)k]) msgs[(size_t)k] = dh_last_error();
+            } catch (const std::exception &e) {  // (an exception leaving a thread would end the process)
+                rcs[(size_t)k] = DH_EINVAL;
+                msgs[(size_t)k] = std::string("dh_process_pileups: a concurrent part of the batch failed: ") + e.what();
+            }
             sts[(size_t)k] = g_pstats;
         });
     rcs[0] = one(ctx, &part[0], &res[0]);
@@ -1861,7 +1871,7 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
         ao.skip_self = 2;  // every unordered pair aligned once, both records emitted (as daligner does)
         // record slots per (read, strand): a read overlaps at most every other read of its pile-up
         {
-            int32_t most = 0;
+            int32_t most = std::min(crop->batch_most, 252);
             for (int32_t a = 0; a < na; a++) most = std::max(most, first_read[(size_t)a + 1] - first_read[(size_t)a]);
             if (most > 252)
                 return dh_fail(DH_EOVERFLOW, "process: a pile-up with more than 252 reads (set max_reads)");
