@@ -1149,7 +1149,11 @@ static int chunk_copies(dh_ctx *ctx, dh_db *B, int32_t r0, int32_t r1, bool want
     if (int rc = dh_scratch(ctx, 28, pbytes, (void **)&d_rcpk)) return rc;
     if (int rc = dh_scratch(ctx, 3, 4 * sizeof(int32_t), (void **)&d_flag)) return rc;
     HIPCHK(hipMemsetAsync(d_flag + 1, 0, 2 * sizeof(int32_t), st));
-    HIPCHK(dhk_memset(st, d_rcpk, 0, pbytes));
+    // k_pack2_rc stores the words inside a read whole and ORs into the words reads share: only those (and the padding on
+    // both sides) are zeroed -- the memset of the whole buffer was 2 GB per chunk of the mapping
+    HIPCHK(hipMemsetAsync(d_rcpk, 0, PK_PAD + 8, st));
+    HIPCHK(hipMemsetAsync(d_rcpk + pbytes - PK_PAD - 8, 0, PK_PAD + 8, st));
+    dhk_pack2_rc_bounds(st, B->d_off + r0, r1 - r0, a0, d_rcpk + PK_PAD);
     dhk_pack2(st, B->d_bases + a0, o1 - a0, d_pk + PK_PAD, d_flag + 1);
     dhk_pack2_rc(st, B->d_bases, B->d_off + r0, r1 - r0, B->max_len, a0, d_rcpk + PK_PAD);
     HIPCHK(hipGetLastError());

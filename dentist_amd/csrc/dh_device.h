@@ -114,6 +114,7 @@ void dhk_cov_mask(hipStream_t st, const uint32_t *cov, const int64_t *off, int32
                   int32_t upper, uint32_t *bits);
 void dhk_pack2_rc(hipStream_t st, const uint8_t *src, const int64_t *off, int32_t n, int32_t max_len, int64_t a0,
                   uint8_t *dst);
+void dhk_pack2_rc_bounds(hipStream_t st, const int64_t *off, int32_t n, int64_t a0, uint8_t *dst);
 void dhk_mask_slices(hipStream_t st, const uint32_t *src_bits, const int64_t *src_off, const int32_t *sidx,
                      const int32_t *sbeg, const int64_t *dst_off, int32_t n, int32_t max_len, uint32_t *dst_bits);
 void dhk_compact(hipStream_t st, const DhLa *la_slots, const uint16_t *tr_slots, int32_t trmax,

@@ -2841,6 +2841,27 @@ void dhk_pack2(hipStream_t st, const uint8_t *src, int64_t total, uint8_t *dst, 
                        flag);
 }
 
+// zeroes the (at most two) destination words every sequence shares with its neighbours: what k_pack2_rc ORs into.
+// Interior words are stored whole, so the rest of the buffer needs no memset (2 GB per chunk of the mapping).
+__global__ void __launch_bounds__(256)
+k_pack2_rc_bounds(const int64_t *__restrict__ off, int32_t n, int64_t a0, uint32_t *__restrict__ dst)
+{
+    const int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int64_t o = off[s], len = off[s + 1] - o;
+    if (len <= 0) return;
+    const int64_t w0 = (o - a0) >> 4, w1 = (o + len - 1 - a0) >> 4;
+    const int64_t g0 = a0 + (w0 << 4), g1 = a0 + (w1 << 4);
+    if (!(g0 >= o && g0 + 16 <= o + len)) dst[w0] = 0;
+    if (!(g1 >= o && g1 + 16 <= o + len)) dst[w1] = 0;
+}
+
+void dhk_pack2_rc_bounds(hipStream_t st, const int64_t *off, int32_t n, int64_t a0, uint8_t *dst)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_pack2_rc_bounds, dim3((n + 255) / 256), dim3(256), 0, st, off, n, a0, (uint32_t *)dst);
+}
+
 void dhk_pack2_rc(hipStream_t st, const uint8_t *src, const int64_t *off, int32_t n, int32_t max_len, int64_t a0,
                   uint8_t *dst)
 {

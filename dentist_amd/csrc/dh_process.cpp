@@ -1602,7 +1602,9 @@ extern "C" int dh_process_pileups_masked(dh_ctx *ctx, dh_db *contigs, dh_db *rea
     // kernels a part has host work -- device-to-host copies of 3.5 M overlap records, LAsort, filters and chains, the
     // per-tile descriptors of the consensus rounds -- during which the device served nobody (configs[2]: one call 188 ms,
     // two concurrent halves 160 ms).  Pile-ups are independent and keep their order; the parts balance n^2.
-    int32_t nparts = 2;
+    // (three parts: with two, both tend to sit in their host phases at the same time -- measured at configs[2] on one
+    // MI355X, two runs each: 2 parts 116.9 / 127.3 ms, 3 parts 109.3 / 110.9 ms, 4 parts 112.1 ms of process wall)
+    int32_t nparts = 3;
     if (const char *e = getenv("DH_PROCESS_PARTS")) nparts = std::max(1, std::min(4, atoi(e)));
     nparts = (int32_t)std::min<size_t>((size_t)nparts, np / 16);
     if (nparts < 2) return one(ctx, piles, out);

@@ -268,7 +268,8 @@ int collect_raw_joins(const char *who, const dh_la *las, int64_t n, const int64_
     // ---- raw joins of the reads, in read order (collectScaffoldJoins, pileups.d:650-667)
     // (every host thread also merges the equal edges of its run of reads: the stable sort keeps the reads of an
     // edge in read order, and the serial merge below then handles a few thousand edges instead of one per read)
-    const int64_t grain = std::max<int64_t>(8192, ((int64_t)nreads + 15) / 16), nchunks = ((int64_t)nreads + grain - 1) / grain;
+    // (64 runs: with 16 the step ran on 16 of the host's cores -- the serial merge takes 64 short edge lists as easily)
+    const int64_t grain = std::max<int64_t>(4096, ((int64_t)nreads + 63) / 64), nchunks = ((int64_t)nreads + grain - 1) / grain;
     if (raws) raws->assign((size_t)std::max<int64_t>(nchunks, 1), {});
     if (edges) edges->assign((size_t)std::max<int64_t>(nchunks, 1), {});
     dh_parallel_for(nchunks, 1, [&](int64_t clo, int64_t chi) {
