@@ -1382,6 +1382,8 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         // all 16 wavefronts the registers allow (configs[2]: pile-up launch -2.5 ms against 12; mapping +1 ms with 16)
         int32_t per_cu = o.skip_self == 2 ? 16 : dhk_tile_waves_per_cu();
         if (const char *e = getenv("DH_TILE_WAVES_PER_CU")) per_cu = std::max(1, atoi(e));
+        if (o.skip_self == 2)
+            if (const char *e = getenv("DH_TILE_SYM_WAVES_PER_CU")) per_cu = std::max(1, atoi(e));  // development
         // (symmetric mode: the work units are groups of candidates, many per item -- a pile-up read meets every other
         // read of its pile-up -- so the items do not bound the lanes that find work)
         const int64_t lanes_wanted = o.skip_self == 2 ? nitems_total * (int64_t)o.max_cand : nitems_total;

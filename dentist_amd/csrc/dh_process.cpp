@@ -1619,13 +1619,29 @@ extern "C" int dh_process_pileups_masked(dh_ctx *ctx, dh_db *contigs, dh_db *rea
         total += cost[p];
     }
     // contiguous runs of pile-ups of about total / nparts each, none empty
+    // cumulative shares of the parts (equal unless DH_PROCESS_SPLIT = "w0,w1,..." says otherwise: development)
+    std::vector<double> wcum((size_t)nparts + 1, 0.0);
+    {
+        std::vector<double> wt((size_t)nparts, 1.0);
+        if (const char *e = getenv("DH_PROCESS_SPLIT")) {
+            const char *q = e;
+            for (int32_t k = 0; k < nparts && *q; k++) {
+                wt[(size_t)k] = std::max(0.01, atof(q));
+                while (*q && *q != ',') q++;
+                if (*q == ',') q++;
+            }
+        }
+        double sum = 0;
+        for (double x : wt) sum += x;
+        for (int32_t k = 0; k < nparts; k++) wcum[(size_t)k + 1] = wcum[(size_t)k] + wt[(size_t)k] / sum;
+    }
     std::vector<size_t> cut((size_t)nparts + 1, np);
     cut[0] = 0;
     {
         size_t p = 0;
         double acc = 0;
         for (int32_t k = 1; k < nparts; k++) {
-            while (p < np && acc + cost[p] <= total * k / nparts) acc += cost[p++];
+            while (p < np && acc + cost[p] <= total * wcum[(size_t)k]) acc += cost[p++];
             while (p < cut[(size_t)k - 1] + 1) acc += cost[p++];
             p = std::min(p, np - (size_t)(nparts - k));
             cut[(size_t)k] = p;

@@ -252,13 +252,47 @@ int collect_raw_joins(const char *who, const dh_la *las, int64_t n, const int64_
     if (bad) return dh_fail(DH_EINVAL, std::string(who) + ": read or contig id out of range");
     std::vector<int64_t> first((size_t)nreads + 1, 0);
     int64_t nlive = 0;
-    for (const auto &v : live) {
-        nlive += (int64_t)v.size();
-        for (const auto &e : v) first[(size_t)e.first + 1]++;
-    }
-    for (int32_t r = 0; r < nreads; r++) first[(size_t)r + 1] += first[(size_t)r];
+    std::vector<int64_t> loff(live.size() + 1, 0);
+    for (size_t ch = 0; ch < live.size(); ch++) loff[ch + 1] = loff[ch] + (int64_t)live[ch].size();
+    nlive = loff.back();
     std::vector<int64_t> order((size_t)nlive);
-    {
+    // records in read order (a mapping as the device hands it over, or LAsort order inside one contig): the live
+    // records are already grouped -- offsets by a merge walk per run of reads instead of a serial counting sort
+    std::atomic<int> unsorted{0};
+    dh_parallel_for((int64_t)live.size(), 1, [&](int64_t clo, int64_t chi) {
+        for (int64_t ch = clo; ch < chi; ch++) {
+            const auto &v = live[(size_t)ch];
+            int32_t prev = ch > 0 && !live[(size_t)ch - 1].empty() ? live[(size_t)ch - 1].back().first : -1;
+            for (size_t k = 0; k < v.size(); k++) {
+                if (v[k].first < prev) unsorted = 1;
+                prev = v[k].first;
+                order[(size_t)loff[(size_t)ch] + k] = v[k].second;
+            }
+        }
+    });
+    if (!unsorted.load()) {
+        const int64_t rgrain = 1 << 15, rchunks = ((int64_t)nreads + 1 + rgrain - 1) / rgrain;
+        dh_parallel_for(rchunks, 1, [&](int64_t clo, int64_t chi) {
+            for (int64_t ch = clo; ch < chi; ch++) {
+                const int64_t r0 = ch * rgrain, r1 = std::min<int64_t>((int64_t)nreads + 1, r0 + rgrain);
+                int64_t lo = 0, hi = nlive;  // first live record of a read >= r0
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if ((int64_t)las[order[(size_t)mid]].bread - read_first < r0)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                for (int64_t r = r0; r < r1; r++) {
+                    while (lo < nlive && (int64_t)las[order[(size_t)lo]].bread - read_first < r) lo++;
+                    first[(size_t)r] = lo;
+                }
+            }
+        });
+    } else {
+        for (const auto &v : live)
+            for (const auto &e : v) first[(size_t)e.first + 1]++;
+        for (int32_t r = 0; r < nreads; r++) first[(size_t)r + 1] += first[(size_t)r];
         std::vector<int64_t> cur(first.begin(), first.end() - 1);
         for (const auto &v : live)
             for (const auto &e : v) order[(size_t)cur[(size_t)e.first]++] = e.second;
@@ -608,8 +642,54 @@ int scaffold_from_edges(std::vector<std::vector<Edge>> &found, int32_t ncontigs,
     // ---- the scaffold: default edges, read joins, input gaps (buildScaffold, scaffold.d:237-244)
     std::vector<Edge> g;
     for (int32_t ct = 0; ct < ncontigs; ct++) g.push_back(make_edge(Node{ct, BEGIN}, Node{ct, END}));
-    for (auto &v : found)
-        for (auto &e : v) g.push_back(std::move(e));
+    // the runs' edge lists are sorted by key and hold every key once (raw_to_edges).  The key space is cut into buckets by
+    // the start contig; a bucket's edges are one range of every run (binary search), and the buckets are merged on the host
+    // threads independently: equal keys concatenate their read alignments in run order (= read order), every read
+    // alignment is copied once.  (One serial stable sort over all runs' edges was 7.7 of the 14 ms of the collect stage
+    // at configs[2]; a pairwise tree merge copied the read alignments once per level and was no faster.)
+    {
+        const int32_t nbuck = (int32_t)std::max<int64_t>(1, std::min<int64_t>(256, ncontigs / 4));
+        std::vector<std::vector<Edge>> merged((size_t)nbuck);
+        auto bucket_lo = [&](int32_t bk) { return (int32_t)((int64_t)ncontigs * bk / nbuck); };
+        dh_parallel_for(nbuck, 1, [&](int64_t blo, int64_t bhi) {
+            std::vector<std::pair<Edge *, int32_t>> items;  // (edge, run)
+            for (int64_t bk = blo; bk < bhi; bk++) {
+                const int32_t c0 = bucket_lo((int32_t)bk), c1 = bucket_lo((int32_t)bk + 1);
+                items.clear();
+                for (size_t run = 0; run < found.size(); run++) {
+                    std::vector<Edge> &v = found[run];
+                    auto lo = std::lower_bound(v.begin(), v.end(), c0, [](const Edge &e, int32_t c) { return e.s.contig < c; });
+                    auto hi = std::lower_bound(lo, v.end(), c1, [](const Edge &e, int32_t c) { return e.s.contig < c; });
+                    for (auto it = lo; it != hi; ++it) items.emplace_back(&*it, (int32_t)run);
+                }
+                std::sort(items.begin(), items.end(), [](const std::pair<Edge *, int32_t> &a, const std::pair<Edge *, int32_t> &b) {
+                    if (key_less(*a.first, *b.first)) return true;
+                    if (key_less(*b.first, *a.first)) return false;
+                    return a.second < b.second;
+                });
+                std::vector<Edge> &out = merged[(size_t)bk];
+                for (size_t i = 0; i < items.size();) {
+                    size_t j = i + 1;
+                    while (j < items.size() && key_eq(*items[i].first, *items[j].first)) j++;
+                    Edge m = std::move(*items[i].first);
+                    if (j - i > 1) {
+                        size_t tot = m.ras.size();
+                        for (size_t x = i + 1; x < j; x++) tot += items[x].first->ras.size();
+                        m.ras.reserve(tot);
+                        for (size_t x = i + 1; x < j; x++) {
+                            m.types |= items[x].first->types;
+                            m.ras.insert(m.ras.end(), items[x].first->ras.begin(), items[x].first->ras.end());
+                            std::vector<dh_read_alignment>().swap(items[x].first->ras);  // freed here, on this thread (not by the serial clear() below)
+                        }
+                    }
+                    out.push_back(std::move(m));
+                    i = j;
+                }
+            }
+        });
+        for (auto &v : merged)
+            for (auto &e : v) g.push_back(std::move(e));
+    }
     found.clear();
     for (int32_t x = 0; x < ngaps; x++) {
         Edge e = make_edge(Node{input_gaps[2 * x], END}, Node{input_gaps[2 * x + 1], BEGIN});
