@@ -337,7 +337,7 @@ def main():
                 "mean_cropped_length": last["pst"]["cropped_bases"] / max(1, last["pst"]["entries"]),
                 "k_tile_process_band_cells_per_s": (cum["wave_cells"] - last["ast"].wave_cells) /
                                                    max(1e-9, (wave_ms - mean(lambda r: r["ast"].ms_wave)) * 1e-3),
-                "note": "rank 0's pile-ups; k_tile time of the two concurrent halves is summed (it overstates the time)"})(
+                "note": "rank 0's pile-ups; k_tile time of the concurrent parts of the batch is summed (it overstates the time)"})(
                     mean(lambda r: r["t_process"]) * 1e3, float(last["pst"]["algorithmic_bytes"])),
             "stages_ms": {"map_wall": mean(lambda r: r["t_map"]) * 1e3,
                           "map_index": mean(lambda r: r["ast"].ms_index),

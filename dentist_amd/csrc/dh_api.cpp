@@ -1570,6 +1570,11 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     double w_g[6] = {0, 0, 0, 0, 0, 0};  // host wall of the chunk loop's phases (DH_TRACE)
 
     const int64_t item_first = 2ll * first, item_end = item_first + nitems_total;
+    // The device-to-host copy of a chunk's records runs as a copy kernel here; beside it the streaming kernels that make
+    // the next chunk's derived copies (pack, reverse complement, planes) ran 2-5 x slower (12 ms between two chunks of
+    // configs[2] for 6.5 ms of work).  The copy -- and the hook that waits for it -- of chunk c is therefore issued after
+    // chunk c + 1's copies have been made: it overlaps that chunk's seed kernel instead.
+    std::function<int()> deferred;
     for (int64_t item0 = item_first; item0 < item_end; item0 += cn) {
         const int32_t ni = (int32_t)std::min<int64_t>(cn, item_end - item0);
         double w_c = now_ms();
@@ -1601,6 +1606,13 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             dhk_pk2planes(st, cc.pk_w0, cc.pk_words);
             dhk_pk2planes(st, cc.rcpk_w0, cc.pk_words);
             HIPCHK(hipGetLastError());
+        }
+        if (deferred) {
+            HIPCHK(hipEventRecord(ctx->ev[6], st));
+            HIPCHK(hipStreamWaitEvent(ctx->cstream, ctx->ev[6], 0));
+            const int rc = deferred();
+            deferred = nullptr;
+            if (rc) return rc;
         }
         // per-chunk arrays are indexed by absolute item inside the kernels: shift the bases
         DhCand *candbase = d_cand - item0 * o.max_cand;
@@ -1863,6 +1875,8 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             if (int rc = read_ovf()) return rc;
         lap(3);
         hipEvent_t copied = nullptr;
+        std::function<int()> enqueue_copy;
+        bool defer_copy = false;
         if (totals[0] > 0) {
             // the compacted buffers are reused: the previous chunk's copies must have left them
             HIPCHK(hipStreamSynchronize(ctx->cstream));
@@ -1896,21 +1910,27 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             hipEvent_t compacted = ctx->cev[nchunk_done & 1];
             copied = ctx->cev[2 + (nchunk_done & 1)];
             HIPCHK(hipEventRecord(compacted, st));
-            HIPCHK(hipStreamWaitEvent(ctx->cstream, compacted, 0));
-            HIPCHK(hipMemcpyAsync(res->la.data() + l0, d_laout, sizeof(dh_la) * (size_t)totals[0],
-                                  hipMemcpyDeviceToHost, ctx->cstream));
-            // the chunk's hook (chain flags, filters, candidates) reads the records only: it starts when they have
-            // arrived, while the trace values -- ten times the bytes -- are still on their way (Tasks::join waits
-            // for the stream before anybody sees the result)
-            HIPCHK(hipEventRecord(copied, ctx->cstream));
             res->d_trace = (t0 == 0 && item0 == item_first && ni == nitems_total) ? d_trout : nullptr;
-            // (want_sorted & 2: the caller reads the trace from the device copy -- the pile-up all-vs-all, whose host
-            // side needs 1 / n of the values: the overlaps of the reference reads -- so the 2 x 160 MB of configs[2] stay)
-            if (totals[1] > 0 && !dev_only)
-                HIPCHK(hipMemcpyAsync(res->trace.data() + t0, d_trout, sizeof(uint16_t) * (size_t)totals[1],
-                                      hipMemcpyDeviceToHost, ctx->cstream));
-            else if (totals[1] > 0)
-                res->d_trace_len = (int64_t)totals[1];
+            if (totals[1] > 0 && dev_only) res->d_trace_len = (int64_t)totals[1];
+            const hipEvent_t copied_ev = copied;
+            const uint32_t nla_c = totals[0], ntr_c = totals[1];
+            hipStream_t cst = ctx->cstream;
+            enqueue_copy = [res, l0, t0, nla_c, ntr_c, dev_only, compacted, copied_ev, cst, d_laout, d_trout]() -> int {
+                HIPCHK(hipStreamWaitEvent(cst, compacted, 0));
+                HIPCHK(hipMemcpyAsync(res->la.data() + l0, d_laout, sizeof(dh_la) * (size_t)nla_c, hipMemcpyDeviceToHost, cst));
+                // the chunk's hook (chain flags, filters, candidates) reads the records only: it starts when they have
+                // arrived, while the trace values -- ten times the bytes -- are still on their way (Tasks::join waits
+                // for the stream before anybody sees the result)
+                HIPCHK(hipEventRecord(copied_ev, cst));
+                // (want_sorted & 2: the caller reads the trace from the device copy -- the pile-up all-vs-all, whose host
+                // side needs 1 / n of the values: the overlaps of the reference reads -- so the 2 x 160 MB of configs[2] stay)
+                if (ntr_c > 0 && !dev_only)
+                    HIPCHK(hipMemcpyAsync(res->trace.data() + t0, d_trout, sizeof(uint16_t) * (size_t)ntr_c, hipMemcpyDeviceToHost, cst));
+                return DH_OK;
+            };
+            defer_copy = hook && tiled && !db_copies && !res2 && !sym_tiled && item0 + cn < item_end && !getenv("DH_NO_DEFER_COPY");
+            if (!defer_copy)
+                if (int rc = enqueue_copy()) return rc;
         }
         if (res2) {
             // the transposed records of the chunk: same compaction, copied on this stream (not the benched path)
@@ -1947,21 +1967,33 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             const int dev = ctx->device;
             const int64_t l0h = (int64_t)(res->la.size() - totals[0]), chunk_no = nchunk_done - 1;
             const bool best = want_best != 0;
-            tasks.v.emplace_back([h, p, cnt, copied, dev, l0h, chunk_no, best, near_ppm] {
-                (void)hipSetDevice(dev);
-                const auto t0 = std::chrono::steady_clock::now();
-                (void)hipEventSynchronize(copied);  // the records of this chunk have arrived
-                const auto t1 = std::chrono::steady_clock::now();
-                if (best) select_best_range(p, (size_t)cnt, near_ppm);  // chain flags: a per-read decision too
-                const auto t2 = std::chrono::steady_clock::now();
-                h(p, cnt, l0h, chunk_no);
-                if (getenv("DH_TRACE"))
-                    fprintf(stderr, "[chunk hook %lld] %lld records: wait %.2f chains %.2f filters + candidates %.2f ms\n",
-                            (long long)chunk_no, (long long)cnt, std::chrono::duration<double, std::milli>(t1 - t0).count(),
-                            std::chrono::duration<double, std::milli>(t2 - t1).count(),
-                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count());
-            });
-        }
+            const hipEvent_t copied_h = copied;
+            auto make_hook = [&tasks, h, p, cnt, copied_h, dev, l0h, chunk_no, best, near_ppm]() {
+                tasks.v.emplace_back([h, p, cnt, copied_h, dev, l0h, chunk_no, best, near_ppm] {
+                    (void)hipSetDevice(dev);
+                    const auto t0 = std::chrono::steady_clock::now();
+                    (void)hipEventSynchronize(copied_h);  // the records of this chunk have arrived
+                    const auto t1 = std::chrono::steady_clock::now();
+                    if (best) select_best_range(p, (size_t)cnt, near_ppm);  // chain flags: a per-read decision too
+                    const auto t2 = std::chrono::steady_clock::now();
+                    h(p, cnt, l0h, chunk_no);
+                    if (getenv("DH_TRACE"))
+                        fprintf(stderr, "[chunk hook %lld] %lld records: wait %.2f chains %.2f filters + candidates %.2f ms\n",
+                                (long long)chunk_no, (long long)cnt, std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                                std::chrono::duration<double, std::milli>(t2 - t1).count(),
+                                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count());
+                });
+            };
+            if (defer_copy)  // (the event the hook waits for is recorded when the copy is issued: both wait for the next chunk)
+                deferred = [enqueue_copy, make_hook]() -> int {
+                    if (int rc = enqueue_copy()) return rc;
+                    make_hook();
+                    return DH_OK;
+                };
+            else
+                make_hook();
+        } else if (defer_copy)
+            deferred = enqueue_copy;
         float t;
         HIPCHK(hipEventElapsedTime(&t, ctx->ev[2], ctx->ev[3]));
         ms_seed += t;

@@ -695,6 +695,9 @@ static bool valid_pileup_alignment(const dh_la &la, bool same, int32_t alen, int
 // defaults of commandline.d:1819, 1982, 2014, 2153, 2165-2173.  `la` is grouped by (aread, bread)
 // [first, last); only chains scoring >= max(minScore, minRelativeScore * best) survive, every
 // other enabled LA of the pair gets DISABLED.  First LA of a chain: START|BEST, the others NEXT.
+// (One shortest-path problem over all LAs of the pair and the global threshold only: exact at the default
+// minRelativeScore = 1.0, the only value dh_process_opts can ask for; the reference's split into components and its
+// alternateChain marking, chaining.d:166-300, matter below 1.0 -- see oracle/process.py:chain_pile_las.)
 static void chain_pair(LaVec &la, size_t first, size_t last, int32_t min_score)
 {
     const int32_t max_indel = 1000, max_gap = 10000;

@@ -263,7 +263,18 @@ def chain_pile_las(las, max_indel=1000, max_gap=10000, max_rel_overlap=0.3, min_
     commandline.d:1819, 1982, 2014, 2153, 2165-2173: per (A, B) pair the chains of collinear LAs are
     rated by a shortest-path problem (node bonus = mean length, edge penalty = indel + gap/10) and
     only chains scoring >= max(minScore, minRelativeScore * best) survive; every other enabled LA
-    of the pair is dropped (DISABLED).  Flags: first LA of a chain START|BEST, the others NEXT."""
+    of the pair is dropped (DISABLED).  Flags: first LA of a chain START|BEST, the others NEXT.
+
+    Simplified against chaining.d:166-300, exact at the default minRelativeScore = 1.0 (commandline.d:2153) and only there:
+    the reference first splits the pair's LAs into connected components of the (undirected) chainability relation, selects
+    per component the end nodes within minRelativeScore of the component's best chain -- marking a chain that shares a
+    prefix with a better one `alternateChain` -- and then keeps the chains within minRelativeScore of the best chain over
+    all components.  Here ONE shortest-path problem runs over all LAs of the pair (LAs of different components are never
+    chainable, so the distances are the same) and only the global threshold is applied; at 1.0 both keep exactly the
+    chains whose score equals the pair's best (ties: every end node with that score, nodes already on a kept chain are not
+    repeated).  With minRelativeScore < 1 the reference would also keep alternate chains and per-component winners that
+    this restatement (and the product, dh_process.cpp:chain_pair) drops or joins differently; the process stage has no
+    knob for it (dh_process_opts), so the default is the only value that can be asked for."""
     las = las.copy()
     groups = {}
     for i, la in enumerate(las):
