@@ -2612,6 +2612,12 @@ extern "C" int dh_shard_plan_create(const uint8_t *const *blobs, const int64_t *
     for (int32_t r = 0; r < world; r++) {
         const CandRec *rec = (const CandRec *)blobs[r];
         for (int64_t i = 0; i < sizes[r] / (int64_t)sizeof(CandRec); i++, at++) {
+            // a corrupted or short collective payload is an error, not an index
+            if (rec[i].gap < 0 || rec[i].read < 0 || rec[i].L.aread != rec[i].gap || rec[i].R.aread != rec[i].gap + 1 ||
+                rec[i].L.bread != rec[i].R.bread || rec[i].L.tlen < 0 || rec[i].R.tlen < 0) {
+                delete p;
+                return dh_fail(DH_EINVAL, "dh_shard_plan_create: candidate record with inconsistent gap / read / alignment ids");
+            }
             p->las[(size_t)(2 * at)] = rec[i].L;
             p->las[(size_t)(2 * at + 1)] = rec[i].R;
             key[(size_t)at] = std::make_pair(rec[i].gap, (int32_t)at);
@@ -2654,7 +2660,12 @@ extern "C" int dh_shard_pack_cropped(dh_cropped *crop, const int32_t *owner, int
     const uint8_t *bases = nr ? dh_cropped_bases(crop) : nullptr;
     if (nr && !bases) return DH_EHIP;
     std::vector<int64_t> cnt((size_t)world, 0), nb((size_t)world, 0);
+    // `owner` has one entry per pile-up of the crop (dh_shard_plan_owner of the plan the crop was made from)
     for (size_t i = 0; i < nr; i++) {
+        if (crop->pile[i] < 0 || (size_t)crop->pile[i] >= crop->rec.size())
+            return dh_fail(DH_EINVAL, "dh_shard_pack_cropped: pile-up index outside the crop's records");
+        if (crop->entry[i] < 0 || crop->entry[i] >= (1 << 28) || (i < crop->kind.size() && crop->kind[i] > 15))
+            return dh_fail(DH_EINVAL, "dh_shard_pack_cropped: entry index or kind does not fit the blob header");
         const int32_t d = owner[crop->pile[i]];
         if (d < 0 || d >= world) return dh_fail(DH_EINVAL, "dh_shard_pack_cropped: owner out of range");
         cnt[(size_t)d]++;

@@ -198,3 +198,23 @@ def test_product_las_filter_roundtrip_of_the_reference(tmp_path):
         assert [la["bread"] + 1, la["bbpos"], la["bepos"]] == exp["b"]
         assert sorted(dentist_flags(int(la["flags"]))) == sorted(exp["flags"])
         assert trace2[la["toff"]:la["toff"] + la["tlen"]].reshape(-1, 2).tolist() == exp["tp"]
+
+
+def test_pileups_of_general_joins_are_validated():
+    """dh_pileups_create_joins: nodes ordered, contig0 < contig1, seeds 0 / 1, an extension has no second contig; the
+    plain creator's pile-ups read back as (c, back, c + 1, front); the sharded glue refuses general joins loudly."""
+    tri = [[(0, 0, 1)], [(1, 2, -1)]]
+    p = dentist_amd.Pileups.from_joins([(0, 1, 3, 1), (2, 0, -1, 0)], tri)
+    assert len(p) == 2 and p.get_join(0) == (0, 1, 3, 1) and p.get_join(1) == (2, 0, -1, 0)
+    assert p.get(1)[1].tolist() == [[1, 2, -1]]
+    q = dentist_amd.Pileups.from_triples([4, 7], [np.asarray([(0, 0, 1)]), np.asarray([(2, 3, 4)])])
+    assert q.get_join(0) == (4, 1, 5, 0) and q.get_join(1) == (7, 1, 8, 0)
+    for bad in ([(3, 1, 0, 1), (4, 0, -1, 0)],          # contig0 > contig1
+                [(2, 0, -1, 0), (0, 1, 3, 1)],          # not ordered by their nodes
+                [(0, 2, 3, 1), (4, 0, -1, 0)],          # seed out of range
+                [(0, 1, 0, 0), (4, 0, -1, 0)]):         # a contig joined with itself
+        with pytest.raises(dentist_amd.DhError):
+            dentist_amd.Pileups.from_joins(bad, tri)
+    las = np.zeros(5, dtype=dentist_amd.LA_DTYPE)
+    with pytest.raises(dentist_amd.DhError, match="general joins"):
+        __import__("dentist_amd._lib", fromlist=["x"]).shard_pack_candidates(p, las)

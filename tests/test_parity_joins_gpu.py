@@ -184,3 +184,89 @@ def test_scrambled_assembly_comes_out_as_the_genome(gpu_ctx, tmp_path):
     assert len(head) >= 100 and len(tail) >= 100
     assert oz.nw(sim.encode(truth[first_pos - len(head):first_pos]), sim.encode(head))[0] <= 0.08 * len(head)
     assert oz.nw(sim.encode(truth[prev_end:prev_end + len(tail)]), sim.encode(tail))[0] <= 0.08 * len(tail)
+
+
+def test_containers_of_general_joins_and_the_repeat_mask_in_the_cropper(gpu_ctx, tmp_path):
+    """(1) pile-ups.db / insertions.db of general joins: every SeededAlignment carries the seed of its flank, every
+    insertion the nodes of its join (makeJoin, base.d:2680-2722: begin = 1, end = 2; a front extension is (pre = 0) ->
+    begin, a back extension end -> (post = 3)) and one overlap per flank.  (2) `process --mask`: a repeat-mask interval
+    over the common trace point of a flank moves the crop to the next trace point outside it (getCommonTracePoint,
+    cropper.d:446-500) -- product (dh_process_pileups_masked) == oracle, crop points, consensus and splice coordinates."""
+    w = sim.Workload(500_000, 4, 1400, 9000, seed=20260931, spacing=70000, gap_max=1200)
+    contigs, placement = scrambled_assembly(w)
+    mo = dentist_amd.default_align_opts(kmer_mod=4, k=20, width=64, xdrop=60, algo=1)
+    po = dentist_amd.default_process_opts(algo=1, rounds=2, max_reads=0)
+    A, B = gpu_ctx.db(contigs), gpu_ctx.db(w.reads)
+    las, trace, _ = gpu_ctx.map_reads(A, B, mo, po, sorted=False, candidates=False)[:3]
+    piles, _ = dentist_amd.scaffold_all_pileups(las, contigs.off, w.reads.off, None, only="both", min_spanning_reads=po.min_reads)
+    joins = [piles.get_join(i) for i in range(len(piles))]
+    # ---- (1) containers
+    pdb, idb = str(tmp_path / "pile-ups.db"), str(tmp_path / "insertions.db")
+    piles.write_db(pdb, las, trace, contigs.off, w.reads.off, tspace=100)
+    got = dentist_amd.pileupdb_read(pdb)
+    assert got["pile_counts"].tolist() == [len(piles.get(i)[1]) for i in range(len(piles))]
+    at = ra = 0
+    for i, j in enumerate(joins):
+        _, tri = piles.get(i)
+        for t in tri:
+            n = got["ra_counts"][ra]
+            assert n == int(t[1] >= 0) + int(t[2] >= 0)
+            for f in (0, 1):
+                if t[1 + f] >= 0:
+                    sa = got["seeded"][at]
+                    assert (sa["contig_a_id"] - 1, sa["seed"]) == (j[2 * f], j[2 * f + 1]) and sa["contig_b_id"] - 1 == t[0]
+                    at += 1
+            ra += 1
+    rec, bases = dentist_amd.process_pileups(gpu_ctx, A, B, las, trace, piles, po, insertions_db=(idb, contigs.off, po.tspace_pile))
+    ins = dentist_amd.insertiondb_read(idb)
+    ok = [i for i in range(len(piles)) if rec[i]["status"] == 0]
+    assert len(ins["insertions"]) == len(ok) == 6
+    at = 0
+    for x, i in zip(ins["insertions"], ok):
+        c0, s0, c1, s1 = joins[i]
+        if c1 < 0:
+            want = (c0 + 1, 0 if s0 == 0 else 2, c0 + 1, 1 if s0 == 0 else 3, 1)
+        else:
+            want = (c0 + 1, 1 if s0 == 0 else 2, c1 + 1, 1 if s1 == 0 else 2, 2)
+        assert (x["start_contig"], x["start_part"], x["end_contig"], x["end_part"], x["noverlaps"]) == want
+        assert x["seq_len"] == rec[i]["cons_len"]
+        for f in range(x["noverlaps"]):
+            sa = ins["seeded"][at]
+            assert (sa["contig_a_id"] - 1, sa["seed"]) == ((c0, s0) if f == 0 else (c1, s1))
+            at += 1
+    # ---- (2) the mask: over the crop point of flank 0 of the skipping join and of flank 1 of the end-end join
+    mask = {}
+    for i, j in enumerate(joins):
+        if j == (2, 1, 4, 0):
+            mask[2] = [(int(rec[i]["crop_left"]) - 150, int(rec[i]["crop_left"]) + 60)]
+        if j == (0, 1, 1, 1):
+            mask[1] = [(int(rec[i]["crop_right"]) - 120, int(rec[i]["crop_right"]) + 250)]
+    assert len(mask) == 2
+    ptr = np.zeros(contigs.n + 1, dtype=np.int64)
+    iv = []
+    for c in range(contigs.n):
+        iv += [x for b_e in mask.get(c, []) for x in b_e]
+        ptr[c + 1] = len(iv) // 2
+    rec2, bases2 = dentist_amd.process_pileups(gpu_ctx, A, B, las, trace, piles, po, repeat_mask=(ptr, np.asarray(iv, dtype=np.int32)))
+    olas, otrace = las, trace
+    moved = 0
+    for i, j in enumerate(joins):
+        _, tri = piles.get(i)
+        ex = pr.process_pile([tuple(int(x) for x in t) for t in tri.tolist()], olas, otrace, contigs, w.reads, j, rounds=po.rounds,
+                             nthreads=os.cpu_count() or 1, algo=1, mask=mask)
+        r = rec2[i]
+        assert (r["status"] == 0) == (ex["status"] == "ok"), (j, int(r["status"]), ex["status"])
+        assert (r["crop_left"], r["crop_right"]) == (ex["cropL"], ex["cropR"])
+        if j in ((2, 1, 4, 0), (0, 1, 1, 1)):
+            f = 0 if j[0] == 2 else 1
+            b, e = mask[j[2 * f]][0]
+            new = int(r["crop_left"] if f == 0 else r["crop_right"])
+            old = int(rec[i]["crop_left"] if f == 0 else rec[i]["crop_right"])
+            assert b <= old < e and not (b <= new < e)
+            moved += 1
+        else:
+            assert (r["crop_left"], r["crop_right"]) == (rec[i]["crop_left"], rec[i]["crop_right"])
+        if r["status"] == 0:
+            assert np.array_equal(bases2[r["cons_off"]:r["cons_off"] + r["cons_len"]], ex["consensus"])
+            assert (r["left_aepos"], r["right_abpos"], r["ins_begin"], r["ins_end"]) == (ex["left_aepos"], ex["right_abpos"], ex["ins_begin"], ex["ins_end"])
+    assert moved == 2
