@@ -1902,8 +1902,9 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             }
             if (l0 + totals[0] > res->la.capacity() || t0 + totals[1] > res->trace.capacity())
                 tasks.join();  // the records are about to move: copies and hooks in flight finish first
-            res->la.resize(l0 + totals[0]);
             const bool dev_only = (want_sorted & 2) && t0 == 0 && item0 == item_first && ni == nitems_total;
+            const bool rec_dev = dev_only && (want_sorted & 4) && sym_tiled && l0 == 0 && !hook;
+            if (!rec_dev) res->la.resize(l0 + totals[0]);
             if (!dev_only) res->trace.resize(t0 + totals[1]);
             lap(4);
             // device-to-host on the copy stream: it overlaps the next chunk's kernels
@@ -1929,7 +1930,12 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
                 return DH_OK;
             };
             defer_copy = hook && tiled && !db_copies && !res2 && !sym_tiled && item0 + cn < item_end && !getenv("DH_NO_DEFER_COPY");
-            if (!defer_copy)
+            if (rec_dev) {  // the caller works on the device copy of the records (dh_process_cropped's funnel)
+                res->d_la = d_laout;
+                res->d_la_n = (int64_t)totals[0];
+                res->d_item_off = d_nla;
+                HIPCHK(hipEventRecord(copied_ev, cst));
+            } else if (!defer_copy)
                 if (int rc = enqueue_copy()) return rc;
         }
         if (res2) {
@@ -2032,7 +2038,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         std::sort(res2->la.begin(), res2->la.end(), la_less);
     }
     w_post = now_ms() - w_a;
-    stats.las = (int64_t)res->la.size();
+    stats.las = res->d_la_n > 0 ? res->d_la_n : (int64_t)res->la.size();
     float t;
     HIPCHK(hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[1]));
     stats.ms_index = t;

@@ -60,6 +60,184 @@ k_gather_parts(const uint8_t *__restrict__ src0, const int64_t *__restrict__ off
     }
 }
 
+// ------------------------------------------------------------------------------------ K6b
+// The alignment funnel of computeQVs (processPileUps/package.d:474-516) on the records the pile-up all-vs-all left on
+// the device -- averageErrorRate <= maxAlignmentError, chainLocalAlignments per (A, B) pair (chaining.d:122-334, the
+// arithmetic of dh_process.cpp:chain_pair), isValidPileUpAlignment (dazzler.d:4126-4141) -- so that 3.5 M records
+// (configs[2]) neither travel to the host nor back for the tile QVs.  One wavefront per A read; its records are one
+// range of the compacted array (item_off: exclusive prefix sums over the items (read, strand)), the records of a pair
+// in ascending index order are what the host sees after its stable merge by B read.  Flags are updated in place:
+// DISABLED (0x20), START | BEST (0x4 | 0x10) / NEXT (0x8) of the kept chains, IMPROPER (0x40: still counted by the tile
+// QVs, dropped afterwards).  la_first[r] = first record of A read r (nreads + 1 entries), live[r] = records of r that
+// stay after the proper-overlap filter.  status |= 1: a read with more than PF_MAXN records or a pair with more than
+// PF_MAXG enabled records -- the caller redoes the batch on the host (never met on pile-ups up to 250 reads).
+#define PF_MAXN 1024
+#define PF_MAXG 8
+__device__ __forceinline__ int32_t pf_score(int32_t ab, int32_t ae, int32_t bb, int32_t be) { return ((ae - ab) + (be - bb)) / 2; }
+
+__global__ void __launch_bounds__(64)
+k_pile_funnel(DhLa *__restrict__ las, const uint32_t *__restrict__ item_off, int32_t nreads, const int64_t *__restrict__ roff,
+              int32_t max_err_ppm, int32_t tsp, int32_t *__restrict__ la_first, int32_t *__restrict__ live,
+              int32_t *__restrict__ status)
+{
+    __shared__ int32_t s_b[PF_MAXN], s_ab[PF_MAXN], s_ae[PF_MAXN], s_bb[PF_MAXN], s_be[PF_MAXN];
+    __shared__ uint32_t s_fl[PF_MAXN];
+    const int32_t r = blockIdx.x;
+    if (r >= nreads) return;
+    const int lane = threadIdx.x;
+    const int32_t l0 = (int32_t)item_off[2 * r], l1 = (int32_t)item_off[2 * r + 2], n = l1 - l0;
+    if (lane == 0) {
+        la_first[r] = l0;
+        if (r == nreads - 1) la_first[nreads] = l1;
+    }
+    if (n > PF_MAXN) {
+        if (lane == 0) {
+            atomicOr(status, 1);
+            live[r] = 0;
+        }
+        return;
+    }
+    for (int32_t i = lane; i < n; i += 64) {
+        const DhLa la = las[l0 + i];
+        uint32_t fl = la.flags;
+        if ((int64_t)la.diffs * 1000000 > (int64_t)max_err_ppm * (la.aepos - la.abpos)) fl |= 0x20u;
+        s_b[i] = la.bread;
+        s_ab[i] = la.abpos;
+        s_ae[i] = la.aepos;
+        s_bb[i] = la.bbpos;
+        s_be[i] = la.bepos;
+        s_fl[i] = fl;
+    }
+    __syncthreads();
+    // ---- chains per (A, B) pair: the lane of a pair's first record does the pair
+    for (int32_t i = lane; i < n; i += 64) {
+        const int32_t b = s_b[i];
+        bool leader = true;
+        for (int32_t j = 0; j < i && leader; j++) leader = s_b[j] != b;
+        if (!leader) continue;
+        int32_t idx[PF_MAXG], nen = 0;
+        for (int32_t j = i; j < n; j++)
+            if (s_b[j] == b && !(s_fl[j] & 0x20u)) {
+                if (nen < PF_MAXG) idx[nen] = j;
+                nen++;
+            }
+        if (nen == 0) continue;
+        if (nen > PF_MAXG) {
+            atomicOr(status, 1);
+            continue;
+        }
+        if (nen == 1) {  // a single enabled record is its own best chain
+            const int32_t x = idx[0];
+            if (pf_score(s_ab[x], s_ae[x], s_bb[x], s_be[x]) < tsp)
+                s_fl[x] |= 0x20u;
+            else
+                s_fl[x] = (s_fl[x] & ~(0x4u | 0x8u | 0x10u)) | 0x4u | 0x10u;
+            continue;
+        }
+        // order by (abpos, bbpos, index): insertion sort, stable
+        for (int32_t u = 1; u < nen; u++) {
+            const int32_t x = idx[u];
+            int32_t v = u - 1;
+            while (v >= 0 && (s_ab[idx[v]] > s_ab[x] || (s_ab[idx[v]] == s_ab[x] && s_bb[idx[v]] > s_bb[x]))) {
+                idx[v + 1] = idx[v];
+                v--;
+            }
+            idx[v + 1] = x;
+        }
+        int32_t dist[PF_MAXG], pred[PF_MAXG];
+        for (int32_t v = 0; v < nen; v++) {
+            dist[v] = -pf_score(s_ab[idx[v]], s_ae[idx[v]], s_bb[idx[v]], s_be[idx[v]]);
+            pred[v] = -1;
+        }
+        for (int32_t u = 0; u < nen; u++)
+            for (int32_t v = u + 1; v < nen; v++) {
+                const int32_t x = idx[u], y = idx[v];
+                if ((s_fl[x] & 1u) != (s_fl[y] & 1u)) continue;
+                const int32_t ga = s_ab[y] - s_ae[x], gb = s_bb[y] - s_be[x];
+                if (!(s_ab[x] < s_ab[y] && s_bb[x] < s_bb[y])) continue;
+                const int32_t aga = ga < 0 ? -ga : ga, agb = gb < 0 ? -gb : gb, dg = ga - gb < 0 ? gb - ga : ga - gb;
+                if (dg > 1000 || (aga > agb ? aga : agb) > 10000) continue;
+                const int32_t lax = s_ae[x] - s_ab[x], lay = s_ae[y] - s_ab[y], lbx = s_be[x] - s_bb[x], lby = s_be[y] - s_bb[y];
+                const int32_t mla = lax < lay ? lax : lay, mlb = lbx < lby ? lbx : lby;
+                if (!((double)(ga < 0 ? -ga : 0) <= 0.3 * (double)mla && (double)(gb < 0 ? -gb : 0) <= 0.3 * (double)mlb)) continue;
+                const int32_t d = dist[u] + dg + (aga > agb ? aga : agb) / 10 - pf_score(s_ab[y], s_ae[y], s_bb[y], s_be[y]);
+                if (dist[v] > d) {
+                    dist[v] = d;
+                    pred[v] = u;
+                }
+            }
+        int32_t mind = dist[0];
+        for (int32_t v = 1; v < nen; v++) mind = dist[v] < mind ? dist[v] : mind;
+        const int32_t best = -mind;
+        const double thr_d = (double)tsp > 1.0 * (double)best ? (double)tsp : 1.0 * (double)best;
+        const int32_t thr = (int32_t)thr_d;
+        int32_t ends[PF_MAXG];  // end nodes by ascending distance, stable
+        for (int32_t v = 0; v < nen; v++) ends[v] = v;
+        for (int32_t u = 1; u < nen; u++) {
+            const int32_t x = ends[u];
+            int32_t v = u - 1;
+            while (v >= 0 && dist[ends[v]] > dist[x]) {
+                ends[v + 1] = ends[v];
+                v--;
+            }
+            ends[v + 1] = x;
+        }
+        uint32_t keep = 0;
+        for (int32_t q = 0; q < nen; q++) {
+            const int32_t e = ends[q];
+            if (-dist[e] < thr || (keep >> e & 1u)) continue;
+            int32_t path[PF_MAXG], np_ = 0;
+            for (int32_t v = e; v >= 0; v = pred[v]) path[np_++] = v;
+            for (int32_t k = 0; k < np_; k++) {
+                const int32_t v = path[np_ - 1 - k];
+                if (keep >> v & 1u) continue;
+                keep |= 1u << v;
+                s_fl[idx[v]] = (s_fl[idx[v]] & ~(0x4u | 0x8u | 0x10u)) | (k == 0 ? (0x4u | 0x10u) : 0x8u);
+            }
+        }
+        for (int32_t v = 0; v < nen; v++)
+            if (!(keep >> v & 1u)) s_fl[idx[v]] |= 0x20u;
+    }
+    __syncthreads();
+    // ---- isValidPileUpAlignment with allowance = trace spacing; flags back, live records counted
+    const int32_t alen = (int32_t)(roff[r + 1] - roff[r]);
+    int32_t cnt = 0;
+    for (int32_t i = lane; i < n; i += 64) {
+        uint32_t fl = s_fl[i];
+        if (!(fl & 0x20u)) {
+            const int32_t b = s_b[i];
+            const int32_t blen = (int32_t)(roff[b + 1] - roff[b]);
+            const bool ab = s_ab[i] <= tsp, bb = s_bb[i] <= tsp;
+            const bool ae = s_ae[i] + tsp >= alen, be = s_be[i] + tsp >= blen;
+            const bool ok = b != r && (((ab && bb) && (ae || be)) || ((ae && be) && (ab || bb)));
+            if (!ok)
+                fl |= 0x40u;
+            else
+                cnt++;
+        }
+        las[l0 + i].flags = fl;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    if (lane == 0) live[r] = cnt;
+}
+
+// records of selected A reads gathered into one array (the overlaps of the reference reads: all the host needs);
+// IMPROPER becomes DISABLED on the way (filterPileUpAlignments runs after the tile QVs, dazzler.d:4043-4094)
+__global__ void __launch_bounds__(64)
+k_gather_read_records(const DhLa *__restrict__ las, const int32_t *__restrict__ la_first, const int32_t *__restrict__ sel,
+                      const int32_t *__restrict__ dst_off, int32_t nsel, DhLa *__restrict__ out)
+{
+    const int32_t s = blockIdx.x;
+    if (s >= nsel) return;
+    const int32_t r = sel[s], l0 = la_first[r], n = la_first[r + 1] - l0, d0 = dst_off[s];
+    for (int32_t i = threadIdx.x; i < n; i += 64) {
+        DhLa la = las[l0 + i];
+        if (la.flags & 0x40u) la.flags = (la.flags & ~0x40u) | 0x20u;
+        out[d0 + i] = la;
+    }
+}
+
 // ------------------------------------------------------------------------------------ K7
 
 // las sorted by aread; la_first[r] .. la_first[r+1] are the LAs with aread == r.
@@ -791,6 +969,21 @@ void dhk_gather_parts(hipStream_t st, const uint8_t *src0, const int64_t *off0, 
         hipLaunchKernelGGL(k_gather_parts, dim3(gx, cnt), dim3(256), 0, st, src0, off0, src1, off1,
                            (const PartDesc *)parts + s0, cnt, dst);
     }
+}
+
+void dhk_pile_funnel(hipStream_t st, DhLa *las, const uint32_t *item_off, int32_t nreads, const int64_t *roff,
+                     int32_t max_err_ppm, int32_t tsp, int32_t *la_first, int32_t *live, int32_t *status)
+{
+    if (nreads <= 0) return;
+    hipLaunchKernelGGL(k_pile_funnel, dim3(nreads), dim3(64), 0, st, las, item_off, nreads, roff, max_err_ppm, tsp, la_first,
+                       live, status);
+}
+
+void dhk_gather_read_records(hipStream_t st, const DhLa *las, const int32_t *la_first, const int32_t *sel,
+                             const int32_t *dst_off, int32_t nsel, DhLa *out)
+{
+    if (nsel <= 0) return;
+    hipLaunchKernelGGL(k_gather_read_records, dim3(nsel), dim3(64), 0, st, las, la_first, sel, dst_off, nsel, out);
 }
 
 void dhk_tile_qv(hipStream_t st, const DhLa *las, const uint16_t *trace, const int32_t *la_first,

@@ -167,6 +167,12 @@ struct dh_la_set {
     // alignment call on the same context, nullptr when the result came in several chunks
     const uint16_t *d_trace = nullptr;
     int64_t d_trace_len = 0;  // > 0: `trace` was left on the device on request (dh_align_db_ex want_sorted & 2), the host vector is empty
+    // want_sorted & 4 (with & 2, symmetric DH-2 call in one chunk): the RECORDS stay on the device as well -- d_la_n of them,
+    // grouped by A-read item, d_item_off[item] = first record of item (read * 2 + strand), nitems + 1 entries; `la` is empty.
+    // Valid until the next alignment call on the context.
+    DhLa *d_la = nullptr;
+    int64_t d_la_n = 0;
+    const uint32_t *d_item_off = nullptr;
     // B reads whose items overflowed a per-item capacity (dropped records / no candidates), see
     // dh_align_stats.overflow_items; the pile-up path skips the pile-ups of such reads
     std::vector<int32_t> ovf_reads;

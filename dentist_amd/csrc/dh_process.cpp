@@ -32,6 +32,10 @@ void dhk_gather_ranges16(hipStream_t st, const uint16_t *src, const int64_t *des
 void dhk_tile_qv(hipStream_t st, const DhLa *las, const uint16_t *trace, const int32_t *la_first,
                  const int64_t *roff, int32_t nreads, int32_t tspace, const int32_t *cov, int32_t maxtiles,
                  uint8_t *qv);
+void dhk_pile_funnel(hipStream_t st, DhLa *las, const uint32_t *item_off, int32_t nreads, const int64_t *roff,
+                     int32_t max_err_ppm, int32_t tsp, int32_t *la_first, int32_t *live, int32_t *status);
+void dhk_gather_read_records(hipStream_t st, const DhLa *las, const int32_t *la_first, const int32_t *sel,
+                             const int32_t *dst_off, int32_t nsel, DhLa *out);
 void dhk_seg_vote(hipStream_t st, const void *segs, int32_t nseg, DbView T, DbView R,
                   const uint8_t *rrc, const int64_t *voff, uint32_t *dmat, int32_t bandmax, int32_t qmax,
                   int32_t ncolmax, uint8_t *opbuf, uint16_t *nops, uint32_t *votes, uint32_t *cdiff,
@@ -1905,11 +1909,67 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
         HIPCHK(hipEventRecord(ev[0], st));
         // (2: the trace values stay on the device -- the tile QVs read them there, the first consensus round fetches the
         // overlaps of the reference reads only, 1 / n of them)
-        if (int rc = dh_align_db_ex(ctx, pile, pile, &ao, 0, 2, &pset)) return rc;
+        // (4: with DH-2 the records stay on the device as well -- the funnel below runs there, only the overlaps of the
+        // reference reads travel; DH_HOST_FUNNEL=1 keeps the host path, which is also the fall-back)
+        const bool want_dev_funnel = palgo == 1 && !getenv("DH_HOST_FUNNEL");
+        if (int rc = dh_align_db_ex(ctx, pile, pile, &ao, 0, want_dev_funnel ? 6 : 2, &pset)) return rc;
         sg.sets.push_back(pset);
         lap("pile align call");
+        const int32_t npr = pile->n;
+        const int32_t maxtiles = std::max(1, (pile->max_len + tsp - 1) / tsp);
+        std::vector<uint8_t> qv((size_t)npr * maxtiles, 255);
+        // cov = max(#allowed reference reads, 4 if pile >= 4) == pile size here (package.d:498-503)
+        // (allowed reference reads = the reads that span the gap, selectAllowedReferenceReadIds :461-472)
+        std::vector<int32_t> cov_of((size_t)npr, 1);
+        for (int32_t a = 0; a < na; a++) {
+            const int32_t r0 = first_read[(size_t)a], r1 = first_read[(size_t)a + 1];
+            int32_t cov = 0;
+            for (int32_t r = r0; r < r1; r++) cov += rkind[(size_t)r] == 0 ? 1 : 0;
+            if (cov < 4 && r1 - r0 >= 4) cov = 4;
+            for (int32_t r = r0; r < r1; r++) cov_of[(size_t)r] = std::max(cov, 1);
+        }
+        // ---- 3' + 4'. the funnel and the tile QVs on the device copy of the records
+        bool on_dev = pset->d_la != nullptr && pset->d_la_n > 0 && pset->d_trace != nullptr;
+        std::vector<int32_t> dev_first, dev_live;  // first record / live records of every pile-up read
+        DevBuf<int32_t> d_first_keep;
+        if (on_dev) {
+            HIPCHK(hipEventRecord(ev[2], st));
+            DevBuf<int32_t> d_live, d_stat, d_cov;
+            DevBuf<uint8_t> d_qv;
+            HIPCHK(d_first_keep.alloc((size_t)npr + 1));
+            HIPCHK(d_live.alloc((size_t)npr));
+            HIPCHK(d_stat.alloc(1));
+            HIPCHK(d_cov.alloc(cov_of.size()));
+            HIPCHK(d_qv.alloc(qv.size()));
+            HIPCHK(hipMemsetAsync(d_stat.p, 0, sizeof(int32_t), st));
+            HIPCHK(hipMemcpyAsync(d_cov.p, cov_of.data(), sizeof(int32_t) * cov_of.size(), hipMemcpyHostToDevice, st));
+            HIPCHK(dhk_memset(st, d_qv.p, 255, qv.size()));
+            dhk_pile_funnel(st, pset->d_la, pset->d_item_off, npr, pile->d_off, o.max_align_err_ppm, tsp, d_first_keep.p, d_live.p, d_stat.p);
+            dhk_tile_qv(st, pset->d_la, pset->d_trace, d_first_keep.p, pile->d_off, npr, tsp, d_cov.p, maxtiles, d_qv.p);
+            HIPCHK(hipGetLastError());
+            dev_first.resize((size_t)npr + 1);
+            dev_live.resize((size_t)npr);
+            int32_t fstat = 0;
+            HIPCHK(hipMemcpyAsync(qv.data(), d_qv.p, qv.size(), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(dev_first.data(), d_first_keep.p, sizeof(int32_t) * dev_first.size(), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(dev_live.data(), d_live.p, sizeof(int32_t) * dev_live.size(), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(&fstat, d_stat.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(hipEventRecord(ev[3], st));
+            if (int rc = elapsed(2, 3, ps.ms[2])) return rc;
+            if (fstat != 0) {
+                // a read or a pair beyond the kernel's capacities: the records come to the host after all (the flags the
+                // kernel has set are a subset of what the host path sets: it runs on them unchanged)
+                on_dev = false;
+                pset->la.resize((size_t)pset->d_la_n);
+                HIPCHK(hipMemcpy(pset->la.data(), pset->d_la, sizeof(dh_la) * (size_t)pset->d_la_n, hipMemcpyDeviceToHost));
+                for (dh_la &la : pset->la) la.flags &= ~FLAG_IMPROPER;
+                std::fill(qv.begin(), qv.end(), (uint8_t)255);
+            }
+            lap("funnel + tile qv (device)");
+        }
         bool grouped = true;  // the symmetric wave kernel already emits grouped by A read
-        {
+        if (!on_dev) {
             std::atomic<int> out_of_order{0};
             const dh_la *lp = pset->la.data();
             dh_parallel_for((int64_t)pset->la.size(), 1 << 16, [&](int64_t lo, int64_t hi) {
@@ -1932,7 +1992,7 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
         HIPCHK(hipEventRecord(ev[1], st));
         if (int rc = elapsed(0, 1, ps.ms[1])) return rc;
         LaVec &pl = pset->la;
-        ps.counters[0] = (int64_t)pl.size();
+        ps.counters[0] = on_dev ? pset->d_la_n : (int64_t)pl.size();
         // reads whose overlaps did not fit the per-read slots: their pile-up is skipped with a status
         // (the reference skips a failing pile-up and carries on, package.d:319-363)
         for (int32_t r : pset->ovf_reads) {
@@ -1950,7 +2010,8 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
         //         maxAlignmentError -> chainLocalAlignments -> isValidPileUpAlignment with
         //         allowance = trace spacing (dazzler.d:4066-4141)
         std::vector<int32_t> la_first;
-        {
+        if (on_dev) la_first = dev_first;
+        if (!on_dev) {
             // the funnel of one A read is independent of the others: host threads take read groups
             // (LAs are grouped by aread; inside a group order by bread to get (A, B) pairs)
             // la_first[r] = first LA of A read r (the LAs are grouped by aread): boundaries found in parallel
@@ -2008,10 +2069,8 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
         }
         lap("filter + chain");
         // ---- 4. tile QVs on the device (LAs are sorted by aread)
+        if (!on_dev) {
         HIPCHK(hipEventRecord(ev[0], st));
-        const int32_t npr = pile->n;
-        const int32_t maxtiles = std::max(1, (pile->max_len + tsp - 1) / tsp);
-        std::vector<uint8_t> qv((size_t)npr * maxtiles, 255);
         {
             DevBuf<DhLa> d_las;
             DevBuf<uint16_t> d_tr;
@@ -2032,16 +2091,6 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
             HIPCHK(hipMemcpyAsync(d_first.p, la_first.data(), sizeof(int32_t) * la_first.size(),
                                   hipMemcpyHostToDevice, st));
             HIPCHK(hipMemsetAsync(d_qv.p, 255, qv.size(), st));
-            // cov = max(#allowed reference reads, 4 if pile >= 4) == pile size here (package.d:498-503)
-            // (allowed reference reads = the reads that span the gap, selectAllowedReferenceReadIds :461-472)
-            std::vector<int32_t> cov_of((size_t)npr, 1);
-            for (int32_t a = 0; a < na; a++) {
-                const int32_t r0 = first_read[(size_t)a], r1 = first_read[(size_t)a + 1];
-                int32_t cov = 0;
-                for (int32_t r = r0; r < r1; r++) cov += rkind[(size_t)r] == 0 ? 1 : 0;
-                if (cov < 4 && r1 - r0 >= 4) cov = 4;
-                for (int32_t r = r0; r < r1; r++) cov_of[(size_t)r] = std::max(cov, 1);
-            }
             DevBuf<int32_t> d_cov;
             HIPCHK(d_cov.alloc(cov_of.size()));
             HIPCHK(hipMemcpyAsync(d_cov.p, cov_of.data(), sizeof(int32_t) * cov_of.size(), hipMemcpyHostToDevice, st));
@@ -2059,6 +2108,7 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
                 if (la.flags & FLAG_IMPROPER) la.flags = (la.flags & ~FLAG_IMPROPER) | DH_FLAG_DISABLED;
             }
         });
+        }
         lap("tile qv");
         // ---- 5. reference read per pile-up: findReferenceReadCandidates (package.d:518-568)
         std::vector<int32_t> ref_of((size_t)na, -1);
@@ -2067,8 +2117,11 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
           for (int32_t a = (int32_t)alo; a < (int32_t)ahi; a++) {  // pile-ups are independent
             const int32_t r0 = first_read[(size_t)a], r1 = first_read[(size_t)a + 1];
             bool any = false;
-            for (int32_t i = la_first[(size_t)r0]; i < la_first[(size_t)r1]; i++)
-                if (!(pl[(size_t)i].flags & DH_FLAG_DISABLED)) any = true;
+            if (on_dev)
+                for (int32_t r = r0; r < r1 && !any; r++) any = dev_live[(size_t)r] > 0;
+            else
+                for (int32_t i = la_first[(size_t)r0]; i < la_first[(size_t)r1]; i++)
+                    if (!(pl[(size_t)i].flags & DH_FLAG_DISABLED)) any = true;
             dh_insertion &rec = res->rec[(size_t)pile_of_active[(size_t)a]];
             if (!any) {
                 if (rec.status == DH_PILE_OK) rec.status = DH_PILE_EMPTY_ALIGNMENT;
@@ -2143,28 +2196,56 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
         if (int rc = dh_db_from_slices(ctx, pile, tidx, tbeg, tlen, tgrp, &T)) return rc;
         dbg.dbs.push_back(T);
         {
-            std::vector<int32_t> tmpl_of(pl.size());
-            dh_parallel_for((int64_t)pl.size(), 1 << 16, [&](int64_t lo, int64_t hi) {
-                for (int64_t i = lo; i < hi; i++) {
-                    const int32_t a = pile->h_group[(size_t)pl[(size_t)i].aread];
-                    tmpl_of[(size_t)i] = (active_ok[(size_t)a] && pl[(size_t)i].aread == ref_of[(size_t)a]) ? a : -1;
-                }
-            });
+            std::vector<int32_t> tmpl_of(on_dev ? 0 : pl.size());
+            if (!on_dev)
+                dh_parallel_for((int64_t)pl.size(), 1 << 16, [&](int64_t lo, int64_t hi) {
+                    for (int64_t i = lo; i < hi; i++) {
+                        const int32_t a = pile->h_group[(size_t)pl[(size_t)i].aread];
+                        tmpl_of[(size_t)i] = (active_ok[(size_t)a] && pl[(size_t)i].aread == ref_of[(size_t)a]) ? a : -1;
+                    }
+                });
             HIPCHK(hipEventRecord(ev[0], st));
             dh_db *nT = nullptr;
             int64_t nseg = 0, ncell = 0;
             if (pset->d_trace_len > 0) {
                 // the overlaps of the reference reads and their trace values, gathered on the device
                 std::vector<size_t> tsel;
-                for (size_t i = 0; i < pl.size(); i++)
-                    if (tmpl_of[i] >= 0) tsel.push_back(i);
+                LaVec dev_tl;                 // device funnel: the records of the reference reads, fetched now
+                std::vector<int32_t> dev_tm;  // ... and their templates
+                if (on_dev) {
+                    std::vector<int32_t> sel, doff{0};
+                    for (int32_t a = 0; a < na; a++)
+                        if (active_ok[(size_t)a] && ref_of[(size_t)a] >= 0) {
+                            const int32_t r = ref_of[(size_t)a];
+                            sel.push_back(r);
+                            doff.push_back(doff.back() + (dev_first[(size_t)r + 1] - dev_first[(size_t)r]));
+                            dev_tm.insert(dev_tm.end(), (size_t)(dev_first[(size_t)r + 1] - dev_first[(size_t)r]), a);
+                        }
+                    dev_tl.resize((size_t)doff.back());
+                    if (!sel.empty() && doff.back() > 0) {
+                        DevBuf<int32_t> d_sel, d_doff;
+                        DevBuf<DhLa> d_out;
+                        HIPCHK(d_sel.alloc(sel.size()));
+                        HIPCHK(d_doff.alloc(doff.size()));
+                        HIPCHK(d_out.alloc((size_t)doff.back()));
+                        HIPCHK(hipMemcpyAsync(d_sel.p, sel.data(), sizeof(int32_t) * sel.size(), hipMemcpyHostToDevice, st));
+                        HIPCHK(hipMemcpyAsync(d_doff.p, doff.data(), sizeof(int32_t) * doff.size(), hipMemcpyHostToDevice, st));
+                        dhk_gather_read_records(st, pset->d_la, d_first_keep.p, d_sel.p, d_doff.p, (int32_t)sel.size(), d_out.p);
+                        HIPCHK(hipGetLastError());
+                        HIPCHK(hipMemcpyAsync(dev_tl.data(), d_out.p, sizeof(dh_la) * dev_tl.size(), hipMemcpyDeviceToHost, st));
+                        HIPCHK(hipStreamSynchronize(st));
+                    }
+                    for (size_t i = 0; i < dev_tl.size(); i++) tsel.push_back(i);
+                } else
+                    for (size_t i = 0; i < pl.size(); i++)
+                        if (tmpl_of[i] >= 0) tsel.push_back(i);
                 LaVec tl(tsel.size());
                 std::vector<int32_t> ttm(tsel.size());
                 std::vector<int64_t, PinnedAlloc<int64_t>> desc(3 * tsel.size());
                 int64_t tot = 0;
                 for (size_t q = 0; q < tsel.size(); q++) {
-                    tl[q] = pl[tsel[q]];
-                    ttm[q] = tmpl_of[tsel[q]];
+                    tl[q] = on_dev ? dev_tl[tsel[q]] : pl[tsel[q]];
+                    ttm[q] = on_dev ? dev_tm[tsel[q]] : tmpl_of[tsel[q]];
                     desc[3 * q] = tl[q].toff;
                     desc[3 * q + 1] = tot;
                     desc[3 * q + 2] = tl[q].tlen;
