@@ -555,8 +555,10 @@ k_seg_vote_bp(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R
         lv.w[k] = k * 64 >= hb ? ~0ull : (k * 64 + 64 <= hb ? 0ull : ~0ull << (hb - k * 64));
     }
 #define DMW(i, k) dmat[((int64_t)(i) * (2 * NW) + (k)) * NDP + dp]
+    uint64_t refw = 0;  // template bases i - 1 .. i + 6: one unaligned 8-byte load per 8 matrix rows (the DBs are padded)
     for (int32_t i = 1; i <= rl; i++) {
-        const uint32_t rc = ref[i - 1] & 7u;
+        if (((i - 1) & 7) == 0) __builtin_memcpy(&refw, ref + (i - 1), 8);
+        const uint32_t rc = (uint32_t)(refw >> (8 * ((i - 1) & 7))) & 7u;
         const uint64_t x0 = 0ull - (uint64_t)(rc & 1u), x1 = 0ull - (uint64_t)((rc >> 1) & 1u), x2 = 0ull - (uint64_t)((rc >> 2) & 1u);
         // rows j >= 1 of this matrix row: arithmetic shift of the 64 NW-bit mask
         {
@@ -619,20 +621,42 @@ k_seg_vote_bp(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R
     // ---- traceback (as k_seg_vote): ops back to front into the interleaved op buffer
 #define OPB(t) opbuf[(int64_t)(t)*NDP + dp]
     int32_t i = rl, j = ql, nops = 0;
+    // (the decision words of a matrix row lie nseg * 8 bytes from the next row's: read one step at a time the walk was a
+    // chain of dependent cache misses -- the words of the next PB rows are fetched together; a step stays in its row (op 2)
+    // or moves to the next one)
+    constexpr int PB = NW == 1 ? 8 : 4;
     while (i > 0 && j > 0) {
-        const int32_t Rr = j - i + HALF;
-        const uint64_t z = DMW(i, Rr >> 6), l = DMW(i, NW + (Rr >> 6));
-        const uint8_t op = ((z >> (Rr & 63)) & 1ull) ? 0 : (((l >> (Rr & 63)) & 1ull) ? 2 : 1);
-        if (op == 0) {
-            --i;
-            --j;
-        } else if (op == 2) {
-            --j;
-        } else {
-            --i;
+        uint64_t zr[PB][NW], lr[PB][NW];
+        const int32_t i0 = i;
+#pragma unroll
+        for (int u = 0; u < PB; u++)
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                zr[u][k] = i0 - u > 0 ? DMW(i0 - u, k) : 0ull;
+                lr[u][k] = i0 - u > 0 ? DMW(i0 - u, NW + k) : 0ull;
+            }
+#pragma unroll
+        for (int u = 0; u < PB; u++) {
+            while (i == i0 - u && i > 0 && j > 0) {
+                const int32_t Rr = j - i + HALF;
+                uint64_t z = zr[u][0], l = lr[u][0];
+                if (NW > 1 && (Rr >> 6)) {
+                    z = zr[u][NW - 1];
+                    l = lr[u][NW - 1];
+                }
+                const uint8_t op = ((z >> (Rr & 63)) & 1ull) ? 0 : (((l >> (Rr & 63)) & 1ull) ? 2 : 1);
+                if (op == 0) {
+                    --i;
+                    --j;
+                } else if (op == 2) {
+                    --j;
+                } else {
+                    --i;
+                }
+                OPB(nops) = op;
+                nops++;
+            }
         }
-        OPB(nops) = op;
-        nops++;
     }
     while (i > 0) {
         OPB(nops) = 1;
@@ -685,25 +709,41 @@ k_seg_vote2(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R,
         IB(x) = 0;
     }
     {
+        // The op list is interleaved over the tiles of the launch (OPB(t) = opbuf[t * nseg + dp]: the producer writes op t
+        // of 64 tiles with one store), so consecutive ops of a tile lie nseg bytes apart: one at a time the loop below was a
+        // chain of ~150 dependent cache misses per tile (k_seg_vote2 at 7 % VALU busy, 76 % of its wave cycles waiting,
+        // 4.6 ms per round at configs[2]).  Eight ops are fetched together, and the query bases they consume come from one
+        // unaligned 8-byte load (the DBs carry 64 bytes of padding).
         int32_t x = 0, y = 0;
-        for (int32_t t = nops - 1; t >= 0; t--) {
-            const uint8_t op = OPB(t);
-            if (op == 0) {
-                CS(x) = qry[y++];
-                x++;
-            } else if (op == 1) {
-                CS(x) = 5;
-                x++;
-            } else {
-                const uint8_t v = IN(x), n = v & 7, q = qry[y];
-                uint8_t nv = v;
-                if (n < MAXINS) {
-                    IB(x) = (uint8_t)(IB(x) | ((q & 3) << (2 * n)));
-                    if (q < 4) nv = (uint8_t)(nv | (8u << n));
+        for (int32_t t = nops - 1; t >= 0; t -= 8) {
+            uint8_t ob[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) ob[u] = t - u >= 0 ? OPB(t - u) : (uint8_t)255;
+            uint64_t qw;
+            __builtin_memcpy(&qw, qry + y, 8);
+            const int32_t y0 = y;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint8_t op = ob[u];
+                if (op == 255) break;
+                if (op == 0) {
+                    CS(x) = (uint8_t)(qw >> (8 * (y - y0)));
+                    y++;
+                    x++;
+                } else if (op == 1) {
+                    CS(x) = 5;
+                    x++;
+                } else {
+                    const uint8_t v = IN(x), n = v & 7, q = (uint8_t)(qw >> (8 * (y - y0)));
+                    uint8_t nv = v;
+                    if (n < MAXINS) {
+                        IB(x) = (uint8_t)(IB(x) | ((q & 3) << (2 * n)));
+                        if (q < 4) nv = (uint8_t)(nv | (8u << n));
+                    }
+                    if (n < 5) nv = (uint8_t)((nv & ~7u) | (n + 1));
+                    IN(x) = nv;
+                    y++;
                 }
-                if (n < 5) nv = (uint8_t)((nv & ~7u) | (n + 1));
-                IN(x) = nv;
-                y++;
             }
         }
     }
@@ -745,6 +785,7 @@ k_seg_vote2(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R,
     uint32_t *v = votes + c0 * VSTRIDE;
     atomicAdd(&cdiff[c0], 1u);
     atomicSub(&cdiff[c0 + rl], 1u);
+    uint64_t rw = 0;  // template bases x .. x + 7 (one 8-byte load per 8 columns)
     for (int32_t x = 0; x <= rl; x++) {
         uint32_t *col = v + (int64_t)x * VSTRIDE;
         const uint8_t iv = IN(x), bits = IB(x);
@@ -753,7 +794,8 @@ k_seg_vote2(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R,
         for (int32_t t = 0; t < n; t++)
             if (iv & (8u << t)) atomicAdd(&col[6 + 4 * t + ((bits >> (2 * t)) & 3)], 1u);
         if (x == rl) break;
-        const uint8_t cs = CS(x), rc = ref[x];
+        if ((x & 7) == 0) __builtin_memcpy(&rw, ref + x, 8);
+        const uint8_t cs = CS(x), rc = (uint8_t)(rw >> (8 * (x & 7)));
         if (cs == rc && rc < 4) continue;
         if (cs == 5)
             atomicAdd(&col[4], 1u);
