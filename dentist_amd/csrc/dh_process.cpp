@@ -1957,6 +1957,7 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
             HIPCHK(hipStreamSynchronize(st));
             HIPCHK(hipEventRecord(ev[3], st));
             if (int rc = elapsed(2, 3, ps.ms[2])) return rc;
+            if (getenv("DH_FUNNEL_FALLBACK")) fstat = 1;  // (tests: the fall-back below must give the same result)
             if (fstat != 0) {
                 // a read or a pair beyond the kernel's capacities: the records come to the host after all (the flags the
                 // kernel has set are a subset of what the host path sets: it runs on them unchanged)

@@ -790,3 +790,27 @@ def test_flank_window_equals_whole_contig_flanks_with_a_repeat_outside_the_windo
         assert np.array_equal(b0[r["cons_off"]:r["cons_off"] + r["cons_len"]], ex["consensus"])
         assert (r["left_aepos"], r["right_abpos"], r["ins_begin"], r["ins_end"]) == \
                (ex["left_aepos"], ex["right_abpos"], ex["ins_begin"], ex["ins_end"])
+
+
+def test_device_funnel_host_funnel_and_the_fall_back_agree(gpu_ctx, monkeypatch):
+    """The alignment funnel of computeQVs (error filter, chains per pair, proper-overlap flags) runs on the device for
+    DH-2 (k_pile_funnel); DH_HOST_FUNNEL=1 keeps the records' round trip and the host code, DH_FUNNEL_FALLBACK=1 lets
+    the kernel run and then takes the fall-back the kernel's capacities would trigger.  Noisy reads (20 % errors: pairs
+    with several local alignments, i.e. real chaining work): every field of every record and every consensus base equal."""
+    w = sim.Workload(200_000, 3, 900, 5000, seed=53, err=0.20, spacing=20000, gap_max=900)
+    mo = dentist_amd.default_align_opts(algo=1, width=64)
+    po = dentist_amd.default_process_opts(rounds=2, algo=1, max_reads=0)
+    A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
+    las, trace = gpu_ctx.align_db(A, B, mo)
+    piles = dentist_amd.Pileups(las, w.contigs.off, po)
+    assert len(piles) >= 2
+    out = []
+    for env in (None, "DH_HOST_FUNNEL", "DH_FUNNEL_FALLBACK"):
+        if env:
+            monkeypatch.setenv(env, "1")
+        out.append(dentist_amd.process_pileups(gpu_ctx, A, B, las, trace, piles, po))
+        if env:
+            monkeypatch.delenv(env)
+    assert (out[0][0]["status"] == 0).sum() >= 2
+    for rec, bases in out[1:]:
+        assert rec.tobytes() == out[0][0].tobytes() and np.array_equal(bases, out[0][1])
