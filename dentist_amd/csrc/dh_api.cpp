@@ -893,11 +893,11 @@ static void select_best_range(dh_la *la, size_t nla, int32_t near_ppm)
     // groups of equal bread are independent: host threads take runs of groups
     const std::vector<int64_t> gstart = dh_run_starts((int64_t)nla, [la](int64_t i) { return la[i].bread; });
     dh_parallel_for((int64_t)gstart.size() - 1, 2048, [&](int64_t glo, int64_t ghi) {
-        struct Chain {
-            int64_t score;
+        struct Chain {  // members = ord[k0 .. k1): a chain only ever continues the chain before it (no vector per chain:
+            int64_t score;  // half a million small allocations per chunk from 256 threads were most of the hook's 2.5 ms)
             int32_t bb, be, comp;
             size_t first;
-            std::vector<size_t> members;
+            size_t k0, k1;
         };
         std::vector<size_t> ord;
         std::vector<Chain> chains;
@@ -912,20 +912,20 @@ static void select_best_range(dh_la *la, size_t nla, int32_t near_ppm)
                 bool linked = false;
                 if (!chains.empty()) {
                     Chain &c = chains.back();
-                    const dh_la &p = la[c.members.back()];
+                    const dh_la &p = la[ord[c.k1 - 1]];
                     const int64_t ga = (int64_t)q.abpos - p.aepos, gb = (int64_t)q.bbpos - p.bepos;
                     linked = p.aread == q.aread && (p.flags & DH_FLAG_COMP) == (q.flags & DH_FLAG_COMP) && ga >= -CHAIN_OVERLAP &&
                              gb >= -CHAIN_OVERLAP && ga <= CHAIN_GAP && gb <= CHAIN_GAP && std::llabs(ga - gb) <= CHAIN_INDEL &&
                              q.aepos > p.aepos && q.bepos > p.bepos;
                     if (linked) {
-                        c.members.push_back(ord[k]);
+                        c.k1 = k + 1;
                         c.score += (int64_t)(q.aepos - q.abpos) - 2 * (int64_t)q.diffs;
                         c.be = q.bepos;
                     }
                 }
                 if (!linked)
                     chains.push_back(Chain{(int64_t)(q.aepos - q.abpos) - 2 * (int64_t)q.diffs, q.bbpos, q.bepos,
-                                           (int32_t)(q.flags & DH_FLAG_COMP), ord[k], {ord[k]}});
+                                           (int32_t)(q.flags & DH_FLAG_COMP), ord[k], k, k + 1});
             }
             for (size_t x = 0; x < chains.size(); x++) {
                 const Chain &p = chains[x];
@@ -942,8 +942,8 @@ static void select_best_range(dh_la *la, size_t nla, int32_t near_ppm)
                         if (near_ppm > 0 && p.score * 1000000ll < (int64_t)near_ppm * q.score) drop = true;
                     }
                 }
-                for (size_t m = 0; m < p.members.size(); m++) {
-                    dh_la &l = la[p.members[m]];
+                for (size_t m = 0; m < p.k1 - p.k0; m++) {
+                    dh_la &l = la[ord[p.k0 + m]];
                     l.flags &= ~(DH_FLAG_START | DH_FLAG_NEXT | DH_FLAG_BEST);
                     l.flags |= (m == 0 ? DH_FLAG_START : DH_FLAG_NEXT) | (best ? DH_FLAG_BEST : 0u) | (drop ? DH_FLAG_DISABLED : 0u);
                 }
