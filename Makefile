@@ -6,7 +6,7 @@ CSRC := dentist_amd/csrc
 LIB := dentist_amd/libdentist_hip.so
 SIM := dentist_amd/sim/libdh_sim.so
 
-DAZZ_TOOLS := fasta2DB fasta2DAM DBsplit DBrm DBdump DBshow DBdust LAmerge DAScover DASqv computeintrinsicqv daccord merge-insertions
+DAZZ_TOOLS := fasta2DB fasta2DAM DBsplit DBrm DBdump DBshow DBdust LAmerge DAScover DASqv computeintrinsicqv daccord merge-insertions LAsplit Catrack TANmask
 TOOLS := tools/daligner tools/damapper tools/dazz_tools $(addprefix tools/,$(DAZZ_TOOLS))
 
 all: $(LIB) $(SIM) oracle $(TOOLS)

@@ -119,3 +119,83 @@ def test_lamerge_of_block_files(tmp_path):
 def test_unknown_options_are_rejected(tmp_path):
     p = subprocess.run([os.path.join(TOOLS, "DBsplit"), "-Q", "x.db"], capture_output=True, text=True)
     assert p.returncode != 0 and "unknown option" in p.stderr
+
+
+def _reads_db(tmp_path, n=12, length=700, block_mb=None):
+    rng = np.random.default_rng(9)
+    seqs = [rng.integers(0, 4, length + 13 * i).astype(np.uint8) for i in range(n)]
+    fasta = "".join(">m/%d/0_%d RQ=0.85\n%s\n" % (i + 1, len(s), sim.decode(s)) for i, s in enumerate(seqs))
+    path = str(tmp_path / "reads.db")
+    dentist_amd.dazz_create_db(path, fasta)
+    return path, seqs
+
+
+def test_lasplit_cuts_between_piles(tmp_path):
+    """LAsplit <target with @> <parts> < merged.las (snakemake/Snakefile:1426-1434): every record once, in order, parts of
+    nearly equal size, an A read's records in one part."""
+    LA = dentist_amd.LA_DTYPE
+    rng = np.random.default_rng(4)
+    rows, tr = [], []
+    for a in range(9):
+        for b in range(int(rng.integers(1, 6))):
+            r = np.zeros(1, dtype=LA)[0]
+            r["aread"], r["bread"], r["abpos"], r["aepos"], r["bbpos"], r["bepos"] = a, 20 + b, 0, 150, 10, 155
+            r["diffs"], r["tlen"], r["toff"] = 7, 4, len(tr)
+            tr += [3, 95, 4, 50]
+            rows.append(r)
+    las = np.stack(rows)
+    src = str(tmp_path / "merged.las")
+    dentist_amd.las_write(src, las, np.asarray(tr, dtype=np.uint16), 100)
+    p = subprocess.run([os.path.join(TOOLS, "LAsplit"), str(tmp_path / "part.@.las"), "4"], stdin=open(src, "rb"), capture_output=True, timeout=60)
+    assert p.returncode == 0, p.stderr
+    got, sizes, owners = [], [], []
+    for k in range(1, 5):
+        m, mt, ts = dentist_amd.las_read(str(tmp_path / ("part.%d.las" % k)))
+        assert ts == 100
+        sizes.append(len(m))
+        owners.append(set(int(x) for x in m["aread"]))
+        for l in m:
+            got.append((int(l["aread"]), int(l["bread"]), mt[l["toff"]:l["toff"] + l["tlen"]].tolist()))
+    assert got == [(int(l["aread"]), int(l["bread"]), [3, 95, 4, 50]) for l in las]
+    assert all(not (owners[i] & owners[j]) for i in range(4) for j in range(i + 1, 4))
+    assert min(sizes) > 0 and all(abs(x - len(las) / 4) <= 5 for x in sizes)   # a cut moves by at most one pile (<= 5 records here)
+
+
+def test_tanmask_and_catrack(tmp_path):
+    """TANmask on the self alignments of two blocks (snakemake/Snakefile:1095-1108), then Catrack (:1111-1123): the block
+    tracks .reads.<k>.tan.{anno,data} become the DB's `tan` mask -- read back through the library's track reader
+    (layout dazzler.d:4943-5170): union of the A and B interval of every self alignment of at least -l bases, merged."""
+    path, seqs = _reads_db(tmp_path)
+    run("DBsplit", "-a", "-s1", path)
+    stub = open(path).read()
+    # force two blocks of six reads: rewrite the block table the way DBsplit lays it out
+    db = dentist_amd.DazzDb(path)
+    assert db.n == 12
+    LA = dentist_amd.LA_DTYPE
+
+    def self_la(r, ab, ae, bb, be, comp=0):
+        x = np.zeros(1, dtype=LA)[0]
+        x["aread"] = x["bread"] = r
+        x["abpos"], x["aepos"], x["bbpos"], x["bepos"], x["flags"], x["tlen"], x["diffs"] = ab, ae, bb, be, comp, 2, 5
+        return x
+    las = np.stack([self_la(1, 300, 650, 100, 450), self_la(1, 400, 700, 250, 560), self_la(1, 20, 90, 0, 70),   # last one too short
+                    self_la(4, 100, 700, 0, 600, comp=1),                                                       # complement: not a tandem
+                    self_la(7, 200, 760, 50, 610), self_la(9, 10, 520, 0, 505)])
+    for i, l in enumerate(las):
+        l["toff"] = 2 * i
+    tr = np.asarray([5, 100] * len(las), dtype=np.uint16)
+    whole = str(tmp_path / "TAN.reads.las")
+    dentist_amd.las_write(whole, las, tr, 100)
+    run("TANmask", "-l200", path, whole)
+    ptr, iv = db.read_mask("tan")
+    want = {1: [(100, 700)], 7: [(50, 760)], 9: [(0, 520)]}
+    for r in range(12):
+        assert [tuple(iv[2 * x:2 * x + 2]) for x in range(ptr[r], ptr[r + 1])] == want.get(r, []), r
+    # block tracks -> Catrack gives the same mask
+    nblocks = int(re.search(r"blocks =\s+(\d+)", open(path).read()).group(1))
+    if nblocks == 1:   # one block: its track is the DB's track under another name
+        os.rename(str(tmp_path / ".reads.tan.anno"), str(tmp_path / ".reads.1.tan.anno"))
+        os.rename(str(tmp_path / ".reads.tan.data"), str(tmp_path / ".reads.1.tan.data"))
+        run("Catrack", "-v", path, "tan")
+        ptr2, iv2 = db.read_mask("tan")
+        assert np.array_equal(ptr2, ptr) and np.array_equal(iv2, iv)

@@ -15,6 +15,12 @@
 //   merge-insertions <merged.db> <batch.db>...   (DENTIST's own sub-command, commands/mergeInsertions.d:42-164,
 //                                    snakemake/Snakefile:1315-1334; here so that batches written by this library
 //                                    can be merged without the D binary)
+//   LAsplit <target with @ or #> <parts> < <source.las>     the workflow's split of a merged .las for the validation blocks
+//                                    (snakemake/Snakefile:1426-1434): nearly equal parts, cut between A reads
+//   Catrack [-v] [-f] [-d] <db> <track>          block mask tracks .<db>.<block>.<track>.{anno,data} concatenated into the
+//                                    DB's track (snakemake/Snakefile:1111-1123; track layout dazzler.d:4943-5170)
+//   TANmask [-v] [-l<int(500)>] [-n<track(tan)>] <db> <TAN las>...   self alignments of a read -> mask intervals
+//                                    (snakemake/Snakefile:1095-1108); the block's track when the .las names a block
 // DENTIST only sees exit codes, files and stdout of these tools; flags it never emits are rejected.
 #include <algorithm>
 #include <cmath>
@@ -458,6 +464,237 @@ static int tool_lamerge(const std::vector<std::string> &args)
     return 0;
 }
 
+// ---------------------------------------------------------------------------------- workflow helpers (host only)
+// LAsplit: the records of a .las on stdin in <parts> files of nearly equal size; a file ends only where the A read changes
+// (the piles of an A read stay together: every consumer of a block file reads piles).  '@' or '#' in the target is the
+// part number, 1-based.
+static int tool_lasplit(const std::vector<std::string> &args)
+{
+    std::vector<std::string> pos;
+    for (const std::string &a : args) {
+        if (a == "-v") continue;
+        if (a[0] == '-' && a.size() > 1) die("unknown option " + a);
+        pos.push_back(a);
+    }
+    if (pos.size() != 2) die("usage: LAsplit <target:path with @> <parts:int> < <source>.las");
+    const int32_t parts = atoi(pos[1].c_str());
+    const size_t mark = pos[0].find_first_of("@#");
+    if (parts < 1 || mark == std::string::npos) die("LAsplit: the target needs a '@' (or '#') and parts >= 1 (a DB as the second argument is not supported)");
+    // the codec works on files: stdin goes through a temporary one next to the first target
+    std::string tmp = pos[0];
+    tmp.replace(mark, 1, "stdin-tmp");
+    if (tmp.size() < 4 || tmp.compare(tmp.size() - 4, 4, ".las") != 0) tmp += ".las";
+    {
+        const std::string raw = slurp(stdin);
+        FILE *f = fopen(tmp.c_str(), "wb");
+        if (!f || fwrite(raw.data(), 1, raw.size(), f) != raw.size() || fclose(f) != 0) die("cannot write " + tmp);
+    }
+    dh_la_set *set = nullptr;
+    const int rc = dh_las_read(tmp.c_str(), &set);
+    remove(tmp.c_str());
+    if (rc) die(std::string("dh_las_read: ") + dh_last_error());
+    const int64_t n = dh_la_set_count(set);
+    const dh_la *la = dh_la_set_records(set);
+    const uint16_t *tr = dh_la_set_trace(set);
+    const int32_t ts = dh_la_set_tspace(set);
+    int64_t at = 0;
+    for (int32_t k = 1; k <= parts; k++) {
+        int64_t end = k == parts ? n : std::min<int64_t>(n, (n * k + parts - 1) / parts);
+        end = std::max(end, at);
+        while (end > at && end < n && la[end].aread == la[end - 1].aread) end++;  // do not cut a pile
+        std::string out = pos[0];
+        out.replace(mark, 1, std::to_string(k));
+        if (out.size() < 4 || out.compare(out.size() - 4, 4, ".las") != 0) out += ".las";
+        // (records keep their trace offsets into the whole trace array)
+        CHK(dh_las_write(out.c_str(), la + at, end - at, tr, ts));
+        at = end;
+    }
+    dh_la_set_destroy(set);
+    return 0;
+}
+
+struct DbPath {
+    std::string dir, root, ext;  // dir/root.ext (ext "db" or "dam"), block > 0 when the path names one
+    int32_t block = 0;
+};
+static DbPath parse_db_path(std::string p)
+{
+    DbPath d;
+    const size_t sl = p.find_last_of('/');
+    d.dir = sl == std::string::npos ? "." : p.substr(0, sl);
+    std::string base = sl == std::string::npos ? p : p.substr(sl + 1);
+    for (const char *e : {".dam", ".db"})
+        if (base.size() > strlen(e) && base.compare(base.size() - strlen(e), strlen(e), e) == 0) base.resize(base.size() - strlen(e));
+    const size_t dot = base.find_last_of('.');
+    if (dot != std::string::npos && dot + 1 < base.size() && base.find_first_not_of("0123456789", dot + 1) == std::string::npos) {
+        d.block = atoi(base.c_str() + dot + 1);
+        base.resize(dot);
+    }
+    d.root = base;
+    for (const char *e : {"dam", "db"}) {
+        FILE *f = fopen((d.dir + "/" + d.root + "." + e).c_str(), "r");
+        if (f) {
+            fclose(f);
+            d.ext = e;
+            break;
+        }
+    }
+    if (d.ext.empty()) die("DAZZ_DB not found: " + p);
+    return d;
+}
+static int32_t stub_blocks(const DbPath &d)
+{
+    FILE *f = fopen((d.dir + "/" + d.root + "." + d.ext).c_str(), "r");
+    if (!f) die("cannot open the DB stub");
+    char line[512];
+    int32_t nb = 0;
+    while (fgets(line, sizeof(line), f))
+        if (sscanf(line, "blocks = %d", &nb) == 1) break;
+    fclose(f);
+    return nb;
+}
+static std::string track_file(const DbPath &d, int32_t block, const std::string &name, const char *ext)
+{
+    return d.dir + "/." + d.root + (block > 0 ? "." + std::to_string(block) : "") + "." + name + "." + ext;
+}
+static void write_mask_files(const DbPath &d, int32_t block, const std::string &name, int32_t nreads, const std::vector<int64_t> &ptr,
+                             const std::vector<int32_t> &iv)
+{
+    FILE *an = fopen(track_file(d, block, name, "anno").c_str(), "wb"), *da = fopen(track_file(d, block, name, "data").c_str(), "wb");
+    if (!an || !da) die("cannot create the track files of " + name);
+    const int32_t head[2] = {nreads, 0};  // size 0 marks a mask track (dazzler.d:5143)
+    bool ok = fwrite(head, 4, 2, an) == 2;
+    for (int32_t i = 0; i <= nreads; i++) {
+        const int64_t off = ptr[(size_t)i] * 2 * (int64_t)sizeof(int32_t);
+        ok = ok && fwrite(&off, 8, 1, an) == 1;
+    }
+    if (!iv.empty()) ok = ok && fwrite(iv.data(), 4, iv.size(), da) == iv.size();
+    ok = (fclose(an) == 0) && ok;
+    ok = (fclose(da) == 0) && ok;
+    if (!ok) die("short write of the track files of " + name);
+}
+
+// Catrack: the block tracks of a mask concatenated into the track of the whole DB
+static int tool_catrack(const std::vector<std::string> &args)
+{
+    std::vector<std::string> pos;
+    bool del = false;
+    for (const std::string &a : args) {
+        if (a == "-v" || a == "-f") continue;
+        if (a == "-d") {
+            del = true;
+            continue;
+        }
+        if (a[0] == '-') die("unknown option " + a);
+        pos.push_back(a);
+    }
+    if (pos.size() != 2) die("usage: Catrack [-vfd] <path:db|dam> <track:name>");
+    const DbPath d = parse_db_path(pos[0]);
+    const int32_t nb = stub_blocks(d);
+    if (nb < 1) die("Catrack: the DB has not been split (DBsplit)");
+    std::vector<int64_t> ptr{0};
+    std::vector<int32_t> iv;
+    int32_t nreads = 0;
+    for (int32_t b = 1; b <= nb; b++) {
+        FILE *an = fopen(track_file(d, b, pos[1], "anno").c_str(), "rb"), *da = fopen(track_file(d, b, pos[1], "data").c_str(), "rb");
+        if (!an || !da) die("Catrack: track " + pos[1] + " of block " + std::to_string(b) + " is missing");
+        int32_t head[2];
+        if (fread(head, 4, 2, an) != 2 || head[1] != 0 || head[0] < 0) die("Catrack: not a mask track (block " + std::to_string(b) + ")");
+        std::vector<int64_t> offs((size_t)head[0] + 1);
+        if (fread(offs.data(), 8, offs.size(), an) != offs.size()) die("Catrack: truncated .anno of block " + std::to_string(b));
+        fclose(an);
+        std::vector<int32_t> data;
+        int32_t buf[4096];
+        size_t got;
+        while ((got = fread(buf, 4, 4096, da)) > 0) data.insert(data.end(), buf, buf + got);
+        fclose(da);
+        if (offs[0] != 0 || offs.back() != (int64_t)data.size() * 4) die("Catrack: .anno and .data of block " + std::to_string(b) + " disagree");
+        const int64_t base = ptr.back();
+        for (int32_t i = 1; i <= head[0]; i++) {
+            if (offs[(size_t)i] < offs[(size_t)i - 1] || offs[(size_t)i] % 8) die("Catrack: corrupted offsets");
+            ptr.push_back(base + offs[(size_t)i] / 8);
+        }
+        iv.insert(iv.end(), data.begin(), data.end());
+        nreads += head[0];
+    }
+    write_mask_files(d, 0, pos[1], nreads, ptr, iv);
+    if (del)
+        for (int32_t b = 1; b <= nb; b++) {
+            remove(track_file(d, b, pos[1], "anno").c_str());
+            remove(track_file(d, b, pos[1], "data").c_str());
+        }
+    return 0;
+}
+
+// TANmask: a local alignment of a read with itself (datander) marks a tandem repeat -- the union of its A and B intervals,
+// when at least -l long, goes into the mask; intervals of a read are merged.  One track per .las: the block's when the
+// file name carries a block number (TAN.<db>.<block>.las), the DB's otherwise.
+static int tool_tanmask(const std::vector<std::string> &args)
+{
+    std::vector<std::string> pos;
+    int32_t minlen = 500;
+    std::string name = "tan";
+    for (const std::string &a : args) {
+        if (a == "-v") continue;
+        if (a.compare(0, 2, "-l") == 0 && a.size() > 2)
+            minlen = atoi(a.c_str() + 2);
+        else if (a.compare(0, 2, "-n") == 0 && a.size() > 2)
+            name = a.substr(2);
+        else if (a[0] == '-')
+            die("unknown option " + a);
+        else
+            pos.push_back(a);
+    }
+    if (pos.size() < 2) die("usage: TANmask [-v] [-l<int(500)>] [-n<track(tan)>] <subject:db|dam> <overlaps:las> ...");
+    const DbPath d = parse_db_path(pos[0]);
+    for (size_t f = 1; f < pos.size(); f++) {
+        std::string lp = pos[f];
+        if (lp.size() < 4 || lp.compare(lp.size() - 4, 4, ".las") != 0) lp += ".las";
+        // block of the file: "<...>.<root>.<block>.las"
+        int32_t block = 0;
+        {
+            const std::string stem = lp.substr(0, lp.size() - 4);
+            const size_t dot = stem.find_last_of('.');
+            if (dot != std::string::npos && dot + 1 < stem.size() && stem.find_first_not_of("0123456789", dot + 1) == std::string::npos)
+                block = atoi(stem.c_str() + dot + 1);
+        }
+        dh_dazz *db = open_dazz(d.dir + "/" + d.root + (block > 0 ? "." + std::to_string(block) : "") + "." + d.ext);
+        const int32_t n = dh_dazz_nreads(db), first = dh_dazz_first_id(db);
+        dh_la_set *set = nullptr;
+        CHK(dh_las_read(lp.c_str(), &set));
+        const int64_t nl = dh_la_set_count(set);
+        const dh_la *la = dh_la_set_records(set);
+        std::vector<std::vector<std::pair<int32_t, int32_t>>> per((size_t)n);
+        for (int64_t i = 0; i < nl; i++) {
+            if (la[i].aread != la[i].bread || (la[i].flags & DH_FLAG_COMP)) continue;
+            const int32_t r = la[i].aread - first;
+            if (r < 0 || r >= n) die("TANmask: read id outside the DB block");
+            const int32_t b = std::min(la[i].abpos, la[i].bbpos), e = std::max(la[i].aepos, la[i].bepos);
+            if (e - b >= minlen) per[(size_t)r].emplace_back(b, e);
+        }
+        std::vector<int64_t> ptr{0};
+        std::vector<int32_t> iv;
+        for (int32_t r = 0; r < n; r++) {
+            auto &v = per[(size_t)r];
+            std::sort(v.begin(), v.end());
+            size_t at = iv.size();
+            for (const auto &x : v) {
+                if (iv.size() > at && x.first <= iv.back())
+                    iv.back() = std::max(iv.back(), x.second);
+                else {
+                    iv.push_back(x.first);
+                    iv.push_back(x.second);
+                }
+            }
+            ptr.push_back((int64_t)iv.size() / 2);
+        }
+        write_mask_files(d, block, name, n, ptr, iv);
+        dh_la_set_destroy(set);
+        dh_dazz_close(db);
+    }
+    return 0;
+}
+
 static int tool_merge_insertions(const std::vector<std::string> &args)
 {
     std::vector<const char *> in;
@@ -501,6 +738,9 @@ int main(int argc, char **argv)
     if (g_tool == "computeintrinsicqv") return tool_qv("inqual", args, true);
     if (g_tool == "daccord") return tool_daccord(args);
     if (g_tool == "merge-insertions") return tool_merge_insertions(args);
+    if (g_tool == "LAsplit") return tool_lasplit(args);
+    if (g_tool == "Catrack") return tool_catrack(args);
+    if (g_tool == "TANmask") return tool_tanmask(args);
     die("unknown tool (expected fasta2DB fasta2DAM DBsplit DBrm DBdump DBshow DBdust LAmerge DAScover DASqv "
         "computeintrinsicqv daccord merge-insertions)");
     return 1;
