@@ -407,7 +407,7 @@ __device__ __forceinline__ int32_t hit_cov(const uint64_t *h, int32_t i, int32_t
 // ncand = -1 and redone by the LCAP == 0 instantiation, whose hit buffer is a slab of HBM
 // (gcap entries per block, items taken from item_list) -- same code, same results.
 #ifdef DH_SEED_PROF
-__device__ unsigned long long g_seed_prof[8];
+__device__ unsigned long long g_seed_prof[12];
 #define SP(i) if (tid == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_seed_prof[i], t_ - tp_); tp_ = t_; }
 #else
 #define SP(i)
@@ -696,6 +696,149 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
         else if (tid < N)
             hits[tid] = ~0ull;
         N = 1;  // the network below has nothing left to do
+    } else if (LCAP > 0 && LCAP <= 8192 && (JOIN || LCAP >= 4096)) {  // (not the mapping launches' small variants: registers)
+        // More than one hit per thread (the pile-up all-vs-all: 2 500 hits per read, where the network below was 55 of the
+        // 97 us a block spent per read): the hits of a read cluster on the diagonals of its overlaps, so they are dealt
+        // into 2 x 1024 diagonal buckets (strand, then equal slices of the read's diagonal range: a counting pass, a scan,
+        // a scatter through registers) and every hit takes its rank among the few hits of its bucket.  A bucket that grew
+        // beyond SORT_BMAX hits (a repeat) sends the read through the network instead -- the same order either way.
+        constexpr int E = LCAP >= SEED_THREADS ? LCAP / SEED_THREADS : 1;
+        constexpr int NB = 2048, NBH = NB / 2, SORT_BMAX = 256;
+        constexpr uint64_t DM = (1ull << HIT_DBITS) - 1;
+        static_assert(sizeof(cands) >= NB * sizeof(uint32_t), "bucket counters overlay the candidate array");
+        uint32_t *bcnt = (uint32_t *)cands;  // not in use yet (the join's segment table is done with it)
+        __shared__ unsigned long long s_dmin, s_dmax;
+        __shared__ uint32_t s_bw[SEED_THREADS / LANES];
+        __shared__ uint32_t s_bmax;
+        for (int32_t i = tid; i < NB; i += SEED_THREADS) bcnt[i] = 0;
+        if (tid == 0) {
+            s_dmin = ~0ull;
+            s_dmax = 0ull;
+            s_bmax = 0;
+        }
+        unsigned long long dmin = ~0ull, dmax = 0ull;
+        for (int32_t i = tid; i < n; i += SEED_THREADS) {
+            const unsigned long long d = (hits[i] >> HIT_QBITS) & DM;
+            dmin = d < dmin ? d : dmin;
+            dmax = d > dmax ? d : dmax;
+        }
+        for (int off = LANES / 2; off > 0; off >>= 1) {
+            const unsigned long long a = __shfl_xor(dmin, off, LANES), c = __shfl_xor(dmax, off, LANES);
+            dmin = a < dmin ? a : dmin;
+            dmax = c > dmax ? c : dmax;
+        }
+        __syncthreads();
+        if ((tid & (LANES - 1)) == 0) {
+            atomicMin(&s_dmin, dmin);
+            atomicMax(&s_dmax, dmax);
+        }
+        __syncthreads();
+        // (slices aligned to their width: the hits of a bucket then differ in their low 24 + sh bits only)
+        uint64_t d0 = s_dmin;
+        int sh = 0;
+        while (((s_dmax - d0) >> sh) >= (uint64_t)NBH) {
+            sh++;
+            d0 = s_dmin & ~((1ull << sh) - 1);
+        }
+        auto bucket = [&](uint64_t key) {
+            return (uint32_t)(key >> 63) * NBH + (uint32_t)((((key >> HIT_QBITS) & DM) - d0) >> sh);
+        };
+        for (int32_t i = tid; i < n; i += SEED_THREADS) atomicAdd(&bcnt[bucket(hits[i])], 1u);
+        __syncthreads();
+        // exclusive scan of the counters (4 per thread), largest bucket
+        uint32_t c4[NB / SEED_THREADS], sum = 0, mx = 0;
+#pragma unroll
+        for (int u = 0; u < NB / SEED_THREADS; u++) {
+            c4[u] = bcnt[tid * (NB / SEED_THREADS) + u];
+            sum += c4[u];
+            mx = c4[u] > mx ? c4[u] : mx;
+        }
+        uint32_t incl = sum;
+        for (int off = 1; off < LANES; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off, LANES);
+            if ((tid & (LANES - 1)) >= off) incl += up;
+        }
+        for (int off = LANES / 2; off > 0; off >>= 1) {
+            const uint32_t a = __shfl_xor(mx, off, LANES);
+            mx = a > mx ? a : mx;
+        }
+        if ((tid & (LANES - 1)) == LANES - 1) s_bw[tid / LANES] = incl;
+        if ((tid & (LANES - 1)) == 0) atomicMax(&s_bmax, mx);
+        __syncthreads();
+        uint32_t base = incl - sum;
+        for (int wv = 0; wv < tid / LANES; wv++) base += s_bw[wv];
+#pragma unroll
+        for (int u = 0; u < NB / SEED_THREADS; u++) {
+            bcnt[tid * (NB / SEED_THREADS) + u] = base;
+            base += c4[u];
+        }
+        uint64_t ke[E];
+#pragma unroll
+        for (int u = 0; u < E; u++) {
+            const int32_t i = tid + u * SEED_THREADS;
+            ke[u] = i < n ? hits[i] : 0ull;
+        }
+        __syncthreads();
+        SP(5)
+        if (s_bmax <= (uint32_t)SORT_BMAX) {
+            // scatter: a bucket's hits in arrival order; the counters end up at the buckets' ends
+#pragma unroll
+            for (int u = 0; u < E; u++) {
+                const int32_t i = tid + u * SEED_THREADS;
+                if (i < n) hits[atomicAdd(&bcnt[bucket(ke[u])], 1u)] = ke[u];
+            }
+            __syncthreads();
+            SP(6)
+            uint32_t dst[E];
+#pragma unroll
+            for (int u = 0; u < E; u++) {
+                const int32_t i = tid + u * SEED_THREADS;
+                dst[u] = 0;
+                if (i < n) {
+                    const uint64_t key = hits[i];
+                    ke[u] = key;
+                    const uint32_t bk = bucket(key);
+                    const uint32_t b0 = bk ? bcnt[bk - 1] : 0u, b1 = bcnt[bk];
+                    // (keys are distinct; four loads in flight: one at a time made every compare a full LDS round trip)
+                    uint32_t rk = b0, x = b0;
+                    if (sh <= 32 - HIT_QBITS) {
+                        // the low words decide (half the LDS traffic of this loop, which is bound by it)
+                        const uint32_t *h32 = (const uint32_t *)hits;
+                        const uint32_t key32 = (uint32_t)key;
+                        for (; x + 8 <= b1; x += 8) {
+                            uint32_t h[8];
+#pragma unroll
+                            for (int j = 0; j < 8; j++) h[j] = h32[2 * (x + j)];
+#pragma unroll
+                            for (int j = 0; j < 8; j++) rk += h[j] < key32 ? 1u : 0u;
+                        }
+                    }
+                    for (; x + 8 <= b1; x += 8) {
+                        uint64_t h[8];
+#pragma unroll
+                        for (int j = 0; j < 8; j++) h[j] = hits[x + j];
+#pragma unroll
+                        for (int j = 0; j < 8; j++) rk += h[j] < key ? 1u : 0u;
+                    }
+                    for (; x + 4 <= b1; x += 4) {
+                        const uint64_t h0 = hits[x], h1 = hits[x + 1], h2 = hits[x + 2], h3 = hits[x + 3];
+                        rk += (h0 < key ? 1u : 0u) + (h1 < key ? 1u : 0u) + (h2 < key ? 1u : 0u) + (h3 < key ? 1u : 0u);
+                    }
+                    for (; x < b1; x++) rk += hits[x] < key ? 1u : 0u;
+                    dst[u] = rk;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < E; u++)
+                if (tid + u * SEED_THREADS < n) hits[dst[u]] = ke[u];
+            N = 1;
+        } else {
+#ifdef DH_SEED_PROF
+            if (tid == 0) atomicAdd(&g_seed_prof[10], 1ull);
+#endif
+            for (int32_t i = n + tid; i < N; i += SEED_THREADS) hits[i] = ~0ull;
+        }
     } else {
         for (int32_t i = n + tid; i < N; i += SEED_THREADS) hits[i] = ~0ull;
     }
@@ -784,8 +927,9 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
     bhead_t *bhead = FB_LDS ? (bhead_t *)bhead_l : (bhead_t *)(bsum + (LCAP > 0 ? LCAP : gcap));
     __shared__ bsum_t s_wsum[SEED_THREADS / LANES];
     __shared__ int32_t s_nbig;
-    __shared__ int32_t bigc[64][4];  // candidate band pairs with long hit ranges: (first, end, P, slot)
-    __shared__ unsigned long long s_bestkeys[64];
+    constexpr int NBIG = (LCAP > 0 && LCAP <= 4096) ? 128 : 64;  // (the 8192-entry variant has no LDS to spare)
+    __shared__ int32_t bigc[NBIG][4];  // candidate band pairs with long hit ranges: (first, end, P, slot)
+    __shared__ unsigned long long s_bestkeys[NBIG];
     const int bs = o.band_shift;
     // seed of a band pair [i, e1): first hit of the same-diagonal run (steps <= k) covering most
     // bases; then the candidate record
@@ -871,7 +1015,7 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
             if (e1 - i > 64) {
                 // long range: the whole block picks the seed below
                 const int32_t bslot = atomicAdd(&s_nbig, 1);
-                if (bslot < 64) {
+                if (bslot < NBIG) {
                     bigc[bslot][0] = i;
                     bigc[bslot][1] = e1;
                     bigc[bslot][2] = P;
@@ -882,28 +1026,49 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
             emit_cand(slot, serial_seed(i, e1), P, band);
         }
         __syncthreads();
-        // long ranges: one wavefront per candidate (no block barrier inside), lanes stride over its hits
-        const int32_t nbig = min(s_nbig, 64);
-        for (int32_t bc = tid; bc < nbig; bc += SEED_THREADS) s_bestkeys[bc] = 0ull;
-        __syncthreads();
-        for (int32_t bc = tid / LANES; bc < nbig; bc += SEED_THREADS / LANES) {
+        SP(8)
+        // long ranges: 16 lanes per candidate, 16 consecutive hits at a time.  The first hit of the run a hit belongs to
+        // (a run = hits of one diagonal at most k apart) is the running maximum of the run heads' positions -- a scan
+        // over the 16 lanes plus the carry of the lanes before --, not a walk back from every run end: the walks were a
+        // chain of dependent LDS round trips as long as the longest run of the wavefront (13 of the 97 us per read)
+        constexpr int GW = 16;
+        const int32_t nbig = min(s_nbig, NBIG);
+        const int gl = tid & (GW - 1);
+        for (int32_t bc = tid / GW; bc < nbig; bc += SEED_THREADS / GW) {
             const int32_t i = bigc[bc][0], e1 = bigc[bc][1];
             unsigned long long best = 0ull;
-            // a run ends where the next hit is not linked; its coverage is the largest of the run
-            for (int32_t x = i + (tid & (LANES - 1)); x < e1; x += LANES) {
-                const bool last = x + 1 >= e1 || hitD(hits[x + 1]) != hitD(hits[x]) ||
-                                  (hitQ(hits[x + 1]) - hitQ(hits[x])) > k;
-                if (!last) continue;
-                int32_t rf = x;
-                while (rf > i && hitD(hits[rf]) == hitD(hits[rf - 1]) && (hitQ(hits[rf]) - hitQ(hits[rf - 1])) <= k) rf--;
-                const uint32_t cov = (uint32_t)(k + hitQ(hits[x]) - hitQ(hits[rf]));
-                // largest coverage, then the earliest run
-                const unsigned long long key = ((unsigned long long)cov << 32) | (uint32_t)(0x7FFFFFFF - rf);
-                best = key > best ? key : best;
+            int32_t carry = i;
+            for (int32_t base = i; base < e1; base += GW) {
+                const int32_t x = base + gl;
+                const bool valid = x < e1;
+                const uint64_t h = valid ? hits[x] : 0ull;
+                const uint64_t hp = valid && x > i ? hits[x - 1] : 0ull;
+                const uint64_t hn = x + 1 < e1 ? hits[x + 1] : 0ull;
+                const bool linked = valid && x > i && hitD(h) == hitD(hp) && (hitQ(h) - hitQ(hp)) <= k;
+                int32_t f = valid && !linked ? x : -1;
+                for (int off = 1; off < GW; off <<= 1) {
+                    const int32_t up = __shfl_up(f, off, GW);
+                    if (gl >= off) f = up > f ? up : f;
+                }
+                f = carry > f ? carry : f;
+                carry = __shfl(f, GW - 1, GW);
+                // a run ends where the next hit is not linked; its coverage is the largest of the run
+                const bool last = valid && (x + 1 >= e1 || hitD(hn) != hitD(h) || (hitQ(hn) - hitQ(h)) > k);
+                if (last) {
+                    const uint32_t cov = (uint32_t)(k + hitQ(h) - hitQ(hits[f]));
+                    // largest coverage, then the earliest run
+                    const unsigned long long key = ((unsigned long long)cov << 32) | (uint32_t)(0x7FFFFFFF - f);
+                    best = key > best ? key : best;
+                }
             }
-            if (best) atomicMax(&s_bestkeys[bc], best);
+            for (int off = GW / 2; off > 0; off >>= 1) {
+                const unsigned long long ot = __shfl_xor(best, off, GW);
+                best = ot > best ? ot : best;
+            }
+            if (gl == 0) s_bestkeys[bc] = best;
         }
         __syncthreads();
+        SP(9)
         for (int32_t bc = tid; bc < nbig; bc += SEED_THREADS)
             emit_cand(bigc[bc][3], 0x7FFFFFFF - (int32_t)(uint32_t)s_bestkeys[bc], bigc[bc][2], hitD(hits[bigc[bc][0]]) >> bs);
     } else {
@@ -946,11 +1111,16 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
     __syncthreads();
     for (int32_t c = tid; c < nc; c += SEED_THREADS) {
         const int32_t st = strand_of(c);
+        const int32_t sc = cands[c].score;
+        const int64_t bc = cband[c];
         int32_t rank = 0;
-        for (int32_t x = 0; x < nc; x++)
-            if (strand_of(x) == st && (cands[x].score > cands[c].score ||
-                                       (cands[x].score == cands[c].score && cband[x] < cband[c])))
-                rank++;
+        // (no branches, loads of four candidates in flight: the loop is a chain of LDS round trips otherwise)
+#pragma unroll 4
+        for (int32_t x = 0; x < nc; x++) {
+            const int64_t bx = cband[x];
+            const int32_t sx = cands[x].score;
+            rank += ((int32_t)((bx >> (BSTR - bs)) & 1) == st && (sx > sc || (sx == sc && bx < bc))) ? 1 : 0;
+        }
         crank[c] = rank;
         atomicAdd(&s_ncs[st], 1);
     }
@@ -961,10 +1131,12 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
         int32_t pos = rank;
         if (o.skip_self == 2) {
             pos = 0;
-            for (int32_t x = 0; x < nc; x++)
-                if (strand_of(x) == st && crank[x] < o.max_cand &&
-                    (cands[x].aseq < cands[c].aseq || (cands[x].aseq == cands[c].aseq && crank[x] < rank)))
-                    pos++;
+            const int32_t ac = cands[c].aseq;
+#pragma unroll 4
+            for (int32_t x = 0; x < nc; x++) {
+                const int32_t ax = cands[x].aseq, rx = crank[x];
+                pos += (strand_of(x) == st && rx < o.max_cand && (ax < ac || (ax == ac && rx < rank))) ? 1 : 0;
+            }
         }
         cand_out[(int64_t)(item + st) * o.max_cand + pos] = cands[c];
     }
@@ -2726,10 +2898,10 @@ void dhk_seed(hipStream_t st, int cap, DbView B, IndexView ix, DhOpts o,
 #ifdef DH_SEED_PROF
 void dhk_seed_prof_dump()
 {
-    unsigned long long h[8];
+    unsigned long long h[12];
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_seed_prof), sizeof(h));
-    fprintf(stderr, "[seed prof] blocks %llu: lookup %.1f sort %.1f bcov %.1f bands %.1f rank %.1f us/block\n", h[7], h[0] / 100.0 / h[7], h[1] / 100.0 / h[7], h[2] / 100.0 / h[7], h[3] / 100.0 / h[7], h[4] / 100.0 / h[7]);
-    unsigned long long z[8] = {0};
+    fprintf(stderr, "[seed prof] blocks %llu: lookup %.1f sort %.1f bcov %.1f bands %.1f rank %.1f us/block (dev slots: %.1f %.1f | %.1f %.1f; %llu reads through the network)\n", h[7], h[0] / 100.0 / h[7], h[1] / 100.0 / h[7], h[2] / 100.0 / h[7], h[3] / 100.0 / h[7], h[4] / 100.0 / h[7], h[5] / 100.0 / h[7], h[6] / 100.0 / h[7], h[8] / 100.0 / h[7], h[9] / 100.0 / h[7], h[10]);
+    unsigned long long z[12] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_seed_prof), z, sizeof(z));
 }
 #endif
