@@ -12,16 +12,16 @@
 #define LANES 64
 
 #ifdef DH_SEED_PROF
-__device__ unsigned long long g_join_prof[8];
+__device__ unsigned long long g_join_prof[12];
 #define JP(i) if (tid == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_join_prof[i], t_ - tp_); tp_ = t_; }
 extern "C" void dhk_join_prof_dump()
 {
-    unsigned long long h[8];
+    unsigned long long h[12];
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_join_prof), sizeof(h));
     if (h[7])
         fprintf(stderr, "[join prof] blocks %llu: gather %.1f chain %.1f count %.1f reserve %.1f emit %.1f us/block\n", h[7],
                 h[0] / 100.0 / h[7], h[1] / 100.0 / h[7], h[2] / 100.0 / h[7], h[3] / 100.0 / h[7], h[4] / 100.0 / h[7]);
-    unsigned long long z[8] = {0};
+    unsigned long long z[12] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_join_prof), z, sizeof(z));
 }
 #else
@@ -183,8 +183,8 @@ __global__ void __launch_bounds__(JOIN_THREADS)
 k_join(JoinView jv, DbView B, DhOpts o, const int64_t *__restrict__ goff, int32_t sepv)
 {
     __shared__ uint64_t keys[CAP];
-    __shared__ uint32_t head[CAP];  // bucket -> last inserted entry + 1 (0 = empty)
-    __shared__ uint16_t nxt[CAP];   // entry -> previous entry of its bucket + 1
+    __shared__ uint32_t head[CAP];  // bucket -> end of its range of `keys` (start = the end of the bucket before it)
+    __shared__ uint16_t nhv[CAP];   // hits of an entry taken as B side (pass 1), so that pass 2 reserves them at once
     __shared__ int64_t lgoff[JOIN_MAX_READS];
     __shared__ int32_t llen[JOIN_MAX_READS];
     __shared__ uint32_t cnt[JOIN_MAX_READS], roff[JOIN_MAX_READS];
@@ -226,13 +226,55 @@ k_join(JoinView jv, DbView B, DhOpts o, const int64_t *__restrict__ goff, int32_
         if (tid == 0) atomicOr(jv.status, DH_ST_JOIN_OVERFLOW);
         return;
     }
-    // ---- chain the entries by bucket
-    for (int32_t i = tid; i < n; i += JOIN_THREADS) {
-        const uint32_t hb = join_bucket<CAP>((uint32_t)(keys[i] >> 32));
-        nxt[i] = (uint16_t)atomicExch(&head[hb], (uint32_t)i + 1u);
+    // ---- the entries bucket by bucket (counts, scan, scatter through registers): a bucket is then a contiguous range of
+    // `keys` whose loads do not depend on each other -- as chains (entry -> previous entry of its bucket) every step of a
+    // walk was an LDS round trip, and a wavefront walks as long as its longest bucket (the true k-mers' ~coverage copies)
+    for (int32_t i = tid; i < n; i += JOIN_THREADS) atomicAdd(&head[join_bucket<CAP>((uint32_t)(keys[i] >> 32))], 1u);
+    __syncthreads();
+    {
+        constexpr int PER = CAP / JOIN_THREADS;
+        uint32_t c[PER], sum = 0;
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            c[u] = head[tid * PER + u];
+            sum += c[u];
+        }
+        uint32_t tot;
+        uint32_t at = block_excl_scan<JOIN_THREADS>(sum, tid, s_w, &tot);
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            head[tid * PER + u] = at;
+            at += c[u];
+        }
+        uint64_t ke[PER];
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int32_t i = tid + u * JOIN_THREADS;
+            ke[u] = i < n ? keys[i] : 0ull;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PER; u++)
+            if (tid + u * JOIN_THREADS < n) keys[atomicAdd(&head[join_bucket<CAP>((uint32_t)(ke[u] >> 32))], 1u)] = ke[u];
     }
     __syncthreads();
     JP(1)
+    // the entries of bucket hb, four at a time (loads past the end read the last entry again and are masked: a branch
+    // per load made every one of them a round trip of its own); fn(key of an entry)
+#define JOIN_WALK(canon_, BODY)                                                                      \
+    {                                                                                                \
+        const uint32_t hb_ = join_bucket<CAP>(canon_);                                               \
+        const uint32_t b1_ = head[hb_];                                                              \
+        for (uint32_t t_ = hb_ ? head[hb_ - 1] : 0u; t_ < b1_; t_ += 4) {                            \
+            uint64_t kk_[4];                                                                         \
+            _Pragma("unroll") for (int j_ = 0; j_ < 4; j_++) kk_[j_] = keys[min(t_ + j_, b1_ - 1)];  \
+            _Pragma("unroll") for (int j_ = 0; j_ < 4; j_++) {                                       \
+                const uint64_t ka = kk_[j_];                                                         \
+                if (t_ + j_ >= b1_ || (uint32_t)(ka >> 32) != canon_) continue;                      \
+                BODY                                                                                 \
+            }                                                                                        \
+        }                                                                                            \
+    }
     const int32_t tcap = o.tcap;
     const int32_t k = o.k;
     // walk of entry i taken as the B side: fn(a key) for every entry of the same canonical k-mer (itself included)
@@ -248,28 +290,24 @@ k_join(JoinView jv, DbView B, DhOpts o, const int64_t *__restrict__ goff, int32_
             const int32_t brl = (int32_t)(key >> 21) & (JOIN_MAX_READS - 1);
             const int32_t R = r0 + brl;
             int32_t n_same = 0, n_opp = 0, k_same = 0, k_opp = 0;
-            for (uint32_t j = head[join_bucket<CAP>(canon)]; j; j = nxt[j - 1]) {
-                const uint64_t ka = keys[j - 1];
-                if ((uint32_t)(ka >> 32) != canon) continue;
+            JOIN_WALK(canon, {
                 const bool same = ((uint32_t)(ka >> 31) & 1u) == ori;
                 const int32_t Aq = r0 + ((int32_t)(ka >> 21) & (JOIN_MAX_READS - 1));
                 bool keep = true;
                 if (o.skip_self == 1) keep = Aq != R;
                 if (o.skip_self == 2) keep = Aq != R && ((Aq < R) == (((Aq + R) & 1) == 0));
-                if (same) {
-                    n_same++;
-                    k_same += keep ? 1 : 0;
-                } else {
-                    n_opp++;
-                    k_opp += keep ? 1 : 0;
-                }
-            }
+                n_same += same ? 1 : 0;
+                k_same += same && keep ? 1 : 0;
+                n_opp += same ? 0 : 1;
+                k_opp += !same && keep ? 1 : 0;
+            })
             // a k-mer occurring more than tcap times in an orientation class yields no hits of that class (its own
             // occurrence counts, as an index entry does)
             const bool dof = n_same <= tcap && (o.strands & 1);
             const bool dor = (pal ? n_same <= tcap : (n_opp >= 1 && n_opp <= tcap)) && (o.strands & 2);
             const int32_t nh = (dof ? k_same : 0) + (dor ? (pal ? k_same : k_opp) : 0);
             dmask |= ((dof ? 1u : 0u) | (dor ? 2u : 0u)) << (2 * slot);
+            nhv[i] = (uint16_t)nh;
             if (nh) atomicAdd(&cnt[brl], (uint32_t)nh);
         }
     }
@@ -307,10 +345,9 @@ k_join(JoinView jv, DbView B, DhOpts o, const int64_t *__restrict__ goff, int32_
             const int32_t q = (int32_t)(key & (JOIN_MAX_LEN - 1));
             const int32_t R = r0 + brl;
             const int32_t qrev = llen[brl] - k - q;  // position on the reverse-complemented read
-            uint64_t *dst = jv.hits + base + roff[brl];
-            for (uint32_t j = head[join_bucket<CAP>(canon)]; j; j = nxt[j - 1]) {
-                const uint64_t ka = keys[j - 1];
-                if ((uint32_t)(ka >> 32) != canon) continue;
+            // (one returning atomic per entry, not one per hit: each was a round trip in front of its store)
+            uint64_t *dst = jv.hits + base + roff[brl] + atomicAdd(&cnt[brl], (uint32_t)nhv[i]);
+            JOIN_WALK(canon, {
                 const bool same = ((uint32_t)(ka >> 31) & 1u) == ori;
                 const int32_t arl = (int32_t)(ka >> 21) & (JOIN_MAX_READS - 1);
                 const int32_t Aq = r0 + arl;
@@ -319,13 +356,13 @@ k_join(JoinView jv, DbView B, DhOpts o, const int64_t *__restrict__ goff, int32_
                 const int64_t gv = lgoff[arl] + (int64_t)(ka & (JOIN_MAX_LEN - 1));
                 if (dof && (same || pal)) {
                     const int64_t D = gv + sepv - q;
-                    dst[atomicAdd(&cnt[brl], 1u)] = ((uint64_t)D << 24) | (uint32_t)q;
+                    *dst++ = ((uint64_t)D << 24) | (uint32_t)q;
                 }
                 if (dor && (!same || pal)) {
                     const int64_t D = gv + sepv - qrev;
-                    dst[atomicAdd(&cnt[brl], 1u)] = (1ull << 63) | ((uint64_t)D << 24) | (uint32_t)qrev;
+                    *dst++ = (1ull << 63) | ((uint64_t)D << 24) | (uint32_t)qrev;
                 }
-            }
+            })
         }
     }
 #ifdef DH_SEED_PROF
@@ -334,6 +371,8 @@ k_join(JoinView jv, DbView B, DhOpts o, const int64_t *__restrict__ goff, int32_
     if (tid == 0) atomicAdd(&g_join_prof[7], 1ull);
 #endif
 }
+
+#undef JOIN_WALK
 
 template __global__ void k_join<JOIN_CAP>(JoinView, DbView, DhOpts, const int64_t *, int32_t);
 

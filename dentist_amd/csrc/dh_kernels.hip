@@ -696,14 +696,17 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
         else if (tid < N)
             hits[tid] = ~0ull;
         N = 1;  // the network below has nothing left to do
-    } else if (LCAP > 0 && LCAP <= 8192 && (JOIN || LCAP >= 4096)) {  // (not the mapping launches' small variants: registers)
+    } else if (LCAP == 0 || (LCAP <= 8192 && (JOIN || LCAP >= 4096))) {  // (not the mapping launches' small variants: registers)
         // More than one hit per thread (the pile-up all-vs-all: 2 500 hits per read, where the network below was 55 of the
         // 97 us a block spent per read): the hits of a read cluster on the diagonals of its overlaps, so they are dealt
         // into 2 x 1024 diagonal buckets (strand, then equal slices of the read's diagonal range: a counting pass, a scan,
         // a scatter through registers) and every hit takes its rank among the few hits of its bucket.  A bucket that grew
         // beyond SORT_BMAX hits (a repeat) sends the read through the network instead -- the same order either way.
+        // The HBM variant (the few reads with more hits than any LDS buffer holds) scatters into the slab's prefix-sum area
+        // instead of registers; its network is a chain of global round trips per exchange (8 ms for 4 reads of a
+        // configs[2] part), so its buckets may grow further before it is the better choice.
         constexpr int E = LCAP >= SEED_THREADS ? LCAP / SEED_THREADS : 1;
-        constexpr int NB = 2048, NBH = NB / 2, SORT_BMAX = 256;
+        constexpr int NB = 2048, NBH = NB / 2, SORT_BMAX = LCAP == 0 ? 2048 : 256;
         constexpr uint64_t DM = (1ull << HIT_DBITS) - 1;
         static_assert(sizeof(cands) >= NB * sizeof(uint32_t), "bucket counters overlay the candidate array");
         uint32_t *bcnt = (uint32_t *)cands;  // not in use yet (the join's segment table is done with it)
@@ -773,14 +776,39 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
             base += c4[u];
         }
         uint64_t ke[E];
+        if (LCAP > 0) {
 #pragma unroll
-        for (int u = 0; u < E; u++) {
-            const int32_t i = tid + u * SEED_THREADS;
-            ke[u] = i < n ? hits[i] : 0ull;
+            for (int u = 0; u < E; u++) {
+                const int32_t i = tid + u * SEED_THREADS;
+                ke[u] = i < n ? hits[i] : 0ull;
+            }
         }
         __syncthreads();
         SP(5)
-        if (s_bmax <= (uint32_t)SORT_BMAX) {
+        if (LCAP == 0 && s_bmax <= (uint32_t)SORT_BMAX) {
+            uint64_t *tmp = hits + gcap;  // the block's prefix sums live here later
+            for (int32_t i = tid; i < n; i += SEED_THREADS) {
+                const uint64_t key = hits[i];
+                tmp[atomicAdd(&bcnt[bucket(key)], 1u)] = key;
+            }
+            __syncthreads();
+            for (int32_t i = tid; i < n; i += SEED_THREADS) {
+                const uint64_t key = tmp[i];
+                const uint32_t bk = bucket(key);
+                const uint32_t b0 = bk ? bcnt[bk - 1] : 0u, b1 = bcnt[bk];
+                uint32_t rk = b0, x = b0;
+                for (; x + 8 <= b1; x += 8) {
+                    uint64_t h[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) h[j] = tmp[x + j];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) rk += h[j] < key ? 1u : 0u;
+                }
+                for (; x < b1; x++) rk += tmp[x] < key ? 1u : 0u;
+                hits[rk] = key;
+            }
+            N = 1;
+        } else if (LCAP > 0 && s_bmax <= (uint32_t)SORT_BMAX) {
             // scatter: a bucket's hits in arrival order; the counters end up at the buckets' ends
 #pragma unroll
             for (int u = 0; u < E; u++) {
@@ -1012,7 +1040,7 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
             if (P < o.hmin || P < Pm1 || P <= Pp1) continue;
             const int32_t slot = atomicAdd(&s_nc, 1);
             if (slot >= 2 * SEED_CCAP) continue;
-            if (e1 - i > 64) {
+            if (e1 - i > 16) {
                 // long range: the whole block picks the seed below
                 const int32_t bslot = atomicAdd(&s_nbig, 1);
                 if (bslot < NBIG) {
@@ -2900,7 +2928,7 @@ void dhk_seed_prof_dump()
 {
     unsigned long long h[12];
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_seed_prof), sizeof(h));
-    fprintf(stderr, "[seed prof] blocks %llu: lookup %.1f sort %.1f bcov %.1f bands %.1f rank %.1f us/block (dev slots: %.1f %.1f | %.1f %.1f; %llu reads through the network)\n", h[7], h[0] / 100.0 / h[7], h[1] / 100.0 / h[7], h[2] / 100.0 / h[7], h[3] / 100.0 / h[7], h[4] / 100.0 / h[7], h[5] / 100.0 / h[7], h[6] / 100.0 / h[7], h[8] / 100.0 / h[7], h[9] / 100.0 / h[7], h[10]);
+    fprintf(stderr, "[seed prof] blocks %llu: lookup %.1f sort %.1f bcov %.1f bands %.1f rank %.1f us/block (of the sort: buckets %.1f scatter %.1f; of the bands: heads %.1f long ranges %.1f; %llu reads through the network)\n", h[7], h[0] / 100.0 / h[7], h[1] / 100.0 / h[7], h[2] / 100.0 / h[7], h[3] / 100.0 / h[7], h[4] / 100.0 / h[7], h[5] / 100.0 / h[7], h[6] / 100.0 / h[7], h[8] / 100.0 / h[7], h[9] / 100.0 / h[7], h[10]);
     unsigned long long z[12] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_seed_prof), z, sizeof(z));
 }

@@ -320,11 +320,28 @@ k_compact_sym(const DhLa *__restrict__ slots, const uint16_t *__restrict__ tr_sl
         la_out[l0 + rank] = la;
     }
     __syncthreads();
-    for (uint32_t x = 0; x < n; x++) {
-        const int32_t xl = stl[x];
-        const uint16_t *src = tr_slots + (int64_t)ssl[x] * trmax + sso[x];
-        uint16_t *dst = tr_out + t0 + sto[x];
-        for (int32_t e = lane; e < xl; e += 64) dst[e] = src[e];
+    // trace pairs, eight records at a time: their loads are in flight together (a record of the pile-up stage has ~50
+    // values, so one record per step was one dependent memory round trip per record with most of it idle)
+    for (uint32_t x0 = 0; x0 < n; x0 += 8) {
+        uint16_t v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t x = x0 + j;
+            v[j] = 0;
+            if (x < n && lane < stl[x]) v[j] = tr_slots[(int64_t)ssl[x] * trmax + sso[x] + lane];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t x = x0 + j;
+            if (x < n && lane < stl[x]) tr_out[t0 + sto[x] + lane] = v[j];
+        }
+        for (uint32_t x = x0; x < min(n, x0 + 8); x++) {
+            const int32_t xl = stl[x];
+            if (xl <= 64) continue;
+            const uint16_t *src = tr_slots + (int64_t)ssl[x] * trmax + sso[x];
+            uint16_t *dst = tr_out + t0 + sto[x];
+            for (int32_t e = lane + 64; e < xl; e += 64) dst[e] = src[e];
+        }
     }
 }
 
