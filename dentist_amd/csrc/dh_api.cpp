@@ -1687,10 +1687,22 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
                     SCR(30, d_fscr2, (size_t)ctx->ncu * DH_SEED_FSCR_BLOCKS_PER_CU * DH_SEED_FSCR_WORDS)
                     HIPCHK(hipMemcpyAsync(d_mid, mid.data(), sizeof(int32_t) * mid.size(), hipMemcpyHostToDevice, st));
                     HIPCHK(hipMemsetAsync(d_queue + 1, 0, sizeof(uint32_t), st));
+#ifdef DH_SEED_PROF
+                    if (getenv("DH_TRACE")) {
+                        fprintf(stderr, "(first tier) ");
+                        dhk_seed_prof_dump();
+                    }
+#endif
                     dhk_seed_join(st, 8192, bv, iv, dopt, jv, (int32_t)item0, ni, candbase, ncandbase, nhitsbase, d_status,
                                   d_queue + 1, ctx->ncu, d_fscr2, d_mid, (int32_t)mid.size());
                     HIPCHK(hipGetLastError());
                     HIPCHK(hipStreamSynchronize(st));  // mid goes out of scope
+#ifdef DH_SEED_PROF
+                    if (getenv("DH_TRACE")) {
+                        fprintf(stderr, "(8192-entry tier) ");
+                        dhk_seed_prof_dump();
+                    }
+#endif
                 }
                 if (getenv("DH_TRACE"))
                     fprintf(stderr, "[seeds] join tiers: %zu reads redone with 8192 entries, %zu from HBM\n", mid.size(), huge.size());
