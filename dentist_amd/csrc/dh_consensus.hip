@@ -674,9 +674,24 @@ k_seg_vote_bp(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R
 }
 
 // K8a (second half): per-column view of every tile from its op list, canonical indel placement,
-// votes.  The per-thread column arrays live in LDS ([column][lane], one byte per entry:
-// conflict-free) -- as private arrays they sat in scratch memory and every one of the ~700
-// dependent accesses of a tile paid an HBM-backed round trip.
+// votes.  The per-thread column arrays live in LDS (one byte per entry) -- as private arrays they sat in scratch
+// memory and every one of the ~700 dependent accesses of a tile paid an HBM-backed round trip.  A lane's three arrays
+// are a row of the block's LDS ([lane][array][column], row stride an odd number of 8-byte words: lanes on the same
+// column hit different banks), so that the passes after the op list read EIGHT columns with one load and go to single
+// bytes only where a column holds an indel: column by column ([column][lane]) each of the ~400 reads of a tile was
+// an LDS round trip in front of a branch (6 wavefronts per CU, 70 % of the wave cycles waiting).
+// bytes of a lane's row: 3 arrays of seg_vote2_arr(ncolmax) bytes + padding
+__host__ __device__ inline int32_t seg_vote2_arr(int32_t ncolmax) { return (ncolmax + 2 + 7) & ~7; }
+__host__ __device__ inline int32_t seg_vote2_row(int32_t ncolmax)
+{
+    const int32_t s = 3 * seg_vote2_arr(ncolmax);
+    return ((s >> 3) & 1) ? s : s + 8;
+}
+__device__ __forceinline__ bool has_byte5(uint64_t w)
+{
+    const uint64_t t = w ^ 0x0505050505050505ull;
+    return (((t - 0x0101010101010101ull) & ~t) & 0x8080808080808080ull) != 0ull;
+}
 __global__ void __launch_bounds__(64)
 k_seg_vote2(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R,
             const uint8_t *__restrict__ rrc, const int64_t *__restrict__ voff,
@@ -698,15 +713,19 @@ k_seg_vote2(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R,
     // count (0..5, 5 = more than MAXINS) in bits 0-2, bits 3-6 = "base t is one of ACGT";
     // ibp[x]: the first MAXINS inserted bases, 2 bits each.  3 bytes per column keep 6 blocks of 64
     // tiles resident per CU.
-    uint8_t *colst = smem + threadIdx.x;
-    uint8_t *ins = smem + (size_t)(ncolmax + 1) * 64 + threadIdx.x;
-    uint8_t *ibp = smem + (size_t)(2 * ncolmax + 3) * 64 + threadIdx.x;
-#define CS(x) colst[(x)*64]
-#define IN(x) ins[(x)*64]
-#define IB(x) ibp[(x)*64]
-    for (int32_t x = 0; x <= rl; x++) {
-        IN(x) = 0;
-        IB(x) = 0;
+    const int32_t ARR = seg_vote2_arr(ncolmax);
+    uint8_t *colst = smem + (size_t)threadIdx.x * seg_vote2_row(ncolmax);
+    uint8_t *ins = colst + ARR;
+    uint8_t *ibp = ins + ARR;
+#define CS(x) colst[(x)]
+#define IN(x) ins[(x)]
+#define IB(x) ibp[(x)]
+#define CS8(x) (*(const uint64_t *)(colst + (x)))
+#define IN8(x) (*(const uint64_t *)(ins + (x)))
+#define IB8(x) (*(const uint64_t *)(ibp + (x)))
+    for (int32_t x = 0; x <= rl; x += 8) {
+        *(uint64_t *)(ins + x) = 0ull;
+        *(uint64_t *)(ibp + x) = 0ull;
     }
     {
         // The op list is interleaved over the tiles of the launch (OPB(t) = opbuf[t * nseg + dp]: the producer writes op t
@@ -747,34 +766,45 @@ k_seg_vote2(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R,
             }
         }
     }
-    // ---- canonical (leftmost) placement of indels inside homopolymer runs of the template
-    for (int32_t x = 0; x < rl; x++) {
-        if (CS(x) != 5) continue;
-        const uint8_t c = ref[x];
-        int32_t st = x;
-        while (st > 0 && CS(st - 1) == c && ref[st - 1] == c && (IN(st) & 7) == 0) st--;
-        if (st < x) {
-            CS(st) = 5;
-            CS(x) = c;
+    // ---- canonical (leftmost) placement of indels inside homopolymer runs of the template.  A column only ever changes
+    // columns before it (and itself), so the eight bytes of a block stay valid while its columns are visited.
+    for (int32_t xb = 0; xb < rl; xb += 8) {
+        const uint64_t w = CS8(xb);
+        if (!has_byte5(w)) continue;
+        for (int32_t j = 0; j < 8; j++) {
+            const int32_t x = xb + j;
+            if (x >= rl || (uint8_t)(w >> (8 * j)) != 5) continue;
+            const uint8_t c = ref[x];
+            int32_t st = x;
+            while (st > 0 && CS(st - 1) == c && ref[st - 1] == c && (IN(st) & 7) == 0) st--;
+            if (st < x) {
+                CS(st) = 5;
+                CS(x) = c;
+            }
         }
     }
-    for (int32_t x = 1; x <= rl; x++) {
-        const uint8_t v = IN(x);
-        const int32_t n = v & 7;
-        if (n == 0 || n > MAXINS) continue;
-        const uint8_t bits = IB(x), c = bits & 3;
-        // all n inserted bases are the same ACGT base
-        const uint8_t want_valid = (uint8_t)(((1u << n) - 1u) << 3);
-        bool same = (v & want_valid) == want_valid;
-        for (int32_t t = 1; t < n; t++) same = same && ((bits >> (2 * t)) & 3) == c;
-        if (!same) continue;
-        int32_t st = x;
-        while (st > 0 && CS(st - 1) == c && ref[st - 1] == c && (IN(st - 1) & 7) == 0) st--;
-        if (st < x) {
-            IB(st) = bits;
-            IN(st) = v;
-            IN(x) = 0;
-            IB(x) = 0;
+    for (int32_t xb = 0; xb <= rl; xb += 8) {
+        const uint64_t w = IN8(xb);
+        if ((w & 0x0707070707070707ull) == 0ull) continue;
+        for (int32_t j = 0; j < 8; j++) {
+            const int32_t x = xb + j;
+            const uint8_t v = (uint8_t)(w >> (8 * j));
+            const int32_t n = v & 7;
+            if (x < 1 || x > rl || n == 0 || n > MAXINS) continue;
+            const uint8_t bits = IB(x), c = bits & 3;
+            // all n inserted bases are the same ACGT base
+            const uint8_t want_valid = (uint8_t)(((1u << n) - 1u) << 3);
+            bool same = (v & want_valid) == want_valid;
+            for (int32_t t = 1; t < n; t++) same = same && ((bits >> (2 * t)) & 3) == c;
+            if (!same) continue;
+            int32_t st = x;
+            while (st > 0 && CS(st - 1) == c && ref[st - 1] == c && (IN(st - 1) & 7) == 0) st--;
+            if (st < x) {
+                IB(st) = bits;
+                IN(st) = v;
+                IN(x) = 0;
+                IB(x) = 0;
+            }
         }
     }
     // ---- votes, sparse: a column whose read base equals the template base casts no atomic at
@@ -785,28 +815,39 @@ k_seg_vote2(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R,
     uint32_t *v = votes + c0 * VSTRIDE;
     atomicAdd(&cdiff[c0], 1u);
     atomicSub(&cdiff[c0 + rl], 1u);
-    uint64_t rw = 0;  // template bases x .. x + 7 (one 8-byte load per 8 columns)
-    for (int32_t x = 0; x <= rl; x++) {
-        uint32_t *col = v + (int64_t)x * VSTRIDE;
-        const uint8_t iv = IN(x), bits = IB(x);
-        const int32_t ic = iv & 7;
-        const int32_t n = ic < MAXINS ? ic : MAXINS;
-        for (int32_t t = 0; t < n; t++)
-            if (iv & (8u << t)) atomicAdd(&col[6 + 4 * t + ((bits >> (2 * t)) & 3)], 1u);
-        if (x == rl) break;
-        if ((x & 7) == 0) __builtin_memcpy(&rw, ref + x, 8);
-        const uint8_t cs = CS(x), rc = (uint8_t)(rw >> (8 * (x & 7)));
-        if (cs == rc && rc < 4) continue;
-        if (cs == 5)
-            atomicAdd(&col[4], 1u);
-        else if (cs < 4)
-            atomicAdd(&col[cs], 1u);
-        else
-            atomicAdd(&vother[c0 + x], 1u);
+    for (int32_t xb = 0; xb <= rl; xb += 8) {
+        const uint64_t wi = IN8(xb), wb = IB8(xb), wc = CS8(xb);
+        uint64_t rw;  // template bases xb .. xb + 7
+        __builtin_memcpy(&rw, ref + xb, 8);
+        // nothing inserted, every read base the template's a / c / g / t: no vote in these eight columns
+        if (xb + 8 <= rl && wi == 0ull && wc == rw && (rw & 0xFCFCFCFCFCFCFCFCull) == 0ull) continue;
+#pragma unroll
+        for (int32_t j = 0; j < 8; j++) {
+            const int32_t x = xb + j;
+            if (x > rl) break;
+            uint32_t *col = v + (int64_t)x * VSTRIDE;
+            const uint8_t iv = (uint8_t)(wi >> (8 * j)), bits = (uint8_t)(wb >> (8 * j));
+            const int32_t ic = iv & 7;
+            const int32_t n = ic < MAXINS ? ic : MAXINS;
+            for (int32_t t = 0; t < n; t++)
+                if (iv & (8u << t)) atomicAdd(&col[6 + 4 * t + ((bits >> (2 * t)) & 3)], 1u);
+            if (x == rl) break;
+            const uint8_t cs = (uint8_t)(wc >> (8 * j)), rc = (uint8_t)(rw >> (8 * j));
+            if (cs == rc && rc < 4) continue;
+            if (cs == 5)
+                atomicAdd(&col[4], 1u);
+            else if (cs < 4)
+                atomicAdd(&col[cs], 1u);
+            else
+                atomicAdd(&vother[c0 + x], 1u);
+        }
     }
 #undef CS
 #undef IN
 #undef IB
+#undef CS8
+#undef IN8
+#undef IB8
 #undef OPB
 }
 
@@ -1058,7 +1099,7 @@ void dhk_seg_vote(hipStream_t st, const void *segs, int32_t nseg, DbView T, DbVi
         hipLaunchKernelGGL(k_seg_vote, dim3((nseg + 63) / 64), dim3(64), lds, st, (const SegDesc *)segs, nseg,
                            T, R, rrc, voff, dmat, bandmax, opbuf, nops, status);
     }
-    const size_t lds2 = (size_t)(3 * ncolmax + 5) * 64;
+    const size_t lds2 = (size_t)seg_vote2_row(ncolmax) * 64;
     if (lds2 > 65536)
         (void)hipFuncSetAttribute((const void *)k_seg_vote2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     hipLaunchKernelGGL(k_seg_vote2, dim3((nseg + 63) / 64), dim3(64), lds2, st, (const SegDesc *)segs, nseg, T, R,
