@@ -53,7 +53,7 @@ def per_kernel(d):
     res = {}
     for i in order:
         name, kb = per[i]
-        fam = "k_seed" if "k_seed<" in name and "k_seed<0>" not in name else ("k_tile" if name.strip() == "k_tile" else
+        fam = "k_seed" if "k_seed<" in name and "k_seed<0>" not in name else ("k_tile" if name.strip() == "k_tile" or "k_tile<" in name else
                                                                                ("k_seed_redo" if "k_seed<0>" in name else None))
         if fam is None:
             continue
