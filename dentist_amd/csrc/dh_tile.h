@@ -284,6 +284,19 @@ DH_HD uint32_t tile_scan(const Tile &t)
 }
 
 // a tile is done: trace pair, next origin or end of the extension
+// trace pair of a tile: (diffs, B bases) as two u16 values -- one 4-byte store on the device (the slots start on
+// multiples of trmax = 4 (nbmax + 1) values of 4-byte aligned buffers; two 2-byte stores per tile and lane doubled the
+// scattered partial writes the bookkeeping loads queue behind)
+DH_HD void store_pair(uint16_t *pairs, int32_t pidx, uint32_t d, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    *(uint32_t *)(pairs + 2 * pidx) = (d & 0xFFFFu) | (b << 16);
+#else
+    pairs[2 * pidx] = (uint16_t)d;
+    pairs[2 * pidx + 1] = (uint16_t)b;
+#endif
+}
+
 DH_HD void tile_end(Lane &l, const Params &P, const Tile &t)
 {
     Ext &e = l.e;
@@ -319,8 +332,7 @@ DH_HD void tile_end(Lane &l, const Params &P, const Tile &t)
             e.best_nseg = e.ntp + (seg ? 1 : 0);
             e.best_pair1 = kt == 1 ? (seg ? pr : 0u) : e.pair1;
             if (seg && kt > 1) {
-                pairs[2 * pidx] = (uint16_t)dt;
-                pairs[2 * pidx + 1] = (uint16_t)(j - tw);
+                store_pair(pairs, pidx, (uint32_t)dt, (uint32_t)(j - tw));
             }
         }
         l.st = L_EXT_END;
@@ -333,8 +345,7 @@ DH_HD void tile_end(Lane &l, const Params &P, const Tile &t)
     if (kt == 1)
         e.pair1 = ((uint32_t)dt << 16) | (uint32_t)j;
     else {
-        pairs[2 * pidx] = (uint16_t)dt;
-        pairs[2 * pidx + 1] = (uint16_t)j;
+        store_pair(pairs, pidx, (uint32_t)dt, (uint32_t)j);
     }
     const int32_t k = e.a0 - e.b0;
     e.klo = k < e.klo ? k : e.klo;
@@ -515,12 +526,10 @@ DH_HD int32_t finish_pairs(const Lane &l, const Params &P, uint16_t *pairs, int3
     const uint32_t seedp = (nf >= 1 ? e.best_pair1 : 0u) + ((l.roff && nr >= 1) ? c.rv_pair1 : 0u);
     const bool seedslot = nf >= 1 || (l.roff && nr >= 1);
     if (seedslot) {
-        pairs[2 * nbmax] = (uint16_t)(seedp >> 16);
-        pairs[2 * nbmax + 1] = (uint16_t)(seedp & 0xFFFFu);
+        store_pair(pairs, nbmax, seedp >> 16, seedp & 0xFFFFu);
     }
     if (!l.roff && nr >= 1) {  // the reverse tile 1 is an interval of its own
-        pairs[2 * (nbmax - 1)] = (uint16_t)(c.rv_pair1 >> 16);
-        pairs[2 * (nbmax - 1) + 1] = (uint16_t)(c.rv_pair1 & 0xFFFFu);
+        store_pair(pairs, nbmax - 1, c.rv_pair1 >> 16, c.rv_pair1 & 0xFFFFu);
     }
     const int32_t lo_idx = nbmax - nr + l.roff;
     const int32_t hi_idx = nbmax + (nf > (seedslot ? 1 : 0) ? nf : (seedslot ? 1 : 0));
