@@ -518,18 +518,29 @@ k_seg_vote_bp(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R
         int32_t wi = HALF / 64, bi = HALF % 64;  // (NW = 1: word 0, bit 32; NW = 2: word 1, bit 0)
 #pragma unroll
         for (int k = 0; k < QW; k++) s_pl[0][k][lane] = s_pl[1][k][lane] = s_pl[2][k][lane] = 0;
-        for (int32_t j = 0; j < ql; j++) {
-            const uint64_t c = qry[j] & 7u;
-            a0 |= (c & 1u) << bi;
-            a1 |= ((c >> 1) & 1u) << bi;
-            a2 |= ((c >> 2) & 1u) << bi;
-            if (++bi == 64 || j + 1 == ql) {
-                s_pl[0][wi][lane] = a0;
-                s_pl[1][wi][lane] = a1;
-                s_pl[2][wi][lane] = a2;
-                a0 = a1 = a2 = 0;
-                bi = 0;
-                wi++;
+        // eight query bases per (unaligned) load, the next eight on their way: one byte at a time the loop waited for a
+        // global load per base (the DBs carry 64 bytes of padding)
+        uint64_t qnext = 0;
+        if (ql > 0) __builtin_memcpy(&qnext, qry, 8);
+        for (int32_t j0 = 0; j0 < ql; j0 += 8) {
+            const uint64_t qw = qnext;
+            if (j0 + 8 < ql) __builtin_memcpy(&qnext, qry + j0 + 8, 8);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int32_t j = j0 + u;
+                if (j >= ql) break;
+                const uint64_t c = (qw >> (8 * u)) & 7u;
+                a0 |= (c & 1u) << bi;
+                a1 |= ((c >> 1) & 1u) << bi;
+                a2 |= ((c >> 2) & 1u) << bi;
+                if (++bi == 64 || j + 1 == ql) {
+                    s_pl[0][wi][lane] = a0;
+                    s_pl[1][wi][lane] = a1;
+                    s_pl[2][wi][lane] = a2;
+                    a0 = a1 = a2 = 0;
+                    bi = 0;
+                    wi++;
+                }
             }
         }
     }
