@@ -1121,9 +1121,13 @@ struct ChunkCopies {
     // the packed words of the chunk themselves (unshifted) -- k_tile turns them into plane words in place
     uint8_t *pk_w0 = nullptr, *rcpk_w0 = nullptr;
     int64_t pk_words = 0;
+    bool planes = false;  // the copies are plane-packed already (made so straight from the bytes)
 };
+// planes: plane-packed copies for k_tile instead of the 2-bit packed ones (a DH-2 mapping that does not keep the packed
+// words for the transposed pairs): the conversion passes over both copies -- 8 of the 24 GB a chunk of configs[2] moves
+// for its copies -- fall away
 static int chunk_copies(dh_ctx *ctx, dh_db *B, int32_t r0, int32_t r1, bool want_packed, bool need_bytes,
-                        ChunkCopies *out)
+                        ChunkCopies *out, bool planes = false)
 {
     hipStream_t st = ctx->stream;
     const int64_t o0 = B->h_off[(size_t)r0], o1 = B->h_off[(size_t)r1];
@@ -1153,9 +1157,15 @@ static int chunk_copies(dh_ctx *ctx, dh_db *B, int32_t r0, int32_t r1, bool want
     // both sides) are zeroed -- the memset of the whole buffer was 2 GB per chunk of the mapping
     HIPCHK(hipMemsetAsync(d_rcpk, 0, PK_PAD + 8, st));
     HIPCHK(hipMemsetAsync(d_rcpk + pbytes - PK_PAD - 8, 0, PK_PAD + 8, st));
-    dhk_pack2_rc_bounds(st, B->d_off + r0, r1 - r0, a0, d_rcpk + PK_PAD);
-    dhk_pack2(st, B->d_bases + a0, o1 - a0, d_pk + PK_PAD, d_flag + 1);
-    dhk_pack2_rc(st, B->d_bases, B->d_off + r0, r1 - r0, B->max_len, a0, d_rcpk + PK_PAD);
+    if (planes) {
+        dhk_pack2_planes(st, B->d_bases + a0, o1 - a0, d_pk + PK_PAD, d_flag + 1);
+        dhk_pack2_rc_planes(st, B->d_bases, B->d_off + r0, r1 - r0, B->max_len, a0, d_rcpk + PK_PAD);
+    } else {
+        dhk_pack2_rc_bounds(st, B->d_off + r0, r1 - r0, a0, d_rcpk + PK_PAD);
+        dhk_pack2(st, B->d_bases + a0, o1 - a0, d_pk + PK_PAD, d_flag + 1);
+        dhk_pack2_rc(st, B->d_bases, B->d_off + r0, r1 - r0, B->max_len, a0, d_rcpk + PK_PAD);
+    }
+    out->planes = planes;
     HIPCHK(hipGetLastError());
     int32_t flag = 0;
     HIPCHK(hipMemcpyAsync(&flag, d_flag + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -1590,7 +1600,8 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             cc.pk = B->d_pk;
             cc.rcpk = B->d_rcpk;
             cc.has_n = B->has_n != 0;
-        } else if (int rc = chunk_copies(ctx, B, (int32_t)(item0 >> 1), (int32_t)((item0 + ni) >> 1), want_packed, A->has_n != 0, &cc))
+        } else if (int rc = chunk_copies(ctx, B, (int32_t)(item0 >> 1), (int32_t)((item0 + ni) >> 1), want_packed, A->has_n != 0, &cc,
+                                         tiled && want_packed && !res2 && !getenv("DH_PLANES_BY_PASS")))
             return rc;
         const bool packed = want_packed && A->has_n == 0 && !cc.has_n && cc.pk && cc.rcpk;
         if (tiled) {
@@ -1603,8 +1614,10 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
                 HIPCHK(hipMemcpyAsync(d_bpk2, cc.pk_w0 - PK_PAD, pbytes, hipMemcpyDeviceToDevice, st));
                 HIPCHK(hipMemcpyAsync(d_brcpk2, cc.rcpk_w0 - PK_PAD, pbytes, hipMemcpyDeviceToDevice, st));
             }
-            dhk_pk2planes(st, cc.pk_w0, cc.pk_words);
-            dhk_pk2planes(st, cc.rcpk_w0, cc.pk_words);
+            if (!cc.planes) {
+                dhk_pk2planes(st, cc.pk_w0, cc.pk_words);
+                dhk_pk2planes(st, cc.rcpk_w0, cc.pk_words);
+            }
             HIPCHK(hipGetLastError());
         }
         if (deferred) {

@@ -65,6 +65,20 @@ k_revcomp(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, const int6
 // 2 * (g & 3), so a little-endian 8-byte load holds 32 consecutive bases, low bits first.
 // One thread per 8-byte word; flag is raised when a code outside 0..3 is met (such DBs are
 // aligned from the byte arrays instead).  The source is readable 63 bytes past `total` (DB_PAD).
+// PLANES: the word is stored plane-packed for k_tile (dh_tile.h: PlanePair -- low bits of the 32 bases in the low
+// half, high bits in the high half) instead of being converted by a pass of its own over the copy
+__device__ __forceinline__ uint32_t squeeze_even64(uint64_t x)
+{
+    x &= 0x5555555555555555ull;
+    x = (x | (x >> 1)) & 0x3333333333333333ull;
+    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+    return (uint32_t)x;
+}
+__device__ __forceinline__ uint64_t pk_to_planes(uint64_t x) { return (uint64_t)squeeze_even64(x) | ((uint64_t)squeeze_even64(x >> 1) << 32); }
+template <bool PLANES>
 __global__ void __launch_bounds__(256)
 k_pack2(const uint8_t *__restrict__ src, int64_t total, uint64_t *__restrict__ dst,
         int32_t *__restrict__ flag)
@@ -85,9 +99,11 @@ k_pack2(const uint8_t *__restrict__ src, int64_t total, uint64_t *__restrict__ d
             out |= (uint64_t)(c & 3u) << (2 * (8 * q + u));
         }
     }
-    dst[wd] = out;
+    dst[wd] = PLANES ? pk_to_planes(out) : out;
     if (bad) atomicOr(flag, 1);
 }
+template __global__ void k_pack2<false>(const uint8_t *, int64_t, uint64_t *, int32_t *);
+template __global__ void k_pack2<true>(const uint8_t *, int64_t, uint64_t *, int32_t *);
 
 // 2-bit packed reverse complements straight from the forward bytes: sequence s occupies the same base
 // range [off[s], off[s+1]) in the packed copy, mirrored inside it.  One thread per 16-base word of the
@@ -127,6 +143,51 @@ k_pack2_rc(const uint8_t *__restrict__ src, const int64_t *__restrict__ off, int
             atomicOr(&dst[w], out);
         }
     }
+}
+
+// the same copy plane-packed, one thread per 32-base word (= one PlanePair); the words a sequence shares with its
+// neighbours are ORed in (the plane form is a permutation of the packed word's bits, so the parts combine the same way)
+__global__ void __launch_bounds__(256)
+k_pack2_rc_planes(const uint8_t *__restrict__ src, const int64_t *__restrict__ off, int32_t n, int64_t a0,
+                  unsigned long long *__restrict__ dst)
+{
+    const int32_t s = blockIdx.y;
+    if (s >= n) return;
+    const int64_t o = off[s], len = off[s + 1] - o;
+    if (len <= 0) return;
+    const int64_t w0 = (o - a0) >> 5, w1 = (o + len - 1 - a0) >> 5;  // first / last destination word
+    const int64_t sbase = 2 * o + len - 1;                           // source of base g is src[sbase - g]
+    for (int64_t w = w0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w <= w1; w += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t gw = a0 + (w << 5);
+        if (gw >= o && gw + 32 <= o + len) {
+            const uint8_t *A = src + (sbase - gw - 31);
+            uint64_t x0, x1, x2, x3;
+            __builtin_memcpy(&x0, A, 8);       // positions 31 .. 24
+            __builtin_memcpy(&x1, A + 8, 8);   // positions 23 .. 16
+            __builtin_memcpy(&x2, A + 16, 8);  // positions 15 .. 8
+            __builtin_memcpy(&x3, A + 24, 8);  // positions 7 .. 0
+            const uint64_t lo = pack8_rc(__builtin_bswap64(x3)) | (pack8_rc(__builtin_bswap64(x2)) << 16);
+            const uint64_t hi = pack8_rc(__builtin_bswap64(x1)) | (pack8_rc(__builtin_bswap64(x0)) << 16);
+            dst[w] = pk_to_planes(lo | (hi << 32));
+        } else {
+            const int64_t g0 = gw > o ? gw : o, g1 = gw + 32 < o + len ? gw + 32 : o + len;
+            uint64_t out = 0;
+            for (int64_t g = g0; g < g1; g++) out |= (uint64_t)((src[sbase - g] ^ 3u) & 3u) << (2 * (int)(g - gw));
+            atomicOr(&dst[w], (unsigned long long)pk_to_planes(out));
+        }
+    }
+}
+__global__ void __launch_bounds__(256)
+k_pack2_rc_bounds32(const int64_t *__restrict__ off, int32_t n, int64_t a0, uint64_t *__restrict__ dst)
+{
+    const int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int64_t o = off[s], len = off[s + 1] - o;
+    if (len <= 0) return;
+    const int64_t w0 = (o - a0) >> 5, w1 = (o + len - 1 - a0) >> 5;
+    const int64_t g0 = a0 + (w0 << 5), g1 = a0 + (w1 << 5);
+    if (!(g0 >= o && g0 + 32 <= o + len)) dst[w0] = 0;
+    if (!(g1 >= o && g1 + 32 <= o + len)) dst[w1] = 0;
 }
 
 // ------------------------------------------------------------------------------------ K2
@@ -3058,7 +3119,15 @@ void dhk_pack2(hipStream_t st, const uint8_t *src, int64_t total, uint8_t *dst, 
 {
     const int64_t nw = (total + 31) >> 5;
     if (nw <= 0) return;
-    hipLaunchKernelGGL(k_pack2, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, src, total, (uint64_t *)dst,
+    hipLaunchKernelGGL(k_pack2<false>, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, src, total, (uint64_t *)dst,
+                       flag);
+}
+// plane-packed forward / reverse-complement copies of a chunk for k_tile, straight from the bytes
+void dhk_pack2_planes(hipStream_t st, const uint8_t *src, int64_t total, uint8_t *dst, int32_t *flag)
+{
+    const int64_t nw = (total + 31) >> 5;
+    if (nw <= 0) return;
+    hipLaunchKernelGGL(k_pack2<true>, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, src, total, (uint64_t *)dst,
                        flag);
 }
 
@@ -3092,6 +3161,19 @@ void dhk_pack2_rc(hipStream_t st, const uint8_t *src, const int64_t *off, int32_
     for (int32_t s0 = 0; s0 < n; s0 += 65535) {
         const int32_t cnt = n - s0 < 65535 ? n - s0 : 65535;
         hipLaunchKernelGGL(k_pack2_rc, dim3(gx, cnt), dim3(256), 0, st, src, off + s0, cnt, a0, (uint32_t *)dst);
+    }
+}
+
+void dhk_pack2_rc_planes(hipStream_t st, const uint8_t *src, const int64_t *off, int32_t n, int32_t max_len, int64_t a0,
+                         uint8_t *dst)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_pack2_rc_bounds32, dim3((n + 255) / 256), dim3(256), 0, st, off, n, a0, (uint64_t *)dst);
+    int gx = (max_len / 32 + 255) / 256;
+    gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+    for (int32_t s0 = 0; s0 < n; s0 += 65535) {
+        const int32_t cnt = n - s0 < 65535 ? n - s0 : 65535;
+        hipLaunchKernelGGL(k_pack2_rc_planes, dim3(gx, cnt), dim3(256), 0, st, src, off + s0, cnt, a0, (unsigned long long *)dst);
     }
 }
 
