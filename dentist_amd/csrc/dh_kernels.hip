@@ -765,9 +765,10 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
         // beyond SORT_BMAX hits (a repeat) sends the read through the network instead -- the same order either way.
         // The HBM variant (the few reads with more hits than any LDS buffer holds) scatters into the slab's prefix-sum area
         // instead of registers; its network is a chain of global round trips per exchange (8 ms for 4 reads of a
-        // configs[2] part), so its buckets may grow further before it is the better choice.
+        // configs[2] part).  Ranking costs (n / 512) x bucket loads from L2 per thread, the network ~0.5 ms at 16 384
+        // hits: measured break-even at buckets of ~340 hits.
         constexpr int E = LCAP >= SEED_THREADS ? LCAP / SEED_THREADS : 1;
-        constexpr int NB = 2048, NBH = NB / 2, SORT_BMAX = LCAP == 0 ? 2048 : 256;
+        constexpr int NB = 2048, NBH = NB / 2, SORT_BMAX = LCAP == 0 ? 384 : 256;
         constexpr uint64_t DM = (1ull << HIT_DBITS) - 1;
         static_assert(sizeof(cands) >= NB * sizeof(uint32_t), "bucket counters overlay the candidate array");
         uint32_t *bcnt = (uint32_t *)cands;  // not in use yet (the join's segment table is done with it)

@@ -288,6 +288,41 @@ def test_kmer_join_falls_back_when_a_slice_overflows(gpu_ctx, monkeypatch, capfd
     assert "falling back to the k-mer directory" in capfd.readouterr().err
 
 
+@pytest.mark.parametrize("nreads,rlen,copies,unit,cap", [(9, 5200, 1, 300, None), (3, 2600, 1, 300, None), (4, 5200, 1, 300, "2048"), (24, 5200, 1, 300, None), (64, 1400, 1, 300, None),
+                                                         (9, 5200, 8, 250, None), (9, 5200, 20, 120, "2048")])
+def test_hit_sort_by_diagonal_buckets_and_its_fall_backs(gpu_ctx, monkeypatch, capfd, nreads, rlen, copies, unit, cap):
+    """The seed back end sorts a read's hits by diagonal buckets and ranks inside a bucket (LDS variants: through
+    registers; HBM variant: through its slab); a bucket above its limit (256 / 2048 hits) sends the read through the bitonic
+    network.  Reads that differ by substitutions only put ALL hits of an overlap on one diagonal: a few of them fit LDS
+    with buckets beyond its limit (network); 64 short ones have more hits than LDS holds, in buckets the HBM variant still
+    ranks; two dozen long ones or a tandem repeat in all of them overflow the HBM variant's buckets too -- records, trace values and the
+    hit / candidate counters as the oracle's every time (pytest -s with a -DDH_SEED_PROF build prints the paths taken)."""
+    rng = np.random.default_rng(17 + copies + nreads)
+    u = rng.integers(0, 4, unit).astype(np.uint8)
+    rep = np.concatenate([u if i == 0 else np.where(rng.random(unit) < 0.03, rng.integers(0, 4, unit), u).astype(np.uint8)
+                          for i in range(copies)])
+    base = rng.integers(0, 4, rlen + 800).astype(np.uint8)
+    if copies > 1:
+        base[1500:1500 + min(len(rep), 4000)] = rep[:4000]
+    reads = []
+    for i in range(nreads):
+        a = int(rng.integers(0, 600))
+        r = base[a:a + rlen].copy()
+        e = rng.random(len(r)) < (0.07 if copies == 1 else 0.04)
+        r[e] = rng.integers(0, 4, int(e.sum()))
+        reads.append(r if i % 3 else (3 - r[::-1]).astype(np.uint8))
+    both = grouped_piles(seeds=(71,), sizes=(5,), gid=(0,), extra=(sim.SeqDb.from_list(reads), 2))
+    if cap:
+        monkeypatch.setenv("DH_SEED_CAP", cap)
+    monkeypatch.setenv("DH_TRACE", "1")
+    las, _ = run_both(gpu_ctx, both, both, same=True, tspace=126, skip_self=2, min_len=500, max_la=256, max_cand=256, tcap=200)
+    assert len(las) > 10
+    err = capfd.readouterr().err
+    print(err)
+    if nreads >= 24 or copies > 1:
+        assert "overflow" in err  # reads with more hits than the LDS tiers hold went to the HBM variant
+
+
 def test_edge_cases_empty_short_and_n_reads(gpu_ctx):
     g = sim.genome(5, 30000)
     rd, _ = sim.reads(6, g, 20, 3000)
