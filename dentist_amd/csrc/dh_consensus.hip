@@ -17,6 +17,22 @@
 #include "dh_device.h"
 
 #define MAXINS 4
+// The op list of a tile (the path of its alignment, back to front: 0 = pair, 1 = deletion, 2 = insertion), eight ops to an
+// 8-byte word, the words interleaved over the tiles of the launch: word g of tile dp = opbuf64[g * nseg + dp].  The
+// producers collect eight ops in a register and store them with one (coalesced) store, the consumer fetches a word per
+// eight ops and has the next one on its way -- one op per byte apart by nseg bytes, every op was a store / a load of its own.
+#define OP_WORD(g) ((uint64_t *)opbuf)[(int64_t)(g)*NDP + dp]
+#define OP_PUT(op_)                                         \
+    {                                                       \
+        oacc |= (uint64_t)(uint8_t)(op_) << (8 * (nops & 7)); \
+        nops++;                                             \
+        if ((nops & 7) == 0) {                              \
+            OP_WORD((nops >> 3) - 1) = oacc;                \
+            oacc = 0;                                       \
+        }                                                   \
+    }
+#define OP_FLUSH \
+    if (nops & 7) OP_WORD(nops >> 3) = oacc;
 #define VSTRIDE (6 + 4 * MAXINS)
 #define MAXQV 50
 #define SEG_MAX 250 /* longest tile side the u8 score matrix supports */
@@ -420,8 +436,8 @@ k_seg_vote(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R,
     // ---- traceback: ops are produced back to front into the interleaved op buffer; opbuf row
     // t = op number t counted from the END of the path.
     const int32_t opcap = 2 * SEG_MAX;
-#define OPB(t) opbuf[(int64_t)(t)*NDP + dp]
     int32_t i = rl, j = ql, nops = 0;
+    uint64_t oacc = 0;
     while (i > 0 && j > 0) {
         const int32_t c = j - i + w;
         const uint8_t op = (uint8_t)((DM(i, c >> 4) >> (2 * (c & 15))) & 3u);
@@ -433,23 +449,20 @@ k_seg_vote(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R,
         } else {
             --i;
         }
-        OPB(nops) = op;
-        nops++;
+        OP_PUT(op)
     }
     while (i > 0) {
-        OPB(nops) = 1;
-        nops++;
+        OP_PUT(1)
         --i;
     }
     while (j > 0) {
-        OPB(nops) = 2;
-        nops++;
+        OP_PUT(2)
         --j;
     }
+    OP_FLUSH
     (void)opcap;
     nops_out[dp] = (uint16_t)nops;
 #undef DM
-#undef OPB
 }
 
 // K8a, bit-parallel fill: the same Needleman-Wunsch tile and the same traceback rule as k_seg_vote, for tiles whose band
@@ -630,8 +643,8 @@ k_seg_vote_bp(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R
         }
     }
     // ---- traceback (as k_seg_vote): ops back to front into the interleaved op buffer
-#define OPB(t) opbuf[(int64_t)(t)*NDP + dp]
     int32_t i = rl, j = ql, nops = 0;
+    uint64_t oacc = 0;
     // (the decision words of a matrix row lie nseg * 8 bytes from the next row's: read one step at a time the walk was a
     // chain of dependent cache misses -- the words of the next PB rows are fetched together; a step stays in its row (op 2)
     // or moves to the next one)
@@ -664,24 +677,21 @@ k_seg_vote_bp(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R
                 } else {
                     --i;
                 }
-                OPB(nops) = op;
-                nops++;
+                OP_PUT(op)
             }
         }
     }
     while (i > 0) {
-        OPB(nops) = 1;
-        nops++;
+        OP_PUT(1)
         --i;
     }
     while (j > 0) {
-        OPB(nops) = 2;
-        nops++;
+        OP_PUT(2)
         --j;
     }
+    OP_FLUSH
     nops_out[dp] = (uint16_t)nops;
 #undef DMW
-#undef OPB
 }
 
 // K8a (second half): per-column view of every tile from its op list, canonical indel placement,
@@ -719,7 +729,6 @@ k_seg_vote2(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R,
     const uint8_t *ref = T.bases + T.off[sg.tmpl] + sg.a0;
     const uint8_t *qry = (sg.comp ? rrc : R.bases) + R.off[sg.bseq] + sg.b0;
     const int64_t NDP = nseg;
-#define OPB(t) opbuf[(int64_t)(t)*NDP + dp]
     // colst[x]: base aligned to column x (5 = deleted); ins[x]: bases inserted before column x --
     // count (0..5, 5 = more than MAXINS) in bits 0-2, bits 3-6 = "base t is one of ACGT";
     // ibp[x]: the first MAXINS inserted bases, 2 bits each.  3 bytes per column keep 6 blocks of 64
@@ -739,23 +748,22 @@ k_seg_vote2(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R,
         *(uint64_t *)(ibp + x) = 0ull;
     }
     {
-        // The op list is interleaved over the tiles of the launch (OPB(t) = opbuf[t * nseg + dp]: the producer writes op t
-        // of 64 tiles with one store), so consecutive ops of a tile lie nseg bytes apart: one at a time the loop below was a
-        // chain of ~150 dependent cache misses per tile (k_seg_vote2 at 7 % VALU busy, 76 % of its wave cycles waiting,
-        // 4.6 ms per round at configs[2]).  Eight ops are fetched together, and the query bases they consume come from one
-        // unaligned 8-byte load (the DBs carry 64 bytes of padding).
+        // eight ops per word (OP_WORD), the next word on its way while this one is applied; the query bases the eight ops
+        // consume come from one unaligned 8-byte load (the DBs carry 64 bytes of padding)
+        const uint64_t *opw = (const uint64_t *)opbuf;
         int32_t x = 0, y = 0;
-        for (int32_t t = nops - 1; t >= 0; t -= 8) {
-            uint8_t ob[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) ob[u] = t - u >= 0 ? OPB(t - u) : (uint8_t)255;
+        int32_t g = (nops - 1) >> 3;
+        uint64_t wnext = opw[(int64_t)g * NDP + dp];
+        for (; g >= 0; g--) {
+            const uint64_t ow = wnext;
+            if (g > 0) wnext = opw[(int64_t)(g - 1) * NDP + dp];
             uint64_t qw;
             __builtin_memcpy(&qw, qry + y, 8);
             const int32_t y0 = y;
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const uint8_t op = ob[u];
-                if (op == 255) break;
+            for (int u = 7; u >= 0; u--) {
+                if (8 * g + u >= nops) continue;
+                const uint8_t op = (uint8_t)(ow >> (8 * u));
                 if (op == 0) {
                     CS(x) = (uint8_t)(qw >> (8 * (y - y0)));
                     y++;
@@ -859,7 +867,6 @@ k_seg_vote2(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R,
 #undef CS8
 #undef IN8
 #undef IB8
-#undef OPB
 }
 
 // column -> template map of the vote space (-1 for the spare column after each template): binary

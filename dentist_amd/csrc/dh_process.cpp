@@ -1025,8 +1025,8 @@ static int consensus_round(dh_ctx *ctx, dh_db *T, dh_db *R, const LaVec &las,
             struct { SegDescH *p; } ds;
             struct { uint8_t *p; } fm, ob;
             SCRP(22, ds, (size_t)cnt)
-            SCRP(23, fm, (size_t)cnt * (size_t)(ts + 1) * mrow + (size_t)cnt * 2 * SEG_MAX + (size_t)cnt * 2 + 16)
-            ob.p = fm.p + (size_t)cnt * (size_t)(ts + 1) * mrow;
+            SCRP(23, fm, (size_t)cnt * (size_t)(ts + 1) * mrow + (size_t)cnt * 2 * SEG_MAX + (size_t)cnt * 2 + 32)
+            ob.p = fm.p + (((size_t)cnt * (size_t)(ts + 1) * mrow + 7) & ~(size_t)7);  // op words: 8 ops each, 8-byte aligned
             uint16_t *d_nops = (uint16_t *)(ob.p + (((size_t)cnt * 2 * SEG_MAX + 7) & ~(size_t)7));
             HIPCHK(hipMemcpyAsync(ds.p, segs.data() + s0, sizeof(SegDescH) * (size_t)cnt, hipMemcpyHostToDevice, st));
             dhk_seg_vote(st, ds.p, cnt, T->view(), R->view(), R->d_rc, d_voff.p, (uint32_t *)fm.p, bandmax, wmax, ts,
