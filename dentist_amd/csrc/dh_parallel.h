@@ -1,6 +1,6 @@
 // dh_parallel.h -- a tiny persistent thread pool for the host-side loops between kernel launches
 // (per-read funnels, record sorts).  dh_parallel_for(n, grain, fn) calls fn(lo, hi) on disjoint
-// chunks of [0, n) from up to DH_HOST_THREADS (default min(16, cores)) threads, the caller included,
+// chunks of [0, n) from up to DH_HOST_THREADS (default min(64, cores / ranks of the node)) threads, the caller included,
 // and returns when all chunks are done.  fn must not throw.
 #pragma once
 #include <atomic>
@@ -48,8 +48,13 @@ public:
 private:
     DhPool()
     {
+        // the cores of the box divided among the ranks of this node (LOCAL_WORLD_SIZE, as torchrun sets it), at most 64:
+        // measured on configs[2] with 256 cores -- collect stage 12.0 / 9.5 / 7.5 ms with 16 / 32 / 64 threads
         int want = (int)std::thread::hardware_concurrency();
-        if (want > 16) want = 16;
+        int local = 1;
+        if (const char *e = getenv("LOCAL_WORLD_SIZE")) local = atoi(e) > 0 ? atoi(e) : 1;
+        want /= local;
+        if (want > 64) want = 64;
         if (const char *e = getenv("DH_HOST_THREADS")) want = atoi(e);
         if (want < 1) want = 1;
         nthreads_ = want;
