@@ -177,56 +177,48 @@ static int collect_filter_units(dh_la *las, int64_t n, const int64_t *contig_off
     // alignments disabled by the running stage (summed over the host threads)
     std::atomic<int64_t> newly{0};
     auto stage_done = [&](int s) { cnt[s] = newly.exchange(0); };
-    // 1-3: per-alignment predicates
-    dh_parallel_for(n, 4096, [&](int64_t lo, int64_t hi) {
-        int64_t local = 0;
-        for (int64_t i = lo; i < hi; i++) {
-            dh_la &l = las[i];
-            if (l.flags & DH_FLAG_DISABLED) continue;
-            if ((int64_t)l.diffs * 1000000 > (int64_t)o.max_align_err_ppm * (covered ? covered[i] : (int64_t)(l.aepos - l.abpos))) {
-                l.flags |= DH_FLAG_DISABLED;
-                local++;
-            }
-        }
-        newly += local;
-    });
-    stage_done(0);
-    dh_parallel_for(n, 4096, [&](int64_t lo, int64_t hi) {
-        int64_t local = 0;
-        for (int64_t i = lo; i < hi; i++) {
-            dh_la &l = las[i];
-            if (l.flags & DH_FLAG_DISABLED) continue;
-            const bool begins = l.abpos <= o.allowance || l.bbpos <= o.allowance;
-            const bool ends = l.aepos + o.allowance >= c.alen(l) || l.bepos + o.allowance >= c.blen(l);
-            if (!(begins && ends)) {
-                l.flags |= DH_FLAG_DISABLED;
-                local++;
-            }
-        }
-        newly += local;
-    });
-    stage_done(1);
-    dh_parallel_for(n, 4096, [&](int64_t lo, int64_t hi) {
-        int64_t local = 0;
-        for (int64_t i = lo; i < hi; i++) {
-            dh_la &l = las[i];
-            if (l.flags & DH_FLAG_DISABLED) continue;
-            int64_t unmasked = l.aepos - l.abpos;
-            if (unmasked_in)
-                unmasked = unmasked_in[i];
-            else if (rep_ptr)
-                for (int64_t j = rep_ptr[l.aread]; j < rep_ptr[l.aread + 1]; j++) {
-                    const int32_t b = std::max(rep_iv[2 * j], l.abpos), e = std::min(rep_iv[2 * j + 1], l.aepos);
-                    if (e > b) unmasked -= e - b;
+    // 1-3: per-alignment predicates, one pass: a record is judged by the first stage it fails (as three passes, each
+    // skipping what the one before disabled, would)
+    {
+        std::atomic<int64_t> s0{0}, s1{0}, s2{0};
+        dh_parallel_for(n, 4096, [&](int64_t lo, int64_t hi) {
+            int64_t l0 = 0, l1 = 0, l2 = 0;
+            for (int64_t i = lo; i < hi; i++) {
+                dh_la &l = las[i];
+                if (l.flags & DH_FLAG_DISABLED) continue;
+                if ((int64_t)l.diffs * 1000000 > (int64_t)o.max_align_err_ppm * (covered ? covered[i] : (int64_t)(l.aepos - l.abpos))) {
+                    l.flags |= DH_FLAG_DISABLED;
+                    l0++;
+                    continue;
                 }
-            if (unmasked <= o.min_anchor) {
-                l.flags |= DH_FLAG_DISABLED;
-                local++;
+                const bool begins = l.abpos <= o.allowance || l.bbpos <= o.allowance;
+                const bool ends = l.aepos + o.allowance >= c.alen(l) || l.bepos + o.allowance >= c.blen(l);
+                if (!(begins && ends)) {
+                    l.flags |= DH_FLAG_DISABLED;
+                    l1++;
+                    continue;
+                }
+                int64_t unmasked = l.aepos - l.abpos;
+                if (unmasked_in)
+                    unmasked = unmasked_in[i];
+                else if (rep_ptr)
+                    for (int64_t j = rep_ptr[l.aread]; j < rep_ptr[l.aread + 1]; j++) {
+                        const int32_t b = std::max(rep_iv[2 * j], l.abpos), e = std::min(rep_iv[2 * j + 1], l.aepos);
+                        if (e > b) unmasked -= e - b;
+                    }
+                if (unmasked <= o.min_anchor) {
+                    l.flags |= DH_FLAG_DISABLED;
+                    l2++;
+                }
             }
-        }
-        newly += local;
-    });
-    stage_done(2);
+            s0 += l0;
+            s1 += l1;
+            s2 += l2;
+        });
+        cnt[0] = s0.load();
+        cnt[1] = s1.load();
+        cnt[2] = s2.load();
+    }
     // Records grouped by read (what the aligner emits, and what the chunk hook of dh_map_reads hands over): the three
     // remaining stages are decisions per read -- `contained` relates alignments of one read on one contig (in the
     // sorted order of stage 4 below the alignments of a read on a contig are neighbours, and the scan leaves a1's

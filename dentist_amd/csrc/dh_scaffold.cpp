@@ -236,7 +236,7 @@ int collect_raw_joins(const char *who, const dh_la *las, int64_t n, const int64_
     auto LAP_ = [&](const char *w) { if (getenv("DH_TRACE")) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[scaffold] %-24s %.2f ms\n", w, std::chrono::duration<double, std::milli>(t - T0_).count()); T0_ = t; } };
     // ---- the enabled LAs grouped by read, input order inside a read
     std::atomic<int> bad{0};
-    const int64_t lgrain = 1 << 16, lchunks = (n + lgrain - 1) / lgrain;
+    const int64_t lgrain = 1 << 14, lchunks = (n + lgrain - 1) / lgrain;  // (a mapping of configs[2]: 70 runs for up to 64 threads)
     std::vector<std::vector<std::pair<int32_t, int32_t>>> live((size_t)std::max<int64_t>(lchunks, 1));
     dh_parallel_for(lchunks, 1, [&](int64_t clo, int64_t chi) {
         for (int64_t ch = clo; ch < chi; ch++) {
@@ -271,7 +271,7 @@ int collect_raw_joins(const char *who, const dh_la *las, int64_t n, const int64_
         }
     });
     if (!unsorted.load()) {
-        const int64_t rgrain = 1 << 15, rchunks = ((int64_t)nreads + 1 + rgrain - 1) / rgrain;
+        const int64_t rgrain = 1 << 13, rchunks = ((int64_t)nreads + 1 + rgrain - 1) / rgrain;
         dh_parallel_for(rchunks, 1, [&](int64_t clo, int64_t chi) {
             for (int64_t ch = clo; ch < chi; ch++) {
                 const int64_t r0 = ch * rgrain, r1 = std::min<int64_t>((int64_t)nreads + 1, r0 + rgrain);
