@@ -15,6 +15,7 @@
 // stage is the same); the counts are chains.  Per-alignment predicates run on the host thread pool.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -100,8 +101,11 @@ extern "C" int dh_collect_filter(dh_la *las, int64_t n, const int64_t *contig_of
                                  const dh_process_opts *opts, int64_t *dropped6, uint8_t *read_used)
 {
     if ((n > 0 && !las) || !contig_off || !read_off || !opts || n < 0) return dh_fail(DH_EINVAL, "dh_collect_filter: bad argument");
+    auto T0_ = std::chrono::steady_clock::now();
+    auto LAP_ = [&](const char *w) { if (getenv("DH_TRACE_FILTER")) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[filter] %-24s %.2f ms\n", w, std::chrono::duration<double, std::milli>(t - T0_).count()); T0_ = t; } };
     dh_chain_view cv;
     dh_chain_view_build(las, n, cv);
+    LAP_("chain view");
     if (cv.trivial)
         return collect_filter_units(las, n, contig_off, ncontigs, read_off, nreads, rep_ptr, rep_iv, opts, dropped6, read_used,
                                     nullptr, nullptr);
@@ -146,9 +150,11 @@ extern "C" int dh_collect_filter(dh_la *las, int64_t n, const int64_t *contig_of
             }
         });
     }
+    LAP_("unmasked");
     if (int rc = collect_filter_units(cv.unit.data(), nc, contig_off, ncontigs, read_off, nreads, rep_ptr, rep_iv, opts, dropped6,
                                       read_used, cv.covered.data(), unmasked.data()))
         return rc;
+    LAP_("units");
     dh_parallel_for(nc, 4096, [&](int64_t lo, int64_t hi) {
         for (int64_t c = lo; c < hi; c++)
             if (cv.unit[(size_t)c].flags & DH_FLAG_DISABLED)
@@ -230,9 +236,13 @@ static int collect_filter_units(dh_la *las, int64_t n, const int64_t *contig_off
         for (int64_t i = std::max<int64_t>(lo, 1); i < hi; i++)
             if (las[i].bread < las[i - 1].bread) ungrouped = 1;
     });
+    auto U0_ = std::chrono::steady_clock::now();
+    auto ULAP_ = [&](const char *w) { if (getenv("DH_TRACE_FILTER")) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[filter units] %-18s %.2f ms\n", w, std::chrono::duration<double, std::milli>(t - U0_).count()); U0_ = t; } };
     if (!ungrouped) {
         const std::vector<int64_t> rs = dh_run_starts(n, [las](int64_t i) { return las[i].bread; });
+        ULAP_("run starts");
         std::vector<uint8_t> used((size_t)nreads, 1);
+        ULAP_("used");
         std::atomic<int64_t> c3{0}, c4{0}, c5{0};
         dh_parallel_for((int64_t)rs.size() - 1, 1024, [&](int64_t rlo, int64_t rhi) {
             int64_t l3 = 0, l4 = 0, l5 = 0;
@@ -308,6 +318,7 @@ static int collect_filter_units(dh_la *las, int64_t n, const int64_t *contig_off
         cnt[3] = c3.load();
         cnt[4] = c4.load();
         cnt[5] = c5.load();
+        ULAP_("per read");
         if (dropped6) memcpy(dropped6, cnt, sizeof(cnt));
         if (read_used) memcpy(read_used, used.data(), (size_t)nreads);
         return DH_OK;
