@@ -124,6 +124,10 @@ def main():
                          "entries it merges into a gap (pileups.d:173-208; the default for every N: at N > 1 the raw joins "
                          "of each rank's reads are all-gathered), 'spanning' = one entry per spanning read, collected per "
                          "chunk while mapping")
+    ap.add_argument("--ref-steps", type=int, default=3,
+                    help="steps of the REFERENCE-BEHAVIOUR configuration timed after the default loop in the same process "
+                         "(no read cap: processPileUps/package.d:283-374 has none; no k-mer sampling: damapper has none, "
+                         "commandline.d:2943-2955) and reported as reference_behaviour_timed; 0 = skip; N = 1 only")
     ap.add_argument("--dev-share-gpu", action="store_true",
                     help="development only: all ranks on cuda:0 with gloo collectives (exercises the N > 1 "
                          "code path on a 1-GPU box; not a measurement)")
@@ -174,7 +178,7 @@ def main():
         args.collect = "graph"
     input_gaps = np.stack([np.arange(w.contigs.n - 1), np.arange(1, w.contigs.n)], axis=1).astype(np.int32)
 
-    def step():
+    def step(mopts=mopts, popts=popts):
         A.drop_cache()  # the k-mer index and the derived copies are rebuilt every step
         B.drop_cache()
         ctx.cum_stats(reset=True)
@@ -234,6 +238,29 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
 
+    # the same workload at the reference's behaviour -- every read alignment of a pile-up is processed (no cap) and every
+    # k-mer of the reads is looked up (no modimer sampling) -- timed here, inside the same run, the same way
+    ref_runs, ref_dt, ref_opts = [], 0.0, None
+    if args.ref_steps > 0 and world == 1 and (args.kmer_mod != 1 or popts.max_reads != 0):
+        for r in runs[:-1]:
+            for key in ("las", "rec", "bases"):
+                r.pop(key, None)
+        rmopts = dentist_amd.default_align_opts(kmer_mod=1, k=args.map_k, width=args.map_width,
+                                                xdrop=args.map_xdrop, algo=args.map_algo)
+        rpopts = dentist_amd.default_process_opts(algo=args.process_algo)
+        rpopts.max_reads = 0
+        ref_opts = (rmopts, rpopts)
+        step(rmopts, rpopts)   # one untimed step (first-use allocations of the larger buffers)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.ref_steps):
+            if ref_runs:
+                for key in ("las", "rec", "bases"):
+                    ref_runs[-1].pop(key, None)
+            ref_runs.append(step(rmopts, rpopts))
+        barrier()
+        ref_dt = time.perf_counter() - t0
+
     last = runs[-1]
     aligned_bp = int((last["las"]["aepos"] - last["las"]["abpos"]).sum())
     mean = lambda f: float(np.mean([f(r) for r in runs]))  # noqa: E731
@@ -261,6 +288,8 @@ def main():
         achieved = alg_bytes / (wave_ms * 1e-3) / 1e9
         seed_traffic, traffic, traffic_src = kernel_traffic(args, world)
         seed_bytes = 1.0 * read_bp * (1.0 + 64.0 / max(1, args.kmer_mod))
+        # what a lookup needs of its line: the 16-byte directory word (dh_kernels.hip, seed_item: ix.fat[...])
+        seed_useful = 1.0 * read_bp * (1.0 + 16.0 / max(1, args.kmer_mod))
         seed_ms = mean(lambda r: r["ast"].ms_seed)
         out = {
             "metric": "gap-bases closed/sec",
@@ -305,6 +334,8 @@ def main():
                          "launches_per_step": int(last["ast"].wave_launches), "kernel_ms_per_step": seed_ms,
                          "avg_launch_ms": seed_ms / max(1, int(last["ast"].wave_launches)),
                          "algorithmic_bytes_per_step": seed_bytes, "traffic_source": traffic_src,
+                         "useful_bytes_per_step": seed_useful,
+                         "useful_frac": seed_useful / (seed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "measured_random_line_ceiling_GBs": CONST["random_line_ceiling_GBs"]},
             # second: the extension kernel, one alignment per lane.  VALU bound (scripts/valu_probe.cpp: 2-cycle class
             # 0.90-0.94, 4-cycle class 0.56-0.58 G wave-instructions/s per SIMD); the HBM fraction is reported as asked
@@ -350,10 +381,29 @@ def main():
                           **{"process_" + k[3:]: mean(lambda r, k=k: r["pst"][k]) for k in last["pst"] if k.startswith("ms_")}},
         }
         # the headline uses two work-reducing knobs the reference does not apply (read cap, modimer sampling): the same
-        # workload at the reference's behaviour, measured by scripts/ref_behaviour.sh on the build named in the file
-        rb = os.path.join(ROOT, "profiles", "reference_behaviour.json")
-        if os.path.exists(rb):
-            out["reference_behaviour"] = json.load(open(rb))
+        # workload at the reference's behaviour, timed above in this very run
+        if ref_runs:
+            rl = ref_runs[-1]
+            rgap, rclosed, redits, rtruth = closed_gap_stats(w, rl["rec"], rl["bases"])
+            rmean = lambda f: float(np.mean([f(r) for r in ref_runs]))  # noqa: E731
+            rseed_ms = rmean(lambda r: r["ast"].ms_seed)
+            out["reference_behaviour_timed"] = {
+                "what": "the same workload with no read cap per pile-up (max_reads = 0) and no k-mer sampling of the mapping "
+                        "index (kmer_mod = 1): what the reference does (processPileUps/package.d:283-374, commandline.d:2943-2955)",
+                "steps": args.ref_steps, "warmup": 1, "ms_per_step": ref_dt / args.ref_steps * 1e3,
+                "value": rgap * args.ref_steps / ref_dt, "unit": "gap-bp/s",
+                "gaps_closed": rclosed, "gap_bases_closed": rgap, "pile_up_entries": int(rl["info"].get("entries", 0)),
+                "consensus_error_rate": (redits / rtruth) if rtruth else None,
+                "read_bp_aligned_per_sec_mapping_stage": int((rl["las"]["aepos"] - rl["las"]["abpos"]).sum()) / rmean(lambda r: r["t_map"]),
+                "k_seed_frac_of_hbm_peak_line_priced": read_bp * 65.0 / (rseed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "k_seed_frac_of_hbm_peak_useful_bytes": read_bp * 17.0 / (rseed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "stages_ms": {"map_wall": rmean(lambda r: r["t_map"]) * 1e3, "map_index": rmean(lambda r: r["ast"].ms_index),
+                              "map_seed": rseed_ms, "map_wave": rmean(lambda r: r["ast"].ms_wave),
+                              "collect_wall": rmean(lambda r: r["t_collect"]) * 1e3,
+                              "process_wall": rmean(lambda r: r["t_process"]) * 1e3,
+                              **{"process_" + k[3:]: rmean(lambda r, k=k: r["pst"][k]) for k in rl["pst"] if k.startswith("ms_")}}}
+        else:
+            out["reference_behaviour_timed"] = None
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(w, last, mopts, popts, args, gap_all, read_all)
         print(json.dumps(out))
