@@ -183,9 +183,29 @@ extern "C" int32_t dh_comm_world(const dh_comm *c) { return c ? c->world : 0; }
 
 // all-gather(v) of one blob per rank.  *out: one malloc'd block holding the blobs in rank order (dh_shard_free),
 // sizes[world] their lengths.
-extern "C" int dh_comm_all_gather(dh_comm *c, const uint8_t *payload, int64_t nbytes, uint8_t **out, int64_t *sizes)
+// A rank that failed locally before an exchange must not leave its peers waiting in it: every exchange starts with the
+// all-gather of the sizes, and a NEGATIVE size says "this rank failed with status -size".  Every rank then returns an
+// error from the same exchange (its own status, or DH_EPEER-like DH_EINVAL naming the first failed rank) and none
+// enters the payload collective.  local_rc = the status of what the rank did since the last exchange.
+static int peers_failed(const int64_t *sizes, int32_t W, int32_t rank, int local_rc, const char *who)
 {
-    if (!c || !out || !sizes || nbytes < 0 || (nbytes > 0 && !payload)) return dh_fail(DH_EINVAL, "dh_comm_all_gather: bad argument");
+    for (int32_t r = 0; r < W; r++)
+        if (sizes[r] < 0) {
+            if (local_rc) return local_rc;  // (the message of the local failure is already set)
+            return dh_fail(DH_EINVAL, std::string(who) + ": rank " + std::to_string(r) + " failed before the exchange (status " +
+                                          std::to_string(-sizes[r]) + "); rank " + std::to_string(rank) + " gives up with it");
+        }
+    return DH_OK;
+}
+
+static int all_gather_st(dh_comm *c, const uint8_t *payload, int64_t nbytes, int local_rc, uint8_t **out, int64_t *sizes)
+{
+    if (!c || !out || !sizes || nbytes < 0 || (nbytes > 0 && !payload)) {
+        if (!c || !sizes || !out) return dh_fail(DH_EINVAL, "dh_comm_all_gather: bad argument");
+        if (!local_rc) local_rc = dh_fail(DH_EINVAL, "dh_comm_all_gather: bad argument");
+    }
+    if (local_rc) nbytes = -(int64_t)(local_rc > 0 ? local_rc : -local_rc);
+    if (local_rc && nbytes == 0) nbytes = -1;
     const int32_t W = c->world;
     *out = nullptr;
     if (c->hub) {
@@ -194,15 +214,23 @@ extern "C" int dh_comm_all_gather(dh_comm *c, const uint8_t *payload, int64_t nb
         h.size[(size_t)c->rank] = nbytes;
         h.barrier();
         int64_t total = 0;
-        for (int32_t r = 0; r < W; r++) total += (sizes[r] = h.size[(size_t)r]);
-        uint8_t *buf = (uint8_t *)malloc((size_t)std::max<int64_t>(total, 1));
-        if (!buf) return dh_fail(DH_ENOMEM, "dh_comm_all_gather: out of memory");
-        int64_t at = 0;
+        bool failed = false;
         for (int32_t r = 0; r < W; r++) {
-            if (sizes[r]) memcpy(buf + at, h.ptr[(size_t)r], (size_t)sizes[r]);
-            at += sizes[r];
+            sizes[r] = h.size[(size_t)r];
+            failed = failed || sizes[r] < 0;
+            total += std::max<int64_t>(sizes[r], 0);
         }
-        h.barrier();  // every rank has copied: the payloads may go
+        uint8_t *buf = failed ? nullptr : (uint8_t *)malloc((size_t)std::max<int64_t>(total, 1));
+        if (buf) {
+            int64_t at = 0;
+            for (int32_t r = 0; r < W; r++) {
+                if (sizes[r]) memcpy(buf + at, h.ptr[(size_t)r], (size_t)sizes[r]);
+                at += sizes[r];
+            }
+        }
+        h.barrier();  // every rank has copied (or given up): the payloads may go -- reached on every path
+        if (failed) return peers_failed(sizes, W, c->rank, local_rc, "dh_comm_all_gather");
+        if (!buf) return dh_fail(DH_ENOMEM, "dh_comm_all_gather: out of memory");
         *out = buf;
         return DH_OK;
     }
@@ -216,6 +244,7 @@ extern "C" int dh_comm_all_gather(dh_comm *c, const uint8_t *payload, int64_t nb
     NCCLCHK(rccl().AllGather(d_sz + W, d_sz, 1, ncclInt64, c->nccl, st));
     HIPCHK(hipMemcpyAsync(sizes, d_sz, sizeof(int64_t) * (size_t)W, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if (int rc = peers_failed(sizes, W, c->rank, local_rc, "dh_comm_all_gather")) return rc;
     int64_t cap = 1, total = 0;
     for (int32_t r = 0; r < W; r++) {
         cap = std::max(cap, sizes[r]);
@@ -251,14 +280,30 @@ extern "C" int dh_comm_all_gather(dh_comm *c, const uint8_t *payload, int64_t nb
     *out = buf;
     return DH_OK;
 }
+extern "C" int dh_comm_all_gather(dh_comm *c, const uint8_t *payload, int64_t nbytes, uint8_t **out, int64_t *sizes)
+{
+    if (!c || !out || !sizes || nbytes < 0 || (nbytes > 0 && !payload)) return dh_fail(DH_EINVAL, "dh_comm_all_gather: bad argument");
+    return all_gather_st(c, payload, nbytes, DH_OK, out, sizes);
+}
 
 // all-to-all(v): per_dest[r] / send_sizes[r] = the blob for rank r.  *out: one malloc'd block with the blobs received in
 // source-rank order (dh_shard_free), recv_sizes[world] their lengths.
-extern "C" int dh_comm_all_to_all(dh_comm *c, const uint8_t *const *per_dest, const int64_t *send_sizes, uint8_t **out,
-                                  int64_t *recv_sizes)
+static int all_to_all_st(dh_comm *c, const uint8_t *const *per_dest, const int64_t *send_sizes_in, int local_rc, uint8_t **out,
+                         int64_t *recv_sizes)
 {
-    if (!c || !per_dest || !send_sizes || !out || !recv_sizes) return dh_fail(DH_EINVAL, "dh_comm_all_to_all: NULL argument");
+    if (!c || !out || !recv_sizes) return dh_fail(DH_EINVAL, "dh_comm_all_to_all: NULL argument");
     const int32_t W = c->world;
+    if (!local_rc && (!per_dest || !send_sizes_in)) local_rc = dh_fail(DH_EINVAL, "dh_comm_all_to_all: NULL argument");
+    if (!local_rc)
+        for (int32_t r = 0; r < W; r++)
+            if (send_sizes_in[r] < 0) local_rc = dh_fail(DH_EINVAL, "dh_comm_all_to_all: negative size");
+    // a failed rank sends its status as a negative size to everybody
+    std::vector<int64_t> fail_sizes;
+    const int64_t *send_sizes = send_sizes_in;
+    if (local_rc) {
+        fail_sizes.assign((size_t)W, -(int64_t)std::max(1, local_rc > 0 ? local_rc : -local_rc));
+        send_sizes = fail_sizes.data();
+    }
     *out = nullptr;
     if (c->hub) {
         LocalHub &h = *c->hub;
@@ -266,15 +311,23 @@ extern "C" int dh_comm_all_to_all(dh_comm *c, const uint8_t *const *per_dest, co
         h.dest_size[(size_t)c->rank] = send_sizes;
         h.barrier();
         int64_t total = 0;
-        for (int32_t r = 0; r < W; r++) total += (recv_sizes[r] = h.dest_size[(size_t)r][c->rank]);
-        uint8_t *buf = (uint8_t *)malloc((size_t)std::max<int64_t>(total, 1));
-        if (!buf) return dh_fail(DH_ENOMEM, "dh_comm_all_to_all: out of memory");
-        int64_t at = 0;
+        bool failed = false;
         for (int32_t r = 0; r < W; r++) {
-            if (recv_sizes[r]) memcpy(buf + at, h.dest_ptr[(size_t)r][c->rank], (size_t)recv_sizes[r]);
-            at += recv_sizes[r];
+            recv_sizes[r] = h.dest_size[(size_t)r][c->rank];
+            failed = failed || recv_sizes[r] < 0;
+            total += std::max<int64_t>(recv_sizes[r], 0);
         }
-        h.barrier();
+        uint8_t *buf = failed ? nullptr : (uint8_t *)malloc((size_t)std::max<int64_t>(total, 1));
+        if (buf) {
+            int64_t at = 0;
+            for (int32_t r = 0; r < W; r++) {
+                if (recv_sizes[r]) memcpy(buf + at, h.dest_ptr[(size_t)r][c->rank], (size_t)recv_sizes[r]);
+                at += recv_sizes[r];
+            }
+        }
+        h.barrier();  // reached on every path
+        if (failed) return peers_failed(recv_sizes, W, c->rank, local_rc, "dh_comm_all_to_all");
+        if (!buf) return dh_fail(DH_ENOMEM, "dh_comm_all_to_all: out of memory");
         *out = buf;
         return DH_OK;
     }
@@ -290,10 +343,11 @@ extern "C" int dh_comm_all_to_all(dh_comm *c, const uint8_t *const *per_dest, co
     HIPCHK(hipMemcpyAsync(rows.data(), d_sz, sizeof(int64_t) * rows.size(), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     int64_t stot = 0, rtot = 0;
+    for (int32_t r = 0; r < W; r++) recv_sizes[r] = rows[(size_t)r * W + c->rank];
+    if (int rc = peers_failed(recv_sizes, W, c->rank, local_rc, "dh_comm_all_to_all")) return rc;
     for (int32_t r = 0; r < W; r++) {
-        if (send_sizes[r] < 0) return dh_fail(DH_EINVAL, "dh_comm_all_to_all: negative size");
         stot += send_sizes[r];
-        rtot += (recv_sizes[r] = rows[(size_t)r * W + c->rank]);
+        rtot += recv_sizes[r];
     }
     uint8_t *d_send, *d_recv;
     if (int rc = dh_scratch(ctx, 56, (size_t)std::max<int64_t>(stot, 16), (void **)&d_send)) return rc;
@@ -314,13 +368,18 @@ extern "C" int dh_comm_all_to_all(dh_comm *c, const uint8_t *const *per_dest, co
     if (stot) HIPCHK(hipMemcpyAsync(d_send, stage, (size_t)stot, hipMemcpyHostToDevice, st));
     NCCLCHK(rccl().GroupStart());
     int64_t so = 0, ro = 0;
-    for (int32_t r = 0; r < W; r++) {
-        if (send_sizes[r]) NCCLCHK(rccl().Send(d_send + so, (size_t)send_sizes[r], ncclUint8, r, c->nccl, st));
-        if (recv_sizes[r]) NCCLCHK(rccl().Recv(d_recv + ro, (size_t)recv_sizes[r], ncclUint8, r, c->nccl, st));
+    ncclResult_t grc = ncclSuccess;  // an error inside the group still closes it
+    for (int32_t r = 0; r < W && grc == ncclSuccess; r++) {
+        if (send_sizes[r]) grc = rccl().Send(d_send + so, (size_t)send_sizes[r], ncclUint8, r, c->nccl, st);
+        if (grc == ncclSuccess && recv_sizes[r]) grc = rccl().Recv(d_recv + ro, (size_t)recv_sizes[r], ncclUint8, r, c->nccl, st);
         so += send_sizes[r];
         ro += recv_sizes[r];
     }
-    NCCLCHK(rccl().GroupEnd());
+    {
+        const ncclResult_t erc = rccl().GroupEnd();
+        NCCLCHK(grc);
+        NCCLCHK(erc);
+    }
     HIPCHK(hipStreamSynchronize(st));
     if (rtot) HIPCHK(hipMemcpyAsync(stage, d_recv, (size_t)rtot, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -329,6 +388,12 @@ extern "C" int dh_comm_all_to_all(dh_comm *c, const uint8_t *const *per_dest, co
     if (rtot) memcpy(buf, stage, (size_t)rtot);
     *out = buf;
     return DH_OK;
+}
+extern "C" int dh_comm_all_to_all(dh_comm *c, const uint8_t *const *per_dest, const int64_t *send_sizes, uint8_t **out,
+                                  int64_t *recv_sizes)
+{
+    if (!c || !per_dest || !send_sizes || !out || !recv_sizes) return dh_fail(DH_EINVAL, "dh_comm_all_to_all: NULL argument");
+    return all_to_all_st(c, per_dest, send_sizes, DH_OK, out, recv_sizes);
 }
 
 // ------------------------------------------------------------------------------------ the sharded collect + process
@@ -348,6 +413,135 @@ std::vector<const uint8_t *> blob_ptrs(const uint8_t *block, const int64_t *size
         at += sizes[r];
     }
     return p;
+}
+
+// the closed gaps of one rank as a blob, and the merge of all ranks' blobs in PILE-UP order: a rank's records are its
+// owned pile-ups in ascending pile-up index (dh_shard_unpack_cropped), owners are assigned by cost (not contiguously), so
+// the k-th record of rank r is the k-th pile-up with owner == r.  The result is then what dh_process_pileups returns on
+// one GPU -- the same order whatever the world size, also when several pile-ups share contig_left (extension joins,
+// contig-skipping or anti-parallel joins) -- with the flank overlaps and read ids re-based as dh_process_pileups does
+// when it appends its parts.
+struct ClosedHead {
+    int64_t nrec, nbases, nflank, ntr, nids, has_ids;
+};
+void pack_closed(const dh_insertions &L, std::vector<uint8_t> &blob)
+{
+    ClosedHead h;
+    h.nrec = (int64_t)L.rec.size();
+    h.nbases = (int64_t)L.bases.size();
+    h.nflank = (int64_t)L.flank.size();
+    h.ntr = (int64_t)L.flank_tr.size();
+    h.has_ids = L.ids_off.size() == L.rec.size() + 1 ? 1 : 0;
+    h.nids = h.has_ids ? (int64_t)L.ids.size() : 0;
+    const size_t bytes = sizeof(h) + sizeof(dh_insertion) * L.rec.size() + 4 * L.rec.size() + (h.has_ids ? 4 * (L.rec.size() + 1) : 0) +
+                         sizeof(dh_la) * L.flank.size() + 2 * L.flank_tr.size() + 4 * (size_t)h.nids + L.bases.size();
+    blob.resize(bytes);
+    uint8_t *p = blob.data();
+    auto put = [&](const void *src, size_t nb) {
+        if (nb) memcpy(p, src, nb);
+        p += nb;
+    };
+    put(&h, sizeof(h));
+    put(L.rec.data(), sizeof(dh_insertion) * L.rec.size());
+    std::vector<int32_t> fo(L.rec.size(), -1);
+    for (size_t i = 0; i < L.rec.size() && i < L.flank_of.size(); i++) fo[i] = L.flank_of[i];
+    put(fo.data(), 4 * fo.size());
+    if (h.has_ids) put(L.ids_off.data(), 4 * L.ids_off.size());
+    put(L.flank.data(), sizeof(dh_la) * L.flank.size());
+    put(L.flank_tr.data(), 2 * L.flank_tr.size());
+    if (h.nids) put(L.ids.data(), 4 * (size_t)h.nids);
+    put(L.bases.data(), L.bases.size());
+}
+int merge_closed(const std::vector<const uint8_t *> &bp, const std::vector<int64_t> &sizes, int32_t W, const int32_t *owner, int32_t npiles,
+                 dh_insertions &res)
+{
+    struct Part {
+        ClosedHead h;
+        const dh_insertion *rec;
+        const int32_t *flank_of, *ids_off, *ids;
+        const dh_la *flank;
+        const uint16_t *tr;
+        const uint8_t *bases;
+        int64_t next = 0;
+    };
+    std::vector<Part> part((size_t)W);
+    bool all_ids = true;
+    for (int32_t r = 0; r < W; r++) {
+        Part &q = part[(size_t)r];
+        if (sizes[(size_t)r] < (int64_t)sizeof(ClosedHead)) return dh_fail(DH_EINVAL, "dh_shard_run: short closed-gap blob");
+        memcpy(&q.h, bp[(size_t)r], sizeof(ClosedHead));
+        const ClosedHead &h = q.h;
+        const int64_t lim = sizes[(size_t)r];
+        if (h.nrec < 0 || h.nbases < 0 || h.nflank < 0 || h.ntr < 0 || h.nids < 0 || (h.has_ids != 0 && h.has_ids != 1) || h.nrec > lim ||
+            h.nbases > lim || h.nflank > lim || h.ntr > lim || h.nids > lim ||
+            (int64_t)sizeof(ClosedHead) + (int64_t)sizeof(dh_insertion) * h.nrec + 4 * h.nrec + (h.has_ids ? 4 * (h.nrec + 1) : 0) +
+                    (int64_t)sizeof(dh_la) * h.nflank + 2 * h.ntr + 4 * h.nids + h.nbases != lim)
+            return dh_fail(DH_EINVAL, "dh_shard_run: malformed closed-gap blob");
+        const uint8_t *p = bp[(size_t)r] + sizeof(ClosedHead);
+        q.rec = (const dh_insertion *)p;
+        p += sizeof(dh_insertion) * (size_t)h.nrec;
+        q.flank_of = (const int32_t *)p;
+        p += 4 * (size_t)h.nrec;
+        q.ids_off = h.has_ids ? (const int32_t *)p : nullptr;
+        p += h.has_ids ? 4 * (size_t)(h.nrec + 1) : 0;
+        q.flank = (const dh_la *)p;
+        p += sizeof(dh_la) * (size_t)h.nflank;
+        q.tr = (const uint16_t *)p;
+        p += 2 * (size_t)h.ntr;
+        q.ids = (const int32_t *)p;
+        p += 4 * (size_t)h.nids;
+        q.bases = p;
+        all_ids = all_ids && h.has_ids;
+    }
+    std::vector<int64_t> owned((size_t)W, 0);
+    for (int32_t g = 0; g < npiles; g++) {
+        if (owner[g] < 0 || owner[g] >= W) return dh_fail(DH_EINVAL, "dh_shard_run: owner out of range");
+        owned[(size_t)owner[g]]++;
+    }
+    for (int32_t r = 0; r < W; r++)
+        if (part[(size_t)r].h.nrec != owned[(size_t)r])
+            return dh_fail(DH_EINVAL, "dh_shard_run: rank " + std::to_string(r) + " returned " + std::to_string(part[(size_t)r].h.nrec) +
+                                          " closed-gap records for " + std::to_string(owned[(size_t)r]) + " owned pile-ups");
+    res.rec.reserve((size_t)npiles);
+    res.flank_of.reserve((size_t)npiles);
+    if (all_ids) res.ids_off.assign(1, 0);
+    for (int32_t g = 0; g < npiles; g++) {
+        Part &q = part[(size_t)owner[g]];
+        const int64_t i = q.next++;
+        dh_insertion x;
+        memcpy(&x, q.rec + i, sizeof(x));
+        if (x.cons_off < 0 || x.cons_len < 0 || x.cons_off + x.cons_len > q.h.nbases) return dh_fail(DH_EINVAL, "dh_shard_run: malformed closed-gap record");
+        const int64_t b0 = (int64_t)res.bases.size();
+        res.bases.insert(res.bases.end(), q.bases + x.cons_off, q.bases + x.cons_off + x.cons_len);
+        x.cons_off = b0;
+        res.rec.push_back(x);
+        int32_t fo;
+        memcpy(&fo, q.flank_of + i, 4);
+        if (fo >= 0) {
+            const int32_t nf = (x.join & DH_JOIN_EXTENSION) ? 1 : 2;
+            if ((int64_t)fo + nf > q.h.nflank) return dh_fail(DH_EINVAL, "dh_shard_run: malformed closed-gap record");
+            res.flank_of.push_back((int32_t)res.flank.size());
+            for (int32_t f = 0; f < nf; f++) {
+                dh_la l;
+                memcpy(&l, q.flank + fo + f, sizeof(l));
+                if (l.toff < 0 || l.tlen < 0 || l.toff + l.tlen > q.h.ntr) return dh_fail(DH_EINVAL, "dh_shard_run: malformed closed-gap record");
+                const int64_t t0 = (int64_t)res.flank_tr.size();
+                res.flank_tr.insert(res.flank_tr.end(), q.tr + l.toff, q.tr + l.toff + l.tlen);
+                l.toff = t0;
+                res.flank.push_back(l);
+            }
+        } else
+            res.flank_of.push_back(-1);
+        if (all_ids) {
+            int32_t i0, i1;
+            memcpy(&i0, q.ids_off + i, 4);
+            memcpy(&i1, q.ids_off + i + 1, 4);
+            if (i0 < 0 || i1 < i0 || i1 > q.h.nids) return dh_fail(DH_EINVAL, "dh_shard_run: malformed closed-gap record");
+            res.ids.insert(res.ids.end(), q.ids + i0, q.ids + i1);
+            res.ids_off.push_back((int32_t)res.ids.size());
+        }
+    }
+    return DH_OK;
 }
 }  // namespace
 
@@ -372,14 +566,14 @@ extern "C" int dh_shard_run(dh_comm *c, dh_db *contigs, dh_db *reads, int32_t re
     const int32_t W = c->world;
     *out = nullptr;
     std::vector<int64_t> sizes((size_t)W);
+    // Every local failure between two exchanges is carried INTO the next exchange (all_gather_st / all_to_all_st): the
+    // peers learn of it from the size all-gather and every rank returns from the same place; nobody is left waiting.
     // ---- 1. this rank's joins / candidates, gathered; the plan
     FreeGuard mine, gathered;
     int64_t nmine = 0;
-    if (cands) {
-        if (int rc = dh_shard_pack_candidates(cands, las, n, read_first, (uint8_t **)&mine.p, &nmine)) return rc;
-    } else if (int rc = dh_shard_read_joins(las, n, contig_off, ncontigs, read_off, read_first, reads->n, (uint8_t **)&mine.p, &nmine))
-        return rc;
-    if (int rc = dh_comm_all_gather(c, (const uint8_t *)mine.p, nmine, (uint8_t **)&gathered.p, sizes.data())) return rc;
+    int lrc = cands ? dh_shard_pack_candidates(cands, las, n, read_first, (uint8_t **)&mine.p, &nmine)
+                    : dh_shard_read_joins(las, n, contig_off, ncontigs, read_off, read_first, reads->n, (uint8_t **)&mine.p, &nmine);
+    if (int rc = all_gather_st(c, (const uint8_t *)mine.p, lrc ? 0 : nmine, lrc, (uint8_t **)&gathered.p, sizes.data())) return rc;
     dh_shard_plan *plan = nullptr;
     {
         const std::vector<const uint8_t *> bp = blob_ptrs((const uint8_t *)gathered.p, sizes.data(), W);
@@ -392,91 +586,64 @@ extern "C" int dh_shard_run(dh_comm *c, dh_db *contigs, dh_db *reads, int32_t re
                 so.min_spanning_reads = opts->min_reads;
             }
         }
-        if (int rc = cands ? dh_shard_plan_create(bp.data(), sizes.data(), W, opts, &plan)
-                           : dh_shard_graph_plan_create(bp.data(), sizes.data(), W, ncontigs, input_gaps, ngaps, &so, opts, &plan))
-            return rc;
+        lrc = cands ? dh_shard_plan_create(bp.data(), sizes.data(), W, opts, &plan)
+                    : dh_shard_graph_plan_create(bp.data(), sizes.data(), W, ncontigs, input_gaps, ngaps, &so, opts, &plan);
     }
     struct PlanGuard {
         dh_shard_plan *p;
         ~PlanGuard() { dh_shard_plan_destroy(p); }
     } pg{plan};
-    const dh_pileups *piles = dh_shard_plan_pileups(plan);
-    const int32_t *owner = dh_shard_plan_owner(plan);
-    const int32_t npiles = dh_pileups_count(piles);
+    const dh_pileups *piles = lrc ? nullptr : dh_shard_plan_pileups(plan);
+    const int32_t *owner = lrc ? nullptr : dh_shard_plan_owner(plan);
+    const int32_t npiles = lrc ? 0 : dh_pileups_count(piles);
     // ---- 2. crop this rank's reads of every pile-up; to the owners
-    dh_cropped *crop = nullptr;
-    if (int rc = dh_crop_pileups(ctx, contigs, reads, read_first, dh_shard_plan_las(plan), dh_shard_plan_nlas(plan), trace, piles,
-                                 opts, &crop))
-        return rc;
     struct CropGuard {
         dh_cropped *p;
         ~CropGuard() { dh_cropped_destroy(p); }
     };
     std::vector<dh_insertion> rec((size_t)npiles);
-    if (npiles) memcpy(rec.data(), dh_cropped_records(crop), sizeof(dh_insertion) * (size_t)npiles);
     std::vector<uint8_t *> dest((size_t)W, nullptr);
     std::vector<int64_t> ssz((size_t)W, 0), rsz((size_t)W, 0);
     FreeGuard sent, recvd;
-    {
+    if (!lrc) {
+        dh_cropped *crop = nullptr;
+        lrc = dh_crop_pileups(ctx, contigs, reads, read_first, dh_shard_plan_las(plan), dh_shard_plan_nlas(plan), trace, piles, opts, &crop);
         CropGuard cg{crop};
-        if (int rc = dh_shard_pack_cropped(crop, owner, W, dest.data(), ssz.data())) return rc;
-        sent.p = dest[0];
+        if (!lrc) {
+            if (npiles) memcpy(rec.data(), dh_cropped_records(crop), sizeof(dh_insertion) * (size_t)npiles);
+            lrc = dh_shard_pack_cropped(crop, owner, W, dest.data(), ssz.data());
+            if (!lrc) sent.p = dest[0];
+        }
     }
-    if (int rc = dh_comm_all_to_all(c, (const uint8_t *const *)dest.data(), ssz.data(), (uint8_t **)&recvd.p, rsz.data())) return rc;
+    if (int rc = all_to_all_st(c, (const uint8_t *const *)dest.data(), ssz.data(), lrc, (uint8_t **)&recvd.p, rsz.data())) return rc;
     // ---- 3. the pile-ups this rank owns
     dh_cropped *own = nullptr;
     {
         const std::vector<const uint8_t *> bp = blob_ptrs((const uint8_t *)recvd.p, rsz.data(), W);
-        if (int rc = dh_shard_unpack_cropped(bp.data(), rsz.data(), W, rec.data(), npiles, owner, c->rank, &own)) return rc;
+        lrc = dh_shard_unpack_cropped(bp.data(), rsz.data(), W, rec.data(), npiles, owner, c->rank, &own);
     }
     dh_insertions *local = nullptr;
     {
         CropGuard og{own};
-        if (int rc = dh_process_cropped(ctx, contigs, own, opts, &local)) return rc;
+        if (!lrc) lrc = dh_process_cropped(ctx, contigs, own, opts, &local);
     }
     struct InsGuard {
         dh_insertions *p;
         ~InsGuard() { dh_insertions_destroy(p); }
     } ig{local};
-    // ---- 4. closed gaps of all ranks (the role of merge-insertions): int64 record bytes, records, bases
-    std::vector<uint8_t> blob(8 + sizeof(dh_insertion) * local->rec.size() + local->bases.size());
-    {
-        const int64_t rb = (int64_t)(sizeof(dh_insertion) * local->rec.size());
-        memcpy(blob.data(), &rb, 8);
-        if (rb) memcpy(blob.data() + 8, local->rec.data(), (size_t)rb);
-        if (!local->bases.empty()) memcpy(blob.data() + 8 + rb, local->bases.data(), local->bases.size());
-    }
+    // ---- 4. closed gaps of all ranks (the role of merge-insertions, mergeInsertions.d:60-164): everything insertions.db
+    // keeps of a pile-up travels -- record, consensus bases, the flank overlaps with their trace points, the read ids
+    std::vector<uint8_t> blob;
+    if (!lrc) pack_closed(*local, blob);
     FreeGuard closed;
-    if (int rc = dh_comm_all_gather(c, blob.data(), (int64_t)blob.size(), (uint8_t **)&closed.p, sizes.data())) return rc;
+    if (int rc = all_gather_st(c, blob.data(), (int64_t)blob.size(), lrc, (uint8_t **)&closed.p, sizes.data())) return rc;
     dh_insertions *res = new dh_insertions();
     {
         const std::vector<const uint8_t *> bp = blob_ptrs((const uint8_t *)closed.p, sizes.data(), W);
-        std::vector<dh_insertion> all;
-        for (int32_t r = 0; r < W; r++) {
-            if (sizes[r] < 8) {
-                delete res;
-                return dh_fail(DH_EINVAL, "dh_shard_run: short closed-gap blob");
-            }
-            int64_t rb;
-            memcpy(&rb, bp[(size_t)r], 8);
-            if (rb < 0 || rb % (int64_t)sizeof(dh_insertion) || 8 + rb > sizes[r]) {
-                delete res;
-                return dh_fail(DH_EINVAL, "dh_shard_run: malformed closed-gap blob");
-            }
-            const size_t nr = (size_t)rb / sizeof(dh_insertion), b0 = res->bases.size();
-            const size_t a0 = all.size();
-            all.resize(a0 + nr);
-            if (nr) memcpy(all.data() + a0, bp[(size_t)r] + 8, (size_t)rb);
-            for (size_t x = a0; x < all.size(); x++) all[x].cons_off += (int64_t)b0;
-            res->bases.insert(res->bases.end(), bp[(size_t)r] + 8 + rb, bp[(size_t)r] + sizes[r]);
+        if (int rc = merge_closed(bp, sizes, W, owner, npiles, *res)) {
+            delete res;
+            return rc;
         }
-        // insertions.sort() by start node (processPileUps/package.d:156): stable by gap, ranks in order
-        std::vector<size_t> order(all.size());
-        std::iota(order.begin(), order.end(), (size_t)0);
-        std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return all[x].contig_left < all[y].contig_left; });
-        res->rec.reserve(all.size());
-        for (size_t x : order) res->rec.push_back(all[x]);
-        res->flank_of.assign(res->rec.size(), -1);
     }
     if (info4) {
         int32_t owned = 0;

@@ -214,16 +214,22 @@ extern "C" void dh_default_scaffold_opts(dh_scaffold_opts *o)
 }
 
 namespace {
-// blob record of the sharded collector (dh_shard_read_joins): one raw join with copies of the LA records it names
+// blob of the sharded collector (dh_shard_read_joins): JoinHead, then one JoinRec per raw join with copies of the FIRST
+// record of the alignment chain of each flank, then the other members of those chains (x0 of flank 0, then x1 of flank 1,
+// join by join) -- an entry of a pile-up names the first record of its chain and the cropper finds the members behind it
 #pragma pack(push, 1)
+struct JoinHead {
+    int64_t njoins, nextra;
+};
 struct JoinRec {
     Node s, e;
     int32_t read;
     uint8_t seed0, seed1, n, pad;
+    int32_t x0, x1;  // chain members after the first, per flank
     dh_la la0, la1;  // la1 zeroed for an extension
 };
 #pragma pack(pop)
-static_assert(sizeof(JoinRec) == 24 + 2 * sizeof(dh_la), "join blob layout");
+static_assert(sizeof(JoinRec) == 32 + 2 * sizeof(dh_la) && sizeof(JoinHead) == 16, "join blob layout");
 
 // The raw joins of the reads [read_first, read_first + nreads) named by `las` (bread = global read id), in read
 // order: runs of reads per host thread, each run either kept raw (`raws`) or turned into edges (`edges`).
@@ -262,7 +268,14 @@ int collect_raw_joins(const char *who, const dh_la *las, int64_t n, const int64_
     dh_parallel_for((int64_t)live.size(), 1, [&](int64_t clo, int64_t chi) {
         for (int64_t ch = clo; ch < chi; ch++) {
             const auto &v = live[(size_t)ch];
-            int32_t prev = ch > 0 && !live[(size_t)ch - 1].empty() ? live[(size_t)ch - 1].back().first : -1;
+            // (the last live record before this chunk: the nearest earlier chunk that has one -- a run of 16 384 disabled
+            // records, e.g. a fully filtered repeat contig in A-major input, must not hide a descent in read id)
+            int32_t prev = -1;
+            for (int64_t pc = ch - 1; pc >= 0; pc--)
+                if (!live[(size_t)pc].empty()) {
+                    prev = live[(size_t)pc].back().first;
+                    break;
+                }
             for (size_t k = 0; k < v.size(); k++) {
                 if (v[k].first < prev) unsorted = 1;
                 prev = v[k].first;
@@ -365,18 +378,38 @@ extern "C" int dh_shard_read_joins(const dh_la *las, int64_t n, const int64_t *c
     if ((n > 0 && !las) || !contig_off || !read_off || !blob || !nbytes || ncontigs < 0 || nreads < 0 || n < 0 || n >= (1ll << 31) ||
         read_first < 0)
         return dh_fail(DH_EINVAL, "dh_shard_read_joins: bad argument");
+    // alignment chains are the unit, as in dh_scaffold_pileups: the joins are collected on one pseudo record per chain,
+    // the blob carries every member (a read with a long indel next to a gap is cropped through the member that covers
+    // the crop point, dh_crop_pileups)
+    dh_chain_view cv;
+    dh_chain_view_build(las, n, cv);
+    const dh_la *u = cv.trivial ? las : cv.unit.data();
+    const int64_t nu = cv.trivial ? n : (int64_t)cv.unit.size();
+    auto mfirst = [&](int32_t ci) { return cv.trivial ? (int64_t)ci : cv.first[(size_t)ci]; };
+    auto mend = [&](int32_t ci) { return cv.trivial ? (int64_t)ci + 1 : cv.first[(size_t)ci + 1]; };
     std::vector<std::vector<RawJoin>> raws;
-    if (int rc = collect_raw_joins("dh_shard_read_joins", las, n, contig_off, ncontigs, read_off, read_first, nreads, &raws, nullptr)) return rc;
-    size_t tot = 0;
-    std::vector<size_t> at(raws.size());
+    if (int rc = collect_raw_joins("dh_shard_read_joins", u, nu, contig_off, ncontigs, read_off, read_first, nreads, &raws, nullptr)) return rc;
+    size_t tot = 0, totx = 0;
+    std::vector<size_t> at(raws.size()), atx(raws.size());
     for (size_t i = 0; i < raws.size(); i++) {
         at[i] = tot;
+        atx[i] = totx;
         tot += raws[i].size();
+        if (!cv.trivial)
+            for (const RawJoin &r : raws[i])
+                totx += (size_t)(mend(r.ra.la0) - mfirst(r.ra.la0) - 1) + (r.ra.la1 >= 0 ? (size_t)(mend(r.ra.la1) - mfirst(r.ra.la1) - 1) : 0);
     }
-    JoinRec *out = (JoinRec *)malloc(std::max<size_t>(tot, 1) * sizeof(JoinRec));
-    if (!out) return dh_fail(DH_EINVAL, "dh_shard_read_joins: out of memory");
+    const size_t bytes = sizeof(JoinHead) + tot * sizeof(JoinRec) + totx * sizeof(dh_la);
+    uint8_t *blk = (uint8_t *)malloc(bytes);
+    if (!blk) return dh_fail(DH_EINVAL, "dh_shard_read_joins: out of memory");
+    JoinHead *head = (JoinHead *)blk;
+    head->njoins = (int64_t)tot;
+    head->nextra = (int64_t)totx;
+    JoinRec *out = (JoinRec *)(blk + sizeof(JoinHead));
+    dh_la *extra = (dh_la *)(blk + sizeof(JoinHead) + tot * sizeof(JoinRec));
     dh_parallel_for((int64_t)raws.size(), 1, [&](int64_t lo, int64_t hi) {
-        for (int64_t i = lo; i < hi; i++)
+        for (int64_t i = lo; i < hi; i++) {
+            size_t xat = atx[(size_t)i];
             for (size_t x = 0; x < raws[(size_t)i].size(); x++) {
                 const RawJoin &r = raws[(size_t)i][x];
                 JoinRec &j = out[at[(size_t)i] + x];
@@ -387,15 +420,24 @@ extern "C" int dh_shard_read_joins(const dh_la *las, int64_t n, const int64_t *c
                 j.seed1 = r.ra.seed1;
                 j.n = r.ra.n;
                 j.pad = 0;
-                j.la0 = las[r.ra.la0];
-                if (r.ra.la1 >= 0)
-                    j.la1 = las[r.ra.la1];
-                else
+                const int64_t f0 = mfirst(r.ra.la0), e0 = mend(r.ra.la0);
+                j.la0 = las[f0];
+                j.x0 = (int32_t)(e0 - f0 - 1);
+                for (int64_t m = f0 + 1; m < e0; m++) extra[xat++] = las[m];
+                if (r.ra.la1 >= 0) {
+                    const int64_t f1 = mfirst(r.ra.la1), e1 = mend(r.ra.la1);
+                    j.la1 = las[f1];
+                    j.x1 = (int32_t)(e1 - f1 - 1);
+                    for (int64_t m = f1 + 1; m < e1; m++) extra[xat++] = las[m];
+                } else {
                     memset(&j.la1, 0, sizeof(dh_la));
+                    j.x1 = 0;
+                }
             }
+        }
     });
-    *blob = (uint8_t *)out;
-    *nbytes = (int64_t)(tot * sizeof(JoinRec));
+    *blob = blk;
+    *nbytes = (int64_t)bytes;
     return DH_OK;
 }
 
@@ -407,19 +449,71 @@ int dh_scaffold_from_join_blobs(const uint8_t *const *blobs, const int64_t *size
 {
     if (!blobs || !sizes || world < 1 || !opts || !out || ncontigs < 0 || (ngaps > 0 && !input_gaps) || ngaps < 0)
         return dh_fail(DH_EINVAL, "dh_shard_graph_plan_create: bad argument");
-    int64_t tot = 0;
+    int64_t tot = 0, totx = 0;
+    std::vector<int64_t> start((size_t)world + 1, 0);
+    std::vector<const JoinRec *> recs((size_t)world, nullptr);
+    std::vector<const dh_la *> extras((size_t)world, nullptr);
     for (int32_t r = 0; r < world; r++) {
-        if (sizes[r] < 0 || sizes[r] % (int64_t)sizeof(JoinRec)) return dh_fail(DH_EINVAL, "dh_shard_graph_plan_create: blob size");
-        tot += sizes[r] / (int64_t)sizeof(JoinRec);
+        if (sizes[r] < (int64_t)sizeof(JoinHead) || !blobs[r]) return dh_fail(DH_EINVAL, "dh_shard_graph_plan_create: blob size");
+        JoinHead h;
+        memcpy(&h, blobs[r], sizeof(h));
+        if (h.njoins < 0 || h.nextra < 0 || h.njoins > sizes[r] / (int64_t)sizeof(JoinRec) || h.nextra > sizes[r] / (int64_t)sizeof(dh_la) ||
+            (int64_t)sizeof(JoinHead) + h.njoins * (int64_t)sizeof(JoinRec) + h.nextra * (int64_t)sizeof(dh_la) != sizes[r])
+            return dh_fail(DH_EINVAL, "dh_shard_graph_plan_create: blob size");
+        recs[(size_t)r] = (const JoinRec *)(blobs[r] + sizeof(JoinHead));
+        extras[(size_t)r] = (const dh_la *)(blobs[r] + sizeof(JoinHead) + h.njoins * sizeof(JoinRec));
+        start[(size_t)r + 1] = start[(size_t)r] + h.njoins;
+        tot += h.njoins;
+        totx += h.nextra;
     }
-    if (2 * tot >= (1ll << 31)) return dh_fail(DH_EINVAL, "dh_shard_graph_plan_create: too many joins");
+    if (4 * tot + totx >= (1ll << 31)) return dh_fail(DH_EINVAL, "dh_shard_graph_plan_create: too many joins");
     for (int32_t g = 0; g < ngaps; g++)
         if (input_gaps[2 * g] < 0 || input_gaps[2 * g] >= ncontigs || input_gaps[2 * g + 1] < 0 || input_gaps[2 * g + 1] >= ncontigs)
             return dh_fail(DH_EINVAL, "dh_shard_graph_plan_create: input gap names a contig out of range");
-    glas.resize((size_t)(2 * tot));
+    // where the records of every join go: the members of a chain behind its first record (la0 chain, then la1 chain).  Two
+    // copies that would read as one chain (a record flagged NEXT without START behind a copy of its own read on the same
+    // contig) are kept apart by a separator record that continues nothing
+    std::vector<int32_t> pos0((size_t)tot), pos1((size_t)tot);
+    std::vector<int64_t> xoff((size_t)tot);
+    int64_t cur = 0;
+    bool malformed = false;
+    {
+        auto may_continue = [](const dh_la &x) { return (x.flags & DH_FLAG_NEXT) && !(x.flags & DH_FLAG_START); };
+        const dh_la *prev = nullptr;  // the record that will precede the next one placed
+        int64_t at = 0;
+        for (int32_t r = 0; r < world && !malformed; r++) {
+            int64_t xr = 0;
+            const int64_t nx = (sizes[r] - (int64_t)sizeof(JoinHead) - (start[(size_t)r + 1] - start[(size_t)r]) * (int64_t)sizeof(JoinRec)) / (int64_t)sizeof(dh_la);
+            for (int64_t i = 0; i < start[(size_t)r + 1] - start[(size_t)r]; i++, at++) {
+                const JoinRec &j = recs[(size_t)r][i];
+                if (j.x0 < 0 || j.x1 < 0 || (j.n != 1 && j.n != 2) || xr + j.x0 + j.x1 > nx) {
+                    malformed = true;
+                    break;
+                }
+                xoff[(size_t)at] = xr;
+                if (prev && may_continue(j.la0) && dh_continues_chain(*prev, j.la0)) cur++;
+                pos0[(size_t)at] = (int32_t)cur;
+                cur += 1 + j.x0;
+                prev = j.x0 ? &extras[(size_t)r][xr + j.x0 - 1] : &j.la0;
+                if (j.n == 2) {
+                    if (may_continue(j.la1) && dh_continues_chain(*prev, j.la1)) cur++;
+                    pos1[(size_t)at] = (int32_t)cur;
+                    cur += 1 + j.x1;
+                    prev = j.x1 ? &extras[(size_t)r][xr + j.x0 + j.x1 - 1] : &j.la1;
+                } else
+                    pos1[(size_t)at] = -1;
+                xr += j.x0 + j.x1;
+            }
+            if (xr != nx) malformed = true;
+        }
+    }
+    if (malformed) return dh_fail(DH_EINVAL, "dh_shard_graph_plan_create: malformed join record");
+    dh_la sep;
+    memset(&sep, 0, sizeof(sep));
+    sep.aread = sep.bread = -1;
+    sep.flags = DH_FLAG_DISABLED;
+    glas.assign((size_t)cur, sep);
     // runs of the concatenation (rank order = read order) become edges on the host threads, as in the single-rank builder
-    std::vector<int64_t> start((size_t)world + 1, 0);
-    for (int32_t r = 0; r < world; r++) start[(size_t)r + 1] = start[(size_t)r] + sizes[r] / (int64_t)sizeof(JoinRec);
     const int64_t grain = 4096, nruns = (tot + grain - 1) / grain;
     std::vector<std::vector<Edge>> found((size_t)std::max<int64_t>(nruns, 1));
     std::atomic<int> bad{0};
@@ -431,19 +525,24 @@ int dh_scaffold_from_join_blobs(const uint8_t *const *blobs, const int64_t *size
             int32_t r = (int32_t)(std::upper_bound(start.begin(), start.end(), a0) - start.begin()) - 1;
             for (int64_t at = a0; at < a1; at++) {
                 while (at >= start[(size_t)r + 1]) r++;
-                const JoinRec &j = ((const JoinRec *)blobs[r])[at - start[(size_t)r]];
+                const JoinRec &j = recs[(size_t)r][at - start[(size_t)r]];
                 if (j.s.contig < 0 || j.s.contig >= ncontigs || j.e.contig < 0 || j.e.contig >= ncontigs || j.s.part < 0 || j.s.part > 3 ||
-                    j.e.part < 0 || j.e.part > 3 || (j.n != 1 && j.n != 2))
+                    j.e.part < 0 || j.e.part > 3)
                     bad = 1;
-                glas[(size_t)(2 * at)] = j.la0;
-                glas[(size_t)(2 * at + 1)] = j.la1;
+                const dh_la *x = extras[(size_t)r] + xoff[(size_t)at];
+                glas[(size_t)pos0[(size_t)at]] = j.la0;
+                for (int32_t m = 0; m < j.x0; m++) glas[(size_t)pos0[(size_t)at] + 1 + (size_t)m] = x[m];
+                if (j.n == 2) {
+                    glas[(size_t)pos1[(size_t)at]] = j.la1;
+                    for (int32_t m = 0; m < j.x1; m++) glas[(size_t)pos1[(size_t)at] + 1 + (size_t)m] = x[j.x0 + m];
+                }
                 RawJoin &q = raw[(size_t)(at - a0)];
                 q.s = j.s;
                 q.e = j.e;
                 memset(&q.ra, 0, sizeof(q.ra));
                 q.ra.read = j.read;
-                q.ra.la0 = (int32_t)(2 * at);
-                q.ra.la1 = j.n == 2 ? (int32_t)(2 * at + 1) : -1;
+                q.ra.la0 = pos0[(size_t)at];
+                q.ra.la1 = pos1[(size_t)at];
                 q.ra.seed0 = j.seed0;
                 q.ra.seed1 = j.seed1;
                 q.ra.n = j.n;

@@ -257,7 +257,7 @@ def sharded_process_steps(ctx, contigs_db, reads_db, read_first, contig_off, las
         lap("read joins")
         blobs = yield ("all_gather", mine)
         _t[0] = time.perf_counter()
-        ncand = sum(len(b) for b in blobs) // 120
+        ncand = sum(int(np.frombuffer(memoryview(b)[:8], dtype=np.int64)[0]) for b in blobs if len(b) >= 16)  # JoinHead.njoins
         plan = ShardPlan(blobs, popts, graph=(len(contig_off) - 1, input_gaps, g))
     else:
         shift = 0 if cands is None else read_first
@@ -295,7 +295,10 @@ def sharded_process_steps(ctx, contigs_db, reads_db, read_first, contig_off, las
     if _laps and rank == 0:
         import sys
         print("[sharded rank 0] " + ", ".join(_laps), file=sys.stderr)
-    order = np.argsort(grec["contig_left"], kind="stable")   # insertions.sort(): by start node
+    # pile-up order (= the single-GPU order, whatever the world size): rank r's records are its owned pile-ups in
+    # ascending pile-up index; several pile-ups may share contig_left, so the start node alone does not order them
+    pile_of = np.concatenate([np.nonzero(owner == r)[0] for r in range(world)]) if len(grec) else np.zeros(0, dtype=np.int64)
+    order = np.argsort(pile_of, kind="stable") if len(pile_of) == len(grec) else np.argsort(grec["contig_left"], kind="stable")
     nentries = int(piles.flat()[1].sum())
     plan.close()
     info = {"piles": len(rec), "owned": len(mine_piles), "candidates": int(ncand), "entries": nentries,

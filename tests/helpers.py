@@ -28,3 +28,40 @@ def check_trace_invariants(las, trace, tspace):
         assert t[1::2].sum() == la["bepos"] - la["bbpos"]
         assert t[0::2].sum() == la["diffs"]
         assert la["tlen"] // 2 == -(-int(la["aepos"]) // tspace) - int(la["abpos"]) // tspace
+
+
+def plant_long_indels(w, rng):
+    """Reads of the workload `w` that span a gap get a 2-5 kb insertion of foreign bases, or lose 2-5 kb of contig bases,
+    1.5-3.5 kb away from the gap (every second eligible read): each then maps as two collinear records on that flank,
+    ONE alignment chain (dazzler.d:1728-1758).  Returns (reads DB, indices of the changed reads)."""
+    from dentist_amd import sim
+    seqs = [w.reads.seq(i) for i in range(w.reads.n)]
+    planted, eligible = [], 0
+    for i, (s0, e0, strand) in enumerate(w.read_truth):
+        for g in range(len(w.gap_begin)):
+            gb, ge = int(w.gap_begin[g]), int(w.gap_end[g])
+            if not (s0 + 1500 < gb and ge + 1500 < e0):
+                continue
+            left = gb - s0 >= e0 - ge          # the longer flank part of the read gets the indel
+            if (gb - s0 if left else e0 - ge) < 7000:
+                continue
+            eligible += 1
+            if eligible % 2:
+                continue
+            # a position 1.5-3.5 kb away from the gap, in read coordinates (reads are ~ (1 + ins - del) longer than the truth)
+            d = int(rng.integers(1500, 3500))
+            gpos = gb - d if left else ge + d
+            scale = len(seqs[i]) / float(e0 - s0)
+            at = int((gpos - s0) * scale) if not strand else int((e0 - gpos) * scale)
+            ln = int(rng.integers(2000, 5000))
+            s = seqs[i]
+            if len(planted) % 2 == 0:    # foreign bases in the read
+                seqs[i] = np.concatenate([s[:at], rng.integers(0, 4, ln).astype(np.uint8), s[at:]])
+            else:                        # contig bases missing from the read: cut away from the gap
+                lo, hi = (at - ln, at) if left != bool(strand) else (at, at + ln)
+                if lo < 1000 or hi > len(s) - 1000:
+                    continue
+                seqs[i] = np.concatenate([s[:lo], s[hi:]])
+            planted.append(i)
+            break
+    return sim.SeqDb.from_list(seqs), planted

@@ -229,7 +229,27 @@ def test_sharded_scaffold_collector_equals_the_single_rank_builder():
     las = np.ascontiguousarray(las[np.argsort(las["bread"], kind="stable")])
     coff, roff = w.contigs.off, w.reads.off
     gaps = np.stack([np.arange(w.contigs.n - 1), np.arange(1, w.contigs.n)], axis=1).astype(np.int32)
-    for max_reads in (0, 6):
+    # the same mapping with ALIGNMENT CHAINS (damapper's START / NEXT records, dazzler.d:1728-1758): every third long
+    # alignment is cut into two chained records around a 40-base hole, as a read with a long indel would be reported
+    parts = []
+    nchained = 0
+    for i, l in enumerate(las):
+        if i % 3 == 0 and l["aepos"] - l["abpos"] > 2500 and not (l["flags"] & 0x20):
+            a, b = np.array([l, l])
+            ma, mb = (l["abpos"] + l["aepos"]) // 2, (l["bbpos"] + l["bepos"]) // 2
+            a["aepos"], a["bepos"], a["diffs"] = ma - 20, mb - 20, l["diffs"] // 2
+            b["abpos"], b["bbpos"], b["diffs"] = ma + 20, mb + 20, l["diffs"] - l["diffs"] // 2
+            a["flags"] = (int(l["flags"]) & 0xFFFFFFF7) | 0x4
+            b["flags"] = (int(l["flags"]) & 0xFFFFFFFB) | 0x8
+            parts += [a, b]
+            nchained += 1
+        else:
+            parts.append(l)
+    las_chained = np.ascontiguousarray(np.array(parts, dtype=las.dtype))
+    assert nchained > 50
+    nchain_seen = 0
+    for max_reads, las in ((0, las), (6, las), (0, las_chained), (6, las_chained)):
+        chained = las is las_chained
         po = dentist_amd.default_process_opts(max_reads=max_reads)
         gp, _ = dentist_amd.scaffold_spanning_pileups(las, coff, roff, gaps, with_extensions=True, min_spanning_reads=po.min_reads)
         ecl, ecnt, etri = gp.select(las, po).flat()
@@ -247,8 +267,18 @@ def test_sharded_scaffold_collector_equals_the_single_rank_builder():
                 assert np.array_equal(tri[:, col] < 0, etri[:, col] < 0)
                 m = tri[:, col] >= 0
                 assert np.array_equal(plan.las[tri[m, col]], las[etri[m, col]])
+                if chained:   # the members of an entry's chain follow its first record on both sides, and nothing else does
+                    nxt_e = np.minimum(etri[m, col] + 1, len(las) - 1)
+                    nxt_p = np.minimum(tri[m, col] + 1, len(plan.las) - 1)
+                    cont = lambda L, i, j: ((L["flags"][j] & 0xC) == 0x8) & (L["aread"][i] == L["aread"][j]) & \
+                        (L["bread"][i] == L["bread"][j]) & ((L["flags"][i] & 1) == (L["flags"][j] & 1)) & (i != j)  # noqa: E731
+                    ce, cp = cont(las, etri[m, col], nxt_e), cont(plan.las, tri[m, col], nxt_p)
+                    assert np.array_equal(ce, cp)
+                    nchain_seen += int(ce.sum())
+                    assert np.array_equal(plan.las[nxt_p[cp]], las[nxt_e[ce]])
             assert len(plan.owner) == len(cl) and set(plan.owner.tolist()) <= set(range(world))
             plan.close()
+    assert nchain_seen > 20   # entries whose chain has a second member, on both sides
 
 
 def test_shard_graph_glue_rejects_malformed_input():
@@ -266,12 +296,12 @@ def test_shard_graph_glue_rejects_malformed_input():
         shard_read_joins(la, coff, roff, 5)
     la["bread"] = 6
     blob = shard_read_joins(la, coff, roff, 5)
-    assert len(blob) % 120 == 0 and len(blob) > 0
+    assert (len(blob) - 16) % 128 == 0 and len(blob) > 16   # JoinHead + JoinRec records, no chain members here
     po = dentist_amd.default_process_opts()
     with pytest.raises(dentist_amd.DhError):
         ShardPlan([blob[:-8]], po, graph=(2, None, {}))             # not a whole number of records
     bad = blob.copy()
-    bad[0:4] = np.asarray([99], dtype=np.int32).view(np.uint8)      # edge names a contig outside the assembly
+    bad[16:20] = np.asarray([99], dtype=np.int32).view(np.uint8)    # edge names a contig outside the assembly
     with pytest.raises(dentist_amd.DhError):
         ShardPlan([bad], po, graph=(2, None, {}))
     plan = ShardPlan([blob], po, graph=(2, None, {"min_spanning_reads": 1}))

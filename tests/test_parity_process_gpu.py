@@ -8,7 +8,7 @@ import pytest
 
 import dentist_amd
 from dentist_amd import sim
-from helpers import assert_same_las
+from helpers import plant_long_indels, assert_same_las
 from oracle import process as pr
 from oracle import pyoracle as oz
 
@@ -526,38 +526,8 @@ def test_chains_with_a_long_indel_next_to_a_gap(gpu_ctx):
     from oracle import collect_filters as cf
     from oracle import scaffold as sc
     w = sim.Workload(600_000, 6, 1500, 12_000, seed=20260930, spacing=60000, gap_max=1500)
-    rng = np.random.default_rng(5)
-    seqs = [w.reads.seq(i) for i in range(w.reads.n)]
-    planted, eligible = [], 0
-    for i, (s0, e0, strand) in enumerate(w.read_truth):
-        for g in range(len(w.gap_begin)):
-            gb, ge = int(w.gap_begin[g]), int(w.gap_end[g])
-            if not (s0 + 1500 < gb and ge + 1500 < e0):
-                continue
-            left = gb - s0 >= e0 - ge          # the longer flank part of the read gets the indel
-            if (gb - s0 if left else e0 - ge) < 7000:
-                continue
-            eligible += 1
-            if eligible % 2:
-                continue
-            # a position 1.5-3.5 kb away from the gap, in read coordinates (reads are ~ (1 + ins - del) longer than the truth)
-            d = int(rng.integers(1500, 3500))
-            gpos = gb - d if left else ge + d
-            scale = len(seqs[i]) / float(e0 - s0)
-            at = int((gpos - s0) * scale) if not strand else int((e0 - gpos) * scale)
-            ln = int(rng.integers(2000, 5000))
-            s = seqs[i]
-            if len(planted) % 2 == 0:    # foreign bases in the read
-                seqs[i] = np.concatenate([s[:at], rng.integers(0, 4, ln).astype(np.uint8), s[at:]])
-            else:                        # contig bases missing from the read: cut away from the gap
-                lo, hi = (at - ln, at) if left != bool(strand) else (at, at + ln)
-                if lo < 1000 or hi > len(s) - 1000:
-                    continue
-                seqs[i] = np.concatenate([s[:lo], s[hi:]])
-            planted.append(i)
-            break
+    reads, planted = plant_long_indels(w, np.random.default_rng(5))
     assert len(planted) >= 12
-    reads = sim.SeqDb.from_list(seqs)
     mo = dentist_amd.default_align_opts(kmer_mod=4, k=20, width=64, xdrop=60, algo=1)
     po = dentist_amd.default_process_opts(algo=1, rounds=2, max_reads=0)
     A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(reads)

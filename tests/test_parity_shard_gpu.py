@@ -230,6 +230,61 @@ def test_dh_shard_run_between_host_threads_equals_the_single_gpu_run(world, coll
         c.close()
 
 
+def test_dh_shard_run_with_alignment_chains_equals_the_single_gpu_run():
+    """Reads with a 2-5 kb indel next to a gap map as CHAINS (START + NEXT records, dazzler.d:1728-1758); the sharded
+    collector has to treat them as the single-GPU one does: joins collected on one unit per chain, every member of the
+    chain in the join blob (dh_shard_read_joins), the members laid out behind the first record on the receiving side
+    (dh_shard_graph_plan_create) so that the cropper translates the crop point through the member that covers it.  With
+    single records these reads would be dropped or cropped through the wrong member (round-4 advisor finding)."""
+    import threading
+    from helpers import plant_long_indels
+    w = sim.Workload(600_000, 6, 1500, 12_000, seed=20260930, spacing=60000, gap_max=1500)
+    reads, planted = plant_long_indels(w, np.random.default_rng(5))
+    assert len(planted) >= 12
+    mo = dentist_amd.default_align_opts(kmer_mod=4, k=20, width=64, xdrop=60, algo=1)
+    po = dentist_amd.default_process_opts(algo=1, rounds=2, max_reads=0)
+    gaps_in = np.stack([np.arange(w.contigs.n - 1), np.arange(1, w.contigs.n)], axis=1).astype(np.int32)
+    ctx0 = dentist_amd.Context(0)
+    A, B = ctx0.db(w.contigs), ctx0.db(reads)
+    las, trace, _ = ctx0.map_reads(A, B, mo, po, sorted=False, candidates=False)[:3]
+    gp, _ = dentist_amd.scaffold_spanning_pileups(las, w.contigs.off, reads.off, gaps_in, with_extensions=True,
+                                                  min_spanning_reads=po.min_reads)
+    piles = gp.select(las, po)
+    tri = piles.flat()[2]
+    nxt = lambda i: (i >= 0) & (i + 1 < len(las)) & ((las["flags"][np.minimum(i + 1, len(las) - 1)] & 0xC) == 0x8)  # noqa: E731
+    assert int(nxt(tri[:, 1]).sum() + nxt(tri[:, 2]).sum()) >= 10, "the planted reads must enter the pile-ups as chains"
+    rec, bases = dentist_amd.process_pileups(ctx0, A, B, las, trace, piles, po)
+    assert (rec["status"] == 0).sum() >= 5
+    for world in (2, 3):
+        ctxs = [dentist_amd.Context(0) for _ in range(world)]
+        comms = dentist_amd.Comm.local(world, ctxs)
+        results, errors = [None] * world, []
+
+        def run(rank):
+            try:
+                ctx = ctxs[rank]
+                lo, hi = parallel.shard_range(reads.n, rank, world)
+                share = sim.SeqDb(reads.bases[reads.off[lo]:reads.off[hi]], reads.off[lo:hi + 1] - reads.off[lo])
+                Ar, Br = ctx.db(w.contigs), ctx.db(share)
+                m = ctx.map_reads(Ar, Br, mo, po, sorted=False, candidates=False)
+                lr, tr = m[0].copy(), m[1]
+                lr["bread"] += lo
+                results[rank] = dentist_amd.shard_run(comms[rank], Ar, Br, lo, w.contigs.off, lr, tr, po,
+                                                      graph=dict(read_off=share.off, input_gaps=gaps_in))
+            except Exception as e:  # noqa: BLE001
+                errors.append((rank, repr(e)))
+                raise
+        threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=600)
+        assert not errors, errors
+        _same(results, rec, bases)
+        for c in comms:
+            c.close()
+
+
 def test_dh_shard_run_over_rccl_at_world_one(gpu_ctx):
     """The RCCL back end of the same entry, executable on a one-GPU box: a communicator of one rank (ncclCommInitRank
     with world 1) -- ncclAllGather of the sizes and of the padded blobs, grouped ncclSend / ncclRecv to itself -- must
