@@ -13,6 +13,7 @@
 
 #include "dh_internal.h"
 #include "dh_join.h"
+#include "dh_mjoin.h"
 #include "dh_tile.h"
 #include "dh_parallel.h"
 
@@ -271,6 +272,15 @@ extern "C" int dh_ctx_sync(dh_ctx *c)
 {
     if (!c) return fail(DH_EINVAL, "ctx is NULL");
     HIPCHK(hipStreamSynchronize(c->stream));
+    return DH_OK;
+}
+
+extern "C" int dh_get_mjoin_counts(dh_ctx *c, int64_t *out2, int32_t reset)
+{
+    if (!c || !out2) return fail(DH_EINVAL, "dh_get_mjoin_counts: NULL");
+    out2[0] = c->mj_chunks;
+    out2[1] = c->mj_fallbacks;
+    if (reset) c->mj_chunks = c->mj_fallbacks = 0;
     return DH_OK;
 }
 
@@ -1574,6 +1584,28 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         cap = jhist[0] <= tol ? 2048 : (jhist[1] <= tol ? 4096 : 8192);
     }
     if (const char *e = getenv("DH_SEED_CAP")) cap = atoi(e);  // development: 1024 .. 16384, power of two
+    // ---- a mapping pass (A != B, ungrouped): the seeds of a chunk of reads come from the radix-partitioned k-mer join
+    // (dh_mjoin.h) -- the reads' k-mers binned by directory slice, every slice joined on chip -- instead of one random
+    // directory line per k-mer; bit-identical hits.  Small chunks keep the directory path (the join's fixed costs: 1 024
+    // partitions, a page per wavefront); DH_NO_MJOIN=1 forces it, DH_MJOIN_MIN sets the threshold (bases of a chunk).
+    bool use_mj = !use_join && A != B && !A->d_group && A->ngroups == 1 && !B->d_group && o.k >= MJ_MINK && o.k <= MJ_MAXK &&
+                  o.skip_self == 0 && want_packed && A->ix.n > 0 && A->ix.n < (1ll << 28) && !getenv("DH_NO_MJOIN");
+    int64_t mj_min_bases = 64ll << 20;
+    if (const char *e = getenv("DH_MJOIN_MIN")) mj_min_bases = atoll(e);
+    if (use_mj && !A->ix.d_bitmap) {
+        // about 16 buckets per indexed k-mer (7 % of the looked-up k-mers then pass the filter without being in A)
+        int32_t nbbits = std::min(MJ_MAXBITS, std::min(2 * o.k, std::max(MJ_PBITS + 5, ceil_log2((uint64_t)A->ix.n) + 4)));
+        const size_t words = (size_t)1 << (nbbits - 5);
+        HIPCHK(dh_dev_alloc(&A->ix.d_bitmap, sizeof(uint32_t) * words));
+        HIPCHK(dhk_memset(st, A->ix.d_bitmap, 0, sizeof(uint32_t) * words));
+        dhk_mj_bitmap(st, A->ix.d_ent, A->ix.n, o.k, nbbits, A->ix.d_bitmap);
+        HIPCHK(hipGetLastError());
+        A->ix.nbbits = nbbits;
+    }
+    JoinView jv_mj = {};
+    bool mj_skip_chunk = false;  // the chunk at hand overflowed a capacity of the join: directory path for it
+    uint32_t *d_mjctr_last = nullptr;
+    int64_t mj_exp_ent_last = 0;
 
     std::vector<int32_t> h_ncand((size_t)cn), h_nhits((size_t)cn);
     float ms_seed = 0, ms_wave = 0, ms_gather = 0;
@@ -1639,8 +1671,77 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         uint64_t *d_fscr = nullptr;
         if (cap > 4096 && cap <= 8192)
             SCR(30, d_fscr, (size_t)ctx->ncu * DH_SEED_FSCR_BLOCKS_PER_CU * DH_SEED_FSCR_WORDS)
-        if (use_join)
-            dhk_seed_join(st, cap, bv, iv, dopt, jv, (int32_t)item0, ni, candbase, ncandbase, nhitsbase, d_status,
+        bool mj_chunk = false;
+        {
+            const int32_t cr0 = (int32_t)(item0 >> 1), cr1 = (int32_t)((item0 + ni) >> 1);
+            const int64_t cb0 = B->h_off[(size_t)cr0], cb1 = B->h_off[(size_t)cr1];
+            if (use_mj && !mj_skip_chunk && !cc.has_n && cb1 - cb0 >= mj_min_bases && cb1 - cb0 < (1ll << 40)) {
+                MjView mv = {};
+                mv.c0 = cb0;
+                mv.c1 = cb1;
+                mv.r0 = cr0;
+                mv.r1 = cr1;
+                mv.k = o.k;
+                mv.kmer_mod = std::max(1, o.kmer_mod);
+                mv.nbbits = A->ix.nbbits;
+                // bases per tile: 7/8 of the tile's capacity expected (modimer sampling is a hash: 12 sigma of slack), every
+                // lane of the block rolls the same number of positions, positions fit MJ_POSBITS
+                int64_t tb = (int64_t)(MJ_CAP / 8 * 7) * mv.kmer_mod;
+                if (mv.kmer_mod == 1) tb = MJ_CAP;
+                tb = std::min<int64_t>(tb, (1 << MJ_POSBITS) - 64);
+                tb = std::max<int64_t>(MJ_THREADS * 8, tb / (MJ_THREADS * 8) * (MJ_THREADS * 8));
+                mv.tb = (int32_t)tb;
+                const int64_t ntiles = (cb1 - cb0 + tb - 1) / tb;
+                mv.ntiles = (int32_t)ntiles;
+                mv.ntiles_pad = (int32_t)((ntiles + MJ_BATCH - 1) / MJ_BATCH * MJ_BATCH);
+                mv.ngroups = mv.ntiles_pad / MJ_GROUP;
+                const int64_t tbg = tb * MJ_GROUP;
+                mv.nseg = (int32_t)((B->max_len + tbg - 1) / tbg + 1);
+                // hit pool: 20 % of the sampled k-mers hit (measured 6 % at 13 % error and k = 20; raised when a pool ran out: low-error
+                // reads) plus the chance matches, a page per wavefront
+                // of the probe kernel on top; the same number of hits regrouped by read
+                // (dens: chance matches of a sampled k-mer per strand, as for the LDS capacity above)
+                const int64_t exp_ent = (cb1 - cb0) / mv.kmer_mod;
+                int64_t npages = (int64_t)((ctx->mj_hit_frac + 2.5 * dens) * (double)exp_ent) / MJ_PAGE + (int64_t)ctx->ncu * (MJ_PROBE_THREADS / 64) + 64;
+                if (const char *e = getenv("DH_MJOIN_PAGES")) npages = std::max<int64_t>(1, atoll(e));  // development / tests: force the fall-back
+                if (ntiles < (1ll << 30) / MJ_P && npages < (1ll << 31) / 2 && mv.nseg <= 512) {
+                    mv.npages = (int32_t)npages;
+                    mv.rcap = npages * MJ_PAGE;
+                    uint32_t *d_mjctr;
+                    SCR(64, mv.ent, (size_t)ntiles * MJ_CAP)
+                    SCR(65, mv.segoff, (size_t)ntiles * MJ_P)
+                    SCR(66, mv.tile_n, (size_t)ntiles)
+                    SCR(67, mv.seg, (size_t)MJ_P * mv.ntiles_pad)
+                    SCR(68, mv.hseg, (size_t)mv.ngroups * MJ_P)
+                    SCR(69, mv.hits, (size_t)npages * MJ_PAGE)
+                    SCR(70, mv.rhits, (size_t)mv.rcap)
+                    SCR(71, mv.segtab, (size_t)(cr1 - cr0) * mv.nseg)
+                    SCR(72, d_mjctr, 16)
+                    mv.ctr = d_mjctr;
+                    d_mjctr_last = d_mjctr;
+                    mj_exp_ent_last = exp_ent;
+                    mv.bitmap = A->ix.d_bitmap;
+                    mv.status = d_status;
+                    HIPCHK(dhk_memset(st, mv.segtab, 0, sizeof(unsigned long long) * (size_t)(cr1 - cr0) * mv.nseg));
+                    dhk_mj_run(st, bv, iv, dopt, mv, ctx->ncu);
+                    HIPCHK(hipGetLastError());
+                    jv_mj = JoinView{};
+                    jv_mj.segtab = (uint64_t *)mv.segtab;
+                    jv_mj.hits = mv.rhits;
+                    jv_mj.status = d_status;
+                    jv_mj.ns_fixed = mv.nseg;
+                    jv_mj.read0 = cr0;
+                    mj_chunk = true;
+                }
+            }
+        }
+        const bool jn = use_join || mj_chunk;            // the back end gathers its hits from segments
+        const JoinView &jvx = mj_chunk ? jv_mj : jv;
+        // (the back end fed from segments exists with 2048, 4096 and 8192 entries of LDS; the 8192-entry one scans in a slab)
+        const int capj = std::min(std::max(cap, 2048), 8192);
+        if (jn && capj > 4096 && !d_fscr) SCR(30, d_fscr, (size_t)ctx->ncu * DH_SEED_FSCR_BLOCKS_PER_CU * DH_SEED_FSCR_WORDS)
+        if (jn)
+            dhk_seed_join(st, capj, bv, iv, dopt, jvx, (int32_t)item0, ni, candbase, ncandbase, nhitsbase, d_status,
                           d_queue + 1, ctx->ncu, d_fscr, nullptr, 0);
         else
             dhk_seed(st, cap, bv, iv, dopt, (int32_t)item0, ni, candbase, ncandbase, nhitsbase, d_status,
@@ -1655,6 +1756,34 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             HIPCHK(hipMemcpyAsync(&status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
             HIPCHK(hipMemcpyAsync(sm, d_summary, sizeof(sm), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
+            if (mj_chunk && (status & DH_ST_MJ_POOL) && !(status & DH_ST_MJ_OVERFLOW) && !getenv("DH_MJOIN_PAGES")) {
+                // the hit pool ran out (more hits per k-mer than planned: low-error reads, short k-mers): sized by the pages
+                // the probe kernel asked for, the chunk runs through the join again -- and the later ones start with that rate
+                uint32_t asked = 0;
+                HIPCHK(hipMemcpyAsync(&asked, d_mjctr_last + 8, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                status &= ~DH_ST_MJ_POOL;
+                HIPCHK(hipMemcpyAsync(d_status, &status, sizeof(int32_t), hipMemcpyHostToDevice, st));
+                HIPCHK(hipStreamSynchronize(st));
+                const double need = 1.3 * (double)asked * MJ_PAGE / std::max<double>(1.0, (double)mj_exp_ent_last);
+                ctx->mj_hit_frac = std::max(ctx->mj_hit_frac * 1.5, need);
+                if (getenv("DH_TRACE")) fprintf(stderr, "[mjoin] hit pool too small (%u pages asked): %.2f hits per k-mer planned from now on\n", asked, ctx->mj_hit_frac);
+                if (ctx->mj_hit_frac <= 64.0) {
+                    item0 -= cn;
+                    continue;
+                }
+                status |= DH_ST_MJ_OVERFLOW;
+            }
+            if (mj_chunk && (status & (DH_ST_MJ_OVERFLOW | DH_ST_MJ_POOL))) {
+                // a capacity of the partitioned join was exceeded (repeat-rich reads): this chunk again, by the directory
+                if (getenv("DH_TRACE")) fprintf(stderr, "[mjoin] a capacity was exceeded: chunk at item %lld redone by the directory path\n", (long long)item0);
+                status &= ~(DH_ST_MJ_OVERFLOW | DH_ST_MJ_POOL);
+                HIPCHK(hipMemcpyAsync(d_status, &status, sizeof(int32_t), hipMemcpyHostToDevice, st));
+                HIPCHK(hipStreamSynchronize(st));
+                mj_skip_chunk = true;
+                ctx->mj_fallbacks++;
+                item0 -= cn;
+                continue;
+            }
             std::vector<int32_t> big;
             int32_t gcap = 0;
             if (sm[2] > 0) {  // the per-item arrays travel only when some item overflowed its LDS buffer
@@ -1674,12 +1803,14 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             if (const char *e = getenv("DH_SEED_BIG_PCT")) redo_all = (size_t)((double)ni * atof(e) / 200.0);  // development (reads = ni / 2)
             if (getenv("DH_TRACE") && !big.empty())
                 fprintf(stderr, "[seeds] cap %d: %zu of %d reads overflow (whole chunk again above %zu)\n", cap, big.size(), ni / 2, redo_all);
-            if (!use_join && big.size() > redo_all && cap < 16384) {
+            if (!jn && big.size() > redo_all && cap < 16384) {
                 cap *= 2;
                 item0 -= cn;
                 continue;
             }
-            if (use_join && cap < 8192 && !big.empty()) {
+            if (mj_chunk) ctx->mj_chunks++;
+            mj_skip_chunk = false;  // (the next chunk tries the join again)
+            if (jn && capj < 8192 && !big.empty()) {
                 // second tier of the join path: the reads above the first capacity that fit the 8192-entry variant
                 std::vector<int32_t> mid, huge;
                 int32_t gcap2 = 0;
@@ -1706,7 +1837,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
                         dhk_seed_prof_dump();
                     }
 #endif
-                    dhk_seed_join(st, 8192, bv, iv, dopt, jv, (int32_t)item0, ni, candbase, ncandbase, nhitsbase, d_status,
+                    dhk_seed_join(st, 8192, bv, iv, dopt, jvx, (int32_t)item0, ni, candbase, ncandbase, nhitsbase, d_status,
                                   d_queue + 1, ctx->ncu, d_fscr2, d_mid, (int32_t)mid.size());
                     HIPCHK(hipGetLastError());
                     HIPCHK(hipStreamSynchronize(st));  // mid goes out of scope
@@ -1737,8 +1868,8 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
                 for (size_t b0 = 0; b0 < big.size(); b0 += per_launch) {
                     const int32_t cnt = (int32_t)std::min(per_launch, big.size() - b0);
                     HIPCHK(hipMemsetAsync(d_queue + 2, 0, sizeof(uint32_t), st));
-                    if (use_join)
-                        dhk_seed_big_join(st, bv, iv, dopt, jv, d_list + b0, cnt, d_gbuf, pow2, candbase, ncandbase,
+                    if (jn)
+                        dhk_seed_big_join(st, bv, iv, dopt, jvx, d_list + b0, cnt, d_gbuf, pow2, candbase, ncandbase,
                                           nhitsbase, d_status, d_queue + 2, ctx->ncu);
                     else
                         dhk_seed_big(st, bv, iv, dopt, d_list + b0, cnt, d_gbuf, pow2, candbase, ncandbase,

@@ -62,6 +62,8 @@ struct dh_ctx {
     hipEvent_t cev[4] = {};
     dh_align_stats stats = {};
     dh_cum_stats cum = {};
+    double mj_hit_frac = 0.2;  // hits per sampled k-mer the hit pool of the partitioned join is sized for (raised when a pool overflowed)
+    int64_t mj_chunks = 0, mj_fallbacks = 0;  // chunks seeded by the partitioned join / redone by the directory (dh_get_mjoin_counts)
     int32_t near_best_ppm = -1;  // damapper -n of this context (dh_ctx_set_near_best); -1 = the process default
     // second context of the same device (own streams and scratch), created on first use: the process stage runs the
     // two halves of a batch of pile-ups concurrently, one on each (dh_process_pileups)
@@ -71,7 +73,7 @@ struct dh_ctx {
     struct Arena {
         void *p = nullptr;
         size_t cap = 0;
-    } arena[64];
+    } arena[96];
 };
 // slot `id` of the context's scratch arena, at least `bytes` large
 int dh_scratch(dh_ctx *ctx, int id, size_t bytes, void **out);
@@ -86,6 +88,10 @@ struct dh_index {
     int32_t *d_page_seq = nullptr;  // virtual page (4096 bases) -> sequence
     int64_t n = 0;
     int32_t k = 0, sepv = 0, shift = 0, pbits = 0, na = 0, kmer_mod = 1;
+    // presence bitmap of the entries' keys for the partitioned join of a mapping pass (dh_mjoin.h): bit key >> (2k - nbbits),
+    // built on first use
+    uint32_t *d_bitmap = nullptr;
+    int32_t nbbits = 0;
     bool light = false;  // virtual axis only (no directory): the hits come from the k-mer join (dh_join.hip)
     void release()
     {
@@ -97,6 +103,9 @@ struct dh_index {
         d_fat = nullptr;
         dh_dev_free(d_page_seq);
         d_page_seq = nullptr;
+        dh_dev_free(d_bitmap);
+        d_bitmap = nullptr;
+        nbbits = 0;
         d_dir = nullptr;
         d_ent = nullptr;
         d_goff = nullptr;

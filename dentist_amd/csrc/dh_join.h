@@ -64,6 +64,9 @@ struct JoinView {
     int64_t hits_cap;
     int32_t *status;
     int32_t npart, njoin;
+    // the partitioned join of a mapping pass (dh_mjoin.h) feeds the same back end: no groups, every read has ns_fixed
+    // segments, row (read - read0) * ns_fixed of segtab (gns == NULL selects this form)
+    int32_t ns_fixed, read0;
 };
 
 #ifdef __cplusplus

@@ -532,10 +532,11 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
         uint64_t *segb = (uint64_t *)cands;                     // [SEED_THREADS] first hit of segment s
         uint32_t *sego = (uint32_t *)(cands + SEED_CCAP) + 1;   // [-1 .. SEED_THREADS) exclusive prefix sums of the counts
         __shared__ uint32_t s_jw[SEED_THREADS / LANES];
-        const int32_t ns = jv.gns[B.group[r]];
+        const int32_t ns = jv.gns ? jv.gns[B.group[r]] : jv.ns_fixed;
+        const int64_t srow = jv.gns ? jv.segrow[r] : (int64_t)(r - jv.read0) * jv.ns_fixed;
         uint32_t c = 0;
         if (tid < ns) {
-            const uint64_t sg = jv.segtab[jv.segrow[r] + tid];
+            const uint64_t sg = jv.segtab[srow + tid];
             c = (uint32_t)(sg & 0xFFFFFFull);
             segb[tid] = sg >> 24;
         }

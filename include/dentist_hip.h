@@ -143,6 +143,11 @@ typedef struct {
     int64_t wave_launches, wave_cells, alignments, las, aligned_bp, trace_values, hits, b_bases;
 } dh_cum_stats;
 int dh_get_cum_stats(dh_ctx *ctx, dh_cum_stats *out, int32_t reset);
+/* Chunks of reads of the mapping calls on this context whose seeds came from the radix-partitioned k-mer join
+ * (csrc/dh_mjoin.h: the damapper role, dazzler.d:6158-6170, without a random directory line per k-mer) -- out2[0] --
+ * and chunks that exceeded one of its capacities and were redone by the directory lookups -- out2[1].  Both paths give
+ * the same alignments; the counts say which one ran (tests, traces). */
+int dh_get_mjoin_counts(dh_ctx *ctx, int64_t *out2, int32_t reset);
 
 /*
  * dh_align_db -- every sequence of B against all of A: k-mer seeds, diagonal band filter, wave

@@ -1,0 +1,149 @@
+"""The radix-partitioned k-mer join that seeds a mapping pass (csrc/dh_mjoin.h; the damapper role,
+dazzler.d:6158-6170) against the CPU oracle and against the directory lookups it replaces -- bit exact: the same
+hits per read, hence the same candidates, alignments and trace values.
+
+The join takes chunks of at least 64 Mbp by default; DH_MJOIN_MIN=0 sends the small inputs of these tests through it
+and dh_get_mjoin_counts tells that it ran."""
+import os
+
+import numpy as np
+import pytest
+
+import dentist_amd
+from dentist_amd import sim
+from helpers import assert_same_las, check_trace_invariants
+from oracle import pyoracle as oz
+from test_parity_map_gpu import both_opts
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _join_for_small_inputs(monkeypatch):
+    monkeypatch.setenv("DH_MJOIN_MIN", "0")
+
+
+def run_both(ctx, A, B, expect_join=True, **kw):
+    g, o = both_opts(**kw)
+    exp = oz.align_db(A, B, o, nthreads=os.cpu_count() or 1)
+    dA, dB = ctx.db(A), ctx.db(B)
+    ctx.mjoin_counts(reset=True)
+    got = ctx.align_db(dA, dB, g)
+    st = ctx.align_stats()
+    chunks, fallbacks = ctx.mjoin_counts()
+    assert (chunks > 0) == expect_join, (chunks, fallbacks)
+    assert (st.hits, st.cands, st.alignments, st.wave_cells) == tuple(int(x) for x in exp[2])
+    assert_same_las(got, exp[:2])
+    check_trace_invariants(got[0], got[1], g.tspace)
+    return got, (chunks, fallbacks)
+
+
+@pytest.mark.parametrize("k,mod,algo", [(20, 8, 1), (20, 1, 1), (20, 4, 0), (14, 1, 1), (14, 2, 0), (17, 3, 1), (22, 4, 1), (12, 1, 1)])
+def test_mapping_through_the_partitioned_join(gpu_ctx, k, mod, algo):
+    w = sim.Workload(400_000, 4, 700, 6000, seed=11 + k, spacing=20000)
+    (las, _), (chunks, fallbacks) = run_both(gpu_ctx, w.contigs, w.reads, k=k, kmer_mod=mod, algo=algo,
+                                           width=64 if algo == 1 else 30)
+    assert fallbacks == 0 and len(set(las["bread"].tolist())) >= 0.98 * w.reads.n
+
+
+def test_equal_to_the_directory_lookups_on_every_field(gpu_ctx, monkeypatch):
+    """The same call with DH_NO_MJOIN=1 (one random directory line per k-mer): identical records, trace and counters."""
+    w = sim.Workload(600_000, 5, 1500, 9000, seed=71, spacing=20000)
+    g = dentist_amd.default_align_opts(k=20, kmer_mod=8, algo=1, width=64, xdrop=60)
+    A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
+    gpu_ctx.mjoin_counts(reset=True)
+    a = gpu_ctx.align_db(A, B, g)
+    sa = gpu_ctx.align_stats()
+    assert gpu_ctx.mjoin_counts() == (1, 0)
+    monkeypatch.setenv("DH_NO_MJOIN", "1")
+    B.drop_cache()
+    A.drop_cache()
+    b = gpu_ctx.align_db(A, B, g)
+    sb = gpu_ctx.align_stats()
+    assert gpu_ctx.mjoin_counts() == (1, 0)
+    assert_same_las(a, b)
+    assert (sa.hits, sa.cands, sa.alignments, sa.wave_cells) == (sb.hits, sb.cands, sb.alignments, sb.wave_cells)
+
+
+def test_ragged_reads_short_empty_and_tile_straddling(gpu_ctx, monkeypatch):
+    """Reads shorter than k, empty reads, reads of a few bases between long ones, a long read over many tiles, read
+    starts at every offset relative to the 8 192-base tiles (kmer_mod 1): no k-mer may cross a read boundary."""
+    rng = np.random.default_rng(3)
+    w = sim.Workload(300_000, 3, 300, 7000, seed=91, spacing=15000)
+    seqs = []
+    for i in range(w.reads.n):
+        seqs.append(w.reads.seq(i))
+        if i % 7 == 0:
+            seqs.append(np.zeros(0, dtype=np.uint8))
+        if i % 5 == 0:
+            seqs.append(rng.integers(0, 4, int(rng.integers(1, 40))).astype(np.uint8))
+        if i % 11 == 0:
+            seqs.append(w.reads.seq(i)[:int(rng.integers(19, 23))])     # k - 1 .. k + 2 bases of a real read
+    truth = w.truth
+    seqs.append(truth[1000:61000].copy())                               # 60 kb: several tiles and tile groups
+    reads = sim.SeqDb.from_list(seqs)
+    (las, _), (chunks, fallbacks) = run_both(gpu_ctx, w.contigs, reads, k=20, kmer_mod=1, algo=1, width=64)
+    assert fallbacks == 0
+    monkeypatch.setenv("DH_ALIGN_CHUNK", "200")      # several chunks: chunk ends in the middle of the DB
+    run_both(gpu_ctx, w.contigs, reads, k=20, kmer_mod=2, algo=1, width=64)
+
+
+def test_soft_masked_reads_and_repeats_with_the_t_cap(gpu_ctx):
+    """-m tracks on the reads (k-mers touching a masked base are not looked up) and a contig set with a 5-copy repeat:
+    multi-entry buckets, the -t cap per orientation class, several hits per looked-up k-mer."""
+    rng = np.random.default_rng(17)
+    unit = rng.integers(0, 4, 3000).astype(np.uint8)
+    parts = []
+    for c in range(6):
+        parts.append(rng.integers(0, 4, 40000).astype(np.uint8))
+        if c < 5:
+            parts.append(unit if c % 2 == 0 else sim.revcomp(unit))
+    genome = np.concatenate(parts)
+    contigs = sim.SeqDb.from_list([genome[:110000], genome[112000:]])
+    reads, _ = sim.reads(99, genome, 400, 6000, 0, min_len=6000)
+    for tcap in (3, 8):
+        run_both(gpu_ctx, contigs, reads, k=14, kmer_mod=1, algo=1, width=64, tcap=tcap)
+    ptr, iv = [0], []
+    for i in range(reads.n):
+        n, pos = reads.length(i), 0
+        while True:
+            pos += int(rng.integers(300, 2500))
+            ln = int(rng.integers(10, 400))
+            if pos + ln >= n:
+                break
+            iv += [pos, pos + ln]
+            pos += ln
+        ptr.append(len(iv) // 2)
+    reads.mask = (np.asarray(ptr, dtype=np.int64), np.asarray(iv + [0, 0], dtype=np.int32))
+    run_both(gpu_ctx, contigs, reads, k=20, kmer_mod=2, algo=1, width=64)
+    masked_hits = gpu_ctx.align_stats().hits
+    reads.mask = None
+    run_both(gpu_ctx, contigs, reads, k=20, kmer_mod=2, algo=1, width=64)
+    assert masked_hits < 0.95 * gpu_ctx.align_stats().hits
+
+
+def test_capacity_overflow_falls_back_to_the_directory(gpu_ctx, monkeypatch):
+    """A hit pool of one page cannot hold the hits of the chunk: the chunk is redone by the directory lookups, the result
+    is the same and the fall-back is counted."""
+    monkeypatch.setenv("DH_MJOIN_PAGES", "1")
+    w = sim.Workload(300_000, 3, 600, 6000, seed=23, spacing=15000)
+    _, (chunks, fallbacks) = run_both(gpu_ctx, w.contigs, w.reads, expect_join=False, k=20, kmer_mod=1, algo=1, width=64)
+    assert fallbacks >= 1
+
+
+def test_map_reads_with_filters_through_the_join(gpu_ctx, monkeypatch):
+    """dh_map_reads (mapping + chain flags + the six collect filters per chunk) with the join underneath == the same call on
+    the directory path."""
+    w = sim.Workload(500_000, 5, 1500, 8000, seed=83, spacing=20000)
+    mo = dentist_amd.default_align_opts(kmer_mod=8, k=20, width=64, xdrop=60, algo=1)
+    po = dentist_amd.default_process_opts(algo=1)
+    A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
+    gpu_ctx.mjoin_counts(reset=True)
+    a = gpu_ctx.map_reads(A, B, mo, po, sorted=False, candidates=False)
+    assert gpu_ctx.mjoin_counts()[0] >= 1
+    monkeypatch.setenv("DH_NO_MJOIN", "1")
+    A.drop_cache()
+    B.drop_cache()
+    b = gpu_ctx.map_reads(A, B, mo, po, sorted=False, candidates=False)
+    assert_same_las(a[:2], b[:2])
+    assert [int(x) for x in a[2]] == [int(x) for x in b[2]]
