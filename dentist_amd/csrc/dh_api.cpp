@@ -1605,7 +1605,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     JoinView jv_mj = {};
     bool mj_skip_chunk = false;  // the chunk at hand overflowed a capacity of the join: directory path for it
     uint32_t *d_mjctr_last = nullptr;
-    int64_t mj_exp_ent_last = 0;
+    int64_t mj_exp_ent_last = 0, mj_npages_last = 0;
 
     std::vector<int32_t> h_ncand((size_t)cn), h_nhits((size_t)cn);
     float ms_seed = 0, ms_wave = 0, ms_gather = 0;
@@ -1684,9 +1684,10 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
                 mv.k = o.k;
                 mv.kmer_mod = std::max(1, o.kmer_mod);
                 mv.nbbits = A->ix.nbbits;
-                // bases per tile: 7/8 of the tile's capacity expected (modimer sampling is a hash: 12 sigma of slack), every
+                // bases per tile: 13/16 of the tile's capacity expected (modimer sampling is a hash), every
                 // lane of the block rolls the same number of positions, positions fit MJ_POSBITS
-                int64_t tb = (int64_t)(MJ_CAP / 8 * 7) * mv.kmer_mod;
+                // (a wavefront stages its eighth of the tile's entries in its own 1 024 slots: 832 expected, 7 sigma of slack)
+                int64_t tb = (int64_t)(MJ_CAP / 16 * 13) * mv.kmer_mod;
                 if (mv.kmer_mod == 1) tb = MJ_CAP;
                 tb = std::min<int64_t>(tb, (1 << MJ_POSBITS) - 64);
                 tb = std::max<int64_t>(MJ_THREADS * 8, tb / (MJ_THREADS * 8) * (MJ_THREADS * 8));
@@ -1702,7 +1703,9 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
                 // of the probe kernel on top; the same number of hits regrouped by read
                 // (dens: chance matches of a sampled k-mer per strand, as for the LDS capacity above)
                 const int64_t exp_ent = (cb1 - cb0) / mv.kmer_mod;
-                int64_t npages = (int64_t)((ctx->mj_hit_frac + 2.5 * dens) * (double)exp_ent) / MJ_PAGE + (int64_t)ctx->ncu * (MJ_PROBE_THREADS / 64) + 64;
+                // (a page is left when less than a quarter of it is free: a third more pages than hits)
+                // (the pool holds the SURVIVORS of the filter: the hits' k-mers and a few per cent of the others)
+                int64_t npages = (int64_t)(1.34 * (ctx->mj_hit_frac + 0.06 + 2.5 * dens) * (double)exp_ent) / MJ_PAGE + (int64_t)ctx->ncu * (MJ_PROBE_THREADS / 64) + 64;
                 if (const char *e = getenv("DH_MJOIN_PAGES")) npages = std::max<int64_t>(1, atoll(e));  // development / tests: force the fall-back
                 if (ntiles < (1ll << 30) / MJ_P && npages < (1ll << 31) / 2 && mv.nseg <= 512) {
                     mv.npages = (int32_t)npages;
@@ -1711,6 +1714,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
                     SCR(64, mv.ent, (size_t)ntiles * MJ_CAP)
                     SCR(65, mv.segoff, (size_t)ntiles * MJ_P)
                     SCR(66, mv.tile_n, (size_t)ntiles)
+                    SCR(73, mv.tile_r, (size_t)ntiles)
                     SCR(67, mv.seg, (size_t)MJ_P * mv.ntiles_pad)
                     SCR(68, mv.hseg, (size_t)mv.ngroups * MJ_P)
                     SCR(69, mv.hits, (size_t)npages * MJ_PAGE)
@@ -1720,8 +1724,10 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
                     mv.ctr = d_mjctr;
                     d_mjctr_last = d_mjctr;
                     mj_exp_ent_last = exp_ent;
+                    mj_npages_last = npages;
                     mv.bitmap = A->ix.d_bitmap;
                     mv.status = d_status;
+                    if (const char *e = getenv("DH_MJ_DBG")) mv.dbg = atoi(e);
                     HIPCHK(dhk_memset(st, mv.segtab, 0, sizeof(unsigned long long) * (size_t)(cr1 - cr0) * mv.nseg));
                     dhk_mj_run(st, bv, iv, dopt, mv, ctx->ncu);
                     HIPCHK(hipGetLastError());
@@ -1759,14 +1765,15 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             if (mj_chunk && (status & DH_ST_MJ_POOL) && !(status & DH_ST_MJ_OVERFLOW) && !getenv("DH_MJOIN_PAGES")) {
                 // the hit pool ran out (more hits per k-mer than planned: low-error reads, short k-mers): sized by the pages
                 // the probe kernel asked for, the chunk runs through the join again -- and the later ones start with that rate
-                uint32_t asked = 0;
-                HIPCHK(hipMemcpyAsync(&asked, d_mjctr_last + 8, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                unsigned long long cnt2[2] = {0, 0};  // hits counted for rhits, survivors that found no page
+                HIPCHK(hipMemcpyAsync(cnt2, d_mjctr_last + 10, sizeof(cnt2), hipMemcpyDeviceToHost, st));
                 status &= ~DH_ST_MJ_POOL;
                 HIPCHK(hipMemcpyAsync(d_status, &status, sizeof(int32_t), hipMemcpyHostToDevice, st));
                 HIPCHK(hipStreamSynchronize(st));
-                const double need = 1.3 * (double)asked * MJ_PAGE / std::max<double>(1.0, (double)mj_exp_ent_last);
+                const double have = (double)mj_npages_last * MJ_PAGE / 1.34;
+                const double need = 1.2 * std::max(have + (double)cnt2[1], (double)cnt2[0]) / std::max<double>(1.0, (double)mj_exp_ent_last);
                 ctx->mj_hit_frac = std::max(ctx->mj_hit_frac * 1.5, need);
-                if (getenv("DH_TRACE")) fprintf(stderr, "[mjoin] hit pool too small (%u pages asked): %.2f hits per k-mer planned from now on\n", asked, ctx->mj_hit_frac);
+                if (getenv("DH_TRACE")) fprintf(stderr, "[mjoin] pool too small (%llu survivors without a page, %llu hits): %.2f per k-mer planned from now on\n", cnt2[1], cnt2[0], ctx->mj_hit_frac);
                 if (ctx->mj_hit_frac <= 64.0) {
                     item0 -= cn;
                     continue;

@@ -41,8 +41,8 @@ __device__ __forceinline__ bool kmer_sampled(uint64_t km, const KmerSampler &s)
     uint32_t h = __umulhi(lo, 0x7F4A7C15u) + lo * 0x9E3779B9u;
     if (!s.small_k) h += hi * 0x7F4A7C15u;
     const uint32_t t = h * s.inv;
-    const uint32_t r = s.rot ? ((t >> s.rot) | (t << (32u - s.rot))) : t;
-    return s.all || r <= s.thresh;
+    const uint32_t r = __builtin_rotateright32(t, s.rot);  // (rot == 0: t itself)
+    return s.all | (r <= s.thresh);
 }
 
 __device__ __forceinline__ uint64_t load8(const uint8_t *p)

@@ -61,7 +61,7 @@
 #define MJ_MAXBITS 30             /* bits of the presence bitmap: 2^20 per partition = 128 KB of LDS */
 
 #define DH_ST_MJ_OVERFLOW 0x20    /* a capacity of the partitioned join was exceeded: the chunk is redone by the directory path */
-#define DH_ST_MJ_POOL 0x40        /* the hit pool was too small: ctr[8] holds the pages asked for, the chunk is run again */
+#define DH_ST_MJ_POOL 0x40        /* the hit pool was too small: ctr[12] counts what found no room, the chunk is run again */
 
 struct MjView {
     int64_t c0, c1;        // base range of the chunk in B.bases
@@ -72,16 +72,18 @@ struct MjView {
     uint64_t *ent;         // ntiles * MJ_CAP
     uint16_t *segoff;      // ntiles * MJ_P: first entry of segment (tile, partition) inside the tile
     uint32_t *tile_n;      // entries of tile t
+    int32_t *tile_r;       // first read that starts behind the first base of tile t
     uint32_t *seg;         // MJ_P * ntiles_pad: start << 16 | count
     const uint32_t *bitmap;
     unsigned long long *hseg;  // ngroups * MJ_P: first hit << 24 | count
     uint64_t *hits;        // npages * MJ_PAGE
     uint64_t *rhits;       // hits grouped by read (capacity rcap)
     unsigned long long *segtab;  // (r1 - r0) * nseg
-    uint32_t *ctr;         // [0..7] work queues of k_mj_probe (one per XCD), [8] page cursor, [10..11] 64-bit cursor of rhits
+    uint32_t *ctr;         // [0..7] work queues of k_mj_probe (one per XCD), [8] page cursor, [10..11] 64-bit cursor of rhits, [12..13] survivors that found no page
     int64_t rcap;
     int32_t npages;
     int32_t *status;
+    int32_t dbg;           // development switches (DH_MJ_DBG)
 };
 
 #ifdef __cplusplus

@@ -38,12 +38,9 @@ __device__ __forceinline__ uint32_t mj_lanes_below(unsigned long long m)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
-__device__ __forceinline__ uint64_t mj_load8(const uint64_t *p)
-{
-    uint64_t x;
-    __builtin_memcpy(&x, p, 8);
-    return x;
-}
+// an entry of the stream (read once: the non-temporal hint keeps it from pushing the partition's directory slice out of
+// the XCD's L2, which the resolve sweep of k_mj_filter lives on)
+__device__ __forceinline__ uint64_t mj_load8(const uint64_t *p) { return __builtin_nontemporal_load(p); }
 
 // exclusive prefix sum over the block's threads (one value each); *total = sum.  s_w: one word per wavefront.
 template <int THREADS>
@@ -75,15 +72,40 @@ constexpr int MJ_REMSH = MJ_POSBITS + 2, MJ_PSH = 53;
 }  // namespace
 
 // ------------------------------------------------------------------------------------ presence bitmap of the index
-__global__ void __launch_bounds__(256) k_mj_bitmap(const ulonglong2 *__restrict__ ent, int64_t n, int32_t bshift, uint32_t *__restrict__ bm)
+// two bits per key inside the slice of its partition: the bucket of a directory of 2^nbbits buckets, and a hash of the key's
+// remainder (a one-probe filter of 11 bits per key lets 9 % of the absent k-mers through, the pair 3 %)
+__device__ __forceinline__ uint32_t mj_bit2(uint64_t rem, int sbits) { return (uint32_t)((rem * 0x9E3779B97F4A7C15ull) >> (64 - sbits)); }
+__global__ void __launch_bounds__(256) k_mj_bitmap(const ulonglong2 *__restrict__ ent, int64_t n, int32_t k, int32_t nbbits, uint32_t *__restrict__ bm)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint64_t bit = (ent[i].x & ~(1ull << 63)) >> bshift;
-    atomicOr(&bm[bit >> 5], 1u << (bit & 31));
+    const int remsh = 2 * k - MJ_PBITS, sbits = nbbits - MJ_PBITS;
+    const uint64_t key = ent[i].x & ~(1ull << 63);
+    const uint64_t p = key >> remsh, rem = key & ((1ull << remsh) - 1);
+    const uint64_t b1 = (p << sbits) | (rem >> (remsh - sbits)), b2 = (p << sbits) | mj_bit2(rem, sbits);
+    atomicOr(&bm[b1 >> 5], 1u << (b1 & 31));
+    atomicOr(&bm[b2 >> 5], 1u << (b2 & 31));
 }
 
 // ------------------------------------------------------------------------------------ partition
+// first read that starts behind the first base of tile t (a binary search per tile, all tiles at once: inside k_mj_part
+// it was a chain of 19 dependent loads in front of every tile)
+__global__ void __launch_bounds__(256) k_mj_tile_reads(DbView B, MjView m)
+{
+    const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m.ntiles) return;
+    const int64_t tb0 = m.c0 + (int64_t)t * m.tb;
+    int32_t lo = m.r0, hi = m.r1;  // (off[r1] = c1 is the last "start": nothing crosses it)
+    while (lo < hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (B.off[mid] > tb0)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    m.tile_r[t] = lo;
+}
+
 __global__ void __launch_bounds__(MJ_THREADS, 4)
 k_mj_part(DbView B, MjView m)
 {
@@ -91,9 +113,9 @@ k_mj_part(DbView B, MjView m)
     __shared__ uint32_t cnt[MJ_P];
     __shared__ int32_t rs[MJ_RS];
     __shared__ uint32_t s_w[MJ_THREADS / LANES];
-    __shared__ uint32_t s_n, s_nrs;
-    __shared__ int32_t s_r;
-    const int tid = threadIdx.x, lane = tid & (LANES - 1);
+    __shared__ uint32_t s_nrs;
+    const int tid = threadIdx.x, lane = tid & (LANES - 1), wave = tid / LANES;
+    constexpr int NW = MJ_THREADS / LANES, WCAP = MJ_CAP / NW;  // a wavefront stages its entries in its own eighth of buf
     const int k = m.k, mm = k - 1;
     const uint64_t mask = (1ull << (2 * k)) - 1;
     const int rcsh = 2 * (k - 1), remsh = 2 * k - MJ_PBITS;
@@ -104,24 +126,12 @@ k_mj_part(DbView B, MjView m)
         const int64_t tb0 = m.c0 + (int64_t)t * m.tb;
         const int32_t tlen = (int32_t)std::min<int64_t>(m.tb, m.c1 - tb0);  // k-mer starts of this tile: [0, tlen)
         for (int i = tid; i < MJ_P; i += MJ_THREADS) cnt[i] = 0;
-        if (tid == 0) {
-            s_n = 0;
-            s_nrs = 0;
-            // the first read that starts behind the tile's first base (off[r1] = c1 is the last "start": nothing crosses it)
-            int32_t lo = m.r0, hi = m.r1;
-            while (lo < hi) {
-                const int32_t mid = (lo + hi) >> 1;
-                if (B.off[mid] > tb0)
-                    hi = mid;
-                else
-                    lo = mid + 1;
-            }
-            s_r = lo;
-        }
+        if (tid == 0) s_nrs = 0;
+        const int32_t rfirst = m.tile_r[t];
         __syncthreads();
         // read starts inside (tb0, tb0 + tlen + k - 1): a k-mer may begin at one, never contain one
         for (int32_t i = tid;; i += MJ_THREADS) {
-            const int32_t r = s_r + i;
+            const int32_t r = rfirst + i;
             if (r > m.r1) break;
             const int64_t o = B.off[r] - tb0;
             if (o >= (int64_t)tlen + k - 1) break;
@@ -163,65 +173,75 @@ k_mj_part(DbView B, MjView m)
             }
         }
         int32_t nxt = jn < nrs ? rs[jn] : 0x7FFFFFFF;
-        uint64_t w = 0;
-        for (int32_t tt = 0; tt < per; tt++) {
-            const int32_t pp = xr0 + mm + tt;  // the base that completes the k-mer starting at xr0 + tt
-            if ((tt & 7) == 0) w = xr0 + tt < tlen ? load8(b + pp) : 0ull;
-            const uint32_t c = (uint32_t)w & 3u;
-            w >>= 8;
-            if (pp == nxt) {
-                valid = 0;
-                do jn++;
-                while (jn < nrs && rs[jn] == pp);
-                nxt = jn < nrs ? rs[jn] : 0x7FFFFFFF;
-            }
-            km = ((km << 2) | c) & mask;
-            rc = (rc >> 2) | ((uint64_t)(3u - c) << rcsh);
-            valid++;
-            const uint64_t canon = km < rc ? km : rc;
-            bool em = xr0 + tt < tlen && valid >= k && kmer_sampled(canon, smp);
-            if (em && B.mask_bits && mask_touch(B.mask_bits, tb0 + xr0 + tt, k)) em = false;
-            const unsigned long long bal = __ballot(em);
-            if (bal) {
-                uint32_t base = 0;
-                const int leader = __ffsll((long long)bal) - 1;
-                if (lane == leader) base = atomicAdd(&s_n, (uint32_t)__popcll(bal));
-                base = __shfl(base, leader, LANES);
-                if (em) {
-                    const uint32_t slot = base + mj_lanes_below(bal);
-                    if (slot < MJ_CAP) {
-                        const uint64_t p = canon >> remsh;
-                        buf[slot] = (p << MJ_PSH) | ((canon & remmask) << MJ_REMSH) | (km == rc ? MJ_PAL_BIT : 0ull) |
-                                    (km != canon ? MJ_ORI_BIT : 0ull) | (uint64_t)(xr0 + tt);
-                        atomicAdd(&cnt[p], 1u);
-                    }
+        uint32_t wcount = 0;  // entries of this wavefront so far (uniform)
+        // The loop does the least per base: roll, sample, and park the sampled k-mer (k-mer << 17 | position) in the
+        // wavefront's eighth of buf -- one lane in kmer_mod is active there; the entry is made of it afterwards with every
+        // lane busy.  Eight bases per loaded word, the next word on its way.
+        uint64_t wnext = xr0 < tlen ? load8(b + xr0 + mm) : 0ull;
+        const int32_t tmax = tlen - xr0;  // k-mer starts of this lane: tt < tmax
+        const bool has_mask = B.mask_bits != nullptr;
+        for (int32_t tt0 = 0; tt0 < per; tt0 += 8) {
+            const uint64_t w = wnext;
+            wnext = tt0 + 8 < tmax ? load8(b + xr0 + mm + tt0 + 8) : 0ull;
+            // (a read begins inside these eight bases, somewhere in the wavefront: rare, the careful steps below)
+            const bool careful = __ballot(nxt < xr0 + mm + tt0 + 8) != 0ull;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int32_t tt = tt0 + u, pp = xr0 + mm + tt;  // pp: the base that completes the k-mer starting at xr0 + tt
+                const uint32_t c = (uint32_t)(w >> (8 * u)) & 3u;
+                if (careful && pp == nxt) {
+                    valid = 0;
+                    do jn++;
+                    while (jn < nrs && rs[jn] == pp);
+                    nxt = jn < nrs ? rs[jn] : 0x7FFFFFFF;
                 }
+                km = ((km << 2) | c) & mask;
+                rc = (rc >> 2) | ((uint64_t)(3u - c) << rcsh);
+                valid++;
+                const uint64_t canon = km < rc ? km : rc;
+                // (no short circuits: every `&&` of lane-varying terms would be a branch on the execution mask)
+                bool em = (tt < tmax) & (valid >= k) & kmer_sampled(canon, smp);
+                if (has_mask) em = em && !mask_touch(B.mask_bits, tb0 + xr0 + tt, k);
+                const unsigned long long bal = __ballot(em);
+                const uint32_t slot = wcount + mj_lanes_below(bal);
+                if (em & (slot < (uint32_t)WCAP)) buf[wave * WCAP + slot] = (km << MJ_POSBITS) | (uint64_t)(xr0 + tt);
+                wcount += (uint32_t)__popcll(bal);
             }
         }
-        __syncthreads();
-        uint32_t n = s_n;
-        if (n > MJ_CAP) {
-            if (tid == 0) atomicOr(m.status, DH_ST_MJ_OVERFLOW);
-            n = MJ_CAP;
+        if (wcount > WCAP) {
+            if (lane == 0) atomicOr(m.status, DH_ST_MJ_OVERFLOW);
+            wcount = WCAP;
         }
-        // ---- counting sort by partition: offsets (two counters per thread), the tile's entries through registers
+        // ---- entries from the parked k-mers (every lane busy), counted per partition
+        uint64_t e16[WCAP / LANES];
+#pragma unroll
+        for (int i = 0; i < WCAP / LANES; i++) {
+            const uint32_t idx = lane + i * LANES;
+            e16[i] = 0;
+            if (idx < wcount) {
+                const uint64_t x = buf[wave * WCAP + idx];
+                const uint64_t kmx = x >> MJ_POSBITS;
+                const uint64_t rcx = (~(mj_revpairs(kmx) >> (64 - 2 * k))) & mask;
+                const uint64_t canon = kmx < rcx ? kmx : rcx;
+                const uint64_t p = canon >> remsh;
+                e16[i] = (1ull << 63) | (p << MJ_PSH) | ((canon & remmask) << MJ_REMSH) | (kmx == rcx ? MJ_PAL_BIT : 0ull) |
+                         (kmx != canon ? MJ_ORI_BIT : 0ull) | (x & ((1ull << MJ_POSBITS) - 1));
+                atomicAdd(&cnt[p], 1u);
+            }
+        }
+        // ---- counting sort by partition: offsets (two counters per thread), then the entries from the registers
+        __syncthreads();
         const uint32_t c0 = cnt[2 * tid], c1 = cnt[2 * tid + 1];
-        uint32_t tot;
-        const uint32_t ex = mj_block_scan<MJ_THREADS>(c0 + c1, tid, s_w, &tot);
+        uint32_t n;
+        const uint32_t ex = mj_block_scan<MJ_THREADS>(c0 + c1, tid, s_w, &n);
         ((uint32_t *)m.segoff)[(int64_t)t * (MJ_P / 2) + tid] = ex | ((ex + c0) << 16);
         cnt[2 * tid] = ex;
         cnt[2 * tid + 1] = ex + c0;
-        uint64_t e16[MJ_CAP / MJ_THREADS];
-#pragma unroll
-        for (int i = 0; i < MJ_CAP / MJ_THREADS; i++) {
-            const uint32_t idx = tid + i * MJ_THREADS;
-            e16[i] = idx < n ? buf[idx] : 0ull;
-        }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < MJ_CAP / MJ_THREADS; i++) {
-            const uint32_t idx = tid + i * MJ_THREADS;
-            if (idx < n) buf[atomicAdd(&cnt[e16[i] >> MJ_PSH], 1u)] = e16[i];
+        for (int i = 0; i < WCAP / LANES; i++) {
+            const uint32_t idx = lane + i * LANES;
+            if (idx < wcount) buf[atomicAdd(&cnt[(e16[i] >> MJ_PSH) & (MJ_P - 1)], 1u)] = e16[i];
         }
         __syncthreads();
         uint4 *dst = (uint4 *)(m.ent + (int64_t)t * MJ_CAP);
@@ -263,10 +283,9 @@ k_mj_transpose(MjView m)
     }
 }
 
-// ------------------------------------------------------------------------------------ probe
-namespace {
 // the lookup of one k-mer with the rules of seed_item's flush() (dh_kernels.hip): the bucket's only entry from the fat
-// directory word, or the walk of a bucket with the -t cap per orientation class
+// directory word, or the walk of a bucket with the -t cap per orientation class; strands as o.strands allows
+namespace {
 template <typename F>
 __device__ __forceinline__ void mj_lookup(const IndexView &ix, const DhOpts &o, uint64_t key, bool ori, bool pal, F &&emit)
 {
@@ -277,8 +296,8 @@ __device__ __forceinline__ void mj_lookup(const IndexView &ix, const DhOpts &o, 
     if ((f.x >> 62) != 1ull) {
         if ((f.x & ~ORI) == key && o.tcap >= 1) {
             const bool same = (f.x & ORI) == bori;
-            if (same || pal) emit(f.y, 0);
-            if (!same || pal) emit(f.y, 1);
+            if ((same || pal) && (o.strands & 1)) emit(f.y, 0);
+            if ((!same || pal) && (o.strands & 2)) emit(f.y, 1);
         }
         return;
     }
@@ -297,6 +316,8 @@ __device__ __forceinline__ void mj_lookup(const IndexView &ix, const DhOpts &o, 
         dor = runr > 0 && runr <= o.tcap;
         if (!dof && !dor) return;
     }
+    dof = dof && (o.strands & 1);
+    dor = dor && (o.strands & 2);
     for (uint32_t t = ss; t < ee; t++) {
         const ulonglong2 en = ix.ent[t];
         if ((en.x & ~ORI) != key) continue;
@@ -307,22 +328,93 @@ __device__ __forceinline__ void mj_lookup(const IndexView &ix, const DhOpts &o, 
 }
 }  // namespace
 
+// ------------------------------------------------------------------------------------ filter
+// A block keeps the bitmap slice of ONE partition in LDS (blocks pull (partition, slice of the tile groups) items, the
+// blocks of an XCD from the same queue).  A wavefront takes one TILE GROUP of the partition at a time: 16 segments, 16
+// lanes each (a segment holds 7 - 8 entries on average, so one coalesced load per lane covers it; longer segments take
+// further rounds), the entries of the groups behind it already in flight.  The entries that pass the filter -- the
+// k-mers of A among them, and 3 % of the others -- go, compacted, to the wavefront's page of the survivor pool, one range
+// per (group, partition): sseg[group][partition] = first << 24 | count.  No dependent global load: the kernel streams.
 __global__ void __launch_bounds__(MJ_PROBE_THREADS)
-k_mj_probe(IndexView ix, DhOpts o, MjView m)
+k_mj_filter(IndexView ix, DhOpts o, MjView m)
 {
     __shared__ uint32_t bm[1 << (MJ_MAXBITS - MJ_PBITS - 5)];
     __shared__ int32_t s_item;
     const int tid = threadIdx.x, lane = tid & (LANES - 1), wave = tid / LANES;
     constexpr int NW = MJ_PROBE_THREADS / LANES;
-    const int k = m.k, remsh = 2 * k - MJ_PBITS, bshift = 2 * k - m.nbbits;
+    constexpr int SPI = LANES / MJ_GROUP;          // segments per load instruction (4)
+    constexpr int NIT = MJ_GROUP / SPI;            // load instructions per group and round (4)
+    constexpr uint32_t SAFE = MJ_PAGE / 4;         // survivors one group may add to the wavefront's page
+    constexpr int DEPTH = 3;                       // groups in flight behind the one at hand
+    const int k = m.k, remsh = 2 * k - MJ_PBITS, sbits = m.nbbits - MJ_PBITS, bshift = remsh - sbits;
     const uint64_t remmask = (1ull << remsh) - 1;
-    const int32_t slice_words = 1 << (m.nbbits - MJ_PBITS - 5);
-    const int32_t nb = m.ntiles_pad / MJ_BATCH;
+    const int32_t slice_words = 1 << (sbits - 5);
+    const int32_t ng = m.ntiles_pad / MJ_GROUP;
     const int32_t nitems_q = (MJ_P / 8) * MJ_SLICES;
     const uint32_t xcc = mj_xcc_id();
+    const int sub = lane / MJ_GROUP, j = lane & (MJ_GROUP - 1);
     uint64_t page_base = 0;
-    uint32_t fill = MJ_PAGE;  // the wavefront has no page yet
+    uint32_t fill = MJ_PAGE + 1;  // the wavefront has no page (yet, or the pool ran out)
+    uint64_t sweep_from = 0;  // survivors of this wavefront from here on are not resolved yet
+    bool pool_out = false;
     int32_t curp = -1;
+    // RESOLVE: the survivors a wavefront has written for the partition at hand are looked up before it leaves the partition
+    // (and before it leaves a page) -- its XCD's L2 then holds the partition's 2 MB slice of the directory, because the
+    // XCD's blocks work on the same partition: 255 G lookups/s there against 54 G/s at random lines of HBM
+    // (scripts/join_probe.cpp).  A survivor becomes, in place: 0 = no hit; its only hit, strand << 63 | virtual A position <<
+    // 23 | position in the group + 1; or itself with bit 62 set = several hits (a palindrome, a repeat): k_mj_hits looks
+    // those up again.  Four lookups per lane in flight; nothing here is on the streaming loop's critical path.
+    auto resolve = [&](uint64_t from, uint64_t to, int32_t p) {
+        constexpr uint64_t ORI = 1ull << 63;
+        constexpr int RU = 4;
+        const uint64_t keytop = (uint64_t)p << remsh;
+        for (uint64_t i0 = from; i0 < to; i0 += RU * LANES) {
+            uint64_t sv[RU];
+            ulonglong2 f[RU];
+#pragma unroll
+            for (int u = 0; u < RU; u++) {
+                const uint64_t i = i0 + (uint64_t)u * LANES + lane;
+                sv[u] = i < to ? m.hits[i] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < RU; u++) {  // the directory words of all of them, together
+                f[u].x = DH_FAT_EMPTY;
+                f[u].y = 0;
+                if (sv[u]) f[u] = ix.fat[(uint32_t)((keytop | ((sv[u] >> MJ_REMSH) & remmask)) >> ix.shift)];
+            }
+#pragma unroll
+            for (int u = 0; u < RU; u++) {
+                const uint64_t i = i0 + (uint64_t)u * LANES + lane;
+                if (i >= to) continue;
+                const uint64_t key = keytop | ((sv[u] >> MJ_REMSH) & remmask);
+                const uint64_t bori = (sv[u] & MJ_ORI_BIT) ? ORI : 0ull;
+                const bool pal = (sv[u] & MJ_PAL_BIT) != 0;
+                const uint64_t posg1 = ((sv[u] >> MJ_PSH) & (uint64_t)(MJ_GROUP - 1)) * (uint64_t)m.tb + (sv[u] & ((1ull << MJ_POSBITS) - 1)) + 1;
+                uint64_t out = 0;
+                if (f[u].x != DH_FAT_EMPTY) {
+                    if ((f[u].x >> 62) != 1ull) {  // the bucket's only entry
+                        if ((f[u].x & ~ORI) == key && o.tcap >= 1) {
+                            const bool same = (f[u].x & ORI) == bori;
+                            const bool h0 = (same || pal) && (o.strands & 1), h1 = (!same || pal) && (o.strands & 2);
+                            if (h0 && h1)
+                                out = sv[u] | (1ull << 62);
+                            else if (h0 || h1)
+                                out = ((uint64_t)(h1 ? 1 : 0) << 63) | ((f[u].y & ((1ull << 39) - 1)) << 23) | posg1;
+                        }
+                    } else {  // several entries: counted with the full rules; one hit is taken from the walk
+                        uint32_t c = 0;
+                        uint64_t hh = 0;
+                        mj_lookup(ix, o, key, bori != 0, pal, [&](uint64_t v, int strand) {
+                            hh = ((uint64_t)strand << 63) | ((v & ((1ull << 39) - 1)) << 23) | posg1;
+                            c++;
+                        });
+                        out = c == 0 ? 0ull : (c == 1 ? hh : (sv[u] | (1ull << 62)));
+                    }
+                }
+                m.hits[i] = out;
+            }
+        }
+    };
     for (int qq = 0; qq < 8; qq++) {
         const uint32_t x = (xcc + qq) & 7u;  // own XCD's queue first, then whatever is left of the others'
         for (;;) {
@@ -339,102 +431,136 @@ k_mj_probe(IndexView ix, DhOpts o, MjView m)
                 curp = p;
                 __syncthreads();
             }
-            const int32_t b0 = (int32_t)((int64_t)nb * sl / MJ_SLICES), b1 = (int32_t)((int64_t)nb * (sl + 1) / MJ_SLICES);
-            const uint64_t keytop = (uint64_t)p << remsh;
-            for (int32_t bb = b0 + wave; bb < b1; bb += NW) {
-                const int32_t t = bb * MJ_BATCH + lane;
-                const uint32_t sd = m.seg[(int64_t)p * m.ntiles_pad + t];  // (tiles beyond ntiles: zero)
-                const uint32_t cnt = t < m.ntiles ? (sd & 0xFFFFu) : 0u;
-                const uint64_t *ptr = m.ent + (int64_t)t * MJ_CAP + (sd >> 16);
-                const uint64_t posbase = (uint64_t)(lane & (MJ_GROUP - 1)) * (uint64_t)m.tb;
-                uint32_t nh = 0;
-                uint64_t h0 = 0, h1 = 0;
-                uint64_t *wr = nullptr;  // second pass: where hit number nh goes
-                auto probe_entry = [&](uint64_t e) {
-                    const uint64_t rem = (e >> MJ_REMSH) & remmask;
-                    const uint32_t bit = (uint32_t)(rem >> bshift);
-                    if (!((bm[bit >> 5] >> (bit & 31)) & 1u)) return;
-                    const uint64_t posg = posbase + (e & ((1ull << MJ_POSBITS) - 1));
-                    mj_lookup(ix, o, keytop | rem, (e & MJ_ORI_BIT) != 0, (e & MJ_PAL_BIT) != 0, [&](uint64_t v, int strand) {
-                        if (!(o.strands & (1 << strand))) return;
-                        const uint64_t h = ((uint64_t)strand << 63) | ((v & ((1ull << 40) - 1)) << 23) | posg;
-                        if (wr) {
-                            if (nh >= 2) wr[nh] = h;
-                        } else if (nh == 0)
-                            h0 = h;
-                        else if (nh == 1)
-                            h1 = h;
-                        nh++;
-                    });
-                };
-                // four entries of the lane's segment per round (independent loads)
-                uint32_t cmax = cnt;
-                for (int off = LANES / 2; off > 0; off >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, off, LANES));
-                for (uint32_t i0 = 0; i0 < cmax; i0 += 4) {
-                    uint64_t e[4];
+            const int32_t g0 = (int32_t)((int64_t)ng * sl / MJ_SLICES), g1 = (int32_t)((int64_t)ng * (sl + 1) / MJ_SLICES);
+            const uint32_t *segp = m.seg + (int64_t)p * m.ntiles_pad;
+            // descriptors of group g (one per lane of a quarter) and, from them, the lane's entries of round 0
+            auto load_desc = [&](int32_t g) { return g < g1 ? segp[(int64_t)g * MJ_GROUP + j] : 0u; };
+            auto load_ent = [&](int32_t g, uint32_t sdv, uint64_t *e) {
+                bool more = false;
 #pragma unroll
-                    for (int u = 0; u < 4; u++) e[u] = i0 + u < cnt ? mj_load8(ptr + i0 + u) : 0ull;
-#pragma unroll
-                    for (int u = 0; u < 4; u++)
-                        if (i0 + u < cnt) probe_entry(e[u]);
+                for (int it = 0; it < NIT; it++) {
+                    const int sidx = it * SPI + sub;  // segment of the group this lane serves in load `it`
+                    const uint32_t sd = __shfl(sdv, sidx, LANES);
+                    const int32_t t = g * MJ_GROUP + sidx;
+                    const uint32_t cn = t < m.ntiles ? (sd & 0xFFFFu) : 0u;
+                    more = more || cn > (uint32_t)MJ_GROUP;
+                    e[it] = (uint32_t)j < cn ? mj_load8(m.ent + (int64_t)t * MJ_CAP + (sd >> 16) + j) : 0ull;  // (entries are never 0)
                 }
-                // the batch's hits in lane (= tile) order: one range per tile group
-                uint32_t incl = nh;
+                return more;
+            };
+            // pipeline: descriptors DEPTH + 1 groups ahead, entries DEPTH groups ahead
+            uint32_t sdv[DEPTH + 2];
+            uint64_t e[DEPTH + 1][NIT];
+            bool more[DEPTH + 1];
+            const int32_t gw = g0 + wave;
 #pragma unroll
-                for (int off = 1; off < LANES; off <<= 1) {
-                    const uint32_t up = __shfl_up(incl, off, LANES);
-                    if (lane >= off) incl += up;
-                }
-                const uint32_t tot = __shfl(incl, LANES - 1, LANES);
-                const uint32_t pre = incl - nh;
-                bool ok = true;
-                if (tot > 0 && fill + tot > MJ_PAGE) {
+            for (int d = 0; d < DEPTH + 2; d++) sdv[d] = load_desc(gw + d * NW);
+#pragma unroll
+            for (int d = 0; d < DEPTH + 1; d++) {
+#pragma unroll
+                for (int it = 0; it < NIT; it++) e[d][it] = 0;
+                more[d] = false;
+                if (d < DEPTH && gw + d * NW < g1) more[d] = load_ent(gw + d * NW, sdv[d], e[d]);
+            }
+            for (int32_t g = gw; g < g1; g += NW) {
+                if (g + DEPTH * NW < g1) more[DEPTH] = load_ent(g + DEPTH * NW, sdv[DEPTH], e[DEPTH]);
+                const uint32_t sd_new = load_desc(g + (DEPTH + 2) * NW);
+                if (fill + SAFE > MJ_PAGE && !pool_out) {  // room for the group's survivors: they form one range
+                    if (fill <= MJ_PAGE && page_base + fill > sweep_from) resolve(sweep_from, page_base + fill, p);
                     uint32_t pg = 0;
                     if (lane == 0) pg = atomicAdd(&m.ctr[8], 1u);
                     pg = __shfl(pg, 0, LANES);
-                    if (tot > MJ_PAGE || pg >= (uint32_t)m.npages) {
-                        // (the page counter keeps counting: the host sizes the pool by it and runs the chunk again)
-                        if (lane == 0) atomicOr(m.status, tot > MJ_PAGE ? DH_ST_MJ_OVERFLOW : DH_ST_MJ_POOL);
-                        ok = false;
+                    if (pg >= (uint32_t)m.npages) {
+                        // (the survivors that find no page are counted: the host sizes the pool by them and runs the chunk again)
+                        if (lane == 0) atomicOr(m.status, DH_ST_MJ_POOL);
+                        fill = MJ_PAGE + 1;
+                        pool_out = true;
                     } else {
                         page_base = (uint64_t)pg * MJ_PAGE;
                         fill = 0;
                     }
+                    sweep_from = page_base + fill;
                 }
-                const uint64_t first = page_base + fill + pre;
-                if (ok && nh > 0) {
-                    uint64_t *dst = m.hits + first;
-                    dst[0] = h0;
-                    if (nh > 1) dst[1] = h1;
-                    if (nh > 2) {  // rare (a k-mer of a repeat): the segment once more, hits from the third on
-                        wr = dst;
-                        nh = 0;
-                        for (uint32_t i = 0; i < cnt; i++) probe_entry(mj_load8(ptr + i));
+                const bool have_page = fill + SAFE <= MJ_PAGE;
+                const uint64_t first = page_base + fill;
+                uint32_t gtot = 0;
+                const bool any_more = __ballot(more[0]) != 0ull;
+                for (uint32_t rnd = 0;; rnd++) {
+                    bool again = false;
+                    if (rnd > 0) {  // (rare: a segment with more than 16 entries)
+#pragma unroll
+                        for (int it = 0; it < NIT; it++) {
+                            const int sidx = it * SPI + sub;
+                            const uint32_t sd = __shfl(sdv[0], sidx, LANES);
+                            const int32_t t = g * MJ_GROUP + sidx;
+                            const uint32_t cn = t < m.ntiles ? (sd & 0xFFFFu) : 0u, jj = rnd * MJ_GROUP + j;
+                            again = again || cn > (rnd + 1) * MJ_GROUP;
+                            e[0][it] = jj < cn ? mj_load8(m.ent + (int64_t)t * MJ_CAP + (sd >> 16) + jj) : 0ull;
+                        }
+                    } else
+                        again = more[0];
+                    // ---- the two bits of every entry; survivors compacted behind the group's earlier ones
+                    uint32_t before = 0;
+#pragma unroll
+                    for (int it = 0; it < NIT; it++) {
+                        const uint64_t ev = e[0][it];
+                        const uint64_t rem = (ev >> MJ_REMSH) & remmask;
+                        const uint32_t b1 = (uint32_t)(rem >> bshift);
+                        bool pass = ev != 0ull && ((bm[b1 >> 5] >> (b1 & 31)) & 1u);
+                        if (pass) {
+                            const uint32_t b2 = mj_bit2(rem, sbits);
+                            pass = (bm[b2 >> 5] >> (b2 & 31)) & 1u;
+                        }
+                        const unsigned long long bal = __ballot(pass);
+                        const uint32_t at = gtot + before + mj_lanes_below(bal);
+                        if (pass && have_page && at < SAFE)
+                            m.hits[first + at] = (ev & ~(0x3FFull << MJ_PSH)) | ((uint64_t)(it * SPI + sub) << MJ_PSH);
+                        before += (uint32_t)__popcll(bal);
                     }
+                    gtot += before;
+                    if (!any_more || __ballot(again) == 0ull) break;
                 }
-                // (shuffles need every lane: the next group's prefix is fetched by all, used by the group heads)
-                const uint32_t pre_next = __shfl(pre, (lane + MJ_GROUP) & (LANES - 1), LANES);
-                if ((lane & (MJ_GROUP - 1)) == 0) {
-                    const uint32_t cg = ok ? ((lane + MJ_GROUP < LANES ? pre_next : tot) - pre) : 0u;
-                    const int64_t g = (int64_t)bb * (MJ_BATCH / MJ_GROUP) + lane / MJ_GROUP;
-                    m.hseg[g * MJ_P + p] = ((unsigned long long)first << 24) | cg;
+                if (gtot > SAFE) {  // more survivors than a group may hold: a degenerate tile (one k-mer all over)
+                    if (lane == 0) atomicOr(m.status, DH_ST_MJ_OVERFLOW);
+                    gtot = 0;
                 }
-                if (ok) fill += tot;
+                if (lane == 0) m.hseg[(int64_t)g * MJ_P + p] = ((unsigned long long)first << 24) | (have_page ? gtot : 0u);
+                if (!have_page && gtot && lane == 0) atomicAdd((unsigned long long *)(m.ctr + 12), (unsigned long long)gtot);
+                if (have_page) fill += gtot;
+                // rotate the pipeline
+#pragma unroll
+                for (int d = 0; d < DEPTH; d++) {
+#pragma unroll
+                    for (int it = 0; it < NIT; it++) e[d][it] = e[d + 1][it];
+                    more[d] = more[d + 1];
+                }
+#pragma unroll
+                for (int d = 0; d < DEPTH + 1; d++) sdv[d] = sdv[d + 1];
+                sdv[DEPTH + 1] = sd_new;
+            }
+            if (fill <= MJ_PAGE && page_base + fill > sweep_from) {
+                resolve(sweep_from, page_base + fill, p);
+                sweep_from = page_base + fill;
             }
         }
     }
 }
 
-// ------------------------------------------------------------------------------------ regroup by read
-// Two passes over the group's hits (no LDS buffer bounds their number: a group of low-error reads holds several times
-// the hits of one at 13 % error): count per read, reserve the group's range of rhits, then finish and scatter.
+// ------------------------------------------------------------------------------------ hits, by read
+// A block per tile group: the survivors of the group's 1024 (partition) lists are looked up in the fat directory with
+// exactly the rules of seed_item's flush() (dh_kernels.hip: the bucket's only entry from the directory word, or the walk
+// of a bucket with the -t cap per orientation class), the hits are counted per read, the group's range of rhits is
+// reserved, and a second pass over the survivors that had hits writes them, finished -- strand << 63 | diagonal << 24 |
+// position on the oriented read: the hit encoding of k_seed --, grouped by read.  No buffer bounds the hits of a group.
+#define MJ_HB_WORDS 2048 /* survivors of one tile group the second pass can mark: 65 536 */
 __global__ void __launch_bounds__(MJ_THREADS)
-k_mj_regroup(DbView B, IndexView ix, MjView m)
+k_mj_hits(DbView B, IndexView ix, DhOpts o, MjView m)
 {
     __shared__ uint32_t hoff[MJ_P + 1];
     __shared__ uint64_t hfirst[MJ_P];
     __shared__ int32_t rsl[MJ_RG_READS + 2];
     __shared__ uint32_t rcnt[MJ_RG_READS], rcur[MJ_RG_READS];
+    __shared__ uint32_t hb[MJ_HB_WORDS], mb[MJ_HB_WORDS];  // survivors with hits / with more than one
     __shared__ uint32_t s_w[MJ_THREADS / LANES];
     __shared__ int32_t s_ra, s_nrd;
     __shared__ unsigned long long s_base;
@@ -444,7 +570,9 @@ k_mj_regroup(DbView B, IndexView ix, MjView m)
     const int64_t gb0 = m.c0 + (int64_t)g * tbg;
     if (gb0 >= m.c1) return;
     const int64_t gb1 = std::min<int64_t>(m.c1, gb0 + tbg);
-    // ---- the group's hit lists, one per partition
+    const int k = m.k, remsh = 2 * k - MJ_PBITS;
+    const uint64_t remmask = (1ull << remsh) - 1;
+    // ---- the group's survivor lists, one per partition
     const unsigned long long hs0 = m.hseg[(int64_t)g * MJ_P + 2 * tid], hs1 = m.hseg[(int64_t)g * MJ_P + 2 * tid + 1];
     const uint32_t c0 = (uint32_t)(hs0 & 0xFFFFFFull), c1 = (uint32_t)(hs1 & 0xFFFFFFull);
     uint32_t n;
@@ -455,39 +583,32 @@ k_mj_regroup(DbView B, IndexView ix, MjView m)
     hfirst[2 * tid + 1] = hs1 >> 24;
     if (tid == 0) {
         hoff[MJ_P] = n;
-        // the read that holds the group's first base, and the reads that begin inside the group
-        int32_t lo = m.r0, hi = m.r1 - 1;  // largest r with off[r] <= gb0
-        while (lo < hi) {
-            const int32_t mid = (lo + hi + 1) >> 1;
-            if (B.off[mid] <= gb0)
-                lo = mid;
-            else
-                hi = mid - 1;
-        }
-        s_ra = lo;
+        // the read that holds the group's first base (the one before the first read that starts behind it: k_mj_tile_reads)
+        s_ra = max(m.r0, m.tile_r[(int64_t)g * MJ_GROUP] - 1);
         s_nrd = 0x7FFFFFFF;
     }
     for (int i = tid; i < MJ_RG_READS; i += MJ_THREADS) rcnt[i] = 0;
+    for (int i = tid; i < MJ_HB_WORDS; i += MJ_THREADS) hb[i] = mb[i] = 0;
     __syncthreads();
     const int32_t ra = s_ra;
     for (int32_t i = tid;; i += MJ_THREADS) {
         const int32_t r = ra + i;
         if (r > m.r1) break;
-        const int64_t o = B.off[r] - gb0;
-        if (i <= MJ_RG_READS + 1) rsl[i] = (int32_t)std::min<int64_t>(o, 0x7FFFFFF0);
-        if (o >= gb1 - gb0 || r == m.r1) {  // the first boundary at or behind the group's end closes its last read
+        const int64_t o2 = B.off[r] - gb0;
+        if (i <= MJ_RG_READS + 1) rsl[i] = (int32_t)std::min<int64_t>(o2, 0x7FFFFFF0);
+        if (o2 >= gb1 - gb0 || r == m.r1) {  // the first boundary at or behind the group's end closes its last read
             atomicMin(&s_nrd, i);
             break;
         }
     }
     __syncthreads();
     const int32_t nrd = s_nrd;  // reads ra .. ra + nrd - 1 overlap the group; rsl[0 .. nrd] their boundaries
-    if (nrd > MJ_RG_READS) {
+    if (nrd > MJ_RG_READS || n > MJ_HB_WORDS * 32u) {
         if (tid == 0) atomicOr(m.status, DH_ST_MJ_OVERFLOW);
         return;
     }
     if (n == 0) return;  // (the reads' rows of this group stay zero)
-    auto fetch = [&](uint32_t e) {  // hit e of the group: the list of the last partition p with hoff[p] <= e
+    auto fetch = [&](uint32_t e, int32_t *pp) {  // survivor e of the group: the list of the last partition p with hoff[p] <= e
         int32_t lo = 0, hi = MJ_P - 1;
         while (lo < hi) {
             const int32_t mid = (lo + hi + 1) >> 1;
@@ -496,6 +617,7 @@ k_mj_regroup(DbView B, IndexView ix, MjView m)
             else
                 hi = mid - 1;
         }
+        *pp = lo;
         return m.hits[hfirst[lo] + (e - hoff[lo])];
     };
     auto read_of = [&](int32_t posg) {  // the last read with rsl[i] <= posg
@@ -509,7 +631,23 @@ k_mj_regroup(DbView B, IndexView ix, MjView m)
         }
         return lo;
     };
-    for (uint32_t e = tid; e < n; e += MJ_THREADS) atomicAdd(&rcnt[read_of((int32_t)(fetch(e) & 0x7FFFFFull))], 1u);
+    auto posg_of = [&](uint64_t sv) { return (int32_t)(((sv >> MJ_PSH) & (uint64_t)(MJ_GROUP - 1)) * (uint64_t)m.tb + (sv & ((1ull << MJ_POSBITS) - 1))); };
+    for (uint32_t e = tid; e < n; e += MJ_THREADS) {
+        int32_t p;
+        const uint64_t sv = fetch(e, &p);
+        if (sv == 0ull) continue;  // resolved by the filter kernel: no hit
+        if (!((sv >> 62) & 1ull)) {  // its only hit, in place
+            atomicOr(&hb[e >> 5], 1u << (e & 31));
+            atomicAdd(&rcnt[read_of((int32_t)(sv & 0x7FFFFFull) - 1)], 1u);
+            continue;
+        }
+        uint32_t c = 0;
+        mj_lookup(ix, o, ((uint64_t)p << remsh) | ((sv >> MJ_REMSH) & remmask), (sv & MJ_ORI_BIT) != 0, (sv & MJ_PAL_BIT) != 0,
+                  [&](uint64_t, int) { c++; });
+        atomicOr(&hb[e >> 5], 1u << (e & 31));
+        atomicOr(&mb[e >> 5], 1u << (e & 31));
+        atomicAdd(&rcnt[read_of(posg_of(sv))], c);
+    }
     __syncthreads();
     uint32_t rc4[MJ_RG_READS / MJ_THREADS], sum = 0;
 #pragma unroll
@@ -520,13 +658,14 @@ k_mj_regroup(DbView B, IndexView ix, MjView m)
     uint32_t tot;
     uint32_t rex = mj_block_scan<MJ_THREADS>(sum, tid, s_w, &tot);
     if (tid == 0) {
-        const unsigned long long base = atomicAdd((unsigned long long *)(m.ctr + 10), (unsigned long long)n);
-        if (base + n > (unsigned long long)m.rcap) atomicOr(m.status, DH_ST_MJ_POOL);
+        // (the cursor keeps counting when the buffer is full: the host sizes it by the count and runs the chunk again)
+        const unsigned long long base = atomicAdd((unsigned long long *)(m.ctr + 10), (unsigned long long)tot);
+        if (base + tot > (unsigned long long)m.rcap) atomicOr(m.status, DH_ST_MJ_POOL);
         s_base = base;
     }
     __syncthreads();
     const unsigned long long base = s_base;
-    if (base + n > (unsigned long long)m.rcap) return;
+    if (tot == 0 || base + tot > (unsigned long long)m.rcap) return;
 #pragma unroll
     for (int u = 0; u < MJ_RG_READS / MJ_THREADS; u++) {
         const int32_t i = tid * (MJ_RG_READS / MJ_THREADS) + u;
@@ -534,28 +673,38 @@ k_mj_regroup(DbView B, IndexView ix, MjView m)
         if (i < nrd) {
             const int32_t r = ra + i;
             const int64_t gfirst = (B.off[r] - m.c0) / tbg;
-            const int64_t j = (int64_t)g - gfirst;
-            if (j >= 0 && j < m.nseg)
-                m.segtab[(int64_t)(r - m.r0) * m.nseg + j] = ((base + rex) << 24) | rc4[u];
+            const int64_t jg = (int64_t)g - gfirst;
+            if (jg >= 0 && jg < m.nseg)
+                m.segtab[(int64_t)(r - m.r0) * m.nseg + jg] = ((base + rex) << 24) | rc4[u];
             else if (rc4[u])
                 atomicOr(m.status, DH_ST_MJ_OVERFLOW);
         }
         rex += rc4[u];
     }
     __syncthreads();
-    // ---- the hit as the seed filter wants it: strand << 63 | diagonal << 24 | position on the oriented read
-    const int k = m.k;
-    for (uint32_t e = tid; e < n; e += MJ_THREADS) {
-        const uint64_t h = fetch(e);
-        const int32_t posg = (int32_t)(h & 0x7FFFFFull);
-        const int32_t strand = (int32_t)(h >> 63);
-        const int64_t gv = (int64_t)((h >> 23) & ((1ull << 40) - 1));
+    for (uint32_t e0 = 0; e0 < n; e0 += MJ_THREADS) {
+        const uint32_t e = e0 + tid;
+        if (e >= n || !((hb[e >> 5] >> (e & 31)) & 1u)) continue;
+        int32_t p;
+        const uint64_t sv = fetch(e, &p);
+        if (!((mb[e >> 5] >> (e & 31)) & 1u)) {  // the hit itself
+            const int32_t posg = (int32_t)(sv & 0x7FFFFFull) - 1, strand = (int32_t)(sv >> 63);
+            const int32_t i = read_of(posg);
+            const int32_t q = posg - rsl[i], blen = rsl[i + 1] - rsl[i];
+            const int32_t qs = strand ? blen - k - q : q;
+            const int64_t D = (int64_t)((sv >> 23) & ((1ull << 39) - 1)) + ix.sepv - qs;
+            m.rhits[base + atomicAdd(&rcur[i], 1u)] = ((uint64_t)strand << 63) | ((uint64_t)D << 24) | (uint32_t)qs;
+            continue;
+        }
+        const int32_t posg = posg_of(sv);
         const int32_t i = read_of(posg);
-        const int32_t q = posg - rsl[i];
-        const int32_t blen = rsl[i + 1] - rsl[i];
-        const int32_t qs = strand ? blen - k - q : q;
-        const int64_t D = gv + ix.sepv - qs;
-        m.rhits[base + atomicAdd(&rcur[i], 1u)] = ((uint64_t)strand << 63) | ((uint64_t)D << 24) | (uint32_t)qs;
+        const int32_t q = posg - rsl[i], blen = rsl[i + 1] - rsl[i];
+        mj_lookup(ix, o, ((uint64_t)p << remsh) | ((sv >> MJ_REMSH) & remmask), (sv & MJ_ORI_BIT) != 0, (sv & MJ_PAL_BIT) != 0,
+                  [&](uint64_t v, int strand) {
+                      const int32_t qs = strand ? blen - k - q : q;
+                      const int64_t D = (int64_t)(v & ((1ull << 40) - 1)) + ix.sepv - qs;
+                      m.rhits[base + atomicAdd(&rcur[i], 1u)] = ((uint64_t)strand << 63) | ((uint64_t)D << 24) | (uint32_t)qs;
+                  });
     }
 }
 
@@ -565,15 +714,16 @@ extern "C" {
 void dhk_mj_bitmap(hipStream_t st, const ulonglong2 *ent, int64_t n, int32_t k, int32_t nbbits, uint32_t *bm)
 {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_mj_bitmap, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ent, n, 2 * k - nbbits, bm);
+    hipLaunchKernelGGL(k_mj_bitmap, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ent, n, k, nbbits, bm);
 }
 
 void dhk_mj_run(hipStream_t st, DbView B, IndexView ix, DhOpts o, MjView m, int32_t ncu)
 {
     (void)hipMemsetAsync(m.ctr, 0, 16 * sizeof(uint32_t), st);
+    hipLaunchKernelGGL(k_mj_tile_reads, dim3((unsigned)((m.ntiles + 255) / 256)), dim3(256), 0, st, B, m);
     hipLaunchKernelGGL(k_mj_part, dim3((unsigned)std::min<int64_t>(m.ntiles, (int64_t)ncu * 2 * 4)), dim3(MJ_THREADS), 0, st, B, m);
     hipLaunchKernelGGL(k_mj_transpose, dim3((unsigned)(m.ntiles_pad / 32)), dim3(256), 0, st, m);
-    hipLaunchKernelGGL(k_mj_probe, dim3((unsigned)ncu), dim3(MJ_PROBE_THREADS), 0, st, ix, o, m);
-    hipLaunchKernelGGL(k_mj_regroup, dim3((unsigned)m.ngroups), dim3(MJ_THREADS), 0, st, B, ix, m);
+    hipLaunchKernelGGL(k_mj_filter, dim3((unsigned)ncu), dim3(MJ_PROBE_THREADS), 0, st, ix, o, m);
+    hipLaunchKernelGGL(k_mj_hits, dim3((unsigned)m.ngroups), dim3(MJ_THREADS), 0, st, B, ix, o, m);
 }
 }
