@@ -275,6 +275,20 @@ extern "C" int dh_ctx_sync(dh_ctx *c)
     return DH_OK;
 }
 
+int dh_db_set_awant(dh_db *db, const uint8_t *flags)
+{
+    if (!db) return fail(DH_EINVAL, "dh_db_set_awant: NULL");
+    if (!flags) {
+        dh_dev_free(db->d_awant);
+        db->d_awant = nullptr;
+        return DH_OK;
+    }
+    if (!db->d_awant) HIPCHK(dh_dev_alloc(&db->d_awant, (size_t)std::max(db->n, 1)));
+    HIPCHK(hipMemcpyAsync(db->d_awant, flags, (size_t)db->n, hipMemcpyHostToDevice, db->ctx->stream));
+    HIPCHK(hipStreamSynchronize(db->ctx->stream));
+    return DH_OK;
+}
+
 extern "C" int dh_get_mjoin_counts(dh_ctx *c, int64_t *out2, int32_t reset)
 {
     if (!c || !out2) return fail(DH_EINVAL, "dh_get_mjoin_counts: NULL");
@@ -399,6 +413,7 @@ extern "C" void dh_db_destroy(dh_db *db)
     dh_dev_free(db->d_off);
     dh_dev_free(db->d_group);
     dh_mask_free(db);
+    dh_dev_free(db->d_awant);
     if (db->has_ix) db->ix.release();
     delete db;
 }
@@ -1581,7 +1596,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         // (tiers: reads above the first capacity are redone by the 8192-entry variant, reads above that from HBM -- so
         // the first tier is the smallest one that serves at least 70 % of the reads)
         const unsigned int tol = (unsigned int)(0.3 * B->n);
-        cap = jhist[0] <= tol ? 2048 : (jhist[1] <= tol ? 4096 : 8192);
+        cap = jhist[0] <= tol ? 2048 : (jhist[1] <= tol ? 4096 : (jhist[2] <= tol ? 8192 : 16384));
     }
     if (const char *e = getenv("DH_SEED_CAP")) cap = atoi(e);  // development: 1024 .. 16384, power of two
     // ---- a mapping pass (A != B, ungrouped): the seeds of a chunk of reads come from the radix-partitioned k-mer join
@@ -1744,8 +1759,9 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         const bool jn = use_join || mj_chunk;            // the back end gathers its hits from segments
         const JoinView &jvx = mj_chunk ? jv_mj : jv;
         // (the back end fed from segments exists with 2048, 4096 and 8192 entries of LDS; the 8192-entry one scans in a slab)
-        const int capj = std::min(std::max(cap, 2048), 8192);
-        if (jn && capj > 4096 && !d_fscr) SCR(30, d_fscr, (size_t)ctx->ncu * DH_SEED_FSCR_BLOCKS_PER_CU * DH_SEED_FSCR_WORDS)
+        const int tier_max = getenv("DH_SEED_NO16K") ? 8192 : 16384;  // development / tests: without the 16384-entry tier
+        const int capj = std::min(std::max(cap, 2048), tier_max);
+        if (jn && capj > 4096) SCR(30, d_fscr, (size_t)ctx->ncu * DH_SEED_FSCR_BLOCKS_PER_CU * (capj > 8192 ? DH_SEED_FSCR_WORDS16 : DH_SEED_FSCR_WORDS))
         if (jn)
             dhk_seed_join(st, capj, bv, iv, dopt, jvx, (int32_t)item0, ni, candbase, ncandbase, nhitsbase, d_status,
                           d_queue + 1, ctx->ncu, d_fscr, nullptr, 0);
@@ -1817,47 +1833,42 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             }
             if (mj_chunk) ctx->mj_chunks++;
             mj_skip_chunk = false;  // (the next chunk tries the join again)
-            if (jn && capj < 8192 && !big.empty()) {
-                // second tier of the join path: the reads above the first capacity that fit the 8192-entry variant
-                std::vector<int32_t> mid, huge;
+            if (jn && capj < tier_max && !big.empty()) {
+                // further tiers of the join path: the reads above the first capacity that fit the 8192-entry variant, then the
+                // 16384-entry one (uncapped pile-ups: ~10 000 hits per read); what is left is staged in HBM
+                std::vector<int32_t> huge;
                 int32_t gcap2 = 0;
-                for (int32_t r : big) {
-                    const size_t it = (size_t)(2 * (int64_t)r - item0);
-                    const int32_t nh = h_nhits[it] + h_nhits[it + 1];
-                    if (nh <= 8192)
-                        mid.push_back(r);
-                    else {
-                        huge.push_back(r);
-                        gcap2 = std::max(gcap2, nh);
+                for (int tier = 8192; tier <= tier_max; tier *= 2) {
+                    if (tier <= capj) continue;
+                    std::vector<int32_t> mid;
+                    huge.clear();
+                    gcap2 = 0;
+                    for (int32_t r : big) {
+                        const size_t it = (size_t)(2 * (int64_t)r - item0);
+                        const int32_t nh = h_nhits[it] + h_nhits[it + 1];
+                        if (nh <= tier)
+                            mid.push_back(r);
+                        else {
+                            huge.push_back(r);
+                            gcap2 = std::max(gcap2, nh);
+                        }
                     }
+                    if (!mid.empty()) {
+                        int32_t *d_mid;
+                        uint64_t *d_fscr2;
+                        SCR(54, d_mid, mid.size())
+                        SCR(30, d_fscr2, (size_t)ctx->ncu * DH_SEED_FSCR_BLOCKS_PER_CU * (tier > 8192 ? DH_SEED_FSCR_WORDS16 : DH_SEED_FSCR_WORDS))
+                        HIPCHK(hipMemcpyAsync(d_mid, mid.data(), sizeof(int32_t) * mid.size(), hipMemcpyHostToDevice, st));
+                        HIPCHK(hipMemsetAsync(d_queue + 1, 0, sizeof(uint32_t), st));
+                        dhk_seed_join(st, tier, bv, iv, dopt, jvx, (int32_t)item0, ni, candbase, ncandbase, nhitsbase, d_status,
+                                      d_queue + 1, ctx->ncu, d_fscr2, d_mid, (int32_t)mid.size());
+                        HIPCHK(hipGetLastError());
+                        HIPCHK(hipStreamSynchronize(st));  // mid goes out of scope
+                    }
+                    if (getenv("DH_TRACE"))
+                        fprintf(stderr, "[seeds] join tiers: %zu reads redone with %d entries, %zu left\n", mid.size(), tier, huge.size());
+                    big = huge;
                 }
-                if (!mid.empty()) {
-                    int32_t *d_mid;
-                    uint64_t *d_fscr2;
-                    SCR(54, d_mid, mid.size())
-                    SCR(30, d_fscr2, (size_t)ctx->ncu * DH_SEED_FSCR_BLOCKS_PER_CU * DH_SEED_FSCR_WORDS)
-                    HIPCHK(hipMemcpyAsync(d_mid, mid.data(), sizeof(int32_t) * mid.size(), hipMemcpyHostToDevice, st));
-                    HIPCHK(hipMemsetAsync(d_queue + 1, 0, sizeof(uint32_t), st));
-#ifdef DH_SEED_PROF
-                    if (getenv("DH_TRACE")) {
-                        fprintf(stderr, "(first tier) ");
-                        dhk_seed_prof_dump();
-                    }
-#endif
-                    dhk_seed_join(st, 8192, bv, iv, dopt, jvx, (int32_t)item0, ni, candbase, ncandbase, nhitsbase, d_status,
-                                  d_queue + 1, ctx->ncu, d_fscr2, d_mid, (int32_t)mid.size());
-                    HIPCHK(hipGetLastError());
-                    HIPCHK(hipStreamSynchronize(st));  // mid goes out of scope
-#ifdef DH_SEED_PROF
-                    if (getenv("DH_TRACE")) {
-                        fprintf(stderr, "(8192-entry tier) ");
-                        dhk_seed_prof_dump();
-                    }
-#endif
-                }
-                if (getenv("DH_TRACE"))
-                    fprintf(stderr, "[seeds] join tiers: %zu reads redone with 8192 entries, %zu from HBM\n", mid.size(), huge.size());
-                big.swap(huge);
                 gcap = gcap2;
             }
             if (!big.empty()) {
@@ -1937,7 +1948,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         HIPCHK(dhk_memset(st, d_ovf, 0, sizeof(int32_t) * (size_t)ni));
         WaveScratch ws{d_pool, d_cdj, d_queue, (const int4 *)d_units, d_queue + 3, poolcap, nbmax, d_ovf - item0};
         if (tiled) {
-            dhtile::Params tp;
+            dhtile::Params tp = {};
             tp.aoff = A->d_off;
             tp.boff = B->d_off;
             tp.apk = (const uint32_t *)A->d_pk;
@@ -1985,6 +1996,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             tp.out_ntr = ntrbase;
             tp.counters = d_counters;
             tp.status = d_status;
+            tp.awant = o.skip_self == 2 ? B->d_awant : nullptr;
             dhk_tile(st, tile_waves, &tp);
         } else if (dual)
             dhk_wave2(st, nslots / per_wave, av, bv, A->d_rc, cc.rc, packed ? A->d_pk : nullptr,

@@ -24,6 +24,11 @@ struct DbView {
     // optional soft mask (daligner -m tracks, DBdust): one bit per base of `bases` (bit g = base g is
     // masked); k-mers touching a masked base are neither indexed nor looked up
     const uint8_t *mask_bits;
+    // optional, symmetric all-vs-all only (skip_self == 2): awant[s] != 0 = records with sequence s as A read are wanted.
+    // Pairs of two unwanted sequences are not seeded, the record of an unwanted A read is not written and the transposed
+    // pair is aligned only for a wanted one (dh_process: tile QVs and consensus read the overlaps of the reads that may
+    // serve as reference read only, processPileUps/package.d:461-472, 518-568).  NULL = every record.
+    const uint8_t *awant;
 };
 
 // fat directory word of a bucket (16 bytes, one load per looked-up k-mer):
@@ -88,6 +93,7 @@ void dhk_seed(hipStream_t st, int cap, DbView B, IndexView ix, DhOpts o,
 // scratch of the 8192-entry seed variant: DH_SEED_FSCR_WORDS 8-byte words per resident block
 // (prefix sums u32[8192] + band heads u16[8192]), DH_SEED_FSCR_BLOCKS_PER_CU blocks per CU at most
 #define DH_SEED_FSCR_WORDS 6144
+#define DH_SEED_FSCR_WORDS16 24576 /* the 16384-entry variant fed from segments: u64 sums + u32 band heads */
 #define DH_SEED_FSCR_BLOCKS_PER_CU 4
 void dhk_seed_big(hipStream_t st, DbView B, IndexView ix, DhOpts o,
                   const int32_t *read_list, int32_t nreads, uint64_t *gbuf, int32_t gcap, DhCand *cand,

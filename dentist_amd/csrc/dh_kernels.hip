@@ -593,6 +593,7 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
             // symmetric: each unordered pair once; which read plays B alternates with the
             // parity of a + b, so every read is B for about half of its partners
             if (o.skip_self == 2 && (aseq == r || ((aseq < r) != (((aseq + r) & 1) == 0)))) return;
+            if (o.skip_self == 2 && B.awant && !B.awant[aseq] && !B.awant[r]) return;  // neither record is wanted
             const int64_t gv = (int64_t)(v & ((1ull << 40) - 1));
             const int32_t qs = strand ? blen - k - q : q;  // position on the oriented read
             const int64_t D = gv + ix.sepv - qs;
@@ -758,7 +759,7 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
         else if (tid < N)
             hits[tid] = ~0ull;
         N = 1;  // the network below has nothing left to do
-    } else if (LCAP == 0 || (LCAP <= 8192 && (JOIN || LCAP >= 4096))) {  // (not the mapping launches' small variants: registers)
+    } else if (LCAP == 0 || ((LCAP <= 8192 || JOIN) && (JOIN || LCAP >= 4096))) {  // (not the mapping launches' small variants: registers)
         // More than one hit per thread (the pile-up all-vs-all: 2 500 hits per read, where the network below was 55 of the
         // 97 us a block spent per read): the hits of a read cluster on the diagonals of its overlaps, so they are dealt
         // into 2 x 1024 diagonal buckets (strand, then equal slices of the read's diagonal range: a counting pass, a scan,
@@ -1004,12 +1005,15 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
     // LDS buffer) scans as well, with 64-bit sums (32 bits of coverage, 32 of head count) and 32-bit head positions in
     // the block's slab behind the hits: the serial walks cost a chain of dependent L2 round trips per hit of a band,
     // 5 - 21 ms for the 27 such reads of a configs[2] half (one block each).
-    constexpr bool FASTB = LCAP <= 8192;
+    // (the 16384-entry variant fed from segments -- uncapped pile-ups: 166 reads, ~10 000 hits per read -- scans as well,
+    // with the wide sums of the HBM variant in a slab of 24 576 words per block; the directory-fed one keeps the walks)
+    constexpr bool FASTB = LCAP <= 8192 || (JOIN && LCAP == 16384);
     constexpr bool FB_LDS = LCAP > 0 && LCAP <= 4096;
     constexpr bool FB_BIG = LCAP == 0;
-    using bsum_t = typename std::conditional<FB_BIG, uint64_t, uint32_t>::type;
-    using bhead_t = typename std::conditional<FB_BIG, uint32_t, uint16_t>::type;
-    constexpr int HSH = FB_BIG ? 32 : 18;
+    constexpr bool FB_WIDE = LCAP == 0 || LCAP == 16384;
+    using bsum_t = typename std::conditional<FB_WIDE, uint64_t, uint32_t>::type;
+    using bhead_t = typename std::conditional<FB_WIDE, uint32_t, uint16_t>::type;
+    constexpr int HSH = FB_WIDE ? 32 : 18;
     constexpr bsum_t CMASK = ((bsum_t)1 << HSH) - 1;
     __shared__ uint32_t bsum_l[FB_LDS ? LCAP : 1];   // inclusive prefix sums
     __shared__ uint16_t bhead_l[FB_LDS ? LCAP : 1];  // positions of the band heads
@@ -1270,6 +1274,7 @@ SEED_INST(0, false)
 SEED_INST(2048, true)
 SEED_INST(4096, true)
 SEED_INST(8192, true)
+SEED_INST(16384, true)
 SEED_INST(0, true)
 
 // ------------------------------------------------------------------------------------ K4b
@@ -3027,14 +3032,16 @@ void dhk_seed_join(hipStream_t st, int cap, DbView B, IndexView ix, DhOpts o, Jo
     const int32_t read0 = item0 / 2, nreads = read_list ? nlist : nitems / 2;
 #define SEED_LAUNCH_J(C)                                                                          \
     hipLaunchKernelGGL((k_seed<C, true>), dim3(seed_grid<C, true>(nreads, ncu)), dim3(SEED_THREADS), 0, st, B, ix, jv, o, \
-                       read0, nreads, cand, ncand, nhits, status, C == 8192 ? fscr : (uint64_t *)nullptr,    \
-                       C == 8192 ? DH_SEED_FSCR_WORDS : 0, read_list, queue)
+                       read0, nreads, cand, ncand, nhits, status, C >= 8192 ? fscr : (uint64_t *)nullptr,    \
+                       C == 8192 ? DH_SEED_FSCR_WORDS : (C == 16384 ? DH_SEED_FSCR_WORDS16 : 0), read_list, queue)
     if (cap <= 2048)
         SEED_LAUNCH_J(2048);
     else if (cap <= 4096)
         SEED_LAUNCH_J(4096);
-    else
+    else if (cap <= 8192)
         SEED_LAUNCH_J(8192);
+    else
+        SEED_LAUNCH_J(16384);
 #undef SEED_LAUNCH_J
 }
 

@@ -1905,6 +1905,26 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
         }
         ao.width = pwidth;
         ao.algo = palgo;
+        // The funnel, the tile QVs, the ranking and the first consensus round read the overlaps of the reads that may serve
+        // as reference read only (selectAllowedReferenceReadIds, package.d:461-472; findReferenceReadCandidates :518-568):
+        // pairs of two other reads are not aligned, and of a mixed pair only the record of the allowed read is made.  A
+        // pile-up without any allowed read keeps every pair (it fails later, with the status it always had).
+        // DH_PILE_ALL_PAIRS=1 aligns everything (what `daligner pile.db pile.db` itself writes; tests compare the two).
+        if (!getenv("DH_PILE_ALL_PAIRS")) {
+            std::vector<uint8_t> want((size_t)pile->n, 1);
+            bool any_cut = false;
+            for (int32_t a = 0; a < na; a++) {
+                const int32_t r0 = first_read[(size_t)a], r1 = first_read[(size_t)a + 1];
+                bool has = false;
+                for (int32_t r = r0; r < r1; r++) has = has || rkind[(size_t)r] == 0;
+                if (!has) continue;
+                for (int32_t r = r0; r < r1; r++) {
+                    want[(size_t)r] = rkind[(size_t)r] == 0 ? 1 : 0;
+                    any_cut = any_cut || !want[(size_t)r];
+                }
+            }
+            if (int rc = dh_db_set_awant(pile, any_cut ? want.data() : nullptr)) return rc;
+        }
         dh_la_set *pset = nullptr;
         HIPCHK(hipEventRecord(ev[0], st));
         // (2: the trace values stay on the device -- the tile QVs read them there, the first consensus round fetches the

@@ -72,7 +72,7 @@ extern "C" long dh_tile_host_align2(const uint8_t *abases, const int64_t *aoff, 
     std::vector<int32_t> nla((size_t)nitems, 0), ntr((size_t)nitems, 0), regs((size_t)MAXREG * REGF, 0);
     uint32_t queue = 0;
     int32_t status = 0;
-    Params P;
+    Params P = {};
     P.aoff = aoff;
     P.boff = boff;
     P.apk = apk.data() + PADW;

@@ -320,6 +320,10 @@ def test_hit_sort_by_diagonal_buckets_and_its_fall_backs(gpu_ctx, monkeypatch, c
     err = capfd.readouterr().err
     print(err)
     if nreads >= 24 or copies > 1:
+        # (the 16384-entry tier of the segment-fed back end takes these reads whole; without it they go on to the HBM variant)
+        monkeypatch.setenv("DH_SEED_NO16K", "1")
+        run_both(gpu_ctx, both, both, same=True, tspace=126, skip_self=2, min_len=500, max_la=256, max_cand=256, tcap=200)
+        err = capfd.readouterr().err
         assert "overflow" in err  # reads with more hits than the LDS tiers hold went to the HBM variant
 
 

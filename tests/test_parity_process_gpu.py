@@ -784,3 +784,37 @@ def test_device_funnel_host_funnel_and_the_fall_back_agree(gpu_ctx, monkeypatch)
     assert (out[0][0]["status"] == 0).sum() >= 2
     for rec, bases in out[1:]:
         assert rec.tobytes() == out[0][0].tobytes() and np.array_equal(bases, out[0][1])
+
+
+def test_pairs_without_a_reference_read_candidate_are_not_aligned_and_nothing_changes(gpu_ctx, monkeypatch):
+    """The pile-up all-vs-all (`daligner pile.db pile.db`, processPileUps/package.d:474-485) feeds the error filter, the
+    chaining, the tile QVs and the first consensus round -- all of which read the overlaps of the ALLOWED reference reads
+    only (the reads that span the gap, :461-472; ranking :518-568).  The product therefore does not align two reads of
+    which neither may serve as reference read, and makes only the allowed read's record of a mixed pair; with
+    DH_PILE_ALL_PAIRS=1 it aligns every pair, as daligner would.  Graph pile-ups with extension entries, no read cap:
+    every record field and every consensus base must be the same either way, with visibly less alignment work."""
+    w = sim.Workload(700_000, 7, 4000, 9000, seed=97, spacing=30000, gap_max=1200)
+    mo = dentist_amd.default_align_opts(kmer_mod=4, k=20, width=64, xdrop=60, algo=1)
+    po = dentist_amd.default_process_opts(algo=1, max_reads=0)
+    gaps = np.stack([np.arange(w.contigs.n - 1), np.arange(1, w.contigs.n)], axis=1).astype(np.int32)
+    A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
+    las, trace, _ = gpu_ctx.map_reads(A, B, mo, po, sorted=False, candidates=False)[:3]
+    gp, _ = dentist_amd.scaffold_spanning_pileups(las, w.contigs.off, w.reads.off, gaps, with_extensions=True,
+                                                  min_spanning_reads=po.min_reads)
+    piles = gp.select(las, po)
+    tri = piles.flat()[2]
+    assert ((tri[:, 1] < 0) | (tri[:, 2] < 0)).sum() > 0.2 * len(tri)     # extension entries: reads that cannot be the reference
+    gpu_ctx.cum_stats(reset=True)
+    rec, bases = dentist_amd.process_pileups(gpu_ctx, A, B, las, trace, piles, po)
+    cut = gpu_ctx.cum_stats().as_dict()
+    monkeypatch.setenv("DH_PILE_ALL_PAIRS", "1")
+    gpu_ctx.cum_stats(reset=True)
+    rec2, bases2 = dentist_amd.process_pileups(gpu_ctx, A, B, las, trace, piles, po)
+    full = gpu_ctx.cum_stats().as_dict()
+    assert (rec["status"] == 0).sum() >= 5
+    for f in rec.dtype.names:
+        if f not in ("cons_off", "pad"):
+            assert np.array_equal(rec[f], rec2[f]), f
+    for a, b in zip(rec, rec2):
+        assert np.array_equal(bases[a["cons_off"]:a["cons_off"] + a["cons_len"]], bases2[b["cons_off"]:b["cons_off"] + b["cons_len"]])
+    assert cut["alignments"] < full["alignments"], (cut["alignments"], full["alignments"])
