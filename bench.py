@@ -128,6 +128,10 @@ def main():
                     help="steps of the REFERENCE-BEHAVIOUR configuration timed after the default loop in the same process "
                          "(no read cap: processPileUps/package.d:283-374 has none; no k-mer sampling: damapper has none, "
                          "commandline.d:2943-2955) and reported as reference_behaviour_timed; 0 = skip; N = 1 only")
+    ap.add_argument("--ref-partners", type=int, default=60,
+                    help="partner reads per read of the pile-up all-vs-all in the third timed configuration (no cap, no sampling, "
+                         "dh_process_opts.max_partners = this): reported as uncapped_partner_cut_timed; 0 = skip")
+    ap.add_argument("--max-partners", type=int, default=None, help="dh_process_opts.max_partners of the headline run (default 0: every pair)")
     ap.add_argument("--dev-share-gpu", action="store_true",
                     help="development only: all ranks on cuda:0 with gloo collectives (exercises the N > 1 "
                          "code path on a 1-GPU box; not a measurement)")
@@ -173,6 +177,8 @@ def main():
     popts = dentist_amd.default_process_opts(algo=args.process_algo)
     if args.max_reads is not None:
         popts.max_reads = args.max_reads
+    if args.max_partners is not None:
+        popts.max_partners = args.max_partners
     read_bp = int(len(w.reads.bases))
     if args.collect is None:
         args.collect = "graph"
@@ -239,8 +245,23 @@ def main():
     dt = time.perf_counter() - t0
 
     # the same workload at the reference's behaviour -- every read alignment of a pile-up is processed (no cap) and every
-    # k-mer of the reads is looked up (no modimer sampling) -- timed here, inside the same run, the same way
-    ref_runs, ref_dt, ref_opts = [], 0.0, None
+    # k-mer of the reads is looked up (no modimer sampling) -- timed here, inside the same run, the same way; and once more
+    # with the pile-up all-vs-all bounded to --ref-partners partner reads per read (dh_process_opts.max_partners: every read
+    # still votes in the consensus), which is NOT the reference's behaviour and is labelled as what it is
+    def timed_variant(vm, vp, nsteps):
+        step(vm, vp)   # one untimed step (first-use allocations of the larger buffers)
+        barrier()
+        t0_ = time.perf_counter()
+        vruns = []
+        for _ in range(nsteps):
+            if vruns:
+                for key in ("las", "rec", "bases"):
+                    vruns[-1].pop(key, None)
+            vruns.append(step(vm, vp))
+        barrier()
+        return vruns, time.perf_counter() - t0_
+
+    ref_runs, ref_dt, cut_runs, cut_dt = [], 0.0, [], 0.0
     if args.ref_steps > 0 and world == 1 and (args.kmer_mod != 1 or popts.max_reads != 0):
         for r in runs[:-1]:
             for key in ("las", "rec", "bases"):
@@ -249,17 +270,12 @@ def main():
                                                 xdrop=args.map_xdrop, algo=args.map_algo)
         rpopts = dentist_amd.default_process_opts(algo=args.process_algo)
         rpopts.max_reads = 0
-        ref_opts = (rmopts, rpopts)
-        step(rmopts, rpopts)   # one untimed step (first-use allocations of the larger buffers)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.ref_steps):
-            if ref_runs:
-                for key in ("las", "rec", "bases"):
-                    ref_runs[-1].pop(key, None)
-            ref_runs.append(step(rmopts, rpopts))
-        barrier()
-        ref_dt = time.perf_counter() - t0
+        ref_runs, ref_dt = timed_variant(rmopts, rpopts, args.ref_steps)
+        if args.ref_partners > 0 and args.process_algo == 1:
+            cpopts = dentist_amd.default_process_opts(algo=args.process_algo)
+            cpopts.max_reads = 0
+            cpopts.max_partners = args.ref_partners
+            cut_runs, cut_dt = timed_variant(rmopts, cpopts, args.ref_steps)
 
     last = runs[-1]
     aligned_bp = int((last["las"]["aepos"] - last["las"]["abpos"]).sum())
@@ -382,16 +398,15 @@ def main():
         }
         # the headline uses two work-reducing knobs the reference does not apply (read cap, modimer sampling): the same
         # workload at the reference's behaviour, timed above in this very run
-        if ref_runs:
-            rl = ref_runs[-1]
+        def variant_block(vruns, vdt, what):
+            rl = vruns[-1]
             rgap, rclosed, redits, rtruth = closed_gap_stats(w, rl["rec"], rl["bases"])
-            rmean = lambda f: float(np.mean([f(r) for r in ref_runs]))  # noqa: E731
+            rmean = lambda f: float(np.mean([f(r) for r in vruns]))  # noqa: E731
             rseed_ms = rmean(lambda r: r["ast"].ms_seed)
-            out["reference_behaviour_timed"] = {
-                "what": "the same workload with no read cap per pile-up (max_reads = 0) and no k-mer sampling of the mapping "
-                        "index (kmer_mod = 1): what the reference does (processPileUps/package.d:283-374, commandline.d:2943-2955)",
-                "steps": args.ref_steps, "warmup": 1, "ms_per_step": ref_dt / args.ref_steps * 1e3,
-                "value": rgap * args.ref_steps / ref_dt, "unit": "gap-bp/s",
+            return {
+                "what": what,
+                "steps": args.ref_steps, "warmup": 1, "ms_per_step": vdt / args.ref_steps * 1e3,
+                "value": rgap * args.ref_steps / vdt, "unit": "gap-bp/s",
                 "gaps_closed": rclosed, "gap_bases_closed": rgap, "pile_up_entries": int(rl["info"].get("entries", 0)),
                 "consensus_error_rate": (redits / rtruth) if rtruth else None,
                 "read_bp_aligned_per_sec_mapping_stage": int((rl["las"]["aepos"] - rl["las"]["abpos"]).sum()) / rmean(lambda r: r["t_map"]),
@@ -402,8 +417,14 @@ def main():
                               "collect_wall": rmean(lambda r: r["t_collect"]) * 1e3,
                               "process_wall": rmean(lambda r: r["t_process"]) * 1e3,
                               **{"process_" + k[3:]: rmean(lambda r, k=k: r["pst"][k]) for k in rl["pst"] if k.startswith("ms_")}}}
-        else:
-            out["reference_behaviour_timed"] = None
+
+        out["reference_behaviour_timed"] = variant_block(
+            ref_runs, ref_dt, "the same workload with no read cap per pile-up (max_reads = 0) and no k-mer sampling of the mapping "
+            "index (kmer_mod = 1): what the reference does (processPileUps/package.d:283-374, commandline.d:2943-2955)") if ref_runs else None
+        out["uncapped_partner_cut_timed"] = variant_block(
+            cut_runs, cut_dt, f"no read cap, no k-mer sampling, and the pile-up all-vs-all bounded to {args.ref_partners} partner reads per "
+            "read (dh_process_opts.max_partners; every read still votes in the consensus rounds) -- NOT the reference's "
+            "behaviour: daligner aligns every pair of a pile-up (package.d:474-485)") if cut_runs else None
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(w, last, mopts, popts, args, gap_all, read_all)
         print(json.dumps(out))

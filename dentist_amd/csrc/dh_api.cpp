@@ -275,16 +275,16 @@ extern "C" int dh_ctx_sync(dh_ctx *c)
     return DH_OK;
 }
 
-int dh_db_set_awant(dh_db *db, const uint8_t *flags)
+int dh_db_set_pflags(dh_db *db, const uint8_t *flags)
 {
-    if (!db) return fail(DH_EINVAL, "dh_db_set_awant: NULL");
+    if (!db) return fail(DH_EINVAL, "dh_db_set_pflags: NULL");
     if (!flags) {
-        dh_dev_free(db->d_awant);
-        db->d_awant = nullptr;
+        dh_dev_free(db->d_pflags);
+        db->d_pflags = nullptr;
         return DH_OK;
     }
-    if (!db->d_awant) HIPCHK(dh_dev_alloc(&db->d_awant, (size_t)std::max(db->n, 1)));
-    HIPCHK(hipMemcpyAsync(db->d_awant, flags, (size_t)db->n, hipMemcpyHostToDevice, db->ctx->stream));
+    if (!db->d_pflags) HIPCHK(dh_dev_alloc(&db->d_pflags, (size_t)std::max(db->n, 1)));
+    HIPCHK(hipMemcpyAsync(db->d_pflags, flags, (size_t)db->n, hipMemcpyHostToDevice, db->ctx->stream));
     HIPCHK(hipStreamSynchronize(db->ctx->stream));
     return DH_OK;
 }
@@ -413,7 +413,7 @@ extern "C" void dh_db_destroy(dh_db *db)
     dh_dev_free(db->d_off);
     dh_dev_free(db->d_group);
     dh_mask_free(db);
-    dh_dev_free(db->d_awant);
+    dh_dev_free(db->d_pflags);
     if (db->has_ix) db->ix.release();
     delete db;
 }
@@ -1996,7 +1996,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             tp.out_ntr = ntrbase;
             tp.counters = d_counters;
             tp.status = d_status;
-            tp.awant = o.skip_self == 2 ? B->d_awant : nullptr;
+            tp.pflags = o.skip_self == 2 ? B->d_pflags : nullptr;
             dhk_tile(st, tile_waves, &tp);
         } else if (dual)
             dhk_wave2(st, nslots / per_wave, av, bv, A->d_rc, cc.rc, packed ? A->d_pk : nullptr,

@@ -24,12 +24,22 @@ struct DbView {
     // optional soft mask (daligner -m tracks, DBdust): one bit per base of `bases` (bit g = base g is
     // masked); k-mers touching a masked base are neither indexed nor looked up
     const uint8_t *mask_bits;
-    // optional, symmetric all-vs-all only (skip_self == 2): awant[s] != 0 = records with sequence s as A read are wanted.
-    // Pairs of two unwanted sequences are not seeded, the record of an unwanted A read is not written and the transposed
-    // pair is aligned only for a wanted one (dh_process: tile QVs and consensus read the overlaps of the reads that may
-    // serve as reference read only, processPileUps/package.d:461-472, 518-568).  NULL = every record.
-    const uint8_t *awant;
+    // optional, symmetric all-vs-all only (skip_self == 2): pflags[s] bit 0 = records with sequence s as A read are
+    // wanted, bit 1 = s may be the B read of a wanted record.  The record (a, b) is wanted iff (pflags[a] & 1) and
+    // (pflags[b] & 2); a pair yields hits iff one of its two records is wanted, an unwanted record is not written and the
+    // transposed pair is aligned only for a wanted one (dh_process: the funnel, the tile QVs and the consensus read the
+    // overlaps of the reads that may serve as reference read only, processPileUps/package.d:461-472, 518-568; with
+    // dh_process_opts.max_partners against a bounded set of partners).  NULL = every record.  oracle/align.c has the
+    // same rule (oz_db.pflags).
+    const uint8_t *pflags;
 };
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define DH_HDI __host__ __device__ inline
+#else
+#define DH_HDI inline
+#endif
+DH_HDI bool dh_rec_wanted(const uint8_t *f, int32_t a, int32_t b) { return (f[a] & 1) && (f[b] & 2); }
+DH_HDI bool dh_pair_seeded(const uint8_t *f, int32_t a, int32_t b) { return dh_rec_wanted(f, a, b) || dh_rec_wanted(f, b, a); }
 
 // fat directory word of a bucket (16 bytes, one load per looked-up k-mer):
 //   x == ~0            empty bucket

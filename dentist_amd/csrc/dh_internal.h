@@ -77,8 +77,8 @@ struct dh_ctx {
 };
 // slot `id` of the context's scratch arena, at least `bytes` large
 int dh_scratch(dh_ctx *ctx, int id, size_t bytes, void **out);
-// per-sequence flags of a symmetric all-vs-all (DbView::awant); NULL clears them
-int dh_db_set_awant(struct dh_db *db, const uint8_t *flags);
+// per-sequence flags of a symmetric all-vs-all (DbView::pflags); NULL clears them
+int dh_db_set_pflags(struct dh_db *db, const uint8_t *flags);
 
 struct dh_index {
     // d_dir (build only, released afterwards) points one word into its allocation: d_dir[-1] == 0, so that
@@ -138,8 +138,8 @@ struct dh_db {
     // inherit into it) and what the library derived (DBdust, alignment coverage).  d_mask_bits is the
     // layer itself while only one exists, their OR in a buffer of its own when both do.
     uint8_t *d_mask_user = nullptr, *d_mask_derived = nullptr;
-    uint8_t *d_awant = nullptr;  // see DbView::awant (dh_db_set_awant)
-    DbView view() const { return DbView{d_bases, d_off, d_group, n, d_mask_bits, d_awant}; }
+    uint8_t *d_pflags = nullptr;  // see DbView::pflags (dh_db_set_pflags)
+    DbView view() const { return DbView{d_bases, d_off, d_group, n, d_mask_bits, d_pflags}; }
 };
 
 // Result buffers live in pooled page-locked host memory: device-to-host copies into them run at

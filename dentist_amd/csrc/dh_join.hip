@@ -296,7 +296,7 @@ k_join(JoinView jv, DbView B, DhOpts o, const int64_t *__restrict__ goff, int32_
                 bool keep = true;
                 if (o.skip_self == 1) keep = Aq != R;
                 if (o.skip_self == 2) keep = Aq != R && ((Aq < R) == (((Aq + R) & 1) == 0));
-                if (o.skip_self == 2 && B.awant && !B.awant[Aq] && !B.awant[R]) keep = false;  // neither record is wanted
+                if (o.skip_self == 2 && B.pflags && !dh_pair_seeded(B.pflags, Aq, R)) keep = false;  // neither record is wanted
                 n_same += same ? 1 : 0;
                 k_same += same && keep ? 1 : 0;
                 n_opp += same ? 0 : 1;
@@ -354,7 +354,7 @@ k_join(JoinView jv, DbView B, DhOpts o, const int64_t *__restrict__ goff, int32_
                 const int32_t Aq = r0 + arl;
                 if (o.skip_self == 1 && Aq == R) continue;
                 if (o.skip_self == 2 && (Aq == R || ((Aq < R) != (((Aq + R) & 1) == 0)))) continue;
-                if (o.skip_self == 2 && B.awant && !B.awant[Aq] && !B.awant[R]) continue;
+                if (o.skip_self == 2 && B.pflags && !dh_pair_seeded(B.pflags, Aq, R)) continue;
                 const int64_t gv = lgoff[arl] + (int64_t)(ka & (JOIN_MAX_LEN - 1));
                 if (dof && (same || pal)) {
                     const int64_t D = gv + sepv - q;

@@ -593,7 +593,7 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
             // symmetric: each unordered pair once; which read plays B alternates with the
             // parity of a + b, so every read is B for about half of its partners
             if (o.skip_self == 2 && (aseq == r || ((aseq < r) != (((aseq + r) & 1) == 0)))) return;
-            if (o.skip_self == 2 && B.awant && !B.awant[aseq] && !B.awant[r]) return;  // neither record is wanted
+            if (o.skip_self == 2 && B.pflags && !dh_pair_seeded(B.pflags, aseq, r)) return;  // neither record is wanted
             const int64_t gv = (int64_t)(v & ((1ull << 40) - 1));
             const int32_t qs = strand ? blen - k - q : q;  // position on the oriented read
             const int64_t D = gv + ix.sepv - qs;

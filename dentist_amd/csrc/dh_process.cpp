@@ -1737,6 +1737,7 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
     const dh_process_opts &o = *opts;
     if (o.max_reads != 0 && (o.max_reads < 3 || o.max_reads > 250))
         return dh_fail(DH_EINVAL, "max_reads must be 0 (no cap) or in [3, 250]");
+    if (o.max_partners != 0 && o.max_partners < 4) return dh_fail(DH_EINVAL, "max_partners must be 0 (every pair) or at least 4");
     if (o.rounds < 1 || o.rounds > 8) return dh_fail(DH_EINVAL, "rounds must be in [1, 8]");
     if (o.tspace_pile < 16 || o.tspace_pile > SEG_MAX) return dh_fail(DH_EINVAL, "tspace_pile out of range");
     HIPCHK(hipSetDevice(ctx->device));
@@ -1910,20 +1911,28 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
         // pairs of two other reads are not aligned, and of a mixed pair only the record of the allowed read is made.  A
         // pile-up without any allowed read keeps every pair (it fails later, with the status it always had).
         // DH_PILE_ALL_PAIRS=1 aligns everything (what `daligner pile.db pile.db` itself writes; tests compare the two).
-        if (!getenv("DH_PILE_ALL_PAIRS")) {
-            std::vector<uint8_t> want((size_t)pile->n, 1);
+        // max_partners (dh_process_opts): the B side of the wanted records is bounded as well -- the first max_partners
+        // reads of the pile-up in the order allowed reads, then the others, each in pile-up order.
+        // (DH-2 only: with DH-1 every pair is aligned; oracle/process.py and oracle/pile.c set the same flags.)
+        if (!getenv("DH_PILE_ALL_PAIRS") && palgo == 1) {
+            std::vector<uint8_t> fl((size_t)pile->n, 3);  // bit 0: records with the read as A are wanted, bit 1: it may be their B
             bool any_cut = false;
             for (int32_t a = 0; a < na; a++) {
                 const int32_t r0 = first_read[(size_t)a], r1 = first_read[(size_t)a + 1];
-                bool has = false;
-                for (int32_t r = r0; r < r1; r++) has = has || rkind[(size_t)r] == 0;
-                if (!has) continue;
+                int32_t nallowed = 0;
+                for (int32_t r = r0; r < r1; r++) nallowed += rkind[(size_t)r] == 0 ? 1 : 0;
+                if (nallowed == 0) continue;
+                const bool cut_b = o.max_partners > 0 && r1 - r0 > o.max_partners;
+                int32_t seen_allowed = 0, seen_other = 0;
                 for (int32_t r = r0; r < r1; r++) {
-                    want[(size_t)r] = rkind[(size_t)r] == 0 ? 1 : 0;
-                    any_cut = any_cut || !want[(size_t)r];
+                    const bool al = rkind[(size_t)r] == 0;
+                    const int32_t rank = al ? seen_allowed++ : nallowed + seen_other++;  // position in (allowed, then others)
+                    const bool partner = !cut_b || rank < o.max_partners;
+                    fl[(size_t)r] = (uint8_t)((al ? 1 : 0) | (partner ? 2 : 0));
+                    any_cut = any_cut || fl[(size_t)r] != 3;
                 }
             }
-            if (int rc = dh_db_set_awant(pile, any_cut ? want.data() : nullptr)) return rc;
+            if (int rc = dh_db_set_pflags(pile, any_cut ? fl.data() : nullptr)) return rc;
         }
         dh_la_set *pset = nullptr;
         HIPCHK(hipEventRecord(ev[0], st));

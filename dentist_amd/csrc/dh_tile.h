@@ -89,7 +89,7 @@ struct Params {
     int32_t *out_nla2, *out_ntr2;
     unsigned long long *counters;     // [0] band cells computed, [1] candidates aligned
     int32_t *status;
-    const uint8_t *awant;             // symmetric mode, optional (DbView::awant): which A reads' records are wanted
+    const uint8_t *pflags;            // symmetric mode, optional (DbView::pflags): which records are wanted
 };
 
 // one running extension (registers)
@@ -610,14 +610,14 @@ DH_HD void lane_ext_end(Lane &l, const Params &P)
         } else if (!sym) {
             P.out_la[(int64_t)item * P.o.max_la + c.nacc] = la;
             c.ntr += 2 * npairs;
-        } else if (!P.awant || P.awant[la.aread]) {
+        } else if (!P.pflags || dh_rec_wanted(P.pflags, la.aread, la.bread)) {
             la.pad = 1;  // valid (the slots start zeroed); grouped by A read after the launch
             P.out_la[2 * ((int64_t)c.cbase + c.c) + mode] = la;
         }
         LP(3)
         if (mode == 0) c.nacc += 1;
         // the second record: the transposed pair, aligned on its own (symmetric mode: when its A read's records are wanted)
-        if ((sym || P.out_la2) && mode == 0 && (!sym || !P.awant || P.awant[item >> 1])) {
+        if ((sym || P.out_la2) && mode == 0 && (!sym || !P.pflags || dh_rec_wanted(P.pflags, item >> 1, c_aseq))) {
             cand_geometry(l, P, 1);
             ext_begin(l, P, 1);
             LP(4)

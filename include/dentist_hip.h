@@ -239,6 +239,14 @@ typedef struct {
                                 * 655-667); the flank DB also inherits the contigs' soft mask (-mrep)       */
     int32_t algo;              /* alignments of the process stages (pile-up all-vs-all, re-alignment to the template,
                                 * flanks): 0 = DH-1 (wave, `width` live diagonals), 1 = DH-2 (tiled band of 64, k_tile) */
+    int32_t max_partners;      /* 0 (default) = the pile-up all-vs-all aligns every read with every other, as
+                                * `daligner pile.db pile.db` does (package.d:474-485).  n > 0 (DH-2 only): a pile-up of more
+                                * than n reads takes n PARTNER reads -- the first n in the order: reads that may serve as
+                                * reference read (:461-472), then the others, each in pile-up order -- and aligns a read with
+                                * the partners only: the tile QVs that rank the reference-read candidates (:498-568) and the
+                                * first consensus round see n overlaps per read instead of all, the later consensus rounds
+                                * still re-align EVERY read of the pile-up to the template.  The n^2 stage becomes n x
+                                * max_partners; every read keeps its vote.  oracle/process.py, oracle/pile.c: same rule. */
 } dh_process_opts;
 void dh_default_process_opts(dh_process_opts *o);
 

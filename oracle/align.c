@@ -314,20 +314,23 @@ static int cand_cmp_aseq(const void *x, const void *y)
 /* bmask/nbmask: sorted masked intervals of this B sequence in the orientation of `b` (or NULL) */
 static int seed_candidates(const oz_index *ix, const uint8_t *b, int32_t blen, int32_t bgroup,
                            int32_t bself, const int32_t *bmask, int64_t nbmask, const oz_opts *o,
-                           oz_cand *out, int32_t *nhits_out);
+                           oz_cand *out, int32_t *nhits_out, const uint8_t *pflags);
+
+/* oz_db.pflags: is the record with A read a and B read b wanted / does the pair {a, b} yield hits at all */
+static int rec_wanted(const uint8_t *f, int32_t a, int32_t b) { return !f || ((f[a] & 1) && (f[b] & 2)); }
+static int pair_seeded(const uint8_t *f, int32_t a, int32_t b) { return !f || rec_wanted(f, a, b) || rec_wanted(f, b, a); }
 
 int oz_seed_candidates(const oz_index *ix, const oz_db *A, const uint8_t *b, int32_t blen,
                        int32_t bgroup, int32_t bself, int32_t sepv_unused, const oz_opts *o,
                        oz_cand *out, int32_t *nhits_out)
 {
-    (void)A;
     (void)sepv_unused;
-    return seed_candidates(ix, b, blen, bgroup, bself, NULL, 0, o, out, nhits_out);
+    return seed_candidates(ix, b, blen, bgroup, bself, NULL, 0, o, out, nhits_out, o->skip_self == 2 && o->algo == 1 ? A->pflags : NULL);
 }
 
 static int seed_candidates(const oz_index *ix, const uint8_t *b, int32_t blen, int32_t bgroup,
                            int32_t bself, const int32_t *bmask, int64_t nbmask, const oz_opts *o,
-                           oz_cand *out, int32_t *nhits_out)
+                           oz_cand *out, int32_t *nhits_out, const uint8_t *pflags)
 {
     const int k = o->k;
     const int32_t sepv = ix->sepv;
@@ -362,6 +365,7 @@ static int seed_candidates(const oz_index *ix, const uint8_t *b, int32_t blen, i
             if (o->skip_self == 2) {
                 const int32_t pa = ix->e[t].aseq;
                 if (pa == bself || ((pa < bself) != (((pa + bself) & 1) == 0))) continue;
+                if (!pair_seeded(pflags, pa, bself)) continue; /* neither record of the pair is wanted */
             }
             int64_t D = ix->goff[ix->e[t].aseq] + ix->e[t].apos + sepv - q;
             if (n == cap) {
@@ -991,7 +995,8 @@ static void align_read(const oz_index *ix, const oz_db *A, const oz_db *B, int32
                 bm = tmpm;
             }
         }
-        int nc = seed_candidates(ix, b, blen, bgroup, r, bm, nbm, o, cands, &nh);
+        const uint8_t *pf = o->skip_self == 2 && o->algo == 1 ? A->pflags : NULL;
+        int nc = seed_candidates(ix, b, blen, bgroup, r, bm, nbm, o, cands, &nh, pf);
         free(tmpm);
         stats[0] += nh;
         stats[1] += nc;
@@ -1032,8 +1037,8 @@ static void align_read(const oz_index *ix, const oz_db *A, const oz_db *B, int32
             la.aread = cd->aseq;
             la.bread = r;
             la.flags = strand ? OZ_FLAG_COMP : 0;
-            la_set_push(out, &la, trace);
-            if ((sym || out2) && tiled) {
+            if (!sym || rec_wanted(pf, cd->aseq, r)) la_set_push(out, &la, trace);
+            if ((sym || out2) && tiled && (!sym || rec_wanted(pf, r, cd->aseq))) {
                 /* DH-2, symmetric (or the transposed file of a mapping): the record (b, a) is the tiled alignment of the transposed pair through the
                  * same seed -- A'' = the read behind B on its forward strand (the trace grid of that record),
                  * B'' = the A read, complemented when B is (then both axes are mirrored: the seed point

@@ -42,6 +42,12 @@ typedef struct {
      * masked interval are neither indexed nor looked up */
     const int64_t *mask_ptr;
     const int32_t *mask_iv;
+    /* optional, symmetric all-vs-all (skip_self == 2, algo 1) only: pflags[s] bit 0 = records with sequence s as A read
+     * are wanted, bit 1 = s may be the B read of a wanted record.  Record (a, b) is wanted iff (pflags[a] & 1) &&
+     * (pflags[b] & 2); a pair yields hits iff one of its two records is wanted, an unwanted record is not emitted.  The
+     * process drivers set it for the pile-up all-vs-all (allowed reference reads as A, dh_process_opts.max_partners for
+     * B); NULL = every record. */
+    const uint8_t *pflags;
 } oz_db;
 
 void oz_encode(const char *ascii, int64_t n, uint8_t *codes);
@@ -182,7 +188,8 @@ int32_t oz_consensus(const uint8_t *ref, int32_t rlen, const oz_db *reads, const
 typedef struct {
     int32_t ts_map, allowance, min_anchor, min_reads, max_reads, ts_pile, rounds, flank_window,
         max_align_err_ppm, max_ins_err_ppm, bad_fraction_ppm, width, dust,
-        algo; /* alignments of the process stages: 0 = DH-1 (wave, `width` live diagonals), 1 = DH-2 (tiled band of 64) */
+        algo, /* alignments of the process stages: 0 = DH-1 (wave, `width` live diagonals), 1 = DH-2 (tiled band of 64) */
+        max_partners; /* 0 = every pair of a pile-up is aligned; n > 0 (algo 1): the first n reads are the partners (dh_process_opts) */
 } oz_process_opts;
 void oz_default_process_opts(oz_process_opts *o);
 typedef struct {

@@ -431,7 +431,7 @@ static void process_one(const oz_db *contigs, const oz_db *reads, const oz_la *l
         goto done_pile;
     }
     {
-        oz_db pdb = {pile.n, pile.off, pile.bases, NULL, NULL, NULL};
+        oz_db pdb = {pile.n, pile.off, pile.bases, NULL, NULL, NULL, NULL};
         /* DBdust pileup.db; daligner ... -mdust (package.d:476-482) */
         int64_t *dptr = NULL;
         int32_t *div = NULL;
@@ -450,10 +450,20 @@ static void process_one(const oz_db *contigs, const oz_db *reads, const oz_la *l
         oz_opts po;
         const int32_t pla = pile.n <= 60 ? 64 : (pile.n <= 124 ? 128 : 256);
         set_opts(&po, tsp, 500, 2, pla, pla * 2 < 256 ? pla * 2 : 256, o->width, o->algo);
+        /* dh_process_opts.max_partners: a read is aligned with the first max_partners reads only (every read of these
+         * pile-ups spans the gap, i.e. may serve as reference read: bit 0 everywhere) */
+        uint8_t *pfl = NULL;
+        if (o->algo == 1 && o->max_partners > 0 && pile.n > o->max_partners) {
+            pfl = (uint8_t *)malloc((size_t)pile.n);
+            for (int32_t i = 0; i < pile.n; i++) pfl[i] = (uint8_t)(1 | (i < o->max_partners ? 2 : 0));
+            pdb.pflags = pfl;
+        }
         oz_la_set ps;
         oz_la_set_init(&ps);
         int64_t st[4];
         oz_align_db(&pdb, &pdb, &po, 1, &ps, st);
+        pdb.pflags = NULL;
+        free(pfl);
         oz_la_set_sort(&ps);
         /* computeQVs' funnel (package.d:474-516) */
         for (int64_t i = 0; i < ps.n; i++)
@@ -507,7 +517,7 @@ static void process_one(const oz_db *contigs, const oz_db *reads, const oz_la *l
         oz_la_set_free(&ps);
         for (int32_t round = 1; round < o->rounds; round++) {
             int64_t toff[2] = {0, clen};
-            oz_db tdb = {1, toff, cons, NULL, NULL, NULL};
+            oz_db tdb = {1, toff, cons, NULL, NULL, NULL, NULL};
             oz_opts ro;
             set_opts(&ro, tsp, 500, 0, 4, 32, o->width, o->algo);
             oz_la_set rs;
@@ -537,7 +547,7 @@ static void process_one(const oz_db *contigs, const oz_db *reads, const oz_la *l
         memcpy(fb, cl + wl, (size_t)fl_len);
         memcpy(fb + fl_len, cr, (size_t)fr_len);
         int64_t foff[3] = {0, fl_len, (int64_t)fl_len + fr_len};
-        oz_db fdb = {2, foff, fb, NULL, NULL, NULL};
+        oz_db fdb = {2, foff, fb, NULL, NULL, NULL, NULL};
         /* DBdust contigs.dam; daligner -A ... -mdust -mrep (package.d:631-667; no repeat mask here) */
         int64_t *fdptr = NULL;
         int32_t *fdiv = NULL;
@@ -548,7 +558,7 @@ static void process_one(const oz_db *contigs, const oz_db *reads, const oz_la *l
             fdb.mask_iv = fdiv;
         }
         int64_t coff[2] = {0, clen};
-        oz_db cdb = {1, coff, cons, NULL, NULL, NULL};
+        oz_db cdb = {1, coff, cons, NULL, NULL, NULL, NULL};
         oz_opts fo;
         set_opts(&fo, tsp, 126, 0, 4, 32, o->width, o->algo);
         oz_la_set fs;

@@ -336,7 +336,8 @@ def chain_pile_las(las, max_indel=1000, max_gap=10000, max_rel_overlap=0.3, min_
     return las
 
 
-def process_pile(entries, las, trace, contigs, reads, g, rounds=3, nthreads=1, flank_window=20000, dust=True, algo=0, mask=None):
+def process_pile(entries, las, trace, contigs, reads, g, rounds=3, nthreads=1, flank_window=20000, dust=True, algo=0, mask=None,
+                 max_partners=0):
     """One pile-up through the `process` sequence; returns a dict describing the insertion.  g: the left contig of a
     plain gap, or any join (contig0, seed0, contig1, seed1) -- see join_of."""
     res = {"gap": g, "status": "ok", "nreads": len(entries)}
@@ -358,14 +359,26 @@ def process_pile(entries, las, trace, contigs, reads, g, rounds=3, nthreads=1, f
     if dust:   # DBdust pileup.db; daligner ... -mdust (package.d:476-482)
         pile = oz.with_dust(pile)
         res["pile"] = pile
-    plas, ptrace, _ = oz.align_db(pile, pile, o, nthreads=nthreads)
-    # computeQVs (package.d:474-516): error filter -> chain -> DAScover/DASqv -> proper-overlap filter
-    chained = filter_pile_las(plas, pile, proper=False)
-    rlen = np.asarray([pile.length(i) for i in range(pile.n)], dtype=np.int32)
     # allowed reference reads = the reads that span the gap (selectAllowedReferenceReadIds, package.d:461-472);
     # coverage = max(their number, 4 if pile >= 4) (package.d:498-503)
     # (an extension pile-up has one flank: every read has its alignment there)
     allowed = np.asarray([1 if (k & 3) == (0 if c1 >= 0 else 1) else 0 for k in kinds], dtype=np.uint8)
+    # Everything downstream reads the overlaps of the allowed reads only, so (DH-2) records with another read as A are not
+    # made and pairs of two such reads not aligned (oz_db.pflags bit 0); max_partners bounds the B side as well (bit 1): the
+    # first max_partners reads in the order allowed reads, then the others, each in pile-up order (dh_process_opts).
+    if algo == 1 and allowed.any():
+        order = [i for i in range(pile.n) if allowed[i]] + [i for i in range(pile.n) if not allowed[i]]
+        partner = np.ones(pile.n, dtype=np.uint8)
+        if max_partners > 0 and pile.n > max_partners:
+            partner[:] = 0
+            partner[order[:max_partners]] = 1
+        fl = (allowed | (partner << 1)).astype(np.uint8)
+        pile.pflags = np.ascontiguousarray(fl) if (fl != 3).any() else None
+    plas, ptrace, _ = oz.align_db(pile, pile, o, nthreads=nthreads)
+    pile.pflags = None
+    # computeQVs (package.d:474-516): error filter -> chain -> DAScover/DASqv -> proper-overlap filter
+    chained = filter_pile_las(plas, pile, proper=False)
+    rlen = np.asarray([pile.length(i) for i in range(pile.n)], dtype=np.int32)
     cov = int(allowed.sum())
     if cov < 4 and pile.n >= 4:
         cov = 4

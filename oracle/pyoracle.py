@@ -37,7 +37,8 @@ class LaSet(ctypes.Structure):
 
 class Db(ctypes.Structure):
     _fields_ = [("n", ctypes.c_int32), ("off", ctypes.c_void_p), ("bases", ctypes.c_void_p),
-                ("group", ctypes.c_void_p), ("mask_ptr", ctypes.c_void_p), ("mask_iv", ctypes.c_void_p)]
+                ("group", ctypes.c_void_p), ("mask_ptr", ctypes.c_void_p), ("mask_iv", ctypes.c_void_p),
+                ("pflags", ctypes.c_void_p)]
 
 
 _LIB = None
@@ -104,6 +105,9 @@ def _db(seqdb):
     if mask is not None:
         d.mask_ptr = mask[0].ctypes.data
         d.mask_iv = mask[1].ctypes.data
+    pf = getattr(seqdb, "pflags", None)   # uint8[n] or None: which records of a symmetric all-vs-all are wanted (oz_db.pflags)
+    if pf is not None:
+        d.pflags = pf.ctypes.data
     return d
 
 
@@ -273,7 +277,7 @@ def valid_pileup_alignment(la, alen, blen, allowance):
 class ProcessOpts(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "ts_map", "allowance", "min_anchor", "min_reads", "max_reads", "ts_pile", "rounds", "flank_window",
-        "max_align_err_ppm", "max_ins_err_ppm", "bad_fraction_ppm", "width", "dust", "algo")]
+        "max_align_err_ppm", "max_ins_err_ppm", "bad_fraction_ppm", "width", "dust", "algo", "max_partners")]
 
 
 OZ_INSERTION_DTYPE = np.dtype([(n, "<i4") for n in (

@@ -345,9 +345,11 @@ def test_scaffold_graph_builder_on_a_mapping(gpu_ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("algo", [0, 1])
-def test_pile_ups_of_the_graph_builder_with_extension_entries(gpu_ctx, algo):
-    """Read-id parity on the path bench.py runs: mapping -> six collect filters -> scaffold-graph builder
+@pytest.mark.parametrize("algo,max_partners", [(0, 0), (1, 0), (1, 12), (1, 5)])
+def test_pile_ups_of_the_graph_builder_with_extension_entries(gpu_ctx, algo, max_partners):
+    """(max_partners > 0: dh_process_opts.max_partners -- a read of a pile-up is aligned with the first max_partners reads
+    only, in the order allowed reference reads, then the others; oracle/process.py applies the same rule.)
+    Read-id parity on the path bench.py runs: mapping -> six collect filters -> scaffold-graph builder
     (pileups.d:173-208) -> gap pile-ups WITH the extension-type read alignments mergeExtensionsWithGaps put
     into them (scaffold.d:789-816; pileups.d:870 makes a read whose first alignment starts after read
     position 0 open with an extension) -> crop -> process.  Membership equals oracle/scaffold.py:build() on
@@ -356,7 +358,7 @@ def test_pile_ups_of_the_graph_builder_with_extension_entries(gpu_ctx, algo):
     from oracle import scaffold as sc
     w = sim.Workload(1_000_000, 10, 8000, 8000, seed=43)
     mo = dentist_amd.default_align_opts(kmer_mod=4, k=20, **(dict(algo=1, width=64) if algo else {}))
-    po = dentist_amd.default_process_opts(rounds=2, algo=algo, max_reads=0)
+    po = dentist_amd.default_process_opts(rounds=2, algo=algo, max_reads=0, max_partners=max_partners)
     A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
     las, trace = gpu_ctx.align_db(A, B, mo, select_best=True)
     las, dropped, _ = dentist_amd.collect_filter(las, w.contigs.off, w.reads.off, po, inplace=True)
@@ -397,11 +399,12 @@ def test_pile_ups_of_the_graph_builder_with_extension_entries(gpu_ctx, algo):
     for i in range(len(piles)):
         g, tri = piles.get(i)
         ex = pr.process_pile([tuple(int(x) for x in t) for t in tri.tolist()], las, trace, w.contigs, w.reads, int(g),
-                             rounds=po.rounds, nthreads=os.cpu_count() or 1, algo=algo)
+                             rounds=po.rounds, nthreads=os.cpu_count() or 1, algo=algo, max_partners=max_partners)
         r = rec[i]
         assert (r["status"] == 0) == (ex["status"] == "ok"), (g, int(r["status"]), ex["status"])
         if r["status"] != 0:
             continue
+        assert max_partners == 0 or ex["pile"].n > max_partners   # (the option bites in every pile-up of this case)
         assert (r["crop_left"], r["crop_right"], r["nreads"]) == (ex["cropL"], ex["cropR"], ex["pile"].n)
         assert r["ref_read"] == ex["ref_idx"] and (ex["kinds"][ex["ref_idx"]] & 3) == 0
         cons = bases[r["cons_off"]:r["cons_off"] + r["cons_len"]]
