@@ -772,7 +772,8 @@ class Comm:
         L = lib()
         L.dh_shard_free.argtypes = [ctypes.c_void_p]
         tot = int(sum(sizes))
-        whole = np.frombuffer(ctypes.string_at(ptr, tot), dtype=np.uint8) if tot else np.zeros(0, np.uint8)
+        # (ctypes.string_at takes a C int: blocks beyond 2 GB go through a typed view of the address)
+        whole = np.frombuffer((ctypes.c_uint8 * tot).from_address(ptr.value), dtype=np.uint8).copy() if tot else np.zeros(0, np.uint8)
         L.dh_shard_free(ptr)
         out, at = [], 0
         for n in sizes:
@@ -1493,7 +1494,11 @@ assert SEEDED_DTYPE.itemsize == 32 and CHAIN_LA_DTYPE.itemsize == 24 and INSERTI
 
 
 def _arr(ptr, n, dt):
-    return np.frombuffer(ctypes.string_at(ptr, n * np.dtype(dt).itemsize), dtype=dt).copy() if n else np.zeros(0, dt)
+    # (no ctypes.string_at: it takes a C int, and a result set of a whole reads DB can be beyond 2 GB)
+    if not n:
+        return np.zeros(0, dt)
+    addr = ptr if isinstance(ptr, int) else ctypes.cast(ptr, ctypes.c_void_p).value
+    return np.frombuffer((ctypes.c_uint8 * (n * np.dtype(dt).itemsize)).from_address(addr), dtype=dt).copy()
 
 
 def _take_chaindb(h):

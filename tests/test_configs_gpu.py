@@ -98,6 +98,72 @@ def test_config3_eight_emulated_ranks_equal_the_single_rank_run(gpu_ctx, cfg2_wo
               f"{t_rest * 1e3:.1f} ms (the ranks' steps run one after the other here)")
 
 
+def bench_chain(ctx, w, A, B, mo, po):
+    """bench.py's call sequence at N = 1: dh_map_reads (mapping + the six collect filters) -> scaffold-graph pile-ups with
+    extension entries -> the min / max reads cut -> dh_process_pileups."""
+    las, trace, dropped = ctx.map_reads(A, B, mo, po, sorted=False, candidates=False)[:3]
+    gaps = np.stack([np.arange(w.contigs.n - 1), np.arange(1, w.contigs.n)], axis=1).astype(np.int32)
+    gp, _ = dentist_amd.scaffold_spanning_pileups(las, w.contigs.off, w.reads.off, gaps, with_extensions=True,
+                                                  min_spanning_reads=po.min_reads)
+    piles = gp.select(las, po)
+    rec, bases = dentist_amd.process_pileups(ctx, A, B, las, trace, piles, po)
+    return las, trace, piles, rec, bases
+
+
+def check_chain(w, las, trace, piles, rec, bases, ngaps, max_err):
+    s, e = w.read_truth[las["bread"], 0], w.read_truth[las["bread"], 1]
+    cs = w.contig_start[las["aread"]]
+    ok = ((las["flags"] & 1) == w.read_truth[las["bread"], 2]) & (cs + las["abpos"] >= s - 80) & (cs + las["aepos"] <= e + 80)
+    assert ok.mean() > 0.999
+    check_trace_invariants(las[:: max(1, len(las) // 3000)], trace, 100)
+    closed = rec[rec["status"] == 0]
+    assert len(piles) == ngaps and len(closed) == ngaps, (len(piles), len(closed))
+    edits, total = consensus_edits(w.truth, w.contig_start, w.gap_end, closed, bases)
+    assert edits <= max_err * total, (edits, total)
+    return edits / total
+
+
+def test_config1_bench_chain_at_every_operating_point(gpu_ctx, capsys):
+    """BASELINE configs[1] (10 Mb / 100 gaps / 100 k x 10 kb) through bench.py's exact chain -- mapping options, collector,
+    cut, process options -- at the headline's knobs (modimers 1/8, read cap 60), at the reference's behaviour (every
+    k-mer, every read: processPileUps/package.d:283-374, commandline.d:2943-2955) and with the bounded partner set
+    (max_partners 60): every gap closed, consensus within north_star's 0.1 % (0.05 % without the cap), every mapped read
+    where the simulator put it."""
+    w = sim.Workload(10_000_000, 100, 100_000, 10_000, seed=20260929)
+    A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
+    out = []
+    for name, kmer_mod, max_reads, partners, tol in (("headline", 8, 60, 0, 0.001), ("reference behaviour", 1, 0, 0, 0.0005),
+                                                      ("every read, 60 partners", 1, 0, 60, 0.0005)):
+        mo = dentist_amd.default_align_opts(**dict(MAP, kmer_mod=kmer_mod))
+        po = dentist_amd.default_process_opts(algo=1, max_reads=max_reads, max_partners=partners)
+        A.drop_cache()
+        B.drop_cache()
+        err = check_chain(w, *bench_chain(gpu_ctx, w, A, B, mo, po), ngaps=100, max_err=tol)
+        out.append(f"{name}: {err:.5f}")
+    with capsys.disabled():
+        print("\n[configs[1], bench chain] consensus error: " + "; ".join(out))
+
+
+def test_config2_bench_chain_at_the_reference_behaviour(gpu_ctx, cfg2_workload, capsys):
+    """BASELINE configs[2] through bench.py's exact chain WITHOUT its two knobs -- no read cap, no k-mer sampling: what the
+    reference does -- and with the bounded partner set on top: 1 000 / 1 000 gaps, consensus <= 0.05 % from the truth.  (The
+    headline's knobs on the same chain: test_config3_eight_emulated_ranks_equal_the_single_rank_run, single-rank part.)"""
+    w = cfg2_workload
+    A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
+    mo = dentist_amd.default_align_opts(**dict(MAP, kmer_mod=1))
+    out = []
+    for name, partners in (("reference behaviour", 0), ("every read, 60 partners", 60)):
+        po = dentist_amd.default_process_opts(algo=1, max_reads=0, max_partners=partners)
+        t0 = time.perf_counter()
+        res = bench_chain(gpu_ctx, w, A, B, mo, po)
+        dt = time.perf_counter() - t0
+        err = check_chain(w, *res, ngaps=1000, max_err=0.0005)
+        out.append(f"{name}: {err:.5f} ({dt * 1e3:.0f} ms incl. first-use allocations)")
+        del res
+    with capsys.disabled():
+        print("\n[configs[2], bench chain] consensus error: " + "; ".join(out))
+
+
 def test_config4_one_rank_of_eight(gpu_ctx, capsys):
     t0 = time.perf_counter()
     s = sim.RankShare(3_000_000_000, 10_000, 10_000_000, 20_000, rank=0, world=8, seed=20260929)

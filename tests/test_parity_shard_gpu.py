@@ -308,3 +308,71 @@ def test_dh_shard_run_over_rccl_at_world_one(gpu_ctx):
     _same([res], rec, bases)
     assert res[2]["owned"] == res[2]["piles"] == len(rec)
     comm.close()
+
+
+def test_collectives_with_empty_ragged_and_large_payloads_hub_and_rccl(gpu_ctx):
+    """Readiness of the exchange code for the first real multi-GPU run: the two ragged collectives of the C ABI with empty
+    payloads, ranks that send or receive nothing at all, ragged sizes and a payload beyond 2 GB (64-bit sizes and
+    offsets) -- through the in-process hub at world 8 (and 2, for the large one) and, blob by blob, through the RCCL back
+    end at world 1 (ncclAllGather of the sizes and of the padded blobs, grouped ncclSend / ncclRecv): identical bytes.
+    A size-0 peer or a 2 GB offset must not be what the first SCALE run dies of."""
+    import threading
+    world = 8
+    rng = np.random.default_rng(11)
+    sizes = [0, 1, 4097, 0, 123457, 64, 1 << 20, 3]
+    payload = [rng.integers(0, 256, n, dtype=np.uint8) for n in sizes]
+    per_dest = [[rng.integers(0, 256, 0 if (src == 3 or dst == 5) else int(rng.integers(0, 3)) * int(rng.integers(1, 70000)),
+                              dtype=np.uint8) for dst in range(world)] for src in range(world)]
+    comms = dentist_amd.Comm.local(world)
+    got_g, got_a, errors = [None] * world, [None] * world, []
+
+    def run(r):
+        try:
+            for _ in range(2):   # the hub is reusable
+                got_g[r] = comms[r].all_gather(payload[r])
+                got_a[r] = comms[r].all_to_all(per_dest[r])
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+            raise
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not errors, errors
+    for r in range(world):
+        assert [len(x) for x in got_g[r]] == sizes
+        for s in range(world):
+            assert np.array_equal(got_g[r][s], payload[s]) and np.array_equal(got_a[r][s], per_dest[s][r])
+    assert all(len(x) == 0 for x in got_a[5]) and all(len(got_a[r][3]) == 0 for r in range(world))
+    for c in comms:
+        c.close()
+    # the same blobs through RCCL at world 1
+    comm = dentist_amd.Comm.create(gpu_ctx, 0, 1, dentist_amd.Comm.unique_id())
+    for r in range(world):
+        g = comm.all_gather(payload[r])
+        assert len(g) == 1 and np.array_equal(g[0], got_g[0][r])
+        a = comm.all_to_all([per_dest[r][r]])
+        assert len(a) == 1 and np.array_equal(a[0], got_a[r][r])
+    # beyond 2 GB: sizes and offsets are 64 bits wide on both back ends
+    big = np.arange((1 << 31) + 200_000_003, dtype=np.uint32).view(np.uint8)[:(1 << 31) + 200_000_003].copy()
+    g = comm.all_gather(big)
+    assert len(g) == 1 and len(g[0]) == len(big) and np.array_equal(g[0][-1000:], big[-1000:]) and np.array_equal(g[0][::4099], big[::4099])
+    a = comm.all_to_all([big])
+    assert len(a[0]) == len(big) and np.array_equal(a[0][::4099], big[::4099])
+    del g, a
+    comm.close()
+    two = dentist_amd.Comm.local(2)
+    out = [None, None]
+
+    def run2(r):
+        out[r] = two[r].all_gather(big if r == 0 else payload[2])
+    ts = [threading.Thread(target=run2, args=(r,)) for r in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=600)
+    for r in range(2):
+        assert len(out[r][0]) == len(big) and np.array_equal(out[r][0][::4099], big[::4099]) and np.array_equal(out[r][1], payload[2])
+    for c in two:
+        c.close()
