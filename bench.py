@@ -198,6 +198,7 @@ def main():
         las, trace, dropped = mapped[:3]
         cands = mapped[3] if len(mapped) > 3 else None
         ast = ctx.align_stats()
+        mj = ctx.mjoin_counts(reset=True)   # (chunks seeded by the partitioned join, chunks redone by the directory)
         t1 = time.perf_counter()
         if world == 1:
             if args.collect == "graph":
@@ -222,7 +223,7 @@ def main():
         pst = dentist_amd.process_stats(ctx)
         cum = ctx.cum_stats().as_dict()  # every k_wave / k_seed launch of the step
         info["filtered"] = dropped.tolist()
-        return dict(las=las, rec=rec, bases=bases, ast=ast, pst=pst, cum=cum, info=info,
+        return dict(las=las, rec=rec, bases=bases, ast=ast, pst=pst, cum=cum, info=info, mj=mj,
                     t_map=t1 - t0, t_collect=t2 - t1, t_process=t3 - t2)
 
     def barrier():
@@ -303,9 +304,14 @@ def main():
         # (2 B per aligned A base at one byte per base) + its trace (2 B per trace value)
         achieved = alg_bytes / (wave_ms * 1e-3) / 1e9
         seed_traffic, traffic, traffic_src = kernel_traffic(args, world)
-        seed_bytes = 1.0 * read_bp * (1.0 + 64.0 / max(1, args.kmer_mod))
-        # what a lookup needs of its line: the 16-byte directory word (dh_kernels.hip, seed_item: ix.fat[...])
+        # Mapping seeds.  Directory path (k_seed<cap, false>): per read base 1 B of sequence, per sampled canonical k-mer one
+        # random 64-byte directory line of which 16 bytes are the directory word.  Partitioned join (round 5, csrc/dh_mjoin.h:
+        # k_mj_part -> k_mj_filter -> k_mj_hits -> k_seed<cap, JOIN>): per read base 1 B read, per sampled k-mer an 8-byte
+        # entry written once and read once -- the same 1 + 16 / kmer_mod bytes per base; that figure prices both paths.
+        joined = last["mj"][0] > 0
+        seed_line = 1.0 * read_bp * (1.0 + 64.0 / max(1, args.kmer_mod))
         seed_useful = 1.0 * read_bp * (1.0 + 16.0 / max(1, args.kmer_mod))
+        seed_bytes = seed_useful if joined else seed_line
         seed_ms = mean(lambda r: r["ast"].ms_seed)
         out = {
             "metric": "gap-bases closed/sec",
@@ -344,7 +350,10 @@ def main():
             # 64-byte lines: per read base 1 B of sequence, per sampled canonical k-mer one 64 B
             # directory line, one pass for both strands; the ceiling of random 64 B lines measured on this part is
             # 55 G lines/s = 3.5 TB/s at working sets of 128 MB - 2 GB, 3.2 at 4 GB, 3.06 at 16 GB (scripts/rand_access_probe.cpp)
-            "roofline": {"bound": "hbm", "kernel": "k_seed (mapping launches)",
+            "roofline": {"bound": "hbm",
+                         "kernel": "mapping seeds per chunk of reads: k_mj_part + k_mj_filter + k_mj_hits + k_seed<cap, JOIN> (partitioned k-mer join)"
+                                   if joined else "k_seed (mapping launches, directory lookups)",
+                         "mapping_chunks_by_join_and_by_directory": list(last["mj"]),
                          "achieved": seed_bytes / (seed_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": seed_bytes / (seed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": seed_traffic,
                          "launches_per_step": int(last["ast"].wave_launches), "kernel_ms_per_step": seed_ms,
@@ -352,6 +361,10 @@ def main():
                          "algorithmic_bytes_per_step": seed_bytes, "traffic_source": traffic_src,
                          "useful_bytes_per_step": seed_useful,
                          "useful_frac": seed_useful / (seed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "line_priced_bytes_per_step": seed_line,
+                         "line_priced_frac": seed_line / (seed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "note": "a `launch` is one chunk's seed kernels together (HIP events around them on the context's stream); "
+                                 "line_priced_* keeps round 4's figure (64 B per looked-up k-mer) for comparison",
                          "measured_random_line_ceiling_GBs": CONST["random_line_ceiling_GBs"]},
             # second: the extension kernel, one alignment per lane.  VALU bound (scripts/valu_probe.cpp: 2-cycle class
             # 0.90-0.94, 4-cycle class 0.56-0.58 G wave-instructions/s per SIMD); the HBM fraction is reported as asked

@@ -336,11 +336,17 @@ extern "C" void dh_default_align_opts(dh_align_opts *o)
 
 // ------------------------------------------------------------------------------------ DB
 
-int dh_alloc_bases(hipStream_t st, int64_t total, uint8_t **alloc, uint8_t **base)
+// pads_only: the caller writes every base itself (dh_db_create: one copy of the whole array) -- only the DB_PAD bytes
+// on both sides get the code 4.  Filling all of a reads DB first wrote 15.7 GB for configs[2] that the copy then overwrote.
+int dh_alloc_bases(hipStream_t st, int64_t total, uint8_t **alloc, uint8_t **base, bool pads_only)
 {
     const size_t nb = (size_t)std::max<int64_t>(total, 0) + 2 * DB_PAD;
     HIPCHK(dh_dev_alloc(alloc, nb));
-    HIPCHK(dhk_memset(st, *alloc, 4, nb));
+    if (pads_only) {
+        HIPCHK(hipMemsetAsync(*alloc, 4, DB_PAD, st));
+        HIPCHK(hipMemsetAsync(*alloc + nb - DB_PAD, 4, DB_PAD, st));
+    } else
+        HIPCHK(dhk_memset(st, *alloc, 4, nb));
     *base = *alloc + DB_PAD;
     return DH_OK;
 }
@@ -384,7 +390,7 @@ extern "C" int dh_db_create(dh_ctx *ctx, const uint8_t *bases, const int64_t *of
             db->ngroups = std::max(db->ngroups, g + 1);
         }
     }
-    if (int rc = dh_alloc_bases(ctx->stream, db->total, &db->d_bases_alloc, &db->d_bases)) return rc;
+    if (int rc = dh_alloc_bases(ctx->stream, db->total, &db->d_bases_alloc, &db->d_bases, true)) return rc;
     HIPCHK(dh_dev_alloc(&db->d_off, sizeof(int64_t) * (size_t)(n + 1)));
     if (db->total > 0)
         HIPCHK(hipMemcpyAsync(db->d_bases, bases, (size_t)db->total, hipMemcpyHostToDevice, ctx->stream));
@@ -1640,58 +1646,15 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             w_g[i] += t - w_c;
             w_c = t;
         };
-        ChunkCopies cc;
-        uint8_t *d_bpk2 = nullptr, *d_brcpk2 = nullptr;
-        if (db_copies) {
-            cc.rc = B->d_rc;
-            cc.pk = B->d_pk;
-            cc.rcpk = B->d_rcpk;
-            cc.has_n = B->has_n != 0;
-        } else if (int rc = chunk_copies(ctx, B, (int32_t)(item0 >> 1), (int32_t)((item0 + ni) >> 1), want_packed, A->has_n != 0, &cc,
-                                         tiled && want_packed && !res2 && !getenv("DH_PLANES_BY_PASS")))
-            return rc;
-        const bool packed = want_packed && A->has_n == 0 && !cc.has_n && cc.pk && cc.rcpk;
-        if (tiled) {
-            if (!packed) return fail(DH_EINVAL, "algo 1 (DH-2) needs sequences of a, c, g, t only (2-bit copies), B holds other codes");
-            if (res2) {
-                // the transposed pairs read this chunk of B as their A'': keep its 2-bit copies
-                const size_t pbytes = (size_t)cc.pk_words * 8 + 2 * PK_PAD;
-                SCR(41, d_bpk2, pbytes)
-                SCR(42, d_brcpk2, pbytes)
-                HIPCHK(hipMemcpyAsync(d_bpk2, cc.pk_w0 - PK_PAD, pbytes, hipMemcpyDeviceToDevice, st));
-                HIPCHK(hipMemcpyAsync(d_brcpk2, cc.rcpk_w0 - PK_PAD, pbytes, hipMemcpyDeviceToDevice, st));
-            }
-            if (!cc.planes) {
-                dhk_pk2planes(st, cc.pk_w0, cc.pk_words);
-                dhk_pk2planes(st, cc.rcpk_w0, cc.pk_words);
-            }
-            HIPCHK(hipGetLastError());
-        }
-        if (deferred) {
-            HIPCHK(hipEventRecord(ctx->ev[6], st));
-            HIPCHK(hipStreamWaitEvent(ctx->cstream, ctx->ev[6], 0));
-            const int rc = deferred();
-            deferred = nullptr;
-            if (rc) return rc;
-        }
-        // per-chunk arrays are indexed by absolute item inside the kernels: shift the bases
-        DhCand *candbase = d_cand - item0 * o.max_cand;
-        DhLa *labase = d_la ? d_la - item0 * o.max_la : nullptr;
-        uint16_t *trbase = d_trslots ? d_trslots - item0 * (int64_t)o.max_la * trmax : nullptr;
-        int32_t *ncandbase = d_ncand - item0, *nhitsbase = d_nhits - item0;
-        int32_t *nlabase = (int32_t *)d_nla - item0, *ntrbase = (int32_t *)d_ntr - item0;
-        lap(0);
-        HIPCHK(hipEventRecord(ctx->ev[2], st));
-        HIPCHK(hipMemsetAsync(d_queue, 0, 4 * sizeof(uint32_t), st));
-        uint64_t *d_fscr = nullptr;
-        if (cap > 4096 && cap <= 8192)
-            SCR(30, d_fscr, (size_t)ctx->ncu * DH_SEED_FSCR_BLOCKS_PER_CU * DH_SEED_FSCR_WORDS)
-        bool mj_chunk = false;
+        // the partitioned join of this chunk is planned here, ahead of the chunk's derived copies and of the previous chunk's
+        // device-to-host copy: its first kernel (k_mj_tile_reads, a binary search per tile) then runs before the copy kernels
+        // take the device (beside them it took 4 ms instead of 10 us)
+        MjView mv = {};
+        bool mj_planned = false;
         {
             const int32_t cr0 = (int32_t)(item0 >> 1), cr1 = (int32_t)((item0 + ni) >> 1);
             const int64_t cb0 = B->h_off[(size_t)cr0], cb1 = B->h_off[(size_t)cr1];
-            if (use_mj && !mj_skip_chunk && !cc.has_n && cb1 - cb0 >= mj_min_bases && cb1 - cb0 < (1ll << 40)) {
-                MjView mv = {};
+            if (use_mj && !mj_skip_chunk && cb1 - cb0 >= mj_min_bases && cb1 - cb0 < (1ll << 40)) {
                 mv.c0 = cb0;
                 mv.c1 = cb1;
                 mv.r0 = cr0;
@@ -1743,18 +1706,71 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
                     mv.bitmap = A->ix.d_bitmap;
                     mv.status = d_status;
                     if (const char *e = getenv("DH_MJ_DBG")) mv.dbg = atoi(e);
-                    HIPCHK(dhk_memset(st, mv.segtab, 0, sizeof(unsigned long long) * (size_t)(cr1 - cr0) * mv.nseg));
-                    dhk_mj_run(st, bv, iv, dopt, mv, ctx->ncu);
+                    dhk_mj_tile_reads(st, bv, mv);
                     HIPCHK(hipGetLastError());
-                    jv_mj = JoinView{};
-                    jv_mj.segtab = (uint64_t *)mv.segtab;
-                    jv_mj.hits = mv.rhits;
-                    jv_mj.status = d_status;
-                    jv_mj.ns_fixed = mv.nseg;
-                    jv_mj.read0 = cr0;
-                    mj_chunk = true;
+                    mj_planned = true;
                 }
             }
+        }
+        ChunkCopies cc;
+        uint8_t *d_bpk2 = nullptr, *d_brcpk2 = nullptr;
+        if (db_copies) {
+            cc.rc = B->d_rc;
+            cc.pk = B->d_pk;
+            cc.rcpk = B->d_rcpk;
+            cc.has_n = B->has_n != 0;
+        } else if (int rc = chunk_copies(ctx, B, (int32_t)(item0 >> 1), (int32_t)((item0 + ni) >> 1), want_packed, A->has_n != 0, &cc,
+                                         tiled && want_packed && !res2 && !getenv("DH_PLANES_BY_PASS")))
+            return rc;
+        const bool packed = want_packed && A->has_n == 0 && !cc.has_n && cc.pk && cc.rcpk;
+        if (tiled) {
+            if (!packed) return fail(DH_EINVAL, "algo 1 (DH-2) needs sequences of a, c, g, t only (2-bit copies), B holds other codes");
+            if (res2) {
+                // the transposed pairs read this chunk of B as their A'': keep its 2-bit copies
+                const size_t pbytes = (size_t)cc.pk_words * 8 + 2 * PK_PAD;
+                SCR(41, d_bpk2, pbytes)
+                SCR(42, d_brcpk2, pbytes)
+                HIPCHK(hipMemcpyAsync(d_bpk2, cc.pk_w0 - PK_PAD, pbytes, hipMemcpyDeviceToDevice, st));
+                HIPCHK(hipMemcpyAsync(d_brcpk2, cc.rcpk_w0 - PK_PAD, pbytes, hipMemcpyDeviceToDevice, st));
+            }
+            if (!cc.planes) {
+                dhk_pk2planes(st, cc.pk_w0, cc.pk_words);
+                dhk_pk2planes(st, cc.rcpk_w0, cc.pk_words);
+            }
+            HIPCHK(hipGetLastError());
+        }
+        if (deferred) {
+            HIPCHK(hipEventRecord(ctx->ev[6], st));
+            HIPCHK(hipStreamWaitEvent(ctx->cstream, ctx->ev[6], 0));
+            const int rc = deferred();
+            deferred = nullptr;
+            if (rc) return rc;
+        }
+        // per-chunk arrays are indexed by absolute item inside the kernels: shift the bases
+        DhCand *candbase = d_cand - item0 * o.max_cand;
+        DhLa *labase = d_la ? d_la - item0 * o.max_la : nullptr;
+        uint16_t *trbase = d_trslots ? d_trslots - item0 * (int64_t)o.max_la * trmax : nullptr;
+        int32_t *ncandbase = d_ncand - item0, *nhitsbase = d_nhits - item0;
+        int32_t *nlabase = (int32_t *)d_nla - item0, *ntrbase = (int32_t *)d_ntr - item0;
+        lap(0);
+        HIPCHK(hipEventRecord(ctx->ev[2], st));
+        HIPCHK(hipMemsetAsync(d_queue, 0, 4 * sizeof(uint32_t), st));
+        uint64_t *d_fscr = nullptr;
+        if (cap > 4096 && cap <= 8192)
+            SCR(30, d_fscr, (size_t)ctx->ncu * DH_SEED_FSCR_BLOCKS_PER_CU * DH_SEED_FSCR_WORDS)
+        bool mj_chunk = false;
+        if (mj_planned && !cc.has_n) {
+            const int32_t cr0 = mv.r0, cr1 = mv.r1;
+            HIPCHK(dhk_memset(st, mv.segtab, 0, sizeof(unsigned long long) * (size_t)(cr1 - cr0) * mv.nseg));
+            dhk_mj_run(st, bv, iv, dopt, mv, ctx->ncu);
+            HIPCHK(hipGetLastError());
+            jv_mj = JoinView{};
+            jv_mj.segtab = (uint64_t *)mv.segtab;
+            jv_mj.hits = mv.rhits;
+            jv_mj.status = d_status;
+            jv_mj.ns_fixed = mv.nseg;
+            jv_mj.read0 = cr0;
+            mj_chunk = true;
         }
         const bool jn = use_join || mj_chunk;            // the back end gathers its hits from segments
         const JoinView &jvx = mj_chunk ? jv_mj : jv;

@@ -41,7 +41,7 @@ int dh_scaffold_from_join_blobs(const uint8_t *const *blobs, const int64_t *size
                                 const int32_t *input_gaps, int32_t ngaps, const struct dh_scaffold_opts *opts,
                                 std::vector<dh_la> &glas, dh_scaffold **out);
 // allocate total + 2 * DB_PAD bytes filled with code 4; *base = alloc + DB_PAD
-int dh_alloc_bases(hipStream_t st, int64_t total, uint8_t **alloc, uint8_t **base);
+int dh_alloc_bases(hipStream_t st, int64_t total, uint8_t **alloc, uint8_t **base, bool pads_only = false);
 
 #define HIPCHK(expr)                                                                             \
     do {                                                                                         \

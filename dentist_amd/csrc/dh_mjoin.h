@@ -91,7 +91,9 @@ extern "C" {
 #endif
 /* presence bitmap of the index entries: bit (key >> (2k - nbbits)); bm must hold 2^(nbbits - 5) zeroed words */
 void dhk_mj_bitmap(hipStream_t st, const ulonglong2 *ent, int64_t n, int32_t k, int32_t nbbits, uint32_t *bm);
-/* partition, transpose, probe, regroup of one chunk (ctr zeroed by the callee) */
+/* first read behind the first base of every tile (m.tile_r): launched ahead of the chunk's other kernels */
+void dhk_mj_tile_reads(hipStream_t st, DbView B, MjView m);
+/* partition, transpose, filter, hits of one chunk (ctr zeroed by the callee; m.tile_r filled by dhk_mj_tile_reads) */
 void dhk_mj_run(hipStream_t st, DbView B, IndexView ix, DhOpts o, MjView m, int32_t ncu);
 #ifdef __cplusplus
 }

@@ -717,10 +717,14 @@ void dhk_mj_bitmap(hipStream_t st, const ulonglong2 *ent, int64_t n, int32_t k, 
     hipLaunchKernelGGL(k_mj_bitmap, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ent, n, k, nbbits, bm);
 }
 
+void dhk_mj_tile_reads(hipStream_t st, DbView B, MjView m)
+{
+    hipLaunchKernelGGL(k_mj_tile_reads, dim3((unsigned)((m.ntiles + 255) / 256)), dim3(256), 0, st, B, m);
+}
+
 void dhk_mj_run(hipStream_t st, DbView B, IndexView ix, DhOpts o, MjView m, int32_t ncu)
 {
     (void)hipMemsetAsync(m.ctr, 0, 16 * sizeof(uint32_t), st);
-    hipLaunchKernelGGL(k_mj_tile_reads, dim3((unsigned)((m.ntiles + 255) / 256)), dim3(256), 0, st, B, m);
     hipLaunchKernelGGL(k_mj_part, dim3((unsigned)std::min<int64_t>(m.ntiles, (int64_t)ncu * 2 * 4)), dim3(MJ_THREADS), 0, st, B, m);
     hipLaunchKernelGGL(k_mj_transpose, dim3((unsigned)(m.ntiles_pad / 32)), dim3(256), 0, st, m);
     hipLaunchKernelGGL(k_mj_filter, dim3((unsigned)ncu), dim3(MJ_PROBE_THREADS), 0, st, ix, o, m);

@@ -1,7 +1,8 @@
 """dev: 8 emulated ranks of the sharded collect + process on configs[2] on ONE GPU; prints the host time
 every rank spends between the collectives (the Python / host glue that does not shrink with N)."""
 import sys, time
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import numpy as np, dentist_amd
 from dentist_amd import sim
 from dentist_amd.parallel import shard_range, sharded_process_steps

@@ -53,8 +53,12 @@ def per_kernel(d):
     res = {}
     for i in order:
         name, kb = per[i]
-        fam = "k_seed" if "k_seed<" in name and "k_seed<0>" not in name else ("k_tile" if name.strip() == "k_tile" or "k_tile<" in name else
-                                                                               ("k_seed_redo" if "k_seed<0>" in name else None))
+        # the seeds of a mapping chunk: the directory lookups (k_seed<cap, false>) or, since round 5, the partitioned join
+        # (k_mj_*) with the segment-fed back end (k_seed<cap, true>) -- one family, counted per chunk
+        fam = ("k_seed" if ("k_seed<" in name and "k_seed<0" not in name) or name.strip().startswith("k_mj_") else
+               ("k_tile" if name.strip() == "k_tile" or "k_tile<" in name else ("k_seed_redo" if "k_seed<0" in name else None)))
+        if name.strip() == "k_mj_part":
+            res.setdefault(("chunks", "mapping"), [0, 0.0])[0] += 1
         if fam is None:
             continue
         stage = "mapping" if first_crop is None or i < first_crop else "process"
@@ -76,6 +80,8 @@ def main(fetch_dir, write_dir, out, workload, kmer_mod, k, algo):
         j["launches"]["%s/%s" % key] = {"launches": n, "fetch_bytes": fb, "write_bytes": wb}
     def per_launch(fam):
         n = sum(v["launches"] for k_, v in j["launches"].items() if k_.startswith(fam + "/mapping"))
+        if fam == "k_seed" and "chunks/mapping" in j["launches"]:
+            n = j["launches"]["chunks/mapping"]["launches"]   # the join's kernels of one chunk count as one launch
         b = sum(v["fetch_bytes"] + v["write_bytes"] for k_, v in j["launches"].items()
                 if k_.startswith(fam + "/mapping") or k_.startswith(fam + "_redo/mapping"))
         return b / n if n else None
