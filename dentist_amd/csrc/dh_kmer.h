@@ -16,7 +16,7 @@
 //    odd, inv = inverse of mod' modulo 2^32 (test for zero remainder, Hacker's Delight 10-17).
 struct KmerSampler {
     uint32_t inv, thresh, rot;
-    bool all, small_k;
+    bool all, small_k, pow2;  // pow2: mod is a power of two -- h % mod == 0 is a mask test, one quarter-rate multiply less
 };
 __device__ __forceinline__ KmerSampler kmer_sampler(int32_t mod, int32_t k)
 {
@@ -32,6 +32,7 @@ __device__ __forceinline__ KmerSampler kmer_sampler(int32_t mod, int32_t k)
     for (int it = 0; it < 5; it++) x *= 2u - d * x;
     s.inv = x;
     s.rot = e;
+    s.pow2 = d == 1u;
     s.thresh = s.all ? 0xFFFFFFFFu : 0xFFFFFFFFu / (uint32_t)mod;
     return s;
 }
@@ -40,6 +41,7 @@ __device__ __forceinline__ bool kmer_sampled(uint64_t km, const KmerSampler &s)
     const uint32_t lo = (uint32_t)km, hi = (uint32_t)(km >> 32);
     uint32_t h = __umulhi(lo, 0x7F4A7C15u) + lo * 0x9E3779B9u;
     if (!s.small_k) h += hi * 0x7F4A7C15u;
+    if (s.pow2) return (h & ((1u << s.rot) - 1u)) == 0u;  // (uniform branch; mod 1: rot == 0, everything is sampled)
     const uint32_t t = h * s.inv;
     const uint32_t r = __builtin_rotateright32(t, s.rot);  // (rot == 0: t itself)
     return s.all | (r <= s.thresh);

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -11,6 +12,25 @@
 #include "dh_mjoin.h"
 
 #define LANES 64
+
+#ifdef DH_MJ_PROF
+__device__ unsigned long long g_mj_prof[16];
+#define MP(i) if (tid == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_mj_prof[i], t_ - tp_); tp_ = t_; }
+#define MP_BEGIN unsigned long long tp_ = wall_clock64();
+extern "C" void dhk_mj_prof_dump()
+{
+    unsigned long long h[16];
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mj_prof), sizeof(h));
+    if (h[15])
+        fprintf(stderr, "[mj prof] k_mj_part, %llu tiles: setup %.1f roll %.1f entries %.1f scan %.1f scatter %.1f write %.1f us per tile and block\n", h[15],
+                h[0] / 100.0 / h[15], h[1] / 100.0 / h[15], h[2] / 100.0 / h[15], h[3] / 100.0 / h[15], h[4] / 100.0 / h[15], h[5] / 100.0 / h[15]);
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mj_prof), z, sizeof(z));
+}
+#else
+#define MP(i)
+#define MP_BEGIN
+#endif
 
 namespace {
 
@@ -74,7 +94,12 @@ constexpr int MJ_REMSH = MJ_POSBITS + 2, MJ_PSH = 53;
 // ------------------------------------------------------------------------------------ presence bitmap of the index
 // two bits per key inside the slice of its partition: the bucket of a directory of 2^nbbits buckets, and a hash of the key's
 // remainder (a one-probe filter of 11 bits per key lets 9 % of the absent k-mers through, the pair 3 %)
-__device__ __forceinline__ uint32_t mj_bit2(uint64_t rem, int sbits) { return (uint32_t)((rem * 0x9E3779B97F4A7C15ull) >> (64 - sbits)); }
+// (one 32-bit multiply: the 64-bit product this began with was six quarter-rate multiplies in front of every second probe)
+__device__ __forceinline__ uint32_t mj_bit2(uint64_t rem, int sbits)
+{
+    const uint32_t x = (uint32_t)rem ^ (uint32_t)(rem >> 19) ^ ((uint32_t)(rem >> 32) << 13);
+    return (x * 0x9E3779B1u) >> (32 - sbits);
+}
 __global__ void __launch_bounds__(256) k_mj_bitmap(const ulonglong2 *__restrict__ ent, int64_t n, int32_t k, int32_t nbbits, uint32_t *__restrict__ bm)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -123,6 +148,7 @@ k_mj_part(DbView B, MjView m)
     const KmerSampler smp = kmer_sampler(m.kmer_mod, k);
     const int32_t per = m.tb / MJ_THREADS;
     for (int32_t t = blockIdx.x; t < m.ntiles; t += gridDim.x) {
+        MP_BEGIN
         const int64_t tb0 = m.c0 + (int64_t)t * m.tb;
         const int32_t tlen = (int32_t)std::min<int64_t>(m.tb, m.c1 - tb0);  // k-mer starts of this tile: [0, tlen)
         for (int i = tid; i < MJ_P; i += MJ_THREADS) cnt[i] = 0;
@@ -144,6 +170,7 @@ k_mj_part(DbView B, MjView m)
             if (tid == 0) atomicOr(m.status, DH_ST_MJ_OVERFLOW);
             nrs = MJ_RS;
         }
+        MP(0)
         const uint8_t *b = B.bases + tb0;
         const int32_t xr0 = tid * per;
         // ---- the rolling pair after the first k - 1 bases of the lane's stretch, from three packed words
@@ -212,6 +239,7 @@ k_mj_part(DbView B, MjView m)
             if (lane == 0) atomicOr(m.status, DH_ST_MJ_OVERFLOW);
             wcount = WCAP;
         }
+        MP(1)
         // ---- entries from the parked k-mers (every lane busy), counted per partition
         uint64_t e16[WCAP / LANES];
 #pragma unroll
@@ -231,6 +259,7 @@ k_mj_part(DbView B, MjView m)
         }
         // ---- counting sort by partition: offsets (two counters per thread), then the entries from the registers
         __syncthreads();
+        MP(2)
         const uint32_t c0 = cnt[2 * tid], c1 = cnt[2 * tid + 1];
         uint32_t n;
         const uint32_t ex = mj_block_scan<MJ_THREADS>(c0 + c1, tid, s_w, &n);
@@ -238,16 +267,22 @@ k_mj_part(DbView B, MjView m)
         cnt[2 * tid] = ex;
         cnt[2 * tid + 1] = ex + c0;
         __syncthreads();
+        MP(3)
 #pragma unroll
         for (int i = 0; i < WCAP / LANES; i++) {
             const uint32_t idx = lane + i * LANES;
             if (idx < wcount) buf[atomicAdd(&cnt[(e16[i] >> MJ_PSH) & (MJ_P - 1)], 1u)] = e16[i];
         }
         __syncthreads();
+        MP(4)
         uint4 *dst = (uint4 *)(m.ent + (int64_t)t * MJ_CAP);
         for (uint32_t i = tid; i < (n + 1) / 2; i += MJ_THREADS) dst[i] = ((const uint4 *)buf)[i];
         if (tid == 0) m.tile_n[t] = n;
         __syncthreads();
+        MP(5)
+#ifdef DH_MJ_PROF
+        if (tid == 0) atomicAdd(&g_mj_prof[15], 1ull);
+#endif
     }
 }
 
@@ -729,5 +764,11 @@ void dhk_mj_run(hipStream_t st, DbView B, IndexView ix, DhOpts o, MjView m, int3
     hipLaunchKernelGGL(k_mj_transpose, dim3((unsigned)(m.ntiles_pad / 32)), dim3(256), 0, st, m);
     hipLaunchKernelGGL(k_mj_filter, dim3((unsigned)ncu), dim3(MJ_PROBE_THREADS), 0, st, ix, o, m);
     hipLaunchKernelGGL(k_mj_hits, dim3((unsigned)m.ngroups), dim3(MJ_THREADS), 0, st, B, ix, o, m);
+#ifdef DH_MJ_PROF
+    if (getenv("DH_TRACE")) {
+        (void)hipStreamSynchronize(st);
+        dhk_mj_prof_dump();
+    }
+#endif
 }
 }
