@@ -67,7 +67,7 @@ SYMBOLS = [
     "dh_last_error", "dh_abi_version", "dh_ctx_create", "dh_ctx_destroy", "dh_ctx_sync",
     "dh_default_align_opts", "dh_db_create", "dh_db_destroy", "dh_db_drop_cache", "dh_db_nreads",
     "dh_db_total_bases", "dh_la_set_destroy", "dh_la_set_count", "dh_la_set_trace_len",
-    "dh_la_set_records", "dh_la_set_trace", "dh_la_set_tspace", "dh_get_align_stats", "dh_get_cum_stats", "dh_get_mjoin_counts",
+    "dh_la_set_records", "dh_la_set_trace", "dh_la_set_tspace", "dh_get_align_stats", "dh_get_cum_stats", "dh_get_mjoin_counts", "dh_ctx_release_scratch",
     "dh_align_db",
     "dh_las_write", "dh_las_read", "dh_default_process_opts", "dh_collect_spanning", "dh_pileups_destroy",
     "dh_pileups_count", "dh_pileups_get", "dh_process_pileups", "dh_insertions_destroy",
@@ -295,6 +295,11 @@ class Context:
         st = AlignStats()
         _check(lib().dh_get_align_stats(self._h, ctypes.byref(st)))
         return st
+
+    def release_scratch(self):
+        """dh_ctx_release_scratch: hand the context's grow-only device scratch back (the next call allocates again)."""
+        lib().dh_ctx_release_scratch.argtypes = [ctypes.c_void_p]
+        _check(lib().dh_ctx_release_scratch(self._h))
 
     def mjoin_counts(self, reset=False):
         """(chunks seeded by the partitioned k-mer join, chunks redone by the directory lookups) of this context's mapping calls."""

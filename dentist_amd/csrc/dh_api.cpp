@@ -75,8 +75,10 @@ hipError_t dh_dev_alloc(void **p, size_t bytes)
     }
     hipError_t e = hipMalloc(p, cls);
     if (e != hipSuccess) {  // out of memory: drop the cache and retry once
+        (void)hipGetLastError();  // (the failure is sticky: a later hipGetLastError() after a launch would report it)
         dh_dev_trim();
         e = hipMalloc(p, cls);
+        if (e != hipSuccess) (void)hipGetLastError();
     }
     if (e == hipSuccess) {
         std::lock_guard<std::mutex> lk(g_alloc_mu);
@@ -261,10 +263,36 @@ int dh_scratch(dh_ctx *ctx, int id, size_t bytes, void **out)
             a.cap = 0;
         }
         const size_t want = bytes + bytes / 8 + 256;
-        HIPCHK(dh_dev_alloc(&a.p, want));
+        hipError_t e = dh_dev_alloc(&a.p, want);
+        if (e != hipSuccess) {
+            // (the other slots cannot be released from here: the caller holds pointers into the ones it asked for earlier
+            // in the same call.  Between calls the host can: dh_ctx_release_scratch)
+            a.p = nullptr;
+            a.cap = 0;
+            return fail(DH_EHIP, std::string("device scratch of ") + std::to_string(want >> 20) + " MB: " +
+                                     hipGetErrorString(e) + " (dh_ctx_release_scratch frees what earlier calls keep)");
+        }
         a.cap = want;
     }
     *out = a.p;
+    return DH_OK;
+}
+
+extern "C" int dh_ctx_release_scratch(dh_ctx *c)
+{
+    if (!c) return fail(DH_EINVAL, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->cstream) HIPCHK(hipStreamSynchronize(c->cstream));
+    for (dh_ctx *s2 : c->sub)
+        if (s2) (void)dh_ctx_release_scratch(s2);
+    for (auto &a : c->arena)
+        if (a.p) {
+            dh_dev_free(a.p);
+            a.p = nullptr;
+            a.cap = 0;
+        }
+    dh_dev_trim();
     return DH_OK;
 }
 
@@ -1190,7 +1218,12 @@ static int chunk_copies(dh_ctx *ctx, dh_db *B, int32_t r0, int32_t r1, bool want
     HIPCHK(hipMemsetAsync(d_rcpk + pbytes - PK_PAD - 8, 0, PK_PAD + 8, st));
     if (planes) {
         dhk_pack2_planes(st, B->d_bases + a0, o1 - a0, d_pk + PK_PAD, d_flag + 1);
-        dhk_pack2_rc_planes(st, B->d_bases, B->d_off + r0, r1 - r0, B->max_len, a0, d_rcpk + PK_PAD);
+        // (the reverse-complement planes from the forward planes: the chunk's bytes are read once, not twice --
+        // DH_RC_FROM_BYTES=1 keeps the pass over the bytes, tests compare)
+        if (getenv("DH_RC_FROM_BYTES"))
+            dhk_pack2_rc_planes(st, B->d_bases, B->d_off + r0, r1 - r0, B->max_len, a0, d_rcpk + PK_PAD);
+        else
+            dhk_planes_rc(st, d_pk + PK_PAD, B->d_off + r0, r1 - r0, B->max_len, a0, d_rcpk + PK_PAD);
     } else {
         dhk_pack2_rc_bounds(st, B->d_off + r0, r1 - r0, a0, d_rcpk + PK_PAD);
         dhk_pack2(st, B->d_bases + a0, o1 - a0, d_pk + PK_PAD, d_flag + 1);

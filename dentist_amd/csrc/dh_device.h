@@ -124,6 +124,8 @@ void dhk_pack2(hipStream_t st, const uint8_t *src, int64_t total, uint8_t *dst, 
 void dhk_pack2_planes(hipStream_t st, const uint8_t *src, int64_t total, uint8_t *dst, int32_t *flag);
 void dhk_pack2_rc_planes(hipStream_t st, const uint8_t *src, const int64_t *off, int32_t n, int32_t max_len, int64_t a0,
                          uint8_t *dst);  // zeroes the shared words itself
+void dhk_planes_rc(hipStream_t st, const uint8_t *fwd_planes, const int64_t *off, int32_t n, int32_t max_len, int64_t a0,
+                   uint8_t *dst);  // plane-packed reverse complements from the plane-packed forward copy; zeroes the shared words itself
 void dhk_or_words(hipStream_t st, uint32_t *dst, const uint32_t *a, const uint32_t *b, int64_t n);
 void dhk_dust(hipStream_t st, const uint8_t *bases, const int64_t *off, const int2 *tiles, int32_t ntiles,
               int32_t chunk, uint32_t *bits);

@@ -177,6 +177,42 @@ k_pack2_rc_planes(const uint8_t *__restrict__ src, const int64_t *__restrict__ o
         }
     }
 }
+// the plane-packed reverse complements from the plane-packed FORWARD copy (made just before by k_pack2<true>) instead of
+// from the bytes again: 8 bytes read per 32 bases instead of 32 -- base g of the reverse complement of sequence s is the
+// complement of forward base sbase - g, so the 32 bases of a destination word are a run of 32 forward bases in reverse
+// order: two funnel shifts over two forward words per plane, a bit reversal, a complement.  Words shared with a
+// neighbouring sequence are ORed in, as in k_pack2_rc_planes.  fwd / dst: word 0 = base a0 (a multiple of 32), readable /
+// zeroed PK_PAD bytes beyond both ends.
+__global__ void __launch_bounds__(256)
+k_planes_rc(const unsigned long long *__restrict__ fwd, const int64_t *__restrict__ off, int32_t n, int64_t a0,
+            unsigned long long *__restrict__ dst)
+{
+    const int32_t s = blockIdx.y;
+    if (s >= n) return;
+    const int64_t o = off[s], len = off[s + 1] - o;
+    if (len <= 0) return;
+    const int64_t w0 = (o - a0) >> 5, w1 = (o + len - 1 - a0) >> 5;  // first / last destination word
+    const int64_t sbase = 2 * o + len - 1;                           // source of base g is forward base sbase - g
+    for (int64_t w = w0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w <= w1; w += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t gw = a0 + (w << 5);
+        const int64_t p = sbase - gw - 31 - a0;  // first forward base of the run, relative to word 0 (may lie in the padding)
+        const int64_t ws = p >> 5;               // (arithmetic shift: floor)
+        const uint32_t sh = (uint32_t)(p & 31);
+        const unsigned long long f0 = fwd[ws], f1 = fwd[ws + 1];
+        const uint32_t lo = __builtin_amdgcn_alignbit((uint32_t)f1, (uint32_t)f0, sh);
+        const uint32_t hi = __builtin_amdgcn_alignbit((uint32_t)(f1 >> 32), (uint32_t)(f0 >> 32), sh);
+        // (run position i = forward base p + i = destination base 31 - i; complement = both planes inverted)
+        unsigned long long out = (unsigned long long)(~__brev(lo)) | ((unsigned long long)(~__brev(hi)) << 32);
+        if (gw >= o && gw + 32 <= o + len)
+            dst[w] = out;
+        else {
+            const int64_t g0 = gw > o ? gw : o, g1 = gw + 32 < o + len ? gw + 32 : o + len;
+            const uint32_t m = (uint32_t)(((g1 - g0) >= 32 ? ~0ull : ((1ull << (g1 - g0)) - 1)) << (g0 - gw));
+            out &= (unsigned long long)m | ((unsigned long long)m << 32);
+            atomicOr(&dst[w], out);
+        }
+    }
+}
 __global__ void __launch_bounds__(256)
 k_pack2_rc_bounds32(const int64_t *__restrict__ off, int32_t n, int64_t a0, uint64_t *__restrict__ dst)
 {
@@ -3183,6 +3219,20 @@ void dhk_pack2_rc_planes(hipStream_t st, const uint8_t *src, const int64_t *off,
     for (int32_t s0 = 0; s0 < n; s0 += 65535) {
         const int32_t cnt = n - s0 < 65535 ? n - s0 : 65535;
         hipLaunchKernelGGL(k_pack2_rc_planes, dim3(gx, cnt), dim3(256), 0, st, src, off + s0, cnt, a0, (unsigned long long *)dst);
+    }
+}
+
+// the same result from the plane-packed forward copy `fwd` of the chunk (dhk_pack2_planes ran before on this stream)
+void dhk_planes_rc(hipStream_t st, const uint8_t *fwd, const int64_t *off, int32_t n, int32_t max_len, int64_t a0, uint8_t *dst)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_pack2_rc_bounds32, dim3((n + 255) / 256), dim3(256), 0, st, off, n, a0, (uint64_t *)dst);
+    int gx = (max_len / 32 + 255) / 256;
+    gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+    for (int32_t s0 = 0; s0 < n; s0 += 65535) {
+        const int32_t cnt = n - s0 < 65535 ? n - s0 : 65535;
+        hipLaunchKernelGGL(k_planes_rc, dim3(gx, cnt), dim3(256), 0, st, (const unsigned long long *)fwd, off + s0, cnt, a0,
+                           (unsigned long long *)dst);
     }
 }
 

@@ -143,6 +143,12 @@ typedef struct {
     int64_t wave_launches, wave_cells, alignments, las, aligned_bp, trace_values, hits, b_bases;
 } dh_cum_stats;
 int dh_get_cum_stats(dh_ctx *ctx, dh_cum_stats *out, int32_t reset);
+/* Releases the context's device scratch (grow-only buffers kept between calls so that no call pays for GB-sized
+ * allocations: the wave / tile slots, the derived copies of a read chunk, the partitioned join's entry and hit pools --
+ * about 100 GB after an unsampled mapping of configs[2]).  For a long-lived host that moves on to another workload; the
+ * next call allocates what it needs again.  (The reference's tools are processes: their memory goes with them,
+ * dazzler.d:6519-6594.) */
+int dh_ctx_release_scratch(dh_ctx *ctx);
 /* Chunks of reads of the mapping calls on this context whose seeds came from the radix-partitioned k-mer join
  * (csrc/dh_mjoin.h: the damapper role, dazzler.d:6158-6170, without a random directory line per k-mer) -- out2[0] --
  * and chunks that exceeded one of its capacities and were redone by the directory lookups -- out2[1].  Both paths give

@@ -165,6 +165,7 @@ def test_config2_bench_chain_at_the_reference_behaviour(gpu_ctx, cfg2_workload, 
 
 
 def test_config4_one_rank_of_eight(gpu_ctx, capsys):
+    gpu_ctx.release_scratch()   # (what the earlier full-size tests left in the session's context: this one needs the HBM)
     t0 = time.perf_counter()
     s = sim.RankShare(3_000_000_000, 10_000, 10_000_000, 20_000, rank=0, world=8, seed=20260929)
     t_sim = time.perf_counter() - t0
