@@ -50,7 +50,7 @@ class ProcessOpts(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "tspace_map", "allowance", "min_anchor", "min_reads", "max_reads", "tspace_pile", "rounds",
         "flank_window", "max_align_err_ppm", "max_ins_err_ppm", "bad_fraction_ppm", "width", "dust", "algo",
-        "max_partners")]
+        "max_partners", "min_relative_score_ppm")]
 
 
 INSERTION_DTYPE = np.dtype([(n, "<i4") for n in (

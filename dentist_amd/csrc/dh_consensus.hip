@@ -85,8 +85,9 @@ k_gather_parts(const uint8_t *__restrict__ src0, const int64_t *__restrict__ off
 // in ascending index order are what the host sees after its stable merge by B read.  Flags are updated in place:
 // DISABLED (0x20), START | BEST (0x4 | 0x10) / NEXT (0x8) of the kept chains, IMPROPER (0x40: still counted by the tile
 // QVs, dropped afterwards).  la_first[r] = first record of A read r (nreads + 1 entries), live[r] = records of r that
-// stay after the proper-overlap filter.  status |= 1: a read with more than PF_MAXN records or a pair with more than
-// PF_MAXG enabled records -- the caller redoes the batch on the host (never met on pile-ups up to 250 reads).
+// stay after the proper-overlap filter.  status |= 1: a read with more than PF_MAXN records, a pair with more than
+// PF_MAXG enabled records, or a pair with two best chains that share records -- the caller redoes the batch on the host
+// (never met on pile-ups up to 250 reads).  The kernel serves the default --min-relative-score 1.0 only.
 #define PF_MAXN 1024
 #define PF_MAXG 8
 __device__ __forceinline__ int32_t pf_score(int32_t ab, int32_t ae, int32_t bb, int32_t be) { return ((ae - ab) + (be - bb)) / 2; }
@@ -198,21 +199,29 @@ k_pile_funnel(DhLa *__restrict__ las, const uint32_t *__restrict__ item_off, int
             }
             ends[v + 1] = x;
         }
-        uint32_t keep = 0;
+        // (a chain that runs into records of a better chain of the pair -- an alternate chain, two chains of the best score
+        // with a common prefix -- is written with its whole path, the shared records twice, chaining.d:247-285: records are
+        // inserted on the host only, the pair is left as it is and reported)
+        uint32_t keep = 0, first = 0;
+        bool shared = false;
         for (int32_t q = 0; q < nen; q++) {
             const int32_t e = ends[q];
             if (-dist[e] < thr || (keep >> e & 1u)) continue;
-            int32_t path[PF_MAXG], np_ = 0;
-            for (int32_t v = e; v >= 0; v = pred[v]) path[np_++] = v;
-            for (int32_t k = 0; k < np_; k++) {
-                const int32_t v = path[np_ - 1 - k];
-                if (keep >> v & 1u) continue;
+            int32_t last = e;
+            for (int32_t v = e; v >= 0; v = pred[v]) {
+                shared = shared || (keep >> v & 1u);
                 keep |= 1u << v;
-                s_fl[idx[v]] = (s_fl[idx[v]] & ~(0x4u | 0x8u | 0x10u)) | (k == 0 ? (0x4u | 0x10u) : 0x8u);
+                last = v;
             }
+            first |= 1u << last;
+        }
+        if (shared) {
+            atomicOr(status, 1);
+            continue;
         }
         for (int32_t v = 0; v < nen; v++)
-            if (!(keep >> v & 1u)) s_fl[idx[v]] |= 0x20u;
+            s_fl[idx[v]] = (keep >> v & 1u) ? (s_fl[idx[v]] & ~(0x4u | 0x8u | 0x10u)) | ((first >> v & 1u) ? (0x4u | 0x10u) : 0x8u)
+                                            : s_fl[idx[v]] | 0x20u;
     }
     __syncthreads();
     // ---- isValidPileUpAlignment with allowance = trace spacing; flags back, live records counted

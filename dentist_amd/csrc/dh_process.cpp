@@ -80,6 +80,7 @@ extern "C" void dh_default_process_opts(dh_process_opts *o)
     o->bad_fraction_ppm = 80000;
     o->width = 30;
     o->dust = 1;
+    o->min_relative_score_ppm = 1000000;
 }
 
 // ------------------------------------------------------------------------------------ DB helpers
@@ -696,16 +697,27 @@ static bool valid_pileup_alignment(const dh_la &la, bool same, int32_t alen, int
 }
 
 // chainLocalAlignments / buildAlignmentChains (common/alignments/chaining.d:122-334) with the
-// defaults of commandline.d:1819, 1982, 2014, 2153, 2165-2173.  `la` is grouped by (aread, bread)
-// [first, last); only chains scoring >= max(minScore, minRelativeScore * best) survive, every
-// other enabled LA of the pair gets DISABLED.  First LA of a chain: START|BEST, the others NEXT.
-// (One shortest-path problem over all LAs of the pair and the global threshold only: exact at the default
-// minRelativeScore = 1.0, the only value dh_process_opts can ask for; the reference's split into components and its
-// alternateChain marking, chaining.d:166-300, matter below 1.0 -- see oracle/process.py:chain_pile_las.)
-static void chain_pair(LaVec &la, size_t first, size_t last, int32_t min_score)
+// defaults of commandline.d:1819, 1982, 2014, 2165-2173 and minRelativeScore = min_rel (--min-relative-score, :2141-2153).
+// `la` is grouped by (aread, bread) [first, last):
+//  * the pair's enabled LAs are split into the connected components of the undirected chainability relation (:182);
+//  * a shortest-path problem rates the chains (:227-233; relaxations over the LAs ordered by (abpos, bbpos, index), a
+//    topological order -- no edge joins two components, so one pass serves all of them);
+//  * per component the end nodes within effectiveMinScore of the component's best chain are taken best first (:236-266):
+//    a node already on a taken chain is no end node, a chain that runs into nodes of a better chain is an ALTERNATE chain
+//    and is composed of its whole path (:269-285) -- the LAs it shares are written once per chain: their further
+//    occurrences go to `dups` (record index, flags) and are inserted behind the first one by the caller;
+//  * the chains scoring >= max(minScore, minRelativeScore * best of the pair) are accepted (:305-312).
+// First LA of a chain: START (+ BEST unless alternate, dazzler.d:2063-2068), the others NEXT; every other enabled LA of the
+// pair gets DISABLED.  Ties: the lower position in the (abpos, bbpos, index) order first (oracle/pile.c:chain_pair).
+struct ChainDup {
+    size_t i;
+    uint32_t flags;
+};
+static void chain_pair(LaVec &la, size_t first, size_t last, int32_t min_score, double min_rel_score, std::vector<ChainDup> &dups)
 {
     const int32_t max_indel = 1000, max_gap = 10000;
-    const double max_rel_overlap = 0.3, min_rel_score = 1.0;
+    const double max_rel_overlap = 0.3;
+    const uint32_t cmask = DH_FLAG_START | DH_FLAG_NEXT | DH_FLAG_BEST;
     // fast path (the common case): a single enabled LA is its own best chain
     size_t nen = 0, only = first;
     for (size_t i = first; i < last; i++)
@@ -717,10 +729,10 @@ static void chain_pair(LaVec &la, size_t first, size_t last, int32_t min_score)
     if (nen == 1) {
         dh_la &l = la[only];
         const int32_t sc = ((l.aepos - l.abpos) + (l.bepos - l.bbpos)) / 2;
-        if (sc < (int32_t)std::max<double>(min_score, 1.0 * sc))
+        if (sc < (int32_t)std::max<double>(min_score, min_rel_score * sc))
             l.flags |= DH_FLAG_DISABLED;
         else
-            l.flags = (l.flags & ~(DH_FLAG_START | DH_FLAG_NEXT | DH_FLAG_BEST)) | DH_FLAG_START | DH_FLAG_BEST;
+            l.flags = (l.flags & ~cmask) | DH_FLAG_START | DH_FLAG_BEST;
         return;
     }
     std::vector<size_t> order;
@@ -746,8 +758,11 @@ static void chain_pair(LaVec &la, size_t first, size_t last, int32_t min_score)
         const int32_t ga = y.abpos - x.aepos, gb = y.bbpos - x.bepos;
         return std::abs(ga - gb) + std::max(std::abs(ga), std::abs(gb)) / 10 - score(y);
     };
-    std::vector<int32_t> dist(n), pred(n, -1);
-    for (size_t v = 0; v < n; v++) dist[v] = -score(la[order[v]]);
+    std::vector<int32_t> dist(n), pred(n, -1), comp(n);
+    for (size_t v = 0; v < n; v++) {
+        dist[v] = -score(la[order[v]]);
+        comp[v] = (int32_t)v;
+    }
     for (size_t u = 0; u < n; u++)
         for (size_t v = u + 1; v < n; v++)
             if (chainable(la[order[u]], la[order[v]])) {
@@ -756,29 +771,66 @@ static void chain_pair(LaVec &la, size_t first, size_t last, int32_t min_score)
                     dist[v] = d;
                     pred[v] = (int32_t)u;
                 }
+                const int32_t cu = comp[u], cv = comp[v];
+                if (cu != cv)
+                    for (size_t w = 0; w < n; w++)
+                        if (comp[w] == cv) comp[w] = cu;
             }
-    const int32_t best = -*std::min_element(dist.begin(), dist.end());
+    // components in the order of their smallest record index (util/graphalgo.d:43-66)
+    std::vector<size_t> cmin(n, SIZE_MAX), cord;
+    for (size_t v = 0; v < n; v++) cmin[(size_t)comp[v]] = std::min(cmin[(size_t)comp[v]], order[v]);
+    for (size_t v = 0; v < n; v++)
+        if (cmin[v] != SIZE_MAX) cord.push_back(v);
+    std::sort(cord.begin(), cord.end(), [&](size_t x, size_t y) { return cmin[x] < cmin[y]; });
+    struct Sel {
+        size_t end;
+        bool alt;
+        int32_t score;
+    };
+    std::vector<Sel> sel;
+    std::vector<uint8_t> forbidden(n, 0);
+    std::vector<size_t> ends;
+    for (size_t c : cord) {
+        ends.clear();
+        for (size_t v = 0; v < n; v++)
+            if ((size_t)comp[v] == c) ends.push_back(v);
+        std::stable_sort(ends.begin(), ends.end(), [&](size_t x, size_t y) { return dist[x] < dist[y]; });
+        const int32_t cbest = -dist[ends[0]];
+        const int32_t cthr = (int32_t)std::max<double>(min_score, min_rel_score * cbest);
+        for (size_t e : ends) {
+            if (forbidden[e] || -dist[e] < cthr) continue;
+            bool alt = false;
+            for (int32_t v = (int32_t)e; v >= 0; v = pred[(size_t)v]) {
+                alt = alt || forbidden[(size_t)v];
+                forbidden[(size_t)v] = 1;
+            }
+            sel.push_back({e, alt, -dist[e]});
+        }
+    }
+    int32_t best = 0;
+    for (size_t x = 0; x < sel.size(); x++)
+        if (x == 0 || sel[x].score > best) best = sel[x].score;
     const int32_t thr = (int32_t)std::max<double>(min_score, min_rel_score * best);
-    std::vector<size_t> ends(n);
-    std::iota(ends.begin(), ends.end(), 0);
-    std::stable_sort(ends.begin(), ends.end(), [&](size_t x, size_t y) { return dist[x] < dist[y]; });
-    std::vector<uint8_t> keep(n, 0);
-    for (size_t e : ends) {
-        if (-dist[e] < thr || keep[e]) continue;
-        std::vector<size_t> path;
-        for (int32_t v = (int32_t)e; v >= 0; v = pred[(size_t)v]) path.push_back((size_t)v);
+    std::vector<uint8_t> occ(n, 0);
+    std::vector<size_t> path;
+    for (const Sel &c : sel) {
+        if (c.score < thr) continue;
+        path.clear();
+        for (int32_t v = (int32_t)c.end; v >= 0; v = pred[(size_t)v]) path.push_back((size_t)v);
         std::reverse(path.begin(), path.end());
         for (size_t k = 0; k < path.size(); k++) {
             const size_t v = path[k];
-            if (keep[v]) continue;
-            keep[v] = 1;
             dh_la &l = la[order[v]];
-            l.flags &= ~(DH_FLAG_START | DH_FLAG_NEXT | DH_FLAG_BEST);
-            l.flags |= k == 0 ? (DH_FLAG_START | DH_FLAG_BEST) : DH_FLAG_NEXT;
+            const uint32_t f = k == 0 ? (DH_FLAG_START | (c.alt ? 0u : DH_FLAG_BEST)) : DH_FLAG_NEXT;
+            if (!occ[v]) {
+                occ[v] = 1;
+                l.flags = (l.flags & ~cmask) | f;
+            } else
+                dups.push_back({order[v], (l.flags & ~cmask) | f});
         }
     }
     for (size_t v = 0; v < n; v++)
-        if (!keep[v]) la[order[v]].flags |= DH_FLAG_DISABLED;
+        if (!occ[v]) la[order[v]].flags |= DH_FLAG_DISABLED;
 }
 
 // ------------------------------------------------------------------------------------ results
@@ -1738,6 +1790,8 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
     if (o.max_reads != 0 && (o.max_reads < 3 || o.max_reads > 250))
         return dh_fail(DH_EINVAL, "max_reads must be 0 (no cap) or in [3, 250]");
     if (o.max_partners != 0 && o.max_partners < 4) return dh_fail(DH_EINVAL, "max_partners must be 0 (every pair) or at least 4");
+    if (o.min_relative_score_ppm < 0 || o.min_relative_score_ppm > 1000000)
+        return dh_fail(DH_EINVAL, "min_relative_score_ppm must be in [0, 1000000]");
     if (o.rounds < 1 || o.rounds > 8) return dh_fail(DH_EINVAL, "rounds must be in [1, 8]");
     if (o.tspace_pile < 16 || o.tspace_pile > SEG_MAX) return dh_fail(DH_EINVAL, "tspace_pile out of range");
     HIPCHK(hipSetDevice(ctx->device));
@@ -1940,7 +1994,9 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
         // overlaps of the reference reads only, 1 / n of them)
         // (4: with DH-2 the records stay on the device as well -- the funnel below runs there, only the overlaps of the
         // reference reads travel; DH_HOST_FUNNEL=1 keeps the host path, which is also the fall-back)
-        const bool want_dev_funnel = palgo == 1 && !getenv("DH_HOST_FUNNEL");
+        // (below the default --min-relative-score the chains can share LAs, which are then written once per chain: the host
+        // funnel inserts them; the kernel reports a pair in which that happens and the batch comes to the host as well)
+        const bool want_dev_funnel = palgo == 1 && !getenv("DH_HOST_FUNNEL") && o.min_relative_score_ppm == 1000000;
         if (int rc = dh_align_db_ex(ctx, pile, pile, &ao, 0, want_dev_funnel ? 6 : 2, &pset)) return rc;
         sg.sets.push_back(pset);
         lap("pile align call");
@@ -2040,6 +2096,7 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
         //         maxAlignmentError -> chainLocalAlignments -> isValidPileUpAlignment with
         //         allowance = trace spacing (dazzler.d:4066-4141)
         std::vector<int32_t> la_first;
+        std::vector<std::vector<ChainDup>> gdups_of_funnel;
         if (on_dev) la_first = dev_first;
         if (!on_dev) {
             // the funnel of one A read is independent of the others: host threads take read groups
@@ -2058,6 +2115,9 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
                     }
                 });
             }
+            const double min_rel = (double)o.min_relative_score_ppm / 1e6;
+            gdups_of_funnel.assign((size_t)pile->n, {});  // LAs that alternate chains share, per A read
+            auto &gdups = gdups_of_funnel;
             dh_parallel_for(pile->n, 64, [&](int64_t glo, int64_t ghi) {
                 for (int64_t g = glo; g < ghi; g++) {
                     const size_t g0 = (size_t)la_first[(size_t)g], g1 = (size_t)la_first[(size_t)g + 1];
@@ -2081,7 +2141,7 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
                     while (p0 < g1) {
                         size_t p1 = p0;
                         while (p1 < g1 && pl[p1].bread == pl[p0].bread) p1++;
-                        chain_pair(pl, p0, p1, tsp);
+                        chain_pair(pl, p0, p1, tsp, min_rel, gdups[(size_t)g]);
                         p0 = p1;
                     }
                     for (size_t i = g0; i < g1; i++) {
@@ -2096,6 +2156,33 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
                     }
                 }
             });
+        }
+        if (!on_dev) {
+            // the further occurrences of LAs that alternate chains share: behind their first occurrence (same trace)
+            size_t ndup = 0;
+            for (const auto &gd : gdups_of_funnel) ndup += gd.size();
+            if (ndup) {
+                LaVec out;
+                out.reserve(pl.size() + ndup);
+                std::vector<int32_t> nf((size_t)pile->n + 1, 0);
+                for (int32_t g = 0; g < pile->n; g++) {
+                    nf[(size_t)g] = (int32_t)out.size();
+                    auto &gd = gdups_of_funnel[(size_t)g];
+                    std::stable_sort(gd.begin(), gd.end(), [](const ChainDup &x, const ChainDup &y) { return x.i < y.i; });
+                    size_t d = 0;
+                    for (size_t i = (size_t)la_first[(size_t)g]; i < (size_t)la_first[(size_t)g + 1]; i++) {
+                        out.push_back(pl[i]);
+                        for (; d < gd.size() && gd[d].i == i; d++) {
+                            dh_la c = pl[i];
+                            c.flags = gd[d].flags | (pl[i].flags & FLAG_IMPROPER);
+                            out.push_back(c);
+                        }
+                    }
+                }
+                nf[(size_t)pile->n] = (int32_t)out.size();
+                pl.swap(out);
+                la_first.swap(nf);
+            }
         }
         lap("filter + chain");
         // ---- 4. tile QVs on the device (LAs are sorted by aread)

@@ -253,6 +253,12 @@ typedef struct {
                                 * first consensus round see n overlaps per read instead of all, the later consensus rounds
                                 * still re-align EVERY read of the pile-up to the template.  The n^2 stage becomes n x
                                 * max_partners; every read keeps its vote.  oracle/process.py, oracle/pile.c: same rule. */
+    int32_t min_relative_score_ppm; /* --min-relative-score of the pile-up chaining (commandline.d:2141-2153; 1 000 000 =
+                                * the default 1.0: only chains with the pair's best score).  Below it the chains of a pair
+                                * within that fraction of its best chain are kept, per connected component of the
+                                * chainability relation, ALTERNATE chains (sharing a prefix with a better chain) included:
+                                * the LAs they share then count once per chain, as in the reference's chained .las
+                                * (chaining.d:166-312, dazzler.d:2050-2085).  The funnel then runs on the host. */
 } dh_process_opts;
 void dh_default_process_opts(dh_process_opts *o);
 

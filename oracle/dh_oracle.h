@@ -189,9 +189,15 @@ typedef struct {
     int32_t ts_map, allowance, min_anchor, min_reads, max_reads, ts_pile, rounds, flank_window,
         max_align_err_ppm, max_ins_err_ppm, bad_fraction_ppm, width, dust,
         algo, /* alignments of the process stages: 0 = DH-1 (wave, `width` live diagonals), 1 = DH-2 (tiled band of 64) */
-        max_partners; /* 0 = every pair of a pile-up is aligned; n > 0 (algo 1): the first n reads are the partners (dh_process_opts) */
+        max_partners, /* 0 = every pair of a pile-up is aligned; n > 0 (algo 1): the first n reads are the partners (dh_process_opts) */
+        min_relative_score_ppm; /* --min-relative-score of the pile-up chaining (commandline.d:2141-2153), default 1 000 000 */
 } oz_process_opts;
 void oz_default_process_opts(oz_process_opts *o);
+/* chainLocalAlignments (common/alignments/chaining.d:122-334) over a set sorted by (aread, bread); min_score = the trace
+ * spacing (commandline.d:2165-2173), min_rel_ppm = minRelativeScore.  Flags in place; LAs shared by alternate chains are
+ * duplicated behind their first occurrence. */
+void oz_chain_set(oz_la_set *s, int32_t min_score, int32_t min_rel_ppm);
+int64_t oz_chain_las(const oz_la *las, int64_t n, int32_t min_score, int32_t min_rel_ppm, oz_la **out);
 typedef struct {
     int32_t gap, status /* 0 ok, 1..7 = DH_PILE_* */, nreads, ref_idx, ref_read_id, crop_left, crop_right,
         left_aepos, right_abpos, ins_begin, ins_end, comp, cons_len, left_diffs, right_diffs, pad;

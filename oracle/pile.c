@@ -39,6 +39,7 @@ void oz_default_process_opts(oz_process_opts *o)
     o->bad_fraction_ppm = 80000;
     o->width = 30;
     o->dust = 1;
+    o->min_relative_score_ppm = 1000000;
 }
 
 /* ------------------------------------------------------------------ collect ------------- */
@@ -260,9 +261,53 @@ static int end_cmp(const void *x, const void *y)
     return p->v < q->v ? -1 : (p->v > q->v ? 1 : 0);
 }
 
-/* chainLocalAlignments for the enabled LAs of one (A, B) pair [first, last) */
-static void chain_pair(oz_la *la, int64_t first, int64_t last, int32_t min_score)
+/* a second (third ...) occurrence of record i: an LA that an ALTERNATE chain shares with a better chain of the pair is
+ * written once per chain (the chains are written one after the other, dazzler.d:2050-2085) */
+typedef struct {
+    int64_t i;
+    uint32_t flags;
+} dup_ent;
+typedef struct {
+    dup_ent *d;
+    int64_t n, cap;
+} dup_list;
+static void dup_push(dup_list *l, int64_t i, uint32_t flags)
 {
+    if (l->n == l->cap) {
+        l->cap = l->cap ? 2 * l->cap : 16;
+        l->d = (dup_ent *)realloc(l->d, (size_t)l->cap * sizeof(dup_ent));
+    }
+    l->d[l->n].i = i;
+    l->d[l->n].flags = flags;
+    l->n++;
+}
+static int dup_cmp(const void *x, const void *y)
+{
+    const dup_ent *p = (const dup_ent *)x, *q = (const dup_ent *)y;
+    return p->i < q->i ? -1 : (p->i > q->i ? 1 : 0);
+}
+typedef struct {
+    int32_t end, alt, score;
+} sel_ent;
+
+/* buildAlignmentChains (common/alignments/chaining.d:151-312) for the enabled LAs of one (A, B) pair [first, last):
+ *  - the LAs are split into the connected components of the undirected chainability relation (:182);
+ *  - per component a shortest-path problem rates the chains (:227-233; the relaxations run over the LAs ordered by
+ *    (abpos, bbpos, index) -- a topological order; no edge joins two components, so one pass serves all of them);
+ *  - per component the end nodes within effectiveMinScore of the component's best chain are taken from best to worst
+ *    (:236-266): a node that already lies on a taken chain is no end node; a chain that runs into nodes of a better
+ *    chain is an ALTERNATE chain (it shares that chain's prefix) -- it is composed of its WHOLE path (:269-285), so the
+ *    shared LAs are written twice;
+ *  - the chains within effectiveMinScore = max(minScore, minRelativeScore * best) of the pair's best chain are accepted
+ *    (:305-312).
+ * First LA of a chain: START (+ BEST unless the chain is an alternate chain, dazzler.d:2063-2068), the others NEXT; LAs on
+ * no accepted chain: DISABLED; further occurrences of an LA go to `dups`.
+ * Ties (equal distances of two end nodes, of two predecessors): the lower position in the (abpos, bbpos, index) order
+ * first -- the reference sorts the end nodes with an unstable sort (:240-245) and relaxes in the order of a depth-first
+ * topological sort (util/graphalgo.d:926-960), neither of which is a property of the data. */
+static void chain_pair(oz_la *la, int64_t first, int64_t last, int32_t min_score, double min_rel, dup_list *dups)
+{
+    const uint32_t cmask = OZ_FLAG_START | OZ_FLAG_NEXT | OZ_FLAG_BEST;
     int32_t n = 0;
     for (int64_t i = first; i < last; i++)
         if (!(la[i].flags & OZ_FLAG_DISABLED)) n++;
@@ -278,54 +323,153 @@ static void chain_pair(oz_la *la, int64_t first, int64_t last, int32_t min_score
         }
     qsort(ord, (size_t)n, sizeof(ord_ent), ord_cmp);
     int32_t *dist = (int32_t *)malloc((size_t)n * sizeof(int32_t)), *pred = (int32_t *)malloc((size_t)n * sizeof(int32_t));
+    int32_t *comp = (int32_t *)malloc((size_t)n * sizeof(int32_t));  /* label = a member of the component */
     for (int32_t v = 0; v < n; v++) {
         dist[v] = -la_score(&la[ord[v].i]);
         pred[v] = -1;
+        comp[v] = v;
     }
     for (int32_t u = 0; u < n; u++)
         for (int32_t v = u + 1; v < n; v++)
-            if (chainable(&la[ord[u].i], &la[ord[v].i])) {
+            if (chainable(&la[ord[u].i], &la[ord[v].i])) {  /* (v before u is impossible: abpos ascends) */
                 const int32_t d = dist[u] + chain_score(&la[ord[u].i], &la[ord[v].i]);
                 if (dist[v] > d) {
                     dist[v] = d;
                     pred[v] = u;
                 }
+                const int32_t cu = comp[u], cv = comp[v];
+                if (cu != cv)
+                    for (int32_t w = 0; w < n; w++)
+                        if (comp[w] == cv) comp[w] = cu;
             }
-    int32_t best = -dist[0];
-    for (int32_t v = 1; v < n; v++)
-        if (-dist[v] > best) best = -dist[v];
-    const double thr_d = (double)min_score > 1.0 * best ? (double)min_score : 1.0 * best;
-    const int32_t thr = (int32_t)thr_d;
-    end_ent *ends = (end_ent *)malloc((size_t)n * sizeof(end_ent));
-    for (int32_t v = 0; v < n; v++) {
-        ends[v].dist = dist[v];
-        ends[v].v = v;
+    /* components in the order of their smallest record index (util/graphalgo.d:43-66) */
+    int64_t *cmin = (int64_t *)malloc((size_t)n * sizeof(int64_t));
+    int32_t *cord = (int32_t *)malloc((size_t)n * sizeof(int32_t)), nc = 0;
+    for (int32_t v = 0; v < n; v++) cmin[v] = -1;
+    for (int32_t v = 0; v < n; v++)
+        if (cmin[comp[v]] < 0 || ord[v].i < cmin[comp[v]]) cmin[comp[v]] = ord[v].i;
+    for (int32_t v = 0; v < n; v++)
+        if (cmin[v] >= 0) cord[nc++] = v;
+    for (int32_t x = 1; x < nc; x++) {
+        const int32_t c = cord[x];
+        int32_t y = x - 1;
+        while (y >= 0 && cmin[cord[y]] > cmin[c]) {
+            cord[y + 1] = cord[y];
+            y--;
+        }
+        cord[y + 1] = c;
     }
-    qsort(ends, (size_t)n, sizeof(end_ent), end_cmp);
-    uint8_t *keep = (uint8_t *)calloc((size_t)n, 1);
+    end_ent *ends = (end_ent *)malloc((size_t)n * sizeof(end_ent));
+    uint8_t *forbidden = (uint8_t *)calloc((size_t)n, 1);
+    sel_ent *sel = (sel_ent *)malloc((size_t)n * sizeof(sel_ent));
+    int32_t nsel = 0;
+    for (int32_t x = 0; x < nc; x++) {
+        int32_t ne = 0;
+        for (int32_t v = 0; v < n; v++)
+            if (comp[v] == cord[x]) {
+                ends[ne].dist = dist[v];
+                ends[ne].v = v;
+                ne++;
+            }
+        qsort(ends, (size_t)ne, sizeof(end_ent), end_cmp);
+        const int32_t cbest = -ends[0].dist;
+        const double cthr_d = (double)min_score > min_rel * cbest ? (double)min_score : min_rel * cbest;
+        const int32_t cthr = (int32_t)cthr_d;
+        for (int32_t y = 0; y < ne; y++) {
+            const int32_t e = ends[y].v;
+            if (forbidden[e] || -dist[e] < cthr) continue;
+            int32_t alt = 0;
+            for (int32_t v = e; v >= 0; v = pred[v]) {
+                if (forbidden[v]) alt = 1;
+                forbidden[v] = 1;
+            }
+            sel[nsel].end = e;
+            sel[nsel].alt = alt;
+            sel[nsel].score = -dist[e];
+            nsel++;
+        }
+    }
+    int32_t best = 0;
+    for (int32_t x = 0; x < nsel; x++)
+        if (x == 0 || sel[x].score > best) best = sel[x].score;
+    const double thr_d = (double)min_score > min_rel * best ? (double)min_score : min_rel * best;
+    const int32_t thr = (int32_t)thr_d;
+    uint8_t *occ = (uint8_t *)calloc((size_t)n, 1);
     int32_t *path = (int32_t *)malloc((size_t)n * sizeof(int32_t));
-    for (int32_t x = 0; x < n; x++) {
-        const int32_t e = ends[x].v;
-        if (-dist[e] < thr || keep[e]) continue;
+    for (int32_t x = 0; x < nsel; x++) {
+        if (sel[x].score < thr) continue;
         int32_t np = 0;
-        for (int32_t v = e; v >= 0; v = pred[v]) path[np++] = v;
+        for (int32_t v = sel[x].end; v >= 0; v = pred[v]) path[np++] = v;
         for (int32_t k = 0; k < np; k++) {
             const int32_t v = path[np - 1 - k];
-            if (keep[v]) continue;
-            keep[v] = 1;
             oz_la *l = &la[ord[v].i];
-            l->flags &= ~(OZ_FLAG_START | OZ_FLAG_NEXT | OZ_FLAG_BEST);
-            l->flags |= k == 0 ? (OZ_FLAG_START | OZ_FLAG_BEST) : OZ_FLAG_NEXT;
+            const uint32_t f = k == 0 ? (OZ_FLAG_START | (sel[x].alt ? 0u : OZ_FLAG_BEST)) : OZ_FLAG_NEXT;
+            if (!occ[v]) {
+                l->flags = (l->flags & ~cmask) | f;
+                occ[v] = 1;
+            } else
+                dup_push(dups, ord[v].i, (l->flags & ~cmask) | f);
         }
     }
     for (int32_t v = 0; v < n; v++)
-        if (!keep[v]) la[ord[v].i].flags |= OZ_FLAG_DISABLED;
+        if (!occ[v]) la[ord[v].i].flags |= OZ_FLAG_DISABLED;
     free(path);
-    free(keep);
+    free(occ);
+    free(sel);
+    free(forbidden);
     free(ends);
+    free(cord);
+    free(cmin);
+    free(comp);
     free(dist);
     free(pred);
     free(ord);
+}
+
+/* chainLocalAlignments over a set sorted by (aread, bread): the pairs one after the other; the further occurrences of
+ * LAs that alternate chains share are inserted behind their first occurrence (same trace) */
+void oz_chain_set(oz_la_set *s, int32_t min_score, int32_t min_rel_ppm)
+{
+    dup_list dups = {NULL, 0, 0};
+    const double rel = (double)min_rel_ppm / 1e6;
+    for (int64_t p0 = 0; p0 < s->n;) {
+        int64_t p1 = p0;
+        while (p1 < s->n && s->la[p1].aread == s->la[p0].aread && s->la[p1].bread == s->la[p0].bread) p1++;
+        chain_pair(s->la, p0, p1, min_score, rel, &dups);
+        p0 = p1;
+    }
+    if (dups.n) {
+        qsort(dups.d, (size_t)dups.n, sizeof(dup_ent), dup_cmp);  /* (pairs come in order: stable enough -- equal i keep any order) */
+        oz_la *out = (oz_la *)malloc((size_t)(s->n + dups.n) * sizeof(oz_la));
+        int64_t w = 0, d = 0;
+        for (int64_t i = 0; i < s->n; i++) {
+            out[w++] = s->la[i];
+            while (d < dups.n && dups.d[d].i == i) {
+                out[w] = s->la[i];
+                out[w].flags = dups.d[d].flags;
+                w++;
+                d++;
+            }
+        }
+        free(s->la);
+        s->la = out;
+        s->n = w;
+        s->cap = w;
+    }
+    free(dups.d);
+}
+
+/* the same on an array (tests): returns the number of records of *out (malloc'd, oz_free) */
+int64_t oz_chain_las(const oz_la *las, int64_t n, int32_t min_score, int32_t min_rel_ppm, oz_la **out)
+{
+    oz_la_set s;
+    oz_la_set_init(&s);
+    s.la = (oz_la *)malloc((size_t)(n > 0 ? n : 1) * sizeof(oz_la));
+    memcpy(s.la, las, (size_t)n * sizeof(oz_la));
+    s.n = s.cap = n;
+    oz_chain_set(&s, min_score, min_rel_ppm);
+    *out = s.la;
+    return s.n;
 }
 
 /* ------------------------------------------------------------------ one pile-up ---------- */
@@ -469,12 +613,7 @@ static void process_one(const oz_db *contigs, const oz_db *reads, const oz_la *l
         for (int64_t i = 0; i < ps.n; i++)
             if ((int64_t)ps.la[i].diffs * 1000000 > (int64_t)o->max_align_err_ppm * (ps.la[i].aepos - ps.la[i].abpos))
                 ps.la[i].flags |= OZ_FLAG_DISABLED;
-        for (int64_t p0 = 0; p0 < ps.n;) {
-            int64_t p1 = p0;
-            while (p1 < ps.n && ps.la[p1].aread == ps.la[p0].aread && ps.la[p1].bread == ps.la[p0].bread) p1++;
-            chain_pair(ps.la, p0, p1, tsp);
-            p0 = p1;
-        }
+        oz_chain_set(&ps, tsp, o->min_relative_score_ppm);
         /* DAScover + DASqv on the chained file, then filterPileUpAlignments (package.d:492-512) */
         const int32_t maxtiles = (maxlen + tsp - 1) / tsp > 0 ? (maxlen + tsp - 1) / tsp : 1;
         uint8_t *qv = (uint8_t *)malloc((size_t)pile.n * maxtiles);

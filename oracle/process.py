@@ -232,7 +232,7 @@ def pile_opts(algo=0, nreads=0):
                            width=stage_width(algo), algo=algo)
 
 
-def filter_pile_las(las, pile, max_err_ppm=300000, allowance=TS_PILE, proper=True):
+def filter_pile_las(las, pile, max_err_ppm=300000, allowance=TS_PILE, proper=True, min_rel_score=1.0):
     """computeQVs' alignment funnel (processPileUps/package.d:474-516): filterLocalAlignments
     (averageErrorRate <= maxAlignmentError) -> chainLocalAlignments -> filterPileUpAlignments
     (properAlignmentAllowance, forceFlat; dazzler.d:4066-4094).  Dropped LAs get DISABLED (0x20)."""
@@ -241,7 +241,7 @@ def filter_pile_las(las, pile, max_err_ppm=300000, allowance=TS_PILE, proper=Tru
         al = int(la["aepos"] - la["abpos"])
         if int(la["diffs"]) * 1000000 > max_err_ppm * al:
             la["flags"] |= 0x20
-    las = chain_pile_las(las)
+    las = chain_pile_las(las, min_rel_score=min_rel_score)
     if proper:
         las = filter_proper(las, pile, allowance)
     return las
@@ -259,22 +259,20 @@ def filter_proper(las, pile, allowance=TS_PILE):
 
 
 def chain_pile_las(las, max_indel=1000, max_gap=10000, max_rel_overlap=0.3, min_rel_score=1.0, min_score=TS_PILE):
-    """chainLocalAlignments (common/alignments/chaining.d:122-334) with the defaults of
-    commandline.d:1819, 1982, 2014, 2153, 2165-2173: per (A, B) pair the chains of collinear LAs are
-    rated by a shortest-path problem (node bonus = mean length, edge penalty = indel + gap/10) and
-    only chains scoring >= max(minScore, minRelativeScore * best) survive; every other enabled LA
-    of the pair is dropped (DISABLED).  Flags: first LA of a chain START|BEST, the others NEXT.
-
-    Simplified against chaining.d:166-300, exact at the default minRelativeScore = 1.0 (commandline.d:2153) and only there:
-    the reference first splits the pair's LAs into connected components of the (undirected) chainability relation, selects
-    per component the end nodes within minRelativeScore of the component's best chain -- marking a chain that shares a
-    prefix with a better one `alternateChain` -- and then keeps the chains within minRelativeScore of the best chain over
-    all components.  Here ONE shortest-path problem runs over all LAs of the pair (LAs of different components are never
-    chainable, so the distances are the same) and only the global threshold is applied; at 1.0 both keep exactly the
-    chains whose score equals the pair's best (ties: every end node with that score, nodes already on a kept chain are not
-    repeated).  With minRelativeScore < 1 the reference would also keep alternate chains and per-component winners that
-    this restatement (and the product, dh_process.cpp:chain_pair) drops or joins differently; the process stage has no
-    knob for it (dh_process_opts), so the default is the only value that can be asked for."""
+    """chainLocalAlignments / buildAlignmentChains (common/alignments/chaining.d:122-334) with the defaults of
+    commandline.d:1819, 1982, 2014, 2153, 2165-2173, per (A, B) pair:
+      * the pair's enabled LAs are split into the connected components of the undirected chainability relation (:182);
+      * per component a shortest-path problem rates the chains (node bonus = mean length, edge penalty = indel + gap/10,
+        :227-233; relaxations over the LAs ordered by (abpos, bbpos, index), a topological order);
+      * per component the end nodes within effectiveMinScore of the component's best chain are taken best first
+        (:236-266): a node already on a taken chain is no end node; a chain that runs into nodes of a better chain is an
+        ALTERNATE chain and is composed of its whole path (:269-285) -- the shared LAs are written once per chain;
+      * the chains scoring >= max(minScore, minRelativeScore * best of the pair) are accepted (:305-312).
+    Flags: first LA of a chain START (+ BEST unless alternate, dazzler.d:2063-2068), the others NEXT; LAs on no accepted
+    chain DISABLED.  Returns a NEW array: further occurrences of shared LAs are inserted behind their first occurrence.
+    Ties (two end nodes / two predecessors with equal distance): the lower position in the (abpos, bbpos, index) order
+    first -- the reference's unstable sort (:240-245) and its depth-first topological order (util/graphalgo.d:926-960)
+    are not properties of the data."""
     las = las.copy()
     groups = {}
     for i, la in enumerate(las):
@@ -301,43 +299,72 @@ def chain_pile_las(las, max_indel=1000, max_gap=10000, max_rel_overlap=0.3, min_
         ga, gb = int(y["abpos"]) - int(x["aepos"]), int(y["bbpos"]) - int(x["bepos"])
         return abs(ga - gb) + max(abs(ga), abs(gb)) // 10 - score(y)
 
+    CMASK = 0x4 | 0x8 | 0x10
+    dups = []   # (record index, flags)
     for idxs in groups.values():
         order = sorted(idxs, key=lambda i: (int(las[i]["abpos"]), int(las[i]["bbpos"]), i))   # a topological order
         n = len(order)
         dist = [-score(las[i]) for i in order]
         pred = [-1] * n
+        comp = list(range(n))
         for u in range(n):
             for v in range(u + 1, n):
                 if chainable(las[order[u]], las[order[v]]):
                     d = dist[u] + chain_score(las[order[u]], las[order[v]])
                     if dist[v] > d:
                         dist[v], pred[v] = d, u
-        best = -min(dist)
+                    cu, cv = comp[u], comp[v]
+                    if cu != cv:
+                        comp = [cu if c == cv else c for c in comp]
+        members = {}
+        for v in range(n):
+            members.setdefault(comp[v], []).append(v)
+        sel = []   # (end node, alternate, score)
+        forbidden = set()
+        for c in sorted(members, key=lambda c: min(order[v] for v in members[c])):
+            ends = sorted(members[c], key=lambda v: (dist[v], v))
+            cthr = int(max(min_score, min_rel_score * -dist[ends[0]]))
+            for e in ends:
+                if e in forbidden or -dist[e] < cthr:
+                    continue
+                alt, v = False, e
+                while v >= 0:
+                    alt = alt or v in forbidden
+                    forbidden.add(v)
+                    v = pred[v]
+                sel.append((e, alt, -dist[e]))
+        best = max((sc for _, _, sc in sel), default=0)
         thr = int(max(min_score, min_rel_score * best))
-        keep = set()
-        for e in sorted(range(n), key=lambda v: (dist[v], v)):
-            if -dist[e] < thr or e in keep:
+        seen = set()
+        for e, alt, sc in sel:
+            if sc < thr:
                 continue
-            path = []
-            v = e
+            path, v = [], e
             while v >= 0:
                 path.append(v)
                 v = pred[v]
             path.reverse()
             for k, v in enumerate(path):
-                if v in keep:
-                    continue
-                keep.add(v)
-                f = int(las[order[v]]["flags"]) & ~(0x4 | 0x8 | 0x10)
-                las[order[v]]["flags"] = f | ((0x4 | 0x10) if k == 0 else 0x8)
+                f = (int(las[order[v]]["flags"]) & ~CMASK) | ((0x4 | (0 if alt else 0x10)) if k == 0 else 0x8)
+                if v not in seen:
+                    seen.add(v)
+                    las[order[v]]["flags"] = f
+                else:
+                    dups.append((order[v], f))
         for v in range(n):
-            if v not in keep:
+            if v not in seen:
                 las[order[v]]["flags"] |= 0x20
+    if dups:
+        dups.sort(key=lambda d: d[0])
+        at = [d[0] + 1 for d in dups]
+        rows = las[[d[0] for d in dups]].copy()
+        rows["flags"] = [d[1] for d in dups]
+        las = np.insert(las, at, rows)
     return las
 
 
 def process_pile(entries, las, trace, contigs, reads, g, rounds=3, nthreads=1, flank_window=20000, dust=True, algo=0, mask=None,
-                 max_partners=0):
+                 max_partners=0, min_rel_score=1.0):
     """One pile-up through the `process` sequence; returns a dict describing the insertion.  g: the left contig of a
     plain gap, or any join (contig0, seed0, contig1, seed1) -- see join_of."""
     res = {"gap": g, "status": "ok", "nreads": len(entries)}
@@ -377,14 +404,14 @@ def process_pile(entries, las, trace, contigs, reads, g, rounds=3, nthreads=1, f
     plas, ptrace, _ = oz.align_db(pile, pile, o, nthreads=nthreads)
     pile.pflags = None
     # computeQVs (package.d:474-516): error filter -> chain -> DAScover/DASqv -> proper-overlap filter
-    chained = filter_pile_las(plas, pile, proper=False)
+    chained = filter_pile_las(plas, pile, proper=False, min_rel_score=min_rel_score)
     rlen = np.asarray([pile.length(i) for i in range(pile.n)], dtype=np.int32)
     cov = int(allowed.sum())
     if cov < 4 and pile.n >= 4:
         cov = 4
     qv = oz.tile_qv(chained, ptrace, rlen, TS_PILE, max(cov, 1))
     plas = filter_proper(chained, pile)
-    res.update(pile_las=plas, pile_trace=ptrace)
+    res.update(pile_las=plas, pile_trace=ptrace, chained_las=chained)
     if not np.any((plas["flags"] & 0x20) == 0):
         res["status"] = "empty pileup alignment after filtering"
         return res

@@ -277,7 +277,8 @@ def valid_pileup_alignment(la, alen, blen, allowance):
 class ProcessOpts(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "ts_map", "allowance", "min_anchor", "min_reads", "max_reads", "ts_pile", "rounds", "flank_window",
-        "max_align_err_ppm", "max_ins_err_ppm", "bad_fraction_ppm", "width", "dust", "algo", "max_partners")]
+        "max_align_err_ppm", "max_ins_err_ppm", "bad_fraction_ppm", "width", "dust", "algo", "max_partners",
+        "min_relative_score_ppm")]
 
 
 OZ_INSERTION_DTYPE = np.dtype([(n, "<i4") for n in (
@@ -293,6 +294,22 @@ def default_process_opts(**kw):
             raise AttributeError(k)
         setattr(o, k, v)
     return o
+
+
+def chain_las_c(las, min_score, min_rel_ppm=1000000):
+    """oz_chain_las: chainLocalAlignments over records sorted by (aread, bread); returns the records with their chain flags
+    (LAs shared by alternate chains duplicated behind their first occurrence)."""
+    L = lib()
+    arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
+    out = ctypes.c_void_p()
+    L.oz_chain_las.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]
+    L.oz_chain_las.restype = ctypes.c_int64
+    L.oz_free.argtypes = [ctypes.c_void_p]
+    n = L.oz_chain_las(arr.ctypes.data, len(arr), int(min_score), int(min_rel_ppm), ctypes.byref(out))
+    res = (np.frombuffer(ctypes.string_at(out, LA_DTYPE.itemsize * n), dtype=LA_DTYPE).copy() if n
+           else np.zeros(0, dtype=LA_DTYPE))
+    L.oz_free(out)
+    return res
 
 
 def collect_spanning_c(las, contigs, popts):

@@ -65,3 +65,27 @@ def plant_long_indels(w, rng):
             planted.append(i)
             break
     return sim.SeqDb.from_list(seqs), planted
+
+
+def plant_gap_insertions(w, rng, ln=1500):
+    """Every second read of the workload `w` that spans a gap gets `ln` foreign bases in the middle of the gap: in the
+    pile-up all-vs-all it aligns with the other reads as TWO local alignments that no chain joins (indel above
+    --max-indel 1000, chaining.d:434-475) -- two components of the pair.  Returns (reads DB, indices of the changed reads)."""
+    from dentist_amd import sim
+    seqs = [w.reads.seq(i) for i in range(w.reads.n)]
+    planted, eligible = [], 0
+    for i, (s0, e0, strand) in enumerate(w.read_truth):
+        for g in range(len(w.gap_begin)):
+            gb, ge = int(w.gap_begin[g]), int(w.gap_end[g])
+            if not (s0 + 1500 < gb and ge + 1500 < e0):
+                continue
+            eligible += 1
+            if eligible % 2:
+                break
+            mid = (gb + ge) // 2
+            scale = len(seqs[i]) / float(e0 - s0)
+            at = int((mid - s0) * scale) if not strand else int((e0 - mid) * scale)
+            seqs[i] = np.concatenate([seqs[i][:at], rng.integers(0, 4, ln).astype(np.uint8), seqs[i][at:]])
+            planted.append(i)
+            break
+    return sim.SeqDb.from_list(seqs), planted

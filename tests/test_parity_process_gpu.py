@@ -8,7 +8,7 @@ import pytest
 
 import dentist_amd
 from dentist_amd import sim
-from helpers import plant_long_indels, assert_same_las
+from helpers import plant_long_indels, plant_gap_insertions, assert_same_las
 from oracle import process as pr
 from oracle import pyoracle as oz
 
@@ -787,6 +787,49 @@ def test_device_funnel_host_funnel_and_the_fall_back_agree(gpu_ctx, monkeypatch)
     assert (out[0][0]["status"] == 0).sum() >= 2
     for rec, bases in out[1:]:
         assert rec.tobytes() == out[0][0].tobytes() and np.array_equal(bases, out[0][1])
+
+
+def test_chains_below_the_default_min_relative_score(gpu_ctx):
+    """dh_process_opts.min_relative_score_ppm (--min-relative-score of `dentist process`, commandline.d:2141-2153;
+    buildAlignmentChains chaining.d:151-312: components of the chainability relation, the chains within that fraction of
+    the pair's best chain, alternate chains with the records they share written once per chain).  Half of the reads of
+    every pile-up carry 1.5 kb of foreign bases inside the gap: with a plain read they align as two records that no chain
+    joins -- at the default the tile QVs (computeQVs, package.d:486-505) see the better one only, at 0.3 both, which changes
+    the ranking of the reference reads.  Product == oracle at 0.3 (crop points, reference read, every consensus base, the
+    splice), and the product's own result differs from its default's in at least one pile-up."""
+    w = sim.Workload(300_000, 2, 1500, 7000, seed=53, spacing=20000, gap_min=1500, gap_max=2500)
+    reads, planted = plant_gap_insertions(w, np.random.default_rng(3))
+    assert len(planted) >= 6
+    g = dentist_amd.default_align_opts(algo=1, width=64)
+    A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(reads)
+    las, trace = gpu_ctx.align_db(A, B, g)
+    olas, otrace, _ = oz.align_db(w.contigs, reads, oz.default_opts(width=64, algo=1), nthreads=os.cpu_count() or 1)
+    assert_same_las((las, trace), (olas, otrace))
+    po = dentist_amd.default_process_opts(rounds=2, algo=1, max_reads=30, min_relative_score_ppm=300000)
+    po1 = dentist_amd.default_process_opts(rounds=2, algo=1, max_reads=30)
+    piles = dentist_amd.Pileups(las, w.contigs.off, po)
+    exp_piles = pr.collect_spanning(olas, otrace, w.contigs, reads, max_reads=30)
+    assert len(piles) == len(exp_piles) == 2
+    rec, bases = dentist_amd.process_pileups(gpu_ctx, A, B, las, trace, piles, po)
+    rec1, bases1 = dentist_amd.process_pileups(gpu_ctx, A, B, las, trace, piles, po1)
+    differs = 0
+    for i in range(len(piles)):
+        gap, _ = piles.get(i)
+        exp = pr.process_pile(exp_piles[gap], olas, otrace, w.contigs, reads, gap, rounds=2, nthreads=os.cpu_count() or 1, algo=1,
+                              min_rel_score=0.3)
+        exp1 = pr.process_pile(exp_piles[gap], olas, otrace, w.contigs, reads, gap, rounds=2, nthreads=os.cpu_count() or 1, algo=1)
+        for r, b, e in ((rec[i], bases, exp), (rec1[i], bases1, exp1)):
+            assert e["status"] == "ok" and r["status"] == 0
+            assert (r["crop_left"], r["crop_right"]) == (e["cropL"], e["cropR"])
+            assert r["nreads"] == e["pile"].n and r["ref_read"] == e["ref_idx"]
+            assert np.array_equal(b[r["cons_off"]:r["cons_off"] + r["cons_len"]], e["consensus"]), f"gap {gap}: consensus differs"
+            assert (r["left_aepos"], r["right_abpos"], r["ins_begin"], r["ins_end"]) == \
+                   (e["left_aepos"], e["right_abpos"], e["ins_begin"], e["ins_end"])
+        assert ((exp["chained_las"]["flags"] & 0x20) == 0).sum() > ((exp1["chained_las"]["flags"] & 0x20) == 0).sum()
+        differs += int(rec[i]["ref_read"] != rec1[i]["ref_read"])
+    assert differs >= 1
+    with pytest.raises(dentist_amd.DhError):
+        dentist_amd.process_pileups(gpu_ctx, A, B, las, trace, piles, dentist_amd.default_process_opts(min_relative_score_ppm=1000001))
 
 
 def test_pairs_without_a_reference_read_candidate_are_not_aligned_and_nothing_changes(gpu_ctx, monkeypatch):
