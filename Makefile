@@ -7,7 +7,7 @@ LIB := dentist_amd/libdentist_hip.so
 SIM := dentist_amd/sim/libdh_sim.so
 
 DAZZ_TOOLS := fasta2DB fasta2DAM DBsplit DBrm DBdump DBshow DBdust LAmerge DAScover DASqv computeintrinsicqv daccord merge-insertions LAsplit Catrack TANmask
-TOOLS := tools/daligner tools/damapper tools/dazz_tools $(addprefix tools/,$(DAZZ_TOOLS))
+TOOLS := tools/daligner tools/damapper tools/datander tools/dazz_tools $(addprefix tools/,$(DAZZ_TOOLS))
 
 all: $(LIB) $(SIM) oracle $(TOOLS)
 
@@ -15,6 +15,9 @@ tools/daligner: tools/aligner_main.cpp include/dentist_hip.h $(LIB)
 	$(HIPCC) -O2 -std=c++17 -o $@ $< -Ldentist_amd -ldentist_hip -Wl,-rpath,'$$ORIGIN/../dentist_amd'
 
 tools/damapper: tools/daligner
+	cp $< $@
+
+tools/datander: tools/daligner
 	cp $< $@
 
 tools/dazz_tools: tools/dazz_main.cpp include/dentist_hip.h $(LIB)

@@ -1274,7 +1274,9 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     if (o.skip_self && A != B) return fail(DH_EINVAL, "skip_self needs A == B");
     if (out_tr && (o.algo != 1 || A == B || hook))
         return fail(DH_EINVAL, "the transposed file is defined for DH-2 (algo 1) mappings of one DB onto another");
-    if (o.skip_self < 0 || o.skip_self > 2) return fail(DH_EINVAL, "skip_self must be 0, 1 or 2");
+    if (o.skip_self < 0 || o.skip_self > 3) return fail(DH_EINVAL, "skip_self must be 0, 1, 2 or 3");
+    if (o.skip_self == 3 && (o.algo != 1 || o.strands != 1 || hook || out_tr))
+        return fail(DH_EINVAL, "skip_self 3 (a read against itself, datander) is defined for DH-2 (algo 1) on the forward strand (strands 1)");
     if (o.kmer_mod < 1 || o.kmer_mod > 64) return fail(DH_EINVAL, "kmer_mod must be in [1, 64]");
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -2046,6 +2048,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             tp.counters = d_counters;
             tp.status = d_status;
             tp.pflags = o.skip_self == 2 ? B->d_pflags : nullptr;
+            tp.tandem = o.skip_self == 3 ? 1 : 0;
             dhk_tile(st, tile_waves, &tp);
         } else if (dual)
             dhk_wave2(st, nslots / per_wave, av, bv, A->d_rc, cc.rc, packed ? A->d_pk : nullptr,

@@ -626,6 +626,8 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
             if (!(o.strands & (1 << strand))) return;
             const int32_t aseq = (int32_t)(v >> 40);
             if (o.skip_self == 1 && aseq == r) return;
+            // tandem (datander): a read against itself, below the main diagonal only (position on A > position on B)
+            if (o.skip_self == 3 && (aseq != r || (int64_t)(v & ((1ull << 40) - 1)) - ix.goff[r] - q < 1)) return;
             // symmetric: each unordered pair once; which read plays B alternates with the
             // parity of a + b, so every read is B for about half of its partners
             if (o.skip_self == 2 && (aseq == r || ((aseq < r) != (((aseq + r) & 1) == 0)))) return;

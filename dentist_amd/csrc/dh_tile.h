@@ -90,6 +90,7 @@ struct Params {
     unsigned long long *counters;     // [0] band cells computed, [1] candidates aligned
     int32_t *status;
     const uint8_t *pflags;            // symmetric mode, optional (DbView::pflags): which records are wanted
+    int32_t tandem;                   // dh_align_opts.skip_self == 3: a read against itself below the main diagonal (Tile::dm)
 };
 
 // one running extension (registers)
@@ -149,6 +150,7 @@ struct Lane {
 // the tile in flight
 struct Tile {
     uint64_t Pv, Mv, lv, wild;
+    uint64_t dm;  // tandem mode only: the rows of the band that may match (B's base before A's on the read)
     int32_t z, dbot, cols, bnr, T;
 };
 // the sequence words of a tile, NTW dwords per lane (registers on the host, LDS on the device):
@@ -209,6 +211,18 @@ DH_HD void tile_setup(const Lane &l, const Params &P, Tile &t, uint32_t *q)
     const int32_t th = t.bnr + W / 2 + 1;  // first bit of column 0 past the end of B'
     t.wild = th >= 64 ? 0ull : ~0ull << th;
     t.z = t.bnr - W / 2 + 1;
+    // tandem mode (dh_align_opts.skip_self == 3, datander: A' and B' are the same read): a cell in which B's base is not
+    // BEFORE A's on the read never matches, so that the alignment of a read with itself stays below the main diagonal.  Row
+    // i of any column of the tile is base b = a + i - W/2 - delta with delta = (ga + a0) - (gb + b0) (read-relative), the (signed) distance
+    // of the tile's origin from the main diagonal in the copies at hand: forward the rows i < delta + W/2 are allowed;
+    // backward the copies are mirrored (delta < 0, B's base must come AFTER A's in them): the rows i > W/2 + delta.
+    t.dm = ~0ull;
+    if (P.tandem) {
+        const int64_t delta = (e.ga - l.c->g_ao + e.a0) - (e.gb - l.c->g_bo + e.b0);
+        const int64_t nlow = l.dir ? W / 2 + delta + 1 : delta + W / 2;
+        const uint64_t low = nlow <= 0 ? 0ull : (nlow >= 64 ? ~0ull : (1ull << nlow) - 1ull);
+        t.dm = l.dir ? ~low : low;
+    }
     // B planes: bit x of the window string = base (gb + b0 - W/2 + x)
     {
         const int64_t g = e.gb + e.b0 - W / 2;
@@ -238,6 +252,7 @@ DH_HD void tile_setup(const Lane &l, const Params &P, Tile &t, uint32_t *q)
 
 // one column of the band: c = 1 .. cols.  (p0, p1) = plane windows of the column: bit i = low / high bit
 // of base B'[b0 + c + i - W/2 - 1], the base a path consumes to reach row i of the column; x = A'[a0 + c - 1]
+template <bool TAN = false>
 DH_HD void tile_col(Tile &t, uint64_t p0, uint64_t p1, uint32_t x)
 {
     const uint64_t x0 = 0ull - (uint64_t)(x & 1u), x1 = 0ull - (uint64_t)((x >> 1) & 1u);
@@ -245,7 +260,7 @@ DH_HD void tile_col(Tile &t, uint64_t p0, uint64_t p1, uint32_t x)
     t.lv = (uint64_t)((int64_t)t.lv >> 1);
     t.z -= 1;
     t.wild = (uint64_t)((int64_t)t.wild >> 1) | ((uint64_t)((uint32_t)t.z & 0x80000000u) << 32);
-    const uint64_t Eq = (~((p0 ^ x0) | (p1 ^ x1)) & t.lv) | t.wild;
+    const uint64_t Eq = (~((p0 ^ x0) | (p1 ^ x1)) & (TAN ? t.lv & t.dm : t.lv)) | t.wild;
     const uint64_t Pv = t.Pv, Mv = t.Mv;
     const uint64_t D0 = (((Eq & Pv) + Pv) ^ Pv) | Eq | Mv;
     const uint64_t HP = Mv | ~(D0 | Pv), HN = Pv & D0;

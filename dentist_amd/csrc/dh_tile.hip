@@ -58,6 +58,7 @@ extern "C" void dhk_tile_prof_dump()
 #define TPC(i, v)
 #endif
 
+template <bool TAN>
 __global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
 {
     __shared__ uint32_t s_q[NTW][64];
@@ -143,7 +144,7 @@ __global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
                     const uint64_t p0 = (uint64_t)funnel(a1, a0, (uint32_t)sh) | ((uint64_t)funnel(a2, a1, (uint32_t)sh) << 32);
                     const uint64_t p1 = (uint64_t)funnel(b1, b0, (uint32_t)sh) | ((uint64_t)funnel(b2, b1, (uint32_t)sh) << 32);
                     const uint32_t x = (uint32_t)(ab >> (2 * sh)) & 3u;
-                    tile_col(t, p0, p1, x);
+                    tile_col<TAN>(t, p0, p1, x);
                 }
             }
         }
@@ -379,7 +380,10 @@ void dhk_compact_sym(hipStream_t st, const DhLa *slots, const uint16_t *tr_slots
 void dhk_tile(hipStream_t st, int32_t nwaves, const Params *P)
 {
     if (P->nitems <= 0 || nwaves <= 0) return;
-    hipLaunchKernelGGL(k_tile, dim3(nwaves), dim3(64), 0, st, *P);
+    if (P->tandem)
+        hipLaunchKernelGGL(k_tile<true>, dim3(nwaves), dim3(64), 0, st, *P);
+    else
+        hipLaunchKernelGGL(k_tile<false>, dim3(nwaves), dim3(64), 0, st, *P);
 }
 // resident wavefronts per CU the host launches: 12 of the 16 the registers allow measured best on configs[2]
 // (mapping pass 31.3 ms against 33.6 with 16: fewer lanes share the queue's tail and the caches)

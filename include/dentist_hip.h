@@ -57,7 +57,11 @@ typedef struct {
     int32_t tcap;        /* -t  k-mers occurring more often in A are ignored                 */
     int32_t strands;     /* bit0 forward B, bit1 reverse-complement B                        */
     int32_t skip_self;   /* A is B: 1 = skip aread == bread (absence of -I); 2 = symmetric: every
-                          * unordered pair is aligned once and both records are emitted        */
+                          * unordered pair is aligned once and both records are emitted;
+                          * 3 = tandem (`datander`, DAMASKER; DENTIST's call commandline.d:2866-2876): every read is
+                          *     aligned with ITSELF only, below the main diagonal -- seeds with A position > B position,
+                          *     cells in which B's base does not come before A's never match; records have aread ==
+                          *     bread and abpos > bbpos.  DH-2 (algo 1), strands = 1 */
     int32_t dmax;        /* cap on differences per extension                                 */
     int32_t width;       /* live diagonals of the wave, <= 62 (one 64-lane wavefront)        */
     int32_t kmer_mod;    /* -%  modimer sampling: only k-mers with hash % kmer_mod == 0; 1 = all     */

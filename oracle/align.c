@@ -360,6 +360,8 @@ static int seed_candidates(const oz_index *ix, const uint8_t *b, int32_t blen, i
         if (e == s || e - s > o->tcap) continue;
         for (int64_t t = s; t < e; t++) {
             if (o->skip_self == 1 && ix->e[t].aseq == bself) continue;
+            /* tandem (datander): a read against itself, below the main diagonal only (a > b) */
+            if (o->skip_self == 3 && (ix->e[t].aseq != bself || ix->e[t].apos - q < 1)) continue;
             /* symmetric: each unordered pair once; which read plays B alternates with the parity of
              * a + b so that every read is B for about half of its partners (balanced work) */
             if (o->skip_self == 2) {
@@ -722,10 +724,15 @@ static int extend(const uint8_t *ap, int astep, int32_t an, const uint8_t *bp, i
  * tp_first + m*ts for m < nbound(best i), diagonal excursion, cells (= band cells computed).
  */
 #define T2_WMAX 64
+/* tan (tandem mode, oz_opts.skip_self == 3: A' and B' are the same read): cells in which B's base is not BEFORE A's on
+ * the read never match -- the alignment of a read with itself stays below the main diagonal (datander reports the
+ * non-trivial self alignments; on the diagonal everything matches).  sd = seed diagonal as - bs > 0; forward (tan 1) a
+ * tile at (a0, b0) lies on the diagonal dd = sd + a0 - b0 and its rows i >= dd + W/2 are barred; backward (tan 2) the
+ * axes are mirrored: dd = sd - (a0 - b0), rows i <= W/2 - dd.  Rows past the end of B' stay wild (they are history). */
 static int extend_tiled(const uint8_t *ap, int astep, int32_t an, const uint8_t *bp, int bstep,
                         int32_t bn, int32_t tp_first, const oz_opts *o, int32_t *bi, int32_t *bj,
                         int32_t *bd_, int32_t *cd, int32_t *cj, int32_t *dlo, int32_t *dhi,
-                        int64_t *cells)
+                        int64_t *cells, int tan, int32_t sd)
 {
     const int32_t W = o->width, lo = -(W / 2), ts = o->tspace, pen = o->pen, xdrop = o->xdrop;
     int32_t a0 = 0, b0 = 0, dsum = 0, ntp = 0;
@@ -754,6 +761,10 @@ static int extend_tiled(const uint8_t *ap, int astep, int32_t an, const uint8_t 
                     eq = 0;
                 else if (j > bnr)
                     eq = 1;
+                else if (tan == 1 && i >= sd + (a0 - b0) + W / 2)
+                    eq = 0;
+                else if (tan == 2 && i <= W / 2 - (sd - (a0 - b0)))
+                    eq = 0;
                 else
                     eq = ach == bp[(int64_t)(b0 + j - 1) * bstep];
                 int32_t v = D[prv][i] + !eq;
@@ -889,10 +900,11 @@ static int local_align2(const uint8_t *a, int32_t alen, const uint8_t *b, int32_
             fprintf(stderr, "oracle: DH-2 has no symmetric mode\n");
             abort();
         }
+        const int tan = o->skip_self == 3;
         nf = extend_tiled(a + as, 1, alen - as, b + bs, 1, blen - bs, fwd_first, o, &fi, &fjv, &fdv, fd, fj,
-                          &flo, &fhi, cells);
+                          &flo, &fhi, cells, tan ? 1 : 0, as - bs);
         nr = extend_tiled(a + as - 1, -1, as, b + bs - 1, -1, bs, rev_first, o, &ri, &rjv, &rdv, rd, rj, &rlo,
-                          &rhi, cells);
+                          &rhi, cells, tan ? 2 : 0, as - bs);
     } else {
         nf = extend(a + as, 1, alen - as, b + bs, 1, blen - bs, fwd_first, fwdb_first, o, &fi, &fjv, &fdv, fd,
                     fj, fdb, fib, &nfb, &flo, &fhi, cells);
@@ -1083,6 +1095,7 @@ int oz_align_db2(const oz_db *A, const oz_db *B, const oz_opts *o, int nthreads,
                  int64_t *stats)
 {
     if (out2 && (o->algo != 1 || o->skip_self == 2)) return -1; /* the transposed file is defined for DH-2 mappings */
+    if (o->skip_self == 3 && (o->algo != 1 || o->strands != 1)) return -1; /* tandem: DH-2, forward strand (A and B: the same DB) */
     int32_t max_blen = 0, max_alen = 0;
     for (int32_t r = 0; r < B->n; r++) {
         int32_t l = (int32_t)(B->off[r + 1] - B->off[r]);

@@ -72,7 +72,9 @@ typedef struct {
     int32_t skip_self;   /* A and B are the same DB: 1 = skip aread == bread (no -I);
                           * 2 = symmetric: every unordered pair is aligned once (the smaller id
                           *     is A when a + b is even, else B) and both records (a,b), (b,a)
-                          *     are emitted from that alignment */
+                          *     are emitted from that alignment;
+                          * 3 = tandem (datander): a read is aligned with ITSELF only, below the main diagonal (seeds
+                          *     with a > b; cells with b >= a never match).  DH-2 (algo 1), forward strand (strands 1) */
     int32_t dmax;        /* hard cap on differences per extension                          */
     int32_t width;       /* max live diagonals of the wave (64 = one wavefront)            */
     int32_t kmer_mod;    /* modimer sampling (daligner -%): only k-mers with hash % kmer_mod == 0, 1 = all */

@@ -89,3 +89,36 @@ def plant_gap_insertions(w, rng, ln=1500):
             planted.append(i)
             break
     return sim.SeqDb.from_list(seqs), planted
+
+
+def tandem_reads(seed=7, n=12):
+    """Random reads, two of three with a tandem array planted: a unit of 24 .. 900 bases repeated so that the array spans
+    at least 700 bases, every copy with 8 % errors.  Returns (SeqDb, [(read, array begin, array end, period)])."""
+    from dentist_amd import sim
+    rng = np.random.default_rng(seed)
+
+    def mutate(u, err):
+        out = []
+        for b in u:
+            x = rng.random()
+            if x < err / 3:
+                continue
+            if x < 2 * err / 3:
+                out.append(int(rng.integers(0, 4)))
+            out.append(int(b) if x >= err else int(rng.integers(0, 4)))
+        return np.array(out, dtype=np.uint8)
+    seqs, truth = [], []
+    periods = [24, 150, 400, 900, 60]
+    for i in range(n):
+        ln = int(rng.integers(6000, 12000))
+        s = rng.integers(0, 4, ln).astype(np.uint8)
+        if i % 3 != 2:
+            per = periods[len(truth) % len(periods)]
+            copies = max(int(rng.integers(4, 12)), 700 // per + 2)
+            unit = rng.integers(0, 4, per).astype(np.uint8)
+            arr = np.concatenate([mutate(unit, 0.08) for _ in range(copies)])
+            at = int(rng.integers(1000, ln - 1000))
+            s = np.concatenate([s[:at], arr, s[at:]])
+            truth.append((i, at, at + len(arr), per))
+        seqs.append(s)
+    return sim.SeqDb.from_list(seqs), truth

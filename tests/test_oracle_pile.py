@@ -124,3 +124,28 @@ def test_c_and_python_drivers_agree_below_the_default_min_relative_score():
         extra += int(((e["chained_las"]["flags"] & 0x20) == 0).sum()) - int(((e1["chained_las"]["flags"] & 0x20) == 0).sum())
         assert np.array_equal(bases[r["cons_off"]:r["cons_off"] + r["cons_len"]], e["consensus"])
     assert closed >= 1 and extra > 0   # (the lower threshold keeps more records)
+
+
+def test_tandem_self_alignments_of_the_oracle():
+    """oz_opts.skip_self = 3 (the role of `datander <block>`, DAMASKER; DENTIST's call commandline.d:2866-2876): a read against
+    itself, below the main diagonal.  Every planted tandem array is found -- records with aread == bread, A after B, on a
+    diagonal that is a multiple of the period, inside the array -- also the one whose period (24) is smaller than half the
+    band of DH-2: the rule that B's base must come before A's keeps the extension off the main diagonal, where everything
+    matches.  Reads without an array give no record."""
+    from helpers import tandem_reads
+    db, truth = tandem_reads()
+    o = oz.default_opts(skip_self=3, strands=1, algo=1, width=64, k=12, band_shift=4, min_len=500, tspace=126)
+    las, tr, _ = oz.align_db(db, db, o, nthreads=4)
+    assert len(las) > 0 and (las["aread"] == las["bread"]).all() and (las["abpos"] > las["bbpos"]).all()
+    assert (las["flags"] & 1 == 0).all()
+    planted = {t[0]: t for t in truth}
+    assert set(las["aread"].tolist()) == set(planted)
+    for la in las:
+        _, b, e, per = planted[int(la["aread"])]
+        d0, d1 = int(la["abpos"] - la["bbpos"]), int(la["aepos"] - la["bepos"])
+        assert b - 60 <= la["bbpos"] and la["aepos"] <= e + 60
+        m = max(1, round(d0 / per))
+        assert abs(d0 - m * per) <= 0.15 * m * per + 8 and abs(d1 - m * per) <= 0.15 * m * per + 8
+    for t in truth:   # the first off-diagonal (one period) covers the array but for its first copy
+        mine = las[las["aread"] == t[0]]
+        assert (mine["aepos"] - mine["bbpos"]).max() >= 0.8 * (t[2] - t[1])

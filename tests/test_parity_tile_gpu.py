@@ -10,7 +10,7 @@ import pytest
 
 import dentist_amd
 from dentist_amd import sim
-from helpers import assert_same_las, check_trace_invariants
+from helpers import assert_same_las, check_trace_invariants, tandem_reads
 from oracle import pyoracle as oz
 from test_parity_map_gpu import run_both
 
@@ -102,6 +102,30 @@ def test_symmetric_all_vs_all(gpu_ctx, seed, grouped):
     assert len(las) > reads.n and not np.any(las["aread"] == las["bread"])
     key = set(zip(las["aread"].tolist(), las["bread"].tolist(), (las["flags"] & 1).tolist()))
     assert all((b, a, c) in key for a, b, c in key)
+
+
+def test_tandem_self_alignments(gpu_ctx):
+    """skip_self = 3 (`datander <block>`, DAMASKER; DENTIST's call commandline.d:2866-2876, Snakefile:1056-1076): every read
+    against itself, below the main diagonal -- seeds with A position > B position in the same read (k_seed), cells in which
+    B's base does not come before A's barred from matching (k_tile<TAN>: a row mask per tile).  Bit-exact against the
+    oracle: records, traces, counters; the planted arrays are all found, also the one of period 24 (inside half a band of
+    the main diagonal)."""
+    db, truth = tandem_reads()
+    kw = dict(skip_self=3, strands=1, k=12, band_shift=4, min_len=500, tspace=126, **T)
+    las, trace = run_both(gpu_ctx, db, db, same=True, **kw)
+    assert len(las) > 0 and (las["aread"] == las["bread"]).all() and (las["abpos"] > las["bbpos"]).all()
+    assert set(las["aread"].tolist()) == {t[0] for t in truth}
+    for t in truth:
+        mine = las[las["aread"] == t[0]]
+        assert (mine["aepos"] - mine["bbpos"]).max() >= 0.8 * (t[2] - t[1])
+    # whole-DB call in chunks of two reads: the same bits
+    d = gpu_ctx.db(db)
+    g = dentist_amd.default_align_opts(**kw)
+    for bad in (dict(algo=0, width=30), dict(strands=3)):
+        with pytest.raises(dentist_amd.DhError):
+            gpu_ctx.align_db(d, d, dentist_amd.default_align_opts(**{**kw, **bad}))
+    with pytest.raises(dentist_amd.DhError):
+        gpu_ctx.align_db(d, gpu_ctx.db(db), g)     # two DBs
 
 
 def test_rejections(gpu_ctx):

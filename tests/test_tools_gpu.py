@@ -8,7 +8,7 @@ import pytest
 
 import dentist_amd
 from dentist_amd import sim
-from helpers import assert_same_las
+from helpers import assert_same_las, tandem_reads
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -107,6 +107,73 @@ def test_daligner_pile_up_call(gpu_ctx, tmp_path):
     exp = gpu_ctx.align_db(d, d, dentist_amd.default_align_opts(tspace=126, skip_self=2, max_la=64, max_cand=128))
     assert len(las) % 2 == 0 and len(las) > 0
     assert_same_las((las, trace), exp)
+
+
+def test_daligner_on_two_dbs_writes_both_files_from_one_pass(gpu_ctx, tmp_path):
+    """`daligner <flags> A B` without -A writes A.B.las and B.A.las (dazzler.d:6121-6140; the workflow's block pairs of the
+    self alignment, Snakefile:998-1022).  Both come out of one pass: the second file holds the transposed pair of every
+    alignment (dh_align_db_transposed, DH-2).  Files == library call; every pair of the first file has its transposed record."""
+    g = sim.genome(41, 30000)
+    ra, _ = sim.reads(42, g, 20, 5000)
+    rb, _ = sim.reads(43, g, 24, 5000)
+    pa, pb = str(tmp_path / "a.db"), str(tmp_path / "b.db")
+    for p, r in ((pa, ra), (pb, rb)):
+        dentist_amd.dazz_create_db(p, fasta_db(r))
+        dentist_amd.dazz_split(p, cutoff=0)
+    r = subprocess.run([os.path.join(ROOT, "tools", "daligner"), "-T1", "-s126", "-l500", "-e0.7", "a", "b"], cwd=tmp_path,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    ab, abt, _ = dentist_amd.las_read(str(tmp_path / "a.b.las"))
+    ba, bat, _ = dentist_amd.las_read(str(tmp_path / "b.a.las"))
+    A, B = gpu_ctx.db(ra), gpu_ctx.db(rb)
+    (el, et), (tl, tt) = gpu_ctx.align_db_transposed(A, B, dentist_amd.default_align_opts(tspace=126, min_len=500, algo=1, width=64))
+    assert_same_las((ab, abt), (el, et))
+    assert_same_las((ba, bat), (tl, tt))
+    assert len(ab) > 50 and len(ba) > 0.9 * len(ab)
+    pairs = set(zip(ba["bread"].tolist(), ba["aread"].tolist(), (ba["flags"] & 1).tolist()))
+    have = sum((a, b, c) in pairs for a, b, c in zip(ab["aread"].tolist(), ab["bread"].tolist(), (ab["flags"] & 1).tolist()))
+    assert have > 0.95 * len(ab)
+    # -A: the first file only
+    os.remove(tmp_path / "b.a.las")
+    r = subprocess.run([os.path.join(ROOT, "tools", "daligner"), "-A", "-T1", "-s126", "-l500", "-e0.7", "a", "b"], cwd=tmp_path,
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and not os.path.exists(tmp_path / "b.a.las")
+
+
+def test_datander_tanmask_sequence(gpu_ctx, tmp_path):
+    """The tandem-mask sequence of the workflow (snakemake/Snakefile:1056-1123): `datander -T<n> -s126 -l500 -e0.7 <dam>.<block>`
+    (commandline.d:2866-2876) writes TAN.<dam>.<block>.las, `TANmask` turns it into the block's `tan` track.  The file equals
+    the library call (dh_align_opts.skip_self = 3 with datander's own -k12 -w4), the mask covers every planted array and
+    nothing in the reads without one."""
+    db, truth = tandem_reads()
+    ref = str(tmp_path / "asm.dam")
+    dentist_amd.dazz_create_dam(ref, fasta_dam(db))
+    dentist_amd.dazz_split(ref, cutoff=20)
+    r = subprocess.run([os.path.join(ROOT, "tools", "datander"), "-T1", "-s126", "-l500", "-e0.7", "asm.1"],
+                       cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    las, trace, ts = dentist_amd.las_read(str(tmp_path / "TAN.asm.1.las"))
+    assert ts == 126 and len(las) > 0
+    d = gpu_ctx.db(db)
+    exp = gpu_ctx.align_db(d, d, dentist_amd.default_align_opts(skip_self=3, strands=1, k=12, band_shift=4, min_len=500,
+                                                                tspace=126, algo=1, width=64))
+    assert_same_las((las, trace), exp)
+    r = subprocess.run([os.path.join(ROOT, "tools", "TANmask"), "-v", "-ntan", ref, "TAN.asm.1.las"], cwd=tmp_path,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert os.path.exists(tmp_path / ".asm.1.tan.anno")       # the block's track; Catrack makes the DB's (Snakefile:1111-1123)
+    r = subprocess.run([os.path.join(ROOT, "tools", "Catrack"), "-v", ref, "tan"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    ptr, iv = dentist_amd.DazzDb(ref).read_mask("tan")
+    planted = {t[0]: t for t in truth}
+    for i in range(db.n):
+        ivs = [tuple(iv[2 * x:2 * x + 2]) for x in range(ptr[i], ptr[i + 1])]
+        if i not in planted:
+            assert ivs == []
+            continue
+        _, b, e, _ = planted[i]
+        covered = sum(min(y, e) - max(x, b) for x, y in ivs if min(y, e) > max(x, b))
+        assert covered >= 0.9 * (e - b) and all(b - 80 <= x and y <= e + 80 for x, y in ivs)
 
 
 def tool(name, *args, cwd=None, stdin=None):

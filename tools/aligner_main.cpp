@@ -1,11 +1,11 @@
-// aligner_main.cpp -- drop-in `daligner` / `damapper` executables over libdentist_hip.so.
+// aligner_main.cpp -- drop-in `daligner` / `damapper` / `datander` executables over libdentist_hip.so.
 //
 // DENTIST spawns these tools by name with cwd = output directory and absolute (or stub) DB
 // arguments and then expects `<A>.<B>.las` next to it (source/dentist/dazzler.d:6121-6170,
 // getLasFile :4339-4354; literal instance tests/test-commands.sh:190-197).  The flag subset DENTIST
 // emits is parsed (source/dentist/commandline.d:2886-2955); -m<track> loads the
 // mask files DENTIST writes (dazzler.d:4870-5170) and excludes masked k-mers from seeding.  The mode is chosen
-// by argv[0] (daligner | damapper) or `--mode`.
+// by argv[0] (daligner | damapper | datander) or `--mode`.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -127,7 +127,7 @@ int main(int argc, char **argv)
     if (slash != std::string::npos) mode = mode.substr(slash + 1);
     dh_align_opts o;
     dh_default_align_opts(&o);
-    bool flagA = false, flagI = false, flagC = false, verbose = false;
+    bool flagA = false, flagI = false, flagC = false, verbose = false, seen_k = false, seen_w = false;
     double e = 0.7, near_best = 1.0;  // damapper's own -n default is 1.00 (best chains only); DENTIST always passes -n.7
     std::vector<std::string> dbs, tracks;
     for (int i = 1; i < argc; i++) {
@@ -142,8 +142,8 @@ int main(int argc, char **argv)
         }
         const char *v = a.c_str() + 2;
         switch (a[1]) {
-        case 'k': o.k = atoi(v); break;
-        case 'w': o.band_shift = atoi(v); break;
+        case 'k': o.k = atoi(v); seen_k = true; break;
+        case 'w': o.band_shift = atoi(v); seen_w = true; break;
         case 'h': o.hmin = atoi(v); break;
         case 't': o.tcap = atoi(v); break;
         case 's': o.tspace = atoi(v); break;
@@ -164,11 +164,15 @@ int main(int argc, char **argv)
         default: die(mode + ": unknown option " + a);
         }
     }
-    if (dbs.size() < 2) die("usage: " + mode + " [-k -w -h -t -s -l -e -A -I -C -T -m...] <subject:db|dam> <target:db|dam> ...");
+    if (mode.find("datander") != std::string::npos) {
+        if (dbs.empty()) die("usage: datander [-v] [-k<int(12)>] [-w<int(4)>] [-h<int(35)>] [-T<int(4)>] [-P<dir>] [-e<double(.70)>] [-l<int(500)>] [-s<int(100)>] <path:db|dam> ...");
+    } else if (dbs.size() < 2)
+        die("usage: " + mode + " [-k -w -h -t -s -l -e -A -I -C -T -m...] <subject:db|dam> <target:db|dam> ...");
     if (e <= 0.5 || e >= 1.0) die(mode + ": -e must be in (0.5, 1)");
     o.pen = (int)floor(2.0 / (1.0 - e));
     o.max_err_ppm = (int)llround((1.0 - e) * 1e6);
     const bool mapper = mode.find("damapper") != std::string::npos;
+    const bool tander = mode.find("datander") != std::string::npos;
     if (mapper && o.min_len == 500 && o.tspace == 100) o.min_len = 500;
     if (mapper) {
         // damapper: the tiled band extension (one alignment per lane) and chains with the -n near-best rule
@@ -179,6 +183,29 @@ int main(int argc, char **argv)
 
     dh_ctx *ctx = nullptr;
     CHK(dh_ctx_create(0, nullptr, &ctx));
+    if (tander) {
+        // datander <block> ...: every read of a block against ITSELF, the local alignments off the main diagonal (tandem
+        // repeats) -> TAN.<block>.las (DAMASKER; DENTIST's call: `datander -T<n> -s126 -l500 -e0.7 <dam>.<block>`,
+        // commandline.d:2866-2876, snakemake/Snakefile:1056-1076; TANmask reads the file).  Its own defaults: -k12 -w4 -h35.
+        if (!seen_k) o.k = 12;
+        if (!seen_w) o.band_shift = 4;
+        o.algo = 1;
+        o.width = 64;
+        o.strands = 1;
+        o.skip_self = 3;
+        for (const std::string &arg : dbs) {
+            OpenDb A = open_db(ctx, arg, tracks);
+            dh_la_set *set = nullptr;
+            CHK(dh_align_db(ctx, A.dev, A.dev, &o, 0, &set));
+            write_las("TAN." + A.name + ".las", set, dh_dazz_first_id(A.dz), dh_dazz_first_id(A.dz), o.tspace);
+            if (verbose) fprintf(stderr, "datander: %lld local alignments -> TAN.%s.las\n", (long long)dh_la_set_count(set), A.name.c_str());
+            dh_la_set_destroy(set);
+            dh_db_destroy(A.dev);
+            dh_dazz_close(A.dz);
+        }
+        dh_ctx_destroy(ctx);
+        return 0;
+    }
     if (mapper) CHK(dh_ctx_set_near_best(ctx, (int32_t)llround(near_best * 1e6)));
     OpenDb A = open_db(ctx, dbs[0], tracks);
     for (size_t bi = 1; bi < dbs.size(); bi++) {
@@ -193,17 +220,22 @@ int main(int argc, char **argv)
             oo.max_cand = std::max(oo.max_cand, 128);
         }
         dh_la_set *ab = nullptr, *ba = nullptr;
-        // damapper -C: the transposed file comes out of the same pass (the transposed pair of every alignment, through
-        // its seed); daligner without -A aligns the DBs in exchanged roles for its second file
-        const bool transposed = !same && mapper && flagC;
+        // damapper -C, and daligner on two DBs without -A (which writes A.B.las and B.A.las, dazzler.d:6121-6140; the
+        // workflow's block pairs `daligner -I ... ref.i ref.j`, Snakefile:998-1022): the second file comes out of the same
+        // pass -- the transposed pair of every alignment, through its seed (dh_align_db_transposed; DH-2, the tiled band)
+        const bool both = !same && !mapper && !flagA;
+        if (both) {
+            oo.algo = 1;
+            oo.width = 64;
+        }
+        const bool transposed = !same && ((mapper && flagC) || both);
         if (transposed)
-            CHK(dh_align_db_transposed(ctx, A.dev, B.dev, &oo, 1, &ab, &ba));
+            CHK(dh_align_db_transposed(ctx, A.dev, B.dev, &oo, mapper ? 1 : 0, &ab, &ba));
         else
             CHK(dh_align_db(ctx, A.dev, B.dev, &oo, mapper ? 1 : 0, &ab));
         write_las(A.name + "." + B.name + ".las", ab, dh_dazz_first_id(A.dz), dh_dazz_first_id(B.dz), o.tspace);
         if (verbose) fprintf(stderr, "%s: %lld local alignments -> %s.%s.las\n", mode.c_str(), (long long)dh_la_set_count(ab), A.name.c_str(), B.name.c_str());
         dh_la_set_destroy(ab);
-        if (!same && !mapper && !flagA) CHK(dh_align_db(ctx, B.dev, A.dev, &oo, 0, &ba));
         if (ba) {
             write_las(B.name + "." + A.name + ".las", ba, dh_dazz_first_id(B.dz), dh_dazz_first_id(A.dz), o.tspace);
             dh_la_set_destroy(ba);
