@@ -114,6 +114,10 @@ def main():
                          "alignment per lane, k_tile), 0 = DH-1 (O(ND) wave, k_wave2)")
     ap.add_argument("--map-width", type=int, default=None,
                     help="DH-2: the band (64); DH-1: live diagonals of the wave (default 14: four alignments per wavefront)")
+    ap.add_argument("--band", type=int, choices=(64, 32), default=64,
+                    help="DH-2: rows of the band of every alignment stage (mapping, pile-up all-vs-all, re-alignment, flanks): 64, "
+                         "or 32 = the same recurrence on 32-bit vectors (half the instructions per column, +- 16 diagonals of "
+                         "drift per tile; bit-exact against the oracle at W = 32 as well)")
     ap.add_argument("--map-xdrop", type=int, default=60, help="score lag that trims the mapping waves")
     ap.add_argument("--process-algo", type=int, default=1,
                     help="alignments of the process stages (pile-up all-vs-all, re-alignment, flanks): 1 = DH-2, 0 = DH-1")
@@ -171,10 +175,11 @@ def main():
     A, B = ctx.db(w.contigs), ctx.db(w.reads)
     # mapping pass: damapper's k-mer length, modimer sampling 1/8 (--kmer-mod), every other option at its default
     if args.map_width is None:
-        args.map_width = 64 if args.map_algo == 1 else 14
+        args.map_width = args.band if args.map_algo == 1 else 14
     mopts = dentist_amd.default_align_opts(kmer_mod=args.kmer_mod, k=args.map_k, width=args.map_width,
                                            xdrop=args.map_xdrop, algo=args.map_algo)
-    popts = dentist_amd.default_process_opts(algo=args.process_algo)
+    band_kw = dict(width=32) if (args.band == 32 and args.process_algo == 1) else {}
+    popts = dentist_amd.default_process_opts(algo=args.process_algo, **band_kw)
     if args.max_reads is not None:
         popts.max_reads = args.max_reads
     if args.max_partners is not None:
@@ -269,11 +274,11 @@ def main():
                 r.pop(key, None)
         rmopts = dentist_amd.default_align_opts(kmer_mod=1, k=args.map_k, width=args.map_width,
                                                 xdrop=args.map_xdrop, algo=args.map_algo)
-        rpopts = dentist_amd.default_process_opts(algo=args.process_algo)
+        rpopts = dentist_amd.default_process_opts(algo=args.process_algo, **band_kw)
         rpopts.max_reads = 0
         ref_runs, ref_dt = timed_variant(rmopts, rpopts, args.ref_steps)
         if args.ref_partners > 0 and args.process_algo == 1:
-            cpopts = dentist_amd.default_process_opts(algo=args.process_algo)
+            cpopts = dentist_amd.default_process_opts(algo=args.process_algo, **band_kw)
             cpopts.max_reads = 0
             cpopts.max_partners = args.ref_partners
             cut_runs, cut_dt = timed_variant(rmopts, cpopts, args.ref_steps)
@@ -335,7 +340,7 @@ def main():
                        "pile_up_entries": int(last["info"].get("entries", 0)),
                        "process": {"algo": "DH-2 tiled band (k_tile)" if popts.algo == 1 else "DH-1 wave (k_wave2)",
                                    "max_reads_per_pile_up": popts.max_reads, "min_reads_per_pile_up": popts.min_reads,
-                                   "consensus_rounds": popts.rounds, "width": 64 if popts.algo == 1 else (popts.width or 30),
+                                   "consensus_rounds": popts.rounds, "width": (32 if popts.width == 32 else 64) if popts.algo == 1 else (popts.width or 30),
                                    "xdrop": 120, "tspace": popts.tspace_pile, "dust": popts.dust},
                        "parallelism": f"reads and gaps sharded over {world} GPU(s)",
                        "read_bp_total": read_all, "pile_ups": int(last["info"]["piles"]),
@@ -483,7 +488,8 @@ def cpu_baseline(w, last, mopts, popts, args, gap_bases, read_bp_total):
 
     rec, las_all = last["rec"], last["las"]
     npiles = int(last["info"]["piles"])
-    po = oz.default_process_opts(rounds=popts.rounds, max_reads=popts.max_reads, min_reads=popts.min_reads, algo=popts.algo)
+    po = oz.default_process_opts(rounds=popts.rounds, max_reads=popts.max_reads, min_reads=popts.min_reads, algo=popts.algo,
+                                 **(dict(width=32) if (popts.algo == 1 and popts.width == 32) else {}))
     gaps_sorted = [int(r["contig_left"]) for r in rec]
     budget, batch = 0.5 * args.cpu_seconds, max(cores, 8)   # a pile-up per OpenMP thread and batch
     done, t_proc, used = 0, 0.0, 0

@@ -1262,7 +1262,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     if (o.algo != 0 && o.algo != 1) return fail(DH_EINVAL, "algo must be 0 (DH-1, wave) or 1 (DH-2, tiled band)");
     const bool tiled = o.algo == 1;
     if (tiled) {
-        if (o.width != dhtile::W) return fail(DH_EINVAL, "algo 1 (DH-2): width is the band, it must be 64");
+        if (o.width != 64 && o.width != 32) return fail(DH_EINVAL, "algo 1 (DH-2): width is the band, it must be 64 or 32");
         if (o.tspace > dhtile::TS_MAX) return fail(DH_EINVAL, "algo 1 (DH-2): tspace must be <= 128");
     } else if (o.width < 1 || o.width > 62)
         return fail(DH_EINVAL, "width must be in [1, 62]");

@@ -1729,7 +1729,11 @@ extern "C" int dh_process_pileups_masked(dh_ctx *ctx, dh_db *contigs, dh_db *rea
             }
             sts[(size_t)k] = g_pstats;
         });
-    rcs[0] = one(ctx, &part[0], &res[0]);
+    try {
+        rcs[0] = one(ctx, &part[0], &res[0]);
+    } catch (const std::exception &e) {  // (the workers must be joined whatever happens here; no exception crosses the C ABI)
+        rcs[0] = dh_fail(DH_EINVAL, std::string("dh_process_pileups: the first part of the batch failed: ") + e.what());
+    }
     for (std::thread &w : workers) w.join();
     // the other contexts' alignment statistics belong to this call (the streams' event times overlap: their sum
     // overstates the kernel time of the step, never understates it)
@@ -1743,7 +1747,7 @@ extern "C" int dh_process_pileups_masked(dh_ctx *ctx, dh_db *contigs, dh_db *rea
     for (int32_t k = 0; k < nparts; k++)
         if (rcs[(size_t)k]) {
             for (dh_insertions *r : res) dh_insertions_destroy(r);
-            if (k == 0) return rcs[0];
+            if (k == 0) return rcs[0];  // (its message is this thread's last error)
             return dh_fail(rcs[(size_t)k], msgs[(size_t)k].empty() ? "dh_process_pileups: a concurrent part of the batch failed" : msgs[(size_t)k]);
         }
     for (int32_t k = 1; k < nparts; k++) {
@@ -1854,7 +1858,7 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
     if (pwidth < 1 || pwidth > 62) return dh_fail(DH_EINVAL, "process: width must be in [1, 62]");
     if (o.algo != 0 && o.algo != 1) return dh_fail(DH_EINVAL, "process: algo must be 0 (DH-1) or 1 (DH-2)");
     const int32_t palgo = o.algo;
-    if (palgo == 1) pwidth = 64;  // DH-2: the band
+    if (palgo == 1) pwidth = o.width == 32 ? 32 : 64;  // DH-2: the band (64 rows; dh_process_opts.width = 32 asks for the narrow one)
 
     // ---- 1. the pile-up DB: the cropped reads of every pile-up that is large enough, grouped by
     // pile-up (group = index among the active pile-ups)

@@ -26,9 +26,19 @@
 
 namespace dhtile {
 
-constexpr int W = 64;        // band rows = bits of one vector
+constexpr int W = 64;        // band rows = bits of one vector (the default band; a band of 32 rows runs on 32-bit vectors:
+                             // half the instructions per column, +- 16 diagonals of drift per tile instead of +- 32)
 constexpr int TS_MAX = 128;  // longest tile (trace spacing) the per-tile buffers hold
 constexpr int NQ = 7;        // plane words of a tile: window bits [0, 224) >= (TS_MAX - 1) + 64 + 31
+template <int WB> struct BandVec;
+template <> struct BandVec<64> {
+    typedef uint64_t U;
+    typedef int64_t S;
+};
+template <> struct BandVec<32> {
+    typedef uint32_t U;
+    typedef int32_t S;
+};
 constexpr int NAW = 9;       // raw packed-A words of a tile: 2 * TS_MAX bits + 30 bits of misalignment
 constexpr int MAXREG = 64;   // aligned regions remembered per (read, strand) item (as DH-1)
 constexpr int REGF = 8;      // ints per region (7 used)
@@ -148,11 +158,13 @@ struct Lane {
 };
 
 // the tile in flight
-struct Tile {
-    uint64_t Pv, Mv, lv, wild;
-    uint64_t dm;  // tandem mode only: the rows of the band that may match (B's base before A's on the read)
+template <int WB>
+struct TileT {
+    typename BandVec<WB>::U Pv, Mv, lv, wild;
+    typename BandVec<WB>::U dm;  // tandem mode only: the rows of the band that may match (B's base before A's on the read)
     int32_t z, dbot, cols, bnr, T;
 };
+typedef TileT<64> Tile;
 // the sequence words of a tile, NTW dwords per lane (registers on the host, LDS on the device):
 //   [0, NQ)        low-bit plane of B': bit x of the 224-bit string = B'[b0 - 32 + x]
 //   [NQ, 2 NQ)     high-bit plane
@@ -196,32 +208,35 @@ DH_HD void ext_begin(Lane &l, const Params &P, int32_t dir)
     l.st = (e.an > 0 && e.bn > 0) ? L_RUN : L_EXT_END;
 }
 
-DH_HD void tile_setup(const Lane &l, const Params &P, Tile &t, uint32_t *q)
+template <int WB>
+DH_HD void tile_setup(const Lane &l, const Params &P, TileT<WB> &t, uint32_t *q)
 {
+    typedef typename BandVec<WB>::U V;
+    constexpr int W = WB;
     const Ext &e = l.e;
     t.T = e.ntp == 0 ? e.tp_first : P.o.tspace;
     const int32_t anr = e.an - e.a0;
     t.bnr = e.bn - e.b0;
     t.cols = t.T < anr ? t.T : anr;
     // column 0: D[0][j] = |j| for the band rows j = i - W/2; vectors aligned for column 1
-    t.Pv = ~0ull << (W / 2);
-    t.Mv = ~t.Pv;
+    t.Pv = (V)(~(V)0 << (W / 2));
+    t.Mv = (V)~t.Pv;
     t.dbot = W / 2 - 1;
-    t.lv = ~0ull << (W / 2 + 1);  // rows j >= 1 of column 0
+    t.lv = (V)(~(V)0 << (W / 2 + 1));  // rows j >= 1 of column 0
     const int32_t th = t.bnr + W / 2 + 1;  // first bit of column 0 past the end of B'
-    t.wild = th >= 64 ? 0ull : ~0ull << th;
+    t.wild = th >= W ? (V)0 : (V)(~(V)0 << th);
     t.z = t.bnr - W / 2 + 1;
     // tandem mode (dh_align_opts.skip_self == 3, datander: A' and B' are the same read): a cell in which B's base is not
     // BEFORE A's on the read never matches, so that the alignment of a read with itself stays below the main diagonal.  Row
     // i of any column of the tile is base b = a + i - W/2 - delta with delta = (ga + a0) - (gb + b0) (read-relative), the (signed) distance
     // of the tile's origin from the main diagonal in the copies at hand: forward the rows i < delta + W/2 are allowed;
     // backward the copies are mirrored (delta < 0, B's base must come AFTER A's in them): the rows i > W/2 + delta.
-    t.dm = ~0ull;
+    t.dm = (V)~(V)0;
     if (P.tandem) {
         const int64_t delta = (e.ga - l.c->g_ao + e.a0) - (e.gb - l.c->g_bo + e.b0);
         const int64_t nlow = l.dir ? W / 2 + delta + 1 : delta + W / 2;
-        const uint64_t low = nlow <= 0 ? 0ull : (nlow >= 64 ? ~0ull : (1ull << nlow) - 1ull);
-        t.dm = l.dir ? ~low : low;
+        const V low = nlow <= 0 ? (V)0 : (nlow >= W ? (V)~(V)0 : (V)(((V)1 << nlow) - (V)1));
+        t.dm = l.dir ? (V)~low : low;
     }
     // B planes: bit x of the window string = base (gb + b0 - W/2 + x)
     {
@@ -252,38 +267,49 @@ DH_HD void tile_setup(const Lane &l, const Params &P, Tile &t, uint32_t *q)
 
 // one column of the band: c = 1 .. cols.  (p0, p1) = plane windows of the column: bit i = low / high bit
 // of base B'[b0 + c + i - W/2 - 1], the base a path consumes to reach row i of the column; x = A'[a0 + c - 1]
-template <bool TAN = false>
-DH_HD void tile_col(Tile &t, uint64_t p0, uint64_t p1, uint32_t x)
+template <bool TAN = false, int WB = 64>
+DH_HD void tile_col(TileT<WB> &t, typename BandVec<WB>::U p0, typename BandVec<WB>::U p1, uint32_t x)
 {
-    const uint64_t x0 = 0ull - (uint64_t)(x & 1u), x1 = 0ull - (uint64_t)((x >> 1) & 1u);
+    typedef typename BandVec<WB>::U V;
+    typedef typename BandVec<WB>::S SV;
+    const V x0 = (V)0 - (V)(x & 1u), x1 = (V)0 - (V)((x >> 1) & 1u);
     // rows before the tile's origin never match (lv), rows past the end of B' match everything (wild)
-    t.lv = (uint64_t)((int64_t)t.lv >> 1);
+    t.lv = (V)((SV)t.lv >> 1);
     t.z -= 1;
-    t.wild = (uint64_t)((int64_t)t.wild >> 1) | ((uint64_t)((uint32_t)t.z & 0x80000000u) << 32);
-    const uint64_t Eq = (~((p0 ^ x0) | (p1 ^ x1)) & (TAN ? t.lv & t.dm : t.lv)) | t.wild;
-    const uint64_t Pv = t.Pv, Mv = t.Mv;
-    const uint64_t D0 = (((Eq & Pv) + Pv) ^ Pv) | Eq | Mv;
-    const uint64_t HP = Mv | ~(D0 | Pv), HN = Pv & D0;
-    const uint64_t Xv = D0 >> 1;
-    t.Pv = HN | ~(Xv | HP);
-    t.Mv = HP & Xv;
-    t.dbot += 1 - (int32_t)(D0 >> 63);
+    t.wild = (V)((V)((SV)t.wild >> 1) | (V)((V)((uint32_t)t.z >> 31) << (WB - 1)));
+    const V Eq = (V)(((V)~((p0 ^ x0) | (p1 ^ x1)) & (TAN ? (V)(t.lv & t.dm) : t.lv)) | t.wild);
+    const V Pv = t.Pv, Mv = t.Mv;
+    const V D0 = (V)((((V)((V)(Eq & Pv) + Pv)) ^ Pv) | Eq | Mv);
+    const V HP = (V)(Mv | (V)~(D0 | Pv)), HN = (V)(Pv & D0);
+    const V Xv = (V)(D0 >> 1);
+    t.Pv = (V)(HN | (V)~(Xv | HP));
+    t.Mv = (V)(HP & Xv);
+    t.dbot += 1 - (int32_t)(D0 >> (WB - 1));
 }
 
 // the columns of a tile in sequence (host; the device kernel runs the same steps in lock step)
-DH_HD void tile_window(const uint32_t *q, int32_t c, uint64_t &p0, uint64_t &p1, uint32_t &x)
+template <int WB = 64>
+DH_HD void tile_window(const uint32_t *q, int32_t c, typename BandVec<WB>::U &p0, typename BandVec<WB>::U &p1, uint32_t &x)
 {
+    typedef typename BandVec<WB>::U V;
     const int32_t cm = c - 1, k = cm >> 5;
     const uint32_t sh = (uint32_t)(cm & 31);
     const uint32_t *q0 = q, *q1 = q + NQ, *aw = q + 2 * NQ;
-    p0 = (uint64_t)funnel(q0[k + 1], q0[k], sh) | ((uint64_t)funnel(q0[k + 2], q0[k + 1], sh) << 32);
-    p1 = (uint64_t)funnel(q1[k + 1], q1[k], sh) | ((uint64_t)funnel(q1[k + 2], q1[k + 1], sh) << 32);
+    if (WB == 64) {
+        p0 = (V)((uint64_t)funnel(q0[k + 1], q0[k], sh) | ((uint64_t)funnel(q0[k + 2], q0[k + 1], sh) << 32));
+        p1 = (V)((uint64_t)funnel(q1[k + 1], q1[k], sh) | ((uint64_t)funnel(q1[k + 2], q1[k + 1], sh) << 32));
+    } else {
+        p0 = (V)funnel(q0[k + 1], q0[k], sh);
+        p1 = (V)funnel(q1[k + 1], q1[k], sh);
+    }
     x = (aw[cm >> 4] >> ((cm & 15) << 1)) & 3u;
 }
 
 // the last column: the row to go on from / to end at.  Returns the key (D << 16 | |row - diagonal| << 8 | W-1-i)
-DH_HD uint32_t tile_scan(const Tile &t)
+template <int WB>
+DH_HD uint32_t tile_scan(const TileT<WB> &t)
 {
+    constexpr int W = WB;
     // eligible rows: j = cols - W/2 + i >= 0 and j - bnr <= cols
     const int32_t imin = W / 2 - t.cols, imax = t.bnr + W / 2;
     uint32_t key = 0xFFFFFFFFu;
@@ -313,8 +339,10 @@ DH_HD void store_pair(uint16_t *pairs, int32_t pidx, uint32_t d, uint32_t b)
 #endif
 }
 
-DH_HD void tile_end(Lane &l, const Params &P, const Tile &t)
+template <int WB>
+DH_HD void tile_end(Lane &l, const Params &P, const TileT<WB> &t)
 {
+    constexpr int W = WB;
     Ext &e = l.e;
     uint16_t *pairs = e.pairs;
     const int32_t ts = P.o.tspace, pen = P.o.pen, nbmax = P.nbmax;

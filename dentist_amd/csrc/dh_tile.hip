@@ -58,7 +58,7 @@ extern "C" void dhk_tile_prof_dump()
 #define TPC(i, v)
 #endif
 
-template <bool TAN>
+template <bool TAN, int WB>
 __global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
 {
     __shared__ uint32_t s_q[NTW][64];
@@ -72,7 +72,8 @@ __global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
 #ifdef DH_SEED_PROF
     for (int i = 0; i < 6; i++) l.pt[i] = 0;
 #endif
-    Tile t;
+    TileT<WB> t;
+    typedef typename BandVec<WB>::U V;
     for (;;) {
         // ---- bookkeeping until every lane extends or is out of work.  A pass costs a handful of dependent memory
         // round trips whatever the number of lanes in it, so it waits until P.book_min lanes want one (or nothing
@@ -134,17 +135,23 @@ __global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
         const int32_t cmax = wave_max_i32(run ? t.cols : 0);
         TP(1)
         for (int32_t blk = 0; 32 * blk < cmax; blk++) {
-            const uint32_t a0 = s_q[blk][threadIdx.x], a1 = s_q[blk + 1][threadIdx.x], a2 = s_q[blk + 2][threadIdx.x];
-            const uint32_t b0 = s_q[NQ + blk][threadIdx.x], b1 = s_q[NQ + blk + 1][threadIdx.x], b2 = s_q[NQ + blk + 2][threadIdx.x];
+            const uint32_t a0 = s_q[blk][threadIdx.x], a1 = s_q[blk + 1][threadIdx.x], a2 = WB == 64 ? s_q[blk + 2][threadIdx.x] : 0u;
+            const uint32_t b0 = s_q[NQ + blk][threadIdx.x], b1 = s_q[NQ + blk + 1][threadIdx.x], b2 = WB == 64 ? s_q[NQ + blk + 2][threadIdx.x] : 0u;
             const uint64_t ab = (uint64_t)s_q[2 * NQ + 2 * blk][threadIdx.x] | ((uint64_t)s_q[2 * NQ + 2 * blk + 1][threadIdx.x] << 32);
             const int32_t nsh = cmax - 32 * blk < 32 ? cmax - 32 * blk : 32;
             for (int32_t sh = 0; sh < nsh; sh++) {
                 const int32_t c = 32 * blk + sh + 1;
                 if (run && c <= t.cols) {
-                    const uint64_t p0 = (uint64_t)funnel(a1, a0, (uint32_t)sh) | ((uint64_t)funnel(a2, a1, (uint32_t)sh) << 32);
-                    const uint64_t p1 = (uint64_t)funnel(b1, b0, (uint32_t)sh) | ((uint64_t)funnel(b2, b1, (uint32_t)sh) << 32);
+                    V p0, p1;
+                    if (WB == 64) {
+                        p0 = (V)((uint64_t)funnel(a1, a0, (uint32_t)sh) | ((uint64_t)funnel(a2, a1, (uint32_t)sh) << 32));
+                        p1 = (V)((uint64_t)funnel(b1, b0, (uint32_t)sh) | ((uint64_t)funnel(b2, b1, (uint32_t)sh) << 32));
+                    } else {
+                        p0 = (V)funnel(a1, a0, (uint32_t)sh);
+                        p1 = (V)funnel(b1, b0, (uint32_t)sh);
+                    }
                     const uint32_t x = (uint32_t)(ab >> (2 * sh)) & 3u;
-                    tile_col<TAN>(t, p0, p1, x);
+                    tile_col<TAN, WB>(t, p0, p1, x);
                 }
             }
         }
@@ -380,10 +387,16 @@ void dhk_compact_sym(hipStream_t st, const DhLa *slots, const uint16_t *tr_slots
 void dhk_tile(hipStream_t st, int32_t nwaves, const Params *P)
 {
     if (P->nitems <= 0 || nwaves <= 0) return;
-    if (P->tandem)
-        hipLaunchKernelGGL(k_tile<true>, dim3(nwaves), dim3(64), 0, st, *P);
+    // (band = dh_align_opts.width: 64 rows on 64-bit vectors, or 32 rows on 32-bit vectors)
+    if (P->o.width == 32) {
+        if (P->tandem)
+            hipLaunchKernelGGL((k_tile<true, 32>), dim3(nwaves), dim3(64), 0, st, *P);
+        else
+            hipLaunchKernelGGL((k_tile<false, 32>), dim3(nwaves), dim3(64), 0, st, *P);
+    } else if (P->tandem)
+        hipLaunchKernelGGL((k_tile<true, 64>), dim3(nwaves), dim3(64), 0, st, *P);
     else
-        hipLaunchKernelGGL(k_tile<false>, dim3(nwaves), dim3(64), 0, st, *P);
+        hipLaunchKernelGGL((k_tile<false, 64>), dim3(nwaves), dim3(64), 0, st, *P);
 }
 // resident wavefronts per CU the host launches: 12 of the 16 the registers allow measured best on configs[2]
 // (mapping pass 31.3 ms against 33.6 with 16: fewer lanes share the queue's tail and the caches)

@@ -483,7 +483,7 @@ static void set_opts(oz_opts *a, int32_t tspace, int32_t min_len, int32_t skip_s
     a->skip_self = skip_self;
     a->max_la = max_la;
     a->max_cand = max_cand;
-    a->width = algo == 1 ? 64 : width;
+    a->width = algo == 1 ? (width == 32 ? 32 : 64) : width; /* DH-2: the band, 64 rows unless 32 are asked for */
     a->algo = algo;
 }
 

@@ -219,17 +219,17 @@ def crop_pile(entries, las, trace, contigs, reads, g, ts_map=100, mask=None):
     return crops[0], (crops[1] if len(crops) > 1 else -1), SeqDb.from_list(seqs), ids, kinds
 
 
-def stage_width(algo):
-    """DH-2 (algo 1): the band of 64; DH-1: the product's default wave width."""
-    return 64 if algo == 1 else WAVE_WIDTH
+def stage_width(algo, band=64):
+    """DH-2 (algo 1): the band (64 rows, or 32 when dh_process_opts.width = 32); DH-1: the product's default wave width."""
+    return (32 if band == 32 else 64) if algo == 1 else WAVE_WIDTH
 
 
-def pile_opts(algo=0, nreads=0):
+def pile_opts(algo=0, nreads=0, band=64):
     # skip_self = 2: every unordered pair aligned once, both records emitted (what daligner does);
     # record slots / candidates per (read, strand) grow with the pile-up (a read overlaps every other read)
     max_la = 64 if nreads <= 60 else (128 if nreads <= 124 else 256)
     return oz.default_opts(tspace=TS_PILE, min_len=500, skip_self=2, max_la=max_la, max_cand=min(256, 2 * max_la),
-                           width=stage_width(algo), algo=algo)
+                           width=stage_width(algo, band), algo=algo)
 
 
 def filter_pile_las(las, pile, max_err_ppm=300000, allowance=TS_PILE, proper=True, min_rel_score=1.0):
@@ -364,7 +364,7 @@ def chain_pile_las(las, max_indel=1000, max_gap=10000, max_rel_overlap=0.3, min_
 
 
 def process_pile(entries, las, trace, contigs, reads, g, rounds=3, nthreads=1, flank_window=20000, dust=True, algo=0, mask=None,
-                 max_partners=0, min_rel_score=1.0):
+                 max_partners=0, min_rel_score=1.0, band=64):
     """One pile-up through the `process` sequence; returns a dict describing the insertion.  g: the left contig of a
     plain gap, or any join (contig0, seed0, contig1, seed1) -- see join_of."""
     res = {"gap": g, "status": "ok", "nreads": len(entries)}
@@ -382,7 +382,7 @@ def process_pile(entries, las, trace, contigs, reads, g, rounds=3, nthreads=1, f
     if pile.n < 3:
         res["status"] = "pile too small"
         return res
-    o = pile_opts(algo, pile.n)
+    o = pile_opts(algo, pile.n, band)
     if dust:   # DBdust pileup.db; daligner ... -mdust (package.d:476-482)
         pile = oz.with_dust(pile)
         res["pile"] = pile
@@ -424,7 +424,7 @@ def process_pile(entries, las, trace, contigs, reads, g, rounds=3, nthreads=1, f
     cons = oz.consensus(pile.seq(ref_idx), pile, plas, ptrace, ref_idx, TS_PILE)
     for _ in range(1, rounds):
         tdb = SeqDb.from_list([cons])
-        o2 = oz.default_opts(tspace=TS_PILE, min_len=500, max_la=4, max_cand=32, width=stage_width(algo), algo=algo)
+        o2 = oz.default_opts(tspace=TS_PILE, min_len=500, max_la=4, max_cand=32, width=stage_width(algo, band), algo=algo)
         rl, rt, _ = oz.align_db(tdb, pile, o2, nthreads=nthreads)
         for la in rl:   # proper overlaps only
             if not oz.valid_pileup_alignment({**{f: la[f] for f in la.dtype.names}, "aread": -1},
@@ -444,7 +444,7 @@ def process_pile(entries, las, trace, contigs, reads, g, rounds=3, nthreads=1, f
     fdb = SeqDb.from_list(slices)
     if dust:   # DBdust contigs.dam; daligner -A ... -mdust -mrep (package.d:631-667)
         fdb = oz.with_dust(fdb)
-    o3 = oz.default_opts(tspace=TS_PILE, min_len=126, max_la=4, max_cand=32, width=stage_width(algo), algo=algo)
+    o3 = oz.default_opts(tspace=TS_PILE, min_len=126, max_la=4, max_cand=32, width=stage_width(algo, band), algo=algo)
     fl_las, fl_tr, _ = oz.align_db(fdb, SeqDb.from_list([cons]), o3, nthreads=nthreads)
     res.update(flank_las=fl_las, flank_trace=fl_tr, flank_off=offs[0], flank_offs=offs)
     allow = TS_PILE

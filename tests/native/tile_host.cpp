@@ -37,6 +37,26 @@ static void revcomp_all(const uint8_t *src, const int64_t *off, int32_t n, std::
 // every item (read * 2 + strand) of B against its candidates; results compacted in item order.
 // out_la: capacity nitems * max_la; out_trace: capacity cap_trace u16; returns the number of records or < 0
 // out_la2 / out_trace2 / n2 (optional): the transposed records of the mapping (`damapper -C`), compacted in item order
+
+// one tile of the lane's running extension: set-up, the columns in sequence, the end of the tile
+template <int WB>
+static void run_tile(Lane &l, const Params &P)
+{
+    TileT<WB> t;
+    uint32_t q[NTW];
+    tile_setup<WB>(l, P, t, q);
+    for (int32_t c = 1; c <= t.cols; c++) {
+        typename BandVec<WB>::U p0, p1;
+        uint32_t x;
+        tile_window<WB>(q, c, p0, p1, x);
+        if (P.tandem)
+            tile_col<true, WB>(t, p0, p1, x);
+        else
+            tile_col<false, WB>(t, p0, p1, x);
+    }
+    tile_end<WB>(l, P, t);
+}
+
 extern "C" long dh_tile_host_align2(const uint8_t *abases, const int64_t *aoff, int32_t na, const uint8_t *bbases,
                                     const int64_t *boff, int32_t nb, const DhOpts *o, const DhCand *cand,
                                     const int32_t *ncand, int32_t nbmax, DhLa *out_la, uint16_t *out_trace,
@@ -114,7 +134,6 @@ extern "C" long dh_tile_host_align2(const uint8_t *abases, const int64_t *aoff, 
     memset(&cold, 0, sizeof(cold));
     P.cold = &cold;
     lane_init(l, 0, &cold);
-    Tile t;
     for (;;) {
         while (l.st != L_RUN && l.st != L_DONE) {
             if (l.st == L_EXT_END)
@@ -130,15 +149,10 @@ extern "C" long dh_tile_host_align2(const uint8_t *abases, const int64_t *aoff, 
             }
         }
         if (l.st == L_DONE) break;
-        uint32_t q[NTW];
-        tile_setup(l, P, t, q);
-        for (int32_t c = 1; c <= t.cols; c++) {
-            uint64_t p0, p1;
-            uint32_t x;
-            tile_window(q, c, p0, p1, x);
-            tile_col(t, p0, p1, x);
-        }
-        tile_end(l, P, t);
+        if (P.o.width == 32)
+            run_tile<32>(l, P);
+        else
+            run_tile<64>(l, P);
     }
     if (l.err) return -(long)l.err;
     counters[0] = l.cells;

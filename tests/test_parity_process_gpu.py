@@ -18,15 +18,15 @@ STATUS = {0: "ok", 1: "no common trace point", 2: "pile too small",
           3: "empty pileup alignment after filtering"}
 
 
-def run_case(ctx, w, rounds, algo=0, truth_slack=1.0):
-    """algo: 0 = DH-1 (waves) everywhere, 1 = DH-2 (tiled band) for the mapping and every process stage."""
-    g = dentist_amd.default_align_opts(**(dict(algo=1, width=64) if algo else {}))
+def run_case(ctx, w, rounds, algo=0, truth_slack=1.0, band=64):
+    """algo: 0 = DH-1 (waves) everywhere, 1 = DH-2 (tiled band) for the mapping and every process stage (band rows: 64 or 32)."""
+    g = dentist_amd.default_align_opts(**(dict(algo=1, width=band) if algo else {}))
     A, B = ctx.db(w.contigs), ctx.db(w.reads)
     las, trace = ctx.align_db(A, B, g)
     # the mapping LAs themselves are covered by test_parity_map_gpu; the oracle re-derives them
     olas, otrace, _ = oz.align_db(w.contigs, w.reads, oz.default_opts(width=g.width, algo=algo), nthreads=os.cpu_count() or 1)
     assert_same_las((las, trace), (olas, otrace))
-    po = dentist_amd.default_process_opts(rounds=rounds, algo=algo)
+    po = dentist_amd.default_process_opts(rounds=rounds, algo=algo, **(dict(width=32) if band == 32 else {}))
     piles = dentist_amd.Pileups(las, w.contigs.off, po)
     exp_piles = pr.collect_spanning(olas, otrace, w.contigs, w.reads)
     assert len(piles) == len(exp_piles) and len(piles) > 0
@@ -37,7 +37,7 @@ def run_case(ctx, w, rounds, algo=0, truth_slack=1.0):
         gap, tri = piles.get(i)
         assert [tuple(t) for t in tri.tolist()] == [tuple(int(x) for x in e) for e in exp_piles[gap]]
         exp = pr.process_pile(exp_piles[gap], olas, otrace, w.contigs, w.reads, gap, rounds=rounds,
-                              nthreads=os.cpu_count() or 1, algo=algo)
+                              nthreads=os.cpu_count() or 1, algo=algo, band=band)
         r = rec[i]
         assert r["contig_left"] == gap
         if exp["status"] != "ok":
@@ -85,6 +85,14 @@ def test_process_with_the_tiled_band_in_every_stage(gpu_ctx, rounds, seed):
     crop points, reference read, every consensus base and the splice coordinates equal the oracle's."""
     w = sim.Workload(400_000, 4, 1600, 6000, seed=seed, spacing=20000, gap_max=1200)
     rec = run_case(gpu_ctx, w, rounds, algo=1)
+    assert (rec["status"] == 0).sum() >= 3
+
+
+def test_process_with_the_band_of_32_rows(gpu_ctx):
+    """dh_process_opts.width = 32 with algo 1: pile-up all-vs-all, re-alignment to the template and flank alignment on the
+    narrow band (k_tile<., 32>); everything equals the oracle's restatement at W = 32."""
+    w = sim.Workload(400_000, 4, 1600, 6000, seed=17, spacing=20000, gap_max=1200)
+    rec = run_case(gpu_ctx, w, 3, algo=1, band=32)
     assert (rec["status"] == 0).sum() >= 3
 
 

@@ -128,12 +128,43 @@ def test_tandem_self_alignments(gpu_ctx):
         gpu_ctx.align_db(d, gpu_ctx.db(db), g)     # two DBs
 
 
+@pytest.mark.parametrize("case", ["mapping", "ragged", "symmetric", "tandem", "noisy"])
+def test_band_of_32_rows(gpu_ctx, case):
+    """dh_align_opts.width = 32 with algo 1: the band of DH-2 on 32-bit vectors (k_tile<., 32>: half the instructions per
+    column; the band re-centres at every tile boundary, so +- 16 diagonals of drift per tile are what it must hold).
+    Bit-exact against the oracle's plain DP at W = 32 in every mode the band of 64 is tested in."""
+    T32 = dict(algo=1, width=32)
+    if case == "mapping":
+        w = sim.Workload(1_000_000, 8, 3000, 10_000, seed=23)
+        las, _ = run_both(gpu_ctx, w.contigs, w.reads, k=20, kmer_mod=8, xdrop=60, **T32)
+        assert len(set(las["bread"].tolist())) >= 0.995 * w.reads.n
+    elif case == "noisy":
+        w = sim.Workload(250_000, 3, 250, 4000, seed=13, err=0.20, spacing=15000)
+        run_both(gpu_ctx, w.contigs, w.reads, tspace=126, **T32)
+    elif case == "ragged":
+        rng = np.random.default_rng(11)
+        g = rng.integers(0, 4, 6000).astype(np.uint8)
+        contigs = sim.SeqDb.from_list([g[:3000], g[3100:3160], g[3200:6000], g[100:140]])
+        reads = sim.SeqDb.from_list([g[2900:3000], g[2950:3160], g[0:3000], g[3150:3300], g[10:70], sim.revcomp(g[3300:5900]),
+                                     g[3100:3160], g[2990:3110], g[20:52]])
+        run_both(gpu_ctx, contigs, reads, k=12, hmin=20, min_len=20, **T32)
+    elif case == "symmetric":
+        g = sim.genome(21, 20000)
+        reads, _ = sim.reads(22, g, 30, 6000)
+        las, _ = run_both(gpu_ctx, reads, reads, same=True, tspace=126, skip_self=2, min_len=500, max_la=64, max_cand=128, **T32)
+        assert len(las) > reads.n
+    else:
+        db, truth = tandem_reads()
+        las, _ = run_both(gpu_ctx, db, db, same=True, skip_self=3, strands=1, k=12, band_shift=4, min_len=500, tspace=126, **T32)
+        assert set(las["aread"].tolist()) == {t[0] for t in truth}
+
+
 def test_rejections(gpu_ctx):
     """DH-2 has one band width, tiles of at most 128 columns, 2-bit sequences only."""
     rng = np.random.default_rng(5)
     g = rng.integers(0, 4, 4000).astype(np.uint8)
     db = gpu_ctx.db(sim.SeqDb.from_list([g, g[100:3000]]))
-    for kw in (dict(width=30), dict(tspace=200)):
+    for kw in (dict(width=30), dict(width=48), dict(tspace=200)):
         with pytest.raises(dentist_amd.DhError):
             gpu_ctx.align_db(db, db, dentist_amd.default_align_opts(**{**T, **kw}))
     gn = g.copy()

@@ -55,10 +55,13 @@ def run_host(L, A, B, o):
     dict(seed=5, tspace=100, err=0.20, xdrop=60),
     dict(seed=6, tspace=64, err=0.05),
     dict(seed=7, tspace=128, err=0.13, min_len=100),
+    dict(seed=3, tspace=100, err=0.13, width=32),      # the band of 32 rows (32-bit vectors)
+    dict(seed=5, tspace=126, err=0.20, xdrop=60, width=32),
+    dict(seed=8, tspace=128, err=0.13, min_len=100, width=32),
 ])
 def test_lane_state_machine_equals_oracle(host_lib, kw):
     w = sim.Workload(300_000, 4, 500, 5000, seed=kw["seed"], err=kw["err"], spacing=20000, gap_max=800)
-    o = oz.default_opts(algo=1, width=64, k=16, kmer_mod=2, tspace=kw["tspace"], xdrop=kw.get("xdrop", 120),
+    o = oz.default_opts(algo=1, width=kw.get("width", 64), k=16, kmer_mod=2, tspace=kw["tspace"], xdrop=kw.get("xdrop", 120),
                         min_len=kw.get("min_len", 500))
     exp_las, exp_trace, stats = oz.align_db(w.contigs, w.reads, o, nthreads=4, sort=False)
     las, trace, counters = run_host(host_lib, w.contigs, w.reads, o)
@@ -76,17 +79,18 @@ def test_short_and_ragged_inputs(host_lib):
     contigs = sim.SeqDb.from_list([g[:3000], g[3100:3160], g[3200:6000], g[100:140]])
     reads = [g[2900:3000], g[2950:3160], g[0:3000], g[3150:3300], g[10:70], sim.revcomp(g[3300:5900]), g[3100:3160],
              g[2990:3110], g[20:52]]
-    o = oz.default_opts(algo=1, width=64, k=12, hmin=20, min_len=20, tspace=100)
     B = sim.SeqDb.from_list(reads)
-    exp_las, exp_trace, _ = oz.align_db(contigs, B, o, nthreads=1, sort=False)
-    las, trace, _ = run_host(host_lib, contigs, B, o)
-    assert len(exp_las) >= 8
-    assert_same_las((las, trace), (exp_las, exp_trace))
-    check_trace_invariants(las, trace, 100)
+    for width in (64, 32):
+        o = oz.default_opts(algo=1, width=width, k=12, hmin=20, min_len=20, tspace=100)
+        exp_las, exp_trace, _ = oz.align_db(contigs, B, o, nthreads=1, sort=False)
+        las, trace, _ = run_host(host_lib, contigs, B, o)
+        assert len(exp_las) >= 8
+        assert_same_las((las, trace), (exp_las, exp_trace))
+        check_trace_invariants(las, trace, 100)
 
 
-@pytest.mark.parametrize("seed,grouped", [(21, False), (57, True)])
-def test_symmetric_all_vs_all(host_lib, seed, grouped):
+@pytest.mark.parametrize("seed,grouped,width", [(21, False, 64), (57, True, 64), (21, False, 32)])
+def test_symmetric_all_vs_all(host_lib, seed, grouped, width):
     """skip_self = 2 (the pile-up stage, daligner -s126 pile x pile): every unordered pair is seeded once;
     DH-2 then aligns the pair and, for the second record, the transposed pair through the same seed (trace
     on the other read's grid, both axes mirrored for complemented overlaps).  Records land in slots claimed
@@ -96,7 +100,7 @@ def test_symmetric_all_vs_all(host_lib, seed, grouped):
     reads, _ = sim.reads(seed + 1, g, 30, 6000)
     if grouped:
         reads = sim.SeqDb(reads.bases, reads.off, group=np.arange(reads.n) % 2)
-    o = oz.default_opts(algo=1, width=64, tspace=126, skip_self=2, min_len=500, max_la=64, max_cand=128)
+    o = oz.default_opts(algo=1, width=width, tspace=126, skip_self=2, min_len=500, max_la=64, max_cand=128)
     exp_las, exp_trace, stats = oz.align_db(reads, reads, o, nthreads=4, sort=False)
     las, trace, counters = run_host(host_lib, reads, reads, o)
     assert len(exp_las) > reads.n
@@ -104,7 +108,8 @@ def test_symmetric_all_vs_all(host_lib, seed, grouped):
     check_trace_invariants(las, trace, 126)
     assert int(counters[0]) == stats[3] and int(counters[1]) == stats[2]
     comp = las[(las["flags"] & 1) != 0]
-    assert len(comp) > 0 and len(las) % 2 == 0
+    # (the record of the transposed pair is accepted on its own length and error: a pair can lose one of its two)
+    assert len(comp) > 0 and (len(las) % 2 == 0 or width == 32)
 
 
 def test_transposed_records_of_a_mapping(host_lib):
