@@ -58,6 +58,37 @@ extern "C" void dhk_tile_prof_dump()
 #define TPC(i, v)
 #endif
 
+// The column step of dh_tile.h:tile_col as the kernel runs it -- the same recurrence, two instruction-count changes:
+//  * the A base arrives as the COMPLEMENTED packed word shifted to the column (nxw: bits 0..1 = ~base): one sign-extending
+//    bit-field extract per bit gives ~x0 / ~x1 as 32-bit masks that serve both halves of a 64-bit vector, and
+//    ~((p0 ^ x0) | (p1 ^ x1)) == (p0 ^ ~x0) & (p1 ^ ~x1)  (was: and, bfe, two moves, two 64-bit adds per column);
+//  * LV = false for the columns behind the first 32: the rows-before-the-origin mask lv = ~0 << (W/2 + 1 - c) is all
+//    ones from column W/2 + 1 on, so neither its shift nor the two ANDs are issued there.
+template <bool TAN, bool LV, int WB>
+__device__ __forceinline__ void tile_col_dev(TileT<WB> &t, typename BandVec<WB>::U p0, typename BandVec<WB>::U p1, uint32_t nxw)
+{
+    typedef typename BandVec<WB>::U V;
+    typedef typename BandVec<WB>::S SV;
+    const uint32_t n0 = (uint32_t)(((int32_t)(nxw << 31)) >> 31), n1 = (uint32_t)(((int32_t)(nxw << 30)) >> 31);
+    const V nx0 = WB == 64 ? (V)(((uint64_t)n0 << 32) | n0) : (V)n0, nx1 = WB == 64 ? (V)(((uint64_t)n1 << 32) | n1) : (V)n1;
+    V eq = (V)((p0 ^ nx0) & (p1 ^ nx1));
+    if (LV) {
+        t.lv = (V)((SV)t.lv >> 1);
+        eq &= t.lv;
+    }
+    if (TAN) eq &= t.dm;
+    t.z -= 1;
+    t.wild = (V)((V)((SV)t.wild >> 1) | (V)((V)((uint32_t)t.z >> 31) << (WB - 1)));
+    const V Eq = (V)(eq | t.wild);
+    const V Pv = t.Pv, Mv = t.Mv;
+    const V D0 = (V)((((V)((V)(Eq & Pv) + Pv)) ^ Pv) | Eq | Mv);
+    const V HP = (V)(Mv | (V)~(D0 | Pv)), HN = (V)(Pv & D0);
+    const V Xv = (V)(D0 >> 1);
+    t.Pv = (V)(HN | (V)~(Xv | HP));
+    t.Mv = (V)(HP & Xv);
+    t.dbot += 1 - (int32_t)(D0 >> (WB - 1));
+}
+
 template <bool TAN, int WB>
 __global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
 {
@@ -137,23 +168,30 @@ __global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
         for (int32_t blk = 0; 32 * blk < cmax; blk++) {
             const uint32_t a0 = s_q[blk][threadIdx.x], a1 = s_q[blk + 1][threadIdx.x], a2 = WB == 64 ? s_q[blk + 2][threadIdx.x] : 0u;
             const uint32_t b0 = s_q[NQ + blk][threadIdx.x], b1 = s_q[NQ + blk + 1][threadIdx.x], b2 = WB == 64 ? s_q[NQ + blk + 2][threadIdx.x] : 0u;
-            const uint64_t ab = (uint64_t)s_q[2 * NQ + 2 * blk][threadIdx.x] | ((uint64_t)s_q[2 * NQ + 2 * blk + 1][threadIdx.x] << 32);
+            // (complemented: tile_col_dev extracts ~x0 / ~x1)
+            const uint64_t nab = ~((uint64_t)s_q[2 * NQ + 2 * blk][threadIdx.x] | ((uint64_t)s_q[2 * NQ + 2 * blk + 1][threadIdx.x] << 32));
             const int32_t nsh = cmax - 32 * blk < 32 ? cmax - 32 * blk : 32;
-            for (int32_t sh = 0; sh < nsh; sh++) {
-                const int32_t c = 32 * blk + sh + 1;
-                if (run && c <= t.cols) {
-                    V p0, p1;
-                    if (WB == 64) {
-                        p0 = (V)((uint64_t)funnel(a1, a0, (uint32_t)sh) | ((uint64_t)funnel(a2, a1, (uint32_t)sh) << 32));
-                        p1 = (V)((uint64_t)funnel(b1, b0, (uint32_t)sh) | ((uint64_t)funnel(b2, b1, (uint32_t)sh) << 32));
-                    } else {
-                        p0 = (V)funnel(a1, a0, (uint32_t)sh);
-                        p1 = (V)funnel(b1, b0, (uint32_t)sh);
-                    }
-                    const uint32_t x = (uint32_t)(ab >> (2 * sh)) & 3u;
-                    tile_col<TAN, WB>(t, p0, p1, x);
-                }
+#define DH_TILE_COLUMNS(LV_)                                                                                                      \
+    for (int32_t sh = 0; sh < nsh; sh++) {                                                                                        \
+        const int32_t c = 32 * blk + sh + 1;                                                                                      \
+        if (run && c <= t.cols) {                                                                                                 \
+            V p0, p1;                                                                                                             \
+            if (WB == 64) {                                                                                                       \
+                p0 = (V)((uint64_t)funnel(a1, a0, (uint32_t)sh) | ((uint64_t)funnel(a2, a1, (uint32_t)sh) << 32));               \
+                p1 = (V)((uint64_t)funnel(b1, b0, (uint32_t)sh) | ((uint64_t)funnel(b2, b1, (uint32_t)sh) << 32));               \
+            } else {                                                                                                              \
+                p0 = (V)funnel(a1, a0, (uint32_t)sh);                                                                             \
+                p1 = (V)funnel(b1, b0, (uint32_t)sh);                                                                             \
+            }                                                                                                                     \
+            tile_col_dev<TAN, LV_, WB>(t, p0, p1, (uint32_t)(nab >> (2 * sh)));                                                   \
+        }                                                                                                                         \
+    }
+            if (blk == 0) {
+                DH_TILE_COLUMNS(true)
+            } else {
+                DH_TILE_COLUMNS(false)
             }
+#undef DH_TILE_COLUMNS
         }
         TP(2)
         if (run) tile_end(l, P, t);
