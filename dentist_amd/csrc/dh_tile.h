@@ -339,15 +339,15 @@ DH_HD void store_pair(uint16_t *pairs, int32_t pidx, uint32_t d, uint32_t b)
 #endif
 }
 
+// (key = tile_scan(t): the kernel passes the key of its own scan, dh_tile.hip:tile_scan_dev)
 template <int WB>
-DH_HD void tile_end(Lane &l, const Params &P, const TileT<WB> &t)
+DH_HD void tile_end_key(Lane &l, const Params &P, const TileT<WB> &t, const uint32_t key)
 {
     constexpr int W = WB;
     Ext &e = l.e;
     uint16_t *pairs = e.pairs;
     const int32_t ts = P.o.tspace, pen = P.o.pen, nbmax = P.nbmax;
     l.cells += (uint64_t)t.cols * W;
-    const uint32_t key = tile_scan(t);
     const int32_t ci = W - 1 - (int32_t)(key & 255u), dt = (int32_t)(key >> 16);
     const int32_t j = t.cols - W / 2 + ci, tw = j > t.bnr ? j - t.bnr : 0;
     // pair index of this tile in the candidate's slot: interval (floor(as / ts) +- ...) -> nbmax +- ...
@@ -410,6 +410,12 @@ DH_HD void tile_end(Lane &l, const Params &P, const TileT<WB> &t)
     }
     if (e.a0 >= e.an || e.b0 >= e.bn) l.st = L_EXT_END;
     (void)ts;
+}
+
+template <int WB>
+DH_HD void tile_end(Lane &l, const Params &P, const TileT<WB> &t)
+{
+    tile_end_key<WB>(l, P, t, tile_scan(t));
 }
 
 // ------------------------------------------------------------------------------ bookkeeping

@@ -89,6 +89,34 @@ __device__ __forceinline__ void tile_col_dev(TileT<WB> &t, typename BandVec<WB>:
     t.dbot += 1 - (int32_t)(D0 >> (WB - 1));
 }
 
+// The scan of the last column (dh_tile.h:tile_scan) as the kernel runs it: the same key -- min over the eligible rows of
+// D << 16 | |row - diagonal| << 8 | W-1-i -- without a branch per row: the eligible rows [imin, imax] as a bit mask whose
+// complement ORs ~0 into the keys of the others, the vertical deltas by bit-field extracts of compile-time positions
+// (7 instructions per row, no exec-mask round trip; was 11 and a branch).
+template <int WB>
+__device__ __forceinline__ uint32_t tile_scan_dev(const TileT<WB> &t)
+{
+    typedef typename BandVec<WB>::U V;
+    constexpr int W = WB;
+    const int32_t imin = W / 2 - t.cols, imax = t.bnr + W / 2;
+    const int32_t lo = imin > 0 ? imin : 0, hi = imax < W - 1 ? imax : W - 1;  // (lo <= W/2 - 1 <= hi: cols >= 1, bnr >= 0)
+    const V ne = (V) ~((V)((V)(~(V)0 << lo)) & (V)(~(V)0 >> (W - 1 - hi)));
+    uint32_t key = 0xFFFFFFFFu;
+    int32_t d = t.dbot;
+#pragma unroll
+    for (int i = W - 1; i >= 0; i--) {
+        const int sh = i & 31;
+        const uint32_t mw = (uint32_t)(WB == 64 && i >= 32 ? (uint64_t)t.Mv >> 32 : (uint64_t)t.Mv);
+        const uint32_t pw = (uint32_t)(WB == 64 && i >= 32 ? (uint64_t)t.Pv >> 32 : (uint64_t)t.Pv);
+        const uint32_t nw = (uint32_t)(WB == 64 && i >= 32 ? (uint64_t)ne >> 32 : (uint64_t)ne);
+        if (i < W - 1) d += (int32_t)((mw >> sh) & 1u) + (((int32_t)(pw << (31 - sh))) >> 31);
+        const uint32_t off = (uint32_t)(i >= W / 2 ? i - W / 2 : W / 2 - i);
+        const uint32_t kk = ((uint32_t)d << 16) | (off << 8) | (uint32_t)(W - 1 - i) | (uint32_t)(((int32_t)(nw << (31 - sh))) >> 31);
+        key = kk < key ? kk : key;
+    }
+    return key;
+}
+
 template <bool TAN, int WB>
 __global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
 {
@@ -194,7 +222,7 @@ __global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
 #undef DH_TILE_COLUMNS
         }
         TP(2)
-        if (run) tile_end(l, P, t);
+        if (run) tile_end_key<WB>(l, P, t, tile_scan_dev<WB>(t));
         TP(3)
     }
 #ifdef DH_SEED_PROF
