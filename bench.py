@@ -379,13 +379,13 @@ def main():
                               "avg_launch_ms": wave_ms / max(1, cum["wave_launches"]),
                               "algorithmic_bytes_per_step": alg_bytes,
                               "band_cells_per_s": cum["wave_cells"] / (wave_ms * 1e-3),
-                              # VALU issue: 74 wave-instructions per 64 lanes x 64 band cells (SQ_INSTS_VALU of the mapping
-                              # launches, profiles/r03_final_pmc_sq_counters.txt) against the measured ceiling of
+                              # VALU issue: 65 wave-instructions per 64 lanes x 64 band cells (SQ_INSTS_VALU of the mapping
+                              # launches, profiles/constants.json) against the measured ceiling of
                               # 0.57 G wave-instructions/s per SIMD (scripts/valu_probe.cpp), 1024 SIMDs
                               "valu_frac": (CONST["k_tile_valu_wave_instr_per_4096_cells"] * cum["wave_cells"] / 4096.0) /
                                            (wave_ms * 1e-3) / (CONST["simds"] * CONST["valu_wave_instr_per_s_per_simd"]),
-                              "note": "rank 0's launches; integer VALU-issue bound: 70 wave-instructions per 64 band "
-                                      "columns, DP cell updates/s is the honest secondary"},
+                              "note": "rank 0's launches; integer VALU-issue bound: 65 wave-instructions per 64 band "
+                                      "columns (45-48 of them the column step), DP cell updates/s is the honest secondary"},
             # third: the stage the metric is named after.  SURVEY 8(d): per closed gap with n reads of mean cropped length L
             # the pile-up alignment reads every read once per partner (n (n - 1) L), the consensus once (n L), flanks and
             # output 2 L -- (n^2 + 2) L bytes; summed over the pile-ups by the library (dh_get_process_work) and divided by
