@@ -8,15 +8,17 @@
 // modimer sampling (daligner -%): the same k-mers are kept on the A and on the B side, decided on the
 // CANONICAL k-mer (the smaller of a k-mer and its reverse complement, both rolled along), so that a
 // k-mer and its reverse complement are sampled together.
-// Keep a k-mer iff h % mod == 0 with h = bits 32..63 of canon * 0x9E3779B97F4A7C15.  32-bit integer
-// multiplies run at quarter rate on CDNA, and this test is evaluated for every base of every
-// read, so it is arranged to need three of them (two when k <= 16):
+// Keep a k-mer iff h % mod == 0 with h = bits 32..63 of canon * 0x9E3779B97F4A7C15.  This test is evaluated for every
+// base of every read, so it is arranged to need three multiplies (two when k <= 16) and no division.  (On gfx950
+// v_mul_lo_u32 / v_mul_hi_u32 issue at the rate of a shift -- scripts/valu_probe.cpp, profiles/r03_valu_probe.txt: 0.56 G
+// wave-instructions/s per SIMD for both -- not at a quarter of it: replacing two of the three by 24-bit multiplies for
+// power-of-two mods, round 5, changed nothing: 56.4 against 56.3 ms of seeds per step.)
 //  * h = mulhi(lo, C_lo) + lo * C_hi + hi * C_lo   (lo / hi = halves of the k-mer);
 //  * h % mod == 0  <=>  rotr(h * inv(mod'), e) <= (2^32 - 1) / mod   for mod = mod' * 2^e, mod'
 //    odd, inv = inverse of mod' modulo 2^32 (test for zero remainder, Hacker's Delight 10-17).
 struct KmerSampler {
     uint32_t inv, thresh, rot;
-    bool all, small_k, pow2;  // pow2: mod is a power of two -- h % mod == 0 is a mask test, one quarter-rate multiply less
+    bool all, small_k, pow2;  // pow2: mod is a power of two -- h % mod == 0 is a mask test, one multiply less
 };
 __device__ __forceinline__ KmerSampler kmer_sampler(int32_t mod, int32_t k)
 {
@@ -38,10 +40,11 @@ __device__ __forceinline__ KmerSampler kmer_sampler(int32_t mod, int32_t k)
 }
 __device__ __forceinline__ bool kmer_sampled(uint64_t km, const KmerSampler &s)
 {
+    if (s.all) return true;  // (uniform: no sampling, no hash)
     const uint32_t lo = (uint32_t)km, hi = (uint32_t)(km >> 32);
     uint32_t h = __umulhi(lo, 0x7F4A7C15u) + lo * 0x9E3779B9u;
     if (!s.small_k) h += hi * 0x7F4A7C15u;
-    if (s.pow2) return (h & ((1u << s.rot) - 1u)) == 0u;  // (uniform branch; mod 1: rot == 0, everything is sampled)
+    if (s.pow2) return (h & ((1u << s.rot) - 1u)) == 0u;  // (uniform branch)
     const uint32_t t = h * s.inv;
     const uint32_t r = __builtin_rotateright32(t, s.rot);  // (rot == 0: t itself)
     return s.all | (r <= s.thresh);

@@ -94,7 +94,7 @@ constexpr int MJ_REMSH = MJ_POSBITS + 2, MJ_PSH = 53;
 // ------------------------------------------------------------------------------------ presence bitmap of the index
 // two bits per key inside the slice of its partition: the bucket of a directory of 2^nbbits buckets, and a hash of the key's
 // remainder (a one-probe filter of 11 bits per key lets 9 % of the absent k-mers through, the pair 3 %)
-// (one 32-bit multiply: the 64-bit product this began with was six quarter-rate multiplies in front of every second probe)
+// (one 32-bit multiply: the 64-bit product this began with was six multiplies in front of every second probe)
 __device__ __forceinline__ uint32_t mj_bit2(uint64_t rem, int sbits)
 {
     const uint32_t x = (uint32_t)rem ^ (uint32_t)(rem >> 19) ^ ((uint32_t)(rem >> 32) << 13);
@@ -131,6 +131,21 @@ __global__ void __launch_bounds__(256) k_mj_tile_reads(DbView B, MjView m)
     m.tile_r[t] = lo;
 }
 
+// the sampler with its kind known at compile time (0: every k-mer, 1: power-of-two modulus, 2: any modulus): the plain
+// step of k_mj_part has no uniform branch left
+template <int SAMP>
+__device__ __forceinline__ bool mj_sampled(uint64_t km, const KmerSampler &s)
+{
+    if (SAMP == 0) return true;
+    const uint32_t lo = (uint32_t)km, hi = (uint32_t)(km >> 32);
+    uint32_t h = __umulhi(lo, 0x7F4A7C15u) + lo * 0x9E3779B9u;
+    if (!s.small_k) h += hi * 0x7F4A7C15u;
+    if (SAMP == 1) return (h & ((1u << s.rot) - 1u)) == 0u;
+    const uint32_t t = h * s.inv;
+    return __builtin_rotateright32(t, s.rot) <= s.thresh;
+}
+
+template <int SAMP, bool MASK>
 __global__ void __launch_bounds__(MJ_THREADS, 4)
 k_mj_part(DbView B, MjView m)
 {
@@ -206,35 +221,49 @@ k_mj_part(DbView B, MjView m)
         // lane busy.  Eight bases per loaded word, the next word on its way.
         uint64_t wnext = xr0 < tlen ? load8(b + xr0 + mm) : 0ull;
         const int32_t tmax = tlen - xr0;  // k-mer starts of this lane: tt < tmax
-        const bool has_mask = B.mask_bits != nullptr;
+        // A group of eight bases is CAREFUL when, somewhere in the wavefront, a read begins inside it, a k-mer is not yet whole
+        // behind an earlier read start, the tile is the chunk's last (short) one, or the wavefront's part of buf could run
+        // full: then every step tests what the plain step takes for granted.  The plain step is roll, canonical choice,
+        // sampler, ballot, store -- nothing else.
+        const bool short_tile = tlen < m.tb;
+#define MJ_STEP(CAREFUL_)                                                                                                        \
+    {                                                                                                                             \
+        const int32_t tt = tt0 + u, pp = xr0 + mm + tt; /* pp: the base that completes the k-mer starting at xr0 + tt */         \
+        const uint32_t c = (uint32_t)(w >> (8 * u)) & 3u;                                                                         \
+        if (CAREFUL_ && pp == nxt) {                                                                                              \
+            valid = 0;                                                                                                            \
+            do jn++;                                                                                                              \
+            while (jn < nrs && rs[jn] == pp);                                                                                     \
+            nxt = jn < nrs ? rs[jn] : 0x7FFFFFFF;                                                                                 \
+        }                                                                                                                         \
+        km = ((km << 2) | c) & mask;                                                                                              \
+        rc = (rc >> 2) | ((uint64_t)(3u - c) << rcsh);                                                                            \
+        if (CAREFUL_) valid++;                                                                                                    \
+        const uint64_t canon = km < rc ? km : rc;                                                                                 \
+        /* (no short circuits: every `&&` of lane-varying terms would be a branch on the execution mask) */                       \
+        bool em = mj_sampled<SAMP>(canon, smp);                                                                                   \
+        if (CAREFUL_) em = em & (tt < tmax) & (valid >= k);                                                                       \
+        if (MASK) em = em && !mask_touch(B.mask_bits, tb0 + xr0 + tt, k);                                                         \
+        const unsigned long long bal = __ballot(em);                                                                              \
+        const uint32_t slot = wcount + mj_lanes_below(bal);                                                                       \
+        if (CAREFUL_ ? (em & (slot < (uint32_t)WCAP)) : em) buf[wave * WCAP + slot] = (km << MJ_POSBITS) | (uint64_t)(xr0 + tt); \
+        wcount += (uint32_t)__popcll(bal);                                                                                        \
+    }
         for (int32_t tt0 = 0; tt0 < per; tt0 += 8) {
             const uint64_t w = wnext;
             wnext = tt0 + 8 < tmax ? load8(b + xr0 + mm + tt0 + 8) : 0ull;
-            // (a read begins inside these eight bases, somewhere in the wavefront: rare, the careful steps below)
-            const bool careful = __ballot(nxt < xr0 + mm + tt0 + 8) != 0ull;
+            const bool careful = short_tile || wcount + 8u * LANES > (uint32_t)WCAP ||
+                                 __ballot((nxt < xr0 + mm + tt0 + 8) | (valid < k)) != 0ull;
+            if (careful) {
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int32_t tt = tt0 + u, pp = xr0 + mm + tt;  // pp: the base that completes the k-mer starting at xr0 + tt
-                const uint32_t c = (uint32_t)(w >> (8 * u)) & 3u;
-                if (careful && pp == nxt) {
-                    valid = 0;
-                    do jn++;
-                    while (jn < nrs && rs[jn] == pp);
-                    nxt = jn < nrs ? rs[jn] : 0x7FFFFFFF;
-                }
-                km = ((km << 2) | c) & mask;
-                rc = (rc >> 2) | ((uint64_t)(3u - c) << rcsh);
-                valid++;
-                const uint64_t canon = km < rc ? km : rc;
-                // (no short circuits: every `&&` of lane-varying terms would be a branch on the execution mask)
-                bool em = (tt < tmax) & (valid >= k) & kmer_sampled(canon, smp);
-                if (has_mask) em = em && !mask_touch(B.mask_bits, tb0 + xr0 + tt, k);
-                const unsigned long long bal = __ballot(em);
-                const uint32_t slot = wcount + mj_lanes_below(bal);
-                if (em & (slot < (uint32_t)WCAP)) buf[wave * WCAP + slot] = (km << MJ_POSBITS) | (uint64_t)(xr0 + tt);
-                wcount += (uint32_t)__popcll(bal);
+                for (int u = 0; u < 8; u++) MJ_STEP(true)
+            } else {
+#pragma unroll
+                for (int u = 0; u < 8; u++) MJ_STEP(false)
+                // (valid stays >= k: it only matters as a threshold until the next read start)
             }
         }
+#undef MJ_STEP
         if (wcount > WCAP) {
             if (lane == 0) atomicOr(m.status, DH_ST_MJ_OVERFLOW);
             wcount = WCAP;
@@ -760,7 +789,20 @@ void dhk_mj_tile_reads(hipStream_t st, DbView B, MjView m)
 void dhk_mj_run(hipStream_t st, DbView B, IndexView ix, DhOpts o, MjView m, int32_t ncu)
 {
     (void)hipMemsetAsync(m.ctr, 0, 16 * sizeof(uint32_t), st);
-    hipLaunchKernelGGL(k_mj_part, dim3((unsigned)std::min<int64_t>(m.ntiles, (int64_t)ncu * 2 * 4)), dim3(MJ_THREADS), 0, st, B, m);
+    {
+        const dim3 grid((unsigned)std::min<int64_t>(m.ntiles, (int64_t)ncu * 2 * 4)), block(MJ_THREADS);
+        const bool masked = B.mask_bits != nullptr;
+        const int samp = m.kmer_mod <= 1 ? 0 : ((m.kmer_mod & (m.kmer_mod - 1)) == 0 ? 1 : 2);
+#define MJ_PART(S_, M_) hipLaunchKernelGGL((k_mj_part<S_, M_>), grid, block, 0, st, B, m)
+        if (samp == 0) {
+            if (masked) MJ_PART(0, true); else MJ_PART(0, false);
+        } else if (samp == 1) {
+            if (masked) MJ_PART(1, true); else MJ_PART(1, false);
+        } else {
+            if (masked) MJ_PART(2, true); else MJ_PART(2, false);
+        }
+#undef MJ_PART
+    }
     hipLaunchKernelGGL(k_mj_transpose, dim3((unsigned)(m.ntiles_pad / 32)), dim3(256), 0, st, m);
     hipLaunchKernelGGL(k_mj_filter, dim3((unsigned)ncu), dim3(MJ_PROBE_THREADS), 0, st, ix, o, m);
     hipLaunchKernelGGL(k_mj_hits, dim3((unsigned)m.ngroups), dim3(MJ_THREADS), 0, st, B, ix, o, m);

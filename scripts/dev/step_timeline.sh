@@ -5,7 +5,7 @@ out=$root/gpurun_out/${1:-tl}
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_tl
-( cd "$root" && rocprofv3 --kernel-trace -d /tmp/prof_tl -o run -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$out/bench.log" 2>&1 )
+( cd "$root" && rocprofv3 --kernel-trace -d /tmp/prof_tl -o run -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --ref-steps 0 > "$out/bench.log" 2>&1 )
 db=$(find /tmp/prof_tl -name "*.db" | head -1)
 python - "$db" > "$out/timeline.txt" <<'PY'
 import sqlite3, sys
@@ -16,8 +16,8 @@ print("# columns:", cols)
 sid = "stream_id" if "stream_id" in cols else ("queue_id" if "queue_id" in cols else None)
 rows = cur.execute(f"select name, start, end, {sid or 0}, grid_x, workgroup_x from kernels order by start").fetchall()
 # the last step: from the last k_kmer_pass<true> preceded by a long mapping... simply the last 45 % of the trace
-idx = [i for i, r in enumerate(rows) if r[0].startswith("void k_seed<1024") and r[2] - r[1] > 10e6]
-i0 = idx[-2] if len(idx) >= 2 else 0
+idx = [i for i, r in enumerate(rows) if r[0].startswith("k_mj_part")] or [i for i, r in enumerate(rows) if r[0].startswith("void k_seed<1024") and r[2] - r[1] > 10e6]
+i0 = idx[-2] if len(idx) >= 2 else 0   # (two mapping chunks per step: the first one of the last step)
 t0 = rows[i0][1]
 streams = sorted({r[3] for r in rows[i0:]})
 print("# streams:", streams)
