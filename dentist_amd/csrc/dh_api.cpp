@@ -1811,7 +1811,10 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         const JoinView &jvx = mj_chunk ? jv_mj : jv;
         // (the back end fed from segments exists with 2048, 4096 and 8192 entries of LDS; the 8192-entry one scans in a slab)
         const int tier_max = getenv("DH_SEED_NO16K") ? 8192 : 16384;  // development / tests: without the 16384-entry tier
-        const int capj = std::min(std::max(cap, 2048), tier_max);
+        // (a mapping chunk through the partitioned join starts with the wavefront-per-read tier: 512 hits, 32 candidate band
+        // pairs -- 140 hits per read at 1/8 sampling; a block of 512 threads per read kept 3 reads per CU in flight and spent
+        // its time in barriers -- then 2048, 8192, 16384 for what overflows; DH_SEED_NO_WAVE_TIER=1: from 2048 as before)
+        const int capj = (mj_chunk && !getenv("DH_SEED_NO_WAVE_TIER")) ? 512 : std::min(std::max(cap, 2048), tier_max);
         if (jn && capj > 4096) SCR(30, d_fscr, (size_t)ctx->ncu * DH_SEED_FSCR_BLOCKS_PER_CU * (capj > 8192 ? DH_SEED_FSCR_WORDS16 : DH_SEED_FSCR_WORDS))
         if (jn)
             dhk_seed_join(st, capj, bv, iv, dopt, jvx, (int32_t)item0, ni, candbase, ncandbase, nhitsbase, d_status,
@@ -1889,7 +1892,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
                 // 16384-entry one (uncapped pile-ups: ~10 000 hits per read); what is left is staged in HBM
                 std::vector<int32_t> huge;
                 int32_t gcap2 = 0;
-                for (int tier = 8192; tier <= tier_max; tier *= 2) {
+                for (int tier = capj < 2048 ? 2048 : 8192; tier <= tier_max; tier = tier < 8192 ? 8192 : tier * 2) {
                     if (tier <= capj) continue;
                     std::vector<int32_t> mid;
                     huge.clear();

@@ -519,7 +519,7 @@ __device__ unsigned long long g_seed_prof[12];
 #define HIT_DBITS 39
 // JOIN: the hits come from the per-pile-up k-mer join (dh_join.hip) -- the read's segments of the hit buffer are
 // gathered instead of looking its k-mers up; everything after the hit buffer is filled is the same code.
-template <int LCAP, bool JOIN>
+template <int LCAP, bool JOIN, int NT, int CC>
 __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &jv,
                           const DhOpts &o, int32_t read0, int32_t work, int32_t slab,
                           DhCand *__restrict__ cand_out, int32_t *__restrict__ ncand_out,
@@ -527,8 +527,8 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
                           uint64_t *__restrict__ gbuf, int32_t gcap, const int32_t *__restrict__ read_list)
 {
     __shared__ uint64_t lhits[LCAP > 0 ? LCAP : 1];
-    __shared__ DhCand cands[2 * SEED_CCAP];
-    __shared__ int64_t cband[2 * SEED_CCAP];
+    __shared__ DhCand cands[2 * CC];
+    __shared__ int64_t cband[2 * CC];
     __shared__ int32_t s_n, s_nc;
 
     const int32_t r = read_list ? read_list[work] : read0 + work;  // (the HBM variant always works from a list)
@@ -565,9 +565,9 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
     if (JOIN) {
         // the read's segments: one per slice of its group (segtab row), first hit << 24 | count.  Their prefix sums
         // and first hits overlay the candidate arrays, which are not in use yet.
-        uint64_t *segb = (uint64_t *)cands;                     // [SEED_THREADS] first hit of segment s
-        uint32_t *sego = (uint32_t *)(cands + SEED_CCAP) + 1;   // [-1 .. SEED_THREADS) exclusive prefix sums of the counts
-        __shared__ uint32_t s_jw[SEED_THREADS / LANES];
+        uint64_t *segb = (uint64_t *)cands;                     // [NT] first hit of segment s
+        uint32_t *sego = (uint32_t *)(cands + CC) + 1;   // [-1 .. NT) exclusive prefix sums of the counts
+        __shared__ uint32_t s_jw[NT / LANES];
         const int32_t ns = jv.gns ? jv.gns[B.group[r]] : jv.ns_fixed;
         const int64_t srow = jv.gns ? jv.segrow[r] : (int64_t)(r - jv.read0) * jv.ns_fixed;
         uint32_t c = 0;
@@ -584,7 +584,7 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
         if ((tid & (LANES - 1)) == LANES - 1) s_jw[tid / LANES] = incl;
         __syncthreads();
         uint32_t base = 0, tot = 0;
-        for (int wv = 0; wv < SEED_THREADS / LANES; wv++) {
+        for (int wv = 0; wv < NT / LANES; wv++) {
             if (wv < tid / LANES) base += s_jw[wv];
             tot += s_jw[wv];
         }
@@ -595,7 +595,7 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
         }
         __syncthreads();
         if ((int32_t)tot <= CAP)
-            for (int32_t e = tid; e < (int32_t)tot; e += SEED_THREADS) {
+            for (int32_t e = tid; e < (int32_t)tot; e += NT) {
                 int32_t lo = 0, hi = ns - 1;  // the segment of hit e: the first s with sego[s] > e
                 while (lo < hi) {
                     const int32_t mid = (lo + hi) >> 1;
@@ -779,7 +779,39 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
     // ---- sort of the hit buffer (keys are distinct: a hit is (strand, diagonal, read position))
     int32_t N = 1;
     while (N < n) N <<= 1;
-    if (LCAP > 0 && n <= SEED_THREADS) {
+    constexpr bool SMALL = NT < SEED_THREADS;  // a wavefront per read (the mapping launches' first tier): LCAP <= 8 NT
+    if (SMALL) {
+        // every thread takes the (at most LCAP / NT) keys tid, tid + NT, ... and counts the keys below each of them: n
+        // broadcast reads for all of its keys together; keys are distinct, the ranks a permutation
+        // (as many keys per thread as the read needs: 140 hits at 1/8 sampling are three)
+        constexpr int E8 = LCAP / NT > 0 ? LCAP / NT : 1;
+        uint64_t ky[E8];
+        int32_t rk8[E8];
+#pragma unroll
+        for (int u = 0; u < E8; u++) {
+            const int32_t i = tid + u * NT;
+            ky[u] = i < n ? hits[i] : ~0ull;
+            rk8[u] = 0;
+        }
+#define DH_RANK_KEYS(M_)                                                   \
+    for (int32_t x = 0; x < n; x++) {                                      \
+        const uint64_t h = hits[x];                                        \
+        _Pragma("unroll") for (int u = 0; u < (M_ < E8 ? M_ : E8); u++) rk8[u] += h < ky[u] ? 1 : 0; \
+    }
+        if (n <= 2 * NT) {
+            DH_RANK_KEYS(2)
+        } else if (n <= 4 * NT) {
+            DH_RANK_KEYS(4)
+        } else {
+            DH_RANK_KEYS(E8)
+        }
+#undef DH_RANK_KEYS
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < E8; u++)
+            if (tid + u * NT < n) hits[rk8[u]] = ky[u];
+        N = 1;  // the network below has nothing left to do
+    } else if (LCAP > 0 && n <= NT) {
         // at most one hit per thread (the mapping launches: 140 hits per read at kmer_mod 8): every thread counts the
         // keys below its own -- n broadcast reads that do not depend on each other -- and stores its key at that rank.
         // The bitonic network below takes log^2 N dependent LDS round trips (36 for N = 256: 8.6 of the 50 us a block
@@ -807,22 +839,22 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
         // instead of registers; its network is a chain of global round trips per exchange (8 ms for 4 reads of a
         // configs[2] part).  Ranking costs (n / 512) x bucket loads from L2 per thread, the network ~0.5 ms at 16 384
         // hits: measured break-even at buckets of ~340 hits.
-        constexpr int E = LCAP >= SEED_THREADS ? LCAP / SEED_THREADS : 1;
+        constexpr int E = LCAP >= NT ? LCAP / NT : 1;
         constexpr int NB = 2048, NBH = NB / 2, SORT_BMAX = LCAP == 0 ? 384 : 256;
         constexpr uint64_t DM = (1ull << HIT_DBITS) - 1;
-        static_assert(sizeof(cands) >= NB * sizeof(uint32_t), "bucket counters overlay the candidate array");
+        static_assert(SMALL || sizeof(cands) >= NB * sizeof(uint32_t), "bucket counters overlay the candidate array");
         uint32_t *bcnt = (uint32_t *)cands;  // not in use yet (the join's segment table is done with it)
         __shared__ unsigned long long s_dmin, s_dmax;
-        __shared__ uint32_t s_bw[SEED_THREADS / LANES];
+        __shared__ uint32_t s_bw[NT / LANES];
         __shared__ uint32_t s_bmax;
-        for (int32_t i = tid; i < NB; i += SEED_THREADS) bcnt[i] = 0;
+        for (int32_t i = tid; i < NB; i += NT) bcnt[i] = 0;
         if (tid == 0) {
             s_dmin = ~0ull;
             s_dmax = 0ull;
             s_bmax = 0;
         }
         unsigned long long dmin = ~0ull, dmax = 0ull;
-        for (int32_t i = tid; i < n; i += SEED_THREADS) {
+        for (int32_t i = tid; i < n; i += NT) {
             const unsigned long long d = (hits[i] >> HIT_QBITS) & DM;
             dmin = d < dmin ? d : dmin;
             dmax = d > dmax ? d : dmax;
@@ -848,13 +880,13 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
         auto bucket = [&](uint64_t key) {
             return (uint32_t)(key >> 63) * NBH + (uint32_t)((((key >> HIT_QBITS) & DM) - d0) >> sh);
         };
-        for (int32_t i = tid; i < n; i += SEED_THREADS) atomicAdd(&bcnt[bucket(hits[i])], 1u);
+        for (int32_t i = tid; i < n; i += NT) atomicAdd(&bcnt[bucket(hits[i])], 1u);
         __syncthreads();
         // exclusive scan of the counters (4 per thread), largest bucket
-        uint32_t c4[NB / SEED_THREADS], sum = 0, mx = 0;
+        uint32_t c4[NB / NT], sum = 0, mx = 0;
 #pragma unroll
-        for (int u = 0; u < NB / SEED_THREADS; u++) {
-            c4[u] = bcnt[tid * (NB / SEED_THREADS) + u];
+        for (int u = 0; u < NB / NT; u++) {
+            c4[u] = bcnt[tid * (NB / NT) + u];
             sum += c4[u];
             mx = c4[u] > mx ? c4[u] : mx;
         }
@@ -873,15 +905,15 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
         uint32_t base = incl - sum;
         for (int wv = 0; wv < tid / LANES; wv++) base += s_bw[wv];
 #pragma unroll
-        for (int u = 0; u < NB / SEED_THREADS; u++) {
-            bcnt[tid * (NB / SEED_THREADS) + u] = base;
+        for (int u = 0; u < NB / NT; u++) {
+            bcnt[tid * (NB / NT) + u] = base;
             base += c4[u];
         }
         uint64_t ke[E];
         if (LCAP > 0) {
 #pragma unroll
             for (int u = 0; u < E; u++) {
-                const int32_t i = tid + u * SEED_THREADS;
+                const int32_t i = tid + u * NT;
                 ke[u] = i < n ? hits[i] : 0ull;
             }
         }
@@ -889,12 +921,12 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
         SP(5)
         if (LCAP == 0 && s_bmax <= (uint32_t)SORT_BMAX) {
             uint64_t *tmp = hits + gcap;  // the block's prefix sums live here later
-            for (int32_t i = tid; i < n; i += SEED_THREADS) {
+            for (int32_t i = tid; i < n; i += NT) {
                 const uint64_t key = hits[i];
                 tmp[atomicAdd(&bcnt[bucket(key)], 1u)] = key;
             }
             __syncthreads();
-            for (int32_t i = tid; i < n; i += SEED_THREADS) {
+            for (int32_t i = tid; i < n; i += NT) {
                 const uint64_t key = tmp[i];
                 const uint32_t bk = bucket(key);
                 const uint32_t b0 = bk ? bcnt[bk - 1] : 0u, b1 = bcnt[bk];
@@ -914,7 +946,7 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
             // scatter: a bucket's hits in arrival order; the counters end up at the buckets' ends
 #pragma unroll
             for (int u = 0; u < E; u++) {
-                const int32_t i = tid + u * SEED_THREADS;
+                const int32_t i = tid + u * NT;
                 if (i < n) hits[atomicAdd(&bcnt[bucket(ke[u])], 1u)] = ke[u];
             }
             __syncthreads();
@@ -922,7 +954,7 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
             uint32_t dst[E];
 #pragma unroll
             for (int u = 0; u < E; u++) {
-                const int32_t i = tid + u * SEED_THREADS;
+                const int32_t i = tid + u * NT;
                 dst[u] = 0;
                 if (i < n) {
                     const uint64_t key = hits[i];
@@ -961,16 +993,16 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
             __syncthreads();
 #pragma unroll
             for (int u = 0; u < E; u++)
-                if (tid + u * SEED_THREADS < n) hits[dst[u]] = ke[u];
+                if (tid + u * NT < n) hits[dst[u]] = ke[u];
             N = 1;
         } else {
 #ifdef DH_SEED_PROF
             if (tid == 0) atomicAdd(&g_seed_prof[10], 1ull);
 #endif
-            for (int32_t i = n + tid; i < N; i += SEED_THREADS) hits[i] = ~0ull;
+            for (int32_t i = n + tid; i < N; i += NT) hits[i] = ~0ull;
         }
     } else {
-        for (int32_t i = n + tid; i < N; i += SEED_THREADS) hits[i] = ~0ull;
+        for (int32_t i = n + tid; i < N; i += NT) hits[i] = ~0ull;
     }
     __syncthreads();
     // Pair p exchanges elements i = insert-zero-bit(p, j) and i | j.  Pairs are dealt to threads in
@@ -986,11 +1018,11 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
             // row per thread and round when 50 000 hits of a repeat-rich read are sorted in the HBM slab (17 ms for the
             // 27 such reads of a configs[2] half)
             constexpr int SORT_U = (LCAP == 0 || LCAP >= 4096) ? 8 : 4;
-            for (int32_t p0 = tid; p0 < (N >> 1); p0 += SEED_THREADS * SORT_U) {
+            for (int32_t p0 = tid; p0 < (N >> 1); p0 += NT * SORT_U) {
                 uint64_t xs[SORT_U], ys[SORT_U];
 #pragma unroll
                 for (int u = 0; u < SORT_U; u++) {
-                    const int32_t p = p0 + u * SEED_THREADS;
+                    const int32_t p = p0 + u * NT;
                     if (p < (N >> 1)) {
                         const int32_t i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
                         xs[u] = hits[i];
@@ -999,7 +1031,7 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
                 }
 #pragma unroll
                 for (int u = 0; u < SORT_U; u++) {
-                    const int32_t p = p0 + u * SEED_THREADS;
+                    const int32_t p = p0 + u * NT;
                     if (p < (N >> 1)) {
                         const int32_t i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
                         const bool up = (i & kk) == 0;
@@ -1058,9 +1090,9 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
     bsum_t *bsum = FB_LDS ? (bsum_t *)bsum_l
                           : (FB_BIG ? (bsum_t *)(hits + gcap) : (bsum_t *)(gbuf + (int64_t)slab * gcap));
     bhead_t *bhead = FB_LDS ? (bhead_t *)bhead_l : (bhead_t *)(bsum + (LCAP > 0 ? LCAP : gcap));
-    __shared__ bsum_t s_wsum[SEED_THREADS / LANES];
+    __shared__ bsum_t s_wsum[NT / LANES];
     __shared__ int32_t s_nbig;
-    constexpr int NBIG = (LCAP > 0 && LCAP <= 4096) ? 128 : 64;  // (the 8192-entry variant has no LDS to spare)
+    constexpr int NBIG = NT < SEED_THREADS ? 8 : ((LCAP > 0 && LCAP <= 4096) ? 128 : 64);  // (the 8192-entry variant has no LDS to spare; what does not fit walks serially)
     __shared__ int32_t bigc[NBIG][4];  // candidate band pairs with long hit ranges: (first, end, P, slot)
     __shared__ unsigned long long s_bestkeys[NBIG];
     const int bs = o.band_shift;
@@ -1097,7 +1129,7 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
     if (FASTB) {
         if (tid == 0) s_nbig = 0;
         // -- scan: thread t owns the elements [t * per, t * per + per)
-        const int32_t per = (n + SEED_THREADS - 1) / SEED_THREADS;
+        const int32_t per = (n + NT - 1) / NT;
         const int32_t x0 = tid * per, x1 = min(n, x0 + per);
         bsum_t acc = 0;
         for (int32_t i = x0; i < x1; i++) {
@@ -1127,7 +1159,7 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
             const int32_t st_ = bhead[rnk], en_ = rnk + 1 < nheads ? bhead[rnk + 1] : n;
             return (int32_t)((bsum[en_ - 1] & CMASK) - (st_ ? (bsum[st_ - 1] & CMASK) : (bsum_t)0));
         };
-        for (int32_t rnk = tid; rnk < nheads; rnk += SEED_THREADS) {
+        for (int32_t rnk = tid; rnk < nheads; rnk += NT) {
             const int32_t i = bhead[rnk];
             const int64_t band = hitD(hits[i]) >> bs;
             int32_t covm1 = 0, cov1 = 0, cov2 = 0, e1;
@@ -1144,7 +1176,7 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
             const int32_t P = cov0 + cov1, Pm1 = covm1 + cov0, Pp1 = cov1 + cov2;
             if (P < o.hmin || P < Pm1 || P <= Pp1) continue;
             const int32_t slot = atomicAdd(&s_nc, 1);
-            if (slot >= 2 * SEED_CCAP) continue;
+            if (slot >= 2 * CC) continue;
             if (e1 - i > 16) {
                 // long range: the whole block picks the seed below
                 const int32_t bslot = atomicAdd(&s_nbig, 1);
@@ -1167,7 +1199,7 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
         constexpr int GW = 16;
         const int32_t nbig = min(s_nbig, NBIG);
         const int gl = tid & (GW - 1);
-        for (int32_t bc = tid / GW; bc < nbig; bc += SEED_THREADS / GW) {
+        for (int32_t bc = tid / GW; bc < nbig; bc += NT / GW) {
             const int32_t i = bigc[bc][0], e1 = bigc[bc][1];
             unsigned long long best = 0ull;
             int32_t carry = i;
@@ -1202,10 +1234,10 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
         }
         __syncthreads();
         SP(9)
-        for (int32_t bc = tid; bc < nbig; bc += SEED_THREADS)
+        for (int32_t bc = tid; bc < nbig; bc += NT)
             emit_cand(bigc[bc][3], 0x7FFFFFFF - (int32_t)(uint32_t)s_bestkeys[bc], bigc[bc][2], hitD(hits[bigc[bc][0]]) >> bs);
     } else {
-        for (int32_t i = tid; i < n; i += SEED_THREADS) {
+        for (int32_t i = tid; i < n; i += NT) {
             const int64_t band = hitD(hits[i]) >> bs;
             if (i > 0 && (hitD(hits[i - 1]) >> bs) == band) continue;  // not a band head
             int32_t covm1 = 0, cov0 = 0, cov1 = 0, cov2 = 0, e1;
@@ -1219,16 +1251,23 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
             const int32_t P = cov0 + cov1, Pm1 = covm1 + cov0, Pp1 = cov1 + cov2;
             if (P < o.hmin || P < Pm1 || P <= Pp1) continue;
             const int32_t slot = atomicAdd(&s_nc, 1);
-            if (slot < 2 * SEED_CCAP) emit_cand(slot, serial_seed(i, e1), P, band);
+            if (slot < 2 * CC) emit_cand(slot, serial_seed(i, e1), P, band);
         }
     }
     __syncthreads();
     SP(3)
     int32_t nc = s_nc;
-    if (nc > 2 * SEED_CCAP) {
+    if (nc > 2 * CC) {
         // more candidate band pairs than one read can sensibly have (a repeat the -t cap did not
         // catch): the read yields no alignments and is reported (ncand = -2), the launch goes on
-        if (tid == 0) ncand_out[item] = ncand_out[item + 1] = -2;
+        // (the wavefront-per-read tier holds fewer: the read goes to the next tier, where the rule above decides)
+        if (tid == 0) {
+            ncand_out[item] = ncand_out[item + 1] = NT < SEED_THREADS ? -1 : -2;
+            if (NT < SEED_THREADS) {
+                nhits_out[item] = n;
+                nhits_out[item + 1] = 0;
+            }
+        }
         return;
     }
     // ---- rank per strand by (score desc, band asc); bands are distinct so ranks are a permutation
@@ -1236,13 +1275,13 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
     // (rank < max_cand) are then grouped by A read, rank order inside a group -- groups are the only
     // candidates that depend on each other (coverage skip), which makes each of them a separate work
     // unit of the wave kernel (k_units).
-    __shared__ int32_t crank[2 * SEED_CCAP];
+    __shared__ int32_t crank[2 * CC];
     __shared__ int32_t s_ncs[2];
     constexpr int BSTR = HIT_DBITS;  // strand bit of a band = bit HIT_DBITS - band_shift
     auto strand_of = [&](int32_t c) { return (int32_t)((cband[c] >> (BSTR - bs)) & 1); };
     if (tid < 2) s_ncs[tid] = 0;
     __syncthreads();
-    for (int32_t c = tid; c < nc; c += SEED_THREADS) {
+    for (int32_t c = tid; c < nc; c += NT) {
         const int32_t st = strand_of(c);
         const int32_t sc = cands[c].score;
         const int64_t bc = cband[c];
@@ -1258,7 +1297,7 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
         atomicAdd(&s_ncs[st], 1);
     }
     __syncthreads();
-    for (int32_t c = tid; c < nc; c += SEED_THREADS) {
+    for (int32_t c = tid; c < nc; c += NT) {
         const int32_t rank = crank[c], st = strand_of(c);
         if (rank >= o.max_cand) continue;
         int32_t pos = rank;
@@ -1281,22 +1320,32 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
 }
 // Persistent blocks: the grid is sized to the resident capacity of the chip and every block pulls
 // items from an atomic queue (no per-item block launch, dynamic balance over ragged read lengths).
-template <int LCAP, bool JOIN>
-__global__ void __launch_bounds__(SEED_THREADS, (LCAP > 0 && LCAP <= 2048) ? 6 : (LCAP == 16384 ? 2 : 4))
+template <int LCAP, bool JOIN, int NT = SEED_THREADS, int CC = SEED_CCAP>
+__global__ void __launch_bounds__(NT, NT < SEED_THREADS ? 4 : ((LCAP > 0 && LCAP <= 2048) ? 6 : (LCAP == 16384 ? 2 : 4)))
 k_seed(DbView B, IndexView ix, JoinView jv, DhOpts o, int32_t read0,
        int32_t nreads, DhCand *__restrict__ cand_out, int32_t *__restrict__ ncand_out,
        int32_t *__restrict__ nhits_out, int32_t *__restrict__ status, uint64_t *__restrict__ gbuf,
        int32_t gcap, const int32_t *__restrict__ read_list, uint32_t *__restrict__ queue)
 {
     __shared__ int32_t s_work;
+    // (the queue is ONE address: half a million reads of a mapping chunk were half a million returning atomics on it, ~11 ns
+    // each whatever the kernel did in between -- 5.7 of the wavefront-per-read tier's 5.7 ms, SQ_WAIT_ANY 88 %.  The small
+    // tiers of the segment-fed back end take eight reads per atomic.)
+    constexpr int32_t BATCH = (JOIN && LCAP > 0 && LCAP <= 2048) ? 8 : 1;
     for (;;) {
         __syncthreads();  // the previous read is finished by every thread (shared state is reused)
-        if (threadIdx.x == 0) s_work = (int32_t)atomicAdd(queue, 1u);
+        if (threadIdx.x == 0) s_work = (int32_t)atomicAdd(queue, (uint32_t)BATCH);
         __syncthreads();
-        const int32_t work = s_work;
-        if (work >= nreads) break;
-        seed_item<LCAP, JOIN>(B, ix, jv, o, read0, work, (int32_t)blockIdx.x, cand_out, ncand_out, nhits_out,
-                              status, gbuf, gcap, read_list);
+        const int32_t work0 = s_work;
+        if (work0 >= nreads) break;
+#pragma unroll 1
+        for (int32_t wi = 0; wi < BATCH; wi++) {
+            const int32_t work = work0 + wi;
+            if (work >= nreads) break;
+            if (wi) __syncthreads();
+            seed_item<LCAP, JOIN, NT, CC>(B, ix, jv, o, read0, work, (int32_t)blockIdx.x, cand_out, ncand_out, nhits_out,
+                                          status, gbuf, gcap, read_list);
+        }
     }
 }
 #define SEED_INST(C, J)                                                                           \
@@ -1310,6 +1359,8 @@ SEED_INST(8192, false)
 SEED_INST(16384, false)
 SEED_INST(0, false)
 SEED_INST(2048, true)
+template __global__ void k_seed<512, true, 64, 32>(DbView, IndexView, JoinView, DhOpts, int32_t, int32_t, DhCand *, int32_t *, int32_t *,
+                                                   int32_t *, uint64_t *, int32_t, const int32_t *, uint32_t *);
 SEED_INST(4096, true)
 SEED_INST(8192, true)
 SEED_INST(16384, true)
@@ -2710,13 +2761,13 @@ k_compact(const DhLa *__restrict__ la_slots, const uint16_t *__restrict__ tr_slo
 // ------------------------------------------------------------------------------------ launchers
 
 // resident blocks of a seed variant on the whole chip (persistent grid size)
-template <int C, bool J = false>
+template <int C, bool J = false, int NT = SEED_THREADS, int CC = SEED_CCAP>
 static int seed_grid(int32_t nitems, int32_t ncu)
 {
     static int per_cu = 0;
     if (per_cu == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_seed<C, J>, SEED_THREADS, 0) != hipSuccess || nb < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_seed<C, J, NT, CC>, NT, 0) != hipSuccess || nb < 1)
             nb = 1;
         per_cu = nb;
     }
@@ -3072,7 +3123,10 @@ void dhk_seed_join(hipStream_t st, int cap, DbView B, IndexView ix, DhOpts o, Jo
     hipLaunchKernelGGL((k_seed<C, true>), dim3(seed_grid<C, true>(nreads, ncu)), dim3(SEED_THREADS), 0, st, B, ix, jv, o, \
                        read0, nreads, cand, ncand, nhits, status, C >= 8192 ? fscr : (uint64_t *)nullptr,    \
                        C == 8192 ? DH_SEED_FSCR_WORDS : (C == 16384 ? DH_SEED_FSCR_WORDS16 : 0), read_list, queue)
-    if (cap <= 2048)
+    if (cap <= 512)  // the first tier of a mapping: a wavefront per read (140 hits at 1/8 sampling), 32 candidate band pairs
+        hipLaunchKernelGGL((k_seed<512, true, 64, 32>), dim3(seed_grid<512, true, 64, 32>(nreads, ncu)), dim3(64), 0, st, B, ix, jv, o,
+                           read0, nreads, cand, ncand, nhits, status, (uint64_t *)nullptr, 0, read_list, queue);
+    else if (cap <= 2048)
         SEED_LAUNCH_J(2048);
     else if (cap <= 4096)
         SEED_LAUNCH_J(4096);
