@@ -1814,7 +1814,21 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         // (a mapping chunk through the partitioned join starts with the wavefront-per-read tier: 512 hits, 32 candidate band
         // pairs -- 140 hits per read at 1/8 sampling; a block of 512 threads per read kept 3 reads per CU in flight and spent
         // its time in barriers -- then 2048, 8192, 16384 for what overflows; DH_SEED_NO_WAVE_TIER=1: from 2048 as before)
-        const int capj = (mj_chunk && !getenv("DH_SEED_NO_WAVE_TIER")) ? 512 : std::min(std::max(cap, 2048), tier_max);
+        // The first tier of a mapping chunk goes by the MEAN hits per read -- 0.075 true seeds per sampled k-mer at 13 % error
+        // plus the random matches -- with half as much again of room (`cap` above goes by the longest read of the DB: right for
+        // the directory path, whose overflowing reads are staged in HBM, two sizes too large here, where the next tiers take
+        // them from a list: the unsampled mapping of configs[2] ran all reads through the 4096-entry variant for 1 100 hits per
+        // read).  The wavefront-per-read tier is switched off for the context once a quarter of a chunk's reads overflowed it.
+        const double kmers_per_read = (double)(B->h_off[(size_t)((item0 + ni) >> 1)] - B->h_off[(size_t)(item0 >> 1)]) /
+                                      std::max(1, ni / 2) / std::max(1, o.kmer_mod);
+        const double mean_hits = kmers_per_read * (2.0 * dens + 0.075);
+        const bool wave_tier = mj_chunk && ctx->seed_wave_tier && 1.5 * mean_hits <= 512.0 && !getenv("DH_SEED_NO_WAVE_TIER");
+        int capj = std::min(std::max(cap, 2048), tier_max);
+        if (mj_chunk) {
+            capj = 2048;
+            while (capj < tier_max && 1.5 * mean_hits > capj) capj *= 2;
+            if (wave_tier) capj = 512;
+        }
         if (jn && capj > 4096) SCR(30, d_fscr, (size_t)ctx->ncu * DH_SEED_FSCR_BLOCKS_PER_CU * (capj > 8192 ? DH_SEED_FSCR_WORDS16 : DH_SEED_FSCR_WORDS))
         if (jn)
             dhk_seed_join(st, capj, bv, iv, dopt, jvx, (int32_t)item0, ni, candbase, ncandbase, nhitsbase, d_status,
@@ -1872,6 +1886,11 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
                         big.push_back((int32_t)((item0 + it) >> 1));
                         gcap = std::max(gcap, h_nhits[(size_t)it] + h_nhits[(size_t)it + 1]);
                     }
+            }
+            if (wave_tier && big.size() * 4 > (size_t)(ni / 2)) {
+                ctx->seed_wave_tier = 0;
+                if (getenv("DH_TRACE"))
+                    fprintf(stderr, "[seeds] %zu of %d reads overflow the wavefront-per-read tier: not used by this context any more\n", big.size(), ni / 2);
             }
             // many items overflow the LDS buffer: the next size is cheaper than HBM staging -- up to 8192; the 16384-entry
             // variant keeps one block per CU resident and pays off only when most items need it

@@ -63,6 +63,7 @@ struct dh_ctx {
     dh_align_stats stats = {};
     dh_cum_stats cum = {};
     double mj_hit_frac = 0.2;  // hits per sampled k-mer the hit pool of the partitioned join is sized for (raised when a pool overflowed)
+    int seed_wave_tier = 1;  // the wavefront-per-read first tier of the segment-fed seed back end (0: most reads overflowed it)
     int64_t mj_chunks = 0, mj_fallbacks = 0;  // chunks seeded by the partitioned join / redone by the directory (dh_get_mjoin_counts)
     int32_t near_best_ppm = -1;  // damapper -n of this context (dh_ctx_set_near_best); -1 = the process default
     // second context of the same device (own streams and scratch), created on first use: the process stage runs the
