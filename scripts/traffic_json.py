@@ -21,12 +21,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def kernel_build_id():
-    """sha1 over the kernel sources: bench.py compares it with the tree it runs from, so that a traffic figure taken on
-    another build of the kernels is never reported as this build's."""
+    """sha1 over the kernel sources -- the .hip files and the headers they include (dh_device.h, dh_join.h, dh_kmer.h,
+    dh_mjoin.h, dh_tile.h); not the host-only headers dh_internal.h / dh_parallel.h -- : bench.py compares it with the tree it
+    runs from, so that a traffic figure taken on another build of the kernels is never reported as this build's."""
     h = hashlib.sha1()
     d = os.path.join(ROOT, "dentist_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h")):
+        if name.endswith((".hip", ".h")) and name not in ("dh_internal.h", "dh_parallel.h"):
             h.update(name.encode())
             h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
