@@ -56,9 +56,10 @@ def per_kernel(d):
         name, kb = per[i]
         # the seeds of a mapping chunk: the directory lookups (k_seed<cap, false>) or, since round 5, the partitioned join
         # (k_mj_*) with the segment-fed back end (k_seed<cap, true>) -- one family, counted per chunk
-        fam = ("k_seed" if ("k_seed<" in name and "k_seed<0" not in name) or name.strip().startswith("k_mj_") else
+        # (templated kernels are named `void k_mj_part<1, false>(...)`: matched by substring)
+        fam = ("k_seed" if ("k_seed<" in name and "k_seed<0" not in name) or "k_mj_" in name else
                ("k_tile" if name.strip() == "k_tile" or "k_tile<" in name else ("k_seed_redo" if "k_seed<0" in name else None)))
-        if name.strip() == "k_mj_part":
+        if "k_mj_part" in name:
             res.setdefault(("chunks", "mapping"), [0, 0.0])[0] += 1
         if fam is None:
             continue
