@@ -46,6 +46,35 @@ def test_mapping_through_the_partitioned_join(gpu_ctx, k, mod, algo):
     assert fallbacks == 0 and len(set(las["bread"].tolist())) >= 0.98 * w.reads.n
 
 
+def test_the_tiers_of_the_seed_back_end(monkeypatch):
+    """A mapping chunk's first tier goes by the mean hits per read: here the wavefront-per-read variant (k_seed<512, JOIN, 64
+    threads, 32 candidate band pairs>; 300 hits per read on average), and the reads it cannot hold -- read lengths are
+    log-normal, the long ones bring 600-1 000 hits -- go through the 2 048-entry tier from a list.  Bit-exact against the
+    oracle, and identical to the same call without the tier (DH_SEED_NO_WAVE_TIER=1) and by the directory (DH_NO_MJOIN=1).
+    A context of its own: the tier is switched off per context when a quarter of a chunk overflows it."""
+    g = sim.genome(5, 600_000)
+    contigs = sim.SeqDb.from_list([g[:290_000], g[300_000:]])
+    rd, _ = sim.reads(6, g, 900, 4000, 2500, min_len=600)
+    lens = rd.off[1:] - rd.off[:-1]
+    assert (lens > 9000).sum() >= 20 and np.median(lens) < 4500
+    ctx = dentist_amd.Context(0)
+    try:
+        kw = dict(k=20, kmer_mod=1, algo=1, width=64, xdrop=60)
+        (las, trace), (chunks, fallbacks) = run_both(ctx, contigs, rd, **kw)
+        assert chunks > 0 and fallbacks == 0
+        st = ctx.align_stats()
+        assert st.hits / rd.n > 150 and st.hits / rd.n < 340          # (the mean that selects the tier)
+        go = dentist_amd.default_align_opts(**kw)
+        A, B = ctx.db(contigs), ctx.db(rd)
+        for env in ("DH_SEED_NO_WAVE_TIER", "DH_NO_MJOIN"):
+            monkeypatch.setenv(env, "1")
+            other = ctx.align_db(A, B, go)
+            monkeypatch.delenv(env)
+            assert_same_las((las, trace), other)
+    finally:
+        ctx.close()
+
+
 def test_equal_to_the_directory_lookups_on_every_field(gpu_ctx, monkeypatch):
     """The same call with DH_NO_MJOIN=1 (one random directory line per k-mer): identical records, trace and counters."""
     w = sim.Workload(600_000, 5, 1500, 9000, seed=71, spacing=20000)
