@@ -338,17 +338,24 @@ k_rec_scatter(const DhLa *__restrict__ slots, int64_t nslots, int32_t item0, con
 // the order the host's (A, B) pair logic expects, deterministic whatever order the scatter listed them in -- and their
 // trace pairs copied in that order.  More than CS_MAX records of one (read, strand): reported (item_ovf), written unordered.
 #define CS_MAX 512
+#define CS_SMALL 128
+// CSM: capacity of the LDS tables.  The CS_SMALL variant serves the items with at most CS_SMALL records (a capped pile-up
+// read has 59) with a quarter of the LDS -- the block per item is a chain of dependent memory round trips (list -> records
+// -> records again -> trace values), what helps is more items in flight: 32 per CU instead of 10 -- and leaves the others
+// to the CS_MAX variant, which skips what the small one took.  Sixteen records' trace values are on their way together.
+template <int CSM>
 __global__ void __launch_bounds__(64)
 k_compact_sym(const DhLa *__restrict__ slots, const uint16_t *__restrict__ tr_slots, int32_t trmax, const int32_t *__restrict__ list,
               const uint32_t *__restrict__ la_off, const uint32_t *__restrict__ tr_off, int64_t tr_base, DhLa *__restrict__ la_out,
               uint16_t *__restrict__ tr_out, int32_t *__restrict__ item_ovf)
 {
-    __shared__ uint64_t sk1[CS_MAX], sk2[CS_MAX];
-    __shared__ int32_t stl[CS_MAX], sso[CS_MAX], ssl[CS_MAX], sto[CS_MAX];
+    __shared__ uint64_t sk1[CSM], sk2[CSM];
+    __shared__ int32_t stl[CSM], sso[CSM], ssl[CSM], sto[CSM];
     const int32_t it = blockIdx.x;
     const int lane = threadIdx.x;
     const uint32_t l0 = la_off[it], n = la_off[it + 1] - l0;
     if (n == 0) return;
+    if (CSM == CS_SMALL ? n > (uint32_t)CS_SMALL : n <= (uint32_t)CS_SMALL) return;  // (the other variant's item)
     const uint32_t t0 = tr_off[it];
     if (n > CS_MAX) {
         if (lane == 0) item_ovf[it] = 1;
@@ -381,6 +388,7 @@ k_compact_sym(const DhLa *__restrict__ slots, const uint16_t *__restrict__ tr_sl
         const uint64_t k1 = sk1[x], k2 = sk2[x];
         const int32_t sx = ssl[x];
         int32_t rank = 0, toff = 0;
+#pragma unroll 4
         for (uint32_t y = 0; y < n; y++) {
             const uint64_t y1 = sk1[y], y2 = sk2[y];
             const bool less = y1 < k1 || (y1 == k1 && (y2 < k2 || (y2 == k2 && ssl[y] < sx)));
@@ -394,22 +402,23 @@ k_compact_sym(const DhLa *__restrict__ slots, const uint16_t *__restrict__ tr_sl
         la_out[l0 + rank] = la;
     }
     __syncthreads();
-    // trace pairs, eight records at a time: their loads are in flight together (a record of the pile-up stage has ~50
+    // trace pairs, sixteen records at a time: their loads are in flight together (a record of the pile-up stage has ~50
     // values, so one record per step was one dependent memory round trip per record with most of it idle)
-    for (uint32_t x0 = 0; x0 < n; x0 += 8) {
-        uint16_t v[8];
+    constexpr int TU = 16;
+    for (uint32_t x0 = 0; x0 < n; x0 += TU) {
+        uint16_t v[TU];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
+        for (int j = 0; j < TU; j++) {
             const uint32_t x = x0 + j;
             v[j] = 0;
             if (x < n && lane < stl[x]) v[j] = tr_slots[(int64_t)ssl[x] * trmax + sso[x] + lane];
         }
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
+        for (int j = 0; j < TU; j++) {
             const uint32_t x = x0 + j;
             if (x < n && lane < stl[x]) tr_out[t0 + sto[x] + lane] = v[j];
         }
-        for (uint32_t x = x0; x < min(n, x0 + 8); x++) {
+        for (uint32_t x = x0; x < min(n, x0 + TU); x++) {
             const int32_t xl = stl[x];
             if (xl <= 64) continue;
             const uint16_t *src = tr_slots + (int64_t)ssl[x] * trmax + sso[x];
@@ -447,8 +456,10 @@ void dhk_compact_sym(hipStream_t st, const DhLa *slots, const uint16_t *tr_slots
                      const uint32_t *la_off, const uint32_t *tr_off, int64_t tr_base, DhLa *la_out, uint16_t *tr_out, int32_t *item_ovf)
 {
     if (nitems <= 0) return;
-    hipLaunchKernelGGL(k_compact_sym, dim3((uint32_t)nitems), dim3(64), 0, st, slots, tr_slots, trmax, list, la_off, tr_off, tr_base,
-                       la_out, tr_out, item_ovf);
+    hipLaunchKernelGGL(k_compact_sym<CS_SMALL>, dim3((uint32_t)nitems), dim3(64), 0, st, slots, tr_slots, trmax, list, la_off, tr_off,
+                       tr_base, la_out, tr_out, item_ovf);
+    hipLaunchKernelGGL(k_compact_sym<CS_MAX>, dim3((uint32_t)nitems), dim3(64), 0, st, slots, tr_slots, trmax, list, la_off, tr_off,
+                       tr_base, la_out, tr_out, item_ovf);
 }
 void dhk_tile(hipStream_t st, int32_t nwaves, const Params *P)
 {
