@@ -1275,7 +1275,10 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
     // (rank < max_cand) are then grouped by A read, rank order inside a group -- groups are the only
     // candidates that depend on each other (coverage skip), which makes each of them a separate work
     // unit of the wave kernel (k_units).
-    __shared__ int32_t crank[2 * CC];
+    // (the ranks overlay the hit buffer, which nobody reads any more: the 2 KB they took kept the 8192-entry variant at 81.5 KB
+    // of LDS -- one block per CU instead of two)
+    __shared__ int32_t crank_s[LCAP > 0 ? 1 : 2 * CC];
+    int32_t *crank = LCAP > 0 ? (int32_t *)lhits : crank_s;
     __shared__ int32_t s_ncs[2];
     constexpr int BSTR = HIT_DBITS;  // strand bit of a band = bit HIT_DBITS - band_shift
     auto strand_of = [&](int32_t c) { return (int32_t)((cband[c] >> (BSTR - bs)) & 1); };
