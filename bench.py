@@ -128,6 +128,9 @@ def main():
                          "entries it merges into a gap (pileups.d:173-208; the default for every N: at N > 1 the raw joins "
                          "of each rank's reads are all-gathered), 'spanning' = one entry per spanning read, collected per "
                          "chunk while mapping")
+    ap.add_argument("--device-trace", action="store_true",
+                    help="leave the mapping's trace values on the device (dh_map_reads want_sorted & 8) for `process` to gather "
+                         "from, instead of copying them to the host chunk by chunk (330 MB per step of configs[2])")
     ap.add_argument("--ref-steps", type=int, default=3,
                     help="steps of the REFERENCE-BEHAVIOUR configuration timed after the default loop in the same process "
                          "(no read cap: processPileUps/package.d:283-374 has none; no k-mer sampling: damapper has none, "
@@ -199,7 +202,10 @@ def main():
         # device maps the next chunk (dh_map_reads)
         # and lists the spanning-read candidates of the chunk; records stay in mapping order (by read)
         # (the spanning-read candidates only when that collector is asked for: the scaffold graph does not use them)
-        mapped = ctx.map_reads(A, B, mopts, popts, sorted=False, candidates=args.collect != "graph")
+        # (--device-trace: the trace values stay in HBM and `process` fetches the ones the cropper reads -- measured slower by
+        # 5 ms per step than copying all of them chunk by chunk beside the next chunk's kernels: DESIGN 10)
+        mapped = ctx.map_reads(A, B, mopts, popts, sorted=False, candidates=args.collect != "graph",
+                               trace_on_device=(world == 1 and args.device_trace))
         las, trace, dropped = mapped[:3]
         cands = mapped[3] if len(mapped) > 3 else None
         ast = ctx.align_stats()

@@ -94,7 +94,7 @@ SYMBOLS = [
     "dh_shard_plan_las", "dh_shard_plan_nlas", "dh_shard_plan_pileups", "dh_shard_plan_owner", "dh_shard_pack_cropped",
     "dh_shard_unpack_cropped", "dh_insertions_read_ids", "dh_insertions_read_ids_off", "dh_output_assembly", "dh_default_output_opts",
     "dh_common_trace_point", "dh_pileups_create_joins", "dh_pileups_get_join", "dh_scaffold_all_pileups",
-    "dh_crop_pileups_masked", "dh_process_pileups_masked", "dh_scaffold_graph_probe",
+    "dh_crop_pileups_masked", "dh_process_pileups_masked", "dh_process_pileups_set", "dh_la_set_trace_on_device", "dh_scaffold_graph_probe",
 ]
 
 _LIB = None
@@ -344,11 +344,14 @@ class Context:
         return las, trace
 
 
-    def map_reads(self, A, B, opts, popts, first=0, count=None, repeat_mask=None, sorted=True, candidates=False):
+    def map_reads(self, A, B, opts, popts, first=0, count=None, repeat_mask=None, sorted=True, candidates=False,
+                  trace_on_device=False):
         """dh_map_reads: the mapping pass (chain flags as with select_best) with the six `collect` filters
         applied chunk by chunk on the host while the device maps on.  Returns (las, trace, dropped[6]);
-        with sorted=False, candidates=True also the spanning-read candidates (Pileups, not yet cut)."""
-        return _map_reads(self, A, B, opts, popts, first, count, repeat_mask, sorted, candidates)
+        with sorted=False, candidates=True also the spanning-read candidates (Pileups, not yet cut).
+        trace_on_device=True: `trace` is a DeviceTrace -- the values stay in HBM (process_pileups takes it as it is and
+        fetches what the cropper reads; .numpy() downloads everything)."""
+        return _map_reads(self, A, B, opts, popts, first, count, repeat_mask, sorted, candidates, trace_on_device)
 
     def align_db_block(self, A, B, first, count, opts, select_best=False, raw=False):
         """`damapper ref reads.<block>`: reads [first, first + count) of B against A.  raw=True
@@ -362,7 +365,33 @@ class Context:
         return las, trace
 
 
-def _map_reads(ctx, A, B, opts, popts, first=0, count=None, repeat_mask=None, sorted=True, candidates=False):
+class DeviceTrace:
+    """The trace values of a mapping result left on the device (dh_map_reads, want_sorted & 8).  Keeps the result set
+    alive; numpy() is the host copy (downloaded on first use)."""
+
+    def __init__(self, owner, handle):
+        self._owner, self._h = owner, handle
+
+    def numpy(self):
+        L = lib()
+        tn = L.dh_la_set_trace_len(self._h)
+        if not tn:
+            return np.zeros(0, dtype=np.uint16)
+        buf = (ctypes.c_uint16 * tn).from_address(L.dh_la_set_trace(self._h))
+        buf._owner = self._owner
+        return np.frombuffer(buf, dtype=np.uint16)
+
+    def on_device(self):
+        L = lib()
+        L.dh_la_set_trace_on_device.argtypes = [ctypes.c_void_p]
+        return bool(L.dh_la_set_trace_on_device(self._h))
+
+    def __len__(self):
+        return int(lib().dh_la_set_trace_len(self._h))
+
+
+def _map_reads(ctx, A, B, opts, popts, first=0, count=None, repeat_mask=None, sorted=True, candidates=False,
+               trace_on_device=False):
     rp = ri = None
     if repeat_mask is not None:
         rp = np.ascontiguousarray(repeat_mask[0], dtype=np.int64)
@@ -378,9 +407,20 @@ def _map_reads(ctx, A, B, opts, popts, first=0, count=None, repeat_mask=None, so
                                ctypes.POINTER(ctypes.c_void_p)]
     _check(L.dh_map_reads(ctx._h, A._h, B._h, int(first), int(count), ctypes.byref(opts), ctypes.byref(popts),
                           rp.ctypes.data if rp is not None else None, ri.ctypes.data if ri is not None else None,
-                          1 if sorted else 0, dropped.ctypes.data, ctypes.byref(h),
+                          (1 if sorted else 0) | (8 if trace_on_device else 0), dropped.ctypes.data, ctypes.byref(h),
                           ctypes.byref(ph) if candidates else None))
-    las, trace, _ = _take_la_set(h)
+    if trace_on_device:
+        n = L.dh_la_set_count(h)
+        owner = _LaSetOwner(h)
+        if n:
+            buf = (ctypes.c_uint8 * (n * LA_DTYPE.itemsize)).from_address(L.dh_la_set_records(h))
+            buf._owner = owner
+            las = np.frombuffer(buf, dtype=LA_DTYPE)
+        else:
+            las = np.zeros(0, dtype=LA_DTYPE)
+        trace = DeviceTrace(owner, h)
+    else:
+        las, trace, _ = _take_la_set(h)
     if candidates:
         return las, trace, dropped, Pileups(None, None, None, _handle=ph)
     return las, trace, dropped
@@ -1285,10 +1325,14 @@ def process_pileups(ctx, contigs, reads, las, trace, piles, opts, insertions_db=
     (ids, off): the read ids of every record's pile-up (what `dentist output` lists in its BED / AGP);
     repeat_mask = (ptr, intervals): the contigs' repeat mask for the cropper (dh_process_pileups_masked)."""
     L = lib()
-    arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
-    tr = np.ascontiguousarray(trace, dtype=np.uint16)
     h = ctypes.c_void_p()
     keep, rp, ri = _mask_args(repeat_mask)
+    if isinstance(trace, DeviceTrace):   # (the records are the set's own: `las` is the view of them map_reads returned)
+        L.dh_process_pileups_set.argtypes = [ctypes.c_void_p] * 9
+        _check(L.dh_process_pileups_set(ctx._h, contigs._h, reads._h, trace._h, piles._h, rp, ri, ctypes.byref(opts), ctypes.byref(h)))
+        return _take_insertions(h, insertions_db, read_ids)
+    arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
+    tr = np.ascontiguousarray(trace, dtype=np.uint16)
     L.dh_process_pileups_masked.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int64] + [ctypes.c_void_p] * 6
     _check(L.dh_process_pileups_masked(ctx._h, contigs._h, reads._h, arr.ctypes.data, len(arr), tr.ctypes.data,
                                        piles._h, rp, ri, ctypes.byref(opts), ctypes.byref(h)))

@@ -899,9 +899,33 @@ static int build_index(dh_db *A, int32_t k, int32_t sepv, int32_t kmer_mod, bool
 
 extern "C" void dh_la_set_destroy(dh_la_set *s) { delete s; }
 extern "C" int64_t dh_la_set_count(const dh_la_set *s) { return s ? (int64_t)s->la.size() : 0; }
-extern "C" int64_t dh_la_set_trace_len(const dh_la_set *s) { return s ? (int64_t)s->trace.size() : 0; }
+dh_la_set::~dh_la_set()
+{
+    if (d_trace_own) {
+        (void)hipSetDevice(device);
+        dh_dev_free(d_trace_own);
+    }
+}
+int dh_la_set_ensure_host_trace(dh_la_set *s)
+{
+    if (!s || !s->trace.empty() || s->d_trace_own_len <= 0) return DH_OK;
+    HIPCHK(hipSetDevice(s->device));
+    s->trace.resize((size_t)s->d_trace_own_len);
+    HIPCHK(hipMemcpy(s->trace.data(), s->d_trace_own, sizeof(uint16_t) * (size_t)s->d_trace_own_len, hipMemcpyDeviceToHost));
+    return DH_OK;
+}
+extern "C" int32_t dh_la_set_trace_on_device(const dh_la_set *s) { return s && s->d_trace_own_len > 0 && s->trace.empty() ? 1 : 0; }
+extern "C" int64_t dh_la_set_trace_len(const dh_la_set *s)
+{
+    return s ? (s->trace.empty() && s->d_trace_own_len > 0 ? s->d_trace_own_len : (int64_t)s->trace.size()) : 0;
+}
 extern "C" const dh_la *dh_la_set_records(const dh_la_set *s) { return s ? s->la.data() : nullptr; }
-extern "C" const uint16_t *dh_la_set_trace(const dh_la_set *s) { return s ? s->trace.data() : nullptr; }
+extern "C" const uint16_t *dh_la_set_trace(const dh_la_set *s)
+{
+    if (!s) return nullptr;
+    if (dh_la_set_ensure_host_trace(const_cast<dh_la_set *>(s)) != DH_OK) return nullptr;  // (left on the device: fetched now)
+    return s->trace.data();
+}
 extern "C" int32_t dh_la_set_tspace(const dh_la_set *s) { return s ? s->tspace : 0; }
 
 // LAsort order (a, b, comp, abpos, aepos, bbpos, bepos, diffs): base.d:1787-1809
@@ -1115,8 +1139,9 @@ extern "C" int dh_map_reads(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_t f
 {
     if (!contigs || !reads || !popts || first < 0 || count < 0 || (int64_t)first + count > reads->n)
         return fail(DH_EINVAL, "dh_map_reads: bad argument");
-    if (cands && want_sorted)
-        return fail(DH_EINVAL, "dh_map_reads: candidates index the records in mapping order (want_sorted = 0)");
+    if (cands && (want_sorted & 1))
+        return fail(DH_EINVAL, "dh_map_reads: candidates index the records in mapping order (want_sorted bit 0 clear)");
+    want_sorted &= 1 | 8;  // (bit 0: LAsort order; bit 3: the trace values stay on the device, dh_la_set_trace fetches them on demand)
     if (cands) *cands = nullptr;
     std::mutex mu;
     int64_t dropped[6] = {0, 0, 0, 0, 0, 0};
@@ -1486,6 +1511,8 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
     SCR(8, d_queue, 4)
     // (symmetric DH-2 launches keep their records in candidate-indexed slots, sized once the candidates are counted)
     const bool sym_tiled = tiled && o.skip_self == 2;
+    // want_sorted & 8 (dh_map_reads): the trace values of every chunk stay on the device in a buffer the result owns
+    const bool keep_dev = (want_sorted & 8) && hook && tiled && !out_tr && !sym_tiled;
     if (!sym_tiled) {
         SCR(9, d_la, (size_t)cn * o.max_la)
         SCR(10, d_trslots, (size_t)cn * o.max_la * trmax)
@@ -2130,8 +2157,28 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             // the compacted buffers are reused: the previous chunk's copies must have left them
             HIPCHK(hipStreamSynchronize(ctx->cstream));
             SCR(13, d_laout, totals[0])
-            SCR(14, d_trout, totals[1])
-            const size_t l0 = res->la.size(), t0 = res->trace.size();
+            const size_t l0 = res->la.size(), t0 = keep_dev ? (size_t)res->d_trace_own_len : res->trace.size();
+            if (keep_dev) {
+                // the chunk's trace values are compacted straight into the set's own device buffer (grown by copy when
+                // the first chunk's yield was a bad guess for the call)
+                const int64_t need = (int64_t)t0 + totals[1];
+                if (need > res->d_trace_own_cap) {
+                    const double f = 1.15 * (double)nitems_total / std::max<double>(1.0, (double)(item0 - item_first + ni));
+                    const int64_t cap = std::max<int64_t>(need + 65536, (int64_t)(f * (double)need) + 65536);
+                    uint16_t *nb = nullptr;
+                    HIPCHK(dh_dev_alloc((void **)&nb, sizeof(uint16_t) * (size_t)cap));
+                    if (res->d_trace_own) {
+                        HIPCHK(hipMemcpyAsync(nb, res->d_trace_own, sizeof(uint16_t) * t0, hipMemcpyDeviceToDevice, st));
+                        HIPCHK(hipStreamSynchronize(st));
+                        dh_dev_free(res->d_trace_own);
+                    }
+                    res->d_trace_own = nb;
+                    res->d_trace_own_cap = cap;
+                    res->device = ctx->device;
+                }
+                d_trout = res->d_trace_own + t0;
+            } else
+                SCR(14, d_trout, totals[1])
             if (sym_tiled) {
                 uint32_t *d_cur;
                 SCR(53, d_cur, (size_t)ni)
@@ -2147,14 +2194,17 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
                 // the result never moves while it grows
                 const double f = 1.15 * (double)nitems_total / ni;
                 res->la.reserve((size_t)(f * totals[0]) + 1024);
-                res->trace.reserve((size_t)(f * totals[1]) + 65536);
+                if (!keep_dev) res->trace.reserve((size_t)(f * totals[1]) + 65536);
             }
-            if (l0 + totals[0] > res->la.capacity() || t0 + totals[1] > res->trace.capacity())
+            if (l0 + totals[0] > res->la.capacity() || (!keep_dev && t0 + totals[1] > res->trace.capacity()))
                 tasks.join();  // the records are about to move: copies and hooks in flight finish first
             const bool dev_only = (want_sorted & 2) && t0 == 0 && item0 == item_first && ni == nitems_total;
             const bool rec_dev = dev_only && (want_sorted & 4) && sym_tiled && l0 == 0 && !hook;
             if (!rec_dev) res->la.resize(l0 + totals[0]);
-            if (!dev_only) res->trace.resize(t0 + totals[1]);
+            if (keep_dev)
+                res->d_trace_own_len = (int64_t)t0 + totals[1];
+            else if (!dev_only)
+                res->trace.resize(t0 + totals[1]);
             lap(4);
             // device-to-host on the copy stream: it overlaps the next chunk's kernels
             hipEvent_t compacted = ctx->cev[nchunk_done & 1];
@@ -2165,7 +2215,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             const hipEvent_t copied_ev = copied;
             const uint32_t nla_c = totals[0], ntr_c = totals[1];
             hipStream_t cst = ctx->cstream;
-            enqueue_copy = [res, l0, t0, nla_c, ntr_c, dev_only, compacted, copied_ev, cst, d_laout, d_trout]() -> int {
+            enqueue_copy = [res, l0, t0, nla_c, ntr_c, dev_only, keep_dev, compacted, copied_ev, cst, d_laout, d_trout]() -> int {
                 HIPCHK(hipStreamWaitEvent(cst, compacted, 0));
                 HIPCHK(hipMemcpyAsync(res->la.data() + l0, d_laout, sizeof(dh_la) * (size_t)nla_c, hipMemcpyDeviceToHost, cst));
                 // the chunk's hook (chain flags, filters, candidates) reads the records only: it starts when they have
@@ -2174,7 +2224,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
                 HIPCHK(hipEventRecord(copied_ev, cst));
                 // (want_sorted & 2: the caller reads the trace from the device copy -- the pile-up all-vs-all, whose host
                 // side needs 1 / n of the values: the overlaps of the reference reads -- so the 2 x 160 MB of configs[2] stay)
-                if (ntr_c > 0 && !dev_only)
+                if (ntr_c > 0 && !dev_only && !keep_dev)
                     HIPCHK(hipMemcpyAsync(res->trace.data() + t0, d_trout, sizeof(uint16_t) * (size_t)ntr_c, hipMemcpyDeviceToHost, cst));
                 return DH_OK;
             };
@@ -2308,7 +2358,7 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
         c.las += stats.las;
         c.hits += stats.hits;
         c.b_bases += stats.b_bases;
-        c.trace_values += res->d_trace_len > 0 ? res->d_trace_len : (int64_t)res->trace.size();
+        c.trace_values += res->d_trace_len > 0 ? res->d_trace_len : (res->d_trace_own_len > 0 ? res->d_trace_own_len : (int64_t)res->trace.size());
         std::atomic<int64_t> abp{0};
         const dh_la *lp = res->la.data();
         dh_parallel_for((int64_t)res->la.size(), 1 << 16, [&](int64_t lo, int64_t hi) {
@@ -2463,6 +2513,7 @@ extern "C" int dh_la_set_merge(const dh_la_set *const *sets, int32_t nsets, dh_l
     size_t nla = 0, ntr = 0;
     for (int32_t i = 0; i < nsets; i++) {
         if (!sets[i]) return fail(DH_EINVAL, "dh_la_set_merge: NULL set");
+        if (int rc = dh_la_set_ensure_host_trace(const_cast<dh_la_set *>(sets[i]))) return rc;
         if (!sets[i]->la.empty()) {
             if (tspace >= 0 && sets[i]->tspace != tspace)
                 return fail(DH_EINVAL, "dh_la_set_merge: sets with different trace spacing");

@@ -189,7 +189,16 @@ struct dh_la_set {
     // B reads whose items overflowed a per-item capacity (dropped records / no candidates), see
     // dh_align_stats.overflow_items; the pile-up path skips the pile-ups of such reads
     std::vector<int32_t> ovf_reads;
+    // dh_map_reads(want_sorted & 8): the trace values of ALL chunks stay on the device in a buffer this set owns (toff
+    // indexes it); `trace` is empty until somebody asks for it (dh_la_set_trace downloads it then).  The cropper of the
+    // process stage reads the trace of one record in ten: dh_process_pileups_set gathers those on the device.
+    uint16_t *d_trace_own = nullptr;
+    int64_t d_trace_own_len = 0, d_trace_own_cap = 0;
+    int device = 0;
+    ~dh_la_set();
 };
+// the host copy of a set's trace values, downloaded on first use when they were left on the device
+int dh_la_set_ensure_host_trace(dh_la_set *s);
 
 // result of the process stage (dh_process.cpp; dh_comm.cpp assembles the gathered result of all ranks)
 struct dh_insertions {

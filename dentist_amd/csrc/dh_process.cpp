@@ -1638,6 +1638,78 @@ extern "C" int dh_process_pileups(dh_ctx *ctx, dh_db *contigs, dh_db *reads, con
     return dh_process_pileups_masked(ctx, contigs, reads, las, n, trace, piles, nullptr, nullptr, opts, out);
 }
 
+// The same on a mapping result whose trace values were left on the device (dh_map_reads, want_sorted & 8): the cropper reads
+// the trace of the pile-up reads' records only -- one record in ten at configs[2] --, so those ranges are gathered on the
+// device (k_gather_ranges16), brought over in one copy and laid out at their offsets in a host array nothing else of
+// which is touched; 330 MB of trace values per step of configs[2] no longer cross PCIe.  rep_ptr / rep_iv may be NULL.
+extern "C" int dh_process_pileups_set(dh_ctx *ctx, dh_db *contigs, dh_db *reads, dh_la_set *set, const dh_pileups *piles,
+                                      const int64_t *rep_ptr, const int32_t *rep_iv, const dh_process_opts *opts,
+                                      dh_insertions **out)
+{
+    if (!ctx || !reads || !set || !piles || !out) return dh_fail(DH_EINVAL, "dh_process_pileups_set: NULL argument");
+    const int64_t n = (int64_t)set->la.size();
+    if (!(set->trace.empty() && set->d_trace_own_len > 0))
+        return dh_process_pileups_masked(ctx, contigs, reads, set->la.data(), n, set->trace.data(), piles, rep_ptr, rep_iv, opts, out);
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::vector<uint8_t> need((size_t)reads->n, 0);
+    for (const auto &t : piles->triples)
+        for (size_t x = 0; x + 2 < t.size(); x += 3) {
+            if (t[x] < 0 || t[x] >= reads->n) return dh_fail(DH_EINVAL, "dh_process_pileups_set: read id out of range");
+            need[(size_t)t[x]] = 1;
+        }
+    const dh_la *la = set->la.data();
+    // the records of the needed reads (all of them: chain members follow their first record), found by the host threads
+    const int64_t grain = 1 << 15, nch = (n + grain - 1) / grain;
+    std::vector<std::vector<int64_t>> part((size_t)std::max<int64_t>(nch, 1));
+    std::atomic<int> bad{0};
+    dh_parallel_for(nch, 1, [&](int64_t clo, int64_t chi) {
+        for (int64_t c = clo; c < chi; c++) {
+            auto &v = part[(size_t)c];
+            for (int64_t i = c * grain; i < std::min(n, (c + 1) * grain); i++) {
+                if (la[i].bread < 0 || la[i].bread >= reads->n) continue;
+                if (!need[(size_t)la[i].bread] || la[i].tlen <= 0) continue;
+                if (la[i].toff < 0 || la[i].toff + la[i].tlen > set->d_trace_own_len) bad = 1;
+                v.push_back(i);
+            }
+        }
+    });
+    if (bad.load()) return dh_fail(DH_EINVAL, "dh_process_pileups_set: a record's trace lies outside the set's trace");
+    std::vector<int64_t> desc;
+    int64_t total = 0;
+    for (const auto &v : part)
+        for (int64_t i : v) {
+            desc.push_back(la[i].toff);
+            desc.push_back(total);
+            desc.push_back(la[i].tlen);
+            total += la[i].tlen;
+        }
+    const int64_t nsel = (int64_t)desc.size() / 3;
+    // (from the pool of page-locked result buffers, as the whole trace would have been: no page is faulted in here -- a
+    // malloc'd array cost 30 ms of first-touch faults per call -- and nothing but the gathered ranges is written)
+    TraceVec sparse_v((size_t)std::max<int64_t>(set->d_trace_own_len, 1));
+    uint16_t *sparse = sparse_v.data();
+    if (nsel > 0) {
+        if (nsel > INT32_MAX) return dh_fail(DH_EOVERFLOW, "dh_process_pileups_set: too many records");
+        DevBuf<int64_t> d_desc;
+        DevBuf<uint16_t> d_tt;
+        HIPCHK(d_desc.alloc(desc.size()));
+        HIPCHK(d_tt.alloc((size_t)total));
+        TraceVec tmp((size_t)total);
+        HIPCHK(hipMemcpyAsync(d_desc.p, desc.data(), sizeof(int64_t) * desc.size(), hipMemcpyHostToDevice, st));
+        dhk_gather_ranges16(st, set->d_trace_own, d_desc.p, (int32_t)nsel, d_tt.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(tmp.data(), d_tt.p, sizeof(uint16_t) * (size_t)total, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        const int64_t *dp = desc.data();
+        const uint16_t *tp = tmp.data();
+        dh_parallel_for(nsel, 4096, [&](int64_t lo, int64_t hi) {
+            for (int64_t r = lo; r < hi; r++) memcpy(sparse + dp[3 * r], tp + dp[3 * r + 1], sizeof(uint16_t) * (size_t)dp[3 * r + 2]);
+        });
+    }
+    return dh_process_pileups_masked(ctx, contigs, reads, la, n, sparse, piles, rep_ptr, rep_iv, opts, out);
+}
+
 // with the repeat mask of the contigs (--mask of `dentist process`: the cropper keeps its trace points out of it)
 extern "C" int dh_process_pileups_masked(dh_ctx *ctx, dh_db *contigs, dh_db *reads, const dh_la *las, int64_t n,
                                          const uint16_t *trace, const dh_pileups *piles, const int64_t *rep_ptr,

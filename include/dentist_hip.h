@@ -348,7 +348,9 @@ int64_t dh_validate_regions(const dh_la *las, int64_t n, const int64_t *contig_o
  * the device maps the next chunk.  want_sorted != 0: result = dh_align_db_block(want_best = 1) followed by
  * dh_collect_filter (same records, flags and dropped6 counts, LAsort order).  want_sorted == 0: the same
  * records in mapping order (by read, strand); then `cands` (may be NULL) receives the spanning-read
- * candidates of dh_collect_candidates, collected chunk by chunk as well (indices into the result). */
+ * candidates of dh_collect_candidates, collected chunk by chunk as well (indices into the result).
+ * want_sorted is a bit set: 1 = LAsort order; 8 = the trace values stay on the device in a buffer the result owns
+ * (dh_la_set_trace downloads them when asked; dh_process_pileups_set gathers what the cropper needs there). */
 int dh_map_reads(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_t first, int32_t count, const dh_align_opts *opts,
                  const dh_process_opts *popts, const int64_t *rep_ptr, const int32_t *rep_iv, int32_t want_sorted,
                  int64_t *dropped6, dh_la_set **out, dh_pileups **cands);
@@ -535,6 +537,13 @@ int dh_crop_pileups_masked(dh_ctx *ctx, dh_db *contigs, dh_db *reads, int32_t re
 int dh_process_pileups_masked(dh_ctx *ctx, dh_db *contigs, dh_db *reads, const dh_la *las, int64_t n,
                               const uint16_t *trace, const dh_pileups *piles, const int64_t *rep_ptr, const int32_t *rep_iv,
                               const dh_process_opts *opts, dh_insertions **out);
+/* dh_process_pileups_masked on the result set of a mapping itself.  For a set whose trace values stayed on the device
+ * (dh_map_reads with want_sorted & 8) only the trace of the pile-up reads' records is brought to the host -- the cropper
+ * (cropper.d:446-550) reads nothing else; otherwise the same as passing dh_la_set_records / dh_la_set_trace. */
+int dh_process_pileups_set(dh_ctx *ctx, dh_db *contigs, dh_db *reads, dh_la_set *set, const dh_pileups *piles,
+                           const int64_t *rep_ptr, const int32_t *rep_iv, const dh_process_opts *opts, dh_insertions **out);
+/* 1: the set's trace values are on the device only (dh_la_set_trace would fetch them now) */
+int32_t dh_la_set_trace_on_device(const dh_la_set *s);
 int dh_cropped_create(const dh_insertion *rec, int32_t npiles, int32_t nreads, const int32_t *pile,
                       const int32_t *entry, const int32_t *read_id, const int64_t *off, const uint8_t *bases,
                       dh_cropped **out);

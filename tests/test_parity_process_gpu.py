@@ -797,6 +797,36 @@ def test_device_funnel_host_funnel_and_the_fall_back_agree(gpu_ctx, monkeypatch)
         assert rec.tobytes() == out[0][0].tobytes() and np.array_equal(bases, out[0][1])
 
 
+def test_trace_values_left_on_the_device(gpu_ctx, monkeypatch):
+    """dh_map_reads with want_sorted & 8: the trace values of every chunk stay in HBM in a buffer the result set owns, and
+    dh_process_pileups_set brings over what the cropper reads (cropper.d:446-550: the records of the pile-up reads) and
+    nothing else.  Several chunks (DH_ALIGN_CHUNK): identical records; the trace downloaded on demand equals the one the
+    plain call copies chunk by chunk; `process` through the set equals `process` on the host arrays, bit for bit."""
+    monkeypatch.setenv("DH_ALIGN_CHUNK", "700")
+    w = sim.Workload(500_000, 5, 1500, 7000, seed=77, spacing=20000, gap_max=1500)
+    mo = dentist_amd.default_align_opts(kmer_mod=4, k=20, width=64, xdrop=60, algo=1)
+    po = dentist_amd.default_process_opts(algo=1, rounds=2)
+    A, B = gpu_ctx.db(w.contigs), gpu_ctx.db(w.reads)
+    las0, trace0, dropped0 = gpu_ctx.map_reads(A, B, mo, po, sorted=False)[:3]
+    las1, dtrace, dropped1 = gpu_ctx.map_reads(A, B, mo, po, sorted=False, trace_on_device=True)[:3]
+    assert isinstance(dtrace, dentist_amd.DeviceTrace) and dtrace.on_device() and len(dtrace) == len(trace0)
+    assert las1.tobytes() == las0.tobytes() and list(dropped0) == list(dropped1)
+    gaps = np.stack([np.arange(w.contigs.n - 1), np.arange(1, w.contigs.n)], axis=1).astype(np.int32)
+    gp, _ = dentist_amd.scaffold_spanning_pileups(las0, w.contigs.off, w.reads.off, gaps, with_extensions=True,
+                                                  min_spanning_reads=po.min_reads)
+    piles = gp.select(las0, po)
+    assert len(piles) >= 3
+    r0, b0 = dentist_amd.process_pileups(gpu_ctx, A, B, las0, trace0, piles, po)
+    r1, b1 = dentist_amd.process_pileups(gpu_ctx, A, B, las1, dtrace, piles, po)
+    assert dtrace.on_device()                      # (process took what it needed, the rest is still in HBM only)
+    assert (r0["status"] == 0).sum() >= 3 and r1.tobytes() == r0.tobytes() and np.array_equal(b0, b1)
+    assert np.array_equal(dtrace.numpy(), trace0) and not dtrace.on_device()
+    # sorted order with the trace on the device: the records are permuted, their offsets still name the same values
+    las2, dtrace2, _ = gpu_ctx.map_reads(A, B, mo, po, sorted=True, trace_on_device=True)[:3]
+    las3, trace3, _ = gpu_ctx.map_reads(A, B, mo, po, sorted=True)[:3]
+    assert_same_las((las2, dtrace2.numpy()), (las3, trace3))
+
+
 def test_chains_below_the_default_min_relative_score(gpu_ctx):
     """dh_process_opts.min_relative_score_ppm (--min-relative-score of `dentist process`, commandline.d:2141-2153;
     buildAlignmentChains chaining.d:151-312: components of the chainability relation, the chains within that fraction of
