@@ -75,6 +75,29 @@ def test_the_tiers_of_the_seed_back_end(monkeypatch):
         ctx.close()
 
 
+def test_release_scratch_between_calls():
+    """dh_ctx_release_scratch hands the context's grow-only device scratch back (a long-lived host between workloads; the
+    partitioned join of an unsampled mapping of configs[2] keeps 100 GB): the next call allocates again and gives the same bits."""
+    w = sim.Workload(300_000, 3, 600, 6000, seed=91, spacing=20000)
+    ctx = dentist_amd.Context(0)
+    try:
+        g = dentist_amd.default_align_opts(k=20, kmer_mod=4, algo=1, width=64)
+        A, B = ctx.db(w.contigs), ctx.db(w.reads)
+        a = ctx.align_db(A, B, g)
+        ctx.release_scratch()
+        ctx.release_scratch()          # (idempotent)
+        b = ctx.align_db(A, B, g)
+        assert_same_las(a, b)
+        po = dentist_amd.default_process_opts(algo=1, rounds=1)
+        piles = dentist_amd.Pileups(a[0], w.contigs.off, po)
+        r0, b0 = dentist_amd.process_pileups(ctx, A, B, a[0], a[1], piles, po)
+        ctx.release_scratch()
+        r1, b1 = dentist_amd.process_pileups(ctx, A, B, a[0], a[1], piles, po)
+        assert r0.tobytes() == r1.tobytes() and np.array_equal(b0, b1) and (r0["status"] == 0).sum() >= 1
+    finally:
+        ctx.close()
+
+
 def test_equal_to_the_directory_lookups_on_every_field(gpu_ctx, monkeypatch):
     """The same call with DH_NO_MJOIN=1 (one random directory line per k-mer): identical records, trace and counters."""
     w = sim.Workload(600_000, 5, 1500, 9000, seed=71, spacing=20000)
