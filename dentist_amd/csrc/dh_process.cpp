@@ -2754,7 +2754,7 @@ static_assert(sizeof(CandRec) == 104 && sizeof(CropHead) == 16, "blob layouts");
 }  // namespace
 
 struct dh_shard_plan {
-    std::vector<dh_la> las;        // L0 R0 L1 R1 ... of every gathered candidate, in gather order
+    dh_la_vec las;                 // L0 R0 L1 R1 ... of every gathered candidate, in gather order
     dh_pileups *piles = nullptr;   // after the min / max reads cut; LA indices into `las`
     std::vector<int32_t> owner;    // rank that processes each pile-up
     ~dh_shard_plan() { delete piles; }
@@ -2799,7 +2799,8 @@ static void plan_owners(dh_shard_plan *p, int32_t world)
 {
     const size_t np = p->piles->contig_left.size();
     std::vector<int64_t> cost(np);
-    for (size_t g = 0; g < np; g++) {
+    dh_parallel_for((int64_t)np, 16, [&](int64_t glo, int64_t ghi) {
+    for (size_t g = (size_t)glo; g < (size_t)ghi; g++) {
         const std::vector<int32_t> &t = p->piles->triples[g];
         const int64_t cnt = (int64_t)t.size() / 3;
         int64_t span = 0;
@@ -2812,6 +2813,7 @@ static void plan_owners(dh_shard_plan *p, int32_t world)
         const double mean = (double)span / (double)std::max<int64_t>(nspan, 1) + 1000.0;
         cost[g] = (int64_t)((double)(cnt * cnt) * mean);
     }
+    });
     std::vector<int32_t> order(np);
     for (size_t g = 0; g < np; g++) order[g] = (int32_t)g;
     std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return cost[(size_t)a] != cost[(size_t)b] ? cost[(size_t)a] > cost[(size_t)b] : a < b; });

@@ -232,10 +232,9 @@ struct JoinRec {
 static_assert(sizeof(JoinRec) == 32 + 2 * sizeof(dh_la) && sizeof(JoinHead) == 16, "join blob layout");
 
 // The raw joins of the reads [read_first, read_first + nreads) named by `las` (bread = global read id), in read
-// order: runs of reads per host thread, each run either kept raw (`raws`) or turned into edges (`edges`).
+// order: one flat array per run of reads (a run per host thread).
 int collect_raw_joins(const char *who, const dh_la *las, int64_t n, const int64_t *contig_off, int32_t ncontigs,
-                      const int64_t *read_off, int32_t read_first, int32_t nreads, std::vector<std::vector<RawJoin>> *raws,
-                      std::vector<std::vector<Edge>> *edges)
+                      const int64_t *read_off, int32_t read_first, int32_t nreads, std::vector<std::vector<RawJoin>> *raws)
 {
     Ctx c{las, contig_off, read_off - read_first};
     auto T0_ = std::chrono::steady_clock::now();
@@ -313,25 +312,21 @@ int collect_raw_joins(const char *who, const dh_la *las, int64_t n, const int64_
     live.clear();
     LAP_("group by read");
     // ---- raw joins of the reads, in read order (collectScaffoldJoins, pileups.d:650-667)
-    // (every host thread also merges the equal edges of its run of reads: the stable sort keeps the reads of an
-    // edge in read order, and the serial merge below then handles a few thousand edges instead of one per read)
-    // (64 runs: with 16 the step ran on 16 of the host's cores -- the serial merge takes 64 short edge lists as easily)
+    // (64 runs: with 16 the step ran on 16 of the host's cores; the runs stay raw -- scaffold_from_runs sorts them by
+    // edge, all runs at once)
     const int64_t grain = std::max<int64_t>(4096, ((int64_t)nreads + 63) / 64), nchunks = ((int64_t)nreads + grain - 1) / grain;
-    if (raws) raws->assign((size_t)std::max<int64_t>(nchunks, 1), {});
-    if (edges) edges->assign((size_t)std::max<int64_t>(nchunks, 1), {});
+    raws->assign((size_t)std::max<int64_t>(nchunks, 1), {});
     dh_parallel_for(nchunks, 1, [&](int64_t clo, int64_t chi) {
         std::vector<SA> sa;
         std::vector<std::pair<size_t, size_t>> sl;
-        std::vector<RawJoin> local;
         for (int64_t ch = clo; ch < chi; ch++) {
-            std::vector<RawJoin> &raw = raws ? (*raws)[(size_t)ch] : local;
+            std::vector<RawJoin> &raw = (*raws)[(size_t)ch];
             const int32_t r1 = (int32_t)std::min<int64_t>(nreads, (ch + 1) * grain);
             raw.clear();
             for (int32_t rd = (int32_t)(ch * grain); rd < r1; rd++) {
                 const int64_t cnt = first[(size_t)rd + 1] - first[(size_t)rd];
                 if (cnt > 0) read_joins(c, order.data() + first[(size_t)rd], cnt, raw, sa, sl);
             }
-            if (edges) raw_to_edges(raw, (*edges)[(size_t)ch]);
         }
     });
     LAP_("read joins");
@@ -339,8 +334,8 @@ int collect_raw_joins(const char *who, const dh_la *las, int64_t n, const int64_
 }
 
 struct Resolver;
-int scaffold_from_edges(std::vector<std::vector<Edge>> &found, int32_t ncontigs, const int32_t *input_gaps, int32_t ngaps,
-                        const dh_scaffold_opts *opts, dh_scaffold **out, Resolver *rs = nullptr);
+int scaffold_from_runs(std::vector<std::vector<RawJoin>> &runs, int32_t ncontigs, const int32_t *input_gaps, int32_t ngaps,
+                       const dh_scaffold_opts *opts, dh_scaffold **out, Resolver *rs = nullptr);
 }  // namespace
 
 extern "C" int dh_scaffold_pileups(const dh_la *las, int64_t n, const int64_t *contig_off, int32_t ncontigs,
@@ -359,9 +354,9 @@ extern "C" int dh_scaffold_pileups(const dh_la *las, int64_t n, const int64_t *c
     dh_chain_view_build(las, n, cv);
     const dh_la *u = cv.trivial ? las : cv.unit.data();
     const int64_t nu = cv.trivial ? n : (int64_t)cv.unit.size();
-    std::vector<std::vector<Edge>> found;
-    if (int rc = collect_raw_joins("dh_scaffold_pileups", u, nu, contig_off, ncontigs, read_off, 0, nreads, nullptr, &found)) return rc;
-    if (int rc = scaffold_from_edges(found, ncontigs, input_gaps, ngaps, opts, out)) return rc;
+    std::vector<std::vector<RawJoin>> found;
+    if (int rc = collect_raw_joins("dh_scaffold_pileups", u, nu, contig_off, ncontigs, read_off, 0, nreads, &found)) return rc;
+    if (int rc = scaffold_from_runs(found, ncontigs, input_gaps, ngaps, opts, out)) return rc;
     if (!cv.trivial)
         for (dh_read_alignment &ra : (*out)->entries) {
             ra.la0 = (int32_t)cv.first[(size_t)ra.la0];
@@ -388,7 +383,7 @@ extern "C" int dh_shard_read_joins(const dh_la *las, int64_t n, const int64_t *c
     auto mfirst = [&](int32_t ci) { return cv.trivial ? (int64_t)ci : cv.first[(size_t)ci]; };
     auto mend = [&](int32_t ci) { return cv.trivial ? (int64_t)ci + 1 : cv.first[(size_t)ci + 1]; };
     std::vector<std::vector<RawJoin>> raws;
-    if (int rc = collect_raw_joins("dh_shard_read_joins", u, nu, contig_off, ncontigs, read_off, read_first, nreads, &raws, nullptr)) return rc;
+    if (int rc = collect_raw_joins("dh_shard_read_joins", u, nu, contig_off, ncontigs, read_off, read_first, nreads, &raws)) return rc;
     size_t tot = 0, totx = 0;
     std::vector<size_t> at(raws.size()), atx(raws.size());
     for (size_t i = 0; i < raws.size(); i++) {
@@ -445,10 +440,12 @@ extern "C" int dh_shard_read_joins(const dh_la *las, int64_t n, const int64_t *c
 // second unused for an extension), which the entries of the scaffold index
 int dh_scaffold_from_join_blobs(const uint8_t *const *blobs, const int64_t *sizes, int32_t world, int32_t ncontigs,
                                 const int32_t *input_gaps, int32_t ngaps, const dh_scaffold_opts *opts,
-                                std::vector<dh_la> &glas, dh_scaffold **out)
+                                dh_la_vec &glas, dh_scaffold **out)
 {
     if (!blobs || !sizes || world < 1 || !opts || !out || ncontigs < 0 || (ngaps > 0 && !input_gaps) || ngaps < 0)
         return dh_fail(DH_EINVAL, "dh_shard_graph_plan_create: bad argument");
+    auto T0_ = std::chrono::steady_clock::now();
+    auto LAP_ = [&](const char *w) { if (getenv("DH_TRACE")) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[scaffold] %-24s %.2f ms\n", w, std::chrono::duration<double, std::milli>(t - T0_).count()); T0_ = t; } };
     int64_t tot = 0, totx = 0;
     std::vector<int64_t> start((size_t)world + 1, 0);
     std::vector<const JoinRec *> recs((size_t)world, nullptr);
@@ -472,31 +469,47 @@ int dh_scaffold_from_join_blobs(const uint8_t *const *blobs, const int64_t *size
             return dh_fail(DH_EINVAL, "dh_shard_graph_plan_create: input gap names a contig out of range");
     // where the records of every join go: the members of a chain behind its first record (la0 chain, then la1 chain).  Two
     // copies that would read as one chain (a record flagged NEXT without START behind a copy of its own read on the same
-    // contig) are kept apart by a separator record that continues nothing
+    // contig) are kept apart by a separator record that continues nothing.  One host thread per rank's blob lays its
+    // records out from zero (the record in front of a blob's first one is the last record of the nearest non-empty blob
+    // before it); the blobs' sizes are then summed up
     std::vector<int32_t> pos0((size_t)tot), pos1((size_t)tot);
     std::vector<int64_t> xoff((size_t)tot);
-    int64_t cur = 0;
-    bool malformed = false;
-    {
+    std::vector<int64_t> nrec((size_t)world + 1, 0);
+    std::vector<std::vector<int32_t>> seps((size_t)world);  // where a blob's separator records go (blob-relative)
+    std::atomic<int> malformed{0};
+    auto last_record = [&](int32_t r) -> const dh_la * {  // of blob r, nullptr: no joins (call only on checked blobs' tails)
+        const int64_t nj = start[(size_t)r + 1] - start[(size_t)r];
+        if (!nj) return nullptr;
+        const JoinRec &j = recs[(size_t)r][nj - 1];
+        const int64_t nx = (sizes[r] - (int64_t)sizeof(JoinHead) - nj * (int64_t)sizeof(JoinRec)) / (int64_t)sizeof(dh_la);
+        const int32_t tail = j.n == 2 ? j.x1 : j.x0;
+        const int64_t last = j.n == 2 ? nx - 1 : nx - 1 - j.x1;
+        if (j.x0 < 0 || j.x1 < 0 || (j.n != 1 && j.n != 2) || (tail > 0 && (last < 0 || last >= nx))) return nullptr;  // (reported as malformed by its own pass)
+        return tail ? &extras[(size_t)r][last] : (j.n == 2 ? &j.la1 : &j.la0);
+    };
+    dh_parallel_for(world, 1, [&](int64_t rlo, int64_t rhi) {
         auto may_continue = [](const dh_la &x) { return (x.flags & DH_FLAG_NEXT) && !(x.flags & DH_FLAG_START); };
-        const dh_la *prev = nullptr;  // the record that will precede the next one placed
-        int64_t at = 0;
-        for (int32_t r = 0; r < world && !malformed; r++) {
-            int64_t xr = 0;
-            const int64_t nx = (sizes[r] - (int64_t)sizeof(JoinHead) - (start[(size_t)r + 1] - start[(size_t)r]) * (int64_t)sizeof(JoinRec)) / (int64_t)sizeof(dh_la);
-            for (int64_t i = 0; i < start[(size_t)r + 1] - start[(size_t)r]; i++, at++) {
+        for (int32_t r = (int32_t)rlo; r < (int32_t)rhi; r++) {
+            const dh_la *prev = nullptr;  // the record that will precede the next one placed
+            for (int32_t q = r - 1; q >= 0 && !prev; q--) prev = last_record(q);
+            int64_t xr = 0, cur = 0;
+            const int64_t nj = start[(size_t)r + 1] - start[(size_t)r];
+            const int64_t nx = (sizes[r] - (int64_t)sizeof(JoinHead) - nj * (int64_t)sizeof(JoinRec)) / (int64_t)sizeof(dh_la);
+            int64_t at = start[(size_t)r];
+            bool bad = false;
+            for (int64_t i = 0; i < nj; i++, at++) {
                 const JoinRec &j = recs[(size_t)r][i];
                 if (j.x0 < 0 || j.x1 < 0 || (j.n != 1 && j.n != 2) || xr + j.x0 + j.x1 > nx) {
-                    malformed = true;
+                    bad = true;
                     break;
                 }
                 xoff[(size_t)at] = xr;
-                if (prev && may_continue(j.la0) && dh_continues_chain(*prev, j.la0)) cur++;
+                if (prev && may_continue(j.la0) && dh_continues_chain(*prev, j.la0)) seps[(size_t)r].push_back((int32_t)cur++);
                 pos0[(size_t)at] = (int32_t)cur;
                 cur += 1 + j.x0;
                 prev = j.x0 ? &extras[(size_t)r][xr + j.x0 - 1] : &j.la0;
                 if (j.n == 2) {
-                    if (may_continue(j.la1) && dh_continues_chain(*prev, j.la1)) cur++;
+                    if (may_continue(j.la1) && dh_continues_chain(*prev, j.la1)) seps[(size_t)r].push_back((int32_t)cur++);
                     pos1[(size_t)at] = (int32_t)cur;
                     cur += 1 + j.x1;
                     prev = j.x1 ? &extras[(size_t)r][xr + j.x0 + j.x1 - 1] : &j.la1;
@@ -504,22 +517,28 @@ int dh_scaffold_from_join_blobs(const uint8_t *const *blobs, const int64_t *size
                     pos1[(size_t)at] = -1;
                 xr += j.x0 + j.x1;
             }
-            if (xr != nx) malformed = true;
+            if (bad || xr != nx) malformed = 1;
+            nrec[(size_t)r + 1] = cur;
         }
-    }
+    });
     if (malformed) return dh_fail(DH_EINVAL, "dh_shard_graph_plan_create: malformed join record");
+    for (int32_t r = 0; r < world; r++) nrec[(size_t)r + 1] += nrec[(size_t)r];
+    LAP_("blobs: positions");
     dh_la sep;
     memset(&sep, 0, sizeof(sep));
     sep.aread = sep.bread = -1;
     sep.flags = DH_FLAG_DISABLED;
-    glas.assign((size_t)cur, sep);
-    // runs of the concatenation (rank order = read order) become edges on the host threads, as in the single-rank builder
+    glas.resize((size_t)nrec[(size_t)world]);  // (unwritten: every record is stored below, by the thread that touches its page first)
+    for (int32_t r = 0; r < world; r++)
+        for (int32_t x : seps[(size_t)r]) glas[(size_t)(nrec[(size_t)r] + x)] = sep;
+    LAP_("blobs: records array");
+    // runs of the concatenation (rank order = read order), as in the single-rank builder
     const int64_t grain = 4096, nruns = (tot + grain - 1) / grain;
-    std::vector<std::vector<Edge>> found((size_t)std::max<int64_t>(nruns, 1));
+    std::vector<std::vector<RawJoin>> found((size_t)std::max<int64_t>(nruns, 1));
     std::atomic<int> bad{0};
     dh_parallel_for(nruns, 1, [&](int64_t lo, int64_t hi) {
-        std::vector<RawJoin> raw;
         for (int64_t run = lo; run < hi; run++) {
+            std::vector<RawJoin> &raw = found[(size_t)run];
             const int64_t a0 = run * grain, a1 = std::min(tot, a0 + grain);
             raw.resize((size_t)(a1 - a0));
             int32_t r = (int32_t)(std::upper_bound(start.begin(), start.end(), a0) - start.begin()) - 1;
@@ -530,28 +549,29 @@ int dh_scaffold_from_join_blobs(const uint8_t *const *blobs, const int64_t *size
                     j.e.part < 0 || j.e.part > 3)
                     bad = 1;
                 const dh_la *x = extras[(size_t)r] + xoff[(size_t)at];
-                glas[(size_t)pos0[(size_t)at]] = j.la0;
-                for (int32_t m = 0; m < j.x0; m++) glas[(size_t)pos0[(size_t)at] + 1 + (size_t)m] = x[m];
+                const size_t p0 = (size_t)(nrec[(size_t)r] + pos0[(size_t)at]), p1 = j.n == 2 ? (size_t)(nrec[(size_t)r] + pos1[(size_t)at]) : 0;
+                glas[p0] = j.la0;
+                for (int32_t m = 0; m < j.x0; m++) glas[p0 + 1 + (size_t)m] = x[m];
                 if (j.n == 2) {
-                    glas[(size_t)pos1[(size_t)at]] = j.la1;
-                    for (int32_t m = 0; m < j.x1; m++) glas[(size_t)pos1[(size_t)at] + 1 + (size_t)m] = x[j.x0 + m];
+                    glas[p1] = j.la1;
+                    for (int32_t m = 0; m < j.x1; m++) glas[p1 + 1 + (size_t)m] = x[j.x0 + m];
                 }
                 RawJoin &q = raw[(size_t)(at - a0)];
                 q.s = j.s;
                 q.e = j.e;
                 memset(&q.ra, 0, sizeof(q.ra));
                 q.ra.read = j.read;
-                q.ra.la0 = pos0[(size_t)at];
-                q.ra.la1 = pos1[(size_t)at];
+                q.ra.la0 = (int32_t)p0;
+                q.ra.la1 = j.n == 2 ? (int32_t)p1 : -1;
                 q.ra.seed0 = j.seed0;
                 q.ra.seed1 = j.seed1;
                 q.ra.n = j.n;
             }
-            if (!bad) raw_to_edges(raw, found[(size_t)run]);
         }
     });
     if (bad) return dh_fail(DH_EINVAL, "dh_shard_graph_plan_create: malformed join record");
-    return scaffold_from_edges(found, ncontigs, input_gaps, ngaps, opts, out);
+    LAP_("blobs: records, raw joins");
+    return scaffold_from_runs(found, ncontigs, input_gaps, ngaps, opts, out);
 }
 
 namespace {
@@ -733,54 +753,60 @@ int resolve_bubbles(std::vector<Edge> &g, int32_t ncontigs, Resolver &rs)
     return DH_OK;
 }
 
-int scaffold_from_edges(std::vector<std::vector<Edge>> &found, int32_t ncontigs, const int32_t *input_gaps, int32_t ngaps,
-                        const dh_scaffold_opts *opts, dh_scaffold **out, Resolver *rs)
+int scaffold_from_runs(std::vector<std::vector<RawJoin>> &found, int32_t ncontigs, const int32_t *input_gaps, int32_t ngaps,
+                       const dh_scaffold_opts *opts, dh_scaffold **out, Resolver *rs)
 {
     auto T0_ = std::chrono::steady_clock::now();
     auto LAP_ = [&](const char *w) { if (getenv("DH_TRACE")) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[scaffold] %-24s %.2f ms\n", w, std::chrono::duration<double, std::milli>(t - T0_).count()); T0_ = t; } };
     // ---- the scaffold: default edges, read joins, input gaps (buildScaffold, scaffold.d:237-244)
     std::vector<Edge> g;
     for (int32_t ct = 0; ct < ncontigs; ct++) g.push_back(make_edge(Node{ct, BEGIN}, Node{ct, END}));
-    // the runs' edge lists are sorted by key and hold every key once (raw_to_edges).  The key space is cut into buckets by
-    // the start contig; a bucket's edges are one range of every run (binary search), and the buckets are merged on the host
-    // threads independently: equal keys concatenate their read alignments in run order (= read order), every read
-    // alignment is copied once.  (One serial stable sort over all runs' edges was 7.7 of the 14 ms of the collect stage
-    // at configs[2]; a pairwise tree merge copied the read alignments once per level and was no faster.)
+    // the runs' raw joins (their concatenation is in read order) become edges by ONE stable sort by edge, spread over the
+    // host threads: the key space is cut into buckets by the start contig, every run counts and then scatters its joins
+    // into the buckets' slices (bucket-major, run order inside: the concatenation's order), every bucket is sorted stably
+    // by edge on its own and yields its edges with their read alignments in read order -- an edge's array is allocated
+    // once, at its size.  (Edges per run first, then a merge of the runs' edge lists: reads lie anywhere, so a run of
+    // 4 096 joins of configs[2] held 2 500 edges of 1.6 read alignments -- 100 000 small arrays allocated, merged and freed,
+    // 3.3 of the plan's 8 ms at N = 8; before that one serial stable sort over all edges: 7.7 of the collect stage's 14 ms.)
     {
         const int32_t nbuck = (int32_t)std::max<int64_t>(1, std::min<int64_t>(256, ncontigs / 4));
+        const int64_t nruns = (int64_t)found.size();
+        auto bucket_of = [&](int32_t contig) { return (int32_t)((int64_t)contig * nbuck / std::max(ncontigs, 1)); };
+        std::vector<int64_t> at((size_t)nruns * (size_t)nbuck + 1, 0);  // [bucket][run] -> first slot
+        dh_parallel_for(nruns, 1, [&](int64_t lo, int64_t hi) {
+            for (int64_t run = lo; run < hi; run++)
+                for (const RawJoin &r : found[(size_t)run]) at[(size_t)bucket_of(r.s.contig) * (size_t)nruns + (size_t)run]++;
+        });
+        int64_t total = 0;
+        for (size_t i = 0; i < (size_t)nruns * (size_t)nbuck; i++) {
+            const int64_t c = at[i];
+            at[i] = total;
+            total += c;
+        }
+        at[(size_t)nruns * (size_t)nbuck] = total;
+        std::vector<const RawJoin *> item((size_t)total);
+        dh_parallel_for(nruns, 1, [&](int64_t lo, int64_t hi) {
+            std::vector<int64_t> cur((size_t)nbuck);
+            for (int64_t run = lo; run < hi; run++) {
+                for (int32_t bk = 0; bk < nbuck; bk++) cur[(size_t)bk] = at[(size_t)bk * (size_t)nruns + (size_t)run];
+                for (const RawJoin &r : found[(size_t)run]) item[(size_t)cur[(size_t)bucket_of(r.s.contig)]++] = &r;
+            }
+        });
         std::vector<std::vector<Edge>> merged((size_t)nbuck);
-        auto bucket_lo = [&](int32_t bk) { return (int32_t)((int64_t)ncontigs * bk / nbuck); };
         dh_parallel_for(nbuck, 1, [&](int64_t blo, int64_t bhi) {
-            std::vector<std::pair<Edge *, int32_t>> items;  // (edge, run)
             for (int64_t bk = blo; bk < bhi; bk++) {
-                const int32_t c0 = bucket_lo((int32_t)bk), c1 = bucket_lo((int32_t)bk + 1);
-                items.clear();
-                for (size_t run = 0; run < found.size(); run++) {
-                    std::vector<Edge> &v = found[run];
-                    auto lo = std::lower_bound(v.begin(), v.end(), c0, [](const Edge &e, int32_t c) { return e.s.contig < c; });
-                    auto hi = std::lower_bound(lo, v.end(), c1, [](const Edge &e, int32_t c) { return e.s.contig < c; });
-                    for (auto it = lo; it != hi; ++it) items.emplace_back(&*it, (int32_t)run);
-                }
-                std::sort(items.begin(), items.end(), [](const std::pair<Edge *, int32_t> &a, const std::pair<Edge *, int32_t> &b) {
-                    if (key_less(*a.first, *b.first)) return true;
-                    if (key_less(*b.first, *a.first)) return false;
-                    return a.second < b.second;
-                });
+                const RawJoin **i0 = item.data() + at[(size_t)bk * (size_t)nruns], **i1 = item.data() + at[(size_t)(bk + 1) * (size_t)nruns];
+                std::stable_sort(i0, i1, [](const RawJoin *a, const RawJoin *b) { return a->s == b->s ? a->e < b->e : a->s < b->s; });
                 std::vector<Edge> &out = merged[(size_t)bk];
-                for (size_t i = 0; i < items.size();) {
-                    size_t j = i + 1;
-                    while (j < items.size() && key_eq(*items[i].first, *items[j].first)) j++;
-                    Edge m = std::move(*items[i].first);
-                    if (j - i > 1) {
-                        size_t tot = m.ras.size();
-                        for (size_t x = i + 1; x < j; x++) tot += items[x].first->ras.size();
-                        m.ras.reserve(tot);
-                        for (size_t x = i + 1; x < j; x++) {
-                            m.types |= items[x].first->types;
-                            m.ras.insert(m.ras.end(), items[x].first->ras.begin(), items[x].first->ras.end());
-                            std::vector<dh_read_alignment>().swap(items[x].first->ras);  // freed here, on this thread (not by the serial clear() below)
-                        }
-                    }
+                for (const RawJoin **i = i0; i < i1;) {
+                    const RawJoin **j = i + 1;
+                    while (j < i1 && (*j)->s == (*i)->s && (*j)->e == (*i)->e) j++;
+                    Edge m;
+                    m.s = (*i)->s;
+                    m.e = (*i)->e;
+                    m.types = T_PILEUP;
+                    m.ras.reserve((size_t)(j - i));
+                    for (const RawJoin **x = i; x < j; x++) m.ras.push_back((*x)->ra);
                     out.push_back(std::move(m));
                     i = j;
                 }
@@ -833,6 +859,7 @@ int scaffold_from_edges(std::vector<std::vector<Edge>> &found, int32_t ncontigs,
             }
         remove_none_joins(g);
     }
+    LAP_("discard ambiguous");
     // ---- enforceMinSpanningReads, removeInputGaps (pileups.d:1807-1852)
     for (Edge &e : g)
         if ((e.types & T_PILEUP) && e.is_gap() && (int64_t)e.ras.size() < opts->min_spanning_reads) {
@@ -865,6 +892,7 @@ int scaffold_from_edges(std::vector<std::vector<Edge>> &found, int32_t ncontigs,
             }
         remove_none_joins(g);
     }
+    LAP_("min reads, extensions");
     // ---- collectPileUps (pileups.d:435-444): valid pile-ups in edge order
     dh_scaffold *res = new dh_scaffold();
     for (const Edge &e : g) {
@@ -888,7 +916,7 @@ int scaffold_from_edges(std::vector<std::vector<Edge>> &found, int32_t ncontigs,
         res->joins.push_back(j);
         res->entries.insert(res->entries.end(), e.ras.begin(), e.ras.end());
     }
-    LAP_("rest");
+    LAP_("collect pile-ups");
     *out = res;
     return DH_OK;
 }
@@ -1081,8 +1109,8 @@ static int scaffold_resolved(const dh_la *las, int64_t n, const int64_t *contig_
     dh_chain_view_build(las, n, cv);
     const dh_la *u = cv.trivial ? las : cv.unit.data();
     const int64_t nu = cv.trivial ? n : (int64_t)cv.unit.size();
-    std::vector<std::vector<Edge>> found;
-    if (int rc = collect_raw_joins("dh_scaffold_pileups", u, nu, contig_off, ncontigs, read_off, 0, nreads, nullptr, &found)) return rc;
+    std::vector<std::vector<RawJoin>> found;
+    if (int rc = collect_raw_joins("dh_scaffold_pileups", u, nu, contig_off, ncontigs, read_off, 0, nreads, &found)) return rc;
     Resolver rs;
     rs.c = Ctx{u, contig_off, read_off};
     rs.c.n = nu;
@@ -1097,7 +1125,7 @@ static int scaffold_resolved(const dh_la *las, int64_t n, const int64_t *contig_
     };
     rs.max_bubble_size = max_bubble_size > 0 ? max_bubble_size : 8;
     rs.max_iterations = max_iterations > 0 ? max_iterations : 4;
-    const int rc = scaffold_from_edges(found, ncontigs, input_gaps, ngaps, opts, out, &rs);
+    const int rc = scaffold_from_runs(found, ncontigs, input_gaps, ngaps, opts, out, &rs);
     if (resolved) *resolved = rs.resolved;
     if (!rc) {
         // unit index -> record index: the first record of the chain; the added alignments follow the n records

@@ -292,9 +292,9 @@ def sharded_process_steps(ctx, contigs_db, reads_db, read_first, contig_off, las
     own.close()
     blobs = yield ("all_gather", _pack_closed(lrec, lbases))
     grec, gbases, origin = _unpack_closed(blobs)
-    if _laps and rank == 0:
+    if _laps and rank == min(1, world - 1):   # (rank 0 pays the first-use allocations of a process)
         import sys
-        print("[sharded rank 0] " + ", ".join(_laps), file=sys.stderr)
+        print("[sharded rank %d] " % rank + ", ".join(_laps), file=sys.stderr)
     # pile-up order (= the single-GPU order, whatever the world size): rank r's records are its owned pile-ups in
     # ascending pile-up index; several pile-ups may share contig_left, so the start node alone does not order them
     pile_of = np.concatenate([np.nonzero(owner == r)[0] for r in range(world)]) if len(grec) else np.zeros(0, dtype=np.int64)
