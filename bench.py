@@ -349,6 +349,7 @@ def main():
                                    "consensus_rounds": popts.rounds, "width": (32 if popts.width == 32 else 64) if popts.algo == 1 else (popts.width or 30),
                                    "xdrop": 120, "tspace": popts.tspace_pile, "dust": popts.dust},
                        "parallelism": f"reads and gaps sharded over {world} GPU(s)",
+                       "collectives": last["info"].get("collectives", "none (one rank)"),
                        "read_bp_total": read_all, "pile_ups": int(last["info"]["piles"]),
                        "collect_filters_dropped_las": dict(zip(("lq", "improper", "weakly_anchored", "contained",
                                                                 "ambiguous", "redundant"), last["info"]["filtered"])),

@@ -174,8 +174,15 @@ def rccl_comm(ctx, rank, world):
     from ._lib import Comm
     key = (id(ctx), rank, world)
     if key not in _COMM:
-        box = [Comm.unique_id() if rank == 0 else None]
+        box = [None]
+        if rank == 0:
+            try:
+                box = [Comm.unique_id()]
+            except Exception as e:   # noqa: BLE001 -- the other ranks wait in the broadcast: they must get an answer
+                box = [e]
         dist.broadcast_object_list(box, src=0)
+        if not isinstance(box[0], (bytes, bytearray)):
+            raise RuntimeError("dh_comm_unique_id failed on rank 0: %r" % (box[0],))
         _COMM[key] = Comm.create(ctx, rank, world, box[0])
     return _COMM[key]
 
@@ -186,11 +193,13 @@ def sharded_process(ctx, contigs_db, reads_db, read_first, contig_off, las, trac
     [read_first, read_first + n).  Returns (records, bases, info): the closed-gap records of ALL
     ranks ordered by gap (identical on every rank) with ref_read_id as whole-DB ids."""
     import torch.distributed as dist
-    if world > 1 and dist.is_initialized() and dist.get_backend() == "nccl":
+    if world > 1 and dist.is_initialized() and dist.get_backend() == "nccl" and _c_abi_collectives(ctx, rank, world):
         # one process per GPU over RCCL: the whole sequence behind the C ABI (dh_shard_run); this module is a thin caller
         from ._lib import shard_run
-        return shard_run(rccl_comm(ctx, rank, world), contigs_db, reads_db, read_first, contig_off, las, trace, popts,
-                         cands=cands, graph=graph)
+        rec, bases, info = shard_run(rccl_comm(ctx, rank, world), contigs_db, reads_db, read_first, contig_off, las, trace, popts,
+                                     cands=cands, graph=graph)
+        info["collectives"] = "dh_comm (RCCL behind the C ABI)"
+        return rec, bases, info
     gen = sharded_process_steps(ctx, contigs_db, reads_db, read_first, contig_off, las, trace, popts, rank, world, cands, graph)
     try:
         req = next(gen)
@@ -198,7 +207,42 @@ def sharded_process(ctx, contigs_db, reads_db, read_first, contig_off, las, trac
             kind, payload = req
             req = gen.send(all_gather_bytes(payload, world) if kind == "all_gather" else all_to_all_bytes(payload, world))
     except StopIteration as done:
-        return done.value
+        rec, bases, info = done.value
+        info["collectives"] = ("torch.distributed (%s), host steps in dh_shard_*" % dist.get_backend()
+                               if world > 1 and dist.is_initialized() else "none (one rank)")
+        return rec, bases, info
+
+
+_C_ABI_OK = {}
+
+
+def _c_abi_collectives(ctx, rank, world):
+    """Whether the ranks run the exchanges behind the C ABI (dh_comm over RCCL).  Decided ONCE per process, by all ranks
+    together: every rank tries to create its communicator and the outcomes are min-reduced over torch.distributed, so that
+    either all ranks take dh_shard_run or all take the torch.distributed collectives (RCCL as well; the host steps between
+    them are the same dh_shard_* functions).  A rank that cannot create the communicator says so on stderr -- the result
+    records which path ran (info["collectives"]).  DH_SHARD_COLLECTIVES=torch forces the second path."""
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    key = (id(ctx), rank, world)
+    if key not in _C_ABI_OK:
+        ok, why = 1, ""
+        if os.environ.get("DH_SHARD_COLLECTIVES", "") == "torch":
+            ok, why = 0, "DH_SHARD_COLLECTIVES=torch"
+        else:
+            try:
+                rccl_comm(ctx, rank, world)
+            except Exception as e:   # noqa: BLE001 -- whatever went wrong, the other ranks must learn of it
+                ok, why = 0, repr(e)
+        flag = torch.tensor([ok], dtype=torch.int32, device=_device(dist))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if not ok:
+            print("[dentist_amd] rank %d: no dh_comm communicator (%s); the exchanges go through torch.distributed" % (rank, why),
+                  file=sys.stderr, flush=True)
+        _C_ABI_OK[key] = bool(int(flag.item()))
+    return _C_ABI_OK[key]
 
 
 def emulate_ranks(gens):
