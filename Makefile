@@ -53,3 +53,7 @@ clean:
 # the DH-2 lane code (dentist_amd/csrc/dh_tile.h) compiled for the CPU: test infrastructure
 tests/native/libdh_tile_host.so: tests/native/tile_host.cpp dentist_amd/csrc/dh_tile.h dentist_amd/csrc/dh_device.h
 	g++ -O2 -g -shared -fPIC -std=c++17 -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -Wno-unknown-pragmas -o $@ $<
+
+# the host thread pool (dentist_amd/csrc/dh_parallel.h) on its own: test infrastructure
+tests/native/libdh_pool_host.so: tests/native/pool_host.cpp dentist_amd/csrc/dh_parallel.h
+	g++ -O2 -g -shared -fPIC -std=c++17 -pthread -o $@ $<

@@ -336,3 +336,64 @@ def test_in_process_hub_collectives_of_the_c_abi():
         assert all(np.array_equal(got_a[r][s], per_dest[s][r]) for s in range(world))
     for c in comms:
         c.close()
+
+
+def test_sharded_plan_keeps_copies_of_one_record_apart():
+    """A read that runs through a short contig contributes that contig's alignment to TWO joins (into it and out of
+    it); the gathered records hold a copy per join, one behind the other.  When that record is flagged NEXT without START
+    (the rest of a chain whose head a filter removed), the second copy would read as the continuation of the first:
+    dh_shard_graph_plan_create puts a separator record between them.  Fabricated alignments (no sequence is read):
+    the plan of 1-3 ranks against the single-rank builder, record by record, and nothing follows an entry's record that
+    does not follow it in the input."""
+    import dentist_amd
+    from dentist_amd._lib import LA_DTYPE, ShardPlan, shard_read_joins
+    lens = np.array([30000, 30000, 2000, 30000, 30000, 1800, 30000], dtype=np.int64)   # contigs 2 and 5 are short
+    gap, LR = 1000, 15000
+    cstart = np.concatenate([[0], np.cumsum(lens + gap)[:-1]])
+    rng = np.random.default_rng(11)
+    starts = np.sort(rng.integers(0, int(cstart[-1] + lens[-1]) - LR, 900))
+    recs = []
+    for r, p in enumerate(starts):
+        for c in range(len(lens)):
+            lo, hi = max(p, cstart[c]), min(p + LR, cstart[c] + lens[c])
+            if hi - lo < 500:
+                continue
+            la = np.zeros(1, dtype=LA_DTYPE)
+            la["aread"], la["bread"] = c, r
+            la["abpos"], la["aepos"] = lo - cstart[c], hi - cstart[c]
+            la["bbpos"], la["bepos"] = lo - p, hi - p
+            la["diffs"] = (hi - lo) // 8
+            # the alignment of a whole short contig inside a read: flagged as the rest of a chain
+            if lens[c] < 5000 and lo == cstart[c] and hi == cstart[c] + lens[c]:
+                la["flags"] = 0x8
+            recs.append(la)
+    las = np.ascontiguousarray(np.concatenate(recs))
+    assert int((las["flags"] == 0x8).sum()) > 20
+    coff = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    roff = (np.arange(len(starts) + 1, dtype=np.int64) * LR)
+    gaps = np.stack([np.arange(len(lens) - 1), np.arange(1, len(lens))], axis=1).astype(np.int32)
+    po = dentist_amd.default_process_opts(max_reads=0)
+    gp, _ = dentist_amd.scaffold_spanning_pileups(las, coff, roff, gaps, with_extensions=True, min_spanning_reads=po.min_reads)
+    ecl, ecnt, etri = gp.select(las, po).flat()
+    assert set(ecl.tolist()) >= {1, 2, 4, 5}   # the joins into and out of both short contigs
+    cont = lambda L, i, j: ((L["flags"][j] & 0xC) == 0x8) & (L["aread"][i] == L["aread"][j]) & \
+        (L["bread"][i] == L["bread"][j]) & ((L["flags"][i] & 1) == (L["flags"][j] & 1)) & (i != j)  # noqa: E731
+    for world in (1, 2, 3):
+        blobs = []
+        for r in range(world):
+            lo, hi = len(starts) * r // world, len(starts) * (r + 1) // world
+            mine = np.ascontiguousarray(las[(las["bread"] >= lo) & (las["bread"] < hi)])
+            blobs.append(shard_read_joins(mine, coff, roff[lo:hi + 1] - roff[lo], lo))
+        plan = ShardPlan(blobs, po, graph=(len(lens), gaps, {"min_spanning_reads": po.min_reads}))
+        cl, cnt, tri = plan.piles.flat()
+        assert np.array_equal(cl, ecl) and np.array_equal(cnt, ecnt) and np.array_equal(tri[:, 0], etri[:, 0])
+        nsep = int(((plan.las["aread"] == -1) & (plan.las["flags"] == 0x20)).sum())
+        assert nsep > 20   # one per read that runs through a short contig
+        for col in (1, 2):
+            m = tri[:, col] >= 0
+            assert np.array_equal(tri[:, col] < 0, etri[:, col] < 0)
+            assert np.array_equal(plan.las[tri[m, col]], las[etri[m, col]])
+            nxt_e = np.minimum(etri[m, col] + 1, len(las) - 1)
+            nxt_p = np.minimum(tri[m, col] + 1, len(plan.las) - 1)
+            assert np.array_equal(cont(las, etri[m, col], nxt_e), cont(plan.las, tri[m, col], nxt_p))
+        plan.close()
