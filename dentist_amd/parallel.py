@@ -196,10 +196,34 @@ def sharded_process(ctx, contigs_db, reads_db, read_first, contig_off, las, trac
     if world > 1 and dist.is_initialized() and dist.get_backend() == "nccl" and _c_abi_collectives(ctx, rank, world):
         # one process per GPU over RCCL: the whole sequence behind the C ABI (dh_shard_run); this module is a thin caller
         from ._lib import shard_run
-        rec, bases, info = shard_run(rccl_comm(ctx, rank, world), contigs_db, reads_db, read_first, contig_off, las, trace, popts,
-                                     cands=cands, graph=graph)
-        info["collectives"] = "dh_comm (RCCL behind the C ABI)"
-        return rec, bases, info
+        key = (id(ctx), rank, world)
+        res, err = None, None
+        try:
+            res = shard_run(rccl_comm(ctx, rank, world), contigs_db, reads_db, read_first, contig_off, las, trace, popts,
+                            cands=cands, graph=graph)
+        except Exception as e:   # noqa: BLE001
+            err = e
+        if not _C_ABI_RAN.get(key):
+            # the FIRST run of this process: the ranks agree that it went through everywhere (a rank that fails inside
+            # dh_shard_run still takes part in the next size exchange with its status, so every rank comes back from the
+            # same exchange, dh_comm.cpp) -- otherwise all of them switch to the torch.distributed collectives for good
+            import sys
+            import torch
+            flag = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=_device(dist))
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                print("[dentist_amd] rank %d: dh_shard_run failed on some rank (%s); the exchanges go through torch.distributed "
+                      "from here on" % (rank, repr(err) if err is not None else "not this one"), file=sys.stderr, flush=True)
+                _C_ABI_OK[key] = False
+                res = None
+            else:
+                _C_ABI_RAN[key] = True
+        elif err is not None:
+            raise err
+        if res is not None:
+            rec, bases, info = res
+            info["collectives"] = "dh_comm (RCCL behind the C ABI)"
+            return rec, bases, info
     gen = sharded_process_steps(ctx, contigs_db, reads_db, read_first, contig_off, las, trace, popts, rank, world, cands, graph)
     try:
         req = next(gen)
@@ -214,6 +238,7 @@ def sharded_process(ctx, contigs_db, reads_db, read_first, contig_off, las, trac
 
 
 _C_ABI_OK = {}
+_C_ABI_RAN = {}
 
 
 def _c_abi_collectives(ctx, rank, world):
