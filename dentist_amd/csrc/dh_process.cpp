@@ -2753,11 +2753,29 @@ struct CropHead {
 static_assert(sizeof(CandRec) == 104 && sizeof(CropHead) == 16, "blob layouts");
 }  // namespace
 
+// record arrays of destroyed plans, kept for the next plan of the process: a plan of configs[2] holds 14 MB of records, and
+// giving them back to the system and faulting them in again cost a rank 2 ms per step (munmap of touched pages on destroy)
+static std::mutex g_plan_las_mu;
+static std::vector<dh_la_vec> g_plan_las;  // at most 8 arrays of at most 64 MB
 struct dh_shard_plan {
     dh_la_vec las;                 // L0 R0 L1 R1 ... of every gathered candidate, in gather order
     dh_pileups *piles = nullptr;   // after the min / max reads cut; LA indices into `las`
     std::vector<int32_t> owner;    // rank that processes each pile-up
-    ~dh_shard_plan() { delete piles; }
+    dh_shard_plan()
+    {
+        std::lock_guard<std::mutex> lk(g_plan_las_mu);
+        if (!g_plan_las.empty()) {
+            las = std::move(g_plan_las.back());
+            g_plan_las.pop_back();
+            las.clear();
+        }
+    }
+    ~dh_shard_plan()
+    {
+        delete piles;
+        std::lock_guard<std::mutex> lk(g_plan_las_mu);
+        if (g_plan_las.size() < 8 && las.capacity() > 0 && las.capacity() * sizeof(dh_la) <= ((size_t)64 << 20)) g_plan_las.push_back(std::move(las));
+    }
 };
 
 extern "C" void dh_shard_free(void *p) { free(p); }

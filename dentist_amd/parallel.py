@@ -360,16 +360,20 @@ def sharded_process_steps(ctx, contigs_db, reads_db, read_first, contig_off, las
     lap("process")
     own.close()
     blobs = yield ("all_gather", _pack_closed(lrec, lbases))
+    _t[0] = time.perf_counter()
     grec, gbases, origin = _unpack_closed(blobs)
-    if _laps and rank == min(1, world - 1):   # (rank 0 pays the first-use allocations of a process)
-        import sys
-        print("[sharded rank %d] " % rank + ", ".join(_laps), file=sys.stderr)
+    lap("unpack closed gaps")
     # pile-up order (= the single-GPU order, whatever the world size): rank r's records are its owned pile-ups in
     # ascending pile-up index; several pile-ups may share contig_left, so the start node alone does not order them
     pile_of = np.concatenate([np.nonzero(owner == r)[0] for r in range(world)]) if len(grec) else np.zeros(0, dtype=np.int64)
     order = np.argsort(pile_of, kind="stable") if len(pile_of) == len(grec) else np.argsort(grec["contig_left"], kind="stable")
     nentries = int(piles.flat()[1].sum())
+    lap("order")
     plan.close()
+    lap("plan released")
+    if _laps and rank == int(os.environ.get("DH_TRACE_RANK", min(1, world - 1))):   # (rank 0 pays the first-use allocations of a process)
+        import sys
+        print("[sharded rank %d] " % rank + ", ".join(_laps), file=sys.stderr)
     info = {"piles": len(rec), "owned": len(mine_piles), "candidates": int(ncand), "entries": nentries,
             "cropped_bytes_sent": int(sum(len(x) for x in per_dest)), "owner": owner}
     return grec[order], gbases, info

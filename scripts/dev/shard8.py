@@ -29,33 +29,35 @@ for r in range(N):
     ranks.append(dict(lo=lo, B=B, las=las, trace=trace, w=w, t_map=t1 - t0))
     print('rank', r, 'map+filter %.1f ms, las %d' % ((t1 - t0) * 1e3, len(las)), flush=True)
 ncg = ranks[0]["w"].contigs.n
+ROUNDS = int(os.environ.get("SHARD8_ROUNDS", "2"))   # the last round is reported: a process in steady state, as bench.py times it
 gaps = np.stack([np.arange(ncg - 1), np.arange(1, ncg)], axis=1).astype(np.int32)
 graph = len(sys.argv) <= 2 or sys.argv[2] != "spanning"
-gens = [sharded_process_steps(ctx, A, R["B"], R["lo"], R["w"].contigs.off, R["las"], R["trace"], po, r, N,
-                              graph=dict(read_off=R["w"].reads.off, input_gaps=gaps) if graph else None) for r, R in enumerate(ranks)]
-phase_t = [[] for _ in range(N)]
-reqs = []
-for r, g in enumerate(gens):
-    t = time.perf_counter(); reqs.append(next(g)); phase_t[r].append(time.perf_counter() - t)
-results = [None] * N
-while any(q is not None for q in reqs):
-    kind = next(q[0] for q in reqs if q is not None)
-    if kind == "all_gather":
-        answers = [[np.asarray(reqs[s][1], dtype=np.uint8) for s in range(N)] for _ in range(N)]
-    else:
-        answers = [[np.asarray(reqs[s][1][d], dtype=np.uint8) for s in range(N)] for d in range(N)]
-    print(kind, 'bytes per rank', [int(np.asarray(q[1]).nbytes) if kind == "all_gather" else int(sum(len(x) for x in q[1])) for q in reqs][:3], flush=True)
-    nxt = []
-    for r, g in enumerate(gens):
-        t = time.perf_counter()
-        try:
-            nxt.append(g.send(answers[r]))
-            if kind == "all_to_all":
-                print('rank', r, 'process stages', {k: round(v, 1) for k, v in dentist_amd.process_stats(ctx).items() if k.startswith('ms_')}, flush=True)
-        except StopIteration as done:
-            results[r] = done.value; nxt.append(None)
-        phase_t[r].append(time.perf_counter() - t)
-    reqs = nxt
+for rnd in range(ROUNDS):
+  gens = [sharded_process_steps(ctx, A, R["B"], R["lo"], R["w"].contigs.off, R["las"], R["trace"], po, r, N,
+                                graph=dict(read_off=R["w"].reads.off, input_gaps=gaps) if graph else None) for r, R in enumerate(ranks)]
+  phase_t = [[] for _ in range(N)]
+  reqs = []
+  for r, g in enumerate(gens):
+      t = time.perf_counter(); reqs.append(next(g)); phase_t[r].append(time.perf_counter() - t)
+  results = [None] * N
+  while any(q is not None for q in reqs):
+      kind = next(q[0] for q in reqs if q is not None)
+      if kind == "all_gather":
+          answers = [[np.asarray(reqs[s][1], dtype=np.uint8) for s in range(N)] for _ in range(N)]
+      else:
+          answers = [[np.asarray(reqs[s][1][d], dtype=np.uint8) for s in range(N)] for d in range(N)]
+      print(kind, 'bytes per rank', [int(np.asarray(q[1]).nbytes) if kind == "all_gather" else int(sum(len(x) for x in q[1])) for q in reqs][:3], flush=True)
+      nxt = []
+      for r, g in enumerate(gens):
+          t = time.perf_counter()
+          try:
+              nxt.append(g.send(answers[r]))
+              if kind == "all_to_all":
+                  print('rank', r, 'process stages', {k: round(v, 1) for k, v in dentist_amd.process_stats(ctx).items() if k.startswith('ms_')}, flush=True)
+          except StopIteration as done:
+              results[r] = done.value; nxt.append(None)
+          phase_t[r].append(time.perf_counter() - t)
+      reqs = nxt
 for r in range(N):
     print('rank', r, 'map %.1f' % (ranks[r]["t_map"] * 1e3), 'phases ms', [round(x * 1e3, 1) for x in phase_t[r]], 'total %.1f' % (1e3 * (ranks[r]["t_map"] + sum(phase_t[r]))))
 rec = results[0][0]
