@@ -27,39 +27,46 @@ public:
     {
         if (n <= 0) return;
         if (grain < 1) grain = 1;
+        while ((n + grain - 1) / grain > (1ll << 31)) grain *= 2;  // (a chunk index is the low half of the ticket)
         const int64_t nchunks = (n + grain - 1) / grain;
         if (nthreads_ <= 1 || nchunks <= 1) {
             fn(0, n);
             return;
         }
         std::unique_lock<std::mutex> serial(serial_);  // one parallel region at a time
-        fn_ = &fn;
-        n_ = n;
-        grain_ = grain;
-        next_.store(0, std::memory_order_relaxed);
-        pending_.store((int)workers_.size(), std::memory_order_relaxed);
-        publish();
-        work();
-        // the caller has nothing else to do: it spins for the stragglers (a region's tail is microseconds), then yields
-        for (int spins = 0; pending_.load(std::memory_order_acquire) != 0; spins++) {
+        fn_.store(&fn, std::memory_order_relaxed);
+        n_.store(n, std::memory_order_relaxed);
+        grain_.store(grain, std::memory_order_relaxed);
+        nchunks_.store(nchunks, std::memory_order_relaxed);
+        done_.store(0, std::memory_order_relaxed);
+        const uint32_t g = (uint32_t)(ticket_.load(std::memory_order_relaxed) >> 32) + 1u;
+        ticket_.store((uint64_t)g << 32, std::memory_order_release);  // generation g, next chunk 0
+        gen_.store(g);  // (seq_cst against the sleepers' count: a worker either sees the new value or is counted)
+        // (one call wakes all sleepers: 45 us for 63 of them before the caller's first chunk.  Waking four and letting every
+        // thread that claims a chunk wake two more was slower on the 256-core hosts -- empty regions 57-82 against 46-56 us,
+        // the sharded plan 4.9-5.4 against 3.6-4.4 ms)
+        if (sleepers_.load() > 0) wake(INT_MAX);
+        work(g);
+        // the region is over when its CHUNKS are done, not when every worker has shown up: a worker that wakes late (or not
+        // before the next region) finds nothing to claim and is waited for by nobody.  The caller has nothing else to do:
+        // it spins for the chunks still running, then yields
+        for (int spins = 0; done_.load(std::memory_order_acquire) != nchunks; spins++) {
             if (spins < 4096)
                 cpu_relax();
             else
                 std::this_thread::yield();
         }
-        fn_ = nullptr;
+        fn_.store(nullptr, std::memory_order_relaxed);
     }
 
 private:
-    // workers sleep on the generation word itself (futex): a wake-up is one system call and the woken threads meet at no
+    // Workers sleep on the generation word itself (futex): a wake-up is one system call and the woken threads meet at no
     // mutex -- with a condition variable the 63 workers of a 64-thread pool queued up at its mutex twice per region, once
     // to sleep and once woken (130-150 us per region on the 256-core hosts of the pool whatever its body,
-    // scripts/dev/pool_probe.cpp)
-    void publish()
-    {
-        gen_.fetch_add(1);                 // (seq_cst against the sleepers' count: a worker either sees the new value or is counted)
-        if (sleepers_.load() > 0) syscall(SYS_futex, (uint32_t *)&gen_, FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
-    }
+    // scripts/dev/pool_probe.cpp).  Chunks are claimed by compare-and-swap on (generation, next chunk) in ONE word: a
+    // claim that succeeds is a chunk of the generation the worker read the region's fields for -- the caller changes them
+    // only when every chunk of the generation is done, and then the word has moved on and the swap fails.
+    void wake(int count) { syscall(SYS_futex, (uint32_t *)&gen_, FUTEX_WAKE_PRIVATE, count, nullptr, nullptr, 0); }
     static uint64_t ticks()
     {
 #if defined(__x86_64__) || defined(__i386__)
@@ -98,16 +105,22 @@ private:
     ~DhPool()
     {
         stop_.store(true);
-        publish();
+        gen_.fetch_add(1);
+        wake(INT_MAX);
         for (auto &t : workers_) t.join();
     }
-    void work()
+    void work(uint32_t g)
     {
         for (;;) {
-            const int64_t c = next_.fetch_add(1);
-            const int64_t lo = c * grain_;
-            if (lo >= n_) break;
-            (*fn_)(lo, lo + grain_ < n_ ? lo + grain_ : n_);
+            uint64_t t = ticket_.load(std::memory_order_acquire);
+            if ((uint32_t)(t >> 32) != g) return;  // (the region this thread was woken for is over)
+            const int64_t c = (int64_t)(uint32_t)t;
+            if (c >= nchunks_.load(std::memory_order_relaxed)) return;
+            if (!ticket_.compare_exchange_weak(t, t + 1, std::memory_order_acq_rel, std::memory_order_acquire)) continue;
+            const int64_t n = n_.load(std::memory_order_relaxed), grain = grain_.load(std::memory_order_relaxed);
+            const int64_t lo = c * grain;
+            (*fn_.load(std::memory_order_relaxed))(lo, lo + grain < n ? lo + grain : n);
+            done_.fetch_add(1, std::memory_order_release);
         }
     }
     void loop()
@@ -129,19 +142,19 @@ private:
             }
             seen = gen_.load(std::memory_order_acquire);
             if (stop_.load()) return;
-            work();
-            pending_.fetch_sub(1, std::memory_order_acq_rel);
+            work(seen);
         }
     }
     std::vector<std::thread> workers_;
     std::mutex serial_;
-    const std::function<void(int64_t, int64_t)> *fn_ = nullptr;
-    int64_t n_ = 0, grain_ = 1;
     int nthreads_ = 1, spin_us_ = 0;
+    // the region's fields (written by the caller before the ticket of the generation is published)
+    std::atomic<const std::function<void(int64_t, int64_t)> *> fn_{nullptr};
+    std::atomic<int64_t> n_{0}, grain_{1}, nchunks_{0};
     // (the words the threads meet at, each on a cache line of its own)
     alignas(64) std::atomic<uint32_t> gen_{0};
-    alignas(64) std::atomic<int64_t> next_{0};
-    alignas(64) std::atomic<int> pending_{0};
+    alignas(64) std::atomic<uint64_t> ticket_{0};  // generation << 32 | next chunk
+    alignas(64) std::atomic<int64_t> done_{0};     // chunks of the generation that have returned
     alignas(64) std::atomic<int> sleepers_{0};
     alignas(64) std::atomic<bool> stop_{false};
 };
