@@ -279,6 +279,13 @@ k_tile_qv(const DhLa *__restrict__ las, const uint16_t *__restrict__ trace,
           int32_t tspace, const int32_t *__restrict__ cov_of, int32_t maxtiles, uint8_t *__restrict__ qv)
 {
     __shared__ int32_t hist[256];
+    // what a tile asks of an overlap -- its A interval, the number of its trace pairs, where they lie --, staged once per
+    // read: every tile of the read walks all of its overlaps, and re-reading the 48-byte records from memory tile after
+    // tile was 1.57 GB of fetches per launch for 170 MB of records (round-4 verdict).  A read with more overlaps than fit
+    // reads the records as before.
+    constexpr int32_t QCAP = 512;
+    __shared__ int32_t s_ab[QCAP], s_ae[QCAP], s_np[QCAP];
+    __shared__ int64_t s_to[QCAP];
     const int32_t r = blockIdx.x;
     if (r >= nreads) return;
     const int lane = threadIdx.x;
@@ -286,21 +293,45 @@ k_tile_qv(const DhLa *__restrict__ las, const uint16_t *__restrict__ trace,
     const int32_t rlen = (int32_t)(roff[r + 1] - roff[r]);
     const int32_t nt = (rlen + tspace - 1) / tspace;
     const int32_t l0 = la_first[r], l1 = la_first[r + 1];
+    const bool staged = l1 - l0 <= QCAP;
+    if (staged)
+        for (int32_t i = lane; i < l1 - l0; i += 64) {
+            const DhLa la = las[l0 + i];
+            s_ab[i] = (la.flags & 0x20u) ? 0x7FFFFFFF : la.abpos;  // (a disabled overlap covers no tile)
+            s_ae[i] = la.aepos;
+            s_np[i] = la.tlen / 2;
+            s_to[i] = la.toff;
+        }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
     for (int32_t t = 0; t < nt && t < maxtiles; t++) {
         const int32_t t0 = t * tspace, t1 = (t0 + tspace < rlen) ? t0 + tspace : rlen;
 #pragma unroll
         for (int x = 0; x < 4; x++) hist[4 * lane + x] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        for (int32_t i = l0 + lane; i < l1; i += 64) {
-            const DhLa la = las[i];
-            if (la.flags & 0x20u) continue;
-            if (la.abpos > t0 || la.aepos < t1) continue;
-            const int32_t e = t - la.abpos / tspace;
-            const int32_t seg0 = e == 0 ? la.abpos : t0;
-            const int32_t seg1 = (e == la.tlen / 2 - 1) ? la.aepos : t1;
+        for (int32_t i = lane; i < l1 - l0; i += 64) {
+            int32_t abpos, aepos, np;
+            int64_t toff;
+            if (staged) {
+                abpos = s_ab[i];
+                aepos = s_ae[i];
+                np = s_np[i];
+                toff = s_to[i];
+            } else {
+                const DhLa la = las[l0 + i];
+                if (la.flags & 0x20u) continue;
+                abpos = la.abpos;
+                aepos = la.aepos;
+                np = la.tlen / 2;
+                toff = la.toff;
+            }
+            if (abpos > t0 || aepos < t1) continue;
+            const int32_t e = t - abpos / tspace;
+            const int32_t seg0 = e == 0 ? abpos : t0;
+            const int32_t seg1 = (e == np - 1) ? aepos : t1;
             if (seg0 != t0 || seg1 != t1) continue;
-            const uint16_t *tr = trace + la.toff;
+            const uint16_t *tr = trace + toff;
             const int32_t val = 200 * (int32_t)tr[2 * e] / ((t1 - t0) + (int32_t)tr[2 * e + 1]);
             atomicAdd(&hist[val < 255 ? val : 255], 1);
         }
