@@ -34,12 +34,16 @@ public:
             return;
         }
         std::unique_lock<std::mutex> serial(serial_);  // one parallel region at a time
+        // the ticket is CLOSED (generation g, no chunk left) before the region's fields change: a worker still looking at
+        // the last region's ticket -- all of its chunks claimed -- must not take the new region's chunk count for the old
+        // one's and claim a chunk beyond the old count (its swap fails now: the word has moved on)
+        const uint32_t g = (uint32_t)(ticket_.load(std::memory_order_relaxed) >> 32) + 1u;
+        ticket_.store(((uint64_t)g << 32) | 0xFFFFFFFFull, std::memory_order_seq_cst);
         fn_.store(&fn, std::memory_order_relaxed);
         n_.store(n, std::memory_order_relaxed);
         grain_.store(grain, std::memory_order_relaxed);
-        nchunks_.store(nchunks, std::memory_order_relaxed);
         done_.store(0, std::memory_order_relaxed);
-        const uint32_t g = (uint32_t)(ticket_.load(std::memory_order_relaxed) >> 32) + 1u;
+        nchunks_.store(nchunks, std::memory_order_release);  // (who sees this count sees the closed ticket, or a later one)
         ticket_.store((uint64_t)g << 32, std::memory_order_release);  // generation g, next chunk 0
         gen_.store(g);  // (seq_cst against the sleepers' count: a worker either sees the new value or is counted)
         // (one call wakes all sleepers: 45 us for 63 of them before the caller's first chunk.  Waking four and letting every
@@ -65,7 +69,8 @@ private:
     // to sleep and once woken (130-150 us per region on the 256-core hosts of the pool whatever its body,
     // scripts/dev/pool_probe.cpp).  Chunks are claimed by compare-and-swap on (generation, next chunk) in ONE word: a
     // claim that succeeds is a chunk of the generation the worker read the region's fields for -- the caller changes them
-    // only when every chunk of the generation is done, and then the word has moved on and the swap fails.
+    // only when every chunk of the generation is done and after it has closed the ticket of the next generation, so the
+    // word has moved on and the swap of a worker that read a field of the next region fails.
     void wake(int count) { syscall(SYS_futex, (uint32_t *)&gen_, FUTEX_WAKE_PRIVATE, count, nullptr, nullptr, 0); }
     static uint64_t ticks()
     {
@@ -115,7 +120,7 @@ private:
             uint64_t t = ticket_.load(std::memory_order_acquire);
             if ((uint32_t)(t >> 32) != g) return;  // (the region this thread was woken for is over)
             const int64_t c = (int64_t)(uint32_t)t;
-            if (c >= nchunks_.load(std::memory_order_relaxed)) return;
+            if (c >= nchunks_.load(std::memory_order_acquire)) return;
             if (!ticket_.compare_exchange_weak(t, t + 1, std::memory_order_acq_rel, std::memory_order_acquire)) continue;
             const int64_t n = n_.load(std::memory_order_relaxed), grain = grain_.load(std::memory_order_relaxed);
             const int64_t lo = c * grain;

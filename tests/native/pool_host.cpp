@@ -55,3 +55,23 @@ extern "C" int32_t dh_pool_host_concurrent(int32_t callers, int32_t reps, int32_
     for (auto &t : th) t.join();
     return bad.load();
 }
+
+// regions of few and of many chunks in turn, empty bodies but a visit count per index: a worker that is still looking at the
+// last region when the next one is set up must not take a chunk of it under the old region's terms (the claim race of the
+// first compare-and-swap version: a chunk index beyond the old count, executed twice).  Returns the number of bad regions.
+extern "C" int32_t dh_pool_host_alternate(int32_t reps, int32_t nsmall, int32_t nlarge)
+{
+    int32_t bad = 0;
+    std::vector<std::atomic<int32_t>> seen((size_t)nlarge);
+    for (int32_t r = 0; r < reps; r++) {
+        const int32_t n = (r & 1) ? nlarge : nsmall;
+        for (int32_t i = 0; i < n; i++) seen[(size_t)i].store(0, std::memory_order_relaxed);
+        dh_parallel_for(n, 1, [&](int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; i++) seen[(size_t)i].fetch_add(1, std::memory_order_relaxed);
+        });
+        bool ok = true;
+        for (int32_t i = 0; i < n; i++) ok = ok && seen[(size_t)i].load(std::memory_order_relaxed) == 1;
+        bad += ok ? 0 : 1;
+    }
+    return bad;
+}

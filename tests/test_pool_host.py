@@ -18,7 +18,10 @@ L.dh_pool_host_regions.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.POINTE
 n = ctypes.c_int64()
 bad = L.dh_pool_host_regions(2000, 37, ctypes.byref(n))
 bad2 = L.dh_pool_host_concurrent(4, 300, 1000)
-print(bad, n.value, bad2)
+# regions of 3 and of 200 chunks in turn: the claim race of the first compare-and-swap version (a worker still looking at
+# the last region's ticket took the next region's chunk count for the old one's) hung or double-ran a chunk within seconds
+bad3 = L.dh_pool_host_alternate(60000, 3, 200)
+print(bad, n.value, bad2 + bad3)
 """
 
 
