@@ -792,7 +792,10 @@ int scaffold_from_runs(std::vector<std::vector<RawJoin>> &found, int32_t ncontig
     {
         const int32_t nbuck = (int32_t)std::max<int64_t>(1, std::min<int64_t>(256, ncontigs / 4));
         const int64_t nruns = (int64_t)found.size();
-        auto bucket_of = [&](int32_t contig) { return (int32_t)((int64_t)contig * nbuck / std::max(ncontigs, 1)); };
+        auto bucket_of = [&](int32_t contig) {  // (monotone in the contig; ids are checked by the callers, the clamp keeps a stray one inside)
+            const int64_t b = (int64_t)contig * nbuck / std::max(ncontigs, 1);
+            return (int32_t)std::min<int64_t>(std::max<int64_t>(b, 0), nbuck - 1);
+        };
         std::vector<int64_t> at((size_t)nruns * (size_t)nbuck + 1, 0);  // [bucket][run] -> first slot
         dh_parallel_for(nruns, 1, [&](int64_t lo, int64_t hi) {
             for (int64_t run = lo; run < hi; run++)
