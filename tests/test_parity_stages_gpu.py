@@ -38,6 +38,39 @@ def test_tile_qv_matches_the_oracle(gpu_ctx, seed):
         assert got.min() <= 50 and (got[got != 255] <= 50).all()
 
 
+def test_tile_qv_with_more_overlaps_than_fit_the_staging(gpu_ctx):
+    """k_tile_qv keeps what a tile asks of an overlap in LDS for up to 512 overlaps of a read; deeper reads walk the
+    records in memory.  Fabricated overlaps (no alignment is run: the stage reads records and trace pairs only): read 0
+    has 700 of them, read 1 exactly 512, read 2 a handful, some disabled, some partial."""
+    rng = np.random.default_rng(7)
+    rl = np.array([3000, 2600, 1900], dtype=np.int64)
+    reads = sim.SeqDb(np.zeros(int(rl.sum()), dtype=np.uint8), np.concatenate([[0], np.cumsum(rl)]))
+    d = gpu_ctx.db(reads)
+    recs, tr = [], []
+    toff = 0
+    for a, n in ((0, 700), (1, 512), (2, 9)):
+        for i in range(n):
+            ab = 0 if i % 3 else int(rng.integers(0, rl[a] // 2))
+            ae = int(rl[a]) if i % 5 else int(rng.integers(ab + 300, rl[a]))
+            ntp = (ae - 1) // TS - ab // TS + 1
+            la = np.zeros(1, dtype=dentist_amd.LA_DTYPE)
+            la["aread"], la["bread"] = a, (a + 1 + i) % 3
+            la["abpos"], la["aepos"], la["bbpos"], la["bepos"] = ab, ae, 0, ae - ab
+            la["tlen"], la["toff"] = 2 * ntp, toff
+            la["flags"] = 0x20 if i % 11 == 0 else 0
+            pairs = np.stack([rng.integers(0, 40, ntp), rng.integers(100, 140, ntp)], axis=1).astype(np.uint16)
+            la["diffs"] = int(pairs[:, 0].sum())
+            recs.append(la)
+            tr.append(pairs.reshape(-1))
+            toff += 2 * ntp
+    las = np.ascontiguousarray(np.concatenate(recs))
+    trace = np.ascontiguousarray(np.concatenate(tr))
+    for cov in (4, 40, 1000):
+        exp = oz.tile_qv(las, trace, rl.astype(np.int32), TS, cov)
+        got = dentist_amd.tile_qv(gpu_ctx, d, las, trace, TS, cov, exp.shape[1])
+        assert np.array_equal(got, exp)
+
+
 @pytest.mark.parametrize("seed", [41, 47])
 def test_consensus_of_one_read_matches_the_oracle(gpu_ctx, seed):
     reads = pile_case(seed)
