@@ -397,3 +397,42 @@ def test_sharded_plan_keeps_copies_of_one_record_apart():
             nxt_p = np.minimum(tri[m, col] + 1, len(plan.las) - 1)
             assert np.array_equal(cont(las, etri[m, col], nxt_e), cont(plan.las, tri[m, col], nxt_p))
         plan.close()
+
+
+def _worker_agree(rank, world, port, q, forced):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import dentist_amd.parallel as par
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if forced:
+        os.environ["DH_SHARD_COLLECTIVES"] = "torch"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    par._device = lambda d: torch.device("cpu")   # (the agreement runs over whatever backend carries torch.distributed)
+
+    class NoCtx:   # no device context here: dh_comm_create must refuse it, on both ranks, and both must learn of it
+        _h = None
+    first = par._c_abi_collectives(NoCtx(), rank, world)
+    again = par._c_abi_collectives(NoCtx(), rank, world)   # decided once per process: no second round of collectives
+    q.put((rank, first, again))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_agree_on_the_collectives_when_the_communicator_cannot_be_made():
+    """parallel._c_abi_collectives: every rank tries to create its dh_comm (rank 0 draws the id and broadcasts it, or its
+    failure), the outcomes are min-reduced, and all ranks take the same path.  On a machine without a GPU no rank can
+    create one: both say False, by agreement and by the DH_SHARD_COLLECTIVES=torch switch."""
+    for forced in (False, True):
+        port = _free_port()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_worker_agree, args=(r, 2, port, q, forced)) for r in range(2)]
+        for p in procs:
+            p.start()
+        got = sorted(q.get(timeout=180) for _ in range(2))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert got == [(0, False, False), (1, False, False)]
