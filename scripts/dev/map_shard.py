@@ -10,7 +10,7 @@ ctx = dentist_amd.Context(0)
 A, B = ctx.db(w.contigs), ctx.db(w.reads)
 mo = dentist_amd.default_align_opts(kmer_mod=8, k=20, width=64, xdrop=60, algo=1)
 po = dentist_amd.default_process_opts(algo=1)
-for mode in ("default", "65536", "default", "65536", "32768"):
+for mode in os.environ.get("SHARD_MAP_MODES", "default 65536 default 65536 32768").split():
     if mode == "default":
         os.environ.pop("DH_ALIGN_CHUNK", None)
     else:
