@@ -105,9 +105,10 @@ def main():
     ap.add_argument("--workload", default="cfg2_100Mb_1000gaps_1Mx15kb")
     ap.add_argument("--cpu-seconds", type=float, default=40.0, help="CPU time budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--kmer-mod", type=int, default=8,
-                    help="modimer sampling of the mapping index: one canonical k-mer in kmer_mod is indexed / looked up "
-                         "(4: 345 ms per step, 8: 311 ms, the same 1000 / 1000 gaps and consensus error; DESIGN 8)")
+    ap.add_argument("--kmer-mod", type=int, default=1,
+                    help="modimer sampling of the mapping index: one canonical k-mer in kmer_mod is indexed / looked up.  "
+                         "1 (default) = every k-mer, the reference's behaviour (damapper has no sampling, "
+                         "commandline.d:2943-2955); 8 is the labelled fast mode (fast_mode_timed)")
     ap.add_argument("--map-k", type=int, default=20, help="k-mer length of the mapping pass (damapper's default)")
     ap.add_argument("--map-algo", type=int, default=1,
                     help="extension algorithm of the mapping pass: 1 = DH-2 (tiled banded bit-parallel DP, one "
@@ -121,8 +122,9 @@ def main():
     ap.add_argument("--map-xdrop", type=int, default=60, help="score lag that trims the mapping waves")
     ap.add_argument("--process-algo", type=int, default=1,
                     help="alignments of the process stages (pile-up all-vs-all, re-alignment, flanks): 1 = DH-2, 0 = DH-1")
-    ap.add_argument("--max-reads", type=int, default=None,
-                    help="reads kept per pile-up (default: dh_default_process_opts = 60; 0 = no cap, the reference's behaviour)")
+    ap.add_argument("--max-reads", type=int, default=0,
+                    help="reads kept per pile-up: 0 (default) = no cap, the reference's behaviour "
+                         "(processPileUps/package.d:283-374 processes every read alignment); 60 is the labelled fast mode")
     ap.add_argument("--collect", choices=("graph", "spanning"), default=None,
                     help="pile-up membership: 'graph' = the scaffold-graph builder of `dentist collect` with the extension "
                          "entries it merges into a gap (pileups.d:173-208; the default for every N: at N > 1 the raw joins "
@@ -131,13 +133,15 @@ def main():
     ap.add_argument("--device-trace", action="store_true",
                     help="leave the mapping's trace values on the device (dh_map_reads want_sorted & 8) for `process` to gather "
                          "from, instead of copying them to the host chunk by chunk (330 MB per step of configs[2])")
-    ap.add_argument("--ref-steps", type=int, default=3,
-                    help="steps of the REFERENCE-BEHAVIOUR configuration timed after the default loop in the same process "
-                         "(no read cap: processPileUps/package.d:283-374 has none; no k-mer sampling: damapper has none, "
-                         "commandline.d:2943-2955) and reported as reference_behaviour_timed; 0 = skip; N = 1 only")
+    ap.add_argument("--fast-steps", "--ref-steps", dest="fast_steps", type=int, default=3,
+                    help="steps of the FAST MODE (modimers 1/8 in the mapping index, 60 reads per pile-up: two work-reducing "
+                         "knobs the reference does not have) timed after the headline loop in the same process and reported "
+                         "as fast_mode_timed; 0 = skip; N = 1 only")
+    ap.add_argument("--fast-kmer-mod", type=int, default=8)
+    ap.add_argument("--fast-max-reads", type=int, default=60)
     ap.add_argument("--ref-partners", type=int, default=60,
-                    help="partner reads per read of the pile-up all-vs-all in the third timed configuration (no cap, no sampling, "
-                         "dh_process_opts.max_partners = this): reported as uncapped_partner_cut_timed; 0 = skip")
+                    help="partner reads per read of the pile-up all-vs-all in the third timed configuration (the headline's knobs "
+                         "plus dh_process_opts.max_partners = this): reported as uncapped_partner_cut_timed; 0 = skip")
     ap.add_argument("--max-partners", type=int, default=None, help="dh_process_opts.max_partners of the headline run (default 0: every pair)")
     ap.add_argument("--dev-share-gpu", action="store_true",
                     help="development only: all ranks on cuda:0 with gloo collectives (exercises the N > 1 "
@@ -183,8 +187,7 @@ def main():
                                            xdrop=args.map_xdrop, algo=args.map_algo)
     band_kw = dict(width=32) if (args.band == 32 and args.process_algo == 1) else {}
     popts = dentist_amd.default_process_opts(algo=args.process_algo, **band_kw)
-    if args.max_reads is not None:
-        popts.max_reads = args.max_reads
+    popts.max_reads = args.max_reads
     if args.max_partners is not None:
         popts.max_partners = args.max_partners
     read_bp = int(len(w.reads.bases))
@@ -256,12 +259,13 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
 
-    # the same workload at the reference's behaviour -- every read alignment of a pile-up is processed (no cap) and every
-    # k-mer of the reads is looked up (no modimer sampling) -- timed here, inside the same run, the same way; and once more
-    # with the pile-up all-vs-all bounded to --ref-partners partner reads per read (dh_process_opts.max_partners: every read
-    # still votes in the consensus), which is NOT the reference's behaviour and is labelled as what it is
+    # The headline loop above runs at the reference's behaviour by default (every k-mer looked up, every read of a pile-up
+    # processed).  Two more operating points are timed here, inside the same run, the same way, and labelled as what they are:
+    # the FAST MODE (modimer sampling + read cap: work the reference does not skip) and the headline's knobs with the pile-up
+    # all-vs-all bounded to --ref-partners partner reads per read (dh_process_opts.max_partners: every read still votes in the
+    # consensus) -- neither is the reference's behaviour
     def timed_variant(vm, vp, nsteps):
-        step(vm, vp)   # one untimed step (first-use allocations of the larger buffers)
+        step(vm, vp)   # one untimed step (first-use allocations of differently sized buffers)
         barrier()
         t0_ = time.perf_counter()
         vruns = []
@@ -273,21 +277,22 @@ def main():
         barrier()
         return vruns, time.perf_counter() - t0_
 
-    ref_runs, ref_dt, cut_runs, cut_dt = [], 0.0, [], 0.0
-    if args.ref_steps > 0 and world == 1 and (args.kmer_mod != 1 or popts.max_reads != 0):
+    fast_runs, fast_dt, cut_runs, cut_dt = [], 0.0, [], 0.0
+    if args.fast_steps > 0 and world == 1:
         for r in runs[:-1]:
             for key in ("las", "rec", "bases"):
                 r.pop(key, None)
-        rmopts = dentist_amd.default_align_opts(kmer_mod=1, k=args.map_k, width=args.map_width,
-                                                xdrop=args.map_xdrop, algo=args.map_algo)
-        rpopts = dentist_amd.default_process_opts(algo=args.process_algo, **band_kw)
-        rpopts.max_reads = 0
-        ref_runs, ref_dt = timed_variant(rmopts, rpopts, args.ref_steps)
-        if args.ref_partners > 0 and args.process_algo == 1:
+        if args.ref_partners > 0 and args.process_algo == 1 and not popts.max_partners:
             cpopts = dentist_amd.default_process_opts(algo=args.process_algo, **band_kw)
-            cpopts.max_reads = 0
+            cpopts.max_reads = popts.max_reads
             cpopts.max_partners = args.ref_partners
-            cut_runs, cut_dt = timed_variant(rmopts, cpopts, args.ref_steps)
+            cut_runs, cut_dt = timed_variant(mopts, cpopts, args.fast_steps)
+        if args.kmer_mod != args.fast_kmer_mod or popts.max_reads != args.fast_max_reads:
+            fmopts = dentist_amd.default_align_opts(kmer_mod=args.fast_kmer_mod, k=args.map_k, width=args.map_width,
+                                                    xdrop=args.map_xdrop, algo=args.map_algo)
+            fpopts = dentist_amd.default_process_opts(algo=args.process_algo, **band_kw)
+            fpopts.max_reads = args.fast_max_reads
+            fast_runs, fast_dt = timed_variant(fmopts, fpopts, args.fast_steps)
 
     last = runs[-1]
     aligned_bp = int((last["las"]["aepos"] - last["las"]["abpos"]).sum())
@@ -421,35 +426,40 @@ def main():
                           "process_wall": mean(lambda r: r["t_process"]) * 1e3,
                           **{"process_" + k[3:]: mean(lambda r, k=k: r["pst"][k]) for k in last["pst"] if k.startswith("ms_")}},
         }
-        # the headline uses two work-reducing knobs the reference does not apply (read cap, modimer sampling): the same
-        # workload at the reference's behaviour, timed above in this very run
-        def variant_block(vruns, vdt, what):
+        # the other operating points timed above in this very run (labelled: not the reference's behaviour)
+        def variant_block(vruns, vdt, what, vkmod):
             rl = vruns[-1]
             rgap, rclosed, redits, rtruth = closed_gap_stats(w, rl["rec"], rl["bases"])
             rmean = lambda f: float(np.mean([f(r) for r in vruns]))  # noqa: E731
             rseed_ms = rmean(lambda r: r["ast"].ms_seed)
             return {
                 "what": what,
-                "steps": args.ref_steps, "warmup": 1, "ms_per_step": vdt / args.ref_steps * 1e3,
-                "value": rgap * args.ref_steps / vdt, "unit": "gap-bp/s",
+                "steps": args.fast_steps, "warmup": 1, "ms_per_step": vdt / args.fast_steps * 1e3,
+                "value": rgap * args.fast_steps / vdt, "unit": "gap-bp/s",
                 "gaps_closed": rclosed, "gap_bases_closed": rgap, "pile_up_entries": int(rl["info"].get("entries", 0)),
                 "consensus_error_rate": (redits / rtruth) if rtruth else None,
                 "read_bp_aligned_per_sec_mapping_stage": int((rl["las"]["aepos"] - rl["las"]["abpos"]).sum()) / rmean(lambda r: r["t_map"]),
-                "k_seed_frac_of_hbm_peak_line_priced": read_bp * 65.0 / (rseed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "k_seed_frac_of_hbm_peak_useful_bytes": read_bp * 17.0 / (rseed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "seeds_frac_of_hbm_peak": read_bp * (1.0 + 16.0 / vkmod) / (rseed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "stages_ms": {"map_wall": rmean(lambda r: r["t_map"]) * 1e3, "map_index": rmean(lambda r: r["ast"].ms_index),
                               "map_seed": rseed_ms, "map_wave": rmean(lambda r: r["ast"].ms_wave),
                               "collect_wall": rmean(lambda r: r["t_collect"]) * 1e3,
                               "process_wall": rmean(lambda r: r["t_process"]) * 1e3,
                               **{"process_" + k[3:]: rmean(lambda r, k=k: r["pst"][k]) for k in rl["pst"] if k.startswith("ms_")}}}
 
-        out["reference_behaviour_timed"] = variant_block(
-            ref_runs, ref_dt, "the same workload with no read cap per pile-up (max_reads = 0) and no k-mer sampling of the mapping "
-            "index (kmer_mod = 1): what the reference does (processPileUps/package.d:283-374, commandline.d:2943-2955)") if ref_runs else None
+        out["operating_point"] = ("reference behaviour: every k-mer of the reads looked up (kmer_mod 1; damapper has no sampling, "
+                                  "commandline.d:2943-2955), every read alignment of a pile-up processed (max_reads 0; "
+                                  "processPileUps/package.d:283-374), every pair of a pile-up aligned (max_partners 0; package.d:474-485)"
+                                  if (args.kmer_mod == 1 and popts.max_reads == 0 and not popts.max_partners) else
+                                  f"NOT the reference's behaviour: kmer_mod {args.kmer_mod}, max_reads {popts.max_reads}, "
+                                  f"max_partners {popts.max_partners}")
+        out["fast_mode_timed"] = variant_block(
+            fast_runs, fast_dt, f"FAST MODE, not the reference's behaviour: modimer sampling 1/{args.fast_kmer_mod} of the mapping k-mers "
+            f"and at most {args.fast_max_reads} reads per pile-up (two work-reducing knobs the reference does not have)",
+            args.fast_kmer_mod) if fast_runs else None
         out["uncapped_partner_cut_timed"] = variant_block(
-            cut_runs, cut_dt, f"no read cap, no k-mer sampling, and the pile-up all-vs-all bounded to {args.ref_partners} partner reads per "
+            cut_runs, cut_dt, f"the headline's knobs with the pile-up all-vs-all bounded to {args.ref_partners} partner reads per "
             "read (dh_process_opts.max_partners; every read still votes in the consensus rounds) -- NOT the reference's "
-            "behaviour: daligner aligns every pair of a pile-up (package.d:474-485)") if cut_runs else None
+            "behaviour: daligner aligns every pair of a pile-up (package.d:474-485)", args.kmer_mod) if cut_runs else None
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(w, last, mopts, popts, args, gap_all, read_all)
         print(json.dumps(out))
@@ -489,15 +499,18 @@ def cpu_baseline(w, last, mopts, popts, args, gap_bases, read_bp_total):
     # spread of the mapping rate: two more samples of a third of the size (different reads would need another DB:
     # the same reads are re-mapped, so this is the timing noise of the box, not of the data)
     rates = [map_bp_s]
-    for _ in range(2):
+    for _ in range(2 if t_index < 3.0 else 0):   # every call rebuilds the index: not repeated when that alone takes seconds
         t_s, bp_s = map_reads(max(4 * cores, n_map // 3))
         rates.append(bp_s / max(t_s - t_index, 1e-3))
 
     rec, las_all = last["rec"], last["las"]
     npiles = int(last["info"]["piles"])
     po = oz.default_process_opts(rounds=popts.rounds, max_reads=popts.max_reads, min_reads=popts.min_reads, algo=popts.algo,
+                                 max_partners=popts.max_partners,
                                  **(dict(width=32) if (popts.algo == 1 and popts.width == 32) else {}))
     gaps_sorted = [int(r["contig_left"]) for r in rec]
+    # the untimed stand-in for the mapping output may sample its k-mers (it only has to place the reads around the sampled gaps)
+    o_standin = oz.default_opts(width=mopts.width, kmer_mod=max(8, mopts.kmer_mod), k=mopts.k, xdrop=mopts.xdrop, algo=mopts.algo)
     budget, batch = 0.5 * args.cpu_seconds, max(cores, 8)   # a pile-up per OpenMP thread and batch
     done, t_proc, used = 0, 0.0, 0
     while done < len(gaps_sorted) and t_proc < budget:
@@ -506,7 +519,7 @@ def cpu_baseline(w, last, mopts, popts, args, gap_bases, read_bp_total):
         rids = np.unique(las_all["bread"][sel]) - w.read_first
         rids = rids[(rids >= 0) & (rids < w.reads.n)]
         remap = sim.SeqDb.from_list([w.reads.seq(int(r)) for r in rids])
-        ol, ot, _ = oz.align_db(w.contigs, remap, o, nthreads=cores)   # not timed (mapping output stand-in)
+        ol, ot, _ = oz.align_db(w.contigs, remap, o_standin, nthreads=cores)   # not timed (mapping output stand-in)
         t = time.perf_counter()
         g2, tris = oz.collect_spanning_c(ol, w.contigs, po)
         keep = [i for i, g in enumerate(g2) if int(g) in set(gs)]
@@ -517,7 +530,8 @@ def cpu_baseline(w, last, mopts, popts, args, gap_bases, read_bp_total):
     per_pile = t_proc / max(used, 1)
     est_map, est_proc = t_index + read_bp_total / map_bp_s, per_pile * npiles
     return {"value": gap_bases / (est_map + est_proc), "unit": "gap-bp/s", "cores": cores, "kind": "port",
-            "label": "CPU restatement of the same algorithm (C + OpenMP) -- not the reference binaries",
+            "label": "CPU restatement of the same algorithm (C + OpenMP) at the same knobs as `value` "
+                     f"(kmer_mod {mopts.kmer_mod}, max_reads {popts.max_reads}, max_partners {popts.max_partners}) -- not the reference binaries",
             "read_bp_mapped_per_sec": map_bp_s, "read_bp_mapped_per_sec_per_core": map_bp_s / cores,
             "read_bp_mapped_per_sec_samples": rates, "pile_ups_per_sec_per_core": 1.0 / max(per_pile, 1e-9) / cores,
             "index_build_s": t_index,

@@ -862,14 +862,21 @@ class Comm:
             pass
 
 
-def shard_run(comm, contigs_db, reads_db, read_first, contig_off, las, trace, opts, cands=None, graph=None):
-    """dh_shard_run: `collect` + `process` of one rank's share with its three exchanges behind the C ABI.  graph =
-    dict(read_off=..., input_gaps=..., scaffold options) selects the scaffold-graph collector, cands the spanning-read
-    one.  Returns (records of all ranks by gap, consensus bases, info)."""
+def shard_run_prepare(comm, contigs_db, reads_db, read_first, contig_off, las, trace, opts, cands=None, graph=None):
+    """Everything of shard_run that can fail BEFORE the C call -- array conversion, option names, missing handles -- done
+    up front; returns the closure that makes the call.  dentist_amd.parallel lets the ranks agree that all of them got this
+    far before any of them enters dh_shard_run's first exchange."""
     L = lib()
+    for what, h in (("communicator", comm), ("contigs DB", contigs_db), ("reads DB", reads_db)):
+        if h is None or not getattr(h, "_h", None):
+            raise ValueError(f"shard_run: no {what}")
+    if cands is None and graph is None:
+        raise ValueError("shard_run: neither candidates nor graph options")
     arr = np.ascontiguousarray(las, dtype=LA_DTYPE)
     tr = np.ascontiguousarray(trace, dtype=np.uint16)
     co = np.ascontiguousarray(contig_off, dtype=np.int64)
+    if co.ndim != 1 or len(co) < 1:
+        raise ValueError("shard_run: contig_off must hold at least one offset")
     ro = ig = so = None
     if cands is None:
         g = dict(graph or {})
@@ -883,17 +890,29 @@ def shard_run(comm, contigs_db, reads_db, read_first, contig_off, las, trace, op
             if not hasattr(so, k):
                 raise TypeError(f"unknown scaffold option {k}")
             setattr(so, k, int(v) if k in ("min_spanning_reads", "merge_extensions") else float(v))
-    h = ctypes.c_void_p()
-    info = (ctypes.c_int64 * 4)()
+    elif not getattr(cands, "_h", None):
+        raise ValueError("shard_run: the candidates have no handle")
     vp = ctypes.c_void_p
     L.dh_shard_run.argtypes = [vp, vp, vp, ctypes.c_int32, vp, ctypes.c_int32, vp, ctypes.c_int64, vp, ctypes.POINTER(ProcessOpts),
                                vp, vp, vp, ctypes.c_int32, vp, ctypes.POINTER(vp), vp]
-    _check(L.dh_shard_run(comm._h, contigs_db._h, reads_db._h, read_first, co.ctypes.data, len(co) - 1, arr.ctypes.data, len(arr),
-                          tr.ctypes.data, ctypes.byref(opts), cands._h if cands is not None else None,
-                          ro.ctypes.data if ro is not None else None, ig.ctypes.data if ig is not None and len(ig) else None,
-                          len(ig) if ig is not None else 0, ctypes.byref(so) if so is not None else None, ctypes.byref(h), info))
-    rec, bases = _take_insertions(h, None, False)
-    return rec, bases, {"piles": int(info[0]), "owned": int(info[1]), "entries": int(info[2]), "cropped_bytes_sent": int(info[3])}
+
+    def call():
+        h = ctypes.c_void_p()
+        info = (ctypes.c_int64 * 4)()
+        _check(L.dh_shard_run(comm._h, contigs_db._h, reads_db._h, read_first, co.ctypes.data, len(co) - 1, arr.ctypes.data, len(arr),
+                              tr.ctypes.data, ctypes.byref(opts), cands._h if cands is not None else None,
+                              ro.ctypes.data if ro is not None else None, ig.ctypes.data if ig is not None and len(ig) else None,
+                              len(ig) if ig is not None else 0, ctypes.byref(so) if so is not None else None, ctypes.byref(h), info))
+        rec, bases = _take_insertions(h, None, False)
+        return rec, bases, {"piles": int(info[0]), "owned": int(info[1]), "entries": int(info[2]), "cropped_bytes_sent": int(info[3])}
+    return call
+
+
+def shard_run(comm, contigs_db, reads_db, read_first, contig_off, las, trace, opts, cands=None, graph=None):
+    """dh_shard_run: `collect` + `process` of one rank's share with its three exchanges behind the C ABI.  graph =
+    dict(read_off=..., input_gaps=..., scaffold options) selects the scaffold-graph collector, cands the spanning-read
+    one.  Returns (records of all ranks by gap, consensus bases, info)."""
+    return shard_run_prepare(comm, contigs_db, reads_db, read_first, contig_off, las, trace, opts, cands=cands, graph=graph)()
 
 
 def shard_pack_cropped(crop, owner, world):

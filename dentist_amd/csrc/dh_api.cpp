@@ -183,7 +183,7 @@ void dh_pinned_trim()
 }
 
 extern "C" const char *dh_last_error(void) { return g_err.c_str(); }
-extern "C" int32_t dh_abi_version(void) { return 3; }  // 3: dh_align_opts.algo
+extern "C" int32_t dh_abi_version(void) { return 4; }  // 4: dh_process_opts.max_partners, .min_relative_score_ppm (64 bytes); 3: dh_align_opts.algo
 
 // ------------------------------------------------------------------------------------ context
 

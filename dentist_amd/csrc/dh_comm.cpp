@@ -34,6 +34,7 @@ struct Rccl {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
@@ -59,7 +60,7 @@ struct Rccl {
         return false;                                                            \
     }
         SYM(GetUniqueId) SYM(CommInitRank) SYM(CommDestroy) SYM(AllGather) SYM(GroupStart) SYM(GroupEnd) SYM(Send) SYM(Recv)
-        SYM(GetErrorString)
+        SYM(GetErrorString) SYM(CommAbort)
 #undef SYM
         return true;
     }
@@ -104,6 +105,11 @@ struct dh_comm {
     dh_ctx *ctx = nullptr;
     ncclComm_t nccl = nullptr;
     LocalHub *hub = nullptr;
+    // RCCL back end: the buffers of the size / status exchanges, made with the communicator -- nothing is allocated
+    // between deciding to enter an exchange and the collective itself
+    int64_t *d_sz = nullptr;   // device: world * (world + 1) + 2 * world words
+    int64_t *h_sz = nullptr;   // page-locked: the same
+    bool aborted = false;      // a collective failed and the communicator was aborted: every later call fails at once
 };
 
 #define NCCLCHK(expr)                                                                                          \
@@ -138,8 +144,16 @@ extern "C" int dh_comm_create(const uint8_t *id128, int32_t rank, int32_t world,
     c->rank = rank;
     c->world = world;
     c->ctx = ctx;
+    const size_t nsz = sizeof(int64_t) * ((size_t)world * (size_t)(world + 1) + 2 * (size_t)world);
+    if (hipMalloc((void **)&c->d_sz, nsz) != hipSuccess || hipHostMalloc((void **)&c->h_sz, nsz, hipHostMallocDefault) != hipSuccess) {
+        if (c->d_sz) (void)hipFree(c->d_sz);
+        delete c;
+        return dh_fail(DH_ENOMEM, "dh_comm_create: no memory for the size exchanges");
+    }
     const ncclResult_t r = rccl().CommInitRank(&c->nccl, world, id, rank);
     if (r != ncclSuccess) {
+        (void)hipFree(c->d_sz);
+        (void)hipHostFree(c->h_sz);
         delete c;
         return dh_fail(DH_EHIP, std::string("ncclCommInitRank: ") + rccl().GetErrorString(r));
     }
@@ -168,6 +182,8 @@ extern "C" void dh_comm_destroy(dh_comm *c)
 {
     if (!c) return;
     if (c->nccl) (void)rccl().CommDestroy(c->nccl);
+    if (c->d_sz) (void)hipFree(c->d_sz);
+    if (c->h_sz) (void)hipHostFree(c->h_sz);
     if (c->hub) {
         bool last;
         {
@@ -194,6 +210,73 @@ static int peers_failed(const int64_t *sizes, int32_t W, int32_t rank, int local
             if (local_rc) return local_rc;  // (the message of the local failure is already set)
             return dh_fail(DH_EINVAL, std::string(who) + ": rank " + std::to_string(r) + " failed before the exchange (status " +
                                           std::to_string(-sizes[r]) + "); rank " + std::to_string(rank) + " gives up with it");
+        }
+    return DH_OK;
+}
+
+
+// ---- RCCL back end: how a rank may fail without stranding its peers.
+//   * BETWEEN two exchanges (anything the rank does on its own): the status travels with the next exchange's sizes
+//     (negative size), every rank returns from that exchange (peers_failed above).
+//   * between the SIZE exchange and the PAYLOAD collective (the buffers are sized by what arrived: scratch, page-locked
+//     staging, the result block): everything is allocated first, then ONE more word per rank is exchanged -- 0 or the
+//     status -- and only if every rank holds its buffers does anybody enter the payload collective (status_exchange).
+//   * INSIDE a collective (an RCCL or HIP call fails: a link or the device is gone): the rank aborts the communicator
+//     (ncclCommAbort) so that the peers' pending collectives end with an error instead of waiting forever; the
+//     communicator is dead from then on (every later call fails at once, on every rank that learns of it the same way).
+static int comm_abort(dh_comm *c, int rc)
+{
+    if (c->nccl) {
+        (void)rccl().CommAbort(c->nccl);
+        c->nccl = nullptr;
+    }
+    c->aborted = true;
+    return rc;
+}
+#define COLL_HIP(expr)                                                                                                   \
+    do {                                                                                                                 \
+        hipError_t e_ = (expr);                                                                                          \
+        if (e_ != hipSuccess)                                                                                            \
+            return comm_abort(c, dh_fail(DH_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " (communicator aborted)")); \
+    } while (0)
+#define COLL_NCCL(expr)                                                                                                  \
+    do {                                                                                                                 \
+        ncclResult_t r_ = (expr);                                                                                        \
+        if (r_ != ncclSuccess)                                                                                           \
+            return comm_abort(c, dh_fail(DH_EHIP, std::string(#expr) + ": " + rccl().GetErrorString(r_) + " (communicator aborted)")); \
+    } while (0)
+static int comm_alive(dh_comm *c, const char *who)
+{
+    if (c->aborted || !c->nccl) return dh_fail(DH_EHIP, std::string(who) + ": the communicator was aborted after a failed collective");
+    if (!c->ctx) return dh_fail(DH_EINVAL, std::string(who) + ": the communicator has no context");
+    return DH_OK;
+}
+// all-gather of `n` words per rank through the communicator's own buffers: out[r * n + i] = word i of rank r
+static int words_exchange(dh_comm *c, const int64_t *mine, size_t n, int64_t *out)
+{
+    const size_t W = (size_t)c->world;
+    hipStream_t st = c->ctx->stream;
+    int64_t *d_all = c->d_sz, *d_mine = c->d_sz + W * W, *h_all = c->h_sz, *h_mine = c->h_sz + W * W;
+    memcpy(h_mine, mine, sizeof(int64_t) * n);
+    COLL_HIP(hipMemcpyAsync(d_mine, h_mine, sizeof(int64_t) * n, hipMemcpyHostToDevice, st));
+    COLL_NCCL(rccl().AllGather(d_mine, d_all, n, ncclInt64, c->nccl, st));
+    COLL_HIP(hipMemcpyAsync(h_all, d_all, sizeof(int64_t) * n * W, hipMemcpyDeviceToHost, st));
+    COLL_HIP(hipStreamSynchronize(st));
+    memcpy(out, h_all, sizeof(int64_t) * n * W);
+    return DH_OK;
+}
+// the second status word: every rank says whether it holds the buffers of the payload collective
+static int status_exchange(dh_comm *c, int local_rc, const char *who)
+{
+    const int32_t W = c->world;
+    const int64_t mine = local_rc ? -(int64_t)std::max(1, local_rc > 0 ? local_rc : -local_rc) : 0;
+    std::vector<int64_t> all((size_t)W);
+    if (int rc = words_exchange(c, &mine, 1, all.data())) return rc;
+    for (int32_t r = 0; r < W; r++)
+        if (all[(size_t)r] < 0) {
+            if (local_rc) return local_rc;
+            return dh_fail(DH_EINVAL, std::string(who) + ": rank " + std::to_string(r) + " could not stage its payload (status " +
+                                          std::to_string(-all[(size_t)r]) + "); rank " + std::to_string(c->rank) + " gives up with it");
         }
     return DH_OK;
 }
@@ -234,16 +317,12 @@ static int all_gather_st(dh_comm *c, const uint8_t *payload, int64_t nbytes, int
         *out = buf;
         return DH_OK;
     }
+    if (int rc = comm_alive(c, "dh_comm_all_gather")) return rc;
     dh_ctx *ctx = c->ctx;
-    HIPCHK(hipSetDevice(ctx->device));
+    COLL_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    // sizes first
-    int64_t *d_sz;
-    if (int rc = dh_scratch(ctx, 55, sizeof(int64_t) * (size_t)(W + 1), (void **)&d_sz)) return rc;
-    HIPCHK(hipMemcpyAsync(d_sz + W, &nbytes, sizeof(int64_t), hipMemcpyHostToDevice, st));
-    NCCLCHK(rccl().AllGather(d_sz + W, d_sz, 1, ncclInt64, c->nccl, st));
-    HIPCHK(hipMemcpyAsync(sizes, d_sz, sizeof(int64_t) * (size_t)W, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    // (1) sizes, a negative one = "this rank failed with status -size"
+    if (int rc = words_exchange(c, &nbytes, 1, sizes)) return rc;
     if (int rc = peers_failed(sizes, W, c->rank, local_rc, "dh_comm_all_gather")) return rc;
     int64_t cap = 1, total = 0;
     for (int32_t r = 0; r < W; r++) {
@@ -251,33 +330,41 @@ static int all_gather_st(dh_comm *c, const uint8_t *payload, int64_t nbytes, int
         total += sizes[r];
     }
     cap = (cap + 15) & ~15ll;
-    uint8_t *d_send, *d_recv;
-    if (int rc = dh_scratch(ctx, 56, (size_t)cap, (void **)&d_send)) return rc;
-    if (int rc = dh_scratch(ctx, 57, (size_t)cap * (size_t)W, (void **)&d_recv)) return rc;
-    // page-locked staging both ways (the blobs the glue hands over are plain malloc'd memory)
-    uint8_t *stage = (uint8_t *)dh_pinned_alloc((size_t)std::max<int64_t>(std::max(nbytes, total), 1));
-    if (!stage) return dh_fail(DH_ENOMEM, "dh_comm_all_gather: out of page-locked memory");
-    struct Unpin {
-        uint8_t *p;
+    // (2) every buffer the payload collective needs, then the second status word: nobody enters the payload collective
+    // unless every rank holds them.  Page-locked staging both ways (the blobs the glue hands over are plain malloc'd memory)
+    uint8_t *d_send = nullptr, *d_recv = nullptr;
+    const size_t nstage = (size_t)std::max<int64_t>(std::max(nbytes, total), 1);
+    uint8_t *stage = nullptr, *buf = nullptr;
+    int rc2 = dh_scratch(ctx, 56, (size_t)cap, (void **)&d_send);
+    if (!rc2) rc2 = dh_scratch(ctx, 57, (size_t)cap * (size_t)W, (void **)&d_recv);
+    if (!rc2 && !(stage = (uint8_t *)dh_pinned_alloc(nstage))) rc2 = dh_fail(DH_ENOMEM, "dh_comm_all_gather: out of page-locked memory");
+    if (!rc2 && !(buf = (uint8_t *)malloc((size_t)std::max<int64_t>(total, 1)))) rc2 = dh_fail(DH_ENOMEM, "dh_comm_all_gather: out of memory");
+    struct Staged {
+        uint8_t *p, *b;
         size_t n;
-        ~Unpin() { dh_pinned_free(p, n); }
-    } unpin{stage, (size_t)std::max<int64_t>(std::max(nbytes, total), 1)};
+        ~Staged()
+        {
+            if (p) dh_pinned_free(p, n);
+            free(b);
+        }
+    } staged{stage, buf, nstage};
+    if (int rc = status_exchange(c, rc2, "dh_comm_all_gather")) return rc;
+    // (3) the payload; a failure in here aborts the communicator
     if (nbytes) {
         memcpy(stage, payload, (size_t)nbytes);
-        HIPCHK(hipMemcpyAsync(d_send, stage, (size_t)nbytes, hipMemcpyHostToDevice, st));
+        COLL_HIP(hipMemcpyAsync(d_send, stage, (size_t)nbytes, hipMemcpyHostToDevice, st));
     }
-    NCCLCHK(rccl().AllGather(d_send, d_recv, (size_t)cap, ncclUint8, c->nccl, st));
-    HIPCHK(hipStreamSynchronize(st));  // (the staging buffer is reused for the way back)
+    COLL_NCCL(rccl().AllGather(d_send, d_recv, (size_t)cap, ncclUint8, c->nccl, st));
+    COLL_HIP(hipStreamSynchronize(st));  // (the staging buffer is reused for the way back)
     int64_t at = 0;
     for (int32_t r = 0; r < W; r++) {
-        if (sizes[r]) HIPCHK(hipMemcpyAsync(stage + at, d_recv + (size_t)r * (size_t)cap, (size_t)sizes[r], hipMemcpyDeviceToHost, st));
+        if (sizes[r]) COLL_HIP(hipMemcpyAsync(stage + at, d_recv + (size_t)r * (size_t)cap, (size_t)sizes[r], hipMemcpyDeviceToHost, st));
         at += sizes[r];
     }
-    HIPCHK(hipStreamSynchronize(st));
-    uint8_t *buf = (uint8_t *)malloc((size_t)std::max<int64_t>(total, 1));
-    if (!buf) return dh_fail(DH_ENOMEM, "dh_comm_all_gather: out of memory");
+    COLL_HIP(hipStreamSynchronize(st));
     if (total) memcpy(buf, stage, (size_t)total);
     *out = buf;
+    staged.b = nullptr;
     return DH_OK;
 }
 extern "C" int dh_comm_all_gather(dh_comm *c, const uint8_t *payload, int64_t nbytes, uint8_t **out, int64_t *sizes)
@@ -331,17 +418,13 @@ static int all_to_all_st(dh_comm *c, const uint8_t *const *per_dest, const int64
         *out = buf;
         return DH_OK;
     }
+    if (int rc = comm_alive(c, "dh_comm_all_to_all")) return rc;
     dh_ctx *ctx = c->ctx;
-    HIPCHK(hipSetDevice(ctx->device));
+    COLL_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    // every rank's row of send sizes: recv_sizes[r] = row r, column rank
-    int64_t *d_sz;
-    if (int rc = dh_scratch(ctx, 55, sizeof(int64_t) * (size_t)W * (size_t)(W + 1), (void **)&d_sz)) return rc;
+    // (1) every rank's row of send sizes: recv_sizes[r] = row r, column rank (a negative row = that rank's status)
     std::vector<int64_t> rows((size_t)W * (size_t)W);
-    HIPCHK(hipMemcpyAsync(d_sz + (size_t)W * W, send_sizes, sizeof(int64_t) * (size_t)W, hipMemcpyHostToDevice, st));
-    NCCLCHK(rccl().AllGather(d_sz + (size_t)W * W, d_sz, (size_t)W, ncclInt64, c->nccl, st));
-    HIPCHK(hipMemcpyAsync(rows.data(), d_sz, sizeof(int64_t) * rows.size(), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    if (int rc = words_exchange(c, send_sizes, (size_t)W, rows.data())) return rc;
     int64_t stot = 0, rtot = 0;
     for (int32_t r = 0; r < W; r++) recv_sizes[r] = rows[(size_t)r * W + c->rank];
     if (int rc = peers_failed(recv_sizes, W, c->rank, local_rc, "dh_comm_all_to_all")) return rc;
@@ -349,24 +432,31 @@ static int all_to_all_st(dh_comm *c, const uint8_t *const *per_dest, const int64
         stot += send_sizes[r];
         rtot += recv_sizes[r];
     }
-    uint8_t *d_send, *d_recv;
-    if (int rc = dh_scratch(ctx, 56, (size_t)std::max<int64_t>(stot, 16), (void **)&d_send)) return rc;
-    if (int rc = dh_scratch(ctx, 57, (size_t)std::max<int64_t>(rtot, 16), (void **)&d_recv)) return rc;
+    // (2) the buffers, then the second status word
+    uint8_t *d_send = nullptr, *d_recv = nullptr, *stage = nullptr, *buf = nullptr;
     const size_t nstage = (size_t)std::max<int64_t>(std::max(stot, rtot), 1);
-    uint8_t *stage = (uint8_t *)dh_pinned_alloc(nstage);
-    if (!stage) return dh_fail(DH_ENOMEM, "dh_comm_all_to_all: out of page-locked memory");
-    struct Unpin {
-        uint8_t *p;
+    int rc2 = dh_scratch(ctx, 56, (size_t)std::max<int64_t>(stot, 16), (void **)&d_send);
+    if (!rc2) rc2 = dh_scratch(ctx, 57, (size_t)std::max<int64_t>(rtot, 16), (void **)&d_recv);
+    if (!rc2 && !(stage = (uint8_t *)dh_pinned_alloc(nstage))) rc2 = dh_fail(DH_ENOMEM, "dh_comm_all_to_all: out of page-locked memory");
+    if (!rc2 && !(buf = (uint8_t *)malloc((size_t)std::max<int64_t>(rtot, 1)))) rc2 = dh_fail(DH_ENOMEM, "dh_comm_all_to_all: out of memory");
+    struct Staged {
+        uint8_t *p, *b;
         size_t n;
-        ~Unpin() { dh_pinned_free(p, n); }
-    } unpin{stage, nstage};
+        ~Staged()
+        {
+            if (p) dh_pinned_free(p, n);
+            free(b);
+        }
+    } staged{stage, buf, nstage};
+    if (int rc = status_exchange(c, rc2, "dh_comm_all_to_all")) return rc;
+    // (3) the payload; a failure in here aborts the communicator
     int64_t at = 0;
     for (int32_t r = 0; r < W; r++) {
         if (send_sizes[r]) memcpy(stage + at, per_dest[r], (size_t)send_sizes[r]);
         at += send_sizes[r];
     }
-    if (stot) HIPCHK(hipMemcpyAsync(d_send, stage, (size_t)stot, hipMemcpyHostToDevice, st));
-    NCCLCHK(rccl().GroupStart());
+    if (stot) COLL_HIP(hipMemcpyAsync(d_send, stage, (size_t)stot, hipMemcpyHostToDevice, st));
+    COLL_NCCL(rccl().GroupStart());
     int64_t so = 0, ro = 0;
     ncclResult_t grc = ncclSuccess;  // an error inside the group still closes it
     for (int32_t r = 0; r < W && grc == ncclSuccess; r++) {
@@ -377,16 +467,15 @@ static int all_to_all_st(dh_comm *c, const uint8_t *const *per_dest, const int64
     }
     {
         const ncclResult_t erc = rccl().GroupEnd();
-        NCCLCHK(grc);
-        NCCLCHK(erc);
+        COLL_NCCL(grc);
+        COLL_NCCL(erc);
     }
-    HIPCHK(hipStreamSynchronize(st));
-    if (rtot) HIPCHK(hipMemcpyAsync(stage, d_recv, (size_t)rtot, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    uint8_t *buf = (uint8_t *)malloc((size_t)std::max<int64_t>(rtot, 1));
-    if (!buf) return dh_fail(DH_ENOMEM, "dh_comm_all_to_all: out of memory");
+    COLL_HIP(hipStreamSynchronize(st));
+    if (rtot) COLL_HIP(hipMemcpyAsync(stage, d_recv, (size_t)rtot, hipMemcpyDeviceToHost, st));
+    COLL_HIP(hipStreamSynchronize(st));
     if (rtot) memcpy(buf, stage, (size_t)rtot);
     *out = buf;
+    staged.b = nullptr;
     return DH_OK;
 }
 extern "C" int dh_comm_all_to_all(dh_comm *c, const uint8_t *const *per_dest, const int64_t *send_sizes, uint8_t **out,

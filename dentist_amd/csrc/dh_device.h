@@ -33,7 +33,7 @@ struct DbView {
     // same rule (oz_db.pflags).
     const uint8_t *pflags;
 };
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define DH_HDI __host__ __device__ inline
 #else
 #define DH_HDI inline

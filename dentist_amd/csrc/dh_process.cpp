@@ -1866,8 +1866,10 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
     if (o.max_reads != 0 && (o.max_reads < 3 || o.max_reads > 250))
         return dh_fail(DH_EINVAL, "max_reads must be 0 (no cap) or in [3, 250]");
     if (o.max_partners != 0 && o.max_partners < 4) return dh_fail(DH_EINVAL, "max_partners must be 0 (every pair) or at least 4");
-    if (o.min_relative_score_ppm < 0 || o.min_relative_score_ppm > 1000000)
-        return dh_fail(DH_EINVAL, "min_relative_score_ppm must be in [0, 1000000]");
+    // (0 is refused: it is what a caller built against the 56-byte struct of ABI 3, or one that zero-fills the struct, would
+    // pass without meaning it -- "every chain at or above min_score" is 1)
+    if (o.min_relative_score_ppm < 1 || o.min_relative_score_ppm > 1000000)
+        return dh_fail(DH_EINVAL, "min_relative_score_ppm must be in [1, 1000000] (1000000 = the default 1.0; fill the struct with dh_default_process_opts)");
     if (o.rounds < 1 || o.rounds > 8) return dh_fail(DH_EINVAL, "rounds must be in [1, 8]");
     if (o.tspace_pile < 16 || o.tspace_pile > SEG_MAX) return dh_fail(DH_EINVAL, "tspace_pile out of range");
     HIPCHK(hipSetDevice(ctx->device));

@@ -187,6 +187,20 @@ def rccl_comm(ctx, rank, world):
     return _COMM[key]
 
 
+# error codes of the C ABI that say "the communicator / RCCL / the device path did not work" (include/dentist_hip.h:
+# DH_ENODEV -2, DH_EHIP -3) -- the only failures of a first dh_shard_run the ranks answer by switching to
+# torch.distributed's collectives; a data error (DH_EINVAL, DH_EOVERFLOW, DH_EIO, DH_ENOMEM) would fail there as well
+_COMM_ERROR_CODES = (-2, -3)
+
+
+def _agree_min(value, dist):
+    """MIN over the ranks of one small integer (every rank must call it at the same point)."""
+    import torch
+    t = torch.tensor([int(value)], dtype=torch.int32, device=_device(dist))
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item())
+
+
 def sharded_process(ctx, contigs_db, reads_db, read_first, contig_off, las, trace, popts, rank, world, cands=None, graph=None):
     """`collect` + `process` for one rank's share of the reads.  las/trace: this rank's mapping
     result with bread ALREADY shifted to ids of the whole reads DB; reads_db holds the reads
@@ -195,29 +209,50 @@ def sharded_process(ctx, contigs_db, reads_db, read_first, contig_off, las, trac
     import torch.distributed as dist
     if world > 1 and dist.is_initialized() and dist.get_backend() == "nccl" and _c_abi_collectives(ctx, rank, world):
         # one process per GPU over RCCL: the whole sequence behind the C ABI (dh_shard_run); this module is a thin caller
-        from ._lib import shard_run
+        import sys
+        from ._lib import DhError, shard_run_prepare
         key = (id(ctx), rank, world)
+        # PRE-FLIGHT, agreed on by all ranks: whatever can fail before the first exchange inside dh_shard_run (array
+        # conversion, option names, NULL handles) fails HERE, and a rank that failed tells the others before anybody
+        # enters a collective of the C ABI -- nobody is left waiting in an RCCL call for a rank that never arrives
+        call, perr = None, None
+        try:
+            call = shard_run_prepare(rccl_comm(ctx, rank, world), contigs_db, reads_db, read_first, contig_off, las, trace, popts,
+                                     cands=cands, graph=graph)
+        except Exception as e:   # noqa: BLE001
+            perr = e
+        if _agree_min(0 if perr is not None else 1, dist) == 0:
+            if perr is not None:
+                raise perr
+            raise RuntimeError("sharded_process: another rank failed before dh_shard_run (its own error names the cause)")
         res, err = None, None
         try:
-            res = shard_run(rccl_comm(ctx, rank, world), contigs_db, reads_db, read_first, contig_off, las, trace, popts,
-                            cands=cands, graph=graph)
+            res = call()
         except Exception as e:   # noqa: BLE001
             err = e
         if not _C_ABI_RAN.get(key):
-            # the FIRST run of this process: the ranks agree that it went through everywhere (a rank that fails inside
-            # dh_shard_run still takes part in the next size exchange with its status, so every rank comes back from the
-            # same exchange, dh_comm.cpp) -- otherwise all of them switch to the torch.distributed collectives for good
-            import sys
-            import torch
-            flag = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=_device(dist))
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
-                print("[dentist_amd] rank %d: dh_shard_run failed on some rank (%s); the exchanges go through torch.distributed "
-                      "from here on" % (rank, repr(err) if err is not None else "not this one"), file=sys.stderr, flush=True)
+            # the FIRST run of this process: the ranks agree on how it went (a rank that fails inside dh_shard_run still takes
+            # part in the next size exchange with its status, so every rank comes back from the same exchange, dh_comm.cpp).
+            # 2 = fine, 1 = a communicator / RCCL / HIP failure, 0 = a data error.  Only a communicator failure sends all
+            # ranks to the torch.distributed collectives (for good); a data error is raised on every rank as it is -- it
+            # would fail the same way there, and computing it twice hides where it came from
+            mine = 2 if err is None else (1 if isinstance(err, DhError) and err.code in _COMM_ERROR_CODES else 0)
+            # (a rank that only learned of a peer's failure reports 2 here: DH_EINVAL "rank r failed before the exchange")
+            if err is not None and isinstance(err, DhError) and "failed before the exchange" in str(err):
+                mine = 2
+            worst = _agree_min(mine, dist)
+            if worst == 2 and err is None:
+                _C_ABI_RAN[key] = True
+            elif worst == 1:
+                print("[dentist_amd] rank %d: dh_shard_run failed in the communicator on some rank (%s); the exchanges go through "
+                      "torch.distributed from here on" % (rank, repr(err) if err is not None else "not this one"),
+                      file=sys.stderr, flush=True)
                 _C_ABI_OK[key] = False
                 res = None
             else:
-                _C_ABI_RAN[key] = True
+                if err is not None:
+                    raise err
+                raise RuntimeError("sharded_process: dh_shard_run failed on another rank with a data error")
         elif err is not None:
             raise err
         if res is not None:
@@ -243,30 +278,32 @@ _C_ABI_RAN = {}
 
 def _c_abi_collectives(ctx, rank, world):
     """Whether the ranks run the exchanges behind the C ABI (dh_comm over RCCL).  Decided ONCE per process, by all ranks
-    together: every rank tries to create its communicator and the outcomes are min-reduced over torch.distributed, so that
-    either all ranks take dh_shard_run or all take the torch.distributed collectives (RCCL as well; the host steps between
-    them are the same dh_shard_* functions).  A rank that cannot create the communicator says so on stderr -- the result
-    records which path ran (info["collectives"]).  DH_SHARD_COLLECTIVES=torch forces the second path."""
+    together: rank 0's DH_SHARD_COLLECTIVES setting is broadcast first (the variable may differ between the ranks'
+    environments; every rank must take the same sequence of collectives from here on), then every rank tries to create its
+    communicator and the outcomes are min-reduced over torch.distributed, so that either all ranks take dh_shard_run or all
+    take the torch.distributed collectives (RCCL as well; the host steps between them are the same dh_shard_* functions).  A
+    rank that cannot create the communicator says so on stderr -- the result records which path ran
+    (info["collectives"]).  DH_SHARD_COLLECTIVES=torch (on rank 0) forces the second path."""
     import os
     import sys
-    import torch
     import torch.distributed as dist
     key = (id(ctx), rank, world)
     if key not in _C_ABI_OK:
+        box = [os.environ.get("DH_SHARD_COLLECTIVES", "") if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
         ok, why = 1, ""
-        if os.environ.get("DH_SHARD_COLLECTIVES", "") == "torch":
-            ok, why = 0, "DH_SHARD_COLLECTIVES=torch"
+        if box[0] == "torch":
+            ok, why = 0, "DH_SHARD_COLLECTIVES=torch on rank 0"
         else:
             try:
                 rccl_comm(ctx, rank, world)
             except Exception as e:   # noqa: BLE001 -- whatever went wrong, the other ranks must learn of it
                 ok, why = 0, repr(e)
-        flag = torch.tensor([ok], dtype=torch.int32, device=_device(dist))
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        agreed = _agree_min(ok, dist)
         if not ok:
             print("[dentist_amd] rank %d: no dh_comm communicator (%s); the exchanges go through torch.distributed" % (rank, why),
                   file=sys.stderr, flush=True)
-        _C_ABI_OK[key] = bool(int(flag.item()))
+        _C_ABI_OK[key] = bool(agreed)
     return _C_ABI_OK[key]
 
 
@@ -366,7 +403,9 @@ def sharded_process_steps(ctx, contigs_db, reads_db, read_first, contig_off, las
     # pile-up order (= the single-GPU order, whatever the world size): rank r's records are its owned pile-ups in
     # ascending pile-up index; several pile-ups may share contig_left, so the start node alone does not order them
     pile_of = np.concatenate([np.nonzero(owner == r)[0] for r in range(world)]) if len(grec) else np.zeros(0, dtype=np.int64)
-    order = np.argsort(pile_of, kind="stable") if len(pile_of) == len(grec) else np.argsort(grec["contig_left"], kind="stable")
+    if len(pile_of) != len(grec):   # (as merge_closed of dh_comm.cpp: an order that depends on the world size must not go unnoticed)
+        raise RuntimeError("sharded_process: the ranks returned %d closed-gap records for %d owned pile-ups" % (len(grec), len(pile_of)))
+    order = np.argsort(pile_of, kind="stable")
     nentries = int(piles.flat()[1].sum())
     lap("order")
     plan.close()

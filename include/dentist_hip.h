@@ -30,7 +30,8 @@ extern "C" {
 #define DH_ENOMEM (-6)
 
 const char *dh_last_error(void);
-/* library / ABI version, bumped on any struct change */
+/* library / ABI version, bumped on any struct change (4: dh_process_opts is 64 bytes -- max_partners,
+ * min_relative_score_ppm; callers check it before passing structs) */
 int32_t dh_abi_version(void);
 
 /* ---- context: one per process == one per GPU (torch.distributed launches one rank per GPU) */
@@ -258,7 +259,8 @@ typedef struct {
                                 * still re-align EVERY read of the pile-up to the template.  The n^2 stage becomes n x
                                 * max_partners; every read keeps its vote.  oracle/process.py, oracle/pile.c: same rule. */
     int32_t min_relative_score_ppm; /* --min-relative-score of the pile-up chaining (commandline.d:2141-2153; 1 000 000 =
-                                * the default 1.0: only chains with the pair's best score).  Below it the chains of a pair
+                                * the default 1.0: only chains with the pair's best score; valid range [1, 1 000 000], 0 is
+                                * refused as the mark of a zero-filled or too short struct).  Below it the chains of a pair
                                 * within that fraction of its best chain are kept, per connected component of the
                                 * chainability relation, ALTERNATE chains (sharing a prefix with a better chain) included:
                                 * the LAs they share then count once per chain, as in the reference's chained .las

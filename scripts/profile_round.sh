@@ -17,7 +17,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/prof_$c -o run -- python "$root/bench.py" --steps 1 --warmup 0 --no-cpu-baseline "$@" > "$out/bench_$c.log" 2>&1
 done
 { echo "# rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two separate passes), python bench.py --steps 1 --warmup 0 --no-cpu-baseline $*"; python "$root/scripts/pmc_summary.py" /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE; } > "$out/pmc_hbm_traffic.txt"
-python "$root/scripts/traffic_json.py" /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE "$out/kernel_traffic.json" "${DH_PROF_WORKLOAD:-cfg2_100Mb_1000gaps_1Mx15kb}" "${DH_PROF_KMER_MOD:-4}" "${DH_PROF_K:-20}" "${DH_PROF_ALGO:-1}"
+python "$root/scripts/traffic_json.py" /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE "$out/kernel_traffic.json" "${DH_PROF_WORKLOAD:-cfg2_100Mb_1000gaps_1Mx15kb}" "${DH_PROF_KMER_MOD:-1}" "${DH_PROF_K:-20}" "${DH_PROF_ALGO:-1}"
 # SQ counters (8 slots per pass): instruction mix / issue, then waits and LDS conflicts
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d /tmp/prof_SQ1 -o run -- python "$root/bench.py" --steps 1 --warmup 0 --no-cpu-baseline "$@" > "$out/bench_SQ1.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU --output-format csv -d /tmp/prof_SQ2 -o run -- python "$root/bench.py" --steps 1 --warmup 0 --no-cpu-baseline "$@" > "$out/bench_SQ2.log" 2>&1

@@ -31,7 +31,19 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(decl):
         assert hasattr(L, name), f"{name} declared in include/ but not exported"
     assert decl == set(_lib.SYMBOLS), "binding list and header disagree"
-    assert L.dh_abi_version() == 3
+    assert L.dh_abi_version() == 4
+
+
+def test_process_opts_layout_matches_the_abi_version():
+    """dh_process_opts grew by two int32 fields with ABI 4 (max_partners, min_relative_score_ppm): the binding's struct is
+    the header's (16 x int32 = 64 bytes), the defaults fill the new fields, and a zero there is refused."""
+    assert ctypes.sizeof(_lib.ProcessOpts) == 64
+    hdr = open(os.path.join(ROOT, "include", "dentist_hip.h")).read()
+    body = hdr[hdr.index("int32_t tspace_map;"):hdr.index("} dh_process_opts;")]
+    fields = re.findall(r"^\s*int32_t\s+(\w+);", body, flags=re.M)
+    assert fields == [n for n, _ in _lib.ProcessOpts._fields_], fields
+    o = dentist_amd.default_process_opts()
+    assert o.min_relative_score_ppm == 1000000 and o.max_partners == 0
 
 
 def o_algo_default():

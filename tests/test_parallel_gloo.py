@@ -406,7 +406,8 @@ def _worker_agree(rank, world, port, q, forced):
     import dentist_amd.parallel as par
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    if forced:
+    os.environ.pop("DH_SHARD_COLLECTIVES", None)
+    if forced is True or forced == "rank%d" % rank:   # ("rank0" / "rank1": the variable differs between the ranks' environments)
         os.environ["DH_SHARD_COLLECTIVES"] = "torch"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     par._device = lambda d: torch.device("cpu")   # (the agreement runs over whatever backend carries torch.distributed)
@@ -423,8 +424,9 @@ def _worker_agree(rank, world, port, q, forced):
 def test_ranks_agree_on_the_collectives_when_the_communicator_cannot_be_made():
     """parallel._c_abi_collectives: every rank tries to create its dh_comm (rank 0 draws the id and broadcasts it, or its
     failure), the outcomes are min-reduced, and all ranks take the same path.  On a machine without a GPU no rank can
-    create one: both say False, by agreement and by the DH_SHARD_COLLECTIVES=torch switch."""
-    for forced in (False, True):
+    create one: both say False, by agreement and by the DH_SHARD_COLLECTIVES=torch switch -- also when the switch is set in
+    one rank's environment only (rank 0's setting is broadcast and decides: no rank skips a collective the other enters)."""
+    for forced in (False, True, "rank0", "rank1"):
         port = _free_port()
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
