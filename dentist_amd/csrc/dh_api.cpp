@@ -2086,6 +2086,8 @@ static int align_range(dh_ctx *ctx, dh_db *A, dh_db *B, int32_t first, int32_t c
             tp.candoff = sym_tiled ? (const int32_t *)d_candoff - item0 : nullptr;
             tp.book_min = 1;
             if (const char *e = getenv("DH_TILE_BOOK_MIN")) tp.book_min = std::max(1, std::min(64, atoi(e)));
+            tp.qbatch = 64;
+            if (const char *e = getenv("DH_TILE_QBATCH")) tp.qbatch = std::max(1, std::min(4096, atoi(e)));  // development
             tp.regs = d_regs;
             tp.cold = d_cold;
             tp.nbmax = nbmax;

@@ -90,6 +90,7 @@ struct Params {
     int32_t *regs;                    // nlanes * MAXREG * REGF
     Cold *cold;                       // nlanes: the lanes' cold state
     int32_t book_min;                 // lanes that must be waiting before a wavefront does a bookkeeping pass (k_tile)
+    int32_t qbatch;                   // work units a wavefront takes from the queue per atomic (k_tile; 0 or 1: what its lanes need)
     int32_t nbmax, trmax;             // pairs a direction can yield; u16 values per output slot (>= 2 * (2 * nbmax + 2))
     DhLa *out_la;                     // max_la records per item (absolute item index); symmetric mode: two per candidate
     uint16_t *out_trace;              // trmax values per record slot

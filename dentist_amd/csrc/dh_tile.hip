@@ -33,13 +33,15 @@ __device__ __forceinline__ int32_t wave_max_i32(int32_t v)
 #ifdef DH_SEED_PROF
 // development: where a wavefront's time goes -- [0] bookkeeping passes (wall), [1] tile set-up, [2] column loops,
 // [3] tile ends, [4] passes, [5] rounds, [6] lanes in the rounds, [7] lane-passes (lanes wanting a pass, summed)
-__device__ unsigned long long g_tile_prof[18];
+__device__ unsigned long long g_tile_prof[20];
+__device__ unsigned long long g_tile_hist[8];  // lane-rounds by tile width: <= 8, <= 32, <= 64, < 126, >= 126; [5] first tiles, [6] partial last tiles, [7] sum of T
 #define TP(i) { const unsigned long long t_ = clock64(); pacc_[i] += t_ - tp_; tp_ = t_; }
 #define TPC(i, v) pacc_[i] += (unsigned long long)(v);
 extern "C" void dhk_tile_prof_dump()
 {
-    unsigned long long h[18];
+    unsigned long long h[20];
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tile_prof), sizeof(h));
+    if (h[5]) fprintf(stderr, "[tile prof] columns a wavefront runs per round (max over its lanes): %.1f\n", (double)h[18] / h[5]);
     if (h[5])
         fprintf(stderr, "[tile prof] ext_end sections (G cycles, max lane per wave): rev->fwd %.2f region %.2f finish_pairs %.2f emit %.2f second %.2f tail %.2f\n",
                 h[12] / 1e9, h[13] / 1e9, h[14] / 1e9, h[15] / 1e9, h[16] / 1e9, h[17] / 1e9);
@@ -50,7 +52,15 @@ extern "C" void dhk_tile_prof_dump()
                         "lanes/round %.1f lanes/pass %.1f; per pass %.0f cycles, per round %.0f cycles\n",
                 h[0] / 1e9, h[1] / 1e9, h[2] / 1e9, h[3] / 1e9, h[4], h[5], (double)h[6] / h[5], (double)h[7] / (h[4] ? h[4] : 1),
                 (double)h[0] / (h[4] ? h[4] : 1), (double)(h[1] + h[2] + h[3]) / h[5]);
-    unsigned long long z[18] = {0};
+    {
+        unsigned long long hh[8];
+        (void)hipMemcpyFromSymbol(hh, HIP_SYMBOL(g_tile_hist), sizeof(hh));
+        const double tot = (double)(hh[0] + hh[1] + hh[2] + hh[3] + hh[4]);
+        if (tot > 0) fprintf(stderr, "[tile prof] lane-rounds by columns: <=8 %.3f <=32 %.3f <=64 %.3f <126 %.3f >=126 %.3f; first tiles %.3f, cols < T %.3f, mean T %.1f\n", hh[0] / tot, hh[1] / tot, hh[2] / tot, hh[3] / tot, hh[4] / tot, hh[5] / tot, hh[6] / tot, hh[7] / tot);
+        unsigned long long zz[8] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tile_hist), zz, sizeof(zz));
+    }
+    unsigned long long z[20] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tile_prof), z, sizeof(z));
 }
 #else
@@ -123,7 +133,8 @@ __global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
     __shared__ uint32_t s_q[NTW][64];
 #ifdef DH_SEED_PROF
     unsigned long long pacc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tp_ = clock64();
+    unsigned long long tp_ = clock64(), pcm_ = 0;
+    unsigned lh_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     Lane l;
     const int32_t slot = (int32_t)(blockIdx.x * 64 + threadIdx.x);
@@ -133,6 +144,7 @@ __global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
 #endif
     TileT<WB> t;
     typedef typename BandVec<WB>::U V;
+    uint32_t wq_base = 0, wq_rem = 0;  // the wavefront's batch of work units (uniform)
     for (;;) {
         // ---- bookkeeping until every lane extends or is out of work.  A pass costs a handful of dependent memory
         // round trips whatever the number of lanes in it, so it waits until P.book_min lanes want one (or nothing
@@ -158,20 +170,39 @@ __global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
             if (l.st == L_CAND) lane_next_cand(l, P);
             TQ(9)
             {
-                // one atomic per wavefront and pass for all lanes that want a work unit (every lane on its own made
-                // 1.75 M returning atomics on one address per pile-up launch)
+                // The queue is ONE address: a returning atomic on it costs ~11 ns chip-wide whatever else happens (92 M/s
+                // measured), and a symmetric launch of uncapped pile-ups hands out 12.6 M units -- one atomic per
+                // pass and wavefront (the lanes of a pass that want a unit share it) was ~10 M of them, a tenth of a second
+                // of the atomic unit's time with every wavefront's other loads queued behind its own.  A wavefront therefore
+                // takes P.qbatch units per atomic and deals them to its lanes from [wq_base, wq_base + wq_rem) (uniform
+                // values); what a pass needs beyond the rest of the batch comes from the next one.  The units a wavefront
+                // holds at the end are at most qbatch - 1: one more unit per lane.
                 const unsigned long long fm = __builtin_amdgcn_ballot_w64(l.st == L_FETCH);
                 if (fm != 0ull) {
-                    const int first = __builtin_ctzll(fm);
-                    uint32_t base = 0;
-                    if ((int)threadIdx.x == first) base = atomicAdd(P.queue, (uint32_t)__builtin_popcountll(fm));
-                    base = (uint32_t)__shfl((int)base, first, 64);
+                    const uint32_t need = (uint32_t)__builtin_popcountll(fm);
+                    uint32_t nb = 0, take = 0;
+                    if (need > wq_rem) {
+                        const uint32_t more = need - wq_rem, qb = (uint32_t)P.qbatch;
+                        take = qb > more ? qb : more;
+                        const int first = __builtin_ctzll(fm);
+                        uint32_t b = 0;
+                        if ((int)threadIdx.x == first) b = atomicAdd(P.queue, take);
+                        nb = (uint32_t)__builtin_amdgcn_readlane((int)b, first);  // (uniform: the batch lives in scalar registers)
+                    }
                     if (l.st == L_FETCH) {
-                        const int32_t it = (int32_t)(base + (uint32_t)__builtin_popcountll(fm & ((1ull << threadIdx.x) - 1ull)));
+                        const uint32_t rank = (uint32_t)__builtin_popcountll(fm & ((1ull << threadIdx.x) - 1ull));
+                        const int32_t it = (int32_t)(rank < wq_rem ? wq_base + rank : nb + (rank - wq_rem));
                         if (it >= (P.units ? (int32_t)*P.nunits : P.nitems))
                             l.st = L_DONE;
                         else
                             lane_fetch(l, P, it);
+                    }
+                    if (need > wq_rem) {
+                        wq_base = nb + (need - wq_rem);
+                        wq_rem = take - (need - wq_rem);
+                    } else {
+                        wq_base += need;
+                        wq_rem -= need;
                     }
                 }
             }
@@ -192,6 +223,15 @@ __global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
             for (int i = 0; i < NTW; i++) s_q[i][threadIdx.x] = q[i];
         }
         const int32_t cmax = wave_max_i32(run ? t.cols : 0);
+#ifdef DH_SEED_PROF
+        if (run) {
+            lh_[t.cols <= 8 ? 0 : (t.cols <= 32 ? 1 : (t.cols <= 64 ? 2 : (t.cols < 126 ? 3 : 4)))]++;
+            if (l.e.ntp == 0) lh_[5]++;
+            if (t.cols < t.T) lh_[6]++;
+            lh_[7] += (unsigned)t.T;
+        }
+        pcm_ += (unsigned long long)cmax;
+#endif
         TP(1)
         for (int32_t blk = 0; 32 * blk < cmax; blk++) {
             const uint32_t a0 = s_q[blk][threadIdx.x], a1 = s_q[blk + 1][threadIdx.x], a2 = WB == 64 ? s_q[blk + 2][threadIdx.x] : 0u;
@@ -228,6 +268,8 @@ __global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
 #ifdef DH_SEED_PROF
     if (threadIdx.x == 0)
         for (int i = 0; i < 12; i++) atomicAdd(&g_tile_prof[i], pacc_[i]);
+    if (threadIdx.x == 0) atomicAdd(&g_tile_prof[18], pcm_);
+    for (int i = 0; i < 8; i++) if (lh_[i]) atomicAdd(&g_tile_hist[i], (unsigned long long)lh_[i]);
     for (int i = 0; i < 6; i++) {  // sections of lane_ext_end: the lanes of a pass run them together, so the largest lane total ~ the wavefront's
         unsigned long long v = l.pt[i];
         for (int off = 32; off > 0; off >>= 1) {
