@@ -481,6 +481,9 @@ __global__ void __launch_bounds__(256) k_scan_apply(uint32_t *__restrict__ v, in
 
 // ------------------------------------------------------------------------------------ K4
 
+// development / tests: 0 = reads with a bucket above SORT_BMAX hits take the bitonic network as before round 6
+// (DH_SEED_NO_REFINE=1; the order is the same either way)
+__device__ int g_seed_sort_refine = 1;
 #define HIT_QBITS 24
 #define HIT_QMASK ((1u << HIT_QBITS) - 1u)
 #define SEED_THREADS 512
@@ -847,11 +850,22 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
         __shared__ unsigned long long s_dmin, s_dmax;
         __shared__ uint32_t s_bw[NT / LANES];
         __shared__ uint32_t s_bmax;
+        // REFINE (round 6): buckets above SORT_BMAX hits are sorted by a second counting pass over their own diagonal range
+        // instead of sending the whole read through the network (below).  The mapping launches need it: a read's ~900 true
+        // hits at kmer_mod 1 lie on a few hundred neighbouring diagonals while its handful of chance hits stretch the
+        // diagonal range over the whole assembly, so the slices are 10^5 diagonals wide and one of them holds everything --
+        // 88 % of the reads of configs[2] took the network, 25.6 of the 41 us a block spent per read.
+        constexpr int HV = 8, NB2 = 1024;            // heavy buckets a read may have; slices of the second pass
+        constexpr bool REFINE = LCAP > 0 && !SMALL;
+        static_assert(!REFINE || sizeof(cband) >= NB2 * sizeof(uint32_t), "the second pass's counters overlay the band array");
+        uint32_t *fcnt = (uint32_t *)cband;          // not in use yet
+        __shared__ uint32_t s_nheavy, s_heavy[HV];
         for (int32_t i = tid; i < NB; i += NT) bcnt[i] = 0;
         if (tid == 0) {
             s_dmin = ~0ull;
             s_dmax = 0ull;
             s_bmax = 0;
+            s_nheavy = 0;
         }
         unsigned long long dmin = ~0ull, dmax = 0ull;
         for (int32_t i = tid; i < n; i += NT) {
@@ -909,6 +923,14 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
             bcnt[tid * (NB / NT) + u] = base;
             base += c4[u];
         }
+        if (REFINE) {
+#pragma unroll
+            for (int u = 0; u < NB / NT; u++)
+                if (c4[u] > (uint32_t)SORT_BMAX) {
+                    const uint32_t slot = atomicAdd(&s_nheavy, 1u);
+                    if (slot < (uint32_t)HV) s_heavy[slot] = (uint32_t)(tid * (NB / NT) + u);
+                }
+        }
         uint64_t ke[E];
         if (LCAP > 0) {
 #pragma unroll
@@ -919,6 +941,7 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
         }
         __syncthreads();
         SP(5)
+        const bool refine = REFINE && g_seed_sort_refine && s_bmax > (uint32_t)SORT_BMAX && s_nheavy <= (uint32_t)HV;
         if (LCAP == 0 && s_bmax <= (uint32_t)SORT_BMAX) {
             uint64_t *tmp = hits + gcap;  // the block's prefix sums live here later
             for (int32_t i = tid; i < n; i += NT) {
@@ -942,7 +965,7 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
                 hits[rk] = key;
             }
             N = 1;
-        } else if (LCAP > 0 && s_bmax <= (uint32_t)SORT_BMAX) {
+        } else if (LCAP > 0 && (s_bmax <= (uint32_t)SORT_BMAX || refine)) {
             // scatter: a bucket's hits in arrival order; the counters end up at the buckets' ends
 #pragma unroll
             for (int u = 0; u < E; u++) {
@@ -952,6 +975,129 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
             __syncthreads();
             SP(6)
             uint32_t dst[E];
+            // keys below `key` among hits[x0, x1) (keys are distinct; eight loads in flight: one at a time made every compare
+            // a full LDS round trip; `low`: the keys of the range agree above their low words, which then decide -- half the
+            // LDS traffic of this loop, which is bound by it)
+            auto count_below = [&](uint32_t x0, uint32_t x1, uint64_t key, bool low) {
+                uint32_t rk = 0, x = x0;
+                if (low) {
+                    const uint32_t *h32 = (const uint32_t *)hits;
+                    const uint32_t key32 = (uint32_t)key;
+                    for (; x + 8 <= x1; x += 8) {
+                        uint32_t h[8];
+#pragma unroll
+                        for (int j = 0; j < 8; j++) h[j] = h32[2 * (x + j)];
+#pragma unroll
+                        for (int j = 0; j < 8; j++) rk += h[j] < key32 ? 1u : 0u;
+                    }
+                }
+                for (; x + 8 <= x1; x += 8) {
+                    uint64_t h[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) h[j] = hits[x + j];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) rk += h[j] < key ? 1u : 0u;
+                }
+                for (; x + 4 <= x1; x += 4) {
+                    const uint64_t h0 = hits[x], h1 = hits[x + 1], h2 = hits[x + 2], h3 = hits[x + 3];
+                    rk += (h0 < key ? 1u : 0u) + (h1 < key ? 1u : 0u) + (h2 < key ? 1u : 0u) + (h3 < key ? 1u : 0u);
+                }
+                for (; x < x1; x++) rk += hits[x] < key ? 1u : 0u;
+                return rk;
+            };
+            const uint32_t nheavy = refine ? s_nheavy : 0u;
+            if (REFINE) {
+                // ---- second pass, one heavy bucket at a time: its hits [hb0, hb1) are dealt into NB2 slices of the bucket's
+                // own diagonal range (counting pass, scan, scatter through registers) and ranked inside their slice; the
+                // bucket ends up sorted in place.  A slice that is still long (hundreds of hits on one diagonal: a
+                // low-complexity read) only makes its ranking loop longer.
+                for (uint32_t hv = 0; hv < nheavy; hv++) {
+                    const uint32_t hb = s_heavy[hv];
+                    const uint32_t hb0 = hb ? bcnt[hb - 1] : 0u, hb1 = bcnt[hb];
+                    if (tid == 0) {
+                        s_dmin = ~0ull;
+                        s_dmax = 0ull;
+                    }
+                    for (int32_t i = tid; i < NB2; i += NT) fcnt[i] = 0;
+                    unsigned long long lmin = ~0ull, lmax = 0ull;
+                    for (uint32_t i = hb0 + tid; i < hb1; i += NT) {
+                        const unsigned long long d = (hits[i] >> HIT_QBITS) & DM;
+                        lmin = d < lmin ? d : lmin;
+                        lmax = d > lmax ? d : lmax;
+                    }
+                    for (int off = LANES / 2; off > 0; off >>= 1) {
+                        const unsigned long long a = __shfl_xor(lmin, off, LANES), c = __shfl_xor(lmax, off, LANES);
+                        lmin = a < lmin ? a : lmin;
+                        lmax = c > lmax ? c : lmax;
+                    }
+                    __syncthreads();
+                    if ((tid & (LANES - 1)) == 0) {
+                        atomicMin(&s_dmin, lmin);
+                        atomicMax(&s_dmax, lmax);
+                    }
+                    __syncthreads();
+                    // (slices aligned to their width, as the buckets are: the hits of a slice then agree above their low
+                    // 24 + sh2 bits, which is what lets count_below compare low words)
+                    uint64_t e0 = s_dmin;
+                    int sh2 = 0;
+                    while (((s_dmax - e0) >> sh2) >= (uint64_t)NB2) {
+                        sh2++;
+                        e0 = s_dmin & ~((1ull << sh2) - 1);
+                    }
+                    auto slice = [&](uint64_t key) { return (uint32_t)((((key >> HIT_QBITS) & DM) - e0) >> sh2); };
+                    for (uint32_t i = hb0 + tid; i < hb1; i += NT) atomicAdd(&fcnt[slice(hits[i])], 1u);
+                    __syncthreads();
+                    uint32_t f2[NB2 / NT > 0 ? NB2 / NT : 1], fsum = 0;
+#pragma unroll
+                    for (int u = 0; u < NB2 / NT; u++) {
+                        f2[u] = fcnt[tid * (NB2 / NT) + u];
+                        fsum += f2[u];
+                    }
+                    uint32_t fincl = fsum;
+                    for (int off = 1; off < LANES; off <<= 1) {
+                        const uint32_t up = __shfl_up(fincl, off, LANES);
+                        if ((tid & (LANES - 1)) >= off) fincl += up;
+                    }
+                    if ((tid & (LANES - 1)) == LANES - 1) s_bw[tid / LANES] = fincl;
+                    __syncthreads();
+                    uint32_t fbase = hb0 + fincl - fsum;
+                    for (int wv = 0; wv < tid / LANES; wv++) fbase += s_bw[wv];
+#pragma unroll
+                    for (int u = 0; u < NB2 / NT; u++) {
+                        fcnt[tid * (NB2 / NT) + u] = fbase;
+                        fbase += f2[u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < E; u++) {
+                        const uint32_t i = hb0 + (uint32_t)tid + (uint32_t)u * NT;
+                        ke[u] = i < hb1 ? hits[i] : 0ull;
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int u = 0; u < E; u++) {
+                        const uint32_t i = hb0 + (uint32_t)tid + (uint32_t)u * NT;
+                        if (i < hb1) hits[atomicAdd(&fcnt[slice(ke[u])], 1u)] = ke[u];
+                    }
+                    __syncthreads();  // fcnt[f] = end of slice f (absolute positions)
+#pragma unroll
+                    for (int u = 0; u < E; u++) {
+                        const uint32_t i = hb0 + (uint32_t)tid + (uint32_t)u * NT;
+                        dst[u] = 0;
+                        if (i < hb1) {
+                            const uint64_t key = hits[i];
+                            ke[u] = key;
+                            const uint32_t f = slice(key);
+                            const uint32_t f0 = f ? fcnt[f - 1] : hb0, f1 = fcnt[f];
+                            dst[u] = f0 + count_below(f0, f1, key, sh2 <= 32 - HIT_QBITS);
+                        }
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int u = 0; u < E; u++)
+                        if (hb0 + (uint32_t)tid + (uint32_t)u * NT < hb1) hits[dst[u]] = ke[u];
+                    __syncthreads();
+                }
+            }
 #pragma unroll
             for (int u = 0; u < E; u++) {
                 const int32_t i = tid + u * NT;
@@ -961,33 +1107,13 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
                     ke[u] = key;
                     const uint32_t bk = bucket(key);
                     const uint32_t b0 = bk ? bcnt[bk - 1] : 0u, b1 = bcnt[bk];
-                    // (keys are distinct; four loads in flight: one at a time made every compare a full LDS round trip)
-                    uint32_t rk = b0, x = b0;
-                    if (sh <= 32 - HIT_QBITS) {
-                        // the low words decide (half the LDS traffic of this loop, which is bound by it)
-                        const uint32_t *h32 = (const uint32_t *)hits;
-                        const uint32_t key32 = (uint32_t)key;
-                        for (; x + 8 <= b1; x += 8) {
-                            uint32_t h[8];
-#pragma unroll
-                            for (int j = 0; j < 8; j++) h[j] = h32[2 * (x + j)];
-#pragma unroll
-                            for (int j = 0; j < 8; j++) rk += h[j] < key32 ? 1u : 0u;
-                        }
-                    }
-                    for (; x + 8 <= b1; x += 8) {
-                        uint64_t h[8];
-#pragma unroll
-                        for (int j = 0; j < 8; j++) h[j] = hits[x + j];
-#pragma unroll
-                        for (int j = 0; j < 8; j++) rk += h[j] < key ? 1u : 0u;
-                    }
-                    for (; x + 4 <= b1; x += 4) {
-                        const uint64_t h0 = hits[x], h1 = hits[x + 1], h2 = hits[x + 2], h3 = hits[x + 3];
-                        rk += (h0 < key ? 1u : 0u) + (h1 < key ? 1u : 0u) + (h2 < key ? 1u : 0u) + (h3 < key ? 1u : 0u);
-                    }
-                    for (; x < b1; x++) rk += hits[x] < key ? 1u : 0u;
-                    dst[u] = rk;
+                    bool heavy = false;
+                    if (REFINE)
+                        for (uint32_t hv = 0; hv < nheavy; hv++) heavy = heavy || s_heavy[hv] == bk;
+                    if (heavy)  // sorted by the second pass
+                        dst[u] = (uint32_t)i;
+                    else
+                        dst[u] = b0 + count_below(b0, b1, key, sh <= 32 - HIT_QBITS);
                 }
             }
             __syncthreads();
@@ -3067,11 +3193,24 @@ void dhk_scan_total(hipStream_t st, uint32_t *v, int64_t n, uint32_t *sums, unsi
 
 // queue: one zeroed uint32 (work counter of the persistent blocks)
 // item0 / nitems: even (both strands of the reads [item0 / 2, (item0 + nitems) / 2))
+// development / tests: DH_SEED_NO_REFINE=1 switches the second counting pass of the seed sort off (read per launch)
+static void seed_sort_switch()
+{
+    static int cur = 1;
+    const int want = getenv("DH_SEED_NO_REFINE") ? 0 : 1;
+    if (want != cur) {
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_seed_sort_refine), &want, sizeof(int));
+        cur = want;
+    }
+}
+
 void dhk_seed(hipStream_t st, int cap, DbView B, IndexView ix, DhOpts o,
               int32_t item0, int32_t nitems, DhCand *cand, int32_t *ncand, int32_t *nhits,
               int32_t *status, uint32_t *queue, int32_t ncu, uint64_t *fscr)
 {
     if (nitems <= 0) return;
+    seed_sort_switch();
     const int32_t read0 = item0 / 2, nreads = nitems / 2;
     const JoinView jv = {};
 #define SEED_LAUNCH(C)                                                                            \
@@ -3119,6 +3258,7 @@ void dhk_seed_join(hipStream_t st, int cap, DbView B, IndexView ix, DhOpts o, Jo
                    uint64_t *fscr, const int32_t *read_list, int32_t nlist)
 {
     if (nitems <= 0 || (read_list && nlist <= 0)) return;
+    seed_sort_switch();
     // read_list (device, nlist absolute read ids): only those reads -- the second tier of the join path, the reads whose
     // hits overflowed the first tier's LDS buffer
     const int32_t read0 = item0 / 2, nreads = read_list ? nlist : nitems / 2;
