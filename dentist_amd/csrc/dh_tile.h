@@ -59,7 +59,12 @@ struct Unit {
     int64_t bo, ao;                // base offsets of the read and of the first candidate's A sequence
     int32_t aseq, apos, bpos, alen;  // the first candidate and the length of its A sequence
     int32_t cbase;                   // first candidate slot of the item (Params.candoff[item])
-    int32_t pad_[3];
+    int32_t nd0;                     // alignments of the item attempted before this unit (the cap of MAXREG attempts per item
+                                     // counts them: k_units_fat splits an item of more than MAXREG candidates)
+    int32_t rest;                    // 1: the unit is the REST of such an item -- its candidates in order, minus the candidates
+                                     // below index MAXREG that are alone in their group (units of their own; each counts as
+                                     // one attempted alignment when the walk passes it)
+    int32_t pad_[1];
 };
 
 struct Params {
@@ -134,6 +139,7 @@ struct Cold {
     uint32_t rv_pair1;
     int32_t nacc2, ntr2;  // transposed records of the item (mapping with the transposed file)
     int32_t cbase;        // symmetric mode: first candidate slot of the item
+    int32_t nd0, rest;    // work units: alignments of the item attempted before this unit / outside it (Unit::nd0, Unit::rest)
 };
 
 struct Lane {
@@ -498,6 +504,8 @@ DH_HD void lane_fetch(Lane &l, const Params &P, int32_t it)
         c.nd = c.nacc = c.ntr = c.nacc2 = c.ntr2 = 0;
         c.c = u.c0;
         c.cbase = u.cbase;
+        c.nd0 = u.nd0;
+        c.rest = u.rest;
         c.c_aseq = u.aseq;
         c.as = u.apos;
         c.bs = u.bpos;
@@ -518,6 +526,8 @@ DH_HD void lane_fetch(Lane &l, const Params &P, int32_t it)
     c.nd = c.nacc = c.ntr = c.nacc2 = c.ntr2 = 0;
     c.c = 0;
     c.cbase = P.candoff ? P.candoff[item] : 0;
+    c.nd0 = 0;
+    c.rest = 0;
     l.st = L_CAND;
 }
 
@@ -529,8 +539,20 @@ DH_HD void lane_next_cand(Lane &l, const Params &P)
     const bool sym = P.o.skip_self == 2;
     int32_t ci = c.c;
     const int32_t nc = c.nc, nd = c.nd, item = c.item;
-    while (ci < nc && (sym || c.nacc < P.o.max_la) && nd < MAXREG) {
+    int32_t nd0 = c.nd0;
+    while (ci < nc && (sym || c.nacc < P.o.max_la) && nd + nd0 < MAXREG) {
         const DhCand cd = P.cand[(int64_t)item * P.o.max_cand + ci];
+        if (c.rest && ci < MAXREG) {
+            // a candidate alone in its group is a unit of its own (k_units_fat): one attempted alignment, whatever comes of it
+            const DhCand *cl = P.cand + (int64_t)item * P.o.max_cand;
+            const bool alone = (ci == 0 || cl[ci - 1].aseq != cd.aseq) && (ci + 1 >= nc || cl[ci + 1].aseq != cd.aseq);
+            if (alone) {
+                nd0++;
+                c.nd0 = nd0;
+                ci++;
+                continue;
+            }
+        }
         const int32_t sdc = cd.apos - cd.bpos;
         bool covd = false;
         for (int32_t x = 0; x < nd; x++) {

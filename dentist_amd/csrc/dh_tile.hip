@@ -34,6 +34,7 @@ __device__ __forceinline__ int32_t wave_max_i32(int32_t v)
 // development: where a wavefront's time goes -- [0] bookkeeping passes (wall), [1] tile set-up, [2] column loops,
 // [3] tile ends, [4] passes, [5] rounds, [6] lanes in the rounds, [7] lane-passes (lanes wanting a pass, summed)
 __device__ unsigned long long g_tile_prof[20];
+__device__ unsigned long long g_tile_wt[8] = {~0ull, 0, 0, 0, 0, 0, 0, 0};  // wall clock (100 MHz): min start, max end, sum of lifetimes, waves, last unit fetch (max)
 __device__ unsigned long long g_tile_hist[8];  // lane-rounds by tile width: <= 8, <= 32, <= 64, < 126, >= 126; [5] first tiles, [6] partial last tiles, [7] sum of T
 #define TP(i) { const unsigned long long t_ = clock64(); pacc_[i] += t_ - tp_; tp_ = t_; }
 #define TPC(i, v) pacc_[i] += (unsigned long long)(v);
@@ -59,6 +60,13 @@ extern "C" void dhk_tile_prof_dump()
         if (tot > 0) fprintf(stderr, "[tile prof] lane-rounds by columns: <=8 %.3f <=32 %.3f <=64 %.3f <126 %.3f >=126 %.3f; first tiles %.3f, cols < T %.3f, mean T %.1f\n", hh[0] / tot, hh[1] / tot, hh[2] / tot, hh[3] / tot, hh[4] / tot, hh[5] / tot, hh[6] / tot, hh[7] / tot);
         unsigned long long zz[8] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tile_hist), zz, sizeof(zz));
+    }
+    {
+        unsigned long long wt[8];
+        (void)hipMemcpyFromSymbol(wt, HIP_SYMBOL(g_tile_wt), sizeof(wt));
+        if (wt[3]) fprintf(stderr, "[tile prof] last launch: %llu wavefronts, kernel %.2f ms, mean wavefront lifetime %.2f ms, last unit handed out at %.2f ms\n", wt[3], (wt[1] - wt[0]) / 1e5, (double)wt[2] / wt[3] / 1e5, (wt[4] - wt[0]) / 1e5);
+        unsigned long long zz[8] = {~0ull, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tile_wt), zz, sizeof(zz));
     }
     unsigned long long z[20] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tile_prof), z, sizeof(z));
@@ -134,6 +142,8 @@ __global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
 #ifdef DH_SEED_PROF
     unsigned long long pacc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tp_ = clock64(), pcm_ = 0;
+    const unsigned long long wt0_ = wall_clock64();
+    unsigned long long wtf_ = wt0_;
     unsigned lh_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     Lane l;
@@ -188,6 +198,9 @@ __global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
                         uint32_t b = 0;
                         if ((int)threadIdx.x == first) b = atomicAdd(P.queue, take);
                         nb = (uint32_t)__builtin_amdgcn_readlane((int)b, first);  // (uniform: the batch lives in scalar registers)
+#ifdef DH_SEED_PROF
+                        if (nb < (P.units ? *P.nunits : (uint32_t)P.nitems)) wtf_ = wall_clock64();
+#endif
                     }
                     if (l.st == L_FETCH) {
                         const uint32_t rank = (uint32_t)__builtin_popcountll(fm & ((1ull << threadIdx.x) - 1ull));
@@ -269,6 +282,14 @@ __global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
     if (threadIdx.x == 0)
         for (int i = 0; i < 12; i++) atomicAdd(&g_tile_prof[i], pacc_[i]);
     if (threadIdx.x == 0) atomicAdd(&g_tile_prof[18], pcm_);
+    if (threadIdx.x == 0) {
+        const unsigned long long wt1_ = wall_clock64();
+        atomicMin(&g_tile_wt[0], wt0_);
+        atomicMax(&g_tile_wt[1], wt1_);
+        atomicAdd(&g_tile_wt[2], wt1_ - wt0_);
+        atomicAdd(&g_tile_wt[3], 1ull);
+        atomicMax(&g_tile_wt[4], wtf_);
+    }
     for (int i = 0; i < 8; i++) if (lh_[i]) atomicAdd(&g_tile_hist[i], (unsigned long long)lh_[i]);
     for (int i = 0; i < 6; i++) {  // sections of lane_ext_end: the lanes of a pass run them together, so the largest lane total ~ the wavefront's
         unsigned long long v = l.pt[i];
@@ -304,8 +325,16 @@ __global__ void __launch_bounds__(256) k_pk2planes(uint64_t *__restrict__ w, int
     w[i] = (uint64_t)squeeze_even(x) | ((uint64_t)squeeze_even(x >> 1) << 32);
 }
 
-// one thread per item: its candidates (grouped by A read by the seed kernel) become units; an item with more than 64
-// candidates stays one unit (the cap of attempted alignments per item must see them in order), as in k_units
+// one thread per item: its candidates (grouped by A read by the seed kernel) become units, one per group -- only the
+// candidates of one group depend on each other (a candidate inside an aligned region of the same A read is skipped).
+// The cap of MAXREG attempted alignments per item (dh_tile.h: lane_next_cand; oracle/align.c) couples the groups of an item
+// with MORE than MAXREG candidates; such an item used to stay one unit -- up to 64 alignments one after the other in one lane,
+// ~90 ms at 166 reads per pile-up: the queue of a symmetric launch ran dry after 75 ms and the launch took 170 (round 6).  It
+// is split exactly.  A group's first candidate is never skipped, so a candidate ALONE in its group means exactly one attempted
+// alignment; if its index is below MAXREG fewer than MAXREG attempts precede it, whatever they were: it is always aligned, a
+// unit of its own.  Everything else -- groups of several candidates (their number of attempts is not known beforehand), and
+// whatever lies at index MAXREG or behind -- is ONE unit, the `rest`: it walks the item's candidates in order from its first
+// one, counts one attempt for every lone candidate below index MAXREG it passes, and applies the cap to its own.
 __global__ void __launch_bounds__(256)
 k_units_fat(const DhCand *__restrict__ cand, const int32_t *__restrict__ ncand, const int32_t *__restrict__ candoff, int32_t item0,
             int32_t nitems, int32_t max_cand, const int64_t *__restrict__ aoff, const int64_t *__restrict__ boff,
@@ -319,13 +348,7 @@ k_units_fat(const DhCand *__restrict__ cand, const int32_t *__restrict__ ncand, 
     const DhCand *cl = cand + (int64_t)item * max_cand;
     const int64_t bo = boff[item >> 1];
     const int32_t blen = (int32_t)(boff[(item >> 1) + 1] - bo);
-    int32_t c0 = 0;
-    while (c0 < nc) {
-        int32_t c1 = c0 + 1;
-        if (nc > 64)
-            c1 = nc;
-        else
-            while (c1 < nc && cl[c1].aseq == cl[c0].aseq) c1++;
+    auto emit = [&](int32_t c0, int32_t c1, int32_t nd0, int32_t rest) {
         Unit u;
         u.it = it;
         u.c0 = c0;
@@ -338,10 +361,31 @@ k_units_fat(const DhCand *__restrict__ cand, const int32_t *__restrict__ ncand, 
         u.ao = aoff[u.aseq];
         u.alen = (int32_t)(aoff[u.aseq + 1] - u.ao);
         u.cbase = candoff[item];
-        u.pad_[0] = u.pad_[1] = u.pad_[2] = 0;
+        u.nd0 = nd0;
+        u.rest = rest;
+        u.pad_[0] = 0;
         units[atomicAdd(nunits, 1u)] = u;
-        c0 = c1;
+    };
+    if (nc <= MAXREG) {  // the cap cannot bind: every group on its own
+        int32_t c0 = 0;
+        while (c0 < nc) {
+            int32_t c1 = c0 + 1;
+            while (c1 < nc && cl[c1].aseq == cl[c0].aseq) c1++;
+            emit(c0, c1, 0, 0);
+            c0 = c1;
+        }
+        return;
     }
+    int32_t first_rest = -1;
+    for (int32_t c = 0; c < nc; c++) {
+        const bool alone = (c == 0 || cl[c - 1].aseq != cl[c].aseq) && (c + 1 >= nc || cl[c + 1].aseq != cl[c].aseq);
+        if (alone && c < MAXREG)
+            emit(c, c + 1, 0, 0);
+        else if (first_rest < 0)
+            first_rest = c;
+    }
+    // (every candidate before first_rest is a lone one below MAXREG: first_rest attempts precede it)
+    if (first_rest >= 0 && first_rest < MAXREG) emit(first_rest, nc, first_rest, 1);
 }
 
 // ---- symmetric launches: the records sit in candidate-indexed slots (dh_tile.h, Params.candoff); three streaming
@@ -506,6 +550,12 @@ void dhk_compact_sym(hipStream_t st, const DhLa *slots, const uint16_t *tr_slots
 void dhk_tile(hipStream_t st, int32_t nwaves, const Params *P)
 {
     if (P->nitems <= 0 || nwaves <= 0) return;
+#ifdef DH_SEED_PROF
+    {
+        unsigned long long zz[8] = {~0ull, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_tile_wt), zz, sizeof(zz), 0, hipMemcpyHostToDevice, st);
+    }
+#endif
     // (band = dh_align_opts.width: 64 rows on 64-bit vectors, or 32 rows on 32-bit vectors)
     if (P->o.width == 32) {
         if (P->tandem)
