@@ -610,6 +610,256 @@ k_mj_filter(IndexView ix, DhOpts o, MjView m)
     }
 }
 
+// ------------------------------------------------------------------------------------ filter, flat lane mapping (round 6)
+// The filter above deals 16 lanes to every segment (tile, partition) -- 7-8 entries on average: half of the lanes idle in
+// every load, bit test, ballot and store, ~400 wave-instructions per 128 entries, the kernel VALU-bound at 62 ms per launch
+// unsampled (58 % VALU-busy SIMDs at 63 % lane use).  Here a wavefront takes 64 TILES of its partition at a time -- one
+// descriptor per lane, one coalesced load -- and maps the ~512 entries of their 64 segments FLAT onto its lanes: an
+// exclusive prefix sum of the counts (six DPP steps), a mark per segment start in a byte array of LDS, and for every round
+// of 64 consecutive entries the segment of a lane's entry is the running maximum of the marks (six more DPP steps and the
+// carry of the round before).  Every lane of a round tests an entry; ~55 wave-instructions per 64 entries.  The loads of
+// the first MJ_F2_R rounds are issued together before the first entry is tested.  Survivors, ranges, pages and the resolve
+// sweep are those of k_mj_filter: sseg[group][partition] still describes one range per group of 16 tiles.
+#define MJ_F2_R 10          /* rounds whose loads are in flight together (640 entries; 512 expected) */
+#define MJ_F2_MARKS 1024    /* flat indices one pass over the marks covers */
+#define MJ_F2_TMAX 2047     /* entries of one partition in 64 tiles (11 bits of prefix); more = a degenerate chunk */
+namespace {
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ uint32_t mj_dpp0(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xF, false);
+}
+// inclusive scans over the 64 lanes: row_shr 1, 2, 4, 8 inside the rows of 16, then row_bcast:15 / row_bcast:31
+__device__ __forceinline__ uint32_t mj_scan_add(uint32_t v)
+{
+    v += mj_dpp0<0x111, 0xF>(v);
+    v += mj_dpp0<0x112, 0xF>(v);
+    v += mj_dpp0<0x114, 0xF>(v);
+    v += mj_dpp0<0x118, 0xF>(v);
+    v += mj_dpp0<0x142, 0xA>(v);
+    v += mj_dpp0<0x143, 0xC>(v);
+    return v;
+}
+__device__ __forceinline__ uint32_t mj_scan_max(uint32_t v)  // (values >= 0; 0 = nothing)
+{
+    v = max(v, mj_dpp0<0x111, 0xF>(v));
+    v = max(v, mj_dpp0<0x112, 0xF>(v));
+    v = max(v, mj_dpp0<0x114, 0xF>(v));
+    v = max(v, mj_dpp0<0x118, 0xF>(v));
+    v = max(v, mj_dpp0<0x142, 0xA>(v));
+    v = max(v, mj_dpp0<0x143, 0xC>(v));
+    return v;
+}
+}  // namespace
+
+__global__ void __launch_bounds__(MJ_PROBE_THREADS)
+k_mj_filter2(IndexView ix, DhOpts o, MjView m)
+{
+    __shared__ uint32_t bm[1 << (MJ_MAXBITS - MJ_PBITS - 5)];
+    __shared__ __attribute__((aligned(16))) uint8_t s_marks[MJ_PROBE_THREADS / LANES][MJ_F2_MARKS];
+    __shared__ int32_t s_item;
+    const int tid = threadIdx.x, lane = tid & (LANES - 1), wave = tid / LANES;
+    constexpr int NW = MJ_PROBE_THREADS / LANES;
+    constexpr int SG = LANES;                      // tiles a wavefront takes at a time
+    constexpr uint32_t SAFE = MJ_PAGE / 4;         // survivors the tiles at hand may add to the wavefront's page
+    constexpr int R = MJ_F2_R;
+    const int k = m.k, remsh = 2 * k - MJ_PBITS, sbits = m.nbbits - MJ_PBITS, bshift = remsh - sbits;
+    const uint64_t remmask = (1ull << remsh) - 1;
+    const int32_t slice_words = 1 << (sbits - 5);
+    const int32_t ng = m.ntiles_pad / MJ_GROUP;
+    const int32_t nitems_q = (MJ_P / 8) * MJ_SLICES;
+    const uint32_t xcc = mj_xcc_id();
+    uint8_t *marks = s_marks[wave];
+    uint64_t page_base = 0;
+    uint32_t fill = MJ_PAGE + 1;  // the wavefront has no page (yet, or the pool ran out)
+    uint64_t sweep_from = 0;      // survivors of this wavefront from here on are not resolved yet
+    bool pool_out = false;
+    int32_t curp = -1;
+    // RESOLVE: as in k_mj_filter
+    auto resolve = [&](uint64_t from, uint64_t to, int32_t p) {
+        constexpr uint64_t ORI = 1ull << 63;
+        constexpr int RU = 4;
+        const uint64_t keytop = (uint64_t)p << remsh;
+        for (uint64_t i0 = from; i0 < to; i0 += RU * LANES) {
+            uint64_t sv[RU];
+            ulonglong2 f[RU];
+#pragma unroll
+            for (int u = 0; u < RU; u++) {
+                const uint64_t i = i0 + (uint64_t)u * LANES + lane;
+                sv[u] = i < to ? m.hits[i] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < RU; u++) {  // the directory words of all of them, together
+                f[u].x = DH_FAT_EMPTY;
+                f[u].y = 0;
+                if (sv[u]) f[u] = ix.fat[(uint32_t)((keytop | ((sv[u] >> MJ_REMSH) & remmask)) >> ix.shift)];
+            }
+#pragma unroll
+            for (int u = 0; u < RU; u++) {
+                const uint64_t i = i0 + (uint64_t)u * LANES + lane;
+                if (i >= to) continue;
+                const uint64_t key = keytop | ((sv[u] >> MJ_REMSH) & remmask);
+                const uint64_t bori = (sv[u] & MJ_ORI_BIT) ? ORI : 0ull;
+                const bool pal = (sv[u] & MJ_PAL_BIT) != 0;
+                const uint64_t posg1 = ((sv[u] >> MJ_PSH) & (uint64_t)(MJ_GROUP - 1)) * (uint64_t)m.tb + (sv[u] & ((1ull << MJ_POSBITS) - 1)) + 1;
+                uint64_t out = 0;
+                if (f[u].x != DH_FAT_EMPTY) {
+                    if ((f[u].x >> 62) != 1ull) {  // the bucket's only entry
+                        if ((f[u].x & ~ORI) == key && o.tcap >= 1) {
+                            const bool same = (f[u].x & ORI) == bori;
+                            const bool h0 = (same || pal) && (o.strands & 1), h1 = (!same || pal) && (o.strands & 2);
+                            if (h0 && h1)
+                                out = sv[u] | (1ull << 62);
+                            else if (h0 || h1)
+                                out = ((uint64_t)(h1 ? 1 : 0) << 63) | ((f[u].y & ((1ull << 39) - 1)) << 23) | posg1;
+                        }
+                    } else {  // several entries: counted with the full rules; one hit is taken from the walk
+                        uint32_t c = 0;
+                        uint64_t hh = 0;
+                        mj_lookup(ix, o, key, bori != 0, pal, [&](uint64_t v, int strand) {
+                            hh = ((uint64_t)strand << 63) | ((v & ((1ull << 39) - 1)) << 23) | posg1;
+                            c++;
+                        });
+                        out = c == 0 ? 0ull : (c == 1 ? hh : (sv[u] | (1ull << 62)));
+                    }
+                }
+                m.hits[i] = out;
+            }
+        }
+    };
+    for (int qq = 0; qq < 8; qq++) {
+        const uint32_t x = (xcc + qq) & 7u;  // own XCD's queue first, then whatever is left of the others'
+        for (;;) {
+            __syncthreads();
+            if (tid == 0) s_item = (int32_t)atomicAdd(&m.ctr[x], 1u);
+            __syncthreads();
+            const int32_t item = s_item;
+            if (item >= nitems_q) break;
+            const int32_t p = (int32_t)x + 8 * (item / MJ_SLICES), sl = item % MJ_SLICES;
+            if (p != curp) {
+                const uint4 *src = (const uint4 *)(m.bitmap + (int64_t)p * slice_words);
+                for (int i = tid; i < slice_words / 4; i += MJ_PROBE_THREADS) ((uint4 *)bm)[i] = src[i];
+                if (slice_words < 4 && tid < slice_words) bm[tid] = m.bitmap[(int64_t)p * slice_words + tid];
+                curp = p;
+                __syncthreads();
+            }
+            const int32_t g0 = (int32_t)((int64_t)ng * sl / MJ_SLICES), g1 = (int32_t)((int64_t)ng * (sl + 1) / MJ_SLICES);
+            const int32_t t_end = g1 * MJ_GROUP;  // tiles [g0 * MJ_GROUP, t_end) of partition p
+            const uint32_t *segp = m.seg + (int64_t)p * m.ntiles_pad;
+            auto load_desc = [&](int32_t tb0) { return tb0 + lane < t_end ? segp[tb0 + lane] : 0u; };
+            int32_t tb0 = g0 * MJ_GROUP + wave * SG;
+            uint32_t sd_next = load_desc(tb0);
+            for (; tb0 < t_end; tb0 += NW * SG) {
+                const uint32_t sd = sd_next;
+                sd_next = load_desc(tb0 + NW * SG);
+                const uint32_t cn = tb0 + lane < m.ntiles ? (sd & 0xFFFFu) : 0u, st0 = sd >> 16;
+                const uint32_t incl = mj_scan_add(cn);
+                const uint32_t excl = incl - cn;
+                uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, LANES - 1);
+                if (T > (uint32_t)MJ_F2_TMAX) {  // (a degenerate chunk: one k-mer all over; the directory path takes it)
+                    if (lane == 0) atomicOr(m.status, DH_ST_MJ_OVERFLOW);
+                    T = 0;
+                }
+                const uint32_t pk = excl | (st0 << 11);
+                // ---- room for the survivors of these tiles: they form one range per group of 16
+                if (fill + SAFE > MJ_PAGE && !pool_out) {
+                    if (fill <= MJ_PAGE && page_base + fill > sweep_from) resolve(sweep_from, page_base + fill, p);
+                    uint32_t pg = 0;
+                    if (lane == 0) pg = atomicAdd(&m.ctr[8], 1u);
+                    pg = __shfl(pg, 0, LANES);
+                    if (pg >= (uint32_t)m.npages) {
+                        // (the survivors that find no page are counted: the host sizes the pool by them and runs the chunk again)
+                        if (lane == 0) atomicOr(m.status, DH_ST_MJ_POOL);
+                        fill = MJ_PAGE + 1;
+                        pool_out = true;
+                    } else {
+                        page_base = (uint64_t)pg * MJ_PAGE;
+                        fill = 0;
+                    }
+                    sweep_from = page_base + fill;
+                }
+                const bool have_page = fill + SAFE <= MJ_PAGE;
+                const uint64_t first = page_base + fill;
+                const uint64_t *ebase = m.ent + (int64_t)tb0 * MJ_CAP;
+                uint32_t gtot = 0, gq0 = 0, gq1 = 0, gq2 = 0;  // survivors so far; of the first three groups of 16 tiles
+                uint32_t carry = 0;
+                // one round: the entries wb + 64 r + lane.  issue(): segment of the lane's entry and its load
+                auto issue = [&](uint32_t wb, uint32_t r, uint32_t *s_out) {
+                    const uint32_t i = wb + r * LANES + lane;
+                    const uint32_t mk = i < T ? (uint32_t)marks[r * LANES + lane] : 0u;
+                    uint32_t s1 = max(mj_scan_max(mk), carry);
+                    carry = (uint32_t)__builtin_amdgcn_readlane((int)s1, LANES - 1);
+                    const uint32_t s = s1 ? s1 - 1u : 0u;
+                    const uint32_t pks = (uint32_t)__shfl((int)pk, (int)s, LANES);
+                    *s_out = s;
+                    const uint32_t off = s * (uint32_t)MJ_CAP + (pks >> 11) + (i - (pks & 0x7FFu));
+                    return i < T ? mj_load8(ebase + off) : 0ull;  // (entries are never 0)
+                };
+                auto process = [&](uint64_t ev, uint32_t s) {
+                    const uint64_t rem = (ev >> MJ_REMSH) & remmask;
+                    const uint32_t b1 = (uint32_t)(rem >> bshift);
+                    bool pass = ev != 0ull && ((bm[b1 >> 5] >> (b1 & 31)) & 1u);
+                    if (pass) {
+                        const uint32_t b2 = mj_bit2(rem, sbits);
+                        pass = (bm[b2 >> 5] >> (b2 & 31)) & 1u;
+                    }
+                    const unsigned long long bal = __ballot(pass);
+                    if (bal == 0ull) return;
+                    const uint32_t at = gtot + mj_lanes_below(bal);
+                    if (pass && have_page && at < SAFE)
+                        m.hits[first + at] = (ev & ~(0x3FFull << MJ_PSH)) | ((uint64_t)(s & (MJ_GROUP - 1)) << MJ_PSH);
+                    gtot += (uint32_t)__popcll(bal);
+                    gq0 += (uint32_t)__popcll(__ballot(pass && s < 16u));
+                    gq1 += (uint32_t)__popcll(__ballot(pass && s < 32u));
+                    gq2 += (uint32_t)__popcll(__ballot(pass && s < 48u));
+                };
+                for (uint32_t wb = 0; wb < T; wb += MJ_F2_MARKS) {
+                    // marks of this window: segment + 1 at the flat index its first entry has
+                    ((uint4 *)marks)[lane] = make_uint4(0u, 0u, 0u, 0u);
+                    if (cn && excl >= wb && excl < wb + (uint32_t)MJ_F2_MARKS) marks[excl - wb] = (uint8_t)(lane + 1);
+                    if (wb) {  // the segment that holds entry wb - 1: the last one that begins before the window
+                        const uint32_t before = mj_scan_max(cn && excl < wb ? (uint32_t)lane + 1u : 0u);
+                        carry = (uint32_t)__builtin_amdgcn_readlane((int)before, LANES - 1);
+                    }
+                    const uint32_t nr = (min(T - wb, (uint32_t)MJ_F2_MARKS) + LANES - 1) / LANES;
+                    uint64_t e[R];
+                    uint32_t sg[R];
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        e[r] = 0ull;
+                        sg[r] = 0;
+                        if ((uint32_t)r < nr) e[r] = issue(wb, (uint32_t)r, &sg[r]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; r++)
+                        if ((uint32_t)r < nr) process(e[r], sg[r]);
+                    for (uint32_t r = R; r < nr; r++) {  // (rare: more than 640 entries in the window)
+                        uint32_t s;
+                        const uint64_t ev = issue(wb, r, &s);
+                        process(ev, s);
+                    }
+                }
+                if (gtot > SAFE) {  // more survivors than the tiles at hand may hold: degenerate tiles (one k-mer all over)
+                    if (lane == 0) atomicOr(m.status, DH_ST_MJ_OVERFLOW);
+                    gtot = gq0 = gq1 = gq2 = 0;
+                }
+                if (lane < SG / MJ_GROUP) {
+                    const int32_t g = tb0 / MJ_GROUP + lane;
+                    const uint32_t lo = lane == 0 ? 0u : (lane == 1 ? gq0 : (lane == 2 ? gq1 : gq2));
+                    const uint32_t hi = lane == 0 ? gq0 : (lane == 1 ? gq1 : (lane == 2 ? gq2 : gtot));
+                    if (g < g1) m.hseg[(int64_t)g * MJ_P + p] = ((unsigned long long)(first + lo) << 24) | (have_page ? hi - lo : 0u);
+                }
+                if (!have_page && gtot && lane == 0) atomicAdd((unsigned long long *)(m.ctr + 12), (unsigned long long)gtot);
+                if (have_page) fill += gtot;
+            }
+            if (fill <= MJ_PAGE && page_base + fill > sweep_from) {
+                resolve(sweep_from, page_base + fill, p);
+                sweep_from = page_base + fill;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ hits, by read
 // A block per tile group: the survivors of the group's 1024 (partition) lists are looked up in the fat directory with
 // exactly the rules of seed_item's flush() (dh_kernels.hip: the bucket's only entry from the directory word, or the walk
@@ -804,7 +1054,10 @@ void dhk_mj_run(hipStream_t st, DbView B, IndexView ix, DhOpts o, MjView m, int3
 #undef MJ_PART
     }
     hipLaunchKernelGGL(k_mj_transpose, dim3((unsigned)(m.ntiles_pad / 32)), dim3(256), 0, st, m);
-    hipLaunchKernelGGL(k_mj_filter, dim3((unsigned)ncu), dim3(MJ_PROBE_THREADS), 0, st, ix, o, m);
+    if (m.dbg & 2)  // development / tests (DH_MJ_DBG=2): the filter of round 5, 16 lanes per segment
+        hipLaunchKernelGGL(k_mj_filter, dim3((unsigned)ncu), dim3(MJ_PROBE_THREADS), 0, st, ix, o, m);
+    else
+        hipLaunchKernelGGL(k_mj_filter2, dim3((unsigned)ncu), dim3(MJ_PROBE_THREADS), 0, st, ix, o, m);
     hipLaunchKernelGGL(k_mj_hits, dim3((unsigned)m.ngroups), dim3(MJ_THREADS), 0, st, B, ix, o, m);
 #ifdef DH_MJ_PROF
     if (getenv("DH_TRACE")) {

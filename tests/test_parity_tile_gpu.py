@@ -104,6 +104,23 @@ def test_symmetric_all_vs_all(gpu_ctx, seed, grouped):
     assert all((b, a, c) in key for a, b, c in key)
 
 
+def test_symmetric_items_with_more_candidates_than_the_attempt_cap(gpu_ctx):
+    """An item (read, strand) attempts at most 64 alignments (oracle/align.c: `nd < 64`; dh_tile.h: MAXREG).  In a pile-up of
+    166 reads -- the reference's behaviour, no read cap: processPileUps/package.d:283-374 -- an item meets more partners than
+    that, and k_units_fat splits it into work units without changing which candidates are aligned: lone candidates below
+    index 64 on their own, the rest of the item in order with the lone ones counted.  180 reads of one locus, all on one
+    strand: ~90 candidates per forward item, some pairs with two candidate band pairs (the `rest` unit)."""
+    g = sim.genome(91, 2600)
+    reads, truth = sim.reads(92, g, 180, 2000, min_len=1500)
+    seqs = [reads.seq(i) if truth[i, 2] == 0 else sim.revcomp(reads.seq(i)) for i in range(reads.n)]
+    reads = sim.SeqDb.from_list(seqs)
+    las, trace = run_both(gpu_ctx, reads, reads, same=True, tspace=126, skip_self=2, min_len=500, max_la=256, max_cand=256, **T)
+    st = gpu_ctx.align_stats()
+    assert st.cands > 64 * reads.n // 2 and st.alignments < st.cands   # items above the cap exist, and the cap dropped candidates
+    per_item = np.bincount(las["bread"][(las["flags"] & 1) == 0], minlength=reads.n)
+    assert per_item.max() <= 2 * 64 + 64
+
+
 def test_tandem_self_alignments(gpu_ctx):
     """skip_self = 3 (`datander <block>`, DAMASKER; DENTIST's call commandline.d:2866-2876, Snakefile:1056-1076): every read
     against itself, below the main diagonal -- seeds with A position > B position in the same read (k_seed), cells in which
