@@ -206,7 +206,7 @@ def main():
         # and lists the spanning-read candidates of the chunk; records stay in mapping order (by read)
         # (the spanning-read candidates only when that collector is asked for: the scaffold graph does not use them)
         # (--device-trace: the trace values stay in HBM and `process` fetches the ones the cropper reads -- measured slower by
-        # 5 ms per step than copying all of them chunk by chunk beside the next chunk's kernels: DESIGN 10)
+        # 5 ms per step than copying all of them chunk by chunk beside the next chunk's kernels: LABNOTES 10)
         mapped = ctx.map_reads(A, B, mopts, popts, sorted=False, candidates=args.collect != "graph",
                                trace_on_device=(world == 1 and args.device_trace))
         las, trace, dropped = mapped[:3]
@@ -364,7 +364,7 @@ def main():
             "read_bp_aligned_per_sec": aligned_all * args.steps / dt,
             "read_bp_aligned_per_sec_mapping_stage": aligned_all / mean(lambda r: r["t_map"]),
             # dominant kernel of the step: the seed filter (k_seed) of the mapping launches.  It is bound by random
-            # 64-byte lines: per read base 1 B of sequence, per sampled canonical k-mer one 64 B
+            # 64-byte lines (LABNOTES 5): per read base 1 B of sequence, per sampled canonical k-mer one 64 B
             # directory line, one pass for both strands; the ceiling of random 64 B lines measured on this part is
             # 55 G lines/s = 3.5 TB/s at working sets of 128 MB - 2 GB, 3.2 at 4 GB, 3.06 at 16 GB (scripts/rand_access_probe.cpp)
             "roofline": {"bound": "hbm",
@@ -511,7 +511,9 @@ def cpu_baseline(w, last, mopts, popts, args, gap_bases, read_bp_total):
     gaps_sorted = [int(r["contig_left"]) for r in rec]
     # the untimed stand-in for the mapping output may sample its k-mers (it only has to place the reads around the sampled gaps)
     o_standin = oz.default_opts(width=mopts.width, kmer_mod=max(8, mopts.kmer_mod), k=mopts.k, xdrop=mopts.xdrop, algo=mopts.algo)
-    budget, batch = 0.5 * args.cpu_seconds, max(cores, 8)   # a pile-up per OpenMP thread and batch
+    # a pile-up per OpenMP thread and batch; uncapped pile-ups (166 reads: ~100 core-seconds each) go 8 threads to a pile-up
+    # (oracle/pile.c nests the all-vs-all's OpenMP loop), so that one batch stays within the budget
+    budget, batch = 0.5 * args.cpu_seconds, max(cores, 8) if popts.max_reads else max(cores // 8, 4)
     done, t_proc, used = 0, 0.0, 0
     while done < len(gaps_sorted) and t_proc < budget:
         gs = gaps_sorted[done:done + batch]

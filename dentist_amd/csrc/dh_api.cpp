@@ -820,7 +820,7 @@ static int build_index(dh_db *A, int32_t k, int32_t sepv, int32_t kmer_mod, bool
     const DbView av = A->view();
     // grouped DB (pile-ups): a group's keys share their top bits, i.e. its buckets are one contiguous range; when the
     // sequences come group by group and a group is cut into few slices, the passes count in LDS (k_group_index)
-    // instead of 2 x nk device-scope atomics on random counters (configs[2]: see DESIGN 8)
+    // instead of 2 x nk device-scope atomics on random counters (configs[2]: see LABNOTES 8)
     int32_t *d_gtile = nullptr;
     int32_t gi_slices = 0, gi_slice = 0;
     struct GtGuard {

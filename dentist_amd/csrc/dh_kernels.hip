@@ -597,18 +597,40 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
             s_n = (int32_t)tot;
         }
         __syncthreads();
-        if ((int32_t)tot <= CAP)
-            for (int32_t e = tid; e < (int32_t)tot; e += NT) {
-                int32_t lo = 0, hi = ns - 1;  // the segment of hit e: the first s with sego[s] > e
-                while (lo < hi) {
-                    const int32_t mid = (lo + hi) >> 1;
-                    if (sego[mid] > (uint32_t)e)
-                        hi = mid;
-                    else
-                        lo = mid + 1;
+        if ((int32_t)tot <= CAP) {
+            // the segment of hit e: the last s with sego[s - 1] <= e (sego[-1] = 0; empty segments repeat a value and lose to
+            // the one behind them).  Four hits per thread at a time, their searches a fixed number of steps without a branch:
+            // the LDS round trips of the four overlap and so do the four loads from the hit buffer (one hit per iteration
+            // made the gather a chain of dependent round trips: 106 of the 170 us a block spent on a pile-up read of 166)
+            constexpr int GU = 4;
+            int32_t top = 1;
+            while (top < ns) top <<= 1;
+            for (int32_t e0 = tid; e0 < (int32_t)tot; e0 += NT * GU) {
+                int32_t lo[GU];
+#pragma unroll
+                for (int u = 0; u < GU; u++) lo[u] = 0;
+                for (int32_t step = top >> 1; step > 0; step >>= 1) {
+#pragma unroll
+                    for (int u = 0; u < GU; u++) {
+                        const int32_t idx = lo[u] + step;
+                        const uint32_t e = (uint32_t)(e0 + u * NT);
+                        if (idx < ns && sego[idx - 1] <= e) lo[u] = idx;
+                    }
                 }
-                hits[e] = jv.hits[segb[lo] + ((uint32_t)e - sego[lo - 1])];
+                uint64_t v[GU];
+#pragma unroll
+                for (int u = 0; u < GU; u++) {
+                    const int32_t e = e0 + u * NT;
+                    v[u] = 0;
+                    if (e < (int32_t)tot) v[u] = jv.hits[segb[lo[u]] + ((uint32_t)e - sego[lo[u] - 1])];
+                }
+#pragma unroll
+                for (int u = 0; u < GU; u++) {
+                    const int32_t e = e0 + u * NT;
+                    if (e < (int32_t)tot) hits[e] = v[u];
+                }
             }
+        }
     } else if (npos > 0 && tid < SEED_LOOKUP_THREADS) {
         constexpr int QN = 4;
         const int32_t per = (npos + SEED_LOOKUP_THREADS - 1) / SEED_LOOKUP_THREADS;

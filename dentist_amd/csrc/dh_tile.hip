@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(64, TILE_WAVES_PER_SIMD) k_tile(Params P)
             TQ(9)
             {
                 // The queue is ONE address: a returning atomic on it costs ~11 ns chip-wide whatever else happens (92 M/s
-                // measured), and a symmetric launch of uncapped pile-ups hands out 12.6 M units -- one atomic per
+                // measured, LABNOTES 10), and a symmetric launch of uncapped pile-ups hands out 12.6 M units -- one atomic per
                 // pass and wavefront (the lanes of a pass that want a unit share it) was ~10 M of them, a tenth of a second
                 // of the atomic unit's time with every wavefront's other loads queued behind its own.  A wavefront therefore
                 // takes P.qbatch units per atomic and deals them to its lanes from [wq_base, wq_base + wq_rem) (uniform

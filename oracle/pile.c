@@ -21,6 +21,8 @@
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
+
+static int g_inner_threads = 1; /* threads of a pile-up's all-vs-all (oz_process_piles sets it) */
 #endif
 
 void oz_default_process_opts(oz_process_opts *o)
@@ -605,7 +607,7 @@ static void process_one(const oz_db *contigs, const oz_db *reads, const oz_la *l
         oz_la_set ps;
         oz_la_set_init(&ps);
         int64_t st[4];
-        oz_align_db(&pdb, &pdb, &po, 1, &ps, st);
+        oz_align_db(&pdb, &pdb, &po, g_inner_threads, &ps, st);  /* (threads inside a pile-up when there are fewer pile-ups than threads) */
         pdb.pflags = NULL;
         free(pfl);
         oz_la_set_sort(&ps);
@@ -748,14 +750,18 @@ done_pile:
     seq_list_free(&pile);
 }
 
-/* every pile-up through the `process` sequence; OpenMP over pile-ups.  out[npiles]; *bases_out =
- * malloc'd concatenation of the consensus sequences (cons_off / cons_len locate them). */
+/* every pile-up through the `process` sequence; OpenMP over pile-ups, and -- when there are fewer pile-ups than threads --
+ * over the reads of a pile-up's all-vs-all (nested; the result does not depend on the thread counts).  out[npiles];
+ * *bases_out = malloc'd concatenation of the consensus sequences (cons_off / cons_len locate them). */
 int oz_process_piles(const oz_db *contigs, const oz_db *reads, const oz_la *las, int64_t n, const uint16_t *trace,
                      const int32_t *gap, const int32_t *count, const int32_t *triples, int32_t npiles,
                      const oz_process_opts *o, int nthreads, oz_insertion *out, uint8_t **bases_out, int64_t *nbases)
 {
     (void)n;
     if (nthreads < 1) nthreads = 1;
+    g_inner_threads = npiles > 0 && nthreads > npiles ? nthreads / npiles : 1;
+    if (g_inner_threads > 1) omp_set_max_active_levels(2);
+    if (nthreads > npiles && npiles > 0) nthreads = npiles;
     int64_t *first = (int64_t *)calloc((size_t)npiles + 1, sizeof(int64_t));
     for (int32_t p = 0; p < npiles; p++) first[p + 1] = first[p] + count[p];
     uint8_t **cons = (uint8_t **)calloc((size_t)(npiles ? npiles : 1), sizeof(uint8_t *));

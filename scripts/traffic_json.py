@@ -6,8 +6,9 @@ usage: traffic_json.py <fetch-dir> <write-dir> <out.json> workload kmer_mod k al
 
 Written as profiles/<round>_kernel_traffic.json, which bench.py reads for `roofline.traffic` when its
 configuration matches.  The counters are taken as rocprofv3 reports them (KB); the x2 correction of the
-microarchitecture guide applies to wide coalesced streaming reads only and is NOT applied: k_seed reads
-8-byte directory entries at random, k_tile 4/8-byte words per lane.  Mapping launches = the dispatches
+microarchitecture guide applies to wide coalesced streaming reads only: it is applied to k_mj_part's
+FETCH_SIZE (the one kernel here that streams -- the read bytes) and to nothing else: the seed kernels read
+8 / 16 bytes at scattered lines, k_tile 4/8-byte words per lane.  Mapping launches = the dispatches
 before the first crop kernel (k_gather_parts) of the step.
 """
 import csv
@@ -45,7 +46,7 @@ def rows(d):
     return out
 
 
-def per_kernel(d):
+def per_kernel(d, fetch=False):
     per = {}
     for did, name, val in rows(d):
         per.setdefault(did, [name, 0.0])[1] += val
@@ -66,16 +67,21 @@ def per_kernel(d):
         stage = "mapping" if first_crop is None or i < first_crop else "process"
         r = res.setdefault((fam, stage), [0, 0.0])
         r[0] += 1
-        r[1] += kb * 1024.0
+        # FETCH_SIZE of k_mj_part: it streams the chunk's bases with 8-byte loads per lane, 512-byte wavefront requests --
+        # the counter reports 4.3 GB for a launch that reads 7.87 GB of bases (profiles/r06a_ref_pmc_hbm_traffic.txt), the
+        # half-counting of wide coalesced reads the microarchitecture guide describes: x2.  Every other kernel of the two
+        # families loads 8 / 16 bytes at scattered lines (calibrated 0.996, profiles/r04b_fetch_size_calibration.txt)
+        r[1] += kb * 1024.0 * (2.0 if fetch and "k_mj_part" in name else 1.0)
     return res
 
 
 def main(fetch_dir, write_dir, out, workload, kmer_mod, k, algo):
-    f, w = per_kernel(fetch_dir), per_kernel(write_dir)
+    f, w = per_kernel(fetch_dir, fetch=True), per_kernel(write_dir)
     j = {"workload": workload, "mapping_kmer_mod": int(kmer_mod), "mapping_k": int(k), "mapping_algo": int(algo),
          "kernel_build_id": kernel_build_id(),
-         "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, as reported (no x2 correction: no wide "
-                   "coalesced streams in these kernels)", "launches": {}}
+         "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE of k_mj_part x2 (wide coalesced "
+                   "stream of the read bytes, half-counted), everything else as reported (8 / 16-byte loads at scattered lines)",
+         "launches": {}}
     for key in sorted(set(f) | set(w)):
         n = (f.get(key) or w.get(key))[0]
         fb, wb = (f.get(key) or [0, 0.0])[1], (w.get(key) or [0, 0.0])[1]

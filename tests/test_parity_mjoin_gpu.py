@@ -75,6 +75,32 @@ def test_the_tiers_of_the_seed_back_end(monkeypatch):
         ctx.close()
 
 
+def test_the_round_6_paths_against_their_switches(monkeypatch):
+    """Round 6: the filter of the join maps the entries of 64 tiles flat onto the lanes (k_mj_filter2; DH_MJ_DBG=2 = the filter
+    of round 5, 16 lanes per segment), the seed sort gives buckets above 256 hits a second counting pass over their own
+    diagonal range (DH_SEED_NO_REFINE=1 = the bitonic network as before) and a k_tile wavefront takes 64 work units per queue
+    atomic (DH_TILE_QBATCH=1 = one atomic per pass).  Unsampled reads of 12 kb on a 2 Mb assembly: ~700 true hits per read on
+    a few hundred neighbouring diagonals next to chance hits anywhere -- one slice of the read's diagonal range holds them
+    all, the case the second pass is for; reads spanning two contigs bring two such clusters.  Bit-exact against the oracle,
+    identical under every switch."""
+    w = sim.Workload(2_000_000, 6, 500, 12000, seed=77, spacing=300_000)
+    ctx = dentist_amd.Context(0)
+    try:
+        kw = dict(k=20, kmer_mod=1, algo=1, width=64, xdrop=60)
+        (las, trace), (chunks, fallbacks) = run_both(ctx, w.contigs, w.reads, **kw)
+        assert chunks > 0 and fallbacks == 0
+        assert ctx.align_stats().hits / w.reads.n > 400
+        go = dentist_amd.default_align_opts(**kw)
+        A, B = ctx.db(w.contigs), ctx.db(w.reads)
+        for env, val in (("DH_MJ_DBG", "2"), ("DH_SEED_NO_REFINE", "1"), ("DH_TILE_QBATCH", "1"), ("DH_NO_MJOIN", "1")):
+            monkeypatch.setenv(env, val)
+            other = ctx.align_db(A, B, go)
+            monkeypatch.delenv(env)
+            assert_same_las((las, trace), other)
+    finally:
+        ctx.close()
+
+
 def test_release_scratch_between_calls():
     """dh_ctx_release_scratch hands the context's grow-only device scratch back (a long-lived host between workloads; the
     partitioned join of an unsampled mapping of configs[2] keeps 100 GB): the next call allocates again and gives the same bits."""
