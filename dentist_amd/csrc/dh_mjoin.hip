@@ -246,7 +246,14 @@ k_mj_part(DbView B, MjView m)
         if (MASK) em = em && !mask_touch(B.mask_bits, tb0 + xr0 + tt, k);                                                         \
         const unsigned long long bal = __ballot(em);                                                                              \
         const uint32_t slot = wcount + mj_lanes_below(bal);                                                                       \
-        if (CAREFUL_ ? (em & (slot < (uint32_t)WCAP)) : em) buf[wave * WCAP + slot] = (km << MJ_POSBITS) | (uint64_t)(xr0 + tt); \
+        /* SAMP == 0 (every k-mer is an entry: the reference's behaviour) parks the FINISHED entry -- canonical k-mer split into */ \
+        /* partition and remainder, orientation, palindrome, position: the canonical choice is at hand here, the second phase  */ \
+        /* then only counts; with sampling one lane in kmer_mod stores, so the k-mer is parked and finished by all lanes later  */ \
+        if (CAREFUL_ ? (em & (slot < (uint32_t)WCAP)) : em)                                                                      \
+            buf[wave * WCAP + slot] = SAMP == 0 ? ((1ull << 63) | ((canon >> remsh) << MJ_PSH) | ((canon & remmask) << MJ_REMSH) | \
+                                                   (km == rc ? MJ_PAL_BIT : 0ull) | (rc < km ? MJ_ORI_BIT : 0ull) |                 \
+                                                   (uint64_t)(xr0 + tt))                                                            \
+                                                : ((km << MJ_POSBITS) | (uint64_t)(xr0 + tt));                                      \
         wcount += (uint32_t)__popcll(bal);                                                                                        \
     }
         for (int32_t tt0 = 0; tt0 < per; tt0 += 8) {
@@ -275,7 +282,12 @@ k_mj_part(DbView B, MjView m)
         for (int i = 0; i < WCAP / LANES; i++) {
             const uint32_t idx = lane + i * LANES;
             e16[i] = 0;
-            if (idx < wcount) {
+            if (SAMP == 0) {
+                if (idx < wcount) {
+                    e16[i] = buf[wave * WCAP + idx];
+                    atomicAdd(&cnt[(e16[i] >> MJ_PSH) & (MJ_P - 1)], 1u);
+                }
+            } else if (idx < wcount) {
                 const uint64_t x = buf[wave * WCAP + idx];
                 const uint64_t kmx = x >> MJ_POSBITS;
                 const uint64_t rcx = (~(mj_revpairs(kmx) >> (64 - 2 * k))) & mask;
