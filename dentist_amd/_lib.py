@@ -735,7 +735,7 @@ class ShardPlan:
             for k, v in (kw or {}).items():
                 if not hasattr(so, k):
                     raise TypeError(f"unknown scaffold option {k}")
-                setattr(so, k, int(v) if k in ("min_spanning_reads", "merge_extensions") else float(v))
+                setattr(so, k, int(v) if k in _SCAFFOLD_INT_OPTS else float(v))
             ig = np.ascontiguousarray(input_gaps if input_gaps is not None else np.zeros((0, 2)), dtype=np.int32).reshape(-1, 2)
             L.dh_shard_graph_plan_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                                      ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ScaffoldOpts),
@@ -889,7 +889,7 @@ def shard_run_prepare(comm, contigs_db, reads_db, read_first, contig_off, las, t
         for k, v in g.items():
             if not hasattr(so, k):
                 raise TypeError(f"unknown scaffold option {k}")
-            setattr(so, k, int(v) if k in ("min_spanning_reads", "merge_extensions") else float(v))
+            setattr(so, k, int(v) if k in _SCAFFOLD_INT_OPTS else float(v))
     elif not getattr(cands, "_h", None):
         raise ValueError("shard_run: the candidates have no handle")
     vp = ctypes.c_void_p
@@ -1060,7 +1060,11 @@ def max_improper_coverage_reads(read_coverage):
 
 class ScaffoldOpts(ctypes.Structure):
     _fields_ = [("min_spanning_reads", ctypes.c_int32), ("merge_extensions", ctypes.c_int32),
-                ("best_pile_up_margin", ctypes.c_double), ("existing_gap_bonus", ctypes.c_double)]
+                ("best_pile_up_margin", ctypes.c_double), ("existing_gap_bonus", ctypes.c_double),
+                ("only_joins", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+
+
+_SCAFFOLD_INT_OPTS = ("min_spanning_reads", "merge_extensions", "only_joins")
 
 
 JOIN_DTYPE = np.dtype([("contig0", "<i4"), ("part0", "<i4"), ("contig1", "<i4"), ("part1", "<i4"), ("type", "<i4"),

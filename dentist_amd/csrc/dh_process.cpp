@@ -2849,7 +2849,8 @@ static void plan_owners(dh_shard_plan *p, int32_t world)
 }
 
 // the sharded scaffold-graph collector: all ranks' join blobs (dh_shard_read_joins, rank order = read order) -> the
-// scaffold, its gap pile-ups with the extension entries (dh_scaffold_gap_pileups), the min / max reads cut, owners
+// scaffold, its gap pile-ups with the extension entries (dh_scaffold_gap_pileups) -- or, sopts->only_joins, every pile-up of
+// the scaffold (dh_scaffold_all_pileups) --, the min / max reads cut, owners
 extern "C" int dh_shard_graph_plan_create(const uint8_t *const *blobs, const int64_t *sizes, int32_t world, int32_t ncontigs,
                                           const int32_t *input_gaps, int32_t ngaps, const dh_scaffold_opts *sopts,
                                           const dh_process_opts *opts, dh_shard_plan **out)
@@ -2871,7 +2872,10 @@ extern "C" int dh_shard_graph_plan_create(const uint8_t *const *blobs, const int
     lap("scaffold");
     dh_pileups *all = nullptr;
     int32_t skipped = 0;
-    int rc = dh_scaffold_gap_pileups(sc, p->las.data(), (int64_t)p->las.size(), &all, &skipped);
+    // (only_joins: every pile-up of the scaffold -- gap joins of any two contig ends, extension joins -- as one rank's
+    // `dentist process` receives them; the crop, the blobs and the process stage carry a pile-up's join with it)
+    int rc = sopts && sopts->only_joins ? dh_scaffold_all_pileups(sc, p->las.data(), (int64_t)p->las.size(), sopts->only_joins & 3, &all, &skipped)
+                                        : dh_scaffold_gap_pileups(sc, p->las.data(), (int64_t)p->las.size(), &all, &skipped);
     dh_scaffold_destroy(sc);
     lap("gap pile-ups");
     if (!rc) rc = dh_pileups_select(all, p->las.data(), (int64_t)p->las.size(), opts, &p->piles);

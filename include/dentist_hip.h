@@ -372,6 +372,14 @@ typedef struct dh_scaffold_opts {
     int32_t merge_extensions;    /* 0 = --no-merge-extension */
     double best_pile_up_margin;  /* --best-pile-up-margin, default 3.0 */
     double existing_gap_bonus;   /* --existing-gap-bonus, default 6.0 */
+    int32_t only_joins;          /* the SHARDED plan only (dh_shard_graph_plan_create, dh_shard_run): 0 (default) = the gap
+                                  * pile-ups between neighbouring contigs with the extension entries merged into them
+                                  * (dh_scaffold_gap_pileups; --only spanning --join-policy scaffoldGaps); otherwise every
+                                  * pile-up of the scaffold `dentist process` is handed, as dh_scaffold_all_pileups(only):
+                                  * & 1 the gap joins of any two contig ends (anti-parallel, contig-skipping), & 2 the
+                                  * extension joins -- what `process --batch` jobs take (snakemake/Snakefile:1315-1334,
+                                  * processPileUps/package.d:146-159).  Ignored by dh_scaffold_pileups*. */
+    int32_t pad_;
 } dh_scaffold_opts;
 void dh_default_scaffold_opts(dh_scaffold_opts *o);
 typedef struct dh_join {        /* one pile-up = the payload of one edge of the scaffold graph */

@@ -285,6 +285,80 @@ def test_dh_shard_run_with_alignment_chains_equals_the_single_gpu_run():
             c.close()
 
 
+def _scrambled_single(ctx, w, contigs, mo, po):
+    A, B = ctx.db(contigs), ctx.db(w.reads)
+    las, trace, _ = ctx.map_reads(A, B, mo, po, sorted=False, candidates=False)[:3]
+    piles, _ = dentist_amd.scaffold_all_pileups(las, contigs.off, w.reads.off, None, only="both", min_spanning_reads=po.min_reads)
+    return dentist_amd.process_pileups(ctx, A, B, las, trace, piles.select(las, po), po)
+
+
+@pytest.mark.parametrize("world,how", [(2, "steps"), (3, "steps"), (2, "dh_shard_run"), (3, "dh_shard_run")])
+def test_sharded_general_joins_equal_the_single_gpu_run(gpu_ctx, world, how):
+    """`process --batch` hands ANY pile-up to any job (snakemake/Snakefile:1315-1334, processPileUps/package.d:146-159): the
+    sharded path with dh_scaffold_opts.only_joins = 3 plans every pile-up of the scaffold graph -- here the scrambled
+    assembly of tests/test_parity_joins_gpu.py: an anti-parallel join (a reverse-complemented contig), joins that skip
+    contig ids (two contigs in swapped order) and the two extension pile-ups at the trimmed ends -- , every rank crops its
+    reads of them, owners process them; the result equals the single-GPU run (dh_scaffold_all_pileups + select +
+    dh_process_pileups) record for record, join for join, base for base.  Through parallel.sharded_process_steps (the
+    exchanges served from memory) and through dh_shard_run between host threads (the C ABI's own sequence)."""
+    import threading
+    from test_parity_joins_gpu import scrambled_assembly
+    w = sim.Workload(500_000, 4, 1400, 9000, seed=20260931, spacing=70000, gap_max=1200)
+    contigs, _ = scrambled_assembly(w)
+    mo = dentist_amd.default_align_opts(kmer_mod=4, k=20, width=64, xdrop=60, algo=1)
+    po = dentist_amd.default_process_opts(algo=1, rounds=2, max_reads=0)
+    rec, bases = _scrambled_single(gpu_ctx, w, contigs, mo, po)
+    assert (rec["status"] == 0).sum() == 6
+    assert (rec["join"] != 0).any() and (rec["contig_right"] < 0).sum() == 2 and (rec["contig_right"] > rec["contig_left"] + 1).any()
+    graph = lambda off: dict(read_off=off, input_gaps=None, only_joins=3, min_spanning_reads=po.min_reads)  # noqa: E731
+    if how == "steps":
+        A = gpu_ctx.db(contigs)
+        gens, keep = [], []
+        for rank in range(world):
+            lo, hi = parallel.shard_range(w.reads.n, rank, world)
+            share = sim.SeqDb(w.reads.bases[w.reads.off[lo]:w.reads.off[hi]], w.reads.off[lo:hi + 1] - w.reads.off[lo])
+            Br = gpu_ctx.db(share)
+            lr, tr, _ = gpu_ctx.map_reads(A, Br, mo, po, sorted=False, candidates=False)[:3]
+            lr = lr.copy()
+            lr["bread"] += lo
+            keep.append((Br, lr, tr))
+            gens.append(parallel.sharded_process_steps(gpu_ctx, A, Br, lo, contigs.off, lr, tr, po, rank, world, graph=graph(share.off)))
+        results = parallel.emulate_ranks(gens)
+    else:
+        ctxs = [dentist_amd.Context(0) for _ in range(world)]
+        comms = dentist_amd.Comm.local(world, ctxs)
+        results, errors = [None] * world, []
+
+        def run(rank):
+            try:
+                ctx = ctxs[rank]
+                lo, hi = parallel.shard_range(w.reads.n, rank, world)
+                share = sim.SeqDb(w.reads.bases[w.reads.off[lo]:w.reads.off[hi]], w.reads.off[lo:hi + 1] - w.reads.off[lo])
+                A, B = ctx.db(contigs), ctx.db(share)
+                m = ctx.map_reads(A, B, mo, po, sorted=False, candidates=False)
+                las, trace = m[0].copy(), m[1]
+                las["bread"] += lo
+                results[rank] = dentist_amd.shard_run(comms[rank], A, B, lo, contigs.off, las, trace, po, graph=graph(share.off))
+            except Exception as e:  # noqa: BLE001
+                errors.append((rank, repr(e)))
+                raise
+        threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=600)
+        assert not errors, errors
+        for c in comms:
+            c.close()
+    for grec, gbases, info in results:
+        assert len(grec) == len(rec)
+        for f in rec.dtype.names:
+            if f not in ("cons_off", "pad"):
+                assert np.array_equal(grec[f], rec[f]), f
+        for a, b in zip(grec, rec):
+            assert np.array_equal(gbases[a["cons_off"]:a["cons_off"] + a["cons_len"]], bases[b["cons_off"]:b["cons_off"] + b["cons_len"]])
+
+
 def test_dh_shard_run_over_rccl_at_world_one(gpu_ctx):
     """The RCCL back end of the same entry, executable on a one-GPU box: a communicator of one rank (ncclCommInitRank
     with world 1) -- ncclAllGather of the sizes and of the padded blobs, grouped ncclSend / ncclRecv to itself -- must
