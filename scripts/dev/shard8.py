@@ -10,8 +10,11 @@ import bench
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 spec = bench.WORKLOADS["cfg2_100Mb_1000gaps_1Mx15kb"]
 ctx = dentist_amd.Context(0)
-mo = dentist_amd.default_align_opts(kmer_mod=8, k=20, width=64, xdrop=60, algo=1)
+# SHARD8_KMER_MOD / SHARD8_MAX_READS: 8 / 60 = the fast mode (round 5's emulation); 1 / 0 = the reference's behaviour
+mo = dentist_amd.default_align_opts(kmer_mod=int(os.environ.get("SHARD8_KMER_MOD", "1")), k=20, width=64, xdrop=60, algo=1)
 po = dentist_amd.default_process_opts(algo=1)
+po.max_reads = int(os.environ.get("SHARD8_MAX_READS", "0"))
+print("knobs: kmer_mod", mo.kmer_mod, "max_reads", po.max_reads, flush=True)
 ranks = []
 A = None
 for r in range(N):
