@@ -5,7 +5,7 @@ out=$root/gpurun_out/${1:-tl}
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_tl
-( cd "$root" && rocprofv3 --kernel-trace -d /tmp/prof_tl -o run -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --ref-steps 0 > "$out/bench.log" 2>&1 )
+( cd "$root" && rocprofv3 --kernel-trace -d /tmp/prof_tl -o run -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --fast-steps 0 --ref-partners 0 > "$out/bench.log" 2>&1 )
 db=$(find /tmp/prof_tl -name "*.db" | head -1)
 python - "$db" > "$out/timeline.txt" <<'PY'
 import sqlite3, sys
