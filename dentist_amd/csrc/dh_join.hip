@@ -187,6 +187,9 @@ k_join(JoinView jv, DbView B, DhOpts o, const int64_t *__restrict__ goff, int32_
     __shared__ uint16_t nhv[CAP];   // hits of an entry taken as B side (pass 1), so that pass 2 reserves them at once
     __shared__ int64_t lgoff[JOIN_MAX_READS];
     __shared__ int32_t llen[JOIN_MAX_READS];
+    // which records of a pair are wanted (DbView::pflags) for the group's reads: the walks below test it for every pair of
+    // entries -- from global memory that was two dependent byte loads inside the innermost loop of both passes
+    __shared__ uint8_t lpf[JOIN_MAX_READS];
     __shared__ uint32_t cnt[JOIN_MAX_READS], roff[JOIN_MAX_READS];
     __shared__ uint32_t s_w[JOIN_THREADS / LANES];
     __shared__ int32_t s_n;
@@ -200,6 +203,7 @@ k_join(JoinView jv, DbView B, DhOpts o, const int64_t *__restrict__ goff, int32_
         lgoff[tid] = goff[r0 + tid];
         llen[tid] = (int32_t)(B.off[r0 + tid + 1] - B.off[r0 + tid]);
     }
+    lpf[tid] = (tid < nr && B.pflags) ? B.pflags[r0 + tid] : (uint8_t)3;  // (no flags: every record is wanted)
     cnt[tid] = 0u;  // JOIN_THREADS == JOIN_MAX_READS
     if (tid == 0) s_n = 0;
 #ifdef DH_SEED_PROF
@@ -289,14 +293,18 @@ k_join(JoinView jv, DbView B, DhOpts o, const int64_t *__restrict__ goff, int32_
             const bool pal = ((key >> 30) & 1ull) != 0;
             const int32_t brl = (int32_t)(key >> 21) & (JOIN_MAX_READS - 1);
             const int32_t R = r0 + brl;
+            const uint32_t pfb = lpf[brl];
             int32_t n_same = 0, n_opp = 0, k_same = 0, k_opp = 0;
             JOIN_WALK(canon, {
                 const bool same = ((uint32_t)(ka >> 31) & 1u) == ori;
-                const int32_t Aq = r0 + ((int32_t)(ka >> 21) & (JOIN_MAX_READS - 1));
+                const int32_t arl_ = (int32_t)(ka >> 21) & (JOIN_MAX_READS - 1);
+                const int32_t Aq = r0 + arl_;
+                const uint32_t pfa = lpf[arl_];
                 bool keep = true;
                 if (o.skip_self == 1) keep = Aq != R;
                 if (o.skip_self == 2) keep = Aq != R && ((Aq < R) == (((Aq + R) & 1) == 0));
-                if (o.skip_self == 2 && B.pflags && !dh_pair_seeded(B.pflags, Aq, R)) keep = false;  // neither record is wanted
+                // neither record of the pair is wanted (dh_pair_seeded: (a, b) wanted iff f[a] & 1 and f[b] & 2)
+                if (o.skip_self == 2 && !(((pfa & 1u) && (pfb & 2u)) || ((pfb & 1u) && (pfa & 2u)))) keep = false;
                 n_same += same ? 1 : 0;
                 k_same += same && keep ? 1 : 0;
                 n_opp += same ? 0 : 1;
@@ -345,6 +353,7 @@ k_join(JoinView jv, DbView B, DhOpts o, const int64_t *__restrict__ goff, int32_
             const int32_t brl = (int32_t)(key >> 21) & (JOIN_MAX_READS - 1);
             const int32_t q = (int32_t)(key & (JOIN_MAX_LEN - 1));
             const int32_t R = r0 + brl;
+            const uint32_t pfb = lpf[brl];
             const int32_t qrev = llen[brl] - k - q;  // position on the reverse-complemented read
             // (one returning atomic per entry, not one per hit: each was a round trip in front of its store)
             uint64_t *dst = jv.hits + base + roff[brl] + atomicAdd(&cnt[brl], (uint32_t)nhv[i]);
@@ -354,7 +363,8 @@ k_join(JoinView jv, DbView B, DhOpts o, const int64_t *__restrict__ goff, int32_
                 const int32_t Aq = r0 + arl;
                 if (o.skip_self == 1 && Aq == R) continue;
                 if (o.skip_self == 2 && (Aq == R || ((Aq < R) != (((Aq + R) & 1) == 0)))) continue;
-                if (o.skip_self == 2 && B.pflags && !dh_pair_seeded(B.pflags, Aq, R)) continue;
+                const uint32_t pfa = lpf[arl];
+                if (o.skip_self == 2 && !(((pfa & 1u) && (pfb & 2u)) || ((pfb & 1u) && (pfa & 2u)))) continue;
                 const int64_t gv = lgoff[arl] + (int64_t)(ka & (JOIN_MAX_LEN - 1));
                 if (dof && (same || pal)) {
                     const int64_t D = gv + sepv - q;

@@ -1,5 +1,5 @@
 export MASTER_ADDR=127.0.0.1
-timeout -s KILL 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 2 --warmup 1 --dev-share-gpu --no-cpu-baseline > gpurun_out/bench_n2.json 2> gpurun_out/bench_n2.err
+timeout -s KILL 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 2 --warmup 1 --dev-share-gpu --no-cpu-baseline "$@" > gpurun_out/bench_n2.json 2> gpurun_out/bench_n2.err
 python - <<'PY'
 import json
 lines = [l for l in open('gpurun_out/bench_n2.json').read().strip().splitlines() if l.startswith('{')]

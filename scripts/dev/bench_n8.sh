@@ -1,7 +1,7 @@
 #!/bin/bash
 # dev: bench.py as EIGHT processes over gloo on ONE GPU (--dev-share-gpu): the multi-process path at world 8 -- results, not times
 export MASTER_ADDR=127.0.0.1
-timeout -s KILL 1500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29577 bench.py --gpus 8 --steps 2 --warmup 1 --dev-share-gpu --no-cpu-baseline --ref-steps 0 > gpurun_out/bench_n8.json 2> gpurun_out/bench_n8.err
+timeout -s KILL 1500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29577 bench.py --gpus 8 --steps 2 --warmup 1 --dev-share-gpu --no-cpu-baseline "$@" > gpurun_out/bench_n8.json 2> gpurun_out/bench_n8.err
 python - <<'PY'
 import json
 lines = [l for l in open('gpurun_out/bench_n8.json').read().strip().splitlines() if l.startswith('{')]
