@@ -2236,7 +2236,14 @@ extern "C" int dh_process_cropped(dh_ctx *ctx, dh_db *contigs, dh_cropped *crop,
             });
         }
         if (!on_dev) {
-            // the further occurrences of LAs that alternate chains share: behind their first occurrence (same trace)
+            // the further occurrences of LAs that alternate chains share: behind their first occurrence (same trace).
+            // NOTE (record order): the reference writes every accepted chain as ONE contiguous run (composeAlignmentChain
+            // per chain, then acceptedChains.sort(): chaining.d:269-312); here a shared LA's copy sits behind its first
+            // occurrence and the chain's other members stay where they were, so in record order two chains may interleave
+            // (START(a), START(a'), NEXT(b) ...).  Everything downstream of the funnel works per LA (tile QVs, validity,
+            // ranking, the first consensus round); code that walks a chain as "START plus the NEXT records behind it"
+            // (dh_chain_view, covering_member, intersect_chain) must NOT be pointed at this output.  Only reachable below
+            // min_relative_score 1.0 or with equal-score chains sharing a prefix.
             size_t ndup = 0;
             for (const auto &gd : gdups_of_funnel) ndup += gd.size();
             if (ndup) {
