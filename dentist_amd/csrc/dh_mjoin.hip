@@ -634,7 +634,8 @@ k_mj_filter(IndexView ix, DhOpts o, MjView m)
 // sweep are those of k_mj_filter: sseg[group][partition] still describes one range per group of 16 tiles.
 #define MJ_F2_R 10          /* rounds whose loads are in flight together (640 entries; 512 expected) */
 #define MJ_F2_MARKS 1024    /* flat indices one pass over the marks covers */
-#define MJ_F2_TMAX 2047     /* entries of one partition in 64 tiles (11 bits of prefix); more = a degenerate chunk */
+#define MJ_F2_TMAX 16383    /* entries of one partition in 64 tiles (14 bits of prefix; 512 expected -- repeat-rich reads put many
+                               copies of a k-mer into one partition); more = a degenerate chunk */
 namespace {
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ uint32_t mj_dpp0(uint32_t v)
@@ -772,7 +773,7 @@ k_mj_filter2(IndexView ix, DhOpts o, MjView m)
                     if (lane == 0) atomicOr(m.status, DH_ST_MJ_OVERFLOW);
                     T = 0;
                 }
-                const uint32_t pk = excl | (st0 << 11);
+                const uint32_t pk = excl | (st0 << 14);  // (start < 2^13)
                 // ---- room for the survivors of these tiles: they form one range per group of 16
                 if (fill + SAFE > MJ_PAGE && !pool_out) {
                     if (fill <= MJ_PAGE && page_base + fill > sweep_from) resolve(sweep_from, page_base + fill, p);
@@ -804,7 +805,7 @@ k_mj_filter2(IndexView ix, DhOpts o, MjView m)
                     const uint32_t s = s1 ? s1 - 1u : 0u;
                     const uint32_t pks = (uint32_t)__shfl((int)pk, (int)s, LANES);
                     *s_out = s;
-                    const uint32_t off = s * (uint32_t)MJ_CAP + (pks >> 11) + (i - (pks & 0x7FFu));
+                    const uint32_t off = s * (uint32_t)MJ_CAP + (pks >> 14) + (i - (pks & 0x3FFFu));
                     return i < T ? mj_load8(ebase + off) : 0ull;  // (entries are never 0)
                 };
                 auto process = [&](uint64_t ev, uint32_t s) {

@@ -200,6 +200,32 @@ def test_soft_masked_reads_and_repeats_with_the_t_cap(gpu_ctx):
     assert masked_hits < 0.95 * gpu_ctx.align_stats().hits
 
 
+def test_reads_with_low_complexity_tails_fill_one_partition(gpu_ctx, monkeypatch):
+    """Every read carries a 110-base poly-A tail: ~95 copies of one k-mer per read, all in ONE partition of the join -- the 64
+    tiles a wavefront of k_mj_filter2 takes hold several thousand entries of that partition instead of ~512, so the flat
+    lane mapping walks several windows of its segment marks (MJ_F2_MARKS = 1 024 flat indices each) and the segments are
+    dozens of entries long.  The assembly holds poly-A stretches too (hits, the -t cap).  Bit-exact against the oracle, the
+    chunk stays with the join (no fall-back), identical to the round-5 filter and to the directory lookups."""
+    rng = np.random.default_rng(41)
+    g = rng.integers(0, 4, 400_000).astype(np.uint8)
+    for at in (50_000, 180_000, 310_000):
+        g[at:at + 60] = 0
+    contigs = sim.SeqDb.from_list([g[:195_000], g[200_000:]])
+    rd, _ = sim.reads(42, g, 700, 4000, 0, min_len=4000)
+    tail = np.zeros(110, dtype=np.uint8)
+    reads = sim.SeqDb.from_list([np.concatenate([rd.seq(i), tail]) for i in range(rd.n)])
+    kw = dict(k=20, kmer_mod=1, algo=1, width=64)
+    (las, trace), (chunks, fallbacks) = run_both(gpu_ctx, contigs, reads, **kw)
+    assert chunks > 0 and fallbacks == 0
+    go = dentist_amd.default_align_opts(**kw)
+    A, B = gpu_ctx.db(contigs), gpu_ctx.db(reads)
+    for env, val in (("DH_MJ_DBG", "2"), ("DH_NO_MJOIN", "1")):
+        monkeypatch.setenv(env, val)
+        other = gpu_ctx.align_db(A, B, go)
+        monkeypatch.delenv(env)
+        assert_same_las((las, trace), other)
+
+
 def test_capacity_overflow_falls_back_to_the_directory(gpu_ctx, monkeypatch):
     """A hit pool of one page cannot hold the hits of the chunk: the chunk is redone by the directory lookups, the result
     is the same and the fall-back is counted."""
