@@ -674,7 +674,6 @@ k_mj_filter2(IndexView ix, DhOpts o, MjView m)
     const int tid = threadIdx.x, lane = tid & (LANES - 1), wave = tid / LANES;
     constexpr int NW = MJ_PROBE_THREADS / LANES;
     constexpr int SG = LANES;                      // tiles a wavefront takes at a time
-    constexpr uint32_t SAFE = MJ_PAGE / 4;         // survivors the tiles at hand may add to the wavefront's page
     constexpr int R = MJ_F2_R;
     const int k = m.k, remsh = 2 * k - MJ_PBITS, sbits = m.nbbits - MJ_PBITS, bshift = remsh - sbits;
     const uint64_t remmask = (1ull << remsh) - 1;
@@ -774,8 +773,10 @@ k_mj_filter2(IndexView ix, DhOpts o, MjView m)
                     T = 0;
                 }
                 const uint32_t pk = excl | (st0 << 14);  // (start < 2^13)
-                // ---- room for the survivors of these tiles: they form one range per group of 16
-                if (fill + SAFE > MJ_PAGE && !pool_out) {
+                // ---- room for the survivors of these tiles (at most their T entries; T <= MJ_F2_TMAX < MJ_PAGE): they form one
+                // range per group of 16.  A page is left only when the entries at hand might not fit: pages fill to the brim.
+                static_assert(MJ_F2_TMAX < MJ_PAGE, "the entries of 64 tiles fit a page");
+                if (fill + T > MJ_PAGE && !pool_out) {
                     if (fill <= MJ_PAGE && page_base + fill > sweep_from) resolve(sweep_from, page_base + fill, p);
                     uint32_t pg = 0;
                     if (lane == 0) pg = atomicAdd(&m.ctr[8], 1u);
@@ -791,7 +792,7 @@ k_mj_filter2(IndexView ix, DhOpts o, MjView m)
                     }
                     sweep_from = page_base + fill;
                 }
-                const bool have_page = fill + SAFE <= MJ_PAGE;
+                const bool have_page = fill + T <= MJ_PAGE;
                 const uint64_t first = page_base + fill;
                 const uint64_t *ebase = m.ent + (int64_t)tb0 * MJ_CAP;
                 uint32_t gtot = 0, gq0 = 0, gq1 = 0, gq2 = 0;  // survivors so far; of the first three groups of 16 tiles
@@ -819,7 +820,7 @@ k_mj_filter2(IndexView ix, DhOpts o, MjView m)
                     const unsigned long long bal = __ballot(pass);
                     if (bal == 0ull) return;
                     const uint32_t at = gtot + mj_lanes_below(bal);
-                    if (pass && have_page && at < SAFE)
+                    if (pass && have_page)  // (at < T)
                         m.hits[first + at] = (ev & ~(0x3FFull << MJ_PSH)) | ((uint64_t)(s & (MJ_GROUP - 1)) << MJ_PSH);
                     gtot += (uint32_t)__popcll(bal);
                     gq0 += (uint32_t)__popcll(__ballot(pass && s < 16u));
@@ -851,10 +852,6 @@ k_mj_filter2(IndexView ix, DhOpts o, MjView m)
                         const uint64_t ev = issue(wb, r, &s);
                         process(ev, s);
                     }
-                }
-                if (gtot > SAFE) {  // more survivors than the tiles at hand may hold: degenerate tiles (one k-mer all over)
-                    if (lane == 0) atomicOr(m.status, DH_ST_MJ_OVERFLOW);
-                    gtot = gq0 = gq1 = gq2 = 0;
                 }
                 if (lane < SG / MJ_GROUP) {
                     const int32_t g = tb0 / MJ_GROUP + lane;
