@@ -16,6 +16,7 @@ ctx = dentist_amd.Context(0)
 KMER_MOD = int(os.environ.get("KMER_MOD", "4"))   # the stress configuration samples 1/4; 8 = bench.py's configs[2] default
 mo = dentist_amd.default_align_opts(kmer_mod=KMER_MOD, k=20, width=64, xdrop=60, algo=1)
 po = dentist_amd.default_process_opts(algo=1)
+po.max_reads = int(os.environ.get("MAX_READS", "60"))   # 0 = no cap, the reference's behaviour
 A, B, P = ctx.db(s.contigs), ctx.db(s.reads), ctx.db(s.pile_reads)
 rows = []
 for step in range(steps + 1):   # the first pass builds the index and sizes the buffers
