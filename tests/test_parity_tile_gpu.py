@@ -104,12 +104,16 @@ def test_symmetric_all_vs_all(gpu_ctx, seed, grouped):
     assert all((b, a, c) in key for a, b, c in key)
 
 
-def test_symmetric_items_with_more_candidates_than_the_attempt_cap(gpu_ctx):
+@pytest.mark.parametrize("qbatch", [None, "1", "7"])
+def test_symmetric_items_with_more_candidates_than_the_attempt_cap(gpu_ctx, monkeypatch, qbatch):
     """An item (read, strand) attempts at most 64 alignments (oracle/align.c: `nd < 64`; dh_tile.h: MAXREG).  In a pile-up of
     166 reads -- the reference's behaviour, no read cap: processPileUps/package.d:283-374 -- an item meets more partners than
     that, and k_units_fat splits it into work units without changing which candidates are aligned: lone candidates below
     index 64 on their own, the rest of the item in order with the lone ones counted.  180 reads of one locus, all on one
-    strand: ~90 candidates per forward item, some pairs with two candidate band pairs (the `rest` unit)."""
+    strand: ~90 candidates per forward item, some pairs with two candidate band pairs (the `rest` unit).  Also with one work
+    unit per queue atomic and with batches of seven (DH_TILE_QBATCH: a wavefront takes 64 per atomic by default)."""
+    if qbatch:
+        monkeypatch.setenv("DH_TILE_QBATCH", qbatch)
     g = sim.genome(91, 2600)
     reads, truth = sim.reads(92, g, 180, 2000, min_len=1500)
     seqs = [reads.seq(i) if truth[i, 2] == 0 else sim.revcomp(reads.seq(i)) for i in range(reads.n)]
