@@ -190,6 +190,13 @@ k_join(JoinView jv, DbView B, DhOpts o, const int64_t *__restrict__ goff, int32_
     // which records of a pair are wanted (DbView::pflags) for the group's reads: the walks below test it for every pair of
     // entries -- from global memory that was two dependent byte loads inside the innermost loop of both passes
     __shared__ uint8_t lpf[JOIN_MAX_READS];
+    // the entries whose bucket holds more than themselves (round 6): of the ~2 800 entries of a slice about 1 000 share their
+    // k-mer with another entry (the intact copies of a true k-mer; 14 entries per such bucket on average) -- the others are
+    // read errors, one of a kind, and most of them sit alone in their bucket: their walk is over after one step.  Dealt to the
+    // lanes by index a wavefront ran as long as its longest walk with a third of its lanes at work.  The two walks go over
+    // this list instead (57 -> 44 ms per step; a list of the entries WITH a partner costs its scan what it saves).
+    __shared__ uint16_t act[CAP];
+    __shared__ uint32_t s_nact;
     __shared__ uint32_t cnt[JOIN_MAX_READS], roff[JOIN_MAX_READS];
     __shared__ uint32_t s_w[JOIN_THREADS / LANES];
     __shared__ int32_t s_n;
@@ -262,6 +269,33 @@ k_join(JoinView jv, DbView B, DhOpts o, const int64_t *__restrict__ goff, int32_
             if (tid + u * JOIN_THREADS < n) keys[atomicAdd(&head[join_bucket<CAP>((uint32_t)(ke[u] >> 32))], 1u)] = ke[u];
     }
     __syncthreads();
+    {
+        // thread t owns the entries [t * PER, (t + 1) * PER): the list keeps the entries in index (= bucket) order, so the
+        // lanes of a wavefront walk buckets of similar length
+        constexpr int PER = CAP / JOIN_THREADS;
+        uint32_t fl = 0, c = 0;
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int32_t i = tid * PER + u;
+            if (i < n) {
+                // an entry alone in its bucket has no partner (without any skip_self rule it still meets itself)
+                const uint32_t hb = join_bucket<CAP>((uint32_t)(keys[i] >> 32));
+                const bool partner = o.skip_self == 0 || head[hb] - (hb ? head[hb - 1] : 0u) >= 2u;
+                if (partner) {
+                    fl |= 1u << u;
+                    c++;
+                }
+            }
+        }
+        uint32_t tot;
+        uint32_t at = block_excl_scan<JOIN_THREADS>(c, tid, s_w, &tot);
+#pragma unroll
+        for (int u = 0; u < PER; u++)
+            if (fl & (1u << u)) act[at++] = (uint16_t)(tid * PER + u);
+        if (tid == 0) s_nact = tot;
+    }
+    __syncthreads();
+    const int32_t nact = (int32_t)s_nact;
     JP(1)
     // the entries of bucket hb, four at a time (loads past the end read the last entry again and are masked: a branch
     // per load made every one of them a round trip of its own); fn(key of an entry)
@@ -286,7 +320,8 @@ k_join(JoinView jv, DbView B, DhOpts o, const int64_t *__restrict__ goff, int32_
     uint32_t dmask = 0;  // (forward ok, reverse ok) of this thread's entries, two bits each
     {
         int slot = 0;
-        for (int32_t i = tid; i < n; i += JOIN_THREADS, slot++) {
+        for (int32_t a = tid; a < nact; a += JOIN_THREADS, slot++) {
+            const int32_t i = act[a];
             const uint64_t key = keys[i];
             const uint32_t canon = (uint32_t)(key >> 32);
             const uint32_t ori = (uint32_t)(key >> 31) & 1u;
@@ -342,9 +377,10 @@ k_join(JoinView jv, DbView B, DhOpts o, const int64_t *__restrict__ goff, int32_
     // ---- pass 2: the hits
     {
         int slot = 0;
-        for (int32_t i = tid; i < n; i += JOIN_THREADS, slot++) {
+        for (int32_t a = tid; a < nact; a += JOIN_THREADS, slot++) {
             const uint32_t dm = (dmask >> (2 * slot)) & 3u;
             if (!dm) continue;
+            const int32_t i = act[a];
             const bool dof = (dm & 1u) != 0, dor = (dm & 2u) != 0;
             const uint64_t key = keys[i];
             const uint32_t canon = (uint32_t)(key >> 32);
