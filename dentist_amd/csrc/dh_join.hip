@@ -217,18 +217,62 @@ k_join(JoinView jv, DbView B, DhOpts o, const int64_t *__restrict__ goff, int32_
     unsigned long long tp_ = wall_clock64();
 #endif
     __syncthreads();
-    // ---- gather the slice's entries from the group's part blocks: a wavefront per part block
-    for (int32_t pb = jv.pfirst[g] + wv; pb < jv.pfirst[g + 1]; pb += JOIN_THREADS / LANES) {
-        const uint32_t u = jv.psub[jv.psubrow[pb] + sl];
-        const int32_t c = (int32_t)(u & 0xFFFFu), st = (int32_t)(u >> 16);
-        if (c == 0) continue;
-        int32_t base = 0;
-        if (lane == 0) base = atomicAdd(&s_n, c);
-        base = __shfl(base, 0, LANES);
-        if (base + c <= CAP) {
-            const uint64_t *src = jv.entries + (int64_t)pb * JP_POS + st;
-            for (int32_t e = lane; e < c; e += LANES) keys[base + e] = src[e];
+    // ---- gather the slice's entries from the group's part blocks.  Every thread reads the (start, count) of one part block,
+    // a block-wide scan places the blocks' runs, and the entries are copied by FLAT index -- each thread finds the part
+    // block of its entry in the scanned counts and up to eight loads per thread are in flight together.  (A wavefront per
+    // part block -- descriptor, an LDS atomic for the place, the copy: three dependent round trips, seven part blocks per
+    // wavefront one after the other -- was 11.6 of the 64 us a block took.)
+    {
+        __shared__ uint32_t gsrc[JOIN_THREADS], gend[JOIN_THREADS];  // start inside the part block; end of its run in `keys`
+        const int32_t pb0 = jv.pfirst[g], npb = jv.pfirst[g + 1] - pb0;
+        uint32_t ntot = 0;
+        for (int32_t c0 = 0; c0 < npb; c0 += JOIN_THREADS) {
+            const int32_t m = min(JOIN_THREADS, npb - c0);
+            const uint32_t u = tid < m ? jv.psub[jv.psubrow[pb0 + c0 + tid] + sl] : 0u;
+            const uint32_t c = u & 0xFFFFu;
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan<JOIN_THREADS>(c, tid, s_w, &tot);
+            gsrc[tid] = u >> 16;
+            gend[tid] = ex + c;
+            __syncthreads();
+            if (ntot + tot <= (uint32_t)CAP) {
+                int32_t top = 1;
+                while (top < m) top <<= 1;
+                constexpr int GU = 8;
+                for (uint32_t f0 = (uint32_t)tid; f0 < tot; f0 += JOIN_THREADS * GU) {
+                    int32_t lo[GU];
+#pragma unroll
+                    for (int q = 0; q < GU; q++) lo[q] = 0;
+                    // the part block of flat index f: the first j with gend[j] > f (empty runs repeat a value and are skipped)
+                    for (int32_t step = top >> 1; step > 0; step >>= 1) {
+#pragma unroll
+                        for (int q = 0; q < GU; q++) {
+                            const int32_t idx = lo[q] + step;
+                            if (idx < m && gend[idx - 1] <= f0 + (uint32_t)q * JOIN_THREADS) lo[q] = idx;
+                        }
+                    }
+                    uint64_t v[GU];
+#pragma unroll
+                    for (int q = 0; q < GU; q++) {
+                        const uint32_t f = f0 + (uint32_t)q * JOIN_THREADS;
+                        v[q] = 0;
+                        if (f < tot) {
+                            const int32_t j = lo[q];
+                            const uint32_t first = j ? gend[j - 1] : 0u;
+                            v[q] = jv.entries[(int64_t)(pb0 + c0 + j) * JP_POS + gsrc[j] + (f - first)];
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < GU; q++) {
+                        const uint32_t f = f0 + (uint32_t)q * JOIN_THREADS;
+                        if (f < tot) keys[ntot + f] = v[q];
+                    }
+                }
+            }
+            ntot += tot;
+            __syncthreads();  // gsrc / gend are rewritten by the next round
         }
+        if (tid == 0) s_n = (int32_t)min(ntot, 0x7FFFFFFFu);
     }
     __syncthreads();
     JP(0)
