@@ -932,18 +932,18 @@ k_mj_hits(DbView B, IndexView ix, DhOpts o, MjView m)
         return;
     }
     if (n == 0) return;  // (the reads' rows of this group stay zero)
-    auto fetch = [&](uint32_t e, int32_t *pp) {  // survivor e of the group: the list of the last partition p with hoff[p] <= e
-        int32_t lo = 0, hi = MJ_P - 1;
-        while (lo < hi) {
-            const int32_t mid = (lo + hi + 1) >> 1;
-            if (hoff[mid] <= e)
-                lo = mid;
-            else
-                hi = mid - 1;
-        }
+    // survivor e of the group: the list of the last partition p with hoff[p] <= e (ten steps without a branch: the searches
+    // and loads of the four survivors a thread handles at a time overlap -- one survivor per iteration was a chain of an
+    // LDS search, a load from the survivor pool and another search per survivor, 22 of them in a row)
+    auto fetch = [&](uint32_t e, int32_t *pp) {
+        int32_t lo = 0;
+#pragma unroll
+        for (int32_t step = MJ_P / 2; step > 0; step >>= 1)
+            if (hoff[lo + step] <= e) lo += step;
         *pp = lo;
         return m.hits[hfirst[lo] + (e - hoff[lo])];
     };
+    constexpr int HU = 4;
     auto read_of = [&](int32_t posg) {  // the last read with rsl[i] <= posg
         int32_t lo = 0, hi = nrd - 1;
         while (lo < hi) {
@@ -956,21 +956,33 @@ k_mj_hits(DbView B, IndexView ix, DhOpts o, MjView m)
         return lo;
     };
     auto posg_of = [&](uint64_t sv) { return (int32_t)(((sv >> MJ_PSH) & (uint64_t)(MJ_GROUP - 1)) * (uint64_t)m.tb + (sv & ((1ull << MJ_POSBITS) - 1))); };
-    for (uint32_t e = tid; e < n; e += MJ_THREADS) {
-        int32_t p;
-        const uint64_t sv = fetch(e, &p);
-        if (sv == 0ull) continue;  // resolved by the filter kernel: no hit
-        if (!((sv >> 62) & 1ull)) {  // its only hit, in place
-            atomicOr(&hb[e >> 5], 1u << (e & 31));
-            atomicAdd(&rcnt[read_of((int32_t)(sv & 0x7FFFFFull) - 1)], 1u);
-            continue;
+    for (uint32_t e0 = tid; e0 < n; e0 += MJ_THREADS * HU) {
+        int32_t pv[HU];
+        uint64_t svv[HU];
+#pragma unroll
+        for (int u = 0; u < HU; u++) {
+            const uint32_t e = e0 + (uint32_t)u * MJ_THREADS;
+            pv[u] = 0;
+            svv[u] = e < n ? fetch(e, &pv[u]) : 0ull;
         }
-        uint32_t c = 0;
-        mj_lookup(ix, o, ((uint64_t)p << remsh) | ((sv >> MJ_REMSH) & remmask), (sv & MJ_ORI_BIT) != 0, (sv & MJ_PAL_BIT) != 0,
-                  [&](uint64_t, int) { c++; });
-        atomicOr(&hb[e >> 5], 1u << (e & 31));
-        atomicOr(&mb[e >> 5], 1u << (e & 31));
-        atomicAdd(&rcnt[read_of(posg_of(sv))], c);
+#pragma unroll
+        for (int u = 0; u < HU; u++) {
+            const uint32_t e = e0 + (uint32_t)u * MJ_THREADS;
+            const uint64_t sv = svv[u];
+            const int32_t p = pv[u];
+            if (sv == 0ull) continue;  // (behind the group's end, or) resolved by the filter kernel: no hit
+            if (!((sv >> 62) & 1ull)) {  // its only hit, in place
+                atomicOr(&hb[e >> 5], 1u << (e & 31));
+                atomicAdd(&rcnt[read_of((int32_t)(sv & 0x7FFFFFull) - 1)], 1u);
+                continue;
+            }
+            uint32_t c = 0;
+            mj_lookup(ix, o, ((uint64_t)p << remsh) | ((sv >> MJ_REMSH) & remmask), (sv & MJ_ORI_BIT) != 0, (sv & MJ_PAL_BIT) != 0,
+                      [&](uint64_t, int) { c++; });
+            atomicOr(&hb[e >> 5], 1u << (e & 31));
+            atomicOr(&mb[e >> 5], 1u << (e & 31));
+            atomicAdd(&rcnt[read_of(posg_of(sv))], c);
+        }
     }
     __syncthreads();
     uint32_t rc4[MJ_RG_READS / MJ_THREADS], sum = 0;
@@ -1006,11 +1018,23 @@ k_mj_hits(DbView B, IndexView ix, DhOpts o, MjView m)
         rex += rc4[u];
     }
     __syncthreads();
-    for (uint32_t e0 = 0; e0 < n; e0 += MJ_THREADS) {
-        const uint32_t e = e0 + tid;
-        if (e >= n || !((hb[e >> 5] >> (e & 31)) & 1u)) continue;
-        int32_t p;
-        const uint64_t sv = fetch(e, &p);
+    for (uint32_t e0 = tid; e0 < n; e0 += MJ_THREADS * HU) {
+        int32_t pv[HU];
+        uint64_t svv[HU];
+        bool live[HU];
+#pragma unroll
+        for (int u = 0; u < HU; u++) {
+            const uint32_t e = e0 + (uint32_t)u * MJ_THREADS;
+            pv[u] = 0;
+            live[u] = e < n && ((hb[e >> 5] >> (e & 31)) & 1u);
+            svv[u] = live[u] ? fetch(e, &pv[u]) : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < HU; u++) {
+        if (!live[u]) continue;
+        const uint32_t e = e0 + (uint32_t)u * MJ_THREADS;
+        const uint64_t sv = svv[u];
+        const int32_t p = pv[u];
         if (!((mb[e >> 5] >> (e & 31)) & 1u)) {  // the hit itself
             const int32_t posg = (int32_t)(sv & 0x7FFFFFull) - 1, strand = (int32_t)(sv >> 63);
             const int32_t i = read_of(posg);
@@ -1029,6 +1053,7 @@ k_mj_hits(DbView B, IndexView ix, DhOpts o, MjView m)
                       const int64_t D = (int64_t)(v & ((1ull << 40) - 1)) + ix.sepv - qs;
                       m.rhits[base + atomicAdd(&rcur[i], 1u)] = ((uint64_t)strand << 63) | ((uint64_t)D << 24) | (uint32_t)qs;
                   });
+        }
     }
 }
 
