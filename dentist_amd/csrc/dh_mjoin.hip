@@ -943,7 +943,7 @@ k_mj_hits(DbView B, IndexView ix, DhOpts o, MjView m)
         *pp = lo;
         return m.hits[hfirst[lo] + (e - hoff[lo])];
     };
-    constexpr int HU = 4;
+    constexpr int HU = 8;
     auto read_of = [&](int32_t posg) {  // the last read with rsl[i] <= posg
         int32_t lo = 0, hi = nrd - 1;
         while (lo < hi) {
