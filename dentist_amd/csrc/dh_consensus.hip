@@ -753,6 +753,94 @@ __device__ __forceinline__ bool has_byte5(uint64_t w)
     const uint64_t t = w ^ 0x0505050505050505ull;
     return (((t - 0x0101010101010101ull) & ~t) & 0x8080808080808080ull) != 0ull;
 }
+#ifdef DH_SEED_PROF
+__device__ unsigned long long g_vote_prof[8];
+#define VP(i)                                          \
+    if (threadIdx.x == 0) {                            \
+        const unsigned long long t_ = wall_clock64();  \
+        atomicAdd(&g_vote_prof[i], t_ - tp_);          \
+        tp_ = t_;                                      \
+    }
+#else
+#define VP(i)
+#endif
+
+// bit i of the result = byte i of `t` is zero
+__device__ __forceinline__ uint32_t zero_bytes8(uint64_t t)
+{
+    const uint64_t m = ~(((t & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | t) & 0x8080808080808080ull;
+    // the four flag bits of a half (at 7, 15, 23, 31) land at 24 .. 27 of one 32-bit product, no two terms on one bit
+    const uint32_t lo = (((uint32_t)m >> 7) * 0x01020408u) >> 24, hi = (((uint32_t)(m >> 32) >> 7) * 0x01020408u) >> 24;
+    return (lo & 15u) | ((hi & 15u) << 4);
+}
+// bit i of the result = bit `k` of byte i
+__device__ __forceinline__ uint32_t bit_plane8(uint64_t t, int k)
+{
+    const uint64_t m = (t >> k) & 0x0101010101010101ull;
+    const uint32_t lo = ((uint32_t)m * 0x01020408u) >> 24, hi = ((uint32_t)(m >> 32) * 0x01020408u) >> 24;
+    return (lo & 15u) | ((hi & 15u) << 4);
+}
+// a set of columns 0 .. 127 in two registers
+struct ColSet {
+    uint64_t lo, hi;
+    __device__ __forceinline__ void put8(int32_t xb, uint32_t m8)  // xb a multiple of 8
+    {
+        if (xb < 64)
+            lo |= (uint64_t)m8 << xb;
+        else
+            hi |= (uint64_t)m8 << (xb - 64);
+    }
+    __device__ __forceinline__ bool test(int32_t x) const { return ((x < 64 ? lo >> x : hi >> (x - 64)) & 1ull) != 0ull; }
+    __device__ __forceinline__ void set(int32_t x)
+    {
+        if (x < 64)
+            lo |= 1ull << x;
+        else
+            hi |= 1ull << (x - 64);
+    }
+    __device__ __forceinline__ void clear(int32_t x)
+    {
+        if (x < 64)
+            lo &= ~(1ull << x);
+        else
+            hi &= ~(1ull << (x - 64));
+    }
+    __device__ __forceinline__ bool any() const { return (lo | hi) != 0ull; }
+    __device__ __forceinline__ int32_t pop_lowest()
+    {
+        if (lo) {
+            const int32_t x = __builtin_ctzll(lo);
+            lo &= lo - 1;
+            return x;
+        }
+        const int32_t x = __builtin_ctzll(hi);
+        hi &= hi - 1;
+        return 64 + x;
+    }
+    __device__ __forceinline__ void keep_below(int32_t n)  // columns 0 .. n - 1, n <= 128
+    {
+        if (n <= 64) {
+            hi = 0ull;
+            if (n < 64) lo &= (1ull << n) - 1ull;
+        } else if (n < 128)
+            hi &= (1ull << (n - 64)) - 1ull;
+    }
+};
+__device__ __forceinline__ ColSet operator&(const ColSet &a, const ColSet &b) { return ColSet{a.lo & b.lo, a.hi & b.hi}; }
+// where a walk to the left from column x ends that may step from st to st - 1 while column st - 1 is in `w`
+// (`while (st > 0 && w[st - 1]) st--`): one more than the highest column below x that is not in w
+__device__ __forceinline__ int32_t walk_left(const ColSet &w, int32_t x)
+{
+    ColSet t{~w.lo, ~w.hi};
+    t.keep_below(x);
+    if (t.hi) return 128 - __builtin_clzll(t.hi);
+    if (t.lo) return 64 - __builtin_clzll(t.lo);
+    return 0;
+}
+
+// NW8 > 0: tiles of up to 8 * NW8 - 2 <= 126 columns, the two canonical-placement passes on column sets in registers;
+// NW8 == 0: any tile length, the passes byte by byte (the formulation the oracle has; DH_VOTE_BYTEWISE=1 selects it)
+template <int NW8>
 __global__ void __launch_bounds__(64)
 k_seg_vote2(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R,
             const uint8_t *__restrict__ rrc, const int64_t *__restrict__ voff,
@@ -771,22 +859,33 @@ k_seg_vote2(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R,
     const int64_t NDP = nseg;
     // colst[x]: base aligned to column x (5 = deleted); ins[x]: bases inserted before column x --
     // count (0..5, 5 = more than MAXINS) in bits 0-2, bits 3-6 = "base t is one of ACGT";
-    // ibp[x]: the first MAXINS inserted bases, 2 bits each.  3 bytes per column keep 6 blocks of 64
+    // ibp[x]: the first MAXINS inserted bases, 2 bits each.  3 bytes per column keep 8 blocks of 64
     // tiles resident per CU.
     const int32_t ARR = seg_vote2_arr(ncolmax);
     uint8_t *colst = smem + (size_t)threadIdx.x * seg_vote2_row(ncolmax);
     uint8_t *ins = colst + ARR;
     uint8_t *ibp = ins + ARR;
+#ifdef DH_SEED_PROF
+    unsigned long long tp_ = wall_clock64();
+#endif
 #define CS(x) colst[(x)]
 #define IN(x) ins[(x)]
 #define IB(x) ibp[(x)]
 #define CS8(x) (*(const uint64_t *)(colst + (x)))
 #define IN8(x) (*(const uint64_t *)(ins + (x)))
 #define IB8(x) (*(const uint64_t *)(ibp + (x)))
+    // the template bases of the tile, eight to a word (the DBs carry 64 bytes of padding): every load in flight before the
+    // op list is walked
+    uint64_t rwv[NW8 > 0 ? NW8 : 1];
+    if (NW8 > 0) {
+#pragma unroll
+        for (int w = 0; w < NW8; w++) __builtin_memcpy(&rwv[w], ref + min(8 * w, rl & ~7), 8);  // (words behind the tile: unused)
+    }
     for (int32_t x = 0; x <= rl; x += 8) {
         *(uint64_t *)(ins + x) = 0ull;
         *(uint64_t *)(ibp + x) = 0ull;
     }
+    VP(0)
     {
         // eight ops per word (OP_WORD), the next word on its way while this one is applied; the query bases the eight ops
         // consume come from one unaligned 8-byte load (the DBs carry 64 bytes of padding)
@@ -794,78 +893,169 @@ k_seg_vote2(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R,
         int32_t x = 0, y = 0;
         int32_t g = (nops - 1) >> 3;
         uint64_t wnext = opw[(int64_t)g * NDP + dp];
+        uint64_t qnext;
+        __builtin_memcpy(&qnext, qry, 8);
+        // the insertion in front of column x is gathered in registers and stored when the column comes (its ops are
+        // consecutive): read-modify-write of ins[x] / ibp[x] per op was two dependent LDS round trips at nearly every op
+        // position of a wavefront
+        uint32_t rn = 0, rv = 0, rb = 0;  // bases so far (0 .. 5), their "is one of ACGT" bits, the first MAXINS bases
         for (; g >= 0; g--) {
-            const uint64_t ow = wnext;
-            if (g > 0) wnext = opw[(int64_t)(g - 1) * NDP + dp];
-            uint64_t qw;
-            __builtin_memcpy(&qw, qry + y, 8);
+            const uint64_t ow = wnext, qw = qnext;
             const int32_t y0 = y;
+            if (g > 0) {
+                // the query bases of the next word start behind the ones this word consumes (every op but a deletion):
+                // known from the word alone, so that the load does not wait for the eight ops
+                const uint32_t nval = (uint32_t)min(8, nops - 8 * g);
+                const uint32_t dels = zero_bytes8(ow ^ 0x0101010101010101ull) & ((1u << nval) - 1u);
+                wnext = opw[(int64_t)(g - 1) * NDP + dp];
+                __builtin_memcpy(&qnext, qry + y + ((int32_t)nval - __builtin_popcount(dels)), 8);
+            }
 #pragma unroll
             for (int u = 7; u >= 0; u--) {
                 if (8 * g + u >= nops) continue;
                 const uint8_t op = (uint8_t)(ow >> (8 * u));
-                if (op == 0) {
-                    CS(x) = (uint8_t)(qw >> (8 * (y - y0)));
-                    y++;
-                    x++;
-                } else if (op == 1) {
-                    CS(x) = 5;
+                if (op <= 1) {
+                    if (rn) {
+                        IN(x) = (uint8_t)(rn | (rv << 3));
+                        IB(x) = (uint8_t)rb;
+                        rn = rv = rb = 0;
+                    }
+                    CS(x) = op == 0 ? (uint8_t)(qw >> (8 * (y - y0))) : (uint8_t)5;
+                    y += op == 0 ? 1 : 0;
                     x++;
                 } else {
-                    const uint8_t v = IN(x), n = v & 7, q = (uint8_t)(qw >> (8 * (y - y0)));
-                    uint8_t nv = v;
-                    if (n < MAXINS) {
-                        IB(x) = (uint8_t)(IB(x) | ((q & 3) << (2 * n)));
-                        if (q < 4) nv = (uint8_t)(nv | (8u << n));
+                    const uint32_t q = (uint8_t)(qw >> (8 * (y - y0)));
+                    if (rn < MAXINS) {
+                        rb |= (q & 3u) << (2 * rn);
+                        if (q < 4) rv |= 1u << rn;
                     }
-                    if (n < 5) nv = (uint8_t)((nv & ~7u) | (n + 1));
-                    IN(x) = nv;
+                    if (rn < 5) rn++;
                     y++;
                 }
             }
         }
+        if (rn) {  // inserted behind the last column
+            IN(x) = (uint8_t)(rn | (rv << 3));
+            IB(x) = (uint8_t)rb;
+        }
     }
-    // ---- canonical (leftmost) placement of indels inside homopolymer runs of the template.  A column only ever changes
-    // columns before it (and itself), so the eight bytes of a block stay valid while its columns are visited.
-    for (int32_t xb = 0; xb < rl; xb += 8) {
-        const uint64_t w = CS8(xb);
-        if (!has_byte5(w)) continue;
-        for (int32_t j = 0; j < 8; j++) {
-            const int32_t x = xb + j;
-            if (x >= rl || (uint8_t)(w >> (8 * j)) != 5) continue;
-            const uint8_t c = ref[x];
-            int32_t st = x;
-            while (st > 0 && CS(st - 1) == c && ref[st - 1] == c && (IN(st) & 7) == 0) st--;
-            if (st < x) {
-                CS(st) = 5;
-                CS(x) = c;
+    VP(1)
+    // ---- canonical (leftmost) placement of indels inside homopolymer runs of the template.
+    // A deleted column x of template base c moves to the start of the run of columns before it that hold c in the template
+    // AND in the read, with nothing inserted in between; an insertion of n equal bases c before column x moves to the left
+    // over columns that hold c in both, with nothing inserted.  Columns are visited in increasing order and a move only
+    // changes columns before the visited one, so the set of visited columns is the set of indels the op list left.
+    bool bytewise = NW8 == 0;
+    ColSet cm{0, 0}, zi{0, 0};
+    if (NW8 > 0) {
+        // Round 6: byte by byte (below) a wavefront visited nearly every column -- some lane of the 64 has an indel there
+        // -- and every visit and every step of its walk was a chain of dependent LDS / global byte loads: 91 of the 180 us of
+        // a wavefront.  Here a lane holds the columns as sets in registers: cm = read base equals template base, zi = nothing
+        // inserted before the column, the two bit planes of the template bases; a walk is one count-leading-zeros
+        ColSet del{0, 0}, pl{0, 0}, ph{0, 0}, pn{0, 0};
+#pragma unroll
+        for (int w = 0; w < NW8; w++) {
+            const int32_t xw = min(8 * w, ARR - 8);  // (ARR < 8 * NW8: the words behind the arrays are not read)
+            const uint64_t cw = CS8(xw), iw = IN8(xw), rw = rwv[w];
+            del.put8(8 * w, zero_bytes8(cw ^ 0x0505050505050505ull));
+            cm.put8(8 * w, zero_bytes8(cw ^ rw));
+            zi.put8(8 * w, zero_bytes8(iw & 0x0707070707070707ull));
+            pl.put8(8 * w, bit_plane8(rw, 0));
+            ph.put8(8 * w, bit_plane8(rw, 1));
+            pn.put8(8 * w, zero_bytes8(rw & 0xFCFCFCFCFCFCFCFCull) ^ 0xFFu);
+        }
+        ColSet ntmpl = pn;
+        ntmpl.keep_below(rl);
+        // (a template base that is none of a / c / g / t inside the tile: the byte-wise passes)
+        bytewise = ntmpl.any();
+        if (!bytewise) {
+            // e[c], the columns whose template base is c, from the two bit planes of the template bases
+            auto tmpl_is = [&](int32_t c) {
+                const uint64_t xl = (c & 1) ? 0ull : ~0ull, xh = (c & 2) ? 0ull : ~0ull;
+                return ColSet{(pl.lo ^ xl) & (ph.lo ^ xh), (pl.hi ^ xl) & (ph.hi ^ xh)};
+            };
+            del.keep_below(rl);
+            const ColSet zs{(zi.lo >> 1) | (zi.hi << 63), zi.hi >> 1};  // zs[p] = nothing inserted before column p + 1
+            while (del.any()) {
+                const int32_t x = del.pop_lowest();
+                const int32_t c = (pl.test(x) ? 1 : 0) | (ph.test(x) ? 2 : 0);
+                const int32_t st = walk_left(tmpl_is(c) & cm & zs, x);
+                if (st < x) {
+                    CS(st) = 5;
+                    CS(x) = (uint8_t)c;
+                    cm.clear(st);
+                    cm.set(x);
+                }
+            }
+            VP(2)
+            ColSet vis{~zi.lo & ~1ull, ~zi.hi};
+            vis.keep_below(rl + 1);
+            while (vis.any()) {
+                const int32_t x = vis.pop_lowest();
+                const uint8_t v = IN(x), bits = IB(x), c = bits & 3;
+                const int32_t n = v & 7;
+                if (n > MAXINS) continue;
+                // all n inserted bases are the same ACGT base
+                const uint8_t want_valid = (uint8_t)(((1u << n) - 1u) << 3);
+                bool same = (v & want_valid) == want_valid;
+                for (int32_t t = 1; t < n; t++) same = same && ((bits >> (2 * t)) & 3) == c;
+                if (!same) continue;
+                const int32_t st = walk_left(tmpl_is(c) & cm & zi, x);
+                if (st < x) {
+                    IB(st) = bits;
+                    IN(st) = v;
+                    IN(x) = 0;
+                    IB(x) = 0;
+                    zi.clear(st);
+                    zi.set(x);
+                }
             }
         }
     }
-    for (int32_t xb = 0; xb <= rl; xb += 8) {
-        const uint64_t w = IN8(xb);
-        if ((w & 0x0707070707070707ull) == 0ull) continue;
-        for (int32_t j = 0; j < 8; j++) {
-            const int32_t x = xb + j;
-            const uint8_t v = (uint8_t)(w >> (8 * j));
-            const int32_t n = v & 7;
-            if (x < 1 || x > rl || n == 0 || n > MAXINS) continue;
-            const uint8_t bits = IB(x), c = bits & 3;
-            // all n inserted bases are the same ACGT base
-            const uint8_t want_valid = (uint8_t)(((1u << n) - 1u) << 3);
-            bool same = (v & want_valid) == want_valid;
-            for (int32_t t = 1; t < n; t++) same = same && ((bits >> (2 * t)) & 3) == c;
-            if (!same) continue;
-            int32_t st = x;
-            while (st > 0 && CS(st - 1) == c && ref[st - 1] == c && (IN(st - 1) & 7) == 0) st--;
-            if (st < x) {
-                IB(st) = bits;
-                IN(st) = v;
-                IN(x) = 0;
-                IB(x) = 0;
+    if (bytewise) {
+        // A column only ever changes columns before it (and itself), so the eight bytes of a block stay valid while its
+        // columns are visited.
+        for (int32_t xb = 0; xb < rl; xb += 8) {
+            const uint64_t w = CS8(xb);
+            if (!has_byte5(w)) continue;
+            for (int32_t j = 0; j < 8; j++) {
+                const int32_t x = xb + j;
+                if (x >= rl || (uint8_t)(w >> (8 * j)) != 5) continue;
+                const uint8_t c = ref[x];
+                int32_t st = x;
+                while (st > 0 && CS(st - 1) == c && ref[st - 1] == c && (IN(st) & 7) == 0) st--;
+                if (st < x) {
+                    CS(st) = 5;
+                    CS(x) = c;
+                }
+            }
+        }
+        for (int32_t xb = 0; xb <= rl; xb += 8) {
+            const uint64_t w = IN8(xb);
+            if ((w & 0x0707070707070707ull) == 0ull) continue;
+            for (int32_t j = 0; j < 8; j++) {
+                const int32_t x = xb + j;
+                const uint8_t v = (uint8_t)(w >> (8 * j));
+                const int32_t n = v & 7;
+                if (x < 1 || x > rl || n == 0 || n > MAXINS) continue;
+                const uint8_t bits = IB(x), c = bits & 3;
+                // all n inserted bases are the same ACGT base
+                const uint8_t want_valid = (uint8_t)(((1u << n) - 1u) << 3);
+                bool same = (v & want_valid) == want_valid;
+                for (int32_t t = 1; t < n; t++) same = same && ((bits >> (2 * t)) & 3) == c;
+                if (!same) continue;
+                int32_t st = x;
+                while (st > 0 && CS(st - 1) == c && ref[st - 1] == c && (IN(st - 1) & 7) == 0) st--;
+                if (st < x) {
+                    IB(st) = bits;
+                    IN(st) = v;
+                    IN(x) = 0;
+                    IB(x) = 0;
+                }
             }
         }
     }
+    VP(3)
     // ---- votes, sparse: a column whose read base equals the template base casts no atomic at
     // all -- the cover of a column comes from a difference array (+1 at the first column of the
     // tile, -1 behind its last one; k_votes_finish scans it) and the template-base count is what
@@ -874,6 +1064,29 @@ k_seg_vote2(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R,
     uint32_t *v = votes + c0 * VSTRIDE;
     atomicAdd(&cdiff[c0], 1u);
     atomicSub(&cdiff[c0 + rl], 1u);
+    if (!bytewise) {
+        // the columns that vote are known as sets (round 6): one atomic per lane and step instead of a walk over all the
+        // columns with three divergent atomic sites -- 290 -> ~60 atomic instructions per wavefront
+        ColSet mm{~cm.lo, ~cm.hi};
+        mm.keep_below(rl);
+        while (mm.any()) {
+            const int32_t x = mm.pop_lowest();
+            const uint8_t cs = CS(x);
+            uint32_t *col = v + (int64_t)x * VSTRIDE;
+            atomicAdd(cs == 5 ? &col[4] : (cs < 4 ? &col[cs] : &vother[c0 + x]), 1u);
+        }
+        ColSet iv{~zi.lo, ~zi.hi};
+        iv.keep_below(rl + 1);
+        while (iv.any()) {
+            const int32_t x = iv.pop_lowest();
+            const uint8_t ivb = IN(x), bits = IB(x);
+            uint32_t *col = v + (int64_t)x * VSTRIDE;
+            const int32_t ic = ivb & 7;
+            const int32_t n = ic < MAXINS ? ic : MAXINS;
+            for (int32_t t = 0; t < n; t++)
+                if (ivb & (8u << t)) atomicAdd(&col[6 + 4 * t + ((bits >> (2 * t)) & 3)], 1u);
+        }
+    } else
     for (int32_t xb = 0; xb <= rl; xb += 8) {
         const uint64_t wi = IN8(xb), wb = IB8(xb), wc = CS8(xb);
         uint64_t rw;  // template bases xb .. xb + 7
@@ -901,6 +1114,10 @@ k_seg_vote2(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R,
                 atomicAdd(&vother[c0 + x], 1u);
         }
     }
+    VP(4)
+#ifdef DH_SEED_PROF
+    if (threadIdx.x == 0) atomicAdd(&g_vote_prof[7], 1ull);
+#endif
 #undef CS
 #undef IN
 #undef IB
@@ -1158,10 +1375,33 @@ void dhk_seg_vote(hipStream_t st, const void *segs, int32_t nseg, DbView T, DbVi
                            T, R, rrc, voff, dmat, bandmax, opbuf, nops, status);
     }
     const size_t lds2 = (size_t)seg_vote2_row(ncolmax) * 64;
-    if (lds2 > 65536)
-        (void)hipFuncSetAttribute((const void *)k_seg_vote2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-    hipLaunchKernelGGL(k_seg_vote2, dim3((nseg + 63) / 64), dim3(64), lds2, st, (const SegDesc *)segs, nseg, T, R,
-                       rrc, voff, opbuf, nops, ncolmax, votes, cdiff, vother);
+    // the canonical-placement passes on column sets in registers: tiles up to 102 / 126 columns (the trace spacing of the
+    // pile-up alignments is 100); longer tiles, or DH_VOTE_BYTEWISE=1, byte by byte
+    const char *ev = getenv("DH_VOTE_BYTEWISE");
+    const bool bytewise = ev && atoi(ev) != 0;
+    const int32_t nw8 = seg_vote2_arr(ncolmax) / 8;
+    auto launch = [&](auto kern) {
+        if (lds2 > 65536) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        hipLaunchKernelGGL(kern, dim3((nseg + 63) / 64), dim3(64), lds2, st, (const SegDesc *)segs, nseg, T, R, rrc, voff,
+                           (const uint8_t *)opbuf, (const uint16_t *)nops, ncolmax, votes, cdiff, vother);
+    };
+    if (bytewise || nw8 > 16)
+        launch(k_seg_vote2<0>);
+    else if (nw8 <= 13)
+        launch(k_seg_vote2<13>);
+    else
+        launch(k_seg_vote2<16>);
+#ifdef DH_SEED_PROF
+    if (getenv("DH_TRACE") && nseg > 100000) {
+        (void)hipStreamSynchronize(st);
+        unsigned long long h[8], z[8] = {0};
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_vote_prof), sizeof h);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_vote_prof), z, sizeof z);
+        const double w = h[7] ? (double)h[7] : 1.0;
+        fprintf(stderr, "[vote prof] %d tiles, %.0f wavefronts timed: init %.1f ops %.1f canon-del %.1f canon-ins %.1f votes %.1f us/wavefront\n",
+                nseg, w, h[0] / w / 100.0, h[1] / w / 100.0, h[2] / w / 100.0, h[3] / w / 100.0, h[4] / w / 100.0);
+    }
+#endif
 }
 
 void dhk_col_tmpl(hipStream_t st, const int64_t *voff, int32_t ntmpl, int64_t ncols_total, int32_t *col_tmpl)

@@ -1279,11 +1279,14 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
         // -- scan: thread t owns the elements [t * per, t * per + per)
         const int32_t per = (n + NT - 1) / NT;
         const int32_t x0 = tid * per, x1 = min(n, x0 + per);
+        // (LCAP > 0: the first pass only sums -- the hits are in LDS, the sums of the 8192 / 16384-entry variants in a slab of
+        // global memory: storing the partial sums here and loading them back below was a chain of dependent round trips per
+        // element; the second pass recomputes an element's term from the hits instead)
         bsum_t acc = 0;
         for (int32_t i = x0; i < x1; i++) {
             const bool head = i == 0 || (hitD(hits[i - 1]) >> bs) != (hitD(hits[i]) >> bs);
             acc += ((bsum_t)(head ? 1u : 0u) << HSH) | (bsum_t)hit_cov(hits, i, k);
-            bsum[i] = acc;
+            if (LCAP == 0) bsum[i] = acc;
         }
         bsum_t incl = acc;  // inclusive scan of the per-thread totals: inside the wavefront ...
         for (int off = 1; off < LANES; off <<= 1) {
@@ -1294,10 +1297,17 @@ __device__ void seed_item(const DbView &B, const IndexView &ix, const JoinView &
         __syncthreads();
         bsum_t base = incl - acc;  // ... plus the wavefronts before this one
         for (int wv = 0; wv < tid / LANES; wv++) base += s_wsum[wv];
+        bsum_t run = base;
         for (int32_t i = x0; i < x1; i++) {
-            const bsum_t v = bsum[i] + base;
-            bsum[i] = v;
             const bool head = i == 0 || (hitD(hits[i - 1]) >> bs) != (hitD(hits[i]) >> bs);
+            bsum_t v;
+            if (LCAP == 0)
+                v = bsum[i] + base;
+            else {
+                run += ((bsum_t)(head ? 1u : 0u) << HSH) | (bsum_t)hit_cov(hits, i, k);
+                v = run;
+            }
+            bsum[i] = v;
             if (head) bhead[(v >> HSH) - 1] = (bhead_t)i;
         }
         __syncthreads();

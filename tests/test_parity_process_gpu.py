@@ -626,6 +626,21 @@ def test_consensus_band_classes_and_scalar_fill_agree(gpu_ctx, monkeypatch):
             assert np.array_equal(rec[f], rec2[f]), f
 
 
+def test_canonical_indel_placement_on_column_sets_equals_the_bytewise_passes(gpu_ctx, monkeypatch):
+    """k_seg_vote2 places indels at the start of template homopolymer runs: since round 6 on sets of columns in registers
+    (one count-leading-zeros per walk; votes cast from the sets), before byte by byte over LDS.  ONT-like reads (indels
+    biased into homopolymer runs: most indels move) against the oracle, and DH_VOTE_BYTEWISE=1 -- the former passes, still
+    the path of tiles above 126 columns -- gives the same bits."""
+    w = sim.Workload(150_000, 2, 600, 4000, seed=53, err=0.12, p_ins=0.30, p_del=0.40, hp_bias=0.5, spacing=15000, gap_max=700)
+    rec = run_case(gpu_ctx, w, 3, algo=1, truth_slack=2.0)
+    monkeypatch.setenv("DH_VOTE_BYTEWISE", "1")
+    rec2 = run_case(gpu_ctx, w, 3, algo=1, truth_slack=2.0)
+    assert int((rec["status"] == 0).sum()) >= 1
+    for f in rec.dtype.names:
+        if f != "pad":
+            assert np.array_equal(rec[f], rec2[f]), f
+
+
 def test_bubble_resolver_on_a_mapping_with_a_masked_contig(gpu_ctx):
     """resolveBubbles end to end (pileups.d:1100-1590): a 3 kb contig is covered by the repeat mask, so the mapping seeds
     nothing on it and the reads that cross it SKIP it -- their join (left contig end -> right contig begin) closes a cycle
