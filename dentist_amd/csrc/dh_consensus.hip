@@ -520,6 +520,18 @@ k_seg_vote(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R,
 //     L   = (left <= up)  = [h(R - 1) + h(R) <= dd(R)]          (top row: 0)
 // Two words per matrix row and plane are stored (op0, L), 64 NW cells each; about 90 (NW = 1) / 170 (NW = 2)
 // instructions per matrix row instead of ~15 per band cell.
+#ifdef DH_SEED_PROF
+__device__ unsigned long long g_vote_prof[16];
+#define VP(i)                                          \
+    if (threadIdx.x == 0) {                            \
+        const unsigned long long t_ = wall_clock64();  \
+        atomicAdd(&g_vote_prof[i], t_ - tp_);          \
+        tp_ = t_;                                      \
+    }
+#else
+#define VP(i)
+#endif
+
 template <int NW>
 struct BV {
     uint64_t w[NW];
@@ -565,6 +577,9 @@ k_seg_vote_bp(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R
     const uint8_t *qry = (sg.comp ? rrc : R.bases) + R.off[sg.bseq] + sg.b0;
     const int64_t NDP = nseg;
     const int lane = threadIdx.x;
+#ifdef DH_SEED_PROF
+    unsigned long long tp_ = wall_clock64();
+#endif
     // ---- planes: bit (HALF + j - 1) of the plane string = bit of the code of query base j (1-based)
     {
         uint64_t a0 = 0, a1 = 0, a2 = 0;
@@ -597,6 +612,7 @@ k_seg_vote_bp(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R
             }
         }
     }
+    VP(8)
     // window of matrix row i: bit R <-> j = i - HALF + R <-> plane string bit (i + R - 1); row 0 would start at bit -1,
     // the loop starts with row 1 at bit 0: the first NW words, and one new bit per row from the feed words
     BV<NW> p0, p1, p2;
@@ -618,6 +634,8 @@ k_seg_vote_bp(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R
         const int hb = HALF + 1;  // lv of column 0: rows j >= 1
         lv.w[k] = k * 64 >= hb ? ~0ull : (k * 64 + 64 <= hb ? 0ull : ~0ull << (hb - k * 64));
     }
+    // (measured, round 6: the decision words of a block's tiles as one contiguous piece, [block][row][word][lane], instead
+    // of interleaved over the launch -- no difference: the fill is VALU-bound, ~150 instructions per matrix row)
 #define DMW(i, k) dmat[((int64_t)(i) * (2 * NW) + (k)) * NDP + dp]
     uint64_t refw = 0;  // template bases i - 1 .. i + 6: one unaligned 8-byte load per 8 matrix rows (the DBs are padded)
     for (int32_t i = 1; i <= rl; i++) {
@@ -682,6 +700,7 @@ k_seg_vote_bp(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R
             fleft = 64;
         }
     }
+    VP(9)
     // ---- traceback (as k_seg_vote): ops back to front into the interleaved op buffer
     int32_t i = rl, j = ql, nops = 0;
     uint64_t oacc = 0;
@@ -731,6 +750,10 @@ k_seg_vote_bp(const SegDesc *__restrict__ segs, int32_t nseg, DbView T, DbView R
     }
     OP_FLUSH
     nops_out[dp] = (uint16_t)nops;
+    VP(10)
+#ifdef DH_SEED_PROF
+    if (threadIdx.x == 0) atomicAdd(&g_vote_prof[15], 1ull);
+#endif
 #undef DMW
 }
 
@@ -753,18 +776,6 @@ __device__ __forceinline__ bool has_byte5(uint64_t w)
     const uint64_t t = w ^ 0x0505050505050505ull;
     return (((t - 0x0101010101010101ull) & ~t) & 0x8080808080808080ull) != 0ull;
 }
-#ifdef DH_SEED_PROF
-__device__ unsigned long long g_vote_prof[8];
-#define VP(i)                                          \
-    if (threadIdx.x == 0) {                            \
-        const unsigned long long t_ = wall_clock64();  \
-        atomicAdd(&g_vote_prof[i], t_ - tp_);          \
-        tp_ = t_;                                      \
-    }
-#else
-#define VP(i)
-#endif
-
 // bit i of the result = byte i of `t` is zero
 __device__ __forceinline__ uint32_t zero_bytes8(uint64_t t)
 {
@@ -1394,10 +1405,12 @@ void dhk_seg_vote(hipStream_t st, const void *segs, int32_t nseg, DbView T, DbVi
 #ifdef DH_SEED_PROF
     if (getenv("DH_TRACE") && nseg > 100000) {
         (void)hipStreamSynchronize(st);
-        unsigned long long h[8], z[8] = {0};
+        unsigned long long h[16], z[16] = {0};
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_vote_prof), sizeof h);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_vote_prof), z, sizeof z);
-        const double w = h[7] ? (double)h[7] : 1.0;
+        const double w = h[7] ? (double)h[7] : 1.0, wb = h[15] ? (double)h[15] : 1.0;
+        fprintf(stderr, "[vote prof] fill mode %d, %.0f wavefronts timed: planes %.1f fill %.1f traceback %.1f us/wavefront\n", mode, wb,
+                h[8] / wb / 100.0, h[9] / wb / 100.0, h[10] / wb / 100.0);
         fprintf(stderr, "[vote prof] %d tiles, %.0f wavefronts timed: init %.1f ops %.1f canon-del %.1f canon-ins %.1f votes %.1f us/wavefront\n",
                 nseg, w, h[0] / w / 100.0, h[1] / w / 100.0, h[2] / w / 100.0, h[3] / w / 100.0, h[4] / w / 100.0);
     }

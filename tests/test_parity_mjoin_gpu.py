@@ -97,6 +97,12 @@ def test_the_round_6_paths_against_their_switches(monkeypatch):
             other = ctx.align_db(A, B, go)
             monkeypatch.delenv(env)
             assert_same_las((las, trace), other)
+        # the presence bitmap of the index, made per partition in LDS (k_mj_bitmap_part) or by scattered global atomics as in
+        # round 5: it is made with the index of a DB, so a fresh DB object
+        monkeypatch.setenv("DH_MJ_BITMAP_ATOMICS", "1")
+        other = ctx.align_db(ctx.db(w.contigs), B, go)
+        monkeypatch.delenv("DH_MJ_BITMAP_ATOMICS")
+        assert_same_las((las, trace), other)
     finally:
         ctx.close()
 
