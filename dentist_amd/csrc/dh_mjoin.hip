@@ -24,6 +24,9 @@ extern "C" void dhk_mj_prof_dump()
     if (h[15])
         fprintf(stderr, "[mj prof] k_mj_part, %llu tiles: setup %.1f roll %.1f entries %.1f scan %.1f scatter %.1f write %.1f us per tile and block\n", h[15],
                 h[0] / 100.0 / h[15], h[1] / 100.0 / h[15], h[2] / 100.0 / h[15], h[3] / 100.0 / h[15], h[4] / 100.0 / h[15], h[5] / 100.0 / h[15]);
+    if (h[11])
+        fprintf(stderr, "[mj prof] k_mj_filter2, %llu wavefronts: lifetime %.1f us, of it resolve %.1f, bitmap slice + item wait %.1f\n", h[11],
+                h[8] / 100.0 / h[11], h[9] / 100.0 / h[11], h[10] / 100.0 / h[11]);
     unsigned long long z[16] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mj_prof), z, sizeof(z));
 }
@@ -722,10 +725,17 @@ k_mj_filter2(IndexView ix, DhOpts o, MjView m)
     uint64_t sweep_from = 0;      // survivors of this wavefront from here on are not resolved yet
     bool pool_out = false;
     int32_t curp = -1;
+#ifdef DH_MJ_PROF
+    unsigned long long t_res_ = 0, t_bm_ = 0;
+    const unsigned long long t_all_ = wall_clock64();
+#endif
     // RESOLVE: as in k_mj_filter
     auto resolve = [&](uint64_t from, uint64_t to, int32_t p) {
         constexpr uint64_t ORI = 1ull << 63;
         constexpr int RU = 4;
+#ifdef DH_MJ_PROF
+        const unsigned long long tr0_ = wall_clock64();
+#endif
         const uint64_t keytop = (uint64_t)p << remsh;
         for (uint64_t i0 = from; i0 < to; i0 += RU * LANES) {
             uint64_t sv[RU];
@@ -741,38 +751,98 @@ k_mj_filter2(IndexView ix, DhOpts o, MjView m)
                 f[u].y = 0;
                 if (sv[u]) f[u] = ix.fat[(uint32_t)((keytop | ((sv[u] >> MJ_REMSH) & remmask)) >> ix.shift)];
             }
+            // the buckets that hold several entries are walked for the RU survivors of a lane TOGETHER, two entries of each per
+            // trip (round 6): one survivor after the other, entry by entry (mj_lookup) the sweep was a chain of ~16 dependent
+            // loads from the index per 256 survivors -- half of A's k-mers share their bucket -- and a third of the kernel
+            uint64_t key[RU], posg1[RU], hh[RU], out[RU];
+            uint32_t ss[RU], nb[RU], c[RU];
+            bool slow[RU];
+#pragma unroll
+            for (int u = 0; u < RU; u++) {
+                const uint64_t i = i0 + (uint64_t)u * LANES + lane;
+                key[u] = keytop | ((sv[u] >> MJ_REMSH) & remmask);
+                posg1[u] = ((sv[u] >> MJ_PSH) & (uint64_t)(MJ_GROUP - 1)) * (uint64_t)m.tb + (sv[u] & ((1ull << MJ_POSBITS) - 1)) + 1;
+                out[u] = 0;
+                hh[u] = 0;
+                ss[u] = nb[u] = c[u] = 0;
+                slow[u] = false;
+                if (i >= to || f[u].x == DH_FAT_EMPTY) continue;
+                const uint64_t bori = (sv[u] & MJ_ORI_BIT) ? ORI : 0ull;
+                const bool pal = (sv[u] & MJ_PAL_BIT) != 0;
+                if ((f[u].x >> 62) != 1ull) {  // the bucket's only entry
+                    if ((f[u].x & ~ORI) == key[u] && o.tcap >= 1) {
+                        const bool same = (f[u].x & ORI) == bori;
+                        const bool h0 = (same || pal) && (o.strands & 1), h1 = (!same || pal) && (o.strands & 2);
+                        if (h0 && h1)
+                            out[u] = sv[u] | (1ull << 62);
+                        else if (h0 || h1)
+                            out[u] = ((uint64_t)(h1 ? 1 : 0) << 63) | ((f[u].y & ((1ull << 39) - 1)) << 23) | posg1[u];
+                    }
+                } else {  // several entries: counted with the full rules; one hit is taken from the walk
+                    ss[u] = (uint32_t)f[u].y;
+                    nb[u] = (uint32_t)(f[u].y >> 32);
+                    if (nb[u] > (uint32_t)max(o.tcap, 0)) {  // (the -t cap may apply: the general walk)
+                        slow[u] = true;
+                        nb[u] = 0;
+                    }
+                }
+            }
+            for (uint32_t j = 0;; j += 2) {
+                bool more = false;
+#pragma unroll
+                for (int u = 0; u < RU; u++) more = more || j < nb[u];
+                if (__ballot(more) == 0ull) break;
+                ulonglong2 en[RU][2];
+#pragma unroll
+                for (int u = 0; u < RU; u++)
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        en[u][q].x = en[u][q].y = 0ull;
+                        if (j + q < nb[u]) en[u][q] = ix.ent[ss[u] + j + q];
+                    }
+#pragma unroll
+                for (int u = 0; u < RU; u++) {
+                    const uint64_t bori = (sv[u] & MJ_ORI_BIT) ? ORI : 0ull;
+                    const bool pal = (sv[u] & MJ_PAL_BIT) != 0;
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        if (j + q >= nb[u] || (en[u][q].x & ~ORI) != key[u]) continue;
+                        const bool same = (en[u][q].x & ORI) == bori;
+                        const uint64_t hv = ((en[u][q].y & ((1ull << 39) - 1)) << 23) | posg1[u];
+                        if ((same || pal) && (o.strands & 1)) {
+                            hh[u] = hv;
+                            c[u]++;
+                        }
+                        if ((!same || pal) && (o.strands & 2)) {
+                            hh[u] = (1ull << 63) | hv;
+                            c[u]++;
+                        }
+                    }
+                }
+            }
 #pragma unroll
             for (int u = 0; u < RU; u++) {
                 const uint64_t i = i0 + (uint64_t)u * LANES + lane;
                 if (i >= to) continue;
-                const uint64_t key = keytop | ((sv[u] >> MJ_REMSH) & remmask);
-                const uint64_t bori = (sv[u] & MJ_ORI_BIT) ? ORI : 0ull;
-                const bool pal = (sv[u] & MJ_PAL_BIT) != 0;
-                const uint64_t posg1 = ((sv[u] >> MJ_PSH) & (uint64_t)(MJ_GROUP - 1)) * (uint64_t)m.tb + (sv[u] & ((1ull << MJ_POSBITS) - 1)) + 1;
-                uint64_t out = 0;
-                if (f[u].x != DH_FAT_EMPTY) {
-                    if ((f[u].x >> 62) != 1ull) {  // the bucket's only entry
-                        if ((f[u].x & ~ORI) == key && o.tcap >= 1) {
-                            const bool same = (f[u].x & ORI) == bori;
-                            const bool h0 = (same || pal) && (o.strands & 1), h1 = (!same || pal) && (o.strands & 2);
-                            if (h0 && h1)
-                                out = sv[u] | (1ull << 62);
-                            else if (h0 || h1)
-                                out = ((uint64_t)(h1 ? 1 : 0) << 63) | ((f[u].y & ((1ull << 39) - 1)) << 23) | posg1;
-                        }
-                    } else {  // several entries: counted with the full rules; one hit is taken from the walk
-                        uint32_t c = 0;
-                        uint64_t hh = 0;
-                        mj_lookup(ix, o, key, bori != 0, pal, [&](uint64_t v, int strand) {
-                            hh = ((uint64_t)strand << 63) | ((v & ((1ull << 39) - 1)) << 23) | posg1;
-                            c++;
-                        });
-                        out = c == 0 ? 0ull : (c == 1 ? hh : (sv[u] | (1ull << 62)));
-                    }
-                }
-                m.hits[i] = out;
+                if (slow[u]) {
+                    const uint64_t bori = (sv[u] & MJ_ORI_BIT) ? ORI : 0ull;
+                    const bool pal = (sv[u] & MJ_PAL_BIT) != 0;
+                    uint32_t cc = 0;
+                    uint64_t h1 = 0;
+                    const uint64_t pg1 = posg1[u];
+                    mj_lookup(ix, o, key[u], bori != 0, pal, [&](uint64_t v, int strand) {
+                        h1 = ((uint64_t)strand << 63) | ((v & ((1ull << 39) - 1)) << 23) | pg1;
+                        cc++;
+                    });
+                    out[u] = cc == 0 ? 0ull : (cc == 1 ? h1 : (sv[u] | (1ull << 62)));
+                } else if (nb[u])
+                    out[u] = c[u] == 0 ? 0ull : (c[u] == 1 ? hh[u] : (sv[u] | (1ull << 62)));
+                m.hits[i] = out[u];
             }
         }
+#ifdef DH_MJ_PROF
+        t_res_ += wall_clock64() - tr0_;
+#endif
     };
     for (int qq = 0; qq < 8; qq++) {
         const uint32_t x = (xcc + qq) & 7u;  // own XCD's queue first, then whatever is left of the others'
@@ -783,6 +853,9 @@ k_mj_filter2(IndexView ix, DhOpts o, MjView m)
             const int32_t item = s_item;
             if (item >= nitems_q) break;
             const int32_t p = (int32_t)x + 8 * (item / MJ_SLICES), sl = item % MJ_SLICES;
+#ifdef DH_MJ_PROF
+            const unsigned long long tb0_ = wall_clock64();
+#endif
             if (p != curp) {
                 const uint4 *src = (const uint4 *)(m.bitmap + (int64_t)p * slice_words);
                 for (int i = tid; i < slice_words / 4; i += MJ_PROBE_THREADS) ((uint4 *)bm)[i] = src[i];
@@ -790,6 +863,9 @@ k_mj_filter2(IndexView ix, DhOpts o, MjView m)
                 curp = p;
                 __syncthreads();
             }
+#ifdef DH_MJ_PROF
+            t_bm_ += wall_clock64() - tb0_;
+#endif
             const int32_t g0 = (int32_t)((int64_t)ng * sl / MJ_SLICES), g1 = (int32_t)((int64_t)ng * (sl + 1) / MJ_SLICES);
             const int32_t t_end = g1 * MJ_GROUP;  // tiles [g0 * MJ_GROUP, t_end) of partition p
             const uint32_t *segp = m.seg + (int64_t)p * m.ntiles_pad;
@@ -903,6 +979,14 @@ k_mj_filter2(IndexView ix, DhOpts o, MjView m)
             }
         }
     }
+#ifdef DH_MJ_PROF
+    if (lane == 0) {
+        atomicAdd(&g_mj_prof[8], wall_clock64() - t_all_);
+        atomicAdd(&g_mj_prof[9], t_res_);
+        atomicAdd(&g_mj_prof[10], t_bm_);
+        atomicAdd(&g_mj_prof[11], 1ull);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------ hits, by read
