@@ -201,7 +201,7 @@ k_join(JoinView jv, DbView B, DhOpts o, const int64_t *__restrict__ goff, int32_
     __shared__ uint32_t s_w[JOIN_THREADS / LANES];
     __shared__ int32_t s_n;
     __shared__ unsigned long long s_base;
-    const int tid = threadIdx.x, lane = tid & (LANES - 1), wv = tid / LANES;
+    const int tid = threadIdx.x;
     const int32_t jb = blockIdx.x;
     const int32_t g = jv.jblk[jb].x, sl = jv.jblk[jb].y;
     const int32_t r0 = jv.gfirst[g], nr = jv.gfirst[g + 1] - r0;
