@@ -42,6 +42,10 @@ for title, part in (("mapping", step[:map_end + 1]), ("process stage (parts one 
     for n, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         if a[1] / 1e6 < 0.3: continue
         print(f"{n[:44]:44s} {a[0]:6d} {a[1] / 1e6:10.2f} {a[2] / 1e6:9.2f} {100.0 * a[1] / tot:6.2f}")
+print("\n## mapping, kernels >= 1 ms in launch order (ms from the step's first kernel)")
+for n, s, e in step[:map_end + 1]:
+    if e - s >= 1e6:
+        print(f"{(s - step[0][1]) / 1e6:9.2f}  {(e - s) / 1e6:8.2f}  {n[:60]}")
 # timeline of the process stage: kernels of at least 1 ms in launch order (the first pile-up batch shows the sequence)
 print("\n## process stage, kernels >= 1 ms in launch order (ms from the stage's first kernel)")
 p = step[map_end + 1:]
@@ -51,4 +55,4 @@ for n, s, e in p:
 PY
 tail -1 "$out/bench.log" | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps({'ms_per_step': d['ms_per_step'], 'stages_ms': d['stages_ms']}))" >> "$out/stage_breakdown.txt"
 grep -E "^\[" "$out/bench.err" | tail -60 > "$out/trace_tail.txt"
-head -80 "$out/stage_breakdown.txt"
+head -120 "$out/stage_breakdown.txt"
