@@ -18,7 +18,7 @@ STATUS = {0: "ok", 1: "no common trace point", 2: "pile too small",
           3: "empty pileup alignment after filtering"}
 
 
-def run_case(ctx, w, rounds, algo=0, truth_slack=1.0, band=64):
+def run_case(ctx, w, rounds, algo=0, truth_slack=1.0, band=64, **po_kw):
     """algo: 0 = DH-1 (waves) everywhere, 1 = DH-2 (tiled band) for the mapping and every process stage (band rows: 64 or 32)."""
     g = dentist_amd.default_align_opts(**(dict(algo=1, width=band) if algo else {}))
     A, B = ctx.db(w.contigs), ctx.db(w.reads)
@@ -26,7 +26,7 @@ def run_case(ctx, w, rounds, algo=0, truth_slack=1.0, band=64):
     # the mapping LAs themselves are covered by test_parity_map_gpu; the oracle re-derives them
     olas, otrace, _ = oz.align_db(w.contigs, w.reads, oz.default_opts(width=g.width, algo=algo), nthreads=os.cpu_count() or 1)
     assert_same_las((las, trace), (olas, otrace))
-    po = dentist_amd.default_process_opts(rounds=rounds, algo=algo, **(dict(width=32) if band == 32 else {}))
+    po = dentist_amd.default_process_opts(rounds=rounds, algo=algo, **(dict(width=32) if band == 32 else {}), **po_kw)
     piles = dentist_amd.Pileups(las, w.contigs.off, po)
     exp_piles = pr.collect_spanning(olas, otrace, w.contigs, w.reads)
     assert len(piles) == len(exp_piles) and len(piles) > 0
@@ -639,6 +639,18 @@ def test_canonical_indel_placement_on_column_sets_equals_the_bytewise_passes(gpu
     for f in rec.dtype.names:
         if f != "pad":
             assert np.array_equal(rec[f], rec2[f]), f
+
+
+@pytest.mark.parametrize("ts,algo", [(100, 1), (128, 1), (200, 0)])
+def test_other_trace_spacings_of_the_pile_up_alignments(gpu_ctx, monkeypatch, ts, algo):
+    """dh_process_opts.tspace_pile other than the default 126: tiles of up to 100 columns take k_seg_vote2<13> (column sets of
+    104 bits); 128 columns -- the most DH-2 takes -- and 200 (DH-1) no longer fit the 128-bit sets: the byte-wise kernel
+    k_seg_vote2<0> (and the two-word / scalar fills of the per-tile Needleman-Wunsch more often).  The oracle's process
+    sequence with the same spacing gives the same bits."""
+    monkeypatch.setattr(pr, "TS_PILE", ts)
+    w = sim.Workload(200_000, 2, 800, 5000, seed=61, spacing=20000, gap_max=900)
+    rec = run_case(gpu_ctx, w, 2, algo=algo, truth_slack=2.0, tspace_pile=ts)   # (parity is the point: the polish is tuned at 126)
+    assert int((rec["status"] == 0).sum()) >= 1
 
 
 def test_bubble_resolver_on_a_mapping_with_a_masked_contig(gpu_ctx):
